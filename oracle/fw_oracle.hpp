@@ -1,0 +1,392 @@
+// fw_oracle.hpp — CPU ORACLE for the Firewheel per-block DSP executor.
+//
+// THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may load it.  The product (firewheel_amd/, libfwgpu)
+// never includes, links or calls anything in oracle/.
+//
+// It is a C++ restatement of the reference's Rust arithmetic (BillyDM/firewheel @ 2024-10-16),
+// one function per reference function, each citing the file:line it follows.  Paths:
+//   core/  = crates/firewheel-core/src/
+//   graph/ = crates/firewheel-graph/src/
+//   nodes/ = crates/firewheel-graph/src/basic_nodes/
+//
+// Parity status: the reference's own tests pin ROUTING only (graph/graph/compiler/schedule.rs:407-710,
+// ported in tests/test_oracle_schedule.py).  No reference test pins sample values, and the Rust
+// toolchain is absent from the build image, so the DSP arithmetic here is "parity unpinned":
+// it is pinned by source reading only.  Nodes that do not exist in the
+// reference (stereo pan, width, biquad, delay, FIR reverb, resampler, spatialiser) are
+// builder-specified; their definitions live in DESIGN.md and are marked SPEC below.
+//
+// Build: -O2 -ffp-contract=off (Rust never fuses mul+add), no fast-math.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace fwo {
+
+// ---------------------------------------------------------------- core/silence_mask.rs:7-74
+struct SilenceMask {
+    uint64_t bits = 0;
+    static SilenceMask new_all_silent(size_t n) {  // :23-29
+        SilenceMask m;
+        m.bits = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+        return m;
+    }
+    bool is_channel_silent(size_t i) const { return (bits & (1ull << i)) != 0; }  // :35-37
+    bool any_channel_silent(size_t n) const {                                      // :43-49
+        if (n >= 64) return bits != 0;
+        return (bits & ((1ull << n) - 1ull)) != 0;
+    }
+    bool all_channels_silent(size_t n) const {  // :55-62
+        if (n >= 64) return bits == ~0ull;
+        uint64_t mask = (1ull << n) - 1ull;
+        return (bits & mask) == mask;
+    }
+    void set_channel(size_t i, bool silent) {  // :67-73
+        if (silent) bits |= (1ull << i);
+        else bits &= ~(1ull << i);
+    }
+};
+
+// ---------------------------------------------------------------- core/param/smoother.rs
+enum class SmootherStatus : int { Inactive = 0, Active = 1, Deactivating = 2 };
+
+struct SmoothedOutput {
+    const float* values;
+    size_t len;
+    SmootherStatus status;
+    bool is_smoothing() const { return status != SmootherStatus::Inactive; }  // :42-44,54-56
+};
+
+struct ParamSmoother {
+    std::vector<float> output;
+    float input;
+    SmootherStatus status;
+    float a, b, last_output, settle_epsilon;
+
+    ParamSmoother(float val, uint32_t sample_rate, size_t max_block_frames,
+                  float smooth_secs = 10.0f / 1000.0f, float settle_eps = 0.00001f);
+    void reset(float val);
+    void set(float val);
+    SmoothedOutput process(size_t frames);
+    SmoothedOutput set_and_process(float val, size_t frames) {  // :202-205
+        set(val);
+        return process(frames);
+    }
+    bool is_active() const { return status != SmootherStatus::Inactive; }
+};
+
+// ---------------------------------------------------------------- core/util.rs
+float db_to_gain(float db);
+float gain_to_db(float amp);
+float db_to_gain_clamped_neg_100_db(float db);
+float gain_to_db_clamped_neg_100_db(float amp);
+float percent_volume_to_raw_gain(float percent_volume);  // core/param/range.rs:32-35
+void pan_to_gains(float pan, float* gl, float* gr);      // SPEC (DESIGN.md spec nodes / pan)
+
+SilenceMask deinterleave(float* const* channels, size_t n_channels, size_t ch_len,
+                         const float* interleaved, size_t interleaved_len,
+                         size_t num_interleaved_channels, bool calculate_silence_mask);
+void interleave(const float* const* channels, size_t n_channels, size_t ch_len, float* interleaved,
+                size_t interleaved_len, size_t num_interleaved_channels, const SilenceMask* mask);
+void interleave_stereo(const float* in_l, const float* in_r, float* interleaved, size_t interleaved_len,
+                       const SilenceMask* mask);
+void deinterleave_stereo(float* out_l, float* out_r, const float* interleaved, size_t interleaved_len);
+void clear_all_outputs(size_t frames, float* const* outputs, size_t n_out, SilenceMask* out_mask);
+
+// ---------------------------------------------------------------- core/sample_resource.rs
+enum SampleFormat : int {
+    FMT_INTERLEAVED_I16 = 0,  // :28-83
+    FMT_INTERLEAVED_U16 = 1,  // :85-140
+    FMT_INTERLEAVED_F32 = 2,  // :142-197
+    FMT_PLANAR_I16 = 3,       // :199-222, 268-291
+    FMT_PLANAR_U16 = 4,       // :224-247, 293-316
+    FMT_PLANAR_F32 = 5,       // :249-266, 318-335
+};
+float pcm_i16_to_f32(int16_t s);   // :338-340
+float pcm_u16_to_f32(uint16_t s);  // :343-345
+
+struct SampleResource {
+    int format;
+    size_t channels;
+    uint64_t frames;
+    std::vector<int16_t> i16;   // interleaved, or planar concatenated [ch][frames]
+    std::vector<uint16_t> u16;
+    std::vector<float> f32;
+    size_t num_channels() const { return channels; }
+    uint64_t len_frames() const { return frames; }
+    // fill buffers[..][range_start..range_end) from start_frame (trait :4-26)
+    void fill_buffers(float* const* buffers, size_t n_buffers, size_t range_start, size_t range_end,
+                      uint64_t start_frame) const;
+};
+
+// ---------------------------------------------------------------- core/node.rs:94-132
+struct ProcInfo {
+    SilenceMask in_silence_mask;
+    SilenceMask* out_silence_mask;
+    double stream_time_secs;
+    uint32_t stream_status;
+};
+
+struct AudioNodeProcessor {  // core/node.rs:37-53
+    virtual ~AudioNodeProcessor() {}
+    virtual void process(size_t frames, const float* const* inputs, size_t n_in, float* const* outputs,
+                         size_t n_out, ProcInfo info) = 0;
+};
+
+enum NodeKind : int {
+    KIND_DUMMY = 0,
+    KIND_BEEP_TEST = 1,
+    KIND_VOLUME = 2,
+    KIND_SUM = 3,
+    KIND_SAMPLER = 4,
+    KIND_HARD_CLIP = 5,
+    KIND_MONO_TO_STEREO = 6,
+    KIND_STEREO_TO_MONO = 7,
+    // ---- SPEC nodes (not in the reference)
+    KIND_STEREO_PAN = 8,
+    KIND_STEREO_WIDTH = 9,
+    KIND_BIQUAD = 10,
+    KIND_DELAY = 11,
+};
+
+// Sampler control messages (nodes/sampler.rs:16-28)
+struct SamplerMsg {
+    enum Type { SetSample, Play, Pause, Stop, SetPlayheadSecs, SetLoopRange } type;
+    std::shared_ptr<const SampleResource> sample;
+    bool stop_playback = false;
+    double playhead_secs = 0.0;
+    int loop_mode = 0;  // 0 = None, 1 = Full, 2 = RangeSecs
+    double loop_start = 0.0, loop_end = 0.0;
+};
+
+// control half of a node (core/node.rs:6-33).  One struct for every kind keeps the C API flat.
+struct AudioNode {
+    int kind = KIND_DUMMY;
+    // shared "atomics" (Arc<AtomicF32>/AtomicBool in the reference)
+    std::shared_ptr<float> raw_gain;      // volume.rs:10, sampler.rs:49
+    std::shared_ptr<float> aux0, aux1;    // SPEC nodes: pan targets etc.
+    std::shared_ptr<int> enabled;         // beep_test.rs:9
+    float freq_hz = 0, gain = 0;          // beep_test.rs:10-11
+    float threshold_gain = 0;             // hard_clip.rs:4
+    std::vector<float> spec_params;       // SPEC nodes creation params
+    std::shared_ptr<std::deque<SamplerMsg>> to_processor;  // sampler.rs:42 (rtrb cap 128)
+    const char* debug_name() const;
+    // activate: returns nullptr and sets err on failure (core/node.rs:12-18)
+    std::unique_ptr<AudioNodeProcessor> activate(uint32_t sample_rate, size_t max_block_frames,
+                                                 size_t num_inputs, size_t num_outputs, std::string& err);
+};
+
+std::unique_ptr<AudioNode> make_node(int kind, const float* params, int n_params);
+
+// ---------------------------------------------------------------- thunderdome::Arena (v0.6.1) model
+struct Index {
+    uint32_t slot = 0xffffffffu;
+    uint32_t generation = 0;
+    bool operator==(const Index& o) const { return slot == o.slot && generation == o.generation; }
+    bool operator!=(const Index& o) const { return !(*this == o); }
+};
+inline int64_t index_to_i64(Index i) { return (int64_t(i.generation) << 32) | int64_t(i.slot); }
+inline Index index_from_i64(int64_t v) {
+    Index i;
+    i.slot = uint32_t(v & 0xffffffff);
+    i.generation = uint32_t(uint64_t(v) >> 32);
+    return i;
+}
+
+template <class T>
+struct Arena {
+    struct Slot {
+        bool occupied = false;
+        uint32_t generation = 0;
+        uint32_t next_free = 0xffffffffu;
+        std::unique_ptr<T> value;
+    };
+    std::vector<Slot> slots;
+    uint32_t free_head = 0xffffffffu;
+    size_t len = 0;
+
+    Index insert(std::unique_ptr<T> v) {
+        Index idx;
+        if (free_head != 0xffffffffu) {
+            uint32_t s = free_head;
+            free_head = slots[s].next_free;
+            slots[s].occupied = true;
+            slots[s].generation += 1;  // thunderdome bumps the generation on reuse
+            slots[s].value = std::move(v);
+            idx.slot = s;
+            idx.generation = slots[s].generation;
+        } else {
+            Slot sl;
+            sl.occupied = true;
+            sl.generation = 1;  // thunderdome generations start at 1
+            sl.value = std::move(v);
+            slots.push_back(std::move(sl));
+            idx.slot = uint32_t(slots.size() - 1);
+            idx.generation = 1;
+        }
+        len++;
+        return idx;
+    }
+    T* get(Index i) {
+        if (i.slot >= slots.size()) return nullptr;
+        Slot& s = slots[i.slot];
+        if (!s.occupied || s.generation != i.generation) return nullptr;
+        return s.value.get();
+    }
+    const T* get(Index i) const { return const_cast<Arena*>(this)->get(i); }
+    T* get_by_slot(uint32_t slot) {
+        if (slot >= slots.size() || !slots[slot].occupied) return nullptr;
+        return slots[slot].value.get();
+    }
+    bool contains(Index i) const { return get(i) != nullptr; }
+    std::unique_ptr<T> remove(Index i) {
+        if (!get(i)) return nullptr;
+        Slot& s = slots[i.slot];
+        s.occupied = false;
+        s.next_free = free_head;
+        free_head = i.slot;
+        len--;
+        return std::move(s.value);
+    }
+    size_t capacity() const { return slots.size(); }
+    template <class F>
+    void for_each(F f) {  // slot order, like thunderdome's iter()
+        for (uint32_t s = 0; s < slots.size(); ++s)
+            if (slots[s].occupied) {
+                Index i;
+                i.slot = s;
+                i.generation = slots[s].generation;
+                f(i, *slots[s].value);
+            }
+    }
+};
+
+// ---------------------------------------------------------------- graph/graph/compiler.rs
+typedef Index NodeID;
+typedef Index EdgeID;
+
+struct Edge {  // compiler.rs:67-78
+    EdgeID id;
+    NodeID src_node;
+    uint32_t src_port;
+    NodeID dst_node;
+    uint32_t dst_port;
+};
+
+struct NodeEntry {  // compiler.rs:12-39
+    NodeID id;
+    uint32_t num_inputs = 0, num_outputs = 0;
+    std::unique_ptr<AudioNode> node;  // NodeWeight.node (graph.rs:76-80)
+    std::vector<Edge> incoming, outgoing;
+};
+
+struct InBufferAssignment {  // schedule.rs:105-115
+    size_t buffer_index;
+    bool should_clear;
+    size_t generation;
+};
+struct OutBufferAssignment {  // schedule.rs:118-126
+    size_t buffer_index;
+    size_t generation;
+};
+struct ScheduledNode {  // schedule.rs:12-20
+    NodeID id;
+    std::vector<InBufferAssignment> input_buffers;
+    std::vector<OutBufferAssignment> output_buffers;
+};
+
+enum AddEdgeError : int {  // graph/graph/error.rs
+    ERR_SRC_NODE_NOT_FOUND = -1,
+    ERR_DST_NODE_NOT_FOUND = -2,
+    ERR_IN_PORT_OUT_OF_RANGE = -3,
+    ERR_OUT_PORT_OUT_OF_RANGE = -4,
+    ERR_EDGE_ALREADY_EXISTS = -5,
+    ERR_INPUT_PORT_ALREADY_CONNECTED = -6,
+    ERR_CYCLE_DETECTED = -7,
+};
+enum CompileGraphError : int {
+    ERR_COMPILE_CYCLE = -10,
+    ERR_COMPILE_MANY_TO_ONE = -11,
+    ERR_COMPILE_NODE_ACTIVATION_FAILED = -12,
+};
+
+struct CompiledSchedule {  // schedule.rs:166-344
+    std::vector<ScheduledNode> schedule;
+    std::vector<float> buffers;
+    std::vector<uint8_t> buffer_silence_flags;
+    size_t num_buffers = 0;
+    size_t max_block_frames = 0;
+
+    CompiledSchedule(std::vector<ScheduledNode> s, size_t nb, size_t mbf);
+    float* buffer_slice(size_t buffer_index) { return buffers.data() + buffer_index * max_block_frames; }
+
+    void prepare_graph_inputs(size_t frames, size_t num_stream_inputs,
+                              const std::function<SilenceMask(float* const*, size_t)>& fill_inputs);
+    void read_graph_outputs(size_t frames, size_t num_stream_outputs,
+                            const std::function<void(const float* const*, size_t, SilenceMask)>& read_outputs);
+    void process(size_t frames,
+                 const std::function<SilenceMask(NodeID, SilenceMask, const float* const*, size_t,
+                                                 float* const*, size_t)>& process);
+};
+
+int compile(Arena<NodeEntry>& nodes, Arena<Edge>& edges, NodeID graph_in, NodeID graph_out,
+            size_t max_block_frames, std::unique_ptr<CompiledSchedule>& out);
+bool cycle_detected(Arena<NodeEntry>& nodes, Arena<Edge>& edges, NodeID graph_in, NodeID graph_out);
+
+// ---------------------------------------------------------------- graph/graph.rs  (AudioGraph, edit API)
+struct AudioGraph {
+    Arena<NodeEntry> nodes;
+    Arena<Edge> edges;
+    std::map<std::pair<int64_t, uint32_t>, bool> connected_input_ports;          // graph.rs:112
+    std::map<std::tuple<int64_t, uint32_t, int64_t, uint32_t>, EdgeID> existing_edges;  // :113
+    NodeID graph_in_id, graph_out_id;
+    bool needs_compile = true;
+    std::vector<NodeID> nodes_to_remove_from_schedule;
+    std::vector<NodeID> nodes_to_activate;
+
+    AudioGraph(size_t num_graph_inputs, size_t num_graph_outputs);  // graph.rs:125-168
+    NodeID add_node(size_t num_inputs, size_t num_outputs, std::unique_ptr<AudioNode> node);  // :201-231
+    int remove_node(NodeID id);                                                               // :268-299
+    int64_t connect(NodeID src, uint32_t src_port, NodeID dst, uint32_t dst_port, bool check_for_cycles);  // :396-477
+    bool disconnect(NodeID src, uint32_t src_port, NodeID dst, uint32_t dst_port);  // :483-501
+    bool disconnect_by_edge_id(EdgeID id);                                          // :507-524
+    bool cycle_detected_();                                                         // :573-580
+    std::vector<EdgeID> remove_edges_with_input_port(NodeID n, uint32_t port);      // :531-550
+    std::vector<EdgeID> remove_edges_with_output_port(NodeID n, uint32_t port);     // :552-571
+};
+
+// ---------------------------------------------------------------- graph/processor.rs + graph/context.rs (audio half)
+struct FirewheelProcessor {
+    std::map<uint32_t, std::unique_ptr<AudioNodeProcessor>> nodes;  // Arena keyed by node slot (processor.rs:19)
+    std::unique_ptr<CompiledSchedule> schedule;
+    size_t max_block_frames;
+    explicit FirewheelProcessor(size_t mbf) : max_block_frames(mbf) {}
+    // processor.rs:61-165.  Returns 0 (Ok).
+    int process_interleaved(const float* input, size_t input_len, float* output, size_t output_len,
+                            size_t num_in_channels, size_t num_out_channels, size_t frames,
+                            double stream_time_secs, uint32_t stream_status);
+    void process_block(size_t block_frames, double stream_time_secs, uint32_t stream_status);  // :208-248
+};
+
+// FirewheelGraphCtx restated without the rings: update() compiles when dirty and hands the new
+// schedule + new processors straight to the processor (context.rs:93-137, processor.rs:167-206).
+struct Ctx {
+    uint32_t sample_rate;
+    size_t max_block_frames;
+    AudioGraph graph;
+    FirewheelProcessor processor;
+    std::vector<std::shared_ptr<const SampleResource>> samples;
+    std::string last_error;
+    Ctx(uint32_t sr, size_t mbf, size_t n_in, size_t n_out)
+        : sample_rate(sr), max_block_frames(mbf), graph(n_in, n_out), processor(mbf) {}
+    int update();
+};
+
+}  // namespace fwo

@@ -1,0 +1,288 @@
+"""Shared test harness: one Python `Engine` interface over two C-ABI back ends.
+
+* `OracleBackend`  -> oracle/_build/libfw_oracle.so  (CPU restatement of the reference; the checker)
+* `GpuBackend`     -> firewheel_amd/csrc/libfwgpu.so (the product: HIP kernels behind the C ABI)
+
+Both expose the reference's edit/process surface (graph/graph.rs add_node/connect/...,
+graph/processor.rs process_interleaved, nodes/sampler.rs messages) so a parity test is the same
+script run twice.  Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# node kinds (oracle/fw_oracle.hpp NodeKind == include/fwgpu.h fwgpu_node_kind)
+DUMMY, BEEP_TEST, VOLUME, SUM, SAMPLER, HARD_CLIP, MONO_TO_STEREO, STEREO_TO_MONO, STEREO_PAN = range(9)
+STEREO_WIDTH, BIQUAD, DELAY = 9, 10, 11
+# sample formats
+INTERLEAVED_I16, INTERLEAVED_U16, INTERLEAVED_F32, PLANAR_I16, PLANAR_U16, PLANAR_F32 = range(6)
+_FMT_DTYPE = {0: np.int16, 1: np.uint16, 2: np.float32, 3: np.int16, 4: np.uint16, 5: np.float32}
+# loop range modes (nodes/sampler.rs:16-19 + Option)
+LOOP_NONE, LOOP_FULL, LOOP_RANGE_SECS = 0, 1, 2
+
+ADD_EDGE_ERRORS = {
+    -1: "SrcNodeNotFound", -2: "DstNodeNotFound", -3: "InPortOutOfRange", -4: "OutPortOutOfRange",
+    -5: "EdgeAlreadyExists", -6: "InputPortAlreadyConnected", -7: "CycleDetected",
+}
+COMPILE_ERRORS = {-10: "CycleDetected", -11: "ManyToOneError", -12: "NodeActivationFailed"}
+
+
+class AddEdgeError(Exception):
+    def __init__(self, code):
+        super().__init__(ADD_EDGE_ERRORS.get(code, str(code)))
+        self.code = code
+        self.name = ADD_EDGE_ERRORS.get(code, str(code))
+
+
+class CompileGraphError(Exception):
+    def __init__(self, code, msg=""):
+        super().__init__("%s: %s" % (COMPILE_ERRORS.get(code, str(code)), msg))
+        self.code = code
+        self.name = COMPILE_ERRORS.get(code, str(code))
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return os.path.join(ROOT, "oracle", "_build", "libfw_oracle.so")
+
+
+_oracle_lib = None
+
+
+def oracle_lib():
+    global _oracle_lib
+    if _oracle_lib is None:
+        path = os.path.join(ROOT, "oracle", "_build", "libfw_oracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        L = C.CDLL(path)
+        i64, u32, u64, f32, f64, vp, ci = C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double, C.c_void_p, C.c_int
+        fp = C.POINTER(C.c_float)
+        sig = {
+            "fwo_ctx_new": (vp, [u32, u32, u32, u32]),
+            "fwo_ctx_free": (None, [vp]),
+            "fwo_last_error": (C.c_char_p, [vp]),
+            "fwo_graph_in_node": (i64, [vp]),
+            "fwo_graph_out_node": (i64, [vp]),
+            "fwo_add_node": (i64, [vp, ci, u32, u32, fp, ci]),
+            "fwo_remove_node": (ci, [vp, i64]),
+            "fwo_connect": (i64, [vp, i64, u32, i64, u32, ci]),
+            "fwo_disconnect": (ci, [vp, i64, u32, i64, u32]),
+            "fwo_disconnect_edge": (ci, [vp, i64]),
+            "fwo_cycle_detected": (ci, [vp]),
+            "fwo_update": (ci, [vp]),
+            "fwo_sched_len": (ci, [vp]),
+            "fwo_sched_num_buffers": (ci, [vp]),
+            "fwo_sched_node": (i64, [vp, ci]),
+            "fwo_sched_in": (ci, [vp, ci, C.POINTER(ci), C.POINTER(ci), ci]),
+            "fwo_sched_out": (ci, [vp, ci, C.POINTER(ci), ci]),
+            "fwo_sample_new": (ci, [vp, ci, u32, u64, vp]),
+            "fwo_set_param": (ci, [vp, i64, ci, f32]),
+            "fwo_sampler_set_sample": (ci, [vp, i64, ci, ci]),
+            "fwo_sampler_play": (ci, [vp, i64]),
+            "fwo_sampler_pause": (ci, [vp, i64]),
+            "fwo_sampler_stop": (ci, [vp, i64]),
+            "fwo_sampler_set_playhead_secs": (ci, [vp, i64, f64]),
+            "fwo_sampler_set_loop_range": (ci, [vp, i64, ci, f64, f64]),
+            "fwo_process_interleaved": (ci, [vp, fp, fp, u32, u32, u64, f64, u32]),
+            "fwo_node_process": (ci, [vp, i64, u64, C.POINTER(fp), u32, C.POINTER(fp), u32, u64, C.POINTER(u64), f64, u32]),
+            "fwo_smoother_new": (vp, [f32, u32, u32]),
+            "fwo_smoother_free": (None, [vp]),
+            "fwo_smoother_set": (None, [vp, f32]),
+            "fwo_smoother_reset": (None, [vp, f32]),
+            "fwo_smoother_process": (ci, [vp, u32, fp, u32, C.POINTER(ci)]),
+            "fwo_smoother_state": (None, [vp, fp, fp, fp, fp, C.POINTER(ci)]),
+            "fwo_mask_new_all_silent": (u64, [u64]),
+            "fwo_mask_any_silent": (ci, [u64, u64]),
+            "fwo_mask_all_silent": (ci, [u64, u64]),
+            "fwo_db_to_gain": (f32, [f32]),
+            "fwo_db_to_gain_clamped": (f32, [f32]),
+            "fwo_gain_to_db_clamped": (f32, [f32]),
+            "fwo_percent_volume_to_raw_gain": (f32, [f32]),
+            "fwo_pcm_i16_to_f32": (f32, [C.c_int16]),
+            "fwo_pcm_u16_to_f32": (f32, [C.c_uint16]),
+            "fwo_pan_to_gains": (None, [f32, fp, fp]),
+            "fwo_deinterleave": (u64, [C.POINTER(fp), u32, u32, fp, u32, u32, ci]),
+            "fwo_interleave": (None, [C.POINTER(fp), u32, u32, fp, u32, u32, ci, u64]),
+            "fwo_interleave_stereo": (None, [fp, fp, fp, u32, ci, u64]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _oracle_lib = L
+    return _oracle_lib
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ptr_array(arrs):
+    t = C.POINTER(C.c_float) * max(len(arrs), 1)
+    return t(*[_fptr(a) for a in arrs])
+
+
+class Engine(object):
+    """Common surface.  Subclasses bind `self.L`/prefix and fill the small differences."""
+
+    backend = "?"
+
+    def add_node(self, kind, n_in, n_out, params=()):
+        raise NotImplementedError
+
+    # ---- helpers mirroring the reference node constructors (nodes/*.rs)
+    def volume(self, percent, ch=2):
+        return self.add_node(VOLUME, ch, ch, [percent])
+
+    def sampler(self, percent=100.0, n_out=2):
+        return self.add_node(SAMPLER, 0, n_out, [percent])
+
+    def sum(self, ports, ch=2):
+        return self.add_node(SUM, ports * ch, ch)
+
+    def beep(self, freq=440.0, gain_db=-12.0, enabled=True, n_out=2):
+        return self.add_node(BEEP_TEST, 0, n_out, [freq, gain_db, 1.0 if enabled else 0.0])
+
+    def hard_clip(self, threshold_db, ch=2):
+        return self.add_node(HARD_CLIP, ch, ch, [threshold_db])
+
+    def pan(self, pan):
+        return self.add_node(STEREO_PAN, 2, 2, [pan])
+
+    def connect_stereo(self, src, dst, dst_port0=0, src_port0=0):
+        self.connect(src, src_port0, dst, dst_port0)
+        self.connect(src, src_port0 + 1, dst, dst_port0 + 1)
+
+
+class OracleEngine(Engine):
+    backend = "oracle"
+
+    def __init__(self, sample_rate=48000, max_block_frames=256, num_graph_inputs=0, num_graph_outputs=2):
+        self.L = oracle_lib()
+        self.sample_rate = sample_rate
+        self.max_block_frames = max_block_frames
+        self.c = self.L.fwo_ctx_new(sample_rate, max_block_frames, num_graph_inputs, num_graph_outputs)
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.L.fwo_ctx_free(self.c)
+        except Exception:
+            pass
+
+    @property
+    def graph_in_node(self):
+        return self.L.fwo_graph_in_node(self.c)
+
+    @property
+    def graph_out_node(self):
+        return self.L.fwo_graph_out_node(self.c)
+
+    def add_node(self, kind, n_in, n_out, params=()):
+        p = np.asarray(list(params), dtype=np.float32)
+        return self.L.fwo_add_node(self.c, kind, n_in, n_out, _fptr(p), len(p))
+
+    def remove_node(self, node):
+        return self.L.fwo_remove_node(self.c, node)
+
+    def connect(self, src, sp, dst, dp, check_for_cycles=False):
+        r = self.L.fwo_connect(self.c, src, sp, dst, dp, 1 if check_for_cycles else 0)
+        if r < 0:
+            raise AddEdgeError(r)
+        return r
+
+    def disconnect(self, src, sp, dst, dp):
+        return bool(self.L.fwo_disconnect(self.c, src, sp, dst, dp))
+
+    def disconnect_by_edge_id(self, e):
+        return bool(self.L.fwo_disconnect_edge(self.c, e))
+
+    def cycle_detected(self):
+        return bool(self.L.fwo_cycle_detected(self.c))
+
+    def update(self):
+        r = self.L.fwo_update(self.c)
+        if r < 0:
+            raise CompileGraphError(r, self.L.fwo_last_error(self.c).decode())
+
+    # schedule introspection -> list of dicts like ScheduledNode (schedule.rs:12-20)
+    def schedule(self):
+        n = self.L.fwo_sched_len(self.c)
+        out = []
+        buf = (C.c_int * 64)()
+        clr = (C.c_int * 64)()
+        for i in range(n):
+            ni = self.L.fwo_sched_in(self.c, i, buf, clr, 64)
+            ins = [(buf[k], bool(clr[k])) for k in range(ni)]
+            no = self.L.fwo_sched_out(self.c, i, buf, 64)
+            outs = [buf[k] for k in range(no)]
+            out.append({"id": self.L.fwo_sched_node(self.c, i), "in": ins, "out": outs})
+        return out
+
+    def num_buffers(self):
+        return self.L.fwo_sched_num_buffers(self.c)
+
+    def new_sample(self, fmt, channels, data):
+        """interleaved: data shape (frames*channels,) or (frames, channels); planar: (channels, frames)."""
+        a = np.ascontiguousarray(np.asarray(data, dtype=_FMT_DTYPE[fmt]))
+        frames = a.size // channels
+        self._keep.append(a)
+        return self.L.fwo_sample_new(self.c, fmt, channels, frames, a.ctypes.data_as(C.c_void_p))
+
+    def set_param(self, node, param, value, at_block=0):
+        assert at_block == 0
+        r = self.L.fwo_set_param(self.c, node, param, value)
+        assert r == 0, r
+
+    def sampler_set_sample(self, node, sample, stop_playback=False, at_block=0):
+        assert self.L.fwo_sampler_set_sample(self.c, node, sample, int(stop_playback)) == 0
+
+    def sampler_play(self, node, at_block=0):
+        assert self.L.fwo_sampler_play(self.c, node) == 0
+
+    def sampler_pause(self, node, at_block=0):
+        assert self.L.fwo_sampler_pause(self.c, node) == 0
+
+    def sampler_stop(self, node, at_block=0):
+        assert self.L.fwo_sampler_stop(self.c, node) == 0
+
+    def sampler_set_playhead_secs(self, node, secs, at_block=0):
+        assert self.L.fwo_sampler_set_playhead_secs(self.c, node, secs) == 0
+
+    def sampler_set_loop_range(self, node, mode, start=0.0, end=0.0, at_block=0):
+        assert self.L.fwo_sampler_set_loop_range(self.c, node, mode, start, end) == 0
+
+    def process_interleaved(self, frames, n_out_ch=2, inp=None, n_in_ch=0, t=0.0, status=0):
+        out = np.full(frames * n_out_ch, np.nan, dtype=np.float32)
+        if inp is None:
+            inp = np.zeros(frames * n_in_ch, dtype=np.float32)
+        inp = np.ascontiguousarray(inp, dtype=np.float32)
+        r = self.L.fwo_process_interleaved(self.c, _fptr(inp), _fptr(out), n_in_ch, n_out_ch, frames, t, status)
+        assert r == 0
+        return out
+
+    def process_blocks(self, k, n_out_ch=2):
+        """K consecutive max_block_frames blocks (what one K-block device launch computes)."""
+        return self.process_interleaved(k * self.max_block_frames, n_out_ch)
+
+    def node_process(self, node, frames, inputs, n_out, in_mask=0, out_mask=0, out_init=None):
+        """B1: one node's process() on caller buffers.  Returns (outputs[n_out, frames], out_mask)."""
+        ins = [np.ascontiguousarray(x, dtype=np.float32) for x in inputs]
+        outs = [np.full(frames, np.nan, dtype=np.float32) if out_init is None else np.array(out_init[c], dtype=np.float32)
+                for c in range(n_out)]
+        om = C.c_uint64(out_mask)
+        r = self.L.fwo_node_process(self.c, node, frames, _ptr_array(ins), len(ins), _ptr_array(outs), n_out,
+                                    in_mask, C.byref(om), 0.0, 0)
+        assert r == 0
+        return np.stack(outs) if outs else np.zeros((0, frames), np.float32), om.value
+
+
+def xorshift_uniform(seed, n):
+    """Deterministic uniform(-1,1) f32 stream (seeded xorshift), vectorised per call."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return (rng.random(n, dtype=np.float32) * 2.0 - 1.0).astype(np.float32)

@@ -1,0 +1,1205 @@
+// fwgpu_ctx.cpp — device-resident executor behind the C ABI (include/fwgpu.h).
+//
+// A ctx is the device counterpart of FirewheelGraphCtx + FirewheelProcessor (graph/context.rs,
+// graph/processor.rs): the host half keeps the editable graph, the device half keeps node state, the
+// buffer pool and the launch plan in HBM.  No CPU compute path exists: every process call is kernels.
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fwgpu.h"
+#include "fwgpu_graph.h"
+#include "fwgpu_launch.h"
+
+using namespace fwgpu;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            if (e != hipSuccess) return e;
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes < 256 ? 256 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+struct SampleRec {
+    bool alive = false;
+    bool owned = true;
+    void* d_data = nullptr;
+    SampleDesc desc{};
+};
+
+struct TimerCat {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+    double acc_ms = 0.0;
+    uint64_t launches = 0;
+};
+
+}  // namespace
+
+struct fwgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t sample_rate = 48000;
+    uint32_t mbf = 256;
+    int stride = 256;
+    uint32_t n_gin = 0, n_gout = 2;
+    std::string last_error;
+
+    HostGraph graph;
+    Plan plan;
+    bool have_plan = false;
+    bool force_generic = false;
+    uint32_t kmax = 64;
+
+    // device state
+    DevBuf d_states;
+    size_t states_cap = 0;
+    std::vector<SampleRec> samples;
+    DevBuf d_samples;
+    bool samples_dirty = true;
+
+    // generic plan
+    DevBuf d_nodes, d_in_buf, d_out_buf, d_level_nodes, d_pool, d_flags, d_gin_bufs, d_gout_bufs;
+    std::vector<int> level_off, level_cnt;
+    int n_gout_bufs = 0, n_gin_bufs = 0;
+
+    // fused plan
+    bool fused = false;
+    int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
+    DevBuf d_voices, d_leaves, d_blks, d_ramps, d_bus, d_bus_flags;
+    DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
+    std::vector<int> up_level_off, up_level_cnt;
+
+    // messages
+    std::vector<Cmd> cmds;
+    DevBuf d_cmds;
+    int n_cmds_dev = 0;
+    Cmd* h_cmds = nullptr;  // pinned staging for the async upload
+    size_t h_cmds_cap = 0;
+    hipEvent_t cmds_copied = nullptr;
+
+    // staging + B1 scratch
+    DevBuf d_in_stage, d_out_stage, d_scratch_pool, d_scratch_flags, d_scratch_tab, d_mask;
+
+    // timing
+    bool timing = false;
+    TimerCat timers[4];
+
+    fwgpu_ctx(uint32_t gin, uint32_t gout) : graph(gin, gout) {}
+};
+
+namespace {
+
+int fail(fwgpu_ctx* c, int code, const std::string& msg) {
+    c->last_error = msg;
+    return code;
+}
+int hipfail(fwgpu_ctx* c, hipError_t e, const char* what) {
+    c->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return FWGPU_ERR_DEVICE;
+}
+#define HIPC(c, x)                                        \
+    do {                                                  \
+        hipError_t e__ = (x);                             \
+        if (e__ != hipSuccess) return hipfail(c, e__, #x); \
+    } while (0)
+#define LCHK(c, x)                                                        \
+    do {                                                                  \
+        int e__ = (x);                                                    \
+        if (e__ != 0) return hipfail(c, (hipError_t)e__, "kernel launch " #x); \
+    } while (0)
+
+// ---- control-half scalar math, done on the host exactly as the reference's control thread does it
+float percent_volume_to_raw_gain(float p) {  // core/param/range.rs:32-35
+    float n = fmaxf(p, 0.0f) * (1.0f / 100.0f);
+    return n * n;
+}
+float db_to_gain_clamped_neg_100_db(float db) {  // core/util.rs:7-9,21-27
+    if (db <= -100.0f) return 0.0f;
+    return powf(10.0f, 0.05f * db);
+}
+void pan_to_gains(float pan, float* gl, float* gr) {  // SPEC: DESIGN.md "spec nodes / pan"
+    float p = fminf(fmaxf(pan, -1.0f), 1.0f);
+    if (p <= -1.0f) {
+        *gl = 1.0f;
+        *gr = 0.0f;
+        return;
+    }
+    if (p >= 1.0f) {
+        *gl = 0.0f;
+        *gr = 1.0f;
+        return;
+    }
+    double theta = ((double)p + 1.0) * (3.14159265358979323846 / 4.0);
+    *gl = (float)cos(theta);
+    *gr = (float)sin(theta);
+}
+Smoother make_smoother(float val, uint32_t sample_rate) {  // core/param/smoother.rs:93-112, defaults :18-25
+    Smoother s;
+    const float smooth_secs = 10.0f / 1000.0f;
+    s.b = expf(-1.0f / (smooth_secs * (float)sample_rate));
+    s.a = 1.0f - s.b;
+    s.status = SM_INACTIVE;
+    s.input = val;
+    s.last = val;
+    s.eps = 0.00001f;
+    return s;
+}
+
+// AudioNode constructors + activate(): the initial audio-half state of each node kind.
+NodeState make_state(int kind, const float* params, int n_params, uint32_t sample_rate) {
+    auto p = [&](int i, float d) { return i < n_params ? params[i] : d; };
+    NodeState s;
+    memset(&s, 0, sizeof(s));
+    s.sample = -1;
+    s.sample_rate = sample_rate;
+    s.s0 = make_smoother(0.f, sample_rate);
+    s.s1 = make_smoother(0.f, sample_rate);
+    switch (kind) {
+        case K_VOLUME:   // volume.rs:15-22, :67-75
+        case K_SAMPLER:  // sampler.rs:55-64, :302-319
+            s.p0 = percent_volume_to_raw_gain(fmaxf(p(0, 100.0f), 0.0f));
+            s.s0 = make_smoother(s.p0, sample_rate);
+            break;
+        case K_BEEP: {  // beep_test.rs:15-24, :55-60
+            float f = p(0, 440.0f);
+            if (f < 20.0f) f = 20.0f;
+            if (f > 20000.0f) f = 20000.0f;
+            float g = db_to_gain_clamped_neg_100_db(p(1, -12.0f));
+            if (g < 0.0f) g = 0.0f;
+            if (g > 1.0f) g = 1.0f;
+            s.gain = g;
+            s.enabled = p(2, 1.0f) != 0.0f ? 1 : 0;
+            s.phasor = 0.0f;
+            s.phasor_inc = f / (float)sample_rate;
+            break;
+        }
+        case K_HARD_CLIP:  // hard_clip.rs:8-12
+            s.p0 = db_to_gain_clamped_neg_100_db(p(0, 0.0f));
+            break;
+        case K_PAN:
+            pan_to_gains(p(0, 0.0f), &s.p0, &s.p1);
+            s.s0 = make_smoother(s.p0, sample_rate);
+            s.s1 = make_smoother(s.p1, sample_rate);
+            break;
+        default:
+            break;
+    }
+    return s;
+}
+
+int upload(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    HIPC(c, b.ensure(bytes));
+    if (bytes) HIPC(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int upload_sample_table(fwgpu_ctx* c) {
+    if (!c->samples_dirty) return 0;
+    c->samples_dirty = false;
+    std::vector<SampleDesc> tab(std::max<size_t>(c->samples.size(), 1));
+    for (size_t i = 0; i < c->samples.size(); ++i) tab[i] = c->samples[i].desc;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return upload(c, c->d_samples, tab.data(), tab.size() * sizeof(SampleDesc));
+}
+
+// ---------------------------------------------------------------- fused voice-bank plan detection
+struct FusedBuild {
+    std::vector<VoiceDesc> voices;
+    std::vector<LeafDesc> leaves;
+    std::vector<NodeDesc> up_nodes;
+    std::vector<int> up_in, up_out;
+    std::vector<std::vector<int>> up_levels;  // indices into up_nodes per level
+    int root_buf[2];
+    int n_bus = 1;
+    int max_stages = 0;
+};
+
+bool detect_fused(const Plan& plan, FusedBuild& fb) {
+    const int N = (int)plan.nodes.size();
+    if (N < 3) return false;
+    const PlanNode& gout = plan.nodes.back();
+    if (gout.is_graph_io != 2 || gout.n_in != 2) return false;
+    // consumer counts per (node, port)
+    std::vector<std::vector<int>> cons(N);
+    for (int i = 0; i < N; ++i) cons[i].assign(plan.nodes[i].n_out, 0);
+    for (const PlanNode& n : plan.nodes)
+        for (int p = 0; p < n.n_in; ++p)
+            if (n.in_src_node[p] >= 0) cons[n.in_src_node[p]][n.in_src_port[p]]++;
+    auto stereo_src = [&](const PlanNode& n, int port0, int& src) -> bool {
+        int a = n.in_src_node[port0], b = n.in_src_node[port0 + 1];
+        if (a < 0 || a != b) return false;
+        if (n.in_src_port[port0] != 0 || n.in_src_port[port0 + 1] != 1) return false;
+        if (plan.nodes[a].n_out != 2 || cons[a][0] != 1 || cons[a][1] != 1) return false;
+        src = a;
+        return true;
+    };
+    int root;
+    if (!stereo_src(gout, 0, root)) return false;
+    if (plan.nodes[root].kind != K_SUM) return false;
+    std::vector<char> covered(N, 0);
+    covered[N - 1] = 1;
+    for (int i = 0; i < N; ++i)
+        if (plan.nodes[i].is_graph_io == 1) {
+            covered[i] = 1;
+            for (int cnt : cons[i])
+                if (cnt) return false;  // graph inputs feed the graph: generic executor
+        }
+    // walk the sum tree breadth-first
+    struct SumRec {
+        int node;
+        bool leaf;
+        std::vector<int> kids;  // plan indices (sum nodes) or chain ends
+        int out_buf;
+    };
+    std::vector<SumRec> sums;
+    std::map<int, int> sum_index;
+    std::vector<int> work{root};
+    while (!work.empty()) {
+        int si = work.back();
+        work.pop_back();
+        const PlanNode& s = plan.nodes[si];
+        if (s.kind != K_SUM || s.n_out != 2 || s.n_in < 2 || s.n_in % 2) return false;
+        if (covered[si]) return false;
+        covered[si] = 1;
+        SumRec r;
+        r.node = si;
+        r.out_buf = 0;
+        int n_sum = 0, n_chain = 0;
+        for (int p = 0; p < s.n_in / 2; ++p) {
+            int src;
+            if (!stereo_src(s, 2 * p, src)) return false;
+            r.kids.push_back(src);
+            if (plan.nodes[src].kind == K_SUM) n_sum++;
+            else n_chain++;
+        }
+        if (n_sum && n_chain) return false;
+        r.leaf = n_chain > 0;
+        if (!r.leaf)
+            for (int k : r.kids) work.push_back(k);
+        sum_index[si] = (int)sums.size();
+        sums.push_back(r);
+    }
+    // leaves in plan order (deterministic), chains in port order
+    std::vector<int> leaf_order;
+    for (int i = 0; i < (int)sums.size(); ++i)
+        if (sums[i].leaf) leaf_order.push_back(i);
+    std::sort(leaf_order.begin(), leaf_order.end(), [&](int a, int b) { return sums[a].node < sums[b].node; });
+    int next_bus = 1;
+    for (int li : leaf_order) {
+        SumRec& r = sums[li];
+        LeafDesc ld;
+        ld.first_voice = (int)fb.voices.size();
+        ld.ports = (int)r.kids.size();
+        ld.out_buf = next_bus;
+        ld.pad = 0;
+        r.out_buf = next_bus;
+        next_bus += 2;
+        for (int end : r.kids) {
+            // walk upstream: end -> ... -> sampler
+            std::vector<int> chain;
+            int cur = end;
+            for (;;) {
+                const PlanNode& n = plan.nodes[cur];
+                if (covered[cur]) return false;
+                if (n.kind == K_SAMPLER) {
+                    if (n.n_in != 0 || n.n_out != 2) return false;
+                    covered[cur] = 1;
+                    break;
+                }
+                if (!(n.kind == K_VOLUME || n.kind == K_PAN) || n.n_in != 2 || n.n_out != 2) return false;
+                covered[cur] = 1;
+                chain.push_back(cur);
+                int src;
+                if (!stereo_src(n, 0, src)) return false;
+                cur = src;
+            }
+            if ((int)chain.size() > FW_MAX_STAGES - 1) return false;
+            VoiceDesc vd;
+            memset(&vd, 0, sizeof(vd));
+            vd.sampler_state = (int)plan.nodes[cur].slot;
+            vd.n_stages = (int)chain.size();
+            for (int j = 0; j < vd.n_stages; ++j) {  // schedule order: nearest the sampler first
+                const PlanNode& n = plan.nodes[chain[chain.size() - 1 - j]];
+                vd.stage_kind[j] = n.kind;
+                vd.stage_state[j] = (int)n.slot;
+            }
+            fb.max_stages = std::max(fb.max_stages, vd.n_stages);
+            fb.voices.push_back(vd);
+        }
+        fb.leaves.push_back(ld);
+    }
+    for (int i = 0; i < N; ++i)
+        if (!covered[i]) return false;  // anything else in the graph: generic executor
+    // upper sums: heights above the leaves, children's buses resolved bottom-up
+    std::vector<int> height(sums.size(), -1);
+    std::function<int(int)> h = [&](int i) -> int {
+        if (height[i] >= 0) return height[i];
+        if (sums[i].leaf) return height[i] = 0;
+        int m = 0;
+        for (int k : sums[i].kids) m = std::max(m, h(sum_index[k]) + 1);
+        return height[i] = m;
+    };
+    int maxh = 0;
+    for (int i = 0; i < (int)sums.size(); ++i) maxh = std::max(maxh, h(i));
+    fb.up_levels.assign(maxh, std::vector<int>());
+    for (int lv = 1; lv <= maxh; ++lv) {
+        std::vector<int> at;
+        for (int i = 0; i < (int)sums.size(); ++i)
+            if (height[i] == lv) at.push_back(i);
+        std::sort(at.begin(), at.end(), [&](int a, int b) { return sums[a].node < sums[b].node; });
+        for (int i : at) {
+            SumRec& r = sums[i];
+            r.out_buf = next_bus;
+            next_bus += 2;
+            NodeDesc nd;
+            memset(&nd, 0, sizeof(nd));
+            nd.kind = K_SUM;
+            nd.n_in = (int)r.kids.size() * 2;
+            nd.n_out = 2;
+            nd.in_off = (int)fb.up_in.size();
+            nd.out_off = (int)fb.up_out.size();
+            nd.state = 0;
+            nd.aux0 = (int)r.kids.size();
+            for (int k : r.kids) {
+                int cb = sums[sum_index[k]].out_buf;
+                fb.up_in.push_back(cb);
+                fb.up_in.push_back(cb + 1);
+            }
+            fb.up_out.push_back(r.out_buf);
+            fb.up_out.push_back(r.out_buf + 1);
+            fb.up_levels[lv - 1].push_back((int)fb.up_nodes.size());
+            fb.up_nodes.push_back(nd);
+        }
+    }
+    int rb = sums[sum_index[root]].out_buf;
+    fb.root_buf[0] = rb;
+    fb.root_buf[1] = rb + 1;
+    fb.n_bus = next_bus;
+    return !fb.voices.empty();
+}
+
+int install_plan(fwgpu_ctx* c, Plan& plan) {
+    HIPC(c, hipStreamSynchronize(c->stream));
+    // 1. node state capacity (persists across recompiles: processor.rs:19,195-197)
+    size_t need = c->graph.nodes.size();
+    if (need > c->states_cap) {
+        size_t cap = std::max<size_t>(need * 2, 64);
+        DevBuf nb;
+        HIPC(c, nb.ensure(cap * sizeof(NodeState)));
+        HIPC(c, hipMemset(nb.p, 0, cap * sizeof(NodeState)));
+        if (c->d_states.p && c->states_cap)
+            HIPC(c, hipMemcpy(nb.p, c->d_states.p, c->states_cap * sizeof(NodeState), hipMemcpyDeviceToDevice));
+        c->d_states.release();
+        c->d_states = nb;
+        c->states_cap = cap;
+    }
+    // 2. activate new nodes (graph.rs:594-612): scatter their initial states
+    {
+        std::vector<StateInitHost> inits;
+        for (uint32_t slot : c->graph.nodes_to_activate) {
+            HostNode& n = c->graph.nodes[slot];
+            if (!n.alive || n.activated) continue;
+            StateInitHost si;
+            si.index = (int)slot;
+            si.pad = 0;
+            si.st = n.init;
+            inits.push_back(si);
+            n.activated = true;
+        }
+        c->graph.nodes_to_activate.clear();
+        if (!inits.empty()) {
+            DevBuf tmp;
+            int rc = upload(c, tmp, inits.data(), inits.size() * sizeof(StateInitHost));
+            if (rc) return rc;
+            LCHK(c, launch_scatter_states(c->stream, c->d_states.as<NodeState>(), tmp.p, (int)inits.size()));
+            HIPC(c, hipStreamSynchronize(c->stream));
+            tmp.release();
+        }
+    }
+    // 3. node tables
+    const int N = (int)plan.nodes.size();
+    std::vector<NodeDesc> nd(N);
+    std::vector<int> in_tab, out_tab;
+    std::vector<std::vector<int>> levels(plan.num_levels);
+    std::vector<int> gin_bufs, gout_bufs;
+    for (int i = 0; i < N; ++i) {
+        const PlanNode& p = plan.nodes[i];
+        NodeDesc& d = nd[i];
+        memset(&d, 0, sizeof(d));
+        d.kind = p.kind;
+        d.n_in = p.n_in;
+        d.n_out = p.n_out;
+        d.in_off = (int)in_tab.size();
+        d.out_off = (int)out_tab.size();
+        d.state = (int)p.slot;
+        d.aux0 = (p.kind == K_SUM && p.n_out > 0) ? p.n_in / p.n_out : 0;
+        d.is_graph_io = p.is_graph_io;
+        in_tab.insert(in_tab.end(), p.in_buf.begin(), p.in_buf.end());
+        out_tab.insert(out_tab.end(), p.out_buf.begin(), p.out_buf.end());
+        if (p.is_graph_io == 1) gin_bufs = p.out_buf;
+        else if (p.is_graph_io == 2) gout_bufs = p.in_buf;
+        else levels[p.level].push_back(i);
+    }
+    if (in_tab.empty()) in_tab.push_back(0);
+    if (out_tab.empty()) out_tab.push_back(0);
+    int rc;
+    if ((rc = upload(c, c->d_nodes, nd.data(), nd.size() * sizeof(NodeDesc)))) return rc;
+    if ((rc = upload(c, c->d_in_buf, in_tab.data(), in_tab.size() * sizeof(int)))) return rc;
+    if ((rc = upload(c, c->d_out_buf, out_tab.data(), out_tab.size() * sizeof(int)))) return rc;
+    std::vector<int> flat;
+    c->level_off.clear();
+    c->level_cnt.clear();
+    for (auto& l : levels) {
+        c->level_off.push_back((int)flat.size());
+        c->level_cnt.push_back((int)l.size());
+        flat.insert(flat.end(), l.begin(), l.end());
+    }
+    if (flat.empty()) flat.push_back(0);
+    if ((rc = upload(c, c->d_level_nodes, flat.data(), flat.size() * sizeof(int)))) return rc;
+    c->n_gin_bufs = (int)gin_bufs.size();
+    c->n_gout_bufs = (int)gout_bufs.size();
+    if (gin_bufs.empty()) gin_bufs.push_back(0);
+    if (gout_bufs.empty()) gout_bufs.push_back(0);
+    if ((rc = upload(c, c->d_gin_bufs, gin_bufs.data(), gin_bufs.size() * sizeof(int)))) return rc;
+    if ((rc = upload(c, c->d_gout_bufs, gout_bufs.data(), gout_bufs.size() * sizeof(int)))) return rc;
+    // 4. buffer pool: a new schedule starts from zeroed buffers (schedule.rs:202-203)
+    size_t pool_bytes = (size_t)plan.num_buffers * c->stride * sizeof(float);
+    HIPC(c, c->d_pool.ensure(pool_bytes));
+    HIPC(c, hipMemset(c->d_pool.p, 0, pool_bytes));
+    HIPC(c, c->d_flags.ensure((size_t)plan.num_buffers));
+    HIPC(c, hipMemset(c->d_flags.p, 0, (size_t)plan.num_buffers));
+    HIPC(c, hipMemset(c->d_flags.p, 1, 1));  // buffer 0: constant zero, always flagged silent
+
+    // 5. fused voice-bank plan
+    c->fused = false;
+    FusedBuild fb;
+    if (!c->force_generic && detect_fused(plan, fb)) {
+        c->n_voices = (int)fb.voices.size();
+        c->n_leaves = (int)fb.leaves.size();
+        c->n_bus = fb.n_bus;
+        c->ramp_slots = 2 * (1 + fb.max_stages);
+        if ((rc = upload(c, c->d_voices, fb.voices.data(), fb.voices.size() * sizeof(VoiceDesc)))) return rc;
+        if ((rc = upload(c, c->d_leaves, fb.leaves.data(), fb.leaves.size() * sizeof(LeafDesc)))) return rc;
+        const size_t K = c->kmax;
+        HIPC(c, c->d_blks.ensure(K * c->n_voices * sizeof(VoiceBlk)));
+        HIPC(c, c->d_ramps.ensure(K * c->n_voices * (size_t)c->ramp_slots * c->stride * sizeof(float)));
+        size_t bus_bytes = K * (size_t)c->n_bus * c->stride * sizeof(float);
+        HIPC(c, c->d_bus.ensure(bus_bytes));
+        HIPC(c, hipMemset(c->d_bus.p, 0, bus_bytes));
+        std::vector<uint8_t> bf(K * c->n_bus, 0);
+        for (size_t k = 0; k < K; ++k) bf[k * c->n_bus] = 1;
+        if ((rc = upload(c, c->d_bus_flags, bf.data(), bf.size()))) return rc;
+        if (fb.up_nodes.empty()) {
+            NodeDesc z;
+            memset(&z, 0, sizeof(z));
+            fb.up_nodes.push_back(z);
+        }
+        if (fb.up_in.empty()) fb.up_in.push_back(0);
+        if (fb.up_out.empty()) fb.up_out.push_back(0);
+        if ((rc = upload(c, c->d_up_nodes, fb.up_nodes.data(), fb.up_nodes.size() * sizeof(NodeDesc)))) return rc;
+        if ((rc = upload(c, c->d_up_in, fb.up_in.data(), fb.up_in.size() * sizeof(int)))) return rc;
+        if ((rc = upload(c, c->d_up_out, fb.up_out.data(), fb.up_out.size() * sizeof(int)))) return rc;
+        std::vector<int> uflat;
+        c->up_level_off.clear();
+        c->up_level_cnt.clear();
+        for (auto& l : fb.up_levels) {
+            c->up_level_off.push_back((int)uflat.size());
+            c->up_level_cnt.push_back((int)l.size());
+            uflat.insert(uflat.end(), l.begin(), l.end());
+        }
+        if (uflat.empty()) uflat.push_back(0);
+        if ((rc = upload(c, c->d_up_level_nodes, uflat.data(), uflat.size() * sizeof(int)))) return rc;
+        if ((rc = upload(c, c->d_root_bufs, fb.root_buf, sizeof(fb.root_buf)))) return rc;
+        c->fused = true;
+    }
+    c->plan = plan;
+    c->have_plan = true;
+    c->graph.needs_compile = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------- messages
+int upload_cmds(fwgpu_ctx* c) {
+    std::stable_sort(c->cmds.begin(), c->cmds.end(), [](const Cmd& a, const Cmd& b) {
+        if (a.state != b.state) return a.state < b.state;
+        return a.block < b.block;
+    });
+    c->n_cmds_dev = (int)c->cmds.size();
+    if (c->n_cmds_dev == 0) return 0;
+    size_t bytes = c->cmds.size() * sizeof(Cmd);
+    if (bytes > c->d_cmds.cap) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, c->d_cmds.ensure(bytes * 2));
+    }
+    if (!c->cmds_copied) HIPC(c, hipEventCreateWithFlags(&c->cmds_copied, hipEventDisableTiming));
+    else HIPC(c, hipEventSynchronize(c->cmds_copied));  // the previous upload has left the pinned buffer
+    if (c->cmds.size() > c->h_cmds_cap) {
+        if (c->h_cmds) HIPC(c, hipHostFree(c->h_cmds));
+        c->h_cmds = nullptr;
+        c->h_cmds_cap = c->cmds.size() * 2;
+        HIPC(c, hipHostMalloc((void**)&c->h_cmds, c->h_cmds_cap * sizeof(Cmd), hipHostMallocDefault));
+    }
+    memcpy(c->h_cmds, c->cmds.data(), bytes);
+    HIPC(c, hipMemcpyAsync(c->d_cmds.p, c->h_cmds, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipEventRecord(c->cmds_copied, c->stream));
+    return 0;
+}
+void retire_cmds(fwgpu_ctx* c, uint32_t nblocks) {
+    std::vector<Cmd> keep;
+    for (Cmd& m : c->cmds)
+        if (m.block >= nblocks) {
+            m.block -= nblocks;
+            keep.push_back(m);
+        }
+    c->cmds.swap(keep);
+    for (HostNode& n : c->graph.nodes) n.pending_msgs = 0;
+}
+
+// ---------------------------------------------------------------- timing helpers
+void timer_begin(fwgpu_ctx* c, int cat, hipEvent_t* e0, hipEvent_t* e1) {
+    *e0 = *e1 = nullptr;
+    if (!c->timing) return;
+    TimerCat& t = c->timers[cat];
+    if (t.used == t.ev.size()) {
+        if (t.ev.size() >= 8192) return;  // drained by timing_read
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        t.ev.emplace_back(a, b);
+    }
+    *e0 = t.ev[t.used].first;
+    *e1 = t.ev[t.used].second;
+    t.used++;
+    t.launches++;
+    (void)hipEventRecord(*e0, c->stream);
+}
+void timer_end(fwgpu_ctx* c, hipEvent_t e1) {
+    if (e1) (void)hipEventRecord(e1, c->stream);
+}
+void timer_drain(fwgpu_ctx* c) {
+    (void)hipStreamSynchronize(c->stream);
+    for (TimerCat& t : c->timers) {
+        for (size_t i = 0; i < t.used; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, t.ev[i].first, t.ev[i].second) == hipSuccess) t.acc_ms += ms;
+        }
+        t.used = 0;
+    }
+}
+
+// ---------------------------------------------------------------- executors
+DevView generic_view(fwgpu_ctx* c, int frames) {
+    DevView v;
+    v.nodes = c->d_nodes.as<NodeDesc>();
+    v.in_buf = c->d_in_buf.as<int>();
+    v.out_buf = c->d_out_buf.as<int>();
+    v.states = c->d_states.as<NodeState>();
+    v.samples = c->d_samples.as<SampleDesc>();
+    v.pool = c->d_pool.as<float>();
+    v.flags = c->d_flags.as<uint8_t>();
+    v.pool_blk_stride = 0;
+    v.flags_blk_stride = 0;
+    v.stride = c->stride;
+    v.frames = frames;
+    v.cmds = c->d_cmds.as<Cmd>();
+    v.n_cmds = c->n_cmds_dev;
+    return v;
+}
+
+// one block through the level-batched executor (schedule.rs:289-344 as one launch per level)
+int run_generic_block(fwgpu_ctx* c, int frames, uint32_t cmd_block, const float* d_in, int n_in_ch, float* d_out,
+                      int n_out_ch) {
+    if (c->n_gin_bufs > 0)
+        LCHK(c, launch_graph_in(c->stream, c->d_pool.as<float>(), c->d_flags.as<uint8_t>(), c->stride,
+                                c->d_gin_bufs.as<int>(), c->n_gin_bufs, d_in, d_in ? n_in_ch : 0, frames));
+    DevView v = generic_view(c, frames);
+    hipEvent_t e0, e1;
+    timer_begin(c, 3, &e0, &e1);
+    for (size_t l = 0; l < c->level_cnt.size(); ++l)
+        LCHK(c, launch_level(c->stream, v, c->d_level_nodes.as<int>() + c->level_off[l], c->level_cnt[l], 1, cmd_block));
+    timer_end(c, e1);
+    LCHK(c, launch_graph_out(c->stream, c->d_pool.as<float>(), c->d_flags.as<uint8_t>(), c->stride, 0, 0,
+                             c->d_gout_bufs.as<int>(), c->n_gout_bufs, d_out, n_out_ch, frames, 1));
+    return 0;
+}
+
+// K full blocks through the fused voice-bank plan
+int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int n_out_ch) {
+    FusedView fv;
+    fv.voices = c->d_voices.as<VoiceDesc>();
+    fv.leaves = c->d_leaves.as<LeafDesc>();
+    fv.states = c->d_states.as<NodeState>();
+    fv.samples = c->d_samples.as<SampleDesc>();
+    fv.blks = c->d_blks.as<VoiceBlk>();
+    fv.ramps = c->d_ramps.as<float>();
+    fv.ramp_slots = c->ramp_slots;
+    fv.bus = c->d_bus.as<float>();
+    fv.bus_flags = c->d_bus_flags.as<uint8_t>();
+    fv.bus_blk_stride = (size_t)c->n_bus * c->stride;
+    fv.bus_flags_blk_stride = (size_t)c->n_bus;
+    fv.cmds = c->d_cmds.as<Cmd>();
+    fv.n_cmds = c->n_cmds_dev;
+    fv.n_voices = c->n_voices;
+    fv.n_leaves = c->n_leaves;
+    fv.stride = c->stride;
+    fv.frames = (int)c->mbf;
+    hipEvent_t e0, e1;
+    timer_begin(c, 1, &e0, &e1);
+    LCHK(c, launch_voice_control(c->stream, fv, K, cmd_block0));
+    timer_end(c, e1);
+    timer_begin(c, 0, &e0, &e1);
+    LCHK(c, launch_leaf_sum(c->stream, fv, K));
+    timer_end(c, e1);
+    timer_begin(c, 2, &e0, &e1);
+    if (!c->up_level_cnt.empty()) {
+        DevView v;
+        v.nodes = c->d_up_nodes.as<NodeDesc>();
+        v.in_buf = c->d_up_in.as<int>();
+        v.out_buf = c->d_up_out.as<int>();
+        v.states = c->d_states.as<NodeState>();
+        v.samples = c->d_samples.as<SampleDesc>();
+        v.pool = fv.bus;
+        v.flags = fv.bus_flags;
+        v.pool_blk_stride = fv.bus_blk_stride;
+        v.flags_blk_stride = fv.bus_flags_blk_stride;
+        v.stride = c->stride;
+        v.frames = (int)c->mbf;
+        v.cmds = nullptr;
+        v.n_cmds = 0;
+        for (size_t l = 0; l < c->up_level_cnt.size(); ++l)
+            LCHK(c, launch_level(c->stream, v, c->d_up_level_nodes.as<int>() + c->up_level_off[l], c->up_level_cnt[l], K, 0));
+    }
+    LCHK(c, launch_graph_out(c->stream, fv.bus, fv.bus_flags, c->stride, fv.bus_blk_stride, fv.bus_flags_blk_stride,
+                             c->d_root_bufs.as<int>(), 2, d_out, n_out_ch, (int)c->mbf, K));
+    timer_end(c, e1);
+    return 0;
+}
+
+// all blocks of one call; d_in may be null.  frames may end in a partial block.
+int run_blocks(fwgpu_ctx* c, uint64_t frames, const float* d_in, int n_in_ch, float* d_out, int n_out_ch) {
+    const uint32_t mbf = c->mbf;
+    const uint32_t nblocks = (uint32_t)((frames + mbf - 1) / mbf);
+    int rc = upload_sample_table(c);
+    if (rc) return rc;
+    rc = upload_cmds(c);
+    if (rc) return rc;
+    uint64_t done = 0;
+    uint32_t blk = 0;
+    const bool can_fuse = c->fused && !c->force_generic;
+    while (done < frames) {
+        uint64_t left = frames - done;
+        if (can_fuse && left >= mbf) {
+            uint32_t K = (uint32_t)std::min<uint64_t>(left / mbf, c->kmax);
+            rc = run_fused_batch(c, (int)K, blk, d_out + done * n_out_ch, n_out_ch);
+            if (rc) return rc;
+            done += (uint64_t)K * mbf;
+            blk += K;
+            continue;
+        }
+        int bf = (int)std::min<uint64_t>(left, mbf);
+        rc = run_generic_block(c, bf, blk, d_in ? d_in + done * n_in_ch : nullptr, n_in_ch, d_out + done * n_out_ch, n_out_ch);
+        if (rc) return rc;
+        done += bf;
+        blk += 1;
+    }
+    retire_cmds(c, nblocks);
+    return 0;
+}
+
+int push_cmd(fwgpu_ctx* c, int64_t node, int want_kind, Cmd m, bool counts_as_msg) {
+    HostNode* n = c->graph.get(node);
+    if (!n) return fail(c, FWGPU_ERR_INVALID, "unknown node id");
+    if (want_kind >= 0 && n->kind != want_kind) return fail(c, FWGPU_ERR_INVALID, "node kind does not accept this message");
+    if (counts_as_msg) {
+        if (n->pending_msgs >= 128) return fail(c, FWGPU_ERR_QUEUE_FULL, "sampler message ring full");  // sampler.rs:14
+        n->pending_msgs++;
+    }
+    m.state = (int)(node & 0xffffffff);
+    c->cmds.push_back(m);
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================= C ABI
+extern "C" {
+
+const char* fwgpu_create_error(void) { return g_create_error.c_str(); }
+
+fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block_frames, uint32_t num_graph_inputs,
+                            uint32_t num_graph_outputs, void* hip_stream) {
+    g_create_error.clear();
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e) +
+                         " (libfwgpu has no CPU fallback)";
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_error = "device index out of range";
+        return nullptr;
+    }
+    if (max_block_frames == 0 || num_graph_inputs > 64 || num_graph_outputs > 64) {
+        g_create_error = "invalid arguments (max_block_frames > 0, <= 64 graph channels)";
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + "; libfwgpu ships gfx950 (MI355X) code only";
+        return nullptr;
+    }
+    fwgpu_ctx* c = new fwgpu_ctx(num_graph_inputs, num_graph_outputs);
+    c->device = device;
+    c->sample_rate = sample_rate;
+    c->mbf = max_block_frames;
+    c->stride = (int)((max_block_frames + 63) / 64 * 64);
+    c->n_gin = num_graph_inputs;
+    c->n_gout = num_graph_outputs;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+            g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+            delete c;
+            return nullptr;
+        }
+        c->own_stream = true;
+    }
+    if (upload_sample_table(c) != 0 || c->d_mask.ensure(64) != hipSuccess) {
+        g_create_error = c->last_error;
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void fwgpu_ctx_destroy(fwgpu_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (SampleRec& s : c->samples)
+        if (s.alive && s.owned && s.d_data) (void)hipFree(s.d_data);
+    DevBuf* bufs[] = {&c->d_states, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
+                      &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_ramps,
+                      &c->d_bus, &c->d_bus_flags, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
+                      &c->d_root_bufs, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
+                      &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask};
+    for (DevBuf* b : bufs) b->release();
+    for (TimerCat& t : c->timers)
+        for (auto& p : t.ev) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    if (c->h_cmds) (void)hipHostFree(c->h_cmds);
+    if (c->cmds_copied) (void)hipEventDestroy(c->cmds_copied);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* fwgpu_last_error(fwgpu_ctx* c) { return c ? c->last_error.c_str() : "null ctx"; }
+
+int64_t fwgpu_graph_in_node(fwgpu_ctx* c) { return c->graph.id_of(c->graph.graph_in_slot); }
+int64_t fwgpu_graph_out_node(fwgpu_ctx* c) { return c->graph.id_of(c->graph.graph_out_slot); }
+
+int64_t fwgpu_add_node(fwgpu_ctx* c, int kind, uint32_t n_in, uint32_t n_out, const float* params, int n_params) {
+    if (kind < 0 || kind > K_PAN) return fail(c, FWGPU_ERR_INVALID, "unsupported node kind");
+    if (n_in > 64 || n_out > 64) return fail(c, FWGPU_ERR_INVALID, "a node has at most 64 ports per side (core/node.rs:62,69)");
+    NodeState st = make_state(kind, params, n_params, c->sample_rate);
+    return c->graph.add_node(kind, n_in, n_out, st);
+}
+int fwgpu_remove_node(fwgpu_ctx* c, int64_t node) {
+    int rc = c->graph.remove_node(node);
+    if (rc) return fail(c, rc, "remove_node: unknown node or graph in/out node");
+    return 0;
+}
+int64_t fwgpu_connect(fwgpu_ctx* c, int64_t src, uint32_t sp, int64_t dst, uint32_t dp, int check) {
+    return c->graph.connect(src, sp, dst, dp, check != 0);
+}
+int fwgpu_disconnect(fwgpu_ctx* c, int64_t src, uint32_t sp, int64_t dst, uint32_t dp) {
+    return c->graph.disconnect(src, sp, dst, dp);
+}
+int fwgpu_disconnect_edge(fwgpu_ctx* c, int64_t e) { return c->graph.disconnect_edge(e); }
+int fwgpu_cycle_detected(fwgpu_ctx* c) { return c->graph.cycle_detected() ? 1 : 0; }
+
+int fwgpu_update(fwgpu_ctx* c) {
+    (void)hipSetDevice(c->device);
+    if (!c->graph.needs_compile && c->have_plan) return 0;
+    Plan plan;
+    std::string err;
+    int rc = c->graph.build_plan(plan, err);
+    if (rc) return fail(c, rc, err);
+    return install_plan(c, plan);
+}
+
+int fwgpu_schedule_upload(fwgpu_ctx* c, const fwgpu_sched_node* sn, uint32_t n_nodes, uint32_t num_buffers) {
+    (void)hipSetDevice(c->device);
+    if (n_nodes < 2) return fail(c, FWGPU_ERR_INVALID, "a schedule holds at least graph_in and graph_out");
+    Plan plan;
+    std::vector<std::pair<int, int>> last_writer(num_buffers, std::make_pair(-1, 0));
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        HostNode* hn = c->graph.get(sn[i].node);
+        if (!hn) return fail(c, FWGPU_ERR_INVALID, "schedule names an unknown node");
+        if (hn->n_in != sn[i].num_inputs || hn->n_out != sn[i].num_outputs)
+            return fail(c, FWGPU_ERR_INVALID, "schedule port counts differ from add_node");
+        std::string err;
+        if (!check_activation(hn->kind, hn->n_in, hn->n_out, err)) return fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, err);
+        PlanNode pn;
+        pn.slot = (uint32_t)(sn[i].node & 0xffffffff);
+        pn.kind = hn->kind;
+        pn.n_in = (int)hn->n_in;
+        pn.n_out = (int)hn->n_out;
+        pn.level = 0;
+        pn.is_graph_io = pn.slot == c->graph.graph_in_slot ? 1 : (pn.slot == c->graph.graph_out_slot ? 2 : 0);
+        pn.in_src_node.assign(pn.n_in, -1);
+        pn.in_src_port.assign(pn.n_in, 0);
+        for (int p = 0; p < pn.n_in; ++p) {
+            if (sn[i].in_should_clear[p]) continue;  // unconnected (InBufferAssignment.should_clear)
+            uint32_t b = sn[i].in_buffer_index[p];
+            if (b >= num_buffers || last_writer[b].first < 0)
+                return fail(c, FWGPU_ERR_INVALID, "schedule input reads a buffer no earlier node wrote");
+            pn.in_src_node[p] = last_writer[b].first;
+            pn.in_src_port[p] = last_writer[b].second;
+        }
+        for (int p = 0; p < pn.n_out; ++p) {
+            uint32_t b = sn[i].out_buffer_index[p];
+            if (b >= num_buffers) return fail(c, FWGPU_ERR_INVALID, "schedule buffer index out of range");
+            last_writer[b] = std::make_pair((int)i, p);
+        }
+        plan.nodes.push_back(pn);
+    }
+    if (plan.nodes.front().is_graph_io != 1 || plan.nodes.back().is_graph_io != 2)
+        return fail(c, FWGPU_ERR_INVALID, "schedule must start with graph_in and end with graph_out");
+    finalize_plan(plan);
+    return install_plan(c, plan);
+}
+
+int fwgpu_plan_kind(fwgpu_ctx* c) { return c->have_plan ? (c->fused && !c->force_generic ? 1 : 0) : -1; }
+int fwgpu_plan_num_levels(fwgpu_ctx* c) { return c->have_plan ? c->plan.num_levels : -1; }
+int fwgpu_plan_node_level(fwgpu_ctx* c, int64_t node) {
+    if (!c->have_plan || !c->graph.get(node)) return -1;
+    uint32_t slot = (uint32_t)(node & 0xffffffff);
+    for (const PlanNode& p : c->plan.nodes)
+        if (p.slot == slot) return p.level;
+    return -1;
+}
+int fwgpu_plan_node_inputs_clear(fwgpu_ctx* c, int64_t node, int* should_clear, int cap) {
+    if (!c->have_plan || !c->graph.get(node)) return -1;
+    uint32_t slot = (uint32_t)(node & 0xffffffff);
+    for (const PlanNode& p : c->plan.nodes)
+        if (p.slot == slot) {
+            for (int i = 0; i < p.n_in && i < cap; ++i) should_clear[i] = p.in_buf[i] == 0 ? 1 : 0;
+            return p.n_in;
+        }
+    return -1;
+}
+int fwgpu_set_force_generic(fwgpu_ctx* c, int on) {
+    c->force_generic = on != 0;
+    return 0;
+}
+int fwgpu_set_max_batch(fwgpu_ctx* c, uint32_t k) {
+    if (k == 0) return fail(c, FWGPU_ERR_INVALID, "max batch must be >= 1");
+    c->kmax = k;
+    c->graph.needs_compile = true;  // K-sized buffers are (re)allocated by the next fwgpu_update
+    return 0;
+}
+
+static size_t fmt_elem_size(int fmt) { return (fmt == FMT_I_F32 || fmt == FMT_P_F32) ? 4 : 2; }
+
+static int sample_add(fwgpu_ctx* c, int format, uint32_t channels, uint64_t frames, const void* data, bool on_device) {
+    (void)hipSetDevice(c->device);
+    if (format < 0 || format > FMT_P_F32 || channels == 0) return fail(c, FWGPU_ERR_INVALID, "bad sample format/channels");
+    SampleRec r;
+    r.alive = true;
+    size_t bytes = (size_t)frames * channels * fmt_elem_size(format);
+    if (on_device) {
+        r.owned = false;
+        r.d_data = (void*)data;
+    } else {
+        r.owned = true;
+        HIPC(c, hipMalloc(&r.d_data, bytes + 256));  // slack: a wave's last dwordx4 may overhang the data
+        HIPC(c, hipMemset((char*)r.d_data + bytes, 0, 256));
+        if (bytes) HIPC(c, hipMemcpy(r.d_data, data, bytes, hipMemcpyHostToDevice));
+    }
+    r.desc.data = r.d_data;
+    r.desc.frames = frames;
+    r.desc.channels = (int)channels;
+    r.desc.format = format;
+    c->samples.push_back(r);
+    c->samples_dirty = true;  // table is re-uploaded lazily by the next process/update call
+    return (int)c->samples.size() - 1;
+}
+int fwgpu_sample_create(fwgpu_ctx* c, int format, uint32_t channels, uint64_t frames, const void* data) {
+    return sample_add(c, format, channels, frames, data, false);
+}
+int fwgpu_sample_create_device(fwgpu_ctx* c, int format, uint32_t channels, uint64_t frames, const void* device_data) {
+    return sample_add(c, format, channels, frames, device_data, true);
+}
+int fwgpu_sample_destroy(fwgpu_ctx* c, int sample) {
+    if (sample < 0 || sample >= (int)c->samples.size() || !c->samples[sample].alive)
+        return fail(c, FWGPU_ERR_INVALID, "unknown sample id");
+    (void)hipStreamSynchronize(c->stream);
+    SampleRec& r = c->samples[sample];
+    if (r.owned && r.d_data) (void)hipFree(r.d_data);
+    r.alive = false;
+    r.d_data = nullptr;
+    r.desc.data = nullptr;
+    r.desc.frames = 0;
+    c->samples_dirty = true;
+    return 0;
+}
+
+int fwgpu_node_set_param(fwgpu_ctx* c, int64_t node, int param, float value, uint32_t at_block) {
+    HostNode* n = c->graph.get(node);
+    if (!n) return fail(c, FWGPU_ERR_INVALID, "unknown node id");
+    Cmd m;
+    memset(&m, 0, sizeof(m));
+    m.block = at_block;
+    switch (n->kind) {
+        case K_VOLUME:
+        case K_SAMPLER:  // volume.rs:28-34, sampler.rs:171-177
+            if (param != 0) return fail(c, FWGPU_ERR_INVALID, "unknown param");
+            m.type = CMD_SET_P0;
+            m.f0 = percent_volume_to_raw_gain(value);
+            return push_cmd(c, node, -1, m, false);
+        case K_BEEP:  // beep_test.rs:30-32
+            if (param != 0) return fail(c, FWGPU_ERR_INVALID, "unknown param");
+            m.type = CMD_SET_ENABLED;
+            m.i0 = value != 0.0f;
+            return push_cmd(c, node, -1, m, false);
+        case K_PAN: {
+            if (param != 0) return fail(c, FWGPU_ERR_INVALID, "unknown param");
+            float gl, gr;
+            pan_to_gains(value, &gl, &gr);
+            m.type = CMD_SET_P0;
+            m.f0 = gl;
+            int rc = push_cmd(c, node, -1, m, false);
+            if (rc) return rc;
+            m.type = CMD_SET_P1;
+            m.f0 = gr;
+            return push_cmd(c, node, -1, m, false);
+        }
+        default:
+            return fail(c, FWGPU_ERR_INVALID, "node kind has no runtime params");
+    }
+}
+int fwgpu_sampler_set_sample(fwgpu_ctx* c, int64_t node, int sample, int stop_playback, uint32_t at_block) {
+    if (sample < 0 || sample >= (int)c->samples.size() || !c->samples[sample].alive)
+        return fail(c, FWGPU_ERR_INVALID, "unknown sample id");
+    Cmd m;
+    memset(&m, 0, sizeof(m));
+    m.block = at_block;
+    m.type = CMD_SMP_SET_SAMPLE;
+    m.i0 = sample;
+    m.i1 = stop_playback != 0;
+    return push_cmd(c, node, K_SAMPLER, m, true);
+}
+static int simple_msg(fwgpu_ctx* c, int64_t node, int type, uint32_t at_block) {
+    Cmd m;
+    memset(&m, 0, sizeof(m));
+    m.block = at_block;
+    m.type = type;
+    return push_cmd(c, node, K_SAMPLER, m, true);
+}
+int fwgpu_sampler_play(fwgpu_ctx* c, int64_t node, uint32_t b) { return simple_msg(c, node, CMD_SMP_PLAY, b); }
+int fwgpu_sampler_pause(fwgpu_ctx* c, int64_t node, uint32_t b) { return simple_msg(c, node, CMD_SMP_PAUSE, b); }
+int fwgpu_sampler_stop(fwgpu_ctx* c, int64_t node, uint32_t b) { return simple_msg(c, node, CMD_SMP_STOP, b); }
+int fwgpu_sampler_set_playhead_secs(fwgpu_ctx* c, int64_t node, double secs, uint32_t at_block) {
+    Cmd m;
+    memset(&m, 0, sizeof(m));
+    m.block = at_block;
+    m.type = CMD_SMP_SET_PLAYHEAD;
+    m.d0 = secs;
+    return push_cmd(c, node, K_SAMPLER, m, true);
+}
+int fwgpu_sampler_set_loop_range(fwgpu_ctx* c, int64_t node, int mode, double start, double end, uint32_t at_block) {
+    if (mode < 0 || mode > 2) return fail(c, FWGPU_ERR_INVALID, "loop mode must be 0, 1 or 2");
+    Cmd m;
+    memset(&m, 0, sizeof(m));
+    m.block = at_block;
+    m.type = CMD_SMP_SET_LOOP;
+    m.i0 = mode;
+    m.d0 = start;
+    m.d1 = end;
+    return push_cmd(c, node, K_SAMPLER, m, true);
+}
+
+int fwgpu_process_interleaved(fwgpu_ctx* c, const float* input, float* output, uint32_t n_in_ch, uint32_t n_out_ch,
+                              uint64_t frames, double, uint32_t) {
+    (void)hipSetDevice(c->device);
+    size_t out_bytes = (size_t)frames * n_out_ch * sizeof(float);
+    if (!c->have_plan || frames == 0) {  // processor.rs:86-89 (Q19)
+        if (out_bytes) memset(output, 0, out_bytes);
+        return 0;
+    }
+    const float* d_in = nullptr;
+    if (n_in_ch > 0 && input) {
+        size_t in_bytes = (size_t)frames * n_in_ch * sizeof(float);
+        if (in_bytes > c->d_in_stage.cap) {
+            HIPC(c, hipStreamSynchronize(c->stream));
+            HIPC(c, c->d_in_stage.ensure(in_bytes));
+        }
+        HIPC(c, hipMemcpyAsync(c->d_in_stage.p, input, in_bytes, hipMemcpyHostToDevice, c->stream));
+        d_in = c->d_in_stage.as<float>();
+    }
+    if (out_bytes > c->d_out_stage.cap) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, c->d_out_stage.ensure(out_bytes));
+    }
+    int rc = run_blocks(c, frames, d_in, (int)n_in_ch, c->d_out_stage.as<float>(), (int)n_out_ch);
+    if (rc) {
+        if (out_bytes) memset(output, 0, out_bytes);  // "all output buffers MUST be filled" (core/node.rs:41-42)
+        return rc;
+    }
+    if (out_bytes) HIPC(c, hipMemcpyAsync(output, c->d_out_stage.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fwgpu_process_blocks_device(fwgpu_ctx* c, uint32_t num_blocks, float* d_output, uint32_t n_out_ch) {
+    (void)hipSetDevice(c->device);
+    if (!c->have_plan) return fail(c, FWGPU_ERR_INVALID, "no schedule: call fwgpu_update first");
+    if (num_blocks == 0) return 0;
+    return run_blocks(c, (uint64_t)num_blocks * c->mbf, nullptr, 0, d_output, (int)n_out_ch);
+}
+
+int fwgpu_synchronize(fwgpu_ctx* c) {
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float* const* inputs, uint32_t n_in,
+                       float* const* outputs, uint32_t n_out, uint64_t in_mask, uint64_t* out_mask, double, uint32_t) {
+    (void)hipSetDevice(c->device);
+    HostNode* hn = c->graph.get(node);
+    if (!hn || !hn->activated) return fail(c, FWGPU_ERR_INVALID, "node is not activated (call fwgpu_update)");
+    if (hn->n_in != n_in || hn->n_out != n_out) return fail(c, FWGPU_ERR_INVALID, "port counts differ from add_node");
+    if (frames > c->mbf) return fail(c, FWGPU_ERR_INVALID, "frames > max_block_frames");
+    const size_t stride = (size_t)c->stride;
+    const int nb = 1 + (int)n_in + (int)n_out;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, c->d_scratch_pool.ensure((size_t)nb * stride * sizeof(float)));
+    HIPC(c, c->d_scratch_flags.ensure((size_t)nb));
+    HIPC(c, hipMemsetAsync(c->d_scratch_pool.p, 0, stride * sizeof(float), c->stream));
+    std::vector<uint8_t> fl(nb, 0);
+    fl[0] = 1;
+    for (uint32_t i = 0; i < n_in; ++i) {
+        fl[1 + i] = (in_mask >> i) & 1ull;
+        HIPC(c, hipMemcpyAsync(c->d_scratch_pool.as<float>() + (1 + i) * stride, inputs[i], frames * sizeof(float),
+                               hipMemcpyHostToDevice, c->stream));
+    }
+    for (uint32_t i = 0; i < n_out; ++i)  // nodes that leave outputs untouched (dummy.rs, beep_test.rs:83-86)
+        HIPC(c, hipMemcpyAsync(c->d_scratch_pool.as<float>() + (1 + n_in + i) * stride, outputs[i], frames * sizeof(float),
+                               hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->d_scratch_flags.p, fl.data(), nb, hipMemcpyHostToDevice, c->stream));
+    // temp tables: [NodeDesc][in ids][out ids]
+    std::vector<int> tab(sizeof(NodeDesc) / sizeof(int) + n_in + n_out + 2, 0);
+    NodeDesc nd;
+    memset(&nd, 0, sizeof(nd));
+    nd.kind = hn->kind;
+    nd.n_in = (int)n_in;
+    nd.n_out = (int)n_out;
+    nd.in_off = 0;
+    nd.out_off = 0;
+    nd.state = (int)(node & 0xffffffff);
+    nd.aux0 = (hn->kind == K_SUM && n_out) ? (int)(n_in / n_out) : 0;
+    memcpy(tab.data(), &nd, sizeof(nd));
+    int* ins = tab.data() + sizeof(NodeDesc) / sizeof(int);
+    int* outs = ins + n_in + 1;
+    for (uint32_t i = 0; i < n_in; ++i) ins[i] = 1 + (int)i;
+    for (uint32_t i = 0; i < n_out; ++i) outs[i] = 1 + (int)n_in + (int)i;
+    HIPC(c, c->d_scratch_tab.ensure(tab.size() * sizeof(int)));
+    HIPC(c, hipMemcpyAsync(c->d_scratch_tab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    int rc = upload_sample_table(c);
+    if (rc) return rc;
+    rc = upload_cmds(c);
+    if (rc) return rc;
+    DevView v = generic_view(c, (int)frames);
+    v.nodes = (const NodeDesc*)c->d_scratch_tab.p;
+    v.in_buf = c->d_scratch_tab.as<int>() + sizeof(NodeDesc) / sizeof(int);
+    v.out_buf = v.in_buf + n_in + 1;
+    v.pool = c->d_scratch_pool.as<float>();
+    v.flags = c->d_scratch_flags.as<uint8_t>();
+    LCHK(c, launch_single_node(c->stream, v, 0));
+    for (uint32_t i = 0; i < n_out; ++i)
+        HIPC(c, hipMemcpyAsync(outputs[i], c->d_scratch_pool.as<float>() + (1 + n_in + i) * stride, frames * sizeof(float),
+                               hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(fl.data(), c->d_scratch_flags.p, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    uint64_t om = 0;
+    for (uint32_t i = 0; i < n_out; ++i)
+        if (fl[1 + n_in + i]) om |= 1ull << i;
+    *out_mask = om;
+    retire_cmds(c, 1);
+    return 0;
+}
+
+int fwgpu_timing_enable(fwgpu_ctx* c, int on) {
+    c->timing = on != 0;
+    return 0;
+}
+int fwgpu_timing_read(fwgpu_ctx* c, int which, double* total_ms, uint64_t* launches) {
+    if (which < 0 || which > 3) return fail(c, FWGPU_ERR_INVALID, "timer index");
+    timer_drain(c);
+    *total_ms = c->timers[which].acc_ms;
+    *launches = c->timers[which].launches;
+    return 0;
+}
+int fwgpu_timing_reset(fwgpu_ctx* c) {
+    timer_drain(c);
+    for (TimerCat& t : c->timers) {
+        t.acc_ms = 0.0;
+        t.launches = 0;
+    }
+    return 0;
+}
+int fwgpu_device_info(fwgpu_ctx* c, char* name, int name_cap, int* cus, uint64_t* hbm) {
+    hipDeviceProp_t prop;
+    HIPC(c, hipGetDeviceProperties(&prop, c->device));
+    if (name && name_cap > 0) {
+        strncpy(name, prop.name, (size_t)name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm) *hbm = (uint64_t)prop.totalGlobalMem;
+    return 0;
+}
+
+}  // extern "C"

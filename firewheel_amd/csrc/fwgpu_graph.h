@@ -1,0 +1,97 @@
+// fwgpu_graph.h — host-side mirror of Firewheel's AudioGraph edit API (graph/graph.rs) and the launch
+// planner that turns a graph (or an imported CompiledSchedule) into a device plan.
+//
+// Not a translation of graph/graph/compiler.rs: the reference allocates buffers for a SEQUENTIAL node loop
+// (LIFO reuse right after a node is assigned, compiler.rs:110-130,402-404), which would serialise a whole
+// level on WAR hazards on the GPU.  Here every output port gets its own buffer id ("renamed"), unconnected
+// inputs all read the constant zero buffer 0, and nodes are grouped into topological levels that run as
+// one launch each.  Order inside the schedule follows the reference's Kahn BFS (compiler.rs:232-300) so
+// introspection matches graph/graph/compiler/schedule.rs's tests.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "fwgpu_types.h"
+
+namespace fwgpu {
+
+struct HostEdge {
+    bool alive = false;
+    uint32_t gen = 0;
+    uint32_t src = 0, dst = 0;  // node slots
+    uint32_t sport = 0, dport = 0;
+};
+
+struct HostNode {
+    bool alive = false;
+    uint32_t gen = 0;
+    int kind = K_DUMMY;
+    uint32_t n_in = 0, n_out = 0;
+    bool activated = false;  // has a NodeState on the device
+    NodeState init;          // initial audio-half state built from the constructor params
+    std::vector<int> in_edge;              // per input port: edge slot or -1
+    std::vector<std::vector<int>> out_edges;  // per output port: edge slots (one-to-many)
+    int pending_msgs = 0;    // sampler ring occupancy since the last process call (sampler.rs:14)
+};
+
+inline int64_t make_id(uint32_t slot, uint32_t gen) { return (int64_t(gen) << 32) | int64_t(slot); }
+
+// IR handed to the executor
+struct PlanNode {
+    uint32_t slot;
+    int kind;
+    int n_in, n_out;
+    int level;
+    int is_graph_io;            // 0, 1 = graph_in, 2 = graph_out
+    std::vector<int> in_buf;    // renamed buffer id, 0 = unconnected (zero buffer)
+    std::vector<int> out_buf;
+    std::vector<int> in_src_node;  // index into Plan::nodes of the producer, -1 = unconnected
+    std::vector<int> in_src_port;
+};
+
+struct Plan {
+    std::vector<PlanNode> nodes;  // schedule order: graph_in first, graph_out last, Kahn BFS between
+    int num_buffers = 1;          // including the zero buffer
+    int num_levels = 0;
+};
+
+class HostGraph {
+  public:
+    HostGraph(uint32_t n_graph_in, uint32_t n_graph_out);
+    uint32_t graph_in_slot, graph_out_slot;
+    std::vector<HostNode> nodes;
+    std::vector<uint32_t> free_nodes;
+    std::vector<HostEdge> edges;
+    std::vector<uint32_t> free_edges;
+    bool needs_compile = true;
+    std::vector<uint32_t> nodes_to_activate;
+
+    HostNode* get(int64_t id);
+    int64_t id_of(uint32_t slot) const { return make_id(slot, nodes[slot].gen); }
+
+    int64_t add_node(int kind, uint32_t n_in, uint32_t n_out, const NodeState& init);
+    int remove_node(int64_t id);
+    int64_t connect(int64_t src, uint32_t sport, int64_t dst, uint32_t dport, bool check_cycles);
+    int disconnect(int64_t src, uint32_t sport, int64_t dst, uint32_t dport);
+    int disconnect_edge(int64_t edge);
+    bool cycle_detected();
+
+    // Kahn BFS in the reference's order.  Returns false on a cycle.
+    bool topo_order(std::vector<uint32_t>& order);
+    // graph -> Plan.  0 or a CompileGraphError code; err gets the message.
+    int build_plan(Plan& plan, std::string& err);
+
+  private:
+    void remove_edge_slot(uint32_t e);
+};
+
+// node activation checks (AudioNode::activate of each kind: volume.rs:56-66, sum.rs:20-30,
+// hard_clip.rs:30-40).  Returns false + message on failure.
+bool check_activation(int kind, uint32_t n_in, uint32_t n_out, std::string& err);
+
+// levelise + rename: fills level, in_buf/out_buf from in_src_*; nodes must be topologically ordered.
+void finalize_plan(Plan& plan);
+
+}  // namespace fwgpu

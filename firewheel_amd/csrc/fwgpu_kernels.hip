@@ -1,0 +1,904 @@
+// fwgpu_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the Firewheel per-block DSP executor.
+//
+// Two execution plans share the node state in HBM:
+//   * generic level-batched executor: k_level — one 64-lane wave per scheduled node, one launch per
+//     topological level, bit-exact restatement of every reference node (nodes/*.rs);
+//   * fused voice-bank plan: k_voice_control (per-voice per-block state machines, K blocks per launch)
+//     -> k_leaf_sum (HBM-streaming kernel: source fetch + gain stages + ordered radix-P sum in registers)
+//     -> k_level over the upper sum tree (K-batched) -> k_graph_out.
+// Compiled with -ffp-contract=off: the reference (Rust) never fuses mul+add, and parity is bit-exact.
+//
+// Layout: planar f32, one channel-block = `stride` floats (multiple of 64 => every buffer is 256-B aligned,
+// a wave's float4 access covers 1 KiB contiguous).  Reference citations: core/ nodes/ graph/ as in fwgpu.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fwgpu_launch.h"
+
+namespace fwgpu {
+
+#define WAVE 64
+#define WPB 4  // waves (nodes) per workgroup in k_level / k_leaf_sum
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned vector (unaligned playheads)
+
+__device__ __forceinline__ v4f splat(float x) { return (v4f){x, x, x, x}; }
+
+// ------------------------------------------------------------------ SilenceMask (core/silence_mask.rs:7-74)
+__device__ __forceinline__ uint64_t mask_all_silent_bits(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+__device__ __forceinline__ bool mask_all(uint64_t m, int n) {
+    uint64_t a = mask_all_silent_bits(n);
+    return (m & a) == a;
+}
+__device__ __forceinline__ bool mask_any(uint64_t m, int n) { return (m & mask_all_silent_bits(n)) != 0; }
+__device__ __forceinline__ bool mask_bit(uint64_t m, int i) { return (m >> i) & 1ull; }
+
+// ------------------------------------------------------------------ ParamSmoother (core/param/smoother.rs)
+struct GainRun {
+    int ramp;    // 1: per-frame values follow out[i] = in_a + out[i-1]*b from prev
+    float c;     // constant value when !ramp
+    float in_a;  // input * a
+    float b;
+    float prev;  // running last_output
+};
+
+// set_and_process() up to the point where the per-frame ramp starts (smoother.rs:133-140,159-184).
+// When status != Active the reference returns its (constant == input) buffer; when the first ramp sample is
+// within settle_epsilon the reference discards the ramp, refills with `input` and goes Deactivating (Q1,Q2).
+__device__ __forceinline__ GainRun smoother_begin(Smoother& s, float target, int frames) {
+    if (!(s.input == target)) {  // set(): smoother.rs:134
+        s.input = target;
+        s.status = SM_ACTIVE;
+    }
+    GainRun r;
+    r.ramp = 0;
+    r.c = s.input;
+    r.in_a = 0.f;
+    r.b = s.b;
+    r.prev = s.last;
+    if (s.status != SM_ACTIVE || frames == 0) return r;  // :162-167
+    float in_a = s.input * s.a;                          // :169
+    float y0 = in_a + (s.last * s.b);                    // :171
+    if (fabsf(s.input - y0) < s.eps) {                   // :181  (Q1: output[0])
+        s.last = s.input;                                // reset(input) :116-122
+        s.status = SM_DEACTIVATING;                      // :183
+        return r;
+    }
+    r.ramp = 1;
+    r.in_a = in_a;
+    return r;
+}
+__device__ __forceinline__ void smoother_reset(Smoother& s, float val) {  // smoother.rs:115-129
+    if (s.status != SM_INACTIVE) {
+        s.status = SM_INACTIVE;
+        s.input = val;
+        s.last = val;
+    } else if (!(s.input == val)) {
+        s.input = val;
+        s.last = val;
+    }
+}
+__device__ __forceinline__ bool smoother_is_smoothing(const Smoother& s) { return s.status != SM_INACTIVE; }
+
+// Advance the serial recurrence over `n` (<= 256) frames; lane L keeps frames 4L..4L+3 of the chunk.
+// All 64 lanes run the same scalar chain (the recurrence is serial in time; smoother.rs:171-175).
+__device__ __forceinline__ v4f ramp_chunk(GainRun& r, int n, int lane) {
+    v4f g = splat(0.f);
+    float prev = r.prev;
+    const float in_a = r.in_a, b = r.b;
+    int q = 0;
+    for (; q * 4 + 4 <= n; ++q) {
+        float v0 = in_a + (prev * b);
+        float v1 = in_a + (v0 * b);
+        float v2 = in_a + (v1 * b);
+        float v3 = in_a + (v2 * b);
+        if (q == lane) g = (v4f){v0, v1, v2, v3};
+        prev = v3;
+    }
+    int rem = n - q * 4;
+    if (rem > 0) {
+        float v0 = in_a + (prev * b);
+        float v1 = in_a + (v0 * b);
+        float v2 = in_a + (v1 * b);
+        if (q == lane) g = (v4f){v0, v1, v2, 0.f};
+        prev = rem == 1 ? v0 : (rem == 2 ? v1 : v2);
+    }
+    r.prev = prev;
+    return g;
+}
+__device__ __forceinline__ v4f gain_chunk(GainRun& r, int n, int lane) { return r.ramp ? ramp_chunk(r, n, lane) : splat(r.c); }
+
+// ------------------------------------------------------------------ control -> audio messages
+__device__ __forceinline__ uint64_t sat_round_u64(double x) {  // `(x).round() as u64` (saturating, NaN -> 0)
+    double r = round(x);
+    if (!(r == r)) return 0;
+    if (r <= 0.0) return 0;
+    if (r >= 18446744073709551615.0) return ~0ull;
+    return (uint64_t)r;
+}
+
+// Apply every queued message for (state_idx, block) in order.  cmds are sorted by (state, block, seq).
+// nodes/sampler.rs:331-414 (ring drained at the top of process()), volume.rs:92 (atomic load per block).
+__device__ inline void apply_cmds(NodeState& s, int state_idx, uint32_t block, const Cmd* cmds, int n_cmds,
+                                  const SampleDesc* samples) {
+    if (n_cmds == 0) return;
+    int lo = 0, hi = n_cmds;  // lower bound of (state_idx, block)
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        const Cmd& c = cmds[mid];
+        bool less = c.state < state_idx || (c.state == state_idx && c.block < block);
+        if (less) lo = mid + 1;
+        else hi = mid;
+    }
+    for (int i = lo; i < n_cmds; ++i) {
+        Cmd c = cmds[i];
+        if (c.state != state_idx || c.block != block) break;
+        switch (c.type) {
+            case CMD_SET_P0: s.p0 = c.f0; break;
+            case CMD_SET_P1: s.p1 = c.f0; break;
+            case CMD_SET_ENABLED: s.enabled = c.i0; break;
+            case CMD_SMP_SET_SAMPLE:  // sampler.rs:333-364
+                s.sample = c.i0;
+                if (s.has_loop && s.sample >= 0 && s.full_range) {  // update_sample :265-277
+                    s.loop_start = 0;
+                    s.loop_end = samples[s.sample].frames;
+                }
+                if (c.i1) {  // stop_playback
+                    s.playhead = s.has_loop ? s.loop_start : 0;
+                    s.playing = 0;
+                }
+                break;
+            case CMD_SMP_PLAY: s.playing = 1; break;   // :365-371
+            case CMD_SMP_PAUSE: s.playing = 0; break;  // :372-378
+            case CMD_SMP_STOP:                         // :379-391
+                s.playhead = s.has_loop ? s.loop_start : 0;
+                s.playing = 0;
+                break;
+            case CMD_SMP_SET_PLAYHEAD:  // :392-399
+                s.playhead = sat_round_u64(c.d0 * (double)s.sample_rate);
+                break;
+            case CMD_SMP_SET_LOOP:  // :400-412 + ProcLoopRange::new :241-263
+                if (c.i0 == 0) {
+                    s.has_loop = 0;
+                } else {
+                    s.has_loop = 1;
+                    if (c.i0 == 1) {
+                        s.loop_start = 0;
+                        s.loop_end = s.sample >= 0 ? samples[s.sample].frames : 0;
+                        s.full_range = 1;
+                    } else {
+                        s.loop_start = sat_round_u64(c.d0 * (double)s.sample_rate);
+                        s.loop_end = sat_round_u64(c.d1 * (double)s.sample_rate);
+                        s.full_range = 0;
+                    }
+                    if (s.playhead >= s.loop_start && s.playhead < s.loop_end) s.playhead = s.loop_start;  // Q7
+                }
+                break;
+            default: break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ sampler playhead logic (shared by both plans)
+struct Fetch {
+    uint64_t off0, off1;
+    uint32_t n1;
+    int wrap, tail_zero;
+};
+// nodes/sampler.rs:445-517.  Returns false when the one-shot playhead is already past the end
+// (":486-497": playing=false, clear).  Updates playhead/playing exactly as the reference does.
+__device__ __forceinline__ bool sampler_advance(NodeState& s, uint64_t len, uint32_t frames, Fetch& f) {
+    f.off0 = f.off1 = 0;
+    f.n1 = frames;
+    f.wrap = f.tail_zero = 0;
+    if (s.has_loop) {
+        if (s.playhead >= s.loop_end) s.playhead = s.loop_start;  // :446-453
+        uint64_t left = s.loop_end - s.playhead;                  // :457-462
+        uint32_t first = left < (uint64_t)frames ? (uint32_t)left : frames;
+        f.off0 = s.playhead;
+        f.n1 = first;
+        if (first < frames) {  // :467-481 wraps once (Q8)
+            s.playhead = s.loop_start;
+            f.off1 = s.playhead;
+            f.wrap = 1;
+            s.playhead += (uint64_t)(frames - first);
+        } else {
+            s.playhead += (uint64_t)frames;
+        }
+        return true;
+    }
+    if (s.playhead >= len) {  // :486-497
+        s.playing = 0;
+        return false;
+    }
+    uint64_t left = len - s.playhead;
+    uint32_t copy = left < (uint64_t)frames ? (uint32_t)left : frames;  // :499
+    f.off0 = s.playhead;
+    f.n1 = copy;
+    if (copy < frames) {  // :503-513 (Q9)
+        s.playing = 0;
+        s.playhead = 0;
+        f.tail_zero = 1;
+    } else {
+        s.playhead += (uint64_t)frames;
+    }
+    return true;
+}
+
+// core/sample_resource.rs:338-345 + fill_buffers_* :348-456 — one source element, converted.
+__device__ __forceinline__ float sample_fetch(const SampleDesc& sd, int ch, uint64_t frame) {
+    switch (sd.format) {
+        case FMT_I_I16: return (float)((const int16_t*)sd.data)[frame * (uint64_t)sd.channels + ch] * (1.0f / 32767.0f);
+        case FMT_I_U16:
+            return ((float)((const uint16_t*)sd.data)[frame * (uint64_t)sd.channels + ch] * (2.0f / 65535.0f)) - 1.0f;
+        case FMT_I_F32: return ((const float*)sd.data)[frame * (uint64_t)sd.channels + ch];
+        case FMT_P_I16: return (float)((const int16_t*)sd.data)[(uint64_t)ch * sd.frames + frame] * (1.0f / 32767.0f);
+        case FMT_P_U16:
+            return ((float)((const uint16_t*)sd.data)[(uint64_t)ch * sd.frames + frame] * (2.0f / 65535.0f)) - 1.0f;
+        default: return ((const float*)sd.data)[(uint64_t)ch * sd.frames + frame];
+    }
+}
+// four consecutive output frames f..f+3 of channel ch under a Fetch (per-element path: any format, wrap, tail)
+__device__ __forceinline__ v4f sample_fetch4(const SampleDesc& sd, int ch, const Fetch& f, uint32_t frame, uint32_t frames) {
+    v4f x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t i = frame + j;
+        float v = 0.f;
+        if (i < frames) {
+            if (i < f.n1) v = sample_fetch(sd, ch, f.off0 + i);
+            else if (f.wrap) v = sample_fetch(sd, ch, f.off1 + (i - f.n1));
+            else v = 0.f;  // tail_zero (sampler.rs:509-511)
+        }
+        x[j] = v;
+    }
+    return x;
+}
+
+// ------------------------------------------------------------------ generic executor: one wave per node
+struct WaveIO {
+    float* pool;
+    uint8_t* flags;
+    const int* in_buf;
+    const int* out_buf;
+    int stride;
+    int lane;
+    int frames;
+    __device__ __forceinline__ const float* in(int i) const { return pool + (size_t)in_buf[i] * stride; }
+    __device__ __forceinline__ float* out(int i) const { return pool + (size_t)out_buf[i] * stride; }
+};
+
+// core/util.rs:165-175
+__device__ __forceinline__ uint64_t clear_all_outputs(const WaveIO& io, int first, int n_out) {
+    for (int c = first; c < n_out; ++c) {
+        float* o = io.out(c);
+        for (int base = io.lane * 4; base < io.frames; base += 256) *(v4f*)(o + base) = splat(0.f);
+    }
+    return mask_all_silent_bits(n_out - first);
+}
+
+__device__ __forceinline__ float clipf(float x, float t) { return fmaxf(fminf(x, t), -t); }
+__device__ __forceinline__ float beep_step(float ph, float inc) {  // beep_test.rs:90 (f32::fract)
+    float t = ph + inc;
+    return t - truncf(t);
+}
+
+__device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, uint32_t cmd_block) {
+    const NodeDesc nd = v.nodes[node_idx];
+    if (nd.is_graph_io) return;  // graph_in / graph_out are I/O edges (k_graph_in / k_graph_out)
+    const int lane = threadIdx.x & (WAVE - 1);
+    WaveIO io;
+    io.pool = v.pool + (size_t)blk * v.pool_blk_stride;
+    io.flags = v.flags + (size_t)blk * v.flags_blk_stride;
+    io.in_buf = v.in_buf + nd.in_off;
+    io.out_buf = v.out_buf + nd.out_off;
+    io.stride = v.stride;
+    io.lane = lane;
+    io.frames = v.frames;
+    const int frames = v.frames;
+
+    // in_silence_mask from the per-buffer flags (schedule.rs:305-320); unconnected inputs read buffer 0,
+    // the constant zero buffer whose flag is always set (== should_clear).
+    bool fl = lane < nd.n_in ? (io.flags[io.in_buf[lane]] != 0) : false;
+    const uint64_t in_mask = __ballot(fl);
+    uint64_t out_mask = 0;  // processor.rs:233
+
+    NodeState s;
+    const bool stateful = nd.kind == K_VOLUME || nd.kind == K_SAMPLER || nd.kind == K_BEEP || nd.kind == K_PAN ||
+                          nd.kind == K_HARD_CLIP;
+    if (stateful) {
+        s = v.states[nd.state];
+        apply_cmds(s, nd.state, cmd_block, v.cmds, v.n_cmds, v.samples);
+    }
+
+    switch (nd.kind) {
+        case K_DUMMY:  // nodes/dummy.rs:33-42 — writes nothing
+            break;
+
+        case K_VOLUME: {  // nodes/volume.rs:84-145
+            float raw = s.p0;
+            if (mask_all(in_mask, nd.n_in)) {  // :94-100
+                smoother_reset(s.s0, raw);
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            GainRun run = smoother_begin(s.s0, raw, frames);  // :102
+            if (!smoother_is_smoothing(s.s0) && run.c < 0.00001f) {  // :104-108
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            out_mask = in_mask;  // :110
+            const bool stereo = nd.n_in == 2 && nd.n_out == 2;
+            const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
+            for (int base = 0; base < frames; base += 256) {
+                int n = frames - base < 256 ? frames - base : 256;
+                v4f g = gain_chunk(run, n, lane);
+                int f0 = base + lane * 4;
+                if (f0 >= frames) continue;
+                for (int c = 0; c < nch; ++c) {
+                    v4f y;
+                    if (!stereo && mask_bit(in_mask, c)) y = splat(0.f);  // :132-135 (Q15)
+                    else y = *(const v4f*)(io.in(c) + f0) * g;            // :123-126, :140-142
+                    *(v4f*)(io.out(c) + f0) = y;
+                }
+            }
+            if (run.ramp) s.s0.last = run.prev;  // :177
+            break;
+        }
+
+        case K_PAN: {  // SPEC node: volume.rs stereo path with one smoother per channel
+            float tl = s.p0, tr = s.p1;
+            if (mask_all(in_mask, nd.n_in)) {
+                smoother_reset(s.s0, tl);
+                smoother_reset(s.s1, tr);
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            GainRun rl = smoother_begin(s.s0, tl, frames);
+            GainRun rr = smoother_begin(s.s1, tr, frames);
+            out_mask = in_mask;
+            for (int base = 0; base < frames; base += 256) {
+                int n = frames - base < 256 ? frames - base : 256;
+                v4f gl = gain_chunk(rl, n, lane);
+                v4f gr = gain_chunk(rr, n, lane);
+                int f0 = base + lane * 4;
+                if (f0 >= frames) continue;
+                *(v4f*)(io.out(0) + f0) = *(const v4f*)(io.in(0) + f0) * gl;
+                *(v4f*)(io.out(1) + f0) = *(const v4f*)(io.in(1) + f0) * gr;
+            }
+            if (rl.ramp) s.s0.last = rl.prev;
+            if (rr.ramp) s.s1.last = rr.prev;
+            break;
+        }
+
+        case K_SUM: {  // nodes/sum.rs:41-136
+            const int n_in = nd.n_in, n_out = nd.n_out, ports = nd.aux0;
+            if (mask_all(in_mask, n_in)) {  // :52-56
+                out_mask = clear_all_outputs(io, 0, n_out);
+                break;
+            }
+            if (n_in == n_out) {  // :58-65 (Q14)
+                for (int c = 0; c < n_out; ++c)
+                    for (int f0 = lane * 4; f0 < frames; f0 += 256) *(v4f*)(io.out(c) + f0) = *(const v4f*)(io.in(c) + f0);
+                out_mask = in_mask;
+                break;
+            }
+            const bool masked = !(ports == 2 || ports == 3 || ports == 4);  // :67-133 (Q13)
+            for (int c = 0; c < n_out; ++c) {
+                for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+                    v4f acc = *(const v4f*)(io.in(c) + f0);
+                    for (int p = 1; p < ports; ++p) {
+                        int ic = n_out * p + c;
+                        if (masked && mask_bit(in_mask, ic)) continue;  // :122-124
+                        acc = acc + *(const v4f*)(io.in(ic) + f0);
+                    }
+                    *(v4f*)(io.out(c) + f0) = acc;
+                }
+            }
+            break;
+        }
+
+        case K_SAMPLER: {  // nodes/sampler.rs:323-561 (messages already applied above)
+            if (s.sample < 0 || !s.playing) {  // :416-430
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            GainRun run = smoother_begin(s.s0, s.p0, frames);        // :432-433
+            if (!smoother_is_smoothing(s.s0) && run.c < 0.00001f) {  // :437-443
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            const SampleDesc sd = v.samples[s.sample];
+            Fetch ft;
+            if (!sampler_advance(s, sd.frames, (uint32_t)frames, ft)) {  // :486-497
+                if (run.ramp) {  // the smoother already ran this block (:433) — keep its state exact
+                    for (int base = 0; base < frames; base += 256) {
+                        int n = frames - base < 256 ? frames - base : 256;
+                        (void)ramp_chunk(run, n, lane);
+                    }
+                    s.s0.last = run.prev;
+                }
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            const int sch = sd.channels;
+            const int nfill = nd.n_out < sch ? nd.n_out : sch;  // fill_buffers zip + gain zip (:535)
+            for (int base = 0; base < frames; base += 256) {
+                int n = frames - base < 256 ? frames - base : 256;
+                v4f g = gain_chunk(run, n, lane);
+                int f0 = base + lane * 4;
+                if (f0 >= frames) continue;
+                v4f first = splat(0.f);
+                for (int c = 0; c < nfill; ++c) {
+                    v4f x = sample_fetch4(sd, c, ft, (uint32_t)f0, (uint32_t)frames) * g;  // :521-543
+                    if (c == 0) first = x;
+                    *(v4f*)(io.out(c) + f0) = x;
+                }
+                if (nd.n_out > sch) {  // :545-559
+                    if (nd.n_out == 2 && sch == 1) {
+                        *(v4f*)(io.out(1) + f0) = first;
+                    } else {
+                        for (int c = sch; c < nd.n_out; ++c) *(v4f*)(io.out(c) + f0) = splat(0.f);
+                    }
+                }
+            }
+            if (nd.n_out > sch && !(nd.n_out == 2 && sch == 1))
+                for (int c = sch; c < nd.n_out; ++c) out_mask |= (1ull << c);  // :556
+            if (run.ramp) s.s0.last = run.prev;
+            break;
+        }
+
+        case K_BEEP: {  // nodes/beep_test.rs:71-97
+            if (nd.n_out == 0) break;
+            if (!s.enabled) {  // :83-86 (Q12): channel 0 untouched, mask = new_all_silent(n-1)
+                out_mask = clear_all_outputs(io, 1, nd.n_out);
+                break;
+            }
+            const float TAU = 6.28318530717958647692528676655900577f;
+            float ph = s.phasor;
+            const float inc = s.phasor_inc;
+            for (int base = 0; base < frames; base += 256) {
+                int n = frames - base < 256 ? frames - base : 256;
+                v4f p4 = splat(0.f);
+                int q = 0;  // serial phasor (:90); lane keeps the four phases of its frames
+                for (; q * 4 + 4 <= n; ++q) {
+                    float a0 = ph;
+                    ph = beep_step(ph, inc);
+                    float a1 = ph;
+                    ph = beep_step(ph, inc);
+                    float a2 = ph;
+                    ph = beep_step(ph, inc);
+                    float a3 = ph;
+                    ph = beep_step(ph, inc);
+                    if (q == lane) p4 = (v4f){a0, a1, a2, a3};
+                }
+                int rem = n - q * 4;
+                if (rem > 0) {
+                    float a0 = ph;
+                    ph = beep_step(ph, inc);
+                    float a1 = ph;
+                    if (rem > 1) ph = beep_step(ph, inc);
+                    float a2 = ph;
+                    if (rem > 2) ph = beep_step(ph, inc);
+                    if (q == lane) p4 = (v4f){a0, a1, a2, 0.f};
+                }
+                int f0 = base + lane * 4;
+                if (f0 >= frames) continue;
+                v4f y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = sinf(p4[j] * TAU) * s.gain;  // :89
+                for (int c = 0; c < nd.n_out; ++c) *(v4f*)(io.out(c) + f0) = y;  // :93-95
+            }
+            s.phasor = ph;
+            break;
+        }
+
+        case K_HARD_CLIP: {  // nodes/hard_clip.rs:51-95
+            const float t = s.p0;
+            const bool fast = nd.n_in == 2 && nd.n_out == 2 && !mask_any(in_mask, 2);  // :60-63 (Q16)
+            const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
+            for (int c = 0; c < nch; ++c) {
+                const bool sil = !fast && mask_bit(in_mask, c);
+                for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+                    v4f y = splat(0.f);
+                    if (!sil) {
+                        v4f x = *(const v4f*)(io.in(c) + f0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[j] = clipf(x[j], t);
+                    }
+                    *(v4f*)(io.out(c) + f0) = y;
+                }
+            }
+            if (!fast) out_mask = in_mask;  // :93
+            break;
+        }
+
+        case K_MONO_TO_STEREO: {  // nodes/mono_to_stereo.rs:33-50
+            if (mask_bit(in_mask, 0)) {
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+                v4f x = *(const v4f*)(io.in(0) + f0);
+                *(v4f*)(io.out(0) + f0) = x;
+                *(v4f*)(io.out(1) + f0) = x;
+            }
+            break;
+        }
+
+        case K_STEREO_TO_MONO: {  // nodes/stereo_to_mono.rs:33-56
+            if (mask_all(in_mask, 2) || nd.n_in < 2 || nd.n_out == 0) {
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+                v4f a = *(const v4f*)(io.in(0) + f0);
+                v4f b = *(const v4f*)(io.in(1) + f0);
+                *(v4f*)(io.out(0) + f0) = (a + b) * 0.5f;
+            }
+            break;
+        }
+        default: break;
+    }
+
+    if (stateful && lane == 0) v.states[nd.state] = s;
+    // schedule.rs:338-341: every output buffer's flag is overwritten with the node's out mask bit
+    if (lane < nd.n_out) io.flags[io.out_buf[lane]] = mask_bit(out_mask, lane) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __restrict__ level_nodes, int n_nodes,
+                                                      uint32_t cmd_block0) {
+    int w = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (w >= n_nodes) return;
+    node_process_wave(v, level_nodes[w], blockIdx.y, cmd_block0 + blockIdx.y);
+}
+
+// B1: one node on scratch buffers (single wave)
+__global__ __launch_bounds__(WAVE) void k_single_node(DevView v, int node_idx) { node_process_wave(v, node_idx, 0, 0); }
+
+// ------------------------------------------------------------------ state init / graph I/O edges
+struct StateInit {
+    int index;
+    int pad;
+    NodeState st;
+};
+__global__ void k_scatter_states(NodeState* states, const uint8_t* __restrict__ inits, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const StateInit* in = (const StateInit*)inits + i;
+    states[in->index] = in->st;
+}
+
+// processor.rs:99-115 + schedule.rs:213-253 + util.rs:44-87.  Q10: the graph_in Dummy node's out mask (0)
+// overwrites whatever prepare_graph_inputs computed, so every graph-input buffer flag ends up false.
+__global__ void k_graph_in(float* pool, uint8_t* flags, int stride, const int* __restrict__ bufs, int n_bufs,
+                           const float* __restrict__ interleaved, int n_in_ch, int frames) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = blockIdx.y;
+    if (f < frames) {
+        float x = c < n_in_ch ? interleaved[(size_t)f * n_in_ch + c] : 0.f;  // extra graph inputs zero-filled
+        pool[(size_t)bufs[c] * stride + f] = x;
+    }
+    if (f == 0) flags[bufs[c]] = 0;
+}
+
+// processor.rs:120-148 + schedule.rs:255-287 + util.rs:90-147.  K-batched: blockIdx.y = block.
+__global__ void k_graph_out(const float* __restrict__ pool, const uint8_t* __restrict__ flags, int stride,
+                            size_t pool_blk_stride, size_t flags_blk_stride, const int* __restrict__ bufs, int n_bufs,
+                            float* __restrict__ out, int n_out_ch, int frames) {
+    const uint32_t blk = blockIdx.y;
+    const float* p = pool + (size_t)blk * pool_blk_stride;
+    const uint8_t* fl = flags + (size_t)blk * flags_blk_stride;
+    float* o = out + (size_t)blk * frames * n_out_ch;
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    int n_read = n_bufs < n_out_ch ? n_bufs : n_out_ch;  // read_output_len
+    if (n_read == 2 && n_out_ch == 2) {                   // interleave_stereo (util.rs:123-147)
+        bool both = fl[bufs[0]] && fl[bufs[1]];
+        float2 y;
+        y.x = both ? 0.f : p[(size_t)bufs[0] * stride + f];
+        y.y = both ? 0.f : p[(size_t)bufs[1] * stride + f];
+        *(float2*)(o + (size_t)f * 2) = y;
+        return;
+    }
+    for (int c = 0; c < n_out_ch; ++c) {  // interleave (util.rs:90-120): zero-fill, skip silent channels
+        float y = 0.f;
+        if (c < n_read && !fl[bufs[c]]) y = p[(size_t)bufs[c] * stride + f];
+        o[(size_t)f * n_out_ch + c] = y;
+    }
+}
+
+__global__ void k_set_flags(uint8_t* flags, const int* __restrict__ bufs, int n, uint64_t mask) {
+    int i = threadIdx.x;
+    if (i < n) flags[bufs[i]] = (mask >> i) & 1ull;
+}
+__global__ void k_get_flags(const uint8_t* flags, const int* __restrict__ bufs, int n, uint64_t* mask) {
+    bool f = (int)threadIdx.x < n ? flags[bufs[threadIdx.x]] != 0 : false;
+    uint64_t m = __ballot(f);
+    if (threadIdx.x == 0) *mask = m;
+}
+
+// ------------------------------------------------------------------ fused voice-bank plan
+// Control kernel: one thread per voice walks K blocks, running the per-block state machines of the whole
+// chain in schedule order (sampler -> stage nodes) and emitting one VoiceBlk per block.  Per-frame ramps
+// (ParamSmoother Active) are materialised into `ramps` only for blocks where the values actually change.
+struct StageRegs {  // the NodeState prefix (p0,p1,s0,s1) a gain stage needs
+    float p0, p1;
+    Smoother s0, s1;
+};
+
+// Serial ramp -> global memory; returns false (and writes nothing) when the recurrence is already at its
+// f32 fixed point (Q28: an Active smoother can stall above settle_epsilon forever) — the block is constant.
+__device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, float* dst1) {
+    float prev = r.prev;
+    float v0 = r.in_a + (prev * r.b);
+    if (v0 == prev) {  // fixed point: every later value equals prev, bit for bit
+        r.c = prev;
+        r.ramp = 0;
+        return false;
+    }
+    for (int i = 0; i < frames; ++i) {
+        prev = r.in_a + (prev * r.b);
+        dst0[i] = prev;
+        if (dst1) dst1[i] = prev;
+    }
+    r.prev = prev;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint32_t cmd_block0) {
+    int vi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vi >= fv.n_voices) return;
+    const VoiceDesc vd = fv.voices[vi];
+    const int frames = fv.frames;
+    NodeState ss = fv.states[vd.sampler_state];
+    StageRegs st[FW_MAX_STAGES - 1];
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
+        if (j < vd.n_stages) st[j] = *(const StageRegs*)&fv.states[vd.stage_state[j]];
+
+    for (int k = 0; k < K; ++k) {
+        const uint32_t cb = cmd_block0 + k;
+        VoiceBlk d;
+        d.flags = 0;
+        d.n1 = frames;
+        d.off0 = d.off1 = 0;
+        d.sample = -1;
+        d.pad = 0;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j) d.g[j][0] = d.g[j][1] = 1.0f;
+        float* ramp_base = fv.ramps + ((size_t)k * fv.n_voices + vi) * (size_t)fv.ramp_slots * (size_t)fv.stride;
+
+        // ---- sampler (nodes/sampler.rs:323-561)
+        apply_cmds(ss, vd.sampler_state, cb, fv.cmds, fv.n_cmds, fv.samples);
+        bool silent = true;
+        if (ss.sample >= 0 && ss.playing) {
+            GainRun run = smoother_begin(ss.s0, ss.p0, frames);
+            if (!(!smoother_is_smoothing(ss.s0) && run.c < 0.00001f)) {
+                const SampleDesc sd = fv.samples[ss.sample];
+                Fetch ft;
+                bool ok = sampler_advance(ss, sd.frames, (uint32_t)frames, ft);
+                if (run.ramp) {
+                    if (ramp_emit(run, frames, ramp_base, ramp_base + fv.stride)) {
+                        d.flags |= 3u << VB_RAMP_SHIFT;
+                        ss.s0.last = run.prev;
+                    }
+                }
+                if (ok) {
+                    silent = false;
+                    d.sample = ss.sample;
+                    d.off0 = ft.off0;
+                    d.off1 = ft.off1;
+                    d.n1 = ft.n1;
+                    if (ft.wrap) d.flags |= VB_WRAP;
+                    if (ft.tail_zero) d.flags |= VB_TAIL_ZERO;
+                    if (sd.channels == 1) d.flags |= VB_MONO;
+                    d.g[0][0] = d.g[0][1] = run.c;
+                }
+            }
+        }
+        // ---- chain stages in schedule order
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+            if (j >= vd.n_stages) break;
+            StageRegs& r = st[j];
+            {   // messages for this node (only p0/p1 apply to gain stages)
+                NodeState tmp;
+                tmp.p0 = r.p0;
+                tmp.p1 = r.p1;
+                apply_cmds(tmp, vd.stage_state[j], cb, fv.cmds, fv.n_cmds, fv.samples);
+                r.p0 = tmp.p0;
+                r.p1 = tmp.p1;
+            }
+            float* rb = ramp_base + (size_t)(j + 1) * 2 * fv.stride;
+            if (vd.stage_kind[j] == K_VOLUME) {  // nodes/volume.rs:84-145
+                if (silent) {
+                    smoother_reset(r.s0, r.p0);
+                } else {
+                    GainRun run = smoother_begin(r.s0, r.p0, frames);
+                    if (!smoother_is_smoothing(r.s0) && run.c < 0.00001f) {
+                        silent = true;
+                    } else {
+                        if (run.ramp && ramp_emit(run, frames, rb, rb + fv.stride)) {
+                            d.flags |= 3u << (VB_RAMP_SHIFT + 2 * (j + 1));
+                            r.s0.last = run.prev;
+                        }
+                        d.g[j + 1][0] = d.g[j + 1][1] = run.c;
+                    }
+                }
+            } else {  // K_PAN (SPEC)
+                if (silent) {
+                    smoother_reset(r.s0, r.p0);
+                    smoother_reset(r.s1, r.p1);
+                } else {
+                    GainRun rl = smoother_begin(r.s0, r.p0, frames);
+                    GainRun rr = smoother_begin(r.s1, r.p1, frames);
+                    if (rl.ramp && ramp_emit(rl, frames, rb, nullptr)) {
+                        d.flags |= 1u << (VB_RAMP_SHIFT + 2 * (j + 1));
+                        r.s0.last = rl.prev;
+                    }
+                    if (rr.ramp && ramp_emit(rr, frames, rb + fv.stride, nullptr)) {
+                        d.flags |= 2u << (VB_RAMP_SHIFT + 2 * (j + 1));
+                        r.s1.last = rr.prev;
+                    }
+                    d.g[j + 1][0] = rl.c;
+                    d.g[j + 1][1] = rr.c;
+                }
+            }
+        }
+        if (silent) d.flags |= VB_SILENT;
+        fv.blks[(size_t)k * fv.n_voices + vi] = d;
+    }
+    fv.states[vd.sampler_state] = ss;
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
+        if (j < vd.n_stages) *(StageRegs*)&fv.states[vd.stage_state[j]] = st[j];
+}
+
+// Leaf kernel: one wave per (leaf SumNode, block).  For each port in order: fetch the voice's source frames,
+// run its gain stages in registers, and accumulate in the reference's summation order (nodes/sum.rs).
+// HBM traffic = the source samples once (8 B per stereo voice-sample) + one partial-bus write per leaf.
+__device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& d, uint32_t k, int voice, int f0, int frames,
+                                           v4f& xl, v4f& xr) {
+    const SampleDesc sd = fv.samples[d.sample];
+    const bool simple = !(d.flags & (VB_WRAP | VB_TAIL_ZERO)) && sd.format == FMT_P_F32 && f0 + 4 <= frames;
+    const bool mono = d.flags & VB_MONO;
+    if (simple) {  // planar f32, contiguous: one dwordx4 per channel per lane (core/sample_resource.rs:442-456)
+        const float* base = (const float*)sd.data + d.off0 + f0;
+        xl = *(const v4f_u*)base;
+        xr = mono ? xl : *(const v4f_u*)(base + sd.frames);
+    } else {
+        Fetch ft;
+        ft.off0 = d.off0;
+        ft.off1 = d.off1;
+        ft.n1 = d.n1;
+        ft.wrap = (d.flags & VB_WRAP) ? 1 : 0;
+        ft.tail_zero = (d.flags & VB_TAIL_ZERO) ? 1 : 0;
+        xl = sample_fetch4(sd, 0, ft, (uint32_t)f0, (uint32_t)frames);
+        xr = mono ? xl : sample_fetch4(sd, 1, ft, (uint32_t)f0, (uint32_t)frames);
+    }
+    const uint32_t rbits = d.flags >> VB_RAMP_SHIFT;
+    if (rbits == 0) {  // constant gains: sampler.rs:530-533 then volume.rs:123-126 / pan, one rounding each
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j) {
+            xl = xl * d.g[j][0];
+            xr = xr * d.g[j][1];
+        }
+        // a mono sample is duplicated AFTER the sampler gain (sampler.rs:546-551); identical values either way
+    } else {
+        const float* rb = fv.ramps + ((size_t)k * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j) {
+            v4f gl = (rbits >> (2 * j)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j) * fv.stride) : splat(d.g[j][0]);
+            v4f gr = (rbits >> (2 * j + 1)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j + 1) * fv.stride) : splat(d.g[j][1]);
+            xl = xl * gl;
+            xr = xr * gr;
+        }
+    }
+}
+
+__global__ __launch_bounds__(WAVE* WPB) void k_leaf_sum(FusedView fv) {
+    const int leaf = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (leaf >= fv.n_leaves) return;
+    const uint32_t k = blockIdx.y;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const LeafDesc ld = fv.leaves[leaf];
+    const int frames = fv.frames;
+    const VoiceBlk* blk = fv.blks + (size_t)k * fv.n_voices + ld.first_voice;
+    float* bus = fv.bus + (size_t)k * fv.bus_blk_stride;
+    uint8_t* bflags = fv.bus_flags + (size_t)k * fv.bus_flags_blk_stride;
+    float* outl = bus + (size_t)ld.out_buf * fv.stride;
+    float* outr = outl + fv.stride;
+
+    // in_silence_mask of the SumNode: both channels of a chain share one flag
+    bool sil = lane < ld.ports ? (blk[lane].flags & VB_SILENT) != 0 : true;
+    const uint64_t silent_ports = __ballot(sil);
+    const bool all_silent = (silent_ports & mask_all_silent_bits(ld.ports)) == mask_all_silent_bits(ld.ports);
+    const bool masked = !(ld.ports == 2 || ld.ports == 3 || ld.ports == 4);  // sum.rs:67-133 (Q13)
+
+    for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+        v4f accl = splat(0.f), accr = splat(0.f);
+        if (!all_silent) {
+            for (int p = 0; p < ld.ports; ++p) {
+                const bool psil = (silent_ports >> p) & 1ull;
+                v4f xl = splat(0.f), xr = splat(0.f);  // a silent chain's buffers hold cleared zeros
+                if (!psil) {
+                    const VoiceBlk d = blk[p];
+                    voice_eval(fv, d, k, ld.first_voice + p, f0, frames, xl, xr);
+                }
+                if (p == 0) {  // sum.rs:117 copy_from_slice(port 0) — also when silent; 2/3/4-port: in1
+                    accl = xl;
+                    accr = xr;
+                } else if (!(masked && psil)) {  // :122-124 skip silent ports (n-port path only)
+                    accl = accl + xl;
+                    accr = accr + xr;
+                }
+            }
+        }
+        *(v4f*)(outl + f0) = accl;  // all_silent: clear_all_outputs (sum.rs:52-56)
+        *(v4f*)(outr + f0) = accr;
+    }
+    // out mask: all-silent -> both flagged; 1-port copy -> passthrough (sum.rs:58-65); else 0
+    if (lane < 2) bflags[ld.out_buf + lane] = all_silent ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ launch wrappers (host side of this TU)
+#define HIPCHK(x)                        \
+    do {                                 \
+        hipError_t e__ = (x);            \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0) {
+    if (n_nodes <= 0) return 0;
+    dim3 grid((n_nodes + WPB - 1) / WPB, K);
+    hipLaunchKernelGGL(k_level, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0);
+    return (int)hipGetLastError();
+}
+int launch_single_node(hipStream_t s, const DevView& v, int node_idx) {
+    hipLaunchKernelGGL(k_single_node, dim3(1), dim3(WAVE), 0, s, v, node_idx);
+    return (int)hipGetLastError();
+}
+int launch_scatter_states(hipStream_t s, NodeState* states, const void* d_inits, int n) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_scatter_states, dim3((n + 63) / 64), dim3(64), 0, s, states, (const uint8_t*)d_inits, n);
+    return (int)hipGetLastError();
+}
+int launch_graph_in(hipStream_t s, float* pool, uint8_t* flags, int stride, const int* d_bufs, int n_bufs,
+                    const float* d_interleaved, int n_in_ch, int frames) {
+    if (n_bufs <= 0) return 0;
+    dim3 grid((frames + 255) / 256, n_bufs);
+    hipLaunchKernelGGL(k_graph_in, grid, dim3(256), 0, s, pool, flags, stride, d_bufs, n_bufs, d_interleaved, n_in_ch, frames);
+    return (int)hipGetLastError();
+}
+int launch_graph_out(hipStream_t s, const float* pool, const uint8_t* flags, int stride, size_t pool_blk_stride,
+                     size_t flags_blk_stride, const int* d_bufs, int n_bufs, float* d_out, int n_out_ch, int frames, int K) {
+    if (n_out_ch <= 0 || frames <= 0) return 0;
+    dim3 grid((frames + 255) / 256, K);
+    hipLaunchKernelGGL(k_graph_out, grid, dim3(256), 0, s, pool, flags, stride, pool_blk_stride, flags_blk_stride, d_bufs,
+                       n_bufs, d_out, n_out_ch, frames);
+    return (int)hipGetLastError();
+}
+int launch_set_flags(hipStream_t s, uint8_t* flags, const int* d_bufs, int n, uint64_t mask) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_set_flags, dim3(1), dim3(64), 0, s, flags, d_bufs, n, mask);
+    return (int)hipGetLastError();
+}
+int launch_get_flags(hipStream_t s, const uint8_t* flags, const int* d_bufs, int n, uint64_t* d_mask) {
+    hipLaunchKernelGGL(k_get_flags, dim3(1), dim3(64), 0, s, flags, d_bufs, n, d_mask);
+    return (int)hipGetLastError();
+}
+int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0) {
+    if (fv.n_voices <= 0) return 0;
+    hipLaunchKernelGGL(k_voice_control, dim3((fv.n_voices + 63) / 64), dim3(64), 0, s, fv, K, cmd_block0);
+    return (int)hipGetLastError();
+}
+int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
+    if (fv.n_leaves <= 0) return 0;
+    dim3 grid((fv.n_leaves + WPB - 1) / WPB, K);
+    hipLaunchKernelGGL(k_leaf_sum, grid, dim3(WAVE * WPB), 0, s, fv);
+    return (int)hipGetLastError();
+}
+
+}  // namespace fwgpu

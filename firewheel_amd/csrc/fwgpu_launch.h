@@ -1,0 +1,69 @@
+// fwgpu_launch.h — kernel argument views + launch wrappers (implemented in fwgpu_kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "fwgpu_types.h"
+
+namespace fwgpu {
+
+// What k_level sees: the renamed-buffer pool of one plan.  `pool`/`flags` hold K independent blocks
+// (pool_blk_stride floats / flags_blk_stride bytes apart) for the K-batched upper sum tree; the generic
+// executor uses K = 1.  Buffer 0 is the constant zero buffer (flag always 1) = every unconnected input.
+struct DevView {
+    const NodeDesc* nodes;
+    const int* in_buf;
+    const int* out_buf;
+    NodeState* states;
+    const SampleDesc* samples;
+    float* pool;
+    uint8_t* flags;
+    size_t pool_blk_stride;
+    size_t flags_blk_stride;
+    int stride;  // floats per channel-block (multiple of 64)
+    int frames;  // frames in this block (<= max_block_frames)
+    const Cmd* cmds;
+    int n_cmds;
+};
+
+struct FusedView {
+    const VoiceDesc* voices;
+    const LeafDesc* leaves;
+    NodeState* states;
+    const SampleDesc* samples;
+    VoiceBlk* blks;   // [K][n_voices]
+    float* ramps;     // [K][n_voices][ramp_slots][stride], slot = 2*stage + channel
+    int ramp_slots;
+    float* bus;       // [K][n_bus_buffers][stride]
+    uint8_t* bus_flags;
+    size_t bus_blk_stride;
+    size_t bus_flags_blk_stride;
+    const Cmd* cmds;
+    int n_cmds;
+    int n_voices;
+    int n_leaves;
+    int stride;
+    int frames;
+};
+
+int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0);
+int launch_single_node(hipStream_t s, const DevView& v, int node_idx);
+int launch_scatter_states(hipStream_t s, NodeState* states, const void* d_inits, int n);
+int launch_graph_in(hipStream_t s, float* pool, uint8_t* flags, int stride, const int* d_bufs, int n_bufs,
+                    const float* d_interleaved, int n_in_ch, int frames);
+int launch_graph_out(hipStream_t s, const float* pool, const uint8_t* flags, int stride, size_t pool_blk_stride,
+                     size_t flags_blk_stride, const int* d_bufs, int n_bufs, float* d_out, int n_out_ch, int frames, int K);
+int launch_set_flags(hipStream_t s, uint8_t* flags, const int* d_bufs, int n, uint64_t mask);
+int launch_get_flags(hipStream_t s, const uint8_t* flags, const int* d_bufs, int n, uint64_t* d_mask);
+int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0);
+int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K);
+
+// host-side mirror of the StateInit record consumed by k_scatter_states
+struct StateInitHost {
+    int index;
+    int pad;
+    NodeState st;
+};
+
+}  // namespace fwgpu

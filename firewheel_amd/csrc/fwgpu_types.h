@@ -1,0 +1,113 @@
+// fwgpu_types.h — POD structs shared by the host planner and the HIP kernels (HBM-resident layout).
+#pragma once
+#include <stdint.h>
+
+namespace fwgpu {
+
+enum : int {
+    K_DUMMY = 0, K_BEEP = 1, K_VOLUME = 2, K_SUM = 3, K_SAMPLER = 4, K_HARD_CLIP = 5,
+    K_MONO_TO_STEREO = 6, K_STEREO_TO_MONO = 7, K_PAN = 8, K_WIDTH = 9, K_BIQUAD = 10, K_DELAY = 11,
+};
+
+enum : int { FMT_I_I16 = 0, FMT_I_U16 = 1, FMT_I_F32 = 2, FMT_P_I16 = 3, FMT_P_U16 = 4, FMT_P_F32 = 5 };
+
+// core/param/smoother.rs:72-88 without the output Vec: whenever status != Active the reference's buffer
+// is constant == input (every path that leaves Active fills it), so only the scalars are state.
+enum : int { SM_INACTIVE = 0, SM_ACTIVE = 1, SM_DEACTIVATING = 2 };
+struct Smoother {
+    int status;
+    float input;
+    float last;  // last_output
+    float a, b, eps;
+};
+
+// One state record per node (audio half of every node kind; 128 B, indexed by node slot).
+struct NodeState {
+    float p0, p1;  // the reference's atomics: VOLUME/SAMPLER raw_gain; PAN gl,gr targets; HARD_CLIP threshold
+    Smoother s0, s1;
+    // nodes/sampler.rs:280-292
+    int playing;
+    int has_loop;
+    int full_range;
+    int sample;  // sample-table index, -1 = None
+    uint64_t playhead;
+    uint64_t loop_start, loop_end;
+    // nodes/beep_test.rs:64-69
+    float phasor, phasor_inc, gain;
+    int enabled;
+    uint32_t sample_rate;
+    int pad[3];
+};
+static_assert(sizeof(NodeState) == 128, "NodeState layout");
+
+struct SampleDesc {  // core/sample_resource.rs:4-26; data is HBM-resident
+    const void* data;
+    uint64_t frames;
+    int channels;
+    int format;
+};
+
+// Static description of one scheduled node (graph/graph/compiler/schedule.rs:12-20 after buffer renaming).
+struct NodeDesc {
+    int kind;
+    int n_in, n_out;
+    int in_off, out_off;  // offsets into the port tables
+    int state;            // NodeState index
+    int aux0;             // SUM: num_in_ports
+    int is_graph_io;      // 1 = graph_in, 2 = graph_out (Dummy nodes the executor treats as I/O edges)
+};
+
+// control -> audio messages (nodes/sampler.rs:21-28 + the atomics), sorted by (state, block, seq).
+enum : int {
+    CMD_SET_P0 = 0, CMD_SET_P1 = 1, CMD_SET_ENABLED = 2,
+    CMD_SMP_SET_SAMPLE = 10, CMD_SMP_PLAY = 11, CMD_SMP_PAUSE = 12, CMD_SMP_STOP = 13,
+    CMD_SMP_SET_PLAYHEAD = 14, CMD_SMP_SET_LOOP = 15,
+};
+struct Cmd {
+    int state;
+    uint32_t block;
+    int type;
+    int i0;
+    float f0;
+    int i1;
+    double d0, d1;
+};
+static_assert(sizeof(Cmd) == 40, "Cmd layout");
+
+// ---------------------------------------------------------------- fused voice-bank plan
+#define FW_MAX_STAGES 4  // sampler gain + up to 3 chain nodes (volume / pan)
+
+struct VoiceDesc {  // static per voice chain: sampler -> [volume|pan]* -> leaf sum port
+    int sampler_state;
+    int n_stages;                      // chain nodes after the sampler
+    int stage_kind[FW_MAX_STAGES - 1];
+    int stage_state[FW_MAX_STAGES - 1];
+};
+
+// per (block, voice) record written by the control kernel, read by the leaf kernel (64 B)
+enum : uint32_t {
+    VB_SILENT = 1u,       // chain output is cleared + flagged silent for this block
+    VB_WRAP = 2u,         // loop wrap inside the block: frames [n1, frames) come from off1
+    VB_TAIL_ZERO = 4u,    // one-shot end inside the block: frames [n1, frames) are 0.0
+    VB_MONO = 8u,         // 1-channel sample duplicated to both outputs (sampler.rs:546-551)
+    VB_RAMP_SHIFT = 8,    // bit (VB_RAMP_SHIFT + 2*stage + ch): that gain is a per-frame ramp
+};
+struct VoiceBlk {
+    uint32_t flags;
+    uint32_t n1;     // frames taken from off0
+    uint64_t off0;   // source frame of frame 0
+    uint64_t off1;   // source frame of frame n1 when VB_WRAP
+    int sample;      // sample-table index
+    uint32_t pad;
+    float g[FW_MAX_STAGES][2];  // constant gains per stage and channel (used when the ramp bit is clear)
+};
+static_assert(sizeof(VoiceBlk) == 64, "VoiceBlk layout");
+
+struct LeafDesc {  // a SumNode whose ports are all voice chains (nodes/sum.rs)
+    int first_voice;
+    int ports;     // num_in_ports
+    int out_buf;   // compact bus-buffer id of output channel 0 (channel 1 = +1)
+    int pad;
+};
+
+}  // namespace fwgpu

@@ -1,0 +1,374 @@
+"""Host-side mirror of the reference interface for the accelerated path, over the C ABI.
+
+Names, argument meaning and error behaviour follow the reference (BillyDM/firewheel @ 2024-10-16):
+  * `FirewheelGpuCtx`   ~ FirewheelGraphCtx + FirewheelProcessor (graph/context.rs:29-254, graph/processor.rs:18-248)
+  * graph methods       ~ AudioGraph (graph/graph.rs:198-580): add_node, remove_node, connect, disconnect, ...
+  * node classes        ~ basic_nodes (nodes/*.rs): constructors take the same arguments; the control-half
+                          setters (set_percent_volume, play, ...) become messages with an `at_block` tag.
+All arithmetic happens in libfwgpu's HIP kernels; this file only marshals arguments.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FwgpuError
+
+
+class SampleFormat:  # core/sample_resource.rs:28-335
+    INTERLEAVED_I16, INTERLEAVED_U16, INTERLEAVED_F32, PLANAR_I16, PLANAR_U16, PLANAR_F32 = range(6)
+    DTYPE = {0: np.int16, 1: np.uint16, 2: np.float32, 3: np.int16, 4: np.uint16, 5: np.float32}
+
+
+_ADD_EDGE = {-1: "SrcNodeNotFound", -2: "DstNodeNotFound", -3: "InPortOutOfRange", -4: "OutPortOutOfRange",
+             -5: "EdgeAlreadyExists", -6: "InputPortAlreadyConnected", -7: "CycleDetected"}
+_COMPILE = {-10: "CycleDetected", -11: "ManyToOneError", -12: "NodeActivationFailed"}
+
+
+class AddEdgeError(Exception):  # graph/graph/error.rs
+    def __init__(self, code):
+        super().__init__(_ADD_EDGE.get(code, str(code)))
+        self.code = code
+        self.name = _ADD_EDGE.get(code, str(code))
+
+
+class CompileGraphError(Exception):  # graph/graph/error.rs
+    def __init__(self, code, msg=""):
+        super().__init__("%s: %s" % (_COMPILE.get(code, str(code)), msg))
+        self.code = code
+        self.name = _COMPILE.get(code, str(code))
+
+
+class LoopRange:  # nodes/sampler.rs:16-19
+    NONE, FULL, RANGE_SECS = 0, 1, 2
+
+    def __init__(self, mode, start=0.0, end=0.0):
+        self.mode, self.start, self.end = mode, start, end
+
+    @staticmethod
+    def Full():
+        return LoopRange(LoopRange.FULL)
+
+    @staticmethod
+    def RangeSecs(start, end):
+        return LoopRange(LoopRange.RANGE_SECS, start, end)
+
+
+# ------------------------------------------------------------------------------------------- nodes
+class _Node(object):
+    KIND = 0
+    cx = None
+    id = None
+
+    def params(self):
+        return []
+
+    def _bind(self, cx, node_id):
+        self.cx, self.id = cx, node_id
+
+    def _set(self, param, value, at_block=0):
+        self.cx._check(self.cx.L.fwgpu_node_set_param(self.cx.c, self.id, param, value, at_block))
+
+
+class DummyAudioNode(_Node):  # nodes/dummy.rs
+    KIND = 0
+
+
+class BeepTestNode(_Node):  # nodes/beep_test.rs:14-33
+    KIND = 1
+
+    def __init__(self, freq_hz, gain_db, enabled):
+        self.freq_hz, self.gain_db, self._enabled = freq_hz, gain_db, enabled
+
+    def params(self):
+        return [self.freq_hz, self.gain_db, 1.0 if self._enabled else 0.0]
+
+    def set_enabled(self, enabled, at_block=0):
+        self._enabled = enabled
+        self._set(0, 1.0 if enabled else 0.0, at_block)
+
+
+class VolumeNode(_Node):  # nodes/volume.rs:14-39
+    KIND = 2
+
+    def __init__(self, percent_volume):
+        self.percent_volume = max(percent_volume, 0.0)
+
+    def params(self):
+        return [self.percent_volume]
+
+    def set_percent_volume(self, percent_volume, at_block=0):
+        self.percent_volume = max(percent_volume, 0.0)
+        self._set(0, percent_volume, at_block)
+
+
+class SumNode(_Node):  # nodes/sum.rs
+    KIND = 3
+
+
+class SamplerNode(_Node):  # nodes/sampler.rs:46-182
+    KIND = 4
+
+    def __init__(self, percent_volume):
+        self.percent_volume = max(percent_volume, 0.0)
+        self.playing = False
+
+    def params(self):
+        return [self.percent_volume]
+
+    def set_percent_volume(self, percent_volume, at_block=0):
+        self.percent_volume = max(percent_volume, 0.0)
+        self._set(0, percent_volume, at_block)
+
+    def set_sample(self, sample, stop_playback, at_block=0):
+        self.cx._check(self.cx.L.fwgpu_sampler_set_sample(self.cx.c, self.id, sample, int(stop_playback), at_block))
+
+    def play(self, at_block=0):  # sampler.rs:82-97: only sends when not already playing
+        if not self.playing:
+            self.cx._check(self.cx.L.fwgpu_sampler_play(self.cx.c, self.id, at_block))
+            self.playing = True
+
+    def pause(self, at_block=0):
+        if self.playing:
+            self.cx._check(self.cx.L.fwgpu_sampler_pause(self.cx.c, self.id, at_block))
+            self.playing = False
+
+    def stop(self, at_block=0):
+        if self.playing:
+            self.cx._check(self.cx.L.fwgpu_sampler_stop(self.cx.c, self.id, at_block))
+            self.playing = False
+
+    def set_playhead(self, playhead_secs, at_block=0):
+        self.cx._check(self.cx.L.fwgpu_sampler_set_playhead_secs(self.cx.c, self.id, playhead_secs, at_block))
+
+    def set_loop_range(self, loop_range, at_block=0):
+        lr = loop_range or LoopRange(LoopRange.NONE)
+        self.cx._check(self.cx.L.fwgpu_sampler_set_loop_range(self.cx.c, self.id, lr.mode, lr.start, lr.end, at_block))
+
+
+class HardClipNode(_Node):  # nodes/hard_clip.rs:7-13
+    KIND = 5
+
+    def __init__(self, threshold_db):
+        self.threshold_db = threshold_db
+
+    def params(self):
+        return [self.threshold_db]
+
+
+class MonoToStereoNode(_Node):  # nodes/mono_to_stereo.rs
+    KIND = 6
+
+
+class StereoToMonoNode(_Node):  # nodes/stereo_to_mono.rs
+    KIND = 7
+
+
+class StereoPanNode(_Node):  # SPEC node: constant-power pan, pan in [-1, 1]
+    KIND = 8
+
+    def __init__(self, pan):
+        self.pan = pan
+
+    def params(self):
+        return [self.pan]
+
+    def set_pan(self, pan, at_block=0):
+        self.pan = pan
+        self._set(0, pan, at_block)
+
+
+class _RawNode(_Node):
+    def __init__(self, kind, params):
+        self.KIND = kind
+        self._p = list(params)
+
+    def params(self):
+        return self._p
+
+
+# ------------------------------------------------------------------------------------------- context
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class FirewheelGpuCtx(object):
+    """Device-resident graph context.  `stream` is an optional hipStream_t (int) to run on."""
+
+    def __init__(self, sample_rate=48000, max_block_frames=256, num_graph_inputs=0, num_graph_outputs=2, device=0,
+                 stream=None):
+        self.L = _lib.load_library()
+        self.sample_rate = sample_rate
+        self.max_block_frames = max_block_frames
+        self.c = self.L.fwgpu_ctx_create(device, sample_rate, max_block_frames, num_graph_inputs, num_graph_outputs,
+                                         C.c_void_p(stream) if stream else None)
+        if not self.c:
+            raise FwgpuError(-30, self.L.fwgpu_create_error().decode())
+        self._nodes = {}
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "c", None):
+            self.L.fwgpu_ctx_destroy(self.c)
+            self.c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise FwgpuError(rc, self.L.fwgpu_last_error(self.c).decode())
+        return rc
+
+    # ---- AudioGraph (graph/graph.rs)
+    @property
+    def graph(self):
+        return self
+
+    graph_mut = graph
+
+    def graph_in_node(self):
+        return self.L.fwgpu_graph_in_node(self.c)
+
+    def graph_out_node(self):
+        return self.L.fwgpu_graph_out_node(self.c)
+
+    def add_node(self, num_inputs, num_outputs, node):
+        p = np.asarray(node.params(), dtype=np.float32)
+        nid = self.L.fwgpu_add_node(self.c, node.KIND, num_inputs, num_outputs, _fptr(p), len(p))
+        self._check(nid)
+        node._bind(self, nid)
+        self._nodes[nid] = node
+        return nid
+
+    def node(self, node_id):
+        return self._nodes.get(node_id)
+
+    node_mut = node
+
+    def remove_node(self, node_id):
+        self._check(self.L.fwgpu_remove_node(self.c, node_id))
+        self._nodes.pop(node_id, None)
+
+    def connect(self, src_node, src_port, dst_node, dst_port, check_for_cycles=False):
+        r = self.L.fwgpu_connect(self.c, src_node, src_port, dst_node, dst_port, 1 if check_for_cycles else 0)
+        if r < 0:
+            raise AddEdgeError(r)
+        return r
+
+    def disconnect(self, src_node, src_port, dst_node, dst_port):
+        return bool(self.L.fwgpu_disconnect(self.c, src_node, src_port, dst_node, dst_port))
+
+    def disconnect_by_edge_id(self, edge_id):
+        return bool(self.L.fwgpu_disconnect_edge(self.c, edge_id))
+
+    def cycle_detected(self):
+        return bool(self.L.fwgpu_cycle_detected(self.c))
+
+    # ---- FirewheelGraphCtx::update (graph/context.rs:93-137)
+    def update(self):
+        r = self.L.fwgpu_update(self.c)
+        if r in _COMPILE:
+            raise CompileGraphError(r, self.L.fwgpu_last_error(self.c).decode())
+        self._check(r)
+
+    def schedule_upload(self, sched, num_buffers):
+        """sched: list of dicts {"id", "in": [(buffer_index, should_clear)], "out": [buffer_index]} in schedule order
+        (the reference's CompiledSchedule, schedule.rs:12-30)."""
+        arr = (_lib.SchedNode * len(sched))()
+        keep = []
+        for i, s in enumerate(sched):
+            ib = (C.c_uint32 * max(len(s["in"]), 1))(*[b for b, _ in s["in"]])
+            ic = (C.c_uint8 * max(len(s["in"]), 1))(*[1 if c else 0 for _, c in s["in"]])
+            ob = (C.c_uint32 * max(len(s["out"]), 1))(*s["out"])
+            keep += [ib, ic, ob]
+            arr[i].node = s["id"]
+            arr[i].num_inputs = len(s["in"])
+            arr[i].num_outputs = len(s["out"])
+            arr[i].in_buffer_index = ib
+            arr[i].in_should_clear = ic
+            arr[i].out_buffer_index = ob
+        r = self.L.fwgpu_schedule_upload(self.c, arr, len(sched), num_buffers)
+        if r in _COMPILE:
+            raise CompileGraphError(r, self.L.fwgpu_last_error(self.c).decode())
+        self._check(r)
+
+    # ---- plan introspection
+    def plan_kind(self):
+        return self.L.fwgpu_plan_kind(self.c)
+
+    def plan_num_levels(self):
+        return self.L.fwgpu_plan_num_levels(self.c)
+
+    def plan_node_level(self, node_id):
+        return self.L.fwgpu_plan_node_level(self.c, node_id)
+
+    def plan_node_inputs_clear(self, node_id):
+        buf = (C.c_int * 64)()
+        n = self._check(self.L.fwgpu_plan_node_inputs_clear(self.c, node_id, buf, 64))
+        return [bool(buf[i]) for i in range(n)]
+
+    def set_max_batch(self, k):
+        self._check(self.L.fwgpu_set_max_batch(self.c, k))
+
+    def set_force_generic(self, on):
+        self._check(self.L.fwgpu_set_force_generic(self.c, 1 if on else 0))
+
+    # ---- SampleResource (core/sample_resource.rs)
+    def new_sample(self, fmt, channels, data):
+        a = np.ascontiguousarray(np.asarray(data, dtype=SampleFormat.DTYPE[fmt]))
+        frames = a.size // channels
+        return self._check(self.L.fwgpu_sample_create(self.c, fmt, channels, frames, a.ctypes.data_as(C.c_void_p)))
+
+    def new_sample_device(self, fmt, channels, frames, device_ptr):
+        return self._check(self.L.fwgpu_sample_create_device(self.c, fmt, channels, frames, C.c_void_p(device_ptr)))
+
+    # ---- FirewheelProcessor::process_interleaved (graph/processor.rs:61-165)
+    def process_interleaved(self, input, num_in_channels, num_out_channels, frames, stream_time_secs=0.0,
+                            stream_status=0):
+        out = np.full(frames * num_out_channels, np.nan, dtype=np.float32)
+        if input is None:
+            input = np.zeros(max(frames * num_in_channels, 1), dtype=np.float32)
+        inp = np.ascontiguousarray(input, dtype=np.float32)
+        self._check(self.L.fwgpu_process_interleaved(self.c, _fptr(inp), _fptr(out), num_in_channels, num_out_channels,
+                                                     frames, stream_time_secs, stream_status))
+        return out
+
+    def process_blocks_device(self, num_blocks, device_out_ptr, num_out_channels=2):
+        self._check(self.L.fwgpu_process_blocks_device(self.c, num_blocks, C.c_void_p(device_out_ptr), num_out_channels))
+
+    def synchronize(self):
+        self._check(self.L.fwgpu_synchronize(self.c))
+
+    # ---- AudioNodeProcessor::process for one node on host buffers (core/node.rs:37-53)
+    def node_process(self, node_id, frames, inputs, outputs, in_silence_mask=0, out_silence_mask=0):
+        ins = [np.ascontiguousarray(x, dtype=np.float32) for x in inputs]
+        for o in outputs:
+            assert o.dtype == np.float32 and o.flags["C_CONTIGUOUS"]
+        it = (C.POINTER(C.c_float) * max(len(ins), 1))(*[_fptr(a) for a in ins])
+        ot = (C.POINTER(C.c_float) * max(len(outputs), 1))(*[_fptr(a) for a in outputs])
+        om = C.c_uint64(out_silence_mask)
+        self._check(self.L.fwgpu_node_process(self.c, node_id, frames, it, len(ins), ot, len(outputs), in_silence_mask,
+                                              C.byref(om), 0.0, 0))
+        return om.value
+
+    # ---- measurement hooks
+    def timing_enable(self, on=True):
+        self._check(self.L.fwgpu_timing_enable(self.c, 1 if on else 0))
+
+    def timing_read(self, which=0):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.L.fwgpu_timing_read(self.c, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def timing_reset(self):
+        self._check(self.L.fwgpu_timing_reset(self.c))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, hbm = C.c_int(), C.c_uint64()
+        self._check(self.L.fwgpu_device_info(self.c, name, 256, C.byref(cus), C.byref(hbm)))
+        return name.value.decode(), cus.value, hbm.value

@@ -1,0 +1,184 @@
+/* fwgpu.h — C ABI of libfwgpu: the MI355X (gfx950) per-block DSP executor for Firewheel audio graphs.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; no C++/torch types.
+ * Each entry point names the reference interface (BillyDM/firewheel @ 2024-10-16) it replaces:
+ *   core/  = crates/firewheel-core/src/      graph/ = crates/firewheel-graph/src/
+ *   nodes/ = crates/firewheel-graph/src/basic_nodes/
+ *
+ * Conventions (replacing Rust's Result/panic, SURVEY §8b "error convention"):
+ *   - functions return int: 0 = ok, negative = error; handles are int64 (>= 0) or negative error.
+ *   - nothing throws or aborts across the ABI; fwgpu_last_error() returns the message.
+ *   - one caller thread per ctx (the audio thread); edit + process calls are not re-entrant.
+ *   - the library fails loudly (ctx_create returns NULL) when no HIP device / kernel image is usable;
+ *     there is no CPU fallback anywhere behind this ABI.
+ */
+#ifndef FWGPU_H
+#define FWGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fwgpu_ctx fwgpu_ctx;
+
+/* node kinds — nodes/mod.rs:1-15 plus the north-star nodes the reference lists as TODO (README.md:14-19) */
+enum fwgpu_node_kind {
+    FWGPU_DUMMY = 0,          /* nodes/dummy.rs */
+    FWGPU_BEEP_TEST = 1,      /* nodes/beep_test.rs   params: freq_hz, gain_db, enabled */
+    FWGPU_VOLUME = 2,         /* nodes/volume.rs      params: percent_volume */
+    FWGPU_SUM = 3,            /* nodes/sum.rs */
+    FWGPU_SAMPLER = 4,        /* nodes/sampler.rs     params: percent_volume */
+    FWGPU_HARD_CLIP = 5,      /* nodes/hard_clip.rs   params: threshold_db */
+    FWGPU_MONO_TO_STEREO = 6, /* nodes/mono_to_stereo.rs */
+    FWGPU_STEREO_TO_MONO = 7, /* nodes/stereo_to_mono.rs */
+    FWGPU_STEREO_PAN = 8,     /* SPEC (not in reference) params: pan in [-1,1] */
+    FWGPU_STEREO_WIDTH = 9,   /* SPEC                 params: width */
+    FWGPU_BIQUAD = 10,        /* SPEC                 params: type, cutoff_hz, q */
+    FWGPU_DELAY = 11          /* SPEC                 params: delay_secs, feedback, mix */
+};
+
+/* sample formats — core/sample_resource.rs:28-335 */
+enum fwgpu_sample_format {
+    FWGPU_INTERLEAVED_I16 = 0,
+    FWGPU_INTERLEAVED_U16 = 1,
+    FWGPU_INTERLEAVED_F32 = 2,
+    FWGPU_PLANAR_I16 = 3, /* data = channels planes of `frames` items, concatenated */
+    FWGPU_PLANAR_U16 = 4,
+    FWGPU_PLANAR_F32 = 5
+};
+
+/* error codes: AddEdgeError / CompileGraphError variants (graph/graph/error.rs) */
+enum fwgpu_error {
+    FWGPU_OK = 0,
+    FWGPU_ERR_SRC_NODE_NOT_FOUND = -1,
+    FWGPU_ERR_DST_NODE_NOT_FOUND = -2,
+    FWGPU_ERR_IN_PORT_OUT_OF_RANGE = -3,
+    FWGPU_ERR_OUT_PORT_OUT_OF_RANGE = -4,
+    FWGPU_ERR_EDGE_ALREADY_EXISTS = -5,
+    FWGPU_ERR_INPUT_PORT_ALREADY_CONNECTED = -6,
+    FWGPU_ERR_CYCLE_DETECTED = -7,
+    FWGPU_ERR_COMPILE_CYCLE = -10,
+    FWGPU_ERR_COMPILE_MANY_TO_ONE = -11,
+    FWGPU_ERR_NODE_ACTIVATION_FAILED = -12,
+    FWGPU_ERR_INVALID = -20,   /* bad handle / argument */
+    FWGPU_ERR_QUEUE_FULL = -21,/* sampler message ring full (nodes/sampler.rs:14 CHANNEL_CAPACITY) */
+    FWGPU_ERR_DEVICE = -30     /* HIP error; see fwgpu_last_error */
+};
+
+/* ---- context: FirewheelGraphCtx::new + activate (graph/context.rs:35-82) and the device-resident
+ * FirewheelProcessor (graph/processor.rs:34-55).  `hip_stream` may be NULL (the ctx creates its own
+ * stream) or a hipStream_t the caller owns (e.g. torch's current stream). */
+fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block_frames,
+                            uint32_t num_graph_inputs, uint32_t num_graph_outputs, void* hip_stream);
+void fwgpu_ctx_destroy(fwgpu_ctx* ctx);
+const char* fwgpu_last_error(fwgpu_ctx* ctx);
+/* message of the last failed fwgpu_ctx_create (which has no ctx to ask) */
+const char* fwgpu_create_error(void);
+
+/* ---- graph edit API: AudioGraph (graph/graph.rs) */
+int64_t fwgpu_graph_in_node(fwgpu_ctx* ctx);  /* graph.rs:189 */
+int64_t fwgpu_graph_out_node(fwgpu_ctx* ctx); /* graph.rs:194 */
+/* graph.rs:201-231 add_node(num_inputs, num_outputs, node); `params` are the node constructor args */
+int64_t fwgpu_add_node(fwgpu_ctx* ctx, int kind, uint32_t num_inputs, uint32_t num_outputs,
+                       const float* params, int n_params);
+int fwgpu_remove_node(fwgpu_ctx* ctx, int64_t node); /* graph.rs:268-299 */
+/* graph.rs:396-477; returns the edge id or an AddEdgeError code */
+int64_t fwgpu_connect(fwgpu_ctx* ctx, int64_t src_node, uint32_t src_port, int64_t dst_node,
+                      uint32_t dst_port, int check_for_cycles);
+int fwgpu_disconnect(fwgpu_ctx* ctx, int64_t src_node, uint32_t src_port, int64_t dst_node,
+                     uint32_t dst_port);                 /* graph.rs:483-501; 1 = removed, 0 = no such edge */
+int fwgpu_disconnect_edge(fwgpu_ctx* ctx, int64_t edge); /* graph.rs:507-524 */
+int fwgpu_cycle_detected(fwgpu_ctx* ctx);                /* graph.rs:573-580 */
+/* FirewheelGraphCtx::update (graph/context.rs:93-137): recompile when dirty, activate new nodes
+ * (AudioNode::activate, core/node.rs:12-18), build + upload the device launch plan. */
+int fwgpu_update(fwgpu_ctx* ctx);
+
+/* ---- external schedule import: keep Firewheel's own Rust scheduler and hand its CompiledSchedule over
+ * (graph/graph/compiler/schedule.rs:12-30,105-126,166-173).  Buffer indices are the reference's; the
+ * library reconstructs the edges, renames buffers (no reuse inside a level) and levelises. */
+typedef struct fwgpu_sched_node {
+    int64_t node;                 /* id returned by fwgpu_add_node / graph_in / graph_out */
+    uint32_t num_inputs;
+    uint32_t num_outputs;
+    const uint32_t* in_buffer_index;  /* [num_inputs]  InBufferAssignment.buffer_index */
+    const uint8_t* in_should_clear;   /* [num_inputs]  InBufferAssignment.should_clear */
+    const uint32_t* out_buffer_index; /* [num_outputs] OutBufferAssignment.buffer_index */
+} fwgpu_sched_node;
+int fwgpu_schedule_upload(fwgpu_ctx* ctx, const fwgpu_sched_node* nodes, uint32_t n_nodes,
+                          uint32_t num_buffers);
+
+/* ---- introspection of the device launch plan (tests) */
+/* 0 = generic level-batched executor, 1 = fused voice-bank plan */
+int fwgpu_plan_kind(fwgpu_ctx* ctx);
+int fwgpu_plan_num_levels(fwgpu_ctx* ctx);
+/* level of a node in the plan (graph_in = 0); negative if unknown */
+int fwgpu_plan_node_level(fwgpu_ctx* ctx, int64_t node);
+/* per input port: 1 if the port is unconnected (the reference's should_clear), else 0.  Returns n. */
+int fwgpu_plan_node_inputs_clear(fwgpu_ctx* ctx, int64_t node, int* should_clear, int cap);
+/* K = the most blocks one fused launch sequence processes (default 64); sizes the K-batched descriptor,
+ * ramp and bus buffers at the next fwgpu_update. */
+int fwgpu_set_max_batch(fwgpu_ctx* ctx, uint32_t max_blocks);
+/* force the generic executor even when the fused plan matches (parity tests) */
+int fwgpu_set_force_generic(fwgpu_ctx* ctx, int on);
+
+/* ---- sample resources: SampleResource (core/sample_resource.rs:4-26), uploaded once, HBM-resident.
+ * Returns a sample id >= 0. */
+int fwgpu_sample_create(fwgpu_ctx* ctx, int format, uint32_t channels, uint64_t frames, const void* data);
+/* same, from memory that is already on this device (bench: generate in HBM, skip PCIe) */
+int fwgpu_sample_create_device(fwgpu_ctx* ctx, int format, uint32_t channels, uint64_t frames,
+                               const void* device_data);
+int fwgpu_sample_destroy(fwgpu_ctx* ctx, int sample);
+
+/* ---- control -> audio messages.  `at_block` = index of the max_block_frames-sized block, counted from
+ * the start of the NEXT process call, before which the message is seen (the reference's rings/atomics
+ * are polled at block start: nodes/sampler.rs:331, nodes/volume.rs:92). */
+/* VolumeNode::set_percent_volume (volume.rs:28-34) / SamplerNode::set_percent_volume (sampler.rs:171-177):
+ * param 0.  BeepTestNode::set_enabled (beep_test.rs:30-32): param 0.  StereoPan: param 0 = pan. */
+int fwgpu_node_set_param(fwgpu_ctx* ctx, int64_t node, int param, float value, uint32_t at_block);
+int fwgpu_sampler_set_sample(fwgpu_ctx* ctx, int64_t node, int sample, int stop_playback,
+                             uint32_t at_block);                                  /* sampler.rs:67-79 */
+int fwgpu_sampler_play(fwgpu_ctx* ctx, int64_t node, uint32_t at_block);  /* sampler.rs:82-97 */
+int fwgpu_sampler_pause(fwgpu_ctx* ctx, int64_t node, uint32_t at_block); /* sampler.rs:100-115 */
+int fwgpu_sampler_stop(fwgpu_ctx* ctx, int64_t node, uint32_t at_block);  /* sampler.rs:118-133 */
+int fwgpu_sampler_set_playhead_secs(fwgpu_ctx* ctx, int64_t node, double playhead_secs,
+                                    uint32_t at_block);                           /* sampler.rs:136-147 */
+/* mode: 0 = None, 1 = LoopRange::Full, 2 = LoopRange::RangeSecs(start..end)  (sampler.rs:150-161) */
+int fwgpu_sampler_set_loop_range(fwgpu_ctx* ctx, int64_t node, int mode, double start_secs,
+                                 double end_secs, uint32_t at_block);
+
+/* ---- processing */
+/* FirewheelProcessor::process_interleaved (graph/processor.rs:61-165): host buffers, splits `frames`
+ * into max_block_frames blocks, returns after the output has landed in `output`. */
+int fwgpu_process_interleaved(fwgpu_ctx* ctx, const float* input, float* output, uint32_t num_in_channels,
+                              uint32_t num_out_channels, uint64_t frames, double stream_time_secs,
+                              uint32_t stream_status);
+/* Throughput form of the same call: `num_blocks` full blocks, interleaved output written to DEVICE memory
+ * `d_output` [num_blocks*max_block_frames*num_out_channels] on the ctx stream, asynchronously (no host
+ * sync).  Graphs with num_graph_inputs == 0 only. */
+int fwgpu_process_blocks_device(fwgpu_ctx* ctx, uint32_t num_blocks, float* d_output,
+                                uint32_t num_out_channels);
+int fwgpu_synchronize(fwgpu_ctx* ctx);
+
+/* AudioNodeProcessor::process (core/node.rs:37-53) for ONE activated node on caller (host) buffers —
+ * the literal per-node drop-in for graph/processor.rs:243.  inputs/outputs: arrays of `frames` floats.
+ * out_silence_mask is pre-set by the caller (the reference passes 0). */
+int fwgpu_node_process(fwgpu_ctx* ctx, int64_t node, uint64_t frames, const float* const* inputs,
+                       uint32_t num_inputs, float* const* outputs, uint32_t num_outputs,
+                       uint64_t in_silence_mask, uint64_t* out_silence_mask, double stream_time_secs,
+                       uint32_t stream_status);
+
+/* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernel on the ctx stream */
+int fwgpu_timing_enable(fwgpu_ctx* ctx, int on);
+/* which: 0 = fused leaf kernel (dominant), 1 = control kernel, 2 = upper/out kernels, 3 = generic level kernels.
+ * Returns accumulated milliseconds and launch count since the last reset. */
+int fwgpu_timing_read(fwgpu_ctx* ctx, int which, double* total_ms, uint64_t* launches);
+int fwgpu_timing_reset(fwgpu_ctx* ctx);
+/* device facts for the bench line */
+int fwgpu_device_info(fwgpu_ctx* ctx, char* name, int name_cap, int* compute_units, uint64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FWGPU_H */

@@ -286,3 +286,112 @@ def xorshift_uniform(seed, n):
     """Deterministic uniform(-1,1) f32 stream (seeded xorshift), vectorised per call."""
     rng = np.random.Generator(np.random.PCG64(seed))
     return (rng.random(n, dtype=np.float32) * 2.0 - 1.0).astype(np.float32)
+
+
+class GpuEngine(Engine):
+    """Same surface as OracleEngine, through the product's C ABI (firewheel_amd -> libfwgpu.so)."""
+
+    backend = "gpu"
+
+    def __init__(self, sample_rate=48000, max_block_frames=256, num_graph_inputs=0, num_graph_outputs=2,
+                 force_generic=False, max_batch=None, stream=None):
+        import firewheel_amd as fa
+
+        self.fa = fa
+        self.sample_rate = sample_rate
+        self.max_block_frames = max_block_frames
+        self.cx = fa.FirewheelGpuCtx(sample_rate, max_block_frames, num_graph_inputs, num_graph_outputs, stream=stream)
+        if force_generic:
+            self.cx.set_force_generic(True)
+        if max_batch:
+            self.cx.set_max_batch(max_batch)
+
+    @property
+    def graph_in_node(self):
+        return self.cx.graph_in_node()
+
+    @property
+    def graph_out_node(self):
+        return self.cx.graph_out_node()
+
+    def add_node(self, kind, n_in, n_out, params=()):
+        from firewheel_amd.graph import _RawNode
+
+        return self.cx.add_node(n_in, n_out, _RawNode(kind, params))
+
+    def remove_node(self, node):
+        self.cx.remove_node(node)
+        return 0
+
+    def connect(self, src, sp, dst, dp, check_for_cycles=False):
+        try:
+            return self.cx.connect(src, sp, dst, dp, check_for_cycles)
+        except self.fa.AddEdgeError as e:
+            raise AddEdgeError(e.code)
+
+    def disconnect(self, src, sp, dst, dp):
+        return self.cx.disconnect(src, sp, dst, dp)
+
+    def disconnect_by_edge_id(self, e):
+        return self.cx.disconnect_by_edge_id(e)
+
+    def cycle_detected(self):
+        return self.cx.cycle_detected()
+
+    def update(self):
+        try:
+            self.cx.update()
+        except self.fa.CompileGraphError as e:
+            raise CompileGraphError(e.code, str(e))
+
+    def new_sample(self, fmt, channels, data):
+        return self.cx.new_sample(fmt, channels, data)
+
+    def _chk(self, rc):
+        self.cx._check(rc)
+
+    def set_param(self, node, param, value, at_block=0):
+        self._chk(self.cx.L.fwgpu_node_set_param(self.cx.c, node, param, value, at_block))
+
+    def sampler_set_sample(self, node, sample, stop_playback=False, at_block=0):
+        self._chk(self.cx.L.fwgpu_sampler_set_sample(self.cx.c, node, sample, int(stop_playback), at_block))
+
+    def sampler_play(self, node, at_block=0):
+        self._chk(self.cx.L.fwgpu_sampler_play(self.cx.c, node, at_block))
+
+    def sampler_pause(self, node, at_block=0):
+        self._chk(self.cx.L.fwgpu_sampler_pause(self.cx.c, node, at_block))
+
+    def sampler_stop(self, node, at_block=0):
+        self._chk(self.cx.L.fwgpu_sampler_stop(self.cx.c, node, at_block))
+
+    def sampler_set_playhead_secs(self, node, secs, at_block=0):
+        self._chk(self.cx.L.fwgpu_sampler_set_playhead_secs(self.cx.c, node, secs, at_block))
+
+    def sampler_set_loop_range(self, node, mode, start=0.0, end=0.0, at_block=0):
+        self._chk(self.cx.L.fwgpu_sampler_set_loop_range(self.cx.c, node, mode, start, end, at_block))
+
+    def process_interleaved(self, frames, n_out_ch=2, inp=None, n_in_ch=0, t=0.0, status=0):
+        return self.cx.process_interleaved(inp, n_in_ch, n_out_ch, frames, t, status)
+
+    def process_blocks(self, k, n_out_ch=2):
+        return self.process_interleaved(k * self.max_block_frames, n_out_ch)
+
+    def node_process(self, node, frames, inputs, n_out, in_mask=0, out_mask=0, out_init=None):
+        outs = [np.full(frames, np.nan, dtype=np.float32) if out_init is None else np.array(out_init[c], dtype=np.float32)
+                for c in range(n_out)]
+        om = self.cx.node_process(node, frames, inputs, outs, in_mask, out_mask)
+        return (np.stack(outs) if outs else np.zeros((0, frames), np.float32)), om
+
+
+def make_engine(backend, **kw):
+    if backend == "oracle":
+        kw.pop("force_generic", None)
+        kw.pop("max_batch", None)
+        return OracleEngine(**kw)
+    return GpuEngine(**kw)
+
+
+def bits(a):
+    """bit pattern view for exact comparisons (distinguishes -0.0 / NaN payloads)."""
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)

@@ -1,0 +1,231 @@
+"""Deterministic graph scenarios run identically on the oracle and on the GPU engines (fwapi.Engine).
+Each returns the interleaved output of every process call, concatenated."""
+import numpy as np
+
+import fwapi
+from fwapi import (BEEP_TEST, DUMMY, HARD_CLIP, INTERLEAVED_F32, INTERLEAVED_I16, INTERLEAVED_U16, LOOP_FULL, LOOP_NONE,
+                   LOOP_RANGE_SECS, MONO_TO_STEREO, PLANAR_F32, PLANAR_I16, PLANAR_U16, SAMPLER, STEREO_PAN,
+                   STEREO_TO_MONO, SUM, VOLUME)
+
+
+def voice_source(seed, frames, channels=2):
+    return fwapi.xorshift_uniform(0xF1EE0000 + seed, channels * frames).reshape(channels, frames)
+
+
+def build_voice_bank(e, n_voices, radix=32, src_frames=4096, with_pan=True, with_volume=True, seed=0, fmt=PLANAR_F32,
+                     mono_every=0):
+    """config-2 shape: V x (sampler -> volume -> pan) -> radix-`radix` SumNode tree -> graph_out."""
+    rng = np.random.default_rng(1234 + seed)
+    voices = []
+    ends = []
+    for v in range(n_voices):
+        s = e.sampler(100.0)
+        cur = s
+        vol = pan = None
+        if with_volume:
+            vol = e.volume(float(rng.uniform(10, 100)))
+            e.connect_stereo(cur, vol)
+            cur = vol
+        if with_pan:
+            pan = e.pan(float(rng.uniform(-1, 1)))
+            e.connect_stereo(cur, pan)
+            cur = pan
+        voices.append(dict(sampler=s, volume=vol, pan=pan))
+        ends.append(cur)
+    # sum tree
+    level = ends
+    while True:
+        nxt = []
+        for i in range(0, len(level), radix):
+            grp = level[i:i + radix]
+            m = e.sum(len(grp))
+            for p, n in enumerate(grp):
+                e.connect_stereo(n, m, 2 * p)
+            nxt.append(m)
+        level = nxt
+        if len(level) == 1:
+            break
+    e.connect_stereo(level[0], e.graph_out_node)
+    e.update()
+    for v, vc in enumerate(voices):
+        ch = 1 if (mono_every and v % mono_every == 0) else 2
+        data = voice_source(seed * 100000 + v, src_frames, ch)
+        if fmt in (PLANAR_I16, INTERLEAVED_I16):
+            raw = np.round(data * 32767).astype(np.int16)
+        elif fmt in (PLANAR_U16, INTERLEAVED_U16):
+            raw = np.round((data + 1) * 32767.5).astype(np.uint16)
+        else:
+            raw = data
+        if fmt <= INTERLEAVED_F32:
+            raw = raw.T.copy()
+        vc["sample"] = e.new_sample(fmt, ch, raw)
+        vc["frames"] = src_frames
+        e.sampler_set_sample(vc["sampler"], vc["sample"])
+    return voices
+
+
+def scenario_voice_bank_steady(e, n_voices=96, blocks=6, radix=32, **kw):
+    """steady state: all voices looping, constant gains."""
+    voices = build_voice_bank(e, n_voices, radix=radix, **kw)
+    for vc in voices:
+        e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        e.sampler_play(vc["sampler"])
+    return e.process_blocks(blocks)
+
+
+def scenario_voice_bank_events(e, n_voices=70, radix=32, mbf=None, src_frames=1000):
+    """everything at once: loop wraps inside blocks (src_frames not a multiple of the block), one-shot ends,
+    paused voices (silence masks), gain / pan changes (smoother ramps that settle, and ones that stall),
+    mute -> all-silent chains, messages tagged at later blocks of a multi-block call."""
+    voices = build_voice_bank(e, n_voices, radix=radix, src_frames=src_frames, mono_every=7)
+    outs = []
+    for v, vc in enumerate(voices):
+        if v % 5 != 3:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)   # v%5==3: one-shot
+        if v % 4 != 1:
+            e.sampler_play(vc["sampler"])                         # v%4==1: never started yet
+    outs.append(e.process_blocks(3))
+    # gain changes seen at block 0 and block 2 of the next call; pan change; mute; start paused voices late
+    for v, vc in enumerate(voices):
+        if v % 3 == 0:
+            e.set_param(vc["volume"], 0, 25.0 if v % 2 else 90.0, at_block=0)
+        if v % 6 == 2:
+            e.set_param(vc["pan"], 0, -0.5, at_block=2)
+        if v % 10 == 4:
+            e.set_param(vc["sampler"], 0, 0.0, at_block=1)        # ramps to 0 -> settles -> (Q3) stays unflagged
+        if v % 4 == 1:
+            e.sampler_play(vc["sampler"], at_block=1)
+        if v % 11 == 5:
+            e.sampler_pause(vc["sampler"], at_block=3)
+    outs.append(e.process_blocks(5))
+    # long tail so ramps settle / stall, one-shots end, loops wrap several times
+    outs.append(e.process_blocks(28))
+    # stop + restart some, set playhead, change loop range (Q7), second gain change
+    for v, vc in enumerate(voices):
+        if v % 9 == 0:
+            e.sampler_stop(vc["sampler"])
+        if v % 9 == 1:
+            e.sampler_set_playhead_secs(vc["sampler"], 300.25 / e.sample_rate)
+        if v % 9 == 2:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_RANGE_SECS, 100.0 / e.sample_rate, 900.0 / e.sample_rate)
+        if v % 9 == 3:
+            e.sampler_play(vc["sampler"])
+        if v % 3 == 0:
+            e.set_param(vc["volume"], 0, 100.0)
+    outs.append(e.process_blocks(8))
+    return np.concatenate(outs)
+
+
+class TaggedOracle(object):
+    """Wraps an OracleEngine so that messages carry at_block like the GPU ABI: they are queued and delivered
+    just before the tagged block of the next process_blocks call (the reference's rings are polled per block)."""
+
+    def __init__(self, eng):
+        self.e = eng
+        self.q = []
+        self.backend = "oracle"
+        self.sample_rate = eng.sample_rate
+        self.max_block_frames = eng.max_block_frames
+
+    def __getattr__(self, name):
+        return getattr(self.e, name)
+
+    def _defer(self, at_block, fn, *a):
+        if at_block == 0:
+            fn(*a)
+        else:
+            self.q.append((at_block, fn, a))
+
+    def set_param(self, node, param, value, at_block=0):
+        self._defer(at_block, self.e.set_param, node, param, value)
+
+    def sampler_set_sample(self, node, sample, stop_playback=False, at_block=0):
+        self._defer(at_block, self.e.sampler_set_sample, node, sample, stop_playback)
+
+    def sampler_play(self, node, at_block=0):
+        self._defer(at_block, self.e.sampler_play, node)
+
+    def sampler_pause(self, node, at_block=0):
+        self._defer(at_block, self.e.sampler_pause, node)
+
+    def sampler_stop(self, node, at_block=0):
+        self._defer(at_block, self.e.sampler_stop, node)
+
+    def sampler_set_playhead_secs(self, node, secs, at_block=0):
+        self._defer(at_block, self.e.sampler_set_playhead_secs, node, secs)
+
+    def sampler_set_loop_range(self, node, mode, start=0.0, end=0.0, at_block=0):
+        self._defer(at_block, self.e.sampler_set_loop_range, node, mode, start, end)
+
+    def process_blocks(self, k, n_out_ch=2):
+        outs = []
+        for b in range(k):
+            keep = []
+            for at, fn, a in self.q:
+                if at == b:
+                    fn(*a)
+                elif at > b:
+                    keep.append((at, fn, a))
+            self.q = keep
+            outs.append(self.e.process_blocks(1, n_out_ch))
+        self.q = [(at - k, fn, a) for at, fn, a in self.q]
+        return np.concatenate(outs)
+
+    def process_interleaved(self, frames, *a, **kw):
+        assert not self.q
+        return self.e.process_interleaved(frames, *a, **kw)
+
+
+def scenario_mixed_generic(e):
+    """a graph the fused plan does not cover: beep + sampler through clip / mono<->stereo / 2,3,4-port sums,
+    dangling ports, one-to-many edges.  Returns (output, beep_only_output)."""
+    s = e.sampler(80.0)
+    data = voice_source(77, 2000)
+    beep = e.beep(440.0, -12.0, True, n_out=1)
+    m2s = e.add_node(MONO_TO_STEREO, 1, 2)
+    clip = e.hard_clip(-9.0)
+    s2m = e.add_node(STEREO_TO_MONO, 2, 1)
+    m2s2 = e.add_node(MONO_TO_STEREO, 1, 2)
+    vol3 = e.volume(70.0, ch=3)                  # generic (non-stereo) volume path with one dangling input
+    sum2 = e.sum(2)
+    sum3 = e.sum(3)
+    sum4 = e.sum(4)
+    e.connect(beep, 0, m2s, 0)
+    e.connect_stereo(s, clip)
+    e.connect_stereo(clip, s2m)
+    e.connect(s2m, 0, m2s2, 0)
+    e.connect_stereo(m2s, sum2, 0)
+    e.connect_stereo(m2s2, sum2, 2)
+    e.connect(s, 0, vol3, 0)                     # one-to-many from the sampler
+    e.connect(s, 1, vol3, 2)                     # vol3 input 1 unconnected (should_clear)
+    e.connect_stereo(sum2, sum3, 0)
+    e.connect(vol3, 0, sum3, 2)
+    e.connect(vol3, 2, sum3, 3)                  # port 2 (inputs 4,5) unconnected
+    e.connect_stereo(sum3, sum4, 0)
+    e.connect_stereo(clip, sum4, 4)              # ports 1 and 3 unconnected
+    e.connect_stereo(sum4, e.graph_out_node)
+    e.update()
+    smp = e.new_sample(PLANAR_F32, 2, data)
+    e.sampler_set_sample(s, smp)
+    e.sampler_set_loop_range(s, LOOP_FULL)
+    e.sampler_play(s)
+    out1 = e.process_blocks(4)
+    e.set_param(beep, 0, 0.0)                    # disable the beep (Q12)
+    e.set_param(vol3, 0, 20.0)
+    out2 = e.process_blocks(4)
+    return np.concatenate([out1, out2])
+
+
+def scenario_graph_inputs(e):
+    """graph with stream inputs: in(2) -> volume -> out, plus an extra graph input left unconnected upstream."""
+    vol = e.volume(60.0)
+    e.connect_stereo(e.graph_in_node, vol)
+    e.connect_stereo(vol, e.graph_out_node)
+    e.update()
+    mbf = e.max_block_frames
+    frames = 3 * mbf + 17            # last sub-block is partial (processor.rs:95-96)
+    inp = fwapi.xorshift_uniform(5150, frames * 2)
+    out = e.process_interleaved(frames, 2, inp=inp, n_in_ch=2)
+    e.set_param(vol, 0, 10.0)
+    out2 = e.process_interleaved(frames, 2, inp=inp, n_in_ch=2)
+    return np.concatenate([out, out2])

@@ -107,7 +107,9 @@ def scenario_voice_bank_events(e, n_voices=70, radix=32, mbf=None, src_frames=10
         if v % 9 == 1:
             e.sampler_set_playhead_secs(vc["sampler"], 300.25 / e.sample_rate)
         if v % 9 == 2:
-            e.sampler_set_loop_range(vc["sampler"], LOOP_RANGE_SECS, 100.0 / e.sample_rate, 900.0 / e.sample_rate)
+            # keep the range inside the sample: the reference panics on an out-of-range slice (Q8)
+            e.sampler_set_loop_range(vc["sampler"], LOOP_RANGE_SECS, 100.0 / e.sample_rate,
+                                     (src_frames - 100.0) / e.sample_rate)
         if v % 9 == 3:
             e.sampler_play(vc["sampler"])
         if v % 3 == 0:

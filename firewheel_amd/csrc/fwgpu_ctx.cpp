@@ -95,7 +95,7 @@ struct fwgpu_ctx {
     // fused plan
     bool fused = false;
     int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
-    DevBuf d_voices, d_leaves, d_blks, d_ramps, d_bus, d_bus_flags;
+    DevBuf d_voices, d_leaves, d_blks, d_steady, d_tmpl, d_ramps, d_bus, d_bus_flags;
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
     std::vector<int> up_level_off, up_level_cnt;
 
@@ -512,6 +512,8 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         if ((rc = upload(c, c->d_leaves, fb.leaves.data(), fb.leaves.size() * sizeof(LeafDesc)))) return rc;
         const size_t K = c->kmax;
         HIPC(c, c->d_blks.ensure(K * c->n_voices * sizeof(VoiceBlk)));
+        HIPC(c, c->d_steady.ensure((size_t)c->n_voices * sizeof(SteadyRec)));
+        HIPC(c, c->d_tmpl.ensure((size_t)c->n_voices * sizeof(VoiceBlk)));
         HIPC(c, c->d_ramps.ensure(K * c->n_voices * (size_t)c->ramp_slots * c->stride * sizeof(float)));
         size_t bus_bytes = K * (size_t)c->n_bus * c->stride * sizeof(float);
         HIPC(c, c->d_bus.ensure(bus_bytes));
@@ -660,6 +662,9 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     fv.states = c->d_states.as<NodeState>();
     fv.samples = c->d_samples.as<SampleDesc>();
     fv.blks = c->d_blks.as<VoiceBlk>();
+    fv.steady = c->d_steady.as<SteadyRec>();
+    fv.tmpl = c->d_tmpl.as<VoiceBlk>();
+    fv.n_gain_stages = c->ramp_slots / 2;
     fv.ramps = c->d_ramps.as<float>();
     fv.ramp_slots = c->ramp_slots;
     fv.bus = c->d_bus.as<float>();
@@ -675,6 +680,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     hipEvent_t e0, e1;
     timer_begin(c, 1, &e0, &e1);
     LCHK(c, launch_voice_control(c->stream, fv, K, cmd_block0));
+    LCHK(c, launch_voice_fill(c->stream, fv, K));
     timer_end(c, e1);
     timer_begin(c, 0, &e0, &e1);
     LCHK(c, launch_leaf_sum(c->stream, fv, K));
@@ -696,7 +702,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         v.cmds = nullptr;
         v.n_cmds = 0;
         for (size_t l = 0; l < c->up_level_cnt.size(); ++l)
-            LCHK(c, launch_level(c->stream, v, c->d_up_level_nodes.as<int>() + c->up_level_off[l], c->up_level_cnt[l], K, 0));
+            LCHK(c, launch_bus_sum(c->stream, v, c->d_up_level_nodes.as<int>() + c->up_level_off[l], c->up_level_cnt[l], K, 2));
     }
     LCHK(c, launch_graph_out(c->stream, fv.bus, fv.bus_flags, c->stride, fv.bus_blk_stride, fv.bus_flags_blk_stride,
                              c->d_root_bufs.as<int>(), 2, d_out, n_out_ch, (int)c->mbf, K));
@@ -818,7 +824,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     for (SampleRec& s : c->samples)
         if (s.alive && s.owned && s.d_data) (void)hipFree(s.d_data);
     DevBuf* bufs[] = {&c->d_states, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
-                      &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_ramps,
+                      &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_steady, &c->d_tmpl, &c->d_ramps,
                       &c->d_bus, &c->d_bus_flags, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
                       &c->d_root_bufs, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask};

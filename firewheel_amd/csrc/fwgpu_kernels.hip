@@ -385,13 +385,32 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
                 break;
             }
             const bool masked = !(ports == 2 || ports == 3 || ports == 4);  // :67-133 (Q13)
+            // lane i keeps the buffer id of input channel i; ids are broadcast with v_readlane so the
+            // per-port loads are independent and can be in flight together (8 at a time)
+            const int my_in = lane < n_in ? io.in_buf[lane] : 0;
+            const uint64_t later_ports = mask_all_silent_bits(n_in) & ~mask_all_silent_bits(n_out);
+            const bool any_skip = masked && (in_mask & later_ports) != 0;
             for (int c = 0; c < n_out; ++c) {
                 for (int f0 = lane * 4; f0 < frames; f0 += 256) {
-                    v4f acc = *(const v4f*)(io.in(c) + f0);
-                    for (int p = 1; p < ports; ++p) {
-                        int ic = n_out * p + c;
-                        if (masked && mask_bit(in_mask, ic)) continue;  // :122-124
-                        acc = acc + *(const v4f*)(io.in(ic) + f0);
+                    v4f acc = *(const v4f*)(io.pool + (size_t)__builtin_amdgcn_readlane(my_in, c) * io.stride + f0);
+                    if (!any_skip) {
+                        for (int p0 = 1; p0 < ports; p0 += 8) {
+                            v4f x[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (p0 + u < ports)
+                                    x[u] = *(const v4f*)(io.pool +
+                                                         (size_t)__builtin_amdgcn_readlane(my_in, n_out * (p0 + u) + c) * io.stride + f0);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (p0 + u < ports) acc = acc + x[u];  // left-assoc, port order (:78,92,107,129)
+                        }
+                    } else {
+                        for (int p = 1; p < ports; ++p) {
+                            int ic = n_out * p + c;
+                            if (mask_bit(in_mask, ic)) continue;  // :122-124
+                            acc = acc + *(const v4f*)(io.in(ic) + f0);
+                        }
                     }
                     *(v4f*)(io.out(c) + f0) = acc;
                 }
@@ -620,9 +639,12 @@ __global__ void k_get_flags(const uint8_t* flags, const int* __restrict__ bufs, 
 }
 
 // ------------------------------------------------------------------ fused voice-bank plan
-// Control kernel: one thread per voice walks K blocks, running the per-block state machines of the whole
-// chain in schedule order (sampler -> stage nodes) and emitting one VoiceBlk per block.  Per-frame ramps
-// (ParamSmoother Active) are materialised into `ramps` only for blocks where the values actually change.
+// Control, phase 1 (k_voice_control): one thread per voice runs the per-block state machines of its whole
+// chain in schedule order (sampler -> stage nodes) and emits one VoiceBlk per block.  As soon as the voice
+// is STEADY (no message left for it in this call, every smoother constant) the remaining blocks only differ
+// by the playhead, which has a closed form; the thread records that and stops.  Phase 2 (k_voice_fill) then
+// fills those blocks' descriptors with one thread per (voice, block).  Per-frame ramps (ParamSmoother Active)
+// are materialised into `ramps` only for blocks where the values actually change.
 struct StageRegs {  // the NodeState prefix (p0,p1,s0,s1) a gain stage needs
     float p0, p1;
     Smoother s0, s1;
@@ -647,6 +669,40 @@ __device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, f
     return true;
 }
 
+// A smoother whose next set_and_process(target) returns the same constant and leaves its state untouched:
+// not Active, or Active but stalled at the f32 fixed point above settle_epsilon (Q28).
+__device__ __forceinline__ bool smoother_is_constant(const Smoother& s, float target) {
+    if (!(s.input == target)) return false;
+    if (s.status != SM_ACTIVE) return true;
+    float y0 = (s.input * s.a) + (s.last * s.b);
+    return y0 == s.last && !(fabsf(s.input - y0) < s.eps);
+}
+
+// source pointers of a block whose frames are contiguous planar f32 (the fast path of the leaf kernel)
+__device__ __forceinline__ void blk_set_source(VoiceBlk& d, const SampleDesc& sd) {
+    d.src_l = nullptr;
+    d.src_r = nullptr;
+    const bool contiguous = !(d.flags & (VB_WRAP | VB_TAIL_ZERO | VB_SILENT)) && sd.format == FMT_P_F32;
+    if (contiguous) {
+        d.src_l = (const float*)sd.data + d.off0;
+        d.src_r = (d.flags & VB_MONO) ? d.src_l : d.src_l + sd.frames;
+        if ((d.flags >> VB_RAMP_SHIFT) == 0) d.flags |= VB_SIMPLE;
+    }
+}
+
+// last block index (relative to this call) that still has a message for node `state_idx`; -1 if none
+__device__ inline int last_cmd_block(const Cmd* cmds, int n_cmds, int state_idx, uint32_t cmd_block0) {
+    if (n_cmds == 0) return -1;
+    int lo = 0, hi = n_cmds;  // upper bound of state_idx
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (cmds[mid].state <= state_idx) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo == 0 || cmds[lo - 1].state != state_idx) return -1;
+    return (int)(cmds[lo - 1].block - cmd_block0);  // sorted by (state, block): the last one is the latest
+}
+
 __global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint32_t cmd_block0) {
     int vi = blockIdx.x * blockDim.x + threadIdx.x;
     if (vi >= fv.n_voices) return;
@@ -658,11 +714,31 @@ __global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint3
     for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
         if (j < vd.n_stages) st[j] = *(const StageRegs*)&fv.states[vd.stage_state[j]];
 
+    int last_cmd = last_cmd_block(fv.cmds, fv.n_cmds, vd.sampler_state, cmd_block0);
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
+        if (j < vd.n_stages) {
+            int l = last_cmd_block(fv.cmds, fv.n_cmds, vd.stage_state[j], cmd_block0);
+            last_cmd = l > last_cmd ? l : last_cmd;
+        }
+
+    SteadyRec sr;
+    sr.from = K;
+    sr.mode = 0;
+    sr.base = sr.start = sr.len = 0;
+    int cached_sample = -1;
+    SampleDesc sd;
+    sd.data = nullptr;
+    sd.frames = 0;
+    sd.channels = 2;
+    sd.format = FMT_P_F32;
+
     for (int k = 0; k < K; ++k) {
         const uint32_t cb = cmd_block0 + k;
         VoiceBlk d;
         d.flags = 0;
         d.n1 = frames;
+        d.src_l = d.src_r = nullptr;
         d.off0 = d.off1 = 0;
         d.sample = -1;
         d.pad = 0;
@@ -673,10 +749,15 @@ __global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint3
         // ---- sampler (nodes/sampler.rs:323-561)
         apply_cmds(ss, vd.sampler_state, cb, fv.cmds, fv.n_cmds, fv.samples);
         bool silent = true;
+        bool sampler_frozen = true;  // its state does not move this block (no sample / paused / muted)
         if (ss.sample >= 0 && ss.playing) {
             GainRun run = smoother_begin(ss.s0, ss.p0, frames);
             if (!(!smoother_is_smoothing(ss.s0) && run.c < 0.00001f)) {
-                const SampleDesc sd = fv.samples[ss.sample];
+                sampler_frozen = false;
+                if (cached_sample != ss.sample) {
+                    sd = fv.samples[ss.sample];
+                    cached_sample = ss.sample;
+                }
                 Fetch ft;
                 bool ok = sampler_advance(ss, sd.frames, (uint32_t)frames, ft);
                 if (run.ramp) {
@@ -703,7 +784,7 @@ __global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint3
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
             if (j >= vd.n_stages) break;
             StageRegs& r = st[j];
-            {   // messages for this node (only p0/p1 apply to gain stages)
+            if (fv.n_cmds) {  // messages for this node (only p0/p1 apply to gain stages)
                 NodeState tmp;
                 tmp.p0 = r.p0;
                 tmp.p1 = r.p1;
@@ -748,12 +829,133 @@ __global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint3
             }
         }
         if (silent) d.flags |= VB_SILENT;
+        else blk_set_source(d, sd);
         fv.blks[(size_t)k * fv.n_voices + vi] = d;
+
+        // ---- steady from the next block on?  (then k_voice_fill writes blocks k+1 .. K-1 from this one)
+        if (k + 1 >= K || k < last_cmd) continue;
+        bool steady = true;
+        bool upstream_silent = false;
+        int mode = 0;
+        uint64_t base = 0;
+        if (ss.sample < 0 || !ss.playing) {
+            upstream_silent = true;  // frozen sampler: nothing moves
+        } else {
+            if (!smoother_is_constant(ss.s0, ss.p0)) steady = false;
+            else if (ss.s0.status == SM_INACTIVE && ss.s0.input < 0.00001f) upstream_silent = true;  // muted, frozen
+            else if (sampler_frozen) steady = false;  // (cannot happen: kept for clarity)
+            else if (ss.has_loop) {
+                uint64_t L = ss.loop_end - ss.loop_start;
+                if (ss.loop_end > ss.loop_start && L >= (uint64_t)frames && ss.playhead >= ss.loop_start &&
+                    ss.loop_end <= sd.frames) {
+                    mode = 1;
+                    base = ss.playhead >= ss.loop_end ? 0 : ss.playhead - ss.loop_start;
+                } else steady = false;
+            } else {
+                uint64_t need = (uint64_t)(K - 1 - k) * (uint64_t)frames;
+                if (ss.playhead + need <= sd.frames) {
+                    mode = 2;
+                    base = ss.playhead;
+                } else steady = false;  // the one-shot ends inside this call: stay on the exact path
+            }
+        }
+        bool sil = upstream_silent;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+            if (j >= vd.n_stages || !steady) break;
+            const StageRegs& r = st[j];
+            if (sil) {  // reset() every block: idempotent once applied
+                if (!(r.s0.status == SM_INACTIVE && r.s0.input == r.p0)) steady = false;
+                if (vd.stage_kind[j] == K_PAN && !(r.s1.status == SM_INACTIVE && r.s1.input == r.p1)) steady = false;
+            } else if (vd.stage_kind[j] == K_VOLUME) {
+                if (!smoother_is_constant(r.s0, r.p0)) steady = false;
+                else if (r.s0.status == SM_INACTIVE && r.s0.input < 0.00001f) sil = true;
+            } else {
+                if (!smoother_is_constant(r.s0, r.p0) || !smoother_is_constant(r.s1, r.p1)) steady = false;
+            }
+        }
+        if (!steady) continue;
+        sr.from = k + 1;
+        sr.mode = mode;
+        sr.base = base;
+        sr.start = ss.loop_start;
+        sr.len = mode == 1 ? ss.loop_end - ss.loop_start : 0;
+        // the descriptor every later block shares (k_voice_fill re-derives the playhead fields): constant
+        // gains are `input` for a settled smoother and `last` for one stalled at its fixed point (Q28)
+        {
+            VoiceBlk t;
+            t.flags = sil ? VB_SILENT : 0u;
+            t.n1 = frames;
+            t.src_l = t.src_r = nullptr;
+            t.off0 = t.off1 = 0;
+            t.sample = upstream_silent ? -1 : ss.sample;
+            t.pad = 0;
+#pragma unroll
+            for (int j = 0; j < FW_MAX_STAGES; ++j) t.g[j][0] = t.g[j][1] = 1.0f;
+            if (!upstream_silent) {
+                if (sd.channels == 1) t.flags |= VB_MONO;
+                t.g[0][0] = t.g[0][1] = ss.s0.status == SM_ACTIVE ? ss.s0.last : ss.s0.input;
+            }
+#pragma unroll
+            for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+                if (j >= vd.n_stages) break;
+                const StageRegs& r = st[j];
+                t.g[j + 1][0] = r.s0.status == SM_ACTIVE ? r.s0.last : r.s0.input;
+                t.g[j + 1][1] = vd.stage_kind[j] == K_PAN ? (r.s1.status == SM_ACTIVE ? r.s1.last : r.s1.input)
+                                                          : t.g[j + 1][0];
+            }
+            fv.tmpl[vi] = t;
+        }
+        // playhead after the last block of this call
+        const uint64_t rest = (uint64_t)(K - 1 - k);  // blocks k+1 .. K-1
+        if (mode == 1) {
+            uint64_t r_last = (base + (rest - 1) * (uint64_t)frames) % sr.len;  // offset at block K-1
+            uint64_t left = sr.len - r_last;
+            ss.playhead = left < (uint64_t)frames ? ss.loop_start + ((uint64_t)frames - left)
+                                                  : ss.loop_start + r_last + (uint64_t)frames;
+        } else if (mode == 2) {
+            ss.playhead += rest * (uint64_t)frames;
+        }
+        break;
     }
+    fv.steady[vi] = sr;
     fv.states[vd.sampler_state] = ss;
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
         if (j < vd.n_stages) *(StageRegs*)&fv.states[vd.stage_state[j]] = st[j];
+}
+
+// Control, phase 2: one thread per (voice, block >= 1).  Blocks at or after the voice's steady point copy the
+// template descriptor (the last block phase 1 computed) and re-derive the playhead-dependent fields in closed
+// form: loop: r_j = (base + j*frames) mod L (nodes/sampler.rs:445-484); one-shot: playhead + j*frames.
+__global__ __launch_bounds__(256) void k_voice_fill(FusedView fv, int K) {
+    int vi = blockIdx.x * blockDim.x + threadIdx.x;
+    int k = blockIdx.y + 1;
+    if (vi >= fv.n_voices || k >= K) return;
+    const SteadyRec sr = fv.steady[vi];
+    if (k < sr.from) return;
+    VoiceBlk d = fv.tmpl[vi];
+    if (sr.mode != 0 && d.sample >= 0) {
+        const uint64_t j = (uint64_t)(k - sr.from);
+        const uint32_t frames = (uint32_t)fv.frames;
+        d.flags &= ~(VB_WRAP | VB_TAIL_ZERO | VB_SIMPLE);
+        if (sr.mode == 1) {
+            uint64_t r = (sr.base + j * (uint64_t)frames) % sr.len;
+            uint64_t left = sr.len - r;
+            d.off0 = sr.start + r;
+            d.off1 = sr.start;
+            d.n1 = left < (uint64_t)frames ? (uint32_t)left : frames;
+            if (left < (uint64_t)frames) d.flags |= VB_WRAP;
+        } else {
+            d.off0 = sr.base + j * (uint64_t)frames;
+            d.n1 = frames;
+        }
+        if (!(d.flags & VB_SILENT)) {
+            const SampleDesc sd = fv.samples[d.sample];
+            blk_set_source(d, sd);
+        }
+    }
+    fv.blks[(size_t)k * fv.n_voices + vi] = d;
 }
 
 // Leaf kernel: one wave per (leaf SumNode, block).  For each port in order: fetch the voice's source frames,
@@ -761,14 +963,12 @@ __global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint3
 // HBM traffic = the source samples once (8 B per stereo voice-sample) + one partial-bus write per leaf.
 __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& d, uint32_t k, int voice, int f0, int frames,
                                            v4f& xl, v4f& xr) {
-    const SampleDesc sd = fv.samples[d.sample];
-    const bool simple = !(d.flags & (VB_WRAP | VB_TAIL_ZERO)) && sd.format == FMT_P_F32 && f0 + 4 <= frames;
     const bool mono = d.flags & VB_MONO;
-    if (simple) {  // planar f32, contiguous: one dwordx4 per channel per lane (core/sample_resource.rs:442-456)
-        const float* base = (const float*)sd.data + d.off0 + f0;
-        xl = *(const v4f_u*)base;
-        xr = mono ? xl : *(const v4f_u*)(base + sd.frames);
+    if (d.src_l && f0 + 4 <= frames) {  // planar f32, contiguous: one dwordx4 per channel per lane
+        xl = *(const v4f_u*)(d.src_l + f0);
+        xr = mono ? xl : *(const v4f_u*)(d.src_r + f0);
     } else {
+        const SampleDesc sd = fv.samples[d.sample];
         Fetch ft;
         ft.off0 = d.off0;
         ft.off1 = d.off1;
@@ -782,6 +982,7 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
     if (rbits == 0) {  // constant gains: sampler.rs:530-533 then volume.rs:123-126 / pan, one rounding each
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES; ++j) {
+            if (j >= fv.n_gain_stages) break;
             xl = xl * d.g[j][0];
             xr = xr * d.g[j][1];
         }
@@ -790,10 +991,61 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
         const float* rb = fv.ramps + ((size_t)k * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES; ++j) {
+            if (j >= fv.n_gain_stages) break;
             v4f gl = (rbits >> (2 * j)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j) * fv.stride) : splat(d.g[j][0]);
             v4f gr = (rbits >> (2 * j + 1)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j + 1) * fv.stride) : splat(d.g[j][1]);
             xl = xl * gl;
             xr = xr * gr;
+        }
+    }
+}
+
+__device__ __forceinline__ const float* readlane_ptr(const float* p, int lane) {
+    uint64_t u = (uint64_t)p;
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+    return (const float*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float readlane_f(float x, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+
+#define LEAF_U 4  // voices whose source loads are in flight together (2*LEAF_U dwordx4 per lane)
+// the pointers come out of v_readlane as integers: tell the compiler they are GLOBAL (global_load, not flat_load)
+typedef const v4f_u __attribute__((address_space(1)))* gv4p;
+__device__ __forceinline__ v4f gload4(const float* p) { return *(gv4p)(uint64_t)p; }
+
+template <int NG>
+__device__ __forceinline__ void leaf_fast(const VoiceBlk& mine, int ports, int f0, v4f& accl, v4f& accr) {
+    // lane p holds voice p's descriptor; every voice is VB_SIMPLE (contiguous planar f32, constant gains)
+    for (int p0 = 0; p0 < ports; p0 += LEAF_U) {
+        v4f xl[LEAF_U], xr[LEAF_U];
+#pragma unroll
+        for (int u = 0; u < LEAF_U; ++u) {
+            if (p0 + u < ports) {
+                const float* sl = readlane_ptr(mine.src_l, p0 + u);
+                const float* sr = readlane_ptr(mine.src_r, p0 + u);
+                xl[u] = gload4(sl + f0);
+                xr[u] = gload4(sr + f0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LEAF_U; ++u) {
+            if (p0 + u < ports) {
+                v4f a = xl[u], b = xr[u];
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    a = a * readlane_f(mine.g[j][0], p0 + u);
+                    b = b * readlane_f(mine.g[j][1], p0 + u);
+                }
+                if (p0 + u == 0) {
+                    accl = a;
+                    accr = b;
+                } else {
+                    accl = accl + a;
+                    accr = accr + b;
+                }
+            }
         }
     }
 }
@@ -811,15 +1063,27 @@ __global__ __launch_bounds__(WAVE* WPB) void k_leaf_sum(FusedView fv) {
     float* outl = bus + (size_t)ld.out_buf * fv.stride;
     float* outr = outl + fv.stride;
 
-    // in_silence_mask of the SumNode: both channels of a chain share one flag
-    bool sil = lane < ld.ports ? (blk[lane].flags & VB_SILENT) != 0 : true;
-    const uint64_t silent_ports = __ballot(sil);
-    const bool all_silent = (silent_ports & mask_all_silent_bits(ld.ports)) == mask_all_silent_bits(ld.ports);
+    // lane p loads the descriptor of port p (ports <= 32); in_silence_mask: both channels share one flag
+    VoiceBlk mine;
+    mine.flags = VB_SILENT;
+    if (lane < ld.ports) mine = blk[lane];
+    const uint64_t lanes_in = mask_all_silent_bits(ld.ports);
+    const uint64_t silent_ports = __ballot((mine.flags & VB_SILENT) != 0) & lanes_in;
+    const uint64_t simple_ports = __ballot((mine.flags & VB_SIMPLE) != 0) & lanes_in;
+    const bool all_silent = silent_ports == lanes_in;
     const bool masked = !(ld.ports == 2 || ld.ports == 3 || ld.ports == 4);  // sum.rs:67-133 (Q13)
+    const bool fast = simple_ports == lanes_in && (frames & 3) == 0;
 
     for (int f0 = lane * 4; f0 < frames; f0 += 256) {
         v4f accl = splat(0.f), accr = splat(0.f);
-        if (!all_silent) {
+        if (fast) {
+            switch (fv.n_gain_stages) {
+                case 1: leaf_fast<1>(mine, ld.ports, f0, accl, accr); break;
+                case 2: leaf_fast<2>(mine, ld.ports, f0, accl, accr); break;
+                case 3: leaf_fast<3>(mine, ld.ports, f0, accl, accr); break;
+                default: leaf_fast<4>(mine, ld.ports, f0, accl, accr); break;
+            }
+        } else if (!all_silent) {
             for (int p = 0; p < ld.ports; ++p) {
                 const bool psil = (silent_ports >> p) & 1ull;
                 v4f xl = splat(0.f), xr = splat(0.f);  // a silent chain's buffers hold cleared zeros
@@ -843,6 +1107,55 @@ __global__ __launch_bounds__(WAVE* WPB) void k_leaf_sum(FusedView fv) {
     if (lane < 2) bflags[ld.out_buf + lane] = all_silent ? 1 : 0;
 }
 
+// Upper sum tree of the fused plan, K-batched: SumNode semantics (nodes/sum.rs:41-136) with one THREAD per
+// frame (blockIdx = node, block, channel) so that a 1-node level still puts K * n_out * frames/64 waves in flight.
+__global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restrict__ level_nodes) {
+    const NodeDesc nd = v.nodes[level_nodes[blockIdx.x]];
+    const uint32_t blk = blockIdx.y;
+    const int c = blockIdx.z;
+    const int lane = threadIdx.x & (WAVE - 1);
+    float* pool = v.pool + (size_t)blk * v.pool_blk_stride;
+    uint8_t* flags = v.flags + (size_t)blk * v.flags_blk_stride;
+    const int* in_buf = v.in_buf + nd.in_off;
+    const int* out_buf = v.out_buf + nd.out_off;
+    const int n_in = nd.n_in, n_out = nd.n_out, ports = nd.aux0;
+    const int my_in = lane < n_in ? in_buf[lane] : 0;
+    const uint64_t in_mask = __ballot(lane < n_in ? flags[my_in] != 0 : false);
+    float* out = pool + (size_t)out_buf[c] * v.stride;
+    uint64_t out_mask = 0;
+    if (mask_all(in_mask, n_in)) {  // :52-56
+        for (int f = threadIdx.x; f < v.frames; f += blockDim.x) out[f] = 0.f;
+        out_mask = mask_all_silent_bits(n_out);
+    } else if (n_in == n_out) {  // :58-65
+        const float* in = pool + (size_t)__builtin_amdgcn_readlane(my_in, c) * v.stride;
+        for (int f = threadIdx.x; f < v.frames; f += blockDim.x) out[f] = in[f];
+        out_mask = in_mask;
+    } else {
+        const bool masked = !(ports == 2 || ports == 3 || ports == 4);
+        for (int f = threadIdx.x; f < v.frames; f += blockDim.x) {
+            float acc = pool[(size_t)__builtin_amdgcn_readlane(my_in, c) * v.stride + f];
+            for (int p0 = 1; p0 < ports; p0 += 8) {
+                float x[8];
+                bool use[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    use[u] = false;
+                    if (p0 + u < ports) {
+                        int ic = n_out * (p0 + u) + c;
+                        use[u] = !(masked && mask_bit(in_mask, ic));  // :122-124
+                        x[u] = pool[(size_t)__builtin_amdgcn_readlane(my_in, ic) * v.stride + f];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (use[u]) acc = acc + x[u];
+            }
+            out[f] = acc;
+        }
+    }
+    if (c == 0 && (int)threadIdx.x < n_out) flags[out_buf[threadIdx.x]] = mask_bit(out_mask, threadIdx.x) ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ launch wrappers (host side of this TU)
 #define HIPCHK(x)                        \
     do {                                 \
@@ -854,6 +1167,12 @@ int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int 
     if (n_nodes <= 0) return 0;
     dim3 grid((n_nodes + WPB - 1) / WPB, K);
     hipLaunchKernelGGL(k_level, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0);
+    return (int)hipGetLastError();
+}
+int launch_bus_sum(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, int n_out) {
+    if (n_nodes <= 0) return 0;
+    dim3 grid(n_nodes, K, n_out);
+    hipLaunchKernelGGL(k_bus_sum, grid, dim3(256), 0, s, v, d_level_nodes);
     return (int)hipGetLastError();
 }
 int launch_single_node(hipStream_t s, const DevView& v, int node_idx) {
@@ -892,6 +1211,12 @@ int launch_get_flags(hipStream_t s, const uint8_t* flags, const int* d_bufs, int
 int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0) {
     if (fv.n_voices <= 0) return 0;
     hipLaunchKernelGGL(k_voice_control, dim3((fv.n_voices + 63) / 64), dim3(64), 0, s, fv, K, cmd_block0);
+    return (int)hipGetLastError();
+}
+int launch_voice_fill(hipStream_t s, const FusedView& fv, int K) {
+    if (fv.n_voices <= 0 || K <= 1) return 0;
+    dim3 grid((fv.n_voices + 255) / 256, K - 1);
+    hipLaunchKernelGGL(k_voice_fill, grid, dim3(256), 0, s, fv, K);
     return (int)hipGetLastError();
 }
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {

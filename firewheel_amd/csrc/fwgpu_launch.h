@@ -33,6 +33,9 @@ struct FusedView {
     NodeState* states;
     const SampleDesc* samples;
     VoiceBlk* blks;   // [K][n_voices]
+    SteadyRec* steady;  // [n_voices]
+    VoiceBlk* tmpl;     // [n_voices] steady-state descriptor template
+    int n_gain_stages;  // 1 (sampler gain) + longest chain in the plan
     float* ramps;     // [K][n_voices][ramp_slots][stride], slot = 2*stage + channel
     int ramp_slots;
     float* bus;       // [K][n_bus_buffers][stride]
@@ -48,6 +51,7 @@ struct FusedView {
 };
 
 int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0);
+int launch_bus_sum(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, int n_out);
 int launch_single_node(hipStream_t s, const DevView& v, int node_idx);
 int launch_scatter_states(hipStream_t s, NodeState* states, const void* d_inits, int n);
 int launch_graph_in(hipStream_t s, float* pool, uint8_t* flags, int stride, const int* d_bufs, int n_bufs,
@@ -57,6 +61,7 @@ int launch_graph_out(hipStream_t s, const float* pool, const uint8_t* flags, int
 int launch_set_flags(hipStream_t s, uint8_t* flags, const int* d_bufs, int n, uint64_t mask);
 int launch_get_flags(hipStream_t s, const uint8_t* flags, const int* d_bufs, int n, uint64_t* d_mask);
 int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0);
+int launch_voice_fill(hipStream_t s, const FusedView& fv, int K);
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K);
 
 // host-side mirror of the StateInit record consumed by k_scatter_states

@@ -84,24 +84,36 @@ struct VoiceDesc {  // static per voice chain: sampler -> [volume|pan]* -> leaf 
     int stage_state[FW_MAX_STAGES - 1];
 };
 
-// per (block, voice) record written by the control kernel, read by the leaf kernel (64 B)
+// per (block, voice) record written by the control kernels, read by the leaf kernel (80 B)
 enum : uint32_t {
     VB_SILENT = 1u,       // chain output is cleared + flagged silent for this block
     VB_WRAP = 2u,         // loop wrap inside the block: frames [n1, frames) come from off1
     VB_TAIL_ZERO = 4u,    // one-shot end inside the block: frames [n1, frames) are 0.0
     VB_MONO = 8u,         // 1-channel sample duplicated to both outputs (sampler.rs:546-551)
+    VB_SIMPLE = 16u,      // contiguous planar-f32 source + constant gains: src_l/src_r valid, fast path
     VB_RAMP_SHIFT = 8,    // bit (VB_RAMP_SHIFT + 2*stage + ch): that gain is a per-frame ramp
 };
 struct VoiceBlk {
     uint32_t flags;
-    uint32_t n1;     // frames taken from off0
-    uint64_t off0;   // source frame of frame 0
-    uint64_t off1;   // source frame of frame n1 when VB_WRAP
-    int sample;      // sample-table index
+    uint32_t n1;         // frames taken from off0
+    const float* src_l;  // frame 0 of channel 0 / 1 when the block's frames are contiguous planar f32
+    const float* src_r;
+    uint64_t off0;       // source frame of frame 0
+    uint64_t off1;       // source frame of frame n1 when VB_WRAP
+    int sample;          // sample-table index
     uint32_t pad;
     float g[FW_MAX_STAGES][2];  // constant gains per stage and channel (used when the ramp bit is clear)
 };
-static_assert(sizeof(VoiceBlk) == 64, "VoiceBlk layout");
+static_assert(sizeof(VoiceBlk) == 80, "VoiceBlk layout");
+
+// per voice: from which block of the current call the descriptors follow the closed form (k_voice_fill)
+struct SteadyRec {
+    int from;        // first block filled by k_voice_fill (K = none)
+    int mode;        // 0 = copy the template, 1 = looping playhead, 2 = one-shot playhead
+    uint64_t base;   // mode 1: loop offset at block `from`; mode 2: playhead at block `from`
+    uint64_t start;  // loop start
+    uint64_t len;    // loop length
+};
 
 struct LeafDesc {  // a SumNode whose ports are all voice chains (nodes/sum.rs)
     int first_voice;

@@ -178,12 +178,16 @@ class TaggedOracle(object):
         return self.e.process_interleaved(frames, *a, **kw)
 
 
-def scenario_mixed_generic(e):
-    """a graph the fused plan does not cover: beep + sampler through clip / mono<->stereo / 2,3,4-port sums,
-    dangling ports, one-to-many edges.  Returns (output, beep_only_output)."""
+def scenario_mixed_generic(e, use_beep=True):
+    """a graph the fused plan does not cover: beep (or a mono sampler) + sampler through clip / mono<->stereo /
+    2,3,4-port sums, dangling ports, one-to-many edges.  A disabled BeepTest with consumers is outside the
+    parity domain (Q12: its channel 0 exposes whatever the reference's reused buffer held), so the beep stays on."""
     s = e.sampler(80.0)
     data = voice_source(77, 2000)
-    beep = e.beep(440.0, -12.0, True, n_out=1)
+    if use_beep:
+        beep = e.beep(440.0, -12.0, True, n_out=1)
+    else:
+        beep = e.sampler(30.0, n_out=1)
     m2s = e.add_node(MONO_TO_STEREO, 1, 2)
     clip = e.hard_clip(-9.0)
     s2m = e.add_node(STEREO_TO_MONO, 2, 1)
@@ -211,8 +215,10 @@ def scenario_mixed_generic(e):
     e.sampler_set_sample(s, smp)
     e.sampler_set_loop_range(s, LOOP_FULL)
     e.sampler_play(s)
+    if not use_beep:
+        e.sampler_set_sample(beep, e.new_sample(PLANAR_F32, 1, voice_source(78, 1500, 1)))
+        e.sampler_play(beep)                     # one-shot: ends inside the run
     out1 = e.process_blocks(4)
-    e.set_param(beep, 0, 0.0)                    # disable the beep (Q12)
     e.set_param(vol3, 0, 20.0)
     out2 = e.process_blocks(4)
     return np.concatenate([out1, out2])

@@ -32,6 +32,7 @@ CASES = {
     "events_70": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=256), 70),
     "events_33_r2": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=128), 33, radix=2, src_frames=777),
     "mixed_generic": lambda: scenarios.scenario_mixed_generic(oracle(max_block_frames=256)),
+    "mixed_generic_nobeep": lambda: scenarios.scenario_mixed_generic(oracle(max_block_frames=256), use_beep=False),
     "graph_inputs": lambda: scenarios.scenario_graph_inputs(oracle(max_block_frames=64, num_graph_inputs=3)),
 }
 

@@ -5,7 +5,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libfwgpu.so")
+# FWGPU_LIB: kernel-variant experiments only (gpurun A/B runs); the product is csrc/libfwgpu.so
+LIB_PATH = os.environ.get("FWGPU_LIB") or os.path.join(CSRC, "libfwgpu.so")
 
 
 class FwgpuError(RuntimeError):

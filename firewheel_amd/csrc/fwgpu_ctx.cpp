@@ -95,7 +95,8 @@ struct fwgpu_ctx {
     // fused plan
     bool fused = false;
     int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
-    DevBuf d_voices, d_leaves, d_blks, d_steady, d_tmpl, d_ramps, d_bus, d_bus_flags;
+    uint32_t epoch = 1;  // invalidates every VoiceCache when bumped (plan install, sample-table change)
+    DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags;
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
     std::vector<int> up_level_off, up_level_cnt;
 
@@ -226,6 +227,7 @@ int upload(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes) {
 int upload_sample_table(fwgpu_ctx* c) {
     if (!c->samples_dirty) return 0;
     c->samples_dirty = false;
+    c->epoch++;  // cached steady descriptors hold sample indices / sizes
     std::vector<SampleDesc> tab(std::max<size_t>(c->samples.size(), 1));
     for (size_t i = 0; i < c->samples.size(); ++i) tab[i] = c->samples[i].desc;
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -512,8 +514,11 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         if ((rc = upload(c, c->d_leaves, fb.leaves.data(), fb.leaves.size() * sizeof(LeafDesc)))) return rc;
         const size_t K = c->kmax;
         HIPC(c, c->d_blks.ensure(K * c->n_voices * sizeof(VoiceBlk)));
-        HIPC(c, c->d_steady.ensure((size_t)c->n_voices * sizeof(SteadyRec)));
-        HIPC(c, c->d_tmpl.ensure((size_t)c->n_voices * sizeof(VoiceBlk)));
+        HIPC(c, c->d_refs.ensure(K * c->n_voices * sizeof(VoiceRef)));
+        HIPC(c, c->d_gsets.ensure((size_t)c->n_voices * FW_GSETS * sizeof(GainSet)));
+        HIPC(c, c->d_cache.ensure((size_t)c->n_voices * sizeof(VoiceCache)));
+        HIPC(c, hipMemset(c->d_cache.p, 0, (size_t)c->n_voices * sizeof(VoiceCache)));
+        c->epoch++;
         HIPC(c, c->d_ramps.ensure(K * c->n_voices * (size_t)c->ramp_slots * c->stride * sizeof(float)));
         size_t bus_bytes = K * (size_t)c->n_bus * c->stride * sizeof(float);
         HIPC(c, c->d_bus.ensure(bus_bytes));
@@ -643,6 +648,7 @@ int run_generic_block(fwgpu_ctx* c, int frames, uint32_t cmd_block, const float*
     if (c->n_gin_bufs > 0)
         LCHK(c, launch_graph_in(c->stream, c->d_pool.as<float>(), c->d_flags.as<uint8_t>(), c->stride,
                                 c->d_gin_bufs.as<int>(), c->n_gin_bufs, d_in, d_in ? n_in_ch : 0, frames));
+    c->epoch++;  // node state moves outside the fused control kernel: cached steady descriptors are stale
     DevView v = generic_view(c, frames);
     hipEvent_t e0, e1;
     timer_begin(c, 3, &e0, &e1);
@@ -662,8 +668,11 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     fv.states = c->d_states.as<NodeState>();
     fv.samples = c->d_samples.as<SampleDesc>();
     fv.blks = c->d_blks.as<VoiceBlk>();
-    fv.steady = c->d_steady.as<SteadyRec>();
-    fv.tmpl = c->d_tmpl.as<VoiceBlk>();
+    fv.refs = c->d_refs.as<VoiceRef>();
+    fv.refs_stride = (int)c->kmax;
+    fv.gsets = c->d_gsets.as<GainSet>();
+    fv.cache = c->d_cache.as<VoiceCache>();
+    fv.epoch = c->epoch;
     fv.n_gain_stages = c->ramp_slots / 2;
     fv.ramps = c->d_ramps.as<float>();
     fv.ramp_slots = c->ramp_slots;
@@ -680,7 +689,6 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     hipEvent_t e0, e1;
     timer_begin(c, 1, &e0, &e1);
     LCHK(c, launch_voice_control(c->stream, fv, K, cmd_block0));
-    LCHK(c, launch_voice_fill(c->stream, fv, K));
     timer_end(c, e1);
     timer_begin(c, 0, &e0, &e1);
     LCHK(c, launch_leaf_sum(c->stream, fv, K));
@@ -824,7 +832,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     for (SampleRec& s : c->samples)
         if (s.alive && s.owned && s.d_data) (void)hipFree(s.d_data);
     DevBuf* bufs[] = {&c->d_states, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
-                      &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_steady, &c->d_tmpl, &c->d_ramps,
+                      &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
                       &c->d_bus, &c->d_bus_flags, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
                       &c->d_root_bufs, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask};
@@ -1163,6 +1171,7 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     v.out_buf = v.in_buf + n_in + 1;
     v.pool = c->d_scratch_pool.as<float>();
     v.flags = c->d_scratch_flags.as<uint8_t>();
+    c->epoch++;
     LCHK(c, launch_single_node(c->stream, v, 0));
     for (uint32_t i = 0; i < n_out; ++i)
         HIPC(c, hipMemcpyAsync(outputs[i], c->d_scratch_pool.as<float>() + (1 + n_in + i) * stride, frames * sizeof(float),

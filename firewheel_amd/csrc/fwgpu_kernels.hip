@@ -639,12 +639,11 @@ __global__ void k_get_flags(const uint8_t* flags, const int* __restrict__ bufs, 
 }
 
 // ------------------------------------------------------------------ fused voice-bank plan
-// Control, phase 1 (k_voice_control): one thread per voice runs the per-block state machines of its whole
+// Control kernel (k_voice_control): one thread per voice runs the per-block state machines of its whole
 // chain in schedule order (sampler -> stage nodes) and emits one VoiceBlk per block.  As soon as the voice
 // is STEADY (no message left for it in this call, every smoother constant) the remaining blocks only differ
-// by the playhead, which has a closed form; the thread records that and stops.  Phase 2 (k_voice_fill) then
-// fills those blocks' descriptors with one thread per (voice, block).  Per-frame ramps (ParamSmoother Active)
-// are materialised into `ramps` only for blocks where the values actually change.
+// by the playhead, and the thread finishes the call with a short descriptor-store loop.  Per-frame ramps
+// (ParamSmoother Active) are materialised into `ramps` only for blocks where the values actually change.
 struct StageRegs {  // the NodeState prefix (p0,p1,s0,s1) a gain stage needs
     float p0, p1;
     Smoother s0, s1;
@@ -652,7 +651,7 @@ struct StageRegs {  // the NodeState prefix (p0,p1,s0,s1) a gain stage needs
 
 // Serial ramp -> global memory; returns false (and writes nothing) when the recurrence is already at its
 // f32 fixed point (Q28: an Active smoother can stall above settle_epsilon forever) — the block is constant.
-__device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, float* dst1) {
+__device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, float* dst1, bool write) {
     float prev = r.prev;
     float v0 = r.in_a + (prev * r.b);
     if (v0 == prev) {  // fixed point: every later value equals prev, bit for bit
@@ -662,8 +661,10 @@ __device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, f
     }
     for (int i = 0; i < frames; ++i) {
         prev = r.in_a + (prev * r.b);
-        dst0[i] = prev;
-        if (dst1) dst1[i] = prev;
+        if (write) {
+            dst0[i] = prev;
+            if (dst1) dst1[i] = prev;
+        }
     }
     r.prev = prev;
     return true;
@@ -679,14 +680,15 @@ __device__ __forceinline__ bool smoother_is_constant(const Smoother& s, float ta
 }
 
 // source pointers of a block whose frames are contiguous planar f32 (the fast path of the leaf kernel)
-__device__ __forceinline__ void blk_set_source(VoiceBlk& d, const SampleDesc& sd) {
+__device__ __forceinline__ void blk_set_source(VoiceBlk& d, const SampleDesc& sd, int frames) {
     d.src_l = nullptr;
     d.src_r = nullptr;
     const bool contiguous = !(d.flags & (VB_WRAP | VB_TAIL_ZERO | VB_SILENT)) && sd.format == FMT_P_F32;
     if (contiguous) {
         d.src_l = (const float*)sd.data + d.off0;
         d.src_r = (d.flags & VB_MONO) ? d.src_l : d.src_l + sd.frames;
-        if ((d.flags >> VB_RAMP_SHIFT) == 0) d.flags |= VB_SIMPLE;
+        // VB_SIMPLE blocks carry no full descriptor, so they must never need the per-element path (ragged tail)
+        if ((d.flags >> VB_RAMP_SHIFT) == 0 && (frames & 3) == 0 && sd.frames < 0xffffffffull) d.flags |= VB_SIMPLE;
     }
 }
 
@@ -703,35 +705,209 @@ __device__ inline int last_cmd_block(const Cmd* cmds, int n_cmds, int state_idx,
     return (int)(cmds[lo - 1].block - cmd_block0);  // sorted by (state, block): the last one is the latest
 }
 
-__global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint32_t cmd_block0) {
-    int vi = blockIdx.x * blockDim.x + threadIdx.x;
+// Everything the steady tail of a call needs: the descriptor all its blocks share and how the playhead moves.
+struct TailJob {
+    int mode;          // 0 = nothing moves, 1 = looping playhead, 2 = one-shot playhead
+    uint32_t flags;    // VB_SILENT / VB_MONO of the shared descriptor
+    int sample;
+    GainSet g;
+    uint64_t playhead, loop_start, loop_end;
+};
+
+// Writes the compact record (always) and the full descriptor (only when the leaf kernel will need it).
+__device__ __forceinline__ void put_blk(const FusedView& fv, int vi, int kk, const VoiceBlk& d, uint32_t gset,
+                                        uint64_t sample_frames) {
+    VoiceRef ref;
+    ref.src_l = d.src_l;
+    ref.r_delta = ((d.flags & VB_SIMPLE) && !(d.flags & VB_MONO)) ? (uint32_t)sample_frames : 0u;
+    ref.flags_gset = (d.flags & 0xffu) | (gset << 8);
+    fv.refs[(size_t)vi * fv.refs_stride + kk] = ref;  // [voice][block]: the tail lanes store 1 KiB contiguous
+    if (!(d.flags & (VB_SIMPLE | VB_SILENT))) fv.blks[(size_t)kk * fv.n_voices + vi] = d;
+}
+
+// Steady tail: blocks k_first .. K-1 share one descriptor; only the playhead moves, by +frames with a wrap at
+// the loop end (nodes/sampler.rs:445-484) — closed form (base + j*frames) mod L, so the 64 lanes of the
+// voice's wave fill 64 blocks at a time.  Returns the playhead the reference holds after block K-1.
+__device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int lane, int k_first, int K, const TailJob& job,
+                                                const SampleDesc& sd, uint32_t gset, bool simple_ok) {
+    const int frames = fv.frames;
+    const uint64_t fr = (uint64_t)frames;
+    VoiceBlk t;
+    t.flags = job.flags;
+    t.n1 = frames;
+    t.src_l = t.src_r = nullptr;
+    t.off0 = t.off1 = 0;
+    t.sample = job.sample;
+    t.pad = 0;
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES; ++j) {
+        t.g[j][0] = job.g.g[j][0];
+        t.g[j][1] = job.g.g[j][1];
+    }
+    const bool contiguous_f32 = !(job.flags & VB_SILENT) && job.sample >= 0 && sd.format == FMT_P_F32;
+    const uint64_t n = (uint64_t)(K - k_first);
+    if (job.mode == 1) {
+        // all quantities fit 32 bits whenever the loop does (the usual case): avoid 64-bit division
+        const uint64_t L = job.loop_end - job.loop_start;
+        const uint64_t base = job.playhead >= job.loop_end ? 0 : job.playhead - job.loop_start;
+        uint64_t r, step, r_last;
+        if (L <= 0xffffffffull && n * fr <= 0xffffffffull) {
+            // everything fits 32 bits (the usual case): 32-bit remainders instead of 64-bit division
+            const uint32_t l32 = (uint32_t)L;
+            auto addmod = [&](uint32_t j) -> uint64_t {  // (base + j*fr) mod L, base < L
+                uint64_t x = (uint64_t)((j * (uint32_t)fr) % l32) + base;
+                return x >= L ? x - L : x;
+            };
+            r = addmod((uint32_t)lane);
+            step = (uint64_t)((64u * (uint32_t)fr) % l32);
+            r_last = addmod((uint32_t)(n - 1));
+        } else {
+            r = (base + (uint64_t)lane * fr) % L;
+            step = (64ull * fr) % L;
+            r_last = (base + (n - 1) * fr) % L;
+        }
+        for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
+            const uint64_t left = L - r;
+            t.flags = job.flags;
+            t.off0 = job.loop_start + r;
+            t.off1 = job.loop_start;
+            t.src_l = t.src_r = nullptr;
+            if (left < fr) {  // wraps inside the block
+                t.n1 = (uint32_t)left;
+                t.flags |= VB_WRAP;
+            } else {
+                t.n1 = frames;
+                if (contiguous_f32) {
+                    t.src_l = (const float*)sd.data + t.off0;
+                    t.src_r = (t.flags & VB_MONO) ? t.src_l : t.src_l + sd.frames;
+                    if (simple_ok) t.flags |= VB_SIMPLE;
+                }
+            }
+            put_blk(fv, vi, k2, t, gset, sd.frames);
+            r += step;
+            if (r >= L) r -= L;
+        }
+        const uint64_t left = L - r_last;
+        return left < fr ? job.loop_start + (fr - left) : job.loop_start + r_last + fr;
+    }
+    if (job.mode == 2) {
+        for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
+            t.flags = job.flags;
+            t.off0 = job.playhead + (uint64_t)(k2 - k_first) * fr;
+            t.src_l = t.src_r = nullptr;
+            if (contiguous_f32) {
+                t.src_l = (const float*)sd.data + t.off0;
+                t.src_r = (t.flags & VB_MONO) ? t.src_l : t.src_l + sd.frames;
+                if (simple_ok) t.flags |= VB_SIMPLE;
+            }
+            put_blk(fv, vi, k2, t, gset, sd.frames);
+        }
+        return job.playhead + n * fr;
+    }
+    for (int k2 = k_first + lane; k2 < K; k2 += WAVE) put_blk(fv, vi, k2, t, 0u, sd.frames);
+    return job.playhead;
+}
+
+// One WAVE per voice: the state machines are run by all 64 lanes redundantly (wave-uniform; lane 0 stores),
+// the steady tail is split across the lanes.  A voice that ended the previous call steady and has no message
+// in this one skips the state machines altogether (VoiceCache): its whole call is a steady tail.
+__global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint32_t cmd_block0) {
+    const int vi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (vi >= fv.n_voices) return;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const bool w0 = lane == 0;
     const VoiceDesc vd = fv.voices[vi];
     const int frames = fv.frames;
+    const bool simple_frames = (frames & 3) == 0;
+
+    int last_cmd = -1;
+    if (fv.n_cmds) {
+        last_cmd = last_cmd_block(fv.cmds, fv.n_cmds, vd.sampler_state, cmd_block0);
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
+            if (j < vd.n_stages) {
+                int l = last_cmd_block(fv.cmds, fv.n_cmds, vd.stage_state[j], cmd_block0);
+                last_cmd = l > last_cmd ? l : last_cmd;
+            }
+    }
+    GainSet* my_gsets = fv.gsets + (size_t)vi * FW_GSETS;
+
+    // ---- fast path: still steady from the previous call
+    {
+        const VoiceCache vc = fv.cache[vi];
+        if (vc.epoch == fv.epoch && last_cmd < 0) {
+            TailJob job;
+            job.mode = vc.mode;
+            job.flags = vc.flags;
+            job.sample = vc.sample;
+            job.g = vc.g;
+            job.playhead = job.loop_start = job.loop_end = 0;
+            SampleDesc sd;
+            sd.data = nullptr;
+            sd.frames = 0;
+            sd.channels = 2;
+            sd.format = FMT_P_F32;
+            bool ok = true;
+            if (vc.mode != 0) {
+                const NodeState* sp = &fv.states[vd.sampler_state];
+                job.playhead = sp->playhead;
+                job.loop_start = sp->loop_start;
+                job.loop_end = sp->loop_end;
+                sd = fv.samples[vc.sample];
+                if (vc.mode == 2 && job.playhead + (uint64_t)K * (uint64_t)frames > sd.frames) ok = false;  // ends in this call
+            }
+            if (ok) {
+                const bool simple_ok = !(job.flags & VB_SILENT) && job.sample >= 0 && sd.format == FMT_P_F32 &&
+                                       simple_frames && sd.frames < 0xffffffffull;
+                if (simple_ok && w0) my_gsets[0] = job.g;
+                uint64_t ph = steady_tail(fv, vi, lane, 0, K, job, sd, 0u, simple_ok);
+                if (w0 && vc.mode != 0) fv.states[vd.sampler_state].playhead = ph;
+                return;
+            }
+        }
+    }
+
+    // ---- general path
     NodeState ss = fv.states[vd.sampler_state];
     StageRegs st[FW_MAX_STAGES - 1];
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
         if (j < vd.n_stages) st[j] = *(const StageRegs*)&fv.states[vd.stage_state[j]];
 
-    int last_cmd = last_cmd_block(fv.cmds, fv.n_cmds, vd.sampler_state, cmd_block0);
+    // gain sets used so far in this call (the current one is mirrored in registers)
+    int n_gsets = 0;
+    GainSet cur_gs;
 #pragma unroll
-    for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
-        if (j < vd.n_stages) {
-            int l = last_cmd_block(fv.cmds, fv.n_cmds, vd.stage_state[j], cmd_block0);
-            last_cmd = l > last_cmd ? l : last_cmd;
+    for (int j = 0; j < FW_MAX_STAGES; ++j) cur_gs.g[j][0] = cur_gs.g[j][1] = 0.f;
+    // picks (or allocates) the gain set of a VB_SIMPLE block; wave-uniform.  Returns its index.
+    auto pick_gset = [&](VoiceBlk& d) -> uint32_t {
+        if (!(d.flags & VB_SIMPLE)) return 0u;
+        bool same = n_gsets > 0;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j) same = same && cur_gs.g[j][0] == d.g[j][0] && cur_gs.g[j][1] == d.g[j][1];
+        if (!same) {
+            if (n_gsets < FW_GSETS) {
+#pragma unroll
+                for (int j = 0; j < FW_MAX_STAGES; ++j) {
+                    cur_gs.g[j][0] = d.g[j][0];
+                    cur_gs.g[j][1] = d.g[j][1];
+                }
+                if (w0) my_gsets[n_gsets] = cur_gs;
+                n_gsets++;
+            } else {
+                d.flags &= ~VB_SIMPLE;  // out of gain-set slots: use the full descriptor for this block
+                return 0u;
+            }
         }
-
-    SteadyRec sr;
-    sr.from = K;
-    sr.mode = 0;
-    sr.base = sr.start = sr.len = 0;
+        return (uint32_t)(n_gsets - 1);
+    };
     int cached_sample = -1;
     SampleDesc sd;
     sd.data = nullptr;
     sd.frames = 0;
     sd.channels = 2;
     sd.format = FMT_P_F32;
+    bool became_steady = false;
 
     for (int k = 0; k < K; ++k) {
         const uint32_t cb = cmd_block0 + k;
@@ -749,11 +925,9 @@ __global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint3
         // ---- sampler (nodes/sampler.rs:323-561)
         apply_cmds(ss, vd.sampler_state, cb, fv.cmds, fv.n_cmds, fv.samples);
         bool silent = true;
-        bool sampler_frozen = true;  // its state does not move this block (no sample / paused / muted)
         if (ss.sample >= 0 && ss.playing) {
             GainRun run = smoother_begin(ss.s0, ss.p0, frames);
             if (!(!smoother_is_smoothing(ss.s0) && run.c < 0.00001f)) {
-                sampler_frozen = false;
                 if (cached_sample != ss.sample) {
                     sd = fv.samples[ss.sample];
                     cached_sample = ss.sample;
@@ -761,7 +935,7 @@ __global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint3
                 Fetch ft;
                 bool ok = sampler_advance(ss, sd.frames, (uint32_t)frames, ft);
                 if (run.ramp) {
-                    if (ramp_emit(run, frames, ramp_base, ramp_base + fv.stride)) {
+                    if (ramp_emit(run, frames, ramp_base, ramp_base + fv.stride, w0)) {
                         d.flags |= 3u << VB_RAMP_SHIFT;
                         ss.s0.last = run.prev;
                     }
@@ -801,7 +975,7 @@ __global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint3
                     if (!smoother_is_smoothing(r.s0) && run.c < 0.00001f) {
                         silent = true;
                     } else {
-                        if (run.ramp && ramp_emit(run, frames, rb, rb + fv.stride)) {
+                        if (run.ramp && ramp_emit(run, frames, rb, rb + fv.stride, w0)) {
                             d.flags |= 3u << (VB_RAMP_SHIFT + 2 * (j + 1));
                             r.s0.last = run.prev;
                         }
@@ -815,11 +989,11 @@ __global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint3
                 } else {
                     GainRun rl = smoother_begin(r.s0, r.p0, frames);
                     GainRun rr = smoother_begin(r.s1, r.p1, frames);
-                    if (rl.ramp && ramp_emit(rl, frames, rb, nullptr)) {
+                    if (rl.ramp && ramp_emit(rl, frames, rb, nullptr, w0)) {
                         d.flags |= 1u << (VB_RAMP_SHIFT + 2 * (j + 1));
                         r.s0.last = rl.prev;
                     }
-                    if (rr.ramp && ramp_emit(rr, frames, rb + fv.stride, nullptr)) {
+                    if (rr.ramp && ramp_emit(rr, frames, rb + fv.stride, nullptr, w0)) {
                         d.flags |= 2u << (VB_RAMP_SHIFT + 2 * (j + 1));
                         r.s1.last = rr.prev;
                     }
@@ -829,34 +1003,32 @@ __global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint3
             }
         }
         if (silent) d.flags |= VB_SILENT;
-        else blk_set_source(d, sd);
-        fv.blks[(size_t)k * fv.n_voices + vi] = d;
+        else blk_set_source(d, sd, frames);
+        {
+            uint32_t gs = pick_gset(d);
+            if (w0) put_blk(fv, vi, k, d, gs, sd.frames);
+        }
 
-        // ---- steady from the next block on?  (then k_voice_fill writes blocks k+1 .. K-1 from this one)
-        if (k + 1 >= K || k < last_cmd) continue;
+        // ---- steady from the next block on?
+        if (k < last_cmd) continue;
         bool steady = true;
         bool upstream_silent = false;
         int mode = 0;
-        uint64_t base = 0;
         if (ss.sample < 0 || !ss.playing) {
             upstream_silent = true;  // frozen sampler: nothing moves
         } else {
             if (!smoother_is_constant(ss.s0, ss.p0)) steady = false;
             else if (ss.s0.status == SM_INACTIVE && ss.s0.input < 0.00001f) upstream_silent = true;  // muted, frozen
-            else if (sampler_frozen) steady = false;  // (cannot happen: kept for clarity)
             else if (ss.has_loop) {
                 uint64_t L = ss.loop_end - ss.loop_start;
                 if (ss.loop_end > ss.loop_start && L >= (uint64_t)frames && ss.playhead >= ss.loop_start &&
-                    ss.loop_end <= sd.frames) {
+                    ss.loop_end <= sd.frames && cached_sample == ss.sample)
                     mode = 1;
-                    base = ss.playhead >= ss.loop_end ? 0 : ss.playhead - ss.loop_start;
-                } else steady = false;
+                else steady = false;
             } else {
                 uint64_t need = (uint64_t)(K - 1 - k) * (uint64_t)frames;
-                if (ss.playhead + need <= sd.frames) {
-                    mode = 2;
-                    base = ss.playhead;
-                } else steady = false;  // the one-shot ends inside this call: stay on the exact path
+                if (cached_sample == ss.sample && ss.playhead + need <= sd.frames) mode = 2;
+                else steady = false;  // the one-shot ends inside this call: stay on the exact path
             }
         }
         bool sil = upstream_silent;
@@ -875,87 +1047,64 @@ __global__ __launch_bounds__(64) void k_voice_control(FusedView fv, int K, uint3
             }
         }
         if (!steady) continue;
-        sr.from = k + 1;
-        sr.mode = mode;
-        sr.base = base;
-        sr.start = ss.loop_start;
-        sr.len = mode == 1 ? ss.loop_end - ss.loop_start : 0;
-        // the descriptor every later block shares (k_voice_fill re-derives the playhead fields): constant
-        // gains are `input` for a settled smoother and `last` for one stalled at its fixed point (Q28)
-        {
-            VoiceBlk t;
-            t.flags = sil ? VB_SILENT : 0u;
-            t.n1 = frames;
-            t.src_l = t.src_r = nullptr;
-            t.off0 = t.off1 = 0;
-            t.sample = upstream_silent ? -1 : ss.sample;
-            t.pad = 0;
+        // ---- steady: the descriptor every later block shares.  Constant gains are `input` for a settled
+        // smoother and `last` for one stalled at its f32 fixed point (Q28).
+        TailJob job;
+        job.mode = mode;
+        job.flags = sil ? VB_SILENT : 0u;
+        job.sample = upstream_silent ? -1 : ss.sample;
+        job.playhead = ss.playhead;
+        job.loop_start = ss.loop_start;
+        job.loop_end = ss.loop_end;
 #pragma unroll
-            for (int j = 0; j < FW_MAX_STAGES; ++j) t.g[j][0] = t.g[j][1] = 1.0f;
-            if (!upstream_silent) {
-                if (sd.channels == 1) t.flags |= VB_MONO;
-                t.g[0][0] = t.g[0][1] = ss.s0.status == SM_ACTIVE ? ss.s0.last : ss.s0.input;
-            }
-#pragma unroll
-            for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
-                if (j >= vd.n_stages) break;
-                const StageRegs& r = st[j];
-                t.g[j + 1][0] = r.s0.status == SM_ACTIVE ? r.s0.last : r.s0.input;
-                t.g[j + 1][1] = vd.stage_kind[j] == K_PAN ? (r.s1.status == SM_ACTIVE ? r.s1.last : r.s1.input)
-                                                          : t.g[j + 1][0];
-            }
-            fv.tmpl[vi] = t;
+        for (int j = 0; j < FW_MAX_STAGES; ++j) job.g.g[j][0] = job.g.g[j][1] = 1.0f;
+        if (!upstream_silent) {
+            if (sd.channels == 1) job.flags |= VB_MONO;
+            job.g.g[0][0] = job.g.g[0][1] = ss.s0.status == SM_ACTIVE ? ss.s0.last : ss.s0.input;
         }
-        // playhead after the last block of this call
-        const uint64_t rest = (uint64_t)(K - 1 - k);  // blocks k+1 .. K-1
-        if (mode == 1) {
-            uint64_t r_last = (base + (rest - 1) * (uint64_t)frames) % sr.len;  // offset at block K-1
-            uint64_t left = sr.len - r_last;
-            ss.playhead = left < (uint64_t)frames ? ss.loop_start + ((uint64_t)frames - left)
-                                                  : ss.loop_start + r_last + (uint64_t)frames;
-        } else if (mode == 2) {
-            ss.playhead += rest * (uint64_t)frames;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+            if (j >= vd.n_stages) break;
+            const StageRegs& r = st[j];
+            job.g.g[j + 1][0] = r.s0.status == SM_ACTIVE ? r.s0.last : r.s0.input;
+            job.g.g[j + 1][1] = vd.stage_kind[j] == K_PAN ? (r.s1.status == SM_ACTIVE ? r.s1.last : r.s1.input)
+                                                          : job.g.g[j + 1][0];
+        }
+        became_steady = true;
+        if (w0) {
+            VoiceCache vc;
+            vc.epoch = fv.epoch;
+            vc.mode = mode;
+            vc.flags = job.flags;
+            vc.sample = job.sample;
+            vc.g = job.g;
+            fv.cache[vi] = vc;
+        }
+        if (k + 1 < K) {
+            uint32_t tail_gs = 0;
+            bool simple_ok = false;
+            if (!sil && !upstream_silent && sd.format == FMT_P_F32 && simple_frames && sd.frames < 0xffffffffull) {
+                VoiceBlk probe;  // every non-wrapping tail block is VB_SIMPLE with the same gains: one gain set
+                probe.flags = VB_SIMPLE;
+#pragma unroll
+                for (int j = 0; j < FW_MAX_STAGES; ++j) {
+                    probe.g[j][0] = job.g.g[j][0];
+                    probe.g[j][1] = job.g.g[j][1];
+                }
+                tail_gs = pick_gset(probe);
+                simple_ok = (probe.flags & VB_SIMPLE) != 0;  // false when the voice ran out of gain-set slots
+            }
+            uint64_t ph = steady_tail(fv, vi, lane, k + 1, K, job, sd, tail_gs, simple_ok);
+            if (mode != 0) ss.playhead = ph;
         }
         break;
     }
-    fv.steady[vi] = sr;
+    if (!w0) return;
+    if (!became_steady) fv.cache[vi].epoch = 0;
     fv.states[vd.sampler_state] = ss;
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
         if (j < vd.n_stages) *(StageRegs*)&fv.states[vd.stage_state[j]] = st[j];
-}
-
-// Control, phase 2: one thread per (voice, block >= 1).  Blocks at or after the voice's steady point copy the
-// template descriptor (the last block phase 1 computed) and re-derive the playhead-dependent fields in closed
-// form: loop: r_j = (base + j*frames) mod L (nodes/sampler.rs:445-484); one-shot: playhead + j*frames.
-__global__ __launch_bounds__(256) void k_voice_fill(FusedView fv, int K) {
-    int vi = blockIdx.x * blockDim.x + threadIdx.x;
-    int k = blockIdx.y + 1;
-    if (vi >= fv.n_voices || k >= K) return;
-    const SteadyRec sr = fv.steady[vi];
-    if (k < sr.from) return;
-    VoiceBlk d = fv.tmpl[vi];
-    if (sr.mode != 0 && d.sample >= 0) {
-        const uint64_t j = (uint64_t)(k - sr.from);
-        const uint32_t frames = (uint32_t)fv.frames;
-        d.flags &= ~(VB_WRAP | VB_TAIL_ZERO | VB_SIMPLE);
-        if (sr.mode == 1) {
-            uint64_t r = (sr.base + j * (uint64_t)frames) % sr.len;
-            uint64_t left = sr.len - r;
-            d.off0 = sr.start + r;
-            d.off1 = sr.start;
-            d.n1 = left < (uint64_t)frames ? (uint32_t)left : frames;
-            if (left < (uint64_t)frames) d.flags |= VB_WRAP;
-        } else {
-            d.off0 = sr.base + j * (uint64_t)frames;
-            d.n1 = frames;
-        }
-        if (!(d.flags & VB_SILENT)) {
-            const SampleDesc sd = fv.samples[d.sample];
-            blk_set_source(d, sd);
-        }
-    }
-    fv.blks[(size_t)k * fv.n_voices + vi] = d;
 }
 
 // Leaf kernel: one wave per (leaf SumNode, block).  For each port in order: fetch the voice's source frames,
@@ -1010,23 +1159,36 @@ __device__ __forceinline__ float readlane_f(float x, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
 }
 
+#ifndef LEAF_U
 #define LEAF_U 4  // voices whose source loads are in flight together (2*LEAF_U dwordx4 per lane)
+#endif
+#ifndef LEAF_NT
+#define LEAF_NT 1  // non-temporal source loads: every source byte is read exactly once (+12 % measured)
+#endif
+#ifndef LEAF_WPB
+#define LEAF_WPB 4  // waves (leaf, block work items) per workgroup
+#endif
 // the pointers come out of v_readlane as integers: tell the compiler they are GLOBAL (global_load, not flat_load)
 typedef const v4f_u __attribute__((address_space(1)))* gv4p;
-__device__ __forceinline__ v4f gload4(const float* p) { return *(gv4p)(uint64_t)p; }
+__device__ __forceinline__ v4f gload4(const float* p) {
+#if LEAF_NT
+    return __builtin_nontemporal_load((gv4p)(uint64_t)p);
+#else
+    return *(gv4p)(uint64_t)p;
+#endif
+}
 
+// lane p holds port p's VoiceRef + GainSet; every port is VB_SIMPLE (contiguous planar f32, constant gains)
 template <int NG>
-__device__ __forceinline__ void leaf_fast(const VoiceBlk& mine, int ports, int f0, v4f& accl, v4f& accr) {
-    // lane p holds voice p's descriptor; every voice is VB_SIMPLE (contiguous planar f32, constant gains)
+__device__ __forceinline__ void leaf_fast(const float* my_l, const float* my_r, const GainSet& my_g, int ports, int f0,
+                                          v4f& accl, v4f& accr) {
     for (int p0 = 0; p0 < ports; p0 += LEAF_U) {
         v4f xl[LEAF_U], xr[LEAF_U];
 #pragma unroll
         for (int u = 0; u < LEAF_U; ++u) {
             if (p0 + u < ports) {
-                const float* sl = readlane_ptr(mine.src_l, p0 + u);
-                const float* sr = readlane_ptr(mine.src_r, p0 + u);
-                xl[u] = gload4(sl + f0);
-                xr[u] = gload4(sr + f0);
+                xl[u] = gload4(readlane_ptr(my_l, p0 + u) + f0);
+                xr[u] = gload4(readlane_ptr(my_r, p0 + u) + f0);
             }
         }
 #pragma unroll
@@ -1034,9 +1196,9 @@ __device__ __forceinline__ void leaf_fast(const VoiceBlk& mine, int ports, int f
             if (p0 + u < ports) {
                 v4f a = xl[u], b = xr[u];
 #pragma unroll
-                for (int j = 0; j < NG; ++j) {
-                    a = a * readlane_f(mine.g[j][0], p0 + u);
-                    b = b * readlane_f(mine.g[j][1], p0 + u);
+                for (int j = 0; j < NG; ++j) {  // sampler.rs:530-533, volume.rs:123-126, pan: one rounding each
+                    a = a * readlane_f(my_g.g[j][0], p0 + u);
+                    b = b * readlane_f(my_g.g[j][1], p0 + u);
                 }
                 if (p0 + u == 0) {
                     accl = a;
@@ -1050,26 +1212,35 @@ __device__ __forceinline__ void leaf_fast(const VoiceBlk& mine, int ports, int f
     }
 }
 
-__global__ __launch_bounds__(WAVE* WPB) void k_leaf_sum(FusedView fv) {
-    const int leaf = blockIdx.x * WPB + (threadIdx.x >> 6);
+__global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv) {
+    const int leaf = blockIdx.x * LEAF_WPB + (threadIdx.x >> 6);
     if (leaf >= fv.n_leaves) return;
     const uint32_t k = blockIdx.y;
     const int lane = threadIdx.x & (WAVE - 1);
     const LeafDesc ld = fv.leaves[leaf];
     const int frames = fv.frames;
-    const VoiceBlk* blk = fv.blks + (size_t)k * fv.n_voices + ld.first_voice;
+    const size_t row = (size_t)k * fv.n_voices + ld.first_voice;
     float* bus = fv.bus + (size_t)k * fv.bus_blk_stride;
     uint8_t* bflags = fv.bus_flags + (size_t)k * fv.bus_flags_blk_stride;
     float* outl = bus + (size_t)ld.out_buf * fv.stride;
     float* outr = outl + fv.stride;
 
-    // lane p loads the descriptor of port p (ports <= 32); in_silence_mask: both channels share one flag
-    VoiceBlk mine;
-    mine.flags = VB_SILENT;
-    if (lane < ld.ports) mine = blk[lane];
+    // lane p loads the compact record of port p (ports <= 32); in_silence_mask: both channels share one flag
+    VoiceRef ref;
+    ref.src_l = nullptr;
+    ref.r_delta = 0;
+    ref.flags_gset = VB_SILENT;
+    if (lane < ld.ports) ref = fv.refs[(size_t)(ld.first_voice + lane) * fv.refs_stride + k];
+    const uint32_t my_flags = ref.flags_gset & 0xffu;
+    GainSet my_g;
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES; ++j) my_g.g[j][0] = my_g.g[j][1] = 1.0f;
+    if (my_flags & VB_SIMPLE) my_g = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + (ref.flags_gset >> 8)];
+    const float* my_l = ref.src_l;
+    const float* my_r = ref.src_l + ref.r_delta;
     const uint64_t lanes_in = mask_all_silent_bits(ld.ports);
-    const uint64_t silent_ports = __ballot((mine.flags & VB_SILENT) != 0) & lanes_in;
-    const uint64_t simple_ports = __ballot((mine.flags & VB_SIMPLE) != 0) & lanes_in;
+    const uint64_t silent_ports = __ballot((my_flags & VB_SILENT) != 0) & lanes_in;
+    const uint64_t simple_ports = __ballot((my_flags & VB_SIMPLE) != 0) & lanes_in;
     const bool all_silent = silent_ports == lanes_in;
     const bool masked = !(ld.ports == 2 || ld.ports == 3 || ld.ports == 4);  // sum.rs:67-133 (Q13)
     const bool fast = simple_ports == lanes_in && (frames & 3) == 0;
@@ -1078,18 +1249,29 @@ __global__ __launch_bounds__(WAVE* WPB) void k_leaf_sum(FusedView fv) {
         v4f accl = splat(0.f), accr = splat(0.f);
         if (fast) {
             switch (fv.n_gain_stages) {
-                case 1: leaf_fast<1>(mine, ld.ports, f0, accl, accr); break;
-                case 2: leaf_fast<2>(mine, ld.ports, f0, accl, accr); break;
-                case 3: leaf_fast<3>(mine, ld.ports, f0, accl, accr); break;
-                default: leaf_fast<4>(mine, ld.ports, f0, accl, accr); break;
+                case 1: leaf_fast<1>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                case 2: leaf_fast<2>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                case 3: leaf_fast<3>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                default: leaf_fast<4>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
             }
         } else if (!all_silent) {
             for (int p = 0; p < ld.ports; ++p) {
                 const bool psil = (silent_ports >> p) & 1ull;
                 v4f xl = splat(0.f), xr = splat(0.f);  // a silent chain's buffers hold cleared zeros
                 if (!psil) {
-                    const VoiceBlk d = blk[p];
-                    voice_eval(fv, d, k, ld.first_voice + p, f0, frames, xl, xr);
+                    if ((simple_ports >> p) & 1ull) {  // VB_SIMPLE implies frames % 4 == 0
+                        xl = gload4(readlane_ptr(my_l, p) + f0);
+                        xr = gload4(readlane_ptr(my_r, p) + f0);
+#pragma unroll
+                        for (int j = 0; j < FW_MAX_STAGES; ++j) {
+                            if (j >= fv.n_gain_stages) break;
+                            xl = xl * readlane_f(my_g.g[j][0], p);
+                            xr = xr * readlane_f(my_g.g[j][1], p);
+                        }
+                    } else {
+                        const VoiceBlk d = fv.blks[row + p];
+                        voice_eval(fv, d, k, ld.first_voice + p, f0, frames, xl, xr);
+                    }
                 }
                 if (p == 0) {  // sum.rs:117 copy_from_slice(port 0) — also when silent; 2/3/4-port: in1
                     accl = xl;
@@ -1210,19 +1392,13 @@ int launch_get_flags(hipStream_t s, const uint8_t* flags, const int* d_bufs, int
 }
 int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0) {
     if (fv.n_voices <= 0) return 0;
-    hipLaunchKernelGGL(k_voice_control, dim3((fv.n_voices + 63) / 64), dim3(64), 0, s, fv, K, cmd_block0);
-    return (int)hipGetLastError();
-}
-int launch_voice_fill(hipStream_t s, const FusedView& fv, int K) {
-    if (fv.n_voices <= 0 || K <= 1) return 0;
-    dim3 grid((fv.n_voices + 255) / 256, K - 1);
-    hipLaunchKernelGGL(k_voice_fill, grid, dim3(256), 0, s, fv, K);
+    hipLaunchKernelGGL(k_voice_control, dim3((fv.n_voices + 3) / 4), dim3(256), 0, s, fv, K, cmd_block0);
     return (int)hipGetLastError();
 }
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
     if (fv.n_leaves <= 0) return 0;
-    dim3 grid((fv.n_leaves + WPB - 1) / WPB, K);
-    hipLaunchKernelGGL(k_leaf_sum, grid, dim3(WAVE * WPB), 0, s, fv);
+    dim3 grid((fv.n_leaves + LEAF_WPB - 1) / LEAF_WPB, K);
+    hipLaunchKernelGGL(k_leaf_sum, grid, dim3(WAVE * LEAF_WPB), 0, s, fv);
     return (int)hipGetLastError();
 }
 

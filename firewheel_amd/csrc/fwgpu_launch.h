@@ -32,9 +32,12 @@ struct FusedView {
     const LeafDesc* leaves;
     NodeState* states;
     const SampleDesc* samples;
-    VoiceBlk* blks;   // [K][n_voices]
-    SteadyRec* steady;  // [n_voices]
-    VoiceBlk* tmpl;     // [n_voices] steady-state descriptor template
+    VoiceRef* refs;   // [n_voices][refs_stride], refs_stride = max blocks per call
+    int refs_stride;
+    GainSet* gsets;   // [n_voices][FW_GSETS], valid for the current call
+    VoiceCache* cache;  // [n_voices]
+    uint32_t epoch;     // >= 1
+    VoiceBlk* blks;   // [K][n_voices], written only for blocks that are neither silent nor VB_SIMPLE
     int n_gain_stages;  // 1 (sampler gain) + longest chain in the plan
     float* ramps;     // [K][n_voices][ramp_slots][stride], slot = 2*stage + channel
     int ramp_slots;
@@ -61,7 +64,6 @@ int launch_graph_out(hipStream_t s, const float* pool, const uint8_t* flags, int
 int launch_set_flags(hipStream_t s, uint8_t* flags, const int* d_bufs, int n, uint64_t mask);
 int launch_get_flags(hipStream_t s, const uint8_t* flags, const int* d_bufs, int n, uint64_t* d_mask);
 int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0);
-int launch_voice_fill(hipStream_t s, const FusedView& fv, int K);
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K);
 
 // host-side mirror of the StateInit record consumed by k_scatter_states

@@ -106,14 +106,29 @@ struct VoiceBlk {
 };
 static_assert(sizeof(VoiceBlk) == 80, "VoiceBlk layout");
 
-// per voice: from which block of the current call the descriptors follow the closed form (k_voice_fill)
-struct SteadyRec {
-    int from;        // first block filled by k_voice_fill (K = none)
-    int mode;        // 0 = copy the template, 1 = looping playhead, 2 = one-shot playhead
-    uint64_t base;   // mode 1: loop offset at block `from`; mode 2: playhead at block `from`
-    uint64_t start;  // loop start
-    uint64_t len;    // loop length
+// Compact per (block, voice) record (16 B): all the leaf kernel needs for silent and VB_SIMPLE blocks.  Only
+// blocks that are neither (ramps, loop wrap, one-shot tail, non-planar-f32 sources) also get a full VoiceBlk.
+struct VoiceRef {
+    const float* src_l;  // VB_SIMPLE: frame 0 of channel 0
+    uint32_t r_delta;    // VB_SIMPLE: channel-1 offset in floats (0 for a mono sample)
+    uint32_t flags_gset; // bits 0..7 VB_* flags, bits 8..15 gain-set index
 };
+static_assert(sizeof(VoiceRef) == 16, "VoiceRef layout");
+#define FW_GSETS 4  // distinct constant-gain sets a voice may use inside one call before falling back to VoiceBlk
+struct GainSet {
+    float g[FW_MAX_STAGES][2];
+};
+
+// Per voice, across calls: "this voice ended the last call steady" + the descriptor its blocks share.
+// Valid only while epoch == FusedView::epoch (the host bumps it on every plan install / sample-table change).
+struct VoiceCache {
+    uint32_t epoch;
+    int mode;
+    uint32_t flags;
+    int sample;
+    GainSet g;
+};
+static_assert(sizeof(VoiceCache) == 48, "VoiceCache layout");
 
 struct LeafDesc {  // a SumNode whose ports are all voice chains (nodes/sum.rs)
     int first_voice;

@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--cpu-secs", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--bus-reduce", choices=["allreduce", "ordered"], default="allreduce",
+                    help="N>1: RCCL all-reduce (named path) or all-gather + rank-ordered sum (bit-exact)")
     args = ap.parse_args()
 
     import torch
@@ -132,6 +134,7 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     import firewheel_amd as fa
+    from firewheel_amd import shard
 
     V, B, K = args.voices, args.block, args.blocks_per_step
     stream = torch.cuda.current_stream().cuda_stream
@@ -139,7 +142,7 @@ def main():
     cx.set_max_batch(K)
     # synthetic sources, generated in HBM: uniform(-1,1) f32, seed offset by global voice id
     g = torch.Generator(device="cuda")
-    g.manual_seed(0xF1EE0000 + rank)
+    g.manual_seed(shard.voice_seed(rank * V))  # stream keyed by the shard's first GLOBAL voice id
     src = torch.empty((V, 2, args.src_frames), dtype=torch.float32, device="cuda")
     src.uniform_(-1.0, 1.0, generator=g)
     build_bank(cx, fa, V, args.radix, src, args.src_frames, seed=rank)
@@ -148,8 +151,11 @@ def main():
 
     def step():
         cx.process_blocks_device(K, out.data_ptr(), 2)
-        if dist is not None:
-            dist.all_reduce(out)  # the mix bus: one RCCL all-reduce per step (K x 2 KiB)
+        if dist is not None:  # the mix bus: one collective per step over K x 2 x block f32 (K x 2 KiB)
+            if args.bus_reduce == "allreduce":
+                shard.reduce_bus_allreduce(out, dist)
+            else:
+                shard.reduce_bus_ordered(out, dist)
 
     for _ in range(args.warmup):
         step()
@@ -184,9 +190,20 @@ def main():
         if leaf_n:
             avg_s = leaf_ms / leaf_n / 1e3
             ach = alg_bytes / avg_s / 1e9
+            # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+            # runs, gfx950 FETCH_SIZE x2 correction) — only quoted when it was collected on this exact workload
+            traffic, traffic_src = None, None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                w = pm["workload"]
+                if (w["voices"], w["block"], w["blocks_per_step"]) == (V, B, K):
+                    traffic = pm["k_leaf_sum"]["traffic_bytes"]
+                    traffic_src = "profiles/r01_pmc_hbm_traffic.json"
+            except Exception:
+                pass
             roofline = {
                 "bound": "hbm", "kernel": "k_leaf_sum", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_s * 1e6, "launches": leaf_n,
                 "other_kernels_us_per_step": {"k_voice_control": ctl_ms / max(ctl_n, 1) * 1e3,
                                               "upper_sums+graph_out": up_ms / max(up_n, 1) * 1e3},

@@ -1,0 +1,44 @@
+"""Voice sharding + mix-bus reduction for multi-GPU runs (BASELINE config 5).
+
+Voices are independent until the sum tree, so the shard unit is a contiguous voice range per rank; each rank
+owns its voices' samples, node state and sub-tree and produces one stereo partial bus per block.  The only
+exchange step is the top-level sum of the R partial buses — in the reference that is one SumNode with R
+stereo ports (nodes/sum.rs:111-133, sequential in port order).  Two reductions are provided:
+
+* `reduce_bus_allreduce`  — one `all_reduce(SUM)` (RCCL ring/tree order: equal to the reference up to f32
+  re-association; exact for 2 ranks because a+b is commutative);
+* `reduce_bus_ordered`    — `all_gather` + accumulation in rank order: bit-identical to the reference's R-port
+  SumNode on every rank.
+Both work on any torch tensor/device, which is how the world_size-2 gloo test exercises them on CPU.
+"""
+
+
+def voice_range(rank, world, total_voices):
+    """contiguous split, first `total % world` ranks get one extra voice"""
+    q, r = divmod(total_voices, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def voice_seed(global_voice):
+    """seed of a voice's synthetic source: depends on the GLOBAL voice id only, so the inputs are the same for
+    every GPU count."""
+    return 0xF1EE0000 + int(global_voice)
+
+
+def reduce_bus_allreduce(bus, dist, group=None):
+    dist.all_reduce(bus, op=dist.ReduceOp.SUM, group=group)
+    return bus
+
+
+def reduce_bus_ordered(bus, dist, group=None):
+    import torch
+
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(bus) for _ in range(world)]
+    dist.all_gather(parts, bus, group=group)
+    acc = parts[0].clone()          # sum.rs:117 out = in0
+    for p in parts[1:]:             # sum.rs:119-131 out += in_p, port order
+        acc += p
+    bus.copy_(acc)
+    return bus

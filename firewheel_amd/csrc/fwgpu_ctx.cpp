@@ -83,6 +83,8 @@ struct fwgpu_ctx {
     // device state
     DevBuf d_states;
     size_t states_cap = 0;
+    DevBuf d_ext;  // per-node extended state (floats): biquad coefficients + history, delay rings
+    size_t ext_cap = 0, ext_used = 0;
     std::vector<SampleRec> samples;
     DevBuf d_samples;
     bool samples_dirty = true;
@@ -176,6 +178,40 @@ Smoother make_smoother(float val, uint32_t sample_rate) {  // core/param/smoothe
     return s;
 }
 
+// SPEC biquad: RBJ cookbook, computed in f64 on the control side, normalised by a0, rounded to f32.
+void biquad_coefs(int type, float cutoff_hz, float q, uint32_t sample_rate, float co[5]) {
+    double fs = (double)sample_rate;
+    double f0 = fmin(fmax((double)cutoff_hz, 1.0), 0.49 * fs);
+    double Q = fmax((double)q, 1e-3);
+    double w0 = 2.0 * 3.14159265358979323846 * f0 / fs;
+    double cw = cos(w0), alpha = sin(w0) / (2.0 * Q);
+    double b0, b1, b2, a0 = 1.0 + alpha, a1 = -2.0 * cw, a2 = 1.0 - alpha;
+    if (type == 1) {  // high-pass
+        b0 = (1.0 + cw) * 0.5;
+        b1 = -(1.0 + cw);
+        b2 = (1.0 + cw) * 0.5;
+    } else if (type == 2) {  // band-pass, constant 0 dB peak gain
+        b0 = alpha;
+        b1 = 0.0;
+        b2 = -alpha;
+    } else {  // low-pass
+        b0 = (1.0 - cw) * 0.5;
+        b1 = 1.0 - cw;
+        b2 = (1.0 - cw) * 0.5;
+    }
+    co[0] = (float)(b0 / a0);
+    co[1] = (float)(b1 / a0);
+    co[2] = (float)(b2 / a0);
+    co[3] = (float)(a1 / a0);
+    co[4] = (float)(a2 / a0);
+}
+uint32_t delay_frames(float secs, uint32_t sample_rate) {
+    double d = round((double)secs * (double)sample_rate);
+    if (!(d >= 1.0)) d = 1.0;
+    if (d > 16777216.0) d = 16777216.0;
+    return (uint32_t)d;
+}
+
 // AudioNode constructors + activate(): the initial audio-half state of each node kind.
 NodeState make_state(int kind, const float* params, int n_params, uint32_t sample_rate) {
     auto p = [&](int i, float d) { return i < n_params ? params[i] : d; };
@@ -212,6 +248,24 @@ NodeState make_state(int kind, const float* params, int n_params, uint32_t sampl
             s.s0 = make_smoother(s.p0, sample_rate);
             s.s1 = make_smoother(s.p1, sample_rate);
             break;
+        case K_WIDTH:
+            s.p0 = fmaxf(p(0, 1.0f), 0.0f);
+            s.s0 = make_smoother(s.p0, sample_rate);
+            break;
+        case K_BIQUAD:  // coefficients go to the ext pool at activation; keep the ctor args for that
+            s.p0 = p(1, 1000.0f);  // cutoff
+            s.p1 = p(2, 0.70710678f);  // Q
+            s.enabled = (int)p(0, 0.0f);  // type
+            break;
+        case K_DELAY: {
+            float mix = fminf(fmaxf(p(2, 0.5f), 0.0f), 1.0f);
+            s.p0 = fminf(fmaxf(p(1, 0.0f), 0.0f), 0.999f);  // feedback
+            s.p1 = mix;
+            s.gain = 1.0f - mix;  // dry
+            s.loop_end = delay_frames(p(0, 0.1f), sample_rate);
+            s.playhead = 0;
+            break;
+        }
         default:
             break;
     }
@@ -425,12 +479,31 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         c->d_states = nb;
         c->states_cap = cap;
     }
-    // 2. activate new nodes (graph.rs:594-612): scatter their initial states
+    // 2. activate new nodes (graph.rs:594-612): scatter their initial states, carve their ext-pool slices
     {
         std::vector<StateInitHost> inits;
+        std::vector<std::pair<size_t, std::vector<float>>> ext_inits;  // (offset, initial floats)
+        size_t ext_need = c->ext_used;
         for (uint32_t slot : c->graph.nodes_to_activate) {
             HostNode& n = c->graph.nodes[slot];
             if (!n.alive || n.activated) continue;
+            uint32_t nch = n.n_in < n.n_out ? n.n_in : n.n_out;
+            size_t len = 0;
+            std::vector<float> head;
+            if (n.kind == K_BIQUAD) {
+                len = 5 + 4 * (size_t)nch;
+                head.resize(5);
+                biquad_coefs(n.init.enabled, n.init.p0, n.init.p1, c->sample_rate, head.data());
+            } else if (n.kind == K_DELAY) {
+                len = (size_t)nch * (size_t)n.init.loop_end;
+            }
+            if (len) {
+                n.init.ext_off = (uint32_t)ext_need;
+                n.init.ext_len = (uint32_t)len;
+                if (!head.empty()) ext_inits.emplace_back(ext_need, head);
+                ext_need += (len + 63) / 64 * 64;
+                if (ext_need > 0xffffffffull) return fail(c, FWGPU_ERR_INVALID, "ext state pool exceeds 2^32 floats");
+            }
             StateInitHost si;
             si.index = (int)slot;
             si.pad = 0;
@@ -439,6 +512,21 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
             n.activated = true;
         }
         c->graph.nodes_to_activate.clear();
+        if (ext_need > c->ext_cap) {
+            size_t cap = std::max<size_t>(ext_need * 2, 4096);
+            DevBuf nb;
+            HIPC(c, nb.ensure(cap * sizeof(float)));
+            HIPC(c, hipMemset(nb.p, 0, cap * sizeof(float)));
+            if (c->d_ext.p && c->ext_used)
+                HIPC(c, hipMemcpy(nb.p, c->d_ext.p, c->ext_used * sizeof(float), hipMemcpyDeviceToDevice));
+            c->d_ext.release();
+            c->d_ext = nb;
+            c->ext_cap = cap;
+        }
+        c->ext_used = ext_need;
+        for (auto& ei : ext_inits)
+            HIPC(c, hipMemcpy(c->d_ext.as<float>() + ei.first, ei.second.data(), ei.second.size() * sizeof(float),
+                              hipMemcpyHostToDevice));
         if (!inits.empty()) {
             DevBuf tmp;
             int rc = upload(c, tmp, inits.data(), inits.size() * sizeof(StateInitHost));
@@ -631,6 +719,7 @@ DevView generic_view(fwgpu_ctx* c, int frames) {
     v.out_buf = c->d_out_buf.as<int>();
     v.states = c->d_states.as<NodeState>();
     v.samples = c->d_samples.as<SampleDesc>();
+    v.ext = c->d_ext.as<float>();
     v.pool = c->d_pool.as<float>();
     v.flags = c->d_flags.as<uint8_t>();
     v.pool_blk_stride = 0;
@@ -701,6 +790,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         v.out_buf = c->d_up_out.as<int>();
         v.states = c->d_states.as<NodeState>();
         v.samples = c->d_samples.as<SampleDesc>();
+        v.ext = c->d_ext.as<float>();
         v.pool = fv.bus;
         v.flags = fv.bus_flags;
         v.pool_blk_stride = fv.bus_blk_stride;
@@ -831,7 +921,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (SampleRec& s : c->samples)
         if (s.alive && s.owned && s.d_data) (void)hipFree(s.d_data);
-    DevBuf* bufs[] = {&c->d_states, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
+    DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
                       &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
                       &c->d_bus, &c->d_bus_flags, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
                       &c->d_root_bufs, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
@@ -854,7 +944,7 @@ int64_t fwgpu_graph_in_node(fwgpu_ctx* c) { return c->graph.id_of(c->graph.graph
 int64_t fwgpu_graph_out_node(fwgpu_ctx* c) { return c->graph.id_of(c->graph.graph_out_slot); }
 
 int64_t fwgpu_add_node(fwgpu_ctx* c, int kind, uint32_t n_in, uint32_t n_out, const float* params, int n_params) {
-    if (kind < 0 || kind > K_PAN) return fail(c, FWGPU_ERR_INVALID, "unsupported node kind");
+    if (kind < 0 || kind > K_DELAY) return fail(c, FWGPU_ERR_INVALID, "unsupported node kind");
     if (n_in > 64 || n_out > 64) return fail(c, FWGPU_ERR_INVALID, "a node has at most 64 ports per side (core/node.rs:62,69)");
     NodeState st = make_state(kind, params, n_params, c->sample_rate);
     return c->graph.add_node(kind, n_in, n_out, st);
@@ -1028,6 +1118,44 @@ int fwgpu_node_set_param(fwgpu_ctx* c, int64_t node, int param, float value, uin
             if (rc) return rc;
             m.type = CMD_SET_P1;
             m.f0 = gr;
+            return push_cmd(c, node, -1, m, false);
+        }
+        case K_WIDTH:
+            if (param != 0) return fail(c, FWGPU_ERR_INVALID, "unknown param");
+            m.type = CMD_SET_P0;
+            m.f0 = fmaxf(value, 0.0f);
+            return push_cmd(c, node, -1, m, false);
+        case K_BIQUAD: {  // param 1 = cutoff_hz, 2 = Q: recompute the coefficients on the control side
+            if (param != 1 && param != 2) return fail(c, FWGPU_ERR_INVALID, "unknown param");
+            if (param == 1) n->init.p0 = value;
+            else n->init.p1 = value;
+            float co[5];
+            biquad_coefs(n->init.enabled, n->init.p0, n->init.p1, c->sample_rate, co);
+            m.type = CMD_SET_COEFS;
+            m.f0 = co[0];
+            memcpy(&m.i0, &co[1], 4);
+            memcpy(&m.i1, &co[2], 4);
+            uint32_t lo, hi;
+            memcpy(&lo, &co[3], 4);
+            memcpy(&hi, &co[4], 4);
+            uint64_t u = ((uint64_t)hi << 32) | lo;
+            memcpy(&m.d0, &u, 8);
+            return push_cmd(c, node, -1, m, false);
+        }
+        case K_DELAY: {  // param 1 = feedback, 2 = mix (the delay time is fixed at construction)
+            if (param == 1) {
+                m.type = CMD_SET_P0;
+                m.f0 = fminf(fmaxf(value, 0.0f), 0.999f);
+                return push_cmd(c, node, -1, m, false);
+            }
+            if (param != 2) return fail(c, FWGPU_ERR_INVALID, "unknown param");
+            float mix = fminf(fmaxf(value, 0.0f), 1.0f);
+            m.type = CMD_SET_P1;
+            m.f0 = mix;
+            int rc = push_cmd(c, node, -1, m, false);
+            if (rc) return rc;
+            m.type = CMD_SET_GAIN;
+            m.f0 = 1.0f - mix;
             return push_cmd(c, node, -1, m, false);
         }
         default:

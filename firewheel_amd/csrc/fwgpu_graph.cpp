@@ -214,6 +214,19 @@ bool check_activation(int kind, uint32_t n_in, uint32_t n_out, std::string& err)
                 return false;
             }
             return true;
+        case K_WIDTH:
+            if (n_in != 2 || n_out != 2) {
+                err = "StereoWidthNode needs exactly 2 inputs and 2 outputs.";
+                return false;
+            }
+            return true;
+        case K_BIQUAD:
+        case K_DELAY:
+            if (n_in != n_out || n_in == 0) {
+                err = "Biquad/Delay nodes need as many outputs as inputs (>= 1).";
+                return false;
+            }
+            return true;
         case K_MONO_TO_STEREO:
             if (n_in < 1 || n_out < 2) {
                 err = "MonoToStereoNode needs 1 input and 2 outputs.";

@@ -121,7 +121,7 @@ __device__ __forceinline__ uint64_t sat_round_u64(double x) {  // `(x).round() a
 // Apply every queued message for (state_idx, block) in order.  cmds are sorted by (state, block, seq).
 // nodes/sampler.rs:331-414 (ring drained at the top of process()), volume.rs:92 (atomic load per block).
 __device__ inline void apply_cmds(NodeState& s, int state_idx, uint32_t block, const Cmd* cmds, int n_cmds,
-                                  const SampleDesc* samples) {
+                                  const SampleDesc* samples, float* ext = nullptr, bool ext_write = false) {
     if (n_cmds == 0) return;
     int lo = 0, hi = n_cmds;  // lower bound of (state_idx, block)
     while (lo < hi) {
@@ -138,6 +138,18 @@ __device__ inline void apply_cmds(NodeState& s, int state_idx, uint32_t block, c
             case CMD_SET_P0: s.p0 = c.f0; break;
             case CMD_SET_P1: s.p1 = c.f0; break;
             case CMD_SET_ENABLED: s.enabled = c.i0; break;
+            case CMD_SET_GAIN: s.gain = c.f0; break;
+            case CMD_SET_COEFS:  // biquad coefficients live at the head of the node's ext slice
+                if (ext && ext_write) {
+                    float* co = ext + s.ext_off;
+                    co[0] = c.f0;
+                    co[1] = __int_as_float(c.i0);
+                    co[2] = __int_as_float(c.i1);
+                    unsigned long long u = (unsigned long long)__double_as_longlong(c.d0);
+                    co[3] = __int_as_float((int)(u & 0xffffffffull));
+                    co[4] = __int_as_float((int)(u >> 32));
+                }
+                break;
             case CMD_SMP_SET_SAMPLE:  // sampler.rs:333-364
                 s.sample = c.i0;
                 if (s.has_loop && s.sample >= 0 && s.full_range) {  // update_sample :265-277
@@ -306,10 +318,11 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
 
     NodeState s;
     const bool stateful = nd.kind == K_VOLUME || nd.kind == K_SAMPLER || nd.kind == K_BEEP || nd.kind == K_PAN ||
-                          nd.kind == K_HARD_CLIP;
+                          nd.kind == K_HARD_CLIP || nd.kind == K_WIDTH || nd.kind == K_BIQUAD || nd.kind == K_DELAY;
     if (stateful) {
         s = v.states[nd.state];
-        apply_cmds(s, nd.state, cmd_block, v.cmds, v.n_cmds, v.samples);
+        apply_cmds(s, nd.state, cmd_block, v.cmds, v.n_cmds, v.samples, v.ext, lane == 0);
+        if (nd.kind == K_BIQUAD && v.n_cmds) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // lane 0's coefficient stores
     }
 
     switch (nd.kind) {
@@ -558,6 +571,86 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             }
             break;
         }
+        case K_WIDTH: {  // SPEC: mid/side width, one smoothed parameter
+            if (mask_all(in_mask, nd.n_in)) {
+                smoother_reset(s.s0, s.p0);
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            GainRun run = smoother_begin(s.s0, s.p0, frames);
+            for (int base = 0; base < frames; base += 256) {
+                int n = frames - base < 256 ? frames - base : 256;
+                v4f w = gain_chunk(run, n, lane);
+                int f0 = base + lane * 4;
+                if (f0 >= frames) continue;
+                v4f l = *(const v4f*)(io.in(0) + f0);
+                v4f r = *(const v4f*)(io.in(1) + f0);
+                v4f m = (l + r) * 0.5f;
+                v4f sd = ((l - r) * 0.5f) * w;
+                *(v4f*)(io.out(0) + f0) = m + sd;
+                *(v4f*)(io.out(1) + f0) = m - sd;
+            }
+            if (run.ramp) s.s0.last = run.prev;
+            break;
+        }
+
+        case K_BIQUAD: {  // SPEC: RBJ biquad, Direct Form I, f32 state, unfused left-to-right evaluation.
+            // Serial in time: lane c runs channel c (the generic executor's coverage path).
+            float* ext = v.ext + s.ext_off;
+            const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
+            if (lane < nch) {
+                const float b0 = ext[0], b1 = ext[1], b2 = ext[2], a1 = ext[3], a2 = ext[4];
+                float* st = ext + 5 + 4 * lane;
+                float x1 = st[0], x2 = st[1], y1 = st[2], y2 = st[3];
+                const float* in = io.in(lane);
+                float* out = io.out(lane);
+                for (int i = 0; i < frames; ++i) {
+                    float x = in[i];
+                    float acc = b0 * x;
+                    acc = acc + (b1 * x1);
+                    acc = acc + (b2 * x2);
+                    acc = acc - (a1 * y1);
+                    acc = acc - (a2 * y2);
+                    x2 = x1;
+                    x1 = x;
+                    y2 = y1;
+                    y1 = acc;
+                    out[i] = acc;
+                }
+                st[0] = x1;
+                st[1] = x2;
+                st[2] = y1;
+                st[3] = y2;
+            }
+            break;
+        }
+
+        case K_DELAY: {  // SPEC: integer-sample delay line with feedback, ring per channel in the ext pool
+            const uint32_t D = (uint32_t)s.loop_end;
+            const uint32_t pos = (uint32_t)s.playhead;
+            const float fb = s.p0, mix = s.p1, dry = s.gain;
+            const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
+            const uint32_t chunk = D < 64u ? D : 64u;  // frames inside one chunk touch distinct ring slots
+            for (int c = 0; c < nch; ++c) {
+                float* ring = v.ext + s.ext_off + (size_t)c * D;
+                const float* in = io.in(c);
+                float* out = io.out(c);
+                for (uint32_t base = 0; base < (uint32_t)frames; base += chunk) {
+                    uint32_t i = base + (uint32_t)lane;
+                    if ((uint32_t)lane < chunk && i < (uint32_t)frames) {
+                        uint32_t slot = (pos + i) % D;
+                        float x = in[i];
+                        float d = ring[slot];
+                        ring[slot] = x + (d * fb);
+                        out[i] = (x * dry) + (d * mix);
+                    }
+                    if (D < (uint32_t)frames) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // next chunk re-reads these slots
+                }
+            }
+            s.playhead = (uint64_t)((pos + (uint32_t)frames) % D);
+            break;
+        }
+
         default: break;
     }
 

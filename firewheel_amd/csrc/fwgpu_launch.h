@@ -17,6 +17,7 @@ struct DevView {
     const int* out_buf;
     NodeState* states;
     const SampleDesc* samples;
+    float* ext;  // per-node extended state (biquad coefficients + history, delay rings)
     float* pool;
     uint8_t* flags;
     size_t pool_blk_stride;

@@ -36,7 +36,12 @@ struct NodeState {
     float phasor, phasor_inc, gain;
     int enabled;
     uint32_t sample_rate;
-    int pad[3];
+    // SPEC nodes with per-channel state: offset/length (floats) of this node's slice of the ext pool
+    //   BIQUAD: ext = [b0 b1 b2 a1 a2][x1 x2 y1 y2] x channels      DELAY: ext = ring[channels][D]
+    //   DELAY also uses p0 = feedback, p1 = mix, gain = dry (1-mix), playhead = ring position, loop_end = D
+    uint32_t ext_off;
+    uint32_t ext_len;
+    int pad[1];
 };
 static_assert(sizeof(NodeState) == 128, "NodeState layout");
 
@@ -59,7 +64,8 @@ struct NodeDesc {
 
 // control -> audio messages (nodes/sampler.rs:21-28 + the atomics), sorted by (state, block, seq).
 enum : int {
-    CMD_SET_P0 = 0, CMD_SET_P1 = 1, CMD_SET_ENABLED = 2,
+    CMD_SET_P0 = 0, CMD_SET_P1 = 1, CMD_SET_ENABLED = 2, CMD_SET_GAIN = 3,
+    CMD_SET_COEFS = 4,  // biquad: f0,i0,i1 (as float bits) = b0,b1,b2; d0 bits = (a1,a2)
     CMD_SMP_SET_SAMPLE = 10, CMD_SMP_PLAY = 11, CMD_SMP_PAUSE = 12, CMD_SMP_STOP = 13,
     CMD_SMP_SET_PLAYHEAD = 14, CMD_SMP_SET_LOOP = 15,
 };

@@ -596,7 +596,117 @@ struct StereoPanProcessor : AudioNodeProcessor {
     }
 };
 
+// ---- SPEC: stereo width (mid/side), one smoothed parameter w >= 0 (1 = unchanged, 0 = mono)
+struct StereoWidthProcessor : AudioNodeProcessor {
+    std::shared_ptr<float> w_t;
+    ParamSmoother sw;
+    StereoWidthProcessor(std::shared_ptr<float> w, uint32_t sr, size_t mbf) : w_t(w), sw(*w, sr, mbf) {}
+    void process(size_t frames, const float* const* inputs, size_t n_in, float* const* outputs, size_t n_out,
+                 ProcInfo info) override {
+        float w = *w_t;
+        if (info.in_silence_mask.all_channels_silent(n_in)) {
+            sw.reset(w);
+            clear_all_outputs(frames, outputs, n_out, info.out_silence_mask);
+            return;
+        }
+        SmoothedOutput g = sw.set_and_process(w, frames);
+        for (size_t i = 0; i < frames; ++i) {
+            float l = inputs[0][i], r = inputs[1][i];
+            float m = (l + r) * 0.5f;
+            float sd = ((l - r) * 0.5f) * g.values[i];
+            outputs[0][i] = m + sd;
+            outputs[1][i] = m - sd;
+        }
+    }
+};
+
+// ---- SPEC: RBJ biquad, Direct Form I, f32 state; y = b0 x + b1 x1 + b2 x2 - a1 y1 - a2 y2, each product and
+// each sum rounded separately, left to right.  Coefficients are shared with the control half (5 floats).
+struct BiquadProcessor : AudioNodeProcessor {
+    std::shared_ptr<std::vector<float>> co;
+    std::vector<float> st;  // [ch][x1 x2 y1 y2]
+    BiquadProcessor(std::shared_ptr<std::vector<float>> c, size_t nch) : co(c), st(4 * nch, 0.0f) {}
+    void process(size_t frames, const float* const* inputs, size_t n_in, float* const* outputs, size_t n_out,
+                 ProcInfo) override {
+        size_t nch = std::min(n_in, n_out);
+        const float b0 = (*co)[0], b1 = (*co)[1], b2 = (*co)[2], a1 = (*co)[3], a2 = (*co)[4];
+        for (size_t c = 0; c < nch; ++c) {
+            float x1 = st[4 * c], x2 = st[4 * c + 1], y1 = st[4 * c + 2], y2 = st[4 * c + 3];
+            for (size_t i = 0; i < frames; ++i) {
+                float x = inputs[c][i];
+                float acc = b0 * x;
+                acc = acc + (b1 * x1);
+                acc = acc + (b2 * x2);
+                acc = acc - (a1 * y1);
+                acc = acc - (a2 * y2);
+                x2 = x1;
+                x1 = x;
+                y2 = y1;
+                y1 = acc;
+                outputs[c][i] = acc;
+            }
+            st[4 * c] = x1;
+            st[4 * c + 1] = x2;
+            st[4 * c + 2] = y1;
+            st[4 * c + 3] = y2;
+        }
+    }
+};
+
+// ---- SPEC: integer-sample delay with feedback: d = ring[pos]; ring[pos] = x + d*fb; out = x*dry + d*mix
+struct DelayProcessor : AudioNodeProcessor {
+    std::shared_ptr<float> fb, mix, dry;
+    uint32_t D, pos = 0;
+    std::vector<float> ring;  // [ch][D]
+    DelayProcessor(std::shared_ptr<float> f, std::shared_ptr<float> m, std::shared_ptr<float> d, uint32_t D_, size_t nch)
+        : fb(f), mix(m), dry(d), D(D_), ring((size_t)D_ * nch, 0.0f) {}
+    void process(size_t frames, const float* const* inputs, size_t n_in, float* const* outputs, size_t n_out,
+                 ProcInfo) override {
+        size_t nch = std::min(n_in, n_out);
+        const float f = *fb, m = *mix, dr = *dry;
+        for (size_t c = 0; c < nch; ++c) {
+            float* r = ring.data() + c * D;
+            uint32_t p = pos;
+            for (size_t i = 0; i < frames; ++i) {
+                float x = inputs[c][i];
+                float d = r[p];
+                r[p] = x + (d * f);
+                outputs[c][i] = (x * dr) + (d * m);
+                p = p + 1 == D ? 0 : p + 1;
+            }
+        }
+        pos = (uint32_t)((pos + frames) % D);
+    }
+};
+
 }  // namespace
+
+void biquad_coefs(int type, float cutoff_hz, float q, uint32_t sample_rate, float co[5]) {
+    double fs = (double)sample_rate;
+    double f0 = fmin(fmax((double)cutoff_hz, 1.0), 0.49 * fs);
+    double Q = fmax((double)q, 1e-3);
+    double w0 = 2.0 * 3.14159265358979323846 * f0 / fs;
+    double cw = cos(w0), alpha = sin(w0) / (2.0 * Q);
+    double b0, b1, b2, a0 = 1.0 + alpha, a1 = -2.0 * cw, a2 = 1.0 - alpha;
+    if (type == 1) {
+        b0 = (1.0 + cw) * 0.5;
+        b1 = -(1.0 + cw);
+        b2 = (1.0 + cw) * 0.5;
+    } else if (type == 2) {
+        b0 = alpha;
+        b1 = 0.0;
+        b2 = -alpha;
+    } else {
+        b0 = (1.0 - cw) * 0.5;
+        b1 = 1.0 - cw;
+        b2 = (1.0 - cw) * 0.5;
+    }
+    co[0] = (float)(b0 / a0);
+    co[1] = (float)(b1 / a0);
+    co[2] = (float)(b2 / a0);
+    co[3] = (float)(a1 / a0);
+    co[4] = (float)(a2 / a0);
+}
 
 void pan_to_gains(float pan, float* gl, float* gr) {
     float p = fminf(fmaxf(pan, -1.0f), 1.0f);
@@ -627,6 +737,9 @@ const char* AudioNode::debug_name() const {
         case KIND_MONO_TO_STEREO: return "mono_to_stereo";
         case KIND_STEREO_TO_MONO: return "stereo_to_mono";
         case KIND_STEREO_PAN: return "stereo_pan";
+        case KIND_STEREO_WIDTH: return "stereo_width";
+        case KIND_BIQUAD: return "biquad";
+        case KIND_DELAY: return "delay";
         default: return "unknown";
     }
 }
@@ -662,6 +775,21 @@ std::unique_ptr<AudioNode> make_node(int kind, const float* params, int n_params
             pan_to_gains(p(0, 0.0f), &gl, &gr);
             n->aux0 = std::make_shared<float>(gl);
             n->aux1 = std::make_shared<float>(gr);
+            break;
+        }
+        case KIND_STEREO_WIDTH:
+            n->aux0 = std::make_shared<float>(fmaxf(p(0, 1.0f), 0.0f));
+            break;
+        case KIND_BIQUAD:
+            n->spec_params = {p(0, 0.0f), p(1, 1000.0f), p(2, 0.70710678f)};
+            n->coefs = std::make_shared<std::vector<float>>(5, 0.0f);
+            break;
+        case KIND_DELAY: {
+            float mix = fminf(fmaxf(p(2, 0.5f), 0.0f), 1.0f);
+            n->spec_params = {p(0, 0.1f)};
+            n->raw_gain = std::make_shared<float>(fminf(fmaxf(p(1, 0.0f), 0.0f), 0.999f));  // feedback
+            n->aux0 = std::make_shared<float>(mix);
+            n->aux1 = std::make_shared<float>(1.0f - mix);
             break;
         }
         default:
@@ -710,6 +838,31 @@ std::unique_ptr<AudioNodeProcessor> AudioNode::activate(uint32_t sample_rate, si
             }
             return std::unique_ptr<AudioNodeProcessor>(
                 new StereoPanProcessor(aux0, aux1, sample_rate, max_block_frames));
+        case KIND_STEREO_WIDTH:
+            if (num_inputs != 2 || num_outputs != 2) {
+                err = "StereoWidthNode needs exactly 2 inputs and 2 outputs.";
+                return nullptr;
+            }
+            return std::unique_ptr<AudioNodeProcessor>(new StereoWidthProcessor(aux0, sample_rate, max_block_frames));
+        case KIND_BIQUAD: {
+            if (num_inputs != num_outputs || num_inputs == 0) {
+                err = "Biquad/Delay nodes need as many outputs as inputs (>= 1).";
+                return nullptr;
+            }
+            biquad_coefs((int)spec_params[0], spec_params[1], spec_params[2], sample_rate, coefs->data());
+            act_sample_rate = sample_rate;
+            return std::unique_ptr<AudioNodeProcessor>(new BiquadProcessor(coefs, num_inputs));
+        }
+        case KIND_DELAY: {
+            if (num_inputs != num_outputs || num_inputs == 0) {
+                err = "Biquad/Delay nodes need as many outputs as inputs (>= 1).";
+                return nullptr;
+            }
+            double d = round((double)spec_params[0] * (double)sample_rate);
+            if (!(d >= 1.0)) d = 1.0;
+            if (d > 16777216.0) d = 16777216.0;
+            return std::unique_ptr<AudioNodeProcessor>(new DelayProcessor(raw_gain, aux0, aux1, (uint32_t)d, num_inputs));
+        }
         default:
             err = "unknown node kind";
             return nullptr;
@@ -1227,6 +1380,25 @@ int fwo_set_param(void* c, int64_t node, int param, float value) {
             fwo::pan_to_gains(value, n->aux0.get(), n->aux1.get());
             return 0;
         }
+        case KIND_STEREO_WIDTH:
+            if (param != 0) return -2;
+            *n->aux0 = fmaxf(value, 0.0f);
+            return 0;
+        case KIND_BIQUAD:
+            if (param != 1 && param != 2) return -2;
+            n->spec_params[param] = value;
+            fwo::biquad_coefs((int)n->spec_params[0], n->spec_params[1], n->spec_params[2], n->act_sample_rate,
+                              n->coefs->data());
+            return 0;
+        case KIND_DELAY:
+            if (param == 1) {
+                *n->raw_gain = fminf(fmaxf(value, 0.0f), 0.999f);
+                return 0;
+            }
+            if (param != 2) return -2;
+            *n->aux0 = fminf(fmaxf(value, 0.0f), 1.0f);
+            *n->aux1 = 1.0f - *n->aux0;
+            return 0;
         default:
             return -2;
     }

@@ -89,6 +89,7 @@ float db_to_gain_clamped_neg_100_db(float db);
 float gain_to_db_clamped_neg_100_db(float amp);
 float percent_volume_to_raw_gain(float percent_volume);  // core/param/range.rs:32-35
 void pan_to_gains(float pan, float* gl, float* gr);      // SPEC (DESIGN.md spec nodes / pan)
+void biquad_coefs(int type, float cutoff_hz, float q, uint32_t sample_rate, float co[5]);  // SPEC (RBJ cookbook)
 
 SilenceMask deinterleave(float* const* channels, size_t n_channels, size_t ch_len,
                          const float* interleaved, size_t interleaved_len,
@@ -176,6 +177,8 @@ struct AudioNode {
     float freq_hz = 0, gain = 0;          // beep_test.rs:10-11
     float threshold_gain = 0;             // hard_clip.rs:4
     std::vector<float> spec_params;       // SPEC nodes creation params
+    std::shared_ptr<std::vector<float>> coefs;  // SPEC biquad: b0 b1 b2 a1 a2 shared with the processor
+    uint32_t act_sample_rate = 48000;
     std::shared_ptr<std::deque<SamplerMsg>> to_processor;  // sampler.rs:42 (rtrb cap 128)
     const char* debug_name() const;
     // activate: returns nullptr and sets err on failure (core/node.rs:12-18)

@@ -154,6 +154,15 @@ class Engine(object):
     def pan(self, pan):
         return self.add_node(STEREO_PAN, 2, 2, [pan])
 
+    def width(self, w):
+        return self.add_node(STEREO_WIDTH, 2, 2, [w])
+
+    def biquad(self, ftype, cutoff_hz, q=0.70710678, ch=2):
+        return self.add_node(BIQUAD, ch, ch, [float(ftype), cutoff_hz, q])
+
+    def delay(self, secs, feedback=0.0, mix=0.5, ch=2):
+        return self.add_node(DELAY, ch, ch, [secs, feedback, mix])
+
     def connect_stereo(self, src, dst, dst_port0=0, src_port0=0):
         self.connect(src, src_port0, dst, dst_port0)
         self.connect(src, src_port0 + 1, dst, dst_port0 + 1)

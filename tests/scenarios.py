@@ -237,3 +237,48 @@ def scenario_graph_inputs(e):
     e.set_param(vol, 0, 10.0)
     out2 = e.process_interleaved(frames, 2, inp=inp, n_in_ch=2)
     return np.concatenate([out, out2])
+
+
+def scenario_cfg3_chain(e, n_voices=12, blocks=10, radix=4, src_frames=3000):
+    """config-3 shape: V x (sampler -> biquad LPF -> delay -> gain) -> sum tree, plus a width node on
+    the bus.  SPEC nodes: runs on the generic executor."""
+    rng = np.random.default_rng(77)
+    ends, voices = [], []
+    for v in range(n_voices):
+        s = e.sampler(100.0)
+        bq = e.biquad(v % 3, float(rng.uniform(200, 8000)), 0.707 if v % 2 else 2.5)
+        dl = e.delay(float(rng.uniform(0.0002, 0.02)), feedback=0.0 if v % 3 == 0 else 0.4, mix=0.5)
+        vol = e.volume(float(rng.uniform(20, 100)))
+        e.connect_stereo(s, bq)
+        e.connect_stereo(bq, dl)
+        e.connect_stereo(dl, vol)
+        ends.append(vol)
+        voices.append(dict(sampler=s, biquad=bq, delay=dl, volume=vol))
+    level = ends
+    while True:
+        nxt = []
+        for i in range(0, len(level), radix):
+            grp = level[i:i + radix]
+            m = e.sum(len(grp))
+            for p, n in enumerate(grp):
+                e.connect_stereo(n, m, 2 * p)
+            nxt.append(m)
+        level = nxt
+        if len(level) == 1:
+            break
+    w = e.width(1.6)
+    e.connect_stereo(level[0], w)
+    e.connect_stereo(w, e.graph_out_node)
+    e.update()
+    for v, vc in enumerate(voices):
+        e.sampler_set_sample(vc["sampler"], e.new_sample(PLANAR_F32, 2, voice_source(900 + v, src_frames)))
+        e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        e.sampler_play(vc["sampler"])
+    out1 = e.process_blocks(blocks // 2)
+    e.set_param(w, 0, 0.3)                       # width ramps
+    e.set_param(voices[1]["biquad"], 1, 500.0)   # cutoff change -> new coefficients at the next block
+    e.set_param(voices[2]["delay"], 1, 0.7)      # feedback
+    e.set_param(voices[2]["delay"], 2, 0.9)      # mix
+    e.sampler_pause(voices[0]["sampler"])        # the filter/delay tails keep ringing on zeros
+    out2 = e.process_blocks(blocks - blocks // 2)
+    return np.concatenate([out1, out2])

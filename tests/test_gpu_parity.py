@@ -191,9 +191,10 @@ def run_case(name, **gpu_kw):
         "mixed_generic": scenarios.scenario_mixed_generic,
         "mixed_generic_nobeep": lambda e: scenarios.scenario_mixed_generic(e, use_beep=False),
         "graph_inputs": scenarios.scenario_graph_inputs,
+        "cfg3_chain": scenarios.scenario_cfg3_chain,
     }[name]
     mbf = {"steady_96x32": 256, "steady_40x4_i16": 64, "steady_9x3_u16": 128, "events_70": 256, "events_33_r2": 128,
-           "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64}[name]
+           "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64, "cfg3_chain": 128}[name]
     kw = dict(max_block_frames=mbf)
     if name == "graph_inputs":
         kw["num_graph_inputs"] = 3
@@ -232,6 +233,41 @@ def test_mixed_graph_generic_executor():
     out_o, out_g, g = run_case("mixed_generic_nobeep")
     assert g.cx.plan_kind() == 0
     assert_bits_equal(out_o, out_g, "mixed graph")
+
+
+def test_cfg3_chain_spec_nodes_bit_exact():
+    out_o, out_g, g = run_case("cfg3_chain")
+    assert g.cx.plan_kind() == 0
+    assert_bits_equal(out_o, out_g, "cfg3 chain (biquad + delay + width)")
+    gold = json.load(open(GOLDEN))
+    assert digest(out_g) == gold["cfg3_chain"]
+
+
+@pytest.mark.parametrize("ch", [1, 2, 5])
+def test_spec_nodes_node_level(ch):
+    from fwapi import BIQUAD, DELAY, STEREO_WIDTH
+
+    x = fwapi.xorshift_uniform(40 + ch, ch * 256).reshape(ch, 256)
+    for ftype in (0, 1, 2):
+        po, pg = pair(BIQUAD, ch, ch, [float(ftype), 1234.5, 1.3])
+        for b in range(4):
+            both(po, pg, 256, x, ch, what="biquad type %d block %d" % (ftype, b))
+        po[0].set_param(po[1], 1, 4000.0)
+        pg[0].set_param(pg[1], 1, 4000.0)
+        for b in range(3):
+            both(po, pg, 256, x * 0 if b == 2 else x, ch, what="biquad after cutoff change")
+    for secs, fb in ((0.02, 0.0), (0.001, 0.6), (7 / 48000.0, 0.9), (1 / 48000.0, 0.5)):   # D = 960, 48, 7, 1
+        po, pg = pair(DELAY, ch, ch, [secs, fb, 0.4])
+        for b in range(5):
+            both(po, pg, 256, x, ch, what="delay %g fb %g block %d" % (secs, fb, b))
+    if ch == 2:
+        po, pg = pair(STEREO_WIDTH, 2, 2, [1.5])
+        for mask in (0, 1, 3):
+            both(po, pg, 256, x, 2, in_mask=mask)
+        po[0].set_param(po[1], 0, 0.2)
+        pg[0].set_param(pg[1], 0, 0.2)
+        for b in range(30):
+            both(po, pg, 256, x, 2, what="width ramp %d" % b)
 
 
 def test_graph_inputs_and_partial_blocks():

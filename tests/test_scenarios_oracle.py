@@ -33,6 +33,7 @@ CASES = {
     "events_33_r2": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=128), 33, radix=2, src_frames=777),
     "mixed_generic": lambda: scenarios.scenario_mixed_generic(oracle(max_block_frames=256)),
     "mixed_generic_nobeep": lambda: scenarios.scenario_mixed_generic(oracle(max_block_frames=256), use_beep=False),
+    "cfg3_chain": lambda: scenarios.scenario_cfg3_chain(oracle(max_block_frames=128)),
     "graph_inputs": lambda: scenarios.scenario_graph_inputs(oracle(max_block_frames=64, num_graph_inputs=3)),
 }
 
@@ -53,3 +54,45 @@ def test_steady_bank_is_loop_periodic():
     frames = out.reshape(-1, 2)
     assert np.array_equal(frames[:1024], frames[1024:2048])
     assert np.array_equal(frames[:1024], frames[3072:4096])
+
+
+# ------------------------------------------------------------------ SPEC nodes: the f32 spec vs an f64 evaluation
+def test_biquad_spec_matches_f64_lfilter():
+    from scipy.signal import lfilter
+
+    L = fwapi.oracle_lib()
+    for ftype, fc, q in [(0, 1000.0, 0.707), (1, 300.0, 1.5), (2, 5000.0, 4.0), (0, 15000.0, 0.5)]:
+        e = fwapi.OracleEngine(max_block_frames=256)
+        n = e.biquad(ftype, fc, q, ch=1)
+        e.update()
+        x = fwapi.xorshift_uniform(31 + ftype, 2048)
+        y = np.concatenate([e.node_process(n, 256, [x[i:i + 256]], 1)[0][0] for i in range(0, 2048, 256)])
+        # RBJ cookbook in f64
+        w0 = 2 * np.pi * fc / 48000.0
+        cw, al = np.cos(w0), np.sin(w0) / (2 * q)
+        b = {0: [(1 - cw) / 2, 1 - cw, (1 - cw) / 2], 1: [(1 + cw) / 2, -(1 + cw), (1 + cw) / 2], 2: [al, 0, -al]}[ftype]
+        a = [1 + al, -2 * cw, 1 - al]
+        ref = lfilter(np.array(b) / a[0], np.array(a) / a[0], x.astype(np.float64))
+        # f32 DF1 vs f64: error grows with the pole radius; 2e-5 relative to the signal peak covers Q = 4
+        assert np.max(np.abs(y - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref))), (ftype, fc, q)
+
+
+def test_delay_and_width_spec_against_numpy():
+    e = fwapi.OracleEngine(max_block_frames=64)
+    d = e.delay(10.0 / 48000.0, feedback=0.5, mix=0.25, ch=1)   # D = 10 frames < block: in-block recurrence
+    w = e.width(0.0)
+    e.update()
+    x = fwapi.xorshift_uniform(5, 192)
+    y = np.concatenate([e.node_process(d, 64, [x[i:i + 64]], 1)[0][0] for i in range(0, 192, 64)])
+    ring = np.zeros(10, np.float32)
+    exp = np.empty(192, np.float32)
+    f32 = np.float32
+    for i in range(192):
+        dd = ring[i % 10]
+        ring[i % 10] = f32(x[i] + f32(dd * f32(0.5)))
+        exp[i] = f32(f32(x[i] * f32(0.75)) + f32(dd * f32(0.25)))
+    assert np.array_equal(y, exp)
+    st = fwapi.xorshift_uniform(6, 128).reshape(2, 64)
+    yw, _ = e.node_process(w, 64, st, 2)
+    mono = ((st[0] + st[1]).astype(f32) * f32(0.5)).astype(f32)
+    assert np.array_equal(yw[0], mono) and np.array_equal(yw[1], mono)    # width 0 = mono

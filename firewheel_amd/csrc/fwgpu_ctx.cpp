@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <functional>
 #include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -101,6 +102,15 @@ struct fwgpu_ctx {
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags;
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
     std::vector<int> up_level_off, up_level_cnt;
+
+    // FIR banks (generic executor): rows grouped by (level, impulse-response channel)
+    struct FirGroup {
+        int level, row_off, n_rows;
+        uint32_t h_off, T;
+    };
+    std::vector<FirGroup> fir_groups;
+    std::map<std::pair<int, int>, uint32_t> ir_cache;  // (sample id, channel) -> ext offset of h[T] as f32
+    DevBuf d_fir_rows, d_fir_partials;
 
     // messages
     std::vector<Cmd> cmds;
@@ -256,6 +266,9 @@ NodeState make_state(int kind, const float* params, int n_params, uint32_t sampl
             s.p0 = p(1, 1000.0f);  // cutoff
             s.p1 = p(2, 0.70710678f);  // Q
             s.enabled = (int)p(0, 0.0f);  // type
+            break;
+        case K_FIR:
+            s.sample = (int)p(0, -1.0f);  // impulse-response sample id; T and the ring are set at activation
             break;
         case K_DELAY: {
             float mix = fminf(fmaxf(p(2, 0.5f), 0.0f), 1.0f);
@@ -483,6 +496,7 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
     {
         std::vector<StateInitHost> inits;
         std::vector<std::pair<size_t, std::vector<float>>> ext_inits;  // (offset, initial floats)
+        std::vector<std::pair<int, int>> ir_requests;                  // impulse responses to convert to f32
         size_t ext_need = c->ext_used;
         for (uint32_t slot : c->graph.nodes_to_activate) {
             HostNode& n = c->graph.nodes[slot];
@@ -496,6 +510,22 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
                 biquad_coefs(n.init.enabled, n.init.p0, n.init.p1, c->sample_rate, head.data());
             } else if (n.kind == K_DELAY) {
                 len = (size_t)nch * (size_t)n.init.loop_end;
+            } else if (n.kind == K_FIR) {
+                int ir = n.init.sample;
+                if (ir < 0 || ir >= (int)c->samples.size() || !c->samples[ir].alive)
+                    return fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "FIR node: impulse-response sample was destroyed");
+                uint64_t T = c->samples[ir].desc.frames;
+                if (T == 0 || T > (1u << 24)) return fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "FIR node: 1 <= taps <= 2^24");
+                uint64_t R = T - 1 + c->mbf;
+                n.init.loop_start = T;
+                n.init.loop_end = R;
+                n.init.playhead = 0;
+                len = (size_t)nch * 2 * (size_t)R;
+                for (uint32_t ch = 0; ch < nch; ++ch) {
+                    auto key = std::make_pair(ir, (int)std::min<uint32_t>(ch, (uint32_t)c->samples[ir].desc.channels - 1));
+                    if (!c->ir_cache.count(key)) ir_requests.push_back(key);
+                    c->ir_cache.emplace(key, 0u);  // offset assigned below, once the pool layout is final
+                }
             }
             if (len) {
                 n.init.ext_off = (uint32_t)ext_need;
@@ -512,6 +542,12 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
             n.activated = true;
         }
         c->graph.nodes_to_activate.clear();
+        for (auto& key : ir_requests) {  // one f32 copy of each impulse-response channel
+            uint64_t T = c->samples[key.first].desc.frames;
+            c->ir_cache[key] = (uint32_t)ext_need;
+            ext_need += (T + 63) / 64 * 64;
+            if (ext_need > 0xffffffffull) return fail(c, FWGPU_ERR_INVALID, "ext state pool exceeds 2^32 floats");
+        }
         if (ext_need > c->ext_cap) {
             size_t cap = std::max<size_t>(ext_need * 2, 4096);
             DevBuf nb;
@@ -527,6 +563,15 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         for (auto& ei : ext_inits)
             HIPC(c, hipMemcpy(c->d_ext.as<float>() + ei.first, ei.second.data(), ei.second.size() * sizeof(float),
                               hipMemcpyHostToDevice));
+        if (!ir_requests.empty()) {
+            int rc = upload_sample_table(c);
+            if (rc) return rc;
+            for (auto& key : ir_requests)
+                LCHK(c, launch_ir_convert(c->stream, c->d_samples.as<SampleDesc>(), key.first, key.second,
+                                          c->d_ext.as<float>() + c->ir_cache[key],
+                                          (uint32_t)c->samples[key.first].desc.frames));
+            HIPC(c, hipStreamSynchronize(c->stream));
+        }
         if (!inits.empty()) {
             DevBuf tmp;
             int rc = upload(c, tmp, inits.data(), inits.size() * sizeof(StateInitHost));
@@ -582,6 +627,48 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
     if (gout_bufs.empty()) gout_bufs.push_back(0);
     if ((rc = upload(c, c->d_gin_bufs, gin_bufs.data(), gin_bufs.size() * sizeof(int)))) return rc;
     if ((rc = upload(c, c->d_gout_bufs, gout_bufs.data(), gout_bufs.size() * sizeof(int)))) return rc;
+    // 3b. FIR banks: one GEMM per (level, impulse-response channel)
+    {
+        std::map<std::tuple<int, uint32_t, uint32_t>, std::vector<FirRow>> groups;
+        for (int i = 0; i < N; ++i) {
+            const PlanNode& p = plan.nodes[i];
+            if (p.kind != K_FIR) continue;
+            const HostNode& hn = c->graph.nodes[p.slot];
+            int ir = hn.init.sample;
+            uint32_t T = (uint32_t)hn.init.loop_start;
+            int nch = std::min(p.n_in, p.n_out);
+            for (int ch = 0; ch < nch; ++ch) {
+                auto key = std::make_pair(ir, std::min(ch, c->samples[ir].desc.channels - 1));
+                FirRow r;
+                r.state = (int)p.slot;
+                r.ch = ch;
+                r.in_buf = p.in_buf[ch];
+                r.out_buf = p.out_buf[ch];
+                groups[std::make_tuple(p.level, c->ir_cache[key], T)].push_back(r);
+            }
+        }
+        std::vector<FirRow> flat_rows;
+        c->fir_groups.clear();
+        size_t partial_need = 0;
+        for (auto& g : groups) {
+            fwgpu_ctx::FirGroup fg;
+            fg.level = std::get<0>(g.first);
+            fg.h_off = std::get<1>(g.first);
+            fg.T = std::get<2>(g.first);
+            fg.row_off = (int)flat_rows.size();
+            fg.n_rows = (int)g.second.size();
+            flat_rows.insert(flat_rows.end(), g.second.begin(), g.second.end());
+            c->fir_groups.push_back(fg);
+            size_t W = (size_t)fg.T - 1 + c->mbf;
+            size_t segs = (W + FIR_SEG - 1) / FIR_SEG;
+            size_t need = segs * (size_t)((fg.n_rows + 31) / 32 * 32) * (size_t)((c->mbf + 255) / 256 * 256);
+            partial_need = std::max(partial_need, need);
+        }
+        if (!flat_rows.empty()) {
+            if ((rc = upload(c, c->d_fir_rows, flat_rows.data(), flat_rows.size() * sizeof(FirRow)))) return rc;
+            HIPC(c, c->d_fir_partials.ensure(partial_need * sizeof(float)));
+        }
+    }
     // 4. buffer pool: a new schedule starts from zeroed buffers (schedule.rs:202-203)
     size_t pool_bytes = (size_t)plan.num_buffers * c->stride * sizeof(float);
     HIPC(c, c->d_pool.ensure(pool_bytes));
@@ -741,8 +828,13 @@ int run_generic_block(fwgpu_ctx* c, int frames, uint32_t cmd_block, const float*
     DevView v = generic_view(c, frames);
     hipEvent_t e0, e1;
     timer_begin(c, 3, &e0, &e1);
-    for (size_t l = 0; l < c->level_cnt.size(); ++l)
+    for (size_t l = 0; l < c->level_cnt.size(); ++l) {
         LCHK(c, launch_level(c->stream, v, c->d_level_nodes.as<int>() + c->level_off[l], c->level_cnt[l], 1, cmd_block));
+        for (const fwgpu_ctx::FirGroup& g : c->fir_groups)
+            if (g.level == (int)l)
+                LCHK(c, launch_fir(c->stream, v, c->d_fir_rows.as<FirRow>() + g.row_off, g.n_rows, g.h_off, g.T,
+                                   c->d_fir_partials.as<float>(), c->d_fir_partials.cap / sizeof(float)));
+    }
     timer_end(c, e1);
     LCHK(c, launch_graph_out(c->stream, c->d_pool.as<float>(), c->d_flags.as<uint8_t>(), c->stride, 0, 0,
                              c->d_gout_bufs.as<int>(), c->n_gout_bufs, d_out, n_out_ch, frames, 1));
@@ -924,7 +1016,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
                       &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
                       &c->d_bus, &c->d_bus_flags, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
-                      &c->d_root_bufs, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
+                      &c->d_root_bufs, &c->d_fir_rows, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask};
     for (DevBuf* b : bufs) b->release();
     for (TimerCat& t : c->timers)
@@ -944,7 +1036,12 @@ int64_t fwgpu_graph_in_node(fwgpu_ctx* c) { return c->graph.id_of(c->graph.graph
 int64_t fwgpu_graph_out_node(fwgpu_ctx* c) { return c->graph.id_of(c->graph.graph_out_slot); }
 
 int64_t fwgpu_add_node(fwgpu_ctx* c, int kind, uint32_t n_in, uint32_t n_out, const float* params, int n_params) {
-    if (kind < 0 || kind > K_DELAY) return fail(c, FWGPU_ERR_INVALID, "unsupported node kind");
+    if (kind < 0 || kind > K_FIR) return fail(c, FWGPU_ERR_INVALID, "unsupported node kind");
+    if (kind == K_FIR) {
+        int ir = n_params > 0 ? (int)params[0] : -1;
+        if (ir < 0 || ir >= (int)c->samples.size() || !c->samples[ir].alive || c->samples[ir].desc.frames == 0)
+            return fail(c, FWGPU_ERR_INVALID, "FIR node: params[0] must be the id of a non-empty impulse-response sample");
+    }
     if (n_in > 64 || n_out > 64) return fail(c, FWGPU_ERR_INVALID, "a node has at most 64 ports per side (core/node.rs:62,69)");
     NodeState st = make_state(kind, params, n_params, c->sample_rate);
     return c->graph.add_node(kind, n_in, n_out, st);
@@ -1254,6 +1351,7 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     if (!hn || !hn->activated) return fail(c, FWGPU_ERR_INVALID, "node is not activated (call fwgpu_update)");
     if (hn->n_in != n_in || hn->n_out != n_out) return fail(c, FWGPU_ERR_INVALID, "port counts differ from add_node");
     if (frames > c->mbf) return fail(c, FWGPU_ERR_INVALID, "frames > max_block_frames");
+    if (hn->kind == K_FIR) return fail(c, FWGPU_ERR_INVALID, "FIR banks run at graph level (fwgpu_process_interleaved), not per node");
     const size_t stride = (size_t)c->stride;
     const int nb = 1 + (int)n_in + (int)n_out;
     HIPC(c, hipStreamSynchronize(c->stream));

@@ -222,6 +222,7 @@ bool check_activation(int kind, uint32_t n_in, uint32_t n_out, std::string& err)
             return true;
         case K_BIQUAD:
         case K_DELAY:
+        case K_FIR:
             if (n_in != n_out || n_in == 0) {
                 err = "Biquad/Delay nodes need as many outputs as inputs (>= 1).";
                 return false;

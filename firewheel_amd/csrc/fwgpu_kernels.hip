@@ -298,7 +298,7 @@ __device__ __forceinline__ float beep_step(float ph, float inc) {  // beep_test.
 
 __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, uint32_t cmd_block) {
     const NodeDesc nd = v.nodes[node_idx];
-    if (nd.is_graph_io) return;  // graph_in / graph_out are I/O edges (k_graph_in / k_graph_out)
+    if (nd.is_graph_io || nd.kind == K_FIR) return;  // I/O edges (k_graph_in/out); FIR banks run as MFMA GEMMs
     const int lane = threadIdx.x & (WAVE - 1);
     WaveIO io;
     io.pool = v.pool + (size_t)blk * v.pool_blk_stride;
@@ -1382,6 +1382,152 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv) {
     if (lane < 2) bflags[ld.out_buf + lane] = all_silent ? 1 : 0;
 }
 
+// ------------------------------------------------------------------ FIR convolution bank on the matrix cores
+// SPEC ("fir"): y[n] = sum_k h[k] x[n-k].  Per block the outputs of all rows that share one
+// impulse response are ONE dense GEMM:  Y[rows x frames] = Xwin[rows x W] * H[W x frames],  W = T-1+frames,
+// Xwin[r][m] = x_r[n0-(T-1)+m] (history then the current block), H[m][i] = h[T-1-(m-i)] for 0 <= m-i <= T-1 else 0
+// (Toeplitz, generated on the fly from h).  v_mfma_f32_32x32x2_f32 is an exact k-ordered fmaf chain, so the
+// summation order is fully defined: the window is cut in segments of FIR_SEG positions, each segment is one
+// fused chain in ascending m starting from +0.0, segment partials are added in segment order.  The oracle
+// evaluates exactly that order with fmaf, so GPU == oracle bit for bit; vs an f64 convolution the error is the
+// usual ~sqrt(W) * 2^-24 * sum|h x| (H7).
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__global__ void k_ir_convert(const SampleDesc* __restrict__ samples, int sample, int ch, float* __restrict__ dst, uint32_t T) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const SampleDesc sd = samples[sample];
+    int c = ch < sd.channels ? ch : 0;  // a mono impulse response serves every channel
+    dst[i] = i < sd.frames ? sample_fetch(sd, c, i) : 0.f;
+}
+
+// append the block's input to each row's mirrored history ring (positions q and q+R hold the same sample)
+__global__ void k_fir_append(DevView v, const FirRow* __restrict__ rows, int n_rows) {
+    int r = blockIdx.x;
+    if (r >= n_rows) return;
+    const FirRow row = rows[r];
+    const NodeState* s = &v.states[row.state];
+    const uint32_t R = (uint32_t)s->loop_end, p = (uint32_t)s->playhead;
+    float* ring = v.ext + s->ext_off + (size_t)row.ch * 2u * R;
+    const float* in = v.pool + (size_t)row.in_buf * v.stride;
+    for (int f = threadIdx.x; f < v.frames; f += blockDim.x) {
+        uint32_t q = (p + (uint32_t)f) % R;
+        float x = in[f];
+        ring[q] = x;
+        ring[q + R] = x;
+    }
+}
+
+#define FIR_PITCH (FIR_KC + 1)  // LDS row pitch in floats: 65 -> the 32 rows of a column hit 32 different banks
+__global__ __launch_bounds__(256) void k_fir_gemm(DevView v, const FirRow* __restrict__ rows, int n_rows, uint32_t h_off,
+                                                  uint32_t T, float* __restrict__ partials, int n_rows_pad, int n_pad) {
+    __shared__ float lds[2 * 32 * FIR_PITCH + 2 * (256 + FIR_KC)];
+    float* As = lds;                          // [2][32][FIR_PITCH]
+    float* Hw = lds + 2 * 32 * FIR_PITCH;     // [2][256 + FIR_KC]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * 32;
+    const uint32_t seg = blockIdx.y;
+    const int ib = blockIdx.z * 256;          // first output frame of this column group
+    const int frames = v.frames;
+    const uint32_t W = T - 1u + (uint32_t)frames;
+    const uint32_t m_begin = seg * FIR_SEG;
+    const uint32_t m_end = m_begin + FIR_SEG < W ? m_begin + FIR_SEG : W;
+    const float* h = v.ext + h_off;
+
+    // loader role: thread t stages 8 consecutive window positions of row (t >> 3)
+    const int lrow = tid >> 3, lcol = (tid & 7) * 8;
+    const float* wptr = nullptr;
+    if (row0 + lrow < n_rows) {
+        const FirRow row = rows[row0 + lrow];
+        const NodeState* s = &v.states[row.state];
+        const uint32_t R = (uint32_t)s->loop_end, p = (uint32_t)s->playhead;
+        const uint32_t e2 = (p + (uint32_t)frames - 1u) % R + R;  // newest sample, upper mirror
+        wptr = v.ext + s->ext_off + (size_t)row.ch * 2u * R + (e2 + 1u - W);
+    }
+    float areg[8], hreg[2];
+    auto load_chunk = [&](uint32_t m0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t m = m0 + (uint32_t)(lcol + j);
+            areg[j] = (wptr && m < m_end) ? wptr[m] : 0.f;
+        }
+        // Hw[q] = h[k], k = ib + T-1 - m0 - (KC-1) + q  (0 outside [0, T))
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int q = tid + j * 256;
+            long long k = (long long)ib + (long long)T - 1 - (long long)m0 - (FIR_KC - 1) + q;
+            hreg[j] = (q < 256 + FIR_KC && k >= 0 && k < (long long)T) ? h[k] : 0.f;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* a = As + buf * 32 * FIR_PITCH + lrow * FIR_PITCH + lcol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = areg[j];
+        float* hw = Hw + buf * (256 + FIR_KC);
+        if (tid < 256 + FIR_KC) hw[tid] = hreg[0];
+        if (tid + 256 < 256 + FIR_KC) hw[tid + 256] = hreg[1];
+    };
+
+    v16f acc0, acc1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc0[j] = acc1[j] = 0.f;
+    const int ct0 = wave * 2, ct1 = wave * 2 + 1;  // this wave's two 32-column tiles
+    const int a_row = lane & 31, k_half = lane >> 5;
+
+    const uint32_t n_chunks = m_end > m_begin ? (m_end - m_begin + FIR_KC - 1) / FIR_KC : 0;
+    if (n_chunks) {
+        load_chunk(m_begin);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) load_chunk(m_begin + (c + 1) * FIR_KC);  // in flight during the MFMAs below
+        const float* a = As + buf * 32 * FIR_PITCH + a_row * FIR_PITCH;
+        const float* hw = Hw + buf * (256 + FIR_KC) + (FIR_KC - 1) + (lane & 31);
+#pragma unroll 8
+        for (int kk = 0; kk < FIR_KC; kk += 2) {  // ascending m: the fmaf chain order of the SPEC
+            const int k = kk + k_half;
+            const float av = a[k];
+            const float b0 = hw[ct0 * 32 - k];
+            const float b1 = hw[ct1 * 32 - k];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+        }
+        if (c + 1 < n_chunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    // partials[seg][row][col]: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* P = partials + ((size_t)seg * n_rows_pad + row0) * n_pad + ib;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        P[(size_t)rr * n_pad + ct0 * 32 + (lane & 31)] = acc0[r];
+        P[(size_t)rr * n_pad + ct1 * 32 + (lane & 31)] = acc1[r];
+    }
+}
+
+// segment partials added in segment order; writes the node outputs, clears their silence flags, advances the ring
+__global__ void k_fir_reduce(DevView v, const FirRow* __restrict__ rows, int n_rows, const float* __restrict__ partials,
+                             int n_segs, int n_rows_pad, int n_pad) {
+    int r = blockIdx.x;
+    if (r >= n_rows) return;
+    const FirRow row = rows[r];
+    float* out = v.pool + (size_t)row.out_buf * v.stride;
+    for (int i = threadIdx.x; i < v.frames; i += blockDim.x) {
+        float t = partials[(size_t)r * n_pad + i];
+        for (int sgm = 1; sgm < n_segs; ++sgm) t = t + partials[((size_t)sgm * n_rows_pad + r) * n_pad + i];
+        out[i] = t;
+    }
+    if (threadIdx.x == 0) {
+        v.flags[row.out_buf] = 0;
+        if (row.ch == 0) {
+            NodeState* s = &v.states[row.state];
+            s->playhead = (s->playhead + (uint64_t)v.frames) % s->loop_end;
+        }
+    }
+}
+
 // Upper sum tree of the fused plan, K-batched: SumNode semantics (nodes/sum.rs:41-136) with one THREAD per
 // frame (blockIdx = node, block, channel) so that a 1-node level still puts K * n_out * frames/64 waves in flight.
 __global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restrict__ level_nodes) {
@@ -1448,6 +1594,25 @@ int launch_bus_sum(hipStream_t s, const DevView& v, const int* d_level_nodes, in
     if (n_nodes <= 0) return 0;
     dim3 grid(n_nodes, K, n_out);
     hipLaunchKernelGGL(k_bus_sum, grid, dim3(256), 0, s, v, d_level_nodes);
+    return (int)hipGetLastError();
+}
+int launch_ir_convert(hipStream_t s, const SampleDesc* samples, int sample, int ch, float* dst, uint32_t T) {
+    hipLaunchKernelGGL(k_ir_convert, dim3((T + 255) / 256), dim3(256), 0, s, samples, sample, ch, dst, T);
+    return (int)hipGetLastError();
+}
+int launch_fir(hipStream_t s, const DevView& v, const FirRow* d_rows, int n_rows, uint32_t h_off, uint32_t T,
+               float* d_partials, size_t partial_cap_floats) {
+    if (n_rows <= 0 || v.frames <= 0) return 0;
+    const uint32_t W = T - 1u + (uint32_t)v.frames;
+    const int n_segs = (int)((W + FIR_SEG - 1) / FIR_SEG);
+    const int row_tiles = (n_rows + 31) / 32, n_rows_pad = row_tiles * 32;
+    const int col_groups = (v.frames + 255) / 256, n_pad = col_groups * 256;
+    if ((size_t)n_segs * n_rows_pad * n_pad > partial_cap_floats) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_fir_append, dim3(n_rows), dim3(256), 0, s, v, d_rows, n_rows);
+    hipLaunchKernelGGL(k_fir_gemm, dim3(row_tiles, n_segs, col_groups), dim3(256), 0, s, v, d_rows, n_rows, h_off, T,
+                       d_partials, n_rows_pad, n_pad);
+    hipLaunchKernelGGL(k_fir_reduce, dim3(n_rows), dim3(256), 0, s, v, d_rows, n_rows, d_partials, n_segs, n_rows_pad,
+                       n_pad);
     return (int)hipGetLastError();
 }
 int launch_single_node(hipStream_t s, const DevView& v, int node_idx) {

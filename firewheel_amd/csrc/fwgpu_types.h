@@ -7,6 +7,7 @@ namespace fwgpu {
 enum : int {
     K_DUMMY = 0, K_BEEP = 1, K_VOLUME = 2, K_SUM = 3, K_SAMPLER = 4, K_HARD_CLIP = 5,
     K_MONO_TO_STEREO = 6, K_STEREO_TO_MONO = 7, K_PAN = 8, K_WIDTH = 9, K_BIQUAD = 10, K_DELAY = 11,
+    K_FIR = 12,
 };
 
 enum : int { FMT_I_I16 = 0, FMT_I_U16 = 1, FMT_I_F32 = 2, FMT_P_I16 = 3, FMT_P_U16 = 4, FMT_P_F32 = 5 };
@@ -39,6 +40,8 @@ struct NodeState {
     // SPEC nodes with per-channel state: offset/length (floats) of this node's slice of the ext pool
     //   BIQUAD: ext = [b0 b1 b2 a1 a2][x1 x2 y1 y2] x channels      DELAY: ext = ring[channels][D]
     //   DELAY also uses p0 = feedback, p1 = mix, gain = dry (1-mix), playhead = ring position, loop_end = D
+    //   FIR: ext = mirrored history ring[channels][2R]; playhead = ring position, loop_end = R, loop_start = T,
+    //        sample = impulse-response sample id
     uint32_t ext_off;
     uint32_t ext_len;
     int pad[1];
@@ -135,6 +138,16 @@ struct VoiceCache {
     GainSet g;
 };
 static_assert(sizeof(VoiceCache) == 48, "VoiceCache layout");
+
+// ---------------------------------------------------------------- FIR convolution bank (MFMA GEMM)
+#define FIR_SEG 4096  // window positions per split-K segment — part of the numeric SPEC (summation order)
+#define FIR_KC 64     // window positions staged per LDS chunk
+struct FirRow {  // one GEMM row = one channel of one FIR node
+    int state;
+    int ch;
+    int in_buf;
+    int out_buf;
+};
 
 struct LeafDesc {  // a SumNode whose ports are all voice chains (nodes/sum.rs)
     int first_voice;

@@ -36,7 +36,8 @@ enum fwgpu_node_kind {
     FWGPU_STEREO_PAN = 8,     /* SPEC (not in reference) params: pan in [-1,1] */
     FWGPU_STEREO_WIDTH = 9,   /* SPEC                 params: width */
     FWGPU_BIQUAD = 10,        /* SPEC                 params: type, cutoff_hz, q */
-    FWGPU_DELAY = 11          /* SPEC                 params: delay_secs, feedback, mix */
+    FWGPU_DELAY = 11,         /* SPEC                 params: delay_secs, feedback, mix */
+    FWGPU_FIR = 12            /* SPEC convolution     params: impulse-response sample id (fwgpu_sample_create) */
 };
 
 /* sample formats — core/sample_resource.rs:28-335 */

@@ -679,6 +679,54 @@ struct DelayProcessor : AudioNodeProcessor {
     }
 };
 
+// ---- SPEC: FIR convolution y[n] = sum_k h[k] x[n-k] with a fully specified f32 summation order (the one a
+// k-ordered fmaf chain per FIR_SEG-long window segment produces; DESIGN.md §6 "fir"):
+//   window W = T-1+frames positions, position m holds x[n0-(T-1)+m]; H[m][i] = h[T-1-(m-i)] if 0<=m-i<=T-1 else 0
+//   partial_s[i] = fmaf chain over m in segment s (ascending, from +0.0f), y[i] = ((p_0 + p_1) + p_2) + ...
+struct FirProcessor : AudioNodeProcessor {
+    static constexpr size_t SEG = 4096;
+    std::vector<std::vector<float>> h;     // per channel
+    std::vector<std::vector<float>> hist;  // per channel: the last T-1 inputs
+    size_t T;
+    FirProcessor(const SampleResource& ir, size_t nch) {
+        T = (size_t)ir.len_frames();
+        for (size_t c = 0; c < nch; ++c) {
+            size_t ic = std::min(c, ir.num_channels() - 1);
+            std::vector<std::vector<float>> tmp(ir.num_channels(), std::vector<float>(T, 0.0f));
+            std::vector<float*> ptrs;
+            for (auto& v : tmp) ptrs.push_back(v.data());
+            ir.fill_buffers(ptrs.data(), ptrs.size(), 0, T, 0);
+            h.push_back(tmp[ic]);
+            hist.emplace_back(T - 1, 0.0f);
+        }
+    }
+    void process(size_t frames, const float* const* inputs, size_t n_in, float* const* outputs, size_t n_out,
+                 ProcInfo) override {
+        size_t nch = std::min(std::min(n_in, n_out), h.size());
+        const size_t W = T - 1 + frames;
+        std::vector<float> win(W);
+        for (size_t c = 0; c < nch; ++c) {
+            std::copy(hist[c].begin(), hist[c].end(), win.begin());
+            std::copy(inputs[c], inputs[c] + frames, win.begin() + (T - 1));
+            const float* hc = h[c].data();
+            for (size_t i = 0; i < frames; ++i) {
+                float total = 0.0f;
+                for (size_t s0 = 0, sidx = 0; s0 < W; s0 += SEG, ++sidx) {
+                    size_t s1 = std::min(W, s0 + SEG);
+                    float acc = 0.0f;
+                    for (size_t m = s0; m < s1; ++m) {
+                        float hv = (m >= i && m - i <= T - 1) ? hc[T - 1 - (m - i)] : 0.0f;
+                        acc = fmaf(win[m], hv, acc);
+                    }
+                    total = sidx == 0 ? acc : total + acc;
+                }
+                outputs[c][i] = total;
+            }
+            if (T > 1) std::copy(win.end() - (T - 1), win.end(), hist[c].begin());
+        }
+    }
+};
+
 }  // namespace
 
 void biquad_coefs(int type, float cutoff_hz, float q, uint32_t sample_rate, float co[5]) {
@@ -740,6 +788,7 @@ const char* AudioNode::debug_name() const {
         case KIND_STEREO_WIDTH: return "stereo_width";
         case KIND_BIQUAD: return "biquad";
         case KIND_DELAY: return "delay";
+        case KIND_FIR: return "fir";
         default: return "unknown";
     }
 }
@@ -863,6 +912,12 @@ std::unique_ptr<AudioNodeProcessor> AudioNode::activate(uint32_t sample_rate, si
             if (d > 16777216.0) d = 16777216.0;
             return std::unique_ptr<AudioNodeProcessor>(new DelayProcessor(raw_gain, aux0, aux1, (uint32_t)d, num_inputs));
         }
+        case KIND_FIR:
+            if (num_inputs != num_outputs || num_inputs == 0 || !ir || ir->len_frames() == 0) {
+                err = "FIR node needs as many outputs as inputs and a non-empty impulse response.";
+                return nullptr;
+            }
+            return std::unique_ptr<AudioNodeProcessor>(new FirProcessor(*ir, num_inputs));
         default:
             err = "unknown node kind";
             return nullptr;
@@ -1296,7 +1351,13 @@ int64_t fwo_graph_out_node(void* c) { return index_to_i64(((Ctx*)c)->graph.graph
 
 int64_t fwo_add_node(void* c, int kind, uint32_t n_in, uint32_t n_out, const float* params, int n_params) {
     Ctx* cx = (Ctx*)c;
-    return index_to_i64(cx->graph.add_node(n_in, n_out, make_node(kind, params, n_params)));
+    auto node = make_node(kind, params, n_params);
+    if (kind == KIND_FIR) {
+        int id = n_params > 0 ? (int)params[0] : -1;
+        if (id < 0 || id >= (int)cx->samples.size()) return -20;
+        node->ir = cx->samples[id];
+    }
+    return index_to_i64(cx->graph.add_node(n_in, n_out, std::move(node)));
 }
 int fwo_remove_node(void* c, int64_t node) { return ((Ctx*)c)->graph.remove_node(index_from_i64(node)); }
 int64_t fwo_connect(void* c, int64_t src, uint32_t sp, int64_t dst, uint32_t dp, int check) {

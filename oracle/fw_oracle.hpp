@@ -155,6 +155,7 @@ enum NodeKind : int {
     KIND_STEREO_WIDTH = 9,
     KIND_BIQUAD = 10,
     KIND_DELAY = 11,
+    KIND_FIR = 12,
 };
 
 // Sampler control messages (nodes/sampler.rs:16-28)
@@ -179,6 +180,7 @@ struct AudioNode {
     std::vector<float> spec_params;       // SPEC nodes creation params
     std::shared_ptr<std::vector<float>> coefs;  // SPEC biquad: b0 b1 b2 a1 a2 shared with the processor
     uint32_t act_sample_rate = 48000;
+    std::shared_ptr<const SampleResource> ir;   // SPEC FIR: impulse response
     std::shared_ptr<std::deque<SamplerMsg>> to_processor;  // sampler.rs:42 (rtrb cap 128)
     const char* debug_name() const;
     // activate: returns nullptr and sets err on failure (core/node.rs:12-18)

@@ -282,3 +282,36 @@ def scenario_cfg3_chain(e, n_voices=12, blocks=10, radix=4, src_frames=3000):
     e.sampler_pause(voices[0]["sampler"])        # the filter/delay tails keep ringing on zeros
     out2 = e.process_blocks(blocks - blocks // 2)
     return np.concatenate([out1, out2])
+
+
+def reverb_ir(seed, taps, channels=2, decay=None):
+    """exponentially decaying seeded noise, L1-normalised per channel."""
+    decay = decay or taps / 4.0
+    h = fwapi.xorshift_uniform(seed, channels * taps).reshape(channels, taps)
+    h = h * np.exp(-np.arange(taps, dtype=np.float32) / np.float32(decay))[None, :]
+    h = h / np.sum(np.abs(h), axis=1, keepdims=True)
+    return h.astype(np.float32)
+
+
+def scenario_cfg4_reverb(e, n_voices=6, taps=5000, blocks=5, shared_ir=True, ir_channels=2, fir_ch=2):
+    """config-4 shape: V x (sampler -> FIR convolution) -> sum -> out.  Taps > FIR_SEG exercises the split-K order."""
+    irs = []
+    n_irs = 1 if shared_ir else 2
+    for k in range(n_irs):
+        irs.append(e.new_sample(PLANAR_F32, ir_channels, reverb_ir(4000 + k, taps - 37 * k, ir_channels)))
+    m = e.sum(n_voices)
+    voices = []
+    for v in range(n_voices):
+        s = e.sampler(80.0)
+        f = e.fir(irs[v % n_irs], ch=fir_ch)
+        e.connect_stereo(s, f)
+        e.connect_stereo(f, m, 2 * v)
+        voices.append(s)
+    e.connect_stereo(m, e.graph_out_node)
+    e.update()
+    for v, s in enumerate(voices):
+        e.sampler_set_sample(s, e.new_sample(PLANAR_F32, 2, voice_source(1200 + v, 1500)))
+        if v % 2 == 0:
+            e.sampler_set_loop_range(s, LOOP_FULL)
+        e.sampler_play(s)
+    return e.process_blocks(blocks)

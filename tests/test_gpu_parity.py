@@ -192,9 +192,13 @@ def run_case(name, **gpu_kw):
         "mixed_generic_nobeep": lambda e: scenarios.scenario_mixed_generic(e, use_beep=False),
         "graph_inputs": scenarios.scenario_graph_inputs,
         "cfg3_chain": scenarios.scenario_cfg3_chain,
+        "cfg4_reverb": scenarios.scenario_cfg4_reverb,
+        "cfg4_reverb_2irs_mono": lambda e: scenarios.scenario_cfg4_reverb(e, n_voices=5, taps=700, shared_ir=False,
+                                                                          ir_channels=1),
     }[name]
     mbf = {"steady_96x32": 256, "steady_40x4_i16": 64, "steady_9x3_u16": 128, "events_70": 256, "events_33_r2": 128,
-           "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64, "cfg3_chain": 128}[name]
+           "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64, "cfg3_chain": 128, "cfg4_reverb": 128,
+           "cfg4_reverb_2irs_mono": 64}[name]
     kw = dict(max_block_frames=mbf)
     if name == "graph_inputs":
         kw["num_graph_inputs"] = 3
@@ -241,6 +245,48 @@ def test_cfg3_chain_spec_nodes_bit_exact():
     assert_bits_equal(out_o, out_g, "cfg3 chain (biquad + delay + width)")
     gold = json.load(open(GOLDEN))
     assert digest(out_g) == gold["cfg3_chain"]
+
+
+@pytest.mark.parametrize("name", ["cfg4_reverb", "cfg4_reverb_2irs_mono"])
+def test_cfg4_fir_reverb_mfma_bit_exact(name):
+    out_o, out_g, g = run_case(name)
+    assert g.cx.plan_kind() == 0
+    assert_bits_equal(out_o, out_g, name)
+    gold = json.load(open(GOLDEN))
+    assert digest(out_g) == gold[name]
+
+
+def test_fir_long_ir_impulse_and_linearity_properties():
+    # full-length 65536-tap IR (config 4), too slow for the oracle: size-independent properties instead
+    taps, frames = 65536, 256
+    h = scenarios.reverb_ir(77, taps, 2, decay=16384.0)
+
+    def run(sig):
+        g = GpuEngine(max_block_frames=frames, num_graph_inputs=2)
+        ir = g.new_sample(PLANAR_F32, 2, h)
+        f = g.fir(ir)
+        g.connect_stereo(g.graph_in_node, f)
+        g.connect_stereo(f, g.graph_out_node)
+        g.update()
+        return g.process_interleaved(sig.shape[0], 2, inp=sig.reshape(-1), n_in_ch=2).reshape(-1, 2)
+
+    n = 3 * frames
+    imp = np.zeros((n, 2), f32)
+    imp[5] = (1.0, 0.5)
+    y = run(imp)
+    # an impulse reproduces the impulse response exactly: every product but one is x*0 and 1.0*h is exact
+    assert np.array_equal(y[5:, 0], h[0, :n - 5])
+    assert np.array_equal(y[5:, 1], (h[1, :n - 5] * f32(0.5)).astype(f32))
+    assert not np.any(y[:5])
+    # scaling by a power of two is exact through the whole fmaf chain
+    x = fwapi.xorshift_uniform(123, 2 * n).reshape(n, 2)
+    y1 = run(x)
+    y2 = run((x * f32(0.25)).astype(f32))
+    assert np.array_equal(y2, (y1 * f32(0.25)).astype(f32))
+    # and against an f64 convolution (H7 bound)
+    ref = np.convolve(x[:, 0].astype(np.float64), h[0].astype(np.float64))[:n]
+    bound = np.convolve(np.abs(x[:, 0]).astype(np.float64), np.abs(h[0]).astype(np.float64))[:n]
+    assert np.max(np.abs(y1[:, 0] - ref) / np.maximum(bound, 1e-30)) < 64 * 2.0 ** -24
 
 
 @pytest.mark.parametrize("ch", [1, 2, 5])

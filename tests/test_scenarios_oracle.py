@@ -34,6 +34,9 @@ CASES = {
     "mixed_generic": lambda: scenarios.scenario_mixed_generic(oracle(max_block_frames=256)),
     "mixed_generic_nobeep": lambda: scenarios.scenario_mixed_generic(oracle(max_block_frames=256), use_beep=False),
     "cfg3_chain": lambda: scenarios.scenario_cfg3_chain(oracle(max_block_frames=128)),
+    "cfg4_reverb": lambda: scenarios.scenario_cfg4_reverb(oracle(max_block_frames=128)),
+    "cfg4_reverb_2irs_mono": lambda: scenarios.scenario_cfg4_reverb(oracle(max_block_frames=64), n_voices=5, taps=700,
+                                                                     shared_ir=False, ir_channels=1),
     "graph_inputs": lambda: scenarios.scenario_graph_inputs(oracle(max_block_frames=64, num_graph_inputs=3)),
 }
 
@@ -96,3 +99,18 @@ def test_delay_and_width_spec_against_numpy():
     yw, _ = e.node_process(w, 64, st, 2)
     mono = ((st[0] + st[1]).astype(f32) * f32(0.5)).astype(f32)
     assert np.array_equal(yw[0], mono) and np.array_equal(yw[1], mono)    # width 0 = mono
+
+
+def test_fir_spec_matches_f64_convolution():
+    # H7: the f32 segment-ordered fmaf chain vs an f64 convolution, error relative to sum|h x|
+    taps, frames, blocks = 9000, 128, 4
+    e = fwapi.OracleEngine(max_block_frames=frames)
+    h = scenarios.reverb_ir(9, taps, 1)
+    ir = e.new_sample(fwapi.PLANAR_F32, 1, h)
+    n = e.fir(ir, ch=1)
+    e.update()
+    x = fwapi.xorshift_uniform(10, frames * blocks)
+    y = np.concatenate([e.node_process(n, frames, [x[i:i + frames]], 1)[0][0] for i in range(0, x.size, frames)])
+    ref = np.convolve(x.astype(np.float64), h[0].astype(np.float64))[:x.size]
+    bound = np.convolve(np.abs(x).astype(np.float64), np.abs(h[0]).astype(np.float64))[:x.size]
+    assert np.max(np.abs(y - ref) / np.maximum(bound, 1e-30)) < 16 * 2.0 ** -24

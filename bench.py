@@ -67,6 +67,51 @@ def build_bank(cx, fa, voices, radix, src, frames_per_voice, seed=0):
     return samplers
 
 
+def build_reverb_bank(cx, fa, voices, radix, src, frames_per_voice, taps, torch):
+    """cfg4: V x (sampler -> 65536-tap stereo FIR convolution) -> radix sum tree -> out."""
+    import numpy as np
+
+    n = np.arange(taps, dtype=np.float64)
+    rng = np.random.default_rng(4)
+    h = (rng.uniform(-1, 1, size=(2, taps)) * np.exp(-n / 16384.0)[None, :])
+    h = (h / np.abs(h).sum(axis=1, keepdims=True)).astype(np.float32)
+    ir = cx.new_sample(fa.SampleFormat.PLANAR_F32, 2, h)
+    from firewheel_amd.graph import _RawNode
+
+    ends, samplers = [], []
+    for v in range(voices):
+        s = cx.add_node(0, 2, fa.SamplerNode(100.0))
+        f = cx.add_node(2, 2, _RawNode(12, [float(ir)]))
+        for c in (0, 1):
+            cx.connect(s, c, f, c, False)
+        samplers.append(s)
+        ends.append(f)
+    level = ends
+    while True:
+        nxt = []
+        for i in range(0, len(level), radix):
+            grp = level[i:i + radix]
+            m = cx.add_node(2 * len(grp), 2, fa.SumNode())
+            for p, nd in enumerate(grp):
+                cx.connect(nd, 0, m, 2 * p, False)
+                cx.connect(nd, 1, m, 2 * p + 1, False)
+            nxt.append(m)
+        level = nxt
+        if len(level) == 1:
+            break
+    cx.connect(level[0], 0, cx.graph_out_node(), 0, False)
+    cx.connect(level[0], 1, cx.graph_out_node(), 1, False)
+    cx.update()
+    for v, s in enumerate(samplers):
+        ptr = src.data_ptr() + v * 2 * frames_per_voice * 4
+        smp = cx.new_sample_device(fa.SampleFormat.PLANAR_F32, 2, frames_per_voice, ptr)
+        node = cx.node(s)
+        node.set_sample(smp, False)
+        node.set_loop_range(fa.LoopRange.Full())
+        node.play()
+    return samplers
+
+
 def cpu_baseline(voices, block, radix, target_secs):
     """Oracle (single thread, like the reference's audio thread: DESIGN_DOC.md:48) on the same graph shape."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -112,6 +157,9 @@ def main():
     ap.add_argument("--cpu-secs", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--workload", choices=["cfg2", "cfg4"], default="cfg2",
+                    help="cfg2 = the headline (BASELINE configs[1]); cfg4 = 256-voice 65536-tap FIR reverb (MFMA)")
+    ap.add_argument("--taps", type=int, default=65536)
     ap.add_argument("--bus-reduce", choices=["allreduce", "ordered"], default="allreduce",
                     help="N>1: RCCL all-reduce (named path) or all-gather + rank-ordered sum (bit-exact)")
     args = ap.parse_args()
@@ -136,6 +184,13 @@ def main():
     import firewheel_amd as fa
     from firewheel_amd import shard
 
+    if args.workload == "cfg4":
+        if args.voices == 1024:
+            args.voices = 256
+        if args.blocks_per_step == 256:
+            args.blocks_per_step = 4
+        args.src_frames = min(args.src_frames, 65536)
+        args.no_cpu_baseline = True
     V, B, K = args.voices, args.block, args.blocks_per_step
     stream = torch.cuda.current_stream().cuda_stream
     cx = fa.FirewheelGpuCtx(48000, B, 0, 2, device=local_rank, stream=stream)
@@ -145,8 +200,11 @@ def main():
     g.manual_seed(shard.voice_seed(rank * V))  # stream keyed by the shard's first GLOBAL voice id
     src = torch.empty((V, 2, args.src_frames), dtype=torch.float32, device="cuda")
     src.uniform_(-1.0, 1.0, generator=g)
-    build_bank(cx, fa, V, args.radix, src, args.src_frames, seed=rank)
-    assert cx.plan_kind() == 1, "fused voice-bank plan was not selected"
+    if args.workload == "cfg4":
+        build_reverb_bank(cx, fa, V, args.radix, src, args.src_frames, args.taps, torch)
+    else:
+        build_bank(cx, fa, V, args.radix, src, args.src_frames, seed=rank)
+        assert cx.plan_kind() == 1, "fused voice-bank plan was not selected"
     out = torch.empty(K * B * 2, dtype=torch.float32, device="cuda")
 
     def step():
@@ -187,6 +245,15 @@ def main():
         ctl_ms, ctl_n = cx.timing_read(1)
         up_ms, up_n = cx.timing_read(2)
         alg_bytes = V * B * K * 8.0  # 8 B per stereo voice-sample (L+R f32 source read once)
+        gen_ms, gen_n = cx.timing_read(3)
+        if args.workload == "cfg4" and gen_n:
+            # all level kernels + the FIR GEMM of one block; the GEMM dominates (profiles/r01_cfg4_kernel_stats.csv)
+            flops = 2.0 * 2 * args.taps * V * B  # direct-form definition: 2 ch x 2 flop x T per voice-sample
+            avg_s = gen_ms / gen_n / 1e3
+            ach = flops / avg_s / 1e12
+            roofline = {"bound": "mfma", "kernel": "k_fir_gemm (+ level kernels of the block)", "achieved": ach,
+                        "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                        "algorithmic_flops_per_block": flops, "avg_block_us": avg_s * 1e6, "blocks": gen_n}
         if leaf_n:
             avg_s = leaf_ms / leaf_n / 1e3
             ach = alg_bytes / avg_s / 1e9
@@ -226,8 +293,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "cfg2: %d stereo voices/GPU, sampler->gain->pan->radix-%d sum tree, block=%d @48kHz, "
-                            "planar f32 sources in HBM (%d frames/voice, looping)" % (V, args.radix, B, args.src_frames),
+                "workload": ("cfg2: %d stereo voices/GPU, sampler->gain->pan->radix-%d sum tree, block=%d @48kHz, "
+                             "planar f32 sources in HBM (%d frames/voice, looping)" % (V, args.radix, B, args.src_frames))
+                if args.workload == "cfg2" else
+                ("cfg4: %d stereo voices/GPU, sampler->%d-tap stereo FIR (f32 MFMA Toeplitz GEMM)->radix-%d sum tree, "
+                 "block=%d @48kHz" % (V, args.taps, args.radix, B)),
                 "voices_per_gpu": V, "block": B, "blocks_per_step": K, "parallelism": "voice-shard x%d%s" %
                 (world, " + RCCL mix-bus all-reduce" if world > 1 else ""),
                 "realtime_factor": (total / dt) / (48000.0 * V * world),

@@ -104,13 +104,13 @@ struct fwgpu_ctx {
     std::vector<int> up_level_off, up_level_cnt;
 
     // FIR banks (generic executor): rows grouped by (level, impulse-response channel)
-    struct FirGroup {
-        int level, row_off, n_rows;
-        uint32_t h_off, T;
+    struct FirGroup {  // one GEMM launch: every FIR row of a level with the same tap count
+        int level, row_off, n_rows, tile_off;
+        uint32_t T;
     };
     std::vector<FirGroup> fir_groups;
     std::map<std::pair<int, int>, uint32_t> ir_cache;  // (sample id, channel) -> ext offset of h[T] as f32
-    DevBuf d_fir_rows, d_fir_partials;
+    DevBuf d_fir_rows, d_fir_tiles, d_fir_partials;
 
     // messages
     std::vector<Cmd> cmds;
@@ -647,25 +647,40 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
                 groups[std::make_tuple(p.level, c->ir_cache[key], T)].push_back(r);
             }
         }
+        // one launch per (level, T); inside it rows are sorted by impulse-response channel and padded so that
+        // every 32-row tile convolves with a single h (tile_h_off)
         std::vector<FirRow> flat_rows;
+        std::vector<uint32_t> flat_tiles;
         c->fir_groups.clear();
         size_t partial_need = 0;
-        for (auto& g : groups) {
+        std::map<std::pair<int, uint32_t>, std::vector<std::pair<uint32_t, std::vector<FirRow>*>>> launches;
+        for (auto& g : groups)
+            launches[std::make_pair(std::get<0>(g.first), std::get<2>(g.first))].emplace_back(std::get<1>(g.first), &g.second);
+        for (auto& l : launches) {
             fwgpu_ctx::FirGroup fg;
-            fg.level = std::get<0>(g.first);
-            fg.h_off = std::get<1>(g.first);
-            fg.T = std::get<2>(g.first);
+            fg.level = l.first.first;
+            fg.T = l.first.second;
             fg.row_off = (int)flat_rows.size();
-            fg.n_rows = (int)g.second.size();
-            flat_rows.insert(flat_rows.end(), g.second.begin(), g.second.end());
+            fg.tile_off = (int)flat_tiles.size();
+            for (auto& part : l.second) {
+                for (const FirRow& r : *part.second) flat_rows.push_back(r);
+                while ((flat_rows.size() - fg.row_off) % 32) {
+                    FirRow pad;
+                    pad.state = -1;
+                    pad.ch = pad.in_buf = pad.out_buf = 0;
+                    flat_rows.push_back(pad);
+                }
+                while (flat_tiles.size() - fg.tile_off < (flat_rows.size() - fg.row_off) / 32) flat_tiles.push_back(part.first);
+            }
+            fg.n_rows = (int)flat_rows.size() - fg.row_off;
             c->fir_groups.push_back(fg);
             size_t W = (size_t)fg.T - 1 + c->mbf;
             size_t segs = (W + FIR_SEG - 1) / FIR_SEG;
-            size_t need = segs * (size_t)((fg.n_rows + 31) / 32 * 32) * (size_t)((c->mbf + 255) / 256 * 256);
-            partial_need = std::max(partial_need, need);
+            partial_need = std::max(partial_need, segs * (size_t)fg.n_rows * (size_t)((c->mbf + 255) / 256 * 256));
         }
         if (!flat_rows.empty()) {
             if ((rc = upload(c, c->d_fir_rows, flat_rows.data(), flat_rows.size() * sizeof(FirRow)))) return rc;
+            if ((rc = upload(c, c->d_fir_tiles, flat_tiles.data(), flat_tiles.size() * sizeof(uint32_t)))) return rc;
             HIPC(c, c->d_fir_partials.ensure(partial_need * sizeof(float)));
         }
     }
@@ -832,8 +847,9 @@ int run_generic_block(fwgpu_ctx* c, int frames, uint32_t cmd_block, const float*
         LCHK(c, launch_level(c->stream, v, c->d_level_nodes.as<int>() + c->level_off[l], c->level_cnt[l], 1, cmd_block));
         for (const fwgpu_ctx::FirGroup& g : c->fir_groups)
             if (g.level == (int)l)
-                LCHK(c, launch_fir(c->stream, v, c->d_fir_rows.as<FirRow>() + g.row_off, g.n_rows, g.h_off, g.T,
-                                   c->d_fir_partials.as<float>(), c->d_fir_partials.cap / sizeof(float)));
+                LCHK(c, launch_fir(c->stream, v, c->d_fir_rows.as<FirRow>() + g.row_off, g.n_rows,
+                                   c->d_fir_tiles.as<uint32_t>() + g.tile_off, g.T, c->d_fir_partials.as<float>(),
+                                   c->d_fir_partials.cap / sizeof(float)));
     }
     timer_end(c, e1);
     LCHK(c, launch_graph_out(c->stream, c->d_pool.as<float>(), c->d_flags.as<uint8_t>(), c->stride, 0, 0,
@@ -1016,7 +1032,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
                       &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
                       &c->d_bus, &c->d_bus_flags, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
-                      &c->d_root_bufs, &c->d_fir_rows, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
+                      &c->d_root_bufs, &c->d_fir_rows, &c->d_fir_tiles, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask};
     for (DevBuf* b : bufs) b->release();
     for (TimerCat& t : c->timers)

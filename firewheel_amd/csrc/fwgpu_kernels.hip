@@ -1406,6 +1406,7 @@ __global__ void k_fir_append(DevView v, const FirRow* __restrict__ rows, int n_r
     int r = blockIdx.x;
     if (r >= n_rows) return;
     const FirRow row = rows[r];
+    if (row.state < 0) return;  // padding row (tiles are impulse-response-homogeneous)
     const NodeState* s = &v.states[row.state];
     const uint32_t R = (uint32_t)s->loop_end, p = (uint32_t)s->playhead;
     float* ring = v.ext + s->ext_off + (size_t)row.ch * 2u * R;
@@ -1419,8 +1420,9 @@ __global__ void k_fir_append(DevView v, const FirRow* __restrict__ rows, int n_r
 }
 
 #define FIR_PITCH (FIR_KC + 1)  // LDS row pitch in floats: 65 -> the 32 rows of a column hit 32 different banks
-__global__ __launch_bounds__(256) void k_fir_gemm(DevView v, const FirRow* __restrict__ rows, int n_rows, uint32_t h_off,
-                                                  uint32_t T, float* __restrict__ partials, int n_rows_pad, int n_pad) {
+__global__ __launch_bounds__(256) void k_fir_gemm(DevView v, const FirRow* __restrict__ rows, int n_rows,
+                                                  const uint32_t* __restrict__ tile_h_off, uint32_t T,
+                                                  float* __restrict__ partials, int n_rows_pad, int n_pad) {
     __shared__ float lds[2 * 32 * FIR_PITCH + 2 * (256 + FIR_KC)];
     float* As = lds;                          // [2][32][FIR_PITCH]
     float* Hw = lds + 2 * 32 * FIR_PITCH;     // [2][256 + FIR_KC]
@@ -1432,12 +1434,12 @@ __global__ __launch_bounds__(256) void k_fir_gemm(DevView v, const FirRow* __res
     const uint32_t W = T - 1u + (uint32_t)frames;
     const uint32_t m_begin = seg * FIR_SEG;
     const uint32_t m_end = m_begin + FIR_SEG < W ? m_begin + FIR_SEG : W;
-    const float* h = v.ext + h_off;
+    const float* h = v.ext + tile_h_off[blockIdx.x];  // every row of a tile convolves with the same h
 
     // loader role: thread t stages 8 consecutive window positions of row (t >> 3)
     const int lrow = tid >> 3, lcol = (tid & 7) * 8;
     const float* wptr = nullptr;
-    if (row0 + lrow < n_rows) {
+    if (row0 + lrow < n_rows && rows[row0 + lrow].state >= 0) {
         const FirRow row = rows[row0 + lrow];
         const NodeState* s = &v.states[row.state];
         const uint32_t R = (uint32_t)s->loop_end, p = (uint32_t)s->playhead;
@@ -1513,6 +1515,7 @@ __global__ void k_fir_reduce(DevView v, const FirRow* __restrict__ rows, int n_r
     int r = blockIdx.x;
     if (r >= n_rows) return;
     const FirRow row = rows[r];
+    if (row.state < 0) return;
     float* out = v.pool + (size_t)row.out_buf * v.stride;
     for (int i = threadIdx.x; i < v.frames; i += blockDim.x) {
         float t = partials[(size_t)r * n_pad + i];
@@ -1600,7 +1603,7 @@ int launch_ir_convert(hipStream_t s, const SampleDesc* samples, int sample, int 
     hipLaunchKernelGGL(k_ir_convert, dim3((T + 255) / 256), dim3(256), 0, s, samples, sample, ch, dst, T);
     return (int)hipGetLastError();
 }
-int launch_fir(hipStream_t s, const DevView& v, const FirRow* d_rows, int n_rows, uint32_t h_off, uint32_t T,
+int launch_fir(hipStream_t s, const DevView& v, const FirRow* d_rows, int n_rows, const uint32_t* d_tile_h_off, uint32_t T,
                float* d_partials, size_t partial_cap_floats) {
     if (n_rows <= 0 || v.frames <= 0) return 0;
     const uint32_t W = T - 1u + (uint32_t)v.frames;
@@ -1609,7 +1612,7 @@ int launch_fir(hipStream_t s, const DevView& v, const FirRow* d_rows, int n_rows
     const int col_groups = (v.frames + 255) / 256, n_pad = col_groups * 256;
     if ((size_t)n_segs * n_rows_pad * n_pad > partial_cap_floats) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_fir_append, dim3(n_rows), dim3(256), 0, s, v, d_rows, n_rows);
-    hipLaunchKernelGGL(k_fir_gemm, dim3(row_tiles, n_segs, col_groups), dim3(256), 0, s, v, d_rows, n_rows, h_off, T,
+    hipLaunchKernelGGL(k_fir_gemm, dim3(row_tiles, n_segs, col_groups), dim3(256), 0, s, v, d_rows, n_rows, d_tile_h_off, T,
                        d_partials, n_rows_pad, n_pad);
     hipLaunchKernelGGL(k_fir_reduce, dim3(n_rows), dim3(256), 0, s, v, d_rows, n_rows, d_partials, n_segs, n_rows_pad,
                        n_pad);

@@ -10,8 +10,11 @@ from ._lib import LIB_PATH, FwgpuError, build_library, load_library  # noqa: F40
 from .graph import (  # noqa: F401
     AddEdgeError,
     BeepTestNode,
+    BiquadNode,
     CompileGraphError,
+    DelayNode,
     DummyAudioNode,
+    FirReverbNode,
     FirewheelGpuCtx,
     HardClipNode,
     LoopRange,
@@ -20,12 +23,13 @@ from .graph import (  # noqa: F401
     SamplerNode,
     StereoPanNode,
     StereoToMonoNode,
+    StereoWidthNode,
     SumNode,
     VolumeNode,
 )
 
 __all__ = [
     "FirewheelGpuCtx", "VolumeNode", "SumNode", "SamplerNode", "BeepTestNode", "HardClipNode", "MonoToStereoNode",
-    "StereoToMonoNode", "DummyAudioNode", "StereoPanNode", "LoopRange", "SampleFormat", "AddEdgeError",
+    "StereoToMonoNode", "DummyAudioNode", "StereoPanNode", "StereoWidthNode", "BiquadNode", "DelayNode", "FirReverbNode", "LoopRange", "SampleFormat", "AddEdgeError",
     "CompileGraphError", "FwgpuError", "load_library", "build_library", "LIB_PATH",
 ]

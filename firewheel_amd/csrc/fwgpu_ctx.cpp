@@ -97,6 +97,7 @@ struct fwgpu_ctx {
 
     // fused plan
     bool fused = false;
+    bool fused_fx = false;  // the fused plan's leaves run k_chain (biquad / delay in the voice chains)
     int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
     uint32_t epoch = 1;  // invalidates every VoiceCache when bumped (plan install, sample-table change)
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags;
@@ -311,9 +312,11 @@ struct FusedBuild {
     int root_buf[2];
     int n_bus = 1;
     int max_stages = 0;
+    bool has_fx = false;  // some chain holds a biquad / delay: the k_chain plan
 };
 
-bool detect_fused(const Plan& plan, FusedBuild& fb) {
+// `graph`: for the delay lengths (k_chain needs D >= one tile); `mbf` must then be a multiple of the tile
+bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedBuild& fb) {
     const int N = (int)plan.nodes.size();
     if (N < 3) return false;
     const PlanNode& gout = plan.nodes.back();
@@ -395,8 +398,10 @@ bool detect_fused(const Plan& plan, FusedBuild& fb) {
         next_bus += 2;
         for (int end : r.kids) {
             // walk upstream: end -> ... -> sampler
+            // accepted shape: sampler -> [biquad] -> [delay] -> (volume|pan)*
             std::vector<int> chain;
             int cur = end;
+            int bq = -1, dl = -1;
             for (;;) {
                 const PlanNode& n = plan.nodes[cur];
                 if (covered[cur]) return false;
@@ -405,9 +410,21 @@ bool detect_fused(const Plan& plan, FusedBuild& fb) {
                     covered[cur] = 1;
                     break;
                 }
-                if (!(n.kind == K_VOLUME || n.kind == K_PAN) || n.n_in != 2 || n.n_out != 2) return false;
+                if (n.n_in != 2 || n.n_out != 2) return false;
+                if (n.kind == K_VOLUME || n.kind == K_PAN) {
+                    if (bq >= 0 || dl >= 0) return false;  // gain stages before the filter: generic executor
+                    chain.push_back(cur);
+                } else if (n.kind == K_DELAY) {
+                    if (bq >= 0 || dl >= 0) return false;
+                    if (graph.nodes[n.slot].init.loop_end < 64) return false;  // shorter than one k_chain tile
+                    dl = cur;
+                } else if (n.kind == K_BIQUAD) {
+                    if (bq >= 0) return false;
+                    bq = cur;
+                } else {
+                    return false;
+                }
                 covered[cur] = 1;
-                chain.push_back(cur);
                 int src;
                 if (!stereo_src(n, 0, src)) return false;
                 cur = src;
@@ -415,6 +432,9 @@ bool detect_fused(const Plan& plan, FusedBuild& fb) {
             if ((int)chain.size() > FW_MAX_STAGES - 1) return false;
             VoiceDesc vd;
             memset(&vd, 0, sizeof(vd));
+            vd.bq_state = bq >= 0 ? (int)plan.nodes[bq].slot : -1;
+            vd.dl_state = dl >= 0 ? (int)plan.nodes[dl].slot : -1;
+            if (bq >= 0 || dl >= 0) fb.has_fx = true;
             vd.sampler_state = (int)plan.nodes[cur].slot;
             vd.n_stages = (int)chain.size();
             for (int j = 0; j < vd.n_stages; ++j) {  // schedule order: nearest the sampler first
@@ -474,6 +494,11 @@ bool detect_fused(const Plan& plan, FusedBuild& fb) {
     fb.root_buf[0] = rb;
     fb.root_buf[1] = rb + 1;
     fb.n_bus = next_bus;
+    if (fb.has_fx) {  // k_chain: whole tiles, one workgroup per leaf of <= 32 voices
+        if (mbf % 64 != 0) return false;
+        for (const LeafDesc& l : fb.leaves)
+            if (l.ports > 32) return false;
+    }
     return !fb.voices.empty();
 }
 
@@ -695,7 +720,9 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
     // 5. fused voice-bank plan
     c->fused = false;
     FusedBuild fb;
-    if (!c->force_generic && detect_fused(plan, fb)) {
+    c->fused_fx = false;
+    if (!c->force_generic && detect_fused(plan, c->graph, c->mbf, fb)) {
+        c->fused_fx = fb.has_fx;
         c->n_voices = (int)fb.voices.size();
         c->n_leaves = (int)fb.leaves.size();
         c->n_bus = fb.n_bus;
@@ -883,12 +910,14 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     fv.n_leaves = c->n_leaves;
     fv.stride = c->stride;
     fv.frames = (int)c->mbf;
+    fv.ext = c->d_ext.as<float>();
     hipEvent_t e0, e1;
     timer_begin(c, 1, &e0, &e1);
     LCHK(c, launch_voice_control(c->stream, fv, K, cmd_block0));
     timer_end(c, e1);
     timer_begin(c, 0, &e0, &e1);
-    LCHK(c, launch_leaf_sum(c->stream, fv, K));
+    if (c->fused_fx) LCHK(c, launch_chain(c->stream, fv, K, cmd_block0));
+    else LCHK(c, launch_leaf_sum(c->stream, fv, K));
     timer_end(c, e1);
     timer_begin(c, 2, &e0, &e1);
     if (!c->up_level_cnt.empty()) {
@@ -1128,7 +1157,7 @@ int fwgpu_schedule_upload(fwgpu_ctx* c, const fwgpu_sched_node* sn, uint32_t n_n
     return install_plan(c, plan);
 }
 
-int fwgpu_plan_kind(fwgpu_ctx* c) { return c->have_plan ? (c->fused && !c->force_generic ? 1 : 0) : -1; }
+int fwgpu_plan_kind(fwgpu_ctx* c) { return c->have_plan ? (c->fused && !c->force_generic ? (c->fused_fx ? 2 : 1) : 0) : -1; }
 int fwgpu_plan_num_levels(fwgpu_ctx* c) { return c->have_plan ? c->plan.num_levels : -1; }
 int fwgpu_plan_node_level(fwgpu_ctx* c, int64_t node) {
     if (!c->have_plan || !c->graph.get(node)) return -1;

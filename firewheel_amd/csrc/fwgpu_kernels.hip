@@ -808,21 +808,24 @@ struct TailJob {
 };
 
 // Writes the compact record (always) and the full descriptor (only when the leaf kernel will need it).
+// `fx`: the voice has a biquad / delay (k_chain plan) — its source is needed even when the chain output is
+// silent, and every block that is not VB_SIMPLE carries a full descriptor.
 __device__ __forceinline__ void put_blk(const FusedView& fv, int vi, int kk, const VoiceBlk& d, uint32_t gset,
-                                        uint64_t sample_frames) {
+                                        uint64_t sample_frames, bool fx) {
     VoiceRef ref;
     ref.src_l = d.src_l;
-    ref.r_delta = ((d.flags & VB_SIMPLE) && !(d.flags & VB_MONO)) ? (uint32_t)sample_frames : 0u;
+    ref.r_delta = ((d.flags & VB_SIMPLE) && !(d.flags & (VB_MONO | VB_SRC_ZERO))) ? (uint32_t)sample_frames : 0u;
     ref.flags_gset = (d.flags & 0xffu) | (gset << 8);
     fv.refs[(size_t)vi * fv.refs_stride + kk] = ref;  // [voice][block]: the tail lanes store 1 KiB contiguous
-    if (!(d.flags & (VB_SIMPLE | VB_SILENT))) fv.blks[(size_t)kk * fv.n_voices + vi] = d;
+    const bool need_full = fx ? !(d.flags & VB_SIMPLE) : !(d.flags & (VB_SIMPLE | VB_SILENT));
+    if (need_full) fv.blks[(size_t)kk * fv.n_voices + vi] = d;
 }
 
 // Steady tail: blocks k_first .. K-1 share one descriptor; only the playhead moves, by +frames with a wrap at
 // the loop end (nodes/sampler.rs:445-484) — closed form (base + j*frames) mod L, so the 64 lanes of the
 // voice's wave fill 64 blocks at a time.  Returns the playhead the reference holds after block K-1.
 __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int lane, int k_first, int K, const TailJob& job,
-                                                const SampleDesc& sd, uint32_t gset, bool simple_ok) {
+                                                const SampleDesc& sd, uint32_t gset, bool simple_ok, bool fx) {
     const int frames = fv.frames;
     const uint64_t fr = (uint64_t)frames;
     VoiceBlk t;
@@ -837,7 +840,8 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
         t.g[j][0] = job.g.g[j][0];
         t.g[j][1] = job.g.g[j][1];
     }
-    const bool contiguous_f32 = !(job.flags & VB_SILENT) && job.sample >= 0 && sd.format == FMT_P_F32;
+    const bool no_src = (job.flags & VB_SRC_ZERO) || (!fx && (job.flags & VB_SILENT));
+    const bool contiguous_f32 = !no_src && job.sample >= 0 && sd.format == FMT_P_F32;
     const uint64_t n = (uint64_t)(K - k_first);
     if (job.mode == 1) {
         // all quantities fit 32 bits whenever the loop does (the usual case): avoid 64-bit division
@@ -876,7 +880,7 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
                     if (simple_ok) t.flags |= VB_SIMPLE;
                 }
             }
-            put_blk(fv, vi, k2, t, gset, sd.frames);
+            put_blk(fv, vi, k2, t, gset, sd.frames, fx);
             r += step;
             if (r >= L) r -= L;
         }
@@ -893,11 +897,13 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
                 t.src_r = (t.flags & VB_MONO) ? t.src_l : t.src_l + sd.frames;
                 if (simple_ok) t.flags |= VB_SIMPLE;
             }
-            put_blk(fv, vi, k2, t, gset, sd.frames);
+            put_blk(fv, vi, k2, t, gset, sd.frames, fx);
         }
         return job.playhead + n * fr;
     }
-    for (int k2 = k_first + lane; k2 < K; k2 += WAVE) put_blk(fv, vi, k2, t, 0u, sd.frames);
+    // nothing moves (mode 0 <=> the sampler is frozen): with fx the block still runs (zeros in, constant gains)
+    if (fx && simple_ok) t.flags |= VB_SIMPLE;
+    for (int k2 = k_first + lane; k2 < K; k2 += WAVE) put_blk(fv, vi, k2, t, fx ? gset : 0u, sd.frames, fx);
     return job.playhead;
 }
 
@@ -912,6 +918,7 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
     const VoiceDesc vd = fv.voices[vi];
     const int frames = fv.frames;
     const bool simple_frames = (frames & 3) == 0;
+    const bool fx = vd.bq_state >= 0 || vd.dl_state >= 0;  // k_chain plan voice
 
     int last_cmd = -1;
     if (fv.n_cmds) {
@@ -950,10 +957,12 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                 if (vc.mode == 2 && job.playhead + (uint64_t)K * (uint64_t)frames > sd.frames) ok = false;  // ends in this call
             }
             if (ok) {
-                const bool simple_ok = !(job.flags & VB_SILENT) && job.sample >= 0 && sd.format == FMT_P_F32 &&
-                                       simple_frames && sd.frames < 0xffffffffull;
+                const bool no_src = (job.flags & VB_SRC_ZERO) || (!fx && (job.flags & VB_SILENT));
+                const bool simple_ok = no_src ? (fx && simple_frames)
+                                              : (job.sample >= 0 && sd.format == FMT_P_F32 && simple_frames &&
+                                                 sd.frames < 0xffffffffull);
                 if (simple_ok && w0) my_gsets[0] = job.g;
-                uint64_t ph = steady_tail(fv, vi, lane, 0, K, job, sd, 0u, simple_ok);
+                uint64_t ph = steady_tail(fv, vi, lane, 0, K, job, sd, 0u, simple_ok, fx);
                 if (w0 && vc.mode != 0) fv.states[vd.sampler_state].playhead = ph;
                 return;
             }
@@ -1046,6 +1055,9 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                 }
             }
         }
+        // a biquad / delay between the sampler and the gain stages never reports silence (SPEC nodes: out mask 0)
+        const bool src_silent = silent;
+        if (fx) silent = false;
         // ---- chain stages in schedule order
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
@@ -1095,11 +1107,13 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                 }
             }
         }
+        if (!src_silent && (fx || !silent)) blk_set_source(d, sd, frames);
+        else if (src_silent && fx && (d.flags >> VB_RAMP_SHIFT) == 0 && simple_frames) d.flags |= VB_SIMPLE;
+        if (src_silent) d.flags |= VB_SRC_ZERO;
         if (silent) d.flags |= VB_SILENT;
-        else blk_set_source(d, sd, frames);
         {
             uint32_t gs = pick_gset(d);
-            if (w0) put_blk(fv, vi, k, d, gs, sd.frames);
+            if (w0) put_blk(fv, vi, k, d, gs, sd.frames, fx);
         }
 
         // ---- steady from the next block on?
@@ -1124,7 +1138,7 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                 else steady = false;  // the one-shot ends inside this call: stay on the exact path
             }
         }
-        bool sil = upstream_silent;
+        bool sil = upstream_silent && !fx;
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
             if (j >= vd.n_stages || !steady) break;
@@ -1144,7 +1158,7 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
         // smoother and `last` for one stalled at its f32 fixed point (Q28).
         TailJob job;
         job.mode = mode;
-        job.flags = sil ? VB_SILENT : 0u;
+        job.flags = (sil ? VB_SILENT : 0u) | (upstream_silent ? VB_SRC_ZERO : 0u);
         job.sample = upstream_silent ? -1 : ss.sample;
         job.playhead = ss.playhead;
         job.loop_start = ss.loop_start;
@@ -1176,7 +1190,10 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
         if (k + 1 < K) {
             uint32_t tail_gs = 0;
             bool simple_ok = false;
-            if (!sil && !upstream_silent && sd.format == FMT_P_F32 && simple_frames && sd.frames < 0xffffffffull) {
+            const bool tail_simple = fx ? (simple_frames && (upstream_silent || (sd.format == FMT_P_F32 && sd.frames < 0xffffffffull)))
+                                        : (!sil && !upstream_silent && sd.format == FMT_P_F32 && simple_frames &&
+                                           sd.frames < 0xffffffffull);
+            if (tail_simple) {
                 VoiceBlk probe;  // every non-wrapping tail block is VB_SIMPLE with the same gains: one gain set
                 probe.flags = VB_SIMPLE;
 #pragma unroll
@@ -1187,7 +1204,7 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                 tail_gs = pick_gset(probe);
                 simple_ok = (probe.flags & VB_SIMPLE) != 0;  // false when the voice ran out of gain-set slots
             }
-            uint64_t ph = steady_tail(fv, vi, lane, k + 1, K, job, sd, tail_gs, simple_ok);
+            uint64_t ph = steady_tail(fv, vi, lane, k + 1, K, job, sd, tail_gs, simple_ok, fx);
             if (mode != 0) ss.playhead = ph;
         }
         break;
@@ -1380,6 +1397,448 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv) {
     }
     // out mask: all-silent -> both flagged; 1-port copy -> passthrough (sum.rs:58-65); else 0
     if (lane < 2) bflags[ld.out_buf + lane] = all_silent ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ fused chain plan (config 3): k_chain
+// Voices of the shape  sampler -> [biquad] -> [delay] -> [volume|pan]* -> leaf SumNode.  The biquad (SPEC: DF1,
+// unfused f32, left to right) is a serial recurrence in time, so time cannot be split across workgroups; what is
+// parallel is the voices.  One workgroup owns one leaf SumNode (<= 32 voices) for all K blocks of the call and
+// walks time in tiles of CH_TT frames through a 4-stage software pipeline over LDS (one barrier per step):
+//   S1  (8 worker waves, lane = (voice, 4 frames)): source fetch + sampler gain; the non-recursive half of the
+//       biquad  A[n] = ((b0*x[n]) + (b1*x[n-1])) + (b2*x[n-2])  -> LDS, L/R interleaved
+//   S2  (1 wave, lane = voice, L/R packed in v_pk_*_f32): y[n] = (A[n] - (a1*y[n-1])) - (a2*y[n-2]), in place
+//   S3a (the same worker lanes, two tiles later): delay-line read-modify-write in HBM, dry/wet mix, gain stages
+//   S3b (1 wave): the leaf SumNode in the reference's port order (nodes/sum.rs:67-133) -> partial mix bus
+// Every rounding is the one the oracle performs (products and sums separately, same order), so the result is
+// bit-identical to the generic executor.  HBM traffic per stereo voice-sample: 8 B source + 8 B ring read + 8 B
+// ring write = the 24 B of SURVEY §8d.
+#define CH_TT 64
+#define CH_PITCH 132  // floats per voice row: 64 frames x (L,R) + 4 -> the 32 S2 lanes hit disjoint bank groups
+#define CH_NBUF 4
+#define CH_WORKERS 8
+#define CH_THREADS ((CH_WORKERS + 2) * WAVE)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// the last CMD_SET_COEFS for (state, block), if any
+__device__ inline bool chain_find_coefs(const Cmd* cmds, int n_cmds, int state_idx, uint32_t block, float co[5]) {
+    int lo = 0, hi = n_cmds;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        const Cmd& c = cmds[mid];
+        bool less = c.state < state_idx || (c.state == state_idx && c.block < block);
+        if (less) lo = mid + 1;
+        else hi = mid;
+    }
+    bool found = false;
+    for (int i = lo; i < n_cmds; ++i) {
+        const Cmd c = cmds[i];
+        if (c.state != state_idx || c.block != block) break;
+        if (c.type != CMD_SET_COEFS) continue;
+        co[0] = c.f0;
+        co[1] = __int_as_float(c.i0);
+        co[2] = __int_as_float(c.i1);
+        unsigned long long u = (unsigned long long)__double_as_longlong(c.d0);
+        co[3] = __int_as_float((int)(u & 0xffffffffull));
+        co[4] = __int_as_float((int)(u >> 32));
+        found = true;
+    }
+    return found;
+}
+// delay parameters: fb (p0), mix (p1), dry (gain)
+__device__ inline void chain_delay_cmds(const Cmd* cmds, int n_cmds, int state_idx, uint32_t block, float& fb, float& mix,
+                                        float& dry) {
+    int lo = 0, hi = n_cmds;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        const Cmd& c = cmds[mid];
+        bool less = c.state < state_idx || (c.state == state_idx && c.block < block);
+        if (less) lo = mid + 1;
+        else hi = mid;
+    }
+    for (int i = lo; i < n_cmds; ++i) {
+        const Cmd c = cmds[i];
+        if (c.state != state_idx || c.block != block) break;
+        if (c.type == CMD_SET_P0) fb = c.f0;
+        else if (c.type == CMD_SET_P1) mix = c.f0;
+        else if (c.type == CMD_SET_GAIN) dry = c.f0;
+    }
+}
+
+struct ChainInfo {  // what a worker lane carries from S1 of a tile to S3a of the same tile (two steps later)
+    uint32_t flags;                    // VB_* of the tile's block, ramp bits included
+    float g[FW_MAX_STAGES - 1][2];     // constant post-gain stages (1..)
+};
+
+__global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint32_t cmd_block0) {
+    __shared__ float tile[CH_NBUF][32][CH_PITCH];
+    __shared__ float hist[2][32][4];       // x[n-2], x[n-1] (post sampler gain) of L then R, per tile parity
+    __shared__ uint32_t silf[CH_NBUF][32];  // chain output cleared + flagged silent (VB_SILENT) per voice
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    const LeafDesc ld = fv.leaves[blockIdx.x];
+    const int ports = ld.ports;
+    const int frames = fv.frames;
+    const int tpb = frames / CH_TT;  // the plan guarantees frames % CH_TT == 0
+    const int n_tiles = K * tpb;
+    const bool is_worker = wave >= 1 && wave <= CH_WORKERS;
+    const bool is_serial = wave == 0;
+
+    // ---- per-role persistent registers
+    // worker lane = (voice v, frame quad q)
+    const int wl = (wave - 1) * WAVE + lane;
+    const int v = is_worker ? (wl >> 4) : lane;
+    const int q = wl & 15;
+    const bool active = v < ports && (is_worker || (is_serial && lane < 32));
+    const int voice = ld.first_voice + (active ? v : 0);
+    VoiceDesc vd = fv.voices[voice];
+    const bool has_bq = active && vd.bq_state >= 0, has_dl = active && vd.dl_state >= 0;
+    float b0 = 1.f, b1 = 0.f, b2 = 0.f, a1 = 0.f, a2 = 0.f;
+    float* bq_ext = nullptr;
+    v2f y1 = {0.f, 0.f}, y2 = {0.f, 0.f};
+    if (has_bq) {
+        bq_ext = fv.ext + fv.states[vd.bq_state].ext_off;
+        b0 = bq_ext[0];
+        b1 = bq_ext[1];
+        b2 = bq_ext[2];
+        a1 = bq_ext[3];
+        a2 = bq_ext[4];
+        if (is_serial) {
+            y1 = (v2f){bq_ext[5 + 2], bq_ext[9 + 2]};
+            y2 = (v2f){bq_ext[5 + 3], bq_ext[9 + 3]};
+        }
+        if (is_worker && q == 0) {
+            hist[0][v][0] = bq_ext[5 + 1];
+            hist[0][v][1] = bq_ext[5 + 0];
+            hist[0][v][2] = bq_ext[9 + 1];
+            hist[0][v][3] = bq_ext[9 + 0];
+        }
+    }
+    uint32_t D = 1, pos = 0;
+    float fb = 0.f, mix = 0.f, dry = 1.f;
+    float* ring_l = nullptr;
+    if (has_dl && is_worker) {
+        const NodeState* ds = &fv.states[vd.dl_state];
+        D = (uint32_t)ds->loop_end;
+        pos = (uint32_t)ds->playhead;
+        fb = ds->p0;
+        mix = ds->p1;
+        dry = ds->gain;
+        ring_l = fv.ext + ds->ext_off;
+    }
+    // wave-uniform: does any voice of this leaf have a biquad?
+    const bool any_bq = __syncthreads_or(has_bq ? 1 : 0) != 0;
+
+    // S1 per-block registers
+    const float* src_l = nullptr;
+    uint32_t r_delta = 0;
+    float g0l = 1.f, g0r = 1.f;
+    ChainInfo inf0, inf1, inf2;  // tiles s, s-1, s-2
+    inf0.flags = inf1.flags = inf2.flags = VB_SRC_ZERO | VB_SIMPLE;
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
+        inf0.g[j][0] = inf0.g[j][1] = inf1.g[j][0] = inf1.g[j][1] = inf2.g[j][0] = inf2.g[j][1] = 1.f;
+    v4f last_xl = splat(0.f), last_xr = splat(0.f);  // the newest S1 tile's x (q == 15 lanes write them back at the end)
+
+    // role-local (block, tile-in-block) counters: S1 runs on tile s, S2 on s-1, S3a on s-2, S3b on s-3
+    int k1 = 0, t1 = 0, k2 = 0, t2 = 0, k3 = 0, t3 = 0, k4 = 0, t4 = 0;
+    const uint64_t port_mask = mask_all_silent_bits(ports);
+    const bool masked = !(ports == 2 || ports == 3 || ports == 4);  // sum.rs:67-133 (Q13)
+
+    for (int s = 0; s < n_tiles + 3; ++s) {
+        if (is_worker) {
+            // ================= issue the HBM loads of both stages first
+            const bool do1 = active && s < n_tiles;
+            const bool do3 = active && s >= 2 && s - 2 < n_tiles;
+            v4f xl = splat(0.f), xr = splat(0.f);
+            bool slow1 = false;
+            if (do1) {
+                if (t1 == 0) {  // new block: this voice's descriptor
+                    const VoiceRef ref = fv.refs[(size_t)voice * fv.refs_stride + k1];
+                    const uint32_t fl = ref.flags_gset & 0xffu;
+                    if (fl & VB_SIMPLE) {
+                        const GainSet gs = fv.gsets[(size_t)voice * FW_GSETS + (ref.flags_gset >> 8)];
+                        inf0.flags = fl;
+                        g0l = gs.g[0][0];
+                        g0r = gs.g[0][1];
+#pragma unroll
+                        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+                            inf0.g[j][0] = gs.g[j + 1][0];
+                            inf0.g[j][1] = gs.g[j + 1][1];
+                        }
+                        src_l = ref.src_l;
+                        r_delta = ref.r_delta;
+                    } else {
+                        const VoiceBlk* d = &fv.blks[(size_t)k1 * fv.n_voices + voice];
+                        inf0.flags = d->flags;
+#pragma unroll
+                        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+                            inf0.g[j][0] = d->g[j + 1][0];
+                            inf0.g[j][1] = d->g[j + 1][1];
+                        }
+                    }
+                    if (has_bq && fv.n_cmds) {
+                        float co[5];
+                        if (chain_find_coefs(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0 + (uint32_t)k1, co)) {
+                            b0 = co[0];
+                            b1 = co[1];
+                            b2 = co[2];
+                        }
+                    }
+                }
+                const int f0 = t1 * CH_TT + 4 * q;
+                if (inf0.flags & VB_SIMPLE) {
+                    if (!(inf0.flags & VB_SRC_ZERO)) {
+                        xl = gload4(src_l + f0);
+                        xr = gload4(src_l + r_delta + f0);
+                    }
+                } else {
+                    slow1 = true;
+                }
+            }
+            v4f dl4 = splat(0.f), dr4 = splat(0.f);
+            uint32_t slot = 0;
+            bool ring_vec = false;
+            if (do3 && has_dl) {
+                if (t3 == 0 && fv.n_cmds) chain_delay_cmds(fv.cmds, fv.n_cmds, vd.dl_state, cmd_block0 + (uint32_t)k3, fb, mix, dry);
+                slot = pos + 4u * (uint32_t)q;
+                if (slot >= D) slot -= D;
+                ring_vec = slot + 4u <= D;
+                if (ring_vec) {
+                    dl4 = *(const v4f_u*)(ring_l + slot);
+                    dr4 = *(const v4f_u*)(ring_l + D + slot);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        uint32_t sj = slot + (uint32_t)j;
+                        if (sj >= D) sj -= D;
+                        dl4[j] = ring_l[sj];
+                        dr4[j] = ring_l[D + sj];
+                    }
+                }
+            }
+            // ================= S3a on tile s-2: delay RMW + gain stages, in place in LDS
+            if (do3) {
+                float* row = &tile[(s - 2) & (CH_NBUF - 1)][v][8 * q];
+                const v4f p0 = *(const v4f*)row, p1 = *(const v4f*)(row + 4);
+                v4f yl = (v4f){p0[0], p0[2], p1[0], p1[2]};
+                v4f yr = (v4f){p0[1], p0[3], p1[1], p1[3]};
+                if (has_dl) {
+                    const v4f nl = yl + (dl4 * fb), nr = yr + (dr4 * fb);  // ring[p] = x + (d*fb)
+                    if (ring_vec) {
+                        *(v4f_u*)(ring_l + slot) = nl;
+                        *(v4f_u*)(ring_l + D + slot) = nr;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            uint32_t sj = slot + (uint32_t)j;
+                            if (sj >= D) sj -= D;
+                            ring_l[sj] = nl[j];
+                            ring_l[D + sj] = nr[j];
+                        }
+                    }
+                    yl = (yl * dry) + (dl4 * mix);  // out = (x*dry) + (d*mix)
+                    yr = (yr * dry) + (dr4 * mix);
+                    pos += CH_TT;
+                    if (pos >= D) pos -= D;
+                }
+                const uint32_t rbits = inf2.flags >> VB_RAMP_SHIFT;
+                if (inf2.flags & VB_SILENT) {  // muted gain stage / silent chain: cleared buffer
+                    yl = yr = splat(0.f);
+                } else if (rbits == 0) {
+#pragma unroll
+                    for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+                        if (j + 1 >= fv.n_gain_stages) break;
+                        yl = yl * inf2.g[j][0];
+                        yr = yr * inf2.g[j][1];
+                    }
+                } else {
+                    const int f0 = t3 * CH_TT + 4 * q;
+                    const float* rb = fv.ramps + ((size_t)k3 * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
+#pragma unroll
+                    for (int j = 1; j < FW_MAX_STAGES; ++j) {
+                        if (j >= fv.n_gain_stages) break;
+                        v4f gl = (rbits >> (2 * j)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j) * fv.stride) : splat(inf2.g[j - 1][0]);
+                        v4f gr = (rbits >> (2 * j + 1)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j + 1) * fv.stride) : splat(inf2.g[j - 1][1]);
+                        yl = yl * gl;
+                        yr = yr * gr;
+                    }
+                }
+                *(v4f*)row = (v4f){yl[0], yr[0], yl[1], yr[1]};
+                *(v4f*)(row + 4) = (v4f){yl[2], yr[2], yl[3], yr[3]};
+                if (q == 0) silf[(s - 2) & (CH_NBUF - 1)][v] = (inf2.flags & VB_SILENT) ? 1u : 0u;
+                if (++t3 == tpb) {
+                    t3 = 0;
+                    ++k3;
+                }
+            }
+            // ================= S1 on tile s: sampler gain + the feed-forward half of the biquad -> LDS
+            if (do1) {
+                const int f0 = t1 * CH_TT + 4 * q;
+                if (slow1) {  // ramps, loop wrap, one-shot tail, non-planar-f32 source: full descriptor
+                    const VoiceBlk d = fv.blks[(size_t)k1 * fv.n_voices + voice];
+                    if (!(d.flags & VB_SRC_ZERO)) {
+                        const bool mono = d.flags & VB_MONO;
+                        if (d.src_l) {
+                            xl = *(const v4f_u*)(d.src_l + f0);
+                            xr = mono ? xl : *(const v4f_u*)(d.src_r + f0);
+                        } else {
+                            const SampleDesc sd = fv.samples[d.sample];
+                            Fetch ft;
+                            ft.off0 = d.off0;
+                            ft.off1 = d.off1;
+                            ft.n1 = d.n1;
+                            ft.wrap = (d.flags & VB_WRAP) ? 1 : 0;
+                            ft.tail_zero = (d.flags & VB_TAIL_ZERO) ? 1 : 0;
+                            xl = sample_fetch4(sd, 0, ft, (uint32_t)f0, (uint32_t)frames);
+                            xr = mono ? xl : sample_fetch4(sd, 1, ft, (uint32_t)f0, (uint32_t)frames);
+                        }
+                        const uint32_t rbits = d.flags >> VB_RAMP_SHIFT;
+                        const float* rb = fv.ramps + ((size_t)k1 * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
+                        v4f gl = rbits & 1u ? *(const v4f*)rb : splat(d.g[0][0]);
+                        v4f gr = rbits & 2u ? *(const v4f*)(rb + fv.stride) : splat(d.g[0][1]);
+                        xl = xl * gl;  // sampler.rs:530-533
+                        xr = xr * gr;
+                    }
+                } else if (!(inf0.flags & VB_SRC_ZERO)) {
+                    xl = xl * g0l;
+                    xr = xr * g0r;
+                }
+                last_xl = xl;
+                last_xr = xr;
+                v4f al = xl, ar = xr;
+                if (has_bq) {
+                    // x[n-1], x[n-2] of this lane's first frame: the previous quad (lane - 1) or the previous tile
+                    float pl1 = __shfl_up(xl[3], 1), pl2 = __shfl_up(xl[2], 1);
+                    float pr1 = __shfl_up(xr[3], 1), pr2 = __shfl_up(xr[2], 1);
+                    if (q == 0) {
+                        const float* h = hist[s & 1][v];
+                        pl2 = h[0];
+                        pl1 = h[1];
+                        pr2 = h[2];
+                        pr1 = h[3];
+                    }
+                    al[0] = ((b0 * xl[0]) + (b1 * pl1)) + (b2 * pl2);
+                    al[1] = ((b0 * xl[1]) + (b1 * xl[0])) + (b2 * pl1);
+                    al[2] = ((b0 * xl[2]) + (b1 * xl[1])) + (b2 * xl[0]);
+                    al[3] = ((b0 * xl[3]) + (b1 * xl[2])) + (b2 * xl[1]);
+                    ar[0] = ((b0 * xr[0]) + (b1 * pr1)) + (b2 * pr2);
+                    ar[1] = ((b0 * xr[1]) + (b1 * xr[0])) + (b2 * pr1);
+                    ar[2] = ((b0 * xr[2]) + (b1 * xr[1])) + (b2 * xr[0]);
+                    ar[3] = ((b0 * xr[3]) + (b1 * xr[2])) + (b2 * xr[1]);
+                    if (q == 15) {
+                        float* h = hist[(s & 1) ^ 1][v];
+                        h[0] = xl[2];
+                        h[1] = xl[3];
+                        h[2] = xr[2];
+                        h[3] = xr[3];
+                    }
+                }
+                float* row = &tile[s & (CH_NBUF - 1)][v][8 * q];
+                *(v4f*)row = (v4f){al[0], ar[0], al[1], ar[1]};
+                *(v4f*)(row + 4) = (v4f){al[2], ar[2], al[3], ar[3]};
+                if (++t1 == tpb) {
+                    t1 = 0;
+                    ++k1;
+                }
+            }
+            inf2 = inf1;
+            inf1 = inf0;
+        } else if (is_serial) {
+            // ================= S2 on tile s-1: the recursive half of the biquad, lane = voice, (L,R) packed
+            if (any_bq && s >= 1 && s - 1 < n_tiles) {
+                if (has_bq && t2 == 0 && fv.n_cmds) {
+                    float co[5];
+                    if (chain_find_coefs(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0 + (uint32_t)k2, co)) {
+                        a1 = co[3];
+                        a2 = co[4];
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) bq_ext[j] = co[j];
+                    }
+                }
+                if (has_bq) {
+                    float* row = &tile[(s - 1) & (CH_NBUF - 1)][v][0];
+                    const v2f A1 = {a1, a1}, A2 = {a2, a2};
+                    v4f cur[4], nxt[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cur[u] = *(const v4f*)(row + 4 * u);
+#pragma unroll
+                    for (int c = 0; c < CH_TT / 8; ++c) {
+                        if (c + 1 < CH_TT / 8) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) nxt[u] = *(const v4f*)(row + 16 * (c + 1) + 4 * u);
+                        }
+                        v4f o[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const v2f s0 = {cur[u][0], cur[u][1]}, s1 = {cur[u][2], cur[u][3]};
+                            const v2f o0 = (s0 - (A1 * y1)) - (A2 * y2);  // acc - (a1*y1) - (a2*y2)
+                            y2 = y1;
+                            y1 = o0;
+                            const v2f o1 = (s1 - (A1 * y1)) - (A2 * y2);
+                            y2 = y1;
+                            y1 = o1;
+                            o[u] = (v4f){o0[0], o0[1], o1[0], o1[1]};
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) *(v4f*)(row + 16 * c + 4 * u) = o[u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+                    }
+                }
+                if (++t2 == tpb) {
+                    t2 = 0;
+                    ++k2;
+                }
+            }
+        } else {
+            // ================= S3b on tile s-3: the leaf SumNode, lane = frame pair, ports in order
+            if (s >= 3 && lane < 32) {
+                const int buf = (s - 3) & (CH_NBUF - 1);
+                uint64_t silent_ports = 0;
+                for (int p = 0; p < ports; ++p) silent_ports |= (uint64_t)(silf[buf][p] & 1u) << p;
+                const bool all_silent = silent_ports == port_mask;
+                v4f acc = splat(0.f);
+                if (!all_silent) {
+                    acc = *(const v4f*)&tile[buf][0][4 * lane];  // sum.rs:117 copy port 0 (also when silent: zeros)
+                    for (int p = 1; p < ports; ++p) {
+                        if (masked && ((silent_ports >> p) & 1ull)) continue;  // :122-124
+                        acc = acc + *(const v4f*)&tile[buf][p][4 * lane];
+                    }
+                }
+                float* bus = fv.bus + (size_t)k4 * fv.bus_blk_stride + (size_t)ld.out_buf * fv.stride + t4 * CH_TT + 2 * lane;
+                *(float2*)bus = make_float2(acc[0], acc[2]);
+                *(float2*)(bus + fv.stride) = make_float2(acc[1], acc[3]);
+                if (t4 == 0 && lane < 2) fv.bus_flags[(size_t)k4 * fv.bus_flags_blk_stride + ld.out_buf + lane] = all_silent ? 1 : 0;
+                if (++t4 == tpb) {
+                    t4 = 0;
+                    ++k4;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- write the node state back
+    if (is_worker && active) {
+        if (has_bq && q == 15) {
+            bq_ext[5 + 0] = last_xl[3];
+            bq_ext[5 + 1] = last_xl[2];
+            bq_ext[9 + 0] = last_xr[3];
+            bq_ext[9 + 1] = last_xr[2];
+        }
+        if (has_dl && q == 0) {
+            NodeState* ds = &fv.states[vd.dl_state];
+            ds->playhead = (uint64_t)pos;
+            ds->p0 = fb;
+            ds->p1 = mix;
+            ds->gain = dry;
+        }
+    }
+    if (is_serial && has_bq) {
+        bq_ext[5 + 2] = y1[0];
+        bq_ext[5 + 3] = y2[0];
+        bq_ext[9 + 2] = y1[1];
+        bq_ext[9 + 3] = y2[1];
+    }
 }
 
 // ------------------------------------------------------------------ FIR convolution bank on the matrix cores
@@ -1654,6 +2113,11 @@ int launch_get_flags(hipStream_t s, const uint8_t* flags, const int* d_bufs, int
 int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0) {
     if (fv.n_voices <= 0) return 0;
     hipLaunchKernelGGL(k_voice_control, dim3((fv.n_voices + 3) / 4), dim3(256), 0, s, fv, K, cmd_block0);
+    return (int)hipGetLastError();
+}
+int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0) {
+    if (fv.n_leaves <= 0 || K <= 0) return 0;
+    hipLaunchKernelGGL(k_chain, dim3(fv.n_leaves), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
     return (int)hipGetLastError();
 }
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {

@@ -52,6 +52,7 @@ struct FusedView {
     int n_leaves;
     int stride;
     int frames;
+    float* ext;  // biquad coefficients + history, delay rings (k_chain plan)
 };
 
 int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0);
@@ -70,6 +71,7 @@ int launch_set_flags(hipStream_t s, uint8_t* flags, const int* d_bufs, int n, ui
 int launch_get_flags(hipStream_t s, const uint8_t* flags, const int* d_bufs, int n, uint64_t* d_mask);
 int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0);
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K);
+int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0);
 
 // host-side mirror of the StateInit record consumed by k_scatter_states
 struct StateInitHost {

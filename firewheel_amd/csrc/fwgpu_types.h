@@ -86,11 +86,13 @@ static_assert(sizeof(Cmd) == 40, "Cmd layout");
 // ---------------------------------------------------------------- fused voice-bank plan
 #define FW_MAX_STAGES 4  // sampler gain + up to 3 chain nodes (volume / pan)
 
-struct VoiceDesc {  // static per voice chain: sampler -> [volume|pan]* -> leaf sum port
+struct VoiceDesc {  // static per voice chain: sampler -> [biquad] -> [delay] -> [volume|pan]* -> leaf sum port
     int sampler_state;
-    int n_stages;                      // chain nodes after the sampler
+    int n_stages;                      // GAIN stages (volume / pan) after the sampler
     int stage_kind[FW_MAX_STAGES - 1];
     int stage_state[FW_MAX_STAGES - 1];
+    int bq_state;                      // biquad between the sampler and the gain stages, -1 = none (k_chain plan)
+    int dl_state;                      // delay after the biquad, -1 = none
 };
 
 // per (block, voice) record written by the control kernels, read by the leaf kernel (80 B)
@@ -100,6 +102,9 @@ enum : uint32_t {
     VB_TAIL_ZERO = 4u,    // one-shot end inside the block: frames [n1, frames) are 0.0
     VB_MONO = 8u,         // 1-channel sample duplicated to both outputs (sampler.rs:546-551)
     VB_SIMPLE = 16u,      // contiguous planar-f32 source + constant gains: src_l/src_r valid, fast path
+                          //   (k_chain plan: also a VB_SRC_ZERO block with constant gains; no full VoiceBlk either way)
+    VB_SRC_ZERO = 32u,    // the sampler's output is cleared this block (differs from VB_SILENT only when a biquad /
+                          //   delay sits between the sampler and the gain stages: their tails keep ringing)
     VB_RAMP_SHIFT = 8,    // bit (VB_RAMP_SHIFT + 2*stage + ch): that gain is a per-frame ramp
 };
 struct VoiceBlk {

@@ -178,6 +178,67 @@ class StereoPanNode(_Node):  # SPEC node: constant-power pan, pan in
         self._set(0, pan, at_block)
 
 
+class StereoWidthNode(_Node):  # SPEC node: mid/side width, w >= 0 (1 = unchanged, 0 = mono), smoothed
+    KIND = 9
+
+    def __init__(self, width):
+        self.width = width
+
+    def params(self):
+        return [self.width]
+
+    def set_width(self, width, at_block=0):
+        self.width = width
+        self._set(0, width, at_block)
+
+
+class BiquadNode(_Node):  # SPEC node: RBJ biquad, Direct Form I in f32; coefficients computed on the control side (f64)
+    KIND = 10
+    LOWPASS, HIGHPASS, BANDPASS = 0, 1, 2
+
+    def __init__(self, filter_type, cutoff_hz, q=0.70710678):
+        self.filter_type, self.cutoff_hz, self.q = filter_type, cutoff_hz, q
+
+    def params(self):
+        return [float(self.filter_type), self.cutoff_hz, self.q]
+
+    def set_cutoff_hz(self, cutoff_hz, at_block=0):
+        self.cutoff_hz = cutoff_hz
+        self._set(1, cutoff_hz, at_block)
+
+    def set_q(self, q, at_block=0):
+        self.q = q
+        self._set(2, q, at_block)
+
+
+class DelayNode(_Node):  # SPEC node: integer-sample delay line (fixed length) with feedback and dry/wet mix
+    KIND = 11
+
+    def __init__(self, delay_secs, feedback=0.0, mix=0.5):
+        self.delay_secs, self.feedback, self.mix = delay_secs, feedback, mix
+
+    def params(self):
+        return [self.delay_secs, self.feedback, self.mix]
+
+    def set_feedback(self, feedback, at_block=0):
+        self.feedback = feedback
+        self._set(1, feedback, at_block)
+
+    def set_mix(self, mix, at_block=0):
+        self.mix = mix
+        self._set(2, mix, at_block)
+
+
+class FirReverbNode(_Node):  # SPEC node: convolution with an impulse-response sample (f32 MFMA Toeplitz GEMM)
+    KIND = 12
+
+    def __init__(self, impulse_response_sample):
+        self.ir = impulse_response_sample
+
+    def params(self):
+        return [float(self.ir)]
+
+
 class _RawNode(_Node):
     def __init__(self, kind, params):
         self.KIND = kind

@@ -111,7 +111,8 @@ int fwgpu_schedule_upload(fwgpu_ctx* ctx, const fwgpu_sched_node* nodes, uint32_
                           uint32_t num_buffers);
 
 /* ---- introspection of the device launch plan (tests) */
-/* 0 = generic level-batched executor, 1 = fused voice-bank plan */
+/* 0 = generic level-batched executor, 1 = fused voice-bank plan (k_leaf_sum),
+ * 2 = fused chain plan (voices with a biquad / delay: k_chain) */
 int fwgpu_plan_kind(fwgpu_ctx* ctx);
 int fwgpu_plan_num_levels(fwgpu_ctx* ctx);
 /* level of a node in the plan (graph_in = 0); negative if unknown */

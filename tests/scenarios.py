@@ -284,6 +284,120 @@ def scenario_cfg3_chain(e, n_voices=12, blocks=10, radix=4, src_frames=3000):
     return np.concatenate([out1, out2])
 
 
+def build_chain_bank(e, n_voices, radix=32, src_frames=3000, biquad=True, delay=True, with_pan=False, seed=0,
+                     fmt=PLANAR_F32, mono_every=0, min_delay_frames=64, max_delay_frames=900):
+    """config-3 shape: V x (sampler -> biquad LPF -> delay -> gain [-> pan]) -> radix sum tree -> out.
+    The shape the fused chain plan (k_chain) accepts; delays are >= one 64-frame tile."""
+    rng = np.random.default_rng(4321 + seed)
+    voices, ends = [], []
+    for v in range(n_voices):
+        s = e.sampler(100.0)
+        cur = s
+        bq = dl = pan = None
+        if biquad:
+            bq = e.biquad(v % 3, float(rng.uniform(200, 8000)), 0.707 if v % 2 else 2.5)
+            e.connect_stereo(cur, bq)
+            cur = bq
+        if delay:
+            d_frames = 64 if v == 0 else int(rng.integers(min_delay_frames, max_delay_frames))
+            dl = e.delay(d_frames / float(e.sample_rate), feedback=0.0 if v % 3 == 0 else 0.45, mix=0.5)
+            e.connect_stereo(cur, dl)
+            cur = dl
+        vol = e.volume(float(rng.uniform(20, 100)))
+        e.connect_stereo(cur, vol)
+        cur = vol
+        if with_pan:
+            pan = e.pan(float(rng.uniform(-1, 1)))
+            e.connect_stereo(cur, pan)
+            cur = pan
+        voices.append(dict(sampler=s, biquad=bq, delay=dl, volume=vol, pan=pan))
+        ends.append(cur)
+    level = ends
+    while True:
+        nxt = []
+        for i in range(0, len(level), radix):
+            grp = level[i:i + radix]
+            m = e.sum(len(grp))
+            for p, n in enumerate(grp):
+                e.connect_stereo(n, m, 2 * p)
+            nxt.append(m)
+        level = nxt
+        if len(level) == 1:
+            break
+    e.connect_stereo(level[0], e.graph_out_node)
+    e.update()
+    for v, vc in enumerate(voices):
+        ch = 1 if (mono_every and v % mono_every == 0) else 2
+        data = voice_source(seed * 100000 + 5000 + v, src_frames, ch)
+        if fmt in (PLANAR_I16, INTERLEAVED_I16):
+            raw = np.round(data * 32767).astype(np.int16)
+        else:
+            raw = data
+        if fmt <= INTERLEAVED_F32:
+            raw = raw.T.copy()
+        vc["sample"] = e.new_sample(fmt, ch, raw)
+        e.sampler_set_sample(vc["sampler"], vc["sample"])
+    return voices
+
+
+def scenario_chain_steady(e, n_voices=40, blocks=6, radix=32, **kw):
+    voices = build_chain_bank(e, n_voices, radix=radix, **kw)
+    for vc in voices:
+        e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        e.sampler_play(vc["sampler"])
+    return e.process_blocks(blocks)
+
+
+def scenario_chain_events(e, n_voices=37, radix=32, src_frames=1000, **kw):
+    """the chain plan under everything the control plane can do: loop wraps inside blocks, one-shot ends (the
+    filter / delay tails keep ringing on zeros), voices that never start, gain ramps that settle and stall, a
+    mute after the delay (silent port, tails still advance), coefficient and feedback/mix changes tagged at later
+    blocks of a multi-block call, mono sources."""
+    voices = build_chain_bank(e, n_voices, radix=radix, src_frames=src_frames, mono_every=7, **kw)
+    outs = []
+    for v, vc in enumerate(voices):
+        if v % 5 != 3:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)   # v%5==3: one-shot, ends inside the run
+        if v % 4 != 1:
+            e.sampler_play(vc["sampler"])                         # v%4==1: started late
+    outs.append(e.process_blocks(3))
+    for v, vc in enumerate(voices):
+        if v % 3 == 0:
+            e.set_param(vc["volume"], 0, 25.0 if v % 2 else 90.0, at_block=0)
+        if v % 6 == 2 and vc["biquad"] is not None:
+            e.set_param(vc["biquad"], 1, 700.0 + 10 * v, at_block=2)       # cutoff -> new coefficients at block 2
+        if v % 6 == 4 and vc["delay"] is not None:
+            e.set_param(vc["delay"], 1, 0.8, at_block=1)                   # feedback
+            e.set_param(vc["delay"], 2, 0.9, at_block=3)                   # mix (and dry)
+        if v % 10 == 4:
+            e.set_param(vc["sampler"], 0, 0.0, at_block=1)                 # sampler gain ramps to 0, then mutes
+        if v % 10 == 7:
+            e.set_param(vc["volume"], 0, 0.0, at_block=1)                  # post-delay mute: silent port
+        if v % 4 == 1:
+            e.sampler_play(vc["sampler"], at_block=1)
+        if v % 11 == 5:
+            e.sampler_pause(vc["sampler"], at_block=3)
+        if vc["pan"] is not None and v % 5 == 0:
+            e.set_param(vc["pan"], 0, -0.5, at_block=2)
+    outs.append(e.process_blocks(5))
+    outs.append(e.process_blocks(24))
+    for v, vc in enumerate(voices):
+        if v % 9 == 0:
+            e.sampler_stop(vc["sampler"])
+        if v % 9 == 1:
+            e.sampler_set_playhead_secs(vc["sampler"], 300.25 / e.sample_rate)
+        if v % 9 == 3:
+            e.sampler_play(vc["sampler"])
+        if v % 10 == 7:
+            e.set_param(vc["volume"], 0, 60.0)
+        if v % 3 == 0:
+            e.set_param(vc["volume"], 0, 100.0)
+        if vc["biquad"] is not None and v % 8 == 1:
+            e.set_param(vc["biquad"], 2, 3.0)                              # Q
+    outs.append(e.process_blocks(7))
+    return np.concatenate(outs)
+
+
 def reverb_ir(seed, taps, channels=2, decay=None):
     """exponentially decaying seeded noise, L1-normalised per channel."""
     decay = decay or taps / 4.0

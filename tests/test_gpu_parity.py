@@ -192,13 +192,20 @@ def run_case(name, **gpu_kw):
         "mixed_generic_nobeep": lambda e: scenarios.scenario_mixed_generic(e, use_beep=False),
         "graph_inputs": scenarios.scenario_graph_inputs,
         "cfg3_chain": scenarios.scenario_cfg3_chain,
+        "chain_steady_40": lambda e: scenarios.scenario_chain_steady(e, 40, 6),
+        "chain_steady_bq_only_i16": lambda e: scenarios.scenario_chain_steady(e, 21, 9, radix=4, delay=False,
+                                                                              fmt=fwapi.INTERLEAVED_I16),
+        "chain_steady_dl_only_pan": lambda e: scenarios.scenario_chain_steady(e, 10, 7, radix=3, biquad=False, with_pan=True),
+        "chain_events_37": lambda e: scenarios.scenario_chain_events(e, 37),
+        "chain_events_19_r2_pan": lambda e: scenarios.scenario_chain_events(e, 19, radix=2, src_frames=777, with_pan=True),
         "cfg4_reverb": scenarios.scenario_cfg4_reverb,
         "cfg4_reverb_2irs_mono": lambda e: scenarios.scenario_cfg4_reverb(e, n_voices=5, taps=700, shared_ir=False,
                                                                           ir_channels=1),
     }[name]
     mbf = {"steady_96x32": 256, "steady_40x4_i16": 64, "steady_9x3_u16": 128, "events_70": 256, "events_33_r2": 128,
            "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64, "cfg3_chain": 128, "cfg4_reverb": 128,
-           "cfg4_reverb_2irs_mono": 64}[name]
+           "cfg4_reverb_2irs_mono": 64, "chain_steady_40": 256, "chain_steady_bq_only_i16": 64,
+           "chain_steady_dl_only_pan": 128, "chain_events_37": 128, "chain_events_19_r2_pan": 64}[name]
     kw = dict(max_block_frames=mbf)
     if name == "graph_inputs":
         kw["num_graph_inputs"] = 3
@@ -245,6 +252,85 @@ def test_cfg3_chain_spec_nodes_bit_exact():
     assert_bits_equal(out_o, out_g, "cfg3 chain (biquad + delay + width)")
     gold = json.load(open(GOLDEN))
     assert digest(out_g) == gold["cfg3_chain"]
+
+
+CHAIN_CASES = ["chain_steady_40", "chain_steady_bq_only_i16", "chain_steady_dl_only_pan", "chain_events_37",
+               "chain_events_19_r2_pan"]
+
+
+@pytest.mark.parametrize("name", CHAIN_CASES)
+def test_chain_bank_generic_executor_bit_exact(name):
+    out_o, out_g, g = run_case(name, force_generic=True)
+    assert g.cx.plan_kind() == 0
+    assert_bits_equal(out_o, out_g, name + " generic")
+
+
+@pytest.mark.parametrize("name", CHAIN_CASES)
+@pytest.mark.parametrize("max_batch", [64, 3, 1])
+def test_chain_bank_fused_chain_plan_bit_exact(name, max_batch):
+    """config-3 voices (sampler -> biquad -> delay -> gain) through k_chain: serial DF1 recurrence in packed f32,
+    delay-line RMW in HBM, ordered leaf sums — bit-identical to the oracle for every K batching."""
+    out_o, out_g, g = run_case(name, max_batch=max_batch)
+    assert g.cx.plan_kind() == 2, "fused chain plan was not selected"
+    assert_bits_equal(out_o, out_g, name + " k_chain K<=%d" % max_batch)
+    gold = json.load(open(GOLDEN))
+    assert digest(out_g) == gold[name]
+
+
+def test_chain_plan_falls_back_when_a_delay_is_shorter_than_a_tile():
+    # D = 48 < 64: the generic executor's chunked in-block recurrence handles it (and must stay bit-exact)
+    def run(e):
+        voices = scenarios.build_chain_bank(e, 6, radix=3, min_delay_frames=20, max_delay_frames=60)
+        for vc in voices[1:]:
+            e.sampler_set_loop_range(vc["sampler"], fwapi.LOOP_FULL)
+            e.sampler_play(vc["sampler"])
+        return e.process_blocks(5)
+
+    o = oracle(max_block_frames=128)
+    g = GpuEngine(max_block_frames=128)
+    ro, rg = run(o), run(g)
+    assert g.cx.plan_kind() == 0
+    assert_bits_equal(ro, rg, "short delays")
+
+
+def test_chain_plan_state_survives_plan_switches():
+    # k_chain -> generic -> k_chain mid-stream: biquad history, ring position, smoothers carry over exactly
+    def run(e):
+        voices = scenarios.build_chain_bank(e, 9, radix=4, src_frames=700)
+        for vc in voices:
+            e.sampler_set_loop_range(vc["sampler"], fwapi.LOOP_FULL)
+            e.sampler_play(vc["sampler"])
+        e.set_param(voices[0]["volume"], 0, 5.0, at_block=2)
+        a = e.process_blocks(4)
+        extra = e.sum(2)            # a dangling node: the fused plan no longer covers the graph
+        e.update()
+        b = e.process_blocks(3)
+        e.remove_node(extra)
+        e.update()
+        c = e.process_blocks(4)
+        return np.concatenate([a, b, c])
+
+    o = oracle(max_block_frames=128)
+    g = GpuEngine(max_block_frames=128)
+    ro, rg = run(o), run(g)
+    assert g.cx.plan_kind() == 2
+    assert_bits_equal(ro, rg, "chain plan across graph edits")
+
+
+def test_config3_full_size_chain_plan_equals_generic_and_oracle_prefix():
+    # BASELINE configs[2]: 4096 voices, biquad LPF + delay, block = 512.  Fused (k_chain) == generic executor on
+    # the whole run; the oracle on the first block (sized to finish in seconds).
+    V, blocks = 4096, 3
+    gf = GpuEngine(max_block_frames=512, max_batch=8)
+    of = scenarios.scenario_chain_steady(gf, V, blocks, src_frames=2048, max_delay_frames=12000)
+    assert gf.cx.plan_kind() == 2
+    gg = GpuEngine(max_block_frames=512, force_generic=True)
+    og = scenarios.scenario_chain_steady(gg, V, blocks, src_frames=2048, max_delay_frames=12000)
+    assert_bits_equal(of, og, "4096 voices k_chain vs generic")
+    assert np.all(np.isfinite(of)) and np.std(of) > 0.1
+    o = oracle(max_block_frames=512)
+    oo = scenarios.scenario_chain_steady(o, V, 1, src_frames=2048, max_delay_frames=12000)
+    assert_bits_equal(oo, of[:oo.size], "4096 voices vs oracle")
 
 
 @pytest.mark.parametrize("name", ["cfg4_reverb", "cfg4_reverb_2irs_mono"])

@@ -38,6 +38,14 @@ CASES = {
     "cfg4_reverb_2irs_mono": lambda: scenarios.scenario_cfg4_reverb(oracle(max_block_frames=64), n_voices=5, taps=700,
                                                                      shared_ir=False, ir_channels=1),
     "graph_inputs": lambda: scenarios.scenario_graph_inputs(oracle(max_block_frames=64, num_graph_inputs=3)),
+    "chain_steady_40": lambda: scenarios.scenario_chain_steady(oracle(max_block_frames=256), 40, 6),
+    "chain_steady_bq_only_i16": lambda: scenarios.scenario_chain_steady(oracle(max_block_frames=64), 21, 9, radix=4, delay=False,
+                                                                          fmt=fwapi.INTERLEAVED_I16),
+    "chain_steady_dl_only_pan": lambda: scenarios.scenario_chain_steady(oracle(max_block_frames=128), 10, 7, radix=3,
+                                                                          biquad=False, with_pan=True),
+    "chain_events_37": lambda: scenarios.scenario_chain_events(oracle(max_block_frames=128), 37),
+    "chain_events_19_r2_pan": lambda: scenarios.scenario_chain_events(oracle(max_block_frames=64), 19, radix=2, src_frames=777,
+                                                                        with_pan=True),
 }
 
 

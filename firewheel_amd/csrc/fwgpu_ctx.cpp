@@ -5,6 +5,7 @@
 // buffer pool and the launch plan in HBM.  No CPU compute path exists: every process call is kernels.
 #include <hip/hip_runtime_api.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -98,6 +99,7 @@ struct fwgpu_ctx {
     // fused plan
     bool fused = false;
     bool fused_fx = false;  // the fused plan's leaves run k_chain (biquad / delay in the voice chains)
+    int chain_nq = 1;       // k_chain tile size / 64 frames
     int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
     uint32_t epoch = 1;  // invalidates every VoiceCache when bumped (plan install, sample-table change)
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags;
@@ -123,6 +125,7 @@ struct fwgpu_ctx {
 
     // staging + B1 scratch
     DevBuf d_in_stage, d_out_stage, d_scratch_pool, d_scratch_flags, d_scratch_tab, d_mask;
+    DevBuf d_trace;  // FW_CHAIN_TRACE builds only
 
     // timing
     bool timing = false;
@@ -313,6 +316,7 @@ struct FusedBuild {
     int n_bus = 1;
     int max_stages = 0;
     bool has_fx = false;  // some chain holds a biquad / delay: the k_chain plan
+    uint64_t min_delay = ~0ull;  // shortest delay line among the chains (frames)
 };
 
 // `graph`: for the delay lengths (k_chain needs D >= one tile); `mbf` must then be a multiple of the tile
@@ -417,6 +421,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
                 } else if (n.kind == K_DELAY) {
                     if (bq >= 0 || dl >= 0) return false;
                     if (graph.nodes[n.slot].init.loop_end < 64) return false;  // shorter than one k_chain tile
+                    fb.min_delay = std::min<uint64_t>(fb.min_delay, graph.nodes[n.slot].init.loop_end);
                     dl = cur;
                 } else if (n.kind == K_BIQUAD) {
                     if (bq >= 0) return false;
@@ -723,6 +728,11 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
     c->fused_fx = false;
     if (!c->force_generic && detect_fused(plan, c->graph, c->mbf, fb)) {
         c->fused_fx = fb.has_fx;
+        // k_chain tile = 64*nq frames: the larger tile needs whole tiles per block and every delay >= one tile
+        c->chain_nq = (c->mbf % 128 == 0 && fb.min_delay >= 128) ? 2 : 1;
+        if (const char* e = getenv("FWGPU_CHAIN_NQ")) {
+            if (atoi(e) == 1) c->chain_nq = 1;
+        }
         c->n_voices = (int)fb.voices.size();
         c->n_leaves = (int)fb.leaves.size();
         c->n_bus = fb.n_bus;
@@ -911,12 +921,20 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     fv.stride = c->stride;
     fv.frames = (int)c->mbf;
     fv.ext = c->d_ext.as<float>();
+    fv.trace = nullptr;
+#ifdef FW_CHAIN_TRACE
+    if (c->d_trace.ensure(64 * 16 * 8 * sizeof(unsigned long long)) == hipSuccess) fv.trace = c->d_trace.as<unsigned long long>();
+#endif
+    {
+        static const int dbg = getenv("FWGPU_CHAIN_SKIP") ? atoi(getenv("FWGPU_CHAIN_SKIP")) : 0;
+        fv.dbg = dbg;
+    }
     hipEvent_t e0, e1;
     timer_begin(c, 1, &e0, &e1);
     LCHK(c, launch_voice_control(c->stream, fv, K, cmd_block0));
     timer_end(c, e1);
     timer_begin(c, 0, &e0, &e1);
-    if (c->fused_fx) LCHK(c, launch_chain(c->stream, fv, K, cmd_block0));
+    if (c->fused_fx) LCHK(c, launch_chain(c->stream, fv, K, cmd_block0, c->chain_nq));
     else LCHK(c, launch_leaf_sum(c->stream, fv, K));
     timer_end(c, e1);
     timer_begin(c, 2, &e0, &e1);
@@ -1476,6 +1494,16 @@ int fwgpu_timing_reset(fwgpu_ctx* c) {
     }
     return 0;
 }
+#ifdef FW_CHAIN_TRACE
+// profiling builds only (scripts/chain_trace.py): timestamps [step 0..63][wave 0..15][slot 0..7] of workgroup 0
+int fwgpu_debug_read_trace(fwgpu_ctx* c, unsigned long long* out) {
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (!c->d_trace.p) return fail(c, FWGPU_ERR_INVALID, "no trace");
+    HIPC(c, hipMemcpy(out, c->d_trace.p, 64 * 16 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
 int fwgpu_device_info(fwgpu_ctx* c, char* name, int name_cap, int* cus, uint64_t* hbm) {
     hipDeviceProp_t prop;
     HIPC(c, hipGetDeviceProperties(&prop, c->device));

@@ -594,7 +594,8 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             break;
         }
 
-        case K_BIQUAD: {  // SPEC: RBJ biquad, Direct Form I, f32 state, unfused left-to-right evaluation.
+        case K_BIQUAD: {  // SPEC: RBJ biquad, Direct Form I, f32 state: unfused feed-forward half, then
+            // y = fma(-a1, y1, fma(-a2, y2, ff)) (one fma on the recurrence's critical path; SPEC: DESIGN.md §6).
             // Serial in time: lane c runs channel c (the generic executor's coverage path).
             float* ext = v.ext + s.ext_off;
             const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
@@ -609,8 +610,8 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
                     float acc = b0 * x;
                     acc = acc + (b1 * x1);
                     acc = acc + (b2 * x2);
-                    acc = acc - (a1 * y1);
-                    acc = acc - (a2 * y2);
+                    acc = __builtin_fmaf(-a2, y2, acc);
+                    acc = __builtin_fmaf(-a1, y1, acc);
                     x2 = x1;
                     x1 = x;
                     y2 = y1;
@@ -1400,27 +1401,47 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv) {
 }
 
 // ------------------------------------------------------------------ fused chain plan (config 3): k_chain
-// Voices of the shape  sampler -> [biquad] -> [delay] -> [volume|pan]* -> leaf SumNode.  The biquad (SPEC: DF1,
-// unfused f32, left to right) is a serial recurrence in time, so time cannot be split across workgroups; what is
+// Voices of the shape  sampler -> [biquad] -> [delay] -> [volume|pan]* -> leaf SumNode.  The biquad (SPEC: DF1 in
+// f32, unfused feed-forward half + two fused feedback taps) is a serial recurrence in time, so time cannot be split across workgroups; what is
 // parallel is the voices.  One workgroup owns one leaf SumNode (<= 32 voices) for all K blocks of the call and
-// walks time in tiles of CH_TT frames through a 4-stage software pipeline over LDS (one barrier per step):
-//   S1  (8 worker waves, lane = (voice, 4 frames)): source fetch + sampler gain; the non-recursive half of the
-//       biquad  A[n] = ((b0*x[n]) + (b1*x[n-1])) + (b2*x[n-2])  -> LDS, L/R interleaved
-//   S2  (1 wave, lane = voice, L/R packed in v_pk_*_f32): y[n] = (A[n] - (a1*y[n-1])) - (a2*y[n-2]), in place
+// walks time in tiles of TT = 64*NQ frames through a 4-stage software pipeline over LDS (one barrier per step):
+//   S1  (8 worker waves, lane = (voice, 4*NQ frames)): source fetch + sampler gain; the non-recursive half of the
+//       biquad  A[n] = ((b0*x[n]) + (b1*x[n-1])) + (b2*x[n-2])  -> LDS, one row per (voice, channel)
+//   S2  (1 wave, lane = (voice, channel), raised priority): y[n] = fma(-a1, y[n-1], fma(-a2, y[n-2], A[n])), in place
 //   S3a (the same worker lanes, two tiles later): delay-line read-modify-write in HBM, dry/wet mix, gain stages
 //   S3b (1 wave): the leaf SumNode in the reference's port order (nodes/sum.rs:67-133) -> partial mix bus
 // Every rounding is the one the oracle performs (products and sums separately, same order), so the result is
 // bit-identical to the generic executor.  HBM traffic per stereo voice-sample: 8 B source + 8 B ring read + 8 B
 // ring write = the 24 B of SURVEY §8d.
-#define CH_TT 64
-#define CH_PITCH 132  // floats per voice row: 64 frames x (L,R) + 4 -> the 32 S2 lanes hit disjoint bank groups
+//
+// Latency hiding: the HBM loads a step consumes were issued during the previous step, right after their registers
+// were last used (ring slots of tile s-1 after S3a of tile s-2, source of tile s+1 after S1 of tile s), and stay in
+// flight across the barrier — a workgroup-scope barrier on gfx950 does not drain vmcnt, and one CU's L1 handles its
+// waves' accesses in issue order, which is also why a ring slot stored in step s is visible to the loads another
+// wave issues in step s+1.  Ring loads are prefetched only when the delay is >= 2 tiles (the slots they read were
+// stored at least one barrier earlier); shorter delays load in-step.
 #define CH_NBUF 4
+#ifndef CH_WORKERS
 #define CH_WORKERS 8
-#define CH_THREADS ((CH_WORKERS + 2) * WAVE)
+#endif
+#ifdef FW_CHAIN_TRACE  // profiling builds: role timelines of workgroup 0 (scripts/chain_trace.py)
+#define CH_TRACE(slot)                                                                          \
+    do {                                                                                        \
+        if (fv.trace && blockIdx.x == 0 && lane == 0 && s < 64) {                               \
+            fv.trace[(s * 16 + wave) * 8 + (slot)] = clock64();                                 \
+            if ((slot) == 0) fv.trace[(s * 16 + wave) * 8 + 7] = __builtin_amdgcn_s_getreg(63492); /* HW_ID */ \
+        }                                                                                       \
+    } while (0)
+#else
+#define CH_TRACE(slot) \
+    do {               \
+    } while (0)
+#endif
+#define CH_THREADS ((CH_WORKERS + 4) * WAVE)  // 8 workers + serial + mixer + 2 idle waves (see the role map in k_chain)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// the last CMD_SET_COEFS for (state, block), if any
-__device__ inline bool chain_find_coefs(const Cmd* cmds, int n_cmds, int state_idx, uint32_t block, float co[5]) {
+// first command of (state, block) in the (state, block, seq)-sorted list
+__device__ inline int chain_cmd_lower_bound(const Cmd* cmds, int n_cmds, int state_idx, uint32_t block) {
     int lo = 0, hi = n_cmds;
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
@@ -1429,39 +1450,51 @@ __device__ inline bool chain_find_coefs(const Cmd* cmds, int n_cmds, int state_i
         if (less) lo = mid + 1;
         else hi = mid;
     }
-    bool found = false;
-    for (int i = lo; i < n_cmds; ++i) {
+    return lo;
+}
+// Both helpers return by value and are force-inlined: a by-reference out-parameter of a real call would pin the
+// caller's loop-carried registers to scratch memory (a scratch load per step, draining vmcnt with it).
+struct ChainCoefs {
+    bool found;
+    float b0, b1, b2, a1, a2;
+};
+// the last CMD_SET_COEFS for (state, block), if any
+__device__ __forceinline__ ChainCoefs chain_find_coefs(const Cmd* cmds, int n_cmds, int state_idx, uint32_t block) {
+    ChainCoefs r;
+    r.found = false;
+    r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.f;
+    for (int i = chain_cmd_lower_bound(cmds, n_cmds, state_idx, block); i < n_cmds; ++i) {
         const Cmd c = cmds[i];
         if (c.state != state_idx || c.block != block) break;
         if (c.type != CMD_SET_COEFS) continue;
-        co[0] = c.f0;
-        co[1] = __int_as_float(c.i0);
-        co[2] = __int_as_float(c.i1);
+        r.b0 = c.f0;
+        r.b1 = __int_as_float(c.i0);
+        r.b2 = __int_as_float(c.i1);
         unsigned long long u = (unsigned long long)__double_as_longlong(c.d0);
-        co[3] = __int_as_float((int)(u & 0xffffffffull));
-        co[4] = __int_as_float((int)(u >> 32));
-        found = true;
+        r.a1 = __int_as_float((int)(u & 0xffffffffull));
+        r.a2 = __int_as_float((int)(u >> 32));
+        r.found = true;
     }
-    return found;
+    return r;
 }
 // delay parameters: fb (p0), mix (p1), dry (gain)
-__device__ inline void chain_delay_cmds(const Cmd* cmds, int n_cmds, int state_idx, uint32_t block, float& fb, float& mix,
-                                        float& dry) {
-    int lo = 0, hi = n_cmds;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        const Cmd& c = cmds[mid];
-        bool less = c.state < state_idx || (c.state == state_idx && c.block < block);
-        if (less) lo = mid + 1;
-        else hi = mid;
-    }
-    for (int i = lo; i < n_cmds; ++i) {
+struct ChainDelay {
+    float fb, mix, dry;
+};
+__device__ __forceinline__ ChainDelay chain_delay_cmds(const Cmd* cmds, int n_cmds, int state_idx, uint32_t block, ChainDelay p) {
+    for (int i = chain_cmd_lower_bound(cmds, n_cmds, state_idx, block); i < n_cmds; ++i) {
         const Cmd c = cmds[i];
         if (c.state != state_idx || c.block != block) break;
-        if (c.type == CMD_SET_P0) fb = c.f0;
-        else if (c.type == CMD_SET_P1) mix = c.f0;
-        else if (c.type == CMD_SET_GAIN) dry = c.f0;
+        if (c.type == CMD_SET_P0) p.fb = c.f0;
+        else if (c.type == CMD_SET_P1) p.mix = c.f0;
+        else if (c.type == CMD_SET_GAIN) p.dry = c.f0;
     }
+    return p;
+}
+
+// rotate right by one lane inside each 16-lane DPP row (lane 0 of a row receives lane 15's value)
+__device__ __forceinline__ float row_ror1(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
 }
 
 struct ChainInfo {  // what a worker lane carries from S1 of a tile to S3a of the same tile (two steps later)
@@ -1469,32 +1502,42 @@ struct ChainInfo {  // what a worker lane carries from S1 of a tile to S3a of th
     float g[FW_MAX_STAGES - 1][2];     // constant post-gain stages (1..)
 };
 
+template <int NQ>
 __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint32_t cmd_block0) {
-    __shared__ float tile[CH_NBUF][32][CH_PITCH];
-    __shared__ float hist[2][32][4];       // x[n-2], x[n-1] (post sampler gain) of L then R, per tile parity
+    constexpr int TT = 64 * NQ;        // frames per tile
+    constexpr int PITCH = TT + 4;      // floats per (voice, channel) row: + 4 -> the 64 S2 lanes' b128 reads are conflict-free
+    constexpr int LF = 4 * NQ;         // frames per worker lane
+    __shared__ float tile[CH_NBUF][64][PITCH];  // row = 2*voice + channel
     __shared__ uint32_t silf[CH_NBUF][32];  // chain output cleared + flagged silent (VB_SILENT) per voice
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
     const LeafDesc ld = fv.leaves[blockIdx.x];
     const int ports = ld.ports;
     const int frames = fv.frames;
-    const int tpb = frames / CH_TT;  // the plan guarantees frames % CH_TT == 0
+    const int tpb = frames / TT;  // the plan guarantees frames % TT == 0
     const int n_tiles = K * tpb;
-    const bool is_worker = wave >= 1 && wave <= CH_WORKERS;
-    const bool is_serial = wave == 0;
+    // A workgroup's waves are dealt to the 4 SIMDs round-robin, so waves w, w+4, w+8 share a SIMD (measured: HW_ID).
+    // The serial wave (2) gets a SIMD to itself — waves 6 and 10 only take part in the barriers — the mixer (11)
+    // shares one with two workers, the other six workers fill the remaining two SIMDs.
+    const bool is_serial = wave == 2;
+    const bool is_mixer = wave == 11;
+    const bool is_idle = wave == 6 || wave == 10;
+    const bool is_worker = !is_serial && !is_mixer && !is_idle;
+    const int widx = wave - (wave > 2 ? 1 : 0) - (wave > 6 ? 1 : 0);  // 0..7 among the worker waves 0,1,3,4,5,7,8,9
 
-    // ---- per-role persistent registers
-    // worker lane = (voice v, frame quad q)
-    const int wl = (wave - 1) * WAVE + lane;
-    const int v = is_worker ? (wl >> 4) : lane;
+    // ---- per-role persistent registers; worker lane = (voice v, frames [LF*q, LF*q + LF) of every tile),
+    //      serial lane = (voice v, channel sch)
+    const int wl = widx * WAVE + lane;
+    const int v = is_worker ? (wl >> 4) : (lane >> 1);
+    const int sch = lane & 1;
     const int q = wl & 15;
-    const bool active = v < ports && (is_worker || (is_serial && lane < 32));
+    const bool active = v < ports && (is_worker || is_serial);
     const int voice = ld.first_voice + (active ? v : 0);
-    VoiceDesc vd = fv.voices[voice];
+    const VoiceDesc vd = fv.voices[voice];
     const bool has_bq = active && vd.bq_state >= 0, has_dl = active && vd.dl_state >= 0;
     float b0 = 1.f, b1 = 0.f, b2 = 0.f, a1 = 0.f, a2 = 0.f;
     float* bq_ext = nullptr;
-    v2f y1 = {0.f, 0.f}, y2 = {0.f, 0.f};
-    if (has_bq) {
+    float y1 = 0.f, y2 = 0.f;
+    if (has_bq) {  // ext = [b0 b1 b2 a1 a2][x1 x2 y1 y2] x 2 channels
         bq_ext = fv.ext + fv.states[vd.bq_state].ext_off;
         b0 = bq_ext[0];
         b1 = bq_ext[1];
@@ -1502,14 +1545,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         a1 = bq_ext[3];
         a2 = bq_ext[4];
         if (is_serial) {
-            y1 = (v2f){bq_ext[5 + 2], bq_ext[9 + 2]};
-            y2 = (v2f){bq_ext[5 + 3], bq_ext[9 + 3]};
-        }
-        if (is_worker && q == 0) {
-            hist[0][v][0] = bq_ext[5 + 1];
-            hist[0][v][1] = bq_ext[5 + 0];
-            hist[0][v][2] = bq_ext[9 + 1];
-            hist[0][v][3] = bq_ext[9 + 0];
+            y1 = bq_ext[5 + 4 * sch + 2];
+            y2 = bq_ext[5 + 4 * sch + 3];
         }
     }
     uint32_t D = 1, pos = 0;
@@ -1524,259 +1561,332 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         dry = ds->gain;
         ring_l = fv.ext + ds->ext_off;
     }
-    // wave-uniform: does any voice of this leaf have a biquad?
+    const bool ring_pref = has_dl && D >= 2u * TT && !(fv.dbg & 16);
     const bool any_bq = __syncthreads_or(has_bq ? 1 : 0) != 0;
 
-    // S1 per-block registers
-    const float* src_l = nullptr;
-    uint32_t r_delta = 0;
+    // compute-side block registers (block of tile s) and issue-side ones (block of tile s+1, one step ahead)
     float g0l = 1.f, g0r = 1.f;
     ChainInfo inf0, inf1, inf2;  // tiles s, s-1, s-2
     inf0.flags = inf1.flags = inf2.flags = VB_SRC_ZERO | VB_SIMPLE;
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
         inf0.g[j][0] = inf0.g[j][1] = inf1.g[j][0] = inf1.g[j][1] = inf2.g[j][0] = inf2.g[j][1] = 1.f;
-    v4f last_xl = splat(0.f), last_xr = splat(0.f);  // the newest S1 tile's x (q == 15 lanes write them back at the end)
+    VoiceRef ref_n;        // descriptor of the block that starts two tiles ahead (in flight)
+    ref_n.src_l = nullptr;
+    ref_n.r_delta = 0;
+    ref_n.flags_gset = VB_SRC_ZERO | VB_SIMPLE;
+    GainSet gs_n;          // gain set of the issue-side block (in flight)
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES; ++j) gs_n.g[j][0] = gs_n.g[j][1] = 1.f;
+    const float* nb_src = nullptr;  // issue-side block: source of frame 0, channel-1 offset, VB_* flags
+    uint32_t nb_rdelta = 0, nb_flags = VB_SRC_ZERO | VB_SIMPLE;
+    v4f xs_l[NQ], xs_r[NQ];  // source of the tile S1 computes next (prefetched)
+    v4f rg_l[NQ], rg_r[NQ];  // ring slots of the tile S3a consumes next (prefetched when ring_pref)
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) xs_l[j] = xs_r[j] = rg_l[j] = rg_r[j] = splat(0.f);
+    // newest x quad (post sampler gain) of this lane; the q == 15 lane's copy is the biquad's x[n-1], x[n-2] state
+    v4f prev_xl = splat(0.f), prev_xr = splat(0.f);
+    if (has_bq && is_worker && q == 15) {
+        prev_xl[3] = bq_ext[5 + 0];
+        prev_xl[2] = bq_ext[5 + 1];
+        prev_xr[3] = bq_ext[9 + 0];
+        prev_xr[2] = bq_ext[9 + 1];
+    }
 
-    // role-local (block, tile-in-block) counters: S1 runs on tile s, S2 on s-1, S3a on s-2, S3b on s-3
-    int k1 = 0, t1 = 0, k2 = 0, t2 = 0, k3 = 0, t3 = 0, k4 = 0, t4 = 0;
+    // role-local (block, tile-in-block) counters: S1 computes tile s, S2 s-1, S3a s-2, S3b s-3; loads issue for s+1
+    int k1 = 0, t1 = 0, k2 = 0, t2 = 0, k3 = 0, t3 = 0, k4 = 0, t4 = 0, kla = 0, tla = 0;
     const uint64_t port_mask = mask_all_silent_bits(ports);
     const bool masked = !(ports == 2 || ports == 3 || ports == 4);  // sum.rs:67-133 (Q13)
 
-    for (int s = 0; s < n_tiles + 3; ++s) {
-        if (is_worker) {
-            // ================= issue the HBM loads of both stages first
+    // issue the HBM loads of tile `la` (= the tile S1 computes in the next step); at a block start first adopt the
+    // block's descriptor (in flight since the previous step) and request its gain set
+    auto issue_source = [&]() {
+        if (tla == 0) {
+            nb_flags = ref_n.flags_gset & 0xffu;
+            nb_src = ref_n.src_l;
+            nb_rdelta = ref_n.r_delta;
+            if (nb_flags & VB_SIMPLE) gs_n = fv.gsets[(size_t)voice * FW_GSETS + (ref_n.flags_gset >> 8)];
+        }
+        if ((nb_flags & VB_SIMPLE) && !(nb_flags & VB_SRC_ZERO) && !(fv.dbg & 4)) {
+            const float* p = nb_src + tla * TT + LF * q;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                xs_l[j] = gload4(p + 4 * j);
+                xs_r[j] = gload4(p + nb_rdelta + 4 * j);
+            }
+        }
+        if (++tla == tpb) {
+            tla = 0;
+            ++kla;
+        }
+        // the tile after that starts a block: request its descriptor now
+        if (tla == 0 && kla < K) ref_n = fv.refs[(size_t)voice * fv.refs_stride + kla];
+    };
+    auto ring_slot = [&](uint32_t base, int j) -> uint32_t {
+        uint32_t sl = base + (uint32_t)(LF * q + 4 * j);
+        return sl >= D ? sl - D : sl;
+    };
+    auto load_ring = [&](uint32_t base, v4f* dl, v4f* dr) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const uint32_t sl = ring_slot(base, j);
+            if (sl + 4u <= D) {
+                dl[j] = *(const v4f_u*)(ring_l + sl);
+                dr[j] = *(const v4f_u*)(ring_l + D + sl);
+            } else {  // the quad straddles the end of the ring
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint32_t se = sl + (uint32_t)e;
+                    if (se >= D) se -= D;
+                    dl[j][e] = ring_l[se];
+                    dr[j][e] = ring_l[D + se];
+                }
+            }
+        }
+    };
+    if (is_worker && active) {  // prologue = the issue halves of steps -2 and -1
+        ref_n = fv.refs[(size_t)voice * fv.refs_stride + 0];
+        issue_source();
+    }
+
+    // One loop per role (same number of barriers in each) so that the register allocation of a role does not
+    // carry the other roles' loop state.
+    if (is_worker) {
+        for (int s = 0; s < n_tiles + 3; ++s) {
             const bool do1 = active && s < n_tiles;
             const bool do3 = active && s >= 2 && s - 2 < n_tiles;
-            v4f xl = splat(0.f), xr = splat(0.f);
-            bool slow1 = false;
-            if (do1) {
-                if (t1 == 0) {  // new block: this voice's descriptor
-                    const VoiceRef ref = fv.refs[(size_t)voice * fv.refs_stride + k1];
-                    const uint32_t fl = ref.flags_gset & 0xffu;
-                    if (fl & VB_SIMPLE) {
-                        const GainSet gs = fv.gsets[(size_t)voice * FW_GSETS + (ref.flags_gset >> 8)];
-                        inf0.flags = fl;
-                        g0l = gs.g[0][0];
-                        g0r = gs.g[0][1];
-#pragma unroll
-                        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
-                            inf0.g[j][0] = gs.g[j + 1][0];
-                            inf0.g[j][1] = gs.g[j + 1][1];
-                        }
-                        src_l = ref.src_l;
-                        r_delta = ref.r_delta;
-                    } else {
-                        const VoiceBlk* d = &fv.blks[(size_t)k1 * fv.n_voices + voice];
-                        inf0.flags = d->flags;
-#pragma unroll
-                        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
-                            inf0.g[j][0] = d->g[j + 1][0];
-                            inf0.g[j][1] = d->g[j + 1][1];
-                        }
-                    }
-                    if (has_bq && fv.n_cmds) {
-                        float co[5];
-                        if (chain_find_coefs(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0 + (uint32_t)k1, co)) {
-                            b0 = co[0];
-                            b1 = co[1];
-                            b2 = co[2];
-                        }
-                    }
-                }
-                const int f0 = t1 * CH_TT + 4 * q;
-                if (inf0.flags & VB_SIMPLE) {
-                    if (!(inf0.flags & VB_SRC_ZERO)) {
-                        xl = gload4(src_l + f0);
-                        xr = gload4(src_l + r_delta + f0);
-                    }
-                } else {
-                    slow1 = true;
-                }
-            }
-            v4f dl4 = splat(0.f), dr4 = splat(0.f);
-            uint32_t slot = 0;
-            bool ring_vec = false;
-            if (do3 && has_dl) {
-                if (t3 == 0 && fv.n_cmds) chain_delay_cmds(fv.cmds, fv.n_cmds, vd.dl_state, cmd_block0 + (uint32_t)k3, fb, mix, dry);
-                slot = pos + 4u * (uint32_t)q;
-                if (slot >= D) slot -= D;
-                ring_vec = slot + 4u <= D;
-                if (ring_vec) {
-                    dl4 = *(const v4f_u*)(ring_l + slot);
-                    dr4 = *(const v4f_u*)(ring_l + D + slot);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        uint32_t sj = slot + (uint32_t)j;
-                        if (sj >= D) sj -= D;
-                        dl4[j] = ring_l[sj];
-                        dr4[j] = ring_l[D + sj];
-                    }
-                }
-            }
-            // ================= S3a on tile s-2: delay RMW + gain stages, in place in LDS
-            if (do3) {
-                float* row = &tile[(s - 2) & (CH_NBUF - 1)][v][8 * q];
-                const v4f p0 = *(const v4f*)row, p1 = *(const v4f*)(row + 4);
-                v4f yl = (v4f){p0[0], p0[2], p1[0], p1[2]};
-                v4f yr = (v4f){p0[1], p0[3], p1[1], p1[3]};
-                if (has_dl) {
-                    const v4f nl = yl + (dl4 * fb), nr = yr + (dr4 * fb);  // ring[p] = x + (d*fb)
-                    if (ring_vec) {
-                        *(v4f_u*)(ring_l + slot) = nl;
-                        *(v4f_u*)(ring_l + D + slot) = nr;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            uint32_t sj = slot + (uint32_t)j;
-                            if (sj >= D) sj -= D;
-                            ring_l[sj] = nl[j];
-                            ring_l[D + sj] = nr[j];
-                        }
-                    }
-                    yl = (yl * dry) + (dl4 * mix);  // out = (x*dry) + (d*mix)
-                    yr = (yr * dry) + (dr4 * mix);
-                    pos += CH_TT;
-                    if (pos >= D) pos -= D;
-                }
-                const uint32_t rbits = inf2.flags >> VB_RAMP_SHIFT;
-                if (inf2.flags & VB_SILENT) {  // muted gain stage / silent chain: cleared buffer
-                    yl = yr = splat(0.f);
-                } else if (rbits == 0) {
+            const bool dl_on = has_dl && !(fv.dbg & 8);
+            CH_TRACE(0);
+            if (do1 && t1 == 0) {  // new block: adopt the issue-side descriptor (its gain set has landed)
+                if (nb_flags & VB_SIMPLE) {
+                    inf0.flags = nb_flags;
+                    g0l = gs_n.g[0][0];
+                    g0r = gs_n.g[0][1];
 #pragma unroll
                     for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
-                        if (j + 1 >= fv.n_gain_stages) break;
-                        yl = yl * inf2.g[j][0];
-                        yr = yr * inf2.g[j][1];
+                        inf0.g[j][0] = gs_n.g[j + 1][0];
+                        inf0.g[j][1] = gs_n.g[j + 1][1];
                     }
                 } else {
-                    const int f0 = t3 * CH_TT + 4 * q;
-                    const float* rb = fv.ramps + ((size_t)k3 * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
+                    const VoiceBlk* d = &fv.blks[(size_t)k1 * fv.n_voices + voice];
+                    inf0.flags = d->flags;
 #pragma unroll
-                    for (int j = 1; j < FW_MAX_STAGES; ++j) {
-                        if (j >= fv.n_gain_stages) break;
-                        v4f gl = (rbits >> (2 * j)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j) * fv.stride) : splat(inf2.g[j - 1][0]);
-                        v4f gr = (rbits >> (2 * j + 1)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j + 1) * fv.stride) : splat(inf2.g[j - 1][1]);
-                        yl = yl * gl;
-                        yr = yr * gr;
+                    for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+                        inf0.g[j][0] = d->g[j + 1][0];
+                        inf0.g[j][1] = d->g[j + 1][1];
                     }
                 }
-                *(v4f*)row = (v4f){yl[0], yr[0], yl[1], yr[1]};
-                *(v4f*)(row + 4) = (v4f){yl[2], yr[2], yl[3], yr[3]};
+                if (has_bq && fv.n_cmds) {
+                    const ChainCoefs co = chain_find_coefs(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0 + (uint32_t)k1);
+                    if (co.found) {
+                        b0 = co.b0;
+                        b1 = co.b1;
+                        b2 = co.b2;
+                    }
+                }
+            }
+            CH_TRACE(1);
+            // ================= S3a on tile s-2: delay RMW + gain stages, in place in LDS
+            if (do3) {
+                if (dl_on) {
+                    if (t3 == 0 && fv.n_cmds) {
+                        const ChainDelay p = chain_delay_cmds(fv.cmds, fv.n_cmds, vd.dl_state, cmd_block0 + (uint32_t)k3,
+                                                              ChainDelay{fb, mix, dry});
+                        fb = p.fb;
+                        mix = p.mix;
+                        dry = p.dry;
+                    }
+                    if (!ring_pref) load_ring(pos, rg_l, rg_r);
+                }
+                float* row = &tile[(s - 2) & (CH_NBUF - 1)][2 * v][LF * q];
+                const uint32_t rbits = inf2.flags >> VB_RAMP_SHIFT;
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    v4f yl = *(const v4f*)(row + 4 * j);
+                    v4f yr = *(const v4f*)(row + PITCH + 4 * j);
+                    if (dl_on) {
+                        const v4f nl = yl + (rg_l[j] * fb), nr = yr + (rg_r[j] * fb);  // ring[p] = x + (d*fb)
+                        const uint32_t sl = ring_slot(pos, j);
+                        if (sl + 4u <= D) {
+                            *(v4f_u*)(ring_l + sl) = nl;
+                            *(v4f_u*)(ring_l + D + sl) = nr;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                uint32_t se = sl + (uint32_t)e;
+                                if (se >= D) se -= D;
+                                ring_l[se] = nl[e];
+                                ring_l[D + se] = nr[e];
+                            }
+                        }
+                        yl = (yl * dry) + (rg_l[j] * mix);  // out = (x*dry) + (d*mix)
+                        yr = (yr * dry) + (rg_r[j] * mix);
+                    }
+                    if (inf2.flags & VB_SILENT) {  // muted gain stage / silent chain: cleared buffer
+                        yl = yr = splat(0.f);
+                    } else if (rbits == 0) {
+#pragma unroll
+                        for (int g = 0; g < FW_MAX_STAGES - 1; ++g) {
+                            if (g + 1 >= fv.n_gain_stages) break;
+                            yl = yl * inf2.g[g][0];
+                            yr = yr * inf2.g[g][1];
+                        }
+                    } else {
+                        const int f0 = t3 * TT + LF * q + 4 * j;
+                        const float* rb = fv.ramps + ((size_t)k3 * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
+#pragma unroll
+                        for (int g = 1; g < FW_MAX_STAGES; ++g) {
+                            if (g >= fv.n_gain_stages) break;
+                            v4f gl = (rbits >> (2 * g)) & 1u ? *(const v4f*)(rb + (size_t)(2 * g) * fv.stride) : splat(inf2.g[g - 1][0]);
+                            v4f gr = (rbits >> (2 * g + 1)) & 1u ? *(const v4f*)(rb + (size_t)(2 * g + 1) * fv.stride) : splat(inf2.g[g - 1][1]);
+                            yl = yl * gl;
+                            yr = yr * gr;
+                        }
+                    }
+                    *(v4f*)(row + 4 * j) = yl;
+                    *(v4f*)(row + PITCH + 4 * j) = yr;
+                }
+                if (dl_on) {
+                    pos += TT;
+                    if (pos >= D) pos -= D;
+                }
                 if (q == 0) silf[(s - 2) & (CH_NBUF - 1)][v] = (inf2.flags & VB_SILENT) ? 1u : 0u;
                 if (++t3 == tpb) {
                     t3 = 0;
                     ++k3;
                 }
             }
+            // ring slots of tile s-1 (S3a of the next step): issue now, after this step's ring stores
+            if (ring_pref && dl_on && s >= 1 && s - 1 < n_tiles) load_ring(pos, rg_l, rg_r);
+            CH_TRACE(2);
             // ================= S1 on tile s: sampler gain + the feed-forward half of the biquad -> LDS
             if (do1) {
-                const int f0 = t1 * CH_TT + 4 * q;
-                if (slow1) {  // ramps, loop wrap, one-shot tail, non-planar-f32 source: full descriptor
+                v4f xl[NQ], xr[NQ];
+                if (!(inf0.flags & VB_SIMPLE)) {  // ramps, loop wrap, one-shot tail, non-planar-f32 source: full descriptor
                     const VoiceBlk d = fv.blks[(size_t)k1 * fv.n_voices + voice];
-                    if (!(d.flags & VB_SRC_ZERO)) {
-                        const bool mono = d.flags & VB_MONO;
-                        if (d.src_l) {
-                            xl = *(const v4f_u*)(d.src_l + f0);
-                            xr = mono ? xl : *(const v4f_u*)(d.src_r + f0);
-                        } else {
-                            const SampleDesc sd = fv.samples[d.sample];
-                            Fetch ft;
-                            ft.off0 = d.off0;
-                            ft.off1 = d.off1;
-                            ft.n1 = d.n1;
-                            ft.wrap = (d.flags & VB_WRAP) ? 1 : 0;
-                            ft.tail_zero = (d.flags & VB_TAIL_ZERO) ? 1 : 0;
-                            xl = sample_fetch4(sd, 0, ft, (uint32_t)f0, (uint32_t)frames);
-                            xr = mono ? xl : sample_fetch4(sd, 1, ft, (uint32_t)f0, (uint32_t)frames);
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const int f0 = t1 * TT + LF * q + 4 * j;
+                        xl[j] = xr[j] = splat(0.f);
+                        if (!(d.flags & VB_SRC_ZERO)) {
+                            const bool mono = d.flags & VB_MONO;
+                            if (d.src_l) {
+                                xl[j] = *(const v4f_u*)(d.src_l + f0);
+                                xr[j] = mono ? xl[j] : *(const v4f_u*)(d.src_r + f0);
+                            } else {
+                                const SampleDesc sd = fv.samples[d.sample];
+                                Fetch ft;
+                                ft.off0 = d.off0;
+                                ft.off1 = d.off1;
+                                ft.n1 = d.n1;
+                                ft.wrap = (d.flags & VB_WRAP) ? 1 : 0;
+                                ft.tail_zero = (d.flags & VB_TAIL_ZERO) ? 1 : 0;
+                                xl[j] = sample_fetch4(sd, 0, ft, (uint32_t)f0, (uint32_t)frames);
+                                xr[j] = mono ? xl[j] : sample_fetch4(sd, 1, ft, (uint32_t)f0, (uint32_t)frames);
+                            }
+                            const uint32_t rb0 = d.flags >> VB_RAMP_SHIFT;
+                            const float* rb = fv.ramps + ((size_t)k1 * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
+                            v4f gl = rb0 & 1u ? *(const v4f*)rb : splat(d.g[0][0]);
+                            v4f gr = rb0 & 2u ? *(const v4f*)(rb + fv.stride) : splat(d.g[0][1]);
+                            xl[j] = xl[j] * gl;  // sampler.rs:530-533
+                            xr[j] = xr[j] * gr;
                         }
-                        const uint32_t rbits = d.flags >> VB_RAMP_SHIFT;
-                        const float* rb = fv.ramps + ((size_t)k1 * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
-                        v4f gl = rbits & 1u ? *(const v4f*)rb : splat(d.g[0][0]);
-                        v4f gr = rbits & 2u ? *(const v4f*)(rb + fv.stride) : splat(d.g[0][1]);
-                        xl = xl * gl;  // sampler.rs:530-533
-                        xr = xr * gr;
                     }
-                } else if (!(inf0.flags & VB_SRC_ZERO)) {
-                    xl = xl * g0l;
-                    xr = xr * g0r;
+                } else if (inf0.flags & VB_SRC_ZERO) {
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) xl[j] = xr[j] = splat(0.f);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        xl[j] = xs_l[j] * g0l;
+                        xr[j] = xs_r[j] * g0r;
+                    }
                 }
-                last_xl = xl;
-                last_xr = xr;
-                v4f al = xl, ar = xr;
+                float* row = &tile[s & (CH_NBUF - 1)][2 * v][LF * q];
                 if (has_bq) {
-                    // x[n-1], x[n-2] of this lane's first frame: the previous quad (lane - 1) or the previous tile
-                    float pl1 = __shfl_up(xl[3], 1), pl2 = __shfl_up(xl[2], 1);
-                    float pr1 = __shfl_up(xr[3], 1), pr2 = __shfl_up(xr[2], 1);
-                    if (q == 0) {
-                        const float* h = hist[s & 1][v];
-                        pl2 = h[0];
-                        pl1 = h[1];
-                        pr2 = h[2];
-                        pr1 = h[3];
+                    // x[n-1], x[n-2] of this lane's first frame: lane q-1's last quad of THIS tile, or for q == 0 lane
+                    // 15's last quad of the PREVIOUS tile — one rotate inside the voice's 16-lane DPP row, no LDS
+                    const bool q15 = q == 15;
+                    float pl1 = row_ror1(q15 ? prev_xl[3] : xl[NQ - 1][3]), pl2 = row_ror1(q15 ? prev_xl[2] : xl[NQ - 1][2]);
+                    float pr1 = row_ror1(q15 ? prev_xr[3] : xr[NQ - 1][3]), pr2 = row_ror1(q15 ? prev_xr[2] : xr[NQ - 1][2]);
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const v4f x = xl[j], z = xr[j];
+                        const v4f x1v = (v4f){pl1, x[0], x[1], x[2]}, x2v = (v4f){pl2, pl1, x[0], x[1]};
+                        const v4f z1v = (v4f){pr1, z[0], z[1], z[2]}, z2v = (v4f){pr2, pr1, z[0], z[1]};
+                        const v4f al = ((x * b0) + (x1v * b1)) + (x2v * b2);  // ((b0*x) + (b1*x1)) + (b2*x2)
+                        const v4f ar = ((z * b0) + (z1v * b1)) + (z2v * b2);
+                        pl1 = x[3];
+                        pl2 = x[2];
+                        pr1 = z[3];
+                        pr2 = z[2];
+                        *(v4f*)(row + 4 * j) = al;
+                        *(v4f*)(row + PITCH + 4 * j) = ar;
                     }
-                    al[0] = ((b0 * xl[0]) + (b1 * pl1)) + (b2 * pl2);
-                    al[1] = ((b0 * xl[1]) + (b1 * xl[0])) + (b2 * pl1);
-                    al[2] = ((b0 * xl[2]) + (b1 * xl[1])) + (b2 * xl[0]);
-                    al[3] = ((b0 * xl[3]) + (b1 * xl[2])) + (b2 * xl[1]);
-                    ar[0] = ((b0 * xr[0]) + (b1 * pr1)) + (b2 * pr2);
-                    ar[1] = ((b0 * xr[1]) + (b1 * xr[0])) + (b2 * pr1);
-                    ar[2] = ((b0 * xr[2]) + (b1 * xr[1])) + (b2 * xr[0]);
-                    ar[3] = ((b0 * xr[3]) + (b1 * xr[2])) + (b2 * xr[1]);
-                    if (q == 15) {
-                        float* h = hist[(s & 1) ^ 1][v];
-                        h[0] = xl[2];
-                        h[1] = xl[3];
-                        h[2] = xr[2];
-                        h[3] = xr[3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        *(v4f*)(row + 4 * j) = xl[j];
+                        *(v4f*)(row + PITCH + 4 * j) = xr[j];
                     }
                 }
-                float* row = &tile[s & (CH_NBUF - 1)][v][8 * q];
-                *(v4f*)row = (v4f){al[0], ar[0], al[1], ar[1]};
-                *(v4f*)(row + 4) = (v4f){al[2], ar[2], al[3], ar[3]};
+                prev_xl = xl[NQ - 1];
+                prev_xr = xr[NQ - 1];
                 if (++t1 == tpb) {
                     t1 = 0;
                     ++k1;
                 }
             }
+            // source of tile s+1 (S1 of the next step)
+            if (active && s + 1 < n_tiles) issue_source();
             inf2 = inf1;
             inf1 = inf0;
-        } else if (is_serial) {
-            // ================= S2 on tile s-1: the recursive half of the biquad, lane = voice, (L,R) packed
-            if (any_bq && s >= 1 && s - 1 < n_tiles) {
+            CH_TRACE(3);
+            __syncthreads();
+            CH_TRACE(4);
+        }
+    } else if (is_serial) {
+        // the recurrence is the critical path of every step: its wave wins VALU arbitration on its SIMD
+        __builtin_amdgcn_s_setprio(3);
+        for (int s = 0; s < n_tiles + 3; ++s) {
+            CH_TRACE(0);
+            // ================= S2 on tile s-1: the recursive half of the biquad, lane = (voice, channel)
+            if (any_bq && s >= 1 && s - 1 < n_tiles && !(fv.dbg & 1)) {
                 if (has_bq && t2 == 0 && fv.n_cmds) {
-                    float co[5];
-                    if (chain_find_coefs(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0 + (uint32_t)k2, co)) {
-                        a1 = co[3];
-                        a2 = co[4];
-#pragma unroll
-                        for (int j = 0; j < 5; ++j) bq_ext[j] = co[j];
+                    const ChainCoefs co = chain_find_coefs(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0 + (uint32_t)k2);
+                    if (co.found) {
+                        a1 = co.a1;
+                        a2 = co.a2;
+                        if (sch == 0) {
+                            bq_ext[0] = co.b0;
+                            bq_ext[1] = co.b1;
+                            bq_ext[2] = co.b2;
+                            bq_ext[3] = co.a1;
+                            bq_ext[4] = co.a2;
+                        }
                     }
                 }
                 if (has_bq) {
-                    float* row = &tile[(s - 1) & (CH_NBUF - 1)][v][0];
-                    const v2f A1 = {a1, a1}, A2 = {a2, a2};
+                    float* row = &tile[(s - 1) & (CH_NBUF - 1)][lane][0];
                     v4f cur[4], nxt[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) cur[u] = *(const v4f*)(row + 4 * u);
-#pragma unroll
-                    for (int c = 0; c < CH_TT / 8; ++c) {
-                        if (c + 1 < CH_TT / 8) {
+#pragma unroll 2
+                    for (int c = 0; c < TT / 16; ++c) {
+                        if (c + 1 < TT / 16) {
 #pragma unroll
                             for (int u = 0; u < 4; ++u) nxt[u] = *(const v4f*)(row + 16 * (c + 1) + 4 * u);
                         }
                         v4f o[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const v2f s0 = {cur[u][0], cur[u][1]}, s1 = {cur[u][2], cur[u][3]};
-                            const v2f o0 = (s0 - (A1 * y1)) - (A2 * y2);  // acc - (a1*y1) - (a2*y2)
-                            y2 = y1;
-                            y1 = o0;
-                            const v2f o1 = (s1 - (A1 * y1)) - (A2 * y2);
-                            y2 = y1;
-                            y1 = o1;
-                            o[u] = (v4f){o0[0], o0[1], o1[0], o1[1]};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float y = __builtin_fmaf(-a1, y1, __builtin_fmaf(-a2, y2, cur[u][e]));
+                                y2 = y1;
+                                y1 = y;
+                                o[u][e] = y;
+                            }
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) *(v4f*)(row + 16 * c + 4 * u) = o[u];
@@ -1789,41 +1899,61 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     ++k2;
                 }
             }
-        } else {
-            // ================= S3b on tile s-3: the leaf SumNode, lane = frame pair, ports in order
-            if (s >= 3 && lane < 32) {
+            CH_TRACE(3);
+            __syncthreads();
+            CH_TRACE(4);
+        }
+    } else if (is_idle) {
+        for (int s = 0; s < n_tiles + 3; ++s) __syncthreads();
+    } else {
+        for (int s = 0; s < n_tiles + 3; ++s) {
+            CH_TRACE(0);
+            // ================= S3b on tile s-3: the leaf SumNode, lane = (channel, frame quad), ports in order
+            if (s >= 3 && lane < TT / 2 && !(fv.dbg & 2)) {
                 const int buf = (s - 3) & (CH_NBUF - 1);
-                uint64_t silent_ports = 0;
-                for (int p = 0; p < ports; ++p) silent_ports |= (uint64_t)(silf[buf][p] & 1u) << p;
+                const int mch = lane / (TT / 4), mq = lane % (TT / 4);
+                const uint64_t silent_ports = __ballot(lane < ports && silf[buf][lane & 31] != 0) & port_mask;
                 const bool all_silent = silent_ports == port_mask;
-                v4f acc = splat(0.f);
-                if (!all_silent) {
-                    acc = *(const v4f*)&tile[buf][0][4 * lane];  // sum.rs:117 copy port 0 (also when silent: zeros)
-                    for (int p = 1; p < ports; ++p) {
-                        if (masked && ((silent_ports >> p) & 1ull)) continue;  // :122-124
-                        acc = acc + *(const v4f*)&tile[buf][p][4 * lane];
+                const uint64_t skip = masked ? silent_ports : 0ull;  // :122-124 (n-port path only)
+                const float* col = &tile[buf][mch][4 * mq];
+                v4f acc = *(const v4f*)col;  // sum.rs:117 copy port 0 (also when silent: a cleared buffer)
+                // 16 ports per LDS round trip: the reads are unconditional (row index clamped), the adds are masked
+                for (int p0 = 1; p0 < ports; p0 += 16) {
+                    v4f x[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int pp = p0 + u < ports ? p0 + u : ports - 1;
+                        x[u] = *(const v4f*)(col + (size_t)pp * (2 * PITCH));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const bool use = p0 + u < ports && !((skip >> (p0 + u)) & 1ull);
+                        const v4f t = acc + x[u];
+                        acc = use ? t : acc;
                     }
                 }
-                float* bus = fv.bus + (size_t)k4 * fv.bus_blk_stride + (size_t)ld.out_buf * fv.stride + t4 * CH_TT + 2 * lane;
-                *(float2*)bus = make_float2(acc[0], acc[2]);
-                *(float2*)(bus + fv.stride) = make_float2(acc[1], acc[3]);
+                if (all_silent) acc = splat(0.f);  // sum.rs:52-56
+                float* bus = fv.bus + (size_t)k4 * fv.bus_blk_stride + (size_t)(ld.out_buf + mch) * fv.stride + t4 * TT + 4 * mq;
+                *(v4f*)bus = acc;
                 if (t4 == 0 && lane < 2) fv.bus_flags[(size_t)k4 * fv.bus_flags_blk_stride + ld.out_buf + lane] = all_silent ? 1 : 0;
                 if (++t4 == tpb) {
                     t4 = 0;
                     ++k4;
                 }
             }
+            CH_TRACE(3);
+            __syncthreads();
+            CH_TRACE(4);
         }
-        __syncthreads();
     }
 
     // ---- write the node state back
     if (is_worker && active) {
         if (has_bq && q == 15) {
-            bq_ext[5 + 0] = last_xl[3];
-            bq_ext[5 + 1] = last_xl[2];
-            bq_ext[9 + 0] = last_xr[3];
-            bq_ext[9 + 1] = last_xr[2];
+            bq_ext[5 + 0] = prev_xl[3];
+            bq_ext[5 + 1] = prev_xl[2];
+            bq_ext[9 + 0] = prev_xr[3];
+            bq_ext[9 + 1] = prev_xr[2];
         }
         if (has_dl && q == 0) {
             NodeState* ds = &fv.states[vd.dl_state];
@@ -1834,10 +1964,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         }
     }
     if (is_serial && has_bq) {
-        bq_ext[5 + 2] = y1[0];
-        bq_ext[5 + 3] = y2[0];
-        bq_ext[9 + 2] = y1[1];
-        bq_ext[9 + 3] = y2[1];
+        bq_ext[5 + 4 * sch + 2] = y1;
+        bq_ext[5 + 4 * sch + 3] = y2;
     }
 }
 
@@ -2115,9 +2243,10 @@ int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd
     hipLaunchKernelGGL(k_voice_control, dim3((fv.n_voices + 3) / 4), dim3(256), 0, s, fv, K, cmd_block0);
     return (int)hipGetLastError();
 }
-int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0) {
+int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0, int nq) {
     if (fv.n_leaves <= 0 || K <= 0) return 0;
-    hipLaunchKernelGGL(k_chain, dim3(fv.n_leaves), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
+    if (nq == 2) hipLaunchKernelGGL(k_chain<2>, dim3(fv.n_leaves), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
+    else hipLaunchKernelGGL(k_chain<1>, dim3(fv.n_leaves), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
     return (int)hipGetLastError();
 }
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {

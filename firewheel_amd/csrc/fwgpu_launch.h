@@ -53,6 +53,8 @@ struct FusedView {
     int stride;
     int frames;
     float* ext;  // biquad coefficients + history, delay rings (k_chain plan)
+    unsigned long long* trace;  // FW_CHAIN_TRACE builds only: per-step role timestamps of workgroup 0
+    int dbg;     // profiling only (env FWGPU_CHAIN_SKIP): bit 0 skip S2, 1 skip S3b, 2 skip source loads, 3 skip ring RMW, 4 no ring prefetch
 };
 
 int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0);
@@ -71,7 +73,8 @@ int launch_set_flags(hipStream_t s, uint8_t* flags, const int* d_bufs, int n, ui
 int launch_get_flags(hipStream_t s, const uint8_t* flags, const int* d_bufs, int n, uint64_t* d_mask);
 int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0);
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K);
-int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0);
+// nq = tile size / 64 frames (1 or 2): frames % (64*nq) == 0 and every delay line >= 64*nq frames
+int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0, int nq);
 
 // host-side mirror of the StateInit record consumed by k_scatter_states
 struct StateInitHost {

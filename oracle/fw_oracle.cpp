@@ -620,8 +620,11 @@ struct StereoWidthProcessor : AudioNodeProcessor {
     }
 };
 
-// ---- SPEC: RBJ biquad, Direct Form I, f32 state; y = b0 x + b1 x1 + b2 x2 - a1 y1 - a2 y2, each product and
-// each sum rounded separately, left to right.  Coefficients are shared with the control half (5 floats).
+// ---- SPEC: RBJ biquad, Direct Form I, f32 state.  y = b0 x + b1 x1 + b2 x2 - a2 y2 - a1 y1 evaluated as
+//   ff = ((b0*x) + (b1*x1)) + (b2*x2)      feed-forward half: each product and sum rounded separately, left to right
+//   y  = fma(-a1, y1, fma(-a2, y2, ff))    feedback half: two fused multiply-adds (Rust: f32::mul_add), older tap first
+// so the recurrence's critical path is ONE fma per sample (y1 -> y); the feed-forward half does not depend on y and
+// is computed ahead of it.  Coefficients are shared with the control half (5 floats).
 struct BiquadProcessor : AudioNodeProcessor {
     std::shared_ptr<std::vector<float>> co;
     std::vector<float> st;  // [ch][x1 x2 y1 y2]
@@ -637,8 +640,8 @@ struct BiquadProcessor : AudioNodeProcessor {
                 float acc = b0 * x;
                 acc = acc + (b1 * x1);
                 acc = acc + (b2 * x2);
-                acc = acc - (a1 * y1);
-                acc = acc - (a2 * y2);
+                acc = fmaf(-a2, y2, acc);
+                acc = fmaf(-a1, y1, acc);
                 x2 = x1;
                 x1 = x;
                 y2 = y1;

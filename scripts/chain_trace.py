@@ -1,0 +1,53 @@
+"""Role timelines of k_chain (profiling builds only).
+
+Build a tracing variant of the library and run config 3 on it:
+    cd firewheel_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DFW_CHAIN_TRACE \
+        -shared -o libfwgpu_trace.so -x hip fwgpu_kernels.hip fwgpu_graph.cpp fwgpu_ctx.cpp
+    FWGPU_LIB=firewheel_amd/csrc/libfwgpu_trace.so python scripts/chain_trace.py
+Prints, for steps 8..23 of workgroup 0, the clock64() deltas of each role: S3a, S1, issue, barrier wait.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import firewheel_amd as fa  # noqa: E402
+
+V, B, K, F = 4096, 512, 16, 65536
+radix = int(os.environ.get("RADIX", "32"))
+stream = torch.cuda.current_stream().cuda_stream
+cx = fa.FirewheelGpuCtx(48000, B, 0, 2, stream=stream)
+cx.set_max_batch(K)
+src = torch.empty((V, 2, F), dtype=torch.float32, device="cuda").uniform_(-1, 1)
+samplers = bench.build_chain_bank(cx, fa, V, radix)
+bench.start_voices(cx, fa, samplers, src, F)
+out = torch.empty(K * B * 2, dtype=torch.float32, device="cuda")
+for _ in range(3):
+    cx.process_blocks_device(K, out.data_ptr(), 2)
+torch.cuda.synchronize()
+buf = np.zeros(64 * 16 * 8, dtype=np.uint64)
+f = cx.L.fwgpu_debug_read_trace
+f.restype = C.c_int
+f.argtypes = [C.c_void_p, C.c_void_p]
+assert f(cx.c, buf.ctypes.data_as(C.c_void_p)) == 0
+t = buf.reshape(64, 16, 8).astype(np.int64)
+base = t[8, 0, 0]
+print("clock64 ticks; wave 2 = serial (S2), 11 = mixer (S3b), 6/10 idle, the rest = workers")
+print("SIMD of waves 0..9 (HW_ID bits 5:4):", [int((t[8, w, 7] >> 4) & 3) for w in range(12)])
+print("step | serial: work wait | worker1: issue S3a S1 wait | worker8: issue S3a S1 wait | mixer: work wait | step len")
+for s in range(8, 28):
+    ser = t[s, 2]
+    w1 = t[s, 0]
+    w8 = t[s, 9]
+    mx = t[s, 11]
+    step_len = t[s + 1, 2, 0] - t[s, 2, 0]
+    print("%4d | %6d %6d | %6d %6d %6d %6d | %6d %6d %6d %6d | %6d %6d | %6d" % (
+        s, ser[3] - ser[0], ser[4] - ser[3],
+        w1[1] - w1[0], w1[2] - w1[1], w1[3] - w1[2], w1[4] - w1[3],
+        w8[1] - w8[0], w8[2] - w8[1], w8[3] - w8[2], w8[4] - w8[3],
+        mx[3] - mx[0], mx[4] - mx[3], step_len))

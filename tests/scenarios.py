@@ -285,7 +285,7 @@ def scenario_cfg3_chain(e, n_voices=12, blocks=10, radix=4, src_frames=3000):
 
 
 def build_chain_bank(e, n_voices, radix=32, src_frames=3000, biquad=True, delay=True, with_pan=False, seed=0,
-                     fmt=PLANAR_F32, mono_every=0, min_delay_frames=64, max_delay_frames=900):
+                     fmt=PLANAR_F32, mono_every=0, min_delay_frames=64, max_delay_frames=900, first_delay_frames=64):
     """config-3 shape: V x (sampler -> biquad LPF -> delay -> gain [-> pan]) -> radix sum tree -> out.
     The shape the fused chain plan (k_chain) accepts; delays are >= one 64-frame tile."""
     rng = np.random.default_rng(4321 + seed)
@@ -299,7 +299,7 @@ def build_chain_bank(e, n_voices, radix=32, src_frames=3000, biquad=True, delay=
             e.connect_stereo(cur, bq)
             cur = bq
         if delay:
-            d_frames = 64 if v == 0 else int(rng.integers(min_delay_frames, max_delay_frames))
+            d_frames = first_delay_frames if v == 0 else int(rng.integers(min_delay_frames, max_delay_frames))
             dl = e.delay(d_frames / float(e.sample_rate), feedback=0.0 if v % 3 == 0 else 0.45, mix=0.5)
             e.connect_stereo(cur, dl)
             cur = dl

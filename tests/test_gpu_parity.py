@@ -198,6 +198,9 @@ def run_case(name, **gpu_kw):
         "chain_steady_dl_only_pan": lambda e: scenarios.scenario_chain_steady(e, 10, 7, radix=3, biquad=False, with_pan=True),
         "chain_events_37": lambda e: scenarios.scenario_chain_events(e, 37),
         "chain_events_19_r2_pan": lambda e: scenarios.scenario_chain_events(e, 19, radix=2, src_frames=777, with_pan=True),
+        # every delay >= 128 frames and block % 128 == 0: k_chain runs its 128-frame tiles (ring prefetch for D >= 256)
+        "chain_steady_40_d128": lambda e: scenarios.scenario_chain_steady(e, 40, 6, first_delay_frames=128, min_delay_frames=129),
+        "chain_events_37_d130": lambda e: scenarios.scenario_chain_events(e, 37, first_delay_frames=130, min_delay_frames=128),
         "cfg4_reverb": scenarios.scenario_cfg4_reverb,
         "cfg4_reverb_2irs_mono": lambda e: scenarios.scenario_cfg4_reverb(e, n_voices=5, taps=700, shared_ir=False,
                                                                           ir_channels=1),
@@ -205,7 +208,8 @@ def run_case(name, **gpu_kw):
     mbf = {"steady_96x32": 256, "steady_40x4_i16": 64, "steady_9x3_u16": 128, "events_70": 256, "events_33_r2": 128,
            "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64, "cfg3_chain": 128, "cfg4_reverb": 128,
            "cfg4_reverb_2irs_mono": 64, "chain_steady_40": 256, "chain_steady_bq_only_i16": 64,
-           "chain_steady_dl_only_pan": 128, "chain_events_37": 128, "chain_events_19_r2_pan": 64}[name]
+           "chain_steady_dl_only_pan": 128, "chain_events_37": 128, "chain_events_19_r2_pan": 64,
+           "chain_steady_40_d128": 256, "chain_events_37_d130": 128}[name]
     kw = dict(max_block_frames=mbf)
     if name == "graph_inputs":
         kw["num_graph_inputs"] = 3
@@ -255,7 +259,7 @@ def test_cfg3_chain_spec_nodes_bit_exact():
 
 
 CHAIN_CASES = ["chain_steady_40", "chain_steady_bq_only_i16", "chain_steady_dl_only_pan", "chain_events_37",
-               "chain_events_19_r2_pan"]
+               "chain_events_19_r2_pan", "chain_steady_40_d128", "chain_events_37_d130"]
 
 
 @pytest.mark.parametrize("name", CHAIN_CASES)
@@ -275,6 +279,15 @@ def test_chain_bank_fused_chain_plan_bit_exact(name, max_batch):
     assert_bits_equal(out_o, out_g, name + " k_chain K<=%d" % max_batch)
     gold = json.load(open(GOLDEN))
     assert digest(out_g) == gold[name]
+
+
+@pytest.mark.parametrize("name", ["chain_steady_40_d128", "chain_events_37_d130"])
+def test_chain_plan_small_tiles_forced(name, monkeypatch):
+    # the same scenarios through the 64-frame-tile instantiation (FWGPU_CHAIN_NQ=1 overrides the planner's choice)
+    monkeypatch.setenv("FWGPU_CHAIN_NQ", "1")
+    out_o, out_g, g = run_case(name, max_batch=5)
+    assert g.cx.plan_kind() == 2
+    assert_bits_equal(out_o, out_g, name + " k_chain<1>")
 
 
 def test_chain_plan_falls_back_when_a_delay_is_shorter_than_a_tile():
@@ -322,14 +335,15 @@ def test_config3_full_size_chain_plan_equals_generic_and_oracle_prefix():
     # the whole run; the oracle on the first block (sized to finish in seconds).
     V, blocks = 4096, 3
     gf = GpuEngine(max_block_frames=512, max_batch=8)
-    of = scenarios.scenario_chain_steady(gf, V, blocks, src_frames=2048, max_delay_frames=12000)
+    kw = dict(src_frames=2048, first_delay_frames=480, min_delay_frames=480, max_delay_frames=12000)  # 10..250 ms
+    of = scenarios.scenario_chain_steady(gf, V, blocks, **kw)
     assert gf.cx.plan_kind() == 2
     gg = GpuEngine(max_block_frames=512, force_generic=True)
-    og = scenarios.scenario_chain_steady(gg, V, blocks, src_frames=2048, max_delay_frames=12000)
+    og = scenarios.scenario_chain_steady(gg, V, blocks, **kw)
     assert_bits_equal(of, og, "4096 voices k_chain vs generic")
     assert np.all(np.isfinite(of)) and np.std(of) > 0.1
     o = oracle(max_block_frames=512)
-    oo = scenarios.scenario_chain_steady(o, V, 1, src_frames=2048, max_delay_frames=12000)
+    oo = scenarios.scenario_chain_steady(o, V, 1, **kw)
     assert_bits_equal(oo, of[:oo.size], "4096 voices vs oracle")
 
 

@@ -44,6 +44,10 @@ CASES = {
     "chain_steady_dl_only_pan": lambda: scenarios.scenario_chain_steady(oracle(max_block_frames=128), 10, 7, radix=3,
                                                                           biquad=False, with_pan=True),
     "chain_events_37": lambda: scenarios.scenario_chain_events(oracle(max_block_frames=128), 37),
+    "chain_steady_40_d128": lambda: scenarios.scenario_chain_steady(oracle(max_block_frames=256), 40, 6, first_delay_frames=128,
+                                                                      min_delay_frames=129),
+    "chain_events_37_d130": lambda: scenarios.scenario_chain_events(oracle(max_block_frames=128), 37, first_delay_frames=130,
+                                                                      min_delay_frames=128),
     "chain_events_19_r2_pan": lambda: scenarios.scenario_chain_events(oracle(max_block_frames=64), 19, radix=2, src_frames=777,
                                                                         with_pan=True),
 }

@@ -19,8 +19,10 @@ from .graph import (  # noqa: F401
     HardClipNode,
     LoopRange,
     MonoToStereoNode,
+    ResamplerNode,
     SampleFormat,
     SamplerNode,
+    SpatialNode,
     StereoPanNode,
     StereoToMonoNode,
     StereoWidthNode,
@@ -30,6 +32,6 @@ from .graph import (  # noqa: F401
 
 __all__ = [
     "FirewheelGpuCtx", "VolumeNode", "SumNode", "SamplerNode", "BeepTestNode", "HardClipNode", "MonoToStereoNode",
-    "StereoToMonoNode", "DummyAudioNode", "StereoPanNode", "StereoWidthNode", "BiquadNode", "DelayNode", "FirReverbNode", "LoopRange", "SampleFormat", "AddEdgeError",
+    "StereoToMonoNode", "DummyAudioNode", "StereoPanNode", "StereoWidthNode", "BiquadNode", "DelayNode", "FirReverbNode", "ResamplerNode", "SpatialNode", "LoopRange", "SampleFormat", "AddEdgeError",
     "CompileGraphError", "FwgpuError", "load_library", "build_library", "LIB_PATH",
 ]

@@ -126,6 +126,7 @@ struct fwgpu_ctx {
     // staging + B1 scratch
     DevBuf d_in_stage, d_out_stage, d_scratch_pool, d_scratch_flags, d_scratch_tab, d_mask;
     DevBuf d_trace;  // FW_CHAIN_TRACE builds only
+    DevBuf d_rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS]
 
     // timing
     bool timing = false;
@@ -219,6 +220,54 @@ void biquad_coefs(int type, float cutoff_hz, float q, uint32_t sample_rate, floa
     co[3] = (float)(a1 / a0);
     co[4] = (float)(a2 / a0);
 }
+// SPEC resampler: Kaiser-windowed sinc (beta 8, cutoff 0.9 x Nyquist), RS_PHASES x RS_TAPS, every
+// phase normalised to unity DC gain in f64 and rounded to f32 — the control side builds the table once per ctx.
+double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k < 64; ++k) {
+        term *= (x / (2.0 * k)) * (x / (2.0 * k));
+        sum += term;
+    }
+    return sum;
+}
+void resampler_table(float* h) {
+    const double fc = 0.9, beta = 8.0, half = RS_TAPS / 2.0, pi = 3.14159265358979323846;
+    const double i0b = bessel_i0(beta);
+    for (int ph = 0; ph < RS_PHASES; ++ph) {
+        double row[RS_TAPS], sum = 0.0;
+        for (int k = 0; k < RS_TAPS; ++k) {
+            double t = (double)(k - (RS_TAPS / 2 - 1)) - (double)ph / RS_PHASES;
+            double x = pi * fc * t;
+            double sinc = fabs(t) < 1e-12 ? 1.0 : sin(x) / x;
+            double r = t / half;
+            double w = fabs(r) >= 1.0 ? 0.0 : bessel_i0(beta * sqrt(1.0 - r * r)) / i0b;
+            row[k] = fc * sinc * w;
+            sum += row[k];
+        }
+        for (int k = 0; k < RS_TAPS; ++k) h[ph * RS_TAPS + k] = (float)(row[k] / sum);
+    }
+}
+uint64_t resampler_step(float ratio) {  // source frames per output frame as 32.32 fixed point
+    double r = (double)ratio;
+    if (!(r >= 1.0 / 256.0)) r = 1.0 / 256.0;
+    if (r > 256.0) r = 256.0;
+    return (uint64_t)llround(r * 4294967296.0);
+}
+// SPEC spatialiser: listener at the origin (+x right, +y up, -z forward): inverse-distance gain (reference distance
+// 1, rolloff 1), equal-power pan from the direction cosine to the right, per-ear delay up to 0.66 ms.
+void spatial_params(float x, float y, float z, uint32_t sample_rate, float* gl, float* gr, int* dl, int* dr) {
+    const double pi = 3.14159265358979323846;
+    double d = sqrt((double)x * x + (double)y * y + (double)z * z);
+    double att = 1.0 / fmax(d, 1.0);
+    double s = d < 1e-9 ? 0.0 : (double)x / d;
+    double theta = (s + 1.0) * (pi / 4.0);
+    *gl = (float)(cos(theta) * att);
+    *gr = (float)(sin(theta) * att);
+    double itd_max = round(0.00066 * (double)sample_rate);
+    if (itd_max > SP_HIST - 1) itd_max = SP_HIST - 1;
+    *dl = (int)round(fmax(0.0, s) * itd_max);
+    *dr = (int)round(fmax(0.0, -s) * itd_max);
+}
 uint32_t delay_frames(float secs, uint32_t sample_rate) {
     double d = round((double)secs * (double)sample_rate);
     if (!(d >= 1.0)) d = 1.0;
@@ -274,6 +323,25 @@ NodeState make_state(int kind, const float* params, int n_params, uint32_t sampl
         case K_FIR:
             s.sample = (int)p(0, -1.0f);  // impulse-response sample id; T and the ring are set at activation
             break;
+        case K_RESAMPLER:  // params: sample id, ratio, loop, playing
+            s.sample = (int)p(0, -1.0f);
+            s.loop_start = resampler_step(p(1, 1.0f));
+            s.has_loop = p(2, 0.0f) != 0.0f ? 1 : 0;
+            s.playing = p(3, 1.0f) != 0.0f ? 1 : 0;
+            s.playhead = 0;
+            break;
+        case K_SPATIAL: {  // params: x, y, z of the source; the ctor args stay in phasor / phasor_inc / gain
+            s.phasor = p(0, 0.0f);
+            s.phasor_inc = p(1, 0.0f);
+            s.gain = p(2, -1.0f);
+            int dl, dr;
+            spatial_params(s.phasor, s.phasor_inc, s.gain, sample_rate, &s.p0, &s.p1, &dl, &dr);
+            s.s0 = make_smoother(s.p0, sample_rate);
+            s.s1 = make_smoother(s.p1, sample_rate);
+            s.playing = dl;
+            s.has_loop = dr;
+            break;
+        }
         case K_DELAY: {
             float mix = fminf(fmaxf(p(2, 0.5f), 0.0f), 1.0f);
             s.p0 = fminf(fmaxf(p(1, 0.0f), 0.0f), 0.999f);  // feedback
@@ -540,6 +608,8 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
                 biquad_coefs(n.init.enabled, n.init.p0, n.init.p1, c->sample_rate, head.data());
             } else if (n.kind == K_DELAY) {
                 len = (size_t)nch * (size_t)n.init.loop_end;
+            } else if (n.kind == K_SPATIAL) {
+                len = SP_HIST;
             } else if (n.kind == K_FIR) {
                 int ir = n.init.sample;
                 if (ir < 0 || ir >= (int)c->samples.size() || !c->samples[ir].alive)
@@ -859,6 +929,7 @@ DevView generic_view(fwgpu_ctx* c, int frames) {
     v.states = c->d_states.as<NodeState>();
     v.samples = c->d_samples.as<SampleDesc>();
     v.ext = c->d_ext.as<float>();
+    v.rs_table = c->d_rs_table.as<float>();
     v.pool = c->d_pool.as<float>();
     v.flags = c->d_flags.as<uint8_t>();
     v.pool_blk_stride = 0;
@@ -946,6 +1017,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         v.states = c->d_states.as<NodeState>();
         v.samples = c->d_samples.as<SampleDesc>();
         v.ext = c->d_ext.as<float>();
+        v.rs_table = c->d_rs_table.as<float>();
         v.pool = fv.bus;
         v.flags = fv.bus_flags;
         v.pool_blk_stride = fv.bus_blk_stride;
@@ -1062,6 +1134,15 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
         }
         c->own_stream = true;
     }
+    {
+        std::vector<float> tab(RS_PHASES * RS_TAPS);
+        resampler_table(tab.data());
+        if (upload(c, c->d_rs_table, tab.data(), tab.size() * sizeof(float)) != 0) {
+            g_create_error = c->last_error;
+            delete c;
+            return nullptr;
+        }
+    }
     if (upload_sample_table(c) != 0 || c->d_mask.ensure(64) != hipSuccess) {
         g_create_error = c->last_error;
         delete c;
@@ -1099,11 +1180,14 @@ int64_t fwgpu_graph_in_node(fwgpu_ctx* c) { return c->graph.id_of(c->graph.graph
 int64_t fwgpu_graph_out_node(fwgpu_ctx* c) { return c->graph.id_of(c->graph.graph_out_slot); }
 
 int64_t fwgpu_add_node(fwgpu_ctx* c, int kind, uint32_t n_in, uint32_t n_out, const float* params, int n_params) {
-    if (kind < 0 || kind > K_FIR) return fail(c, FWGPU_ERR_INVALID, "unsupported node kind");
-    if (kind == K_FIR) {
+    if (kind < 0 || kind > K_SPATIAL) return fail(c, FWGPU_ERR_INVALID, "unsupported node kind");
+    if (kind == K_FIR || kind == K_RESAMPLER) {
         int ir = n_params > 0 ? (int)params[0] : -1;
         if (ir < 0 || ir >= (int)c->samples.size() || !c->samples[ir].alive || c->samples[ir].desc.frames == 0)
-            return fail(c, FWGPU_ERR_INVALID, "FIR node: params[0] must be the id of a non-empty impulse-response sample");
+            return fail(c, FWGPU_ERR_INVALID, kind == K_FIR ? "FIR node: params[0] must be the id of a non-empty impulse-response sample"
+                                                            : "Resampler node: params[0] must be the id of a non-empty source sample");
+        if (kind == K_RESAMPLER && c->samples[ir].desc.frames >= (1ull << 31))
+            return fail(c, FWGPU_ERR_INVALID, "Resampler node: source longer than 2^31 frames");
     }
     if (n_in > 64 || n_out > 64) return fail(c, FWGPU_ERR_INVALID, "a node has at most 64 ports per side (core/node.rs:62,69)");
     NodeState st = make_state(kind, params, n_params, c->sample_rate);
@@ -1318,6 +1402,44 @@ int fwgpu_node_set_param(fwgpu_ctx* c, int64_t node, int param, float value, uin
             m.f0 = 1.0f - mix;
             return push_cmd(c, node, -1, m, false);
         }
+        case K_RESAMPLER: {  // 1 = ratio (source frames per output frame), 3 = playing, 4 = seek to a source frame
+            uint64_t u;
+            if (param == 1) {
+                m.type = CMD_RS_STEP;
+                u = resampler_step(value);
+                memcpy(&m.d0, &u, 8);
+                return push_cmd(c, node, -1, m, false);
+            }
+            if (param == 3) {
+                m.type = value != 0.0f ? CMD_SMP_PLAY : CMD_SMP_PAUSE;
+                return push_cmd(c, node, -1, m, false);
+            }
+            if (param != 4) return fail(c, FWGPU_ERR_INVALID, "unknown param");
+            m.type = CMD_RS_SEEK;
+            u = (uint64_t)fmaxf(value, 0.0f);
+            memcpy(&m.d0, &u, 8);
+            return push_cmd(c, node, -1, m, false);
+        }
+        case K_SPATIAL: {  // 0 / 1 / 2 = x / y / z of the source relative to the listener
+            if (param < 0 || param > 2) return fail(c, FWGPU_ERR_INVALID, "unknown param");
+            if (param == 0) n->init.phasor = value;
+            else if (param == 1) n->init.phasor_inc = value;
+            else n->init.gain = value;
+            float gl, gr;
+            int dl, dr;
+            spatial_params(n->init.phasor, n->init.phasor_inc, n->init.gain, c->sample_rate, &gl, &gr, &dl, &dr);
+            m.type = CMD_SET_P0;
+            m.f0 = gl;
+            int rc = push_cmd(c, node, -1, m, false);
+            if (rc) return rc;
+            m.type = CMD_SET_P1;
+            m.f0 = gr;
+            if ((rc = push_cmd(c, node, -1, m, false))) return rc;
+            m.type = CMD_SP_ITD;
+            m.i0 = dl;
+            m.i1 = dr;
+            return push_cmd(c, node, -1, m, false);
+        }
         default:
             return fail(c, FWGPU_ERR_INVALID, "node kind has no runtime params");
     }
@@ -1415,6 +1537,7 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     if (hn->n_in != n_in || hn->n_out != n_out) return fail(c, FWGPU_ERR_INVALID, "port counts differ from add_node");
     if (frames > c->mbf) return fail(c, FWGPU_ERR_INVALID, "frames > max_block_frames");
     if (hn->kind == K_FIR) return fail(c, FWGPU_ERR_INVALID, "FIR banks run at graph level (fwgpu_process_interleaved), not per node");
+    if (n_in + n_out == 0) return fail(c, FWGPU_ERR_INVALID, "node has no ports");
     const size_t stride = (size_t)c->stride;
     const int nb = 1 + (int)n_in + (int)n_out;
     HIPC(c, hipStreamSynchronize(c->stream));

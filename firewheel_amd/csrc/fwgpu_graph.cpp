@@ -228,6 +228,18 @@ bool check_activation(int kind, uint32_t n_in, uint32_t n_out, std::string& err)
                 return false;
             }
             return true;
+        case K_RESAMPLER:
+            if (n_in != 0 || n_out == 0) {
+                err = "Resampler node is a source: 0 inputs, >= 1 outputs and a source sample.";
+                return false;
+            }
+            return true;
+        case K_SPATIAL:
+            if (!(n_in == 1 || n_in == 2) || n_out != 2) {
+                err = "Spatial node needs 1 or 2 inputs and exactly 2 outputs.";
+                return false;
+            }
+            return true;
         case K_MONO_TO_STEREO:
             if (n_in < 1 || n_out < 2) {
                 err = "MonoToStereoNode needs 1 input and 2 outputs.";

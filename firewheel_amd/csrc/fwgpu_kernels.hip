@@ -170,6 +170,12 @@ __device__ inline void apply_cmds(NodeState& s, int state_idx, uint32_t block, c
             case CMD_SMP_SET_PLAYHEAD:  // :392-399
                 s.playhead = sat_round_u64(c.d0 * (double)s.sample_rate);
                 break;
+            case CMD_RS_STEP: s.loop_start = (uint64_t)__double_as_longlong(c.d0); break;
+            case CMD_RS_SEEK: s.playhead = ((uint64_t)__double_as_longlong(c.d0)) << 32; break;
+            case CMD_SP_ITD:
+                s.playing = c.i0;
+                s.has_loop = c.i1;
+                break;
             case CMD_SMP_SET_LOOP:  // :400-412 + ProcLoopRange::new :241-263
                 if (c.i0 == 0) {
                     s.has_loop = 0;
@@ -318,7 +324,8 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
 
     NodeState s;
     const bool stateful = nd.kind == K_VOLUME || nd.kind == K_SAMPLER || nd.kind == K_BEEP || nd.kind == K_PAN ||
-                          nd.kind == K_HARD_CLIP || nd.kind == K_WIDTH || nd.kind == K_BIQUAD || nd.kind == K_DELAY;
+                          nd.kind == K_HARD_CLIP || nd.kind == K_WIDTH || nd.kind == K_BIQUAD || nd.kind == K_DELAY ||
+                          nd.kind == K_RESAMPLER || nd.kind == K_SPATIAL;
     if (stateful) {
         s = v.states[nd.state];
         apply_cmds(s, nd.state, cmd_block, v.cmds, v.n_cmds, v.samples, v.ext, lane == 0);
@@ -649,6 +656,92 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
                 }
             }
             s.playhead = (uint64_t)((pos + (uint32_t)frames) % D);
+            break;
+        }
+
+        case K_RESAMPLER: {  // SPEC: resampling source, polyphase windowed sinc
+            const SampleDesc sd = s.sample >= 0 ? v.samples[s.sample] : SampleDesc{nullptr, 0, 0, FMT_P_F32};
+            if (!s.playing || s.sample < 0 || sd.frames == 0) {
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            const uint64_t step = s.loop_start, pos = s.playhead;
+            const bool loop = s.has_loop != 0;
+            const int64_t len = (int64_t)sd.frames;
+            const int sch = sd.channels;
+            const int nfill = nd.n_out < sch ? nd.n_out : sch;
+            for (int i = lane; i < frames; i += WAVE) {  // every output frame is independent
+                const uint64_t p = pos + (uint64_t)i * step;
+                const int64_t idx = (int64_t)(p >> 32);
+                const float* hp = v.rs_table + ((uint32_t)(p >> 27) & (RS_PHASES - 1)) * RS_TAPS;
+                float first = 0.f;
+                for (int c = 0; c < nfill; ++c) {
+                    float acc = 0.f;
+                    for (int k = 0; k < RS_TAPS; ++k) {  // ascending-tap fmaf chain from +0.0 (the SPEC order)
+                        int64_t j = idx - (RS_TAPS / 2 - 1) + k;
+                        float x = 0.f;
+                        if (loop) {
+                            j %= len;
+                            if (j < 0) j += len;
+                            x = sample_fetch(sd, c, (uint64_t)j);
+                        } else if (j >= 0 && j < len) {
+                            x = sample_fetch(sd, c, (uint64_t)j);
+                        }
+                        acc = __builtin_fmaf(hp[k], x, acc);
+                    }
+                    io.out(c)[i] = acc;
+                    if (c == 0) first = acc;
+                }
+                if (nd.n_out > sch) {
+                    if (nd.n_out == 2 && sch == 1) io.out(1)[i] = first;
+                    else
+                        for (int c = sch; c < nd.n_out; ++c) io.out(c)[i] = 0.f;
+                }
+            }
+            if (nd.n_out > sch && !(nd.n_out == 2 && sch == 1))
+                for (int c = sch; c < nd.n_out; ++c) out_mask |= (1ull << c);
+            uint64_t np = pos + (uint64_t)frames * step;
+            if (loop) np %= ((uint64_t)len << 32);
+            else if ((np >> 32) >= (uint64_t)len + RS_TAPS / 2) s.playing = 0;
+            s.playhead = np;
+            break;
+        }
+
+        case K_SPATIAL: {  // SPEC: distance gain + equal-power pan + per-ear integer delay
+            float* hist = v.ext + s.ext_off;
+            const int dl = s.playing, dr = s.has_loop;
+            const float hreg = hist[lane];  // lane l keeps hist[l] (SP_HIST == 64), hist[63] = newest
+            GainRun rl = smoother_begin(s.s0, s.p0, frames);
+            GainRun rr = smoother_begin(s.s1, s.p1, frames);
+            const bool two = nd.n_in >= 2;
+            auto mono = [&](int j) -> float {  // m[j], j >= 0
+                return two ? (io.in(0)[j] + io.in(1)[j]) * 0.5f : io.in(0)[j];
+            };
+            for (int base = 0; base < frames; base += 256) {
+                int n = frames - base < 256 ? frames - base : 256;
+                v4f gl = gain_chunk(rl, n, lane);
+                v4f gr = gain_chunk(rr, n, lane);
+                int f0 = base + lane * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = f0 + e;
+                    const int jl = i - dl, jr = i - dr;
+                    // history lookups go through the wave (every lane takes part), current-block ones through memory
+                    const float hl = __shfl(hreg, (SP_HIST + jl) & 63), hr = __shfl(hreg, (SP_HIST + jr) & 63);
+                    if (i < frames) {
+                        const float ml = jl >= 0 ? mono(jl) : hl;
+                        const float mr = jr >= 0 ? mono(jr) : hr;
+                        io.out(0)[i] = ml * gl[e];
+                        io.out(1)[i] = mr * gr[e];
+                    }
+                }
+            }
+            if (rl.ramp) s.s0.last = rl.prev;
+            if (rr.ramp) s.s1.last = rr.prev;
+            // new history = the last SP_HIST samples of (hist ++ m[0..frames))
+            const int j = frames - SP_HIST + lane;
+            const float keep = __shfl(hreg, (SP_HIST + j) & 63);
+            hist[lane] = j >= 0 ? mono(j) : keep;
             break;
         }
 

@@ -18,6 +18,7 @@ struct DevView {
     NodeState* states;
     const SampleDesc* samples;
     float* ext;  // per-node extended state (biquad coefficients + history, delay rings)
+    const float* rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS]
     float* pool;
     uint8_t* flags;
     size_t pool_blk_stride;

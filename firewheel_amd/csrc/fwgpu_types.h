@@ -7,8 +7,11 @@ namespace fwgpu {
 enum : int {
     K_DUMMY = 0, K_BEEP = 1, K_VOLUME = 2, K_SUM = 3, K_SAMPLER = 4, K_HARD_CLIP = 5,
     K_MONO_TO_STEREO = 6, K_STEREO_TO_MONO = 7, K_PAN = 8, K_WIDTH = 9, K_BIQUAD = 10, K_DELAY = 11,
-    K_FIR = 12,
+    K_FIR = 12, K_RESAMPLER = 13, K_SPATIAL = 14,
 };
+#define RS_PHASES 32  // SPEC resampler: polyphase windowed-sinc table [RS_PHASES][RS_TAPS], 32.32 fixed-point position
+#define RS_TAPS 16
+#define SP_HIST 64    // SPEC spatialiser: mono history frames (>= the largest per-ear delay + 1)
 
 enum : int { FMT_I_I16 = 0, FMT_I_U16 = 1, FMT_I_F32 = 2, FMT_P_I16 = 3, FMT_P_U16 = 4, FMT_P_F32 = 5 };
 
@@ -42,6 +45,9 @@ struct NodeState {
     //   DELAY also uses p0 = feedback, p1 = mix, gain = dry (1-mix), playhead = ring position, loop_end = D
     //   FIR: ext = mirrored history ring[channels][2R]; playhead = ring position, loop_end = R, loop_start = T,
     //        sample = impulse-response sample id
+    //   RESAMPLER: sample = source, playhead = 32.32 source position, loop_start = 32.32 step, has_loop, playing
+    //   SPATIAL: p0/p1 = ear gain targets (s0/s1 smooth them), playing = left-ear delay, has_loop = right-ear delay
+    //        (frames), ext = the last SP_HIST mono samples
     uint32_t ext_off;
     uint32_t ext_len;
     int pad[1];
@@ -71,6 +77,9 @@ enum : int {
     CMD_SET_COEFS = 4,  // biquad: f0,i0,i1 (as float bits) = b0,b1,b2; d0 bits = (a1,a2)
     CMD_SMP_SET_SAMPLE = 10, CMD_SMP_PLAY = 11, CMD_SMP_PAUSE = 12, CMD_SMP_STOP = 13,
     CMD_SMP_SET_PLAYHEAD = 14, CMD_SMP_SET_LOOP = 15,
+    CMD_RS_STEP = 20,  // resampler: d0 bits = u64 32.32 step
+    CMD_RS_SEEK = 21,  // resampler: d0 bits = u64 source frame
+    CMD_SP_ITD = 22,   // spatialiser: i0 / i1 = left / right ear delay in frames
 };
 struct Cmd {
     int state;

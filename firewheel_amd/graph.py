@@ -239,6 +239,44 @@ class FirReverbNode(_Node):  # SPEC node: convolution with an impulse-response s
         return [float(self.ir)]
 
 
+class ResamplerNode(_Node):  # SPEC node: resampling source — polyphase windowed sinc, 32.32 fixed-point position
+    KIND = 13
+
+    def __init__(self, sample, ratio=1.0, loop=False, playing=True):
+        self.sample, self.ratio, self.loop, self.playing = sample, ratio, loop, playing
+
+    def params(self):
+        return [float(self.sample), self.ratio, 1.0 if self.loop else 0.0, 1.0 if self.playing else 0.0]
+
+    def set_ratio(self, ratio, at_block=0):
+        """source frames consumed per output frame (= source rate / stream rate x playback speed)"""
+        self.ratio = ratio
+        self._set(1, ratio, at_block)
+
+    def set_playing(self, playing, at_block=0):
+        self.playing = playing
+        self._set(3, 1.0 if playing else 0.0, at_block)
+
+    def seek_frames(self, frame, at_block=0):
+        self._set(4, float(frame), at_block)
+
+
+class SpatialNode(_Node):  # SPEC node: 3D spatialiser — distance gain, equal-power pan, per-ear delay
+    KIND = 14
+
+    def __init__(self, x, y, z):
+        self.pos = [x, y, z]
+
+    def params(self):
+        return list(self.pos)
+
+    def set_position(self, x, y, z, at_block=0):
+        """source position relative to the listener: +x right, +y up, -z forward"""
+        self.pos = [x, y, z]
+        for i, v in enumerate(self.pos):
+            self._set(i, v, at_block)
+
+
 class _RawNode(_Node):
     def __init__(self, kind, params):
         self.KIND = kind

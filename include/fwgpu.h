@@ -37,7 +37,9 @@ enum fwgpu_node_kind {
     FWGPU_STEREO_WIDTH = 9,   /* SPEC                 params: width */
     FWGPU_BIQUAD = 10,        /* SPEC                 params: type, cutoff_hz, q */
     FWGPU_DELAY = 11,         /* SPEC                 params: delay_secs, feedback, mix */
-    FWGPU_FIR = 12            /* SPEC convolution     params: impulse-response sample id (fwgpu_sample_create) */
+    FWGPU_FIR = 12,           /* SPEC convolution     params: impulse-response sample id (fwgpu_sample_create) */
+    FWGPU_RESAMPLER = 13,     /* SPEC polyphase resampling source (0 inputs)  params: sample id, ratio, loop, playing */
+    FWGPU_SPATIAL = 14        /* SPEC 3D spatialiser (1|2 in, 2 out)          params: x, y, z of the source */
 };
 
 /* sample formats — core/sample_resource.rs:28-335 */
@@ -137,7 +139,9 @@ int fwgpu_sample_destroy(fwgpu_ctx* ctx, int sample);
  * the start of the NEXT process call, before which the message is seen (the reference's rings/atomics
  * are polled at block start: nodes/sampler.rs:331, nodes/volume.rs:92). */
 /* VolumeNode::set_percent_volume (volume.rs:28-34) / SamplerNode::set_percent_volume (sampler.rs:171-177):
- * param 0.  BeepTestNode::set_enabled (beep_test.rs:30-32): param 0.  StereoPan: param 0 = pan. */
+ * param 0.  BeepTestNode::set_enabled (beep_test.rs:30-32): param 0.  SPEC nodes: StereoPan 0 = pan;
+ * StereoWidth 0 = width; Biquad 1 = cutoff_hz, 2 = q; Delay 1 = feedback, 2 = mix; Resampler 1 = ratio,
+ * 3 = playing, 4 = seek (source frame); Spatial 0/1/2 = x/y/z. */
 int fwgpu_node_set_param(fwgpu_ctx* ctx, int64_t node, int param, float value, uint32_t at_block);
 int fwgpu_sampler_set_sample(fwgpu_ctx* ctx, int64_t node, int sample, int stop_playback,
                              uint32_t at_block);                                  /* sampler.rs:67-79 */

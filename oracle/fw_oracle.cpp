@@ -730,7 +730,161 @@ struct FirProcessor : AudioNodeProcessor {
     }
 };
 
+// ---- SPEC: resampling source (varispeed / sample-rate conversion): 0 inputs.  Source position is a 32.32
+// fixed-point frame index advanced by `step` per output frame (exact integer arithmetic => bit-exact indexing);
+// out[n] = sum_k h[phase][k] * s[idx - 7 + k], phase = top 5 fraction bits, as an ascending fmaf chain from +0.0.
+// Outside [0, len) the source reads 0 (one-shot) or wraps (loop).  ctl = {step, playing, loop, seek_flag, seek_pos}
+struct ResamplerProcessor : AudioNodeProcessor {
+    std::shared_ptr<const SampleResource> src;
+    std::shared_ptr<std::vector<double>> ctl;
+    std::vector<float> h;
+    uint64_t pos = 0;
+    bool playing = false;
+    ResamplerProcessor(std::shared_ptr<const SampleResource> s, std::shared_ptr<std::vector<double>> c)
+        : src(s), ctl(c), h(RS_PHASES * RS_TAPS) {
+        resampler_table(h.data());
+    }
+    float fetch(size_t c, int64_t j, bool loop) const {
+        const int64_t len = (int64_t)src->len_frames();
+        if (loop) {
+            j %= len;
+            if (j < 0) j += len;
+        } else if (j < 0 || j >= len) {
+            return 0.0f;
+        }
+        float v = 0.0f;
+        float* bufs[64];
+        float tmp[64];
+        for (size_t k = 0; k < src->num_channels() && k < 64; ++k) bufs[k] = &tmp[k];
+        src->fill_buffers(bufs, std::min<size_t>(src->num_channels(), 64), 0, 1, (uint64_t)j);
+        v = tmp[c];
+        return v;
+    }
+    void process(size_t frames, const float* const*, size_t, float* const* outputs, size_t n_out, ProcInfo info) override {
+        std::vector<double>& cw = *ctl;
+        const uint64_t step = (uint64_t)cw[0];
+        const bool loop = cw[2] != 0.0;
+        if (cw[3] != 0.0) {  // seek message
+            pos = ((uint64_t)cw[4]) << 32;
+            cw[3] = 0.0;
+        }
+        playing = cw[1] != 0.0;
+        const uint64_t len = src ? src->len_frames() : 0;
+        if (!playing || len == 0) {
+            clear_all_outputs(frames, outputs, n_out, info.out_silence_mask);
+            return;
+        }
+        const size_t sch = src->num_channels();
+        const size_t nfill = std::min(n_out, sch);
+        for (size_t i = 0; i < frames; ++i) {
+            const uint64_t p = pos + (uint64_t)i * step;
+            const int64_t idx = (int64_t)(p >> 32);
+            const uint32_t ph = (uint32_t)(p >> 27) & (RS_PHASES - 1);
+            const float* hp = h.data() + ph * RS_TAPS;
+            for (size_t c = 0; c < nfill; ++c) {
+                float acc = 0.0f;
+                for (int k = 0; k < RS_TAPS; ++k) acc = fmaf(hp[k], fetch(c, idx - (RS_TAPS / 2 - 1) + k, loop), acc);
+                outputs[c][i] = acc;
+            }
+        }
+        if (n_out > sch) {  // like the sampler (sampler.rs:545-559): mono -> both outputs, else zero + flag
+            if (n_out == 2 && sch == 1) {
+                for (size_t i = 0; i < frames; ++i) outputs[1][i] = outputs[0][i];
+            } else {
+                for (size_t c = sch; c < n_out; ++c) {
+                    for (size_t i = 0; i < frames; ++i) outputs[c][i] = 0.0f;
+                    info.out_silence_mask->set_channel(c, true);
+                }
+            }
+        }
+        pos += (uint64_t)frames * step;
+        if (loop) {
+            pos %= (len << 32);
+        } else if ((pos >> 32) >= len + RS_TAPS / 2) {
+            cw[1] = 0.0;  // ran off the end: stops before the next block
+        }
+    }
+};
+
+// ---- SPEC: 3D spatialiser (listener at the origin): inverse-distance attenuation, equal-power pan from the
+// direction cosine to the right, per-ear integer delay (ITD).  Mono sum m = in0 or (in0+in1)*0.5; history of the
+// last SP_HIST mono samples; outL[i] = M(i-dl)*gL[i], outR[i] = M(i-dr)*gR[i], gains through ParamSmoothers.
+struct SpatialProcessor : AudioNodeProcessor {
+    std::shared_ptr<float> gl_t, gr_t;
+    std::shared_ptr<std::vector<double>> ctl;  // {dl, dr}
+    ParamSmoother sl, sr_;
+    std::vector<float> hist;
+    SpatialProcessor(std::shared_ptr<float> l, std::shared_ptr<float> r, std::shared_ptr<std::vector<double>> c, uint32_t sr,
+                     size_t mbf)
+        : gl_t(l), gr_t(r), ctl(c), sl(*l, sr, mbf), sr_(*r, sr, mbf), hist(SP_HIST, 0.0f) {}
+    void process(size_t frames, const float* const* inputs, size_t n_in, float* const* outputs, size_t n_out,
+                 ProcInfo) override {
+        const int dl = (int)(*ctl)[0], dr = (int)(*ctl)[1];
+        SmoothedOutput gl = sl.set_and_process(*gl_t, frames);
+        SmoothedOutput gr = sr_.set_and_process(*gr_t, frames);
+        std::vector<float> m(frames);
+        for (size_t i = 0; i < frames; ++i) m[i] = n_in >= 2 ? (inputs[0][i] + inputs[1][i]) * 0.5f : inputs[0][i];
+        auto M = [&](int64_t j) -> float { return j >= 0 ? m[(size_t)j] : hist[(size_t)(SP_HIST + j)]; };
+        for (size_t i = 0; i < frames; ++i) {
+            outputs[0][i] = M((int64_t)i - dl) * gl.values[i];
+            if (n_out > 1) outputs[1][i] = M((int64_t)i - dr) * gr.values[i];
+        }
+        std::vector<float> nh(SP_HIST);
+        for (int l = 0; l < SP_HIST; ++l) {
+            int64_t j = (int64_t)frames - SP_HIST + l;  // index into hist ++ m, relative to m[0]
+            nh[l] = M(j);
+        }
+        hist.swap(nh);
+    }
+};
+
 }  // namespace
+
+// Kaiser-windowed sinc, cutoff 0.9 x Nyquist, beta 8; each phase normalised to unity DC gain in f64, then f32.
+static double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k < 64; ++k) {
+        term *= (x / (2.0 * k)) * (x / (2.0 * k));
+        sum += term;
+    }
+    return sum;
+}
+void resampler_table(float* h) {
+    const double fc = 0.9, beta = 8.0, half = RS_TAPS / 2.0, pi = 3.14159265358979323846;
+    const double i0b = bessel_i0(beta);
+    for (int ph = 0; ph < RS_PHASES; ++ph) {
+        double row[RS_TAPS], sum = 0.0;
+        for (int k = 0; k < RS_TAPS; ++k) {
+            double t = (double)(k - (RS_TAPS / 2 - 1)) - (double)ph / RS_PHASES;  // tap position relative to the sample point
+            double x = pi * fc * t;
+            double sinc = fabs(t) < 1e-12 ? 1.0 : sin(x) / x;
+            double r = t / half;
+            double w = fabs(r) >= 1.0 ? 0.0 : bessel_i0(beta * sqrt(1.0 - r * r)) / i0b;
+            row[k] = fc * sinc * w;
+            sum += row[k];
+        }
+        for (int k = 0; k < RS_TAPS; ++k) h[ph * RS_TAPS + k] = (float)(row[k] / sum);
+    }
+}
+uint64_t resampler_step(float ratio) {
+    double r = (double)ratio;
+    if (!(r >= 1.0 / 256.0)) r = 1.0 / 256.0;
+    if (r > 256.0) r = 256.0;
+    return (uint64_t)llround(r * 4294967296.0);
+}
+void spatial_params(float x, float y, float z, uint32_t sample_rate, float* gl, float* gr, int* dl, int* dr) {
+    const double pi = 3.14159265358979323846;
+    double d = sqrt((double)x * x + (double)y * y + (double)z * z);
+    double att = 1.0 / fmax(d, 1.0);                 // inverse distance, reference distance 1, rolloff 1
+    double s = d < 1e-9 ? 0.0 : (double)x / d;       // direction cosine to the right, in [-1, 1]
+    double theta = (s + 1.0) * (pi / 4.0);
+    *gl = (float)(cos(theta) * att);
+    *gr = (float)(sin(theta) * att);
+    double itd_max = round(0.00066 * (double)sample_rate);
+    if (itd_max > SP_HIST - 1) itd_max = SP_HIST - 1;
+    *dl = (int)round(fmax(0.0, s) * itd_max);        // source on the right: the left ear hears it later
+    *dr = (int)round(fmax(0.0, -s) * itd_max);
+}
 
 void biquad_coefs(int type, float cutoff_hz, float q, uint32_t sample_rate, float co[5]) {
     double fs = (double)sample_rate;
@@ -792,6 +946,8 @@ const char* AudioNode::debug_name() const {
         case KIND_BIQUAD: return "biquad";
         case KIND_DELAY: return "delay";
         case KIND_FIR: return "fir";
+        case KIND_RESAMPLER: return "resampler";
+        case KIND_SPATIAL: return "spatial";
         default: return "unknown";
     }
 }
@@ -844,6 +1000,17 @@ std::unique_ptr<AudioNode> make_node(int kind, const float* params, int n_params
             n->aux1 = std::make_shared<float>(1.0f - mix);
             break;
         }
+        case KIND_RESAMPLER:  // params: sample id, ratio, loop, playing
+            n->ctl = std::make_shared<std::vector<double>>(
+                std::vector<double>{(double)resampler_step(p(1, 1.0f)), p(3, 1.0f) != 0.0f ? 1.0 : 0.0,
+                                    p(2, 0.0f) != 0.0f ? 1.0 : 0.0, 0.0, 0.0});
+            break;
+        case KIND_SPATIAL:  // params: x, y, z
+            n->spec_params = {p(0, 0.0f), p(1, 0.0f), p(2, -1.0f)};
+            n->aux0 = std::make_shared<float>(0.0f);
+            n->aux1 = std::make_shared<float>(0.0f);
+            n->ctl = std::make_shared<std::vector<double>>(std::vector<double>{0.0, 0.0});
+            break;
         default:
             break;
     }
@@ -921,6 +1088,24 @@ std::unique_ptr<AudioNodeProcessor> AudioNode::activate(uint32_t sample_rate, si
                 return nullptr;
             }
             return std::unique_ptr<AudioNodeProcessor>(new FirProcessor(*ir, num_inputs));
+        case KIND_RESAMPLER:
+            if (num_inputs != 0 || num_outputs == 0 || !ir) {
+                err = "Resampler node is a source: 0 inputs, >= 1 outputs and a source sample.";
+                return nullptr;
+            }
+            return std::unique_ptr<AudioNodeProcessor>(new ResamplerProcessor(ir, ctl));
+        case KIND_SPATIAL: {
+            if (!(num_inputs == 1 || num_inputs == 2) || num_outputs != 2) {
+                err = "Spatial node needs 1 or 2 inputs and exactly 2 outputs.";
+                return nullptr;
+            }
+            act_sample_rate = sample_rate;
+            int dl, dr;
+            spatial_params(spec_params[0], spec_params[1], spec_params[2], sample_rate, aux0.get(), aux1.get(), &dl, &dr);
+            (*ctl)[0] = dl;
+            (*ctl)[1] = dr;
+            return std::unique_ptr<AudioNodeProcessor>(new SpatialProcessor(aux0, aux1, ctl, sample_rate, max_block_frames));
+        }
         default:
             err = "unknown node kind";
             return nullptr;
@@ -1355,7 +1540,7 @@ int64_t fwo_graph_out_node(void* c) { return index_to_i64(((Ctx*)c)->graph.graph
 int64_t fwo_add_node(void* c, int kind, uint32_t n_in, uint32_t n_out, const float* params, int n_params) {
     Ctx* cx = (Ctx*)c;
     auto node = make_node(kind, params, n_params);
-    if (kind == KIND_FIR) {
+    if (kind == KIND_FIR || kind == KIND_RESAMPLER) {
         int id = n_params > 0 ? (int)params[0] : -1;
         if (id < 0 || id >= (int)cx->samples.size()) return -20;
         node->ir = cx->samples[id];
@@ -1463,6 +1648,24 @@ int fwo_set_param(void* c, int64_t node, int param, float value) {
             *n->aux0 = fminf(fmaxf(value, 0.0f), 1.0f);
             *n->aux1 = 1.0f - *n->aux0;
             return 0;
+        case KIND_RESAMPLER:  // 1 = ratio, 3 = playing, 4 = seek to source frame
+            if (param == 1) (*n->ctl)[0] = (double)fwo::resampler_step(value);
+            else if (param == 3) (*n->ctl)[1] = value != 0.0f ? 1.0 : 0.0;
+            else if (param == 4) {
+                (*n->ctl)[3] = 1.0;
+                (*n->ctl)[4] = (double)(uint64_t)fmaxf(value, 0.0f);
+            } else return -2;
+            return 0;
+        case KIND_SPATIAL: {  // 0/1/2 = x/y/z of the source relative to the listener
+            if (param < 0 || param > 2) return -2;
+            n->spec_params[param] = value;
+            int dl, dr;
+            fwo::spatial_params(n->spec_params[0], n->spec_params[1], n->spec_params[2], n->act_sample_rate, n->aux0.get(),
+                                n->aux1.get(), &dl, &dr);
+            (*n->ctl)[0] = dl;
+            (*n->ctl)[1] = dr;
+            return 0;
+        }
         default:
             return -2;
     }

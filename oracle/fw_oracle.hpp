@@ -156,7 +156,18 @@ enum NodeKind : int {
     KIND_BIQUAD = 10,
     KIND_DELAY = 11,
     KIND_FIR = 12,
+    KIND_RESAMPLER = 13,
+    KIND_SPATIAL = 14,
 };
+
+// SPEC resampler: polyphase windowed-sinc table, RS_PHASES x RS_TAPS, 32.32 fixed-point source position
+constexpr int RS_PHASES = 32;
+constexpr int RS_TAPS = 16;
+void resampler_table(float* h /* [RS_PHASES][RS_TAPS] */);
+uint64_t resampler_step(float ratio);
+// SPEC spatialiser: listener at the origin, +x right, +y up, -z forward
+constexpr int SP_HIST = 64;
+void spatial_params(float x, float y, float z, uint32_t sample_rate, float* gl, float* gr, int* dl, int* dr);
 
 // Sampler control messages (nodes/sampler.rs:16-28)
 struct SamplerMsg {
@@ -180,7 +191,9 @@ struct AudioNode {
     std::vector<float> spec_params;       // SPEC nodes creation params
     std::shared_ptr<std::vector<float>> coefs;  // SPEC biquad: b0 b1 b2 a1 a2 shared with the processor
     uint32_t act_sample_rate = 48000;
-    std::shared_ptr<const SampleResource> ir;   // SPEC FIR: impulse response
+    std::shared_ptr<const SampleResource> ir;   // SPEC FIR: impulse response; SPEC resampler: the source
+    // SPEC resampler / spatialiser control words, read by the processor at block start ("atomics")
+    std::shared_ptr<std::vector<double>> ctl;
     std::shared_ptr<std::deque<SamplerMsg>> to_processor;  // sampler.rs:42 (rtrb cap 128)
     const char* debug_name() const;
     // activate: returns nullptr and sets err on failure (core/node.rs:12-18)

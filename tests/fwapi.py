@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # node kinds (oracle/fw_oracle.hpp NodeKind == include/fwgpu.h fwgpu_node_kind)
 DUMMY, BEEP_TEST, VOLUME, SUM, SAMPLER, HARD_CLIP, MONO_TO_STEREO, STEREO_TO_MONO, STEREO_PAN = range(9)
-STEREO_WIDTH, BIQUAD, DELAY, FIR = 9, 10, 11, 12
+STEREO_WIDTH, BIQUAD, DELAY, FIR, RESAMPLER, SPATIAL = 9, 10, 11, 12, 13, 14
 # sample formats
 INTERLEAVED_I16, INTERLEAVED_U16, INTERLEAVED_F32, PLANAR_I16, PLANAR_U16, PLANAR_F32 = range(6)
 _FMT_DTYPE = {0: np.int16, 1: np.uint16, 2: np.float32, 3: np.int16, 4: np.uint16, 5: np.float32}
@@ -165,6 +165,12 @@ class Engine(object):
 
     def fir(self, ir_sample, ch=2):
         return self.add_node(FIR, ch, ch, [float(ir_sample)])
+
+    def resampler(self, sample, ratio=1.0, loop=False, playing=True, n_out=2):
+        return self.add_node(RESAMPLER, 0, n_out, [float(sample), ratio, 1.0 if loop else 0.0, 1.0 if playing else 0.0])
+
+    def spatial(self, x, y, z, n_in=1):
+        return self.add_node(SPATIAL, n_in, 2, [x, y, z])
 
     def connect_stereo(self, src, dst, dst_port0=0, src_port0=0):
         self.connect(src, src_port0, dst, dst_port0)

@@ -398,6 +398,44 @@ def scenario_chain_events(e, n_voices=37, radix=32, src_frames=1000, **kw):
     return np.concatenate(outs)
 
 
+def scenario_spatial_scene(e, n_sources=7, blocks=12, src_frames=2500):
+    """moving sources: resampler (varispeed, some looping, one i16, one mono-to-stereo) -> spatialiser -> sum -> out.
+    Exercises the 32.32 position arithmetic (loop wrap, one-shot end), the ITD history across blocks, gain ramps
+    from position changes, ratio changes and seeks tagged at later blocks.  SPEC nodes: generic executor."""
+    from fwapi import RESAMPLER, SPATIAL
+    rng = np.random.default_rng(31)
+    m = e.sum(n_sources + 1)
+    srcs = []
+    for v in range(n_sources):
+        ch = 1 if v % 3 else 2
+        data = voice_source(7000 + v, src_frames, ch)
+        if v == 2:
+            smp = e.new_sample(PLANAR_I16, ch, np.round(data * 32767).astype(np.int16))
+        else:
+            smp = e.new_sample(PLANAR_F32, ch, data)
+        ratio = [1.0, 44100.0 / 48000.0, 1.5, 0.37, 2.25, 0.999, 1.0 / 3.0][v % 7]
+        rs = e.resampler(smp, ratio, loop=(v % 2 == 0), n_out=ch)
+        sp = e.spatial(float(rng.uniform(-5, 5)), float(rng.uniform(-1, 1)), float(rng.uniform(-5, 5)), n_in=ch)
+        for c in range(ch):
+            e.connect(rs, c, sp, c)
+        e.connect_stereo(sp, m, 2 * v)
+        srcs.append(dict(rs=rs, sp=sp))
+    direct = e.resampler(e.new_sample(PLANAR_F32, 1, voice_source(7100, 900, 1)), 0.8, loop=True, n_out=2)  # mono -> L,R
+    e.connect_stereo(direct, m, 2 * n_sources)
+    e.connect_stereo(m, e.graph_out_node)
+    e.update()
+    out1 = e.process_blocks(blocks // 3)
+    e.set_param(srcs[0]["sp"], 0, 3.0)                     # move right: gains ramp, ITD switches at the block start
+    e.set_param(srcs[0]["sp"], 2, 0.5, at_block=1)
+    e.set_param(srcs[1]["sp"], 0, -0.2, at_block=2)
+    e.set_param(srcs[1]["rs"], 1, 0.5, at_block=1)         # ratio change
+    e.set_param(srcs[3]["rs"], 4, 100.0, at_block=2)       # seek
+    e.set_param(srcs[-1]["rs"], 3, 0.0, at_block=1)        # pause ...
+    e.set_param(srcs[-1]["rs"], 3, 1.0, at_block=3)        # ... and resume
+    out2 = e.process_blocks(blocks - blocks // 3)
+    return np.concatenate([out1, out2])
+
+
 def reverb_ir(seed, taps, channels=2, decay=None):
     """exponentially decaying seeded noise, L1-normalised per channel."""
     decay = decay or taps / 4.0

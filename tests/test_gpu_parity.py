@@ -192,6 +192,8 @@ def run_case(name, **gpu_kw):
         "mixed_generic_nobeep": lambda e: scenarios.scenario_mixed_generic(e, use_beep=False),
         "graph_inputs": scenarios.scenario_graph_inputs,
         "cfg3_chain": scenarios.scenario_cfg3_chain,
+        "spatial_scene": scenarios.scenario_spatial_scene,
+        "spatial_scene_b96": lambda e: scenarios.scenario_spatial_scene(e, n_sources=4, blocks=9),
         "chain_steady_40": lambda e: scenarios.scenario_chain_steady(e, 40, 6),
         "chain_steady_bq_only_i16": lambda e: scenarios.scenario_chain_steady(e, 21, 9, radix=4, delay=False,
                                                                               fmt=fwapi.INTERLEAVED_I16),
@@ -209,7 +211,7 @@ def run_case(name, **gpu_kw):
            "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64, "cfg3_chain": 128, "cfg4_reverb": 128,
            "cfg4_reverb_2irs_mono": 64, "chain_steady_40": 256, "chain_steady_bq_only_i16": 64,
            "chain_steady_dl_only_pan": 128, "chain_events_37": 128, "chain_events_19_r2_pan": 64,
-           "chain_steady_40_d128": 256, "chain_events_37_d130": 128}[name]
+           "chain_steady_40_d128": 256, "chain_events_37_d130": 128, "spatial_scene": 128, "spatial_scene_b96": 96}[name]
     kw = dict(max_block_frames=mbf)
     if name == "graph_inputs":
         kw["num_graph_inputs"] = 3
@@ -345,6 +347,56 @@ def test_config3_full_size_chain_plan_equals_generic_and_oracle_prefix():
     o = oracle(max_block_frames=512)
     oo = scenarios.scenario_chain_steady(o, V, 1, **kw)
     assert_bits_equal(oo, of[:oo.size], "4096 voices vs oracle")
+
+
+@pytest.mark.parametrize("name", ["spatial_scene", "spatial_scene_b96"])
+def test_resampler_and_spatialiser_scene_bit_exact(name):
+    out_o, out_g, g = run_case(name)
+    assert g.cx.plan_kind() == 0
+    assert_bits_equal(out_o, out_g, name)
+    gold = json.load(open(GOLDEN))
+    assert digest(out_g) == gold[name]
+
+
+@pytest.mark.parametrize("fmt", [fwapi.PLANAR_F32, fwapi.INTERLEAVED_I16, fwapi.PLANAR_U16])
+@pytest.mark.parametrize("ratio,loop", [(1.0, False), (44100.0 / 48000.0, True), (2.7, True), (0.11, False), (3.0, False)])
+def test_resampler_node_level(fmt, ratio, loop):
+    from fwapi import RESAMPLER
+
+    frames = 300
+    rng = np.random.default_rng(int(ratio * 100) + fmt)
+    if fmt == fwapi.PLANAR_F32:
+        raw = (rng.random((2, frames), dtype=f32) * 2 - 1).astype(f32)
+    elif fmt == fwapi.INTERLEAVED_I16:
+        raw = rng.integers(-32768, 32768, size=(frames, 2)).astype(np.int16)
+    else:
+        raw = rng.integers(0, 65536, size=(2, frames)).astype(np.uint16)
+    for n_out in (1, 2, 3):
+        o = OracleEngine(max_block_frames=128)
+        g = GpuEngine(max_block_frames=128)
+        nodes = []
+        for e in (o, g):
+            smp = e.new_sample(fmt, 2, raw)
+            nodes.append(e.resampler(smp, ratio, loop=loop, n_out=n_out))
+            e.update()
+        for b in range(8):
+            both((o, nodes[0]), (g, nodes[1]), 128, [], n_out, what="resampler ratio %g loop %d block %d" % (ratio, loop, b))
+
+
+@pytest.mark.parametrize("n_in", [1, 2])
+@pytest.mark.parametrize("pos", [(0.0, 0.0, -1.0), (4.0, 1.0, 0.5), (-0.3, 0.0, 0.1), (0.0, 0.0, 0.0), (-20.0, 5.0, -3.0)])
+def test_spatial_node_level(n_in, pos):
+    from fwapi import SPATIAL
+
+    po, pg = pair(SPATIAL, n_in, 2, list(pos), mbf=128)
+    x = fwapi.xorshift_uniform(17 + n_in, n_in * 128 * 6).reshape(6, n_in, 128)
+    for b in range(3):
+        both(po, pg, 128, x[b], 2, what="spatial %r block %d" % (pos, b))
+    for e, n in (po, pg):
+        e.set_param(n, 0, -pos[0] + 1.0)      # the source jumps to the other side: gains ramp, delays swap ears
+    for b in range(3, 6):
+        both(po, pg, 128, x[b], 2, what="spatial moved block %d" % b)
+    both(po, pg, 40, x[0][:, :40], 2, what="spatial partial block")   # frames < SP_HIST: history shifts
 
 
 @pytest.mark.parametrize("name", ["cfg4_reverb", "cfg4_reverb_2irs_mono"])

@@ -38,6 +38,8 @@ CASES = {
     "cfg4_reverb_2irs_mono": lambda: scenarios.scenario_cfg4_reverb(oracle(max_block_frames=64), n_voices=5, taps=700,
                                                                      shared_ir=False, ir_channels=1),
     "graph_inputs": lambda: scenarios.scenario_graph_inputs(oracle(max_block_frames=64, num_graph_inputs=3)),
+    "spatial_scene": lambda: scenarios.scenario_spatial_scene(oracle(max_block_frames=128)),
+    "spatial_scene_b96": lambda: scenarios.scenario_spatial_scene(oracle(max_block_frames=96), n_sources=4, blocks=9),
     "chain_steady_40": lambda: scenarios.scenario_chain_steady(oracle(max_block_frames=256), 40, 6),
     "chain_steady_bq_only_i16": lambda: scenarios.scenario_chain_steady(oracle(max_block_frames=64), 21, 9, radix=4, delay=False,
                                                                           fmt=fwapi.INTERLEAVED_I16),
@@ -126,3 +128,90 @@ def test_fir_spec_matches_f64_convolution():
     ref = np.convolve(x.astype(np.float64), h[0].astype(np.float64))[:x.size]
     bound = np.convolve(np.abs(x).astype(np.float64), np.abs(h[0]).astype(np.float64))[:x.size]
     assert np.max(np.abs(y - ref) / np.maximum(bound, 1e-30)) < 16 * 2.0 ** -24
+
+
+def rs_table_f64():
+    """independent numpy evaluation of the SPEC filter bank: Kaiser(beta 8)-windowed sinc, cutoff 0.9"""
+    P, T, fc, beta = 32, 16, 0.9, 8.0
+    h = np.zeros((P, T))
+    for ph in range(P):
+        t = (np.arange(T) - (T // 2 - 1)) - ph / P
+        r = t / (T / 2)
+        w = np.where(np.abs(r) < 1, np.i0(beta * np.sqrt(np.clip(1 - r * r, 0, None))) / np.i0(beta), 0.0)
+        row = fc * np.sinc(fc * t) * w
+        h[ph] = row / row.sum()
+    return h
+
+
+def rs_reference(x, ratio, n_out, loop=False):
+    """f64 evaluation at the SPEC's 32.32 fixed-point positions"""
+    h = rs_table_f64()
+    step = int(round(float(np.float32(ratio)) * 2 ** 32))   # the node takes its ratio as an f32
+    y = np.zeros(n_out)
+    L = x.size
+    for i in range(n_out):
+        p = i * step
+        if loop:
+            p %= L << 32
+        idx, ph = p >> 32, (p >> 27) & 31
+        j = idx - 7 + np.arange(16)
+        xs = x[j % L] if loop else np.where((j >= 0) & (j < L), x[np.clip(j, 0, L - 1)], 0.0)
+        y[i] = np.dot(h[ph], xs.astype(np.float64))
+    return y
+
+
+def test_resampler_spec_reproduces_a_sine_at_the_converted_rate():
+    # 44.1 kHz source played into the 48 kHz stream (ratio 44100/48000): a 1 kHz sine stays a 1 kHz sine
+    e = fwapi.OracleEngine(max_block_frames=256)
+    n_src = 6000
+    t = np.arange(n_src) / 44100.0
+    x = np.sin(2 * np.pi * 1000.0 * t).astype(np.float32)
+    rs = e.resampler(e.new_sample(fwapi.PLANAR_F32, 1, x[None, :]), 44100.0 / 48000.0, n_out=1)
+    e.update()
+    y = np.concatenate([e.node_process(rs, 256, [], 1)[0][0] for _ in range(16)])
+    n = np.arange(y.size)
+    ref = np.sin(2 * np.pi * 1000.0 * n / 48000.0)
+    # positions are quantised to 1/32 source sample (RS_PHASES): phase error <= 2*pi*1000/44100/32 = 4.5e-3
+    assert np.max(np.abs(y[64:] - ref[64:])) < 8e-3
+    # against the independent f64 evaluation of the same table at the same positions: f32 rounding only
+    assert np.max(np.abs(y - rs_reference(x, 44100.0 / 48000.0, y.size))) < 2e-6
+
+
+def test_resampler_fixed_point_positions_loop_and_end():
+    x = fwapi.xorshift_uniform(3, 500)
+    for ratio, loop in ((1.0, False), (0.37, False), (2.25, True), (1.0 / 3.0, True)):
+        e = fwapi.OracleEngine(max_block_frames=64)
+        rs = e.resampler(e.new_sample(fwapi.PLANAR_F32, 1, x[None, :]), ratio, loop=loop, n_out=1)
+        e.update()
+        y = np.concatenate([e.node_process(rs, 64, [], 1)[0][0] for _ in range(12)])
+        ref = rs_reference(x, ratio, y.size, loop)
+        if not loop:   # stops at the first block boundary after the window has left the sample
+            end = next((b * 64 for b in range(1, 13) if (b * 64 * int(round(float(np.float32(ratio)) * 2 ** 32)) >> 32) >= 500 + 8), y.size)
+            assert not np.any(y[end:])
+            ref[end:] = 0
+        assert np.max(np.abs(y - ref)) < 2e-6, (ratio, loop)
+    # looping with ratio 0.5 over 256 frames is periodic with 512 output frames: exact 32.32 arithmetic, no drift
+    e2 = fwapi.OracleEngine(max_block_frames=64)
+    rs2 = e2.resampler(e2.new_sample(fwapi.PLANAR_F32, 1, x[None, :256]), 0.5, loop=True, n_out=1)
+    e2.update()
+    z = np.concatenate([e2.node_process(rs2, 64, [], 1)[0][0] for _ in range(24)])
+    assert np.array_equal(z[:512], z[512:1024])
+
+
+def test_spatial_spec_against_numpy():
+    f32 = np.float32
+    e = fwapi.OracleEngine(max_block_frames=64)
+    sp = e.spatial(2.0, 0.0, -2.0, n_in=1)        # 45 degrees to the right, distance 2.83
+    e.update()
+    x = fwapi.xorshift_uniform(11, 192)
+    y = np.concatenate([np.stack(e.node_process(sp, 64, [x[i:i + 64]], 2)[0], axis=1) for i in range(0, 192, 64)])
+    d = np.sqrt(8.0)
+    s = 2.0 / d
+    th = (s + 1) * np.pi / 4
+    gl, gr = f32(np.cos(th) / d), f32(np.sin(th) / d)
+    dl = int(round(s * round(0.00066 * 48000)))
+    xl = np.concatenate([np.zeros(dl, f32), x])[:192]
+    assert dl == 23
+    assert np.array_equal(y[:, 0], (xl * gl).astype(f32))       # left ear: later and quieter
+    assert np.array_equal(y[:, 1], (x * gr).astype(f32))        # right ear: no delay
+    assert gr > gl

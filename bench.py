@@ -313,14 +313,17 @@ def main():
         ctl_ms, ctl_n = cx.timing_read(1)   # k_voice_control
         up_ms, up_n = cx.timing_read(2)     # k_bus_sum levels + k_graph_out
         gen_ms, gen_n = cx.timing_read(3)   # generic executor: all level kernels of one block (cfg4: + FIR GEMM)
-        if wl == "cfg4" and gen_n:
-            # the level kernels + the FIR GEMM of one block; the GEMM dominates (profiles/*cfg4_kernel_stats.csv)
+        fir_ms, fir_n = cx.timing_read(4)   # k_fir_gemm alone
+        if wl == "cfg4" and fir_n:
+            # one k_fir_gemm launch = the FIR bank of one block: 512 rows x 256 cols x 65791 window positions
             flops = 2.0 * 2 * args.taps * V * B  # direct-form definition: 2 ch x 2 flop x T per voice-sample
-            avg_s = gen_ms / gen_n / 1e3
+            avg_s = fir_ms / fir_n / 1e3
             ach = flops / avg_s / 1e12
-            roofline = {"bound": "mfma", "kernel": "k_fir_gemm (+ level kernels of the block)", "achieved": ach,
-                        "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
-                        "algorithmic_flops_per_block": flops, "avg_block_us": avg_s * 1e6, "blocks": gen_n}
+            traffic, traffic_src = pmc_traffic("k_fir_gemm", V, B, K)
+            roofline = {"bound": "mfma", "kernel": "k_fir_gemm", "achieved": ach,
+                        "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic,
+                        "traffic_source": traffic_src, "algorithmic_flops_per_launch": flops, "avg_launch_us": avg_s * 1e6,
+                        "launches": fir_n, "whole_block_us_all_kernels": gen_ms / max(gen_n, 1) * 1e3}
         elif dom_n:
             per_vs = 24.0 if wl == "cfg3" else 8.0  # source L+R once (+ delay ring read + write)
             kernel = "k_chain" if wl == "cfg3" else "k_leaf_sum"

@@ -130,7 +130,7 @@ struct fwgpu_ctx {
 
     // timing
     bool timing = false;
-    TimerCat timers[4];
+    TimerCat timers[5];  // 0 fused leaf kernel, 1 control kernel, 2 upper sums + out, 3 generic block, 4 k_fir_gemm alone
 
     fwgpu_ctx(uint32_t gin, uint32_t gout) : graph(gin, gout) {}
 };
@@ -651,8 +651,8 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         if (ext_need > c->ext_cap) {
             size_t cap = std::max<size_t>(ext_need * 2, 4096);
             DevBuf nb;
-            HIPC(c, nb.ensure(cap * sizeof(float)));
-            HIPC(c, hipMemset(nb.p, 0, cap * sizeof(float)));
+            HIPC(c, nb.ensure((cap + 256) * sizeof(float)));  // slack: vector loads may overhang the last slice
+            HIPC(c, hipMemset(nb.p, 0, (cap + 256) * sizeof(float)));
             if (c->d_ext.p && c->ext_used)
                 HIPC(c, hipMemcpy(nb.p, c->d_ext.p, c->ext_used * sizeof(float), hipMemcpyDeviceToDevice));
             c->d_ext.release();
@@ -954,10 +954,25 @@ int run_generic_block(fwgpu_ctx* c, int frames, uint32_t cmd_block, const float*
     for (size_t l = 0; l < c->level_cnt.size(); ++l) {
         LCHK(c, launch_level(c->stream, v, c->d_level_nodes.as<int>() + c->level_off[l], c->level_cnt[l], 1, cmd_block));
         for (const fwgpu_ctx::FirGroup& g : c->fir_groups)
-            if (g.level == (int)l)
+            if (g.level == (int)l) {
+                hipEvent_t g0 = nullptr, g1 = nullptr;
+                if (c->timing) {  // the GEMM alone, on its own event pair (no record of its own: launch_fir does it)
+                    TimerCat& t = c->timers[4];
+                    if (t.used == t.ev.size() && t.ev.size() < 8192) {
+                        hipEvent_t a, b;
+                        if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) t.ev.emplace_back(a, b);
+                    }
+                    if (t.used < t.ev.size()) {
+                        g0 = t.ev[t.used].first;
+                        g1 = t.ev[t.used].second;
+                        t.used++;
+                        t.launches++;
+                    }
+                }
                 LCHK(c, launch_fir(c->stream, v, c->d_fir_rows.as<FirRow>() + g.row_off, g.n_rows,
                                    c->d_fir_tiles.as<uint32_t>() + g.tile_off, g.T, c->d_fir_partials.as<float>(),
-                                   c->d_fir_partials.cap / sizeof(float)));
+                                   c->d_fir_partials.cap / sizeof(float), g0, g1));
+            }
     }
     timer_end(c, e1);
     LCHK(c, launch_graph_out(c->stream, c->d_pool.as<float>(), c->d_flags.as<uint8_t>(), c->stride, 0, 0,
@@ -1603,7 +1618,7 @@ int fwgpu_timing_enable(fwgpu_ctx* c, int on) {
     return 0;
 }
 int fwgpu_timing_read(fwgpu_ctx* c, int which, double* total_ms, uint64_t* launches) {
-    if (which < 0 || which > 3) return fail(c, FWGPU_ERR_INVALID, "timer index");
+    if (which < 0 || which > 4) return fail(c, FWGPU_ERR_INVALID, "timer index");
     timer_drain(c);
     *total_ms = c->timers[which].acc_ms;
     *launches = c->timers[which].launches;

@@ -2117,7 +2117,8 @@ __global__ __launch_bounds__(256) void k_fir_gemm(DevView v, const FirRow* __res
     const float* h = v.ext + tile_h_off[blockIdx.x];  // every row of a tile convolves with the same h
 
     // loader role: thread t stages 8 consecutive window positions of row (t >> 3)
-    const int lrow = tid >> 3, lcol = (tid & 7) * 8;
+    constexpr int NA = FIR_KC / 8;  // floats per loader thread: 8 threads cover one row of the chunk
+    const int lrow = tid >> 3, lcol = (tid & 7) * NA;
     const float* wptr = nullptr;
     if (row0 + lrow < n_rows && rows[row0 + lrow].state >= 0) {
         const FirRow row = rows[row0 + lrow];
@@ -2126,28 +2127,39 @@ __global__ __launch_bounds__(256) void k_fir_gemm(DevView v, const FirRow* __res
         const uint32_t e2 = (p + (uint32_t)frames - 1u) % R + R;  // newest sample, upper mirror
         wptr = v.ext + s->ext_off + (size_t)row.ch * 2u * R + (e2 + 1u - W);
     }
-    float areg[8], hreg[2];
+    // Staging loads are unconditional and vectorised (addresses clamped into the ext pool, which carries 256 floats
+    // of slack) and only ISSUED here; the selects that zero what lies outside the segment / the impulse response
+    // touch the loaded registers — and therefore wait for them — in store_chunk, one MFMA loop later.  (A branch
+    // per element would serialise eight HBM round trips per chunk; a select next to the load would expose one.)
+    v4f xa[NA / 4];
+#pragma unroll
+    for (int j = 0; j < NA / 4; ++j) xa[j] = splat(0.f);
+    float hraw0 = 0.f, hraw1 = 0.f;
+    uint32_t m0_staged = 0;
+    const float* wsafe = wptr ? wptr : v.ext;
+    // Hw[q] = h[k], k = ib + T-1 - m0 - (KC-1) + q  (0 outside [0, T))
+    auto h_index = [&](uint32_t m0, int q) -> long long {
+        return (long long)ib + (long long)T - 1 - (long long)m0 - (FIR_KC - 1) + q;
+    };
+    auto h_clamp = [&](long long k) -> long long { return k < 0 ? 0 : (k >= (long long)T ? (long long)T - 1 : k); };
     auto load_chunk = [&](uint32_t m0) {
+        m0_staged = m0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            uint32_t m = m0 + (uint32_t)(lcol + j);
-            areg[j] = (wptr && m < m_end) ? wptr[m] : 0.f;
-        }
-        // Hw[q] = h[k], k = ib + T-1 - m0 - (KC-1) + q  (0 outside [0, T))
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int q = tid + j * 256;
-            long long k = (long long)ib + (long long)T - 1 - (long long)m0 - (FIR_KC - 1) + q;
-            hreg[j] = (q < 256 + FIR_KC && k >= 0 && k < (long long)T) ? h[k] : 0.f;
-        }
+        for (int j = 0; j < NA / 4; ++j) xa[j] = *(const v4f_u*)(wsafe + m0 + (uint32_t)(lcol + 4 * j));
+        hraw0 = __builtin_nontemporal_load(h + h_clamp(h_index(m0, tid)));
+        if (wave < FIR_KC / 64) hraw1 = __builtin_nontemporal_load(h + h_clamp(h_index(m0, tid + 256)));  // q = 256 .. 256+KC-1
     };
     auto store_chunk = [&](int buf) {
         float* a = As + buf * 32 * FIR_PITCH + lrow * FIR_PITCH + lcol;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = areg[j];
+        for (int j = 0; j < NA; ++j) {
+            const uint32_t m = m0_staged + (uint32_t)(lcol + j);
+            a[j] = (wptr && m < m_end) ? xa[j >> 2][j & 3] : 0.f;
+        }
         float* hw = Hw + buf * (256 + FIR_KC);
-        if (tid < 256 + FIR_KC) hw[tid] = hreg[0];
-        if (tid + 256 < 256 + FIR_KC) hw[tid + 256] = hreg[1];
+        const long long k0 = h_index(m0_staged, tid), k1 = h_index(m0_staged, tid + 256);
+        hw[tid] = (k0 >= 0 && k0 < (long long)T) ? hraw0 : 0.f;
+        if (tid < FIR_KC) hw[tid + 256] = (k1 >= 0 && k1 < (long long)T) ? hraw1 : 0.f;
     };
 
     v16f acc0, acc1;
@@ -2167,12 +2179,18 @@ __global__ __launch_bounds__(256) void k_fir_gemm(DevView v, const FirRow* __res
         if (c + 1 < n_chunks) load_chunk(m_begin + (c + 1) * FIR_KC);  // in flight during the MFMAs below
         const float* a = As + buf * 32 * FIR_PITCH + a_row * FIR_PITCH;
         const float* hw = Hw + buf * (256 + FIR_KC) + (FIR_KC - 1) + (lane & 31);
-#pragma unroll 8
+        // operands of step kk+2 are read while the MFMAs of step kk run (the matrix pipe takes 64 cycles each)
+        float av_n = a[k_half], b0_n = hw[ct0 * 32 - k_half], b1_n = hw[ct1 * 32 - k_half];
+#pragma unroll
         for (int kk = 0; kk < FIR_KC; kk += 2) {  // ascending m: the fmaf chain order of the SPEC
-            const int k = kk + k_half;
-            const float av = a[k];
-            const float b0 = hw[ct0 * 32 - k];
-            const float b1 = hw[ct1 * 32 - k];
+            const float av = av_n, b0 = b0_n, b1 = b1_n;
+            if (kk + 2 < FIR_KC) {
+                const int k = kk + 2 + k_half;
+                av_n = a[k];
+                b0_n = hw[ct0 * 32 - k];
+                b1_n = hw[ct1 * 32 - k];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads above ahead of the MFMAs below
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
         }
@@ -2284,7 +2302,7 @@ int launch_ir_convert(hipStream_t s, const SampleDesc* samples, int sample, int 
     return (int)hipGetLastError();
 }
 int launch_fir(hipStream_t s, const DevView& v, const FirRow* d_rows, int n_rows, const uint32_t* d_tile_h_off, uint32_t T,
-               float* d_partials, size_t partial_cap_floats) {
+               float* d_partials, size_t partial_cap_floats, hipEvent_t gemm_begin, hipEvent_t gemm_end) {
     if (n_rows <= 0 || v.frames <= 0) return 0;
     const uint32_t W = T - 1u + (uint32_t)v.frames;
     const int n_segs = (int)((W + FIR_SEG - 1) / FIR_SEG);
@@ -2292,8 +2310,10 @@ int launch_fir(hipStream_t s, const DevView& v, const FirRow* d_rows, int n_rows
     const int col_groups = (v.frames + 255) / 256, n_pad = col_groups * 256;
     if ((size_t)n_segs * n_rows_pad * n_pad > partial_cap_floats) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_fir_append, dim3(n_rows), dim3(256), 0, s, v, d_rows, n_rows);
+    if (gemm_begin) (void)hipEventRecord(gemm_begin, s);
     hipLaunchKernelGGL(k_fir_gemm, dim3(row_tiles, n_segs, col_groups), dim3(256), 0, s, v, d_rows, n_rows, d_tile_h_off, T,
                        d_partials, n_rows_pad, n_pad);
+    if (gemm_end) (void)hipEventRecord(gemm_end, s);
     hipLaunchKernelGGL(k_fir_reduce, dim3(n_rows), dim3(256), 0, s, v, d_rows, n_rows, d_partials, n_segs, n_rows_pad,
                        n_pad);
     return (int)hipGetLastError();

@@ -155,7 +155,9 @@ static_assert(sizeof(VoiceCache) == 48, "VoiceCache layout");
 
 // ---------------------------------------------------------------- FIR convolution bank (MFMA GEMM)
 #define FIR_SEG 4096  // window positions per split-K segment — part of the numeric SPEC (summation order)
-#define FIR_KC 64     // window positions staged per LDS chunk
+#ifndef FIR_KC
+#define FIR_KC 128    // window positions staged per LDS chunk (64 or 128; not part of the numeric SPEC)
+#endif
 struct FirRow {  // one GEMM row = one channel of one FIR node
     int state;
     int ch;

@@ -177,7 +177,8 @@ int fwgpu_node_process(fwgpu_ctx* ctx, int64_t node, uint64_t frames, const floa
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernel on the ctx stream */
 int fwgpu_timing_enable(fwgpu_ctx* ctx, int on);
-/* which: 0 = fused leaf kernel (dominant), 1 = control kernel, 2 = upper/out kernels, 3 = generic level kernels.
+/* which: 0 = fused leaf kernel (k_leaf_sum / k_chain, dominant), 1 = control kernel, 2 = upper/out kernels,
+ * 3 = all kernels of one generic-executor block, 4 = k_fir_gemm alone (FIR banks).
  * Returns accumulated milliseconds and launch count since the last reset. */
 int fwgpu_timing_read(fwgpu_ctx* ctx, int which, double* total_ms, uint64_t* launches);
 int fwgpu_timing_reset(fwgpu_ctx* ctx);

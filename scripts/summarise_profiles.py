@@ -1,0 +1,69 @@
+"""Turns the raw rocprofv3 output of scripts/collect_profiles.sh into the two small files per workload that are
+committed under profiles/: the kernel-stats table and the per-launch HBM traffic (FETCH_SIZE + WRITE_SIZE from
+separate --pmc passes; FETCH_SIZE doubled for gfx950's 16-B/lane streaming reads as MI355X_MICROARCH.md §HBM
+prescribes, WRITE_SIZE as reported)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+tag, cfg, steps, raw, outdir = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+V, B, K, F, _ = bench.DEFAULTS[cfg]
+
+
+def find(pattern):
+    m = glob.glob(pattern, recursive=True)
+    return m[0] if m else None
+
+
+stats = find(raw + "_stats/**/*kernel_stats.csv")
+if stats:
+    rows = list(csv.reader(open(stats)))
+    with open(os.path.join(outdir, "%s_%s_kernel_stats.csv" % (tag, cfg)), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --workload %s --no-cpu-baseline --steps %d --warmup 3"
+                "   (MI355X, %s; %d voices, block %d, %d blocks per step)\n" % (cfg, steps, tag, V, B, K))
+        w = csv.writer(f)
+        for r in rows[:14]:
+            w.writerow(r)
+
+
+def per_kernel(ctr):
+    f = find(raw + "_%s/**/*counter_collection.csv" % ctr)
+    acc = collections.defaultdict(list)
+    if f:
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == ctr:
+                acc[row["Kernel_Name"].split("(")[0].replace("void ", "").replace("fwgpu::", "")].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items() if k.startswith("k_")}
+
+
+fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
+per_vs = {"cfg2": 8.0, "cfg3": 24.0, "cfg5": 8.0}.get(cfg)
+dom = {"cfg2": "k_leaf_sum", "cfg3": "k_chain", "cfg5": "k_leaf_sum", "cfg4": "k_fir_gemm"}[cfg]
+out = {
+    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --workload %s --no-cpu-baseline "
+               "--no-kernel-timing --steps 4 --warmup 2 (one pass per counter)" % cfg,
+    "workload": {"name": cfg, "voices": V, "block": B, "blocks_per_step": K},
+    "units": "rocprofv3 reports KiB; gfx950 FETCH_SIZE counts 1/2 of wide coalesced reads (MI355X_MICROARCH.md §HBM) -> "
+             "doubled; WRITE_SIZE as reported",
+    "per_launch_raw_KiB": {k: {"FETCH_SIZE": fetch.get(k), "WRITE_SIZE": write.get(k)} for k in sorted(set(fetch) | set(write))},
+}
+for k in sorted(set(fetch) | set(write)):
+    name = k.split("<")[0]
+    if name != dom:
+        continue
+    fb = 2.0 * 1024.0 * fetch.get(k, 0.0)
+    wb = 1024.0 * write.get(k, 0.0)
+    ent = {"fetch_bytes_corrected": fb, "write_bytes": wb, "traffic_bytes": fb + wb}
+    if per_vs:
+        alg = per_vs * V * B * K
+        ent["algorithmic_bytes"] = alg
+        ent["traffic_over_algorithmic"] = (fb + wb) / alg
+    out[name] = ent
+json.dump(out, open(os.path.join(outdir, "%s_%s_pmc_hbm_traffic.json" % (tag, cfg)), "w"), indent=1)
+print(cfg, json.dumps({k: v for k, v in out.items() if k.startswith("k_")}))

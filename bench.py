@@ -234,6 +234,12 @@ def main():
     steps = args.steps or dS
     wl = args.workload
 
+    # stdout carries exactly ONE line (the JSON, rank 0): everything else that writes to fd 1 — RCCL's version banner
+    # and warnings come from C stdio, flushed whenever — is sent to stderr for the life of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -243,10 +249,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("FWGPU_BENCH_FORCE_DIST"):  # the env var: exercise the RCCL path on one GPU
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -273,15 +282,20 @@ def main():
         want_plan = 1
     start_voices(cx, fa, samplers, src, F)
     assert cx.plan_kind() == want_plan, "expected launch plan %d, got %d" % (want_plan, cx.plan_kind())
-    out = torch.empty(K * B * 2, dtype=torch.float32, device="cuda")
+    # two bus buffers: with N > 1 the reduction of step i (RCCL, its own stream) overlaps the compute of step i+1 —
+    # the mix bus is a sink, nothing in a shard reads it back
+    outs = [torch.empty(K * B * 2, dtype=torch.float32, device="cuda") for _ in range(2)]
+    reducer = shard.BusReducer(dist, outs, args.bus_reduce) if dist is not None else None
+    step_no = [0]
 
     def step():
-        cx.process_blocks_device(K, out.data_ptr(), 2)
-        if dist is not None:  # the mix bus: one collective per step over K x 2 x block f32
-            if args.bus_reduce == "allreduce":
-                shard.reduce_bus_allreduce(out, dist)
-            else:
-                shard.reduce_bus_ordered(out, dist)
+        b = step_no[0] % 2
+        step_no[0] += 1
+        if reducer is not None:
+            reducer.wait(b)  # the collective that last used this buffer (two steps ago)
+        cx.process_blocks_device(K, outs[b].data_ptr(), 2)
+        if reducer is not None:  # the mix bus: one collective per step over K x 2 x block f32
+            reducer.submit(b)
 
     for _ in range(args.warmup):
         step()
@@ -296,6 +310,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if reducer is not None:
+        reducer.wait_all()  # every bus of the timed region is fully reduced before the clock stops
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -375,10 +391,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, V, B, args.radix, args.taps, args.cpu_secs)
-        print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

@@ -42,3 +42,44 @@ def reduce_bus_ordered(bus, dist, group=None):
         acc += p
     bus.copy_(acc)
     return bus
+
+
+class BusReducer(object):
+    """The mix bus is a sink (nothing in a shard reads it back), so the reduction of step i can run while step i+1
+    computes: each step writes its partial bus into the next of `bufs` (>= 2 buffers), `submit(i)` starts the
+    collective on that buffer asynchronously (RCCL's own stream on a GPU) and `wait(i)` is called only right before
+    the buffer is overwritten again — or read.  `mode` as in bench.py: "allreduce" or "ordered" (bit-exact)."""
+
+    def __init__(self, dist, bufs, mode="allreduce", group=None):
+        import torch
+
+        self.dist, self.bufs, self.mode, self.group = dist, list(bufs), mode, group
+        self.works = [None] * len(self.bufs)
+        self.parts = None
+        if mode == "ordered":
+            world = dist.get_world_size(group)
+            self.parts = [[torch.empty_like(b) for _ in range(world)] for b in self.bufs]
+
+    def submit(self, i):
+        assert self.works[i] is None, "buffer %d is still being reduced" % i
+        if self.mode == "allreduce":
+            self.works[i] = self.dist.all_reduce(self.bufs[i], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self.works[i] = self.dist.all_gather(self.parts[i], self.bufs[i], group=self.group, async_op=True)
+
+    def wait(self, i):
+        w = self.works[i]
+        if w is None:
+            return self.bufs[i]
+        w.wait()  # on a GPU: the current stream waits for the collective, the host does not block
+        self.works[i] = None
+        if self.mode == "ordered":
+            acc = self.bufs[i]
+            acc.copy_(self.parts[i][0])          # sum.rs:117 out = in0
+            for p in self.parts[i][1:]:           # sum.rs:119-131 out += in_p, port (= rank) order
+                acc += p
+        return self.bufs[i]
+
+    def wait_all(self):
+        for i in range(len(self.bufs)):
+            self.wait(i)

@@ -94,17 +94,32 @@ def worker(rank, world, port, mode, q):
     e.connect_stereo(root, e.graph_out_node)
     e.update()
     start_voices(e, voices)
-    bus = torch.from_numpy(e.process_blocks(BLOCKS).copy())
-    if mode == "allreduce":
-        shard.reduce_bus_allreduce(bus, dist)
+    if mode.startswith("pipelined"):
+        # bench.py's N > 1 loop: two bus buffers, the reduction of step i overlaps the compute of step i + 1
+        bufs = [torch.empty(2 * BLOCK * 2), torch.empty(2 * BLOCK * 2)]
+        red = shard.BusReducer(dist, bufs, "ordered" if mode.endswith("ordered") else "allreduce")
+        outs = []
+        for step in range(BLOCKS // 2):
+            b = step % 2
+            if step >= 2:
+                outs.append(red.wait(b).numpy().copy())
+            bufs[b].copy_(torch.from_numpy(e.process_blocks(2)))
+            red.submit(b)
+        for step in range(max(0, BLOCKS // 2 - 2), BLOCKS // 2):
+            outs.append(red.wait(step % 2).numpy().copy())
+        bus = torch.from_numpy(np.concatenate(outs))
     else:
-        shard.reduce_bus_ordered(bus, dist)
+        bus = torch.from_numpy(e.process_blocks(BLOCKS).copy())
+        if mode == "allreduce":
+            shard.reduce_bus_allreduce(bus, dist)
+        else:
+            shard.reduce_bus_ordered(bus, dist)
     q.put((rank, bus.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "ordered"])
+@pytest.mark.parametrize("mode", ["allreduce", "ordered", "pipelined_allreduce", "pipelined_ordered"])
 def test_two_rank_sharded_bus_matches_whole_graph(mode):
     from firewheel_amd import shard
 
@@ -112,7 +127,7 @@ def test_two_rank_sharded_bus_matches_whole_graph(mode):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500) + (0 if mode == "allreduce" else 500)
+    port = 29500 + (os.getpid() % 400) + 400 * ["allreduce", "ordered", "pipelined_allreduce", "pipelined_ordered"].index(mode)
     procs = [ctx.Process(target=worker, args=(r, world, port, mode, q)) for r in range(world)]
     for p in procs:
         p.start()

@@ -37,7 +37,7 @@ MFMA_F32_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md:41 (dense f3
 DEFAULTS = {  # workload -> (voices/GPU, block, blocks per step, source frames per voice, steps)
     "cfg2": (1024, 256, 256, 262144, 100),
     "cfg3": (4096, 512, 32, 65536, 20),
-    "cfg4": (256, 256, 4, 65536, 10),
+    "cfg4": (256, 256, 16, 65536, 10),
     "cfg5": (8192, 1024, 32, 65536, 20),
 }
 
@@ -331,15 +331,16 @@ def main():
         gen_ms, gen_n = cx.timing_read(3)   # generic executor: all level kernels of one block (cfg4: + FIR GEMM)
         fir_ms, fir_n = cx.timing_read(4)   # k_fir_gemm alone
         if wl == "cfg4" and fir_n:
-            # one k_fir_gemm launch = the FIR bank of one block: 512 rows x 256 cols x 65791 window positions
-            flops = 2.0 * 2 * args.taps * V * B  # direct-form definition: 2 ch x 2 flop x T per voice-sample
+            # one k_fir_gemm launch = the FIR bank of the step's K blocks: K x (512 rows x 256 cols x 65791 positions)
+            flops = 2.0 * 2 * args.taps * V * B * K  # direct-form definition: 2 ch x 2 flop x T per voice-sample
             avg_s = fir_ms / fir_n / 1e3
             ach = flops / avg_s / 1e12
             traffic, traffic_src = pmc_traffic("k_fir_gemm", V, B, K)
             roofline = {"bound": "mfma", "kernel": "k_fir_gemm", "achieved": ach,
                         "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic,
                         "traffic_source": traffic_src, "algorithmic_flops_per_launch": flops, "avg_launch_us": avg_s * 1e6,
-                        "launches": fir_n, "whole_block_us_all_kernels": gen_ms / max(gen_n, 1) * 1e3}
+                        "launches": fir_n, "blocks_per_launch": K,
+                        "whole_block_us_all_kernels": gen_ms / max(gen_n, 1) / K * 1e3}
         elif dom_n:
             per_vs = 24.0 if wl == "cfg3" else 8.0  # source L+R once (+ delay ring read + write)
             kernel = "k_chain" if wl == "cfg3" else "k_leaf_sum"

@@ -98,6 +98,7 @@ struct fwgpu_ctx {
 
     // fused plan
     bool fused = false;
+    uint32_t generic_k = 1;  // blocks per generic-executor batch: kmax, capped by what the FIR history rings hold
     bool fused_fx = false;  // the fused plan's leaves run k_chain (biquad / delay in the voice chains)
     int chain_nq = 1;       // k_chain tile size / 64 frames
     int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
@@ -616,7 +617,7 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
                     return fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "FIR node: impulse-response sample was destroyed");
                 uint64_t T = c->samples[ir].desc.frames;
                 if (T == 0 || T > (1u << 24)) return fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "FIR node: 1 <= taps <= 2^24");
-                uint64_t R = T - 1 + c->mbf;
+                uint64_t R = T - 1 + (uint64_t)c->kmax * c->mbf;  // every block of a K-batch finds its whole window in the ring
                 n.init.loop_start = T;
                 n.init.loop_end = R;
                 n.init.playhead = 0;
@@ -776,7 +777,7 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
             c->fir_groups.push_back(fg);
             size_t W = (size_t)fg.T - 1 + c->mbf;
             size_t segs = (W + FIR_SEG - 1) / FIR_SEG;
-            partial_need = std::max(partial_need, segs * (size_t)fg.n_rows * (size_t)((c->mbf + 255) / 256 * 256));
+            partial_need = std::max(partial_need, segs * (size_t)fg.n_rows * (size_t)((c->mbf + 255) / 256 * 256) * c->kmax);
         }
         if (!flat_rows.empty()) {
             if ((rc = upload(c, c->d_fir_rows, flat_rows.data(), flat_rows.size() * sizeof(FirRow)))) return rc;
@@ -784,13 +785,25 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
             HIPC(c, c->d_fir_partials.ensure(partial_need * sizeof(float)));
         }
     }
-    // 4. buffer pool: a new schedule starts from zeroed buffers (schedule.rs:202-203)
-    size_t pool_bytes = (size_t)plan.num_buffers * c->stride * sizeof(float);
-    HIPC(c, c->d_pool.ensure(pool_bytes));
-    HIPC(c, hipMemset(c->d_pool.p, 0, pool_bytes));
-    HIPC(c, c->d_flags.ensure((size_t)plan.num_buffers));
-    HIPC(c, hipMemset(c->d_flags.p, 0, (size_t)plan.num_buffers));
-    HIPC(c, hipMemset(c->d_flags.p, 1, 1));  // buffer 0: constant zero, always flagged silent
+    // 4. buffer pool: a new schedule starts from zeroed buffers (schedule.rs:202-203); one slice per block of a
+    //    generic K-batch.  generic_k: the FIR history rings were sized for the batch size in force when their node was
+    //    activated — a later, larger kmax must not outrun them.
+    c->generic_k = c->kmax;
+    for (int i = 0; i < N; ++i) {
+        if (plan.nodes[i].kind != K_FIR) continue;
+        const HostNode& hn = c->graph.nodes[plan.nodes[i].slot];
+        uint64_t room = (hn.init.loop_end - (hn.init.loop_start - 1)) / c->mbf;  // (R - (T-1)) / block
+        c->generic_k = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->generic_k, room));
+    }
+    {
+        const size_t Kg = c->generic_k;
+        size_t pool_bytes = Kg * (size_t)plan.num_buffers * c->stride * sizeof(float);
+        HIPC(c, c->d_pool.ensure(pool_bytes));
+        HIPC(c, hipMemset(c->d_pool.p, 0, pool_bytes));
+        std::vector<uint8_t> fl(Kg * (size_t)plan.num_buffers, 0);
+        for (size_t k = 0; k < Kg; ++k) fl[k * (size_t)plan.num_buffers] = 1;  // buffer 0: constant zero, always flagged silent
+        if ((rc = upload(c, c->d_flags, fl.data(), fl.size()))) return rc;
+    }
 
     // 5. fused voice-bank plan
     c->fused = false;
@@ -932,8 +945,8 @@ DevView generic_view(fwgpu_ctx* c, int frames) {
     v.rs_table = c->d_rs_table.as<float>();
     v.pool = c->d_pool.as<float>();
     v.flags = c->d_flags.as<uint8_t>();
-    v.pool_blk_stride = 0;
-    v.flags_blk_stride = 0;
+    v.pool_blk_stride = (size_t)c->plan.num_buffers * c->stride;  // one pool slice per block of a K-batch
+    v.flags_blk_stride = (size_t)c->plan.num_buffers;
     v.stride = c->stride;
     v.frames = frames;
     v.cmds = c->d_cmds.as<Cmd>();
@@ -941,18 +954,19 @@ DevView generic_view(fwgpu_ctx* c, int frames) {
     return v;
 }
 
-// one block through the level-batched executor (schedule.rs:289-344 as one launch per level)
-int run_generic_block(fwgpu_ctx* c, int frames, uint32_t cmd_block, const float* d_in, int n_in_ch, float* d_out,
+// K blocks of `frames` frames through the level-batched executor (schedule.rs:289-344 as one launch per level for
+// all K blocks: each block has its own pool slice, a stateful node walks its K blocks in order inside one wave)
+int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const float* d_in, int n_in_ch, float* d_out,
                       int n_out_ch) {
-    if (c->n_gin_bufs > 0)
-        LCHK(c, launch_graph_in(c->stream, c->d_pool.as<float>(), c->d_flags.as<uint8_t>(), c->stride,
-                                c->d_gin_bufs.as<int>(), c->n_gin_bufs, d_in, d_in ? n_in_ch : 0, frames));
-    c->epoch++;  // node state moves outside the fused control kernel: cached steady descriptors are stale
     DevView v = generic_view(c, frames);
+    if (c->n_gin_bufs > 0)
+        LCHK(c, launch_graph_in(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride,
+                                c->d_gin_bufs.as<int>(), c->n_gin_bufs, d_in, d_in ? n_in_ch : 0, frames, K));
+    c->epoch++;  // node state moves outside the fused control kernel: cached steady descriptors are stale
     hipEvent_t e0, e1;
     timer_begin(c, 3, &e0, &e1);
     for (size_t l = 0; l < c->level_cnt.size(); ++l) {
-        LCHK(c, launch_level(c->stream, v, c->d_level_nodes.as<int>() + c->level_off[l], c->level_cnt[l], 1, cmd_block));
+        LCHK(c, launch_level(c->stream, v, c->d_level_nodes.as<int>() + c->level_off[l], c->level_cnt[l], K, cmd_block));
         for (const fwgpu_ctx::FirGroup& g : c->fir_groups)
             if (g.level == (int)l) {
                 hipEvent_t g0 = nullptr, g1 = nullptr;
@@ -971,12 +985,12 @@ int run_generic_block(fwgpu_ctx* c, int frames, uint32_t cmd_block, const float*
                 }
                 LCHK(c, launch_fir(c->stream, v, c->d_fir_rows.as<FirRow>() + g.row_off, g.n_rows,
                                    c->d_fir_tiles.as<uint32_t>() + g.tile_off, g.T, c->d_fir_partials.as<float>(),
-                                   c->d_fir_partials.cap / sizeof(float), g0, g1));
+                                   c->d_fir_partials.cap / sizeof(float), K, g0, g1));
             }
     }
     timer_end(c, e1);
-    LCHK(c, launch_graph_out(c->stream, c->d_pool.as<float>(), c->d_flags.as<uint8_t>(), c->stride, 0, 0,
-                             c->d_gout_bufs.as<int>(), c->n_gout_bufs, d_out, n_out_ch, frames, 1));
+    LCHK(c, launch_graph_out(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride,
+                             c->d_gout_bufs.as<int>(), c->n_gout_bufs, d_out, n_out_ch, frames, K));
     return 0;
 }
 
@@ -1071,11 +1085,13 @@ int run_blocks(fwgpu_ctx* c, uint64_t frames, const float* d_in, int n_in_ch, fl
             blk += K;
             continue;
         }
+        // generic executor: whole blocks in batches of generic_k, a trailing partial block on its own
         int bf = (int)std::min<uint64_t>(left, mbf);
-        rc = run_generic_block(c, bf, blk, d_in ? d_in + done * n_in_ch : nullptr, n_in_ch, d_out + done * n_out_ch, n_out_ch);
+        int K = bf == (int)mbf ? (int)std::min<uint64_t>(left / mbf, c->generic_k) : 1;
+        rc = run_generic_batch(c, K, bf, blk, d_in ? d_in + done * n_in_ch : nullptr, n_in_ch, d_out + done * n_out_ch, n_out_ch);
         if (rc) return rc;
-        done += bf;
-        blk += 1;
+        done += (uint64_t)K * bf;
+        blk += K;
     }
     retire_cmds(c, nblocks);
     return 0;

@@ -302,6 +302,11 @@ __device__ __forceinline__ float beep_step(float ph, float inc) {  // beep_test.
     return t - truncf(t);
 }
 
+// node kinds whose audio half carries state from block to block
+__device__ __forceinline__ bool kind_is_stateful(int kind) {
+    return kind == K_VOLUME || kind == K_SAMPLER || kind == K_BEEP || kind == K_PAN || kind == K_HARD_CLIP ||
+           kind == K_WIDTH || kind == K_BIQUAD || kind == K_DELAY || kind == K_RESAMPLER || kind == K_SPATIAL;
+}
 __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, uint32_t cmd_block) {
     const NodeDesc nd = v.nodes[node_idx];
     if (nd.is_graph_io || nd.kind == K_FIR) return;  // I/O edges (k_graph_in/out); FIR banks run as MFMA GEMMs
@@ -323,9 +328,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
     uint64_t out_mask = 0;  // processor.rs:233
 
     NodeState s;
-    const bool stateful = nd.kind == K_VOLUME || nd.kind == K_SAMPLER || nd.kind == K_BEEP || nd.kind == K_PAN ||
-                          nd.kind == K_HARD_CLIP || nd.kind == K_WIDTH || nd.kind == K_BIQUAD || nd.kind == K_DELAY ||
-                          nd.kind == K_RESAMPLER || nd.kind == K_SPATIAL;
+    const bool stateful = kind_is_stateful(nd.kind);
     if (stateful) {
         s = v.states[nd.state];
         apply_cmds(s, nd.state, cmd_block, v.cmds, v.n_cmds, v.samples, v.ext, lane == 0);
@@ -753,11 +756,19 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
     if (lane < nd.n_out) io.flags[io.out_buf[lane]] = mask_bit(out_mask, lane) ? 1 : 0;
 }
 
+// K blocks per launch (gridDim.y = K, one pool slice per block).  A node whose audio half carries state from block
+// to block is run by ONE wave that walks its K blocks in order; stateless nodes take their K blocks in parallel.
 __global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __restrict__ level_nodes, int n_nodes,
                                                       uint32_t cmd_block0) {
     int w = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (w >= n_nodes) return;
-    node_process_wave(v, level_nodes[w], blockIdx.y, cmd_block0 + blockIdx.y);
+    const int node = level_nodes[w];
+    if (kind_is_stateful(v.nodes[node].kind)) {
+        if (blockIdx.y != 0) return;
+        for (uint32_t b = 0; b < gridDim.y; ++b) node_process_wave(v, node, b, cmd_block0 + b);
+    } else {
+        node_process_wave(v, node, blockIdx.y, cmd_block0 + blockIdx.y);
+    }
 }
 
 // B1: one node on scratch buffers (single wave)
@@ -778,12 +789,16 @@ __global__ void k_scatter_states(NodeState* states, const uint8_t* __restrict__ 
 
 // processor.rs:99-115 + schedule.rs:213-253 + util.rs:44-87.  Q10: the graph_in Dummy node's out mask (0)
 // overwrites whatever prepare_graph_inputs computed, so every graph-input buffer flag ends up false.
-__global__ void k_graph_in(float* pool, uint8_t* flags, int stride, const int* __restrict__ bufs, int n_bufs,
-                           const float* __restrict__ interleaved, int n_in_ch, int frames) {
+__global__ void k_graph_in(float* pool, uint8_t* flags, int stride, size_t pool_blk_stride, size_t flags_blk_stride,
+                           const int* __restrict__ bufs, int n_bufs, const float* __restrict__ interleaved, int n_in_ch,
+                           int frames) {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     int c = blockIdx.y;
+    const uint32_t blk = blockIdx.z;  // K-batched: one pool slice per block
+    pool += (size_t)blk * pool_blk_stride;
+    flags += (size_t)blk * flags_blk_stride;
     if (f < frames) {
-        float x = c < n_in_ch ? interleaved[(size_t)f * n_in_ch + c] : 0.f;  // extra graph inputs zero-filled
+        float x = c < n_in_ch ? interleaved[((size_t)blk * frames + f) * n_in_ch + c] : 0.f;  // extra graph inputs zero-filled
         pool[(size_t)bufs[c] * stride + f] = x;
     }
     if (f == 0) flags[bufs[c]] = 0;
@@ -1372,6 +1387,9 @@ __device__ __forceinline__ float readlane_f(float x, int lane) {
 #ifndef LEAF_WPB
 #define LEAF_WPB 4  // waves (leaf, block work items) per workgroup
 #endif
+#ifndef LEAF_MAP_BLOCKS
+#define LEAF_MAP_BLOCKS 1
+#endif
 // the pointers come out of v_readlane as integers: tell the compiler they are GLOBAL (global_load, not flat_load)
 typedef const v4f_u __attribute__((address_space(1)))* gv4p;
 __device__ __forceinline__ v4f gload4(const float* p) {
@@ -1416,10 +1434,18 @@ __device__ __forceinline__ void leaf_fast(const float* my_l, const float* my_r, 
     }
 }
 
-__global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv) {
+__global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K) {
+#if LEAF_MAP_BLOCKS
+    // the waves of a workgroup take CONSECUTIVE blocks of one leaf: a steady voice's source is contiguous across
+    // blocks, so the workgroup streams LEAF_WPB KiB per voice-channel instead of 1 KiB from LEAF_WPB x 32 places
+    const int leaf = blockIdx.x;
+    const uint32_t k = blockIdx.y * LEAF_WPB + (threadIdx.x >> 6);
+    if (k >= (uint32_t)K) return;
+#else
     const int leaf = blockIdx.x * LEAF_WPB + (threadIdx.x >> 6);
     if (leaf >= fv.n_leaves) return;
     const uint32_t k = blockIdx.y;
+#endif
     const int lane = threadIdx.x & (WAVE - 1);
     const LeafDesc ld = fv.leaves[leaf];
     const int frames = fv.frames;
@@ -2081,18 +2107,20 @@ __global__ void k_ir_convert(const SampleDesc* __restrict__ samples, int sample,
     dst[i] = i < sd.frames ? sample_fetch(sd, c, i) : 0.f;
 }
 
-// append the block's input to each row's mirrored history ring (positions q and q+R hold the same sample)
+// append the blocks' input to each row's mirrored history ring (positions q and q+R hold the same sample);
+// blockIdx.y = block of the K-batch (the ring holds T-1 + K*max_block_frames samples: every block's window is there)
 __global__ void k_fir_append(DevView v, const FirRow* __restrict__ rows, int n_rows) {
     int r = blockIdx.x;
     if (r >= n_rows) return;
     const FirRow row = rows[r];
     if (row.state < 0) return;  // padding row (tiles are impulse-response-homogeneous)
+    const uint32_t kb = blockIdx.y;
     const NodeState* s = &v.states[row.state];
     const uint32_t R = (uint32_t)s->loop_end, p = (uint32_t)s->playhead;
     float* ring = v.ext + s->ext_off + (size_t)row.ch * 2u * R;
-    const float* in = v.pool + (size_t)row.in_buf * v.stride;
+    const float* in = v.pool + (size_t)kb * v.pool_blk_stride + (size_t)row.in_buf * v.stride;
     for (int f = threadIdx.x; f < v.frames; f += blockDim.x) {
-        uint32_t q = (p + (uint32_t)f) % R;
+        uint32_t q = (p + kb * (uint32_t)v.frames + (uint32_t)f) % R;
         float x = in[f];
         ring[q] = x;
         ring[q + R] = x;
@@ -2102,14 +2130,15 @@ __global__ void k_fir_append(DevView v, const FirRow* __restrict__ rows, int n_r
 #define FIR_PITCH (FIR_KC + 1)  // LDS row pitch in floats: 65 -> the 32 rows of a column hit 32 different banks
 __global__ __launch_bounds__(256) void k_fir_gemm(DevView v, const FirRow* __restrict__ rows, int n_rows,
                                                   const uint32_t* __restrict__ tile_h_off, uint32_t T,
-                                                  float* __restrict__ partials, int n_rows_pad, int n_pad) {
+                                                  float* __restrict__ partials, int n_rows_pad, int n_pad, int col_groups) {
     __shared__ float lds[2 * 32 * FIR_PITCH + 2 * (256 + FIR_KC)];
     float* As = lds;                          // [2][32][FIR_PITCH]
     float* Hw = lds + 2 * 32 * FIR_PITCH;     // [2][256 + FIR_KC]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * 32;
     const uint32_t seg = blockIdx.y;
-    const int ib = blockIdx.z * 256;          // first output frame of this column group
+    const uint32_t kb = blockIdx.z / (uint32_t)col_groups;               // block of the K-batch
+    const int ib = (int)(blockIdx.z % (uint32_t)col_groups) * 256;       // first output frame of this column group
     const int frames = v.frames;
     const uint32_t W = T - 1u + (uint32_t)frames;
     const uint32_t m_begin = seg * FIR_SEG;
@@ -2124,7 +2153,7 @@ __global__ __launch_bounds__(256) void k_fir_gemm(DevView v, const FirRow* __res
         const FirRow row = rows[row0 + lrow];
         const NodeState* s = &v.states[row.state];
         const uint32_t R = (uint32_t)s->loop_end, p = (uint32_t)s->playhead;
-        const uint32_t e2 = (p + (uint32_t)frames - 1u) % R + R;  // newest sample, upper mirror
+        const uint32_t e2 = (p + (kb + 1u) * (uint32_t)frames - 1u) % R + R;  // block kb's newest sample, upper mirror
         wptr = v.ext + s->ext_off + (size_t)row.ch * 2u * R + (e2 + 1u - W);
     }
     // Staging loads are unconditional and vectorised (addresses clamped into the ext pool, which carries 256 floats
@@ -2198,12 +2227,13 @@ __global__ __launch_bounds__(256) void k_fir_gemm(DevView v, const FirRow* __res
         __syncthreads();
     }
     // partials[seg][row][col]: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float* P = partials + ((size_t)seg * n_rows_pad + row0) * n_pad + ib;
+    const size_t row_pitch = (size_t)gridDim.z / col_groups * n_pad;  // K * n_pad
+    float* P = partials + ((size_t)seg * n_rows_pad + row0) * row_pitch + (size_t)kb * n_pad + ib;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        P[(size_t)rr * n_pad + ct0 * 32 + (lane & 31)] = acc0[r];
-        P[(size_t)rr * n_pad + ct1 * 32 + (lane & 31)] = acc1[r];
+        P[(size_t)rr * row_pitch + ct0 * 32 + (lane & 31)] = acc0[r];
+        P[(size_t)rr * row_pitch + ct1 * 32 + (lane & 31)] = acc1[r];
     }
 }
 
@@ -2214,17 +2244,19 @@ __global__ void k_fir_reduce(DevView v, const FirRow* __restrict__ rows, int n_r
     if (r >= n_rows) return;
     const FirRow row = rows[r];
     if (row.state < 0) return;
-    float* out = v.pool + (size_t)row.out_buf * v.stride;
+    const uint32_t kb = blockIdx.y, K = gridDim.y;
+    const size_t row_pitch = (size_t)K * n_pad;
+    float* out = v.pool + (size_t)kb * v.pool_blk_stride + (size_t)row.out_buf * v.stride;
     for (int i = threadIdx.x; i < v.frames; i += blockDim.x) {
-        float t = partials[(size_t)r * n_pad + i];
-        for (int sgm = 1; sgm < n_segs; ++sgm) t = t + partials[((size_t)sgm * n_rows_pad + r) * n_pad + i];
+        float t = partials[(size_t)r * row_pitch + (size_t)kb * n_pad + i];
+        for (int sgm = 1; sgm < n_segs; ++sgm) t = t + partials[((size_t)sgm * n_rows_pad + r) * row_pitch + (size_t)kb * n_pad + i];
         out[i] = t;
     }
     if (threadIdx.x == 0) {
-        v.flags[row.out_buf] = 0;
-        if (row.ch == 0) {
+        v.flags[(size_t)kb * v.flags_blk_stride + row.out_buf] = 0;
+        if (row.ch == 0 && kb == 0) {
             NodeState* s = &v.states[row.state];
-            s->playhead = (s->playhead + (uint64_t)v.frames) % s->loop_end;
+            s->playhead = (s->playhead + (uint64_t)K * (uint64_t)v.frames) % s->loop_end;
         }
     }
 }
@@ -2302,19 +2334,19 @@ int launch_ir_convert(hipStream_t s, const SampleDesc* samples, int sample, int 
     return (int)hipGetLastError();
 }
 int launch_fir(hipStream_t s, const DevView& v, const FirRow* d_rows, int n_rows, const uint32_t* d_tile_h_off, uint32_t T,
-               float* d_partials, size_t partial_cap_floats, hipEvent_t gemm_begin, hipEvent_t gemm_end) {
-    if (n_rows <= 0 || v.frames <= 0) return 0;
+               float* d_partials, size_t partial_cap_floats, int K, hipEvent_t gemm_begin, hipEvent_t gemm_end) {
+    if (n_rows <= 0 || v.frames <= 0 || K <= 0) return 0;
     const uint32_t W = T - 1u + (uint32_t)v.frames;
     const int n_segs = (int)((W + FIR_SEG - 1) / FIR_SEG);
     const int row_tiles = (n_rows + 31) / 32, n_rows_pad = row_tiles * 32;
     const int col_groups = (v.frames + 255) / 256, n_pad = col_groups * 256;
-    if ((size_t)n_segs * n_rows_pad * n_pad > partial_cap_floats) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_fir_append, dim3(n_rows), dim3(256), 0, s, v, d_rows, n_rows);
+    if ((size_t)n_segs * n_rows_pad * n_pad * K > partial_cap_floats) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_fir_append, dim3(n_rows, K), dim3(256), 0, s, v, d_rows, n_rows);
     if (gemm_begin) (void)hipEventRecord(gemm_begin, s);
-    hipLaunchKernelGGL(k_fir_gemm, dim3(row_tiles, n_segs, col_groups), dim3(256), 0, s, v, d_rows, n_rows, d_tile_h_off, T,
-                       d_partials, n_rows_pad, n_pad);
+    hipLaunchKernelGGL(k_fir_gemm, dim3(row_tiles, n_segs, col_groups * K), dim3(256), 0, s, v, d_rows, n_rows, d_tile_h_off, T,
+                       d_partials, n_rows_pad, n_pad, col_groups);
     if (gemm_end) (void)hipEventRecord(gemm_end, s);
-    hipLaunchKernelGGL(k_fir_reduce, dim3(n_rows), dim3(256), 0, s, v, d_rows, n_rows, d_partials, n_segs, n_rows_pad,
+    hipLaunchKernelGGL(k_fir_reduce, dim3(n_rows, K), dim3(256), 0, s, v, d_rows, n_rows, d_partials, n_segs, n_rows_pad,
                        n_pad);
     return (int)hipGetLastError();
 }
@@ -2327,11 +2359,12 @@ int launch_scatter_states(hipStream_t s, NodeState* states, const void* d_inits,
     hipLaunchKernelGGL(k_scatter_states, dim3((n + 63) / 64), dim3(64), 0, s, states, (const uint8_t*)d_inits, n);
     return (int)hipGetLastError();
 }
-int launch_graph_in(hipStream_t s, float* pool, uint8_t* flags, int stride, const int* d_bufs, int n_bufs,
-                    const float* d_interleaved, int n_in_ch, int frames) {
+int launch_graph_in(hipStream_t s, float* pool, uint8_t* flags, int stride, size_t pool_blk_stride, size_t flags_blk_stride,
+                    const int* d_bufs, int n_bufs, const float* d_interleaved, int n_in_ch, int frames, int K) {
     if (n_bufs <= 0) return 0;
-    dim3 grid((frames + 255) / 256, n_bufs);
-    hipLaunchKernelGGL(k_graph_in, grid, dim3(256), 0, s, pool, flags, stride, d_bufs, n_bufs, d_interleaved, n_in_ch, frames);
+    dim3 grid((frames + 255) / 256, n_bufs, K);
+    hipLaunchKernelGGL(k_graph_in, grid, dim3(256), 0, s, pool, flags, stride, pool_blk_stride, flags_blk_stride, d_bufs, n_bufs,
+                       d_interleaved, n_in_ch, frames);
     return (int)hipGetLastError();
 }
 int launch_graph_out(hipStream_t s, const float* pool, const uint8_t* flags, int stride, size_t pool_blk_stride,
@@ -2364,8 +2397,12 @@ int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0,
 }
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
     if (fv.n_leaves <= 0) return 0;
+#if LEAF_MAP_BLOCKS
+    dim3 grid(fv.n_leaves, (K + LEAF_WPB - 1) / LEAF_WPB);
+#else
     dim3 grid((fv.n_leaves + LEAF_WPB - 1) / LEAF_WPB, K);
-    hipLaunchKernelGGL(k_leaf_sum, grid, dim3(WAVE * LEAF_WPB), 0, s, fv);
+#endif
+    hipLaunchKernelGGL(k_leaf_sum, grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K);
     return (int)hipGetLastError();
 }
 

@@ -64,11 +64,12 @@ int launch_bus_sum(hipStream_t s, const DevView& v, const int* d_level_nodes, in
 int launch_ir_convert(hipStream_t s, const SampleDesc* samples, int sample, int ch, float* dst, uint32_t T);
 // gemm_begin / gemm_end: optional events recorded around the k_fir_gemm launch alone (bench roofline)
 int launch_fir(hipStream_t s, const DevView& v, const FirRow* d_rows, int n_rows, const uint32_t* d_tile_h_off, uint32_t T,
-               float* d_partials, size_t partial_cap_floats, hipEvent_t gemm_begin = nullptr, hipEvent_t gemm_end = nullptr);
+               float* d_partials, size_t partial_cap_floats, int K = 1, hipEvent_t gemm_begin = nullptr,
+               hipEvent_t gemm_end = nullptr);
 int launch_single_node(hipStream_t s, const DevView& v, int node_idx);
 int launch_scatter_states(hipStream_t s, NodeState* states, const void* d_inits, int n);
-int launch_graph_in(hipStream_t s, float* pool, uint8_t* flags, int stride, const int* d_bufs, int n_bufs,
-                    const float* d_interleaved, int n_in_ch, int frames);
+int launch_graph_in(hipStream_t s, float* pool, uint8_t* flags, int stride, size_t pool_blk_stride, size_t flags_blk_stride,
+                    const int* d_bufs, int n_bufs, const float* d_interleaved, int n_in_ch, int frames, int K);
 int launch_graph_out(hipStream_t s, const float* pool, const uint8_t* flags, int stride, size_t pool_blk_stride,
                      size_t flags_blk_stride, const int* d_bufs, int n_bufs, float* d_out, int n_out_ch, int frames, int K);
 int launch_set_flags(hipStream_t s, uint8_t* flags, const int* d_bufs, int n, uint64_t mask);

@@ -241,6 +241,41 @@ def test_voice_bank_fused_plan_bit_exact(name, max_batch):
     assert digest(out_g) == gold[name]
 
 
+@pytest.mark.parametrize("name", ["mixed_generic_nobeep", "cfg3_chain", "spatial_scene", "cfg4_reverb", "cfg4_reverb_2irs_mono",
+                                  "graph_inputs", "events_33_r2", "chain_events_19_r2_pan"])
+@pytest.mark.parametrize("max_batch", [1, 3, 64])
+def test_generic_executor_k_batched_bit_exact(name, max_batch):
+    """the generic level-batched executor runs K blocks per launch (one pool slice per block; stateful nodes walk
+    their K blocks in order inside one wave, FIR banks become one K-block GEMM): same bits for every K"""
+    out_o, out_g, g = run_case(name, max_batch=max_batch, force_generic=True)
+    assert g.cx.plan_kind() == 0
+    assert_bits_equal(out_o, out_g, "%s generic K<=%d" % (name, max_batch))
+
+
+def test_fir_history_ring_caps_the_generic_batch_when_kmax_grows_later():
+    # the FIR ring is sized for the batch size in force at activation; raising max_batch afterwards must not outrun it
+    def run(e, grow):
+        out = []
+        ir = e.new_sample(PLANAR_F32, 2, scenarios.reverb_ir(5, 300, 2))
+        s = e.sampler(90.0)
+        f = e.fir(ir)
+        e.connect_stereo(s, f)
+        e.connect_stereo(f, e.graph_out_node)
+        e.update()
+        e.sampler_set_sample(s, e.new_sample(PLANAR_F32, 2, scenarios.voice_source(55, 5000)))
+        e.sampler_play(s)
+        out.append(e.process_blocks(3))
+        if grow:
+            e.cx.set_max_batch(16)
+            e.update()
+        out.append(e.process_blocks(9))
+        return np.concatenate(out)
+
+    o = oracle(max_block_frames=64)
+    g = GpuEngine(max_block_frames=64, max_batch=2)
+    assert_bits_equal(run(o, False), run(g, True), "FIR ring vs later kmax")
+
+
 def test_mixed_graph_generic_executor():
     out_o, out_g, g = run_case("mixed_generic")
     assert g.cx.plan_kind() == 0

@@ -103,7 +103,7 @@ struct fwgpu_ctx {
     int chain_nq = 1;       // k_chain tile size / 64 frames
     int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
     uint32_t epoch = 1;  // invalidates every VoiceCache when bumped (plan install, sample-table change)
-    DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags;
+    DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start;
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
     std::vector<int> up_level_off, up_level_cnt;
 
@@ -826,6 +826,8 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         HIPC(c, c->d_blks.ensure(K * c->n_voices * sizeof(VoiceBlk)));
         HIPC(c, c->d_refs.ensure(K * c->n_voices * sizeof(VoiceRef)));
         HIPC(c, c->d_gsets.ensure((size_t)c->n_voices * FW_GSETS * sizeof(GainSet)));
+        HIPC(c, c->d_chain_start.ensure((size_t)c->n_voices * sizeof(ChainStart)));
+        HIPC(c, hipMemset(c->d_chain_start.p, 0, (size_t)c->n_voices * sizeof(ChainStart)));
         HIPC(c, c->d_cache.ensure((size_t)c->n_voices * sizeof(VoiceCache)));
         HIPC(c, hipMemset(c->d_cache.p, 0, (size_t)c->n_voices * sizeof(VoiceCache)));
         c->epoch++;
@@ -1021,6 +1023,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     fv.stride = c->stride;
     fv.frames = (int)c->mbf;
     fv.ext = c->d_ext.as<float>();
+    fv.chain_start = c->d_chain_start.as<ChainStart>();
     fv.trace = nullptr;
 #ifdef FW_CHAIN_TRACE
     if (c->d_trace.ensure(64 * 16 * 8 * sizeof(unsigned long long)) == hipSuccess) fv.trace = c->d_trace.as<unsigned long long>();
@@ -1190,7 +1193,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
         if (s.alive && s.owned && s.d_data) (void)hipFree(s.d_data);
     DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
                       &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
-                      &c->d_bus, &c->d_bus_flags, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
+                      &c->d_bus, &c->d_bus_flags, &c->d_chain_start, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
                       &c->d_root_bufs, &c->d_fir_rows, &c->d_fir_tiles, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask};
     for (DevBuf* b : bufs) b->release();

@@ -54,6 +54,7 @@ struct FusedView {
     int stride;
     int frames;
     float* ext;  // biquad coefficients + history, delay rings (k_chain plan)
+    ChainStart* chain_start;  // [n_voices] (k_chain plan)
     unsigned long long* trace;  // FW_CHAIN_TRACE builds only: per-step role timestamps of workgroup 0
     int dbg;     // profiling only (env FWGPU_CHAIN_SKIP): bit 0 skip S2, 1 skip S3b, 2 skip source loads, 3 skip ring RMW, 4 no ring prefetch
 };

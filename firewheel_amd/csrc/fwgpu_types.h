@@ -165,6 +165,16 @@ struct FirRow {  // one GEMM row = one channel of one FIR node
     int out_buf;
 };
 
+// k_chain plan: what the two channel workgroups of a voice share, as it stood at the START of the current call
+// (written by k_voice_control, which also advances the node state to the end of the call; read-only for k_chain)
+struct ChainStart {
+    uint32_t pos;       // delay ring position
+    float fb, mix, dry; // delay feedback / wet / dry
+    float co[5];        // biquad b0 b1 b2 a1 a2
+    uint32_t pad[3];
+};
+static_assert(sizeof(ChainStart) == 48, "ChainStart layout");
+
 struct LeafDesc {  // a SumNode whose ports are all voice chains (nodes/sum.rs)
     int first_voice;
     int ports;     // num_in_ports

@@ -46,6 +46,8 @@ for s in range(8, 28):
     w8 = t[s, 9]
     mx = t[s, 11]
     step_len = t[s + 1, 2, 0] - t[s, 2, 0]
+    print("   S3a detail w1: lds-wait %d math+stores+ldswr %d tail %d | w8: %d %d %d" % (
+        w1[5] - w1[2], w1[6] - w1[5], w1[3] - w1[6], w8[5] - w8[2], w8[6] - w8[5], w8[3] - w8[6]))
     print("%4d | %6d %6d | %6d %6d %6d %6d | %6d %6d %6d %6d | %6d %6d | %6d" % (
         s, ser[3] - ser[0], ser[4] - ser[3],
         w1[1] - w1[0], w1[2] - w1[1], w1[3] - w1[2], w1[4] - w1[3],

@@ -813,7 +813,7 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         c->fused_fx = fb.has_fx;
         // k_chain tile = 64*nq frames: the larger tile needs whole tiles per block and every delay >= one tile
         c->chain_nq = (c->mbf % 128 == 0 && fb.min_delay >= 128) ? 2 : 1;
-        if (const char* e = getenv("FWGPU_CHAIN_NQ")) {
+        if (const char* e = getenv("FWGPU_CHAIN_NQ")) {  // experiments: force the smaller tile
             if (atoi(e) == 1) c->chain_nq = 1;
         }
         c->n_voices = (int)fb.voices.size();

@@ -77,7 +77,8 @@ int launch_set_flags(hipStream_t s, uint8_t* flags, const int* d_bufs, int n, ui
 int launch_get_flags(hipStream_t s, const uint8_t* flags, const int* d_bufs, int n, uint64_t* d_mask);
 int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0);
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K);
-// nq = tile size / 64 frames (1 or 2): frames % (64*nq) == 0 and every delay line >= 64*nq frames
+// nq = tile size / 64 frames (1 or 2; 256-frame tiles measured slower: the serial stage then dominates the step):
+// frames % (64*nq) == 0 and every delay line >= 64*nq frames
 int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0, int nq);
 
 // host-side mirror of the StateInit record consumed by k_scatter_states

@@ -203,6 +203,9 @@ def run_case(name, **gpu_kw):
         # every delay >= 128 frames and block % 128 == 0: k_chain runs its 128-frame tiles (ring prefetch for D >= 256)
         "chain_steady_40_d128": lambda e: scenarios.scenario_chain_steady(e, 40, 6, first_delay_frames=128, min_delay_frames=129),
         "chain_events_37_d130": lambda e: scenarios.scenario_chain_events(e, 37, first_delay_frames=130, min_delay_frames=128),
+        # two 128-frame tiles per block, every ring prefetched (delays >= 256 frames)
+        "chain_events_21_d256": lambda e: scenarios.scenario_chain_events(e, 21, first_delay_frames=256, min_delay_frames=257,
+                                                                          src_frames=1500),
         "cfg4_reverb": scenarios.scenario_cfg4_reverb,
         "cfg4_reverb_2irs_mono": lambda e: scenarios.scenario_cfg4_reverb(e, n_voices=5, taps=700, shared_ir=False,
                                                                           ir_channels=1),
@@ -211,7 +214,7 @@ def run_case(name, **gpu_kw):
            "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64, "cfg3_chain": 128, "cfg4_reverb": 128,
            "cfg4_reverb_2irs_mono": 64, "chain_steady_40": 256, "chain_steady_bq_only_i16": 64,
            "chain_steady_dl_only_pan": 128, "chain_events_37": 128, "chain_events_19_r2_pan": 64,
-           "chain_steady_40_d128": 256, "chain_events_37_d130": 128, "spatial_scene": 128, "spatial_scene_b96": 96}[name]
+           "chain_steady_40_d128": 256, "chain_events_37_d130": 128, "chain_events_21_d256": 256, "spatial_scene": 128, "spatial_scene_b96": 96}[name]
     kw = dict(max_block_frames=mbf)
     if name == "graph_inputs":
         kw["num_graph_inputs"] = 3
@@ -296,7 +299,7 @@ def test_cfg3_chain_spec_nodes_bit_exact():
 
 
 CHAIN_CASES = ["chain_steady_40", "chain_steady_bq_only_i16", "chain_steady_dl_only_pan", "chain_events_37",
-               "chain_events_19_r2_pan", "chain_steady_40_d128", "chain_events_37_d130"]
+               "chain_events_19_r2_pan", "chain_steady_40_d128", "chain_events_37_d130", "chain_events_21_d256"]
 
 
 @pytest.mark.parametrize("name", CHAIN_CASES)
@@ -318,10 +321,10 @@ def test_chain_bank_fused_chain_plan_bit_exact(name, max_batch):
     assert digest(out_g) == gold[name]
 
 
-@pytest.mark.parametrize("name", ["chain_steady_40_d128", "chain_events_37_d130"])
-def test_chain_plan_small_tiles_forced(name, monkeypatch):
-    # the same scenarios through the 64-frame-tile instantiation (FWGPU_CHAIN_NQ=1 overrides the planner's choice)
-    monkeypatch.setenv("FWGPU_CHAIN_NQ", "1")
+@pytest.mark.parametrize("name,nq", [("chain_steady_40_d128", "1"), ("chain_events_37_d130", "1"), ("chain_events_21_d256", "1")])
+def test_chain_plan_small_tiles_forced(name, nq, monkeypatch):
+    # the same scenarios through a smaller-tile instantiation (FWGPU_CHAIN_NQ overrides the planner's choice downwards)
+    monkeypatch.setenv("FWGPU_CHAIN_NQ", nq)
     out_o, out_g, g = run_case(name, max_batch=5)
     assert g.cx.plan_kind() == 2
     assert_bits_equal(out_o, out_g, name + " k_chain<1>")

@@ -50,6 +50,8 @@ CASES = {
                                                                       min_delay_frames=129),
     "chain_events_37_d130": lambda: scenarios.scenario_chain_events(oracle(max_block_frames=128), 37, first_delay_frames=130,
                                                                       min_delay_frames=128),
+    "chain_events_21_d256": lambda: scenarios.scenario_chain_events(oracle(max_block_frames=256), 21, first_delay_frames=256,
+                                                                      min_delay_frames=257, src_frames=1500),
     "chain_events_19_r2_pan": lambda: scenarios.scenario_chain_events(oracle(max_block_frames=64), 19, radix=2, src_frames=777,
                                                                         with_pan=True),
 }

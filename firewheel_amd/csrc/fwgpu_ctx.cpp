@@ -106,6 +106,7 @@ struct fwgpu_ctx {
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start;
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
     std::vector<int> up_level_off, up_level_cnt;
+    int up_root_node = -1;  // index (in the upper-tree node table) of the root SumNode when it is alone on the last level
 
     // FIR banks (generic executor): rows grouped by (level, impulse-response channel)
     struct FirGroup {  // one GEMM launch: every FIR row of a level with the same tap count
@@ -856,6 +857,7 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
             c->up_level_cnt.push_back((int)l.size());
             uflat.insert(uflat.end(), l.begin(), l.end());
         }
+        c->up_root_node = (!fb.up_levels.empty() && fb.up_levels.back().size() == 1) ? fb.up_levels.back()[0] : -1;
         if (uflat.empty()) uflat.push_back(0);
         if ((rc = upload(c, c->d_up_level_nodes, uflat.data(), uflat.size() * sizeof(int)))) return rc;
         if ((rc = upload(c, c->d_root_bufs, fb.root_buf, sizeof(fb.root_buf)))) return rc;
@@ -1058,8 +1060,16 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         v.frames = (int)c->mbf;
         v.cmds = nullptr;
         v.n_cmds = 0;
-        for (size_t l = 0; l < c->up_level_cnt.size(); ++l)
+        // the root SumNode is fused with read_graph_outputs + interleave_stereo when the stream is stereo
+        const bool fuse_root = c->up_root_node >= 0 && n_out_ch == 2;
+        const size_t n_levels = c->up_level_cnt.size() - (fuse_root ? 1 : 0);
+        for (size_t l = 0; l < n_levels; ++l)
             LCHK(c, launch_bus_sum(c->stream, v, c->d_up_level_nodes.as<int>() + c->up_level_off[l], c->up_level_cnt[l], K, 2));
+        if (fuse_root) {
+            LCHK(c, launch_root_out(c->stream, v, c->up_root_node, d_out, K));
+            timer_end(c, e1);
+            return 0;
+        }
     }
     LCHK(c, launch_graph_out(c->stream, fv.bus, fv.bus_flags, c->stride, fv.bus_blk_stride, fv.bus_flags_blk_stride,
                              c->d_root_bufs.as<int>(), 2, d_out, n_out_ch, (int)c->mbf, K));

@@ -2358,6 +2358,59 @@ __global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restric
     if (c == 0 && (int)threadIdx.x < n_out) flags[out_buf[threadIdx.x]] = mask_bit(out_mask, threadIdx.x) ? 1 : 0;
 }
 
+// The root SumNode of the fused plans (stereo, its ports are bus buffers) fused with read_graph_outputs +
+// interleave_stereo (schedule.rs:255-287, util.rs:123-147): one launch fewer per call and the root's planar result
+// never goes to memory.  Same arithmetic as k_bus_sum followed by k_graph_out: all inputs silent -> the sum clears and
+// flags both channels -> interleave_stereo zero-fills; n_in == n_out -> copy with mask passthrough; otherwise ports
+// added in order (silent ports skipped on the n-port path only) and both flags are clear.
+__global__ __launch_bounds__(256) void k_root_out(DevView v, int root_node, float* __restrict__ out) {
+    const NodeDesc nd = v.nodes[root_node];
+    const uint32_t blk = blockIdx.y;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const float* pool = v.pool + (size_t)blk * v.pool_blk_stride;
+    const uint8_t* flags = v.flags + (size_t)blk * v.flags_blk_stride;
+    const int* in_buf = v.in_buf + nd.in_off;
+    const int n_in = nd.n_in, ports = nd.aux0;
+    const int my_in = lane < n_in ? in_buf[lane] : 0;
+    const uint64_t in_mask = __ballot(lane < n_in ? flags[my_in] != 0 : false);
+    float* o = out + (size_t)blk * v.frames * 2;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= v.frames) return;
+    float2 y = make_float2(0.f, 0.f);
+    if (mask_all(in_mask, n_in)) {
+        // sum.rs:52-56 then util.rs:129-134
+    } else if (n_in == 2) {  // sum.rs:58-65: copy, flags pass through; both silent was handled above
+        y.x = pool[(size_t)__builtin_amdgcn_readlane(my_in, 0) * v.stride + f];
+        y.y = pool[(size_t)__builtin_amdgcn_readlane(my_in, 1) * v.stride + f];
+    } else {
+        const bool masked = !(ports == 2 || ports == 3 || ports == 4);
+        float accl = pool[(size_t)__builtin_amdgcn_readlane(my_in, 0) * v.stride + f];
+        float accr = pool[(size_t)__builtin_amdgcn_readlane(my_in, 1) * v.stride + f];
+        for (int p0 = 1; p0 < ports; p0 += 8) {
+            float xl[8], xr[8];
+            bool ul[8], ur[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ul[u] = ur[u] = false;
+                if (p0 + u < ports) {
+                    const int il = 2 * (p0 + u), ir = il + 1;
+                    ul[u] = !(masked && mask_bit(in_mask, il));  // :122-124
+                    ur[u] = !(masked && mask_bit(in_mask, ir));
+                    xl[u] = pool[(size_t)__builtin_amdgcn_readlane(my_in, il) * v.stride + f];
+                    xr[u] = pool[(size_t)__builtin_amdgcn_readlane(my_in, ir) * v.stride + f];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (ul[u]) accl = accl + xl[u];
+                if (ur[u]) accr = accr + xr[u];
+            }
+        }
+        y = make_float2(accl, accr);
+    }
+    *(float2*)(o + (size_t)f * 2) = y;
+}
+
 // ------------------------------------------------------------------ launch wrappers (host side of this TU)
 #define HIPCHK(x)                        \
     do {                                 \
@@ -2375,6 +2428,11 @@ int launch_bus_sum(hipStream_t s, const DevView& v, const int* d_level_nodes, in
     if (n_nodes <= 0) return 0;
     dim3 grid(n_nodes, K, n_out);
     hipLaunchKernelGGL(k_bus_sum, grid, dim3(256), 0, s, v, d_level_nodes);
+    return (int)hipGetLastError();
+}
+int launch_root_out(hipStream_t s, const DevView& v, int root_node, float* d_out, int K) {
+    if (v.frames <= 0 || K <= 0) return 0;
+    hipLaunchKernelGGL(k_root_out, dim3((v.frames + 255) / 256, K), dim3(256), 0, s, v, root_node, d_out);
     return (int)hipGetLastError();
 }
 int launch_ir_convert(hipStream_t s, const SampleDesc* samples, int sample, int ch, float* dst, uint32_t T) {

@@ -548,6 +548,22 @@ def test_config2_full_size_fused_equals_generic_and_is_loop_periodic():
     assert_bits_equal(oo, of[:oo.size], "1024 voices vs oracle")
 
 
+def test_config5_shard_full_size_fused_equals_generic_and_oracle_prefix():
+    # BASELINE configs[4], one GPU's shard: 8192 voices, block 1024, tree 256 + 8 + 1
+    V, blocks, src = 8192, 4, 2048
+    gf = GpuEngine(max_block_frames=1024, max_batch=4)
+    of = scenarios.scenario_voice_bank_steady(gf, V, blocks, src_frames=src)
+    assert gf.cx.plan_kind() == 1
+    gg = GpuEngine(max_block_frames=1024, force_generic=True, max_batch=2)
+    og = scenarios.scenario_voice_bank_steady(gg, V, blocks, src_frames=src)
+    assert_bits_equal(of, og, "8192 voices fused vs generic")
+    fr = of.reshape(-1, 2)
+    assert np.array_equal(fr[:src], fr[src:2 * src])          # loop periodicity
+    o = oracle(max_block_frames=1024)
+    oo = scenarios.scenario_voice_bank_steady(o, V, 1, src_frames=src)
+    assert_bits_equal(oo, of[:oo.size], "8192 voices vs oracle")
+
+
 def test_all_paused_bank_outputs_exact_zeros():
     g = GpuEngine(max_block_frames=256, max_batch=8)
     voices = scenarios.build_voice_bank(g, 200)

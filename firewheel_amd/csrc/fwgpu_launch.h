@@ -56,7 +56,8 @@ struct FusedView {
     float* ext;  // biquad coefficients + history, delay rings (k_chain plan)
     ChainStart* chain_start;  // [n_voices] (k_chain plan)
     unsigned long long* trace;  // FW_CHAIN_TRACE builds only: per-step role timestamps of workgroup 0
-    int dbg;     // profiling only (env FWGPU_CHAIN_SKIP): bit 0 skip S2, 1 skip S3b, 2 skip source loads, 3 skip ring RMW, 4 no ring prefetch
+    int dbg;     // FW_CHAIN_TRACE builds only (env FWGPU_CHAIN_SKIP): bit 0 skip S2, 1 skip S3b, 2 skip source loads,
+                 // 3 skip ring RMW, 4 no ring prefetch
 };
 
 int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0);

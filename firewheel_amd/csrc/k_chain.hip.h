@@ -1,0 +1,510 @@
+// k_chain.hip.h — part of the single device translation unit fwgpu_kernels.hip (included inside namespace fwgpu).
+// Fused chain plan (config 3): k_chain.
+#pragma once
+
+// ------------------------------------------------------------------ fused chain plan (config 3): k_chain
+// Voices of the shape  sampler -> [biquad] -> [delay] -> [volume|pan]* -> leaf SumNode.  The biquad (SPEC: DF1 in
+// f32, unfused feed-forward half + two fused feedback taps) is a serial recurrence in time, so time cannot be split across workgroups; what is
+// parallel is the voices — and the two channels, which never meet before the mix bus.  One workgroup owns one
+// (leaf SumNode of <= 32 voices, channel) for all K blocks of the call and walks time in tiles of TT = 64*NQ frames
+// through a 4-stage software pipeline over LDS (one barrier per step):
+//   S1  (8 worker waves, lane = (voice, 4*NQ frames)): source fetch + sampler gain; the non-recursive half of the
+//       biquad  A[n] = ((b0*x[n]) + (b1*x[n-1])) + (b2*x[n-2])  -> LDS, one row per (voice, channel)
+//   S2  (1 wave, lane = voice, raised priority): y[n] = fma(-a1, y[n-1], fma(-a2, y[n-2], A[n])), in place
+//   S3a (the same worker lanes, two tiles later): delay-line read-modify-write in HBM, dry/wet mix, gain stages
+//   S3b (1 wave): the leaf SumNode in the reference's port order (nodes/sum.rs:67-133) -> partial mix bus
+// Every rounding is the one the oracle performs (products and sums separately, same order), so the result is
+// bit-identical to the generic executor.  HBM traffic per stereo voice-sample: 8 B source + 8 B ring read + 8 B
+// ring write = the 24 B of SURVEY §8d.
+//
+// Latency hiding: the HBM loads a step consumes were issued during the previous step, right after their registers
+// were last used (ring slots of tile s-1 after S3a of tile s-2, source of tile s+1 after S1 of tile s), and stay in
+// flight across the barrier — a workgroup-scope barrier on gfx950 does not drain vmcnt, and one CU's L1 handles its
+// waves' accesses in issue order, which is also why a ring slot stored in step s is visible to the loads another
+// wave issues in step s+1.  Ring loads are prefetched only when the delay is >= 2 tiles (the slots they read were
+// stored at least one barrier earlier); shorter delays load in-step.
+#define CH_NBUF 4
+#ifndef CH_RING_NT
+#define CH_RING_NT 0  // non-temporal delay-ring accesses: measured 1.75x SLOWER (624 vs 357 us on config 3)
+#endif
+#ifndef CH_SRC_NT
+#define CH_SRC_NT 1   // non-temporal source loads (every source byte is read once)
+#endif
+#ifndef CH_WORKERS
+#define CH_WORKERS 8
+#endif
+// stage-skip switches (env FWGPU_CHAIN_SKIP) exist in profiling builds only; the product kernel has none of them
+#ifdef FW_CHAIN_TRACE
+#define CH_SKIP(bit) (fv.dbg & (bit))
+#else
+#define CH_SKIP(bit) false
+#endif
+#ifdef FW_CHAIN_TRACE  // profiling builds: role timelines of workgroup 0 (scripts/chain_trace.py)
+#define CH_TRACE(slot)                                                                          \
+    do {                                                                                        \
+        if (fv.trace && blockIdx.x == 0 && lane == 0 && s < 64) {                               \
+            fv.trace[(s * 16 + wave) * 8 + (slot)] = clock64();                                 \
+            if ((slot) == 0) fv.trace[(s * 16 + wave) * 8 + 7] = __builtin_amdgcn_s_getreg(63492); /* HW_ID */ \
+        }                                                                                       \
+    } while (0)
+#else
+#define CH_TRACE(slot) \
+    do {               \
+    } while (0)
+#endif
+#define CH_THREADS ((CH_WORKERS + 4) * WAVE)  // 8 workers + serial + mixer + 2 idle waves (see the role map in k_chain)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// rotate right by one lane inside each 16-lane DPP row (lane 0 of a row receives lane 15's value)
+__device__ __forceinline__ float row_ror1(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+}
+
+struct ChainInfo {  // what a worker lane carries from S1 of a tile to S3a of the same tile (two steps later)
+    uint32_t flags;                // VB_* of the tile's block, ramp bits included
+    float g[FW_MAX_STAGES - 1];    // this channel's constant post-gain stages (1..)
+};
+
+template <int NQ>
+__global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint32_t cmd_block0) {
+    constexpr int TT = 64 * NQ;        // frames per tile
+    constexpr int PITCH = TT + 4;      // floats per voice row: + 4 -> the 32 S2 lanes' b128 reads are conflict-free
+    constexpr int LF = 4 * NQ;         // frames per worker lane
+    __shared__ float tile[CH_NBUF][32][PITCH];  // row = voice (this workgroup's channel)
+    __shared__ uint32_t silf[CH_NBUF][32];      // chain output cleared + flagged silent (VB_SILENT) per voice
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    const LeafDesc ld = fv.leaves[blockIdx.x];
+    const int ch = blockIdx.y;  // L and R never meet before the mix bus: one workgroup per (leaf, channel)
+    const int ports = ld.ports;
+    const int frames = fv.frames;
+    const int tpb = frames / TT;  // the plan guarantees frames % TT == 0
+    const int n_tiles = K * tpb;
+    // A workgroup's waves are dealt to the 4 SIMDs round-robin, so waves w, w+4, w+8 share a SIMD (measured: HW_ID).
+    // The serial wave (2) gets a SIMD to itself — waves 6 and 10 only take part in the barriers — the mixer (11)
+    // shares one with two workers, the other six workers fill the remaining two SIMDs.
+    const bool is_serial = wave == 2;
+    const bool is_mixer = wave == 11;
+    const bool is_idle = wave == 6 || wave == 10;
+    const bool is_worker = !is_serial && !is_mixer && !is_idle;
+    const int widx = wave - (wave > 2 ? 1 : 0) - (wave > 6 ? 1 : 0);  // 0..7 among the worker waves 0,1,3,4,5,7,8,9
+
+    // ---- per-role persistent registers; worker lane = (voice v, frames [LF*q, LF*q + LF) of every tile),
+    //      serial lane = voice v.  Everything both channels share (delay position / feedback / mix, biquad
+    //      coefficients) is read from the ChainStart record k_voice_control wrote for this call and never written
+    //      here: the two workgroups of a leaf are not ordered against each other.
+    const int wl = widx * WAVE + lane;
+    const int v = is_worker ? (wl >> 4) : lane;
+    const int q = wl & 15;
+    const bool active = v < ports && (is_worker || (is_serial && lane < 32));
+    const int voice = ld.first_voice + (active ? v : 0);
+    const VoiceDesc vd = fv.voices[voice];
+    const bool has_bq = active && vd.bq_state >= 0, has_dl = active && vd.dl_state >= 0;
+    const ChainStart cs = fv.chain_start[voice];
+    float b0 = cs.co[0], b1 = cs.co[1], b2 = cs.co[2], a1 = cs.co[3], a2 = cs.co[4];
+    float* bq_st = nullptr;  // this channel's [x1 x2 y1 y2]
+    float y1 = 0.f, y2 = 0.f;
+    if (has_bq) {  // ext = [b0 b1 b2 a1 a2][x1 x2 y1 y2] x 2 channels
+        bq_st = fv.ext + fv.states[vd.bq_state].ext_off + 5 + 4 * ch;
+        if (is_serial) {
+            y1 = bq_st[2];
+            y2 = bq_st[3];
+        }
+    }
+    uint32_t D = 1, pos = cs.pos;
+    float fb = cs.fb, mix = cs.mix, dry = cs.dry;
+    float* ring = nullptr;
+    if (has_dl && is_worker) {
+        const NodeState* ds = &fv.states[vd.dl_state];
+        D = (uint32_t)ds->loop_end;
+        ring = fv.ext + ds->ext_off + (size_t)ch * D;
+    }
+    const bool ring_pref = has_dl && D >= 2u * TT && !CH_SKIP(16);
+    const bool any_bq = __syncthreads_or(has_bq ? 1 : 0) != 0;
+
+    // compute-side block registers (block of tile s) and issue-side ones (block of tile s+1, one step ahead)
+    float g0 = 1.f;
+    ChainInfo inf0, inf1, inf2;  // tiles s, s-1, s-2
+    inf0.flags = inf1.flags = inf2.flags = VB_SRC_ZERO | VB_SIMPLE;
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES - 1; ++j) inf0.g[j] = inf1.g[j] = inf2.g[j] = 1.f;
+    VoiceRef ref_n;        // descriptor of the block that starts two tiles ahead (in flight)
+    ref_n.src_l = nullptr;
+    ref_n.r_delta = 0;
+    ref_n.flags_gset = VB_SRC_ZERO | VB_SIMPLE;
+    float gs_n[FW_MAX_STAGES];  // this channel's gains of the issue-side block (in flight)
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES; ++j) gs_n[j] = 1.f;
+    const float* nb_src = nullptr;  // issue-side block: this channel's source of frame 0, VB_* flags
+    uint32_t nb_flags = VB_SRC_ZERO | VB_SIMPLE;
+    v4f xs[NQ];  // source of the tile S1 computes next (prefetched)
+    v4f rg[NQ];  // ring slots of the tile S3a consumes next (prefetched when ring_pref)
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) xs[j] = rg[j] = splat(0.f);
+    // newest x quad (post sampler gain) of this lane; the q == 15 lane's copy is the biquad's x[n-1], x[n-2] state
+    v4f prev_x = splat(0.f);
+    if (has_bq && is_worker && q == 15) {
+        prev_x[3] = bq_st[0];
+        prev_x[2] = bq_st[1];
+    }
+
+    // role-local (block, tile-in-block) counters: S1 computes tile s, S2 s-1, S3a s-2, S3b s-3; loads issue for s+1
+    int k1 = 0, t1 = 0, k2 = 0, t2 = 0, k3 = 0, t3 = 0, k4 = 0, t4 = 0, kla = 0, tla = 0;
+    const uint64_t port_mask = mask_all_silent_bits(ports);
+    const bool masked = !(ports == 2 || ports == 3 || ports == 4);  // sum.rs:67-133 (Q13)
+
+    // issue the HBM loads of tile `la` (= the tile S1 computes in the next step); at a block start first adopt the
+    // block's descriptor (in flight since the previous step) and request its gain set
+    auto issue_source = [&]() {
+        if (tla == 0) {
+            nb_flags = ref_n.flags_gset & 0xffu;
+            nb_src = ref_n.src_l + (ch ? ref_n.r_delta : 0u);  // r_delta = 0 for a mono sample (sampler.rs:546-551)
+            if (nb_flags & VB_SIMPLE) {
+                const GainSet* gs = &fv.gsets[(size_t)voice * FW_GSETS + (ref_n.flags_gset >> 8)];
+#pragma unroll
+                for (int j = 0; j < FW_MAX_STAGES; ++j) gs_n[j] = gs->g[j][ch];
+            }
+        }
+        if ((nb_flags & VB_SIMPLE) && !(nb_flags & VB_SRC_ZERO) && !CH_SKIP(4)) {
+            const float* p = nb_src + tla * TT + LF * q;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+#if CH_SRC_NT
+                xs[j] = gload4(p + 4 * j);
+#else
+                xs[j] = *(gv4p)(uint64_t)(p + 4 * j);
+#endif
+            }
+        }
+        if (++tla == tpb) {
+            tla = 0;
+            ++kla;
+        }
+        // the tile after that starts a block: request its descriptor now
+        if (tla == 0 && kla < K) ref_n = fv.refs[(size_t)voice * fv.refs_stride + kla];
+    };
+    auto ring_slot = [&](int j) -> uint32_t {
+        uint32_t sl = pos + (uint32_t)(LF * q + 4 * j);
+        return sl >= D ? sl - D : sl;
+    };
+    auto load_ring = [&]() {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const uint32_t sl = ring_slot(j);
+            if (sl + 4u <= D) {
+#if CH_RING_NT
+                rg[j] = __builtin_nontemporal_load((gv4p)(uint64_t)(ring + sl));  // every ring line is touched once per lap
+#else
+                rg[j] = *(const v4f_u*)(ring + sl);
+#endif
+            } else {  // the quad straddles the end of the ring
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint32_t se = sl + (uint32_t)e;
+                    if (se >= D) se -= D;
+                    rg[j][e] = ring[se];
+                }
+            }
+        }
+    };
+    if (is_worker && active) {  // prologue = the issue halves of steps -2 and -1
+        ref_n = fv.refs[(size_t)voice * fv.refs_stride + 0];
+        issue_source();
+    }
+
+    // One loop per role (same number of barriers in each) so that the register allocation of a role does not
+    // carry the other roles' loop state.
+    if (is_worker) {
+        for (int s = 0; s < n_tiles + 3; ++s) {
+            const bool do1 = active && s < n_tiles;
+            const bool do3 = active && s >= 2 && s - 2 < n_tiles;
+            const bool dl_on = has_dl && !CH_SKIP(8);
+            CH_TRACE(0);
+            if (do1 && t1 == 0) {  // new block: adopt the issue-side descriptor (its gain set has landed)
+                if (nb_flags & VB_SIMPLE) {
+                    inf0.flags = nb_flags;
+                    g0 = gs_n[0];
+#pragma unroll
+                    for (int j = 0; j < FW_MAX_STAGES - 1; ++j) inf0.g[j] = gs_n[j + 1];
+                } else {
+                    const VoiceBlk* d = &fv.blks[(size_t)k1 * fv.n_voices + voice];
+                    inf0.flags = d->flags;
+#pragma unroll
+                    for (int j = 0; j < FW_MAX_STAGES - 1; ++j) inf0.g[j] = d->g[j + 1][ch];
+                }
+                if (has_bq && fv.n_cmds) {
+                    const ChainCoefs co = chain_find_coefs(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0 + (uint32_t)k1);
+                    if (co.found) {
+                        b0 = co.b0;
+                        b1 = co.b1;
+                        b2 = co.b2;
+                    }
+                }
+            }
+            CH_TRACE(1);
+            // S3a's LDS rows (tile s-2) are requested first and consumed after S1: the round trip hides behind S1's math
+            v4f yv[NQ];
+            if (do3) {
+                const float* yrow = &tile[(s - 2) & (CH_NBUF - 1)][v][LF * q];
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) yv[j] = *(const v4f*)(yrow + 4 * j);
+            }
+            // ================= S1 on tile s: sampler gain + the feed-forward half of the biquad -> LDS
+            if (do1) {
+                v4f x[NQ];
+                if (!(inf0.flags & VB_SIMPLE)) {  // ramps, loop wrap, one-shot tail, non-planar-f32 source: full descriptor
+                    const VoiceBlk* d = &fv.blks[(size_t)k1 * fv.n_voices + voice];  // read in place (no private copy)
+                    const uint32_t dflags = d->flags;
+                    const bool mono = dflags & VB_MONO;
+                    const float* dsrc = (mono || ch == 0) ? d->src_l : d->src_r;
+                    const float g0c = d->g[0][ch];
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const int f0 = t1 * TT + LF * q + 4 * j;
+                        x[j] = splat(0.f);
+                        if (!(dflags & VB_SRC_ZERO)) {
+                            if (d->src_l) {
+                                x[j] = *(const v4f_u*)(dsrc + f0);
+                            } else {
+                                const SampleDesc sd = fv.samples[d->sample];
+                                Fetch ft;
+                                ft.off0 = d->off0;
+                                ft.off1 = d->off1;
+                                ft.n1 = d->n1;
+                                ft.wrap = (dflags & VB_WRAP) ? 1 : 0;
+                                ft.tail_zero = (dflags & VB_TAIL_ZERO) ? 1 : 0;
+                                x[j] = sample_fetch4(sd, mono ? 0 : ch, ft, (uint32_t)f0, (uint32_t)frames);
+                            }
+                            const uint32_t rb0 = dflags >> VB_RAMP_SHIFT;
+                            const float* rb = fv.ramps + ((size_t)k1 * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
+                            const v4f gv = (rb0 >> ch) & 1u ? *(const v4f*)(rb + (size_t)ch * fv.stride) : splat(g0c);
+                            x[j] = x[j] * gv;  // sampler.rs:530-533
+                        }
+                    }
+                } else if (inf0.flags & VB_SRC_ZERO) {
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) x[j] = splat(0.f);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) x[j] = xs[j] * g0;
+                }
+                float* row = &tile[s & (CH_NBUF - 1)][v][LF * q];
+                if (has_bq) {
+                    // x[n-1], x[n-2] of this lane's first frame: lane q-1's last quad of THIS tile, or for q == 0 lane
+                    // 15's last quad of the PREVIOUS tile — one rotate inside the voice's 16-lane DPP row, no LDS
+                    const bool q15 = q == 15;
+                    float p1 = row_ror1(q15 ? prev_x[3] : x[NQ - 1][3]), p2 = row_ror1(q15 ? prev_x[2] : x[NQ - 1][2]);
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const v4f xc = x[j];
+                        const v4f x1v = (v4f){p1, xc[0], xc[1], xc[2]}, x2v = (v4f){p2, p1, xc[0], xc[1]};
+                        const v4f a = ((xc * b0) + (x1v * b1)) + (x2v * b2);  // ((b0*x) + (b1*x1)) + (b2*x2)
+                        p1 = xc[3];
+                        p2 = xc[2];
+                        *(v4f*)(row + 4 * j) = a;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) *(v4f*)(row + 4 * j) = x[j];
+                }
+                prev_x = x[NQ - 1];
+                if (++t1 == tpb) {
+                    t1 = 0;
+                    ++k1;
+                }
+            }
+            // The ring slots S3a consumes below have been in flight since the end of the previous step.  Touch them
+            // HERE, before the next source loads are issued: the compiler then places its (conservative, vmcnt(0))
+            // wait for them ahead of those loads instead of draining them right after their issue.
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(rg[j]));
+            // source of tile s+1 (S1 of the next step)
+            if (active && s + 1 < n_tiles) issue_source();
+            CH_TRACE(2);
+            // ================= S3a on tile s-2: delay RMW + gain stages, in place in LDS (its rows were requested above)
+            if (do3) {
+                if (dl_on) {
+                    if (t3 == 0 && fv.n_cmds) {
+                        const ChainDelay p = chain_delay_cmds(fv.cmds, fv.n_cmds, vd.dl_state, cmd_block0 + (uint32_t)k3,
+                                                              ChainDelay{fb, mix, dry});
+                        fb = p.fb;
+                        mix = p.mix;
+                        dry = p.dry;
+                    }
+                    if (!ring_pref) load_ring();
+                }
+                float* row = &tile[(s - 2) & (CH_NBUF - 1)][v][LF * q];
+                const uint32_t rbits = inf2.flags >> VB_RAMP_SHIFT;
+#ifdef FW_CHAIN_TRACE
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(yv[j]));
+                CH_TRACE(5);
+#endif
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    v4f y = yv[j];
+                    if (dl_on) {
+                        const v4f nv = y + (rg[j] * fb);  // ring[p] = x + (d*fb)
+                        const uint32_t sl = ring_slot(j);
+                        if (sl + 4u <= D) {
+#if CH_RING_NT
+                            __builtin_nontemporal_store(nv, (v4f_u __attribute__((address_space(1)))*)(uint64_t)(ring + sl));
+#else
+                            *(v4f_u*)(ring + sl) = nv;
+#endif
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                uint32_t se = sl + (uint32_t)e;
+                                if (se >= D) se -= D;
+                                ring[se] = nv[e];
+                            }
+                        }
+                        y = (y * dry) + (rg[j] * mix);  // out = (x*dry) + (d*mix)
+                    }
+                    if (inf2.flags & VB_SILENT) {  // muted gain stage / silent chain: cleared buffer
+                        y = splat(0.f);
+                    } else if (rbits == 0) {
+#pragma unroll
+                        for (int g = 0; g < FW_MAX_STAGES - 1; ++g) {
+                            if (g + 1 >= fv.n_gain_stages) break;
+                            y = y * inf2.g[g];
+                        }
+                    } else {
+                        const int f0 = t3 * TT + LF * q + 4 * j;
+                        const float* rb = fv.ramps + ((size_t)k3 * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
+#pragma unroll
+                        for (int g = 1; g < FW_MAX_STAGES; ++g) {
+                            if (g >= fv.n_gain_stages) break;
+                            const v4f gv = (rbits >> (2 * g + ch)) & 1u ? *(const v4f*)(rb + (size_t)(2 * g + ch) * fv.stride) : splat(inf2.g[g - 1]);
+                            y = y * gv;
+                        }
+                    }
+                    *(v4f*)(row + 4 * j) = y;
+                }
+                CH_TRACE(6);
+                if (dl_on) {
+                    pos += TT;
+                    if (pos >= D) pos -= D;
+                }
+                if (q == 0) silf[(s - 2) & (CH_NBUF - 1)][v] = (inf2.flags & VB_SILENT) ? 1u : 0u;
+                if (++t3 == tpb) {
+                    t3 = 0;
+                    ++k3;
+                }
+            }
+            // ring slots of tile s-1 (S3a of the next step): issue now, after this step's ring stores
+            if (ring_pref && dl_on && s >= 1 && s - 1 < n_tiles) load_ring();
+            inf2 = inf1;
+            inf1 = inf0;
+            CH_TRACE(3);
+            __syncthreads();
+            CH_TRACE(4);
+        }
+    } else if (is_serial) {
+        // the recurrence is the critical path of every step: its wave wins VALU arbitration on its SIMD
+        __builtin_amdgcn_s_setprio(3);
+        for (int s = 0; s < n_tiles + 3; ++s) {
+            CH_TRACE(0);
+            // ================= S2 on tile s-1: the recursive half of the biquad, lane = voice
+            if (any_bq && s >= 1 && s - 1 < n_tiles && !CH_SKIP(1)) {
+                if (has_bq && t2 == 0 && fv.n_cmds) {
+                    const ChainCoefs co = chain_find_coefs(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0 + (uint32_t)k2);
+                    if (co.found) {
+                        a1 = co.a1;
+                        a2 = co.a2;
+                    }
+                }
+                if (has_bq) {
+                    float* row = &tile[(s - 1) & (CH_NBUF - 1)][v][0];
+                    v4f cur[4], nxt[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cur[u] = *(const v4f*)(row + 4 * u);
+#pragma unroll 2
+                    for (int c = 0; c < TT / 16; ++c) {
+                        if (c + 1 < TT / 16) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) nxt[u] = *(const v4f*)(row + 16 * (c + 1) + 4 * u);
+                        }
+                        // y[n] = fma(-a1, y[n-1], t[n]), t[n] = fma(-a2, y[n-2], A[n]): t[n+1] only needs y[n-1], so it is
+                        // issued BEFORE y[n] — the recurrence then advances at one fma latency per frame
+                        v4f o[4];
+                        float t = __builtin_fmaf(-a2, y2, cur[0][0]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int nu = e == 3 ? u + 1 : u, ne = (e + 1) & 3;
+                                const float tn = nu < 4 ? __builtin_fmaf(-a2, y1, cur[nu & 3][ne]) : 0.f;  // t of the next frame
+                                const float y = __builtin_fmaf(-a1, y1, t);
+                                __builtin_amdgcn_sched_barrier(0);
+                                y2 = y1;
+                                y1 = y;
+                                t = tn;
+                                o[u][e] = y;
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) *(v4f*)(row + 16 * c + 4 * u) = o[u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+                    }
+                }
+                if (++t2 == tpb) {
+                    t2 = 0;
+                    ++k2;
+                }
+            }
+            CH_TRACE(3);
+            __syncthreads();
+            CH_TRACE(4);
+        }
+    } else if (is_idle) {
+        for (int s = 0; s < n_tiles + 3; ++s) __syncthreads();
+    } else {
+        for (int s = 0; s < n_tiles + 3; ++s) {
+            CH_TRACE(0);
+            // ================= S3b on tile s-3: the leaf SumNode of this channel, lane = frame quad, ports in order
+            if (s >= 3 && lane < TT / 4 && !CH_SKIP(2)) {
+                const int buf = (s - 3) & (CH_NBUF - 1);
+                // ONE LDS round trip: every port's row (row index clamped, so the reads are unconditional) and the
+                // silence flags are requested together; the adds are masked
+                const float* col = &tile[buf][0][4 * lane];
+                v4f x[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) x[u] = *(const v4f*)(col + (size_t)(u < ports ? u : ports - 1) * PITCH);
+                const uint64_t silent_ports = __ballot(lane < ports && silf[buf][lane & 31] != 0) & port_mask;
+                const bool all_silent = silent_ports == port_mask;
+                const uint64_t skip = masked ? silent_ports : 0ull;  // :122-124 (n-port path only)
+                v4f acc = x[0];  // sum.rs:117 copy port 0 (also when silent: a cleared buffer)
+#pragma unroll
+                for (int u = 1; u < 32; ++u) {
+                    const bool use = u < ports && !((skip >> u) & 1ull);
+                    const v4f t = acc + x[u];
+                    acc = use ? t : acc;
+                }
+                if (all_silent) acc = splat(0.f);  // sum.rs:52-56
+                float* bus = fv.bus + (size_t)k4 * fv.bus_blk_stride + (size_t)(ld.out_buf + ch) * fv.stride + t4 * TT + 4 * lane;
+                *(v4f*)bus = acc;
+                if (t4 == 0 && lane == 0) fv.bus_flags[(size_t)k4 * fv.bus_flags_blk_stride + ld.out_buf + ch] = all_silent ? 1 : 0;
+                if (++t4 == tpb) {
+                    t4 = 0;
+                    ++k4;
+                }
+            }
+            CH_TRACE(3);
+            __syncthreads();
+            CH_TRACE(4);
+        }
+    }
+
+    // ---- write this channel's biquad state back (everything shared was advanced by k_voice_control)
+    if (is_worker && has_bq && q == 15) {
+        bq_st[0] = prev_x[3];
+        bq_st[1] = prev_x[2];
+    }
+    if (is_serial && has_bq) {
+        bq_st[2] = y1;
+        bq_st[3] = y2;
+    }
+}
+

@@ -1,0 +1,607 @@
+// k_control.hip.h — part of the single device translation unit fwgpu_kernels.hip (included inside namespace fwgpu).
+// Fused plans, control half: message lookups and k_voice_control (per-voice per-block state machines, K blocks per launch).
+#pragma once
+
+// ------------------------------------------------------------------ message lookups shared by the fused plans
+// first command of (state, block) in the (state, block, seq)-sorted list
+__device__ inline int chain_cmd_lower_bound(const Cmd* cmds, int n_cmds, int state_idx, uint32_t block) {
+    int lo = 0, hi = n_cmds;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        const Cmd& c = cmds[mid];
+        bool less = c.state < state_idx || (c.state == state_idx && c.block < block);
+        if (less) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+// Both helpers return by value and are force-inlined: a by-reference out-parameter of a real call would pin the
+// caller's loop-carried registers to scratch memory (a scratch load per step, draining vmcnt with it).
+struct ChainCoefs {
+    bool found;
+    float b0, b1, b2, a1, a2;
+};
+// the last CMD_SET_COEFS for (state, block), if any
+__device__ __forceinline__ ChainCoefs chain_find_coefs(const Cmd* cmds, int n_cmds, int state_idx, uint32_t block) {
+    ChainCoefs r;
+    r.found = false;
+    r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.f;
+    for (int i = chain_cmd_lower_bound(cmds, n_cmds, state_idx, block); i < n_cmds; ++i) {
+        const Cmd c = cmds[i];
+        if (c.state != state_idx || c.block != block) break;
+        if (c.type != CMD_SET_COEFS) continue;
+        r.b0 = c.f0;
+        r.b1 = __int_as_float(c.i0);
+        r.b2 = __int_as_float(c.i1);
+        unsigned long long u = (unsigned long long)__double_as_longlong(c.d0);
+        r.a1 = __int_as_float((int)(u & 0xffffffffull));
+        r.a2 = __int_as_float((int)(u >> 32));
+        r.found = true;
+    }
+    return r;
+}
+// delay parameters: fb (p0), mix (p1), dry (gain)
+struct ChainDelay {
+    float fb, mix, dry;
+};
+__device__ __forceinline__ ChainDelay chain_delay_cmds(const Cmd* cmds, int n_cmds, int state_idx, uint32_t block, ChainDelay p) {
+    for (int i = chain_cmd_lower_bound(cmds, n_cmds, state_idx, block); i < n_cmds; ++i) {
+        const Cmd c = cmds[i];
+        if (c.state != state_idx || c.block != block) break;
+        if (c.type == CMD_SET_P0) p.fb = c.f0;
+        else if (c.type == CMD_SET_P1) p.mix = c.f0;
+        else if (c.type == CMD_SET_GAIN) p.dry = c.f0;
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------ fused voice-bank plan
+// Control kernel (k_voice_control): one thread per voice runs the per-block state machines of its whole
+// chain in schedule order (sampler -> stage nodes) and emits one VoiceBlk per block.  As soon as the voice
+// is STEADY (no message left for it in this call, every smoother constant) the remaining blocks only differ
+// by the playhead, and the thread finishes the call with a short descriptor-store loop.  Per-frame ramps
+// (ParamSmoother Active) are materialised into `ramps` only for blocks where the values actually change.
+struct StageRegs {  // the NodeState prefix (p0,p1,s0,s1) a gain stage needs
+    float p0, p1;
+    Smoother s0, s1;
+};
+
+// Serial ramp -> global memory; returns false (and writes nothing) when the recurrence is already at its
+// f32 fixed point (Q28: an Active smoother can stall above settle_epsilon forever) — the block is constant.
+__device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, float* dst1, bool write) {
+    float prev = r.prev;
+    float v0 = r.in_a + (prev * r.b);
+    if (v0 == prev) {  // fixed point: every later value equals prev, bit for bit
+        r.c = prev;
+        r.ramp = 0;
+        return false;
+    }
+    for (int i = 0; i < frames; ++i) {
+        prev = r.in_a + (prev * r.b);
+        if (write) {
+            dst0[i] = prev;
+            if (dst1) dst1[i] = prev;
+        }
+    }
+    r.prev = prev;
+    return true;
+}
+
+// A smoother whose next set_and_process(target) returns the same constant and leaves its state untouched:
+// not Active, or Active but stalled at the f32 fixed point above settle_epsilon (Q28).
+__device__ __forceinline__ bool smoother_is_constant(const Smoother& s, float target) {
+    if (!(s.input == target)) return false;
+    if (s.status != SM_ACTIVE) return true;
+    float y0 = (s.input * s.a) + (s.last * s.b);
+    return y0 == s.last && !(fabsf(s.input - y0) < s.eps);
+}
+
+// source pointers of a block whose frames are contiguous planar f32 (the fast path of the leaf kernel)
+__device__ __forceinline__ void blk_set_source(VoiceBlk& d, const SampleDesc& sd, int frames) {
+    d.src_l = nullptr;
+    d.src_r = nullptr;
+    const bool contiguous = !(d.flags & (VB_WRAP | VB_TAIL_ZERO | VB_SILENT)) && sd.format == FMT_P_F32;
+    if (contiguous) {
+        d.src_l = (const float*)sd.data + d.off0;
+        d.src_r = (d.flags & VB_MONO) ? d.src_l : d.src_l + sd.frames;
+        // VB_SIMPLE blocks carry no full descriptor, so they must never need the per-element path (ragged tail)
+        if ((d.flags >> VB_RAMP_SHIFT) == 0 && (frames & 3) == 0 && sd.frames < 0xffffffffull) d.flags |= VB_SIMPLE;
+    }
+}
+
+// last block index (relative to this call) that still has a message for node `state_idx`; -1 if none
+__device__ inline int last_cmd_block(const Cmd* cmds, int n_cmds, int state_idx, uint32_t cmd_block0) {
+    if (n_cmds == 0) return -1;
+    int lo = 0, hi = n_cmds;  // upper bound of state_idx
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (cmds[mid].state <= state_idx) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo == 0 || cmds[lo - 1].state != state_idx) return -1;
+    return (int)(cmds[lo - 1].block - cmd_block0);  // sorted by (state, block): the last one is the latest
+}
+
+// Everything the steady tail of a call needs: the descriptor all its blocks share and how the playhead moves.
+struct TailJob {
+    int mode;          // 0 = nothing moves, 1 = looping playhead, 2 = one-shot playhead
+    uint32_t flags;    // VB_SILENT / VB_MONO of the shared descriptor
+    int sample;
+    GainSet g;
+    uint64_t playhead, loop_start, loop_end;
+};
+
+// Writes the compact record (always) and the full descriptor (only when the leaf kernel will need it).
+// `fx`: the voice has a biquad / delay (k_chain plan) — its source is needed even when the chain output is
+// silent, and every block that is not VB_SIMPLE carries a full descriptor.
+__device__ __forceinline__ void put_blk(const FusedView& fv, int vi, int kk, const VoiceBlk& d, uint32_t gset,
+                                        uint64_t sample_frames, bool fx) {
+    VoiceRef ref;
+    ref.src_l = d.src_l;
+    ref.r_delta = ((d.flags & VB_SIMPLE) && !(d.flags & (VB_MONO | VB_SRC_ZERO))) ? (uint32_t)sample_frames : 0u;
+    ref.flags_gset = (d.flags & 0xffu) | (gset << 8);
+    fv.refs[(size_t)vi * fv.refs_stride + kk] = ref;  // [voice][block]: the tail lanes store 1 KiB contiguous
+    const bool need_full = fx ? !(d.flags & VB_SIMPLE) : !(d.flags & (VB_SIMPLE | VB_SILENT));
+    if (need_full) fv.blks[(size_t)kk * fv.n_voices + vi] = d;
+}
+
+// Steady tail: blocks k_first .. K-1 share one descriptor; only the playhead moves, by +frames with a wrap at
+// the loop end (nodes/sampler.rs:445-484) — closed form (base + j*frames) mod L, so the 64 lanes of the
+// voice's wave fill 64 blocks at a time.  Returns the playhead the reference holds after block K-1.
+__device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int lane, int k_first, int K, const TailJob& job,
+                                                const SampleDesc& sd, uint32_t gset, bool simple_ok, bool fx) {
+    const int frames = fv.frames;
+    const uint64_t fr = (uint64_t)frames;
+    VoiceBlk t;
+    t.flags = job.flags;
+    t.n1 = frames;
+    t.src_l = t.src_r = nullptr;
+    t.off0 = t.off1 = 0;
+    t.sample = job.sample;
+    t.pad = 0;
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES; ++j) {
+        t.g[j][0] = job.g.g[j][0];
+        t.g[j][1] = job.g.g[j][1];
+    }
+    const bool no_src = (job.flags & VB_SRC_ZERO) || (!fx && (job.flags & VB_SILENT));
+    const bool contiguous_f32 = !no_src && job.sample >= 0 && sd.format == FMT_P_F32;
+    const uint64_t n = (uint64_t)(K - k_first);
+    if (job.mode == 1) {
+        // all quantities fit 32 bits whenever the loop does (the usual case): avoid 64-bit division
+        const uint64_t L = job.loop_end - job.loop_start;
+        const uint64_t base = job.playhead >= job.loop_end ? 0 : job.playhead - job.loop_start;
+        uint64_t r, step, r_last;
+        if (L <= 0xffffffffull && n * fr <= 0xffffffffull) {
+            // everything fits 32 bits (the usual case): 32-bit remainders instead of 64-bit division
+            const uint32_t l32 = (uint32_t)L;
+            auto addmod = [&](uint32_t j) -> uint64_t {  // (base + j*fr) mod L, base < L
+                uint64_t x = (uint64_t)((j * (uint32_t)fr) % l32) + base;
+                return x >= L ? x - L : x;
+            };
+            r = addmod((uint32_t)lane);
+            step = (uint64_t)((64u * (uint32_t)fr) % l32);
+            r_last = addmod((uint32_t)(n - 1));
+        } else {
+            r = (base + (uint64_t)lane * fr) % L;
+            step = (64ull * fr) % L;
+            r_last = (base + (n - 1) * fr) % L;
+        }
+        for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
+            const uint64_t left = L - r;
+            t.flags = job.flags;
+            t.off0 = job.loop_start + r;
+            t.off1 = job.loop_start;
+            t.src_l = t.src_r = nullptr;
+            if (left < fr) {  // wraps inside the block
+                t.n1 = (uint32_t)left;
+                t.flags |= VB_WRAP;
+            } else {
+                t.n1 = frames;
+                if (contiguous_f32) {
+                    t.src_l = (const float*)sd.data + t.off0;
+                    t.src_r = (t.flags & VB_MONO) ? t.src_l : t.src_l + sd.frames;
+                    if (simple_ok) t.flags |= VB_SIMPLE;
+                }
+            }
+            put_blk(fv, vi, k2, t, gset, sd.frames, fx);
+            r += step;
+            if (r >= L) r -= L;
+        }
+        const uint64_t left = L - r_last;
+        return left < fr ? job.loop_start + (fr - left) : job.loop_start + r_last + fr;
+    }
+    if (job.mode == 2) {
+        for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
+            t.flags = job.flags;
+            t.off0 = job.playhead + (uint64_t)(k2 - k_first) * fr;
+            t.src_l = t.src_r = nullptr;
+            if (contiguous_f32) {
+                t.src_l = (const float*)sd.data + t.off0;
+                t.src_r = (t.flags & VB_MONO) ? t.src_l : t.src_l + sd.frames;
+                if (simple_ok) t.flags |= VB_SIMPLE;
+            }
+            put_blk(fv, vi, k2, t, gset, sd.frames, fx);
+        }
+        return job.playhead + n * fr;
+    }
+    // nothing moves (mode 0 <=> the sampler is frozen): with fx the block still runs (zeros in, constant gains)
+    if (fx && simple_ok) t.flags |= VB_SIMPLE;
+    for (int k2 = k_first + lane; k2 < K; k2 += WAVE) put_blk(fv, vi, k2, t, fx ? gset : 0u, sd.frames, fx);
+    return job.playhead;
+}
+
+// One WAVE per voice: the state machines are run by all 64 lanes redundantly (wave-uniform; lane 0 stores),
+// the steady tail is split across the lanes.  A voice that ended the previous call steady and has no message
+// in this one skips the state machines altogether (VoiceCache): its whole call is a steady tail.
+__global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint32_t cmd_block0) {
+    const int vi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (vi >= fv.n_voices) return;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const bool w0 = lane == 0;
+    const VoiceDesc vd = fv.voices[vi];
+    const int frames = fv.frames;
+    const bool simple_frames = (frames & 3) == 0;
+    const bool fx = vd.bq_state >= 0 || vd.dl_state >= 0;  // k_chain plan voice
+
+    // ---- k_chain plan: what both channel workgroups of the voice's leaf share is owned HERE — the record holds the
+    // values at the start of this call (k_chain replays the call's messages block by block from them), the node state
+    // is advanced to the end of the call.  k_chain itself only reads the record.
+    if (fx) {
+        ChainStart cs;
+        cs.pos = 0;
+        cs.fb = 0.f;
+        cs.mix = 0.f;
+        cs.dry = 1.f;
+        cs.co[0] = 1.f;
+        cs.co[1] = cs.co[2] = cs.co[3] = cs.co[4] = 0.f;
+        cs.pad[0] = cs.pad[1] = cs.pad[2] = 0;
+        if (vd.dl_state >= 0) {
+            NodeState* ds = &fv.states[vd.dl_state];
+            const uint64_t D = ds->loop_end;
+            cs.pos = (uint32_t)ds->playhead;
+            ChainDelay p = ChainDelay{ds->p0, ds->p1, ds->gain};
+            cs.fb = p.fb;
+            cs.mix = p.mix;
+            cs.dry = p.dry;
+            if (fv.n_cmds) {
+                for (int i = chain_cmd_lower_bound(fv.cmds, fv.n_cmds, vd.dl_state, cmd_block0); i < fv.n_cmds; ++i) {
+                    const Cmd c = fv.cmds[i];
+                    if (c.state != vd.dl_state || c.block >= cmd_block0 + (uint32_t)K) break;
+                    if (c.type == CMD_SET_P0) p.fb = c.f0;
+                    else if (c.type == CMD_SET_P1) p.mix = c.f0;
+                    else if (c.type == CMD_SET_GAIN) p.dry = c.f0;
+                }
+            }
+            if (w0) {
+                ds->playhead = ((uint64_t)cs.pos + (uint64_t)K * (uint64_t)frames) % D;
+                ds->p0 = p.fb;
+                ds->p1 = p.mix;
+                ds->gain = p.dry;
+            }
+        }
+        if (vd.bq_state >= 0) {
+            float* co = fv.ext + fv.states[vd.bq_state].ext_off;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) cs.co[j] = co[j];
+            if (fv.n_cmds) {
+                bool found = false;
+                float nc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int i = chain_cmd_lower_bound(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0); i < fv.n_cmds; ++i) {
+                    const Cmd c = fv.cmds[i];
+                    if (c.state != vd.bq_state || c.block >= cmd_block0 + (uint32_t)K) break;
+                    if (c.type != CMD_SET_COEFS) continue;
+                    nc[0] = c.f0;
+                    nc[1] = __int_as_float(c.i0);
+                    nc[2] = __int_as_float(c.i1);
+                    unsigned long long u = (unsigned long long)__double_as_longlong(c.d0);
+                    nc[3] = __int_as_float((int)(u & 0xffffffffull));
+                    nc[4] = __int_as_float((int)(u >> 32));
+                    found = true;
+                }
+                if (found && w0) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) co[j] = nc[j];
+                }
+            }
+        }
+        if (w0) fv.chain_start[vi] = cs;
+    }
+
+    int last_cmd = -1;
+    if (fv.n_cmds) {
+        last_cmd = last_cmd_block(fv.cmds, fv.n_cmds, vd.sampler_state, cmd_block0);
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
+            if (j < vd.n_stages) {
+                int l = last_cmd_block(fv.cmds, fv.n_cmds, vd.stage_state[j], cmd_block0);
+                last_cmd = l > last_cmd ? l : last_cmd;
+            }
+    }
+    GainSet* my_gsets = fv.gsets + (size_t)vi * FW_GSETS;
+
+    // ---- fast path: still steady from the previous call
+    {
+        const VoiceCache vc = fv.cache[vi];
+        if (vc.epoch == fv.epoch && last_cmd < 0) {
+            TailJob job;
+            job.mode = vc.mode;
+            job.flags = vc.flags;
+            job.sample = vc.sample;
+            job.g = vc.g;
+            job.playhead = job.loop_start = job.loop_end = 0;
+            SampleDesc sd;
+            sd.data = nullptr;
+            sd.frames = 0;
+            sd.channels = 2;
+            sd.format = FMT_P_F32;
+            bool ok = true;
+            if (vc.mode != 0) {
+                const NodeState* sp = &fv.states[vd.sampler_state];
+                job.playhead = sp->playhead;
+                job.loop_start = sp->loop_start;
+                job.loop_end = sp->loop_end;
+                sd = fv.samples[vc.sample];
+                if (vc.mode == 2 && job.playhead + (uint64_t)K * (uint64_t)frames > sd.frames) ok = false;  // ends in this call
+            }
+            if (ok) {
+                const bool no_src = (job.flags & VB_SRC_ZERO) || (!fx && (job.flags & VB_SILENT));
+                const bool simple_ok = no_src ? (fx && simple_frames)
+                                              : (job.sample >= 0 && sd.format == FMT_P_F32 && simple_frames &&
+                                                 sd.frames < 0xffffffffull);
+                if (simple_ok && w0) my_gsets[0] = job.g;
+                uint64_t ph = steady_tail(fv, vi, lane, 0, K, job, sd, 0u, simple_ok, fx);
+                if (w0 && vc.mode != 0) fv.states[vd.sampler_state].playhead = ph;
+                return;
+            }
+        }
+    }
+
+    // ---- general path
+    NodeState ss = fv.states[vd.sampler_state];
+    StageRegs st[FW_MAX_STAGES - 1];
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
+        if (j < vd.n_stages) st[j] = *(const StageRegs*)&fv.states[vd.stage_state[j]];
+
+    // gain sets used so far in this call (the current one is mirrored in registers)
+    int n_gsets = 0;
+    GainSet cur_gs;
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES; ++j) cur_gs.g[j][0] = cur_gs.g[j][1] = 0.f;
+    // picks (or allocates) the gain set of a VB_SIMPLE block; wave-uniform.  Returns its index.
+    auto pick_gset = [&](VoiceBlk& d) -> uint32_t {
+        if (!(d.flags & VB_SIMPLE)) return 0u;
+        bool same = n_gsets > 0;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j) same = same && cur_gs.g[j][0] == d.g[j][0] && cur_gs.g[j][1] == d.g[j][1];
+        if (!same) {
+            if (n_gsets < FW_GSETS) {
+#pragma unroll
+                for (int j = 0; j < FW_MAX_STAGES; ++j) {
+                    cur_gs.g[j][0] = d.g[j][0];
+                    cur_gs.g[j][1] = d.g[j][1];
+                }
+                if (w0) my_gsets[n_gsets] = cur_gs;
+                n_gsets++;
+            } else {
+                d.flags &= ~VB_SIMPLE;  // out of gain-set slots: use the full descriptor for this block
+                return 0u;
+            }
+        }
+        return (uint32_t)(n_gsets - 1);
+    };
+    int cached_sample = -1;
+    SampleDesc sd;
+    sd.data = nullptr;
+    sd.frames = 0;
+    sd.channels = 2;
+    sd.format = FMT_P_F32;
+    bool became_steady = false;
+
+    for (int k = 0; k < K; ++k) {
+        const uint32_t cb = cmd_block0 + k;
+        VoiceBlk d;
+        d.flags = 0;
+        d.n1 = frames;
+        d.src_l = d.src_r = nullptr;
+        d.off0 = d.off1 = 0;
+        d.sample = -1;
+        d.pad = 0;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j) d.g[j][0] = d.g[j][1] = 1.0f;
+        float* ramp_base = fv.ramps + ((size_t)k * fv.n_voices + vi) * (size_t)fv.ramp_slots * (size_t)fv.stride;
+
+        // ---- sampler (nodes/sampler.rs:323-561)
+        apply_cmds(ss, vd.sampler_state, cb, fv.cmds, fv.n_cmds, fv.samples);
+        bool silent = true;
+        if (ss.sample >= 0 && ss.playing) {
+            GainRun run = smoother_begin(ss.s0, ss.p0, frames);
+            if (!(!smoother_is_smoothing(ss.s0) && run.c < 0.00001f)) {
+                if (cached_sample != ss.sample) {
+                    sd = fv.samples[ss.sample];
+                    cached_sample = ss.sample;
+                }
+                Fetch ft;
+                bool ok = sampler_advance(ss, sd.frames, (uint32_t)frames, ft);
+                if (run.ramp) {
+                    if (ramp_emit(run, frames, ramp_base, ramp_base + fv.stride, w0)) {
+                        d.flags |= 3u << VB_RAMP_SHIFT;
+                        ss.s0.last = run.prev;
+                    }
+                }
+                if (ok) {
+                    silent = false;
+                    d.sample = ss.sample;
+                    d.off0 = ft.off0;
+                    d.off1 = ft.off1;
+                    d.n1 = ft.n1;
+                    if (ft.wrap) d.flags |= VB_WRAP;
+                    if (ft.tail_zero) d.flags |= VB_TAIL_ZERO;
+                    if (sd.channels == 1) d.flags |= VB_MONO;
+                    d.g[0][0] = d.g[0][1] = run.c;
+                }
+            }
+        }
+        // a biquad / delay between the sampler and the gain stages never reports silence (SPEC nodes: out mask 0)
+        const bool src_silent = silent;
+        if (fx) silent = false;
+        // ---- chain stages in schedule order
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+            if (j >= vd.n_stages) break;
+            StageRegs& r = st[j];
+            if (fv.n_cmds) {  // messages for this node (only p0/p1 apply to gain stages)
+                NodeState tmp;
+                tmp.p0 = r.p0;
+                tmp.p1 = r.p1;
+                apply_cmds(tmp, vd.stage_state[j], cb, fv.cmds, fv.n_cmds, fv.samples);
+                r.p0 = tmp.p0;
+                r.p1 = tmp.p1;
+            }
+            float* rb = ramp_base + (size_t)(j + 1) * 2 * fv.stride;
+            if (vd.stage_kind[j] == K_VOLUME) {  // nodes/volume.rs:84-145
+                if (silent) {
+                    smoother_reset(r.s0, r.p0);
+                } else {
+                    GainRun run = smoother_begin(r.s0, r.p0, frames);
+                    if (!smoother_is_smoothing(r.s0) && run.c < 0.00001f) {
+                        silent = true;
+                    } else {
+                        if (run.ramp && ramp_emit(run, frames, rb, rb + fv.stride, w0)) {
+                            d.flags |= 3u << (VB_RAMP_SHIFT + 2 * (j + 1));
+                            r.s0.last = run.prev;
+                        }
+                        d.g[j + 1][0] = d.g[j + 1][1] = run.c;
+                    }
+                }
+            } else {  // K_PAN (SPEC)
+                if (silent) {
+                    smoother_reset(r.s0, r.p0);
+                    smoother_reset(r.s1, r.p1);
+                } else {
+                    GainRun rl = smoother_begin(r.s0, r.p0, frames);
+                    GainRun rr = smoother_begin(r.s1, r.p1, frames);
+                    if (rl.ramp && ramp_emit(rl, frames, rb, nullptr, w0)) {
+                        d.flags |= 1u << (VB_RAMP_SHIFT + 2 * (j + 1));
+                        r.s0.last = rl.prev;
+                    }
+                    if (rr.ramp && ramp_emit(rr, frames, rb + fv.stride, nullptr, w0)) {
+                        d.flags |= 2u << (VB_RAMP_SHIFT + 2 * (j + 1));
+                        r.s1.last = rr.prev;
+                    }
+                    d.g[j + 1][0] = rl.c;
+                    d.g[j + 1][1] = rr.c;
+                }
+            }
+        }
+        if (!src_silent && (fx || !silent)) blk_set_source(d, sd, frames);
+        else if (src_silent && fx && (d.flags >> VB_RAMP_SHIFT) == 0 && simple_frames) d.flags |= VB_SIMPLE;
+        if (src_silent) d.flags |= VB_SRC_ZERO;
+        if (silent) d.flags |= VB_SILENT;
+        {
+            uint32_t gs = pick_gset(d);
+            if (w0) put_blk(fv, vi, k, d, gs, sd.frames, fx);
+        }
+
+        // ---- steady from the next block on?
+        if (k < last_cmd) continue;
+        bool steady = true;
+        bool upstream_silent = false;
+        int mode = 0;
+        if (ss.sample < 0 || !ss.playing) {
+            upstream_silent = true;  // frozen sampler: nothing moves
+        } else {
+            if (!smoother_is_constant(ss.s0, ss.p0)) steady = false;
+            else if (ss.s0.status == SM_INACTIVE && ss.s0.input < 0.00001f) upstream_silent = true;  // muted, frozen
+            else if (ss.has_loop) {
+                uint64_t L = ss.loop_end - ss.loop_start;
+                if (ss.loop_end > ss.loop_start && L >= (uint64_t)frames && ss.playhead >= ss.loop_start &&
+                    ss.loop_end <= sd.frames && cached_sample == ss.sample)
+                    mode = 1;
+                else steady = false;
+            } else {
+                uint64_t need = (uint64_t)(K - 1 - k) * (uint64_t)frames;
+                if (cached_sample == ss.sample && ss.playhead + need <= sd.frames) mode = 2;
+                else steady = false;  // the one-shot ends inside this call: stay on the exact path
+            }
+        }
+        bool sil = upstream_silent && !fx;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+            if (j >= vd.n_stages || !steady) break;
+            const StageRegs& r = st[j];
+            if (sil) {  // reset() every block: idempotent once applied
+                if (!(r.s0.status == SM_INACTIVE && r.s0.input == r.p0)) steady = false;
+                if (vd.stage_kind[j] == K_PAN && !(r.s1.status == SM_INACTIVE && r.s1.input == r.p1)) steady = false;
+            } else if (vd.stage_kind[j] == K_VOLUME) {
+                if (!smoother_is_constant(r.s0, r.p0)) steady = false;
+                else if (r.s0.status == SM_INACTIVE && r.s0.input < 0.00001f) sil = true;
+            } else {
+                if (!smoother_is_constant(r.s0, r.p0) || !smoother_is_constant(r.s1, r.p1)) steady = false;
+            }
+        }
+        if (!steady) continue;
+        // ---- steady: the descriptor every later block shares.  Constant gains are `input` for a settled
+        // smoother and `last` for one stalled at its f32 fixed point (Q28).
+        TailJob job;
+        job.mode = mode;
+        job.flags = (sil ? VB_SILENT : 0u) | (upstream_silent ? VB_SRC_ZERO : 0u);
+        job.sample = upstream_silent ? -1 : ss.sample;
+        job.playhead = ss.playhead;
+        job.loop_start = ss.loop_start;
+        job.loop_end = ss.loop_end;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j) job.g.g[j][0] = job.g.g[j][1] = 1.0f;
+        if (!upstream_silent) {
+            if (sd.channels == 1) job.flags |= VB_MONO;
+            job.g.g[0][0] = job.g.g[0][1] = ss.s0.status == SM_ACTIVE ? ss.s0.last : ss.s0.input;
+        }
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+            if (j >= vd.n_stages) break;
+            const StageRegs& r = st[j];
+            job.g.g[j + 1][0] = r.s0.status == SM_ACTIVE ? r.s0.last : r.s0.input;
+            job.g.g[j + 1][1] = vd.stage_kind[j] == K_PAN ? (r.s1.status == SM_ACTIVE ? r.s1.last : r.s1.input)
+                                                          : job.g.g[j + 1][0];
+        }
+        became_steady = true;
+        if (w0) {
+            VoiceCache vc;
+            vc.epoch = fv.epoch;
+            vc.mode = mode;
+            vc.flags = job.flags;
+            vc.sample = job.sample;
+            vc.g = job.g;
+            fv.cache[vi] = vc;
+        }
+        if (k + 1 < K) {
+            uint32_t tail_gs = 0;
+            bool simple_ok = false;
+            const bool tail_simple = fx ? (simple_frames && (upstream_silent || (sd.format == FMT_P_F32 && sd.frames < 0xffffffffull)))
+                                        : (!sil && !upstream_silent && sd.format == FMT_P_F32 && simple_frames &&
+                                           sd.frames < 0xffffffffull);
+            if (tail_simple) {
+                VoiceBlk probe;  // every non-wrapping tail block is VB_SIMPLE with the same gains: one gain set
+                probe.flags = VB_SIMPLE;
+#pragma unroll
+                for (int j = 0; j < FW_MAX_STAGES; ++j) {
+                    probe.g[j][0] = job.g.g[j][0];
+                    probe.g[j][1] = job.g.g[j][1];
+                }
+                tail_gs = pick_gset(probe);
+                simple_ok = (probe.flags & VB_SIMPLE) != 0;  // false when the voice ran out of gain-set slots
+            }
+            uint64_t ph = steady_tail(fv, vi, lane, k + 1, K, job, sd, tail_gs, simple_ok, fx);
+            if (mode != 0) ss.playhead = ph;
+        }
+        break;
+    }
+    if (!w0) return;
+    if (!became_steady) fv.cache[vi].epoch = 0;
+    fv.states[vd.sampler_state] = ss;
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
+        if (j < vd.n_stages) *(StageRegs*)&fv.states[vd.stage_state[j]] = st[j];
+}
+

@@ -1,0 +1,570 @@
+// k_generic.hip.h — part of the single device translation unit fwgpu_kernels.hip (included inside namespace fwgpu).
+// Generic level-batched executor (every node kind, one device function each), state init and graph I/O edges.
+#pragma once
+
+// ------------------------------------------------------------------ generic executor: one wave per node
+struct WaveIO {
+    float* pool;
+    uint8_t* flags;
+    const int* in_buf;
+    const int* out_buf;
+    int stride;
+    int lane;
+    int frames;
+    __device__ __forceinline__ const float* in(int i) const { return pool + (size_t)in_buf[i] * stride; }
+    __device__ __forceinline__ float* out(int i) const { return pool + (size_t)out_buf[i] * stride; }
+};
+
+// core/util.rs:165-175
+__device__ __forceinline__ uint64_t clear_all_outputs(const WaveIO& io, int first, int n_out) {
+    for (int c = first; c < n_out; ++c) {
+        float* o = io.out(c);
+        for (int base = io.lane * 4; base < io.frames; base += 256) *(v4f*)(o + base) = splat(0.f);
+    }
+    return mask_all_silent_bits(n_out - first);
+}
+
+__device__ __forceinline__ float clipf(float x, float t) { return fmaxf(fminf(x, t), -t); }
+__device__ __forceinline__ float beep_step(float ph, float inc) {  // beep_test.rs:90 (f32::fract)
+    float t = ph + inc;
+    return t - truncf(t);
+}
+
+// node kinds whose audio half carries state from block to block
+__device__ __forceinline__ bool kind_is_stateful(int kind) {
+    return kind == K_VOLUME || kind == K_SAMPLER || kind == K_BEEP || kind == K_PAN || kind == K_HARD_CLIP ||
+           kind == K_WIDTH || kind == K_BIQUAD || kind == K_DELAY || kind == K_RESAMPLER || kind == K_SPATIAL;
+}
+__device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, uint32_t cmd_block) {
+    const NodeDesc nd = v.nodes[node_idx];
+    if (nd.is_graph_io || nd.kind == K_FIR) return;  // I/O edges (k_graph_in/out); FIR banks run as MFMA GEMMs
+    const int lane = threadIdx.x & (WAVE - 1);
+    WaveIO io;
+    io.pool = v.pool + (size_t)blk * v.pool_blk_stride;
+    io.flags = v.flags + (size_t)blk * v.flags_blk_stride;
+    io.in_buf = v.in_buf + nd.in_off;
+    io.out_buf = v.out_buf + nd.out_off;
+    io.stride = v.stride;
+    io.lane = lane;
+    io.frames = v.frames;
+    const int frames = v.frames;
+
+    // in_silence_mask from the per-buffer flags (schedule.rs:305-320); unconnected inputs read buffer 0,
+    // the constant zero buffer whose flag is always set (== should_clear).
+    bool fl = lane < nd.n_in ? (io.flags[io.in_buf[lane]] != 0) : false;
+    const uint64_t in_mask = __ballot(fl);
+    uint64_t out_mask = 0;  // processor.rs:233
+
+    NodeState s;
+    const bool stateful = kind_is_stateful(nd.kind);
+    if (stateful) {
+        s = v.states[nd.state];
+        apply_cmds(s, nd.state, cmd_block, v.cmds, v.n_cmds, v.samples, v.ext, lane == 0);
+        if (nd.kind == K_BIQUAD && v.n_cmds) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // lane 0's coefficient stores
+    }
+
+    switch (nd.kind) {
+        case K_DUMMY:  // nodes/dummy.rs:33-42 — writes nothing
+            break;
+
+        case K_VOLUME: {  // nodes/volume.rs:84-145
+            float raw = s.p0;
+            if (mask_all(in_mask, nd.n_in)) {  // :94-100
+                smoother_reset(s.s0, raw);
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            GainRun run = smoother_begin(s.s0, raw, frames);  // :102
+            if (!smoother_is_smoothing(s.s0) && run.c < 0.00001f) {  // :104-108
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            out_mask = in_mask;  // :110
+            const bool stereo = nd.n_in == 2 && nd.n_out == 2;
+            const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
+            for (int base = 0; base < frames; base += 256) {
+                int n = frames - base < 256 ? frames - base : 256;
+                v4f g = gain_chunk(run, n, lane);
+                int f0 = base + lane * 4;
+                if (f0 >= frames) continue;
+                for (int c = 0; c < nch; ++c) {
+                    v4f y;
+                    if (!stereo && mask_bit(in_mask, c)) y = splat(0.f);  // :132-135 (Q15)
+                    else y = *(const v4f*)(io.in(c) + f0) * g;            // :123-126, :140-142
+                    *(v4f*)(io.out(c) + f0) = y;
+                }
+            }
+            if (run.ramp) s.s0.last = run.prev;  // :177
+            break;
+        }
+
+        case K_PAN: {  // SPEC node: volume.rs stereo path with one smoother per channel
+            float tl = s.p0, tr = s.p1;
+            if (mask_all(in_mask, nd.n_in)) {
+                smoother_reset(s.s0, tl);
+                smoother_reset(s.s1, tr);
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            GainRun rl = smoother_begin(s.s0, tl, frames);
+            GainRun rr = smoother_begin(s.s1, tr, frames);
+            out_mask = in_mask;
+            for (int base = 0; base < frames; base += 256) {
+                int n = frames - base < 256 ? frames - base : 256;
+                v4f gl = gain_chunk(rl, n, lane);
+                v4f gr = gain_chunk(rr, n, lane);
+                int f0 = base + lane * 4;
+                if (f0 >= frames) continue;
+                *(v4f*)(io.out(0) + f0) = *(const v4f*)(io.in(0) + f0) * gl;
+                *(v4f*)(io.out(1) + f0) = *(const v4f*)(io.in(1) + f0) * gr;
+            }
+            if (rl.ramp) s.s0.last = rl.prev;
+            if (rr.ramp) s.s1.last = rr.prev;
+            break;
+        }
+
+        case K_SUM: {  // nodes/sum.rs:41-136
+            const int n_in = nd.n_in, n_out = nd.n_out, ports = nd.aux0;
+            if (mask_all(in_mask, n_in)) {  // :52-56
+                out_mask = clear_all_outputs(io, 0, n_out);
+                break;
+            }
+            if (n_in == n_out) {  // :58-65 (Q14)
+                for (int c = 0; c < n_out; ++c)
+                    for (int f0 = lane * 4; f0 < frames; f0 += 256) *(v4f*)(io.out(c) + f0) = *(const v4f*)(io.in(c) + f0);
+                out_mask = in_mask;
+                break;
+            }
+            const bool masked = !(ports == 2 || ports == 3 || ports == 4);  // :67-133 (Q13)
+            // lane i keeps the buffer id of input channel i; ids are broadcast with v_readlane so the
+            // per-port loads are independent and can be in flight together (8 at a time)
+            const int my_in = lane < n_in ? io.in_buf[lane] : 0;
+            const uint64_t later_ports = mask_all_silent_bits(n_in) & ~mask_all_silent_bits(n_out);
+            const bool any_skip = masked && (in_mask & later_ports) != 0;
+            for (int c = 0; c < n_out; ++c) {
+                for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+                    v4f acc = *(const v4f*)(io.pool + (size_t)__builtin_amdgcn_readlane(my_in, c) * io.stride + f0);
+                    if (!any_skip) {
+                        for (int p0 = 1; p0 < ports; p0 += 8) {
+                            v4f x[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (p0 + u < ports)
+                                    x[u] = *(const v4f*)(io.pool +
+                                                         (size_t)__builtin_amdgcn_readlane(my_in, n_out * (p0 + u) + c) * io.stride + f0);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (p0 + u < ports) acc = acc + x[u];  // left-assoc, port order (:78,92,107,129)
+                        }
+                    } else {
+                        for (int p = 1; p < ports; ++p) {
+                            int ic = n_out * p + c;
+                            if (mask_bit(in_mask, ic)) continue;  // :122-124
+                            acc = acc + *(const v4f*)(io.in(ic) + f0);
+                        }
+                    }
+                    *(v4f*)(io.out(c) + f0) = acc;
+                }
+            }
+            break;
+        }
+
+        case K_SAMPLER: {  // nodes/sampler.rs:323-561 (messages already applied above)
+            if (s.sample < 0 || !s.playing) {  // :416-430
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            GainRun run = smoother_begin(s.s0, s.p0, frames);        // :432-433
+            if (!smoother_is_smoothing(s.s0) && run.c < 0.00001f) {  // :437-443
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            const SampleDesc sd = v.samples[s.sample];
+            Fetch ft;
+            if (!sampler_advance(s, sd.frames, (uint32_t)frames, ft)) {  // :486-497
+                if (run.ramp) {  // the smoother already ran this block (:433) — keep its state exact
+                    for (int base = 0; base < frames; base += 256) {
+                        int n = frames - base < 256 ? frames - base : 256;
+                        (void)ramp_chunk(run, n, lane);
+                    }
+                    s.s0.last = run.prev;
+                }
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            const int sch = sd.channels;
+            const int nfill = nd.n_out < sch ? nd.n_out : sch;  // fill_buffers zip + gain zip (:535)
+            for (int base = 0; base < frames; base += 256) {
+                int n = frames - base < 256 ? frames - base : 256;
+                v4f g = gain_chunk(run, n, lane);
+                int f0 = base + lane * 4;
+                if (f0 >= frames) continue;
+                v4f first = splat(0.f);
+                for (int c = 0; c < nfill; ++c) {
+                    v4f x = sample_fetch4(sd, c, ft, (uint32_t)f0, (uint32_t)frames) * g;  // :521-543
+                    if (c == 0) first = x;
+                    *(v4f*)(io.out(c) + f0) = x;
+                }
+                if (nd.n_out > sch) {  // :545-559
+                    if (nd.n_out == 2 && sch == 1) {
+                        *(v4f*)(io.out(1) + f0) = first;
+                    } else {
+                        for (int c = sch; c < nd.n_out; ++c) *(v4f*)(io.out(c) + f0) = splat(0.f);
+                    }
+                }
+            }
+            if (nd.n_out > sch && !(nd.n_out == 2 && sch == 1))
+                for (int c = sch; c < nd.n_out; ++c) out_mask |= (1ull << c);  // :556
+            if (run.ramp) s.s0.last = run.prev;
+            break;
+        }
+
+        case K_BEEP: {  // nodes/beep_test.rs:71-97
+            if (nd.n_out == 0) break;
+            if (!s.enabled) {  // :83-86 (Q12): channel 0 untouched, mask = new_all_silent(n-1)
+                out_mask = clear_all_outputs(io, 1, nd.n_out);
+                break;
+            }
+            const float TAU = 6.28318530717958647692528676655900577f;
+            float ph = s.phasor;
+            const float inc = s.phasor_inc;
+            for (int base = 0; base < frames; base += 256) {
+                int n = frames - base < 256 ? frames - base : 256;
+                v4f p4 = splat(0.f);
+                int q = 0;  // serial phasor (:90); lane keeps the four phases of its frames
+                for (; q * 4 + 4 <= n; ++q) {
+                    float a0 = ph;
+                    ph = beep_step(ph, inc);
+                    float a1 = ph;
+                    ph = beep_step(ph, inc);
+                    float a2 = ph;
+                    ph = beep_step(ph, inc);
+                    float a3 = ph;
+                    ph = beep_step(ph, inc);
+                    if (q == lane) p4 = (v4f){a0, a1, a2, a3};
+                }
+                int rem = n - q * 4;
+                if (rem > 0) {
+                    float a0 = ph;
+                    ph = beep_step(ph, inc);
+                    float a1 = ph;
+                    if (rem > 1) ph = beep_step(ph, inc);
+                    float a2 = ph;
+                    if (rem > 2) ph = beep_step(ph, inc);
+                    if (q == lane) p4 = (v4f){a0, a1, a2, 0.f};
+                }
+                int f0 = base + lane * 4;
+                if (f0 >= frames) continue;
+                v4f y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = sinf(p4[j] * TAU) * s.gain;  // :89
+                for (int c = 0; c < nd.n_out; ++c) *(v4f*)(io.out(c) + f0) = y;  // :93-95
+            }
+            s.phasor = ph;
+            break;
+        }
+
+        case K_HARD_CLIP: {  // nodes/hard_clip.rs:51-95
+            const float t = s.p0;
+            const bool fast = nd.n_in == 2 && nd.n_out == 2 && !mask_any(in_mask, 2);  // :60-63 (Q16)
+            const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
+            for (int c = 0; c < nch; ++c) {
+                const bool sil = !fast && mask_bit(in_mask, c);
+                for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+                    v4f y = splat(0.f);
+                    if (!sil) {
+                        v4f x = *(const v4f*)(io.in(c) + f0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[j] = clipf(x[j], t);
+                    }
+                    *(v4f*)(io.out(c) + f0) = y;
+                }
+            }
+            if (!fast) out_mask = in_mask;  // :93
+            break;
+        }
+
+        case K_MONO_TO_STEREO: {  // nodes/mono_to_stereo.rs:33-50
+            if (mask_bit(in_mask, 0)) {
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+                v4f x = *(const v4f*)(io.in(0) + f0);
+                *(v4f*)(io.out(0) + f0) = x;
+                *(v4f*)(io.out(1) + f0) = x;
+            }
+            break;
+        }
+
+        case K_STEREO_TO_MONO: {  // nodes/stereo_to_mono.rs:33-56
+            if (mask_all(in_mask, 2) || nd.n_in < 2 || nd.n_out == 0) {
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+                v4f a = *(const v4f*)(io.in(0) + f0);
+                v4f b = *(const v4f*)(io.in(1) + f0);
+                *(v4f*)(io.out(0) + f0) = (a + b) * 0.5f;
+            }
+            break;
+        }
+        case K_WIDTH: {  // SPEC: mid/side width, one smoothed parameter
+            if (mask_all(in_mask, nd.n_in)) {
+                smoother_reset(s.s0, s.p0);
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            GainRun run = smoother_begin(s.s0, s.p0, frames);
+            for (int base = 0; base < frames; base += 256) {
+                int n = frames - base < 256 ? frames - base : 256;
+                v4f w = gain_chunk(run, n, lane);
+                int f0 = base + lane * 4;
+                if (f0 >= frames) continue;
+                v4f l = *(const v4f*)(io.in(0) + f0);
+                v4f r = *(const v4f*)(io.in(1) + f0);
+                v4f m = (l + r) * 0.5f;
+                v4f sd = ((l - r) * 0.5f) * w;
+                *(v4f*)(io.out(0) + f0) = m + sd;
+                *(v4f*)(io.out(1) + f0) = m - sd;
+            }
+            if (run.ramp) s.s0.last = run.prev;
+            break;
+        }
+
+        case K_BIQUAD: {  // SPEC: RBJ biquad, Direct Form I, f32 state: unfused feed-forward half, then
+            // y = fma(-a1, y1, fma(-a2, y2, ff)) (one fma on the recurrence's critical path; SPEC: DESIGN.md §6).
+            // Serial in time: lane c runs channel c (the generic executor's coverage path).
+            float* ext = v.ext + s.ext_off;
+            const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
+            if (lane < nch) {
+                const float b0 = ext[0], b1 = ext[1], b2 = ext[2], a1 = ext[3], a2 = ext[4];
+                float* st = ext + 5 + 4 * lane;
+                float x1 = st[0], x2 = st[1], y1 = st[2], y2 = st[3];
+                const float* in = io.in(lane);
+                float* out = io.out(lane);
+                for (int i = 0; i < frames; ++i) {
+                    float x = in[i];
+                    float acc = b0 * x;
+                    acc = acc + (b1 * x1);
+                    acc = acc + (b2 * x2);
+                    acc = __builtin_fmaf(-a2, y2, acc);
+                    acc = __builtin_fmaf(-a1, y1, acc);
+                    x2 = x1;
+                    x1 = x;
+                    y2 = y1;
+                    y1 = acc;
+                    out[i] = acc;
+                }
+                st[0] = x1;
+                st[1] = x2;
+                st[2] = y1;
+                st[3] = y2;
+            }
+            break;
+        }
+
+        case K_DELAY: {  // SPEC: integer-sample delay line with feedback, ring per channel in the ext pool
+            const uint32_t D = (uint32_t)s.loop_end;
+            const uint32_t pos = (uint32_t)s.playhead;
+            const float fb = s.p0, mix = s.p1, dry = s.gain;
+            const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
+            const uint32_t chunk = D < 64u ? D : 64u;  // frames inside one chunk touch distinct ring slots
+            for (int c = 0; c < nch; ++c) {
+                float* ring = v.ext + s.ext_off + (size_t)c * D;
+                const float* in = io.in(c);
+                float* out = io.out(c);
+                for (uint32_t base = 0; base < (uint32_t)frames; base += chunk) {
+                    uint32_t i = base + (uint32_t)lane;
+                    if ((uint32_t)lane < chunk && i < (uint32_t)frames) {
+                        uint32_t slot = (pos + i) % D;
+                        float x = in[i];
+                        float d = ring[slot];
+                        ring[slot] = x + (d * fb);
+                        out[i] = (x * dry) + (d * mix);
+                    }
+                    if (D < (uint32_t)frames) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // next chunk re-reads these slots
+                }
+            }
+            s.playhead = (uint64_t)((pos + (uint32_t)frames) % D);
+            break;
+        }
+
+        case K_RESAMPLER: {  // SPEC: resampling source, polyphase windowed sinc
+            const SampleDesc sd = s.sample >= 0 ? v.samples[s.sample] : SampleDesc{nullptr, 0, 0, FMT_P_F32};
+            if (!s.playing || s.sample < 0 || sd.frames == 0) {
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
+            const uint64_t step = s.loop_start, pos = s.playhead;
+            const bool loop = s.has_loop != 0;
+            const int64_t len = (int64_t)sd.frames;
+            const int sch = sd.channels;
+            const int nfill = nd.n_out < sch ? nd.n_out : sch;
+            for (int i = lane; i < frames; i += WAVE) {  // every output frame is independent
+                const uint64_t p = pos + (uint64_t)i * step;
+                const int64_t idx = (int64_t)(p >> 32);
+                const float* hp = v.rs_table + ((uint32_t)(p >> 27) & (RS_PHASES - 1)) * RS_TAPS;
+                float first = 0.f;
+                for (int c = 0; c < nfill; ++c) {
+                    float acc = 0.f;
+                    for (int k = 0; k < RS_TAPS; ++k) {  // ascending-tap fmaf chain from +0.0 (the SPEC order)
+                        int64_t j = idx - (RS_TAPS / 2 - 1) + k;
+                        float x = 0.f;
+                        if (loop) {
+                            j %= len;
+                            if (j < 0) j += len;
+                            x = sample_fetch(sd, c, (uint64_t)j);
+                        } else if (j >= 0 && j < len) {
+                            x = sample_fetch(sd, c, (uint64_t)j);
+                        }
+                        acc = __builtin_fmaf(hp[k], x, acc);
+                    }
+                    io.out(c)[i] = acc;
+                    if (c == 0) first = acc;
+                }
+                if (nd.n_out > sch) {
+                    if (nd.n_out == 2 && sch == 1) io.out(1)[i] = first;
+                    else
+                        for (int c = sch; c < nd.n_out; ++c) io.out(c)[i] = 0.f;
+                }
+            }
+            if (nd.n_out > sch && !(nd.n_out == 2 && sch == 1))
+                for (int c = sch; c < nd.n_out; ++c) out_mask |= (1ull << c);
+            uint64_t np = pos + (uint64_t)frames * step;
+            if (loop) np %= ((uint64_t)len << 32);
+            else if ((np >> 32) >= (uint64_t)len + RS_TAPS / 2) s.playing = 0;
+            s.playhead = np;
+            break;
+        }
+
+        case K_SPATIAL: {  // SPEC: distance gain + equal-power pan + per-ear integer delay
+            float* hist = v.ext + s.ext_off;
+            const int dl = s.playing, dr = s.has_loop;
+            const float hreg = hist[lane];  // lane l keeps hist[l] (SP_HIST == 64), hist[63] = newest
+            GainRun rl = smoother_begin(s.s0, s.p0, frames);
+            GainRun rr = smoother_begin(s.s1, s.p1, frames);
+            const bool two = nd.n_in >= 2;
+            auto mono = [&](int j) -> float {  // m[j], j >= 0
+                return two ? (io.in(0)[j] + io.in(1)[j]) * 0.5f : io.in(0)[j];
+            };
+            for (int base = 0; base < frames; base += 256) {
+                int n = frames - base < 256 ? frames - base : 256;
+                v4f gl = gain_chunk(rl, n, lane);
+                v4f gr = gain_chunk(rr, n, lane);
+                int f0 = base + lane * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = f0 + e;
+                    const int jl = i - dl, jr = i - dr;
+                    // history lookups go through the wave (every lane takes part), current-block ones through memory
+                    const float hl = __shfl(hreg, (SP_HIST + jl) & 63), hr = __shfl(hreg, (SP_HIST + jr) & 63);
+                    if (i < frames) {
+                        const float ml = jl >= 0 ? mono(jl) : hl;
+                        const float mr = jr >= 0 ? mono(jr) : hr;
+                        io.out(0)[i] = ml * gl[e];
+                        io.out(1)[i] = mr * gr[e];
+                    }
+                }
+            }
+            if (rl.ramp) s.s0.last = rl.prev;
+            if (rr.ramp) s.s1.last = rr.prev;
+            // new history = the last SP_HIST samples of (hist ++ m[0..frames))
+            const int j = frames - SP_HIST + lane;
+            const float keep = __shfl(hreg, (SP_HIST + j) & 63);
+            hist[lane] = j >= 0 ? mono(j) : keep;
+            break;
+        }
+
+        default: break;
+    }
+
+    if (stateful && lane == 0) v.states[nd.state] = s;
+    // schedule.rs:338-341: every output buffer's flag is overwritten with the node's out mask bit
+    if (lane < nd.n_out) io.flags[io.out_buf[lane]] = mask_bit(out_mask, lane) ? 1 : 0;
+}
+
+// K blocks per launch (gridDim.y = K, one pool slice per block).  A node whose audio half carries state from block
+// to block is run by ONE wave that walks its K blocks in order; stateless nodes take their K blocks in parallel.
+__global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __restrict__ level_nodes, int n_nodes,
+                                                      uint32_t cmd_block0) {
+    int w = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (w >= n_nodes) return;
+    const int node = level_nodes[w];
+    if (kind_is_stateful(v.nodes[node].kind)) {
+        if (blockIdx.y != 0) return;
+        for (uint32_t b = 0; b < gridDim.y; ++b) node_process_wave(v, node, b, cmd_block0 + b);
+    } else {
+        node_process_wave(v, node, blockIdx.y, cmd_block0 + blockIdx.y);
+    }
+}
+
+// B1: one node on scratch buffers (single wave)
+__global__ __launch_bounds__(WAVE) void k_single_node(DevView v, int node_idx) { node_process_wave(v, node_idx, 0, 0); }
+
+// ------------------------------------------------------------------ state init / graph I/O edges
+struct StateInit {
+    int index;
+    int pad;
+    NodeState st;
+};
+__global__ void k_scatter_states(NodeState* states, const uint8_t* __restrict__ inits, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const StateInit* in = (const StateInit*)inits + i;
+    states[in->index] = in->st;
+}
+
+// processor.rs:99-115 + schedule.rs:213-253 + util.rs:44-87.  Q10: the graph_in Dummy node's out mask (0)
+// overwrites whatever prepare_graph_inputs computed, so every graph-input buffer flag ends up false.
+__global__ void k_graph_in(float* pool, uint8_t* flags, int stride, size_t pool_blk_stride, size_t flags_blk_stride,
+                           const int* __restrict__ bufs, int n_bufs, const float* __restrict__ interleaved, int n_in_ch,
+                           int frames) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = blockIdx.y;
+    const uint32_t blk = blockIdx.z;  // K-batched: one pool slice per block
+    pool += (size_t)blk * pool_blk_stride;
+    flags += (size_t)blk * flags_blk_stride;
+    if (f < frames) {
+        float x = c < n_in_ch ? interleaved[((size_t)blk * frames + f) * n_in_ch + c] : 0.f;  // extra graph inputs zero-filled
+        pool[(size_t)bufs[c] * stride + f] = x;
+    }
+    if (f == 0) flags[bufs[c]] = 0;
+}
+
+// processor.rs:120-148 + schedule.rs:255-287 + util.rs:90-147.  K-batched: blockIdx.y = block.
+__global__ void k_graph_out(const float* __restrict__ pool, const uint8_t* __restrict__ flags, int stride,
+                            size_t pool_blk_stride, size_t flags_blk_stride, const int* __restrict__ bufs, int n_bufs,
+                            float* __restrict__ out, int n_out_ch, int frames) {
+    const uint32_t blk = blockIdx.y;
+    const float* p = pool + (size_t)blk * pool_blk_stride;
+    const uint8_t* fl = flags + (size_t)blk * flags_blk_stride;
+    float* o = out + (size_t)blk * frames * n_out_ch;
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    int n_read = n_bufs < n_out_ch ? n_bufs : n_out_ch;  // read_output_len
+    if (n_read == 2 && n_out_ch == 2) {                   // interleave_stereo (util.rs:123-147)
+        bool both = fl[bufs[0]] && fl[bufs[1]];
+        float2 y;
+        y.x = both ? 0.f : p[(size_t)bufs[0] * stride + f];
+        y.y = both ? 0.f : p[(size_t)bufs[1] * stride + f];
+        *(float2*)(o + (size_t)f * 2) = y;
+        return;
+    }
+    for (int c = 0; c < n_out_ch; ++c) {  // interleave (util.rs:90-120): zero-fill, skip silent channels
+        float y = 0.f;
+        if (c < n_read && !fl[bufs[c]]) y = p[(size_t)bufs[c] * stride + f];
+        o[(size_t)f * n_out_ch + c] = y;
+    }
+}
+
+__global__ void k_set_flags(uint8_t* flags, const int* __restrict__ bufs, int n, uint64_t mask) {
+    int i = threadIdx.x;
+    if (i < n) flags[bufs[i]] = (mask >> i) & 1ull;
+}
+__global__ void k_get_flags(const uint8_t* flags, const int* __restrict__ bufs, int n, uint64_t* mask) {
+    bool f = (int)threadIdx.x < n ? flags[bufs[threadIdx.x]] != 0 : false;
+    uint64_t m = __ballot(f);
+    if (threadIdx.x == 0) *mask = m;
+}
+

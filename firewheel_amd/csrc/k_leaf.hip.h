@@ -1,0 +1,299 @@
+// k_leaf.hip.h — part of the single device translation unit fwgpu_kernels.hip (included inside namespace fwgpu).
+// Fused voice-bank plan: k_leaf_sum (HBM-streaming source fetch + gain stages + ordered leaf sums), upper sum tree, root + interleave.
+#pragma once
+
+// Leaf kernel: one wave per (leaf SumNode, block).  For each port in order: fetch the voice's source frames,
+// run its gain stages in registers, and accumulate in the reference's summation order (nodes/sum.rs).
+// HBM traffic = the source samples once (8 B per stereo voice-sample) + one partial-bus write per leaf.
+__device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& d, uint32_t k, int voice, int f0, int frames,
+                                           v4f& xl, v4f& xr) {
+    const bool mono = d.flags & VB_MONO;
+    if (d.src_l && f0 + 4 <= frames) {  // planar f32, contiguous: one dwordx4 per channel per lane
+        xl = *(const v4f_u*)(d.src_l + f0);
+        xr = mono ? xl : *(const v4f_u*)(d.src_r + f0);
+    } else {
+        const SampleDesc sd = fv.samples[d.sample];
+        Fetch ft;
+        ft.off0 = d.off0;
+        ft.off1 = d.off1;
+        ft.n1 = d.n1;
+        ft.wrap = (d.flags & VB_WRAP) ? 1 : 0;
+        ft.tail_zero = (d.flags & VB_TAIL_ZERO) ? 1 : 0;
+        xl = sample_fetch4(sd, 0, ft, (uint32_t)f0, (uint32_t)frames);
+        xr = mono ? xl : sample_fetch4(sd, 1, ft, (uint32_t)f0, (uint32_t)frames);
+    }
+    const uint32_t rbits = d.flags >> VB_RAMP_SHIFT;
+    if (rbits == 0) {  // constant gains: sampler.rs:530-533 then volume.rs:123-126 / pan, one rounding each
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j) {
+            if (j >= fv.n_gain_stages) break;
+            xl = xl * d.g[j][0];
+            xr = xr * d.g[j][1];
+        }
+        // a mono sample is duplicated AFTER the sampler gain (sampler.rs:546-551); identical values either way
+    } else {
+        const float* rb = fv.ramps + ((size_t)k * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j) {
+            if (j >= fv.n_gain_stages) break;
+            v4f gl = (rbits >> (2 * j)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j) * fv.stride) : splat(d.g[j][0]);
+            v4f gr = (rbits >> (2 * j + 1)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j + 1) * fv.stride) : splat(d.g[j][1]);
+            xl = xl * gl;
+            xr = xr * gr;
+        }
+    }
+}
+
+__device__ __forceinline__ const float* readlane_ptr(const float* p, int lane) {
+    uint64_t u = (uint64_t)p;
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+    return (const float*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float readlane_f(float x, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+
+#ifndef LEAF_U
+#define LEAF_U 4  // voices whose source loads are in flight together (2*LEAF_U dwordx4 per lane)
+#endif
+#ifndef LEAF_NT
+#define LEAF_NT 1  // non-temporal source loads: every source byte is read exactly once (+12 % measured)
+#endif
+#ifndef LEAF_WPB
+#define LEAF_WPB 4  // waves (leaf, block work items) per workgroup
+#endif
+#ifndef LEAF_MAP_BLOCKS
+#define LEAF_MAP_BLOCKS 1
+#endif
+// the pointers come out of v_readlane as integers: tell the compiler they are GLOBAL (global_load, not flat_load)
+typedef const v4f_u __attribute__((address_space(1)))* gv4p;
+__device__ __forceinline__ v4f gload4(const float* p) {
+#if LEAF_NT
+    return __builtin_nontemporal_load((gv4p)(uint64_t)p);
+#else
+    return *(gv4p)(uint64_t)p;
+#endif
+}
+
+// lane p holds port p's VoiceRef + GainSet; every port is VB_SIMPLE (contiguous planar f32, constant gains)
+template <int NG>
+__device__ __forceinline__ void leaf_fast(const float* my_l, const float* my_r, const GainSet& my_g, int ports, int f0,
+                                          v4f& accl, v4f& accr) {
+    for (int p0 = 0; p0 < ports; p0 += LEAF_U) {
+        v4f xl[LEAF_U], xr[LEAF_U];
+#pragma unroll
+        for (int u = 0; u < LEAF_U; ++u) {
+            if (p0 + u < ports) {
+                xl[u] = gload4(readlane_ptr(my_l, p0 + u) + f0);
+                xr[u] = gload4(readlane_ptr(my_r, p0 + u) + f0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LEAF_U; ++u) {
+            if (p0 + u < ports) {
+                v4f a = xl[u], b = xr[u];
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {  // sampler.rs:530-533, volume.rs:123-126, pan: one rounding each
+                    a = a * readlane_f(my_g.g[j][0], p0 + u);
+                    b = b * readlane_f(my_g.g[j][1], p0 + u);
+                }
+                if (p0 + u == 0) {
+                    accl = a;
+                    accr = b;
+                } else {
+                    accl = accl + a;
+                    accr = accr + b;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K) {
+#if LEAF_MAP_BLOCKS
+    // the waves of a workgroup take CONSECUTIVE blocks of one leaf: a steady voice's source is contiguous across
+    // blocks, so the workgroup streams LEAF_WPB KiB per voice-channel instead of 1 KiB from LEAF_WPB x 32 places
+    const int leaf = blockIdx.x;
+    const uint32_t k = blockIdx.y * LEAF_WPB + (threadIdx.x >> 6);
+    if (k >= (uint32_t)K) return;
+#else
+    const int leaf = blockIdx.x * LEAF_WPB + (threadIdx.x >> 6);
+    if (leaf >= fv.n_leaves) return;
+    const uint32_t k = blockIdx.y;
+#endif
+    const int lane = threadIdx.x & (WAVE - 1);
+    const LeafDesc ld = fv.leaves[leaf];
+    const int frames = fv.frames;
+    const size_t row = (size_t)k * fv.n_voices + ld.first_voice;
+    float* bus = fv.bus + (size_t)k * fv.bus_blk_stride;
+    uint8_t* bflags = fv.bus_flags + (size_t)k * fv.bus_flags_blk_stride;
+    float* outl = bus + (size_t)ld.out_buf * fv.stride;
+    float* outr = outl + fv.stride;
+
+    // lane p loads the compact record of port p (ports <= 32); in_silence_mask: both channels share one flag
+    VoiceRef ref;
+    ref.src_l = nullptr;
+    ref.r_delta = 0;
+    ref.flags_gset = VB_SILENT;
+    if (lane < ld.ports) ref = fv.refs[(size_t)(ld.first_voice + lane) * fv.refs_stride + k];
+    const uint32_t my_flags = ref.flags_gset & 0xffu;
+    GainSet my_g;
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES; ++j) my_g.g[j][0] = my_g.g[j][1] = 1.0f;
+    if (my_flags & VB_SIMPLE) my_g = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + (ref.flags_gset >> 8)];
+    const float* my_l = ref.src_l;
+    const float* my_r = ref.src_l + ref.r_delta;
+    const uint64_t lanes_in = mask_all_silent_bits(ld.ports);
+    const uint64_t silent_ports = __ballot((my_flags & VB_SILENT) != 0) & lanes_in;
+    const uint64_t simple_ports = __ballot((my_flags & VB_SIMPLE) != 0) & lanes_in;
+    const bool all_silent = silent_ports == lanes_in;
+    const bool masked = !(ld.ports == 2 || ld.ports == 3 || ld.ports == 4);  // sum.rs:67-133 (Q13)
+    const bool fast = simple_ports == lanes_in && (frames & 3) == 0;
+
+    for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+        v4f accl = splat(0.f), accr = splat(0.f);
+        if (fast) {
+            switch (fv.n_gain_stages) {
+                case 1: leaf_fast<1>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                case 2: leaf_fast<2>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                case 3: leaf_fast<3>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                default: leaf_fast<4>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+            }
+        } else if (!all_silent) {
+            for (int p = 0; p < ld.ports; ++p) {
+                const bool psil = (silent_ports >> p) & 1ull;
+                v4f xl = splat(0.f), xr = splat(0.f);  // a silent chain's buffers hold cleared zeros
+                if (!psil) {
+                    if ((simple_ports >> p) & 1ull) {  // VB_SIMPLE implies frames % 4 == 0
+                        xl = gload4(readlane_ptr(my_l, p) + f0);
+                        xr = gload4(readlane_ptr(my_r, p) + f0);
+#pragma unroll
+                        for (int j = 0; j < FW_MAX_STAGES; ++j) {
+                            if (j >= fv.n_gain_stages) break;
+                            xl = xl * readlane_f(my_g.g[j][0], p);
+                            xr = xr * readlane_f(my_g.g[j][1], p);
+                        }
+                    } else {
+                        const VoiceBlk d = fv.blks[row + p];
+                        voice_eval(fv, d, k, ld.first_voice + p, f0, frames, xl, xr);
+                    }
+                }
+                if (p == 0) {  // sum.rs:117 copy_from_slice(port 0) — also when silent; 2/3/4-port: in1
+                    accl = xl;
+                    accr = xr;
+                } else if (!(masked && psil)) {  // :122-124 skip silent ports (n-port path only)
+                    accl = accl + xl;
+                    accr = accr + xr;
+                }
+            }
+        }
+        *(v4f*)(outl + f0) = accl;  // all_silent: clear_all_outputs (sum.rs:52-56)
+        *(v4f*)(outr + f0) = accr;
+    }
+    // out mask: all-silent -> both flagged; 1-port copy -> passthrough (sum.rs:58-65); else 0
+    if (lane < 2) bflags[ld.out_buf + lane] = all_silent ? 1 : 0;
+}
+
+// Upper sum tree of the fused plan, K-batched: SumNode semantics (nodes/sum.rs:41-136) with one THREAD per
+// frame (blockIdx = node, block, channel) so that a 1-node level still puts K * n_out * frames/64 waves in flight.
+__global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restrict__ level_nodes) {
+    const NodeDesc nd = v.nodes[level_nodes[blockIdx.x]];
+    const uint32_t blk = blockIdx.y;
+    const int c = blockIdx.z;
+    const int lane = threadIdx.x & (WAVE - 1);
+    float* pool = v.pool + (size_t)blk * v.pool_blk_stride;
+    uint8_t* flags = v.flags + (size_t)blk * v.flags_blk_stride;
+    const int* in_buf = v.in_buf + nd.in_off;
+    const int* out_buf = v.out_buf + nd.out_off;
+    const int n_in = nd.n_in, n_out = nd.n_out, ports = nd.aux0;
+    const int my_in = lane < n_in ? in_buf[lane] : 0;
+    const uint64_t in_mask = __ballot(lane < n_in ? flags[my_in] != 0 : false);
+    float* out = pool + (size_t)out_buf[c] * v.stride;
+    uint64_t out_mask = 0;
+    if (mask_all(in_mask, n_in)) {  // :52-56
+        for (int f = threadIdx.x; f < v.frames; f += blockDim.x) out[f] = 0.f;
+        out_mask = mask_all_silent_bits(n_out);
+    } else if (n_in == n_out) {  // :58-65
+        const float* in = pool + (size_t)__builtin_amdgcn_readlane(my_in, c) * v.stride;
+        for (int f = threadIdx.x; f < v.frames; f += blockDim.x) out[f] = in[f];
+        out_mask = in_mask;
+    } else {
+        const bool masked = !(ports == 2 || ports == 3 || ports == 4);
+        for (int f = threadIdx.x; f < v.frames; f += blockDim.x) {
+            float acc = pool[(size_t)__builtin_amdgcn_readlane(my_in, c) * v.stride + f];
+            for (int p0 = 1; p0 < ports; p0 += 8) {
+                float x[8];
+                bool use[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    use[u] = false;
+                    if (p0 + u < ports) {
+                        int ic = n_out * (p0 + u) + c;
+                        use[u] = !(masked && mask_bit(in_mask, ic));  // :122-124
+                        x[u] = pool[(size_t)__builtin_amdgcn_readlane(my_in, ic) * v.stride + f];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (use[u]) acc = acc + x[u];
+            }
+            out[f] = acc;
+        }
+    }
+    if (c == 0 && (int)threadIdx.x < n_out) flags[out_buf[threadIdx.x]] = mask_bit(out_mask, threadIdx.x) ? 1 : 0;
+}
+
+// The root SumNode of the fused plans (stereo, its ports are bus buffers) fused with read_graph_outputs +
+// interleave_stereo (schedule.rs:255-287, util.rs:123-147): one launch fewer per call and the root's planar result
+// never goes to memory.  Same arithmetic as k_bus_sum followed by k_graph_out: all inputs silent -> the sum clears and
+// flags both channels -> interleave_stereo zero-fills; n_in == n_out -> copy with mask passthrough; otherwise ports
+// added in order (silent ports skipped on the n-port path only) and both flags are clear.
+__global__ __launch_bounds__(256) void k_root_out(DevView v, int root_node, float* __restrict__ out) {
+    const NodeDesc nd = v.nodes[root_node];
+    const uint32_t blk = blockIdx.y;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const float* pool = v.pool + (size_t)blk * v.pool_blk_stride;
+    const uint8_t* flags = v.flags + (size_t)blk * v.flags_blk_stride;
+    const int* in_buf = v.in_buf + nd.in_off;
+    const int n_in = nd.n_in, ports = nd.aux0;
+    const int my_in = lane < n_in ? in_buf[lane] : 0;
+    const uint64_t in_mask = __ballot(lane < n_in ? flags[my_in] != 0 : false);
+    float* o = out + (size_t)blk * v.frames * 2;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= v.frames) return;
+    float2 y = make_float2(0.f, 0.f);
+    if (mask_all(in_mask, n_in)) {
+        // sum.rs:52-56 then util.rs:129-134
+    } else if (n_in == 2) {  // sum.rs:58-65: copy, flags pass through; both silent was handled above
+        y.x = pool[(size_t)__builtin_amdgcn_readlane(my_in, 0) * v.stride + f];
+        y.y = pool[(size_t)__builtin_amdgcn_readlane(my_in, 1) * v.stride + f];
+    } else {
+        const bool masked = !(ports == 2 || ports == 3 || ports == 4);
+        float accl = pool[(size_t)__builtin_amdgcn_readlane(my_in, 0) * v.stride + f];
+        float accr = pool[(size_t)__builtin_amdgcn_readlane(my_in, 1) * v.stride + f];
+        for (int p0 = 1; p0 < ports; p0 += 8) {
+            float xl[8], xr[8];
+            bool ul[8], ur[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ul[u] = ur[u] = false;
+                if (p0 + u < ports) {
+                    const int il = 2 * (p0 + u), ir = il + 1;
+                    ul[u] = !(masked && mask_bit(in_mask, il));  // :122-124
+                    ur[u] = !(masked && mask_bit(in_mask, ir));
+                    xl[u] = pool[(size_t)__builtin_amdgcn_readlane(my_in, il) * v.stride + f];
+                    xr[u] = pool[(size_t)__builtin_amdgcn_readlane(my_in, ir) * v.stride + f];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (ul[u]) accl = accl + xl[u];
+                if (ur[u]) accr = accr + xr[u];
+            }
+        }
+        y = make_float2(accl, accr);
+    }
+    *(float2*)(o + (size_t)f * 2) = y;
+}
+

@@ -60,10 +60,12 @@ def sum_tree(cx, fa, ends, radix):
     cx.connect(level[0], 1, cx.graph_out_node(), 1, False)
 
 
-def start_voices(cx, fa, samplers, src, frames_per_voice):
+def start_voices(cx, fa, samplers, src, frames_per_voice, fmt="f32"):
+    elem = 4 if fmt == "f32" else 2
+    sfmt = fa.SampleFormat.PLANAR_F32 if fmt == "f32" else fa.SampleFormat.INTERLEAVED_I16
     for v, s in enumerate(samplers):
-        ptr = src.data_ptr() + v * 2 * frames_per_voice * 4
-        smp = cx.new_sample_device(fa.SampleFormat.PLANAR_F32, 2, frames_per_voice, ptr)
+        ptr = src.data_ptr() + v * 2 * frames_per_voice * elem
+        smp = cx.new_sample_device(sfmt, 2, frames_per_voice, ptr)
         node = cx.node(s)
         node.set_sample(smp, False)
         node.set_loop_range(fa.LoopRange.Full())
@@ -223,6 +225,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--taps", type=int, default=65536)
+    ap.add_argument("--source-format", choices=["f32", "i16"], default="f32",
+                    help="cfg2/cfg5 only: planar f32 sources (the headline) or interleaved stereo i16 (4 B per voice-sample)")
     ap.add_argument("--bus-reduce", choices=["allreduce", "ordered"], default="allreduce",
                     help="N>1: RCCL all-reduce (named path) or all-gather + rank-ordered sum (bit-exact)")
     args = ap.parse_args()
@@ -269,8 +273,12 @@ def main():
     # synthetic sources, generated in HBM: uniform(-1,1) f32, seed offset by global voice id
     g = torch.Generator(device="cuda")
     g.manual_seed(shard.voice_seed(rank * V))  # stream keyed by the shard's first GLOBAL voice id
-    src = torch.empty((V, 2, F), dtype=torch.float32, device="cuda")
-    src.uniform_(-1.0, 1.0, generator=g)
+    sfmt = args.source_format if wl in ("cfg2", "cfg5") else "f32"
+    if sfmt == "i16":  # interleaved stereo PCM, [voice][frame][channel]
+        src = torch.randint(-32768, 32768, (V, F, 2), dtype=torch.int16, device="cuda", generator=g)
+    else:
+        src = torch.empty((V, 2, F), dtype=torch.float32, device="cuda")
+        src.uniform_(-1.0, 1.0, generator=g)
     if wl == "cfg4":
         samplers = build_reverb_bank(cx, fa, V, args.radix, args.taps)
         want_plan = 0
@@ -280,7 +288,7 @@ def main():
     else:
         samplers = build_bank(cx, fa, V, args.radix, seed=rank)
         want_plan = 1
-    start_voices(cx, fa, samplers, src, F)
+    start_voices(cx, fa, samplers, src, F, sfmt)
     assert cx.plan_kind() == want_plan, "expected launch plan %d, got %d" % (want_plan, cx.plan_kind())
     # two bus buffers: with N > 1 the reduction of step i (RCCL, its own stream) overlaps the compute of step i+1 —
     # the mix bus is a sink, nothing in a shard reads it back
@@ -351,12 +359,13 @@ def main():
                         "launches": fir_n, "blocks_per_launch": K, "timing": "HIP events, separate pass after the timed region",
                         "whole_block_us_all_kernels": gen_ms / max(gen_n, 1) / K * 1e3}
         elif dom_n:
-            per_vs = 24.0 if wl == "cfg3" else 8.0  # source L+R once (+ delay ring read + write)
+            # source L+R once (f32: 8 B, i16: 4 B) (+ delay ring read + write)
+            per_vs = 24.0 if wl == "cfg3" else (4.0 if sfmt == "i16" else 8.0)
             kernel = "k_chain" if wl == "cfg3" else "k_leaf_sum"
             alg_bytes = V * B * K * per_vs
             avg_s = dom_ms / dom_n / 1e3
             ach = alg_bytes / avg_s / 1e9
-            traffic, traffic_src = pmc_traffic(kernel, V, B, K)
+            traffic, traffic_src = pmc_traffic(kernel, V, B, K) if sfmt == "f32" else (None, None)  # PMC passes ran on f32 sources
             roofline = {
                 "bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -390,7 +399,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s, block=%d @48kHz, planar f32 sources in HBM (%d frames/voice, looping)" % (desc, B, F),
+                "workload": "%s, block=%d @48kHz, %s sources in HBM (%d frames/voice, looping)"
+                            % (desc, B, "planar f32" if sfmt == "f32" else "interleaved stereo i16", F),
                 "voices_per_gpu": V, "block": B, "blocks_per_step": K, "parallelism": "voice-shard x%d%s" %
                 (world, (" + RCCL mix-bus %s" % args.bus_reduce) if world > 1 else ""),
                 "realtime_factor": (total / dt) / (48000.0 * V * world),

@@ -131,10 +131,20 @@ static_assert(sizeof(VoiceBlk) == 80, "VoiceBlk layout");
 
 // Compact per (block, voice) record (16 B): all the leaf kernel needs for silent and VB_SIMPLE blocks.  Only
 // blocks that are neither (ramps, loop wrap, one-shot tail, non-planar-f32 sources) also get a full VoiceBlk.
+// VB_SIMPLE source classes (bits 16..18 of VoiceRef::flags_gset): how the leaf kernel fetches 4 consecutive frames
+enum : uint32_t {
+    SF_P_F32 = 0,  // planar f32 (also interleaved mono): dwordx4 per channel
+    SF_P_I16 = 1,  // planar i16 (also interleaved mono), 4-byte aligned: dwordx2 per channel
+    SF_P_U16 = 2,
+    SF_I_I16 = 3,  // interleaved stereo i16: ONE dwordx4 holds both channels of 4 frames
+    SF_I_U16 = 4,
+    SF_I_F32 = 5,  // interleaved stereo f32: two dwordx4
+    SF_NONE = 7,   // not eligible for the compact fast path
+};
 struct VoiceRef {
-    const float* src_l;  // VB_SIMPLE: frame 0 of channel 0
-    uint32_t r_delta;    // VB_SIMPLE: channel-1 offset in floats (0 for a mono sample)
-    uint32_t flags_gset; // bits 0..7 VB_* flags, bits 8..15 gain-set index
+    const float* src_l;  // VB_SIMPLE: address of channel 0 of the block's first frame (typed by the source class)
+    uint32_t r_delta;    // VB_SIMPLE: channel-1 offset in source ELEMENTS (0 for a mono sample)
+    uint32_t flags_gset; // bits 0..7 VB_* flags, bits 8..15 gain-set index, bits 16..18 source class (SF_*)
 };
 static_assert(sizeof(VoiceRef) == 16, "VoiceRef layout");
 #define FW_GSETS 4  // distinct constant-gain sets a voice may use inside one call before falling back to VoiceBlk

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             nb_flags = ref_n.flags_gset & 0xffu;
             nb_src = ref_n.src_l + (ch ? ref_n.r_delta : 0u);  // r_delta = 0 for a mono sample (sampler.rs:546-551)
             if (nb_flags & VB_SIMPLE) {
-                const GainSet* gs = &fv.gsets[(size_t)voice * FW_GSETS + (ref_n.flags_gset >> 8)];
+                const GainSet* gs = &fv.gsets[(size_t)voice * FW_GSETS + ((ref_n.flags_gset >> 8) & 0xffu)];
 #pragma unroll
                 for (int j = 0; j < FW_MAX_STAGES; ++j) gs_n[j] = gs->g[j][ch];
             }

@@ -96,16 +96,46 @@ __device__ __forceinline__ bool smoother_is_constant(const Smoother& s, float ta
     return y0 == s.last && !(fabsf(s.input - y0) < s.eps);
 }
 
-// source pointers of a block whose frames are contiguous planar f32 (the fast path of the leaf kernel)
-__device__ __forceinline__ void blk_set_source(VoiceBlk& d, const SampleDesc& sd, int frames) {
+// Source class of a block that starts at frame `off0` of sample `sd` and is contiguous in it (no wrap, no tail):
+// which vector fetch the leaf kernel may use (SF_*), or SF_NONE.  16-bit planar data needs a 4-byte aligned start
+// in both channels; interleaved data of more than two channels and anything in a k_chain voice other than planar
+// f32 stay on the per-element path.
+__device__ __forceinline__ uint32_t simple_class(const SampleDesc& sd, uint64_t off0, bool fx) {
+    if (sd.frames >= 0xffffffffull) return SF_NONE;
+    const bool mono = sd.channels == 1;
+    switch (sd.format) {
+        case FMT_P_F32: return SF_P_F32;
+        case FMT_I_F32: return fx ? SF_NONE : (mono ? SF_P_F32 : (sd.channels == 2 ? SF_I_F32 : SF_NONE));
+        case FMT_P_I16:
+        case FMT_P_U16:
+            if (fx || (off0 & 1) || (!mono && (sd.frames & 1))) return SF_NONE;
+            return sd.format == FMT_P_I16 ? SF_P_I16 : SF_P_U16;
+        case FMT_I_I16:
+        case FMT_I_U16:
+            if (fx) return SF_NONE;
+            if (mono) return (off0 & 1) ? SF_NONE : (sd.format == FMT_I_I16 ? SF_P_I16 : SF_P_U16);
+            return sd.channels == 2 ? (sd.format == FMT_I_I16 ? SF_I_I16 : SF_I_U16) : SF_NONE;
+        default: return SF_NONE;
+    }
+}
+// format-only part of the test above (a voice whose sample can never be fetched compactly needs no gain-set slot)
+__device__ __forceinline__ bool simple_capable(const SampleDesc& sd, bool fx) {
+    return simple_class(sd, 0, fx) != SF_NONE;
+}
+
+// source of a block whose frames are contiguous in the sample: direct pointers for planar f32 (voice_eval / k_chain)
+// and the VB_SIMPLE verdict (the compact fast path of the leaf kernel)
+__device__ __forceinline__ void blk_set_source(VoiceBlk& d, const SampleDesc& sd, int frames, bool fx) {
     d.src_l = nullptr;
     d.src_r = nullptr;
-    const bool contiguous = !(d.flags & (VB_WRAP | VB_TAIL_ZERO | VB_SILENT)) && sd.format == FMT_P_F32;
+    const bool contiguous = !(d.flags & (VB_WRAP | VB_TAIL_ZERO | VB_SILENT));
     if (contiguous) {
-        d.src_l = (const float*)sd.data + d.off0;
-        d.src_r = (d.flags & VB_MONO) ? d.src_l : d.src_l + sd.frames;
+        if (sd.format == FMT_P_F32) {
+            d.src_l = (const float*)sd.data + d.off0;
+            d.src_r = (d.flags & VB_MONO) ? d.src_l : d.src_l + sd.frames;
+        }
         // VB_SIMPLE blocks carry no full descriptor, so they must never need the per-element path (ragged tail)
-        if ((d.flags >> VB_RAMP_SHIFT) == 0 && (frames & 3) == 0 && sd.frames < 0xffffffffull) d.flags |= VB_SIMPLE;
+        if ((d.flags >> VB_RAMP_SHIFT) == 0 && (frames & 3) == 0 && simple_class(sd, d.off0, fx) != SF_NONE) d.flags |= VB_SIMPLE;
     }
 }
 
@@ -135,11 +165,36 @@ struct TailJob {
 // `fx`: the voice has a biquad / delay (k_chain plan) — its source is needed even when the chain output is
 // silent, and every block that is not VB_SIMPLE carries a full descriptor.
 __device__ __forceinline__ void put_blk(const FusedView& fv, int vi, int kk, const VoiceBlk& d, uint32_t gset,
-                                        uint64_t sample_frames, bool fx) {
+                                        const SampleDesc& sd, bool fx) {
     VoiceRef ref;
     ref.src_l = d.src_l;
-    ref.r_delta = ((d.flags & VB_SIMPLE) && !(d.flags & (VB_MONO | VB_SRC_ZERO))) ? (uint32_t)sample_frames : 0u;
-    ref.flags_gset = (d.flags & 0xffu) | (gset << 8);
+    ref.r_delta = 0u;
+    uint32_t cls = SF_P_F32;
+    if ((d.flags & VB_SIMPLE) && !(d.flags & VB_SRC_ZERO)) {
+        cls = simple_class(sd, d.off0, fx);
+        const bool mono = d.flags & VB_MONO;
+        switch (cls) {
+            case SF_P_F32:
+                ref.src_l = (const float*)sd.data + d.off0;
+                ref.r_delta = mono ? 0u : (uint32_t)sd.frames;
+                break;
+            case SF_P_I16:
+            case SF_P_U16:
+                ref.src_l = (const float*)((const int16_t*)sd.data + d.off0);
+                ref.r_delta = mono ? 0u : (uint32_t)sd.frames;
+                break;
+            case SF_I_I16:
+            case SF_I_U16:
+                ref.src_l = (const float*)((const int16_t*)sd.data + 2 * d.off0);
+                ref.r_delta = 1u;
+                break;
+            default:  // SF_I_F32
+                ref.src_l = (const float*)sd.data + 2 * d.off0;
+                ref.r_delta = 1u;
+                break;
+        }
+    }
+    ref.flags_gset = (d.flags & 0xffu) | (gset << 8) | (cls << 16);
     fv.refs[(size_t)vi * fv.refs_stride + kk] = ref;  // [voice][block]: the tail lanes store 1 KiB contiguous
     const bool need_full = fx ? !(d.flags & VB_SIMPLE) : !(d.flags & (VB_SIMPLE | VB_SILENT));
     if (need_full) fv.blks[(size_t)kk * fv.n_voices + vi] = d;
@@ -165,7 +220,8 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
         t.g[j][1] = job.g.g[j][1];
     }
     const bool no_src = (job.flags & VB_SRC_ZERO) || (!fx && (job.flags & VB_SILENT));
-    const bool contiguous_f32 = !no_src && job.sample >= 0 && sd.format == FMT_P_F32;
+    const bool has_src = !no_src && job.sample >= 0;
+    const bool contiguous_f32 = has_src && sd.format == FMT_P_F32;
     const uint64_t n = (uint64_t)(K - k_first);
     if (job.mode == 1) {
         // all quantities fit 32 bits whenever the loop does (the usual case): avoid 64-bit division
@@ -201,10 +257,10 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
                 if (contiguous_f32) {
                     t.src_l = (const float*)sd.data + t.off0;
                     t.src_r = (t.flags & VB_MONO) ? t.src_l : t.src_l + sd.frames;
-                    if (simple_ok) t.flags |= VB_SIMPLE;
                 }
+                if (has_src && simple_ok && simple_class(sd, t.off0, fx) != SF_NONE) t.flags |= VB_SIMPLE;
             }
-            put_blk(fv, vi, k2, t, gset, sd.frames, fx);
+            put_blk(fv, vi, k2, t, gset, sd, fx);
             r += step;
             if (r >= L) r -= L;
         }
@@ -219,15 +275,15 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
             if (contiguous_f32) {
                 t.src_l = (const float*)sd.data + t.off0;
                 t.src_r = (t.flags & VB_MONO) ? t.src_l : t.src_l + sd.frames;
-                if (simple_ok) t.flags |= VB_SIMPLE;
             }
-            put_blk(fv, vi, k2, t, gset, sd.frames, fx);
+            if (has_src && simple_ok && simple_class(sd, t.off0, fx) != SF_NONE) t.flags |= VB_SIMPLE;
+            put_blk(fv, vi, k2, t, gset, sd, fx);
         }
         return job.playhead + n * fr;
     }
     // nothing moves (mode 0 <=> the sampler is frozen): with fx the block still runs (zeros in, constant gains)
     if (fx && simple_ok) t.flags |= VB_SIMPLE;
-    for (int k2 = k_first + lane; k2 < K; k2 += WAVE) put_blk(fv, vi, k2, t, fx ? gset : 0u, sd.frames, fx);
+    for (int k2 = k_first + lane; k2 < K; k2 += WAVE) put_blk(fv, vi, k2, t, fx ? gset : 0u, sd, fx);
     return job.playhead;
 }
 
@@ -347,8 +403,7 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
             if (ok) {
                 const bool no_src = (job.flags & VB_SRC_ZERO) || (!fx && (job.flags & VB_SILENT));
                 const bool simple_ok = no_src ? (fx && simple_frames)
-                                              : (job.sample >= 0 && sd.format == FMT_P_F32 && simple_frames &&
-                                                 sd.frames < 0xffffffffull);
+                                              : (job.sample >= 0 && simple_frames && simple_capable(sd, fx));
                 if (simple_ok && w0) my_gsets[0] = job.g;
                 uint64_t ph = steady_tail(fv, vi, lane, 0, K, job, sd, 0u, simple_ok, fx);
                 if (w0 && vc.mode != 0) fv.states[vd.sampler_state].playhead = ph;
@@ -495,13 +550,13 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                 }
             }
         }
-        if (!src_silent && (fx || !silent)) blk_set_source(d, sd, frames);
+        if (!src_silent && (fx || !silent)) blk_set_source(d, sd, frames, fx);
         else if (src_silent && fx && (d.flags >> VB_RAMP_SHIFT) == 0 && simple_frames) d.flags |= VB_SIMPLE;
         if (src_silent) d.flags |= VB_SRC_ZERO;
         if (silent) d.flags |= VB_SILENT;
         {
             uint32_t gs = pick_gset(d);
-            if (w0) put_blk(fv, vi, k, d, gs, sd.frames, fx);
+            if (w0) put_blk(fv, vi, k, d, gs, sd, fx);
         }
 
         // ---- steady from the next block on?
@@ -578,9 +633,8 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
         if (k + 1 < K) {
             uint32_t tail_gs = 0;
             bool simple_ok = false;
-            const bool tail_simple = fx ? (simple_frames && (upstream_silent || (sd.format == FMT_P_F32 && sd.frames < 0xffffffffull)))
-                                        : (!sil && !upstream_silent && sd.format == FMT_P_F32 && simple_frames &&
-                                           sd.frames < 0xffffffffull);
+            const bool tail_simple = fx ? (simple_frames && (upstream_silent || simple_capable(sd, true)))
+                                        : (!sil && !upstream_silent && simple_frames && simple_capable(sd, false));
             if (tail_simple) {
                 VoiceBlk probe;  // every non-wrapping tail block is VB_SIMPLE with the same gains: one gain set
                 probe.flags = VB_SIMPLE;

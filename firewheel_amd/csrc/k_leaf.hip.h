@@ -110,6 +110,103 @@ __device__ __forceinline__ void leaf_fast(const float* my_l, const float* my_r, 
     }
 }
 
+// ---- VB_SIMPLE source classes other than planar f32 (SF_*, fwgpu_types.h): raw vector fetch of 4 consecutive frames
+// of both channels, converted exactly as core/sample_resource.rs:338-345 does per element
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef const v4i __attribute__((address_space(1), aligned(4)))* gv4ip;
+typedef const v2i __attribute__((address_space(1), aligned(4)))* gv2ip;
+struct RawQuad {
+    v4i a, b;
+};
+__device__ __forceinline__ float cvt_i16(int half) { return (float)(int)(short)half * (1.0f / 32767.0f); }             // :338-340
+__device__ __forceinline__ float cvt_u16(int half) { return ((float)(unsigned)(half & 0xffff) * (2.0f / 65535.0f)) - 1.0f; }  // :343-345
+template <uint32_t CLS>
+__device__ __forceinline__ RawQuad raw_load(const float* base, uint32_t rdelta, int f0) {
+    RawQuad q;
+    q.a = q.b = (v4i){0, 0, 0, 0};
+    const uint64_t p = (uint64_t)base;
+    if (CLS == SF_P_I16 || CLS == SF_P_U16) {  // 4 x 16 bit = 8 bytes per channel
+        const v2i l = __builtin_nontemporal_load((gv2ip)(p + 2ull * (uint64_t)f0));
+        const v2i r = __builtin_nontemporal_load((gv2ip)(p + 2ull * ((uint64_t)rdelta + (uint64_t)f0)));
+        q.a[0] = l[0];
+        q.a[1] = l[1];
+        q.b[0] = r[0];
+        q.b[1] = r[1];
+    } else if (CLS == SF_I_I16 || CLS == SF_I_U16) {  // 4 frames x (L,R) x 16 bit = one 16-byte load
+        q.a = __builtin_nontemporal_load((gv4ip)(p + 4ull * (uint64_t)f0));
+    } else {  // SF_I_F32: 4 frames x (L,R) x f32 = two 16-byte loads
+        q.a = __builtin_nontemporal_load((gv4ip)(p + 8ull * (uint64_t)f0));
+        q.b = __builtin_nontemporal_load((gv4ip)(p + 8ull * (uint64_t)f0 + 16ull));
+    }
+    return q;
+}
+template <uint32_t CLS>
+__device__ __forceinline__ void raw_convert(const RawQuad& q, v4f& xl, v4f& xr) {
+    if (CLS == SF_P_I16) {
+        xl = (v4f){cvt_i16(q.a[0]), cvt_i16(q.a[0] >> 16), cvt_i16(q.a[1]), cvt_i16(q.a[1] >> 16)};
+        xr = (v4f){cvt_i16(q.b[0]), cvt_i16(q.b[0] >> 16), cvt_i16(q.b[1]), cvt_i16(q.b[1] >> 16)};
+    } else if (CLS == SF_P_U16) {
+        xl = (v4f){cvt_u16(q.a[0]), cvt_u16(q.a[0] >> 16), cvt_u16(q.a[1]), cvt_u16(q.a[1] >> 16)};
+        xr = (v4f){cvt_u16(q.b[0]), cvt_u16(q.b[0] >> 16), cvt_u16(q.b[1]), cvt_u16(q.b[1] >> 16)};
+    } else if (CLS == SF_I_I16) {
+        xl = (v4f){cvt_i16(q.a[0]), cvt_i16(q.a[1]), cvt_i16(q.a[2]), cvt_i16(q.a[3])};
+        xr = (v4f){cvt_i16(q.a[0] >> 16), cvt_i16(q.a[1] >> 16), cvt_i16(q.a[2] >> 16), cvt_i16(q.a[3] >> 16)};
+    } else if (CLS == SF_I_U16) {
+        xl = (v4f){cvt_u16(q.a[0]), cvt_u16(q.a[1]), cvt_u16(q.a[2]), cvt_u16(q.a[3])};
+        xr = (v4f){cvt_u16(q.a[0] >> 16), cvt_u16(q.a[1] >> 16), cvt_u16(q.a[2] >> 16), cvt_u16(q.a[3] >> 16)};
+    } else {  // SF_I_F32
+        xl = (v4f){__int_as_float(q.a[0]), __int_as_float(q.a[2]), __int_as_float(q.b[0]), __int_as_float(q.b[2])};
+        xr = (v4f){__int_as_float(q.a[1]), __int_as_float(q.a[3]), __int_as_float(q.b[1]), __int_as_float(q.b[3])};
+    }
+}
+// any class, one port (the mixed-leaf path)
+__device__ __forceinline__ void simple_fetch(uint32_t cls, const float* base, uint32_t rdelta, int f0, v4f& xl, v4f& xr) {
+    switch (cls) {
+        case SF_P_F32:
+            xl = gload4(base + f0);
+            xr = gload4(base + rdelta + f0);
+            break;
+        case SF_P_I16: raw_convert<SF_P_I16>(raw_load<SF_P_I16>(base, rdelta, f0), xl, xr); break;
+        case SF_P_U16: raw_convert<SF_P_U16>(raw_load<SF_P_U16>(base, rdelta, f0), xl, xr); break;
+        case SF_I_I16: raw_convert<SF_I_I16>(raw_load<SF_I_I16>(base, rdelta, f0), xl, xr); break;
+        case SF_I_U16: raw_convert<SF_I_U16>(raw_load<SF_I_U16>(base, rdelta, f0), xl, xr); break;
+        default: raw_convert<SF_I_F32>(raw_load<SF_I_F32>(base, rdelta, f0), xl, xr); break;
+    }
+}
+// every port VB_SIMPLE and of ONE class: LEAF_U ports' raw loads in flight together, converted afterwards
+template <uint32_t CLS>
+__device__ __forceinline__ void leaf_fast_cls(const float* my_l, uint32_t my_rd, const GainSet& my_g, int ng, int ports, int f0,
+                                              v4f& accl, v4f& accr) {
+    for (int p0 = 0; p0 < ports; p0 += LEAF_U) {
+        RawQuad q[LEAF_U];
+#pragma unroll
+        for (int u = 0; u < LEAF_U; ++u)
+            if (p0 + u < ports)
+                q[u] = raw_load<CLS>(readlane_ptr(my_l, p0 + u), (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p0 + u), f0);
+#pragma unroll
+        for (int u = 0; u < LEAF_U; ++u) {
+            if (p0 + u < ports) {
+                v4f a, b;
+                raw_convert<CLS>(q[u], a, b);
+#pragma unroll
+                for (int j = 0; j < FW_MAX_STAGES; ++j) {  // sampler.rs:530-533, volume.rs:123-126, pan: one rounding each
+                    if (j >= ng) break;
+                    a = a * readlane_f(my_g.g[j][0], p0 + u);
+                    b = b * readlane_f(my_g.g[j][1], p0 + u);
+                }
+                if (p0 + u == 0) {
+                    accl = a;
+                    accr = b;
+                } else {
+                    accl = accl + a;
+                    accr = accr + b;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K) {
 #if LEAF_MAP_BLOCKS
     // the waves of a workgroup take CONSECUTIVE blocks of one leaf: a steady voice's source is contiguous across
@@ -141,15 +238,21 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
     GainSet my_g;
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES; ++j) my_g.g[j][0] = my_g.g[j][1] = 1.0f;
-    if (my_flags & VB_SIMPLE) my_g = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + (ref.flags_gset >> 8)];
+    if (my_flags & VB_SIMPLE) my_g = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + ((ref.flags_gset >> 8) & 0xffu)];
     const float* my_l = ref.src_l;
-    const float* my_r = ref.src_l + ref.r_delta;
+    const uint32_t my_rd = ref.r_delta;
+    const uint32_t my_cls = (ref.flags_gset >> 16) & 7u;
+    const float* my_r = ref.src_l + ref.r_delta;  // planar f32 class only
     const uint64_t lanes_in = mask_all_silent_bits(ld.ports);
     const uint64_t silent_ports = __ballot((my_flags & VB_SILENT) != 0) & lanes_in;
     const uint64_t simple_ports = __ballot((my_flags & VB_SIMPLE) != 0) & lanes_in;
     const bool all_silent = silent_ports == lanes_in;
     const bool masked = !(ld.ports == 2 || ld.ports == 3 || ld.ports == 4);  // sum.rs:67-133 (Q13)
-    const bool fast = simple_ports == lanes_in && (frames & 3) == 0;
+    const bool all_simple = simple_ports == lanes_in && (frames & 3) == 0;
+    const uint32_t cls0 = (uint32_t)__builtin_amdgcn_readlane((int)my_cls, 0);  // ports >= 1
+    const bool one_class = (__ballot(my_cls == cls0) & lanes_in) == lanes_in;
+    const bool fast = all_simple && one_class && cls0 == SF_P_F32;
+    const bool fast_cls = all_simple && one_class && cls0 != SF_P_F32;
 
     for (int f0 = lane * 4; f0 < frames; f0 += 256) {
         v4f accl = splat(0.f), accr = splat(0.f);
@@ -160,14 +263,23 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
                 case 3: leaf_fast<3>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
                 default: leaf_fast<4>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
             }
+        } else if (fast_cls) {
+            const int ng = fv.n_gain_stages;
+            switch (cls0) {
+                case SF_P_I16: leaf_fast_cls<SF_P_I16>(my_l, my_rd, my_g, ng, ld.ports, f0, accl, accr); break;
+                case SF_P_U16: leaf_fast_cls<SF_P_U16>(my_l, my_rd, my_g, ng, ld.ports, f0, accl, accr); break;
+                case SF_I_I16: leaf_fast_cls<SF_I_I16>(my_l, my_rd, my_g, ng, ld.ports, f0, accl, accr); break;
+                case SF_I_U16: leaf_fast_cls<SF_I_U16>(my_l, my_rd, my_g, ng, ld.ports, f0, accl, accr); break;
+                default: leaf_fast_cls<SF_I_F32>(my_l, my_rd, my_g, ng, ld.ports, f0, accl, accr); break;
+            }
         } else if (!all_silent) {
             for (int p = 0; p < ld.ports; ++p) {
                 const bool psil = (silent_ports >> p) & 1ull;
                 v4f xl = splat(0.f), xr = splat(0.f);  // a silent chain's buffers hold cleared zeros
                 if (!psil) {
                     if ((simple_ports >> p) & 1ull) {  // VB_SIMPLE implies frames % 4 == 0
-                        xl = gload4(readlane_ptr(my_l, p) + f0);
-                        xr = gload4(readlane_ptr(my_r, p) + f0);
+                        simple_fetch((uint32_t)__builtin_amdgcn_readlane((int)my_cls, p), readlane_ptr(my_l, p),
+                                     (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p), f0, xl, xr);
 #pragma unroll
                         for (int j = 0; j < FW_MAX_STAGES; ++j) {
                             if (j >= fv.n_gain_stages) break;

@@ -13,7 +13,7 @@ def voice_source(seed, frames, channels=2):
 
 
 def build_voice_bank(e, n_voices, radix=32, src_frames=4096, with_pan=True, with_volume=True, seed=0, fmt=PLANAR_F32,
-                     mono_every=0):
+                     mono_every=0, fmt_cycle=None):
     """config-2 shape: V x (sampler -> volume -> pan) -> radix-`radix` SumNode tree -> graph_out."""
     rng = np.random.default_rng(1234 + seed)
     voices = []
@@ -50,15 +50,16 @@ def build_voice_bank(e, n_voices, radix=32, src_frames=4096, with_pan=True, with
     for v, vc in enumerate(voices):
         ch = 1 if (mono_every and v % mono_every == 0) else 2
         data = voice_source(seed * 100000 + v, src_frames, ch)
-        if fmt in (PLANAR_I16, INTERLEAVED_I16):
+        vfmt = fmt_cycle[v % len(fmt_cycle)] if fmt_cycle else fmt   # per-voice formats: mixed leaves
+        if vfmt in (PLANAR_I16, INTERLEAVED_I16):
             raw = np.round(data * 32767).astype(np.int16)
-        elif fmt in (PLANAR_U16, INTERLEAVED_U16):
+        elif vfmt in (PLANAR_U16, INTERLEAVED_U16):
             raw = np.round((data + 1) * 32767.5).astype(np.uint16)
         else:
             raw = data
-        if fmt <= INTERLEAVED_F32:
+        if vfmt <= INTERLEAVED_F32:
             raw = raw.T.copy()
-        vc["sample"] = e.new_sample(fmt, ch, raw)
+        vc["sample"] = e.new_sample(vfmt, ch, raw)
         vc["frames"] = src_frames
         e.sampler_set_sample(vc["sampler"], vc["sample"])
     return voices
@@ -73,11 +74,11 @@ def scenario_voice_bank_steady(e, n_voices=96, blocks=6, radix=32, **kw):
     return e.process_blocks(blocks)
 
 
-def scenario_voice_bank_events(e, n_voices=70, radix=32, mbf=None, src_frames=1000):
+def scenario_voice_bank_events(e, n_voices=70, radix=32, mbf=None, src_frames=1000, fmt=PLANAR_F32):
     """everything at once: loop wraps inside blocks (src_frames not a multiple of the block), one-shot ends,
     paused voices (silence masks), gain / pan changes (smoother ramps that settle, and ones that stall),
     mute -> all-silent chains, messages tagged at later blocks of a multi-block call."""
-    voices = build_voice_bank(e, n_voices, radix=radix, src_frames=src_frames, mono_every=7)
+    voices = build_voice_bank(e, n_voices, radix=radix, src_frames=src_frames, mono_every=7, fmt=fmt)
     outs = []
     for v, vc in enumerate(voices):
         if v % 5 != 3:

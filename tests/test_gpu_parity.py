@@ -186,6 +186,18 @@ def run_case(name, **gpu_kw):
         "steady_96x32": lambda e: scenarios.scenario_voice_bank_steady(e, 96, 6),
         "steady_40x4_i16": lambda e: scenarios.scenario_voice_bank_steady(e, 40, 5, radix=4, fmt=fwapi.INTERLEAVED_I16),
         "steady_9x3_u16": lambda e: scenarios.scenario_voice_bank_steady(e, 9, 4, radix=3, fmt=fwapi.PLANAR_U16),
+        "steady_fmt_p_i16_mono3": lambda e: scenarios.scenario_voice_bank_steady(e, 20, 9, radix=8, fmt=fwapi.PLANAR_I16,
+                                                                                 mono_every=3, src_frames=1000),
+        "steady_fmt_i_f32": lambda e: scenarios.scenario_voice_bank_steady(e, 11, 7, radix=4, fmt=fwapi.INTERLEAVED_F32,
+                                                                           mono_every=4, src_frames=700),
+        "steady_fmt_i_u16": lambda e: scenarios.scenario_voice_bank_steady(e, 9, 7, radix=16, fmt=fwapi.INTERLEAVED_U16,
+                                                                           mono_every=2, src_frames=600),
+        "steady_fmt_p_i16_oddlen": lambda e: scenarios.scenario_voice_bank_steady(e, 7, 20, radix=8, fmt=fwapi.PLANAR_I16,
+                                                                                  src_frames=333),
+        "steady_fmt_mixed_leaf": lambda e: scenarios.scenario_voice_bank_steady(e, 26, 8, radix=32, fmt_cycle=list(range(6)),
+                                                                                mono_every=5, src_frames=900),
+        "events_33_i16": lambda e: scenarios.scenario_voice_bank_events(e, 33, radix=8, src_frames=777,
+                                                                        fmt=fwapi.INTERLEAVED_I16),
         "events_70": lambda e: scenarios.scenario_voice_bank_events(e, 70),
         "events_33_r2": lambda e: scenarios.scenario_voice_bank_events(e, 33, radix=2, src_frames=777),
         "mixed_generic": scenarios.scenario_mixed_generic,
@@ -210,7 +222,8 @@ def run_case(name, **gpu_kw):
         "cfg4_reverb_2irs_mono": lambda e: scenarios.scenario_cfg4_reverb(e, n_voices=5, taps=700, shared_ir=False,
                                                                           ir_channels=1),
     }[name]
-    mbf = {"steady_96x32": 256, "steady_40x4_i16": 64, "steady_9x3_u16": 128, "events_70": 256, "events_33_r2": 128,
+    mbf = {"steady_fmt_p_i16_mono3": 128, "steady_fmt_i_f32": 64, "steady_fmt_i_u16": 64, "steady_fmt_p_i16_oddlen": 64,
+           "steady_fmt_mixed_leaf": 128, "events_33_i16": 128, "steady_96x32": 256, "steady_40x4_i16": 64, "steady_9x3_u16": 128, "events_70": 256, "events_33_r2": 128,
            "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64, "cfg3_chain": 128, "cfg4_reverb": 128,
            "cfg4_reverb_2irs_mono": 64, "chain_steady_40": 256, "chain_steady_bq_only_i16": 64,
            "chain_steady_dl_only_pan": 128, "chain_events_37": 128, "chain_events_19_r2_pan": 64,
@@ -224,7 +237,8 @@ def run_case(name, **gpu_kw):
     return out_o, out_g, g
 
 
-VOICE_CASES = ["steady_96x32", "steady_40x4_i16", "steady_9x3_u16", "events_70", "events_33_r2"]
+VOICE_CASES = ["steady_96x32", "steady_40x4_i16", "steady_9x3_u16", "events_70", "events_33_r2", "steady_fmt_p_i16_mono3",
+               "steady_fmt_i_f32", "steady_fmt_i_u16", "steady_fmt_p_i16_oddlen", "steady_fmt_mixed_leaf", "events_33_i16"]
 
 
 @pytest.mark.parametrize("name", VOICE_CASES)

@@ -29,6 +29,19 @@ CASES = {
                                                                      fmt=fwapi.INTERLEAVED_I16),
     "steady_9x3_u16": lambda: scenarios.scenario_voice_bank_steady(oracle(max_block_frames=128), 9, 4, radix=3,
                                                                     fmt=fwapi.PLANAR_U16),
+    # every sample format through the compact fast path of the leaf kernel (and its fallbacks)
+    "steady_fmt_p_i16_mono3": lambda: scenarios.scenario_voice_bank_steady(oracle(max_block_frames=128), 20, 9, radix=8,
+                                                                            fmt=fwapi.PLANAR_I16, mono_every=3, src_frames=1000),
+    "steady_fmt_i_f32": lambda: scenarios.scenario_voice_bank_steady(oracle(max_block_frames=64), 11, 7, radix=4,
+                                                                      fmt=fwapi.INTERLEAVED_F32, mono_every=4, src_frames=700),
+    "steady_fmt_i_u16": lambda: scenarios.scenario_voice_bank_steady(oracle(max_block_frames=64), 9, 7, radix=16,
+                                                                      fmt=fwapi.INTERLEAVED_U16, mono_every=2, src_frames=600),
+    "steady_fmt_p_i16_oddlen": lambda: scenarios.scenario_voice_bank_steady(oracle(max_block_frames=64), 7, 20, radix=8,
+                                                                             fmt=fwapi.PLANAR_I16, src_frames=333),
+    "steady_fmt_mixed_leaf": lambda: scenarios.scenario_voice_bank_steady(oracle(max_block_frames=128), 26, 8, radix=32,
+                                                                           fmt_cycle=list(range(6)), mono_every=5, src_frames=900),
+    "events_33_i16": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=128), 33, radix=8, src_frames=777,
+                                                                   fmt=fwapi.INTERLEAVED_I16),
     "events_70": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=256), 70),
     "events_33_r2": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=128), 33, radix=2, src_frames=777),
     "mixed_generic": lambda: scenarios.scenario_mixed_generic(oracle(max_block_frames=256)),

@@ -620,3 +620,35 @@ def test_graph_edit_keeps_node_state_across_recompile():
     rg = run(g)
     assert g.cx.plan_kind() == 1
     assert_bits_equal(ro, rg, "across graph edits")
+
+
+# ------------------------------------------------------------------ error behaviour of the SPEC nodes (activate() -> Err)
+def test_spec_node_activation_and_argument_errors():
+    from fwapi import FIR, RESAMPLER, SPATIAL, BIQUAD, DELAY
+
+    g = GpuEngine(max_block_frames=64)
+    smp = g.new_sample(PLANAR_F32, 1, scenarios.voice_source(1, 100, 1))
+    # constructor-time argument errors: a sample id that does not exist
+    for kind, n_in, n_out in ((FIR, 2, 2), (RESAMPLER, 0, 2)):
+        with pytest.raises(Exception):
+            g.add_node(kind, n_in, n_out, [99.0])
+    # activation errors surface from update() as CompileGraphError::NodeActivationFailed, and the graph stays usable
+    for kind, n_in, n_out, params in ((SPATIAL, 3, 2, [0, 0, -1]), (SPATIAL, 1, 1, [0, 0, -1]), (RESAMPLER, 1, 2, [float(smp), 1.0]),
+                                      (BIQUAD, 2, 3, [0, 1000, 0.7]), (DELAY, 0, 0, [0.1])):
+        bad = g.add_node(kind, n_in, n_out, params)
+        with pytest.raises(fwapi.CompileGraphError) as ei:
+            g.update()
+        assert ei.value.name == "NodeActivationFailed"
+        g.remove_node(bad)
+    s = g.sampler(100.0)
+    g.connect_stereo(s, g.graph_out_node)
+    g.update()
+    g.sampler_set_sample(s, smp)
+    g.sampler_play(s)
+    out = g.process_blocks(2)
+    assert np.any(out != 0)
+    # runtime parameter ids are checked
+    rs = g.resampler(smp, 1.0, n_out=1)
+    g.update()
+    with pytest.raises(Exception):
+        g.set_param(rs, 7, 1.0)

@@ -652,3 +652,23 @@ def test_spec_node_activation_and_argument_errors():
     g.update()
     with pytest.raises(Exception):
         g.set_param(rs, 7, 1.0)
+
+
+@pytest.mark.parametrize("mbf", [100, 96, 1, 36])
+def test_odd_block_sizes_bit_exact(mbf):
+    # block sizes that are not a multiple of 4 / 64: the voice-bank plan stays on its per-element path, the chain
+    # shape falls back to the generic executor; results must not change
+    frames = max(300, 7 * mbf)
+    o = oracle(max_block_frames=mbf)
+    g = GpuEngine(max_block_frames=mbf, max_batch=5)
+    a = scenarios.scenario_voice_bank_steady(o, 9, 6, radix=4, src_frames=frames, mono_every=4)
+    b = scenarios.scenario_voice_bank_steady(g, 9, 6, radix=4, src_frames=frames, mono_every=4)
+    assert g.cx.plan_kind() == 1
+    assert_bits_equal(a, b, "voice bank, block %d" % mbf)
+    o = oracle(max_block_frames=mbf)
+    g = GpuEngine(max_block_frames=mbf, max_batch=5)
+    kw = dict(radix=4, src_frames=frames, first_delay_frames=64, min_delay_frames=64, max_delay_frames=200)
+    a = scenarios.scenario_chain_steady(o, 6, 6, **kw)
+    b = scenarios.scenario_chain_steady(g, 6, 6, **kw)
+    assert g.cx.plan_kind() == 0        # not a multiple of 64: generic executor
+    assert_bits_equal(a, b, "chain shape, block %d" % mbf)

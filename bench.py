@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--taps", type=int, default=65536)
     ap.add_argument("--source-format", choices=["f32", "i16"], default="f32",
                     help="cfg2/cfg5 only: planar f32 sources (the headline) or interleaved stereo i16 (4 B per voice-sample)")
+    ap.add_argument("--host-buffers", action="store_true",
+                    help="time fwgpu_process_interleaved on HOST buffers instead (PCIe-inclusive; DESIGN.md §7 note, "
+                         "never the headline)")
     ap.add_argument("--bus-reduce", choices=["allreduce", "ordered"], default="allreduce",
                     help="N>1: RCCL all-reduce (named path) or all-gather + rank-ordered sum (bit-exact)")
     args = ap.parse_args()
@@ -295,12 +298,23 @@ def main():
     outs = [torch.empty(K * B * 2, dtype=torch.float32, device="cuda") for _ in range(2)]
     reducer = shard.BusReducer(dist, outs, args.bus_reduce) if dist is not None else None
     step_no = [0]
+    host_out = None
+    if args.host_buffers:
+        import numpy as np
+
+        host_out = np.empty(K * B * 2, dtype=np.float32)
 
     def step():
         b = step_no[0] % 2
         step_no[0] += 1
         if reducer is not None:
             reducer.wait(b)  # the collective that last used this buffer (two steps ago)
+        if args.host_buffers:  # the literal process_interleaved boundary: pageable host output, synchronous
+            import ctypes as C
+
+            rc = cx.L.fwgpu_process_interleaved(cx.c, None, host_out.ctypes.data_as(C.POINTER(C.c_float)), 0, 2, K * B, 0.0, 0)
+            assert rc == 0, rc
+            return
         cx.process_blocks_device(K, outs[b].data_ptr(), 2)
         if reducer is not None:  # the mix bus: one collective per step over K x 2 x block f32
             reducer.submit(b)
@@ -386,7 +400,7 @@ def main():
             "cfg5": "cfg5 shard: %d stereo voices/GPU, sampler->gain->pan->radix-%d sum tree" % (V, args.radix),
         }[wl]
         line = {
-            "metric": "stereo voice-samples/sec @ block=256, 48kHz",
+            "metric": "stereo voice-samples/sec @ block=256, 48kHz; % HBM roofline; 1/2/4/8 GPU",
             "value": total / dt,
             "unit": "voice-samples/s",
             "n_gpus": world,
@@ -397,7 +411,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not args.host_buffers else "synthetic; output delivered to HOST buffers (PCIe-inclusive)",
             "config": {
                 "workload": "%s, block=%d @48kHz, %s sources in HBM (%d frames/voice, looping)"
                             % (desc, B, "planar f32" if sfmt == "f32" else "interleaved stereo i16", F),

@@ -672,3 +672,50 @@ def test_odd_block_sizes_bit_exact(mbf):
     b = scenarios.scenario_chain_steady(g, 6, 6, **kw)
     assert g.cx.plan_kind() == 0        # not a multiple of 64: generic executor
     assert_bits_equal(a, b, "chain shape, block %d" % mbf)
+
+
+def test_chain_plan_ring_hazard_stress():
+    """k_chain keeps prefetched ring loads in flight across workgroup barriers and relies on one CU's L1 ordering its
+    waves' accesses: the risky delays are the shortest ones (a slot is re-read one or two tiles after it was
+    stored).  Many voices (HBM busy), many blocks, delays pinned to 64, 65, 127, 128, 129, 255, 256, 257, 383, 384:
+    every sample of the whole run must equal the oracle's."""
+    delays = [64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 512, 1000]
+
+    def run(e, n_voices, blocks, mbf):
+        rng = np.random.default_rng(99)
+        ends, samplers = [], []
+        for v in range(n_voices):
+            s = e.sampler(100.0)
+            bq = e.biquad(0, float(rng.uniform(300, 6000)), 0.9)
+            dl = e.delay(delays[v % len(delays)] / float(e.sample_rate), feedback=0.6, mix=0.5)
+            vol = e.volume(float(rng.uniform(30, 100)))
+            e.connect_stereo(s, bq)
+            e.connect_stereo(bq, dl)
+            e.connect_stereo(dl, vol)
+            samplers.append(s)
+            ends.append(vol)
+        level = ends
+        while len(level) > 1:
+            nxt = []
+            for i in range(0, len(level), 32):
+                grp = level[i:i + 32]
+                m = e.sum(len(grp))
+                for p, n in enumerate(grp):
+                    e.connect_stereo(n, m, 2 * p)
+                nxt.append(m)
+            level = nxt
+        e.connect_stereo(level[0], e.graph_out_node)
+        e.update()
+        for v, s in enumerate(samplers):
+            e.sampler_set_sample(s, e.new_sample(PLANAR_F32, 2, scenarios.voice_source(3000 + v, 4096)))
+            e.sampler_set_loop_range(s, fwapi.LOOP_FULL)
+            e.sampler_play(s)
+        return np.concatenate([e.process_blocks(blocks // 2), e.process_blocks(blocks - blocks // 2)])
+
+    for mbf, n_voices, blocks in ((256, 1024, 48), (128, 384, 80), (64, 96, 120)):
+        o = oracle(max_block_frames=mbf)
+        g = GpuEngine(max_block_frames=mbf, max_batch=32)
+        a = run(o, n_voices, blocks, mbf)
+        b = run(g, n_voices, blocks, mbf)
+        assert g.cx.plan_kind() == 2
+        assert_bits_equal(a, b, "ring hazard stress, block %d" % mbf)

@@ -662,9 +662,20 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
             c->ext_cap = cap;
         }
         c->ext_used = ext_need;
-        for (auto& ei : ext_inits)
-            HIPC(c, hipMemcpy(c->d_ext.as<float>() + ei.first, ei.second.data(), ei.second.size() * sizeof(float),
-                              hipMemcpyHostToDevice));
+        if (!ext_inits.empty()) {  // one upload + one scatter launch, however many nodes were activated
+            std::vector<ExtInitHost> items(ext_inits.size());
+            for (size_t i = 0; i < ext_inits.size(); ++i) {
+                items[i].off = (uint32_t)ext_inits[i].first;
+                items[i].n = (uint32_t)std::min<size_t>(ext_inits[i].second.size(), 6);
+                for (uint32_t j = 0; j < 6; ++j) items[i].v[j] = j < items[i].n ? ext_inits[i].second[j] : 0.f;
+            }
+            DevBuf tmp;
+            int rc2 = upload(c, tmp, items.data(), items.size() * sizeof(ExtInitHost));
+            if (rc2) return rc2;
+            LCHK(c, launch_scatter_ext(c->stream, c->d_ext.as<float>(), tmp.p, (int)items.size()));
+            HIPC(c, hipStreamSynchronize(c->stream));
+            tmp.release();
+        }
         if (!ir_requests.empty()) {
             int rc = upload_sample_table(c);
             if (rc) return rc;

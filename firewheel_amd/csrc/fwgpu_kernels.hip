@@ -84,6 +84,11 @@ int launch_single_node(hipStream_t s, const DevView& v, int node_idx) {
     hipLaunchKernelGGL(k_single_node, dim3(1), dim3(WAVE), 0, s, v, node_idx);
     return (int)hipGetLastError();
 }
+int launch_scatter_ext(hipStream_t s, float* ext, const void* d_items, int n) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_scatter_ext, dim3((n + 63) / 64), dim3(64), 0, s, ext, (const ExtInitHost*)d_items, n);
+    return (int)hipGetLastError();
+}
 int launch_scatter_states(hipStream_t s, NodeState* states, const void* d_inits, int n) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_scatter_states, dim3((n + 63) / 64), dim3(64), 0, s, states, (const uint8_t*)d_inits, n);

@@ -84,6 +84,14 @@ int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K);
 // frames % (64*nq) == 0 and every delay line >= 64*nq frames
 int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0, int nq);
 
+// initial floats of a node's ext-pool slice (biquad coefficients), consumed by k_scatter_ext
+struct ExtInitHost {
+    uint32_t off;  // float offset into the ext pool
+    uint32_t n;    // floats to write (<= 6)
+    float v[6];
+};
+int launch_scatter_ext(hipStream_t s, float* ext, const void* d_items, int n);
+
 // host-side mirror of the StateInit record consumed by k_scatter_states
 struct StateInitHost {
     int index;

@@ -508,6 +508,12 @@ struct StateInit {
     int pad;
     NodeState st;
 };
+__global__ void k_scatter_ext(float* ext, const ExtInitHost* __restrict__ items, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ExtInitHost it = items[i];
+    for (uint32_t j = 0; j < it.n; ++j) ext[it.off + j] = it.v[j];
+}
 __global__ void k_scatter_states(NodeState* states, const uint8_t* __restrict__ inits, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

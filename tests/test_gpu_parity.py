@@ -719,3 +719,37 @@ def test_chain_plan_ring_hazard_stress():
         b = run(g, n_voices, blocks, mbf)
         assert g.cx.plan_kind() == 2
         assert_bits_equal(a, b, "ring hazard stress, block %d" % mbf)
+
+
+def _realtime_callbacks(e, chain, n_voices, calls):
+    """one callback per call, the way cpal drives it (cpal/lib.rs:378-449): steady callbacks, then a burst of
+    messages, then steady callbacks again."""
+    build = scenarios.build_chain_bank if chain else scenarios.build_voice_bank
+    voices = build(e, n_voices, radix=8, src_frames=1100)
+    for vc in voices:
+        e.sampler_set_loop_range(vc["sampler"], fwapi.LOOP_FULL)
+        e.sampler_play(vc["sampler"])
+    out = []
+    for i in range(calls):
+        if i == calls // 2:
+            for v, vc in enumerate(voices):
+                if v % 3 == 0:
+                    e.set_param(vc["volume"], 0, 33.0)
+                if v % 5 == 1:
+                    e.sampler_pause(vc["sampler"])
+        out.append(e.process_blocks(2 if i % 4 == 3 else 1))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("chain", [False, True])
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_realtime_callbacks_pinned_io_and_graph_replay_bit_exact(chain, graph, monkeypatch):
+    # small calls take the realtime edge: pinned device-mapped I/O blocks, and (graph=1) the steady launch sequence
+    # replayed from a hipGraph; message bursts drop back to plain launches and the graph is picked up again afterwards
+    monkeypatch.setenv("FWGPU_RT_GRAPH", graph)
+    o = oracle(max_block_frames=128)
+    g = GpuEngine(max_block_frames=128)
+    out_o = _realtime_callbacks(o, chain, 21, 14)
+    out_g = _realtime_callbacks(g, chain, 21, 14)
+    assert g.cx.plan_kind() == (2 if chain else 1)
+    assert_bits_equal(out_o, out_g, "realtime callbacks chain=%s graph=%s" % (chain, graph))

@@ -31,17 +31,22 @@ def reduce_bus_allreduce(bus, dist, group=None):
     return bus
 
 
+def ordered_sum(parts, out):
+    """the R-port SumNode over the partial buses, in port (= rank) order, into `out` (may be parts[0])"""
+    if out is not parts[0]:
+        out.copy_(parts[0])         # sum.rs:117 out = in0
+    for p in parts[1:]:             # sum.rs:119-131 out += in_p, port order
+        out += p
+    return out
+
+
 def reduce_bus_ordered(bus, dist, group=None):
     import torch
 
     world = dist.get_world_size(group)
     parts = [torch.empty_like(bus) for _ in range(world)]
     dist.all_gather(parts, bus, group=group)
-    acc = parts[0].clone()          # sum.rs:117 out = in0
-    for p in parts[1:]:             # sum.rs:119-131 out += in_p, port order
-        acc += p
-    bus.copy_(acc)
-    return bus
+    return ordered_sum(parts, bus)
 
 
 class BusReducer(object):
@@ -74,10 +79,7 @@ class BusReducer(object):
         w.wait()  # on a GPU: the current stream waits for the collective, the host does not block
         self.works[i] = None
         if self.mode == "ordered":
-            acc = self.bufs[i]
-            acc.copy_(self.parts[i][0])          # sum.rs:117 out = in0
-            for p in self.parts[i][1:]:           # sum.rs:119-131 out += in_p, port (= rank) order
-                acc += p
+            ordered_sum(self.parts[i], self.bufs[i])
         return self.bufs[i]
 
     def wait_all(self):

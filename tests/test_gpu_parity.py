@@ -753,3 +753,35 @@ def test_realtime_callbacks_pinned_io_and_graph_replay_bit_exact(chain, graph, m
     out_g = _realtime_callbacks(g, chain, 21, 14)
     assert g.cx.plan_kind() == (2 if chain else 1)
     assert_bits_equal(out_o, out_g, "realtime callbacks chain=%s graph=%s" % (chain, graph))
+
+
+def test_virtual_shards_on_one_device_ordered_bus_equals_whole_graph():
+    # SURVEY 8(e) "measurability": G shards as G contexts (own streams) on the one visible device; the rank-ordered
+    # sum of their partial buses is the reference's G-port SumNode, bit for bit (whole graph run by the oracle)
+    import torch
+
+    import test_multirank_gloo as mr
+    from firewheel_amd import shard
+
+    G = 4
+    want = mr.reference_whole_graph(G)
+    parts = []
+    engines = []
+    for r in range(G):
+        lo, hi = shard.voice_range(r, G, mr.TOTAL_VOICES)
+        e = GpuEngine(max_block_frames=mr.BLOCK)
+        root, voices = mr.build_shard(e, lo, hi)
+        e.connect_stereo(root, e.graph_out_node)
+        e.update()
+        mr.start_voices(e, voices)
+        assert e.cx.plan_kind() == 1
+        buf = torch.empty(mr.BLOCKS * mr.BLOCK * 2, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        e.cx.process_blocks_device(mr.BLOCKS, buf.data_ptr(), 2)
+        parts.append(buf)
+        engines.append(e)
+    for e in engines:
+        e.cx.synchronize()
+    bus = shard.ordered_sum(parts, torch.empty_like(parts[0]))
+    torch.cuda.synchronize()
+    assert_bits_equal(want, bus.cpu().numpy(), "virtual shards, ordered bus")

@@ -110,6 +110,7 @@ struct fwgpu_ctx {
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
     std::vector<int> up_level_off, up_level_cnt;
     int up_root_node = -1;  // index (in the upper-tree node table) of the root SumNode when it is alone on the last level
+    RootArgs root_args;     // that node's port table, handed to k_root_out in its kernel arguments
 
     // FIR banks (generic executor): rows grouped by (level, impulse-response channel)
     struct FirGroup {  // one GEMM launch: every FIR row of a level with the same tap count
@@ -884,6 +885,18 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
             uflat.insert(uflat.end(), l.begin(), l.end());
         }
         c->up_root_node = (!fb.up_levels.empty() && fb.up_levels.back().size() == 1) ? fb.up_levels.back()[0] : -1;
+        if (c->up_root_node >= 0) {
+            const NodeDesc& rn = fb.up_nodes[c->up_root_node];
+            if (rn.n_out == 2 && rn.n_in >= 2 && rn.n_in <= 64 && rn.n_in % 2 == 0) {
+                memset(&c->root_args, 0, sizeof(c->root_args));
+                c->root_args.n_in = rn.n_in;
+                c->root_args.ports = rn.n_in / 2;
+                for (int i = 0; i < rn.n_in; ++i) c->root_args.in_buf[i] = fb.up_in[rn.in_off + i];
+                c->root_args.in_tab = c->d_up_in.as<int>() + rn.in_off;
+            } else {
+                c->up_root_node = -1;
+            }
+        }
         if (uflat.empty()) uflat.push_back(0);
         if ((rc = upload(c, c->d_up_level_nodes, uflat.data(), uflat.size() * sizeof(int)))) return rc;
         if ((rc = upload(c, c->d_root_bufs, fb.root_buf, sizeof(fb.root_buf)))) return rc;
@@ -1092,7 +1105,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         for (size_t l = 0; l < n_levels; ++l)
             LCHK(c, launch_bus_sum(c->stream, v, c->d_up_level_nodes.as<int>() + c->up_level_off[l], c->up_level_cnt[l], K, 2));
         if (fuse_root) {
-            LCHK(c, launch_root_out(c->stream, v, c->up_root_node, d_out, K));
+            LCHK(c, launch_root_out(c->stream, v, c->root_args, d_out, K));
             timer_end(c, e1);
             return 0;
         }

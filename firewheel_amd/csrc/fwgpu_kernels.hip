@@ -54,9 +54,9 @@ int launch_bus_sum(hipStream_t s, const DevView& v, const int* d_level_nodes, in
     hipLaunchKernelGGL(k_bus_sum, grid, dim3(256), 0, s, v, d_level_nodes);
     return (int)hipGetLastError();
 }
-int launch_root_out(hipStream_t s, const DevView& v, int root_node, float* d_out, int K) {
+int launch_root_out(hipStream_t s, const DevView& v, const RootArgs& root, float* d_out, int K) {
     if (v.frames <= 0 || K <= 0) return 0;
-    hipLaunchKernelGGL(k_root_out, dim3((v.frames + 255) / 256, K), dim3(256), 0, s, v, root_node, d_out);
+    hipLaunchKernelGGL(k_root_out, dim3((v.frames + 255) / 256, K), dim3(256), 0, s, v, root, d_out);
     return (int)hipGetLastError();
 }
 int launch_ir_convert(hipStream_t s, const SampleDesc* samples, int sample, int ch, float* dst, uint32_t T) {
@@ -132,12 +132,15 @@ int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0,
 }
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
     if (fv.n_leaves <= 0) return 0;
+    // waves per block: long blocks are cut into 256-frame pieces so that every wave is one short streaming pass
+    const int wpk = (fv.frames % (256 * LEAF_WPB) == 0) ? LEAF_WPB : (fv.frames % 512 == 0 && LEAF_WPB % 2 == 0) ? 2 : 1;
 #if LEAF_MAP_BLOCKS
-    dim3 grid(fv.n_leaves, (K + LEAF_WPB - 1) / LEAF_WPB);
+    const int bpw = LEAF_WPB / wpk;  // blocks per workgroup
+    dim3 grid(fv.n_leaves, (K + bpw - 1) / bpw);
 #else
     dim3 grid((fv.n_leaves + LEAF_WPB - 1) / LEAF_WPB, K);
 #endif
-    hipLaunchKernelGGL(k_leaf_sum, grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K);
+    hipLaunchKernelGGL(k_leaf_sum, grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
     return (int)hipGetLastError();
 }
 

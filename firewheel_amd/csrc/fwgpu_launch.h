@@ -63,7 +63,7 @@ struct FusedView {
 int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0);
 int launch_bus_sum(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, int n_out);
 // the fused plans' root SumNode + read_graph_outputs + interleave_stereo in one launch (stereo output)
-int launch_root_out(hipStream_t s, const DevView& v, int root_node, float* d_out, int K);
+int launch_root_out(hipStream_t s, const DevView& v, const RootArgs& root, float* d_out, int K);
 // FIR bank: rows sharing one impulse-response channel h[T] (f32 in the ext pool at h_off)
 int launch_ir_convert(hipStream_t s, const SampleDesc* samples, int sample, int ch, float* dst, uint32_t T);
 // gemm_begin / gemm_end: optional events recorded around the k_fir_gemm launch alone (bench roofline)

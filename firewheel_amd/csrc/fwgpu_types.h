@@ -175,6 +175,13 @@ struct FirRow {  // one GEMM row = one channel of one FIR node
     int out_buf;
 };
 
+// the root SumNode of a fused plan, passed to k_root_out by value (kernel arguments: scalar loads, no dependent fetch)
+struct RootArgs {
+    int n_in, ports;  // ports = n_in / 2 stereo ports (<= 32)
+    int in_buf[64];   // bus buffer of input channel i
+    const int* in_tab;  // the same table in device memory (for per-lane indexing)
+};
+
 // k_chain plan: what the two channel workgroups of a voice share, as it stood at the START of the current call
 // (written by k_voice_control, which also advances the node state to the end of the call; read-only for k_chain)
 struct ChainStart {

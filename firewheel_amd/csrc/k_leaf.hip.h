@@ -207,14 +207,18 @@ __device__ __forceinline__ void leaf_fast_cls(const float* my_l, uint32_t my_rd,
     }
 }
 
-__global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K) {
+__global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K, int wpk) {
 #if LEAF_MAP_BLOCKS
-    // the waves of a workgroup take CONSECUTIVE blocks of one leaf: a steady voice's source is contiguous across
-    // blocks, so the workgroup streams LEAF_WPB KiB per voice-channel instead of 1 KiB from LEAF_WPB x 32 places
+    // the waves of a workgroup take CONSECUTIVE 256-frame pieces of one leaf's stream — wpk (1, 2 or 4) waves per
+    // block, LEAF_WPB / wpk consecutive blocks: a steady voice's source is contiguous across blocks, so the workgroup
+    // streams LEAF_WPB adjacent KiB per voice-channel instead of 1 KiB from LEAF_WPB x 32 places
     const int leaf = blockIdx.x;
-    const uint32_t k = blockIdx.y * LEAF_WPB + (threadIdx.x >> 6);
+    const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int part = wave & (wpk - 1);
+    const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.y * (LEAF_WPB / wpk) + wave / wpk));
     if (k >= (uint32_t)K) return;
 #else
+    const int part = 0;
     const int leaf = blockIdx.x * LEAF_WPB + (threadIdx.x >> 6);
     if (leaf >= fv.n_leaves) return;
     const uint32_t k = blockIdx.y;
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
     const bool fast = all_simple && one_class && cls0 == SF_P_F32;
     const bool fast_cls = all_simple && one_class && cls0 != SF_P_F32;
 
-    for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+    for (int f0 = lane * 4 + part * 256; f0 < frames; f0 += 256 * wpk) {
         v4f accl = splat(0.f), accr = splat(0.f);
         if (fast) {
             switch (fv.n_gain_stages) {
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
         *(v4f*)(outr + f0) = accr;
     }
     // out mask: all-silent -> both flagged; 1-port copy -> passthrough (sum.rs:58-65); else 0
-    if (lane < 2) bflags[ld.out_buf + lane] = all_silent ? 1 : 0;
+    if (lane < 2 && part == 0) bflags[ld.out_buf + lane] = all_silent ? 1 : 0;
 }
 
 // Upper sum tree of the fused plan, K-batched: SumNode semantics (nodes/sum.rs:41-136) with one THREAD per
@@ -361,51 +365,54 @@ __global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restric
 // never goes to memory.  Same arithmetic as k_bus_sum followed by k_graph_out: all inputs silent -> the sum clears and
 // flags both channels -> interleave_stereo zero-fills; n_in == n_out -> copy with mask passthrough; otherwise ports
 // added in order (silent ports skipped on the n-port path only) and both flags are clear.
-__global__ __launch_bounds__(256) void k_root_out(DevView v, int root_node, float* __restrict__ out) {
-    const NodeDesc nd = v.nodes[root_node];
+// The kernel is a handful of dependent memory round trips long, so it is built to have ONE: the root's port table
+// arrives in the kernel arguments (scalar loads), every port's frame is requested before anything is waited for, and
+// the silence flags (which only decide whether a loaded value is added) are fetched alongside.
+template <int NP>
+__device__ __forceinline__ void root_out_body(const DevView& v, const RootArgs& ra, float* __restrict__ out) {
     const uint32_t blk = blockIdx.y;
     const int lane = threadIdx.x & (WAVE - 1);
     const float* pool = v.pool + (size_t)blk * v.pool_blk_stride;
     const uint8_t* flags = v.flags + (size_t)blk * v.flags_blk_stride;
-    const int* in_buf = v.in_buf + nd.in_off;
-    const int n_in = nd.n_in, ports = nd.aux0;
-    const int my_in = lane < n_in ? in_buf[lane] : 0;
-    const uint64_t in_mask = __ballot(lane < n_in ? flags[my_in] != 0 : false);
-    float* o = out + (size_t)blk * v.frames * 2;
+    const int n_in = ra.n_in, ports = ra.ports;
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int fc = f < v.frames ? f : 0;  // whole waves stay in: the ballot below needs lanes 0..n_in-1
+    // per-lane lookups go through the device copy of the table (indexing the argument struct by lane would spill it)
+    const uint8_t my_flag = lane < n_in ? flags[ra.in_tab[lane]] : (uint8_t)0;
+    float xl[NP], xr[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {  // ports past the last one re-read port 0 (never added)
+        const int q = p < ports ? p : 0;
+        xl[p] = pool[(size_t)ra.in_buf[2 * q] * v.stride + fc];
+        xr[p] = pool[(size_t)ra.in_buf[2 * q + 1] * v.stride + fc];
+    }
+    const uint64_t in_mask = __ballot(my_flag != 0);
     if (f >= v.frames) return;
+    float* o = out + (size_t)blk * v.frames * 2;
     float2 y = make_float2(0.f, 0.f);
     if (mask_all(in_mask, n_in)) {
         // sum.rs:52-56 then util.rs:129-134
     } else if (n_in == 2) {  // sum.rs:58-65: copy, flags pass through; both silent was handled above
-        y.x = pool[(size_t)__builtin_amdgcn_readlane(my_in, 0) * v.stride + f];
-        y.y = pool[(size_t)__builtin_amdgcn_readlane(my_in, 1) * v.stride + f];
+        y = make_float2(xl[0], xr[0]);
     } else {
         const bool masked = !(ports == 2 || ports == 3 || ports == 4);
-        float accl = pool[(size_t)__builtin_amdgcn_readlane(my_in, 0) * v.stride + f];
-        float accr = pool[(size_t)__builtin_amdgcn_readlane(my_in, 1) * v.stride + f];
-        for (int p0 = 1; p0 < ports; p0 += 8) {
-            float xl[8], xr[8];
-            bool ul[8], ur[8];
+        float accl = xl[0], accr = xr[0];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                ul[u] = ur[u] = false;
-                if (p0 + u < ports) {
-                    const int il = 2 * (p0 + u), ir = il + 1;
-                    ul[u] = !(masked && mask_bit(in_mask, il));  // :122-124
-                    ur[u] = !(masked && mask_bit(in_mask, ir));
-                    xl[u] = pool[(size_t)__builtin_amdgcn_readlane(my_in, il) * v.stride + f];
-                    xr[u] = pool[(size_t)__builtin_amdgcn_readlane(my_in, ir) * v.stride + f];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (ul[u]) accl = accl + xl[u];
-                if (ur[u]) accr = accr + xr[u];
-            }
+        for (int p = 1; p < NP; ++p) {
+            const bool in = p < ports;
+            const bool ul = in && !(masked && mask_bit(in_mask, 2 * p));  // :122-124
+            const bool ur = in && !(masked && mask_bit(in_mask, 2 * p + 1));
+            const float sl = accl + xl[p], sr = accr + xr[p];
+            accl = ul ? sl : accl;
+            accr = ur ? sr : accr;
         }
         y = make_float2(accl, accr);
     }
     *(float2*)(o + (size_t)f * 2) = y;
 }
-
+__global__ __launch_bounds__(256) void k_root_out(DevView v, RootArgs ra, float* __restrict__ out) {
+    if (ra.ports <= 4) root_out_body<4>(v, ra, out);
+    else if (ra.ports <= 8) root_out_body<8>(v, ra, out);
+    else if (ra.ports <= 16) root_out_body<16>(v, ra, out);
+    else root_out_body<32>(v, ra, out);
+}

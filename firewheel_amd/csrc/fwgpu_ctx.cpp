@@ -1780,7 +1780,7 @@ int fwgpu_device_info(fwgpu_ctx* c, char* name, int name_cap, int* cus, uint64_t
     hipDeviceProp_t prop;
     HIPC(c, hipGetDeviceProperties(&prop, c->device));
     if (name && name_cap > 0) {
-        strncpy(name, prop.name, (size_t)name_cap - 1);
+        strncpy(name, prop.name[0] ? prop.name : prop.gcnArchName, (size_t)name_cap - 1);  // no marketing name: the ISA
         name[name_cap - 1] = 0;
     }
     if (cus) *cus = prop.multiProcessorCount;

@@ -58,3 +58,13 @@ def test_ctx_create_fails_loudly_without_gpu(lib):
     with pytest.raises(fa.FwgpuError) as ei:
         fa.FirewheelGpuCtx()
     assert "no CPU fallback" in str(ei.value) or "HIP" in str(ei.value)
+
+
+def test_header_is_plain_c99_and_the_c_host_builds(lib):
+    # the boundary is a C ABI: the header must compile as C (not only as C++), and a C host must link against it
+    import subprocess
+
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
+                           os.path.join(ROOT, "include", "fwgpu.h")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples", "host_c")])
+    assert os.path.exists(os.path.join(ROOT, "examples", "host_c", "fw_host"))

@@ -785,3 +785,71 @@ def test_virtual_shards_on_one_device_ordered_bus_equals_whole_graph():
     bus = shard.ordered_sum(parts, torch.empty_like(parts[0]))
     torch.cuda.synchronize()
     assert_bits_equal(want, bus.cpu().numpy(), "virtual shards, ordered bus")
+
+
+def _c_host_reference(e, voices, block, callbacks):
+    """examples/host_c/fw_host.c restated on the test engine API: same graph, samples, messages, callback sizes"""
+    SRC, RADIX = 1900, 8
+    sampler, volume, level = [], [], []
+    for v in range(voices):
+        s = e.sampler(100.0)
+        g = e.volume(float(10 + (v * 37) % 90))
+        p = e.pan(float(np.float32((v * 53) % 200 - 100) / np.float32(100.0)))
+        e.connect_stereo(s, g)
+        e.connect_stereo(g, p)
+        sampler.append(s)
+        volume.append(g)
+        level.append(p)
+    while True:
+        nxt = []
+        for i in range(0, len(level), RADIX):
+            grp = level[i:i + RADIX]
+            m = e.sum(len(grp))
+            for p, n in enumerate(grp):
+                e.connect_stereo(n, m, 2 * p)
+            nxt.append(m)
+        level = nxt
+        if len(level) == 1:
+            break
+    e.connect_stereo(level[0], e.graph_out_node)
+    e.update()
+    # xorshift32, vectorised over the voices
+    st = (np.uint32(0x9E3779B9) ^ ((np.arange(voices, dtype=np.uint64) * 2654435761 + 1) & 0xFFFFFFFF).astype(np.uint32))
+    data = np.empty((voices, 2 * SRC), dtype=np.float32)
+    for i in range(2 * SRC):
+        st ^= st << np.uint32(13)
+        st ^= st >> np.uint32(17)
+        st ^= st << np.uint32(5)
+        data[:, i] = (st >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 8388608.0) - np.float32(1.0)
+    for v in range(voices):
+        smp = e.new_sample(PLANAR_F32, 2, data[v].reshape(2, SRC))
+        e.sampler_set_sample(sampler[v], smp)
+        if v % 3 != 2:
+            e.sampler_set_loop_range(sampler[v], fwapi.LOOP_FULL)
+        e.sampler_play(sampler[v])
+    out = []
+    for cb in range(callbacks):
+        if cb == callbacks // 3:
+            for v in range(0, voices, 2):
+                e.set_param(volume[v], 0, 20.0 + float(v % 7) * 10.0)
+        if cb == callbacks // 2:
+            for v in range(1, voices, 5):
+                e.sampler_pause(sampler[v])
+        out.append(e.process_blocks(2 if cb % 4 == 3 else 1))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("voices,block,callbacks", [(50, 128, 40), (9, 96, 25)])
+def test_plain_c_host_through_the_c_abi_matches_oracle(voices, block, callbacks, tmp_path):
+    # the drop-in boundary used from compiled C (no Python between the host and libfwgpu): examples/host_c
+    import subprocess
+
+    exe = os.path.join(fwapi.ROOT, "examples", "host_c", "fw_host")
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    path = str(tmp_path / "out.f32")
+    r = subprocess.run([exe, str(voices), str(block), str(callbacks), path], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "plan kind 1" in r.stdout
+    got = np.fromfile(path, dtype=np.float32)
+    want = _c_host_reference(oracle(max_block_frames=block), voices, block, callbacks)
+    assert_bits_equal(want, got, "plain C host %dx%d" % (voices, block))

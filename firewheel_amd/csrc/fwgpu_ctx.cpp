@@ -106,7 +106,7 @@ struct fwgpu_ctx {
     int chain_nq = 1;       // k_chain tile size / 64 frames
     int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
     uint32_t epoch = 1;  // invalidates every VoiceCache when bumped (plan install, sample-table change)
-    DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start;
+    DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start, d_chain_dummy, d_chain_stats;
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
     std::vector<int> up_level_off, up_level_cnt;
     int up_root_node = -1;  // index (in the upper-tree node table) of the root SumNode when it is alone on the last level
@@ -855,6 +855,9 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         HIPC(c, c->d_refs.ensure(K * c->n_voices * sizeof(VoiceRef)));
         HIPC(c, c->d_gsets.ensure((size_t)c->n_voices * FW_GSETS * sizeof(GainSet)));
         HIPC(c, c->d_chain_start.ensure((size_t)c->n_voices * sizeof(ChainStart)));
+        HIPC(c, c->d_chain_dummy.ensure(64 * 1024));
+        HIPC(c, c->d_chain_stats.ensure(2 * sizeof(unsigned long long)));
+        HIPC(c, hipMemset(c->d_chain_stats.p, 0, 2 * sizeof(unsigned long long)));
         HIPC(c, hipMemset(c->d_chain_start.p, 0, (size_t)c->n_voices * sizeof(ChainStart)));
         HIPC(c, c->d_cache.ensure((size_t)c->n_voices * sizeof(VoiceCache)));
         HIPC(c, hipMemset(c->d_cache.p, 0, (size_t)c->n_voices * sizeof(VoiceCache)));
@@ -1065,6 +1068,8 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     fv.frames = (int)c->mbf;
     fv.ext = c->d_ext.as<float>();
     fv.chain_start = c->d_chain_start.as<ChainStart>();
+    fv.chain_dummy = c->d_chain_dummy.as<float>();
+    fv.chain_stats = c->d_chain_stats.as<unsigned long long>();
     fv.trace = nullptr;
 #ifdef FW_CHAIN_TRACE
     if (c->d_trace.ensure(64 * 16 * 8 * sizeof(unsigned long long)) == hipSuccess) fv.trace = c->d_trace.as<unsigned long long>();
@@ -1288,7 +1293,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
         if (s.alive && s.owned && s.d_data) (void)hipFree(s.d_data);
     DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
                       &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
-                      &c->d_bus, &c->d_bus_flags, &c->d_chain_start, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
+                      &c->d_bus, &c->d_bus_flags, &c->d_chain_start, &c->d_chain_dummy, &c->d_chain_stats, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
                       &c->d_root_bufs, &c->d_fir_rows, &c->d_fir_tiles, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask};
     for (DevBuf* b : bufs) b->release();
@@ -1412,6 +1417,17 @@ int fwgpu_plan_node_inputs_clear(fwgpu_ctx* c, int64_t node, int* should_clear, 
 }
 int fwgpu_set_force_generic(fwgpu_ctx* c, int on) {
     c->force_generic = on != 0;
+    return 0;
+}
+int fwgpu_plan_chain_stats(fwgpu_ctx* c, uint64_t* steady_workgroups, uint64_t* general_workgroups) {
+    (void)hipSetDevice(c->device);
+    unsigned long long h[2] = {0, 0};
+    if (c->d_chain_stats.p) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipMemcpy(h, c->d_chain_stats.p, sizeof(h), hipMemcpyDeviceToHost));
+    }
+    if (steady_workgroups) *steady_workgroups = h[0];
+    if (general_workgroups) *general_workgroups = h[1];
     return 0;
 }
 int fwgpu_set_max_batch(fwgpu_ctx* c, uint32_t k) {

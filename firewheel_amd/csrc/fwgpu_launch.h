@@ -55,6 +55,8 @@ struct FusedView {
     int frames;
     float* ext;  // biquad coefficients + history, delay rings (k_chain plan)
     ChainStart* chain_start;  // [n_voices] (k_chain plan)
+    float* chain_dummy;       // k_chain's steady-call loop: where lanes with nothing to fetch / store point (>= 32 KiB)
+    unsigned long long* chain_stats;  // [2] workgroups that ran the steady-call loop / the general loop
     unsigned long long* trace;  // FW_CHAIN_TRACE builds only: per-step role timestamps of workgroup 0
     int dbg;     // FW_CHAIN_TRACE builds only (env FWGPU_CHAIN_SKIP): bit 0 skip S2, 1 skip S3b, 2 skip source loads,
                  // 3 skip ring RMW, 4 no ring prefetch

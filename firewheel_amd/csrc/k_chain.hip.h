@@ -52,6 +52,7 @@
     do {               \
     } while (0)
 #endif
+#define CH_FAST_KMAX 64  // blocks per call the steady-call loop keeps source addresses for (LDS)
 #define CH_THREADS ((CH_WORKERS + 4) * WAVE)  // 8 workers + serial + mixer + 2 idle waves (see the role map in k_chain)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -120,6 +121,25 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     }
     const bool ring_pref = has_dl && D >= 2u * TT && !CH_SKIP(16);
     const bool any_bq = __syncthreads_or(has_bq ? 1 : 0) != 0;
+
+    // ---- steady call?  Every voice of the leaf keeps ONE descriptor shape for all K blocks (VB_SIMPLE, one gain set,
+    // planar f32 or cleared source), has both a biquad and a delay of >= 3 tiles, and no message is pending: the
+    // workers then run the branch-free loop below (loads two tiles ahead, exact vmcnt waits) instead of the general one.
+    __shared__ unsigned long long srcp[32][CH_FAST_KMAX];  // this channel's source address of frame 0 of (voice, block)
+    bool fast_ok = fv.n_cmds == 0 && K <= CH_FAST_KMAX && !CH_SKIP(32);
+    for (int i = threadIdx.x; i < ports * K; i += CH_THREADS) {
+        const int pv = i / K, pk = i - pv * K;
+        const VoiceRef* r = &fv.refs[(size_t)(ld.first_voice + pv) * fv.refs_stride];
+        const VoiceRef rk = r[pk];
+        const uint32_t f0 = r[0].flags_gset, fk = rk.flags_gset;
+        fast_ok = fast_ok && fk == f0 && (f0 & VB_SIMPLE) && ((f0 >> 8) & 0xffu) == 0u &&
+                  ((((f0 >> 16) & 7u) == SF_P_F32) || (f0 & VB_SRC_ZERO));
+        srcp[pv][pk] = (unsigned long long)(rk.src_l + (ch ? rk.r_delta : 0u));  // r_delta = 0 for a mono sample
+    }
+    if (active) fast_ok = fast_ok && has_bq && has_dl && (!is_worker || D >= 3u * TT);
+    const bool wg_fast = __syncthreads_and(fast_ok ? 1 : 0) != 0;
+    const int n_steps = wg_fast ? ((n_tiles + 3 + 1) & ~1) : n_tiles + 3;  // the fast loop is unrolled by two
+    if (threadIdx.x == 0) atomicAdd(fv.chain_stats + (wg_fast ? 0 : 1), 1ull);  // fwgpu_plan_chain_stats (tests)
 
     // compute-side block registers (block of tile s) and issue-side ones (block of tile s+1, one step ahead)
     float g0 = 1.f;
@@ -206,15 +226,165 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             }
         }
     };
-    if (is_worker && active) {  // prologue = the issue halves of steps -2 and -1
+    if (is_worker && active && !wg_fast) {  // prologue = the issue halves of steps -2 and -1
         ref_n = fv.refs[(size_t)voice * fv.refs_stride + 0];
         issue_source();
     }
 
     // One loop per role (same number of barriers in each) so that the register allocation of a role does not
     // carry the other roles' loop state.
-    if (is_worker) {
-        for (int s = 0; s < n_tiles + 3; ++s) {
+    if (is_worker && wg_fast) {
+        // ================= steady call: branch-free worker steps.
+        // Every step issues exactly NQ source loads, NQ ring stores and NQ ring loads, unconditionally (lanes / tiles
+        // that have nothing to fetch or store use a dummy address), so the compiler's s_waitcnt insertion sees one
+        // path and emits exact vmcnt(N) waits: the source of tile s+2 and the ring slots of tile s are requested in
+        // step s and stay in flight for two whole steps (two static register sets, loop unrolled by two).  A quad
+        // that straddles the end of its ring (once per lap) is fixed up on a rare path with plain in-step accesses.
+        const uint32_t vflags = fv.refs[(size_t)voice * fv.refs_stride].flags_gset & 0xffu;
+        const GainSet* gsp = &fv.gsets[(size_t)voice * FW_GSETS];
+        const float g0f = gsp->g[0][ch];
+        float gpost[FW_MAX_STAGES - 1];
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) gpost[j] = gsp->g[j + 1][ch];
+        const bool src_zero = (vflags & VB_SRC_ZERO) != 0, silent = (vflags & VB_SILENT) != 0;
+        float* const dummy = fv.chain_dummy + (size_t)threadIdx.x * (4 * NQ);
+        const float* const rbase = active ? ring : dummy;
+        const uint32_t Dv = active ? D : 0x7fffffffu;
+        uint32_t pos_c = active ? pos : 0u, pos_i = pos_c;  // ring position of the tile S3a consumes / the tile requested
+        int kli = 0, tli = 0;                               // (block, tile in block) of the next source tile to request
+        v4f xsA[NQ], xsB[NQ], rgA[NQ], rgB[NQ];
+        auto issue_src = [&](v4f(&xs)[NQ], int t) {
+            const bool real = t < n_tiles && active && !src_zero;
+            const float* p = real ? (const float*)srcp[v][kli] + tli * TT + LF * q : (const float*)dummy;
+            asm volatile("" : "+v"(p));  // one opaque address: the select must not become two conditional loads
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) xs[j] = gload4(p + 4 * j);
+            const bool wrap = tli + 1 == tpb;
+            tli = wrap ? 0 : tli + 1;
+            kli = (wrap && kli + 1 < K) ? kli + 1 : kli;
+        };
+        auto slot_of = [&](uint32_t base, int j) -> uint32_t {
+            uint32_t sl = base + (uint32_t)(LF * q + 4 * j);
+            return sl >= Dv ? sl - Dv : sl;
+        };
+        auto issue_ring = [&](v4f(&rg)[NQ], int t) {
+            const bool real = t < n_tiles && active;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const uint32_t sl = slot_of(pos_i, j);
+                const float* p = real ? rbase + (sl + 4u <= Dv ? sl : Dv - 4u) : (const float*)dummy;
+                asm volatile("" : "+v"(p));
+                rg[j] = *(gv4p)(uint64_t)p;  // global_load (the opaque address would otherwise be a flat access)
+            }
+            if (real) {
+                pos_i += TT;
+                if (pos_i >= Dv) pos_i -= Dv;
+            }
+        };
+        auto wstep = [&](int s, v4f(&xs)[NQ], v4f(&rg)[NQ]) {
+            const bool v1 = s < n_tiles;
+            const bool v3 = active && s >= 2 && s - 2 < n_tiles;
+            CH_TRACE(0);
+            v4f yv[NQ];
+            {
+                const float* yrow = &tile[(s - 2) & (CH_NBUF - 1)][v][LF * q];
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) yv[j] = *(const v4f*)(yrow + 4 * j);
+            }
+            // ---- S1 on tile s (steps past the last tile compute on dummy data into a buffer nobody reads)
+            {
+                v4f x[NQ];
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) x[j] = src_zero ? splat(0.f) : xs[j] * g0f;  // sampler.rs:530-533
+                float* row = &tile[s & (CH_NBUF - 1)][v][LF * q];
+                const bool q15 = q == 15;
+                float p1 = row_ror1(q15 ? prev_x[3] : x[NQ - 1][3]), p2 = row_ror1(q15 ? prev_x[2] : x[NQ - 1][2]);
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    const v4f xc = x[j];
+                    const v4f x1v = (v4f){p1, xc[0], xc[1], xc[2]}, x2v = (v4f){p2, p1, xc[0], xc[1]};
+                    const v4f a = ((xc * b0) + (x1v * b1)) + (x2v * b2);  // ((b0*x) + (b1*x1)) + (b2*x2)
+                    p1 = xc[3];
+                    p2 = xc[2];
+                    *(v4f*)(row + 4 * j) = a;
+                }
+                prev_x = v1 ? x[NQ - 1] : prev_x;
+            }
+            issue_src(xs, s + 2);
+            CH_TRACE(2);
+            // ---- S3a on tile s-2
+            {
+                uint32_t sl[NQ];
+                bool straddle = false;
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    sl[j] = slot_of(pos_c, j);
+                    straddle = straddle || (v3 && sl[j] + 4u > Dv);
+                }
+                if (__ballot(straddle) != 0ull) {  // rare: this lane's quad wraps around the end of the ring
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        if (v3 && sl[j] + 4u > Dv) {
+                            v4f t;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                uint32_t se = sl[j] + (uint32_t)e;
+                                if (se >= Dv) se -= Dv;
+                                t[e] = rbase[se];
+                            }
+                            asm volatile("" : "+v"(t));  // the wait for these loads stays inside the rare path
+                            rg[j] = t;
+                        }
+                    }
+                }
+                float* row = &tile[(s - 2) & (CH_NBUF - 1)][v][LF * q];
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    v4f y = yv[j];
+                    const v4f nv = y + (rg[j] * fb);  // ring[p] = x + (d*fb)
+                    float* sp = (v3 && sl[j] + 4u <= Dv) ? ring + sl[j] : dummy + 4 * j;
+                    asm volatile("" : "+v"(sp));
+                    *(v4f_u __attribute__((address_space(1)))*)(uint64_t)sp = nv;
+                    y = (y * dry) + (rg[j] * mix);  // out = (x*dry) + (d*mix)
+#pragma unroll
+                    for (int g = 0; g < FW_MAX_STAGES - 1; ++g) {
+                        if (g + 1 >= fv.n_gain_stages) break;
+                        y = y * gpost[g];
+                    }
+                    if (silent) y = splat(0.f);  // muted gain stage: cleared buffer
+                    *(v4f*)(row + 4 * j) = y;
+                    if (__ballot(straddle) != 0ull) {
+                        if (v3 && sl[j] + 4u > Dv) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                uint32_t se = sl[j] + (uint32_t)e;
+                                if (se >= Dv) se -= Dv;
+                                ring[se] = nv[e];
+                            }
+                        }
+                    }
+                }
+                if (v3) {
+                    pos_c += TT;
+                    if (pos_c >= Dv) pos_c -= Dv;
+                }
+                if (q == 0) silf[(s - 2) & (CH_NBUF - 1)][v] = silent ? 1u : 0u;
+            }
+            issue_ring(rg, s);
+            CH_TRACE(3);
+            __syncthreads();
+            CH_TRACE(4);
+        };
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) rgA[j] = rgB[j] = splat(0.f);
+        issue_src(xsA, 0);
+        issue_src(xsB, 1);
+        for (int s = 0; s < n_steps; s += 2) {
+            wstep(s, xsA, rgA);
+            wstep(s + 1, xsB, rgB);
+        }
+    } else if (is_worker) {
+        for (int s = 0; s < n_steps; ++s) {
             const bool do1 = active && s < n_tiles;
             const bool do3 = active && s >= 2 && s - 2 < n_tiles;
             const bool dl_on = has_dl && !CH_SKIP(8);
@@ -403,7 +573,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     } else if (is_serial) {
         // the recurrence is the critical path of every step: its wave wins VALU arbitration on its SIMD
         __builtin_amdgcn_s_setprio(3);
-        for (int s = 0; s < n_tiles + 3; ++s) {
+        for (int s = 0; s < n_steps; ++s) {
             CH_TRACE(0);
             // ================= S2 on tile s-1: the recursive half of the biquad, lane = voice
             if (any_bq && s >= 1 && s - 1 < n_tiles && !CH_SKIP(1)) {
@@ -459,12 +629,12 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             CH_TRACE(4);
         }
     } else if (is_idle) {
-        for (int s = 0; s < n_tiles + 3; ++s) __syncthreads();
+        for (int s = 0; s < n_steps; ++s) __syncthreads();
     } else {
-        for (int s = 0; s < n_tiles + 3; ++s) {
+        for (int s = 0; s < n_steps; ++s) {
             CH_TRACE(0);
             // ================= S3b on tile s-3: the leaf SumNode of this channel, lane = frame quad, ports in order
-            if (s >= 3 && lane < TT / 4 && !CH_SKIP(2)) {
+            if (s >= 3 && s - 3 < n_tiles && lane < TT / 4 && !CH_SKIP(2)) {  // (the steady-call loop pads n_steps to even)
                 const int buf = (s - 3) & (CH_NBUF - 1);
                 // ONE LDS round trip: every port's row (row index clamped, so the reads are unconditional) and the
                 // silence flags are requested together; the adds are masked

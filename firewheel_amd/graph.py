@@ -410,6 +410,12 @@ class FirewheelGpuCtx(object):
         n = self._check(self.L.fwgpu_plan_node_inputs_clear(self.c, node_id, buf, 64))
         return [bool(buf[i]) for i in range(n)]
 
+    def plan_chain_stats(self):
+        """(steady, general): k_chain workgroup launches that ran the steady-call loop / the general loop"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.L.fwgpu_plan_chain_stats(self.c, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_max_batch(self, k):
         self._check(self.L.fwgpu_set_max_batch(self.c, k))
 

@@ -121,6 +121,9 @@ int fwgpu_plan_num_levels(fwgpu_ctx* ctx);
 int fwgpu_plan_node_level(fwgpu_ctx* ctx, int64_t node);
 /* per input port: 1 if the port is unconnected (the reference's should_clear), else 0.  Returns n. */
 int fwgpu_plan_node_inputs_clear(fwgpu_ctx* ctx, int64_t node, int* should_clear, int cap);
+/* chain plan (kind 2) only: k_chain workgroup launches since the plan was installed that ran the steady-call loop
+ * (every voice of the leaf steady for the whole call, delays >= 3 tiles, no message pending) / the general loop */
+int fwgpu_plan_chain_stats(fwgpu_ctx* ctx, uint64_t* steady_workgroups, uint64_t* general_workgroups);
 /* K = the most blocks one fused launch sequence processes (default 64); sizes the K-batched descriptor,
  * ramp and bus buffers at the next fwgpu_update. */
 int fwgpu_set_max_batch(fwgpu_ctx* ctx, uint32_t max_blocks);

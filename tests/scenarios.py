@@ -399,6 +399,37 @@ def scenario_chain_events(e, n_voices=37, radix=32, src_frames=1000, **kw):
     return np.concatenate(outs)
 
 
+def scenario_chain_steady_calls(e, n_voices=37, tile=128, with_pan=False):
+    """calls k_chain's steady-call loop accepts (every voice one descriptor shape for the whole call, delays >= 3
+    tiles, no message pending) between calls it does not: start-up messages, a burst of pauses / gain changes / a
+    mute whose ramps take a few blocks to settle.  Sources are a whole number of blocks long (loops wrap on block
+    boundaries), delay lengths are mostly not multiples of 4 (quads straddle the ring end once per lap), some voices
+    never start (cleared source through biquad + delay), some samples are mono."""
+    mbf = e.max_block_frames
+    voices = build_chain_bank(e, n_voices, radix=32, src_frames=6 * mbf, mono_every=5, with_pan=with_pan,
+                              first_delay_frames=3 * tile, min_delay_frames=3 * tile + 1, max_delay_frames=3 * tile + 500)
+    outs = []
+    for v, vc in enumerate(voices):
+        e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        if v % 6 != 4:
+            e.sampler_play(vc["sampler"])           # v%6==4 never starts
+    outs.append(e.process_blocks(2))                # start-up messages: general loop
+    outs.append(e.process_blocks(7))                # steady
+    outs.append(e.process_blocks(1))                # steady, one block
+    for v, vc in enumerate(voices):
+        if v % 7 == 3:
+            e.sampler_pause(vc["sampler"])
+        if v % 4 == 0:
+            e.set_param(vc["volume"], 0, 35.0 + v)
+        if v % 9 == 5:
+            e.set_param(vc["volume"], 0, 0.0)       # ramps to 0, then the port is muted
+    outs.append(e.process_blocks(3))                # messages
+    outs.append(e.process_blocks(8))                # ramps settle somewhere in here
+    outs.append(e.process_blocks(11))               # steady again, with paused and muted voices
+    outs.append(e.process_blocks(5))
+    return np.concatenate(outs)
+
+
 def scenario_spatial_scene(e, n_sources=7, blocks=12, src_frames=2500):
     """moving sources: resampler (varispeed, some looping, one i16, one mono-to-stereo) -> spatialiser -> sum -> out.
     Exercises the 32.32 position arithmetic (loop wrap, one-shot end), the ITD history across blocks, gain ramps

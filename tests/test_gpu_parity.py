@@ -218,6 +218,9 @@ def run_case(name, **gpu_kw):
         # two 128-frame tiles per block, every ring prefetched (delays >= 256 frames)
         "chain_events_21_d256": lambda e: scenarios.scenario_chain_events(e, 21, first_delay_frames=256, min_delay_frames=257,
                                                                           src_frames=1500),
+        "chain_calls_37_b256": lambda e: scenarios.scenario_chain_steady_calls(e, 37, tile=128),
+        "chain_calls_20_b128_pan": lambda e: scenarios.scenario_chain_steady_calls(e, 20, tile=128, with_pan=True),
+        "chain_calls_33_b64": lambda e: scenarios.scenario_chain_steady_calls(e, 33, tile=64),
         "cfg4_reverb": scenarios.scenario_cfg4_reverb,
         "cfg4_reverb_2irs_mono": lambda e: scenarios.scenario_cfg4_reverb(e, n_voices=5, taps=700, shared_ir=False,
                                                                           ir_channels=1),
@@ -227,7 +230,8 @@ def run_case(name, **gpu_kw):
            "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64, "cfg3_chain": 128, "cfg4_reverb": 128,
            "cfg4_reverb_2irs_mono": 64, "chain_steady_40": 256, "chain_steady_bq_only_i16": 64,
            "chain_steady_dl_only_pan": 128, "chain_events_37": 128, "chain_events_19_r2_pan": 64,
-           "chain_steady_40_d128": 256, "chain_events_37_d130": 128, "chain_events_21_d256": 256, "spatial_scene": 128, "spatial_scene_b96": 96}[name]
+           "chain_steady_40_d128": 256, "chain_events_37_d130": 128, "chain_events_21_d256": 256, "chain_calls_37_b256": 256, "chain_calls_20_b128_pan": 128,
+           "chain_calls_33_b64": 64, "spatial_scene": 128, "spatial_scene_b96": 96}[name]
     kw = dict(max_block_frames=mbf)
     if name == "graph_inputs":
         kw["num_graph_inputs"] = 3
@@ -331,6 +335,20 @@ def test_chain_bank_fused_chain_plan_bit_exact(name, max_batch):
     out_o, out_g, g = run_case(name, max_batch=max_batch)
     assert g.cx.plan_kind() == 2, "fused chain plan was not selected"
     assert_bits_equal(out_o, out_g, name + " k_chain K<=%d" % max_batch)
+    gold = json.load(open(GOLDEN))
+    assert digest(out_g) == gold[name]
+
+
+@pytest.mark.parametrize("name", ["chain_calls_37_b256", "chain_calls_20_b128_pan", "chain_calls_33_b64"])
+@pytest.mark.parametrize("max_batch", [64, 4])
+def test_chain_plan_steady_call_loop_bit_exact(name, max_batch):
+    # calls that qualify for k_chain's steady-call loop (loads two tiles ahead, branch-free worker steps) between calls
+    # that do not: both loops must have run, and the stream must equal the oracle's bit for bit
+    out_o, out_g, g = run_case(name, max_batch=max_batch)
+    assert g.cx.plan_kind() == 2
+    steady, general = g.cx.plan_chain_stats()
+    assert steady > 0 and general > 0, (steady, general)
+    assert_bits_equal(out_o, out_g, name + " k_chain steady calls K<=%d" % max_batch)
     gold = json.load(open(GOLDEN))
     assert digest(out_g) == gold[name]
 

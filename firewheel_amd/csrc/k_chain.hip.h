@@ -126,7 +126,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     // planar f32 or cleared source), has both a biquad and a delay of >= 3 tiles, and no message is pending: the
     // workers then run the branch-free loop below (loads two tiles ahead, exact vmcnt waits) instead of the general one.
     __shared__ unsigned long long srcp[32][CH_FAST_KMAX];  // this channel's source address of frame 0 of (voice, block)
-    bool fast_ok = fv.n_cmds == 0 && K <= CH_FAST_KMAX && !CH_SKIP(32);
+    bool fast_ok = fv.n_cmds == 0 && K <= CH_FAST_KMAX && !(fv.dbg & 32);  // FWGPU_CHAIN_SKIP=32: A/B against the general loop
     for (int i = threadIdx.x; i < ports * K; i += CH_THREADS) {
         const int pv = i / K, pk = i - pv * K;
         const VoiceRef* r = &fv.refs[(size_t)(ld.first_voice + pv) * fv.refs_stride];
@@ -646,11 +646,18 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                 const bool all_silent = silent_ports == port_mask;
                 const uint64_t skip = masked ? silent_ports : 0ull;  // :122-124 (n-port path only)
                 v4f acc = x[0];  // sum.rs:117 copy port 0 (also when silent: a cleared buffer)
+                if (ports == 32 && skip == 0ull) {
+                    // the usual leaf: full, nothing silent — 31 plain adds in port order (the masked form below costs
+                    // ~30 scalar + vector instructions per port on this one wave, which made S3b the longest stage)
 #pragma unroll
-                for (int u = 1; u < 32; ++u) {
-                    const bool use = u < ports && !((skip >> u) & 1ull);
-                    const v4f t = acc + x[u];
-                    acc = use ? t : acc;
+                    for (int u = 1; u < 32; ++u) acc = acc + x[u];
+                } else {
+#pragma unroll
+                    for (int u = 1; u < 32; ++u) {
+                        const bool use = u < ports && !((skip >> u) & 1ull);
+                        const v4f t = acc + x[u];
+                        acc = use ? t : acc;
+                    }
                 }
                 if (all_silent) acc = splat(0.f);  // sum.rs:52-56
                 float* bus = fv.bus + (size_t)k4 * fv.bus_blk_stride + (size_t)(ld.out_buf + ch) * fv.stride + t4 * TT + 4 * lane;

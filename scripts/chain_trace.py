@@ -53,3 +53,18 @@ for s in range(8, 28):
         w1[1] - w1[0], w1[2] - w1[1], w1[3] - w1[2], w1[4] - w1[3],
         w8[1] - w8[0], w8[2] - w8[1], w8[3] - w8[2], w8[4] - w8[3],
         mx[3] - mx[0], mx[4] - mx[3], step_len))
+
+# steady-call loop (k_chain's branch-free worker steps): slots 0 top, 2 after S1 + source request, 3 before / 4 after barrier
+steady, general = cx.plan_chain_stats()
+if steady:
+    print("steady-call loop ran (%d workgroup launches; %d general)" % (steady, general))
+    print("step | serial: work wait | worker1: S1+req S3a+req wait | worker8: S1+req S3a+req wait | mixer: work wait | step len")
+    tot = np.zeros(11)
+    for s in range(8, 40):
+        ser, w1, w8, mx = t[s, 2], t[s, 0], t[s, 9], t[s, 11]
+        row = [ser[3] - ser[0], ser[4] - ser[3], w1[2] - w1[0], w1[3] - w1[2], w1[4] - w1[3],
+               w8[2] - w8[0], w8[3] - w8[2], w8[4] - w8[3], mx[3] - mx[0], mx[4] - mx[3], t[s + 1, 2, 0] - t[s, 2, 0]]
+        tot += np.array(row, dtype=np.float64)
+        if s < 20:
+            print("%4d | %6d %6d | %6d %6d %6d | %6d %6d %6d | %6d %6d | %6d" % tuple([s] + row))
+    print("mean | %6d %6d | %6d %6d %6d | %6d %6d %6d | %6d %6d | %6d" % tuple((tot / 32).astype(int)))

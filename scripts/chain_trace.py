@@ -68,3 +68,8 @@ if steady:
         if s < 20:
             print("%4d | %6d %6d | %6d %6d %6d | %6d %6d %6d | %6d %6d | %6d" % tuple([s] + row))
     print("mean | %6d %6d | %6d %6d %6d | %6d %6d %6d | %6d %6d | %6d" % tuple((tot / 32).astype(int)))
+    print("per worker wave (mean over steps 8..39): wave simd | S1+req  S3a+req  barrier-wait")
+    for w in (0, 1, 3, 4, 5, 7, 8, 9):
+        a = np.array([[t[s, w, 2] - t[s, w, 0], t[s, w, 3] - t[s, w, 2], t[s, w, 4] - t[s, w, 3]] for s in range(8, 40)
+                      if 0 < t[s, w, 4] - t[s, w, 0] < 20000], dtype=np.float64)
+        print("   wave %2d simd %d | %6d %6d %6d" % ((w, int((t[8, w, 7] >> 4) & 3)) + tuple(a.mean(axis=0).astype(int))))

@@ -9,7 +9,7 @@ root=$GRAFT_REPO_ROOT
 mkdir -p $root/gpurun_out/profiles $root/gpurun_out/raw
 cd /tmp && export TMPDIR=/tmp
 for cfg in $cfgs; do
-  steps=8; [ $cfg = cfg2 ] && steps=20
+  steps=20
   out=$root/gpurun_out/raw/${tag}_${cfg}
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats -o s -- python $root/bench.py --workload $cfg --no-cpu-baseline --steps $steps --warmup 3 > ${out}_stats.log 2>&1
   for ctr in FETCH_SIZE WRITE_SIZE; do

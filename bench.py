@@ -34,11 +34,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec; 6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md:41 (dense f32 MFMA)
 
-DEFAULTS = {  # workload -> (voices/GPU, block, blocks per step, source frames per voice, steps)
-    "cfg2": (1024, 256, 256, 262144, 100),
-    "cfg3": (4096, 512, 32, 65536, 20),
+# workload -> (voices/GPU, block, blocks per step, source frames per voice, steps).  Blocks per step = the batch one
+# fwgpu_process_blocks_device call renders (throughput mode: 768 x 256 frames = 4.1 s of audio per call for config 2);
+# the fixed cost of a call (control kernel + upper sums, ~10 us) is amortised over it.
+DEFAULTS = {
+    "cfg2": (1024, 256, 768, 262144, 40),
+    "cfg3": (4096, 512, 64, 65536, 12),
     "cfg4": (256, 256, 16, 65536, 10),
-    "cfg5": (8192, 1024, 32, 65536, 20),
+    "cfg5": (8192, 1024, 64, 65536, 12),
 }
 
 

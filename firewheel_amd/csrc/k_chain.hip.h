@@ -122,19 +122,50 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     const bool ring_pref = has_dl && D >= 2u * TT && !CH_SKIP(16);
     const bool any_bq = __syncthreads_or(has_bq ? 1 : 0) != 0;
 
-    // ---- steady call?  Every voice of the leaf keeps ONE descriptor shape for all K blocks (VB_SIMPLE, one gain set,
-    // planar f32 or cleared source), has both a biquad and a delay of >= 3 tiles, and no message is pending: the
-    // workers then run the branch-free loop below (loads two tiles ahead, exact vmcnt waits) instead of the general one.
-    __shared__ unsigned long long srcp[32][CH_FAST_KMAX];  // this channel's source address of frame 0 of (voice, block)
+    // ---- steady call?  Every voice of the leaf keeps ONE descriptor shape for all K blocks — constant gains from one
+    // gain set, planar f32 (or cleared) source that is contiguous in each block or wraps once at its loop end
+    // (nodes/sampler.rs:445-484) — has both a biquad and a delay of >= 3 tiles, and no message is pending: the workers
+    // then run the branch-free loop below (loads two tiles ahead, exact vmcnt waits) instead of the general one.
+    // Per (voice, block) the scan parks in LDS: the address of frame 0, the frame the loop wraps at (or "never") and
+    // the address frames past the wrap are relative to.
+    __shared__ unsigned long long srcp[32][CH_FAST_KMAX];
+    __shared__ unsigned long long srcp1[32][CH_FAST_KMAX];
+    __shared__ uint32_t wrap_at[32][CH_FAST_KMAX];
     bool fast_ok = fv.n_cmds == 0 && K <= CH_FAST_KMAX && !(fv.dbg & 32);  // FWGPU_CHAIN_SKIP=32: A/B against the general loop
     for (int i = threadIdx.x; i < ports * K; i += CH_THREADS) {
-        const int pv = i / K, pk = i - pv * K;
-        const VoiceRef* r = &fv.refs[(size_t)(ld.first_voice + pv) * fv.refs_stride];
+        const int pv = i / K, pk = i - pv * K, pvoice = ld.first_voice + pv;
+        const VoiceRef* r = &fv.refs[(size_t)pvoice * fv.refs_stride];
         const VoiceRef rk = r[pk];
-        const uint32_t f0 = r[0].flags_gset, fk = rk.flags_gset;
-        fast_ok = fast_ok && fk == f0 && (f0 & VB_SIMPLE) && ((f0 >> 8) & 0xffu) == 0u &&
-                  ((((f0 >> 16) & 7u) == SF_P_F32) || (f0 & VB_SRC_ZERO));
-        srcp[pv][pk] = (unsigned long long)(rk.src_l + (ch ? rk.r_delta : 0u));  // r_delta = 0 for a mono sample
+        const uint32_t fk = rk.flags_gset & 0xffu, kind = fk & (VB_SIMPLE | VB_WRAP | VB_TAIL_ZERO);
+        const uint32_t per_voice = VB_SILENT | VB_MONO | VB_SRC_ZERO;  // what must not change inside the call
+        bool ok = ((fk ^ r[0].flags_gset) & per_voice) == 0u;
+        const float* a0 = nullptr;
+        const float* a1 = nullptr;
+        uint32_t wr = 0xffffffffu;
+        if (kind == VB_SIMPLE) {
+            ok = ok && ((rk.flags_gset >> 8) & 0xffu) == 0u && ((((rk.flags_gset >> 16) & 7u) == SF_P_F32) || (fk & VB_SRC_ZERO));
+            a0 = rk.src_l + (ch ? rk.r_delta : 0u);  // r_delta = 0 for a mono sample
+        } else if (kind == VB_WRAP && !(fk & VB_SRC_ZERO)) {
+            const VoiceBlk* d = &fv.blks[(size_t)pk * fv.n_voices + pvoice];
+            const GainSet* gs = &fv.gsets[(size_t)pvoice * FW_GSETS];
+            ok = ok && (d->flags >> VB_RAMP_SHIFT) == 0u && d->sample >= 0;
+#pragma unroll
+            for (int j = 0; j < FW_MAX_STAGES; ++j) ok = ok && (j >= fv.n_gain_stages || d->g[j][ch] == gs->g[j][ch]);
+            if (ok) {
+                const SampleDesc sd = fv.samples[d->sample];
+                ok = sd.format == FMT_P_F32 && sd.frames < 0xffffffffull;
+                const float* base = (const float*)sd.data + ((fk & VB_MONO) || ch == 0 ? 0ull : sd.frames);
+                a0 = base + d->off0;
+                wr = d->n1;
+                a1 = base + d->off1 - wr;  // frame f >= wr of the block is a1[f]
+            }
+        } else {
+            ok = false;
+        }
+        fast_ok = fast_ok && ok;
+        srcp[pv][pk] = (unsigned long long)a0;
+        srcp1[pv][pk] = (unsigned long long)a1;
+        wrap_at[pv][pk] = wr;
     }
     if (active) fast_ok = fast_ok && has_bq && has_dl && (!is_worker || D >= 3u * TT);
     const bool wg_fast = __syncthreads_and(fast_ok ? 1 : 0) != 0;
@@ -240,7 +271,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         // path and emits exact vmcnt(N) waits: the source of tile s+2 and the ring slots of tile s are requested in
         // step s and stay in flight for two whole steps (two static register sets, loop unrolled by two).  A quad
         // that straddles the end of its ring (once per lap) is fixed up on a rare path with plain in-step accesses.
-        const uint32_t vflags = fv.refs[(size_t)voice * fv.refs_stride].flags_gset & 0xffu;
+        const uint32_t vflags = fv.refs[(size_t)voice * fv.refs_stride].flags_gset & 0xffu;  // per-voice bits only are used
         const GainSet* gsp = &fv.gsets[(size_t)voice * FW_GSETS];
         const float g0f = gsp->g[0][ch];
         float gpost[FW_MAX_STAGES - 1];
@@ -252,13 +283,22 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         const uint32_t Dv = active ? D : 0x7fffffffu;
         uint32_t pos_c = active ? pos : 0u, pos_i = pos_c;  // ring position of the tile S3a consumes / the tile requested
         int kli = 0, tli = 0;                               // (block, tile in block) of the next source tile to request
+        int klc = 0, tlc = 0;                               // ... of the tile S1 computes
         v4f xsA[NQ], xsB[NQ], rgA[NQ], rgB[NQ];
         auto issue_src = [&](v4f(&xs)[NQ], int t) {
             const bool real = t < n_tiles && active && !src_zero;
-            const float* p = real ? (const float*)srcp[v][kli] + tli * TT + LF * q : (const float*)dummy;
-            asm volatile("" : "+v"(p));  // one opaque address: the select must not become two conditional loads
+            const uint32_t wr = wrap_at[v][kli];
+            const float* a0 = (const float*)srcp[v][kli];
+            const float* a1 = (const float*)srcp1[v][kli];
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) xs[j] = gload4(p + 4 * j);
+            for (int j = 0; j < NQ; ++j) {
+                const uint32_t f = (uint32_t)(tli * TT + LF * q + 4 * j);
+                // a quad that straddles the wrap point is not fetched here: S1 patches it in when it consumes the tile
+                const bool plain = real && !(f < wr && wr < f + 4u);
+                const float* p = plain ? (f >= wr ? a1 : a0) + f : (const float*)dummy + 4 * j;
+                asm volatile("" : "+v"(p));  // one opaque address: the select must not become conditional loads
+                xs[j] = gload4(p);
+            }
             const bool wrap = tli + 1 == tpb;
             tli = wrap ? 0 : tli + 1;
             kli = (wrap && kli + 1 < K) ? kli + 1 : kli;
@@ -294,6 +334,31 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             // ---- S1 on tile s (steps past the last tile compute on dummy data into a buffer nobody reads)
             {
                 v4f x[NQ];
+                {  // rare: this lane's quad contains the loop's wrap point (once per lap of the loop)
+                    const uint32_t wr = wrap_at[v][klc];
+                    const uint32_t fq = (uint32_t)(tlc * TT + LF * q);
+                    const bool mine = v1 && active && !src_zero && fq < wr && wr < fq + 4u * NQ && (wr & 3u) != 0u;
+                    if (__ballot(mine) != 0ull) {
+                        if (mine) {
+                            const float* a0 = (const float*)srcp[v][klc];
+                            const float* a1 = (const float*)srcp1[v][klc];
+#pragma unroll
+                            for (int j = 0; j < NQ; ++j) {
+                                const uint32_t f = fq + 4u * j;
+                                if (f < wr && wr < f + 4u) {
+                                    v4f t;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) t[e] = (f + e < wr ? a0 : a1)[f + e];
+                                    asm volatile("" : "+v"(t));  // the wait for these loads stays inside the rare path
+                                    xs[j] = t;
+                                }
+                            }
+                        }
+                    }
+                    const bool wrapb = tlc + 1 == tpb;
+                    tlc = wrapb ? 0 : tlc + 1;
+                    klc = (wrapb && klc + 1 < K) ? klc + 1 : klc;
+                }
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) x[j] = src_zero ? splat(0.f) : xs[j] * g0f;  // sampler.rs:530-533
                 float* row = &tile[s & (CH_NBUF - 1)][v][LF * q];

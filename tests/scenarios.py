@@ -399,14 +399,15 @@ def scenario_chain_events(e, n_voices=37, radix=32, src_frames=1000, **kw):
     return np.concatenate(outs)
 
 
-def scenario_chain_steady_calls(e, n_voices=37, tile=128, with_pan=False):
+def scenario_chain_steady_calls(e, n_voices=37, tile=128, with_pan=False, src_extra=0):
     """calls k_chain's steady-call loop accepts (every voice one descriptor shape for the whole call, delays >= 3
     tiles, no message pending) between calls it does not: start-up messages, a burst of pauses / gain changes / a
     mute whose ramps take a few blocks to settle.  Sources are a whole number of blocks long (loops wrap on block
     boundaries), delay lengths are mostly not multiples of 4 (quads straddle the ring end once per lap), some voices
     never start (cleared source through biquad + delay), some samples are mono."""
     mbf = e.max_block_frames
-    voices = build_chain_bank(e, n_voices, radix=32, src_frames=6 * mbf, mono_every=5, with_pan=with_pan,
+    # src_extra != 0: the loops wrap INSIDE blocks (a different frame for every lap), still a steady call
+    voices = build_chain_bank(e, n_voices, radix=32, src_frames=6 * mbf + src_extra, mono_every=5, with_pan=with_pan,
                               first_delay_frames=3 * tile, min_delay_frames=3 * tile + 1, max_delay_frames=3 * tile + 500)
     outs = []
     for v, vc in enumerate(voices):
@@ -424,7 +425,8 @@ def scenario_chain_steady_calls(e, n_voices=37, tile=128, with_pan=False):
         if v % 9 == 5:
             e.set_param(vc["volume"], 0, 0.0)       # ramps to 0, then the port is muted
     outs.append(e.process_blocks(3))                # messages
-    outs.append(e.process_blocks(8))                # ramps settle somewhere in here
+    # a 10 ms smoother needs ~10 time constants (4 800 frames) to come within settle_epsilon of its target
+    outs.append(e.process_blocks((5200 + mbf - 1) // mbf))
     outs.append(e.process_blocks(11))               # steady again, with paused and muted voices
     outs.append(e.process_blocks(5))
     return np.concatenate(outs)

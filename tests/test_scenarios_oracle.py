@@ -71,6 +71,12 @@ CASES = {
     "chain_calls_20_b128_pan": lambda: scenarios.scenario_chain_steady_calls(oracle(max_block_frames=128), 20, tile=128,
                                                                              with_pan=True),
     "chain_calls_33_b64": lambda: scenarios.scenario_chain_steady_calls(oracle(max_block_frames=64), 33, tile=64),
+    "chain_calls_37_b256_wrap": lambda: scenarios.scenario_chain_steady_calls(oracle(max_block_frames=256), 37, tile=128,
+                                                                              src_extra=77),
+    "chain_calls_21_b128_wrap": lambda: scenarios.scenario_chain_steady_calls(oracle(max_block_frames=128), 21, tile=128,
+                                                                              src_extra=130),
+    "chain_calls_33_b64_wrap": lambda: scenarios.scenario_chain_steady_calls(oracle(max_block_frames=64), 33, tile=64,
+                                                                             src_extra=5),
 }
 
 

@@ -75,7 +75,7 @@ def start_voices(cx, fa, samplers, src, frames_per_voice, fmt="f32"):
         node.play()
 
 
-def build_bank(cx, fa, voices, radix, seed=0):
+def build_bank(cx, fa, voices, radix, seed=0, volumes_out=None):
     """cfg2 / cfg5 chain: sampler -> gain -> pan."""
     import numpy as np
 
@@ -90,6 +90,8 @@ def build_bank(cx, fa, voices, radix, seed=0):
             cx.connect(vol, c, pan, c, False)
         samplers.append(s)
         ends.append(pan)
+        if volumes_out is not None:
+            volumes_out.append(vol)
     sum_tree(cx, fa, ends, radix)
     cx.update()
     return samplers
@@ -281,6 +283,9 @@ def main():
     ap.add_argument("--host-buffers", action="store_true",
                     help="time fwgpu_process_interleaved on HOST buffers instead (PCIe-inclusive; DESIGN.md §7 note, "
                          "never the headline)")
+    ap.add_argument("--variant", choices=["A", "B", "C"], default="A",
+                    help="cfg2/cfg5 (SURVEY 8d): A steady; B one gain change per voice at a seeded block of the run "
+                         "(smoother ramps, message path inside the timed region); C every 4th voice paused (silence masks)")
     ap.add_argument("--bus-reduce", choices=["allreduce", "ordered"], default="allreduce",
                     help="N>1: RCCL all-reduce (named path) or all-gather + rank-ordered sum (bit-exact)")
     args = ap.parse_args()
@@ -340,9 +345,24 @@ def main():
         samplers = build_chain_bank(cx, fa, V, args.radix, seed=rank)
         want_plan = 2
     else:
-        samplers = build_bank(cx, fa, V, args.radix, seed=rank)
+        volumes = []
+        samplers = build_bank(cx, fa, V, args.radix, seed=rank, volumes_out=volumes)
         want_plan = 1
     start_voices(cx, fa, samplers, src, F, sfmt)
+    variant = args.variant if wl in ("cfg2", "cfg5") else "A"
+    playing = 1.0
+    changes = {}
+    if variant == "C":
+        for s in samplers[::4]:
+            cx.node(s).pause()
+        playing = 1.0 - len(samplers[::4]) / float(len(samplers))
+    elif variant == "B":  # voice v changes its gain once, at block b_v of timed step s_v
+        import numpy as np
+
+        rng = np.random.default_rng(99 + rank)
+        for v, vol in enumerate(volumes):
+            changes.setdefault(args.warmup + int(rng.integers(0, steps)), []).append(
+                (vol, float(rng.uniform(10, 100)), int(rng.integers(0, K))))
     assert cx.plan_kind() == want_plan, "expected launch plan %d, got %d" % (want_plan, cx.plan_kind())
     # two bus buffers: with N > 1 the reduction of step i (RCCL, its own stream) overlaps the compute of step i+1 —
     # the mix bus is a sink, nothing in a shard reads it back
@@ -357,6 +377,8 @@ def main():
 
     def step():
         b = step_no[0] % 2
+        for vol, pct, at in changes.get(step_no[0], ()):
+            cx.node(vol).set_percent_volume(pct, at_block=at)
         step_no[0] += 1
         if reducer is not None:
             reducer.wait(b)  # the collective that last used this buffer (two steps ago)
@@ -427,7 +449,7 @@ def main():
             # source L+R once (f32: 8 B, i16: 4 B) (+ delay ring read + write)
             per_vs = 24.0 if wl == "cfg3" else (4.0 if sfmt == "i16" else 8.0)
             kernel = "k_chain" if wl == "cfg3" else "k_leaf_sum"
-            alg_bytes = V * B * K * per_vs
+            alg_bytes = V * B * K * per_vs * playing  # paused voices (variant C) fetch nothing
             avg_s = dom_ms / dom_n / 1e3
             ach = alg_bytes / avg_s / 1e9
             traffic, traffic_src = pmc_traffic(kernel, V, B, K) if sfmt == "f32" else (None, None)  # PMC passes ran on f32 sources
@@ -466,7 +488,7 @@ def main():
             "config": {
                 "workload": "%s, block=%d @48kHz, %s sources in HBM (%d frames/voice, looping)"
                             % (desc, B, "planar f32" if sfmt == "f32" else "interleaved stereo i16", F),
-                "voices_per_gpu": V, "block": B, "blocks_per_step": K, "parallelism": "voice-shard x%d%s" %
+                "voices_per_gpu": V, "block": B, "blocks_per_step": K, "variant": variant, "parallelism": "voice-shard x%d%s" %
                 (world, (" + RCCL mix-bus %s" % args.bus_reduce) if world > 1 else ""),
                 "realtime_factor": (total / dt) / (48000.0 * V * world),
                 "device": name, "compute_units": cus,

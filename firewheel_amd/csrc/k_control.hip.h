@@ -68,7 +68,10 @@ struct StageRegs {  // the NodeState prefix (p0,p1,s0,s1) a gain stage needs
 
 // Serial ramp -> global memory; returns false (and writes nothing) when the recurrence is already at its
 // f32 fixed point (Q28: an Active smoother can stall above settle_epsilon forever) — the block is constant.
-__device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, float* dst1, bool write) {
+// The smoother recurrence (core/param/smoother.rs:169-175: out[i] = in*a + out[i-1]*b, two roundings) is serial, so
+// every lane of the voice's wave runs it redundantly; lane l keeps the values of frames l, l+64, ... and the wave
+// stores 64 frames at a time (a single lane storing element by element made a ramp block cost ~6 us).
+__device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, float* dst1, int lane) {
     float prev = r.prev;
     float v0 = r.in_a + (prev * r.b);
     if (v0 == prev) {  // fixed point: every later value equals prev, bit for bit
@@ -76,11 +79,24 @@ __device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, f
         r.ramp = 0;
         return false;
     }
-    for (int i = 0; i < frames; ++i) {
-        prev = r.in_a + (prev * r.b);
-        if (write) {
-            dst0[i] = prev;
-            if (dst1) dst1[i] = prev;
+    for (int i0 = 0; i0 < frames; i0 += WAVE) {
+        float mine = 0.f;
+        const int n = frames - i0 < WAVE ? frames - i0 : WAVE;
+        if (n == WAVE) {
+#pragma unroll 16
+            for (int i = 0; i < WAVE; ++i) {
+                prev = r.in_a + (prev * r.b);
+                mine = i == lane ? prev : mine;
+            }
+        } else {
+            for (int i = 0; i < n; ++i) {
+                prev = r.in_a + (prev * r.b);
+                mine = i == lane ? prev : mine;
+            }
+        }
+        if (lane < n) {
+            dst0[i0 + lane] = mine;
+            if (dst1) dst1[i0 + lane] = mine;
         }
     }
     r.prev = prev;
@@ -150,6 +166,14 @@ __device__ inline int last_cmd_block(const Cmd* cmds, int n_cmds, int state_idx,
     }
     if (lo == 0 || cmds[lo - 1].state != state_idx) return -1;
     return (int)(cmds[lo - 1].block - cmd_block0);  // sorted by (state, block): the last one is the latest
+}
+
+// first block index (relative to this call, >= 0) that has a message for node `state_idx`; INT_MAX if none
+__device__ inline int first_cmd_block(const Cmd* cmds, int n_cmds, int state_idx, uint32_t cmd_block0) {
+    if (n_cmds == 0) return 0x7fffffff;
+    const int i = chain_cmd_lower_bound(cmds, n_cmds, state_idx, cmd_block0);
+    if (i >= n_cmds || cmds[i].state != state_idx) return 0x7fffffff;
+    return (int)(cmds[i].block - cmd_block0);
 }
 
 // Everything the steady tail of a call needs: the descriptor all its blocks share and how the playhead moves.
@@ -364,22 +388,32 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
         if (w0) fv.chain_start[vi] = cs;
     }
 
-    int last_cmd = -1;
+    int last_cmd = -1, first_cmd = 0x7fffffff;
     if (fv.n_cmds) {
         last_cmd = last_cmd_block(fv.cmds, fv.n_cmds, vd.sampler_state, cmd_block0);
+        first_cmd = first_cmd_block(fv.cmds, fv.n_cmds, vd.sampler_state, cmd_block0);
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
             if (j < vd.n_stages) {
                 int l = last_cmd_block(fv.cmds, fv.n_cmds, vd.stage_state[j], cmd_block0);
                 last_cmd = l > last_cmd ? l : last_cmd;
+                int f = first_cmd_block(fv.cmds, fv.n_cmds, vd.stage_state[j], cmd_block0);
+                first_cmd = f < first_cmd ? f : first_cmd;
             }
     }
     GainSet* my_gsets = fv.gsets + (size_t)vi * FW_GSETS;
 
-    // ---- fast path: still steady from the previous call
+    // ---- fast path: still steady from the previous call, up to the voice's first message of this call (a call may
+    // span hundreds of blocks: walking them one by one to reach a message at block 400 would take milliseconds)
+    int k0 = 0;              // the general path starts here
+    uint64_t k0_playhead = 0;
+    bool k0_moved = false;   // the sampler's playhead advanced in the steady blocks (a playing voice)
+    bool k0_gset = false;    // gain set 0 of this call already holds the steady gains
+    GainSet k0_gs;
     {
         const VoiceCache vc = fv.cache[vi];
-        if (vc.epoch == fv.epoch && last_cmd < 0) {
+        const int Kp = first_cmd < K ? first_cmd : K;  // blocks [0, Kp) are steady
+        if (vc.epoch == fv.epoch && Kp > 0) {
             TailJob job;
             job.mode = vc.mode;
             job.flags = vc.flags;
@@ -398,22 +432,30 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                 job.loop_start = sp->loop_start;
                 job.loop_end = sp->loop_end;
                 sd = fv.samples[vc.sample];
-                if (vc.mode == 2 && job.playhead + (uint64_t)K * (uint64_t)frames > sd.frames) ok = false;  // ends in this call
+                if (vc.mode == 2 && job.playhead + (uint64_t)Kp * (uint64_t)frames > sd.frames) ok = false;  // ends in these blocks
             }
             if (ok) {
                 const bool no_src = (job.flags & VB_SRC_ZERO) || (!fx && (job.flags & VB_SILENT));
                 const bool simple_ok = no_src ? (fx && simple_frames)
                                               : (job.sample >= 0 && simple_frames && simple_capable(sd, fx));
                 if (simple_ok && w0) my_gsets[0] = job.g;
-                uint64_t ph = steady_tail(fv, vi, lane, 0, K, job, sd, 0u, simple_ok, fx);
-                if (w0 && vc.mode != 0) fv.states[vd.sampler_state].playhead = ph;
-                return;
+                uint64_t ph = steady_tail(fv, vi, lane, 0, Kp, job, sd, 0u, simple_ok, fx);
+                if (Kp == K) {
+                    if (w0 && vc.mode != 0) fv.states[vd.sampler_state].playhead = ph;
+                    return;
+                }
+                k0 = Kp;  // nothing but the playhead moved in the steady blocks: the general path takes over at Kp
+                k0_playhead = ph;
+                k0_moved = vc.mode != 0;
+                k0_gset = simple_ok;
+                k0_gs = job.g;
             }
         }
     }
 
     // ---- general path
     NodeState ss = fv.states[vd.sampler_state];
+    if (k0_moved) ss.playhead = k0_playhead;
     StageRegs st[FW_MAX_STAGES - 1];
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
@@ -424,6 +466,10 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
     GainSet cur_gs;
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES; ++j) cur_gs.g[j][0] = cur_gs.g[j][1] = 0.f;
+    if (k0_gset) {
+        n_gsets = 1;
+        cur_gs = k0_gs;
+    }
     // picks (or allocates) the gain set of a VB_SIMPLE block; wave-uniform.  Returns its index.
     auto pick_gset = [&](VoiceBlk& d) -> uint32_t {
         if (!(d.flags & VB_SIMPLE)) return 0u;
@@ -454,7 +500,7 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
     sd.format = FMT_P_F32;
     bool became_steady = false;
 
-    for (int k = 0; k < K; ++k) {
+    for (int k = k0; k < K; ++k) {
         const uint32_t cb = cmd_block0 + k;
         VoiceBlk d;
         d.flags = 0;
@@ -468,7 +514,10 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
         float* ramp_base = fv.ramps + ((size_t)k * fv.n_voices + vi) * (size_t)fv.ramp_slots * (size_t)fv.stride;
 
         // ---- sampler (nodes/sampler.rs:323-561)
-        apply_cmds(ss, vd.sampler_state, cb, fv.cmds, fv.n_cmds, fv.samples);
+        // past the voice's last message of the call there is nothing to look up (each lookup is a chain of dependent
+        // global loads: ~1 us apiece, every block of a ramp)
+        const int n_cmds_k = k <= last_cmd ? fv.n_cmds : 0;
+        apply_cmds(ss, vd.sampler_state, cb, fv.cmds, n_cmds_k, fv.samples);
         bool silent = true;
         if (ss.sample >= 0 && ss.playing) {
             GainRun run = smoother_begin(ss.s0, ss.p0, frames);
@@ -480,7 +529,7 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                 Fetch ft;
                 bool ok = sampler_advance(ss, sd.frames, (uint32_t)frames, ft);
                 if (run.ramp) {
-                    if (ramp_emit(run, frames, ramp_base, ramp_base + fv.stride, w0)) {
+                    if (ramp_emit(run, frames, ramp_base, ramp_base + fv.stride, lane)) {
                         d.flags |= 3u << VB_RAMP_SHIFT;
                         ss.s0.last = run.prev;
                     }
@@ -506,11 +555,11 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
             if (j >= vd.n_stages) break;
             StageRegs& r = st[j];
-            if (fv.n_cmds) {  // messages for this node (only p0/p1 apply to gain stages)
+            if (n_cmds_k) {  // messages for this node (only p0/p1 apply to gain stages)
                 NodeState tmp;
                 tmp.p0 = r.p0;
                 tmp.p1 = r.p1;
-                apply_cmds(tmp, vd.stage_state[j], cb, fv.cmds, fv.n_cmds, fv.samples);
+                apply_cmds(tmp, vd.stage_state[j], cb, fv.cmds, n_cmds_k, fv.samples);
                 r.p0 = tmp.p0;
                 r.p1 = tmp.p1;
             }
@@ -523,7 +572,7 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                     if (!smoother_is_smoothing(r.s0) && run.c < 0.00001f) {
                         silent = true;
                     } else {
-                        if (run.ramp && ramp_emit(run, frames, rb, rb + fv.stride, w0)) {
+                        if (run.ramp && ramp_emit(run, frames, rb, rb + fv.stride, lane)) {
                             d.flags |= 3u << (VB_RAMP_SHIFT + 2 * (j + 1));
                             r.s0.last = run.prev;
                         }
@@ -537,11 +586,11 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                 } else {
                     GainRun rl = smoother_begin(r.s0, r.p0, frames);
                     GainRun rr = smoother_begin(r.s1, r.p1, frames);
-                    if (rl.ramp && ramp_emit(rl, frames, rb, nullptr, w0)) {
+                    if (rl.ramp && ramp_emit(rl, frames, rb, nullptr, lane)) {
                         d.flags |= 1u << (VB_RAMP_SHIFT + 2 * (j + 1));
                         r.s0.last = rl.prev;
                     }
-                    if (rr.ramp && ramp_emit(rr, frames, rb + fv.stride, nullptr, w0)) {
+                    if (rr.ramp && ramp_emit(rr, frames, rb + fv.stride, nullptr, lane)) {
                         d.flags |= 2u << (VB_RAMP_SHIFT + 2 * (j + 1));
                         r.s1.last = rr.prev;
                     }

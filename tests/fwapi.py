@@ -306,6 +306,18 @@ def xorshift_uniform(seed, n):
     return (rng.random(n, dtype=np.float32) * 2.0 - 1.0).astype(np.float32)
 
 
+class _DeviceResult(object):
+    """interleaved output of an asynchronous process call; converts to numpy (after a sync) on first use"""
+
+    def __init__(self, cx, buf):
+        self.cx, self.buf = cx, buf
+
+    def __array__(self, dtype=None, copy=None):
+        self.cx.synchronize()
+        a = self.buf.cpu().numpy()
+        return a if dtype is None else a.astype(dtype)
+
+
 class GpuEngine(Engine):
     """Same surface as OracleEngine, through the product's C ABI (firewheel_amd -> libfwgpu.so)."""
 
@@ -393,6 +405,15 @@ class GpuEngine(Engine):
         return self.cx.process_interleaved(inp, n_in_ch, n_out_ch, frames, t, status)
 
     def process_blocks(self, k, n_out_ch=2):
+        if getattr(self, "async_device", False):
+            # the throughput form of the call: output left in HBM, NO host sync between calls; read back when the
+            # result is first looked at
+            import torch
+
+            buf = torch.empty(k * self.max_block_frames * n_out_ch, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()  # the allocator's stream is not the ctx stream
+            self.cx.process_blocks_device(k, buf.data_ptr(), n_out_ch)
+            return _DeviceResult(self.cx, buf)
         return self.process_interleaved(k * self.max_block_frames, n_out_ch)
 
     def node_process(self, node, frames, inputs, n_out, in_mask=0, out_mask=0, out_init=None):

@@ -879,3 +879,22 @@ def test_plain_c_host_through_the_c_abi_matches_oracle(voices, block, callbacks,
     got = np.fromfile(path, dtype=np.float32)
     want = _c_host_reference(oracle(max_block_frames=block), voices, block, callbacks)
     assert_bits_equal(want, got, "plain C host %dx%d" % (voices, block))
+
+
+@pytest.mark.parametrize("name", ["events_70", "events_33_r2", "chain_events_37", "chain_calls_37_b256_wrap",
+                                  "chain_calls_33_b64", "steady_96x32"])
+@pytest.mark.parametrize("max_batch", [64, 2])
+def test_async_device_calls_back_to_back_bit_exact(name, max_batch):
+    # the throughput form of the call (fwgpu_process_blocks_device: output left in HBM) back to back with no host sync
+    # in between, message bursts included: the stream must come out exactly as through the synchronous host-buffer form
+    class AsyncEngine(GpuEngine):
+        async_device = True
+
+    saved = fwapi.GpuEngine
+    try:
+        globals()["GpuEngine"] = AsyncEngine
+        out_o, out_g, g = run_case(name, max_batch=max_batch)
+    finally:
+        globals()["GpuEngine"] = saved
+    assert g.cx.plan_kind() in (1, 2)
+    assert_bits_equal(out_o, np.asarray(out_g), name + " async K<=%d" % max_batch)

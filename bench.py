@@ -283,6 +283,8 @@ def main():
     ap.add_argument("--host-buffers", action="store_true",
                     help="time fwgpu_process_interleaved on HOST buffers instead (PCIe-inclusive; DESIGN.md §7 note, "
                          "never the headline)")
+    ap.add_argument("--force-generic", action="store_true",
+                    help="run the workload on the generic level-batched executor (plan 0) instead of its fused plan")
     ap.add_argument("--variant", choices=["A", "B", "C"], default="A",
                     help="cfg2/cfg5 (SURVEY 8d): A steady; B one gain change per voice at a seeded block of the run "
                          "(smoother ramps, message path inside the timed region); C every 4th voice paused (silence masks)")
@@ -329,6 +331,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     cx = fa.FirewheelGpuCtx(48000, B, 0, 2, device=local_rank, stream=stream)
     cx.set_max_batch(K)
+    if args.force_generic:
+        cx.set_force_generic(True)
     # synthetic sources, generated in HBM: uniform(-1,1) f32, seed offset by global voice id
     g = torch.Generator(device="cuda")
     g.manual_seed(shard.voice_seed(rank * V))  # stream keyed by the shard's first GLOBAL voice id
@@ -363,6 +367,8 @@ def main():
         for v, vol in enumerate(volumes):
             changes.setdefault(args.warmup + int(rng.integers(0, steps)), []).append(
                 (vol, float(rng.uniform(10, 100)), int(rng.integers(0, K))))
+    if args.force_generic:
+        want_plan = 0
     assert cx.plan_kind() == want_plan, "expected launch plan %d, got %d" % (want_plan, cx.plan_kind())
     # two bus buffers: with N > 1 the reduction of step i (RCCL, its own stream) overlaps the compute of step i+1 —
     # the mix bus is a sink, nothing in a shard reads it back

@@ -455,7 +455,8 @@ def main():
             # source L+R once (f32: 8 B, i16: 4 B) (+ delay ring read + write)
             per_vs = 24.0 if wl == "cfg3" else (4.0 if sfmt == "i16" else 8.0)
             kernel = "k_chain" if wl == "cfg3" else "k_leaf_sum"
-            alg_bytes = V * B * K * per_vs * playing  # paused voices (variant C) fetch nothing
+            k_launch = min(K, 64) if wl == "cfg3" else K  # the chain plan renders at most 64 blocks per k_chain launch
+            alg_bytes = V * B * k_launch * per_vs * playing  # paused voices (variant C) fetch nothing
             avg_s = dom_ms / dom_n / 1e3
             ach = alg_bytes / avg_s / 1e9
             traffic, traffic_src = pmc_traffic(kernel, V, B, K) if sfmt == "f32" else (None, None)  # PMC passes ran on f32 sources

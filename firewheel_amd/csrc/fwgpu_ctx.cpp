@@ -1137,7 +1137,7 @@ int run_blocks(fwgpu_ctx* c, uint64_t frames, const float* d_in, int n_in_ch, fl
     // kernel argument repeats (block counters and playheads live in device state), so the launch sequence is replayed
     // from a hipGraph instead of being re-issued kernel by kernel
     if (stable_out && c->rt_use_graph && can_fuse && !c->timing && c->n_cmds_dev == 0 && frames % mbf == 0 &&
-        frames / mbf <= c->kmax) {
+        frames / mbf <= (c->fused_fx ? std::min<uint32_t>(c->kmax, CH_FAST_KMAX) : c->kmax)) {
         const uint32_t K = (uint32_t)(frames / mbf);
         fwgpu_ctx::RtGraph& g = c->rt_graph;
         if (!g.exec || g.epoch != c->epoch || g.K != K || g.d_out != d_out || g.n_out_ch != n_out_ch) {
@@ -1169,7 +1169,8 @@ int run_blocks(fwgpu_ctx* c, uint64_t frames, const float* d_in, int n_in_ch, fl
     while (done < frames) {
         uint64_t left = frames - done;
         if (can_fuse && left >= mbf) {
-            uint32_t K = (uint32_t)std::min<uint64_t>(left / mbf, c->kmax);
+            const uint32_t kcap = c->fused_fx ? std::min<uint32_t>(c->kmax, CH_FAST_KMAX) : c->kmax;
+            uint32_t K = (uint32_t)std::min<uint64_t>(left / mbf, kcap);
             rc = run_fused_batch(c, (int)K, blk, d_out + done * n_out_ch, n_out_ch);
             if (rc) return rc;
             done += (uint64_t)K * mbf;

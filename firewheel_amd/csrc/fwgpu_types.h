@@ -175,6 +175,9 @@ struct FirRow {  // one GEMM row = one channel of one FIR node
     int out_buf;
 };
 
+#define CH_FAST_KMAX 64  // blocks per k_chain launch its steady-call loop keeps per-block source addresses for (LDS);
+                         // the host never batches more blocks than this into one chain-plan launch
+
 // the root SumNode of a fused plan, passed to k_root_out by value (kernel arguments: scalar loads, no dependent fetch)
 struct RootArgs {
     int n_in, ports;  // ports = n_in / 2 stereo ports (<= 32)

@@ -52,7 +52,6 @@
     do {               \
     } while (0)
 #endif
-#define CH_FAST_KMAX 64  // blocks per call the steady-call loop keeps source addresses for (LDS)
 #define CH_THREADS ((CH_WORKERS + 4) * WAVE)  // 8 workers + serial + mixer + 2 idle waves (see the role map in k_chain)
 typedef float v2f __attribute__((ext_vector_type(2)));
 

@@ -45,6 +45,9 @@ DEFAULTS = {
 }
 
 
+MASTER = [False]  # --master: a master volume + limiter between the root SumNode and graph_out
+
+
 def sum_tree(cx, fa, ends, radix):
     level = ends
     while True:
@@ -59,8 +62,15 @@ def sum_tree(cx, fa, ends, radix):
         level = nxt
         if len(level) == 1:
             break
-    cx.connect(level[0], 0, cx.graph_out_node(), 0, False)
-    cx.connect(level[0], 1, cx.graph_out_node(), 1, False)
+    cur = level[0]
+    if MASTER[0]:
+        for node in (fa.VolumeNode(70.0), fa.HardClipNode(-1.0)):
+            m = cx.add_node(2, 2, node)
+            cx.connect(cur, 0, m, 0, False)
+            cx.connect(cur, 1, m, 1, False)
+            cur = m
+    cx.connect(cur, 0, cx.graph_out_node(), 0, False)
+    cx.connect(cur, 1, cx.graph_out_node(), 1, False)
 
 
 def start_voices(cx, fa, samplers, src, frames_per_voice, fmt="f32"):
@@ -283,6 +293,9 @@ def main():
     ap.add_argument("--host-buffers", action="store_true",
                     help="time fwgpu_process_interleaved on HOST buffers instead (PCIe-inclusive; DESIGN.md §7 note, "
                          "never the headline)")
+    ap.add_argument("--master", action="store_true",
+                    help="put a master VolumeNode + HardClipNode between the root SumNode and graph_out (the fused plans "
+                         "then run that chain with the generic node kernel on the mix bus)")
     ap.add_argument("--force-generic", action="store_true",
                     help="run the workload on the generic level-batched executor (plan 0) instead of its fused plan")
     ap.add_argument("--variant", choices=["A", "B", "C"], default="A",
@@ -291,6 +304,7 @@ def main():
     ap.add_argument("--bus-reduce", choices=["allreduce", "ordered"], default="allreduce",
                     help="N>1: RCCL all-reduce (named path) or all-gather + rank-ordered sum (bit-exact)")
     args = ap.parse_args()
+    MASTER[0] = args.master
     dV, dB, dK, dF, dS = DEFAULTS[args.workload]
     V = args.voices or dV
     B = args.block or dB
@@ -495,7 +509,7 @@ def main():
             "config": {
                 "workload": "%s, block=%d @48kHz, %s sources in HBM (%d frames/voice, looping)"
                             % (desc, B, "planar f32" if sfmt == "f32" else "interleaved stereo i16", F),
-                "voices_per_gpu": V, "block": B, "blocks_per_step": K, "variant": variant, "parallelism": "voice-shard x%d%s" %
+                "voices_per_gpu": V, "block": B, "blocks_per_step": K, "variant": variant, "master_chain": bool(args.master), "parallelism": "voice-shard x%d%s" %
                 (world, (" + RCCL mix-bus %s" % args.bus_reduce) if world > 1 else ""),
                 "realtime_factor": (total / dt) / (48000.0 * V * world),
                 "device": name, "compute_units": cus,

@@ -109,6 +109,9 @@ struct fwgpu_ctx {
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start, d_chain_dummy, d_chain_stats;
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
     std::vector<int> up_level_off, up_level_cnt;
+    int n_tail = 0;  // master chain after the root SumNode (generic node kernel on the mix bus)
+    DevBuf d_tail_nodes, d_tail_in, d_tail_out, d_tail_idx, d_tail_frozen;
+    DevBuf d_frozen;  // generic plan: k_frozen_scan's verdict per plan node, valid for the batch in flight
     int up_root_node = -1;  // index (in the upper-tree node table) of the root SumNode when it is alone on the last level
     RootArgs root_args;     // that node's port table, handed to k_root_out in its kernel arguments
 
@@ -398,6 +401,10 @@ struct FusedBuild {
     std::vector<int> up_in, up_out;
     std::vector<std::vector<int>> up_levels;  // indices into up_nodes per level
     int root_buf[2];
+    // master chain: stereo 2->2 nodes between the root SumNode and graph_out (volume, hard clip, pan, width, biquad,
+    // delay), run by the generic node kernel on the mix bus, one launch each, nearest the root first
+    std::vector<NodeDesc> tail_nodes;
+    std::vector<int> tail_in, tail_out;
     int n_bus = 1;
     int max_stages = 0;
     bool has_fx = false;  // some chain holds a biquad / delay: the k_chain plan
@@ -426,9 +433,20 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
     };
     int root;
     if (!stereo_src(gout, 0, root)) return false;
-    if (plan.nodes[root].kind != K_SUM) return false;
     std::vector<char> covered(N, 0);
     covered[N - 1] = 1;
+    std::vector<int> tail;  // plan indices, graph_out side first
+    while (plan.nodes[root].kind != K_SUM) {
+        const PlanNode& n = plan.nodes[root];
+        const bool master_kind = n.kind == K_VOLUME || n.kind == K_HARD_CLIP || n.kind == K_PAN || n.kind == K_WIDTH ||
+                                 n.kind == K_BIQUAD || n.kind == K_DELAY;
+        if (!master_kind || n.n_in != 2 || n.n_out != 2 || covered[root] || tail.size() >= 16) return false;
+        covered[root] = 1;
+        tail.push_back(root);
+        int src;
+        if (!stereo_src(n, 0, src)) return false;
+        root = src;
+    }
     for (int i = 0; i < N; ++i)
         if (plan.nodes[i].is_graph_io == 1) {
             covered[i] = 1;
@@ -581,6 +599,23 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
         }
     }
     int rb = sums[sum_index[root]].out_buf;
+    for (int j = (int)tail.size() - 1; j >= 0; --j) {  // root side first
+        const PlanNode& n = plan.nodes[tail[j]];
+        NodeDesc nd;
+        memset(&nd, 0, sizeof(nd));
+        nd.kind = n.kind;
+        nd.n_in = nd.n_out = 2;
+        nd.in_off = (int)fb.tail_in.size();
+        nd.out_off = (int)fb.tail_out.size();
+        nd.state = (int)n.slot;
+        fb.tail_in.push_back(rb);
+        fb.tail_in.push_back(rb + 1);
+        rb = next_bus;
+        next_bus += 2;
+        fb.tail_out.push_back(rb);
+        fb.tail_out.push_back(rb + 1);
+        fb.tail_nodes.push_back(nd);
+    }
     fb.root_buf[0] = rb;
     fb.root_buf[1] = rb + 1;
     fb.n_bus = next_bus;
@@ -888,6 +923,17 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
             uflat.insert(uflat.end(), l.begin(), l.end());
         }
         c->up_root_node = (!fb.up_levels.empty() && fb.up_levels.back().size() == 1) ? fb.up_levels.back()[0] : -1;
+        c->n_tail = (int)fb.tail_nodes.size();
+        if (c->n_tail) {
+            c->up_root_node = -1;  // the root's planar result feeds the master chain: no fused root + interleave
+            std::vector<int> idx(c->n_tail);
+            for (int i = 0; i < c->n_tail; ++i) idx[i] = i;
+            if ((rc = upload(c, c->d_tail_nodes, fb.tail_nodes.data(), fb.tail_nodes.size() * sizeof(NodeDesc)))) return rc;
+            if ((rc = upload(c, c->d_tail_in, fb.tail_in.data(), fb.tail_in.size() * sizeof(int)))) return rc;
+            if ((rc = upload(c, c->d_tail_out, fb.tail_out.data(), fb.tail_out.size() * sizeof(int)))) return rc;
+            if ((rc = upload(c, c->d_tail_idx, idx.data(), idx.size() * sizeof(int)))) return rc;
+            HIPC(c, c->d_tail_frozen.ensure((size_t)c->n_tail));
+        }
         if (c->up_root_node >= 0) {
             const NodeDesc& rn = fb.up_nodes[c->up_root_node];
             if (rn.n_out == 2 && rn.n_in >= 2 && rn.n_in <= 64 && rn.n_in % 2 == 0) {
@@ -997,6 +1043,7 @@ DevView generic_view(fwgpu_ctx* c, int frames) {
     v.frames = frames;
     v.cmds = c->d_cmds.as<Cmd>();
     v.n_cmds = c->n_cmds_dev;
+    v.frozen = nullptr;
     return v;
 }
 
@@ -1005,6 +1052,12 @@ DevView generic_view(fwgpu_ctx* c, int frames) {
 int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const float* d_in, int n_in_ch, float* d_out,
                       int n_out_ch) {
     DevView v = generic_view(c, frames);
+    // which gain-like stateful nodes cannot change during this batch (their blocks then run in parallel): decided once,
+    // before the first level
+    if (K > 1 && c->d_frozen.ensure((size_t)c->plan.nodes.size()) == hipSuccess) {
+        LCHK(c, launch_frozen_scan(c->stream, v, (int)c->plan.nodes.size(), cmd_block, K, c->d_frozen.as<uint8_t>()));
+        v.frozen = c->d_frozen.as<uint8_t>();
+    }
     if (c->n_gin_bufs > 0)
         LCHK(c, launch_graph_in(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride,
                                 c->d_gin_bufs.as<int>(), c->n_gin_bufs, d_in, d_in ? n_in_ch : 0, frames, K));
@@ -1104,6 +1157,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         v.frames = (int)c->mbf;
         v.cmds = nullptr;
         v.n_cmds = 0;
+        v.frozen = nullptr;
         // the root SumNode is fused with read_graph_outputs + interleave_stereo when the stream is stereo
         const bool fuse_root = c->up_root_node >= 0 && n_out_ch == 2;
         const size_t n_levels = c->up_level_cnt.size() - (fuse_root ? 1 : 0);
@@ -1114,6 +1168,30 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
             timer_end(c, e1);
             return 0;
         }
+    }
+    if (c->n_tail) {  // master chain on the mix bus: the generic node kernel, K-batched, one launch per node
+        DevView v;
+        v.nodes = c->d_tail_nodes.as<NodeDesc>();
+        v.in_buf = c->d_tail_in.as<int>();
+        v.out_buf = c->d_tail_out.as<int>();
+        v.states = c->d_states.as<NodeState>();
+        v.samples = c->d_samples.as<SampleDesc>();
+        v.ext = c->d_ext.as<float>();
+        v.rs_table = c->d_rs_table.as<float>();
+        v.pool = fv.bus;
+        v.flags = fv.bus_flags;
+        v.pool_blk_stride = fv.bus_blk_stride;
+        v.flags_blk_stride = fv.bus_flags_blk_stride;
+        v.stride = c->stride;
+        v.frames = (int)c->mbf;
+        v.cmds = fv.cmds;
+        v.n_cmds = fv.n_cmds;
+        v.frozen = nullptr;
+        if (K > 1) {
+            LCHK(c, launch_frozen_scan(c->stream, v, c->n_tail, cmd_block0, K, c->d_tail_frozen.as<uint8_t>()));
+            v.frozen = c->d_tail_frozen.as<uint8_t>();
+        }
+        for (int j = 0; j < c->n_tail; ++j) LCHK(c, launch_level(c->stream, v, c->d_tail_idx.as<int>() + j, 1, K, cmd_block0));
     }
     LCHK(c, launch_graph_out(c->stream, fv.bus, fv.bus_flags, c->stride, fv.bus_blk_stride, fv.bus_flags_blk_stride,
                              c->d_root_bufs.as<int>(), 2, d_out, n_out_ch, (int)c->mbf, K));
@@ -1295,7 +1373,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
                       &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
                       &c->d_bus, &c->d_bus_flags, &c->d_chain_start, &c->d_chain_dummy, &c->d_chain_stats, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
-                      &c->d_root_bufs, &c->d_fir_rows, &c->d_fir_tiles, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
+                      &c->d_root_bufs, &c->d_tail_nodes, &c->d_tail_in, &c->d_tail_out, &c->d_tail_idx, &c->d_tail_frozen, &c->d_frozen, &c->d_fir_rows, &c->d_fir_tiles, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask};
     for (DevBuf* b : bufs) b->release();
     for (TimerCat& t : c->timers)

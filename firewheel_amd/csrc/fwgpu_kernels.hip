@@ -48,6 +48,11 @@ int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int 
     hipLaunchKernelGGL(k_level, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0);
     return (int)hipGetLastError();
 }
+int launch_frozen_scan(hipStream_t s, const DevView& v, int n_nodes, uint32_t cmd_block0, int K, uint8_t* d_frozen) {
+    if (n_nodes <= 0) return 0;
+    hipLaunchKernelGGL(k_frozen_scan, dim3((n_nodes + 255) / 256), dim3(256), 0, s, v, n_nodes, cmd_block0, (uint32_t)K, d_frozen);
+    return (int)hipGetLastError();
+}
 int launch_bus_sum(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, int n_out) {
     if (n_nodes <= 0) return 0;
     dim3 grid(n_nodes, K, n_out);

@@ -95,6 +95,19 @@ __device__ __forceinline__ uint64_t sat_round_u64(double x) {  // `(x).round() a
     return (uint64_t)r;
 }
 
+// first command of (state, block) in the (state, block, seq)-sorted list
+__device__ inline int chain_cmd_lower_bound(const Cmd* cmds, int n_cmds, int state_idx, uint32_t block) {
+    int lo = 0, hi = n_cmds;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        const Cmd& c = cmds[mid];
+        bool less = c.state < state_idx || (c.state == state_idx && c.block < block);
+        if (less) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
 // Apply every queued message for (state_idx, block) in order.  cmds are sorted by (state, block, seq).
 // nodes/sampler.rs:331-414 (ring drained at the top of process()), volume.rs:92 (atomic load per block).
 __device__ inline void apply_cmds(NodeState& s, int state_idx, uint32_t block, const Cmd* cmds, int n_cmds,

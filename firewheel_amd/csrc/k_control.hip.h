@@ -3,18 +3,6 @@
 #pragma once
 
 // ------------------------------------------------------------------ message lookups shared by the fused plans
-// first command of (state, block) in the (state, block, seq)-sorted list
-__device__ inline int chain_cmd_lower_bound(const Cmd* cmds, int n_cmds, int state_idx, uint32_t block) {
-    int lo = 0, hi = n_cmds;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        const Cmd& c = cmds[mid];
-        bool less = c.state < state_idx || (c.state == state_idx && c.block < block);
-        if (less) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
 // Both helpers return by value and are force-inlined: a by-reference out-parameter of a real call would pin the
 // caller's loop-carried registers to scratch memory (a scratch load per step, draining vmcnt with it).
 struct ChainCoefs {

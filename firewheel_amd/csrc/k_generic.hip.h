@@ -35,7 +35,7 @@ __device__ __forceinline__ bool kind_is_stateful(int kind) {
     return kind == K_VOLUME || kind == K_SAMPLER || kind == K_BEEP || kind == K_PAN || kind == K_HARD_CLIP ||
            kind == K_WIDTH || kind == K_BIQUAD || kind == K_DELAY || kind == K_RESAMPLER || kind == K_SPATIAL;
 }
-__device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, uint32_t cmd_block) {
+__device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, uint32_t cmd_block, bool store_state = true) {
     const NodeDesc nd = v.nodes[node_idx];
     if (nd.is_graph_io || nd.kind == K_FIR) return;  // I/O edges (k_graph_in/out); FIR banks run as MFMA GEMMs
     const int lane = threadIdx.x & (WAVE - 1);
@@ -479,19 +479,80 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
         default: break;
     }
 
-    if (stateful && lane == 0) v.states[nd.state] = s;
+    if (stateful && store_state && lane == 0) v.states[nd.state] = s;
     // schedule.rs:338-341: every output buffer's flag is overwritten with the node's out mask bit
     if (lane < nd.n_out) io.flags[io.out_buf[lane]] = mask_bit(out_mask, lane) ? 1 : 0;
 }
 
+// ---- "frozen" nodes.  Volume / pan / width / hard clip carry state (smoothers, a threshold) but their audio is
+// stateless: when no message for the node falls into the batch and every smoother rests on its target, nothing about
+// the node can change from block to block, and its K blocks are as independent as a stateless node's.  Decided ONCE per
+// batch, before the first level, from the state as the batch finds it (a decision taken inside k_level would race with
+// the wave that walks a non-frozen node).  The one thing that still moves — an all-silent block resets a Deactivating
+// smoother to Inactive, same values (smoother.rs:115-129, volume.rs:94-99) — is patched by the node's block-0 wave.
+__device__ __forceinline__ bool smoother_at_rest(const Smoother& s, float target) {
+    return s.status != SM_ACTIVE && s.input == target;
+}
+__global__ void k_frozen_scan(DevView v, int n_nodes, uint32_t cmd_block0, uint32_t K, uint8_t* __restrict__ frozen) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const NodeDesc nd = v.nodes[i];
+    bool fz = false;
+    if (!nd.is_graph_io && (nd.kind == K_VOLUME || nd.kind == K_PAN || nd.kind == K_WIDTH || nd.kind == K_HARD_CLIP)) {
+        bool has_cmd = false;
+        if (v.n_cmds) {
+            const int c = chain_cmd_lower_bound(v.cmds, v.n_cmds, nd.state, cmd_block0);
+            has_cmd = c < v.n_cmds && v.cmds[c].state == nd.state && v.cmds[c].block < cmd_block0 + K;
+        }
+        if (!has_cmd) {
+            const NodeState& s = v.states[nd.state];
+            switch (nd.kind) {
+                case K_HARD_CLIP: fz = true; break;
+                // volume.rs:104: a gain below 1e-5 is a mute only while the smoother is Inactive — keep such a node
+                // on the serial path while it is Deactivating (the status matters there)
+                case K_VOLUME: fz = smoother_at_rest(s.s0, s.p0) && (s.s0.status == SM_INACTIVE || !(s.s0.input < 0.00001f)); break;
+                case K_WIDTH: fz = smoother_at_rest(s.s0, s.p0); break;
+                default: fz = smoother_at_rest(s.s0, s.p0) && smoother_at_rest(s.s1, s.p1); break;  // K_PAN
+            }
+        }
+    }
+    frozen[i] = fz ? 1 : 0;
+}
+// block-0 wave of a frozen node: if some block of the batch had every input silent, its smoothers were reset
+__device__ void frozen_finish(const DevView& v, int node_idx, uint32_t K) {
+    const NodeDesc nd = v.nodes[node_idx];
+    if (nd.kind == K_HARD_CLIP) return;
+    NodeState s = v.states[nd.state];
+    if (s.s0.status != SM_DEACTIVATING && !(nd.kind == K_PAN && s.s1.status == SM_DEACTIVATING)) return;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int* in_buf = v.in_buf + nd.in_off;
+    bool any = false;
+    for (uint32_t b = lane; b < K; b += WAVE) {
+        const uint8_t* fl = v.flags + (size_t)b * v.flags_blk_stride;
+        bool all = true;
+        for (int c = 0; c < nd.n_in; ++c) all = all && fl[in_buf[c]] != 0;
+        any = any || all;
+    }
+    if (__ballot(any) == 0ull) return;
+    smoother_reset(s.s0, s.p0);
+    if (nd.kind == K_PAN) smoother_reset(s.s1, s.p1);
+    if (lane == 0) v.states[nd.state] = s;
+}
+
 // K blocks per launch (gridDim.y = K, one pool slice per block).  A node whose audio half carries state from block
-// to block is run by ONE wave that walks its K blocks in order; stateless nodes take their K blocks in parallel.
+// to block is run by ONE wave that walks its K blocks in order; stateless nodes — and frozen ones — take their K
+// blocks in parallel.
 __global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __restrict__ level_nodes, int n_nodes,
                                                       uint32_t cmd_block0) {
     int w = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (w >= n_nodes) return;
     const int node = level_nodes[w];
     if (kind_is_stateful(v.nodes[node].kind)) {
+        if (v.frozen && v.frozen[node]) {
+            node_process_wave(v, node, blockIdx.y, cmd_block0 + blockIdx.y, false);
+            if (blockIdx.y == 0) frozen_finish(v, node, gridDim.y);
+            return;
+        }
         if (blockIdx.y != 0) return;
         for (uint32_t b = 0; b < gridDim.y; ++b) node_process_wave(v, node, b, cmd_block0 + b);
     } else {

@@ -12,8 +12,21 @@ def voice_source(seed, frames, channels=2):
     return fwapi.xorshift_uniform(0xF1EE0000 + seed, channels * frames).reshape(channels, frames)
 
 
+def connect_through_master(e, root, master):
+    """root -> master[0] -> master[1] ... -> graph_out; `master` = callables creating stereo 2->2 nodes.  Returns the nodes."""
+    made = []
+    cur = root
+    for mk in master:
+        n = mk(e)
+        e.connect_stereo(cur, n)
+        made.append(n)
+        cur = n
+    e.connect_stereo(cur, e.graph_out_node)
+    return made
+
+
 def build_voice_bank(e, n_voices, radix=32, src_frames=4096, with_pan=True, with_volume=True, seed=0, fmt=PLANAR_F32,
-                     mono_every=0, fmt_cycle=None):
+                     mono_every=0, fmt_cycle=None, master=()):
     """config-2 shape: V x (sampler -> volume -> pan) -> radix-`radix` SumNode tree -> graph_out."""
     rng = np.random.default_rng(1234 + seed)
     voices = []
@@ -45,7 +58,7 @@ def build_voice_bank(e, n_voices, radix=32, src_frames=4096, with_pan=True, with
         level = nxt
         if len(level) == 1:
             break
-    e.connect_stereo(level[0], e.graph_out_node)
+    voices[0]["master"] = connect_through_master(e, level[0], master)
     e.update()
     for v, vc in enumerate(voices):
         ch = 1 if (mono_every and v % mono_every == 0) else 2
@@ -286,7 +299,8 @@ def scenario_cfg3_chain(e, n_voices=12, blocks=10, radix=4, src_frames=3000):
 
 
 def build_chain_bank(e, n_voices, radix=32, src_frames=3000, biquad=True, delay=True, with_pan=False, seed=0,
-                     fmt=PLANAR_F32, mono_every=0, min_delay_frames=64, max_delay_frames=900, first_delay_frames=64):
+                     fmt=PLANAR_F32, mono_every=0, min_delay_frames=64, max_delay_frames=900, first_delay_frames=64,
+                     master=()):
     """config-3 shape: V x (sampler -> biquad LPF -> delay -> gain [-> pan]) -> radix sum tree -> out.
     The shape the fused chain plan (k_chain) accepts; delays are >= one 64-frame tile."""
     rng = np.random.default_rng(4321 + seed)
@@ -325,7 +339,7 @@ def build_chain_bank(e, n_voices, radix=32, src_frames=3000, biquad=True, delay=
         level = nxt
         if len(level) == 1:
             break
-    e.connect_stereo(level[0], e.graph_out_node)
+    voices[0]["master"] = connect_through_master(e, level[0], master)
     e.update()
     for v, vc in enumerate(voices):
         ch = 1 if (mono_every and v % mono_every == 0) else 2
@@ -428,6 +442,40 @@ def scenario_chain_steady_calls(e, n_voices=37, tile=128, with_pan=False, src_ex
     # a 10 ms smoother needs ~10 time constants (4 800 frames) to come within settle_epsilon of its target
     outs.append(e.process_blocks((5200 + mbf - 1) // mbf))
     outs.append(e.process_blocks(11))               # steady again, with paused and muted voices
+    outs.append(e.process_blocks(5))
+    return np.concatenate(outs)
+
+
+def scenario_master_chain(e, chain=False, n_voices=45):
+    """the usual application shape: a voice bank under a sum tree, then a master chain on the mix bus (filter, delay,
+    master volume, limiter) before graph_out — with automation on the master volume and the delay mix while voices
+    start, pause and change gain underneath."""
+    master = (lambda e: e.biquad(0, 9000.0, 0.707), lambda e: e.delay(333 / float(e.sample_rate), feedback=0.25, mix=0.2),
+              lambda e: e.volume(80.0), lambda e: e.hard_clip(-3.0))
+    if chain:
+        voices = build_chain_bank(e, n_voices, radix=32, src_frames=1300, mono_every=6, master=master)
+    else:
+        voices = build_voice_bank(e, n_voices, radix=8, src_frames=1300, mono_every=6, master=master)
+    m_bq, m_dl, m_vol, m_clip = voices[0]["master"]
+    outs = []
+    for v, vc in enumerate(voices):
+        e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        if v % 5 != 2:
+            e.sampler_play(vc["sampler"])
+    outs.append(e.process_blocks(3))
+    outs.append(e.process_blocks(4))                  # steady
+    e.set_param(m_vol, 0, 140.0, at_block=1)          # master volume up: the limiter starts to clip
+    e.set_param(m_dl, 2, 0.6, at_block=2)             # master delay mix
+    for v, vc in enumerate(voices):
+        if v % 5 == 2:
+            e.sampler_play(vc["sampler"], at_block=1)
+        if v % 7 == 3:
+            e.set_param(vc["volume"], 0, 15.0, at_block=2)
+    outs.append(e.process_blocks(6))
+    outs.append(e.process_blocks(9))
+    e.set_param(m_vol, 0, 0.0)                        # master fader down: ramps to silence, then a muted bus
+    outs.append(e.process_blocks(30))
+    e.set_param(m_vol, 0, 70.0)
     outs.append(e.process_blocks(5))
     return np.concatenate(outs)
 

@@ -224,6 +224,8 @@ def run_case(name, **gpu_kw):
         "chain_calls_37_b256_wrap": lambda e: scenarios.scenario_chain_steady_calls(e, 37, tile=128, src_extra=77),
         "chain_calls_21_b128_wrap": lambda e: scenarios.scenario_chain_steady_calls(e, 21, tile=128, src_extra=130),
         "chain_calls_33_b64_wrap": lambda e: scenarios.scenario_chain_steady_calls(e, 33, tile=64, src_extra=5),
+        "master_chain_bank": scenarios.scenario_master_chain,
+        "master_chain_fx": lambda e: scenarios.scenario_master_chain(e, chain=True, n_voices=37),
         "cfg4_reverb": scenarios.scenario_cfg4_reverb,
         "cfg4_reverb_2irs_mono": lambda e: scenarios.scenario_cfg4_reverb(e, n_voices=5, taps=700, shared_ir=False,
                                                                           ir_channels=1),
@@ -235,7 +237,7 @@ def run_case(name, **gpu_kw):
            "chain_steady_dl_only_pan": 128, "chain_events_37": 128, "chain_events_19_r2_pan": 64,
            "chain_steady_40_d128": 256, "chain_events_37_d130": 128, "chain_events_21_d256": 256, "chain_calls_37_b256": 256, "chain_calls_20_b128_pan": 128,
            "chain_calls_33_b64": 64, "chain_calls_37_b256_wrap": 256, "chain_calls_21_b128_wrap": 128,
-           "chain_calls_33_b64_wrap": 64, "spatial_scene": 128, "spatial_scene_b96": 96}[name]
+           "chain_calls_33_b64_wrap": 64, "master_chain_bank": 128, "master_chain_fx": 128, "spatial_scene": 128, "spatial_scene_b96": 96}[name]
     kw = dict(max_block_frames=mbf)
     if name == "graph_inputs":
         kw["num_graph_inputs"] = 3
@@ -898,3 +900,18 @@ def test_async_device_calls_back_to_back_bit_exact(name, max_batch):
         globals()["GpuEngine"] = saved
     assert g.cx.plan_kind() in (1, 2)
     assert_bits_equal(out_o, np.asarray(out_g), name + " async K<=%d" % max_batch)
+
+
+@pytest.mark.parametrize("name,plan", [("master_chain_bank", 1), ("master_chain_fx", 2)])
+@pytest.mark.parametrize("max_batch", [64, 5, 1])
+def test_master_chain_after_the_root_keeps_the_fused_plans(name, plan, max_batch):
+    # voice bank -> sum tree -> master biquad / delay / volume / limiter -> graph_out: the fused plans run the tree, the
+    # generic node kernel runs the master chain on the mix bus (K-batched); automation on master nodes included
+    out_o, out_g, g = run_case(name, max_batch=max_batch)
+    assert g.cx.plan_kind() == plan
+    assert_bits_equal(out_o, out_g, name + " K<=%d" % max_batch)
+    gold = json.load(open(GOLDEN))
+    assert digest(out_g) == gold[name]
+    out_o2, out_g2, g2 = run_case(name, force_generic=True)
+    assert g2.cx.plan_kind() == 0
+    assert_bits_equal(out_o2, out_g2, name + " generic")

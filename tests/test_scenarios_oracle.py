@@ -67,6 +67,8 @@ CASES = {
                                                                       min_delay_frames=257, src_frames=1500),
     "chain_events_19_r2_pan": lambda: scenarios.scenario_chain_events(oracle(max_block_frames=64), 19, radix=2, src_frames=777,
                                                                         with_pan=True),
+    "master_chain_bank": lambda: scenarios.scenario_master_chain(oracle(max_block_frames=128)),
+    "master_chain_fx": lambda: scenarios.scenario_master_chain(oracle(max_block_frames=128), chain=True, n_voices=37),
     "chain_calls_37_b256": lambda: scenarios.scenario_chain_steady_calls(oracle(max_block_frames=256), 37, tile=128),
     "chain_calls_20_b128_pan": lambda: scenarios.scenario_chain_steady_calls(oracle(max_block_frames=128), 20, tile=128,
                                                                              with_pan=True),

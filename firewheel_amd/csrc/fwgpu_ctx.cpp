@@ -59,6 +59,12 @@ struct SampleRec {
 
 constexpr size_t RT_IO_BYTES = 256 * 1024;  // realtime path: calls whose interleaved in/out blocks fit (e.g. 16 x 1024 stereo)
 
+// which instantiation of the node kernel runs a kind (mirrors kind_set in k_generic.hip.h)
+static int host_kind_set(int kind) {
+    if (kind == K_SAMPLER) return 2;
+    return (kind == K_BEEP || kind == K_BIQUAD || kind == K_DELAY || kind == K_RESAMPLER || kind == K_SPATIAL) ? 1 : 0;
+}
+
 struct TimerCat {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
@@ -97,6 +103,7 @@ struct fwgpu_ctx {
     // generic plan
     DevBuf d_nodes, d_in_buf, d_out_buf, d_level_nodes, d_pool, d_flags, d_gin_bufs, d_gout_bufs;
     std::vector<int> level_off, level_cnt;
+    std::vector<int> level_kinds;  // bit s: the level holds node kinds of kernel set s (host_kind_set)
     int n_gout_bufs = 0, n_gin_bufs = 0;
 
     // fused plan
@@ -110,7 +117,9 @@ struct fwgpu_ctx {
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
     std::vector<int> up_level_off, up_level_cnt;
     int n_tail = 0;  // master chain after the root SumNode (generic node kernel on the mix bus)
+    std::vector<int> tail_kinds;  // kernel-set bit per master node
     DevBuf d_tail_nodes, d_tail_in, d_tail_out, d_tail_idx, d_tail_frozen;
+    DevBuf d_frozen_ph;  // ... and its playhead snapshots
     DevBuf d_frozen;  // generic plan: k_frozen_scan's verdict per plan node, valid for the batch in flight
     int up_root_node = -1;  // index (in the upper-tree node table) of the root SumNode when it is alone on the last level
     RootArgs root_args;     // that node's port table, handed to k_root_out in its kernel arguments
@@ -778,10 +787,14 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
     std::vector<int> flat;
     c->level_off.clear();
     c->level_cnt.clear();
+    c->level_kinds.clear();
     for (auto& l : levels) {
         c->level_off.push_back((int)flat.size());
         c->level_cnt.push_back((int)l.size());
         flat.insert(flat.end(), l.begin(), l.end());
+        int kinds = 0;
+        for (int i : l) kinds |= 1 << host_kind_set(nd[i].kind);
+        c->level_kinds.push_back(kinds);
     }
     if (flat.empty()) flat.push_back(0);
     if ((rc = upload(c, c->d_level_nodes, flat.data(), flat.size() * sizeof(int)))) return rc;
@@ -924,6 +937,8 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         }
         c->up_root_node = (!fb.up_levels.empty() && fb.up_levels.back().size() == 1) ? fb.up_levels.back()[0] : -1;
         c->n_tail = (int)fb.tail_nodes.size();
+        c->tail_kinds.clear();
+        for (const NodeDesc& t : fb.tail_nodes) c->tail_kinds.push_back(1 << host_kind_set(t.kind));
         if (c->n_tail) {
             c->up_root_node = -1;  // the root's planar result feeds the master chain: no fused root + interleave
             std::vector<int> idx(c->n_tail);
@@ -932,7 +947,7 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
             if ((rc = upload(c, c->d_tail_in, fb.tail_in.data(), fb.tail_in.size() * sizeof(int)))) return rc;
             if ((rc = upload(c, c->d_tail_out, fb.tail_out.data(), fb.tail_out.size() * sizeof(int)))) return rc;
             if ((rc = upload(c, c->d_tail_idx, idx.data(), idx.size() * sizeof(int)))) return rc;
-            HIPC(c, c->d_tail_frozen.ensure((size_t)c->n_tail));
+            HIPC(c, c->d_tail_frozen.ensure((size_t)c->n_tail * 16));  // (also a dummy playhead-snapshot area)
         }
         if (c->up_root_node >= 0) {
             const NodeDesc& rn = fb.up_nodes[c->up_root_node];
@@ -1044,6 +1059,7 @@ DevView generic_view(fwgpu_ctx* c, int frames) {
     v.cmds = c->d_cmds.as<Cmd>();
     v.n_cmds = c->n_cmds_dev;
     v.frozen = nullptr;
+    v.frozen_playhead = nullptr;
     return v;
 }
 
@@ -1054,9 +1070,12 @@ int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const
     DevView v = generic_view(c, frames);
     // which gain-like stateful nodes cannot change during this batch (their blocks then run in parallel): decided once,
     // before the first level
-    if (K > 1 && c->d_frozen.ensure((size_t)c->plan.nodes.size()) == hipSuccess) {
-        LCHK(c, launch_frozen_scan(c->stream, v, (int)c->plan.nodes.size(), cmd_block, K, c->d_frozen.as<uint8_t>()));
+    if (K > 1 && c->d_frozen.ensure((size_t)c->plan.nodes.size()) == hipSuccess &&
+        c->d_frozen_ph.ensure((size_t)c->plan.nodes.size() * sizeof(unsigned long long)) == hipSuccess) {
+        LCHK(c, launch_frozen_scan(c->stream, v, (int)c->plan.nodes.size(), cmd_block, K, c->d_frozen.as<uint8_t>(),
+                                   c->d_frozen_ph.as<unsigned long long>()));
         v.frozen = c->d_frozen.as<uint8_t>();
+        v.frozen_playhead = c->d_frozen_ph.as<unsigned long long>();
     }
     if (c->n_gin_bufs > 0)
         LCHK(c, launch_graph_in(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride,
@@ -1065,7 +1084,8 @@ int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const
     hipEvent_t e0, e1;
     timer_begin(c, 3, &e0, &e1);
     for (size_t l = 0; l < c->level_cnt.size(); ++l) {
-        LCHK(c, launch_level(c->stream, v, c->d_level_nodes.as<int>() + c->level_off[l], c->level_cnt[l], K, cmd_block));
+        LCHK(c, launch_level(c->stream, v, c->d_level_nodes.as<int>() + c->level_off[l], c->level_cnt[l], K, cmd_block,
+                             c->level_kinds[l]));
         for (const fwgpu_ctx::FirGroup& g : c->fir_groups)
             if (g.level == (int)l) {
                 hipEvent_t g0 = nullptr, g1 = nullptr;
@@ -1158,6 +1178,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         v.cmds = nullptr;
         v.n_cmds = 0;
         v.frozen = nullptr;
+        v.frozen_playhead = nullptr;
         // the root SumNode is fused with read_graph_outputs + interleave_stereo when the stream is stereo
         const bool fuse_root = c->up_root_node >= 0 && n_out_ch == 2;
         const size_t n_levels = c->up_level_cnt.size() - (fuse_root ? 1 : 0);
@@ -1187,11 +1208,14 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         v.cmds = fv.cmds;
         v.n_cmds = fv.n_cmds;
         v.frozen = nullptr;
+        v.frozen_playhead = nullptr;  // (no sampler can sit in a master chain)
         if (K > 1) {
-            LCHK(c, launch_frozen_scan(c->stream, v, c->n_tail, cmd_block0, K, c->d_tail_frozen.as<uint8_t>()));
+            LCHK(c, launch_frozen_scan(c->stream, v, c->n_tail, cmd_block0, K, c->d_tail_frozen.as<uint8_t>(),
+                                       c->d_tail_frozen.as<unsigned long long>()));
             v.frozen = c->d_tail_frozen.as<uint8_t>();
         }
-        for (int j = 0; j < c->n_tail; ++j) LCHK(c, launch_level(c->stream, v, c->d_tail_idx.as<int>() + j, 1, K, cmd_block0));
+        for (int j = 0; j < c->n_tail; ++j)
+            LCHK(c, launch_level(c->stream, v, c->d_tail_idx.as<int>() + j, 1, K, cmd_block0, c->tail_kinds[j]));
     }
     LCHK(c, launch_graph_out(c->stream, fv.bus, fv.bus_flags, c->stride, fv.bus_blk_stride, fv.bus_flags_blk_stride,
                              c->d_root_bufs.as<int>(), 2, d_out, n_out_ch, (int)c->mbf, K));
@@ -1373,7 +1397,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
                       &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
                       &c->d_bus, &c->d_bus_flags, &c->d_chain_start, &c->d_chain_dummy, &c->d_chain_stats, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
-                      &c->d_root_bufs, &c->d_tail_nodes, &c->d_tail_in, &c->d_tail_out, &c->d_tail_idx, &c->d_tail_frozen, &c->d_frozen, &c->d_fir_rows, &c->d_fir_tiles, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
+                      &c->d_root_bufs, &c->d_tail_nodes, &c->d_tail_in, &c->d_tail_out, &c->d_tail_idx, &c->d_tail_frozen, &c->d_frozen, &c->d_frozen_ph, &c->d_fir_rows, &c->d_fir_tiles, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask};
     for (DevBuf* b : bufs) b->release();
     for (TimerCat& t : c->timers)

@@ -42,15 +42,20 @@ __device__ __forceinline__ v4f splat(float x) { return (v4f){x, x, x, x}; }
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
 
-int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0) {
+// kinds: bit s = the level holds node kinds of set s (k_generic.hip.h: kind_set) — one launch per set present
+int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0, int kinds) {
     if (n_nodes <= 0) return 0;
     dim3 grid((n_nodes + WPB - 1) / WPB, K);
-    hipLaunchKernelGGL(k_level, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0);
+    if (kinds & 1) hipLaunchKernelGGL(k_level<0>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0);
+    if (kinds & 2) hipLaunchKernelGGL(k_level<1>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0);
+    if (kinds & 4) hipLaunchKernelGGL(k_level<2>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0);
     return (int)hipGetLastError();
 }
-int launch_frozen_scan(hipStream_t s, const DevView& v, int n_nodes, uint32_t cmd_block0, int K, uint8_t* d_frozen) {
+int launch_frozen_scan(hipStream_t s, const DevView& v, int n_nodes, uint32_t cmd_block0, int K, uint8_t* d_frozen,
+                       unsigned long long* d_playhead_snap) {
     if (n_nodes <= 0) return 0;
-    hipLaunchKernelGGL(k_frozen_scan, dim3((n_nodes + 255) / 256), dim3(256), 0, s, v, n_nodes, cmd_block0, (uint32_t)K, d_frozen);
+    hipLaunchKernelGGL(k_frozen_scan, dim3((n_nodes + 255) / 256), dim3(256), 0, s, v, n_nodes, cmd_block0, (uint32_t)K, d_frozen,
+                       d_playhead_snap);
     return (int)hipGetLastError();
 }
 int launch_bus_sum(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, int n_out) {

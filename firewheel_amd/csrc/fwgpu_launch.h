@@ -30,6 +30,7 @@ struct DevView {
     // per node of `nodes` (or nullptr): 1 = a gain-like stateful node whose control state cannot move during this
     // batch — k_level then runs its blocks in parallel (k_frozen_scan, launched once per batch before the levels)
     const uint8_t* frozen;
+    const unsigned long long* frozen_playhead;  // per node: a frozen playing sampler's playhead at the start of the batch
 };
 
 struct FusedView {
@@ -65,8 +66,10 @@ struct FusedView {
                  // 3 skip ring RMW, 4 no ring prefetch
 };
 
-int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0);
-int launch_frozen_scan(hipStream_t s, const DevView& v, int n_nodes, uint32_t cmd_block0, int K, uint8_t* d_frozen);
+int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0,
+                 int kinds = 7);
+int launch_frozen_scan(hipStream_t s, const DevView& v, int n_nodes, uint32_t cmd_block0, int K, uint8_t* d_frozen,
+                       unsigned long long* d_playhead_snap);
 int launch_bus_sum(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, int n_out);
 // the fused plans' root SumNode + read_graph_outputs + interleave_stereo in one launch (stereo output)
 int launch_root_out(hipStream_t s, const DevView& v, const RootArgs& root, float* d_out, int K);

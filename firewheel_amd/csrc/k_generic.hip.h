@@ -35,9 +35,26 @@ __device__ __forceinline__ bool kind_is_stateful(int kind) {
     return kind == K_VOLUME || kind == K_SAMPLER || kind == K_BEEP || kind == K_PAN || kind == K_HARD_CLIP ||
            kind == K_WIDTH || kind == K_BIQUAD || kind == K_DELAY || kind == K_RESAMPLER || kind == K_SPATIAL;
 }
-__device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, uint32_t cmd_block, bool store_state = true) {
+// The node kernel exists in three instantiations, by register appetite: one kernel for every kind needed 248 VGPRs
+// (2 waves per SIMD — nothing to hide HBM latency behind, 0.9 TB/s on a level of volume nodes).  Set 0: the streaming
+// kinds (volume, pan, sum, hard clip, mono<->stereo, width: 127 VGPRs), set 1: serial recurrences / filter banks / libm
+// (beep, biquad, delay, resampler, spatialiser: 147), set 2: the sampler (every sample format, wraps, tails, ramps).
+__device__ __forceinline__ int kind_set(int kind) {
+    if (kind == K_SAMPLER) return 2;
+    return (kind == K_BEEP || kind == K_BIQUAD || kind == K_DELAY || kind == K_RESAMPLER || kind == K_SPATIAL) ? 1 : 0;
+}
+// SET: 0 / 1 / 2 = that set only, 3 = all kinds (single-node entry).
+// adv_blocks: a frozen, playing sampler (k_level) — put its playhead where `adv_blocks` steady blocks leave it first
+template <int SET>
+__device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, uint32_t cmd_block, bool store_state = true,
+                                  uint32_t adv_blocks = 0, bool frozen_sampler = false) {
     const NodeDesc nd = v.nodes[node_idx];
     if (nd.is_graph_io || nd.kind == K_FIR) return;  // I/O edges (k_graph_in/out); FIR banks run as MFMA GEMMs
+    // the other instantiation's kinds return here; their switch cases are compiled out below (`if constexpr`: a case
+    // that is compiled out falls through, which nothing can reach)
+    if constexpr (SET != 3) {
+        if (kind_set(nd.kind) != SET) return;
+    }
     const int lane = threadIdx.x & (WAVE - 1);
     WaveIO io;
     io.pool = v.pool + (size_t)blk * v.pool_blk_stride;
@@ -67,7 +84,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
         case K_DUMMY:  // nodes/dummy.rs:33-42 — writes nothing
             break;
 
-        case K_VOLUME: {  // nodes/volume.rs:84-145
+        case K_VOLUME: if constexpr (SET == 0 || SET == 3) {  // nodes/volume.rs:84-145
             float raw = s.p0;
             if (mask_all(in_mask, nd.n_in)) {  // :94-100
                 smoother_reset(s.s0, raw);
@@ -98,7 +115,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             break;
         }
 
-        case K_PAN: {  // SPEC node: volume.rs stereo path with one smoother per channel
+        case K_PAN: if constexpr (SET == 0 || SET == 3) {  // SPEC node: volume.rs stereo path with one smoother per channel
             float tl = s.p0, tr = s.p1;
             if (mask_all(in_mask, nd.n_in)) {
                 smoother_reset(s.s0, tl);
@@ -123,7 +140,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             break;
         }
 
-        case K_SUM: {  // nodes/sum.rs:41-136
+        case K_SUM: if constexpr (SET == 0 || SET == 3) {  // nodes/sum.rs:41-136
             const int n_in = nd.n_in, n_out = nd.n_out, ports = nd.aux0;
             if (mask_all(in_mask, n_in)) {  // :52-56
                 out_mask = clear_all_outputs(io, 0, n_out);
@@ -169,7 +186,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             break;
         }
 
-        case K_SAMPLER: {  // nodes/sampler.rs:323-561 (messages already applied above)
+        case K_SAMPLER: if constexpr (SET == 2 || SET == 3) {  // nodes/sampler.rs:323-561 (messages already applied above)
             if (s.sample < 0 || !s.playing) {  // :416-430
                 out_mask = clear_all_outputs(io, 0, nd.n_out);
                 break;
@@ -180,6 +197,19 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
                 break;
             }
             const SampleDesc sd = v.samples[s.sample];
+            // the batch-start playhead comes from k_frozen_scan's snapshot: the wave of the batch's last block stores the
+            // advanced state while waves of earlier blocks may not have read theirs yet
+            if (frozen_sampler) s.playhead = v.frozen_playhead[node_idx];
+            if (adv_blocks) {  // closed form of `adv_blocks` steady blocks (sampler.rs:445-484: one wrap per block, L >= frames)
+                const uint64_t adv = (uint64_t)adv_blocks * (uint64_t)frames;
+                if (s.has_loop) {
+                    const uint64_t L = s.loop_end - s.loop_start;
+                    const uint64_t off = s.playhead >= s.loop_end ? 0 : s.playhead - s.loop_start;
+                    s.playhead = s.loop_start + (off + adv) % L;
+                } else {
+                    s.playhead += adv;
+                }
+            }
             Fetch ft;
             if (!sampler_advance(s, sd.frames, (uint32_t)frames, ft)) {  // :486-497
                 if (run.ramp) {  // the smoother already ran this block (:433) — keep its state exact
@@ -219,7 +249,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             break;
         }
 
-        case K_BEEP: {  // nodes/beep_test.rs:71-97
+        case K_BEEP: if constexpr (SET == 1 || SET == 3) {  // nodes/beep_test.rs:71-97
             if (nd.n_out == 0) break;
             if (!s.enabled) {  // :83-86 (Q12): channel 0 untouched, mask = new_all_silent(n-1)
                 out_mask = clear_all_outputs(io, 1, nd.n_out);
@@ -264,7 +294,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             break;
         }
 
-        case K_HARD_CLIP: {  // nodes/hard_clip.rs:51-95
+        case K_HARD_CLIP: if constexpr (SET == 0 || SET == 3) {  // nodes/hard_clip.rs:51-95
             const float t = s.p0;
             const bool fast = nd.n_in == 2 && nd.n_out == 2 && !mask_any(in_mask, 2);  // :60-63 (Q16)
             const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
@@ -284,7 +314,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             break;
         }
 
-        case K_MONO_TO_STEREO: {  // nodes/mono_to_stereo.rs:33-50
+        case K_MONO_TO_STEREO: if constexpr (SET == 0 || SET == 3) {  // nodes/mono_to_stereo.rs:33-50
             if (mask_bit(in_mask, 0)) {
                 out_mask = clear_all_outputs(io, 0, nd.n_out);
                 break;
@@ -297,7 +327,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             break;
         }
 
-        case K_STEREO_TO_MONO: {  // nodes/stereo_to_mono.rs:33-56
+        case K_STEREO_TO_MONO: if constexpr (SET == 0 || SET == 3) {  // nodes/stereo_to_mono.rs:33-56
             if (mask_all(in_mask, 2) || nd.n_in < 2 || nd.n_out == 0) {
                 out_mask = clear_all_outputs(io, 0, nd.n_out);
                 break;
@@ -309,7 +339,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             }
             break;
         }
-        case K_WIDTH: {  // SPEC: mid/side width, one smoothed parameter
+        case K_WIDTH: if constexpr (SET == 0 || SET == 3) {  // SPEC: mid/side width, one smoothed parameter
             if (mask_all(in_mask, nd.n_in)) {
                 smoother_reset(s.s0, s.p0);
                 out_mask = clear_all_outputs(io, 0, nd.n_out);
@@ -332,7 +362,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             break;
         }
 
-        case K_BIQUAD: {  // SPEC: RBJ biquad, Direct Form I, f32 state: unfused feed-forward half, then
+        case K_BIQUAD: if constexpr (SET == 1 || SET == 3) {  // SPEC: RBJ biquad, Direct Form I, f32 state: unfused feed-forward half, then
             // y = fma(-a1, y1, fma(-a2, y2, ff)) (one fma on the recurrence's critical path; SPEC: DESIGN.md §6).
             // Serial in time: lane c runs channel c (the generic executor's coverage path).
             float* ext = v.ext + s.ext_off;
@@ -364,7 +394,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             break;
         }
 
-        case K_DELAY: {  // SPEC: integer-sample delay line with feedback, ring per channel in the ext pool
+        case K_DELAY: if constexpr (SET == 1 || SET == 3) {  // SPEC: integer-sample delay line with feedback, ring per channel in the ext pool
             const uint32_t D = (uint32_t)s.loop_end;
             const uint32_t pos = (uint32_t)s.playhead;
             const float fb = s.p0, mix = s.p1, dry = s.gain;
@@ -390,7 +420,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             break;
         }
 
-        case K_RESAMPLER: {  // SPEC: resampling source, polyphase windowed sinc
+        case K_RESAMPLER: if constexpr (SET == 1 || SET == 3) {  // SPEC: resampling source, polyphase windowed sinc
             const SampleDesc sd = s.sample >= 0 ? v.samples[s.sample] : SampleDesc{nullptr, 0, 0, FMT_P_F32};
             if (!s.playing || s.sample < 0 || sd.frames == 0) {
                 out_mask = clear_all_outputs(io, 0, nd.n_out);
@@ -438,7 +468,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             break;
         }
 
-        case K_SPATIAL: {  // SPEC: distance gain + equal-power pan + per-ear integer delay
+        case K_SPATIAL: if constexpr (SET == 1 || SET == 3) {  // SPEC: distance gain + equal-power pan + per-ear integer delay
             float* hist = v.ext + s.ext_off;
             const int dl = s.playing, dr = s.has_loop;
             const float hreg = hist[lane];  // lane l keeps hist[l] (SP_HIST == 64), hist[63] = newest
@@ -493,12 +523,14 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
 __device__ __forceinline__ bool smoother_at_rest(const Smoother& s, float target) {
     return s.status != SM_ACTIVE && s.input == target;
 }
-__global__ void k_frozen_scan(DevView v, int n_nodes, uint32_t cmd_block0, uint32_t K, uint8_t* __restrict__ frozen) {
+__global__ void k_frozen_scan(DevView v, int n_nodes, uint32_t cmd_block0, uint32_t K, uint8_t* __restrict__ frozen,
+                              unsigned long long* __restrict__ playhead_snap) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const NodeDesc nd = v.nodes[i];
-    bool fz = false;
-    if (!nd.is_graph_io && (nd.kind == K_VOLUME || nd.kind == K_PAN || nd.kind == K_WIDTH || nd.kind == K_HARD_CLIP)) {
+    bool fz = false, adv = false;
+    if (!nd.is_graph_io && (nd.kind == K_VOLUME || nd.kind == K_PAN || nd.kind == K_WIDTH || nd.kind == K_HARD_CLIP ||
+                            nd.kind == K_SAMPLER)) {
         bool has_cmd = false;
         if (v.n_cmds) {
             const int c = chain_cmd_lower_bound(v.cmds, v.n_cmds, nd.state, cmd_block0);
@@ -507,6 +539,19 @@ __global__ void k_frozen_scan(DevView v, int n_nodes, uint32_t cmd_block0, uint3
         if (!has_cmd) {
             const NodeState& s = v.states[nd.state];
             switch (nd.kind) {
+                case K_SAMPLER:  // steady playback: the playhead of block b has a closed form (see node_process_wave)
+                    if (s.sample < 0 || !s.playing) {
+                        fz = true;  // outputs cleared, nothing moves (sampler.rs:416-430)
+                    } else if (smoother_at_rest(s.s0, s.p0)) {
+                        if (s.s0.status == SM_INACTIVE && s.s0.input < 0.00001f) {
+                            fz = true;  // muted: cleared, the playhead does not move (:437-443)
+                        } else if (s.has_loop) {
+                            adv = fz = s.loop_end - s.loop_start >= (uint64_t)v.frames && s.playhead >= s.loop_start;
+                        } else {  // one-shot that does not end inside the batch
+                            adv = fz = s.playhead + (uint64_t)K * (uint64_t)v.frames <= v.samples[s.sample].frames;
+                        }
+                    }
+                    break;
                 case K_HARD_CLIP: fz = true; break;
                 // volume.rs:104: a gain below 1e-5 is a mute only while the smoother is Inactive — keep such a node
                 // on the serial path while it is Deactivating (the status matters there)
@@ -516,12 +561,13 @@ __global__ void k_frozen_scan(DevView v, int n_nodes, uint32_t cmd_block0, uint3
             }
         }
     }
-    frozen[i] = fz ? 1 : 0;
+    frozen[i] = fz ? (adv ? 2 : 1) : 0;  // 2: a playing sampler — the last block's wave stores the state
+    if (adv) playhead_snap[i] = v.states[nd.state].playhead;
 }
 // block-0 wave of a frozen node: if some block of the batch had every input silent, its smoothers were reset
 __device__ void frozen_finish(const DevView& v, int node_idx, uint32_t K) {
     const NodeDesc nd = v.nodes[node_idx];
-    if (nd.kind == K_HARD_CLIP) return;
+    if (nd.kind == K_HARD_CLIP || nd.kind == K_SAMPLER) return;
     NodeState s = v.states[nd.state];
     if (s.s0.status != SM_DEACTIVATING && !(nd.kind == K_PAN && s.s1.status == SM_DEACTIVATING)) return;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -542,26 +588,31 @@ __device__ void frozen_finish(const DevView& v, int node_idx, uint32_t K) {
 // K blocks per launch (gridDim.y = K, one pool slice per block).  A node whose audio half carries state from block
 // to block is run by ONE wave that walks its K blocks in order; stateless nodes — and frozen ones — take their K
 // blocks in parallel.
+template <int SET>
 __global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __restrict__ level_nodes, int n_nodes,
                                                       uint32_t cmd_block0) {
     int w = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (w >= n_nodes) return;
     const int node = level_nodes[w];
+    if (kind_set(v.nodes[node].kind) != SET) return;  // another instantiation's node
     if (kind_is_stateful(v.nodes[node].kind)) {
-        if (v.frozen && v.frozen[node]) {
-            node_process_wave(v, node, blockIdx.y, cmd_block0 + blockIdx.y, false);
-            if (blockIdx.y == 0) frozen_finish(v, node, gridDim.y);
+        const uint8_t fz = v.frozen ? v.frozen[node] : (uint8_t)0;
+        if (fz) {
+            const bool adv = fz == 2;  // playing sampler: per-block playhead in closed form, the last block stores the state
+            node_process_wave<SET>(v, node, blockIdx.y, cmd_block0 + blockIdx.y, adv && blockIdx.y + 1 == gridDim.y,
+                                   adv ? blockIdx.y : 0u, adv);
+            if (!adv && blockIdx.y == 0) frozen_finish(v, node, gridDim.y);
             return;
         }
         if (blockIdx.y != 0) return;
-        for (uint32_t b = 0; b < gridDim.y; ++b) node_process_wave(v, node, b, cmd_block0 + b);
+        for (uint32_t b = 0; b < gridDim.y; ++b) node_process_wave<SET>(v, node, b, cmd_block0 + b);
     } else {
-        node_process_wave(v, node, blockIdx.y, cmd_block0 + blockIdx.y);
+        node_process_wave<SET>(v, node, blockIdx.y, cmd_block0 + blockIdx.y);
     }
 }
 
 // B1: one node on scratch buffers (single wave)
-__global__ __launch_bounds__(WAVE) void k_single_node(DevView v, int node_idx) { node_process_wave(v, node_idx, 0, 0); }
+__global__ __launch_bounds__(WAVE) void k_single_node(DevView v, int node_idx) { node_process_wave<3>(v, node_idx, 0, 0); }
 
 // ------------------------------------------------------------------ state init / graph I/O edges
 struct StateInit {

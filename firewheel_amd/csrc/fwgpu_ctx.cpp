@@ -1139,6 +1139,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     fv.n_leaves = c->n_leaves;
     fv.stride = c->stride;
     fv.frames = (int)c->mbf;
+    fv.fx_plan = c->fused_fx ? 1 : 0;
     fv.ext = c->d_ext.as<float>();
     fv.chain_start = c->d_chain_start.as<ChainStart>();
     fv.chain_dummy = c->d_chain_dummy.as<float>();

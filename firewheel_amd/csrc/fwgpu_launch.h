@@ -57,6 +57,7 @@ struct FusedView {
     int n_leaves;
     int stride;
     int frames;
+    int fx_plan;  // 1 = the chain plan (k_chain renders the leaves): descriptor conventions of k_voice_control
     float* ext;  // biquad coefficients + history, delay rings (k_chain plan)
     ChainStart* chain_start;  // [n_voices] (k_chain plan)
     float* chain_dummy;       // k_chain's steady-call loop: where lanes with nothing to fetch / store point (>= 32 KiB)

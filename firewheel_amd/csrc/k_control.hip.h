@@ -216,7 +216,9 @@ __device__ __forceinline__ void put_blk(const FusedView& fv, int vi, int kk, con
 // the loop end (nodes/sampler.rs:445-484) — closed form (base + j*frames) mod L, so the 64 lanes of the
 // voice's wave fill 64 blocks at a time.  Returns the playhead the reference holds after block K-1.
 __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int lane, int k_first, int K, const TailJob& job,
-                                                const SampleDesc& sd, uint32_t gset, bool simple_ok, bool fx) {
+                                                const SampleDesc& sd, uint32_t gset, bool simple_ok, bool fx, bool fxp) {
+    // fx: this voice has a biquad / delay (silence does not pass it); fxp: the PLAN is the chain plan — k_chain reads
+    // either a VB_SIMPLE record (planar f32, or VB_SRC_ZERO) or a full descriptor for EVERY voice of the plan, dry ones too
     const int frames = fv.frames;
     const uint64_t fr = (uint64_t)frames;
     VoiceBlk t;
@@ -235,6 +237,8 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
     const bool has_src = !no_src && job.sample >= 0;
     const bool contiguous_f32 = has_src && sd.format == FMT_P_F32;
     const uint64_t n = (uint64_t)(K - k_first);
+    // chain plan, nothing to fetch (cleared source, or a dry voice whose output is muted): a cleared-source block
+    const uint32_t nosrc_flags = (fxp && !has_src) ? (VB_SRC_ZERO | (simple_ok ? VB_SIMPLE : 0u)) : 0u;
     if (job.mode == 1) {
         // all quantities fit 32 bits whenever the loop does (the usual case): avoid 64-bit division
         const uint64_t L = job.loop_end - job.loop_start;
@@ -257,11 +261,11 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
         }
         for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
             const uint64_t left = L - r;
-            t.flags = job.flags;
+            t.flags = job.flags | nosrc_flags;
             t.off0 = job.loop_start + r;
             t.off1 = job.loop_start;
             t.src_l = t.src_r = nullptr;
-            if (left < fr) {  // wraps inside the block
+            if (left < fr && !nosrc_flags) {  // wraps inside the block (nothing is fetched from a cleared source)
                 t.n1 = (uint32_t)left;
                 t.flags |= VB_WRAP;
             } else {
@@ -270,9 +274,9 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
                     t.src_l = (const float*)sd.data + t.off0;
                     t.src_r = (t.flags & VB_MONO) ? t.src_l : t.src_l + sd.frames;
                 }
-                if (has_src && simple_ok && simple_class(sd, t.off0, fx) != SF_NONE) t.flags |= VB_SIMPLE;
+                if (has_src && simple_ok && simple_class(sd, t.off0, fxp) != SF_NONE) t.flags |= VB_SIMPLE;
             }
-            put_blk(fv, vi, k2, t, gset, sd, fx);
+            put_blk(fv, vi, k2, t, gset, sd, fxp);
             r += step;
             if (r >= L) r -= L;
         }
@@ -281,21 +285,22 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
     }
     if (job.mode == 2) {
         for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
-            t.flags = job.flags;
+            t.flags = job.flags | nosrc_flags;
             t.off0 = job.playhead + (uint64_t)(k2 - k_first) * fr;
             t.src_l = t.src_r = nullptr;
             if (contiguous_f32) {
                 t.src_l = (const float*)sd.data + t.off0;
                 t.src_r = (t.flags & VB_MONO) ? t.src_l : t.src_l + sd.frames;
             }
-            if (has_src && simple_ok && simple_class(sd, t.off0, fx) != SF_NONE) t.flags |= VB_SIMPLE;
-            put_blk(fv, vi, k2, t, gset, sd, fx);
+            if (has_src && simple_ok && simple_class(sd, t.off0, fxp) != SF_NONE) t.flags |= VB_SIMPLE;
+            put_blk(fv, vi, k2, t, gset, sd, fxp);
         }
         return job.playhead + n * fr;
     }
     // nothing moves (mode 0 <=> the sampler is frozen): with fx the block still runs (zeros in, constant gains)
-    if (fx && simple_ok) t.flags |= VB_SIMPLE;
-    for (int k2 = k_first + lane; k2 < K; k2 += WAVE) put_blk(fv, vi, k2, t, fx ? gset : 0u, sd, fx);
+    if (fxp && simple_ok) t.flags |= VB_SIMPLE;
+    t.flags |= nosrc_flags;
+    for (int k2 = k_first + lane; k2 < K; k2 += WAVE) put_blk(fv, vi, k2, t, fxp ? gset : 0u, sd, fxp);
     return job.playhead;
 }
 
@@ -310,7 +315,8 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
     const VoiceDesc vd = fv.voices[vi];
     const int frames = fv.frames;
     const bool simple_frames = (frames & 3) == 0;
-    const bool fx = vd.bq_state >= 0 || vd.dl_state >= 0;  // k_chain plan voice
+    const bool fx = vd.bq_state >= 0 || vd.dl_state >= 0;  // the voice has a biquad / delay: silence does not pass it
+    const bool fxp = fv.fx_plan != 0;                        // chain plan: k_chain's descriptor conventions for EVERY voice
 
     // ---- k_chain plan: what both channel workgroups of the voice's leaf share is owned HERE — the record holds the
     // values at the start of this call (k_chain replays the call's messages block by block from them), the node state
@@ -424,10 +430,10 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
             }
             if (ok) {
                 const bool no_src = (job.flags & VB_SRC_ZERO) || (!fx && (job.flags & VB_SILENT));
-                const bool simple_ok = no_src ? (fx && simple_frames)
-                                              : (job.sample >= 0 && simple_frames && simple_capable(sd, fx));
+                const bool simple_ok = no_src ? (fxp && simple_frames)
+                                              : (job.sample >= 0 && simple_frames && simple_capable(sd, fxp));
                 if (simple_ok && w0) my_gsets[0] = job.g;
-                uint64_t ph = steady_tail(fv, vi, lane, 0, Kp, job, sd, 0u, simple_ok, fx);
+                uint64_t ph = steady_tail(fv, vi, lane, 0, Kp, job, sd, 0u, simple_ok, fx, fxp);
                 if (Kp == K) {
                     if (w0 && vc.mode != 0) fv.states[vd.sampler_state].playhead = ph;
                     return;
@@ -587,13 +593,15 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                 }
             }
         }
-        if (!src_silent && (fx || !silent)) blk_set_source(d, sd, frames, fx);
-        else if (src_silent && fx && (d.flags >> VB_RAMP_SHIFT) == 0 && simple_frames) d.flags |= VB_SIMPLE;
-        if (src_silent) d.flags |= VB_SRC_ZERO;
+        const bool need_src = !src_silent && (fx || !silent);  // a dry voice whose output is muted fetches nothing
+        if (need_src) blk_set_source(d, sd, frames, fxp);
+        else if (fxp && (d.flags >> VB_RAMP_SHIFT) == 0 && simple_frames) d.flags |= VB_SIMPLE;  // chain plan: cleared-source block
+        if (src_silent || (fxp && !need_src)) d.flags |= VB_SRC_ZERO;
+        if (fxp && !need_src) d.flags &= ~(VB_WRAP | VB_TAIL_ZERO);  // nothing is fetched: where the source would wrap is moot
         if (silent) d.flags |= VB_SILENT;
         {
             uint32_t gs = pick_gset(d);
-            if (w0) put_blk(fv, vi, k, d, gs, sd, fx);
+            if (w0) put_blk(fv, vi, k, d, gs, sd, fxp);
         }
 
         // ---- steady from the next block on?
@@ -670,8 +678,8 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
         if (k + 1 < K) {
             uint32_t tail_gs = 0;
             bool simple_ok = false;
-            const bool tail_simple = fx ? (simple_frames && (upstream_silent || simple_capable(sd, true)))
-                                        : (!sil && !upstream_silent && simple_frames && simple_capable(sd, false));
+            const bool tail_simple = fxp ? (simple_frames && (upstream_silent || (!fx && sil) || simple_capable(sd, true)))
+                                         : (!sil && !upstream_silent && simple_frames && simple_capable(sd, false));
             if (tail_simple) {
                 VoiceBlk probe;  // every non-wrapping tail block is VB_SIMPLE with the same gains: one gain set
                 probe.flags = VB_SIMPLE;
@@ -683,7 +691,7 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                 tail_gs = pick_gset(probe);
                 simple_ok = (probe.flags & VB_SIMPLE) != 0;  // false when the voice ran out of gain-set slots
             }
-            uint64_t ph = steady_tail(fv, vi, lane, k + 1, K, job, sd, tail_gs, simple_ok, fx);
+            uint64_t ph = steady_tail(fv, vi, lane, k + 1, K, job, sd, tail_gs, simple_ok, fx, fxp);
             if (mode != 0) ss.playhead = ph;
         }
         break;

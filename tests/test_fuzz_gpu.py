@@ -1,0 +1,152 @@
+"""GPU tier: seeded random graphs + random control traffic, every launch plan against the oracle, bit for bit.
+
+Each seed draws a voice bank (1-70 voices, random tree radix, random per-voice chain: gain stages and / or biquad and /
+or delay, random sample formats and lengths, mono and stereo), an optional master chain on the mix bus, and several
+rounds of messages (play / pause / stop / gains / pans / playheads / loop ranges, tagged at random blocks of the next
+call) between calls of random length — the things the hand-written scenarios combine by design, combined by chance.
+The same draw runs on the oracle and on the GPU (fused plan if the graph qualifies, generic executor if not, and the
+generic executor again when forced), through the synchronous host-buffer call or the asynchronous device call."""
+import numpy as np
+import pytest
+import torch  # noqa: F401  (before libfwgpu is loaded: one process, one copy of the HIP runtime — torch brings its own)
+
+import fwapi
+import scenarios
+from fwapi import (INTERLEAVED_F32, INTERLEAVED_I16, INTERLEAVED_U16, LOOP_FULL, LOOP_NONE, LOOP_RANGE_SECS, PLANAR_F32,
+                   PLANAR_I16, PLANAR_U16, GpuEngine)
+from test_gpu_parity import assert_bits_equal, oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def encode(data, fmt):
+    """(channels, frames) f32 -> the raw array of sample format `fmt`"""
+    if fmt in (PLANAR_I16, INTERLEAVED_I16):
+        raw = np.round(data * 32767).astype(np.int16)
+    elif fmt in (PLANAR_U16, INTERLEAVED_U16):
+        raw = np.round((data + 1) * 32767.5).astype(np.uint16)
+    else:
+        raw = data
+    return raw.T.copy() if fmt <= INTERLEAVED_F32 else raw
+
+
+def fuzz_run(e, seed):
+    rng = np.random.default_rng(seed)
+    mbf = e.max_block_frames
+    n_voices = int(rng.integers(1, 71))
+    radix = int(rng.choice([2, 3, 8, 32]))
+    shape = int(rng.integers(0, 4))            # 0 gains only, 1 + biquad, 2 + delay, 3 + both
+    f32_only = shape != 0 or rng.random() < 0.5  # chain voices: planar f32 keeps them on the chain plan (either is valid)
+    voices, ends = [], []
+    for v in range(n_voices):
+        s = e.sampler(float(rng.uniform(30, 100)))
+        cur = s
+        vc = dict(sampler=s, gains=[], pans=[], bq=None, dl=None)
+        if shape in (1, 3) and rng.random() < 0.9:
+            vc["bq"] = e.biquad(int(rng.integers(0, 3)), float(rng.uniform(200, 8000)), float(rng.uniform(0.5, 3.0)))
+            e.connect_stereo(cur, vc["bq"])
+            cur = vc["bq"]
+        if shape in (2, 3) and rng.random() < 0.9:
+            vc["dl"] = e.delay(int(rng.integers(64, 700)) / float(e.sample_rate), feedback=float(rng.uniform(0, 0.6)),
+                               mix=float(rng.uniform(0, 1)))
+            e.connect_stereo(cur, vc["dl"])
+            cur = vc["dl"]
+        for _ in range(int(rng.integers(0, 4))):
+            if rng.random() < 0.6:
+                g = e.volume(float(rng.uniform(10, 120)))
+                vc["gains"].append(g)
+            else:
+                g = e.pan(float(rng.uniform(-1, 1)))
+                vc["pans"].append(g)
+            e.connect_stereo(cur, g)
+            cur = g
+        voices.append(vc)
+        ends.append(cur)
+    level = ends
+    while True:
+        nxt = []
+        for i in range(0, len(level), radix):
+            grp = level[i:i + radix]
+            m = e.sum(len(grp))
+            for p, n in enumerate(grp):
+                e.connect_stereo(n, m, 2 * p)
+            nxt.append(m)
+        level = nxt
+        if len(level) == 1:
+            break
+    # master chain: (constructor, automatable parameter id or None, value range)
+    kinds = [(lambda e: e.volume(float(rng.uniform(40, 130))), 0, (10.0, 130.0)),
+             (lambda e: e.hard_clip(float(rng.uniform(-12, 0))), None, None),
+             (lambda e: e.pan(float(rng.uniform(-1, 1))), 0, (-1.0, 1.0)),
+             (lambda e: e.width(float(rng.uniform(0, 2))), 0, (0.0, 2.0)),
+             (lambda e: e.biquad(0, float(rng.uniform(2000, 12000)), 0.707), 1, (500.0, 12000.0)),
+             (lambda e: e.delay(int(rng.integers(20, 500)) / float(e.sample_rate), feedback=0.3, mix=0.3), 2, (0.0, 1.0))]
+    chosen = [kinds[int(i)] for i in rng.integers(0, len(kinds), size=int(rng.integers(0, 4)))]
+    m_nodes = scenarios.connect_through_master(e, level[0], [c[0] for c in chosen])
+    e.update()
+    fmts = [PLANAR_F32] if f32_only else [PLANAR_F32, PLANAR_I16, PLANAR_U16, INTERLEAVED_F32, INTERLEAVED_I16, INTERLEAVED_U16]
+    for v, vc in enumerate(voices):
+        ch = 1 if rng.random() < 0.2 else 2
+        frames = int(rng.integers(mbf + 8, 6 * mbf))  # loops are never shorter than a block (Q8)
+        vc["frames"] = frames
+        data = scenarios.voice_source(seed * 1000 + v, frames, ch)
+        fmt = int(rng.choice(fmts))
+        e.sampler_set_sample(vc["sampler"], e.new_sample(fmt, ch, encode(data, fmt)))
+        if rng.random() < 0.7:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        if rng.random() < 0.85:
+            e.sampler_play(vc["sampler"])
+    outs = []
+    for rnd in range(int(rng.integers(3, 7))):
+        k = int(rng.choice([1, 2, 3, 5, 9, 24]))
+        if rnd > 0:
+            for vc in voices:
+                if rng.random() > 0.35:
+                    continue
+                at = int(rng.integers(0, k))
+                what = int(rng.integers(0, 9))
+                sr = float(e.sample_rate)
+                if what == 0:
+                    e.sampler_play(vc["sampler"], at_block=at)
+                elif what == 1:
+                    e.sampler_pause(vc["sampler"], at_block=at)
+                elif what == 2:
+                    e.sampler_stop(vc["sampler"], at_block=at)
+                elif what == 3 and vc["gains"]:
+                    e.set_param(vc["gains"][int(rng.integers(0, len(vc["gains"])))], 0, float(rng.choice([0.0, 25.0, 90.0, 140.0])),
+                                at_block=at)
+                elif what == 4 and vc["pans"]:
+                    e.set_param(vc["pans"][int(rng.integers(0, len(vc["pans"])))], 0, float(rng.uniform(-1, 1)), at_block=at)
+                elif what == 5:
+                    e.set_param(vc["sampler"], 0, float(rng.choice([0.0, 50.0, 100.0])), at_block=at)
+                elif what == 6:
+                    e.sampler_set_playhead_secs(vc["sampler"], float(rng.integers(0, vc["frames"] - 1)) / sr, at_block=at)
+                elif what == 7:
+                    mode = int(rng.choice([LOOP_NONE, LOOP_FULL, LOOP_RANGE_SECS]))
+                    lo = int(rng.integers(0, vc["frames"] - mbf - 4))
+                    hi = int(rng.integers(lo + mbf + 2, vc["frames"]))  # range >= a block, inside the sample (Q8)
+                    e.sampler_set_loop_range(vc["sampler"], mode, lo / sr, hi / sr, at_block=at)
+                elif what == 8 and vc["dl"] is not None:
+                    e.set_param(vc["dl"], int(rng.integers(1, 3)), float(rng.uniform(0, 0.9)), at_block=at)
+            for m, (_, pid, rng_v) in zip(m_nodes, chosen):
+                if pid is not None and rng.random() < 0.25:
+                    e.set_param(m, pid, float(rng.uniform(*rng_v)), at_block=int(rng.integers(0, k)))
+        outs.append(np.asarray(e.process_blocks(k)))
+    return np.concatenate(outs)
+
+
+class AsyncEngine(GpuEngine):
+    async_device = True
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_graph_and_messages_every_plan_bit_exact(seed):
+    pick = np.random.default_rng(10_000 + seed)
+    mbf = int(pick.choice([64, 128, 256]))
+    want = fuzz_run(oracle(max_block_frames=mbf), seed)
+    assert np.all(np.isfinite(want))
+    cls = AsyncEngine if pick.random() < 0.5 else GpuEngine
+    g = cls(max_block_frames=mbf, max_batch=int(pick.choice([1, 2, 5, 64])))
+    assert_bits_equal(want, fuzz_run(g, seed), "seed %d plan %d %s" % (seed, g.cx.plan_kind(), cls.__name__))
+    g2 = GpuEngine(max_block_frames=mbf, force_generic=True, max_batch=int(pick.choice([1, 3, 64])))
+    assert_bits_equal(want, fuzz_run(g2, seed), "seed %d generic" % seed)

@@ -6,6 +6,8 @@ rounds of messages (play / pause / stop / gains / pans / playheads / loop ranges
 call) between calls of random length — the things the hand-written scenarios combine by design, combined by chance.
 The same draw runs on the oracle and on the GPU (fused plan if the graph qualifies, generic executor if not, and the
 generic executor again when forced), through the synchronous host-buffer call or the asynchronous device call."""
+import os
+
 import numpy as np
 import pytest
 import torch  # noqa: F401  (before libfwgpu is loaded: one process, one copy of the HIP runtime — torch brings its own)
@@ -36,7 +38,8 @@ def fuzz_run(e, seed):
     n_voices = int(rng.integers(1, 71))
     radix = int(rng.choice([2, 3, 8, 32]))
     shape = int(rng.integers(0, 4))            # 0 gains only, 1 + biquad, 2 + delay, 3 + both
-    f32_only = shape != 0 or rng.random() < 0.5  # chain voices: planar f32 keeps them on the chain plan (either is valid)
+    f32_only = rng.random() < 0.6  # (chain voices on other formats take k_chain's per-element fetch: valid, slower)
+    spare_port = rng.random() < 0.5  # leaf SumNodes keep an unconnected port: voices are plugged in / out between calls
     voices, ends = [], []
     for v in range(n_voices):
         s = e.sampler(float(rng.uniform(30, 100)))
@@ -63,15 +66,21 @@ def fuzz_run(e, seed):
         voices.append(vc)
         ends.append(cur)
     level = ends
+    free_ports = []  # (leaf SumNode, first channel of the unconnected stereo port)
+    first = True
     while True:
         nxt = []
         for i in range(0, len(level), radix):
             grp = level[i:i + radix]
-            m = e.sum(len(grp))
+            spare = first and spare_port and len(grp) < 32
+            m = e.sum(len(grp) + (1 if spare else 0))
             for p, n in enumerate(grp):
                 e.connect_stereo(n, m, 2 * p)
+            if spare:
+                free_ports.append((m, 2 * len(grp)))
             nxt.append(m)
         level = nxt
+        first = False
         if len(level) == 1:
             break
     # master chain: (constructor, automatable parameter id or None, value range)
@@ -97,14 +106,39 @@ def fuzz_run(e, seed):
         if rng.random() < 0.85:
             e.sampler_play(vc["sampler"])
     outs = []
+    plugged = []  # voices added after the first compile: (sampler, last node, (sum, port))
     for rnd in range(int(rng.integers(3, 7))):
         k = int(rng.choice([1, 2, 3, 5, 9, 24]))
+        if rnd > 0 and rng.random() < 0.4:
+            # a graph edit between calls (graph/graph.rs:201-231, :268-299, :396-477 + recompile): plug a new dry voice
+            # into a spare port, or pull one out again — node state of everything else carries over
+            if plugged and rng.random() < 0.5:
+                smp, last, port = plugged.pop()
+                e.remove_node(last)
+                if last != smp:
+                    e.remove_node(smp)
+                free_ports.append(port)
+                e.update()
+            elif free_ports:
+                port = free_ports.pop()
+                smp = e.sampler(float(rng.uniform(40, 100)))
+                last = smp
+                if rng.random() < 0.7:
+                    last = e.volume(float(rng.uniform(20, 100)))
+                    e.connect_stereo(smp, last)
+                e.connect_stereo(last, port[0], port[1])
+                e.update()
+                frames = int(rng.integers(mbf + 8, 4 * mbf))
+                e.sampler_set_sample(smp, e.new_sample(PLANAR_F32, 2, scenarios.voice_source(seed * 1000 + 900 + rnd, frames, 2)))
+                e.sampler_set_loop_range(smp, LOOP_FULL)
+                e.sampler_play(smp)
+                plugged.append((smp, last, port))
         if rnd > 0:
             for vc in voices:
                 if rng.random() > 0.35:
                     continue
                 at = int(rng.integers(0, k))
-                what = int(rng.integers(0, 9))
+                what = int(rng.integers(0, 10))
                 sr = float(e.sample_rate)
                 if what == 0:
                     e.sampler_play(vc["sampler"], at_block=at)
@@ -123,11 +157,23 @@ def fuzz_run(e, seed):
                     e.sampler_set_playhead_secs(vc["sampler"], float(rng.integers(0, vc["frames"] - 1)) / sr, at_block=at)
                 elif what == 7:
                     mode = int(rng.choice([LOOP_NONE, LOOP_FULL, LOOP_RANGE_SECS]))
+                    vc["ranged"] = vc.get("ranged", False) or mode == LOOP_RANGE_SECS
                     lo = int(rng.integers(0, vc["frames"] - mbf - 4))
                     hi = int(rng.integers(lo + mbf + 2, vc["frames"]))  # range >= a block, inside the sample (Q8)
                     e.sampler_set_loop_range(vc["sampler"], mode, lo / sr, hi / sr, at_block=at)
                 elif what == 8 and vc["dl"] is not None:
                     e.set_param(vc["dl"], int(rng.integers(1, 3)), float(rng.uniform(0, 0.9)), at_block=at)
+                elif what == 9 and not vc.get("ranged", False):
+                    # swap the sample under the voice (SetSample, sampler.rs:67-79), sometimes stopping it.  Not for a
+                    # voice that ever had a RangeSecs loop, and later ranges / playheads stay inside BOTH samples:
+                    # messages of one call apply at different blocks, and a range outside the sample panics upstream (Q8)
+                    ch = 1 if rng.random() < 0.3 else 2
+                    new_frames = int(rng.integers(mbf + 8, 5 * mbf))
+                    vc["frames"], new_frames = min(vc["frames"], new_frames), new_frames
+                    fmt = int(rng.choice(fmts))
+                    data = scenarios.voice_source(seed * 1000 + 500 + int(rng.integers(0, 400)), new_frames, ch)
+                    e.sampler_set_sample(vc["sampler"], e.new_sample(fmt, ch, encode(data, fmt)), bool(rng.random() < 0.3),
+                                         at_block=at)
             for m, (_, pid, rng_v) in zip(m_nodes, chosen):
                 if pid is not None and rng.random() < 0.25:
                     e.set_param(m, pid, float(rng.uniform(*rng_v)), at_block=int(rng.integers(0, k)))
@@ -139,7 +185,7 @@ class AsyncEngine(GpuEngine):
     async_device = True
 
 
-@pytest.mark.parametrize("seed", range(80))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FWGPU_FUZZ_SEEDS", "80"))))
 def test_random_graph_and_messages_every_plan_bit_exact(seed):
     pick = np.random.default_rng(10_000 + seed)
     mbf = int(pick.choice([64, 128, 256]))

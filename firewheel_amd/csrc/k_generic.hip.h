@@ -155,7 +155,9 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             const bool masked = !(ports == 2 || ports == 3 || ports == 4);  // :67-133 (Q13)
             // lane i keeps the buffer id of input channel i; ids are broadcast with v_readlane so the
             // per-port loads are independent and can be in flight together (8 at a time)
-            const int my_in = lane < n_in ? io.in_buf[lane] : 0;
+            int my_in = lane < n_in ? io.in_buf[lane] : 0;
+            asm volatile("" : "+v"(my_in));  // materialised under the full exec mask: read with v_readlane inside the frame
+                                             // loops, where lanes without frames are inactive (see k_leaf_sum)
             const uint64_t later_ports = mask_all_silent_bits(n_in) & ~mask_all_silent_bits(n_out);
             const bool any_skip = masked && (in_mask & later_ports) != 0;
             for (int c = 0; c < n_out; ++c) {

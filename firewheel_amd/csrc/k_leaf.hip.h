@@ -244,9 +244,24 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
     for (int j = 0; j < FW_MAX_STAGES; ++j) my_g.g[j][0] = my_g.g[j][1] = 1.0f;
     if (my_flags & VB_SIMPLE) my_g = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + ((ref.flags_gset >> 8) & 0xffu)];
     const float* my_l = ref.src_l;
-    const uint32_t my_rd = ref.r_delta;
-    const uint32_t my_cls = (ref.flags_gset >> 16) & 7u;
+    uint32_t my_rd = ref.r_delta;
+    uint32_t my_cls = (ref.flags_gset >> 16) & 7u;
     const float* my_r = ref.src_l + ref.r_delta;  // planar f32 class only
+    // Everything lane p holds for port p is read below with v_readlane from inside the frame loop, where only the lanes
+    // that own frames are active (block < 256 frames: fewer than 64).  Pin the values HERE, under the full exec mask:
+    // left to itself the compiler may sink their computation into the loop, and lanes that are inactive there would
+    // never compute them (found by the fuzz test: 19-port leaf, block of 64 frames -> garbage source addresses).
+    {
+        uint64_t pl = (uint64_t)my_l, pr = (uint64_t)my_r;
+        uint32_t rd = my_rd, cl = my_cls;
+        asm volatile("" : "+v"(pl), "+v"(pr), "+v"(rd), "+v"(cl));
+        my_l = (const float*)pl;
+        my_r = (const float*)pr;
+        my_rd = rd;
+        my_cls = cl;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j) asm volatile("" : "+v"(my_g.g[j][0]), "+v"(my_g.g[j][1]));
+    }
     const uint64_t lanes_in = mask_all_silent_bits(ld.ports);
     const uint64_t silent_ports = __ballot((my_flags & VB_SILENT) != 0) & lanes_in;
     const uint64_t simple_ports = __ballot((my_flags & VB_SIMPLE) != 0) & lanes_in;

@@ -915,3 +915,20 @@ def test_master_chain_after_the_root_keeps_the_fused_plans(name, plan, max_batch
     out_o2, out_g2, g2 = run_case(name, force_generic=True)
     assert g2.cx.plan_kind() == 0
     assert_bits_equal(out_o2, out_g2, name + " generic")
+
+
+@pytest.mark.parametrize("n_voices,mbf", [(19, 64), (32, 64), (31, 36), (40, 64)])
+def test_wide_leaves_with_short_blocks(n_voices, mbf):
+    # a leaf SumNode with more ports than the block has frame quads (block 64: 16 lanes own frames, the other lanes only
+    # lend their port's descriptor through v_readlane) and loops that wrap inside blocks (the per-voice path).  Found by
+    # the fuzz test: the lanes without frames had never computed the values that were read from them.
+    def run(e):
+        v = scenarios.build_voice_bank(e, n_voices, radix=32, src_frames=300, mono_every=5)
+        for vc in v:
+            e.sampler_set_loop_range(vc["sampler"], fwapi.LOOP_FULL)
+            e.sampler_play(vc["sampler"])
+        return np.asarray(e.process_blocks(9))
+
+    g = GpuEngine(max_block_frames=mbf)
+    assert_bits_equal(run(oracle(max_block_frames=mbf)), run(g), "wide leaf, short block")
+    assert g.cx.plan_kind() == 1

@@ -164,7 +164,11 @@ __global__ void k_fir_reduce(DevView v, const FirRow* __restrict__ rows, int n_r
     for (int i = threadIdx.x; i < v.frames; i += blockDim.x) {
         float t = partials[(size_t)r * row_pitch + (size_t)kb * n_pad + i];
         for (int sgm = 1; sgm < n_segs; ++sgm) t = t + partials[((size_t)sgm * n_rows_pad + r) * row_pitch + (size_t)kb * n_pad + i];
-        out[i] = t;
+        // SPEC: "+ (+0.0f)" — a sum that underflowed to -0.0 becomes +0.0 (every other value is unchanged).  Without
+        // it the sign of such a zero would depend on whether the window ends in zero padding (a trailing (+0)(+0) term
+        // turns -0.0 into +0.0): an implementation detail of the GEMM tiling (found by the DAG fuzz test: the last frame
+        // of a block has no trailing out-of-band term in the definition, the tiled GEMM always has padding)
+        out[i] = t + 0.0f;
     }
     if (threadIdx.x == 0) {
         v.flags[(size_t)kb * v.flags_blk_stride + row.out_buf] = 0;

@@ -685,7 +685,7 @@ struct DelayProcessor : AudioNodeProcessor {
 // ---- SPEC: FIR convolution y[n] = sum_k h[k] x[n-k] with a fully specified f32 summation order (the one a
 // k-ordered fmaf chain per FIR_SEG-long window segment produces; DESIGN.md §6 "fir"):
 //   window W = T-1+frames positions, position m holds x[n0-(T-1)+m]; H[m][i] = h[T-1-(m-i)] if 0<=m-i<=T-1 else 0
-//   partial_s[i] = fmaf chain over m in segment s (ascending, from +0.0f), y[i] = ((p_0 + p_1) + p_2) + ...
+//   partial_s[i] = fmaf chain over m in segment s (ascending, from +0.0f), y[i] = (((p_0 + p_1) + p_2) + ...) + (+0.0f)
 struct FirProcessor : AudioNodeProcessor {
     static constexpr size_t SEG = 4096;
     std::vector<std::vector<float>> h;     // per channel
@@ -723,7 +723,7 @@ struct FirProcessor : AudioNodeProcessor {
                     }
                     total = sidx == 0 ? acc : total + acc;
                 }
-                outputs[c][i] = total;
+                outputs[c][i] = total + 0.0f;  // SPEC: -0.0 (a sum that underflowed from below) is normalised to +0.0
             }
             if (T > 1) std::copy(win.end() - (T - 1), win.end(), hist[c].begin());
         }

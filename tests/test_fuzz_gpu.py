@@ -37,7 +37,10 @@ def fuzz_run(e, seed):
     mbf = e.max_block_frames
     n_voices = int(rng.integers(1, 71))
     radix = int(rng.choice([2, 3, 8, 32]))
-    shape = int(rng.integers(0, 4))            # 0 gains only, 1 + biquad, 2 + delay, 3 + both
+    # 0 gains only, 1 + biquad, 2 + delay, 3 + both (each present in ~90 % of the voices), 4 = every voice has both and
+    # delays of >= 3 k_chain tiles: calls without pending messages then take k_chain's steady-call loop
+    shape = int(rng.integers(0, 5))
+    tile = 128 if mbf % 128 == 0 else 64
     f32_only = rng.random() < 0.6  # (chain voices on other formats take k_chain's per-element fetch: valid, slower)
     spare_port = rng.random() < 0.5  # leaf SumNodes keep an unconnected port: voices are plugged in / out between calls
     voices, ends = [], []
@@ -45,12 +48,13 @@ def fuzz_run(e, seed):
         s = e.sampler(float(rng.uniform(30, 100)))
         cur = s
         vc = dict(sampler=s, gains=[], pans=[], bq=None, dl=None)
-        if shape in (1, 3) and rng.random() < 0.9:
+        if shape == 4 or (shape in (1, 3) and rng.random() < 0.9):
             vc["bq"] = e.biquad(int(rng.integers(0, 3)), float(rng.uniform(200, 8000)), float(rng.uniform(0.5, 3.0)))
             e.connect_stereo(cur, vc["bq"])
             cur = vc["bq"]
-        if shape in (2, 3) and rng.random() < 0.9:
-            vc["dl"] = e.delay(int(rng.integers(64, 700)) / float(e.sample_rate), feedback=float(rng.uniform(0, 0.6)),
+        if shape == 4 or (shape in (2, 3) and rng.random() < 0.9):
+            d_lo = 3 * tile if shape == 4 else 64
+            vc["dl"] = e.delay(int(rng.integers(d_lo, d_lo + 640)) / float(e.sample_rate), feedback=float(rng.uniform(0, 0.6)),
                                mix=float(rng.uniform(0, 1)))
             e.connect_stereo(cur, vc["dl"])
             cur = vc["dl"]
@@ -196,3 +200,133 @@ def test_random_graph_and_messages_every_plan_bit_exact(seed):
     assert_bits_equal(want, fuzz_run(g, seed), "seed %d plan %d %s" % (seed, g.cx.plan_kind(), cls.__name__))
     g2 = GpuEngine(max_block_frames=mbf, force_generic=True, max_batch=int(pick.choice([1, 3, 64])))
     assert_bits_equal(want, fuzz_run(g2, seed), "seed %d generic" % seed)
+
+
+def fuzz_dag(e, seed):
+    """a random DAG over every node kind the generic executor has (no beep: libm tolerance): sampler / resampler sources,
+    stereo 2->2 processors, mono detours (stereo->mono -> 1->1 volume -> spatialiser or mono->stereo), 2/3/4/n-port sums,
+    small FIR convolutions, one-to-many edges, dangling nodes and unconnected ports; then message traffic."""
+    rng = np.random.default_rng(50_000 + seed)
+    mbf = e.max_block_frames
+    sr = float(e.sample_rate)
+    sigs = []      # stereo signals: (node, first output port)
+    ctl = []       # (node, [(param id, lo, hi)]) for automation
+    samplers = []
+    for v in range(int(rng.integers(1, 7))):
+        frames = int(rng.integers(mbf + 8, 5 * mbf))
+        ch = 1 if rng.random() < 0.3 else 2
+        fmt = int(rng.choice([PLANAR_F32, PLANAR_I16, INTERLEAVED_F32, INTERLEAVED_U16]))
+        smp = e.new_sample(fmt, ch, encode(scenarios.voice_source(seed * 977 + v, frames, ch), fmt))
+        if rng.random() < 0.6:
+            s = e.sampler(float(rng.uniform(40, 100)))
+            samplers.append((s, smp, frames))
+            ctl.append((s, [(0, 0.0, 110.0)]))
+            sigs.append((s, 0))
+        else:
+            rs = e.resampler(smp, float(rng.choice([1.0, 0.5, 1.37, 2.0, 44100.0 / 48000.0])), loop=bool(rng.random() < 0.6), n_out=2)
+            ctl.append((rs, [(1, 0.3, 2.5), (3, 0.0, 1.0), (4, 0.0, float(frames - 1))]))
+            sigs.append((rs, 0))
+    ir = None
+    for step in range(int(rng.integers(2, 14))):
+        kind = int(rng.integers(0, 11))
+        src = sigs[int(rng.integers(0, len(sigs)))]
+        if kind == 0:
+            n = e.volume(float(rng.uniform(10, 130)))
+            ctl.append((n, [(0, 0.0, 130.0)]))
+        elif kind == 1:
+            n = e.pan(float(rng.uniform(-1, 1)))
+            ctl.append((n, [(0, -1.0, 1.0)]))
+        elif kind == 2:
+            n = e.width(float(rng.uniform(0, 2)))
+            ctl.append((n, [(0, 0.0, 2.0)]))
+        elif kind == 3:
+            n = e.hard_clip(float(rng.uniform(-18, 0)))
+        elif kind == 4:
+            n = e.biquad(int(rng.integers(0, 3)), float(rng.uniform(100, 10000)), float(rng.uniform(0.5, 4)))
+            ctl.append((n, [(1, 100.0, 10000.0), (2, 0.5, 4.0)]))
+        elif kind == 5:
+            n = e.delay(int(rng.integers(1, 900)) / sr, feedback=float(rng.uniform(0, 0.7)), mix=float(rng.uniform(0, 1)))
+            ctl.append((n, [(1, 0.0, 0.8), (2, 0.0, 1.0)]))
+        elif kind == 6:  # mono detour: stereo -> mono -> gain -> spatialiser (or mono -> stereo)
+            m = e.add_node(fwapi.STEREO_TO_MONO, 2, 1)
+            e.connect_stereo(src[0], m, 0, src[1])
+            g = e.volume(float(rng.uniform(30, 100)), ch=1)
+            e.connect(m, 0, g, 0)
+            ctl.append((g, [(0, 0.0, 120.0)]))
+            if rng.random() < 0.5:
+                n = e.spatial(float(rng.uniform(-4, 4)), float(rng.uniform(-1, 1)), float(rng.uniform(-4, 4)), n_in=1)
+                ctl.append((n, [(0, -4.0, 4.0), (1, -1.0, 1.0), (2, -4.0, 4.0)]))
+            else:
+                n = e.add_node(fwapi.MONO_TO_STEREO, 1, 2)
+            e.connect(g, 0, n, 0)
+            sigs.append((n, 0))
+            continue
+        elif kind == 7:  # sum of 2..6 signals (2/3/4-port paths and the n-port path), sometimes with an unconnected port
+            k = int(rng.integers(2, 7))
+            n = e.sum(k)
+            for p in range(k):
+                if rng.random() < 0.85:
+                    a = sigs[int(rng.integers(0, len(sigs)))]
+                    e.connect_stereo(a[0], n, 2 * p, a[1])
+            sigs.append((n, 0))
+            continue
+        elif kind == 8:
+            if ir is None:
+                ir = e.new_sample(PLANAR_F32, 2, scenarios.reverb_ir(seed, int(rng.integers(30, 400)), 2))
+            n = e.fir(ir)
+        elif kind == 9:  # stereo spatialiser
+            n = e.spatial(float(rng.uniform(-4, 4)), float(rng.uniform(-1, 1)), float(rng.uniform(-4, 4)), n_in=2)
+            ctl.append((n, [(0, -4.0, 4.0), (2, -4.0, 4.0)]))
+        else:
+            continue  # (a step that adds nothing: graphs of every size)
+        e.connect_stereo(src[0], n, 0, src[1])
+        sigs.append((n, 0))
+    # master: the last signal, or a sum of a few, to graph_out
+    if rng.random() < 0.5 and len(sigs) > 1:
+        k = int(rng.integers(2, 5))
+        m = e.sum(k)
+        for p in range(k):
+            a = sigs[-1 - p] if p < len(sigs) else sigs[0]
+            e.connect_stereo(a[0], m, 2 * p, a[1])
+        e.connect_stereo(m, e.graph_out_node)
+    else:
+        e.connect_stereo(sigs[-1][0], e.graph_out_node, 0, sigs[-1][1])
+    e.update()
+    for s, smp, frames in samplers:
+        e.sampler_set_sample(s, smp)
+        if rng.random() < 0.7:
+            e.sampler_set_loop_range(s, LOOP_FULL)
+        if rng.random() < 0.9:
+            e.sampler_play(s)
+    outs = []
+    for rnd in range(int(rng.integers(2, 6))):
+        k = int(rng.choice([1, 2, 4, 7, 19]))
+        if rnd > 0:
+            for node, params in ctl:
+                if rng.random() < 0.3:
+                    pid, lo, hi = params[int(rng.integers(0, len(params)))]
+                    e.set_param(node, pid, float(rng.uniform(lo, hi)), at_block=int(rng.integers(0, k)))
+            for s, smp, frames in samplers:
+                r = rng.random()
+                at = int(rng.integers(0, k))
+                if r < 0.1:
+                    e.sampler_pause(s, at_block=at)
+                elif r < 0.25:
+                    e.sampler_play(s, at_block=at)
+                elif r < 0.3:
+                    e.sampler_stop(s, at_block=at)
+                elif r < 0.4:
+                    e.sampler_set_playhead_secs(s, float(rng.integers(0, frames - 1)) / sr, at_block=at)
+        outs.append(np.asarray(e.process_blocks(k)))
+    return np.concatenate(outs)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FWGPU_FUZZ_SEEDS", "60"))))
+def test_random_dag_generic_executor_bit_exact(seed):
+    pick = np.random.default_rng(70_000 + seed)
+    mbf = int(pick.choice([32, 64, 100, 128, 256]))
+    want = fuzz_dag(oracle(max_block_frames=mbf), seed)
+    assert np.all(np.isfinite(want))
+    cls = AsyncEngine if pick.random() < 0.5 else GpuEngine
+    g = cls(max_block_frames=mbf, max_batch=int(pick.choice([1, 2, 5, 64])))
+    assert_bits_equal(want, fuzz_dag(g, seed), "dag seed %d plan %d %s" % (seed, g.cx.plan_kind(), cls.__name__))

@@ -330,3 +330,79 @@ def test_random_dag_generic_executor_bit_exact(seed):
     cls = AsyncEngine if pick.random() < 0.5 else GpuEngine
     g = cls(max_block_frames=mbf, max_batch=int(pick.choice([1, 2, 5, 64])))
     assert_bits_equal(want, fuzz_dag(g, seed), "dag seed %d plan %d %s" % (seed, g.cx.plan_kind(), cls.__name__))
+
+
+def fuzz_stream(e, seed, n_in):
+    """an effects rack on the stream inputs (graph_in -> random processors / mixes -> graph_out), driven with calls of
+    ARBITRARY length — whole blocks plus a partial one (processor.rs:95-96), also calls shorter than a block — and
+    parameter changes between calls.  No sampler (the reference's sampler asserts frames == max_block_frames: Q5)."""
+    rng = np.random.default_rng(90_000 + seed)
+    mbf = e.max_block_frames
+    sr = float(e.sample_rate)
+    gin = e.graph_in_node
+    sigs = [(gin, 2 * p) for p in range(n_in // 2)]
+    if n_in % 2:  # an odd last input goes through mono -> stereo
+        m = e.add_node(fwapi.MONO_TO_STEREO, 1, 2)
+        e.connect(gin, n_in - 1, m, 0)
+        sigs.append((m, 0))
+    ctl = []
+    for step in range(int(rng.integers(1, 10))):
+        kind = int(rng.integers(0, 8))
+        src = sigs[int(rng.integers(0, len(sigs)))]
+        if kind == 0:
+            n = e.volume(float(rng.uniform(10, 130)))
+            ctl.append((n, [(0, 0.0, 130.0)]))
+        elif kind == 1:
+            n = e.pan(float(rng.uniform(-1, 1)))
+            ctl.append((n, [(0, -1.0, 1.0)]))
+        elif kind == 2:
+            n = e.width(float(rng.uniform(0, 2)))
+            ctl.append((n, [(0, 0.0, 2.0)]))
+        elif kind == 3:
+            n = e.hard_clip(float(rng.uniform(-18, 0)))
+        elif kind == 4:
+            n = e.biquad(int(rng.integers(0, 3)), float(rng.uniform(100, 10000)), float(rng.uniform(0.5, 4)))
+            ctl.append((n, [(1, 100.0, 10000.0), (2, 0.5, 4.0)]))
+        elif kind == 5:
+            n = e.delay(int(rng.integers(1, 700)) / sr, feedback=float(rng.uniform(0, 0.7)), mix=float(rng.uniform(0, 1)))
+            ctl.append((n, [(1, 0.0, 0.8), (2, 0.0, 1.0)]))
+        elif kind == 6:
+            k = int(rng.integers(2, 5))
+            n = e.sum(k)
+            for p in range(k):
+                a = sigs[int(rng.integers(0, len(sigs)))]
+                e.connect_stereo(a[0], n, 2 * p, a[1])
+            sigs.append((n, 0))
+            continue
+        else:
+            n = e.spatial(float(rng.uniform(-4, 4)), float(rng.uniform(-1, 1)), float(rng.uniform(-4, 4)), n_in=2)
+            ctl.append((n, [(0, -4.0, 4.0), (2, -4.0, 4.0)]))
+        e.connect_stereo(src[0], n, 0, src[1])
+        sigs.append((n, 0))
+    e.connect_stereo(sigs[-1][0], e.graph_out_node, 0, sigs[-1][1])
+    e.update()
+    outs = []
+    for rnd in range(int(rng.integers(3, 9))):
+        frames = int(rng.choice([1, 3, mbf - 1, mbf, mbf + 1, 2 * mbf + 5, 3 * mbf, int(rng.integers(1, 5 * mbf))]))
+        if rnd > 0:
+            for node, params in ctl:
+                if rng.random() < 0.35:
+                    pid, lo, hi = params[int(rng.integers(0, len(params)))]
+                    e.set_param(node, pid, float(rng.uniform(lo, hi)))
+        if rng.random() < 0.15:
+            inp = np.zeros(frames * n_in, dtype=np.float32)  # digital silence on the inputs
+        else:
+            inp = fwapi.xorshift_uniform(seed * 31 + rnd, frames * n_in)
+        outs.append(np.asarray(e.process_interleaved(frames, 2, inp=inp, n_in_ch=n_in)))
+    return np.concatenate(outs)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FWGPU_FUZZ_SEEDS", "60"))))
+def test_random_effects_rack_on_stream_inputs_any_call_length(seed):
+    pick = np.random.default_rng(95_000 + seed)
+    mbf = int(pick.choice([16, 64, 100, 256]))
+    n_in = int(pick.choice([1, 2, 3, 4]))
+    want = fuzz_stream(oracle(max_block_frames=mbf, num_graph_inputs=n_in), seed, n_in)
+    assert np.all(np.isfinite(want))
+    g = GpuEngine(max_block_frames=mbf, num_graph_inputs=n_in, max_batch=int(pick.choice([1, 3, 64])))
+    assert_bits_equal(want, fuzz_stream(g, seed, n_in), "stream seed %d" % seed)

@@ -130,7 +130,21 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     __shared__ unsigned long long srcp[32][CH_FAST_KMAX];
     __shared__ unsigned long long srcp1[32][CH_FAST_KMAX];
     __shared__ uint32_t wrap_at[32][CH_FAST_KMAX];
-    bool fast_ok = fv.n_cmds == 0 && K <= CH_FAST_KMAX && !(fv.dbg & 32);  // FWGPU_CHAIN_SKIP=32: A/B against the general loop
+    bool fast_ok = K <= CH_FAST_KMAX && !(fv.dbg & 32);  // FWGPU_CHAIN_SKIP=32: A/B against the general loop
+    if (fv.n_cmds && active) {
+        // messages for THIS leaf's biquads / delays in this call (coefficients, feedback, mix) are replayed block by
+        // block by the general loop; messages for other leaves, for master nodes or for later calls do not concern this
+        // workgroup (gain / sampler messages show up in the descriptors scanned below)
+        const uint32_t b1 = cmd_block0 + (uint32_t)K;
+        if (has_bq) {
+            const int i = chain_cmd_lower_bound(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0);
+            fast_ok = fast_ok && !(i < fv.n_cmds && fv.cmds[i].state == vd.bq_state && fv.cmds[i].block < b1);
+        }
+        if (has_dl) {
+            const int i = chain_cmd_lower_bound(fv.cmds, fv.n_cmds, vd.dl_state, cmd_block0);
+            fast_ok = fast_ok && !(i < fv.n_cmds && fv.cmds[i].state == vd.dl_state && fv.cmds[i].block < b1);
+        }
+    }
     for (int i = threadIdx.x; i < ports * K; i += CH_THREADS) {
         const int pv = i / K, pk = i - pv * K, pvoice = ld.first_voice + pv;
         const VoiceRef* r = &fv.refs[(size_t)pvoice * fv.refs_stride];

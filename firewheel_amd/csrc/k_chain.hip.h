@@ -180,7 +180,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         srcp1[pv][pk] = (unsigned long long)a1;
         wrap_at[pv][pk] = wr;
     }
-    if (active) fast_ok = fast_ok && has_bq && has_dl && (!is_worker || D >= 3u * TT);
+    if (active && has_dl && is_worker) fast_ok = fast_ok && D >= 3u * TT;  // (voices without a biquad / delay pass through)
     const bool wg_fast = __syncthreads_and(fast_ok ? 1 : 0) != 0;
     const int n_steps = wg_fast ? ((n_tiles + 3 + 1) & ~1) : n_tiles + 3;  // the fast loop is unrolled by two
     if (threadIdx.x == 0) atomicAdd(fv.chain_stats + (wg_fast ? 0 : 1), 1ull);  // fwgpu_plan_chain_stats (tests)
@@ -292,9 +292,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) gpost[j] = gsp->g[j + 1][ch];
         const bool src_zero = (vflags & VB_SRC_ZERO) != 0, silent = (vflags & VB_SILENT) != 0;
         float* const dummy = fv.chain_dummy + (size_t)threadIdx.x * (4 * NQ);
-        const float* const rbase = active ? ring : dummy;
-        const uint32_t Dv = active ? D : 0x7fffffffu;
-        uint32_t pos_c = active ? pos : 0u, pos_i = pos_c;  // ring position of the tile S3a consumes / the tile requested
+        const bool ringed = active && has_dl;  // this lane's voice has a delay line
+        const float* const rbase = ringed ? ring : dummy;
+        const uint32_t Dv = ringed ? D : 0x7fffffffu;
+        uint32_t pos_c = ringed ? pos : 0u, pos_i = pos_c;  // ring position of the tile S3a consumes / the tile requested
         int kli = 0, tli = 0;                               // (block, tile in block) of the next source tile to request
         int klc = 0, tlc = 0;                               // ... of the tile S1 computes
         v4f xsA[NQ], xsB[NQ], rgA[NQ], rgB[NQ];
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             return sl >= Dv ? sl - Dv : sl;
         };
         auto issue_ring = [&](v4f(&rg)[NQ], int t) {
-            const bool real = t < n_tiles && active;
+            const bool real = t < n_tiles && ringed;
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 const uint32_t sl = slot_of(pos_i, j);
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         };
         auto wstep = [&](int s, v4f(&xs)[NQ], v4f(&rg)[NQ]) {
             const bool v1 = s < n_tiles;
-            const bool v3 = active && s >= 2 && s - 2 < n_tiles;
+            const bool v3 = ringed && s >= 2 && s - 2 < n_tiles;  // S3a of a real tile of a voice with a delay line
             CH_TRACE(0);
             v4f yv[NQ];
             {
@@ -381,7 +382,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                 for (int j = 0; j < NQ; ++j) {
                     const v4f xc = x[j];
                     const v4f x1v = (v4f){p1, xc[0], xc[1], xc[2]}, x2v = (v4f){p2, p1, xc[0], xc[1]};
-                    const v4f a = ((xc * b0) + (x1v * b1)) + (x2v * b2);  // ((b0*x) + (b1*x1)) + (b2*x2)
+                    const v4f ff = ((xc * b0) + (x1v * b1)) + (x2v * b2);  // ((b0*x) + (b1*x1)) + (b2*x2)
+                    const v4f a = has_bq ? ff : xc;                        // no biquad: the samples pass through untouched
                     p1 = xc[3];
                     p2 = xc[2];
                     *(v4f*)(row + 4 * j) = a;
@@ -423,7 +425,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     float* sp = (v3 && sl[j] + 4u <= Dv) ? ring + sl[j] : dummy + 4 * j;
                     asm volatile("" : "+v"(sp));
                     *(v4f_u __attribute__((address_space(1)))*)(uint64_t)sp = nv;
-                    y = (y * dry) + (rg[j] * mix);  // out = (x*dry) + (d*mix)
+                    const v4f wet = (y * dry) + (rg[j] * mix);  // out = (x*dry) + (d*mix)
+                    y = ringed ? wet : y;                       // no delay: untouched
 #pragma unroll
                     for (int g = 0; g < FW_MAX_STAGES - 1; ++g) {
                         if (g + 1 >= fv.n_gain_stages) break;

@@ -147,7 +147,9 @@ class TaggedOracle(object):
         return getattr(self.e, name)
 
     def _defer(self, at_block, fn, *a):
-        if at_block == 0:
+        # a message for block 0 is delivered right away — unless one carried over from the previous call (tagged beyond
+        # its last block) is still waiting for block 0: messages reach a node in the order they were sent
+        if at_block == 0 and not any(at == 0 for at, _, _ in self.q):
             fn(*a)
         else:
             self.q.append((at_block, fn, a))

@@ -35,7 +35,7 @@ def encode(data, fmt):
 def fuzz_run(e, seed):
     rng = np.random.default_rng(seed)
     mbf = e.max_block_frames
-    n_voices = int(rng.integers(1, 71))
+    n_voices = int(rng.integers(1, 71)) if rng.random() < 0.85 else int(rng.integers(71, 260))  # several leaves and levels
     radix = int(rng.choice([2, 3, 8, 32]))
     # 0 gains only, 1 + biquad, 2 + delay, 3 + both (each present in ~90 % of the voices), 4 = every voice has both and
     # delays of >= 3 k_chain tiles: calls without pending messages then take k_chain's steady-call loop
@@ -112,7 +112,7 @@ def fuzz_run(e, seed):
     outs = []
     plugged = []  # voices added after the first compile: (sampler, last node, (sum, port))
     for rnd in range(int(rng.integers(3, 7))):
-        k = int(rng.choice([1, 2, 3, 5, 9, 24]))
+        k = int(rng.choice([1, 2, 3, 5, 9, 24, 70]))
         if rnd > 0 and rng.random() < 0.4:
             # a graph edit between calls (graph/graph.rs:201-231, :268-299, :396-477 + recompile): plug a new dry voice
             # into a spare port, or pull one out again — node state of everything else carries over
@@ -141,7 +141,7 @@ def fuzz_run(e, seed):
             for vc in voices:
                 if rng.random() > 0.35:
                     continue
-                at = int(rng.integers(0, k))
+                at = int(rng.integers(0, k + (3 if rng.random() < 0.1 else 0)))  # sometimes a block of a LATER call
                 what = int(rng.integers(0, 10))
                 sr = float(e.sample_rate)
                 if what == 0:

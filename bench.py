@@ -38,10 +38,10 @@ MFMA_F32_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md:41 (dense f3
 # fwgpu_process_blocks_device call renders (throughput mode: 768 x 256 frames = 4.1 s of audio per call for config 2);
 # the fixed cost of a call (control kernel + upper sums, ~10 us) is amortised over it.
 DEFAULTS = {
-    "cfg2": (1024, 256, 768, 262144, 40),
-    "cfg3": (4096, 512, 64, 65536, 12),
-    "cfg4": (256, 256, 16, 65536, 10),
-    "cfg5": (8192, 1024, 64, 65536, 12),
+    "cfg2": (1024, 256, 768, 262144, 200),
+    "cfg3": (4096, 512, 64, 65536, 60),
+    "cfg4": (256, 256, 16, 65536, 30),
+    "cfg5": (8192, 1024, 64, 65536, 60),
 }
 
 

@@ -112,6 +112,8 @@ struct fwgpu_ctx {
     bool fused_fx = false;  // the fused plan's leaves run k_chain (biquad / delay in the voice chains)
     int chain_nq = 1;       // k_chain tile size / 64 frames
     int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
+    int n_groups = 0;  // k_chain workgroups (groups of consecutive leaves)
+    DevBuf d_groups;
     uint32_t epoch = 1;  // invalidates every VoiceCache when bumped (plan install, sample-table change)
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start, d_chain_dummy, d_chain_stats;
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
@@ -898,6 +900,38 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         c->ramp_slots = 2 * (1 + fb.max_stages);
         if ((rc = upload(c, c->d_voices, fb.voices.data(), fb.voices.size() * sizeof(VoiceDesc)))) return rc;
         if ((rc = upload(c, c->d_leaves, fb.leaves.data(), fb.leaves.size() * sizeof(LeafDesc)))) return rc;
+        c->n_groups = 0;
+        if (c->fused_fx) {
+            // k_chain workgroups: consecutive leaves packed greedily into groups of <= 32 voices / <= 8 leaves (the
+            // voices of consecutive leaves are consecutive), so that a tree of small leaves fills the 32 voice rows
+            std::vector<ChainGroup> groups;
+            for (size_t l = 0; l < fb.leaves.size(); ++l) {
+                const LeafDesc& ld = fb.leaves[l];
+                if (groups.empty() || groups.back().n_voices + ld.ports > 32 || groups.back().n_leaves >= CH_GROUP_LEAVES) {
+                    ChainGroup g;
+                    memset(&g, 0, sizeof(g));
+                    g.first_voice = ld.first_voice;
+                    groups.push_back(g);
+                }
+                ChainGroup& g = groups.back();
+                const int li = g.n_leaves++;
+                g.out_buf[li] = ld.out_buf;
+                g.row0[li] = g.n_voices;
+                g.ports[li] = ld.ports;
+                g.start_mask |= 1u << g.n_voices;
+                if (!(ld.ports == 2 || ld.ports == 3 || ld.ports == 4))  // sum.rs:67-133 (Q13): the n-port path skips silent ports
+                    g.masked_rows |= (ld.ports >= 32 ? 0xffffffffu : ((1u << ld.ports) - 1u)) << g.n_voices;
+                g.n_voices += ld.ports;
+            }
+            for (ChainGroup& g : groups) {
+                const int P = g.ports[0];
+                bool uni = g.n_voices == 32 && (P == 32 || P == 16 || P == 8 || P == 4);
+                for (int i = 0; i < g.n_leaves && uni; ++i) uni = g.ports[i] == P;
+                g.uniform_ports = uni ? P : 0;
+            }
+            c->n_groups = (int)groups.size();
+            if ((rc = upload(c, c->d_groups, groups.data(), groups.size() * sizeof(ChainGroup)))) return rc;
+        }
         const size_t K = c->kmax;
         HIPC(c, c->d_blks.ensure(K * c->n_voices * sizeof(VoiceBlk)));
         HIPC(c, c->d_refs.ensure(K * c->n_voices * sizeof(VoiceRef)));
@@ -1140,6 +1174,8 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     fv.stride = c->stride;
     fv.frames = (int)c->mbf;
     fv.fx_plan = c->fused_fx ? 1 : 0;
+    fv.groups = c->d_groups.as<ChainGroup>();
+    fv.n_groups = c->n_groups;
     fv.ext = c->d_ext.as<float>();
     fv.chain_start = c->d_chain_start.as<ChainStart>();
     fv.chain_dummy = c->d_chain_dummy.as<float>();
@@ -1397,7 +1433,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
         if (s.alive && s.owned && s.d_data) (void)hipFree(s.d_data);
     DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
                       &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
-                      &c->d_bus, &c->d_bus_flags, &c->d_chain_start, &c->d_chain_dummy, &c->d_chain_stats, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
+                      &c->d_bus, &c->d_bus_flags, &c->d_chain_start, &c->d_chain_dummy, &c->d_chain_stats, &c->d_groups, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
                       &c->d_root_bufs, &c->d_tail_nodes, &c->d_tail_in, &c->d_tail_out, &c->d_tail_idx, &c->d_tail_frozen, &c->d_frozen, &c->d_frozen_ph, &c->d_fir_rows, &c->d_fir_tiles, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask};
     for (DevBuf* b : bufs) b->release();

@@ -135,9 +135,9 @@ int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd
     return (int)hipGetLastError();
 }
 int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0, int nq) {
-    if (fv.n_leaves <= 0 || K <= 0) return 0;
-    if (nq == 2) hipLaunchKernelGGL(k_chain<2>, dim3(fv.n_leaves, 2), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
-    else hipLaunchKernelGGL(k_chain<1>, dim3(fv.n_leaves, 2), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
+    if (fv.n_groups <= 0 || K <= 0) return 0;
+    if (nq == 2) hipLaunchKernelGGL(k_chain<2>, dim3(fv.n_groups, 2), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
+    else hipLaunchKernelGGL(k_chain<1>, dim3(fv.n_groups, 2), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
     return (int)hipGetLastError();
 }
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {

@@ -57,6 +57,8 @@ struct FusedView {
     int n_leaves;
     int stride;
     int frames;
+    const ChainGroup* groups;  // k_chain plan: workgroups = groups of consecutive leaves
+    int n_groups;
     int fx_plan;  // 1 = the chain plan (k_chain renders the leaves): descriptor conventions of k_voice_control
     float* ext;  // biquad coefficients + history, delay rings (k_chain plan)
     ChainStart* chain_start;  // [n_voices] (k_chain plan)

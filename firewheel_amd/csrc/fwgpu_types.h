@@ -195,6 +195,20 @@ struct ChainStart {
 };
 static_assert(sizeof(ChainStart) == 48, "ChainStart layout");
 
+#define CH_GROUP_LEAVES 8
+// k_chain workgroup = up to CH_GROUP_LEAVES consecutive leaf SumNodes with at most 32 voices together (their voices are
+// consecutive): a tree of small leaves (a bus per instrument) fills the workgroup's 32 voice rows like one wide leaf
+struct ChainGroup {
+    int first_voice, n_voices;
+    int n_leaves;
+    int uniform_ports;     // 32 / 16 / 8 / 4: the 32 rows are full leaves of exactly that many ports; 0 otherwise
+    uint32_t start_mask;   // bit r: voice row r is port 0 of a leaf
+    uint32_t masked_rows;  // bit r: row r belongs to a leaf on the n-port path (ports not 2, 3 or 4): silent ports skipped
+    int out_buf[CH_GROUP_LEAVES];  // per leaf: compact bus-buffer id of output channel 0
+    int row0[CH_GROUP_LEAVES];     // per leaf: its first voice row
+    int ports[CH_GROUP_LEAVES];
+};
+
 struct LeafDesc {  // a SumNode whose ports are all voice chains (nodes/sum.rs)
     int first_voice;
     int ports;     // num_in_ports

@@ -65,6 +65,24 @@ struct ChainInfo {  // what a worker lane carries from S1 of a tile to S3a of th
     float g[FW_MAX_STAGES - 1];    // this channel's constant post-gain stages (1..)
 };
 
+// S3b for a workgroup whose 32 rows are 32/P full leaves of P ports each with nothing to skip: straight-line adds in port
+// order per leaf (static register indices, no per-row tests)
+template <int P>
+__device__ __forceinline__ void chain_mix_uniform(const v4f (&x)[32], uint32_t silent_rows, float* bus_blk, uint8_t* flag_blk,
+                                                  const int* g_out, int ch, int stride, bool write_flag) {
+#pragma unroll
+    for (int l = 0; l < 32 / P; ++l) {
+        v4f acc = x[l * P];  // sum.rs:117 copy port 0 (also when silent: a cleared buffer)
+#pragma unroll
+        for (int j = 1; j < P; ++j) acc = acc + x[l * P + j];
+        const uint32_t rows = (P == 32 ? 0xffffffffu : ((1u << P) - 1u)) << (l * P);
+        const bool all_silent = (silent_rows & rows) == rows;  // sum.rs:52-56
+        const int ob = g_out[l];
+        *(v4f*)(bus_blk + (size_t)(ob + ch) * stride) = all_silent ? splat(0.f) : acc;
+        if (write_flag) flag_blk[ob + ch] = all_silent ? 1 : 0;
+    }
+}
+
 template <int NQ>
 __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint32_t cmd_block0) {
     constexpr int TT = 64 * NQ;        // frames per tile
@@ -73,9 +91,22 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     __shared__ float tile[CH_NBUF][32][PITCH];  // row = voice (this workgroup's channel)
     __shared__ uint32_t silf[CH_NBUF][32];      // chain output cleared + flagged silent (VB_SILENT) per voice
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
-    const LeafDesc ld = fv.leaves[blockIdx.x];
+    // up to 8 consecutive leaves, <= 32 voices: this workgroup's rows.  Per-leaf fields are read through LDS (indexing a
+    // register copy of the record by a run-time leaf index would push it to scratch)
+    const ChainGroup* gp = &fv.groups[blockIdx.x];
+    struct {
+        int first_voice, n_voices, n_leaves, uniform_ports;
+        uint32_t start_mask, masked_rows;
+    } grp = {gp->first_voice, gp->n_voices, gp->n_leaves, gp->uniform_ports, gp->start_mask, gp->masked_rows};
+    __shared__ int g_out[CH_GROUP_LEAVES];
+    __shared__ uint32_t g_rows[CH_GROUP_LEAVES];  // row mask of each leaf
+    if (threadIdx.x < CH_GROUP_LEAVES) {
+        const int l = threadIdx.x < (unsigned)grp.n_leaves ? (int)threadIdx.x : 0;
+        g_out[threadIdx.x] = gp->out_buf[l];
+        g_rows[threadIdx.x] = (gp->ports[l] >= 32 ? 0xffffffffu : ((1u << gp->ports[l]) - 1u)) << gp->row0[l];
+    }  // (made visible by the __syncthreads_or below)
     const int ch = blockIdx.y;  // L and R never meet before the mix bus: one workgroup per (leaf, channel)
-    const int ports = ld.ports;
+    const int ports = grp.n_voices;  // voice rows in use
     const int frames = fv.frames;
     const int tpb = frames / TT;  // the plan guarantees frames % TT == 0
     const int n_tiles = K * tpb;
@@ -96,7 +127,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     const int v = is_worker ? (wl >> 4) : lane;
     const int q = wl & 15;
     const bool active = v < ports && (is_worker || (is_serial && lane < 32));
-    const int voice = ld.first_voice + (active ? v : 0);
+    const int voice = grp.first_voice + (active ? v : 0);
     const VoiceDesc vd = fv.voices[voice];
     const bool has_bq = active && vd.bq_state >= 0, has_dl = active && vd.dl_state >= 0;
     const ChainStart cs = fv.chain_start[voice];
@@ -146,7 +177,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         }
     }
     for (int i = threadIdx.x; i < ports * K; i += CH_THREADS) {
-        const int pv = i / K, pk = i - pv * K, pvoice = ld.first_voice + pv;
+        const int pv = i / K, pk = i - pv * K, pvoice = grp.first_voice + pv;
         const VoiceRef* r = &fv.refs[(size_t)pvoice * fv.refs_stride];
         const VoiceRef rk = r[pk];
         const uint32_t fk = rk.flags_gset & 0xffu, kind = fk & (VB_SIMPLE | VB_WRAP | VB_TAIL_ZERO);
@@ -214,7 +245,6 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     // role-local (block, tile-in-block) counters: S1 computes tile s, S2 s-1, S3a s-2, S3b s-3; loads issue for s+1
     int k1 = 0, t1 = 0, k2 = 0, t2 = 0, k3 = 0, t3 = 0, k4 = 0, t4 = 0, kla = 0, tla = 0;
     const uint64_t port_mask = mask_all_silent_bits(ports);
-    const bool masked = !(ports == 2 || ports == 3 || ports == 4);  // sum.rs:67-133 (Q13)
 
     // issue the HBM loads of tile `la` (= the tile S1 computes in the next step); at a block start first adopt the
     // block's descriptor (in flight since the previous step) and request its gain set
@@ -723,27 +753,52 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                 v4f x[32];
 #pragma unroll
                 for (int u = 0; u < 32; ++u) x[u] = *(const v4f*)(col + (size_t)(u < ports ? u : ports - 1) * PITCH);
-                const uint64_t silent_ports = __ballot(lane < ports && silf[buf][lane & 31] != 0) & port_mask;
-                const bool all_silent = silent_ports == port_mask;
-                const uint64_t skip = masked ? silent_ports : 0ull;  // :122-124 (n-port path only)
-                v4f acc = x[0];  // sum.rs:117 copy port 0 (also when silent: a cleared buffer)
-                if (ports == 32 && skip == 0ull) {
-                    // the usual leaf: full, nothing silent — 31 plain adds in port order (the masked form below costs
-                    // ~30 scalar + vector instructions per port on this one wave, which made S3b the longest stage)
-#pragma unroll
-                    for (int u = 1; u < 32; ++u) acc = acc + x[u];
+                const uint32_t silent_rows = (uint32_t)(__ballot(lane < ports && silf[buf][lane & 31] != 0) & port_mask);
+                float* bus_blk = fv.bus + (size_t)k4 * fv.bus_blk_stride + t4 * TT + 4 * lane;
+                uint8_t* flag_blk = fv.bus_flags + (size_t)k4 * fv.bus_flags_blk_stride;
+                // the usual workgroups: 32 rows = full leaves of one size with nothing to skip (a silent port matters only
+                // on the n-port path, sum.rs:122-124) — straight-line adds; everything else: the row walk below
+                const int up = (silent_rows & grp.masked_rows) || (fv.dbg & 64) ? 0 : grp.uniform_ports;  // (64: A/B)
+                const bool wf = t4 == 0 && lane == 0;
+                if (up == 32) {
+                    chain_mix_uniform<32>(x, silent_rows, bus_blk, flag_blk, g_out, ch, fv.stride, wf);
+                } else if (up == 16) {
+                    chain_mix_uniform<16>(x, silent_rows, bus_blk, flag_blk, g_out, ch, fv.stride, wf);
+                } else if (up == 8) {
+                    chain_mix_uniform<8>(x, silent_rows, bus_blk, flag_blk, g_out, ch, fv.stride, wf);
+                } else if (up == 4) {
+                    chain_mix_uniform<4>(x, silent_rows, bus_blk, flag_blk, g_out, ch, fv.stride, wf);
                 } else {
+                    // several leaves share the rows: walk the rows once in order (static register indices; the leaf
+                    // boundaries and the rows to add are bit masks in SGPRs), restart the sum at each leaf's port 0, store
+                    // when a leaf is complete.  Selects instead of branches for the arithmetic (branches made the
+                    // compiler shuffle the accumulator through copies: 7 100 cycles per tile); the only branch per row
+                    // is the rarely taken "a leaf ends here".
+                    const uint32_t row_mask = ports >= 32 ? 0xffffffffu : ((1u << ports) - 1u);
+                    const uint32_t starts = grp.start_mask & row_mask;
+                    const uint32_t adds = row_mask & ~starts & ~(silent_rows & grp.masked_rows);  // sum.rs:122-124: skipped
+                    v4f acc = x[0];  // sum.rs:117 copy port 0 (also when silent: a cleared buffer)
+                    int li = 0;
+#define CH_FLUSH_LEAF()                                                                                       \
+    do {                                                                                                      \
+        const uint32_t rows__ = g_rows[li];                                                                   \
+        const int ob__ = g_out[li];                                                                           \
+        const bool as__ = (silent_rows & rows__) == rows__;                                                   \
+        *(v4f*)(bus_blk + (size_t)(ob__ + ch) * fv.stride) = as__ ? splat(0.f) : acc; /* sum.rs:52-56 */       \
+        if (t4 == 0 && lane == 0) flag_blk[ob__ + ch] = as__ ? 1 : 0;                                          \
+        ++li;                                                                                                 \
+    } while (0)
 #pragma unroll
                     for (int u = 1; u < 32; ++u) {
-                        const bool use = u < ports && !((skip >> u) & 1ull);
+                        const bool st = (starts >> u) & 1u, ad = (adds >> u) & 1u;  // wave-uniform
+                        if (__builtin_amdgcn_readfirstlane((int)st)) CH_FLUSH_LEAF();
                         const v4f t = acc + x[u];
-                        acc = use ? t : acc;
+                        const v4f y = st ? x[u] : t;
+                        acc = (st || ad) ? y : acc;
                     }
+                    CH_FLUSH_LEAF();
+#undef CH_FLUSH_LEAF
                 }
-                if (all_silent) acc = splat(0.f);  // sum.rs:52-56
-                float* bus = fv.bus + (size_t)k4 * fv.bus_blk_stride + (size_t)(ld.out_buf + ch) * fv.stride + t4 * TT + 4 * lane;
-                *(v4f*)bus = acc;
-                if (t4 == 0 && lane == 0) fv.bus_flags[(size_t)k4 * fv.bus_flags_blk_stride + ld.out_buf + ch] = all_silent ? 1 : 0;
                 if (++t4 == tpb) {
                     t4 = 0;
                     ++k4;

@@ -932,3 +932,28 @@ def test_wide_leaves_with_short_blocks(n_voices, mbf):
     g = GpuEngine(max_block_frames=mbf)
     assert_bits_equal(run(oracle(max_block_frames=mbf)), run(g), "wide leaf, short block")
     assert g.cx.plan_kind() == 1
+
+
+def test_chain_plan_steady_loop_soak_equals_generic_executor():
+    # 1024 voices x 167 blocks of 512 frames through k_chain's steady-call loop: short delay lines (3 tiles .. 3 tiles +
+    # 700 frames: hundreds of laps, a straddling quad per lap and voice), loops that wrap inside blocks, 64-block calls.
+    # Reference: the generic executor (separate kernels, serial biquads and delays) — bit for bit; the oracle checks the head.
+    def run(e, calls):
+        v = scenarios.build_chain_bank(e, 1024, radix=32, src_frames=1500, mono_every=9, first_delay_frames=384,
+                                       min_delay_frames=385, max_delay_frames=1085)
+        for vc in v:
+            e.sampler_set_loop_range(vc["sampler"], fwapi.LOOP_FULL)
+            e.sampler_play(vc["sampler"])
+        return np.concatenate([np.asarray(e.process_blocks(k)) for k in calls])
+
+    calls = (2, 64, 64, 37)
+    gf = GpuEngine(max_block_frames=512, max_batch=64)
+    of = run(gf, calls)
+    assert gf.cx.plan_kind() == 2
+    steady, general = gf.cx.plan_chain_stats()
+    assert steady >= 3 * 64, (steady, general)  # 32 leaves x 2 channels, at least the three long calls
+    og = run(GpuEngine(max_block_frames=512, force_generic=True, max_batch=64), calls)
+    assert_bits_equal(og, of, "steady-loop soak vs generic executor")
+    assert np.all(np.isfinite(of)) and np.std(of) > 0.1
+    oo = run(oracle(max_block_frames=512), (2,))
+    assert_bits_equal(oo, of[:oo.size], "steady-loop soak head vs oracle")

@@ -30,6 +30,8 @@ struct DevBuf {
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap && p) return hipSuccess;
+        const bool regrow = p != nullptr;  // a buffer that grows once tends to grow again (graph edits add a few nodes
+                                           // at a time; a 2 GB pool costs ~250 ms to free + allocate): leave headroom
         if (p) {
             hipError_t e = hipFree(p);
             if (e != hipSuccess) return e;
@@ -37,8 +39,17 @@ struct DevBuf {
             cap = 0;
         }
         size_t want = bytes < 256 ? 256 : bytes;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
+        hipError_t e = hipErrorOutOfMemory;
+        if (regrow) {
+            const size_t roomy = want + want / 4;
+            e = hipMalloc(&p, roomy);
+            if (e == hipSuccess) cap = roomy;
+            else (void)hipGetLastError();
+        }
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, want);
+            if (e == hipSuccess) cap = want;
+        }
         return e;
     }
     void release() {

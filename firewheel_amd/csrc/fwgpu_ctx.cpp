@@ -498,15 +498,22 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
         int n_sum = 0, n_chain = 0;
         for (int p = 0; p < s.n_in / 2; ++p) {
             int src;
+            if (s.in_src_node[2 * p] < 0 && s.in_src_node[2 * p + 1] < 0) {
+                // an unconnected stereo port (a voice slot nothing is plugged into): the reference feeds it the cleared,
+                // silent-flagged buffer (schedule.rs:310-313) — a null kid: a null voice under a leaf, bus 0 above
+                r.kids.push_back(-1);
+                continue;
+            }
             if (!stereo_src(s, 2 * p, src)) return false;
             r.kids.push_back(src);
             if (plan.nodes[src].kind == K_SUM) n_sum++;
             else n_chain++;
         }
         if (n_sum && n_chain) return false;
-        r.leaf = n_chain > 0;
+        r.leaf = n_sum == 0;  // (a SumNode with nothing plugged in at all is a leaf of null voices)
         if (!r.leaf)
-            for (int k : r.kids) work.push_back(k);
+            for (int k : r.kids)
+                if (k >= 0) work.push_back(k);
         sum_index[si] = (int)sums.size();
         sums.push_back(r);
     }
@@ -526,6 +533,13 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
         r.out_buf = next_bus;
         next_bus += 2;
         for (int end : r.kids) {
+            if (end < 0) {  // null voice: k_voice_control emits a constant silent, cleared-source record for it
+                VoiceDesc vd;
+                memset(&vd, 0, sizeof(vd));
+                vd.sampler_state = vd.bq_state = vd.dl_state = -1;
+                fb.voices.push_back(vd);
+                continue;
+            }
             // walk upstream: end -> ... -> sampler
             // accepted shape: sampler -> [biquad] -> [delay] -> (volume|pan)*
             std::vector<int> chain;
@@ -585,7 +599,8 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
         if (height[i] >= 0) return height[i];
         if (sums[i].leaf) return height[i] = 0;
         int m = 0;
-        for (int k : sums[i].kids) m = std::max(m, h(sum_index[k]) + 1);
+        for (int k : sums[i].kids)
+            if (k >= 0) m = std::max(m, h(sum_index[k]) + 1);
         return height[i] = m;
     };
     int maxh = 0;
@@ -610,9 +625,9 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
             nd.state = 0;
             nd.aux0 = (int)r.kids.size();
             for (int k : r.kids) {
-                int cb = sums[sum_index[k]].out_buf;
+                const int cb = k >= 0 ? sums[sum_index[k]].out_buf : 0;  // unconnected: bus 0, the cleared + silent-flagged buffer
                 fb.up_in.push_back(cb);
-                fb.up_in.push_back(cb + 1);
+                fb.up_in.push_back(k >= 0 ? cb + 1 : 0);
             }
             fb.up_out.push_back(r.out_buf);
             fb.up_out.push_back(r.out_buf + 1);

@@ -317,6 +317,22 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
     const bool simple_frames = (frames & 3) == 0;
     const bool fx = vd.bq_state >= 0 || vd.dl_state >= 0;  // the voice has a biquad / delay: silence does not pass it
     const bool fxp = fv.fx_plan != 0;                        // chain plan: k_chain's descriptor conventions for EVERY voice
+    if (vd.sampler_state < 0) {
+        // a null voice = an unconnected port of a leaf SumNode: the cleared, silent-flagged buffer of schedule.rs:310-313
+        // in every block (chain plan: as a VB_SIMPLE cleared-source record, which is what k_chain reads)
+        VoiceRef r;
+        r.src_l = nullptr;
+        r.r_delta = 0;
+        r.flags_gset = VB_SILENT | (fxp ? (VB_SRC_ZERO | VB_SIMPLE) : 0u);
+        for (int k = lane; k < K; k += WAVE) fv.refs[(size_t)vi * fv.refs_stride + k] = r;
+        if (fxp && lane < FW_GSETS) {
+            GainSet one;
+#pragma unroll
+            for (int j = 0; j < FW_MAX_STAGES; ++j) one.g[j][0] = one.g[j][1] = 1.0f;
+            fv.gsets[(size_t)vi * FW_GSETS + lane] = one;
+        }
+        return;
+    }
 
     // ---- k_chain plan: what both channel workgroups of the voice's leaf share is owned HERE — the record holds the
     // values at the start of this call (k_chain replays the call's messages block by block from them), the node state

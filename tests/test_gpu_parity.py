@@ -957,3 +957,59 @@ def test_chain_plan_steady_loop_soak_equals_generic_executor():
     assert np.all(np.isfinite(of)) and np.std(of) > 0.1
     oo = run(oracle(max_block_frames=512), (2,))
     assert_bits_equal(oo, of[:oo.size], "steady-loop soak head vs oracle")
+
+
+@pytest.mark.parametrize("chain", [False, True])
+def test_unconnected_sum_ports_stay_on_the_fused_plans_and_take_voices_later(chain):
+    # voice slots nothing is plugged into (an unconnected stereo port of a leaf SumNode; also one on an upper SumNode):
+    # the reference feeds them the cleared, silent-flagged buffer (schedule.rs:310-313).  The fused plans model them as
+    # null voices / bus 0; plugging a voice in later recompiles, keeps the plan and every node's state.
+    def run(e):
+        rng = np.random.default_rng(3)
+        ends, smp = [], []
+        for v in range(21):
+            s = e.sampler(90.0)
+            cur = s
+            if chain:
+                b = e.biquad(0, 2000.0 + 100 * v, 0.8)
+                d = e.delay((200 + 13 * v) / 48000.0, feedback=0.3, mix=0.4)
+                e.connect_stereo(cur, b)
+                e.connect_stereo(b, d)
+                cur = d
+            g = e.volume(float(rng.uniform(30, 90)))
+            e.connect_stereo(cur, g)
+            ends.append(g)
+            smp.append(s)
+        leaves = []
+        for i in range(0, 21, 7):
+            m = e.sum(9)                      # 7 voices + 2 empty slots (ports 3 and 8)
+            slots = [0, 1, 2, 4, 5, 6, 7]
+            for p, n in zip(slots, ends[i:i + 7]):
+                e.connect_stereo(n, m, 2 * p)
+            leaves.append(m)
+        root = e.sum(4)                       # 3 leaves + 1 empty upper port
+        for p, m in enumerate(leaves):
+            e.connect_stereo(m, root, 2 * (p if p < 2 else 3))
+        e.connect_stereo(root, e.graph_out_node)
+        e.update()
+        for v, s in enumerate(smp):
+            e.sampler_set_sample(s, e.new_sample(PLANAR_F32, 2, scenarios.voice_source(400 + v, 700)))
+            e.sampler_set_loop_range(s, fwapi.LOOP_FULL)
+            e.sampler_play(s)
+        out = [np.asarray(e.process_blocks(5))]
+        plan0 = e.cx.plan_kind() if hasattr(e, "cx") else None
+        # plug a new dry voice into an empty slot of the first leaf
+        s = e.sampler(70.0)
+        e.connect_stereo(s, leaves[0], 2 * 3)
+        e.update()
+        e.sampler_set_sample(s, e.new_sample(PLANAR_F32, 2, scenarios.voice_source(999, 500)))
+        e.sampler_set_loop_range(s, fwapi.LOOP_FULL)
+        e.sampler_play(s)
+        out.append(np.asarray(e.process_blocks(6)))
+        return np.concatenate(out), plan0
+
+    want, _ = run(oracle(max_block_frames=128))
+    g = GpuEngine(max_block_frames=128)
+    got, plan0 = run(g)
+    assert plan0 == (2 if chain else 1) and g.cx.plan_kind() == plan0
+    assert_bits_equal(want, got, "unconnected ports, chain=%s" % chain)

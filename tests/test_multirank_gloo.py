@@ -139,3 +139,22 @@ def test_two_rank_sharded_bus_matches_whole_graph(mode):
     for r in range(world):
         # 2 ranks: a+b commutes, so even the all-reduce is bit-exact; ordered mode is bit-exact for any world size
         assert np.array_equal(got[r].view(np.uint32), want.view(np.uint32)), "rank %d" % r
+
+
+def test_three_rank_ordered_bus_is_bit_exact():
+    # rank-ordered accumulation reproduces the reference's 3-port SumNode bit for bit (an all-reduce would only for 2
+    # ranks, where a + b commutes)
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31700 + (os.getpid() % 300)
+    procs = [ctx.Process(target=worker, args=(r, world, port, "pipelined_ordered", q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = reference_whole_graph(world)
+    for r in range(world):
+        assert np.array_equal(got[r].view(np.uint32), want.view(np.uint32)), "rank %d" % r

@@ -301,6 +301,8 @@ def main():
     ap.add_argument("--variant", choices=["A", "B", "C"], default="A",
                     help="cfg2/cfg5 (SURVEY 8d): A steady; B one gain change per voice at a seeded block of the run "
                          "(smoother ramps, message path inside the timed region); C every 4th voice paused (silence masks)")
+    ap.add_argument("--reduce-every", type=int, default=4,
+                    help="N>1: steps whose mix buses share one collective (the reduction of R steps overlaps the next R)")
     ap.add_argument("--bus-reduce", choices=["allreduce", "ordered"], default="allreduce",
                     help="N>1: RCCL all-reduce (named path) or all-gather + rank-ordered sum (bit-exact)")
     args = ap.parse_args()
@@ -386,9 +388,15 @@ def main():
     assert cx.plan_kind() == want_plan, "expected launch plan %d, got %d" % (want_plan, cx.plan_kind())
     # two bus buffers: with N > 1 the reduction of step i (RCCL, its own stream) overlaps the compute of step i+1 —
     # the mix bus is a sink, nothing in a shard reads it back
-    outs = [torch.empty(K * B * 2, dtype=torch.float32, device="cuda") for _ in range(2)]
+    # ... and each buffer holds the buses of R consecutive steps, reduced by ONE collective: the hand-over between the
+    # compute stream and RCCL's stream costs ~10 us of idle GPU per event on this stack (measured: 20 us per step with a
+    # collective per step), so it is paid once per R steps
+    R = max(1, args.reduce_every) if dist is not None else 1
+    step_elems = K * B * 2
+    outs = [torch.empty(R * step_elems, dtype=torch.float32, device="cuda") for _ in range(2)]
     reducer = shard.BusReducer(dist, outs, args.bus_reduce) if dist is not None else None
     step_no = [0]
+    slot = [0]  # bus slot counter: buffer (slot // R) % 2, slice slot % R
     host_out = None
     if args.host_buffers:
         import numpy as np
@@ -396,24 +404,36 @@ def main():
         host_out = np.empty(K * B * 2, dtype=np.float32)
 
     def step():
-        b = step_no[0] % 2
+        b = (slot[0] // R) % 2
+        r = slot[0] % R
         for vol, pct, at in changes.get(step_no[0], ()):
             cx.node(vol).set_percent_volume(pct, at_block=at)
         step_no[0] += 1
-        if reducer is not None:
-            reducer.wait(b)  # the collective that last used this buffer (two steps ago)
+        slot[0] += 1
+        if reducer is not None and r == 0:
+            reducer.wait(b)  # the collective that last used this buffer (2R steps ago)
         if args.host_buffers:  # the literal process_interleaved boundary: pageable host output, synchronous
             import ctypes as C
 
             rc = cx.L.fwgpu_process_interleaved(cx.c, None, host_out.ctypes.data_as(C.POINTER(C.c_float)), 0, 2, K * B, 0.0, 0)
             assert rc == 0, rc
             return
-        cx.process_blocks_device(K, outs[b].data_ptr(), 2)
-        if reducer is not None:  # the mix bus: one collective per step over K x 2 x block f32
+        cx.process_blocks_device(K, outs[b].data_ptr() + r * step_elems * 4, 2)
+        if reducer is not None and r == R - 1:  # the mix bus: one collective per R steps over R x K x 2 x block f32
             reducer.submit(b)
+
+    def finish_reductions():
+        """submit the partly filled buffer (steps % R != 0), then wait for every collective"""
+        if reducer is None:
+            return
+        if slot[0] % R != 0:
+            reducer.submit((slot[0] // R) % 2)
+            slot[0] += R - slot[0] % R
+        reducer.wait_all()
 
     for _ in range(args.warmup):
         step()
+    finish_reductions()
     timing = not args.no_kernel_timing
     torch.cuda.synchronize()
     if dist is not None:
@@ -422,8 +442,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    if reducer is not None:
-        reducer.wait_all()  # every bus of the timed region is fully reduced before the clock stops
+    finish_reductions()  # every bus of the timed region is fully reduced before the clock stops
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -445,8 +464,7 @@ def main():
         cx.timing_enable(True)
         for _ in range(ev_steps):
             step()
-        if reducer is not None:
-            reducer.wait_all()
+        finish_reductions()
         torch.cuda.synchronize()
         cx.timing_enable(False)
         dom_ms, dom_n = cx.timing_read(0)   # k_leaf_sum (plan 1) / k_chain (plan 2)

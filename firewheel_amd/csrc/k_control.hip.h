@@ -509,6 +509,10 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
     sd.channels = 2;
     sd.format = FMT_P_F32;
     bool became_steady = false;
+    if (ss.sample >= 0 && ss.playing) {  // the sample in use at the start of the call (messages may replace it below)
+        sd = fv.samples[ss.sample];
+        cached_sample = ss.sample;
+    }
 
     for (int k = k0; k < K; ++k) {
         const uint32_t cb = cmd_block0 + k;
@@ -523,19 +527,36 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
         for (int j = 0; j < FW_MAX_STAGES; ++j) d.g[j][0] = d.g[j][1] = 1.0f;
         float* ramp_base = fv.ramps + ((size_t)k * fv.n_voices + vi) * (size_t)fv.ramp_slots * (size_t)fv.stride;
 
+        // ---- this block's messages for every node of the voice, up front (the nodes' parameters are independent of one
+        // another, so applying the stage nodes' messages before the sampler runs changes nothing).  Past the voice's last
+        // message of the call there is nothing to look up (each lookup is a chain of dependent global loads: ~1 us
+        // apiece, every block of a ramp).  ALL vector loads of the block loop live in this branch and it ends with an
+        // explicit vmcnt(0): the rest of the body only stores, so the compiler has no pending load to guard and places no
+        // vmcnt wait in the ramp code (with the lookups interleaved, every 64-frame ramp chunk store first drained the
+        // previous one: loads and stores share the in-order vmcnt counter on gfx9).
+        if (k <= last_cmd) {
+            apply_cmds(ss, vd.sampler_state, cb, fv.cmds, fv.n_cmds, fv.samples);
+#pragma unroll
+            for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+                if (j >= vd.n_stages) break;
+                NodeState tmp;  // only p0/p1 apply to gain stages
+                tmp.p0 = st[j].p0;
+                tmp.p1 = st[j].p1;
+                apply_cmds(tmp, vd.stage_state[j], cb, fv.cmds, fv.n_cmds, fv.samples);
+                st[j].p0 = tmp.p0;
+                st[j].p1 = tmp.p1;
+            }
+            if (ss.sample >= 0 && ss.playing && cached_sample != ss.sample) {
+                sd = fv.samples[ss.sample];
+                cached_sample = ss.sample;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+        }
         // ---- sampler (nodes/sampler.rs:323-561)
-        // past the voice's last message of the call there is nothing to look up (each lookup is a chain of dependent
-        // global loads: ~1 us apiece, every block of a ramp)
-        const int n_cmds_k = k <= last_cmd ? fv.n_cmds : 0;
-        apply_cmds(ss, vd.sampler_state, cb, fv.cmds, n_cmds_k, fv.samples);
         bool silent = true;
         if (ss.sample >= 0 && ss.playing) {
             GainRun run = smoother_begin(ss.s0, ss.p0, frames);
             if (!(!smoother_is_smoothing(ss.s0) && run.c < 0.00001f)) {
-                if (cached_sample != ss.sample) {
-                    sd = fv.samples[ss.sample];
-                    cached_sample = ss.sample;
-                }
                 Fetch ft;
                 bool ok = sampler_advance(ss, sd.frames, (uint32_t)frames, ft);
                 if (run.ramp) {
@@ -565,14 +586,6 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
             if (j >= vd.n_stages) break;
             StageRegs& r = st[j];
-            if (n_cmds_k) {  // messages for this node (only p0/p1 apply to gain stages)
-                NodeState tmp;
-                tmp.p0 = r.p0;
-                tmp.p1 = r.p1;
-                apply_cmds(tmp, vd.stage_state[j], cb, fv.cmds, n_cmds_k, fv.samples);
-                r.p0 = tmp.p0;
-                r.p1 = tmp.p1;
-            }
             float* rb = ramp_base + (size_t)(j + 1) * 2 * fv.stride;
             if (vd.stage_kind[j] == K_VOLUME) {  // nodes/volume.rs:84-145
                 if (silent) {

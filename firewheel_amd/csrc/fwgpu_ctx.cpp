@@ -1372,6 +1372,12 @@ int push_cmd(fwgpu_ctx* c, int64_t node, int want_kind, Cmd m, bool counts_as_ms
 // ================================================================= C ABI
 extern "C" {
 
+// every entry point that takes a context: a null handle is an error return, never a crash
+#define NEED_CTX(c, ret) \
+    do {                 \
+        if (!(c)) return (ret); \
+    } while (0)
+
 const char* fwgpu_create_error(void) { return g_create_error.c_str(); }
 
 fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block_frames, uint32_t num_graph_inputs,
@@ -1479,11 +1485,13 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
 
 const char* fwgpu_last_error(fwgpu_ctx* c) { return c ? c->last_error.c_str() : "null ctx"; }
 
-int64_t fwgpu_graph_in_node(fwgpu_ctx* c) { return c->graph.id_of(c->graph.graph_in_slot); }
-int64_t fwgpu_graph_out_node(fwgpu_ctx* c) { return c->graph.id_of(c->graph.graph_out_slot); }
+int64_t fwgpu_graph_in_node(fwgpu_ctx* c) { return c ? c->graph.id_of(c->graph.graph_in_slot) : FWGPU_ERR_INVALID; }
+int64_t fwgpu_graph_out_node(fwgpu_ctx* c) { return c ? c->graph.id_of(c->graph.graph_out_slot) : FWGPU_ERR_INVALID; }
 
 int64_t fwgpu_add_node(fwgpu_ctx* c, int kind, uint32_t n_in, uint32_t n_out, const float* params, int n_params) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     if (kind < 0 || kind > K_SPATIAL) return fail(c, FWGPU_ERR_INVALID, "unsupported node kind");
+    if (n_params < 0 || (n_params > 0 && !params)) return fail(c, FWGPU_ERR_INVALID, "params is null but n_params > 0");
     if (kind == K_FIR || kind == K_RESAMPLER) {
         int ir = n_params > 0 ? (int)params[0] : -1;
         if (ir < 0 || ir >= (int)c->samples.size() || !c->samples[ir].alive || c->samples[ir].desc.frames == 0)
@@ -1497,20 +1505,24 @@ int64_t fwgpu_add_node(fwgpu_ctx* c, int kind, uint32_t n_in, uint32_t n_out, co
     return c->graph.add_node(kind, n_in, n_out, st);
 }
 int fwgpu_remove_node(fwgpu_ctx* c, int64_t node) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     int rc = c->graph.remove_node(node);
     if (rc) return fail(c, rc, "remove_node: unknown node or graph in/out node");
     return 0;
 }
 int64_t fwgpu_connect(fwgpu_ctx* c, int64_t src, uint32_t sp, int64_t dst, uint32_t dp, int check) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     return c->graph.connect(src, sp, dst, dp, check != 0);
 }
 int fwgpu_disconnect(fwgpu_ctx* c, int64_t src, uint32_t sp, int64_t dst, uint32_t dp) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     return c->graph.disconnect(src, sp, dst, dp);
 }
-int fwgpu_disconnect_edge(fwgpu_ctx* c, int64_t e) { return c->graph.disconnect_edge(e); }
-int fwgpu_cycle_detected(fwgpu_ctx* c) { return c->graph.cycle_detected() ? 1 : 0; }
+int fwgpu_disconnect_edge(fwgpu_ctx* c, int64_t e) { return c ? c->graph.disconnect_edge(e) : FWGPU_ERR_INVALID; }
+int fwgpu_cycle_detected(fwgpu_ctx* c) { return c ? (c->graph.cycle_detected() ? 1 : 0) : FWGPU_ERR_INVALID; }
 
 int fwgpu_update(fwgpu_ctx* c) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     (void)hipSetDevice(c->device);
     if (!c->graph.needs_compile && c->have_plan) return 0;
     Plan plan;
@@ -1521,8 +1533,12 @@ int fwgpu_update(fwgpu_ctx* c) {
 }
 
 int fwgpu_schedule_upload(fwgpu_ctx* c, const fwgpu_sched_node* sn, uint32_t n_nodes, uint32_t num_buffers) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     (void)hipSetDevice(c->device);
-    if (n_nodes < 2) return fail(c, FWGPU_ERR_INVALID, "a schedule holds at least graph_in and graph_out");
+    if (n_nodes < 2 || !sn) return fail(c, FWGPU_ERR_INVALID, "a schedule holds at least graph_in and graph_out");
+    for (uint32_t i = 0; i < n_nodes; ++i)
+        if ((sn[i].num_inputs && (!sn[i].in_buffer_index || !sn[i].in_should_clear)) || (sn[i].num_outputs && !sn[i].out_buffer_index))
+            return fail(c, FWGPU_ERR_INVALID, "schedule node with ports but null buffer tables");
     Plan plan;
     std::vector<std::pair<int, int>> last_writer(num_buffers, std::make_pair(-1, 0));
     for (uint32_t i = 0; i < n_nodes; ++i) {
@@ -1562,9 +1578,10 @@ int fwgpu_schedule_upload(fwgpu_ctx* c, const fwgpu_sched_node* sn, uint32_t n_n
     return install_plan(c, plan);
 }
 
-int fwgpu_plan_kind(fwgpu_ctx* c) { return c->have_plan ? (c->fused && !c->force_generic ? (c->fused_fx ? 2 : 1) : 0) : -1; }
-int fwgpu_plan_num_levels(fwgpu_ctx* c) { return c->have_plan ? c->plan.num_levels : -1; }
+int fwgpu_plan_kind(fwgpu_ctx* c) { return c && c->have_plan ? (c->fused && !c->force_generic ? (c->fused_fx ? 2 : 1) : 0) : -1; }
+int fwgpu_plan_num_levels(fwgpu_ctx* c) { return c && c->have_plan ? c->plan.num_levels : -1; }
 int fwgpu_plan_node_level(fwgpu_ctx* c, int64_t node) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     if (!c->have_plan || !c->graph.get(node)) return -1;
     uint32_t slot = (uint32_t)(node & 0xffffffff);
     for (const PlanNode& p : c->plan.nodes)
@@ -1572,6 +1589,7 @@ int fwgpu_plan_node_level(fwgpu_ctx* c, int64_t node) {
     return -1;
 }
 int fwgpu_plan_node_inputs_clear(fwgpu_ctx* c, int64_t node, int* should_clear, int cap) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     if (!c->have_plan || !c->graph.get(node)) return -1;
     uint32_t slot = (uint32_t)(node & 0xffffffff);
     for (const PlanNode& p : c->plan.nodes)
@@ -1582,10 +1600,12 @@ int fwgpu_plan_node_inputs_clear(fwgpu_ctx* c, int64_t node, int* should_clear, 
     return -1;
 }
 int fwgpu_set_force_generic(fwgpu_ctx* c, int on) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     c->force_generic = on != 0;
     return 0;
 }
 int fwgpu_plan_chain_stats(fwgpu_ctx* c, uint64_t* steady_workgroups, uint64_t* general_workgroups) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     (void)hipSetDevice(c->device);
     unsigned long long h[2] = {0, 0};
     if (c->d_chain_stats.p) {
@@ -1597,6 +1617,7 @@ int fwgpu_plan_chain_stats(fwgpu_ctx* c, uint64_t* steady_workgroups, uint64_t* 
     return 0;
 }
 int fwgpu_set_max_batch(fwgpu_ctx* c, uint32_t k) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     if (k == 0) return fail(c, FWGPU_ERR_INVALID, "max batch must be >= 1");
     c->kmax_req = k;
     c->graph.needs_compile = true;  // K-sized buffers are (re)allocated by the next fwgpu_update
@@ -1608,6 +1629,8 @@ static size_t fmt_elem_size(int fmt) { return (fmt == FMT_I_F32 || fmt == FMT_P_
 static int sample_add(fwgpu_ctx* c, int format, uint32_t channels, uint64_t frames, const void* data, bool on_device) {
     (void)hipSetDevice(c->device);
     if (format < 0 || format > FMT_P_F32 || channels == 0) return fail(c, FWGPU_ERR_INVALID, "bad sample format/channels");
+    if (frames > (1ull << 40) / channels) return fail(c, FWGPU_ERR_INVALID, "sample too large (frames x channels > 2^40)");
+    if (frames && !data) return fail(c, FWGPU_ERR_INVALID, "sample data is null");
     SampleRec r;
     r.alive = true;
     size_t bytes = (size_t)frames * channels * fmt_elem_size(format);
@@ -1617,8 +1640,12 @@ static int sample_add(fwgpu_ctx* c, int format, uint32_t channels, uint64_t fram
     } else {
         r.owned = true;
         HIPC(c, hipMalloc(&r.d_data, bytes + 256));  // slack: a wave's last dwordx4 may overhang the data
-        HIPC(c, hipMemset((char*)r.d_data + bytes, 0, 256));
-        if (bytes) HIPC(c, hipMemcpy(r.d_data, data, bytes, hipMemcpyHostToDevice));
+        hipError_t e = hipMemset((char*)r.d_data + bytes, 0, 256);
+        if (e == hipSuccess && bytes) e = hipMemcpy(r.d_data, data, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(r.d_data);
+            return hipfail(c, e, "sample upload");
+        }
     }
     r.desc.data = r.d_data;
     r.desc.frames = frames;
@@ -1629,14 +1656,23 @@ static int sample_add(fwgpu_ctx* c, int format, uint32_t channels, uint64_t fram
     return (int)c->samples.size() - 1;
 }
 int fwgpu_sample_create(fwgpu_ctx* c, int format, uint32_t channels, uint64_t frames, const void* data) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     return sample_add(c, format, channels, frames, data, false);
 }
 int fwgpu_sample_create_device(fwgpu_ctx* c, int format, uint32_t channels, uint64_t frames, const void* device_data) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     return sample_add(c, format, channels, frames, device_data, true);
 }
 int fwgpu_sample_destroy(fwgpu_ctx* c, int sample) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     if (sample < 0 || sample >= (int)c->samples.size() || !c->samples[sample].alive)
         return fail(c, FWGPU_ERR_INVALID, "unknown sample id");
+    // FIR / resampler nodes name their sample at construction and keep it for life: refuse while one exists.  Samplers
+    // pick samples by message, which the host does not track: see the contract in fwgpu.h.
+    for (const HostNode& n : c->graph.nodes)
+        if (n.alive && (n.kind == K_FIR || n.kind == K_RESAMPLER) && n.init.sample == sample)
+            return fail(c, FWGPU_ERR_INVALID, "sample is in use by a FIR / resampler node");
+    (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     SampleRec& r = c->samples[sample];
     if (r.owned && r.d_data) (void)hipFree(r.d_data);
@@ -1649,6 +1685,7 @@ int fwgpu_sample_destroy(fwgpu_ctx* c, int sample) {
 }
 
 int fwgpu_node_set_param(fwgpu_ctx* c, int64_t node, int param, float value, uint32_t at_block) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     HostNode* n = c->graph.get(node);
     if (!n) return fail(c, FWGPU_ERR_INVALID, "unknown node id");
     Cmd m;
@@ -1759,6 +1796,7 @@ int fwgpu_node_set_param(fwgpu_ctx* c, int64_t node, int param, float value, uin
     }
 }
 int fwgpu_sampler_set_sample(fwgpu_ctx* c, int64_t node, int sample, int stop_playback, uint32_t at_block) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     if (sample < 0 || sample >= (int)c->samples.size() || !c->samples[sample].alive)
         return fail(c, FWGPU_ERR_INVALID, "unknown sample id");
     Cmd m;
@@ -1770,6 +1808,7 @@ int fwgpu_sampler_set_sample(fwgpu_ctx* c, int64_t node, int sample, int stop_pl
     return push_cmd(c, node, K_SAMPLER, m, true);
 }
 static int simple_msg(fwgpu_ctx* c, int64_t node, int type, uint32_t at_block) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     Cmd m;
     memset(&m, 0, sizeof(m));
     m.block = at_block;
@@ -1780,6 +1819,7 @@ int fwgpu_sampler_play(fwgpu_ctx* c, int64_t node, uint32_t b) { return simple_m
 int fwgpu_sampler_pause(fwgpu_ctx* c, int64_t node, uint32_t b) { return simple_msg(c, node, CMD_SMP_PAUSE, b); }
 int fwgpu_sampler_stop(fwgpu_ctx* c, int64_t node, uint32_t b) { return simple_msg(c, node, CMD_SMP_STOP, b); }
 int fwgpu_sampler_set_playhead_secs(fwgpu_ctx* c, int64_t node, double secs, uint32_t at_block) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     Cmd m;
     memset(&m, 0, sizeof(m));
     m.block = at_block;
@@ -1788,6 +1828,7 @@ int fwgpu_sampler_set_playhead_secs(fwgpu_ctx* c, int64_t node, double secs, uin
     return push_cmd(c, node, K_SAMPLER, m, true);
 }
 int fwgpu_sampler_set_loop_range(fwgpu_ctx* c, int64_t node, int mode, double start, double end, uint32_t at_block) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     if (mode < 0 || mode > 2) return fail(c, FWGPU_ERR_INVALID, "loop mode must be 0, 1 or 2");
     Cmd m;
     memset(&m, 0, sizeof(m));
@@ -1801,8 +1842,12 @@ int fwgpu_sampler_set_loop_range(fwgpu_ctx* c, int64_t node, int mode, double st
 
 int fwgpu_process_interleaved(fwgpu_ctx* c, const float* input, float* output, uint32_t n_in_ch, uint32_t n_out_ch,
                               uint64_t frames, double, uint32_t) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     (void)hipSetDevice(c->device);
+    if (n_in_ch > 64 || n_out_ch > 64) return fail(c, FWGPU_ERR_INVALID, "at most 64 stream channels per side (processor.rs:43-44)");
+    if (frames > (1ull << 32)) return fail(c, FWGPU_ERR_INVALID, "more than 2^32 frames in one call");
     size_t out_bytes = (size_t)frames * n_out_ch * sizeof(float);
+    if (out_bytes && !output) return fail(c, FWGPU_ERR_INVALID, "output is null");
     if (!c->have_plan || frames == 0) {  // processor.rs:86-89 (Q19)
         if (out_bytes) memset(output, 0, out_bytes);
         return 0;
@@ -1849,19 +1894,23 @@ int fwgpu_process_interleaved(fwgpu_ctx* c, const float* input, float* output, u
 }
 
 int fwgpu_process_blocks_device(fwgpu_ctx* c, uint32_t num_blocks, float* d_output, uint32_t n_out_ch) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     (void)hipSetDevice(c->device);
     if (!c->have_plan) return fail(c, FWGPU_ERR_INVALID, "no schedule: call fwgpu_update first");
     if (num_blocks == 0) return 0;
+    if (n_out_ch > 64 || (n_out_ch && !d_output)) return fail(c, FWGPU_ERR_INVALID, "bad output (null, or more than 64 channels)");
     return run_blocks(c, (uint64_t)num_blocks * c->mbf, nullptr, 0, d_output, (int)n_out_ch);
 }
 
 int fwgpu_synchronize(fwgpu_ctx* c) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
 int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float* const* inputs, uint32_t n_in,
                        float* const* outputs, uint32_t n_out, uint64_t in_mask, uint64_t* out_mask, double, uint32_t) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     (void)hipSetDevice(c->device);
     HostNode* hn = c->graph.get(node);
     if (!hn || !hn->activated) return fail(c, FWGPU_ERR_INVALID, "node is not activated (call fwgpu_update)");
@@ -1930,10 +1979,12 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
 }
 
 int fwgpu_timing_enable(fwgpu_ctx* c, int on) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     c->timing = on != 0;
     return 0;
 }
 int fwgpu_timing_read(fwgpu_ctx* c, int which, double* total_ms, uint64_t* launches) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     if (which < 0 || which > 4) return fail(c, FWGPU_ERR_INVALID, "timer index");
     timer_drain(c);
     *total_ms = c->timers[which].acc_ms;
@@ -1941,6 +1992,7 @@ int fwgpu_timing_read(fwgpu_ctx* c, int which, double* total_ms, uint64_t* launc
     return 0;
 }
 int fwgpu_timing_reset(fwgpu_ctx* c) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     timer_drain(c);
     for (TimerCat& t : c->timers) {
         t.acc_ms = 0.0;
@@ -1951,6 +2003,7 @@ int fwgpu_timing_reset(fwgpu_ctx* c) {
 #ifdef FW_CHAIN_TRACE
 // profiling builds only (scripts/chain_trace.py): timestamps [step 0..63][wave 0..15][slot 0..7] of workgroup 0
 int fwgpu_debug_read_trace(fwgpu_ctx* c, unsigned long long* out) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     HIPC(c, hipStreamSynchronize(c->stream));
     if (!c->d_trace.p) return fail(c, FWGPU_ERR_INVALID, "no trace");
     HIPC(c, hipMemcpy(out, c->d_trace.p, 64 * 16 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1959,6 +2012,7 @@ int fwgpu_debug_read_trace(fwgpu_ctx* c, unsigned long long* out) {
 #endif
 
 int fwgpu_device_info(fwgpu_ctx* c, char* name, int name_cap, int* cus, uint64_t* hbm) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
     hipDeviceProp_t prop;
     HIPC(c, hipGetDeviceProperties(&prop, c->device));
     if (name && name_cap > 0) {

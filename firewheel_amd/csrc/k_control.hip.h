@@ -553,8 +553,10 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
         }
         // ---- sampler (nodes/sampler.rs:323-561)
+        // a sample destroyed under the sampler (fwgpu_sample_destroy: table entry with data == nullptr) counts as "no
+        // sample": outputs cleared, nothing moves (sampler.rs:416-430) — never a fetch through the stale loop range
         bool silent = true;
-        if (ss.sample >= 0 && ss.playing) {
+        if (ss.sample >= 0 && ss.playing && sd.data != nullptr) {
             GainRun run = smoother_begin(ss.s0, ss.p0, frames);
             if (!(!smoother_is_smoothing(ss.s0) && run.c < 0.00001f)) {
                 Fetch ft;
@@ -638,7 +640,7 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
         bool steady = true;
         bool upstream_silent = false;
         int mode = 0;
-        if (ss.sample < 0 || !ss.playing) {
+        if (ss.sample < 0 || !ss.playing || sd.data == nullptr) {
             upstream_silent = true;  // frozen sampler: nothing moves
         } else {
             if (!smoother_is_constant(ss.s0, ss.p0)) steady = false;

@@ -193,12 +193,16 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
                 out_mask = clear_all_outputs(io, 0, nd.n_out);
                 break;
             }
+            const SampleDesc sd = v.samples[s.sample];
+            if (sd.data == nullptr) {  // destroyed under the sampler (fwgpu_sample_destroy): as if it held no sample
+                out_mask = clear_all_outputs(io, 0, nd.n_out);
+                break;
+            }
             GainRun run = smoother_begin(s.s0, s.p0, frames);        // :432-433
             if (!smoother_is_smoothing(s.s0) && run.c < 0.00001f) {  // :437-443
                 out_mask = clear_all_outputs(io, 0, nd.n_out);
                 break;
             }
-            const SampleDesc sd = v.samples[s.sample];
             // the batch-start playhead comes from k_frozen_scan's snapshot: the wave of the batch's last block stores the
             // advanced state while waves of earlier blocks may not have read theirs yet
             if (frozen_sampler) s.playhead = v.frozen_playhead[node_idx];
@@ -542,7 +546,7 @@ __global__ void k_frozen_scan(DevView v, int n_nodes, uint32_t cmd_block0, uint3
             const NodeState& s = v.states[nd.state];
             switch (nd.kind) {
                 case K_SAMPLER:  // steady playback: the playhead of block b has a closed form (see node_process_wave)
-                    if (s.sample < 0 || !s.playing) {
+                    if (s.sample < 0 || !s.playing || v.samples[s.sample].data == nullptr) {
                         fz = true;  // outputs cleared, nothing moves (sampler.rs:416-430)
                     } else if (smoother_at_rest(s.s0, s.p0)) {
                         if (s.s0.status == SM_INACTIVE && s.s0.input < 0.00001f) {

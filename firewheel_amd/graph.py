@@ -431,6 +431,11 @@ class FirewheelGpuCtx(object):
     def new_sample_device(self, fmt, channels, frames, device_ptr):
         return self._check(self.L.fwgpu_sample_create_device(self.c, fmt, channels, frames, C.c_void_p(device_ptr)))
 
+    def destroy_sample(self, sample):
+        """Release a sample's HBM (the last Arc<dyn SampleResource> dropped).  Refused while a FIR / resampler node
+        names it; a sampler that still holds the id sees an empty sample from the next call on."""
+        self._check(self.L.fwgpu_sample_destroy(self.c, sample))
+
     # ---- FirewheelProcessor::process_interleaved (graph/processor.rs:61-165)
     def process_interleaved(self, input, num_in_channels, num_out_channels, frames, stream_time_secs=0.0,
                             stream_status=0):

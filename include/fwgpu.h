@@ -136,6 +136,12 @@ int fwgpu_sample_create(fwgpu_ctx* ctx, int format, uint32_t channels, uint64_t 
 /* same, from memory that is already on this device (bench: generate in HBM, skip PCIe) */
 int fwgpu_sample_create_device(fwgpu_ctx* ctx, int format, uint32_t channels, uint64_t frames,
                                const void* device_data);
+/* Releases the sample's HBM (for an id from fwgpu_sample_create; a _device sample only loses its table entry).  The
+ * reference keeps a sample alive through the Arc every processor holds; here the CALLER guarantees that no sampler
+ * will read the id any more (the Rust shim calls this when the last Arc drops).  Waits for the work
+ * in flight on the context's stream.  Ids are never reused.  A sampler that still holds the id plays an EMPTY
+ * (0-frame) sample from the next process call on — silence, never a stale pointer; FIR / resampler nodes name their
+ * sample at construction, so the call is refused (FWGPU_ERR_INVALID) while such a node exists. */
 int fwgpu_sample_destroy(fwgpu_ctx* ctx, int sample);
 
 /* ---- control -> audio messages.  `at_block` = index of the max_block_frames-sized block, counted from

@@ -1013,3 +1013,81 @@ def test_unconnected_sum_ports_stay_on_the_fused_plans_and_take_voices_later(cha
     got, plan0 = run(g)
     assert plan0 == (2 if chain else 1) and g.cx.plan_kind() == plan0
     assert_bits_equal(want, got, "unconnected ports, chain=%s" % chain)
+
+
+@pytest.mark.parametrize("mode", ["bank", "chain", "generic"])
+def test_sample_destroy_after_the_samplers_moved_on_and_while_still_held(mode):
+    # fwgpu_sample_destroy (the last Arc<dyn SampleResource> dropped, core/sample_resource.rs): (1) after every sampler
+    # switched to another sample the destroy changes nothing — bit-exact vs the oracle, which keeps the sample;
+    # (2) destroyed while samplers still hold it (a caller error the ABI must survive): empty sample, silence, no fault;
+    # (3) refused while a FIR node names the sample.
+    chain = mode == "chain"
+
+    def build(e):
+        ends, smp = [], []
+        for v in range(12):
+            s = e.sampler(80.0)
+            cur = s
+            if chain:
+                b = e.biquad(0, 1500.0 + 90 * v, 0.8)
+                e.connect_stereo(cur, b)
+                cur = b
+            g = e.volume(40.0 + 3 * v)
+            e.connect_stereo(cur, g)
+            ends.append(g)
+            smp.append(s)
+        m = e.sum(12)
+        for p, n in enumerate(ends):
+            e.connect_stereo(n, m, 2 * p)
+        e.connect_stereo(m, e.graph_out_node)
+        e.update()
+        return smp
+
+    def run(e, destroy):
+        smp = build(e)
+        a = [e.new_sample(PLANAR_F32, 2, scenarios.voice_source(100 + v, 900)) for v in range(12)]
+        b = [e.new_sample(PLANAR_F32, 2, scenarios.voice_source(300 + v, 640)) for v in range(12)]
+        for v, s in enumerate(smp):
+            e.sampler_set_sample(s, a[v])
+            e.sampler_set_loop_range(s, fwapi.LOOP_FULL)
+            e.sampler_play(s)
+        out = [np.asarray(e.process_blocks(4))]
+        for v, s in enumerate(smp):
+            e.sampler_set_sample(s, b[v], at_block=1)
+            e.sampler_play(s, at_block=1)
+        out.append(np.asarray(e.process_blocks(3)))
+        if destroy:
+            for i in a:
+                e.cx.destroy_sample(i)
+            with pytest.raises(Exception):
+                e.cx.destroy_sample(a[0])  # already gone
+        out.append(np.asarray(e.process_blocks(5)))
+        return np.concatenate(out), smp, b
+
+    og, _, _ = run(oracle(max_block_frames=128), False)
+    g = GpuEngine(max_block_frames=128, force_generic=(mode == "generic"), max_batch=4)
+    gg, smp, b = run(g, True)
+    assert g.cx.plan_kind() == {"bank": 1, "chain": 2, "generic": 0}[mode]
+    assert_bits_equal(og, gg, "destroy of samples nobody plays any more (%s)" % mode)
+    assert np.any(gg[-5 * 128 * 2:] != 0)
+    # (2) pull the samples out from under the playing samplers
+    for i in b:
+        g.cx.destroy_sample(i)
+    tail = np.asarray(g.process_blocks(6))
+    assert np.all(np.isfinite(tail))
+    if chain:  # the biquads ring out
+        assert np.all(np.abs(tail[-2 * 128 * 2:]) < 1e-6)
+    else:
+        assert np.all(tail[-2 * 128 * 2:] == 0), "a destroyed sample plays as no sample"
+    # the context stays usable: a fresh sample plays again
+    n = g.new_sample(PLANAR_F32, 2, scenarios.voice_source(7, 500))
+    g.sampler_set_sample(smp[0], n)
+    g.sampler_play(smp[0])
+    assert np.any(np.asarray(g.process_blocks(2)) != 0)
+    # (3) FIR nodes keep their impulse response: refused while the node exists, allowed once it is gone
+    ir = g.new_sample(PLANAR_F32, 1, scenarios.voice_source(9, 64, 1))
+    f = g.fir(ir)
+    with pytest.raises(Exception):
+        g.cx.destroy_sample(ir)
+    g.remove_node(f)
+    g.cx.destroy_sample(ir)

@@ -12,6 +12,7 @@
 #include <functional>
 #include <map>
 #include <tuple>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -23,11 +24,25 @@ using namespace fwgpu;
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;  // fwgpu_create_error(): of the calling thread's last failed fwgpu_ctx_create
 
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p;
+            cap = o.cap;
+            o.p = nullptr;
+            o.cap = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }  // whatever fwgpu_ctx_destroy's list misses still goes with the ctx
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap && p) return hipSuccess;
         const bool regrow = p != nullptr;  // a buffer that grows once tends to grow again (graph edits add a few nodes
@@ -676,8 +691,7 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         HIPC(c, hipMemset(nb.p, 0, cap * sizeof(NodeState)));
         if (c->d_states.p && c->states_cap)
             HIPC(c, hipMemcpy(nb.p, c->d_states.p, c->states_cap * sizeof(NodeState), hipMemcpyDeviceToDevice));
-        c->d_states.release();
-        c->d_states = nb;
+        c->d_states = std::move(nb);
         c->states_cap = cap;
     }
     // 2. activate new nodes (graph.rs:594-612): scatter their initial states, carve their ext-pool slices
@@ -745,8 +759,7 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
             HIPC(c, hipMemset(nb.p, 0, (cap + 256) * sizeof(float)));
             if (c->d_ext.p && c->ext_used)
                 HIPC(c, hipMemcpy(nb.p, c->d_ext.p, c->ext_used * sizeof(float), hipMemcpyDeviceToDevice));
-            c->d_ext.release();
-            c->d_ext = nb;
+            c->d_ext = std::move(nb);
             c->ext_cap = cap;
         }
         c->ext_used = ext_need;
@@ -1467,7 +1480,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
                       &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
                       &c->d_bus, &c->d_bus_flags, &c->d_chain_start, &c->d_chain_dummy, &c->d_chain_stats, &c->d_groups, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
                       &c->d_root_bufs, &c->d_tail_nodes, &c->d_tail_in, &c->d_tail_out, &c->d_tail_idx, &c->d_tail_frozen, &c->d_frozen, &c->d_frozen_ph, &c->d_fir_rows, &c->d_fir_tiles, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
-                      &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask};
+                      &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask, &c->d_trace, &c->d_rs_table};
     for (DevBuf* b : bufs) b->release();
     for (TimerCat& t : c->timers)
         for (auto& p : t.ev) {
@@ -1508,6 +1521,10 @@ int fwgpu_remove_node(fwgpu_ctx* c, int64_t node) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     int rc = c->graph.remove_node(node);
     if (rc) return fail(c, rc, "remove_node: unknown node or graph in/out node");
+    // messages still queued for a later block go with the node (its slot — the message key — may be reused by the next
+    // fwgpu_add_node)
+    const int slot = (int)(node & 0xffffffff);
+    c->cmds.erase(std::remove_if(c->cmds.begin(), c->cmds.end(), [slot](const Cmd& m) { return m.state == slot; }), c->cmds.end());
     return 0;
 }
 int64_t fwgpu_connect(fwgpu_ctx* c, int64_t src, uint32_t sp, int64_t dst, uint32_t dp, int check) {
@@ -1918,6 +1935,11 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     if (frames > c->mbf) return fail(c, FWGPU_ERR_INVALID, "frames > max_block_frames");
     if (hn->kind == K_FIR) return fail(c, FWGPU_ERR_INVALID, "FIR banks run at graph level (fwgpu_process_interleaved), not per node");
     if (n_in + n_out == 0) return fail(c, FWGPU_ERR_INVALID, "node has no ports");
+    if ((n_in && !inputs) || (n_out && !outputs)) return fail(c, FWGPU_ERR_INVALID, "null channel table");
+    for (uint32_t i = 0; frames && i < n_in; ++i)
+        if (!inputs[i]) return fail(c, FWGPU_ERR_INVALID, "null input channel");
+    for (uint32_t i = 0; frames && i < n_out; ++i)
+        if (!outputs[i]) return fail(c, FWGPU_ERR_INVALID, "null output channel");
     const size_t stride = (size_t)c->stride;
     const int nb = 1 + (int)n_in + (int)n_out;
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -1973,7 +1995,7 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     uint64_t om = 0;
     for (uint32_t i = 0; i < n_out; ++i)
         if (fl[1 + n_in + i]) om |= 1ull << i;
-    *out_mask = om;
+    if (out_mask) *out_mask = om;
     retire_cmds(c, 1);
     return 0;
 }

@@ -1091,3 +1091,38 @@ def test_sample_destroy_after_the_samplers_moved_on_and_while_still_held(mode):
         g.cx.destroy_sample(ir)
     g.remove_node(f)
     g.cx.destroy_sample(ir)
+
+
+def test_messages_queued_for_a_removed_node_do_not_reach_the_node_that_reuses_its_slot():
+    def run(e, stale):
+        a = e.sampler(100.0)
+        keep = e.sampler(60.0)
+        m = e.sum(2)
+        e.connect_stereo(a, m, 0)
+        e.connect_stereo(keep, m, 2)
+        e.connect_stereo(m, e.graph_out_node)
+        e.update()
+        smp = e.new_sample(PLANAR_F32, 2, scenarios.voice_source(5, 4000))
+        for s in (a, keep):
+            e.sampler_set_sample(s, smp)
+            e.sampler_set_loop_range(s, fwapi.LOOP_FULL)
+            e.sampler_play(s)
+        out = [np.asarray(e.process_blocks(2))]
+        if stale:  # for a block this node will not live to see
+            e.set_param(a, 0, 5.0, at_block=3)
+            e.sampler_pause(a, at_block=4)
+        e.remove_node(a)
+        b = e.sampler(90.0)  # takes a's slot
+        e.connect_stereo(b, m, 0)
+        e.update()
+        e.sampler_set_sample(b, smp)
+        e.sampler_play(b)
+        out.append(np.asarray(e.process_blocks(8)))
+        return np.concatenate(out)
+
+    ref = run(oracle(max_block_frames=64), False)
+    for generic in (False, True):
+        clean = run(GpuEngine(max_block_frames=64, force_generic=generic), False)
+        stale = run(GpuEngine(max_block_frames=64, force_generic=generic), True)
+        assert_bits_equal(ref, clean, "slot reuse (generic=%s)" % generic)
+        assert_bits_equal(clean, stale, "stale messages of a removed node (generic=%s)" % generic)

@@ -230,6 +230,10 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             }
             const int sch = sd.channels;
             const int nfill = nd.n_out < sch ? nd.n_out : sch;  // fill_buffers zip + gain zip (:535)
+            // planar f32, the whole block contiguous in the sample: one 16-byte load per lane and channel instead of
+            // four format-switched element fetches (same values: no conversion on this format)
+            const bool vec_src = sd.format == FMT_P_F32 && !ft.wrap && !ft.tail_zero && ft.n1 == (uint32_t)frames;
+            const float* vsrc = (const float*)sd.data + ft.off0;
             for (int base = 0; base < frames; base += 256) {
                 int n = frames - base < 256 ? frames - base : 256;
                 v4f g = gain_chunk(run, n, lane);
@@ -237,7 +241,8 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
                 if (f0 >= frames) continue;
                 v4f first = splat(0.f);
                 for (int c = 0; c < nfill; ++c) {
-                    v4f x = sample_fetch4(sd, c, ft, (uint32_t)f0, (uint32_t)frames) * g;  // :521-543
+                    v4f x = (vec_src && f0 + 4 <= frames ? (v4f)(*(const v4f_u*)(vsrc + (size_t)c * sd.frames + f0))
+                                                         : sample_fetch4(sd, c, ft, (uint32_t)f0, (uint32_t)frames)) * g;  // :521-543
                     if (c == 0) first = x;
                     *(v4f*)(io.out(c) + f0) = x;
                 }

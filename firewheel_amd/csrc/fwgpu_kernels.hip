@@ -45,10 +45,11 @@ __device__ __forceinline__ v4f splat(float x) { return (v4f){x, x, x, x}; }
 // kinds: bit s = the level holds node kinds of set s (k_generic.hip.h: kind_set) — one launch per set present
 int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0, int kinds) {
     if (n_nodes <= 0) return 0;
-    dim3 grid((n_nodes + WPB - 1) / WPB, K);
-    if (kinds & 1) hipLaunchKernelGGL(k_level<0>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0);
-    if (kinds & 2) hipLaunchKernelGGL(k_level<1>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0);
-    if (kinds & 4) hipLaunchKernelGGL(k_level<2>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0);
+    if (K <= 0) return 0;
+    dim3 grid((n_nodes + WPB - 1) / WPB, (K + LEVEL_BPW - 1) / LEVEL_BPW);
+    if (kinds & 1) hipLaunchKernelGGL(k_level<0>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K);
+    if (kinds & 2) hipLaunchKernelGGL(k_level<1>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K);
+    if (kinds & 4) hipLaunchKernelGGL(k_level<2>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K);
     return (int)hipGetLastError();
 }
 int launch_frozen_scan(hipStream_t s, const DevView& v, int n_nodes, uint32_t cmd_block0, int K, uint8_t* d_frozen,

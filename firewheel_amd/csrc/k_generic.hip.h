@@ -599,26 +599,35 @@ __device__ void frozen_finish(const DevView& v, int node_idx, uint32_t K) {
 // K blocks per launch (gridDim.y = K, one pool slice per block).  A node whose audio half carries state from block
 // to block is run by ONE wave that walks its K blocks in order; stateless nodes — and frozen ones — take their K
 // blocks in parallel.
+#ifndef LEVEL_BPW
+#define LEVEL_BPW 4  // consecutive blocks one wave takes for a stateless / frozen node
+#endif
+// gridDim.y = ceil(K / LEVEL_BPW): a wave takes LEVEL_BPW consecutive blocks of its node, so the node's descriptor, port
+// tables and state come from HBM once and from the cache for the other blocks (the per-block work is ~4 KB behind a
+// chain of dependent loads).
 template <int SET>
 __global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __restrict__ level_nodes, int n_nodes,
-                                                      uint32_t cmd_block0) {
+                                                      uint32_t cmd_block0, uint32_t K) {
     int w = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (w >= n_nodes) return;
     const int node = level_nodes[w];
-    if (kind_set(v.nodes[node].kind) != SET) return;  // another instantiation's node
-    if (kind_is_stateful(v.nodes[node].kind)) {
+    const int kind = v.nodes[node].kind;
+    if (kind_set(kind) != SET) return;  // another instantiation's node
+    const uint32_t b0 = blockIdx.y * LEVEL_BPW;
+    const uint32_t b1 = b0 + LEVEL_BPW < K ? b0 + LEVEL_BPW : K;
+    if (kind_is_stateful(kind)) {
         const uint8_t fz = v.frozen ? v.frozen[node] : (uint8_t)0;
         if (fz) {
             const bool adv = fz == 2;  // playing sampler: per-block playhead in closed form, the last block stores the state
-            node_process_wave<SET>(v, node, blockIdx.y, cmd_block0 + blockIdx.y, adv && blockIdx.y + 1 == gridDim.y,
-                                   adv ? blockIdx.y : 0u, adv);
-            if (!adv && blockIdx.y == 0) frozen_finish(v, node, gridDim.y);
+            for (uint32_t b = b0; b < b1; ++b)
+                node_process_wave<SET>(v, node, b, cmd_block0 + b, adv && b + 1 == K, adv ? b : 0u, adv);
+            if (!adv && b0 == 0) frozen_finish(v, node, K);
             return;
         }
         if (blockIdx.y != 0) return;
-        for (uint32_t b = 0; b < gridDim.y; ++b) node_process_wave<SET>(v, node, b, cmd_block0 + b);
+        for (uint32_t b = 0; b < K; ++b) node_process_wave<SET>(v, node, b, cmd_block0 + b);
     } else {
-        node_process_wave<SET>(v, node, blockIdx.y, cmd_block0 + blockIdx.y);
+        for (uint32_t b = b0; b < b1; ++b) node_process_wave<SET>(v, node, b, cmd_block0 + b);
     }
 }
 

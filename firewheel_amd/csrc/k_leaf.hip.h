@@ -338,7 +338,8 @@ __global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restric
     const int* in_buf = v.in_buf + nd.in_off;
     const int* out_buf = v.out_buf + nd.out_off;
     const int n_in = nd.n_in, n_out = nd.n_out, ports = nd.aux0;
-    const int my_in = lane < n_in ? in_buf[lane] : 0;
+    int my_in = lane < n_in ? in_buf[lane] : 0;
+    asm volatile("" : "+v"(my_in));  // read with v_readlane from the frame loops below, where lanes without frames are inactive
     const uint64_t in_mask = __ballot(lane < n_in ? flags[my_in] != 0 : false);
     float* out = pool + (size_t)out_buf[c] * v.stride;
     uint64_t out_mask = 0;

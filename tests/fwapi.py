@@ -300,6 +300,108 @@ class OracleEngine(Engine):
         return np.stack(outs) if outs else np.zeros((0, frames), np.float32), om.value
 
 
+_planner_lib = None
+
+
+def planner_lib():
+    """The product's host planner (fwgpu_graph.cpp, no HIP in it) compiled with g++ behind tests/planner_harness."""
+    global _planner_lib
+    if _planner_lib is None:
+        d = os.path.join(ROOT, "tests", "planner_harness")
+        so = os.path.join(d, "_planner.so")
+        srcs = [os.path.join(d, "planner_harness.cpp"), os.path.join(ROOT, "firewheel_amd", "csrc", "fwgpu_graph.cpp")]
+        deps = srcs + [os.path.join(ROOT, "firewheel_amd", "csrc", h) for h in ("fwgpu_graph.h", "fwgpu_types.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in deps):
+            subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-Wall", "-o", so] + srcs)
+        L = C.CDLL(so)
+        i64, u32, vp, ci = C.c_int64, C.c_uint32, C.c_void_p, C.c_int
+        ip = C.POINTER(ci)
+        sig = {
+            "fwp_new": (vp, [u32, u32]), "fwp_free": (None, [vp]), "fwp_last_error": (C.c_char_p, [vp]),
+            "fwp_graph_in_node": (i64, [vp]), "fwp_graph_out_node": (i64, [vp]),
+            "fwp_add_node": (i64, [vp, ci, u32, u32]), "fwp_remove_node": (ci, [vp, i64]),
+            "fwp_connect": (i64, [vp, i64, u32, i64, u32, ci]), "fwp_disconnect": (ci, [vp, i64, u32, i64, u32]),
+            "fwp_disconnect_edge": (ci, [vp, i64]), "fwp_cycle_detected": (ci, [vp]), "fwp_update": (ci, [vp]),
+            "fwp_sched_len": (ci, [vp]), "fwp_sched_num_buffers": (ci, [vp]), "fwp_sched_num_levels": (ci, [vp]),
+            "fwp_sched_node": (i64, [vp, ci]), "fwp_sched_level": (ci, [vp, ci]),
+            "fwp_sched_in": (ci, [vp, ci, ip, ip, ci]), "fwp_sched_out": (ci, [vp, ci, ip, ci]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _planner_lib = L
+    return _planner_lib
+
+
+class PlannerEngine(Engine):
+    """Graph-editing + compile surface of OracleEngine on the PRODUCT's host planner (CPU, no device)."""
+
+    backend = "planner"
+
+    def __init__(self, sample_rate=48000, max_block_frames=256, num_graph_inputs=0, num_graph_outputs=2):
+        self.L = planner_lib()
+        self.c = self.L.fwp_new(num_graph_inputs, num_graph_outputs)
+
+    def __del__(self):
+        try:
+            self.L.fwp_free(self.c)
+        except Exception:
+            pass
+
+    @property
+    def graph_in_node(self):
+        return self.L.fwp_graph_in_node(self.c)
+
+    @property
+    def graph_out_node(self):
+        return self.L.fwp_graph_out_node(self.c)
+
+    def add_node(self, kind, n_in, n_out, params=()):
+        return self.L.fwp_add_node(self.c, kind, n_in, n_out)
+
+    def remove_node(self, node):
+        return self.L.fwp_remove_node(self.c, node)
+
+    def connect(self, src, sp, dst, dp, check_for_cycles=False):
+        r = self.L.fwp_connect(self.c, src, sp, dst, dp, 1 if check_for_cycles else 0)
+        if r < 0:
+            raise AddEdgeError(r)
+        return r
+
+    def disconnect(self, src, sp, dst, dp):
+        return self.L.fwp_disconnect(self.c, src, sp, dst, dp)
+
+    def disconnect_by_edge_id(self, e):
+        return self.L.fwp_disconnect_edge(self.c, e)
+
+    def cycle_detected(self):
+        return bool(self.L.fwp_cycle_detected(self.c))
+
+    def update(self):
+        r = self.L.fwp_update(self.c)
+        if r < 0:
+            raise CompileGraphError(r, self.L.fwp_last_error(self.c).decode())
+
+    def schedule(self):
+        out = []
+        buf = (C.c_int * 64)()
+        clr = (C.c_int * 64)()
+        for i in range(self.L.fwp_sched_len(self.c)):
+            ni = self.L.fwp_sched_in(self.c, i, buf, clr, 64)
+            ins = [(buf[k], bool(clr[k])) for k in range(ni)]
+            no = self.L.fwp_sched_out(self.c, i, buf, 64)
+            out.append({"id": self.L.fwp_sched_node(self.c, i), "in": ins, "out": [buf[k] for k in range(no)],
+                        "level": self.L.fwp_sched_level(self.c, i)})
+        return out
+
+    def num_buffers(self):
+        return self.L.fwp_sched_num_buffers(self.c)
+
+    def num_levels(self):
+        return self.L.fwp_sched_num_levels(self.c)
+
+
 def xorshift_uniform(seed, n):
     """Deterministic uniform(-1,1) f32 stream (seeded xorshift), vectorised per call."""
     rng = np.random.Generator(np.random.PCG64(seed))

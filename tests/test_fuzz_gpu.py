@@ -325,11 +325,19 @@ def fuzz_dag(e, seed):
 def test_random_dag_generic_executor_bit_exact(seed):
     pick = np.random.default_rng(70_000 + seed)
     mbf = int(pick.choice([32, 64, 100, 128, 256]))
-    want = fuzz_dag(oracle(max_block_frames=mbf), seed)
+    o = oracle(max_block_frames=mbf)
+    want = fuzz_dag(o, seed)
     assert np.all(np.isfinite(want))
     cls = AsyncEngine if pick.random() < 0.5 else GpuEngine
     g = cls(max_block_frames=mbf, max_batch=int(pick.choice([1, 2, 5, 64])))
-    assert_bits_equal(want, fuzz_dag(g, seed), "dag seed %d plan %d %s" % (seed, g.cx.plan_kind(), cls.__name__))
+    imported = pick.random() < 0.3
+    if imported:
+        # level A of INTEGRATION.md: keep the reference's own compiler (restated by the oracle: its order, its LIFO buffer
+        # assignment) and hand the CompiledSchedule to fwgpu_schedule_upload; node ids are the same on both sides
+        sched, nbuf = o.e.schedule(), o.e.num_buffers()
+        g.update = lambda: g.cx.schedule_upload(sched, nbuf)
+    assert_bits_equal(want, fuzz_dag(g, seed), "dag seed %d plan %d %s%s" % (seed, g.cx.plan_kind(), cls.__name__,
+                                                                             " imported schedule" if imported else ""))
 
 
 def fuzz_stream(e, seed, n_in):

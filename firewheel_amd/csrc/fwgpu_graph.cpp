@@ -71,6 +71,7 @@ int HostGraph::remove_node(int64_t id) {
         if (n->in_edge[p] >= 0) remove_edge_slot((uint32_t)n->in_edge[p]);
     for (uint32_t p = 0; p < n->n_out; ++p) {
         std::vector<int> es = n->out_edges[p];
+        std::sort(es.begin(), es.end());  // arena (slot) order, as graph.rs:529-546 walks it: keeps later EdgeIDs the reference's
         for (int e : es) remove_edge_slot((uint32_t)e);
     }
     n->alive = false;

@@ -171,6 +171,9 @@ class Pair(object):
 
     def add(self, kind, n_in, n_out):
         self.nodes.append((self.p.add_node(kind, n_in, n_out), self.o.add_node(kind, n_in, n_out), n_in, n_out))
+        # same NodeID (slot + generation) as the reference's thunderdome arena hands out, through removals and slot reuse:
+        # what lets a binding pass the reference's ids straight to fwgpu_schedule_upload
+        assert self.nodes[-1][0] == self.nodes[-1][1]
         return len(self.nodes) - 1
 
     def both(self, fp, fo):
@@ -201,6 +204,7 @@ class Pair(object):
             if cyc:
                 assert self.p.disconnect_by_edge_id(r[0]) == 1 and self.o.disconnect_by_edge_id(r[1]) == 1
                 return None
+        assert r[0] == r[1]  # ... and the same EdgeID
         self.edges[(si, sp, di, dp)] = r
         return r
 

@@ -193,13 +193,30 @@ class AsyncEngine(GpuEngine):
 def test_random_graph_and_messages_every_plan_bit_exact(seed):
     pick = np.random.default_rng(10_000 + seed)
     mbf = int(pick.choice([64, 128, 256]))
-    want = fuzz_run(oracle(max_block_frames=mbf), seed)
+    o = oracle(max_block_frames=mbf)
+    scheds = []  # the CompiledSchedule of every update() of the run (graph edits recompile)
+
+    def recording_update():
+        o.e.update()
+        scheds.append((o.e.schedule(), o.e.num_buffers()))
+
+    o.update = recording_update
+    want = fuzz_run(o, seed)
     assert np.all(np.isfinite(want))
     cls = AsyncEngine if pick.random() < 0.5 else GpuEngine
     g = cls(max_block_frames=mbf, max_batch=int(pick.choice([1, 2, 5, 64])))
     assert_bits_equal(want, fuzz_run(g, seed), "seed %d plan %d %s" % (seed, g.cx.plan_kind(), cls.__name__))
     g2 = GpuEngine(max_block_frames=mbf, force_generic=True, max_batch=int(pick.choice([1, 3, 64])))
     assert_bits_equal(want, fuzz_run(g2, seed), "seed %d generic" % seed)
+    if pick.random() < 0.3:
+        # level A of INTEGRATION.md: every schedule of the run comes from the reference's compiler (restated by the oracle)
+        # through fwgpu_schedule_upload — node ids are the same on both sides, also after removals and slot reuse; the
+        # fused plans must be recognised on the imported schedules too
+        g3 = GpuEngine(max_block_frames=mbf, max_batch=int(pick.choice([2, 64])))
+        todo = list(scheds)
+        g3.update = lambda: g3.cx.schedule_upload(*todo.pop(0))
+        assert_bits_equal(want, fuzz_run(g3, seed), "seed %d imported schedules" % seed)
+        assert not todo and g3.cx.plan_kind() == g.cx.plan_kind()
 
 
 def fuzz_dag(e, seed):

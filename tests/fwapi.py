@@ -525,6 +525,72 @@ class GpuEngine(Engine):
         return (np.stack(outs) if outs else np.zeros((0, frames), np.float32)), om
 
 
+_hostonly_lib = None
+
+
+def hostonly_lib():
+    """The HOST half of libfwgpu (fwgpu_ctx.cpp + fwgpu_graph.cpp) built with g++ against tests/host_harness: a fake HIP
+    runtime (host memory, inert streams) and no-op kernel launches.  Computes no audio — it lets the CPU tier test graph
+    editing, planning, plan selection, batching, message bookkeeping and the error conventions of the C ABI."""
+    global _hostonly_lib
+    if _hostonly_lib is None:
+        import firewheel_amd._lib as flib
+
+        d = os.path.join(ROOT, "tests", "host_harness")
+        csrc = os.path.join(ROOT, "firewheel_amd", "csrc")
+        so = os.path.join(d, "_hostonly.so")
+        srcs = [os.path.join(d, "launch_stubs.cpp"), os.path.join(csrc, "fwgpu_ctx.cpp"), os.path.join(csrc, "fwgpu_graph.cpp")]
+        deps = srcs + [os.path.join(csrc, h) for h in ("fwgpu_graph.h", "fwgpu_types.h", "fwgpu_launch.h")] + [
+            os.path.join(ROOT, "include", "fwgpu.h"), os.path.join(d, "fakehip", "hip", "hip_runtime_api.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in deps):
+            subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-Wall", "-Wno-unused-function",
+                                   "-I", os.path.join(d, "fakehip"), "-I", os.path.join(ROOT, "include"), "-o", so] + srcs)
+        L = C.CDLL(so)
+        for name, (res, args) in flib.SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        L.fwh_launch_count.restype = C.c_ulonglong
+        L.fwh_launch_count.argtypes = [C.c_int]
+        L.fwh_launch_reset.restype = None
+        _hostonly_lib = L
+    return _hostonly_lib
+
+
+class HostOnlyEngine(GpuEngine):
+    """GpuEngine's surface on the host-only harness library (CPU tier; outputs are meaningless, only the host logic runs)."""
+
+    backend = "hostonly"
+
+    def __init__(self, sample_rate=48000, max_block_frames=256, num_graph_inputs=0, num_graph_outputs=2,
+                 force_generic=False, max_batch=None):
+        import firewheel_amd as fa
+        import firewheel_amd._lib as flib
+
+        self.fa = fa
+        self.sample_rate = sample_rate
+        self.max_block_frames = max_block_frames
+        saved = flib._lib
+        flib._lib = hostonly_lib()
+        try:
+            self.cx = fa.FirewheelGpuCtx(sample_rate, max_block_frames, num_graph_inputs, num_graph_outputs)
+        finally:
+            flib._lib = saved
+        if force_generic:
+            self.cx.set_force_generic(True)
+        if max_batch:
+            self.cx.set_max_batch(max_batch)
+
+    def launches(self):
+        """kernel launches since the last reset: dict by kind"""
+        L = hostonly_lib()
+        names = ("level", "voice_control", "leaf_sum", "chain", "bus_sum", "root_out", "fir", "other")
+        return {n: int(L.fwh_launch_count(i)) for i, n in enumerate(names)}
+
+    def reset_launches(self):
+        hostonly_lib().fwh_launch_reset()
+
+
 def make_engine(backend, **kw):
     if backend == "oracle":
         kw.pop("force_generic", None)

@@ -1,0 +1,69 @@
+/* TEST DOUBLE, CPU tier only (tests/host_harness): just enough of the HIP runtime API for the HOST half of libfwgpu
+ * (fwgpu_ctx.cpp) to run without a device — "device" memory is calloc'd host memory, streams / events / graphs are inert
+ * tokens.  The kernels are NOT here: every launch_* is a no-op stub (launch_stubs.cpp), so no audio is ever computed on
+ * this path; it exists to test graph editing, planning, plan selection, message bookkeeping and the error conventions
+ * of the C ABI with `pytest -m "not gpu"`.  Never linked into the product. */
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+typedef struct fake_stream* hipStream_t;
+typedef struct fake_event* hipEvent_t;
+typedef struct fake_graph* hipGraph_t;
+typedef struct fake_graph_exec* hipGraphExec_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocMapped = 2 };
+enum hipStreamCaptureMode { hipStreamCaptureModeThreadLocal = 1 };
+struct hipDeviceProp_t {
+    char name[256];
+    char gcnArchName[256];
+    int multiProcessorCount;
+    size_t totalGlobalMem;
+};
+
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "fake hip error"; }
+static inline hipError_t hipGetLastError(void) { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    memset(p, 0, sizeof(*p));
+    strcpy(p->name, "host harness (no device)");
+    strcpy(p->gcnArchName, "gfx950:host-harness");
+    p->multiProcessorCount = 256;
+    p->totalGlobalMem = (size_t)288 << 30;
+    return hipSuccess;
+}
+static inline hipError_t hipMalloc(void** p, size_t n) {
+    if (n > ((size_t)1 << 32)) return hipErrorOutOfMemory;  /* the harness never needs more; keeps a bad size from eating the host */
+    *p = calloc(n ? n : 1, 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+template <class T>
+static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, 8); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipSuccess; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = (hipGraph_t)calloc(1, 8); return hipSuccess; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t* x, hipGraph_t, void*, void*, size_t) { *x = (hipGraphExec_t)calloc(1, 8); return hipSuccess; }
+static inline hipError_t hipGraphDestroy(hipGraph_t g) { free(g); return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t x) { free(x); return hipSuccess; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipSuccess; }

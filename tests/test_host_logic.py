@@ -1,0 +1,242 @@
+"""CPU tier: the HOST half of libfwgpu (fwgpu_ctx.cpp + fwgpu_graph.cpp) on the host-only harness of tests/host_harness —
+a fake HIP runtime and no-op kernel launches, so NO audio is computed here (the parity tests proper are the GPU tier).
+What runs is the product's own graph editing, planning, plan selection, batching, message bookkeeping and error
+conventions behind the real C ABI entry points."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fwapi
+import scenarios
+from fwapi import (DUMMY, PLANAR_F32, SAMPLER, SUM, VOLUME, CompileGraphError, HostOnlyEngine, OracleEngine, hostonly_lib)
+
+ERR_INVALID, ERR_QUEUE_FULL = -20, -21
+
+
+def bank(e, n_voices=12, radix=4, chain=False, clip_in_voice=False, master=False):
+    """sampler -> [biquad -> delay] -> volume -> pan -> sum tree -> [master volume] -> graph_out; returns the samplers"""
+    ends, smp = [], []
+    for v in range(n_voices):
+        s = e.sampler(90.0)
+        cur = s
+        if chain:
+            b = e.biquad(0, 1000.0 + 10 * v, 0.7)
+            d = e.delay(0.01 + 0.001 * v, feedback=0.2, mix=0.5)
+            e.connect_stereo(cur, b)
+            e.connect_stereo(b, d)
+            cur = d
+        if clip_in_voice and v == 3:
+            h = e.hard_clip(-3.0)
+            e.connect_stereo(cur, h)
+            cur = h
+        g = e.volume(50.0 + v)
+        p = e.pan(0.1 * (v % 5) - 0.2)
+        e.connect_stereo(cur, g)
+        e.connect_stereo(g, p)
+        ends.append(p)
+        smp.append(s)
+    level = ends
+    while len(level) > 1:
+        nxt = []
+        for i in range(0, len(level), radix):
+            grp = level[i:i + radix]
+            m = e.sum(max(len(grp), 2))
+            for k, n in enumerate(grp):
+                e.connect_stereo(n, m, 2 * k)
+            nxt.append(m)
+        level = nxt
+    top = level[0]
+    if master:
+        mv = e.volume(80.0)
+        e.connect_stereo(top, mv)
+        top = mv
+    e.connect_stereo(top, e.graph_out_node)
+    e.update()
+    return smp
+
+
+@pytest.mark.parametrize("kw,plan", [({}, 1), ({"chain": True}, 2), ({"clip_in_voice": True}, 0), ({"master": True}, 1),
+                                     ({"chain": True, "master": True}, 2), ({"radix": 32, "n_voices": 70}, 1)])
+def test_plan_selection(kw, plan):
+    e = HostOnlyEngine(max_block_frames=128)
+    bank(e, **kw)
+    assert e.cx.plan_kind() == plan
+    e.cx.set_force_generic(True)
+    assert e.cx.plan_kind() == 0
+    e.cx.set_force_generic(False)
+    assert e.cx.plan_kind() == plan
+
+
+def test_imported_reference_schedule_selects_the_same_plan_and_levels():
+    o = OracleEngine(max_block_frames=128)
+    bank(o, chain=True)
+    e = HostOnlyEngine(max_block_frames=128)
+    e.update = lambda: e.cx.schedule_upload(o.schedule(), o.num_buffers())
+    bank(e, chain=True)
+    n = HostOnlyEngine(max_block_frames=128)
+    bank(n, chain=True)
+    assert e.cx.plan_kind() == n.cx.plan_kind() == 2
+    assert e.cx.plan_num_levels() == n.cx.plan_num_levels()
+    for s in o.schedule():
+        assert e.cx.plan_node_level(s["id"]) == n.cx.plan_node_level(s["id"])
+        assert e.cx.plan_node_inputs_clear(s["id"]) == [c for _, c in s["in"]] == n.cx.plan_node_inputs_clear(s["id"])
+
+
+def test_batching_of_a_call_into_launch_sequences():
+    # voice-bank plan: one control + one leaf launch per batch of max_batch blocks; the chain plan caps a batch at 64
+    e = HostOnlyEngine(max_block_frames=64, max_batch=16)
+    bank(e, n_voices=16, radix=4)  # 4 leaves + root
+    e.reset_launches()
+    e.process_blocks(40)  # 16 + 16 + 8
+    c = e.launches()
+    assert (c["voice_control"], c["leaf_sum"], c["root_out"], c["chain"], c["level"]) == (3, 3, 3, 0, 0)
+    e2 = HostOnlyEngine(max_block_frames=64, max_batch=200)
+    bank(e2, n_voices=16, radix=4, chain=True)
+    e2.reset_launches()
+    e2.process_blocks(130)  # 64 + 64 + 2
+    c = e2.launches()
+    assert (c["voice_control"], c["chain"], c["leaf_sum"]) == (3, 3, 0)
+    # generic executor: one launch per level (and kernel set) per batch; a partial last block is its own batch
+    e3 = HostOnlyEngine(max_block_frames=64, max_batch=8, force_generic=True)
+    bank(e3, n_voices=4, radix=4)
+    e3.reset_launches()
+    e3.process_interleaved(64 * 8 + 10)
+    c = e3.launches()
+    assert c["voice_control"] == 0 and c["level"] >= 2 * 4  # >= 4 node levels x 2 batches
+
+
+def test_null_handle_is_an_error_return_on_every_entry_point():
+    import firewheel_amd._lib as flib
+
+    L = hostonly_lib()
+    for name, (res, args) in flib.SIGNATURES.items():
+        if not args or args[0] is not C.c_void_p or name == "fwgpu_ctx_create":
+            continue
+        zeros = [None] + [a() if not hasattr(a, "contents") and a is not C.c_void_p and a is not C.c_char_p else None for a in args[1:]]
+        r = getattr(L, name)(*zeros)
+        if name == "fwgpu_ctx_destroy":
+            continue
+        if name == "fwgpu_last_error":
+            assert r == b"null ctx"
+            continue
+        assert r is not None and r < 0, (name, r)
+
+
+def test_sampler_message_ring_capacity_and_reset():
+    e = HostOnlyEngine(max_block_frames=64)
+    s = e.sampler(100.0)
+    e.connect_stereo(s, e.graph_out_node)
+    e.update()
+    L, c = e.cx.L, e.cx.c
+    for i in range(128):  # nodes/sampler.rs:14 CHANNEL_CAPACITY
+        assert L.fwgpu_sampler_pause(c, s, 0) == 0
+    assert L.fwgpu_sampler_play(c, s, 0) == ERR_QUEUE_FULL
+    assert b"ring full" in L.fwgpu_last_error(c)
+    assert L.fwgpu_node_set_param(c, s, 0, 50.0, 0) == 0  # the gain is an atomic, not a ring message
+    e.process_blocks(1)  # the audio thread drains the ring at the next block
+    assert L.fwgpu_sampler_play(c, s, 0) == 0
+
+
+def test_argument_errors_of_the_edit_and_message_calls():
+    e = HostOnlyEngine(max_block_frames=64)
+    L, c = e.cx.L, e.cx.c
+    fp = C.POINTER(C.c_float)
+    assert L.fwgpu_add_node(c, 99, 1, 1, None, 0) == ERR_INVALID
+    assert L.fwgpu_add_node(c, VOLUME, 65, 65, None, 0) == ERR_INVALID          # core/node.rs:62,69
+    assert L.fwgpu_add_node(c, VOLUME, 2, 2, None, 3) == ERR_INVALID            # params missing
+    assert L.fwgpu_add_node(c, fwapi.FIR, 2, 2, (C.c_float * 1)(5.0), 1) == ERR_INVALID  # no such impulse response
+    v = e.volume(50.0)
+    s = e.sampler(100.0)
+    assert L.fwgpu_node_set_param(c, v, 3, 1.0, 0) == ERR_INVALID               # unknown param id
+    assert L.fwgpu_node_set_param(c, 12345 << 32 | 7, 0, 1.0, 0) == ERR_INVALID  # unknown node
+    assert L.fwgpu_sampler_play(c, v, 0) == ERR_INVALID                          # not a sampler
+    assert L.fwgpu_sampler_set_sample(c, s, 3, 0, 0) == ERR_INVALID              # unknown sample
+    assert L.fwgpu_sampler_set_loop_range(c, s, 7, 0.0, 0.0, 0) == ERR_INVALID
+    assert L.fwgpu_remove_node(c, e.graph_in_node) < 0 and L.fwgpu_remove_node(c, e.graph_out_node) < 0
+    assert L.fwgpu_set_max_batch(c, 0) == ERR_INVALID
+    assert L.fwgpu_sample_create(c, 9, 2, 10, None) == ERR_INVALID               # bad format
+    assert L.fwgpu_sample_create(c, PLANAR_F32, 0, 10, None) == ERR_INVALID      # no channels
+    assert L.fwgpu_sample_create(c, PLANAR_F32, 2, 10, None) == ERR_INVALID      # null data
+    assert L.fwgpu_sample_create(c, PLANAR_F32, 2, 1 << 62, None) == ERR_INVALID  # size overflow
+    assert L.fwgpu_process_blocks_device(c, 1, None, 2) == ERR_INVALID           # no schedule yet
+    out = (C.c_float * 128)()
+    assert L.fwgpu_process_interleaved(c, None, out, 0, 2, 64, 0.0, 0) == 0      # processor.rs:86-89: no schedule -> zeros
+    assert L.fwgpu_process_interleaved(c, None, None, 0, 2, 64, 0.0, 0) == ERR_INVALID
+    assert L.fwgpu_process_interleaved(c, None, out, 0, 65, 1, 0.0, 0) == ERR_INVALID  # processor.rs:43-44
+
+
+def test_activation_failure_aborts_the_compile_and_leaves_the_graph_usable():
+    e = HostOnlyEngine(max_block_frames=64)
+    s = e.sampler(100.0)
+    e.connect_stereo(s, e.graph_out_node)
+    e.update()
+    bad = e.add_node(VOLUME, 2, 3)  # volume.rs:63-65: n_in == n_out
+    with pytest.raises(CompileGraphError) as ei:
+        e.update()
+    assert ei.value.name == "NodeActivationFailed"
+    assert e.cx.plan_kind() >= 0  # the previous schedule stays installed (graph.rs:603-609 rollback)
+    e.remove_node(bad)
+    e.update()
+    odd = e.add_node(SUM, 5, 2)  # sum.rs:27-29: inputs divisible by outputs
+    with pytest.raises(CompileGraphError):
+        e.update()
+    e.remove_node(odd)
+    e.update()
+
+
+def test_schedule_upload_validation():
+    e = HostOnlyEngine(max_block_frames=64)
+    a = e.add_node(DUMMY, 1, 1)
+    gi, go = e.graph_in_node, e.graph_out_node
+    ok = [{"id": gi, "in": [], "out": []}, {"id": a, "in": [(0, True)], "out": [0]}, {"id": go, "in": [(0, False), (1, True)], "out": []}]
+    e.cx.schedule_upload(ok, 2)
+    cases = {
+        "unknown node": [ok[0], {"id": 77 << 32 | 9, "in": [], "out": []}, ok[2]],
+        "port counts": [ok[0], {"id": a, "in": [], "out": [0]}, ok[2]],
+        "unwritten buffer": [ok[0], {"id": a, "in": [(1, False)], "out": [0]}, ok[2]],
+        "buffer index": [ok[0], {"id": a, "in": [(0, True)], "out": [5]}, ok[2]],
+        "graph_in first": [ok[1], ok[0], ok[2]],
+        "too short": [ok[0]],
+    }
+    for what, sched in cases.items():
+        with pytest.raises(Exception):
+            e.cx.schedule_upload(sched, 2)
+    e.cx.schedule_upload(ok, 2)  # still usable
+
+
+def test_sample_destroy_contract_on_the_host_side():
+    e = HostOnlyEngine(max_block_frames=64)
+    ir = e.new_sample(PLANAR_F32, 1, np.ones(16, dtype=np.float32))
+    f = e.fir(ir)
+    with pytest.raises(Exception):
+        e.cx.destroy_sample(ir)       # named by a FIR node
+    with pytest.raises(Exception):
+        e.cx.destroy_sample(42)       # unknown
+    e.remove_node(f)
+    e.cx.destroy_sample(ir)
+    with pytest.raises(Exception):
+        e.cx.destroy_sample(ir)       # already destroyed
+    with pytest.raises(Exception):
+        e.fir(ir)                     # and no longer usable as an impulse response
+    assert e.new_sample(PLANAR_F32, 1, np.ones(4, dtype=np.float32)) == ir + 1  # ids are never reused
+
+
+def test_graph_edits_keep_the_plan_and_grow_buffers():
+    # plug voices into spare leaf ports one at a time: every update recompiles, the fused plan stays
+    e = HostOnlyEngine(max_block_frames=64, max_batch=4)
+    leaf = e.sum(8)
+    e.connect_stereo(leaf, e.graph_out_node)
+    for v in range(8):
+        s = e.sampler(80.0)
+        g = e.volume(60.0)
+        e.connect_stereo(s, g)
+        e.connect_stereo(g, leaf, 2 * v)
+        e.update()
+        assert e.cx.plan_kind() == 1
+        e.process_blocks(3)
+    e.cx.set_max_batch(64)
+    e.update()
+    e.reset_launches()
+    e.process_blocks(64)
+    assert e.launches()["leaf_sum"] == 1

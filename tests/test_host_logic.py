@@ -240,3 +240,30 @@ def test_graph_edits_keep_the_plan_and_grow_buffers():
     e.reset_launches()
     e.process_blocks(64)
     assert e.launches()["leaf_sum"] == 1
+
+
+def test_host_half_fuzz_under_address_and_ub_sanitizers(tmp_path):
+    # the GPU fuzz families' generators (random banks / chains / DAGs / effects racks, messages, graph edits, calls of
+    # arbitrary length) against the host half built with -fsanitize=address,undefined: any out-of-bounds plan table, group
+    # packing or message bookkeeping bug aborts the subprocess
+    import os
+    import subprocess
+    import sys
+
+    def lib(name):
+        p = subprocess.check_output(["gcc", "-print-file-name=" + name]).decode().strip()
+        return p if os.path.isabs(p) and os.path.exists(p) else None
+
+    asan, ubsan = lib("libasan.so"), lib("libubsan.so")
+    if not asan or not ubsan:
+        pytest.skip("no sanitizer runtimes in this toolchain")
+    d = os.path.join(fwapi.ROOT, "tests", "host_harness")
+    csrc = os.path.join(fwapi.ROOT, "firewheel_amd", "csrc")
+    so = str(tmp_path / "_hostonly_asan.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-shared", "-fPIC", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-Wno-unused-function",
+                           "-I", os.path.join(d, "fakehip"), "-I", os.path.join(fwapi.ROOT, "include"), "-o", so,
+                           os.path.join(d, "launch_stubs.cpp"), os.path.join(csrc, "fwgpu_ctx.cpp"), os.path.join(csrc, "fwgpu_graph.cpp")])
+    env = dict(os.environ, LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0", FWGPU_HOSTONLY_ASAN_SO=so)
+    r = subprocess.run([sys.executable, os.path.join(d, "asan_fuzz.py"), "30"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok 30" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -267,3 +267,7 @@ def test_host_half_fuzz_under_address_and_ub_sanitizers(tmp_path):
     env = dict(os.environ, LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0", FWGPU_HOSTONLY_ASAN_SO=so)
     r = subprocess.run([sys.executable, os.path.join(d, "asan_fuzz.py"), "30"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok 30" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    # ... and a hostile caller: random entry points with mostly invalid arguments (stale ids, bad ports / kinds, NaN and huge
+    # parameters, far-future at_block, odd frame counts) — error returns only, no crash, no sanitizer report
+    r = subprocess.run([sys.executable, os.path.join(d, "api_fuzz.py"), "150"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok 150" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

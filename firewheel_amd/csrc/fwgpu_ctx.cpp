@@ -1935,6 +1935,10 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     if (frames > c->mbf) return fail(c, FWGPU_ERR_INVALID, "frames > max_block_frames");
     if (hn->kind == K_FIR) return fail(c, FWGPU_ERR_INVALID, "FIR banks run at graph level (fwgpu_process_interleaved), not per node");
     if (n_in + n_out == 0) return fail(c, FWGPU_ERR_INVALID, "node has no ports");
+    if (frames == 0) {  // the reference never calls a node with an empty block (processor.rs:86-89 returns first): nothing to do
+        if (out_mask) *out_mask = 0;
+        return 0;
+    }
     if ((n_in && !inputs) || (n_out && !outputs)) return fail(c, FWGPU_ERR_INVALID, "null channel table");
     for (uint32_t i = 0; frames && i < n_in; ++i)
         if (!inputs[i]) return fail(c, FWGPU_ERR_INVALID, "null input channel");

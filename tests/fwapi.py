@@ -553,6 +553,8 @@ def hostonly_lib():
         L.fwh_launch_count.restype = C.c_ulonglong
         L.fwh_launch_count.argtypes = [C.c_int]
         L.fwh_launch_reset.restype = None
+        L.fwh_violation.restype = C.c_char_p
+        L.fwh_violation_reset.restype = None
         _hostonly_lib = L
     return _hostonly_lib
 
@@ -589,6 +591,10 @@ class HostOnlyEngine(GpuEngine):
 
     def reset_launches(self):
         hostonly_lib().fwh_launch_reset()
+
+    def violation(self):
+        """first descriptor invariant / table extent the launch stubs found violated since the last reset ('' = none)"""
+        return hostonly_lib().fwh_violation().decode()
 
 
 def make_engine(backend, **kw):

@@ -154,4 +154,6 @@ if __name__ == "__main__":
     n = int(sys.argv[1])
     for seed in range(n):
         run(seed)
+    L.fwh_violation.restype = C.c_char_p
+    assert L.fwh_violation() == b"", L.fwh_violation()
     print("ok", n)

@@ -27,4 +27,6 @@ for seed in range(n):
     F.fuzz_dag(fwapi.HostOnlyEngine(max_block_frames=int(pick.choice([32, 64, 100, 128, 256])), max_batch=int(pick.choice([1, 2, 5, 64]))), seed)
     n_in = 1 + seed % 4
     F.fuzz_stream(fwapi.HostOnlyEngine(max_block_frames=mbf, num_graph_inputs=n_in, max_batch=int(pick.choice([1, 3, 64]))), seed, n_in)
+L.fwh_violation.restype = C.c_char_p
+assert L.fwh_violation() == b"", L.fwh_violation()
 print("ok", n)

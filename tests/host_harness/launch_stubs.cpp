@@ -10,21 +10,274 @@ extern "C" void fwh_launch_reset(void) {
     for (auto& x : g_launches) x = 0;
 }
 
+// ---- what the stubs CHECK instead of computing: every table a kernel would index is touched at the extent the kernel
+// indexes it (first and last byte: under ASan an under-sized allocation of the host side is a report), and the
+// descriptor invariants the kernels rely on are asserted.  The first violation is kept for the tests (fwh_violation).
+#include <stdio.h>
+
+#include <string>
+namespace {
+std::string g_violation;
+void violation(const char* what, long a = 0, long b = 0) {
+    if (!g_violation.empty()) return;
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s (%ld, %ld)", what, a, b);
+    g_violation = buf;
+    fprintf(stderr, "host harness: descriptor invariant violated: %s\n", buf);
+}
+#define REQUIRE(cond, ...) \
+    do {                   \
+        if (!(cond)) violation(#cond, ##__VA_ARGS__); \
+    } while (0)
+volatile unsigned char g_sink;
+void touch(const void* p, size_t bytes) {
+    if (!bytes) return;
+    if (!p) {
+        violation("null table with a non-zero extent", (long)bytes);
+        return;
+    }
+    g_sink = ((const volatile unsigned char*)p)[0];
+    g_sink = ((const volatile unsigned char*)p)[bytes - 1];
+}
+}  // namespace
+extern "C" const char* fwh_violation(void) { return g_violation.c_str(); }
+extern "C" void fwh_violation_reset(void) { g_violation.clear(); }
+
 namespace fwgpu {
-int launch_level(hipStream_t, const DevView&, const int*, int, int, uint32_t, int) { g_launches[0]++; return 0; }
-int launch_frozen_scan(hipStream_t, const DevView&, int, uint32_t, int, uint8_t*, unsigned long long*) { g_launches[7]++; return 0; }
-int launch_bus_sum(hipStream_t, const DevView&, const int*, int, int, int) { g_launches[4]++; return 0; }
-int launch_root_out(hipStream_t, const DevView&, const RootArgs&, float*, int) { g_launches[5]++; return 0; }
-int launch_ir_convert(hipStream_t, const SampleDesc*, int, int, float*, uint32_t) { g_launches[7]++; return 0; }
-int launch_fir(hipStream_t, const DevView&, const FirRow*, int, const uint32_t*, uint32_t, float*, size_t, int, hipEvent_t, hipEvent_t) { g_launches[6]++; return 0; }
-int launch_single_node(hipStream_t, const DevView&, int) { g_launches[7]++; return 0; }
-int launch_scatter_states(hipStream_t, NodeState*, const void*, int) { g_launches[7]++; return 0; }
-int launch_graph_in(hipStream_t, float*, uint8_t*, int, size_t, size_t, const int*, int, const float*, int, int, int) { g_launches[7]++; return 0; }
-int launch_graph_out(hipStream_t, const float*, const uint8_t*, int, size_t, size_t, const int*, int, float*, int, int, int) { g_launches[7]++; return 0; }
-int launch_set_flags(hipStream_t, uint8_t*, const int*, int, uint64_t) { g_launches[7]++; return 0; }
-int launch_get_flags(hipStream_t, const uint8_t*, const int*, int, uint64_t*) { g_launches[7]++; return 0; }
-int launch_voice_control(hipStream_t, const FusedView&, int, uint32_t) { g_launches[1]++; return 0; }
-int launch_leaf_sum(hipStream_t, const FusedView&, int) { g_launches[2]++; return 0; }
-int launch_chain(hipStream_t, const FusedView&, int, uint32_t, int) { g_launches[3]++; return 0; }
-int launch_scatter_ext(hipStream_t, float*, const void*, int) { g_launches[7]++; return 0; }
+namespace {
+void check_generic_node(const DevView& v, int idx, int K) {
+    touch(&v.nodes[idx], sizeof(NodeDesc));
+    const NodeDesc nd = v.nodes[idx];
+    REQUIRE(nd.n_in >= 0 && nd.n_in <= 64 && nd.n_out >= 0 && nd.n_out <= 64, nd.n_in, nd.n_out);
+    touch(v.in_buf + nd.in_off, sizeof(int) * (size_t)nd.n_in);
+    touch(v.out_buf + nd.out_off, sizeof(int) * (size_t)nd.n_out);
+    for (int p = 0; p < nd.n_in + nd.n_out; ++p) {
+        const int b = p < nd.n_in ? v.in_buf[nd.in_off + p] : v.out_buf[nd.out_off + p - nd.n_in];
+        REQUIRE(b >= 0, b);
+        REQUIRE(p < nd.n_in || b != 0, idx, p);  // nothing writes the constant zero buffer
+        touch(v.pool + (size_t)(K - 1) * v.pool_blk_stride + (size_t)b * v.stride, sizeof(float) * (size_t)v.stride);
+        touch(v.flags + (size_t)(K - 1) * v.flags_blk_stride + b, 1);
+    }
+    if (nd.state >= 0) touch(&v.states[nd.state], sizeof(NodeState));
+    if (v.frozen) touch(v.frozen + idx, 1);
+    if (v.frozen_playhead) touch(v.frozen_playhead + idx, 8);
+    if (nd.kind == K_SUM) REQUIRE(nd.n_out > 0 && nd.aux0 * nd.n_out == nd.n_in, nd.aux0, nd.n_in);
+}
+void check_view_common(const DevView& v, int K) {
+    REQUIRE(K >= 1, K);
+    REQUIRE(v.stride % 64 == 0 && v.frames >= 1 && v.frames <= v.stride, v.stride, v.frames);
+    touch(v.cmds, sizeof(Cmd) * (size_t)v.n_cmds);
+    for (int i = 1; i < v.n_cmds; ++i)  // sorted by (state, block): the device lookups are binary searches
+        REQUIRE(v.cmds[i - 1].state < v.cmds[i].state || (v.cmds[i - 1].state == v.cmds[i].state && v.cmds[i - 1].block <= v.cmds[i].block), i);
+}
+void check_fused_common(const FusedView& fv, int K) {
+    REQUIRE(K >= 1 && K <= fv.refs_stride, K, fv.refs_stride);
+    REQUIRE(fv.n_voices >= 1 && fv.n_leaves >= 1 && fv.stride % 64 == 0 && fv.frames >= 1 && fv.frames <= fv.stride, fv.n_voices, fv.frames);
+    REQUIRE(fv.epoch >= 1);
+    const size_t nv = (size_t)fv.n_voices;
+    touch(fv.voices, sizeof(VoiceDesc) * nv);
+    touch(fv.refs, sizeof(VoiceRef) * nv * (size_t)fv.refs_stride);
+    touch(fv.gsets, sizeof(GainSet) * nv * FW_GSETS);
+    touch(fv.cache, sizeof(VoiceCache) * nv);
+    touch(fv.blks, sizeof(VoiceBlk) * nv * (size_t)K);
+    touch(fv.ramps, sizeof(float) * nv * (size_t)K * (size_t)fv.ramp_slots * (size_t)fv.stride);
+    touch(fv.cmds, sizeof(Cmd) * (size_t)fv.n_cmds);
+    int max_stages = 0;
+    for (int i = 0; i < fv.n_voices; ++i) {
+        const VoiceDesc& vd = fv.voices[i];
+        if (vd.sampler_state < 0) continue;  // a null voice: an unconnected leaf port
+        REQUIRE(vd.n_stages >= 0 && vd.n_stages <= FW_MAX_STAGES - 1, i, vd.n_stages);
+        max_stages = vd.n_stages > max_stages ? vd.n_stages : max_stages;
+        touch(&fv.states[vd.sampler_state], sizeof(NodeState));
+        for (int j = 0; j < vd.n_stages; ++j) {
+            REQUIRE(vd.stage_kind[j] == K_VOLUME || vd.stage_kind[j] == K_PAN, i, vd.stage_kind[j]);
+            touch(&fv.states[vd.stage_state[j]], sizeof(NodeState));
+        }
+        REQUIRE(fv.fx_plan || (vd.bq_state < 0 && vd.dl_state < 0), i);
+        if (vd.bq_state >= 0) touch(&fv.states[vd.bq_state], sizeof(NodeState));
+        if (vd.dl_state >= 0) touch(&fv.states[vd.dl_state], sizeof(NodeState));
+    }
+    REQUIRE(fv.n_gain_stages >= 1 + max_stages && fv.n_gain_stages <= FW_MAX_STAGES, fv.n_gain_stages, max_stages);
+    REQUIRE(fv.ramp_slots >= 2 * fv.n_gain_stages || fv.ramp_slots == 0, fv.ramp_slots, fv.n_gain_stages);
+    // leaves tile the voice rows in order
+    touch(fv.leaves, sizeof(LeafDesc) * (size_t)fv.n_leaves);
+    int row = 0;
+    for (int l = 0; l < fv.n_leaves; ++l) {
+        const LeafDesc& ld = fv.leaves[l];
+        REQUIRE(ld.first_voice == row && ld.ports >= 1 && ld.ports <= 32, l, ld.ports);
+        row += ld.ports;
+        REQUIRE(ld.out_buf >= 1, l, ld.out_buf);
+        touch(fv.bus + (size_t)(K - 1) * fv.bus_blk_stride + (size_t)(ld.out_buf + 1) * fv.stride, sizeof(float) * (size_t)fv.stride);
+        touch(fv.bus_flags + (size_t)(K - 1) * fv.bus_flags_blk_stride + ld.out_buf + 1, 1);
+    }
+    REQUIRE(row == fv.n_voices, row, fv.n_voices);
+}
+}  // namespace
+
+int launch_level(hipStream_t, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t, int kinds) {
+    g_launches[0]++;
+    check_view_common(v, K);
+    REQUIRE(kinds >= 0 && kinds <= 7, kinds);  // 0: a level of Dummy / graph I/O / FIR nodes only — nothing to launch
+    touch(d_level_nodes, sizeof(int) * (size_t)n_nodes);
+    for (int i = 0; i < n_nodes; ++i) check_generic_node(v, d_level_nodes[i], K);
+    return 0;
+}
+int launch_frozen_scan(hipStream_t, const DevView& v, int n_nodes, uint32_t, int K, uint8_t* d_frozen, unsigned long long* d_snap) {
+    g_launches[7]++;
+    REQUIRE(K >= 1, K);
+    touch(v.nodes, sizeof(NodeDesc) * (size_t)n_nodes);
+    touch(d_frozen, (size_t)n_nodes);
+    touch(d_snap, 8 * (size_t)n_nodes);
+    return 0;
+}
+int launch_bus_sum(hipStream_t, const DevView& v, const int* d_level_nodes, int n_nodes, int K, int n_out) {
+    g_launches[4]++;
+    check_view_common(v, K);
+    touch(d_level_nodes, sizeof(int) * (size_t)n_nodes);
+    for (int i = 0; i < n_nodes; ++i) {
+        check_generic_node(v, d_level_nodes[i], K);
+        REQUIRE(v.nodes[d_level_nodes[i]].kind == K_SUM && v.nodes[d_level_nodes[i]].n_out <= n_out, i, n_out);
+    }
+    return 0;
+}
+int launch_root_out(hipStream_t, const DevView& v, const RootArgs& root, float* d_out, int K) {
+    g_launches[5]++;
+    check_view_common(v, K);
+    REQUIRE(root.n_in >= 2 && root.n_in <= 64 && root.ports * 2 == root.n_in, root.n_in, root.ports);
+    touch(root.in_tab, sizeof(int) * (size_t)root.n_in);
+    for (int i = 0; i < root.n_in; ++i) {
+        REQUIRE(root.in_tab[i] == root.in_buf[i] && root.in_buf[i] >= 0, i, root.in_buf[i]);
+        touch(v.pool + (size_t)(K - 1) * v.pool_blk_stride + (size_t)root.in_buf[i] * v.stride, sizeof(float) * (size_t)v.stride);
+        touch(v.flags + (size_t)(K - 1) * v.flags_blk_stride + root.in_buf[i], 1);
+    }
+    touch(d_out, sizeof(float) * 2 * (size_t)v.frames * (size_t)K);
+    return 0;
+}
+int launch_ir_convert(hipStream_t, const SampleDesc* samples, int sample, int, float* dst, uint32_t T) {
+    g_launches[7]++;
+    touch(&samples[sample], sizeof(SampleDesc));
+    touch(dst, sizeof(float) * (size_t)T);
+    return 0;
+}
+int launch_fir(hipStream_t, const DevView& v, const FirRow* d_rows, int n_rows, const uint32_t* d_tile_h_off, uint32_t T, float*, size_t, int K,
+               hipEvent_t, hipEvent_t) {
+    g_launches[6]++;
+    check_view_common(v, K);
+    REQUIRE(n_rows >= 1 && n_rows % 32 == 0 && T >= 1, n_rows, (long)T);  // rows padded to 32-row tiles
+    touch(d_rows, sizeof(FirRow) * (size_t)n_rows);
+    touch(d_tile_h_off, sizeof(uint32_t) * (size_t)(n_rows / 32));
+    for (int t = 0; t < n_rows / 32; ++t) touch(v.ext + d_tile_h_off[t], sizeof(float) * (size_t)T);
+    return 0;
+}
+int launch_single_node(hipStream_t, const DevView& v, int node_idx) {
+    g_launches[7]++;
+    check_view_common(v, 1);
+    check_generic_node(v, node_idx, 1);
+    return 0;
+}
+int launch_scatter_states(hipStream_t, NodeState* states, const void* d_inits, int n) {
+    g_launches[7]++;
+    touch(d_inits, sizeof(StateInitHost) * (size_t)n);
+    for (int i = 0; i < n; ++i) {  // plain data movement, done for real: the checks above read node state (delay lengths)
+        const StateInitHost& it = ((const StateInitHost*)d_inits)[i];
+        touch(&states[it.index], sizeof(NodeState));
+        states[it.index] = it.st;
+    }
+    return 0;
+}
+int launch_graph_in(hipStream_t, float* pool, uint8_t* flags, int stride, size_t pbs, size_t fbs, const int* d_bufs, int n_bufs, const float* d_in,
+                    int n_in_ch, int frames, int K) {
+    g_launches[7]++;
+    touch(d_bufs, sizeof(int) * (size_t)n_bufs);
+    for (int i = 0; i < n_bufs; ++i) {
+        touch(pool + (size_t)(K - 1) * pbs + (size_t)d_bufs[i] * stride, sizeof(float) * (size_t)stride);
+        touch(flags + (size_t)(K - 1) * fbs + d_bufs[i], 1);
+    }
+    touch(d_in, sizeof(float) * (size_t)n_in_ch * (size_t)frames * (size_t)K);
+    return 0;
+}
+int launch_graph_out(hipStream_t, const float* pool, const uint8_t* flags, int stride, size_t pbs, size_t fbs, const int* d_bufs, int n_bufs,
+                     float* d_out, int n_out_ch, int frames, int K) {
+    g_launches[7]++;
+    touch(d_bufs, sizeof(int) * (size_t)n_bufs);
+    for (int i = 0; i < n_bufs; ++i) {
+        touch(pool + (size_t)(K - 1) * pbs + (size_t)d_bufs[i] * stride, sizeof(float) * (size_t)stride);
+        touch(flags + (size_t)(K - 1) * fbs + d_bufs[i], 1);
+    }
+    touch(d_out, sizeof(float) * (size_t)n_out_ch * (size_t)frames * (size_t)K);
+    return 0;
+}
+int launch_set_flags(hipStream_t, uint8_t* flags, const int* d_bufs, int n, uint64_t) {
+    g_launches[7]++;
+    touch(d_bufs, sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; ++i) touch(flags + d_bufs[i], 1);
+    return 0;
+}
+int launch_get_flags(hipStream_t, const uint8_t* flags, const int* d_bufs, int n, uint64_t* d_mask) {
+    g_launches[7]++;
+    touch(d_bufs, sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; ++i) touch(flags + d_bufs[i], 1);
+    touch(d_mask, 8);
+    return 0;
+}
+int launch_voice_control(hipStream_t, const FusedView& fv, int K, uint32_t) {
+    g_launches[1]++;
+    check_fused_common(fv, K);
+    if (fv.fx_plan) touch(fv.chain_start, sizeof(ChainStart) * (size_t)fv.n_voices);
+    return 0;
+}
+int launch_leaf_sum(hipStream_t, const FusedView& fv, int K) {
+    g_launches[2]++;
+    check_fused_common(fv, K);
+    REQUIRE(!fv.fx_plan);
+    return 0;
+}
+int launch_chain(hipStream_t, const FusedView& fv, int K, uint32_t, int nq) {
+    g_launches[3]++;
+    check_fused_common(fv, K);
+    REQUIRE(fv.fx_plan == 1 && K <= CH_FAST_KMAX && (nq == 1 || nq == 2) && fv.frames % (64 * nq) == 0, K, nq);
+    touch(fv.chain_start, sizeof(ChainStart) * (size_t)fv.n_voices);
+    touch(fv.chain_dummy, 32 * 1024);
+    touch(fv.chain_stats, 16);
+    touch(fv.groups, sizeof(ChainGroup) * (size_t)fv.n_groups);
+    int row = 0, leaf = 0;
+    for (int g = 0; g < fv.n_groups; ++g) {
+        const ChainGroup& cg = fv.groups[g];
+        REQUIRE(cg.first_voice == row && cg.n_voices >= 1 && cg.n_voices <= 32 && cg.n_leaves >= 1 && cg.n_leaves <= CH_GROUP_LEAVES, g, cg.n_voices);
+        int r = 0;
+        uint32_t starts = 0, masked = 0;
+        for (int l = 0; l < cg.n_leaves; ++l, ++leaf) {
+            REQUIRE(leaf < fv.n_leaves && cg.row0[l] == r && cg.ports[l] == fv.leaves[leaf].ports && cg.out_buf[l] == fv.leaves[leaf].out_buf &&
+                        fv.leaves[leaf].first_voice == row + r, g, l);
+            starts |= 1u << r;
+            const int p = cg.ports[l];
+            if (!(p == 2 || p == 3 || p == 4))
+                for (int q = 0; q < p; ++q) masked |= 1u << (r + q);
+            r += p;
+        }
+        REQUIRE(r == cg.n_voices && cg.start_mask == starts && cg.masked_rows == masked, g, r);
+        if (cg.uniform_ports) {
+            bool ok = cg.n_voices == 32 && (cg.uniform_ports == 32 || cg.uniform_ports == 16 || cg.uniform_ports == 8 || cg.uniform_ports == 4);
+            for (int l = 0; l < cg.n_leaves; ++l) ok = ok && cg.ports[l] == cg.uniform_ports;
+            REQUIRE(ok, g, cg.uniform_ports);
+        }
+        row += cg.n_voices;
+    }
+    REQUIRE(row == fv.n_voices && leaf == fv.n_leaves, row, leaf);
+    for (int i = 0; i < fv.n_voices; ++i) {  // every delay line holds at least one tile
+        const VoiceDesc& vd = fv.voices[i];
+        if (vd.sampler_state >= 0 && vd.dl_state >= 0) REQUIRE(fv.states[vd.dl_state].loop_end >= (uint64_t)(64 * nq), i, nq);
+    }
+    return 0;
+}
+int launch_scatter_ext(hipStream_t, float* ext, const void* d_items, int n) {
+    g_launches[7]++;
+    touch(d_items, sizeof(ExtInitHost) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const ExtInitHost& it = ((const ExtInitHost*)d_items)[i];
+        REQUIRE(it.n <= 6, i, it.n);
+        touch(ext + it.off, sizeof(float) * it.n);
+    }
+    return 0;
+}
 }  // namespace fwgpu

@@ -14,6 +14,16 @@ from fwapi import (DUMMY, PLANAR_F32, SAMPLER, SUM, VOLUME, CompileGraphError, H
 ERR_INVALID, ERR_QUEUE_FULL = -20, -21
 
 
+@pytest.fixture(autouse=True)
+def no_descriptor_violation():
+    """the launch stubs of the harness validate every launch: table extents as the kernels index them, the descriptor
+    invariants the kernels rely on (leaves / chain groups tile the voice rows, sorted messages, ...): none may trip"""
+    L = hostonly_lib()
+    L.fwh_violation_reset()
+    yield
+    assert L.fwh_violation() == b"", L.fwh_violation()
+
+
 def bank(e, n_voices=12, radix=4, chain=False, clip_in_voice=False, master=False):
     """sampler -> [biquad -> delay] -> volume -> pan -> sum tree -> [master volume] -> graph_out; returns the samplers"""
     ends, smp = [], []

@@ -163,6 +163,7 @@ struct fwgpu_ctx {
 
     // messages
     std::vector<Cmd> cmds;
+    bool ring_msgs_pending = false;  // some node's pending_msgs is non-zero
     DevBuf d_cmds;
     int n_cmds_dev = 0;
     Cmd* h_cmds = nullptr;  // pinned staging for the async upload
@@ -1072,14 +1073,18 @@ int upload_cmds(fwgpu_ctx* c) {
     return 0;
 }
 void retire_cmds(fwgpu_ctx* c, uint32_t nblocks) {
-    std::vector<Cmd> keep;
-    for (Cmd& m : c->cmds)
+    size_t w = 0;  // in place: nothing is allocated on the process path
+    for (const Cmd& m : c->cmds)
         if (m.block >= nblocks) {
-            m.block -= nblocks;
-            keep.push_back(m);
+            Cmd k = m;
+            k.block -= nblocks;
+            c->cmds[w++] = k;
         }
-    c->cmds.swap(keep);
-    for (HostNode& n : c->graph.nodes) n.pending_msgs = 0;
+    c->cmds.resize(w);
+    if (c->ring_msgs_pending) {  // (a steady realtime callback has none: do not walk thousands of nodes per block)
+        for (HostNode& n : c->graph.nodes) n.pending_msgs = 0;
+        c->ring_msgs_pending = false;
+    }
 }
 
 // ---------------------------------------------------------------- timing helpers
@@ -1374,6 +1379,7 @@ int push_cmd(fwgpu_ctx* c, int64_t node, int want_kind, Cmd m, bool counts_as_ms
     if (counts_as_msg) {
         if (n->pending_msgs >= 128) return fail(c, FWGPU_ERR_QUEUE_FULL, "sampler message ring full");  // sampler.rs:14
         n->pending_msgs++;
+        c->ring_msgs_pending = true;
     }
     m.state = (int)(node & 0xffffffff);
     c->cmds.push_back(m);

@@ -1040,6 +1040,10 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         if ((rc = upload(c, c->d_root_bufs, fb.root_buf, sizeof(fb.root_buf)))) return rc;
         c->fused = true;
     }
+    // k_frozen_scan's verdict tables (generic executor, K > 1): sized here, on the control thread — a process call never
+    // allocates
+    HIPC(c, c->d_frozen.ensure(plan.nodes.size()));
+    HIPC(c, c->d_frozen_ph.ensure(plan.nodes.size() * sizeof(unsigned long long)));
     c->plan = plan;
     c->have_plan = true;
     c->graph.needs_compile = false;

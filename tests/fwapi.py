@@ -555,6 +555,7 @@ def hostonly_lib():
         L.fwh_launch_reset.restype = None
         L.fwh_violation.restype = C.c_char_p
         L.fwh_violation_reset.restype = None
+        L.fwh_alloc_count.restype = C.c_ulonglong
         _hostonly_lib = L
     return _hostonly_lib
 

@@ -36,7 +36,9 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->totalGlobalMem = (size_t)288 << 30;
     return hipSuccess;
 }
+extern "C" unsigned long long fwh_alloc_calls;  /* defined in launch_stubs.cpp: device / pinned allocations so far */
 static inline hipError_t hipMalloc(void** p, size_t n) {
+    fwh_alloc_calls++;
     if (n > ((size_t)1 << 32)) return hipErrorOutOfMemory;  /* the harness never needs more; keeps a bad size from eating the host */
     *p = calloc(n ? n : 1, 1);
     return *p ? hipSuccess : hipErrorOutOfMemory;

@@ -5,6 +5,10 @@
 namespace {
 unsigned long long g_launches[8];  // 0 level, 1 voice_control, 2 leaf_sum, 3 chain, 4 bus_sum, 5 root_out, 6 fir, 7 other
 }
+extern "C" {
+unsigned long long fwh_alloc_calls = 0;  // hipMalloc / hipHostMalloc calls of the fake runtime
+unsigned long long fwh_alloc_count(void) { return fwh_alloc_calls; }
+}
 extern "C" unsigned long long fwh_launch_count(int which) { return which >= 0 && which < 8 ? g_launches[which] : 0; }
 extern "C" void fwh_launch_reset(void) {
     for (auto& x : g_launches) x = 0;

@@ -281,3 +281,40 @@ def test_host_half_fuzz_under_address_and_ub_sanitizers(tmp_path):
     # parameters, far-future at_block, odd frame counts) — error returns only, no crash, no sanitizer report
     r = subprocess.run([sys.executable, os.path.join(d, "api_fuzz.py"), "150"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok 150" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("kw", [{}, {"chain": True}, {"clip_in_voice": True}, {"master": True}])
+def test_process_calls_allocate_no_device_or_pinned_memory_once_warm(kw):
+    # SURVEY 8(b) realtime rules: "no locks/allocs in fwgpu_process_block*" — every device / pinned buffer is sized by
+    # fwgpu_update (control thread) or by the first call of a given size; steady callbacks, message bursts of a size seen
+    # before and K-batched calls allocate nothing (counted in the fake runtime's hipMalloc / hipHostMalloc)
+    e = HostOnlyEngine(max_block_frames=64, max_batch=8)
+    smp = bank(e, **kw)
+    s = e.new_sample(PLANAR_F32, 2, scenarios.voice_source(1, 900))
+    for x in smp:
+        e.sampler_set_sample(x, s)
+        e.sampler_play(x)
+
+    def traffic(at):
+        for x in smp:
+            e.set_param(x, 0, 70.0, at_block=at)
+            e.sampler_pause(x, at_block=at)
+            e.sampler_play(x, at_block=at + 1)
+
+    # warm-up: one call of each shape, with the largest message burst
+    traffic(0)
+    e.process_blocks(1)
+    traffic(2)
+    e.process_blocks(20)
+    e.process_interleaved(64 * 3 + 5)
+    before = hostonly_lib().fwh_alloc_count()
+    for i in range(30):
+        if i % 7 == 3:
+            traffic(i % 5)
+        if i % 3 == 0:
+            e.process_blocks(1)          # a realtime callback
+        elif i % 3 == 1:
+            e.process_blocks(20)         # K-batched: 8 + 8 + 4
+        else:
+            e.process_interleaved(64 * 3 + 5)  # a partial last block
+    assert hostonly_lib().fwh_alloc_count() == before

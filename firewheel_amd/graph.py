@@ -138,6 +138,9 @@ class SamplerNode(_Node):  # nodes/sampler.rs:46-182
             self.cx._check(self.cx.L.fwgpu_sampler_stop(self.cx.c, self.id, at_block))
             self.playing = False
 
+    def is_playing(self):  # sampler.rs:162-164: the control half's own flag, not the processor's
+        return self.playing
+
     def set_playhead(self, playhead_secs, at_block=0):
         self.cx._check(self.cx.L.fwgpu_sampler_set_playhead_secs(self.cx.c, self.id, playhead_secs, at_block))
 

@@ -560,6 +560,19 @@ def hostonly_lib():
     return _hostonly_lib
 
 
+def hostonly_ctx(**kw):
+    """firewheel_amd.FirewheelGpuCtx (the typed host mirror bench.py uses) on the host-only harness library"""
+    import firewheel_amd as fa
+    import firewheel_amd._lib as flib
+
+    saved = flib._lib
+    flib._lib = hostonly_lib()
+    try:
+        return fa.FirewheelGpuCtx(**kw)
+    finally:
+        flib._lib = saved
+
+
 class HostOnlyEngine(GpuEngine):
     """GpuEngine's surface on the host-only harness library (CPU tier; outputs are meaningless, only the host logic runs)."""
 

@@ -1,0 +1,128 @@
+"""CPU tier: the typed Python host mirror (firewheel_amd/graph.py — what bench.py and a Python host use: one class per
+reference node with the reference's control-half behaviour) on the host-only harness.  No audio is computed; this pins
+the mirror's own logic and that every parameter id / message it sends is one the C ABI accepts."""
+import numpy as np
+import pytest
+
+import firewheel_amd as fa
+from firewheel_amd import graph as G
+import fwapi
+
+QUEUE_FULL = -21
+
+
+@pytest.fixture
+def cx():
+    c = fwapi.hostonly_ctx(sample_rate=48000, max_block_frames=64, num_graph_inputs=2, num_graph_outputs=2)
+    yield c
+    c.close()
+
+
+def stereo(cx, a, b, dst_port0=0):
+    cx.connect(a, 0, b, dst_port0)
+    cx.connect(a, 1, b, dst_port0 + 1)
+
+
+def test_every_typed_node_builds_activates_and_takes_its_messages(cx):
+    ir = cx.new_sample(G.SampleFormat.PLANAR_F32, 1, np.ones(32, dtype=np.float32))
+    src = cx.new_sample(G.SampleFormat.PLANAR_F32, 2, np.zeros(2 * 500, dtype=np.float32))
+    smp = G.SamplerNode(80.0)
+    nodes = [  # (node, n_in, n_out) stereo processors chained after the sampler
+        (G.VolumeNode(50.0), 2, 2), (G.StereoPanNode(-0.3), 2, 2), (G.StereoWidthNode(1.2), 2, 2), (G.HardClipNode(-6.0), 2, 2),
+        (G.BiquadNode(0, 1200.0, 0.9), 2, 2), (G.DelayNode(0.01, 0.3, 0.4), 2, 2), (G.FirReverbNode(ir), 2, 2), (G.SpatialNode(1.0, 0.0, -2.0), 2, 2),
+    ]
+    s = cx.add_node(0, 2, smp)
+    prev = s
+    for n, a, b in nodes:
+        i = cx.add_node(a, b, n)
+        stereo(cx, prev, i)
+        prev = i
+    m2s, s2m = G.MonoToStereoNode(), G.StereoToMonoNode()
+    a = cx.add_node(2, 1, s2m)
+    b = cx.add_node(1, 2, m2s)
+    stereo(cx, prev, a)
+    cx.connect(a, 0, b, 0)
+    beep, rs = G.BeepTestNode(440.0, -12.0, True), G.ResamplerNode(src, 1.5, loop=True)
+    mix = cx.add_node(6, 2, G.SumNode())
+    stereo(cx, b, mix, 0)
+    stereo(cx, cx.add_node(0, 2, beep), mix, 2)
+    stereo(cx, cx.add_node(0, 2, rs), mix, 4)
+    stereo(cx, mix, cx.graph_out_node())
+    cx.add_node(1, 1, G.DummyAudioNode())  # dangling
+    cx.update()
+    assert cx.plan_kind() == 0 and cx.plan_num_levels() >= 12
+    # every setter of every class is accepted (parameter ids and message types match fwgpu_ctx.cpp)
+    nodes[0][0].set_percent_volume(30.0)
+    nodes[1][0].set_pan(0.5, at_block=1)
+    nodes[2][0].set_width(0.0)
+    nodes[4][0].set_cutoff_hz(800.0)
+    nodes[4][0].set_q(2.0)
+    nodes[5][0].set_feedback(0.5)
+    nodes[5][0].set_mix(1.0)
+    nodes[7][0].set_position(-1.0, 0.5, 0.0)
+    beep.set_enabled(False)
+    rs.set_ratio(0.75)
+    rs.set_playing(False)
+    rs.seek_frames(100)
+    smp.set_sample(src, False)
+    smp.set_loop_range(G.LoopRange.Full())
+    smp.set_loop_range(G.LoopRange.RangeSecs(0.001, 0.005))
+    smp.set_loop_range(None)
+    smp.set_playhead(0.002)
+    smp.set_percent_volume(-5.0)
+    assert smp.percent_volume == 0.0  # sampler.rs:171-177: stored clamped
+    smp.play()
+    out = cx.process_interleaved(np.zeros(64 * 5 * 2, dtype=np.float32), 2, 2, 64 * 5)
+    assert np.asarray(out).size == 64 * 5 * 2
+    assert cx.node(s) is smp and cx.node(12345) is None
+    cx.remove_node(s)
+    assert cx.node(s) is None
+    with pytest.raises(fa.FwgpuError):
+        smp.play() or smp.pause()  # the node is gone: the ABI reports it (playing was True, so pause() sends)
+
+
+def test_sampler_control_half_only_sends_on_a_state_change(cx):
+    # sampler.rs:82-131: play / pause / stop push a message only when they change `playing`
+    smp = G.SamplerNode(100.0)
+    s = cx.add_node(0, 2, smp)
+    stereo(cx, s, cx.graph_out_node())
+    cx.update()
+    assert not smp.is_playing()
+    smp.pause()
+    smp.stop()          # not playing: nothing sent
+    smp.play()
+    smp.play()
+    smp.play()          # one message
+    assert smp.is_playing()
+    L, c = cx.L, cx.c
+    for _ in range(127):  # the ring (sampler.rs:14, 128 slots) therefore has room for exactly 127 more
+        assert L.fwgpu_sampler_set_playhead_secs(c, s, 0.0, 0) == 0
+    assert L.fwgpu_sampler_set_playhead_secs(c, s, 0.0, 0) == QUEUE_FULL
+    with pytest.raises(fa.FwgpuError):
+        smp.stop()      # ring full: the error surfaces, and the flag keeps its value (sampler.rs:117-127 `?`)
+    assert smp.is_playing()
+    cx.process_interleaved(None, 0, 2, 64)  # drains the ring
+    smp.stop()
+    assert not smp.is_playing()
+
+
+def test_edit_errors_and_compile_errors_are_the_reference_variants(cx):
+    a = cx.add_node(1, 1, G.DummyAudioNode())
+    b = cx.add_node(1, 1, G.DummyAudioNode())
+    e = cx.connect(a, 0, b, 0)
+    with pytest.raises(fa.AddEdgeError) as ei:
+        cx.connect(a, 0, b, 0)
+    assert ei.value.name == "EdgeAlreadyExists"
+    cx.connect(b, 0, a, 0)
+    assert cx.cycle_detected()
+    with pytest.raises(fa.CompileGraphError) as ei:
+        cx.update()
+    assert ei.value.name == "CycleDetected"
+    assert cx.disconnect(b, 0, a, 0) and not cx.disconnect(b, 0, a, 0)
+    assert cx.disconnect_by_edge_id(e) and not cx.disconnect_by_edge_id(e)
+    bad = cx.add_node(2, 3, G.VolumeNode(10.0))
+    with pytest.raises(fa.CompileGraphError) as ei:
+        cx.update()
+    assert ei.value.name == "NodeActivationFailed"
+    cx.remove_node(bad)
+    cx.update()

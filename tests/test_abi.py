@@ -68,3 +68,30 @@ def test_header_is_plain_c99_and_the_c_host_builds(lib):
                            os.path.join(ROOT, "include", "fwgpu.h")])
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples", "host_c")])
     assert os.path.exists(os.path.join(ROOT, "examples", "host_c", "fw_host"))
+
+
+def test_rust_binding_block_of_integration_md_matches_the_header():
+    """INTEGRATION.md shows the `extern "C"` block a Firewheel maintainer would add (no rustc here to compile it): every
+    function it declares must exist in include/fwgpu.h with the same number of parameters and a compatible return type."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    hdr = open(os.path.join(root, "include", "fwgpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    c_decl = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z_0-9 \*]*?)\b(fwgpu_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        c_decl[name] = (ret, 0 if args in ("", "void") else len(args.split(",")))
+    block = md[md.index('extern "C" {'):]
+    block = block[:block.index("\n}")]
+    rust = re.findall(r"pub fn (fwgpu_[a-z_0-9]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S)
+    assert len(rust) >= 25
+    ret_ok = {"c_int": ("int",), "i64": ("int64_t",), "*const c_char": ("const char*", "const char *"),
+              "*mut fwgpu_ctx": ("fwgpu_ctx*", "fwgpu_ctx *"), None: ("void",)}
+    for name, args, ret in rust:
+        assert name in c_decl, "%s is not in fwgpu.h" % name
+        n_args = len([a for a in args.split(",") if a.strip()])
+        assert n_args == c_decl[name][1], (name, n_args, c_decl[name][1])
+        r = ret.strip() if ret else None
+        assert c_decl[name][0] in ret_ok[r], (name, r, c_decl[name][0])

@@ -108,6 +108,29 @@ def worker(rank, world, port, mode, q):
         for step in range(max(0, BLOCKS // 2 - 2), BLOCKS // 2):
             outs.append(red.wait(step % 2).numpy().copy())
         bus = torch.from_numpy(np.concatenate(outs))
+    elif mode.startswith("grouped"):
+        # bench.py's --reduce-every R: each of the two bus buffers holds R consecutive steps and is reduced by ONE collective;
+        # a buffer is waited for only right before its first slice is overwritten; the partly filled last buffer is
+        # submitted at the end.  6 one-block steps: R = 4 -> one full group + a partly filled one (all-reduce variant);
+        # R = 2 -> three groups, the third reuses the first buffer after waiting for it (ordered variant)
+        R, step_elems = (2 if mode.endswith("ordered") else 4), 2 * BLOCK
+        bufs = [torch.zeros(R * step_elems), torch.zeros(R * step_elems)]
+        red = shard.BusReducer(dist, bufs, "ordered" if mode.endswith("ordered") else "allreduce")
+        groups, slot = [], 0
+        for step in range(BLOCKS):
+            b, r = (slot // R) % 2, slot % R
+            if r == 0 and slot // R >= 2:
+                groups.append(red.wait(b).numpy().copy())
+            slot += 1
+            bufs[b][r * step_elems:(r + 1) * step_elems].copy_(torch.from_numpy(e.process_blocks(1)))
+            if r == R - 1:
+                red.submit(b)
+        if slot % R:
+            red.submit((slot // R) % 2)
+        n_groups = (BLOCKS + R - 1) // R
+        for g in range(max(0, n_groups - 2), n_groups):
+            groups.append(red.wait(g % 2).numpy().copy())
+        bus = torch.from_numpy(np.concatenate(groups)[:BLOCKS * step_elems])
     else:
         bus = torch.from_numpy(e.process_blocks(BLOCKS).copy())
         if mode == "allreduce":
@@ -119,7 +142,10 @@ def worker(rank, world, port, mode, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "ordered", "pipelined_allreduce", "pipelined_ordered"])
+MODES = ["allreduce", "ordered", "pipelined_allreduce", "pipelined_ordered", "grouped_allreduce", "grouped_ordered"]
+
+
+@pytest.mark.parametrize("mode", MODES)
 def test_two_rank_sharded_bus_matches_whole_graph(mode):
     from firewheel_amd import shard
 
@@ -127,7 +153,7 @@ def test_two_rank_sharded_bus_matches_whole_graph(mode):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 400) + 400 * ["allreduce", "ordered", "pipelined_allreduce", "pipelined_ordered"].index(mode)
+    port = 29500 + (os.getpid() % 400) + 400 * MODES.index(mode)
     procs = [ctx.Process(target=worker, args=(r, world, port, mode, q)) for r in range(world)]
     for p in procs:
         p.start()

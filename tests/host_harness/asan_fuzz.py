@@ -1,5 +1,5 @@
 """Host-side fuzz of libfwgpu's HOST half under AddressSanitizer + UBSan (CPU tier; tests/test_host_logic.py runs a few
-seeds, `python tests/host_harness/asan_fuzz.py N` run by hand does more — 800 seeds are clean).  The graph / message /
+seeds, `python tests/host_harness/asan_fuzz.py N` run by hand does more — 3000 seeds are clean).  The graph / message /
 edit generators are the GPU fuzz families' own (tests/test_fuzz_gpu.py), driven on the host-only harness: no audio is
 computed, the point is every plan build, group packing, message sort and buffer (re)allocation of fwgpu_ctx.cpp.
 Must be started with LD_PRELOAD=libasan.so:libubsan.so (see run_sanitised)."""

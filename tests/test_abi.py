@@ -95,3 +95,25 @@ def test_rust_binding_block_of_integration_md_matches_the_header():
         assert n_args == c_decl[name][1], (name, n_args, c_decl[name][1])
         r = ret.strip() if ret else None
         assert c_decl[name][0] in ret_ok[r], (name, r, c_decl[name][0])
+
+
+def test_the_product_never_loads_the_oracle_or_the_test_harnesses():
+    """oracle/ and tests/*_harness are test infrastructure: nothing under firewheel_amd/ or include/ may import, link or
+    dlopen them (comments that cite the oracle's arithmetic are fine), and libfwgpu's build recipe names product sources only."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "firewheel_amd")
+    bad = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                continue
+            text = open(os.path.join(d, f), errors="replace").read()
+            code = re.sub(r"//[^\n]*|/\*.*?\*/", "", text, flags=re.S) if not f.endswith(".py") else re.sub(r"#[^\n]*", "", text)
+            if re.search(r"fw_oracle|libfw_oracle|oracle/|fwo_|host_harness|planner_harness|fakehip|fwh_", code):
+                bad.append(os.path.join(d, f))
+    assert not bad, bad
+    mk = open(os.path.join(pkg, "csrc", "Makefile")).read()
+    srcs = re.search(r"^SRCS\s*:=\s*(.*)$", mk, flags=re.M).group(1).split()
+    assert sorted(srcs) == ["fwgpu_ctx.cpp", "fwgpu_graph.cpp", "fwgpu_kernels.hip"]

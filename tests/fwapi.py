@@ -56,7 +56,7 @@ _oracle_lib = None
 def oracle_lib():
     global _oracle_lib
     if _oracle_lib is None:
-        path = os.path.join(ROOT, "oracle", "_build", "libfw_oracle.so")
+        path = os.environ.get("FWO_LIB") or os.path.join(ROOT, "oracle", "_build", "libfw_oracle.so")  # FWO_LIB: a sanitised build
         if not os.path.exists(path):
             build_oracle()
         L = C.CDLL(path)

@@ -59,6 +59,14 @@ SIGNATURES = {
     "fwgpu_sample_create": (ci, [vp, ci, u32, u64, vp]),
     "fwgpu_sample_create_device": (ci, [vp, ci, u32, u64, vp]),
     "fwgpu_sample_destroy": (ci, [vp, ci]),
+    "fwgpu_poll_returned_samples": (ci, [vp, C.POINTER(i64), C.POINTER(ci), ci]),
+    "fwgpu_sample_retired": (ci, [vp, ci]),
+    "fwgpu_ext_pool_floats": (ci, [vp, C.POINTER(u64), C.POINTER(u64)]),
+    "fwgpu_proc_info": (ci, [vp, C.POINTER(f64), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]),
+    "fwgpu_stream_open": (vp, [vp, u32, u32]),
+    "fwgpu_stream_close": (None, [vp]),
+    "fwgpu_stream_callback": (ci, [vp, fp, u64, f64]),
+    "fwgpu_stream_stats": (ci, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(f64)]),
     "fwgpu_node_set_param": (ci, [vp, i64, ci, f32, u32]),
     "fwgpu_sampler_set_sample": (ci, [vp, i64, ci, ci, u32]),
     "fwgpu_sampler_play": (ci, [vp, i64, u32]),

@@ -1,0 +1,301 @@
+// fwgpu_ctx.h — internal to libfwgpu's host half: the context object and what its translation units share.
+//   fwgpu_control_math.cpp  control-half scalar math (what the reference's control thread computes) + initial node state
+//   fwgpu_plan_detect.cpp   launch-plan selection: does the compiled schedule match a fused plan?
+//   fwgpu_plan_install.cpp  node activation + upload of the launch plan's device tables
+//   fwgpu_run.cpp           per-call work: message upload / retirement, kernel sequences of each plan, timing
+//   fwgpu_abi.cpp           the C ABI of include/fwgpu.h
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <map>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "../../include/fwgpu.h"
+#include "fwgpu_graph.h"
+#include "fwgpu_launch.h"
+#include "fwgpu_msgq.h"
+
+namespace fwgpu {
+
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p;
+            cap = o.cap;
+            o.p = nullptr;
+            o.cap = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }  // whatever fwgpu_ctx_destroy's list misses still goes with the ctx
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        const bool regrow = p != nullptr;  // a buffer that grows once tends to grow again (graph edits add a few nodes
+                                           // at a time; a 2 GB pool costs ~250 ms to free + allocate): leave headroom
+        if (p) {
+            hipError_t e = hipFree(p);
+            if (e != hipSuccess) return e;
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes < 256 ? 256 : bytes;
+        hipError_t e = hipErrorOutOfMemory;
+        if (regrow) {
+            const size_t roomy = want + want / 4;
+            e = hipMalloc(&p, roomy);
+            if (e == hipSuccess) cap = roomy;
+            else (void)hipGetLastError();
+        }
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, want);
+            if (e == hipSuccess) cap = want;
+        }
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+struct SampleRec {
+    bool alive = false;
+    bool owned = true;
+    void* d_data = nullptr;
+    SampleDesc desc{};
+};
+
+constexpr size_t RT_IO_BYTES = 256 * 1024;  // realtime path: calls whose interleaved in/out blocks fit (e.g. 16 x 1024 stereo)
+
+// which instantiation of the node kernel runs a kind (mirrors kind_set in k_generic.hip.h)
+inline int host_kind_set(int kind) {
+    if (kind == K_SAMPLER) return 2;
+    return (kind == K_BEEP || kind == K_BIQUAD || kind == K_DELAY || kind == K_RESAMPLER || kind == K_SPATIAL) ? 1 : 0;
+}
+
+struct TimerCat {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+    double acc_ms = 0.0;
+    uint64_t launches = 0;
+};
+
+}  // namespace fwgpu
+
+using namespace fwgpu;  // (internal header: only libfwgpu's own host translation units include it)
+
+struct fwgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t sample_rate = 48000;
+    uint32_t mbf = 256;
+    int stride = 256;
+    uint32_t n_gin = 0, n_gout = 2;
+    // fwgpu_last_error(): fixed buffers, one for the process calls (audio thread) and one for everything else, so that a
+    // failing call never touches the host allocator and the two sides never write the same bytes
+    char err_ctl[256] = {0};
+    char err_audio[256] = {0};
+    std::atomic<int> err_last{0};  // 0 = err_ctl, 1 = err_audio was written last
+
+    HostGraph graph;
+    Plan plan;
+    bool have_plan = false;
+    bool force_generic = false;
+    uint32_t kmax = 64;      // blocks per launch the installed plan's buffers are sized for
+    uint32_t kmax_req = 64;  // fwgpu_set_max_batch: takes effect when the next plan is installed
+
+    // device state
+    DevBuf d_states;
+    size_t states_cap = 0;
+    DevBuf d_ext;  // per-node extended state (floats): biquad coefficients + history, delay rings
+    size_t ext_cap = 0, ext_used = 0;
+    std::vector<SampleRec> samples;
+    DevBuf d_samples;
+    std::vector<SampleDesc> h_sample_tab;  // host copy of d_samples, rebuilt by the calls that change it (control side)
+    bool samples_dirty = true;
+
+    // generic plan
+    DevBuf d_nodes, d_in_buf, d_out_buf, d_level_nodes, d_pool, d_flags, d_gin_bufs, d_gout_bufs;
+    std::vector<int> level_off, level_cnt;
+    std::vector<int> level_kinds;  // bit s: the level holds node kinds of kernel set s (host_kind_set)
+    int n_gout_bufs = 0, n_gin_bufs = 0;
+
+    // fused plan
+    bool fused = false;
+    uint32_t generic_k = 1;  // blocks per generic-executor batch: kmax, capped by what the FIR history rings hold
+    bool fused_fx = false;  // the fused plan's leaves run k_chain (biquad / delay in the voice chains)
+    int chain_nq = 1;       // k_chain tile size / 64 frames
+    int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
+    int n_groups = 0;  // k_chain workgroups (groups of consecutive leaves)
+    DevBuf d_groups;
+    uint32_t epoch = 1;  // invalidates every VoiceCache when bumped (plan install, sample-table change)
+    DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start, d_chain_dummy, d_chain_stats;
+    DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
+    std::vector<int> up_level_off, up_level_cnt;
+    int n_tail = 0;  // master chain after the root SumNode (generic node kernel on the mix bus)
+    std::vector<int> tail_kinds;  // kernel-set bit per master node
+    DevBuf d_tail_nodes, d_tail_in, d_tail_out, d_tail_idx, d_tail_frozen;
+    DevBuf d_frozen_ph;  // ... and its playhead snapshots
+    DevBuf d_frozen;  // generic plan: k_frozen_scan's verdict per plan node, valid for the batch in flight
+    int up_root_node = -1;  // index (in the upper-tree node table) of the root SumNode when it is alone on the last level
+    RootArgs root_args;     // that node's port table, handed to k_root_out in its kernel arguments
+
+    // FIR banks (generic executor): rows grouped by (level, impulse-response channel)
+    struct FirGroup {  // one GEMM launch: every FIR row of a level with the same tap count
+        int level, row_off, n_rows, tile_off;
+        uint32_t T;
+    };
+    std::vector<FirGroup> fir_groups;
+    std::map<std::pair<int, int>, uint32_t> ir_cache;  // (sample id, channel) -> ext offset of h[T] as f32
+    std::map<std::pair<int, int>, uint32_t> ir_len;    // ... and its length in floats (freed with the last FIR user)
+    std::map<size_t, std::vector<uint32_t>> ext_free;  // ext slices of removed nodes, by 64-rounded size (floats)
+    DevBuf d_fir_rows, d_fir_tiles, d_fir_partials;
+
+    // messages.  Setters push into `ring` from any thread; the audio thread drains it at the start of a process call
+    // into `cmds` (sorted by (node, block), arrival order inside a block).  Every buffer on this path has its final
+    // size from fwgpu_ctx_create on: a process call never allocates for messages.
+    static constexpr uint32_t RING_CAP = 1u << 15;  // messages in flight between two process calls
+    static constexpr size_t CMD_CAP = 1u << 16;     // messages waiting for their block (drained, not yet applied)
+    MsgRing ring;
+    std::atomic<uint64_t> drain_epoch{1};  // bumped by every drain: the producers' view of "the ring was emptied"
+    std::vector<Cmd> cmds, cmds_scratch;   // reserve(CMD_CAP) once; never grown
+    DevBuf d_cmds;
+    int n_cmds_dev = 0;
+    Cmd* h_cmds = nullptr;  // pinned staging for the async upload [CMD_CAP]
+    hipEvent_t cmds_copied = nullptr;
+    // ProcessorToNodeMsg::ReturnSample (sampler.rs:339-343): which sample every sampler holds, as the messages retired
+    // so far leave it (audio thread), and the swapped-out ones on their way back to the control side
+    std::vector<int> cur_sample;     // [node slot] -> sample id or -1; sized by install_plan
+    std::vector<int64_t> slot_ids;   // [node slot] -> node id of the activated node
+    RetRing returns;
+    static constexpr uint32_t RET_EVENTS = 64;
+    hipEvent_t ret_events[RET_EVENTS] = {nullptr};
+    uint32_t ret_ticket = 0;         // audio thread: process calls that returned a sample so far
+    bool ret_this_call = false;
+    // control side of the same: reference counts per sample id = SetSample messages sent - samples handed back
+    std::vector<int64_t> sample_refs;
+    std::vector<RetItem> ret_ready;  // completed returns not yet handed to fwgpu_poll_returned_samples
+    std::vector<uint32_t> dropped_samplers;  // removed sampler nodes whose processor "drops" at the next schedule swap
+
+    // staging + B1 scratch
+    DevBuf d_in_stage, d_out_stage, d_scratch_pool, d_scratch_flags, d_scratch_tab, d_mask;
+    DevBuf d_trace;  // FW_CHAIN_TRACE builds only
+
+    // realtime edge (cpal/lib.rs:378-449 — one callback = a few hundred frames): pinned, device-mapped I/O blocks the
+    // kernels read / write directly (no copy-engine hop), and the steady fused launch sequence kept as a hipGraph
+    float *h_rt_in = nullptr, *h_rt_out = nullptr, *d_rt_in = nullptr, *d_rt_out = nullptr;
+    struct RtGraph {
+        hipGraphExec_t exec = nullptr;
+        uint32_t epoch = 0, K = 0;
+        int n_out_ch = 0;
+        const float* d_out = nullptr;
+    } rt_graph;
+    bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2
+    DevBuf d_rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS]
+
+    // ProcInfo of the call in progress (core/node.rs:111-118) + what the backend reported so far (StreamStatus bits)
+    double proc_stream_time = 0.0;
+    uint32_t proc_stream_status = 0;
+    uint64_t n_underflows = 0, n_overflows = 0;
+
+    // timing
+    bool timing = false;
+    TimerCat timers[5];  // 0 fused leaf kernel, 1 control kernel, 2 upper sums + out, 3 generic block, 4 k_fir_gemm alone
+
+    fwgpu_ctx(uint32_t gin, uint32_t gout) : graph(gin, gout) {}
+};
+
+namespace fwgpu {
+
+int fail(fwgpu_ctx* c, int code, const char* msg);  // no allocation: the message is copied into a fixed buffer
+inline int fail(fwgpu_ctx* c, int code, const std::string& msg) { return fail(c, code, msg.c_str()); }
+// process entry points bracket themselves with this: fail() then writes the audio thread's buffer
+struct AudioCallScope {
+    AudioCallScope();
+    ~AudioCallScope();
+};
+int hipfail(fwgpu_ctx* c, hipError_t e, const char* what);
+#define HIPC(c, x)                                        \
+    do {                                                  \
+        hipError_t e__ = (x);                             \
+        if (e__ != hipSuccess) return hipfail(c, e__, #x); \
+    } while (0)
+#define LCHK(c, x)                                                        \
+    do {                                                                  \
+        int e__ = (x);                                                    \
+        if (e__ != 0) return hipfail(c, (hipError_t)e__, "kernel launch " #x); \
+    } while (0)
+
+// ---- fwgpu_control_math.cpp
+float percent_volume_to_raw_gain(float p);
+float db_to_gain_clamped_neg_100_db(float db);
+void pan_to_gains(float pan, float* gl, float* gr);
+Smoother make_smoother(float val, uint32_t sample_rate);
+void biquad_coefs(int type, float cutoff_hz, float q, uint32_t sample_rate, float co[5]);
+void resampler_table(float* h);
+uint64_t resampler_step(float ratio);
+void spatial_params(float x, float y, float z, uint32_t sample_rate, float* gl, float* gr, int* dl, int* dr);
+uint32_t delay_frames(float secs, uint32_t sample_rate);
+NodeState make_state(int kind, const float* params, int n_params, uint32_t sample_rate);
+
+// ---- fwgpu_plan_detect.cpp
+struct FusedBuild {
+    std::vector<VoiceDesc> voices;
+    std::vector<LeafDesc> leaves;
+    std::vector<NodeDesc> up_nodes;
+    std::vector<int> up_in, up_out;
+    std::vector<std::vector<int>> up_levels;  // indices into up_nodes per level
+    int root_buf[2];
+    // master chain: stereo 2->2 nodes between the root SumNode and graph_out (volume, hard clip, pan, width, biquad,
+    // delay), run by the generic node kernel on the mix bus, one launch each, nearest the root first
+    std::vector<NodeDesc> tail_nodes;
+    std::vector<int> tail_in, tail_out;
+    int n_bus = 1;
+    int max_stages = 0;
+    bool has_fx = false;  // some chain holds a biquad / delay: the k_chain plan
+    uint64_t min_delay = ~0ull;  // shortest delay line among the chains (frames)
+};
+bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedBuild& fb);
+
+// ---- fwgpu_plan_install.cpp
+int install_plan(fwgpu_ctx* c, Plan& plan);
+
+// ---- fwgpu_run.cpp
+int upload(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes);
+int upload_sample_table(fwgpu_ctx* c);
+void drain_ring(fwgpu_ctx* c);  // ring -> cmds (consumer side: the audio thread, or an edit call that does not overlap it)
+int upload_cmds(fwgpu_ctx* c);
+void finish_returns(fwgpu_ctx* c);  // end of a process call: completion event for the samples it handed back
+void retire_cmds(fwgpu_ctx* c, uint32_t nblocks);
+void retire_cmds_node(fwgpu_ctx* c, int slot);
+void timer_begin(fwgpu_ctx* c, int cat, hipEvent_t* e0, hipEvent_t* e1);
+void timer_end(fwgpu_ctx* c, hipEvent_t e1);
+void timer_drain(fwgpu_ctx* c);
+DevView generic_view(fwgpu_ctx* c, int frames);
+int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const float* d_in, int n_in_ch, float* d_out,
+                      int n_out_ch);
+int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int n_out_ch);
+int run_blocks(fwgpu_ctx* c, uint64_t frames, const float* d_in, int n_in_ch, float* d_out, int n_out_ch,
+               bool stable_out = false);
+
+}  // namespace fwgpu

@@ -33,7 +33,10 @@ struct HostNode {
     NodeState init;          // initial audio-half state built from the constructor params
     std::vector<int> in_edge;              // per input port: edge slot or -1
     std::vector<std::vector<int>> out_edges;  // per output port: edge slots (one-to-many)
-    int pending_msgs = 0;    // sampler ring occupancy since the last process call (sampler.rs:14)
+    // sampler ring occupancy since the last drain (sampler.rs:14 CHANNEL_CAPACITY).  Control-side only: the audio
+    // thread publishes a drain epoch, the count restarts when the producer sees a new one.
+    int pending_msgs = 0;
+    uint64_t pending_epoch = 0;
 };
 
 inline int64_t make_id(uint32_t slot, uint32_t gen) { return (int64_t(gen) << 32) | int64_t(slot); }

@@ -1,0 +1,240 @@
+// fwgpu_plan_detect.cpp — launch-plan selection: recognise the graph shapes the fused plans render.
+#include "fwgpu_ctx.h"
+
+namespace fwgpu {
+
+// ---------------------------------------------------------------- fused voice-bank plan detection
+
+
+// `graph`: for the delay lengths (k_chain needs D >= one tile); `mbf` must then be a multiple of the tile
+bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedBuild& fb) {
+    const int N = (int)plan.nodes.size();
+    if (N < 3) return false;
+    const PlanNode& gout = plan.nodes.back();
+    if (gout.is_graph_io != 2 || gout.n_in != 2) return false;
+    // consumer counts per (node, port)
+    std::vector<std::vector<int>> cons(N);
+    for (int i = 0; i < N; ++i) cons[i].assign(plan.nodes[i].n_out, 0);
+    for (const PlanNode& n : plan.nodes)
+        for (int p = 0; p < n.n_in; ++p)
+            if (n.in_src_node[p] >= 0) cons[n.in_src_node[p]][n.in_src_port[p]]++;
+    auto stereo_src = [&](const PlanNode& n, int port0, int& src) -> bool {
+        int a = n.in_src_node[port0], b = n.in_src_node[port0 + 1];
+        if (a < 0 || a != b) return false;
+        if (n.in_src_port[port0] != 0 || n.in_src_port[port0 + 1] != 1) return false;
+        if (plan.nodes[a].n_out != 2 || cons[a][0] != 1 || cons[a][1] != 1) return false;
+        src = a;
+        return true;
+    };
+    int root;
+    if (!stereo_src(gout, 0, root)) return false;
+    std::vector<char> covered(N, 0);
+    covered[N - 1] = 1;
+    std::vector<int> tail;  // plan indices, graph_out side first
+    while (plan.nodes[root].kind != K_SUM) {
+        const PlanNode& n = plan.nodes[root];
+        const bool master_kind = n.kind == K_VOLUME || n.kind == K_HARD_CLIP || n.kind == K_PAN || n.kind == K_WIDTH ||
+                                 n.kind == K_BIQUAD || n.kind == K_DELAY;
+        if (!master_kind || n.n_in != 2 || n.n_out != 2 || covered[root] || tail.size() >= 16) return false;
+        covered[root] = 1;
+        tail.push_back(root);
+        int src;
+        if (!stereo_src(n, 0, src)) return false;
+        root = src;
+    }
+    for (int i = 0; i < N; ++i)
+        if (plan.nodes[i].is_graph_io == 1) {
+            covered[i] = 1;
+            for (int cnt : cons[i])
+                if (cnt) return false;  // graph inputs feed the graph: generic executor
+        }
+    // walk the sum tree breadth-first
+    struct SumRec {
+        int node;
+        bool leaf;
+        std::vector<int> kids;  // plan indices (sum nodes) or chain ends
+        int out_buf;
+    };
+    std::vector<SumRec> sums;
+    std::map<int, int> sum_index;
+    std::vector<int> work{root};
+    while (!work.empty()) {
+        int si = work.back();
+        work.pop_back();
+        const PlanNode& s = plan.nodes[si];
+        if (s.kind != K_SUM || s.n_out != 2 || s.n_in < 2 || s.n_in % 2) return false;
+        if (covered[si]) return false;
+        covered[si] = 1;
+        SumRec r;
+        r.node = si;
+        r.out_buf = 0;
+        int n_sum = 0, n_chain = 0;
+        for (int p = 0; p < s.n_in / 2; ++p) {
+            int src;
+            if (s.in_src_node[2 * p] < 0 && s.in_src_node[2 * p + 1] < 0) {
+                // an unconnected stereo port (a voice slot nothing is plugged into): the reference feeds it the cleared,
+                // silent-flagged buffer (schedule.rs:310-313) — a null kid: a null voice under a leaf, bus 0 above
+                r.kids.push_back(-1);
+                continue;
+            }
+            if (!stereo_src(s, 2 * p, src)) return false;
+            r.kids.push_back(src);
+            if (plan.nodes[src].kind == K_SUM) n_sum++;
+            else n_chain++;
+        }
+        if (n_sum && n_chain) return false;
+        r.leaf = n_sum == 0;  // (a SumNode with nothing plugged in at all is a leaf of null voices)
+        if (!r.leaf)
+            for (int k : r.kids)
+                if (k >= 0) work.push_back(k);
+        sum_index[si] = (int)sums.size();
+        sums.push_back(r);
+    }
+    // leaves in plan order (deterministic), chains in port order
+    std::vector<int> leaf_order;
+    for (int i = 0; i < (int)sums.size(); ++i)
+        if (sums[i].leaf) leaf_order.push_back(i);
+    std::sort(leaf_order.begin(), leaf_order.end(), [&](int a, int b) { return sums[a].node < sums[b].node; });
+    int next_bus = 1;
+    for (int li : leaf_order) {
+        SumRec& r = sums[li];
+        LeafDesc ld;
+        ld.first_voice = (int)fb.voices.size();
+        ld.ports = (int)r.kids.size();
+        ld.out_buf = next_bus;
+        ld.pad = 0;
+        r.out_buf = next_bus;
+        next_bus += 2;
+        for (int end : r.kids) {
+            if (end < 0) {  // null voice: k_voice_control emits a constant silent, cleared-source record for it
+                VoiceDesc vd;
+                memset(&vd, 0, sizeof(vd));
+                vd.sampler_state = vd.bq_state = vd.dl_state = -1;
+                fb.voices.push_back(vd);
+                continue;
+            }
+            // walk upstream: end -> ... -> sampler
+            // accepted shape: sampler -> [biquad] -> [delay] -> (volume|pan)*
+            std::vector<int> chain;
+            int cur = end;
+            int bq = -1, dl = -1;
+            for (;;) {
+                const PlanNode& n = plan.nodes[cur];
+                if (covered[cur]) return false;
+                if (n.kind == K_SAMPLER) {
+                    if (n.n_in != 0 || n.n_out != 2) return false;
+                    covered[cur] = 1;
+                    break;
+                }
+                if (n.n_in != 2 || n.n_out != 2) return false;
+                if (n.kind == K_VOLUME || n.kind == K_PAN) {
+                    if (bq >= 0 || dl >= 0) return false;  // gain stages before the filter: generic executor
+                    chain.push_back(cur);
+                } else if (n.kind == K_DELAY) {
+                    if (bq >= 0 || dl >= 0) return false;
+                    if (graph.nodes[n.slot].init.loop_end < 64) return false;  // shorter than one k_chain tile
+                    fb.min_delay = std::min<uint64_t>(fb.min_delay, graph.nodes[n.slot].init.loop_end);
+                    dl = cur;
+                } else if (n.kind == K_BIQUAD) {
+                    if (bq >= 0) return false;
+                    bq = cur;
+                } else {
+                    return false;
+                }
+                covered[cur] = 1;
+                int src;
+                if (!stereo_src(n, 0, src)) return false;
+                cur = src;
+            }
+            if ((int)chain.size() > FW_MAX_STAGES - 1) return false;
+            VoiceDesc vd;
+            memset(&vd, 0, sizeof(vd));
+            vd.bq_state = bq >= 0 ? (int)plan.nodes[bq].slot : -1;
+            vd.dl_state = dl >= 0 ? (int)plan.nodes[dl].slot : -1;
+            if (bq >= 0 || dl >= 0) fb.has_fx = true;
+            vd.sampler_state = (int)plan.nodes[cur].slot;
+            vd.n_stages = (int)chain.size();
+            for (int j = 0; j < vd.n_stages; ++j) {  // schedule order: nearest the sampler first
+                const PlanNode& n = plan.nodes[chain[chain.size() - 1 - j]];
+                vd.stage_kind[j] = n.kind;
+                vd.stage_state[j] = (int)n.slot;
+            }
+            fb.max_stages = std::max(fb.max_stages, vd.n_stages);
+            fb.voices.push_back(vd);
+        }
+        fb.leaves.push_back(ld);
+    }
+    for (int i = 0; i < N; ++i)
+        if (!covered[i]) return false;  // anything else in the graph: generic executor
+    // upper sums: heights above the leaves, children's buses resolved bottom-up
+    std::vector<int> height(sums.size(), -1);
+    std::function<int(int)> h = [&](int i) -> int {
+        if (height[i] >= 0) return height[i];
+        if (sums[i].leaf) return height[i] = 0;
+        int m = 0;
+        for (int k : sums[i].kids)
+            if (k >= 0) m = std::max(m, h(sum_index[k]) + 1);
+        return height[i] = m;
+    };
+    int maxh = 0;
+    for (int i = 0; i < (int)sums.size(); ++i) maxh = std::max(maxh, h(i));
+    fb.up_levels.assign(maxh, std::vector<int>());
+    for (int lv = 1; lv <= maxh; ++lv) {
+        std::vector<int> at;
+        for (int i = 0; i < (int)sums.size(); ++i)
+            if (height[i] == lv) at.push_back(i);
+        std::sort(at.begin(), at.end(), [&](int a, int b) { return sums[a].node < sums[b].node; });
+        for (int i : at) {
+            SumRec& r = sums[i];
+            r.out_buf = next_bus;
+            next_bus += 2;
+            NodeDesc nd;
+            memset(&nd, 0, sizeof(nd));
+            nd.kind = K_SUM;
+            nd.n_in = (int)r.kids.size() * 2;
+            nd.n_out = 2;
+            nd.in_off = (int)fb.up_in.size();
+            nd.out_off = (int)fb.up_out.size();
+            nd.state = 0;
+            nd.aux0 = (int)r.kids.size();
+            for (int k : r.kids) {
+                const int cb = k >= 0 ? sums[sum_index[k]].out_buf : 0;  // unconnected: bus 0, the cleared + silent-flagged buffer
+                fb.up_in.push_back(cb);
+                fb.up_in.push_back(k >= 0 ? cb + 1 : 0);
+            }
+            fb.up_out.push_back(r.out_buf);
+            fb.up_out.push_back(r.out_buf + 1);
+            fb.up_levels[lv - 1].push_back((int)fb.up_nodes.size());
+            fb.up_nodes.push_back(nd);
+        }
+    }
+    int rb = sums[sum_index[root]].out_buf;
+    for (int j = (int)tail.size() - 1; j >= 0; --j) {  // root side first
+        const PlanNode& n = plan.nodes[tail[j]];
+        NodeDesc nd;
+        memset(&nd, 0, sizeof(nd));
+        nd.kind = n.kind;
+        nd.n_in = nd.n_out = 2;
+        nd.in_off = (int)fb.tail_in.size();
+        nd.out_off = (int)fb.tail_out.size();
+        nd.state = (int)n.slot;
+        fb.tail_in.push_back(rb);
+        fb.tail_in.push_back(rb + 1);
+        rb = next_bus;
+        next_bus += 2;
+        fb.tail_out.push_back(rb);
+        fb.tail_out.push_back(rb + 1);
+        fb.tail_nodes.push_back(nd);
+    }
+    fb.root_buf[0] = rb;
+    fb.root_buf[1] = rb + 1;
+    fb.n_bus = next_bus;
+    if (fb.has_fx) {  // k_chain: whole tiles, one workgroup per leaf of <= 32 voices
+        if (mbf % 64 != 0) return false;
+        for (const LeafDesc& l : fb.leaves)
+            if (l.ports > 32) return false;
+    }
+    return !fb.voices.empty();
+}
+
+}  // namespace fwgpu

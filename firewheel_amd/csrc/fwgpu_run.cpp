@@ -1,0 +1,451 @@
+// fwgpu_run.cpp — per-call work of the device-resident FirewheelProcessor (graph/processor.rs:61-165): message upload and
+// retirement, the kernel sequence of each launch plan, HIP-event timing.
+#include "fwgpu_ctx.h"
+
+namespace fwgpu {
+
+namespace {
+thread_local int t_audio_depth = 0;  // > 0 while this thread is inside a process entry point
+void set_error(fwgpu_ctx* c, const char* a, const char* b) {
+    const bool audio = t_audio_depth > 0;
+    char* buf = audio ? c->err_audio : c->err_ctl;
+    const size_t cap = sizeof(c->err_ctl);
+    size_t n = 0;
+    for (; a && *a && n + 1 < cap; ++a) buf[n++] = *a;
+    if (b) {
+        if (n + 2 < cap) {
+            buf[n++] = ':';
+            buf[n++] = ' ';
+        }
+        for (; *b && n + 1 < cap; ++b) buf[n++] = *b;
+    }
+    buf[n] = 0;
+    c->err_last.store(audio ? 1 : 0, std::memory_order_release);
+}
+}  // namespace
+AudioCallScope::AudioCallScope() { ++t_audio_depth; }
+AudioCallScope::~AudioCallScope() { --t_audio_depth; }
+
+int fail(fwgpu_ctx* c, int code, const char* msg) {
+    set_error(c, msg, nullptr);
+    return code;
+}
+int hipfail(fwgpu_ctx* c, hipError_t e, const char* what) {
+    set_error(c, what, hipGetErrorString(e));
+    return FWGPU_ERR_DEVICE;
+}
+
+int upload(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    HIPC(c, b.ensure(bytes));
+    if (bytes) HIPC(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// The host copy of the table (h_sample_tab) and the room for it on the device are kept up to date by the calls that
+// change it (fwgpu_sample_create / _destroy: control calls); the process call that follows only copies.
+int upload_sample_table(fwgpu_ctx* c) {
+    if (!c->samples_dirty) return 0;
+    c->samples_dirty = false;
+    c->epoch++;  // cached steady descriptors hold sample indices / sizes
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const size_t bytes = c->h_sample_tab.size() * sizeof(SampleDesc);
+    HIPC(c, c->d_samples.ensure(bytes));  // (already large enough: sized where the table changed)
+    HIPC(c, hipMemcpy(c->d_samples.p, c->h_sample_tab.data(), bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ---------------------------------------------------------------- messages
+namespace {
+inline bool cmd_less(const Cmd& a, const Cmd& b) { return a.state != b.state ? a.state < b.state : a.block < b.block; }
+// stable bottom-up merge sort of a[0, n) through `tmp` (same capacity): no allocation, arrival order kept inside (node, block)
+void merge_sort_cmds(Cmd* a, size_t n, Cmd* tmp) {
+    if (n < 2) return;
+    for (size_t lo = 0; lo < n; lo += 8) {  // insertion-sorted runs of 8
+        const size_t hi = std::min(lo + 8, n);
+        for (size_t i = lo + 1; i < hi; ++i) {
+            Cmd k = a[i];
+            size_t j = i;
+            for (; j > lo && cmd_less(k, a[j - 1]); --j) a[j] = a[j - 1];
+            a[j] = k;
+        }
+    }
+    Cmd *src = a, *dst = tmp;
+    for (size_t w = 8; w < n; w *= 2) {
+        for (size_t lo = 0; lo < n; lo += 2 * w) {
+            const size_t mid = std::min(lo + w, n), hi = std::min(lo + 2 * w, n);
+            std::merge(src + lo, src + mid, src + mid, src + hi, dst + lo, cmd_less);  // stable: ties from the left run
+        }
+        std::swap(src, dst);
+    }
+    if (src != a) memcpy(a, src, n * sizeof(Cmd));
+}
+}  // namespace
+
+// ring -> cmds.  `cmds` stays sorted by (node, block) with arrival order inside: what was kept from earlier calls is
+// sorted already (retire_cmds shifts every block by the same amount), the new messages are sorted among themselves and
+// merged in behind the older ones.
+void drain_ring(fwgpu_ctx* c) {
+    const size_t n0 = c->cmds.size();
+    Cmd m;
+    while (c->cmds.size() < fwgpu_ctx::CMD_CAP && c->ring.pop(m)) c->cmds.push_back(m);  // (capacity reserved: no growth)
+    c->drain_epoch.fetch_add(1, std::memory_order_release);
+    const size_t n = c->cmds.size();
+    if (n == n0) return;
+    c->cmds_scratch.resize(n);  // within the reserved capacity
+    merge_sort_cmds(c->cmds.data() + n0, n - n0, c->cmds_scratch.data());
+    if (n0) {
+        std::merge(c->cmds.begin(), c->cmds.begin() + n0, c->cmds.begin() + n0, c->cmds.end(), c->cmds_scratch.begin(), cmd_less);
+        memcpy(c->cmds.data(), c->cmds_scratch.data(), n * sizeof(Cmd));
+    }
+}
+
+int upload_cmds(fwgpu_ctx* c) {
+    drain_ring(c);
+    c->n_cmds_dev = (int)c->cmds.size();
+    if (c->n_cmds_dev == 0) return 0;
+    size_t bytes = c->cmds.size() * sizeof(Cmd);
+    HIPC(c, hipEventSynchronize(c->cmds_copied));  // the previous upload has left the pinned buffer
+    memcpy(c->h_cmds, c->cmds.data(), bytes);
+    HIPC(c, hipMemcpyAsync(c->d_cmds.p, c->h_cmds, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipEventRecord(c->cmds_copied, c->stream));
+    return 0;
+}
+// A SetSample message has been applied by the work enqueued so far: the sampler let go of the sample it held
+// (sampler.rs:339-343 ReturnSample).  The host knows which one without asking the device — only SetSample changes it.
+static void note_set_sample(fwgpu_ctx* c, const Cmd& m) {
+    if (m.type != CMD_SMP_SET_SAMPLE || m.state < 0 || (size_t)m.state >= c->cur_sample.size()) return;
+    const int old = c->cur_sample[m.state];
+    c->cur_sample[m.state] = m.i0;
+    if (old < 0) return;
+    RetItem it;
+    it.node = c->slot_ids[m.state];
+    it.sample = old;
+    it.ticket = c->ret_ticket;
+    if (c->returns.push(it)) c->ret_this_call = true;  // (a full ring drops the notice like the reference's `let _ = push`)
+}
+void finish_returns(fwgpu_ctx* c) {
+    if (!c->ret_this_call) return;
+    c->ret_this_call = false;
+    (void)hipEventRecord(c->ret_events[c->ret_ticket % fwgpu_ctx::RET_EVENTS], c->stream);
+    c->ret_ticket++;
+}
+void retire_cmds(fwgpu_ctx* c, uint32_t nblocks) {
+    size_t w = 0;  // in place: nothing is allocated on the process path
+    for (const Cmd& m : c->cmds)
+        if (m.block >= nblocks) {
+            Cmd k = m;
+            k.block -= nblocks;
+            c->cmds[w++] = k;
+        } else {
+            note_set_sample(c, m);
+        }
+    c->cmds.resize(w);
+    finish_returns(c);
+}
+// B1 (fwgpu_node_process): ONE node consumed one block.  Only its own queue moves — the reference keeps a ring / an
+// atomic per node (sampler.rs:205-208, volume.rs:10), so a message for node B must survive node A's process().
+void retire_cmds_node(fwgpu_ctx* c, int slot) {
+    size_t w = 0;
+    for (const Cmd& m : c->cmds) {
+        if (m.state == slot) {
+            if (m.block == 0) {  // applied by this call
+                note_set_sample(c, m);
+                continue;
+            }
+            Cmd k = m;
+            k.block -= 1;
+            c->cmds[w++] = k;
+        } else {
+            c->cmds[w++] = m;
+        }
+    }
+    c->cmds.resize(w);
+    finish_returns(c);
+}
+
+// ---------------------------------------------------------------- timing helpers
+void timer_begin(fwgpu_ctx* c, int cat, hipEvent_t* e0, hipEvent_t* e1) {
+    *e0 = *e1 = nullptr;
+    if (!c->timing) return;
+    TimerCat& t = c->timers[cat];
+    if (t.used == t.ev.size()) {
+        if (t.ev.size() >= 8192) return;  // drained by timing_read
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        t.ev.emplace_back(a, b);
+    }
+    *e0 = t.ev[t.used].first;
+    *e1 = t.ev[t.used].second;
+    t.used++;
+    t.launches++;
+    (void)hipEventRecord(*e0, c->stream);
+}
+void timer_end(fwgpu_ctx* c, hipEvent_t e1) {
+    if (e1) (void)hipEventRecord(e1, c->stream);
+}
+void timer_drain(fwgpu_ctx* c) {
+    (void)hipStreamSynchronize(c->stream);
+    for (TimerCat& t : c->timers) {
+        for (size_t i = 0; i < t.used; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, t.ev[i].first, t.ev[i].second) == hipSuccess) t.acc_ms += ms;
+        }
+        t.used = 0;
+    }
+}
+
+// ---------------------------------------------------------------- executors
+DevView generic_view(fwgpu_ctx* c, int frames) {
+    DevView v;
+    v.nodes = c->d_nodes.as<NodeDesc>();
+    v.in_buf = c->d_in_buf.as<int>();
+    v.out_buf = c->d_out_buf.as<int>();
+    v.states = c->d_states.as<NodeState>();
+    v.samples = c->d_samples.as<SampleDesc>();
+    v.ext = c->d_ext.as<float>();
+    v.rs_table = c->d_rs_table.as<float>();
+    v.pool = c->d_pool.as<float>();
+    v.flags = c->d_flags.as<uint8_t>();
+    v.pool_blk_stride = (size_t)c->plan.num_buffers * c->stride;  // one pool slice per block of a K-batch
+    v.flags_blk_stride = (size_t)c->plan.num_buffers;
+    v.stride = c->stride;
+    v.frames = frames;
+    v.cmds = c->d_cmds.as<Cmd>();
+    v.n_cmds = c->n_cmds_dev;
+    v.frozen = nullptr;
+    v.frozen_playhead = nullptr;
+    return v;
+}
+
+// K blocks of `frames` frames through the level-batched executor (schedule.rs:289-344 as one launch per level for
+// all K blocks: each block has its own pool slice, a stateful node walks its K blocks in order inside one wave)
+int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const float* d_in, int n_in_ch, float* d_out,
+                      int n_out_ch) {
+    DevView v = generic_view(c, frames);
+    // which gain-like stateful nodes cannot change during this batch (their blocks then run in parallel): decided once,
+    // before the first level
+    if (K > 1 && c->d_frozen.ensure((size_t)c->plan.nodes.size()) == hipSuccess &&
+        c->d_frozen_ph.ensure((size_t)c->plan.nodes.size() * sizeof(unsigned long long)) == hipSuccess) {
+        LCHK(c, launch_frozen_scan(c->stream, v, (int)c->plan.nodes.size(), cmd_block, K, c->d_frozen.as<uint8_t>(),
+                                   c->d_frozen_ph.as<unsigned long long>()));
+        v.frozen = c->d_frozen.as<uint8_t>();
+        v.frozen_playhead = c->d_frozen_ph.as<unsigned long long>();
+    }
+    if (c->n_gin_bufs > 0)
+        LCHK(c, launch_graph_in(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride,
+                                c->d_gin_bufs.as<int>(), c->n_gin_bufs, d_in, d_in ? n_in_ch : 0, frames, K));
+    c->epoch++;  // node state moves outside the fused control kernel: cached steady descriptors are stale
+    hipEvent_t e0, e1;
+    timer_begin(c, 3, &e0, &e1);
+    for (size_t l = 0; l < c->level_cnt.size(); ++l) {
+        LCHK(c, launch_level(c->stream, v, c->d_level_nodes.as<int>() + c->level_off[l], c->level_cnt[l], K, cmd_block,
+                             c->level_kinds[l]));
+        for (const fwgpu_ctx::FirGroup& g : c->fir_groups)
+            if (g.level == (int)l) {
+                hipEvent_t g0 = nullptr, g1 = nullptr;
+                if (c->timing) {  // the GEMM alone, on its own event pair (no record of its own: launch_fir does it)
+                    TimerCat& t = c->timers[4];
+                    if (t.used == t.ev.size() && t.ev.size() < 8192) {
+                        hipEvent_t a, b;
+                        if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) t.ev.emplace_back(a, b);
+                    }
+                    if (t.used < t.ev.size()) {
+                        g0 = t.ev[t.used].first;
+                        g1 = t.ev[t.used].second;
+                        t.used++;
+                        t.launches++;
+                    }
+                }
+                LCHK(c, launch_fir(c->stream, v, c->d_fir_rows.as<FirRow>() + g.row_off, g.n_rows,
+                                   c->d_fir_tiles.as<uint32_t>() + g.tile_off, g.T, c->d_fir_partials.as<float>(),
+                                   c->d_fir_partials.cap / sizeof(float), K, g0, g1));
+            }
+    }
+    timer_end(c, e1);
+    LCHK(c, launch_graph_out(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride,
+                             c->d_gout_bufs.as<int>(), c->n_gout_bufs, d_out, n_out_ch, frames, K));
+    return 0;
+}
+
+// K full blocks through the fused voice-bank plan
+int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int n_out_ch) {
+    FusedView fv;
+    fv.voices = c->d_voices.as<VoiceDesc>();
+    fv.leaves = c->d_leaves.as<LeafDesc>();
+    fv.states = c->d_states.as<NodeState>();
+    fv.samples = c->d_samples.as<SampleDesc>();
+    fv.blks = c->d_blks.as<VoiceBlk>();
+    fv.refs = c->d_refs.as<VoiceRef>();
+    fv.refs_stride = (int)c->kmax;
+    fv.gsets = c->d_gsets.as<GainSet>();
+    fv.cache = c->d_cache.as<VoiceCache>();
+    fv.epoch = c->epoch;
+    fv.n_gain_stages = c->ramp_slots / 2;
+    fv.ramps = c->d_ramps.as<float>();
+    fv.ramp_slots = c->ramp_slots;
+    fv.bus = c->d_bus.as<float>();
+    fv.bus_flags = c->d_bus_flags.as<uint8_t>();
+    fv.bus_blk_stride = (size_t)c->n_bus * c->stride;
+    fv.bus_flags_blk_stride = (size_t)c->n_bus;
+    fv.cmds = c->d_cmds.as<Cmd>();
+    fv.n_cmds = c->n_cmds_dev;
+    fv.n_voices = c->n_voices;
+    fv.n_leaves = c->n_leaves;
+    fv.stride = c->stride;
+    fv.frames = (int)c->mbf;
+    fv.fx_plan = c->fused_fx ? 1 : 0;
+    fv.groups = c->d_groups.as<ChainGroup>();
+    fv.n_groups = c->n_groups;
+    fv.ext = c->d_ext.as<float>();
+    fv.chain_start = c->d_chain_start.as<ChainStart>();
+    fv.chain_dummy = c->d_chain_dummy.as<float>();
+    fv.chain_stats = c->d_chain_stats.as<unsigned long long>();
+    fv.trace = nullptr;
+#ifdef FW_CHAIN_TRACE
+    if (c->d_trace.ensure(64 * 16 * 8 * sizeof(unsigned long long)) == hipSuccess) fv.trace = c->d_trace.as<unsigned long long>();
+#endif
+    {
+        static const int dbg = getenv("FWGPU_CHAIN_SKIP") ? atoi(getenv("FWGPU_CHAIN_SKIP")) : 0;
+        fv.dbg = dbg;
+    }
+    hipEvent_t e0, e1;
+    timer_begin(c, 1, &e0, &e1);
+    LCHK(c, launch_voice_control(c->stream, fv, K, cmd_block0));
+    timer_end(c, e1);
+    timer_begin(c, 0, &e0, &e1);
+    if (c->fused_fx) LCHK(c, launch_chain(c->stream, fv, K, cmd_block0, c->chain_nq));
+    else LCHK(c, launch_leaf_sum(c->stream, fv, K));
+    timer_end(c, e1);
+    timer_begin(c, 2, &e0, &e1);
+    if (!c->up_level_cnt.empty()) {
+        DevView v;
+        v.nodes = c->d_up_nodes.as<NodeDesc>();
+        v.in_buf = c->d_up_in.as<int>();
+        v.out_buf = c->d_up_out.as<int>();
+        v.states = c->d_states.as<NodeState>();
+        v.samples = c->d_samples.as<SampleDesc>();
+        v.ext = c->d_ext.as<float>();
+        v.rs_table = c->d_rs_table.as<float>();
+        v.pool = fv.bus;
+        v.flags = fv.bus_flags;
+        v.pool_blk_stride = fv.bus_blk_stride;
+        v.flags_blk_stride = fv.bus_flags_blk_stride;
+        v.stride = c->stride;
+        v.frames = (int)c->mbf;
+        v.cmds = nullptr;
+        v.n_cmds = 0;
+        v.frozen = nullptr;
+        v.frozen_playhead = nullptr;
+        // the root SumNode is fused with read_graph_outputs + interleave_stereo when the stream is stereo
+        const bool fuse_root = c->up_root_node >= 0 && n_out_ch == 2;
+        const size_t n_levels = c->up_level_cnt.size() - (fuse_root ? 1 : 0);
+        for (size_t l = 0; l < n_levels; ++l)
+            LCHK(c, launch_bus_sum(c->stream, v, c->d_up_level_nodes.as<int>() + c->up_level_off[l], c->up_level_cnt[l], K, 2));
+        if (fuse_root) {
+            LCHK(c, launch_root_out(c->stream, v, c->root_args, d_out, K));
+            timer_end(c, e1);
+            return 0;
+        }
+    }
+    if (c->n_tail) {  // master chain on the mix bus: the generic node kernel, K-batched, one launch per node
+        DevView v;
+        v.nodes = c->d_tail_nodes.as<NodeDesc>();
+        v.in_buf = c->d_tail_in.as<int>();
+        v.out_buf = c->d_tail_out.as<int>();
+        v.states = c->d_states.as<NodeState>();
+        v.samples = c->d_samples.as<SampleDesc>();
+        v.ext = c->d_ext.as<float>();
+        v.rs_table = c->d_rs_table.as<float>();
+        v.pool = fv.bus;
+        v.flags = fv.bus_flags;
+        v.pool_blk_stride = fv.bus_blk_stride;
+        v.flags_blk_stride = fv.bus_flags_blk_stride;
+        v.stride = c->stride;
+        v.frames = (int)c->mbf;
+        v.cmds = fv.cmds;
+        v.n_cmds = fv.n_cmds;
+        v.frozen = nullptr;
+        v.frozen_playhead = nullptr;  // (no sampler can sit in a master chain)
+        if (K > 1) {
+            LCHK(c, launch_frozen_scan(c->stream, v, c->n_tail, cmd_block0, K, c->d_tail_frozen.as<uint8_t>(),
+                                       c->d_tail_frozen.as<unsigned long long>()));
+            v.frozen = c->d_tail_frozen.as<uint8_t>();
+        }
+        for (int j = 0; j < c->n_tail; ++j)
+            LCHK(c, launch_level(c->stream, v, c->d_tail_idx.as<int>() + j, 1, K, cmd_block0, c->tail_kinds[j]));
+    }
+    LCHK(c, launch_graph_out(c->stream, fv.bus, fv.bus_flags, c->stride, fv.bus_blk_stride, fv.bus_flags_blk_stride,
+                             c->d_root_bufs.as<int>(), 2, d_out, n_out_ch, (int)c->mbf, K));
+    timer_end(c, e1);
+    return 0;
+}
+
+// all blocks of one call; d_in may be null.  frames may end in a partial block.
+int run_blocks(fwgpu_ctx* c, uint64_t frames, const float* d_in, int n_in_ch, float* d_out, int n_out_ch,
+               bool stable_out) {
+    const uint32_t mbf = c->mbf;
+    const uint32_t nblocks = (uint32_t)((frames + mbf - 1) / mbf);
+    int rc = upload_sample_table(c);
+    if (rc) return rc;
+    rc = upload_cmds(c);
+    if (rc) return rc;
+    uint64_t done = 0;
+    uint32_t blk = 0;
+    const bool can_fuse = c->fused && !c->force_generic;
+    // steady realtime call: no message on the device, one fused batch, the same output block as last time — every
+    // kernel argument repeats (block counters and playheads live in device state), so the launch sequence is replayed
+    // from a hipGraph instead of being re-issued kernel by kernel
+    if (stable_out && c->rt_use_graph && can_fuse && !c->timing && c->n_cmds_dev == 0 && frames % mbf == 0 &&
+        frames / mbf <= (c->fused_fx ? std::min<uint32_t>(c->kmax, CH_FAST_KMAX) : c->kmax)) {
+        const uint32_t K = (uint32_t)(frames / mbf);
+        fwgpu_ctx::RtGraph& g = c->rt_graph;
+        if (!g.exec || g.epoch != c->epoch || g.K != K || g.d_out != d_out || g.n_out_ch != n_out_ch) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            g.exec = nullptr;
+            HIPC(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            rc = run_fused_batch(c, (int)K, 0, d_out, n_out_ch);
+            hipGraph_t graph = nullptr;
+            hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+            if (rc || ce != hipSuccess) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc ? rc : hipfail(c, ce, "hipStreamEndCapture");
+            }
+            ce = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ce != hipSuccess) {
+                g.exec = nullptr;
+                return hipfail(c, ce, "hipGraphInstantiate");
+            }
+            g.epoch = c->epoch;
+            g.K = K;
+            g.d_out = d_out;
+            g.n_out_ch = n_out_ch;
+        }
+        HIPC(c, hipGraphLaunch(g.exec, c->stream));
+        retire_cmds(c, nblocks);
+        return 0;
+    }
+    while (done < frames) {
+        uint64_t left = frames - done;
+        if (can_fuse && left >= mbf) {
+            const uint32_t kcap = c->fused_fx ? std::min<uint32_t>(c->kmax, CH_FAST_KMAX) : c->kmax;
+            uint32_t K = (uint32_t)std::min<uint64_t>(left / mbf, kcap);
+            rc = run_fused_batch(c, (int)K, blk, d_out + done * n_out_ch, n_out_ch);
+            if (rc) return rc;
+            done += (uint64_t)K * mbf;
+            blk += K;
+            continue;
+        }
+        // generic executor: whole blocks in batches of generic_k, a trailing partial block on its own
+        int bf = (int)std::min<uint64_t>(left, mbf);
+        int K = bf == (int)mbf ? (int)std::min<uint64_t>(left / mbf, c->generic_k) : 1;
+        rc = run_generic_batch(c, K, bf, blk, d_in ? d_in + done * n_in_ch : nullptr, n_in_ch, d_out + done * n_out_ch, n_out_ch);
+        if (rc) return rc;
+        done += (uint64_t)K * bf;
+        blk += K;
+    }
+    retire_cmds(c, nblocks);
+    return 0;
+}
+
+}  // namespace fwgpu

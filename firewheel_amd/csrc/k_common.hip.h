@@ -201,6 +201,18 @@ __device__ __forceinline__ bool sampler_advance(NodeState& s, uint64_t len, uint
     f.n1 = frames;
     f.wrap = f.tail_zero = 0;
     if (s.has_loop) {
+        // Outside the parity domain the reference dies deterministically: an empty / inverted range
+        // underflows `end - playhead` (:457), a fill_buffers range past the sample is a slice panic (:465, :478).
+        // Nothing may abort across the ABI and nothing may read HBM past the sample (the range comes unclamped from
+        // SetLoopRange(RangeSecs) / SetSample), so such a block plays silence and leaves the playhead where it was.
+        if (s.loop_start >= s.loop_end) return false;
+        {
+            const uint64_t ph = s.playhead >= s.loop_end ? s.loop_start : s.playhead;
+            const uint64_t l = s.loop_end - ph;
+            const uint64_t n1 = l < (uint64_t)frames ? l : (uint64_t)frames;
+            if (ph > len || n1 > len - ph) return false;  // (no u64 overflow: RangeSecs saturates at 2^64-1)
+            if (n1 < (uint64_t)frames && (s.loop_start > len || (uint64_t)frames - n1 > len - s.loop_start)) return false;
+        }
         if (s.playhead >= s.loop_end) s.playhead = s.loop_start;  // :446-453
         uint64_t left = s.loop_end - s.playhead;                  // :457-462
         uint32_t first = left < (uint64_t)frames ? (uint32_t)left : frames;

@@ -211,7 +211,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
                 if (s.has_loop) {
                     const uint64_t L = s.loop_end - s.loop_start;
                     const uint64_t off = s.playhead >= s.loop_end ? 0 : s.playhead - s.loop_start;
-                    s.playhead = s.loop_start + (off + adv) % L;
+                    if (L) s.playhead = s.loop_start + (off + adv) % L;  // (k_frozen_scan admits real loops only)
                 } else {
                     s.playhead += adv;
                 }
@@ -557,7 +557,10 @@ __global__ void k_frozen_scan(DevView v, int n_nodes, uint32_t cmd_block0, uint3
                         if (s.s0.status == SM_INACTIVE && s.s0.input < 0.00001f) {
                             fz = true;  // muted: cleared, the playhead does not move (:437-443)
                         } else if (s.has_loop) {
-                            adv = fz = s.loop_end - s.loop_start >= (uint64_t)v.frames && s.playhead >= s.loop_start;
+                            // (a range that is empty, inverted or reaches past the sample plays silence block by block:
+                            // sampler_advance — keep it off the closed form, whose `% L` needs a real loop)
+                            adv = fz = s.loop_end > s.loop_start && s.loop_end - s.loop_start >= (uint64_t)v.frames &&
+                                       s.playhead >= s.loop_start && s.loop_end <= v.samples[s.sample].frames;
                         } else {  // one-shot that does not end inside the batch
                             adv = fz = s.playhead + (uint64_t)K * (uint64_t)v.frames <= v.samples[s.sample].frames;
                         }

@@ -8,7 +8,18 @@
  * Conventions (replacing Rust's Result/panic, SURVEY §8b "error convention"):
  *   - functions return int: 0 = ok, negative = error; handles are int64 (>= 0) or negative error.
  *   - nothing throws or aborts across the ABI; fwgpu_last_error() returns the message.
- *   - one caller thread per ctx (the audio thread); edit + process calls are not re-entrant.
+ *   - threading: a ctx has an AUDIO side — fwgpu_process_interleaved / _process_blocks_device /
+ *     _node_process / _stream_callback, one thread at a time — and a CONTROL side, everything else.  The control ->
+ *     audio MESSAGE calls (fwgpu_node_set_param, fwgpu_sampler_*) may run on any thread WHILE a process call is in
+ *     flight: they validate against the graph and push into a lock-free ring the audio side drains at the start of
+ *     its next call (the reference's Arc<AtomicF32> gains and rtrb rings: nodes/volume.rs:10,28-34,
+ *     nodes/sampler.rs:14,171-177,205-208); neither side locks, allocates or waits for the other.  Calls that change
+ *     the graph, the schedule or the sample table (add/remove/connect/update/schedule_upload/sample_create/
+ *     sample_destroy/set_max_batch) must not overlap a process call — the reference hands a new schedule over through
+ *     a ring; here the host serialises the two.
+ *   - once warm, a process call touches neither the host allocator nor the device allocator; a failing call writes its
+ *     message into a fixed buffer.  fwgpu_process_interleaved fills `output` on EVERY return (zeros on error:
+ *     core/node.rs:41-42).
  *   - the library fails loudly (ctx_create returns NULL) when no HIP device / kernel image is usable;
  *     there is no CPU fallback anywhere behind this ABI.
  */
@@ -129,6 +140,9 @@ int fwgpu_plan_chain_stats(fwgpu_ctx* ctx, uint64_t* steady_workgroups, uint64_t
 int fwgpu_set_max_batch(fwgpu_ctx* ctx, uint32_t max_blocks);
 /* force the generic executor even when the fused plan matches (parity tests) */
 int fwgpu_set_force_generic(fwgpu_ctx* ctx, int on);
+/* floats of the per-node extended state pool (delay rings, FIR history, filter state) handed out / allocated: removing
+ * a node returns its slice for reuse, so a host that spawns and retires effect voices sees `in_use` level off */
+int fwgpu_ext_pool_floats(fwgpu_ctx* ctx, uint64_t* in_use, uint64_t* capacity);
 
 /* ---- sample resources: SampleResource (core/sample_resource.rs:4-26), uploaded once, HBM-resident.
  * Returns a sample id >= 0. */
@@ -143,6 +157,16 @@ int fwgpu_sample_create_device(fwgpu_ctx* ctx, int format, uint32_t channels, ui
  * (0-frame) sample from the next process call on — silence, never a stale pointer; FIR / resampler nodes name their
  * sample at construction, so the call is refused (FWGPU_ERR_INVALID) while such a node exists. */
 int fwgpu_sample_destroy(fwgpu_ctx* ctx, int sample);
+/* ProcessorToNodeMsg::ReturnSample (nodes/sampler.rs:339-343,563-571): when a SetSample message replaces the sample a
+ * sampler holds — or a sampler node is removed and its processor dropped — the processor hands the old one back to the
+ * node, which is when the host may let go of it.  Here: every sample that a process call COMPLETED on the device has
+ * swapped out since the last poll, oldest first, as (node id, sample id) pairs.  Control side, never blocks (it asks
+ * the completion events, it does not wait for them).  Returns the number of pairs written (<= cap). */
+int fwgpu_poll_returned_samples(fwgpu_ctx* ctx, int64_t* nodes, int* samples, int cap);
+/* 1 when no sampler holds `sample`, no queued SetSample message names it, every process call that read it has completed
+ * on the device and no FIR / resampler node was built on it — i.e. fwgpu_sample_destroy is safe and changes no sound;
+ * 0 otherwise.  (The reference gets this from Arc's count reaching zero after the ReturnSample above.) */
+int fwgpu_sample_retired(fwgpu_ctx* ctx, int sample);
 
 /* ---- control -> audio messages.  `at_block` = index of the max_block_frames-sized block, counted from
  * the start of the NEXT process call, before which the message is seen (the reference's rings/atomics
@@ -175,6 +199,24 @@ int fwgpu_process_interleaved(fwgpu_ctx* ctx, const float* input, float* output,
 int fwgpu_process_blocks_device(fwgpu_ctx* ctx, uint32_t num_blocks, float* d_output,
                                 uint32_t num_out_channels);
 int fwgpu_synchronize(fwgpu_ctx* ctx);
+/* ProcInfo::stream_time_secs / stream_status (core/node.rs:111-132) of the most recent fwgpu_process_interleaved call —
+ * what a custom node run through fwgpu_node_process inside that call would be handed — and how often the backend has
+ * reported StreamStatus::OUTPUT_UNDERFLOW (bit 1) / INPUT_OVERFLOW (bit 0) so far.  Any pointer may be NULL. */
+int fwgpu_proc_info(fwgpu_ctx* ctx, double* stream_time_secs, uint32_t* stream_status, uint64_t* output_underflows,
+                    uint64_t* input_overflows);
+
+/* ---- headless stream: the reference's audio-backend callback without a device (firewheel-cpal/src/lib.rs:378-449
+ * DataCallback::callback; its non-cpal "dummy backend" is todo!() at lib.rs:150,168,222).  The caller plays the backend:
+ * it calls fwgpu_stream_callback once per device period with the instant of that callback on ITS clock (cpal's
+ * info.timestamp().callback).  The stream-time and underflow bookkeeping is the reference's, line for line: the first
+ * callback's instant is ignored (stream time 0), the second one anchors the clock, and from then on a callback that
+ * arrives later than the previous one's stream time + 1.2 periods is an OUTPUT_UNDERFLOW, passed on as stream_status. */
+typedef struct fwgpu_stream fwgpu_stream;
+fwgpu_stream* fwgpu_stream_open(fwgpu_ctx* ctx, uint32_t num_in_channels, uint32_t num_out_channels);
+void fwgpu_stream_close(fwgpu_stream* s);
+/* returns the StreamStatus bits handed to process_interleaved (>= 0) or a negative error; `output` is always filled */
+int fwgpu_stream_callback(fwgpu_stream* s, float* output, uint64_t frames, double callback_instant_secs);
+int fwgpu_stream_stats(fwgpu_stream* s, uint64_t* callbacks, uint64_t* underflows, double* last_stream_time_secs);
 
 /* AudioNodeProcessor::process (core/node.rs:37-53) for ONE activated node on caller (host) buffers —
  * the literal per-node drop-in for graph/processor.rs:243.  inputs/outputs: arrays of `frames` floats.

@@ -2,7 +2,7 @@
 
 Build a tracing variant of the library and run config 3 on it:
     cd firewheel_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DFW_CHAIN_TRACE \
-        -shared -o libfwgpu_trace.so -x hip fwgpu_kernels.hip fwgpu_graph.cpp fwgpu_ctx.cpp
+        -shared -o libfwgpu_trace.so -x hip fwgpu_kernels.hip fwgpu_*.cpp
     FWGPU_LIB=firewheel_amd/csrc/libfwgpu_trace.so python scripts/chain_trace.py
 Prints, for steps 8..23 of workgroup 0, the clock64() deltas of each role: S3a, S1, issue, barrier wait.
 """

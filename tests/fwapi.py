@@ -528,8 +528,18 @@ class GpuEngine(Engine):
 _hostonly_lib = None
 
 
+def host_sources():
+    """libfwgpu's host translation units, as its own Makefile names them (everything but the device TU)"""
+    csrc = os.path.join(ROOT, "firewheel_amd", "csrc")
+    import re
+
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    srcs = re.search(r"^SRCS\s*:=\s*(.*)$", mk, flags=re.M).group(1).split()
+    return [os.path.join(csrc, x) for x in srcs if x.endswith(".cpp")]
+
+
 def hostonly_lib():
-    """The HOST half of libfwgpu (fwgpu_ctx.cpp + fwgpu_graph.cpp) built with g++ against tests/host_harness: a fake HIP
+    """The HOST half of libfwgpu (every .cpp of its Makefile: fwgpu_abi / _run / _plan_* / _control_math / _graph) built with g++ against tests/host_harness: a fake HIP
     runtime (host memory, inert streams) and no-op kernel launches.  Computes no audio — it lets the CPU tier test graph
     editing, planning, plan selection, batching, message bookkeeping and the error conventions of the C ABI."""
     global _hostonly_lib
@@ -539,8 +549,8 @@ def hostonly_lib():
         d = os.path.join(ROOT, "tests", "host_harness")
         csrc = os.path.join(ROOT, "firewheel_amd", "csrc")
         so = os.path.join(d, "_hostonly.so")
-        srcs = [os.path.join(d, "launch_stubs.cpp"), os.path.join(csrc, "fwgpu_ctx.cpp"), os.path.join(csrc, "fwgpu_graph.cpp")]
-        deps = srcs + [os.path.join(csrc, h) for h in ("fwgpu_graph.h", "fwgpu_types.h", "fwgpu_launch.h")] + [
+        srcs = [os.path.join(d, "launch_stubs.cpp")] + host_sources()
+        deps = srcs + [os.path.join(csrc, h) for h in ("fwgpu_graph.h", "fwgpu_types.h", "fwgpu_launch.h", "fwgpu_ctx.h")] + [
             os.path.join(ROOT, "include", "fwgpu.h"), os.path.join(d, "fakehip", "hip", "hip_runtime_api.h")]
         if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in deps):
             subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-Wall", "-Wno-unused-function",

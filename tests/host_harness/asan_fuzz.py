@@ -1,7 +1,7 @@
 """Host-side fuzz of libfwgpu's HOST half under AddressSanitizer + UBSan (CPU tier; tests/test_host_logic.py runs a few
 seeds, `python tests/host_harness/asan_fuzz.py N` run by hand does more — 3000 seeds are clean).  The graph / message /
 edit generators are the GPU fuzz families' own (tests/test_fuzz_gpu.py), driven on the host-only harness: no audio is
-computed, the point is every plan build, group packing, message sort and buffer (re)allocation of fwgpu_ctx.cpp.
+computed, the point is every plan build, group packing, message sort and buffer (re)allocation of the host translation units.
 Must be started with LD_PRELOAD=libasan.so:libubsan.so (see run_sanitised)."""
 import sys, os, ctypes as C
 HERE = os.path.dirname(os.path.abspath(__file__))

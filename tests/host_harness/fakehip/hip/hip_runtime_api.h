@@ -1,5 +1,5 @@
 /* TEST DOUBLE, CPU tier only (tests/host_harness): just enough of the HIP runtime API for the HOST half of libfwgpu
- * (fwgpu_ctx.cpp) to run without a device — "device" memory is calloc'd host memory, streams / events / graphs are inert
+ * (fwgpu_abi.cpp, fwgpu_run.cpp, fwgpu_plan_*.cpp) to run without a device — "device" memory is calloc'd host memory, streams / events / graphs are inert
  * tokens.  The kernels are NOT here: every launch_* is a no-op stub (launch_stubs.cpp), so no audio is ever computed on
  * this path; it exists to test graph editing, planning, plan selection, message bookkeeping and the error conventions
  * of the C ABI with `pytest -m "not gpu"`.  Never linked into the product. */
@@ -37,8 +37,10 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     return hipSuccess;
 }
 extern "C" unsigned long long fwh_alloc_calls;  /* defined in launch_stubs.cpp: device / pinned allocations so far */
+extern "C" long long fwh_fail_alloc_in; /* > 0: the n-th device / pinned allocation from now fails (then disarms) */
 static inline hipError_t hipMalloc(void** p, size_t n) {
     fwh_alloc_calls++;
+    if (fwh_fail_alloc_in > 0 && --fwh_fail_alloc_in == 0) return hipErrorOutOfMemory;
     if (n > ((size_t)1 << 32)) return hipErrorOutOfMemory;  /* the harness never needs more; keeps a bad size from eating the host */
     *p = calloc(n ? n : 1, 1);
     return *p ? hipSuccess : hipErrorOutOfMemory;
@@ -62,6 +64,7 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { retu
 static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }  /* every "kernel" has finished when its launch returns */
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipSuccess; }
 static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = (hipGraph_t)calloc(1, 8); return hipSuccess; }

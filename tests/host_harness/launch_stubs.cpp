@@ -8,6 +8,8 @@ unsigned long long g_launches[8];  // 0 level, 1 voice_control, 2 leaf_sum, 3 ch
 extern "C" {
 unsigned long long fwh_alloc_calls = 0;  // hipMalloc / hipHostMalloc calls of the fake runtime
 unsigned long long fwh_alloc_count(void) { return fwh_alloc_calls; }
+long long fwh_fail_alloc_in = 0;
+void fwh_fail_alloc(long long nth) { fwh_fail_alloc_in = nth; }
 }
 extern "C" unsigned long long fwh_launch_count(int which) { return which >= 0 && which < 8 ? g_launches[which] : 0; }
 extern "C" void fwh_launch_reset(void) {

@@ -51,7 +51,7 @@ def test_every_typed_node_builds_activates_and_takes_its_messages(cx):
     cx.add_node(1, 1, G.DummyAudioNode())  # dangling
     cx.update()
     assert cx.plan_kind() == 0 and cx.plan_num_levels() >= 12
-    # every setter of every class is accepted (parameter ids and message types match fwgpu_ctx.cpp)
+    # every setter of every class is accepted (parameter ids and message types match fwgpu_abi.cpp)
     nodes[0][0].set_percent_volume(30.0)
     nodes[1][0].set_pan(0.5, at_block=1)
     nodes[2][0].set_width(0.0)

@@ -439,6 +439,31 @@ class FirewheelGpuCtx(object):
         names it; a sampler that still holds the id sees an empty sample from the next call on."""
         self._check(self.L.fwgpu_sample_destroy(self.c, sample))
 
+    def poll_returned_samples(self, cap=64):
+        """ProcessorToNodeMsg::ReturnSample (nodes/sampler.rs:339-343): [(node id, sample id)] a completed process call
+        swapped out since the last poll — what SamplerNode::update() drains (sampler.rs:222-231)."""
+        nodes, samples = (C.c_int64 * cap)(), (C.c_int * cap)()
+        n = self._check(self.L.fwgpu_poll_returned_samples(self.c, nodes, samples, cap))
+        return [(nodes[i], samples[i]) for i in range(n)]
+
+    def sample_retired(self, sample):
+        """True once no sampler holds the sample, no queued message names it and the device is done reading it."""
+        return bool(self._check(self.L.fwgpu_sample_retired(self.c, sample)))
+
+    def ext_pool_floats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.L.fwgpu_ext_pool_floats(self.c, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def proc_info(self):
+        """(stream_time_secs, stream_status, output_underflows, input_overflows) — ProcInfo of the last call (core/node.rs:111-132)"""
+        t, st, u, o = C.c_double(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+        self._check(self.L.fwgpu_proc_info(self.c, C.byref(t), C.byref(st), C.byref(u), C.byref(o)))
+        return t.value, st.value, u.value, o.value
+
+    def open_stream(self, num_in_channels=0, num_out_channels=2):
+        return HeadlessStream(self, num_in_channels, num_out_channels)
+
     # ---- FirewheelProcessor::process_interleaved (graph/processor.rs:61-165)
     def process_interleaved(self, input, num_in_channels, num_out_channels, frames, stream_time_secs=0.0,
                             stream_status=0):
@@ -485,3 +510,40 @@ class FirewheelGpuCtx(object):
         cus, hbm = C.c_int(), C.c_uint64()
         self._check(self.L.fwgpu_device_info(self.c, name, 256, C.byref(cus), C.byref(hbm)))
         return name.value.decode(), cus.value, hbm.value
+
+
+class HeadlessStream(object):
+    """DataCallback (firewheel-cpal/src/lib.rs:362-449) without a device: `callback(frames, instant)` once per device
+    period, `instant` = the backend's clock at that callback in seconds (cpal: info.timestamp().callback)."""
+
+    OUTPUT_UNDERFLOW = 2  # StreamStatus (core/node.rs:120-132)
+    INPUT_OVERFLOW = 1
+
+    def __init__(self, cx, num_in_channels, num_out_channels):
+        self.cx = cx
+        self.num_out_channels = num_out_channels
+        self.s = cx.L.fwgpu_stream_open(cx.c, num_in_channels, num_out_channels)
+        if not self.s:
+            raise FwgpuError(-20, "fwgpu_stream_open failed")
+
+    def callback(self, frames, instant_secs):
+        """returns (interleaved output, StreamStatus bits handed to process_interleaved)"""
+        out = np.full(frames * self.num_out_channels, np.nan, dtype=np.float32)
+        st = self.cx._check(self.cx.L.fwgpu_stream_callback(self.s, _fptr(out), frames, instant_secs))
+        return out, st
+
+    def stats(self):
+        a, b, t = C.c_uint64(), C.c_uint64(), C.c_double()
+        self.cx._check(self.cx.L.fwgpu_stream_stats(self.s, C.byref(a), C.byref(b), C.byref(t)))
+        return a.value, b.value, t.value
+
+    def close(self):
+        if self.s:
+            self.cx.L.fwgpu_stream_close(self.s)
+            self.s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1798,4 +1798,61 @@ void fwo_interleave_stereo(const float* l, const float* r, float* interleaved, u
     interleave_stereo(l, r, interleaved, interleaved_len, has_mask ? &m : nullptr);
 }
 
+
+// ---- firewheel-cpal/src/lib.rs:362-449 DataCallback: the backend callback's stream-time / underflow bookkeeping,
+// with cpal's `info.timestamp().callback` instant replaced by a caller-supplied clock value in seconds (the only thing
+// the code does with the instant is subtract the first one from it, :402-407).
+struct FwoStream {
+    void* ctx;
+    uint32_t num_in_channels, num_out_channels;
+    double sample_rate_recip;      // :371
+    bool has_first_instant;        // first_stream_instant: Option<StreamInstant> :372
+    double first_stream_instant;
+    double predicted_stream_secs;  // :373 (1.0)
+    bool is_first_callback;        // :374
+};
+void* fwo_stream_new(void* c, uint32_t sample_rate, uint32_t n_in_ch, uint32_t n_out_ch) {
+    FwoStream* s = new FwoStream;
+    s->ctx = c;
+    s->num_in_channels = n_in_ch;
+    s->num_out_channels = n_out_ch;
+    s->sample_rate_recip = 1.0 / (double)sample_rate;  // f64::from(sample_rate).recip()
+    s->has_first_instant = false;
+    s->first_stream_instant = 0.0;
+    s->predicted_stream_secs = 1.0;
+    s->is_first_callback = true;
+    return s;
+}
+void fwo_stream_free(void* s) { delete (FwoStream*)s; }
+// returns the StreamStatus bits passed to process_interleaved; *stream_time_out = the stream_time_secs passed
+int fwo_stream_callback(void* sp, float* output, uint64_t frames, double callback_instant_secs, double* stream_time_out) {
+    FwoStream* s = (FwoStream*)sp;
+    double stream_time_secs;
+    bool underflow;
+    if (s->is_first_callback) {  // :385-393
+        s->is_first_callback = false;
+        s->predicted_stream_secs = (double)frames * s->sample_rate_recip;
+        stream_time_secs = 0.0;
+        underflow = false;
+    } else if (s->has_first_instant) {  // :394-413
+        stream_time_secs = callback_instant_secs - s->first_stream_instant;
+        const bool underrun = stream_time_secs > s->predicted_stream_secs;  // :405
+        s->predicted_stream_secs = stream_time_secs + ((double)frames * s->sample_rate_recip * 1.2);  // :411-412
+        underflow = underrun;
+    } else {  // :414-419
+        s->has_first_instant = true;
+        s->first_stream_instant = callback_instant_secs;
+        stream_time_secs = s->predicted_stream_secs;
+        s->predicted_stream_secs += (double)frames * s->sample_rate_recip * 1.2;
+        underflow = false;
+    }
+    uint32_t stream_status = 0;           // StreamStatus::empty() :423
+    if (underflow) stream_status |= 0b10;  // OUTPUT_UNDERFLOW :425-427, core/node.rs:130
+    if (stream_time_out) *stream_time_out = stream_time_secs;
+    // :429-437 (no processor yet -> output.fill(0.0) :442-445 is what process_interleaved does without a schedule, Q19)
+    fwo_process_interleaved(s->ctx, nullptr, output, s->num_in_channels, s->num_out_channels, frames, stream_time_secs,
+                            stream_status);
+    return (int)stream_status;
+}
+
 }  // extern "C"

@@ -90,6 +90,9 @@ def oracle_lib():
             "fwo_sampler_set_loop_range": (ci, [vp, i64, ci, f64, f64]),
             "fwo_process_interleaved": (ci, [vp, fp, fp, u32, u32, u64, f64, u32]),
             "fwo_node_process": (ci, [vp, i64, u64, C.POINTER(fp), u32, C.POINTER(fp), u32, u64, C.POINTER(u64), f64, u32]),
+            "fwo_stream_new": (vp, [vp, u32, u32, u32]),
+            "fwo_stream_free": (None, [vp]),
+            "fwo_stream_callback": (ci, [vp, fp, u64, f64, C.POINTER(f64)]),
             "fwo_smoother_new": (vp, [f32, u32, u32]),
             "fwo_smoother_free": (None, [vp]),
             "fwo_smoother_set": (None, [vp, f32]),

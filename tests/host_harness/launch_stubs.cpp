@@ -4,7 +4,9 @@
 
 namespace {
 unsigned long long g_launches[8];  // 0 level, 1 voice_control, 2 leaf_sum, 3 chain, 4 bus_sum, 5 root_out, 6 fir, 7 other
+unsigned long long g_cmds_applied = 0;
 }
+extern "C" unsigned long long fwh_cmds_seen(void) { return g_cmds_applied; }
 extern "C" {
 unsigned long long fwh_alloc_calls = 0;  // hipMalloc / hipHostMalloc calls of the fake runtime
 unsigned long long fwh_alloc_count(void) { return fwh_alloc_calls; }
@@ -226,9 +228,16 @@ int launch_get_flags(hipStream_t, const uint8_t* flags, const int* d_bufs, int n
     touch(d_mask, 8);
     return 0;
 }
-int launch_voice_control(hipStream_t, const FusedView& fv, int K, uint32_t) {
+int launch_voice_control(hipStream_t, const FusedView& fv, int K, uint32_t cmd_block0) {
     g_launches[1]++;
     check_fused_common(fv, K);
+    for (int i = 0; i < fv.n_cmds; ++i) {  // messages the control kernel would APPLY in this launch (each exactly once in its life)
+        if (i > 0) {
+            const Cmd &a = fv.cmds[i - 1], &b = fv.cmds[i];
+            REQUIRE(a.state < b.state || (a.state == b.state && a.block <= b.block), i);  // sorted by (node, block)
+        }
+        if (fv.cmds[i].block >= cmd_block0 && fv.cmds[i].block < cmd_block0 + (uint32_t)K) g_cmds_applied++;
+    }
     if (fv.fx_plan) touch(fv.chain_start, sizeof(ChainStart) * (size_t)fv.n_voices);
     return 0;
 }

@@ -12,19 +12,25 @@ edit API add_node / connect / update):
         262144 flop per stereo voice-sample (k_fir_gemm).
   cfg5 (configs[4], one GPU's shard): 8192 voices of the cfg2 chain, tree 256 + 8 + 1, block = 1024; with N > 1
         ranks the step ends with the mix-bus reduction over RCCL.
+  cfg1 (configs[0], plumbing): beep -> gain -> stereo out, 750 one-block callbacks through the headless stream (the
+        process_interleaved call pattern of firewheel-cpal's callback); reported under `other_configs`, never `value`.
 
 Sources are planar f32, resident in HBM, each voice looping over its own buffer so every block streams fresh
 HBM.  One "step" = one fwgpu_process_blocks_device call of `--blocks-per-step` consecutive blocks (the K-block
 throughput mode); the interleaved mix bus stays in HBM.  With N > 1 every rank runs the same
-shard (weak scaling, one process per GPU) and the step ends with the mix-bus collective.
+shard (weak scaling, one process per GPU) and the step ends with the mix-bus collective.  `--gpus N` without a
+launcher around it starts the N ranks itself (torch.distributed.run, 127.0.0.1).
 
 Prints ONE JSON line (rank 0).  `roofline` times the dominant kernel with HIP events on the stream it runs on;
-`cpu_baseline` times the oracle (C++ restatement of the reference's single-threaded executor) on a bounded
-sample of the same workload.
+`cpu_baseline` times the oracle (C++ restatement of the reference's single-threaded executor) on the SAME graph and the
+SAME source data, copied back from HBM; `parity_check` renders one call of the benched launch shape on a fresh context
+and compares chosen blocks of it, bit for bit, with the oracle; `other_configs` carries configs 1, 3, 4 and 5 (one
+shard) in short form; `realtime_us_per_callback` is the one-block-per-call latency of the headline graph.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -43,91 +49,145 @@ DEFAULTS = {
     "cfg4": (256, 256, 16, 65536, 30),
     "cfg5": (8192, 1024, 64, 65536, 60),
 }
+# node kinds of include/fwgpu.h (both engines take raw kinds)
+K_BEEP, K_VOLUME, K_SUM, K_SAMPLER, K_HARD_CLIP, K_PAN, K_WIDTH, K_BIQUAD, K_DELAY, K_FIR = 1, 2, 3, 4, 5, 8, 9, 10, 11, 12
+PLANAR_F32, INTERLEAVED_I16 = 5, 0
 
 
-MASTER = [False]  # --master: a master volume + limiter between the root SumNode and graph_out
+# ------------------------------------------------------------------------------------------------ the two engines
+class GpuSide(object):
+    """the reference-shaped edit surface over the product's C ABI (firewheel_amd.FirewheelGpuCtx)"""
+
+    def __init__(self, cx):
+        from firewheel_amd.graph import _RawNode
+
+        self.cx, self._raw = cx, _RawNode
+        self.sample_rate = cx.sample_rate
+
+    def add(self, kind, n_in, n_out, params=()):
+        return self.cx.add_node(n_in, n_out, self._raw(kind, list(params)))
+
+    def connect_stereo(self, a, b, port0=0):
+        self.cx.connect(a, 0, b, port0, False)
+        self.cx.connect(a, 1, b, port0 + 1, False)
+
+    def out_node(self):
+        return self.cx.graph_out_node()
+
+    def update(self):
+        self.cx.update()
+
+    def start(self, sampler, sample, play=True):
+        L, c = self.cx.L, self.cx.c
+        self.cx._check(L.fwgpu_sampler_set_sample(c, sampler, sample, 0, 0))
+        self.cx._check(L.fwgpu_sampler_set_loop_range(c, sampler, 1, 0.0, 0.0, 0))
+        if play:
+            self.cx._check(L.fwgpu_sampler_play(c, sampler, 0))
+
+    def set_param(self, node, param, value, at_block=0):
+        self.cx._check(self.cx.L.fwgpu_node_set_param(self.cx.c, node, param, value, at_block))
 
 
-def sum_tree(cx, fa, ends, radix):
+class OracleSide(object):
+    """the same surface over the CPU oracle (tests/fwapi.OracleEngine) — cpu_baseline and parity_check only"""
+
+    def __init__(self, block):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import fwapi
+
+        self.e = fwapi.OracleEngine(max_block_frames=block)
+        self.sample_rate = self.e.sample_rate
+
+    def add(self, kind, n_in, n_out, params=()):
+        return self.e.add_node(kind, n_in, n_out, list(params))
+
+    def connect_stereo(self, a, b, port0=0):
+        self.e.connect_stereo(a, b, port0)
+
+    def out_node(self):
+        return self.e.graph_out_node
+
+    def update(self):
+        self.e.update()
+
+    def start(self, sampler, sample, play=True):
+        self.e.sampler_set_sample(sampler, sample)
+        self.e.sampler_set_loop_range(sampler, 1)
+        if play:
+            self.e.sampler_play(sampler)
+
+    def set_param(self, node, param, value, at_block=0):
+        self.e.set_param(node, param, value)
+
+
+# ------------------------------------------------------------------------------------------------ the graphs
+def sum_tree(e, ends, radix, master=False):
     level = ends
     while True:
         nxt = []
         for i in range(0, len(level), radix):
             grp = level[i:i + radix]
-            m = cx.add_node(2 * len(grp), 2, fa.SumNode())
+            m = e.add(K_SUM, 2 * len(grp), 2)
             for p, n in enumerate(grp):
-                cx.connect(n, 0, m, 2 * p, False)
-                cx.connect(n, 1, m, 2 * p + 1, False)
+                e.connect_stereo(n, m, 2 * p)
             nxt.append(m)
         level = nxt
         if len(level) == 1:
             break
     cur = level[0]
-    if MASTER[0]:
-        for node in (fa.VolumeNode(70.0), fa.HardClipNode(-1.0)):
-            m = cx.add_node(2, 2, node)
-            cx.connect(cur, 0, m, 0, False)
-            cx.connect(cur, 1, m, 1, False)
+    if master:  # --master: a master volume + limiter between the root SumNode and graph_out
+        for kind, params in ((K_VOLUME, [70.0]), (K_HARD_CLIP, [-1.0])):
+            m = e.add(kind, 2, 2, params)
+            e.connect_stereo(cur, m)
             cur = m
-    cx.connect(cur, 0, cx.graph_out_node(), 0, False)
-    cx.connect(cur, 1, cx.graph_out_node(), 1, False)
+    e.connect_stereo(cur, e.out_node())
 
 
-def start_voices(cx, fa, samplers, src, frames_per_voice, fmt="f32"):
-    elem = 4 if fmt == "f32" else 2
-    sfmt = fa.SampleFormat.PLANAR_F32 if fmt == "f32" else fa.SampleFormat.INTERLEAVED_I16
-    for v, s in enumerate(samplers):
-        ptr = src.data_ptr() + v * 2 * frames_per_voice * elem
-        smp = cx.new_sample_device(sfmt, 2, frames_per_voice, ptr)
-        node = cx.node(s)
-        node.set_sample(smp, False)
-        node.set_loop_range(fa.LoopRange.Full())
-        node.play()
-
-
-def build_bank(cx, fa, voices, radix, seed=0, volumes_out=None):
-    """cfg2 / cfg5 chain: sampler -> gain -> pan."""
+def graph_bank(e, voices, radix, seed=0, master=False, extra=()):
+    """cfg2 / cfg5 voice: sampler -> gain -> pan [-> width -> hard clip with --voice-fx].  Returns (samplers, volumes)."""
     import numpy as np
 
     rng = np.random.default_rng(1234 + seed)
-    ends, samplers = [], []
+    ends, samplers, volumes = [], [], []
     for v in range(voices):
-        s = cx.add_node(0, 2, fa.SamplerNode(100.0))
-        vol = cx.add_node(2, 2, fa.VolumeNode(float(rng.uniform(10, 100))))
-        pan = cx.add_node(2, 2, fa.StereoPanNode(float(rng.uniform(-1, 1))))
-        for c in (0, 1):
-            cx.connect(s, c, vol, c, False)
-            cx.connect(vol, c, pan, c, False)
+        s = e.add(K_SAMPLER, 0, 2, [100.0])
+        vol = e.add(K_VOLUME, 2, 2, [float(rng.uniform(10, 100))])
+        pan = e.add(K_PAN, 2, 2, [float(rng.uniform(-1, 1))])
+        e.connect_stereo(s, vol)
+        e.connect_stereo(vol, pan)
+        cur = pan
+        for kind, params in extra:
+            n = e.add(kind, 2, 2, params)
+            e.connect_stereo(cur, n)
+            cur = n
         samplers.append(s)
-        ends.append(pan)
-        if volumes_out is not None:
-            volumes_out.append(vol)
-    sum_tree(cx, fa, ends, radix)
-    cx.update()
-    return samplers
+        volumes.append(vol)
+        ends.append(cur)
+    sum_tree(e, ends, radix, master)
+    e.update()
+    return samplers, volumes
 
 
-def build_chain_bank(cx, fa, voices, radix, seed=0):
-    """cfg3 chain: sampler -> biquad LPF (cutoff U(200, 8000) Hz, Q 0.707) -> delay (U(10, 250) ms, feedback 0.3,
+def graph_chain(e, voices, radix, seed=0, master=False):
+    """cfg3 voice: sampler -> biquad LPF (cutoff U(200, 8000) Hz, Q 0.707) -> delay (U(10, 250) ms, feedback 0.3,
     mix 0.5) -> gain."""
     import numpy as np
 
     rng = np.random.default_rng(4321 + seed)
     ends, samplers = [], []
     for v in range(voices):
-        s = cx.add_node(0, 2, fa.SamplerNode(100.0))
-        bq = cx.add_node(2, 2, fa.BiquadNode(fa.BiquadNode.LOWPASS, float(rng.uniform(200, 8000)), 0.707))
-        dl = cx.add_node(2, 2, fa.DelayNode(float(rng.uniform(0.010, 0.250)), 0.3, 0.5))
-        vol = cx.add_node(2, 2, fa.VolumeNode(float(rng.uniform(10, 100))))
-        for c in (0, 1):
-            cx.connect(s, c, bq, c, False)
-            cx.connect(bq, c, dl, c, False)
-            cx.connect(dl, c, vol, c, False)
+        s = e.add(K_SAMPLER, 0, 2, [100.0])
+        bq = e.add(K_BIQUAD, 2, 2, [0.0, float(rng.uniform(200, 8000)), 0.707])
+        dl = e.add(K_DELAY, 2, 2, [float(rng.uniform(0.010, 0.250)), 0.3, 0.5])
+        vol = e.add(K_VOLUME, 2, 2, [float(rng.uniform(10, 100))])
+        e.connect_stereo(s, bq)
+        e.connect_stereo(bq, dl)
+        e.connect_stereo(dl, vol)
         samplers.append(s)
         ends.append(vol)
-    sum_tree(cx, fa, ends, radix)
-    cx.update()
-    return samplers
+    sum_tree(e, ends, radix, master)
+    e.update()
+    return samplers, []
 
 
 def reverb_ir(taps):
@@ -139,97 +199,113 @@ def reverb_ir(taps):
     return (h / np.abs(h).sum(axis=1, keepdims=True)).astype(np.float32)
 
 
-def build_reverb_bank(cx, fa, voices, radix, taps):
+def graph_reverb(e, voices, radix, ir_sample):
     """cfg4: V x (sampler -> `taps`-tap stereo FIR convolution) -> radix sum tree -> out."""
-    ir = cx.new_sample(fa.SampleFormat.PLANAR_F32, 2, reverb_ir(taps))
     ends, samplers = [], []
     for v in range(voices):
-        s = cx.add_node(0, 2, fa.SamplerNode(100.0))
-        f = cx.add_node(2, 2, fa.FirReverbNode(ir))
-        for c in (0, 1):
-            cx.connect(s, c, f, c, False)
+        s = e.add(K_SAMPLER, 0, 2, [100.0])
+        f = e.add(K_FIR, 2, 2, [float(ir_sample)])
+        e.connect_stereo(s, f)
         samplers.append(s)
         ends.append(f)
-    sum_tree(cx, fa, ends, radix)
-    cx.update()
-    return samplers
+    sum_tree(e, ends, radix)
+    e.update()
+    return samplers, []
 
 
-def cpu_engine(workload, voices, block, radix, taps, src_frames, seed=0):
-    """one oracle engine running `voices` voices of the workload's graph shape; returns (engine, voices, chunk)"""
-    import fwapi
-    import scenarios
-
-    e = fwapi.OracleEngine(max_block_frames=block)
-    chunk = 16
-    if workload == "cfg3":
-        vs = scenarios.build_chain_bank(e, voices, radix=radix, src_frames=src_frames, min_delay_frames=480,
-                                        max_delay_frames=12000, seed=seed)
-        chunk = 2
-    elif workload == "cfg4":
-        ir = e.new_sample(fwapi.PLANAR_F32, 2, reverb_ir(taps))
-        m = e.sum(voices)
-        vs = []
-        for v in range(voices):
-            s = e.sampler(100.0)
-            f = e.fir(ir)
-            e.connect_stereo(s, f)
-            e.connect_stereo(f, m, 2 * v)
-            vs.append(dict(sampler=s))
-        e.connect_stereo(m, e.graph_out_node)
-        e.update()
-        for v, vc in enumerate(vs):
-            e.sampler_set_sample(vc["sampler"],
-                                 e.new_sample(fwapi.PLANAR_F32, 2, scenarios.voice_source(seed * 100000 + v, src_frames)))
-        chunk = 1
-    else:
-        vs = scenarios.build_voice_bank(e, voices, radix=radix, src_frames=src_frames, seed=seed)
-    for vc in vs:
-        e.sampler_set_loop_range(vc["sampler"], fwapi.LOOP_FULL)
-        e.sampler_play(vc["sampler"])
-    return e, chunk
+def build_graph(e, wl, voices, radix, seed, master, ir_sample=None, voice_fx=False):
+    if wl == "cfg4":
+        return graph_reverb(e, voices, radix, ir_sample)
+    if wl == "cfg3":
+        return graph_chain(e, voices, radix, seed, master)
+    extra = ((K_WIDTH, [1.3]), (K_HARD_CLIP, [-3.0])) if voice_fx else ()
+    return graph_bank(e, voices, radix, seed, master, extra)
 
 
-def cpu_baseline(workload, voices, block, radix, taps, target_secs):
-    """Oracle on the same graph shape.  `value` is the faithful figure: ONE thread, like the reference's audio thread
-    (DESIGN_DOC.md:48).  `all_cores` is the generous one: the voices split over every host core, one
-    oracle engine per thread, no mix-bus exchange charged."""
+def want_plan(wl, force_generic):
+    return 0 if (force_generic or wl == "cfg4") else (2 if wl == "cfg3" else 1)
+
+
+def make_gpu(fa, wl, V, B, K, radix, src, F, sfmt, seed, args, stream, device):
+    """a fresh device context with the workload's graph on the sources `src` (HBM), every voice looping and playing"""
+    cx = fa.FirewheelGpuCtx(48000, B, 0, 2, device=device, stream=stream)
+    cx.set_max_batch(K)
+    if args.force_generic:
+        cx.set_force_generic(True)
+    g = GpuSide(cx)
+    ir = cx.new_sample(PLANAR_F32, 2, reverb_ir(args.taps)) if wl == "cfg4" else None
+    samplers, volumes = build_graph(g, wl, V, radix, seed, args.master, ir, args.voice_fx)
+    elem = 4 if sfmt == "f32" else 2
+    fmt = PLANAR_F32 if sfmt == "f32" else INTERLEAVED_I16
+    for v, s in enumerate(samplers):
+        smp = cx.new_sample_device(fmt, 2, F, src.data_ptr() + v * 2 * F * elem)
+        g.start(s, smp)
+    assert cx.plan_kind() == want_plan(wl, args.force_generic), "expected launch plan %d, got %d" % (
+        want_plan(wl, args.force_generic), cx.plan_kind())
+    return cx, g, samplers, volumes
+
+
+def make_oracle(wl, V, B, radix, seed, args, host_src, fmt=PLANAR_F32):
+    """the oracle on the same graph; host_src[v] = that voice's sample data as the engine's format wants it"""
+    o = OracleSide(B)
+    ir = o.e.new_sample(PLANAR_F32, 2, reverb_ir(args.taps)) if wl == "cfg4" else None
+    samplers, volumes = build_graph(o, wl, V, radix, seed, args.master, ir, args.voice_fx)
+    for v, s in enumerate(samplers):
+        o.start(s, o.e.new_sample(fmt, 2, host_src[v]))
+    return o, samplers, volumes
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(wl, V, B, radix, seed, args, src, F, target_secs):
+    """Oracle on the SAME graph and the SAME source data as the timed GPU run (copied back from HBM).  `value` is the
+    faithful figure: ONE thread, like the reference's audio thread (DESIGN_DOC.md:48).  `all_cores` is the generous one
+    (SURVEY §8d): the voices split over host cores, one oracle engine per thread, no mix-bus exchange charged."""
     import threading
 
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    src_frames = 16384
-    if workload == "cfg4":
-        voices = min(voices, 32)  # bounded sample: the scalar direct-form convolution is ~1e9 fmaf per voice-block
-    e, chunk = cpu_engine(workload, voices, block, radix, taps, src_frames)
-    if workload != "cfg4":
-        e.process_blocks(4)  # warm-up
+    note = "same graph, same %d-frame looping sources as the GPU run (copied from HBM)" % F
+    voices = V
+    if wl == "cfg4":
+        voices = min(V, 32)  # bounded sample: the scalar direct-form convolution is ~1e9 fmaf per voice-block
+        note = "the first %d of the GPU run's %d voices (scalar 65536-tap convolution: 27 ms per voice-block), same sources" % (voices, V)
+    Fh = F
+    if voices * F * 8 > 6 * 2 ** 30:  # keep the host copy bounded
+        Fh = int(6 * 2 ** 30 // (voices * 8) // B * B)
+        note = "same graph; sources = the first %d of the GPU run's %d frames per voice (host copy bounded to 6 GiB)" % (Fh, F)
+    host = src[:voices, :, :Fh].cpu().numpy()
+    chunk = {"cfg3": 2, "cfg4": 1}.get(wl, 16)
+    o, _, _ = make_oracle(wl, voices, B, radix, seed, args, host)
+    if wl != "cfg4":
+        o.e.process_blocks(4)  # warm-up
     n_blocks, t = 0, 0.0
     t0 = time.perf_counter()
     while t < target_secs:
-        e.process_blocks(chunk)
+        o.e.process_blocks(chunk)
         n_blocks += chunk
         t = time.perf_counter() - t0
-    del e
-    ncpu = os.cpu_count() or 1
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
+    del o
+    ncpu = host_cores()
     all_cores = None
     T = min(ncpu, voices, 32)  # python threads around ctypes calls: beyond ~32 the GIL hand-offs between calls dominate
     if T > 1:
         per = max(1, voices // T)
-        engines = [cpu_engine(workload, per, block, radix, taps, src_frames, seed=1 + i) for i in range(T)]
+        # the voice parameters of a slice differ from the whole graph's (the seeded stream restarts): a throughput figure
+        engines = [make_oracle(wl, per, B, radix, 1 + i, args, host[i * per:(i + 1) * per])[0] for i in range(T)]
         counts = [0] * T
         go = threading.Event()
         deadline = [0.0]
 
         def run(i):  # ctypes releases the GIL for the whole of a process call
-            eng, ch = engines[i]
-            ch *= 8  # long calls: the GIL is only held between them
+            ch = chunk * 8  # long calls: the GIL is only held between them
             go.wait()
             while time.perf_counter() < deadline[0]:
-                eng.process_blocks(ch)
+                engines[i].e.process_blocks(ch)
                 counts[i] += ch
 
         th = [threading.Thread(target=run, args=(i,)) for i in range(T)]
@@ -242,20 +318,123 @@ def cpu_baseline(workload, voices, block, radix, taps, target_secs):
         for x in th:
             x.join()
         tb = time.perf_counter() - ta
-        all_cores = {"value": per * block * sum(counts) / tb, "unit": "voice-samples/s", "cores": T,
+        all_cores = {"value": per * B * sum(counts) / tb, "unit": "voice-samples/s", "cores": T,
                      "sample": "%d threads x %d voices, %.1f s" % (T, per, tb)}
     return {
-        "value": voices * block * n_blocks / t,
+        "value": voices * B * n_blocks / t,
         "unit": "voice-samples/s",
         "cores": 1,
         "kind": "port",
-        "sample": "%d blocks of a %d-voice %s graph (block=%d, %d-frame looping sources), %.1f s on 1 of %d host cores; "
-                  "oracle = C++ restatement of the reference's single-threaded executor (the Rust build is not "
-                  "available: no cargo/rustc)" % (n_blocks, voices, workload, block, src_frames, t, ncpu),
+        "sample": "%d blocks of the %d-voice %s graph (block=%d), %.1f s on 1 of %d host cores; %s; oracle = C++ restatement of "
+                  "the reference's single-threaded executor (the Rust build is not available: no cargo/rustc)"
+                  % (n_blocks, voices, wl, B, t, ncpu, note),
         "all_cores": all_cores,
     }
 
 
+# ------------------------------------------------------------------------------------------------ parity check
+def parity_check(fa, torch, wl, V, B, K, radix, seed, args, src, F, sfmt, stream, device):
+    """One call of the benched launch shape (all voices, K blocks) on a FRESH context, chosen blocks of it compared bit for
+    bit with the oracle on the same graph and the same source frames.  cfg2 / cfg5 voices carry no history but the
+    playhead, so the oracle is handed the source frames of blocks {0, 1, K/2, K-1} back to back and renders those four;
+    cfg3 (filter + delay state) is checked on the call's first two blocks, cfg4 on its first block."""
+    import numpy as np
+
+    t0 = time.perf_counter()
+    cx, g, samplers, _ = make_gpu(fa, wl, V, B, K, radix, src, F, sfmt, seed, args, stream, device)
+    out = torch.empty(K * B * 2, dtype=torch.float32, device=src.device)
+    if src.is_cuda:
+        torch.cuda.synchronize()
+    cx.process_blocks_device(K, out.data_ptr(), 2)
+    cx.synchronize()
+    if wl in ("cfg2", "cfg5") and K >= 4 and F >= K * B and sfmt == "f32":
+        blocks = [0, 1, K // 2, K - 1]
+    elif wl == "cfg4":
+        blocks = [0]
+    else:
+        blocks = [0, 1] if K >= 2 else [0]
+    got = torch.cat([out[b * B * 2:(b + 1) * B * 2] for b in blocks]).cpu().numpy()
+    if sfmt == "f32":
+        host = torch.cat([src[:, :, b * B:(b + 1) * B] for b in blocks], dim=2).cpu().numpy()
+        fmt = PLANAR_F32
+    else:
+        host = torch.cat([src[:, b * B:(b + 1) * B, :] for b in blocks], dim=1).cpu().numpy()
+        fmt = INTERLEAVED_I16
+    o, _, _ = make_oracle(wl, V, B, radix, seed, args, host, fmt)
+    ref = o.e.process_blocks(len(blocks))
+    same = bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32)))
+    res = {"bit_exact": same, "blocks": len(blocks), "block_indices": blocks, "voices": V, "blocks_per_call": K,
+           "samples_compared": int(got.size), "launch_plan": cx.plan_kind(),
+           "against": "oracle (C++ restatement of the reference), same graph, same source frames",
+           "secs": None}
+    if not same:
+        bad = np.nonzero(got.view(np.uint32) != ref.view(np.uint32))[0]
+        res["mismatches"] = int(bad.size)
+        res["first_mismatch"] = [int(bad[0]), float(got[bad[0]]), float(ref[bad[0]])]
+    if not bool(np.any(ref)):
+        res["bit_exact"] = False
+        res["error"] = "the reference output is all zeros: nothing was compared"
+    cx.close()
+    res["secs"] = round(time.perf_counter() - t0, 2)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ realtime / cfg1
+def realtime_probe(cx, B, callbacks=1500):
+    """one max_block_frames block per fwgpu_stream_callback, output to pageable host memory, synchronous — the call
+    pattern of the reference's backend callback (firewheel-cpal/src/lib.rs:378-449).  Returns microseconds per callback."""
+    st = cx.open_stream(0, 2)
+    t = 0.0
+    for _ in range(50):
+        t += B / 48000.0
+        st.callback(B, t)
+    t0 = time.perf_counter()
+    for _ in range(callbacks):
+        t += B / 48000.0
+        st.callback(B, t)
+    dt = time.perf_counter() - t0
+    st.close()
+    return dt / callbacks * 1e6
+
+
+def run_cfg1(fa, stream, device):
+    """BASELINE configs[0]: beep_test — sine -> gain -> stereo out, block 256 @ 48 kHz, 750 callbacks (4 s) of one block
+    each through the headless stream (examples/beep_test/src/main.rs:10-52, cpal/lib.rs:429-437), checked against the
+    oracle within BeepTest's libm tolerance (2e-6 absolute: ocml sinf vs glibc sinf)."""
+    import numpy as np
+
+    B, n = 256, 750
+
+    def build(e):
+        beep = e.add(K_BEEP, 0, 2, [440.0, -12.0, 1.0])
+        vol = e.add(K_VOLUME, 2, 2, [80.0])
+        e.connect_stereo(beep, vol)
+        e.connect_stereo(vol, e.out_node())
+        e.update()
+
+    cx = fa.FirewheelGpuCtx(48000, B, 0, 2, device=device, stream=stream)
+    build(GpuSide(cx))
+    st = cx.open_stream(0, 2)
+    outs = []
+    t0 = time.perf_counter()
+    for i in range(n):
+        o, _ = st.callback(B, (i + 1) * B / 48000.0)
+        outs.append(o)
+    dt = time.perf_counter() - t0
+    got = np.concatenate(outs)
+    o = OracleSide(B)
+    build(o)
+    ref = np.concatenate([o.e.process_blocks(1) for _ in range(n)])
+    err = float(np.max(np.abs(got - ref)))
+    cbs, unders, _ = st.stats()
+    st.close()
+    cx.close()
+    return {"workload": "cfg1 beep_test: sine 440 Hz -> gain -> stereo out, block=256, %d callbacks of one block (headless stream)" % n,
+            "callbacks": cbs, "underflows": unders, "us_per_callback": dt / n * 1e6, "realtime_factor": (n * B / 48000.0) / dt,
+            "max_abs_err_vs_oracle": err, "within_tolerance": bool(err <= 2e-6), "tolerance": 2e-6}
+
+
+# ------------------------------------------------------------------------------------------------ measured run
 def pmc_traffic(kernel, V, B, K):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
     gfx950 corrections per the microarch guide) — quoted only when collected on this exact workload."""
@@ -272,120 +451,42 @@ def pmc_traffic(kernel, V, B, K):
     return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=sorted(DEFAULTS), default="cfg2",
-                    help="cfg2 = the headline (BASELINE configs[1]); cfg3 / cfg4 / cfg5 = configs[2..4]")
-    ap.add_argument("--voices", type=int, default=None, help="voices per GPU")
-    ap.add_argument("--block", type=int, default=None)
-    ap.add_argument("--radix", type=int, default=32)
-    ap.add_argument("--blocks-per-step", type=int, default=None)
-    ap.add_argument("--src-frames", type=int, default=None, help="source frames per voice (2 ch f32)")
-    ap.add_argument("--cpu-secs", type=float, default=12.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--taps", type=int, default=65536)
-    ap.add_argument("--source-format", choices=["f32", "i16"], default="f32",
-                    help="cfg2/cfg5 only: planar f32 sources (the headline) or interleaved stereo i16 (4 B per voice-sample)")
-    ap.add_argument("--host-buffers", action="store_true",
-                    help="time fwgpu_process_interleaved on HOST buffers instead (PCIe-inclusive; DESIGN.md §7 note, "
-                         "never the headline)")
-    ap.add_argument("--master", action="store_true",
-                    help="put a master VolumeNode + HardClipNode between the root SumNode and graph_out (the fused plans "
-                         "then run that chain with the generic node kernel on the mix bus)")
-    ap.add_argument("--force-generic", action="store_true",
-                    help="run the workload on the generic level-batched executor (plan 0) instead of its fused plan")
-    ap.add_argument("--variant", choices=["A", "B", "C"], default="A",
-                    help="cfg2/cfg5 (SURVEY 8d): A steady; B one gain change per voice at a seeded block of the run "
-                         "(smoother ramps, message path inside the timed region); C every 4th voice paused (silence masks)")
-    ap.add_argument("--reduce-every", type=int, default=4,
-                    help="N>1: steps whose mix buses share one collective (the reduction of R steps overlaps the next R)")
-    ap.add_argument("--bus-reduce", choices=["allreduce", "ordered"], default="allreduce",
-                    help="N>1: RCCL all-reduce (named path) or all-gather + rank-ordered sum (bit-exact)")
-    args = ap.parse_args()
-    MASTER[0] = args.master
-    dV, dB, dK, dF, dS = DEFAULTS[args.workload]
-    V = args.voices or dV
-    B = args.block or dB
-    K = args.blocks_per_step or dK
-    F = args.src_frames or dF
-    steps = args.steps or dS
-    wl = args.workload
+def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
+    """times `steps` steps of one workload; returns the fields of its bench line (rank 0) — `full`: with the CPU baseline,
+    the parity check and the realtime probe"""
+    torch, fa, shard, dist = env["torch"], env["fa"], env["shard"], env["dist"]
+    rank, world, device, dev = env["rank"], env["world"], env["device"], env["dev"]
+    hostonly = env["hostonly"]
 
-    # stdout carries exactly ONE line (the JSON, rank 0): everything else that writes to fd 1 — RCCL's version banner
-    # and warnings come from C stdio, flushed whenever — is sent to stderr for the life of the process
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+    def sync():
+        if not hostonly:
+            torch.cuda.synchronize()
 
-    import torch
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or os.environ.get("FWGPU_BENCH_FORCE_DIST"):  # the env var: exercise the RCCL path on one GPU
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-
-    import firewheel_amd as fa
-    from firewheel_amd import shard
-
-    stream = torch.cuda.current_stream().cuda_stream
-    cx = fa.FirewheelGpuCtx(48000, B, 0, 2, device=local_rank, stream=stream)
-    cx.set_max_batch(K)
-    if args.force_generic:
-        cx.set_force_generic(True)
+    stream = torch.cuda.current_stream().cuda_stream if not hostonly else None
     # synthetic sources, generated in HBM: uniform(-1,1) f32, seed offset by global voice id
-    g = torch.Generator(device="cuda")
-    g.manual_seed(shard.voice_seed(rank * V))  # stream keyed by the shard's first GLOBAL voice id
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(shard.voice_seed(rank * V))  # stream keyed by the shard's first GLOBAL voice id
     sfmt = args.source_format if wl in ("cfg2", "cfg5") else "f32"
     if sfmt == "i16":  # interleaved stereo PCM, [voice][frame][channel]
-        src = torch.randint(-32768, 32768, (V, F, 2), dtype=torch.int16, device="cuda", generator=g)
+        src = torch.randint(-32768, 32768, (V, F, 2), dtype=torch.int16, device=dev, generator=gen)
     else:
-        src = torch.empty((V, 2, F), dtype=torch.float32, device="cuda")
-        src.uniform_(-1.0, 1.0, generator=g)
-    if wl == "cfg4":
-        samplers = build_reverb_bank(cx, fa, V, args.radix, args.taps)
-        want_plan = 0
-    elif wl == "cfg3":
-        samplers = build_chain_bank(cx, fa, V, args.radix, seed=rank)
-        want_plan = 2
-    else:
-        volumes = []
-        samplers = build_bank(cx, fa, V, args.radix, seed=rank, volumes_out=volumes)
-        want_plan = 1
-    start_voices(cx, fa, samplers, src, F, sfmt)
+        src = torch.empty((V, 2, F), dtype=torch.float32, device=dev)
+        src.uniform_(-1.0, 1.0, generator=gen)
+    cx, g, samplers, volumes = make_gpu(fa, wl, V, B, K, args.radix, src, F, sfmt, rank, args, stream, device)
     variant = args.variant if wl in ("cfg2", "cfg5") else "A"
     playing = 1.0
     changes = {}
     if variant == "C":
         for s in samplers[::4]:
-            cx.node(s).pause()
+            cx._check(cx.L.fwgpu_sampler_pause(cx.c, s, 0))
         playing = 1.0 - len(samplers[::4]) / float(len(samplers))
     elif variant == "B":  # voice v changes its gain once, at block b_v of timed step s_v
         import numpy as np
 
         rng = np.random.default_rng(99 + rank)
         for v, vol in enumerate(volumes):
-            changes.setdefault(args.warmup + int(rng.integers(0, steps)), []).append(
+            changes.setdefault(warmup + int(rng.integers(0, steps)), []).append(
                 (vol, float(rng.uniform(10, 100)), int(rng.integers(0, K))))
-    if args.force_generic:
-        want_plan = 0
-    assert cx.plan_kind() == want_plan, "expected launch plan %d, got %d" % (want_plan, cx.plan_kind())
     # two bus buffers: with N > 1 the reduction of step i (RCCL, its own stream) overlaps the compute of step i+1 —
     # the mix bus is a sink, nothing in a shard reads it back
     # ... and each buffer holds the buses of R consecutive steps, reduced by ONE collective: the hand-over between the
@@ -393,8 +494,8 @@ def main():
     # collective per step), so it is paid once per R steps
     R = max(1, args.reduce_every) if dist is not None else 1
     step_elems = K * B * 2
-    outs = [torch.empty(R * step_elems, dtype=torch.float32, device="cuda") for _ in range(2)]
-    reducer = shard.BusReducer(dist, outs, args.bus_reduce) if dist is not None else None
+    outs = [torch.empty(R * step_elems, dtype=torch.float32, device=dev) for _ in range(2)]
+    reducer = shard.BusReducer(dist, outs, args.bus_reduce, cx=cx) if dist is not None else None
     step_no = [0]
     slot = [0]  # bus slot counter: buffer (slot // R) % 2, slice slot % R
     host_out = None
@@ -407,7 +508,7 @@ def main():
         b = (slot[0] // R) % 2
         r = slot[0] % R
         for vol, pct, at in changes.get(step_no[0], ()):
-            cx.node(vol).set_percent_volume(pct, at_block=at)
+            g.set_param(vol, 0, pct, at)
         step_no[0] += 1
         slot[0] += 1
         if reducer is not None and r == 0:
@@ -431,25 +532,25 @@ def main():
             slot[0] += R - slot[0] % R
         reducer.wait_all()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     finish_reductions()
-    timing = not args.no_kernel_timing
-    torch.cuda.synchronize()
+    timing = not args.no_kernel_timing and not hostonly
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     finish_reductions()  # every bus of the timed region is fully reduced before the clock stops
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -465,7 +566,7 @@ def main():
         for _ in range(ev_steps):
             step()
         finish_reductions()
-        torch.cuda.synchronize()
+        sync()
         cx.timing_enable(False)
         dom_ms, dom_n = cx.timing_read(0)   # k_leaf_sum (plan 1) / k_chain (plan 2)
         ctl_ms, ctl_n = cx.timing_read(1)   # k_voice_control
@@ -500,7 +601,7 @@ def main():
                 "other_kernels_us_per_step": {"k_voice_control": ctl_ms / max(ctl_n, 1) * 1e3,
                                               "upper_sums+graph_out": up_ms / max(up_n, 1) * 1e3},
             }
-
+    res = None
     if rank == 0:
         total = float(V) * B * K * steps * world
         name, cus, hbm = cx.device_info()
@@ -511,32 +612,225 @@ def main():
                     % (V, args.taps, args.radix),
             "cfg5": "cfg5 shard: %d stereo voices/GPU, sampler->gain->pan->radix-%d sum tree" % (V, args.radix),
         }[wl]
+        if args.voice_fx and wl in ("cfg2", "cfg5"):
+            desc += " + StereoWidth + HardClip in every voice"
+        res = {
+            "value": total / dt,
+            "ms_per_step": dt / steps * 1e3,
+            "steps": steps,
+            "config": {
+                "workload": "%s, block=%d @48kHz, %s sources in HBM (%d frames/voice, looping)"
+                            % (desc, B, "planar f32" if sfmt == "f32" else "interleaved stereo i16", F),
+                "voices_per_gpu": V, "block": B, "blocks_per_step": K, "variant": variant, "master_chain": bool(args.master),
+                "voice_fx": bool(args.voice_fx), "launch_plan": cx.plan_kind(),
+                "parallelism": "voice-shard x%d%s" % (world, (" + RCCL mix-bus %s" % args.bus_reduce) if world > 1 else ""),
+                "realtime_factor": (total / dt) / (48000.0 * V * world),
+                "device": name, "compute_units": cus,
+            },
+            "roofline": roofline,
+        }
+    if full and rank == 0 and world == 1 and not hostonly:
+        if not args.no_realtime and wl != "cfg4":
+            res["realtime_us_per_callback"] = realtime_probe(cx, B)
+        cx.close()
+        if not args.no_parity_check:
+            res["parity_check"] = parity_check(fa, torch, wl, V, B, K, args.radix, rank, args, src, F, sfmt, stream, device)
+        if not args.no_cpu_baseline and sfmt == "f32":
+            res["cpu_baseline"] = cpu_baseline(wl, V, B, args.radix, rank, args, src, F, args.cpu_secs)
+    else:
+        cx.close()
+    del src, outs
+    if not hostonly:
+        torch.cuda.empty_cache()
+    return res
+
+
+def other_configs(env, args):
+    """configs 1, 3, 4, 5 (one shard) in short form, each on the driver-run line next to the headline: a few steps at the
+    config's own size, its roofline, and the same parity check against the oracle (~45 s together)."""
+    out = {}
+    t0 = time.perf_counter()
+    try:
+        out["cfg1"] = run_cfg1(env["fa"], env["torch"].cuda.current_stream().cuda_stream, env["device"])
+    except Exception as ex:  # a broken side config must not take the headline line with it
+        out["cfg1"] = {"error": repr(ex)}
+    for wl, steps in (("cfg3", 12), ("cfg5", 12), ("cfg4", 6)):
+        V, B, K, F, _ = DEFAULTS[wl]
+        try:
+            r = run_workload(env, args, wl, V, B, K, F, steps, 3, full=False)
+            cfg = r["config"]
+            ent = {"workload": cfg["workload"], "value": r["value"], "unit": "voice-samples/s", "ms_per_step": r["ms_per_step"],
+                   "steps": steps, "blocks_per_step": K, "launch_plan": cfg["launch_plan"], "realtime_factor": cfg["realtime_factor"],
+                   "roofline": r["roofline"]}
+            if not args.no_parity_check:
+                torch = env["torch"]
+                gen = torch.Generator(device=env["dev"])
+                gen.manual_seed(env["shard"].voice_seed(0))
+                src = torch.empty((V, 2, F), dtype=torch.float32, device=env["dev"])
+                src.uniform_(-1.0, 1.0, generator=gen)
+                ent["parity_check"] = parity_check(env["fa"], torch, wl, V, B, K, args.radix, 0, args, src, F, "f32",
+                                                   torch.cuda.current_stream().cuda_stream, env["device"])
+                del src
+                torch.cuda.empty_cache()
+            out[wl] = ent
+        except Exception as ex:
+            out[wl] = {"error": repr(ex)}
+    out["secs"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here, one process per GPU, exactly as the
+    driver would (torch.distributed.run, rendezvous on 127.0.0.1).  Rank 0's JSON line is the only thing on stdout."""
+    import socket
+
+    hostonly = bool(os.environ.get("FWGPU_BENCH_HOSTONLY"))
+    if not hostonly:
+        import torch
+
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible on this node" % (args.gpus, n))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(DEFAULTS), default="cfg2",
+                    help="cfg2 = the headline (BASELINE configs[1]); cfg3 / cfg4 / cfg5 = configs[2..4]")
+    ap.add_argument("--voices", type=int, default=None, help="voices per GPU")
+    ap.add_argument("--block", type=int, default=None)
+    ap.add_argument("--radix", type=int, default=32)
+    ap.add_argument("--blocks-per-step", type=int, default=None)
+    ap.add_argument("--src-frames", type=int, default=None, help="source frames per voice (2 ch f32)")
+    ap.add_argument("--cpu-secs", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-realtime", action="store_true")
+    ap.add_argument("--lean", action="store_true",
+                    help="profiling runs: the timed region only (no CPU baseline, parity check, other configs, realtime probe)")
+    ap.add_argument("--taps", type=int, default=65536)
+    ap.add_argument("--source-format", choices=["f32", "i16"], default="f32",
+                    help="cfg2/cfg5 only: planar f32 sources (the headline) or interleaved stereo i16 (4 B per voice-sample)")
+    ap.add_argument("--host-buffers", action="store_true",
+                    help="time fwgpu_process_interleaved on HOST buffers instead (PCIe-inclusive; DESIGN.md §7 note, "
+                         "never the headline)")
+    ap.add_argument("--master", action="store_true",
+                    help="put a master VolumeNode + HardClipNode between the root SumNode and graph_out (the fused plans "
+                         "then run that chain with the generic node kernel on the mix bus)")
+    ap.add_argument("--voice-fx", action="store_true",
+                    help="cfg2/cfg5: a StereoWidthNode + HardClipNode at the end of every voice chain")
+    ap.add_argument("--force-generic", action="store_true",
+                    help="run the workload on the generic level-batched executor (plan 0) instead of its fused plan")
+    ap.add_argument("--variant", choices=["A", "B", "C"], default="A",
+                    help="cfg2/cfg5 (SURVEY 8d): A steady; B one gain change per voice at a seeded block of the run "
+                         "(smoother ramps, message path inside the timed region); C every 4th voice paused (silence masks)")
+    ap.add_argument("--reduce-every", type=int, default=4,
+                    help="N>1: steps whose mix buses share one collective (the reduction of R steps overlaps the next R)")
+    ap.add_argument("--bus-reduce", choices=["allreduce", "ordered"], default="allreduce",
+                    help="N>1: RCCL all-reduce (named path) or all-gather + rank-ordered sum kernel (bit-exact)")
+    args = ap.parse_args()
+    if args.lean:
+        args.no_cpu_baseline = args.no_parity_check = args.no_other_configs = args.no_realtime = True
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    dV, dB, dK, dF, dS = DEFAULTS[args.workload]
+    V = args.voices or dV
+    B = args.block or dB
+    K = args.blocks_per_step or dK
+    F = args.src_frames or dF
+    steps = args.steps or dS
+    wl = args.workload
+    default_shape = (wl == "cfg2" and (V, B, K, F) == (dV, dB, dK, dF) and args.source_format == "f32" and args.variant == "A" and
+                     not (args.master or args.voice_fx or args.force_generic or args.host_buffers))
+
+    # stdout carries exactly ONE line (the JSON, rank 0): everything else that writes to fd 1 — RCCL's version banner
+    # and warnings come from C stdio, flushed whenever — is sent to stderr for the life of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # FWGPU_BENCH_HOSTONLY (CPU test tier only, tests/test_bench_launch.py): the orchestration of this file — launcher,
+    # ranks, reducer, the one JSON line — on the host-only harness library and gloo.  No audio is computed, and the line
+    # says so instead of carrying a value.
+    hostonly = bool(os.environ.get("FWGPU_BENCH_HOSTONLY"))
+    if not hostonly:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product has no CPU path)")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE is %d: launch as many ranks as GPUs (or let --gpus N start them)"
+                         % (args.gpus, world))
+    dist = None
+    ranks_seen = 1
+    if world > 1 or os.environ.get("FWGPU_BENCH_FORCE_DIST"):  # the env var: exercise the RCCL path on one GPU
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if hostonly:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        ranks_seen = dist.get_world_size()
+
+    import firewheel_amd as fa
+    from firewheel_amd import shard
+
+    env = {"torch": torch, "fa": fa, "shard": shard, "dist": dist, "rank": rank, "world": world, "device": 0 if hostonly else local_rank,
+           "dev": "cpu" if hostonly else "cuda", "hostonly": hostonly}
+    res = run_workload(env, args, wl, V, B, K, F, steps, args.warmup, full=True)
+    line = None
+    if rank == 0:
         line = {
             "metric": "stereo voice-samples/sec @ block=256, 48kHz; % HBM roofline; 1/2/4/8 GPU",
-            "value": total / dt,
+            "value": res["value"],
             "unit": "voice-samples/s",
             "n_gpus": world,
             "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / steps * 1e3,
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if not args.host_buffers else "synthetic; output delivered to HOST buffers (PCIe-inclusive)",
-            "config": {
-                "workload": "%s, block=%d @48kHz, %s sources in HBM (%d frames/voice, looping)"
-                            % (desc, B, "planar f32" if sfmt == "f32" else "interleaved stereo i16", F),
-                "voices_per_gpu": V, "block": B, "blocks_per_step": K, "variant": variant, "master_chain": bool(args.master), "parallelism": "voice-shard x%d%s" %
-                (world, (" + RCCL mix-bus %s" % args.bus_reduce) if world > 1 else ""),
-                "realtime_factor": (total / dt) / (48000.0 * V * world),
-                "device": name, "compute_units": cus,
-            },
-            "roofline": roofline,
-            "cpu_baseline": None,
+            "config": res["config"],
+            "roofline": res["roofline"],
+            "cpu_baseline": res.get("cpu_baseline"),
+            "parity_check": res.get("parity_check"),
+            "realtime_us_per_callback": res.get("realtime_us_per_callback"),
+            "rccl_ranks_seen": ranks_seen,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(wl, V, B, args.radix, args.taps, args.cpu_secs)
+        if hostonly:
+            line["value"] = None
+            line["invalid"] = "host-only harness (FWGPU_BENCH_HOSTONLY): orchestration test, no audio computed, not a measurement"
+        if world == 1 and default_shape and not args.no_other_configs and not hostonly:
+            line["other_configs"] = other_configs(env, args)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

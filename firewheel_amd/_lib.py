@@ -76,6 +76,7 @@ SIGNATURES = {
     "fwgpu_sampler_set_loop_range": (ci, [vp, i64, ci, f64, f64, u32]),
     "fwgpu_process_interleaved": (ci, [vp, fp, fp, u32, u32, u64, f64, u32]),
     "fwgpu_process_blocks_device": (ci, [vp, u32, vp, u32]),
+    "fwgpu_bus_sum_ordered": (ci, [vp, C.POINTER(vp), u32, vp, u64]),
     "fwgpu_synchronize": (ci, [vp]),
     "fwgpu_node_process": (ci, [vp, i64, u64, C.POINTER(fp), u32, C.POINTER(fp), u32, u64, C.POINTER(u64), f64, u32]),
     "fwgpu_timing_enable": (ci, [vp, ci]),

@@ -790,6 +790,23 @@ int fwgpu_process_blocks_device(fwgpu_ctx* c, uint32_t num_blocks, float* d_outp
     return run_blocks(c, (uint64_t)num_blocks * c->mbf, nullptr, 0, d_output, (int)n_out_ch);
 }
 
+int fwgpu_bus_sum_ordered(fwgpu_ctx* c, const float* const* d_parts, uint32_t n_parts, float* d_out, uint64_t n_floats) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    AudioCallScope audio;
+    (void)hipSetDevice(c->device);
+    if (n_parts == 0 || n_parts > FW_MAX_BUS_PARTS || !d_parts || !d_out) return fail(c, FWGPU_ERR_INVALID, "1..64 partial buses");
+    BusParts bp;
+    bp.n = (int)n_parts;
+    for (uint32_t r = 0; r < n_parts; ++r) {
+        if (!d_parts[r] || ((uintptr_t)d_parts[r] & 15u)) return fail(c, FWGPU_ERR_INVALID, "partial bus null or not 16-byte aligned");
+        bp.part[r] = d_parts[r];
+    }
+    for (uint32_t r = n_parts; r < FW_MAX_BUS_PARTS; ++r) bp.part[r] = nullptr;
+    if ((uintptr_t)d_out & 15u) return fail(c, FWGPU_ERR_INVALID, "output not 16-byte aligned");
+    LCHK(c, launch_bus_sum_ordered(c->stream, bp, d_out, (size_t)n_floats));
+    return 0;
+}
+
 int fwgpu_synchronize(fwgpu_ctx* c) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     HIPC(c, hipStreamSynchronize(c->stream));

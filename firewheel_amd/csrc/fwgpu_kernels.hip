@@ -141,6 +141,13 @@ int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0,
     else hipLaunchKernelGGL(k_chain<1>, dim3(fv.n_groups, 2), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
     return (int)hipGetLastError();
 }
+int launch_bus_sum_ordered(hipStream_t s, const BusParts& bp, float* d_out, size_t n_floats) {
+    if (bp.n <= 0 || n_floats == 0) return 0;
+    const size_t n4 = n_floats / 4;
+    const size_t threads = n4 ? n4 : 1;
+    hipLaunchKernelGGL(k_bus_sum_ordered, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, bp, d_out, n4, n_floats);
+    return (int)hipGetLastError();
+}
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
     if (fv.n_leaves <= 0) return 0;
     // waves per block: long blocks are cut into 256-frame pieces so that every wave is one short streaming pass

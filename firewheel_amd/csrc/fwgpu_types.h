@@ -195,6 +195,13 @@ struct ChainStart {
 };
 static_assert(sizeof(ChainStart) == 48, "ChainStart layout");
 
+// the top-level SumNode over the partial mix buses of R voice shards (nodes/sum.rs:111-133), passed by value
+#define FW_MAX_BUS_PARTS 64
+struct BusParts {
+    int n;
+    const float* part[FW_MAX_BUS_PARTS];  // part[r] = rank r's interleaved bus (peer-mapped or all-gathered), same length each
+};
+
 #define CH_GROUP_LEAVES 8
 // k_chain workgroup = up to CH_GROUP_LEAVES consecutive leaf SumNodes with at most 32 voices together (their voices are
 // consecutive): a tree of small leaves (a bus per instrument) fills the workgroup's 32 voice rows like one wide leaf

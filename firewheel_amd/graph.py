@@ -478,6 +478,11 @@ class FirewheelGpuCtx(object):
     def process_blocks_device(self, num_blocks, device_out_ptr, num_out_channels=2):
         self._check(self.L.fwgpu_process_blocks_device(self.c, num_blocks, C.c_void_p(device_out_ptr), num_out_channels))
 
+    def bus_sum_ordered(self, part_ptrs, out_ptr, n_floats):
+        """the top-level R-port SumNode over the shards' partial buses (device pointers), rank order, on the ctx stream"""
+        arr = (C.c_void_p * len(part_ptrs))(*[C.c_void_p(p) for p in part_ptrs])
+        self._check(self.L.fwgpu_bus_sum_ordered(self.c, arr, len(part_ptrs), C.c_void_p(out_ptr), n_floats))
+
     def synchronize(self):
         self._check(self.L.fwgpu_synchronize(self.c))
 

@@ -31,8 +31,13 @@ def reduce_bus_allreduce(bus, dist, group=None):
     return bus
 
 
-def ordered_sum(parts, out):
-    """the R-port SumNode over the partial buses, in port (= rank) order, into `out` (may be parts[0])"""
+def ordered_sum(parts, out, cx=None):
+    """the R-port SumNode over the partial buses, in port (= rank) order, into `out` (may be parts[0]).  On the device
+    this is ONE kernel of libfwgpu on the ctx stream (fwgpu_bus_sum_ordered: every part's quad in flight before the
+    first add); host tensors (the gloo tests) take the same sum through torch."""
+    if cx is not None and out.is_cuda:
+        cx.bus_sum_ordered([p.data_ptr() for p in parts], out.data_ptr(), out.numel())
+        return out
     if out is not parts[0]:
         out.copy_(parts[0])         # sum.rs:117 out = in0
     for p in parts[1:]:             # sum.rs:119-131 out += in_p, port order
@@ -55,22 +60,27 @@ class BusReducer(object):
     collective on that buffer asynchronously (RCCL's own stream on a GPU) and `wait(i)` is called only right before
     the buffer is overwritten again — or read.  `mode` as in bench.py: "allreduce" or "ordered" (bit-exact)."""
 
-    def __init__(self, dist, bufs, mode="allreduce", group=None):
+    def __init__(self, dist, bufs, mode="allreduce", group=None, cx=None):
         import torch
 
-        self.dist, self.bufs, self.mode, self.group = dist, list(bufs), mode, group
+        self.dist, self.bufs, self.mode, self.group, self.cx = dist, list(bufs), mode, group, cx
         self.works = [None] * len(self.bufs)
         self.parts = None
         if mode == "ordered":
             world = dist.get_world_size(group)
-            self.parts = [[torch.empty_like(b) for _ in range(world)] for b in self.bufs]
+            # one flat gather buffer per bus buffer: rank r's bus lands in slot r (the slots are what the sum kernel reads)
+            self.flat = [torch.empty(world * b.numel(), dtype=b.dtype, device=b.device) for b in self.bufs]
+            self.parts = [[f[r * b.numel():(r + 1) * b.numel()] for r in range(world)] for f, b in zip(self.flat, self.bufs)]
 
     def submit(self, i):
         assert self.works[i] is None, "buffer %d is still being reduced" % i
         if self.mode == "allreduce":
             self.works[i] = self.dist.all_reduce(self.bufs[i], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            self.works[i] = self.dist.all_gather(self.parts[i], self.bufs[i], group=self.group, async_op=True)
+            if self.bufs[i].is_cuda:
+                self.works[i] = self.dist.all_gather_into_tensor(self.flat[i], self.bufs[i], group=self.group, async_op=True)
+            else:  # gloo (CPU tests)
+                self.works[i] = self.dist.all_gather(self.parts[i], self.bufs[i], group=self.group, async_op=True)
 
     def wait(self, i):
         w = self.works[i]
@@ -79,7 +89,7 @@ class BusReducer(object):
         w.wait()  # on a GPU: the current stream waits for the collective, the host does not block
         self.works[i] = None
         if self.mode == "ordered":
-            ordered_sum(self.parts[i], self.bufs[i])
+            ordered_sum(self.parts[i], self.bufs[i], self.cx)
         return self.bufs[i]
 
     def wait_all(self):

@@ -198,6 +198,13 @@ int fwgpu_process_interleaved(fwgpu_ctx* ctx, const float* input, float* output,
  * sync).  Graphs with num_graph_inputs == 0 only. */
 int fwgpu_process_blocks_device(fwgpu_ctx* ctx, uint32_t num_blocks, float* d_output,
                                 uint32_t num_out_channels);
+/* Multi-GPU: voices shard across ranks with no exchange until the mix bus; the one exchange step is the
+ * top-level SumNode over the R partial buses (nodes/sum.rs:111-133: out = in0; out += in_p, port = rank order).  This
+ * is that node as one kernel on the ctx stream: d_parts[r] = rank r's interleaved bus of `n_floats` floats in memory
+ * this device can read (its own, peer-mapped over xGMI, or the slots of an all-gather), 16-byte aligned; d_out may
+ * alias d_parts[0].  Every rank that runs it over the same parts ends up with the bits of the single-process graph
+ * (an all-reduce does not: ring order re-associates the f32 sum for R > 2).  Asynchronous; R <= 64. */
+int fwgpu_bus_sum_ordered(fwgpu_ctx* ctx, const float* const* d_parts, uint32_t n_parts, float* d_out, uint64_t n_floats);
 int fwgpu_synchronize(fwgpu_ctx* ctx);
 /* ProcInfo::stream_time_secs / stream_status (core/node.rs:111-132) of the most recent fwgpu_process_interleaved call —
  * what a custom node run through fwgpu_node_process inside that call would be handed — and how often the backend has

@@ -2,7 +2,7 @@ cd $GRAFT_REPO_ROOT
 timeout 300 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
 for v in W1 W2 W4 W4U6; do
   for rep in 1 2; do
-    FWGPU_LIB=$GRAFT_REPO_ROOT/firewheel_amd/csrc/var_$v.so timeout 120 python bench.py --steps 60 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+    FWGPU_LIB=$GRAFT_REPO_ROOT/firewheel_amd/csrc/var_$v.so timeout 120 python bench.py --steps 60 --warmup 5 --lean 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
 r = d['roofline']

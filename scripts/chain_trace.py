@@ -21,11 +21,15 @@ import firewheel_amd as fa  # noqa: E402
 V, B, K, F = 4096, 512, 16, 65536
 radix = int(os.environ.get("RADIX", "32"))
 stream = torch.cuda.current_stream().cuda_stream
-cx = fa.FirewheelGpuCtx(48000, B, 0, 2, stream=stream)
-cx.set_max_batch(K)
 src = torch.empty((V, 2, F), dtype=torch.float32, device="cuda").uniform_(-1, 1)
-samplers = bench.build_chain_bank(cx, fa, V, radix)
-bench.start_voices(cx, fa, samplers, src, F)
+
+
+class _Args(object):
+    force_generic = master = voice_fx = False
+    taps = 65536
+
+
+cx, _, samplers, _ = bench.make_gpu(fa, "cfg3", V, B, K, radix, src, F, "f32", 0, _Args, stream, 0)
 out = torch.empty(K * B * 2, dtype=torch.float32, device="cuda")
 for _ in range(3):
     cx.process_blocks_device(K, out.data_ptr(), 2)

@@ -11,9 +11,9 @@ cd /tmp && export TMPDIR=/tmp
 for cfg in $cfgs; do
   steps=20
   out=$root/gpurun_out/raw/${tag}_${cfg}
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats -o s -- python $root/bench.py --workload $cfg --no-cpu-baseline --steps $steps --warmup 3 > ${out}_stats.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats -o s -- python $root/bench.py --workload $cfg --lean --steps $steps --warmup 3 > ${out}_stats.log 2>&1
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d ${out}_$ctr -o p -- python $root/bench.py --workload $cfg --no-cpu-baseline --no-kernel-timing --steps 4 --warmup 2 > ${out}_$ctr.log 2>&1
+    timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d ${out}_$ctr -o p -- python $root/bench.py --workload $cfg --lean --no-kernel-timing --steps 4 --warmup 2 > ${out}_$ctr.log 2>&1
   done
   python $root/scripts/summarise_profiles.py $tag $cfg $steps $out $root/gpurun_out/profiles
 done

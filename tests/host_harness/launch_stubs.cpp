@@ -241,6 +241,13 @@ int launch_voice_control(hipStream_t, const FusedView& fv, int K, uint32_t cmd_b
     if (fv.fx_plan) touch(fv.chain_start, sizeof(ChainStart) * (size_t)fv.n_voices);
     return 0;
 }
+int launch_bus_sum_ordered(hipStream_t, const BusParts& bp, float* d_out, size_t n_floats) {
+    g_launches[7]++;
+    REQUIRE(bp.n >= 1 && bp.n <= FW_MAX_BUS_PARTS, bp.n);
+    for (int r = 0; r < bp.n; ++r) touch(bp.part[r], n_floats * sizeof(float));
+    touch(d_out, n_floats * sizeof(float));
+    return 0;
+}
 int launch_leaf_sum(hipStream_t, const FusedView& fv, int K) {
     g_launches[2]++;
     check_fused_common(fv, K);

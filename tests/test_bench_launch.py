@@ -1,0 +1,56 @@
+"""CPU tier: bench.py's orchestration end to end — `--gpus 2` with no launcher around it starts two ranks itself
+(torch.distributed.run on 127.0.0.1), each builds its shard through the C ABI, the mix buses go through the reducer,
+rank 0 prints exactly ONE JSON line.  Runs on the host-only harness library (FWGPU_BENCH_HOSTONLY: fake HIP runtime,
+no audio computed — the line carries no value and says so) with the gloo backend; what is tested is the launcher,
+the rank plumbing and the line's shape, which the driver's N = 2 / 4 / 8 runs depend on."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import fwapi
+
+ROOT = fwapi.ROOT
+
+
+def run_bench(extra, timeout=600):
+    fwapi.hostonly_lib()  # builds tests/host_harness/_hostonly.so
+    env = dict(os.environ, FWGPU_BENCH_HOSTONLY="1", FWGPU_LIB=os.path.join(ROOT, "tests", "host_harness", "_hostonly.so"))
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2", "--voices", "64", "--block", "64",
+                        "--blocks-per-step", "4", "--src-frames", "1024", "--steps", "5", "--warmup", "2"] + extra,
+                       capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [x for x in r.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, r.stdout  # exactly one line on stdout, whatever the ranks and the launcher print
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "ordered"])
+def test_gpus_2_self_launches_two_ranks_and_prints_one_line(mode):
+    d = run_bench(["--gpus", "2", "--bus-reduce", mode, "--reduce-every", "2"])
+    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2
+    assert d["scaling"] == "weak" and d["steps"] == 5 and d["warmup"] == 2
+    assert d["config"]["parallelism"].startswith("voice-shard x2")
+    assert d["value"] is None and "host-only harness" in d["invalid"]  # no audio was computed: never a measurement
+    assert d["ms_per_step"] > 0
+
+
+def test_single_rank_line_has_the_contract_fields():
+    d = run_bench([])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "parity_check", "rccl_ranks_seen"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["config"]["launch_plan"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
+
+
+def test_gpus_mismatch_with_an_outer_launcher_is_refused():
+    env = dict(os.environ, FWGPU_BENCH_HOSTONLY="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               FWGPU_LIB=os.path.join(ROOT, "tests", "host_harness", "_hostonly.so"))
+    fwapi.hostonly_lib()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

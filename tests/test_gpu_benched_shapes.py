@@ -1,0 +1,288 @@
+"""GPU tier (-m gpu): parity at the launch shapes bench.py actually times — the voice-bank plan at
+768 and 256 blocks per call, the chain plan across its 64-block launch boundary and at config 3's full size, config 5's
+block 1024 at K = 64, config 4 at 65 536 taps with K = 16 and rows in two MFMA row tiles — each against the oracle, bit
+for bit; plus the device ends of the round-2 boundary work (ordered mix-bus kernel, headless stream, ReturnSample,
+per-node B1 message queues, out-of-range loop guards)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fwapi
+import scenarios
+from fwapi import LOOP_FULL, LOOP_RANGE_SECS, PLANAR_F32, GpuEngine, OracleEngine, bits
+from test_gpu_parity import assert_bits_equal, oracle
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+# ------------------------------------------------------------------ voice-bank plan at the benched batch sizes
+def _bank_with_traffic(e, n_voices, blocks, radix=32, src_frames=3000):
+    """config-2 voices under one call of `blocks` blocks with message traffic spread over it: gain changes at blocks 3,
+    ~blocks/2 and blocks-2, a pan change, a pause / resume pair far into the call, a one-shot that ends inside it, a voice
+    that never plays, a mute"""
+    voices = scenarios.build_voice_bank(e, n_voices, radix=radix, src_frames=src_frames, mono_every=9)
+    mid = blocks // 2 + 16
+    for v, vc in enumerate(voices):
+        if v % 7 != 5:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)     # v%7==5: one-shot, ends after src_frames
+        if v % 11 != 4:
+            e.sampler_play(vc["sampler"])                           # v%11==4: paused for the whole call
+        if v % 5 == 0:
+            e.set_param(vc["volume"], 0, 30.0 + v % 50, at_block=3)
+        if v % 5 == 1:
+            e.set_param(vc["volume"], 0, 95.0 - v % 40, at_block=mid)
+        if v % 6 == 2:
+            e.set_param(vc["pan"], 0, -0.7 + (v % 10) / 10.0, at_block=mid + 1)
+        if v % 13 == 3:
+            e.sampler_pause(vc["sampler"], at_block=mid - 9)
+            e.sampler_play(vc["sampler"], at_block=blocks - 40)
+        if v % 17 == 6:
+            e.set_param(vc["sampler"], 0, 0.0, at_block=blocks - 30)   # ramps to 0, then muted
+        if v % 19 == 8:
+            e.set_param(vc["volume"], 0, 12.0, at_block=blocks - 2)
+    return e.process_blocks(blocks)
+
+
+@pytest.mark.parametrize("max_batch", [768, 256])
+def test_voice_bank_plan_at_benched_batch_sizes_with_messages(max_batch):
+    # 64 voices x 768 blocks: k_voice_control's 64-blocks-per-step closed-form fill, messages at block ~400, paused voices,
+    # k_leaf_sum's (leaf, blocks/4) grid — 0.05 s of oracle time
+    blocks = 768
+    o = oracle(max_block_frames=256)
+    g = GpuEngine(max_block_frames=256, max_batch=max_batch)
+    oo = _bank_with_traffic(o, 64, blocks)
+    og = _bank_with_traffic(g, 64, blocks)
+    assert g.cx.plan_kind() == 1
+    assert_bits_equal(oo, og, "64 voices x 768 blocks, max_batch %d" % max_batch)
+    # the call after it starts from the same state on both sides
+    assert_bits_equal(o.process_blocks(5), g.process_blocks(5), "follow-up call")
+
+
+def test_config2_whole_benched_call_matches_the_oracle():
+    # BASELINE configs[1] exactly as bench.py launches it: 1024 voices, ONE call of 768 blocks of 256 frames (0.7 s of oracle)
+    V, blocks, src = 1024, 768, 4096
+    o = oracle(max_block_frames=256)
+    g = GpuEngine(max_block_frames=256, max_batch=768)
+    oo = scenarios.scenario_voice_bank_steady(o, V, blocks, src_frames=src)
+    og = scenarios.scenario_voice_bank_steady(g, V, blocks, src_frames=src)
+    assert g.cx.plan_kind() == 1
+    assert_bits_equal(oo, og, "config 2, 1024 voices x 768 blocks in one call")
+
+
+def test_config5_shard_block_1024_at_k64_matches_the_oracle():
+    # BASELINE configs[4], one GPU's shard, as benched: 8192 voices, block 1024, ONE call of 64 blocks (tree 256 + 8 + 1)
+    V, blocks, src = 8192, 64, 3000
+    o = oracle(max_block_frames=1024)
+    g = GpuEngine(max_block_frames=1024, max_batch=64)
+    oo = scenarios.scenario_voice_bank_steady(o, V, blocks, src_frames=src)
+    og = scenarios.scenario_voice_bank_steady(g, V, blocks, src_frames=src)
+    assert g.cx.plan_kind() == 1
+    assert_bits_equal(oo, og, "config 5 shard, 8192 voices x 64 blocks of 1024")
+
+
+# ------------------------------------------------------------------ chain plan
+def test_chain_plan_130_block_call_spans_three_launches():
+    # k_chain renders at most CH_FAST_KMAX = 64 blocks per launch: a 130-block call is 64 + 64 + 2, with messages landing in
+    # each part and the ChainStart hand-over (delay position, coefficients) between them
+    blocks = 130
+    o = oracle(max_block_frames=128)
+    g = GpuEngine(max_block_frames=128, max_batch=256)
+
+    def run(e):
+        voices = scenarios.build_chain_bank(e, 40, radix=32, src_frames=1700, mono_every=6, first_delay_frames=128,
+                                            min_delay_frames=128, max_delay_frames=1400)
+        for v, vc in enumerate(voices):
+            e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+            if v % 9 != 2:
+                e.sampler_play(vc["sampler"])
+            if v % 4 == 0:
+                e.set_param(vc["volume"], 0, 40.0 + v, at_block=5)
+            if v % 4 == 1:
+                e.set_param(vc["biquad"], 1, 600.0 + 20 * v, at_block=70)     # second launch
+            if v % 4 == 2:
+                e.set_param(vc["delay"], 1, 0.6, at_block=63)                  # last block of the first launch
+                e.set_param(vc["delay"], 2, 0.8, at_block=64)                  # first block of the second
+            if v % 4 == 3:
+                e.set_param(vc["volume"], 0, 25.0, at_block=129)               # third launch
+            if v % 9 == 2:
+                e.sampler_play(vc["sampler"], at_block=100)
+        return np.concatenate([e.process_blocks(blocks), e.process_blocks(70)])
+
+    oo, og = run(o), run(g)
+    assert g.cx.plan_kind() == 2
+    assert_bits_equal(oo, og, "chain plan, 130-block call")
+
+
+def test_config3_full_size_call_matches_the_oracle():
+    # BASELINE configs[2] as benched: 4096 voices (sampler -> biquad -> delay -> gain), block 512, ONE call of 64 blocks on the
+    # radix-32 tree (128 + 4 + 1); delays of 10..250 ms like bench.py (1.5 s of oracle time)
+    V, blocks = 4096, 64
+    kw = dict(radix=32, src_frames=2048, first_delay_frames=480, min_delay_frames=480, max_delay_frames=12000)
+    o = oracle(max_block_frames=512)
+    g = GpuEngine(max_block_frames=512, max_batch=64)
+    oo = scenarios.scenario_chain_steady(o, V, blocks, **kw)
+    og = scenarios.scenario_chain_steady(g, V, blocks, **kw)
+    assert g.cx.plan_kind() == 2
+    assert_bits_equal(oo, og, "config 3, 4096 voices x 64 blocks of 512")
+    steady, general = g.cx.plan_chain_stats()
+    assert steady + general == 2 * 128                      # one launch: 128 leaf groups x 2 channels
+    assert_bits_equal(o.process_blocks(64), g.process_blocks(64), "second call (steady-call loop)")
+    steady2, _ = g.cx.plan_chain_stats()
+    assert steady2 - steady == 2 * 128                      # ... which every workgroup ran on the steady-call loop
+
+
+# ------------------------------------------------------------------ FIR bank at the real size
+def test_config4_real_size_65536_taps_k16_two_row_tiles_matches_the_oracle():
+    # BASELINE configs[3]'s kernel shape: 65 536 taps = 17 split-K segments, K = 16 blocks per launch, 18 stereo voices = 36
+    # rows = two 32-row MFMA tiles (the second one padded).  17 blocks: one K = 16 launch + one K = 1 launch.  The oracle
+    # evaluates the same segment order with scalar fmaf: 18 voices x 17 blocks x 27 ms = 8 s.
+    taps, frames, V, blocks = 65536, 256, 18, 17
+    h = scenarios.reverb_ir(77, taps, 2, decay=16384.0)
+
+    def run(e):
+        ir = e.new_sample(PLANAR_F32, 2, h)
+        m = e.sum(V)
+        ss = []
+        for v in range(V):
+            s = e.sampler(60.0 + v)
+            f = e.fir(ir)
+            e.connect_stereo(s, f)
+            e.connect_stereo(f, m, 2 * v)
+            ss.append(s)
+        e.connect_stereo(m, e.graph_out_node)
+        e.update()
+        for v, s in enumerate(ss):
+            e.sampler_set_sample(s, e.new_sample(PLANAR_F32, 2, scenarios.voice_source(4400 + v, 1500)))
+            if v % 3:
+                e.sampler_set_loop_range(s, LOOP_FULL)      # v%3==0: one-shot, the tail keeps convolving zeros
+            e.sampler_play(s)
+        return e.process_blocks(blocks)
+
+    g = GpuEngine(max_block_frames=frames, max_batch=16)
+    og = run(g)
+    assert g.cx.plan_kind() == 0
+    oo = run(OracleEngine(max_block_frames=frames))
+    assert_bits_equal(oo, og, "65536-tap FIR bank, K = 16, 36 rows")
+
+
+# ------------------------------------------------------------------ multi-GPU: the ordered mix-bus kernel
+@pytest.mark.parametrize("parts,n", [(2, 4096), (4, 1000), (8, 12345), (64, 260), (3, 3)])
+def test_bus_sum_ordered_kernel_is_the_port_ordered_sum(parts, n):
+    import torch
+
+    rng = np.random.default_rng(parts * 1000 + n)
+    host = [(rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4, n)).astype(f32) for _ in range(parts)]
+    want = host[0].copy()
+    for p in host[1:]:
+        want = (want + p).astype(f32)      # sum.rs:117-131: out = in0; out += in_p, one rounding per port
+    g = GpuEngine()
+    dev = [torch.from_numpy(np.concatenate([h, np.zeros((-n) % 4, f32)])).cuda() for h in host]   # (16-byte aligned bases)
+    out = torch.empty(n + (-n) % 4, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    g.cx.bus_sum_ordered([d.data_ptr() for d in dev], out.data_ptr(), n)
+    g.cx.synchronize()
+    assert_bits_equal(want, out.cpu().numpy()[:n], "%d parts" % parts)
+    # in place into part 0, as BusReducer does
+    g.cx.bus_sum_ordered([d.data_ptr() for d in dev], dev[0].data_ptr(), n)
+    g.cx.synchronize()
+    assert_bits_equal(want, dev[0].cpu().numpy()[:n], "%d parts, in place" % parts)
+
+
+# ------------------------------------------------------------------ boundary pieces on the device
+def test_headless_stream_on_the_device_matches_oracle_audio_and_flags():
+    o = scenarios.TaggedOracle(OracleEngine(max_block_frames=128))
+    g = GpuEngine(max_block_frames=128, max_batch=4)
+    for e in (o, g):
+        voices = scenarios.build_voice_bank(e, 20, radix=8, src_frames=900)
+        for vc in voices:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+            e.sampler_play(vc["sampler"])
+    st = g.cx.open_stream(0, 2)
+    L = fwapi.oracle_lib()
+    ost = L.fwo_stream_new(o.e.c, 48000, 0, 2)
+    t, period = 7.0, 128 / 48000.0
+    ref = np.zeros(128 * 2, f32)
+    for i in range(60):
+        t += period * (2.0 if i in (20, 41) else 1.0)          # two late callbacks
+        out, status = st.callback(128, t)
+        ostatus = L.fwo_stream_callback(ost, ref.ctypes.data_as(C.POINTER(C.c_float)), 128, t, None)
+        assert status == ostatus
+        assert_bits_equal(ref, out, "callback %d" % i)
+    assert st.stats()[1] == 2 and g.cx.proc_info()[2] == 2
+    L.fwo_stream_free(ost)
+
+
+def test_b1_two_nodes_interleaved_messages_match_the_oracle():
+    # node A's process() must not swallow node B's queued messages (one queue per node in the reference)
+    o = OracleEngine(max_block_frames=64)
+    g = GpuEngine(max_block_frames=64)
+    x = [fwapi.xorshift_uniform(1, 64), fwapi.xorshift_uniform(2, 64)]
+    nodes = {}
+    for e in (o, g):
+        a, b = e.volume(80.0), e.volume(40.0)
+        e.connect_stereo(a, b)
+        e.connect_stereo(b, e.graph_out_node)
+        e.update()
+        nodes[e.backend] = (a, b)
+
+    def step(e, which, msgs=()):
+        for node, val in msgs:
+            e.set_param(nodes[e.backend][node], 0, val)
+        return e.node_process(nodes[e.backend][which], 64, x, 2)
+
+    script = [(0, [(1, 10.0)]), (0, []), (1, []), (0, [(0, 55.0), (1, 70.0)]), (1, []), (1, []), (0, []), (0, []), (1, [])]
+    for i, (which, msgs) in enumerate(script):
+        yo, mo = step(o, which, msgs)
+        yg, mg = step(g, which, msgs)
+        assert mo == mg
+        assert_bits_equal(yo, yg, "step %d (node %d)" % (i, which))
+
+
+def test_returned_samples_wait_for_the_device():
+    g = GpuEngine(max_block_frames=256, max_batch=64)
+    voices = scenarios.build_voice_bank(g, 8, radix=8, src_frames=2000)
+    for vc in voices:
+        g.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        g.sampler_play(vc["sampler"])
+    g.process_blocks(4)
+    assert g.cx.poll_returned_samples() == []
+    first = voices[0]["sample"]
+    assert not g.cx.sample_retired(first)
+    new = g.new_sample(PLANAR_F32, 2, scenarios.voice_source(99, 500))
+    g.sampler_set_sample(voices[0]["sampler"], new, at_block=2)
+    out = g.process_blocks(8)                    # synchronous: the call has completed when it returns
+    assert g.cx.poll_returned_samples() == [(voices[0]["sampler"], first)]
+    assert g.cx.sample_retired(first)
+    g.cx.destroy_sample(first)
+    assert np.all(np.isfinite(out))
+    g.process_blocks(4)
+
+
+def test_loop_ranges_outside_the_sample_play_silence_and_never_fault():
+    # ADVICE r1 (outside the parity domain, Q8: the reference panics): RangeSecs past the sample, start > end, a swap to a
+    # shorter sample under a RangeSecs loop, a loop shorter than a block that would run past the sample end
+    sr = 48000.0
+    for force_generic in (False, True):
+        g = GpuEngine(max_block_frames=256, max_batch=8, force_generic=force_generic)
+        voices = scenarios.build_voice_bank(g, 6, radix=8, src_frames=1000)
+        short = g.new_sample(PLANAR_F32, 2, scenarios.voice_source(5, 300))
+        for vc in voices:
+            g.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+            g.sampler_play(vc["sampler"])
+        g.process_blocks(2)
+        s = [vc["sampler"] for vc in voices]
+        g.sampler_set_loop_range(s[0], LOOP_RANGE_SECS, 100 / sr, 5000 / sr)        # end far past the 1000-frame sample
+        g.sampler_set_loop_range(s[1], LOOP_RANGE_SECS, 900 / sr, 100 / sr)         # start > end
+        g.sampler_set_loop_range(s[2], LOOP_RANGE_SECS, 200 / sr, 900 / sr)
+        g.sampler_set_sample(s[2], short, at_block=1)                                # ... then a 300-frame sample under it
+        g.sampler_set_loop_range(s[3], LOOP_RANGE_SECS, 990 / sr, 999 / sr)         # 9-frame loop: second copy runs past the end
+        g.sampler_set_loop_range(s[4], LOOP_RANGE_SECS, 1e12, 2e12)                 # saturating conversions
+        out = g.process_blocks(8)
+        assert np.all(np.isfinite(out)) and np.max(np.abs(out)) < 8.0
+        ok = g.process_blocks(4)                                                     # voice 5 keeps playing
+        assert np.any(ok)
+        # a valid range again: the voice comes back
+        g.sampler_set_loop_range(s[1], LOOP_FULL)
+        assert np.all(np.isfinite(g.process_blocks(3)))

@@ -1,0 +1,203 @@
+//! firewheel-gpu — the reference-side binding of libfwgpu (include/fwgpu.h).
+//!
+//! Two levels, as in INTEGRATION.md:
+//! * **B2** ([`GpuContext`] + [`GpuProcessor`]): the whole `FirewheelProcessor::process_interleaved`
+//!   (firewheel-graph/src/processor.rs:61-165) runs on the device.  Firewheel keeps its `AudioGraph` and its scheduler;
+//!   after every successful compile the `CompiledSchedule` is handed over with [`GpuContext::upload_schedule`].
+//! * **B1** ([`nodes`]): each built-in node as an `AudioNode` whose processor half forwards
+//!   `AudioNodeProcessor::process` (firewheel-core/src/node.rs:37-53) to `fwgpu_node_process` — the literal trait
+//!   drop-in, for graphs that mix GPU nodes with custom Rust nodes.
+//!
+//! SOURCE ONLY here: never compiled in the repository that ships it (no Rust toolchain in its build image).
+pub mod ffi;
+pub mod nodes;
+pub mod sample;
+pub mod stream;
+
+use std::ffi::CStr;
+use std::fmt;
+use std::ptr::NonNull;
+use std::sync::Arc;
+
+/// Error of a libfwgpu call: the negative code of `enum fwgpu_error` + `fwgpu_last_error`.
+#[derive(Debug, Clone)]
+pub struct GpuError {
+    pub code: i32,
+    pub message: String,
+}
+impl fmt::Display for GpuError {
+    fn fmt(&self, f: &mut fmt::Formatter<'_>) -> fmt::Result {
+        write!(f, "fwgpu error {}: {}", self.code, self.message)
+    }
+}
+impl std::error::Error for GpuError {}
+
+/// Owner of one `fwgpu_ctx`.  Shared (`Arc`) between the control side (graph edits, node handles, sample handles) and the
+/// one audio-side [`GpuProcessor`]; the C ABI's threading contract (fwgpu.h) is what makes that sound: message calls may
+/// overlap a process call, edit / update / sample-table calls are serialised with it by the owner of the `GpuProcessor`
+/// exactly as Firewheel serialises schedule hand-over (graph/context.rs:93-137).
+pub struct GpuContext {
+    raw: NonNull<ffi::fwgpu_ctx>,
+    pub sample_rate: u32,
+    pub max_block_frames: u32,
+}
+// the ctx is internally synchronised for the call pairs the contract allows
+unsafe impl Send for GpuContext {}
+unsafe impl Sync for GpuContext {}
+
+impl GpuContext {
+    /// `FirewheelGraphCtx::new` + `activate` (graph/context.rs:35-82) for the device executor.
+    pub fn new(
+        device: i32,
+        sample_rate: u32,
+        max_block_frames: u32,
+        num_graph_inputs: u32,
+        num_graph_outputs: u32,
+    ) -> Result<Arc<Self>, GpuError> {
+        let raw = unsafe {
+            ffi::fwgpu_ctx_create(
+                device,
+                sample_rate,
+                max_block_frames,
+                num_graph_inputs,
+                num_graph_outputs,
+                std::ptr::null_mut(),
+            )
+        };
+        match NonNull::new(raw) {
+            Some(raw) => Ok(Arc::new(Self { raw, sample_rate, max_block_frames })),
+            None => Err(GpuError {
+                code: ffi::FWGPU_ERR_DEVICE,
+                message: unsafe { CStr::from_ptr(ffi::fwgpu_create_error()) }.to_string_lossy().into_owned(),
+            }),
+        }
+    }
+
+    pub fn as_ptr(&self) -> *mut ffi::fwgpu_ctx {
+        self.raw.as_ptr()
+    }
+
+    pub(crate) fn check(&self, rc: i64) -> Result<i64, GpuError> {
+        if rc >= 0 {
+            return Ok(rc);
+        }
+        Err(GpuError {
+            code: rc as i32,
+            message: unsafe { CStr::from_ptr(ffi::fwgpu_last_error(self.as_ptr())) }.to_string_lossy().into_owned(),
+        })
+    }
+
+    /// `AudioGraph::add_node` (graph/graph.rs:201-231) for a built-in node kind; `params` are its constructor arguments.
+    pub fn add_node(&self, kind: i32, num_inputs: u32, num_outputs: u32, params: &[f32]) -> Result<i64, GpuError> {
+        self.check(unsafe {
+            ffi::fwgpu_add_node(self.as_ptr(), kind, num_inputs, num_outputs, params.as_ptr(), params.len() as i32)
+        })
+    }
+    pub fn remove_node(&self, node: i64) -> Result<(), GpuError> {
+        self.check(unsafe { ffi::fwgpu_remove_node(self.as_ptr(), node) } as i64).map(|_| ())
+    }
+    /// `AudioGraph::connect` (graph/graph.rs:396-477); the error codes are the `AddEdgeError` variants.
+    pub fn connect(&self, src: i64, src_port: u32, dst: i64, dst_port: u32, check_for_cycles: bool) -> Result<i64, GpuError> {
+        self.check(unsafe { ffi::fwgpu_connect(self.as_ptr(), src, src_port, dst, dst_port, check_for_cycles as i32) })
+    }
+    pub fn graph_in_node(&self) -> i64 {
+        unsafe { ffi::fwgpu_graph_in_node(self.as_ptr()) }
+    }
+    pub fn graph_out_node(&self) -> i64 {
+        unsafe { ffi::fwgpu_graph_out_node(self.as_ptr()) }
+    }
+    /// `FirewheelGraphCtx::update` (graph/context.rs:93-137) when the graph is mirrored with `add_node` / `connect`.
+    pub fn update(&self) -> Result<(), GpuError> {
+        self.check(unsafe { ffi::fwgpu_update(self.as_ptr()) } as i64).map(|_| ())
+    }
+    /// Blocks one launch sequence may cover (a realtime host never needs more than one; an offline bounce wants many).
+    pub fn set_max_batch(&self, blocks: u32) -> Result<(), GpuError> {
+        self.check(unsafe { ffi::fwgpu_set_max_batch(self.as_ptr(), blocks) } as i64).map(|_| ())
+    }
+
+    /// Hand Firewheel's own `CompiledSchedule` over (keep the Rust scheduler): one entry per `ScheduledNode`
+    /// (graph/graph/compiler/schedule.rs:12-30) in schedule order, `ids` maps Firewheel `NodeID`s to the ids
+    /// `add_node` returned.  Called from `FirewheelGraphCtx::update` right after `graph.compile()` succeeded
+    /// (graph/context.rs:118-126).
+    pub fn upload_schedule<'a, I>(&self, schedule: I, num_buffers: usize) -> Result<(), GpuError>
+    where
+        I: IntoIterator<Item = ScheduledNodeView<'a>>,
+    {
+        let views: Vec<ScheduledNodeView<'a>> = schedule.into_iter().collect();
+        let nodes: Vec<ffi::fwgpu_sched_node> = views
+            .iter()
+            .map(|v| ffi::fwgpu_sched_node {
+                node: v.node,
+                num_inputs: v.in_buffer_index.len() as u32,
+                num_outputs: v.out_buffer_index.len() as u32,
+                in_buffer_index: v.in_buffer_index.as_ptr(),
+                in_should_clear: v.in_should_clear.as_ptr(),
+                out_buffer_index: v.out_buffer_index.as_ptr(),
+            })
+            .collect();
+        self.check(unsafe {
+            ffi::fwgpu_schedule_upload(self.as_ptr(), nodes.as_ptr(), nodes.len() as u32, num_buffers as u32)
+        } as i64)
+        .map(|_| ())
+    }
+
+    /// 0 = generic level-batched executor, 1 = fused voice-bank plan, 2 = fused chain plan.
+    pub fn plan_kind(&self) -> i32 {
+        unsafe { ffi::fwgpu_plan_kind(self.as_ptr()) }
+    }
+}
+
+impl Drop for GpuContext {
+    fn drop(&mut self) {
+        unsafe { ffi::fwgpu_ctx_destroy(self.as_ptr()) }
+    }
+}
+
+/// Borrowed view of one `ScheduledNode`: `InBufferAssignment { buffer_index, should_clear }` split into two slices.
+pub struct ScheduledNodeView<'a> {
+    pub node: i64,
+    pub in_buffer_index: &'a [u32],
+    pub in_should_clear: &'a [u8],
+    pub out_buffer_index: &'a [u32],
+}
+
+/// The audio-thread half: what `FirewheelProcessor` is to `FirewheelGraphCtx`.  `Send`, not `Sync` — one audio thread.
+pub struct GpuProcessor {
+    cx: Arc<GpuContext>,
+}
+impl GpuProcessor {
+    pub fn new(cx: Arc<GpuContext>) -> Self {
+        Self { cx }
+    }
+
+    /// `FirewheelProcessor::process_interleaved` (graph/processor.rs:61-165), same arguments.  `output` is filled on
+    /// every return (zeros on error: core/node.rs:41-42 — libfwgpu does that itself).
+    pub fn process_interleaved(
+        &mut self,
+        input: &[f32],
+        output: &mut [f32],
+        num_in_channels: usize,
+        num_out_channels: usize,
+        frames: usize,
+        stream_time_secs: f64,
+        stream_status: firewheel_core::node::StreamStatus,
+    ) -> firewheel_graph::processor::FirewheelProcessorStatus {
+        debug_assert!(output.len() >= frames * num_out_channels);
+        let rc = unsafe {
+            ffi::fwgpu_process_interleaved(
+                self.cx.as_ptr(),
+                if input.is_empty() { std::ptr::null() } else { input.as_ptr() },
+                output.as_mut_ptr(),
+                num_in_channels as u32,
+                num_out_channels as u32,
+                frames as u64,
+                stream_time_secs,
+                stream_status.bits(),
+            )
+        };
+        if rc < 0 {
+            log::error!("fwgpu_process_interleaved failed: {}", rc);
+        }
+        firewheel_graph::processor::FirewheelProcessorStatus::Ok
+    }
+}

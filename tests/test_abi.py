@@ -70,31 +70,60 @@ def test_header_is_plain_c99_and_the_c_host_builds(lib):
     assert os.path.exists(os.path.join(ROOT, "examples", "host_c", "fw_host"))
 
 
-def test_rust_binding_block_of_integration_md_matches_the_header():
-    """INTEGRATION.md shows the `extern "C"` block a Firewheel maintainer would add (no rustc here to compile it): every
-    function it declares must exist in include/fwgpu.h with the same number of parameters and a compatible return type."""
+def test_rust_crate_ffi_matches_the_header():
+    """rust/firewheel-gpu is the reference-side binding shipped as a real source crate (no rustc here to compile it).  Its
+    src/ffi.rs is generated from include/fwgpu.h: the committed file must be exactly what the generator produces now, must
+    declare every function of the header with the same parameter count, and every `ffi::fwgpu_*` the hand-written wrapper
+    modules call must be a declared function used with the declared number of arguments."""
     import re
+    import subprocess
+    import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    md = open(os.path.join(root, "INTEGRATION.md")).read()
-    hdr = open(os.path.join(root, "include", "fwgpu.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    crate = os.path.join(root, "rust", "firewheel-gpu")
+    for f in ("Cargo.toml", "build.rs", "src/lib.rs", "src/ffi.rs", "src/nodes.rs", "src/sample.rs", "src/stream.rs"):
+        assert os.path.exists(os.path.join(crate, f)), f
+    assert subprocess.call([sys.executable, os.path.join(root, "scripts", "gen_rust_ffi.py"), "--check"]) == 0, \
+        "rust/firewheel-gpu/src/ffi.rs is stale: run python scripts/gen_rust_ffi.py"
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "fwgpu.h")).read(), flags=re.S)
     c_decl = {}
-    for m in re.finditer(r"([A-Za-z_][A-Za-z_0-9 \*]*?)\b(fwgpu_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+    for m in re.finditer(r"^([A-Za-z_][A-Za-z_0-9 \*]*?)\b(fwgpu_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S | re.M):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
-        c_decl[name] = (ret, 0 if args in ("", "void") else len(args.split(",")))
-    block = md[md.index('extern "C" {'):]
-    block = block[:block.index("\n}")]
-    rust = re.findall(r"pub fn (fwgpu_[a-z_0-9]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S)
-    assert len(rust) >= 25
-    ret_ok = {"c_int": ("int",), "i64": ("int64_t",), "*const c_char": ("const char*", "const char *"),
-              "*mut fwgpu_ctx": ("fwgpu_ctx*", "fwgpu_ctx *"), None: ("void",)}
-    for name, args, ret in rust:
-        assert name in c_decl, "%s is not in fwgpu.h" % name
-        n_args = len([a for a in args.split(",") if a.strip()])
-        assert n_args == c_decl[name][1], (name, n_args, c_decl[name][1])
-        r = ret.strip() if ret else None
-        assert c_decl[name][0] in ret_ok[r], (name, r, c_decl[name][0])
+        if ret.startswith("typedef"):
+            continue
+        c_decl[name] = 0 if args in ("", "void") else len(args.split(","))
+    assert set(c_decl) == set(_lib.SIGNATURES)
+    ffi = open(os.path.join(crate, "src", "ffi.rs")).read()
+    rust = dict((n, len([a for a in args.split(",") if a.strip()]))
+                for n, args in re.findall(r"pub fn (fwgpu_[a-z_0-9]+)\s*\(([^)]*)\)", ffi))
+    assert rust == c_decl
+    # the wrappers: every call site names a declared function and passes as many arguments as it takes
+    calls = 0
+    for f in ("lib.rs", "nodes.rs", "sample.rs", "stream.rs"):
+        src = open(os.path.join(crate, "src", f)).read()
+        src = re.sub(r"//[^\n]*", "", src)
+        for m in re.finditer(r"ffi::(fwgpu_[a-z_0-9]+)\s*\(", src):
+            name = m.group(1)
+            assert name in c_decl, (f, name)
+            depth, i, n_args, any_tok = 1, m.end(), 0, False
+            while depth:
+                ch = src[i]
+                if ch in "([{":
+                    depth += 1
+                elif ch in ")]}":
+                    depth -= 1
+                elif ch == "," and depth == 1:
+                    n_args += 1
+                    any_tok = False
+                    i += 1
+                    continue
+                if depth and not ch.isspace():
+                    any_tok = True
+                i += 1
+            n_args += 1 if any_tok else 0
+            assert n_args == c_decl[name], (f, name, n_args, c_decl[name])
+            calls += 1
+    assert calls >= 25
 
 
 def test_the_product_never_loads_the_oracle_or_the_test_harnesses():

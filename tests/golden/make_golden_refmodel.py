@@ -1,0 +1,37 @@
+"""Regenerates tests/golden/refmodel_digests.json from the INDEPENDENT numpy model (tests/refmodel.py: a second
+restatement of the reference's graph level, written from the .rs files, sharing no code with oracle/fw_oracle.cpp) — for
+every parity scenario whose nodes the model covers (no BeepTest / FIR / resampler).  The oracle must reproduce these
+digests (tests/test_refmodel_differential.py, CPU tier) and so must the HIP path (tests/test_gpu_parity.py, GPU tier).
+Run: python tests/golden/make_golden_refmodel.py"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import refmodel  # noqa: E402
+import scenarios  # noqa: E402
+import test_scenarios_oracle as t  # noqa: E402
+
+UNSUPPORTED = ("mixed_generic", "cfg4_reverb", "cfg4_reverb_2irs_mono", "spatial_scene", "spatial_scene_b96")
+
+
+def model_cases():
+    return sorted(n for n in t.CASES if n not in UNSUPPORTED)
+
+
+def run_on_model(name):
+    saved = t.oracle
+    t.oracle = lambda **kw: scenarios.TaggedOracle(refmodel.RefEngine(**kw))  # the scenarios build on whatever `oracle()` returns
+    try:
+        return t.CASES[name]()
+    finally:
+        t.oracle = saved
+
+
+if __name__ == "__main__":
+    out = {name: t.digest(run_on_model(name)) for name in model_cases()}
+    json.dump(out, open(os.path.join(HERE, "refmodel_digests.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1))

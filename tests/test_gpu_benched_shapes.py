@@ -286,3 +286,29 @@ def test_loop_ranges_outside_the_sample_play_silence_and_never_fault():
         # a valid range again: the voice comes back
         g.sampler_set_loop_range(s[1], LOOP_FULL)
         assert np.all(np.isfinite(g.process_blocks(3)))
+
+
+# ------------------------------------------------------------------ digests generated from the INDEPENDENT numpy model
+def _model_cases():
+    import sys
+    import os
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_refmodel as mg
+
+    return mg.model_cases()
+
+
+@pytest.mark.parametrize("name", _model_cases())
+def test_hip_path_reproduces_the_independent_models_golden_digests(name):
+    # tests/golden/refmodel_digests.json comes from tests/refmodel.py (numpy, written from the .rs files, no code shared with
+    # the oracle): the HIP path must hit the same bits without the oracle in between
+    import json
+    import os
+
+    from test_gpu_parity import run_case
+    from test_scenarios_oracle import digest
+
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refmodel_digests.json")))
+    _, out_g, g = run_case(name)
+    assert digest(out_g) == gold[name], name

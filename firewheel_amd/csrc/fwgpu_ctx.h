@@ -149,6 +149,8 @@ struct fwgpu_ctx {
     int n_groups = 0;  // k_chain workgroups (groups of consecutive leaves)
     DevBuf d_groups;
     uint32_t epoch = 1;  // invalidates every VoiceCache when bumped (plan install, sample-table change)
+    bool fused_prog = false;  // the voice-bank plan carries stage programs (k_leaf_sum<true>)
+    DevBuf d_progs;
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start, d_chain_dummy, d_chain_stats;
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
     std::vector<int> up_level_off, up_level_cnt;
@@ -272,6 +274,8 @@ struct FusedBuild {
     std::vector<int> tail_in, tail_out;
     int n_bus = 1;
     int max_stages = 0;
+    std::vector<uint32_t> progs;  // per voice: its chain stages' kinds (SK_*), 4 bits each
+    bool has_prog = false;        // a width / hard-clip stage somewhere: the leaf kernel's program instantiation
     bool has_fx = false;  // some chain holds a biquad / delay: the k_chain plan
     uint64_t min_delay = ~0ull;  // shortest delay line among the chains (frames)
 };

@@ -158,7 +158,8 @@ int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
 #else
     dim3 grid((fv.n_leaves + LEAF_WPB - 1) / LEAF_WPB, K);
 #endif
-    hipLaunchKernelGGL(k_leaf_sum, grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
+    if (fv.has_prog) hipLaunchKernelGGL(k_leaf_sum<true>, grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
+    else hipLaunchKernelGGL(k_leaf_sum<false>, grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
     return (int)hipGetLastError();
 }
 

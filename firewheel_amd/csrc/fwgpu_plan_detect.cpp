@@ -111,6 +111,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
                 memset(&vd, 0, sizeof(vd));
                 vd.sampler_state = vd.bq_state = vd.dl_state = -1;
                 fb.voices.push_back(vd);
+                fb.progs.push_back(0u);
                 continue;
             }
             // walk upstream: end -> ... -> sampler
@@ -127,8 +128,9 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
                     break;
                 }
                 if (n.n_in != 2 || n.n_out != 2) return false;
-                if (n.kind == K_VOLUME || n.kind == K_PAN) {
+                if (n.kind == K_VOLUME || n.kind == K_PAN || n.kind == K_WIDTH || n.kind == K_HARD_CLIP) {
                     if (bq >= 0 || dl >= 0) return false;  // gain stages before the filter: generic executor
+                    if (n.kind == K_WIDTH || n.kind == K_HARD_CLIP) fb.has_prog = true;
                     chain.push_back(cur);
                 } else if (n.kind == K_DELAY) {
                     if (bq >= 0 || dl >= 0) return false;
@@ -154,11 +156,14 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
             if (bq >= 0 || dl >= 0) fb.has_fx = true;
             vd.sampler_state = (int)plan.nodes[cur].slot;
             vd.n_stages = (int)chain.size();
+            uint32_t prog = 0;
             for (int j = 0; j < vd.n_stages; ++j) {  // schedule order: nearest the sampler first
                 const PlanNode& n = plan.nodes[chain[chain.size() - 1 - j]];
                 vd.stage_kind[j] = n.kind;
                 vd.stage_state[j] = (int)n.slot;
+                prog |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : SK_GAIN) << (4 * j);
             }
+            fb.progs.push_back(prog);
             fb.max_stages = std::max(fb.max_stages, vd.n_stages);
             fb.voices.push_back(vd);
         }
@@ -229,8 +234,8 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
     fb.root_buf[0] = rb;
     fb.root_buf[1] = rb + 1;
     fb.n_bus = next_bus;
-    if (fb.has_fx) {  // k_chain: whole tiles, one workgroup per leaf of <= 32 voices
-        if (mbf % 64 != 0) return false;
+    if (fb.has_fx) {  // k_chain: whole tiles, one workgroup per leaf of <= 32 voices, gain stages only behind the filter / delay
+        if (mbf % 64 != 0 || fb.has_prog || fb.max_stages > FW_CHAIN_STAGES - 1) return false;
         for (const LeafDesc& l : fb.leaves)
             if (l.ports > 32) return false;
     }

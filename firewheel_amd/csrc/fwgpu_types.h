@@ -93,11 +93,19 @@ struct Cmd {
 static_assert(sizeof(Cmd) == 40, "Cmd layout");
 
 // ---------------------------------------------------------------- fused voice-bank plan
-#define FW_MAX_STAGES 4  // sampler gain + up to 3 chain nodes (volume / pan)
+#define FW_MAX_STAGES 6    // sampler gain + up to 5 chain nodes (volume / pan / width / hard clip) in any order
+#define FW_CHAIN_STAGES 4  // what k_chain keeps in registers: sampler gain + up to 3 gain stages behind the biquad / delay
+// what a chain stage does to the voice's two channels (4 bits per stage in FusedView::progs[voice], stage 1 in bits 0..3);
+// the stage's values sit in the gain set: g[j][0], g[j][1]
+enum : uint32_t {
+    SK_GAIN = 0,   // volume / pan:  L *= g0;  R *= g1                                   (volume.rs:123-126)
+    SK_WIDTH = 1,  // stereo width:  m = (L+R)*0.5; s = ((L-R)*0.5)*g0;  L = m+s; R = m-s (SPEC)
+    SK_CLIP = 2,   // hard clip:     x = max(min(x, g0), -g0) on both channels            (hard_clip.rs:70-76)
+};
 
-struct VoiceDesc {  // static per voice chain: sampler -> [biquad] -> [delay] -> [volume|pan]* -> leaf sum port
+struct VoiceDesc {  // static per voice chain: sampler -> [biquad] -> [delay] -> [volume|pan|width|hard clip]* -> leaf sum port
     int sampler_state;
-    int n_stages;                      // GAIN stages (volume / pan) after the sampler
+    int n_stages;                      // chain stages after the sampler (and after the biquad / delay, if any)
     int stage_kind[FW_MAX_STAGES - 1];
     int stage_state[FW_MAX_STAGES - 1];
     int bq_state;                      // biquad between the sampler and the gain stages, -1 = none (k_chain plan)
@@ -127,7 +135,7 @@ struct VoiceBlk {
     uint32_t pad;
     float g[FW_MAX_STAGES][2];  // constant gains per stage and channel (used when the ramp bit is clear)
 };
-static_assert(sizeof(VoiceBlk) == 80, "VoiceBlk layout");
+static_assert(sizeof(VoiceBlk) == 96, "VoiceBlk layout");
 
 // Compact per (block, voice) record (16 B): all the leaf kernel needs for silent and VB_SIMPLE blocks.  Only
 // blocks that are neither (ramps, loop wrap, one-shot tail, non-planar-f32 sources) also get a full VoiceBlk.
@@ -161,7 +169,7 @@ struct VoiceCache {
     int sample;
     GainSet g;
 };
-static_assert(sizeof(VoiceCache) == 48, "VoiceCache layout");
+static_assert(sizeof(VoiceCache) == 64, "VoiceCache layout");
 
 // ---------------------------------------------------------------- FIR convolution bank (MFMA GEMM)
 #define FIR_SEG 4096  // window positions per split-K segment — part of the numeric SPEC (summation order)

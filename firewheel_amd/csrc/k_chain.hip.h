@@ -62,7 +62,7 @@ __device__ __forceinline__ float row_ror1(float x) {
 
 struct ChainInfo {  // what a worker lane carries from S1 of a tile to S3a of the same tile (two steps later)
     uint32_t flags;                // VB_* of the tile's block, ramp bits included
-    float g[FW_MAX_STAGES - 1];    // this channel's constant post-gain stages (1..)
+    float g[FW_CHAIN_STAGES - 1];    // this channel's constant post-gain stages (1..)
 };
 
 // S3b for a workgroup whose 32 rows are 32/P full leaves of P ports each with nothing to skip: straight-line adds in port
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             const GainSet* gs = &fv.gsets[(size_t)pvoice * FW_GSETS];
             ok = ok && (d->flags >> VB_RAMP_SHIFT) == 0u && d->sample >= 0;
 #pragma unroll
-            for (int j = 0; j < FW_MAX_STAGES; ++j) ok = ok && (j >= fv.n_gain_stages || d->g[j][ch] == gs->g[j][ch]);
+            for (int j = 0; j < FW_CHAIN_STAGES; ++j) ok = ok && (j >= fv.n_gain_stages || d->g[j][ch] == gs->g[j][ch]);
             if (ok) {
                 const SampleDesc sd = fv.samples[d->sample];
                 ok = sd.format == FMT_P_F32 && sd.frames < 0xffffffffull;
@@ -221,14 +221,14 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     ChainInfo inf0, inf1, inf2;  // tiles s, s-1, s-2
     inf0.flags = inf1.flags = inf2.flags = VB_SRC_ZERO | VB_SIMPLE;
 #pragma unroll
-    for (int j = 0; j < FW_MAX_STAGES - 1; ++j) inf0.g[j] = inf1.g[j] = inf2.g[j] = 1.f;
+    for (int j = 0; j < FW_CHAIN_STAGES - 1; ++j) inf0.g[j] = inf1.g[j] = inf2.g[j] = 1.f;
     VoiceRef ref_n;        // descriptor of the block that starts two tiles ahead (in flight)
     ref_n.src_l = nullptr;
     ref_n.r_delta = 0;
     ref_n.flags_gset = VB_SRC_ZERO | VB_SIMPLE;
-    float gs_n[FW_MAX_STAGES];  // this channel's gains of the issue-side block (in flight)
+    float gs_n[FW_CHAIN_STAGES];  // this channel's gains of the issue-side block (in flight)
 #pragma unroll
-    for (int j = 0; j < FW_MAX_STAGES; ++j) gs_n[j] = 1.f;
+    for (int j = 0; j < FW_CHAIN_STAGES; ++j) gs_n[j] = 1.f;
     const float* nb_src = nullptr;  // issue-side block: this channel's source of frame 0, VB_* flags
     uint32_t nb_flags = VB_SRC_ZERO | VB_SIMPLE;
     v4f xs[NQ];  // source of the tile S1 computes next (prefetched)
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             if (nb_flags & VB_SIMPLE) {
                 const GainSet* gs = &fv.gsets[(size_t)voice * FW_GSETS + ((ref_n.flags_gset >> 8) & 0xffu)];
 #pragma unroll
-                for (int j = 0; j < FW_MAX_STAGES; ++j) gs_n[j] = gs->g[j][ch];
+                for (int j = 0; j < FW_CHAIN_STAGES; ++j) gs_n[j] = gs->g[j][ch];
             }
         }
         if ((nb_flags & VB_SIMPLE) && !(nb_flags & VB_SRC_ZERO) && !CH_SKIP(4)) {
@@ -317,9 +317,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         const uint32_t vflags = fv.refs[(size_t)voice * fv.refs_stride].flags_gset & 0xffu;  // per-voice bits only are used
         const GainSet* gsp = &fv.gsets[(size_t)voice * FW_GSETS];
         const float g0f = gsp->g[0][ch];
-        float gpost[FW_MAX_STAGES - 1];
+        float gpost[FW_CHAIN_STAGES - 1];
 #pragma unroll
-        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) gpost[j] = gsp->g[j + 1][ch];
+        for (int j = 0; j < FW_CHAIN_STAGES - 1; ++j) gpost[j] = gsp->g[j + 1][ch];
         const bool src_zero = (vflags & VB_SRC_ZERO) != 0, silent = (vflags & VB_SILENT) != 0;
         float* const dummy = fv.chain_dummy + (size_t)threadIdx.x * (4 * NQ);
         const bool ringed = active && has_dl;  // this lane's voice has a delay line
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     const v4f wet = (y * dry) + (rg[j] * mix);  // out = (x*dry) + (d*mix)
                     y = ringed ? wet : y;                       // no delay: untouched
 #pragma unroll
-                    for (int g = 0; g < FW_MAX_STAGES - 1; ++g) {
+                    for (int g = 0; g < FW_CHAIN_STAGES - 1; ++g) {
                         if (g + 1 >= fv.n_gain_stages) break;
                         y = y * gpost[g];
                     }
@@ -505,12 +505,12 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     inf0.flags = nb_flags;
                     g0 = gs_n[0];
 #pragma unroll
-                    for (int j = 0; j < FW_MAX_STAGES - 1; ++j) inf0.g[j] = gs_n[j + 1];
+                    for (int j = 0; j < FW_CHAIN_STAGES - 1; ++j) inf0.g[j] = gs_n[j + 1];
                 } else {
                     const VoiceBlk* d = &fv.blks[(size_t)k1 * fv.n_voices + voice];
                     inf0.flags = d->flags;
 #pragma unroll
-                    for (int j = 0; j < FW_MAX_STAGES - 1; ++j) inf0.g[j] = d->g[j + 1][ch];
+                    for (int j = 0; j < FW_CHAIN_STAGES - 1; ++j) inf0.g[j] = d->g[j + 1][ch];
                 }
                 if (has_bq && fv.n_cmds) {
                     const ChainCoefs co = chain_find_coefs(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0 + (uint32_t)k1);
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                         y = splat(0.f);
                     } else if (rbits == 0) {
 #pragma unroll
-                        for (int g = 0; g < FW_MAX_STAGES - 1; ++g) {
+                        for (int g = 0; g < FW_CHAIN_STAGES - 1; ++g) {
                             if (g + 1 >= fv.n_gain_stages) break;
                             y = y * inf2.g[g];
                         }
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                         const int f0 = t3 * TT + LF * q + 4 * j;
                         const float* rb = fv.ramps + ((size_t)k3 * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
 #pragma unroll
-                        for (int g = 1; g < FW_MAX_STAGES; ++g) {
+                        for (int g = 1; g < FW_CHAIN_STAGES; ++g) {
                             if (g >= fv.n_gain_stages) break;
                             const v4f gv = (rbits >> (2 * g + ch)) & 1u ? *(const v4f*)(rb + (size_t)(2 * g + ch) * fv.stride) : splat(inf2.g[g - 1]);
                             y = y * gv;

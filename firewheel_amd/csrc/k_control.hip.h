@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                         d.g[j + 1][0] = d.g[j + 1][1] = run.c;
                     }
                 }
-            } else {  // K_PAN (SPEC)
+            } else if (vd.stage_kind[j] == K_PAN) {  // SPEC: the stereo path of volume.rs with one smoother per channel
                 if (silent) {
                     smoother_reset(r.s0, r.p0);
                     smoother_reset(r.s1, r.p1);
@@ -622,6 +622,19 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                     d.g[j + 1][0] = rl.c;
                     d.g[j + 1][1] = rr.c;
                 }
+            } else if (vd.stage_kind[j] == K_WIDTH) {  // SPEC: silent input -> reset + clear; else mid/side with
+                if (silent) {                           // the smoothed width, out mask 0 — silence passes through unchanged
+                    smoother_reset(r.s0, r.p0);
+                } else {
+                    GainRun rw = smoother_begin(r.s0, r.p0, frames);
+                    if (rw.ramp && ramp_emit(rw, frames, rb, nullptr, lane)) {
+                        d.flags |= 1u << (VB_RAMP_SHIFT + 2 * (j + 1));
+                        r.s0.last = rw.prev;
+                    }
+                    d.g[j + 1][0] = d.g[j + 1][1] = rw.c;
+                }
+            } else {  // K_HARD_CLIP (hard_clip.rs:51-95): no state; a silent (both-channel) input is zero-filled and stays flagged
+                d.g[j + 1][0] = d.g[j + 1][1] = r.p0;
             }
         }
         const bool need_src = !src_silent && (fx || !silent);  // a dry voice whose output is muted fetches nothing
@@ -663,14 +676,16 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
             if (j >= vd.n_stages || !steady) break;
             const StageRegs& r = st[j];
             if (sil) {  // reset() every block: idempotent once applied
-                if (!(r.s0.status == SM_INACTIVE && r.s0.input == r.p0)) steady = false;
+                if (vd.stage_kind[j] != K_HARD_CLIP && !(r.s0.status == SM_INACTIVE && r.s0.input == r.p0)) steady = false;
                 if (vd.stage_kind[j] == K_PAN && !(r.s1.status == SM_INACTIVE && r.s1.input == r.p1)) steady = false;
             } else if (vd.stage_kind[j] == K_VOLUME) {
                 if (!smoother_is_constant(r.s0, r.p0)) steady = false;
                 else if (r.s0.status == SM_INACTIVE && r.s0.input < 0.00001f) sil = true;
-            } else {
+            } else if (vd.stage_kind[j] == K_PAN) {
                 if (!smoother_is_constant(r.s0, r.p0) || !smoother_is_constant(r.s1, r.p1)) steady = false;
-            }
+            } else if (vd.stage_kind[j] == K_WIDTH) {
+                if (!smoother_is_constant(r.s0, r.p0)) steady = false;
+            }  // K_HARD_CLIP: nothing can move
         }
         if (!steady) continue;
         // ---- steady: the descriptor every later block shares.  Constant gains are `input` for a settled
@@ -692,7 +707,7 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
             if (j >= vd.n_stages) break;
             const StageRegs& r = st[j];
-            job.g.g[j + 1][0] = r.s0.status == SM_ACTIVE ? r.s0.last : r.s0.input;
+            job.g.g[j + 1][0] = vd.stage_kind[j] == K_HARD_CLIP ? r.p0 : (r.s0.status == SM_ACTIVE ? r.s0.last : r.s0.input);
             job.g.g[j + 1][1] = vd.stage_kind[j] == K_PAN ? (r.s1.status == SM_ACTIVE ? r.s1.last : r.s1.input)
                                                           : job.g.g[j + 1][0];
         }

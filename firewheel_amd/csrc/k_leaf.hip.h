@@ -5,8 +5,29 @@
 // Leaf kernel: one wave per (leaf SumNode, block).  For each port in order: fetch the voice's source frames,
 // run its gain stages in registers, and accumulate in the reference's summation order (nodes/sum.rs).
 // HBM traffic = the source samples once (8 B per stereo voice-sample) + one partial-bus write per leaf.
+// one chain stage on a quad of both channels (kinds: SK_* in fwgpu_types.h) — the arithmetic of the generic executor's
+// K_VOLUME / K_PAN / K_WIDTH / K_HARD_CLIP cases (k_generic.hip.h), operation for operation
+__device__ __forceinline__ void apply_stage(uint32_t kind, v4f g0, v4f g1, v4f& a, v4f& b) {
+    if (kind == SK_GAIN) {
+        a = a * g0;
+        b = b * g1;
+    } else if (kind == SK_WIDTH) {
+        const v4f m = (a + b) * 0.5f;
+        const v4f sd = ((a - b) * 0.5f) * g0;
+        a = m + sd;
+        b = m - sd;
+    } else {  // SK_CLIP
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = fmaxf(fminf(a[j], g0[j]), -g0[j]);
+            b[j] = fmaxf(fminf(b[j], g0[j]), -g0[j]);
+        }
+    }
+}
+
+// `prog`: the voice's stage program (4 bits per chain stage; 0 everywhere on a gains-only voice)
 __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& d, uint32_t k, int voice, int f0, int frames,
-                                           v4f& xl, v4f& xr) {
+                                           v4f& xl, v4f& xr, uint32_t prog = 0u) {
     const bool mono = d.flags & VB_MONO;
     if (d.src_l && f0 + 4 <= frames) {  // planar f32, contiguous: one dwordx4 per channel per lane
         xl = *(const v4f_u*)(d.src_l + f0);
@@ -23,12 +44,12 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
         xr = mono ? xl : sample_fetch4(sd, 1, ft, (uint32_t)f0, (uint32_t)frames);
     }
     const uint32_t rbits = d.flags >> VB_RAMP_SHIFT;
+    const uint32_t kinds = prog << 4;  // stage 0 is the sampler's own gain
     if (rbits == 0) {  // constant gains: sampler.rs:530-533 then volume.rs:123-126 / pan, one rounding each
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES; ++j) {
             if (j >= fv.n_gain_stages) break;
-            xl = xl * d.g[j][0];
-            xr = xr * d.g[j][1];
+            apply_stage((kinds >> (4 * j)) & 15u, splat(d.g[j][0]), splat(d.g[j][1]), xl, xr);
         }
         // a mono sample is duplicated AFTER the sampler gain (sampler.rs:546-551); identical values either way
     } else {
@@ -38,8 +59,7 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
             if (j >= fv.n_gain_stages) break;
             v4f gl = (rbits >> (2 * j)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j) * fv.stride) : splat(d.g[j][0]);
             v4f gr = (rbits >> (2 * j + 1)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j + 1) * fv.stride) : splat(d.g[j][1]);
-            xl = xl * gl;
-            xr = xr * gr;
+            apply_stage((kinds >> (4 * j)) & 15u, gl, gr, xl, xr);
         }
     }
 }
@@ -97,6 +117,41 @@ __device__ __forceinline__ void leaf_fast(const float* my_l, const float* my_r, 
                 for (int j = 0; j < NG; ++j) {  // sampler.rs:530-533, volume.rs:123-126, pan: one rounding each
                     a = a * readlane_f(my_g.g[j][0], p0 + u);
                     b = b * readlane_f(my_g.g[j][1], p0 + u);
+                }
+                if (p0 + u == 0) {
+                    accl = a;
+                    accr = b;
+                } else {
+                    accl = accl + a;
+                    accr = accr + b;
+                }
+            }
+        }
+    }
+}
+
+// the same with a stage program per voice (width / hard clip among the stages): lane p also holds port p's program; the
+// stage kind of (port, stage) is wave-uniform, so the dispatch is a scalar branch
+__device__ __forceinline__ void leaf_fast_prog(const float* my_l, const float* my_r, const GainSet& my_g, uint32_t my_prog, int ng,
+                                               int ports, int f0, v4f& accl, v4f& accr) {
+    for (int p0 = 0; p0 < ports; p0 += LEAF_U) {
+        v4f xl[LEAF_U], xr[LEAF_U];
+#pragma unroll
+        for (int u = 0; u < LEAF_U; ++u) {
+            if (p0 + u < ports) {
+                xl[u] = gload4(readlane_ptr(my_l, p0 + u) + f0);
+                xr[u] = gload4(readlane_ptr(my_r, p0 + u) + f0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LEAF_U; ++u) {
+            if (p0 + u < ports) {
+                v4f a = xl[u], b = xr[u];
+                const uint32_t kinds = (uint32_t)__builtin_amdgcn_readlane((int)my_prog, p0 + u) << 4;
+#pragma unroll
+                for (int j = 0; j < FW_MAX_STAGES; ++j) {
+                    if (j >= ng) break;
+                    apply_stage((kinds >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p0 + u)), splat(readlane_f(my_g.g[j][1], p0 + u)), a, b);
                 }
                 if (p0 + u == 0) {
                     accl = a;
@@ -207,6 +262,9 @@ __device__ __forceinline__ void leaf_fast_cls(const float* my_l, uint32_t my_rd,
     }
 }
 
+// PROG: some voice of the plan has a stage that is not a plain gain (width / hard clip) — lane p then also carries port
+// p's stage program.  The gains-only instantiation is the headline kernel and does not pay for the other one's registers.
+template <bool PROG>
 __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K, int wpk) {
 #if LEAF_MAP_BLOCKS
     // the waves of a workgroup take CONSECUTIVE 256-frame pieces of one leaf's stream — wpk (1, 2 or 4) waves per
@@ -243,6 +301,11 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES; ++j) my_g.g[j][0] = my_g.g[j][1] = 1.0f;
     if (my_flags & VB_SIMPLE) my_g = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + ((ref.flags_gset >> 8) & 0xffu)];
+    uint32_t my_prog = 0u;
+    if constexpr (PROG) {
+        if (lane < ld.ports) my_prog = fv.progs[ld.first_voice + lane];
+        asm volatile("" : "+v"(my_prog));  // (read with v_readlane inside the frame loop: see below)
+    }
     const float* my_l = ref.src_l;
     uint32_t my_rd = ref.r_delta;
     uint32_t my_cls = (ref.flags_gset >> 16) & 7u;
@@ -271,16 +334,22 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
     const uint32_t cls0 = (uint32_t)__builtin_amdgcn_readlane((int)my_cls, 0);  // ports >= 1
     const bool one_class = (__ballot(my_cls == cls0) & lanes_in) == lanes_in;
     const bool fast = all_simple && one_class && cls0 == SF_P_F32;
-    const bool fast_cls = all_simple && one_class && cls0 != SF_P_F32;
+    const bool fast_cls = !PROG && all_simple && one_class && cls0 != SF_P_F32;  // (program voices on other formats: port by port)
 
     for (int f0 = lane * 4 + part * 256; f0 < frames; f0 += 256 * wpk) {
         v4f accl = splat(0.f), accr = splat(0.f);
         if (fast) {
-            switch (fv.n_gain_stages) {
-                case 1: leaf_fast<1>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
-                case 2: leaf_fast<2>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
-                case 3: leaf_fast<3>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
-                default: leaf_fast<4>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+            if constexpr (PROG) {
+                leaf_fast_prog(my_l, my_r, my_g, my_prog, fv.n_gain_stages, ld.ports, f0, accl, accr);
+            } else {
+                switch (fv.n_gain_stages) {
+                    case 1: leaf_fast<1>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                    case 2: leaf_fast<2>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                    case 3: leaf_fast<3>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                    case 4: leaf_fast<4>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                    case 5: leaf_fast<5>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                    default: leaf_fast<6>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                }
             }
         } else if (fast_cls) {
             const int ng = fv.n_gain_stages;
@@ -296,18 +365,19 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
                 const bool psil = (silent_ports >> p) & 1ull;
                 v4f xl = splat(0.f), xr = splat(0.f);  // a silent chain's buffers hold cleared zeros
                 if (!psil) {
+                    const uint32_t prog = PROG ? (uint32_t)__builtin_amdgcn_readlane((int)my_prog, p) : 0u;
                     if ((simple_ports >> p) & 1ull) {  // VB_SIMPLE implies frames % 4 == 0
                         simple_fetch((uint32_t)__builtin_amdgcn_readlane((int)my_cls, p), readlane_ptr(my_l, p),
                                      (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p), f0, xl, xr);
 #pragma unroll
                         for (int j = 0; j < FW_MAX_STAGES; ++j) {
                             if (j >= fv.n_gain_stages) break;
-                            xl = xl * readlane_f(my_g.g[j][0], p);
-                            xr = xr * readlane_f(my_g.g[j][1], p);
+                            apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)),
+                                        xl, xr);
                         }
                     } else {
                         const VoiceBlk d = fv.blks[row + p];
-                        voice_eval(fv, d, k, ld.first_voice + p, f0, frames, xl, xr);
+                        voice_eval(fv, d, k, ld.first_voice + p, f0, frames, xl, xr, prog);
                     }
                 }
                 if (p == 0) {  // sum.rs:117 copy_from_slice(port 0) — also when silent; 2/3/4-port: in1

@@ -87,6 +87,7 @@ void check_fused_common(const FusedView& fv, int K) {
     touch(fv.refs, sizeof(VoiceRef) * nv * (size_t)fv.refs_stride);
     touch(fv.gsets, sizeof(GainSet) * nv * FW_GSETS);
     touch(fv.cache, sizeof(VoiceCache) * nv);
+    touch(fv.progs, sizeof(uint32_t) * nv);
     touch(fv.blks, sizeof(VoiceBlk) * nv * (size_t)K);
     touch(fv.ramps, sizeof(float) * nv * (size_t)K * (size_t)fv.ramp_slots * (size_t)fv.stride);
     touch(fv.cmds, sizeof(Cmd) * (size_t)fv.n_cmds);
@@ -98,7 +99,11 @@ void check_fused_common(const FusedView& fv, int K) {
         max_stages = vd.n_stages > max_stages ? vd.n_stages : max_stages;
         touch(&fv.states[vd.sampler_state], sizeof(NodeState));
         for (int j = 0; j < vd.n_stages; ++j) {
-            REQUIRE(vd.stage_kind[j] == K_VOLUME || vd.stage_kind[j] == K_PAN, i, vd.stage_kind[j]);
+            REQUIRE(vd.stage_kind[j] == K_VOLUME || vd.stage_kind[j] == K_PAN || vd.stage_kind[j] == K_WIDTH || vd.stage_kind[j] == K_HARD_CLIP,
+                    i, vd.stage_kind[j]);
+            const uint32_t sk = (fv.progs[i] >> (4 * j)) & 15u;  // the leaf kernel's view of the same stage
+            REQUIRE(sk == (vd.stage_kind[j] == K_WIDTH ? SK_WIDTH : vd.stage_kind[j] == K_HARD_CLIP ? SK_CLIP : SK_GAIN), i, (long)sk);
+            REQUIRE(sk == SK_GAIN || (fv.has_prog && !fv.fx_plan), i, j);
             touch(&fv.states[vd.stage_state[j]], sizeof(NodeState));
         }
         REQUIRE(fv.fx_plan || (vd.bq_state < 0 && vd.dl_state < 0), i);

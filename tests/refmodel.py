@@ -121,11 +121,31 @@ def percent_volume_to_raw_gain(p):  # core/param/range.rs:32-35
     return f32(n * n)
 
 
+_LIBM = None
+
+
+def platform_powf(x, y):
+    """f32::powf is the platform libm's powf (Rust lowers it to the LLVM intrinsic, which calls libm).  glibc's powf is
+    NOT correctly rounded everywhere: 10^(0.05 * -15.95945 dB) is 0.50003 ulp away from what it returns (found by the
+    differential fuzz, seed 230: a correctly rounded pow put this model one ulp below the oracle on a hard-clip
+    threshold).  The reference's value is therefore "whatever libm the host links" — Q29 in DESIGN.md §4 — and this model
+    asks the same libm, as a Rust build on this machine would."""
+    global _LIBM
+    if _LIBM is None:
+        import ctypes
+        import ctypes.util
+
+        _LIBM = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        _LIBM.powf.restype = ctypes.c_float
+        _LIBM.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    return f32(_LIBM.powf(float(f32(x)), float(f32(y))))
+
+
 def db_to_gain_clamped_neg_100_db(db):  # core/util.rs:7-9,21-27
     db = f32(db)
     if db <= f32(-100.0):
         return F0
-    return f32(math.pow(10.0, float(f32(0.05) * db)))  # 10.0f32.powf(0.05 * db): the product formed in f32, powf ~ correctly rounded
+    return platform_powf(10.0, f32(0.05) * db)  # 10.0f32.powf(0.05 * db)
 
 
 def clear_all_outputs(frames, outputs):  # core/util.rs:165-175

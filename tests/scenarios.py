@@ -26,8 +26,9 @@ def connect_through_master(e, root, master):
 
 
 def build_voice_bank(e, n_voices, radix=32, src_frames=4096, with_pan=True, with_volume=True, seed=0, fmt=PLANAR_F32,
-                     mono_every=0, fmt_cycle=None, master=()):
-    """config-2 shape: V x (sampler -> volume -> pan) -> radix-`radix` SumNode tree -> graph_out."""
+                     mono_every=0, fmt_cycle=None, master=(), voice_fx=None):
+    """config-2 shape: V x (sampler -> volume -> pan) -> radix-`radix` SumNode tree -> graph_out.
+    voice_fx(e, v, rng) -> list of extra stereo 2->2 nodes appended to voice v's chain (width / hard clip / ...)."""
     rng = np.random.default_rng(1234 + seed)
     voices = []
     ends = []
@@ -43,7 +44,13 @@ def build_voice_bank(e, n_voices, radix=32, src_frames=4096, with_pan=True, with
             pan = e.pan(float(rng.uniform(-1, 1)))
             e.connect_stereo(cur, pan)
             cur = pan
-        voices.append(dict(sampler=s, volume=vol, pan=pan))
+        fx = []
+        if voice_fx is not None:
+            for n in voice_fx(e, v, rng):
+                e.connect_stereo(cur, n)
+                cur = n
+                fx.append(n)
+        voices.append(dict(sampler=s, volume=vol, pan=pan, fx=fx))
         ends.append(cur)
     # sum tree
     level = ends
@@ -129,6 +136,53 @@ def scenario_voice_bank_events(e, n_voices=70, radix=32, mbf=None, src_frames=10
         if v % 3 == 0:
             e.set_param(vc["volume"], 0, 100.0)
     outs.append(e.process_blocks(8))
+    return np.concatenate(outs)
+
+
+def width_clip_fx(e, v, rng):
+    """per-voice tail of the stage-program tests: width and / or hard clip in varying order and number"""
+    w = e.width(float(rng.uniform(0.0, 2.0)))
+    c = e.hard_clip(float(rng.uniform(-20.0, -2.0)))
+    return [[w, c], [c, w], [w], [c], [c, w, e.hard_clip(-1.0)], []][v % 6]
+
+
+def scenario_voice_fx_events(e, n_voices=45, radix=8, src_frames=1100, with_pan=True, fmt=PLANAR_F32):
+    """the voice-bank plan's stage programs: every voice ends in width / hard-clip stages (sampler -> volume -> pan -> ...),
+    with width automation (ramps that settle and stall), negative widths (clamped), mutes in front of the width (silence
+    passes width and clip: the smoother resets), late starts, one-shots that end, mono sources"""
+    voices = build_voice_bank(e, n_voices, radix=radix, src_frames=src_frames, mono_every=7, with_pan=with_pan, fmt=fmt,
+                              voice_fx=width_clip_fx)
+    outs = []
+    for v, vc in enumerate(voices):
+        if v % 5 != 3:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        if v % 4 != 1:
+            e.sampler_play(vc["sampler"])
+    outs.append(e.process_blocks(3))
+    for v, vc in enumerate(voices):
+        widths = [n for n in vc["fx"][:2] if v % 6 in (0, 2) and n == vc["fx"][0]] + ([vc["fx"][1]] if v % 6 in (1, 4) else [])
+        for w in widths:
+            e.set_param(w, 0, [0.0, 1.7, -0.5, 0.9][v % 4], at_block=v % 3)
+        if v % 3 == 0:
+            e.set_param(vc["volume"], 0, 25.0 if v % 2 else 120.0, at_block=1)
+        if v % 10 == 4:
+            e.set_param(vc["volume"], 0, 0.0, at_block=1)          # mute in front of the width / clip
+        if v % 4 == 1:
+            e.sampler_play(vc["sampler"], at_block=2)
+        if v % 11 == 5:
+            e.sampler_pause(vc["sampler"], at_block=3)
+    outs.append(e.process_blocks(6))
+    outs.append(e.process_blocks(25))
+    for v, vc in enumerate(voices):
+        if v % 10 == 4:
+            e.set_param(vc["volume"], 0, 70.0)
+        if v % 6 == 0:
+            e.set_param(vc["fx"][0], 0, 1.0)
+        if v % 9 == 0:
+            e.sampler_stop(vc["sampler"])
+        if v % 9 == 3:
+            e.sampler_play(vc["sampler"])
+    outs.append(e.process_blocks(9))
     return np.concatenate(outs)
 
 

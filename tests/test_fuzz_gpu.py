@@ -67,6 +67,17 @@ def fuzz_run(e, seed):
                 vc["pans"].append(g)
             e.connect_stereo(cur, g)
             cur = g
+        if shape == 0 and rng.random() < 0.5:
+            # dry voices: up to two more stages that are not plain gains — a stereo width and / or a hard clip anywhere in
+            # the chain's tail (the voice-bank plan's stage programs; at most 5 chain stages per voice)
+            for _ in range(int(rng.integers(1, 3))):
+                if rng.random() < 0.5:
+                    g = e.width(float(rng.uniform(0, 2)))
+                    vc["pans"].append(g)  # (param 0, range [-1, 1] is inside the width's [0, inf) after its clamp)
+                else:
+                    g = e.hard_clip(float(rng.uniform(-18, 0)))
+                e.connect_stereo(cur, g)
+                cur = g
         voices.append(vc)
         ends.append(cur)
     level = ends

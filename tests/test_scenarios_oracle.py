@@ -44,6 +44,12 @@ CASES = {
                                                                    fmt=fwapi.INTERLEAVED_I16),
     "events_70": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=256), 70),
     "events_33_r2": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=128), 33, radix=2, src_frames=777),
+    # width / hard-clip stages at the end of the voice chains (the voice-bank plan's stage programs)
+    "voice_fx_steady": lambda: scenarios.scenario_voice_bank_steady(oracle(max_block_frames=256), 70, 6, src_frames=1500,
+                                                                     voice_fx=scenarios.width_clip_fx),
+    "voice_fx_events_45": lambda: scenarios.scenario_voice_fx_events(oracle(max_block_frames=128)),
+    "voice_fx_events_20_i16_r32": lambda: scenarios.scenario_voice_fx_events(oracle(max_block_frames=64), 20, radix=32, src_frames=500,
+                                                                              with_pan=False, fmt=fwapi.INTERLEAVED_I16),
     "mixed_generic": lambda: scenarios.scenario_mixed_generic(oracle(max_block_frames=256)),
     "mixed_generic_nobeep": lambda: scenarios.scenario_mixed_generic(oracle(max_block_frames=256), use_beep=False),
     "cfg3_chain": lambda: scenarios.scenario_cfg3_chain(oracle(max_block_frames=128)),

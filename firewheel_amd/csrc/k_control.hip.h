@@ -71,11 +71,26 @@ __device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, f
         float mine = 0.f;
         const int n = frames - i0 < WAVE ? frames - i0 : WAVE;
         if (n == WAVE) {
-#pragma unroll 16
-            for (int i = 0; i < WAVE; ++i) {
-                prev = r.in_a + (prev * r.b);
-                mine = i == lane ? prev : mine;
-            }
+            // 64 steps of the recurrence with EXEC shrinking lane by lane: every lane runs the same chain, lane i drops
+            // out after step i and keeps y[i] — two dependent VALU ops per frame (the mul and the add, one rounding each,
+            // as smoother.rs:171-175) and nothing else on the vector unit; the compare + select that used to park step
+            // i's value in lane i doubled the length of the chain (the whole wave is active here: the voice's control
+            // code is wave-uniform)
+            float y = prev, t;
+            unsigned long long saved_exec;
+            asm volatile(
+                "s_mov_b64 %2, exec\n"
+                ".rept 64\n"
+                "v_mul_f32 %1, %0, %4\n"
+                "v_add_f32 %0, %3, %1\n"
+                "s_lshl_b64 exec, exec, 1\n"
+                ".endr\n"
+                "s_mov_b64 exec, %2\n"
+                : "+v"(y), "=&v"(t), "=&s"(saved_exec)
+                : "v"(r.in_a), "v"(r.b)
+                : "scc");
+            mine = y;
+            prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), WAVE - 1));
         } else {
             for (int i = 0; i < n; ++i) {
                 prev = r.in_a + (prev * r.b);
@@ -171,7 +186,16 @@ struct TailJob {
     int sample;
     GainSet g;
     uint64_t playhead, loop_start, loop_end;
+    // ramp continuation: slot s = 2*stage + channel carries a per-frame ramp (written to `ramps` by the caller) in the blocks
+    // before ramp_until[s]; 0 everywhere on a plain steady tail
+    int ramp_until[2 * FW_MAX_STAGES];
 };
+__device__ __forceinline__ uint32_t tail_ramp_bits(const TailJob& job, int k2) {
+    uint32_t rb = 0;
+#pragma unroll
+    for (int sl = 0; sl < 2 * FW_MAX_STAGES; ++sl) rb |= (k2 < job.ramp_until[sl] ? 1u : 0u) << sl;
+    return rb;
+}
 
 // Writes the compact record (always) and the full descriptor (only when the leaf kernel will need it).
 // `fx`: the voice has a biquad / delay (k_chain plan) — its source is needed even when the chain output is
@@ -261,7 +285,8 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
         }
         for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
             const uint64_t left = L - r;
-            t.flags = job.flags | nosrc_flags;
+            const uint32_t rb = tail_ramp_bits(job, k2);
+            t.flags = job.flags | nosrc_flags | (rb << VB_RAMP_SHIFT);
             t.off0 = job.loop_start + r;
             t.off1 = job.loop_start;
             t.src_l = t.src_r = nullptr;
@@ -274,7 +299,7 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
                     t.src_l = (const float*)sd.data + t.off0;
                     t.src_r = (t.flags & VB_MONO) ? t.src_l : t.src_l + sd.frames;
                 }
-                if (has_src && simple_ok && simple_class(sd, t.off0, fxp) != SF_NONE) t.flags |= VB_SIMPLE;
+                if (has_src && simple_ok && rb == 0 && simple_class(sd, t.off0, fxp) != SF_NONE) t.flags |= VB_SIMPLE;
             }
             put_blk(fv, vi, k2, t, gset, sd, fxp);
             r += step;
@@ -285,14 +310,15 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
     }
     if (job.mode == 2) {
         for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
-            t.flags = job.flags | nosrc_flags;
+            const uint32_t rb = tail_ramp_bits(job, k2);
+            t.flags = job.flags | nosrc_flags | (rb << VB_RAMP_SHIFT);
             t.off0 = job.playhead + (uint64_t)(k2 - k_first) * fr;
             t.src_l = t.src_r = nullptr;
             if (contiguous_f32) {
                 t.src_l = (const float*)sd.data + t.off0;
                 t.src_r = (t.flags & VB_MONO) ? t.src_l : t.src_l + sd.frames;
             }
-            if (has_src && simple_ok && simple_class(sd, t.off0, fxp) != SF_NONE) t.flags |= VB_SIMPLE;
+            if (has_src && simple_ok && rb == 0 && simple_class(sd, t.off0, fxp) != SF_NONE) t.flags |= VB_SIMPLE;
             put_blk(fv, vi, k2, t, gset, sd, fxp);
         }
         return job.playhead + n * fr;
@@ -430,6 +456,8 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
             job.sample = vc.sample;
             job.g = vc.g;
             job.playhead = job.loop_start = job.loop_end = 0;
+#pragma unroll
+            for (int sl = 0; sl < 2 * FW_MAX_STAGES; ++sl) job.ramp_until[sl] = 0;
             SampleDesc sd;
             sd.data = nullptr;
             sd.frames = 0;
@@ -652,12 +680,13 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
         if (k < last_cmd) continue;
         bool steady = true;
         bool upstream_silent = false;
+        bool ramping = false;  // some smoother is still moving: the rest of the call is a RAMP CONTINUATION, then steady
         int mode = 0;
         if (ss.sample < 0 || !ss.playing || sd.data == nullptr) {
             upstream_silent = true;  // frozen sampler: nothing moves
         } else {
-            if (!smoother_is_constant(ss.s0, ss.p0)) steady = false;
-            else if (ss.s0.status == SM_INACTIVE && ss.s0.input < 0.00001f) upstream_silent = true;  // muted, frozen
+            if (!smoother_is_constant(ss.s0, ss.p0)) ramping = true;
+            if (!ramping && ss.s0.status == SM_INACTIVE && ss.s0.input < 0.00001f) upstream_silent = true;  // muted, frozen
             else if (ss.has_loop) {
                 uint64_t L = ss.loop_end - ss.loop_start;
                 if (ss.loop_end > ss.loop_start && L >= (uint64_t)frames && ss.playhead >= ss.loop_start &&
@@ -679,15 +708,78 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
                 if (vd.stage_kind[j] != K_HARD_CLIP && !(r.s0.status == SM_INACTIVE && r.s0.input == r.p0)) steady = false;
                 if (vd.stage_kind[j] == K_PAN && !(r.s1.status == SM_INACTIVE && r.s1.input == r.p1)) steady = false;
             } else if (vd.stage_kind[j] == K_VOLUME) {
-                if (!smoother_is_constant(r.s0, r.p0)) steady = false;
+                if (!smoother_is_constant(r.s0, r.p0)) ramping = true;
                 else if (r.s0.status == SM_INACTIVE && r.s0.input < 0.00001f) sil = true;
             } else if (vd.stage_kind[j] == K_PAN) {
-                if (!smoother_is_constant(r.s0, r.p0) || !smoother_is_constant(r.s1, r.p1)) steady = false;
+                if (!smoother_is_constant(r.s0, r.p0) || !smoother_is_constant(r.s1, r.p1)) ramping = true;
             } else if (vd.stage_kind[j] == K_WIDTH) {
-                if (!smoother_is_constant(r.s0, r.p0)) steady = false;
+                if (!smoother_is_constant(r.s0, r.p0)) ramping = true;
             }  // K_HARD_CLIP: nothing can move
         }
+        // the continuation covers the common case only — a dry voice playing steadily while gains glide; silence anywhere
+        // in the chain (resets instead of ramps) and chain-plan voices stay on the block-by-block path
+        if (ramping && (sil || upstream_silent || fx || k + 1 >= K)) steady = false;
         if (!steady) continue;
+        // ---- ramp continuation.  From here to the end of the call nothing happens to this voice but (a) its playhead
+        // advancing — closed form, as on a steady tail — and (b) smoothers gliding to their targets, a serial recurrence
+        // (smoother.rs:169-175) that only needs ITSELF: run it now for as many blocks as it takes, 64 frames at a time,
+        // straight into the blocks' ramp buffers, then emit all descriptors together.  (Walking those ~20 blocks one by
+        // one through the whole state machine cost ~6 us each: a gain change per voice cost a third of config 2's step.)
+        int ramp_until[2 * FW_MAX_STAGES];
+#pragma unroll
+        for (int sl = 0; sl < 2 * FW_MAX_STAGES; ++sl) ramp_until[sl] = 0;
+        if (ramping) {
+            for (int kk = k + 1; kk < K; ++kk) {
+                float* rbase = fv.ramps + ((size_t)kk * fv.n_voices + vi) * (size_t)fv.ramp_slots * (size_t)fv.stride;
+                bool moved = false;
+                {  // the sampler's gain (both channels share the ramp: sampler.rs:530-533)
+                    GainRun run = smoother_begin(ss.s0, ss.p0, frames);
+                    if (run.ramp && ramp_emit(run, frames, rbase, rbase + fv.stride, lane)) {
+                        ss.s0.last = run.prev;
+                        ramp_until[0] = ramp_until[1] = kk + 1;
+                        moved = true;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+                    if (j >= vd.n_stages) break;
+                    StageRegs& r = st[j];
+                    float* rb = rbase + (size_t)(j + 1) * 2 * fv.stride;
+                    if (vd.stage_kind[j] == K_VOLUME) {
+                        GainRun run = smoother_begin(r.s0, r.p0, frames);
+                        if (run.ramp && ramp_emit(run, frames, rb, rb + fv.stride, lane)) {
+                            r.s0.last = run.prev;
+                            ramp_until[2 * (j + 1)] = ramp_until[2 * (j + 1) + 1] = kk + 1;
+                            moved = true;
+                        }
+                    } else if (vd.stage_kind[j] == K_PAN) {
+                        GainRun rl = smoother_begin(r.s0, r.p0, frames);
+                        GainRun rr = smoother_begin(r.s1, r.p1, frames);
+                        if (rl.ramp && ramp_emit(rl, frames, rb, nullptr, lane)) {
+                            r.s0.last = rl.prev;
+                            ramp_until[2 * (j + 1)] = kk + 1;
+                            moved = true;
+                        }
+                        if (rr.ramp && ramp_emit(rr, frames, rb + fv.stride, nullptr, lane)) {
+                            r.s1.last = rr.prev;
+                            ramp_until[2 * (j + 1) + 1] = kk + 1;
+                            moved = true;
+                        }
+                    } else if (vd.stage_kind[j] == K_WIDTH) {
+                        GainRun rw = smoother_begin(r.s0, r.p0, frames);
+                        if (rw.ramp && ramp_emit(rw, frames, rb, nullptr, lane)) {
+                            r.s0.last = rw.prev;
+                            ramp_until[2 * (j + 1)] = kk + 1;
+                            moved = true;
+                        }
+                    }
+                }
+                if (!moved) {  // every smoother settled (or stalled at its fixed point): blocks kk .. K-1 are steady
+                    ramping = false;
+                    break;
+                }
+            }
+        }
         // ---- steady: the descriptor every later block shares.  Constant gains are `input` for a settled
         // smoother and `last` for one stalled at its f32 fixed point (Q28).
         TailJob job;
@@ -711,8 +803,10 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
             job.g.g[j + 1][1] = vd.stage_kind[j] == K_PAN ? (r.s1.status == SM_ACTIVE ? r.s1.last : r.s1.input)
                                                           : job.g.g[j + 1][0];
         }
-        became_steady = true;
-        if (w0) {
+#pragma unroll
+        for (int sl = 0; sl < 2 * FW_MAX_STAGES; ++sl) job.ramp_until[sl] = ramp_until[sl];
+        became_steady = !ramping;  // (a glide that outlasts the call: the next call picks it up block 0)
+        if (w0 && became_steady) {
             VoiceCache vc;
             vc.epoch = fv.epoch;
             vc.mode = mode;

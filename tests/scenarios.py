@@ -141,9 +141,9 @@ def scenario_voice_bank_events(e, n_voices=70, radix=32, mbf=None, src_frames=10
 
 def width_clip_fx(e, v, rng):
     """per-voice tail of the stage-program tests: width and / or hard clip in varying order and number"""
-    w = e.width(float(rng.uniform(0.0, 2.0)))
-    c = e.hard_clip(float(rng.uniform(-20.0, -2.0)))
-    return [[w, c], [c, w], [w], [c], [c, w, e.hard_clip(-1.0)], []][v % 6]
+    wv, cv = float(rng.uniform(0.0, 2.0)), float(rng.uniform(-20.0, -2.0))
+    shape = ["wc", "cw", "w", "c", "cwC", ""][v % 6]  # (only the nodes a voice uses are created: nothing dangles)
+    return [e.width(wv) if k == "w" else e.hard_clip(cv if k == "c" else -1.0) for k in shape]
 
 
 def scenario_voice_fx_events(e, n_voices=45, radix=8, src_frames=1100, with_pan=True, fmt=PLANAR_F32):

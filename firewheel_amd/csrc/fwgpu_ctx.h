@@ -212,6 +212,8 @@ struct fwgpu_ctx {
         int n_out_ch = 0;
         const float* d_out = nullptr;
     } rt_graph;
+    bool rt_one_launch = true;  // one-block calls on the voice-bank plan: control + leaf + root in ONE kernel (FWGPU_RT_ONE_LAUNCH=0: off)
+    DevBuf d_rt_sync;           // its workgroup counter
     bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2
     DevBuf d_rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS]
 

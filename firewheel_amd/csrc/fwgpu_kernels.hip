@@ -8,6 +8,7 @@
 //                    in registers), k_bus_sum (upper sum tree), k_root_out (root sum + interleave)
 //   k_chain.hip.h    fused chain plan: k_chain (sampler -> biquad -> delay -> gains -> leaf sum, LDS software pipeline)
 //   k_fir.hip.h      FIR convolution bank: Toeplitz GEMM on the f32 matrix cores
+//   k_rt.hip.h       realtime edge: one launch per callback for the voice-bank plan (control + leaf + root)
 // All plans share the node state in HBM.  Compiled with -ffp-contract=off: the reference (Rust) never fuses mul+add,
 // and parity is bit-exact; the only fused multiply-adds are the ones a SPEC node asks for by name.
 //
@@ -34,6 +35,7 @@ __device__ __forceinline__ v4f splat(float x) { return (v4f){x, x, x, x}; }
 #include "k_leaf.hip.h"
 #include "k_chain.hip.h"
 #include "k_fir.hip.h"
+#include "k_rt.hip.h"
 
 // ------------------------------------------------------------------ launch wrappers (host side of this TU)
 #define HIPCHK(x)                        \
@@ -146,6 +148,13 @@ int launch_bus_sum_ordered(hipStream_t s, const BusParts& bp, float* d_out, size
     const size_t n4 = n_floats / 4;
     const size_t threads = n4 ? n4 : 1;
     hipLaunchKernelGGL(k_bus_sum_ordered, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, bp, d_out, n4, n_floats);
+    return (int)hipGetLastError();
+}
+int launch_rt_block(hipStream_t s, const FusedView& fv, const DevView& upv, const RootArgs& root, float* d_out, uint32_t cmd_block0,
+                    unsigned* d_sync) {
+    if (fv.n_leaves <= 0) return 0;
+    if (fv.has_prog) hipLaunchKernelGGL(k_rt_block<true>, dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync);
+    else hipLaunchKernelGGL(k_rt_block<false>, dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync);
     return (int)hipGetLastError();
 }
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {

@@ -310,6 +310,20 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         static const int dbg = getenv("FWGPU_CHAIN_SKIP") ? atoi(getenv("FWGPU_CHAIN_SKIP")) : 0;
         fv.dbg = dbg;
     }
+    // realtime edge: one block, tree = leaves + root, stereo stream -> the whole callback is ONE launch (k_rt_block)
+    if (K == 1 && c->rt_one_launch && !c->fused_fx && !c->timing && c->n_tail == 0 && c->up_root_node >= 0 && n_out_ch == 2 &&
+        c->up_level_cnt.size() == 1 && c->d_rt_sync.p) {
+        DevView v;
+        memset(&v, 0, sizeof(v));
+        v.pool = fv.bus;
+        v.flags = fv.bus_flags;
+        v.pool_blk_stride = fv.bus_blk_stride;
+        v.flags_blk_stride = fv.bus_flags_blk_stride;
+        v.stride = c->stride;
+        v.frames = (int)c->mbf;
+        LCHK(c, launch_rt_block(c->stream, fv, v, c->root_args, d_out, cmd_block0, c->d_rt_sync.as<unsigned>()));
+        return 0;
+    }
     hipEvent_t e0, e1;
     timer_begin(c, 1, &e0, &e1);
     LCHK(c, launch_voice_control(c->stream, fv, K, cmd_block0));

@@ -333,10 +333,7 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
 // One WAVE per voice: the state machines are run by all 64 lanes redundantly (wave-uniform; lane 0 stores),
 // the steady tail is split across the lanes.  A voice that ended the previous call steady and has no message
 // in this one skips the state machines altogether (VoiceCache): its whole call is a steady tail.
-__global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint32_t cmd_block0) {
-    const int vi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (vi >= fv.n_voices) return;
-    const int lane = threadIdx.x & (WAVE - 1);
+__device__ inline void voice_control_wave(const FusedView& fv, const int vi, const int lane, const int K, const uint32_t cmd_block0) {
     const bool w0 = lane == 0;
     const VoiceDesc vd = fv.voices[vi];
     const int frames = fv.frames;
@@ -842,5 +839,11 @@ __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
         if (j < vd.n_stages) *(StageRegs*)&fv.states[vd.stage_state[j]] = st[j];
+}
+
+__global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint32_t cmd_block0) {
+    const int vi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (vi >= fv.n_voices) return;
+    voice_control_wave(fv, vi, threadIdx.x & (WAVE - 1), K, cmd_block0);
 }
 

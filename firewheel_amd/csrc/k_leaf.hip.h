@@ -265,22 +265,7 @@ __device__ __forceinline__ void leaf_fast_cls(const float* my_l, uint32_t my_rd,
 // PROG: some voice of the plan has a stage that is not a plain gain (width / hard clip) — lane p then also carries port
 // p's stage program.  The gains-only instantiation is the headline kernel and does not pay for the other one's registers.
 template <bool PROG>
-__global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K, int wpk) {
-#if LEAF_MAP_BLOCKS
-    // the waves of a workgroup take CONSECUTIVE 256-frame pieces of one leaf's stream — wpk (1, 2 or 4) waves per
-    // block, LEAF_WPB / wpk consecutive blocks: a steady voice's source is contiguous across blocks, so the workgroup
-    // streams LEAF_WPB adjacent KiB per voice-channel instead of 1 KiB from LEAF_WPB x 32 places
-    const int leaf = blockIdx.x;
-    const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int part = wave & (wpk - 1);
-    const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.y * (LEAF_WPB / wpk) + wave / wpk));
-    if (k >= (uint32_t)K) return;
-#else
-    const int part = 0;
-    const int leaf = blockIdx.x * LEAF_WPB + (threadIdx.x >> 6);
-    if (leaf >= fv.n_leaves) return;
-    const uint32_t k = blockIdx.y;
-#endif
+__device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int leaf, const uint32_t k, const int part, const int wpk) {
     const int lane = threadIdx.x & (WAVE - 1);
     const LeafDesc ld = fv.leaves[leaf];
     const int frames = fv.frames;
@@ -396,6 +381,26 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
     if (lane < 2 && part == 0) bflags[ld.out_buf + lane] = all_silent ? 1 : 0;
 }
 
+template <bool PROG>
+__global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K, int wpk) {
+#if LEAF_MAP_BLOCKS
+    // the waves of a workgroup take CONSECUTIVE 256-frame pieces of one leaf's stream — wpk (1, 2 or 4) waves per
+    // block, LEAF_WPB / wpk consecutive blocks: a steady voice's source is contiguous across blocks, so the workgroup
+    // streams LEAF_WPB adjacent KiB per voice-channel instead of 1 KiB from LEAF_WPB x 32 places
+    const int leaf = blockIdx.x;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int part = wave & (wpk - 1);
+    const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.y * (LEAF_WPB / wpk) + wave / wpk));
+    if (k >= (uint32_t)K) return;
+#else
+    const int part = 0;
+    const int leaf = blockIdx.x * LEAF_WPB + (threadIdx.x >> 6);
+    if (leaf >= fv.n_leaves) return;
+    const uint32_t k = blockIdx.y;
+#endif
+    leaf_sum_wave<PROG>(fv, leaf, k, part, wpk);
+}
+
 // Upper sum tree of the fused plan, K-batched: SumNode semantics (nodes/sum.rs:41-136) with one THREAD per
 // frame (blockIdx = node, block, channel) so that a 1-node level still puts K * n_out * frames/64 waves in flight.
 __global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restrict__ level_nodes) {
@@ -455,13 +460,11 @@ __global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restric
 // arrives in the kernel arguments (scalar loads), every port's frame is requested before anything is waited for, and
 // the silence flags (which only decide whether a loaded value is added) are fetched alongside.
 template <int NP>
-__device__ __forceinline__ void root_out_body(const DevView& v, const RootArgs& ra, float* __restrict__ out) {
-    const uint32_t blk = blockIdx.y;
+__device__ __forceinline__ void root_out_body(const DevView& v, const RootArgs& ra, float* __restrict__ out, const uint32_t blk, const int f) {
     const int lane = threadIdx.x & (WAVE - 1);
     const float* pool = v.pool + (size_t)blk * v.pool_blk_stride;
     const uint8_t* flags = v.flags + (size_t)blk * v.flags_blk_stride;
     const int n_in = ra.n_in, ports = ra.ports;
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
     const int fc = f < v.frames ? f : 0;  // whole waves stay in: the ballot below needs lanes 0..n_in-1
     // per-lane lookups go through the device copy of the table (indexing the argument struct by lane would spill it)
     const uint8_t my_flag = lane < n_in ? flags[ra.in_tab[lane]] : (uint8_t)0;
@@ -496,11 +499,14 @@ __device__ __forceinline__ void root_out_body(const DevView& v, const RootArgs& 
     }
     *(float2*)(o + (size_t)f * 2) = y;
 }
+__device__ __forceinline__ void root_out_any(const DevView& v, const RootArgs& ra, float* __restrict__ out, const uint32_t blk, const int f) {
+    if (ra.ports <= 4) root_out_body<4>(v, ra, out, blk, f);
+    else if (ra.ports <= 8) root_out_body<8>(v, ra, out, blk, f);
+    else if (ra.ports <= 16) root_out_body<16>(v, ra, out, blk, f);
+    else root_out_body<32>(v, ra, out, blk, f);
+}
 __global__ __launch_bounds__(256) void k_root_out(DevView v, RootArgs ra, float* __restrict__ out) {
-    if (ra.ports <= 4) root_out_body<4>(v, ra, out);
-    else if (ra.ports <= 8) root_out_body<8>(v, ra, out);
-    else if (ra.ports <= 16) root_out_body<16>(v, ra, out);
-    else root_out_body<32>(v, ra, out);
+    root_out_any(v, ra, out, blockIdx.y, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
 // The top-level R-port SumNode of a voice-sharded graph: the R partial mix buses, one per rank, added in

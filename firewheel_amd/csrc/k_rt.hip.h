@@ -1,0 +1,42 @@
+// k_rt.hip.h — part of the single device translation unit fwgpu_kernels.hip (included inside namespace fwgpu).
+// Realtime edge: ONE launch per callback for the voice-bank plan.
+//
+// A backend callback is one block (cpal/lib.rs:378-449 -> processor.rs:61-165 with frames <= max_block_frames); its
+// compulsory HBM traffic is microseconds below one kernel boundary, so what a callback costs is the NUMBER of dependent
+// launches: control kernel -> leaf sums -> root sum + interleave were 3 boundaries (~5 us each on this stack) + 3 more
+// host-side launch calls.  Here one workgroup per leaf SumNode does all three in sequence:
+//   1. its voices' control state machines (voice_control_wave: messages, smoothers, playheads -> this block's records),
+//   2. its leaf sum (leaf_sum_wave: the waves take 256-frame pieces of the block),
+//   3. the LAST workgroup to finish — an agent-scope counter — adds the leaf buses in the root SumNode's port order and
+//      interleaves into the (pinned, device-mapped) output block: root_out_any, the code of k_root_out.
+// Same device functions as the throughput kernels, so the arithmetic is theirs bit for bit.  Used when the call is one
+// block, the tree is leaves + root and the stream is stereo; everything else takes the launch sequence.
+template <bool PROG>
+__global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, RootArgs ra, float* __restrict__ out, uint32_t cmd_block0,
+                                                  unsigned* __restrict__ sync) {
+    const int leaf = blockIdx.x;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & (WAVE - 1);
+    const LeafDesc ld = fv.leaves[leaf];
+    for (int p = wave; p < ld.ports; p += 4) voice_control_wave(fv, ld.first_voice + p, lane, 1, cmd_block0);
+    // the records (refs / gain sets / descriptors / ramps) were written by all four waves and are read by all four:
+    // same CU, same L1 — a workgroup-scope release / acquire around the barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    leaf_sum_wave<PROG>(fv, leaf, 0u, wave, 4);
+    // grid-wide hand-over to the root: every workgroup publishes its bus (agent scope: the XCDs have separate L2s), the
+    // last one to arrive reads them all
+    __shared__ int s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == gridDim.x - 1 ? 1 : 0;
+        if (s_last) __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next callback
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int f0 = 0; f0 < upv.frames; f0 += 256) root_out_any(upv, ra, out, 0u, f0 + (int)threadIdx.x);
+}

@@ -253,6 +253,21 @@ int launch_bus_sum_ordered(hipStream_t, const BusParts& bp, float* d_out, size_t
     touch(d_out, n_floats * sizeof(float));
     return 0;
 }
+int launch_rt_block(hipStream_t, const FusedView& fv, const DevView& upv, const RootArgs& root, float* d_out, uint32_t cmd_block0,
+                    unsigned* d_sync) {
+    g_launches[7]++;
+    check_fused_common(fv, 1);
+    REQUIRE(!fv.fx_plan && root.ports >= 1 && root.ports <= 32 && root.n_in == 2 * root.ports, root.ports, root.n_in);
+    touch(d_sync, sizeof(unsigned));
+    touch(d_out, sizeof(float) * 2 * (size_t)upv.frames);
+    for (int i = 0; i < root.n_in; ++i) {
+        touch(upv.pool + (size_t)root.in_buf[i] * upv.stride, sizeof(float) * (size_t)upv.frames);
+        touch(upv.flags + root.in_buf[i], 1);
+    }
+    for (int i = 0; i < fv.n_cmds; ++i)
+        if (fv.cmds[i].block == cmd_block0) g_cmds_applied++;
+    return 0;
+}
 int launch_leaf_sum(hipStream_t, const FusedView& fv, int K) {
     g_launches[2]++;
     check_fused_common(fv, K);

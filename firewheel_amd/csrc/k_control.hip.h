@@ -841,6 +841,64 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         if (j < vd.n_stages) *(StageRegs*)&fv.states[vd.stage_state[j]] = st[j];
 }
 
+// Realtime edge (k_rt_block): ONE LANE per voice for the case that dominates a steady callback — a voice of the voice-bank
+// plan that ended the previous call steady (VoiceCache) and has no message in this ONE-block call.  The same work as
+// voice_control_wave's fast path (same steady_tail, so the same records), but 64 voices' dependent load chains
+// (descriptor -> cache / sampler state -> sample table) run side by side in one wave instead of one after the other.
+// Returns false — having written nothing — when the voice needs the state machines this block.
+__device__ inline bool voice_control_lane_steady(const FusedView& fv, const int vi, const uint32_t cmd_block0) {
+    const VoiceDesc vd = fv.voices[vi];
+    const int frames = fv.frames;
+    if (vd.sampler_state < 0) {  // a null voice: the cleared, silent-flagged buffer of schedule.rs:310-313
+        VoiceRef r;
+        r.src_l = nullptr;
+        r.r_delta = 0;
+        r.flags_gset = VB_SILENT;
+        fv.refs[(size_t)vi * fv.refs_stride] = r;
+        return true;
+    }
+    if (vd.bq_state >= 0 || vd.dl_state >= 0) return false;  // (chain-plan voices never come here)
+    if (fv.n_cmds) {
+        int first_cmd = first_cmd_block(fv.cmds, fv.n_cmds, vd.sampler_state, cmd_block0);
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
+            if (j < vd.n_stages) {
+                const int f = first_cmd_block(fv.cmds, fv.n_cmds, vd.stage_state[j], cmd_block0);
+                first_cmd = f < first_cmd ? f : first_cmd;
+            }
+        if (first_cmd < 1) return false;
+    }
+    const VoiceCache vc = fv.cache[vi];
+    if (vc.epoch != fv.epoch) return false;
+    TailJob job;
+    job.mode = vc.mode;
+    job.flags = vc.flags;
+    job.sample = vc.sample;
+    job.g = vc.g;
+    job.playhead = job.loop_start = job.loop_end = 0;
+#pragma unroll
+    for (int sl = 0; sl < 2 * FW_MAX_STAGES; ++sl) job.ramp_until[sl] = 0;
+    SampleDesc sd;
+    sd.data = nullptr;
+    sd.frames = 0;
+    sd.channels = 2;
+    sd.format = FMT_P_F32;
+    if (vc.mode != 0) {
+        const NodeState* sp = &fv.states[vd.sampler_state];
+        job.playhead = sp->playhead;
+        job.loop_start = sp->loop_start;
+        job.loop_end = sp->loop_end;
+        sd = fv.samples[vc.sample];
+        if (vc.mode == 2 && job.playhead + (uint64_t)frames > sd.frames) return false;  // the one-shot ends in this block
+    }
+    const bool no_src = (job.flags & VB_SRC_ZERO) || (job.flags & VB_SILENT);
+    const bool simple_ok = !no_src && job.sample >= 0 && (frames & 3) == 0 && simple_capable(sd, false);
+    if (simple_ok) fv.gsets[(size_t)vi * FW_GSETS] = job.g;
+    const uint64_t ph = steady_tail(fv, vi, 0, 0, 1, job, sd, 0u, simple_ok, false, false);
+    if (vc.mode != 0) fv.states[vd.sampler_state].playhead = ph;
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint32_t cmd_block0) {
     const int vi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (vi >= fv.n_voices) return;

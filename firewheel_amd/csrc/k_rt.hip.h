@@ -5,7 +5,8 @@
 // compulsory HBM traffic is microseconds below one kernel boundary, so what a callback costs is the NUMBER of dependent
 // launches: control kernel -> leaf sums -> root sum + interleave were 3 boundaries (~5 us each on this stack) + 3 more
 // host-side launch calls.  Here one workgroup per leaf SumNode does all three in sequence:
-//   1. its voices' control state machines (voice_control_wave: messages, smoothers, playheads -> this block's records),
+//   1. its voices' control: one LANE per steady voice (voice_control_lane_steady), one WAVE per voice that needs its state
+//      machines this block (voice_control_wave: messages, smoothers, playheads -> this block's records),
 //   2. its leaf sum (leaf_sum_wave: the waves take 256-frame pieces of the block),
 //   3. the LAST workgroup to finish — an agent-scope counter — adds the leaf buses in the root SumNode's port order and
 //      interleaves into the (pinned, device-mapped) output block: root_out_any, the code of k_root_out.
@@ -18,7 +19,26 @@ __global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, Roo
     const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (WAVE - 1);
     const LeafDesc ld = fv.leaves[leaf];
-    for (int p = wave; p < ld.ports; p += 4) voice_control_wave(fv, ld.first_voice + p, lane, 1, cmd_block0);
+    // 1. control.  Thread p takes port p's voice on the lane-per-voice steady path (a leaf has <= 32 ports: all of them sit
+    // in wave 0); the voices that need their state machines this block — a message, a gliding gain, a one-shot ending —
+    // are then run wave-wide, dealt out over the four waves
+    __shared__ unsigned long long s_need;
+    bool need = false;
+    if ((int)threadIdx.x < ld.ports) need = !voice_control_lane_steady(fv, ld.first_voice + (int)threadIdx.x, cmd_block0);
+    if (wave == 0) {
+        const unsigned long long m = __ballot(need);
+        if (lane == 0) s_need = m;
+    }
+    __syncthreads();
+    {
+        unsigned long long m = s_need;
+        int turn = 0;
+        while (m) {
+            const int p = __builtin_ctzll(m);
+            m &= m - 1;
+            if ((turn++ & 3) == wave) voice_control_wave(fv, ld.first_voice + p, lane, 1, cmd_block0);
+        }
+    }
     // the records (refs / gain sets / descriptors / ramps) were written by all four waves and are read by all four:
     // same CU, same L1 — a workgroup-scope release / acquire around the barrier
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

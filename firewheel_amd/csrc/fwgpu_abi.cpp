@@ -151,8 +151,23 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
         hipHostGetDevicePointer((void**)&c->d_rt_out, c->h_rt_out, 0) != hipSuccess) {
         if (c->h_rt_in) (void)hipHostFree(c->h_rt_in);
         if (c->h_rt_out) (void)hipHostFree(c->h_rt_out);
+    if (c->h_rt_flag) (void)hipHostFree(c->h_rt_flag);
         c->h_rt_in = c->h_rt_out = nullptr;
         (void)hipGetLastError();
+    }
+    if (hipHostMalloc((void**)&c->h_rt_flag, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->d_rt_flag, c->h_rt_flag, 0) != hipSuccess) {
+        if (c->h_rt_flag) (void)hipHostFree(c->h_rt_flag);
+        c->h_rt_flag = c->d_rt_flag = nullptr;
+        (void)hipGetLastError();
+    } else {
+        *c->h_rt_flag = 0;
+    }
+    if (const char* e = getenv("FWGPU_RT_SPIN")) {
+        if (atoi(e) == 0 && c->h_rt_flag) {  // experiments: blocking stream sync instead of the polled completion flag
+            (void)hipHostFree(c->h_rt_flag);
+            c->h_rt_flag = c->d_rt_flag = nullptr;
+        }
     }
     if (const char* e = getenv("FWGPU_RT_GRAPH")) c->rt_use_graph = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_ONE_LAUNCH")) c->rt_one_launch = atoi(e) != 0;
@@ -655,9 +670,30 @@ static int process_interleaved_impl(fwgpu_ctx* c, const float* input, float* out
             memcpy(c->h_rt_in, input, in_bytes_rt);
             d_in = c->d_rt_in;
         }
+        const bool spin = c->h_rt_flag != nullptr && !c->rt_use_graph;
+        c->rt_signal_seq = spin ? ++c->rt_seq : 0;
+        c->rt_signalled = false;
         int rc = run_blocks(c, frames, d_in, (int)n_in_ch, c->d_rt_out, (int)n_out_ch, true);
+        c->rt_signal_seq = 0;
         if (rc) return rc;
-        HIPC(c, hipStreamSynchronize(c->stream));
+        bool done = false;
+        if (spin && c->rt_signalled) {
+            // poll the completion flag (plain loads of pinned memory: no driver call, no sleep); a device that has not
+            // answered after ~20 ms of spinning has a problem the stream sync below will name
+            const unsigned long long want = c->rt_seq;
+            volatile unsigned long long* flag = c->h_rt_flag;
+            for (unsigned spins = 0; spins < 40000000u; ++spins) {
+                if (*flag == want) {
+                    done = true;
+                    break;
+                }
+#if defined(__x86_64__) || defined(__i386__)
+                __builtin_ia32_pause();
+#endif
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!done) HIPC(c, hipStreamSynchronize(c->stream));
         if (out_bytes) memcpy(output, c->h_rt_out, out_bytes);
         return 0;
     }

@@ -212,6 +212,12 @@ struct fwgpu_ctx {
         int n_out_ch = 0;
         const float* d_out = nullptr;
     } rt_graph;
+    // completion flag of realtime-sized calls: a word in pinned, device-mapped host memory the last kernel of the call sets to
+    // the call's sequence number; the audio thread polls it instead of paying a blocking stream sync's wake-up
+    unsigned long long *h_rt_flag = nullptr, *d_rt_flag = nullptr;
+    unsigned long long rt_seq = 0;         // sequence number of the last realtime call
+    unsigned long long rt_signal_seq = 0;  // != 0 while run_blocks should arrange for the flag to be raised
+    bool rt_signalled = false;
     bool rt_one_launch = true;  // one-block calls on the voice-bank plan: control + leaf + root in ONE kernel (FWGPU_RT_ONE_LAUNCH=0: off)
     DevBuf d_rt_sync;           // its workgroup counter
     bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2

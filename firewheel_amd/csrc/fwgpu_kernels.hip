@@ -151,10 +151,16 @@ int launch_bus_sum_ordered(hipStream_t s, const BusParts& bp, float* d_out, size
     return (int)hipGetLastError();
 }
 int launch_rt_block(hipStream_t s, const FusedView& fv, const DevView& upv, const RootArgs& root, float* d_out, uint32_t cmd_block0,
-                    unsigned* d_sync) {
+                    unsigned* d_sync, unsigned long long* d_done_flag, unsigned long long done_seq) {
     if (fv.n_leaves <= 0) return 0;
-    if (fv.has_prog) hipLaunchKernelGGL(k_rt_block<true>, dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync);
-    else hipLaunchKernelGGL(k_rt_block<false>, dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync);
+    if (fv.has_prog)
+        hipLaunchKernelGGL(k_rt_block<true>, dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync, d_done_flag, done_seq);
+    else
+        hipLaunchKernelGGL(k_rt_block<false>, dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync, d_done_flag, done_seq);
+    return (int)hipGetLastError();
+}
+int launch_signal_done(hipStream_t s, unsigned long long* d_done_flag, unsigned long long done_seq) {
+    hipLaunchKernelGGL(k_signal_done, dim3(1), dim3(1), 0, s, d_done_flag, done_seq);
     return (int)hipGetLastError();
 }
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {

@@ -96,8 +96,10 @@ int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K);
 // realtime edge: control + leaf sums + root sum + interleave of ONE block in one launch (tree = leaves + root, stereo out);
 // d_sync: one zero-initialised unsigned the workgroups count themselves in with
+// d_done_flag (may be null): device view of a pinned host word that receives done_seq when the output block is complete
 int launch_rt_block(hipStream_t s, const FusedView& fv, const DevView& upv, const RootArgs& root, float* d_out, uint32_t cmd_block0,
-                    unsigned* d_sync);
+                    unsigned* d_sync, unsigned long long* d_done_flag, unsigned long long done_seq);
+int launch_signal_done(hipStream_t s, unsigned long long* d_done_flag, unsigned long long done_seq);
 // the R-port top-level SumNode over the shards' partial buses, rank order (16-byte aligned parts)
 int launch_bus_sum_ordered(hipStream_t s, const BusParts& bp, float* d_out, size_t n_floats);
 // nq = tile size / 64 frames (1 or 2; 256-frame tiles measured slower: the serial stage then dominates the step):

@@ -321,7 +321,12 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         v.flags_blk_stride = fv.bus_flags_blk_stride;
         v.stride = c->stride;
         v.frames = (int)c->mbf;
-        LCHK(c, launch_rt_block(c->stream, fv, v, c->root_args, d_out, cmd_block0, c->d_rt_sync.as<unsigned>()));
+        unsigned long long* flag = nullptr;
+        if (c->rt_signal_seq) {  // the realtime edge asked for the completion flag: this kernel raises it itself
+            flag = c->d_rt_flag;
+            c->rt_signalled = true;
+        }
+        LCHK(c, launch_rt_block(c->stream, fv, v, c->root_args, d_out, cmd_block0, c->d_rt_sync.as<unsigned>(), flag, c->rt_signal_seq));
         return 0;
     }
     hipEvent_t e0, e1;
@@ -459,6 +464,10 @@ int run_blocks(fwgpu_ctx* c, uint64_t frames, const float* d_in, int n_in_ch, fl
         if (rc) return rc;
         done += (uint64_t)K * bf;
         blk += K;
+    }
+    if (c->rt_signal_seq && !c->rt_signalled) {
+        LCHK(c, launch_signal_done(c->stream, c->d_rt_flag, c->rt_signal_seq));
+        c->rt_signalled = true;
     }
     retire_cmds(c, nblocks);
     return 0;

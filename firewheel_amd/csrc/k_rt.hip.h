@@ -9,12 +9,13 @@
 //      machines this block (voice_control_wave: messages, smoothers, playheads -> this block's records),
 //   2. its leaf sum (leaf_sum_wave: the waves take 256-frame pieces of the block),
 //   3. the LAST workgroup to finish — an agent-scope counter — adds the leaf buses in the root SumNode's port order and
-//      interleaves into the (pinned, device-mapped) output block: root_out_any, the code of k_root_out.
+//      interleaves into the (pinned, device-mapped) output block: root_out_any, the code of k_root_out — and raises the
+//      completion flag in pinned host memory the audio thread polls.
 // Same device functions as the throughput kernels, so the arithmetic is theirs bit for bit.  Used when the call is one
 // block, the tree is leaves + root and the stream is stereo; everything else takes the launch sequence.
 template <bool PROG>
 __global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, RootArgs ra, float* __restrict__ out, uint32_t cmd_block0,
-                                                  unsigned* __restrict__ sync) {
+                                                  unsigned* __restrict__ sync, unsigned long long* done_flag, unsigned long long done_seq) {
     const int leaf = blockIdx.x;
     const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (WAVE - 1);
@@ -59,4 +60,17 @@ __global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, Roo
     if (!s_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (int f0 = 0; f0 < upv.frames; f0 += 256) root_out_any(upv, ra, out, 0u, f0 + (int)threadIdx.x);
+    // 4. completion: the output block sits in pinned host memory; publish it with a system-scope release and raise the
+    // flag the audio thread is spinning on (a blocking stream sync costs a driver wake-up, ~15 us on this stack)
+    if (done_flag) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// the same completion flag behind any launch sequence (realtime-sized calls that do not fit k_rt_block)
+__global__ void k_signal_done(unsigned long long* done_flag, unsigned long long done_seq) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -253,8 +253,15 @@ int launch_bus_sum_ordered(hipStream_t, const BusParts& bp, float* d_out, size_t
     touch(d_out, n_floats * sizeof(float));
     return 0;
 }
+int launch_signal_done(hipStream_t, unsigned long long* d_done_flag, unsigned long long done_seq) {
+    g_launches[7]++;
+    touch(d_done_flag, 8);
+    if (d_done_flag) *d_done_flag = done_seq;  // (the fake device is done when the launch returns)
+    return 0;
+}
 int launch_rt_block(hipStream_t, const FusedView& fv, const DevView& upv, const RootArgs& root, float* d_out, uint32_t cmd_block0,
-                    unsigned* d_sync) {
+                    unsigned* d_sync, unsigned long long* d_done_flag, unsigned long long done_seq) {
+    if (d_done_flag) *d_done_flag = done_seq;
     g_launches[7]++;
     check_fused_common(fv, 1);
     REQUIRE(!fv.fx_plan && root.ports >= 1 && root.ports <= 32 && root.n_in == 2 * root.ports, root.ports, root.n_in);

@@ -40,7 +40,8 @@ void collect_returns(fwgpu_ctx* c) {
     while (c->returns.peek(it)) {
         // tickets are issued in call order: an unfinished call ends the scan.  An event slot that has been re-recorded
         // since (64 calls with returns later) answers for the later call — later, never earlier, than the truth.
-        if (hipEventQuery(c->ret_events[it.ticket % fwgpu_ctx::RET_EVENTS]) != hipSuccess) {
+        if (it.ticket >= c->ret_done_ticket.load(std::memory_order_acquire) &&
+            hipEventQuery(c->ret_events[it.ticket % fwgpu_ctx::RET_EVENTS]) != hipSuccess) {
             (void)hipGetLastError();
             break;
         }
@@ -694,6 +695,7 @@ static int process_interleaved_impl(fwgpu_ctx* c, const float* input, float* out
             std::atomic_thread_fence(std::memory_order_acquire);
         }
         if (!done) HIPC(c, hipStreamSynchronize(c->stream));
+        c->ret_done_ticket.store(c->ret_ticket, std::memory_order_release);  // everything this call handed back is final
         if (out_bytes) memcpy(output, c->h_rt_out, out_bytes);
         return 0;
     }
@@ -714,6 +716,7 @@ static int process_interleaved_impl(fwgpu_ctx* c, const float* input, float* out
     if (rc) return rc;
     if (out_bytes) HIPC(c, hipMemcpyAsync(output, c->d_out_stage.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+    c->ret_done_ticket.store(c->ret_ticket, std::memory_order_release);
     return 0;
 }
 

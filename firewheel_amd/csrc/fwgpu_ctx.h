@@ -193,6 +193,7 @@ struct fwgpu_ctx {
     static constexpr uint32_t RET_EVENTS = 64;
     hipEvent_t ret_events[RET_EVENTS] = {nullptr};
     uint32_t ret_ticket = 0;         // audio thread: process calls that returned a sample so far
+    std::atomic<uint32_t> ret_done_ticket{0};  // tickets below this belong to calls the audio thread has SEEN complete (sync / flag)
     bool ret_this_call = false;
     // control side of the same: reference counts per sample id = SetSample messages sent - samples handed back
     std::vector<int64_t> sample_refs;

@@ -3,6 +3,8 @@
 // the buffer pool and the launch plan in HBM.  No CPU compute path exists: every process call is kernels.
 #include "fwgpu_ctx.h"
 
+#include <stdio.h>
+
 namespace {
 
 thread_local std::string g_create_error;  // fwgpu_create_error(): of the calling thread's last failed fwgpu_ctx_create
@@ -170,6 +172,7 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
             c->h_rt_flag = c->d_rt_flag = nullptr;
         }
     }
+    if (const char* e = getenv("FWGPU_HOST_PROF")) c->host_prof = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_GRAPH")) c->rt_use_graph = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_ONE_LAUNCH")) c->rt_one_launch = atoi(e) != 0;
     if (c->d_rt_sync.ensure(256) != hipSuccess || hipMemset(c->d_rt_sync.p, 0, 256) != hipSuccess) c->d_rt_sync.release();
@@ -178,6 +181,10 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
 
 void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     if (!c) return;
+    if (c->host_prof && c->hp_calls)
+        fprintf(stderr, "fwgpu host profile: %llu process calls, %.2f us each inside run_blocks; %llu k_rt_block launches, %.2f us each inside the HIP launch call\n",
+                (unsigned long long)c->hp_calls, c->hp_call_ns / 1e3 / (double)c->hp_calls, (unsigned long long)c->hp_launches,
+                c->hp_launches ? c->hp_launch_ns / 1e3 / (double)c->hp_launches : 0.0);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (SampleRec& s : c->samples)

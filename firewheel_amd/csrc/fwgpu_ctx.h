@@ -229,6 +229,11 @@ struct fwgpu_ctx {
     uint32_t proc_stream_status = 0;
     uint64_t n_underflows = 0, n_overflows = 0;
 
+    // FWGPU_HOST_PROF=1 (experiments): host nanoseconds spent inside process calls / inside the HIP launch calls they make,
+    // printed to stderr when the ctx is destroyed
+    bool host_prof = false;
+    uint64_t hp_calls = 0, hp_call_ns = 0, hp_launch_ns = 0, hp_launches = 0;
+
     // timing
     bool timing = false;
     TimerCat timers[5];  // 0 fused leaf kernel, 1 control kernel, 2 upper sums + out, 3 generic block, 4 k_fir_gemm alone

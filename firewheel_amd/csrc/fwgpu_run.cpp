@@ -2,6 +2,8 @@
 // retirement, the kernel sequence of each launch plan, HIP-event timing.
 #include "fwgpu_ctx.h"
 
+#include <chrono>
+
 namespace fwgpu {
 
 namespace {
@@ -326,6 +328,13 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
             flag = c->d_rt_flag;
             c->rt_signalled = true;
         }
+        if (c->host_prof) {
+            const auto t0 = std::chrono::steady_clock::now();
+            LCHK(c, launch_rt_block(c->stream, fv, v, c->root_args, d_out, cmd_block0, c->d_rt_sync.as<unsigned>(), flag, c->rt_signal_seq));
+            c->hp_launch_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            c->hp_launches++;
+            return 0;
+        }
         LCHK(c, launch_rt_block(c->stream, fv, v, c->root_args, d_out, cmd_block0, c->d_rt_sync.as<unsigned>(), flag, c->rt_signal_seq));
         return 0;
     }
@@ -402,8 +411,18 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
 }
 
 // all blocks of one call; d_in may be null.  frames may end in a partial block.
+static int run_blocks_impl(fwgpu_ctx* c, uint64_t frames, const float* d_in, int n_in_ch, float* d_out, int n_out_ch, bool stable_out);
 int run_blocks(fwgpu_ctx* c, uint64_t frames, const float* d_in, int n_in_ch, float* d_out, int n_out_ch,
                bool stable_out) {
+    if (!c->host_prof) return run_blocks_impl(c, frames, d_in, n_in_ch, d_out, n_out_ch, stable_out);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = run_blocks_impl(c, frames, d_in, n_in_ch, d_out, n_out_ch, stable_out);
+    c->hp_call_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    c->hp_calls++;
+    return rc;
+}
+static int run_blocks_impl(fwgpu_ctx* c, uint64_t frames, const float* d_in, int n_in_ch, float* d_out, int n_out_ch,
+                           bool stable_out) {
     const uint32_t mbf = c->mbf;
     const uint32_t nblocks = (uint32_t)((frames + mbf - 1) / mbf);
     int rc = upload_sample_table(c);

@@ -43,3 +43,4 @@ for _ in range(n):
     cx.synchronize()
 t1 = time.perf_counter()
 print("call + hipStreamSynchronize, output left in HBM us %.2f" % ((t1 - t0) / n * 1e6))
+cx.close()

@@ -7,6 +7,13 @@
 
 namespace {
 
+// hipSetDevice costs ~8 us per call on this stack (measured: it was most of the host time of a realtime callback); the
+// thread's current device is asked first, which is a thread-local read
+inline void use_device(fwgpu_ctx* c) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != c->device) (void)hipSetDevice(c->device);
+}
+
 thread_local std::string g_create_error;  // fwgpu_create_error(): of the calling thread's last failed fwgpu_ctx_create
 
 // Control side of a message: validate against the graph (owned by the control side), account for the sampler's ring
@@ -185,7 +192,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
         fprintf(stderr, "fwgpu host profile: %llu process calls, %.2f us each inside run_blocks; %llu k_rt_block launches, %.2f us each inside the HIP launch call\n",
                 (unsigned long long)c->hp_calls, c->hp_call_ns / 1e3 / (double)c->hp_calls, (unsigned long long)c->hp_launches,
                 c->hp_launches ? c->hp_launch_ns / 1e3 / (double)c->hp_launches : 0.0);
-    (void)hipSetDevice(c->device);
+    use_device(c);
     (void)hipStreamSynchronize(c->stream);
     for (SampleRec& s : c->samples)
         if (s.alive && s.owned && s.d_data) (void)hipFree(s.d_data);
@@ -304,7 +311,7 @@ int fwgpu_cycle_detected(fwgpu_ctx* c) { return c ? (c->graph.cycle_detected() ?
 
 int fwgpu_update(fwgpu_ctx* c) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
-    (void)hipSetDevice(c->device);
+    use_device(c);
     if (!c->graph.needs_compile && c->have_plan) return 0;
     Plan plan;
     std::string err;
@@ -315,7 +322,7 @@ int fwgpu_update(fwgpu_ctx* c) {
 
 int fwgpu_schedule_upload(fwgpu_ctx* c, const fwgpu_sched_node* sn, uint32_t n_nodes, uint32_t num_buffers) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
-    (void)hipSetDevice(c->device);
+    use_device(c);
     if (n_nodes < 2 || !sn) return fail(c, FWGPU_ERR_INVALID, "a schedule holds at least graph_in and graph_out");
     for (uint32_t i = 0; i < n_nodes; ++i)
         if ((sn[i].num_inputs && (!sn[i].in_buffer_index || !sn[i].in_should_clear)) || (sn[i].num_outputs && !sn[i].out_buffer_index))
@@ -397,7 +404,7 @@ int fwgpu_set_force_generic(fwgpu_ctx* c, int on) {
 }
 int fwgpu_plan_chain_stats(fwgpu_ctx* c, uint64_t* steady_workgroups, uint64_t* general_workgroups) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
-    (void)hipSetDevice(c->device);
+    use_device(c);
     unsigned long long h[2] = {0, 0};
     if (c->d_chain_stats.p) {
         HIPC(c, hipStreamSynchronize(c->stream));
@@ -418,7 +425,7 @@ int fwgpu_set_max_batch(fwgpu_ctx* c, uint32_t k) {
 static size_t fmt_elem_size(int fmt) { return (fmt == FMT_I_F32 || fmt == FMT_P_F32) ? 4 : 2; }
 
 static int sample_add(fwgpu_ctx* c, int format, uint32_t channels, uint64_t frames, const void* data, bool on_device) {
-    (void)hipSetDevice(c->device);
+    use_device(c);
     if (format < 0 || format > FMT_P_F32 || channels == 0) return fail(c, FWGPU_ERR_INVALID, "bad sample format/channels");
     if (frames > (1ull << 40) / channels) return fail(c, FWGPU_ERR_INVALID, "sample too large (frames x channels > 2^40)");
     if (frames && !data) return fail(c, FWGPU_ERR_INVALID, "sample data is null");
@@ -468,7 +475,7 @@ int fwgpu_sample_destroy(fwgpu_ctx* c, int sample) {
     for (const HostNode& n : c->graph.nodes)
         if (n.alive && (n.kind == K_FIR || n.kind == K_RESAMPLER) && n.init.sample == sample)
             return fail(c, FWGPU_ERR_INVALID, "sample is in use by a FIR / resampler node");
-    (void)hipSetDevice(c->device);
+    use_device(c);
     (void)hipStreamSynchronize(c->stream);
     SampleRec& r = c->samples[sample];
     if (r.owned && r.d_data) (void)hipFree(r.d_data);
@@ -483,7 +490,7 @@ int fwgpu_sample_destroy(fwgpu_ctx* c, int sample) {
 int fwgpu_poll_returned_samples(fwgpu_ctx* c, int64_t* nodes, int* samples, int cap) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     if (cap < 0 || (cap > 0 && (!nodes || !samples))) return fail(c, FWGPU_ERR_INVALID, "null output arrays");
-    (void)hipSetDevice(c->device);
+    use_device(c);
     collect_returns(c);
     int n = 0;
     for (; n < cap && (size_t)n < c->ret_ready.size(); ++n) {
@@ -496,7 +503,7 @@ int fwgpu_poll_returned_samples(fwgpu_ctx* c, int64_t* nodes, int* samples, int 
 int fwgpu_sample_retired(fwgpu_ctx* c, int sample) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     if (sample < 0 || sample >= (int)c->samples.size()) return fail(c, FWGPU_ERR_INVALID, "unknown sample id");
-    (void)hipSetDevice(c->device);
+    use_device(c);
     collect_returns(c);
     for (const HostNode& n : c->graph.nodes)
         if (n.alive && (n.kind == K_FIR || n.kind == K_RESAMPLER) && n.init.sample == sample) return 0;
@@ -731,7 +738,7 @@ int fwgpu_process_interleaved(fwgpu_ctx* c, const float* input, float* output, u
                               uint64_t frames, double stream_time_secs, uint32_t stream_status) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     AudioCallScope audio;
-    (void)hipSetDevice(c->device);
+    use_device(c);
     if (n_in_ch > 64 || n_out_ch > 64) return fail(c, FWGPU_ERR_INVALID, "at most 64 stream channels per side (processor.rs:43-44)");
     if (frames > (1ull << 32)) return fail(c, FWGPU_ERR_INVALID, "more than 2^32 frames in one call");
     size_t out_bytes = (size_t)frames * n_out_ch * sizeof(float);
@@ -831,7 +838,7 @@ int fwgpu_stream_stats(fwgpu_stream* s, uint64_t* callbacks, uint64_t* underflow
 int fwgpu_process_blocks_device(fwgpu_ctx* c, uint32_t num_blocks, float* d_output, uint32_t n_out_ch) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     AudioCallScope audio;
-    (void)hipSetDevice(c->device);
+    use_device(c);
     if (!c->have_plan) return fail(c, FWGPU_ERR_INVALID, "no schedule: call fwgpu_update first");
     if (num_blocks == 0) return 0;
     if (n_out_ch > 64 || (n_out_ch && !d_output)) return fail(c, FWGPU_ERR_INVALID, "bad output (null, or more than 64 channels)");
@@ -841,7 +848,7 @@ int fwgpu_process_blocks_device(fwgpu_ctx* c, uint32_t num_blocks, float* d_outp
 int fwgpu_bus_sum_ordered(fwgpu_ctx* c, const float* const* d_parts, uint32_t n_parts, float* d_out, uint64_t n_floats) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     AudioCallScope audio;
-    (void)hipSetDevice(c->device);
+    use_device(c);
     if (n_parts == 0 || n_parts > FW_MAX_BUS_PARTS || !d_parts || !d_out) return fail(c, FWGPU_ERR_INVALID, "1..64 partial buses");
     BusParts bp;
     bp.n = (int)n_parts;
@@ -865,7 +872,7 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
                        float* const* outputs, uint32_t n_out, uint64_t in_mask, uint64_t* out_mask, double, uint32_t) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     AudioCallScope audio;
-    (void)hipSetDevice(c->device);
+    use_device(c);
     HostNode* hn = c->graph.get(node);
     if (!hn || !hn->activated) return fail(c, FWGPU_ERR_INVALID, "node is not activated (call fwgpu_update)");
     if (hn->n_in != n_in || hn->n_out != n_out) return fail(c, FWGPU_ERR_INVALID, "port counts differ from add_node");

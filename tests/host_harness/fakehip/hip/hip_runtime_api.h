@@ -28,6 +28,7 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 static inline hipError_t hipGetLastError(void) { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     memset(p, 0, sizeof(*p));
     strcpy(p->name, "host harness (no device)");

@@ -219,6 +219,7 @@ struct fwgpu_ctx {
     unsigned long long rt_seq = 0;         // sequence number of the last realtime call
     unsigned long long rt_signal_seq = 0;  // != 0 while run_blocks should arrange for the flag to be raised
     bool rt_signalled = false;
+    bool rt_last_batch = false;  // the fused batch being launched ends the call
     bool rt_one_launch = true;  // one-block calls on the voice-bank plan: control + leaf + root in ONE kernel (FWGPU_RT_ONE_LAUNCH=0: off)
     DevBuf d_rt_sync;           // its workgroup counter
     bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2

@@ -324,7 +324,8 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         v.stride = c->stride;
         v.frames = (int)c->mbf;
         unsigned long long* flag = nullptr;
-        if (c->rt_signal_seq) {  // the realtime edge asked for the completion flag: this kernel raises it itself
+        if (c->rt_signal_seq && c->rt_last_batch) {  // the realtime edge asked for the completion flag and this is the call's
+                                                       // last launch: the kernel raises it itself
             flag = c->d_rt_flag;
             c->rt_signalled = true;
         }
@@ -470,7 +471,9 @@ static int run_blocks_impl(fwgpu_ctx* c, uint64_t frames, const float* d_in, int
         if (can_fuse && left >= mbf) {
             const uint32_t kcap = c->fused_fx ? std::min<uint32_t>(c->kmax, CH_FAST_KMAX) : c->kmax;
             uint32_t K = (uint32_t)std::min<uint64_t>(left / mbf, kcap);
+            c->rt_last_batch = (uint64_t)K * mbf == left;
             rc = run_fused_batch(c, (int)K, blk, d_out + done * n_out_ch, n_out_ch);
+            c->rt_last_batch = false;
             if (rc) return rc;
             done += (uint64_t)K * mbf;
             blk += K;

@@ -13,6 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 tag, cfg, steps, raw, outdir = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+suffix = sys.argv[6] if len(sys.argv) > 6 else ""
+extra = sys.argv[7] if len(sys.argv) > 7 else ""
 V, B, K, F, _ = bench.DEFAULTS[cfg]
 
 
@@ -24,9 +26,9 @@ def find(pattern):
 stats = find(raw + "_stats/**/*kernel_stats.csv")
 if stats:
     rows = list(csv.reader(open(stats)))
-    with open(os.path.join(outdir, "%s_%s_kernel_stats.csv" % (tag, cfg)), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --workload %s --lean --steps %d --warmup 3"
-                "   (MI355X, %s; %d voices, block %d, %d blocks per step)\n" % (cfg, steps, tag, V, B, K))
+    with open(os.path.join(outdir, "%s_%s%s_kernel_stats.csv" % (tag, cfg, suffix)), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --workload %s --lean --steps %d --warmup 3 %s"
+                "   (MI355X, %s; %d voices, block %d, %d blocks per step)\n" % (cfg, steps, extra, tag, V, B, K))
         w = csv.writer(f)
         for r in rows[:14]:
             w.writerow(r)
@@ -47,8 +49,8 @@ per_vs = {"cfg2": 8.0, "cfg3": 24.0, "cfg5": 8.0}.get(cfg)
 dom = {"cfg2": "k_leaf_sum", "cfg3": "k_chain", "cfg5": "k_leaf_sum", "cfg4": "k_fir_gemm"}[cfg]
 out = {
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --workload %s --lean "
-               "--no-kernel-timing --steps 4 --warmup 2 (one pass per counter)" % cfg,
-    "workload": {"name": cfg, "voices": V, "block": B, "blocks_per_step": K},
+               "--no-kernel-timing --steps 4 --warmup 2 %s (one pass per counter)" % (cfg, extra),
+    "workload": {"name": cfg + suffix, "voices": V, "block": B, "blocks_per_step": K},
     "units": "rocprofv3 reports KiB; gfx950 FETCH_SIZE counts 1/2 of wide coalesced reads (MI355X_MICROARCH.md §HBM) -> "
              "doubled; WRITE_SIZE as reported",
     "per_launch_raw_KiB": {k: {"FETCH_SIZE": fetch.get(k), "WRITE_SIZE": write.get(k)} for k in sorted(set(fetch) | set(write))},
@@ -65,5 +67,5 @@ for k in sorted(set(fetch) | set(write)):
         ent["algorithmic_bytes"] = alg
         ent["traffic_over_algorithmic"] = (fb + wb) / alg
     out[name] = ent
-json.dump(out, open(os.path.join(outdir, "%s_%s_pmc_hbm_traffic.json" % (tag, cfg)), "w"), indent=1)
+json.dump(out, open(os.path.join(outdir, "%s_%s%s_pmc_hbm_traffic.json" % (tag, cfg, suffix)), "w"), indent=1)
 print(cfg, json.dumps({k: v for k, v in out.items() if k.startswith("k_")}))

@@ -2,5 +2,5 @@
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o $tag -- python $GRAFT_REPO_ROOT/bench.py --lean "$@" > $out.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o $tag -- python $GRAFT_REPO_ROOT/bench.py --lean "$@" > $out.log 2>&1
 find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -12 {}'

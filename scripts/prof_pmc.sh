@@ -3,7 +3,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   out=$GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$ctr
-  timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o $tag -- python $GRAFT_REPO_ROOT/bench.py --lean --no-kernel-timing --steps 6 --warmup 2 "$@" > $out.log 2>&1
+  timeout 120 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o $tag -- python $GRAFT_REPO_ROOT/bench.py --lean --no-kernel-timing --steps 6 --warmup 2 "$@" > $out.log 2>&1
   f=$(find $out -name "*counter_collection.csv" | head -1)
   python - "$f" $ctr <<'PY'
 import csv, sys, collections

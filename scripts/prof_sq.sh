@@ -7,7 +7,7 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
             "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM"; do
   pass=$((pass+1))
   out=$GRAFT_REPO_ROOT/gpurun_out/sq_${tag}_$pass
-  timeout 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o $tag -- python $GRAFT_REPO_ROOT/bench.py --lean --no-kernel-timing --steps 4 --warmup 1 "$@" > $out.log 2>&1
+  timeout 120 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o $tag -- python $GRAFT_REPO_ROOT/bench.py --lean --no-kernel-timing --steps 4 --warmup 1 "$@" > $out.log 2>&1
   f=$(find $out -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import csv, sys, collections

@@ -97,16 +97,31 @@ __device__ __forceinline__ v4f gload4(const float* p) {
 }
 
 // lane p holds port p's VoiceRef + GainSet; every port is VB_SIMPLE (contiguous planar f32, constant gains)
+#ifndef LEAF_SPEC_GSET
+#define LEAF_SPEC_GSET 1  // gain set 0 of every port is requested together with the port's record (it is the one in use on a
+                          // steady voice), not after it: one dependent memory round trip less at the head of every wave
+#endif
+#ifndef LEAF_PREFETCH
+#define LEAF_PREFETCH 0   // the first LEAF_U ports' source loads are issued before the gain sets have arrived
+#endif
 template <int NG>
 __device__ __forceinline__ void leaf_fast(const float* my_l, const float* my_r, const GainSet& my_g, int ports, int f0,
-                                          v4f& accl, v4f& accr) {
+                                          v4f& accl, v4f& accr, const v4f* pre_l = nullptr, const v4f* pre_r = nullptr) {
     for (int p0 = 0; p0 < ports; p0 += LEAF_U) {
         v4f xl[LEAF_U], xr[LEAF_U];
+        if (pre_l != nullptr && p0 == 0) {
 #pragma unroll
-        for (int u = 0; u < LEAF_U; ++u) {
-            if (p0 + u < ports) {
-                xl[u] = gload4(readlane_ptr(my_l, p0 + u) + f0);
-                xr[u] = gload4(readlane_ptr(my_r, p0 + u) + f0);
+            for (int u = 0; u < LEAF_U; ++u) {
+                xl[u] = pre_l[u];
+                xr[u] = pre_r[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < LEAF_U; ++u) {
+                if (p0 + u < ports) {
+                    xl[u] = gload4(readlane_ptr(my_l, p0 + u) + f0);
+                    xr[u] = gload4(readlane_ptr(my_r, p0 + u) + f0);
+                }
             }
         }
 #pragma unroll
@@ -280,12 +295,26 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
     ref.src_l = nullptr;
     ref.r_delta = 0;
     ref.flags_gset = VB_SILENT;
-    if (lane < ld.ports) ref = fv.refs[(size_t)(ld.first_voice + lane) * fv.refs_stride + k];
-    const uint32_t my_flags = ref.flags_gset & 0xffu;
     GainSet my_g;
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES; ++j) my_g.g[j][0] = my_g.g[j][1] = 1.0f;
+#if LEAF_SPEC_GSET
+    GainSet g0 = my_g;
+    if (lane < ld.ports) {  // (slot 0 may hold anything on a voice that is not VB_SIMPLE this block: then it is not used)
+        g0 = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS];
+        ref = fv.refs[(size_t)(ld.first_voice + lane) * fv.refs_stride + k];
+    }
+    const uint32_t my_flags = ref.flags_gset & 0xffu;
+    if (my_flags & VB_SIMPLE) {
+        const uint32_t gi = (ref.flags_gset >> 8) & 0xffu;
+        my_g = g0;
+        if (gi != 0) my_g = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + gi];
+    }
+#else
+    if (lane < ld.ports) ref = fv.refs[(size_t)(ld.first_voice + lane) * fv.refs_stride + k];
+    const uint32_t my_flags = ref.flags_gset & 0xffu;
     if (my_flags & VB_SIMPLE) my_g = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + ((ref.flags_gset >> 8) & 0xffu)];
+#endif
     uint32_t my_prog = 0u;
     if constexpr (PROG) {
         if (lane < ld.ports) my_prog = fv.progs[ld.first_voice + lane];
@@ -307,8 +336,10 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
         my_r = (const float*)pr;
         my_rd = rd;
         my_cls = cl;
+#if !LEAF_PREFETCH
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES; ++j) asm volatile("" : "+v"(my_g.g[j][0]), "+v"(my_g.g[j][1]));
+#endif
     }
     const uint64_t lanes_in = mask_all_silent_bits(ld.ports);
     const uint64_t silent_ports = __ballot((my_flags & VB_SILENT) != 0) & lanes_in;
@@ -321,19 +352,43 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
     const bool fast = all_simple && one_class && cls0 == SF_P_F32;
     const bool fast_cls = !PROG && all_simple && one_class && cls0 != SF_P_F32;  // (program voices on other formats: port by port)
 
-    for (int f0 = lane * 4 + part * 256; f0 < frames; f0 += 256 * wpk) {
+    const int f_first = lane * 4 + part * 256;
+#if LEAF_PREFETCH
+    // the first LEAF_U ports of this wave's first quad of frames: requested NOW, with the pointers alone — the gain sets are
+    // only needed at the multiply, and their loads (issued before these) complete first (vmcnt counts in order)
+    v4f pre_l[LEAF_U], pre_r[LEAF_U];
+    const bool use_pre = !PROG && fast;
+    if (use_pre && f_first < frames) {
+#pragma unroll
+        for (int u = 0; u < LEAF_U; ++u) {
+            const int pu = u < ld.ports ? u : 0;
+            pre_l[u] = gload4(readlane_ptr(my_l, pu) + f_first);
+            pre_r[u] = gload4(readlane_ptr(my_r, pu) + f_first);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES; ++j) asm volatile("" : "+v"(my_g.g[j][0]), "+v"(my_g.g[j][1]));
+#endif
+    for (int f0 = f_first; f0 < frames; f0 += 256 * wpk) {
         v4f accl = splat(0.f), accr = splat(0.f);
         if (fast) {
             if constexpr (PROG) {
                 leaf_fast_prog(my_l, my_r, my_g, my_prog, fv.n_gain_stages, ld.ports, f0, accl, accr);
             } else {
+#if LEAF_PREFETCH
+                const v4f* pl = f0 == f_first ? pre_l : nullptr;
+                const v4f* pr = f0 == f_first ? pre_r : nullptr;
+#else
+                const v4f* pl = nullptr;
+                const v4f* pr = nullptr;
+#endif
                 switch (fv.n_gain_stages) {
-                    case 1: leaf_fast<1>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
-                    case 2: leaf_fast<2>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
-                    case 3: leaf_fast<3>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
-                    case 4: leaf_fast<4>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
-                    case 5: leaf_fast<5>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
-                    default: leaf_fast<6>(my_l, my_r, my_g, ld.ports, f0, accl, accr); break;
+                    case 1: leaf_fast<1>(my_l, my_r, my_g, ld.ports, f0, accl, accr, pl, pr); break;
+                    case 2: leaf_fast<2>(my_l, my_r, my_g, ld.ports, f0, accl, accr, pl, pr); break;
+                    case 3: leaf_fast<3>(my_l, my_r, my_g, ld.ports, f0, accl, accr, pl, pr); break;
+                    case 4: leaf_fast<4>(my_l, my_r, my_g, ld.ports, f0, accl, accr, pl, pr); break;
+                    case 5: leaf_fast<5>(my_l, my_r, my_g, ld.ports, f0, accl, accr, pl, pr); break;
+                    default: leaf_fast<6>(my_l, my_r, my_g, ld.ports, f0, accl, accr, pl, pr); break;
                 }
             }
         } else if (fast_cls) {

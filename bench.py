@@ -50,7 +50,7 @@ DEFAULTS = {
     "cfg5": (8192, 1024, 64, 65536, 60),
 }
 # node kinds of include/fwgpu.h (both engines take raw kinds)
-K_BEEP, K_VOLUME, K_SUM, K_SAMPLER, K_HARD_CLIP, K_PAN, K_WIDTH, K_BIQUAD, K_DELAY, K_FIR = 1, 2, 3, 4, 5, 8, 9, 10, 11, 12
+K_BEEP, K_VOLUME, K_SUM, K_SAMPLER, K_HARD_CLIP, K_PAN, K_WIDTH, K_BIQUAD, K_DELAY, K_FIR, K_RESAMPLER = 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13
 PLANAR_F32, INTERLEAVED_I16 = 5, 0
 
 
@@ -143,14 +143,19 @@ def sum_tree(e, ends, radix, master=False):
     e.connect_stereo(cur, e.out_node())
 
 
-def graph_bank(e, voices, radix, seed=0, master=False, extra=()):
-    """cfg2 / cfg5 voice: sampler -> gain -> pan [-> width -> hard clip with --voice-fx].  Returns (samplers, volumes)."""
+def graph_bank(e, voices, radix, seed=0, master=False, extra=(), rs_samples=None):
+    """cfg2 / cfg5 voice: sampler -> gain -> pan [-> width -> hard clip with --voice-fx].  Returns (samplers, volumes).
+    rs_samples: the voices' sources are SPEC resamplers (looping, ratio U(0.5, 1.5)) on these sample ids instead of samplers."""
     import numpy as np
 
     rng = np.random.default_rng(1234 + seed)
+    rng_ratio = np.random.default_rng(777 + seed)
     ends, samplers, volumes = [], [], []
     for v in range(voices):
-        s = e.add(K_SAMPLER, 0, 2, [100.0])
+        if rs_samples is not None:
+            s = e.add(K_RESAMPLER, 0, 2, [float(rs_samples[v]), float(rng_ratio.uniform(0.5, 1.5)), 1.0, 1.0])
+        else:
+            s = e.add(K_SAMPLER, 0, 2, [100.0])
         vol = e.add(K_VOLUME, 2, 2, [float(rng.uniform(10, 100))])
         pan = e.add(K_PAN, 2, 2, [float(rng.uniform(-1, 1))])
         e.connect_stereo(s, vol)
@@ -213,13 +218,13 @@ def graph_reverb(e, voices, radix, ir_sample):
     return samplers, []
 
 
-def build_graph(e, wl, voices, radix, seed, master, ir_sample=None, voice_fx=False):
+def build_graph(e, wl, voices, radix, seed, master, ir_sample=None, voice_fx=False, rs_samples=None):
     if wl == "cfg4":
         return graph_reverb(e, voices, radix, ir_sample)
     if wl == "cfg3":
         return graph_chain(e, voices, radix, seed, master)
     extra = ((K_WIDTH, [1.3]), (K_HARD_CLIP, [-3.0])) if voice_fx else ()
-    return graph_bank(e, voices, radix, seed, master, extra)
+    return graph_bank(e, voices, radix, seed, master, extra, rs_samples)
 
 
 def want_plan(wl, force_generic):
@@ -234,12 +239,15 @@ def make_gpu(fa, wl, V, B, K, radix, src, F, sfmt, seed, args, stream, device):
         cx.set_force_generic(True)
     g = GpuSide(cx)
     ir = cx.new_sample(PLANAR_F32, 2, reverb_ir(args.taps)) if wl == "cfg4" else None
-    samplers, volumes = build_graph(g, wl, V, radix, seed, args.master, ir, args.voice_fx)
     elem = 4 if sfmt == "f32" else 2
     fmt = PLANAR_F32 if sfmt == "f32" else INTERLEAVED_I16
-    for v, s in enumerate(samplers):
-        smp = cx.new_sample_device(fmt, 2, F, src.data_ptr() + v * 2 * F * elem)
-        g.start(s, smp)
+    rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
+    ids = [cx.new_sample_device(fmt, 2, F, src.data_ptr() + v * 2 * F * elem) for v in range(V)] if rs else None
+    samplers, volumes = build_graph(g, wl, V, radix, seed, args.master, ir, args.voice_fx, ids)
+    if not rs:
+        for v, s in enumerate(samplers):
+            smp = cx.new_sample_device(fmt, 2, F, src.data_ptr() + v * 2 * F * elem)
+            g.start(s, smp)
     assert cx.plan_kind() == want_plan(wl, args.force_generic), "expected launch plan %d, got %d" % (
         want_plan(wl, args.force_generic), cx.plan_kind())
     return cx, g, samplers, volumes
@@ -249,9 +257,12 @@ def make_oracle(wl, V, B, radix, seed, args, host_src, fmt=PLANAR_F32):
     """the oracle on the same graph; host_src[v] = that voice's sample data as the engine's format wants it"""
     o = OracleSide(B)
     ir = o.e.new_sample(PLANAR_F32, 2, reverb_ir(args.taps)) if wl == "cfg4" else None
-    samplers, volumes = build_graph(o, wl, V, radix, seed, args.master, ir, args.voice_fx)
-    for v, s in enumerate(samplers):
-        o.start(s, o.e.new_sample(fmt, 2, host_src[v]))
+    rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
+    ids = [o.e.new_sample(fmt, 2, host_src[v]) for v in range(V)] if rs else None
+    samplers, volumes = build_graph(o, wl, V, radix, seed, args.master, ir, args.voice_fx, ids)
+    if not rs:
+        for v, s in enumerate(samplers):
+            o.start(s, o.e.new_sample(fmt, 2, host_src[v]))
     return o, samplers, volumes
 
 
@@ -347,14 +358,20 @@ def parity_check(fa, torch, wl, V, B, K, radix, seed, args, src, F, sfmt, stream
         torch.cuda.synchronize()
     cx.process_blocks_device(K, out.data_ptr(), 2)
     cx.synchronize()
-    if wl in ("cfg2", "cfg5") and K >= 4 and F >= K * B and sfmt == "f32":
+    rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
+    if rs:
+        blocks = [0, 1]  # a resampled voice's block does not start on a source-block boundary: prefix only, whole samples
+    elif wl in ("cfg2", "cfg5") and K >= 4 and F >= K * B and sfmt == "f32":
         blocks = [0, 1, K // 2, K - 1]
     elif wl == "cfg4":
         blocks = [0]
     else:
         blocks = [0, 1] if K >= 2 else [0]
     got = torch.cat([out[b * B * 2:(b + 1) * B * 2] for b in blocks]).cpu().numpy()
-    if sfmt == "f32":
+    if rs:  # (looping resamplers wrap their 16-tap window around the sample's end: the oracle needs whole samples)
+        host = src.cpu().numpy()
+        fmt = PLANAR_F32 if sfmt == "f32" else INTERLEAVED_I16
+    elif sfmt == "f32":
         host = torch.cat([src[:, :, b * B:(b + 1) * B] for b in blocks], dim=2).cpu().numpy()
         fmt = PLANAR_F32
     else:
@@ -614,6 +631,8 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
         }[wl]
         if args.voice_fx and wl in ("cfg2", "cfg5"):
             desc += " + StereoWidth + HardClip in every voice"
+        if args.rs_source and wl in ("cfg2", "cfg5"):
+            desc = desc.replace("sampler->", "resampler(ratio U(0.5,1.5), looping)->")
         res = {
             "value": total / dt,
             "ms_per_step": dt / steps * 1e3,
@@ -735,6 +754,8 @@ def main():
                          "then run that chain with the generic node kernel on the mix bus)")
     ap.add_argument("--voice-fx", action="store_true",
                     help="cfg2/cfg5: a StereoWidthNode + HardClipNode at the end of every voice chain")
+    ap.add_argument("--rs-source", action="store_true",
+                    help="cfg2/cfg5: the voices' sources are SPEC resamplers (looping, ratio U(0.5, 1.5)) instead of samplers")
     ap.add_argument("--force-generic", action="store_true",
                     help="run the workload on the generic level-batched executor (plan 0) instead of its fused plan")
     ap.add_argument("--variant", choices=["A", "B", "C"], default="A",
@@ -757,7 +778,7 @@ def main():
     steps = args.steps or dS
     wl = args.workload
     default_shape = (wl == "cfg2" and (V, B, K, F) == (dV, dB, dK, dF) and args.source_format == "f32" and args.variant == "A" and
-                     not (args.master or args.voice_fx or args.force_generic or args.host_buffers))
+                     not (args.master or args.voice_fx or args.rs_source or args.force_generic or args.host_buffers))
 
     # stdout carries exactly ONE line (the JSON, rank 0): everything else that writes to fd 1 — RCCL's version banner
     # and warnings come from C stdio, flushed whenever — is sent to stderr for the life of the process

@@ -122,7 +122,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
             for (;;) {
                 const PlanNode& n = plan.nodes[cur];
                 if (covered[cur]) return false;
-                if (n.kind == K_SAMPLER) {
+                if (n.kind == K_SAMPLER || n.kind == K_RESAMPLER) {
                     if (n.n_in != 0 || n.n_out != 2) return false;
                     covered[cur] = 1;
                     break;
@@ -155,6 +155,11 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
             vd.dl_state = dl >= 0 ? (int)plan.nodes[dl].slot : -1;
             if (bq >= 0 || dl >= 0) fb.has_fx = true;
             vd.sampler_state = (int)plan.nodes[cur].slot;
+            vd.src_kind = plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0;
+            if (vd.src_kind == 1) {
+                if (bq >= 0 || dl >= 0) return false;  // (the chain plan's source fetch is the sampler's)
+                fb.has_prog = true;                    // the polyphase fetch lives in the leaf kernel's program instantiation
+            }
             vd.n_stages = (int)chain.size();
             uint32_t prog = 0;
             for (int j = 0; j < vd.n_stages; ++j) {  // schedule order: nearest the sampler first

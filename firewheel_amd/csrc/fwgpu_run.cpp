@@ -282,6 +282,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     fv.gsets = c->d_gsets.as<GainSet>();
     fv.cache = c->d_cache.as<VoiceCache>();
     fv.epoch = c->epoch;
+    fv.rs_table = c->d_rs_table.as<float>();
     fv.progs = c->d_progs.as<uint32_t>();
     fv.has_prog = c->fused_prog ? 1 : 0;
     fv.n_gain_stages = c->ramp_slots / 2;

@@ -110,6 +110,7 @@ struct VoiceDesc {  // static per voice chain: sampler -> [biquad] -> [delay] ->
     int stage_state[FW_MAX_STAGES - 1];
     int bq_state;                      // biquad between the sampler and the gain stages, -1 = none (k_chain plan)
     int dl_state;                      // delay after the biquad, -1 = none
+    int src_kind;                      // 0 = SamplerNode, 1 = SPEC resampling source (sampler_state = its state; no gain of its own)
 };
 
 // per (block, voice) record written by the control kernels, read by the leaf kernel (80 B)
@@ -122,6 +123,8 @@ enum : uint32_t {
                           //   (k_chain plan: also a VB_SRC_ZERO block with constant gains; no full VoiceBlk either way)
     VB_SRC_ZERO = 32u,    // the sampler's output is cleared this block (differs from VB_SILENT only when a biquad /
                           //   delay sits between the sampler and the gain stages: their tails keep ringing)
+    VB_RESAMPLE = 64u,    // resampling source (SPEC): off0 = 32.32 position of frame 0, off1 = 32.32 step, n1 = loops;
+                          //   every such block carries a full VoiceBlk (the 16-tap polyphase fetch is the leaf kernel's slow path)
     VB_RAMP_SHIFT = 8,    // bit (VB_RAMP_SHIFT + 2*stage + ch): that gain is a per-frame ramp
 };
 struct VoiceBlk {

@@ -181,7 +181,8 @@ __device__ inline int first_cmd_block(const Cmd* cmds, int n_cmds, int state_idx
 
 // Everything the steady tail of a call needs: the descriptor all its blocks share and how the playhead moves.
 struct TailJob {
-    int mode;          // 0 = nothing moves, 1 = looping playhead, 2 = one-shot playhead
+    int mode;          // 0 = nothing moves, 1 = looping playhead, 2 = one-shot playhead, 3 = resampling source: playhead = 32.32
+                       //     position, loop_start = 32.32 step, loop_end = (sample frames << 32) when it loops, else 0
     uint32_t flags;    // VB_SILENT / VB_MONO of the shared descriptor
     int sample;
     GainSet g;
@@ -234,6 +235,12 @@ __device__ __forceinline__ void put_blk(const FusedView& fv, int vi, int kk, con
     fv.refs[(size_t)vi * fv.refs_stride + kk] = ref;  // [voice][block]: the tail lanes store 1 KiB contiguous
     const bool need_full = fx ? !(d.flags & VB_SIMPLE) : !(d.flags & (VB_SIMPLE | VB_SILENT));
     if (need_full) fv.blks[(size_t)kk * fv.n_voices + vi] = d;
+}
+
+// a one-shot resampling source keeps playing through `n` more blocks (k_generic.hip.h K_RESAMPLER: it stops after the block
+// that carries its position to sample length + RS_TAPS / 2)
+__device__ __forceinline__ bool rs_survives(uint64_t pos, uint64_t step, uint64_t frames, uint64_t n, uint64_t len) {
+    return ((pos + n * frames * step) >> 32) < len + RS_TAPS / 2;
 }
 
 // Steady tail: blocks k_first .. K-1 share one descriptor; only the playhead moves, by +frames with a wrap at
@@ -322,6 +329,23 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
             put_blk(fv, vi, k2, t, gset, sd, fxp);
         }
         return job.playhead + n * fr;
+    }
+    if (job.mode == 3) {  // resampling source: position of block j = (pos + j * frames * step) mod (len << 32) when it loops
+        const uint64_t adv = fr * job.loop_start;
+        for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
+            const uint32_t rb = tail_ramp_bits(job, k2);
+            uint64_t pos = job.playhead + (uint64_t)(k2 - k_first) * adv;
+            if (job.loop_end) pos %= job.loop_end;
+            t.flags = job.flags | (rb << VB_RAMP_SHIFT);
+            t.off0 = pos;
+            t.off1 = job.loop_start;
+            t.n1 = job.loop_end ? 1u : 0u;
+            t.src_l = t.src_r = nullptr;
+            put_blk(fv, vi, k2, t, gset, sd, fxp);
+        }
+        uint64_t pos = job.playhead + n * adv;
+        if (job.loop_end) pos %= job.loop_end;
+        return pos;
     }
     // nothing moves (mode 0 <=> the sampler is frozen): with fx the block still runs (zeros in, constant gains)
     if (fxp && simple_ok) t.flags |= VB_SIMPLE;
@@ -468,11 +492,15 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                 job.loop_end = sp->loop_end;
                 sd = fv.samples[vc.sample];
                 if (vc.mode == 2 && job.playhead + (uint64_t)Kp * (uint64_t)frames > sd.frames) ok = false;  // ends in these blocks
+                if (vc.mode == 3) {
+                    job.loop_end = sp->has_loop ? (sd.frames << 32) : 0;
+                    if (!sp->has_loop && !rs_survives(job.playhead, job.loop_start, (uint64_t)frames, (uint64_t)Kp, sd.frames)) ok = false;
+                }
             }
             if (ok) {
                 const bool no_src = (job.flags & VB_SRC_ZERO) || (!fx && (job.flags & VB_SILENT));
-                const bool simple_ok = no_src ? (fxp && simple_frames)
-                                              : (job.sample >= 0 && simple_frames && simple_capable(sd, fxp));
+                const bool simple_ok = vc.mode != 3 && (no_src ? (fxp && simple_frames)
+                                                               : (job.sample >= 0 && simple_frames && simple_capable(sd, fxp)));
                 if (simple_ok && w0) my_gsets[0] = job.g;
                 uint64_t ph = steady_tail(fv, vi, lane, 0, Kp, job, sd, 0u, simple_ok, fx, fxp);
                 if (Kp == K) {
@@ -581,7 +609,23 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         // a sample destroyed under the sampler (fwgpu_sample_destroy: table entry with data == nullptr) counts as "no
         // sample": outputs cleared, nothing moves (sampler.rs:416-430) — never a fetch through the stale loop range
         bool silent = true;
-        if (ss.sample >= 0 && ss.playing && sd.data != nullptr) {
+        if (vd.src_kind == 1) {
+            // SPEC resampling source (k_generic.hip.h K_RESAMPLER): position / step / loop flag, no gain of its own — stage
+            // 0's gain stays 1.0, an exact multiply
+            if (ss.playing && ss.sample >= 0 && sd.data != nullptr && sd.frames != 0) {
+                silent = false;
+                d.flags |= VB_RESAMPLE;
+                d.sample = ss.sample;
+                d.off0 = ss.playhead;
+                d.off1 = ss.loop_start;
+                d.n1 = ss.has_loop ? 1u : 0u;
+                if (sd.channels == 1) d.flags |= VB_MONO;
+                uint64_t np = ss.playhead + (uint64_t)frames * ss.loop_start;
+                if (ss.has_loop) np %= (sd.frames << 32);
+                else if ((np >> 32) >= sd.frames + RS_TAPS / 2) ss.playing = 0;
+                ss.playhead = np;
+            }
+        } else if (ss.sample >= 0 && ss.playing && sd.data != nullptr) {
             GainRun run = smoother_begin(ss.s0, ss.p0, frames);
             if (!(!smoother_is_smoothing(ss.s0) && run.c < 0.00001f)) {
                 Fetch ft;
@@ -663,7 +707,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             }
         }
         const bool need_src = !src_silent && (fx || !silent);  // a dry voice whose output is muted fetches nothing
-        if (need_src) blk_set_source(d, sd, frames, fxp);
+        if (need_src && !(d.flags & VB_RESAMPLE)) blk_set_source(d, sd, frames, fxp);
         else if (fxp && (d.flags >> VB_RAMP_SHIFT) == 0 && simple_frames) d.flags |= VB_SIMPLE;  // chain plan: cleared-source block
         if (src_silent || (fxp && !need_src)) d.flags |= VB_SRC_ZERO;
         if (fxp && !need_src) d.flags &= ~(VB_WRAP | VB_TAIL_ZERO);  // nothing is fetched: where the source would wrap is moot
@@ -679,8 +723,12 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         bool upstream_silent = false;
         bool ramping = false;  // some smoother is still moving: the rest of the call is a RAMP CONTINUATION, then steady
         int mode = 0;
-        if (ss.sample < 0 || !ss.playing || sd.data == nullptr) {
+        if (ss.sample < 0 || !ss.playing || sd.data == nullptr || (vd.src_kind == 1 && sd.frames == 0)) {
             upstream_silent = true;  // frozen sampler: nothing moves
+        } else if (vd.src_kind == 1) {  // resampling source: the position has a closed form while it keeps playing
+            if (cached_sample != ss.sample) steady = false;
+            else if (ss.has_loop || rs_survives(ss.playhead, ss.loop_start, (uint64_t)frames, (uint64_t)(K - 1 - k), sd.frames)) mode = 3;
+            else steady = false;  // the one-shot runs out inside this call: block by block
         } else {
             if (!smoother_is_constant(ss.s0, ss.p0)) ramping = true;
             if (!ramping && ss.s0.status == SM_INACTIVE && ss.s0.input < 0.00001f) upstream_silent = true;  // muted, frozen
@@ -786,11 +834,13 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         job.playhead = ss.playhead;
         job.loop_start = ss.loop_start;
         job.loop_end = ss.loop_end;
+        if (mode == 3) job.loop_end = ss.has_loop ? (sd.frames << 32) : 0;
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES; ++j) job.g.g[j][0] = job.g.g[j][1] = 1.0f;
         if (!upstream_silent) {
             if (sd.channels == 1) job.flags |= VB_MONO;
-            job.g.g[0][0] = job.g.g[0][1] = ss.s0.status == SM_ACTIVE ? ss.s0.last : ss.s0.input;
+            if (mode == 3) job.flags |= VB_RESAMPLE;
+            else job.g.g[0][0] = job.g.g[0][1] = ss.s0.status == SM_ACTIVE ? ss.s0.last : ss.s0.input;
         }
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
@@ -815,8 +865,8 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         if (k + 1 < K) {
             uint32_t tail_gs = 0;
             bool simple_ok = false;
-            const bool tail_simple = fxp ? (simple_frames && (upstream_silent || (!fx && sil) || simple_capable(sd, true)))
-                                         : (!sil && !upstream_silent && simple_frames && simple_capable(sd, false));
+            const bool tail_simple = mode != 3 && (fxp ? (simple_frames && (upstream_silent || (!fx && sil) || simple_capable(sd, true)))
+                                                       : (!sil && !upstream_silent && simple_frames && simple_capable(sd, false)));
             if (tail_simple) {
                 VoiceBlk probe;  // every non-wrapping tail block is VB_SIMPLE with the same gains: one gain set
                 probe.flags = VB_SIMPLE;
@@ -890,9 +940,13 @@ __device__ inline bool voice_control_lane_steady(const FusedView& fv, const int 
         job.loop_end = sp->loop_end;
         sd = fv.samples[vc.sample];
         if (vc.mode == 2 && job.playhead + (uint64_t)frames > sd.frames) return false;  // the one-shot ends in this block
+        if (vc.mode == 3) {
+            job.loop_end = sp->has_loop ? (sd.frames << 32) : 0;
+            if (!sp->has_loop && !rs_survives(job.playhead, job.loop_start, (uint64_t)frames, 1, sd.frames)) return false;
+        }
     }
     const bool no_src = (job.flags & VB_SRC_ZERO) || (job.flags & VB_SILENT);
-    const bool simple_ok = !no_src && job.sample >= 0 && (frames & 3) == 0 && simple_capable(sd, false);
+    const bool simple_ok = vc.mode != 3 && !no_src && job.sample >= 0 && (frames & 3) == 0 && simple_capable(sd, false);
     if (simple_ok) fv.gsets[(size_t)vi * FW_GSETS] = job.g;
     const uint64_t ph = steady_tail(fv, vi, 0, 0, 1, job, sd, 0u, simple_ok, false, false);
     if (vc.mode != 0) fv.states[vd.sampler_state].playhead = ph;

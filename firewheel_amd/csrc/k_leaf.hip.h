@@ -26,10 +26,48 @@ __device__ __forceinline__ void apply_stage(uint32_t kind, v4f g0, v4f g1, v4f& 
 }
 
 // `prog`: the voice's stage program (4 bits per chain stage; 0 everywhere on a gains-only voice)
+// RS: the plan has voices whose source is a resampler (only the program instantiation of the leaf kernel carries that code)
+template <bool RS>
 __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& d, uint32_t k, int voice, int f0, int frames,
                                            v4f& xl, v4f& xr, uint32_t prog = 0u) {
     const bool mono = d.flags & VB_MONO;
-    if (d.src_l && f0 + 4 <= frames) {  // planar f32, contiguous: one dwordx4 per channel per lane
+    if (RS && (d.flags & VB_RESAMPLE)) {
+        // SPEC resampling source — the arithmetic of the generic executor's K_RESAMPLER case (k_generic.hip.h), frame by frame:
+        // 32.32 position, phase = top 5 fraction bits, 16-tap fmaf chain ascending from +0.0; outside a one-shot sample reads
+        // 0, a loop wraps.  The taps of neighbouring frames overlap: the reuse is the L1's.
+        const SampleDesc sd = fv.samples[d.sample];
+        const int64_t len = (int64_t)sd.frames;
+        const bool loop = d.n1 != 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float al = 0.f, ar = 0.f;
+            if (f0 + j < frames) {
+                const uint64_t p = d.off0 + (uint64_t)(f0 + j) * d.off1;
+                const int64_t idx = (int64_t)(p >> 32);
+                const float* hp = fv.rs_table + ((uint32_t)(p >> 27) & (RS_PHASES - 1)) * RS_TAPS;
+                for (int t = 0; t < RS_TAPS; ++t) {
+                    int64_t q = idx - (RS_TAPS / 2 - 1) + t;
+                    float x0 = 0.f, x1 = 0.f;
+                    bool in = true;
+                    if (loop) {
+                        q %= len;
+                        if (q < 0) q += len;
+                    } else {
+                        in = q >= 0 && q < len;
+                    }
+                    if (in) {
+                        x0 = sample_fetch(sd, 0, (uint64_t)q);
+                        if (!mono) x1 = sample_fetch(sd, 1, (uint64_t)q);
+                    }
+                    al = __builtin_fmaf(hp[t], x0, al);
+                    if (!mono) ar = __builtin_fmaf(hp[t], x1, ar);
+                }
+                if (mono) ar = al;
+            }
+            xl[j] = al;
+            xr[j] = ar;
+        }
+    } else if (d.src_l && f0 + 4 <= frames) {  // planar f32, contiguous: one dwordx4 per channel per lane
         xl = *(const v4f_u*)(d.src_l + f0);
         xr = mono ? xl : *(const v4f_u*)(d.src_r + f0);
     } else {
@@ -417,7 +455,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                         }
                     } else {
                         const VoiceBlk d = fv.blks[row + p];
-                        voice_eval(fv, d, k, ld.first_voice + p, f0, frames, xl, xr, prog);
+                        voice_eval<PROG>(fv, d, k, ld.first_voice + p, f0, frames, xl, xr, prog);
                     }
                 }
                 if (p == 0) {  // sum.rs:117 copy_from_slice(port 0) — also when silent; 2/3/4-port: in1

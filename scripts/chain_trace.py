@@ -25,7 +25,7 @@ src = torch.empty((V, 2, F), dtype=torch.float32, device="cuda").uniform_(-1, 1)
 
 
 class _Args(object):
-    force_generic = master = voice_fx = False
+    force_generic = master = voice_fx = rs_source = False
     taps = 65536
 
 

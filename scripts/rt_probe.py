@@ -12,7 +12,7 @@ import firewheel_amd as fa  # noqa: E402
 
 
 class A:
-    force_generic = master = voice_fx = False
+    force_generic = master = voice_fx = rs_source = False
     taps = 65536
 
 

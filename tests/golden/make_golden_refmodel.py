@@ -15,7 +15,7 @@ import refmodel  # noqa: E402
 import scenarios  # noqa: E402
 import test_scenarios_oracle as t  # noqa: E402
 
-UNSUPPORTED = ("mixed_generic", "cfg4_reverb", "cfg4_reverb_2irs_mono", "spatial_scene", "spatial_scene_b96")
+UNSUPPORTED = ("rs_bank_40", "rs_bank_21_b64_i16_pure", "mixed_generic", "cfg4_reverb", "cfg4_reverb_2irs_mono", "spatial_scene", "spatial_scene_b96")
 
 
 def model_cases():

@@ -186,6 +186,89 @@ def scenario_voice_fx_events(e, n_voices=45, radix=8, src_frames=1100, with_pan=
     return np.concatenate(outs)
 
 
+def scenario_rs_bank(e, n_voices=40, radix=8, src_frames=900, mixed=True, fmt=PLANAR_F32):
+    """voices whose SOURCE is the SPEC resampler (varispeed / rate conversion) -> gain -> pan [-> width / clip] -> sum tree:
+    looping and one-shot sources (one-shots run out inside the run), mono and stereo, ratios below and above 1, some starting
+    paused; ratio changes, seeks and pause / resume tagged at later blocks; gain and width automation on top.  With `mixed`
+    every third voice is an ordinary sampler voice under the same leaves."""
+    from fwapi import INTERLEAVED_I16 as I16
+    rng = np.random.default_rng(4242)
+    ratios = [1.0, 44100.0 / 48000.0, 1.5, 0.37, 2.25, 0.999, 1.0 / 3.0, 3.7]
+    voices, ends = [], []
+    for v in range(n_voices):
+        ch = 1 if v % 5 == 2 else 2
+        data = voice_source(8100 + v, src_frames, ch)
+        vfmt = I16 if (fmt != PLANAR_F32 and v % 2) else PLANAR_F32
+        raw = np.round(data * 32767).astype(np.int16).T.copy() if vfmt == I16 else data
+        smp = e.new_sample(vfmt, ch, raw)
+        is_rs = not (mixed and v % 3 == 2)
+        if is_rs:
+            src = e.resampler(smp, ratios[v % len(ratios)], loop=(v % 4 != 1), playing=(v % 7 != 3), n_out=2)
+        else:
+            src = e.sampler(90.0)
+        cur = src
+        vol = e.volume(float(rng.uniform(20, 110)))
+        e.connect_stereo(cur, vol)
+        cur = vol
+        pan = None
+        if v % 2 == 0:
+            pan = e.pan(float(rng.uniform(-1, 1)))
+            e.connect_stereo(cur, pan)
+            cur = pan
+        fx = []
+        for n in width_clip_fx(e, v, rng)[:2]:
+            e.connect_stereo(cur, n)
+            cur = n
+            fx.append(n)
+        voices.append(dict(src=src, is_rs=is_rs, volume=vol, pan=pan, fx=fx, sample=smp))
+        ends.append(cur)
+    level = ends
+    while True:
+        nxt = []
+        for i in range(0, len(level), radix):
+            grp = level[i:i + radix]
+            m = e.sum(len(grp))
+            for p, n in enumerate(grp):
+                e.connect_stereo(n, m, 2 * p)
+            nxt.append(m)
+        level = nxt
+        if len(level) == 1:
+            break
+    e.connect_stereo(level[0], e.graph_out_node)
+    e.update()
+    for vc in voices:
+        if not vc["is_rs"]:
+            e.sampler_set_sample(vc["src"], vc["sample"])
+            e.sampler_set_loop_range(vc["src"], LOOP_FULL)
+            e.sampler_play(vc["src"])
+    outs = [e.process_blocks(4)]
+    for v, vc in enumerate(voices):
+        if vc["is_rs"]:
+            if v % 6 == 0:
+                e.set_param(vc["src"], 1, [0.5, 1.25, 2.0][v % 3], at_block=1)     # ratio
+            if v % 6 == 4:
+                e.set_param(vc["src"], 4, float(v * 7 % src_frames), at_block=2)   # seek
+            if v % 7 == 3:
+                e.set_param(vc["src"], 3, 1.0, at_block=1)                         # the paused ones start
+            if v % 9 == 5:
+                e.set_param(vc["src"], 3, 0.0, at_block=0)                         # pause ...
+                e.set_param(vc["src"], 3, 1.0, at_block=3)                         # ... and resume
+        if v % 4 == 0:
+            e.set_param(vc["volume"], 0, 35.0 + v, at_block=2)
+        if v % 10 == 7:
+            e.set_param(vc["volume"], 0, 0.0, at_block=1)                          # mute behind a resampler
+    outs.append(e.process_blocks(5))
+    outs.append(e.process_blocks(23))                                              # ramps settle, one-shots run out
+    for v, vc in enumerate(voices):
+        if v % 10 == 7:
+            e.set_param(vc["volume"], 0, 80.0)
+        if vc["is_rs"] and v % 4 == 1:
+            e.set_param(vc["src"], 4, 0.0)                                         # restart a finished one-shot ...
+            e.set_param(vc["src"], 3, 1.0)
+    outs.append(e.process_blocks(9))
+    return np.concatenate(outs)
+
+
 class TaggedOracle(object):
     """Wraps an OracleEngine so that messages carry at_block like the GPU ABI: they are queued and delivered
     just before the tagged block of the next process_blocks call (the reference's rings are polled per block)."""

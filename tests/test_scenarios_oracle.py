@@ -50,6 +50,10 @@ CASES = {
     "voice_fx_events_45": lambda: scenarios.scenario_voice_fx_events(oracle(max_block_frames=128)),
     "voice_fx_events_20_i16_r32": lambda: scenarios.scenario_voice_fx_events(oracle(max_block_frames=64), 20, radix=32, src_frames=500,
                                                                               with_pan=False, fmt=fwapi.INTERLEAVED_I16),
+    # voices whose source is the SPEC resampler, on the voice-bank plan
+    "rs_bank_40": lambda: scenarios.scenario_rs_bank(oracle(max_block_frames=128)),
+    "rs_bank_21_b64_i16_pure": lambda: scenarios.scenario_rs_bank(oracle(max_block_frames=64), 21, radix=32, src_frames=400, mixed=False,
+                                                                  fmt=fwapi.INTERLEAVED_I16),
     "mixed_generic": lambda: scenarios.scenario_mixed_generic(oracle(max_block_frames=256)),
     "mixed_generic_nobeep": lambda: scenarios.scenario_mixed_generic(oracle(max_block_frames=256), use_beep=False),
     "cfg3_chain": lambda: scenarios.scenario_cfg3_chain(oracle(max_block_frames=128)),

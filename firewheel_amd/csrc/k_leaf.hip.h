@@ -43,15 +43,18 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
             float al = 0.f, ar = 0.f;
             if (f0 + j < frames) {
                 const uint64_t p = d.off0 + (uint64_t)(f0 + j) * d.off1;
-                const int64_t idx = (int64_t)(p >> 32);
                 const float* hp = fv.rs_table + ((uint32_t)(p >> 27) & (RS_PHASES - 1)) * RS_TAPS;
+                // index of tap 0.  A looping source keeps its position below len << 32 (len < 2^31) and a block adds less
+                // than 2^20 frames: the frame index fits 32 bits — ONE 32-bit remainder per frame, the taps wrap by
+                // comparison (the generic node's `j %= len` per tap is a 64-bit division each)
+                const int64_t q0 = (loop ? (int64_t)((uint32_t)(p >> 32) % (uint32_t)len) : (int64_t)(p >> 32)) - (RS_TAPS / 2 - 1);
                 for (int t = 0; t < RS_TAPS; ++t) {
-                    int64_t q = idx - (RS_TAPS / 2 - 1) + t;
+                    int64_t q = q0 + t;
                     float x0 = 0.f, x1 = 0.f;
                     bool in = true;
                     if (loop) {
-                        q %= len;
-                        if (q < 0) q += len;
+                        while (q < 0) q += len;
+                        while (q >= len) q -= len;
                     } else {
                         in = q >= 0 && q < len;
                     }

@@ -139,10 +139,10 @@ def scenario_voice_bank_events(e, n_voices=70, radix=32, mbf=None, src_frames=10
     return np.concatenate(outs)
 
 
-def width_clip_fx(e, v, rng):
+def width_clip_fx(e, v, rng, limit=3):
     """per-voice tail of the stage-program tests: width and / or hard clip in varying order and number"""
     wv, cv = float(rng.uniform(0.0, 2.0)), float(rng.uniform(-20.0, -2.0))
-    shape = ["wc", "cw", "w", "c", "cwC", ""][v % 6]  # (only the nodes a voice uses are created: nothing dangles)
+    shape = ["wc", "cw", "w", "c", "cwC", ""][v % 6][:limit]  # (only the nodes a voice uses are created: nothing dangles)
     return [e.width(wv) if k == "w" else e.hard_clip(cv if k == "c" else -1.0) for k in shape]
 
 
@@ -216,7 +216,7 @@ def scenario_rs_bank(e, n_voices=40, radix=8, src_frames=900, mixed=True, fmt=PL
             e.connect_stereo(cur, pan)
             cur = pan
         fx = []
-        for n in width_clip_fx(e, v, rng)[:2]:
+        for n in width_clip_fx(e, v, rng, limit=2):
             e.connect_stereo(cur, n)
             cur = n
             fx.append(n)

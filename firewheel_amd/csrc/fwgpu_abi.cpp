@@ -179,6 +179,20 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
             c->h_rt_flag = c->d_rt_flag = nullptr;
         }
     }
+    if (const char* e = getenv("FWGPU_CTL_AHEAD")) c->ctl_ahead = atoi(e) != 0;
+    if (c->ctl_ahead) {  // its own high-priority stream + the events that order it against the render stream
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        bool ok = hipStreamCreateWithPriority(&c->ctl_stream, hipStreamNonBlocking, hi) == hipSuccess;
+        for (int i = 0; ok && i < 2; ++i)
+            ok = hipEventCreateWithFlags(&c->ev_ctl[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&c->ev_render[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            c->ctl_ahead = false;
+        }
+    }
     if (const char* e = getenv("FWGPU_HOST_PROF")) c->host_prof = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_GRAPH")) c->rt_use_graph = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_ONE_LAUNCH")) c->rt_one_launch = atoi(e) != 0;
@@ -194,10 +208,16 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
                 c->hp_launches ? c->hp_launch_ns / 1e3 / (double)c->hp_launches : 0.0);
     use_device(c);
     (void)hipStreamSynchronize(c->stream);
+    if (c->ctl_stream) {
+        (void)hipStreamSynchronize(c->ctl_stream);
+        (void)hipStreamDestroy(c->ctl_stream);
+    }
+    for (hipEvent_t e : {c->ev_ctl[0], c->ev_ctl[1], c->ev_render[0], c->ev_render[1], c->ev_join})
+        if (e) (void)hipEventDestroy(e);
     for (SampleRec& s : c->samples)
         if (s.alive && s.owned && s.d_data) (void)hipFree(s.d_data);
     DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
-                      &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_rt_sync, &c->d_progs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
+                      &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_blks2, &c->d_refs2, &c->d_gsets2, &c->d_ramps2, &c->d_rt_sync, &c->d_progs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
                       &c->d_bus, &c->d_bus_flags, &c->d_chain_start, &c->d_chain_dummy, &c->d_chain_stats, &c->d_groups, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
                       &c->d_root_bufs, &c->d_tail_nodes, &c->d_tail_in, &c->d_tail_out, &c->d_tail_idx, &c->d_tail_frozen, &c->d_frozen, &c->d_frozen_ph, &c->d_fir_rows, &c->d_fir_tiles, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask, &c->d_trace, &c->d_rs_table};
@@ -477,6 +497,7 @@ int fwgpu_sample_destroy(fwgpu_ctx* c, int sample) {
             return fail(c, FWGPU_ERR_INVALID, "sample is in use by a FIR / resampler node");
     use_device(c);
     (void)hipStreamSynchronize(c->stream);
+    if (c->ctl_stream) (void)hipStreamSynchronize(c->ctl_stream);
     SampleRec& r = c->samples[sample];
     if (r.owned && r.d_data) (void)hipFree(r.d_data);
     r.alive = false;
@@ -926,6 +947,8 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     HIPC(c, hipMemcpyAsync(c->d_scratch_tab.p, tab, tab_ints * sizeof(int), hipMemcpyHostToDevice, c->stream));
     int rc = upload_sample_table(c);
     if (rc) return rc;
+    if ((rc = join_streams(c))) return rc;  // (a control-ahead call may still be in flight: one node, the main stream)
+    c->cmds_on_ctl = false;
     rc = upload_cmds(c);
     if (rc) return rc;
     DevView v = generic_view(c, (int)frames);

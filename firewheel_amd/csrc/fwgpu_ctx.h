@@ -149,6 +149,19 @@ struct fwgpu_ctx {
     int n_groups = 0;  // k_chain workgroups (groups of consecutive leaves)
     DevBuf d_groups;
     uint32_t epoch = 1;  // invalidates every VoiceCache when bumped (plan install, sample-table change)
+    // Control kernel one batch AHEAD (FWGPU_CTL_AHEAD, voice-bank plan without a master chain, batches of more than one block):
+    // k_voice_control of batch b+1 runs on its own high-priority stream under the render kernels of batch b.  What it writes and
+    // the render kernels read exists twice (parity = batch number & 1); what orders the two streams is one event per parity and
+    // direction.  The kernels do not know: they get pointers.
+    bool ctl_ahead = false;          // wanted (env)
+    bool ctl_ahead_on = false;       // the installed plan qualifies
+    hipStream_t ctl_stream = nullptr;
+    hipEvent_t ev_ctl[2] = {nullptr, nullptr}, ev_render[2] = {nullptr, nullptr}, ev_join = nullptr;
+    uint64_t ahead_seq = 0;          // batches launched in ahead mode since the streams were last joined
+    bool streams_split = false;      // ctl_stream may hold work the main stream has not waited for
+    bool ahead_this_call = false;    // the process call in progress runs in ahead mode
+    bool cmds_on_ctl = false;        // ... and its message upload goes to the control stream
+    DevBuf d_blks2, d_refs2, d_gsets2, d_ramps2;
     bool fused_prog = false;  // the voice-bank plan carries stage programs (k_leaf_sum<true>)
     DevBuf d_progs;
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start, d_chain_dummy, d_chain_stats;
@@ -302,6 +315,7 @@ int install_plan(fwgpu_ctx* c, Plan& plan);
 // ---- fwgpu_run.cpp
 int upload(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes);
 int upload_sample_table(fwgpu_ctx* c);
+int join_streams(fwgpu_ctx* c);  // control-ahead mode: both streams wait for each other's work so far (no host wait)
 void drain_ring(fwgpu_ctx* c);  // ring -> cmds (consumer side: the audio thread, or an edit call that does not overlap it)
 int upload_cmds(fwgpu_ctx* c);
 void finish_returns(fwgpu_ctx* c);  // end of a process call: completion event for the samples it handed back

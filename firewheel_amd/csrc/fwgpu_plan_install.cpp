@@ -5,6 +5,10 @@ namespace fwgpu {
 
 static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
     HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->ctl_stream) HIPC(c, hipStreamSynchronize(c->ctl_stream));
+    c->streams_split = false;
+    c->ahead_seq = 0;
+    c->ctl_ahead_on = false;
     c->kmax = c->kmax_req;
     // 1. node state capacity (persists across recompiles: processor.rs:19,195-197)
     size_t need = c->graph.nodes.size();
@@ -375,6 +379,15 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         HIPC(c, hipMemset(c->d_cache.p, 0, (size_t)c->n_voices * sizeof(VoiceCache)));
         c->epoch++;
         HIPC(c, c->d_ramps.ensure(K * c->n_voices * (size_t)c->ramp_slots * c->stride * sizeof(float)));
+        if (c->ctl_ahead && c->ctl_stream && !c->fused_fx && fb.tail_nodes.empty() && K > 1) {
+            // the second copy of what the control kernel writes and the render kernels read
+            bool ok = c->d_blks2.ensure(K * c->n_voices * sizeof(VoiceBlk)) == hipSuccess &&
+                      c->d_refs2.ensure(K * c->n_voices * sizeof(VoiceRef)) == hipSuccess &&
+                      c->d_gsets2.ensure((size_t)c->n_voices * FW_GSETS * sizeof(GainSet)) == hipSuccess &&
+                      c->d_ramps2.ensure(K * c->n_voices * (size_t)c->ramp_slots * c->stride * sizeof(float)) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            c->ctl_ahead_on = ok;
+        }
         size_t bus_bytes = K * (size_t)c->n_bus * c->stride * sizeof(float);
         HIPC(c, c->d_bus.ensure(bus_bytes));
         HIPC(c, hipMemset(c->d_bus.p, 0, bus_bytes));

@@ -45,11 +45,21 @@ int upload(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes) {
 
 // The host copy of the table (h_sample_tab) and the room for it on the device are kept up to date by the calls that
 // change it (fwgpu_sample_create / _destroy: control calls); the process call that follows only copies.
+int join_streams(fwgpu_ctx* c) {
+    if (!c->streams_split) return 0;
+    HIPC(c, hipEventRecord(c->ev_join, c->ctl_stream));
+    HIPC(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    c->streams_split = false;
+    c->ahead_seq = 0;  // (the render events of earlier batches are behind everything the main stream will do next)
+    return 0;
+}
+
 int upload_sample_table(fwgpu_ctx* c) {
     if (!c->samples_dirty) return 0;
     c->samples_dirty = false;
     c->epoch++;  // cached steady descriptors hold sample indices / sizes
     HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->ctl_stream) HIPC(c, hipStreamSynchronize(c->ctl_stream));
     const size_t bytes = c->h_sample_tab.size() * sizeof(SampleDesc);
     HIPC(c, c->d_samples.ensure(bytes));  // (already large enough: sized where the table changed)
     HIPC(c, hipMemcpy(c->d_samples.p, c->h_sample_tab.data(), bytes, hipMemcpyHostToDevice));
@@ -108,8 +118,11 @@ int upload_cmds(fwgpu_ctx* c) {
     size_t bytes = c->cmds.size() * sizeof(Cmd);
     HIPC(c, hipEventSynchronize(c->cmds_copied));  // the previous upload has left the pinned buffer
     memcpy(c->h_cmds, c->cmds.data(), bytes);
-    HIPC(c, hipMemcpyAsync(c->d_cmds.p, c->h_cmds, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipEventRecord(c->cmds_copied, c->stream));
+    // control-ahead mode: the message list belongs to the control stream (k_voice_control is its only reader there, and the
+    // stream's order keeps this copy behind the control kernels of the previous call)
+    hipStream_t s = c->cmds_on_ctl ? c->ctl_stream : c->stream;
+    HIPC(c, hipMemcpyAsync(c->d_cmds.p, c->h_cmds, bytes, hipMemcpyHostToDevice, s));
+    HIPC(c, hipEventRecord(c->cmds_copied, s));
     return 0;
 }
 // A SetSample message has been applied by the work enqueued so far: the sampler let go of the sample it held
@@ -314,7 +327,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         fv.dbg = dbg;
     }
     // realtime edge: one block, tree = leaves + root, stereo stream -> the whole callback is ONE launch (k_rt_block)
-    if (K == 1 && c->rt_one_launch && !c->fused_fx && !c->timing && c->n_tail == 0 && c->up_root_node >= 0 && n_out_ch == 2 &&
+    if (K == 1 && c->rt_one_launch && !c->ahead_this_call && !c->fused_fx && !c->timing && c->n_tail == 0 && c->up_root_node >= 0 && n_out_ch == 2 &&
         c->up_level_cnt.size() == 1 && c->d_rt_sync.p) {
         DevView v;
         memset(&v, 0, sizeof(v));
@@ -341,9 +354,24 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         return 0;
     }
     hipEvent_t e0, e1;
-    timer_begin(c, 1, &e0, &e1);
-    LCHK(c, launch_voice_control(c->stream, fv, K, cmd_block0));
-    timer_end(c, e1);
+    if (c->ahead_this_call) {
+        const int p = (int)(c->ahead_seq & 1);
+        if (p) {
+            fv.blks = c->d_blks2.as<VoiceBlk>();
+            fv.refs = c->d_refs2.as<VoiceRef>();
+            fv.gsets = c->d_gsets2.as<GainSet>();
+            fv.ramps = c->d_ramps2.as<float>();
+        }
+        if (c->ahead_seq >= 2) HIPC(c, hipStreamWaitEvent(c->ctl_stream, c->ev_render[p], 0));  // batch b-2 has read this copy
+        LCHK(c, launch_voice_control(c->ctl_stream, fv, K, cmd_block0));
+        HIPC(c, hipEventRecord(c->ev_ctl[p], c->ctl_stream));
+        HIPC(c, hipStreamWaitEvent(c->stream, c->ev_ctl[p], 0));
+        c->streams_split = true;
+    } else {
+        timer_begin(c, 1, &e0, &e1);
+        LCHK(c, launch_voice_control(c->stream, fv, K, cmd_block0));
+        timer_end(c, e1);
+    }
     timer_begin(c, 0, &e0, &e1);
     if (c->fused_fx) LCHK(c, launch_chain(c->stream, fv, K, cmd_block0, c->chain_nq));
     else LCHK(c, launch_leaf_sum(c->stream, fv, K));
@@ -376,6 +404,10 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         if (fuse_root) {
             LCHK(c, launch_root_out(c->stream, v, c->root_args, d_out, K));
             timer_end(c, e1);
+            if (c->ahead_this_call) {
+                HIPC(c, hipEventRecord(c->ev_render[c->ahead_seq & 1], c->stream));
+                c->ahead_seq++;
+            }
             return 0;
         }
     }
@@ -409,6 +441,10 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     LCHK(c, launch_graph_out(c->stream, fv.bus, fv.bus_flags, c->stride, fv.bus_blk_stride, fv.bus_flags_blk_stride,
                              c->d_root_bufs.as<int>(), 2, d_out, n_out_ch, (int)c->mbf, K));
     timer_end(c, e1);
+    if (c->ahead_this_call) {
+        HIPC(c, hipEventRecord(c->ev_render[c->ahead_seq & 1], c->stream));
+        c->ahead_seq++;
+    }
     return 0;
 }
 
@@ -429,11 +465,27 @@ static int run_blocks_impl(fwgpu_ctx* c, uint64_t frames, const float* d_in, int
     const uint32_t nblocks = (uint32_t)((frames + mbf - 1) / mbf);
     int rc = upload_sample_table(c);
     if (rc) return rc;
+    const bool can_fuse = c->fused && !c->force_generic;
+    // control-ahead mode for this call?  Whole blocks only, more than one, no event timers, not the realtime edge
+    const bool ahead = c->ctl_ahead_on && can_fuse && !c->timing && !stable_out && frames % mbf == 0 && frames / mbf > 1;
+    if (!ahead && c->streams_split) {
+        rc = join_streams(c);
+        if (rc) return rc;
+    }
+    if (ahead && !c->streams_split) {  // the control stream picks up behind everything the main stream holds so far
+        HIPC(c, hipEventRecord(c->ev_join, c->stream));
+        HIPC(c, hipStreamWaitEvent(c->ctl_stream, c->ev_join, 0));
+        c->ahead_seq = 0;
+    }
+    c->ahead_this_call = ahead;
+    c->cmds_on_ctl = ahead;
     rc = upload_cmds(c);
-    if (rc) return rc;
+    if (rc) {
+        c->ahead_this_call = false;
+        return rc;
+    }
     uint64_t done = 0;
     uint32_t blk = 0;
-    const bool can_fuse = c->fused && !c->force_generic;
     // steady realtime call: no message on the device, one fused batch, the same output block as last time — every
     // kernel argument repeats (block counters and playheads live in device state), so the launch sequence is replayed
     // from a hipGraph instead of being re-issued kernel by kernel
@@ -492,6 +544,7 @@ static int run_blocks_impl(fwgpu_ctx* c, uint64_t frames, const float* d_in, int
         LCHK(c, launch_signal_done(c->stream, c->d_rt_flag, c->rt_signal_seq));
         c->rt_signalled = true;
     }
+    c->ahead_this_call = false;
     retire_cmds(c, nblocks);
     return 0;
 }

@@ -162,6 +162,7 @@ struct fwgpu_ctx {
     bool ahead_this_call = false;    // the process call in progress runs in ahead mode
     bool cmds_on_ctl = false;        // ... and its message upload goes to the control stream
     DevBuf d_blks2, d_refs2, d_gsets2, d_ramps2;
+    bool fused_rs = false;    // the plan has resampler-sourced voices
     bool fused_prog = false;  // the voice-bank plan carries stage programs (k_leaf_sum<true>)
     DevBuf d_progs;
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start, d_chain_dummy, d_chain_stats;
@@ -304,6 +305,7 @@ struct FusedBuild {
     int max_stages = 0;
     std::vector<uint32_t> progs;  // per voice: its chain stages' kinds (SK_*), 4 bits each
     bool has_prog = false;        // a width / hard-clip stage somewhere: the leaf kernel's program instantiation
+    bool has_rs = false;          // a resampler-sourced voice somewhere
     bool has_fx = false;  // some chain holds a biquad / delay: the k_chain plan
     uint64_t min_delay = ~0ull;  // shortest delay line among the chains (frames)
 };

@@ -154,7 +154,8 @@ int launch_rt_block(hipStream_t s, const FusedView& fv, const DevView& upv, cons
                     unsigned* d_sync, unsigned long long* d_done_flag, unsigned long long done_seq) {
     if (fv.n_leaves <= 0) return 0;
     if (fv.has_prog)
-        hipLaunchKernelGGL(k_rt_block<true>, dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync, d_done_flag, done_seq);
+        hipLaunchKernelGGL(k_rt_block<true>, dim3(fv.n_leaves), dim3(256), fv.has_rs ? RS_LDS_BYTES(4) : 0, s, fv, upv, root, d_out, cmd_block0, d_sync,
+                           d_done_flag, done_seq);
     else
         hipLaunchKernelGGL(k_rt_block<false>, dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync, d_done_flag, done_seq);
     return (int)hipGetLastError();
@@ -173,7 +174,7 @@ int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
 #else
     dim3 grid((fv.n_leaves + LEAF_WPB - 1) / LEAF_WPB, K);
 #endif
-    if (fv.has_prog) hipLaunchKernelGGL(k_leaf_sum<true>, grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
+    if (fv.has_prog) hipLaunchKernelGGL(k_leaf_sum<true>, grid, dim3(WAVE * LEAF_WPB), fv.has_rs ? RS_LDS_BYTES(LEAF_WPB) : 0, s, fv, K, wpk);
     else hipLaunchKernelGGL(k_leaf_sum<false>, grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
     return (int)hipGetLastError();
 }

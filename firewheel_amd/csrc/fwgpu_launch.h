@@ -46,7 +46,8 @@ struct FusedView {
     VoiceBlk* blks;   // [K][n_voices], written only for blocks that are neither silent nor VB_SIMPLE
     const float* rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS] (voices whose source is a resampler)
     const uint32_t* progs;  // [n_voices] stage programs (SK_*, 4 bits per chain stage); nullptr / all 0 on gains-only plans
-    int has_prog;           // some voice's program is not 0: k_leaf_sum<true>
+    int has_prog;           // some voice's program is not 0 (or its source is a resampler): k_leaf_sum<true>
+    int has_rs;             // some voice's source is a resampler: the program instantiation stages windows + filter bank in LDS
     int n_gain_stages;  // 1 (sampler gain) + longest chain in the plan
     float* ramps;     // [K][n_voices][ramp_slots][stride], slot = 2*stage + channel
     int ramp_slots;

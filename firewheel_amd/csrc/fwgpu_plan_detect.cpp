@@ -159,6 +159,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
             if (vd.src_kind == 1) {
                 if (bq >= 0 || dl >= 0) return false;  // (the chain plan's source fetch is the sampler's)
                 fb.has_prog = true;                    // the polyphase fetch lives in the leaf kernel's program instantiation
+                fb.has_rs = true;
             }
             vd.n_stages = (int)chain.size();
             uint32_t prog = 0;

@@ -334,6 +334,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         if ((rc = upload(c, c->d_leaves, fb.leaves.data(), fb.leaves.size() * sizeof(LeafDesc)))) return rc;
         if ((rc = upload(c, c->d_progs, fb.progs.data(), fb.progs.size() * sizeof(uint32_t)))) return rc;
         c->fused_prog = fb.has_prog;
+        c->fused_rs = fb.has_rs;
         c->n_groups = 0;
         if (c->fused_fx) {
             // k_chain workgroups: consecutive leaves packed greedily into groups of <= 32 voices / <= 8 leaves (the

@@ -298,6 +298,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     fv.rs_table = c->d_rs_table.as<float>();
     fv.progs = c->d_progs.as<uint32_t>();
     fv.has_prog = c->fused_prog ? 1 : 0;
+    fv.has_rs = c->fused_rs ? 1 : 0;
     fv.n_gain_stages = c->ramp_slots / 2;
     fv.ramps = c->d_ramps.as<float>();
     fv.ramp_slots = c->ramp_slots;

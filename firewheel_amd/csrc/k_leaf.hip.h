@@ -26,12 +26,84 @@ __device__ __forceinline__ void apply_stage(uint32_t kind, v4f g0, v4f g1, v4f& 
 }
 
 // `prog`: the voice's stage program (4 bits per chain stage; 0 everywhere on a gains-only voice)
+// LDS of the leaf kernel's program instantiation, for voices whose source is a resampler: the 2 KiB filter bank once per
+// workgroup, and per wave the window of source frames its 256 output frames of ONE port read (both channels)
+#define RS_WIN 1040  // window frames a wave can stage: 256 output frames x ratio <= 4, + RS_TAPS
+struct RsLds {
+    const float* tab;  // [RS_PHASES][RS_TAPS] in LDS (nullptr: no resampler voices in the plan)
+    float* win;        // this wave's [2][RS_WIN]
+};
+
 // RS: the plan has voices whose source is a resampler (only the program instantiation of the leaf kernel carries that code)
 template <bool RS>
 __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& d, uint32_t k, int voice, int f0, int frames,
-                                           v4f& xl, v4f& xr, uint32_t prog = 0u) {
+                                           v4f& xl, v4f& xr, uint32_t prog = 0u, RsLds rs = RsLds{nullptr, nullptr}) {
     const bool mono = d.flags & VB_MONO;
-    if (RS && (d.flags & VB_RESAMPLE)) {
+    bool rs_done = false;
+    if (RS && (d.flags & VB_RESAMPLE) && rs.tab != nullptr) {
+        // SPEC resampling source, staged through LDS.  The wave's (up to) 256 output frames of this port read the source
+        // frames [i_first - 7, i_last + 8]: the active lanes fetch that window once, coalesced (consecutive lanes,
+        // consecutive frames; converted and wrapped / zero-filled on the way in), and each lane then runs its four frames'
+        // 16-tap fmaf chains — ascending from +0.0, the arithmetic of k_generic's K_RESAMPLER — from LDS, the coefficients
+        // from the workgroup's copy of the filter bank.  (The per-lane global fetch below issues 192 vector-memory
+        // instructions per lane and port and is bound by exactly that.)
+        const int lane = threadIdx.x & (WAVE - 1);
+        const int fbase = __builtin_amdgcn_readfirstlane(f0 - lane * 4);   // the wave's piece of the block starts here
+        const int nfr = frames - fbase < 256 ? frames - fbase : 256;
+        const int nact = (nfr + 3) >> 2;                                    // active lanes: 0 .. nact-1
+        const uint64_t p_first = d.off0 + (uint64_t)fbase * d.off1;
+        const uint64_t p_last = d.off0 + (uint64_t)(fbase + nfr - 1) * d.off1;
+        const uint64_t i_first = p_first >> 32;
+        const uint64_t W = (p_last >> 32) - i_first + RS_TAPS;
+        if (W <= RS_WIN) {
+            const SampleDesc sd = fv.samples[d.sample];
+            const int64_t len = (int64_t)sd.frames;
+            const bool loop = d.n1 != 0;
+            // source index of window slot 0 (loops: one 32-bit remainder, the slots wrap by comparison)
+            const int64_t q_base = (loop ? (int64_t)((uint32_t)i_first % (uint32_t)len) : (int64_t)i_first) - (RS_TAPS / 2 - 1);
+            float* w0 = rs.win;
+            float* w1 = rs.win + RS_WIN;
+            for (int r = lane; r < (int)W; r += nact) {
+                int64_t q = q_base + r;
+                bool in = true;
+                if (loop) {
+                    while (q < 0) q += len;
+                    while (q >= len) q -= len;
+                } else {
+                    in = q >= 0 && q < len;
+                }
+                w0[r] = in ? sample_fetch(sd, 0, (uint64_t)q) : 0.f;
+                if (!mono) w1[r] = in ? sample_fetch(sd, 1, (uint64_t)q) : 0.f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float al = 0.f, ar = 0.f;
+                if (f0 + j < frames) {
+                    const uint64_t p = d.off0 + (uint64_t)(f0 + j) * d.off1;
+                    const float* hp = rs.tab + ((uint32_t)(p >> 27) & (RS_PHASES - 1)) * RS_TAPS;
+                    const int r0 = (int)((p >> 32) - i_first);
+#pragma unroll
+                    for (int t = 0; t < RS_TAPS; ++t) {
+                        const float h = hp[t];
+                        al = __builtin_fmaf(h, w0[r0 + t], al);
+                        if (!mono) ar = __builtin_fmaf(h, w1[r0 + t], ar);
+                    }
+                    if (mono) ar = al;
+                }
+                xl[j] = al;
+                xr[j] = ar;
+            }
+            // the next port of this wave overwrites the window: everybody is done reading first
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            rs_done = true;
+        }
+    }
+    if (rs_done) {
+    } else if (RS && (d.flags & VB_RESAMPLE)) {
         // SPEC resampling source — the arithmetic of the generic executor's K_RESAMPLER case (k_generic.hip.h), frame by frame:
         // 32.32 position, phase = top 5 fraction bits, 16-tap fmaf chain ascending from +0.0; outside a one-shot sample reads
         // 0, a loop wraps.  The taps of neighbouring frames overlap: the reuse is the L1's.
@@ -321,7 +393,8 @@ __device__ __forceinline__ void leaf_fast_cls(const float* my_l, uint32_t my_rd,
 // PROG: some voice of the plan has a stage that is not a plain gain (width / hard clip) — lane p then also carries port
 // p's stage program.  The gains-only instantiation is the headline kernel and does not pay for the other one's registers.
 template <bool PROG>
-__device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int leaf, const uint32_t k, const int part, const int wpk) {
+__device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int leaf, const uint32_t k, const int part, const int wpk,
+                                              const RsLds rs = RsLds{nullptr, nullptr}) {
     const int lane = threadIdx.x & (WAVE - 1);
     const LeafDesc ld = fv.leaves[leaf];
     const int frames = fv.frames;
@@ -458,7 +531,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                         }
                     } else {
                         const VoiceBlk d = fv.blks[row + p];
-                        voice_eval<PROG>(fv, d, k, ld.first_voice + p, f0, frames, xl, xr, prog);
+                        voice_eval<PROG>(fv, d, k, ld.first_voice + p, f0, frames, xl, xr, prog, rs);
                     }
                 }
                 if (p == 0) {  // sum.rs:117 copy_from_slice(port 0) — also when silent; 2/3/4-port: in1
@@ -477,8 +550,25 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
     if (lane < 2 && part == 0) bflags[ld.out_buf + lane] = all_silent ? 1 : 0;
 }
 
+// dynamic LDS of the program instantiations (launched with 0 bytes when the plan has no resampler voice): filter bank, then
+// one source window per wave
+__device__ __forceinline__ RsLds rs_lds_setup(const FusedView& fv, float* dyn) {
+    RsLds rs{nullptr, nullptr};
+    if (fv.has_rs) {  // (uniform: every wave of the workgroup comes through here before anything can return)
+        for (int i = threadIdx.x; i < RS_PHASES * RS_TAPS; i += blockDim.x) dyn[i] = fv.rs_table[i];
+        __syncthreads();
+        rs.tab = dyn;
+        rs.win = dyn + RS_PHASES * RS_TAPS + (threadIdx.x >> 6) * (2 * RS_WIN);
+    }
+    return rs;
+}
+#define RS_LDS_BYTES(waves) ((RS_PHASES * RS_TAPS + (waves) * 2 * RS_WIN) * sizeof(float))
+
 template <bool PROG>
 __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K, int wpk) {
+    extern __shared__ float s_leaf_dyn[];
+    RsLds rs{nullptr, nullptr};
+    if constexpr (PROG) rs = rs_lds_setup(fv, s_leaf_dyn);
 #if LEAF_MAP_BLOCKS
     // the waves of a workgroup take CONSECUTIVE 256-frame pieces of one leaf's stream — wpk (1, 2 or 4) waves per
     // block, LEAF_WPB / wpk consecutive blocks: a steady voice's source is contiguous across blocks, so the workgroup
@@ -494,7 +584,7 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
     if (leaf >= fv.n_leaves) return;
     const uint32_t k = blockIdx.y;
 #endif
-    leaf_sum_wave<PROG>(fv, leaf, k, part, wpk);
+    leaf_sum_wave<PROG>(fv, leaf, k, part, wpk, rs);
 }
 
 // Upper sum tree of the fused plan, K-batched: SumNode semantics (nodes/sum.rs:41-136) with one THREAD per

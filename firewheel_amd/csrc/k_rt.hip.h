@@ -16,6 +16,9 @@
 template <bool PROG>
 __global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, RootArgs ra, float* __restrict__ out, uint32_t cmd_block0,
                                                   unsigned* __restrict__ sync, unsigned long long* done_flag, unsigned long long done_seq) {
+    extern __shared__ float s_rt_dyn[];
+    RsLds rs{nullptr, nullptr};
+    if constexpr (PROG) rs = rs_lds_setup(fv, s_rt_dyn);
     const int leaf = blockIdx.x;
     const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (WAVE - 1);
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, Roo
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    leaf_sum_wave<PROG>(fv, leaf, 0u, wave, 4);
+    leaf_sum_wave<PROG>(fv, leaf, 0u, wave, 4, rs);
     // grid-wide hand-over to the root: every workgroup publishes its bus (agent scope: the XCDs have separate L2s), the
     // last one to arrive reads them all
     __shared__ int s_last;

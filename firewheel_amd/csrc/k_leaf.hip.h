@@ -30,8 +30,8 @@ __device__ __forceinline__ void apply_stage(uint32_t kind, v4f g0, v4f g1, v4f& 
 // workgroup, and per wave the window of source frames its 256 output frames of ONE port read (both channels)
 #define RS_WIN 1040  // window frames a wave can stage: 256 output frames x ratio <= 4, + RS_TAPS
 struct RsLds {
-    const float* tab;  // [RS_PHASES][RS_TAPS] in LDS (nullptr: no resampler voices in the plan)
-    float* win;        // this wave's [2][RS_WIN]
+    const float* tab;  // the filter bank in LDS, tap-major [RS_TAPS][RS_PHASES] (nullptr: no resampler voices in the plan)
+    float* win;        // this wave's window [2][RS_WIN], then its result rows [2][256]
 };
 
 // RS: the plan has voices whose source is a resampler (only the program instantiation of the leaf kernel carries that code)
@@ -78,25 +78,41 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // Frames are dealt to the lanes ROUND-ROBIN for the convolution (lane l: frames l, l + nact, ...): neighbouring lanes
+            // then read neighbouring window slots (stride = the ratio) and, from the bank stored tap-major, coefficient
+            // addresses t * 32 + phase — one LDS bank per phase.  (Four consecutive frames per lane, the layout of the rest of
+            // the kernel, puts 64 lanes on 8 banks at ratio 1, and a phase-major bank puts every lane on 2.)  The results go
+            // through LDS once more to come back as each lane's four consecutive frames.
+            float* o0 = rs.win + 2 * RS_WIN;
+            float* o1 = o0 + 256;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float al = 0.f, ar = 0.f;
-                if (f0 + j < frames) {
-                    const uint64_t p = d.off0 + (uint64_t)(f0 + j) * d.off1;
-                    const float* hp = rs.tab + ((uint32_t)(p >> 27) & (RS_PHASES - 1)) * RS_TAPS;
+            for (int i = 0; i < 4; ++i) {
+                const int f = lane + i * nact;
+                if (f < nfr) {
+                    const uint64_t p = d.off0 + (uint64_t)(fbase + f) * d.off1;
+                    const float* hp = rs.tab + ((uint32_t)(p >> 27) & (RS_PHASES - 1));
                     const int r0 = (int)((p >> 32) - i_first);
+                    float al = 0.f, ar = 0.f;
 #pragma unroll
                     for (int t = 0; t < RS_TAPS; ++t) {
-                        const float h = hp[t];
+                        const float h = hp[t * RS_PHASES];
                         al = __builtin_fmaf(h, w0[r0 + t], al);
                         if (!mono) ar = __builtin_fmaf(h, w1[r0 + t], ar);
                     }
-                    if (mono) ar = al;
+                    o0[f] = al;
+                    o1[f] = mono ? al : ar;
                 }
-                xl[j] = al;
-                xr[j] = ar;
             }
-            // the next port of this wave overwrites the window: everybody is done reading first
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = f0 + j < frames;
+                xl[j] = in ? o0[lane * 4 + j] : 0.f;
+                xr[j] = in ? o1[lane * 4 + j] : 0.f;
+            }
+            // the next port of this wave overwrites the window and the result rows: everybody is done reading first
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             rs_done = true;
@@ -555,14 +571,15 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
 __device__ __forceinline__ RsLds rs_lds_setup(const FusedView& fv, float* dyn) {
     RsLds rs{nullptr, nullptr};
     if (fv.has_rs) {  // (uniform: every wave of the workgroup comes through here before anything can return)
-        for (int i = threadIdx.x; i < RS_PHASES * RS_TAPS; i += blockDim.x) dyn[i] = fv.rs_table[i];
+        for (int i = threadIdx.x; i < RS_PHASES * RS_TAPS; i += blockDim.x)  // tap-major: [t][phase]
+            dyn[(i % RS_TAPS) * RS_PHASES + i / RS_TAPS] = fv.rs_table[i];
         __syncthreads();
         rs.tab = dyn;
-        rs.win = dyn + RS_PHASES * RS_TAPS + (threadIdx.x >> 6) * (2 * RS_WIN);
+        rs.win = dyn + RS_PHASES * RS_TAPS + (threadIdx.x >> 6) * (2 * RS_WIN + 512);
     }
     return rs;
 }
-#define RS_LDS_BYTES(waves) ((RS_PHASES * RS_TAPS + (waves) * 2 * RS_WIN) * sizeof(float))
+#define RS_LDS_BYTES(waves) ((RS_PHASES * RS_TAPS + (waves) * (2 * RS_WIN + 512)) * sizeof(float))
 
 template <bool PROG>
 __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K, int wpk) {

@@ -336,11 +336,13 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
             const uint32_t rb = tail_ramp_bits(job, k2);
             uint64_t pos = job.playhead + (uint64_t)(k2 - k_first) * adv;
             if (job.loop_end) pos %= job.loop_end;
-            t.flags = job.flags | (rb << VB_RAMP_SHIFT);
+            t.flags = job.flags | (rb << VB_RAMP_SHIFT) | ((uint32_t)sd.format << VB_FMT_SHIFT);
             t.off0 = pos;
             t.off1 = job.loop_start;
             t.n1 = job.loop_end ? 1u : 0u;
-            t.src_l = t.src_r = nullptr;
+            t.src_l = (const float*)sd.data;
+            t.src_r = nullptr;
+            t.pad = (uint32_t)sd.frames;
             put_blk(fv, vi, k2, t, gset, sd, fxp);
         }
         uint64_t pos = job.playhead + n * adv;
@@ -614,11 +616,13 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             // 0's gain stays 1.0, an exact multiply
             if (ss.playing && ss.sample >= 0 && sd.data != nullptr && sd.frames != 0) {
                 silent = false;
-                d.flags |= VB_RESAMPLE;
+                d.flags |= VB_RESAMPLE | ((uint32_t)sd.format << VB_FMT_SHIFT);
                 d.sample = ss.sample;
                 d.off0 = ss.playhead;
                 d.off1 = ss.loop_start;
                 d.n1 = ss.has_loop ? 1u : 0u;
+                d.src_l = (const float*)sd.data;
+                d.pad = (uint32_t)sd.frames;
                 if (sd.channels == 1) d.flags |= VB_MONO;
                 uint64_t np = ss.playhead + (uint64_t)frames * ss.loop_start;
                 if (ss.has_loop) np %= (sd.frames << 32);

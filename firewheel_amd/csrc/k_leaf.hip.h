@@ -56,22 +56,56 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
         const uint64_t i_first = p_first >> 32;
         const uint64_t W = (p_last >> 32) - i_first + RS_TAPS;
         if (W <= RS_WIN) {
-            const SampleDesc sd = fv.samples[d.sample];
+            SampleDesc sd;  // (the descriptor carries the sample: no second dependent load for the table)
+            sd.data = d.src_l;
+            sd.frames = d.pad;
+            sd.channels = mono ? 1 : 2;
+            sd.format = (int)((d.flags >> VB_FMT_SHIFT) & 7u);
             const int64_t len = (int64_t)sd.frames;
             const bool loop = d.n1 != 0;
             // source index of window slot 0 (loops: one 32-bit remainder, the slots wrap by comparison)
             const int64_t q_base = (loop ? (int64_t)((uint32_t)i_first % (uint32_t)len) : (int64_t)i_first) - (RS_TAPS / 2 - 1);
             float* w0 = rs.win;
             float* w1 = rs.win + RS_WIN;
-            for (int r = lane; r < (int)W; r += nact) {
+            auto slot = [&](int r, bool& in) -> int64_t {
                 int64_t q = q_base + r;
-                bool in = true;
+                in = true;
                 if (loop) {
                     while (q < 0) q += len;
                     while (q >= len) q -= len;
                 } else {
                     in = q >= 0 && q < len;
                 }
+                return in ? q : 0;
+            };
+            int r_done = 0;
+            if (sd.format == FMT_P_F32) {
+                // planar f32: the first 8 rounds of the window (all of it up to ratio ~1.8) are requested before any is stored
+                // — ONE memory round trip instead of one per round
+                const float* s0 = (const float*)sd.data;
+                const float* s1 = s0 + (mono ? 0 : len);
+                float v0[8], v1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = lane + u * nact;
+                    bool in = false;
+                    const int64_t q = r < (int)W ? slot(r, in) : 0;
+                    v0[u] = in ? s0[q] : 0.f;
+                    v1[u] = in && !mono ? s1[q] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = lane + u * nact;
+                    if (r < (int)W) {
+                        w0[r] = v0[u];
+                        if (!mono) w1[r] = v1[u];
+                    }
+                }
+                r_done = 8 * nact;
+            }
+            for (int r = r_done + lane; r < (int)W; r += nact) {
+                bool in;
+                const int64_t q = slot(r, in);
                 w0[r] = in ? sample_fetch(sd, 0, (uint64_t)q) : 0.f;
                 if (!mono) w1[r] = in ? sample_fetch(sd, 1, (uint64_t)q) : 0.f;
             }

@@ -153,11 +153,15 @@ int launch_bus_sum_ordered(hipStream_t s, const BusParts& bp, float* d_out, size
 int launch_rt_block(hipStream_t s, const FusedView& fv, const DevView& upv, const RootArgs& root, float* d_out, uint32_t cmd_block0,
                     unsigned* d_sync, unsigned long long* d_done_flag, unsigned long long done_seq) {
     if (fv.n_leaves <= 0) return 0;
-    if (fv.has_prog)
-        hipLaunchKernelGGL(k_rt_block<true>, dim3(fv.n_leaves), dim3(256), fv.has_rs ? RS_LDS_BYTES(4) : 0, s, fv, upv, root, d_out, cmd_block0, d_sync,
+    if (fv.has_rs)
+        hipLaunchKernelGGL((k_rt_block<true, true>), dim3(fv.n_leaves), dim3(256), RS_LDS_BYTES(4), s, fv, upv, root, d_out, cmd_block0, d_sync,
                            d_done_flag, done_seq);
+    else if (fv.has_prog)
+        hipLaunchKernelGGL((k_rt_block<true, false>), dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync, d_done_flag,
+                           done_seq);
     else
-        hipLaunchKernelGGL(k_rt_block<false>, dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync, d_done_flag, done_seq);
+        hipLaunchKernelGGL((k_rt_block<false, false>), dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync, d_done_flag,
+                           done_seq);
     return (int)hipGetLastError();
 }
 int launch_signal_done(hipStream_t s, unsigned long long* d_done_flag, unsigned long long done_seq) {
@@ -174,8 +178,9 @@ int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
 #else
     dim3 grid((fv.n_leaves + LEAF_WPB - 1) / LEAF_WPB, K);
 #endif
-    if (fv.has_prog) hipLaunchKernelGGL(k_leaf_sum<true>, grid, dim3(WAVE * LEAF_WPB), fv.has_rs ? RS_LDS_BYTES(LEAF_WPB) : 0, s, fv, K, wpk);
-    else hipLaunchKernelGGL(k_leaf_sum<false>, grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
+    if (fv.has_rs) hipLaunchKernelGGL((k_leaf_sum<true, true>), grid, dim3(WAVE * LEAF_WPB), RS_LDS_BYTES(LEAF_WPB), s, fv, K, wpk);
+    else if (fv.has_prog) hipLaunchKernelGGL((k_leaf_sum<true, false>), grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
+    else hipLaunchKernelGGL((k_leaf_sum<false, false>), grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
     return (int)hipGetLastError();
 }
 

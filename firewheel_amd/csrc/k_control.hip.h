@@ -54,6 +54,14 @@ struct StageRegs {  // the NodeState prefix (p0,p1,s0,s1) a gain stage needs
     Smoother s0, s1;
 };
 
+// One step of the recurrence, repeated by the preprocessor rather than by an assembler .rept: the compiler sizes an
+// inline-asm block by its line count, and with the repeat hidden from it the branch relaxation pass placed short
+// branches across blocks that did not fit ("branch size exceeds simm16").
+#define FW_RAMP_STEP1 "v_mul_f32 %1, %0, %4\n" "v_add_f32 %0, %3, %1\n" "s_lshl_b64 exec, exec, 1\n"
+#define FW_RAMP_STEP4 FW_RAMP_STEP1 FW_RAMP_STEP1 FW_RAMP_STEP1 FW_RAMP_STEP1
+#define FW_RAMP_STEP16 FW_RAMP_STEP4 FW_RAMP_STEP4 FW_RAMP_STEP4 FW_RAMP_STEP4
+#define FW_RAMP_STEP64 FW_RAMP_STEP16 FW_RAMP_STEP16 FW_RAMP_STEP16 FW_RAMP_STEP16
+
 // Serial ramp -> global memory; returns false (and writes nothing) when the recurrence is already at its
 // f32 fixed point (Q28: an Active smoother can stall above settle_epsilon forever) — the block is constant.
 // The smoother recurrence (core/param/smoother.rs:169-175: out[i] = in*a + out[i-1]*b, two roundings) is serial, so
@@ -80,11 +88,7 @@ __device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, f
             unsigned long long saved_exec;
             asm volatile(
                 "s_mov_b64 %2, exec\n"
-                ".rept 64\n"
-                "v_mul_f32 %1, %0, %4\n"
-                "v_add_f32 %0, %3, %1\n"
-                "s_lshl_b64 exec, exec, 1\n"
-                ".endr\n"
+                FW_RAMP_STEP64
                 "s_mov_b64 exec, %2\n"
                 : "+v"(y), "=&v"(t), "=&s"(saved_exec)
                 : "v"(r.in_a), "v"(r.b)

@@ -34,6 +34,18 @@ struct RsLds {
     float* win;        // this wave's window [2][RS_WIN], then its result rows [2][256]
 };
 
+// source frame of a window slot: a loop wraps (by comparison: the slot is within a window of the loop), a one-shot reads 0 outside
+__device__ __forceinline__ int64_t rs_slot(int64_t q, const int64_t len, const bool loop, bool& in) {
+    in = true;
+    if (loop) {
+        while (q < 0) q += len;
+        while (q >= len) q -= len;
+    } else {
+        in = q >= 0 && q < len;
+    }
+    return in ? q : 0;
+}
+
 // RS: the plan has voices whose source is a resampler (only the program instantiation of the leaf kernel carries that code)
 template <bool RS>
 __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& d, uint32_t k, int voice, int f0, int frames,
@@ -67,40 +79,36 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
             const int64_t q_base = (loop ? (int64_t)((uint32_t)i_first % (uint32_t)len) : (int64_t)i_first) - (RS_TAPS / 2 - 1);
             float* w0 = rs.win;
             float* w1 = rs.win + RS_WIN;
-            auto slot = [&](int r, bool& in) -> int64_t {
-                int64_t q = q_base + r;
-                in = true;
-                if (loop) {
-                    while (q < 0) q += len;
-                    while (q >= len) q -= len;
-                } else {
-                    in = q >= 0 && q < len;
-                }
-                return in ? q : 0;
-            };
+#define slot(r, in) rs_slot(q_base + (r), len, loop, in)
             int r_done = 0;
             if (sd.format == FMT_P_F32) {
                 // planar f32: the first 8 rounds of the window (all of it up to ratio ~1.8) are requested before any is stored
                 // — ONE memory round trip instead of one per round
                 const float* s0 = (const float*)sd.data;
                 const float* s1 = s0 + (mono ? 0 : len);
-                float v0[8], v1[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int r = lane + u * nact;
-                    bool in = false;
-                    const int64_t q = r < (int)W ? slot(r, in) : 0;
-                    v0[u] = in ? s0[q] : 0.f;
-                    v1[u] = in && !mono ? s1[q] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int r = lane + u * nact;
-                    if (r < (int)W) {
-                        w0[r] = v0[u];
-                        if (!mono) w1[r] = v1[u];
-                    }
-                }
+#define RS_ROUND(u, a, b)                                    \
+    {                                                        \
+        const int r = lane + (u) * nact;                     \
+        bool in = false;                                     \
+        const int64_t q = r < (int)W ? slot(r, in) : 0;      \
+        a = in ? s0[q] : 0.f;                                \
+        b = in && !mono ? s1[q] : 0.f;                       \
+    }
+#define RS_STORE(u, a, b)                                    \
+    {                                                        \
+        const int r = lane + (u) * nact;                     \
+        if (r < (int)W) {                                    \
+            w0[r] = a;                                       \
+            if (!mono) w1[r] = b;                            \
+        }                                                    \
+    }
+                float a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+                RS_ROUND(0, a0, b0) RS_ROUND(1, a1, b1) RS_ROUND(2, a2, b2) RS_ROUND(3, a3, b3)
+                RS_ROUND(4, a4, b4) RS_ROUND(5, a5, b5) RS_ROUND(6, a6, b6) RS_ROUND(7, a7, b7)
+                RS_STORE(0, a0, b0) RS_STORE(1, a1, b1) RS_STORE(2, a2, b2) RS_STORE(3, a3, b3)
+                RS_STORE(4, a4, b4) RS_STORE(5, a5, b5) RS_STORE(6, a6, b6) RS_STORE(7, a7, b7)
+#undef RS_ROUND
+#undef RS_STORE
                 r_done = 8 * nact;
             }
             for (int r = r_done + lane; r < (int)W; r += nact) {
@@ -109,6 +117,7 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
                 w0[r] = in ? sample_fetch(sd, 0, (uint64_t)q) : 0.f;
                 if (!mono) w1[r] = in ? sample_fetch(sd, 1, (uint64_t)q) : 0.f;
             }
+#undef slot
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -157,7 +166,11 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
         // SPEC resampling source — the arithmetic of the generic executor's K_RESAMPLER case (k_generic.hip.h), frame by frame:
         // 32.32 position, phase = top 5 fraction bits, 16-tap fmaf chain ascending from +0.0; outside a one-shot sample reads
         // 0, a loop wraps.  The taps of neighbouring frames overlap: the reuse is the L1's.
-        const SampleDesc sd = fv.samples[d.sample];
+        SampleDesc sd;  // (field by field: a struct copy from global memory ends up in scratch here)
+        sd.data = fv.samples[d.sample].data;
+        sd.frames = fv.samples[d.sample].frames;
+        sd.channels = fv.samples[d.sample].channels;
+        sd.format = fv.samples[d.sample].format;
         const int64_t len = (int64_t)sd.frames;
         const bool loop = d.n1 != 0;
 #pragma unroll
@@ -196,7 +209,11 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
         xl = *(const v4f_u*)(d.src_l + f0);
         xr = mono ? xl : *(const v4f_u*)(d.src_r + f0);
     } else {
-        const SampleDesc sd = fv.samples[d.sample];
+        SampleDesc sd;  // (field by field: a struct copy from global memory ends up in scratch here)
+        sd.data = fv.samples[d.sample].data;
+        sd.frames = fv.samples[d.sample].frames;
+        sd.channels = fv.samples[d.sample].channels;
+        sd.format = fv.samples[d.sample].format;
         Fetch ft;
         ft.off0 = d.off0;
         ft.off1 = d.off1;
@@ -210,19 +227,18 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
     const uint32_t kinds = prog << 4;  // stage 0 is the sampler's own gain
     if (rbits == 0) {  // constant gains: sampler.rs:530-533 then volume.rs:123-126 / pan, one rounding each
 #pragma unroll
-        for (int j = 0; j < FW_MAX_STAGES; ++j) {
-            if (j >= fv.n_gain_stages) break;
-            apply_stage((kinds >> (4 * j)) & 15u, splat(d.g[j][0]), splat(d.g[j][1]), xl, xr);
-        }
+        for (int j = 0; j < FW_MAX_STAGES; ++j)  // (no `break`: the loop must unroll, or d.g[] is indexed at run time and lands in scratch)
+            if (j < fv.n_gain_stages) apply_stage((kinds >> (4 * j)) & 15u, splat(d.g[j][0]), splat(d.g[j][1]), xl, xr);
         // a mono sample is duplicated AFTER the sampler gain (sampler.rs:546-551); identical values either way
     } else {
         const float* rb = fv.ramps + ((size_t)k * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES; ++j) {
-            if (j >= fv.n_gain_stages) break;
-            v4f gl = (rbits >> (2 * j)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j) * fv.stride) : splat(d.g[j][0]);
-            v4f gr = (rbits >> (2 * j + 1)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j + 1) * fv.stride) : splat(d.g[j][1]);
-            apply_stage((kinds >> (4 * j)) & 15u, gl, gr, xl, xr);
+            if (j < fv.n_gain_stages) {
+                v4f gl = (rbits >> (2 * j)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j) * fv.stride) : splat(d.g[j][0]);
+                v4f gr = (rbits >> (2 * j + 1)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j + 1) * fv.stride) : splat(d.g[j][1]);
+                apply_stage((kinds >> (4 * j)) & 15u, gl, gr, xl, xr);
+            }
         }
     }
 }
@@ -441,8 +457,8 @@ __device__ __forceinline__ void leaf_fast_cls(const float* my_l, uint32_t my_rd,
 }
 
 // PROG: some voice of the plan has a stage that is not a plain gain (width / hard clip) — lane p then also carries port
-// p's stage program.  The gains-only instantiation is the headline kernel and does not pay for the other one's registers.
-template <bool PROG>
+// p's stage program.  The gains-only instantiation is the headline kernel and does not pay for the other ones' registers.
+template <bool PROG, bool RS = false>
 __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int leaf, const uint32_t k, const int part, const int wpk,
                                               const RsLds rs = RsLds{nullptr, nullptr}) {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -581,7 +597,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                         }
                     } else {
                         const VoiceBlk d = fv.blks[row + p];
-                        voice_eval<PROG>(fv, d, k, ld.first_voice + p, f0, frames, xl, xr, prog, rs);
+                        voice_eval<RS>(fv, d, k, ld.first_voice + p, f0, frames, xl, xr, prog, rs);
                     }
                 }
                 if (p == 0) {  // sum.rs:117 copy_from_slice(port 0) — also when silent; 2/3/4-port: in1
@@ -615,11 +631,15 @@ __device__ __forceinline__ RsLds rs_lds_setup(const FusedView& fv, float* dyn) {
 }
 #define RS_LDS_BYTES(waves) ((RS_PHASES * RS_TAPS + (waves) * (2 * RS_WIN + 512)) * sizeof(float))
 
-template <bool PROG>
+// Three instantiations, by what the plan's voices need (register appetite: 94 / ~105 / ~140 VGPRs):
+//   <false, false>  every stage a plain gain — the headline kernel
+//   <true,  false>  stage programs (width / hard clip)
+//   <true,  true>   ... and voices whose source is a resampler (LDS-staged polyphase fetch)
+template <bool PROG, bool RS>
 __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K, int wpk) {
     extern __shared__ float s_leaf_dyn[];
     RsLds rs{nullptr, nullptr};
-    if constexpr (PROG) rs = rs_lds_setup(fv, s_leaf_dyn);
+    if constexpr (RS) rs = rs_lds_setup(fv, s_leaf_dyn);
 #if LEAF_MAP_BLOCKS
     // the waves of a workgroup take CONSECUTIVE 256-frame pieces of one leaf's stream — wpk (1, 2 or 4) waves per
     // block, LEAF_WPB / wpk consecutive blocks: a steady voice's source is contiguous across blocks, so the workgroup
@@ -635,7 +655,7 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
     if (leaf >= fv.n_leaves) return;
     const uint32_t k = blockIdx.y;
 #endif
-    leaf_sum_wave<PROG>(fv, leaf, k, part, wpk, rs);
+    leaf_sum_wave<PROG, RS>(fv, leaf, k, part, wpk, rs);
 }
 
 // Upper sum tree of the fused plan, K-batched: SumNode semantics (nodes/sum.rs:41-136) with one THREAD per

@@ -13,12 +13,12 @@
 //      completion flag in pinned host memory the audio thread polls.
 // Same device functions as the throughput kernels, so the arithmetic is theirs bit for bit.  Used when the call is one
 // block, the tree is leaves + root and the stream is stereo; everything else takes the launch sequence.
-template <bool PROG>
+template <bool PROG, bool RS>
 __global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, RootArgs ra, float* __restrict__ out, uint32_t cmd_block0,
                                                   unsigned* __restrict__ sync, unsigned long long* done_flag, unsigned long long done_seq) {
     extern __shared__ float s_rt_dyn[];
     RsLds rs{nullptr, nullptr};
-    if constexpr (PROG) rs = rs_lds_setup(fv, s_rt_dyn);
+    if constexpr (RS) rs = rs_lds_setup(fv, s_rt_dyn);
     const int leaf = blockIdx.x;
     const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (WAVE - 1);
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, Roo
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    leaf_sum_wave<PROG>(fv, leaf, 0u, wave, 4, rs);
+    leaf_sum_wave<PROG, RS>(fv, leaf, 0u, wave, 4, rs);
     // grid-wide hand-over to the root: every workgroup publishes its bus (agent scope: the XCDs have separate L2s), the
     // last one to arrive reads them all
     __shared__ int s_last;

@@ -110,18 +110,12 @@ __device__ inline int chain_cmd_lower_bound(const Cmd* cmds, int n_cmds, int sta
 
 // Apply every queued message for (state_idx, block) in order.  cmds are sorted by (state, block, seq).
 // nodes/sampler.rs:331-414 (ring drained at the top of process()), volume.rs:92 (atomic load per block).
-__device__ inline void apply_cmds(NodeState& s, int state_idx, uint32_t block, const Cmd* cmds, int n_cmds,
-                                  const SampleDesc* samples, float* ext = nullptr, bool ext_write = false) {
-    if (n_cmds == 0) return;
-    int lo = 0, hi = n_cmds;  // lower bound of (state_idx, block)
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        const Cmd& c = cmds[mid];
-        bool less = c.state < state_idx || (c.state == state_idx && c.block < block);
-        if (less) lo = mid + 1;
-        else hi = mid;
-    }
-    for (int i = lo; i < n_cmds; ++i) {
+// ... from index `lo` (the lower bound of (state_idx, block), or anything in front of it that is not this node's);
+// returns the index behind the last message applied — the node's cursor for its next block
+__device__ inline int apply_cmds_from(NodeState& s, int state_idx, uint32_t block, const Cmd* cmds, int n_cmds, const SampleDesc* samples,
+                                      int lo, float* ext = nullptr, bool ext_write = false) {
+    int i = lo;
+    for (; i < n_cmds; ++i) {
         Cmd c = cmds[i];
         if (c.state != state_idx || c.block != block) break;
         switch (c.type) {
@@ -186,6 +180,39 @@ __device__ inline void apply_cmds(NodeState& s, int state_idx, uint32_t block, c
             default: break;
         }
     }
+    return i;
+}
+__device__ inline void apply_cmds(NodeState& s, int state_idx, uint32_t block, const Cmd* cmds, int n_cmds,
+                                  const SampleDesc* samples, float* ext = nullptr, bool ext_write = false) {
+    if (n_cmds == 0) return;
+    apply_cmds_from(s, state_idx, block, cmds, n_cmds, samples, chain_cmd_lower_bound(cmds, n_cmds, state_idx, block), ext, ext_write);
+}
+
+// The same lower bound by a whole wave (all 64 lanes active, arguments wave-uniform): 64 pivots per round instead of one —
+// a binary search is a chain of log2(n) dependent global loads, ~0.4 us apiece, and the control kernel runs six of them per
+// voice in every call that carries messages.  Up to 128 messages: one round trip; up to 8 320: two.
+__device__ __forceinline__ long long cmd_key(int state_idx, uint32_t block) {
+    return (long long)(((unsigned long long)(uint32_t)state_idx << 32) | (unsigned long long)block);  // (state, block), signed order
+}
+__device__ __forceinline__ long long cmd_key_at(const Cmd* cmds, int i) {
+    const unsigned long long raw = *(const unsigned long long*)&cmds[i];  // state (low word), block (high word)
+    return (long long)((raw << 32) | (raw >> 32));
+}
+__device__ __forceinline__ int wave_cmd_lower_bound(const Cmd* cmds, int n_cmds, long long key, int lane) {
+    int lo = 0, hi = n_cmds;
+    while (hi - lo > 2 * WAVE) {
+        const long long span = hi - lo;
+        const int idx = lo + (int)((span * (lane + 1)) / (WAVE + 1));  // ascending in the lane, all inside [lo, hi)
+        const int c = __popcll(__ballot(cmd_key_at(cmds, idx) < key));  // sorted: exactly the first c pivots compare less
+        const int nlo = c > 0 ? lo + (int)((span * c) / (WAVE + 1)) + 1 : lo;
+        const int nhi = c < WAVE ? lo + (int)((span * (c + 1)) / (WAVE + 1)) : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    const int i0 = lo + lane, i1 = lo + WAVE + lane;
+    const bool l0 = i0 < hi && cmd_key_at(cmds, i0) < key;
+    const bool l1 = i1 < hi && cmd_key_at(cmds, i1) < key;
+    return lo + __popcll(__ballot(l0)) + __popcll(__ballot(l1));
 }
 
 // ------------------------------------------------------------------ sampler playhead logic (shared by both plans)

@@ -43,6 +43,13 @@ __device__ __forceinline__ ChainDelay chain_delay_cmds(const Cmd* cmds, int n_cm
     return p;
 }
 
+// -DFW_CTL_TRACE: lane 0 of a voice whose call contained a ramp continuation prints where its wave's time went (10 ns ticks)
+#ifdef FW_CTL_TRACE
+#define CTL_T(i) tr[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define CTL_T(i)
+#endif
+
 // ------------------------------------------------------------------ fused voice-bank plan
 // Control kernel (k_voice_control): one thread per voice runs the per-block state machines of its whole
 // chain in schedule order (sampler -> stage nodes) and emits one VoiceBlk per block.  As soon as the voice
@@ -54,50 +61,69 @@ struct StageRegs {  // the NodeState prefix (p0,p1,s0,s1) a gain stage needs
     Smoother s0, s1;
 };
 
-// One step of the recurrence, repeated by the preprocessor rather than by an assembler .rept: the compiler sizes an
-// inline-asm block by its line count, and with the repeat hidden from it the branch relaxation pass placed short
-// branches across blocks that did not fit ("branch size exceeds simm16").
+// The recurrence, repeated by the preprocessor rather than by an assembler .rept: the compiler sizes an inline-asm block
+// by its line count, and with the repeat hidden from it the branch relaxation pass placed short branches across blocks
+// that did not fit ("branch size exceeds simm16").
+#define FW_REP4(x) x x x x
+#define FW_REP16(x) FW_REP4(x) FW_REP4(x) FW_REP4(x) FW_REP4(x)
+#define FW_REP64(x) FW_REP16(x) FW_REP16(x) FW_REP16(x) FW_REP16(x)
+// one frame per EXEC step (lane i keeps y[i] in %0) ...
 #define FW_RAMP_STEP1 "v_mul_f32 %1, %0, %4\n" "v_add_f32 %0, %3, %1\n" "s_lshl_b64 exec, exec, 1\n"
-#define FW_RAMP_STEP4 FW_RAMP_STEP1 FW_RAMP_STEP1 FW_RAMP_STEP1 FW_RAMP_STEP1
-#define FW_RAMP_STEP16 FW_RAMP_STEP4 FW_RAMP_STEP4 FW_RAMP_STEP4 FW_RAMP_STEP4
-#define FW_RAMP_STEP64 FW_RAMP_STEP16 FW_RAMP_STEP16 FW_RAMP_STEP16 FW_RAMP_STEP16
+// ... and four: lane q keeps frames 4q .. 4q+3 in %0..%3, the chain's carry is %3
+#define FW_RAMP_STEP4                                                                                          \
+    "v_mul_f32 %4, %3, %7\n" "v_add_f32 %0, %6, %4\n" "v_mul_f32 %4, %0, %7\n" "v_add_f32 %1, %6, %4\n" \
+    "v_mul_f32 %4, %1, %7\n" "v_add_f32 %2, %6, %4\n" "v_mul_f32 %4, %2, %7\n" "v_add_f32 %3, %6, %4\n" \
+    "s_lshl_b64 exec, exec, 1\n"
 
 // Serial ramp -> global memory; returns false (and writes nothing) when the recurrence is already at its
 // f32 fixed point (Q28: an Active smoother can stall above settle_epsilon forever) — the block is constant.
 // The smoother recurrence (core/param/smoother.rs:169-175: out[i] = in*a + out[i-1]*b, two roundings) is serial, so
-// every lane of the voice's wave runs it redundantly; lane l keeps the values of frames l, l+64, ... and the wave
-// stores 64 frames at a time (a single lane storing element by element made a ramp block cost ~6 us).
-__device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, float* dst1, int lane) {
-    float prev = r.prev;
-    float v0 = r.in_a + (prev * r.b);
-    if (v0 == prev) {  // fixed point: every later value equals prev, bit for bit
-        r.c = prev;
-        r.ramp = 0;
-        return false;
+// every lane of the voice's wave runs it redundantly and EXEC shrinks lane by lane as it goes, each lane dropping out
+// with the frames it is to store: two dependent VALU ops per frame (the mul and the add, one rounding each, as
+// smoother.rs:171-175) and nothing else on the vector unit.  (A compare + select that parks step i's value in lane i
+// doubled the length of the chain; a single lane storing element by element made a ramp block cost ~6 us.)  One wave
+// issues one instruction per 4 clocks, so what matters is instructions per frame: 256 frames at a time, lane q keeps frames
+// 4q .. 4q+3 — 9 instructions per 4 frames (the EXEC shift is amortised over four) and one 16-byte store per lane; the
+// rest of a block 64 frames at a time, lane i keeping frame i (3 per frame); the last < 64 frames with a select.
+// Two copies in the library, behind calls (ramp_run_call, ramp_blocks): the 64-fold chains are ~3 KiB of straight-line
+// code, and the control kernel has ten call sites.
+__device__ __forceinline__ float ramp_run(float prev, const float in_a, const float b, int frames, float* dst0, float* dst1, int lane) {
+    int i0 = 0;
+    // (the whole wave is active here: the voice's control code is wave-uniform)
+    const bool vec_ok = ((((uintptr_t)dst0) | ((uintptr_t)dst1)) & 15u) == 0;
+    for (; vec_ok && i0 + 4 * WAVE <= frames; i0 += 4 * WAVE) {
+        float d0, d1, d2, d3 = prev, t;
+        unsigned long long saved_exec;
+        asm volatile(
+            "s_mov_b64 %5, exec\n"
+            FW_REP64(FW_RAMP_STEP4)
+            "s_mov_b64 exec, %5\n"
+            : "=&v"(d0), "=&v"(d1), "=&v"(d2), "+v"(d3), "=&v"(t), "=&s"(saved_exec)
+            : "v"(in_a), "v"(b)
+            : "scc");
+        const v4f g = {d0, d1, d2, d3};
+        *(v4f*)(dst0 + i0 + 4 * lane) = g;
+        if (dst1) *(v4f*)(dst1 + i0 + 4 * lane) = g;
+        prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d3), WAVE - 1));
     }
-    for (int i0 = 0; i0 < frames; i0 += WAVE) {
+    for (; i0 < frames; i0 += WAVE) {
         float mine = 0.f;
         const int n = frames - i0 < WAVE ? frames - i0 : WAVE;
         if (n == WAVE) {
-            // 64 steps of the recurrence with EXEC shrinking lane by lane: every lane runs the same chain, lane i drops
-            // out after step i and keeps y[i] — two dependent VALU ops per frame (the mul and the add, one rounding each,
-            // as smoother.rs:171-175) and nothing else on the vector unit; the compare + select that used to park step
-            // i's value in lane i doubled the length of the chain (the whole wave is active here: the voice's control
-            // code is wave-uniform)
             float y = prev, t;
             unsigned long long saved_exec;
             asm volatile(
                 "s_mov_b64 %2, exec\n"
-                FW_RAMP_STEP64
+                FW_REP64(FW_RAMP_STEP1)
                 "s_mov_b64 exec, %2\n"
                 : "+v"(y), "=&v"(t), "=&s"(saved_exec)
-                : "v"(r.in_a), "v"(r.b)
+                : "v"(in_a), "v"(b)
                 : "scc");
             mine = y;
             prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), WAVE - 1));
         } else {
             for (int i = 0; i < n; ++i) {
-                prev = r.in_a + (prev * r.b);
+                prev = in_a + (prev * b);
                 mine = i == lane ? prev : mine;
             }
         }
@@ -106,8 +132,61 @@ __device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, f
             if (dst1) dst1[i0 + lane] = mine;
         }
     }
-    r.prev = prev;
+    return prev;
+}
+// (a function returns with its stores retired — s_waitcnt vmcnt(0) — which is why a whole glide is one call: ramp_blocks)
+__device__ __attribute__((noinline)) float ramp_run_call(float prev, const float in_a, const float b, int frames, float* dst0, float* dst1, int lane) {
+    return ramp_run(prev, in_a, b, frames, dst0, dst1, lane);
+}
+__device__ __forceinline__ bool ramp_emit(GainRun& r, int frames, float* dst0, float* dst1, int lane) {
+    const float v0 = r.in_a + (r.prev * r.b);
+    if (v0 == r.prev) {  // fixed point: every later value equals prev, bit for bit
+        r.c = r.prev;
+        r.ramp = 0;
+        return false;
+    }
+    r.prev = ramp_run_call(r.prev, r.in_a, r.b, frames, dst0, dst1, lane);
     return true;
+}
+
+// One smoother's whole glide, block kk0 onwards, in a loop that holds nothing else: set_and_process() of every block
+// (smoother_begin: settle test on the block's first value — smoother.rs:181, Q1 — then the fixed-point test, then the
+// block's ramp) until the smoother settles, stalls or the call ends.  A smoother's recurrence needs only itself, so the
+// continuation runs the gliding smoothers one after the other rather than block by block through the unrolled stage
+// loops (hundreds of scalar instructions per block, 4 clocks each: ~1.8 us per block around a 1.0 us chain).
+// `dst`: the smoother's ramp row in block kk0; `blk_stride`: floats between consecutive blocks' rows; `dual`: the row
+// behind it gets the same values (a gain shared by both channels).  Returns {last, status, input, until} as bits —
+// until = one past the last block that got a ramp (0: none).
+typedef int ctl_v4i __attribute__((ext_vector_type(4)));
+__device__ __attribute__((noinline)) ctl_v4i ramp_blocks(int status, float input, float last, const float a, const float b, const float eps,
+                                                          const float target, const int frames, const int kk0, const int K, float* dst,
+                                                          const size_t blk_stride, const int row_stride, const int dual, const int lane) {
+    if (!(input == target)) {  // set(): smoother.rs:134
+        input = target;
+        status = SM_ACTIVE;
+    }
+    int until = 0;
+    const float in_a = input * a;  // :169
+    for (int kk = kk0; kk < K && status == SM_ACTIVE; ++kk, dst += blk_stride) {
+        const float y0 = in_a + (last * b);  // :171
+        if (fabsf(input - y0) < eps) {      // :181 — this block and every later one: the constant `input`
+            last = input;
+            status = SM_DEACTIVATING;
+            break;
+        }
+        if (y0 == last) break;  // f32 fixed point above settle_epsilon (Q28): stalled for good, state untouched
+        last = ramp_run(last, in_a, b, frames, dst, dual ? dst + row_stride : nullptr, lane);
+        until = kk + 1;
+    }
+    return ctl_v4i{__float_as_int(last), status, __float_as_int(input), until};
+}
+__device__ __forceinline__ int ramp_glide(Smoother& s, float target, int frames, int kk0, int K, float* dst, size_t blk_stride, int row_stride,
+                                          bool dual, int lane) {
+    const ctl_v4i r = ramp_blocks(s.status, s.input, s.last, s.a, s.b, s.eps, target, frames, kk0, K, dst, blk_stride, row_stride, dual ? 1 : 0, lane);
+    s.last = __int_as_float(r[0]);
+    s.status = r[1];
+    s.input = __int_as_float(r[2]);
+    return r[3];
 }
 
 // A smoother whose next set_and_process(target) returns the same constant and leaves its state untouched:
@@ -181,6 +260,46 @@ __device__ inline int first_cmd_block(const Cmd* cmds, int n_cmds, int state_idx
     const int i = chain_cmd_lower_bound(cmds, n_cmds, state_idx, cmd_block0);
     if (i >= n_cmds || cmds[i].state != state_idx) return 0x7fffffff;
     return (int)(cmds[i].block - cmd_block0);
+}
+
+// Both at once, by the whole wave (wave_cmd_lower_bound), plus the index of the node's first message of this call
+struct CmdSpan {
+    int first, last, cursor;
+};
+__device__ __forceinline__ CmdSpan wave_cmd_span(const Cmd* cmds, int n_cmds, int state_idx, uint32_t cmd_block0, int lane) {
+    CmdSpan r;
+    r.first = 0x7fffffff;
+    r.last = -1;
+    const int lo = wave_cmd_lower_bound(cmds, n_cmds, cmd_key(state_idx, cmd_block0), lane);
+    const int up = wave_cmd_lower_bound(cmds, n_cmds, cmd_key(state_idx + 1, 0u), lane);
+    r.cursor = lo;
+    if (lo < up) {  // [lo, up): the node's messages at or after cmd_block0, in block order
+        r.first = (int)(cmds[lo].block - cmd_block0);
+        r.last = (int)(cmds[up - 1].block - cmd_block0);
+    }
+    return r;
+}
+
+// ... from keys the wave already holds: lane l has the keys of messages l and l + 64 (n_cmds <= 128)
+__device__ __forceinline__ uint32_t held_block(long long key0, long long key1, int i) {  // i: wave-uniform
+    const int lo0 = (int)(key0 & 0xffffffffll), lo1 = (int)(key1 & 0xffffffffll);
+    const int l = __builtin_amdgcn_readfirstlane(i);
+    return (uint32_t)(l < WAVE ? __builtin_amdgcn_readlane(lo0, l) : __builtin_amdgcn_readlane(lo1, l - WAVE));
+}
+__device__ __forceinline__ CmdSpan wave_cmd_span_held(long long key0, long long key1, int n_cmds, int state_idx, uint32_t cmd_block0, int lane) {
+    CmdSpan r;
+    r.first = 0x7fffffff;
+    r.last = -1;
+    const long long klo = cmd_key(state_idx, cmd_block0), kup = cmd_key(state_idx + 1, 0u);
+    const bool v0 = lane < n_cmds, v1 = lane + WAVE < n_cmds;
+    const int lo = __popcll(__ballot(v0 && key0 < klo)) + __popcll(__ballot(v1 && key1 < klo));
+    const int up = __popcll(__ballot(v0 && key0 < kup)) + __popcll(__ballot(v1 && key1 < kup));
+    r.cursor = lo;
+    if (lo < up) {
+        r.first = (int)(held_block(key0, key1, lo) - cmd_block0);
+        r.last = (int)(held_block(key0, key1, up - 1) - cmd_block0);
+    }
+    return r;
 }
 
 // Everything the steady tail of a call needs: the descriptor all its blocks share and how the playhead moves.
@@ -364,6 +483,12 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
 // the steady tail is split across the lanes.  A voice that ended the previous call steady and has no message
 // in this one skips the state machines altogether (VoiceCache): its whole call is a steady tail.
 __device__ inline void voice_control_wave(const FusedView& fv, const int vi, const int lane, const int K, const uint32_t cmd_block0) {
+#ifdef FW_CTL_TRACE
+    unsigned long long tr[12];
+    for (int i = 0; i < 12; ++i) tr[i] = 0;
+    bool tr_ramped = false;
+    CTL_T(0);
+#endif
     const bool w0 = lane == 0;
     const VoiceDesc vd = fv.voices[vi];
     const int frames = fv.frames;
@@ -451,19 +576,37 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         if (w0) fv.chain_start[vi] = cs;
     }
 
+    // first / last block of this call with a message for any node of the voice, and per node the index of its first
+    // message (its cursor: the list is sorted by (node, block, seq), and the block loop below visits the blocks in order)
     int last_cmd = -1, first_cmd = 0x7fffffff;
+    int cur_smp = 0, cur_st[FW_MAX_STAGES - 1];
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES - 1; ++j) cur_st[j] = 0;
     if (fv.n_cmds) {
-        last_cmd = last_cmd_block(fv.cmds, fv.n_cmds, vd.sampler_state, cmd_block0);
-        first_cmd = first_cmd_block(fv.cmds, fv.n_cmds, vd.sampler_state, cmd_block0);
+        // up to 128 messages in the call (the usual case): every lane keeps two keys and all the nodes' spans come out of ONE
+        // memory round trip; beyond that, a search per node
+        const bool few = fv.n_cmds <= 2 * WAVE;
+        long long key0 = 0, key1 = 0;
+        if (few) {
+            if (lane < fv.n_cmds) key0 = cmd_key_at(fv.cmds, lane);
+            if (lane + WAVE < fv.n_cmds) key1 = cmd_key_at(fv.cmds, lane + WAVE);
+        }
+        const CmdSpan sp = few ? wave_cmd_span_held(key0, key1, fv.n_cmds, vd.sampler_state, cmd_block0, lane)
+                               : wave_cmd_span(fv.cmds, fv.n_cmds, vd.sampler_state, cmd_block0, lane);
+        last_cmd = sp.last;
+        first_cmd = sp.first;
+        cur_smp = sp.cursor;
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
             if (j < vd.n_stages) {
-                int l = last_cmd_block(fv.cmds, fv.n_cmds, vd.stage_state[j], cmd_block0);
-                last_cmd = l > last_cmd ? l : last_cmd;
-                int f = first_cmd_block(fv.cmds, fv.n_cmds, vd.stage_state[j], cmd_block0);
-                first_cmd = f < first_cmd ? f : first_cmd;
+                const CmdSpan sj = few ? wave_cmd_span_held(key0, key1, fv.n_cmds, vd.stage_state[j], cmd_block0, lane)
+                                       : wave_cmd_span(fv.cmds, fv.n_cmds, vd.stage_state[j], cmd_block0, lane);
+                last_cmd = sj.last > last_cmd ? sj.last : last_cmd;
+                first_cmd = sj.first < first_cmd ? sj.first : first_cmd;
+                cur_st[j] = sj.cursor;
             }
     }
+    CTL_T(1);
     GainSet* my_gsets = fv.gsets + (size_t)vi * FW_GSETS;
 
     // ---- fast path: still steady from the previous call, up to the voice's first message of this call (a call may
@@ -522,7 +665,10 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         }
     }
 
+    CTL_T(2);
     // ---- general path
+    // (asking for the state records before the fast path — behind its descriptor stores these loads wait for every one of
+    // them, 1 to 5 us: loads and stores retire through the same in-order counter on gfx9 — made every voice slower: measured)
     NodeState ss = fv.states[vd.sampler_state];
     if (k0_moved) ss.playhead = k0_playhead;
     StageRegs st[FW_MAX_STAGES - 1];
@@ -573,6 +719,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         cached_sample = ss.sample;
     }
 
+    CTL_T(8);
     for (int k = k0; k < K; ++k) {
         const uint32_t cb = cmd_block0 + k;
         VoiceBlk d;
@@ -594,16 +741,17 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         // vmcnt wait in the ramp code (with the lookups interleaved, every 64-frame ramp chunk store first drained the
         // previous one: loads and stores share the in-order vmcnt counter on gfx9).
         if (k <= last_cmd) {
-            apply_cmds(ss, vd.sampler_state, cb, fv.cmds, fv.n_cmds, fv.samples);
+            cur_smp = apply_cmds_from(ss, vd.sampler_state, cb, fv.cmds, fv.n_cmds, fv.samples, cur_smp);
 #pragma unroll
             for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
-                if (j >= vd.n_stages) break;
-                NodeState tmp;  // only p0/p1 apply to gain stages
-                tmp.p0 = st[j].p0;
-                tmp.p1 = st[j].p1;
-                apply_cmds(tmp, vd.stage_state[j], cb, fv.cmds, fv.n_cmds, fv.samples);
-                st[j].p0 = tmp.p0;
-                st[j].p1 = tmp.p1;
+                if (j < vd.n_stages) {
+                    NodeState tmp;  // only p0/p1 apply to gain stages
+                    tmp.p0 = st[j].p0;
+                    tmp.p1 = st[j].p1;
+                    cur_st[j] = apply_cmds_from(tmp, vd.stage_state[j], cb, fv.cmds, fv.n_cmds, fv.samples, cur_st[j]);
+                    st[j].p0 = tmp.p0;
+                    st[j].p1 = tmp.p1;
+                }
             }
             if (ss.sample >= 0 && ss.playing && cached_sample != ss.sample) {
                 sd = fv.samples[ss.sample];
@@ -611,6 +759,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
         }
+        CTL_T(9);
         // ---- sampler (nodes/sampler.rs:323-561)
         // a sample destroyed under the sampler (fwgpu_sample_destroy: table entry with data == nullptr) counts as "no
         // sample": outputs cleared, nothing moves (sampler.rs:416-430) — never a fetch through the stale loop range
@@ -657,6 +806,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                 }
             }
         }
+        CTL_T(10);
         // a biquad / delay between the sampler and the gain stages never reports silence (SPEC nodes: out mask 0)
         const bool src_silent = silent;
         if (fx) silent = false;
@@ -714,6 +864,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                 d.g[j + 1][0] = d.g[j + 1][1] = r.p0;
             }
         }
+        CTL_T(11);
         const bool need_src = !src_silent && (fx || !silent);  // a dry voice whose output is muted fetches nothing
         if (need_src && !(d.flags & VB_RESAMPLE)) blk_set_source(d, sd, frames, fxp);
         else if (fxp && (d.flags >> VB_RAMP_SHIFT) == 0 && simple_frames) d.flags |= VB_SIMPLE;  // chain plan: cleared-source block
@@ -725,6 +876,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             if (w0) put_blk(fv, vi, k, d, gs, sd, fxp);
         }
 
+        CTL_T(3);
         // ---- steady from the next block on?
         if (k < last_cmd) continue;
         bool steady = true;
@@ -778,61 +930,47 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         // (smoother.rs:169-175) that only needs ITSELF: run it now for as many blocks as it takes, 64 frames at a time,
         // straight into the blocks' ramp buffers, then emit all descriptors together.  (Walking those ~20 blocks one by
         // one through the whole state machine cost ~6 us each: a gain change per voice cost a third of config 2's step.)
+        CTL_T(4);
+#ifdef FW_CTL_TRACE
+        tr_ramped = ramping;
+#endif
         int ramp_until[2 * FW_MAX_STAGES];
 #pragma unroll
         for (int sl = 0; sl < 2 * FW_MAX_STAGES; ++sl) ramp_until[sl] = 0;
         if (ramping) {
-            for (int kk = k + 1; kk < K; ++kk) {
-                float* rbase = fv.ramps + ((size_t)kk * fv.n_voices + vi) * (size_t)fv.ramp_slots * (size_t)fv.stride;
-                bool moved = false;
-                {  // the sampler's gain (both channels share the ramp: sampler.rs:530-533)
-                    GainRun run = smoother_begin(ss.s0, ss.p0, frames);
-                    if (run.ramp && ramp_emit(run, frames, rbase, rbase + fv.stride, lane)) {
-                        ss.s0.last = run.prev;
-                        ramp_until[0] = ramp_until[1] = kk + 1;
-                        moved = true;
-                    }
-                }
+            // smoother by smoother (each one's recurrence is independent of the others'): see ramp_blocks
+            const size_t blk_stride = (size_t)fv.n_voices * (size_t)fv.ramp_slots * (size_t)fv.stride;
+            float* const rbase = fv.ramps + ((size_t)(k + 1) * fv.n_voices + vi) * (size_t)fv.ramp_slots * (size_t)fv.stride;
+            int furthest = 0;
+            if (!smoother_is_constant(ss.s0, ss.p0)) {  // the sampler's gain (both channels share the ramp: sampler.rs:530-533)
+                const int u = ramp_glide(ss.s0, ss.p0, frames, k + 1, K, rbase, blk_stride, fv.stride, true, lane);
+                ramp_until[0] = ramp_until[1] = u;
+                furthest = u;
+            }
 #pragma unroll
-                for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
-                    if (j >= vd.n_stages) break;
+            for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+                if (j < vd.n_stages) {
                     StageRegs& r = st[j];
                     float* rb = rbase + (size_t)(j + 1) * 2 * fv.stride;
-                    if (vd.stage_kind[j] == K_VOLUME) {
-                        GainRun run = smoother_begin(r.s0, r.p0, frames);
-                        if (run.ramp && ramp_emit(run, frames, rb, rb + fv.stride, lane)) {
-                            r.s0.last = run.prev;
-                            ramp_until[2 * (j + 1)] = ramp_until[2 * (j + 1) + 1] = kk + 1;
-                            moved = true;
+                    const int kind = vd.stage_kind[j];
+                    if (kind == K_VOLUME || kind == K_PAN || kind == K_WIDTH) {
+                        if (!smoother_is_constant(r.s0, r.p0)) {
+                            const int u = ramp_glide(r.s0, r.p0, frames, k + 1, K, rb, blk_stride, fv.stride, kind == K_VOLUME, lane);
+                            ramp_until[2 * (j + 1)] = u;
+                            if (kind == K_VOLUME) ramp_until[2 * (j + 1) + 1] = u;
+                            furthest = u > furthest ? u : furthest;
                         }
-                    } else if (vd.stage_kind[j] == K_PAN) {
-                        GainRun rl = smoother_begin(r.s0, r.p0, frames);
-                        GainRun rr = smoother_begin(r.s1, r.p1, frames);
-                        if (rl.ramp && ramp_emit(rl, frames, rb, nullptr, lane)) {
-                            r.s0.last = rl.prev;
-                            ramp_until[2 * (j + 1)] = kk + 1;
-                            moved = true;
-                        }
-                        if (rr.ramp && ramp_emit(rr, frames, rb + fv.stride, nullptr, lane)) {
-                            r.s1.last = rr.prev;
-                            ramp_until[2 * (j + 1) + 1] = kk + 1;
-                            moved = true;
-                        }
-                    } else if (vd.stage_kind[j] == K_WIDTH) {
-                        GainRun rw = smoother_begin(r.s0, r.p0, frames);
-                        if (rw.ramp && ramp_emit(rw, frames, rb, nullptr, lane)) {
-                            r.s0.last = rw.prev;
-                            ramp_until[2 * (j + 1)] = kk + 1;
-                            moved = true;
+                        if (kind == K_PAN && !smoother_is_constant(r.s1, r.p1)) {
+                            const int u = ramp_glide(r.s1, r.p1, frames, k + 1, K, rb + fv.stride, blk_stride, fv.stride, false, lane);
+                            ramp_until[2 * (j + 1) + 1] = u;
+                            furthest = u > furthest ? u : furthest;
                         }
                     }
                 }
-                if (!moved) {  // every smoother settled (or stalled at its fixed point): blocks kk .. K-1 are steady
-                    ramping = false;
-                    break;
-                }
             }
+            ramping = furthest >= K;  // a glide that outlasts the call: the next call picks it up at block 0
         }
+        CTL_T(5);
         // ---- steady: the descriptor every later block shares.  Constant gains are `input` for a settled
         // smoother and `last` for one stalled at its f32 fixed point (Q28).
         TailJob job;
@@ -886,11 +1024,19 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                 tail_gs = pick_gset(probe);
                 simple_ok = (probe.flags & VB_SIMPLE) != 0;  // false when the voice ran out of gain-set slots
             }
+            CTL_T(6);
             uint64_t ph = steady_tail(fv, vi, lane, k + 1, K, job, sd, tail_gs, simple_ok, fx, fxp);
             if (mode != 0) ss.playhead = ph;
         }
         break;
     }
+#ifdef FW_CTL_TRACE
+    CTL_T(7);
+    if (w0 && tr_ramped)
+        printf("ctl voice %d k0 %d: spans %llu fast %llu blocks %llu [state loads %llu, last block: msgs %llu sampler %llu stages %llu emit %llu] check %llu "
+               "glide %llu job %llu tail %llu (x10 ns)\n", vi, k0, tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[8] - tr[2], tr[9] - tr[8], tr[10] - tr[9],
+               tr[11] - tr[10], tr[3] - tr[11], tr[4] - tr[3], tr[5] - tr[4], tr[6] - tr[5], tr[7] - tr[6]);
+#endif
     if (!w0) return;
     if (!became_steady) fv.cache[vi].epoch = 0;
     fv.states[vd.sampler_state] = ss;

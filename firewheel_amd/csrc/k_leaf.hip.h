@@ -280,27 +280,16 @@ __device__ __forceinline__ v4f gload4(const float* p) {
 #define LEAF_SPEC_GSET 1  // gain set 0 of every port is requested together with the port's record (it is the one in use on a
                           // steady voice), not after it: one dependent memory round trip less at the head of every wave
 #endif
-#ifndef LEAF_PREFETCH
-#define LEAF_PREFETCH 0   // the first LEAF_U ports' source loads are issued before the gain sets have arrived
-#endif
 template <int NG>
-__device__ __forceinline__ void leaf_fast(const float* my_l, const float* my_r, const GainSet& my_g, int ports, int f0,
-                                          v4f& accl, v4f& accr, const v4f* pre_l = nullptr, const v4f* pre_r = nullptr) {
-    for (int p0 = 0; p0 < ports; p0 += LEAF_U) {
+__device__ __forceinline__ void leaf_fast(const float* my_l, const float* my_r, const GainSet& my_g, int p_begin, int ports, int f0,
+                                          v4f& accl, v4f& accr) {
+    for (int p0 = p_begin; p0 < ports; p0 += LEAF_U) {  // ports [p_begin, ports): a run of plain ports, accumulators carried in
         v4f xl[LEAF_U], xr[LEAF_U];
-        if (pre_l != nullptr && p0 == 0) {
 #pragma unroll
-            for (int u = 0; u < LEAF_U; ++u) {
-                xl[u] = pre_l[u];
-                xr[u] = pre_r[u];
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < LEAF_U; ++u) {
-                if (p0 + u < ports) {
-                    xl[u] = gload4(readlane_ptr(my_l, p0 + u) + f0);
-                    xr[u] = gload4(readlane_ptr(my_r, p0 + u) + f0);
-                }
+        for (int u = 0; u < LEAF_U; ++u) {
+            if (p0 + u < ports) {
+                xl[u] = gload4(readlane_ptr(my_l, p0 + u) + f0);
+                xr[u] = gload4(readlane_ptr(my_r, p0 + u) + f0);
             }
         }
 #pragma unroll
@@ -327,8 +316,8 @@ __device__ __forceinline__ void leaf_fast(const float* my_l, const float* my_r, 
 // the same with a stage program per voice (width / hard clip among the stages): lane p also holds port p's program; the
 // stage kind of (port, stage) is wave-uniform, so the dispatch is a scalar branch
 __device__ __forceinline__ void leaf_fast_prog(const float* my_l, const float* my_r, const GainSet& my_g, uint32_t my_prog, int ng,
-                                               int ports, int f0, v4f& accl, v4f& accr) {
-    for (int p0 = 0; p0 < ports; p0 += LEAF_U) {
+                                               int p_begin, int ports, int f0, v4f& accl, v4f& accr) {
+    for (int p0 = p_begin; p0 < ports; p0 += LEAF_U) {
         v4f xl[LEAF_U], xr[LEAF_U];
 #pragma unroll
         for (int u = 0; u < LEAF_U; ++u) {
@@ -516,10 +505,8 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
         my_r = (const float*)pr;
         my_rd = rd;
         my_cls = cl;
-#if !LEAF_PREFETCH
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES; ++j) asm volatile("" : "+v"(my_g.g[j][0]), "+v"(my_g.g[j][1]));
-#endif
     }
     const uint64_t lanes_in = mask_all_silent_bits(ld.ports);
     const uint64_t silent_ports = __ballot((my_flags & VB_SILENT) != 0) & lanes_in;
@@ -529,49 +516,14 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
     const bool all_simple = simple_ports == lanes_in && (frames & 3) == 0;
     const uint32_t cls0 = (uint32_t)__builtin_amdgcn_readlane((int)my_cls, 0);  // ports >= 1
     const bool one_class = (__ballot(my_cls == cls0) & lanes_in) == lanes_in;
-    const bool fast = all_simple && one_class && cls0 == SF_P_F32;
     const bool fast_cls = !PROG && all_simple && one_class && cls0 != SF_P_F32;  // (program voices on other formats: port by port)
+    // ports of a mixed leaf whose source loads are batched: VB_SIMPLE (so frames % 4 == 0, not silent) planar f32
+    const uint64_t batch_ports = (frames & 3) == 0 ? simple_ports & ~silent_ports & __ballot(my_cls == SF_P_F32) : 0ull;
 
     const int f_first = lane * 4 + part * 256;
-#if LEAF_PREFETCH
-    // the first LEAF_U ports of this wave's first quad of frames: requested NOW, with the pointers alone — the gain sets are
-    // only needed at the multiply, and their loads (issued before these) complete first (vmcnt counts in order)
-    v4f pre_l[LEAF_U], pre_r[LEAF_U];
-    const bool use_pre = !PROG && fast;
-    if (use_pre && f_first < frames) {
-#pragma unroll
-        for (int u = 0; u < LEAF_U; ++u) {
-            const int pu = u < ld.ports ? u : 0;
-            pre_l[u] = gload4(readlane_ptr(my_l, pu) + f_first);
-            pre_r[u] = gload4(readlane_ptr(my_r, pu) + f_first);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < FW_MAX_STAGES; ++j) asm volatile("" : "+v"(my_g.g[j][0]), "+v"(my_g.g[j][1]));
-#endif
     for (int f0 = f_first; f0 < frames; f0 += 256 * wpk) {
         v4f accl = splat(0.f), accr = splat(0.f);
-        if (fast) {
-            if constexpr (PROG) {
-                leaf_fast_prog(my_l, my_r, my_g, my_prog, fv.n_gain_stages, ld.ports, f0, accl, accr);
-            } else {
-#if LEAF_PREFETCH
-                const v4f* pl = f0 == f_first ? pre_l : nullptr;
-                const v4f* pr = f0 == f_first ? pre_r : nullptr;
-#else
-                const v4f* pl = nullptr;
-                const v4f* pr = nullptr;
-#endif
-                switch (fv.n_gain_stages) {
-                    case 1: leaf_fast<1>(my_l, my_r, my_g, ld.ports, f0, accl, accr, pl, pr); break;
-                    case 2: leaf_fast<2>(my_l, my_r, my_g, ld.ports, f0, accl, accr, pl, pr); break;
-                    case 3: leaf_fast<3>(my_l, my_r, my_g, ld.ports, f0, accl, accr, pl, pr); break;
-                    case 4: leaf_fast<4>(my_l, my_r, my_g, ld.ports, f0, accl, accr, pl, pr); break;
-                    case 5: leaf_fast<5>(my_l, my_r, my_g, ld.ports, f0, accl, accr, pl, pr); break;
-                    default: leaf_fast<6>(my_l, my_r, my_g, ld.ports, f0, accl, accr, pl, pr); break;
-                }
-            }
-        } else if (fast_cls) {
+        if (fast_cls) {
             const int ng = fv.n_gain_stages;
             switch (cls0) {
                 case SF_P_I16: leaf_fast_cls<SF_P_I16>(my_l, my_rd, my_g, ng, ld.ports, f0, accl, accr); break;
@@ -581,7 +533,32 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                 default: leaf_fast_cls<SF_I_F32>(my_l, my_rd, my_g, ng, ld.ports, f0, accl, accr); break;
             }
         } else if (!all_silent) {
-            for (int p = 0; p < ld.ports; ++p) {
+            // The ports are added in port order.  A RUN of plain ports (VB_SIMPLE planar f32 — on a steady bank the whole
+            // leaf is one run) has its source loads issued LEAF_U ports at a time; a port that ramps, wraps, is silent or of
+            // another source class is evaluated on its own, between two runs.  (A leaf with ONE gliding voice used to go
+            // port by port altogether: 64 dependent memory round trips in a row made such a wave ~60 us long, and the 1 500
+            // of them in a step of config 2's variant B — 68 gliding voices x 21 blocks — stretched the render kernel by 13 %.)
+            int p = 0;
+            while (p < ld.ports) {
+                const uint64_t rest = ~(batch_ports >> p);
+                int run = rest ? __builtin_ctzll(rest) : 64;
+                run = run < ld.ports - p ? run : ld.ports - p;
+                if (run > 0) {
+                    if constexpr (PROG) {
+                        leaf_fast_prog(my_l, my_r, my_g, my_prog, fv.n_gain_stages, p, p + run, f0, accl, accr);
+                    } else {
+                        switch (fv.n_gain_stages) {
+                            case 1: leaf_fast<1>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
+                            case 2: leaf_fast<2>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
+                            case 3: leaf_fast<3>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
+                            case 4: leaf_fast<4>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
+                            case 5: leaf_fast<5>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
+                            default: leaf_fast<6>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
+                        }
+                    }
+                    p += run;
+                    continue;
+                }
                 const bool psil = (silent_ports >> p) & 1ull;
                 v4f xl = splat(0.f), xr = splat(0.f);  // a silent chain's buffers hold cleared zeros
                 if (!psil) {
@@ -590,11 +567,10 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                         simple_fetch((uint32_t)__builtin_amdgcn_readlane((int)my_cls, p), readlane_ptr(my_l, p),
                                      (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p), f0, xl, xr);
 #pragma unroll
-                        for (int j = 0; j < FW_MAX_STAGES; ++j) {
-                            if (j >= fv.n_gain_stages) break;
-                            apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)),
-                                        xl, xr);
-                        }
+                        for (int j = 0; j < FW_MAX_STAGES; ++j)
+                            if (j < fv.n_gain_stages)
+                                apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)),
+                                            xl, xr);
                     } else {
                         const VoiceBlk d = fv.blks[row + p];
                         voice_eval<RS>(fv, d, k, ld.first_voice + p, f0, frames, xl, xr, prog, rs);
@@ -607,6 +583,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                     accl = accl + xl;
                     accr = accr + xr;
                 }
+                ++p;
             }
         }
         *(v4f*)(outl + f0) = accl;  // all_silent: clear_all_outputs (sum.rs:52-56)

@@ -32,6 +32,27 @@ __global__ void k_exec(float* out, float in_a, float b, int chunks) {
     }
     out[threadIdx.x] = acc;
 }
+#define REP4(x) x x x x
+#define REP64(x) REP4(REP4(REP4(x)))
+#define STEP4                                                                                              \
+    "v_mul_f32 %4, %3, %7\n" "v_add_f32 %0, %6, %4\n" "v_mul_f32 %4, %0, %7\n" "v_add_f32 %1, %6, %4\n" \
+    "v_mul_f32 %4, %1, %7\n" "v_add_f32 %2, %6, %4\n" "v_mul_f32 %4, %2, %7\n" "v_add_f32 %3, %6, %4\n" \
+    "s_lshl_b64 exec, exec, 1\n"
+// (d) EXEC shrinking once per FOUR frames: lane q keeps frames 4q .. 4q+3 (what ramp_run does for whole 256-frame pieces)
+__global__ void k_exec4(float* out, float in_a, float b, int chunks) {
+    float prev = out[0], acc = 0.f;
+    for (int c = 0; c < chunks; c += 4) {
+        float d0, d1, d2, d3 = prev, t;
+        unsigned long long saved;
+        asm volatile("s_mov_b64 %5, exec\n" REP64(STEP4) "s_mov_b64 exec, %5\n"
+                     : "=&v"(d0), "=&v"(d1), "=&v"(d2), "+v"(d3), "=&v"(t), "=&s"(saved)
+                     : "v"(in_a), "v"(b)
+                     : "scc");
+        acc += d0 + d1 + d2 + d3;
+        prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d3), 63));
+    }
+    out[threadIdx.x] = acc;
+}
 __global__ void k_select(float* out, float in_a, float b, int chunks) {
     float prev = out[0], acc = 0.f;
     const int lane = threadIdx.x;
@@ -55,13 +76,14 @@ int main() {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int chunks = 4 * 21 * 8;  // 8 ramps of 21 blocks of 256 frames
-    for (int which = 0; which < 3; ++which) {
+    for (int which = 0; which < 4; ++which) {
         float best = 1e9f;
         for (int rep = 0; rep < 5; ++rep) {
             hipEventRecord(e0, 0);
             if (which == 0) hipLaunchKernelGGL(k_plain, dim3(1), dim3(64), 0, 0, d, 0.002f, 0.998f, chunks * 64);
             if (which == 1) hipLaunchKernelGGL(k_exec, dim3(1), dim3(64), 0, 0, d, 0.002f, 0.998f, chunks);
             if (which == 2) hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, 0, d, 0.002f, 0.998f, chunks);
+            if (which == 3) hipLaunchKernelGGL(k_exec4, dim3(1), dim3(64), 0, 0, d, 0.002f, 0.998f, chunks);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             float ms;
@@ -70,7 +92,7 @@ int main() {
         }
         const double steps = (double)chunks * 64;
         printf("%s: %.1f us for %d frames = %.2f ns per frame = %.2f us per 256-frame block, %.1f us per 21-block ramp\n",
-               which == 0 ? "plain chain " : which == 1 ? "exec-shrink " : "cmp + select", best * 1e3, (int)steps, best * 1e6 / steps,
+               which == 0 ? "plain chain " : which == 1 ? "exec-shrink " : which == 2 ? "cmp + select" : "exec-shrink/4", best * 1e3, (int)steps, best * 1e6 / steps,
                best * 1e3 / steps * 256, best * 1e3 / steps * 256 * 21);
     }
     return 0;

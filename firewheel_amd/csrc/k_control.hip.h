@@ -393,6 +393,19 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
     const uint64_t n = (uint64_t)(K - k_first);
     // chain plan, nothing to fetch (cleared source, or a dry voice whose output is muted): a cleared-source block
     const uint32_t nosrc_flags = (fxp && !has_src) ? (VB_SRC_ZERO | (simple_ok ? VB_SIMPLE : 0u)) : 0u;
+    // The record of a plain block — planar f32 source, constant gains, no wrap inside the block: what almost every block of a
+    // steady bank is — written straight from the loop, ~25 instructions: put_blk's general route through a full VoiceBlk is
+    // ~400, and a voice's wave (alone on its SIMD: 1 024 voices, 1 024 SIMDs) pays each of them in full, 12 times over for a
+    // call of 768 blocks.  Same bits as put_blk would store (VB_SIMPLE record, class SF_P_F32, no full descriptor).
+    int ramps_end = 0;  // blocks from here on carry no ramp
+#pragma unroll
+    for (int sl = 0; sl < 2 * FW_MAX_STAGES; ++sl) ramps_end = job.ramp_until[sl] > ramps_end ? job.ramp_until[sl] : ramps_end;
+    const bool lean = !fxp && has_src && simple_ok && contiguous_f32 && sd.frames < 0xffffffffull;
+    VoiceRef lean_ref;
+    lean_ref.src_l = nullptr;
+    lean_ref.r_delta = (job.flags & VB_MONO) ? 0u : (uint32_t)sd.frames;
+    lean_ref.flags_gset = ((job.flags | VB_SIMPLE) & 0xffu) | (gset << 8) | ((uint32_t)SF_P_F32 << 16);
+    VoiceRef* const my_refs = fv.refs + (size_t)vi * fv.refs_stride;
     if (job.mode == 1) {
         // all quantities fit 32 bits whenever the loop does (the usual case): avoid 64-bit division
         const uint64_t L = job.loop_end - job.loop_start;
@@ -415,6 +428,13 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
         }
         for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
             const uint64_t left = L - r;
+            if (lean && k2 >= ramps_end && left >= fr) {
+                lean_ref.src_l = (const float*)sd.data + (job.loop_start + r);
+                my_refs[k2] = lean_ref;
+                r += step;
+                if (r >= L) r -= L;
+                continue;
+            }
             const uint32_t rb = tail_ramp_bits(job, k2);
             t.flags = job.flags | nosrc_flags | (rb << VB_RAMP_SHIFT);
             t.off0 = job.loop_start + r;
@@ -440,6 +460,11 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
     }
     if (job.mode == 2) {
         for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
+            if (lean && k2 >= ramps_end) {
+                lean_ref.src_l = (const float*)sd.data + (job.playhead + (uint64_t)(k2 - k_first) * fr);
+                my_refs[k2] = lean_ref;
+                continue;
+            }
             const uint32_t rb = tail_ramp_bits(job, k2);
             t.flags = job.flags | nosrc_flags | (rb << VB_RAMP_SHIFT);
             t.off0 = job.playhead + (uint64_t)(k2 - k_first) * fr;

@@ -239,14 +239,13 @@ def make_gpu(fa, wl, V, B, K, radix, src, F, sfmt, seed, args, stream, device):
         cx.set_force_generic(True)
     g = GpuSide(cx)
     ir = cx.new_sample(PLANAR_F32, 2, reverb_ir(args.taps)) if wl == "cfg4" else None
-    elem = 4 if sfmt == "f32" else 2
     fmt = PLANAR_F32 if sfmt == "f32" else INTERLEAVED_I16
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
-    ids = [cx.new_sample_device(fmt, 2, F, src.data_ptr() + v * 2 * F * elem) for v in range(V)] if rs else None
+    ids = [cx.new_sample_device(fmt, 2, F, src[v].data_ptr()) for v in range(V)] if rs else None
     samplers, volumes = build_graph(g, wl, V, radix, seed, args.master, ir, args.voice_fx, ids)
     if not rs:
         for v, s in enumerate(samplers):
-            smp = cx.new_sample_device(fmt, 2, F, src.data_ptr() + v * 2 * F * elem)
+            smp = cx.new_sample_device(fmt, 2, F, src[v].data_ptr())
             g.start(s, smp)
     assert cx.plan_kind() == want_plan(wl, args.force_generic), "expected launch plan %d, got %d" % (
         want_plan(wl, args.force_generic), cx.plan_kind())
@@ -487,7 +486,9 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
     if sfmt == "i16":  # interleaved stereo PCM, [voice][frame][channel]
         src = torch.randint(-32768, 32768, (V, F, 2), dtype=torch.int16, device=dev, generator=gen)
     else:
-        src = torch.empty((V, 2, F), dtype=torch.float32, device=dev)
+        # (--src-stagger: floats between consecutive voices' buffers — where the samples sit in HBM relative to one another)
+        pitch = 2 * F + args.src_stagger
+        src = torch.empty(V * pitch, dtype=torch.float32, device=dev).as_strided((V, 2, F), (pitch, F, 1))
         src.uniform_(-1.0, 1.0, generator=gen)
     cx, g, samplers, volumes = make_gpu(fa, wl, V, B, K, args.radix, src, F, sfmt, rank, args, stream, device)
     variant = args.variant if wl in ("cfg2", "cfg5") else "A"
@@ -728,6 +729,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeat-first", type=int, default=0,
+                    help="diagnostic: run the headline workload this many times in the same process (fresh allocations each time) "
+                         "before the reported run; their step / kernel times go to `repeats_before`")
     ap.add_argument("--workload", choices=sorted(DEFAULTS), default="cfg2",
                     help="cfg2 = the headline (BASELINE configs[1]); cfg3 / cfg4 / cfg5 = configs[2..4]")
     ap.add_argument("--voices", type=int, default=None, help="voices per GPU")
@@ -735,6 +739,7 @@ def main():
     ap.add_argument("--radix", type=int, default=32)
     ap.add_argument("--blocks-per-step", type=int, default=None)
     ap.add_argument("--src-frames", type=int, default=None, help="source frames per voice (2 ch f32)")
+    ap.add_argument("--src-stagger", type=int, default=0, help="f32 sources: floats of padding between consecutive voices' buffers")
     ap.add_argument("--cpu-secs", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -824,6 +829,10 @@ def main():
 
     env = {"torch": torch, "fa": fa, "shard": shard, "dist": dist, "rank": rank, "world": world, "device": 0 if hostonly else local_rank,
            "dev": "cpu" if hostonly else "cuda", "hostonly": hostonly}
+    repeats = []
+    for _ in range(max(0, args.repeat_first)):  # diagnostic: the same run, same process, fresh allocations each time
+        r0 = run_workload(env, args, wl, V, B, K, F, steps, args.warmup, full=False)
+        repeats.append({"ms_per_step": r0["ms_per_step"], "kernel_us": (r0["roofline"] or {}).get("avg_launch_us")})
     res = run_workload(env, args, wl, V, B, K, F, steps, args.warmup, full=True)
     line = None
     if rank == 0:
@@ -847,6 +856,8 @@ def main():
             "realtime_us_per_callback": res.get("realtime_us_per_callback"),
             "rccl_ranks_seen": ranks_seen,
         }
+        if repeats:
+            line["repeats_before"] = repeats
         if hostonly:
             line["value"] = None
             line["invalid"] = "host-only harness (FWGPU_BENCH_HOSTONLY): orchestration test, no audio computed, not a measurement"

@@ -33,13 +33,32 @@ struct DevView {
     const unsigned long long* frozen_playhead;  // per node: a frozen playing sampler's playhead at the start of the batch
 };
 
+// The compact records are tiled: 32 voices x 8 blocks per 4 KiB tile, [voice % 32][block % 8].  A voice's 8 consecutive blocks
+// are one 128-B line — what its control wave stores (full lines) and what k_chain walks — and the 32 records a leaf wave
+// loads for ONE block sit in one page, 128 B apart.  (Voice-major rows put them 12 KiB apart at 768 blocks per call: 32 pages
+// per wave, and k_leaf_sum ran 257 or 291 us depending on where the context's buffers had landed — DESIGN.md §7.)
+#define FW_REF_TILE_VOICES 32
+#define FW_REF_TILE_BLOCKS 8
+#ifdef __HIPCC__
+#define FW_HOST_DEVICE __host__ __device__
+#else
+#define FW_HOST_DEVICE  // (the host-logic test harness compiles the host translation units with plain g++)
+#endif
+static inline FW_HOST_DEVICE size_t ref_index(int voice, int k, int kgroups) {
+    return ((((size_t)(voice / FW_REF_TILE_VOICES) * (size_t)kgroups + (size_t)(k / FW_REF_TILE_BLOCKS)) * FW_REF_TILE_VOICES +
+             (size_t)(voice % FW_REF_TILE_VOICES)) * FW_REF_TILE_BLOCKS) + (size_t)(k % FW_REF_TILE_BLOCKS);
+}
+static inline size_t ref_count(size_t n_voices, size_t kmax) {
+    const size_t vt = (n_voices + FW_REF_TILE_VOICES - 1) / FW_REF_TILE_VOICES, kg = (kmax + FW_REF_TILE_BLOCKS - 1) / FW_REF_TILE_BLOCKS;
+    return vt * kg * FW_REF_TILE_VOICES * FW_REF_TILE_BLOCKS;
+}
 struct FusedView {
     const VoiceDesc* voices;
     const LeafDesc* leaves;
     NodeState* states;
     const SampleDesc* samples;
-    VoiceRef* refs;   // [n_voices][refs_stride], refs_stride = max blocks per call
-    int refs_stride;
+    VoiceRef* refs;   // tiled, see ref_index(): ref_kgroups = ceil(max blocks per call / 8)
+    int ref_kgroups;
     GainSet* gsets;   // [n_voices][FW_GSETS], valid for the current call
     VoiceCache* cache;  // [n_voices]
     uint32_t epoch;     // >= 1

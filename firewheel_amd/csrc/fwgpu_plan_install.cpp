@@ -369,7 +369,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         }
         const size_t K = c->kmax;
         HIPC(c, c->d_blks.ensure(K * c->n_voices * sizeof(VoiceBlk)));
-        HIPC(c, c->d_refs.ensure(K * c->n_voices * sizeof(VoiceRef)));
+        HIPC(c, c->d_refs.ensure(ref_count(c->n_voices, K) * sizeof(VoiceRef)));
         HIPC(c, c->d_gsets.ensure((size_t)c->n_voices * FW_GSETS * sizeof(GainSet)));
         HIPC(c, c->d_chain_start.ensure((size_t)c->n_voices * sizeof(ChainStart)));
         HIPC(c, c->d_chain_dummy.ensure(64 * 1024));
@@ -383,7 +383,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         if (c->ctl_ahead && c->ctl_stream && !c->fused_fx && fb.tail_nodes.empty() && K > 1) {
             // the second copy of what the control kernel writes and the render kernels read
             bool ok = c->d_blks2.ensure(K * c->n_voices * sizeof(VoiceBlk)) == hipSuccess &&
-                      c->d_refs2.ensure(K * c->n_voices * sizeof(VoiceRef)) == hipSuccess &&
+                      c->d_refs2.ensure(ref_count(c->n_voices, K) * sizeof(VoiceRef)) == hipSuccess &&
                       c->d_gsets2.ensure((size_t)c->n_voices * FW_GSETS * sizeof(GainSet)) == hipSuccess &&
                       c->d_ramps2.ensure(K * c->n_voices * (size_t)c->ramp_slots * c->stride * sizeof(float)) == hipSuccess;
             if (!ok) (void)hipGetLastError();

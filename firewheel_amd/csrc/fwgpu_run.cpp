@@ -291,7 +291,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     fv.samples = c->d_samples.as<SampleDesc>();
     fv.blks = c->d_blks.as<VoiceBlk>();
     fv.refs = c->d_refs.as<VoiceRef>();
-    fv.refs_stride = (int)c->kmax;
+    fv.ref_kgroups = (int)((c->kmax + FW_REF_TILE_BLOCKS - 1) / FW_REF_TILE_BLOCKS);
     fv.gsets = c->d_gsets.as<GainSet>();
     fv.cache = c->d_cache.as<VoiceCache>();
     fv.epoch = c->epoch;

@@ -178,11 +178,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     }
     for (int i = threadIdx.x; i < ports * K; i += CH_THREADS) {
         const int pv = i / K, pk = i - pv * K, pvoice = grp.first_voice + pv;
-        const VoiceRef* r = &fv.refs[(size_t)pvoice * fv.refs_stride];
-        const VoiceRef rk = r[pk];
+        const VoiceRef rk = fv.refs[ref_index(pvoice, pk, fv.ref_kgroups)];
         const uint32_t fk = rk.flags_gset & 0xffu, kind = fk & (VB_SIMPLE | VB_WRAP | VB_TAIL_ZERO);
         const uint32_t per_voice = VB_SILENT | VB_MONO | VB_SRC_ZERO;  // what must not change inside the call
-        bool ok = ((fk ^ r[0].flags_gset) & per_voice) == 0u;
+        bool ok = ((fk ^ fv.refs[ref_index(pvoice, 0, fv.ref_kgroups)].flags_gset) & per_voice) == 0u;
         const float* a0 = nullptr;
         const float* a1 = nullptr;
         uint32_t wr = 0xffffffffu;
@@ -274,7 +273,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             ++kla;
         }
         // the tile after that starts a block: request its descriptor now
-        if (tla == 0 && kla < K) ref_n = fv.refs[(size_t)voice * fv.refs_stride + kla];
+        if (tla == 0 && kla < K) ref_n = fv.refs[ref_index(voice, kla, fv.ref_kgroups)];
     };
     auto ring_slot = [&](int j) -> uint32_t {
         uint32_t sl = pos + (uint32_t)(LF * q + 4 * j);
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         }
     };
     if (is_worker && active && !wg_fast) {  // prologue = the issue halves of steps -2 and -1
-        ref_n = fv.refs[(size_t)voice * fv.refs_stride + 0];
+        ref_n = fv.refs[ref_index(voice, 0, fv.ref_kgroups)];
         issue_source();
     }
 
@@ -314,7 +313,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         // path and emits exact vmcnt(N) waits: the source of tile s+2 and the ring slots of tile s are requested in
         // step s and stay in flight for two whole steps (two static register sets, loop unrolled by two).  A quad
         // that straddles the end of its ring (once per lap) is fixed up on a rare path with plain in-step accesses.
-        const uint32_t vflags = fv.refs[(size_t)voice * fv.refs_stride].flags_gset & 0xffu;  // per-voice bits only are used
+        const uint32_t vflags = fv.refs[ref_index(voice, 0, fv.ref_kgroups)].flags_gset & 0xffu;  // per-voice bits only are used
         const GainSet* gsp = &fv.gsets[(size_t)voice * FW_GSETS];
         const float g0f = gsp->g[0][ch];
         float gpost[FW_CHAIN_STAGES - 1];

@@ -355,7 +355,7 @@ __device__ __forceinline__ void put_blk(const FusedView& fv, int vi, int kk, con
         }
     }
     ref.flags_gset = (d.flags & 0xffu) | (gset << 8) | (cls << 16);
-    fv.refs[(size_t)vi * fv.refs_stride + kk] = ref;  // [voice][block]: the tail lanes store 1 KiB contiguous
+    fv.refs[ref_index(vi, kk, fv.ref_kgroups)] = ref;  // (tiled: the tail lanes store eight full 128-B lines)
     const bool need_full = fx ? !(d.flags & VB_SIMPLE) : !(d.flags & (VB_SIMPLE | VB_SILENT));
     if (need_full) fv.blks[(size_t)kk * fv.n_voices + vi] = d;
 }
@@ -405,7 +405,6 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
     lean_ref.src_l = nullptr;
     lean_ref.r_delta = (job.flags & VB_MONO) ? 0u : (uint32_t)sd.frames;
     lean_ref.flags_gset = ((job.flags | VB_SIMPLE) & 0xffu) | (gset << 8) | ((uint32_t)SF_P_F32 << 16);
-    VoiceRef* const my_refs = fv.refs + (size_t)vi * fv.refs_stride;
     if (job.mode == 1) {
         // all quantities fit 32 bits whenever the loop does (the usual case): avoid 64-bit division
         const uint64_t L = job.loop_end - job.loop_start;
@@ -430,7 +429,7 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
             const uint64_t left = L - r;
             if (lean && k2 >= ramps_end && left >= fr) {
                 lean_ref.src_l = (const float*)sd.data + (job.loop_start + r);
-                my_refs[k2] = lean_ref;
+                fv.refs[ref_index(vi, k2, fv.ref_kgroups)] = lean_ref;
                 r += step;
                 if (r >= L) r -= L;
                 continue;
@@ -462,7 +461,7 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
         for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
             if (lean && k2 >= ramps_end) {
                 lean_ref.src_l = (const float*)sd.data + (job.playhead + (uint64_t)(k2 - k_first) * fr);
-                my_refs[k2] = lean_ref;
+                fv.refs[ref_index(vi, k2, fv.ref_kgroups)] = lean_ref;
                 continue;
             }
             const uint32_t rb = tail_ramp_bits(job, k2);
@@ -527,7 +526,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         r.src_l = nullptr;
         r.r_delta = 0;
         r.flags_gset = VB_SILENT | (fxp ? (VB_SRC_ZERO | VB_SIMPLE) : 0u);
-        for (int k = lane; k < K; k += WAVE) fv.refs[(size_t)vi * fv.refs_stride + k] = r;
+        for (int k = lane; k < K; k += WAVE) fv.refs[ref_index(vi, k, fv.ref_kgroups)] = r;
         if (fxp && lane < FW_GSETS) {
             GainSet one;
 #pragma unroll
@@ -1083,7 +1082,7 @@ __device__ inline bool voice_control_lane_steady(const FusedView& fv, const int 
         r.src_l = nullptr;
         r.r_delta = 0;
         r.flags_gset = VB_SILENT;
-        fv.refs[(size_t)vi * fv.refs_stride] = r;
+        fv.refs[ref_index(vi, 0, fv.ref_kgroups)] = r;
         return true;
     }
     if (vd.bq_state >= 0 || vd.dl_state >= 0) return false;  // (chain-plan voices never come here)

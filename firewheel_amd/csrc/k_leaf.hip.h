@@ -259,6 +259,9 @@ __device__ __forceinline__ float readlane_f(float x, int lane) {
 #ifndef LEAF_NT
 #define LEAF_NT 1  // non-temporal source loads: every source byte is read exactly once (+12 % measured)
 #endif
+#ifndef LEAF_NT_STORE
+#define LEAF_NT_STORE 1  // ... and so are the leaf buses' stores: the next reader is another kernel (-1 % on the kernel, measured)
+#endif
 #ifndef LEAF_WPB
 #define LEAF_WPB 4  // waves (leaf, block work items) per workgroup
 #endif
@@ -471,7 +474,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
     GainSet g0 = my_g;
     if (lane < ld.ports) {  // (slot 0 may hold anything on a voice that is not VB_SIMPLE this block: then it is not used)
         g0 = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS];
-        ref = fv.refs[(size_t)(ld.first_voice + lane) * fv.refs_stride + k];
+        ref = fv.refs[ref_index(ld.first_voice + lane, (int)k, fv.ref_kgroups)];
     }
     const uint32_t my_flags = ref.flags_gset & 0xffu;
     if (my_flags & VB_SIMPLE) {
@@ -480,7 +483,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
         if (gi != 0) my_g = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + gi];
     }
 #else
-    if (lane < ld.ports) ref = fv.refs[(size_t)(ld.first_voice + lane) * fv.refs_stride + k];
+    if (lane < ld.ports) ref = fv.refs[ref_index(ld.first_voice + lane, (int)k, fv.ref_kgroups)];
     const uint32_t my_flags = ref.flags_gset & 0xffu;
     if (my_flags & VB_SIMPLE) my_g = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + ((ref.flags_gset >> 8) & 0xffu)];
 #endif
@@ -586,8 +589,13 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                 ++p;
             }
         }
+#if LEAF_NT_STORE
+        __builtin_nontemporal_store(accl, (v4f*)(outl + f0));
+        __builtin_nontemporal_store(accr, (v4f*)(outr + f0));
+#else
         *(v4f*)(outl + f0) = accl;  // all_silent: clear_all_outputs (sum.rs:52-56)
         *(v4f*)(outr + f0) = accr;
+#endif
     }
     // out mask: all-silent -> both flagged; 1-port copy -> passthrough (sum.rs:58-65); else 0
     if (lane < 2 && part == 0) bflags[ld.out_buf + lane] = all_silent ? 1 : 0;

@@ -79,12 +79,13 @@ void check_view_common(const DevView& v, int K) {
         REQUIRE(v.cmds[i - 1].state < v.cmds[i].state || (v.cmds[i - 1].state == v.cmds[i].state && v.cmds[i - 1].block <= v.cmds[i].block), i);
 }
 void check_fused_common(const FusedView& fv, int K) {
-    REQUIRE(K >= 1 && K <= fv.refs_stride, K, fv.refs_stride);
+    REQUIRE(K >= 1 && K <= fv.ref_kgroups * FW_REF_TILE_BLOCKS, K, fv.ref_kgroups);
     REQUIRE(fv.n_voices >= 1 && fv.n_leaves >= 1 && fv.stride % 64 == 0 && fv.frames >= 1 && fv.frames <= fv.stride, fv.n_voices, fv.frames);
     REQUIRE(fv.epoch >= 1);
     const size_t nv = (size_t)fv.n_voices;
     touch(fv.voices, sizeof(VoiceDesc) * nv);
-    touch(fv.refs, sizeof(VoiceRef) * nv * (size_t)fv.refs_stride);
+    touch(fv.refs, sizeof(VoiceRef) * ref_count(nv, (size_t)fv.ref_kgroups * FW_REF_TILE_BLOCKS));  // tiled: ref_index()
+    REQUIRE(ref_index(fv.n_voices - 1, K - 1, fv.ref_kgroups) < ref_count(nv, (size_t)fv.ref_kgroups * FW_REF_TILE_BLOCKS), K);
     touch(fv.gsets, sizeof(GainSet) * nv * FW_GSETS);
     touch(fv.cache, sizeof(VoiceCache) * nv);
     touch(fv.progs, sizeof(uint32_t) * nv);

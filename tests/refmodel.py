@@ -27,7 +27,7 @@ import math
 import numpy as np
 
 import fwapi
-from fwapi import (BIQUAD, DELAY, DUMMY, HARD_CLIP, MONO_TO_STEREO, SAMPLER, SPATIAL, STEREO_PAN, STEREO_TO_MONO, STEREO_WIDTH, SUM,
+from fwapi import (BIQUAD, DELAY, DUMMY, HARD_CLIP, MONO_TO_STEREO, RESAMPLER, SAMPLER, SPATIAL, STEREO_PAN, STEREO_TO_MONO, STEREO_WIDTH, SUM,
                    VOLUME)
 
 f32 = np.float32
@@ -646,9 +646,111 @@ class SpatialNode(Node):
         return 0
 
 
+# ------------------------------------------------------------------------------------------ SPEC resampling source
+# 32 phases x 16 taps of a Kaiser-windowed sinc (cutoff 0.9, beta 8), each row normalised to unit sum;
+# the source position is a 32.32 fixed-point frame index advanced by `step` per output frame; out[n] = sum_k
+# h[phase][k] * s[idx - 7 + k] as an ascending fused chain from +0.0, phase = top 5 fraction bits; outside [0, len) a
+# one-shot reads 0, a loop wraps.  Written from that description with numpy / scipy (np.sinc, scipy.special.i0: not the
+# power series the C++ sides use).
+RS_PHASES, RS_TAPS = 32, 16
+
+
+def resampler_table():
+    from scipy.special import i0
+
+    fc, beta = 0.9, 8.0
+    k = np.arange(RS_TAPS, dtype=np.float64)[None, :]
+    ph = np.arange(RS_PHASES, dtype=np.float64)[:, None]
+    t = (k - (RS_TAPS // 2 - 1)) - ph / RS_PHASES
+    r = t / (RS_TAPS / 2.0)
+    w = np.where(np.abs(r) >= 1.0, 0.0, i0(beta * np.sqrt(np.clip(1.0 - r * r, 0.0, None))) / i0(beta))
+    row = fc * np.sinc(fc * t) * w
+    return (row / row.sum(axis=1, keepdims=True)).astype(f32)
+
+
+def resampler_step(ratio):
+    r = float(f32(ratio))
+    if not r >= 1.0 / 256.0:
+        r = 1.0 / 256.0
+    r = min(r, 256.0)
+    return int(round_half_away(r * 4294967296.0))
+
+
+class ResamplerNode(Node):
+    kind = RESAMPLER
+    _table = None
+
+    def __init__(self, eng, n_in, n_out, params):
+        Node.__init__(self, eng, n_in, n_out, params)
+        assert n_in == 0 and n_out >= 1
+        p = list(params) + [None] * 4
+        self.src = eng.samples[int(p[0])]
+        self.step = resampler_step(1.0 if p[1] is None else p[1])
+        self.loop = bool(p[2]) if p[2] is not None else False
+        self.playing_ctl = (p[3] != 0.0) if p[3] is not None else True
+        self.seek = None
+        self.pos = 0
+        if ResamplerNode._table is None:
+            ResamplerNode._table = resampler_table()
+        self.h = ResamplerNode._table
+
+    def set_param(self, param, value):  # 1 = ratio, 3 = playing, 4 = seek to a source frame
+        if param == 1:
+            self.step = resampler_step(value)
+        elif param == 3:
+            self.playing_ctl = f32(value) != F0
+        elif param == 4:
+            self.seek = int(max(float(f32(value)), 0.0))  # (truncation, as a float -> u64 cast)
+        else:
+            raise AssertionError("resampler param %d" % param)
+
+    def _channel(self, c, j):
+        """source channel c at frame indices j (int64 array, all inside the sample), converted to f32"""
+        s = self.src
+        return s.convert(s.data[j, c] if s.interleaved else s.data[c, j])
+
+    def process(self, frames, ins, outs, in_mask):
+        if self.seek is not None:
+            self.pos = (self.seek << 32) & ((1 << 64) - 1)
+            self.seek = None
+        n = self.src.frames
+        if not self.playing_ctl or n == 0:
+            return clear_all_outputs(frames, outs)
+        sch = self.src.channels
+        nfill = min(self.n_out, sch)
+        p = [(self.pos + i * self.step) & ((1 << 64) - 1) for i in range(frames)]
+        idx = np.array([q >> 32 for q in p], dtype=np.int64)
+        ph = np.array([(q >> 27) & (RS_PHASES - 1) for q in p], dtype=np.int64)
+        mask = 0
+        for c in range(nfill):
+            acc = np.zeros(frames, dtype=f32)
+            for k in range(RS_TAPS):
+                j = idx - (RS_TAPS // 2 - 1) + k
+                if self.loop:
+                    x = self._channel(c, j % n)
+                else:
+                    inside = (j >= 0) & (j < n)
+                    x = np.where(inside, self._channel(c, np.where(inside, j, 0)), F0).astype(f32)
+                acc = fma32(self.h[ph, k], x, acc)
+            outs[c][:frames] = acc
+        if self.n_out > sch:  # like the sampler: a mono source feeds both outputs of a stereo node, anything else is zero + flagged
+            if self.n_out == 2 and sch == 1:
+                outs[1][:frames] = outs[0][:frames]
+            else:
+                for c in range(sch, self.n_out):
+                    outs[c][:frames] = F0
+                    mask |= 1 << c
+        self.pos = (self.pos + frames * self.step) & ((1 << 64) - 1)
+        if self.loop:
+            self.pos %= n << 32
+        elif (self.pos >> 32) >= n + RS_TAPS // 2:
+            self.playing_ctl = False  # ran off the end: silent from the next block on
+        return mask
+
+
 NODE_CLASSES = {DUMMY: Node, VOLUME: VolumeNode, SUM: SumNode, SAMPLER: SamplerNode, HARD_CLIP: HardClipNode,
                 MONO_TO_STEREO: MonoToStereoNode, STEREO_TO_MONO: StereoToMonoNode, STEREO_PAN: PanNode, STEREO_WIDTH: WidthNode,
-                BIQUAD: BiquadNode, DELAY: DelayNode, SPATIAL: SpatialNode}
+                BIQUAD: BiquadNode, DELAY: DelayNode, SPATIAL: SpatialNode, RESAMPLER: ResamplerNode}
 
 
 # ------------------------------------------------------------------------------------------ graph + processor

@@ -96,5 +96,83 @@ def test_model_golden_digests_are_current_and_the_oracle_reproduces_them():
     for name in mg.model_cases():
         assert t.digest(t.CASES[name]()) == gold[name], "oracle differs from the independent model's golden digest: " + name
     # the committed digests really are what the model produces now (spot-checked: the full regeneration is the script)
-    for name in ("events_70", "chain_events_37", "master_chain_fx", "graph_inputs"):
+    for name in ("events_70", "chain_events_37", "master_chain_fx", "graph_inputs", "rs_bank_40", "spatial_scene"):
         assert t.digest(mg.run_on_model(name)) == gold[name], "refmodel_digests.json is stale: " + name
+
+
+def test_resampler_control_math_of_the_model_and_the_oracle_agree_bit_for_bit():
+    """the SPEC resampler's filter bank and step are the same TEXT in the product (fwgpu_control_math.cpp) and the oracle
+    (VERDICT r1, weak #2); the model builds them another way — np.sinc and scipy.special.i0 instead of the power series —
+    and all 512 coefficients and the 32.32 steps of 2 000 ratios come out identical"""
+    import ctypes
+
+    import refmodel
+
+    lib = ctypes.CDLL(fwapi.oracle_lib()._name)
+    h = np.zeros(refmodel.RS_PHASES * refmodel.RS_TAPS, dtype=np.float32)
+    lib._ZN3fwo15resampler_tableEPf(h.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(fwapi.bits(h), fwapi.bits(refmodel.resampler_table().ravel()))
+    step = lib._ZN3fwo14resampler_stepEf
+    step.restype, step.argtypes = ctypes.c_uint64, [ctypes.c_float]
+    rng = np.random.default_rng(1)
+    for r in list(rng.uniform(0.001, 300.0, 2000).astype(np.float32)) + [1.0, 0.5, 44100.0 / 48000.0, 1.0 / 3.0, 1e-9, float("nan"), 1e9]:
+        assert step(ctypes.c_float(r)) == refmodel.resampler_step(r), r
+
+
+def _rs_fuzz(e, seed):
+    """resampling sources of every format / channel count, looping and one-shot, with ratio changes, seeks and pauses tagged at
+    random blocks, some through a spatialiser"""
+    rng = np.random.default_rng(77_000 + seed)
+    n = int(rng.integers(1, 6))
+    m = e.sum(n)
+    nodes = []
+    for v in range(n):
+        ch = int(rng.choice([1, 2]))
+        frames = int(rng.integers(40, 3000))
+        fmt = int(rng.choice([fwapi.PLANAR_F32, fwapi.PLANAR_I16, fwapi.INTERLEAVED_I16, fwapi.INTERLEAVED_F32, fwapi.PLANAR_U16, fwapi.INTERLEAVED_U16]))
+        x = scenarios.voice_source(9000 + 31 * seed + v, frames, ch)  # [ch][frames]
+        if fmt in (fwapi.PLANAR_I16, fwapi.INTERLEAVED_I16):
+            x = np.round(x * 32767).astype(np.int16)
+        elif fmt in (fwapi.PLANAR_U16, fwapi.INTERLEAVED_U16):
+            x = np.round((x + 1.0) * 32767.5).astype(np.uint16)
+        if fmt <= fwapi.INTERLEAVED_F32:
+            x = np.ascontiguousarray(x.T)
+        smp = e.new_sample(fmt, ch, x)
+        n_out = 2 if rng.random() < 0.7 else ch
+        rs = e.resampler(smp, float(rng.choice([1.0, 0.5, 2.0, 44100.0 / 48000.0, float(rng.uniform(0.05, 6.0))])), loop=bool(rng.random() < 0.5),
+                         playing=bool(rng.random() < 0.9), n_out=n_out)
+        if n_out == 2 and rng.random() < 0.3:
+            sp = e.spatial(float(rng.uniform(-4, 4)), float(rng.uniform(-1, 1)), float(rng.uniform(-4, 4)), n_in=2)
+            e.connect_stereo(rs, sp)
+            e.connect_stereo(sp, m, 2 * v)
+        else:
+            for c in range(n_out):
+                e.connect(rs, c, m, 2 * v + c)
+        nodes.append(rs)
+    e.connect_stereo(m, e.graph_out_node)
+    e.update()
+    outs = []
+    for _ in range(3):
+        nb = int(rng.integers(2, 9))
+        for _ in range(int(rng.integers(0, 5))):
+            rs = nodes[int(rng.integers(0, n))]
+            kind = int(rng.integers(0, 3))
+            at = int(rng.integers(0, nb))
+            if kind == 0:
+                e.set_param(rs, 1, float(rng.uniform(0.05, 6.0)), at_block=at)
+            elif kind == 1:
+                e.set_param(rs, 4, float(rng.integers(0, 3200)), at_block=at)
+            else:
+                e.set_param(rs, 3, float(rng.integers(0, 2)), at_block=at)
+        outs.append(e.process_blocks(nb))
+    return np.concatenate(outs)
+
+
+def test_resampler_sources_fuzz_model_against_oracle():
+    import refmodel
+
+    for seed in range(60):
+        mbf = int(np.random.default_rng(5 + seed).choice([16, 64, 100, 256]))
+        want = _rs_fuzz(scenarios.TaggedOracle(fwapi.OracleEngine(max_block_frames=mbf)), seed)
+        got = _rs_fuzz(scenarios.TaggedOracle(refmodel.RefEngine(max_block_frames=mbf)), seed)
+        assert np.array_equal(fwapi.bits(want), fwapi.bits(got)), seed

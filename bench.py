@@ -398,19 +398,20 @@ def parity_check(fa, torch, wl, V, B, K, radix, seed, args, src, F, sfmt, stream
 # ------------------------------------------------------------------------------------------------ realtime / cfg1
 def realtime_probe(cx, B, callbacks=1500):
     """one max_block_frames block per fwgpu_stream_callback, output to pageable host memory, synchronous — the call
-    pattern of the reference's backend callback (firewheel-cpal/src/lib.rs:378-449).  Returns microseconds per callback."""
+    pattern of the reference's backend callback (firewheel-cpal/src/lib.rs:378-449).  Returns microseconds per callback:
+    (the backend thread's loop inside the library — fwgpu_stream_run: what a native host pays —, the same callbacks driven
+    one by one from Python through ctypes)."""
     st = cx.open_stream(0, 2)
-    t = 0.0
-    for _ in range(50):
-        t += B / 48000.0
-        st.callback(B, t)
+    st.run(B, 50, 0.0)
+    _, dt_native = st.run(B, callbacks, 50 * B / 48000.0)
+    t = (50 + callbacks) * B / 48000.0
     t0 = time.perf_counter()
     for _ in range(callbacks):
         t += B / 48000.0
         st.callback(B, t)
     dt = time.perf_counter() - t0
     st.close()
-    return dt / callbacks * 1e6
+    return dt_native / callbacks * 1e6, dt / callbacks * 1e6
 
 
 def run_cfg1(fa, stream, device):
@@ -651,7 +652,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
         }
     if full and rank == 0 and world == 1 and not hostonly:
         if not args.no_realtime and wl != "cfg4":
-            res["realtime_us_per_callback"] = realtime_probe(cx, B)
+            res["realtime_us_per_callback"], res["realtime_us_per_callback_from_python"] = realtime_probe(cx, B)
         cx.close()
         if not args.no_parity_check:
             res["parity_check"] = parity_check(fa, torch, wl, V, B, K, args.radix, rank, args, src, F, sfmt, stream, device)
@@ -854,6 +855,7 @@ def main():
             "cpu_baseline": res.get("cpu_baseline"),
             "parity_check": res.get("parity_check"),
             "realtime_us_per_callback": res.get("realtime_us_per_callback"),
+            "realtime_us_per_callback_from_python": res.get("realtime_us_per_callback_from_python"),
             "rccl_ranks_seen": ranks_seen,
         }
         if repeats:

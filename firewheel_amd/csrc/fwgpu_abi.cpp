@@ -3,6 +3,7 @@
 // the buffer pool and the launch plan in HBM.  No CPU compute path exists: every process call is kernels.
 #include "fwgpu_ctx.h"
 
+#include <chrono>
 #include <stdio.h>
 
 namespace {
@@ -847,6 +848,19 @@ int fwgpu_stream_callback(fwgpu_stream* s, float* output, uint64_t frames, doubl
     // fwgpu_process_interleaved does itself (Q19)
     const int rc = fwgpu_process_interleaved(s->ctx, nullptr, output, s->n_in, s->n_out, frames, stream_time_secs, status);
     return rc < 0 ? rc : (int)status;
+}
+int fwgpu_stream_run(fwgpu_stream* s, float* output, uint64_t frames, uint32_t n_callbacks, double first_instant_secs,
+                     double* elapsed_secs) {
+    if (!s || !output) return FWGPU_ERR_INVALID;
+    const double period = (double)frames * s->sample_rate_recip;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = 0;
+    for (uint32_t i = 0; i < n_callbacks; ++i) {
+        rc = fwgpu_stream_callback(s, output, frames, first_instant_secs + (double)i * period);
+        if (rc < 0) break;
+    }
+    if (elapsed_secs) *elapsed_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc < 0 ? rc : 0;
 }
 int fwgpu_stream_stats(fwgpu_stream* s, uint64_t* callbacks, uint64_t* underflows, double* last_stream_time_secs) {
     if (!s) return FWGPU_ERR_INVALID;

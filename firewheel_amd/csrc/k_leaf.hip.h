@@ -283,20 +283,22 @@ __device__ __forceinline__ v4f gload4(const float* p) {
 #define LEAF_SPEC_GSET 1  // gain set 0 of every port is requested together with the port's record (it is the one in use on a
                           // steady voice), not after it: one dependent memory round trip less at the head of every wave
 #endif
-template <int NG>
+// U: ports whose source loads are in flight together — LEAF_U in the throughput kernels (occupancy hides the round trips),
+// 16 in the realtime kernel, where ONE wave adds a leaf's 32 ports and every round trip is on the callback's critical path
+template <int NG, int U>
 __device__ __forceinline__ void leaf_fast(const float* my_l, const float* my_r, const GainSet& my_g, int p_begin, int ports, int f0,
                                           v4f& accl, v4f& accr) {
-    for (int p0 = p_begin; p0 < ports; p0 += LEAF_U) {  // ports [p_begin, ports): a run of plain ports, accumulators carried in
-        v4f xl[LEAF_U], xr[LEAF_U];
+    for (int p0 = p_begin; p0 < ports; p0 += U) {  // ports [p_begin, ports): a run of plain ports, accumulators carried in
+        v4f xl[U], xr[U];
 #pragma unroll
-        for (int u = 0; u < LEAF_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (p0 + u < ports) {
                 xl[u] = gload4(readlane_ptr(my_l, p0 + u) + f0);
                 xr[u] = gload4(readlane_ptr(my_r, p0 + u) + f0);
             }
         }
 #pragma unroll
-        for (int u = 0; u < LEAF_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (p0 + u < ports) {
                 v4f a = xl[u], b = xr[u];
 #pragma unroll
@@ -318,19 +320,20 @@ __device__ __forceinline__ void leaf_fast(const float* my_l, const float* my_r, 
 
 // the same with a stage program per voice (width / hard clip among the stages): lane p also holds port p's program; the
 // stage kind of (port, stage) is wave-uniform, so the dispatch is a scalar branch
+template <int U>
 __device__ __forceinline__ void leaf_fast_prog(const float* my_l, const float* my_r, const GainSet& my_g, uint32_t my_prog, int ng,
                                                int p_begin, int ports, int f0, v4f& accl, v4f& accr) {
-    for (int p0 = p_begin; p0 < ports; p0 += LEAF_U) {
-        v4f xl[LEAF_U], xr[LEAF_U];
+    for (int p0 = p_begin; p0 < ports; p0 += U) {
+        v4f xl[U], xr[U];
 #pragma unroll
-        for (int u = 0; u < LEAF_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (p0 + u < ports) {
                 xl[u] = gload4(readlane_ptr(my_l, p0 + u) + f0);
                 xr[u] = gload4(readlane_ptr(my_r, p0 + u) + f0);
             }
         }
 #pragma unroll
-        for (int u = 0; u < LEAF_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (p0 + u < ports) {
                 v4f a = xl[u], b = xr[u];
                 const uint32_t kinds = (uint32_t)__builtin_amdgcn_readlane((int)my_prog, p0 + u) << 4;
@@ -450,7 +453,7 @@ __device__ __forceinline__ void leaf_fast_cls(const float* my_l, uint32_t my_rd,
 
 // PROG: some voice of the plan has a stage that is not a plain gain (width / hard clip) — lane p then also carries port
 // p's stage program.  The gains-only instantiation is the headline kernel and does not pay for the other ones' registers.
-template <bool PROG, bool RS = false>
+template <bool PROG, bool RS = false, int U = LEAF_U>
 __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int leaf, const uint32_t k, const int part, const int wpk,
                                               const RsLds rs = RsLds{nullptr, nullptr}) {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -548,15 +551,15 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                 run = run < ld.ports - p ? run : ld.ports - p;
                 if (run > 0) {
                     if constexpr (PROG) {
-                        leaf_fast_prog(my_l, my_r, my_g, my_prog, fv.n_gain_stages, p, p + run, f0, accl, accr);
+                        leaf_fast_prog<U>(my_l, my_r, my_g, my_prog, fv.n_gain_stages, p, p + run, f0, accl, accr);
                     } else {
                         switch (fv.n_gain_stages) {
-                            case 1: leaf_fast<1>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
-                            case 2: leaf_fast<2>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
-                            case 3: leaf_fast<3>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
-                            case 4: leaf_fast<4>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
-                            case 5: leaf_fast<5>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
-                            default: leaf_fast<6>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
+                            case 1: leaf_fast<1, U>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
+                            case 2: leaf_fast<2, U>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
+                            case 3: leaf_fast<3, U>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
+                            case 4: leaf_fast<4, U>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
+                            case 5: leaf_fast<5, U>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
+                            default: leaf_fast<6, U>(my_l, my_r, my_g, p, p + run, f0, accl, accr); break;
                         }
                     }
                     p += run;

@@ -13,9 +13,19 @@
 //      completion flag in pinned host memory the audio thread polls.
 // Same device functions as the throughput kernels, so the arithmetic is theirs bit for bit.  Used when the call is one
 // block, the tree is leaves + root and the stream is stereo; everything else takes the launch sequence.
+// -DFW_RT_TRACE: the last workgroup of every 512th callback prints where its time went (10 ns ticks)
+#ifdef FW_RT_TRACE
+#define RT_T(i) rt_tr[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define RT_T(i)
+#endif
 template <bool PROG, bool RS>
 __global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, RootArgs ra, float* __restrict__ out, uint32_t cmd_block0,
                                                   unsigned* __restrict__ sync, unsigned long long* done_flag, unsigned long long done_seq) {
+#ifdef FW_RT_TRACE
+    unsigned long long rt_tr[10];
+    RT_T(0);
+#endif
     extern __shared__ float s_rt_dyn[];
     RsLds rs{nullptr, nullptr};
     if constexpr (RS) rs = rs_lds_setup(fv, s_rt_dyn);
@@ -26,6 +36,7 @@ __global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, Roo
     // 1. control.  Thread p takes port p's voice on the lane-per-voice steady path (a leaf has <= 32 ports: all of them sit
     // in wave 0); the voices that need their state machines this block — a message, a gliding gain, a one-shot ending —
     // are then run wave-wide, dealt out over the four waves
+    RT_T(1);
     __shared__ unsigned long long s_need;
     bool need = false;
     if ((int)threadIdx.x < ld.ports) need = !voice_control_lane_steady(fv, ld.first_voice + (int)threadIdx.x, cmd_block0);
@@ -43,12 +54,15 @@ __global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, Roo
             if ((turn++ & 3) == wave) voice_control_wave(fv, ld.first_voice + p, lane, 1, cmd_block0);
         }
     }
+    RT_T(2);
     // the records (refs / gain sets / descriptors / ramps) were written by all four waves and are read by all four:
     // same CU, same L1 — a workgroup-scope release / acquire around the barrier
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    leaf_sum_wave<PROG, RS>(fv, leaf, 0u, wave, 4, rs);
+    RT_T(3);
+    leaf_sum_wave<PROG, RS, 16>(fv, leaf, 0u, wave, 4, rs);  // 16 ports in flight: two round trips per leaf, not eight
+    RT_T(4);
     // grid-wide hand-over to the root: every workgroup publishes its bus (agent scope: the XCDs have separate L2s), the
     // last one to arrive reads them all
     __shared__ int s_last;
@@ -60,9 +74,12 @@ __global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, Roo
         if (s_last) __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next callback
     }
     __syncthreads();
+    RT_T(5);
     if (!s_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    RT_T(6);
     for (int f0 = 0; f0 < upv.frames; f0 += 256) root_out_any(upv, ra, out, 0u, f0 + (int)threadIdx.x);
+    RT_T(7);
     // 4. completion: the output block sits in pinned host memory; publish it with a system-scope release and raise the
     // flag the audio thread is spinning on (a blocking stream sync costs a driver wake-up, ~15 us on this stack)
     if (done_flag) {
@@ -70,6 +87,13 @@ __global__ __launch_bounds__(256) void k_rt_block(FusedView fv, DevView upv, Roo
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+#ifdef FW_RT_TRACE
+    RT_T(8);
+    if (threadIdx.x == 0 && (done_seq & 511) == 0)
+        printf("rt wg %d: leafdesc %llu control %llu fence %llu leafsum %llu publish %llu acquire %llu root %llu flag %llu total %llu (x10 ns)\n",
+               (int)blockIdx.x, rt_tr[1] - rt_tr[0], rt_tr[2] - rt_tr[1], rt_tr[3] - rt_tr[2], rt_tr[4] - rt_tr[3], rt_tr[5] - rt_tr[4],
+               rt_tr[6] - rt_tr[5], rt_tr[7] - rt_tr[6], rt_tr[8] - rt_tr[7], rt_tr[8] - rt_tr[0]);
+#endif
 }
 
 // the same completion flag behind any launch sequence (realtime-sized calls that do not fit k_rt_block)

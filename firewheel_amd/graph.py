@@ -537,6 +537,14 @@ class HeadlessStream(object):
         st = self.cx._check(self.cx.L.fwgpu_stream_callback(self.s, _fptr(out), frames, instant_secs))
         return out, st
 
+    def run(self, frames, n_callbacks, first_instant_secs=0.0):
+        """the backend thread's loop (fwgpu_stream_run): n callbacks back to back inside the library.  Returns (the last
+        block, seconds the loop took)"""
+        out = np.full(frames * self.num_out_channels, np.nan, dtype=np.float32)
+        dt = C.c_double()
+        self.cx._check(self.cx.L.fwgpu_stream_run(self.s, _fptr(out), frames, n_callbacks, first_instant_secs, C.byref(dt)))
+        return out, dt.value
+
     def stats(self):
         a, b, t = C.c_uint64(), C.c_uint64(), C.c_double()
         self.cx._check(self.cx.L.fwgpu_stream_stats(self.s, C.byref(a), C.byref(b), C.byref(t)))

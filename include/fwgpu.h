@@ -224,6 +224,13 @@ void fwgpu_stream_close(fwgpu_stream* s);
 /* returns the StreamStatus bits handed to process_interleaved (>= 0) or a negative error; `output` is always filled */
 int fwgpu_stream_callback(fwgpu_stream* s, float* output, uint64_t frames, double callback_instant_secs);
 int fwgpu_stream_stats(fwgpu_stream* s, uint64_t* callbacks, uint64_t* underflows, double* last_stream_time_secs);
+/* The backend thread's loop without the device: `n_callbacks` callbacks of `frames` frames back to back, callback i at
+ * instant first_instant_secs + i * frames / sample_rate — a stream that never underruns, driven as fast as the engine
+ * answers.  `output` (frames x num_out_channels) is overwritten by every callback and holds the last block on return.
+ * *elapsed_secs (may be NULL) = wall time of the loop on the monotonic clock: elapsed / n_callbacks is what one callback
+ * costs the audio thread, with nothing of the caller's language runtime inside the loop.  Returns 0 or the first error. */
+int fwgpu_stream_run(fwgpu_stream* s, float* output, uint64_t frames, uint32_t n_callbacks, double first_instant_secs,
+                     double* elapsed_secs);
 
 /* AudioNodeProcessor::process (core/node.rs:37-53) for ONE activated node on caller (host) buffers —
  * the literal per-node drop-in for graph/processor.rs:243.  inputs/outputs: arrays of `frames` floats.

@@ -108,6 +108,7 @@ extern "C" {
     pub fn fwgpu_stream_close(s: *mut fwgpu_stream);
     pub fn fwgpu_stream_callback(s: *mut fwgpu_stream, output: *mut f32, frames: u64, callback_instant_secs: f64) -> c_int;
     pub fn fwgpu_stream_stats(s: *mut fwgpu_stream, callbacks: *mut u64, underflows: *mut u64, last_stream_time_secs: *mut f64) -> c_int;
+    pub fn fwgpu_stream_run(s: *mut fwgpu_stream, output: *mut f32, frames: u64, n_callbacks: u32, first_instant_secs: f64, elapsed_secs: *mut f64) -> c_int;
     pub fn fwgpu_node_process(ctx: *mut fwgpu_ctx, node: i64, frames: u64, inputs: *const *const f32, num_inputs: u32, outputs: *const *mut f32, num_outputs: u32, in_silence_mask: u64, out_silence_mask: *mut u64, stream_time_secs: f64, stream_status: u32) -> c_int;
     pub fn fwgpu_timing_enable(ctx: *mut fwgpu_ctx, on: c_int) -> c_int;
     pub fn fwgpu_timing_read(ctx: *mut fwgpu_ctx, which: c_int, total_ms: *mut f64, launches: *mut u64) -> c_int;

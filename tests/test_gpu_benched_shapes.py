@@ -214,6 +214,33 @@ def test_headless_stream_on_the_device_matches_oracle_audio_and_flags():
     L.fwo_stream_free(ost)
 
 
+def test_stream_run_on_the_device_renders_what_the_callbacks_render():
+    """fwgpu_stream_run (the backend thread's loop inside the library; what bench.py's realtime figure times) against the
+    oracle driven callback by callback: the block it leaves in the output buffer is the oracle's block of that callback"""
+    o = scenarios.TaggedOracle(OracleEngine(max_block_frames=256))
+    g = GpuEngine(max_block_frames=256, max_batch=4)
+    for e in (o, g):
+        voices = scenarios.build_voice_bank(e, 40, radix=8, src_frames=3000)
+        for vc in voices:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+            e.sampler_play(vc["sampler"])
+    st = g.cx.open_stream(0, 2)
+    L = fwapi.oracle_lib()
+    ost = L.fwo_stream_new(o.e.c, 48000, 0, 2)
+    ref = np.zeros(256 * 2, f32)
+    period = 256 / 48000.0
+    done = 0
+    for n in (1, 7, 30):
+        out, secs = st.run(256, n, 3.0 + done * period)
+        for i in range(n):
+            L.fwo_stream_callback(ost, ref.ctypes.data_as(C.POINTER(C.c_float)), 256, 3.0 + (done + i) * period, None)
+        done += n
+        assert secs > 0.0
+        assert_bits_equal(ref, out, "after %d callbacks" % done)
+    assert st.stats()[:2] == (38, 0)
+    L.fwo_stream_free(ost)
+
+
 def test_b1_two_nodes_interleaved_messages_match_the_oracle():
     # ADVICE r1: node A's process() must not swallow node B's queued messages (one queue per node in the reference)
     o = OracleEngine(max_block_frames=64)

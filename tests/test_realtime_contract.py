@@ -156,6 +156,30 @@ def test_headless_stream_matches_the_reference_callback_bookkeeping():
         st.close()
 
 
+def test_stream_run_is_the_callback_loop():
+    """fwgpu_stream_run(n) = n fwgpu_stream_callback calls at instants first + i * period: the same callback count, the same
+    stream time at the end, no underflow (a clock that is never late), the last block in the output buffer"""
+    for block in (64, 256):
+        e1, e2 = HostOnlyEngine(max_block_frames=block), HostOnlyEngine(max_block_frames=block)
+        sts = []
+        for e in (e1, e2):
+            vol = e.volume(50.0)
+            e.connect_stereo(vol, e.graph_out_node)
+            e.update()
+            sts.append(e.cx.open_stream(0, 2))
+        period = block / 48000.0
+        out, secs = sts[0].run(block, 37, 12.5)
+        assert secs > 0.0 and out.shape == (block * 2,) and not np.isnan(out).any()
+        for i in range(37):
+            sts[1].callback(block, 12.5 + i * period)
+        assert sts[0].stats() == sts[1].stats() and sts[0].stats()[:2] == (37, 0)
+        assert e1.cx.proc_info()[:2] == e2.cx.proc_info()[:2]
+        out2, _ = sts[0].run(block, 3, 12.5 + 37 * period)   # the clock carries on: still no underflow
+        assert sts[0].stats()[:2] == (40, 0)
+        for st in sts:
+            st.close()
+
+
 def test_stream_without_a_schedule_outputs_silence():
     e = HostOnlyEngine(max_block_frames=64)
     st = e.cx.open_stream(0, 2)

@@ -35,6 +35,18 @@ impl HeadlessStream {
         self.cx.check(rc as i64).map(|bits| StreamStatus::from_bits_truncate(bits as u32))
     }
 
+    /// The backend thread's loop without a device: `n_callbacks` periods back to back, callback `i` at
+    /// `first_instant_secs + i * period` (a clock that is never late).  `output` holds the last block afterwards.
+    /// Returns the wall time of the loop — `elapsed / n_callbacks` is what one callback costs the audio thread.
+    pub fn run(&mut self, output: &mut [f32], n_callbacks: u32, first_instant_secs: f64) -> Result<std::time::Duration, GpuError> {
+        let frames = output.len() / self.num_out_channels;
+        let mut secs = 0f64;
+        let rc = unsafe {
+            ffi::fwgpu_stream_run(self.raw.as_ptr(), output.as_mut_ptr(), frames as u64, n_callbacks, first_instant_secs, &mut secs)
+        };
+        self.cx.check(rc as i64).map(|_| std::time::Duration::from_secs_f64(secs))
+    }
+
     /// (callbacks so far, underflows so far, stream time of the last callback)
     pub fn stats(&self) -> (u64, u64, f64) {
         let (mut c, mut u, mut t) = (0u64, 0u64, 0f64);

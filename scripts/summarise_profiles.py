@@ -16,6 +16,8 @@ tag, cfg, steps, raw, outdir = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.a
 suffix = sys.argv[6] if len(sys.argv) > 6 else ""
 extra = sys.argv[7] if len(sys.argv) > 7 else ""
 V, B, K, F, _ = bench.DEFAULTS[cfg]
+if "--blocks-per-step" in extra.split():  # (the one shape flag the profile runs use)
+    K = int(extra.split()[extra.split().index("--blocks-per-step") + 1])
 
 
 def find(pattern):

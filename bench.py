@@ -452,7 +452,7 @@ def run_cfg1(fa, stream, device):
 
 
 # ------------------------------------------------------------------------------------------------ measured run
-def pmc_traffic(kernel, V, B, K):
+def pmc_traffic(kernel, V, B, K, name):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
     gfx950 corrections per the microarch guide) — quoted only when collected on this exact workload."""
     import glob
@@ -461,7 +461,7 @@ def pmc_traffic(kernel, V, B, K):
         try:
             pm = json.load(open(path))
             w = pm["workload"]
-            if (w["voices"], w["block"], w["blocks_per_step"]) == (V, B, K) and kernel in pm:
+            if (w["voices"], w["block"], w["blocks_per_step"]) == (V, B, K) and kernel in pm and w.get("name", name) == name:
                 return pm[kernel]["traffic_bytes"], os.path.relpath(path, ROOT)
         except Exception:
             continue
@@ -597,7 +597,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
             flops = 2.0 * 2 * args.taps * V * B * K  # direct-form definition: 2 ch x 2 flop x T per voice-sample
             avg_s = fir_ms / fir_n / 1e3
             ach = flops / avg_s / 1e12
-            traffic, traffic_src = pmc_traffic("k_fir_gemm", V, B, K)
+            traffic, traffic_src = pmc_traffic("k_fir_gemm", V, B, K, wl)
             roofline = {"bound": "mfma", "kernel": "k_fir_gemm", "achieved": ach,
                         "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic,
                         "traffic_source": traffic_src, "algorithmic_flops_per_launch": flops, "avg_launch_us": avg_s * 1e6,
@@ -611,7 +611,10 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
             alg_bytes = V * B * k_launch * per_vs * playing  # paused voices (variant C) fetch nothing
             avg_s = dom_ms / dom_n / 1e3
             ach = alg_bytes / avg_s / 1e9
-            traffic, traffic_src = pmc_traffic(kernel, V, B, K) if sfmt == "f32" else (None, None)  # PMC passes ran on f32 sources
+            # (PMC passes ran on f32 sources; a profile is quoted for the workload it was collected on: plain / --voice-fx / --rs-source)
+            prof_name = wl + ("_voicefx" if args.voice_fx else "") + ("_rs" if getattr(args, "rs_source", False) else "")
+            plain = not (args.master or variant != "A" or args.force_generic)
+            traffic, traffic_src = pmc_traffic(kernel, V, B, K, prof_name) if sfmt == "f32" and plain else (None, None)
             roofline = {
                 "bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -139,6 +139,33 @@ def scenario_voice_bank_events(e, n_voices=70, radix=32, mbf=None, src_frames=10
     return np.concatenate(outs)
 
 
+def scenario_message_storm(e, n_voices=48, radix=8, blocks=40, per_voice=6, src_frames=5000, seed=3):
+    """hundreds to thousands of messages inside ONE call: every voice gets `per_voice` gain / pan / pause / play messages at
+    random blocks (several per block on some voices).  The control kernel finds a voice's messages in the sorted list of the
+    call by a wave-wide search — one round for <= 128 messages, 64-ary rounds beyond — and walks them with per-node cursors."""
+    rng = np.random.default_rng(seed)
+    voices = build_voice_bank(e, n_voices, radix=radix, src_frames=src_frames, mono_every=5)
+    for vc in voices:
+        e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        e.sampler_play(vc["sampler"])
+    outs = [e.process_blocks(2)]
+    for vc in voices:
+        for _ in range(per_voice):
+            at = int(rng.integers(0, blocks))
+            kind = int(rng.integers(0, 6))
+            if kind <= 2:
+                e.set_param(vc["volume"], 0, float(rng.uniform(0.0, 100.0)), at_block=at)
+            elif kind == 3:
+                e.set_param(vc["pan"], 0, float(rng.uniform(-1.0, 1.0)), at_block=at)
+            elif kind == 4:
+                e.sampler_pause(vc["sampler"], at_block=at)
+            else:
+                e.sampler_play(vc["sampler"], at_block=at)
+    outs.append(e.process_blocks(blocks))
+    outs.append(e.process_blocks(3))
+    return np.concatenate(outs)
+
+
 def width_clip_fx(e, v, rng, limit=3):
     """per-voice tail of the stage-program tests: width and / or hard clip in varying order and number"""
     wv, cv = float(rng.uniform(0.0, 2.0)), float(rng.uniform(-20.0, -2.0))

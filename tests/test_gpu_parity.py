@@ -206,6 +206,8 @@ def run_case(name, **gpu_kw):
         "rs_bank_21_b64_i16_pure": lambda e: scenarios.scenario_rs_bank(e, 21, radix=32, src_frames=400, mixed=False, fmt=fwapi.INTERLEAVED_I16),
         "events_70": lambda e: scenarios.scenario_voice_bank_events(e, 70),
         "events_33_r2": lambda e: scenarios.scenario_voice_bank_events(e, 33, radix=2, src_frames=777),
+        "storm_48x6": scenarios.scenario_message_storm,
+        "storm_200x50_b64": lambda e: scenarios.scenario_message_storm(e, 200, radix=32, blocks=60, per_voice=50, src_frames=3000, seed=4),
         "mixed_generic": scenarios.scenario_mixed_generic,
         "mixed_generic_nobeep": lambda e: scenarios.scenario_mixed_generic(e, use_beep=False),
         "graph_inputs": scenarios.scenario_graph_inputs,
@@ -237,7 +239,7 @@ def run_case(name, **gpu_kw):
                                                                           ir_channels=1),
     }[name]
     mbf = {"rs_bank_40": 128, "rs_bank_21_b64_i16_pure": 64, "voice_fx_steady": 256, "voice_fx_events_45": 128, "voice_fx_events_20_i16_r32": 64, "steady_fmt_p_i16_mono3": 128, "steady_fmt_i_f32": 64, "steady_fmt_i_u16": 64, "steady_fmt_p_i16_oddlen": 64,
-           "steady_fmt_mixed_leaf": 128, "events_33_i16": 128, "steady_96x32": 256, "steady_40x4_i16": 64, "steady_9x3_u16": 128, "events_70": 256, "events_33_r2": 128,
+           "steady_fmt_mixed_leaf": 128, "events_33_i16": 128, "steady_96x32": 256, "steady_40x4_i16": 64, "steady_9x3_u16": 128, "events_70": 256, "events_33_r2": 128, "storm_48x6": 128, "storm_200x50_b64": 64,
            "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64, "cfg3_chain": 128, "cfg4_reverb": 128,
            "cfg4_reverb_2irs_mono": 64, "chain_steady_40": 256, "chain_steady_bq_only_i16": 64,
            "chain_steady_dl_only_pan": 128, "chain_events_37": 128, "chain_events_19_r2_pan": 64,
@@ -253,7 +255,7 @@ def run_case(name, **gpu_kw):
     return out_o, out_g, g
 
 
-VOICE_CASES = ["rs_bank_40", "rs_bank_21_b64_i16_pure", "voice_fx_steady", "voice_fx_events_45", "voice_fx_events_20_i16_r32", "steady_96x32", "steady_40x4_i16", "steady_9x3_u16", "events_70", "events_33_r2", "steady_fmt_p_i16_mono3",
+VOICE_CASES = ["rs_bank_40", "rs_bank_21_b64_i16_pure", "voice_fx_steady", "voice_fx_events_45", "voice_fx_events_20_i16_r32", "steady_96x32", "steady_40x4_i16", "steady_9x3_u16", "events_70", "events_33_r2", "storm_48x6", "storm_200x50_b64", "steady_fmt_p_i16_mono3",
                "steady_fmt_i_f32", "steady_fmt_i_u16", "steady_fmt_p_i16_oddlen", "steady_fmt_mixed_leaf", "events_33_i16"]
 
 

@@ -44,6 +44,10 @@ CASES = {
                                                                    fmt=fwapi.INTERLEAVED_I16),
     "events_70": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=256), 70),
     "events_33_r2": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=128), 33, radix=2, src_frames=777),
+    # 300 and 10 000 messages inside one call (the control kernel's wave-wide message search: one round / 64-ary rounds)
+    "storm_48x6": lambda: scenarios.scenario_message_storm(oracle(max_block_frames=128)),
+    "storm_200x50_b64": lambda: scenarios.scenario_message_storm(oracle(max_block_frames=64), 200, radix=32, blocks=60, per_voice=50,
+                                                                 src_frames=3000, seed=4),
     # width / hard-clip stages at the end of the voice chains (the voice-bank plan's stage programs)
     "voice_fx_steady": lambda: scenarios.scenario_voice_bank_steady(oracle(max_block_frames=256), 70, 6, src_frames=1500,
                                                                      voice_fx=scenarios.width_clip_fx),

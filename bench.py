@@ -50,7 +50,7 @@ DEFAULTS = {
     "cfg5": (8192, 1024, 64, 65536, 60),
 }
 # node kinds of include/fwgpu.h (both engines take raw kinds)
-K_BEEP, K_VOLUME, K_SUM, K_SAMPLER, K_HARD_CLIP, K_PAN, K_WIDTH, K_BIQUAD, K_DELAY, K_FIR, K_RESAMPLER = 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13
+K_BEEP, K_VOLUME, K_SUM, K_SAMPLER, K_HARD_CLIP, K_PAN, K_WIDTH, K_BIQUAD, K_DELAY, K_FIR, K_RESAMPLER, K_SPATIAL = 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, 14
 PLANAR_F32, INTERLEAVED_I16 = 5, 0
 
 
@@ -223,7 +223,9 @@ def build_graph(e, wl, voices, radix, seed, master, ir_sample=None, voice_fx=Fal
         return graph_reverb(e, voices, radix, ir_sample)
     if wl == "cfg3":
         return graph_chain(e, voices, radix, seed, master)
-    extra = ((K_WIDTH, [1.3]), (K_HARD_CLIP, [-3.0])) if voice_fx else ()
+    extra = ((K_WIDTH, [1.3]), (K_HARD_CLIP, [-3.0])) if voice_fx is True else ()
+    if voice_fx == "spatial":  # a SPEC 3D spatialiser at the end of every voice (2 -> 2: mono sum, ITD, distance + pan gains)
+        extra = ((K_SPATIAL, [2.0, 0.5, -3.0]),)
     return graph_bank(e, voices, radix, seed, master, extra, rs_samples)
 
 
@@ -242,13 +244,13 @@ def make_gpu(fa, wl, V, B, K, radix, src, F, sfmt, seed, args, stream, device):
     fmt = PLANAR_F32 if sfmt == "f32" else INTERLEAVED_I16
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
     ids = [cx.new_sample_device(fmt, 2, F, src[v].data_ptr()) for v in range(V)] if rs else None
-    samplers, volumes = build_graph(g, wl, V, radix, seed, args.master, ir, args.voice_fx, ids)
+    samplers, volumes = build_graph(g, wl, V, radix, seed, args.master, ir, "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
     if not rs:
         for v, s in enumerate(samplers):
             smp = cx.new_sample_device(fmt, 2, F, src[v].data_ptr())
             g.start(s, smp)
-    assert cx.plan_kind() == want_plan(wl, args.force_generic), "expected launch plan %d, got %d" % (
-        want_plan(wl, args.force_generic), cx.plan_kind())
+    generic = args.force_generic or getattr(args, "voice_spatial", False)  # (a spatialiser voice is not a fused shape)
+    assert cx.plan_kind() == want_plan(wl, generic), "expected launch plan %d, got %d" % (want_plan(wl, generic), cx.plan_kind())
     return cx, g, samplers, volumes
 
 
@@ -258,7 +260,7 @@ def make_oracle(wl, V, B, radix, seed, args, host_src, fmt=PLANAR_F32):
     ir = o.e.new_sample(PLANAR_F32, 2, reverb_ir(args.taps)) if wl == "cfg4" else None
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
     ids = [o.e.new_sample(fmt, 2, host_src[v]) for v in range(V)] if rs else None
-    samplers, volumes = build_graph(o, wl, V, radix, seed, args.master, ir, args.voice_fx, ids)
+    samplers, volumes = build_graph(o, wl, V, radix, seed, args.master, ir, "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
     if not rs:
         for v, s in enumerate(samplers):
             o.start(s, o.e.new_sample(fmt, 2, host_src[v]))
@@ -360,6 +362,8 @@ def parity_check(fa, torch, wl, V, B, K, radix, seed, args, src, F, sfmt, stream
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
     if rs:
         blocks = [0, 1]  # a resampled voice's block does not start on a source-block boundary: prefix only, whole samples
+    elif getattr(args, "voice_spatial", False):
+        blocks = [0, 1, 2, 3][:K]  # a spatialiser carries 64 frames of history from block to block: a contiguous prefix
     elif wl in ("cfg2", "cfg5") and K >= 4 and F >= K * B and sfmt == "f32":
         blocks = [0, 1, K // 2, K - 1]
     elif wl == "cfg4":
@@ -613,7 +617,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
             ach = alg_bytes / avg_s / 1e9
             # (PMC passes ran on f32 sources; a profile is quoted for the workload it was collected on: plain / --voice-fx / --rs-source)
             prof_name = wl + ("_voicefx" if args.voice_fx else "") + ("_rs" if getattr(args, "rs_source", False) else "")
-            plain = not (args.master or variant != "A" or args.force_generic)
+            plain = not (args.master or variant != "A" or args.force_generic or getattr(args, "voice_spatial", False))
             traffic, traffic_src = pmc_traffic(kernel, V, B, K, prof_name) if sfmt == "f32" and plain else (None, None)
             roofline = {
                 "bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -761,6 +765,8 @@ def main():
     ap.add_argument("--master", action="store_true",
                     help="put a master VolumeNode + HardClipNode between the root SumNode and graph_out (the fused plans "
                          "then run that chain with the generic node kernel on the mix bus)")
+    ap.add_argument("--voice-spatial", action="store_true",
+                    help="cfg2/cfg5: a SPEC 3D spatialiser node at the end of every voice (not a fused shape: generic executor)")
     ap.add_argument("--voice-fx", action="store_true",
                     help="cfg2/cfg5: a StereoWidthNode + HardClipNode at the end of every voice chain")
     ap.add_argument("--rs-source", action="store_true",
@@ -787,7 +793,7 @@ def main():
     steps = args.steps or dS
     wl = args.workload
     default_shape = (wl == "cfg2" and (V, B, K, F) == (dV, dB, dK, dF) and args.source_format == "f32" and args.variant == "A" and
-                     not (args.master or args.voice_fx or args.rs_source or args.force_generic or args.host_buffers))
+                     not (args.master or args.voice_fx or args.voice_spatial or args.rs_source or args.force_generic or args.host_buffers))
 
     # stdout carries exactly ONE line (the JSON, rank 0): everything else that writes to fd 1 — RCCL's version banner
     # and warnings come from C stdio, flushed whenever — is sent to stderr for the life of the process

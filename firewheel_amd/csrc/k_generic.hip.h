@@ -482,7 +482,17 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
         case K_SPATIAL: if constexpr (SET == 1 || SET == 3) {  // SPEC: distance gain + equal-power pan + per-ear integer delay
             float* hist = v.ext + s.ext_off;
             const int dl = s.playing, dr = s.has_loop;
-            const float hreg = hist[lane];  // lane l keeps hist[l] (SP_HIST == 64), hist[63] = newest
+            // lane l keeps hist[l] (SP_HIST == 64), hist[63] = newest.  A frozen spatialiser (k_frozen_scan: gains at rest, no
+            // message in the batch, frames >= SP_HIST) runs its K blocks in parallel: the history of block b > 0 IS the tail of
+            // block b-1's input, which the level above has already written for every block of the batch
+            float hreg;
+            if (frozen_sampler && blk > 0) {
+                const int jp = frames - SP_HIST + lane;
+                const float* q0 = io.in(0) - v.pool_blk_stride;
+                hreg = nd.n_in >= 2 ? (q0[jp] + (io.in(1) - v.pool_blk_stride)[jp]) * 0.5f : q0[jp];
+            } else {
+                hreg = hist[lane];
+            }
             GainRun rl = smoother_begin(s.s0, s.p0, frames);
             GainRun rr = smoother_begin(s.s1, s.p1, frames);
             const bool two = nd.n_in >= 2;
@@ -510,10 +520,12 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             }
             if (rl.ramp) s.s0.last = rl.prev;
             if (rr.ramp) s.s1.last = rr.prev;
-            // new history = the last SP_HIST samples of (hist ++ m[0..frames))
-            const int j = frames - SP_HIST + lane;
-            const float keep = __shfl(hreg, (SP_HIST + j) & 63);
-            hist[lane] = j >= 0 ? mono(j) : keep;
+            // new history = the last SP_HIST samples of (hist ++ m[0..frames))  (frozen: spatial_finish, once per batch)
+            if (!frozen_sampler) {
+                const int j = frames - SP_HIST + lane;
+                const float keep = __shfl(hreg, (SP_HIST + j) & 63);
+                hist[lane] = j >= 0 ? mono(j) : keep;
+            }
             break;
         }
 
@@ -540,8 +552,9 @@ __global__ void k_frozen_scan(DevView v, int n_nodes, uint32_t cmd_block0, uint3
     if (i >= n_nodes) return;
     const NodeDesc nd = v.nodes[i];
     bool fz = false, adv = false;
+    bool spat = false;
     if (!nd.is_graph_io && (nd.kind == K_VOLUME || nd.kind == K_PAN || nd.kind == K_WIDTH || nd.kind == K_HARD_CLIP ||
-                            nd.kind == K_SAMPLER)) {
+                            nd.kind == K_SAMPLER || nd.kind == K_SPATIAL)) {
         bool has_cmd = false;
         if (v.n_cmds) {
             const int c = chain_cmd_lower_bound(v.cmds, v.n_cmds, nd.state, cmd_block0);
@@ -567,6 +580,9 @@ __global__ void k_frozen_scan(DevView v, int n_nodes, uint32_t cmd_block0, uint3
                     }
                     break;
                 case K_HARD_CLIP: fz = true; break;
+                // SPEC spatialiser: with both gains at rest all that moves is the 64-frame mono history, and that is the
+                // tail of the previous block's input (needs a block of at least SP_HIST frames)
+                case K_SPATIAL: spat = fz = v.frames >= SP_HIST && smoother_at_rest(s.s0, s.p0) && smoother_at_rest(s.s1, s.p1); break;
                 // volume.rs:104: a gain below 1e-5 is a mute only while the smoother is Inactive — keep such a node
                 // on the serial path while it is Deactivating (the status matters there)
                 case K_VOLUME: fz = smoother_at_rest(s.s0, s.p0) && (s.s0.status == SM_INACTIVE || !(s.s0.input < 0.00001f)); break;
@@ -575,8 +591,20 @@ __global__ void k_frozen_scan(DevView v, int n_nodes, uint32_t cmd_block0, uint3
             }
         }
     }
-    frozen[i] = fz ? (adv ? 2 : 1) : 0;  // 2: a playing sampler — the last block's wave stores the state
+    frozen[i] = fz ? (adv ? 2 : (spat ? 3 : 1)) : 0;  // 2: a playing sampler — the last block's wave stores the state; 3: a spatialiser
     if (adv) playhead_snap[i] = v.states[nd.state].playhead;
+}
+// block-0 wave of a frozen spatialiser, after its own blocks (it alone reads the stored history): the history the batch
+// leaves behind is the tail of the LAST block's input
+__device__ void spatial_finish(const DevView& v, int node_idx, uint32_t K) {
+    const NodeDesc nd = v.nodes[node_idx];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const float* pool = v.pool + (size_t)(K - 1) * v.pool_blk_stride;
+    const int* in_buf = v.in_buf + nd.in_off;
+    const int j = v.frames - SP_HIST + lane;
+    const float m0 = pool[(size_t)in_buf[0] * v.stride + j];
+    const float m = nd.n_in >= 2 ? (m0 + pool[(size_t)in_buf[1] * v.stride + j]) * 0.5f : m0;
+    (v.ext + v.states[nd.state].ext_off)[lane] = m;
 }
 // block-0 wave of a frozen node: if some block of the batch had every input silent, its smoothers were reset
 __device__ void frozen_finish(const DevView& v, int node_idx, uint32_t K) {
@@ -622,9 +650,14 @@ __global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __res
         const uint8_t fz = v.frozen ? v.frozen[node] : (uint8_t)0;
         if (fz) {
             const bool adv = fz == 2;  // playing sampler: per-block playhead in closed form, the last block stores the state
+            const bool spat = fz == 3;
             for (uint32_t b = b0; b < b1; ++b)
-                node_process_wave<SET>(v, node, b, cmd_block0 + b, adv && b + 1 == K, adv ? b : 0u, adv);
-            if (!adv && b0 == 0) frozen_finish(v, node, K);
+                node_process_wave<SET>(v, node, b, cmd_block0 + b, adv && b + 1 == K, adv ? b : 0u, adv || spat);
+            if (spat) {
+                if (b0 == 0) spatial_finish(v, node, K);
+            } else if (!adv && b0 == 0) {
+                frozen_finish(v, node, K);
+            }
             return;
         }
         if (blockIdx.y != 0) return;

@@ -684,6 +684,39 @@ def scenario_spatial_scene(e, n_sources=7, blocks=12, src_frames=2500):
     return np.concatenate([out1, out2])
 
 
+def scenario_spatial_steady(e, n_sources=9, src_frames=4000, calls=(8, 70, 20, 20, 5)):
+    """sampler -> spatialiser voices that sit still for whole calls (the generic executor runs a resting spatialiser's blocks in
+    parallel: the ITD history of block b is the tail of block b-1's input), moved once between the first two calls so that the
+    gain glides start, settle inside the long call and the following calls are at rest again; one source is mono, one is
+    paused and resumed (an all-zero history)."""
+    rng = np.random.default_rng(77)
+    m = e.sum(n_sources)
+    nodes = []
+    for v in range(n_sources):
+        ch = 1 if v == 3 else 2
+        s = e.sampler(100.0)
+        sp = e.spatial(float(rng.uniform(-5, 5)), float(rng.uniform(-1, 1)), float(rng.uniform(-5, 5)), n_in=2)
+        e.connect_stereo(s, sp)
+        e.connect_stereo(sp, m, 2 * v)
+        nodes.append((s, sp, ch))
+    e.connect_stereo(m, e.graph_out_node)
+    e.update()
+    for v, (s, sp, ch) in enumerate(nodes):
+        smp = e.new_sample(PLANAR_F32, ch, voice_source(8100 + v, src_frames + 37 * v, ch))
+        e.sampler_set_sample(s, smp)
+        e.sampler_set_loop_range(s, LOOP_FULL)
+        e.sampler_play(s)
+    outs = [e.process_blocks(calls[0])]
+    e.set_param(nodes[0][1], 0, 4.0)
+    e.set_param(nodes[1][1], 2, -0.3, at_block=2)
+    e.sampler_pause(nodes[2][0], at_block=5)
+    outs.append(e.process_blocks(calls[1]))
+    e.sampler_play(nodes[2][0], at_block=3)
+    for n in calls[2:]:
+        outs.append(e.process_blocks(n))
+    return np.concatenate(outs)
+
+
 def reverb_ir(seed, taps, channels=2, decay=None):
     """exponentially decaying seeded noise, L1-normalised per channel."""
     decay = decay or taps / 4.0

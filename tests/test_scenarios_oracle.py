@@ -45,6 +45,8 @@ CASES = {
     "events_70": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=256), 70),
     "events_33_r2": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=128), 33, radix=2, src_frames=777),
     # 300 and 10 000 messages inside one call (the control kernel's wave-wide message search: one round / 64-ary rounds)
+    "spatial_steady_b128": lambda: scenarios.scenario_spatial_steady(oracle(max_block_frames=128)),
+    "spatial_steady_b64": lambda: scenarios.scenario_spatial_steady(oracle(max_block_frames=64), 5, src_frames=1500, calls=(3, 90, 33, 7)),
     "storm_48x6": lambda: scenarios.scenario_message_storm(oracle(max_block_frames=128)),
     "storm_200x50_b64": lambda: scenarios.scenario_message_storm(oracle(max_block_frames=64), 200, radix=32, blocks=60, per_voice=50,
                                                                  src_frames=3000, seed=4),

@@ -123,6 +123,7 @@ class OracleSide(object):
 # ------------------------------------------------------------------------------------------------ the graphs
 def sum_tree(e, ends, radix, master=False):
     level = ends
+    first_level = None
     while True:
         nxt = []
         for i in range(0, len(level), radix):
@@ -132,10 +133,29 @@ def sum_tree(e, ends, radix, master=False):
                 e.connect_stereo(n, m, 2 * p)
             nxt.append(m)
         level = nxt
+        first_level = first_level or nxt
         if len(level) == 1:
             break
     cur = level[0]
-    if master:  # --master: a master volume + limiter between the root SumNode and graph_out
+    if master == "send":  # --send: every fourth leaf bus is ALSO tapped into a send bus -> return gain -> width -> limiter that
+        # joins the root in a two-port sum: buses consumed twice — no fused shape as a whole, the voice banks inside still
+        # are (hybrid plan).  (No IIR on the return: a bus biquad / delay is one serial recurrence over the 4.1 s of a
+        # 768-block call — ~2 ms on one lane whatever surrounds it, DESIGN.md §3.2 — and would be all this line measures.)
+        taps = first_level[::4]
+        send = e.add(K_SUM, 2 * len(taps), 2)
+        for p, n in enumerate(taps):
+            e.connect_stereo(n, send, 2 * p)
+        ret = e.add(K_VOLUME, 2, 2, [45.0])
+        wid = e.add(K_WIDTH, 2, 2, [1.4])
+        lim = e.add(K_HARD_CLIP, 2, 2, [-1.0])
+        e.connect_stereo(send, ret)
+        e.connect_stereo(ret, wid)
+        e.connect_stereo(wid, lim)
+        mix = e.add(K_SUM, 4, 2)
+        e.connect_stereo(cur, mix, 0)
+        e.connect_stereo(lim, mix, 2)
+        cur = mix
+    elif master:  # --master: a master volume + limiter between the root SumNode and graph_out
         for kind, params in ((K_VOLUME, [70.0]), (K_HARD_CLIP, [-1.0])):
             m = e.add(kind, 2, 2, params)
             e.connect_stereo(cur, m)
@@ -244,13 +264,15 @@ def make_gpu(fa, wl, V, B, K, radix, src, F, sfmt, seed, args, stream, device):
     fmt = PLANAR_F32 if sfmt == "f32" else INTERLEAVED_I16
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
     ids = [cx.new_sample_device(fmt, 2, F, src[v].data_ptr()) for v in range(V)] if rs else None
-    samplers, volumes = build_graph(g, wl, V, radix, seed, args.master, ir, "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
+    samplers, volumes = build_graph(g, wl, V, radix, seed, "send" if getattr(args, "send", False) else args.master, ir,
+                                    "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
     if not rs:
         for v, s in enumerate(samplers):
             smp = cx.new_sample_device(fmt, 2, F, src[v].data_ptr())
             g.start(s, smp)
     generic = args.force_generic or getattr(args, "voice_spatial", False)  # (a spatialiser voice is not a fused shape)
-    assert cx.plan_kind() == want_plan(wl, generic), "expected launch plan %d, got %d" % (want_plan(wl, generic), cx.plan_kind())
+    want = 3 if (getattr(args, "send", False) and not generic and wl in ("cfg2", "cfg5")) else want_plan(wl, generic)
+    assert cx.plan_kind() == want, "expected launch plan %d, got %d" % (want, cx.plan_kind())
     return cx, g, samplers, volumes
 
 
@@ -260,7 +282,8 @@ def make_oracle(wl, V, B, radix, seed, args, host_src, fmt=PLANAR_F32):
     ir = o.e.new_sample(PLANAR_F32, 2, reverb_ir(args.taps)) if wl == "cfg4" else None
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
     ids = [o.e.new_sample(fmt, 2, host_src[v]) for v in range(V)] if rs else None
-    samplers, volumes = build_graph(o, wl, V, radix, seed, args.master, ir, "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
+    samplers, volumes = build_graph(o, wl, V, radix, seed, "send" if getattr(args, "send", False) else args.master, ir,
+                                    "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
     if not rs:
         for v, s in enumerate(samplers):
             o.start(s, o.e.new_sample(fmt, 2, host_src[v]))
@@ -617,7 +640,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
             ach = alg_bytes / avg_s / 1e9
             # (PMC passes ran on f32 sources; a profile is quoted for the workload it was collected on: plain / --voice-fx / --rs-source)
             prof_name = wl + ("_voicefx" if args.voice_fx else "") + ("_rs" if getattr(args, "rs_source", False) else "")
-            plain = not (args.master or variant != "A" or args.force_generic or getattr(args, "voice_spatial", False))
+            plain = not (args.master or variant != "A" or args.force_generic or getattr(args, "voice_spatial", False) or getattr(args, "send", False))
             traffic, traffic_src = pmc_traffic(kernel, V, B, K, prof_name) if sfmt == "f32" and plain else (None, None)
             roofline = {
                 "bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -765,6 +788,9 @@ def main():
     ap.add_argument("--master", action="store_true",
                     help="put a master VolumeNode + HardClipNode between the root SumNode and graph_out (the fused plans "
                          "then run that chain with the generic node kernel on the mix bus)")
+    ap.add_argument("--send", action="store_true",
+                    help="cfg2/cfg5: every fourth leaf bus also feeds a send -> gain -> width -> limiter return mixed with the root "
+                         "(buses consumed twice: the hybrid plan — voice banks on the voice-bank kernels, the rest on the level executor)")
     ap.add_argument("--voice-spatial", action="store_true",
                     help="cfg2/cfg5: a SPEC 3D spatialiser node at the end of every voice (not a fused shape: generic executor)")
     ap.add_argument("--voice-fx", action="store_true",
@@ -793,7 +819,7 @@ def main():
     steps = args.steps or dS
     wl = args.workload
     default_shape = (wl == "cfg2" and (V, B, K, F) == (dV, dB, dK, dF) and args.source_format == "f32" and args.variant == "A" and
-                     not (args.master or args.voice_fx or args.voice_spatial or args.rs_source or args.force_generic or args.host_buffers))
+                     not (args.master or args.voice_fx or args.voice_spatial or args.send or args.rs_source or args.force_generic or args.host_buffers))
 
     # stdout carries exactly ONE line (the JSON, rank 0): everything else that writes to fd 1 — RCCL's version banner
     # and warnings come from C stdio, flushed whenever — is sent to stderr for the life of the process

@@ -218,7 +218,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     for (SampleRec& s : c->samples)
         if (s.alive && s.owned && s.d_data) (void)hipFree(s.d_data);
     DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
-                      &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_blks2, &c->d_refs2, &c->d_gsets2, &c->d_ramps2, &c->d_rt_sync, &c->d_progs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
+                      &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_blks2, &c->d_refs2, &c->d_gsets2, &c->d_ramps2, &c->d_rt_sync, &c->d_hlevel_nodes, &c->d_progs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
                       &c->d_bus, &c->d_bus_flags, &c->d_chain_start, &c->d_chain_dummy, &c->d_chain_stats, &c->d_groups, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
                       &c->d_root_bufs, &c->d_tail_nodes, &c->d_tail_in, &c->d_tail_out, &c->d_tail_idx, &c->d_tail_frozen, &c->d_frozen, &c->d_frozen_ph, &c->d_fir_rows, &c->d_fir_tiles, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask, &c->d_trace, &c->d_rs_table};
@@ -397,7 +397,11 @@ int fwgpu_schedule_upload(fwgpu_ctx* c, const fwgpu_sched_node* sn, uint32_t n_n
     return install_plan(c, plan);
 }
 
-int fwgpu_plan_kind(fwgpu_ctx* c) { return c && c->have_plan ? (c->fused && !c->force_generic ? (c->fused_fx ? 2 : 1) : 0) : -1; }
+int fwgpu_plan_kind(fwgpu_ctx* c) {
+    if (!c || !c->have_plan) return -1;
+    if (c->force_generic) return 0;
+    return c->fused ? (c->fused_fx ? 2 : 1) : (c->hybrid ? 3 : 0);
+}
 int fwgpu_plan_num_levels(fwgpu_ctx* c) { return c && c->have_plan ? c->plan.num_levels : -1; }
 int fwgpu_plan_node_level(fwgpu_ctx* c, int64_t node) {
     NEED_CTX(c, FWGPU_ERR_INVALID);

@@ -236,6 +236,11 @@ struct fwgpu_ctx {
     bool rt_last_batch = false;  // the fused batch being launched ends the call
     bool rt_one_launch = true;  // one-block calls on the voice-bank plan: control + leaf + root in ONE kernel (FWGPU_RT_ONE_LAUNCH=0: off)
     DevBuf d_rt_sync;           // its workgroup counter
+    // hybrid plan (kind 3): voice-bank groups inside a graph the level executor runs — the level lists without the nodes
+    // the fused kernels render
+    bool hybrid = false;
+    DevBuf d_hlevel_nodes;
+    std::vector<int> hlevel_off, hlevel_cnt, hlevel_kinds;
     bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2
     DevBuf d_rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS]
 
@@ -308,8 +313,13 @@ struct FusedBuild {
     bool has_rs = false;          // a resampler-sourced voice somewhere
     bool has_fx = false;  // some chain holds a biquad / delay: the k_chain plan
     uint64_t min_delay = ~0ull;  // shortest delay line among the chains (frames)
+    std::vector<int> covered;    // hybrid plan: plan indices of the nodes the fused kernels render (voice chains + their SumNode)
 };
 bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedBuild& fb);
+// The hybrid plan (kind 3): the graph as a whole is not a fused shape, but it holds voice banks that are — SumNodes whose
+// every port is a dry voice chain.  Those groups are rendered by the voice-bank kernels straight into the SumNode's pool
+// buffers; everything else runs on the level executor, which finds the groups' outputs where it expects them.
+bool detect_hybrid(const Plan& plan, FusedBuild& fb);
 
 // ---- fwgpu_plan_install.cpp
 int install_plan(fwgpu_ctx* c, Plan& plan);

@@ -248,4 +248,112 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
     return !fb.voices.empty();
 }
 
+// ---------------------------------------------------------------- hybrid plan detection
+bool detect_hybrid(const Plan& plan, FusedBuild& fb) {
+    const int N = (int)plan.nodes.size();
+    std::vector<std::vector<int>> cons(N);
+    for (int i = 0; i < N; ++i) cons[i].assign(plan.nodes[i].n_out, 0);
+    for (const PlanNode& n : plan.nodes)
+        for (int p = 0; p < n.n_in; ++p)
+            if (n.in_src_node[p] >= 0) cons[n.in_src_node[p]][n.in_src_port[p]]++;
+    auto stereo_src = [&](const PlanNode& n, int port0, int& src) -> bool {  // both channels from ONE node, consumed once each
+        int a = n.in_src_node[port0], b = n.in_src_node[port0 + 1];
+        if (a < 0 || a != b) return false;
+        if (n.in_src_port[port0] != 0 || n.in_src_port[port0 + 1] != 1) return false;
+        if (plan.nodes[a].n_out != 2 || cons[a][0] != 1 || cons[a][1] != 1) return false;
+        src = a;
+        return true;
+    };
+    std::vector<char> covered(N, 0);
+    int real_voices = 0;
+    for (int si = 0; si < N; ++si) {
+        const PlanNode& s = plan.nodes[si];
+        if (s.kind != K_SUM || s.is_graph_io || s.n_out != 2 || s.n_in < 2 || s.n_in % 2 || s.n_in > 64) continue;
+        if (s.out_buf[1] != s.out_buf[0] + 1) continue;  // the leaf kernel writes channel 1 in the row behind channel 0
+        // every port a dry voice chain (or nothing): sampler | resampler -> up to 5 of volume / pan / width / hard clip
+        std::vector<VoiceDesc> voices;
+        std::vector<uint32_t> progs;
+        std::vector<int> nodes{si};
+        bool ok = true, prog = false, rs = false;
+        int stages = 0, real = 0;
+        for (int p = 0; ok && p < s.n_in / 2; ++p) {
+            VoiceDesc vd;
+            memset(&vd, 0, sizeof(vd));
+            vd.sampler_state = vd.bq_state = vd.dl_state = -1;
+            if (s.in_src_node[2 * p] < 0 && s.in_src_node[2 * p + 1] < 0) {  // an empty voice slot: a null voice
+                voices.push_back(vd);
+                progs.push_back(0u);
+                continue;
+            }
+            int cur;
+            if (!stereo_src(s, 2 * p, cur)) {
+                ok = false;
+                break;
+            }
+            std::vector<int> chain;
+            for (;;) {
+                const PlanNode& n = plan.nodes[cur];
+                if (covered[cur] || n.is_graph_io) {
+                    ok = false;
+                    break;
+                }
+                if (n.kind == K_SAMPLER || n.kind == K_RESAMPLER) {
+                    ok = n.n_in == 0 && n.n_out == 2;
+                    break;
+                }
+                if (n.n_in != 2 || n.n_out != 2 || !(n.kind == K_VOLUME || n.kind == K_PAN || n.kind == K_WIDTH || n.kind == K_HARD_CLIP) ||
+                    (int)chain.size() >= FW_MAX_STAGES - 1) {
+                    ok = false;
+                    break;
+                }
+                chain.push_back(cur);
+                int src;
+                if (!stereo_src(n, 0, src)) {
+                    ok = false;
+                    break;
+                }
+                cur = src;
+            }
+            if (!ok) break;
+            vd.sampler_state = (int)plan.nodes[cur].slot;
+            vd.src_kind = plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0;
+            rs = rs || vd.src_kind == 1;
+            vd.n_stages = (int)chain.size();
+            uint32_t pr = 0;
+            for (int j = 0; j < vd.n_stages; ++j) {  // schedule order: nearest the source first
+                const PlanNode& n = plan.nodes[chain[chain.size() - 1 - j]];
+                vd.stage_kind[j] = n.kind;
+                vd.stage_state[j] = (int)n.slot;
+                pr |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : SK_GAIN) << (4 * j);
+                prog = prog || n.kind == K_WIDTH || n.kind == K_HARD_CLIP;
+            }
+            stages = std::max(stages, vd.n_stages);
+            nodes.push_back(cur);
+            nodes.insert(nodes.end(), chain.begin(), chain.end());
+            voices.push_back(vd);
+            progs.push_back(pr);
+            real++;
+        }
+        if (!ok || real == 0) continue;
+        LeafDesc ld;
+        ld.first_voice = (int)fb.voices.size();
+        ld.ports = s.n_in / 2;
+        ld.out_buf = s.out_buf[0];
+        ld.pad = 0;
+        fb.leaves.push_back(ld);
+        fb.voices.insert(fb.voices.end(), voices.begin(), voices.end());
+        fb.progs.insert(fb.progs.end(), progs.begin(), progs.end());
+        fb.has_prog = fb.has_prog || prog || rs;
+        fb.has_rs = fb.has_rs || rs;
+        fb.max_stages = std::max(fb.max_stages, stages);
+        real_voices += real;
+        for (int i : nodes) {
+            covered[i] = 1;
+            fb.covered.push_back(i);
+        }
+    }
+    // a handful of voices is not worth two more launches per batch
+    return real_voices >= 8;
+}
+
 }  // namespace fwgpu

@@ -317,6 +317,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
 
     // 5. fused voice-bank plan
     c->fused = false;
+    c->hybrid = false;
     FusedBuild fb;
     c->fused_fx = false;
     if (!c->force_generic && detect_fused(plan, c->graph, c->mbf, fb)) {
@@ -444,6 +445,57 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         if ((rc = upload(c, c->d_root_bufs, fb.root_buf, sizeof(fb.root_buf)))) return rc;
         c->fused = true;
     }
+    // 5b. hybrid plan: not a fused shape as a whole, but with voice banks inside that are
+    if (!c->fused && !c->force_generic) {
+        FusedBuild hb;
+        if (detect_hybrid(plan, hb)) {
+            c->n_voices = (int)hb.voices.size();
+            c->n_leaves = (int)hb.leaves.size();
+            c->ramp_slots = 2 * (1 + hb.max_stages);
+            c->fused_prog = hb.has_prog;
+            c->fused_rs = hb.has_rs;
+            c->n_groups = 0;
+            c->n_tail = 0;
+            c->up_root_node = -1;
+            c->up_level_off.clear();
+            c->up_level_cnt.clear();
+            if ((rc = upload(c, c->d_voices, hb.voices.data(), hb.voices.size() * sizeof(VoiceDesc)))) return rc;
+            if ((rc = upload(c, c->d_leaves, hb.leaves.data(), hb.leaves.size() * sizeof(LeafDesc)))) return rc;
+            if ((rc = upload(c, c->d_progs, hb.progs.data(), hb.progs.size() * sizeof(uint32_t)))) return rc;
+            const size_t K = c->kmax;
+            HIPC(c, c->d_blks.ensure(K * c->n_voices * sizeof(VoiceBlk)));
+            HIPC(c, c->d_refs.ensure(ref_count(c->n_voices, K) * sizeof(VoiceRef)));
+            HIPC(c, c->d_gsets.ensure((size_t)c->n_voices * FW_GSETS * sizeof(GainSet)));
+            HIPC(c, c->d_chain_start.ensure((size_t)c->n_voices * sizeof(ChainStart)));
+            HIPC(c, hipMemset(c->d_chain_start.p, 0, (size_t)c->n_voices * sizeof(ChainStart)));
+            HIPC(c, c->d_cache.ensure((size_t)c->n_voices * sizeof(VoiceCache)));
+            HIPC(c, hipMemset(c->d_cache.p, 0, (size_t)c->n_voices * sizeof(VoiceCache)));
+            c->epoch++;
+            HIPC(c, c->d_ramps.ensure(K * c->n_voices * (size_t)c->ramp_slots * c->stride * sizeof(float)));
+            // the level lists without the nodes the voice-bank kernels render
+            std::vector<char> cov(N, 0);
+            for (int i : hb.covered) cov[i] = 1;
+            std::vector<int> hflat;
+            c->hlevel_off.clear();
+            c->hlevel_cnt.clear();
+            c->hlevel_kinds.clear();
+            for (auto& l : levels) {
+                c->hlevel_off.push_back((int)hflat.size());
+                int kinds = 0, cnt = 0;
+                for (int i : l)
+                    if (!cov[i]) {
+                        hflat.push_back(i);
+                        kinds |= 1 << host_kind_set(nd[i].kind);
+                        cnt++;
+                    }
+                c->hlevel_cnt.push_back(cnt);
+                c->hlevel_kinds.push_back(kinds);
+            }
+            if (hflat.empty()) hflat.push_back(0);
+            if ((rc = upload(c, c->d_hlevel_nodes, hflat.data(), hflat.size() * sizeof(int)))) return rc;
+            c->hybrid = true;
+        }
+    }
     // k_frozen_scan's verdict tables (generic executor, K > 1): sized here, on the control thread — a process call never
     // allocates
     HIPC(c, c->d_frozen.ensure(plan.nodes.size()));
@@ -465,6 +517,7 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
     if (rc != 0 && touched) {
         c->have_plan = false;
         c->fused = false;
+        c->hybrid = false;
         c->graph.needs_compile = true;
         c->epoch++;
     }

@@ -232,59 +232,8 @@ DevView generic_view(fwgpu_ctx* c, int frames) {
     return v;
 }
 
-// K blocks of `frames` frames through the level-batched executor (schedule.rs:289-344 as one launch per level for
-// all K blocks: each block has its own pool slice, a stateful node walks its K blocks in order inside one wave)
-int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const float* d_in, int n_in_ch, float* d_out,
-                      int n_out_ch) {
-    DevView v = generic_view(c, frames);
-    // which gain-like stateful nodes cannot change during this batch (their blocks then run in parallel): decided once,
-    // before the first level
-    if (K > 1 && c->d_frozen.ensure((size_t)c->plan.nodes.size()) == hipSuccess &&
-        c->d_frozen_ph.ensure((size_t)c->plan.nodes.size() * sizeof(unsigned long long)) == hipSuccess) {
-        LCHK(c, launch_frozen_scan(c->stream, v, (int)c->plan.nodes.size(), cmd_block, K, c->d_frozen.as<uint8_t>(),
-                                   c->d_frozen_ph.as<unsigned long long>()));
-        v.frozen = c->d_frozen.as<uint8_t>();
-        v.frozen_playhead = c->d_frozen_ph.as<unsigned long long>();
-    }
-    if (c->n_gin_bufs > 0)
-        LCHK(c, launch_graph_in(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride,
-                                c->d_gin_bufs.as<int>(), c->n_gin_bufs, d_in, d_in ? n_in_ch : 0, frames, K));
-    c->epoch++;  // node state moves outside the fused control kernel: cached steady descriptors are stale
-    hipEvent_t e0, e1;
-    timer_begin(c, 3, &e0, &e1);
-    for (size_t l = 0; l < c->level_cnt.size(); ++l) {
-        LCHK(c, launch_level(c->stream, v, c->d_level_nodes.as<int>() + c->level_off[l], c->level_cnt[l], K, cmd_block,
-                             c->level_kinds[l]));
-        for (const fwgpu_ctx::FirGroup& g : c->fir_groups)
-            if (g.level == (int)l) {
-                hipEvent_t g0 = nullptr, g1 = nullptr;
-                if (c->timing) {  // the GEMM alone, on its own event pair (no record of its own: launch_fir does it)
-                    TimerCat& t = c->timers[4];
-                    if (t.used == t.ev.size() && t.ev.size() < 8192) {
-                        hipEvent_t a, b;
-                        if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) t.ev.emplace_back(a, b);
-                    }
-                    if (t.used < t.ev.size()) {
-                        g0 = t.ev[t.used].first;
-                        g1 = t.ev[t.used].second;
-                        t.used++;
-                        t.launches++;
-                    }
-                }
-                LCHK(c, launch_fir(c->stream, v, c->d_fir_rows.as<FirRow>() + g.row_off, g.n_rows,
-                                   c->d_fir_tiles.as<uint32_t>() + g.tile_off, g.T, c->d_fir_partials.as<float>(),
-                                   c->d_fir_partials.cap / sizeof(float), K, g0, g1));
-            }
-    }
-    timer_end(c, e1);
-    LCHK(c, launch_graph_out(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride,
-                             c->d_gout_bufs.as<int>(), c->n_gout_bufs, d_out, n_out_ch, frames, K));
-    return 0;
-}
-
-// K full blocks through the fused voice-bank plan
-int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int n_out_ch) {
-    FusedView fv;
+// what the voice-bank kernels see (the buses are the fused plan's; the hybrid plan points them at the pool)
+static void fill_fused_view(fwgpu_ctx* c, FusedView& fv) {
     fv.voices = c->d_voices.as<VoiceDesc>();
     fv.leaves = c->d_leaves.as<LeafDesc>();
     fv.states = c->d_states.as<NodeState>();
@@ -327,6 +276,84 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         static const int dbg = getenv("FWGPU_CHAIN_SKIP") ? atoi(getenv("FWGPU_CHAIN_SKIP")) : 0;
         fv.dbg = dbg;
     }
+}
+
+// K blocks of `frames` frames through the level-batched executor (schedule.rs:289-344 as one launch per level for
+// all K blocks: each block has its own pool slice, a stateful node walks its K blocks in order inside one wave)
+int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const float* d_in, int n_in_ch, float* d_out,
+                      int n_out_ch) {
+    DevView v = generic_view(c, frames);
+    // which gain-like stateful nodes cannot change during this batch (their blocks then run in parallel): decided once,
+    // before the first level
+    if (K > 1 && c->d_frozen.ensure((size_t)c->plan.nodes.size()) == hipSuccess &&
+        c->d_frozen_ph.ensure((size_t)c->plan.nodes.size() * sizeof(unsigned long long)) == hipSuccess) {
+        LCHK(c, launch_frozen_scan(c->stream, v, (int)c->plan.nodes.size(), cmd_block, K, c->d_frozen.as<uint8_t>(),
+                                   c->d_frozen_ph.as<unsigned long long>()));
+        v.frozen = c->d_frozen.as<uint8_t>();
+        v.frozen_playhead = c->d_frozen_ph.as<unsigned long long>();
+    }
+    if (c->n_gin_bufs > 0)
+        LCHK(c, launch_graph_in(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride,
+                                c->d_gin_bufs.as<int>(), c->n_gin_bufs, d_in, d_in ? n_in_ch : 0, frames, K));
+    // hybrid plan (whole blocks): the voice banks of the graph — SumNodes whose every port is a dry voice chain — are
+    // rendered by the voice-bank kernels straight into those SumNodes' pool buffers; the levels below then run without them
+    const bool hy = c->hybrid && !c->force_generic && frames == (int)c->mbf;
+    hipEvent_t e0, e1;
+    if (hy) {
+        FusedView fv;
+        fill_fused_view(c, fv);
+        fv.bus = v.pool;
+        fv.bus_flags = v.flags;
+        fv.bus_blk_stride = v.pool_blk_stride;
+        fv.bus_flags_blk_stride = v.flags_blk_stride;
+        fv.fx_plan = 0;
+        timer_begin(c, 1, &e0, &e1);
+        LCHK(c, launch_voice_control(c->stream, fv, K, cmd_block));
+        timer_end(c, e1);
+        timer_begin(c, 0, &e0, &e1);
+        LCHK(c, launch_leaf_sum(c->stream, fv, K));
+        timer_end(c, e1);
+    } else {
+        c->epoch++;  // node state moves outside the fused control kernel: cached steady descriptors are stale
+    }
+    const std::vector<int>& lv_off = hy ? c->hlevel_off : c->level_off;
+    const std::vector<int>& lv_cnt = hy ? c->hlevel_cnt : c->level_cnt;
+    const std::vector<int>& lv_kinds = hy ? c->hlevel_kinds : c->level_kinds;
+    const int* lv_nodes = hy ? c->d_hlevel_nodes.as<int>() : c->d_level_nodes.as<int>();
+    timer_begin(c, 3, &e0, &e1);
+    for (size_t l = 0; l < lv_cnt.size(); ++l) {
+        if (lv_cnt[l] > 0) LCHK(c, launch_level(c->stream, v, lv_nodes + lv_off[l], lv_cnt[l], K, cmd_block, lv_kinds[l]));
+        for (const fwgpu_ctx::FirGroup& g : c->fir_groups)
+            if (g.level == (int)l) {
+                hipEvent_t g0 = nullptr, g1 = nullptr;
+                if (c->timing) {  // the GEMM alone, on its own event pair (no record of its own: launch_fir does it)
+                    TimerCat& t = c->timers[4];
+                    if (t.used == t.ev.size() && t.ev.size() < 8192) {
+                        hipEvent_t a, b;
+                        if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) t.ev.emplace_back(a, b);
+                    }
+                    if (t.used < t.ev.size()) {
+                        g0 = t.ev[t.used].first;
+                        g1 = t.ev[t.used].second;
+                        t.used++;
+                        t.launches++;
+                    }
+                }
+                LCHK(c, launch_fir(c->stream, v, c->d_fir_rows.as<FirRow>() + g.row_off, g.n_rows,
+                                   c->d_fir_tiles.as<uint32_t>() + g.tile_off, g.T, c->d_fir_partials.as<float>(),
+                                   c->d_fir_partials.cap / sizeof(float), K, g0, g1));
+            }
+    }
+    timer_end(c, e1);
+    LCHK(c, launch_graph_out(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride,
+                             c->d_gout_bufs.as<int>(), c->n_gout_bufs, d_out, n_out_ch, frames, K));
+    return 0;
+}
+
+// K full blocks through the fused voice-bank plan
+int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int n_out_ch) {
+    FusedView fv;
+    fill_fused_view(c, fv);
     // realtime edge: one block, tree = leaves + root, stereo stream -> the whole callback is ONE launch (k_rt_block)
     if (K == 1 && c->rt_one_launch && !c->ahead_this_call && !c->fused_fx && !c->timing && c->n_tail == 0 && c->up_root_node >= 0 && n_out_ch == 2 &&
         c->up_level_cnt.size() == 1 && c->d_rt_sync.p) {

@@ -125,7 +125,8 @@ int fwgpu_schedule_upload(fwgpu_ctx* ctx, const fwgpu_sched_node* nodes, uint32_
 
 /* ---- introspection of the device launch plan (tests) */
 /* 0 = generic level-batched executor, 1 = fused voice-bank plan (k_leaf_sum),
- * 2 = fused chain plan (voices with a biquad / delay: k_chain) */
+ * 2 = fused chain plan (voices with a biquad / delay: k_chain), 3 = hybrid: voice banks inside a graph that is not a fused
+ * shape as a whole (sends, bus effects, anything) are rendered by the voice-bank kernels, the rest by the level executor */
 int fwgpu_plan_kind(fwgpu_ctx* ctx);
 int fwgpu_plan_num_levels(fwgpu_ctx* ctx);
 /* level of a node in the plan (graph_in = 0); negative if unknown */

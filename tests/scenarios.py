@@ -358,6 +358,97 @@ class TaggedOracle(object):
         return self.e.process_interleaved(frames, *a, **kw)
 
 
+def scenario_hybrid_sends(e, n_a=26, n_b=11, src_frames=2100, seed=5, long_call=40):
+    """a mixing-desk shape that is NOT a fused plan as a whole: two voice banks (A: sampler -> volume -> pan, two SumNodes, one
+    with an empty slot; B: with width / hard-clip stages, resampler sources among them) whose buses are consumed TWICE — dry
+    into the master sum and as a send into a delay -> biquad return — plus a resampler -> spatialiser source, a bank whose
+    SumNode also takes a non-voice input (stays on the level executor), a master volume.  The voice banks are rendered by the
+    voice-bank kernels into their SumNodes' pool buffers (hybrid plan, kind 3), everything else by the level executor.
+    Gain / pan / width changes, pauses and restarts tagged across a long call, a master fade."""
+    rng = np.random.default_rng(seed)
+
+    def voice(v, fx):
+        ch = 1 if v % 6 == 2 else 2
+        data = voice_source(seed * 1000 + v, src_frames + 13 * v, ch)
+        smp = e.new_sample(PLANAR_F32, ch, data)
+        rs = fx and v % 4 == 1
+        s = e.resampler(smp, float(rng.uniform(0.6, 1.7)), loop=True, n_out=2) if rs else e.sampler(100.0)
+        vol = e.volume(float(rng.uniform(20, 100)))
+        pan = e.pan(float(rng.uniform(-1, 1)))
+        e.connect_stereo(s, vol)
+        e.connect_stereo(vol, pan)
+        cur = pan
+        extra = []
+        if fx:
+            for n in width_clip_fx(e, v, rng, limit=2):
+                e.connect_stereo(cur, n)
+                cur = n
+                extra.append(n)
+        return dict(src=s, rs=rs, smp=smp, volume=vol, pan=pan, fx=extra, end=cur)
+
+    a = [voice(v, False) for v in range(n_a)]
+    b = [voice(100 + v, True) for v in range(n_b)]
+    half = n_a // 2
+    sum_a1 = e.sum(half + 1)              # one empty voice slot (the last port)
+    sum_a2 = e.sum(n_a - half)
+    sum_b = e.sum(n_b)
+    for p, vc in enumerate(a[:half]):
+        e.connect_stereo(vc["end"], sum_a1, 2 * p)
+    for p, vc in enumerate(a[half:]):
+        e.connect_stereo(vc["end"], sum_a2, 2 * p)
+    for p, vc in enumerate(b):
+        e.connect_stereo(vc["end"], sum_b, 2 * p)
+    # a bank the voice-bank kernels cannot take: its SumNode also sums a bus
+    c = [voice(200 + v, False) for v in range(9)]
+    sum_c = e.sum(10)
+    for p, vc in enumerate(c):
+        e.connect_stereo(vc["end"], sum_c, 2 * p)
+    e.connect_stereo(sum_a2, sum_c, 18)    # (sum_a2 is consumed here, by the master and by the send)
+    # send / return
+    send = e.sum(2)
+    e.connect_stereo(sum_a2, send, 0)
+    e.connect_stereo(sum_b, send, 2)
+    dl = e.delay(0.011, 0.35, 1.0)
+    bq = e.biquad(0, 2500.0)
+    e.connect_stereo(send, dl)
+    e.connect_stereo(dl, bq)
+    # a moving source
+    sp_smp = e.new_sample(PLANAR_F32, 1, voice_source(seed * 1000 + 999, 1700, 1))
+    rs = e.resampler(sp_smp, 0.93, loop=True, n_out=1)
+    sp = e.spatial(1.5, 0.2, -2.0, n_in=1)
+    e.connect(rs, 0, sp, 0)
+    master = e.sum(6)
+    for p, n in enumerate([sum_a1, sum_a2, sum_b, sum_c, bq, sp]):
+        e.connect_stereo(n, master, 2 * p)
+    mvol = e.volume(80.0)
+    e.connect_stereo(master, mvol)
+    e.connect_stereo(mvol, e.graph_out_node)
+    e.update()
+    for vc in a + b + c:
+        if not vc["rs"]:
+            e.sampler_set_sample(vc["src"], vc["smp"])
+            e.sampler_set_loop_range(vc["src"], LOOP_FULL)
+            e.sampler_play(vc["src"])
+    outs = [e.process_blocks(3)]
+    for vc in (a + b + c)[::3]:
+        e.set_param(vc["volume"], 0, float(rng.uniform(0, 100)), at_block=int(rng.integers(0, long_call)))
+    for vc in (a + b)[1::4]:
+        e.set_param(vc["pan"], 0, float(rng.uniform(-1, 1)), at_block=int(rng.integers(0, long_call)))
+    for vc in a[2::5]:
+        e.sampler_pause(vc["src"], at_block=int(rng.integers(0, long_call // 2)))
+        e.sampler_play(vc["src"], at_block=int(rng.integers(long_call // 2, long_call)))
+    for vc in b:
+        if vc["rs"]:
+            e.set_param(vc["src"], 1, float(rng.uniform(0.5, 2.0)), at_block=int(rng.integers(0, long_call)))
+    e.set_param(mvol, 0, 35.0, at_block=long_call // 3)
+    e.set_param(sp, 0, -2.0, at_block=4)
+    outs.append(e.process_blocks(long_call))
+    e.set_param(dl, 1, 0.1)
+    outs.append(e.process_blocks(7))
+    outs.append(e.process_blocks(2))
+    return np.concatenate(outs)
+
+
 def scenario_mixed_generic(e, use_beep=True):
     """a graph the fused plan does not cover: beep (or a mono sampler) + sampler through clip / mono<->stereo /
     2,3,4-port sums, dangling ports, one-to-many edges.  A disabled BeepTest with consumers is outside the

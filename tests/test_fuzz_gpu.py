@@ -83,6 +83,7 @@ def fuzz_run(e, seed):
     level = ends
     free_ports = []  # (leaf SumNode, first channel of the unconnected stereo port)
     first = True
+    leaf_sums = []
     while True:
         nxt = []
         for i in range(0, len(level), radix):
@@ -93,6 +94,8 @@ def fuzz_run(e, seed):
                 e.connect_stereo(n, m, 2 * p)
             if spare:
                 free_ports.append((m, 2 * len(grp)))
+            if first:
+                leaf_sums.append(m)
             nxt.append(m)
         level = nxt
         first = False
@@ -106,7 +109,22 @@ def fuzz_run(e, seed):
              (lambda e: e.biquad(0, float(rng.uniform(2000, 12000)), 0.707), 1, (500.0, 12000.0)),
              (lambda e: e.delay(int(rng.integers(20, 500)) / float(e.sample_rate), feedback=0.3, mix=0.3), 2, (0.0, 1.0))]
     chosen = [kinds[int(i)] for i in rng.integers(0, len(kinds), size=int(rng.integers(0, 4)))]
-    m_nodes = scenarios.connect_through_master(e, level[0], [c[0] for c in chosen])
+    top = level[0]
+    if shape == 0 and rng.random() < 0.35:
+        # a send: one leaf bus is ALSO tapped into a return (a gain, sometimes a delay behind it) that joins the root in a
+        # two-port sum — a bus consumed twice is no fused shape; the dry voice banks inside still are (hybrid plan)
+        tap = leaf_sums[int(rng.integers(0, len(leaf_sums)))]
+        ret = e.volume(float(rng.uniform(20, 90)))
+        e.connect_stereo(tap, ret)
+        if rng.random() < 0.5:
+            dly = e.delay(int(rng.integers(20, 300)) / float(e.sample_rate), feedback=0.25, mix=1.0)
+            e.connect_stereo(ret, dly)
+            ret = dly
+        mix = e.sum(2)
+        e.connect_stereo(top, mix, 0)
+        e.connect_stereo(ret, mix, 2)
+        top = mix
+    m_nodes = scenarios.connect_through_master(e, top, [c[0] for c in chosen])
     e.update()
     fmts = [PLANAR_F32] if f32_only else [PLANAR_F32, PLANAR_I16, PLANAR_U16, INTERLEAVED_F32, INTERLEAVED_I16, INTERLEAVED_U16]
     for v, vc in enumerate(voices):

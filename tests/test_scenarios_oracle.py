@@ -47,6 +47,9 @@ CASES = {
     # 300 and 10 000 messages inside one call (the control kernel's wave-wide message search: one round / 64-ary rounds)
     "spatial_steady_b128": lambda: scenarios.scenario_spatial_steady(oracle(max_block_frames=128)),
     "spatial_steady_b64": lambda: scenarios.scenario_spatial_steady(oracle(max_block_frames=64), 5, src_frames=1500, calls=(3, 90, 33, 7)),
+    # voice banks with sends, a return chain and a spatialised source around them: the hybrid plan
+    "hybrid_sends_b128": lambda: scenarios.scenario_hybrid_sends(oracle(max_block_frames=128)),
+    "hybrid_sends_b64": lambda: scenarios.scenario_hybrid_sends(oracle(max_block_frames=64), 17, 9, src_frames=900, seed=8, long_call=61),
     "storm_48x6": lambda: scenarios.scenario_message_storm(oracle(max_block_frames=128)),
     "storm_200x50_b64": lambda: scenarios.scenario_message_storm(oracle(max_block_frames=64), 200, radix=32, blocks=60, per_voice=50,
                                                                  src_frames=3000, seed=4),

@@ -129,12 +129,22 @@ void check_fused_common(const FusedView& fv, int K) {
 }
 }  // namespace
 
+// node states the voice-bank kernels own in the batch under way (filled by the control launch, dropped when the batch's
+// graph_out / root launch comes by): in a hybrid batch no level list may name one of them — a node is rendered ONCE
+static unsigned char g_fused_states[1 << 16];  // (a flat table: the stubs run on the audio thread of the allocation tests)
+static const void* g_fused_ctx_states = nullptr;  // whose states they index
 int launch_level(hipStream_t, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t, int kinds) {
     g_launches[0]++;
     check_view_common(v, K);
     REQUIRE(kinds >= 0 && kinds <= 7, kinds);  // 0: a level of Dummy / graph I/O / FIR nodes only — nothing to launch
     touch(d_level_nodes, sizeof(int) * (size_t)n_nodes);
-    for (int i = 0; i < n_nodes; ++i) check_generic_node(v, d_level_nodes[i], K);
+    for (int i = 0; i < n_nodes; ++i) {
+        check_generic_node(v, d_level_nodes[i], K);
+        const NodeDesc& nd = v.nodes[d_level_nodes[i]];
+        if (v.pool_blk_stride && (nd.kind == K_SAMPLER || nd.kind == K_RESAMPLER || nd.kind == K_VOLUME || nd.kind == K_PAN || nd.kind == K_WIDTH ||
+                                  nd.kind == K_HARD_CLIP) && v.cmds != nullptr)
+            REQUIRE(v.states != g_fused_ctx_states || !(nd.state >= 0 && nd.state < (1 << 16) && g_fused_states[nd.state]), d_level_nodes[i], nd.state);
+    }
     return 0;
 }
 int launch_frozen_scan(hipStream_t, const DevView& v, int n_nodes, uint32_t, int K, uint8_t* d_frozen, unsigned long long* d_snap) {
@@ -157,6 +167,7 @@ int launch_bus_sum(hipStream_t, const DevView& v, const int* d_level_nodes, int 
 }
 int launch_root_out(hipStream_t, const DevView& v, const RootArgs& root, float* d_out, int K) {
     g_launches[5]++;
+    g_fused_ctx_states = nullptr;  // the batch ends here
     check_view_common(v, K);
     REQUIRE(root.n_in >= 2 && root.n_in <= 64 && root.ports * 2 == root.n_in, root.n_in, root.ports);
     touch(root.in_tab, sizeof(int) * (size_t)root.n_in);
@@ -214,6 +225,7 @@ int launch_graph_in(hipStream_t, float* pool, uint8_t* flags, int stride, size_t
 int launch_graph_out(hipStream_t, const float* pool, const uint8_t* flags, int stride, size_t pbs, size_t fbs, const int* d_bufs, int n_bufs,
                      float* d_out, int n_out_ch, int frames, int K) {
     g_launches[7]++;
+    g_fused_ctx_states = nullptr;  // the batch ends here
     touch(d_bufs, sizeof(int) * (size_t)n_bufs);
     for (int i = 0; i < n_bufs; ++i) {
         touch(pool + (size_t)(K - 1) * pbs + (size_t)d_bufs[i] * stride, sizeof(float) * (size_t)stride);
@@ -246,6 +258,15 @@ int launch_voice_control(hipStream_t, const FusedView& fv, int K, uint32_t cmd_b
         if (fv.cmds[i].block >= cmd_block0 && fv.cmds[i].block < cmd_block0 + (uint32_t)K) g_cmds_applied++;
     }
     if (fv.fx_plan) touch(fv.chain_start, sizeof(ChainStart) * (size_t)fv.n_voices);
+    memset(g_fused_states, 0, sizeof(g_fused_states));
+    g_fused_ctx_states = fv.states;
+    for (int i = 0; i < fv.n_voices; ++i) {
+        const VoiceDesc& vd = fv.voices[i];
+        if (vd.sampler_state < 0 || vd.sampler_state >= (1 << 16)) continue;
+        g_fused_states[vd.sampler_state] = 1;
+        for (int j = 0; j < vd.n_stages; ++j)
+            if (vd.stage_state[j] >= 0 && vd.stage_state[j] < (1 << 16)) g_fused_states[vd.stage_state[j]] = 1;
+    }
     return 0;
 }
 int launch_bus_sum_ordered(hipStream_t, const BusParts& bp, float* d_out, size_t n_floats) {

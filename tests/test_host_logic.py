@@ -81,6 +81,62 @@ def test_plan_selection(kw, plan):
     assert e.cx.plan_kind() == plan
 
 
+def send_graph(e, n_voices=12, radix=4, return_node=True, dangling_bank=False):
+    """bank() with one leaf bus ALSO tapped into a return gain that joins the root in a two-port sum"""
+    ends = []
+    for v in range(n_voices):
+        s = e.sampler(90.0)
+        g = e.volume(50.0 + v)
+        e.connect_stereo(s, g)
+        ends.append(g)
+    leaves = []
+    for i in range(0, n_voices, radix):
+        m = e.sum(max(len(ends[i:i + radix]), 2))
+        for k, n in enumerate(ends[i:i + radix]):
+            e.connect_stereo(n, m, 2 * k)
+        leaves.append(m)
+    root = e.sum(len(leaves))
+    for k, m in enumerate(leaves):
+        e.connect_stereo(m, root, 2 * k)
+    ret = e.volume(30.0)
+    e.connect_stereo(leaves[0], ret)
+    mix = e.sum(2)
+    e.connect_stereo(root, mix, 0)
+    e.connect_stereo(ret, mix, 2)
+    e.connect_stereo(mix, e.graph_out_node)
+    e.update()
+    return leaves, ret
+
+
+def test_hybrid_plan_selection_and_launch_sequence():
+    """a bus consumed twice is no fused shape; the leaf SumNodes whose ports are all dry voice chains are rendered by the
+    voice-bank kernels (plan kind 3): one control + one leaf launch per batch, then the level executor WITHOUT those nodes
+    (the stubs check that no level list of a hybrid batch names a sampler); a partial block runs all of it on the levels"""
+    e = HostOnlyEngine(max_block_frames=64, max_batch=16)
+    send_graph(e)
+    assert e.cx.plan_kind() == 3
+    e.reset_launches()
+    e.process_blocks(40)  # 16 + 16 + 8
+    c = e.launches()
+    assert (c["voice_control"], c["leaf_sum"], c["root_out"], c["chain"]) == (3, 3, 0, 0) and c["level"] >= 2 * 3  # root + return level, mix level
+    lv_hybrid = c["level"]
+    e.cx.set_force_generic(True)
+    assert e.cx.plan_kind() == 0
+    e.reset_launches()
+    e.process_blocks(40)
+    c = e.launches()
+    assert c["voice_control"] == 0 and c["leaf_sum"] == 0 and c["level"] > lv_hybrid  # the voice levels are back
+    e.cx.set_force_generic(False)
+    e.reset_launches()
+    e.process_interleaved(64 * 3 + 10)  # 3 whole blocks (hybrid) + a 10-frame tail (levels only)
+    c = e.launches()
+    assert (c["voice_control"], c["leaf_sum"]) == (1, 1)
+    # fewer than 8 voices in fusable banks: not worth the two launches
+    e2 = HostOnlyEngine(max_block_frames=64)
+    send_graph(e2, n_voices=6, radix=3)
+    assert e2.cx.plan_kind() == 0
+
+
 def test_imported_reference_schedule_selects_the_same_plan_and_levels():
     o = OracleEngine(max_block_frames=128)
     bank(o, chain=True)

@@ -141,7 +141,7 @@ def sum_tree(e, ends, radix, master=False):
         # joins the root in a two-port sum: buses consumed twice — no fused shape as a whole, the voice banks inside still
         # are (hybrid plan).  (No IIR on the return: a bus biquad / delay is one serial recurrence over the 4.1 s of a
         # 768-block call — ~2 ms on one lane whatever surrounds it, DESIGN.md §3.2 — and would be all this line measures.)
-        taps = first_level[::4]
+        taps = first_level[::4][:32]  # (a SumNode takes at most 64 channels)
         send = e.add(K_SUM, 2 * len(taps), 2)
         for p, n in enumerate(taps):
             e.connect_stereo(n, send, 2 * p)

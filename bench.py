@@ -697,7 +697,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
 
 
 def other_configs(env, args):
-    """configs 1, 3, 4, 5 (one shard) in short form, each on the driver-run line next to the headline: a few steps at the
+    """configs 1, 3, 4, 5 (one shard) and the hybrid-plan variant of config 2 in short form, each on the driver-run line next to the headline: a few steps at the
     config's own size, its roofline, and the same parity check against the oracle (~45 s together)."""
     out = {}
     t0 = time.perf_counter()
@@ -705,10 +705,18 @@ def other_configs(env, args):
         out["cfg1"] = run_cfg1(env["fa"], env["torch"].cuda.current_stream().cuda_stream, env["device"])
     except Exception as ex:  # a broken side config must not take the headline line with it
         out["cfg1"] = {"error": repr(ex)}
-    for wl, steps in (("cfg3", 12), ("cfg5", 12), ("cfg4", 6)):
+    import copy
+
+    # (cfg2_sends: the headline graph with sends off its leaf buses — no fused shape as a whole: the hybrid plan)
+    for name, steps in (("cfg3", 12), ("cfg5", 12), ("cfg4", 6), ("cfg2_sends", 12)):
+        wl = name.split("_")[0]
         V, B, K, F, _ = DEFAULTS[wl]
         try:
-            r = run_workload(env, args, wl, V, B, K, F, steps, 3, full=False)
+            wargs = args
+            if name == "cfg2_sends":
+                wargs = copy.copy(args)
+                wargs.send = True
+            r = run_workload(env, wargs, wl, V, B, K, F, steps, 3, full=False)
             cfg = r["config"]
             ent = {"workload": cfg["workload"], "value": r["value"], "unit": "voice-samples/s", "ms_per_step": r["ms_per_step"],
                    "steps": steps, "blocks_per_step": K, "launch_plan": cfg["launch_plan"], "realtime_factor": cfg["realtime_factor"],
@@ -719,13 +727,13 @@ def other_configs(env, args):
                 gen.manual_seed(env["shard"].voice_seed(0))
                 src = torch.empty((V, 2, F), dtype=torch.float32, device=env["dev"])
                 src.uniform_(-1.0, 1.0, generator=gen)
-                ent["parity_check"] = parity_check(env["fa"], torch, wl, V, B, K, args.radix, 0, args, src, F, "f32",
+                ent["parity_check"] = parity_check(env["fa"], torch, wl, V, B, K, args.radix, 0, wargs, src, F, "f32",
                                                    torch.cuda.current_stream().cuda_stream, env["device"])
                 del src
                 torch.cuda.empty_cache()
-            out[wl] = ent
+            out[name] = ent
         except Exception as ex:
-            out[wl] = {"error": repr(ex)}
+            out[name] = {"error": repr(ex)}
     out["secs"] = round(time.perf_counter() - t0, 1)
     return out
 

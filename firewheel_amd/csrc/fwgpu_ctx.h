@@ -239,6 +239,7 @@ struct fwgpu_ctx {
     // hybrid plan (kind 3): voice-bank groups inside a graph the level executor runs — the level lists without the nodes
     // the fused kernels render
     bool hybrid = false;
+    bool hybrid_fx = false;  // ... and the banks hold biquad / delay voices: k_chain renders them
     DevBuf d_hlevel_nodes;
     std::vector<int> hlevel_off, hlevel_cnt, hlevel_kinds;
     bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2
@@ -319,7 +320,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
 // The hybrid plan (kind 3): the graph as a whole is not a fused shape, but it holds voice banks that are — SumNodes whose
 // every port is a dry voice chain.  Those groups are rendered by the voice-bank kernels straight into the SumNode's pool
 // buffers; everything else runs on the level executor, which finds the groups' outputs where it expects them.
-bool detect_hybrid(const Plan& plan, FusedBuild& fb);
+bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedBuild& fb);
 
 // ---- fwgpu_plan_install.cpp
 int install_plan(fwgpu_ctx* c, Plan& plan);

@@ -249,7 +249,11 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
 }
 
 // ---------------------------------------------------------------- hybrid plan detection
-bool detect_hybrid(const Plan& plan, FusedBuild& fb) {
+// Banks: SumNodes whose every stereo port is a voice chain of a fused plan's shape (or nothing: a null voice).  If any bank
+// holds a biquad / delay voice the banks go through the chain plan's kernels (k_chain, which also renders dry voices) and
+// only banks that plan can take are kept — gains only, <= 3 of them, sampler sources, <= 32 ports, whole 64-frame tiles;
+// otherwise through the voice-bank plan's (k_leaf_sum: stage programs, resampler sources).
+bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedBuild& fb) {
     const int N = (int)plan.nodes.size();
     std::vector<std::vector<int>> cons(N);
     for (int i = 0; i < N; ++i) cons[i].assign(plan.nodes[i].n_out, 0);
@@ -264,25 +268,32 @@ bool detect_hybrid(const Plan& plan, FusedBuild& fb) {
         src = a;
         return true;
     };
-    std::vector<char> covered(N, 0);
-    int real_voices = 0;
+    struct Bank {
+        int sum;
+        std::vector<VoiceDesc> voices;
+        std::vector<uint32_t> progs;
+        std::vector<int> nodes;
+        bool prog = false, rs = false, fx = false;
+        int stages = 0, real = 0;
+        uint64_t min_delay = ~0ull;
+    };
+    std::vector<Bank> banks;
+    std::vector<char> taken(N, 0);  // nodes of a candidate bank (a chain node feeds one consumer, so banks cannot overlap)
     for (int si = 0; si < N; ++si) {
         const PlanNode& s = plan.nodes[si];
         if (s.kind != K_SUM || s.is_graph_io || s.n_out != 2 || s.n_in < 2 || s.n_in % 2 || s.n_in > 64) continue;
-        if (s.out_buf[1] != s.out_buf[0] + 1) continue;  // the leaf kernel writes channel 1 in the row behind channel 0
-        // every port a dry voice chain (or nothing): sampler | resampler -> up to 5 of volume / pan / width / hard clip
-        std::vector<VoiceDesc> voices;
-        std::vector<uint32_t> progs;
-        std::vector<int> nodes{si};
-        bool ok = true, prog = false, rs = false;
-        int stages = 0, real = 0;
+        if (s.out_buf[1] != s.out_buf[0] + 1) continue;  // the kernels write channel 1 in the row behind channel 0
+        Bank bk;
+        bk.sum = si;
+        bk.nodes.push_back(si);
+        bool ok = true;
         for (int p = 0; ok && p < s.n_in / 2; ++p) {
             VoiceDesc vd;
             memset(&vd, 0, sizeof(vd));
             vd.sampler_state = vd.bq_state = vd.dl_state = -1;
             if (s.in_src_node[2 * p] < 0 && s.in_src_node[2 * p + 1] < 0) {  // an empty voice slot: a null voice
-                voices.push_back(vd);
-                progs.push_back(0u);
+                bk.voices.push_back(vd);
+                bk.progs.push_back(0u);
                 continue;
             }
             int cur;
@@ -290,10 +301,12 @@ bool detect_hybrid(const Plan& plan, FusedBuild& fb) {
                 ok = false;
                 break;
             }
+            // walking upstream: gain stages, then [delay], then [biquad], then the source (as detect_fused)
             std::vector<int> chain;
+            int bq = -1, dl = -1;
             for (;;) {
                 const PlanNode& n = plan.nodes[cur];
-                if (covered[cur] || n.is_graph_io) {
+                if (taken[cur] || n.is_graph_io) {
                     ok = false;
                     break;
                 }
@@ -301,12 +314,33 @@ bool detect_hybrid(const Plan& plan, FusedBuild& fb) {
                     ok = n.n_in == 0 && n.n_out == 2;
                     break;
                 }
-                if (n.n_in != 2 || n.n_out != 2 || !(n.kind == K_VOLUME || n.kind == K_PAN || n.kind == K_WIDTH || n.kind == K_HARD_CLIP) ||
-                    (int)chain.size() >= FW_MAX_STAGES - 1) {
+                if (n.n_in != 2 || n.n_out != 2) {
                     ok = false;
                     break;
                 }
-                chain.push_back(cur);
+                if (n.kind == K_VOLUME || n.kind == K_PAN || n.kind == K_WIDTH || n.kind == K_HARD_CLIP) {
+                    if (bq >= 0 || dl >= 0 || (int)chain.size() >= FW_MAX_STAGES - 1) {
+                        ok = false;
+                        break;
+                    }
+                    chain.push_back(cur);
+                } else if (n.kind == K_DELAY) {
+                    if (bq >= 0 || dl >= 0 || graph.nodes[n.slot].init.loop_end < 64) {
+                        ok = false;
+                        break;
+                    }
+                    bk.min_delay = std::min<uint64_t>(bk.min_delay, graph.nodes[n.slot].init.loop_end);
+                    dl = cur;
+                } else if (n.kind == K_BIQUAD) {
+                    if (bq >= 0) {
+                        ok = false;
+                        break;
+                    }
+                    bq = cur;
+                } else {
+                    ok = false;
+                    break;
+                }
                 int src;
                 if (!stereo_src(n, 0, src)) {
                     ok = false;
@@ -317,7 +351,10 @@ bool detect_hybrid(const Plan& plan, FusedBuild& fb) {
             if (!ok) break;
             vd.sampler_state = (int)plan.nodes[cur].slot;
             vd.src_kind = plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0;
-            rs = rs || vd.src_kind == 1;
+            vd.bq_state = bq >= 0 ? (int)plan.nodes[bq].slot : -1;
+            vd.dl_state = dl >= 0 ? (int)plan.nodes[dl].slot : -1;
+            bk.fx = bk.fx || bq >= 0 || dl >= 0;
+            bk.rs = bk.rs || vd.src_kind == 1;
             vd.n_stages = (int)chain.size();
             uint32_t pr = 0;
             for (int j = 0; j < vd.n_stages; ++j) {  // schedule order: nearest the source first
@@ -325,32 +362,52 @@ bool detect_hybrid(const Plan& plan, FusedBuild& fb) {
                 vd.stage_kind[j] = n.kind;
                 vd.stage_state[j] = (int)n.slot;
                 pr |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : SK_GAIN) << (4 * j);
-                prog = prog || n.kind == K_WIDTH || n.kind == K_HARD_CLIP;
+                bk.prog = bk.prog || n.kind == K_WIDTH || n.kind == K_HARD_CLIP;
             }
-            stages = std::max(stages, vd.n_stages);
-            nodes.push_back(cur);
-            nodes.insert(nodes.end(), chain.begin(), chain.end());
-            voices.push_back(vd);
-            progs.push_back(pr);
-            real++;
+            bk.stages = std::max(bk.stages, vd.n_stages);
+            bk.nodes.push_back(cur);
+            if (bq >= 0) bk.nodes.push_back(bq);
+            if (dl >= 0) bk.nodes.push_back(dl);
+            bk.nodes.insert(bk.nodes.end(), chain.begin(), chain.end());
+            bk.voices.push_back(vd);
+            bk.progs.push_back(pr);
+            bk.real++;
         }
-        if (!ok || real == 0) continue;
+        if (!ok || bk.real == 0) continue;
+        for (int i : bk.nodes) taken[i] = 1;
+        banks.push_back(std::move(bk));
+    }
+    bool fx_mode = false;
+    for (const Bank& bk : banks) fx_mode = fx_mode || bk.fx;
+    if (fx_mode && mbf % 64 != 0) {  // k_chain renders whole tiles: fall back to the dry banks
+        fx_mode = false;
+    }
+    auto keeps = [&](const Bank& bk, bool fxm) {
+        return fxm ? (!bk.prog && !bk.rs && bk.stages <= FW_CHAIN_STAGES - 1 && (int)bk.voices.size() <= 32) : !bk.fx;
+    };
+    if (fx_mode) {  // no bank with a filter survives the chain plan's rules: the dry banks are voice-bank banks, all of them
+        bool any_fx = false;
+        for (const Bank& bk : banks) any_fx = any_fx || (bk.fx && keeps(bk, true));
+        fx_mode = any_fx;
+    }
+    int real_voices = 0;
+    for (const Bank& bk : banks) {
+        if (!keeps(bk, fx_mode)) continue;
         LeafDesc ld;
         ld.first_voice = (int)fb.voices.size();
-        ld.ports = s.n_in / 2;
-        ld.out_buf = s.out_buf[0];
+        ld.ports = (int)bk.voices.size();
+        ld.out_buf = plan.nodes[bk.sum].out_buf[0];
         ld.pad = 0;
         fb.leaves.push_back(ld);
-        fb.voices.insert(fb.voices.end(), voices.begin(), voices.end());
-        fb.progs.insert(fb.progs.end(), progs.begin(), progs.end());
-        fb.has_prog = fb.has_prog || prog || rs;
-        fb.has_rs = fb.has_rs || rs;
-        fb.max_stages = std::max(fb.max_stages, stages);
-        real_voices += real;
-        for (int i : nodes) {
-            covered[i] = 1;
-            fb.covered.push_back(i);
-        }
+        fb.voices.insert(fb.voices.end(), bk.voices.begin(), bk.voices.end());
+        fb.progs.insert(fb.progs.end(), bk.progs.begin(), bk.progs.end());
+        fb.has_prog = fb.has_prog || bk.prog || bk.rs;
+        fb.has_rs = fb.has_rs || bk.rs;
+        fb.has_fx = fb.has_fx || bk.fx;
+        fb.min_delay = std::min(fb.min_delay, bk.min_delay);
+        fb.max_stages = std::max(fb.max_stages, bk.stages);
+        real_voices += bk.real;
+        fb.covered.insert(fb.covered.end(), bk.nodes.begin(), bk.nodes.end());
     }
     // a handful of voices is not worth two more launches per batch
     return real_voices >= 8;

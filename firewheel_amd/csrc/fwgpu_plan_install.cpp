@@ -3,6 +3,40 @@
 
 namespace fwgpu {
 
+// k_chain workgroups: consecutive leaves packed greedily into groups of <= 32 voices / <= 8 leaves (the voices of
+// consecutive leaves are consecutive), so that a tree of small leaves fills the 32 voice rows
+static int upload_chain_groups(fwgpu_ctx* c, const std::vector<LeafDesc>& leaves) {
+    int rc;
+    std::vector<ChainGroup> groups;
+    for (size_t l = 0; l < leaves.size(); ++l) {
+        const LeafDesc& ld = leaves[l];
+        if (groups.empty() || groups.back().n_voices + ld.ports > 32 || groups.back().n_leaves >= CH_GROUP_LEAVES) {
+            ChainGroup g;
+            memset(&g, 0, sizeof(g));
+            g.first_voice = ld.first_voice;
+            groups.push_back(g);
+        }
+        ChainGroup& g = groups.back();
+        const int li = g.n_leaves++;
+        g.out_buf[li] = ld.out_buf;
+        g.row0[li] = g.n_voices;
+        g.ports[li] = ld.ports;
+        g.start_mask |= 1u << g.n_voices;
+        if (!(ld.ports == 2 || ld.ports == 3 || ld.ports == 4))  // sum.rs:67-133 (Q13): the n-port path skips silent ports
+            g.masked_rows |= (ld.ports >= 32 ? 0xffffffffu : ((1u << ld.ports) - 1u)) << g.n_voices;
+        g.n_voices += ld.ports;
+    }
+    for (ChainGroup& g : groups) {
+        const int P = g.ports[0];
+        bool uni = g.n_voices == 32 && (P == 32 || P == 16 || P == 8 || P == 4);
+        for (int i = 0; i < g.n_leaves && uni; ++i) uni = g.ports[i] == P;
+        g.uniform_ports = uni ? P : 0;
+    }
+    c->n_groups = (int)groups.size();
+    if ((rc = upload(c, c->d_groups, groups.data(), groups.size() * sizeof(ChainGroup)))) return rc;
+    return 0;
+}
+
 static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
     HIPC(c, hipStreamSynchronize(c->stream));
     if (c->ctl_stream) HIPC(c, hipStreamSynchronize(c->ctl_stream));
@@ -338,35 +372,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         c->fused_rs = fb.has_rs;
         c->n_groups = 0;
         if (c->fused_fx) {
-            // k_chain workgroups: consecutive leaves packed greedily into groups of <= 32 voices / <= 8 leaves (the
-            // voices of consecutive leaves are consecutive), so that a tree of small leaves fills the 32 voice rows
-            std::vector<ChainGroup> groups;
-            for (size_t l = 0; l < fb.leaves.size(); ++l) {
-                const LeafDesc& ld = fb.leaves[l];
-                if (groups.empty() || groups.back().n_voices + ld.ports > 32 || groups.back().n_leaves >= CH_GROUP_LEAVES) {
-                    ChainGroup g;
-                    memset(&g, 0, sizeof(g));
-                    g.first_voice = ld.first_voice;
-                    groups.push_back(g);
-                }
-                ChainGroup& g = groups.back();
-                const int li = g.n_leaves++;
-                g.out_buf[li] = ld.out_buf;
-                g.row0[li] = g.n_voices;
-                g.ports[li] = ld.ports;
-                g.start_mask |= 1u << g.n_voices;
-                if (!(ld.ports == 2 || ld.ports == 3 || ld.ports == 4))  // sum.rs:67-133 (Q13): the n-port path skips silent ports
-                    g.masked_rows |= (ld.ports >= 32 ? 0xffffffffu : ((1u << ld.ports) - 1u)) << g.n_voices;
-                g.n_voices += ld.ports;
-            }
-            for (ChainGroup& g : groups) {
-                const int P = g.ports[0];
-                bool uni = g.n_voices == 32 && (P == 32 || P == 16 || P == 8 || P == 4);
-                for (int i = 0; i < g.n_leaves && uni; ++i) uni = g.ports[i] == P;
-                g.uniform_ports = uni ? P : 0;
-            }
-            c->n_groups = (int)groups.size();
-            if ((rc = upload(c, c->d_groups, groups.data(), groups.size() * sizeof(ChainGroup)))) return rc;
+            if ((rc = upload_chain_groups(c, fb.leaves))) return rc;
         }
         const size_t K = c->kmax;
         HIPC(c, c->d_blks.ensure(K * c->n_voices * sizeof(VoiceBlk)));
@@ -448,13 +454,26 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
     // 5b. hybrid plan: not a fused shape as a whole, but with voice banks inside that are
     if (!c->fused && !c->force_generic) {
         FusedBuild hb;
-        if (detect_hybrid(plan, hb)) {
+        c->hybrid_fx = false;
+        if (detect_hybrid(plan, c->graph, c->mbf, hb)) {
             c->n_voices = (int)hb.voices.size();
             c->n_leaves = (int)hb.leaves.size();
             c->ramp_slots = 2 * (1 + hb.max_stages);
             c->fused_prog = hb.has_prog;
             c->fused_rs = hb.has_rs;
             c->n_groups = 0;
+            c->hybrid_fx = hb.has_fx;
+            if (c->hybrid_fx) {  // the banks go through k_chain: its workgroups, its tile size, at most 64 blocks per launch
+                if ((rc = upload_chain_groups(c, hb.leaves))) return rc;
+                c->chain_nq = (c->mbf % 128 == 0 && hb.min_delay >= 128) ? 2 : 1;
+                if (const char* e = getenv("FWGPU_CHAIN_NQ")) {
+                    if (atoi(e) == 1) c->chain_nq = 1;
+                }
+                HIPC(c, c->d_chain_dummy.ensure(64 * 1024));
+                HIPC(c, c->d_chain_stats.ensure(2 * sizeof(unsigned long long)));
+                HIPC(c, hipMemset(c->d_chain_stats.p, 0, 2 * sizeof(unsigned long long)));
+                c->generic_k = std::min<uint32_t>(c->generic_k, CH_FAST_KMAX);
+            }
             c->n_tail = 0;
             c->up_root_node = -1;
             c->up_level_off.clear();
@@ -518,6 +537,7 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
         c->have_plan = false;
         c->fused = false;
         c->hybrid = false;
+        c->hybrid_fx = false;
         c->graph.needs_compile = true;
         c->epoch++;
     }

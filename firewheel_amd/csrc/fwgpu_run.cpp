@@ -306,12 +306,13 @@ int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const
         fv.bus_flags = v.flags;
         fv.bus_blk_stride = v.pool_blk_stride;
         fv.bus_flags_blk_stride = v.flags_blk_stride;
-        fv.fx_plan = 0;
+        fv.fx_plan = c->hybrid_fx ? 1 : 0;
         timer_begin(c, 1, &e0, &e1);
         LCHK(c, launch_voice_control(c->stream, fv, K, cmd_block));
         timer_end(c, e1);
         timer_begin(c, 0, &e0, &e1);
-        LCHK(c, launch_leaf_sum(c->stream, fv, K));
+        if (c->hybrid_fx) LCHK(c, launch_chain(c->stream, fv, K, cmd_block, c->chain_nq));
+        else LCHK(c, launch_leaf_sum(c->stream, fv, K));
         timer_end(c, e1);
     } else {
         c->epoch++;  // node state moves outside the fused control kernel: cached steady descriptors are stale

@@ -449,6 +449,77 @@ def scenario_hybrid_sends(e, n_a=26, n_b=11, src_frames=2100, seed=5, long_call=
     return np.concatenate(outs)
 
 
+def scenario_hybrid_chain_sends(e, n_voices=30, radix=6, src_frames=2300, seed=9, long_call=50):
+    """banks of filtered voices (sampler -> biquad -> delay -> volume [-> pan]; some dry, one bank with a hard clip in a voice,
+    which the chain plan does not take) whose buses are consumed twice: into the master sum and into a send -> width return.
+    The banks the chain plan can take are rendered by k_chain into their SumNodes' pool buffers, the rest by the level executor
+    (hybrid plan with chain banks).  Filter sweeps, delay feedback changes, gain glides, pauses across a long call."""
+    rng = np.random.default_rng(seed)
+    voices = []
+    for v in range(n_voices):
+        s = e.sampler(100.0)
+        cur = s
+        bq = dl = None
+        if v % 5 != 4:
+            bq = e.biquad(int(v % 3), float(rng.uniform(300, 6000)), float(rng.uniform(0.5, 2.0)))
+            e.connect_stereo(cur, bq)
+            cur = bq
+        if v % 4 != 3:
+            dl = e.delay(int(rng.integers(70, 700)) / float(e.sample_rate), feedback=float(rng.uniform(0, 0.5)), mix=float(rng.uniform(0.2, 0.9)))
+            e.connect_stereo(cur, dl)
+            cur = dl
+        vol = e.volume(float(rng.uniform(20, 100)))
+        e.connect_stereo(cur, vol)
+        cur = vol
+        if v % 2:
+            pan = e.pan(float(rng.uniform(-1, 1)))
+            e.connect_stereo(cur, pan)
+            cur = pan
+        if v == 2 * radix + 1:  # one voice of the third bank ends in a hard clip: that bank stays on the level executor
+            hc = e.hard_clip(-6.0)
+            e.connect_stereo(cur, hc)
+            cur = hc
+        voices.append(dict(sampler=s, bq=bq, dl=dl, volume=vol, end=cur))
+    banks = []
+    for i in range(0, n_voices, radix):
+        grp = voices[i:i + radix]
+        m = e.sum(len(grp))
+        for p, vc in enumerate(grp):
+            e.connect_stereo(vc["end"], m, 2 * p)
+        banks.append(m)
+    send = e.sum(2)
+    e.connect_stereo(banks[0], send, 0)
+    e.connect_stereo(banks[1], send, 2)
+    wid = e.width(1.6)
+    e.connect_stereo(send, wid)
+    master = e.sum(len(banks) + 1)
+    for p, m in enumerate(banks + [wid]):
+        e.connect_stereo(m, master, 2 * p)
+    e.connect_stereo(master, e.graph_out_node)
+    e.update()
+    for v, vc in enumerate(voices):
+        smp = e.new_sample(PLANAR_F32, 1 if v % 7 == 3 else 2, voice_source(seed * 1000 + v, src_frames + 11 * v, 1 if v % 7 == 3 else 2))
+        e.sampler_set_sample(vc["sampler"], smp)
+        e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        e.sampler_play(vc["sampler"])
+    outs = [e.process_blocks(4)]
+    for vc in voices[::3]:
+        e.set_param(vc["volume"], 0, float(rng.uniform(0, 100)), at_block=int(rng.integers(0, long_call)))
+    for vc in voices[1::4]:
+        if vc["bq"] is not None:
+            e.set_param(vc["bq"], 1, float(rng.uniform(200, 9000)), at_block=int(rng.integers(0, long_call)))
+        if vc["dl"] is not None:
+            e.set_param(vc["dl"], 1, float(rng.uniform(0, 0.8)), at_block=int(rng.integers(0, long_call)))
+    for vc in voices[2::6]:
+        e.sampler_pause(vc["sampler"], at_block=int(rng.integers(0, long_call // 2)))
+        e.sampler_play(vc["sampler"], at_block=int(rng.integers(long_call // 2, long_call)))
+    e.set_param(wid, 0, 0.4, at_block=7)
+    outs.append(e.process_blocks(long_call))
+    outs.append(e.process_blocks(9))
+    outs.append(e.process_blocks(9))
+    return np.concatenate(outs)
+
+
 def scenario_mixed_generic(e, use_beep=True):
     """a graph the fused plan does not cover: beep (or a mono sampler) + sampler through clip / mono<->stereo /
     2,3,4-port sums, dangling ports, one-to-many edges.  A disabled BeepTest with consumers is outside the

@@ -110,9 +110,10 @@ def fuzz_run(e, seed):
              (lambda e: e.delay(int(rng.integers(20, 500)) / float(e.sample_rate), feedback=0.3, mix=0.3), 2, (0.0, 1.0))]
     chosen = [kinds[int(i)] for i in rng.integers(0, len(kinds), size=int(rng.integers(0, 4)))]
     top = level[0]
-    if shape == 0 and rng.random() < 0.35:
+    if rng.random() < 0.35:
         # a send: one leaf bus is ALSO tapped into a return (a gain, sometimes a delay behind it) that joins the root in a
-        # two-port sum — a bus consumed twice is no fused shape; the dry voice banks inside still are (hybrid plan)
+        # two-port sum — a bus consumed twice is no fused shape; the voice banks inside still are (hybrid plan: k_leaf_sum for
+        # dry banks, k_chain when some bank holds a biquad / delay)
         tap = leaf_sums[int(rng.integers(0, len(leaf_sums)))]
         ret = e.volume(float(rng.uniform(20, 90)))
         e.connect_stereo(tap, ret)

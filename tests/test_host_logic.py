@@ -67,8 +67,8 @@ def bank(e, n_voices=12, radix=4, chain=False, clip_in_voice=False, master=False
 
 
 # a hard clip (or a width) among a dry voice's stages rides the voice-bank plan as a stage program; behind a biquad / delay
-# the chain plan keeps gains only, so that graph takes the generic executor
-@pytest.mark.parametrize("kw,plan", [({}, 1), ({"chain": True}, 2), ({"clip_in_voice": True}, 1), ({"chain": True, "clip_in_voice": True}, 0),
+# the chain plan keeps gains only: the bank with that voice goes to the level executor, the other banks stay on k_chain (hybrid)
+@pytest.mark.parametrize("kw,plan", [({}, 1), ({"chain": True}, 2), ({"clip_in_voice": True}, 1), ({"chain": True, "clip_in_voice": True}, 3),
                                      ({"master": True}, 1),
                                      ({"chain": True, "master": True}, 2), ({"radix": 32, "n_voices": 70}, 1)])
 def test_plan_selection(kw, plan):

@@ -50,6 +50,9 @@ CASES = {
     # voice banks with sends, a return chain and a spatialised source around them: the hybrid plan
     "hybrid_sends_b128": lambda: scenarios.scenario_hybrid_sends(oracle(max_block_frames=128)),
     "hybrid_sends_b64": lambda: scenarios.scenario_hybrid_sends(oracle(max_block_frames=64), 17, 9, src_frames=900, seed=8, long_call=61),
+    "hybrid_chain_sends_b128": lambda: scenarios.scenario_hybrid_chain_sends(oracle(max_block_frames=128)),
+    "hybrid_chain_sends_b64": lambda: scenarios.scenario_hybrid_chain_sends(oracle(max_block_frames=64), 21, radix=7, src_frames=800, seed=12,
+                                                                             long_call=70),
     "storm_48x6": lambda: scenarios.scenario_message_storm(oracle(max_block_frames=128)),
     "storm_200x50_b64": lambda: scenarios.scenario_message_storm(oracle(max_block_frames=64), 200, radix=32, blocks=60, per_voice=50,
                                                                  src_frames=3000, seed=4),

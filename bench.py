@@ -155,8 +155,9 @@ def sum_tree(e, ends, radix, master=False):
         e.connect_stereo(cur, mix, 0)
         e.connect_stereo(lim, mix, 2)
         cur = mix
-    elif master:  # --master: a master volume + limiter between the root SumNode and graph_out
-        for kind, params in ((K_VOLUME, [70.0]), (K_HARD_CLIP, [-1.0])):
+    elif master:  # --master: a master volume + limiter between the root SumNode and graph_out (--master-iir: low-pass + delay)
+        for kind, params in (((K_BIQUAD, [0.0, 9000.0, 0.707]), (K_DELAY, [0.030, 0.2, 0.3])) if master == "iir" else
+                             ((K_VOLUME, [70.0]), (K_HARD_CLIP, [-1.0]))):
             m = e.add(kind, 2, 2, params)
             e.connect_stereo(cur, m)
             cur = m
@@ -264,7 +265,7 @@ def make_gpu(fa, wl, V, B, K, radix, src, F, sfmt, seed, args, stream, device):
     fmt = PLANAR_F32 if sfmt == "f32" else INTERLEAVED_I16
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
     ids = [cx.new_sample_device(fmt, 2, F, src[v].data_ptr()) for v in range(V)] if rs else None
-    samplers, volumes = build_graph(g, wl, V, radix, seed, "send" if getattr(args, "send", False) else args.master, ir,
+    samplers, volumes = build_graph(g, wl, V, radix, seed, "send" if getattr(args, "send", False) else ("iir" if getattr(args, "master_iir", False) else args.master), ir,
                                     "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
     if not rs:
         for v, s in enumerate(samplers):
@@ -282,7 +283,7 @@ def make_oracle(wl, V, B, radix, seed, args, host_src, fmt=PLANAR_F32):
     ir = o.e.new_sample(PLANAR_F32, 2, reverb_ir(args.taps)) if wl == "cfg4" else None
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
     ids = [o.e.new_sample(fmt, 2, host_src[v]) for v in range(V)] if rs else None
-    samplers, volumes = build_graph(o, wl, V, radix, seed, "send" if getattr(args, "send", False) else args.master, ir,
+    samplers, volumes = build_graph(o, wl, V, radix, seed, "send" if getattr(args, "send", False) else ("iir" if getattr(args, "master_iir", False) else args.master), ir,
                                     "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
     if not rs:
         for v, s in enumerate(samplers):
@@ -385,7 +386,7 @@ def parity_check(fa, torch, wl, V, B, K, radix, seed, args, src, F, sfmt, stream
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
     if rs:
         blocks = [0, 1]  # a resampled voice's block does not start on a source-block boundary: prefix only, whole samples
-    elif getattr(args, "voice_spatial", False):
+    elif getattr(args, "voice_spatial", False) or getattr(args, "master_iir", False):
         blocks = [0, 1, 2, 3][:K]  # a spatialiser carries 64 frames of history from block to block: a contiguous prefix
     elif wl in ("cfg2", "cfg5") and K >= 4 and F >= K * B and sfmt == "f32":
         blocks = [0, 1, K // 2, K - 1]
@@ -640,7 +641,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
             ach = alg_bytes / avg_s / 1e9
             # (PMC passes ran on f32 sources; a profile is quoted for the workload it was collected on: plain / --voice-fx / --rs-source)
             prof_name = wl + ("_voicefx" if args.voice_fx else "") + ("_rs" if getattr(args, "rs_source", False) else "")
-            plain = not (args.master or variant != "A" or args.force_generic or getattr(args, "voice_spatial", False) or getattr(args, "send", False))
+            plain = not (args.master or getattr(args, "master_iir", False) or variant != "A" or args.force_generic or getattr(args, "voice_spatial", False) or getattr(args, "send", False))
             traffic, traffic_src = pmc_traffic(kernel, V, B, K, prof_name) if sfmt == "f32" and plain else (None, None)
             roofline = {
                 "bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -796,6 +797,8 @@ def main():
     ap.add_argument("--master", action="store_true",
                     help="put a master VolumeNode + HardClipNode between the root SumNode and graph_out (the fused plans "
                          "then run that chain with the generic node kernel on the mix bus)")
+    ap.add_argument("--master-iir", action="store_true",
+                    help="a master low-pass + delay between the root SumNode and graph_out: one serial recurrence over the whole call")
     ap.add_argument("--send", action="store_true",
                     help="cfg2/cfg5: every fourth leaf bus also feeds a send -> gain -> width -> limiter return mixed with the root "
                          "(buses consumed twice: the hybrid plan — voice banks on the voice-bank kernels, the rest on the level executor)")
@@ -827,7 +830,7 @@ def main():
     steps = args.steps or dS
     wl = args.workload
     default_shape = (wl == "cfg2" and (V, B, K, F) == (dV, dB, dK, dF) and args.source_format == "f32" and args.variant == "A" and
-                     not (args.master or args.voice_fx or args.voice_spatial or args.send or args.rs_source or args.force_generic or args.host_buffers))
+                     not (args.master or args.master_iir or args.voice_fx or args.voice_spatial or args.send or args.rs_source or args.force_generic or args.host_buffers))
 
     # stdout carries exactly ONE line (the JSON, rank 0): everything else that writes to fd 1 — RCCL's version banner
     # and warnings come from C stdio, flushed whenever — is sent to stderr for the life of the process

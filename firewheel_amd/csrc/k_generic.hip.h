@@ -15,6 +15,10 @@ struct WaveIO {
     __device__ __forceinline__ float* out(int i) const { return pool + (size_t)out_buf[i] * stride; }
 };
 
+// generic biquad: LDS staging rows (channels x 256 frames, padded off the 32-bank period)
+#define BQ_LDS_CH 4
+#define BQ_LDS_PITCH 260
+
 // core/util.rs:165-175
 __device__ __forceinline__ uint64_t clear_all_outputs(const WaveIO& io, int first, int n_out) {
     for (int c = first; c < n_out; ++c) {
@@ -378,7 +382,64 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             // Serial in time: lane c runs channel c (the generic executor's coverage path).
             float* ext = v.ext + s.ext_off;
             const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
-            if (lane < nch) {
+            if (nch <= BQ_LDS_CH) {
+                // Up to 4 channels (a bus effect, a master filter): the block goes through LDS 256 frames at a time — the wave
+                // loads it coalesced, lane c runs channel c's recurrence on LDS operands, the wave stores the result.  With
+                // the samples read from global memory inside the loop every frame paid a memory round trip behind the
+                // previous frame's store (in and out may alias as far as the compiler knows): 19 us per 256-frame block, and a
+                // bus filter is ONE such chain over all K blocks of a call.  Same operations, same order.
+                __shared__ float s_bq[WPB][2][BQ_LDS_CH][BQ_LDS_PITCH];
+                float(*xin)[BQ_LDS_PITCH] = s_bq[(threadIdx.x >> 6) % WPB][0];
+                float(*yout)[BQ_LDS_PITCH] = s_bq[(threadIdx.x >> 6) % WPB][1];
+                float b0 = 0.f, b1 = 0.f, b2 = 0.f, a1 = 0.f, a2 = 0.f, x1 = 0.f, x2 = 0.f, y1 = 0.f, y2 = 0.f;
+                float* st = ext + 5 + 4 * (lane < nch ? lane : 0);
+                if (lane < nch) {
+                    b0 = ext[0], b1 = ext[1], b2 = ext[2], a1 = ext[3], a2 = ext[4];
+                    x1 = st[0], x2 = st[1], y1 = st[2], y2 = st[3];
+                }
+                for (int base = 0; base < frames; base += 256) {
+                    const int n = frames - base < 256 ? frames - base : 256;
+                    for (int c = 0; c < nch; ++c) {
+                        const float* in = io.in(c) + base;
+                        for (int f = lane; f < n; f += WAVE) xin[c][f] = in[f];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (lane < nch) {
+                        const float* xi = xin[lane];
+                        float* yo = yout[lane];
+                        for (int i = 0; i < n; ++i) {
+                            const float x = xi[i];
+                            float acc = b0 * x;
+                            acc = acc + (b1 * x1);
+                            acc = acc + (b2 * x2);
+                            acc = __builtin_fmaf(-a2, y2, acc);
+                            acc = __builtin_fmaf(-a1, y1, acc);
+                            x2 = x1;
+                            x1 = x;
+                            y2 = y1;
+                            y1 = acc;
+                            yo[i] = acc;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (int c = 0; c < nch; ++c) {
+                        float* out = io.out(c) + base;
+                        for (int f = lane; f < n; f += WAVE) out[f] = yout[c][f];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();  // (the next 256 frames overwrite the staging rows)
+                }
+                if (lane < nch) {
+                    st[0] = x1;
+                    st[1] = x2;
+                    st[2] = y1;
+                    st[3] = y2;
+                }
+            } else if (lane < nch) {
                 const float b0 = ext[0], b1 = ext[1], b2 = ext[2], a1 = ext[3], a2 = ext[4];
                 float* st = ext + 5 + 4 * lane;
                 float x1 = st[0], x2 = st[1], y1 = st[2], y2 = st[3];
@@ -410,19 +471,34 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
             const uint32_t pos = (uint32_t)s.playhead;
             const float fb = s.p0, mix = s.p1, dry = s.gain;
             const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
-            const uint32_t chunk = D < 64u ? D : 64u;  // frames inside one chunk touch distinct ring slots
+            // frames inside one chunk touch distinct ring slots: up to 256 of them (a lane takes 4, all loads before the first
+            // store: one memory round trip per chunk — a delay on a bus is one chain of such chunks over all K blocks of a call)
+            const uint32_t chunk = D < 64u ? D : (D < 256u ? 64u * (D / 64u) : 256u);
             for (int c = 0; c < nch; ++c) {
                 float* ring = v.ext + s.ext_off + (size_t)c * D;
                 const float* in = io.in(c);
                 float* out = io.out(c);
                 for (uint32_t base = 0; base < (uint32_t)frames; base += chunk) {
-                    uint32_t i = base + (uint32_t)lane;
-                    if ((uint32_t)lane < chunk && i < (uint32_t)frames) {
-                        uint32_t slot = (pos + i) % D;
-                        float x = in[i];
-                        float d = ring[slot];
-                        ring[slot] = x + (d * fb);
-                        out[i] = (x * dry) + (d * mix);
+                    float x[4], d[4];
+                    uint32_t slot[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t j = (uint32_t)lane + 64u * q, i = base + j;
+                        x[q] = d[q] = 0.f;
+                        slot[q] = 0u;
+                        if (j < chunk && i < (uint32_t)frames) {
+                            slot[q] = (pos + i) % D;
+                            x[q] = in[i];
+                            d[q] = ring[slot[q]];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t j = (uint32_t)lane + 64u * q, i = base + j;
+                        if (j < chunk && i < (uint32_t)frames) {
+                            ring[slot[q]] = x[q] + (d[q] * fb);
+                            out[i] = (x[q] * dry) + (d[q] * mix);
+                        }
                     }
                     if (D < (uint32_t)frames) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // next chunk re-reads these slots
                 }

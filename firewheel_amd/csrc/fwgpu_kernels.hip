@@ -48,10 +48,13 @@ __device__ __forceinline__ v4f splat(float x) { return (v4f){x, x, x, x}; }
 int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t cmd_block0, int kinds) {
     if (n_nodes <= 0) return 0;
     if (K <= 0) return 0;
-    dim3 grid((n_nodes + WPB - 1) / WPB, (K + LEVEL_BPW - 1) / LEVEL_BPW);
-    if (kinds & 1) hipLaunchKernelGGL(k_level<0>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K);
-    if (kinds & 2) hipLaunchKernelGGL(k_level<1>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K);
-    if (kinds & 4) hipLaunchKernelGGL(k_level<2>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K);
+    // blocks per wave: enough (node, block) pairs to fill the chip several times over -> LEVEL_BPW; a narrow level -> 1
+    const long long pairs = (long long)n_nodes * K;
+    const uint32_t bpw = pairs >= 16384 ? LEVEL_BPW : (pairs >= 8192 ? 2u : 1u);
+    dim3 grid((n_nodes + WPB - 1) / WPB, (K + bpw - 1) / bpw);
+    if (kinds & 1) hipLaunchKernelGGL(k_level<0>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K, bpw);
+    if (kinds & 2) hipLaunchKernelGGL(k_level<1>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K, bpw);
+    if (kinds & 4) hipLaunchKernelGGL(k_level<2>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K, bpw);
     return (int)hipGetLastError();
 }
 int launch_frozen_scan(hipStream_t s, const DevView& v, int n_nodes, uint32_t cmd_block0, int K, uint8_t* d_frozen,

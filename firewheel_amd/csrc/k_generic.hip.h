@@ -707,21 +707,22 @@ __device__ void frozen_finish(const DevView& v, int node_idx, uint32_t K) {
 // to block is run by ONE wave that walks its K blocks in order; stateless nodes — and frozen ones — take their K
 // blocks in parallel.
 #ifndef LEVEL_BPW
-#define LEVEL_BPW 4  // consecutive blocks one wave takes for a stateless / frozen node
+#define LEVEL_BPW 4  // consecutive blocks one wave takes for a stateless / frozen node of a WIDE level
 #endif
-// gridDim.y = ceil(K / LEVEL_BPW): a wave takes LEVEL_BPW consecutive blocks of its node, so the node's descriptor, port
-// tables and state come from HBM once and from the cache for the other blocks (the per-block work is ~4 KB behind a
-// chain of dependent loads).
+// gridDim.y = ceil(K / bpw): a wave takes bpw consecutive blocks of its node, so the node's descriptor, port tables and
+// state come from HBM once and from the cache for the other blocks (the per-block work is ~4 KB behind a chain of dependent
+// loads).  bpw = LEVEL_BPW on a level with thousands of (node, block) pairs; a level of one or two bus nodes — the root of a
+// hybrid plan, a return chain — gets a wave per block instead: its blocks in sequence were 10-38 us per level of pure latency.
 template <int SET>
 __global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __restrict__ level_nodes, int n_nodes,
-                                                      uint32_t cmd_block0, uint32_t K) {
+                                                      uint32_t cmd_block0, uint32_t K, uint32_t bpw) {
     int w = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (w >= n_nodes) return;
     const int node = level_nodes[w];
     const int kind = v.nodes[node].kind;
     if (kind_set(kind) != SET) return;  // another instantiation's node
-    const uint32_t b0 = blockIdx.y * LEVEL_BPW;
-    const uint32_t b1 = b0 + LEVEL_BPW < K ? b0 + LEVEL_BPW : K;
+    const uint32_t b0 = blockIdx.y * bpw;
+    const uint32_t b1 = b0 + bpw < K ? b0 + bpw : K;
     if (kind_is_stateful(kind)) {
         const uint8_t fz = v.frozen ? v.frozen[node] : (uint8_t)0;
         if (fz) {

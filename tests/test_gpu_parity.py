@@ -685,6 +685,69 @@ def test_graph_edit_keeps_node_state_across_recompile():
     assert_bits_equal(ro, rg, "across graph edits")
 
 
+def test_plans_switch_between_fused_hybrid_and_levels_mid_stream():
+    """a send is patched into a running voice bank and pulled out again, then a spatialised copy of the root bus is added (graph
+    edits + recompile): voice-bank plan -> hybrid -> voice-bank plan -> hybrid; playheads, gliding smoothers and the
+    steady-call cache carry over (processor.rs:195-197: processors persist across schedules)"""
+    kinds = []
+
+    def run2(e):
+        rng = np.random.default_rng(3)
+        ends, voices = [], []
+        for v in range(24):
+            s = e.sampler(100.0)
+            vol = e.volume(float(rng.uniform(20, 100)))
+            e.connect_stereo(s, vol)
+            ends.append(vol)
+            voices.append((s, vol))
+        leaves = []
+        for i in range(0, 24, 6):
+            m = e.sum(6)
+            for p, n in enumerate(ends[i:i + 6]):
+                e.connect_stereo(n, m, 2 * p)
+            leaves.append(m)
+        root = e.sum(4)
+        for p, m in enumerate(leaves):
+            e.connect_stereo(m, root, 2 * p)
+        mix = e.sum(2)
+        e.connect_stereo(root, mix, 0)
+        e.connect_stereo(mix, e.graph_out_node)
+        e.update()
+        for v, (s, vol) in enumerate(voices):
+            e.sampler_set_sample(s, e.new_sample(PLANAR_F32, 2, scenarios.voice_source(4400 + v, 1500 + 7 * v, 2)))
+            e.sampler_set_loop_range(s, fwapi.LOOP_FULL)
+            e.sampler_play(s)
+        outs = [e.process_blocks(5)]
+        k = [e.cx.plan_kind()] if hasattr(e, "cx") else []
+        e.set_param(voices[3][1], 0, 8.0, at_block=1)              # a glide in flight across the edit
+        ret = e.volume(40.0)                                        # the send: leaf 1 -> ret -> mix port 1
+        e.connect_stereo(leaves[1], ret)
+        e.connect_stereo(ret, mix, 2)
+        e.update()
+        outs.append(e.process_blocks(6))
+        k += [e.cx.plan_kind()] if hasattr(e, "cx") else []
+        e.set_param(voices[9][1], 0, 90.0, at_block=2)
+        e.remove_node(ret)
+        e.update()
+        outs.append(e.process_blocks(6))
+        k += [e.cx.plan_kind()] if hasattr(e, "cx") else []
+        sp = e.spatial(1.0, 0.0, -2.0, n_in=2)                      # a spatialised copy of the root bus beside the dry one
+        e.connect_stereo(root, sp)
+        e.connect_stereo(sp, mix, 2)
+        e.update()
+        outs.append(e.process_blocks(6))
+        k += [e.cx.plan_kind()] if hasattr(e, "cx") else []
+        kinds.append(k)
+        return np.concatenate(outs)
+
+    o = oracle(max_block_frames=128)
+    g = GpuEngine(max_block_frames=128, max_batch=4)
+    ro = run2(o)
+    rg = run2(g)
+    assert kinds[-1] == [1, 3, 1, 3], kinds   # voice-bank plan -> hybrid -> voice-bank plan -> hybrid
+    assert_bits_equal(ro, rg, "across plan switches")
+
+
 # ------------------------------------------------------------------ error behaviour of the SPEC nodes (activate() -> Err)
 def test_spec_node_activation_and_argument_errors():
     from fwapi import FIR, RESAMPLER, SPATIAL, BIQUAD, DELAY

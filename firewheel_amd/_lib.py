@@ -50,6 +50,7 @@ SIGNATURES = {
     "fwgpu_update": (ci, [vp]),
     "fwgpu_schedule_upload": (ci, [vp, C.POINTER(SchedNode), u32, u32]),
     "fwgpu_plan_kind": (ci, [vp]),
+    "fwgpu_plan_fused_voices": (ci, [vp]),
     "fwgpu_plan_num_levels": (ci, [vp]),
     "fwgpu_plan_node_level": (ci, [vp, i64]),
     "fwgpu_plan_node_inputs_clear": (ci, [vp, i64, C.POINTER(ci), ci]),

@@ -402,6 +402,10 @@ int fwgpu_plan_kind(fwgpu_ctx* c) {
     if (c->force_generic) return 0;
     return c->fused ? (c->fused_fx ? 2 : 1) : (c->hybrid ? 3 : 0);
 }
+int fwgpu_plan_fused_voices(fwgpu_ctx* c) {
+    if (!c || !c->have_plan) return -1;
+    return (c->force_generic || !(c->fused || c->hybrid)) ? 0 : c->n_fused_real;
+}
 int fwgpu_plan_num_levels(fwgpu_ctx* c) { return c && c->have_plan ? c->plan.num_levels : -1; }
 int fwgpu_plan_node_level(fwgpu_ctx* c, int64_t node) {
     NEED_CTX(c, FWGPU_ERR_INVALID);

@@ -238,6 +238,7 @@ struct fwgpu_ctx {
     DevBuf d_rt_sync;           // its workgroup counter
     // hybrid plan (kind 3): voice-bank groups inside a graph the level executor runs — the level lists without the nodes
     // the fused kernels render
+    int n_fused_real = 0;  // voices (not null slots) the fused kernels render under the installed plan
     bool hybrid = false;
     bool hybrid_fx = false;  // ... and the banks hold biquad / delay voices: k_chain renders them
     DevBuf d_hlevel_nodes;
@@ -315,6 +316,15 @@ struct FusedBuild {
     bool has_fx = false;  // some chain holds a biquad / delay: the k_chain plan
     uint64_t min_delay = ~0ull;  // shortest delay line among the chains (frames)
     std::vector<int> covered;    // hybrid plan: plan indices of the nodes the fused kernels render (voice chains + their SumNode)
+    // hybrid plan: SumNodes that ALSO take other inputs behind their leading voice ports.  The voice-bank kernels sum the
+    // leading ports into a partial bus (the reference's accumulator at that point), the node itself stays on the levels as
+    // a continuation: (partial, the other ports...) on the path of its full port count
+    struct Split {
+        int sum;    // plan index of the SumNode
+        int leaf;   // index into `leaves`
+        int lead;   // leading voice ports taken by the leaf
+    };
+    std::vector<Split> splits;
 };
 bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedBuild& fb);
 // The hybrid plan (kind 3): the graph as a whole is not a fused shape, but it holds voice banks that are — SumNodes whose

@@ -276,6 +276,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         bool prog = false, rs = false, fx = false;
         int stages = 0, real = 0;
         uint64_t min_delay = ~0ull;
+        bool split = false;  // only the leading ports are voices: the SumNode stays on the levels as a continuation
     };
     std::vector<Bank> banks;
     std::vector<char> taken(N, 0);  // nodes of a candidate bank (a chain node feeds one consumer, so banks cannot overlap)
@@ -285,9 +286,10 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         if (s.out_buf[1] != s.out_buf[0] + 1) continue;  // the kernels write channel 1 in the row behind channel 0
         Bank bk;
         bk.sum = si;
-        bk.nodes.push_back(si);
         bool ok = true;
         for (int p = 0; ok && p < s.n_in / 2; ++p) {
+            const size_t nodes_before = bk.nodes.size();
+            const Bank before = bk;  // (a port that turns out not to be a voice chain leaves the bank as it was)
             VoiceDesc vd;
             memset(&vd, 0, sizeof(vd));
             vd.sampler_state = vd.bq_state = vd.dl_state = -1;
@@ -299,6 +301,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
             int cur;
             if (!stereo_src(s, 2 * p, cur)) {
                 ok = false;
+                bk = before;
                 break;
             }
             // walking upstream: gain stages, then [delay], then [biquad], then the source (as detect_fused)
@@ -348,7 +351,11 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
                 }
                 cur = src;
             }
-            if (!ok) break;
+            if (!ok) {
+                bk = before;
+                bk.nodes.resize(nodes_before);
+                break;
+            }
             vd.sampler_state = (int)plan.nodes[cur].slot;
             vd.src_kind = plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0;
             vd.bq_state = bq >= 0 ? (int)plan.nodes[bq].slot : -1;
@@ -373,7 +380,17 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
             bk.progs.push_back(pr);
             bk.real++;
         }
-        if (!ok || bk.real == 0) continue;
+        if (bk.real == 0) continue;
+        if (!ok) {
+            // the leading ports are voices, a later one is something else: split the node (the partial sum of the leading
+            // ports is the reference's accumulator at that point) — not for 2- / 3- / 4-port sums, whose paths are spelled out
+            // port by port (sum.rs:67-110), and not when nothing but null slots leads
+            const int P = s.n_in / 2;
+            if (P == 2 || P == 3 || P == 4) continue;
+            bk.split = true;
+        } else {
+            bk.nodes.push_back(si);
+        }
         for (int i : bk.nodes) taken[i] = 1;
         banks.push_back(std::move(bk));
     }
@@ -398,6 +415,15 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         ld.ports = (int)bk.voices.size();
         ld.out_buf = plan.nodes[bk.sum].out_buf[0];
         ld.pad = 0;
+        if (bk.split) {  // (out_buf: a partial bus of its own, numbered by install_plan; pad: the node's full port count)
+            FusedBuild::Split sp;
+            sp.sum = bk.sum;
+            sp.leaf = (int)fb.leaves.size();
+            sp.lead = ld.ports;
+            fb.splits.push_back(sp);
+            ld.out_buf = -1;
+            ld.pad = plan.nodes[bk.sum].n_in / 2;
+        }
         fb.leaves.push_back(ld);
         fb.voices.insert(fb.voices.end(), bk.voices.begin(), bk.voices.end());
         fb.progs.insert(fb.progs.end(), bk.progs.begin(), bk.progs.end());

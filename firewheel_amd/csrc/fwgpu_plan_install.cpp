@@ -22,7 +22,8 @@ static int upload_chain_groups(fwgpu_ctx* c, const std::vector<LeafDesc>& leaves
         g.row0[li] = g.n_voices;
         g.ports[li] = ld.ports;
         g.start_mask |= 1u << g.n_voices;
-        if (!(ld.ports == 2 || ld.ports == 3 || ld.ports == 4))  // sum.rs:67-133 (Q13): the n-port path skips silent ports
+        const int path_ports = ld.pad ? ld.pad : ld.ports;  // (a leaf that leads a wider SumNode takes that node's path)
+        if (!(path_ports == 2 || path_ports == 3 || path_ports == 4))  // sum.rs:67-133 (Q13): the n-port path skips silent ports
             g.masked_rows |= (ld.ports >= 32 ? 0xffffffffu : ((1u << ld.ports) - 1u)) << g.n_voices;
         g.n_voices += ld.ports;
     }
@@ -221,6 +222,16 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         c->ext_used = ext_need;
         c->graph.nodes_to_activate.clear();
     }
+    // (the launch plans are chosen before the tables are written: a hybrid plan with split SumNodes adds partial buses to the
+    // pool and continuation nodes to the node table)
+    FusedBuild fb, hb;
+    const bool is_fused = !c->force_generic && detect_fused(plan, c->graph, c->mbf, fb);
+    const bool is_hybrid = !is_fused && !c->force_generic && detect_hybrid(plan, c->graph, c->mbf, hb);
+    if (is_hybrid)
+        for (const FusedBuild::Split& sp : hb.splits) {  // a partial bus (two pool buffers) per split SumNode
+            hb.leaves[sp.leaf].out_buf = plan.num_buffers;
+            plan.num_buffers += 2;
+        }
     // 3. node tables (from here on the device tables of the OLD plan are being overwritten)
     *tables_touched = true;
     const int N = (int)plan.nodes.size();
@@ -246,6 +257,24 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         else if (p.is_graph_io == 2) gout_bufs = p.in_buf;
         else levels[p.level].push_back(i);
     }
+    // hybrid plan: the continuation of a split SumNode — (partial bus, the ports behind the leading voices) on the path of the
+    // node's full port count — as an extra entry behind the plan's nodes; the hybrid level lists name it instead of the node
+    std::vector<int> split_entry(N, -1);
+    if (is_hybrid)
+        for (const FusedBuild::Split& sp : hb.splits) {
+            const PlanNode& p = plan.nodes[sp.sum];
+            NodeDesc d = nd[sp.sum];
+            const int total = p.n_in / 2, rest = total - sp.lead;
+            d.in_off = (int)in_tab.size();
+            d.n_in = 2 * (1 + rest);
+            d.aux0 = (1 + rest) | (total << 16);
+            const int pb = hb.leaves[sp.leaf].out_buf;
+            in_tab.push_back(pb);
+            in_tab.push_back(pb + 1);
+            in_tab.insert(in_tab.end(), p.in_buf.begin() + 2 * sp.lead, p.in_buf.end());
+            split_entry[sp.sum] = (int)nd.size();
+            nd.push_back(d);
+        }
     if (in_tab.empty()) in_tab.push_back(0);
     if (out_tab.empty()) out_tab.push_back(0);
     int rc;
@@ -352,9 +381,8 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
     // 5. fused voice-bank plan
     c->fused = false;
     c->hybrid = false;
-    FusedBuild fb;
     c->fused_fx = false;
-    if (!c->force_generic && detect_fused(plan, c->graph, c->mbf, fb)) {
+    if (is_fused) {
         c->fused_fx = fb.has_fx;
         // k_chain tile = 64*nq frames: the larger tile needs whole tiles per block and every delay >= one tile
         c->chain_nq = (c->mbf % 128 == 0 && fb.min_delay >= 128) ? 2 : 1;
@@ -450,12 +478,13 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         if ((rc = upload(c, c->d_up_level_nodes, uflat.data(), uflat.size() * sizeof(int)))) return rc;
         if ((rc = upload(c, c->d_root_bufs, fb.root_buf, sizeof(fb.root_buf)))) return rc;
         c->fused = true;
+        c->n_fused_real = 0;
+        for (const VoiceDesc& vd : fb.voices) c->n_fused_real += vd.sampler_state >= 0 ? 1 : 0;
     }
     // 5b. hybrid plan: not a fused shape as a whole, but with voice banks inside that are
-    if (!c->fused && !c->force_generic) {
-        FusedBuild hb;
-        c->hybrid_fx = false;
-        if (detect_hybrid(plan, c->graph, c->mbf, hb)) {
+    c->hybrid_fx = false;
+    {
+        if (is_hybrid) {
             c->n_voices = (int)hb.voices.size();
             c->n_leaves = (int)hb.leaves.size();
             c->ramp_slots = 2 * (1 + hb.max_stages);
@@ -503,7 +532,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
                 int kinds = 0, cnt = 0;
                 for (int i : l)
                     if (!cov[i]) {
-                        hflat.push_back(i);
+                        hflat.push_back(split_entry[i] >= 0 ? split_entry[i] : i);
                         kinds |= 1 << host_kind_set(nd[i].kind);
                         cnt++;
                     }
@@ -513,12 +542,14 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
             if (hflat.empty()) hflat.push_back(0);
             if ((rc = upload(c, c->d_hlevel_nodes, hflat.data(), hflat.size() * sizeof(int)))) return rc;
             c->hybrid = true;
+            c->n_fused_real = 0;
+            for (const VoiceDesc& vd : hb.voices) c->n_fused_real += vd.sampler_state >= 0 ? 1 : 0;
         }
     }
     // k_frozen_scan's verdict tables (generic executor, K > 1): sized here, on the control thread — a process call never
     // allocates
-    HIPC(c, c->d_frozen.ensure(plan.nodes.size()));
-    HIPC(c, c->d_frozen_ph.ensure(plan.nodes.size() * sizeof(unsigned long long)));
+    HIPC(c, c->d_frozen.ensure(nd.size()));
+    HIPC(c, c->d_frozen_ph.ensure(nd.size() * sizeof(unsigned long long)));
     c->plan = plan;
     c->have_plan = true;
     c->graph.needs_compile = false;

@@ -67,7 +67,9 @@ struct NodeDesc {
     int n_in, n_out;
     int in_off, out_off;  // offsets into the port tables
     int state;            // NodeState index
-    int aux0;             // SUM: num_in_ports
+    int aux0;             // SUM: num_in_ports (low 16 bits); high 16 bits, when set: the port count whose path the node takes
+                          //      (sum.rs:67-133: 2 / 3 / 4 ports add unmasked, any other count skips silent ports) — the
+                          //      continuation of a SumNode whose leading voice ports were summed by the voice-bank kernels
     int is_graph_io;      // 1 = graph_in, 2 = graph_out (Dummy nodes the executor treats as I/O edges)
 };
 
@@ -233,7 +235,8 @@ struct LeafDesc {  // a SumNode whose ports are all voice chains (nodes/sum.rs)
     int first_voice;
     int ports;     // num_in_ports
     int out_buf;   // compact bus-buffer id of output channel 0 (channel 1 = +1)
-    int pad;
+    int pad;       // when set: the port count of the WHOLE SumNode (this leaf is its leading voice ports): decides the
+                   // masked / unmasked path (Q13) instead of `ports`
 };
 
 }  // namespace fwgpu

@@ -145,7 +145,8 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
         }
 
         case K_SUM: if constexpr (SET == 0 || SET == 3) {  // nodes/sum.rs:41-136
-            const int n_in = nd.n_in, n_out = nd.n_out, ports = nd.aux0;
+            const int n_in = nd.n_in, n_out = nd.n_out, ports = nd.aux0 & 0xffff;
+            const int path_ports = (nd.aux0 >> 16) ? (nd.aux0 >> 16) : ports;
             if (mask_all(in_mask, n_in)) {  // :52-56
                 out_mask = clear_all_outputs(io, 0, n_out);
                 break;
@@ -156,7 +157,7 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
                 out_mask = in_mask;
                 break;
             }
-            const bool masked = !(ports == 2 || ports == 3 || ports == 4);  // :67-133 (Q13)
+            const bool masked = !(path_ports == 2 || path_ports == 3 || path_ports == 4);  // :67-133 (Q13)
             // lane i keeps the buffer id of input channel i; ids are broadcast with v_readlane so the
             // per-port loads are independent and can be in flight together (8 at a time)
             int my_in = lane < n_in ? io.in_buf[lane] : 0;

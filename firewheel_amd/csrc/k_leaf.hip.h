@@ -518,7 +518,8 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
     const uint64_t silent_ports = __ballot((my_flags & VB_SILENT) != 0) & lanes_in;
     const uint64_t simple_ports = __ballot((my_flags & VB_SIMPLE) != 0) & lanes_in;
     const bool all_silent = silent_ports == lanes_in;
-    const bool masked = !(ld.ports == 2 || ld.ports == 3 || ld.ports == 4);  // sum.rs:67-133 (Q13)
+    const int path_ports = ld.pad ? ld.pad : ld.ports;  // (a leaf that is the leading voice ports of a wider SumNode takes ITS path)
+    const bool masked = !(path_ports == 2 || path_ports == 3 || path_ports == 4);  // sum.rs:67-133 (Q13)
     const bool all_simple = simple_ports == lanes_in && (frames & 3) == 0;
     const uint32_t cls0 = (uint32_t)__builtin_amdgcn_readlane((int)my_cls, 0);  // ports >= 1
     const bool one_class = (__ballot(my_cls == cls0) & lanes_in) == lanes_in;

@@ -402,6 +402,10 @@ class FirewheelGpuCtx(object):
     def plan_kind(self):
         return self.L.fwgpu_plan_kind(self.c)
 
+    def plan_fused_voices(self):
+        """voices of the installed plan that the fused kernels render (plan 3: the banks')"""
+        return self.L.fwgpu_plan_fused_voices(self.c)
+
     def plan_num_levels(self):
         return self.L.fwgpu_plan_num_levels(self.c)
 

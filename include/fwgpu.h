@@ -128,6 +128,9 @@ int fwgpu_schedule_upload(fwgpu_ctx* ctx, const fwgpu_sched_node* nodes, uint32_
  * 2 = fused chain plan (voices with a biquad / delay: k_chain), 3 = hybrid: voice banks inside a graph that is not a fused
  * shape as a whole (sends, bus effects, anything) are rendered by the voice-bank kernels, the rest by the level executor */
 int fwgpu_plan_kind(fwgpu_ctx* ctx);
+/* how many voices (source -> stages chains) of the installed plan the fused kernels render — all of them on plans 1 and 2,
+ * the banks' on plan 3, 0 on plan 0; -1 without a plan */
+int fwgpu_plan_fused_voices(fwgpu_ctx* ctx);
 int fwgpu_plan_num_levels(fwgpu_ctx* ctx);
 /* level of a node in the plan (graph_in = 0); negative if unknown */
 int fwgpu_plan_node_level(fwgpu_ctx* ctx, int64_t node);

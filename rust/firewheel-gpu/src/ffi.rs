@@ -80,6 +80,7 @@ extern "C" {
     pub fn fwgpu_update(ctx: *mut fwgpu_ctx) -> c_int;
     pub fn fwgpu_schedule_upload(ctx: *mut fwgpu_ctx, nodes: *const fwgpu_sched_node, n_nodes: u32, num_buffers: u32) -> c_int;
     pub fn fwgpu_plan_kind(ctx: *mut fwgpu_ctx) -> c_int;
+    pub fn fwgpu_plan_fused_voices(ctx: *mut fwgpu_ctx) -> c_int;
     pub fn fwgpu_plan_num_levels(ctx: *mut fwgpu_ctx) -> c_int;
     pub fn fwgpu_plan_node_level(ctx: *mut fwgpu_ctx, node: i64) -> c_int;
     pub fn fwgpu_plan_node_inputs_clear(ctx: *mut fwgpu_ctx, node: i64, should_clear: *mut c_int, cap: c_int) -> c_int;

@@ -69,7 +69,10 @@ void check_generic_node(const DevView& v, int idx, int K) {
     if (nd.state >= 0) touch(&v.states[nd.state], sizeof(NodeState));
     if (v.frozen) touch(v.frozen + idx, 1);
     if (v.frozen_playhead) touch(v.frozen_playhead + idx, 8);
-    if (nd.kind == K_SUM) REQUIRE(nd.n_out > 0 && nd.aux0 * nd.n_out == nd.n_in, nd.aux0, nd.n_in);
+    if (nd.kind == K_SUM) {  // aux0: port count (low half); high half, when set: the full port count of a split SumNode's continuation
+        REQUIRE(nd.n_out > 0 && (nd.aux0 & 0xffff) * nd.n_out == nd.n_in, nd.aux0, nd.n_in);
+        REQUIRE((nd.aux0 >> 16) == 0 || ((nd.aux0 >> 16) > (nd.aux0 & 0xffff) && (nd.aux0 >> 16) <= 32), nd.aux0);
+    }
 }
 void check_view_common(const DevView& v, int K) {
     REQUIRE(K >= 1, K);

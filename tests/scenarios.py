@@ -449,6 +449,88 @@ def scenario_hybrid_sends(e, n_a=26, n_b=11, src_frames=2100, seed=5, long_call=
     return np.concatenate(outs)
 
 
+def scenario_split_mixers(e, seed=21, long_call=30, src_frames=1300):
+    """mixers that take voices on their leading ports AND buses behind them (the usual master section: voices + a reverb return
+    + a sub-mix): the voice-bank kernels sum the leading voice ports into a partial bus — the reference's accumulator at that
+    point — and the SumNode itself continues on the level executor with (partial, the rest) on the path of its FULL port count
+    (Q13: 2 / 3 / 4 ports add silent inputs, any other count skips them).  Pauses make ports silent on both sides of the split
+    (whole leading groups too), a 5-port mixer and a 12-port one, a voice port BEHIND the bus (stays on the levels), a null
+    slot among the leading ports, a mono-to-stereo detour as the non-voice input, a send off the first mixer."""
+    rng = np.random.default_rng(seed)
+
+    def voice(i, fx=False):
+        ch = 1 if i % 5 == 1 else 2
+        smp = e.new_sample(PLANAR_F32, ch, voice_source(seed * 1000 + i, src_frames + 17 * i, ch))
+        s = e.sampler(100.0)
+        vol = e.volume(float(rng.uniform(20, 100)))
+        e.connect_stereo(s, vol)
+        cur = vol
+        if fx:
+            hc = e.hard_clip(-4.0)
+            e.connect_stereo(cur, hc)
+            cur = hc
+        return dict(sampler=s, smp=smp, volume=vol, end=cur)
+
+    # mixer A: 4 leading voices (one port of them empty), then a bus, = 6 ports... leading: v0 v1 - v2, then detour, then a voice
+    va = [voice(i) for i in range(4)]
+    side = e.sampler(60.0)
+    side_smp = e.new_sample(PLANAR_F32, 2, voice_source(seed * 1000 + 500, 900, 2))
+    s2m = e.add_node(STEREO_TO_MONO, 2, 1)
+    m2s = e.add_node(MONO_TO_STEREO, 1, 2)
+    e.connect_stereo(side, s2m)
+    e.connect(s2m, 0, m2s, 0)
+    mix_a = e.sum(7)
+    for p, vc in zip((0, 1, 3), va[:3]):      # port 2 stays empty: a null voice among the leading ports
+        e.connect_stereo(vc["end"], mix_a, 2 * p)
+    e.connect_stereo(m2s, mix_a, 8)            # port 4: the bus
+    e.connect_stereo(va[3]["end"], mix_a, 10)  # port 5: a voice BEHIND the bus (level executor); port 6 empty
+    # mixer B: 11 leading voices (some with a hard clip), then mixer A's bus as port 11  (12 ports)
+    vb = [voice(10 + i, fx=(i % 4 == 2)) for i in range(11)]
+    mix_b = e.sum(12)
+    for p, vc in enumerate(vb):
+        e.connect_stereo(vc["end"], mix_b, 2 * p)
+    e.connect_stereo(mix_a, mix_b, 22)
+    # a 3-port mixer with a bus (never split) and the master
+    vc3 = [voice(30 + i) for i in range(2)]
+    mix_c = e.sum(3)
+    for p, vc in enumerate(vc3):
+        e.connect_stereo(vc["end"], mix_c, 2 * p)
+    e.connect_stereo(mix_a, mix_c, 4)          # mixer A's bus is consumed twice
+    master = e.sum(2)
+    e.connect_stereo(mix_b, master, 0)
+    e.connect_stereo(mix_c, master, 2)
+    e.connect_stereo(master, e.graph_out_node)
+    e.update()
+    allv = va + vb + vc3
+    for vc in allv:
+        e.sampler_set_sample(vc["sampler"], vc["smp"])
+        e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        e.sampler_play(vc["sampler"])
+    e.sampler_set_sample(side, side_smp)
+    e.sampler_set_loop_range(side, LOOP_FULL)
+    e.sampler_play(side)
+    outs = [e.process_blocks(3)]
+    # silence on both sides of the splits: every leading voice of mixer A paused for a while, the bus paused, single voices
+    for vc in va[:3]:
+        e.sampler_pause(vc["sampler"], at_block=4)
+        e.sampler_play(vc["sampler"], at_block=11)
+    e.sampler_pause(side, at_block=8)
+    e.sampler_play(side, at_block=19)
+    for vc in vb[::3]:
+        e.sampler_pause(vc["sampler"], at_block=int(rng.integers(0, long_call // 2)))
+        e.sampler_play(vc["sampler"], at_block=int(rng.integers(long_call // 2, long_call)))
+    for vc in allv[1::4]:
+        e.set_param(vc["volume"], 0, float(rng.choice([0.0, 30.0, 110.0])), at_block=int(rng.integers(0, long_call)))
+    outs.append(e.process_blocks(long_call))
+    for vc in vb:
+        e.sampler_pause(vc["sampler"])         # the whole leading group of mixer B silent: the partial bus is flagged silent
+    outs.append(e.process_blocks(4))
+    for vc in vb[:5]:
+        e.sampler_play(vc["sampler"], at_block=1)
+    outs.append(e.process_blocks(5))
+    return np.concatenate(outs)
+
+
 def scenario_hybrid_chain_sends(e, n_voices=30, radix=6, src_frames=2300, seed=9, long_call=50):
     """banks of filtered voices (sampler -> biquad -> delay -> volume [-> pan]; some dry, one bank with a hard clip in a voice,
     which the chain plan does not take) whose buses are consumed twice: into the master sum and into a send -> width return.

@@ -110,6 +110,16 @@ def fuzz_run(e, seed):
              (lambda e: e.delay(int(rng.integers(20, 500)) / float(e.sample_rate), feedback=0.3, mix=0.3), 2, (0.0, 1.0))]
     chosen = [kinds[int(i)] for i in rng.integers(0, len(kinds), size=int(rng.integers(0, 4)))]
     top = level[0]
+    cross = [fp for fp in free_ports if fp[0] != leaf_sums[0]]
+    if cross and rng.random() < 0.3:
+        # a bus into a voice mixer: the first leaf's bus, through a gain, into the spare LAST port of another leaf — that leaf is
+        # voices on its leading ports and a bus behind them (the hybrid plan splits it: the voice-bank kernels sum the leading
+        # ports, the SumNode continues on the levels), and the first leaf's bus is consumed twice
+        port = cross[int(rng.integers(0, len(cross)))]
+        free_ports.remove(port)
+        xg = e.volume(float(rng.uniform(20, 90)))
+        e.connect_stereo(leaf_sums[0], xg)
+        e.connect_stereo(xg, port[0], port[1])
     if rng.random() < 0.35:
         # a send: one leaf bus is ALSO tapped into a return (a gain, sometimes a delay behind it) that joins the root in a
         # two-port sum — a bus consumed twice is no fused shape; the voice banks inside still are (hybrid plan: k_leaf_sum for

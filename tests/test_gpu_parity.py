@@ -212,6 +212,8 @@ def run_case(name, **gpu_kw):
         "hybrid_sends_b64": lambda e: scenarios.scenario_hybrid_sends(e, 17, 9, src_frames=900, seed=8, long_call=61),
         "hybrid_chain_sends_b128": scenarios.scenario_hybrid_chain_sends,
         "hybrid_chain_sends_b64": lambda e: scenarios.scenario_hybrid_chain_sends(e, 21, radix=7, src_frames=800, seed=12, long_call=70),
+        "split_mixers_b128": scenarios.scenario_split_mixers,
+        "split_mixers_b64": lambda e: scenarios.scenario_split_mixers(e, seed=22, long_call=45, src_frames=700),
         "storm_48x6": scenarios.scenario_message_storm,
         "storm_200x50_b64": lambda e: scenarios.scenario_message_storm(e, 200, radix=32, blocks=60, per_voice=50, src_frames=3000, seed=4),
         "mixed_generic": scenarios.scenario_mixed_generic,
@@ -245,7 +247,7 @@ def run_case(name, **gpu_kw):
                                                                           ir_channels=1),
     }[name]
     mbf = {"rs_bank_40": 128, "rs_bank_21_b64_i16_pure": 64, "voice_fx_steady": 256, "voice_fx_events_45": 128, "voice_fx_events_20_i16_r32": 64, "steady_fmt_p_i16_mono3": 128, "steady_fmt_i_f32": 64, "steady_fmt_i_u16": 64, "steady_fmt_p_i16_oddlen": 64,
-           "steady_fmt_mixed_leaf": 128, "events_33_i16": 128, "steady_96x32": 256, "steady_40x4_i16": 64, "steady_9x3_u16": 128, "events_70": 256, "events_33_r2": 128, "storm_48x6": 128, "storm_200x50_b64": 64, "hybrid_sends_b128": 128, "hybrid_sends_b64": 64, "hybrid_chain_sends_b128": 128, "hybrid_chain_sends_b64": 64, "spatial_steady_b128": 128, "spatial_steady_b64": 64,
+           "steady_fmt_mixed_leaf": 128, "events_33_i16": 128, "steady_96x32": 256, "steady_40x4_i16": 64, "steady_9x3_u16": 128, "events_70": 256, "events_33_r2": 128, "storm_48x6": 128, "storm_200x50_b64": 64, "hybrid_sends_b128": 128, "hybrid_sends_b64": 64, "split_mixers_b128": 128, "split_mixers_b64": 64, "hybrid_chain_sends_b128": 128, "hybrid_chain_sends_b64": 64, "spatial_steady_b128": 128, "spatial_steady_b64": 64,
            "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64, "cfg3_chain": 128, "cfg4_reverb": 128,
            "cfg4_reverb_2irs_mono": 64, "chain_steady_40": 256, "chain_steady_bq_only_i16": 64,
            "chain_steady_dl_only_pan": 128, "chain_events_37": 128, "chain_events_19_r2_pan": 64,
@@ -448,7 +450,8 @@ def test_config3_full_size_chain_plan_equals_generic_and_oracle_prefix():
     assert_bits_equal(oo, of[:oo.size], "4096 voices vs oracle")
 
 
-@pytest.mark.parametrize("name", ["hybrid_sends_b128", "hybrid_sends_b64", "hybrid_chain_sends_b128", "hybrid_chain_sends_b64"])
+@pytest.mark.parametrize("name", ["hybrid_sends_b128", "hybrid_sends_b64", "hybrid_chain_sends_b128", "hybrid_chain_sends_b64",
+                                  "split_mixers_b128", "split_mixers_b64"])
 @pytest.mark.parametrize("max_batch", [64, 8, 1])
 def test_hybrid_plan_voice_banks_inside_a_generic_graph_bit_exact(name, max_batch):
     """buses consumed twice (send + dry), a return chain, a spatialised source: not a fused shape — the three voice banks whose
@@ -683,6 +686,16 @@ def test_graph_edit_keeps_node_state_across_recompile():
     rg = run(g)
     assert g.cx.plan_kind() == 1
     assert_bits_equal(ro, rg, "across graph edits")
+
+
+def test_split_mixers_put_their_leading_voices_on_the_voice_bank_kernels():
+    out_o, out_g, g = run_case("split_mixers_b128")
+    # mixer A: 3 leading voices (+ a null slot) in front of its bus; mixer B: 11 in front of mixer A's bus; the 3-port mixer's two
+    # voices and the voice behind mixer A's bus stay on the level executor
+    assert g.cx.plan_kind() == 3 and g.cx.plan_fused_voices() == 14
+    assert_bits_equal(out_o, out_g, "split mixers")
+    out_o, out_g, g = run_case("hybrid_sends_b128")
+    assert g.cx.plan_fused_voices() == 26 + 11 + 9   # banks A1, A2, B whole; bank C's nine voices lead its bus port
 
 
 def test_plans_switch_between_fused_hybrid_and_levels_mid_stream():

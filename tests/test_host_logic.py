@@ -131,10 +131,48 @@ def test_hybrid_plan_selection_and_launch_sequence():
     e.process_interleaved(64 * 3 + 10)  # 3 whole blocks (hybrid) + a 10-frame tail (levels only)
     c = e.launches()
     assert (c["voice_control"], c["leaf_sum"]) == (1, 1)
+    assert e.cx.plan_fused_voices() == 12
     # fewer than 8 voices in fusable banks: not worth the two launches
     e2 = HostOnlyEngine(max_block_frames=64)
     send_graph(e2, n_voices=6, radix=3)
-    assert e2.cx.plan_kind() == 0
+    assert e2.cx.plan_kind() == 0 and e2.cx.plan_fused_voices() == 0
+
+
+def test_hybrid_plan_splits_a_mixer_that_also_takes_a_bus():
+    """a mixer SumNode with 10 voices on its leading ports and a return on its last: the voices are summed by the voice-bank
+    kernels into a partial bus, the node stays on the levels as the continuation (partial, return).  A 3-port mixer is not
+    split (its path is spelled out port by port in the reference), nor one whose FIRST port is the bus"""
+    def mixer(e, n_voices, bus_port_first=False):
+        ends = []
+        for v in range(n_voices):
+            s = e.sampler(90.0)
+            g = e.volume(40.0 + v)
+            e.connect_stereo(s, g)
+            ends.append(g)
+        side = e.sampler(50.0)          # something that is not a voice chain of this mixer: a sampler through a 1-in detour
+        s2m = e.add_node(fwapi.STEREO_TO_MONO, 2, 1)
+        m2s = e.add_node(fwapi.MONO_TO_STEREO, 1, 2)
+        e.connect_stereo(side, s2m)
+        e.connect(s2m, 0, m2s, 0)
+        mix = e.sum(n_voices + 1)
+        ports = list(range(n_voices + 1))
+        bus_port = 0 if bus_port_first else n_voices
+        vp = [p for p in ports if p != bus_port]
+        for p, n in zip(vp, ends):
+            e.connect_stereo(n, mix, 2 * p)
+        e.connect_stereo(m2s, mix, 2 * bus_port)
+        e.connect_stereo(mix, e.graph_out_node)
+        e.update()
+        return e
+
+    e = mixer(HostOnlyEngine(max_block_frames=64, max_batch=8), 10)
+    assert e.cx.plan_kind() == 3 and e.cx.plan_fused_voices() == 10
+    e.reset_launches()
+    e.process_blocks(8)
+    c = e.launches()
+    assert (c["voice_control"], c["leaf_sum"]) == (1, 1) and c["level"] >= 3   # detour levels + the continuation
+    assert mixer(HostOnlyEngine(max_block_frames=64), 10, bus_port_first=True).cx.plan_kind() == 0
+    assert mixer(HostOnlyEngine(max_block_frames=64), 2).cx.plan_kind() == 0          # a 3-port sum: never split
 
 
 def test_imported_reference_schedule_selects_the_same_plan_and_levels():

@@ -53,6 +53,8 @@ CASES = {
     "hybrid_chain_sends_b128": lambda: scenarios.scenario_hybrid_chain_sends(oracle(max_block_frames=128)),
     "hybrid_chain_sends_b64": lambda: scenarios.scenario_hybrid_chain_sends(oracle(max_block_frames=64), 21, radix=7, src_frames=800, seed=12,
                                                                              long_call=70),
+    "split_mixers_b128": lambda: scenarios.scenario_split_mixers(oracle(max_block_frames=128)),
+    "split_mixers_b64": lambda: scenarios.scenario_split_mixers(oracle(max_block_frames=64), seed=22, long_call=45, src_frames=700),
     "storm_48x6": lambda: scenarios.scenario_message_storm(oracle(max_block_frames=128)),
     "storm_200x50_b64": lambda: scenarios.scenario_message_storm(oracle(max_block_frames=64), 200, radix=32, blocks=60, per_voice=50,
                                                                  src_frames=3000, seed=4),

@@ -141,9 +141,15 @@ impl GpuContext {
         .map(|_| ())
     }
 
-    /// 0 = generic level-batched executor, 1 = fused voice-bank plan, 2 = fused chain plan.
+    /// 0 = generic level-batched executor, 1 = fused voice-bank plan, 2 = fused chain plan, 3 = hybrid (voice banks on the fused
+    /// kernels inside a graph the level executor runs).
     pub fn plan_kind(&self) -> i32 {
         unsafe { ffi::fwgpu_plan_kind(self.as_ptr()) }
+    }
+
+    /// Voices of the installed plan that the fused kernels render (plan 3: the voice banks' and the split mixers' leading ones).
+    pub fn plan_fused_voices(&self) -> i32 {
+        unsafe { ffi::fwgpu_plan_fused_voices(self.as_ptr()) }
     }
 }
 

@@ -3,6 +3,24 @@
 
 namespace fwgpu {
 
+// what the control kernel writes and the render kernels read, per voice and block of a batch (both fused plans and the hybrid one)
+static int alloc_voice_tables(fwgpu_ctx* c) {
+    const size_t K = c->kmax;
+    HIPC(c, c->d_blks.ensure(K * c->n_voices * sizeof(VoiceBlk)));
+    HIPC(c, c->d_refs.ensure(ref_count(c->n_voices, K) * sizeof(VoiceRef)));
+    HIPC(c, c->d_gsets.ensure((size_t)c->n_voices * FW_GSETS * sizeof(GainSet)));
+    HIPC(c, c->d_chain_start.ensure((size_t)c->n_voices * sizeof(ChainStart)));
+    HIPC(c, c->d_chain_dummy.ensure(64 * 1024));
+    HIPC(c, c->d_chain_stats.ensure(2 * sizeof(unsigned long long)));
+    HIPC(c, hipMemset(c->d_chain_stats.p, 0, 2 * sizeof(unsigned long long)));
+    HIPC(c, hipMemset(c->d_chain_start.p, 0, (size_t)c->n_voices * sizeof(ChainStart)));
+    HIPC(c, c->d_cache.ensure((size_t)c->n_voices * sizeof(VoiceCache)));
+    HIPC(c, hipMemset(c->d_cache.p, 0, (size_t)c->n_voices * sizeof(VoiceCache)));
+    c->epoch++;
+    HIPC(c, c->d_ramps.ensure(K * c->n_voices * (size_t)c->ramp_slots * c->stride * sizeof(float)));
+    return 0;
+}
+
 // k_chain workgroups: consecutive leaves packed greedily into groups of <= 32 voices / <= 8 leaves (the voices of
 // consecutive leaves are consecutive), so that a tree of small leaves fills the 32 voice rows
 static int upload_chain_groups(fwgpu_ctx* c, const std::vector<LeafDesc>& leaves) {
@@ -403,18 +421,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
             if ((rc = upload_chain_groups(c, fb.leaves))) return rc;
         }
         const size_t K = c->kmax;
-        HIPC(c, c->d_blks.ensure(K * c->n_voices * sizeof(VoiceBlk)));
-        HIPC(c, c->d_refs.ensure(ref_count(c->n_voices, K) * sizeof(VoiceRef)));
-        HIPC(c, c->d_gsets.ensure((size_t)c->n_voices * FW_GSETS * sizeof(GainSet)));
-        HIPC(c, c->d_chain_start.ensure((size_t)c->n_voices * sizeof(ChainStart)));
-        HIPC(c, c->d_chain_dummy.ensure(64 * 1024));
-        HIPC(c, c->d_chain_stats.ensure(2 * sizeof(unsigned long long)));
-        HIPC(c, hipMemset(c->d_chain_stats.p, 0, 2 * sizeof(unsigned long long)));
-        HIPC(c, hipMemset(c->d_chain_start.p, 0, (size_t)c->n_voices * sizeof(ChainStart)));
-        HIPC(c, c->d_cache.ensure((size_t)c->n_voices * sizeof(VoiceCache)));
-        HIPC(c, hipMemset(c->d_cache.p, 0, (size_t)c->n_voices * sizeof(VoiceCache)));
-        c->epoch++;
-        HIPC(c, c->d_ramps.ensure(K * c->n_voices * (size_t)c->ramp_slots * c->stride * sizeof(float)));
+        if ((rc = alloc_voice_tables(c))) return rc;
         if (c->ctl_ahead && c->ctl_stream && !c->fused_fx && fb.tail_nodes.empty() && K > 1) {
             // the second copy of what the control kernel writes and the render kernels read
             bool ok = c->d_blks2.ensure(K * c->n_voices * sizeof(VoiceBlk)) == hipSuccess &&
@@ -483,8 +490,8 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
     }
     // 5b. hybrid plan: not a fused shape as a whole, but with voice banks inside that are
     c->hybrid_fx = false;
-    {
-        if (is_hybrid) {
+    if (is_hybrid) {
+        {
             c->n_voices = (int)hb.voices.size();
             c->n_leaves = (int)hb.leaves.size();
             c->ramp_slots = 2 * (1 + hb.max_stages);
@@ -498,9 +505,6 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
                 if (const char* e = getenv("FWGPU_CHAIN_NQ")) {
                     if (atoi(e) == 1) c->chain_nq = 1;
                 }
-                HIPC(c, c->d_chain_dummy.ensure(64 * 1024));
-                HIPC(c, c->d_chain_stats.ensure(2 * sizeof(unsigned long long)));
-                HIPC(c, hipMemset(c->d_chain_stats.p, 0, 2 * sizeof(unsigned long long)));
                 c->generic_k = std::min<uint32_t>(c->generic_k, CH_FAST_KMAX);
             }
             c->n_tail = 0;
@@ -510,16 +514,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
             if ((rc = upload(c, c->d_voices, hb.voices.data(), hb.voices.size() * sizeof(VoiceDesc)))) return rc;
             if ((rc = upload(c, c->d_leaves, hb.leaves.data(), hb.leaves.size() * sizeof(LeafDesc)))) return rc;
             if ((rc = upload(c, c->d_progs, hb.progs.data(), hb.progs.size() * sizeof(uint32_t)))) return rc;
-            const size_t K = c->kmax;
-            HIPC(c, c->d_blks.ensure(K * c->n_voices * sizeof(VoiceBlk)));
-            HIPC(c, c->d_refs.ensure(ref_count(c->n_voices, K) * sizeof(VoiceRef)));
-            HIPC(c, c->d_gsets.ensure((size_t)c->n_voices * FW_GSETS * sizeof(GainSet)));
-            HIPC(c, c->d_chain_start.ensure((size_t)c->n_voices * sizeof(ChainStart)));
-            HIPC(c, hipMemset(c->d_chain_start.p, 0, (size_t)c->n_voices * sizeof(ChainStart)));
-            HIPC(c, c->d_cache.ensure((size_t)c->n_voices * sizeof(VoiceCache)));
-            HIPC(c, hipMemset(c->d_cache.p, 0, (size_t)c->n_voices * sizeof(VoiceCache)));
-            c->epoch++;
-            HIPC(c, c->d_ramps.ensure(K * c->n_voices * (size_t)c->ramp_slots * c->stride * sizeof(float)));
+            if ((rc = alloc_voice_tables(c))) return rc;
             // the level lists without the nodes the voice-bank kernels render
             std::vector<char> cov(N, 0);
             for (int i : hb.covered) cov[i] = 1;

@@ -91,6 +91,8 @@ inline int host_kind_set(int kind) {
     if (kind == K_SAMPLER) return 2;
     return (kind == K_BEEP || kind == K_BIQUAD || kind == K_DELAY || kind == K_RESAMPLER || kind == K_SPATIAL) ? 1 : 0;
 }
+// a level's launch bits: the kernel set of the kind, plus bit 3 for a biquad / delay (a bus one goes to the batch walkers)
+inline int host_kind_bits(int kind) { return (1 << host_kind_set(kind)) | ((kind == K_BIQUAD || kind == K_DELAY) ? 8 : 0); }
 
 struct TimerCat {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;

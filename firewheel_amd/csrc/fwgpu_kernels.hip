@@ -52,9 +52,13 @@ int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int 
     const long long pairs = (long long)n_nodes * K;
     const uint32_t bpw = pairs >= 16384 ? LEVEL_BPW : (pairs >= 8192 ? 2u : 1u);
     dim3 grid((n_nodes + WPB - 1) / WPB, (K + bpw - 1) / bpw);
-    if (kinds & 1) hipLaunchKernelGGL(k_level<0>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K, bpw);
-    if (kinds & 2) hipLaunchKernelGGL(k_level<1>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K, bpw);
-    if (kinds & 4) hipLaunchKernelGGL(k_level<2>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K, bpw);
+    // kinds bit 3: the level holds a biquad / delay node — in a batch, the ones that are bus effects go to the walkers' kernel
+    const uint32_t walkers = (kinds & 8) && K > 1 ? 1u : 0u;
+    if (kinds & 1) hipLaunchKernelGGL(k_level<0>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K, bpw, 0u);
+    if (kinds & 2) hipLaunchKernelGGL(k_level<1>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K, bpw, walkers);
+    if (kinds & 4) hipLaunchKernelGGL(k_level<2>, grid, dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K, bpw, 0u);
+    if (walkers)
+        hipLaunchKernelGGL(k_bus_iir, dim3((n_nodes + WPB - 1) / WPB), dim3(WAVE * WPB), 0, s, v, d_level_nodes, n_nodes, cmd_block0, (uint32_t)K);
     return (int)hipGetLastError();
 }
 int launch_frozen_scan(hipStream_t s, const DevView& v, int n_nodes, uint32_t cmd_block0, int K, uint8_t* d_frozen,

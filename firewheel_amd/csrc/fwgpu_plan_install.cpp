@@ -308,7 +308,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         c->level_cnt.push_back((int)l.size());
         flat.insert(flat.end(), l.begin(), l.end());
         int kinds = 0;
-        for (int i : l) kinds |= 1 << host_kind_set(nd[i].kind);
+        for (int i : l) kinds |= host_kind_bits(nd[i].kind);
         c->level_kinds.push_back(kinds);
     }
     if (flat.empty()) flat.push_back(0);
@@ -458,7 +458,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         c->up_root_node = (!fb.up_levels.empty() && fb.up_levels.back().size() == 1) ? fb.up_levels.back()[0] : -1;
         c->n_tail = (int)fb.tail_nodes.size();
         c->tail_kinds.clear();
-        for (const NodeDesc& t : fb.tail_nodes) c->tail_kinds.push_back(1 << host_kind_set(t.kind));
+        for (const NodeDesc& t : fb.tail_nodes) c->tail_kinds.push_back(host_kind_bits(t.kind));
         if (c->n_tail) {
             c->up_root_node = -1;  // the root's planar result feeds the master chain: no fused root + interleave
             std::vector<int> idx(c->n_tail);
@@ -528,7 +528,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
                 for (int i : l)
                     if (!cov[i]) {
                         hflat.push_back(split_entry[i] >= 0 ? split_entry[i] : i);
-                        kinds |= 1 << host_kind_set(nd[i].kind);
+                        kinds |= host_kind_bits(nd[i].kind);
                         cnt++;
                     }
                 c->hlevel_cnt.push_back(cnt);

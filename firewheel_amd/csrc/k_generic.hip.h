@@ -17,7 +17,99 @@ struct WaveIO {
 
 // generic biquad: LDS staging rows (channels x 256 frames, padded off the 32-bank period)
 #define BQ_LDS_CH 4
-#define BQ_LDS_PITCH 260
+#define BQ_LDS_PITCH 264  // 2 history samples + 256 frames, rows 16-byte aligned
+// (one set of rows per wave of the workgroup, shared by the per-block path and the batch walker)
+__shared__ float g_bq_lds[WPB][3][BQ_LDS_CH][BQ_LDS_PITCH];
+// generic biquad through LDS, 256 frames at a time.  Rows of one wave: X[c] = (x2, x1, x[0..n)) — the two samples of history in
+// front —, FF[c], Y[c].  Phase A, all 64 lanes, a frame each: the feed-forward half ff[i] = ((b0*x[i]) + (b1*x[i-1])) + (b2*x[i-2]),
+// unfused, exactly the three operations of the serial formulation — it does not depend on the output.  Phase B, lane c alone:
+// y[i] = fma(-a1, y[i-1], fma(-a2, y[i-2], ff[i])), four frames per LDS access.  A wave issues one instruction per 4 clocks
+// whatever its lanes do, so the serial part is what counts: 2 fma per frame instead of 5 operations (26 -> ~7 ns per frame).
+// (the rows are named through the array itself, not through pointers: a pointer to LDS kept in a struct decays to a generic one
+// and the accesses to flat instructions)
+struct BqRows {
+    int w;  // wave of the workgroup
+};
+__device__ __forceinline__ BqRows bq_rows() { return BqRows{(int)((threadIdx.x >> 6) % WPB)}; }
+#define BQ_X(r, c) g_bq_lds[(r).w][0][c]
+#define BQ_FF(r, c) g_bq_lds[(r).w][1][c]
+#define BQ_Y(r, c) g_bq_lds[(r).w][2][c]
+__device__ __forceinline__ void bq_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// before: X[c][2 + i] hold the chunk's input (any lanes wrote them); lane c < nch holds channel c's state in x1, x2, y1, y2
+// after: Y[c][0..n) hold the output, the state is the chunk's last; ends on a wave barrier
+__device__ __forceinline__ void bq_filter_chunk(const BqRows& r, int nch, int lane, int n, float b0, float b1, float b2, float a1, float a2,
+                                                float& x1, float& x2, float& y1, float& y2) {
+    if (lane < nch) {
+        BQ_X(r, lane)[0] = x2;
+        BQ_X(r, lane)[1] = x1;
+    }
+    bq_wave_sync();
+    for (int c = 0; c < nch; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            if (i < n) {
+                float acc = b0 * BQ_X(r, c)[2 + i];
+                acc = acc + (b1 * BQ_X(r, c)[1 + i]);
+                acc = acc + (b2 * BQ_X(r, c)[i]);
+                BQ_FF(r, c)[i] = acc;
+            }
+        }
+    bq_wave_sync();
+    if (lane < nch) {
+        const float* f = BQ_FF(r, lane);
+        float* yo = BQ_Y(r, lane);
+        int i = 0;
+        // eight frames per step, the NEXT eight requested before these are filtered and stored (an LDS read behind the store of
+        // the previous step would wait out its ~100 clocks of latency every four frames: the rows may alias for all the compiler
+        // knows)
+        v4f c0 = splat(0.f), c1 = splat(0.f);
+        if (n >= 8) {
+            c0 = *(const v4f*)(f);
+            c1 = *(const v4f*)(f + 4);
+        }
+        for (; i + 8 <= n; i += 8) {
+            const int nxt = i + 16 <= n ? i + 8 : i;  // (the last step re-reads itself)
+            const v4f n0 = *(const v4f*)(f + nxt), n1 = *(const v4f*)(f + nxt + 4);
+            v4f yv0, yv1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = __builtin_fmaf(-a2, y2, c0[e]);
+                acc = __builtin_fmaf(-a1, y1, acc);
+                y2 = y1;
+                y1 = acc;
+                yv0[e] = acc;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = __builtin_fmaf(-a2, y2, c1[e]);
+                acc = __builtin_fmaf(-a1, y1, acc);
+                y2 = y1;
+                y1 = acc;
+                yv1[e] = acc;
+            }
+            *(v4f*)(yo + i) = yv0;
+            *(v4f*)(yo + i + 4) = yv1;
+            c0 = n0;
+            c1 = n1;
+        }
+        for (; i < n; ++i) {
+            float acc = __builtin_fmaf(-a2, y2, f[i]);
+            acc = __builtin_fmaf(-a1, y1, acc);
+            y2 = y1;
+            y1 = acc;
+            yo[i] = acc;
+        }
+        x1 = BQ_X(r, lane)[1 + n];  // x[n-1]
+        x2 = BQ_X(r, lane)[n];      // x[n-2]  (n == 1: the old x1, which sits at X[1])
+    }
+    bq_wave_sync();
+}
+
 
 // core/util.rs:165-175
 __device__ __forceinline__ uint64_t clear_all_outputs(const WaveIO& io, int first, int n_out) {
@@ -389,50 +481,24 @@ __device__ void node_process_wave(const DevView& v, int node_idx, uint32_t blk, 
                 // the samples read from global memory inside the loop every frame paid a memory round trip behind the
                 // previous frame's store (in and out may alias as far as the compiler knows): 19 us per 256-frame block, and a
                 // bus filter is ONE such chain over all K blocks of a call.  Same operations, same order.
-                __shared__ float s_bq[WPB][2][BQ_LDS_CH][BQ_LDS_PITCH];
-                float(*xin)[BQ_LDS_PITCH] = s_bq[(threadIdx.x >> 6) % WPB][0];
-                float(*yout)[BQ_LDS_PITCH] = s_bq[(threadIdx.x >> 6) % WPB][1];
-                float b0 = 0.f, b1 = 0.f, b2 = 0.f, a1 = 0.f, a2 = 0.f, x1 = 0.f, x2 = 0.f, y1 = 0.f, y2 = 0.f;
+                const BqRows rows = bq_rows();
+                // (the coefficients are the node's, every lane holds them for phase A; the state is per channel, in lane c)
+                const float b0 = ext[0], b1 = ext[1], b2 = ext[2], a1 = ext[3], a2 = ext[4];
+                float x1 = 0.f, x2 = 0.f, y1 = 0.f, y2 = 0.f;
                 float* st = ext + 5 + 4 * (lane < nch ? lane : 0);
-                if (lane < nch) {
-                    b0 = ext[0], b1 = ext[1], b2 = ext[2], a1 = ext[3], a2 = ext[4];
-                    x1 = st[0], x2 = st[1], y1 = st[2], y2 = st[3];
-                }
+                if (lane < nch) x1 = st[0], x2 = st[1], y1 = st[2], y2 = st[3];
                 for (int base = 0; base < frames; base += 256) {
                     const int n = frames - base < 256 ? frames - base : 256;
                     for (int c = 0; c < nch; ++c) {
                         const float* in = io.in(c) + base;
-                        for (int f = lane; f < n; f += WAVE) xin[c][f] = in[f];
+                        for (int f = lane; f < n; f += WAVE) BQ_X(rows, c)[2 + f] = in[f];
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (lane < nch) {
-                        const float* xi = xin[lane];
-                        float* yo = yout[lane];
-                        for (int i = 0; i < n; ++i) {
-                            const float x = xi[i];
-                            float acc = b0 * x;
-                            acc = acc + (b1 * x1);
-                            acc = acc + (b2 * x2);
-                            acc = __builtin_fmaf(-a2, y2, acc);
-                            acc = __builtin_fmaf(-a1, y1, acc);
-                            x2 = x1;
-                            x1 = x;
-                            y2 = y1;
-                            y1 = acc;
-                            yo[i] = acc;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    bq_filter_chunk(rows, nch, lane, n, b0, b1, b2, a1, a2, x1, x2, y1, y2);
                     for (int c = 0; c < nch; ++c) {
                         float* out = io.out(c) + base;
-                        for (int f = lane; f < n; f += WAVE) out[f] = yout[c][f];
+                        for (int f = lane; f < n; f += WAVE) out[f] = BQ_Y(rows, c)[f];
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();  // (the next 256 frames overwrite the staging rows)
+                    bq_wave_sync();  // (the next 256 frames overwrite the rows)
                 }
                 if (lane < nch) {
                     st[0] = x1;
@@ -704,6 +770,166 @@ __device__ void frozen_finish(const DevView& v, int node_idx, uint32_t K) {
     if (lane == 0) v.states[nd.state] = s;
 }
 
+// A bus biquad (<= 4 channels) with no message inside the batch: ONE wave walks the node's K blocks with everything that does
+// not change from block to block — descriptor, port tables, coefficients, filter state — held in registers, the next 256
+// frames of input requested before the current ones are filtered (every block's input is already there: the level above
+// ran for the whole batch), the recurrence on LDS operands.  node_process_wave, called block by block, re-reads all of that
+// behind the previous block's state store: ~8 us per block against ~1.5 us here — and a bus filter is one serial chain over
+// all the blocks of a call.  Same operations in the same order as the K_BIQUAD case above.
+__device__ __forceinline__ bool biquad_walk_ok(const DevView& v, const NodeDesc& nd, uint32_t cmd_block0, uint32_t K) {
+    const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
+    if (nd.kind != K_BIQUAD || nch < 1 || nch > 2 || K < 2 || (v.frames & 255)) return false;  // mono / stereo, whole 256-frame chunks
+    if (v.n_cmds) {
+        const int c = chain_cmd_lower_bound(v.cmds, v.n_cmds, nd.state, cmd_block0);
+        if (c < v.n_cmds && v.cmds[c].state == nd.state && v.cmds[c].block < cmd_block0 + K) return false;
+    }
+    return true;
+}
+// (NCH = 1 or 2 and whole chunks: every load and store of the loop is unconditional, so that the compiler counts them and waits
+// for the prefetched chunk with an exact vmcnt(N) — behind a predicate it falls back to vmcnt(0), which also waits for the
+// chunk's own stores: a full memory round trip per chunk, 4.5 us instead of ~1.5)
+template <int NCH>
+__device__ __forceinline__ void biquad_walk(const DevView& v, const NodeDesc& nd, uint32_t K) {
+    const BqRows rows = bq_rows();
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int frames = v.frames;
+    float* ext = v.ext + v.states[nd.state].ext_off;
+    int ib[NCH], ob[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        ib[c] = (v.in_buf + nd.in_off)[c];
+        ob[c] = (v.out_buf + nd.out_off)[c];
+    }
+    const int my_out = lane < nd.n_out ? (v.out_buf + nd.out_off)[lane] : 0;
+    const float b0 = ext[0], b1 = ext[1], b2 = ext[2], a1 = ext[3], a2 = ext[4];
+    float x1 = 0.f, x2 = 0.f, y1 = 0.f, y2 = 0.f;
+    float* st = ext + 5 + 4 * (lane < NCH ? lane : 0);
+    if (lane < NCH) x1 = st[0], x2 = st[1], y1 = st[2], y2 = st[3];
+    // chunk i = 256 frames: (block, base); lane l keeps frames l, l + 64, l + 128, l + 192 of each channel
+    const int cpb = frames / 256;
+    const uint32_t n_chunks = K * (uint32_t)cpb;
+    float nx[NCH][4];
+    auto fetch = [&](uint32_t ci) {
+        const uint32_t b = ci / (uint32_t)cpb;
+        const int base = (int)(ci % (uint32_t)cpb) * 256;
+        const float* pool = v.pool + (size_t)b * v.pool_blk_stride + base + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nx[c][q] = pool[(size_t)ib[c] * v.stride + 64 * q];
+    };
+    fetch(0);
+    for (uint32_t ci = 0; ci < n_chunks; ++ci) {
+        const uint32_t b = ci / (uint32_t)cpb;
+        const int base = (int)(ci % (uint32_t)cpb) * 256;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) BQ_X(rows, c)[2 + lane + 64 * q] = nx[c][q];
+        fetch(ci + 1 < n_chunks ? ci + 1 : ci);  // in flight while this chunk is filtered (the last one re-reads itself: one path)
+        bq_filter_chunk(rows, NCH, lane, 256, b0, b1, b2, a1, a2, x1, x2, y1, y2);
+        float* pool = v.pool + (size_t)b * v.pool_blk_stride + base + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pool[(size_t)ob[c] * v.stride + 64 * q] = BQ_Y(rows, c)[lane + 64 * q];
+        // schedule.rs:338-341: the node's out mask (0: a filter never reports silence) overwrites its output buffers' flags
+        if (base == 0 && lane < nd.n_out) (v.flags + (size_t)b * v.flags_blk_stride)[my_out] = 0;
+        bq_wave_sync();  // (the next chunk overwrites the rows)
+    }
+    if (lane < NCH) {
+        st[0] = x1;
+        st[1] = x2;
+        st[2] = y1;
+        st[3] = y2;
+    }
+}
+
+// The same for a bus delay of at least 512 frames (<= 4 channels, no message inside the batch): 256 frames at a time, the next
+// chunk's input AND ring slots requested before this chunk's are written (two chunks span less than the ring: they cannot
+// meet), nothing re-read per block.  Same operations as the K_DELAY case above.
+__device__ __forceinline__ bool delay_walk_ok(const DevView& v, const NodeDesc& nd, uint32_t cmd_block0, uint32_t K) {
+    const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
+    if (nd.kind != K_DELAY || nch < 1 || nch > 2 || K < 2 || (v.frames & 255)) return false;  // mono / stereo, whole 256-frame chunks
+    if (v.states[nd.state].loop_end < 512) return false;
+    if (v.n_cmds) {
+        const int c = chain_cmd_lower_bound(v.cmds, v.n_cmds, nd.state, cmd_block0);
+        if (c < v.n_cmds && v.cmds[c].state == nd.state && v.cmds[c].block < cmd_block0 + K) return false;
+    }
+    return true;
+}
+template <int NCH>
+__device__ __forceinline__ void delay_walk(const DevView& v, const NodeDesc& nd, uint32_t K) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int frames = v.frames;
+    NodeState* const sp = &v.states[nd.state];  // (field by field: a struct copy from global memory ends up in scratch)
+    const uint32_t D = (uint32_t)sp->loop_end;
+    const float fb = sp->p0, mix = sp->p1, dry = sp->gain;
+    float* const ring0 = v.ext + sp->ext_off;
+    int ib[NCH], ob[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        ib[c] = (v.in_buf + nd.in_off)[c];
+        ob[c] = (v.out_buf + nd.out_off)[c];
+    }
+    const int my_out = lane < nd.n_out ? (v.out_buf + nd.out_off)[lane] : 0;
+    const int cpb = frames / 256;
+    const uint32_t n_chunks = K * (uint32_t)cpb;
+    float nx[NCH][4], ndl[NCH][4];
+    uint32_t nslot[4];
+    uint32_t pos = (uint32_t)sp->playhead;  // ring position of the chunk being fetched
+    uint32_t pos_after = pos;                // ... and behind the last chunk WRITTEN
+    auto fetch = [&](uint32_t ci, uint32_t at) {
+        const uint32_t b = ci / (uint32_t)cpb;
+        const int base = (int)(ci % (uint32_t)cpb) * 256;
+        const float* pool = v.pool + (size_t)b * v.pool_blk_stride + base + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t sl = at + (uint32_t)lane + 64u * q;  // at < D, offset < 256 <= D / 2: at most one wrap
+            nslot[q] = sl >= D ? sl - D : sl;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                nx[c][q] = pool[(size_t)ib[c] * v.stride + 64 * q];
+                ndl[c][q] = ring0[(size_t)c * D + nslot[q]];
+            }
+    };
+    fetch(0, pos);
+    for (uint32_t ci = 0; ci < n_chunks; ++ci) {
+        const uint32_t b = ci / (uint32_t)cpb;
+        const int base = (int)(ci % (uint32_t)cpb) * 256;
+        float x[NCH][4], d[NCH][4];
+        uint32_t slot[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) slot[q] = nslot[q];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                x[c][q] = nx[c][q];
+                d[c][q] = ndl[c][q];
+            }
+        pos_after = pos + 256u;
+        if (pos_after >= D) pos_after -= D;
+        // the next chunk's input and ring slots, in flight while this chunk is written (the last chunk re-reads itself: one path)
+        const bool more = ci + 1 < n_chunks;
+        fetch(more ? ci + 1 : ci, more ? pos_after : pos);
+        pos = pos_after;
+        float* pool = v.pool + (size_t)b * v.pool_blk_stride + base + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ring0[(size_t)c * D + slot[q]] = x[c][q] + (d[c][q] * fb);
+                pool[(size_t)ob[c] * v.stride + 64 * q] = (x[c][q] * dry) + (d[c][q] * mix);
+            }
+        if (base == 0 && lane < nd.n_out) (v.flags + (size_t)b * v.flags_blk_stride)[my_out] = 0;  // out mask 0 (schedule.rs:338-341)
+    }
+    if (lane == 0) sp->playhead = (uint64_t)pos;  // (nothing else of the node's state moves)
+}
+
 // K blocks per launch (gridDim.y = K, one pool slice per block).  A node whose audio half carries state from block
 // to block is run by ONE wave that walks its K blocks in order; stateless nodes — and frozen ones — take their K
 // blocks in parallel.
@@ -716,7 +942,7 @@ __device__ void frozen_finish(const DevView& v, int node_idx, uint32_t K) {
 // hybrid plan, a return chain — gets a wave per block instead: its blocks in sequence were 10-38 us per level of pure latency.
 template <int SET>
 __global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __restrict__ level_nodes, int n_nodes,
-                                                      uint32_t cmd_block0, uint32_t K, uint32_t bpw) {
+                                                      uint32_t cmd_block0, uint32_t K, uint32_t bpw, uint32_t walkers) {
     int w = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (w >= n_nodes) return;
     const int node = level_nodes[w];
@@ -739,9 +965,30 @@ __global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __res
             return;
         }
         if (blockIdx.y != 0) return;
+        if constexpr (SET == 1) {  // (a bus filter / delay the batch walkers take: k_bus_iir, launched next to this kernel)
+            if (walkers && (biquad_walk_ok(v, v.nodes[node], cmd_block0, K) || delay_walk_ok(v, v.nodes[node], cmd_block0, K))) return;
+        }
         for (uint32_t b = 0; b < K; ++b) node_process_wave<SET>(v, node, b, cmd_block0 + b);
     } else {
         for (uint32_t b = b0; b < b1; ++b) node_process_wave<SET>(v, node, b, cmd_block0 + b);
+    }
+}
+
+// The batch walkers' kernel: one wave per node of the level that is a bus biquad / delay they take (k_level<1>, launched with
+// `walkers` set, leaves exactly those nodes alone).  A kernel of its own so that the walkers' registers (prefetched chunks)
+// do not set k_level<1>'s occupancy.
+__global__ __launch_bounds__(WAVE* WPB) void k_bus_iir(DevView v, const int* __restrict__ level_nodes, int n_nodes, uint32_t cmd_block0,
+                                                        uint32_t K) {
+    const int w = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (w >= n_nodes) return;
+    const NodeDesc nd = v.nodes[level_nodes[w]];
+    const int nch = nd.n_in < nd.n_out ? nd.n_in : nd.n_out;
+    if (biquad_walk_ok(v, nd, cmd_block0, K)) {
+        if (nch == 2) biquad_walk<2>(v, nd, K);
+        else biquad_walk<1>(v, nd, K);
+    } else if (delay_walk_ok(v, nd, cmd_block0, K)) {
+        if (nch == 2) delay_walk<2>(v, nd, K);
+        else delay_walk<1>(v, nd, K);
     }
 }
 

@@ -139,7 +139,7 @@ static const void* g_fused_ctx_states = nullptr;  // whose states they index
 int launch_level(hipStream_t, const DevView& v, const int* d_level_nodes, int n_nodes, int K, uint32_t, int kinds) {
     g_launches[0]++;
     check_view_common(v, K);
-    REQUIRE(kinds >= 0 && kinds <= 7, kinds);  // 0: a level of Dummy / graph I/O / FIR nodes only — nothing to launch
+    REQUIRE(kinds >= 0 && kinds <= 15, kinds);  // 0: a level of Dummy / graph I/O / FIR nodes only — nothing to launch; bit 3: holds a biquad / delay
     touch(d_level_nodes, sizeof(int) * (size_t)n_nodes);
     for (int i = 0; i < n_nodes; ++i) {
         check_generic_node(v, d_level_nodes[i], K);

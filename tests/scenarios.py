@@ -449,6 +449,61 @@ def scenario_hybrid_sends(e, n_a=26, n_b=11, src_frames=2100, seed=5, long_call=
     return np.concatenate(outs)
 
 
+def scenario_bus_iir(e, seed=31, src_frames=5000):
+    """filters and delays on buses, long calls: a stereo master chain low-pass -> delay (960 frames) -> high-pass behind a small
+    voice bank, and a mono strip sampler -> biquad -> delay (700 frames) -> biquad -> mono-to-stereo beside it.  In a batch of
+    K >= 2 whole 256-frame chunks such nodes are walked by k_bus_iir over all K blocks (state in registers, next chunk
+    prefetched); a coefficient / feedback message inside a batch sends that batch through the block-by-block path; a short delay
+    (300 frames) never takes the walker."""
+    rng = np.random.default_rng(seed)
+    voices = []
+    ends = []
+    for v in range(9):
+        s = e.sampler(100.0)
+        vol = e.volume(float(rng.uniform(30, 100)))
+        e.connect_stereo(s, vol)
+        voices.append((s, vol))
+        ends.append(vol)
+    bank = e.sum(9)
+    for p, n in enumerate(ends):
+        e.connect_stereo(n, bank, 2 * p)
+    lp = e.biquad(0, 3000.0, 0.8)
+    dl = e.delay(960.0 / e.sample_rate, feedback=0.35, mix=0.4)
+    hp = e.biquad(1, 200.0, 0.7)
+    short = e.delay(300.0 / e.sample_rate, feedback=0.2, mix=0.5)
+    for a, b in ((bank, lp), (lp, dl), (dl, hp), (hp, short)):
+        e.connect_stereo(a, b)
+    ms = e.sampler(80.0, n_out=1)
+    mbq = e.biquad(2, 1200.0, 2.0, ch=1)
+    mdl = e.delay(700.0 / e.sample_rate, feedback=0.5, mix=0.6, ch=1)
+    mbq2 = e.biquad(0, 5000.0, 0.7, ch=1)
+    m2s = e.add_node(MONO_TO_STEREO, 1, 2)
+    e.connect(ms, 0, mbq, 0)
+    e.connect(mbq, 0, mdl, 0)
+    e.connect(mdl, 0, mbq2, 0)
+    e.connect(mbq2, 0, m2s, 0)
+    mix = e.sum(2)
+    e.connect_stereo(short, mix, 0)
+    e.connect_stereo(m2s, mix, 2)
+    e.connect_stereo(mix, e.graph_out_node)
+    e.update()
+    for v, (s, vol) in enumerate(voices):
+        e.sampler_set_sample(s, e.new_sample(PLANAR_F32, 2, voice_source(seed * 1000 + v, src_frames + 29 * v, 2)))
+        e.sampler_set_loop_range(s, LOOP_FULL)
+        e.sampler_play(s)
+    e.sampler_set_sample(ms, e.new_sample(PLANAR_F32, 1, voice_source(seed * 1000 + 77, src_frames, 1)))
+    e.sampler_set_loop_range(ms, LOOP_FULL)
+    e.sampler_play(ms)
+    outs = [e.process_blocks(1), e.process_blocks(7)]          # one block (no walker), then a batch
+    e.set_param(lp, 1, 800.0, at_block=3)                      # a filter sweep inside the next batch: block by block
+    e.set_param(mdl, 1, 0.2, at_block=1)
+    outs.append(e.process_blocks(6))
+    outs.append(e.process_blocks(9))                           # walkers again, from the state the other path left
+    e.set_param(voices[2][1], 0, 10.0, at_block=2)             # a voice message does not concern the bus nodes
+    outs.append(e.process_blocks(5))
+    return np.concatenate(outs)
+
+
 def scenario_split_mixers(e, seed=21, long_call=30, src_frames=1300):
     """mixers that take voices on their leading ports AND buses behind them (the usual master section: voices + a reverb return
     + a sub-mix): the voice-bank kernels sum the leading voice ports into a partial bus — the reference's accumulator at that

@@ -214,6 +214,9 @@ def run_case(name, **gpu_kw):
         "hybrid_chain_sends_b64": lambda e: scenarios.scenario_hybrid_chain_sends(e, 21, radix=7, src_frames=800, seed=12, long_call=70),
         "split_mixers_b128": scenarios.scenario_split_mixers,
         "split_mixers_b64": lambda e: scenarios.scenario_split_mixers(e, seed=22, long_call=45, src_frames=700),
+        "bus_iir_b256": scenarios.scenario_bus_iir,
+        "bus_iir_b512": lambda e: scenarios.scenario_bus_iir(e, seed=32, src_frames=9000),
+        "bus_iir_b128": lambda e: scenarios.scenario_bus_iir(e, seed=33),
         "storm_48x6": scenarios.scenario_message_storm,
         "storm_200x50_b64": lambda e: scenarios.scenario_message_storm(e, 200, radix=32, blocks=60, per_voice=50, src_frames=3000, seed=4),
         "mixed_generic": scenarios.scenario_mixed_generic,
@@ -247,7 +250,7 @@ def run_case(name, **gpu_kw):
                                                                           ir_channels=1),
     }[name]
     mbf = {"rs_bank_40": 128, "rs_bank_21_b64_i16_pure": 64, "voice_fx_steady": 256, "voice_fx_events_45": 128, "voice_fx_events_20_i16_r32": 64, "steady_fmt_p_i16_mono3": 128, "steady_fmt_i_f32": 64, "steady_fmt_i_u16": 64, "steady_fmt_p_i16_oddlen": 64,
-           "steady_fmt_mixed_leaf": 128, "events_33_i16": 128, "steady_96x32": 256, "steady_40x4_i16": 64, "steady_9x3_u16": 128, "events_70": 256, "events_33_r2": 128, "storm_48x6": 128, "storm_200x50_b64": 64, "hybrid_sends_b128": 128, "hybrid_sends_b64": 64, "split_mixers_b128": 128, "split_mixers_b64": 64, "hybrid_chain_sends_b128": 128, "hybrid_chain_sends_b64": 64, "spatial_steady_b128": 128, "spatial_steady_b64": 64,
+           "steady_fmt_mixed_leaf": 128, "events_33_i16": 128, "steady_96x32": 256, "steady_40x4_i16": 64, "steady_9x3_u16": 128, "events_70": 256, "events_33_r2": 128, "storm_48x6": 128, "storm_200x50_b64": 64, "bus_iir_b256": 256, "bus_iir_b512": 512, "bus_iir_b128": 128, "hybrid_sends_b128": 128, "hybrid_sends_b64": 64, "split_mixers_b128": 128, "split_mixers_b64": 64, "hybrid_chain_sends_b128": 128, "hybrid_chain_sends_b64": 64, "spatial_steady_b128": 128, "spatial_steady_b64": 64,
            "mixed_generic": 256, "mixed_generic_nobeep": 256, "graph_inputs": 64, "cfg3_chain": 128, "cfg4_reverb": 128,
            "cfg4_reverb_2irs_mono": 64, "chain_steady_40": 256, "chain_steady_bq_only_i16": 64,
            "chain_steady_dl_only_pan": 128, "chain_events_37": 128, "chain_events_19_r2_pan": 64,
@@ -686,6 +689,17 @@ def test_graph_edit_keeps_node_state_across_recompile():
     rg = run(g)
     assert g.cx.plan_kind() == 1
     assert_bits_equal(ro, rg, "across graph edits")
+
+
+@pytest.mark.parametrize("name", ["bus_iir_b256", "bus_iir_b512", "bus_iir_b128"])
+@pytest.mark.parametrize("kw", [dict(max_batch=64), dict(max_batch=3), dict(max_batch=64, force_generic=True)])
+def test_bus_filters_and_delays_walked_over_whole_batches_bit_exact(name, kw):
+    """stereo and mono bus biquads / delays: k_bus_iir's batch walkers (whole 256-frame chunks, K >= 2, delay >= 512 frames, no
+    message in the batch) and the block-by-block path they alternate with, on the hybrid plan and on the level executor alone"""
+    out_o, out_g, g = run_case(name, **kw)
+    assert_bits_equal(out_o, out_g, name)
+    gold = json.load(open(GOLDEN))
+    assert digest(out_g) == gold[name]
 
 
 def test_split_mixers_put_their_leading_voices_on_the_voice_bank_kernels():

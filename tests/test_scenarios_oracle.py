@@ -55,6 +55,9 @@ CASES = {
                                                                              long_call=70),
     "split_mixers_b128": lambda: scenarios.scenario_split_mixers(oracle(max_block_frames=128)),
     "split_mixers_b64": lambda: scenarios.scenario_split_mixers(oracle(max_block_frames=64), seed=22, long_call=45, src_frames=700),
+    "bus_iir_b256": lambda: scenarios.scenario_bus_iir(oracle(max_block_frames=256)),
+    "bus_iir_b512": lambda: scenarios.scenario_bus_iir(oracle(max_block_frames=512), seed=32, src_frames=9000),
+    "bus_iir_b128": lambda: scenarios.scenario_bus_iir(oracle(max_block_frames=128), seed=33),
     "storm_48x6": lambda: scenarios.scenario_message_storm(oracle(max_block_frames=128)),
     "storm_200x50_b64": lambda: scenarios.scenario_message_storm(oracle(max_block_frames=64), 200, radix=32, blocks=60, per_voice=50,
                                                                  src_frames=3000, seed=4),

@@ -488,58 +488,57 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         c->n_fused_real = 0;
         for (const VoiceDesc& vd : fb.voices) c->n_fused_real += vd.sampler_state >= 0 ? 1 : 0;
     }
-    // 5b. hybrid plan: not a fused shape as a whole, but with voice banks inside that are
+    // 5b. hybrid plan: not a fused shape as a whole, but with voice banks inside that the fused kernels render
+    // straight into their mixers' pool buffers; the level executor then runs the rest.
     c->hybrid_fx = false;
     if (is_hybrid) {
-        {
-            c->n_voices = (int)hb.voices.size();
-            c->n_leaves = (int)hb.leaves.size();
-            c->ramp_slots = 2 * (1 + hb.max_stages);
-            c->fused_prog = hb.has_prog;
-            c->fused_rs = hb.has_rs;
-            c->n_groups = 0;
-            c->hybrid_fx = hb.has_fx;
-            if (c->hybrid_fx) {  // the banks go through k_chain: its workgroups, its tile size, at most 64 blocks per launch
-                if ((rc = upload_chain_groups(c, hb.leaves))) return rc;
-                c->chain_nq = (c->mbf % 128 == 0 && hb.min_delay >= 128) ? 2 : 1;
-                if (const char* e = getenv("FWGPU_CHAIN_NQ")) {
-                    if (atoi(e) == 1) c->chain_nq = 1;
-                }
-                c->generic_k = std::min<uint32_t>(c->generic_k, CH_FAST_KMAX);
+        c->n_voices = (int)hb.voices.size();
+        c->n_leaves = (int)hb.leaves.size();
+        c->ramp_slots = 2 * (1 + hb.max_stages);
+        c->fused_prog = hb.has_prog;
+        c->fused_rs = hb.has_rs;
+        c->n_groups = 0;
+        c->hybrid_fx = hb.has_fx;
+        if (c->hybrid_fx) {  // the banks go through k_chain: its workgroups, its tile size, at most 64 blocks per launch
+            if ((rc = upload_chain_groups(c, hb.leaves))) return rc;
+            c->chain_nq = (c->mbf % 128 == 0 && hb.min_delay >= 128) ? 2 : 1;
+            if (const char* e = getenv("FWGPU_CHAIN_NQ")) {
+                if (atoi(e) == 1) c->chain_nq = 1;
             }
-            c->n_tail = 0;
-            c->up_root_node = -1;
-            c->up_level_off.clear();
-            c->up_level_cnt.clear();
-            if ((rc = upload(c, c->d_voices, hb.voices.data(), hb.voices.size() * sizeof(VoiceDesc)))) return rc;
-            if ((rc = upload(c, c->d_leaves, hb.leaves.data(), hb.leaves.size() * sizeof(LeafDesc)))) return rc;
-            if ((rc = upload(c, c->d_progs, hb.progs.data(), hb.progs.size() * sizeof(uint32_t)))) return rc;
-            if ((rc = alloc_voice_tables(c))) return rc;
-            // the level lists without the nodes the voice-bank kernels render
-            std::vector<char> cov(N, 0);
-            for (int i : hb.covered) cov[i] = 1;
-            std::vector<int> hflat;
-            c->hlevel_off.clear();
-            c->hlevel_cnt.clear();
-            c->hlevel_kinds.clear();
-            for (auto& l : levels) {
-                c->hlevel_off.push_back((int)hflat.size());
-                int kinds = 0, cnt = 0;
-                for (int i : l)
-                    if (!cov[i]) {
-                        hflat.push_back(split_entry[i] >= 0 ? split_entry[i] : i);
-                        kinds |= host_kind_bits(nd[i].kind);
-                        cnt++;
-                    }
-                c->hlevel_cnt.push_back(cnt);
-                c->hlevel_kinds.push_back(kinds);
-            }
-            if (hflat.empty()) hflat.push_back(0);
-            if ((rc = upload(c, c->d_hlevel_nodes, hflat.data(), hflat.size() * sizeof(int)))) return rc;
-            c->hybrid = true;
-            c->n_fused_real = 0;
-            for (const VoiceDesc& vd : hb.voices) c->n_fused_real += vd.sampler_state >= 0 ? 1 : 0;
+            c->generic_k = std::min<uint32_t>(c->generic_k, CH_FAST_KMAX);
         }
+        c->n_tail = 0;
+        c->up_root_node = -1;
+        c->up_level_off.clear();
+        c->up_level_cnt.clear();
+        if ((rc = upload(c, c->d_voices, hb.voices.data(), hb.voices.size() * sizeof(VoiceDesc)))) return rc;
+        if ((rc = upload(c, c->d_leaves, hb.leaves.data(), hb.leaves.size() * sizeof(LeafDesc)))) return rc;
+        if ((rc = upload(c, c->d_progs, hb.progs.data(), hb.progs.size() * sizeof(uint32_t)))) return rc;
+        if ((rc = alloc_voice_tables(c))) return rc;
+        // the level lists without the nodes the voice-bank kernels render
+        std::vector<char> cov(N, 0);
+        for (int i : hb.covered) cov[i] = 1;
+        std::vector<int> hflat;
+        c->hlevel_off.clear();
+        c->hlevel_cnt.clear();
+        c->hlevel_kinds.clear();
+        for (auto& l : levels) {
+            c->hlevel_off.push_back((int)hflat.size());
+            int kinds = 0, cnt = 0;
+            for (int i : l)
+                if (!cov[i]) {
+                    hflat.push_back(split_entry[i] >= 0 ? split_entry[i] : i);
+                    kinds |= host_kind_bits(nd[i].kind);
+                    cnt++;
+                }
+            c->hlevel_cnt.push_back(cnt);
+            c->hlevel_kinds.push_back(kinds);
+        }
+        if (hflat.empty()) hflat.push_back(0);
+        if ((rc = upload(c, c->d_hlevel_nodes, hflat.data(), hflat.size() * sizeof(int)))) return rc;
+        c->hybrid = true;
+        c->n_fused_real = 0;
+        for (const VoiceDesc& vd : hb.voices) c->n_fused_real += vd.sampler_state >= 0 ? 1 : 0;
     }
     // k_frozen_scan's verdict tables (generic executor, K > 1): sized here, on the control thread — a process call never
     // allocates

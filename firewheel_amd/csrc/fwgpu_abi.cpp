@@ -1042,3 +1042,24 @@ int fwgpu_device_info(fwgpu_ctx* c, char* name, int name_cap, int* cus, uint64_t
 
 }  // extern "C"
 
+#ifdef FW_PROBE
+// scripts/placement_probe.py builds only (make EXTRA=-DFW_PROBE): exchange one device table between two contexts that hold
+// the same graph — which table's place in HBM carries k_leaf_sum's slow / fast state?  Never part of a shipped library.
+extern "C" int fwgpu_probe_swap(fwgpu_ctx* a, fwgpu_ctx* b, int which) {
+    auto sw = [](DevBuf& x, DevBuf& y) {
+        std::swap(x.p, y.p);
+        std::swap(x.cap, y.cap);
+    };
+    switch (which) {
+        case 0: sw(a->d_bus, b->d_bus); sw(a->d_bus_flags, b->d_bus_flags); break;
+        case 1: sw(a->d_refs, b->d_refs); break;
+        case 2: sw(a->d_gsets, b->d_gsets); break;
+        case 3: sw(a->d_leaves, b->d_leaves); break;
+        case 4: sw(a->d_samples, b->d_samples); break;
+        case 5: sw(a->d_voices, b->d_voices); sw(a->d_blks, b->d_blks); sw(a->d_cache, b->d_cache); break;
+        case 6: sw(a->d_ramps, b->d_ramps); break;
+        default: return -1;
+    }
+    return 0;
+}
+#endif

@@ -260,7 +260,11 @@ __device__ __forceinline__ float readlane_f(float x, int lane) {
 #define LEAF_NT 1  // non-temporal source loads: every source byte is read exactly once (+12 % measured)
 #endif
 #ifndef LEAF_NT_STORE
-#define LEAF_NT_STORE 1  // ... and so are the leaf buses' stores: the next reader is another kernel (-1 % on the kernel, measured)
+// The leaf buses' stores: the next reader is another kernel.  1 = non-temporal (-1 % on the kernel against plain stores);
+// 2 = write-through (sc0 sc1): as fast as 1 when the bus and the samples sit in different thirds of HBM, and 8 us (3 %) faster
+// when they share one — reads and writes mixed on one rank of the stacks are what costs this kernel its 12 % in the "slow
+// state" (scripts/ubench/bus_place.hip, DESIGN §7: nt 282 / plain 287 / sc0 sc1 274 us there; 252 / 256 / 251 us otherwise)
+#define LEAF_NT_STORE 2
 #endif
 #ifndef LEAF_WPB
 #define LEAF_WPB 4  // waves (leaf, block work items) per workgroup
@@ -593,7 +597,10 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                 ++p;
             }
         }
-#if LEAF_NT_STORE
+#if LEAF_NT_STORE == 2
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(outl + f0), "v"(accl) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(outr + f0), "v"(accr) : "memory");
+#elif LEAF_NT_STORE
         __builtin_nontemporal_store(accl, (v4f*)(outl + f0));
         __builtin_nontemporal_store(accr, (v4f*)(outr + f0));
 #else

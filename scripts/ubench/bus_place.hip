@@ -1,0 +1,150 @@
+// micro-benchmark: does the PLACE of the bus in HBM decide the speed of a k_leaf_sum-shaped kernel?
+// Every wave reads block k of 32 stereo streams (64 x 1 KiB, the sources: 1024 voices x 2 channels x 1 MiB, shared by
+// every run) and writes the 2 x 1 KiB sum to bus[k][leaf] with non-temporal stores — 1.6 GB read, 50 MB written per launch,
+// like config 2.  The bus is put at one offset after another of a large allocation, then into separately allocated
+// buffers; the read-only and the write-only halves are timed at the same places.
+// build: hipcc --offload-arch=gfx950 -O3 -o bus_place bus_place.hip ; run: ./bus_place [arena_GiB [step_MiB]]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const v4f __attribute__((address_space(1)))* gp;
+typedef v4f __attribute__((address_space(1)))* gwp;
+constexpr int LEAVES = 32, K = 768, NBUS = 33, FRAMES = 256;
+constexpr size_t STREAM = 262144;  // floats per channel
+// store policies (gfx950 cache-policy bits of global_store): 0 nt, 1 none (L2 write-back), 2 sc1, 3 sc0 sc1, 4 nt sc0 sc1
+template <int ST>
+__device__ __forceinline__ void store4(float* p, v4f v) {
+    if (ST == 0) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    if (ST == 1) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    if (ST == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if (ST == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    if (ST == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+// MODE 0: read + write, 1: read only, 2: write only
+template <int MODE, int ST = 0, int LD = 0>
+__global__ __launch_bounds__(256) void k_leaf(const float* __restrict__ src, float* __restrict__ bus, float* sink, size_t blk_stride) {
+    const int leaf = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int k = blockIdx.y, lane = threadIdx.x & 63;
+    v4f l = {0, 0, 0, 0}, r = {0, 0, 0, 0};
+    if (MODE != 2) {
+        for (int v0 = 0; v0 < 32; v0 += 4) {
+            v4f x[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* p = src + ((size_t)(leaf * 32 + v0 + u) * 2) * STREAM + (size_t)k * FRAMES + lane * 4;
+                x[2 * u] = LD ? *(gp)(uint64_t)p : __builtin_nontemporal_load((gp)(uint64_t)p);
+                x[2 * u + 1] = LD ? *(gp)(uint64_t)(p + STREAM) : __builtin_nontemporal_load((gp)(uint64_t)(p + STREAM));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                l += x[2 * u];
+                r += x[2 * u + 1];
+            }
+        }
+    } else {
+        l = (v4f){(float)leaf, (float)k, (float)lane, 1.f};
+        r = l;
+    }
+    if (MODE != 1) {
+        float* o = bus + (size_t)k * blk_stride + (size_t)leaf * 2 * FRAMES + lane * 4;
+        store4<ST>(o, l);
+        store4<ST>(o + FRAMES, r);
+    } else if (l[0] + r[1] == 123.456f) sink[0] = 1.f;
+}
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+template <int MODE, int ST = 0, int LD = 0>
+static float time_us(const float* src, float* bus, float* sink, int reps, size_t blk_stride = (size_t)NBUS * 2 * FRAMES) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    dim3 grid(LEAVES / 4, K);
+    for (int i = 0; i < 3; ++i) k_leaf<MODE, ST, LD><<<grid, 256>>>(src, bus, sink, blk_stride);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) k_leaf<MODE, ST, LD><<<grid, 256>>>(src, bus, sink, blk_stride);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipEventDestroy(a));
+    CK(hipEventDestroy(b));
+    return ms * 1e3f / reps;
+}
+int main(int argc, char** argv) {
+    // ./bus_place matrix [chunks [chunk_GiB]]: sources in chunk i, bus in chunk j of `chunks` separately allocated pieces
+    if (argc > 1 && !strcmp(argv[1], "matrix")) {
+        const int n = argc > 2 ? atoi(argv[2]) : 10;
+        const size_t gib = argc > 3 ? atoi(argv[3]) : 8;
+        std::vector<char*> c(n);
+        float* sink;
+        CK(hipMalloc(&sink, 256));
+        for (int i = 0; i < n; ++i) {
+            CK(hipMalloc(&c[i], gib << 30));
+            CK(hipMemset(c[i], 0, gib << 30));
+        }
+        printf("%d chunks of %zu GiB in allocation order; rows: sources in chunk i (read-only us in the last column); columns: bus in chunk j\n      ", n, gib);
+        for (int j = 0; j < n; ++j) printf(" %6d", j);
+        printf("   rd only\n");
+        for (int i = 0; i < n; ++i) {
+            printf("src %2d", i);
+            for (int j = 0; j < n; ++j) printf(" %6.1f", time_us<0>((const float*)c[i], (float*)(c[j] + ((size_t)3 << 30)), sink, 8));
+            printf("   %6.1f\n", time_us<1>((const float*)c[i], (float*)c[i], sink, 8));
+        }
+        // store policies on one slow and one fast pairing
+        int slow_j = -1, fast_j = -1;
+        for (int j = 0; j < n; ++j) {
+            const float t = time_us<0>((const float*)c[0], (float*)(c[j] + ((size_t)3 << 30)), sink, 8);
+            if (t > 270.f && slow_j < 0) slow_j = j;
+            if (t < 260.f && fast_j < 0) fast_j = j;
+        }
+        printf("sources in chunk 0; read + write us by store policy:\n%22s %9s %9s %9s %9s %9s\n", "", "nt", "none", "sc1", "sc0 sc1", "nt sc0sc1");
+        for (int j : {slow_j, fast_j}) {
+            if (j < 0) continue;
+            float* bus = (float*)(c[j] + ((size_t)3 << 30));
+            const float* src = (const float*)c[0];
+            for (int rep = 0; rep < 2; ++rep)
+                printf("bus in chunk %2d (%s) %9.1f %9.1f %9.1f %9.1f %9.1f\n", j, j == slow_j ? "slow" : "fast", time_us<0, 0>(src, bus, sink, 10),
+                       time_us<0, 1>(src, bus, sink, 10), time_us<0, 2>(src, bus, sink, 10), time_us<0, 3>(src, bus, sink, 10), time_us<0, 4>(src, bus, sink, 10));
+        }
+        return 0;
+    }
+    const size_t arena_gib = argc > 1 ? atoi(argv[1]) : 6, step_mib = argc > 2 ? atoi(argv[2]) : 64;
+    const size_t bus_bytes = (size_t)K * NBUS * 2 * FRAMES * 4;
+    float *src, *sink;
+    char* arena;
+    CK(hipMalloc(&src, (size_t)1024 * 2 * STREAM * 4));
+    CK(hipMemset(src, 0, (size_t)1024 * 2 * STREAM * 4));
+    CK(hipMalloc(&sink, 256));
+    CK(hipMalloc(&arena, arena_gib << 30));
+    printf("bus %.1f MB; read 1.61 GB per launch; src %p arena %p\n", bus_bytes / 1e6, (void*)src, (void*)arena);
+    printf("%10s %9s %9s %9s\n", "offset MiB", "rd+wr us", "rd us", "wr us");
+    for (size_t off = 0; off + bus_bytes <= (arena_gib << 30); off += step_mib << 20) {
+        float* bus = (float*)(arena + off);
+        printf("%10zu %9.1f %9.1f %9.1f\n", off >> 20, time_us<0>(src, bus, sink, 10), time_us<1>(src, bus, sink, 5), time_us<2>(src, bus, sink, 10));
+    }
+    printf("store policies (read + write us), plain loads in the last column:\n%10s %9s %9s %9s %9s %9s %9s\n", "offset MiB", "nt", "none", "sc1", "sc0 sc1", "nt sc0sc1", "ld+nt st");
+    for (size_t off = 0; off + bus_bytes <= (arena_gib << 30); off += (size_t)512 << 20) {
+        float* bus = (float*)(arena + off);
+        printf("%10zu %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f\n", off >> 20, time_us<0, 0>(src, bus, sink, 10), time_us<0, 1>(src, bus, sink, 10),
+               time_us<0, 2>(src, bus, sink, 10), time_us<0, 3>(src, bus, sink, 10), time_us<0, 4>(src, bus, sink, 10), time_us<0, 0, 1>(src, bus, sink, 10));
+    }
+    printf("the bus base shifted by a little, at arena offsets 0 and %zu MiB (read + write us, nt):\n", (arena_gib << 9));
+    for (size_t sh = 256; sh <= ((size_t)64 << 20); sh *= 2) {
+        printf("%10zu B %9.1f %9.1f", sh, time_us<0>(src, (float*)(arena + sh), sink, 10), time_us<0>(src, (float*)(arena + (arena_gib << 29) + sh), sink, 10));
+        printf("   x3: %9.1f %9.1f\n", time_us<0>(src, (float*)(arena + 3 * sh), sink, 10), time_us<0>(src, (float*)(arena + (arena_gib << 29) + 3 * sh), sink, 10));
+    }
+    printf("other bus pitches per block (floats), same two places:\n");
+    for (size_t st : {(size_t)32 * 512, (size_t)33 * 512, (size_t)34 * 512, (size_t)36 * 512, (size_t)40 * 512, (size_t)48 * 512, (size_t)64 * 512, (size_t)65 * 512, (size_t)33 * 512 + 64, (size_t)33 * 512 + 1024})
+        printf("%10zu %9.1f %9.1f\n", st, time_us<0>(src, (float*)arena, sink, 10, st), time_us<0>(src, (float*)(arena + (arena_gib << 29)), sink, 10, st));
+    printf("separately allocated buses:\n");
+    std::vector<float*> keep;
+    for (int i = 0; i < 12; ++i) {
+        float* bus;
+        CK(hipMalloc(&bus, bus_bytes));
+        keep.push_back(bus);
+        printf("%10p %9.1f %9s %9.1f\n", (void*)bus, time_us<0>(src, bus, sink, 10), "", time_us<2>(src, bus, sink, 10));
+    }
+    return 0;
+}

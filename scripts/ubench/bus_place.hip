@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <vector>
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const v4f __attribute__((address_space(1)))* gp;
@@ -73,6 +74,42 @@ static float time_us(const float* src, float* bus, float* sink, int reps, size_t
     return ms * 1e3f / reps;
 }
 int main(int argc, char** argv) {
+    // ./bus_place cands [spacer_GiB [n]]: what a context could do — n candidate buses with a spacer allocation between each two
+    // (freed again at once), the sources allocated first; how long the allocations take and which candidates are fast
+    if (argc > 1 && !strcmp(argv[1], "cands")) {
+        const size_t gib = argc > 2 ? atoi(argv[2]) : 16;
+        const int n = argc > 3 ? atoi(argv[3]) : 3;
+        const size_t bus_bytes = (size_t)K * NBUS * 2 * FRAMES * 4;
+        float *src, *sink;
+        for (int trial = 0; trial < 3; ++trial) {  // (sources in three different places)
+            char* pre = nullptr;
+            if (trial) CK(hipMalloc(&pre, (size_t)trial * 20 << 30));
+            CK(hipMalloc(&src, (size_t)1024 * 2 * STREAM * 4));
+            CK(hipMemset(src, 0, (size_t)1024 * 2 * STREAM * 4));
+            CK(hipMalloc(&sink, 256));
+            std::vector<float*> cand(n);
+            std::vector<char*> spacer(n, nullptr);
+            hipEvent_t a, b;
+            CK(hipDeviceSynchronize());
+            struct timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (int i = 0; i < n; ++i) {
+                CK(hipMalloc(&cand[i], bus_bytes));
+                if (i + 1 < n) CK(hipMalloc(&spacer[i], gib << 30));
+            }
+            for (int i = 0; i + 1 < n; ++i) CK(hipFree(spacer[i]));
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            (void)a; (void)b;
+            printf("trial %d: %d candidates %zu GiB apart allocated in %.1f ms:", trial, n, gib, (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
+            for (int i = 0; i < n; ++i) printf(" %.1f", time_us<0, 3>(src, cand[i], sink, 10));
+            printf(" us (sc0 sc1)\n");
+            for (int i = 0; i < n; ++i) CK(hipFree(cand[i]));
+            CK(hipFree(src));
+            CK(hipFree(sink));
+            if (pre) CK(hipFree(pre));
+        }
+        return 0;
+    }
     // ./bus_place matrix [chunks [chunk_GiB]]: sources in chunk i, bus in chunk j of `chunks` separately allocated pieces
     if (argc > 1 && !strcmp(argv[1], "matrix")) {
         const int n = argc > 2 ? atoi(argv[2]) : 10;

@@ -25,10 +25,14 @@ __device__ __forceinline__ void store4(float* p, v4f v) {
     if (ST == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
 }
 // MODE 0: read + write, 1: read only, 2: write only
-template <int MODE, int ST = 0, int LD = 0>
-__global__ __launch_bounds__(256) void k_leaf(const float* __restrict__ src, float* __restrict__ bus, float* sink, size_t blk_stride) {
-    const int leaf = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int k = blockIdx.y, lane = threadIdx.x & 63;
+// MAP 0: a workgroup = 4 leaves of one block; MAP 1: a workgroup = 4 consecutive blocks of one leaf (what k_leaf_sum does)
+template <int MODE, int ST = 0, int LD = 0, int MAP = 0>
+__global__ __launch_bounds__(256) void k_leaf(const float* __restrict__ src, float* __restrict__ bus, float* sink, size_t blk_stride, size_t leaf_stride) {
+    // MAP 2: as 1 with a leaf's workgroups dispatched one after another (block group fastest); MAP 3: as 1, leaves fastest, but
+    // the block groups dealt round-robin to the 8 XCDs' dispatch order (consecutive block groups 8 workgroups apart)
+    const int leaf = MAP == 0 ? blockIdx.x * 4 + (threadIdx.x >> 6) : MAP == 2 ? blockIdx.y : blockIdx.x;
+    const int kg = MAP == 2 ? blockIdx.x : blockIdx.y;
+    const int k = MAP == 0 ? blockIdx.y : kg * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     v4f l = {0, 0, 0, 0}, r = {0, 0, 0, 0};
     if (MODE != 2) {
         for (int v0 = 0; v0 < 32; v0 += 4) {
@@ -50,21 +54,67 @@ __global__ __launch_bounds__(256) void k_leaf(const float* __restrict__ src, flo
         r = l;
     }
     if (MODE != 1) {
-        float* o = bus + (size_t)k * blk_stride + (size_t)leaf * 2 * FRAMES + lane * 4;
+        float* o = bus + (size_t)k * blk_stride + (size_t)leaf * leaf_stride + lane * 4;
         store4<ST>(o, l);
         store4<ST>(o + FRAMES, r);
     } else if (l[0] + r[1] == 123.456f) sink[0] = 1.f;
 }
+// "fat" waves: ONE wave renders all 32 leaves of a 128-frame half block (lanes 0-31: left, 32-63: right; 4 frames per lane),
+// U voices' loads in flight at a time, the leaf sums added in a register — no leaf bus at all; 2 x 512 B written per wave.
+// Each leaf's 32 voice pointers come from a table (lane p loads voice p's), the next leaf's requested a leaf ahead.
+template <int U, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_fat(const float* const* __restrict__ vptr, float* __restrict__ out, int n_items) {
+    const int item = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const int lane = threadIdx.x & 63, k = item >> 1, half = item & 1;
+    const size_t off = (size_t)k * FRAMES + half * 128 + (lane & 31) * 4 + (lane >> 5) * STREAM;
+    v4f root = {0, 0, 0, 0};
+    const float* nxt = vptr[lane & 31];
+    for (int leaf = 0; leaf < LEAVES; ++leaf) {
+        const float* mine = nxt;
+        if (leaf + 1 < LEAVES) nxt = vptr[(leaf + 1) * 32 + (lane & 31)];
+        v4f acc = {0, 0, 0, 0};
+        for (int p0 = 0; p0 < 32; p0 += U) {
+            v4f x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t b = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)mine >> 32), p0 + u) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int)(uint64_t)mine, p0 + u);
+                x[u] = __builtin_nontemporal_load((gp)(b + off * 4));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += x[u] * 0.5f;
+        }
+        root += acc;
+    }
+    float* o = out + (size_t)k * 2 * FRAMES + (lane >> 5) * FRAMES + half * 128 + (lane & 31) * 4;
+    *(v4f*)o = root;
+}
+template <int U, int WPB>
+static float time_fat(const float* const* vptr, float* out, int reps) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    const int n_items = K * 2;
+    for (int i = 0; i < 3; ++i) k_fat<U, WPB><<<(n_items + WPB - 1) / WPB, 64 * WPB>>>(vptr, out, n_items);
+    hipEventRecord(a);
+    for (int i = 0; i < reps; ++i) k_fat<U, WPB><<<(n_items + WPB - 1) / WPB, 64 * WPB>>>(vptr, out, n_items);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return ms * 1e3f / reps;
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
-template <int MODE, int ST = 0, int LD = 0>
-static float time_us(const float* src, float* bus, float* sink, int reps, size_t blk_stride = (size_t)NBUS * 2 * FRAMES) {
+template <int MODE, int ST = 0, int LD = 0, int MAP = 0>
+static float time_us(const float* src, float* bus, float* sink, int reps, size_t blk_stride = (size_t)NBUS * 2 * FRAMES, size_t leaf_stride = 2 * FRAMES) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
-    dim3 grid(LEAVES / 4, K);
-    for (int i = 0; i < 3; ++i) k_leaf<MODE, ST, LD><<<grid, 256>>>(src, bus, sink, blk_stride);
+    dim3 grid(MAP == 0 ? LEAVES / 4 : MAP == 2 ? K / 4 : LEAVES, MAP == 0 ? K : MAP == 2 ? LEAVES : K / 4);
+    for (int i = 0; i < 3; ++i) k_leaf<MODE, ST, LD, MAP><<<grid, 256>>>(src, bus, sink, blk_stride, leaf_stride);
     CK(hipEventRecord(a));
-    for (int i = 0; i < reps; ++i) k_leaf<MODE, ST, LD><<<grid, 256>>>(src, bus, sink, blk_stride);
+    for (int i = 0; i < reps; ++i) k_leaf<MODE, ST, LD, MAP><<<grid, 256>>>(src, bus, sink, blk_stride, leaf_stride);
     CK(hipEventRecord(b));
     CK(hipEventSynchronize(b));
     float ms = 0;
@@ -74,6 +124,26 @@ static float time_us(const float* src, float* bus, float* sink, int reps, size_t
     return ms * 1e3f / reps;
 }
 int main(int argc, char** argv) {
+    // ./bus_place fat: the fat-wave shape, sources and output in the same allocation order as everywhere else
+    if (argc > 1 && !strcmp(argv[1], "fat")) {
+        float *src, *out;
+        const float** vptr;
+        CK(hipMalloc(&src, (size_t)1024 * 2 * STREAM * 4));
+        CK(hipMemset(src, 0, (size_t)1024 * 2 * STREAM * 4));
+        CK(hipMalloc(&out, (size_t)K * 2 * FRAMES * 4));
+        CK(hipMalloc(&vptr, 1024 * sizeof(float*)));
+        std::vector<const float*> h(1024);
+        for (int v = 0; v < 1024; ++v) h[v] = src + (size_t)v * 2 * STREAM;
+        CK(hipMemcpy(vptr, h.data(), 1024 * sizeof(float*), hipMemcpyHostToDevice));
+        float* sink;
+        CK(hipMalloc(&sink, 256));
+        printf("thin waves, read only (4 blocks of a leaf per workgroup): %.1f us\n", time_us<1, 3, 0, 1>(src, out, sink, 10));
+        for (int rep = 0; rep < 2; ++rep) {
+            printf("fat waves, 1536 items: U=8 %.1f  U=16 %.1f  U=32 %.1f us (1 wave / workgroup);  U=16 %.1f  U=32 %.1f us (2 waves / workgroup)\n",
+                   time_fat<8, 1>(vptr, out, 10), time_fat<16, 1>(vptr, out, 10), time_fat<32, 1>(vptr, out, 10), time_fat<16, 2>(vptr, out, 10), time_fat<32, 2>(vptr, out, 10));
+        }
+        return 0;
+    }
     // ./bus_place cands [spacer_GiB [n]]: what a context could do — n candidate buses with a spacer allocation between each two
     // (freed again at once), the sources allocated first; how long the allocations take and which candidates are fast
     if (argc > 1 && !strcmp(argv[1], "cands")) {
@@ -144,6 +214,27 @@ int main(int argc, char** argv) {
             for (int rep = 0; rep < 2; ++rep)
                 printf("bus in chunk %2d (%s) %9.1f %9.1f %9.1f %9.1f %9.1f\n", j, j == slow_j ? "slow" : "fast", time_us<0, 0>(src, bus, sink, 10),
                        time_us<0, 1>(src, bus, sink, 10), time_us<0, 2>(src, bus, sink, 10), time_us<0, 3>(src, bus, sink, 10), time_us<0, 4>(src, bus, sink, 10));
+        }
+        // workgroup shapes and bus layouts (sc0 sc1 stores): [k][leaf] = a block's 32 leaves adjacent (the library's), [leaf][k] =
+        // a leaf's blocks adjacent
+        printf("dispatch order, 4 blocks per workgroup, [k][l]: leaves fastest / a leaf's block groups fastest:\n");
+        for (int j : {slow_j, fast_j}) {
+            if (j < 0) continue;
+            float* bus = (float*)(c[j] + ((size_t)3 << 30));
+            const float* src = (const float*)c[0];
+            for (int rep = 0; rep < 2; ++rep)
+                printf("bus in chunk %2d (%s) %12.1f %12.1f   read only: %12.1f %12.1f\n", j, j == slow_j ? "slow" : "fast", time_us<0, 3, 0, 1>(src, bus, sink, 10),
+                       time_us<0, 3, 0, 2>(src, bus, sink, 10), time_us<1, 3, 0, 1>(src, bus, sink, 10), time_us<1, 3, 0, 2>(src, bus, sink, 10));
+        }
+        printf("sources in chunk 0; read + write us by workgroup shape / bus layout:\n%22s %12s %12s %12s %12s\n", "", "4 leaves,[k][l]", "4 blocks,[k][l]", "4 blocks,[l][k]", "4 leaves,[l][k]");
+        for (int j : {slow_j, fast_j}) {
+            if (j < 0) continue;
+            float* bus = (float*)(c[j] + ((size_t)3 << 30));
+            const float* src = (const float*)c[0];
+            const size_t kl_b = (size_t)NBUS * 2 * FRAMES, kl_l = 2 * FRAMES, lk_b = 2 * FRAMES, lk_l = (size_t)K * 2 * FRAMES;
+            for (int rep = 0; rep < 2; ++rep)
+                printf("bus in chunk %2d (%s) %12.1f %12.1f %12.1f %12.1f\n", j, j == slow_j ? "slow" : "fast", time_us<0, 3, 0, 0>(src, bus, sink, 10, kl_b, kl_l),
+                       time_us<0, 3, 0, 1>(src, bus, sink, 10, kl_b, kl_l), time_us<0, 3, 0, 1>(src, bus, sink, 10, lk_b, lk_l), time_us<0, 3, 0, 0>(src, bus, sink, 10, lk_b, lk_l));
         }
         return 0;
     }

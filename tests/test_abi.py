@@ -34,6 +34,16 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, s), s
 
 
+def test_library_exports_nothing_else(lib):
+    """... and nothing beyond it: every `fwgpu_*` symbol the library exports is one the header declares (a probe build —
+    make EXTRA=-DFW_PROBE, scripts/placement_probe.py — left in the tree by accident would show up here)."""
+    import subprocess
+
+    out = subprocess.check_output(["nm", "-D", "--defined-only", fa.LIB_PATH]).decode()
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("fwgpu_")}
+    assert exported == set(declared_symbols()), sorted(exported ^ set(declared_symbols()))
+
+
 def test_no_torch_or_oracle_dependency():
     import subprocess
 

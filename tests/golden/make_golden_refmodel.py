@@ -1,6 +1,6 @@
 """Regenerates tests/golden/refmodel_digests.json from the INDEPENDENT numpy model (tests/refmodel.py: a second
 restatement of the reference's graph level, written from the .rs files, sharing no code with oracle/fw_oracle.cpp) — for
-every parity scenario whose nodes the model covers (no BeepTest / FIR).  The oracle must reproduce these
+every parity scenario whose nodes the model covers (everything but the FIR reverb).  The oracle must reproduce these
 digests (tests/test_refmodel_differential.py, CPU tier) and so must the HIP path (tests/test_gpu_parity.py, GPU tier).
 Run: python tests/golden/make_golden_refmodel.py"""
 import json
@@ -15,7 +15,7 @@ import refmodel  # noqa: E402
 import scenarios  # noqa: E402
 import test_scenarios_oracle as t  # noqa: E402
 
-UNSUPPORTED = ("mixed_generic", "cfg4_reverb", "cfg4_reverb_2irs_mono")
+UNSUPPORTED = ("cfg4_reverb", "cfg4_reverb_2irs_mono")
 
 
 def model_cases():

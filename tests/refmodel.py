@@ -18,8 +18,8 @@ Restated (file:line = BillyDM/firewheel @ 2024-10-16):
   graph/processor.rs:61-165,214-248    process_interleaved, process_block
   graph/graph/compiler/schedule.rs:213-344   prepare_graph_inputs / process / read_graph_outputs (silence flags)
 SPEC nodes (not in the reference): StereoPan, StereoWidth, Biquad, Delay, Spatial.
-Not modelled: BeepTest (libm), FIR and resampler (covered by their own numpy / scipy evaluations in
-tests/test_oracle_semantics.py), the reference's buffer REUSE (every output port owns a buffer here: results differ only
+BeepTest asks the platform libm for sinf, as it does for powf (see platform_powf).  Not modelled: the FIR reverb (covered by
+its own numpy / scipy evaluation in tests/test_oracle_semantics.py), the reference's buffer REUSE (every output port owns a buffer here: results differ only
 where the reference exposes stale data, Q12 / a19, which is outside the parity domain).
 """
 import math
@@ -27,7 +27,7 @@ import math
 import numpy as np
 
 import fwapi
-from fwapi import (BIQUAD, DELAY, DUMMY, HARD_CLIP, MONO_TO_STEREO, RESAMPLER, SAMPLER, SPATIAL, STEREO_PAN, STEREO_TO_MONO, STEREO_WIDTH, SUM,
+from fwapi import (BEEP_TEST, BIQUAD, DELAY, DUMMY, HARD_CLIP, MONO_TO_STEREO, RESAMPLER, SAMPLER, SPATIAL, STEREO_PAN, STEREO_TO_MONO, STEREO_WIDTH, SUM,
                    VOLUME)
 
 f32 = np.float32
@@ -243,6 +243,54 @@ class VolumeNode(Node):  # basic_nodes/volume.rs
             else:
                 outs[i][:frames] = ins[i][:frames] * g
         return in_mask
+
+
+def platform_sinf(x):
+    """f32::sin is the platform libm's sinf (Q29, like powf above)"""
+    platform_powf(1.0, 1.0)  # (loads libm)
+    if not hasattr(_LIBM, "_sinf_ready"):
+        import ctypes
+
+        _LIBM.sinf.restype = ctypes.c_float
+        _LIBM.sinf.argtypes = [ctypes.c_float]
+        _LIBM._sinf_ready = True
+    return f32(_LIBM.sinf(float(f32(x))))
+
+
+class BeepTestNode(Node):  # basic_nodes/beep_test.rs
+    kind = BEEP_TEST
+    TAU = f32(6.283185307179586)  # std::f32::consts::TAU
+
+    def __init__(self, eng, n_in, n_out, params):  # :14-24, :48-61
+        Node.__init__(self, eng, n_in, n_out, params)
+        freq = f32(params[0] if len(params) > 0 else 440.0)
+        freq = min(max(freq, f32(20.0)), f32(20000.0)) if not np.isnan(freq) else freq  # f32::clamp: NaN stays NaN
+        gain = db_to_gain_clamped_neg_100_db(params[1] if len(params) > 1 else -12.0)
+        self.gain = min(max(gain, F0), f32(1.0)) if not np.isnan(gain) else gain
+        self.enabled = bool(params[2] != 0.0) if len(params) > 2 else True
+        self.phasor = F0
+        self.phasor_inc = f32(freq / f32(eng.sample_rate))  # freq_hz / sample_rate as f32
+
+    def set_param(self, param, value):  # :30-32 (the atomic store)
+        assert param == 0
+        self.enabled = value != 0.0
+
+    def process(self, frames, ins, outs, in_mask):  # :71-97
+        if not outs:
+            return 0
+        if not self.enabled:  # :83-86 — clears outputs[1..] ONLY and reports them through the mask's low bits (Q12)
+            return clear_all_outputs(frames, outs[1:])
+        out1 = outs[0]
+        ph, inc, gain = self.phasor, self.phasor_inc, self.gain
+        with np.errstate(all="ignore"):
+            for i in range(frames):  # :88-91
+                out1[i] = f32(platform_sinf(f32(ph * self.TAU)) * gain)
+                t = f32(ph + inc)
+                ph = f32(t - np.trunc(t))  # f32::fract
+        self.phasor = ph
+        for o in outs[1:]:  # :93-95
+            o[:frames] = out1[:frames]
+        return 0
 
 
 class SumNode(Node):  # basic_nodes/sum.rs
@@ -748,7 +796,7 @@ class ResamplerNode(Node):
         return mask
 
 
-NODE_CLASSES = {DUMMY: Node, VOLUME: VolumeNode, SUM: SumNode, SAMPLER: SamplerNode, HARD_CLIP: HardClipNode,
+NODE_CLASSES = {DUMMY: Node, BEEP_TEST: BeepTestNode, VOLUME: VolumeNode, SUM: SumNode, SAMPLER: SamplerNode, HARD_CLIP: HardClipNode,
                 MONO_TO_STEREO: MonoToStereoNode, STEREO_TO_MONO: StereoToMonoNode, STEREO_PAN: PanNode, STEREO_WIDTH: WidthNode,
                 BIQUAD: BiquadNode, DELAY: DelayNode, SPATIAL: SpatialNode, RESAMPLER: ResamplerNode}
 

@@ -1,6 +1,6 @@
 """Regenerates tests/golden/refmodel_digests.json from the INDEPENDENT numpy model (tests/refmodel.py: a second
 restatement of the reference's graph level, written from the .rs files, sharing no code with oracle/fw_oracle.cpp) — for
-every parity scenario whose nodes the model covers (everything but the FIR reverb).  The oracle must reproduce these
+every parity scenario (the model covers every node kind).  The oracle must reproduce these
 digests (tests/test_refmodel_differential.py, CPU tier) and so must the HIP path (tests/test_gpu_parity.py, GPU tier).
 Run: python tests/golden/make_golden_refmodel.py"""
 import json
@@ -15,7 +15,10 @@ import refmodel  # noqa: E402
 import scenarios  # noqa: E402
 import test_scenarios_oracle as t  # noqa: E402
 
-UNSUPPORTED = ("cfg4_reverb", "cfg4_reverb_2irs_mono")
+UNSUPPORTED = ()
+# scenarios the HIP path matches within a tolerance only (BeepTest: ocml's sinf is not glibc's, H6): the model and the oracle
+# agree on them bit for bit, the GPU tier checks them its own way (test_gpu_parity.py)
+GPU_TOLERANCE_ONLY = ("mixed_generic",)
 
 
 def model_cases():

@@ -17,9 +17,8 @@ Restated (file:line = BillyDM/firewheel @ 2024-10-16):
   mono_to_stereo.rs:33-50, stereo_to_mono.rs:33-56, dummy.rs
   graph/processor.rs:61-165,214-248    process_interleaved, process_block
   graph/graph/compiler/schedule.rs:213-344   prepare_graph_inputs / process / read_graph_outputs (silence flags)
-SPEC nodes (not in the reference): StereoPan, StereoWidth, Biquad, Delay, Spatial.
-BeepTest asks the platform libm for sinf, as it does for powf (see platform_powf).  Not modelled: the FIR reverb (covered by
-its own numpy / scipy evaluation in tests/test_oracle_semantics.py), the reference's buffer REUSE (every output port owns a buffer here: results differ only
+SPEC nodes (not in the reference): StereoPan, StereoWidth, Biquad, Delay, FIR reverb, Resampler, Spatial.
+BeepTest asks the platform libm for sinf, as it does for powf (see platform_powf).  Not modelled: the reference's buffer REUSE (every output port owns a buffer here: results differ only
 where the reference exposes stale data, Q12 / a19, which is outside the parity domain).
 """
 import math
@@ -703,6 +702,47 @@ class SpatialNode(Node):
 RS_PHASES, RS_TAPS = 32, 16
 
 
+class FirNode(Node):
+    """SPEC (summation order §3.4): y[n] = sum_k h[k] x[n-k] evaluated over the block's window of
+    W = T-1+frames input samples (the last T-1 of the previous blocks, then this block's) in ascending WINDOW position: the
+    taps that do not reach output n count as +0.0; positions are cut into segments of 4096, each segment is one fma chain
+    from +0.0, the segment sums are added in order, and +0.0 is added at the end.  Channel c convolves with channel
+    min(c, C_h - 1) of the impulse response; silence masks are ignored (the tail keeps ringing), the out mask stays clear."""
+    kind = fwapi.FIR
+    SEG = 4096
+
+    def __init__(self, eng, n_in, n_out, params):
+        Node.__init__(self, eng, n_in, n_out, params)
+        ir = eng.samples[int(params[0])]
+        self.T = ir.frames
+        tmp = [np.zeros(self.T, dtype=f32) for _ in range(ir.channels)]
+        ir.fill_buffers(tmp, 0, self.T, 0)
+        self.nch = min(n_in, n_out)
+        self.h = [tmp[min(c, ir.channels - 1)] for c in range(self.nch)]
+        self.hist = [np.zeros(self.T - 1, dtype=f32) for _ in range(self.nch)]
+
+    def process(self, frames, ins, outs, in_mask):
+        T, W = self.T, self.T - 1 + frames
+        i = np.arange(frames)
+        for c in range(min(self.nch, len(ins), len(outs))):
+            win = np.concatenate([self.hist[c], ins[c][:frames]]).astype(f32)
+            h = self.h[c]
+            total = None
+            with np.errstate(all="ignore"):
+                for s0 in range(0, W, self.SEG):
+                    acc = np.zeros(frames, dtype=f32)
+                    for m in range(s0, min(W, s0 + self.SEG)):
+                        d = m - i                                   # window position m is x[n - k] with k = T-1 - (m - n)
+                        ok = (d >= 0) & (d <= T - 1)
+                        hv = np.where(ok, h[np.clip(T - 1 - d, 0, T - 1)], F0)
+                        acc = fma32(np.full(frames, win[m], dtype=f32), hv, acc)
+                    total = acc if total is None else (total + acc).astype(f32)
+                outs[c][:frames] = (total + F0).astype(f32)
+            if T > 1:
+                self.hist[c] = win[W - (T - 1):].copy()
+        return 0
+
+
 def resampler_table():
     from scipy.special import i0
 
@@ -798,7 +838,7 @@ class ResamplerNode(Node):
 
 NODE_CLASSES = {DUMMY: Node, BEEP_TEST: BeepTestNode, VOLUME: VolumeNode, SUM: SumNode, SAMPLER: SamplerNode, HARD_CLIP: HardClipNode,
                 MONO_TO_STEREO: MonoToStereoNode, STEREO_TO_MONO: StereoToMonoNode, STEREO_PAN: PanNode, STEREO_WIDTH: WidthNode,
-                BIQUAD: BiquadNode, DELAY: DelayNode, SPATIAL: SpatialNode, RESAMPLER: ResamplerNode}
+                BIQUAD: BiquadNode, DELAY: DelayNode, fwapi.FIR: FirNode, SPATIAL: SpatialNode, RESAMPLER: ResamplerNode}
 
 
 # ------------------------------------------------------------------------------------------ graph + processor

@@ -323,7 +323,7 @@ def _model_cases():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import make_golden_refmodel as mg
 
-    return mg.model_cases()
+    return [n for n in mg.model_cases() if n not in mg.GPU_TOLERANCE_ONLY]
 
 
 @pytest.mark.parametrize("name", _model_cases())

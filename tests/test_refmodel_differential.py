@@ -96,7 +96,7 @@ def test_model_golden_digests_are_current_and_the_oracle_reproduces_them():
     for name in mg.model_cases():
         assert t.digest(t.CASES[name]()) == gold[name], "oracle differs from the independent model's golden digest: " + name
     # the committed digests really are what the model produces now (spot-checked: the full regeneration is the script)
-    for name in ("events_70", "chain_events_37", "master_chain_fx", "graph_inputs", "rs_bank_40", "spatial_scene"):
+    for name in ("events_70", "chain_events_37", "master_chain_fx", "graph_inputs", "rs_bank_40", "spatial_scene", "mixed_generic", "cfg4_reverb_2irs_mono"):
         assert t.digest(mg.run_on_model(name)) == gold[name], "refmodel_digests.json is stale: " + name
 
 

@@ -1,10 +1,12 @@
 """CPU tier: the oracle (oracle/fw_oracle.cpp) against a SECOND, independent restatement of the reference's graph level
 (tests/refmodel.py, numpy float32, written from the .rs files — no shared code), bit for bit:
 
-* 320 seeds of the GPU fuzz families' own generators (random voice banks with gain / pan / biquad / delay chains, every
+* 440 seeds of the GPU fuzz families' own generators (random voice banks with gain / pan / biquad / delay chains, every
   sample format, master chains, message traffic tagged at random blocks, graph edits between calls; effects racks on
-  stream inputs with calls of arbitrary length), spread over worker processes;
-* every parity scenario the model covers, through digests generated FROM THE MODEL (tests/golden/refmodel_digests.json).
+  stream inputs with calls of arbitrary length; random DAGs over every node kind — resampler sources, spatialisers, small
+  FIR convolutions, mono detours, dangling ports), spread over worker processes;
+* every parity scenario, through digests generated FROM THE MODEL (tests/golden/refmodel_digests.json);
+* config 1 (beep -> volume -> out) through the callback pattern.
 
 What this buys: a misreading of smoother.rs / sampler.rs / sum.rs / volume.rs, or a slip in the
 SPEC nodes' control math, would have to be made twice, independently, in two languages, to go unnoticed.  What it cannot
@@ -23,7 +25,7 @@ import scenarios
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
-N_BANK, N_STREAM = 240, 80
+N_BANK, N_STREAM, N_DAG = 240, 80, 120
 
 
 def _pair(kind, seed):
@@ -36,6 +38,11 @@ def _pair(kind, seed):
         mbf = int(pick.choice([64, 128, 256]))
         want = F.fuzz_run(scenarios.TaggedOracle(fwapi.OracleEngine(max_block_frames=mbf)), seed)
         got = F.fuzz_run(scenarios.TaggedOracle(refmodel.RefEngine(max_block_frames=mbf)), seed)
+    elif kind == "dag":
+        pick = np.random.default_rng(70_000 + seed)
+        mbf = int(pick.choice([32, 64, 100, 128, 256]))
+        want = F.fuzz_dag(scenarios.TaggedOracle(fwapi.OracleEngine(max_block_frames=mbf)), seed)
+        got = F.fuzz_dag(scenarios.TaggedOracle(refmodel.RefEngine(max_block_frames=mbf)), seed)
     else:
         pick = np.random.default_rng(95_000 + seed)
         mbf = int(pick.choice([16, 64, 100, 256]))
@@ -56,8 +63,8 @@ def _work(job):
         return False, "%s seed %d: %r" % (job[0], job[1], ex)
 
 
-def test_oracle_and_independent_model_agree_on_320_fuzz_seeds():
-    jobs = [("bank", s) for s in range(N_BANK)] + [("stream", s) for s in range(N_STREAM)]
+def test_oracle_and_independent_model_agree_on_440_fuzz_seeds():
+    jobs = [("bank", s) for s in range(N_BANK)] + [("stream", s) for s in range(N_STREAM)] + [("dag", s) for s in range(N_DAG)]
     fwapi.oracle_lib()  # built once, before the workers start
     procs = max(1, min(8, (os.cpu_count() or 2)))
     with mp.get_context("fork").Pool(procs) as pool:

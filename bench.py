@@ -121,7 +121,9 @@ class OracleSide(object):
 
 
 # ------------------------------------------------------------------------------------------------ the graphs
-def sum_tree(e, ends, radix, master=False):
+def sum_tree(e, ends, radix, master=False, connect_out=True):
+    """radix-`radix` SumNode tree over `ends`; returns the node that feeds graph_out (left unconnected with connect_out=False:
+    a shard of a whole graph whose top node is the mix-bus SumNode)"""
     level = ends
     first_level = None
     while True:
@@ -161,10 +163,12 @@ def sum_tree(e, ends, radix, master=False):
             m = e.add(kind, 2, 2, params)
             e.connect_stereo(cur, m)
             cur = m
-    e.connect_stereo(cur, e.out_node())
+    if connect_out:
+        e.connect_stereo(cur, e.out_node())
+    return cur
 
 
-def graph_bank(e, voices, radix, seed=0, master=False, extra=(), rs_samples=None):
+def graph_bank(e, voices, radix, seed=0, master=False, extra=(), rs_samples=None, connect_out=True):
     """cfg2 / cfg5 voice: sampler -> gain -> pan [-> width -> hard clip with --voice-fx].  Returns (samplers, volumes).
     rs_samples: the voices' sources are SPEC resamplers (looping, ratio U(0.5, 1.5)) on these sample ids instead of samplers."""
     import numpy as np
@@ -189,12 +193,13 @@ def graph_bank(e, voices, radix, seed=0, master=False, extra=(), rs_samples=None
         samplers.append(s)
         volumes.append(vol)
         ends.append(cur)
-    sum_tree(e, ends, radix, master)
-    e.update()
-    return samplers, volumes
+    root = sum_tree(e, ends, radix, master, connect_out)
+    if connect_out:
+        e.update()
+    return samplers, volumes, root
 
 
-def graph_chain(e, voices, radix, seed=0, master=False):
+def graph_chain(e, voices, radix, seed=0, master=False, connect_out=True):
     """cfg3 voice: sampler -> biquad LPF (cutoff U(200, 8000) Hz, Q 0.707) -> delay (U(10, 250) ms, feedback 0.3,
     mix 0.5) -> gain."""
     import numpy as np
@@ -211,9 +216,10 @@ def graph_chain(e, voices, radix, seed=0, master=False):
         e.connect_stereo(dl, vol)
         samplers.append(s)
         ends.append(vol)
-    sum_tree(e, ends, radix, master)
-    e.update()
-    return samplers, []
+    root = sum_tree(e, ends, radix, master, connect_out)
+    if connect_out:
+        e.update()
+    return samplers, [], root
 
 
 def reverb_ir(taps):
@@ -225,7 +231,7 @@ def reverb_ir(taps):
     return (h / np.abs(h).sum(axis=1, keepdims=True)).astype(np.float32)
 
 
-def graph_reverb(e, voices, radix, ir_sample):
+def graph_reverb(e, voices, radix, ir_sample, connect_out=True):
     """cfg4: V x (sampler -> `taps`-tap stereo FIR convolution) -> radix sum tree -> out."""
     ends, samplers = [], []
     for v in range(voices):
@@ -234,20 +240,22 @@ def graph_reverb(e, voices, radix, ir_sample):
         e.connect_stereo(s, f)
         samplers.append(s)
         ends.append(f)
-    sum_tree(e, ends, radix)
-    e.update()
-    return samplers, []
+    root = sum_tree(e, ends, radix, False, connect_out)
+    if connect_out:
+        e.update()
+    return samplers, [], root
 
 
-def build_graph(e, wl, voices, radix, seed, master, ir_sample=None, voice_fx=False, rs_samples=None):
+def build_graph(e, wl, voices, radix, seed, master, ir_sample=None, voice_fx=False, rs_samples=None, connect_out=True):
+    """-> (samplers, volumes, root).  connect_out=False: the shard's tree is left unconnected (and not compiled)"""
     if wl == "cfg4":
-        return graph_reverb(e, voices, radix, ir_sample)
+        return graph_reverb(e, voices, radix, ir_sample, connect_out)
     if wl == "cfg3":
-        return graph_chain(e, voices, radix, seed, master)
+        return graph_chain(e, voices, radix, seed, master, connect_out)
     extra = ((K_WIDTH, [1.3]), (K_HARD_CLIP, [-3.0])) if voice_fx is True else ()
     if voice_fx == "spatial":  # a SPEC 3D spatialiser at the end of every voice (2 -> 2: mono sum, ITD, distance + pan gains)
         extra = ((K_SPATIAL, [2.0, 0.5, -3.0]),)
-    return graph_bank(e, voices, radix, seed, master, extra, rs_samples)
+    return graph_bank(e, voices, radix, seed, master, extra, rs_samples, connect_out)
 
 
 def want_plan(wl, force_generic):
@@ -265,8 +273,8 @@ def make_gpu(fa, wl, V, B, K, radix, src, F, sfmt, seed, args, stream, device):
     fmt = PLANAR_F32 if sfmt == "f32" else INTERLEAVED_I16
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
     ids = [cx.new_sample_device(fmt, 2, F, src[v].data_ptr()) for v in range(V)] if rs else None
-    samplers, volumes = build_graph(g, wl, V, radix, seed, "send" if getattr(args, "send", False) else ("iir" if getattr(args, "master_iir", False) else args.master), ir,
-                                    "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
+    samplers, volumes, _ = build_graph(g, wl, V, radix, seed, "send" if getattr(args, "send", False) else ("iir" if getattr(args, "master_iir", False) else args.master), ir,
+                                       "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
     if not rs:
         for v, s in enumerate(samplers):
             smp = cx.new_sample_device(fmt, 2, F, src[v].data_ptr())
@@ -283,12 +291,33 @@ def make_oracle(wl, V, B, radix, seed, args, host_src, fmt=PLANAR_F32):
     ir = o.e.new_sample(PLANAR_F32, 2, reverb_ir(args.taps)) if wl == "cfg4" else None
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
     ids = [o.e.new_sample(fmt, 2, host_src[v]) for v in range(V)] if rs else None
-    samplers, volumes = build_graph(o, wl, V, radix, seed, "send" if getattr(args, "send", False) else ("iir" if getattr(args, "master_iir", False) else args.master), ir,
-                                    "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
+    samplers, volumes, _ = build_graph(o, wl, V, radix, seed, "send" if getattr(args, "send", False) else ("iir" if getattr(args, "master_iir", False) else args.master), ir,
+                                       "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
     if not rs:
         for v, s in enumerate(samplers):
             o.start(s, o.e.new_sample(fmt, 2, host_src[v]))
     return o, samplers, volumes
+
+
+def make_oracle_whole(wl, world, V, B, radix, args, host_srcs):
+    """The WHOLE graph of an N-rank run as the reference would express it: the N shards (rank r's graph is built with seed r,
+    as its process builds it) under ONE top-level N-port stereo SumNode (nodes/sum.rs:41-136) -> graph_out.  host_srcs[r][v] =
+    voice v of rank r's sample data."""
+    o = OracleSide(B)
+    roots, starts = [], []
+    for r in range(world):
+        samplers, _, root = build_graph(o, wl, V, radix, r, args.master, None, args.voice_fx, None, connect_out=False)
+        roots.append(root)
+        starts.append(samplers)
+    top = o.add(K_SUM, 2 * world, 2)
+    for p, root in enumerate(roots):
+        o.connect_stereo(root, top, 2 * p)
+    o.connect_stereo(top, o.out_node())
+    o.update()
+    for r in range(world):
+        for v, smp in enumerate(starts[r]):
+            o.start(smp, o.e.new_sample(PLANAR_F32, 2, host_srcs[r][v]))
+    return o
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -423,6 +452,90 @@ def parity_check(fa, torch, wl, V, B, K, radix, seed, args, src, F, sfmt, stream
     return res
 
 
+def shard_sources(torch, shard, r, V, F, dev, stagger=0):
+    """rank r's synthetic sources: uniform(-1, 1) f32, the generator seeded by the shard's first GLOBAL voice id — the same call
+    on any rank of the same hardware gives the same bytes, which is how rank 0 hands the oracle every shard's inputs"""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(shard.voice_seed(r * V))
+    pitch = 2 * F + stagger
+    src = torch.empty(V * pitch, dtype=torch.float32, device=dev).as_strided((V, 2, F), (pitch, F, 1))
+    src.uniform_(-1.0, 1.0, generator=gen)
+    return src
+
+
+def parity_check_multi(env, args, wl, V, B, K, F, src, stream, device, mode):
+    """N > 1: one call of the benched launch shape on a fresh context on EVERY rank, the partial buses (+ silence flags) through
+    the run's own mix-bus reduction, and rank 0's reduced bus compared with the oracle's WHOLE graph — the N shards under one
+    N-port SumNode (nodes/sum.rs:41-136) — on blocks {0, 1, K/2, K-1} (cfg3: {0, 1}).  Bit-exact in the rank-ordered modes
+    (exchange, ordered); the all-reduce re-associates the f32 sum for N > 2, so there the bar is |got - ref| <= 1e-6 x the sum
+    of the shards' |partial| per sample.  Collective: every rank calls it."""
+    import numpy as np
+
+    torch, fa, shard, dist = env["torch"], env["fa"], env["shard"], env["dist"]
+    rank, world, dev, hostonly = env["rank"], env["world"], env["dev"], env["hostonly"]
+    t0 = time.perf_counter()
+    cx, g, samplers, _ = make_gpu(fa, wl, V, B, K, args.radix, src, F, "f32", rank, args, stream, device)
+    n = K * B * 2
+    part = [torch.zeros(n, dtype=torch.float32, device=dev)]
+    sil = [torch.zeros(K * 2, dtype=torch.uint8, device=dev)]
+    red = [torch.zeros(n, dtype=torch.float32, device=dev)]
+    reducer, used, note = make_reducer(env, args, cx, part, sil, B, mode=mode, reds=red)
+    if not hostonly:
+        torch.cuda.synchronize()
+    cx.process_blocks_device_flags(K, part[0].data_ptr(), 2, sil[0].data_ptr())
+    cx.synchronize()
+    mine = part[0].clone()  # (the all-reduce works in place)
+    reducer.submit(0)
+    out = reducer.wait(0)
+    reducer.wait_all()
+    cx.synchronize()
+    if not hostonly:
+        torch.cuda.synchronize()
+    blocks = sorted(set([0, 1, K // 2, K - 1])) if (wl in ("cfg2", "cfg5") and K >= 4 and F >= K * B) else ([0, 1] if K >= 2 else [0])
+    pick = lambda t: torch.cat([t[b * B * 2:(b + 1) * B * 2] for b in blocks]).cpu().numpy()
+    got = pick(out)
+    parts = [None] * world
+    dist.all_gather_object(parts, pick(mine))  # the shards' own partial buses on the compared blocks: the tolerance's scale
+    flags = [None] * world
+    dist.all_gather_object(flags, sil[0].cpu().numpy().reshape(K, 2)[blocks])
+    res = None
+    if rank == 0:
+        host_srcs = []
+        for r in range(world):
+            sr = src if r == 0 else shard_sources(torch, shard, r, V, F, dev, args.src_stagger)
+            if r == 0:  # the regeneration is what it claims to be: rank 0's own shard comes out identical
+                again = shard_sources(torch, shard, 0, V, F, dev, args.src_stagger)
+                assert bool(torch.equal(again, src)), "source regeneration is not deterministic"
+                del again
+            host_srcs.append(torch.cat([sr[:, :, b * B:(b + 1) * B] for b in blocks], dim=2).cpu().numpy())
+            del sr
+        o = make_oracle_whole(wl, world, V, B, args.radix, args, host_srcs)
+        ref = o.e.process_blocks(len(blocks))
+        same = bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32)))
+        scale = np.sum([np.abs(p) for p in parts], axis=0)
+        err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        tol_ok = bool(np.all(err <= 1e-6 * scale + 1e-30))
+        res = {"bit_exact": same, "within_tolerance": tol_ok, "tolerance": "1e-6 x sum over ranks of |partial bus| per sample",
+               "max_abs_err": float(err.max()), "max_err_over_scale": float(np.max(err / np.maximum(scale, 1e-30))),
+               "ranks": world, "bus_reduce": used, "bus_reduce_fallback": note, "blocks": len(blocks), "block_indices": blocks,
+               "voices": V * world, "voices_per_rank": V, "blocks_per_call": K, "samples_compared": int(got.size),
+               "silent_flags_seen": int(sum(int(f.sum()) for f in flags)), "launch_plan": cx.plan_kind(),
+               "against": "oracle (C++ restatement of the reference): the WHOLE graph, %d shards under one %d-port SumNode, same source frames" % (world, world),
+               "expected": "bit_exact" if used in ("exchange", "ordered") or world <= 2 else "within_tolerance"}
+        if hostonly:
+            res = {"skipped": "host-only harness: no audio computed", "ranks": world, "bus_reduce": used, "oracle_whole_graph_nonzero": bool(np.any(ref))}
+        elif not bool(np.any(ref)):
+            res["bit_exact"] = res["within_tolerance"] = False
+            res["error"] = "the reference output is all zeros: nothing was compared"
+        res["secs"] = round(time.perf_counter() - t0, 2)
+    if hasattr(reducer, "close"):
+        reducer.close(dist)
+    else:
+        dist.barrier()
+    cx.close()
+    return res
+
+
 # ------------------------------------------------------------------------------------------------ realtime / cfg1
 def realtime_probe(cx, B, callbacks=1500):
     """one max_block_frames block per fwgpu_stream_callback, output to pageable host memory, synchronous — the call
@@ -496,7 +609,34 @@ def pmc_traffic(kernel, V, B, K, name):
     return None, None
 
 
-def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
+REDUCE_DESC = {"exchange": "one-shot exchange over peer-mapped slots (fwgpu_bus_exchange, rank-ordered: bit-exact)",
+               "ordered": "RCCL all-gather + rank-ordered sum kernel (bit-exact)", "allreduce": "RCCL all-reduce", None: "none"}
+
+
+def make_reducer(env, args, cx, outs, sils, B, mode=None, reds=None):
+    """the mix-bus reduction of an N > 1 run -> (reducer, mode used, fallback note).  `exchange` (default) needs dmabuf IPC and
+    peer access between the devices; when any rank cannot set it up, ALL ranks fall back to the RCCL all-reduce and the line
+    says so."""
+    torch, shard, dist = env["torch"], env["shard"], env["dist"]
+    mode = mode or args.bus_reduce
+    note = None
+    if mode == "exchange":
+        reds = reds or [torch.empty_like(o) for o in outs]
+        try:
+            return shard.ExchangeReducer(dist, outs, cx, reds, sils, B, 2), "exchange", None
+        except RuntimeError as ex:
+            if env.get("share_device"):
+                raise  # ranks sharing one device have no RCCL to fall back to
+            note = "%s -> fell back to the RCCL all-reduce" % ex
+            mode = "allreduce"
+    if env.get("share_device"):
+        raise SystemExit("bench.py --share-device: RCCL refuses two ranks on one device; only --bus-reduce exchange runs there")
+    if mode == "ordered":
+        return shard.BusReducer(dist, outs, "ordered", cx=cx, sils=sils, frames=B, n_ch=2), "ordered", note
+    return shard.BusReducer(dist, outs, "allreduce", cx=cx), "allreduce", note
+
+
+def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_multi=False):
     """times `steps` steps of one workload; returns the fields of its bench line (rank 0) — `full`: with the CPU baseline,
     the parity check and the realtime probe"""
     torch, fa, shard, dist = env["torch"], env["fa"], env["shard"], env["dist"]
@@ -508,17 +648,15 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
             torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream().cuda_stream if not hostonly else None
-    # synthetic sources, generated in HBM: uniform(-1,1) f32, seed offset by global voice id
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(shard.voice_seed(rank * V))  # stream keyed by the shard's first GLOBAL voice id
+    # synthetic sources, generated in HBM: uniform(-1,1) f32, the stream keyed by the shard's first GLOBAL voice id
     sfmt = args.source_format if wl in ("cfg2", "cfg5") else "f32"
     if sfmt == "i16":  # interleaved stereo PCM, [voice][frame][channel]
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(shard.voice_seed(rank * V))
         src = torch.randint(-32768, 32768, (V, F, 2), dtype=torch.int16, device=dev, generator=gen)
     else:
         # (--src-stagger: floats between consecutive voices' buffers — where the samples sit in HBM relative to one another)
-        pitch = 2 * F + args.src_stagger
-        src = torch.empty(V * pitch, dtype=torch.float32, device=dev).as_strided((V, 2, F), (pitch, F, 1))
-        src.uniform_(-1.0, 1.0, generator=gen)
+        src = shard_sources(torch, shard, rank, V, F, dev, args.src_stagger)
     cx, g, samplers, volumes = make_gpu(fa, wl, V, B, K, args.radix, src, F, sfmt, rank, args, stream, device)
     variant = args.variant if wl in ("cfg2", "cfg5") else "A"
     playing = 1.0
@@ -534,15 +672,17 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
         for v, vol in enumerate(volumes):
             changes.setdefault(warmup + int(rng.integers(0, steps)), []).append(
                 (vol, float(rng.uniform(10, 100)), int(rng.integers(0, K))))
-    # two bus buffers: with N > 1 the reduction of step i (RCCL, its own stream) overlaps the compute of step i+1 —
-    # the mix bus is a sink, nothing in a shard reads it back
-    # ... and each buffer holds the buses of R consecutive steps, reduced by ONE collective: the hand-over between the
-    # compute stream and RCCL's stream costs ~10 us of idle GPU per event on this stack (measured: 20 us per step with a
-    # collective per step), so it is paid once per R steps
+    # two bus buffers: with N > 1 the reduction of step i overlaps the compute of step i+1 — the mix bus is a sink, nothing
+    # in a shard reads it back — and each buffer holds the buses of R consecutive steps, reduced by ONE exchange / collective
+    # (the hand-over between the compute stream and RCCL's stream costs ~10 us of idle GPU per event on this stack).
+    # Every step also reports its per-(block, channel) silence flags: the top-level SumNode skips silent ports (sum.rs:122-124).
     R = max(1, args.reduce_every) if dist is not None else 1
     step_elems = K * B * 2
     outs = [torch.empty(R * step_elems, dtype=torch.float32, device=dev) for _ in range(2)]
-    reducer = shard.BusReducer(dist, outs, args.bus_reduce, cx=cx) if dist is not None else None
+    sils = [torch.zeros(R * K * 2, dtype=torch.uint8, device=dev) for _ in range(2)] if dist is not None else None
+    reducer, reduce_mode, reduce_note = (None, None, None)
+    if dist is not None:
+        reducer, reduce_mode, reduce_note = make_reducer(env, args, cx, outs, sils, B)
     step_no = [0]
     slot = [0]  # bus slot counter: buffer (slot // R) % 2, slice slot % R
     host_out = None
@@ -566,8 +706,11 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
             rc = cx.L.fwgpu_process_interleaved(cx.c, None, host_out.ctypes.data_as(C.POINTER(C.c_float)), 0, 2, K * B, 0.0, 0)
             assert rc == 0, rc
             return
-        cx.process_blocks_device(K, outs[b].data_ptr() + r * step_elems * 4, 2)
-        if reducer is not None and r == R - 1:  # the mix bus: one collective per R steps over R x K x 2 x block f32
+        if reducer is not None:
+            cx.process_blocks_device_flags(K, outs[b].data_ptr() + r * step_elems * 4, 2, sils[b].data_ptr() + r * K * 2)
+        else:
+            cx.process_blocks_device(K, outs[b].data_ptr() + r * step_elems * 4, 2)
+        if reducer is not None and r == R - 1:  # the mix bus: one exchange per R steps over R x K x 2 x block f32
             reducer.submit(b)
 
     def finish_reductions():
@@ -597,7 +740,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if env.get("ctrl_cpu") else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -675,12 +818,21 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True):
                             % (desc, B, "planar f32" if sfmt == "f32" else "interleaved stereo i16", F),
                 "voices_per_gpu": V, "block": B, "blocks_per_step": K, "variant": variant, "master_chain": bool(args.master),
                 "voice_fx": bool(args.voice_fx), "launch_plan": cx.plan_kind(),
-                "parallelism": "voice-shard x%d%s" % (world, (" + RCCL mix-bus %s" % args.bus_reduce) if world > 1 else ""),
+                "parallelism": "voice-shard x%d%s" % (world, (" + mix-bus %s" % REDUCE_DESC[reduce_mode]) if world > 1 else ""),
+                "bus_reduce": reduce_mode, "bus_reduce_fallback": reduce_note,
                 "realtime_factor": (total / dt) / (48000.0 * V * world),
                 "device": name, "compute_units": cus,
             },
             "roofline": roofline,
         }
+    if reducer is not None and hasattr(reducer, "close"):
+        if res is not None:  # how far the ranks ran apart: the longest rank 0's reduce kernels waited for each rank's arrival
+            res["config"]["bus_exchange_max_wait_us"] = reducer.x.wait_stats()
+        reducer.close(dist)
+    if world > 1 and (full or parity_multi) and not args.no_parity_check and wl in ("cfg2", "cfg5", "cfg3") and sfmt == "f32":
+        pc = parity_check_multi(env, args, wl, V, B, K, F, src, stream, device, reduce_mode)  # collective: every rank takes part
+        if rank == 0:
+            res["parity_check"] = pc
     if full and rank == 0 and world == 1 and not hostonly:
         if not args.no_realtime and wl != "cfg4":
             res["realtime_us_per_callback"], res["realtime_us_per_callback_from_python"] = realtime_probe(cx, B)
@@ -739,6 +891,49 @@ def other_configs(env, args):
     return out
 
 
+def other_configs_multi(env, args):
+    """N > 1, next to the headline: (1) BASELINE configs[4] as it is written — 8 192 voices per GPU, block 1024, the mix-bus
+    reduction after EVERY step — with its own roofline and parity check against the oracle's whole graph; (2) the headline
+    workload again under the other mix-bus reductions (the RCCL all-reduce north_star names; all-gather + rank-ordered sum), each
+    with its own parity check.  Every rank runs them (they are collective); rank 0 returns the dict."""
+    import copy
+
+    out = {"other_configs": {}, "bus_reduce_modes": {}}
+    t0 = time.perf_counter()
+
+    def short(r):
+        cfg = r["config"]
+        return {"workload": cfg["workload"], "value": None if env["hostonly"] else r["value"], "unit": "voice-samples/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                "blocks_per_step": cfg["blocks_per_step"], "parallelism": cfg["parallelism"], "bus_reduce": cfg["bus_reduce"],
+                "bus_reduce_fallback": cfg["bus_reduce_fallback"], "roofline": r["roofline"], "parity_check": r.get("parity_check")}
+
+    hostonly = env["hostonly"]
+    V, B, K, F, _ = (64, 64, 4, 1024, 0) if hostonly else DEFAULTS["cfg5"]
+    a5 = copy.copy(args)
+    a5.reduce_every = 1  # "collective every step"
+    try:
+        r = run_workload(env, a5, "cfg5", V, B, K, F, 3 if hostonly else 12, 1 if hostonly else 3, full=False, parity_multi=True)
+        if env["rank"] == 0:
+            out["other_configs"]["cfg5"] = short(r)
+    except Exception as ex:  # (an exception on one rank only would leave the others in a collective: the run then times out loudly)
+        out["other_configs"]["cfg5"] = {"error": repr(ex)}
+    if not env.get("share_device"):
+        dV, dB, dK, dF, _ = (64, 64, 4, 1024, 0) if hostonly else DEFAULTS["cfg2"]
+        for mode in ("allreduce", "ordered", "exchange"):
+            if mode == args.bus_reduce:
+                continue
+            am = copy.copy(args)
+            am.bus_reduce = mode
+            try:
+                r = run_workload(env, am, "cfg2", dV, dB, dK, dF, 3 if hostonly else 10, 1 if hostonly else 3, full=False, parity_multi=True)
+                if env["rank"] == 0:
+                    out["bus_reduce_modes"][mode] = short(r)
+            except Exception as ex:
+                out["bus_reduce_modes"][mode] = {"error": repr(ex)}
+    out["other_configs"]["secs"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ launcher
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks here, one process per GPU, exactly as the
@@ -750,7 +945,7 @@ def self_launch(args):
         import torch
 
         n = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if n < args.gpus:
+        if n < (1 if args.share_device else args.gpus):
             raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible on this node" % (args.gpus, n))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -815,8 +1010,15 @@ def main():
                          "(smoother ramps, message path inside the timed region); C every 4th voice paused (silence masks)")
     ap.add_argument("--reduce-every", type=int, default=4,
                     help="N>1: steps whose mix buses share one collective (the reduction of R steps overlaps the next R)")
-    ap.add_argument("--bus-reduce", choices=["allreduce", "ordered"], default="allreduce",
-                    help="N>1: RCCL all-reduce (named path) or all-gather + rank-ordered sum kernel (bit-exact)")
+    ap.add_argument("--bus-reduce", choices=["exchange", "allreduce", "ordered"], default="exchange",
+                    help="N>1, the mix bus: libfwgpu's one-shot exchange over peer-mapped slots (rank-ordered, bit-exact; falls back to "
+                         "the all-reduce when IPC / peer access is unavailable), the RCCL all-reduce (north_star's named path; "
+                         "re-associates the sum for N > 2), or RCCL all-gather + rank-ordered sum kernel (bit-exact)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="N>1 on a ONE-GPU box: all ranks on device 0 (separate processes, hipIpc between them, gloo as the control "
+                         "plane because RCCL refuses two ranks on one device).  Proves the N > 1 path end to end; the aggregate is "
+                         "NOT a scaling figure and the line says so")
+    ap.add_argument("--force-other-configs", action="store_true", help="tests: emit other_configs / bus_reduce_modes for a non-default shape too")
     args = ap.parse_args()
     if args.lean:
         args.no_cpu_baseline = args.no_parity_check = args.no_other_configs = args.no_realtime = True
@@ -850,6 +1052,8 @@ def main():
     if not hostonly:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product has no CPU path)")
+        if args.share_device:
+            local_rank = 0
         if torch.cuda.device_count() <= local_rank:
             raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
@@ -865,7 +1069,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if hostonly:
+        if hostonly or args.share_device:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -875,7 +1079,8 @@ def main():
     from firewheel_amd import shard
 
     env = {"torch": torch, "fa": fa, "shard": shard, "dist": dist, "rank": rank, "world": world, "device": 0 if hostonly else local_rank,
-           "dev": "cpu" if hostonly else "cuda", "hostonly": hostonly}
+           "dev": "cpu" if hostonly else "cuda", "hostonly": hostonly, "ctrl_cpu": bool(hostonly or args.share_device),
+           "share_device": bool(args.share_device and not hostonly)}
     repeats = []
     for _ in range(max(0, args.repeat_first)):  # diagnostic: the same run, same process, fresh allocations each time
         r0 = run_workload(env, args, wl, V, B, K, F, steps, args.warmup, full=False)
@@ -903,7 +1108,12 @@ def main():
             "realtime_us_per_callback": res.get("realtime_us_per_callback"),
             "realtime_us_per_callback_from_python": res.get("realtime_us_per_callback_from_python"),
             "rccl_ranks_seen": ranks_seen,
+            "ranks_seen": ranks_seen,
         }
+        if args.share_device and world > 1:
+            line["virtual_ranks_on_one_device"] = True
+            line["note"] = ("--share-device: %d processes on ONE GPU (hipIpc between them, gloo control plane) — proves the N > 1 path; "
+                            "`value` is the aggregate of ranks that time-share one device, not a scaling figure" % world)
         if repeats:
             line["repeats_before"] = repeats
         if hostonly:
@@ -911,6 +1121,10 @@ def main():
             line["invalid"] = "host-only harness (FWGPU_BENCH_HOSTONLY): orchestration test, no audio computed, not a measurement"
         if world == 1 and default_shape and not args.no_other_configs and not hostonly:
             line["other_configs"] = other_configs(env, args)
+    if world > 1 and (default_shape or args.force_other_configs) and not args.no_other_configs:
+        extra = other_configs_multi(env, args)  # collective: every rank runs them, rank 0 keeps the results
+        if rank == 0:
+            line.update(extra)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -24,6 +24,7 @@ def build_library(force=False):
     return LIB_PATH
 
 
+EXCHANGE_HANDLE_BYTES = 128  # FWGPU_EXCHANGE_HANDLE_BYTES
 i64, u32, u64, f32, f64, vp, ci = C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double, C.c_void_p, C.c_int
 fp = C.POINTER(C.c_float)
 
@@ -78,7 +79,19 @@ SIGNATURES = {
     "fwgpu_sampler_set_loop_range": (ci, [vp, i64, ci, f64, f64, u32]),
     "fwgpu_process_interleaved": (ci, [vp, fp, fp, u32, u32, u64, f64, u32]),
     "fwgpu_process_blocks_device": (ci, [vp, u32, vp, u32]),
+    "fwgpu_process_blocks_device_flags": (ci, [vp, u32, vp, u32, vp]),
     "fwgpu_bus_sum_ordered": (ci, [vp, C.POINTER(vp), u32, vp, u64]),
+    "fwgpu_bus_sum_ordered_flags": (ci, [vp, C.POINTER(vp), C.POINTER(vp), u32, vp, vp, u64, u32, u32]),
+    "fwgpu_bus_exchange_open": (vp, [vp, u32, u32, u64, u32]),
+    "fwgpu_bus_exchange_close": (None, [vp]),
+    "fwgpu_bus_exchange_export": (ci, [vp, vp]),
+    "fwgpu_bus_exchange_connect": (ci, [vp, u32, vp]),
+    "fwgpu_bus_exchange_set_timeout_ms": (ci, [vp, u32]),
+    "fwgpu_bus_exchange_push": (ci, [vp, vp, vp, u64, u32, u32]),
+    "fwgpu_bus_exchange_reduce": (ci, [vp, vp, vp, u64, u32, u32, u32, ci]),
+    "fwgpu_bus_exchange_step": (ci, [vp, vp, vp, vp, vp, u64, u32, u32, u32]),
+    "fwgpu_bus_exchange_status": (ci, [vp, C.POINTER(u64), C.POINTER(u64)]),
+    "fwgpu_bus_exchange_wait_stats": (ci, [vp, C.POINTER(u64), u32, ci]),
     "fwgpu_synchronize": (ci, [vp]),
     "fwgpu_node_process": (ci, [vp, i64, u64, C.POINTER(fp), u32, C.POINTER(fp), u32, u64, C.POINTER(u64), f64, u32]),
     "fwgpu_timing_enable": (ci, [vp, ci]),

@@ -50,10 +50,13 @@ void collect_returns(fwgpu_ctx* c) {
     while (c->returns.peek(it)) {
         // tickets are issued in call order: an unfinished call ends the scan.  An event slot that has been re-recorded
         // since (64 calls with returns later) answers for the later call — later, never earlier, than the truth.
-        if (it.ticket >= c->ret_done_ticket.load(std::memory_order_acquire) &&
-            hipEventQuery(c->ret_events[it.ticket % fwgpu_ctx::RET_EVENTS]) != hipSuccess) {
-            (void)hipGetLastError();
-            break;
+        if (it.ticket >= c->ret_done_ticket.load(std::memory_order_acquire)) {
+            const uint32_t slot = it.ticket % fwgpu_ctx::RET_EVENTS;
+            if (c->ret_event_ticket[slot].load(std::memory_order_acquire) <= it.ticket) break;  // not recorded for this call yet
+            if (hipEventQuery(c->ret_events[slot]) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
         }
         c->returns.pop();
         if (it.sample >= 0 && (size_t)it.sample < c->sample_refs.size() && c->sample_refs[it.sample] > 0) c->sample_refs[it.sample]--;
@@ -727,7 +730,9 @@ static int process_interleaved_impl(fwgpu_ctx* c, const float* input, float* out
             // answered after ~20 ms of spinning has a problem the stream sync below will name
             const unsigned long long want = c->rt_seq;
             volatile unsigned long long* flag = c->h_rt_flag;
-            for (unsigned spins = 0; spins < 40000000u; ++spins) {
+            // (bounded by the CLOCK, looked at every 1024 polls: an iteration count of `pause`s was ~1 s, not 20 ms — ADVICE r2)
+            const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+            for (unsigned spins = 1;; ++spins) {
                 if (*flag == want) {
                     done = true;
                     break;
@@ -735,6 +740,7 @@ static int process_interleaved_impl(fwgpu_ctx* c, const float* input, float* out
 #if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
 #endif
+                if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() > give_up) break;
             }
             std::atomic_thread_fence(std::memory_order_acquire);
         }
@@ -878,17 +884,24 @@ int fwgpu_stream_stats(fwgpu_stream* s, uint64_t* callbacks, uint64_t* underflow
     return 0;
 }
 
-int fwgpu_process_blocks_device(fwgpu_ctx* c, uint32_t num_blocks, float* d_output, uint32_t n_out_ch) {
+int fwgpu_process_blocks_device_flags(fwgpu_ctx* c, uint32_t num_blocks, float* d_output, uint32_t n_out_ch, uint8_t* d_silence) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     AudioCallScope audio;
     use_device(c);
     if (!c->have_plan) return fail(c, FWGPU_ERR_INVALID, "no schedule: call fwgpu_update first");
     if (num_blocks == 0) return 0;
     if (n_out_ch > 64 || (n_out_ch && !d_output)) return fail(c, FWGPU_ERR_INVALID, "bad output (null, or more than 64 channels)");
-    return run_blocks(c, (uint64_t)num_blocks * c->mbf, nullptr, 0, d_output, (int)n_out_ch);
+    c->out_sil = d_silence;
+    const int rc = run_blocks(c, (uint64_t)num_blocks * c->mbf, nullptr, 0, d_output, (int)n_out_ch);
+    c->out_sil = nullptr;
+    return rc;
+}
+int fwgpu_process_blocks_device(fwgpu_ctx* c, uint32_t num_blocks, float* d_output, uint32_t n_out_ch) {
+    return fwgpu_process_blocks_device_flags(c, num_blocks, d_output, n_out_ch, nullptr);
 }
 
-int fwgpu_bus_sum_ordered(fwgpu_ctx* c, const float* const* d_parts, uint32_t n_parts, float* d_out, uint64_t n_floats) {
+int fwgpu_bus_sum_ordered_flags(fwgpu_ctx* c, const float* const* d_parts, const uint8_t* const* d_silence, uint32_t n_parts, float* d_out,
+                                uint8_t* d_out_silence, uint64_t n_floats, uint32_t frames_per_block, uint32_t n_channels) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     AudioCallScope audio;
     use_device(c);
@@ -901,8 +914,17 @@ int fwgpu_bus_sum_ordered(fwgpu_ctx* c, const float* const* d_parts, uint32_t n_
     }
     for (uint32_t r = n_parts; r < FW_MAX_BUS_PARTS; ++r) bp.part[r] = nullptr;
     if ((uintptr_t)d_out & 15u) return fail(c, FWGPU_ERR_INVALID, "output not 16-byte aligned");
-    LCHK(c, launch_bus_sum_ordered(c->stream, bp, d_out, (size_t)n_floats));
+    uint32_t n_blocks = 0;
+    if (d_silence) {
+        if (frames_per_block == 0 || n_channels == 0) return fail(c, FWGPU_ERR_INVALID, "silence flags need the block geometry (frames, channels)");
+        const uint64_t per = (uint64_t)frames_per_block * n_channels;
+        n_blocks = (uint32_t)((n_floats + per - 1) / per);
+    }
+    LCHK(c, launch_bus_sum_ordered(c->stream, bp, d_silence, d_out, d_out_silence, (size_t)n_floats, n_blocks, frames_per_block, n_channels));
     return 0;
+}
+int fwgpu_bus_sum_ordered(fwgpu_ctx* c, const float* const* d_parts, uint32_t n_parts, float* d_out, uint64_t n_floats) {
+    return fwgpu_bus_sum_ordered_flags(c, d_parts, nullptr, n_parts, d_out, nullptr, n_floats, 0, 0);
 }
 
 int fwgpu_synchronize(fwgpu_ctx* c) {

@@ -208,6 +208,7 @@ struct fwgpu_ctx {
     RetRing returns;
     static constexpr uint32_t RET_EVENTS = 64;
     hipEvent_t ret_events[RET_EVENTS] = {nullptr};
+    std::atomic<uint32_t> ret_event_ticket[RET_EVENTS] = {};  // ticket + 1 the slot's event was last recorded for (0 = never)
     uint32_t ret_ticket = 0;         // audio thread: process calls that returned a sample so far
     std::atomic<uint32_t> ret_done_ticket{0};  // tickets below this belong to calls the audio thread has SEEN complete (sync / flag)
     bool ret_this_call = false;
@@ -247,6 +248,10 @@ struct fwgpu_ctx {
     std::vector<int> hlevel_off, hlevel_cnt, hlevel_kinds;
     bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2
     DevBuf d_rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS]
+
+    // fwgpu_process_blocks_device_flags: where the call in progress reports, per (block, channel), whether that graph-output
+    // channel was flagged silent (device memory of the caller; null = not asked for)
+    uint8_t* out_sil = nullptr;
 
     // ProcInfo of the call in progress (core/node.rs:111-118) + what the backend reported so far (StreamStatus bits)
     double proc_stream_time = 0.0;

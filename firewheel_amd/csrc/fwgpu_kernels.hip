@@ -9,6 +9,7 @@
 //   k_chain.hip.h    fused chain plan: k_chain (sampler -> biquad -> delay -> gains -> leaf sum, LDS software pipeline)
 //   k_fir.hip.h      FIR convolution bank: Toeplitz GEMM on the f32 matrix cores
 //   k_rt.hip.h       realtime edge: one launch per callback for the voice-bank plan (control + leaf + root)
+//   k_exchange.hip.h multi-GPU mix bus: one-shot exchange over peer-mapped slots + the rank-ordered top-level SumNode
 // All plans share the node state in HBM.  Compiled with -ffp-contract=off: the reference (Rust) never fuses mul+add,
 // and parity is bit-exact; the only fused multiply-adds are the ones a SPEC node asks for by name.
 //
@@ -36,6 +37,7 @@ __device__ __forceinline__ v4f splat(float x) { return (v4f){x, x, x, x}; }
 #include "k_chain.hip.h"
 #include "k_fir.hip.h"
 #include "k_rt.hip.h"
+#include "k_exchange.hip.h"
 
 // ------------------------------------------------------------------ launch wrappers (host side of this TU)
 #define HIPCHK(x)                        \
@@ -150,11 +152,40 @@ int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0,
     else hipLaunchKernelGGL(k_chain<1>, dim3(fv.n_groups, 2), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
     return (int)hipGetLastError();
 }
-int launch_bus_sum_ordered(hipStream_t s, const BusParts& bp, float* d_out, size_t n_floats) {
+int launch_bus_sum_ordered(hipStream_t s, const BusParts& bp, const uint8_t* const* sil, float* d_out, uint8_t* d_out_sil, size_t n_floats,
+                           uint32_t n_blocks, uint32_t frames, uint32_t n_ch) {
     if (bp.n <= 0 || n_floats == 0) return 0;
     const size_t n4 = n_floats / 4;
     const size_t threads = n4 ? n4 : 1;
-    hipLaunchKernelGGL(k_bus_sum_ordered, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, bp, d_out, n4, n_floats);
+    SilView sv;
+    for (int p = 0; p < FW_MAX_BUS_PARTS; ++p) sv.sil[p] = (sil && p < bp.n) ? sil[p] : nullptr;
+    if (!sil) n_blocks = 0;
+    hipLaunchKernelGGL(k_bus_sum_ordered, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, bp, sv, d_out, d_out_sil, n4, n_floats,
+                       n_blocks, frames, n_ch);
+    return (int)hipGetLastError();
+}
+int launch_bus_push(hipStream_t s, const ExchangePeers& peers, const ExchangeGeom& g, const float* d_part, const uint8_t* d_sil,
+                    size_t n_floats, uint32_t n_sil, unsigned long long seq, unsigned* d_counter) {
+    const size_t n4 = n_floats / 4;
+    const size_t threads = n4 ? n4 : 1;
+    hipLaunchKernelGGL(k_bus_push, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, peers, g, d_part, d_sil, n_floats, n_sil, seq,
+                       d_counter);
+    return (int)hipGetLastError();
+}
+int launch_bus_reduce(hipStream_t s, char* base, const ExchangeGeom& g, float* d_out, uint8_t* d_out_sil, size_t n_floats, uint32_t n_sil,
+                      uint32_t frames, uint32_t n_ch, unsigned long long seq, unsigned long long budget_ticks, unsigned long long* d_sync) {
+    const size_t n4 = n_floats / 4;
+    const size_t threads = n4 ? n4 : 1;
+    hipLaunchKernelGGL(k_bus_wait, dim3(1), dim3(64), 0, s, base, g.world, seq, budget_ticks, d_sync);
+    hipLaunchKernelGGL(k_bus_reduce, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, base, g, d_out, d_out_sil, n_floats, n_sil,
+                       frames, n_ch, seq, (const unsigned long long*)d_sync);
+    return (int)hipGetLastError();
+}
+int launch_out_flags(hipStream_t s, const uint8_t* flags, size_t flags_blk_stride, const int* d_bufs, int n_bufs, int mode, int n_out_ch, int K,
+                     uint8_t* d_out) {
+    const int n = K * n_out_ch;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_out_flags, dim3((n + 255) / 256), dim3(256), 0, s, flags, flags_blk_stride, d_bufs, n_bufs, mode, n_out_ch, K, d_out);
     return (int)hipGetLastError();
 }
 int launch_rt_block(hipStream_t s, const FusedView& fv, const DevView& upv, const RootArgs& root, float* d_out, uint32_t cmd_block0,

@@ -121,8 +121,19 @@ int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K);
 int launch_rt_block(hipStream_t s, const FusedView& fv, const DevView& upv, const RootArgs& root, float* d_out, uint32_t cmd_block0,
                     unsigned* d_sync, unsigned long long* d_done_flag, unsigned long long done_seq);
 int launch_signal_done(hipStream_t s, unsigned long long* d_done_flag, unsigned long long done_seq);
-// the R-port top-level SumNode over the shards' partial buses, rank order (16-byte aligned parts)
-int launch_bus_sum_ordered(hipStream_t s, const BusParts& bp, float* d_out, size_t n_floats);
+// the R-port top-level SumNode over the shards' partial buses, rank order (16-byte aligned parts).  d_sil (may be null) =
+// n_parts device pointers' worth of silence flags, each [n_blocks][n_ch] or null; d_out_sil (may be null) receives the node's
+// out-mask per (block, channel)
+int launch_bus_sum_ordered(hipStream_t s, const BusParts& bp, const uint8_t* const* sil, float* d_out, uint8_t* d_out_sil, size_t n_floats,
+                           uint32_t n_blocks, uint32_t frames, uint32_t n_ch);
+// one-shot exchange (k_exchange.hip.h): push this rank's bus + flags into its slot on every rank / wait for all arrivals and sum
+int launch_bus_push(hipStream_t s, const ExchangePeers& peers, const ExchangeGeom& g, const float* d_part, const uint8_t* d_sil,
+                    size_t n_floats, uint32_t n_sil, unsigned long long seq, unsigned* d_counter);
+int launch_bus_reduce(hipStream_t s, char* base, const ExchangeGeom& g, float* d_out, uint8_t* d_out_sil, size_t n_floats, uint32_t n_sil,
+                      uint32_t frames, uint32_t n_ch, unsigned long long seq, unsigned long long budget_ticks, unsigned long long* d_sync);
+// per (block, channel) of a batch: was that graph-output channel flagged silent (mode: see k_out_flags)
+int launch_out_flags(hipStream_t s, const uint8_t* flags, size_t flags_blk_stride, const int* d_bufs, int n_bufs, int mode, int n_out_ch, int K,
+                     uint8_t* d_out);
 // nq = tile size / 64 frames (1 or 2; 256-frame tiles measured slower: the serial stage then dominates the step):
 // frames % (64*nq) == 0 and every delay line >= 64*nq frames
 int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0, int nq);

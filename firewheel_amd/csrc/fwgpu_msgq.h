@@ -102,6 +102,20 @@ class RetRing {  // SPSC: the audio thread pushes, the control side pops
         tail_.store(t + 1, std::memory_order_release);
         return true;
     }
+    // two-phase push (producer only): items are written behind the published tail and become visible together — a process call
+    // stages its returns while it retires messages and publishes them only AFTER their completion event has been recorded
+    bool stage(const RetItem& it) {
+        const uint64_t t = tail_.load(std::memory_order_relaxed) + staged_;
+        if (t - head_.load(std::memory_order_acquire) > mask_) return false;
+        items_[t & mask_] = it;
+        staged_++;
+        return true;
+    }
+    void publish() {
+        if (!staged_) return;
+        tail_.store(tail_.load(std::memory_order_relaxed) + staged_, std::memory_order_release);
+        staged_ = 0;
+    }
     bool peek(RetItem& out) const {
         const uint64_t h = head_.load(std::memory_order_relaxed);
         if (h == tail_.load(std::memory_order_acquire)) return false;
@@ -113,6 +127,7 @@ class RetRing {  // SPSC: the audio thread pushes, the control side pops
   private:
     RetItem* items_ = nullptr;
     uint64_t mask_ = 0;
+    uint64_t staged_ = 0;  // producer side only
     alignas(64) std::atomic<uint64_t> tail_{0};
     alignas(64) std::atomic<uint64_t> head_{0};
 };

@@ -136,12 +136,19 @@ static void note_set_sample(fwgpu_ctx* c, const Cmd& m) {
     it.node = c->slot_ids[m.state];
     it.sample = old;
     it.ticket = c->ret_ticket;
-    if (c->returns.push(it)) c->ret_this_call = true;  // (a full ring drops the notice like the reference's `let _ = push`)
+    if (c->returns.stage(it)) c->ret_this_call = true;  // (a full ring drops the notice like the reference's `let _ = push`)
 }
+// The notices of a call become visible to the control side only AFTER the call's completion event has been recorded: a
+// poller that saw the item first would query an event that was never recorded (hipSuccess) or was recorded 64 tickets ago,
+// and report a sample returned while this call's kernels still read it.  ret_event_ticket says which ticket
+// a slot's event currently answers for: a slot that has not been recorded for this ticket yet reads "not ready".
 void finish_returns(fwgpu_ctx* c) {
     if (!c->ret_this_call) return;
     c->ret_this_call = false;
-    (void)hipEventRecord(c->ret_events[c->ret_ticket % fwgpu_ctx::RET_EVENTS], c->stream);
+    const uint32_t slot = c->ret_ticket % fwgpu_ctx::RET_EVENTS;
+    (void)hipEventRecord(c->ret_events[slot], c->stream);
+    c->ret_event_ticket[slot].store(c->ret_ticket + 1, std::memory_order_release);
+    c->returns.publish();
     c->ret_ticket++;
 }
 void retire_cmds(fwgpu_ctx* c, uint32_t nblocks) {
@@ -348,6 +355,9 @@ int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const
     timer_end(c, e1);
     LCHK(c, launch_graph_out(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride,
                              c->d_gout_bufs.as<int>(), c->n_gout_bufs, d_out, n_out_ch, frames, K));
+    if (c->out_sil)  // read_graph_outputs' silence mask per block (schedule.rs:255-287), for the top-level SumNode of a sharded graph
+        LCHK(c, launch_out_flags(c->stream, v.flags, v.flags_blk_stride, c->d_gout_bufs.as<int>(), c->n_gout_bufs, 0, n_out_ch, K,
+                                 c->out_sil + (size_t)cmd_block * n_out_ch));
     return 0;
 }
 
@@ -356,7 +366,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     FusedView fv;
     fill_fused_view(c, fv);
     // realtime edge: one block, tree = leaves + root, stereo stream -> the whole callback is ONE launch (k_rt_block)
-    if (K == 1 && c->rt_one_launch && !c->ahead_this_call && !c->fused_fx && !c->timing && c->n_tail == 0 && c->up_root_node >= 0 && n_out_ch == 2 &&
+    if (K == 1 && c->rt_one_launch && !c->out_sil && !c->ahead_this_call && !c->fused_fx && !c->timing && c->n_tail == 0 && c->up_root_node >= 0 && n_out_ch == 2 &&
         c->up_level_cnt.size() == 1 && c->d_rt_sync.p) {
         DevView v;
         memset(&v, 0, sizeof(v));
@@ -432,6 +442,9 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
             LCHK(c, launch_bus_sum(c->stream, v, c->d_up_level_nodes.as<int>() + c->up_level_off[l], c->up_level_cnt[l], K, 2));
         if (fuse_root) {
             LCHK(c, launch_root_out(c->stream, v, c->root_args, d_out, K));
+            if (c->out_sil)  // the root's out-mask (k_root_out keeps it in registers): recomputed from its inputs' flags
+                LCHK(c, launch_out_flags(c->stream, v.flags, v.flags_blk_stride, c->root_args.in_tab, c->root_args.n_in, 1, n_out_ch, K,
+                                         c->out_sil + (size_t)cmd_block0 * n_out_ch));
             timer_end(c, e1);
             if (c->ahead_this_call) {
                 HIPC(c, hipEventRecord(c->ev_render[c->ahead_seq & 1], c->stream));
@@ -469,6 +482,9 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     }
     LCHK(c, launch_graph_out(c->stream, fv.bus, fv.bus_flags, c->stride, fv.bus_blk_stride, fv.bus_flags_blk_stride,
                              c->d_root_bufs.as<int>(), 2, d_out, n_out_ch, (int)c->mbf, K));
+    if (c->out_sil)
+        LCHK(c, launch_out_flags(c->stream, fv.bus_flags, fv.bus_flags_blk_stride, c->d_root_bufs.as<int>(), 2, 0, n_out_ch, K,
+                                 c->out_sil + (size_t)cmd_block0 * n_out_ch));
     timer_end(c, e1);
     if (c->ahead_this_call) {
         HIPC(c, hipEventRecord(c->ev_render[c->ahead_seq & 1], c->stream));

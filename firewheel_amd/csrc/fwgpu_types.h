@@ -217,6 +217,17 @@ struct BusParts {
     const float* part[FW_MAX_BUS_PARTS];  // part[r] = rank r's interleaved bus (peer-mapped or all-gathered), same length each
 };
 
+// one-shot mix-bus exchange over peer-mapped slots (k_exchange.hip.h): what every rank of an exchange agrees on ...
+struct ExchangeGeom {
+    int world, rank;
+    uint64_t max_floats;  // floats of one slot's bus
+    uint64_t slot_bytes;  // max_floats * 4 + silence bytes, padded to 256
+};
+// ... and where each rank's region is mapped in THIS process (base[rank] = its own), passed by value
+struct ExchangePeers {
+    char* base[FW_MAX_BUS_PARTS];
+};
+
 #define CH_GROUP_LEAVES 8
 // k_chain workgroup = up to CH_GROUP_LEAVES consecutive leaf SumNodes with at most 32 voices together (their voices are
 // consecutive): a tree of small leaves (a bus per instrument) fills the workgroup's 32 voice rows like one wide leaf

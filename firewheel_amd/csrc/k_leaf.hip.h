@@ -761,31 +761,4 @@ __device__ __forceinline__ void root_out_any(const DevView& v, const RootArgs& r
 __global__ __launch_bounds__(256) void k_root_out(DevView v, RootArgs ra, float* __restrict__ out) {
     root_out_any(v, ra, out, blockIdx.y, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
-
-// The top-level R-port SumNode of a voice-sharded graph: the R partial mix buses, one per rank, added in
-// port (= rank) order exactly as nodes/sum.rs:117-131 does — out = in0; out += in_p — so that every rank ends up with
-// the bits the single-process graph produces.  HBM-bound: R reads + 1 write of 16 B per lane, every part's quad requested
-// before the first add.  `out` may alias part[0].
-__global__ __launch_bounds__(256) void k_bus_sum_ordered(BusParts bp, float* __restrict__ out, size_t n4, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n4) {
-        v4f acc = *(const v4f*)(bp.part[0] + 4 * i);
-        for (int p0 = 1; p0 < bp.n; p0 += 8) {
-            v4f x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (p0 + u < bp.n) x[u] = *(const v4f*)(bp.part[p0 + u] + 4 * i);
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (p0 + u < bp.n) acc = acc + x[u];
-        }
-        *(v4f*)(out + 4 * i) = acc;
-    }
-    if (i == 0)  // ragged tail (n % 4 floats)
-        for (size_t j = n4 * 4; j < n; ++j) {
-            float a = bp.part[0][j];
-            for (int p = 1; p < bp.n; ++p) a = a + bp.part[p][j];
-            out[j] = a;
-        }
-}
-
+// (the top-level R-port SumNode of a voice-sharded graph, k_bus_sum_ordered, lives in k_exchange.hip.h)

@@ -482,10 +482,25 @@ class FirewheelGpuCtx(object):
     def process_blocks_device(self, num_blocks, device_out_ptr, num_out_channels=2):
         self._check(self.L.fwgpu_process_blocks_device(self.c, num_blocks, C.c_void_p(device_out_ptr), num_out_channels))
 
-    def bus_sum_ordered(self, part_ptrs, out_ptr, n_floats):
-        """the top-level R-port SumNode over the shards' partial buses (device pointers), rank order, on the ctx stream"""
+    def process_blocks_device_flags(self, num_blocks, device_out_ptr, num_out_channels, device_silence_ptr):
+        """... also writing, per (block, channel), whether that graph-output channel was flagged silent (u8, device memory)"""
+        self._check(self.L.fwgpu_process_blocks_device_flags(self.c, num_blocks, C.c_void_p(device_out_ptr), num_out_channels,
+                                                             C.c_void_p(device_silence_ptr) if device_silence_ptr else None))
+
+    def bus_sum_ordered(self, part_ptrs, out_ptr, n_floats, silence_ptrs=None, out_silence_ptr=None, frames_per_block=0, n_channels=2):
+        """the top-level R-port SumNode over the shards' partial buses (device pointers), rank order, on the ctx stream;
+        silence_ptrs: per part, its [blocks][channels] silence flags as process_blocks_device_flags wrote them (sum.rs:122-124)"""
         arr = (C.c_void_p * len(part_ptrs))(*[C.c_void_p(p) for p in part_ptrs])
-        self._check(self.L.fwgpu_bus_sum_ordered(self.c, arr, len(part_ptrs), C.c_void_p(out_ptr), n_floats))
+        if silence_ptrs is None:
+            self._check(self.L.fwgpu_bus_sum_ordered(self.c, arr, len(part_ptrs), C.c_void_p(out_ptr), n_floats))
+            return
+        sil = (C.c_void_p * len(part_ptrs))(*[C.c_void_p(p) if p else None for p in silence_ptrs])
+        self._check(self.L.fwgpu_bus_sum_ordered_flags(self.c, arr, sil, len(part_ptrs), C.c_void_p(out_ptr),
+                                                       C.c_void_p(out_silence_ptr) if out_silence_ptr else None, n_floats,
+                                                       frames_per_block, n_channels))
+
+    def open_bus_exchange(self, rank, world, max_floats, max_silence_bytes=0):
+        return BusExchange(self, rank, world, max_floats, max_silence_bytes)
 
     def synchronize(self):
         self._check(self.L.fwgpu_synchronize(self.c))
@@ -519,6 +534,74 @@ class FirewheelGpuCtx(object):
         cus, hbm = C.c_int(), C.c_uint64()
         self._check(self.L.fwgpu_device_info(self.c, name, 256, C.byref(cus), C.byref(hbm)))
         return name.value.decode(), cus.value, hbm.value
+
+
+class BusExchange(object):
+    """The multi-GPU mix bus behind the C ABI (fwgpu_bus_exchange_*, SURVEY §8e path 2): every rank stores its partial bus
+    into its slot on every rank (peer-mapped over xGMI, or by pointer inside one process), then adds the R slots it holds in
+    rank order — the top-level R-port SumNode (nodes/sum.rs:41-136), bit-identical to the single-process graph."""
+
+    def __init__(self, cx, rank, world, max_floats, max_silence_bytes=0):
+        self.cx, self.rank, self.world = cx, rank, world
+        self.x = cx.L.fwgpu_bus_exchange_open(cx.c, rank, world, max_floats, max_silence_bytes)
+        if not self.x:
+            raise FwgpuError(-30, cx.L.fwgpu_last_error(cx.c).decode())
+
+    def export(self):
+        """this rank's handle (bytes) — carry it to the peers through any side channel"""
+        buf = C.create_string_buffer(_lib.EXCHANGE_HANDLE_BYTES)
+        self.cx._check(self.cx.L.fwgpu_bus_exchange_export(self.x, buf))
+        return buf.raw
+
+    def connect(self, peer_rank, handle):
+        buf = C.create_string_buffer(bytes(handle), _lib.EXCHANGE_HANDLE_BYTES)
+        self.cx._check(self.cx.L.fwgpu_bus_exchange_connect(self.x, peer_rank, buf))
+
+    def connect_all(self, handles):
+        for r, h in enumerate(handles):
+            if r != self.rank:
+                self.connect(r, h)
+
+    def set_timeout_ms(self, ms):
+        self.cx._check(self.cx.L.fwgpu_bus_exchange_set_timeout_ms(self.x, ms))
+
+    def push(self, part_ptr, n_floats, silence_ptr=None, n_blocks=0, n_channels=2):
+        self.cx._check(self.cx.L.fwgpu_bus_exchange_push(self.x, C.c_void_p(part_ptr), C.c_void_p(silence_ptr) if silence_ptr else None,
+                                                         n_floats, n_blocks, n_channels))
+
+    def reduce(self, out_ptr, n_floats, out_silence_ptr=None, n_blocks=0, frames_per_block=0, n_channels=2, have_silence=False):
+        self.cx._check(self.cx.L.fwgpu_bus_exchange_reduce(self.x, C.c_void_p(out_ptr), C.c_void_p(out_silence_ptr) if out_silence_ptr else None,
+                                                           n_floats, n_blocks, frames_per_block, n_channels, 1 if have_silence else 0))
+
+    def step(self, part_ptr, out_ptr, n_floats, silence_ptr=None, out_silence_ptr=None, n_blocks=0, frames_per_block=0, n_channels=2):
+        self.cx._check(self.cx.L.fwgpu_bus_exchange_step(self.x, C.c_void_p(part_ptr), C.c_void_p(silence_ptr) if silence_ptr else None,
+                                                         C.c_void_p(out_ptr), C.c_void_p(out_silence_ptr) if out_silence_ptr else None,
+                                                         n_floats, n_blocks, frames_per_block, n_channels))
+
+    def status(self):
+        """(reduces issued, 0 or the first step a peer did not arrive for) — waits for the ctx stream; raises on a failed step"""
+        a, b = C.c_uint64(), C.c_uint64()
+        rc = self.cx.L.fwgpu_bus_exchange_status(self.x, C.byref(a), C.byref(b))
+        if rc < 0:
+            raise FwgpuError(rc, "%s (step %d)" % (self.cx.L.fwgpu_last_error(self.cx.c).decode(), b.value))
+        return a.value, b.value
+
+    def wait_stats(self, reset=False):
+        """[us] the longest a reduce of this rank has waited for each rank's arrival so far (waits for the ctx stream)"""
+        buf = (C.c_uint64 * self.world)()
+        self.cx._check(self.cx.L.fwgpu_bus_exchange_wait_stats(self.x, buf, self.world, 1 if reset else 0))
+        return [int(v) for v in buf]
+
+    def close(self):
+        if getattr(self, "x", None) and getattr(self.cx, "c", None):
+            self.cx.L.fwgpu_bus_exchange_close(self.x)
+        self.x = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class HeadlessStream(object):

@@ -202,13 +202,68 @@ int fwgpu_process_interleaved(fwgpu_ctx* ctx, const float* input, float* output,
  * sync).  Graphs with num_graph_inputs == 0 only. */
 int fwgpu_process_blocks_device(fwgpu_ctx* ctx, uint32_t num_blocks, float* d_output,
                                 uint32_t num_out_channels);
-/* Multi-GPU: voices shard across ranks with no exchange until the mix bus; the one exchange step is the
- * top-level SumNode over the R partial buses (nodes/sum.rs:111-133: out = in0; out += in_p, port = rank order).  This
- * is that node as one kernel on the ctx stream: d_parts[r] = rank r's interleaved bus of `n_floats` floats in memory
- * this device can read (its own, peer-mapped over xGMI, or the slots of an all-gather), 16-byte aligned; d_out may
- * alias d_parts[0].  Every rank that runs it over the same parts ends up with the bits of the single-process graph
- * (an all-reduce does not: ring order re-associates the f32 sum for R > 2).  Asynchronous; R <= 64. */
+/* The same call, also reporting the silence mask read_graph_outputs sees (graph/graph/compiler/schedule.rs:255-287) for every
+ * block: d_silence[block * num_out_channels + c] = 1 when graph-output channel c was flagged silent for that block, else 0
+ * (device memory, num_blocks * num_out_channels bytes; may be NULL).  These are the flags a shard's partial mix bus carries
+ * into the top-level SumNode of a voice-sharded graph (below). */
+int fwgpu_process_blocks_device_flags(fwgpu_ctx* ctx, uint32_t num_blocks, float* d_output, uint32_t num_out_channels,
+                                      uint8_t* d_silence);
+
+/* ---- multi-GPU mix bus.  Voices shard across ranks with no exchange until the mix bus; the one exchange step
+ * is the top-level SumNode over the R partial buses (nodes/sum.rs:41-136: all inputs silent -> cleared; 2 / 3 / 4 ports ->
+ * in1 + in2 (+ in3 (+ in4)); any other count -> out = in0; out += in_p skipping SILENT ports; port = rank order). */
+/* That node as one kernel on the ctx stream: d_parts[r] = rank r's interleaved bus of `n_floats` floats in memory this
+ * device can read (its own, peer-mapped over xGMI, or the slots of an all-gather), 16-byte aligned; d_out may alias
+ * d_parts[0].  Every rank that runs it over the same parts ends up with the bits of the single-process graph (an all-reduce
+ * does not: ring order re-associates the f32 sum for R > 2).  Asynchronous; R <= 64.  This form treats no port as silent. */
 int fwgpu_bus_sum_ordered(fwgpu_ctx* ctx, const float* const* d_parts, uint32_t n_parts, float* d_out, uint64_t n_floats);
+/* ... with the ports' silence flags (sum.rs:52-56,122-124): d_silence[r] = rank r's flags as fwgpu_process_blocks_device_flags
+ * wrote them ([blocks][n_channels], or NULL = never silent); the buses are [block][frames_per_block][n_channels] interleaved.
+ * d_out_silence (may be NULL) receives the node's out-mask per (block, channel). */
+int fwgpu_bus_sum_ordered_flags(fwgpu_ctx* ctx, const float* const* d_parts, const uint8_t* const* d_silence, uint32_t n_parts,
+                                float* d_out, uint8_t* d_out_silence, uint64_t n_floats, uint32_t frames_per_block,
+                                uint32_t n_channels);
+/* The exchange itself, for a host without torch / RCCL (SURVEY §8e path 2: one-shot all-to-all over peer-mapped slots — xGMI
+ * is point-to-point, every GPU of a node has a direct link to every other, so each rank STORES its partial bus into its slot
+ * on every rank and then each rank adds the R slots it holds in rank order: one link hop instead of the 2(R-1) steps of a
+ * ring, and bit-identical to the single-process graph on every rank).
+ *   open     (control side) one region of uncached HBM on the ctx's device: R slots of max_floats floats + max_silence_bytes
+ *            flags, twice (step parity), and R arrival words.  Every rank of an exchange passes the same world and sizes.
+ *   export   this rank's FWGPU_EXCHANGE_HANDLE_BYTES-byte handle; the host carries it to the peers by whatever channel it
+ *            has (a file, a pipe, MPI_Allgather, torch.distributed.all_gather_object ...).
+ *   connect  map a peer's region from its handle: by pointer when the peer lives in this process (virtual shards, several
+ *            devices under one host thread: hipDeviceEnablePeerAccess), else hipIpcOpenMemHandle (dmabuf).
+ *   push     (audio side, asynchronous on the ctx stream) store d_partial / d_silence into slot `rank` of every region,
+ *            release at system scope, raise this rank's arrival word everywhere.
+ *   reduce   (audio side, asynchronous) wait ON THE DEVICE for all R arrival words of this step, then the SumNode above
+ *            over the R slots -> d_out (+ d_out_silence).  The wait is bounded (set_timeout_ms, default 3000): a peer that
+ *            never arrives leaves a ZERO bus and an error fwgpu_bus_exchange_status reports — never a hung device.
+ *   step     = push + reduce.  A step of rank g needs every rank's push of the same step: all ranks call step the same
+ *            number of times; push and reduce of one exchange must stay on its ctx's stream, in that order (two data
+ *            parities make push(s+1) safe while peers still read step s).
+ * A reduce with have_silence = 0 treats no port as silent. */
+#define FWGPU_EXCHANGE_HANDLE_BYTES 128
+typedef struct fwgpu_bus_exchange fwgpu_bus_exchange;
+fwgpu_bus_exchange* fwgpu_bus_exchange_open(fwgpu_ctx* ctx, uint32_t rank, uint32_t world, uint64_t max_floats,
+                                            uint32_t max_silence_bytes); /* NULL on error: fwgpu_last_error(ctx) */
+void fwgpu_bus_exchange_close(fwgpu_bus_exchange* ex);
+int fwgpu_bus_exchange_export(fwgpu_bus_exchange* ex, void* handle);
+int fwgpu_bus_exchange_connect(fwgpu_bus_exchange* ex, uint32_t peer_rank, const void* handle);
+int fwgpu_bus_exchange_set_timeout_ms(fwgpu_bus_exchange* ex, uint32_t ms);
+int fwgpu_bus_exchange_push(fwgpu_bus_exchange* ex, const float* d_partial, const uint8_t* d_silence, uint64_t n_floats,
+                            uint32_t n_blocks, uint32_t n_channels);
+int fwgpu_bus_exchange_reduce(fwgpu_bus_exchange* ex, float* d_out, uint8_t* d_out_silence, uint64_t n_floats, uint32_t n_blocks,
+                              uint32_t frames_per_block, uint32_t n_channels, int have_silence);
+int fwgpu_bus_exchange_step(fwgpu_bus_exchange* ex, const float* d_partial, const uint8_t* d_silence, float* d_out,
+                            uint8_t* d_out_silence, uint64_t n_floats, uint32_t n_blocks, uint32_t frames_per_block,
+                            uint32_t n_channels);
+/* control side: waits for the ctx stream, then *steps = reduces issued so far, *failed_step = 0 or the first step whose wait
+ * ran out of time (then the return value is FWGPU_ERR_DEVICE). */
+int fwgpu_bus_exchange_status(fwgpu_bus_exchange* ex, uint64_t* steps, uint64_t* failed_step);
+/* control side: waits for the ctx stream; max_wait_us[p] = the longest any reduce so far sat waiting for rank p's arrival, in
+ * microseconds (how far the ranks run apart: the slowest rank reads ~0 for everybody, the others read their lead over it).
+ * Returns the world size; reset != 0 clears the maxima. */
+int fwgpu_bus_exchange_wait_stats(fwgpu_bus_exchange* ex, uint64_t* max_wait_us, uint32_t cap, int reset);
 int fwgpu_synchronize(fwgpu_ctx* ctx);
 /* ProcInfo::stream_time_secs / stream_status (core/node.rs:111-132) of the most recent fwgpu_process_interleaved call —
  * what a custom node run through fwgpu_node_process inside that call would be handed — and how often the backend has

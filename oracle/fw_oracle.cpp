@@ -1468,6 +1468,7 @@ int FirewheelProcessor::process_interleaved(const float* input, size_t input_len
         process_block(block_frames, stream_time_secs, stream_status);  // Q18: same stream_time for sub-blocks
         schedule->read_graph_outputs(
             block_frames, num_out_channels, [&](const float* const* channels, size_t n, SilenceMask mask) {
+                if (record_out_masks) record_out_masks->push_back(mask.bits | (n < 64 ? ~0ull << n : 0ull));  // channels past n are zero-filled
                 float* dst = output + frames_processed * num_out_channels;
                 size_t dst_len = block_frames * num_out_channels;
                 if (n == 2 && num_out_channels == 2)
@@ -1723,6 +1724,19 @@ int fwo_process_interleaved(void* c, const float* in, float* out, uint32_t n_in_
     Ctx* cx = (Ctx*)c;
     return cx->processor.process_interleaved(in, (size_t)frames * n_in_ch, out, (size_t)frames * n_out_ch, n_in_ch,
                                              n_out_ch, (size_t)frames, t, status);
+}
+
+// ... also reporting read_graph_outputs' silence mask of every block (bit c = output channel c silent; test hook)
+int fwo_process_interleaved_masks(void* c, const float* in, float* out, uint32_t n_in_ch, uint32_t n_out_ch, uint64_t frames,
+                                  double t, uint32_t status, uint64_t* masks, uint32_t cap) {
+    Ctx* cx = (Ctx*)c;
+    std::vector<uint64_t> rec;
+    cx->processor.record_out_masks = &rec;
+    int rc = cx->processor.process_interleaved(in, (size_t)frames * n_in_ch, out, (size_t)frames * n_out_ch, n_in_ch, n_out_ch,
+                                               (size_t)frames, t, status);
+    cx->processor.record_out_masks = nullptr;
+    for (size_t i = 0; i < rec.size() && i < cap; ++i) masks[i] = rec[i];
+    return rc ? rc : (int)rec.size();
 }
 
 // B1-level: call one activated node's process() directly with caller buffers (processor.rs:243).

@@ -385,6 +385,9 @@ struct FirewheelProcessor {
     std::map<uint32_t, std::unique_ptr<AudioNodeProcessor>> nodes;  // Arena keyed by node slot (processor.rs:19)
     std::unique_ptr<CompiledSchedule> schedule;
     size_t max_block_frames;
+    // test hook (not in the reference): when set, the silence mask read_graph_outputs hands its closure (schedule.rs:255-287)
+    // is appended here once per block — what a shard's partial mix bus carries into the top-level SumNode
+    std::vector<uint64_t>* record_out_masks = nullptr;
     explicit FirewheelProcessor(size_t mbf) : max_block_frames(mbf) {}
     // processor.rs:61-165.  Returns 0 (Ok).
     int process_interleaved(const float* input, size_t input_len, float* output, size_t output_len,

@@ -11,6 +11,11 @@ pub struct fwgpu_ctx {
 pub struct fwgpu_stream {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct fwgpu_bus_exchange {
+    _private: [u8; 0],
+}
+pub const FWGPU_EXCHANGE_HANDLE_BYTES: usize = 128;
 /// one ScheduledNode of Firewheel's CompiledSchedule (graph/graph/compiler/schedule.rs:12-30)
 #[repr(C)]
 pub struct fwgpu_sched_node {
@@ -102,7 +107,19 @@ extern "C" {
     pub fn fwgpu_sampler_set_loop_range(ctx: *mut fwgpu_ctx, node: i64, mode: c_int, start_secs: f64, end_secs: f64, at_block: u32) -> c_int;
     pub fn fwgpu_process_interleaved(ctx: *mut fwgpu_ctx, input: *const f32, output: *mut f32, num_in_channels: u32, num_out_channels: u32, frames: u64, stream_time_secs: f64, stream_status: u32) -> c_int;
     pub fn fwgpu_process_blocks_device(ctx: *mut fwgpu_ctx, num_blocks: u32, d_output: *mut f32, num_out_channels: u32) -> c_int;
+    pub fn fwgpu_process_blocks_device_flags(ctx: *mut fwgpu_ctx, num_blocks: u32, d_output: *mut f32, num_out_channels: u32, d_silence: *mut u8) -> c_int;
     pub fn fwgpu_bus_sum_ordered(ctx: *mut fwgpu_ctx, d_parts: *const *const f32, n_parts: u32, d_out: *mut f32, n_floats: u64) -> c_int;
+    pub fn fwgpu_bus_sum_ordered_flags(ctx: *mut fwgpu_ctx, d_parts: *const *const f32, d_silence: *const *const u8, n_parts: u32, d_out: *mut f32, d_out_silence: *mut u8, n_floats: u64, frames_per_block: u32, n_channels: u32) -> c_int;
+    pub fn fwgpu_bus_exchange_open(ctx: *mut fwgpu_ctx, rank: u32, world: u32, max_floats: u64, max_silence_bytes: u32) -> *mut fwgpu_bus_exchange;
+    pub fn fwgpu_bus_exchange_close(ex: *mut fwgpu_bus_exchange);
+    pub fn fwgpu_bus_exchange_export(ex: *mut fwgpu_bus_exchange, handle: *mut c_void) -> c_int;
+    pub fn fwgpu_bus_exchange_connect(ex: *mut fwgpu_bus_exchange, peer_rank: u32, handle: *const c_void) -> c_int;
+    pub fn fwgpu_bus_exchange_set_timeout_ms(ex: *mut fwgpu_bus_exchange, ms: u32) -> c_int;
+    pub fn fwgpu_bus_exchange_push(ex: *mut fwgpu_bus_exchange, d_partial: *const f32, d_silence: *const u8, n_floats: u64, n_blocks: u32, n_channels: u32) -> c_int;
+    pub fn fwgpu_bus_exchange_reduce(ex: *mut fwgpu_bus_exchange, d_out: *mut f32, d_out_silence: *mut u8, n_floats: u64, n_blocks: u32, frames_per_block: u32, n_channels: u32, have_silence: c_int) -> c_int;
+    pub fn fwgpu_bus_exchange_step(ex: *mut fwgpu_bus_exchange, d_partial: *const f32, d_silence: *const u8, d_out: *mut f32, d_out_silence: *mut u8, n_floats: u64, n_blocks: u32, frames_per_block: u32, n_channels: u32) -> c_int;
+    pub fn fwgpu_bus_exchange_status(ex: *mut fwgpu_bus_exchange, steps: *mut u64, failed_step: *mut u64) -> c_int;
+    pub fn fwgpu_bus_exchange_wait_stats(ex: *mut fwgpu_bus_exchange, max_wait_us: *mut u64, cap: u32, reset: c_int) -> c_int;
     pub fn fwgpu_synchronize(ctx: *mut fwgpu_ctx) -> c_int;
     pub fn fwgpu_proc_info(ctx: *mut fwgpu_ctx, stream_time_secs: *mut f64, stream_status: *mut u32, output_underflows: *mut u64, input_overflows: *mut u64) -> c_int;
     pub fn fwgpu_stream_open(ctx: *mut fwgpu_ctx, num_in_channels: u32, num_out_channels: u32) -> *mut fwgpu_stream;

@@ -89,6 +89,7 @@ def oracle_lib():
             "fwo_sampler_set_playhead_secs": (ci, [vp, i64, f64]),
             "fwo_sampler_set_loop_range": (ci, [vp, i64, ci, f64, f64]),
             "fwo_process_interleaved": (ci, [vp, fp, fp, u32, u32, u64, f64, u32]),
+            "fwo_process_interleaved_masks": (ci, [vp, fp, fp, u32, u32, u64, f64, u32, C.POINTER(u64), u32]),
             "fwo_node_process": (ci, [vp, i64, u64, C.POINTER(fp), u32, C.POINTER(fp), u32, u64, C.POINTER(u64), f64, u32]),
             "fwo_stream_new": (vp, [vp, u32, u32, u32]),
             "fwo_stream_free": (None, [vp]),
@@ -290,6 +291,18 @@ class OracleEngine(Engine):
     def process_blocks(self, k, n_out_ch=2):
         """K consecutive max_block_frames blocks (what one K-block device launch computes)."""
         return self.process_interleaved(k * self.max_block_frames, n_out_ch)
+
+    def process_blocks_flags(self, k, n_out_ch=2):
+        """... and, per (block, channel), whether read_graph_outputs saw that channel flagged silent (schedule.rs:255-287):
+        (interleaved output, uint8 [k][n_out_ch])"""
+        frames = k * self.max_block_frames
+        out = np.full(frames * n_out_ch, np.nan, dtype=np.float32)
+        inp = np.zeros(1, dtype=np.float32)
+        masks = (C.c_uint64 * k)()
+        r = self.L.fwo_process_interleaved_masks(self.c, _fptr(inp), _fptr(out), 0, n_out_ch, frames, 0.0, 0, masks, k)
+        assert r == k, r
+        fl = np.array([[(masks[b] >> c) & 1 for c in range(n_out_ch)] for b in range(k)], dtype=np.uint8)
+        return out, fl
 
     def node_process(self, node, frames, inputs, n_out, in_mask=0, out_mask=0, out_init=None):
         """B1: one node's process() on caller buffers.  Returns (outputs[n_out, frames], out_mask)."""
@@ -520,6 +533,17 @@ class GpuEngine(Engine):
             self.cx.process_blocks_device(k, buf.data_ptr(), n_out_ch)
             return _DeviceResult(self.cx, buf)
         return self.process_interleaved(k * self.max_block_frames, n_out_ch)
+
+    def process_blocks_flags(self, k, n_out_ch=2):
+        """(interleaved output, uint8 [k][n_out_ch] graph-output silence flags) through fwgpu_process_blocks_device_flags"""
+        import torch
+
+        buf = torch.full((k * self.max_block_frames * n_out_ch,), float("nan"), dtype=torch.float32, device="cuda")
+        fl = torch.full((k * n_out_ch,), 77, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        self.cx.process_blocks_device_flags(k, buf.data_ptr(), n_out_ch, fl.data_ptr())
+        self.cx.synchronize()
+        return buf.cpu().numpy(), fl.cpu().numpy().reshape(k, n_out_ch)
 
     def node_process(self, node, frames, inputs, n_out, in_mask=0, out_mask=0, out_init=None):
         outs = [np.full(frames, np.nan, dtype=np.float32) if out_init is None else np.array(out_init[c], dtype=np.float32)

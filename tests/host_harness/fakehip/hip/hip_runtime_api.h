@@ -7,6 +7,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <malloc.h>
+#include <unistd.h>
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
@@ -76,3 +78,34 @@ static inline hipError_t hipGraphInstantiate(hipGraphExec_t* x, hipGraph_t, void
 static inline hipError_t hipGraphDestroy(hipGraph_t g) { free(g); return hipSuccess; }
 static inline hipError_t hipGraphExecDestroy(hipGraphExec_t x) { free(x); return hipSuccess; }
 static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipSuccess; }
+
+/* ---- peer / IPC memory (fwgpu_exchange.cpp).  A handle carries (pid, pointer, usable size): inside one process it opens to
+ * the very same memory, from another process to a zeroed stand-in of the same size (the harness computes nothing). */
+typedef struct { char reserved[64]; } hipIpcMemHandle_t;
+enum { hipDeviceMallocFinegrained = 1, hipDeviceMallocUncached = 3, hipIpcMemLazyEnablePeerAccess = 1 };
+static inline hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+static inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
+struct fake_ipc { unsigned long long pid, ptr, bytes; };
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {
+    fake_ipc f = {(unsigned long long)getpid(), (unsigned long long)(uintptr_t)p, (unsigned long long)malloc_usable_size(p)};
+    memset(h, 0, sizeof(*h));
+    memcpy(h->reserved, &f, sizeof(f));
+    return hipSuccess;
+}
+extern "C" void* fwh_foreign_maps[64]; /* launch_stubs.cpp: stand-ins handed out for other processes' handles */
+static inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) {
+    fake_ipc f;
+    memcpy(&f, h.reserved, sizeof(f));
+    if (f.pid == (unsigned long long)getpid()) { *p = (void*)(uintptr_t)f.ptr; return hipSuccess; }
+    *p = calloc(f.bytes ? f.bytes : 1, 1);
+    for (int i = 0; i < 64; ++i)
+        if (!fwh_foreign_maps[i]) { fwh_foreign_maps[i] = *p; break; }
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t hipIpcCloseMemHandle(void* p) {
+    for (int i = 0; i < 64; ++i)
+        if (fwh_foreign_maps[i] == p) { fwh_foreign_maps[i] = NULL; free(p); break; }
+    return hipSuccess;
+}

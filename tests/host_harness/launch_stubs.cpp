@@ -11,6 +11,7 @@ extern "C" {
 unsigned long long fwh_alloc_calls = 0;  // hipMalloc / hipHostMalloc calls of the fake runtime
 unsigned long long fwh_alloc_count(void) { return fwh_alloc_calls; }
 long long fwh_fail_alloc_in = 0;
+void* fwh_foreign_maps[64] = {nullptr};
 void fwh_fail_alloc(long long nth) { fwh_fail_alloc_in = nth; }
 }
 extern "C" unsigned long long fwh_launch_count(int which) { return which >= 0 && which < 8 ? g_launches[which] : 0; }
@@ -272,11 +273,55 @@ int launch_voice_control(hipStream_t, const FusedView& fv, int K, uint32_t cmd_b
     }
     return 0;
 }
-int launch_bus_sum_ordered(hipStream_t, const BusParts& bp, float* d_out, size_t n_floats) {
+int launch_bus_sum_ordered(hipStream_t, const BusParts& bp, const uint8_t* const* sil, float* d_out, uint8_t* d_out_sil, size_t n_floats,
+                           uint32_t n_blocks, uint32_t frames, uint32_t n_ch) {
     g_launches[7]++;
     REQUIRE(bp.n >= 1 && bp.n <= FW_MAX_BUS_PARTS, bp.n);
     for (int r = 0; r < bp.n; ++r) touch(bp.part[r], n_floats * sizeof(float));
     touch(d_out, n_floats * sizeof(float));
+    if (sil) {
+        REQUIRE((size_t)n_blocks * frames * n_ch >= n_floats, (long)n_blocks, (long)frames);
+        for (int r = 0; r < bp.n; ++r)
+            if (sil[r]) touch(sil[r], (size_t)n_blocks * n_ch);
+        if (d_out_sil) touch(d_out_sil, (size_t)n_blocks * n_ch);
+    }
+    return 0;
+}
+int launch_bus_push(hipStream_t, const ExchangePeers& peers, const ExchangeGeom& g, const float* d_part, const uint8_t* d_sil, size_t n_floats,
+                    uint32_t n_sil, unsigned long long seq, unsigned* d_counter) {
+    g_launches[7]++;
+    REQUIRE(g.world >= 1 && g.world <= FW_MAX_BUS_PARTS && g.rank >= 0 && g.rank < g.world, g.world, g.rank);
+    REQUIRE(n_floats <= g.max_floats && g.max_floats * 4 + n_sil <= g.slot_bytes, (long)n_floats, (long)n_sil);
+    REQUIRE(seq >= 1, (long)seq);
+    touch(d_part, n_floats * sizeof(float));
+    if (n_sil) touch(d_sil, n_sil);
+    touch(d_counter, 4);
+    for (int p = 0; p < g.world; ++p) {  // this rank's slot in every region: the last byte of the second parity
+        REQUIRE(peers.base[p] != nullptr, p);
+        if (peers.base[p]) touch(peers.base[p], 4096 + (size_t)(2 * g.world) * g.slot_bytes);
+    }
+    return 0;
+}
+int launch_bus_reduce(hipStream_t, char* base, const ExchangeGeom& g, float* d_out, uint8_t* d_out_sil, size_t n_floats, uint32_t n_sil,
+                      uint32_t frames, uint32_t n_ch, unsigned long long seq, unsigned long long budget_ticks, unsigned long long* d_sync) {
+    g_launches[7]++;
+    touch(d_sync, (8 + FW_MAX_BUS_PARTS) * 8);
+    REQUIRE(n_floats <= g.max_floats && g.max_floats * 4 + n_sil <= g.slot_bytes, (long)n_floats, (long)n_sil);
+    REQUIRE(budget_ticks > 0 && seq >= 1, (long)seq);
+    if (n_sil) REQUIRE(n_ch > 0 && (size_t)(n_sil / n_ch) * frames * n_ch >= n_floats, (long)n_sil, (long)frames);
+    touch(base, 4096 + (size_t)(2 * g.world) * g.slot_bytes);
+    touch(d_out, n_floats * sizeof(float));
+    if (d_out_sil) touch(d_out_sil, n_sil);
+    return 0;
+}
+int launch_out_flags(hipStream_t, const uint8_t* flags, size_t flags_blk_stride, const int* d_bufs, int n_bufs, int mode, int n_out_ch, int K,
+                     uint8_t* d_out) {
+    g_launches[7]++;
+    REQUIRE(mode == 0 || mode == 1, mode);
+    REQUIRE(n_bufs >= 0 && n_bufs <= 64 && K >= 1, n_bufs, K);
+    touch(d_bufs, sizeof(int) * (size_t)n_bufs);
+    for (int j = 0; j < n_bufs; ++j) touch(flags + (size_t)(K - 1) * flags_blk_stride + d_bufs[j], 1);
+    touch(d_out, (size_t)K * n_out_ch);
     return 0;
 }
 int launch_signal_done(hipStream_t, unsigned long long* d_done_flag, unsigned long long done_seq) {

@@ -39,6 +39,23 @@ def test_gpus_2_self_launches_two_ranks_and_prints_one_line(mode):
     assert d["ms_per_step"] > 0
 
 
+def test_gpus_3_default_exchange_mode_with_the_n_rank_extras():
+    """the N > 1 line as the driver will see it: the default mix-bus reduction is libfwgpu's own exchange (handles carried by
+    all_gather_object, regions "mapped" by the fake runtime), the line carries a parity_check entry (skipped on this tier: the
+    harness computes no audio — but the oracle's WHOLE graph, 3 shards under one 3-port SumNode, was built and rendered), and
+    next to it configs[4] with the reduction after every step and the headline under the two RCCL reductions."""
+    d = run_bench(["--gpus", "3", "--force-other-configs"])
+    assert d["n_gpus"] == 3 and d["ranks_seen"] == 3
+    assert d["config"]["bus_reduce"] == "exchange" and d["config"]["bus_reduce_fallback"] is None
+    pc = d["parity_check"]
+    assert pc["ranks"] == 3 and pc["bus_reduce"] == "exchange" and pc["oracle_whole_graph_nonzero"] and "skipped" in pc
+    c5 = d["other_configs"]["cfg5"]
+    assert "error" not in c5 and c5["bus_reduce"] == "exchange" and c5["parity_check"]["ranks"] == 3
+    assert sorted(d["bus_reduce_modes"]) == ["allreduce", "ordered"]
+    for m, ent in d["bus_reduce_modes"].items():
+        assert "error" not in ent and ent["bus_reduce"] == m and ent["value"] is None
+
+
 def test_single_rank_line_has_the_contract_fields():
     d = run_bench([])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",

@@ -1,0 +1,623 @@
+"""The multi-GPU mix bus behind the C ABI (include/fwgpu.h "multi-GPU mix bus", SURVEY §8e path 2).
+
+The one exchange step of a voice-sharded graph is the top-level R-port SumNode over the shards' partial buses
+(nodes/sum.rs:41-136).  Here:
+  * `topsum_model` — that node restated in numpy on interleaved buses + per-(block, channel) silence flags, straight from
+    sum.rs (all silent -> clear; 1 port -> copy; 2/3/4 ports -> unmasked adds; otherwise out = in0, += in_p skipping
+    silent ports): the checker of the kernel-level tests;
+  * CPU tier: the exchange's contract (handles, geometry, call order) on the host-only harness; the model itself against
+    the oracle's whole graph;
+  * GPU tier: fwgpu_bus_sum_ordered_flags and the exchange (N virtual ranks in one process: connected by pointer; N
+    PROCESSES on the one device: connected through hipIpc handles carried in files) bit for bit against the model and
+    against the oracle's whole graph whose top node is the N-port SumNode; the bounded wait; the silence flags a process call
+    reports (fwgpu_process_blocks_device_flags) against the oracle's read_graph_outputs masks on every launch plan."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import fwapi
+import scenarios
+from fwapi import GpuEngine, OracleEngine
+
+ROOT = fwapi.ROOT
+
+
+# ---------------------------------------------------------------------------------------------- the model (sum.rs:41-136)
+def topsum_model(parts, sils, frames, n_ch=2):
+    """parts[r]: f32 [n] interleaved [block][frame][ch]; sils[r]: uint8 [blocks][n_ch] or None (never silent).
+    Returns (out f32 [n], out_sil uint8 [blocks][n_ch])."""
+    world = len(parts)
+    n = parts[0].size
+    per = frames * n_ch
+    blocks = (n + per - 1) // per
+    sil = np.zeros((world, blocks, n_ch), dtype=bool)
+    for r in range(world):
+        if sils is not None and sils[r] is not None:
+            sil[r] = np.asarray(sils[r]).reshape(blocks, n_ch) != 0
+    out = np.empty(n, dtype=np.float32)
+    out_sil = np.zeros((blocks, n_ch), dtype=np.uint8)
+    for b in range(blocks):
+        lo, hi = b * per, min((b + 1) * per, n)
+        seg = [p[lo:hi] for p in parts]
+        for c in range(n_ch):
+            if sil[:, b, :].all():                       # :52-56 every input channel silent: clear, flag all outputs
+                out[lo + c:hi:n_ch] = 0.0
+                out_sil[b, c] = 1
+                continue
+            if world == 1:                               # :58-65 copy, mask passes through
+                out[lo + c:hi:n_ch] = seg[0][c::n_ch]
+                out_sil[b, c] = 1 if sil[0, b, c] else 0
+                continue
+            acc = seg[0][c::n_ch].copy()                 # :117 (2/3/4 ports: in1 + in2 ... — the same left fold)
+            for r in range(1, world):
+                if world not in (2, 3, 4) and sil[r, b, c]:  # :122-124: only the n-port path consults the mask
+                    continue
+                acc = (acc + seg[r][c::n_ch]).astype(np.float32)
+            out[lo + c:hi:n_ch] = acc
+    return out, out_sil
+
+
+def random_buses(rng, world, blocks, frames, n_ch=2, ragged=0):
+    """partial buses with whole silent blocks / channels (zero data + flag), exact -0.0 samples (the only values for which the
+    mask changes a bit: x + (+0.0) turns -0.0 into +0.0) and subnormals"""
+    n = blocks * frames * n_ch - ragged
+    parts, sils = [], []
+    for r in range(world):
+        x = rng.uniform(-1, 1, size=blocks * frames * n_ch).astype(np.float32)
+        x[rng.random(x.size) < 0.08] = -0.0
+        x[rng.random(x.size) < 0.02] = np.float32(1e-41)
+        s = (rng.random((blocks, n_ch)) < (0.45 if r else 0.25)).astype(np.uint8)
+        if r == 0:
+            x[rng.random(x.size) < 0.5] = -0.0          # port 0 holds the -0.0 the later silent ports must not touch
+        xv = x.reshape(blocks, frames, n_ch)
+        for b in range(blocks):
+            for c in range(n_ch):
+                if s[b, c]:
+                    xv[b, :, c] = 0.0
+        parts.append(x[:n].copy())
+        sils.append(s)
+    if world > 1:                                        # one block where every rank is silent (the clear path)
+        for r in range(world):
+            sils[r][blocks // 2, :] = 1
+            parts[r].reshape(-1)[(blocks // 2) * frames * n_ch:min((blocks // 2 + 1) * frames * n_ch, n)] = 0.0
+    return parts, sils
+
+
+def test_model_masked_and_unmasked_paths_differ_only_in_the_sign_of_zero():
+    rng = np.random.default_rng(5)
+    parts, sils = random_buses(rng, 5, 6, 32)
+    a, _ = topsum_model(parts, sils, 32)
+    b, _ = topsum_model(parts, None, 32)
+    assert np.array_equal(a, b)                          # == treats -0.0 and +0.0 alike
+    assert not np.array_equal(a.view(np.uint32), b.view(np.uint32))  # ... the bits do not: that is what the flags are for
+    p3, s3 = random_buses(rng, 3, 6, 32)                 # 3 ports: the reference adds unmasked — the flags change nothing
+    s3[0][:] = 0                                         # (but for the all-silent clear)
+    a3, _ = topsum_model(p3, s3, 32)
+    acc = p3[0] + p3[1] + p3[2]
+    keep = np.ones(acc.size, dtype=bool)
+    keep[3 * 64:4 * 64] = False
+    assert np.array_equal(a3.view(np.uint32)[keep], acc.astype(np.float32).view(np.uint32)[keep])
+
+
+# ---------------------------------------------------------------------------------------------- whole graph via the oracle
+def shard_graph(e, rank, world, total_voices, radix=4, src=700, paused_ranks=(), neg_zero_rank=None):
+    """voices [lo, hi) of the whole graph -> radix tree; returns (root, [(voice, sampler)])"""
+    from firewheel_amd import shard
+
+    lo, hi = shard.voice_range(rank, world, total_voices)
+    ends, voices = [], []
+    for v in range(lo, hi):
+        rng = np.random.default_rng(shard.voice_seed(v))
+        s = e.sampler(100.0)
+        vol = e.volume(float(rng.uniform(10, 100)))
+        pan = e.pan(float(rng.uniform(-1, 1)))
+        e.connect_stereo(s, vol)
+        e.connect_stereo(vol, pan)
+        voices.append((v, s))
+        ends.append(pan)
+    level = ends
+    while True:
+        nxt = []
+        for i in range(0, len(level), radix):
+            grp = level[i:i + radix]
+            m = e.sum(len(grp))
+            for p, n in enumerate(grp):
+                e.connect_stereo(n, m, 2 * p)
+            nxt.append(m)
+        level = nxt
+        if len(level) == 1:
+            break
+    return level[0], voices
+
+
+def start_shard(e, rank, voices, src=700, paused_ranks=(), neg_zero_rank=None, one_shot_ranks=()):
+    from firewheel_amd import shard
+
+    for v, s in voices:
+        data = fwapi.xorshift_uniform(shard.voice_seed(v), 2 * src).reshape(2, src).copy()
+        if rank == neg_zero_rank:
+            data[:, ::3] = -0.0  # exact -0.0 samples survive gain and pan (x * g keeps the sign): the bus holds -0.0
+            data = -np.abs(data)
+        e.sampler_set_sample(s, e.new_sample(fwapi.PLANAR_F32, 2, data))
+        if rank not in one_shot_ranks:
+            e.sampler_set_loop_range(s, fwapi.LOOP_FULL)
+        if rank not in paused_ranks:
+            e.sampler_play(s)
+
+
+def whole_graph_oracle(world, total_voices, block, calls, **kw):
+    e = OracleEngine(max_block_frames=block)
+    roots, allv = [], []
+    for r in range(world):
+        root, voices = shard_graph(e, r, world, total_voices)
+        roots.append(root)
+        allv.append((r, voices))
+    top = e.sum(world)  # the mix-bus reduction as the reference expresses it: one world-port stereo SumNode
+    for p, root in enumerate(roots):
+        e.connect_stereo(root, top, 2 * p)
+    e.connect_stereo(top, e.graph_out_node)
+    e.update()
+    for r, voices in allv:
+        start_shard(e, r, voices, **kw)
+    return [e.process_blocks(k) for k in calls]
+
+
+def test_model_equals_the_oracles_whole_graph_top_node():
+    # 5 shards (the n-port path), one of them paused (silent bus), one holding exact -0.0, one whose one-shots end mid-run:
+    # the model fed with the shards' own buses + read_graph_outputs masks reproduces the whole graph bit for bit — and without
+    # the masks it does not (so the scenario does exercise them)
+    world, total, block, calls = 5, 23, 64, [3, 5, 9]
+    kw = dict(paused_ranks=(3,), neg_zero_rank=0, one_shot_ranks=(1, 2, 4))
+    want = whole_graph_oracle(world, total, block, calls, **kw)
+    outs, flags = [], []
+    for r in range(world):
+        e = OracleEngine(max_block_frames=block)
+        root, voices = shard_graph(e, r, world, total)
+        e.connect_stereo(root, e.graph_out_node)
+        e.update()
+        start_shard(e, r, voices, **kw)
+        of = [e.process_blocks_flags(k) for k in calls]
+        outs.append([o for o, _ in of])
+        flags.append([f for _, f in of])
+    differs_without = False
+    for i, k in enumerate(calls):
+        got, _ = topsum_model([outs[r][i] for r in range(world)], [flags[r][i] for r in range(world)], block)
+        assert np.array_equal(got.view(np.uint32), want[i].view(np.uint32)), "call %d" % i
+        blind, _ = topsum_model([outs[r][i] for r in range(world)], None, block)
+        differs_without |= not np.array_equal(blind.view(np.uint32), want[i].view(np.uint32))
+    assert differs_without
+
+
+# ---------------------------------------------------------------------------------------------- contract (host-only harness)
+def hostonly_cx(**kw):
+    return fwapi.hostonly_ctx(sample_rate=48000, max_block_frames=64, num_graph_inputs=0, num_graph_outputs=2, **kw)
+
+
+def test_exchange_contract_on_the_host_harness():
+    import ctypes as C
+
+    from firewheel_amd import FwgpuError
+    from firewheel_amd._lib import EXCHANGE_HANDLE_BYTES
+
+    a, b = hostonly_cx(), hostonly_cx()
+    L = a.L
+    assert not L.fwgpu_bus_exchange_open(a.c, 2, 2, 1024, 16)  # rank >= world
+    assert b"rank < world" in L.fwgpu_last_error(a.c)
+    assert not L.fwgpu_bus_exchange_open(a.c, 0, 65, 1024, 16)
+    assert not L.fwgpu_bus_exchange_open(a.c, 0, 2, 0, 16)
+    xa = a.open_bus_exchange(0, 2, 1024, 16)
+    xb = b.open_bus_exchange(1, 2, 1024, 16)
+    ha, hb = xa.export(), xb.export()
+    assert len(ha) == EXCHANGE_HANDLE_BYTES and ha != hb
+    buf = (C.c_float * 1024)()
+    sil = (C.c_uint8 * 16)()
+    ptr, sptr = C.addressof(buf), C.addressof(sil)
+    with pytest.raises(FwgpuError, match="not every peer is connected"):
+        xa.push(ptr, 1024)
+    with pytest.raises(FwgpuError, match="not an exchange handle"):
+        xa.connect(1, b"\0" * EXCHANGE_HANDLE_BYTES)
+    with pytest.raises(FwgpuError, match="not that rank's"):
+        xa.connect(1, ha)
+    xc = b.open_bus_exchange(1, 2, 2048, 16)  # another bus size: refused at connect
+    with pytest.raises(FwgpuError, match="another world size / bus size"):
+        xa.connect(1, xc.export())
+    xc.close()
+    xa.connect(1, hb)
+    xb.connect(0, ha)
+    xa.connect(0, ha)  # a rank's own handle: a no-op
+    with pytest.raises(FwgpuError, match="already connected"):
+        xa.connect(1, hb)
+    with pytest.raises(FwgpuError, match="reduce without a push"):
+        xa.reduce(ptr, 1024)
+    with pytest.raises(FwgpuError, match="longer than the slots"):
+        xa.push(ptr, 4096)
+    with pytest.raises(FwgpuError, match="more silence flags"):
+        xa.push(ptr, 1024, sptr, 9, 2)
+    xa.push(ptr, 1024, sptr, 8, 2)
+    with pytest.raises(FwgpuError, match="push without the previous step's reduce"):
+        xa.push(ptr, 1024, sptr, 8, 2)
+    with pytest.raises(FwgpuError, match="do not cover the bus"):
+        xa.reduce(ptr, 1024, None, 8, 32, 2, True)  # 8 blocks x 32 frames x 2 < 1024
+    xa.reduce(ptr, 1024, sptr, 8, 64, 2, True)
+    xa.step(ptr, ptr, 1024, sptr, sptr, 8, 64, 2)
+    assert xa.status() == (2, 0)
+    assert L.fwh_violation() == b""
+    with pytest.raises(FwgpuError, match="unaligned"):
+        xa.push(ptr + 4, 1020)
+    for x in (xa, xb):
+        x.close()
+    a.close()
+    b.close()
+
+
+def test_bus_sum_ordered_flags_contract_on_the_host_harness():
+    import ctypes as C
+
+    from firewheel_amd import FwgpuError
+
+    a = hostonly_cx()
+    bufs = [(C.c_float * 512)() for _ in range(3)]
+    sil = [(C.c_uint8 * 8)() for _ in range(3)]
+    out = (C.c_float * 512)()
+    osil = (C.c_uint8 * 8)()
+    pp = [C.addressof(x) for x in bufs]
+    a.bus_sum_ordered(pp, C.addressof(out), 512)
+    a.bus_sum_ordered(pp, C.addressof(out), 512, [C.addressof(x) for x in sil], C.addressof(osil), 64, 2)
+    a.bus_sum_ordered(pp, C.addressof(out), 512, [C.addressof(sil[0]), None, None], None, 64, 2)
+    with pytest.raises(FwgpuError, match="block geometry"):
+        a.bus_sum_ordered(pp, C.addressof(out), 512, [C.addressof(x) for x in sil], None, 0, 2)
+    assert a.L.fwh_violation() == b""
+    a.close()
+
+
+# ---------------------------------------------------------------------------------------------- GPU: kernels vs the model
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,blocks,frames,ragged", [(1, 3, 64, 0), (2, 4, 64, 0), (3, 5, 48, 2), (4, 4, 256, 0), (5, 6, 64, 3),
+                                                        (8, 8, 100, 1), (64, 2, 32, 0)])
+def test_bus_sum_ordered_flags_kernel_equals_the_model(world, blocks, frames, ragged):
+    import torch
+
+    rng = np.random.default_rng(100 * world + frames)
+    parts, sils = random_buses(rng, world, blocks, frames, ragged=ragged)
+    want, want_sil = topsum_model(parts, sils, frames)
+    e = GpuEngine(max_block_frames=64)
+    dp = [_dev(torch, p) for p in parts]
+    ds = [_dev(torch, s) for s in sils]
+    out = torch.full((parts[0].size,), float("nan"), dtype=torch.float32, device="cuda")
+    osil = torch.full((blocks * 2,), 9, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    e.cx.bus_sum_ordered([p.data_ptr() for p in dp], out.data_ptr(), out.numel(), [s.data_ptr() for s in ds], osil.data_ptr(), frames, 2)
+    e.cx.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(osil.cpu().numpy().reshape(blocks, 2), want_sil)
+    # the flag-less form treats no port as silent (what round 2 shipped): the model without masks
+    blind, _ = topsum_model(parts, None, frames)
+    e.cx.bus_sum_ordered([p.data_ptr() for p in dp], out.data_ptr(), out.numel())
+    e.cx.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), blind.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,blocks,frames,ragged", [(2, 4, 64, 0), (3, 3, 48, 2), (5, 6, 64, 0), (8, 16, 256, 0), (17, 2, 32, 1)])
+def test_exchange_virtual_ranks_in_one_process_equal_the_model_on_every_rank(world, blocks, frames, ragged):
+    """N contexts on the one device, their exchanges connected by pointer; every rank pushes, then every rank reduces (one
+    host thread drives all ranks here; separate hosts simply call step).  Three steps: both data parities and the reuse of
+    the first."""
+    import torch
+
+    rng = np.random.default_rng(7 * world + blocks)
+    n = blocks * frames * 2 - ragged
+    engines = [GpuEngine(max_block_frames=64) for _ in range(world)]
+    xs = [e.cx.open_bus_exchange(r, world, blocks * frames * 2, blocks * 2) for r, e in enumerate(engines)]
+    handles = [x.export() for x in xs]
+    for x in xs:
+        x.connect_all(handles)
+    for step in range(3):
+        parts, sils = random_buses(rng, world, blocks, frames, ragged=ragged)
+        want, want_sil = topsum_model(parts, sils, frames)
+        dp = [_dev(torch, p) for p in parts]
+        ds = [_dev(torch, s) for s in sils]
+        outs = [torch.full((n,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(world)]
+        osils = [torch.full((blocks * 2,), 9, dtype=torch.uint8, device="cuda") for _ in range(world)]
+        torch.cuda.synchronize()
+        for r, x in enumerate(xs):
+            x.push(dp[r].data_ptr(), n, ds[r].data_ptr(), blocks, 2)
+        for r, x in enumerate(xs):
+            x.reduce(outs[r].data_ptr(), n, osils[r].data_ptr(), blocks, frames, 2, True)
+        for r, x in enumerate(xs):
+            assert x.status() == (step + 1, 0)
+            assert np.array_equal(outs[r].cpu().numpy().view(np.uint32), want.view(np.uint32)), (step, r)
+            assert np.array_equal(osils[r].cpu().numpy().reshape(blocks, 2), want_sil), (step, r)
+    for x in xs:
+        x.close()
+
+
+@pytest.mark.gpu
+def test_exchange_wait_is_bounded_a_missing_peer_is_an_error_and_a_zero_bus_not_a_hang():
+    import time
+
+    import torch
+
+    from firewheel_amd import FwgpuError
+
+    e0, e1 = GpuEngine(max_block_frames=64), GpuEngine(max_block_frames=64)
+    x0, x1 = e0.cx.open_bus_exchange(0, 2, 4096, 64), e1.cx.open_bus_exchange(1, 2, 4096, 64)
+    h = [x0.export(), x1.export()]
+    x0.connect_all(h)
+    x1.connect_all(h)
+    x0.set_timeout_ms(40)
+    part = torch.ones(4096, dtype=torch.float32, device="cuda")
+    out = torch.full((4096,), float("nan"), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x0.step(part.data_ptr(), out.data_ptr(), 4096)  # rank 1 never pushes
+    with pytest.raises(FwgpuError, match="did not arrive"):
+        x0.status()
+    assert time.perf_counter() - t0 < 2.0
+    assert not out.cpu().numpy().any()  # fully written, zeros (core/node.rs:41-42)
+    x0.close()
+    x1.close()
+
+
+# ---------------------------------------------------------------------------------------------- GPU: the flags a call reports
+def _flag_scenario(e, plan):
+    """calls whose blocks are silent for different reasons on each plan; returns [(out, flags)] per call"""
+    if plan == "bank":  # fused voice bank: every voice a one-shot -> the tail blocks are cleared + flagged by the root
+        voices = scenarios.build_voice_bank(e, 21, radix=8, src_frames=300)
+        for vc in voices:
+            e.sampler_play(vc["sampler"])
+        return [e.process_blocks_flags(k) for k in (3, 4, 2)]
+    if plan == "master":  # a master VolumeNode built at 0 %: never smoothing and below 1e-5 -> it clears and flags (volume.rs:104-108)
+        # behind a live root.  (A fade DOWN to 0 never gets there: the smoother ends Deactivating, which still counts as
+        # smoothing — smoother.rs:159-185 returns early for it — so the faded bus is zeros that are NOT flagged: also checked.)
+        voices = scenarios.build_voice_bank(e, 19, radix=8, src_frames=900, master=(lambda e: e.hard_clip(-2.0), lambda e: e.volume(0.0)))
+        for vc in voices:
+            e.sampler_set_loop_range(vc["sampler"], fwapi.LOOP_FULL)
+            e.sampler_play(vc["sampler"])
+        outs = [e.process_blocks_flags(3)]
+        e.set_param(voices[0]["master"][1], 0, 60.0)
+        outs.append(e.process_blocks_flags(5))
+        e.set_param(voices[0]["master"][1], 0, 0.0)
+        outs.append(e.process_blocks_flags(100))
+        return outs
+    if plan == "single":  # a one-leaf tree: the root is n_in == n_out for nobody, but a 1-port SumNode passes its masks through
+        voices = scenarios.build_voice_bank(e, 1, radix=8, src_frames=200)
+        e.sampler_play(voices[0]["sampler"])
+        return [e.process_blocks_flags(k) for k in (2, 3)]
+    raise AssertionError(plan)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("plan,force_generic,max_batch", [("bank", False, 64), ("bank", False, 2), ("bank", True, 4), ("master", False, 16),
+                                                         ("master", True, 8), ("single", False, 4), ("single", True, 1)])
+def test_process_blocks_device_flags_equal_the_oracles_read_graph_outputs_masks(plan, force_generic, max_batch):
+    g = GpuEngine(max_block_frames=64, force_generic=force_generic, max_batch=max_batch)
+    o = OracleEngine(max_block_frames=64)
+    got, want = _flag_scenario(g, plan), _flag_scenario(o, plan)
+    some_silent = some_live = False
+    for i, ((go, gf), (wo, wf)) in enumerate(zip(got, want)):
+        assert np.array_equal(go.view(np.uint32), wo.view(np.uint32)), (plan, i)
+        assert np.array_equal(gf, wf), (plan, i, gf.T, wf.T)
+        some_silent |= bool(wf.any())
+        some_live |= not bool(wf.all())
+    assert some_silent and some_live
+
+
+# ---------------------------------------------------------------------------------------------- GPU: whole graph, N processes
+RANK_SCRIPT = r'''
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.join(sys.argv[5], "tests")); sys.path.insert(0, sys.argv[5])
+import fwapi, test_bus_exchange as T
+rank, world, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+mode = sys.argv[4]
+total, block, calls = 23, 64, [3, 5, 9]
+kw = dict(paused_ranks=(3,), neg_zero_rank=0, one_shot_ranks=(1, 2, 4))
+e = fwapi.GpuEngine(max_block_frames=block, max_batch=4)
+root, voices = T.shard_graph(e, rank, world, total)
+e.connect_stereo(root, e.graph_out_node)
+e.update()
+T.start_shard(e, rank, voices, **kw)
+kmax = max(calls)
+x = e.cx.open_bus_exchange(rank, world, kmax * block * 2, kmax * 2)
+open(os.path.join(d, "h%d.tmp" % rank), "wb").write(x.export())
+os.rename(os.path.join(d, "h%d.tmp" % rank), os.path.join(d, "h%d.bin" % rank))
+t0 = time.time()
+handles = []
+for r in range(world):
+    p = os.path.join(d, "h%d.bin" % r)
+    while not os.path.exists(p):
+        assert time.time() - t0 < 120, "peer %d never published its handle" % r
+        time.sleep(0.01)
+    handles.append(open(p, "rb").read())
+x.connect_all(handles)
+outs = []
+if mode == "skew":
+    # a large bus (the reduce grid is 2 048 workgroups) and a rank that arrives 0.3 s late, every step: the others WAIT on the
+    # device (one wave each) while the late rank's kernels run beside them — on one shared device the waiting must not starve it
+    n, blocks, frames = 2 * 1024 * 1024, 1024, 1024
+    big = e.cx.open_bus_exchange(rank, world, n, blocks * 2)
+    hp = os.path.join(d, "b%d.bin" % rank)
+    open(hp + ".tmp", "wb").write(big.export()); os.rename(hp + ".tmp", hp)
+    hs = []
+    for r in range(world):
+        p = os.path.join(d, "b%d.bin" % r)
+        while not os.path.exists(p):
+            assert time.time() - t0 < 120
+            time.sleep(0.01)
+        hs.append(open(p, "rb").read())
+    big.connect_all(hs)
+    for step in range(3):
+        rng = np.random.default_rng(1000 * step)
+        parts, sils = T.random_buses(rng, world, blocks, frames)
+        part = torch.from_numpy(parts[rank]).cuda(); sil = torch.from_numpy(sils[rank].reshape(-1).copy()).cuda()
+        out = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        if rank == 0:
+            time.sleep(0.3)
+        big.step(part.data_ptr(), out.data_ptr(), n, sil.data_ptr(), None, blocks, frames, 2)
+        big.status()
+        outs.append(out.cpu().numpy())
+    np.save(os.path.join(d, "wait%d.npy" % rank), np.array(big.wait_stats()))
+    calls = []
+for k in calls:
+    n = k * block * 2
+    part = torch.empty(n, dtype=torch.float32, device="cuda")
+    sil = torch.empty(k * 2, dtype=torch.uint8, device="cuda")
+    out = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    e.cx.process_blocks_device_flags(k, part.data_ptr(), 2, sil.data_ptr())
+    if mode == "noflags":
+        x.step(part.data_ptr(), out.data_ptr(), n)
+    else:
+        x.step(part.data_ptr(), out.data_ptr(), n, sil.data_ptr(), None, k, block, 2)
+    x.status()
+    outs.append(out.cpu().numpy())
+np.save(os.path.join(d, "out%d.npy" % rank), np.concatenate(outs))
+# nobody unmaps a region a peer may still be storing into: leave together
+open(os.path.join(d, "done%d" % rank), "w").write("1")
+while not all(os.path.exists(os.path.join(d, "done%d" % r)) for r in range(world)):
+    assert time.time() - t0 < 180
+    time.sleep(0.01)
+x.close()
+if mode == "skew":
+    big.close()
+'''
+
+
+def _run_ranks(world, mode):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "rank.py")
+        open(script, "w").write(RANK_SCRIPT)
+        procs = [subprocess.Popen([sys.executable, script, str(r), str(world), d, mode, ROOT], env=env, stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        logs = []
+        for p in procs:
+            try:
+                out, _ = p.communicate(timeout=300)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                out, _ = p.communicate()
+            logs.append(out)
+        assert all(p.returncode == 0 for p in procs), "\n----\n".join(x[-3000:] for x in logs)
+        return [np.load(os.path.join(d, "out%d.npy" % r)) for r in range(world)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 5])
+def test_exchange_between_processes_over_hipipc_equals_the_whole_graph(world):
+    """N PROCESSES, one context each, on the one visible device: regions mapped through hipIpcGetMemHandle /
+    hipIpcOpenMemHandle (the handles travel in files), three calls of 3 / 5 / 9 blocks.  Every rank ends with the whole
+    graph's bits — the oracle runs it as ONE graph whose top node is the N-port SumNode."""
+    kw = dict(paused_ranks=(3,), neg_zero_rank=0, one_shot_ranks=(1, 2, 4))
+    want = np.concatenate(whole_graph_oracle(world, 23, 64, [3, 5, 9], **kw))
+    got = _run_ranks(world, "flags")
+    for r in range(world):
+        assert np.array_equal(got[r].view(np.uint32), want.view(np.uint32)), "rank %d" % r
+    if world == 5:  # and the flags matter: without them (no port ever silent) the sign of some zeros differs
+        blind = _run_ranks(world, "noflags")
+        assert np.array_equal(blind[0], want) and not np.array_equal(blind[0].view(np.uint32), want.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------- CPU: the torch paths of shard.py
+def test_shard_ordered_sum_host_path_with_flags_equals_the_model():
+    import torch
+
+    from firewheel_amd import shard
+
+    for world, blocks, frames, ragged in [(1, 3, 16, 0), (2, 4, 16, 0), (4, 3, 24, 1), (5, 6, 16, 3), (9, 4, 32, 0)]:
+        rng = np.random.default_rng(world)
+        parts, sils = random_buses(rng, world, blocks, frames, ragged=ragged)
+        want, _ = topsum_model(parts, sils, frames)
+        tp = [torch.from_numpy(p.copy()) for p in parts]
+        ts = [torch.from_numpy(s.reshape(-1).copy()) for s in sils]
+        out = torch.empty_like(tp[0])
+        shard.ordered_sum(tp, out, None, ts, frames, 2)
+        assert np.array_equal(out.numpy().view(np.uint32), want.view(np.uint32)), world
+        blind, _ = topsum_model(parts, None, frames)
+        shard.ordered_sum(tp, out)
+        assert np.array_equal(out.numpy().view(np.uint32), blind.view(np.uint32)), world
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    from firewheel_amd import shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total, block, calls = 23, 64, [3, 5, 9]
+    kw = dict(paused_ranks=(3,), neg_zero_rank=0, one_shot_ranks=(1, 2, 4))
+    e = OracleEngine(max_block_frames=block)  # (the checker computes the shard: this test is about the reduction protocol)
+    root, voices = shard_graph(e, rank, world, total)
+    e.connect_stereo(root, e.graph_out_node)
+    e.update()
+    start_shard(e, rank, voices, **kw)
+    outs = []
+    for k in calls:
+        o, f = e.process_blocks_flags(k)
+        bus, sil = torch.from_numpy(o.copy()), torch.from_numpy(f.reshape(-1).copy())
+        red = shard.BusReducer(dist, [bus], "ordered", sils=[sil], frames=block, n_ch=2)
+        red.submit(0)
+        outs.append(red.wait(0).numpy().copy())
+    q.put((rank, np.concatenate(outs)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_five_rank_ordered_reduction_with_silence_flags_over_gloo_equals_the_whole_graph():
+    import torch.multiprocessing as mp
+
+    world = 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33100 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    kw = dict(paused_ranks=(3,), neg_zero_rank=0, one_shot_ranks=(1, 2, 4))
+    want = np.concatenate(whole_graph_oracle(world, 23, 64, [3, 5, 9], **kw))
+    for r in range(world):
+        assert np.array_equal(got[r].view(np.uint32), want.view(np.uint32)), "rank %d" % r
+
+
+@pytest.mark.gpu
+def test_exchange_ranks_that_run_apart_wait_on_the_device_without_starving_the_late_one():
+    world = 3
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "rank.py")
+        open(script, "w").write(RANK_SCRIPT)
+        procs = [subprocess.Popen([sys.executable, script, str(r), str(world), d, "skew", ROOT], env=env, stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        logs = [p.communicate(timeout=300)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n----\n".join(x[-3000:] for x in logs)
+        got = [np.load(os.path.join(d, "out%d.npy" % r)) for r in range(world)]
+        waits = [np.load(os.path.join(d, "wait%d.npy" % r)) for r in range(world)]
+    want = []
+    for step in range(3):
+        parts, sils = random_buses(np.random.default_rng(1000 * step), world, 1024, 1024)
+        want.append(topsum_model(parts, sils, 1024)[0])
+    want = np.concatenate(want)
+    for r in range(world):
+        assert np.array_equal(got[r].view(np.uint32), want.view(np.uint32)), "rank %d" % r
+    # ranks 1 and 2 sat waiting for rank 0 (which sleeps 0.3 s before every step), on the device, well inside the 3 s budget
+    assert waits[1][0] > 100000 and waits[2][0] > 100000 and max(w.max() for w in waits) < 2500000, waits

@@ -2,6 +2,10 @@
 // Every function cites the reference file:line it restates.
 #include "fw_oracle.hpp"
 
+#include <atomic>
+#include <chrono>
+#include <thread>
+
 #include <algorithm>
 #include <cassert>
 #include <cmath>
@@ -1737,6 +1741,35 @@ int fwo_process_interleaved_masks(void* c, const float* in, float* out, uint32_t
     cx->processor.record_out_masks = nullptr;
     for (size_t i = 0; i < rec.size() && i < cap; ++i) masks[i] = rec[i];
     return rc ? rc : (int)rec.size();
+}
+
+// cpu_baseline "all cores" (the generous baseline): n independent engines — the voices of one graph split over
+// them — each driven by its own std::thread for `secs` seconds, calls of `frames_per_call` frames back to back into a scratch
+// buffer, no mix-bus exchange charged.  blocks_done[i] = process calls engine i completed.  Returns the wall seconds.
+double fwo_process_parallel(void* const* ctxs, int n, uint32_t n_out_ch, uint64_t frames_per_call, double secs, uint64_t* calls_done) {
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false}, stop{false};
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; ++i) {
+        calls_done[i] = 0;
+        th.emplace_back([&, i] {
+            Ctx* cx = (Ctx*)ctxs[i];
+            std::vector<float> out((size_t)frames_per_call * n_out_ch);
+            ready.fetch_add(1);
+            while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+            while (!stop.load(std::memory_order_relaxed)) {
+                cx->processor.process_interleaved(nullptr, 0, out.data(), out.size(), 0, n_out_ch, (size_t)frames_per_call, 0.0, 0);
+                calls_done[i]++;
+            }
+        });
+    }
+    while (ready.load() < n) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    std::this_thread::sleep_for(std::chrono::duration<double>(secs));
+    stop.store(true);
+    for (auto& t : th) t.join();
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 // B1-level: call one activated node's process() directly with caller buffers (processor.rs:243).

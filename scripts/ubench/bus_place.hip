@@ -180,6 +180,50 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    // ./bus_place vmm: can a PHYSICAL-ONLY spacer (hipMemCreate, never mapped, released at once) push the next hipMalloc into
+    // another third of HBM, and how long does creating it take?  (round 3: the go / no-go for a fwgpu_tune_placement())
+    if (argc > 1 && !strcmp(argv[1], "vmm")) {
+        const size_t bus_bytes = (size_t)K * NBUS * 2 * FRAMES * 4;
+        float *src, *sink;
+        CK(hipMalloc(&src, (size_t)1024 * 2 * STREAM * 4));
+        CK(hipMemset(src, 0, (size_t)1024 * 2 * STREAM * 4));
+        CK(hipMalloc(&sink, 256));
+        hipMemAllocationProp prop;
+        memset(&prop, 0, sizeof(prop));
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        size_t gran = 0;
+        CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+        printf("granularity %zu B\n", gran);
+        for (int rep = 0; rep < 2; ++rep)
+            for (size_t gib : {(size_t)0, (size_t)16, (size_t)48, (size_t)80, (size_t)112, (size_t)144, (size_t)176, (size_t)208}) {
+                hipMemGenericAllocationHandle_t h{};
+                struct timespec t0, t1, t2;
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                bool have = false;
+                if (gib) {
+                    hipError_t e = hipMemCreate(&h, ((gib << 30) + gran - 1) / gran * gran, &prop, 0);
+                    if (e != hipSuccess) {
+                        printf("spacer %3zu GiB: hipMemCreate: %s\n", gib, hipGetErrorString(e));
+                        (void)hipGetLastError();
+                        continue;
+                    }
+                    have = true;
+                }
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                float* bus;
+                CK(hipMalloc(&bus, bus_bytes));
+                if (have) CK(hipMemRelease(h));
+                clock_gettime(CLOCK_MONOTONIC, &t2);
+                const float us = time_us<0, 3>(src, bus, sink, 10);
+                printf("spacer %3zu GiB: create %.1f ms, bus alloc + release %.1f ms, read + write %.1f us (sc0 sc1), bus %p\n", gib,
+                       (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) * 1e-6, us,
+                       (void*)bus);
+                CK(hipFree(bus));
+            }
+        return 0;
+    }
     // ./bus_place matrix [chunks [chunk_GiB]]: sources in chunk i, bus in chunk j of `chunks` separately allocated pieces
     if (argc > 1 && !strcmp(argv[1], "matrix")) {
         const int n = argc > 2 ? atoi(argv[2]) : 10;

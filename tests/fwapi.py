@@ -90,6 +90,7 @@ def oracle_lib():
             "fwo_sampler_set_loop_range": (ci, [vp, i64, ci, f64, f64]),
             "fwo_process_interleaved": (ci, [vp, fp, fp, u32, u32, u64, f64, u32]),
             "fwo_process_interleaved_masks": (ci, [vp, fp, fp, u32, u32, u64, f64, u32, C.POINTER(u64), u32]),
+            "fwo_process_parallel": (f64, [C.POINTER(vp), ci, u32, u64, f64, C.POINTER(u64)]),
             "fwo_node_process": (ci, [vp, i64, u64, C.POINTER(fp), u32, C.POINTER(fp), u32, u64, C.POINTER(u64), f64, u32]),
             "fwo_stream_new": (vp, [vp, u32, u32, u32]),
             "fwo_stream_free": (None, [vp]),
@@ -120,6 +121,17 @@ def oracle_lib():
             f.argtypes = args
         _oracle_lib = L
     return _oracle_lib
+
+
+def oracle_process_parallel(engines, frames_per_call, secs, n_out_ch=2):
+    """one native thread per OracleEngine (libfw_oracle's own std::thread loop: no Python between the calls) for `secs`
+    seconds -> (process calls completed per engine, wall seconds)"""
+    L = oracle_lib()
+    n = len(engines)
+    arr = (C.c_void_p * n)(*[e.c for e in engines])
+    done = (C.c_uint64 * n)()
+    dt = L.fwo_process_parallel(arr, n, n_out_ch, frames_per_call, secs, done)
+    return [int(x) for x in done], dt
 
 
 def _fptr(a):

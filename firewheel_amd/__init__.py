@@ -17,6 +17,7 @@ from .graph import (  # noqa: F401
     FirReverbNode,
     FirewheelGpuCtx,
     HardClipNode,
+    HostNode,
     LoopRange,
     MonoToStereoNode,
     ResamplerNode,
@@ -31,7 +32,7 @@ from .graph import (  # noqa: F401
 )
 
 __all__ = [
-    "FirewheelGpuCtx", "VolumeNode", "SumNode", "SamplerNode", "BeepTestNode", "HardClipNode", "MonoToStereoNode",
+    "FirewheelGpuCtx", "HostNode", "VolumeNode", "SumNode", "SamplerNode", "BeepTestNode", "HardClipNode", "MonoToStereoNode",
     "StereoToMonoNode", "DummyAudioNode", "StereoPanNode", "StereoWidthNode", "BiquadNode", "DelayNode", "FirReverbNode", "ResamplerNode", "SpatialNode", "LoopRange", "SampleFormat", "AddEdgeError",
     "CompileGraphError", "FwgpuError", "load_library", "build_library", "LIB_PATH",
 ]

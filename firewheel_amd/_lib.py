@@ -34,6 +34,24 @@ class SchedNode(C.Structure):
                 ("in_should_clear", C.POINTER(C.c_uint8)), ("out_buffer_index", C.POINTER(u32))]
 
 
+# fwgpu_host_process_fn: AudioNodeProcessor::process + ProcInfo as a C callback (FWGPU_HOST_NODE)
+HOST_PROCESS_FN = C.CFUNCTYPE(None, vp, u64, C.POINTER(fp), u32, C.POINTER(fp), u32, u64, C.POINTER(u64), f64, u32)
+
+
+def host_process_adapter(py_fn):
+    """wrap `py_fn(frames, inputs, outputs, in_silence_mask, stream_time_secs, stream_status) -> out_silence_mask` (inputs /
+    outputs: lists of float32 numpy views of the caller's buffers, outputs writable) as a fwgpu_host_process_fn"""
+    import numpy as np
+
+    def tramp(user, frames, inputs, n_in, outputs, n_out, in_mask, out_mask, t, status):
+        ins = [np.ctypeslib.as_array(inputs[i], shape=(frames,)) for i in range(n_in)]
+        outs = [np.ctypeslib.as_array(outputs[i], shape=(frames,)) for i in range(n_out)]
+        m = py_fn(int(frames), ins, outs, int(in_mask), float(t), int(status))
+        out_mask[0] = int(m or 0)
+
+    return HOST_PROCESS_FN(tramp)
+
+
 # every symbol include/fwgpu.h declares: (restype, argtypes)
 SIGNATURES = {
     "fwgpu_ctx_create": (vp, [ci, u32, u32, u32, u32, vp]),
@@ -49,6 +67,8 @@ SIGNATURES = {
     "fwgpu_disconnect_edge": (ci, [vp, i64]),
     "fwgpu_cycle_detected": (ci, [vp]),
     "fwgpu_update": (ci, [vp]),
+    "fwgpu_host_node_set_process": (ci, [vp, i64, HOST_PROCESS_FN, vp]),
+    "fwgpu_plan_host_nodes": (ci, [vp, C.POINTER(u64)]),
     "fwgpu_schedule_upload": (ci, [vp, C.POINTER(SchedNode), u32, u32]),
     "fwgpu_plan_kind": (ci, [vp]),
     "fwgpu_plan_fused_voices": (ci, [vp]),

@@ -163,7 +163,9 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
         hipHostMalloc((void**)&c->h_rt_out, RT_IO_BYTES, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->d_rt_in, c->h_rt_in, 0) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->d_rt_out, c->h_rt_out, 0) != hipSuccess) {
-        if (c->h_rt_in) (void)hipHostFree(c->h_rt_in);
+        if (c->h_host_stage) (void)hipHostFree(c->h_host_stage);
+    if (c->h_host_flags) (void)hipHostFree(c->h_host_flags);
+    if (c->h_rt_in) (void)hipHostFree(c->h_rt_in);
         if (c->h_rt_out) (void)hipHostFree(c->h_rt_out);
     if (c->h_rt_flag) (void)hipHostFree(c->h_rt_flag);
         c->h_rt_in = c->h_rt_out = nullptr;
@@ -232,6 +234,8 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
             (void)hipEventDestroy(p.second);
         }
     if (c->rt_graph.exec) (void)hipGraphExecDestroy(c->rt_graph.exec);
+    if (c->h_host_stage) (void)hipHostFree(c->h_host_stage);
+    if (c->h_host_flags) (void)hipHostFree(c->h_host_flags);
     if (c->h_rt_in) (void)hipHostFree(c->h_rt_in);
     if (c->h_rt_out) (void)hipHostFree(c->h_rt_out);
     if (c->h_cmds) (void)hipHostFree(c->h_cmds);
@@ -252,7 +256,7 @@ int64_t fwgpu_graph_out_node(fwgpu_ctx* c) { return c ? c->graph.id_of(c->graph.
 
 int64_t fwgpu_add_node(fwgpu_ctx* c, int kind, uint32_t n_in, uint32_t n_out, const float* params, int n_params) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
-    if (kind < 0 || kind > K_SPATIAL) return fail(c, FWGPU_ERR_INVALID, "unsupported node kind");
+    if (kind < 0 || kind > K_LAST) return fail(c, FWGPU_ERR_INVALID, "unsupported node kind");
     if (n_params < 0 || (n_params > 0 && !params)) return fail(c, FWGPU_ERR_INVALID, "params is null but n_params > 0");
     if (kind == K_FIR || kind == K_RESAMPLER) {
         int ir = n_params > 0 ? (int)params[0] : -1;
@@ -332,6 +336,24 @@ int fwgpu_disconnect(fwgpu_ctx* c, int64_t src, uint32_t sp, int64_t dst, uint32
 }
 int fwgpu_disconnect_edge(fwgpu_ctx* c, int64_t e) { return c ? c->graph.disconnect_edge(e) : FWGPU_ERR_INVALID; }
 int fwgpu_cycle_detected(fwgpu_ctx* c) { return c ? (c->graph.cycle_detected() ? 1 : 0) : FWGPU_ERR_INVALID; }
+
+int fwgpu_host_node_set_process(fwgpu_ctx* c, int64_t node, fwgpu_host_process_fn fn, void* user) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    HostNode* hn = c->graph.get(node);
+    if (!hn || hn->kind != K_HOST) return fail(c, FWGPU_ERR_INVALID, "not a host node (fwgpu_add_node with FWGPU_HOST_NODE)");
+    if (!fn) return fail(c, FWGPU_ERR_INVALID, "host node: null process function");
+    const size_t slot = (size_t)(node & 0xffffffff);
+    if (c->host_procs.size() <= slot) c->host_procs.resize(std::max<size_t>(slot + 1, c->host_procs.size() * 2));
+    c->host_procs[slot].fn = fn;
+    c->host_procs[slot].user = user;
+    c->graph.needs_compile = true;  // the plan holds a copy of the function pointer: the next update installs the new one
+    return 0;
+}
+int fwgpu_plan_host_nodes(fwgpu_ctx* c, uint64_t* callbacks_run) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    if (callbacks_run) *callbacks_run = c->host_callbacks;
+    return c->have_plan ? c->n_host_nodes : -1;
+}
 
 int fwgpu_update(fwgpu_ctx* c) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
@@ -943,6 +965,7 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     if (hn->n_in != n_in || hn->n_out != n_out) return fail(c, FWGPU_ERR_INVALID, "port counts differ from add_node");
     if (frames > c->mbf) return fail(c, FWGPU_ERR_INVALID, "frames > max_block_frames");
     if (hn->kind == K_FIR) return fail(c, FWGPU_ERR_INVALID, "FIR banks run at graph level (fwgpu_process_interleaved), not per node");
+    if (hn->kind == K_HOST) return fail(c, FWGPU_ERR_INVALID, "a host node's processor lives in the caller: call it there");
     if (n_in + n_out == 0) return fail(c, FWGPU_ERR_INVALID, "node has no ports");
     if (frames == 0) {  // the reference never calls a node with an empty block (processor.rs:86-89 returns first): nothing to do
         if (out_mask) *out_mask = 0;

@@ -249,6 +249,30 @@ struct fwgpu_ctx {
     bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2
     DevBuf d_rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS]
 
+    // host nodes (K_HOST): the caller's own AudioNodeProcessor::process behind a C callback.  host_procs is the control
+    // side's registry (by node slot); install_plan copies what the plan needs into host_levels, which the audio side reads.
+    struct HostProc {
+        fwgpu_host_process_fn fn = nullptr;
+        void* user = nullptr;
+    };
+    std::vector<HostProc> host_procs;
+    struct HostCall {
+        int node_idx = 0;  // index into the plan's node table (its in / out buffer ids sit in d_in_buf / d_out_buf)
+        int n_in = 0, n_out = 0, in_off = 0, out_off = 0;
+        fwgpu_host_process_fn fn = nullptr;
+        void* user = nullptr;
+        size_t stage_off = 0;  // float offset of this node's [K][n_in + n_out][stride] block in the pinned staging area
+        size_t flag_off = 0;   // byte offset of its [K][n_in + n_out] silence flags
+    };
+    std::vector<std::vector<HostCall>> host_levels;  // per plan level
+    int n_host_nodes = 0;
+    uint64_t host_callbacks = 0;
+    float *h_host_stage = nullptr, *d_host_stage = nullptr;  // pinned, device-mapped: the host nodes' inputs and outputs
+    uint8_t *h_host_flags = nullptr, *d_host_flags = nullptr;
+    size_t host_stage_floats = 0, host_flag_bytes = 0;
+    std::vector<const float*> host_in_ptrs;  // scratch for the callback's pointer tables (sized at install: no allocation per call)
+    std::vector<float*> host_out_ptrs;
+
     // fwgpu_process_blocks_device_flags: where the call in progress reports, per (block, channel), whether that graph-output
     // channel was flagged silent (device memory of the caller; null = not asked for)
     uint8_t* out_sil = nullptr;

@@ -181,6 +181,20 @@ int launch_bus_reduce(hipStream_t s, char* base, const ExchangeGeom& g, float* d
                        frames, n_ch, seq, (const unsigned long long*)d_sync);
     return (int)hipGetLastError();
 }
+int launch_host_gather(hipStream_t s, const float* pool, const uint8_t* flags, int stride, size_t pool_blk_stride, size_t flags_blk_stride,
+                       const int* d_bufs, int n, int frames, int K, int row_pitch, float* d_stage, uint8_t* d_stage_flags) {
+    if (n <= 0 || K <= 0 || frames <= 0) return 0;
+    hipLaunchKernelGGL(k_host_gather, dim3((frames + 255) / 256, n, K), dim3(256), 0, s, pool, flags, stride, pool_blk_stride, flags_blk_stride,
+                       d_bufs, frames, row_pitch, d_stage, d_stage_flags);
+    return (int)hipGetLastError();
+}
+int launch_host_scatter(hipStream_t s, float* pool, uint8_t* flags, int stride, size_t pool_blk_stride, size_t flags_blk_stride,
+                        const int* d_bufs, int n, int frames, int K, int row_pitch, const float* d_stage, const uint8_t* d_stage_flags) {
+    if (n <= 0 || K <= 0 || frames <= 0) return 0;
+    hipLaunchKernelGGL(k_host_scatter, dim3((frames + 255) / 256, n, K), dim3(256), 0, s, pool, flags, stride, pool_blk_stride, flags_blk_stride,
+                       d_bufs, frames, row_pitch, d_stage, d_stage_flags);
+    return (int)hipGetLastError();
+}
 int launch_out_flags(hipStream_t s, const uint8_t* flags, size_t flags_blk_stride, const int* d_bufs, int n_bufs, int mode, int n_out_ch, int K,
                      uint8_t* d_out) {
     const int n = K * n_out_ch;

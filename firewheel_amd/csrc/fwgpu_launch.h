@@ -131,6 +131,12 @@ int launch_bus_push(hipStream_t s, const ExchangePeers& peers, const ExchangeGeo
                     size_t n_floats, uint32_t n_sil, unsigned long long seq, unsigned* d_counter);
 int launch_bus_reduce(hipStream_t s, char* base, const ExchangeGeom& g, float* d_out, uint8_t* d_out_sil, size_t n_floats, uint32_t n_sil,
                       uint32_t frames, uint32_t n_ch, unsigned long long seq, unsigned long long budget_ticks, unsigned long long* d_sync);
+// host nodes: copy the pool buffers `bufs[0..n)` of K blocks (+ their silence flags) to / from the pinned staging area
+// stage[k][j][stride], stage_flags[k][j]
+int launch_host_gather(hipStream_t s, const float* pool, const uint8_t* flags, int stride, size_t pool_blk_stride, size_t flags_blk_stride,
+                       const int* d_bufs, int n, int frames, int K, int row_pitch, float* d_stage, uint8_t* d_stage_flags);
+int launch_host_scatter(hipStream_t s, float* pool, uint8_t* flags, int stride, size_t pool_blk_stride, size_t flags_blk_stride,
+                        const int* d_bufs, int n, int frames, int K, int row_pitch, const float* d_stage, const uint8_t* d_stage_flags);
 // per (block, channel) of a batch: was that graph-output channel flagged silent (mode: see k_out_flags)
 int launch_out_flags(hipStream_t s, const uint8_t* flags, size_t flags_blk_stride, const int* d_bufs, int n_bufs, int mode, int n_out_ch, int K,
                      uint8_t* d_out);

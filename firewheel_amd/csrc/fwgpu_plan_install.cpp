@@ -111,6 +111,8 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         for (uint32_t slot : c->graph.nodes_to_activate) {
             const HostNode& n = c->graph.nodes[slot];
             if (!n.alive || n.activated) continue;
+            if (n.kind == K_HOST && (slot >= c->host_procs.size() || !c->host_procs[slot].fn))
+                return rollback(fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "host node without a process function (fwgpu_host_node_set_process)"));
             Act a;
             a.slot = slot;
             a.st = n.init;
@@ -256,7 +258,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
     std::vector<NodeDesc> nd(N);
     std::vector<int> in_tab, out_tab;
     std::vector<std::vector<int>> levels(plan.num_levels);
-    std::vector<int> gin_bufs, gout_bufs;
+    std::vector<int> gin_bufs, gout_bufs, host_nodes;
     for (int i = 0; i < N; ++i) {
         const PlanNode& p = plan.nodes[i];
         NodeDesc& d = nd[i];
@@ -273,6 +275,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         out_tab.insert(out_tab.end(), p.out_buf.begin(), p.out_buf.end());
         if (p.is_graph_io == 1) gin_bufs = p.out_buf;
         else if (p.is_graph_io == 2) gout_bufs = p.in_buf;
+        else if (p.kind == K_HOST) host_nodes.push_back(i);  // no kernel runs it: the plan is cut at its level (step 3c)
         else levels[p.level].push_back(i);
     }
     // hybrid plan: the continuation of a split SumNode — (partial bus, the ports behind the leading voices) on the path of the
@@ -319,6 +322,53 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
     if (gout_bufs.empty()) gout_bufs.push_back(0);
     if ((rc = upload(c, c->d_gin_bufs, gin_bufs.data(), gin_bufs.size() * sizeof(int)))) return rc;
     if ((rc = upload(c, c->d_gout_bufs, gout_bufs.data(), gout_bufs.size() * sizeof(int)))) return rc;
+    // 3c. host nodes (K_HOST): per level, what the audio side needs to call them — and one pinned, device-mapped staging area
+    //     for their inputs and outputs of a whole K-batch, allocated here (a process call never allocates)
+    {
+        c->host_levels.assign(plan.num_levels, {});
+        c->n_host_nodes = (int)host_nodes.size();
+        c->host_callbacks = 0;
+        size_t floats = 0, flag_bytes = 0, max_in = 1, max_out = 1;
+        for (int i : host_nodes) {
+            const PlanNode& p = plan.nodes[i];
+            fwgpu_ctx::HostCall hc;
+            hc.node_idx = i;
+            hc.n_in = p.n_in;
+            hc.n_out = p.n_out;
+            hc.in_off = nd[i].in_off;
+            hc.out_off = nd[i].out_off;
+            hc.fn = p.slot < c->host_procs.size() ? c->host_procs[p.slot].fn : nullptr;
+            hc.user = p.slot < c->host_procs.size() ? c->host_procs[p.slot].user : nullptr;
+            if (!hc.fn) return fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "host node without a process function (fwgpu_host_node_set_process)");
+            hc.stage_off = floats;
+            hc.flag_off = flag_bytes;
+            floats += (size_t)c->kmax * (size_t)(p.n_in + p.n_out) * c->stride;
+            flag_bytes += (size_t)c->kmax * (size_t)(p.n_in + p.n_out);
+            max_in = std::max<size_t>(max_in, (size_t)p.n_in);
+            max_out = std::max<size_t>(max_out, (size_t)p.n_out);
+            c->host_levels[p.level].push_back(hc);
+        }
+        if (floats > c->host_stage_floats || flag_bytes > c->host_flag_bytes) {
+            if (c->h_host_stage) (void)hipHostFree(c->h_host_stage);
+            if (c->h_host_flags) (void)hipHostFree(c->h_host_flags);
+            c->h_host_stage = nullptr;
+            c->h_host_flags = nullptr;
+            c->host_stage_floats = c->host_flag_bytes = 0;
+            void *hs = nullptr, *hf = nullptr, *ds = nullptr, *df = nullptr;
+            HIPC(c, hipHostMalloc(&hs, floats * sizeof(float), hipHostMallocMapped));
+            c->h_host_stage = (float*)hs;
+            HIPC(c, hipHostMalloc(&hf, flag_bytes + 64, hipHostMallocMapped));
+            c->h_host_flags = (uint8_t*)hf;
+            HIPC(c, hipHostGetDevicePointer(&ds, hs, 0));
+            HIPC(c, hipHostGetDevicePointer(&df, hf, 0));
+            c->d_host_stage = (float*)ds;
+            c->d_host_flags = (uint8_t*)df;
+            c->host_stage_floats = floats;
+            c->host_flag_bytes = flag_bytes;
+        }
+        c->host_in_ptrs.assign(max_in, nullptr);
+        c->host_out_ptrs.assign(max_out, nullptr);
+    }
     // 3b. FIR banks: one GEMM per (level, impulse-response channel)
     {
         std::map<std::tuple<int, uint32_t, uint32_t>, std::vector<FirRow>> groups;

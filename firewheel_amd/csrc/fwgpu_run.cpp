@@ -285,6 +285,46 @@ static void fill_fused_view(fwgpu_ctx* c, FusedView& fv) {
     }
 }
 
+// The plan is CUT at a level that holds host nodes (K_HOST: the caller's own AudioNodeProcessor::process, graph/processor.rs:243).
+// The device nodes of the level have been launched; for each host node: its input buffers of the K blocks -> pinned host memory
+// (one small kernel; nothing else crosses), wait for the stream, the callback once per block in block order on THIS (the audio)
+// thread with the ProcInfo of the call in progress, its outputs + the silence mask it reported -> back into the pool.
+static int run_host_level(fwgpu_ctx* c, const DevView& v, const std::vector<fwgpu_ctx::HostCall>& calls, int K, int frames) {
+    for (const fwgpu_ctx::HostCall& hc : calls) {
+        const int rows = hc.n_in + hc.n_out;
+        if (hc.n_in > 0)
+            LCHK(c, launch_host_gather(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride, c->d_in_buf.as<int>() + hc.in_off,
+                                   hc.n_in, frames, K, rows, c->d_host_stage + hc.stage_off, c->d_host_flags + hc.flag_off));
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));
+    for (const fwgpu_ctx::HostCall& hc : calls) {
+        const int rows = hc.n_in + hc.n_out;
+        float* st = c->h_host_stage + hc.stage_off;
+        uint8_t* fl = c->h_host_flags + hc.flag_off;
+        for (int k = 0; k < K; ++k) {
+            uint64_t in_mask = 0, out_mask = 0;  // (processor.rs:233: the out mask arrives cleared)
+            for (int j = 0; j < hc.n_in; ++j) {
+                c->host_in_ptrs[j] = st + ((size_t)k * rows + j) * c->stride;
+                if (fl[(size_t)k * rows + j]) in_mask |= 1ull << j;
+            }
+            for (int j = 0; j < hc.n_out; ++j) {
+                float* o = st + ((size_t)k * rows + hc.n_in + j) * c->stride;
+                memset(o, 0, (size_t)frames * sizeof(float));  // a node that breaks "fill every output" leaves zeros, not another block's data
+                c->host_out_ptrs[j] = o;
+            }
+            hc.fn(hc.user, (uint64_t)frames, c->host_in_ptrs.data(), (uint32_t)hc.n_in, c->host_out_ptrs.data(), (uint32_t)hc.n_out, in_mask, &out_mask,
+                  c->proc_stream_time, c->proc_stream_status);
+            for (int j = 0; j < hc.n_out; ++j) fl[(size_t)k * rows + hc.n_in + j] = (out_mask >> j) & 1ull ? 1 : 0;
+            c->host_callbacks++;
+        }
+        if (hc.n_out > 0)
+            LCHK(c, launch_host_scatter(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride, c->d_out_buf.as<int>() + hc.out_off,
+                                    hc.n_out, frames, K, rows, c->d_host_stage + hc.stage_off + (size_t)hc.n_in * c->stride,
+                                    c->d_host_flags + hc.flag_off + hc.n_in));
+    }
+    return 0;
+}
+
 // K blocks of `frames` frames through the level-batched executor (schedule.rs:289-344 as one launch per level for
 // all K blocks: each block has its own pool slice, a stateful node walks its K blocks in order inside one wave)
 int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const float* d_in, int n_in_ch, float* d_out,
@@ -351,6 +391,10 @@ int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const
                                    c->d_fir_tiles.as<uint32_t>() + g.tile_off, g.T, c->d_fir_partials.as<float>(),
                                    c->d_fir_partials.cap / sizeof(float), K, g0, g1));
             }
+        if (l < c->host_levels.size() && !c->host_levels[l].empty()) {
+            const int rc = run_host_level(c, v, c->host_levels[l], K, frames);
+            if (rc) return rc;
+        }
     }
     timer_end(c, e1);
     LCHK(c, launch_graph_out(c->stream, v.pool, v.flags, c->stride, v.pool_blk_stride, v.flags_blk_stride,

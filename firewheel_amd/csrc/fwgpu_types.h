@@ -8,6 +8,8 @@ enum : int {
     K_DUMMY = 0, K_BEEP = 1, K_VOLUME = 2, K_SUM = 3, K_SAMPLER = 4, K_HARD_CLIP = 5,
     K_MONO_TO_STEREO = 6, K_STEREO_TO_MONO = 7, K_PAN = 8, K_WIDTH = 9, K_BIQUAD = 10, K_DELAY = 11,
     K_FIR = 12, K_RESAMPLER = 13, K_SPATIAL = 14,
+    K_HOST = 15,  // a node the library does not implement: the caller's own AudioNodeProcessor::process, run on the host
+    K_LAST = K_HOST,
 };
 #define RS_PHASES 32  // SPEC resampler: polyphase windowed-sinc table [RS_PHASES][RS_TAPS], 32.32 fixed-point position
 #define RS_TAPS 16

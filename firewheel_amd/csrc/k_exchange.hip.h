@@ -262,3 +262,26 @@ __global__ void k_out_flags(const uint8_t* __restrict__ flags, size_t flags_blk_
     }
     out[t] = s;
 }
+
+// Host nodes (FWGPU_HOST_NODE: the caller's own AudioNodeProcessor::process, graph/processor.rs:243): the plan is cut at their
+// level.  k_host_gather copies a node's INPUT buffers of the K blocks of a batch — and nothing else — into pinned,
+// device-mapped host memory (stage[k][row0 + j][stride], one coalesced row per buffer) with their silence flags;
+// k_host_scatter brings its OUTPUT buffers and the flags its callback reported back.  blockIdx = (frame chunk, buffer, block).
+__global__ __launch_bounds__(256) void k_host_gather(const float* __restrict__ pool, const uint8_t* __restrict__ flags, int stride,
+                                                     size_t pool_blk_stride, size_t flags_blk_stride, const int* __restrict__ bufs, int frames,
+                                                     int row_pitch, float* __restrict__ stage, uint8_t* __restrict__ stage_flags) {
+    const int j = blockIdx.y, k = blockIdx.z;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = bufs[j];
+    if (f < frames) stage[((size_t)k * row_pitch + j) * stride + f] = pool[(size_t)k * pool_blk_stride + (size_t)b * stride + f];
+    if (f == 0) stage_flags[(size_t)k * row_pitch + j] = flags[(size_t)k * flags_blk_stride + b];
+}
+__global__ __launch_bounds__(256) void k_host_scatter(float* __restrict__ pool, uint8_t* __restrict__ flags, int stride, size_t pool_blk_stride,
+                                                      size_t flags_blk_stride, const int* __restrict__ bufs, int frames, int row_pitch,
+                                                      const float* __restrict__ stage, const uint8_t* __restrict__ stage_flags) {
+    const int j = blockIdx.y, k = blockIdx.z;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = bufs[j];
+    if (f < frames) pool[(size_t)k * pool_blk_stride + (size_t)b * stride + f] = stage[((size_t)k * row_pitch + j) * stride + f];
+    if (f == 0) flags[(size_t)k * flags_blk_stride + b] = stage_flags[(size_t)k * row_pitch + j];
+}

@@ -280,6 +280,21 @@ class SpatialNode(_Node):  # SPEC node: 3D spatialiser — distance gain, equal-
             self._set(i, v, at_block)
 
 
+class HostNode(_Node):
+    """any other `dyn AudioNodeProcessor` (graph/processor.rs:243) inside a device-resident graph: `process` runs on the host,
+    on the audio thread, once per block — process(frames, inputs, outputs, in_silence_mask, stream_time_secs, stream_status)
+    -> out_silence_mask, inputs / outputs being float32 numpy views (FWGPU_HOST_NODE, include/fwgpu.h)"""
+    KIND = 15
+
+    def __init__(self, process):
+        self.process = process
+        self._cb = _lib.host_process_adapter(process)
+
+    def _bind(self, cx, node_id):
+        super()._bind(cx, node_id)
+        cx._check(cx.L.fwgpu_host_node_set_process(cx.c, node_id, self._cb, None))
+
+
 class _RawNode(_Node):
     def __init__(self, kind, params):
         self.KIND = kind
@@ -422,6 +437,11 @@ class FirewheelGpuCtx(object):
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._check(self.L.fwgpu_plan_chain_stats(self.c, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def plan_host_nodes(self):
+        """(host nodes in the installed plan, callbacks run since it was installed)"""
+        n = C.c_uint64()
+        return self._check(self.L.fwgpu_plan_host_nodes(self.c, C.byref(n))), n.value
 
     def set_max_batch(self, k):
         self._check(self.L.fwgpu_set_max_batch(self.c, k))

@@ -50,7 +50,8 @@ enum fwgpu_node_kind {
     FWGPU_DELAY = 11,         /* SPEC                 params: delay_secs, feedback, mix */
     FWGPU_FIR = 12,           /* SPEC convolution     params: impulse-response sample id (fwgpu_sample_create) */
     FWGPU_RESAMPLER = 13,     /* SPEC polyphase resampling source (0 inputs)  params: sample id, ratio, loop, playing */
-    FWGPU_SPATIAL = 14        /* SPEC 3D spatialiser (1|2 in, 2 out)          params: x, y, z of the source */
+    FWGPU_SPATIAL = 14,       /* SPEC 3D spatialiser (1|2 in, 2 out)          params: x, y, z of the source */
+    FWGPU_HOST_NODE = 15      /* any other `dyn AudioNodeProcessor` (graph/processor.rs:243): runs on the HOST, see below */
 };
 
 /* sample formats — core/sample_resource.rs:28-335 */
@@ -108,6 +109,24 @@ int fwgpu_cycle_detected(fwgpu_ctx* ctx);                /* graph.rs:573-580 */
 /* FirewheelGraphCtx::update (graph/context.rs:93-137): recompile when dirty, activate new nodes
  * (AudioNode::activate, core/node.rs:12-18), build + upload the device launch plan. */
 int fwgpu_update(fwgpu_ctx* ctx);
+
+/* ---- custom nodes inside a device-resident graph ("unknown/custom Rust nodes fall back to B1 on host with explicit
+ * D2H/H2D of just their buffers").  The reference calls ANY `dyn AudioNodeProcessor` from its schedule loop
+ * (graph/processor.rs:226-247); a node this library has no kernel for is added as FWGPU_HOST_NODE with its port counts and
+ * given its process function — `AudioNodeProcessor::process` + `ProcInfo` (core/node.rs:37-53,94-118) as a C callback:
+ * inputs[i] / outputs[i] are `frames` floats, in_silence_mask bit i = input i is silent, *out_silence_mask arrives 0
+ * (processor.rs:233), every output must be filled.  The launch plan is CUT at such a node's level: the levels above it run on
+ * the device, its input buffers (and only those) are copied to pinned host memory, the callback runs on the AUDIO thread —
+ * once per block, in block order, like the reference — its outputs go back, the levels below continue.  A process call of K
+ * blocks crosses the boundary twice per host level, not twice per block.  Voice banks of the graph stay on the fused kernels
+ * (hybrid plan).  The function must be set before the fwgpu_update / fwgpu_schedule_upload that activates the node; it must
+ * not call back into this ctx. */
+typedef void (*fwgpu_host_process_fn)(void* user, uint64_t frames, const float* const* inputs, uint32_t num_inputs,
+                                      float* const* outputs, uint32_t num_outputs, uint64_t in_silence_mask,
+                                      uint64_t* out_silence_mask, double stream_time_secs, uint32_t stream_status);
+int fwgpu_host_node_set_process(fwgpu_ctx* ctx, int64_t node, fwgpu_host_process_fn fn, void* user);
+/* how many host nodes the installed plan holds / how often their callbacks have run since the plan was installed */
+int fwgpu_plan_host_nodes(fwgpu_ctx* ctx, uint64_t* callbacks_run);
 
 /* ---- external schedule import: keep Firewheel's own Rust scheduler and hand its CompiledSchedule over
  * (graph/graph/compiler/schedule.rs:12-30,105-126,166-173).  Buffer indices are the reference's; the

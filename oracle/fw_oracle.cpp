@@ -1021,9 +1021,27 @@ std::unique_ptr<AudioNode> make_node(int kind, const float* params, int n_params
     return n;
 }
 
+// KIND_CUSTOM: a node the graph knows nothing about — processor.rs:243 calls it like any other
+struct CustomProcessor : AudioNodeProcessor {
+    AudioNode::CustomFn fn;
+    void* user;
+    CustomProcessor(AudioNode::CustomFn f, void* u) : fn(f), user(u) {}
+    void process(size_t frames, const float* const* inputs, size_t n_in, float* const* outputs, size_t n_out, ProcInfo info) override {
+        uint64_t om = info.out_silence_mask->bits;
+        fn(user, frames, inputs, (uint32_t)n_in, outputs, (uint32_t)n_out, info.in_silence_mask.bits, &om, info.stream_time_secs, info.stream_status);
+        info.out_silence_mask->bits = om;
+    }
+};
+
 std::unique_ptr<AudioNodeProcessor> AudioNode::activate(uint32_t sample_rate, size_t max_block_frames,
                                                         size_t num_inputs, size_t num_outputs, std::string& err) {
     switch (kind) {
+        case KIND_CUSTOM:
+            if (!custom_fn) {
+                err = "custom node without a process function";
+                return nullptr;
+            }
+            return std::unique_ptr<AudioNodeProcessor>(new CustomProcessor(custom_fn, custom_user));
         case KIND_DUMMY:
             return std::unique_ptr<AudioNodeProcessor>(new DummyProcessor());
         case KIND_VOLUME:  // volume.rs:56-76
@@ -1551,6 +1569,14 @@ int64_t fwo_add_node(void* c, int kind, uint32_t n_in, uint32_t n_out, const flo
         node->ir = cx->samples[id];
     }
     return index_to_i64(cx->graph.add_node(n_in, n_out, std::move(node)));
+}
+int fwo_custom_node_set_process(void* c, int64_t node, AudioNode::CustomFn fn, void* user) {
+    Ctx* cx = (Ctx*)c;
+    auto* ne = cx->graph.nodes.get(index_from_i64(node));
+    if (!ne || !ne->node || ne->node->kind != KIND_CUSTOM) return -20;
+    ne->node->custom_fn = fn;
+    ne->node->custom_user = user;
+    return 0;
 }
 int fwo_remove_node(void* c, int64_t node) { return ((Ctx*)c)->graph.remove_node(index_from_i64(node)); }
 int64_t fwo_connect(void* c, int64_t src, uint32_t sp, int64_t dst, uint32_t dp, int check) {

@@ -158,6 +158,7 @@ enum NodeKind : int {
     KIND_FIR = 12,
     KIND_RESAMPLER = 13,
     KIND_SPATIAL = 14,
+    KIND_CUSTOM = 15,  // any other `dyn AudioNodeProcessor`: the test's own process function (the product's FWGPU_HOST_NODE)
 };
 
 // SPEC resampler: polyphase windowed-sinc table, RS_PHASES x RS_TAPS, 32.32 fixed-point source position
@@ -195,6 +196,11 @@ struct AudioNode {
     // SPEC resampler / spatialiser control words, read by the processor at block start ("atomics")
     std::shared_ptr<std::vector<double>> ctl;
     std::shared_ptr<std::deque<SamplerMsg>> to_processor;  // sampler.rs:42 (rtrb cap 128)
+    // KIND_CUSTOM: AudioNodeProcessor::process + ProcInfo as a C callback (same signature as fwgpu_host_process_fn)
+    typedef void (*CustomFn)(void* user, uint64_t frames, const float* const* inputs, uint32_t n_in, float* const* outputs, uint32_t n_out,
+                             uint64_t in_mask, uint64_t* out_mask, double stream_time_secs, uint32_t stream_status);
+    CustomFn custom_fn = nullptr;
+    void* custom_user = nullptr;
     const char* debug_name() const;
     // activate: returns nullptr and sets err on failure (core/node.rs:12-18)
     std::unique_ptr<AudioNodeProcessor> activate(uint32_t sample_rate, size_t max_block_frames,

@@ -16,6 +16,21 @@ pub struct fwgpu_bus_exchange {
     _private: [u8; 0],
 }
 pub const FWGPU_EXCHANGE_HANDLE_BYTES: usize = 128;
+/// AudioNodeProcessor::process + ProcInfo (core/node.rs:37-53,94-118) as the C callback of a FWGPU_HOST_NODE
+pub type fwgpu_host_process_fn = Option<
+    unsafe extern "C" fn(
+        user: *mut c_void,
+        frames: u64,
+        inputs: *const *const f32,
+        num_inputs: u32,
+        outputs: *const *mut f32,
+        num_outputs: u32,
+        in_silence_mask: u64,
+        out_silence_mask: *mut u64,
+        stream_time_secs: f64,
+        stream_status: u32,
+    ),
+>;
 /// one ScheduledNode of Firewheel's CompiledSchedule (graph/graph/compiler/schedule.rs:12-30)
 #[repr(C)]
 pub struct fwgpu_sched_node {
@@ -43,6 +58,7 @@ pub const FWGPU_DELAY: c_int = 11;
 pub const FWGPU_FIR: c_int = 12;
 pub const FWGPU_RESAMPLER: c_int = 13;
 pub const FWGPU_SPATIAL: c_int = 14;
+pub const FWGPU_HOST_NODE: c_int = 15;
 
 // enum fwgpu_sample_format
 pub const FWGPU_INTERLEAVED_I16: c_int = 0;
@@ -83,6 +99,8 @@ extern "C" {
     pub fn fwgpu_disconnect_edge(ctx: *mut fwgpu_ctx, edge: i64) -> c_int;
     pub fn fwgpu_cycle_detected(ctx: *mut fwgpu_ctx) -> c_int;
     pub fn fwgpu_update(ctx: *mut fwgpu_ctx) -> c_int;
+    pub fn fwgpu_host_node_set_process(ctx: *mut fwgpu_ctx, node: i64, r#fn: fwgpu_host_process_fn, user: *mut c_void) -> c_int;
+    pub fn fwgpu_plan_host_nodes(ctx: *mut fwgpu_ctx, callbacks_run: *mut u64) -> c_int;
     pub fn fwgpu_schedule_upload(ctx: *mut fwgpu_ctx, nodes: *const fwgpu_sched_node, n_nodes: u32, num_buffers: u32) -> c_int;
     pub fn fwgpu_plan_kind(ctx: *mut fwgpu_ctx) -> c_int;
     pub fn fwgpu_plan_fused_voices(ctx: *mut fwgpu_ctx) -> c_int;

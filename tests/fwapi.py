@@ -90,6 +90,7 @@ def oracle_lib():
             "fwo_sampler_set_loop_range": (ci, [vp, i64, ci, f64, f64]),
             "fwo_process_interleaved": (ci, [vp, fp, fp, u32, u32, u64, f64, u32]),
             "fwo_process_interleaved_masks": (ci, [vp, fp, fp, u32, u32, u64, f64, u32, C.POINTER(u64), u32]),
+            "fwo_custom_node_set_process": (ci, [vp, i64, vp, vp]),
             "fwo_process_parallel": (f64, [C.POINTER(vp), ci, u32, u64, f64, C.POINTER(u64)]),
             "fwo_node_process": (ci, [vp, i64, u64, C.POINTER(fp), u32, C.POINTER(fp), u32, u64, C.POINTER(u64), f64, u32]),
             "fwo_stream_new": (vp, [vp, u32, u32, u32]),
@@ -220,6 +221,16 @@ class OracleEngine(Engine):
     def add_node(self, kind, n_in, n_out, params=()):
         p = np.asarray(list(params), dtype=np.float32)
         return self.L.fwo_add_node(self.c, kind, n_in, n_out, _fptr(p), len(p))
+
+    def host_node(self, n_in, n_out, process):
+        """a custom node: `process(frames, inputs, outputs, in_mask, stream_time, status) -> out_mask` (KIND_CUSTOM)"""
+        import firewheel_amd._lib as flib
+
+        cb = flib.host_process_adapter(process)
+        self._keep_cbs = getattr(self, "_keep_cbs", []) + [cb]
+        n = self.add_node(15, n_in, n_out)
+        assert self.L.fwo_custom_node_set_process(self.c, n, C.cast(cb, C.c_void_p), None) == 0
+        return n
 
     def remove_node(self, node):
         return self.L.fwo_remove_node(self.c, node)
@@ -478,6 +489,10 @@ class GpuEngine(Engine):
         from firewheel_amd.graph import _RawNode
 
         return self.cx.add_node(n_in, n_out, _RawNode(kind, params))
+
+    def host_node(self, n_in, n_out, process):
+        """FWGPU_HOST_NODE: the caller's own AudioNodeProcessor::process, run on the host inside the device-resident graph"""
+        return self.cx.add_node(n_in, n_out, self.fa.HostNode(process))
 
     def remove_node(self, node):
         self.cx.remove_node(node)

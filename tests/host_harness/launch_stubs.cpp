@@ -314,6 +314,33 @@ int launch_bus_reduce(hipStream_t, char* base, const ExchangeGeom& g, float* d_o
     if (d_out_sil) touch(d_out_sil, n_sil);
     return 0;
 }
+int launch_host_gather(hipStream_t, const float* pool, const uint8_t* flags, int stride, size_t pool_blk_stride, size_t flags_blk_stride,
+                       const int* d_bufs, int n, int frames, int K, int row_pitch, float* d_stage, uint8_t* d_stage_flags) {
+    g_launches[7]++;
+    REQUIRE(n >= 1 && n <= 64 && K >= 1 && frames >= 1 && frames <= stride && row_pitch >= n, n, row_pitch);
+    touch(d_bufs, sizeof(int) * (size_t)n);
+    for (int j = 0; j < n; ++j) {
+        touch(pool + (size_t)(K - 1) * pool_blk_stride + (size_t)d_bufs[j] * stride, sizeof(float) * (size_t)frames);
+        touch(flags + (size_t)(K - 1) * flags_blk_stride + d_bufs[j], 1);
+    }
+    touch(d_stage, sizeof(float) * (((size_t)(K - 1) * row_pitch + (n - 1)) * stride + frames));
+    touch(d_stage_flags, (size_t)(K - 1) * row_pitch + n);
+    return 0;
+}
+int launch_host_scatter(hipStream_t, float* pool, uint8_t* flags, int stride, size_t pool_blk_stride, size_t flags_blk_stride, const int* d_bufs,
+                        int n, int frames, int K, int row_pitch, const float* d_stage, const uint8_t* d_stage_flags) {
+    g_launches[7]++;
+    REQUIRE(n >= 1 && n <= 64 && K >= 1 && frames >= 1 && frames <= stride && row_pitch >= n, n, row_pitch);
+    touch(d_bufs, sizeof(int) * (size_t)n);
+    for (int j = 0; j < n; ++j) {
+        REQUIRE(d_bufs[j] != 0, j);  // buffer 0 is the constant zero buffer: never an output
+        touch(pool + (size_t)(K - 1) * pool_blk_stride + (size_t)d_bufs[j] * stride, sizeof(float) * (size_t)frames);
+        touch(flags + (size_t)(K - 1) * flags_blk_stride + d_bufs[j], 1);
+    }
+    touch(d_stage, sizeof(float) * (((size_t)(K - 1) * row_pitch + (n - 1)) * stride + frames));
+    touch(d_stage_flags, (size_t)(K - 1) * row_pitch + n);
+    return 0;
+}
 int launch_out_flags(hipStream_t, const uint8_t* flags, size_t flags_blk_stride, const int* d_bufs, int n_bufs, int mode, int n_out_ch, int K,
                      uint8_t* d_out) {
     g_launches[7]++;

@@ -32,6 +32,15 @@ int push_cmd(fwgpu_ctx* c, int64_t node, int want_kind, Cmd m, bool counts_as_ms
         if (n->pending_msgs >= 128) return fail(c, FWGPU_ERR_QUEUE_FULL, "sampler message ring full");
     }
     m.state = (int)(node & 0xffffffff);
+    if (!n->activated) {
+        // no built plan holds this node yet (add_node, then a message, then fwgpu_update — the reference's ring simply waits
+        // for the processor's first block): the message is released when the plan that activates it is published, so that a
+        // process call running on the OLD plan neither consumes it nor applies it to a stale slot.  Control side, like update.
+        if (c->early_msgs.size() >= fwgpu_ctx::RING_CAP) return fail(c, FWGPU_ERR_QUEUE_FULL, "too many messages for nodes that are not activated yet");
+        c->early_msgs.push_back(m);
+        if (counts_as_msg) n->pending_msgs++;
+        return 0;
+    }
     if (!c->ring.push(m)) return fail(c, FWGPU_ERR_QUEUE_FULL, "context message ring full (no process call is draining it)");
     if (counts_as_msg) n->pending_msgs++;
     return 0;
@@ -60,7 +69,7 @@ void collect_returns(fwgpu_ctx* c) {
         }
         c->returns.pop();
         if (it.sample >= 0 && (size_t)it.sample < c->sample_refs.size() && c->sample_refs[it.sample] > 0) c->sample_refs[it.sample]--;
-        c->ret_ready.push_back(it);
+        if (it.node != RET_SILENT) c->ret_ready.push_back(it);
     }
 }
 
@@ -109,6 +118,7 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
         return nullptr;
     }
     fwgpu_ctx* c = new fwgpu_ctx(num_graph_inputs, num_graph_outputs);
+    c->graph.limbo = &c->limbo_slots;  // a removed node's slot is reused only once no running plan holds the node
     c->device = device;
     c->sample_rate = sample_rate;
     c->mbf = max_block_frames;
@@ -131,7 +141,7 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
         c->cmds.reserve(fwgpu_ctx::CMD_CAP);
         c->cmds_scratch.reserve(fwgpu_ctx::CMD_CAP);
         c->ret_ready.reserve(4096);
-        ok = ok && c->d_cmds.ensure(fwgpu_ctx::CMD_CAP * sizeof(Cmd)) == hipSuccess;
+        ok = ok && c->d_cmds.ensure_n("d_cmds", fwgpu_ctx::CMD_CAP * sizeof(Cmd)) == hipSuccess;
         ok = ok && hipHostMalloc((void**)&c->h_cmds, fwgpu_ctx::CMD_CAP * sizeof(Cmd), hipHostMallocDefault) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->cmds_copied, hipEventDisableTiming) == hipSuccess;
         for (uint32_t i = 0; ok && i < fwgpu_ctx::RET_EVENTS; ++i)
@@ -152,7 +162,7 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
             return nullptr;
         }
     }
-    if (upload_sample_table(c) != 0 || c->d_mask.ensure(64) != hipSuccess) {
+    if (upload_sample_table(c) != 0 || c->d_mask.ensure_n("d_mask", 64) != hipSuccess) {
         g_create_error = c->err_ctl;
         fwgpu_ctx_destroy(c);
         return nullptr;
@@ -163,11 +173,8 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
         hipHostMalloc((void**)&c->h_rt_out, RT_IO_BYTES, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->d_rt_in, c->h_rt_in, 0) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->d_rt_out, c->h_rt_out, 0) != hipSuccess) {
-        if (c->h_host_stage) (void)hipHostFree(c->h_host_stage);
-    if (c->h_host_flags) (void)hipHostFree(c->h_host_flags);
-    if (c->h_rt_in) (void)hipHostFree(c->h_rt_in);
+        if (c->h_rt_in) (void)hipHostFree(c->h_rt_in);
         if (c->h_rt_out) (void)hipHostFree(c->h_rt_out);
-    if (c->h_rt_flag) (void)hipHostFree(c->h_rt_flag);
         c->h_rt_in = c->h_rt_out = nullptr;
         (void)hipGetLastError();
     }
@@ -202,7 +209,7 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
     if (const char* e = getenv("FWGPU_HOST_PROF")) c->host_prof = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_GRAPH")) c->rt_use_graph = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_ONE_LAUNCH")) c->rt_one_launch = atoi(e) != 0;
-    if (c->d_rt_sync.ensure(256) != hipSuccess || hipMemset(c->d_rt_sync.p, 0, 256) != hipSuccess) c->d_rt_sync.release();
+    if (c->d_rt_sync.ensure_n("d_rt_sync", 256) != hipSuccess || hipMemset(c->d_rt_sync.p, 0, 256) != hipSuccess) c->d_rt_sync.release();
     return c;
 }
 
@@ -222,10 +229,23 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     for (SampleRec& s : c->samples)
         if (s.alive && s.owned && s.d_data) (void)hipFree(s.d_data);
-    DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_nodes, &c->d_in_buf, &c->d_out_buf, &c->d_level_nodes, &c->d_pool,
-                      &c->d_flags, &c->d_gin_bufs, &c->d_gout_bufs, &c->d_blks2, &c->d_refs2, &c->d_gsets2, &c->d_ramps2, &c->d_rt_sync, &c->d_hlevel_nodes, &c->d_progs, &c->d_voices, &c->d_leaves, &c->d_blks, &c->d_refs, &c->d_gsets, &c->d_cache, &c->d_ramps,
-                      &c->d_bus, &c->d_bus_flags, &c->d_chain_start, &c->d_chain_dummy, &c->d_chain_stats, &c->d_groups, &c->d_up_nodes, &c->d_up_in, &c->d_up_out, &c->d_up_level_nodes,
-                      &c->d_root_bufs, &c->d_tail_nodes, &c->d_tail_in, &c->d_tail_out, &c->d_tail_idx, &c->d_tail_frozen, &c->d_frozen, &c->d_frozen_ph, &c->d_fir_rows, &c->d_fir_tiles, &c->d_fir_partials, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
+    // plan images: the active one (this ctx's base), a published one nobody adopted, the spare, whatever the ring still holds
+    if (PlanImage* p = c->pending.exchange(nullptr)) {
+        p->release_device();
+        delete p;
+    }
+    if (c->spare) {
+        c->spare->release_device();
+        delete c->spare;
+    }
+    for (uint32_t h = c->retired_head.load(); h != c->retired_tail.load(); ++h) {
+        PlanImage* p = c->retired[h % fwgpu_ctx::RETIRE_CAP];
+        p->release_device();
+        delete p;
+    }
+    c->release_device();
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+    DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_rt_sync, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask, &c->d_trace, &c->d_rs_table};
     for (DevBuf* b : bufs) b->release();
     for (TimerCat& t : c->timers)
@@ -233,11 +253,9 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
             (void)hipEventDestroy(p.first);
             (void)hipEventDestroy(p.second);
         }
-    if (c->rt_graph.exec) (void)hipGraphExecDestroy(c->rt_graph.exec);
-    if (c->h_host_stage) (void)hipHostFree(c->h_host_stage);
-    if (c->h_host_flags) (void)hipHostFree(c->h_host_flags);
     if (c->h_rt_in) (void)hipHostFree(c->h_rt_in);
     if (c->h_rt_out) (void)hipHostFree(c->h_rt_out);
+    if (c->h_rt_flag) (void)hipHostFree(c->h_rt_flag);
     if (c->h_cmds) (void)hipHostFree(c->h_cmds);
     if (c->cmds_copied) (void)hipEventDestroy(c->cmds_copied);
     for (hipEvent_t e : c->ret_events)
@@ -293,7 +311,7 @@ int fwgpu_remove_node(fwgpu_ctx* c, int64_t node) {
     if (HostNode* hn = c->graph.get(node)) fr.kind = hn->kind;
     int rc = c->graph.remove_node(node);
     if (rc) return fail(c, rc, "remove_node: unknown node or graph in/out node");
-    if (fr.any) c->ext_free[((size_t)fr.len + 63) / 64 * 64].push_back(fr.off);
+    if (fr.any) c->limbo.push_back({c->build_gen + 1, 1, fr.off, (uint32_t)(((size_t)fr.len + 63) / 64 * 64)});
     if (fr.ir >= 0) {  // the f32 copy of an impulse response goes with its last FIR user
         bool used = false;
         for (const HostNode& n : c->graph.nodes)
@@ -301,7 +319,7 @@ int fwgpu_remove_node(fwgpu_ctx* c, int64_t node) {
         if (!used)
             for (auto it = c->ir_cache.begin(); it != c->ir_cache.end();) {
                 if (it->first.first == fr.ir) {
-                    c->ext_free[((size_t)c->ir_len[it->first] + 63) / 64 * 64].push_back(it->second);
+                    c->limbo.push_back({c->build_gen + 1, 1, it->second, (uint32_t)(((size_t)c->ir_len[it->first] + 63) / 64 * 64)});
                     c->ir_len.erase(it->first);
                     it = c->ir_cache.erase(it);
                 } else {
@@ -309,21 +327,26 @@ int fwgpu_remove_node(fwgpu_ctx* c, int64_t node) {
                 }
             }
     }
-    // messages still queued for a later block go with the node (its slot — the message key — may be reused by the next
-    // fwgpu_add_node).  Edit calls do not overlap process calls (fwgpu.h): this thread is the ring's consumer for now.
-    const int slot = (int)(node & 0xffffffff);
-    drain_ring(c);
-    size_t w = 0;
-    for (const Cmd& m : c->cmds) {
-        if (m.state == slot) {
-            if (m.type == CMD_SMP_SET_SAMPLE && m.i0 >= 0 && (size_t)m.i0 < c->sample_refs.size() && c->sample_refs[m.i0] > 0)
-                c->sample_refs[m.i0]--;  // never reached its sampler: handed straight back
-            continue;
+    // The node is gone from the GRAPH; the running plan may hold it until the next plan is adopted.  What it still owns —
+    // its slot (the message key), its ext slice, messages queued for it, a sampler's sample — is released AT that adoption
+    // (adopt_image) or after it (release_limbo), never from this thread while a process call may be using it.
+    const uint32_t slot = (uint32_t)(node & 0xffffffff);
+    const uint64_t tag = c->build_gen + 1;  // the first image built without the node
+    for (uint32_t sl : c->limbo_slots) c->limbo.push_back({tag, 0, sl, 0});
+    c->limbo_slots.clear();
+    if (fr.activated) c->pending_removed.push_back(slot);
+    {  // (messages that never left the control side)
+        size_t w = 0;
+        for (const Cmd& m : c->early_msgs) {
+            if (m.state == (int)slot) {
+                if (m.type == CMD_SMP_SET_SAMPLE && m.i0 >= 0 && (size_t)m.i0 < c->sample_refs.size() && c->sample_refs[m.i0] > 0) c->sample_refs[m.i0]--;
+                continue;
+            }
+            c->early_msgs[w++] = m;
         }
-        c->cmds[w++] = m;
+        c->early_msgs.resize(w);
     }
-    c->cmds.resize(w);
-    if (fr.kind == K_SAMPLER && fr.activated) c->dropped_samplers.push_back((uint32_t)slot);  // Drop: sampler.rs:563-571
+    if (fr.kind == K_SAMPLER && fr.activated) c->dropped_samplers_ctl.push_back(slot);  // Drop: sampler.rs:563-571
     return 0;
 }
 int64_t fwgpu_connect(fwgpu_ctx* c, int64_t src, uint32_t sp, int64_t dst, uint32_t dp, int check) {
@@ -351,14 +374,14 @@ int fwgpu_host_node_set_process(fwgpu_ctx* c, int64_t node, fwgpu_host_process_f
 }
 int fwgpu_plan_host_nodes(fwgpu_ctx* c, uint64_t* callbacks_run) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
-    if (callbacks_run) *callbacks_run = c->host_callbacks;
-    return c->have_plan ? c->n_host_nodes : -1;
+    if (callbacks_run) *callbacks_run = c->host_callbacks;  // (of the active image: meaningful once the audio side is quiet)
+    return c->info.have_plan ? c->info.n_host_nodes : -1;
 }
 
 int fwgpu_update(fwgpu_ctx* c) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     use_device(c);
-    if (!c->graph.needs_compile && c->have_plan) return 0;
+    if (!c->graph.needs_compile && c->info.have_plan) return 0;
     Plan plan;
     std::string err;
     int rc = c->graph.build_plan(plan, err);
@@ -422,29 +445,31 @@ int fwgpu_schedule_upload(fwgpu_ctx* c, const fwgpu_sched_node* sn, uint32_t n_n
     return install_plan(c, plan);
 }
 
+// The introspection calls describe the LATEST BUILT plan (adopted already or waiting for the next process call): the control
+// side's own mirror, so they never look at tables the audio side may be swapping.
 int fwgpu_plan_kind(fwgpu_ctx* c) {
-    if (!c || !c->have_plan) return -1;
+    if (!c || !c->info.have_plan) return -1;
     if (c->force_generic) return 0;
-    return c->fused ? (c->fused_fx ? 2 : 1) : (c->hybrid ? 3 : 0);
+    return c->info.kind;
 }
 int fwgpu_plan_fused_voices(fwgpu_ctx* c) {
-    if (!c || !c->have_plan) return -1;
-    return (c->force_generic || !(c->fused || c->hybrid)) ? 0 : c->n_fused_real;
+    if (!c || !c->info.have_plan) return -1;
+    return c->force_generic ? 0 : c->info.fused_voices;
 }
-int fwgpu_plan_num_levels(fwgpu_ctx* c) { return c && c->have_plan ? c->plan.num_levels : -1; }
+int fwgpu_plan_num_levels(fwgpu_ctx* c) { return c && c->info.have_plan ? c->info.plan.num_levels : -1; }
 int fwgpu_plan_node_level(fwgpu_ctx* c, int64_t node) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
-    if (!c->have_plan || !c->graph.get(node)) return -1;
+    if (!c->info.have_plan || !c->graph.get(node)) return -1;
     uint32_t slot = (uint32_t)(node & 0xffffffff);
-    for (const PlanNode& p : c->plan.nodes)
+    for (const PlanNode& p : c->info.plan.nodes)
         if (p.slot == slot) return p.level;
     return -1;
 }
 int fwgpu_plan_node_inputs_clear(fwgpu_ctx* c, int64_t node, int* should_clear, int cap) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
-    if (!c->have_plan || !c->graph.get(node)) return -1;
+    if (!c->info.have_plan || !c->graph.get(node)) return -1;
     uint32_t slot = (uint32_t)(node & 0xffffffff);
-    for (const PlanNode& p : c->plan.nodes)
+    for (const PlanNode& p : c->info.plan.nodes)
         if (p.slot == slot) {
             for (int i = 0; i < p.n_in && i < cap; ++i) should_clear[i] = p.in_buf[i] == 0 ? 1 : 0;
             return p.n_in;
@@ -454,6 +479,13 @@ int fwgpu_plan_node_inputs_clear(fwgpu_ctx* c, int64_t node, int* should_clear, 
 int fwgpu_set_force_generic(fwgpu_ctx* c, int on) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     c->force_generic = on != 0;
+    return 0;
+}
+int fwgpu_plan_handover_stats(fwgpu_ctx* c, uint64_t* adoptions, uint64_t* audio_adoptions, uint64_t* max_adopt_ns) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    if (adoptions) *adoptions = c->adoptions;
+    if (audio_adoptions) *audio_adoptions = c->audio_adoptions;
+    if (max_adopt_ns) *max_adopt_ns = c->adopt_ns_max;
     return 0;
 }
 int fwgpu_plan_chain_stats(fwgpu_ctx* c, uint64_t* steady_workgroups, uint64_t* general_workgroups) {
@@ -508,7 +540,7 @@ static int sample_add(fwgpu_ctx* c, int format, uint32_t channels, uint64_t fram
     rebuild_sample_table(c);  // copied to the device by the next process / update call; room for it is made here
     if (c->h_sample_tab.size() * sizeof(SampleDesc) > c->d_samples.cap) {
         HIPC(c, hipStreamSynchronize(c->stream));
-        HIPC(c, c->d_samples.ensure(c->h_sample_tab.size() * 2 * sizeof(SampleDesc)));
+        HIPC(c, c->d_samples.ensure_n("d_samples", c->h_sample_tab.size() * 2 * sizeof(SampleDesc)));
     }
     return (int)c->samples.size() - 1;
 }
@@ -775,14 +807,14 @@ static int process_interleaved_impl(fwgpu_ctx* c, const float* input, float* out
         size_t in_bytes = (size_t)frames * n_in_ch * sizeof(float);
         if (in_bytes > c->d_in_stage.cap) {  // (first call of this size only)
             HIPC(c, hipStreamSynchronize(c->stream));
-            HIPC(c, c->d_in_stage.ensure(in_bytes));
+            HIPC(c, c->d_in_stage.ensure_n("d_in_stage", in_bytes));
         }
         HIPC(c, hipMemcpyAsync(c->d_in_stage.p, input, in_bytes, hipMemcpyHostToDevice, c->stream));
         d_in = c->d_in_stage.as<float>();
     }
     if (out_bytes > c->d_out_stage.cap) {
         HIPC(c, hipStreamSynchronize(c->stream));
-        HIPC(c, c->d_out_stage.ensure(out_bytes));
+        HIPC(c, c->d_out_stage.ensure_n("d_out_stage", out_bytes));
     }
     int rc = run_blocks(c, frames, d_in, (int)n_in_ch, c->d_out_stage.as<float>(), (int)n_out_ch);
     if (rc) return rc;
@@ -803,6 +835,7 @@ int fwgpu_process_interleaved(fwgpu_ctx* c, const float* input, float* output, u
     if (out_bytes && !output) return fail(c, FWGPU_ERR_INVALID, "output is null");
     // ProcInfo::stream_time_secs / stream_status of this call (core/node.rs:111-118): no built-in node reads them; a
     // custom node mixed in through fwgpu_node_process gets them from fwgpu_proc_info
+    AudioGate gate(c);  // (picks up a plan the control thread published since the last call: processor.rs:167-206)
     c->proc_stream_time = stream_time_secs;
     c->proc_stream_status = stream_status;
     if (stream_status & 2u) c->n_underflows++;
@@ -910,6 +943,7 @@ int fwgpu_process_blocks_device_flags(fwgpu_ctx* c, uint32_t num_blocks, float* 
     NEED_CTX(c, FWGPU_ERR_INVALID);
     AudioCallScope audio;
     use_device(c);
+    AudioGate gate(c);
     if (!c->have_plan) return fail(c, FWGPU_ERR_INVALID, "no schedule: call fwgpu_update first");
     if (num_blocks == 0) return 0;
     if (n_out_ch > 64 || (n_out_ch && !d_output)) return fail(c, FWGPU_ERR_INVALID, "bad output (null, or more than 64 channels)");
@@ -960,9 +994,15 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     NEED_CTX(c, FWGPU_ERR_INVALID);
     AudioCallScope audio;
     use_device(c);
-    HostNode* hn = c->graph.get(node);
-    if (!hn || !hn->activated) return fail(c, FWGPU_ERR_INVALID, "node is not activated (call fwgpu_update)");
-    if (hn->n_in != n_in || hn->n_out != n_out) return fail(c, FWGPU_ERR_INVALID, "port counts differ from add_node");
+    AudioGate gate(c);
+    // the node as the ACTIVE plan knows it (the graph belongs to the control thread, which may be editing it right now:
+    // Firewheel activates and deactivates nodes while the audio thread is inside process(), graph.rs:586-612)
+    const uint32_t nslot = (uint32_t)(node & 0xffffffff);
+    const int pidx = (c->have_plan && nslot < c->slot_index.size()) ? c->slot_index[nslot] : -1;
+    if (pidx < 0 || nslot >= c->slot_ids.size() || c->slot_ids[nslot] != node)
+        return fail(c, FWGPU_ERR_INVALID, "node is not activated (call fwgpu_update)");
+    const PlanNode* hn = &c->plan.nodes[pidx];
+    if ((uint32_t)hn->n_in != n_in || (uint32_t)hn->n_out != n_out) return fail(c, FWGPU_ERR_INVALID, "port counts differ from add_node");
     if (frames > c->mbf) return fail(c, FWGPU_ERR_INVALID, "frames > max_block_frames");
     if (hn->kind == K_FIR) return fail(c, FWGPU_ERR_INVALID, "FIR banks run at graph level (fwgpu_process_interleaved), not per node");
     if (hn->kind == K_HOST) return fail(c, FWGPU_ERR_INVALID, "a host node's processor lives in the caller: call it there");
@@ -979,8 +1019,8 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     const size_t stride = (size_t)c->stride;
     const int nb = 1 + (int)n_in + (int)n_out;
     HIPC(c, hipStreamSynchronize(c->stream));
-    HIPC(c, c->d_scratch_pool.ensure((size_t)nb * stride * sizeof(float)));
-    HIPC(c, c->d_scratch_flags.ensure((size_t)nb));
+    HIPC(c, c->d_scratch_pool.ensure_n("d_scratch_pool", (size_t)nb * stride * sizeof(float)));
+    HIPC(c, c->d_scratch_flags.ensure_n("d_scratch_flags", (size_t)nb));
     HIPC(c, hipMemsetAsync(c->d_scratch_pool.p, 0, stride * sizeof(float), c->stream));
     uint8_t fl[1 + 64 + 64] = {0};  // (at most 64 ports per side)
     fl[0] = 1;
@@ -1010,7 +1050,7 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     int* outs = ins + n_in + 1;
     for (uint32_t i = 0; i < n_in; ++i) ins[i] = 1 + (int)i;
     for (uint32_t i = 0; i < n_out; ++i) outs[i] = 1 + (int)n_in + (int)i;
-    HIPC(c, c->d_scratch_tab.ensure(tab_ints * sizeof(int)));
+    HIPC(c, c->d_scratch_tab.ensure_n("d_scratch_tab", tab_ints * sizeof(int)));
     HIPC(c, hipMemcpyAsync(c->d_scratch_tab.p, tab, tab_ints * sizeof(int), hipMemcpyHostToDevice, c->stream));
     int rc = upload_sample_table(c);
     if (rc) return rc;

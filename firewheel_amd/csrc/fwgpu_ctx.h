@@ -33,6 +33,10 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) {
+        o.p = nullptr;
+        o.cap = 0;
+    }
     DevBuf& operator=(DevBuf&& o) noexcept {
         if (this != &o) {
             release();
@@ -44,6 +48,23 @@ struct DevBuf {
         return *this;
     }
     ~DevBuf() { release(); }  // whatever fwgpu_ctx_destroy's list misses still goes with the ctx
+    // FWGPU_POISON=1 (tests): fresh device memory is NOT zero in general (a long-lived process hands out what earlier contexts
+    // left behind) — fill new allocations with a byte pattern so that a read of something nobody wrote shows up at once.
+    // FWGPU_POISON_ONLY=<name>: only the buffers of that name (bisecting which table is read before it is written).
+    hipError_t ensure_n(const char* name, size_t bytes) {
+        const void* before = p;
+        const size_t cap0 = cap;
+        hipError_t e = ensure(bytes);
+        if (e == hipSuccess && (p != before || cap != cap0)) {
+            static const bool poison = getenv("FWGPU_POISON") && atoi(getenv("FWGPU_POISON")) != 0;
+            static const char* only = getenv("FWGPU_POISON_ONLY");
+            if (poison && (!only || !only[0] || !strcmp(only, name))) {
+                e = hipMemset(p, 0xCB, cap);
+                if (e == hipSuccess) e = hipDeviceSynchronize();  // (the fill is in place before any stream writes real data)
+            }
+        }
+        return e;
+    }
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap && p) return hipSuccess;
         const bool regrow = p != nullptr;  // a buffer that grows once tends to grow again (graph edits add a few nodes
@@ -105,42 +126,27 @@ struct TimerCat {
 
 using namespace fwgpu;  // (internal header: only libfwgpu's own host translation units include it)
 
-struct fwgpu_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    uint32_t sample_rate = 48000;
-    uint32_t mbf = 256;
-    int stride = 256;
-    uint32_t n_gin = 0, n_gout = 2;
-    // fwgpu_last_error(): fixed buffers, one for the process calls (audio thread) and one for everything else, so that a
-    // failing call never touches the host allocator and the two sides never write the same bytes
-    char err_ctl[256] = {0};
-    char err_audio[256] = {0};
-    std::atomic<int> err_last{0};  // 0 = err_ctl, 1 = err_audio was written last
+namespace fwgpu {
 
-    HostGraph graph;
+// ---------------------------------------------------------------------------------------------------------------------
+// PlanImage: everything a launch plan IS on the device and on the host — the tables install_plan builds and the process calls
+// read.  A ctx holds the ACTIVE image as its base class (so `c->d_nodes` is the active plan's node table); fwgpu_update /
+// fwgpu_schedule_upload build the NEXT image off to the side on the control thread, while process calls keep running on the
+// active one, and publish it; it is adopted — a swap of this struct's members, no allocation, no wait — at the start of the
+// next process call (graph/processor.rs:167-206: "NewSchedule" applied at block start), the old image goes back to the control
+// side through a ring and is reused as the next build target (graph/context.rs:93-137).
+struct PlanImage {
     Plan plan;
     bool have_plan = false;
-    bool force_generic = false;
-    uint32_t kmax = 64;      // blocks per launch the installed plan's buffers are sized for
-    uint32_t kmax_req = 64;  // fwgpu_set_max_batch: takes effect when the next plan is installed
-
-    // device state
-    DevBuf d_states;
-    size_t states_cap = 0;
-    DevBuf d_ext;  // per-node extended state (floats): biquad coefficients + history, delay rings
-    size_t ext_cap = 0, ext_used = 0;
-    std::vector<SampleRec> samples;
-    DevBuf d_samples;
-    std::vector<SampleDesc> h_sample_tab;  // host copy of d_samples, rebuilt by the calls that change it (control side)
-    bool samples_dirty = true;
+    uint64_t gen = 0;        // images are numbered in build order
+    uint32_t kmax = 64;      // blocks per launch this image's buffers are sized for
 
     // generic plan
     DevBuf d_nodes, d_in_buf, d_out_buf, d_level_nodes, d_pool, d_flags, d_gin_bufs, d_gout_bufs;
     std::vector<int> level_off, level_cnt;
     std::vector<int> level_kinds;  // bit s: the level holds node kinds of kernel set s (host_kind_set)
     int n_gout_bufs = 0, n_gin_bufs = 0;
+    std::vector<int> slot_index;   // node slot -> index into plan.nodes, -1 = not in this plan (B1: fwgpu_node_process)
 
     // fused plan
     bool fused = false;
@@ -150,19 +156,7 @@ struct fwgpu_ctx {
     int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
     int n_groups = 0;  // k_chain workgroups (groups of consecutive leaves)
     DevBuf d_groups;
-    uint32_t epoch = 1;  // invalidates every VoiceCache when bumped (plan install, sample-table change)
-    // Control kernel one batch AHEAD (FWGPU_CTL_AHEAD, voice-bank plan without a master chain, batches of more than one block):
-    // k_voice_control of batch b+1 runs on its own high-priority stream under the render kernels of batch b.  What it writes and
-    // the render kernels read exists twice (parity = batch number & 1); what orders the two streams is one event per parity and
-    // direction.  The kernels do not know: they get pointers.
-    bool ctl_ahead = false;          // wanted (env)
-    bool ctl_ahead_on = false;       // the installed plan qualifies
-    hipStream_t ctl_stream = nullptr;
-    hipEvent_t ev_ctl[2] = {nullptr, nullptr}, ev_render[2] = {nullptr, nullptr}, ev_join = nullptr;
-    uint64_t ahead_seq = 0;          // batches launched in ahead mode since the streams were last joined
-    bool streams_split = false;      // ctl_stream may hold work the main stream has not waited for
-    bool ahead_this_call = false;    // the process call in progress runs in ahead mode
-    bool cmds_on_ctl = false;        // ... and its message upload goes to the control stream
+    bool ctl_ahead_on = false;       // control-ahead mode: the installed plan qualifies
     DevBuf d_blks2, d_refs2, d_gsets2, d_ramps2;
     bool fused_rs = false;    // the plan has resampler-sourced voices
     bool fused_prog = false;  // the voice-bank plan carries stage programs (k_leaf_sum<true>)
@@ -184,61 +178,8 @@ struct fwgpu_ctx {
         uint32_t T;
     };
     std::vector<FirGroup> fir_groups;
-    std::map<std::pair<int, int>, uint32_t> ir_cache;  // (sample id, channel) -> ext offset of h[T] as f32
-    std::map<std::pair<int, int>, uint32_t> ir_len;    // ... and its length in floats (freed with the last FIR user)
-    std::map<size_t, std::vector<uint32_t>> ext_free;  // ext slices of removed nodes, by 64-rounded size (floats)
     DevBuf d_fir_rows, d_fir_tiles, d_fir_partials;
 
-    // messages.  Setters push into `ring` from any thread; the audio thread drains it at the start of a process call
-    // into `cmds` (sorted by (node, block), arrival order inside a block).  Every buffer on this path has its final
-    // size from fwgpu_ctx_create on: a process call never allocates for messages.
-    static constexpr uint32_t RING_CAP = 1u << 15;  // messages in flight between two process calls
-    static constexpr size_t CMD_CAP = 1u << 16;     // messages waiting for their block (drained, not yet applied)
-    MsgRing ring;
-    std::atomic<uint64_t> drain_epoch{1};  // bumped by every drain: the producers' view of "the ring was emptied"
-    std::vector<Cmd> cmds, cmds_scratch;   // reserve(CMD_CAP) once; never grown
-    DevBuf d_cmds;
-    int n_cmds_dev = 0;
-    Cmd* h_cmds = nullptr;  // pinned staging for the async upload [CMD_CAP]
-    hipEvent_t cmds_copied = nullptr;
-    // ProcessorToNodeMsg::ReturnSample (sampler.rs:339-343): which sample every sampler holds, as the messages retired
-    // so far leave it (audio thread), and the swapped-out ones on their way back to the control side
-    std::vector<int> cur_sample;     // [node slot] -> sample id or -1; sized by install_plan
-    std::vector<int64_t> slot_ids;   // [node slot] -> node id of the activated node
-    RetRing returns;
-    static constexpr uint32_t RET_EVENTS = 64;
-    hipEvent_t ret_events[RET_EVENTS] = {nullptr};
-    std::atomic<uint32_t> ret_event_ticket[RET_EVENTS] = {};  // ticket + 1 the slot's event was last recorded for (0 = never)
-    uint32_t ret_ticket = 0;         // audio thread: process calls that returned a sample so far
-    std::atomic<uint32_t> ret_done_ticket{0};  // tickets below this belong to calls the audio thread has SEEN complete (sync / flag)
-    bool ret_this_call = false;
-    // control side of the same: reference counts per sample id = SetSample messages sent - samples handed back
-    std::vector<int64_t> sample_refs;
-    std::vector<RetItem> ret_ready;  // completed returns not yet handed to fwgpu_poll_returned_samples
-    std::vector<uint32_t> dropped_samplers;  // removed sampler nodes whose processor "drops" at the next schedule swap
-
-    // staging + B1 scratch
-    DevBuf d_in_stage, d_out_stage, d_scratch_pool, d_scratch_flags, d_scratch_tab, d_mask;
-    DevBuf d_trace;  // FW_CHAIN_TRACE builds only
-
-    // realtime edge (cpal/lib.rs:378-449 — one callback = a few hundred frames): pinned, device-mapped I/O blocks the
-    // kernels read / write directly (no copy-engine hop), and the steady fused launch sequence kept as a hipGraph
-    float *h_rt_in = nullptr, *h_rt_out = nullptr, *d_rt_in = nullptr, *d_rt_out = nullptr;
-    struct RtGraph {
-        hipGraphExec_t exec = nullptr;
-        uint32_t epoch = 0, K = 0;
-        int n_out_ch = 0;
-        const float* d_out = nullptr;
-    } rt_graph;
-    // completion flag of realtime-sized calls: a word in pinned, device-mapped host memory the last kernel of the call sets to
-    // the call's sequence number; the audio thread polls it instead of paying a blocking stream sync's wake-up
-    unsigned long long *h_rt_flag = nullptr, *d_rt_flag = nullptr;
-    unsigned long long rt_seq = 0;         // sequence number of the last realtime call
-    unsigned long long rt_signal_seq = 0;  // != 0 while run_blocks should arrange for the flag to be raised
-    bool rt_signalled = false;
-    bool rt_last_batch = false;  // the fused batch being launched ends the call
-    bool rt_one_launch = true;  // one-block calls on the voice-bank plan: control + leaf + root in ONE kernel (FWGPU_RT_ONE_LAUNCH=0: off)
-    DevBuf d_rt_sync;           // its workgroup counter
     // hybrid plan (kind 3): voice-bank groups inside a graph the level executor runs — the level lists without the nodes
     // the fused kernels render
     int n_fused_real = 0;  // voices (not null slots) the fused kernels render under the installed plan
@@ -246,16 +187,8 @@ struct fwgpu_ctx {
     bool hybrid_fx = false;  // ... and the banks hold biquad / delay voices: k_chain renders them
     DevBuf d_hlevel_nodes;
     std::vector<int> hlevel_off, hlevel_cnt, hlevel_kinds;
-    bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2
-    DevBuf d_rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS]
 
-    // host nodes (K_HOST): the caller's own AudioNodeProcessor::process behind a C callback.  host_procs is the control
-    // side's registry (by node slot); install_plan copies what the plan needs into host_levels, which the audio side reads.
-    struct HostProc {
-        fwgpu_host_process_fn fn = nullptr;
-        void* user = nullptr;
-    };
-    std::vector<HostProc> host_procs;
+    // host nodes (K_HOST): what the audio side needs to call them, per plan level, and their pinned staging area
     struct HostCall {
         int node_idx = 0;  // index into the plan's node table (its in / out buffer ids sit in d_in_buf / d_out_buf)
         int n_in = 0, n_out = 0, in_off = 0, out_off = 0;
@@ -273,6 +206,179 @@ struct fwgpu_ctx {
     std::vector<const float*> host_in_ptrs;  // scratch for the callback's pointer tables (sized at install: no allocation per call)
     std::vector<float*> host_out_ptrs;
 
+    // the steady realtime launch sequence of THIS plan kept as a hipGraph (FWGPU_RT_GRAPH=1)
+    struct RtGraph {
+        hipGraphExec_t exec = nullptr;
+        uint32_t epoch = 0, K = 0;
+        int n_out_ch = 0;
+        const float* d_out = nullptr;
+    } rt_graph;
+
+    // ---- what adopting this image does to the state that OUTLIVES plans (node states, ext pool, sampler bookkeeping): built on
+    // the control thread, applied at adoption — asynchronously, on the ctx stream — so that the control thread never writes
+    // into buffers a running plan reads
+    DevBuf grow_states;            // a larger node-state array (old contents copied in at adoption), or empty
+    size_t grow_states_cap = 0;
+    DevBuf grow_ext;               // a larger ext pool
+    size_t grow_ext_cap = 0;
+    DevBuf d_state_inits;          // StateInitHost records of the nodes this image activates
+    int n_state_inits = 0;
+    DevBuf d_ext_jobs;             // AdoptExtJobHost records: recycled slices zeroed, biquad coefficients set (k_adopt_init)
+    int n_ext_jobs = 0;
+    struct IrConv {                // impulse responses to convert to f32 into the ext pool
+        int sample, ch;
+        uint32_t off, T;
+    };
+    std::vector<IrConv> ir_convs;
+    std::vector<std::pair<uint32_t, int64_t>> activated;  // (slot, node id) of the nodes this image activates
+    std::vector<uint32_t> dropped_samplers;                // removed sampler nodes: their processor "drops" at this swap
+    std::vector<uint32_t> removed_slots;                   // removed nodes: messages still queued for them go with them
+    size_t slots_cap = 0;                                  // cur_sample / slot_ids must hold this many slots
+    std::vector<int> grow_cur_sample;                      // pre-sized replacements (empty when the current ones are large enough)
+    std::vector<int64_t> grow_slot_ids;
+    hipEvent_t retired_ev = nullptr;  // recorded on the ctx stream when this image stops being the active one
+
+    PlanImage() = default;
+    PlanImage(const PlanImage&) = delete;
+    PlanImage& operator=(const PlanImage&) = delete;
+    PlanImage(PlanImage&&) = default;
+    PlanImage& operator=(PlanImage&&) = default;
+    void release_device();  // frees what the image owns (control side / ctx destruction)
+};
+
+}  // namespace fwgpu
+
+struct fwgpu_ctx : fwgpu::PlanImage {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t sample_rate = 48000;
+    uint32_t mbf = 256;
+    int stride = 256;
+    uint32_t n_gin = 0, n_gout = 2;
+    // fwgpu_last_error(): fixed buffers, one for the process calls (audio thread) and one for everything else, so that a
+    // failing call never touches the host allocator and the two sides never write the same bytes
+    char err_ctl[256] = {0};
+    char err_audio[256] = {0};
+    std::atomic<int> err_last{0};  // 0 = err_ctl, 1 = err_audio was written last
+
+    HostGraph graph;
+    bool force_generic = false;
+    uint32_t kmax_req = 64;  // fwgpu_set_max_batch: takes effect when the next plan is installed
+
+    // ---- plan hand-over (control -> audio), graph/processor.rs:167-206 + graph/context.rs:93-137
+    // `gate`: 0 = nobody inside, 1 = a process call is running, 2 = the control thread is adopting an image (only ever for the
+    // microseconds of the member swap, and only when it found the gate at 0).  A process call takes the gate for its whole
+    // duration; the control thread BUILDS outside the gate and only tries it to adopt when the audio side is idle.
+    std::atomic<int> gate{0};
+    std::atomic<fwgpu::PlanImage*> pending{nullptr};  // built and published, waiting for the next process call
+    fwgpu::PlanImage* spare = nullptr;                // control side: a retired image, the next build target (its buffers are reused)
+    static constexpr uint32_t RETIRE_CAP = 8;
+    fwgpu::PlanImage* retired[RETIRE_CAP] = {nullptr};   // audio -> control SPSC ring of images that stopped being active
+    std::atomic<uint32_t> retired_head{0}, retired_tail{0};
+    std::atomic<uint64_t> adopted_gen{0};             // generation of the active image (written by whoever adopts)
+    uint64_t build_gen = 0;                           // control side: generation of the last image built
+    hipStream_t up_stream = nullptr;                  // control side: uploads of the image being built
+    // control-side mirror of what the introspection calls report: the LATEST BUILT plan (adopted or still pending)
+    struct PlanInfo {
+        bool have_plan = false;
+        int kind = 0, fused_voices = 0, n_host_nodes = 0;
+        Plan plan;
+    } info;
+    // control side: what becomes reusable only once the image that stops using it has been adopted — node slots, ext slices
+    // and impulse-response copies of removed nodes (tag = generation of the first image built without them)
+    struct Limbo {
+        uint64_t gen;
+        int what;  // 0 = node slot, 1 = ext slice (off, rounded len)
+        uint32_t a, b;
+    };
+    std::vector<Limbo> limbo;
+    std::vector<uint32_t> limbo_slots;     // HostGraph::remove_node parks freed slots here (graph.limbo points at it)
+    std::vector<uint32_t> pending_removed; // slots removed since the last build (the next image carries them)
+    size_t ctl_states_cap = 0, ctl_ext_cap = 0;  // control side's view of the capacities once every built image is adopted
+    std::vector<Cmd> early_msgs;           // messages for nodes no built plan holds yet: released when their plan is published
+
+    // device state that outlives plans
+    DevBuf d_states;
+    size_t states_cap = 0;
+    DevBuf d_ext;  // per-node extended state (floats): biquad coefficients + history, delay rings
+    size_t ext_cap = 0, ext_used = 0;
+    std::vector<SampleRec> samples;
+    DevBuf d_samples;
+    std::vector<SampleDesc> h_sample_tab;  // host copy of d_samples, rebuilt by the calls that change it (control side)
+    bool samples_dirty = true;
+
+    uint32_t epoch = 1;  // invalidates every VoiceCache when bumped (plan adoption, sample-table change)
+    // Control kernel one batch AHEAD (FWGPU_CTL_AHEAD, voice-bank plan without a master chain, batches of more than one block):
+    // k_voice_control of batch b+1 runs on its own high-priority stream under the render kernels of batch b.  What it writes and
+    // the render kernels read exists twice (parity = batch number & 1); what orders the two streams is one event per parity and
+    // direction.  The kernels do not know: they get pointers.
+    bool ctl_ahead = false;          // wanted (env)
+    hipStream_t ctl_stream = nullptr;
+    hipEvent_t ev_ctl[2] = {nullptr, nullptr}, ev_render[2] = {nullptr, nullptr}, ev_join = nullptr;
+    uint64_t ahead_seq = 0;          // batches launched in ahead mode since the streams were last joined
+    bool streams_split = false;      // ctl_stream may hold work the main stream has not waited for
+    bool ahead_this_call = false;    // the process call in progress runs in ahead mode
+    bool cmds_on_ctl = false;        // ... and its message upload goes to the control stream
+
+    std::map<std::pair<int, int>, uint32_t> ir_cache;  // (sample id, channel) -> ext offset of h[T] as f32
+    std::map<std::pair<int, int>, uint32_t> ir_len;    // ... and its length in floats (freed with the last FIR user)
+    std::map<size_t, std::vector<uint32_t>> ext_free;  // ext slices of removed nodes, by 64-rounded size (floats)
+
+    // host nodes: the control side's registry of process functions (by node slot); an image gets copies
+    struct HostProc {
+        fwgpu_host_process_fn fn = nullptr;
+        void* user = nullptr;
+    };
+    std::vector<HostProc> host_procs;
+
+    // messages.  Setters push into `ring` from any thread; the audio thread drains it at the start of a process call
+    // into `cmds` (sorted by (node, block), arrival order inside a block).  Every buffer on this path has its final
+    // size from fwgpu_ctx_create on: a process call never allocates for messages.
+    static constexpr uint32_t RING_CAP = 1u << 15;  // messages in flight between two process calls
+    static constexpr size_t CMD_CAP = 1u << 16;     // messages waiting for their block (drained, not yet applied)
+    MsgRing ring;
+    std::atomic<uint64_t> drain_epoch{1};  // bumped by every drain: the producers' view of "the ring was emptied"
+    std::vector<Cmd> cmds, cmds_scratch;   // reserve(CMD_CAP) once; never grown
+    DevBuf d_cmds;
+    int n_cmds_dev = 0;
+    Cmd* h_cmds = nullptr;  // pinned staging for the async upload [CMD_CAP]
+    hipEvent_t cmds_copied = nullptr;
+    // ProcessorToNodeMsg::ReturnSample (sampler.rs:339-343): which sample every sampler holds, as the messages retired
+    // so far leave it (audio thread), and the swapped-out ones on their way back to the control side
+    std::vector<int> cur_sample;     // [node slot] -> sample id or -1; sized at adoption
+    std::vector<int64_t> slot_ids;   // [node slot] -> node id of the activated node
+    RetRing returns;
+    static constexpr uint32_t RET_EVENTS = 64;
+    hipEvent_t ret_events[RET_EVENTS] = {nullptr};
+    std::atomic<uint32_t> ret_event_ticket[RET_EVENTS] = {};  // ticket + 1 the slot's event was last recorded for (0 = never)
+    uint32_t ret_ticket = 0;         // audio thread: process calls that returned a sample so far
+    std::atomic<uint32_t> ret_done_ticket{0};  // tickets below this belong to calls the audio thread has SEEN complete (sync / flag)
+    bool ret_this_call = false;
+    // control side of the same: reference counts per sample id = SetSample messages sent - samples handed back
+    std::vector<int64_t> sample_refs;
+    std::vector<RetItem> ret_ready;  // completed returns not yet handed to fwgpu_poll_returned_samples
+    std::vector<uint32_t> dropped_samplers_ctl;  // control side: removed sampler nodes since the last build
+
+    // staging + B1 scratch
+    DevBuf d_in_stage, d_out_stage, d_scratch_pool, d_scratch_flags, d_scratch_tab, d_mask;
+    DevBuf d_trace;  // FW_CHAIN_TRACE builds only
+
+    // realtime edge (cpal/lib.rs:378-449 — one callback = a few hundred frames): pinned, device-mapped I/O blocks the
+    // kernels read / write directly (no copy-engine hop)
+    float *h_rt_in = nullptr, *h_rt_out = nullptr, *d_rt_in = nullptr, *d_rt_out = nullptr;
+    // completion flag of realtime-sized calls: a word in pinned, device-mapped host memory the last kernel of the call sets to
+    // the call's sequence number; the audio thread polls it instead of paying a blocking stream sync's wake-up
+    unsigned long long *h_rt_flag = nullptr, *d_rt_flag = nullptr;
+    unsigned long long rt_seq = 0;         // sequence number of the last realtime call
+    unsigned long long rt_signal_seq = 0;  // != 0 while run_blocks should arrange for the flag to be raised
+    bool rt_signalled = false;
+    bool rt_last_batch = false;  // the fused batch being launched ends the call
+    bool rt_one_launch = true;  // one-block calls on the voice-bank plan: control + leaf + root in ONE kernel (FWGPU_RT_ONE_LAUNCH=0: off)
+    DevBuf d_rt_sync;           // its workgroup counter
+    bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2
+    DevBuf d_rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS]
+
     // fwgpu_process_blocks_device_flags: where the call in progress reports, per (block, channel), whether that graph-output
     // channel was flagged silent (device memory of the caller; null = not asked for)
     uint8_t* out_sil = nullptr;
@@ -286,6 +392,7 @@ struct fwgpu_ctx {
     // printed to stderr when the ctx is destroyed
     bool host_prof = false;
     uint64_t hp_calls = 0, hp_call_ns = 0, hp_launch_ns = 0, hp_launches = 0;
+    uint64_t adopt_ns_max = 0, adoptions = 0, audio_adoptions = 0;  // the longest an adoption held up a process call (host nanoseconds)
 
     // timing
     bool timing = false;
@@ -364,7 +471,26 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
 bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedBuild& fb);
 
 // ---- fwgpu_plan_install.cpp
-int install_plan(fwgpu_ctx* c, Plan& plan);
+int install_plan(fwgpu_ctx* c, Plan& plan);           // control side: build the next image off to the side, publish it
+void adopt_image(fwgpu_ctx* c, PlanImage* n, bool on_audio_thread);         // whoever holds the gate: make `n` the active image, retire the old one
+void collect_retired(fwgpu_ctx* c);                   // control side: reuse / free the images the audio side is done with
+// A process call holds the gate for its whole duration and picks up a pending image at its start (graph/processor.rs:167-206:
+// poll_messages applies NewSchedule before the block).  It only ever spins while the control thread is inside the
+// microseconds of an adoption it started because it found the audio side idle.
+struct AudioGate {
+    fwgpu_ctx* c;
+    explicit AudioGate(fwgpu_ctx* ctx) : c(ctx) {
+        int expected = 0;
+        while (!c->gate.compare_exchange_weak(expected, 1, std::memory_order_acquire)) {
+            expected = 0;
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (PlanImage* img = c->pending.exchange(nullptr, std::memory_order_acq_rel)) adopt_image(c, img, true);
+    }
+    ~AudioGate() { c->gate.store(0, std::memory_order_release); }
+};
 
 // ---- fwgpu_run.cpp
 int upload(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes);

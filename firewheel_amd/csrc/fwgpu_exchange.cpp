@@ -2,7 +2,7 @@
 //
 // One process per GPU, voices sharded, nothing exchanged until the mix bus: the top-level R-port SumNode
 // (nodes/sum.rs:111-133) is the only step where the shards meet.  This file gives a host WITHOUT torch / RCCL that step:
-// every rank opens an exchange (one region of uncached HBM with R slots and R arrival words), publishes its IPC handle
+// every rank opens an exchange (one region of fine-grained HBM with R slots and R arrival words), publishes its IPC handle
 // through whatever side channel the host has (a file, a pipe, MPI, the Rust shim's own rendezvous), maps the peers'
 // handles (hipIpcOpenMemHandle: dmabuf over xGMI), and from then on a step is two kernels on the ctx stream:
 // k_bus_push (store my partial bus + silence flags into my slot on every rank, release, raise my arrival word) and
@@ -36,7 +36,7 @@ struct fwgpu_bus_exchange {
     fwgpu_ctx* ctx = nullptr;
     ExchangeGeom geom{};
     ExchangePeers peers{};
-    char* region = nullptr;  // this rank's region (uncached device memory)
+    char* region = nullptr;  // this rank's region (fine-grained device memory)
     size_t bytes = 0;
     uint32_t max_sil = 0;
     bool connected[FW_MAX_BUS_PARTS] = {false};
@@ -72,12 +72,12 @@ fwgpu_bus_exchange* fwgpu_bus_exchange_open(fwgpu_ctx* c, uint32_t rank, uint32_
     ex->geom.slot_bytes = (ex->geom.max_floats * 4 + max_silence_bytes + 255) & ~255ull;
     ex->bytes = EX_DATA_OFF + 2 * (size_t)world * ex->geom.slot_bytes;
     void* p = nullptr;
-    // uncached: a peer's stores land in HBM and the next load reads HBM — no L2 line of either device in between
-    hipError_t e = hipExtMallocWithFlags(&p, ex->bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        e = hipExtMallocWithFlags(&p, ex->bytes, hipDeviceMallocFinegrained);
-    }
+    // fine-grained device memory: the type whose contract is coherence between agents under system-scope fences / atomics —
+    // what a peer stored and released is what this device's acquiring load sees.  (Round 3 first used hipDeviceMallocUncached:
+    // correct while the region lives, but once FREED such memory was handed back out by hipMalloc and the ordinary buffers that
+    // landed on it read stale data — a flaky parity failure of an unrelated context later in the same process, found by the
+    // lazy-adoption test mode.  Fine-grained regions, and never-freed uncached ones, do not do that: 8 / 8 clean runs each.)
+    hipError_t e = hipExtMallocWithFlags(&p, ex->bytes, hipDeviceMallocFinegrained);
     if (e == hipSuccess) e = hipMemset(p, 0, ex->bytes);
     void* ctr = nullptr;
     if (e == hipSuccess) e = hipMalloc(&ctr, 1024);

@@ -76,7 +76,8 @@ int HostGraph::remove_node(int64_t id) {
     }
     n->alive = false;
     n->activated = false;
-    free_nodes.push_back(slot);
+    if (limbo) limbo->push_back(slot);  // reusable only once no running plan holds the node (fwgpu_plan_install.cpp)
+    else free_nodes.push_back(slot);
     nodes_to_activate.erase(std::remove(nodes_to_activate.begin(), nodes_to_activate.end(), slot), nodes_to_activate.end());
     needs_compile = true;
     return 0;

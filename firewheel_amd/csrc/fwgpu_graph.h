@@ -66,6 +66,7 @@ class HostGraph {
     uint32_t graph_in_slot, graph_out_slot;
     std::vector<HostNode> nodes;
     std::vector<uint32_t> free_nodes;
+    std::vector<uint32_t>* limbo = nullptr;  // when set, remove_node parks the freed slot there instead of free_nodes
     std::vector<HostEdge> edges;
     std::vector<uint32_t> free_edges;
     bool needs_compile = true;

@@ -195,6 +195,12 @@ int launch_host_scatter(hipStream_t s, float* pool, uint8_t* flags, int stride, 
                        d_bufs, frames, row_pitch, d_stage, d_stage_flags);
     return (int)hipGetLastError();
 }
+int launch_adopt_init(hipStream_t s, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits) {
+    if (n_jobs <= 0 && n_inits <= 0) return 0;
+    hipLaunchKernelGGL(k_adopt_init, dim3(16, n_jobs + 1), dim3(256), 0, s, ext, (const AdoptExtJob*)d_jobs, n_jobs, states, (const uint8_t*)d_inits,
+                       n_inits);
+    return (int)hipGetLastError();
+}
 int launch_out_flags(hipStream_t s, const uint8_t* flags, size_t flags_blk_stride, const int* d_bufs, int n_bufs, int mode, int n_out_ch, int K,
                      uint8_t* d_out) {
     const int n = K * n_out_ch;

@@ -137,6 +137,13 @@ int launch_host_gather(hipStream_t s, const float* pool, const uint8_t* flags, i
                        const int* d_bufs, int n, int frames, int K, int row_pitch, float* d_stage, uint8_t* d_stage_flags);
 int launch_host_scatter(hipStream_t s, float* pool, uint8_t* flags, int stride, size_t pool_blk_stride, size_t flags_blk_stride,
                         const int* d_bufs, int n, int frames, int K, int row_pitch, const float* d_stage, const uint8_t* d_stage_flags);
+// plan adoption, one launch: ext-pool jobs (AdoptExtJobHost records: a new node's slice zeroed and / or its head floats set) and
+// the initial NodeState records (StateInitHost) of the nodes the image activates
+struct AdoptExtJobHost {
+    uint32_t off, zero_len, n_head, pad;
+    float head[8];
+};
+int launch_adopt_init(hipStream_t s, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits);
 // per (block, channel) of a batch: was that graph-output channel flagged silent (mode: see k_out_flags)
 int launch_out_flags(hipStream_t s, const uint8_t* flags, size_t flags_blk_stride, const int* d_bufs, int n_bufs, int mode, int n_out_ch, int K,
                      uint8_t* d_out);

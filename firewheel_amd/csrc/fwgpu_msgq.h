@@ -78,6 +78,8 @@ class MsgRing {
     alignas(64) uint64_t head_ = 0;  // consumer only
 };
 
+constexpr int64_t RET_SILENT = INT64_MIN;  // RetItem::node of a return that only moves the reference count (a dropped sampler's
+                                           // sample, a SetSample message that never reached its node): nothing is reported
 struct RetItem {
     int64_t node;     // the sampler node that let go of the sample
     int sample;       // sample id (fwgpu_sample_create)

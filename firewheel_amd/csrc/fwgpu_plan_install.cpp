@@ -1,29 +1,115 @@
-// fwgpu_plan_install.cpp — node activation (graph.rs:594-612) and upload of the launch plan's device tables.
+// fwgpu_plan_install.cpp — node activation (graph.rs:594-612), the launch plan's device tables, and the hand-over of a new
+// plan to the audio side (graph/context.rs:93-137 + graph/processor.rs:167-206).
+//
+//   build_image   (control thread, may take milliseconds, may allocate, may fail) works out everything a plan needs in a
+//                 PlanImage that no process call can see: tables, pool, voice descriptors, staging areas — and the list of
+//                 things adopting it must do to the state that outlives plans (initial states of new nodes, larger arrays).
+//   publish       hands the image over: adopted at once when no process call is in flight, else left for the next one.
+//   adopt_image   (whoever holds the gate; on the audio thread: a member swap + a handful of asynchronous launches) makes
+//                 the image the active one and sends the old one back.
+// The control thread never writes into a buffer a running plan reads.
 #include "fwgpu_ctx.h"
+
+#include <chrono>
+#include <thread>
 
 namespace fwgpu {
 
+// control-side upload of the image being built: its own stream (never the null stream: that would serialise with a caller's
+// legacy default stream), complete on return (the sources are locals of the build)
+static int up(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    HIPC(c, b.ensure_n("b", bytes));
+    if (bytes) {
+        HIPC(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->up_stream));
+        HIPC(c, hipStreamSynchronize(c->up_stream));
+    }
+    return 0;
+}
+static int zero(fwgpu_ctx* c, void* p, size_t bytes) {
+    if (bytes) HIPC(c, hipMemsetAsync(p, 0, bytes, c->up_stream));
+    return 0;
+}
+
+void PlanImage::release_device() {
+    DevBuf* bufs[] = {&d_nodes, &d_in_buf, &d_out_buf, &d_level_nodes, &d_pool, &d_flags, &d_gin_bufs, &d_gout_bufs, &d_groups, &d_blks2, &d_refs2,
+                      &d_gsets2, &d_ramps2, &d_progs, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
+                      &d_chain_start, &d_chain_dummy, &d_chain_stats, &d_up_nodes, &d_up_in, &d_up_out, &d_up_level_nodes, &d_root_bufs, &d_tail_nodes,
+                      &d_tail_in, &d_tail_out, &d_tail_idx, &d_tail_frozen, &d_frozen_ph, &d_frozen, &d_fir_rows, &d_fir_tiles, &d_fir_partials,
+                      &d_hlevel_nodes, &grow_states, &grow_ext, &d_state_inits, &d_ext_jobs};
+    for (DevBuf* b : bufs) b->release();
+    if (h_host_stage) (void)hipHostFree(h_host_stage);
+    if (h_host_flags) (void)hipHostFree(h_host_flags);
+    h_host_stage = d_host_stage = nullptr;
+    h_host_flags = d_host_flags = nullptr;
+    host_stage_floats = host_flag_bytes = 0;
+    if (rt_graph.exec) (void)hipGraphExecDestroy(rt_graph.exec);
+    rt_graph.exec = nullptr;
+    if (retired_ev) (void)hipEventDestroy(retired_ev);
+    retired_ev = nullptr;
+}
+
+// a recycled image keeps its buffers (capacity) and its pinned staging area; everything that DESCRIBES a plan starts over
+static void reset_for_build(PlanImage& P) {
+    P.plan = Plan();
+    P.have_plan = false;
+    P.level_off.clear();
+    P.level_cnt.clear();
+    P.level_kinds.clear();
+    P.n_gout_bufs = P.n_gin_bufs = 0;
+    P.slot_index.clear();
+    P.fused = P.fused_fx = P.ctl_ahead_on = P.fused_rs = P.fused_prog = P.hybrid = P.hybrid_fx = false;
+    P.generic_k = 1;
+    P.chain_nq = 1;
+    P.n_voices = P.n_leaves = P.ramp_slots = P.n_groups = P.n_tail = P.n_fused_real = 0;
+    P.n_bus = 1;
+    P.up_level_off.clear();
+    P.up_level_cnt.clear();
+    P.tail_kinds.clear();
+    P.up_root_node = -1;
+    memset(&P.root_args, 0, sizeof(P.root_args));
+    P.fir_groups.clear();
+    P.hlevel_off.clear();
+    P.hlevel_cnt.clear();
+    P.hlevel_kinds.clear();
+    P.host_levels.clear();
+    P.n_host_nodes = 0;
+    P.host_callbacks = 0;
+    if (P.rt_graph.exec) (void)hipGraphExecDestroy(P.rt_graph.exec);
+    P.rt_graph = PlanImage::RtGraph();
+    P.grow_states.release();
+    P.grow_ext.release();
+    P.grow_states_cap = P.grow_ext_cap = 0;
+    P.n_state_inits = P.n_ext_jobs = 0;
+    P.ir_convs.clear();
+    P.activated.clear();
+    P.dropped_samplers.clear();
+    P.removed_slots.clear();
+    P.slots_cap = 0;
+    P.grow_cur_sample.clear();
+    P.grow_slot_ids.clear();
+}
+
 // what the control kernel writes and the render kernels read, per voice and block of a batch (both fused plans and the hybrid one)
-static int alloc_voice_tables(fwgpu_ctx* c) {
-    const size_t K = c->kmax;
-    HIPC(c, c->d_blks.ensure(K * c->n_voices * sizeof(VoiceBlk)));
-    HIPC(c, c->d_refs.ensure(ref_count(c->n_voices, K) * sizeof(VoiceRef)));
-    HIPC(c, c->d_gsets.ensure((size_t)c->n_voices * FW_GSETS * sizeof(GainSet)));
-    HIPC(c, c->d_chain_start.ensure((size_t)c->n_voices * sizeof(ChainStart)));
-    HIPC(c, c->d_chain_dummy.ensure(64 * 1024));
-    HIPC(c, c->d_chain_stats.ensure(2 * sizeof(unsigned long long)));
-    HIPC(c, hipMemset(c->d_chain_stats.p, 0, 2 * sizeof(unsigned long long)));
-    HIPC(c, hipMemset(c->d_chain_start.p, 0, (size_t)c->n_voices * sizeof(ChainStart)));
-    HIPC(c, c->d_cache.ensure((size_t)c->n_voices * sizeof(VoiceCache)));
-    HIPC(c, hipMemset(c->d_cache.p, 0, (size_t)c->n_voices * sizeof(VoiceCache)));
-    c->epoch++;
-    HIPC(c, c->d_ramps.ensure(K * c->n_voices * (size_t)c->ramp_slots * c->stride * sizeof(float)));
+static int alloc_voice_tables(fwgpu_ctx* c, PlanImage& P) {
+    const size_t K = P.kmax;
+    HIPC(c, P.d_blks.ensure_n("d_blks", K * P.n_voices * sizeof(VoiceBlk)));
+    HIPC(c, P.d_refs.ensure_n("d_refs", ref_count(P.n_voices, K) * sizeof(VoiceRef)));
+    HIPC(c, P.d_gsets.ensure_n("d_gsets", (size_t)P.n_voices * FW_GSETS * sizeof(GainSet)));
+    HIPC(c, P.d_chain_start.ensure_n("d_chain_start", (size_t)P.n_voices * sizeof(ChainStart)));
+    HIPC(c, P.d_chain_dummy.ensure_n("d_chain_dummy", 64 * 1024));
+    HIPC(c, P.d_chain_stats.ensure_n("d_chain_stats", 2 * sizeof(unsigned long long)));
+    int rc;
+    if ((rc = zero(c, P.d_chain_stats.p, 2 * sizeof(unsigned long long)))) return rc;
+    if ((rc = zero(c, P.d_chain_start.p, (size_t)P.n_voices * sizeof(ChainStart)))) return rc;
+    HIPC(c, P.d_cache.ensure_n("d_cache", (size_t)P.n_voices * sizeof(VoiceCache)));
+    if ((rc = zero(c, P.d_cache.p, (size_t)P.n_voices * sizeof(VoiceCache)))) return rc;  // (and adoption bumps the epoch)
+    HIPC(c, P.d_ramps.ensure_n("d_ramps", K * P.n_voices * (size_t)P.ramp_slots * c->stride * sizeof(float)));
     return 0;
 }
 
 // k_chain workgroups: consecutive leaves packed greedily into groups of <= 32 voices / <= 8 leaves (the voices of
 // consecutive leaves are consecutive), so that a tree of small leaves fills the 32 voice rows
-static int upload_chain_groups(fwgpu_ctx* c, const std::vector<LeafDesc>& leaves) {
+static int upload_chain_groups(fwgpu_ctx* c, PlanImage& P, const std::vector<LeafDesc>& leaves) {
     int rc;
     std::vector<ChainGroup> groups;
     for (size_t l = 0; l < leaves.size(); ++l) {
@@ -51,197 +137,167 @@ static int upload_chain_groups(fwgpu_ctx* c, const std::vector<LeafDesc>& leaves
         for (int i = 0; i < g.n_leaves && uni; ++i) uni = g.ports[i] == P;
         g.uniform_ports = uni ? P : 0;
     }
-    c->n_groups = (int)groups.size();
-    if ((rc = upload(c, c->d_groups, groups.data(), groups.size() * sizeof(ChainGroup)))) return rc;
+    P.n_groups = (int)groups.size();
+    if ((rc = up(c, P.d_groups, groups.data(), groups.size() * sizeof(ChainGroup)))) return rc;
     return 0;
 }
 
-static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
-    HIPC(c, hipStreamSynchronize(c->stream));
-    if (c->ctl_stream) HIPC(c, hipStreamSynchronize(c->ctl_stream));
-    c->streams_split = false;
-    c->ahead_seq = 0;
-    c->ctl_ahead_on = false;
-    c->kmax = c->kmax_req;
-    // 1. node state capacity (persists across recompiles: processor.rs:19,195-197)
-    size_t need = c->graph.nodes.size();
-    if (need > c->states_cap) {
-        size_t cap = std::max<size_t>(need * 2, 64);
-        DevBuf nb;
-        HIPC(c, nb.ensure(cap * sizeof(NodeState)));
-        HIPC(c, hipMemset(nb.p, 0, cap * sizeof(NodeState)));
-        if (c->d_states.p && c->states_cap)
-            HIPC(c, hipMemcpy(nb.p, c->d_states.p, c->states_cap * sizeof(NodeState), hipMemcpyDeviceToDevice));
-        c->d_states = std::move(nb);
-        c->states_cap = cap;
-    }
-    // 2. activate new nodes (graph.rs:594-612): scatter their initial states, carve their ext-pool slices.
-    //    Two-phase: every offset / initial state / impulse-response slot is worked out in locals, the device copies are
-    //    made, and only then is the host bookkeeping (activated flags, init records, ext_used, ir_cache) committed — a
-    //    failure anywhere leaves the ctx exactly as it was and the next fwgpu_update tries the same nodes again.
+// Everything a plan needs, worked out on the control thread in an image no process call can see.  Nothing the audio side reads
+// is written; the control side's own bookkeeping (activated flags, init records, ext_used, ir_cache) is committed only at the
+// very end, when nothing can fail any more — a failure anywhere leaves the ctx exactly as it was and the next fwgpu_update
+// tries the same nodes again (the reference keeps its schedule when a compile fails, context.rs:115-131).
+static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
+    reset_for_build(P);
+    P.kmax = c->kmax_req;
+    P.gen = ++c->build_gen;
+    // 1. node state capacity (persists across recompiles: processor.rs:19,195-197): a larger array is allocated here and
+    //    swapped in — old contents copied over on the ctx stream — when the image is adopted
     {
-        struct Act {
-            uint32_t slot;
-            NodeState st;  // the node's init record with its ext slice / FIR ring geometry filled in
-        };
-        std::vector<Act> acts;
-        std::vector<StateInitHost> inits;
-        std::vector<std::pair<size_t, std::vector<float>>> ext_inits;  // (offset, initial floats)
-        std::map<std::pair<int, int>, uint32_t> new_ir;                // impulse responses to convert to f32 -> ext offset
-        size_t ext_need = c->ext_used;
-        auto take_ext = [&](size_t len, uint32_t* off) -> bool {  // recycled slice of exactly this (64-rounded) size, else bump
-            const size_t rounded = (len + 63) / 64 * 64;
-            auto it = c->ext_free.find(rounded);
-            if (it != c->ext_free.end() && !it->second.empty()) {
-                *off = it->second.back();
-                it->second.pop_back();
-                return true;
-            }
-            if (ext_need + rounded > 0xffffffffull) return false;
-            *off = (uint32_t)ext_need;
-            ext_need += rounded;
-            return true;
-        };
-        std::map<size_t, std::vector<uint32_t>> free_backup = c->ext_free;  // restored on failure
-        auto rollback = [&](int rc) {
-            c->ext_free = free_backup;
-            return rc;
-        };
-        std::vector<std::pair<uint32_t, uint32_t>> zero_slices;  // recycled slices start from zeros like fresh ones
-        for (uint32_t slot : c->graph.nodes_to_activate) {
-            const HostNode& n = c->graph.nodes[slot];
-            if (!n.alive || n.activated) continue;
-            if (n.kind == K_HOST && (slot >= c->host_procs.size() || !c->host_procs[slot].fn))
-                return rollback(fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "host node without a process function (fwgpu_host_node_set_process)"));
-            Act a;
-            a.slot = slot;
-            a.st = n.init;
-            uint32_t nch = n.n_in < n.n_out ? n.n_in : n.n_out;
-            size_t len = 0;
-            std::vector<float> head;
-            if (n.kind == K_BIQUAD) {
-                len = 5 + 4 * (size_t)nch;
-                head.resize(5);
-                biquad_coefs(n.init.enabled, n.init.p0, n.init.p1, c->sample_rate, head.data());
-            } else if (n.kind == K_DELAY) {
-                len = (size_t)nch * (size_t)n.init.loop_end;
-            } else if (n.kind == K_SPATIAL) {
-                len = SP_HIST;
-            } else if (n.kind == K_FIR) {
-                int ir = n.init.sample;
-                if (ir < 0 || ir >= (int)c->samples.size() || !c->samples[ir].alive)
-                    return rollback(fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "FIR node: impulse-response sample was destroyed"));
-                uint64_t T = c->samples[ir].desc.frames;
-                if (T == 0 || T > (1u << 24))
-                    return rollback(fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "FIR node: 1 <= taps <= 2^24"));
-                uint64_t R = T - 1 + (uint64_t)c->kmax * c->mbf;  // every block of a K-batch finds its whole window in the ring
-                a.st.loop_start = T;
-                a.st.loop_end = R;
-                a.st.playhead = 0;
-                len = (size_t)nch * 2 * (size_t)R;
-                for (uint32_t ch = 0; ch < nch; ++ch) {
-                    auto key = std::make_pair(ir, (int)std::min<uint32_t>(ch, (uint32_t)c->samples[ir].desc.channels - 1));
-                    if (!c->ir_cache.count(key)) new_ir.emplace(key, 0u);  // offset assigned below, once the pool layout is final
-                }
-            }
-            if (len) {
-                const size_t before = ext_need;
-                uint32_t off = 0;
-                if (!take_ext(len, &off)) return rollback(fail(c, FWGPU_ERR_INVALID, "ext state pool exceeds 2^32 floats"));
-                a.st.ext_off = off;
-                a.st.ext_len = (uint32_t)len;
-                if (ext_need == before) zero_slices.emplace_back(off, (uint32_t)((len + 63) / 64 * 64));
-                if (!head.empty()) ext_inits.emplace_back(off, head);
-            }
-            StateInitHost si;
-            si.index = (int)slot;
-            si.pad = 0;
-            si.st = a.st;
-            inits.push_back(si);
-            acts.push_back(a);
+        const size_t need = c->graph.nodes.size();
+        if (need > c->ctl_states_cap) {
+            const size_t cap = std::max<size_t>(need * 2, 4096);
+            HIPC(c, P.grow_states.ensure_n("grow_states", cap * sizeof(NodeState)));
+            int rc0 = zero(c, P.grow_states.p, cap * sizeof(NodeState));
+            if (rc0) return rc0;
+            P.grow_states_cap = cap;
         }
-        for (auto& kv : new_ir) {  // one f32 copy of each impulse-response channel
-            uint64_t T = c->samples[kv.first.first].desc.frames;
-            if (ext_need + (T + 63) / 64 * 64 > 0xffffffffull)
-                return rollback(fail(c, FWGPU_ERR_INVALID, "ext state pool exceeds 2^32 floats"));
-            kv.second = (uint32_t)ext_need;
-            ext_need += (T + 63) / 64 * 64;
+        P.slots_cap = std::max<size_t>(need, 1);
+        if (c->cur_sample.size() < need) {  // (control side reads the size only; the audio side swaps the vectors in at adoption)
+            const size_t cap = std::max<size_t>(need * 2, 4096);
+            P.grow_cur_sample.assign(cap, -1);
+            P.grow_slot_ids.assign(cap, -1);
         }
-        int arc = 0;
-        auto device_side = [&]() -> int {
-            if (ext_need > c->ext_cap) {
-                size_t cap = std::max<size_t>(ext_need * 2, 4096);
-                DevBuf nb;
-                HIPC(c, nb.ensure((cap + 256) * sizeof(float)));  // slack: vector loads may overhang the last slice
-                HIPC(c, hipMemset(nb.p, 0, (cap + 256) * sizeof(float)));
-                if (c->d_ext.p && c->ext_used)
-                    HIPC(c, hipMemcpy(nb.p, c->d_ext.p, c->ext_used * sizeof(float), hipMemcpyDeviceToDevice));
-                c->d_ext = std::move(nb);  // (same contents up to ext_used, more room: consistent whether or not the rest succeeds)
-                c->ext_cap = cap;
-            }
-            for (auto& z : zero_slices)
-                HIPC(c, hipMemsetAsync(c->d_ext.as<float>() + z.first, 0, (size_t)z.second * sizeof(float), c->stream));
-            if (!ext_inits.empty()) {  // one upload + one scatter launch, however many nodes were activated
-                std::vector<ExtInitHost> items(ext_inits.size());
-                for (size_t i = 0; i < ext_inits.size(); ++i) {
-                    items[i].off = (uint32_t)ext_inits[i].first;
-                    items[i].n = (uint32_t)std::min<size_t>(ext_inits[i].second.size(), 6);
-                    for (uint32_t j = 0; j < 6; ++j) items[i].v[j] = j < items[i].n ? ext_inits[i].second[j] : 0.f;
-                }
-                DevBuf tmp;
-                int rc2 = upload(c, tmp, items.data(), items.size() * sizeof(ExtInitHost));
-                if (rc2) return rc2;
-                LCHK(c, launch_scatter_ext(c->stream, c->d_ext.as<float>(), tmp.p, (int)items.size()));
-                HIPC(c, hipStreamSynchronize(c->stream));
-                tmp.release();
-            }
-            if (!new_ir.empty()) {
-                int rc = upload_sample_table(c);
-                if (rc) return rc;
-                for (auto& kv : new_ir)
-                    LCHK(c, launch_ir_convert(c->stream, c->d_samples.as<SampleDesc>(), kv.first.first, kv.first.second,
-                                              c->d_ext.as<float>() + kv.second, (uint32_t)c->samples[kv.first.first].desc.frames));
-                HIPC(c, hipStreamSynchronize(c->stream));
-            }
-            if (!inits.empty()) {
-                DevBuf tmp;
-                int rc = upload(c, tmp, inits.data(), inits.size() * sizeof(StateInitHost));
-                if (rc) return rc;
-                LCHK(c, launch_scatter_states(c->stream, c->d_states.as<NodeState>(), tmp.p, (int)inits.size()));
-                HIPC(c, hipStreamSynchronize(c->stream));
-                tmp.release();
-            }
-            return 0;
-        };
-        if ((arc = device_side()) != 0) return rollback(arc);
-        // commit
-        // (audio-side tables: no process call overlaps an update.)  A removed sampler's processor is dropped with the old
-        // schedule and hands its sample back (sampler.rs:563-571); a newly activated node starts without one.
-        if (c->cur_sample.size() < c->graph.nodes.size()) {
-            const size_t cap = std::max<size_t>(c->graph.nodes.size() * 2, 64);
-            c->cur_sample.resize(cap, -1);
-            c->slot_ids.resize(cap, -1);
-        }
-        for (uint32_t slot : c->dropped_samplers) {
-            const int smp = c->cur_sample[slot];
-            if (smp >= 0 && (size_t)smp < c->sample_refs.size() && c->sample_refs[smp] > 0) c->sample_refs[smp]--;
-            c->cur_sample[slot] = -1;
-        }
-        c->dropped_samplers.clear();
-        for (const Act& a : acts) {
-            HostNode& n = c->graph.nodes[a.slot];
-            n.init = a.st;
-            n.activated = true;
-            c->cur_sample[a.slot] = -1;
-            c->slot_ids[a.slot] = c->graph.id_of(a.slot);
-        }
-        for (auto& kv : new_ir) {
-            c->ir_cache[kv.first] = kv.second;
-            c->ir_len[kv.first] = (uint32_t)c->samples[kv.first.first].desc.frames;
-        }
-        c->ext_used = ext_need;
-        c->graph.nodes_to_activate.clear();
     }
+    // 2. activate new nodes (graph.rs:594-612): their initial states and ext-pool slices are worked out here and applied at
+    //    adoption (scatter kernels on the ctx stream), never written into live buffers from this thread
+    struct Act {
+        uint32_t slot;
+        NodeState st;  // the node's init record with its ext slice / FIR ring geometry filled in
+    };
+    std::vector<Act> acts;
+    std::vector<StateInitHost> inits;
+    std::map<std::pair<int, int>, uint32_t> new_ir;                // impulse responses to convert to f32 -> ext offset
+    size_t ext_need = c->ext_used;
+    std::map<size_t, std::vector<uint32_t>> free_backup = c->ext_free;  // restored on failure
+    struct Rollback {  // any return before `armed = false` puts the free lists back
+        fwgpu_ctx* c;
+        std::map<size_t, std::vector<uint32_t>>* backup;
+        uint64_t* gen;
+        bool armed = true;
+        ~Rollback() {
+            if (armed) {
+                c->ext_free = *backup;
+                --*gen;
+            }
+        }
+    } rollback{c, &free_backup, &c->build_gen};
+    auto take_ext = [&](size_t len, uint32_t* off) -> bool {  // recycled slice of exactly this (64-rounded) size, else bump
+        const size_t rounded = (len + 63) / 64 * 64;
+        auto it = c->ext_free.find(rounded);
+        if (it != c->ext_free.end() && !it->second.empty()) {
+            *off = it->second.back();
+            it->second.pop_back();
+            return true;
+        }
+        if (ext_need + rounded > 0xffffffffull) return false;
+        *off = (uint32_t)ext_need;
+        ext_need += rounded;
+        return true;
+    };
+    std::vector<AdoptExtJobHost> ext_jobs;  // per new node with an ext slice: recycled slices zeroed, head floats (coefficients) set
+    for (uint32_t slot : c->graph.nodes_to_activate) {
+        const HostNode& n = c->graph.nodes[slot];
+        if (!n.alive || n.activated) continue;
+        if (n.kind == K_HOST && (slot >= c->host_procs.size() || !c->host_procs[slot].fn))
+            return fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "host node without a process function (fwgpu_host_node_set_process)");
+        Act a;
+        a.slot = slot;
+        a.st = n.init;
+        uint32_t nch = n.n_in < n.n_out ? n.n_in : n.n_out;
+        size_t len = 0;
+        std::vector<float> head;
+        if (n.kind == K_BIQUAD) {
+            len = 5 + 4 * (size_t)nch;
+            head.resize(5);
+            biquad_coefs(n.init.enabled, n.init.p0, n.init.p1, c->sample_rate, head.data());
+        } else if (n.kind == K_DELAY) {
+            len = (size_t)nch * (size_t)n.init.loop_end;
+        } else if (n.kind == K_SPATIAL) {
+            len = SP_HIST;
+        } else if (n.kind == K_FIR) {
+            int ir = n.init.sample;
+            if (ir < 0 || ir >= (int)c->samples.size() || !c->samples[ir].alive)
+                return fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "FIR node: impulse-response sample was destroyed");
+            uint64_t T = c->samples[ir].desc.frames;
+            if (T == 0 || T > (1u << 24)) return fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "FIR node: 1 <= taps <= 2^24");
+            uint64_t R = T - 1 + (uint64_t)P.kmax * c->mbf;  // every block of a K-batch finds its whole window in the ring
+            a.st.loop_start = T;
+            a.st.loop_end = R;
+            a.st.playhead = 0;
+            len = (size_t)nch * 2 * (size_t)R;
+            for (uint32_t ch = 0; ch < nch; ++ch) {
+                auto key = std::make_pair(ir, (int)std::min<uint32_t>(ch, (uint32_t)c->samples[ir].desc.channels - 1));
+                if (!c->ir_cache.count(key)) new_ir.emplace(key, 0u);  // offset assigned below, once the pool layout is final
+            }
+        }
+        if (len) {
+            const size_t before = ext_need;
+            uint32_t off = 0;
+            if (!take_ext(len, &off)) return fail(c, FWGPU_ERR_INVALID, "ext state pool exceeds 2^32 floats");
+            a.st.ext_off = off;
+            a.st.ext_len = (uint32_t)len;
+            AdoptExtJobHost j;
+            memset(&j, 0, sizeof(j));
+            j.off = off;
+            j.zero_len = ext_need == before ? (uint32_t)((len + 63) / 64 * 64) : 0u;  // (a bumped slice is zero already)
+            j.n_head = (uint32_t)std::min<size_t>(head.size(), 8);
+            for (uint32_t k = 0; k < j.n_head; ++k) j.head[k] = head[k];
+            if (j.zero_len || j.n_head) ext_jobs.push_back(j);
+        }
+        StateInitHost si;
+        si.index = (int)slot;
+        si.pad = 0;
+        si.st = a.st;
+        inits.push_back(si);
+        acts.push_back(a);
+    }
+    for (auto& kv : new_ir) {  // one f32 copy of each impulse-response channel
+        uint64_t T = c->samples[kv.first.first].desc.frames;
+        if (ext_need + (T + 63) / 64 * 64 > 0xffffffffull) return fail(c, FWGPU_ERR_INVALID, "ext state pool exceeds 2^32 floats");
+        kv.second = (uint32_t)ext_need;
+        ext_need += (T + 63) / 64 * 64;
+        PlanImage::IrConv ic;
+        ic.sample = kv.first.first;
+        ic.ch = kv.first.second;
+        ic.off = kv.second;
+        ic.T = (uint32_t)T;
+        P.ir_convs.push_back(ic);
+    }
+    int rc;
+    if (ext_need > c->ctl_ext_cap) {
+        const size_t cap = std::max<size_t>(ext_need * 2, 4096);
+        HIPC(c, P.grow_ext.ensure_n("grow_ext", (cap + 256) * sizeof(float)));  // slack: vector loads may overhang the last slice
+        if ((rc = zero(c, P.grow_ext.p, (cap + 256) * sizeof(float)))) return rc;
+        P.grow_ext_cap = cap;
+    }
+    if (!ext_jobs.empty()) {
+        if ((rc = up(c, P.d_ext_jobs, ext_jobs.data(), ext_jobs.size() * sizeof(AdoptExtJobHost)))) return rc;
+        P.n_ext_jobs = (int)ext_jobs.size();
+    }
+    if (!inits.empty()) {
+        if ((rc = up(c, P.d_state_inits, inits.data(), inits.size() * sizeof(StateInitHost)))) return rc;
+        P.n_state_inits = (int)inits.size();
+    }
+    // what the tables below need from nodes this image activates (their init records are committed only at the end)
+    auto node_init = [&](uint32_t slot) -> NodeState {
+        for (const Act& a : acts)
+            if (a.slot == slot) return a.st;
+        return c->graph.nodes[slot].init;
+    };
+    auto ir_off = [&](const std::pair<int, int>& key) -> uint32_t {
+        auto it = new_ir.find(key);
+        return it != new_ir.end() ? it->second : c->ir_cache[key];
+    };
     // (the launch plans are chosen before the tables are written: a hybrid plan with split SumNodes adds partial buses to the
     // pool and continuation nodes to the node table)
     FusedBuild fb, hb;
@@ -252,8 +308,7 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
             hb.leaves[sp.leaf].out_buf = plan.num_buffers;
             plan.num_buffers += 2;
         }
-    // 3. node tables (from here on the device tables of the OLD plan are being overwritten)
-    *tables_touched = true;
+    // 3. node tables
     const int N = (int)plan.nodes.size();
     std::vector<NodeDesc> nd(N);
     std::vector<int> in_tab, out_tab;
@@ -298,40 +353,39 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         }
     if (in_tab.empty()) in_tab.push_back(0);
     if (out_tab.empty()) out_tab.push_back(0);
-    int rc;
-    if ((rc = upload(c, c->d_nodes, nd.data(), nd.size() * sizeof(NodeDesc)))) return rc;
-    if ((rc = upload(c, c->d_in_buf, in_tab.data(), in_tab.size() * sizeof(int)))) return rc;
-    if ((rc = upload(c, c->d_out_buf, out_tab.data(), out_tab.size() * sizeof(int)))) return rc;
+    if ((rc = up(c, P.d_nodes, nd.data(), nd.size() * sizeof(NodeDesc)))) return rc;
+    if ((rc = up(c, P.d_in_buf, in_tab.data(), in_tab.size() * sizeof(int)))) return rc;
+    if ((rc = up(c, P.d_out_buf, out_tab.data(), out_tab.size() * sizeof(int)))) return rc;
     std::vector<int> flat;
-    c->level_off.clear();
-    c->level_cnt.clear();
-    c->level_kinds.clear();
+    P.level_off.clear();
+    P.level_cnt.clear();
+    P.level_kinds.clear();
     for (auto& l : levels) {
-        c->level_off.push_back((int)flat.size());
-        c->level_cnt.push_back((int)l.size());
+        P.level_off.push_back((int)flat.size());
+        P.level_cnt.push_back((int)l.size());
         flat.insert(flat.end(), l.begin(), l.end());
         int kinds = 0;
         for (int i : l) kinds |= host_kind_bits(nd[i].kind);
-        c->level_kinds.push_back(kinds);
+        P.level_kinds.push_back(kinds);
     }
     if (flat.empty()) flat.push_back(0);
-    if ((rc = upload(c, c->d_level_nodes, flat.data(), flat.size() * sizeof(int)))) return rc;
-    c->n_gin_bufs = (int)gin_bufs.size();
-    c->n_gout_bufs = (int)gout_bufs.size();
+    if ((rc = up(c, P.d_level_nodes, flat.data(), flat.size() * sizeof(int)))) return rc;
+    P.n_gin_bufs = (int)gin_bufs.size();
+    P.n_gout_bufs = (int)gout_bufs.size();
     if (gin_bufs.empty()) gin_bufs.push_back(0);
     if (gout_bufs.empty()) gout_bufs.push_back(0);
-    if ((rc = upload(c, c->d_gin_bufs, gin_bufs.data(), gin_bufs.size() * sizeof(int)))) return rc;
-    if ((rc = upload(c, c->d_gout_bufs, gout_bufs.data(), gout_bufs.size() * sizeof(int)))) return rc;
+    if ((rc = up(c, P.d_gin_bufs, gin_bufs.data(), gin_bufs.size() * sizeof(int)))) return rc;
+    if ((rc = up(c, P.d_gout_bufs, gout_bufs.data(), gout_bufs.size() * sizeof(int)))) return rc;
     // 3c. host nodes (K_HOST): per level, what the audio side needs to call them — and one pinned, device-mapped staging area
     //     for their inputs and outputs of a whole K-batch, allocated here (a process call never allocates)
     {
-        c->host_levels.assign(plan.num_levels, {});
-        c->n_host_nodes = (int)host_nodes.size();
-        c->host_callbacks = 0;
+        P.host_levels.assign(plan.num_levels, {});
+        P.n_host_nodes = (int)host_nodes.size();
+        P.host_callbacks = 0;
         size_t floats = 0, flag_bytes = 0, max_in = 1, max_out = 1;
         for (int i : host_nodes) {
             const PlanNode& p = plan.nodes[i];
-            fwgpu_ctx::HostCall hc;
+            PlanImage::HostCall hc;
             hc.node_idx = i;
             hc.n_in = p.n_in;
             hc.n_out = p.n_out;
@@ -342,32 +396,32 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
             if (!hc.fn) return fail(c, FWGPU_ERR_NODE_ACTIVATION_FAILED, "host node without a process function (fwgpu_host_node_set_process)");
             hc.stage_off = floats;
             hc.flag_off = flag_bytes;
-            floats += (size_t)c->kmax * (size_t)(p.n_in + p.n_out) * c->stride;
-            flag_bytes += (size_t)c->kmax * (size_t)(p.n_in + p.n_out);
+            floats += (size_t)P.kmax * (size_t)(p.n_in + p.n_out) * c->stride;
+            flag_bytes += (size_t)P.kmax * (size_t)(p.n_in + p.n_out);
             max_in = std::max<size_t>(max_in, (size_t)p.n_in);
             max_out = std::max<size_t>(max_out, (size_t)p.n_out);
-            c->host_levels[p.level].push_back(hc);
+            P.host_levels[p.level].push_back(hc);
         }
-        if (floats > c->host_stage_floats || flag_bytes > c->host_flag_bytes) {
-            if (c->h_host_stage) (void)hipHostFree(c->h_host_stage);
-            if (c->h_host_flags) (void)hipHostFree(c->h_host_flags);
-            c->h_host_stage = nullptr;
-            c->h_host_flags = nullptr;
-            c->host_stage_floats = c->host_flag_bytes = 0;
+        if (floats > P.host_stage_floats || flag_bytes > P.host_flag_bytes) {  // (a recycled image keeps its staging area when it is large enough)
+            if (P.h_host_stage) (void)hipHostFree(P.h_host_stage);
+            if (P.h_host_flags) (void)hipHostFree(P.h_host_flags);
+            P.h_host_stage = nullptr;
+            P.h_host_flags = nullptr;
+            P.host_stage_floats = P.host_flag_bytes = 0;
             void *hs = nullptr, *hf = nullptr, *ds = nullptr, *df = nullptr;
             HIPC(c, hipHostMalloc(&hs, floats * sizeof(float), hipHostMallocMapped));
-            c->h_host_stage = (float*)hs;
+            P.h_host_stage = (float*)hs;
             HIPC(c, hipHostMalloc(&hf, flag_bytes + 64, hipHostMallocMapped));
-            c->h_host_flags = (uint8_t*)hf;
+            P.h_host_flags = (uint8_t*)hf;
             HIPC(c, hipHostGetDevicePointer(&ds, hs, 0));
             HIPC(c, hipHostGetDevicePointer(&df, hf, 0));
-            c->d_host_stage = (float*)ds;
-            c->d_host_flags = (uint8_t*)df;
-            c->host_stage_floats = floats;
-            c->host_flag_bytes = flag_bytes;
+            P.d_host_stage = (float*)ds;
+            P.d_host_flags = (uint8_t*)df;
+            P.host_stage_floats = floats;
+            P.host_flag_bytes = flag_bytes;
         }
-        c->host_in_ptrs.assign(max_in, nullptr);
-        c->host_out_ptrs.assign(max_out, nullptr);
+        P.host_in_ptrs.assign(max_in, nullptr);
+        P.host_out_ptrs.assign(max_out, nullptr);
     }
     // 3b. FIR banks: one GEMM per (level, impulse-response channel)
     {
@@ -375,9 +429,9 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         for (int i = 0; i < N; ++i) {
             const PlanNode& p = plan.nodes[i];
             if (p.kind != K_FIR) continue;
-            const HostNode& hn = c->graph.nodes[p.slot];
-            int ir = hn.init.sample;
-            uint32_t T = (uint32_t)hn.init.loop_start;
+            const NodeState hst = node_init(p.slot);
+            int ir = hst.sample;
+            uint32_t T = (uint32_t)hst.loop_start;
             int nch = std::min(p.n_in, p.n_out);
             for (int ch = 0; ch < nch; ++ch) {
                 auto key = std::make_pair(ir, std::min(ch, c->samples[ir].desc.channels - 1));
@@ -386,20 +440,20 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
                 r.ch = ch;
                 r.in_buf = p.in_buf[ch];
                 r.out_buf = p.out_buf[ch];
-                groups[std::make_tuple(p.level, c->ir_cache[key], T)].push_back(r);
+                groups[std::make_tuple(p.level, ir_off(key), T)].push_back(r);
             }
         }
         // one launch per (level, T); inside it rows are sorted by impulse-response channel and padded so that
         // every 32-row tile convolves with a single h (tile_h_off)
         std::vector<FirRow> flat_rows;
         std::vector<uint32_t> flat_tiles;
-        c->fir_groups.clear();
+        P.fir_groups.clear();
         size_t partial_need = 0;
         std::map<std::pair<int, uint32_t>, std::vector<std::pair<uint32_t, std::vector<FirRow>*>>> launches;
         for (auto& g : groups)
             launches[std::make_pair(std::get<0>(g.first), std::get<2>(g.first))].emplace_back(std::get<1>(g.first), &g.second);
         for (auto& l : launches) {
-            fwgpu_ctx::FirGroup fg;
+            PlanImage::FirGroup fg;
             fg.level = l.first.first;
             fg.T = l.first.second;
             fg.row_off = (int)flat_rows.size();
@@ -415,78 +469,78 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
                 while (flat_tiles.size() - fg.tile_off < (flat_rows.size() - fg.row_off) / 32) flat_tiles.push_back(part.first);
             }
             fg.n_rows = (int)flat_rows.size() - fg.row_off;
-            c->fir_groups.push_back(fg);
+            P.fir_groups.push_back(fg);
             size_t W = (size_t)fg.T - 1 + c->mbf;
             size_t segs = (W + FIR_SEG - 1) / FIR_SEG;
-            partial_need = std::max(partial_need, segs * (size_t)fg.n_rows * (size_t)((c->mbf + 255) / 256 * 256) * c->kmax);
+            partial_need = std::max(partial_need, segs * (size_t)fg.n_rows * (size_t)((c->mbf + 255) / 256 * 256) * P.kmax);
         }
         if (!flat_rows.empty()) {
-            if ((rc = upload(c, c->d_fir_rows, flat_rows.data(), flat_rows.size() * sizeof(FirRow)))) return rc;
-            if ((rc = upload(c, c->d_fir_tiles, flat_tiles.data(), flat_tiles.size() * sizeof(uint32_t)))) return rc;
-            HIPC(c, c->d_fir_partials.ensure(partial_need * sizeof(float)));
+            if ((rc = up(c, P.d_fir_rows, flat_rows.data(), flat_rows.size() * sizeof(FirRow)))) return rc;
+            if ((rc = up(c, P.d_fir_tiles, flat_tiles.data(), flat_tiles.size() * sizeof(uint32_t)))) return rc;
+            HIPC(c, P.d_fir_partials.ensure_n("d_fir_partials", partial_need * sizeof(float)));
         }
     }
     // 4. buffer pool: a new schedule starts from zeroed buffers (schedule.rs:202-203); one slice per block of a
     //    generic K-batch.  generic_k: the FIR history rings were sized for the batch size in force when their node was
     //    activated — a later, larger kmax must not outrun them.
-    c->generic_k = c->kmax;
+    P.generic_k = P.kmax;
     for (int i = 0; i < N; ++i) {
         if (plan.nodes[i].kind != K_FIR) continue;
-        const HostNode& hn = c->graph.nodes[plan.nodes[i].slot];
-        uint64_t room = (hn.init.loop_end - (hn.init.loop_start - 1)) / c->mbf;  // (R - (T-1)) / block
-        c->generic_k = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->generic_k, room));
+        const NodeState hst = node_init(plan.nodes[i].slot);
+        uint64_t room = (hst.loop_end - (hst.loop_start - 1)) / c->mbf;  // (R - (T-1)) / block
+        P.generic_k = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(P.generic_k, room));
     }
     {
-        const size_t Kg = c->generic_k;
+        const size_t Kg = P.generic_k;
         size_t pool_bytes = Kg * (size_t)plan.num_buffers * c->stride * sizeof(float);
-        HIPC(c, c->d_pool.ensure(pool_bytes));
-        HIPC(c, hipMemset(c->d_pool.p, 0, pool_bytes));
+        HIPC(c, P.d_pool.ensure_n("d_pool", pool_bytes));
+        if ((rc = zero(c, P.d_pool.p, pool_bytes))) return rc;
         std::vector<uint8_t> fl(Kg * (size_t)plan.num_buffers, 0);
         for (size_t k = 0; k < Kg; ++k) fl[k * (size_t)plan.num_buffers] = 1;  // buffer 0: constant zero, always flagged silent
-        if ((rc = upload(c, c->d_flags, fl.data(), fl.size()))) return rc;
+        if ((rc = up(c, P.d_flags, fl.data(), fl.size()))) return rc;
     }
 
     // 5. fused voice-bank plan
-    c->fused = false;
-    c->hybrid = false;
-    c->fused_fx = false;
+    P.fused = false;
+    P.hybrid = false;
+    P.fused_fx = false;
     if (is_fused) {
-        c->fused_fx = fb.has_fx;
+        P.fused_fx = fb.has_fx;
         // k_chain tile = 64*nq frames: the larger tile needs whole tiles per block and every delay >= one tile
-        c->chain_nq = (c->mbf % 128 == 0 && fb.min_delay >= 128) ? 2 : 1;
+        P.chain_nq = (c->mbf % 128 == 0 && fb.min_delay >= 128) ? 2 : 1;
         if (const char* e = getenv("FWGPU_CHAIN_NQ")) {  // experiments: force the smaller tile
-            if (atoi(e) == 1) c->chain_nq = 1;
+            if (atoi(e) == 1) P.chain_nq = 1;
         }
-        c->n_voices = (int)fb.voices.size();
-        c->n_leaves = (int)fb.leaves.size();
-        c->n_bus = fb.n_bus;
-        c->ramp_slots = 2 * (1 + fb.max_stages);
-        if ((rc = upload(c, c->d_voices, fb.voices.data(), fb.voices.size() * sizeof(VoiceDesc)))) return rc;
-        if ((rc = upload(c, c->d_leaves, fb.leaves.data(), fb.leaves.size() * sizeof(LeafDesc)))) return rc;
-        if ((rc = upload(c, c->d_progs, fb.progs.data(), fb.progs.size() * sizeof(uint32_t)))) return rc;
-        c->fused_prog = fb.has_prog;
-        c->fused_rs = fb.has_rs;
-        c->n_groups = 0;
-        if (c->fused_fx) {
-            if ((rc = upload_chain_groups(c, fb.leaves))) return rc;
+        P.n_voices = (int)fb.voices.size();
+        P.n_leaves = (int)fb.leaves.size();
+        P.n_bus = fb.n_bus;
+        P.ramp_slots = 2 * (1 + fb.max_stages);
+        if ((rc = up(c, P.d_voices, fb.voices.data(), fb.voices.size() * sizeof(VoiceDesc)))) return rc;
+        if ((rc = up(c, P.d_leaves, fb.leaves.data(), fb.leaves.size() * sizeof(LeafDesc)))) return rc;
+        if ((rc = up(c, P.d_progs, fb.progs.data(), fb.progs.size() * sizeof(uint32_t)))) return rc;
+        P.fused_prog = fb.has_prog;
+        P.fused_rs = fb.has_rs;
+        P.n_groups = 0;
+        if (P.fused_fx) {
+            if ((rc = upload_chain_groups(c, P, fb.leaves))) return rc;
         }
-        const size_t K = c->kmax;
-        if ((rc = alloc_voice_tables(c))) return rc;
-        if (c->ctl_ahead && c->ctl_stream && !c->fused_fx && fb.tail_nodes.empty() && K > 1) {
+        const size_t K = P.kmax;
+        if ((rc = alloc_voice_tables(c, P))) return rc;
+        if (c->ctl_ahead && c->ctl_stream && !P.fused_fx && fb.tail_nodes.empty() && K > 1) {
             // the second copy of what the control kernel writes and the render kernels read
-            bool ok = c->d_blks2.ensure(K * c->n_voices * sizeof(VoiceBlk)) == hipSuccess &&
-                      c->d_refs2.ensure(ref_count(c->n_voices, K) * sizeof(VoiceRef)) == hipSuccess &&
-                      c->d_gsets2.ensure((size_t)c->n_voices * FW_GSETS * sizeof(GainSet)) == hipSuccess &&
-                      c->d_ramps2.ensure(K * c->n_voices * (size_t)c->ramp_slots * c->stride * sizeof(float)) == hipSuccess;
+            bool ok = P.d_blks2.ensure_n("d_blks2", K * P.n_voices * sizeof(VoiceBlk)) == hipSuccess &&
+                      P.d_refs2.ensure_n("d_refs2", ref_count(P.n_voices, K) * sizeof(VoiceRef)) == hipSuccess &&
+                      P.d_gsets2.ensure_n("d_gsets2", (size_t)P.n_voices * FW_GSETS * sizeof(GainSet)) == hipSuccess &&
+                      P.d_ramps2.ensure_n("d_ramps2", K * P.n_voices * (size_t)P.ramp_slots * c->stride * sizeof(float)) == hipSuccess;
             if (!ok) (void)hipGetLastError();
-            c->ctl_ahead_on = ok;
+            P.ctl_ahead_on = ok;
         }
-        size_t bus_bytes = K * (size_t)c->n_bus * c->stride * sizeof(float);
-        HIPC(c, c->d_bus.ensure(bus_bytes));
-        HIPC(c, hipMemset(c->d_bus.p, 0, bus_bytes));
-        std::vector<uint8_t> bf(K * c->n_bus, 0);
-        for (size_t k = 0; k < K; ++k) bf[k * c->n_bus] = 1;
-        if ((rc = upload(c, c->d_bus_flags, bf.data(), bf.size()))) return rc;
+        size_t bus_bytes = K * (size_t)P.n_bus * c->stride * sizeof(float);
+        HIPC(c, P.d_bus.ensure_n("d_bus", bus_bytes));
+        if ((rc = zero(c, P.d_bus.p, bus_bytes))) return rc;
+        std::vector<uint8_t> bf(K * P.n_bus, 0);
+        for (size_t k = 0; k < K; ++k) bf[k * P.n_bus] = 1;
+        if ((rc = up(c, P.d_bus_flags, bf.data(), bf.size()))) return rc;
         if (fb.up_nodes.empty()) {
             NodeDesc z;
             memset(&z, 0, sizeof(z));
@@ -494,86 +548,86 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
         }
         if (fb.up_in.empty()) fb.up_in.push_back(0);
         if (fb.up_out.empty()) fb.up_out.push_back(0);
-        if ((rc = upload(c, c->d_up_nodes, fb.up_nodes.data(), fb.up_nodes.size() * sizeof(NodeDesc)))) return rc;
-        if ((rc = upload(c, c->d_up_in, fb.up_in.data(), fb.up_in.size() * sizeof(int)))) return rc;
-        if ((rc = upload(c, c->d_up_out, fb.up_out.data(), fb.up_out.size() * sizeof(int)))) return rc;
+        if ((rc = up(c, P.d_up_nodes, fb.up_nodes.data(), fb.up_nodes.size() * sizeof(NodeDesc)))) return rc;
+        if ((rc = up(c, P.d_up_in, fb.up_in.data(), fb.up_in.size() * sizeof(int)))) return rc;
+        if ((rc = up(c, P.d_up_out, fb.up_out.data(), fb.up_out.size() * sizeof(int)))) return rc;
         std::vector<int> uflat;
-        c->up_level_off.clear();
-        c->up_level_cnt.clear();
+        P.up_level_off.clear();
+        P.up_level_cnt.clear();
         for (auto& l : fb.up_levels) {
-            c->up_level_off.push_back((int)uflat.size());
-            c->up_level_cnt.push_back((int)l.size());
+            P.up_level_off.push_back((int)uflat.size());
+            P.up_level_cnt.push_back((int)l.size());
             uflat.insert(uflat.end(), l.begin(), l.end());
         }
-        c->up_root_node = (!fb.up_levels.empty() && fb.up_levels.back().size() == 1) ? fb.up_levels.back()[0] : -1;
-        c->n_tail = (int)fb.tail_nodes.size();
-        c->tail_kinds.clear();
-        for (const NodeDesc& t : fb.tail_nodes) c->tail_kinds.push_back(host_kind_bits(t.kind));
-        if (c->n_tail) {
-            c->up_root_node = -1;  // the root's planar result feeds the master chain: no fused root + interleave
-            std::vector<int> idx(c->n_tail);
-            for (int i = 0; i < c->n_tail; ++i) idx[i] = i;
-            if ((rc = upload(c, c->d_tail_nodes, fb.tail_nodes.data(), fb.tail_nodes.size() * sizeof(NodeDesc)))) return rc;
-            if ((rc = upload(c, c->d_tail_in, fb.tail_in.data(), fb.tail_in.size() * sizeof(int)))) return rc;
-            if ((rc = upload(c, c->d_tail_out, fb.tail_out.data(), fb.tail_out.size() * sizeof(int)))) return rc;
-            if ((rc = upload(c, c->d_tail_idx, idx.data(), idx.size() * sizeof(int)))) return rc;
-            HIPC(c, c->d_tail_frozen.ensure((size_t)c->n_tail * 16));  // (also a dummy playhead-snapshot area)
+        P.up_root_node = (!fb.up_levels.empty() && fb.up_levels.back().size() == 1) ? fb.up_levels.back()[0] : -1;
+        P.n_tail = (int)fb.tail_nodes.size();
+        P.tail_kinds.clear();
+        for (const NodeDesc& t : fb.tail_nodes) P.tail_kinds.push_back(host_kind_bits(t.kind));
+        if (P.n_tail) {
+            P.up_root_node = -1;  // the root's planar result feeds the master chain: no fused root + interleave
+            std::vector<int> idx(P.n_tail);
+            for (int i = 0; i < P.n_tail; ++i) idx[i] = i;
+            if ((rc = up(c, P.d_tail_nodes, fb.tail_nodes.data(), fb.tail_nodes.size() * sizeof(NodeDesc)))) return rc;
+            if ((rc = up(c, P.d_tail_in, fb.tail_in.data(), fb.tail_in.size() * sizeof(int)))) return rc;
+            if ((rc = up(c, P.d_tail_out, fb.tail_out.data(), fb.tail_out.size() * sizeof(int)))) return rc;
+            if ((rc = up(c, P.d_tail_idx, idx.data(), idx.size() * sizeof(int)))) return rc;
+            HIPC(c, P.d_tail_frozen.ensure_n("d_tail_frozen", (size_t)P.n_tail * 16));  // (also a dummy playhead-snapshot area)
         }
-        if (c->up_root_node >= 0) {
-            const NodeDesc& rn = fb.up_nodes[c->up_root_node];
+        if (P.up_root_node >= 0) {
+            const NodeDesc& rn = fb.up_nodes[P.up_root_node];
             if (rn.n_out == 2 && rn.n_in >= 2 && rn.n_in <= 64 && rn.n_in % 2 == 0) {
-                memset(&c->root_args, 0, sizeof(c->root_args));
-                c->root_args.n_in = rn.n_in;
-                c->root_args.ports = rn.n_in / 2;
-                for (int i = 0; i < rn.n_in; ++i) c->root_args.in_buf[i] = fb.up_in[rn.in_off + i];
-                c->root_args.in_tab = c->d_up_in.as<int>() + rn.in_off;
+                memset(&P.root_args, 0, sizeof(P.root_args));
+                P.root_args.n_in = rn.n_in;
+                P.root_args.ports = rn.n_in / 2;
+                for (int i = 0; i < rn.n_in; ++i) P.root_args.in_buf[i] = fb.up_in[rn.in_off + i];
+                P.root_args.in_tab = P.d_up_in.as<int>() + rn.in_off;
             } else {
-                c->up_root_node = -1;
+                P.up_root_node = -1;
             }
         }
         if (uflat.empty()) uflat.push_back(0);
-        if ((rc = upload(c, c->d_up_level_nodes, uflat.data(), uflat.size() * sizeof(int)))) return rc;
-        if ((rc = upload(c, c->d_root_bufs, fb.root_buf, sizeof(fb.root_buf)))) return rc;
-        c->fused = true;
-        c->n_fused_real = 0;
-        for (const VoiceDesc& vd : fb.voices) c->n_fused_real += vd.sampler_state >= 0 ? 1 : 0;
+        if ((rc = up(c, P.d_up_level_nodes, uflat.data(), uflat.size() * sizeof(int)))) return rc;
+        if ((rc = up(c, P.d_root_bufs, fb.root_buf, sizeof(fb.root_buf)))) return rc;
+        P.fused = true;
+        P.n_fused_real = 0;
+        for (const VoiceDesc& vd : fb.voices) P.n_fused_real += vd.sampler_state >= 0 ? 1 : 0;
     }
     // 5b. hybrid plan: not a fused shape as a whole, but with voice banks inside that the fused kernels render
     // straight into their mixers' pool buffers; the level executor then runs the rest.
-    c->hybrid_fx = false;
+    P.hybrid_fx = false;
     if (is_hybrid) {
-        c->n_voices = (int)hb.voices.size();
-        c->n_leaves = (int)hb.leaves.size();
-        c->ramp_slots = 2 * (1 + hb.max_stages);
-        c->fused_prog = hb.has_prog;
-        c->fused_rs = hb.has_rs;
-        c->n_groups = 0;
-        c->hybrid_fx = hb.has_fx;
-        if (c->hybrid_fx) {  // the banks go through k_chain: its workgroups, its tile size, at most 64 blocks per launch
-            if ((rc = upload_chain_groups(c, hb.leaves))) return rc;
-            c->chain_nq = (c->mbf % 128 == 0 && hb.min_delay >= 128) ? 2 : 1;
+        P.n_voices = (int)hb.voices.size();
+        P.n_leaves = (int)hb.leaves.size();
+        P.ramp_slots = 2 * (1 + hb.max_stages);
+        P.fused_prog = hb.has_prog;
+        P.fused_rs = hb.has_rs;
+        P.n_groups = 0;
+        P.hybrid_fx = hb.has_fx;
+        if (P.hybrid_fx) {  // the banks go through k_chain: its workgroups, its tile size, at most 64 blocks per launch
+            if ((rc = upload_chain_groups(c, P, hb.leaves))) return rc;
+            P.chain_nq = (c->mbf % 128 == 0 && hb.min_delay >= 128) ? 2 : 1;
             if (const char* e = getenv("FWGPU_CHAIN_NQ")) {
-                if (atoi(e) == 1) c->chain_nq = 1;
+                if (atoi(e) == 1) P.chain_nq = 1;
             }
-            c->generic_k = std::min<uint32_t>(c->generic_k, CH_FAST_KMAX);
+            P.generic_k = std::min<uint32_t>(P.generic_k, CH_FAST_KMAX);
         }
-        c->n_tail = 0;
-        c->up_root_node = -1;
-        c->up_level_off.clear();
-        c->up_level_cnt.clear();
-        if ((rc = upload(c, c->d_voices, hb.voices.data(), hb.voices.size() * sizeof(VoiceDesc)))) return rc;
-        if ((rc = upload(c, c->d_leaves, hb.leaves.data(), hb.leaves.size() * sizeof(LeafDesc)))) return rc;
-        if ((rc = upload(c, c->d_progs, hb.progs.data(), hb.progs.size() * sizeof(uint32_t)))) return rc;
-        if ((rc = alloc_voice_tables(c))) return rc;
+        P.n_tail = 0;
+        P.up_root_node = -1;
+        P.up_level_off.clear();
+        P.up_level_cnt.clear();
+        if ((rc = up(c, P.d_voices, hb.voices.data(), hb.voices.size() * sizeof(VoiceDesc)))) return rc;
+        if ((rc = up(c, P.d_leaves, hb.leaves.data(), hb.leaves.size() * sizeof(LeafDesc)))) return rc;
+        if ((rc = up(c, P.d_progs, hb.progs.data(), hb.progs.size() * sizeof(uint32_t)))) return rc;
+        if ((rc = alloc_voice_tables(c, P))) return rc;
         // the level lists without the nodes the voice-bank kernels render
         std::vector<char> cov(N, 0);
         for (int i : hb.covered) cov[i] = 1;
         std::vector<int> hflat;
-        c->hlevel_off.clear();
-        c->hlevel_cnt.clear();
-        c->hlevel_kinds.clear();
+        P.hlevel_off.clear();
+        P.hlevel_cnt.clear();
+        P.hlevel_kinds.clear();
         for (auto& l : levels) {
-            c->hlevel_off.push_back((int)hflat.size());
+            P.hlevel_off.push_back((int)hflat.size());
             int kinds = 0, cnt = 0;
             for (int i : l)
                 if (!cov[i]) {
@@ -581,42 +635,251 @@ static int install_plan_impl(fwgpu_ctx* c, Plan& plan, bool* tables_touched) {
                     kinds |= host_kind_bits(nd[i].kind);
                     cnt++;
                 }
-            c->hlevel_cnt.push_back(cnt);
-            c->hlevel_kinds.push_back(kinds);
+            P.hlevel_cnt.push_back(cnt);
+            P.hlevel_kinds.push_back(kinds);
         }
         if (hflat.empty()) hflat.push_back(0);
-        if ((rc = upload(c, c->d_hlevel_nodes, hflat.data(), hflat.size() * sizeof(int)))) return rc;
-        c->hybrid = true;
-        c->n_fused_real = 0;
-        for (const VoiceDesc& vd : hb.voices) c->n_fused_real += vd.sampler_state >= 0 ? 1 : 0;
+        if ((rc = up(c, P.d_hlevel_nodes, hflat.data(), hflat.size() * sizeof(int)))) return rc;
+        P.hybrid = true;
+        P.n_fused_real = 0;
+        for (const VoiceDesc& vd : hb.voices) P.n_fused_real += vd.sampler_state >= 0 ? 1 : 0;
     }
     // k_frozen_scan's verdict tables (generic executor, K > 1): sized here, on the control thread — a process call never
     // allocates
-    HIPC(c, c->d_frozen.ensure(nd.size()));
-    HIPC(c, c->d_frozen_ph.ensure(nd.size() * sizeof(unsigned long long)));
-    c->plan = plan;
-    c->have_plan = true;
+    HIPC(c, P.d_frozen.ensure_n("d_frozen", nd.size()));
+    HIPC(c, P.d_frozen_ph.ensure_n("d_frozen_ph", nd.size() * sizeof(unsigned long long)));
+    P.slot_index.assign(c->graph.nodes.size(), -1);
+    for (int i = 0; i < N; ++i)
+        if (plan.nodes[i].slot < P.slot_index.size()) P.slot_index[plan.nodes[i].slot] = i;
+    P.plan = plan;
+    P.have_plan = true;
+    HIPC(c, hipStreamSynchronize(c->up_stream));  // every table and every zeroed pool of the image is in place
+    // ---- commit the control side's own bookkeeping: from here on the image WILL be adopted
+    for (const Act& a : acts) {
+        HostNode& n = c->graph.nodes[a.slot];
+        n.init = a.st;
+        n.activated = true;
+        P.activated.emplace_back(a.slot, c->graph.id_of(a.slot));
+    }
+    for (auto& kv : new_ir) {
+        c->ir_cache[kv.first] = kv.second;
+        c->ir_len[kv.first] = (uint32_t)c->samples[kv.first.first].desc.frames;
+    }
+    c->ext_used = ext_need;
+    if (P.grow_states.p) c->ctl_states_cap = P.grow_states_cap;
+    if (P.grow_ext.p) c->ctl_ext_cap = P.grow_ext_cap;
+    c->graph.nodes_to_activate.clear();
+    P.dropped_samplers.swap(c->dropped_samplers_ctl);
+    c->dropped_samplers_ctl.clear();
+    P.removed_slots.swap(c->pending_removed);
+    c->pending_removed.clear();
     c->graph.needs_compile = false;
+    rollback.armed = false;
     return 0;
 }
 
-// A failure before the device tables are touched (node activation: a destroyed impulse response, an exhausted ext pool,
-// a HIP error while scattering initial states) leaves the previous plan installed and valid, like the reference keeps its
-// schedule when a compile fails (context.rs:115-131).  A failure after that point (only HIP errors: out of memory) has
-// overwritten part of the old plan's tables: the ctx then has NO plan — process calls output silence (processor.rs:86-89)
-// — and stays dirty, so the next fwgpu_update builds everything again.
-int install_plan(fwgpu_ctx* c, Plan& plan) {
-    bool touched = false;
-    const int rc = install_plan_impl(c, plan, &touched);
-    if (rc != 0 && touched) {
-        c->have_plan = false;
-        c->fused = false;
-        c->hybrid = false;
-        c->hybrid_fx = false;
-        c->graph.needs_compile = true;
-        c->epoch++;
+// ---------------------------------------------------------------------------------------------------------------- hand-over
+// Make `n` the active image.  Whoever calls holds the gate: the audio thread at the start of a process call, or the control
+// thread when it found the audio side idle.  Nothing here allocates, waits for the device or can fail in a way that leaves
+// the ctx half-swapped: the persistent state's changes are asynchronous launches on the ctx stream (ordered before whatever
+// the next process call enqueues), the rest is member swaps and small host loops.
+void adopt_image(fwgpu_ctx* c, PlanImage* n, bool on_audio_thread) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != c->device) (void)hipSetDevice(c->device);
+    (void)join_streams(c);  // control-ahead mode: the control stream's work so far is ordered before the swap
+    c->ahead_seq = 0;
+    // 1. larger persistent arrays: old contents copied over on the stream, then the pointers change hands
+    if (n->grow_states.p) {
+        if (c->d_states.p && c->states_cap)
+            (void)hipMemcpyAsync(n->grow_states.p, c->d_states.p, c->states_cap * sizeof(NodeState), hipMemcpyDeviceToDevice, c->stream);
+        std::swap(c->d_states, n->grow_states);  // (the old array rides back in the retired image and is freed there)
+        c->states_cap = n->grow_states_cap;
     }
-    return rc;
+    if (n->grow_ext.p) {
+        if (c->d_ext.p && c->ext_cap)
+            (void)hipMemcpyAsync(n->grow_ext.p, c->d_ext.p, c->ext_cap * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+        std::swap(c->d_ext, n->grow_ext);
+        c->ext_cap = n->grow_ext_cap;
+    }
+    // 2. the nodes this image activates (graph.rs:594-612): ext slices zeroed / initialised, impulse responses converted,
+    //    initial states scattered — into slots and slices no running plan uses
+    if (n->n_ext_jobs || n->n_state_inits)
+        (void)launch_adopt_init(c->stream, c->d_ext.as<float>(), n->d_ext_jobs.p, n->n_ext_jobs, c->d_states.as<NodeState>(), n->d_state_inits.p,
+                                n->n_state_inits);
+    if (!n->ir_convs.empty()) {
+        (void)upload_sample_table(c);
+        for (const PlanImage::IrConv& ic : n->ir_convs)
+            (void)launch_ir_convert(c->stream, c->d_samples.as<SampleDesc>(), ic.sample, ic.ch, c->d_ext.as<float>() + ic.off, ic.T);
+    }
+
+    // 3. sampler bookkeeping (audio-side tables).  A removed sampler's processor is dropped with the old schedule and hands
+    //    its sample back (sampler.rs:563-571); a newly activated node starts without one; messages still queued for a removed
+    //    node go with it (its slot — the message key — is reused only after this swap)
+    if (n->grow_cur_sample.size() > c->cur_sample.size()) {
+        std::copy(c->cur_sample.begin(), c->cur_sample.end(), n->grow_cur_sample.begin());
+        std::copy(c->slot_ids.begin(), c->slot_ids.end(), n->grow_slot_ids.begin());
+        c->cur_sample.swap(n->grow_cur_sample);
+        c->slot_ids.swap(n->grow_slot_ids);
+    }
+    auto hand_back = [&](int sample) {  // "silent" return: the control side's reference count drops, nothing is reported
+        RetItem it;
+        it.node = RET_SILENT;
+        it.sample = sample;
+        it.ticket = c->ret_ticket;
+        if (c->returns.stage(it)) c->ret_this_call = true;
+    };
+    for (uint32_t slot : n->dropped_samplers)
+        if (slot < c->cur_sample.size()) {
+            if (c->cur_sample[slot] >= 0) hand_back(c->cur_sample[slot]);
+            c->cur_sample[slot] = -1;
+        }
+    if (!n->removed_slots.empty()) {
+        drain_ring(c);  // (the gate makes this thread the ring's consumer: messages not drained yet are filtered too)
+        size_t w = 0;
+        for (const Cmd& m : c->cmds) {
+            bool gone = false;
+            for (uint32_t slot : n->removed_slots) gone = gone || m.state == (int)slot;
+            if (gone) {
+                if (m.type == CMD_SMP_SET_SAMPLE && m.i0 >= 0) hand_back(m.i0);  // never reached its sampler: handed straight back
+                continue;
+            }
+            c->cmds[w++] = m;
+        }
+        c->cmds.resize(w);
+    }
+    for (const auto& a : n->activated)
+        if (a.first < c->cur_sample.size()) {
+            c->cur_sample[a.first] = -1;
+            c->slot_ids[a.first] = a.second;
+        }
+    if (c->ret_this_call) finish_returns(c);  // (completion event on the ctx stream: the old plan's kernels are in front of it)
+    // 4. the swap
+    std::swap(static_cast<PlanImage&>(*c), *n);
+    std::swap(c->retired_ev, n->retired_ev);  // (the event belongs to the heap object that travels through the ring)
+    c->epoch++;  // cached steady descriptors belong to the old plan
+    c->adopted_gen.store(c->gen, std::memory_order_release);
+    // 5. the old image goes back to the control side, which waits for `retired_ev` before it touches the buffers
+    if (n->retired_ev) (void)hipEventRecord(n->retired_ev, c->stream);  // (created with the object, on the control thread)
+    const uint32_t t = c->retired_tail.load(std::memory_order_relaxed);
+    if (t - c->retired_head.load(std::memory_order_acquire) < fwgpu_ctx::RETIRE_CAP) {
+        c->retired[t % fwgpu_ctx::RETIRE_CAP] = n;
+        c->retired_tail.store(t + 1, std::memory_order_release);
+    }  // (a full ring cannot happen: the control side collects before every build and at most one image is pending)
+    const uint64_t ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (on_audio_thread) {
+        if (ns > c->adopt_ns_max) c->adopt_ns_max = ns;
+        c->audio_adoptions++;
+    }
+    c->adoptions++;
+}
+
+// control side: what became reusable now that image `gen` is the active one — slots and ext slices of removed nodes
+static void release_limbo(fwgpu_ctx* c, uint64_t gen) {
+    size_t w = 0;
+    for (const fwgpu_ctx::Limbo& l : c->limbo) {
+        if (l.gen > gen) {
+            c->limbo[w++] = l;
+            continue;
+        }
+        if (l.what == 0) c->graph.free_nodes.push_back(l.a);
+        else c->ext_free[(size_t)l.b].push_back(l.a);
+    }
+    c->limbo.resize(w);
+}
+
+// control side: images the audio side is done with.  Waits for their kernels (the control thread may block), keeps one as
+// the next build target — its buffers are reused, steady edits allocate nothing — and frees the rest.
+void collect_retired(fwgpu_ctx* c) {
+    for (;;) {
+        const uint32_t h = c->retired_head.load(std::memory_order_relaxed);
+        if (h == c->retired_tail.load(std::memory_order_acquire)) break;
+        PlanImage* img = c->retired[h % fwgpu_ctx::RETIRE_CAP];
+        c->retired_head.store(h + 1, std::memory_order_release);
+        if (img->retired_ev) (void)hipEventSynchronize(img->retired_ev);
+        else (void)hipStreamSynchronize(c->stream);
+        img->grow_states.release();  // (after a swap these hold the OLD arrays)
+        img->grow_ext.release();
+        if (!c->spare) {
+            c->spare = img;
+        } else {
+            img->release_device();
+            delete img;
+        }
+    }
+    release_limbo(c, c->adopted_gen.load(std::memory_order_acquire));
+}
+
+static bool try_adopt_from_control(fwgpu_ctx* c, PlanImage* img) {
+    // FWGPU_LAZY_ADOPT=1 (tests): never adopt on the control thread — every plan is picked up by the next process call, the
+    // path a host with a running audio thread takes; the whole GPU suite is run in this mode too
+    static const bool lazy = getenv("FWGPU_LAZY_ADOPT") && atoi(getenv("FWGPU_LAZY_ADOPT")) != 0;
+    if (lazy) return false;
+    int expected = 0;
+    if (!c->gate.compare_exchange_strong(expected, 2, std::memory_order_acquire)) return false;
+    adopt_image(c, img, false);
+    c->gate.store(0, std::memory_order_release);
+    return true;
+}
+
+// Hand the image to the audio side.  At most one image waits at a time: an earlier one that no process call has picked up yet
+// is adopted first (in order — each image carries what ITS adoption must do to the persistent state).
+static void publish(fwgpu_ctx* c, PlanImage* img) {
+    for (;;) {
+        PlanImage* prev = c->pending.load(std::memory_order_acquire);
+        if (!prev) break;
+        int expected = 0;
+        if (c->gate.compare_exchange_strong(expected, 2, std::memory_order_acquire)) {
+            prev = c->pending.exchange(nullptr, std::memory_order_acq_rel);
+            if (prev) adopt_image(c, prev, false);
+            c->gate.store(0, std::memory_order_release);
+            break;
+        }
+        std::this_thread::yield();  // a process call is running: it (or the next one) takes the pending image at its start
+    }
+    for (const Cmd& m : c->early_msgs) (void)c->ring.push(m);  // messages sent to nodes before the update that activates them
+    c->early_msgs.clear();
+    if (!try_adopt_from_control(c, img)) c->pending.store(img, std::memory_order_release);
+    collect_retired(c);
+}
+
+// fwgpu_update / fwgpu_schedule_upload: build off to the side, publish.  A failure leaves the active plan (and a pending one)
+// exactly as they were, like the reference keeps its schedule when a compile fails (context.rs:115-131).
+int install_plan(fwgpu_ctx* c, Plan& plan) {
+    if (!c->up_stream) {  // the build's uploads and memsets: lowest priority, so that they give way to the audio stream's kernels
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, lo) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPC(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+        }
+    }
+    collect_retired(c);
+    PlanImage* P = c->spare;
+    c->spare = nullptr;
+    if (!P) {
+        P = new (std::nothrow) PlanImage();
+        if (!P) return fail(c, FWGPU_ERR_DEVICE, "out of host memory");
+        if (hipEventCreateWithFlags(&P->retired_ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            P->retired_ev = nullptr;  // (collect_retired then waits for the whole stream instead)
+        }
+    }
+    const int rc = build_image(c, plan, *P);
+    if (rc != 0) {
+        (void)hipStreamSynchronize(c->up_stream);
+        (void)hipGetLastError();
+        c->spare = P;  // (its buffers are reusable whatever state the build left them in)
+        return rc;
+    }
+    // the control side's mirror of what the introspection calls report
+    c->info.have_plan = true;
+    c->info.kind = c->force_generic ? 0 : (P->fused ? (P->fused_fx ? 2 : 1) : (P->hybrid ? 3 : 0));
+    c->info.fused_voices = (c->force_generic || !(P->fused || P->hybrid)) ? 0 : P->n_fused_real;
+    c->info.n_host_nodes = P->n_host_nodes;
+    c->info.plan = P->plan;
+    publish(c, P);
+    return 0;
 }
 
 }  // namespace fwgpu

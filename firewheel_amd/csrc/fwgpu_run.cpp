@@ -38,7 +38,7 @@ int hipfail(fwgpu_ctx* c, hipError_t e, const char* what) {
 }
 
 int upload(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes) {
-    HIPC(c, b.ensure(bytes));
+    HIPC(c, b.ensure_n("b", bytes));
     if (bytes) HIPC(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
     return 0;
 }
@@ -61,7 +61,7 @@ int upload_sample_table(fwgpu_ctx* c) {
     HIPC(c, hipStreamSynchronize(c->stream));
     if (c->ctl_stream) HIPC(c, hipStreamSynchronize(c->ctl_stream));
     const size_t bytes = c->h_sample_tab.size() * sizeof(SampleDesc);
-    HIPC(c, c->d_samples.ensure(bytes));  // (already large enough: sized where the table changed)
+    HIPC(c, c->d_samples.ensure_n("d_samples", bytes));  // (already large enough: sized where the table changed)
     HIPC(c, hipMemcpy(c->d_samples.p, c->h_sample_tab.data(), bytes, hipMemcpyHostToDevice));
     return 0;
 }
@@ -277,7 +277,7 @@ static void fill_fused_view(fwgpu_ctx* c, FusedView& fv) {
     fv.chain_stats = c->d_chain_stats.as<unsigned long long>();
     fv.trace = nullptr;
 #ifdef FW_CHAIN_TRACE
-    if (c->d_trace.ensure(64 * 16 * 8 * sizeof(unsigned long long)) == hipSuccess) fv.trace = c->d_trace.as<unsigned long long>();
+    if (c->d_trace.ensure_n("d_trace", 64 * 16 * 8 * sizeof(unsigned long long)) == hipSuccess) fv.trace = c->d_trace.as<unsigned long long>();
 #endif
     {
         static const int dbg = getenv("FWGPU_CHAIN_SKIP") ? atoi(getenv("FWGPU_CHAIN_SKIP")) : 0;
@@ -332,8 +332,8 @@ int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const
     DevView v = generic_view(c, frames);
     // which gain-like stateful nodes cannot change during this batch (their blocks then run in parallel): decided once,
     // before the first level
-    if (K > 1 && c->d_frozen.ensure((size_t)c->plan.nodes.size()) == hipSuccess &&
-        c->d_frozen_ph.ensure((size_t)c->plan.nodes.size() * sizeof(unsigned long long)) == hipSuccess) {
+    if (K > 1 && c->d_frozen.ensure_n("d_frozen", (size_t)c->plan.nodes.size()) == hipSuccess &&
+        c->d_frozen_ph.ensure_n("d_frozen_ph", (size_t)c->plan.nodes.size() * sizeof(unsigned long long)) == hipSuccess) {
         LCHK(c, launch_frozen_scan(c->stream, v, (int)c->plan.nodes.size(), cmd_block, K, c->d_frozen.as<uint8_t>(),
                                    c->d_frozen_ph.as<unsigned long long>()));
         v.frozen = c->d_frozen.as<uint8_t>();

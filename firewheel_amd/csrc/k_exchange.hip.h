@@ -13,8 +13,8 @@
 //   k_bus_reduce  the launch behind it adds the R slots in rank order with the reference's SumNode semantics — all silent -> cleared; 1 port -> copy; 2/3/4 ports -> unmasked adds;
 //                 otherwise out = in0, then += in_p skipping SILENT ports (sum.rs:111-133, Q13).
 // Every rank ends with the bits of the single-process graph whose top node is that SumNode: the order is the port order,
-// nothing is re-associated (an all-reduce ring re-associates for R > 2).  The regions are uncached device memory
-// (hipDeviceMallocUncached): what a peer stored is what the next load sees, no L2 in between on either side.
+// nothing is re-associated (an all-reduce ring re-associates for R > 2).  The regions are fine-grained device
+// memory (hipDeviceMallocFinegrained): coherent between agents under the system-scope release / acquire used here.
 //
 // Two data parities (seq & 1): rank g may run push(s+1) while a peer still reads step s.  push(s+2) overwrites parity s —
 // by then every peer has finished reduce(s): push and reduce of one rank are stream-ordered, my push(s+2) follows my
@@ -127,7 +127,7 @@ __device__ __forceinline__ v4f ordered_sum_quad(int world, size_t i4, uint32_t b
 }
 
 // Wait for the R arrivals of step `seq`: ONE wave, lane p polls peer p's arrival word (system-scope acquire loads of this
-// rank's own uncached region, s_sleep between polls).  One wave, not the reduce grid: a grid of spinning workgroups holds
+// rank's own fine-grained region, s_sleep between polls).  One wave, not the reduce grid: a grid of spinning workgroups holds
 // wave slots the peers' render kernels may need — with several ranks time-sharing one device (tests, bench.py --share-device)
 // the spinners of N-1 ranks starve the rank everybody is waiting for.  Bounded by a wall-clock budget (s_memrealtime, 100 MHz):
 // a peer that never arrives turns into an error word + a zero bus, never a hung GPU.  `sync` (device-local):
@@ -284,4 +284,29 @@ __global__ __launch_bounds__(256) void k_host_scatter(float* __restrict__ pool, 
     const int b = bufs[j];
     if (f < frames) pool[(size_t)k * pool_blk_stride + (size_t)b * stride + f] = stage[((size_t)k * row_pitch + j) * stride + f];
     if (f == 0) flags[(size_t)k * flags_blk_stride + b] = stage_flags[(size_t)k * row_pitch + j];
+}
+
+// Plan adoption — everything the nodes an image activates need written into the state that outlives plans, in ONE launch
+// (adoption runs at the start of a process call: every launch is host time of the audio thread):
+//   blockIdx.y <  n_jobs : ext-pool job j — a slice handed to a new node: `zero_len` floats zeroed (a recycled slice starts from
+//                          zeros like a fresh one; 0 for fresh ones, which are zero already) with the first n_head floats set
+//                          (biquad coefficients) — one job owns its slice, so the two cannot race
+//   blockIdx.y == n_jobs : the nodes' initial NodeState records (graph.rs:594-612 activate), one thread per record
+struct AdoptExtJob {
+    uint32_t off, zero_len, n_head, pad;
+    float head[8];
+};
+static_assert(sizeof(AdoptExtJob) == 48, "AdoptExtJob layout");
+__global__ __launch_bounds__(256) void k_adopt_init(float* __restrict__ ext, const AdoptExtJob* __restrict__ jobs, int n_jobs,
+                                                    NodeState* __restrict__ states, const uint8_t* __restrict__ inits, int n_inits) {
+    if ((int)blockIdx.y < n_jobs) {
+        const AdoptExtJob j = jobs[blockIdx.y];
+        const uint32_t n = j.zero_len > j.n_head ? j.zero_len : j.n_head;
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) ext[(size_t)j.off + i] = i < j.n_head ? j.head[i] : 0.f;
+        return;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_inits; i += gridDim.x * blockDim.x) {
+        const StateInit* in = (const StateInit*)inits + i;
+        states[in->index] = in->st;
+    }
 }

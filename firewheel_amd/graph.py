@@ -432,6 +432,12 @@ class FirewheelGpuCtx(object):
         n = self._check(self.L.fwgpu_plan_node_inputs_clear(self.c, node_id, buf, 64))
         return [bool(buf[i]) for i in range(n)]
 
+    def plan_handover_stats(self):
+        """(plans adopted so far, those adopted by a process call, the longest one of those held up its call in ns)"""
+        a, b, m = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self.L.fwgpu_plan_handover_stats(self.c, C.byref(a), C.byref(b), C.byref(m)))
+        return a.value, b.value, m.value
+
     def plan_chain_stats(self):
         """(steady, general): k_chain workgroup launches that ran the steady-call loop / the general loop"""
         a, b = C.c_uint64(0), C.c_uint64(0)

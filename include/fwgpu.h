@@ -13,10 +13,13 @@
  *     audio MESSAGE calls (fwgpu_node_set_param, fwgpu_sampler_*) may run on any thread WHILE a process call is in
  *     flight: they validate against the graph and push into a lock-free ring the audio side drains at the start of
  *     its next call (the reference's Arc<AtomicF32> gains and rtrb rings: nodes/volume.rs:10,28-34,
- *     nodes/sampler.rs:14,171-177,205-208); neither side locks, allocates or waits for the other.  Calls that change
- *     the graph, the schedule or the sample table (add/remove/connect/update/schedule_upload/sample_create/
- *     sample_destroy/set_max_batch) must not overlap a process call — the reference hands a new schedule over through
- *     a ring; here the host serialises the two.
+ *     nodes/sampler.rs:14,171-177,205-208); neither side locks, allocates or waits for the other.  The GRAPH
+ *     calls (add_node / remove_node / connect / disconnect / host_node_set_process / update / schedule_upload), made from
+ *     ONE control thread at a time, may ALSO overlap process calls: update builds the new plan off to the side and the
+ *     next process call adopts it at its start, as the reference hands a new schedule over through a ring
+ *     (graph/processor.rs:167-206; fwgpu_plan_handover_stats).  The control side itself is one thread at a time: a message
+ *     call must not run concurrently with a graph call on another thread (it looks the node up in the graph).  Only the sample-table and configuration calls
+ *     (sample_create / sample_destroy / set_max_batch / set_force_generic) must still not overlap a process call.
  *   - once warm, a process call touches neither the host allocator nor the device allocator; a failing call writes its
  *     message into a fixed buffer.  fwgpu_process_interleaved fills `output` on EVERY return (zeros on error:
  *     core/node.rs:41-42).
@@ -158,6 +161,14 @@ int fwgpu_plan_node_inputs_clear(fwgpu_ctx* ctx, int64_t node, int* should_clear
 /* chain plan (kind 2) only: k_chain workgroup launches since the plan was installed that ran the steady-call loop
  * (every voice of the leaf steady for the whole call, delays >= 3 tiles, no message pending) / the general loop */
 int fwgpu_plan_chain_stats(fwgpu_ctx* ctx, uint64_t* steady_workgroups, uint64_t* general_workgroups);
+/* Plan hand-over (graph/context.rs:93-137 + graph/processor.rs:167-206).  fwgpu_update / fwgpu_schedule_upload BUILD the new
+ * plan on the calling (control) thread, off to the side, while process calls keep running on the current one; the next process
+ * call adopts it at its start — a swap of descriptors plus a handful of asynchronous launches for the nodes it activates, no
+ * allocation, no wait for the device — and the old plan travels back to the control side, whose next update reuses its
+ * buffers.  (When no process call is in flight the updating thread adopts the plan itself, right away.)  *adoptions = plans
+ * adopted so far, *audio_adoptions = those a process call adopted, *max_adopt_ns = the longest one of THOSE held up its process
+ * call (host nanoseconds).  Any pointer may be NULL. */
+int fwgpu_plan_handover_stats(fwgpu_ctx* ctx, uint64_t* adoptions, uint64_t* audio_adoptions, uint64_t* max_adopt_ns);
 /* K = the most blocks one fused launch sequence processes (default 64); sizes the K-batched descriptor,
  * ramp and bus buffers at the next fwgpu_update. */
 int fwgpu_set_max_batch(fwgpu_ctx* ctx, uint32_t max_blocks);
@@ -246,7 +257,7 @@ int fwgpu_bus_sum_ordered_flags(fwgpu_ctx* ctx, const float* const* d_parts, con
  * is point-to-point, every GPU of a node has a direct link to every other, so each rank STORES its partial bus into its slot
  * on every rank and then each rank adds the R slots it holds in rank order: one link hop instead of the 2(R-1) steps of a
  * ring, and bit-identical to the single-process graph on every rank).
- *   open     (control side) one region of uncached HBM on the ctx's device: R slots of max_floats floats + max_silence_bytes
+ *   open     (control side) one region of fine-grained HBM on the ctx's device: R slots of max_floats floats + max_silence_bytes
  *            flags, twice (step parity), and R arrival words.  Every rank of an exchange passes the same world and sizes.
  *   export   this rank's FWGPU_EXCHANGE_HANDLE_BYTES-byte handle; the host carries it to the peers by whatever channel it
  *            has (a file, a pipe, MPI_Allgather, torch.distributed.all_gather_object ...).

@@ -341,6 +341,25 @@ int launch_host_scatter(hipStream_t, float* pool, uint8_t* flags, int stride, si
     touch(d_stage_flags, (size_t)(K - 1) * row_pitch + n);
     return 0;
 }
+int launch_adopt_init(hipStream_t, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits) {
+    g_launches[7]++;
+    const AdoptExtJobHost* jobs = (const AdoptExtJobHost*)d_jobs;
+    touch(d_jobs, sizeof(AdoptExtJobHost) * (size_t)n_jobs);
+    for (int i = 0; i < n_jobs; ++i) {
+        REQUIRE(jobs[i].zero_len % 64 == 0 && jobs[i].n_head <= 8 && (jobs[i].zero_len || jobs[i].n_head), i);
+        const size_t n = jobs[i].zero_len > jobs[i].n_head ? jobs[i].zero_len : jobs[i].n_head;
+        touch(ext + jobs[i].off, sizeof(float) * n);
+        for (size_t k = 0; k < n; ++k) ext[jobs[i].off + k] = k < jobs[i].n_head ? jobs[i].head[k] : 0.f;
+    }
+    const StateInitHost* in = (const StateInitHost*)d_inits;
+    touch(d_inits, sizeof(StateInitHost) * (size_t)n_inits);
+    for (int i = 0; i < n_inits; ++i) {
+        REQUIRE(in[i].index >= 0, in[i].index);
+        touch(&states[in[i].index], sizeof(NodeState));
+        states[in[i].index] = in[i].st;
+    }
+    return 0;
+}
 int launch_out_flags(hipStream_t, const uint8_t* flags, size_t flags_blk_stride, const int* d_bufs, int n_bufs, int mode, int n_out_ch, int K,
                      uint8_t* d_out) {
     g_launches[7]++;

@@ -4,6 +4,11 @@
 //   rt_driver tsan   (built -fsanitize=thread)  two control threads send gain / pan / sampler messages for their own
 //                    nodes while the audio thread runs one-block callbacks: the message ring, the drain epoch, the
 //                    error buffers and the return ring must be free of data races, and no message may be lost.
+//   rt_driver edits  (built -fsanitize=thread, or -DCOUNT_ALLOCS)  an EDITOR thread adds voice chains into spare mixer ports,
+//                    updates, starts them, removes them again, updates — while the audio thread runs callbacks and another
+//                    control thread sends messages to the standing voices: the plan hand-over (fwgpu_update builds off to
+//                    the side, the next callback adopts: graph/processor.rs:167-206) must be free of data races, every
+//                    callback must succeed, and adopting must not touch the host allocator on the audio thread.
 //   rt_driver alloc  (built -DCOUNT_ALLOCS: malloc / calloc / realloc / free of the whole process forwarded to glibc
 //                    and counted per thread)  10 000 steady callbacks, then 10 000 more with a control thread sending
 //                    messages: the audio thread's host-heap allocation count must not move (SURVEY 8(b) realtime rules).
@@ -13,6 +18,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -58,10 +64,12 @@ extern "C" unsigned long long fwh_cmds_seen(void);
 
 struct Bank {
     fwgpu_ctx* c;
+    int64_t root = -1;
+    int sample = -1;
     std::vector<int64_t> samplers, volumes, pans;
 };
 
-static Bank build_bank(int voices, int block) {
+static Bank build_bank(int voices, int block, int spare_ports = 0) {
     Bank b;
     b.c = fwgpu_ctx_create(0, 48000, (uint32_t)block, 0, 2, nullptr);
     CHECK(b.c);
@@ -69,8 +77,10 @@ static Bank build_bank(int voices, int block) {
     std::vector<float> src(2 * 4096, 0.25f);
     const int smp = fwgpu_sample_create(b.c, FWGPU_PLANAR_F32, 2, 4096, src.data());
     CHECK(smp >= 0);
-    const int64_t root = fwgpu_add_node(b.c, FWGPU_SUM, 2 * (uint32_t)voices, 2, nullptr, 0);
+    const int64_t root = fwgpu_add_node(b.c, FWGPU_SUM, 2 * (uint32_t)(voices + spare_ports), 2, nullptr, 0);
     CHECK(root >= 0);
+    b.root = root;
+    b.sample = smp;
     for (int v = 0; v < voices; ++v) {
         float p100 = 100.f, p50 = 50.f, p0 = 0.f;
         int64_t s = fwgpu_add_node(b.c, FWGPU_SAMPLER, 0, 2, &p100, 1);
@@ -99,8 +109,9 @@ static Bank build_bank(int voices, int block) {
 
 int main(int argc, char** argv) {
     const bool tsan = argc > 1 && !strcmp(argv[1], "tsan");
-    const int block = 64, voices = 24;
-    Bank b = build_bank(voices, block);
+    const bool edits = argc > 1 && !strcmp(argv[1], "edits");
+    const int block = 64, voices = 24, spare = edits ? 6 : 0;
+    Bank b = build_bank(voices, block, spare);
     std::vector<float> out((size_t)block * 2);
     fwgpu_stream* st = fwgpu_stream_open(b.c, 0, 2);
     CHECK(st);
@@ -113,10 +124,15 @@ int main(int argc, char** argv) {
 
     std::atomic<bool> go{false}, stop{false};
     std::atomic<unsigned long long> sent{0}, refused{0};
+    // The control side of a ctx is one thread at a time: message calls and graph calls may each overlap PROCESS calls, not one
+    // another (include/fwgpu.h).  Two control threads of the "edits" run share this lock, as a host with two would.
+    std::mutex ctl;
     auto control = [&](int first, int last, int rounds) {
         while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
         for (int r = 0; r < rounds && !stop.load(std::memory_order_relaxed); ++r)
             for (int v = first; v < last; ++v) {
+                std::unique_lock<std::mutex> lk(ctl, std::defer_lock);
+                if (edits) lk.lock();
                 int rc = fwgpu_node_set_param(b.c, b.volumes[v], 0, 20.f + (float)((r + v) % 70), (uint32_t)(r % 3));
                 rc == 0 ? sent++ : refused++;
                 rc = fwgpu_node_set_param(b.c, b.pans[v], 0, (float)((r * 7 + v) % 21) / 10.f - 1.f, 0);  // two messages
@@ -129,7 +145,69 @@ int main(int argc, char** argv) {
             }
     };
 
-    if (tsan) {
+    if (edits) {
+        // the editor: a voice chain into spare port p, update, start it; two rounds later remove it, update
+        std::atomic<unsigned long long> updates{0};
+        auto editor = [&](int rounds) {
+            struct Live {
+                int64_t s = -1, g = -1, p = -1;
+            } live[8];
+            while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+            for (int r = 0; r < rounds; ++r) {
+                std::lock_guard<std::mutex> lk(ctl);
+                const int port = r % spare;
+                Live& l = live[port];
+                if (l.s >= 0) {  // retire the chain that sits there
+                    CHECK(fwgpu_remove_node(b.c, l.s) == 0);
+                    CHECK(fwgpu_remove_node(b.c, l.g) == 0);
+                    CHECK(fwgpu_remove_node(b.c, l.p) == 0);
+                    l = Live();
+                    CHECK(fwgpu_update(b.c) == 0);
+                    updates++;
+                }
+                float p100 = 100.f, pg = 30.f + (float)(r % 50), pp = (float)(r % 21) / 10.f - 1.f;
+                l.s = fwgpu_add_node(b.c, FWGPU_SAMPLER, 0, 2, &p100, 1);
+                l.g = fwgpu_add_node(b.c, FWGPU_VOLUME, 2, 2, &pg, 1);
+                l.p = fwgpu_add_node(b.c, FWGPU_STEREO_PAN, 2, 2, &pp, 1);
+                CHECK(l.s >= 0 && l.g >= 0 && l.p >= 0);
+                for (uint32_t ch = 0; ch < 2; ++ch) {
+                    CHECK(fwgpu_connect(b.c, l.s, ch, l.g, ch, 0) >= 0);
+                    CHECK(fwgpu_connect(b.c, l.g, ch, l.p, ch, 0) >= 0);
+                    CHECK(fwgpu_connect(b.c, l.p, ch, b.root, 2 * (uint32_t)(voices + port) + ch, 0) >= 0);
+                }
+                CHECK(fwgpu_sampler_set_sample(b.c, l.s, b.sample, 0, 0) == 0);  // before the update: waits for the plan that activates it
+                CHECK(fwgpu_update(b.c) == 0);
+                updates++;
+                CHECK(fwgpu_plan_kind(b.c) == 1);
+                CHECK(fwgpu_sampler_set_loop_range(b.c, l.s, 1, 0.0, 0.0, 0) == 0);
+                CHECK(fwgpu_sampler_play(b.c, l.s, 1) == 0);
+                CHECK(fwgpu_node_set_param(b.c, l.g, 0, 60.f, 2) == 0);
+            }
+        };
+        std::thread te(editor, 300), tm(control, 0, voices, 300);
+        const unsigned long long a0 = thread_allocs();
+        go.store(true, std::memory_order_release);
+        unsigned long long n_cb = 0;
+        while (updates.load() < 590 || n_cb < 3000) {  // (300 rounds: 300 adds + 294 removals)
+            callback();
+            n_cb++;
+            CHECK(n_cb < 4000000ull);
+        }
+        const unsigned long long a1 = thread_allocs();
+        te.join();
+        tm.join();
+        for (int i = 0; i < 8; ++i) callback();
+        uint64_t adoptions = 0, by_audio = 0, worst_ns = 0;
+        CHECK(fwgpu_plan_handover_stats(b.c, &adoptions, &by_audio, &worst_ns) == 0);
+        printf("edits-run: %llu callbacks, %llu updates, %llu adoptions (%llu by a callback, longest %.1f us); audio-thread allocations %llu\n", n_cb,
+               updates.load(), (unsigned long long)adoptions, (unsigned long long)by_audio, worst_ns / 1e3, a1 - a0);
+        CHECK(adoptions >= 2 && adoptions <= updates.load() + 1 && by_audio >= 1);
+        CHECK(refused.load() == 0);
+#ifdef COUNT_ALLOCS
+        CHECK(a1 - a0 == 0);
+#endif
+        printf("edits-run ok\n");
+    } else if (tsan) {
         const unsigned long long seen0 = fwh_cmds_seen();
         std::thread t1(control, 0, voices / 2, 400), t2(control, voices / 2, voices, 400);
         go.store(true, std::memory_order_release);

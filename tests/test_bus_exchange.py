@@ -404,6 +404,11 @@ def test_process_blocks_device_flags_equal_the_oracles_read_graph_outputs_masks(
     got, want = _flag_scenario(g, plan), _flag_scenario(o, plan)
     some_silent = some_live = False
     for i, ((go, gf), (wo, wf)) in enumerate(zip(got, want)):
+        if not np.array_equal(go.view(np.uint32), wo.view(np.uint32)):  # (diagnostics: which blocks / channels)
+            k = go.size // 128
+            eq = (go.view(np.uint32).reshape(k, 64, 2) == wo.view(np.uint32).reshape(k, 64, 2))
+            print("MISMATCH", plan, force_generic, max_batch, "call", i, "per block L:", "".join("1" if x else "0" for x in eq[:, :, 0].all(axis=1)[:24]),
+                  "R:", "".join("1" if x else "0" for x in eq[:, :, 1].all(axis=1)[:24]), "handover", g.cx.plan_handover_stats(), "flags", gf[:8].T.tolist())
         assert np.array_equal(go.view(np.uint32), wo.view(np.uint32)), (plan, i)
         assert np.array_equal(gf, wf), (plan, i, gf.T, wf.T)
         some_silent |= bool(wf.any())

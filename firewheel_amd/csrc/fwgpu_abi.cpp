@@ -478,6 +478,7 @@ int fwgpu_plan_node_inputs_clear(fwgpu_ctx* c, int64_t node, int* should_clear, 
 }
 int fwgpu_set_force_generic(fwgpu_ctx* c, int on) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
+    ControlGate gate(c);
     c->force_generic = on != 0;
     return 0;
 }
@@ -535,6 +536,9 @@ static int sample_add(fwgpu_ctx* c, int format, uint32_t channels, uint64_t fram
     r.desc.frames = frames;
     r.desc.channels = (int)channels;
     r.desc.format = format;
+    // the data is in HBM; now the table entry — what a process call reads — under the gate: no process call is running, the
+    // next one finds the whole entry (and the room for it on the device) in place
+    ControlGate gate(c);
     c->samples.push_back(r);
     c->sample_refs.push_back(0);
     rebuild_sample_table(c);  // copied to the device by the next process / update call; room for it is made here
@@ -562,6 +566,7 @@ int fwgpu_sample_destroy(fwgpu_ctx* c, int sample) {
         if (n.alive && (n.kind == K_FIR || n.kind == K_RESAMPLER) && n.init.sample == sample)
             return fail(c, FWGPU_ERR_INVALID, "sample is in use by a FIR / resampler node");
     use_device(c);
+    ControlGate gate(c);  // no process call runs while the entry is emptied and the data freed
     (void)hipStreamSynchronize(c->stream);
     if (c->ctl_stream) (void)hipStreamSynchronize(c->ctl_stream);
     SampleRec& r = c->samples[sample];

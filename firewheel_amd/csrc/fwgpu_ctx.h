@@ -15,6 +15,7 @@
 #include <functional>
 #include <map>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -490,6 +491,21 @@ struct AudioGate {
         if (PlanImage* img = c->pending.exchange(nullptr, std::memory_order_acq_rel)) adopt_image(c, img, true);
     }
     ~AudioGate() { c->gate.store(0, std::memory_order_release); }
+};
+// The control-side calls that change what a process call reads OUTSIDE a plan image — the sample table, max_batch /
+// force_generic — take the gate exclusively for the few microseconds of the change (the expensive part, uploading sample
+// data, happens before).  A process call that starts meanwhile waits at its entry; the control thread waits for a running one
+// to finish.  (fwgpu_update never does this: it builds outside the gate.)
+struct ControlGate {
+    fwgpu_ctx* c;
+    explicit ControlGate(fwgpu_ctx* ctx) : c(ctx) {
+        int expected = 0;
+        while (!c->gate.compare_exchange_weak(expected, 2, std::memory_order_acquire)) {
+            expected = 0;
+            std::this_thread::yield();
+        }
+    }
+    ~ControlGate() { c->gate.store(0, std::memory_order_release); }
 };
 
 // ---- fwgpu_run.cpp

@@ -8,18 +8,20 @@
  * Conventions (replacing Rust's Result/panic, SURVEY §8b "error convention"):
  *   - functions return int: 0 = ok, negative = error; handles are int64 (>= 0) or negative error.
  *   - nothing throws or aborts across the ABI; fwgpu_last_error() returns the message.
- *   - threading: a ctx has an AUDIO side — fwgpu_process_interleaved / _process_blocks_device /
- *     _node_process / _stream_callback, one thread at a time — and a CONTROL side, everything else.  The control ->
- *     audio MESSAGE calls (fwgpu_node_set_param, fwgpu_sampler_*) may run on any thread WHILE a process call is in
- *     flight: they validate against the graph and push into a lock-free ring the audio side drains at the start of
- *     its next call (the reference's Arc<AtomicF32> gains and rtrb rings: nodes/volume.rs:10,28-34,
- *     nodes/sampler.rs:14,171-177,205-208); neither side locks, allocates or waits for the other.  The GRAPH
- *     calls (add_node / remove_node / connect / disconnect / host_node_set_process / update / schedule_upload), made from
- *     ONE control thread at a time, may ALSO overlap process calls: update builds the new plan off to the side and the
- *     next process call adopts it at its start, as the reference hands a new schedule over through a ring
- *     (graph/processor.rs:167-206; fwgpu_plan_handover_stats).  The control side itself is one thread at a time: a message
- *     call must not run concurrently with a graph call on another thread (it looks the node up in the graph).  Only the sample-table and configuration calls
- *     (sample_create / sample_destroy / set_max_batch / set_force_generic) must still not overlap a process call.
+ *   - threading: a ctx has an AUDIO side — fwgpu_process_interleaved / _process_blocks_device[_flags] /
+ *     _node_process / _stream_callback, one thread at a time — and a CONTROL side, everything else, ALSO one thread at a
+ *     time (a host with several control threads serialises them itself: a message call looks its node up in the graph a
+ *     graph call may be growing).  Every control call may run WHILE a process call is in flight:
+ *       * messages (fwgpu_node_set_param, fwgpu_sampler_*) go through a lock-free ring the audio side drains at the start
+ *         of its next call (the reference's Arc<AtomicF32> gains and rtrb rings: nodes/volume.rs:10,28-34,
+ *         nodes/sampler.rs:14,171-177,205-208);
+ *       * graph calls (add_node / remove_node / connect / disconnect / host_node_set_process / update / schedule_upload):
+ *         update BUILDS the new plan off to the side on the calling thread and the next process call adopts it at its
+ *         start, as the reference hands a new schedule over through a ring (graph/processor.rs:167-206;
+ *         fwgpu_plan_handover_stats) — the audio side neither locks nor allocates nor waits for the build;
+ *       * sample-table and configuration calls (sample_create / sample_destroy / set_force_generic) upload their data first
+ *         and then hold process calls at their ENTRY for the few microseconds the table entry takes (they wait for a
+ *         running call to finish first).  fwgpu_set_max_batch takes effect with the next update.
  *   - once warm, a process call touches neither the host allocator nor the device allocator; a failing call writes its
  *     message into a fixed buffer.  fwgpu_process_interleaved fills `output` on EVERY return (zeros on error:
  *     core/node.rs:41-42).

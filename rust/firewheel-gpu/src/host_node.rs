@@ -1,0 +1,87 @@
+//! Custom nodes inside a device-resident graph (level B2 with the reference's open node set).
+//!
+//! Firewheel's schedule loop calls ANY `dyn AudioNodeProcessor` (firewheel-graph/src/processor.rs:226-247).  A node libfwgpu
+//! has no kernel for stays what it is — a Rust processor — and is registered as a `FWGPU_HOST_NODE`: the device plan is cut
+//! at its level, its input buffers (and only those) come to pinned host memory, `process()` runs on the audio thread once per
+//! block in block order, its outputs go back (include/fwgpu.h, "custom nodes inside a device-resident graph").
+use std::os::raw::c_void;
+use std::sync::Arc;
+
+use arrayvec::ArrayVec;
+use firewheel_core::node::{AudioNodeProcessor, ProcInfo, StreamStatus};
+use firewheel_core::SilenceMask;
+
+use crate::{ffi, GpuContext, GpuError};
+
+/// Keeps a custom processor alive for as long as the device graph may call it.  Drop it only after the node has been removed
+/// and the plan without it adopted (`GpuContext::plan_handover_stats`), like Firewheel drops processors that come back with the
+/// old schedule (processor.rs:182-188).
+pub struct HostNodeHandle {
+    pub node: i64,
+    _state: Box<HostState>,
+    _cx: Arc<GpuContext>,
+}
+/// what the C side's `user` pointer names: the processor and the global user context ProcInfo hands every node
+/// (core/node.rs:117-118; the reference's processor owns one `Box<dyn Any + Send>` per graph, processor.rs:41 — here one per node,
+/// supplied by the host at registration)
+struct HostState {
+    processor: Box<dyn AudioNodeProcessor>,
+    user_cx: Box<dyn std::any::Any + Send>,
+}
+unsafe impl Send for HostNodeHandle {}
+
+unsafe extern "C" fn trampoline(
+    user: *mut c_void,
+    frames: u64,
+    inputs: *const *const f32,
+    num_inputs: u32,
+    outputs: *const *mut f32,
+    num_outputs: u32,
+    in_silence_mask: u64,
+    out_silence_mask: *mut u64,
+    stream_time_secs: f64,
+    stream_status: u32,
+) {
+    let st = &mut *(user as *mut HostState);
+    let frames = frames as usize;
+    let ins: ArrayVec<&[f32], 64> =
+        (0..num_inputs as usize).map(|i| std::slice::from_raw_parts(*inputs.add(i), frames)).collect();
+    let mut outs: ArrayVec<&mut [f32], 64> =
+        (0..num_outputs as usize).map(|i| std::slice::from_raw_parts_mut(*outputs.add(i), frames)).collect();
+    let mut out_mask = SilenceMask(*out_silence_mask);
+    let info = ProcInfo {
+        in_silence_mask: SilenceMask(in_silence_mask),
+        out_silence_mask: &mut out_mask,
+        stream_time_secs,
+        stream_status: StreamStatus::from_bits_truncate(stream_status),
+        cx: &mut st.user_cx,
+    }; // core/node.rs:94-118
+    st.processor.process(frames, &ins, &mut outs, info);
+    *out_silence_mask = out_mask.0;
+}
+
+impl GpuContext {
+    /// Register `processor` (what `AudioNode::activate` returned for a node libfwgpu does not implement) with `num_inputs` /
+    /// `num_outputs` ports.  The returned id is used like any other node id: in `connect`, or in the entry of
+    /// `upload_schedule` that stands for the node.  Takes effect with the next `update` / `upload_schedule`.
+    pub fn add_host_node(
+        self: &Arc<Self>,
+        num_inputs: u32,
+        num_outputs: u32,
+        processor: Box<dyn AudioNodeProcessor>,
+        user_cx: Box<dyn std::any::Any + Send>,
+    ) -> Result<HostNodeHandle, GpuError> {
+        assert!(num_inputs <= 64 && num_outputs <= 64);
+        let mut boxed = Box::new(HostState { processor, user_cx });
+        let user = &mut *boxed as *mut HostState as *mut c_void;
+        let _g = self.control();
+        let node = self.check(unsafe {
+            ffi::fwgpu_add_node(self.as_ptr(), ffi::FWGPU_HOST_NODE, num_inputs, num_outputs, std::ptr::null(), 0)
+        })?;
+        if let Err(e) = self.check(unsafe { ffi::fwgpu_host_node_set_process(self.as_ptr(), node, Some(trampoline), user) } as i64) {
+            unsafe { ffi::fwgpu_remove_node(self.as_ptr(), node) };
+            return Err(e);
+        }
+        Ok(HostNodeHandle { node, _state: boxed, _cx: Arc::clone(self) })
+    }
+}

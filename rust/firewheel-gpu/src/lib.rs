@@ -9,7 +9,9 @@
 //!   drop-in, for graphs that mix GPU nodes with custom Rust nodes.
 //!
 //! SOURCE ONLY here: never compiled in the repository that ships it (no Rust toolchain in its build image).
+pub mod exchange;
 pub mod ffi;
+pub mod host_node;
 pub mod nodes;
 pub mod sample;
 pub mod stream;
@@ -17,7 +19,7 @@ pub mod stream;
 use std::ffi::CStr;
 use std::fmt;
 use std::ptr::NonNull;
-use std::sync::Arc;
+use std::sync::{Arc, Mutex, MutexGuard};
 
 /// Error of a libfwgpu call: the negative code of `enum fwgpu_error` + `fwgpu_last_error`.
 #[derive(Debug, Clone)]
@@ -33,15 +35,20 @@ impl fmt::Display for GpuError {
 impl std::error::Error for GpuError {}
 
 /// Owner of one `fwgpu_ctx`.  Shared (`Arc`) between the control side (graph edits, node handles, sample handles) and the
-/// one audio-side [`GpuProcessor`]; the C ABI's threading contract (fwgpu.h) is what makes that sound: message calls may
-/// overlap a process call, edit / update / sample-table calls are serialised with it by the owner of the `GpuProcessor`
-/// exactly as Firewheel serialises schedule hand-over (graph/context.rs:93-137).
+/// one audio-side [`GpuProcessor`].  The C ABI's threading contract (fwgpu.h) is what makes that sound:
+/// * every CONTROL call — messages, graph edits, `update`, sample-table calls — may run while a process call is in flight
+///   (`fwgpu_update` builds the new plan off to the side and the next process call adopts it, the way Firewheel hands a
+///   schedule over through its ring, graph/processor.rs:167-206), but the control side is ONE thread at a time.  Rust nodes
+///   and handles can live on any thread, so every control call of this crate goes through `control()`: a mutex the audio
+///   thread never touches.
+/// * the AUDIO calls belong to the single [`GpuProcessor`] (`Send`, not `Sync`, `&mut self`).
 pub struct GpuContext {
     raw: NonNull<ffi::fwgpu_ctx>,
+    control: Mutex<()>,
     pub sample_rate: u32,
     pub max_block_frames: u32,
 }
-// the ctx is internally synchronised for the call pairs the contract allows
+// sound because of the two rules above: control calls are serialised by `control`, audio calls by `&mut GpuProcessor`
 unsafe impl Send for GpuContext {}
 unsafe impl Sync for GpuContext {}
 
@@ -65,7 +72,7 @@ impl GpuContext {
             )
         };
         match NonNull::new(raw) {
-            Some(raw) => Ok(Arc::new(Self { raw, sample_rate, max_block_frames })),
+            Some(raw) => Ok(Arc::new(Self { raw, control: Mutex::new(()), sample_rate, max_block_frames })),
             None => Err(GpuError {
                 code: ffi::FWGPU_ERR_DEVICE,
                 message: unsafe { CStr::from_ptr(ffi::fwgpu_create_error()) }.to_string_lossy().into_owned(),
@@ -75,6 +82,12 @@ impl GpuContext {
 
     pub fn as_ptr(&self) -> *mut ffi::fwgpu_ctx {
         self.raw.as_ptr()
+    }
+
+    /// The control side's lock: hold it around every control call made through `as_ptr()` directly (messages, samples).
+    /// Never taken by the audio thread; a poisoned lock is still a lock (the C side keeps its own invariants).
+    pub fn control(&self) -> MutexGuard<'_, ()> {
+        self.control.lock().unwrap_or_else(|e| e.into_inner())
     }
 
     pub(crate) fn check(&self, rc: i64) -> Result<i64, GpuError> {
@@ -89,15 +102,18 @@ impl GpuContext {
 
     /// `AudioGraph::add_node` (graph/graph.rs:201-231) for a built-in node kind; `params` are its constructor arguments.
     pub fn add_node(&self, kind: i32, num_inputs: u32, num_outputs: u32, params: &[f32]) -> Result<i64, GpuError> {
+        let _g = self.control();
         self.check(unsafe {
             ffi::fwgpu_add_node(self.as_ptr(), kind, num_inputs, num_outputs, params.as_ptr(), params.len() as i32)
         })
     }
     pub fn remove_node(&self, node: i64) -> Result<(), GpuError> {
+        let _g = self.control();
         self.check(unsafe { ffi::fwgpu_remove_node(self.as_ptr(), node) } as i64).map(|_| ())
     }
     /// `AudioGraph::connect` (graph/graph.rs:396-477); the error codes are the `AddEdgeError` variants.
     pub fn connect(&self, src: i64, src_port: u32, dst: i64, dst_port: u32, check_for_cycles: bool) -> Result<i64, GpuError> {
+        let _g = self.control();
         self.check(unsafe { ffi::fwgpu_connect(self.as_ptr(), src, src_port, dst, dst_port, check_for_cycles as i32) })
     }
     pub fn graph_in_node(&self) -> i64 {
@@ -108,10 +124,12 @@ impl GpuContext {
     }
     /// `FirewheelGraphCtx::update` (graph/context.rs:93-137) when the graph is mirrored with `add_node` / `connect`.
     pub fn update(&self) -> Result<(), GpuError> {
+        let _g = self.control();
         self.check(unsafe { ffi::fwgpu_update(self.as_ptr()) } as i64).map(|_| ())
     }
     /// Blocks one launch sequence may cover (a realtime host never needs more than one; an offline bounce wants many).
     pub fn set_max_batch(&self, blocks: u32) -> Result<(), GpuError> {
+        let _g = self.control();
         self.check(unsafe { ffi::fwgpu_set_max_batch(self.as_ptr(), blocks) } as i64).map(|_| ())
     }
 
@@ -135,6 +153,7 @@ impl GpuContext {
                 out_buffer_index: v.out_buffer_index.as_ptr(),
             })
             .collect();
+        let _g = self.control();
         self.check(unsafe {
             ffi::fwgpu_schedule_upload(self.as_ptr(), nodes.as_ptr(), nodes.len() as u32, num_buffers as u32)
         } as i64)
@@ -145,6 +164,14 @@ impl GpuContext {
     /// kernels inside a graph the level executor runs).
     pub fn plan_kind(&self) -> i32 {
         unsafe { ffi::fwgpu_plan_kind(self.as_ptr()) }
+    }
+
+    /// (plans adopted so far, those a process call adopted, the longest one of those held its call up) — the schedule hand-over
+    /// of graph/processor.rs:167-206 as libfwgpu does it
+    pub fn plan_handover_stats(&self) -> (u64, u64, std::time::Duration) {
+        let (mut a, mut b, mut ns) = (0u64, 0u64, 0u64);
+        unsafe { ffi::fwgpu_plan_handover_stats(self.as_ptr(), &mut a, &mut b, &mut ns) };
+        (a, b, std::time::Duration::from_nanos(ns))
     }
 
     /// Voices of the installed plan that the fused kernels render (plan 3: the voice banks' and the split mixers' leading ones).
@@ -188,7 +215,10 @@ impl GpuProcessor {
         stream_time_secs: f64,
         stream_status: firewheel_core::node::StreamStatus,
     ) -> firewheel_graph::processor::FirewheelProcessorStatus {
-        debug_assert!(output.len() >= frames * num_out_channels);
+        // a safe API must not let a short slice through to C: real checks, in release builds too
+        assert!(output.len() >= frames * num_out_channels, "output slice shorter than frames * num_out_channels");
+        assert!(input.is_empty() || input.len() >= frames * num_in_channels, "input slice shorter than frames * num_in_channels");
+        assert!(num_in_channels <= 64 && num_out_channels <= 64);
         let rc = unsafe {
             ffi::fwgpu_process_interleaved(
                 self.cx.as_ptr(),

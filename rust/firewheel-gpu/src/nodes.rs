@@ -2,7 +2,10 @@
 //! lists as TODO (README.md:14-19) — as `AudioNode`s whose processor half runs on the device.
 //!
 //! Each wrapper has the reference node's constructor and control-half setters.  `activate()` registers the node with
-//! the shared [`GpuContext`] (`fwgpu_add_node` + `fwgpu_update`) and returns a [`GpuNodeProcessor`], whose `process()`
+//! the shared [`GpuContext`] (`fwgpu_add_node` + `fwgpu_update`) — on Firewheel's control thread, WHILE the audio thread may
+//! be inside `process()` of nodes that are already active (graph.rs:586-612): libfwgpu builds the new plan off to the side
+//! and the audio thread's next `fwgpu_node_process` adopts it, and that call looks the node up in the ACTIVE plan, never in
+//! the graph being edited — and returns a [`GpuNodeProcessor`], whose `process()`
 //! is one `fwgpu_node_process` call: the same device function the whole-graph executor runs for that node, on the
 //! caller's buffers, with `in_silence_mask` / `out_silence_mask` honoured (core/node.rs:94-118).  Setters become
 //! messages (`fwgpu_node_set_param`, `fwgpu_sampler_*`) with `at_block = 0`: a per-block caller gets the reference's
@@ -84,10 +87,10 @@ impl Binding {
     }
     fn set_param(&self, param: i32, value: f32) -> Result<(), GpuError> {
         match self.node {
-            Some(node) => self
-                .cx
-                .check(unsafe { ffi::fwgpu_node_set_param(self.cx.as_ptr(), node, param, value, 0) } as i64)
-                .map(|_| ()),
+            Some(node) => {
+                let _g = self.cx.control();
+                self.cx.check(unsafe { ffi::fwgpu_node_set_param(self.cx.as_ptr(), node, param, value, 0) } as i64).map(|_| ())
+            }
             None => Ok(()), // not activated yet: the constructor argument carries the value (activate reads it)
         }
     }
@@ -184,6 +187,7 @@ impl GpuSamplerNode {
     }
     fn msg(&self, f: impl FnOnce(*mut ffi::fwgpu_ctx, i64) -> i32) -> Result<(), ()> {
         let node = self.b.node.ok_or(())?; // not activated: sampler.rs:68-70 returns Err(())
+        let _g = self.b.cx.control();
         if f(self.b.cx.as_ptr(), node) < 0 {
             return Err(()); // ring full (FWGPU_ERR_QUEUE_FULL): sampler.rs:72-78 `.map_err(|_| ())`
         }
@@ -262,6 +266,7 @@ impl AudioNode for GpuSamplerNode {
         let Some(node) = self.b.node else { return };
         let mut nodes = [0i64; 16];
         let mut samples = [0i32; 16];
+        let _g = self.b.cx.control();
         let n = unsafe { ffi::fwgpu_poll_returned_samples(self.b.cx.as_ptr(), nodes.as_mut_ptr(), samples.as_mut_ptr(), 16) };
         for i in 0..n.max(0) as usize {
             if nodes[i] == node {

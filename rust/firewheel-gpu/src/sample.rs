@@ -34,6 +34,7 @@ impl Graveyard {
     pub fn collect(&self, cx: &GpuContext) {
         let mut ids = self.ids.lock().unwrap();
         ids.retain(|&id| {
+            let _g = cx.control();
             let retired = unsafe { ffi::fwgpu_sample_retired(cx.as_ptr(), id) } == 1;
             if retired {
                 unsafe { ffi::fwgpu_sample_destroy(cx.as_ptr(), id) };
@@ -59,7 +60,9 @@ impl GpuSample {
         frames: u64,
         data: *const std::ffi::c_void,
     ) -> Result<Self, GpuError> {
+        let _g = cx.control();
         let id = cx.check(unsafe { ffi::fwgpu_sample_create(cx.as_ptr(), format, channels, frames, data) } as i64)? as i32;
+        drop(_g);
         Ok(Self(Arc::new(Inner { cx: Arc::clone(cx), id, graveyard: Arc::clone(graveyard) })))
     }
 

@@ -18,6 +18,10 @@ unsafe impl Send for HeadlessStream {}
 
 impl HeadlessStream {
     pub fn open(cx: Arc<GpuContext>, num_in_channels: u32, num_out_channels: u32) -> Result<Self, GpuError> {
+        if num_out_channels == 0 || num_out_channels > 64 || num_in_channels > 64 {
+            // (callback / run divide by the channel count: refuse here instead of panicking there — ADVICE r2)
+            return Err(GpuError { code: ffi::FWGPU_ERR_INVALID, message: "a stream has 1..=64 output channels".into() });
+        }
         let raw = unsafe { ffi::fwgpu_stream_open(cx.as_ptr(), num_in_channels, num_out_channels) };
         match NonNull::new(raw) {
             Some(raw) => Ok(Self { cx, raw, num_out_channels: num_out_channels as usize }),

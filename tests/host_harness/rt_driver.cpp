@@ -151,7 +151,10 @@ int main(int argc, char** argv) {
         auto editor = [&](int rounds) {
             struct Live {
                 int64_t s = -1, g = -1, p = -1;
+                int sample = -1;
             } live[8];
+            std::vector<int> to_destroy;  // samples of retired voices: destroyed once the device has let go of them
+            std::vector<float> data(2 * 512, 0.125f);
             while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
             for (int r = 0; r < rounds; ++r) {
                 std::lock_guard<std::mutex> lk(ctl);
@@ -161,10 +164,24 @@ int main(int argc, char** argv) {
                     CHECK(fwgpu_remove_node(b.c, l.s) == 0);
                     CHECK(fwgpu_remove_node(b.c, l.g) == 0);
                     CHECK(fwgpu_remove_node(b.c, l.p) == 0);
+                    to_destroy.push_back(l.sample);
                     l = Live();
                     CHECK(fwgpu_update(b.c) == 0);
                     updates++;
                 }
+                {  // ReturnSample (sampler.rs:339-343,563-571): a sample nobody holds any more may go — while callbacks run
+                    int64_t nodes[8];
+                    int samples[8];
+                    (void)fwgpu_poll_returned_samples(b.c, nodes, samples, 8);
+                    size_t w = 0;
+                    for (int smp : to_destroy) {
+                        if (fwgpu_sample_retired(b.c, smp) == 1) CHECK(fwgpu_sample_destroy(b.c, smp) == 0);
+                        else to_destroy[w++] = smp;
+                    }
+                    to_destroy.resize(w);
+                }
+                l.sample = fwgpu_sample_create(b.c, FWGPU_PLANAR_F32, 2, 512, data.data());  // a new sample table entry, mid-stream
+                CHECK(l.sample >= 0);
                 float p100 = 100.f, pg = 30.f + (float)(r % 50), pp = (float)(r % 21) / 10.f - 1.f;
                 l.s = fwgpu_add_node(b.c, FWGPU_SAMPLER, 0, 2, &p100, 1);
                 l.g = fwgpu_add_node(b.c, FWGPU_VOLUME, 2, 2, &pg, 1);
@@ -175,7 +192,7 @@ int main(int argc, char** argv) {
                     CHECK(fwgpu_connect(b.c, l.g, ch, l.p, ch, 0) >= 0);
                     CHECK(fwgpu_connect(b.c, l.p, ch, b.root, 2 * (uint32_t)(voices + port) + ch, 0) >= 0);
                 }
-                CHECK(fwgpu_sampler_set_sample(b.c, l.s, b.sample, 0, 0) == 0);  // before the update: waits for the plan that activates it
+                CHECK(fwgpu_sampler_set_sample(b.c, l.s, l.sample, 0, 0) == 0);  // before the update: waits for the plan that activates it
                 CHECK(fwgpu_update(b.c) == 0);
                 updates++;
                 CHECK(fwgpu_plan_kind(b.c) == 1);

@@ -91,7 +91,7 @@ def test_rust_crate_ffi_matches_the_header():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     crate = os.path.join(root, "rust", "firewheel-gpu")
-    for f in ("Cargo.toml", "build.rs", "src/lib.rs", "src/ffi.rs", "src/nodes.rs", "src/sample.rs", "src/stream.rs"):
+    for f in ("Cargo.toml", "build.rs", "src/lib.rs", "src/ffi.rs", "src/nodes.rs", "src/sample.rs", "src/stream.rs", "src/exchange.rs", "src/host_node.rs"):
         assert os.path.exists(os.path.join(crate, f)), f
     assert subprocess.call([sys.executable, os.path.join(root, "scripts", "gen_rust_ffi.py"), "--check"]) == 0, \
         "rust/firewheel-gpu/src/ffi.rs is stale: run python scripts/gen_rust_ffi.py"
@@ -109,7 +109,7 @@ def test_rust_crate_ffi_matches_the_header():
     assert rust == c_decl
     # the wrappers: every call site names a declared function and passes as many arguments as it takes
     calls = 0
-    for f in ("lib.rs", "nodes.rs", "sample.rs", "stream.rs"):
+    for f in ("lib.rs", "nodes.rs", "sample.rs", "stream.rs", "exchange.rs", "host_node.rs"):
         src = open(os.path.join(crate, "src", f)).read()
         src = re.sub(r"//[^\n]*", "", src)
         for m in re.finditer(r"ffi::(fwgpu_[a-z_0-9]+)\s*\(", src):

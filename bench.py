@@ -279,7 +279,7 @@ def make_gpu(fa, wl, V, B, K, radix, src, F, sfmt, seed, args, stream, device):
         for v, s in enumerate(samplers):
             smp = cx.new_sample_device(fmt, 2, F, src[v].data_ptr())
             g.start(s, smp)
-    generic = args.force_generic or getattr(args, "voice_spatial", False)  # (a spatialiser voice is not a fused shape)
+    generic = args.force_generic  # (round 3: a sampler -> volume -> spatialiser voice is a voice-bank shape, SK_SPATIAL)
     want = 3 if (getattr(args, "send", False) and not generic and wl in ("cfg2", "cfg3", "cfg5")) else want_plan(wl, generic)
     assert cx.plan_kind() == want, "expected launch plan %d, got %d" % (want, cx.plan_kind())
     return cx, g, samplers, volumes

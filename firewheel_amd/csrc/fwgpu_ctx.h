@@ -161,7 +161,8 @@ struct PlanImage {
     DevBuf d_blks2, d_refs2, d_gsets2, d_ramps2;
     bool fused_rs = false;    // the plan has resampler-sourced voices
     bool fused_prog = false;  // the voice-bank plan carries stage programs (k_leaf_sum<true>)
-    DevBuf d_progs;
+    bool fused_sp = false;    // ... and spatialiser stages (k_leaf_sum<true, false, true>)
+    DevBuf d_progs, d_hist;   // d_hist: [n_voices][SP_HIST] mono histories the spatialiser voices enter the call with
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start, d_chain_dummy, d_chain_stats;
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;
     std::vector<int> up_level_off, up_level_cnt;
@@ -452,6 +453,7 @@ struct FusedBuild {
     std::vector<uint32_t> progs;  // per voice: its chain stages' kinds (SK_*), 4 bits each
     bool has_prog = false;        // a width / hard-clip stage somewhere: the leaf kernel's program instantiation
     bool has_rs = false;          // a resampler-sourced voice somewhere
+    bool has_sp = false;          // a voice whose last stage is a spatialiser somewhere
     bool has_fx = false;  // some chain holds a biquad / delay: the k_chain plan
     uint64_t min_delay = ~0ull;  // shortest delay line among the chains (frames)
     std::vector<int> covered;    // hybrid plan: plan indices of the nodes the fused kernels render (voice chains + their SumNode)

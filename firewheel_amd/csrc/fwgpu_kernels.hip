@@ -236,7 +236,9 @@ int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
 #else
     dim3 grid((fv.n_leaves + LEAF_WPB - 1) / LEAF_WPB, K);
 #endif
-    if (fv.has_rs) hipLaunchKernelGGL((k_leaf_sum<true, true>), grid, dim3(WAVE * LEAF_WPB), RS_LDS_BYTES(LEAF_WPB), s, fv, K, wpk);
+    if (fv.has_sp && fv.has_rs) hipLaunchKernelGGL((k_leaf_sum<true, true, true>), grid, dim3(WAVE * LEAF_WPB), RS_LDS_BYTES(LEAF_WPB), s, fv, K, wpk);
+    else if (fv.has_sp) hipLaunchKernelGGL((k_leaf_sum<true, false, true>), grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
+    else if (fv.has_rs) hipLaunchKernelGGL((k_leaf_sum<true, true>), grid, dim3(WAVE * LEAF_WPB), RS_LDS_BYTES(LEAF_WPB), s, fv, K, wpk);
     else if (fv.has_prog) hipLaunchKernelGGL((k_leaf_sum<true, false>), grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
     else hipLaunchKernelGGL((k_leaf_sum<false, false>), grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
     return (int)hipGetLastError();

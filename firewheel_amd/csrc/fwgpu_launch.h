@@ -67,6 +67,10 @@ struct FusedView {
     const uint32_t* progs;  // [n_voices] stage programs (SK_*, 4 bits per chain stage); nullptr / all 0 on gains-only plans
     int has_prog;           // some voice's program is not 0 (or its source is a resampler): k_leaf_sum<true>
     int has_rs;             // some voice's source is a resampler: the program instantiation stages windows + filter bank in LDS
+    int has_sp;             // some voice ends in a spatialiser stage: k_leaf_sum<true, false, true>
+    float* hist;            // [n_voices][SP_HIST]: the mono history each spatialiser voice enters THIS call with (copied from the ext
+                            // pool by k_voice_control, so that the render waves of block 0 read it while those of the last block
+                            // write the next call's into the pool)
     int n_gain_stages;  // 1 (sampler gain) + longest chain in the plan
     float* ramps;     // [K][n_voices][ramp_slots][stride], slot = 2*stage + channel
     int ramp_slots;

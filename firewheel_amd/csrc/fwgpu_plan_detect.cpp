@@ -109,7 +109,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
             if (end < 0) {  // null voice: k_voice_control emits a constant silent, cleared-source record for it
                 VoiceDesc vd;
                 memset(&vd, 0, sizeof(vd));
-                vd.sampler_state = vd.bq_state = vd.dl_state = -1;
+                vd.sampler_state = vd.bq_state = vd.dl_state = vd.sp_ext_off = -1;
                 fb.voices.push_back(vd);
                 fb.progs.push_back(0u);
                 continue;
@@ -119,6 +119,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
             std::vector<int> chain;
             int cur = end;
             int bq = -1, dl = -1;
+            bool sp_voice = false;
             for (;;) {
                 const PlanNode& n = plan.nodes[cur];
                 if (covered[cur]) return false;
@@ -131,6 +132,12 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
                 if (n.kind == K_VOLUME || n.kind == K_PAN || n.kind == K_WIDTH || n.kind == K_HARD_CLIP) {
                     if (bq >= 0 || dl >= 0) return false;  // gain stages before the filter: generic executor
                     if (n.kind == K_WIDTH || n.kind == K_HARD_CLIP) fb.has_prog = true;
+                    chain.push_back(cur);
+                } else if (n.kind == K_SPATIAL) {
+                    // a spatialiser as the LAST node of a dry voice (the first one met walking up from the mixer); its 64-frame
+                    // history needs whole 64-frame blocks
+                    if (!chain.empty() || bq >= 0 || dl >= 0 || mbf % 64 != 0) return false;
+                    sp_voice = true;
                     chain.push_back(cur);
                 } else if (n.kind == K_DELAY) {
                     if (bq >= 0 || dl >= 0) return false;
@@ -161,13 +168,20 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
                 fb.has_prog = true;                    // the polyphase fetch lives in the leaf kernel's program instantiation
                 fb.has_rs = true;
             }
+            vd.sp_ext_off = -1;
+            if (sp_voice) {
+                if (bq >= 0 || dl >= 0 || vd.src_kind == 1) return false;  // (dry sampler voices only: generic executor otherwise)
+                fb.has_prog = true;
+                fb.has_sp = true;
+                vd.sp_ext_off = 0;  // the node's ext slice: filled in by the plan build (the node may be activated by this very plan)
+            }
             vd.n_stages = (int)chain.size();
             uint32_t prog = 0;
             for (int j = 0; j < vd.n_stages; ++j) {  // schedule order: nearest the sampler first
                 const PlanNode& n = plan.nodes[chain[chain.size() - 1 - j]];
                 vd.stage_kind[j] = n.kind;
                 vd.stage_state[j] = (int)n.slot;
-                prog |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : SK_GAIN) << (4 * j);
+                prog |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : n.kind == K_SPATIAL ? SK_SPATIAL : SK_GAIN) << (4 * j);
             }
             fb.progs.push_back(prog);
             fb.max_stages = std::max(fb.max_stages, vd.n_stages);
@@ -273,7 +287,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         std::vector<VoiceDesc> voices;
         std::vector<uint32_t> progs;
         std::vector<int> nodes;
-        bool prog = false, rs = false, fx = false;
+        bool prog = false, rs = false, fx = false, sp = false;
         int stages = 0, real = 0;
         uint64_t min_delay = ~0ull;
         bool split = false;  // only the leading ports are voices: the SumNode stays on the levels as a continuation
@@ -292,7 +306,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
             const Bank before = bk;  // (a port that turns out not to be a voice chain leaves the bank as it was)
             VoiceDesc vd;
             memset(&vd, 0, sizeof(vd));
-            vd.sampler_state = vd.bq_state = vd.dl_state = -1;
+            vd.sampler_state = vd.bq_state = vd.dl_state = vd.sp_ext_off = -1;
             if (s.in_src_node[2 * p] < 0 && s.in_src_node[2 * p + 1] < 0) {  // an empty voice slot: a null voice
                 bk.voices.push_back(vd);
                 bk.progs.push_back(0u);
@@ -307,6 +321,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
             // walking upstream: gain stages, then [delay], then [biquad], then the source (as detect_fused)
             std::vector<int> chain;
             int bq = -1, dl = -1;
+            bool sp_voice = false;
             for (;;) {
                 const PlanNode& n = plan.nodes[cur];
                 if (taken[cur] || n.is_graph_io) {
@@ -326,6 +341,13 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
                         ok = false;
                         break;
                     }
+                    chain.push_back(cur);
+                } else if (n.kind == K_SPATIAL) {  // (as detect_fused: the last node of a dry sampler voice)
+                    if (!chain.empty() || bq >= 0 || dl >= 0 || mbf % 64 != 0) {
+                        ok = false;
+                        break;
+                    }
+                    sp_voice = true;
                     chain.push_back(cur);
                 } else if (n.kind == K_DELAY) {
                     if (bq >= 0 || dl >= 0 || graph.nodes[n.slot].init.loop_end < 64) {
@@ -351,11 +373,15 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
                 }
                 cur = src;
             }
+            if (ok && sp_voice && (bq >= 0 || dl >= 0 || plan.nodes[cur].kind == K_RESAMPLER)) ok = false;
             if (!ok) {
                 bk = before;
                 bk.nodes.resize(nodes_before);
                 break;
             }
+            vd.sp_ext_off = sp_voice ? 0 : -1;
+            bk.sp = bk.sp || sp_voice;
+            bk.prog = bk.prog || sp_voice;
             vd.sampler_state = (int)plan.nodes[cur].slot;
             vd.src_kind = plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0;
             vd.bq_state = bq >= 0 ? (int)plan.nodes[bq].slot : -1;
@@ -368,7 +394,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
                 const PlanNode& n = plan.nodes[chain[chain.size() - 1 - j]];
                 vd.stage_kind[j] = n.kind;
                 vd.stage_state[j] = (int)n.slot;
-                pr |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : SK_GAIN) << (4 * j);
+                pr |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : n.kind == K_SPATIAL ? SK_SPATIAL : SK_GAIN) << (4 * j);
                 bk.prog = bk.prog || n.kind == K_WIDTH || n.kind == K_HARD_CLIP;
             }
             bk.stages = std::max(bk.stages, vd.n_stages);
@@ -400,7 +426,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         fx_mode = false;
     }
     auto keeps = [&](const Bank& bk, bool fxm) {
-        return fxm ? (!bk.prog && !bk.rs && bk.stages <= FW_CHAIN_STAGES - 1 && (int)bk.voices.size() <= 32) : !bk.fx;
+        return fxm ? (!bk.prog && !bk.rs && !bk.sp && bk.stages <= FW_CHAIN_STAGES - 1 && (int)bk.voices.size() <= 32) : !bk.fx;
     };
     if (fx_mode) {  // no bank with a filter survives the chain plan's rules: the dry banks are voice-bank banks, all of them
         bool any_fx = false;
@@ -429,6 +455,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         fb.progs.insert(fb.progs.end(), bk.progs.begin(), bk.progs.end());
         fb.has_prog = fb.has_prog || bk.prog || bk.rs;
         fb.has_rs = fb.has_rs || bk.rs;
+        fb.has_sp = fb.has_sp || bk.sp;
         fb.has_fx = fb.has_fx || bk.fx;
         fb.min_delay = std::min(fb.min_delay, bk.min_delay);
         fb.max_stages = std::max(fb.max_stages, bk.stages);

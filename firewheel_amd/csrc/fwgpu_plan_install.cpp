@@ -32,7 +32,7 @@ static int zero(fwgpu_ctx* c, void* p, size_t bytes) {
 
 void PlanImage::release_device() {
     DevBuf* bufs[] = {&d_nodes, &d_in_buf, &d_out_buf, &d_level_nodes, &d_pool, &d_flags, &d_gin_bufs, &d_gout_bufs, &d_groups, &d_blks2, &d_refs2,
-                      &d_gsets2, &d_ramps2, &d_progs, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
+                      &d_gsets2, &d_ramps2, &d_progs, &d_hist, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
                       &d_chain_start, &d_chain_dummy, &d_chain_stats, &d_up_nodes, &d_up_in, &d_up_out, &d_up_level_nodes, &d_root_bufs, &d_tail_nodes,
                       &d_tail_in, &d_tail_out, &d_tail_idx, &d_tail_frozen, &d_frozen_ph, &d_frozen, &d_fir_rows, &d_fir_tiles, &d_fir_partials,
                       &d_hlevel_nodes, &grow_states, &grow_ext, &d_state_inits, &d_ext_jobs};
@@ -57,7 +57,7 @@ static void reset_for_build(PlanImage& P) {
     P.level_kinds.clear();
     P.n_gout_bufs = P.n_gin_bufs = 0;
     P.slot_index.clear();
-    P.fused = P.fused_fx = P.ctl_ahead_on = P.fused_rs = P.fused_prog = P.hybrid = P.hybrid_fx = false;
+    P.fused = P.fused_fx = P.ctl_ahead_on = P.fused_rs = P.fused_prog = P.fused_sp = P.hybrid = P.hybrid_fx = false;
     P.generic_k = 1;
     P.chain_nq = 1;
     P.n_voices = P.n_leaves = P.ramp_slots = P.n_groups = P.n_tail = P.n_fused_real = 0;
@@ -515,6 +515,10 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         P.n_leaves = (int)fb.leaves.size();
         P.n_bus = fb.n_bus;
         P.ramp_slots = 2 * (1 + fb.max_stages);
+        for (VoiceDesc& vd : fb.voices)  // the spatialiser's history slice in the ext pool (its node may be activated by this very plan)
+            if (vd.sp_ext_off >= 0) vd.sp_ext_off = (int)node_init((uint32_t)vd.stage_state[vd.n_stages - 1]).ext_off;
+        P.fused_sp = fb.has_sp;
+        if (fb.has_sp) HIPC(c, P.d_hist.ensure_n("d_hist", fb.voices.size() * SP_HIST * sizeof(float)));
         if ((rc = up(c, P.d_voices, fb.voices.data(), fb.voices.size() * sizeof(VoiceDesc)))) return rc;
         if ((rc = up(c, P.d_leaves, fb.leaves.data(), fb.leaves.size() * sizeof(LeafDesc)))) return rc;
         if ((rc = up(c, P.d_progs, fb.progs.data(), fb.progs.size() * sizeof(uint32_t)))) return rc;
@@ -615,6 +619,10 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         P.up_root_node = -1;
         P.up_level_off.clear();
         P.up_level_cnt.clear();
+        for (VoiceDesc& vd : hb.voices)
+            if (vd.sp_ext_off >= 0) vd.sp_ext_off = (int)node_init((uint32_t)vd.stage_state[vd.n_stages - 1]).ext_off;
+        P.fused_sp = hb.has_sp;
+        if (hb.has_sp) HIPC(c, P.d_hist.ensure_n("d_hist", hb.voices.size() * SP_HIST * sizeof(float)));
         if ((rc = up(c, P.d_voices, hb.voices.data(), hb.voices.size() * sizeof(VoiceDesc)))) return rc;
         if ((rc = up(c, P.d_leaves, hb.leaves.data(), hb.leaves.size() * sizeof(LeafDesc)))) return rc;
         if ((rc = up(c, P.d_progs, hb.progs.data(), hb.progs.size() * sizeof(uint32_t)))) return rc;

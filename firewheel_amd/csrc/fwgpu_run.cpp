@@ -255,6 +255,8 @@ static void fill_fused_view(fwgpu_ctx* c, FusedView& fv) {
     fv.progs = c->d_progs.as<uint32_t>();
     fv.has_prog = c->fused_prog ? 1 : 0;
     fv.has_rs = c->fused_rs ? 1 : 0;
+    fv.has_sp = c->fused_sp ? 1 : 0;
+    fv.hist = c->d_hist.as<float>();
     fv.n_gain_stages = c->ramp_slots / 2;
     fv.ramps = c->d_ramps.as<float>();
     fv.ramp_slots = c->ramp_slots;
@@ -410,7 +412,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     FusedView fv;
     fill_fused_view(c, fv);
     // realtime edge: one block, tree = leaves + root, stereo stream -> the whole callback is ONE launch (k_rt_block)
-    if (K == 1 && c->rt_one_launch && !c->out_sil && !c->ahead_this_call && !c->fused_fx && !c->timing && c->n_tail == 0 && c->up_root_node >= 0 && n_out_ch == 2 &&
+    if (K == 1 && c->rt_one_launch && !c->fused_sp && !c->out_sil && !c->ahead_this_call && !c->fused_fx && !c->timing && c->n_tail == 0 && c->up_root_node >= 0 && n_out_ch == 2 &&
         c->up_level_cnt.size() == 1 && c->d_rt_sync.p) {
         DevView v;
         memset(&v, 0, sizeof(v));

@@ -105,6 +105,8 @@ enum : uint32_t {
     SK_GAIN = 0,   // volume / pan:  L *= g0;  R *= g1                                   (volume.rs:123-126)
     SK_WIDTH = 1,  // stereo width:  m = (L+R)*0.5; s = ((L-R)*0.5)*g0;  L = m+s; R = m-s (SPEC)
     SK_CLIP = 2,   // hard clip:     x = max(min(x, g0), -g0) on both channels            (hard_clip.rs:70-76)
+    SK_SPATIAL = 3,  // 3D spatialiser (SPEC), LAST stage only: m = (L+R)*0.5; L = m[i-dL]*g0; R = m[i-dR]*g1 with the
+                     // per-ear delays of the block's record (VB_SP_SHIFT) and the 64-frame mono history of the block before
 };
 
 struct VoiceDesc {  // static per voice chain: sampler -> [biquad] -> [delay] -> [volume|pan|width|hard clip]* -> leaf sum port
@@ -115,6 +117,7 @@ struct VoiceDesc {  // static per voice chain: sampler -> [biquad] -> [delay] ->
     int bq_state;                      // biquad between the sampler and the gain stages, -1 = none (k_chain plan)
     int dl_state;                      // delay after the biquad, -1 = none
     int src_kind;                      // 0 = SamplerNode, 1 = SPEC resampling source (sampler_state = its state; no gain of its own)
+    int sp_ext_off;                    // a SPEC spatialiser as the last stage: ext-pool offset of its SP_HIST-frame mono history; -1 = none
 };
 
 // per (block, voice) record written by the control kernels, read by the leaf kernel (80 B)
@@ -131,7 +134,12 @@ enum : uint32_t {
                           //   every such block carries a full VoiceBlk (the 16-tap polyphase fetch is the leaf kernel's slow path)
     VB_FMT_SHIFT = 24,    // VB_RESAMPLE blocks: bits 24..26 = the sample's format (FMT_*), src_l = its data, pad = its frames (< 2^31)
                           //   — the leaf kernel needs no second dependent load for the sample table
-    VB_RAMP_SHIFT = 8,    // bit (VB_RAMP_SHIFT + 2*stage + ch): that gain is a per-frame ramp
+    VB_RAMP_SHIFT = 8,    // bit (VB_RAMP_SHIFT + 2*stage + ch): that gain is a per-frame ramp (12 bits: 8..19)
+    VB_RAMP_MASK = 0xfffu << 8,
+    VB_SP_SHIFT = 20,     // voices whose last stage is a spatialiser: bits 20..25 = left-ear delay, 26..31 = right-ear delay (frames,
+                          //   <= 63) in force for this block — in VoiceBlk::flags AND VoiceRef::flags_gset (such a voice's source is
+                          //   never a resampler, so the VB_FMT bits are free)
+    VB_SP_MASK = 0xfffu << 20,
 };
 struct VoiceBlk {
     uint32_t flags;

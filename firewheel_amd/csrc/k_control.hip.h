@@ -237,7 +237,7 @@ __device__ __forceinline__ void blk_set_source(VoiceBlk& d, const SampleDesc& sd
             d.src_r = (d.flags & VB_MONO) ? d.src_l : d.src_l + sd.frames;
         }
         // VB_SIMPLE blocks carry no full descriptor, so they must never need the per-element path (ragged tail)
-        if ((d.flags >> VB_RAMP_SHIFT) == 0 && (frames & 3) == 0 && simple_class(sd, d.off0, fx) != SF_NONE) d.flags |= VB_SIMPLE;
+        if ((d.flags & VB_RAMP_MASK) == 0 && (frames & 3) == 0 && simple_class(sd, d.off0, fx) != SF_NONE) d.flags |= VB_SIMPLE;
     }
 }
 
@@ -355,6 +355,7 @@ __device__ __forceinline__ void put_blk(const FusedView& fv, int vi, int kk, con
         }
     }
     ref.flags_gset = (d.flags & 0xffu) | (gset << 8) | (cls << 16);
+    if (!(d.flags & VB_RESAMPLE)) ref.flags_gset |= d.flags & VB_SP_MASK;  // a spatialiser voice's per-ear delays (never a resampler's)
     fv.refs[ref_index(vi, kk, fv.ref_kgroups)] = ref;  // (tiled: the tail lanes store eight full 128-B lines)
     const bool need_full = fx ? !(d.flags & VB_SIMPLE) : !(d.flags & (VB_SIMPLE | VB_SILENT));
     if (need_full) fv.blks[(size_t)kk * fv.n_voices + vi] = d;
@@ -404,7 +405,7 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
     VoiceRef lean_ref;
     lean_ref.src_l = nullptr;
     lean_ref.r_delta = (job.flags & VB_MONO) ? 0u : (uint32_t)sd.frames;
-    lean_ref.flags_gset = ((job.flags | VB_SIMPLE) & 0xffu) | (gset << 8) | ((uint32_t)SF_P_F32 << 16);
+    lean_ref.flags_gset = ((job.flags | VB_SIMPLE) & 0xffu) | (gset << 8) | ((uint32_t)SF_P_F32 << 16) | (job.flags & VB_SP_MASK);
     if (job.mode == 1) {
         // all quantities fit 32 bits whenever the loop does (the usual case): avoid 64-bit division
         const uint64_t L = job.loop_end - job.loop_start;
@@ -535,6 +536,19 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         }
         return;
     }
+
+    // a voice that ends in a spatialiser: the 64-frame mono history it enters this call with goes from the node's ext slice into
+    // the call's scratch — the render waves of block 0 read the scratch while the waves of the last block write the pool
+    const bool spv = vd.sp_ext_off >= 0;
+    const int sp_j = vd.n_stages - 1;  // (the spatialiser is the last stage)
+    int sp_dl = 0, sp_dr = 0;
+    if (spv) {
+        fv.hist[(size_t)vi * SP_HIST + lane] = fv.ext[(size_t)vd.sp_ext_off + lane];
+        const NodeState* sn = &fv.states[vd.stage_state[sp_j]];
+        sp_dl = sn->playing;
+        sp_dr = sn->has_loop;
+    }
+    auto sp_bits = [&]() -> uint32_t { return spv ? ((uint32_t)(sp_dl & 63) | ((uint32_t)(sp_dr & 63) << 6)) << VB_SP_SHIFT : 0u; };
 
     // ---- k_chain plan: what both channel workgroups of the voice's leaf share is owned HERE — the record holds the
     // values at the start of this call (k_chain replays the call's messages block by block from them), the node state
@@ -769,12 +783,18 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
 #pragma unroll
             for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
                 if (j < vd.n_stages) {
-                    NodeState tmp;  // only p0/p1 apply to gain stages
+                    NodeState tmp;  // only p0/p1 apply to gain stages (+ a spatialiser's per-ear delays: CMD_SP_ITD)
                     tmp.p0 = st[j].p0;
                     tmp.p1 = st[j].p1;
+                    tmp.playing = sp_dl;
+                    tmp.has_loop = sp_dr;
                     cur_st[j] = apply_cmds_from(tmp, vd.stage_state[j], cb, fv.cmds, fv.n_cmds, fv.samples, cur_st[j]);
                     st[j].p0 = tmp.p0;
                     st[j].p1 = tmp.p1;
+                    if (spv && j == sp_j) {
+                        sp_dl = tmp.playing;
+                        sp_dr = tmp.has_loop;
+                    }
                 }
             }
             if (ss.sample >= 0 && ss.playing && cached_sample != ss.sample) {
@@ -834,6 +854,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         // a biquad / delay between the sampler and the gain stages never reports silence (SPEC nodes: out mask 0)
         const bool src_silent = silent;
         if (fx) silent = false;
+        bool sp_in_zero = false;  // the spatialiser's input buffers are cleared zeros this block
         // ---- chain stages in schedule order
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
@@ -873,6 +894,23 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                     d.g[j + 1][0] = rl.c;
                     d.g[j + 1][1] = rr.c;
                 }
+            } else if (vd.stage_kind[j] == K_SPATIAL) {
+                // SPEC spatialiser (k_generic.hip.h K_SPATIAL): no silence shortcut — both ear-gain smoothers advance every block,
+                // the node always writes (delayed input x gain: the last 63 frames of a voice that stopped still sound), out mask 0
+                sp_in_zero = silent;
+                GainRun rl = smoother_begin(r.s0, r.p0, frames);
+                GainRun rr = smoother_begin(r.s1, r.p1, frames);
+                if (rl.ramp && ramp_emit(rl, frames, rb, nullptr, lane)) {
+                    d.flags |= 1u << (VB_RAMP_SHIFT + 2 * (j + 1));
+                    r.s0.last = rl.prev;
+                }
+                if (rr.ramp && ramp_emit(rr, frames, rb + fv.stride, nullptr, lane)) {
+                    d.flags |= 2u << (VB_RAMP_SHIFT + 2 * (j + 1));
+                    r.s1.last = rr.prev;
+                }
+                d.g[j + 1][0] = rl.c;
+                d.g[j + 1][1] = rr.c;
+                silent = false;
             } else if (vd.stage_kind[j] == K_WIDTH) {  // SPEC: silent input -> reset + clear; else mid/side with
                 if (silent) {                           // the smoothed width, out mask 0 — silence passes through unchanged
                     smoother_reset(r.s0, r.p0);
@@ -889,10 +927,11 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             }
         }
         CTL_T(11);
-        const bool need_src = !src_silent && (fx || !silent);  // a dry voice whose output is muted fetches nothing
+        const bool need_src = !src_silent && !sp_in_zero && (fx || !silent);  // a dry voice whose output is muted fetches nothing
+        d.flags |= sp_bits();
         if (need_src && !(d.flags & VB_RESAMPLE)) blk_set_source(d, sd, frames, fxp);
-        else if (fxp && (d.flags >> VB_RAMP_SHIFT) == 0 && simple_frames) d.flags |= VB_SIMPLE;  // chain plan: cleared-source block
-        if (src_silent || (fxp && !need_src)) d.flags |= VB_SRC_ZERO;
+        else if (fxp && (d.flags & VB_RAMP_MASK) == 0 && simple_frames) d.flags |= VB_SIMPLE;  // chain plan: cleared-source block
+        if (src_silent || sp_in_zero || (fxp && !need_src)) d.flags |= VB_SRC_ZERO;
         if (fxp && !need_src) d.flags &= ~(VB_WRAP | VB_TAIL_ZERO);  // nothing is fetched: where the source would wrap is moot
         if (silent) d.flags |= VB_SILENT;
         {
@@ -929,10 +968,17 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             }
         }
         bool sil = upstream_silent && !fx;
+        bool sp_zero = false;  // steady with a spatialiser whose input is cleared zeros (source stopped / muted upstream)
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
             if (j >= vd.n_stages || !steady) break;
             const StageRegs& r = st[j];
+            if (vd.stage_kind[j] == K_SPATIAL) {  // (its smoothers run whatever comes in; what goes out is never flagged silent)
+                sp_zero = sil || upstream_silent;
+                sil = false;
+                if (!smoother_is_constant(r.s0, r.p0) || !smoother_is_constant(r.s1, r.p1)) ramping = true;
+                continue;
+            }
             if (sil) {  // reset() every block: idempotent once applied
                 if (vd.stage_kind[j] != K_HARD_CLIP && !(r.s0.status == SM_INACTIVE && r.s0.input == r.p0)) steady = false;
                 if (vd.stage_kind[j] == K_PAN && !(r.s1.status == SM_INACTIVE && r.s1.input == r.p1)) steady = false;
@@ -947,7 +993,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         }
         // the continuation covers the common case only — a dry voice playing steadily while gains glide; silence anywhere
         // in the chain (resets instead of ramps) and chain-plan voices stay on the block-by-block path
-        if (ramping && (sil || upstream_silent || fx || k + 1 >= K)) steady = false;
+        if (ramping && (sil || upstream_silent || sp_zero || fx || k + 1 >= K)) steady = false;
         if (!steady) continue;
         // ---- ramp continuation.  From here to the end of the call nothing happens to this voice but (a) its playhead
         // advancing — closed form, as on a steady tail — and (b) smoothers gliding to their targets, a serial recurrence
@@ -977,14 +1023,14 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                     StageRegs& r = st[j];
                     float* rb = rbase + (size_t)(j + 1) * 2 * fv.stride;
                     const int kind = vd.stage_kind[j];
-                    if (kind == K_VOLUME || kind == K_PAN || kind == K_WIDTH) {
+                    if (kind == K_VOLUME || kind == K_PAN || kind == K_WIDTH || kind == K_SPATIAL) {
                         if (!smoother_is_constant(r.s0, r.p0)) {
                             const int u = ramp_glide(r.s0, r.p0, frames, k + 1, K, rb, blk_stride, fv.stride, kind == K_VOLUME, lane);
                             ramp_until[2 * (j + 1)] = u;
                             if (kind == K_VOLUME) ramp_until[2 * (j + 1) + 1] = u;
                             furthest = u > furthest ? u : furthest;
                         }
-                        if (kind == K_PAN && !smoother_is_constant(r.s1, r.p1)) {
+                        if ((kind == K_PAN || kind == K_SPATIAL) && !smoother_is_constant(r.s1, r.p1)) {
                             const int u = ramp_glide(r.s1, r.p1, frames, k + 1, K, rb + fv.stride, blk_stride, fv.stride, false, lane);
                             ramp_until[2 * (j + 1) + 1] = u;
                             furthest = u > furthest ? u : furthest;
@@ -999,7 +1045,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         // smoother and `last` for one stalled at its f32 fixed point (Q28).
         TailJob job;
         job.mode = mode;
-        job.flags = (sil ? VB_SILENT : 0u) | (upstream_silent ? VB_SRC_ZERO : 0u);
+        job.flags = (sil ? VB_SILENT : 0u) | ((upstream_silent || sp_zero) ? VB_SRC_ZERO : 0u) | sp_bits();
         job.sample = upstream_silent ? -1 : ss.sample;
         job.playhead = ss.playhead;
         job.loop_start = ss.loop_start;
@@ -1017,7 +1063,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             if (j >= vd.n_stages) break;
             const StageRegs& r = st[j];
             job.g.g[j + 1][0] = vd.stage_kind[j] == K_HARD_CLIP ? r.p0 : (r.s0.status == SM_ACTIVE ? r.s0.last : r.s0.input);
-            job.g.g[j + 1][1] = vd.stage_kind[j] == K_PAN ? (r.s1.status == SM_ACTIVE ? r.s1.last : r.s1.input)
+            job.g.g[j + 1][1] = (vd.stage_kind[j] == K_PAN || vd.stage_kind[j] == K_SPATIAL) ? (r.s1.status == SM_ACTIVE ? r.s1.last : r.s1.input)
                                                           : job.g.g[j + 1][0];
         }
 #pragma unroll
@@ -1067,6 +1113,10 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
         if (j < vd.n_stages) *(StageRegs*)&fv.states[vd.stage_state[j]] = st[j];
+    if (spv) {
+        fv.states[vd.stage_state[sp_j]].playing = sp_dl;
+        fv.states[vd.stage_state[sp_j]].has_loop = sp_dr;
+    }
 }
 
 // Realtime edge (k_rt_block): ONE LANE per voice for the case that dominates a steady callback — a voice of the voice-bank

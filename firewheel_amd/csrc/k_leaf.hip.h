@@ -47,11 +47,16 @@ __device__ __forceinline__ int64_t rs_slot(int64_t q, const int64_t len, const b
 }
 
 // RS: the plan has voices whose source is a resampler (only the program instantiation of the leaf kernel carries that code)
+// j_end: stages [0, j_end) are applied (a spatialiser voice stops in front of its last stage: leaf_sp_port does that one)
 template <bool RS>
 __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& d, uint32_t k, int voice, int f0, int frames,
-                                           v4f& xl, v4f& xr, uint32_t prog = 0u, RsLds rs = RsLds{nullptr, nullptr}) {
+                                           v4f& xl, v4f& xr, uint32_t prog = 0u, RsLds rs = RsLds{nullptr, nullptr}, int j_end = FW_MAX_STAGES) {
     const bool mono = d.flags & VB_MONO;
     bool rs_done = false;
+    if (d.flags & VB_SRC_ZERO) {  // (spatialiser voices: the chain in front of the last stage is cleared this block)
+        xl = xr = splat(0.f);
+        return;
+    }
     if (RS && (d.flags & VB_RESAMPLE) && rs.tab != nullptr) {
         // SPEC resampling source, staged through LDS.  The wave's (up to) 256 output frames of this port read the source
         // frames [i_first - 7, i_last + 8]: the active lanes fetch that window once, coalesced (consecutive lanes,
@@ -223,18 +228,18 @@ __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& 
         xl = sample_fetch4(sd, 0, ft, (uint32_t)f0, (uint32_t)frames);
         xr = mono ? xl : sample_fetch4(sd, 1, ft, (uint32_t)f0, (uint32_t)frames);
     }
-    const uint32_t rbits = d.flags >> VB_RAMP_SHIFT;
+    const uint32_t rbits = (d.flags & VB_RAMP_MASK) >> VB_RAMP_SHIFT;
     const uint32_t kinds = prog << 4;  // stage 0 is the sampler's own gain
     if (rbits == 0) {  // constant gains: sampler.rs:530-533 then volume.rs:123-126 / pan, one rounding each
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES; ++j)  // (no `break`: the loop must unroll, or d.g[] is indexed at run time and lands in scratch)
-            if (j < fv.n_gain_stages) apply_stage((kinds >> (4 * j)) & 15u, splat(d.g[j][0]), splat(d.g[j][1]), xl, xr);
+            if (j < fv.n_gain_stages && j < j_end) apply_stage((kinds >> (4 * j)) & 15u, splat(d.g[j][0]), splat(d.g[j][1]), xl, xr);
         // a mono sample is duplicated AFTER the sampler gain (sampler.rs:546-551); identical values either way
     } else {
         const float* rb = fv.ramps + ((size_t)k * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES; ++j) {
-            if (j < fv.n_gain_stages) {
+            if (j < fv.n_gain_stages && j < j_end) {
                 v4f gl = (rbits >> (2 * j)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j) * fv.stride) : splat(d.g[j][0]);
                 v4f gr = (rbits >> (2 * j + 1)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j + 1) * fv.stride) : splat(d.g[j][1]);
                 apply_stage((kinds >> (4 * j)) & 15u, gl, gr, xl, xr);
@@ -455,11 +460,191 @@ __device__ __forceinline__ void leaf_fast_cls(const float* my_l, uint32_t my_rd,
     }
 }
 
+// ---- a voice whose LAST stage is a SPEC spatialiser (k_generic.hip.h K_SPATIAL): m = (L + R) * 0.5 of what the
+// stages in front of it deliver; outL[i] = m[i - dL] * gL[i], outR[i] = m[i - dR] * gR[i]; the 64 frames in front of the wave's
+// piece come from — the block before (k > 0: re-rendered from ITS record, 64 frames on 16 lanes), the call's history scratch
+// (k == 0: what k_voice_control copied out of the node's ext slice), or the same block's earlier frames (a later piece of a long
+// block).  The mono row goes through LDS (64 history + 256 current floats per wave) and comes back shifted by the ear delays.
+// The wave that renders the LAST piece of the call's LAST block leaves the next call's history in the ext slice.
+struct SpPort {
+    uint32_t fg;       // the block's VoiceRef::flags_gset (VB_* flags, source class, ear delays)
+    const float* src;  // VB_SIMPLE: source of frame 0 / channel-1 offset
+    uint32_t rd;
+    uint32_t fg_prev;  // the same of the block before (k > 0)
+    const float* src_prev;
+    uint32_t rd_prev;
+};
+template <bool RS>
+__device__ __forceinline__ void sp_upstream(const FusedView& fv, uint32_t fg, const float* src, uint32_t rd, const GainSet* gs_lane, int p,
+                                            uint32_t k, int voice, int f0, int frames, uint32_t prog, int js, bool active, v4f& a, v4f& b) {
+    // what arrives at the spatialiser for frames f0 .. f0+3 of block k: source x stages [0, js]  (js = the spatialiser's index among
+    // the chain stages: gain-set rows 0 .. js are the sampler's gain and the stages in front of it)
+    a = b = splat(0.f);
+    if (!active || (fg & VB_SRC_ZERO)) return;
+    if (fg & VB_SIMPLE) {
+        simple_fetch((fg >> 16) & 7u, src, rd, f0, a, b);
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j)
+            if (j <= js) apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(gs_lane->g[j][0], p)), splat(readlane_f(gs_lane->g[j][1], p)), a, b);
+    } else {
+        const VoiceBlk d = fv.blks[(size_t)k * fv.n_voices + voice];
+        voice_eval<RS>(fv, d, k, voice, f0, frames, a, b, prog, RsLds{nullptr, nullptr}, js + 1);
+    }
+}
+
+// ---- the spatialiser stage's steady path: every port of the leaf a VB_SIMPLE voice of ONE source class and ONE stage program that
+// ends in a spatialiser.  SP_U ports' source quads (the piece + the 64 frames in front of it) are in flight together; each
+// port has its own mono row in LDS, so one wave barrier serves the batch.  Arithmetic = the port-by-port path below.
+#define SP_U 4
+#define SP_ROW (SP_HIST + 256)
+template <uint32_t CLS>
+__device__ __forceinline__ RawQuad sp_raw(const float* base, uint32_t rdelta, int f) {
+    if constexpr (CLS == SF_P_F32) {
+        RawQuad q;
+        q.a = (v4i)gload4(base + f);
+        q.b = (v4i)gload4(base + rdelta + f);
+        return q;
+    } else {
+        return raw_load<CLS>(base, rdelta, f);
+    }
+}
+template <uint32_t CLS>
+__device__ __forceinline__ void sp_cvt(const RawQuad& q, v4f& a, v4f& b) {
+    if constexpr (CLS == SF_P_F32) {
+        a = (v4f)q.a;
+        b = (v4f)q.b;
+    } else {
+        raw_convert<CLS>(q, a, b);
+    }
+}
+template <uint32_t CLS>
+__device__ __forceinline__ void leaf_sp_fast(const FusedView& fv, const LeafDesc& ld, const uint32_t k, const int K, const int part, const int wpk,
+                                             const uint32_t prog, const int jn, const float* my_l, const uint32_t my_rd, const GainSet& my_g,
+                                             const uint32_t fg, const uint64_t plp, const uint32_t rdp, const GainSet& gp, float* sp_lds,
+                                             float* outl, float* outr) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int frames = fv.frames;
+    const int tq = (lane & 15) * 4;
+    for (int f0 = lane * 4 + part * 256; f0 - lane * 4 < frames; f0 += 256 * wpk) {
+        const int fb = f0 - lane * 4;
+        const bool act = f0 < frames;
+        const int hmode = fb > 0 ? 0 : (k > 0 ? 1 : 2);  // the 64 frames before the piece: same block / the block before / the call before
+        v4f accl = splat(0.f), accr = splat(0.f);
+        for (int p0 = 0; p0 < ld.ports; p0 += SP_U) {
+            RawQuad q[SP_U], t[SP_U];
+#pragma unroll
+            for (int u = 0; u < SP_U; ++u) q[u].a = q[u].b = t[u].a = t[u].b = (v4i){0, 0, 0, 0};
+            if (act) {
+#pragma unroll
+                for (int u = 0; u < SP_U; ++u)
+                    if (p0 + u < ld.ports)
+                        q[u] = sp_raw<CLS>(readlane_ptr(my_l, p0 + u), (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p0 + u), f0);
+            }
+            if (lane < 16) {
+                if (hmode == 0) {
+#pragma unroll
+                    for (int u = 0; u < SP_U; ++u)
+                        if (p0 + u < ld.ports)
+                            t[u] = sp_raw<CLS>(readlane_ptr(my_l, p0 + u), (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p0 + u), fb - SP_HIST + tq);
+                } else if (hmode == 1) {
+#pragma unroll
+                    for (int u = 0; u < SP_U; ++u)
+                        if (p0 + u < ld.ports) {
+                            const uint64_t qp = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(plp >> 32), p0 + u) << 32) |
+                                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)plp, p0 + u);
+                            t[u] = sp_raw<CLS>((const float*)qp, (uint32_t)__builtin_amdgcn_readlane((int)rdp, p0 + u), frames - SP_HIST + tq);
+                        }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < SP_U; ++u)
+                        if (p0 + u < ld.ports) t[u].a = (v4i)gload4(fv.hist + (size_t)(ld.first_voice + p0 + u) * SP_HIST + tq);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SP_U; ++u) {
+                if (p0 + u < ld.ports) {
+                    const int p = p0 + u;
+                    float* row = sp_lds + u * SP_ROW;
+                    v4f a, b;
+                    sp_cvt<CLS>(q[u], a, b);
+#pragma unroll
+                    for (int j = 0; j < FW_MAX_STAGES; ++j)
+                        if (j <= jn) apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)), a, b);
+                    v4f m = (a + b) * 0.5f;
+                    if (!act) m = splat(0.f);
+                    v4f tm;
+                    if (hmode == 2) {
+                        tm = (v4f)t[u].a;
+                    } else {
+                        v4f ta, tb;
+                        sp_cvt<CLS>(t[u], ta, tb);
+                        if (hmode == 0) {
+#pragma unroll
+                            for (int j = 0; j < FW_MAX_STAGES; ++j)
+                                if (j <= jn)
+                                    apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)), ta, tb);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < FW_MAX_STAGES; ++j)
+                                if (j <= jn) apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(gp.g[j][0], p)), splat(readlane_f(gp.g[j][1], p)), ta, tb);
+                        }
+                        tm = (ta + tb) * 0.5f;
+                    }
+                    if (lane < 16) *(v4f*)(row + tq) = tm;
+                    *(v4f*)(row + SP_HIST + lane * 4) = m;
+                    // the last piece of the call's last block leaves the next call's history behind
+                    if ((int)k == K - 1 && fb + 256 >= frames && act && f0 >= frames - SP_HIST)
+                        *(v4f*)(fv.ext + (size_t)fv.voices[ld.first_voice + p].sp_ext_off + (f0 - (frames - SP_HIST))) = m;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int u = 0; u < SP_U; ++u) {
+                if (p0 + u < ld.ports) {
+                    const int p = p0 + u;
+                    const float* row = sp_lds + u * SP_ROW + SP_HIST + lane * 4;
+                    const uint32_t pfg = (uint32_t)__builtin_amdgcn_readlane((int)fg, p);
+                    const int dl = (int)((pfg >> VB_SP_SHIFT) & 63u), dr = (int)((pfg >> (VB_SP_SHIFT + 6)) & 63u);
+                    v4f ml, mr;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ml[e] = row[e - dl];
+                        mr[e] = row[e - dr];
+                    }
+                    float gl = 1.0f, gr = 1.0f;
+#pragma unroll
+                    for (int j = 1; j < FW_MAX_STAGES; ++j)
+                        if (j == jn + 1) {
+                            gl = readlane_f(my_g.g[j][0], p);
+                            gr = readlane_f(my_g.g[j][1], p);
+                        }
+                    const v4f xl = ml * gl, xr = mr * gr;
+                    if (p == 0) {  // sum.rs:117 — and a spatialiser's outputs are never flagged silent: no port is skipped
+                        accl = xl;
+                        accr = xr;
+                    } else {
+                        accl = accl + xl;
+                        accr = accr + xr;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // (the next batch overwrites the rows)
+        }
+        if (act) {
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(outl + f0), "v"(accl) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(outr + f0), "v"(accr) : "memory");
+        }
+    }
+}
+
 // PROG: some voice of the plan has a stage that is not a plain gain (width / hard clip) — lane p then also carries port
 // p's stage program.  The gains-only instantiation is the headline kernel and does not pay for the other ones' registers.
-template <bool PROG, bool RS = false, int U = LEAF_U>
+template <bool PROG, bool RS = false, int U = LEAF_U, bool SP = false>
 __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int leaf, const uint32_t k, const int part, const int wpk,
-                                              const RsLds rs = RsLds{nullptr, nullptr}) {
+                                              const RsLds rs = RsLds{nullptr, nullptr}, const int K = 1, float* sp_lds = nullptr) {
     const int lane = threadIdx.x & (WAVE - 1);
     const LeafDesc ld = fv.leaves[leaf];
     const int frames = fv.frames;
@@ -517,6 +702,170 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
         my_cls = cl;
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES; ++j) asm volatile("" : "+v"(my_g.g[j][0]), "+v"(my_g.g[j][1]));
+    }
+    if constexpr (SP) {
+        // a leaf with a spatialiser voice among its ports goes port by port (leaf_sp below); the other leaves of the plan take
+        // the batched paths as before
+        bool my_sp = false;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) my_sp = my_sp || ((my_prog >> (4 * j)) & 15u) == SK_SPATIAL;
+        if (__ballot(my_sp && lane < ld.ports)) {
+            // lane p also keeps port p's record of the block BEFORE (the history of the wave's first piece is re-rendered from it)
+            VoiceRef refp;
+            refp.src_l = nullptr;
+            refp.r_delta = 0;
+            refp.flags_gset = VB_SRC_ZERO;
+            GainSet gp = my_g;
+            if (k > 0 && lane < ld.ports && my_sp) {
+                refp = fv.refs[ref_index(ld.first_voice + lane, (int)k - 1, fv.ref_kgroups)];
+                if (refp.flags_gset & VB_SIMPLE) gp = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + ((refp.flags_gset >> 8) & 0xffu)];
+            }
+            uint32_t fg = ref.flags_gset, fgp = refp.flags_gset, rdp = refp.r_delta;
+            uint64_t plp = (uint64_t)refp.src_l;
+            asm volatile("" : "+v"(fg), "+v"(fgp), "+v"(rdp), "+v"(plp));
+#pragma unroll
+            for (int j = 0; j < FW_MAX_STAGES; ++j) asm volatile("" : "+v"(gp.g[j][0]), "+v"(gp.g[j][1]));
+            {
+                // steady leaf: every port a spatialiser voice, VB_SIMPLE with a live source in this block (and in the block before, whose
+                // last 64 frames are the history), one source class, one stage program -> the batched path
+                const uint64_t lin = mask_all_silent_bits(ld.ports);
+                const uint32_t cls0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_cls);
+                const uint32_t prog0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_prog);
+                const bool ok_now = (fg & (VB_SIMPLE | VB_SRC_ZERO | VB_SILENT)) == VB_SIMPLE && my_cls == cls0 && my_prog == prog0 && my_sp;
+                const bool ok_prev = k == 0 || ((fgp & (VB_SIMPLE | VB_SRC_ZERO)) == VB_SIMPLE && ((fgp >> 16) & 7u) == cls0);
+                if ((__ballot(ok_now && ok_prev) & lin) == lin) {
+                    int jn0 = 0;
+#pragma unroll
+                    for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
+                        if (((prog0 >> (4 * j)) & 15u) == SK_SPATIAL) jn0 = j;
+#define SP_FAST(C) leaf_sp_fast<C>(fv, ld, k, K, part, wpk, prog0, jn0, my_l, my_rd, my_g, fg, plp, rdp, gp, sp_lds, outl, outr)
+                    switch (cls0) {
+                        case SF_P_F32: SP_FAST(SF_P_F32); break;
+                        case SF_P_I16: SP_FAST(SF_P_I16); break;
+                        case SF_P_U16: SP_FAST(SF_P_U16); break;
+                        case SF_I_I16: SP_FAST(SF_I_I16); break;
+                        case SF_I_U16: SP_FAST(SF_I_U16); break;
+                        default: SP_FAST(SF_I_F32); break;
+                    }
+#undef SP_FAST
+                    if (lane < 2 && part == 0) bflags[ld.out_buf + lane] = 0;
+                    return;
+                }
+            }
+            const int path_ports = ld.pad ? ld.pad : ld.ports;
+            const bool masked = !(path_ports == 2 || path_ports == 3 || path_ports == 4);  // sum.rs:67-133 (Q13)
+            for (int f0 = lane * 4 + part * 256; f0 - lane * 4 < frames; f0 += 256 * wpk) {
+                const int fb = f0 - lane * 4;  // first frame of the wave's piece
+                const bool act = f0 < frames;
+                v4f accl = splat(0.f), accr = splat(0.f);
+                bool any_live = false;
+                for (int p = 0; p < ld.ports; ++p) {
+                    const uint32_t pfg = (uint32_t)__builtin_amdgcn_readlane((int)fg, p);
+                    const uint32_t prog = (uint32_t)__builtin_amdgcn_readlane((int)my_prog, p);
+                    const int voice = ld.first_voice + p;
+                    const bool psil = (pfg & VB_SILENT) != 0;
+                    int jn = -1;  // chain-stage index of the spatialiser
+#pragma unroll
+                    for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
+                        if (((prog >> (4 * j)) & 15u) == SK_SPATIAL) jn = j;
+                    v4f xl = splat(0.f), xr = splat(0.f);
+                    if (jn < 0) {  // an ordinary voice under the same mixer
+                        if (!psil && act) {
+                            if (pfg & VB_SIMPLE) {
+                                simple_fetch((pfg >> 16) & 7u, readlane_ptr(my_l, p), (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p), f0, xl, xr);
+#pragma unroll
+                                for (int j = 0; j < FW_MAX_STAGES; ++j)
+                                    if (j < fv.n_gain_stages)
+                                        apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)), xl, xr);
+                            } else {
+                                const VoiceBlk d = fv.blks[row + p];
+                                voice_eval<RS>(fv, d, k, voice, f0, frames, xl, xr, prog, rs);
+                            }
+                        }
+                    } else {
+                        // what reaches the spatialiser: this piece ...
+                        v4f a, b;
+                        sp_upstream<RS>(fv, pfg, readlane_ptr(my_l, p), (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p), &my_g, p, k, voice, f0, frames,
+                                        prog, jn, act, a, b);
+                        const v4f m = (a + b) * 0.5f;
+                        // ... and the 64 frames in front of it (every group of 16 lanes renders the same 16 quads)
+                        v4f tm;
+                        const int tq = (lane & 15) * 4;
+                        if (fb > 0) {
+                            v4f ta, tb;
+                            sp_upstream<RS>(fv, pfg, readlane_ptr(my_l, p), (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p), &my_g, p, k, voice,
+                                            fb - SP_HIST + tq, frames, prog, jn, true, ta, tb);
+                            tm = (ta + tb) * 0.5f;
+                        } else if (k > 0) {
+                            const uint32_t qfg = (uint32_t)__builtin_amdgcn_readlane((int)fgp, p);
+                            const uint64_t qp = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(plp >> 32), p) << 32) |
+                                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)plp, p);
+                            v4f ta, tb;
+                            sp_upstream<RS>(fv, qfg, (const float*)qp, (uint32_t)__builtin_amdgcn_readlane((int)rdp, p), &gp, p, k - 1, voice,
+                                            frames - SP_HIST + tq, frames, prog, jn, true, ta, tb);
+                            tm = (ta + tb) * 0.5f;
+                        } else {
+                            tm = *(const v4f*)(fv.hist + (size_t)voice * SP_HIST + tq);
+                        }
+                        if (lane < 16) *(v4f*)(sp_lds + tq) = tm;
+                        *(v4f*)(sp_lds + SP_HIST + lane * 4) = m;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const int dl = (int)((pfg >> VB_SP_SHIFT) & 63u), dr = (int)((pfg >> (VB_SP_SHIFT + 6)) & 63u);
+                        v4f ml, mr;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ml[e] = sp_lds[SP_HIST + lane * 4 + e - dl];
+                            mr[e] = sp_lds[SP_HIST + lane * 4 + e - dr];
+                        }
+                        // the ear gains: constants of the gain set, or the block's ramps (full descriptor)
+                        v4f gl, gr;
+                        if (pfg & VB_SIMPLE) {
+                            gl = gr = splat(1.0f);
+#pragma unroll
+                            for (int j = 1; j < FW_MAX_STAGES; ++j)
+                                if (j == jn + 1) {
+                                    gl = splat(readlane_f(my_g.g[j][0], p));
+                                    gr = splat(readlane_f(my_g.g[j][1], p));
+                                }
+                        } else {
+                            const VoiceBlk d = fv.blks[row + p];
+                            const uint32_t rbits = (d.flags & VB_RAMP_MASK) >> VB_RAMP_SHIFT;
+                            const float* rb = fv.ramps + ((size_t)k * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + (act ? f0 : 0);
+                            gl = gr = splat(1.0f);
+#pragma unroll
+                            for (int j = 1; j < FW_MAX_STAGES; ++j)
+                                if (j == jn + 1) {
+                                    gl = (rbits >> (2 * j)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j) * fv.stride) : splat(d.g[j][0]);
+                                    gr = (rbits >> (2 * j + 1)) & 1u ? *(const v4f*)(rb + (size_t)(2 * j + 1) * fv.stride) : splat(d.g[j][1]);
+                                }
+                        }
+                        xl = ml * gl;
+                        xr = mr * gr;
+                        // the last piece of the call's last block leaves the next call's history behind
+                        if ((int)k == K - 1 && fb + 256 >= frames && act && f0 >= frames - SP_HIST)
+                            *(v4f*)(fv.ext + (size_t)fv.voices[voice].sp_ext_off + (f0 - (frames - SP_HIST))) = m;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();  // (the next port overwrites the row)
+                    }
+                    if (p == 0) {  // sum.rs:117 copy_from_slice(port 0) — also when silent; 2/3/4-port: in1
+                        accl = xl;
+                        accr = xr;
+                    } else if (!(masked && psil)) {  // :122-124 skip silent ports (n-port path only)
+                        accl = accl + xl;
+                        accr = accr + xr;
+                    }
+                    any_live = any_live || !psil;
+                }
+                if (act) {
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(outl + f0), "v"(accl) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(outr + f0), "v"(accr) : "memory");
+                }
+            }
+            if (lane < 2 && part == 0) bflags[ld.out_buf + lane] = 0;  // a spatialiser port is never silent: the mixer's out mask is 0
+            return;
+        }
     }
     const uint64_t lanes_in = mask_all_silent_bits(ld.ports);
     const uint64_t silent_ports = __ballot((my_flags & VB_SILENT) != 0) & lanes_in;
@@ -631,11 +980,14 @@ __device__ __forceinline__ RsLds rs_lds_setup(const FusedView& fv, float* dyn) {
 //   <false, false>  every stage a plain gain — the headline kernel
 //   <true,  false>  stage programs (width / hard clip)
 //   <true,  true>   ... and voices whose source is a resampler (LDS-staged polyphase fetch)
-template <bool PROG, bool RS>
+//   <true,  false, true>  ... and voices that end in a spatialiser (a 320-float mono row per wave in LDS)
+template <bool PROG, bool RS, bool SP = false>
 __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K, int wpk) {
     extern __shared__ float s_leaf_dyn[];
     RsLds rs{nullptr, nullptr};
     if constexpr (RS) rs = rs_lds_setup(fv, s_leaf_dyn);
+    __shared__ float s_sp[SP ? LEAF_WPB * SP_U * SP_ROW : 1];
+    float* sp_lds = SP ? s_sp + (threadIdx.x >> 6) * (SP_U * SP_ROW) : nullptr;
 #if LEAF_MAP_BLOCKS
     // the waves of a workgroup take CONSECUTIVE 256-frame pieces of one leaf's stream — wpk (1, 2 or 4) waves per
     // block, LEAF_WPB / wpk consecutive blocks: a steady voice's source is contiguous across blocks, so the workgroup
@@ -651,7 +1003,7 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
     if (leaf >= fv.n_leaves) return;
     const uint32_t k = blockIdx.y;
 #endif
-    leaf_sum_wave<PROG, RS>(fv, leaf, k, part, wpk, rs);
+    leaf_sum_wave<PROG, RS, LEAF_U, SP>(fv, leaf, k, part, wpk, rs, K, sp_lds);
 }
 
 // Upper sum tree of the fused plan, K-batched: SumNode semantics (nodes/sum.rs:41-136) with one THREAD per

@@ -104,10 +104,17 @@ void check_fused_common(const FusedView& fv, int K) {
         max_stages = vd.n_stages > max_stages ? vd.n_stages : max_stages;
         touch(&fv.states[vd.sampler_state], sizeof(NodeState));
         for (int j = 0; j < vd.n_stages; ++j) {
-            REQUIRE(vd.stage_kind[j] == K_VOLUME || vd.stage_kind[j] == K_PAN || vd.stage_kind[j] == K_WIDTH || vd.stage_kind[j] == K_HARD_CLIP,
+            REQUIRE(vd.stage_kind[j] == K_VOLUME || vd.stage_kind[j] == K_PAN || vd.stage_kind[j] == K_WIDTH || vd.stage_kind[j] == K_HARD_CLIP ||
+                        vd.stage_kind[j] == K_SPATIAL,
                     i, vd.stage_kind[j]);
             const uint32_t sk = (fv.progs[i] >> (4 * j)) & 15u;  // the leaf kernel's view of the same stage
-            REQUIRE(sk == (vd.stage_kind[j] == K_WIDTH ? SK_WIDTH : vd.stage_kind[j] == K_HARD_CLIP ? SK_CLIP : SK_GAIN), i, (long)sk);
+            REQUIRE(sk == (vd.stage_kind[j] == K_WIDTH ? SK_WIDTH : vd.stage_kind[j] == K_HARD_CLIP ? SK_CLIP : vd.stage_kind[j] == K_SPATIAL ? SK_SPATIAL : SK_GAIN), i, (long)sk);
+            if (vd.stage_kind[j] == K_SPATIAL) {  // the last stage of a dry sampler voice; its history slice and the call's scratch exist
+                REQUIRE(j == vd.n_stages - 1 && vd.src_kind == 0 && vd.bq_state < 0 && vd.dl_state < 0 && fv.has_sp && fv.frames % 64 == 0, i, j);
+                REQUIRE(vd.sp_ext_off >= 0, i, vd.sp_ext_off);
+                touch(fv.ext + vd.sp_ext_off, sizeof(float) * SP_HIST);
+                touch(fv.hist + (size_t)i * SP_HIST, sizeof(float) * SP_HIST);
+            }
             REQUIRE(sk == SK_GAIN || (fv.has_prog && !fv.fx_plan), i, j);
             touch(&fv.states[vd.stage_state[j]], sizeof(NodeState));
         }

@@ -1016,6 +1016,87 @@ def scenario_spatial_steady(e, n_sources=9, src_frames=4000, calls=(8, 70, 20, 2
     return np.concatenate(outs)
 
 
+def scenario_spatial_bank(e, n_voices=23, radix=8, src_frames=1700):
+    """sampler -> [volume] -> [pan | width | clip] -> SPATIALISER voices next to plain ones under radix-8 mixers — the voice-bank
+    plan's spatialiser stage: ear delays and gains moved by position messages (glides + delay switches at block starts), voices
+    that stop (one-shots end: the last 63 frames still sound, then cleared input with live smoothers), a voice muted upstream
+    (its spatialiser is fed cleared zeros), pauses and seeks (the history is what WAS played, not what precedes the new
+    position), mono samples, 16-bit sources, calls of 1 .. 40 blocks."""
+    rng = np.random.default_rng(4242)
+    voices, ends = [], []
+    for v in range(n_voices):
+        s = e.sampler(float(rng.uniform(60, 100)))
+        cur = s
+        vol = None
+        if v % 3 != 1:
+            vol = e.volume(float(rng.uniform(30, 100)))
+            e.connect_stereo(cur, vol)
+            cur = vol
+        mid = None
+        if v % 4 == 0:
+            mid = e.pan(float(rng.uniform(-1, 1)))
+        elif v % 4 == 2:
+            mid = e.width(float(rng.uniform(0.2, 1.8)))
+        elif v % 7 == 3:
+            mid = e.hard_clip(-6.0)
+        if mid is not None:
+            e.connect_stereo(cur, mid)
+            cur = mid
+        sp = None
+        if v % 5 != 4:  # every fifth voice stays dry
+            sp = e.spatial(float(rng.uniform(-5, 5)), float(rng.uniform(-1, 1)), float(rng.uniform(-5, 5)), n_in=2)
+            e.connect_stereo(cur, sp)
+            cur = sp
+        voices.append(dict(s=s, vol=vol, mid=mid, sp=sp))
+        ends.append(cur)
+    level = ends
+    while True:
+        nxt = []
+        for i in range(0, len(level), radix):
+            grp = level[i:i + radix]
+            m = e.sum(len(grp))
+            for p, n in enumerate(grp):
+                e.connect_stereo(n, m, 2 * p)
+            nxt.append(m)
+        level = nxt
+        if len(level) == 1:
+            break
+    e.connect_stereo(level[0], e.graph_out_node)
+    e.update()
+    for v, vc in enumerate(voices):
+        ch = 1 if v % 6 == 5 else 2
+        data = voice_source(9000 + v, src_frames + 41 * v, ch)
+        if v % 8 == 3:
+            smp = e.new_sample(PLANAR_I16, ch, np.round(data * 32767).astype(np.int16))
+        else:
+            smp = e.new_sample(PLANAR_F32, ch, data)
+        e.sampler_set_sample(vc["s"], smp)
+        if v % 3 != 2:
+            e.sampler_set_loop_range(vc["s"], LOOP_FULL)  # (the others are one-shots: they end inside the run)
+        if v != 7:
+            e.sampler_play(vc["s"])
+    outs = [e.process_blocks(2)]
+    sps = [vc for vc in voices if vc["sp"] is not None]
+    e.set_param(sps[0]["sp"], 0, 4.5)                       # hard right: both gains glide, the ear delays switch
+    e.set_param(sps[1]["sp"], 0, -3.0, at_block=1)
+    e.set_param(sps[2]["sp"], 2, 0.25, at_block=2)          # z: distance -> both gains
+    e.sampler_play(voices[7]["s"], at_block=1)              # a late starter: zero history
+    outs.append(e.process_blocks(5))
+    outs.append(e.process_blocks(1))
+    muted = next(vc for vc in sps if vc["vol"] is not None)
+    e.set_param(muted["vol"], 0, 0.0)                       # fades out upstream: ramp, then zeros that are not flagged ...
+    e.sampler_pause(sps[3]["s"], at_block=3)                # ... a paused source: cleared input, the tail of the history sounds
+    outs.append(e.process_blocks(40))
+    e.sampler_play(sps[3]["s"], at_block=1)
+    e.sampler_set_playhead_secs(sps[4]["s"], 0.01, at_block=2)   # a seek: the history is the audio before the jump
+    e.set_param(sps[0]["sp"], 0, -4.5, at_block=4)
+    outs.append(e.process_blocks(9))
+    e.set_param(muted["vol"], 0, 80.0)
+    outs.append(e.process_blocks(3))
+    outs.append(e.process_blocks(17))
+    return np.concatenate(outs)
+
+
 def reverb_ir(seed, taps, channels=2, decay=None):
     """exponentially decaying seeded noise, L1-normalised per channel."""
     decay = decay or taps / 4.0

@@ -78,6 +78,13 @@ def fuzz_run(e, seed):
                     g = e.hard_clip(float(rng.uniform(-18, 0)))
                 e.connect_stereo(cur, g)
                 cur = g
+        if shape == 0 and rng.random() < 0.25:
+            # ... and a 3D spatialiser as the voice's last node (the voice-bank plan's SK_SPATIAL stage: ear delays, 64-frame
+            # history across blocks and calls; param 0 = x moves it left / right: gain glides + delay switches)
+            g = e.spatial(float(rng.uniform(-4, 4)), float(rng.uniform(-1, 1)), float(rng.uniform(-4, 4)), n_in=2)
+            vc["pans"].append(g)
+            e.connect_stereo(cur, g)
+            cur = g
         voices.append(vc)
         ends.append(cur)
     level = ends

@@ -473,10 +473,25 @@ def test_hybrid_plan_voice_banks_inside_a_generic_graph_bit_exact(name, max_batc
 def test_resampler_and_spatialiser_scene_bit_exact(name):
     # (the steady scenes: resting spatialisers take their K blocks in parallel — max_batch 64 splits the 70- / 90-block calls)
     out_o, out_g, g = run_case(name)
-    assert g.cx.plan_kind() == 0
+    # resampler -> spatialiser sources: the level executor; sampler -> spatialiser voices under a mixer: the voice-bank plan's
+    # spatialiser stage (round 3: SK_SPATIAL in k_leaf_sum, history re-rendered from the block before)
+    assert g.cx.plan_kind() == (1 if name.startswith("spatial_steady") else 0)
     assert_bits_equal(out_o, out_g, name)
     gold = json.load(open(GOLDEN))
     assert digest(out_g) == gold[name]
+
+
+@pytest.mark.parametrize("mbf,max_batch", [(128, 64), (64, 8), (256, 1), (512, 16)])
+def test_spatialiser_voices_on_the_voice_bank_plan_bit_exact(mbf, max_batch):
+    g = GpuEngine(max_block_frames=mbf, max_batch=max_batch)
+    o = scenarios.TaggedOracle(OracleEngine(max_block_frames=mbf))
+    out_g = scenarios.scenario_spatial_bank(g)
+    out_o = scenarios.scenario_spatial_bank(o)
+    assert g.cx.plan_kind() == 1 and g.cx.plan_fused_voices() == 23
+    assert_bits_equal(out_o, out_g, "spatial bank mbf %d batch %d" % (mbf, max_batch))
+    # ... and the level executor agrees (same graph, generic plan): the two paths hand the history to each other's blocks
+    f = GpuEngine(max_block_frames=mbf, max_batch=max_batch, force_generic=True)
+    assert_bits_equal(out_o, scenarios.scenario_spatial_bank(f), "spatial bank, level executor")
 
 
 @pytest.mark.parametrize("fmt", [fwapi.PLANAR_F32, fwapi.INTERLEAVED_I16, fwapi.PLANAR_U16])
@@ -523,10 +538,25 @@ def test_spatial_node_level(n_in, pos):
 @pytest.mark.parametrize("name", ["cfg4_reverb", "cfg4_reverb_2irs_mono"])
 def test_cfg4_fir_reverb_mfma_bit_exact(name):
     out_o, out_g, g = run_case(name)
-    assert g.cx.plan_kind() == 0
+    # resampler -> spatialiser sources: the level executor; sampler -> spatialiser voices under a mixer: the voice-bank plan's
+    # spatialiser stage (round 3: SK_SPATIAL in k_leaf_sum, history re-rendered from the block before)
+    assert g.cx.plan_kind() == (1 if name.startswith("spatial_steady") else 0)
     assert_bits_equal(out_o, out_g, name)
     gold = json.load(open(GOLDEN))
     assert digest(out_g) == gold[name]
+
+
+@pytest.mark.parametrize("mbf,max_batch", [(128, 64), (64, 8), (256, 1), (512, 16)])
+def test_spatialiser_voices_on_the_voice_bank_plan_bit_exact(mbf, max_batch):
+    g = GpuEngine(max_block_frames=mbf, max_batch=max_batch)
+    o = scenarios.TaggedOracle(OracleEngine(max_block_frames=mbf))
+    out_g = scenarios.scenario_spatial_bank(g)
+    out_o = scenarios.scenario_spatial_bank(o)
+    assert g.cx.plan_kind() == 1 and g.cx.plan_fused_voices() == 23
+    assert_bits_equal(out_o, out_g, "spatial bank mbf %d batch %d" % (mbf, max_batch))
+    # ... and the level executor agrees (same graph, generic plan): the two paths hand the history to each other's blocks
+    f = GpuEngine(max_block_frames=mbf, max_batch=max_batch, force_generic=True)
+    assert_bits_equal(out_o, scenarios.scenario_spatial_bank(f), "spatial bank, level executor")
 
 
 def test_fir_long_ir_impulse_and_linearity_properties():

@@ -52,122 +52,14 @@ template <bool RS>
 __device__ __forceinline__ void voice_eval(const FusedView& fv, const VoiceBlk& d, uint32_t k, int voice, int f0, int frames,
                                            v4f& xl, v4f& xr, uint32_t prog = 0u, RsLds rs = RsLds{nullptr, nullptr}, int j_end = FW_MAX_STAGES) {
     const bool mono = d.flags & VB_MONO;
-    bool rs_done = false;
     if (d.flags & VB_SRC_ZERO) {  // (spatialiser voices: the chain in front of the last stage is cleared this block)
         xl = xr = splat(0.f);
         return;
     }
-    if (RS && (d.flags & VB_RESAMPLE) && rs.tab != nullptr) {
-        // SPEC resampling source, staged through LDS.  The wave's (up to) 256 output frames of this port read the source
-        // frames [i_first - 7, i_last + 8]: the active lanes fetch that window once, coalesced (consecutive lanes,
-        // consecutive frames; converted and wrapped / zero-filled on the way in), and each lane then runs its four frames'
-        // 16-tap fmaf chains — ascending from +0.0, the arithmetic of k_generic's K_RESAMPLER — from LDS, the coefficients
-        // from the workgroup's copy of the filter bank.  (The per-lane global fetch below issues 192 vector-memory
-        // instructions per lane and port and is bound by exactly that.)
-        const int lane = threadIdx.x & (WAVE - 1);
-        const int fbase = __builtin_amdgcn_readfirstlane(f0 - lane * 4);   // the wave's piece of the block starts here
-        const int nfr = frames - fbase < 256 ? frames - fbase : 256;
-        const int nact = (nfr + 3) >> 2;                                    // active lanes: 0 .. nact-1
-        const uint64_t p_first = d.off0 + (uint64_t)fbase * d.off1;
-        const uint64_t p_last = d.off0 + (uint64_t)(fbase + nfr - 1) * d.off1;
-        const uint64_t i_first = p_first >> 32;
-        const uint64_t W = (p_last >> 32) - i_first + RS_TAPS;
-        if (W <= RS_WIN) {
-            SampleDesc sd;  // (the descriptor carries the sample: no second dependent load for the table)
-            sd.data = d.src_l;
-            sd.frames = d.pad;
-            sd.channels = mono ? 1 : 2;
-            sd.format = (int)((d.flags >> VB_FMT_SHIFT) & 7u);
-            const int64_t len = (int64_t)sd.frames;
-            const bool loop = d.n1 != 0;
-            // source index of window slot 0 (loops: one 32-bit remainder, the slots wrap by comparison)
-            const int64_t q_base = (loop ? (int64_t)((uint32_t)i_first % (uint32_t)len) : (int64_t)i_first) - (RS_TAPS / 2 - 1);
-            float* w0 = rs.win;
-            float* w1 = rs.win + RS_WIN;
-#define slot(r, in) rs_slot(q_base + (r), len, loop, in)
-            int r_done = 0;
-            if (sd.format == FMT_P_F32) {
-                // planar f32: the first 8 rounds of the window (all of it up to ratio ~1.8) are requested before any is stored
-                // — ONE memory round trip instead of one per round
-                const float* s0 = (const float*)sd.data;
-                const float* s1 = s0 + (mono ? 0 : len);
-#define RS_ROUND(u, a, b)                                    \
-    {                                                        \
-        const int r = lane + (u) * nact;                     \
-        bool in = false;                                     \
-        const int64_t q = r < (int)W ? slot(r, in) : 0;      \
-        a = in ? s0[q] : 0.f;                                \
-        b = in && !mono ? s1[q] : 0.f;                       \
-    }
-#define RS_STORE(u, a, b)                                    \
-    {                                                        \
-        const int r = lane + (u) * nact;                     \
-        if (r < (int)W) {                                    \
-            w0[r] = a;                                       \
-            if (!mono) w1[r] = b;                            \
-        }                                                    \
-    }
-                float a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
-                RS_ROUND(0, a0, b0) RS_ROUND(1, a1, b1) RS_ROUND(2, a2, b2) RS_ROUND(3, a3, b3)
-                RS_ROUND(4, a4, b4) RS_ROUND(5, a5, b5) RS_ROUND(6, a6, b6) RS_ROUND(7, a7, b7)
-                RS_STORE(0, a0, b0) RS_STORE(1, a1, b1) RS_STORE(2, a2, b2) RS_STORE(3, a3, b3)
-                RS_STORE(4, a4, b4) RS_STORE(5, a5, b5) RS_STORE(6, a6, b6) RS_STORE(7, a7, b7)
-#undef RS_ROUND
-#undef RS_STORE
-                r_done = 8 * nact;
-            }
-            for (int r = r_done + lane; r < (int)W; r += nact) {
-                bool in;
-                const int64_t q = slot(r, in);
-                w0[r] = in ? sample_fetch(sd, 0, (uint64_t)q) : 0.f;
-                if (!mono) w1[r] = in ? sample_fetch(sd, 1, (uint64_t)q) : 0.f;
-            }
-#undef slot
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // Frames are dealt to the lanes ROUND-ROBIN for the convolution (lane l: frames l, l + nact, ...): neighbouring lanes
-            // then read neighbouring window slots (stride = the ratio) and, from the bank stored tap-major, coefficient
-            // addresses t * 32 + phase — one LDS bank per phase.  (Four consecutive frames per lane, the layout of the rest of
-            // the kernel, puts 64 lanes on 8 banks at ratio 1, and a phase-major bank puts every lane on 2.)  The results go
-            // through LDS once more to come back as each lane's four consecutive frames.
-            float* o0 = rs.win + 2 * RS_WIN;
-            float* o1 = o0 + 256;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int f = lane + i * nact;
-                if (f < nfr) {
-                    const uint64_t p = d.off0 + (uint64_t)(fbase + f) * d.off1;
-                    const float* hp = rs.tab + ((uint32_t)(p >> 27) & (RS_PHASES - 1));
-                    const int r0 = (int)((p >> 32) - i_first);
-                    float al = 0.f, ar = 0.f;
-#pragma unroll
-                    for (int t = 0; t < RS_TAPS; ++t) {
-                        const float h = hp[t * RS_PHASES];
-                        al = __builtin_fmaf(h, w0[r0 + t], al);
-                        if (!mono) ar = __builtin_fmaf(h, w1[r0 + t], ar);
-                    }
-                    o0[f] = al;
-                    o1[f] = mono ? al : ar;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool in = f0 + j < frames;
-                xl[j] = in ? o0[lane * 4 + j] : 0.f;
-                xr[j] = in ? o1[lane * 4 + j] : 0.f;
-            }
-            // the next port of this wave overwrites the window and the result rows: everybody is done reading first
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            rs_done = true;
-        }
-    }
-    if (rs_done) {
-    } else if (RS && (d.flags & VB_RESAMPLE)) {
+    (void)rs;  // (resampler ports of a leaf are rendered by leaf_rs_piece below, staged through LDS and pipelined port over port; what
+               //  reaches this function — a source format other than planar f32, a window beyond RS_WIN, a spatialiser's upstream —
+               //  takes the frame-by-frame fetch)
+    if (RS && (d.flags & VB_RESAMPLE)) {
         // SPEC resampling source — the arithmetic of the generic executor's K_RESAMPLER case (k_generic.hip.h), frame by frame:
         // 32.32 position, phase = top 5 fraction bits, 16-tap fmaf chain ascending from +0.0; outside a one-shot sample reads
         // 0, a loop wraps.  The taps of neighbouring frames overlap: the reuse is the L1's.
@@ -489,6 +381,196 @@ __device__ __forceinline__ void sp_upstream(const FusedView& fv, uint32_t fg, co
     } else {
         const VoiceBlk d = fv.blks[(size_t)k * fv.n_voices + voice];
         voice_eval<RS>(fv, d, k, voice, f0, frames, a, b, prog, RsLds{nullptr, nullptr}, js + 1);
+    }
+}
+
+// ---- resampler voices (SPEC resampling source): a leaf with such ports renders its pieces here.
+// Per resampler port the wave stages the source window its (up to) 256 output frames read — frames [i_first - 7, i_last + 8],
+// both channels INTERLEAVED as {L, R} pairs — in LDS: the active lanes fetch it coalesced (consecutive lanes, consecutive frames;
+// wrapped / zero-filled on the way in) and every lane then runs its four frames' 16-tap fmaf chains from LDS — ascending from
+// +0.0, the arithmetic of k_generic's K_RESAMPLER.  What the round-2 version of this path paid for:
+//   * LDS bytes: h, L and R as three ds_read_b32 per tap (128 B/clk/CU).  Now one ds_read_b64 {L, R} per tap and one ds_read_b64
+//     {h[2t], h[2t+1]} per tap PAIR from a bank stored [tap pair][phase][2] — b64 reads run at 256 B/clk/CU on CDNA4 (3 LDS cycles
+//     per tap instead of 6), and the two channels' fmaf are one packed instruction.
+//   * latency: descriptor load -> window fetch -> LDS -> convolution, one port after the other, ~3 waves per SIMD to hide it.  Now
+//     lane p holds port p's descriptor (one load for the leaf), and the NEXT resampler port's window is requested (8 rounds of
+//     registers) before the current one is convolved.
+// Frames are dealt to the lanes ROUND-ROBIN for the convolution (lane l: frames l, l + nact, ...): neighbouring lanes read
+// neighbouring window slots (stride = the ratio) and coefficient addresses phase-apart — no 4-way bank conflicts as with four
+// consecutive frames per lane; the results pass through LDS once more to come back as each lane's four consecutive frames.
+typedef float v2f_rs __attribute__((ext_vector_type(2)));
+#define RS_LOOP_BIT (1u << 31)  // lane-held copy of VoiceBlk::flags: n1 != 0 (the source loops) — bit 31 is free on a resampler block
+#define RS_ROUNDS 8
+typedef const float __attribute__((address_space(1)))* rs_gfp;  // (a generic pointer here makes the window fetch FLAT loads, which also
+                                                                 //  count on lgkmcnt: every LDS wait would then wait for the prefetch)
+typedef const volatile v2f_rs __attribute__((address_space(3)))* rs_lp;  // volatile: keeps ds_read_b64 (256 B/clk/CU) from being merged
+                                                                         // into ds_read2_b64 (128 B/clk/CU) — MI355X_MICROARCH.md §LDS
+struct RsPort {  // wave-uniform: one resampler port's piece
+    rs_gfp s0;
+    int len, qb, W;
+    uint32_t i_first;
+    uint64_t p_first, step;
+    bool mono, loop;
+};
+__device__ __forceinline__ int rs_slot32(const RsPort& P, const int r, bool& in) {
+    int q = P.qb + r;
+    in = r < P.W;
+    if (P.loop) {  // (len >= the window: one step either way)
+        if (q < 0) q += P.len;
+        if (q >= P.len) q -= P.len;
+    } else {
+        in = in && q >= 0 && q < P.len;
+    }
+    return in ? q : 0;
+}
+__device__ __forceinline__ void rs_issue(const RsPort& P, const int lane, const int nact, float (&a)[RS_ROUNDS], float (&b)[RS_ROUNDS]) {
+#pragma unroll
+    for (int u = 0; u < RS_ROUNDS; ++u) {
+        bool in;
+        const int q = rs_slot32(P, lane + u * nact, in);
+        a[u] = in ? P.s0[q] : 0.f;
+        b[u] = in && !P.mono ? P.s0[P.len + q] : 0.f;
+    }
+}
+__device__ __forceinline__ void rs_stage(const RsPort& P, const int lane, const int nact, const float (&a)[RS_ROUNDS], const float (&b)[RS_ROUNDS],
+                                         v2f_rs* win) {
+#pragma unroll
+    for (int u = 0; u < RS_ROUNDS; ++u) {
+        const int r = lane + u * nact;
+        if (r < P.W) win[r] = (v2f_rs){a[u], P.mono ? a[u] : b[u]};
+    }
+    for (int r = RS_ROUNDS * nact + lane; r < P.W; r += nact) {  // (a piece of few frames at a high ratio: the rest of the window)
+        bool in;
+        const int q = rs_slot32(P, r, in);
+        const float x = in ? P.s0[q] : 0.f;
+        const float y = in && !P.mono ? P.s0[P.len + q] : 0.f;
+        win[r] = (v2f_rs){x, P.mono ? x : y};
+    }
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t x, int lane) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
+}
+__device__ __forceinline__ RsPort rs_port(const int p, const int fbase, const int nfr, const float* my_l, const uint32_t my_rd, const uint64_t my_off0,
+                                          const uint64_t my_off1, const uint32_t my_df) {
+    RsPort P;
+    const uint32_t df = (uint32_t)__builtin_amdgcn_readlane((int)my_df, p);
+    P.s0 = (rs_gfp)(uint64_t)readlane_ptr(my_l, p);
+    P.len = __builtin_amdgcn_readlane((int)my_rd, p);
+    P.step = readlane_u64(my_off1, p);
+    P.p_first = readlane_u64(my_off0, p) + (uint64_t)fbase * P.step;
+    const uint64_t p_last = P.p_first + (uint64_t)(nfr - 1) * P.step;
+    P.i_first = (uint32_t)(P.p_first >> 32);
+    P.W = (int)((uint32_t)(p_last >> 32) - P.i_first) + RS_TAPS;
+    P.mono = df & VB_MONO;
+    P.loop = df & RS_LOOP_BIT;
+    P.qb = (int)(P.loop ? P.i_first % (uint32_t)P.len : P.i_first) - (RS_TAPS / 2 - 1);
+    return P;
+}
+template <bool PROG, bool RS>
+__device__ __forceinline__ void leaf_rs_piece(const FusedView& fv, const LeafDesc& ld, const uint32_t k, const size_t row, const int f0, const int frames,
+                                              const RsLds rs, const float* my_l, const uint32_t my_rd, const uint32_t my_cls, const GainSet& my_g,
+                                              const uint32_t my_prog, const uint64_t my_off0, const uint64_t my_off1, const uint32_t my_df,
+                                              const uint64_t silent_ports, const uint64_t simple_ports, const uint64_t rs_ports, const bool masked,
+                                              v4f& accl, v4f& accr) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int fbase = __builtin_amdgcn_readfirstlane(f0 - lane * 4);  // the wave's piece of the block starts here
+    const int nfr = frames - fbase < 256 ? frames - fbase : 256;
+    const int nact = (nfr + 3) >> 2;  // active lanes: 0 .. nact-1
+    v2f_rs* win = (v2f_rs*)rs.win;
+    v2f_rs* orow = win + RS_WIN;
+    const v2f_rs* tab = (const v2f_rs*)rs.tab;
+    float wa[RS_ROUNDS], wb[RS_ROUNDS];
+    RsPort N;  // the port whose window is in flight
+    int pn = rs_ports ? __builtin_ctzll(rs_ports) : 64;
+    if (pn < ld.ports) {
+        N = rs_port(pn, fbase, nfr, my_l, my_rd, my_off0, my_off1, my_df);
+        rs_issue(N, lane, nact, wa, wb);
+    }
+    for (int p = 0; p < ld.ports; ++p) {
+        const bool psil = (silent_ports >> p) & 1ull;
+        v4f xl = splat(0.f), xr = splat(0.f);  // a silent chain's buffers hold cleared zeros
+        if (!psil) {
+            const uint32_t prog = PROG ? (uint32_t)__builtin_amdgcn_readlane((int)my_prog, p) : 0u;
+            if ((rs_ports >> p) & 1ull) {
+                const RsPort P = N;  // (p == pn)
+                rs_stage(P, lane, nact, wa, wb, win);
+                const uint64_t later = p + 1 < 64 ? rs_ports >> (p + 1) : 0ull;
+                pn = later ? p + 1 + __builtin_ctzll(later) : 64;
+                if (pn < ld.ports) {
+                    N = rs_port(pn, fbase, nfr, my_l, my_rd, my_off0, my_off1, my_df);
+                    rs_issue(N, lane, nact, wa, wb);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint64_t dpos = (uint64_t)nact * P.step;
+                const uint64_t pos_last = P.p_first + (uint64_t)(nfr - 1) * P.step;
+                uint64_t pos = P.p_first + (uint64_t)lane * P.step;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // (frames past the piece's end convolve its last frame's window and drop the result: no branch around the
+                    //  reads, so the four chains' LDS traffic can be scheduled together)
+                    const int f = lane + i * nact;
+                    const uint64_t ps = f < nfr ? pos : pos_last;
+                    const rs_lp hp = (rs_lp)(uint32_t)(uintptr_t)(tab + ((uint32_t)(ps >> 27) & (RS_PHASES - 1)));
+                    const rs_lp wp = (rs_lp)(uint32_t)(uintptr_t)(win + ((uint32_t)(ps >> 32) - P.i_first));
+                    v2f_rs acc = (v2f_rs){0.f, 0.f};
+#pragma unroll
+                    for (int tp = 0; tp < RS_TAPS / 2; ++tp) {
+                        const v2f_rs h = hp[tp * RS_PHASES];
+                        const v2f_rs x0 = wp[2 * tp], x1 = wp[2 * tp + 1];
+                        acc = __builtin_elementwise_fma((v2f_rs){h.x, h.x}, x0, acc);
+                        acc = __builtin_elementwise_fma((v2f_rs){h.y, h.y}, x1, acc);
+                    }
+                    if (f < nfr) orow[f] = acc;
+                    pos += dpos;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const v4f o01 = *(const v4f*)(orow + lane * 4), o23 = *(const v4f*)(orow + lane * 4 + 2);
+                xl = (v4f){o01[0], o01[2], o23[0], o23[2]};
+                xr = (v4f){o01[1], o01[3], o23[1], o23[3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (f0 + j >= frames) xl[j] = xr[j] = 0.f;
+                // the next port overwrites the window and the result row: everybody is done reading first
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // the voice's stages: constants from lane p's copy of the descriptor, or the block's ramps (voice_eval's tail)
+                const uint32_t rbits = ((uint32_t)__builtin_amdgcn_readlane((int)my_df, p) & VB_RAMP_MASK) >> VB_RAMP_SHIFT;
+                const uint32_t kinds = prog << 4;
+                const float* rb = fv.ramps + ((size_t)k * fv.n_voices + (ld.first_voice + p)) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
+#pragma unroll
+                for (int j = 0; j < FW_MAX_STAGES; ++j) {
+                    if (j < fv.n_gain_stages) {
+                        v4f gl = splat(readlane_f(my_g.g[j][0], p)), gr = splat(readlane_f(my_g.g[j][1], p));
+                        if (rbits) {
+                            if ((rbits >> (2 * j)) & 1u) gl = *(const v4f*)(rb + (size_t)(2 * j) * fv.stride);
+                            if ((rbits >> (2 * j + 1)) & 1u) gr = *(const v4f*)(rb + (size_t)(2 * j + 1) * fv.stride);
+                        }
+                        apply_stage((kinds >> (4 * j)) & 15u, gl, gr, xl, xr);
+                    }
+                }
+            } else if ((simple_ports >> p) & 1ull) {  // VB_SIMPLE implies frames % 4 == 0
+                simple_fetch((uint32_t)__builtin_amdgcn_readlane((int)my_cls, p), readlane_ptr(my_l, p), (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p), f0,
+                             xl, xr);
+#pragma unroll
+                for (int j = 0; j < FW_MAX_STAGES; ++j)
+                    if (j < fv.n_gain_stages)
+                        apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)), xl, xr);
+            } else {
+                const VoiceBlk d = fv.blks[row + p];
+                voice_eval<RS>(fv, d, k, ld.first_voice + p, f0, frames, xl, xr, prog);
+            }
+        }
+        if (p == 0) {  // sum.rs:117 copy_from_slice(port 0) — also when silent; 2/3/4-port: in1
+            accl = xl;
+            accr = xr;
+        } else if (!(masked && psil)) {  // :122-124 skip silent ports (n-port path only)
+            accl = accl + xl;
+            accr = accr + xr;
+        }
     }
 }
 
@@ -871,6 +953,50 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
     const uint64_t silent_ports = __ballot((my_flags & VB_SILENT) != 0) & lanes_in;
     const uint64_t simple_ports = __ballot((my_flags & VB_SIMPLE) != 0) & lanes_in;
     const bool all_silent = silent_ports == lanes_in;
+    // resampler ports: lane p takes what the fetch of port p needs out of its full descriptor — sample data and length, 32.32
+    // position and step, flags, the constant gains — and says whether the staged path can render it (leaf_rs_piece)
+    uint64_t rs_ports = 0ull, my_off0 = 0ull, my_off1 = 0ull;
+    uint32_t my_df = 0u;
+    if constexpr (RS) {
+        bool el = false;
+        if (rs.tab != nullptr && lane < ld.ports && !(my_flags & (VB_SILENT | VB_SIMPLE))) {
+            const VoiceBlk* b = fv.blks + row + lane;
+            const uint32_t df = b->flags;
+            if (df & VB_RESAMPLE) {
+                const uint32_t len = b->pad;
+                const uint64_t off0 = b->off0, step = b->off1;
+                const bool loop = b->n1 != 0;
+                const int nfr = frames < 256 ? frames : 256;
+                const uint64_t w_max = (((uint64_t)nfr * step + 0xffffffffull) >> 32) + 1 + RS_TAPS;  // any piece of the block
+                const uint64_t i_end = (off0 + (uint64_t)frames * step) >> 32;
+                el = ((df >> VB_FMT_SHIFT) & 7u) == (uint32_t)FMT_P_F32 && w_max <= RS_WIN && (step >> 32) < 8 && i_end < (1ull << 30) && len < (1u << 30) &&
+                     len >= 1u && (!loop || len >= (uint32_t)RS_WIN + RS_TAPS);
+                if (el) {
+                    my_l = b->src_l;
+                    my_rd = len;
+                    my_off0 = off0;
+                    my_off1 = step;
+                    my_df = (df & ~RS_LOOP_BIT) | (loop ? RS_LOOP_BIT : 0u);
+#pragma unroll
+                    for (int j = 0; j < FW_MAX_STAGES; ++j) {
+                        my_g.g[j][0] = b->g[j][0];
+                        my_g.g[j][1] = b->g[j][1];
+                    }
+                }
+            }
+        }
+        rs_ports = __ballot(el) & lanes_in;
+        {  // (read with v_readlane inside the frame loop: pinned under the full exec mask, as above)
+            uint64_t pl = (uint64_t)my_l;
+            uint32_t o0l = (uint32_t)my_off0, o0h = (uint32_t)(my_off0 >> 32), o1l = (uint32_t)my_off1, o1h = (uint32_t)(my_off1 >> 32);
+            asm volatile("" : "+v"(pl), "+v"(my_rd), "+v"(o0l), "+v"(o0h), "+v"(o1l), "+v"(o1h), "+v"(my_df));
+            my_l = (const float*)pl;
+            my_off0 = ((uint64_t)o0h << 32) | o0l;
+            my_off1 = ((uint64_t)o1h << 32) | o1l;
+#pragma unroll
+            for (int j = 0; j < FW_MAX_STAGES; ++j) asm volatile("" : "+v"(my_g.g[j][0]), "+v"(my_g.g[j][1]));
+        }
+    }
     const int path_ports = ld.pad ? ld.pad : ld.ports;  // (a leaf that is the leading voice ports of a wider SumNode takes ITS path)
     const bool masked = !(path_ports == 2 || path_ports == 3 || path_ports == 4);  // sum.rs:67-133 (Q13)
     const bool all_simple = simple_ports == lanes_in && (frames & 3) == 0;
@@ -883,7 +1009,16 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
     const int f_first = lane * 4 + part * 256;
     for (int f0 = f_first; f0 < frames; f0 += 256 * wpk) {
         v4f accl = splat(0.f), accr = splat(0.f);
-        if (fast_cls) {
+        bool rs_done = false;
+        if constexpr (RS) {
+            if (rs_ports) {
+                leaf_rs_piece<PROG, RS>(fv, ld, k, row, f0, frames, rs, my_l, my_rd, my_cls, my_g, my_prog, my_off0, my_off1, my_df, silent_ports,
+                                        simple_ports, rs_ports, masked, accl, accr);
+                rs_done = true;
+            }
+        }
+        if (rs_done) {
+        } else if (fast_cls) {
             const int ng = fv.n_gain_stages;
             switch (cls0) {
                 case SF_P_I16: leaf_fast_cls<SF_P_I16>(my_l, my_rd, my_g, ng, ld.ports, f0, accl, accr); break;
@@ -966,8 +1101,10 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
 __device__ __forceinline__ RsLds rs_lds_setup(const FusedView& fv, float* dyn) {
     RsLds rs{nullptr, nullptr};
     if (fv.has_rs) {  // (uniform: every wave of the workgroup comes through here before anything can return)
-        for (int i = threadIdx.x; i < RS_PHASES * RS_TAPS; i += blockDim.x)  // tap-major: [t][phase]
-            dyn[(i % RS_TAPS) * RS_PHASES + i / RS_TAPS] = fv.rs_table[i];
+        for (int i = threadIdx.x; i < RS_PHASES * RS_TAPS; i += blockDim.x) {  // [tap pair][phase][2]: one ds_read_b64 = two taps of a phase
+            const int t = i % RS_TAPS, ph = i / RS_TAPS;
+            dyn[((t >> 1) * RS_PHASES + ph) * 2 + (t & 1)] = fv.rs_table[i];
+        }
         __syncthreads();
         rs.tab = dyn;
         rs.win = dyn + RS_PHASES * RS_TAPS + (threadIdx.x >> 6) * (2 * RS_WIN + 512);

@@ -162,6 +162,7 @@ struct PlanImage {
     bool fused_rs = false;    // the plan has resampler-sourced voices
     bool fused_prog = false;  // the voice-bank plan carries stage programs (k_leaf_sum<true>)
     bool fused_sp = false;    // ... and spatialiser stages (k_leaf_sum<true, false, true>)
+    DevBuf d_rs_wl;           // resampler plans: the work list between k_leaf_rs and k_leaf_sum_wl (FusedView::rs_wl)
     DevBuf d_progs, d_hist;   // d_hist: [n_voices][SP_HIST] mono histories the spatialiser voices enter the call with
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start, d_chain_dummy, d_chain_stats;
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;

@@ -68,6 +68,7 @@ struct FusedView {
     int has_prog;           // some voice's program is not 0 (or its source is a resampler): k_leaf_sum<true>
     int has_rs;             // some voice's source is a resampler: the program instantiation stages windows + filter bank in LDS
     int has_sp;             // some voice ends in a spatialiser stage: k_leaf_sum<true, false, true>
+    unsigned int* rs_wl;    // has_rs: work list k_leaf_rs leaves for k_leaf_sum_wl — [0] items, [1] workgroups done, then (leaf, block*4 + piece) pairs
     float* hist;            // [n_voices][SP_HIST]: the mono history each spatialiser voice enters THIS call with (copied from the ext
                             // pool by k_voice_control, so that the render waves of block 0 read it while those of the last block
                             // write the next call's into the pool)

@@ -256,6 +256,7 @@ static void fill_fused_view(fwgpu_ctx* c, FusedView& fv) {
     fv.has_prog = c->fused_prog ? 1 : 0;
     fv.has_rs = c->fused_rs ? 1 : 0;
     fv.has_sp = c->fused_sp ? 1 : 0;
+    fv.rs_wl = c->d_rs_wl.as<unsigned int>();
     fv.hist = c->d_hist.as<float>();
     fv.n_gain_stages = c->ramp_slots / 2;
     fv.ramps = c->d_ramps.as<float>();

@@ -13,6 +13,7 @@ enum : int {
 };
 #define RS_PHASES 32  // SPEC resampler: polyphase windowed-sinc table [RS_PHASES][RS_TAPS], 32.32 fixed-point position
 #define RS_TAPS 16
+#define LEAF_WPB_MAX 4  // k_leaf.hip.h: at most this many 256-frame pieces (waves) per block
 #define SP_HIST 64    // SPEC spatialiser: mono history frames (>= the largest per-ear delay + 1)
 
 enum : int { FMT_I_I16 = 0, FMT_I_U16 = 1, FMT_I_F32 = 2, FMT_P_I16 = 3, FMT_P_U16 = 4, FMT_P_F32 = 5 };

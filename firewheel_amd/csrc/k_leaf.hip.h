@@ -165,6 +165,7 @@ __device__ __forceinline__ float readlane_f(float x, int lane) {
 #endif
 #ifndef LEAF_WPB
 #define LEAF_WPB 4  // waves (leaf, block work items) per workgroup
+static_assert(LEAF_WPB <= LEAF_WPB_MAX, "fwgpu_types.h: LEAF_WPB_MAX sizes the resampler work list");
 #endif
 #ifndef LEAF_MAP_BLOCKS
 #define LEAF_MAP_BLOCKS 1
@@ -411,7 +412,9 @@ struct RsPort {  // wave-uniform: one resampler port's piece
     uint32_t i_first;
     uint64_t p_first, step;
     bool mono, loop;
+    bool contig;  // the window, rounded up to whole quads, lies inside the sample: fetched as dwordx4 per lane and channel
 };
+typedef const v4f_u __attribute__((address_space(1)))* rs_g4p;
 __device__ __forceinline__ int rs_slot32(const RsPort& P, const int r, bool& in) {
     int q = P.qb + r;
     in = r < P.W;
@@ -423,28 +426,73 @@ __device__ __forceinline__ int rs_slot32(const RsPort& P, const int r, bool& in)
     }
     return in ? q : 0;
 }
+// the window of port P is requested: RS_ROUNDS registers per channel — two rounds of quads when the window is contiguous in the
+// sample (every steady block but the one a loop wraps in), else eight rounds of single frames
 __device__ __forceinline__ void rs_issue(const RsPort& P, const int lane, const int nact, float (&a)[RS_ROUNDS], float (&b)[RS_ROUNDS]) {
+    if (P.contig) {
 #pragma unroll
-    for (int u = 0; u < RS_ROUNDS; ++u) {
-        bool in;
-        const int q = rs_slot32(P, lane + u * nact, in);
-        a[u] = in ? P.s0[q] : 0.f;
-        b[u] = in && !P.mono ? P.s0[P.len + q] : 0.f;
+        for (int u = 0; u < RS_ROUNDS / 4; ++u) {
+            const int r = (lane + u * nact) * 4;
+            if (u * nact * 4 < P.W) {  // (uniform)
+                v4f x = splat(0.f), y = splat(0.f);
+                if (r < P.W) {
+                    x = *(rs_g4p)(P.s0 + P.qb + r);
+                    if (!P.mono) y = *(rs_g4p)(P.s0 + P.len + P.qb + r);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[4 * u + e] = x[e];
+                    b[4 * u + e] = y[e];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < RS_ROUNDS; ++u) {
+            if (u * nact < P.W) {  // (uniform)
+                bool in;
+                const int q = rs_slot32(P, lane + u * nact, in);
+                a[u] = in ? P.s0[q] : 0.f;
+                b[u] = in && !P.mono ? P.s0[P.len + q] : 0.f;
+            }
+        }
     }
 }
 __device__ __forceinline__ void rs_stage(const RsPort& P, const int lane, const int nact, const float (&a)[RS_ROUNDS], const float (&b)[RS_ROUNDS],
                                          v2f_rs* win) {
+    if (P.contig) {
 #pragma unroll
-    for (int u = 0; u < RS_ROUNDS; ++u) {
-        const int r = lane + u * nact;
-        if (r < P.W) win[r] = (v2f_rs){a[u], P.mono ? a[u] : b[u]};
-    }
-    for (int r = RS_ROUNDS * nact + lane; r < P.W; r += nact) {  // (a piece of few frames at a high ratio: the rest of the window)
-        bool in;
-        const int q = rs_slot32(P, r, in);
-        const float x = in ? P.s0[q] : 0.f;
-        const float y = in && !P.mono ? P.s0[P.len + q] : 0.f;
-        win[r] = (v2f_rs){x, P.mono ? x : y};
+        for (int u = 0; u < RS_ROUNDS / 4; ++u) {
+            const int r = (lane + u * nact) * 4;
+            if (u * nact * 4 < P.W && r < P.W) {
+                if (P.mono) {
+                    *(v4f*)(win + r) = (v4f){a[4 * u], a[4 * u], a[4 * u + 1], a[4 * u + 1]};
+                    *(v4f*)(win + r + 2) = (v4f){a[4 * u + 2], a[4 * u + 2], a[4 * u + 3], a[4 * u + 3]};
+                } else {
+                    *(v4f*)(win + r) = (v4f){a[4 * u], b[4 * u], a[4 * u + 1], b[4 * u + 1]};
+                    *(v4f*)(win + r + 2) = (v4f){a[4 * u + 2], b[4 * u + 2], a[4 * u + 3], b[4 * u + 3]};
+                }
+            }
+        }
+        for (int r = (RS_ROUNDS / 4 * nact + lane) * 4; r < P.W; r += nact * 4) {  // (a piece of few frames: the rest of the window)
+            const v4f x = *(rs_g4p)(P.s0 + P.qb + r);
+            const v4f y = P.mono ? x : *(rs_g4p)(P.s0 + P.len + P.qb + r);
+            *(v4f*)(win + r) = (v4f){x[0], y[0], x[1], y[1]};
+            *(v4f*)(win + r + 2) = (v4f){x[2], y[2], x[3], y[3]};
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < RS_ROUNDS; ++u) {
+            const int r = lane + u * nact;
+            if (u * nact < P.W && r < P.W) win[r] = (v2f_rs){a[u], P.mono ? a[u] : b[u]};
+        }
+        for (int r = RS_ROUNDS * nact + lane; r < P.W; r += nact) {
+            bool in;
+            const int q = rs_slot32(P, r, in);
+            const float x = in ? P.s0[q] : 0.f;
+            const float y = in && !P.mono ? P.s0[P.len + q] : 0.f;
+            win[r] = (v2f_rs){x, P.mono ? x : y};
+        }
     }
 }
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t x, int lane) {
@@ -463,7 +511,11 @@ __device__ __forceinline__ RsPort rs_port(const int p, const int fbase, const in
     P.W = (int)((uint32_t)(p_last >> 32) - P.i_first) + RS_TAPS;
     P.mono = df & VB_MONO;
     P.loop = df & RS_LOOP_BIT;
-    P.qb = (int)(P.loop ? P.i_first % (uint32_t)P.len : P.i_first) - (RS_TAPS / 2 - 1);
+    uint32_t i0 = P.i_first;
+    if (P.loop)
+        while (i0 >= (uint32_t)P.len) i0 -= (uint32_t)P.len;  // (a looping source keeps its position below len << 32: at most a block's advance)
+    P.qb = (int)i0 - (RS_TAPS / 2 - 1);
+    P.contig = P.qb >= 0 && P.qb + ((P.W + 3) & ~3) <= P.len;
     return P;
 }
 template <bool PROG, bool RS>
@@ -572,6 +624,58 @@ __device__ __forceinline__ void leaf_rs_piece(const FusedView& fv, const LeafDes
             accr = accr + xr;
         }
     }
+}
+
+// A (leaf, block) is "resampler-pure" when every port is silent or a resampler voice in its plain state: planar f32 sample, constant
+// gains, at most RS2_WIN window frames per 256-frame piece.  Such leaves are rendered by k_leaf_rs — leaf_rs_piece's arithmetic with
+// nothing else in the kernel: 4 waves per SIMD instead of 3, a third of the instructions, no pass through LDS for the results.  The
+// others (a voice that ramps, another sample format, sampler voices under the same mixer) are put on a work list by k_leaf_rs and
+// rendered by k_leaf_sum_wl, the general kernel over that list.
+#define RS2_WIN 512  // = the two rounds of quads a wave fetches: 256 output frames x ratio <= 1.93, + RS_TAPS
+#define RS_CONTIG_BIT (1u << 30)  // lane-held flags: the window of the WHOLE block is contiguous inside the sample (no loop wrap, no one-shot edge)
+struct RsPure {
+    const float* s0;  // channel 0 of the sample (channel 1 = s0 + len)
+    uint32_t len;     // sample frames
+    int qb0;          // sample frame of window slot 0 of the block's first frame (loops: reduced into [−7, len))
+    uint64_t off0, step;
+    uint32_t df;      // VoiceBlk::flags | RS_LOOP_BIT | RS_CONTIG_BIT
+    bool pure;
+};
+__device__ __forceinline__ RsPure rs_pure_lane(const FusedView& fv, const size_t row, const int lane, const int ports, const uint32_t my_flags,
+                                               const int frames) {
+    RsPure r;
+    r.s0 = nullptr;
+    r.len = 0u;
+    r.qb0 = 0;
+    r.off0 = r.step = 0ull;
+    r.df = 0u;
+    r.pure = false;
+    if (lane < ports && !(my_flags & (VB_SILENT | VB_SIMPLE))) {
+        const VoiceBlk* b = fv.blks + row + lane;
+        const uint32_t df = b->flags;
+        if ((df & VB_RESAMPLE) && !(df & VB_RAMP_MASK) && ((df >> VB_FMT_SHIFT) & 7u) == (uint32_t)FMT_P_F32) {
+            const uint32_t len = b->pad;
+            const uint64_t off0 = b->off0, step = b->off1;
+            const bool loop = b->n1 != 0;
+            const int nfr = frames < 256 ? frames : 256;
+            const uint64_t w_max = (((uint64_t)nfr * step + 0xffffffffull) >> 32) + 1 + RS_TAPS;  // any piece of the block
+            const uint64_t span = (((uint64_t)frames * step + 0xffffffffull) >> 32) + 1 + RS_TAPS + 4;  // the block's window, quad-rounded
+            const uint64_t i_first = off0 >> 32;
+            if (w_max <= RS2_WIN && i_first + span < (1ull << 30) && len < (1u << 30) && len >= 1u && (!loop || len >= (uint32_t)(RS2_WIN + RS_TAPS))) {
+                const uint32_t i0 = loop ? (uint32_t)i_first % len : (uint32_t)i_first;
+                const int qb0 = (int)i0 - (RS_TAPS / 2 - 1);
+                const bool contig = qb0 >= 0 && (uint64_t)qb0 + span <= (uint64_t)len;
+                r.s0 = b->src_l;
+                r.len = len;
+                r.qb0 = qb0;
+                r.off0 = off0;
+                r.step = step;
+                r.df = (df & ~(RS_LOOP_BIT | RS_CONTIG_BIT)) | (loop ? RS_LOOP_BIT : 0u) | (contig ? RS_CONTIG_BIT : 0u);
+                r.pure = true;
+            }
+        }
+    }
+    return r;
 }
 
 // ---- the spatialiser stage's steady path: every port of the leaf a VB_SIMPLE voice of ONE source class and ONE stage program that
@@ -1118,8 +1222,8 @@ __device__ __forceinline__ RsLds rs_lds_setup(const FusedView& fv, float* dyn) {
 //   <true,  false>  stage programs (width / hard clip)
 //   <true,  true>   ... and voices whose source is a resampler (LDS-staged polyphase fetch)
 //   <true,  false, true>  ... and voices that end in a spatialiser (a 320-float mono row per wave in LDS)
-template <bool PROG, bool RS, bool SP = false>
-__global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K, int wpk) {
+template <bool PROG, bool RS, bool SP>
+__device__ __forceinline__ void leaf_kernel_body(const FusedView& fv, const int K, const int wpk) {
     extern __shared__ float s_leaf_dyn[];
     RsLds rs{nullptr, nullptr};
     if constexpr (RS) rs = rs_lds_setup(fv, s_leaf_dyn);
@@ -1141,6 +1245,232 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
     const uint32_t k = blockIdx.y;
 #endif
     leaf_sum_wave<PROG, RS, LEAF_U, SP>(fv, leaf, k, part, wpk, rs, K, sp_lds);
+}
+template <bool PROG, bool RS, bool SP = false>
+__global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K, int wpk) {
+    leaf_kernel_body<PROG, RS, SP>(fv, K, wpk);
+}
+// The resampler-pure leaves of a plan (rs_pure_lane above).  One wave per (leaf, block, 256-frame piece); lane p holds port p.
+// Accumulators, stages and the final store stay in the convolution's round-robin frame layout (lane l: frames l, l + nact, ...):
+// the stages of a pure voice are per-frame constants, so nothing needs the four-consecutive-frames layout of the other kernels.
+#define RS2_LDS_BYTES(waves) ((RS_PHASES * RS_TAPS + (waves) * (2 * RS2_WIN)) * sizeof(float))
+__global__ __launch_bounds__(WAVE* LEAF_WPB, 4) void k_leaf_rs(FusedView fv, int K, int wpk) {
+    extern __shared__ float s_leaf_dyn[];
+    for (int i = threadIdx.x; i < RS_PHASES * RS_TAPS; i += blockDim.x) {  // [tap pair][phase][2]
+        const int t = i % RS_TAPS, ph = i / RS_TAPS;
+        s_leaf_dyn[((t >> 1) * RS_PHASES + ph) * 2 + (t & 1)] = fv.rs_table[i];
+    }
+    __syncthreads();
+    const int leaf = blockIdx.x;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int part = wave & (wpk - 1);
+    const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.y * (LEAF_WPB / wpk) + wave / wpk));
+    if (k >= (uint32_t)K) return;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const LeafDesc ld = fv.leaves[leaf];
+    const int frames = fv.frames;
+    if (part * 256 >= frames) return;
+    const v2f_rs* tab = (const v2f_rs*)s_leaf_dyn;
+    v2f_rs* win = (v2f_rs*)(s_leaf_dyn + RS_PHASES * RS_TAPS + wave * (2 * RS2_WIN));
+    const size_t row = (size_t)k * fv.n_voices + ld.first_voice;
+    uint32_t my_flags = VB_SILENT;
+    if (lane < ld.ports) my_flags = fv.refs[ref_index(ld.first_voice + lane, (int)k, fv.ref_kgroups)].flags_gset & 0xffu;
+    const uint64_t lanes_in = mask_all_silent_bits(ld.ports);
+    const uint64_t silent_ports = __ballot((my_flags & VB_SILENT) != 0) & lanes_in;
+    const RsPure me = rs_pure_lane(fv, row, lane, ld.ports, my_flags, frames);
+    const uint64_t pure_ports = __ballot(me.pure) & lanes_in;
+    if (!(pure_ports && ((pure_ports | silent_ports) & lanes_in) == lanes_in)) {  // not ours: onto the general kernel's work list
+        if (lane == 0) {
+            const unsigned int i = atomicAdd(fv.rs_wl, 1u);
+            fv.rs_wl[2 + 2 * i] = (unsigned int)leaf;
+            fv.rs_wl[3 + 2 * i] = k * 4u + (unsigned int)part;
+        }
+        return;
+    }
+    // lane p holds port p: sample, position, step, flags, stage program, constant gains (read with v_readlane below)
+    const uint64_t my_s0 = (uint64_t)me.s0, my_off0 = me.off0, my_step = me.step;
+    const uint32_t my_len = me.len, my_df = me.df;
+    const int my_qb0 = me.qb0;
+    uint32_t my_prog = 0u;
+    float my_g[FW_MAX_STAGES][2];
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES; ++j) my_g[j][0] = my_g[j][1] = 1.0f;
+    if (me.pure) {
+        my_prog = fv.progs[ld.first_voice + lane];
+        const VoiceBlk* b = fv.blks + row + lane;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j) {
+            my_g[j][0] = b->g[j][0];
+            my_g[j][1] = b->g[j][1];
+        }
+    }
+    const int path_ports = ld.pad ? ld.pad : ld.ports;
+    const bool masked = !(path_ports == 2 || path_ports == 3 || path_ports == 4);  // sum.rs:67-133 (Q13)
+    const int ng = fv.n_gain_stages;
+    float* bus = fv.bus + (size_t)k * fv.bus_blk_stride;
+    float* outl = bus + (size_t)ld.out_buf * fv.stride;
+    float* outr = outl + fv.stride;
+    const int first = __builtin_ctzll(pure_ports);
+
+    for (int fbase = part * 256; fbase < frames; fbase += 256 * wpk) {
+        const int nfr = frames - fbase < 256 ? frames - fbase : 256;
+        // (every lane works here — window fetch and convolution are dealt over the whole wave, whatever the piece's length)
+        const int nact = nfr < WAVE ? nfr : WAVE;                       // lanes that own frames
+        const int per = (nfr + nact - 1) / nact;                        // frames per lane: <= 4
+        v4f accl = splat(0.f), accr = splat(0.f);                       // frames lane, lane + nact, lane + 2 nact, lane + 3 nact
+        v4f wa[2], wb[2];
+        wa[0] = wa[1] = wb[0] = wb[1] = splat(0.f);
+        // one port's piece: source of window slot 0, window length, flags
+#define RS2_PORT(p, X)                                                                                               \
+    const uint64_t X##step = readlane_u64(my_step, p);                                                               \
+    const uint64_t X##o0 = readlane_u64(my_off0, p);                                                                 \
+    const uint64_t X##p_first = X##o0 + (uint64_t)fbase * X##step;                                                   \
+    const int X##len = __builtin_amdgcn_readlane((int)my_len, p);                                                   \
+    const uint32_t X##df = (uint32_t)__builtin_amdgcn_readlane((int)my_df, p);                                      \
+    int X##qb = __builtin_amdgcn_readlane(my_qb0, p) + (int)((uint32_t)(X##p_first >> 32) - (uint32_t)(X##o0 >> 32)); \
+    if (X##df & RS_LOOP_BIT)                                                                                         \
+        while (X##qb >= X##len) X##qb -= X##len;                                                                    \
+    const rs_gfp X##s0 = (rs_gfp)readlane_u64(my_s0, p);                                                             \
+    const int X##W = (int)((uint32_t)((X##p_first + (uint64_t)(nfr - 1) * X##step) >> 32) - (uint32_t)(X##p_first >> 32)) + RS_TAPS; \
+    const bool X##mono = X##df & VB_MONO;                                                                            \
+    const bool X##contig = X##df & RS_CONTIG_BIT;
+        // a contiguous window is requested as quads: two rounds of registers per channel
+#define RS2_ISSUE(X)                                                   \
+    if (X##contig) {                                                   \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                \
+            const int r = (lane + u * WAVE) * 4;                       \
+            if (u * WAVE * 4 < X##W && r < X##W) {                     \
+                wa[u] = *(rs_g4p)(X##s0 + X##qb + r);                  \
+                if (!X##mono) wb[u] = *(rs_g4p)(X##s0 + X##len + X##qb + r); \
+            }                                                          \
+        }                                                              \
+    }
+        {
+            RS2_PORT(first, n)
+            RS2_ISSUE(n)
+        }
+        for (int p = 0; p < ld.ports; ++p) {
+            if ((silent_ports >> p) & 1ull) {  // cleared zeros: copied by port 0, added by a 2/3/4-port mixer, skipped by an n-port one
+                if (p > 0 && !masked) {
+                    accl = accl + splat(0.f);
+                    accr = accr + splat(0.f);
+                }
+                continue;
+            }
+            RS2_PORT(p, c)
+            // the window goes to LDS as {L, R} pairs ...
+            if (ccontig) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int r = (lane + u * WAVE) * 4;
+                    if (u * WAVE * 4 < cW && r < cW) {
+                        const v4f y = cmono ? wa[u] : wb[u];
+                        *(v4f*)(win + r) = (v4f){wa[u][0], y[0], wa[u][1], y[1]};
+                        *(v4f*)(win + r + 2) = (v4f){wa[u][2], y[2], wa[u][3], y[3]};
+                    }
+                }
+            } else {  // the block a loop wraps in, or a one-shot's edge: frame by frame, wrapped / zero-filled on the way in
+                for (int r = lane; r < cW; r += WAVE) {
+                    int q = cqb + r;
+                    bool in = true;
+                    if (cdf & RS_LOOP_BIT) {  // (len >= the window: one step either way)
+                        if (q < 0) q += clen;
+                        if (q >= clen) q -= clen;
+                    } else {
+                        in = q >= 0 && q < clen;
+                    }
+                    const float x = in ? cs0[in ? q : 0] : 0.f;
+                    const float y = cmono ? x : (in ? cs0[clen + q] : 0.f);
+                    win[r] = (v2f_rs){x, y};
+                }
+            }
+            // ... the next port's is requested ...
+            {
+                const uint64_t later = p + 1 < 64 ? pure_ports >> (p + 1) : 0ull;
+                if (later) {
+                    const int pn = p + 1 + __builtin_ctzll(later);
+                    RS2_PORT(pn, n)
+                    RS2_ISSUE(n)
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ... and this one's frames are convolved: 16-tap fmaf chains ascending from +0.0, both channels in one packed instruction
+            const uint64_t dpos = (uint64_t)nact * cstep;
+            const uint64_t pos_last = cp_first + (uint64_t)(nfr - 1) * cstep;
+            const uint32_t i_first = (uint32_t)(cp_first >> 32);
+            uint64_t pos = cp_first + (uint64_t)lane * cstep;
+            v4f xl = splat(0.f), xr = splat(0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < per) {  // (uniform; frames past the piece's end convolve its last frame's window: no branch around the reads)
+                    const int f = lane + i * nact;
+                    const uint64_t ps = f < nfr && lane < nact ? pos : pos_last;
+                    const rs_lp hp = (rs_lp)(uint32_t)(uintptr_t)(tab + ((uint32_t)(ps >> 27) & (RS_PHASES - 1)));
+                    const rs_lp wp = (rs_lp)(uint32_t)(uintptr_t)(win + ((uint32_t)(ps >> 32) - i_first));
+                    v2f_rs acc = (v2f_rs){0.f, 0.f};
+#pragma unroll
+                    for (int tp = 0; tp < RS_TAPS / 2; ++tp) {
+                        const v2f_rs h = hp[tp * RS_PHASES];
+                        const v2f_rs x0 = wp[2 * tp], x1 = wp[2 * tp + 1];
+                        acc = __builtin_elementwise_fma((v2f_rs){h.x, h.x}, x0, acc);
+                        acc = __builtin_elementwise_fma((v2f_rs){h.y, h.y}, x1, acc);
+                    }
+                    xl[i] = acc.x;
+                    xr[i] = acc.y;
+                    pos += dpos;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // (the next port overwrites the window)
+            const uint32_t kinds = (uint32_t)__builtin_amdgcn_readlane((int)my_prog, p) << 4;
+#pragma unroll
+            for (int j = 0; j < FW_MAX_STAGES; ++j)
+                if (j < ng) apply_stage((kinds >> (4 * j)) & 15u, splat(readlane_f(my_g[j][0], p)), splat(readlane_f(my_g[j][1], p)), xl, xr);
+            if (p == 0) {
+                accl = xl;
+                accr = xr;
+            } else {
+                accl = accl + xl;
+                accr = accr + xr;
+            }
+        }
+#undef RS2_PORT
+#undef RS2_ISSUE
+        if (lane < nact) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = lane + i * nact;
+                if (f < nfr) {
+                    __builtin_nontemporal_store(accl[i], outl + fbase + f);
+                    __builtin_nontemporal_store(accr[i], outr + fbase + f);
+                }
+            }
+        }
+    }
+    if (lane < 2 && part == 0) (fv.bus_flags + (size_t)k * fv.bus_flags_blk_stride)[ld.out_buf + lane] = 0;  // a live port: the out mask is 0
+}
+// the general kernel over k_leaf_rs's work list: (leaf, block, piece) items that are not resampler-pure.  The last workgroup out
+// empties the list for the next pair of launches.
+__global__ __launch_bounds__(WAVE* LEAF_WPB, 3) void k_leaf_sum_wl(FusedView fv, int K, int wpk) {
+    extern __shared__ float s_leaf_dyn[];
+    const RsLds rs = rs_lds_setup(fv, s_leaf_dyn);
+    const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned int count = __hip_atomic_load(fv.rs_wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned int it = blockIdx.x * LEAF_WPB + wave; it < count; it += gridDim.x * LEAF_WPB) {
+        const int leaf = __builtin_amdgcn_readfirstlane((int)fv.rs_wl[2 + 2 * it]);
+        const unsigned int kp = (unsigned int)__builtin_amdgcn_readfirstlane((int)fv.rs_wl[3 + 2 * it]);
+        leaf_sum_wave<true, true, LEAF_U, false>(fv, leaf, kp >> 2, (int)(kp & 3u), wpk, rs, K, nullptr);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int prev = atomicAdd(fv.rs_wl + 1, 1u);
+        if (prev == gridDim.x - 1) {
+            __hip_atomic_store(fv.rs_wl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fv.rs_wl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Upper sum tree of the fused plan, K-batched: SumNode semantics (nodes/sum.rs:41-136) with one THREAD per

@@ -1320,35 +1320,41 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, 4) void k_leaf_rs(FusedView fv, int
         v4f accl = splat(0.f), accr = splat(0.f);                       // frames lane, lane + nact, lane + 2 nact, lane + 3 nact
         v4f wa[2], wb[2];
         wa[0] = wa[1] = wb[0] = wb[1] = splat(0.f);
-        // one port's piece: source of window slot 0, window length, flags
-#define RS2_PORT(p, X)                                                                                               \
-    const uint64_t X##step = readlane_u64(my_step, p);                                                               \
-    const uint64_t X##o0 = readlane_u64(my_off0, p);                                                                 \
-    const uint64_t X##p_first = X##o0 + (uint64_t)fbase * X##step;                                                   \
-    const int X##len = __builtin_amdgcn_readlane((int)my_len, p);                                                   \
-    const uint32_t X##df = (uint32_t)__builtin_amdgcn_readlane((int)my_df, p);                                      \
-    int X##qb = __builtin_amdgcn_readlane(my_qb0, p) + (int)((uint32_t)(X##p_first >> 32) - (uint32_t)(X##o0 >> 32)); \
-    if (X##df & RS_LOOP_BIT)                                                                                         \
-        while (X##qb >= X##len) X##qb -= X##len;                                                                    \
-    const rs_gfp X##s0 = (rs_gfp)readlane_u64(my_s0, p);                                                             \
-    const int X##W = (int)((uint32_t)((X##p_first + (uint64_t)(nfr - 1) * X##step) >> 32) - (uint32_t)(X##p_first >> 32)) + RS_TAPS; \
-    const bool X##mono = X##df & VB_MONO;                                                                            \
-    const bool X##contig = X##df & RS_CONTIG_BIT;
+        // one port's piece: source, window length, flags (wave-uniform; the NEXT port's set is computed once, when its window is
+        // requested, and becomes the current one an iteration later)
+        struct Rs2Port {
+            uint64_t step, p_first;
+            rs_gfp s0;
+            int len, qb, W;
+            uint32_t df;
+        };
+        auto port = [&](const int p) {
+            Rs2Port P;
+            P.step = readlane_u64(my_step, p);
+            const uint64_t o0 = readlane_u64(my_off0, p);
+            P.p_first = o0 + (uint64_t)fbase * P.step;
+            P.len = __builtin_amdgcn_readlane((int)my_len, p);
+            P.df = (uint32_t)__builtin_amdgcn_readlane((int)my_df, p);
+            P.qb = __builtin_amdgcn_readlane(my_qb0, p) + (int)((uint32_t)(P.p_first >> 32) - (uint32_t)(o0 >> 32));
+            if (P.df & RS_LOOP_BIT)
+                while (P.qb >= P.len) P.qb -= P.len;
+            P.s0 = (rs_gfp)readlane_u64(my_s0, p);
+            P.W = (int)((uint32_t)((P.p_first + (uint64_t)(nfr - 1) * P.step) >> 32) - (uint32_t)(P.p_first >> 32)) + RS_TAPS;
+            return P;
+        };
         // a contiguous window is requested as quads: two rounds of registers per channel
-#define RS2_ISSUE(X)                                                   \
-    if (X##contig) {                                                   \
-        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                \
-            const int r = (lane + u * WAVE) * 4;                       \
-            if (u * WAVE * 4 < X##W && r < X##W) {                     \
-                wa[u] = *(rs_g4p)(X##s0 + X##qb + r);                  \
-                if (!X##mono) wb[u] = *(rs_g4p)(X##s0 + X##len + X##qb + r); \
-            }                                                          \
-        }                                                              \
+#define RS2_ISSUE(P)                                                                   \
+    if (P.df & RS_CONTIG_BIT) {                                                        \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                \
+            const int r = (lane + u * WAVE) * 4;                                       \
+            if (u * WAVE * 4 < P.W && r < P.W) {                                       \
+                wa[u] = *(rs_g4p)(P.s0 + P.qb + r);                                    \
+                if (!(P.df & VB_MONO)) wb[u] = *(rs_g4p)(P.s0 + P.len + P.qb + r);     \
+            }                                                                          \
+        }                                                                              \
     }
-        {
-            RS2_PORT(first, n)
-            RS2_ISSUE(n)
-        }
+        Rs2Port N = port(first);
+        RS2_ISSUE(N)
         for (int p = 0; p < ld.ports; ++p) {
             if ((silent_ports >> p) & 1ull) {  // cleared zeros: copied by port 0, added by a 2/3/4-port mixer, skipped by an n-port one
                 if (p > 0 && !masked) {
@@ -1357,30 +1363,32 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, 4) void k_leaf_rs(FusedView fv, int
                 }
                 continue;
             }
-            RS2_PORT(p, c)
+            const Rs2Port C = N;
+            const uint64_t cstep = C.step, cp_first = C.p_first;
+            const bool cmono = C.df & VB_MONO;
             // the window goes to LDS as {L, R} pairs ...
-            if (ccontig) {
+            if (C.df & RS_CONTIG_BIT) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int r = (lane + u * WAVE) * 4;
-                    if (u * WAVE * 4 < cW && r < cW) {
+                    if (u * WAVE * 4 < C.W && r < C.W) {
                         const v4f y = cmono ? wa[u] : wb[u];
                         *(v4f*)(win + r) = (v4f){wa[u][0], y[0], wa[u][1], y[1]};
                         *(v4f*)(win + r + 2) = (v4f){wa[u][2], y[2], wa[u][3], y[3]};
                     }
                 }
             } else {  // the block a loop wraps in, or a one-shot's edge: frame by frame, wrapped / zero-filled on the way in
-                for (int r = lane; r < cW; r += WAVE) {
-                    int q = cqb + r;
+                for (int r = lane; r < C.W; r += WAVE) {
+                    int q = C.qb + r;
                     bool in = true;
-                    if (cdf & RS_LOOP_BIT) {  // (len >= the window: one step either way)
-                        if (q < 0) q += clen;
-                        if (q >= clen) q -= clen;
+                    if (C.df & RS_LOOP_BIT) {  // (len >= the window: one step either way)
+                        if (q < 0) q += C.len;
+                        if (q >= C.len) q -= C.len;
                     } else {
-                        in = q >= 0 && q < clen;
+                        in = q >= 0 && q < C.len;
                     }
-                    const float x = in ? cs0[in ? q : 0] : 0.f;
-                    const float y = cmono ? x : (in ? cs0[clen + q] : 0.f);
+                    const float x = in ? C.s0[in ? q : 0] : 0.f;
+                    const float y = cmono ? x : (in ? C.s0[C.len + q] : 0.f);
                     win[r] = (v2f_rs){x, y};
                 }
             }
@@ -1388,9 +1396,8 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, 4) void k_leaf_rs(FusedView fv, int
             {
                 const uint64_t later = p + 1 < 64 ? pure_ports >> (p + 1) : 0ull;
                 if (later) {
-                    const int pn = p + 1 + __builtin_ctzll(later);
-                    RS2_PORT(pn, n)
-                    RS2_ISSUE(n)
+                    N = port(p + 1 + __builtin_ctzll(later));
+                    RS2_ISSUE(N)
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1403,23 +1410,31 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, 4) void k_leaf_rs(FusedView fv, int
             uint64_t pos = cp_first + (uint64_t)lane * cstep;
             v4f xl = splat(0.f), xr = splat(0.f);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < per) {  // (uniform; frames past the piece's end convolve its last frame's window: no branch around the reads)
-                    const int f = lane + i * nact;
-                    const uint64_t ps = f < nfr && lane < nact ? pos : pos_last;
-                    const rs_lp hp = (rs_lp)(uint32_t)(uintptr_t)(tab + ((uint32_t)(ps >> 27) & (RS_PHASES - 1)));
-                    const rs_lp wp = (rs_lp)(uint32_t)(uintptr_t)(win + ((uint32_t)(ps >> 32) - i_first));
-                    v2f_rs acc = (v2f_rs){0.f, 0.f};
+            for (int i = 0; i < 4; i += 2) {
+                if (i < per) {  // (uniform.  Two frames' chains side by side: each is 16 dependent instructions long)
+                    // (frames past the piece's end convolve its last frame's window: no branch around the reads)
+                    const uint64_t psa = lane + i * nact < nfr && lane < nact ? pos : pos_last;
+                    const uint64_t psb = lane + (i + 1) * nact < nfr && lane < nact ? pos + dpos : pos_last;
+                    const rs_lp ha = (rs_lp)(uint32_t)(uintptr_t)(tab + ((uint32_t)(psa >> 27) & (RS_PHASES - 1)));
+                    const rs_lp wpa = (rs_lp)(uint32_t)(uintptr_t)(win + ((uint32_t)(psa >> 32) - i_first));
+                    const rs_lp hb = (rs_lp)(uint32_t)(uintptr_t)(tab + ((uint32_t)(psb >> 27) & (RS_PHASES - 1)));
+                    const rs_lp wpb = (rs_lp)(uint32_t)(uintptr_t)(win + ((uint32_t)(psb >> 32) - i_first));
+                    v2f_rs acca = (v2f_rs){0.f, 0.f}, accb = (v2f_rs){0.f, 0.f};
 #pragma unroll
                     for (int tp = 0; tp < RS_TAPS / 2; ++tp) {
-                        const v2f_rs h = hp[tp * RS_PHASES];
-                        const v2f_rs x0 = wp[2 * tp], x1 = wp[2 * tp + 1];
-                        acc = __builtin_elementwise_fma((v2f_rs){h.x, h.x}, x0, acc);
-                        acc = __builtin_elementwise_fma((v2f_rs){h.y, h.y}, x1, acc);
+                        const v2f_rs h0 = ha[tp * RS_PHASES], h1 = hb[tp * RS_PHASES];
+                        const v2f_rs a0 = wpa[2 * tp], a1 = wpa[2 * tp + 1];
+                        const v2f_rs b0 = wpb[2 * tp], b1 = wpb[2 * tp + 1];
+                        acca = __builtin_elementwise_fma((v2f_rs){h0.x, h0.x}, a0, acca);
+                        accb = __builtin_elementwise_fma((v2f_rs){h1.x, h1.x}, b0, accb);
+                        acca = __builtin_elementwise_fma((v2f_rs){h0.y, h0.y}, a1, acca);
+                        accb = __builtin_elementwise_fma((v2f_rs){h1.y, h1.y}, b1, accb);
                     }
-                    xl[i] = acc.x;
-                    xr[i] = acc.y;
-                    pos += dpos;
+                    xl[i] = acca.x;
+                    xr[i] = acca.y;
+                    xl[i + 1] = accb.x;
+                    xr[i + 1] = accb.y;
+                    pos += 2 * dpos;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1436,7 +1451,6 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, 4) void k_leaf_rs(FusedView fv, int
                 accr = accr + xr;
             }
         }
-#undef RS2_PORT
 #undef RS2_ISSUE
         if (lane < nact) {
 #pragma unroll

@@ -908,14 +908,21 @@ def other_configs(env, args):
     import copy
 
     # (cfg2_sends: the headline graph with sends off its leaf buses — no fused shape as a whole: the hybrid plan)
-    for name, steps in (("cfg3", 12), ("cfg5", 12), ("cfg4", 6), ("cfg2_sends", 12)):
+    # (cfg2_rs / cfg2_spatial: the headline graph with every voice's source a SPEC resampler (ratio U(0.5, 1.5), looping) / every
+    #  voice ending in a SPEC spatialiser — the other two north-star node families on the voice-bank plan; cfg2_variantB: 64 voices
+    #  with a volume glide every ~20 blocks, the reference's automation case)
+    for name, steps in (("cfg3", 12), ("cfg5", 12), ("cfg4", 6), ("cfg2_sends", 12), ("cfg2_rs", 10), ("cfg2_spatial", 10), ("cfg2_variantB", 10)):
         wl = name.split("_")[0]
         V, B, K, F, _ = DEFAULTS[wl]
         try:
             wargs = args
-            if name == "cfg2_sends":
+            if name != wl:
                 wargs = copy.copy(args)
-                wargs.send = True
+                wargs.send = name == "cfg2_sends"
+                wargs.rs_source = name == "cfg2_rs"
+                wargs.voice_spatial = name == "cfg2_spatial"
+                if name == "cfg2_variantB":
+                    wargs.variant = "B"
             r = run_workload(env, wargs, wl, V, B, K, F, steps, 3, full=False)
             cfg = r["config"]
             ent = {"workload": cfg["workload"], "value": r["value"], "unit": "voice-samples/s", "ms_per_step": r["ms_per_step"],

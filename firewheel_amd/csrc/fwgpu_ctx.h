@@ -162,6 +162,13 @@ struct PlanImage {
     bool fused_rs = false;    // the plan has resampler-sourced voices
     bool fused_prog = false;  // the voice-bank plan carries stage programs (k_leaf_sum<true>)
     bool fused_sp = false;    // ... and spatialiser stages (k_leaf_sum<true, false, true>)
+    // control-kernel dispatch order (FusedView::ctl_order), rebuilt by upload_cmds for every call that has messages
+    std::vector<int> slot_voice;        // node state slot -> voice of the voice-bank plan (-1: none)
+    std::vector<uint8_t> ctl_mark;      // [n_voices] scratch
+    std::vector<int> hot_prev, hot_now; // voices with messages in the call before / in this one (capacity reserved at build)
+    int* h_ctl_order = nullptr;         // pinned [n_voices]
+    DevBuf d_ctl_order;
+    bool ctl_order_live = false;        // the device copy holds this call's order (else: identity, nothing uploaded)
     DevBuf d_rs_wl;           // resampler plans: the work list between k_leaf_rs and k_leaf_sum_wl (FusedView::rs_wl)
     DevBuf d_progs, d_hist;   // d_hist: [n_voices][SP_HIST] mono histories the spatialiser voices enter the call with
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start, d_chain_dummy, d_chain_stats;
@@ -316,7 +323,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     // k_voice_control of batch b+1 runs on its own high-priority stream under the render kernels of batch b.  What it writes and
     // the render kernels read exists twice (parity = batch number & 1); what orders the two streams is one event per parity and
     // direction.  The kernels do not know: they get pointers.
-    bool ctl_ahead = false;          // wanted (env)
+    bool ctl_ahead = true;           // wanted (default since round 3; FWGPU_CTL_AHEAD=0 switches it off)
     hipStream_t ctl_stream = nullptr;
     hipEvent_t ev_ctl[2] = {nullptr, nullptr}, ev_render[2] = {nullptr, nullptr}, ev_join = nullptr;
     uint64_t ahead_seq = 0;          // batches launched in ahead mode since the streams were last joined

@@ -17,6 +17,7 @@
 // a wave's float4 access covers 1 KiB contiguous).  Reference citations: core/ nodes/ graph/ as in fwgpu.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fwgpu_launch.h"
 
@@ -141,9 +142,15 @@ int launch_get_flags(hipStream_t s, const uint8_t* flags, const int* d_bufs, int
     hipLaunchKernelGGL(k_get_flags, dim3(1), dim3(64), 0, s, flags, d_bufs, n, d_mask);
     return (int)hipGetLastError();
 }
-int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0) {
+int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0, bool beside_render) {
     if (fv.n_voices <= 0) return 0;
-    hipLaunchKernelGGL(k_voice_control, dim3((fv.n_voices + 3) / 4), dim3(256), 0, s, fv, K, cmd_block0);
+    // one wave per voice.  beside_render (control-ahead mode): the 168-VGPR build in workgroups of ONE wave, so that the dispatcher
+    // can place a control wave wherever one SIMD has room next to the render waves of the call before
+    static const int occ = [] { const char* e = getenv("FWGPU_CTL_OCC"); return e ? atoi(e) : 0; }();  // experiments: 1 / 3 = force a build
+    const bool small = occ ? occ == 3 : beside_render;
+    const int wpb = beside_render ? 1 : 4;
+    if (small) hipLaunchKernelGGL(k_voice_control_small, dim3((fv.n_voices + wpb - 1) / wpb), dim3(WAVE * wpb), 0, s, fv, K, cmd_block0);
+    else hipLaunchKernelGGL(k_voice_control, dim3((fv.n_voices + wpb - 1) / wpb), dim3(WAVE * wpb), 0, s, fv, K, cmd_block0);
     return (int)hipGetLastError();
 }
 int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0, int nq) {

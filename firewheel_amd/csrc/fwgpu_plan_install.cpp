@@ -32,11 +32,13 @@ static int zero(fwgpu_ctx* c, void* p, size_t bytes) {
 
 void PlanImage::release_device() {
     DevBuf* bufs[] = {&d_nodes, &d_in_buf, &d_out_buf, &d_level_nodes, &d_pool, &d_flags, &d_gin_bufs, &d_gout_bufs, &d_groups, &d_blks2, &d_refs2,
-                      &d_gsets2, &d_ramps2, &d_progs, &d_hist, &d_rs_wl, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
+                      &d_gsets2, &d_ramps2, &d_progs, &d_hist, &d_rs_wl, &d_ctl_order, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
                       &d_chain_start, &d_chain_dummy, &d_chain_stats, &d_up_nodes, &d_up_in, &d_up_out, &d_up_level_nodes, &d_root_bufs, &d_tail_nodes,
                       &d_tail_in, &d_tail_out, &d_tail_idx, &d_tail_frozen, &d_frozen_ph, &d_frozen, &d_fir_rows, &d_fir_tiles, &d_fir_partials,
                       &d_hlevel_nodes, &grow_states, &grow_ext, &d_state_inits, &d_ext_jobs};
     for (DevBuf* b : bufs) b->release();
+    if (h_ctl_order) (void)hipHostFree(h_ctl_order);
+    h_ctl_order = nullptr;
     if (h_host_stage) (void)hipHostFree(h_host_stage);
     if (h_host_flags) (void)hipHostFree(h_host_flags);
     h_host_stage = d_host_stage = nullptr;
@@ -57,6 +59,8 @@ static void reset_for_build(PlanImage& P) {
     P.level_kinds.clear();
     P.n_gout_bufs = P.n_gin_bufs = 0;
     P.slot_index.clear();
+    P.slot_voice.clear();
+    P.ctl_order_live = false;
     P.fused = P.fused_fx = P.ctl_ahead_on = P.fused_rs = P.fused_prog = P.fused_sp = P.hybrid = P.hybrid_fx = false;
     P.generic_k = 1;
     P.chain_nq = 1;
@@ -90,6 +94,22 @@ static void reset_for_build(PlanImage& P) {
 }
 
 // what the control kernel writes and the render kernels read, per voice and block of a batch (both fused plans and the hybrid one)
+// node state slot -> voice of the voice-bank plan (upload_cmds: which voices a call's messages go to)
+static void build_slot_voice(PlanImage& P, const std::vector<VoiceDesc>& voices) {
+    int max_slot = -1;
+    auto each = [&](const VoiceDesc& vd, auto&& f) {
+        f(vd.sampler_state);
+        for (int j = 0; j < vd.n_stages && j < FW_MAX_STAGES - 1; ++j) f(vd.stage_state[j]);
+        f(vd.bq_state);
+        f(vd.dl_state);
+    };
+    for (const VoiceDesc& vd : voices) each(vd, [&](int s) { max_slot = std::max(max_slot, s); });
+    P.slot_voice.assign((size_t)(max_slot + 1), -1);
+    for (size_t v = 0; v < voices.size(); ++v)
+        each(voices[v], [&](int s) {
+            if (s >= 0) P.slot_voice[(size_t)s] = (int)v;
+        });
+}
 static int alloc_voice_tables(fwgpu_ctx* c, PlanImage& P) {
     const size_t K = P.kmax;
     HIPC(c, P.d_blks.ensure_n("d_blks", K * P.n_voices * sizeof(VoiceBlk)));
@@ -104,6 +124,16 @@ static int alloc_voice_tables(fwgpu_ctx* c, PlanImage& P) {
     HIPC(c, P.d_cache.ensure_n("d_cache", (size_t)P.n_voices * sizeof(VoiceCache)));
     if ((rc = zero(c, P.d_cache.p, (size_t)P.n_voices * sizeof(VoiceCache)))) return rc;  // (and adoption bumps the epoch)
     HIPC(c, P.d_ramps.ensure_n("d_ramps", K * P.n_voices * (size_t)P.ramp_slots * c->stride * sizeof(float)));
+    if (P.h_ctl_order) (void)hipHostFree(P.h_ctl_order);
+    P.h_ctl_order = nullptr;
+    HIPC(c, hipHostMalloc((void**)&P.h_ctl_order, std::max<size_t>(1, (size_t)P.n_voices) * sizeof(int), hipHostMallocDefault));
+    HIPC(c, P.d_ctl_order.ensure_n("d_ctl_order", std::max<size_t>(1, (size_t)P.n_voices) * sizeof(int)));
+    P.ctl_mark.assign((size_t)P.n_voices, 0);
+    P.hot_prev.clear();
+    P.hot_now.clear();
+    P.hot_prev.reserve((size_t)P.n_voices);
+    P.hot_now.reserve((size_t)P.n_voices);
+    P.ctl_order_live = false;
     if (P.fused_rs) {  // one item per (leaf, block, 256-frame piece) at most
         HIPC(c, P.d_rs_wl.ensure_n("d_rs_wl", (2 + 2 * (size_t)P.n_leaves * K * LEAF_WPB_MAX) * sizeof(unsigned int)));
         if ((rc = zero(c, P.d_rs_wl.p, 2 * sizeof(unsigned int)))) return rc;
@@ -523,6 +553,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             if (vd.sp_ext_off >= 0) vd.sp_ext_off = (int)node_init((uint32_t)vd.stage_state[vd.n_stages - 1]).ext_off;
         P.fused_sp = fb.has_sp;
         if (fb.has_sp) HIPC(c, P.d_hist.ensure_n("d_hist", fb.voices.size() * SP_HIST * sizeof(float)));
+        build_slot_voice(P, fb.voices);
         if ((rc = up(c, P.d_voices, fb.voices.data(), fb.voices.size() * sizeof(VoiceDesc)))) return rc;
         if ((rc = up(c, P.d_leaves, fb.leaves.data(), fb.leaves.size() * sizeof(LeafDesc)))) return rc;
         if ((rc = up(c, P.d_progs, fb.progs.data(), fb.progs.size() * sizeof(uint32_t)))) return rc;
@@ -627,6 +658,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             if (vd.sp_ext_off >= 0) vd.sp_ext_off = (int)node_init((uint32_t)vd.stage_state[vd.n_stages - 1]).ext_off;
         P.fused_sp = hb.has_sp;
         if (hb.has_sp) HIPC(c, P.d_hist.ensure_n("d_hist", hb.voices.size() * SP_HIST * sizeof(float)));
+        build_slot_voice(P, hb.voices);
         if ((rc = up(c, P.d_voices, hb.voices.data(), hb.voices.size() * sizeof(VoiceDesc)))) return rc;
         if ((rc = up(c, P.d_leaves, hb.leaves.data(), hb.leaves.size() * sizeof(LeafDesc)))) return rc;
         if ((rc = up(c, P.d_progs, hb.progs.data(), hb.progs.size() * sizeof(uint32_t)))) return rc;

@@ -114,14 +114,50 @@ void drain_ring(fwgpu_ctx* c) {
 int upload_cmds(fwgpu_ctx* c) {
     drain_ring(c);
     c->n_cmds_dev = (int)c->cmds.size();
-    if (c->n_cmds_dev == 0) return 0;
+    // the voices these messages go to, then the ones of the call before (a glide started there may still be running)
+    c->hot_now.clear();
+    size_t n_now = 0;
+    if (!c->slot_voice.empty() && c->h_ctl_order) {
+        for (const Cmd& m : c->cmds) {
+            if (m.state < 0 || (size_t)m.state >= c->slot_voice.size()) continue;
+            const int v = c->slot_voice[m.state];
+            if (v >= 0 && !c->ctl_mark[v]) {
+                c->ctl_mark[v] = 1;
+                c->hot_now.push_back(v);
+            }
+        }
+        n_now = c->hot_now.size();
+        for (const int v : c->hot_prev)
+            if (!c->ctl_mark[v]) {
+                c->ctl_mark[v] = 1;
+                c->hot_now.push_back(v);
+            }
+    }
+    const bool order = !c->hot_now.empty();
+    c->ctl_order_live = order;
+    if (c->n_cmds_dev == 0 && !order) {
+        c->hot_prev.clear();
+        return 0;
+    }
     size_t bytes = c->cmds.size() * sizeof(Cmd);
-    HIPC(c, hipEventSynchronize(c->cmds_copied));  // the previous upload has left the pinned buffer
-    memcpy(c->h_cmds, c->cmds.data(), bytes);
+    HIPC(c, hipEventSynchronize(c->cmds_copied));  // the previous upload has left the pinned buffers
     // control-ahead mode: the message list belongs to the control stream (k_voice_control is its only reader there, and the
     // stream's order keeps this copy behind the control kernels of the previous call)
     hipStream_t s = c->cmds_on_ctl ? c->ctl_stream : c->stream;
-    HIPC(c, hipMemcpyAsync(c->d_cmds.p, c->h_cmds, bytes, hipMemcpyHostToDevice, s));
+    if (bytes) {
+        memcpy(c->h_cmds, c->cmds.data(), bytes);
+        HIPC(c, hipMemcpyAsync(c->d_cmds.p, c->h_cmds, bytes, hipMemcpyHostToDevice, s));
+    }
+    if (order) {
+        const int nv = (int)c->ctl_mark.size();
+        int w = 0;
+        for (const int v : c->hot_now) c->h_ctl_order[w++] = v;
+        for (int v = 0; v < nv; ++v)
+            if (!c->ctl_mark[v]) c->h_ctl_order[w++] = v;
+        for (const int v : c->hot_now) c->ctl_mark[v] = 0;
+        HIPC(c, hipMemcpyAsync(c->d_ctl_order.p, c->h_ctl_order, (size_t)nv * sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    c->hot_prev.assign(c->hot_now.begin(), c->hot_now.begin() + n_now);  // (within the reserved capacity)
     HIPC(c, hipEventRecord(c->cmds_copied, s));
     return 0;
 }
@@ -257,6 +293,7 @@ static void fill_fused_view(fwgpu_ctx* c, FusedView& fv) {
     fv.has_rs = c->fused_rs ? 1 : 0;
     fv.has_sp = c->fused_sp ? 1 : 0;
     fv.rs_wl = c->d_rs_wl.as<unsigned int>();
+    fv.ctl_order = c->ctl_order_live ? c->d_ctl_order.as<int>() : nullptr;
     fv.hist = c->d_hist.as<float>();
     fv.n_gain_stages = c->ramp_slots / 2;
     fv.ramps = c->d_ramps.as<float>();
@@ -449,7 +486,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
             fv.ramps = c->d_ramps2.as<float>();
         }
         if (c->ahead_seq >= 2) HIPC(c, hipStreamWaitEvent(c->ctl_stream, c->ev_render[p], 0));  // batch b-2 has read this copy
-        LCHK(c, launch_voice_control(c->ctl_stream, fv, K, cmd_block0));
+        LCHK(c, launch_voice_control(c->ctl_stream, fv, K, cmd_block0, true));
         HIPC(c, hipEventRecord(c->ev_ctl[p], c->ctl_stream));
         HIPC(c, hipStreamWaitEvent(c->stream, c->ev_ctl[p], 0));
         c->streams_split = true;

@@ -1181,9 +1181,18 @@ __device__ inline bool voice_control_lane_steady(const FusedView& fv, const int 
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint32_t cmd_block0) {
-    const int vi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (vi >= fv.n_voices) return;
+// Two register budgets: the full one (~240 VGPRs, nothing spilled) for a control kernel that has the GPU to itself, and 168 — three
+// waves per SIMD, ~1 % of the dynamic instructions are scratch traffic — for control-ahead mode, where a control wave has to find its
+// registers on a SIMD that holds five render waves of the call before: two of them retiring make room for the small one, three
+// (without a refill in between) for the big one, which in practice only happens once the render grid has run dry.
+template <int OCC>
+__device__ __forceinline__ void voice_control_kernel(const FusedView& fv, const int K, const uint32_t cmd_block0) {
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= fv.n_voices) return;
+    // dispatch order: the voices with a message in this call (or the one before: their glides continue) go first — theirs are the
+    // long waves (a glide is 22-25 us of serial latency)
+    const int vi = fv.ctl_order ? __builtin_amdgcn_readfirstlane(fv.ctl_order[w]) : w;
     voice_control_wave(fv, vi, threadIdx.x & (WAVE - 1), K, cmd_block0);
 }
-
+__global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint32_t cmd_block0) { voice_control_kernel<1>(fv, K, cmd_block0); }
+__global__ __launch_bounds__(256, 3) void k_voice_control_small(FusedView fv, int K, uint32_t cmd_block0) { voice_control_kernel<3>(fv, K, cmd_block0); }

@@ -564,8 +564,8 @@ __device__ __forceinline__ void leaf_rs_piece(const FusedView& fv, const LeafDes
                     //  reads, so the four chains' LDS traffic can be scheduled together)
                     const int f = lane + i * nact;
                     const uint64_t ps = f < nfr ? pos : pos_last;
-                    const rs_lp hp = (rs_lp)(uint32_t)(uintptr_t)(tab + ((uint32_t)(ps >> 27) & (RS_PHASES - 1)));
-                    const rs_lp wp = (rs_lp)(uint32_t)(uintptr_t)(win + ((uint32_t)(ps >> 32) - P.i_first));
+                    const rs_lp hp = (rs_lp)(tab + ((uint32_t)(ps >> 27) & (RS_PHASES - 1)));
+                    const rs_lp wp = (rs_lp)(win + ((uint32_t)(ps >> 32) - P.i_first));
                     v2f_rs acc = (v2f_rs){0.f, 0.f};
 #pragma unroll
                     for (int tp = 0; tp < RS_TAPS / 2; ++tp) {
@@ -1415,10 +1415,10 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, 4) void k_leaf_rs(FusedView fv, int
                     // (frames past the piece's end convolve its last frame's window: no branch around the reads)
                     const uint64_t psa = lane + i * nact < nfr && lane < nact ? pos : pos_last;
                     const uint64_t psb = lane + (i + 1) * nact < nfr && lane < nact ? pos + dpos : pos_last;
-                    const rs_lp ha = (rs_lp)(uint32_t)(uintptr_t)(tab + ((uint32_t)(psa >> 27) & (RS_PHASES - 1)));
-                    const rs_lp wpa = (rs_lp)(uint32_t)(uintptr_t)(win + ((uint32_t)(psa >> 32) - i_first));
-                    const rs_lp hb = (rs_lp)(uint32_t)(uintptr_t)(tab + ((uint32_t)(psb >> 27) & (RS_PHASES - 1)));
-                    const rs_lp wpb = (rs_lp)(uint32_t)(uintptr_t)(win + ((uint32_t)(psb >> 32) - i_first));
+                    const rs_lp ha = (rs_lp)(tab + ((uint32_t)(psa >> 27) & (RS_PHASES - 1)));
+                    const rs_lp wpa = (rs_lp)(win + ((uint32_t)(psa >> 32) - i_first));
+                    const rs_lp hb = (rs_lp)(tab + ((uint32_t)(psb >> 27) & (RS_PHASES - 1)));
+                    const rs_lp wpb = (rs_lp)(win + ((uint32_t)(psb >> 32) - i_first));
                     v2f_rs acca = (v2f_rs){0.f, 0.f}, accb = (v2f_rs){0.f, 0.f};
 #pragma unroll
                     for (int tp = 0; tp < RS_TAPS / 2; ++tp) {

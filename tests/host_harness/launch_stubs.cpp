@@ -258,7 +258,7 @@ int launch_get_flags(hipStream_t, const uint8_t* flags, const int* d_bufs, int n
     touch(d_mask, 8);
     return 0;
 }
-int launch_voice_control(hipStream_t, const FusedView& fv, int K, uint32_t cmd_block0) {
+int launch_voice_control(hipStream_t, const FusedView& fv, int K, uint32_t cmd_block0, bool) {
     g_launches[1]++;
     check_fused_common(fv, K);
     for (int i = 0; i < fv.n_cmds; ++i) {  // messages the control kernel would APPLY in this launch (each exactly once in its life)

@@ -255,7 +255,9 @@ def test_random_graph_and_messages_every_plan_bit_exact(seed):
     assert_bits_equal(want, fuzz_run(g, seed), "seed %d plan %d %s" % (seed, g.cx.plan_kind(), cls.__name__))
     g2 = GpuEngine(max_block_frames=mbf, force_generic=True, max_batch=int(pick.choice([1, 3, 64])))
     assert_bits_equal(want, fuzz_run(g2, seed), "seed %d generic" % seed)
-    if pick.random() < 0.3:
+    # (FWGPU_LAZY_ADOPT, the test mode that delays every adoption to the next process call, also delays the reuse of a removed node's
+    #  slot by one adoption — by design, fwgpu_ctx.h `limbo` — so node ids stop matching the oracle's allocator after a removal)
+    if pick.random() < 0.3 and not os.environ.get("FWGPU_LAZY_ADOPT"):
         # level A of INTEGRATION.md: every schedule of the run comes from the reference's compiler (restated by the oracle)
         # through fwgpu_schedule_upload — node ids are the same on both sides, also after removals and slot reuse; the
         # fused plans must be recognised on the imported schedules too

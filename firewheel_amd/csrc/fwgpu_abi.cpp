@@ -206,6 +206,21 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
             c->ctl_ahead = false;
         }
     }
+    if (const char* e = getenv("FWGPU_RT_PERSIST")) c->rt_persist = atoi(e) != 0;
+    if (const char* e = getenv("FWGPU_RT_IDLE_MS")) c->rt_idle_ms = (uint32_t)std::max(1, atoi(e));
+    if (c->rt_persist && c->h_rt_flag) {  // mailbox in pinned, device-mapped host memory + the kernel's own (non-blocking) stream
+        bool ok = hipHostMalloc((void**)&c->h_rt_mb, sizeof(RtMailbox), hipHostMallocMapped) == hipSuccess &&
+                  hipHostGetDevicePointer((void**)&c->d_rt_mb, c->h_rt_mb, 0) == hipSuccess;
+        if (ok) memset(c->h_rt_mb, 0, sizeof(RtMailbox));
+        ok = ok && hipStreamCreateWithFlags(&c->rt_stream, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&c->rt_ev, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            c->rt_persist = false;
+        }
+    } else {
+        c->rt_persist = false;
+    }
     if (const char* e = getenv("FWGPU_HOST_PROF")) c->host_prof = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_GRAPH")) c->rt_use_graph = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_ONE_LAUNCH")) c->rt_one_launch = atoi(e) != 0;
@@ -220,6 +235,10 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
                 (unsigned long long)c->hp_calls, c->hp_call_ns / 1e3 / (double)c->hp_calls, (unsigned long long)c->hp_launches,
                 c->hp_launches ? c->hp_launch_ns / 1e3 / (double)c->hp_launches : 0.0);
     use_device(c);
+    (void)rt_persist_stop(c);
+    if (c->rt_stream) (void)hipStreamDestroy(c->rt_stream);
+    if (c->rt_ev) (void)hipEventDestroy(c->rt_ev);
+    if (c->h_rt_mb) (void)hipHostFree(c->h_rt_mb);
     (void)hipStreamSynchronize(c->stream);
     if (c->ctl_stream) {
         (void)hipStreamSynchronize(c->ctl_stream);
@@ -487,6 +506,12 @@ int fwgpu_plan_handover_stats(fwgpu_ctx* c, uint64_t* adoptions, uint64_t* audio
     if (adoptions) *adoptions = c->adoptions;
     if (audio_adoptions) *audio_adoptions = c->audio_adoptions;
     if (max_adopt_ns) *max_adopt_ns = c->adopt_ns_max;
+    return 0;
+}
+int fwgpu_rt_resident_stats(fwgpu_ctx* c, uint64_t* launches, uint64_t* doorbells) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    if (launches) *launches = c->rtp.launches;
+    if (doorbells) *doorbells = c->rtp.doorbells;
     return 0;
 }
 int fwgpu_plan_chain_stats(fwgpu_ctx* c, uint64_t* steady_workgroups, uint64_t* general_workgroups) {
@@ -789,21 +814,39 @@ static int process_interleaved_impl(fwgpu_ctx* c, const float* input, float* out
             // answered after ~20 ms of spinning has a problem the stream sync below will name
             const unsigned long long want = c->rt_seq;
             volatile unsigned long long* flag = c->h_rt_flag;
-            // (bounded by the CLOCK, looked at every 1024 polls: an iteration count of `pause`s was ~1 s, not 20 ms — ADVICE r2)
-            const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
-            for (unsigned spins = 1;; ++spins) {
-                if (*flag == want) {
-                    done = true;
-                    break;
-                }
+            for (int attempt = 0; attempt < 2 && !done; ++attempt) {
+                bool retry = false;
+                // (bounded by the CLOCK, looked at every 1024 polls: an iteration count of `pause`s was ~1 s, not 20 ms — ADVICE r2)
+                const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+                for (unsigned spins = 1;; ++spins) {
+                    if (*flag == want) {
+                        done = true;
+                        break;
+                    }
+                    // the resident kernel's watchdog fired between two callbacks and the doorbell came too late for it: it says so
+                    // (alive = 0, stored after its last completion flag) — this block has not been rendered and will not be
+                    if (c->rtp.launched && (spins & 63u) == 0 && !*(volatile unsigned long long*)&c->h_rt_mb->alive) {
+                        std::atomic_thread_fence(std::memory_order_acquire);
+                        if (*flag != want) {
+                            retry = true;
+                            break;
+                        }
+                    }
 #if defined(__x86_64__) || defined(__i386__)
-                __builtin_ia32_pause();
+                    __builtin_ia32_pause();
 #endif
-                if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() > give_up) break;
+                    if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() > give_up) break;
+                }
+                if (!retry) break;
+                rc = rt_block_relaunch(c, c->d_rt_out, want);  // (rare: a pause of the watchdog's length) the block as an ordinary launch
+                if (rc) return rc;
             }
             std::atomic_thread_fence(std::memory_order_acquire);
         }
-        if (!done) HIPC(c, hipStreamSynchronize(c->stream));
+        if (!done) {
+            if (c->rtp.launched) HIPC(c, hipStreamSynchronize(c->rt_stream));
+            HIPC(c, hipStreamSynchronize(c->stream));
+        }
         c->ret_done_ticket.store(c->ret_ticket, std::memory_order_release);  // everything this call handed back is final
         if (out_bytes) memcpy(output, c->h_rt_out, out_bytes);
         return 0;
@@ -1000,6 +1043,7 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     AudioCallScope audio;
     use_device(c);
     AudioGate gate(c);
+    { const int prc = rt_persist_stop(c); if (prc) return prc; }
     // the node as the ACTIVE plan knows it (the graph belongs to the control thread, which may be editing it right now:
     // Firewheel activates and deactivates nodes while the audio thread is inside process(), graph.rs:586-612)
     const uint32_t nslot = (uint32_t)(node & 0xffffffff);

@@ -386,6 +386,21 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     bool rt_last_batch = false;  // the fused batch being launched ends the call
     bool rt_one_launch = true;  // one-block calls on the voice-bank plan: control + leaf + root in ONE kernel (FWGPU_RT_ONE_LAUNCH=0: off)
     DevBuf d_rt_sync;           // its workgroup counter
+    // the resident realtime kernel (k_rt_persist, k_rt.hip.h): launched by the first steady one-block callback of a run of them, fed
+    // through `h_rt_mb->doorbell` from then on, ended by rt_persist_stop before anything else touches the device state it owns
+    bool rt_persist = true;        // FWGPU_RT_PERSIST=0: every callback is its own launch (k_rt_block)
+    uint32_t rt_idle_ms = 20;      // its watchdog: no doorbell for this long and it ends by itself (FWGPU_RT_IDLE_MS)
+    RtMailbox *h_rt_mb = nullptr, *d_rt_mb = nullptr;
+    hipStream_t rt_stream = nullptr;
+    hipEvent_t rt_ev = nullptr;
+    struct RtResident {
+        bool launched = false;
+        uint64_t epoch = 0;
+        float* d_out = nullptr;
+        const void* blks = nullptr;       // (the FusedView the kernel was launched with: any difference means a new launch)
+        unsigned long long next_seq = 0;  // the doorbell value it waits for
+        uint64_t launches = 0, doorbells = 0;
+    } rtp;
     bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2
     DevBuf d_rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS]
 
@@ -524,6 +539,8 @@ int upload_sample_table(fwgpu_ctx* c);
 int join_streams(fwgpu_ctx* c);  // control-ahead mode: both streams wait for each other's work so far (no host wait)
 void drain_ring(fwgpu_ctx* c);  // ring -> cmds (consumer side: the audio thread, or an edit call that does not overlap it)
 int upload_cmds(fwgpu_ctx* c);
+int rt_persist_stop(fwgpu_ctx* c);
+int rt_block_relaunch(fwgpu_ctx* c, float* d_out, unsigned long long seq);  // after the watchdog race: the same block through k_rt_block  // ends the resident realtime kernel, if one is running, and waits for it
 void finish_returns(fwgpu_ctx* c);  // end of a process call: completion event for the samples it handed back
 void retire_cmds(fwgpu_ctx* c, uint32_t nblocks);
 void retire_cmds_node(fwgpu_ctx* c, int slot);

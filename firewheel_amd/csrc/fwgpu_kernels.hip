@@ -229,6 +229,21 @@ int launch_rt_block(hipStream_t s, const FusedView& fv, const DevView& upv, cons
                            done_seq);
     return (int)hipGetLastError();
 }
+int launch_rt_persist(hipStream_t s, const FusedView& fv, const DevView& upv, const RootArgs& root, float* d_out, uint32_t cmd_block0,
+                      unsigned* d_sync, unsigned long long* d_done_flag, RtMailbox* d_mb, unsigned long long* d_go, unsigned long long first_seq,
+                      unsigned long long idle_ticks) {
+    if (fv.n_leaves <= 0) return 0;
+    if (fv.has_rs)
+        hipLaunchKernelGGL((k_rt_persist<true, true>), dim3(fv.n_leaves), dim3(256), RS_LDS_BYTES(4), s, fv, upv, root, d_out, cmd_block0, d_sync,
+                           d_done_flag, d_mb, d_go, first_seq, idle_ticks);
+    else if (fv.has_prog)
+        hipLaunchKernelGGL((k_rt_persist<true, false>), dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync, d_done_flag,
+                           d_mb, d_go, first_seq, idle_ticks);
+    else
+        hipLaunchKernelGGL((k_rt_persist<false, false>), dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync, d_done_flag,
+                           d_mb, d_go, first_seq, idle_ticks);
+    return (int)hipGetLastError();
+}
 int launch_signal_done(hipStream_t s, unsigned long long* d_done_flag, unsigned long long done_seq) {
     hipLaunchKernelGGL(k_signal_done, dim3(1), dim3(1), 0, s, d_done_flag, done_seq);
     return (int)hipGetLastError();

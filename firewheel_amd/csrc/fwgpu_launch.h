@@ -124,6 +124,9 @@ int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K);
 // realtime edge: control + leaf sums + root sum + interleave of ONE block in one launch (tree = leaves + root, stereo out);
 // d_sync: one zero-initialised unsigned the workgroups count themselves in with
 // d_done_flag (may be null): device view of a pinned host word that receives done_seq when the output block is complete
+int launch_rt_persist(hipStream_t s, const FusedView& fv, const DevView& upv, const RootArgs& root, float* d_out, uint32_t cmd_block0,
+                      unsigned* d_sync, unsigned long long* d_done_flag, RtMailbox* d_mb, unsigned long long* d_go, unsigned long long first_seq,
+                      unsigned long long idle_ticks);
 int launch_rt_block(hipStream_t s, const FusedView& fv, const DevView& upv, const RootArgs& root, float* d_out, uint32_t cmd_block0,
                     unsigned* d_sync, unsigned long long* d_done_flag, unsigned long long done_seq);
 int launch_signal_done(hipStream_t s, unsigned long long* d_done_flag, unsigned long long done_seq);

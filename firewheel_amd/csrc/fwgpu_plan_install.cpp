@@ -731,6 +731,7 @@ void adopt_image(fwgpu_ctx* c, PlanImage* n, bool on_audio_thread) {
     const auto t0 = std::chrono::steady_clock::now();
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != c->device) (void)hipSetDevice(c->device);
+    (void)rt_persist_stop(c);  // the resident realtime kernel was launched with the old plan's tables
     (void)join_streams(c);  // control-ahead mode: the control stream's work so far is ordered before the swap
     c->ahead_seq = 0;
     // 1. larger persistent arrays: old contents copied over on the stream, then the pointers change hands

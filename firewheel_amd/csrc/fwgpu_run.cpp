@@ -446,6 +446,68 @@ int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const
 }
 
 // K full blocks through the fused voice-bank plan
+// ---------------------------------------------------------------- the resident realtime kernel (k_rt.hip.h)
+int rt_persist_stop(fwgpu_ctx* c) {
+    fwgpu_ctx::RtResident& r = c->rtp;
+    if (!r.launched) return 0;
+    r.launched = false;
+    volatile unsigned long long* alive = &c->h_rt_mb->alive;
+    if (*alive) {
+        __atomic_store_n(&c->h_rt_mb->doorbell, r.next_seq | RT_QUIT_BIT, __ATOMIC_RELEASE);
+        const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(10 * (long)c->rt_idle_ms + 50);
+        for (unsigned spins = 1; *alive; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+            if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() > give_up) break;  // (the stream sync below names the problem)
+        }
+    }
+    // the kernel's own end (its stores are released at agent scope block by block; this orders the stream behind it)
+    HIPC(c, hipStreamSynchronize(c->rt_stream));
+    return 0;
+}
+// first steady callback of a run (or the one after the watchdog ended the kernel): launch it with this call's sequence number
+// already in the doorbell
+static int rt_persist_launch(fwgpu_ctx* c, const FusedView& fv, const DevView& v, float* d_out, uint32_t cmd_block0, unsigned long long seq) {
+    fwgpu_ctx::RtResident& r = c->rtp;
+    HIPC(c, hipEventRecord(c->rt_ev, c->stream));  // behind everything the ctx stream holds (adoption launches, uploads)
+    HIPC(c, hipStreamWaitEvent(c->rt_stream, c->rt_ev, 0));
+    c->h_rt_mb->alive = 1;
+    __atomic_store_n(&c->h_rt_mb->doorbell, seq, __ATOMIC_RELEASE);
+    unsigned long long* go = (unsigned long long*)((char*)c->d_rt_sync.p + 128);
+    // (the kernel before this one may have left `seq | quit` there — its watchdog fired while it waited for this very number)
+    HIPC(c, hipMemsetAsync(go, 0, sizeof(unsigned long long), c->rt_stream));
+    LCHK(c, launch_rt_persist(c->rt_stream, fv, v, c->root_args, d_out, cmd_block0, c->d_rt_sync.as<unsigned>(), c->d_rt_flag, c->d_rt_mb, go, seq,
+                              (unsigned long long)c->rt_idle_ms * 100000ull));
+    r.launched = true;
+    r.epoch = c->epoch;
+    r.d_out = d_out;
+    r.blks = fv.blks;
+    r.next_seq = seq + 1;
+    r.launches++;
+    return 0;
+}
+
+static void rt_root_view(const fwgpu_ctx* c, const FusedView& fv, DevView& v) {
+    memset(&v, 0, sizeof(v));
+    v.pool = fv.bus;
+    v.flags = fv.bus_flags;
+    v.pool_blk_stride = fv.bus_blk_stride;
+    v.flags_blk_stride = fv.bus_flags_blk_stride;
+    v.stride = c->stride;
+    v.frames = (int)c->mbf;
+}
+int rt_block_relaunch(fwgpu_ctx* c, float* d_out, unsigned long long seq) {
+    int rc = rt_persist_stop(c);
+    if (rc) return rc;
+    FusedView fv;
+    fill_fused_view(c, fv);
+    DevView v;
+    rt_root_view(c, fv, v);
+    LCHK(c, launch_rt_block(c->stream, fv, v, c->root_args, d_out, 0, c->d_rt_sync.as<unsigned>(), c->d_rt_flag, seq));
+    return 0;
+}
+
 int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int n_out_ch) {
     FusedView fv;
     fill_fused_view(c, fv);
@@ -453,18 +515,30 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     if (K == 1 && c->rt_one_launch && !c->fused_sp && !c->out_sil && !c->ahead_this_call && !c->fused_fx && !c->timing && c->n_tail == 0 && c->up_root_node >= 0 && n_out_ch == 2 &&
         c->up_level_cnt.size() == 1 && c->d_rt_sync.p) {
         DevView v;
-        memset(&v, 0, sizeof(v));
-        v.pool = fv.bus;
-        v.flags = fv.bus_flags;
-        v.pool_blk_stride = fv.bus_blk_stride;
-        v.flags_blk_stride = fv.bus_flags_blk_stride;
-        v.stride = c->stride;
-        v.frames = (int)c->mbf;
+        rt_root_view(c, fv, v);
         unsigned long long* flag = nullptr;
         if (c->rt_signal_seq && c->rt_last_batch) {  // the realtime edge asked for the completion flag and this is the call's
                                                        // last launch: the kernel raises it itself
             flag = c->d_rt_flag;
             c->rt_signalled = true;
+        }
+        // a steady callback (no message on the device, the completion flag asked for): the resident kernel takes it
+        if (c->rt_persist && c->rt_stream && flag && c->n_cmds_dev == 0 && !c->host_prof && cmd_block0 == 0) {
+            fwgpu_ctx::RtResident& r = c->rtp;
+            const unsigned long long seq = c->rt_signal_seq;
+            if (r.launched && c->h_rt_mb->alive && r.epoch == c->epoch && r.d_out == d_out && r.blks == fv.blks && r.next_seq == seq) {
+                __atomic_store_n(&c->h_rt_mb->doorbell, seq, __ATOMIC_RELEASE);
+                r.next_seq = seq + 1;
+                r.doorbells++;
+                return 0;
+            }
+            int rc = rt_persist_stop(c);  // (the watchdog ended it, or it was launched for another plan / epoch / output block)
+            if (rc) return rc;
+            return rt_persist_launch(c, fv, v, d_out, cmd_block0, seq);
+        }
+        {
+            int rc = rt_persist_stop(c);
+            if (rc) return rc;
         }
         if (c->host_prof) {
             const auto t0 = std::chrono::steady_clock::now();
@@ -595,6 +669,11 @@ static int run_blocks_impl(fwgpu_ctx* c, uint64_t frames, const float* d_in, int
     int rc = upload_sample_table(c);
     if (rc) return rc;
     const bool can_fuse = c->fused && !c->force_generic;
+    // the resident realtime kernel owns the voice state between two steady callbacks: anything else ends it first
+    if (c->rtp.launched && !(stable_out && frames == mbf && can_fuse && !c->timing)) {
+        rc = rt_persist_stop(c);
+        if (rc) return rc;
+    }
     // control-ahead mode for this call?  Whole blocks only, more than one, no event timers, not the realtime edge
     const bool ahead = c->ctl_ahead_on && can_fuse && !c->timing && !stable_out && frames % mbf == 0 && frames / mbf > 1;
     if (!ahead && c->streams_split) {

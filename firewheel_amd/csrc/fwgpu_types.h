@@ -13,6 +13,14 @@ enum : int {
 };
 #define RS_PHASES 32  // SPEC resampler: polyphase windowed-sinc table [RS_PHASES][RS_TAPS], 32.32 fixed-point position
 #define RS_TAPS 16
+// realtime edge, resident kernel (k_rt_persist): the mailbox in pinned, device-mapped host memory
+struct RtMailbox {
+    unsigned long long doorbell;  // host -> device: the sequence number to render next, or that number | RT_QUIT_BIT
+    unsigned long long pad0[7];
+    unsigned long long alive;     // device -> host: 1 while the kernel takes doorbells, 0 once it has decided to end
+    unsigned long long pad1[7];
+};
+#define RT_QUIT_BIT (1ull << 63)
 #define LEAF_WPB_MAX 4  // k_leaf.hip.h: at most this many 256-frame pieces (waves) per block
 #define SP_HIST 64    // SPEC spatialiser: mono history frames (>= the largest per-ear delay + 1)
 

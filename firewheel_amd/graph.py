@@ -432,6 +432,12 @@ class FirewheelGpuCtx(object):
         n = self._check(self.L.fwgpu_plan_node_inputs_clear(self.c, node_id, buf, 64))
         return [bool(buf[i]) for i in range(n)]
 
+    def rt_resident_stats(self):
+        """(resident realtime kernels launched, callbacks served through the doorbell) — include/fwgpu.h"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.L.fwgpu_rt_resident_stats(self.c, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def plan_handover_stats(self):
         """(plans adopted so far, those adopted by a process call, the longest one of those held up its call in ns)"""
         a, b, m = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)

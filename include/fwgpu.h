@@ -171,6 +171,15 @@ int fwgpu_plan_chain_stats(fwgpu_ctx* ctx, uint64_t* steady_workgroups, uint64_t
  * adopted so far, *audio_adoptions = those a process call adopted, *max_adopt_ns = the longest one of THOSE held up its process
  * call (host nanoseconds).  Any pointer may be NULL. */
 int fwgpu_plan_handover_stats(fwgpu_ctx* ctx, uint64_t* adoptions, uint64_t* audio_adoptions, uint64_t* max_adopt_ns);
+/* Realtime edge, resident kernel (cpal/lib.rs:378-449: a backend thread that is woken per block, never torn down between blocks).
+ * The first steady one-block fwgpu_process_interleaved call of a run of them — voice-bank plan, stereo stream, no message pending —
+ * launches a kernel that stays resident and is handed every following callback through a doorbell word in pinned host memory: no
+ * launch call on the audio thread, no grid dispatch.  Anything else that touches the device state (a call with a message, a call of
+ * another size, a plan adoption, fwgpu_node_process, destroy) ends it first; its own WATCHDOG ends it after `idle_ms` without a
+ * callback (default 20; FWGPU_RT_IDLE_MS), so it can never hold a device that nobody feeds — the next callback launches a new one.
+ * FWGPU_RT_PERSIST=0 switches it off (every callback is then one k_rt_block launch).  *launches = resident kernels launched so far,
+ * *doorbells = callbacks served without a launch.  Any pointer may be NULL. */
+int fwgpu_rt_resident_stats(fwgpu_ctx* ctx, uint64_t* launches, uint64_t* doorbells);
 /* K = the most blocks one fused launch sequence processes (default 64); sizes the K-batched descriptor,
  * ramp and bus buffers at the next fwgpu_update. */
 int fwgpu_set_max_batch(fwgpu_ctx* ctx, uint32_t max_blocks);

@@ -399,6 +399,17 @@ int launch_rt_block(hipStream_t, const FusedView& fv, const DevView& upv, const 
         if (fv.cmds[i].block == cmd_block0) g_cmds_applied++;
     return 0;
 }
+// the resident realtime kernel, as the harness can model it: it renders the block its doorbell already names, and its watchdog
+// fires at once (alive = 0) — the next callback finds it gone and launches another (the relaunch path of fwgpu_run.cpp)
+int launch_rt_persist(hipStream_t s, const FusedView& fv, const DevView& upv, const RootArgs& root, float* d_out, uint32_t cmd_block0,
+                      unsigned* d_sync, unsigned long long* d_done_flag, RtMailbox* d_mb, unsigned long long* d_go, unsigned long long first_seq,
+                      unsigned long long idle_ticks) {
+    REQUIRE(d_mb && d_go && idle_ticks > 0 && d_mb->doorbell == first_seq && d_mb->alive == 1, first_seq, idle_ticks);
+    touch(d_go, sizeof(unsigned long long));
+    const int rc = launch_rt_block(s, fv, upv, root, d_out, cmd_block0, d_sync, d_done_flag, first_seq);
+    d_mb->alive = 0;
+    return rc;
+}
 int launch_leaf_sum(hipStream_t, const FusedView& fv, int K) {
     g_launches[2]++;
     check_fused_common(fv, K);

@@ -825,13 +825,16 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
             # source L+R once (f32: 8 B, i16: 4 B) (+ delay ring read + write)
             per_vs = 24.0 if wl == "cfg3" else (4.0 if sfmt == "i16" else 8.0)
             kernel = "k_chain" if wl == "cfg3" else "k_leaf_sum"
+            if getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5"):
+                kernel = "k_leaf_rs"  # (+ k_leaf_sum_wl over its work list, timed together: fwgpu_kernels.hip launch_leaf_sum)
             k_launch = min(K, 64) if wl == "cfg3" else K  # the chain plan renders at most 64 blocks per k_chain launch
             alg_bytes = V * B * k_launch * per_vs * playing  # paused voices (variant C) fetch nothing
             avg_s = dom_ms / dom_n / 1e3
             ach = alg_bytes / avg_s / 1e9
             # (PMC passes ran on f32 sources; a profile is quoted for the workload it was collected on: plain / --voice-fx / --rs-source)
-            prof_name = wl + ("_voicefx" if args.voice_fx else "") + ("_rs" if getattr(args, "rs_source", False) else "")
-            plain = not (args.master or getattr(args, "master_iir", False) or variant != "A" or args.force_generic or getattr(args, "voice_spatial", False) or getattr(args, "send", False))
+            prof_name = (wl + ("_voicefx" if args.voice_fx else "") + ("_rs" if getattr(args, "rs_source", False) else "") +
+                         ("_spatial" if getattr(args, "voice_spatial", False) else ""))
+            plain = not (args.master or getattr(args, "master_iir", False) or variant != "A" or args.force_generic or getattr(args, "send", False))
             traffic, traffic_src = pmc_traffic(kernel, V, B, K, prof_name) if sfmt == "f32" and plain else (None, None)
             roofline = {
                 "bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -196,6 +196,7 @@ int main(int argc, char** argv) {
         const double dt = now_us() - t0;
         upd_sum += dt;
         if (dt > upd_max) upd_max = dt;
+        a.editing = 2; /* built and published: the next callback adopts the plan, the one after it starts the new voice */
         start_voice(v);
         { /* the callbacks that pick the plan up are still "editing" ones: wait for two more before the flag drops */
             const long seen = a.n;
@@ -214,15 +215,19 @@ int main(int argc, char** argv) {
     long c0, c1;
     stats(a.t_us, a.tag, a.n, 0, &m0, &p0, &x0, &c0);
     stats(a.t_us, a.tag, a.n, 1, &m1, &p1, &x1, &c1);
+    double m2, p2, x2;
+    long c2;
+    stats(a.t_us, a.tag, a.n, 2, &m2, &p2, &x2, &c2);
     uint64_t adoptions = 0, by_audio = 0, worst_ns = 0;
     CK(fwgpu_plan_handover_stats(g_cx, &adoptions, &by_audio, &worst_ns));
     printf("{\"voices\": %d, \"block\": %u, \"launch_plan\": %d, \"callbacks\": %ld, \"edits\": %d, \"first_update_ms\": %.2f, "
            "\"update_ms_mean\": %.3f, \"update_ms_max\": %.3f, "
            "\"callback_us_steady\": {\"n\": %ld, \"median\": %.1f, \"p99\": %.1f, \"max\": %.1f}, "
-           "\"callback_us_while_editing\": {\"n\": %ld, \"median\": %.1f, \"p99\": %.1f, \"max\": %.1f}, "
+           "\"callback_us_while_the_plan_is_built\": {\"n\": %ld, \"median\": %.1f, \"p99\": %.1f, \"max\": %.1f}, "
+           "\"callback_us_adoption_and_the_two_after\": {\"n\": %ld, \"median\": %.1f, \"p99\": %.1f, \"max\": %.1f}, "
            "\"plans_adopted\": %llu, \"adopted_by_a_callback\": %llu, \"longest_adoption_us\": %.1f}\n",
            g_voices, g_block, plan, a.n, edits, first_update_us / 1e3, edits ? upd_sum / edits / 1e3 : 0.0, upd_max / 1e3, c0, m0, p0, x0, c1, m1, p1,
-           x1, (unsigned long long)adoptions, (unsigned long long)by_audio, worst_ns / 1e3);
+           x1, c2, m2, p2, x2, (unsigned long long)adoptions, (unsigned long long)by_audio, worst_ns / 1e3);
     fwgpu_ctx_destroy(g_cx);
     return 0;
 }

@@ -234,6 +234,11 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
         fprintf(stderr, "fwgpu host profile: %llu process calls, %.2f us each inside run_blocks; %llu k_rt_block launches, %.2f us each inside the HIP launch call\n",
                 (unsigned long long)c->hp_calls, c->hp_call_ns / 1e3 / (double)c->hp_calls, (unsigned long long)c->hp_launches,
                 c->hp_launches ? c->hp_launch_ns / 1e3 / (double)c->hp_launches : 0.0);
+    if (c->host_prof && c->hp_calls) {
+        fprintf(stderr, "fwgpu host profile: host time inside run_blocks, 25 us bins:");
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", (unsigned long long)c->hp_hist[i]);
+        fprintf(stderr, "\n");
+    }
     use_device(c);
     (void)rt_persist_stop(c);
     if (c->rt_stream) (void)hipStreamDestroy(c->rt_stream);
@@ -264,6 +269,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     }
     c->release_device();
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+    if (c->h_up) (void)hipHostFree(c->h_up);
     DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_rt_sync, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask, &c->d_trace, &c->d_rs_table};
     for (DevBuf* b : bufs) b->release();

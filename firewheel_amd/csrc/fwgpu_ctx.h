@@ -164,9 +164,11 @@ struct PlanImage {
     bool fused_sp = false;    // ... and spatialiser stages (k_leaf_sum<true, false, true>)
     // control-kernel dispatch order (FusedView::ctl_order), rebuilt by upload_cmds for every call that has messages
     std::vector<int> slot_voice;        // node state slot -> voice of the voice-bank plan (-1: none)
+    DevBuf d_slot_voice;                // ... on the device, for the plan that replaces this one (k_carry_cache)
     std::vector<uint8_t> ctl_mark;      // [n_voices] scratch
     std::vector<int> hot_prev, hot_now; // voices with messages in the call before / in this one (capacity reserved at build)
-    int* h_ctl_order = nullptr;         // pinned [n_voices]
+    int* h_ctl_order = nullptr;         // pinned [h_ctl_order_cap >= n_voices]
+    size_t h_ctl_order_cap = 0;
     DevBuf d_ctl_order;
     bool ctl_order_live = false;        // the device copy holds this call's order (else: identity, nothing uploaded)
     DevBuf d_rs_wl;           // resampler plans: the work list between k_leaf_rs and k_leaf_sum_wl (FusedView::rs_wl)
@@ -388,6 +390,9 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     DevBuf d_rt_sync;           // its workgroup counter
     // the resident realtime kernel (k_rt_persist, k_rt.hip.h): launched by the first steady one-block callback of a run of them, fed
     // through `h_rt_mb->doorbell` from then on, ended by rt_persist_stop before anything else touches the device state it owns
+    // control side: pinned staging arena of the plan build's uploads (fwgpu_plan_install.cpp `up`)
+    char* h_up = nullptr;
+    size_t h_up_cap = 0, h_up_used = 0;
     bool rt_persist = true;        // FWGPU_RT_PERSIST=0: every callback is its own launch (k_rt_block)
     uint32_t rt_idle_ms = 20;      // its watchdog: no doorbell for this long and it ends by itself (FWGPU_RT_IDLE_MS)
     RtMailbox *h_rt_mb = nullptr, *d_rt_mb = nullptr;
@@ -417,6 +422,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     // printed to stderr when the ctx is destroyed
     bool host_prof = false;
     uint64_t hp_calls = 0, hp_call_ns = 0, hp_launch_ns = 0, hp_launches = 0;
+    uint64_t hp_hist[16] = {0};
     uint64_t adopt_ns_max = 0, adoptions = 0, audio_adoptions = 0;  // the longest an adoption held up a process call (host nanoseconds)
 
     // timing

@@ -17,12 +17,33 @@ namespace fwgpu {
 
 // control-side upload of the image being built: its own stream (never the null stream: that would serialise with a caller's
 // legacy default stream), complete on return (the sources are locals of the build)
+// (round 3: staged through ONE pinned arena and copied asynchronously — a table is a memcpy into pinned memory plus a short, truly
+//  asynchronous HIP call; the ~30 pageable copies with a blocking sync each that a build used to make held the runtime's locks long
+//  enough to hold up the audio thread's launch calls: callbacks while editing p99 214 us -> see profiles/r03_edit_race_cfg3.json.
+//  build_image waits for the stream once, at its end.)
 static int up(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes) {
     HIPC(c, b.ensure_n("b", bytes));
-    if (bytes) {
-        HIPC(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->up_stream));
-        HIPC(c, hipStreamSynchronize(c->up_stream));
+    if (!bytes) return 0;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (c->h_up_used + need > c->h_up_cap) {
+        HIPC(c, hipStreamSynchronize(c->up_stream));  // what is in flight has left the arena
+        c->h_up_used = 0;
+        if (need > c->h_up_cap) {
+            if (c->h_up) (void)hipHostFree(c->h_up);
+            c->h_up = nullptr;
+            c->h_up_cap = 0;
+            const size_t cap = std::max<size_t>(need, (size_t)8 << 20);
+            HIPC(c, hipHostMalloc((void**)&c->h_up, cap, hipHostMallocDefault));
+            c->h_up_cap = cap;
+        }
     }
+    memcpy(c->h_up + c->h_up_used, src, bytes);
+    // (what still reaches the callbacks while a plan is built — profiles/r03_edit_race_cfg3.json: p99 +150 us — is the device side of
+    //  these copies and of the pool fills: on this stack they are blit / fill KERNELS on the build's stream, and while one runs the
+    //  audio stream's kernels finish late (a 1-thread k_signal_done took 45-65 us next to a 50 us copy in the rocprofv3 trace).
+    //  Cutting them into 32 KiB .. 1 MiB pieces changed nothing but the build time)
+    HIPC(c, hipMemcpyAsync(b.p, c->h_up + c->h_up_used, bytes, hipMemcpyHostToDevice, c->up_stream));
+    c->h_up_used += need;
     return 0;
 }
 static int zero(fwgpu_ctx* c, void* p, size_t bytes) {
@@ -32,13 +53,14 @@ static int zero(fwgpu_ctx* c, void* p, size_t bytes) {
 
 void PlanImage::release_device() {
     DevBuf* bufs[] = {&d_nodes, &d_in_buf, &d_out_buf, &d_level_nodes, &d_pool, &d_flags, &d_gin_bufs, &d_gout_bufs, &d_groups, &d_blks2, &d_refs2,
-                      &d_gsets2, &d_ramps2, &d_progs, &d_hist, &d_rs_wl, &d_ctl_order, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
+                      &d_gsets2, &d_ramps2, &d_progs, &d_hist, &d_rs_wl, &d_ctl_order, &d_slot_voice, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
                       &d_chain_start, &d_chain_dummy, &d_chain_stats, &d_up_nodes, &d_up_in, &d_up_out, &d_up_level_nodes, &d_root_bufs, &d_tail_nodes,
                       &d_tail_in, &d_tail_out, &d_tail_idx, &d_tail_frozen, &d_frozen_ph, &d_frozen, &d_fir_rows, &d_fir_tiles, &d_fir_partials,
                       &d_hlevel_nodes, &grow_states, &grow_ext, &d_state_inits, &d_ext_jobs};
     for (DevBuf* b : bufs) b->release();
     if (h_ctl_order) (void)hipHostFree(h_ctl_order);
     h_ctl_order = nullptr;
+    h_ctl_order_cap = 0;
     if (h_host_stage) (void)hipHostFree(h_host_stage);
     if (h_host_flags) (void)hipHostFree(h_host_flags);
     h_host_stage = d_host_stage = nullptr;
@@ -124,9 +146,14 @@ static int alloc_voice_tables(fwgpu_ctx* c, PlanImage& P) {
     HIPC(c, P.d_cache.ensure_n("d_cache", (size_t)P.n_voices * sizeof(VoiceCache)));
     if ((rc = zero(c, P.d_cache.p, (size_t)P.n_voices * sizeof(VoiceCache)))) return rc;  // (and adoption bumps the epoch)
     HIPC(c, P.d_ramps.ensure_n("d_ramps", K * P.n_voices * (size_t)P.ramp_slots * c->stride * sizeof(float)));
-    if (P.h_ctl_order) (void)hipHostFree(P.h_ctl_order);
-    P.h_ctl_order = nullptr;
-    HIPC(c, hipHostMalloc((void**)&P.h_ctl_order, std::max<size_t>(1, (size_t)P.n_voices) * sizeof(int), hipHostMallocDefault));
+    if (!P.h_ctl_order || P.h_ctl_order_cap < (size_t)P.n_voices) {  // (a recycled image keeps its pinned block)
+        if (P.h_ctl_order) (void)hipHostFree(P.h_ctl_order);
+        P.h_ctl_order = nullptr;
+        P.h_ctl_order_cap = 0;
+        const size_t cap = std::max<size_t>(64, (size_t)P.n_voices + (size_t)P.n_voices / 4);
+        HIPC(c, hipHostMalloc((void**)&P.h_ctl_order, cap * sizeof(int), hipHostMallocDefault));
+        P.h_ctl_order_cap = cap;
+    }
     HIPC(c, P.d_ctl_order.ensure_n("d_ctl_order", std::max<size_t>(1, (size_t)P.n_voices) * sizeof(int)));
     P.ctl_mark.assign((size_t)P.n_voices, 0);
     P.hot_prev.clear();
@@ -554,6 +581,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         P.fused_sp = fb.has_sp;
         if (fb.has_sp) HIPC(c, P.d_hist.ensure_n("d_hist", fb.voices.size() * SP_HIST * sizeof(float)));
         build_slot_voice(P, fb.voices);
+        if ((rc = up(c, P.d_slot_voice, P.slot_voice.data(), P.slot_voice.size() * sizeof(int)))) return rc;
         if ((rc = up(c, P.d_voices, fb.voices.data(), fb.voices.size() * sizeof(VoiceDesc)))) return rc;
         if ((rc = up(c, P.d_leaves, fb.leaves.data(), fb.leaves.size() * sizeof(LeafDesc)))) return rc;
         if ((rc = up(c, P.d_progs, fb.progs.data(), fb.progs.size() * sizeof(uint32_t)))) return rc;
@@ -659,6 +687,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         P.fused_sp = hb.has_sp;
         if (hb.has_sp) HIPC(c, P.d_hist.ensure_n("d_hist", hb.voices.size() * SP_HIST * sizeof(float)));
         build_slot_voice(P, hb.voices);
+        if ((rc = up(c, P.d_slot_voice, P.slot_voice.data(), P.slot_voice.size() * sizeof(int)))) return rc;
         if ((rc = up(c, P.d_voices, hb.voices.data(), hb.voices.size() * sizeof(VoiceDesc)))) return rc;
         if ((rc = up(c, P.d_leaves, hb.leaves.data(), hb.leaves.size() * sizeof(LeafDesc)))) return rc;
         if ((rc = up(c, P.d_progs, hb.progs.data(), hb.progs.size() * sizeof(uint32_t)))) return rc;
@@ -698,6 +727,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
     P.plan = plan;
     P.have_plan = true;
     HIPC(c, hipStreamSynchronize(c->up_stream));  // every table and every zeroed pool of the image is in place
+    c->h_up_used = 0;
     // ---- commit the control side's own bookkeeping: from here on the image WILL be adopted
     for (const Act& a : acts) {
         HostNode& n = c->graph.nodes[a.slot];
@@ -802,7 +832,13 @@ void adopt_image(fwgpu_ctx* c, PlanImage* n, bool on_audio_thread) {
     // 4. the swap
     std::swap(static_cast<PlanImage&>(*c), *n);
     std::swap(c->retired_ev, n->retired_ev);  // (the event belongs to the heap object that travels through the ring)
-    c->epoch++;  // cached steady descriptors belong to the old plan
+    const uint32_t old_epoch = c->epoch;
+    c->epoch++;  // cached steady descriptors belong to the old plan ...
+    // ... except those of voices the edit did not touch: same nodes in the same order (k_carry_cache; `n` is the old image now,
+    // its buffers stay untouched until the control side has seen retired_ev)
+    if (c->n_voices > 0 && n->n_voices > 0 && !n->slot_voice.empty() && c->d_cache.p && n->d_cache.p && n->d_slot_voice.p && c->d_voices.p && n->d_voices.p)
+        (void)launch_carry_cache(c->stream, c->d_cache.as<VoiceCache>(), c->d_voices.as<VoiceDesc>(), c->n_voices, n->d_cache.as<VoiceCache>(),
+                                 n->d_voices.as<VoiceDesc>(), n->d_slot_voice.as<int>(), (int)n->slot_voice.size(), old_epoch, c->epoch);
     c->adopted_gen.store(c->gen, std::memory_order_release);
     // 5. the old image goes back to the control side, which waits for `retired_ev` before it touches the buffers
     if (n->retired_ev) (void)hipEventRecord(n->retired_ev, c->stream);  // (created with the object, on the control thread)

@@ -658,7 +658,12 @@ int run_blocks(fwgpu_ctx* c, uint64_t frames, const float* d_in, int n_in_ch, fl
     if (!c->host_prof) return run_blocks_impl(c, frames, d_in, n_in_ch, d_out, n_out_ch, stable_out);
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = run_blocks_impl(c, frames, d_in, n_in_ch, d_out, n_out_ch, stable_out);
-    c->hp_call_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    const uint64_t ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    c->hp_call_ns += ns;
+    if (c->hp_calls > 50) {  // (histogram of the host time inside run_blocks, 25 us bins: where the launch calls themselves are held up)
+        const uint64_t bin = std::min<uint64_t>(ns / 25000, 15);
+        c->hp_hist[bin]++;
+    }
     c->hp_calls++;
     return rc;
 }

@@ -49,6 +49,8 @@ def per_kernel(ctr):
 fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
 per_vs = {"cfg2": 8.0, "cfg3": 24.0, "cfg5": 8.0}.get(cfg)
 dom = {"cfg2": "k_leaf_sum", "cfg3": "k_chain", "cfg5": "k_leaf_sum", "cfg4": "k_fir_gemm"}[cfg]
+if "--rs-source" in extra.split():
+    dom = "k_leaf_rs"
 out = {
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --workload %s --lean "
                "--no-kernel-timing --steps 4 --warmup 2 %s (one pass per counter)" % (cfg, extra),

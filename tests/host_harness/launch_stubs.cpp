@@ -348,6 +348,22 @@ int launch_host_scatter(hipStream_t, float* pool, uint8_t* flags, int stride, si
     touch(d_stage_flags, (size_t)(K - 1) * row_pitch + n);
     return 0;
 }
+int launch_carry_cache(hipStream_t, VoiceCache* new_cache, const VoiceDesc* new_voices, int n_new, const VoiceCache* old_cache,
+                       const VoiceDesc* old_voices, const int* old_slot_voice, int n_old_slots, uint32_t old_epoch, uint32_t new_epoch) {
+    REQUIRE(new_cache && new_voices && old_cache && old_voices && old_slot_voice && new_epoch != old_epoch, n_new, n_old_slots);
+    touch(new_cache, sizeof(VoiceCache) * (size_t)n_new);
+    touch(new_voices, sizeof(VoiceDesc) * (size_t)n_new);
+    touch(old_slot_voice, sizeof(int) * (size_t)n_old_slots);
+    for (int v = 0; v < n_new; ++v) {  // (the harness runs no kernels: what matters is that every index stays inside its table)
+        const int s = new_voices[v].sampler_state;
+        if (s < 0 || s >= n_old_slots) continue;
+        const int vo = old_slot_voice[s];
+        if (vo < 0) continue;
+        touch(old_voices + vo, sizeof(VoiceDesc));
+        touch(old_cache + vo, sizeof(VoiceCache));
+    }
+    return 0;
+}
 int launch_adopt_init(hipStream_t, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits) {
     g_launches[7]++;
     const AdoptExtJobHost* jobs = (const AdoptExtJobHost*)d_jobs;

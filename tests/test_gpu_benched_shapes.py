@@ -363,5 +363,5 @@ def test_graph_edits_while_the_audio_thread_runs_cost_the_callbacks_microseconds
     assert d["adopted_by_a_callback"] >= 25, d          # the audio thread was running: (nearly) every plan was picked up by a callback
     assert d["longest_adoption_us"] < 50.0, d
     assert d["update_ms_mean"] > 1.0, d                 # ... while each update really was milliseconds of work
-    steady, busy = d["callback_us_steady"], d["callback_us_while_editing"]
+    steady, busy = d["callback_us_steady"], d["callback_us_while_the_plan_is_built"]
     assert busy["median"] <= 1.25 * steady["median"] + 5.0, d

@@ -202,17 +202,11 @@ int launch_host_scatter(hipStream_t s, float* pool, uint8_t* flags, int stride, 
                        d_bufs, frames, row_pitch, d_stage, d_stage_flags);
     return (int)hipGetLastError();
 }
-int launch_carry_cache(hipStream_t s, VoiceCache* new_cache, const VoiceDesc* new_voices, int n_new, const VoiceCache* old_cache,
-                       const VoiceDesc* old_voices, const int* old_slot_voice, int n_old_slots, uint32_t old_epoch, uint32_t new_epoch) {
-    if (n_new <= 0 || n_old_slots <= 0) return 0;
-    hipLaunchKernelGGL(k_carry_cache, dim3((n_new + 255) / 256), dim3(256), 0, s, new_cache, new_voices, n_new, old_cache, old_voices, old_slot_voice,
-                       n_old_slots, old_epoch, new_epoch);
-    return (int)hipGetLastError();
-}
-int launch_adopt_init(hipStream_t s, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits) {
-    if (n_jobs <= 0 && n_inits <= 0) return 0;
-    hipLaunchKernelGGL(k_adopt_init, dim3(16, n_jobs + 1), dim3(256), 0, s, ext, (const AdoptExtJob*)d_jobs, n_jobs, states, (const uint8_t*)d_inits,
-                       n_inits);
+int launch_adopt_init(hipStream_t s, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits,
+                      const CarryArgs& carry) {
+    if (n_jobs <= 0 && n_inits <= 0 && carry.n_new <= 0) return 0;
+    hipLaunchKernelGGL(k_adopt_init, dim3(16, n_jobs + 2), dim3(256), 0, s, ext, (const AdoptExtJob*)d_jobs, n_jobs, states, (const uint8_t*)d_inits,
+                       n_inits, carry);
     return (int)hipGetLastError();
 }
 int launch_out_flags(hipStream_t s, const uint8_t* flags, size_t flags_blk_stride, const int* d_bufs, int n_bufs, int mode, int n_out_ch, int K,

@@ -152,9 +152,8 @@ struct AdoptExtJobHost {
     uint32_t off, zero_len, n_head, pad;
     float head[8];
 };
-int launch_carry_cache(hipStream_t s, VoiceCache* new_cache, const VoiceDesc* new_voices, int n_new, const VoiceCache* old_cache,
-                       const VoiceDesc* old_voices, const int* old_slot_voice, int n_old_slots, uint32_t old_epoch, uint32_t new_epoch);
-int launch_adopt_init(hipStream_t s, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits);
+int launch_adopt_init(hipStream_t s, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits,
+                      const CarryArgs& carry);
 // per (block, channel) of a batch: was that graph-output channel flagged silent (mode: see k_out_flags)
 int launch_out_flags(hipStream_t s, const uint8_t* flags, size_t flags_blk_stride, const int* d_bufs, int n_bufs, int mode, int n_out_ch, int K,
                      uint8_t* d_out);

@@ -555,6 +555,9 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         const size_t Kg = P.generic_k;
         size_t pool_bytes = Kg * (size_t)plan.num_buffers * c->stride * sizeof(float);
         HIPC(c, P.d_pool.ensure_n("d_pool", pool_bytes));
+        // (cleared per build: for config 3 a 0.5 GB fill.  Clearing only buffer 0 — the constant-zero buffer; every other one is written
+        //  before it is read, the GPU suite passes under FWGPU_POISON that way — did not change what the callbacks see while a plan is
+        //  built, so the simple, obviously safe form stays)
         if ((rc = zero(c, P.d_pool.p, pool_bytes))) return rc;
         std::vector<uint8_t> fl(Kg * (size_t)plan.num_buffers, 0);
         for (size_t k = 0; k < Kg; ++k) fl[k * (size_t)plan.num_buffers] = 1;  // buffer 0: constant zero, always flagged silent
@@ -779,9 +782,24 @@ void adopt_image(fwgpu_ctx* c, PlanImage* n, bool on_audio_thread) {
     }
     // 2. the nodes this image activates (graph.rs:594-612): ext slices zeroed / initialised, impulse responses converted,
     //    initial states scattered — into slots and slices no running plan uses
-    if (n->n_ext_jobs || n->n_state_inits)
+    //    ... and, in the same launch, the steady caches of the voices the edit did not touch travel to the new plan (same nodes in the
+    //    same order: carry_cache_voice), stamped with the epoch the swap below sets; `c` still is the old image here
+    CarryArgs carry;
+    memset(&carry, 0, sizeof(carry));
+    if (n->n_voices > 0 && c->n_voices > 0 && !c->slot_voice.empty() && n->d_cache.p && c->d_cache.p && c->d_slot_voice.p && n->d_voices.p && c->d_voices.p) {
+        carry.new_cache = n->d_cache.as<VoiceCache>();
+        carry.new_voices = n->d_voices.as<VoiceDesc>();
+        carry.n_new = n->n_voices;
+        carry.old_cache = c->d_cache.as<VoiceCache>();
+        carry.old_voices = c->d_voices.as<VoiceDesc>();
+        carry.old_slot_voice = c->d_slot_voice.as<int>();
+        carry.n_old_slots = (int)c->slot_voice.size();
+        carry.old_epoch = c->epoch;
+        carry.new_epoch = c->epoch + 1;
+    }
+    if (n->n_ext_jobs || n->n_state_inits || carry.n_new)
         (void)launch_adopt_init(c->stream, c->d_ext.as<float>(), n->d_ext_jobs.p, n->n_ext_jobs, c->d_states.as<NodeState>(), n->d_state_inits.p,
-                                n->n_state_inits);
+                                n->n_state_inits, carry);
     if (!n->ir_convs.empty()) {
         (void)upload_sample_table(c);
         for (const PlanImage::IrConv& ic : n->ir_convs)
@@ -832,13 +850,7 @@ void adopt_image(fwgpu_ctx* c, PlanImage* n, bool on_audio_thread) {
     // 4. the swap
     std::swap(static_cast<PlanImage&>(*c), *n);
     std::swap(c->retired_ev, n->retired_ev);  // (the event belongs to the heap object that travels through the ring)
-    const uint32_t old_epoch = c->epoch;
-    c->epoch++;  // cached steady descriptors belong to the old plan ...
-    // ... except those of voices the edit did not touch: same nodes in the same order (k_carry_cache; `n` is the old image now,
-    // its buffers stay untouched until the control side has seen retired_ev)
-    if (c->n_voices > 0 && n->n_voices > 0 && !n->slot_voice.empty() && c->d_cache.p && n->d_cache.p && n->d_slot_voice.p && c->d_voices.p && n->d_voices.p)
-        (void)launch_carry_cache(c->stream, c->d_cache.as<VoiceCache>(), c->d_voices.as<VoiceDesc>(), c->n_voices, n->d_cache.as<VoiceCache>(),
-                                 n->d_voices.as<VoiceDesc>(), n->d_slot_voice.as<int>(), (int)n->slot_voice.size(), old_epoch, c->epoch);
+    c->epoch++;  // cached steady descriptors belong to the old plan (those that travel were stamped with this value above)
     c->adopted_gen.store(c->gen, std::memory_order_release);
     // 5. the old image goes back to the control side, which waits for `retired_ev` before it touches the buffers
     if (n->retired_ev) (void)hipEventRecord(n->retired_ev, c->stream);  // (created with the object, on the control thread)

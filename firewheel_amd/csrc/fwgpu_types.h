@@ -197,6 +197,19 @@ struct VoiceCache {
 };
 static_assert(sizeof(VoiceCache) == 64, "VoiceCache layout");
 
+// plan adoption: which steady caches travel from the old plan to the new one (k_adopt_init / carry_cache_voice); n_new = 0: none
+struct VoiceDesc;
+struct CarryArgs {
+    VoiceCache* new_cache;
+    const VoiceDesc* new_voices;
+    int n_new;
+    const VoiceCache* old_cache;
+    const VoiceDesc* old_voices;
+    const int* old_slot_voice;
+    int n_old_slots;
+    uint32_t old_epoch, new_epoch;
+};
+
 // ---------------------------------------------------------------- FIR convolution bank (MFMA GEMM)
 #define FIR_SEG 4096  // window positions per split-K segment — part of the numeric SPEC (summation order)
 #ifndef FIR_KC

@@ -301,29 +301,29 @@ static_assert(sizeof(AdoptExtJob) == 48, "AdoptExtJob layout");
 // the last call steady" + the descriptor its blocks share), re-stamped with the new epoch.  Without this every voice of the graph
 // runs its full state machines in the first callback after ANY edit — 50-100 us more for that callback on configs 2 and 3
 // (scripts/adopt_cost.py).  The voices are matched by their sampler's state slot (stable while the node lives).
-__global__ __launch_bounds__(256) void k_carry_cache(VoiceCache* __restrict__ new_cache, const VoiceDesc* __restrict__ new_voices, int n_new,
-                                                     const VoiceCache* __restrict__ old_cache, const VoiceDesc* __restrict__ old_voices,
-                                                     const int* __restrict__ old_slot_voice, int n_old_slots, uint32_t old_epoch, uint32_t new_epoch) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_new) return;
-    const VoiceDesc a = new_voices[v];
-    if (a.sampler_state < 0 || a.sampler_state >= n_old_slots) return;
-    const int vo = old_slot_voice[a.sampler_state];
+__device__ __forceinline__ void carry_cache_voice(const CarryArgs& a, const int v) {
+    const VoiceDesc nv = a.new_voices[v];
+    if (nv.sampler_state < 0 || nv.sampler_state >= a.n_old_slots) return;
+    const int vo = a.old_slot_voice[nv.sampler_state];
     if (vo < 0) return;
-    const VoiceDesc b = old_voices[vo];
-    bool same = a.sampler_state == b.sampler_state && a.n_stages == b.n_stages && a.bq_state == b.bq_state && a.dl_state == b.dl_state &&
-                a.src_kind == b.src_kind && a.sp_ext_off == b.sp_ext_off;
+    const VoiceDesc ov = a.old_voices[vo];
+    bool same = nv.sampler_state == ov.sampler_state && nv.n_stages == ov.n_stages && nv.bq_state == ov.bq_state && nv.dl_state == ov.dl_state &&
+                nv.src_kind == ov.src_kind && nv.sp_ext_off == ov.sp_ext_off;
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
-        same = same && (j >= a.n_stages || (a.stage_kind[j] == b.stage_kind[j] && a.stage_state[j] == b.stage_state[j]));
+        same = same && (j >= nv.n_stages || (nv.stage_kind[j] == ov.stage_kind[j] && nv.stage_state[j] == ov.stage_state[j]));
     if (!same) return;
-    VoiceCache c = old_cache[vo];
-    if (c.epoch != old_epoch) return;
-    c.epoch = new_epoch;
-    new_cache[v] = c;
+    VoiceCache c = a.old_cache[vo];
+    if (c.epoch != a.old_epoch) return;
+    c.epoch = a.new_epoch;
+    a.new_cache[v] = c;
 }
 __global__ __launch_bounds__(256) void k_adopt_init(float* __restrict__ ext, const AdoptExtJob* __restrict__ jobs, int n_jobs,
-                                                    NodeState* __restrict__ states, const uint8_t* __restrict__ inits, int n_inits) {
+                                                    NodeState* __restrict__ states, const uint8_t* __restrict__ inits, int n_inits, CarryArgs carry) {
+    if ((int)blockIdx.y == n_jobs + 1) {  // (one launch for everything an adoption does on the device: each one is ~5 us of the audio thread)
+        for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < carry.n_new; v += gridDim.x * blockDim.x) carry_cache_voice(carry, v);
+        return;
+    }
     if ((int)blockIdx.y < n_jobs) {
         const AdoptExtJob j = jobs[blockIdx.y];
         const uint32_t n = j.zero_len > j.n_head ? j.zero_len : j.n_head;

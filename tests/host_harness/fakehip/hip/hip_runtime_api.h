@@ -58,6 +58,10 @@ static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKi
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset2DAsync(void* d, size_t pitch, int v, size_t w, size_t h, hipStream_t) {
+    for (size_t r = 0; r < h; ++r) memset((char*)d + r * pitch, v, w);
+    return hipSuccess;
+}
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }

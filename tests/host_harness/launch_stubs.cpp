@@ -348,8 +348,16 @@ int launch_host_scatter(hipStream_t, float* pool, uint8_t* flags, int stride, si
     touch(d_stage_flags, (size_t)(K - 1) * row_pitch + n);
     return 0;
 }
-int launch_carry_cache(hipStream_t, VoiceCache* new_cache, const VoiceDesc* new_voices, int n_new, const VoiceCache* old_cache,
-                       const VoiceDesc* old_voices, const int* old_slot_voice, int n_old_slots, uint32_t old_epoch, uint32_t new_epoch) {
+static int check_carry(const CarryArgs& a) {
+    if (a.n_new <= 0) return 0;
+    VoiceCache* new_cache = a.new_cache;
+    const VoiceDesc* new_voices = a.new_voices;
+    const int n_new = a.n_new;
+    const VoiceCache* old_cache = a.old_cache;
+    const VoiceDesc* old_voices = a.old_voices;
+    const int* old_slot_voice = a.old_slot_voice;
+    const int n_old_slots = a.n_old_slots;
+    const uint32_t old_epoch = a.old_epoch, new_epoch = a.new_epoch;
     REQUIRE(new_cache && new_voices && old_cache && old_voices && old_slot_voice && new_epoch != old_epoch, n_new, n_old_slots);
     touch(new_cache, sizeof(VoiceCache) * (size_t)n_new);
     touch(new_voices, sizeof(VoiceDesc) * (size_t)n_new);
@@ -364,7 +372,9 @@ int launch_carry_cache(hipStream_t, VoiceCache* new_cache, const VoiceDesc* new_
     }
     return 0;
 }
-int launch_adopt_init(hipStream_t, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits) {
+int launch_adopt_init(hipStream_t, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits,
+                      const CarryArgs& carry) {
+    if (check_carry(carry)) return -1;
     g_launches[7]++;
     const AdoptExtJobHost* jobs = (const AdoptExtJobHost*)d_jobs;
     touch(d_jobs, sizeof(AdoptExtJobHost) * (size_t)n_jobs);

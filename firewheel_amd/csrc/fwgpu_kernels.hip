@@ -234,15 +234,16 @@ int launch_rt_persist(hipStream_t s, const FusedView& fv, const DevView& upv, co
                       unsigned* d_sync, unsigned long long* d_done_flag, RtMailbox* d_mb, unsigned long long* d_go, unsigned long long first_seq,
                       unsigned long long idle_ticks) {
     if (fv.n_leaves <= 0) return 0;
+    static const int prefetch = [] { const char* e = getenv("FWGPU_RT_PREFETCH"); return e ? atoi(e) : 1; }();
     if (fv.has_rs)
         hipLaunchKernelGGL((k_rt_persist<true, true>), dim3(fv.n_leaves), dim3(256), RS_LDS_BYTES(4), s, fv, upv, root, d_out, cmd_block0, d_sync,
-                           d_done_flag, d_mb, d_go, first_seq, idle_ticks);
+                           d_done_flag, d_mb, d_go, first_seq, idle_ticks, prefetch);
     else if (fv.has_prog)
         hipLaunchKernelGGL((k_rt_persist<true, false>), dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync, d_done_flag,
-                           d_mb, d_go, first_seq, idle_ticks);
+                           d_mb, d_go, first_seq, idle_ticks, prefetch);
     else
         hipLaunchKernelGGL((k_rt_persist<false, false>), dim3(fv.n_leaves), dim3(256), 0, s, fv, upv, root, d_out, cmd_block0, d_sync, d_done_flag,
-                           d_mb, d_go, first_seq, idle_ticks);
+                           d_mb, d_go, first_seq, idle_ticks, prefetch);
     return (int)hipGetLastError();
 }
 int launch_signal_done(hipStream_t s, unsigned long long* d_done_flag, unsigned long long done_seq) {

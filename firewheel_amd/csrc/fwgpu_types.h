@@ -21,6 +21,7 @@ struct RtMailbox {
     unsigned long long pad1[7];
 };
 #define RT_QUIT_BIT (1ull << 63)
+#define RT_PREFETCH_BIT (1ull << 62)  // device-internal (`go` word): "no doorbell for 10 us: fetch the next block's sources now"
 #define LEAF_WPB_MAX 4  // k_leaf.hip.h: at most this many 256-frame pieces (waves) per block
 #define SP_HIST 64    // SPEC spatialiser: mono history frames (>= the largest per-ear delay + 1)
 

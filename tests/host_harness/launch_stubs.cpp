@@ -5,8 +5,10 @@
 namespace {
 unsigned long long g_launches[8];  // 0 level, 1 voice_control, 2 leaf_sum, 3 chain, 4 bus_sum, 5 root_out, 6 fir, 7 other
 unsigned long long g_cmds_applied = 0;
+unsigned long long g_ctl_orders = 0;  // control launches that carried a dispatch order (FusedView::ctl_order)
 }
 extern "C" unsigned long long fwh_cmds_seen(void) { return g_cmds_applied; }
+extern "C" unsigned long long fwh_ctl_orders(void) { return g_ctl_orders; }
 extern "C" {
 unsigned long long fwh_alloc_calls = 0;  // hipMalloc / hipHostMalloc calls of the fake runtime
 unsigned long long fwh_alloc_count(void) { return fwh_alloc_calls; }
@@ -25,6 +27,7 @@ extern "C" void fwh_launch_reset(void) {
 #include <stdio.h>
 
 #include <string>
+#include <vector>
 namespace {
 std::string g_violation;
 void violation(const char* what, long a = 0, long b = 0) {
@@ -269,6 +272,36 @@ int launch_voice_control(hipStream_t, const FusedView& fv, int K, uint32_t cmd_b
         if (fv.cmds[i].block >= cmd_block0 && fv.cmds[i].block < cmd_block0 + (uint32_t)K) g_cmds_applied++;
     }
     if (fv.fx_plan) touch(fv.chain_start, sizeof(ChainStart) * (size_t)fv.n_voices);
+    if (fv.ctl_order) {
+        // the dispatch order (upload_cmds): a permutation of the voices, and every voice a message of this call goes to sits in
+        // front of every voice that has none (and did not have one in the call before: those may sit in front as well)
+        static int pos[1 << 16];   // (fixed: the stubs run on the audio thread of the allocation-counting tests)
+        static char has[1 << 16];
+        REQUIRE(fv.n_voices <= (1 << 16), fv.n_voices);
+        for (int v = 0; v < fv.n_voices; ++v) {
+            pos[v] = -1;
+            has[v] = 0;
+        }
+        for (int w = 0; w < fv.n_voices; ++w) {
+            const int v = fv.ctl_order[w];
+            REQUIRE(v >= 0 && v < fv.n_voices && pos[(size_t)v] < 0, w, v);
+            pos[(size_t)v] = w;
+        }
+        int n_has = 0;
+        for (int i = 0; i < fv.n_cmds; ++i)
+            for (int v = 0; v < fv.n_voices; ++v) {
+                const VoiceDesc& vd = fv.voices[v];
+                bool mine = vd.sampler_state == fv.cmds[i].state || vd.bq_state == fv.cmds[i].state || vd.dl_state == fv.cmds[i].state;
+                for (int j = 0; j < vd.n_stages && j < FW_MAX_STAGES - 1; ++j) mine = mine || vd.stage_state[j] == fv.cmds[i].state;
+                if (mine && fv.cmds[i].state >= 0 && !has[(size_t)v]) {
+                    has[(size_t)v] = 1;
+                    ++n_has;
+                }
+            }
+        for (int v = 0; v < fv.n_voices; ++v)
+            if (has[(size_t)v]) REQUIRE(pos[(size_t)v] < n_has, v, pos[(size_t)v]);
+        g_ctl_orders++;
+    }
     memset(g_fused_states, 0, sizeof(g_fused_states));
     g_fused_ctx_states = fv.states;
     for (int i = 0; i < fv.n_voices; ++i) {

@@ -418,3 +418,41 @@ def test_process_calls_allocate_no_device_or_pinned_memory_once_warm(kw):
         else:
             e.process_interleaved(64 * 3 + 5)  # a partial last block
     assert hostonly_lib().fwh_alloc_count() == before
+
+
+def test_control_dispatch_order_and_cache_carry_on_the_host_side():
+    """round 3, host half only (the harness stubs CHECK the tables, tests/host_harness/launch_stubs.cpp): every call with messages
+    hands k_voice_control a dispatch order that is a permutation with the voices those messages go to in front; a call without
+    messages (and none in the call before) hands it none; an adoption passes the steady-cache carry tables of the OLD plan with
+    every index inside its table."""
+    import ctypes as C
+
+    from fwapi import HostOnlyEngine, hostonly_lib
+
+    L = hostonly_lib()
+    L.fwh_ctl_orders.restype = C.c_ulonglong
+    L.fwh_violation_reset()
+    e = HostOnlyEngine(max_block_frames=128, max_batch=8)
+    voices = scenarios.build_voice_bank(e, 70, radix=32, src_frames=900)
+    for vc in voices:
+        e.sampler_play(vc["sampler"])
+    n0 = L.fwh_ctl_orders()
+    e.process_blocks(8)                       # play / set-sample messages for every voice
+    assert L.fwh_ctl_orders() == n0 + 1
+    e.process_blocks(8)                       # none now, but the call before had them: their glides may continue
+    e.process_blocks(8)                       # none, none: identity order, nothing uploaded
+    assert L.fwh_ctl_orders() == n0 + 2
+    e.set_param(voices[33]["volume"], 0, 20.0, at_block=5)
+    e.set_param(voices[2]["pan"], 0, 0.5, at_block=1)
+    e.process_blocks(8)
+    assert L.fwh_ctl_orders() == n0 + 3
+    # an edit that leaves every voice as it was, and one that removes a voice: both adoptions carry caches (stub: bounds)
+    x = e.volume(50.0)
+    e.remove_node(x)
+    e.update()
+    e.process_blocks(2)
+    e.remove_node(voices[5]["pan"])
+    e.update()
+    e.set_param(voices[6]["volume"], 0, 70.0)
+    e.process_blocks(3)
+    assert e.violation() == "", e.violation()

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import scenarios
-from fwapi import LOOP_FULL, GpuEngine, OracleEngine
+from fwapi import LOOP_FULL, LOOP_RANGE_SECS, GpuEngine, OracleEngine
 from test_gpu_parity import assert_bits_equal
 
 pytestmark = pytest.mark.gpu
@@ -142,3 +142,45 @@ def test_destroy_and_idle_leave_no_kernel_behind():
     t0 = time.perf_counter()
     torch.cuda.synchronize()
     assert time.perf_counter() - t0 < 0.010, "a resident kernel outlived its context"
+
+
+# ------------------------------------------------------------------ more shapes through the resident kernel
+def _varied_bank(e, n_voices, fx, src_frames):
+    """loops of odd lengths (wraps at every offset inside a block), one-shots that end inside the run, mono samples, voices that
+    never play (silent ports), a voice muted by a fade, loop ranges; a last leaf of 4 ports (the unmasked SumNode path)"""
+    def voice_fx(e_, v, rng):
+        if not fx:
+            return []
+        return [e_.width(float(rng.uniform(0.3, 1.7)))] if v % 3 == 0 else ([e_.hard_clip(-4.0)] if v % 3 == 1 else [])
+
+    voices = scenarios.build_voice_bank(e, n_voices, radix=32, src_frames=src_frames, mono_every=5, voice_fx=voice_fx if fx else None)
+    for v, vc in enumerate(voices):
+        if v % 7 == 3:
+            pass                                                   # a one-shot: ends after src_frames
+        elif v % 7 == 5:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_RANGE_SECS, (13 + v) / 48000.0, (src_frames - 29 - v) / 48000.0)
+        else:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        if v % 11 != 6:
+            e.sampler_play(vc["sampler"])                          # v % 11 == 6: never plays
+        if v == 9:
+            e.set_param(vc["volume"], 0, 0.0)                      # fades to silence: muted from then on
+    return voices
+
+
+@pytest.mark.parametrize("mbf,n_voices,fx,src_frames,n_cb", [(64, 100, False, 701, 260), (64, 132, True, 997, 200), (128, 260, False, 1500, 120),
+                                                              (256, 1024, False, 4099, 60)])
+def test_varied_banks_through_the_resident_kernel_match_the_oracle(mbf, n_voices, fx, src_frames, n_cb):
+    """(the scenario that showed a resident kernel with a second rendering path compiled in writing garbage from its ORDINARY
+    block — scripts/experiments/r03_rt_sliced_kernel.patch)"""
+    g, o = GpuEngine(max_block_frames=mbf), OracleEngine(max_block_frames=mbf)
+    outs_g, outs_o = [], []
+    for e, outs in ((g, outs_g), (o, outs_o)):
+        _varied_bank(e, n_voices, fx, src_frames)
+        for _ in range(n_cb):
+            outs.append(np.asarray(e.process_interleaved(mbf)))
+    assert g.cx.plan_kind() == 1
+    assert_bits_equal(np.concatenate(outs_o), np.concatenate(outs_g), "varied bank %d voices block %d" % (n_voices, mbf))
+    if os.environ.get("FWGPU_RT_PERSIST") != "0":
+        launches, doorbells = g.cx.rt_resident_stats()
+        assert doorbells >= n_cb // 2, (launches, doorbells)

@@ -236,7 +236,19 @@ class AsyncEngine(GpuEngine):
     async_device = True
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FWGPU_FUZZ_SEEDS", "80"))))
+def test_spatialiser_history_crosses_calls_that_are_not_waited_for():
+    """the scenario of test_gpu_parity's spatial bank through fwgpu_process_blocks_device with nothing between the calls: the next
+    call's control kernel must not read the 64-frame histories before the render kernel of this call has left them behind"""
+    for mbf, batch in ((128, 64), (64, 16)):
+        g = AsyncEngine(max_block_frames=mbf, max_batch=batch)
+        o = oracle(max_block_frames=mbf)
+        assert_bits_equal(scenarios.scenario_spatial_bank(o), scenarios.scenario_spatial_bank(g), "spatial bank, async calls, block %d" % mbf)
+        assert g.cx.plan_kind() == 1
+
+
+# (91, 196, 384: spatialiser voices across calls with the control kernel running a call ahead — the history hand-over raced; found
+#  by a 500-seed run in round 3, in the suite since)
+@pytest.mark.parametrize("seed", sorted(set(range(int(os.environ.get("FWGPU_FUZZ_SEEDS", "80")))) | {91, 196, 384}))
 def test_random_graph_and_messages_every_plan_bit_exact(seed):
     pick = np.random.default_rng(10_000 + seed)
     mbf = int(pick.choice([64, 128, 256]))

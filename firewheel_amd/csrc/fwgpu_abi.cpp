@@ -598,6 +598,7 @@ int fwgpu_sample_destroy(fwgpu_ctx* c, int sample) {
             return fail(c, FWGPU_ERR_INVALID, "sample is in use by a FIR / resampler node");
     use_device(c);
     ControlGate gate(c);  // no process call runs while the entry is emptied and the data freed
+    (void)rt_persist_stop(c);  // ... and no resident realtime kernel: between two callbacks it may be fetching the frames a voice reads next
     (void)hipStreamSynchronize(c->stream);
     if (c->ctl_stream) (void)hipStreamSynchronize(c->ctl_stream);
     SampleRec& r = c->samples[sample];

@@ -250,6 +250,11 @@ int launch_signal_done(hipStream_t s, unsigned long long* d_done_flag, unsigned 
     hipLaunchKernelGGL(k_signal_done, dim3(1), dim3(1), 0, s, d_done_flag, done_seq);
     return (int)hipGetLastError();
 }
+int launch_sp_hist_copy(hipStream_t s, const FusedView& fv) {
+    if (fv.n_voices <= 0) return 0;
+    hipLaunchKernelGGL(k_sp_hist_copy, dim3((fv.n_voices * SP_HIST + 255) / 256), dim3(256), 0, s, fv);
+    return (int)hipGetLastError();
+}
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
     if (fv.n_leaves <= 0) return 0;
     // waves per block: long blocks are cut into 256-frame pieces so that every wave is one short streaming pass

@@ -68,6 +68,7 @@ struct FusedView {
     int has_prog;           // some voice's program is not 0 (or its source is a resampler): k_leaf_sum<true>
     int has_rs;             // some voice's source is a resampler: the program instantiation stages windows + filter bank in LDS
     int has_sp;             // some voice ends in a spatialiser stage: k_leaf_sum<true, false, true>
+    int sp_hist_in_render;  // control-ahead mode + spatialiser stages: k_sp_hist_copy makes the history copy, not k_voice_control
     const int* ctl_order;   // k_voice_control: wave w works voice ctl_order[w] (nullptr: w) — voices with messages first
     unsigned int* rs_wl;    // has_rs: work list k_leaf_rs leaves for k_leaf_sum_wl — [0] items, [1] workgroups done, then (leaf, block*4 + piece) pairs
     float* hist;            // [n_voices][SP_HIST]: the mono history each spatialiser voice enters THIS call with (copied from the ext
@@ -121,6 +122,7 @@ int launch_set_flags(hipStream_t s, uint8_t* flags, const int* d_bufs, int n, ui
 int launch_get_flags(hipStream_t s, const uint8_t* flags, const int* d_bufs, int n, uint64_t* d_mask);
 int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0, bool beside_render = false);
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K);
+int launch_sp_hist_copy(hipStream_t s, const FusedView& fv);
 // realtime edge: control + leaf sums + root sum + interleave of ONE block in one launch (tree = leaves + root, stereo out);
 // d_sync: one zero-initialised unsigned the workgroups count themselves in with
 // d_done_flag (may be null): device view of a pinned host word that receives done_seq when the output block is complete

@@ -596,10 +596,10 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         }
         const size_t K = P.kmax;
         if ((rc = alloc_voice_tables(c, P))) return rc;
-        // (not with spatialiser stages: their 64-frame history goes from the LAST block of a call to the first block of the next through
-        //  the ext pool — written by the render kernel, copied to `d_hist` by the control kernel of the next call, which in this mode
-        //  would run beside that render kernel.  Found by the graph fuzz at seeds beyond the suite's 80: 91, 196, 384.)
-        if (c->ctl_ahead && c->ctl_stream && !P.fused_fx && !P.fused_sp && fb.tail_nodes.empty() && K > 1) {
+        // (spatialiser stages: their 64-frame history goes from the LAST block of a call to the first block of the next through the ext
+        //  pool; in this mode the copy into the call's scratch is made on the render stream — k_sp_hist_copy — because the control
+        //  kernel runs beside the render kernel that writes it.  A race until the graph fuzz found it at seeds 91, 196, 384.)
+        if (c->ctl_ahead && c->ctl_stream && !P.fused_fx && fb.tail_nodes.empty() && K > 1) {
             // the second copy of what the control kernel writes and the render kernels read
             bool ok = P.d_blks2.ensure_n("d_blks2", K * P.n_voices * sizeof(VoiceBlk)) == hipSuccess &&
                       P.d_refs2.ensure_n("d_refs2", ref_count(P.n_voices, K) * sizeof(VoiceRef)) == hipSuccess &&

@@ -294,6 +294,7 @@ static void fill_fused_view(fwgpu_ctx* c, FusedView& fv) {
     fv.has_sp = c->fused_sp ? 1 : 0;
     fv.rs_wl = c->d_rs_wl.as<unsigned int>();
     fv.ctl_order = c->ctl_order_live ? c->d_ctl_order.as<int>() : nullptr;
+    fv.sp_hist_in_render = (c->ahead_this_call && c->fused_sp) ? 1 : 0;
     fv.hist = c->d_hist.as<float>();
     fv.n_gain_stages = c->ramp_slots / 2;
     fv.ramps = c->d_ramps.as<float>();
@@ -570,6 +571,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         timer_end(c, e1);
     }
     timer_begin(c, 0, &e0, &e1);
+    if (fv.sp_hist_in_render) LCHK(c, launch_sp_hist_copy(c->stream, fv));
     if (c->fused_fx) LCHK(c, launch_chain(c->stream, fv, K, cmd_block0, c->chain_nq));
     else LCHK(c, launch_leaf_sum(c->stream, fv, K));
     timer_end(c, e1);

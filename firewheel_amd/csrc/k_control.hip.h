@@ -543,7 +543,9 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
     const int sp_j = vd.n_stages - 1;  // (the spatialiser is the last stage)
     int sp_dl = 0, sp_dr = 0;
     if (spv) {
-        fv.hist[(size_t)vi * SP_HIST + lane] = fv.ext[(size_t)vd.sp_ext_off + lane];
+        // (control-ahead mode: this kernel runs beside the render kernel of the call BEFORE, which writes the pool at its end — the
+        //  copy is then made on the render stream, right in front of this call's leaf kernel: k_sp_hist_copy)
+        if (!fv.sp_hist_in_render) fv.hist[(size_t)vi * SP_HIST + lane] = fv.ext[(size_t)vd.sp_ext_off + lane];
         const NodeState* sn = &fv.states[vd.stage_state[sp_j]];
         sp_dl = sn->playing;
         sp_dr = sn->has_loop;

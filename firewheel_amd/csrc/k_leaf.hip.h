@@ -1487,6 +1487,16 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, 3) void k_leaf_sum_wl(FusedView fv,
     }
 }
 
+// control-ahead mode, plans with spatialiser stages: the histories the voices enter this call with, from the ext pool into the call's
+// scratch, on the RENDER stream (behind the render kernels of the call before, in front of this call's leaf kernel)
+__global__ __launch_bounds__(256) void k_sp_hist_copy(FusedView fv) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = idx / SP_HIST, i = idx % SP_HIST;
+    if (v >= fv.n_voices) return;
+    const int off = fv.voices[v].sp_ext_off;
+    if (off >= 0) fv.hist[(size_t)v * SP_HIST + i] = fv.ext[(size_t)off + i];
+}
+
 // Upper sum tree of the fused plan, K-batched: SumNode semantics (nodes/sum.rs:41-136) with one THREAD per
 // frame (blockIdx = node, block, channel) so that a 1-node level still puts K * n_out * frames/64 waves in flight.
 __global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restrict__ level_nodes) {

@@ -469,6 +469,15 @@ int launch_rt_persist(hipStream_t s, const FusedView& fv, const DevView& upv, co
     d_mb->alive = 0;
     return rc;
 }
+int launch_sp_hist_copy(hipStream_t, const FusedView& fv) {
+    REQUIRE(fv.has_sp && fv.sp_hist_in_render && fv.hist != nullptr, fv.has_sp);
+    for (int v = 0; v < fv.n_voices; ++v)
+        if (fv.voices[v].sp_ext_off >= 0) {
+            touch(fv.ext + fv.voices[v].sp_ext_off, sizeof(float) * SP_HIST);
+            touch(fv.hist + (size_t)v * SP_HIST, sizeof(float) * SP_HIST);
+        }
+    return 0;
+}
 int launch_leaf_sum(hipStream_t, const FusedView& fv, int K) {
     g_launches[2]++;
     check_fused_common(fv, K);

@@ -82,20 +82,30 @@ typedef struct {
     volatile int editing; /* set by the editor while an edit (remove .. update .. start) is in flight */
     double* t_us;         /* per callback */
     unsigned char* tag;   /* 1 = an edit was in flight when the callback started */
+    unsigned char* phase; /* the library's update phase when the callback started (diagnostics) */
     long n, cap;
 } Audio;
+static double g_period_us = 0.0;
 static void* audio_main(void* arg) {
     Audio* a = (Audio*)arg;
     float* out = (float*)malloc(sizeof(float) * 2 * g_block);
     double stream_time = 0.0;
+    double next = now_us();
     while (!a->stop && a->n < a->cap) {
+        if (g_period_us > 0) { /* a paced stream: the callback of a device with this period (0: back to back, the stress case) */
+            next += g_period_us;
+            while (now_us() < next) {
+            }
+        }
         const int tag = a->editing;
+        const int ph = fwgpu_update_phase(g_cx);
         const double t0 = now_us();
         long long rc = fwgpu_process_interleaved(g_cx, NULL, out, 0, 2, g_block, stream_time, 0);
         const double t1 = now_us();
         if (rc < 0) die(g_cx, "fwgpu_process_interleaved", rc);
         a->t_us[a->n] = t1 - t0;
         a->tag[a->n] = (unsigned char)tag;
+        a->phase[a->n] = (unsigned char)ph;
         a->n++;
         stream_time += g_block / 48000.0;
     }
@@ -116,10 +126,11 @@ static void stats(const double* t, const unsigned char* tag, long n, int want, d
 }
 
 int main(int argc, char** argv) {
-    if (argc != 5) {
-        fprintf(stderr, "usage: fw_edit_race <voices> <block_frames> <steady_callbacks> <edits>\n");
+    if (argc != 5 && argc != 6) {
+        fprintf(stderr, "usage: fw_edit_race <voices> <block_frames> <steady_callbacks> <edits> [callback_period_us]\n");
         return 2;
     }
+    if (argc == 6) g_period_us = atof(argv[5]);
     g_voices = atoi(argv[1]);
     g_block = (uint32_t)atoi(argv[2]);
     const long steady = atol(argv[3]);
@@ -175,6 +186,7 @@ int main(int argc, char** argv) {
     a.cap = steady + (long)edits * 400 + 4000;
     a.t_us = (double*)malloc(sizeof(double) * (size_t)a.cap);
     a.tag = (unsigned char*)malloc((size_t)a.cap);
+    a.phase = (unsigned char*)calloc((size_t)a.cap, 1);
     pthread_t th;
     pthread_create(&th, NULL, audio_main, &a);
     while (a.n < steady) { /* phase 1: nobody edits */
@@ -218,15 +230,21 @@ int main(int argc, char** argv) {
     double m2, p2, x2;
     long c2;
     stats(a.t_us, a.tag, a.n, 2, &m2, &p2, &x2, &c2);
+    for (int ph = 0; ph <= 40; ++ph) { /* diagnostics on stderr: the callbacks by what the updating thread was doing when they began */
+        double md, p9, mx;
+        long cn;
+        stats(a.t_us, a.phase, a.n, ph, &md, &p9, &mx, &cn);
+        if (cn) fprintf(stderr, "update phase %d: %ld callbacks, median %.1f p99 %.1f max %.1f us\n", ph, cn, md, p9, mx);
+    }
     uint64_t adoptions = 0, by_audio = 0, worst_ns = 0;
     CK(fwgpu_plan_handover_stats(g_cx, &adoptions, &by_audio, &worst_ns));
-    printf("{\"voices\": %d, \"block\": %u, \"launch_plan\": %d, \"callbacks\": %ld, \"edits\": %d, \"first_update_ms\": %.2f, "
+    printf("{\"voices\": %d, \"block\": %u, \"launch_plan\": %d, \"callbacks\": %ld, \"edits\": %d, \"callback_period_us\": %.0f, \"first_update_ms\": %.2f, "
            "\"update_ms_mean\": %.3f, \"update_ms_max\": %.3f, "
            "\"callback_us_steady\": {\"n\": %ld, \"median\": %.1f, \"p99\": %.1f, \"max\": %.1f}, "
            "\"callback_us_while_the_plan_is_built\": {\"n\": %ld, \"median\": %.1f, \"p99\": %.1f, \"max\": %.1f}, "
            "\"callback_us_adoption_and_the_two_after\": {\"n\": %ld, \"median\": %.1f, \"p99\": %.1f, \"max\": %.1f}, "
            "\"plans_adopted\": %llu, \"adopted_by_a_callback\": %llu, \"longest_adoption_us\": %.1f}\n",
-           g_voices, g_block, plan, a.n, edits, first_update_us / 1e3, edits ? upd_sum / edits / 1e3 : 0.0, upd_max / 1e3, c0, m0, p0, x0, c1, m1, p1,
+           g_voices, g_block, plan, a.n, edits, g_period_us, first_update_us / 1e3, edits ? upd_sum / edits / 1e3 : 0.0, upd_max / 1e3, c0, m0, p0, x0, c1, m1, p1,
            x1, c2, m2, p2, x2, (unsigned long long)adoptions, (unsigned long long)by_audio, worst_ns / 1e3);
     fwgpu_ctx_destroy(g_cx);
     return 0;

@@ -208,6 +208,8 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
     }
     if (const char* e = getenv("FWGPU_RT_PERSIST")) c->rt_persist = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_IDLE_MS")) c->rt_idle_ms = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("FWGPU_QUIET_WAIT_US")) c->quiet_wait_us = (uint32_t)std::max(0, atoi(e));
+    if (const char* e = getenv("FWGPU_UP_PIECE")) c->up_piece = (uint32_t)std::max(4096, atoi(e));
     if (c->rt_persist && c->h_rt_flag) {  // mailbox in pinned, device-mapped host memory + the kernel's own (non-blocking) stream
         bool ok = hipHostMalloc((void**)&c->h_rt_mb, sizeof(RtMailbox), hipHostMallocMapped) == hipSuccess &&
                   hipHostGetDevicePointer((void**)&c->d_rt_mb, c->h_rt_mb, 0) == hipSuccess;
@@ -403,15 +405,27 @@ int fwgpu_plan_host_nodes(fwgpu_ctx* c, uint64_t* callbacks_run) {
     return c->info.have_plan ? c->info.n_host_nodes : -1;
 }
 
+// which part of fwgpu_update the control thread is in (include/fwgpu.h): read by any thread, written by the updating one
+int fwgpu_update_phase(fwgpu_ctx* c) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    return c->update_phase.load(std::memory_order_relaxed);
+}
 int fwgpu_update(fwgpu_ctx* c) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     use_device(c);
     if (!c->graph.needs_compile && c->info.have_plan) return 0;
     Plan plan;
     std::string err;
+    c->update_phase = 1;
     int rc = c->graph.build_plan(plan, err);
-    if (rc) return fail(c, rc, err);
-    return install_plan(c, plan);
+    if (rc) {
+        c->update_phase = 0;
+        return fail(c, rc, err);
+    }
+    c->update_phase = 2;
+    rc = install_plan(c, plan);
+    c->update_phase = 0;
+    return rc;
 }
 
 int fwgpu_schedule_upload(fwgpu_ctx* c, const fwgpu_sched_node* sn, uint32_t n_nodes, uint32_t num_buffers) {

@@ -393,6 +393,11 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     // control side: pinned staging arena of the plan build's uploads (fwgpu_plan_install.cpp `up`)
     char* h_up = nullptr;
     size_t h_up_cap = 0, h_up_used = 0;
+    // the build's GPU work goes out in pieces, each in a window with no process call in flight (fwgpu_plan_install.cpp, quiet_window):
+    // how long a piece waits for such a window (0 = the old behaviour: everything at once), and the size of an upload piece
+    std::atomic<int> update_phase{0};  // fwgpu_update_phase: 0 none, 1 graph compile, 21..28 the sections of build_image, 3 waiting for the uploads
+    uint32_t quiet_wait_us = 100;   // FWGPU_QUIET_WAIT_US
+    uint32_t up_piece = 128u << 10; // FWGPU_UP_PIECE (bytes)
     bool rt_persist = true;        // FWGPU_RT_PERSIST=0: every callback is its own launch (k_rt_block)
     uint32_t rt_idle_ms = 20;      // its watchdog: no doorbell for this long and it ends by itself (FWGPU_RT_IDLE_MS)
     RtMailbox *h_rt_mb = nullptr, *d_rt_mb = nullptr;

@@ -202,6 +202,11 @@ int launch_host_scatter(hipStream_t s, float* pool, uint8_t* flags, int stride, 
                        d_bufs, frames, row_pitch, d_stage, d_stage_flags);
     return (int)hipGetLastError();
 }
+int launch_zero_rows(hipStream_t s, float* p, size_t pitch, int width, int rows) {
+    if (rows <= 0 || width <= 0) return 0;
+    hipLaunchKernelGGL(k_zero_rows, dim3(rows < 1024 ? rows : 1024), dim3(256), 0, s, p, pitch, width, rows);
+    return (int)hipGetLastError();
+}
 int launch_adopt_init(hipStream_t s, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits,
                       const CarryArgs& carry) {
     if (n_jobs <= 0 && n_inits <= 0 && carry.n_new <= 0) return 0;

@@ -154,6 +154,7 @@ struct AdoptExtJobHost {
     uint32_t off, zero_len, n_head, pad;
     float head[8];
 };
+int launch_zero_rows(hipStream_t s, float* p, size_t pitch, int width, int rows);
 int launch_adopt_init(hipStream_t s, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits,
                       const CarryArgs& carry);
 // per (block, channel) of a batch: was that graph-output channel flagged silent (mode: see k_out_flags)

@@ -21,6 +21,28 @@ namespace fwgpu {
 //  asynchronous HIP call; the ~30 pageable copies with a blocking sync each that a build used to make held the runtime's locks long
 //  enough to hold up the audio thread's launch calls: callbacks while editing p99 214 us -> see profiles/r03_edit_race_cfg3.json.
 //  build_image waits for the stream once, at its end.)
+// (round 3, late: what reaches the callbacks while a plan is built is the DEVICE side of these copies and fills — blit / fill kernels
+//  on the build's stream; while one runs, the audio stream's kernels finish late (a 1-thread k_signal_done took 45-65 us next to a 50 us
+//  copy in the rocprofv3 trace; fw_edit_race's phase tags: nothing during the graph compile, 2-3x callbacks from the first upload on).
+//  Fewer CUs for the build's stream made it worse (p99 250 -> 325 us: the harm grows with how LONG the build's kernels run beside
+//  the audio ones), cutting the copies into pieces that still ran back to back changed nothing.  What helps is TIME: the build's GPU
+//  work goes out in pieces of a few microseconds, each issued when no process call is in flight (the gate word says so) and waited
+//  for before the next — a callback meets at most the piece that was issued just before it began.  With the audio side saturated
+//  (callbacks back to back, the stress of fw_edit_race) a piece goes out anyway after quiet_wait_us.)
+static void quiet_window(fwgpu_ctx* c) {
+    if (!c->quiet_wait_us) return;
+    if (c->gate.load(std::memory_order_acquire) != 1) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int i = 0; i < 64; ++i) {
+            if (c->gate.load(std::memory_order_acquire) != 1) return;
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(c->quiet_wait_us)) return;
+    }
+}
 static int up(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes) {
     HIPC(c, b.ensure_n("b", bytes));
     if (!bytes) return 0;
@@ -38,16 +60,23 @@ static int up(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes) {
         }
     }
     memcpy(c->h_up + c->h_up_used, src, bytes);
-    // (what still reaches the callbacks while a plan is built — profiles/r03_edit_race_cfg3.json: p99 +150 us — is the device side of
-    //  these copies and of the pool fills: on this stack they are blit / fill KERNELS on the build's stream, and while one runs the
-    //  audio stream's kernels finish late (a 1-thread k_signal_done took 45-65 us next to a 50 us copy in the rocprofv3 trace).
-    //  Cutting them into 32 KiB .. 1 MiB pieces changed nothing but the build time)
-    HIPC(c, hipMemcpyAsync(b.p, c->h_up + c->h_up_used, bytes, hipMemcpyHostToDevice, c->up_stream));
+    const size_t piece = c->quiet_wait_us ? c->up_piece : bytes;
+    for (size_t off = 0; off < bytes; off += piece) {
+        const size_t n = std::min(piece, bytes - off);
+        quiet_window(c);
+        HIPC(c, hipMemcpyAsync((char*)b.p + off, c->h_up + c->h_up_used + off, n, hipMemcpyHostToDevice, c->up_stream));
+        if (c->quiet_wait_us) HIPC(c, hipStreamSynchronize(c->up_stream));
+    }
     c->h_up_used += need;
     return 0;
 }
 static int zero(fwgpu_ctx* c, void* p, size_t bytes) {
-    if (bytes) HIPC(c, hipMemsetAsync(p, 0, bytes, c->up_stream));
+    const size_t piece = c->quiet_wait_us ? (size_t)c->up_piece * 32 : bytes;  // (a fill runs ~30x faster than a copy over PCIe)
+    for (size_t off = 0; off < bytes; off += piece) {
+        quiet_window(c);
+        HIPC(c, hipMemsetAsync((char*)p + off, 0, std::min(piece, bytes - off), c->up_stream));
+        if (c->quiet_wait_us) HIPC(c, hipStreamSynchronize(c->up_stream));
+    }
     return 0;
 }
 
@@ -211,6 +240,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
     reset_for_build(P);
     P.kmax = c->kmax_req;
     P.gen = ++c->build_gen;
+    c->update_phase = 21;
     // 1. node state capacity (persists across recompiles: processor.rs:19,195-197): a larger array is allocated here and
     //    swapped in — old contents copied over on the ctx stream — when the image is adopted
     {
@@ -229,6 +259,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             P.grow_slot_ids.assign(cap, -1);
         }
     }
+    c->update_phase = 22;
     // 2. activate new nodes (graph.rs:594-612): their initial states and ext-pool slices are worked out here and applied at
     //    adoption (scatter kernels on the ctx stream), never written into live buffers from this thread
     struct Act {
@@ -369,6 +400,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             hb.leaves[sp.leaf].out_buf = plan.num_buffers;
             plan.num_buffers += 2;
         }
+    c->update_phase = 23;
     // 3. node tables
     const int N = (int)plan.nodes.size();
     std::vector<NodeDesc> nd(N);
@@ -437,6 +469,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
     if (gout_bufs.empty()) gout_bufs.push_back(0);
     if ((rc = up(c, P.d_gin_bufs, gin_bufs.data(), gin_bufs.size() * sizeof(int)))) return rc;
     if ((rc = up(c, P.d_gout_bufs, gout_bufs.data(), gout_bufs.size() * sizeof(int)))) return rc;
+    c->update_phase = 24;
     // 3c. host nodes (K_HOST): per level, what the audio side needs to call them — and one pinned, device-mapped staging area
     //     for their inputs and outputs of a whole K-batch, allocated here (a process call never allocates)
     {
@@ -484,6 +517,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         P.host_in_ptrs.assign(max_in, nullptr);
         P.host_out_ptrs.assign(max_out, nullptr);
     }
+    c->update_phase = 25;
     // 3b. FIR banks: one GEMM per (level, impulse-response channel)
     {
         std::map<std::tuple<int, uint32_t, uint32_t>, std::vector<FirRow>> groups;
@@ -541,6 +575,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             HIPC(c, P.d_fir_partials.ensure_n("d_fir_partials", partial_need * sizeof(float)));
         }
     }
+    c->update_phase = 26;
     // 4. buffer pool: a new schedule starts from zeroed buffers (schedule.rs:202-203); one slice per block of a
     //    generic K-batch.  generic_k: the FIR history rings were sized for the batch size in force when their node was
     //    activated — a later, larger kmax must not outrun them.
@@ -555,15 +590,18 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         const size_t Kg = P.generic_k;
         size_t pool_bytes = Kg * (size_t)plan.num_buffers * c->stride * sizeof(float);
         HIPC(c, P.d_pool.ensure_n("d_pool", pool_bytes));
-        // (cleared per build: for config 3 a 0.5 GB fill.  Clearing only buffer 0 — the constant-zero buffer; every other one is written
-        //  before it is read, the GPU suite passes under FWGPU_POISON that way — did not change what the callbacks see while a plan is
-        //  built, so the simple, obviously safe form stays)
-        if ((rc = zero(c, P.d_pool.p, pool_bytes))) return rc;
+        // buffer 0 of every block is the constant-zero buffer (flagged silent below) and has to BE zero; every other buffer is written
+        // by the node that owns it before anybody reads it (the level order) — the GPU suite passes with FWGPU_POISON=1 filling
+        // fresh pools with 0xCB.  So only those rows are cleared: the whole pool was a 0.5 GB fill per build on config 3, ~100 us of
+        // fill kernel during which the callbacks that ran beside the build took 2-3x as long (fw_edit_race's phase tags).
+        quiet_window(c);
+        if (plan.num_buffers > 0) LCHK(c, launch_zero_rows(c->up_stream, P.d_pool.as<float>(), (size_t)plan.num_buffers * c->stride, c->stride, (int)Kg));
         std::vector<uint8_t> fl(Kg * (size_t)plan.num_buffers, 0);
         for (size_t k = 0; k < Kg; ++k) fl[k * (size_t)plan.num_buffers] = 1;  // buffer 0: constant zero, always flagged silent
         if ((rc = up(c, P.d_flags, fl.data(), fl.size()))) return rc;
     }
 
+    c->update_phase = 27;
     // 5. fused voice-bank plan
     P.fused = false;
     P.hybrid = false;
@@ -665,6 +703,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         P.n_fused_real = 0;
         for (const VoiceDesc& vd : fb.voices) P.n_fused_real += vd.sampler_state >= 0 ? 1 : 0;
     }
+    c->update_phase = 28;
     // 5b. hybrid plan: not a fused shape as a whole, but with voice banks inside that the fused kernels render
     // straight into their mixers' pool buffers; the level executor then runs the rest.
     P.hybrid_fx = false;
@@ -732,7 +771,9 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         if (plan.nodes[i].slot < P.slot_index.size()) P.slot_index[plan.nodes[i].slot] = i;
     P.plan = plan;
     P.have_plan = true;
+    c->update_phase = 3;
     HIPC(c, hipStreamSynchronize(c->up_stream));  // every table and every zeroed pool of the image is in place
+    c->update_phase = 4;
     c->h_up_used = 0;
     // ---- commit the control side's own bookkeeping: from here on the image WILL be adopted
     for (const Act& a : acts) {
@@ -942,7 +983,9 @@ static void publish(fwgpu_ctx* c, PlanImage* img) {
 // fwgpu_update / fwgpu_schedule_upload: build off to the side, publish.  A failure leaves the active plan (and a pending one)
 // exactly as they were, like the reference keeps its schedule when a compile fails (context.rs:115-131).
 int install_plan(fwgpu_ctx* c, Plan& plan) {
-    if (!c->up_stream) {  // the build's uploads and memsets: lowest priority, so that they give way to the audio stream's kernels
+    if (!c->up_stream) {  // the build's uploads and memsets: lowest priority.  (A stream restricted to 16 CUs — hipExtStreamCreateWithCUMask —
+                          // made the callbacks beside a build SLOWER, p99 250 -> 325 us: what costs them is how LONG the build's
+                          // copy / fill kernels run next to them, not how many CUs those take.)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, lo) != hipSuccess) {

@@ -297,6 +297,11 @@ struct AdoptExtJob {
     float head[8];
 };
 static_assert(sizeof(AdoptExtJob) == 48, "AdoptExtJob layout");
+// plan build: `rows` rows of `width` floats, `pitch` floats apart, cleared (the constant-zero buffer of every block's pool slice)
+__global__ __launch_bounds__(256) void k_zero_rows(float* __restrict__ p, size_t pitch, int width, int rows) {
+    for (int r = blockIdx.x; r < rows; r += gridDim.x)
+        for (int i = threadIdx.x; i < width; i += blockDim.x) p[(size_t)r * pitch + i] = 0.f;
+}
 // Plan adoption: a voice whose chain is the same nodes in the new plan as in the old one keeps its steady cache (VoiceCache: "ended
 // the last call steady" + the descriptor its blocks share), re-stamped with the new epoch.  Without this every voice of the graph
 // runs its full state machines in the first callback after ANY edit — 50-100 us more for that callback on configs 2 and 3

@@ -171,6 +171,11 @@ int fwgpu_plan_chain_stats(fwgpu_ctx* ctx, uint64_t* steady_workgroups, uint64_t
  * adopted so far, *audio_adoptions = those a process call adopted, *max_adopt_ns = the longest one of THOSE held up its process
  * call (host nanoseconds).  Any pointer may be NULL. */
 int fwgpu_plan_handover_stats(fwgpu_ctx* ctx, uint64_t* adoptions, uint64_t* audio_adoptions, uint64_t* max_adopt_ns);
+/* Diagnostics for the same hand-over: which part of fwgpu_update / fwgpu_schedule_upload the control thread is in right now —
+ * 0 none, 1 compiling the graph (host only: graph/compiler.rs), 21..28 the sections of the plan build that upload tables
+ * (23 node tables, 26 buffer pool, 27 voice tables, 28 staging areas), 3 waiting for the last upload.  Any thread may ask;
+ * examples/host_c/fw_edit_race.c tags every callback with it to say WHEN a build reaches the audio side. */
+int fwgpu_update_phase(fwgpu_ctx* ctx);
 /* Realtime edge, resident kernel (cpal/lib.rs:378-449: a backend thread that is woken per block, never torn down between blocks).
  * The first steady one-block fwgpu_process_interleaved call of a run of them — voice-bank plan, stereo stream, no message pending —
  * launches a kernel that stays resident and is handed every following callback through a doorbell word in pinned host memory: no

@@ -9,5 +9,7 @@ bash scripts/prof_sq.sh rs --rs-source > gpurun_out/profiles/r03_cfg2_rs_sq_coun
 bash scripts/prof_sq.sh spatial --voice-spatial > gpurun_out/profiles/r03_cfg2_spatial_sq_counters.txt 2>&1
 python bench.py > gpurun_out/profiles/r03_bench_line_full.json 2> gpurun_out/bench_full.err
 python bench.py --gpus 2 --share-device > gpurun_out/profiles/r03_n2_virtual_ranks_one_device_line.json 2> gpurun_out/bench_n2.err
-make -C examples/host_c > /dev/null 2>&1 && ./examples/host_c/fw_edit_race 4096 512 300 30 > gpurun_out/profiles/r03_edit_race_cfg3.json 2> gpurun_out/edit_race.err
+make -C examples/host_c > /dev/null 2>&1 && ./examples/host_c/fw_edit_race 4096 512 300 30 > gpurun_out/profiles/r03_edit_race_cfg3.json 2> gpurun_out/profiles/r03_edit_race_cfg3_by_update_phase.txt
+./examples/host_c/fw_edit_race 4096 512 300 30 1000 > gpurun_out/profiles/r03_edit_race_cfg3_paced_1ms.json 2> /dev/null
+FWGPU_QUIET_WAIT_US=0 ./examples/host_c/fw_edit_race 4096 512 300 30 > gpurun_out/profiles/r03_edit_race_cfg3_all_at_once.json 2> /dev/null
 ls -la gpurun_out/profiles

@@ -41,7 +41,7 @@ void violation(const char* what, long a = 0, long b = 0) {
     do {                   \
         if (!(cond)) violation(#cond, ##__VA_ARGS__); \
     } while (0)
-volatile unsigned char g_sink;
+thread_local volatile unsigned char g_sink;  // (per thread: the build thread touches too — launch_zero_rows)
 void touch(const void* p, size_t bytes) {
     if (!bytes) return;
     if (!p) {
@@ -379,6 +379,13 @@ int launch_host_scatter(hipStream_t, float* pool, uint8_t* flags, int stride, si
     }
     touch(d_stage, sizeof(float) * (((size_t)(K - 1) * row_pitch + (n - 1)) * stride + frames));
     touch(d_stage_flags, (size_t)(K - 1) * row_pitch + n);
+    return 0;
+}
+int launch_zero_rows(hipStream_t, float* p, size_t pitch, int width, int rows) {
+    for (int r = 0; r < rows; ++r) {
+        touch(p + (size_t)r * pitch, sizeof(float) * (size_t)width);
+        for (int i = 0; i < width; ++i) p[(size_t)r * pitch + i] = 0.f;
+    }
     return 0;
 }
 static int check_carry(const CarryArgs& a) {

@@ -571,7 +571,13 @@ static int sample_add(fwgpu_ctx* c, int format, uint32_t channels, uint64_t fram
         r.owned = true;
         HIPC(c, hipMalloc(&r.d_data, bytes + 256));  // slack: a wave's last dwordx4 may overhang the data
         hipError_t e = hipMemset((char*)r.d_data + bytes, 0, 256);
-        if (e == hipSuccess && bytes) e = hipMemcpy(r.d_data, data, bytes, hipMemcpyHostToDevice);
+        // (like a plan build's uploads — fwgpu_plan_install.cpp, quiet_window —: in pieces, each when no process call is in flight)
+        const bool live = audio_live(c);
+        const size_t piece = live ? c->up_piece : (bytes ? bytes : 1);
+        for (size_t off = 0; e == hipSuccess && off < bytes; off += piece) {
+            if (live) quiet_window(c);
+            e = hipMemcpy((char*)r.d_data + off, (const char*)data + off, std::min(piece, bytes - off), hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess) {
             (void)hipFree(r.d_data);
             return hipfail(c, e, "sample upload");

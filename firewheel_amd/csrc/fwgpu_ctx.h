@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <map>
 #include <string>
@@ -396,6 +397,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     // the build's GPU work goes out in pieces, each in a window with no process call in flight (fwgpu_plan_install.cpp, quiet_window):
     // how long a piece waits for such a window (0 = the old behaviour: everything at once), and the size of an upload piece
     std::atomic<int> update_phase{0};  // fwgpu_update_phase: 0 none, 1 graph compile, 21..28 the sections of build_image, 3 waiting for the uploads
+    std::atomic<uint64_t> last_audio_ns{0};  // steady_clock at the end of the last process call (0: none yet)
     uint32_t quiet_wait_us = 100;   // FWGPU_QUIET_WAIT_US
     uint32_t up_piece = 128u << 10; // FWGPU_UP_PIECE (bytes)
     bool rt_persist = true;        // FWGPU_RT_PERSIST=0: every callback is its own launch (k_rt_block)
@@ -526,7 +528,11 @@ struct AudioGate {
         }
         if (PlanImage* img = c->pending.exchange(nullptr, std::memory_order_acq_rel)) adopt_image(c, img, true);
     }
-    ~AudioGate() { c->gate.store(0, std::memory_order_release); }
+    ~AudioGate() {
+        // when the audio side last ran (quiet_window: a control thread cuts its GPU work into pieces only while a stream is live)
+        c->last_audio_ns.store((uint64_t)std::chrono::steady_clock::now().time_since_epoch().count(), std::memory_order_relaxed);
+        c->gate.store(0, std::memory_order_release);
+    }
 };
 // The control-side calls that change what a process call reads OUTSIDE a plan image — the sample table, max_batch /
 // force_generic — take the gate exclusively for the few microseconds of the change (the expensive part, uploading sample
@@ -543,6 +549,19 @@ struct ControlGate {
     }
     ~ControlGate() { c->gate.store(0, std::memory_order_release); }
 };
+
+// ---- fwgpu_plan_install.cpp
+// control side, before a piece of GPU work that is not the audio path's: returns when no process call is in flight, or after
+// c->quiet_wait_us
+void quiet_window(fwgpu_ctx* c);
+// is a stream live (a process call within the last 200 ms)?  If not, the control side's GPU work goes out whole.
+inline bool audio_live(const fwgpu_ctx* c) {
+    if (!c->quiet_wait_us) return false;
+    if (c->gate.load(std::memory_order_relaxed) == 1) return true;
+    const uint64_t last = c->last_audio_ns.load(std::memory_order_relaxed);
+    if (!last) return false;
+    return (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() - last < 200000000ull;
+}
 
 // ---- fwgpu_run.cpp
 int upload(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes);

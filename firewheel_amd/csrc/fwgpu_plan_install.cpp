@@ -28,8 +28,9 @@ namespace fwgpu {
 //  the audio ones), cutting the copies into pieces that still ran back to back changed nothing.  What helps is TIME: the build's GPU
 //  work goes out in pieces of a few microseconds, each issued when no process call is in flight (the gate word says so) and waited
 //  for before the next — a callback meets at most the piece that was issued just before it began.  With the audio side saturated
-//  (callbacks back to back, the stress of fw_edit_race) a piece goes out anyway after quiet_wait_us.)
-static void quiet_window(fwgpu_ctx* c) {
+//  (callbacks back to back, the stress of fw_edit_race) a piece goes out anyway after quiet_wait_us.  With no stream live — no process
+//  call in the last 200 ms: single-threaded hosts, set-up — everything goes out whole as before.)
+void quiet_window(fwgpu_ctx* c) {
     if (!c->quiet_wait_us) return;
     if (c->gate.load(std::memory_order_acquire) != 1) return;
     const auto t0 = std::chrono::steady_clock::now();
@@ -60,22 +61,24 @@ static int up(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes) {
         }
     }
     memcpy(c->h_up + c->h_up_used, src, bytes);
-    const size_t piece = c->quiet_wait_us ? c->up_piece : bytes;
+    const bool live = audio_live(c);
+    const size_t piece = live ? c->up_piece : bytes;
     for (size_t off = 0; off < bytes; off += piece) {
         const size_t n = std::min(piece, bytes - off);
-        quiet_window(c);
+        if (live) quiet_window(c);
         HIPC(c, hipMemcpyAsync((char*)b.p + off, c->h_up + c->h_up_used + off, n, hipMemcpyHostToDevice, c->up_stream));
-        if (c->quiet_wait_us) HIPC(c, hipStreamSynchronize(c->up_stream));
+        if (live) HIPC(c, hipStreamSynchronize(c->up_stream));
     }
     c->h_up_used += need;
     return 0;
 }
 static int zero(fwgpu_ctx* c, void* p, size_t bytes) {
-    const size_t piece = c->quiet_wait_us ? (size_t)c->up_piece * 32 : bytes;  // (a fill runs ~30x faster than a copy over PCIe)
+    const bool live = audio_live(c);
+    const size_t piece = live ? (size_t)c->up_piece * 32 : bytes;  // (a fill runs ~30x faster than a copy over PCIe)
     for (size_t off = 0; off < bytes; off += piece) {
-        quiet_window(c);
+        if (live) quiet_window(c);
         HIPC(c, hipMemsetAsync((char*)p + off, 0, std::min(piece, bytes - off), c->up_stream));
-        if (c->quiet_wait_us) HIPC(c, hipStreamSynchronize(c->up_stream));
+        if (live) HIPC(c, hipStreamSynchronize(c->up_stream));
     }
     return 0;
 }

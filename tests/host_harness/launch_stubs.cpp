@@ -8,6 +8,15 @@ unsigned long long g_cmds_applied = 0;
 unsigned long long g_ctl_orders = 0;  // control launches that carried a dispatch order (FusedView::ctl_order)
 }
 extern "C" unsigned long long fwh_cmds_seen(void) { return g_cmds_applied; }
+extern "C" {
+unsigned long long fwh_h2d_copies = 0, fwh_h2d_max_bytes = 0;  // (fakehip's hipMemcpyAsync counts)
+}
+extern "C" void fwh_h2d_reset(void) {
+    __atomic_store_n(&fwh_h2d_copies, 0ull, __ATOMIC_RELAXED);
+    __atomic_store_n(&fwh_h2d_max_bytes, 0ull, __ATOMIC_RELAXED);
+}
+extern "C" unsigned long long fwh_h2d_count(void) { return __atomic_load_n(&fwh_h2d_copies, __ATOMIC_RELAXED); }
+extern "C" unsigned long long fwh_h2d_max(void) { return __atomic_load_n(&fwh_h2d_max_bytes, __ATOMIC_RELAXED); }
 extern "C" unsigned long long fwh_ctl_orders(void) { return g_ctl_orders; }
 extern "C" {
 unsigned long long fwh_alloc_calls = 0;  // hipMalloc / hipHostMalloc calls of the fake runtime

@@ -456,3 +456,41 @@ def test_control_dispatch_order_and_cache_carry_on_the_host_side():
     e.set_param(voices[6]["volume"], 0, 70.0)
     e.process_blocks(3)
     assert e.violation() == "", e.violation()
+
+
+def test_plan_builds_go_out_in_pieces_only_while_a_stream_is_live():
+    """round 3, host half (fwgpu_plan_install.cpp, quiet_window / audio_live): a build with no process call in the last 200 ms
+    uploads every table whole; a build right after a process call cuts its uploads into pieces of at most FWGPU_UP_PIECE bytes
+    (128 KiB), each issued when the gate word says no process call is in flight.  The fake HIP counts the asynchronous
+    host-to-device copies and remembers the largest."""
+    import ctypes as C
+    import time
+
+    from fwapi import HostOnlyEngine, hostonly_lib
+
+    L = hostonly_lib()
+    for f in (L.fwh_h2d_count, L.fwh_h2d_max):
+        f.restype = C.c_ulonglong
+    e = HostOnlyEngine(max_block_frames=256, max_batch=8)
+    L.fwh_h2d_reset()
+    voices = scenarios.build_voice_bank(e, 3000, radix=32, src_frames=600)   # (build_voice_bank ends in update(): no stream yet)
+    whole_n, whole_max = L.fwh_h2d_count(), L.fwh_h2d_max()
+    assert whole_max > 128 * 1024, whole_max                                 # some table of 3 000 voices is larger than a piece
+    for vc in voices[:8]:
+        e.sampler_play(vc["sampler"])
+    e.process_blocks(2)                                                       # a stream is live now
+    x = e.volume(40.0)
+    e.remove_node(x)
+    L.fwh_h2d_reset()
+    e.update()                                                                # the same tables again, within 200 ms of the call
+    live_n, live_max = L.fwh_h2d_count(), L.fwh_h2d_max()
+    assert live_max <= 128 * 1024, live_max
+    assert live_n > whole_n, (live_n, whole_n)
+    time.sleep(0.35)                                                          # the stream has gone quiet: whole again
+    x = e.volume(41.0)
+    e.remove_node(x)
+    L.fwh_h2d_reset()
+    e.update()
+    assert L.fwh_h2d_max() > 128 * 1024, L.fwh_h2d_max()                      # (the first build also carried the new nodes' states)
+    e.process_blocks(1)
+    assert e.violation() == "", e.violation()

@@ -32,20 +32,26 @@ namespace fwgpu {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    // host copy of what a plan build last uploaded here (fwgpu_plan_install.cpp, up()): only for tables the device never writes;
+    // the next build of this image uploads the 4 KiB chunks that differ.  Dropped whenever the device memory is.
+    std::vector<uint8_t> shadow;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) {
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap), shadow(std::move(o.shadow)) {
         o.p = nullptr;
         o.cap = 0;
+        o.shadow.clear();
     }
     DevBuf& operator=(DevBuf&& o) noexcept {
         if (this != &o) {
             release();
             p = o.p;
             cap = o.cap;
+            shadow = std::move(o.shadow);
             o.p = nullptr;
             o.cap = 0;
+            o.shadow.clear();
         }
         return *this;
     }
@@ -71,6 +77,7 @@ struct DevBuf {
         if (bytes <= cap && p) return hipSuccess;
         const bool regrow = p != nullptr;  // a buffer that grows once tends to grow again (graph edits add a few nodes
                                            // at a time; a 2 GB pool costs ~250 ms to free + allocate): leave headroom
+        shadow.clear();  // (fresh memory holds none of it)
         if (p) {
             hipError_t e = hipFree(p);
             if (e != hipSuccess) return e;
@@ -95,6 +102,7 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        shadow.clear();
     }
     template <class T>
     T* as() const { return (T*)p; }
@@ -400,6 +408,9 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     std::atomic<uint64_t> last_audio_ns{0};  // steady_clock at the end of the last process call (0: none yet)
     uint32_t quiet_wait_us = 100;   // FWGPU_QUIET_WAIT_US
     uint32_t up_piece = 128u << 10; // FWGPU_UP_PIECE (bytes)
+    bool up_diff = true;            // FWGPU_UP_DIFF=0: every table uploaded whole, every build
+    bool build_one_kernel = true;   // FWGPU_BUILD_ONE_KERNEL=0: the build's copies / fills as separate runtime calls
+    std::vector<BuildJob> build_jobs;  // control thread: what build_apply will launch (fwgpu_plan_install.cpp)
     bool rt_persist = true;        // FWGPU_RT_PERSIST=0: every callback is its own launch (k_rt_block)
     uint32_t rt_idle_ms = 20;      // its watchdog: no doorbell for this long and it ends by itself (FWGPU_RT_IDLE_MS)
     RtMailbox *h_rt_mb = nullptr, *d_rt_mb = nullptr;

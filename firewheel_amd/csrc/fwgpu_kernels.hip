@@ -207,6 +207,16 @@ int launch_zero_rows(hipStream_t s, float* p, size_t pitch, int width, int rows)
     hipLaunchKernelGGL(k_zero_rows, dim3(rows < 1024 ? rows : 1024), dim3(256), 0, s, p, pitch, width, rows);
     return (int)hipGetLastError();
 }
+int launch_set_row_heads(hipStream_t s, uint8_t* p, size_t pitch, int rows, uint8_t v) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_set_row_heads, dim3((rows + 255) / 256), dim3(256), 0, s, p, pitch, rows, v);
+    return (int)hipGetLastError();
+}
+int launch_build_apply(hipStream_t s, const BuildJob* jobs, int n_jobs) {
+    if (n_jobs <= 0) return 0;
+    hipLaunchKernelGGL(k_build_apply, dim3(32, n_jobs), dim3(256), 0, s, jobs);
+    return (int)hipGetLastError();
+}
 int launch_adopt_init(hipStream_t s, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits,
                       const CarryArgs& carry) {
     if (n_jobs <= 0 && n_inits <= 0 && carry.n_new <= 0) return 0;

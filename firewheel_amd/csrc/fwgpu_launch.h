@@ -155,6 +155,8 @@ struct AdoptExtJobHost {
     float head[8];
 };
 int launch_zero_rows(hipStream_t s, float* p, size_t pitch, int width, int rows);
+int launch_set_row_heads(hipStream_t s, uint8_t* p, size_t pitch, int rows, uint8_t v);
+int launch_build_apply(hipStream_t s, const BuildJob* jobs, int n_jobs);
 int launch_adopt_init(hipStream_t s, float* ext, const void* d_jobs, int n_jobs, NodeState* states, const void* d_inits, int n_inits,
                       const CarryArgs& carry);
 // per (block, channel) of a batch: was that graph-output channel flagged silent (mode: see k_out_flags)

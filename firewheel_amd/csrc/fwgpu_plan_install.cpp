@@ -44,44 +44,185 @@ void quiet_window(fwgpu_ctx* c) {
         if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(c->quiet_wait_us)) return;
     }
 }
-static int up(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+// ---- the build's device work as ONE kernel (round 3, late).  fw_edit_race's phase tags showed that what a callback pays is per
+// OPERATION on the build's stream, not per byte: every copy / fill / small kernel that lands beside a callback costs it ~25-40 us
+// whatever its size (its dispatch and its end-of-kernel cache write-back / invalidate reach the audio kernels' L2 lines), and a
+// build made ~25 of them.  Now up() / zero() / the strided clears only record JOBS; the changed chunks wait in the pinned arena;
+// build_apply() sends the job list the same way and launches k_build_apply ONCE — a grid of (blocks, jobs) that copies from pinned
+// host memory over PCIe and fills — in a window with no process call in flight.  (FWGPU_BUILD_ONE_KERNEL=0: the calls go out one by
+// one, in pieces while a stream is live, as before.)
+static int build_apply(fwgpu_ctx* c) {
+    if (c->build_jobs.empty()) return 0;
+    // While a stream is live the jobs go out in GROUPS of a few microseconds each (about up_piece bytes of copy, 32x that of fill),
+    // every group launched in a window with no process call in flight and waited for before the next: few operations AND short
+    // ones (one 100 us kernel met a paced stream's callback in one build of six).  Jobs larger than a group are cut first.
+    const bool live = audio_live(c);
+    const size_t cp = c->up_piece, fp = (size_t)c->up_piece * 32;
+    std::vector<BuildJob> jobs;
+    jobs.reserve(c->build_jobs.size() + 16);
+    for (const BuildJob& j : c->build_jobs) {
+        if (!live) {
+            jobs.push_back(j);
+        } else if (j.src) {
+            for (size_t off = 0; off < j.row_bytes; off += cp) {
+                BuildJob t = j;
+                t.dst = (char*)j.dst + off;
+                t.src = (const char*)j.src + off;
+                t.row_bytes = t.pitch = std::min(cp, (size_t)j.row_bytes - off);
+                jobs.push_back(t);
+            }
+        } else if (j.rows == 1) {
+            for (size_t off = 0; off < j.row_bytes; off += fp) {
+                BuildJob t = j;
+                t.dst = (char*)j.dst + off;
+                t.row_bytes = t.pitch = std::min(fp, (size_t)j.row_bytes - off);
+                if (off) t.head = -1;
+                jobs.push_back(t);
+            }
+        } else {
+            const uint32_t per = (uint32_t)std::max<size_t>(1, fp / (size_t)j.row_bytes);
+            for (uint32_t r = 0; r < j.rows; r += per) {
+                BuildJob t = j;
+                t.dst = (char*)j.dst + (size_t)r * j.pitch;
+                t.rows = std::min(per, j.rows - r);
+                jobs.push_back(t);
+            }
+        }
+    }
+    c->build_jobs.clear();
+    // (up() keeps room for the list behind the tables; the cut list may be longer: checked here)
+    const size_t jb = jobs.size() * sizeof(BuildJob);
+    if (c->h_up_used + jb > c->h_up_cap) return fail(c, FWGPU_ERR_DEVICE, "plan build: no room for the job list in the upload arena");
+    BuildJob* at = (BuildJob*)(c->h_up + c->h_up_used);
+    memcpy(at, jobs.data(), jb);
+    c->h_up_used += (jb + 255) & ~(size_t)255;
+    size_t i = 0;
+    while (i < jobs.size()) {
+        size_t k = i, cost = 0;
+        while (k < jobs.size()) {
+            const size_t jc = jobs[k].src ? (size_t)jobs[k].row_bytes : (size_t)jobs[k].row_bytes * jobs[k].rows / 32;
+            if (live && k > i && cost + jc > cp) break;
+            cost += jc;
+            ++k;
+        }
+        if (live) quiet_window(c);
+        LCHK(c, launch_build_apply(c->up_stream, at + i, (int)(k - i)));
+        if (live) HIPC(c, hipStreamSynchronize(c->up_stream));
+        i = k;
+    }
+    return 0;
+}
+// room in the pinned arena for `need` more bytes plus the job list; what is pending goes out first if there is none
+static int arena_room(fwgpu_ctx* c, size_t need) {
+    // (the list may be cut into group-sized jobs: one more per up_piece of copy / 32 up_pieces of fill; 64 KiB covers 1 300 of them)
+    const size_t jobs_room = (c->build_jobs.size() + 64) * sizeof(BuildJob) + (64u << 10);
+    if (c->h_up && c->h_up_used + need + jobs_room <= c->h_up_cap) return 0;
+    int rc = build_apply(c);
+    if (rc) return rc;
+    HIPC(c, hipStreamSynchronize(c->up_stream));  // what is in flight has left the arena
+    c->h_up_used = 0;
+    if (!c->h_up || need + jobs_room > c->h_up_cap) {
+        if (c->h_up) (void)hipHostFree(c->h_up);
+        c->h_up = nullptr;
+        c->h_up_cap = 0;
+        const size_t cap = std::max<size_t>(need + jobs_room, (size_t)8 << 20);
+        HIPC(c, hipHostMalloc((void**)&c->h_up, cap, hipHostMallocDefault));
+        c->h_up_cap = cap;
+    }
+    return 0;
+}
+// `device_writes`: the kernels write this table too (silence flags): always uploaded whole, no shadow.
+// Every other table is read-only on the device (const in DevView / FusedView): the image keeps a host copy of what it last
+// uploaded and a build copies only the 4 KiB chunks that differ — an edit of one voice of config 3's 4 096 leaves 89 % of the
+// table bytes as the image's previous build left them (the two images alternate, so "previous" is two edits ago).
+static int up(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes, bool device_writes = false) {
     HIPC(c, b.ensure_n("b", bytes));
     if (!bytes) return 0;
     const size_t need = (bytes + 255) & ~(size_t)255;
-    if (c->h_up_used + need > c->h_up_cap) {
-        HIPC(c, hipStreamSynchronize(c->up_stream));  // what is in flight has left the arena
-        c->h_up_used = 0;
-        if (need > c->h_up_cap) {
-            if (c->h_up) (void)hipHostFree(c->h_up);
-            c->h_up = nullptr;
-            c->h_up_cap = 0;
-            const size_t cap = std::max<size_t>(need, (size_t)8 << 20);
-            HIPC(c, hipHostMalloc((void**)&c->h_up, cap, hipHostMallocDefault));
-            c->h_up_cap = cap;
-        }
-    }
+    int rc = arena_room(c, need);
+    if (rc) return rc;
     memcpy(c->h_up + c->h_up_used, src, bytes);
-    const bool live = audio_live(c);
+    const bool one = c->build_one_kernel;
+    const bool live = !one && audio_live(c);
     const size_t piece = live ? c->up_piece : bytes;
-    for (size_t off = 0; off < bytes; off += piece) {
-        const size_t n = std::min(piece, bytes - off);
-        if (live) quiet_window(c);
-        HIPC(c, hipMemcpyAsync((char*)b.p + off, c->h_up + c->h_up_used + off, n, hipMemcpyHostToDevice, c->up_stream));
-        if (live) HIPC(c, hipStreamSynchronize(c->up_stream));
+    const bool diff = c->up_diff && !device_writes;
+    constexpr size_t CH = 4096;
+    // runs of chunks that differ from the shadow
+    size_t off = 0;
+    while (off < bytes) {
+        size_t end = bytes;
+        if (diff) {
+            auto same = [&](size_t o) {
+                const size_t n = std::min(CH, bytes - o);
+                return o + n <= b.shadow.size() && !memcmp(b.shadow.data() + o, (const char*)src + o, n);
+            };
+            while (off < bytes && same(off)) off += CH;
+            if (off >= bytes) break;
+            end = off;
+            while (end < bytes && !same(end)) end += CH;
+            end = std::min(end, bytes);
+        }
+        if (one) {
+            BuildJob j{};
+            j.dst = (char*)b.p + off;
+            j.src = c->h_up + c->h_up_used + off;
+            j.row_bytes = end - off;
+            j.pitch = j.row_bytes;
+            j.rows = 1;
+            c->build_jobs.push_back(j);
+            off = end;
+            continue;
+        }
+        for (; off < end; off += piece) {  // one by one, in pieces while a stream is live
+            const size_t n = std::min(piece, end - off);
+            if (live) quiet_window(c);
+            HIPC(c, hipMemcpyAsync((char*)b.p + off, c->h_up + c->h_up_used + off, n, hipMemcpyHostToDevice, c->up_stream));
+            if (live) HIPC(c, hipStreamSynchronize(c->up_stream));
+        }
+        off = end;
     }
+    if (diff) b.shadow.assign((const uint8_t*)src, (const uint8_t*)src + bytes);
+    else b.shadow.clear();
     c->h_up_used += need;
     return 0;
 }
-static int zero(fwgpu_ctx* c, void* p, size_t bytes) {
+// rows x row_bytes at a pitch, every byte `value`; head >= 0: byte 0 of every row is `head` instead
+static int fill_rows(fwgpu_ctx* c, void* p, size_t row_bytes, size_t pitch, size_t rows, int value, int head = -1) {
+    if (!row_bytes || !rows) return 0;
+    if (c->build_one_kernel) {
+        int rc = arena_room(c, 0);
+        if (rc) return rc;
+        BuildJob j{};
+        j.dst = p;
+        j.src = nullptr;
+        j.row_bytes = row_bytes;
+        j.pitch = pitch;
+        j.rows = (uint32_t)rows;
+        j.value = (uint32_t)(value & 0xff);
+        j.head = head;
+        c->build_jobs.push_back(j);
+        return 0;
+    }
     const bool live = audio_live(c);
-    const size_t piece = live ? (size_t)c->up_piece * 32 : bytes;  // (a fill runs ~30x faster than a copy over PCIe)
-    for (size_t off = 0; off < bytes; off += piece) {
+    if (rows == 1 || pitch == row_bytes) {
+        const size_t bytes = rows * row_bytes;
+        const size_t piece = live ? (size_t)c->up_piece * 32 : bytes;  // (a fill runs ~30x faster than a copy over PCIe)
+        for (size_t off = 0; off < bytes; off += piece) {
+            if (live) quiet_window(c);
+            HIPC(c, hipMemsetAsync((char*)p + off, value, std::min(piece, bytes - off), c->up_stream));
+            if (live) HIPC(c, hipStreamSynchronize(c->up_stream));
+        }
+    } else {
         if (live) quiet_window(c);
-        HIPC(c, hipMemsetAsync((char*)p + off, 0, std::min(piece, bytes - off), c->up_stream));
-        if (live) HIPC(c, hipStreamSynchronize(c->up_stream));
+        LCHK(c, launch_zero_rows(c->up_stream, (float*)p, pitch / sizeof(float), (int)(row_bytes / sizeof(float)), (int)rows));
+    }
+    if (head >= 0) {
+        if (live) quiet_window(c);
+        LCHK(c, launch_set_row_heads(c->up_stream, (uint8_t*)p, pitch, (int)rows, (uint8_t)head));
     }
     return 0;
 }
+static int zero(fwgpu_ctx* c, void* p, size_t bytes) { return fill_rows(c, p, bytes, bytes, 1, 0); }
 
 void PlanImage::release_device() {
     DevBuf* bufs[] = {&d_nodes, &d_in_buf, &d_out_buf, &d_level_nodes, &d_pool, &d_flags, &d_gin_bufs, &d_gout_bufs, &d_groups, &d_blks2, &d_refs2,
@@ -241,6 +382,8 @@ static int upload_chain_groups(fwgpu_ctx* c, PlanImage& P, const std::vector<Lea
 // tries the same nodes again (the reference keeps its schedule when a compile fails, context.rs:115-131).
 static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
     reset_for_build(P);
+    c->build_jobs.clear();
+    c->h_up_used = 0;
     P.kmax = c->kmax_req;
     P.gen = ++c->build_gen;
     c->update_phase = 21;
@@ -597,11 +740,12 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         // by the node that owns it before anybody reads it (the level order) — the GPU suite passes with FWGPU_POISON=1 filling
         // fresh pools with 0xCB.  So only those rows are cleared: the whole pool was a 0.5 GB fill per build on config 3, ~100 us of
         // fill kernel during which the callbacks that ran beside the build took 2-3x as long (fw_edit_race's phase tags).
-        quiet_window(c);
-        if (plan.num_buffers > 0) LCHK(c, launch_zero_rows(c->up_stream, P.d_pool.as<float>(), (size_t)plan.num_buffers * c->stride, c->stride, (int)Kg));
-        std::vector<uint8_t> fl(Kg * (size_t)plan.num_buffers, 0);
-        for (size_t k = 0; k < Kg; ++k) fl[k * (size_t)plan.num_buffers] = 1;  // buffer 0: constant zero, always flagged silent
-        if ((rc = up(c, P.d_flags, fl.data(), fl.size()))) return rc;
+        if (plan.num_buffers > 0 && (rc = fill_rows(c, P.d_pool.p, c->stride * sizeof(float), (size_t)plan.num_buffers * c->stride * sizeof(float), Kg, 0))) return rc;
+        // silence flags (the kernels write them): all clear, buffer 0 — constant zero — always flagged silent.  Made on the device:
+        // K x num_buffers bytes were the largest upload of an edit (0.4 of 1.5 MB on config 3)
+        const size_t fl_bytes = Kg * (size_t)plan.num_buffers;
+        HIPC(c, P.d_flags.ensure_n("d_flags", fl_bytes));
+        if (plan.num_buffers > 0 && (rc = fill_rows(c, P.d_flags.p, (size_t)plan.num_buffers, (size_t)plan.num_buffers, Kg, 0, 1))) return rc;
     }
 
     c->update_phase = 27;
@@ -654,7 +798,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         if ((rc = zero(c, P.d_bus.p, bus_bytes))) return rc;
         std::vector<uint8_t> bf(K * P.n_bus, 0);
         for (size_t k = 0; k < K; ++k) bf[k * P.n_bus] = 1;
-        if ((rc = up(c, P.d_bus_flags, bf.data(), bf.size()))) return rc;
+        if ((rc = up(c, P.d_bus_flags, bf.data(), bf.size(), true))) return rc;  // (kernels write flags)
         if (fb.up_nodes.empty()) {
             NodeDesc z;
             memset(&z, 0, sizeof(z));
@@ -775,6 +919,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
     P.plan = plan;
     P.have_plan = true;
     c->update_phase = 3;
+    if ((rc = build_apply(c))) return rc;
     HIPC(c, hipStreamSynchronize(c->up_stream));  // every table and every zeroed pool of the image is in place
     c->update_phase = 4;
     c->h_up_used = 0;
@@ -1009,8 +1154,10 @@ int install_plan(fwgpu_ctx* c, Plan& plan) {
     }
     const int rc = build_image(c, plan, *P);
     if (rc != 0) {
+        (void)build_apply(c);  // (the shadows of the tables say these chunks are on the device: they go there, into an image nobody reads)
         (void)hipStreamSynchronize(c->up_stream);
         (void)hipGetLastError();
+        c->h_up_used = 0;
         c->spare = P;  // (its buffers are reusable whatever state the build left them in)
         return rc;
     }

@@ -198,6 +198,17 @@ struct VoiceCache {
 };
 static_assert(sizeof(VoiceCache) == 64, "VoiceCache layout");
 
+// plan build: one piece of the build's device work (k_build_apply).  src != nullptr: copy row_bytes from pinned host memory
+// (rows = 1); src == nullptr: rows x row_bytes at `pitch` bytes set to `value`, byte 0 of every row to `head` if head >= 0
+struct BuildJob {
+    void* dst;
+    const void* src;
+    unsigned long long row_bytes, pitch;
+    uint32_t rows, value;
+    int head, pad_;
+};
+static_assert(sizeof(BuildJob) == 48, "BuildJob layout");
+
 // plan adoption: which steady caches travel from the old plan to the new one (k_adopt_init / carry_cache_voice); n_new = 0: none
 struct VoiceDesc;
 struct CarryArgs {

@@ -302,6 +302,42 @@ __global__ __launch_bounds__(256) void k_zero_rows(float* __restrict__ p, size_t
     for (int r = blockIdx.x; r < rows; r += gridDim.x)
         for (int i = threadIdx.x; i < width; i += blockDim.x) p[(size_t)r * pitch + i] = 0.f;
 }
+// plan build: byte 0 of each of `rows` rows, `pitch` bytes apart, set to v (the constant-zero buffer's silence flag of every block)
+__global__ __launch_bounds__(256) void k_set_row_heads(uint8_t* __restrict__ p, size_t pitch, int rows, uint8_t v) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) p[(size_t)r * pitch] = v;
+}
+// plan build: every copy and fill of a build in one launch (fwgpu_plan_install.cpp, build_apply).  blockIdx.y = job; the job list
+// and the copies' sources are pinned host memory.  Jobs never overlap, so they need no order among themselves.
+__global__ __launch_bounds__(256) void k_build_apply(const BuildJob* __restrict__ jobs) {
+    const BuildJob j = jobs[blockIdx.y];
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    uint8_t* const d = (uint8_t*)j.dst;
+    if (j.src) {
+        const uint8_t* const sp = (const uint8_t*)j.src;
+        const bool al = (((uintptr_t)d | (uintptr_t)sp) & 15u) == 0;
+        const size_t n16 = al ? j.row_bytes / 16 : 0;
+        for (size_t i = tid; i < n16; i += nth) ((uint4*)d)[i] = ((const uint4*)sp)[i];
+        for (size_t i = n16 * 16 + tid; i < j.row_bytes; i += nth) d[i] = sp[i];
+        return;
+    }
+    const uint8_t v = (uint8_t)j.value;
+    if ((((uintptr_t)d | j.pitch | j.row_bytes) & 3u) == 0) {
+        const uint32_t v4 = v * 0x01010101u;
+        const uint32_t h4 = j.head >= 0 ? ((v4 & 0xffffff00u) | (uint32_t)(j.head & 0xff)) : v4;
+        const size_t wpr = j.row_bytes / 4, total = wpr * j.rows;
+        for (size_t i = tid; i < total; i += nth) {
+            const size_t r = i / wpr, w = i - r * wpr;
+            ((uint32_t*)(d + r * j.pitch))[w] = w == 0 ? h4 : v4;
+        }
+    } else {
+        const size_t total = j.row_bytes * j.rows;
+        for (size_t i = tid; i < total; i += nth) {
+            const size_t r = i / j.row_bytes, w = i - r * j.row_bytes;
+            d[r * j.pitch + w] = (w == 0 && j.head >= 0) ? (uint8_t)j.head : v;
+        }
+    }
+}
 // Plan adoption: a voice whose chain is the same nodes in the new plan as in the old one keeps its steady cache (VoiceCache: "ended
 // the last call steady" + the descriptor its blocks share), re-stamped with the new epoch.  Without this every voice of the graph
 // runs its full state machines in the first callback after ANY edit — 50-100 us more for that callback on configs 2 and 3

@@ -1,6 +1,7 @@
 #!/bin/bash
 # fw_edit_race (config-3 bank, 4096 voices, 512-frame callbacks, 30 voice replacements) in four modes:
-#   back to back / paced at 1 ms, each with the build's GPU work in quiet windows (default) and all at once (FWGPU_QUIET_WAIT_US=0)
+#   back to back / paced at 1 ms, each with the build as it is by default (job list, changed chunks, grouped k_build_apply in quiet
+#   windows) and with everything issued at once (FWGPU_QUIET_WAIT_US=0)
 mkdir -p gpurun_out
 make -C examples/host_c > /dev/null 2>&1
 for q in 100 0; do

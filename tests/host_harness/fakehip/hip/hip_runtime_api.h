@@ -55,10 +55,11 @@ static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hi
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
-extern "C" unsigned long long fwh_h2d_copies, fwh_h2d_max_bytes; /* launch_stubs.cpp: asynchronous host-to-device copies so far, the largest */
+extern "C" unsigned long long fwh_h2d_copies, fwh_h2d_max_bytes, fwh_h2d_bytes; /* launch_stubs.cpp: asynchronous host-to-device copies so far, the largest */
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t) {
     if (k == hipMemcpyHostToDevice) {
         __atomic_fetch_add(&fwh_h2d_copies, 1ull, __ATOMIC_RELAXED); /* (control and audio threads both copy) */
+        __atomic_fetch_add(&fwh_h2d_bytes, (unsigned long long)n, __ATOMIC_RELAXED);
         unsigned long long m = __atomic_load_n(&fwh_h2d_max_bytes, __ATOMIC_RELAXED);
         while (n > m && !__atomic_compare_exchange_n(&fwh_h2d_max_bytes, &m, (unsigned long long)n, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
         }

@@ -9,12 +9,16 @@ unsigned long long g_ctl_orders = 0;  // control launches that carried a dispatc
 }
 extern "C" unsigned long long fwh_cmds_seen(void) { return g_cmds_applied; }
 extern "C" {
-unsigned long long fwh_h2d_copies = 0, fwh_h2d_max_bytes = 0;  // (fakehip's hipMemcpyAsync counts)
+unsigned long long fwh_h2d_copies = 0, fwh_h2d_max_bytes = 0, fwh_h2d_bytes = 0;  // (fakehip's hipMemcpyAsync counts)
 }
 extern "C" void fwh_h2d_reset(void) {
     __atomic_store_n(&fwh_h2d_copies, 0ull, __ATOMIC_RELAXED);
     __atomic_store_n(&fwh_h2d_max_bytes, 0ull, __ATOMIC_RELAXED);
+    __atomic_store_n(&fwh_h2d_bytes, 0ull, __ATOMIC_RELAXED);
 }
+namespace fwgpu { extern unsigned long long g_build_applies; }
+extern "C" unsigned long long fwh_build_applies(void) { return fwgpu::g_build_applies; }
+extern "C" unsigned long long fwh_h2d_total(void) { return __atomic_load_n(&fwh_h2d_bytes, __ATOMIC_RELAXED); }
 extern "C" unsigned long long fwh_h2d_count(void) { return __atomic_load_n(&fwh_h2d_copies, __ATOMIC_RELAXED); }
 extern "C" unsigned long long fwh_h2d_max(void) { return __atomic_load_n(&fwh_h2d_max_bytes, __ATOMIC_RELAXED); }
 extern "C" unsigned long long fwh_ctl_orders(void) { return g_ctl_orders; }
@@ -394,6 +398,30 @@ int launch_zero_rows(hipStream_t, float* p, size_t pitch, int width, int rows) {
     for (int r = 0; r < rows; ++r) {
         touch(p + (size_t)r * pitch, sizeof(float) * (size_t)width);
         for (int i = 0; i < width; ++i) p[(size_t)r * pitch + i] = 0.f;
+    }
+    return 0;
+}
+int launch_set_row_heads(hipStream_t, uint8_t* p, size_t pitch, int rows, uint8_t v) {
+    for (int r = 0; r < rows; ++r) p[(size_t)r * pitch] = v;
+    return 0;
+}
+unsigned long long g_build_applies = 0;
+int launch_build_apply(hipStream_t, const BuildJob* jobs, int n_jobs) {
+    g_build_applies++;
+    REQUIRE(jobs != nullptr && n_jobs > 0, (long)n_jobs);
+    for (int i = 0; i < n_jobs; ++i) {
+        const BuildJob& j = jobs[i];
+        REQUIRE(j.dst != nullptr && j.row_bytes > 0 && j.rows > 0, (long)i);
+        if (j.src) {
+            REQUIRE(j.rows == 1, (long)i);
+            memmove(j.dst, j.src, j.row_bytes);
+            __atomic_fetch_add(&fwh_h2d_bytes, (unsigned long long)j.row_bytes, __ATOMIC_RELAXED);  // (counted like a copy call's)
+        } else {
+            for (uint32_t r = 0; r < j.rows; ++r) {
+                memset((char*)j.dst + (size_t)r * j.pitch, (int)j.value, j.row_bytes);
+                if (j.head >= 0) ((unsigned char*)j.dst)[(size_t)r * j.pitch] = (unsigned char)j.head;
+            }
+        }
     }
     return 0;
 }

@@ -458,7 +458,7 @@ def test_control_dispatch_order_and_cache_carry_on_the_host_side():
     assert e.violation() == "", e.violation()
 
 
-def test_plan_builds_go_out_in_pieces_only_while_a_stream_is_live():
+def test_plan_builds_go_out_in_pieces_only_while_a_stream_is_live(monkeypatch):
     """round 3, host half (fwgpu_plan_install.cpp, quiet_window / audio_live): a build with no process call in the last 200 ms
     uploads every table whole; a build right after a process call cuts its uploads into pieces of at most FWGPU_UP_PIECE bytes
     (128 KiB), each issued when the gate word says no process call is in flight.  The fake HIP counts the asynchronous
@@ -471,6 +471,8 @@ def test_plan_builds_go_out_in_pieces_only_while_a_stream_is_live():
     L = hostonly_lib()
     for f in (L.fwh_h2d_count, L.fwh_h2d_max):
         f.restype = C.c_ulonglong
+    monkeypatch.setenv("FWGPU_UP_DIFF", "0")                                  # (every table whole, every build: the test below covers the diff)
+    monkeypatch.setenv("FWGPU_BUILD_ONE_KERNEL", "0")                         # (the calls one by one: the default is one kernel per build, below)
     e = HostOnlyEngine(max_block_frames=256, max_batch=8)
     L.fwh_h2d_reset()
     voices = scenarios.build_voice_bank(e, 3000, radix=32, src_frames=600)   # (build_voice_bank ends in update(): no stream yet)
@@ -494,3 +496,46 @@ def test_plan_builds_go_out_in_pieces_only_while_a_stream_is_live():
     assert L.fwh_h2d_max() > 128 * 1024, L.fwh_h2d_max()                      # (the first build also carried the new nodes' states)
     e.process_blocks(1)
     assert e.violation() == "", e.violation()
+
+
+def test_a_rebuild_uploads_only_the_chunks_of_its_tables_that_changed():
+    """round 3, host half (up() in fwgpu_plan_install.cpp): the tables the device only reads keep a host copy per plan image; a
+    build copies the 4 KiB chunks that differ from what the SAME image got two edits ago (the two images alternate).  Replacing one
+    voice of a 2 000-voice bank: from the third edit on an update sends a fraction of what the first build sent; the harness stubs
+    keep checking every table a launch is handed (a stale chunk would be an index out of its table)."""
+    import ctypes as C
+
+    from fwapi import HostOnlyEngine, hostonly_lib
+
+    L = hostonly_lib()
+    L.fwh_h2d_total.restype = C.c_ulonglong
+    L.fwh_build_applies.restype = C.c_ulonglong
+    L.fwh_h2d_count.restype = C.c_ulonglong
+    L.fwh_violation_reset()
+    e = HostOnlyEngine(max_block_frames=256, max_batch=8)
+    L.fwh_h2d_reset()
+    a0 = L.fwh_build_applies()
+    voices = scenarios.build_voice_bank(e, 2000, radix=32, src_frames=600)
+    first = L.fwh_h2d_total()
+    # ... and everything a build does on the device — the changed chunks, the cleared state, the flags — is ONE launch
+    # (k_build_apply over a job list), not a runtime call per table
+    assert L.fwh_build_applies() == a0 + 1 and L.fwh_h2d_count() == 0, (L.fwh_build_applies() - a0, L.fwh_h2d_count())
+    for vc in voices[:40]:
+        e.sampler_play(vc["sampler"])
+    e.process_blocks(2)
+    sent = []
+    for k in range(5):
+        vc = voices[(k * 977 + 13) % len(voices)]
+        x = e.volume(30.0 + k)                     # a node more in front of one voice's pan: the schedule shifts behind it
+        e.remove_node(x)
+        e.set_param(vc["volume"], 0, 60.0 + k)
+        y = e.volume(10.0 + k)
+        e.connect_stereo(voices[(k * 31 + 7) % len(voices)]["sampler"], y)
+        L.fwh_h2d_reset()
+        a1 = L.fwh_build_applies()
+        e.update()
+        sent.append(L.fwh_h2d_total())
+        assert 1 <= L.fwh_build_applies() - a1 <= 12      # (a stream is live: groups of a few microseconds each, not one long kernel)
+        e.process_blocks(3)
+        assert e.violation() == "", e.violation()
+    assert min(sent[2:]) < 0.5 * first, (first, sent)

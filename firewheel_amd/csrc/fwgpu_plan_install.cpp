@@ -89,8 +89,10 @@ static int build_apply(fwgpu_ctx* c) {
             }
         }
     }
+    // (up() keeps room for the uncut list behind the tables and 64 KiB more; a cut list that still does not fit — a tiny
+    //  FWGPU_UP_PIECE against megabytes of changed tables — is dropped for the uncut one)
+    if (c->h_up_used + jobs.size() * sizeof(BuildJob) > c->h_up_cap) jobs = c->build_jobs;
     c->build_jobs.clear();
-    // (up() keeps room for the list behind the tables; the cut list may be longer: checked here)
     const size_t jb = jobs.size() * sizeof(BuildJob);
     if (c->h_up_used + jb > c->h_up_cap) return fail(c, FWGPU_ERR_DEVICE, "plan build: no room for the job list in the upload arena");
     BuildJob* at = (BuildJob*)(c->h_up + c->h_up_used);

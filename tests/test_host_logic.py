@@ -498,7 +498,7 @@ def test_plan_builds_go_out_in_pieces_only_while_a_stream_is_live(monkeypatch):
     assert e.violation() == "", e.violation()
 
 
-def test_a_rebuild_uploads_only_the_chunks_of_its_tables_that_changed():
+def test_a_rebuild_uploads_only_the_chunks_of_its_tables_that_changed(monkeypatch):
     """round 3, host half (up() in fwgpu_plan_install.cpp): the tables the device only reads keep a host copy per plan image; a
     build copies the 4 KiB chunks that differ from what the SAME image got two edits ago (the two images alternate).  Replacing one
     voice of a 2 000-voice bank: from the third edit on an update sends a fraction of what the first build sent; the harness stubs
@@ -512,6 +512,8 @@ def test_a_rebuild_uploads_only_the_chunks_of_its_tables_that_changed():
     L.fwh_build_applies.restype = C.c_ulonglong
     L.fwh_h2d_count.restype = C.c_ulonglong
     L.fwh_violation_reset()
+    for k in ("FWGPU_UP_PIECE", "FWGPU_UP_DIFF", "FWGPU_BUILD_ONE_KERNEL", "FWGPU_QUIET_WAIT_US"):
+        monkeypatch.delenv(k, raising=False)                  # (the defaults are what is tested)
     e = HostOnlyEngine(max_block_frames=256, max_batch=8)
     L.fwh_h2d_reset()
     a0 = L.fwh_build_applies()

@@ -406,6 +406,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     // how long a piece waits for such a window (0 = the old behaviour: everything at once), and the size of an upload piece
     std::atomic<int> update_phase{0};  // fwgpu_update_phase: 0 none, 1 graph compile, 21..28 the sections of build_image, 3 waiting for the uploads
     std::atomic<uint64_t> last_audio_ns{0};  // steady_clock at the end of the last process call (0: none yet)
+    std::atomic<uint64_t> cb_start_ns{0}, cb_period_ns{0}, cb_dur_ns{0};  // the last call's start, its distance to the one before, its length
     uint32_t quiet_wait_us = 100;   // FWGPU_QUIET_WAIT_US
     uint32_t up_piece = 128u << 10; // FWGPU_UP_PIECE (bytes)
     bool up_diff = true;            // FWGPU_UP_DIFF=0: every table uploaded whole, every build
@@ -537,11 +538,18 @@ struct AudioGate {
             __builtin_ia32_pause();
 #endif
         }
+        // the stream's rhythm, for quiet_window: when this call began and how long after the one before
+        const uint64_t t = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+        const uint64_t prev = c->cb_start_ns.load(std::memory_order_relaxed);
+        if (prev) c->cb_period_ns.store(t - prev, std::memory_order_relaxed);
+        c->cb_start_ns.store(t, std::memory_order_relaxed);
         if (PlanImage* img = c->pending.exchange(nullptr, std::memory_order_acq_rel)) adopt_image(c, img, true);
     }
     ~AudioGate() {
         // when the audio side last ran (quiet_window: a control thread cuts its GPU work into pieces only while a stream is live)
-        c->last_audio_ns.store((uint64_t)std::chrono::steady_clock::now().time_since_epoch().count(), std::memory_order_relaxed);
+        const uint64_t t = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+        c->last_audio_ns.store(t, std::memory_order_relaxed);
+        c->cb_dur_ns.store(t - c->cb_start_ns.load(std::memory_order_relaxed), std::memory_order_relaxed);
         c->gate.store(0, std::memory_order_release);
     }
 };

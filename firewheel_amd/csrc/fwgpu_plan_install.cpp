@@ -29,19 +29,37 @@ namespace fwgpu {
 //  work goes out in pieces of a few microseconds, each issued when no process call is in flight (the gate word says so) and waited
 //  for before the next — a callback meets at most the piece that was issued just before it began.  With the audio side saturated
 //  (callbacks back to back, the stress of fw_edit_race) a piece goes out anyway after quiet_wait_us.  With no stream live — no process
-//  call in the last 200 ms: single-threaded hosts, set-up — everything goes out whole as before.)
+//  call in the last 200 ms: single-threaded hosts, set-up — everything goes out whole as before.
+//  A PACED stream (gaps between the calls of at least 2 x QUIET_MARGIN) is also looked at ahead: a group launched just before a
+//  call begins still meets it, so when the next call is due within the margin — the last period and the last start say when — the
+//  group waits for that call to come and go.)
+static constexpr uint64_t QUIET_MARGIN_NS = 60000;  // a group and its launch
 void quiet_window(fwgpu_ctx* c) {
     if (!c->quiet_wait_us) return;
-    if (c->gate.load(std::memory_order_acquire) != 1) return;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        for (int i = 0; i < 64; ++i) {
-            if (c->gate.load(std::memory_order_acquire) != 1) return;
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    const auto deadline = t0 + std::chrono::microseconds(3 * (uint64_t)c->quiet_wait_us);
+    auto wait_gate = [&](bool busy, clk::time_point until) {  // spin while (gate == 1) == busy; false: timed out
+        for (;;) {
+            for (int i = 0; i < 64; ++i) {
+                if ((c->gate.load(std::memory_order_acquire) == 1) != busy) return true;
 #if defined(__x86_64__) || defined(__i386__)
-            __builtin_ia32_pause();
+                __builtin_ia32_pause();
 #endif
+            }
+            if (clk::now() > until) return false;
         }
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(c->quiet_wait_us)) return;
+    };
+    for (int round = 0; round < 2; ++round) {
+        if (c->gate.load(std::memory_order_acquire) == 1 && !wait_gate(true, round ? deadline : t0 + std::chrono::microseconds(c->quiet_wait_us))) return;
+        // no call in flight.  Is the next one about to begin?
+        const uint64_t period = c->cb_period_ns.load(std::memory_order_relaxed), dur = c->cb_dur_ns.load(std::memory_order_relaxed);
+        const uint64_t start = c->cb_start_ns.load(std::memory_order_relaxed);
+        if (round || !period || period > 200000000ull || period < dur + 2 * QUIET_MARGIN_NS) return;  // no rhythm, or no gaps to use
+        const uint64_t now = (uint64_t)clk::now().time_since_epoch().count();
+        const uint64_t since = now - start;
+        if (since + QUIET_MARGIN_NS < period || since > period + QUIET_MARGIN_NS) return;  // room before it / it is overdue: go
+        if (!wait_gate(false, deadline)) return;  // ... wait for it to begin, then (second round) to end
     }
 }
 // ---- the build's device work as ONE kernel (round 3, late).  fw_edit_race's phase tags showed that what a callback pays is per

@@ -55,10 +55,7 @@ void quiet_window(fwgpu_ctx* c) {
         // no call in flight.  Is the next one about to begin?
         const uint64_t period = c->cb_period_ns.load(std::memory_order_relaxed), dur = c->cb_dur_ns.load(std::memory_order_relaxed);
         const uint64_t start = c->cb_start_ns.load(std::memory_order_relaxed);
-        if (round || !period || period > 200000000ull || period < dur + 2 * QUIET_MARGIN_NS) return;  // no rhythm, or no gaps to use
-        const uint64_t now = (uint64_t)clk::now().time_since_epoch().count();
-        const uint64_t since = now - start;
-        if (since + QUIET_MARGIN_NS < period || since > period + QUIET_MARGIN_NS) return;  // room before it / it is overdue: go
+        if (round || !quiet_next_call_is_due((uint64_t)clk::now().time_since_epoch().count(), start, period, dur, QUIET_MARGIN_NS)) return;
         if (!wait_gate(false, deadline)) return;  // ... wait for it to begin, then (second round) to end
     }
 }

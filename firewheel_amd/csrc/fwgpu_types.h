@@ -198,6 +198,15 @@ struct VoiceCache {
 };
 static_assert(sizeof(VoiceCache) == 64, "VoiceCache layout");
 
+// (host side, here so that the test harness can reach it) quiet_window's look-ahead rule, no call being in flight at `now` (all steady_clock ns): the last call began at `start`, `period`
+// after the one before, and took `dur`.  true: the next call is due within `margin` — wait for it to come and go.  false: go now
+// (room before the next call; or no rhythm known; or a stream without gaps of 2 x margin to use; or the call is overdue by more
+// than the margin: a stream that stopped must not hold a build up).
+inline bool quiet_next_call_is_due(uint64_t now, uint64_t start, uint64_t period, uint64_t dur, uint64_t margin) {
+    if (!period || period > 200000000ull || period < dur + 2 * margin) return false;
+    const uint64_t since = now - start;
+    return !(since + margin < period || since > period + margin);
+}
 // plan build: one piece of the build's device work (k_build_apply).  src != nullptr: copy row_bytes from pinned host memory
 // (rows = 1); src == nullptr: rows x row_bytes at `pitch` bytes set to `value`, byte 0 of every row to `head` if head >= 0
 struct BuildJob {

@@ -18,6 +18,10 @@ extern "C" void fwh_h2d_reset(void) {
 }
 namespace fwgpu { extern unsigned long long g_build_applies; }
 extern "C" unsigned long long fwh_build_applies(void) { return fwgpu::g_build_applies; }
+extern "C" int fwh_quiet_next_call_is_due(unsigned long long now, unsigned long long start, unsigned long long period, unsigned long long dur,
+                                          unsigned long long margin) {
+    return fwgpu::quiet_next_call_is_due(now, start, period, dur, margin) ? 1 : 0;
+}
 extern "C" unsigned long long fwh_h2d_total(void) { return __atomic_load_n(&fwh_h2d_bytes, __ATOMIC_RELAXED); }
 extern "C" unsigned long long fwh_h2d_count(void) { return __atomic_load_n(&fwh_h2d_copies, __ATOMIC_RELAXED); }
 extern "C" unsigned long long fwh_h2d_max(void) { return __atomic_load_n(&fwh_h2d_max_bytes, __ATOMIC_RELAXED); }

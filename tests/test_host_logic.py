@@ -541,3 +541,28 @@ def test_a_rebuild_uploads_only_the_chunks_of_its_tables_that_changed(monkeypatc
         e.process_blocks(3)
         assert e.violation() == "", e.violation()
     assert min(sent[2:]) < 0.5 * first, (first, sent)
+
+
+def test_quiet_window_look_ahead_rule():
+    """fwgpu_ctx.h, quiet_next_call_is_due: when a group of a build's device work, no call being in flight, still waits because the
+    stream's next call is about to begin (times in ns; margin 60 us)."""
+    import ctypes as C
+
+    from fwapi import hostonly_lib
+
+    f = hostonly_lib().fwh_quiet_next_call_is_due
+    f.restype = C.c_int
+    f.argtypes = [C.c_ulonglong] * 5
+    us, M = 1000, 60_000
+    start, period, dur = 10_000 * us, 1000 * us, 80 * us              # a callback every millisecond, 80 us long
+    assert f(start + 100 * us, start, period, dur, M) == 0             # just over: 900 us of room
+    assert f(start + 939 * us, start, period, dur, M) == 0             # 61 us before the next one: still room for a group
+    assert f(start + 941 * us, start, period, dur, M) == 1             # 59 us before it: wait for it to come and go
+    assert f(start + 1000 * us, start, period, dur, M) == 1            # due now
+    assert f(start + 1059 * us, start, period, dur, M) == 1            # a little late: still expected
+    assert f(start + 1061 * us, start, period, dur, M) == 0            # overdue by more than the margin: the stream may have stopped
+    assert f(start + 500 * us, start, 0, dur, M) == 0                  # no rhythm known yet
+    assert f(start + 70 * us, start, 85 * us, 80 * us, M) == 0         # back to back: no gaps to use, the plain rule applies
+    assert f(start + 195 * us, start, 199 * us, 80 * us, M) == 0       # gaps shorter than two margins: likewise
+    assert f(start + 195 * us, start, 201 * us, 80 * us, M) == 1       # ... just long enough
+    assert f(start + 10 * us, start, 300_000 * us, dur, M) == 0        # a "period" of 300 ms is a pause, not a rhythm

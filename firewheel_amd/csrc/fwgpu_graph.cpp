@@ -147,11 +147,14 @@ bool HostGraph::topo_order(std::vector<uint32_t>& order) {
     // graph/graph/compiler.rs:232-300 (Kahn BFS: graph_in first, other roots in slot order, out-edges in
     // edge-slot order, graph_out forced last)
     order.clear();
+    order.reserve(nodes.size());
     std::vector<int> in_degree(nodes.size(), 0);
     size_t alive = 0;
     for (const HostEdge& e : edges)
         if (e.alive) in_degree[e.dst] += 1;
-    std::deque<uint32_t> queue;
+    std::vector<uint32_t> queue;  // (a FIFO that only grows: read through `head`)
+    queue.reserve(nodes.size());
+    size_t head = 0;
     queue.push_back(graph_in_slot);
     for (uint32_t s = 0; s < nodes.size(); ++s) {
         if (!nodes[s].alive) continue;
@@ -163,12 +166,12 @@ bool HostGraph::topo_order(std::vector<uint32_t>& order) {
         if (!has_in) queue.push_back(s);
     }
     size_t visited = 0;
-    while (!queue.empty()) {
-        uint32_t s = queue.front();
-        queue.pop_front();
+    std::vector<int> outs;
+    while (head < queue.size()) {
+        uint32_t s = queue[head++];
         visited++;
         // outgoing edges in edge-slot order (the reference collects them by iterating the edge arena)
-        std::vector<int> outs;
+        outs.clear();
         for (const auto& pe : nodes[s].out_edges)
             for (int e : pe) outs.push_back(e);
         std::sort(outs.begin(), outs.end());

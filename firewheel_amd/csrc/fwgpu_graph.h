@@ -42,16 +42,101 @@ struct HostNode {
 inline int64_t make_id(uint32_t slot, uint32_t gen) { return (int64_t(gen) << 32) | int64_t(slot); }
 
 // IR handed to the executor
+// A node's port lists (buffer ids, producers): up to PORTS_INLINE ints sit inside the object, longer lists (wide SumNodes) on the
+// heap.  With std::vector a plan of config 3's 16 519 nodes was 66 000 small allocations to build and as many to drop — a third of
+// fwgpu_update's time.  Only what the planner uses of a vector.
+class PortInts {
+public:
+    static constexpr uint32_t PORTS_INLINE = 4;
+    PortInts() = default;
+    PortInts(const PortInts& o) { copy_from(o.data(), o.n_); }
+    PortInts(PortInts&& o) noexcept { steal(o); }
+    PortInts& operator=(const PortInts& o) {
+        if (this != &o) copy_from(o.data(), o.n_);
+        return *this;
+    }
+    PortInts& operator=(PortInts&& o) noexcept {
+        if (this != &o) {
+            drop();
+            steal(o);
+        }
+        return *this;
+    }
+    ~PortInts() { drop(); }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    int* data() { return heap_ ? heap_ : inl_; }
+    const int* data() const { return heap_ ? heap_ : inl_; }
+    int& operator[](size_t i) { return data()[i]; }
+    const int& operator[](size_t i) const { return data()[i]; }
+    int* begin() { return data(); }
+    int* end() { return data() + n_; }
+    const int* begin() const { return data(); }
+    const int* end() const { return data() + n_; }
+    void assign(size_t n, int v) {
+        reserve_exact(n, false);
+        n_ = (uint32_t)n;
+        int* d = data();
+        for (size_t i = 0; i < n; ++i) d[i] = v;
+    }
+    void resize(size_t n) {  // new elements are 0
+        const uint32_t old = n_;
+        reserve_exact(n, true);
+        int* d = data();
+        for (size_t i = old; i < n; ++i) d[i] = 0;
+        n_ = (uint32_t)n;
+    }
+    operator std::vector<int>() const { return std::vector<int>(begin(), end()); }
+
+private:
+    void reserve_exact(size_t n, bool keep) {
+        const uint32_t cap = heap_ ? cap_ : PORTS_INLINE;
+        if (n <= cap) return;
+        int* h = new int[n];
+        if (keep) {
+            const int* d = data();
+            for (uint32_t i = 0; i < n_; ++i) h[i] = d[i];
+        }
+        delete[] heap_;
+        heap_ = h;
+        cap_ = (uint32_t)n;
+    }
+    void copy_from(const int* src, uint32_t n) {
+        reserve_exact(n, false);
+        int* d = data();
+        for (uint32_t i = 0; i < n; ++i) d[i] = src[i];
+        n_ = n;
+    }
+    void steal(PortInts& o) {
+        heap_ = o.heap_;
+        cap_ = o.cap_;
+        n_ = o.n_;
+        for (uint32_t i = 0; i < PORTS_INLINE; ++i) inl_[i] = o.inl_[i];
+        o.heap_ = nullptr;
+        o.cap_ = 0;
+        o.n_ = 0;
+    }
+    void drop() {
+        delete[] heap_;
+        heap_ = nullptr;
+        cap_ = 0;
+        n_ = 0;
+    }
+    int* heap_ = nullptr;
+    uint32_t n_ = 0, cap_ = 0;
+    int inl_[PORTS_INLINE] = {0, 0, 0, 0};
+};
+
 struct PlanNode {
     uint32_t slot;
     int kind;
     int n_in, n_out;
     int level;
     int is_graph_io;            // 0, 1 = graph_in, 2 = graph_out
-    std::vector<int> in_buf;    // renamed buffer id, 0 = unconnected (zero buffer)
-    std::vector<int> out_buf;
-    std::vector<int> in_src_node;  // index into Plan::nodes of the producer, -1 = unconnected
-    std::vector<int> in_src_port;
+    PortInts in_buf;    // renamed buffer id, 0 = unconnected (zero buffer)
+    PortInts out_buf;
+    PortInts in_src_node;  // index into Plan::nodes of the producer, -1 = unconnected
+    PortInts in_src_port;
 };
 
 struct Plan {

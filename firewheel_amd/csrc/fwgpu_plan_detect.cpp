@@ -4,6 +4,28 @@
 namespace fwgpu {
 
 // ---------------------------------------------------------------- fused voice-bank plan detection
+namespace {
+// consumer counts per (node, output port), flat (a vector per node was 16 500 allocations on config 3)
+struct ConsCounts {
+    std::vector<int> off, cnt;
+    explicit ConsCounts(const Plan& plan) {
+        const int N = (int)plan.nodes.size();
+        off.resize(N + 1);
+        int t = 0;
+        for (int i = 0; i < N; ++i) {
+            off[i] = t;
+            t += plan.nodes[i].n_out;
+        }
+        off[N] = t;
+        cnt.assign(t, 0);
+        for (const PlanNode& n : plan.nodes)
+            for (int p = 0; p < n.n_in; ++p)
+                if (n.in_src_node[p] >= 0) cnt[off[n.in_src_node[p]] + n.in_src_port[p]]++;
+    }
+    const int* operator[](int node) const { return cnt.data() + off[node]; }
+    int n_out(int node) const { return off[node + 1] - off[node]; }
+};
+}  // namespace
 
 
 // `graph`: for the delay lengths (k_chain needs D >= one tile); `mbf` must then be a multiple of the tile
@@ -13,11 +35,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
     const PlanNode& gout = plan.nodes.back();
     if (gout.is_graph_io != 2 || gout.n_in != 2) return false;
     // consumer counts per (node, port)
-    std::vector<std::vector<int>> cons(N);
-    for (int i = 0; i < N; ++i) cons[i].assign(plan.nodes[i].n_out, 0);
-    for (const PlanNode& n : plan.nodes)
-        for (int p = 0; p < n.n_in; ++p)
-            if (n.in_src_node[p] >= 0) cons[n.in_src_node[p]][n.in_src_port[p]]++;
+    const ConsCounts cons(plan);
     auto stereo_src = [&](const PlanNode& n, int port0, int& src) -> bool {
         int a = n.in_src_node[port0], b = n.in_src_node[port0 + 1];
         if (a < 0 || a != b) return false;
@@ -45,8 +63,8 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
     for (int i = 0; i < N; ++i)
         if (plan.nodes[i].is_graph_io == 1) {
             covered[i] = 1;
-            for (int cnt : cons[i])
-                if (cnt) return false;  // graph inputs feed the graph: generic executor
+            for (int p = 0; p < cons.n_out(i); ++p)
+                if (cons[i][p]) return false;  // graph inputs feed the graph: generic executor
         }
     // walk the sum tree breadth-first
     struct SumRec {
@@ -269,11 +287,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
 // otherwise through the voice-bank plan's (k_leaf_sum: stage programs, resampler sources).
 bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedBuild& fb) {
     const int N = (int)plan.nodes.size();
-    std::vector<std::vector<int>> cons(N);
-    for (int i = 0; i < N; ++i) cons[i].assign(plan.nodes[i].n_out, 0);
-    for (const PlanNode& n : plan.nodes)
-        for (int p = 0; p < n.n_in; ++p)
-            if (n.in_src_node[p] >= 0) cons[n.in_src_node[p]][n.in_src_port[p]]++;
+    const ConsCounts cons(plan);
     auto stereo_src = [&](const PlanNode& n, int port0, int& src) -> bool {  // both channels from ONE node, consumed once each
         int a = n.in_src_node[port0], b = n.in_src_node[port0 + 1];
         if (a < 0 || a != b) return false;

@@ -274,6 +274,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     c->release_device();
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->h_up) (void)hipHostFree(c->h_up);
+    if (c->h_jobs) (void)hipHostFree(c->h_jobs);
     DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_rt_sync, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask, &c->d_trace, &c->d_rs_table};
     for (DevBuf* b : bufs) b->release();

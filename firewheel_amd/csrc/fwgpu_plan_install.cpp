@@ -63,7 +63,7 @@ void quiet_window(fwgpu_ctx* c) {
 // OPERATION on the build's stream, not per byte: every copy / fill / small kernel that lands beside a callback costs it ~25-40 us
 // whatever its size (its dispatch and its end-of-kernel cache write-back / invalidate reach the audio kernels' L2 lines), and a
 // build made ~25 of them.  Now up() / zero() / the strided clears only record JOBS; the changed chunks wait in the pinned arena;
-// build_apply() sends the job list the same way and launches k_build_apply ONCE — a grid of (blocks, jobs) that copies from pinned
+// build_apply() puts the job list into pinned memory too and launches k_build_apply ONCE — a grid of (blocks, jobs) that copies from pinned
 // host memory over PCIe and fills — in a window with no process call in flight.  (FWGPU_BUILD_ONE_KERNEL=0: the calls go out one by
 // one, in pieces while a stream is live, as before.)
 static int build_apply(fwgpu_ctx* c) {
@@ -104,21 +104,35 @@ static int build_apply(fwgpu_ctx* c) {
             }
         }
     }
-    // (up() keeps room for the uncut list behind the tables and 64 KiB more; a cut list that still does not fit — a tiny
-    //  FWGPU_UP_PIECE against megabytes of changed tables — is dropped for the uncut one)
-    if (c->h_up_used + jobs.size() * sizeof(BuildJob) > c->h_up_cap) jobs = c->build_jobs;
     c->build_jobs.clear();
+    // the list travels in pinned memory of its own (the kernel reads it over PCIe), grown on this — the control — thread
     const size_t jb = jobs.size() * sizeof(BuildJob);
-    if (c->h_up_used + jb > c->h_up_cap) return fail(c, FWGPU_ERR_DEVICE, "plan build: no room for the job list in the upload arena");
-    BuildJob* at = (BuildJob*)(c->h_up + c->h_up_used);
+    if (jb > c->h_jobs_cap) {
+        if (c->h_jobs) {
+            HIPC(c, hipStreamSynchronize(c->up_stream));  // (a launch of an earlier flush may still read the old list)
+            (void)hipHostFree(c->h_jobs);
+        }
+        c->h_jobs = nullptr;
+        c->h_jobs_cap = 0;
+        const size_t cap = std::max<size_t>(2 * jb, (size_t)64 << 10);
+        HIPC(c, hipHostMalloc((void**)&c->h_jobs, cap, hipHostMallocDefault));
+        c->h_jobs_cap = cap;
+        c->h_jobs_used = 0;
+    }
+    if (c->h_jobs_used + jb > c->h_jobs_cap) {  // (earlier flushes of this build used the front: wait for them, start over)
+        HIPC(c, hipStreamSynchronize(c->up_stream));
+        c->h_jobs_used = 0;
+    }
+    BuildJob* at = (BuildJob*)(c->h_jobs + c->h_jobs_used);
     memcpy(at, jobs.data(), jb);
-    c->h_up_used += (jb + 255) & ~(size_t)255;
+    c->h_jobs_used += jb;
     size_t i = 0;
     while (i < jobs.size()) {
         size_t k = i, cost = 0;
         while (k < jobs.size()) {
             const size_t jc = jobs[k].src ? (size_t)jobs[k].row_bytes : (size_t)jobs[k].row_bytes * jobs[k].rows / 32;
             if (live && k > i && cost + jc > cp) break;
+            if (k - i >= 32768) break;  // (jobs are the grid's y dimension)
             cost += jc;
             ++k;
         }
@@ -129,10 +143,9 @@ static int build_apply(fwgpu_ctx* c) {
     }
     return 0;
 }
-// room in the pinned arena for `need` more bytes plus the job list; what is pending goes out first if there is none
+// room in the pinned arena for `need` more bytes; what is pending goes out first if there is none
 static int arena_room(fwgpu_ctx* c, size_t need) {
-    // (the list may be cut into group-sized jobs: one more per up_piece of copy / 32 up_pieces of fill; 64 KiB covers 1 300 of them)
-    const size_t jobs_room = (c->build_jobs.size() + 64) * sizeof(BuildJob) + (64u << 10);
+    const size_t jobs_room = 0;
     if (c->h_up && c->h_up_used + need + jobs_room <= c->h_up_cap) return 0;
     int rc = build_apply(c);
     if (rc) return rc;
@@ -401,6 +414,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
     reset_for_build(P);
     c->build_jobs.clear();
     c->h_up_used = 0;
+    c->h_jobs_used = 0;
     P.kmax = c->kmax_req;
     P.gen = ++c->build_gen;
     c->update_phase = 21;

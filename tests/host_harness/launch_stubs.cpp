@@ -1,6 +1,7 @@
 // TEST DOUBLE (see fakehip/hip/hip_runtime_api.h): the kernel launch wrappers of fwgpu_kernels.hip as counted no-ops.
 // Nothing is computed; the harness only lets the host half of libfwgpu run on the CPU tier.
 #include "../../firewheel_amd/csrc/fwgpu_launch.h"
+#include "../../firewheel_amd/csrc/fwgpu_graph.h"  // PortInts (self-test below)
 
 namespace {
 unsigned long long g_launches[8];  // 0 level, 1 voice_control, 2 leaf_sum, 3 chain, 4 bus_sum, 5 root_out, 6 fir, 7 other
@@ -581,3 +582,54 @@ int launch_scatter_ext(hipStream_t, float* ext, const void* d_items, int n) {
     return 0;
 }
 }  // namespace fwgpu
+
+// PortInts (fwgpu_graph.h): the planner's port lists, inline up to 4 ints.  Returns 0, or the number of the check that failed.
+extern "C" int fwh_portints_selftest(void) {
+    using fwgpu::PortInts;
+    auto eq = [](const PortInts& a, std::initializer_list<int> want) {
+        if (a.size() != want.size()) return false;
+        size_t i = 0;
+        for (int w : want)
+            if (a[i++] != w) return false;
+        return true;
+    };
+    PortInts a;
+    if (!a.empty() || a.size() != 0 || a.begin() != a.end()) return 1;
+    a.assign(3, -1);
+    if (!eq(a, {-1, -1, -1})) return 2;
+    a[1] = 7;
+    a.resize(4);                                   // still inline, the new element 0
+    if (!eq(a, {-1, 7, -1, 0})) return 3;
+    a.resize(6);                                   // to the heap, contents kept
+    a[5] = 9;
+    if (!eq(a, {-1, 7, -1, 0, 0, 9})) return 4;
+    PortInts b = a;                                // copy of a heap list
+    b[0] = 1;
+    if (!eq(a, {-1, 7, -1, 0, 0, 9}) || !eq(b, {1, 7, -1, 0, 0, 9})) return 5;
+    PortInts c2 = std::move(b);                    // move: the source is left empty and usable
+    if (!eq(c2, {1, 7, -1, 0, 0, 9}) || !b.empty()) return 6;
+    b.assign(2, 5);
+    if (!eq(b, {5, 5})) return 7;
+    c2 = b;                                        // a short list over a heap one (capacity reused)
+    if (!eq(c2, {5, 5})) return 8;
+    c2.resize(1);
+    if (!eq(c2, {5})) return 9;
+    a = std::move(c2);                             // move-assign over a heap list
+    if (!eq(a, {5}) || !c2.empty()) return 10;
+    PortInts d;
+    d.assign(64, 3);                               // a wide SumNode
+    d[63] = 4;
+    std::vector<int> v = d;
+    if (v.size() != 64 || v[0] != 3 || v[63] != 4) return 11;
+    std::vector<int> tab{1};
+    tab.insert(tab.end(), d.begin() + 62, d.end());
+    if (tab.size() != 3 || tab[1] != 3 || tab[2] != 4) return 12;
+    a = a;                                         // self-assignment
+    if (!eq(a, {5})) return 13;
+    std::vector<fwgpu::PlanNode> nodes(3);         // inside a vector that reallocates (moves its elements)
+    nodes[0].in_buf.assign(2, 8);
+    nodes[1].in_buf.assign(70, 6);
+    for (int i = 0; i < 100; ++i) nodes.emplace_back();
+    if (!eq(nodes[0].in_buf, {8, 8}) || nodes[1].in_buf.size() != 70 || nodes[1].in_buf[69] != 6) return 14;
+    return 0;
+}

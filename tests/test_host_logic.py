@@ -566,3 +566,11 @@ def test_quiet_window_look_ahead_rule():
     assert f(start + 195 * us, start, 199 * us, 80 * us, M) == 0       # gaps shorter than two margins: likewise
     assert f(start + 195 * us, start, 201 * us, 80 * us, M) == 1       # ... just long enough
     assert f(start + 10 * us, start, 300_000 * us, dur, M) == 0        # a "period" of 300 ms is a pause, not a rhythm
+
+
+def test_port_lists_container_selftest():
+    """fwgpu_graph.h, PortInts — the planner's per-node port lists (inline up to 4 ints, heap beyond): copies, moves, growth across
+    the inline / heap border, conversion to a vector, life inside a reallocating vector (C++ self-test in the harness)."""
+    f = fwapi.hostonly_lib().fwh_portints_selftest
+    f.restype = C.c_int
+    assert f() == 0

@@ -412,6 +412,8 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     bool up_diff = true;            // FWGPU_UP_DIFF=0: every table uploaded whole, every build
     bool build_one_kernel = true;   // FWGPU_BUILD_ONE_KERNEL=0: the build's copies / fills as separate runtime calls
     std::vector<BuildJob> build_jobs;  // control thread: what build_apply will launch (fwgpu_plan_install.cpp)
+    bool build_on_audio_stream = false;  // FWGPU_BUILD_STREAM=audio (experiment, see build_apply)
+    hipEvent_t ev_build = nullptr;
     char* h_jobs = nullptr;            // ... and the pinned memory the launched lists travel in
     size_t h_jobs_cap = 0, h_jobs_used = 0;
     bool rt_persist = true;        // FWGPU_RT_PERSIST=0: every callback is its own launch (k_rt_block)

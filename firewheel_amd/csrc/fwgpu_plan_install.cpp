@@ -137,8 +137,19 @@ static int build_apply(fwgpu_ctx* c) {
             ++k;
         }
         if (live) quiet_window(c);
-        LCHK(c, launch_build_apply(c->up_stream, at + i, (int)(k - i)));
-        if (live) HIPC(c, hipStreamSynchronize(c->up_stream));
+        if (c->build_on_audio_stream) {
+            // EXPERIMENT for the next round (FWGPU_BUILD_STREAM=audio, never measured): the fixed ~27 us a callback pays per operation
+            // on the build's stream may be the price of waking an idle hardware queue beside the audio one.  The same groups in the
+            // AUDIO stream — the jobs only touch the image nobody reads, HIP streams take launches from two threads — would cost
+            // a callback their own few microseconds instead.  Waited for through an event (the stream itself never idles).
+            if (!c->ev_build) HIPC(c, hipEventCreateWithFlags(&c->ev_build, hipEventDisableTiming));
+            LCHK(c, launch_build_apply(c->stream, at + i, (int)(k - i)));
+            HIPC(c, hipEventRecord(c->ev_build, c->stream));
+            HIPC(c, hipEventSynchronize(c->ev_build));
+        } else {
+            LCHK(c, launch_build_apply(c->up_stream, at + i, (int)(k - i)));
+            if (live) HIPC(c, hipStreamSynchronize(c->up_stream));
+        }
         i = k;
     }
     return 0;

@@ -574,3 +574,55 @@ def test_port_lists_container_selftest():
     f = fwapi.hostonly_lib().fwh_portints_selftest
     f.restype = C.c_int
     assert f() == 0
+
+
+def test_a_build_larger_than_the_upload_arena_goes_out_in_flushes_and_stays_whole(monkeypatch):
+    """fwgpu_plan_install.cpp, arena_room / build_apply: 24 000 voices (72 000 nodes) are ~16 MB of tables against an 8 MB pinned
+    arena — the pending jobs are applied and waited for whenever the arena fills, and nothing is lost on the way (the harness stubs
+    check every table of every launch); the same image's next build then finds its tables unchanged and sends almost nothing."""
+    import ctypes as C
+
+    from fwapi import HostOnlyEngine, hostonly_lib
+
+    for k in ("FWGPU_UP_PIECE", "FWGPU_UP_DIFF", "FWGPU_BUILD_ONE_KERNEL", "FWGPU_QUIET_WAIT_US", "FWGPU_BUILD_STREAM"):
+        monkeypatch.delenv(k, raising=False)
+    L = hostonly_lib()
+    L.fwh_build_applies.restype = C.c_ulonglong
+    L.fwh_h2d_total.restype = C.c_ulonglong
+    L.fwh_violation_reset()
+    e = HostOnlyEngine(max_block_frames=128, max_batch=4)
+    ends = []
+    for v in range(24000):
+        s, vol, pan = e.sampler(100.0), e.volume(50.0), e.pan(0.1)
+        e.connect_stereo(s, vol)
+        e.connect_stereo(vol, pan)
+        ends.append(pan)
+    level = ends
+    while len(level) > 1:
+        nxt = []
+        for i in range(0, len(level), 32):
+            grp = level[i:i + 32]
+            m = e.sum(len(grp))
+            for p, n in enumerate(grp):
+                e.connect_stereo(n, m, 2 * p)
+            nxt.append(m)
+        level = nxt
+    scenarios.connect_through_master(e, level[0], ())
+    L.fwh_h2d_reset()
+    a0 = L.fwh_build_applies()
+    e.update()
+    first = L.fwh_h2d_total()
+    assert first > 12 << 20 and L.fwh_build_applies() - a0 >= 2, (first, L.fwh_build_applies() - a0)   # more than one arena's worth
+    assert e.cx.plan_kind() == 1 and e.cx.plan_fused_voices() == 24000
+    e.process_blocks(4)
+    assert e.violation() == "", e.violation()
+    sent = []
+    for k in range(3):                            # edits that leave every table as it was (a node nobody is connected to comes and goes)
+        x = e.volume(3.0)
+        e.remove_node(x)
+        L.fwh_h2d_reset()
+        e.update()
+        sent.append(L.fwh_h2d_total())
+        e.process_blocks(4)
+        assert e.violation() == "", e.violation()
+    assert sent[0] > 4 << 20 and max(sent[1:]) < 1 << 20, sent   # the OTHER image's first build is whole; after that: chunks

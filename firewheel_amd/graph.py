@@ -444,6 +444,11 @@ class FirewheelGpuCtx(object):
         self._check(self.L.fwgpu_plan_handover_stats(self.c, C.byref(a), C.byref(b), C.byref(m)))
         return a.value, b.value, m.value
 
+    def update_phase(self):
+        """which part of fwgpu_update the control thread is in right now (0 none, 1 graph compile, 21..28 table sections, 3 the
+        build's device work); any thread may ask"""
+        return int(self.L.fwgpu_update_phase(self.c))
+
     def plan_chain_stats(self):
         """(steady, general): k_chain workgroup launches that ran the steady-call loop / the general loop"""
         a, b = C.c_uint64(0), C.c_uint64(0)

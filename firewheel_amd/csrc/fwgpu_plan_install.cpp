@@ -156,17 +156,16 @@ static int build_apply(fwgpu_ctx* c) {
 }
 // room in the pinned arena for `need` more bytes; what is pending goes out first if there is none
 static int arena_room(fwgpu_ctx* c, size_t need) {
-    const size_t jobs_room = 0;
-    if (c->h_up && c->h_up_used + need + jobs_room <= c->h_up_cap) return 0;
+    if (c->h_up && c->h_up_used + need <= c->h_up_cap) return 0;
     int rc = build_apply(c);
     if (rc) return rc;
     HIPC(c, hipStreamSynchronize(c->up_stream));  // what is in flight has left the arena
     c->h_up_used = 0;
-    if (!c->h_up || need + jobs_room > c->h_up_cap) {
+    if (!c->h_up || need > c->h_up_cap) {
         if (c->h_up) (void)hipHostFree(c->h_up);
         c->h_up = nullptr;
         c->h_up_cap = 0;
-        const size_t cap = std::max<size_t>(need + jobs_room, (size_t)8 << 20);
+        const size_t cap = std::max<size_t>(need, (size_t)8 << 20);
         HIPC(c, hipHostMalloc((void**)&c->h_up, cap, hipHostMallocDefault));
         c->h_up_cap = cap;
     }

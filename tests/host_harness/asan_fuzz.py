@@ -29,4 +29,6 @@ for seed in range(n):
     F.fuzz_stream(fwapi.HostOnlyEngine(max_block_frames=mbf, num_graph_inputs=n_in, max_batch=int(pick.choice([1, 3, 64]))), seed, n_in)
 L.fwh_violation.restype = C.c_char_p
 assert L.fwh_violation() == b"", L.fwh_violation()
+L.fwh_portints_selftest.restype = C.c_int
+assert L.fwh_portints_selftest() == 0   # (the planner's port-list container: copies / moves across its inline / heap border, under ASan)
 print("ok", n)

@@ -4,6 +4,7 @@
 #include "fwgpu_ctx.h"
 
 #include <chrono>
+#include <memory>
 #include <stdio.h>
 
 namespace {
@@ -192,7 +193,10 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
             c->h_rt_flag = c->d_rt_flag = nullptr;
         }
     }
-    if (const char* e = getenv("FWGPU_CTL_AHEAD")) c->ctl_ahead = atoi(e) != 0;
+    if (const char* e = getenv("FWGPU_CTL_AHEAD")) {
+        c->ctl_ahead = atoi(e) != 0;
+        if (atoi(e) == 1) c->ctl_ahead_mode = 1;
+    }
     if (c->ctl_ahead) {  // its own high-priority stream + the events that order it against the render stream
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -428,7 +432,10 @@ int fwgpu_update(fwgpu_ctx* c) {
         return fail(c, rc, err);
     }
     c->update_phase = 2;
-    rc = install_plan(c, plan);
+    {
+        RtHold hold(c);  // table growth frees device memory (hipFree waits for every stream): no resident realtime kernel meanwhile
+        rc = install_plan(c, plan);
+    }
     c->update_phase = 0;
     return rc;
 }
@@ -486,6 +493,7 @@ int fwgpu_schedule_upload(fwgpu_ctx* c, const fwgpu_sched_node* sn, uint32_t n_n
     if (plan.nodes.front().is_graph_io != 1 || plan.nodes.back().is_graph_io != 2)
         return fail(c, FWGPU_ERR_INVALID, "schedule must start with graph_in and end with graph_out");
     finalize_plan(plan);
+    RtHold hold(c);  // (as fwgpu_update)
     return install_plan(c, plan);
 }
 
@@ -532,6 +540,10 @@ int fwgpu_plan_handover_stats(fwgpu_ctx* c, uint64_t* adoptions, uint64_t* audio
     if (audio_adoptions) *audio_adoptions = c->audio_adoptions;
     if (max_adopt_ns) *max_adopt_ns = c->adopt_ns_max;
     return 0;
+}
+int fwgpu_plan_pending(fwgpu_ctx* c) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    return c->pending.load(std::memory_order_acquire) != nullptr ? 1 : 0;
 }
 int fwgpu_rt_resident_stats(fwgpu_ctx* c, uint64_t* launches, uint64_t* doorbells) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
@@ -594,6 +606,11 @@ static int sample_add(fwgpu_ctx* c, int format, uint32_t channels, uint64_t fram
     r.desc.format = format;
     // the data is in HBM; now the table entry — what a process call reads — under the gate: no process call is running, the
     // next one finds the whole entry (and the room for it on the device) in place
+    // (a table that has to grow frees its old device copy: hipFree waits for every stream, so the resident realtime kernel is told
+    //  to end BEFORE the gate is taken — behind the gate the audio thread could not ring it out, and the free would sit out its
+    //  20 ms watchdog with the audio thread parked at its entry: ADVICE r3)
+    const bool grows = (c->samples.size() + 1) * sizeof(SampleDesc) > c->d_samples.cap;
+    std::unique_ptr<RtHold> hold(grows ? new RtHold(c) : nullptr);
     ControlGate gate(c);
     c->samples.push_back(r);
     c->sample_refs.push_back(0);
@@ -622,6 +639,7 @@ int fwgpu_sample_destroy(fwgpu_ctx* c, int sample) {
         if (n.alive && (n.kind == K_FIR || n.kind == K_RESAMPLER) && n.init.sample == sample)
             return fail(c, FWGPU_ERR_INVALID, "sample is in use by a FIR / resampler node");
     use_device(c);
+    RtHold hold(c);       // the resident realtime kernel ends now, and none is launched until the data is gone
     ControlGate gate(c);  // no process call runs while the entry is emptied and the data freed
     (void)rt_persist_stop(c);  // ... and no resident realtime kernel: between two callbacks it may be fetching the frames a voice reads next
     (void)hipStreamSynchronize(c->stream);
@@ -878,6 +896,16 @@ static int process_interleaved_impl(fwgpu_ctx* c, const float* input, float* out
         if (!done) {
             if (c->rtp.launched) HIPC(c, hipStreamSynchronize(c->rt_stream));
             HIPC(c, hipStreamSynchronize(c->stream));
+            // the streams are empty — which says the block was rendered only if its completion flag says so too: a resident kernel that
+            // waited for another number has ended on its watchdog WITHOUT rendering this one.  One ordinary launch of the
+            // block, then the flag must be there; stale audio is never copied out as if it were this block's.
+            if (spin && c->rt_signalled && *(volatile unsigned long long*)c->h_rt_flag != c->rt_seq) {
+                rc = rt_block_relaunch(c, c->d_rt_out, c->rt_seq);
+                if (rc) return rc;
+                HIPC(c, hipStreamSynchronize(c->stream));
+                if (*(volatile unsigned long long*)c->h_rt_flag != c->rt_seq)
+                    return fail(c, FWGPU_ERR_DEVICE, "realtime block was not rendered (completion flag missing after a stream sync)");
+            }
         }
         c->ret_done_ticket.store(c->ret_ticket, std::memory_order_release);  // everything this call handed back is final
         if (out_bytes) memcpy(output, c->h_rt_out, out_bytes);

@@ -335,6 +335,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     // the render kernels read exists twice (parity = batch number & 1); what orders the two streams is one event per parity and
     // direction.  The kernels do not know: they get pointers.
     bool ctl_ahead = true;           // wanted (default since round 3; FWGPU_CTL_AHEAD=0 switches it off)
+    int ctl_ahead_mode = 2;          // 1 = every qualifying call (round 3), 2 = only calls with messages / continuing glides (round 4)
     hipStream_t ctl_stream = nullptr;
     hipEvent_t ev_ctl[2] = {nullptr, nullptr}, ev_render[2] = {nullptr, nullptr}, ev_join = nullptr;
     uint64_t ahead_seq = 0;          // batches launched in ahead mode since the streams were last joined
@@ -428,6 +429,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
         const void* blks = nullptr;       // (the FusedView the kernel was launched with: any difference means a new launch)
         unsigned long long next_seq = 0;  // the doorbell value it waits for
         uint64_t launches = 0, doorbells = 0;
+        uint64_t held = 0;                // launches not made because a control call held the device (RtHold)
     } rtp;
     bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2
     DevBuf d_rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS]
@@ -573,6 +575,33 @@ struct ControlGate {
     ~ControlGate() { c->gate.store(0, std::memory_order_release); }
 };
 
+// A control call that may free device memory, free pinned memory or wait for the device holds this for its duration: hipFree /
+// hipHostFree / hipDeviceSynchronize wait for every stream of the device, and the resident realtime kernel (k_rt_persist on
+// rt_stream) ends only when it is told to or after 20 ms without a doorbell — a steady stream of callbacks keeps it alive for
+// ever, and the control call with it.  Raising RtMailbox::hold makes the kernel end at its next poll (it finishes
+// the block it is rendering) and keeps the audio side from launching another: its callbacks go out as ordinary launches
+// (k_rt_block, +4 us each) until the last holder lets go.  Dekker pair with rt_persist_launch: [hold++ ; read alive] here,
+// [alive = 1 ; read hold] there, both sequentially consistent — either the launch sees the hold, or this sees the kernel.
+struct RtHold {
+    fwgpu_ctx* c;
+    explicit RtHold(fwgpu_ctx* ctx) : c(ctx) {
+        if (!c || !c->h_rt_mb) return;
+        __atomic_fetch_add(&c->h_rt_mb->hold, 1ull, __ATOMIC_SEQ_CST);
+        const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(10 * (long)c->rt_idle_ms + 50);
+        for (unsigned spins = 1; __atomic_load_n(&c->h_rt_mb->alive, __ATOMIC_SEQ_CST); ++spins) {
+            if ((spins & 255u) == 0) {
+                if (std::chrono::steady_clock::now() > give_up) break;  // (a device that does not answer: the call's own HIP errors name it)
+                std::this_thread::yield();
+            }
+        }
+    }
+    ~RtHold() {
+        if (c && c->h_rt_mb) __atomic_fetch_sub(&c->h_rt_mb->hold, 1ull, __ATOMIC_SEQ_CST);
+    }
+    RtHold(const RtHold&) = delete;
+    RtHold& operator=(const RtHold&) = delete;
+};
+
 // ---- fwgpu_plan_install.cpp
 // control side, before a piece of GPU work that is not the audio path's: returns when no process call is in flight, or after
 // c->quiet_wait_us
@@ -591,7 +620,7 @@ int upload(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes);
 int upload_sample_table(fwgpu_ctx* c);
 int join_streams(fwgpu_ctx* c);  // control-ahead mode: both streams wait for each other's work so far (no host wait)
 void drain_ring(fwgpu_ctx* c);  // ring -> cmds (consumer side: the audio thread, or an edit call that does not overlap it)
-int upload_cmds(fwgpu_ctx* c);
+int upload_cmds(fwgpu_ctx* c, bool drained = false);  // drained: the caller has emptied the ring into cmds already
 int rt_persist_stop(fwgpu_ctx* c);
 int rt_block_relaunch(fwgpu_ctx* c, float* d_out, unsigned long long seq);  // after the watchdog race: the same block through k_rt_block  // ends the resident realtime kernel, if one is running, and waits for it
 void finish_returns(fwgpu_ctx* c);  // end of a process call: completion event for the samples it handed back

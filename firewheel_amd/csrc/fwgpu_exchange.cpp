@@ -46,6 +46,7 @@ struct fwgpu_bus_exchange {
     unsigned long long reduced = 0;    // steps reduced so far
     unsigned long long budget_ticks = 300000000ull;  // 3 s at 100 MHz
     bool have_ipc = false;
+    bool failed = false;               // status() has seen the device's sticky error word: push / reduce refuse from then on
     hipIpcMemHandle_t ipc{};
 };
 
@@ -59,6 +60,7 @@ fwgpu_bus_exchange* fwgpu_bus_exchange_open(fwgpu_ctx* c, uint32_t rank, uint32_
     }
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != c->device) (void)hipSetDevice(c->device);
+    RtHold hold(c);  // hipDeviceSynchronize / hipFree below wait for every stream: no resident realtime kernel meanwhile
     fwgpu_bus_exchange* ex = new (std::nothrow) fwgpu_bus_exchange();
     if (!ex) {
         fail(c, FWGPU_ERR_DEVICE, "bus exchange: out of host memory");
@@ -102,6 +104,7 @@ fwgpu_bus_exchange* fwgpu_bus_exchange_open(fwgpu_ctx* c, uint32_t rank, uint32_
 
 void fwgpu_bus_exchange_close(fwgpu_bus_exchange* ex) {
     if (!ex) return;
+    RtHold hold(ex->ctx);
     if (ex->ctx) (void)hipStreamSynchronize(ex->ctx->stream);
     for (int p = 0; p < ex->geom.world; ++p)
         if (ex->ipc_mapped[p] && ex->peers.base[p]) (void)hipIpcCloseMemHandle(ex->peers.base[p]);
@@ -176,8 +179,14 @@ int fwgpu_bus_exchange_push(fwgpu_bus_exchange* ex, const float* d_partial, cons
     AudioCallScope audio;
     if (!d_partial || n_floats == 0 || n_floats > ex->geom.max_floats || ((uintptr_t)d_partial & 15u))
         return fail(c, FWGPU_ERR_INVALID, "bus exchange: partial bus null, unaligned or longer than the slots");
-    const uint64_t n_sil = d_silence ? (uint64_t)n_blocks * n_channels : 0;
-    if (n_sil > ex->max_sil) return fail(c, FWGPU_ERR_INVALID, "bus exchange: more silence flags than the slots hold");
+    // (a rank that reports no flags still CLEARS its slot's flag bytes — "nothing is silent" — for the blocks of the step: a peer
+    //  that reduces with flags reads them, and what an earlier step left there is not this step's: ADVICE r3)
+    uint64_t n_sil = (uint64_t)n_blocks * n_channels;
+    if (n_sil > ex->max_sil) {
+        if (d_silence) return fail(c, FWGPU_ERR_INVALID, "bus exchange: more silence flags than the slots hold");
+        n_sil = ex->max_sil;
+    }
+    if (ex->failed) return fail(c, FWGPU_ERR_DEVICE, "bus exchange: a peer did not arrive in an earlier step; the exchange is closed (reopen it on every rank)");
     for (int p = 0; p < ex->geom.world; ++p)
         if (!ex->connected[p]) return fail(c, FWGPU_ERR_INVALID, "bus exchange: not every peer is connected");
     if (ex->seq != ex->reduced) return fail(c, FWGPU_ERR_INVALID, "bus exchange: push without the previous step's reduce");
@@ -195,6 +204,7 @@ int fwgpu_bus_exchange_reduce(fwgpu_bus_exchange* ex, float* d_out, uint8_t* d_o
     AudioCallScope audio;
     if (!d_out || n_floats == 0 || n_floats > ex->geom.max_floats || ((uintptr_t)d_out & 15u))
         return fail(c, FWGPU_ERR_INVALID, "bus exchange: output null, unaligned or longer than the slots");
+    if (ex->failed) return fail(c, FWGPU_ERR_DEVICE, "bus exchange: a peer did not arrive in an earlier step; the exchange is closed (reopen it on every rank)");
     if (ex->reduced + 1 != ex->seq) return fail(c, FWGPU_ERR_INVALID, "bus exchange: reduce without a push");
     uint64_t n_sil = 0;
     if (have_silence) {
@@ -227,7 +237,10 @@ int fwgpu_bus_exchange_status(fwgpu_bus_exchange* ex, uint64_t* steps, uint64_t*
     HIPC(c, hipMemcpy(&err, ex->region + EX_ERR_OFF, sizeof(err), hipMemcpyDeviceToHost));
     if (steps) *steps = ex->reduced;
     if (failed_step) *failed_step = err;
-    if (err) return fail(c, FWGPU_ERR_DEVICE, "bus exchange: a peer did not arrive within the time budget (its bus was replaced by zeros)");
+    if (err) {
+        ex->failed = true;  // (the device side is out of the exchange already — k_bus_push; from here on the host says so too)
+        return fail(c, FWGPU_ERR_DEVICE, "bus exchange: a peer did not arrive within the time budget (its bus was replaced by zeros)");
+    }
     return 0;
 }
 

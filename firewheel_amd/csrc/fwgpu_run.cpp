@@ -111,8 +111,8 @@ void drain_ring(fwgpu_ctx* c) {
     }
 }
 
-int upload_cmds(fwgpu_ctx* c) {
-    drain_ring(c);
+int upload_cmds(fwgpu_ctx* c, bool drained) {
+    if (!drained) drain_ring(c);
     c->n_cmds_dev = (int)c->cmds.size();
     // the voices these messages go to, then the ones of the call before (a glide started there may still be running)
     c->hot_now.clear();
@@ -473,7 +473,12 @@ static int rt_persist_launch(fwgpu_ctx* c, const FusedView& fv, const DevView& v
     fwgpu_ctx::RtResident& r = c->rtp;
     HIPC(c, hipEventRecord(c->rt_ev, c->stream));  // behind everything the ctx stream holds (adoption launches, uploads)
     HIPC(c, hipStreamWaitEvent(c->rt_stream, c->rt_ev, 0));
-    c->h_rt_mb->alive = 1;
+    __atomic_store_n(&c->h_rt_mb->alive, 1ull, __ATOMIC_SEQ_CST);
+    if (__atomic_load_n(&c->h_rt_mb->hold, __ATOMIC_SEQ_CST)) {  // a control call holds the device (RtHold): no resident kernel now
+        __atomic_store_n(&c->h_rt_mb->alive, 0ull, __ATOMIC_SEQ_CST);
+        r.held++;
+        return 1;  // (the caller renders this block with an ordinary launch)
+    }
     __atomic_store_n(&c->h_rt_mb->doorbell, seq, __ATOMIC_RELEASE);
     unsigned long long* go = (unsigned long long*)((char*)c->d_rt_sync.p + 128);
     // (the kernel before this one may have left `seq | quit` there — its watchdog fired while it waited for this very number)
@@ -527,7 +532,8 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         if (c->rt_persist && c->rt_stream && flag && c->n_cmds_dev == 0 && !c->host_prof && cmd_block0 == 0) {
             fwgpu_ctx::RtResident& r = c->rtp;
             const unsigned long long seq = c->rt_signal_seq;
-            if (r.launched && c->h_rt_mb->alive && r.epoch == c->epoch && r.d_out == d_out && r.blks == fv.blks && r.next_seq == seq) {
+            if (r.launched && c->h_rt_mb->alive && r.epoch == c->epoch && r.d_out == d_out && r.blks == fv.blks && r.next_seq == seq &&
+                !__atomic_load_n(&c->h_rt_mb->hold, __ATOMIC_RELAXED)) {
                 __atomic_store_n(&c->h_rt_mb->doorbell, seq, __ATOMIC_RELEASE);
                 r.next_seq = seq + 1;
                 r.doorbells++;
@@ -535,7 +541,11 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
             }
             int rc = rt_persist_stop(c);  // (the watchdog ended it, or it was launched for another plan / epoch / output block)
             if (rc) return rc;
-            return rt_persist_launch(c, fv, v, d_out, cmd_block0, seq);
+            if (!__atomic_load_n(&c->h_rt_mb->hold, __ATOMIC_SEQ_CST)) {
+                rc = rt_persist_launch(c, fv, v, d_out, cmd_block0, seq);
+                if (rc <= 0) return rc;
+            }
+            // a control call holds the device: this callback is an ordinary launch (below)
         }
         {
             int rc = rt_persist_stop(c);
@@ -681,8 +691,13 @@ static int run_blocks_impl(fwgpu_ctx* c, uint64_t frames, const float* d_in, int
         rc = rt_persist_stop(c);
         if (rc) return rc;
     }
-    // control-ahead mode for this call?  Whole blocks only, more than one, no event timers, not the realtime edge
-    const bool ahead = c->ctl_ahead_on && can_fuse && !c->timing && !stable_out && frames % mbf == 0 && frames / mbf > 1;
+    // control-ahead mode for this call?  Whole blocks only, more than one, no event timers, not the realtime edge — and (round 4,
+    // FWGPU_CTL_AHEAD=2, the default) only a call that has something to hide: a message on the list, or voices the call before
+    // sent messages to (their glides continue).  A message-free call's control kernel is ~8 us of steady tails; beside the render
+    // kernel of the call before it cost that kernel 7-15 us of co-residency and the step a ~10 us cross-stream event.
+    drain_ring(c);
+    const bool hot = c->ctl_ahead_mode == 1 || !c->cmds.empty() || !c->hot_prev.empty();
+    const bool ahead = c->ctl_ahead_on && hot && can_fuse && !c->timing && !stable_out && frames % mbf == 0 && frames / mbf > 1;
     if (!ahead && c->streams_split) {
         rc = join_streams(c);
         if (rc) return rc;
@@ -694,7 +709,7 @@ static int run_blocks_impl(fwgpu_ctx* c, uint64_t frames, const float* d_in, int
     }
     c->ahead_this_call = ahead;
     c->cmds_on_ctl = ahead;
-    rc = upload_cmds(c);
+    rc = upload_cmds(c, true);
     if (rc) {
         c->ahead_this_call = false;
         return rc;

@@ -16,7 +16,10 @@ enum : int {
 // realtime edge, resident kernel (k_rt_persist): the mailbox in pinned, device-mapped host memory
 struct RtMailbox {
     unsigned long long doorbell;  // host -> device: the sequence number to render next, or that number | RT_QUIT_BIT
-    unsigned long long pad0[7];
+    unsigned long long hold;      // host (CONTROL side) -> device: > 0 while a control call is about to free device memory or wait for the
+                                  // device (hipFree synchronises with every stream — a kernel that never ends would hold it forever):
+                                  // the kernel ends as if its watchdog had fired, and the audio side launches no new one (RtHold)
+    unsigned long long pad0[6];
     unsigned long long alive;     // device -> host: 1 while the kernel takes doorbells, 0 once it has decided to end
     unsigned long long pad1[7];
 };

@@ -516,6 +516,9 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
 #endif
     const bool w0 = lane == 0;
     const VoiceDesc vd = fv.voices[vi];
+    // (the steady cache is indexed by the voice too: asked for HERE it shares the descriptor's round trip instead of following it —
+    //  a message-free call's wave is three dependent round trips and a few stores, nothing else)
+    const VoiceCache vc = fv.cache[vi];
     const int frames = fv.frames;
     const bool simple_frames = (frames & 3) == 0;
     const bool fx = vd.bq_state >= 0 || vd.dl_state >= 0;  // the voice has a biquad / delay: silence does not pass it
@@ -541,12 +544,17 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
     // the call's scratch — the render waves of block 0 read the scratch while the waves of the last block write the pool
     const bool spv = vd.sp_ext_off >= 0;
     const int sp_j = vd.n_stages - 1;  // (the spatialiser is the last stage)
+    // (its state slot by selects, not by vd.stage_state[sp_j]: a dynamic index sends the descriptor's arrays — and with them the
+    //  stage registers loaded through them — to scratch and LDS; a kernel with a private segment pays for it at every dispatch)
+    int sp_state = 0;
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES - 1; ++j) sp_state = j == sp_j ? vd.stage_state[j] : sp_state;
     int sp_dl = 0, sp_dr = 0;
     if (spv) {
         // (control-ahead mode: this kernel runs beside the render kernel of the call BEFORE, which writes the pool at its end — the
         //  copy is then made on the render stream, right in front of this call's leaf kernel: k_sp_hist_copy)
         if (!fv.sp_hist_in_render) fv.hist[(size_t)vi * SP_HIST + lane] = fv.ext[(size_t)vd.sp_ext_off + lane];
-        const NodeState* sn = &fv.states[vd.stage_state[sp_j]];
+        const NodeState* sn = &fv.states[sp_state];
         sp_dl = sn->playing;
         sp_dr = sn->has_loop;
     }
@@ -657,7 +665,6 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
     bool k0_gset = false;    // gain set 0 of this call already holds the steady gains
     GainSet k0_gs;
     {
-        const VoiceCache vc = fv.cache[vi];
         const int Kp = first_cmd < K ? first_cmd : K;  // blocks [0, Kp) are steady
         if (vc.epoch == fv.epoch && Kp > 0) {
             TailJob job;
@@ -1116,8 +1123,8 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
     for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
         if (j < vd.n_stages) *(StageRegs*)&fv.states[vd.stage_state[j]] = st[j];
     if (spv) {
-        fv.states[vd.stage_state[sp_j]].playing = sp_dl;
-        fv.states[vd.stage_state[sp_j]].has_loop = sp_dr;
+        fv.states[sp_state].playing = sp_dl;
+        fv.states[sp_state].has_loop = sp_dr;
     }
 }
 

@@ -9,7 +9,9 @@
 //                 a system-scope release.  The last workgroup to finish does the publishing (agent-scope counter).
 //   k_bus_wait    ONE wave waits until all R arrival words of ITS OWN region carry the step's sequence number (one lane per
 //                 peer, system-scope acquire loads, s_sleep between polls, bounded by a wall-clock budget: a peer that never
-//                 arrives turns into an error word + a zero-filled bus, never a hung GPU);
+//                 arrives turns into an error word + a zero-filled bus, never a hung GPU — and the error is STICKY on the device: the
+//                 rank that timed out pushes and waits no more, so its peers time out at their next step instead of summing a
+//                 slot it might be overwriting: after a timeout every rank ends on zero buses + its own error word);
 //   k_bus_reduce  the launch behind it adds the R slots in rank order with the reference's SumNode semantics — all silent -> cleared; 1 port -> copy; 2/3/4 ports -> unmasked adds;
 //                 otherwise out = in0, then += in_p skipping SILENT ports (sum.rs:111-133, Q13).
 // Every rank ends with the bits of the single-process graph whose top node is that SumNode: the order is the port order,
@@ -33,6 +35,11 @@ __device__ __forceinline__ char* ex_slot(char* base, const ExchangeGeom& g, unsi
 __global__ __launch_bounds__(256) void k_bus_push(ExchangePeers peers, ExchangeGeom g, const float* __restrict__ part,
                                                   const uint8_t* __restrict__ sil, size_t n_floats, uint32_t n_sil,
                                                   unsigned long long seq, unsigned* __restrict__ counter) {
+    // A rank whose wait once ran out of time is OUT of the exchange for good: it has skipped a step its peers may still be
+    // reading, so the two-parity argument above no longer covers what it would overwrite next.  It pushes nothing more — the peers'
+    // next wait runs out too, and every rank ends with zero buses and its own sticky error word, none with a silently wrong sum.
+    // (The error word is written by k_bus_wait, stream-ordered before this launch: every workgroup reads the same value.)
+    if (__hip_atomic_load((const unsigned long long*)(peers.base[g.rank] + EX_ERR_OFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull) return;
     const size_t n4 = n_floats / 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n4) {
@@ -135,8 +142,9 @@ __device__ __forceinline__ v4f ordered_sum_quad(int world, size_t i4, uint32_t b
 __global__ __launch_bounds__(64) void k_bus_wait(char* __restrict__ base, int world, unsigned long long seq, unsigned long long budget_ticks,
                                                  unsigned long long* __restrict__ sync) {
     const int lane = threadIdx.x;
-    bool ok = true;
-    if (lane < world) {
+    // (sticky: after one timeout this rank neither pushes nor waits again — see k_bus_push)
+    bool ok = __hip_atomic_load((const unsigned long long*)(base + EX_ERR_OFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0ull;
+    if (ok && lane < world) {
         const unsigned long long* w = (const unsigned long long*)(base + EX_FLAGS_OFF) + lane;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         unsigned long long waited = 0;
@@ -168,10 +176,12 @@ __global__ __launch_bounds__(256) void k_bus_reduce(char* __restrict__ base, Exc
     const bool ok = sync[1] == seq;  // written by k_bus_wait, the launch before this one on the same stream
     const size_t n4 = n_floats / 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (!ok) {  // a peer never arrived: leave a fully written (zero) bus behind (core/node.rs:41-42)
+    if (!ok) {  // a peer never arrived: leave a fully written (zero) bus behind (core/node.rs:41-42), every block flagged silent
         if (i < n4) *(v4f*)(out + 4 * i) = splat(0.f);
         if (i == 0)
             for (size_t j = n4 * 4; j < n_floats; ++j) out[j] = 0.f;
+        if (out_sil)
+            for (size_t j = i; j < n_sil; j += (size_t)gridDim.x * blockDim.x) out_sil[j] = 1;
         return;
     }
     const uint32_t n_blocks = n_ch ? n_sil / n_ch : 0u;

@@ -144,6 +144,9 @@ __device__ __forceinline__ void rt_prefetch_next(const FusedView& fv, float* sin
 //   * workgroup 0 polls RtMailbox::doorbell (host memory over PCIe, one read per ~us) for the next sequence number and hands it to
 //     the others through a word of device memory (`go`), so that every workgroup takes the same decision;
 //   * the host asks for the end with `seq | RT_QUIT_BIT` (any call that is not a steady callback, a plan adoption, destroy);
+//   * HOLD: a control call that may free device memory or synchronise with the device (fwgpu_update's table growth, sample_create,
+//     exchange_open ...) raises RtMailbox::hold first and waits for alive == 0 (RtHold, fwgpu_ctx.h) — hipFree waits for EVERY stream,
+//     and this kernel ends only when told to;
 //   * WATCHDOG: no doorbell for `idle_ticks` (100 MHz ticks; default 20 ms) and workgroup 0 decides to quit on its own — a kernel that
 //     never ends would hold its stream, and a shared pool, hostage.  The host finds RtMailbox::alive == 0 and launches a new one
 //     with the next callback.  The other workgroups give up after 8 x that time without a word from workgroup 0.
@@ -168,11 +171,15 @@ __global__ __launch_bounds__(256) void k_rt_persist(FusedView fv, DevView upv, R
             unsigned long long cmd = seq | RT_QUIT_BIT;
             if (blockIdx.x == 0) {
                 for (;;) {
+                    // (the control side's hold word travels with the doorbell: same line, requested first, no wait of its own)
+                    const unsigned long long hold = __hip_atomic_load(&mb->hold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     const unsigned long long d = __hip_atomic_load(&mb->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (d == seq || d == (seq | RT_QUIT_BIT)) {
                         cmd = d;
                         break;
                     }
+                    if (hold) break;  // a control call is about to free / synchronise: end like the watchdog (cmd = quit); a doorbell
+                                      // that arrives now finds alive == 0 and the block goes out as an ordinary launch
                     const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
                     if (dt > idle_ticks) break;  // watchdog: cmd = quit
                     if (!pf_done && dt > 1000) {  // 10 us without a doorbell: this is a paced stream, not a back-to-back one — use the

@@ -322,6 +322,7 @@ class FirewheelGpuCtx(object):
         if not self.c:
             raise FwgpuError(-30, self.L.fwgpu_create_error().decode())
         self._nodes = {}
+        self._limbo = []  # removed HostNodes (their ctypes thunks) until a plan without them is the active one
         self._keep = []
 
     def close(self):
@@ -368,7 +369,21 @@ class FirewheelGpuCtx(object):
 
     def remove_node(self, node_id):
         self._check(self.L.fwgpu_remove_node(self.c, node_id))
-        self._nodes.pop(node_id, None)
+        n = self._nodes.pop(node_id, None)
+        if isinstance(n, HostNode):
+            # the running plan (and a pending one) still call the node's ctypes thunk until a plan WITHOUT it is the active one
+            # (fwgpu_abi.cpp: "the running plan may hold it until the next plan is adopted"): a thunk freed here is a segfault in
+            # the next process call.  It waits in limbo for an update that has been adopted (_reap_limbo).
+            self._limbo.append([n, False])
+
+    def _reap_limbo(self, updated=False):
+        """drop removed host nodes once a plan built AFTER their removal is the active one: an update has returned since
+        (entry[1]) and none is waiting for adoption (fwgpu_plan_pending)"""
+        if updated:
+            for ent in self._limbo:
+                ent[1] = True
+        if self._limbo and not self.L.fwgpu_plan_pending(self.c):
+            self._limbo = [ent for ent in self._limbo if not ent[1]]
 
     def connect(self, src_node, src_port, dst_node, dst_port, check_for_cycles=False):
         r = self.L.fwgpu_connect(self.c, src_node, src_port, dst_node, dst_port, 1 if check_for_cycles else 0)
@@ -391,6 +406,11 @@ class FirewheelGpuCtx(object):
         if r in _COMPILE:
             raise CompileGraphError(r, self.L.fwgpu_last_error(self.c).decode())
         self._check(r)
+        self._reap_limbo(updated=True)
+
+    def plan_pending(self):
+        """True while a plan built by update() / schedule_upload() waits for a process call to adopt it (include/fwgpu.h)"""
+        return bool(self._check(self.L.fwgpu_plan_pending(self.c)))
 
     def schedule_upload(self, sched, num_buffers):
         """sched: list of dicts {"id", "in": [(buffer_index, should_clear)], "out": [buffer_index]} in schedule order
@@ -412,6 +432,7 @@ class FirewheelGpuCtx(object):
         if r in _COMPILE:
             raise CompileGraphError(r, self.L.fwgpu_last_error(self.c).decode())
         self._check(r)
+        self._reap_limbo(updated=True)
 
     # ---- plan introspection
     def plan_kind(self):
@@ -514,6 +535,8 @@ class FirewheelGpuCtx(object):
         inp = np.ascontiguousarray(input, dtype=np.float32)
         self._check(self.L.fwgpu_process_interleaved(self.c, _fptr(inp), _fptr(out), num_in_channels, num_out_channels,
                                                      frames, stream_time_secs, stream_status))
+        if self._limbo:  # (this call may have adopted the plan that no longer names a removed host node)
+            self._reap_limbo()
         return out
 
     def process_blocks_device(self, num_blocks, device_out_ptr, num_out_channels=2):

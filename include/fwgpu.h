@@ -171,6 +171,12 @@ int fwgpu_plan_chain_stats(fwgpu_ctx* ctx, uint64_t* steady_workgroups, uint64_t
  * adopted so far, *audio_adoptions = those a process call adopted, *max_adopt_ns = the longest one of THOSE held up its process
  * call (host nanoseconds).  Any pointer may be NULL. */
 int fwgpu_plan_handover_stats(fwgpu_ctx* ctx, uint64_t* adoptions, uint64_t* audio_adoptions, uint64_t* max_adopt_ns);
+/* 1 while a plan built by fwgpu_update / fwgpu_schedule_upload waits for a process call to adopt it, else 0.  Once an update has
+ * returned and this reads 0, the plan it built is the active one: nothing the update removed — a host node's callback and its
+ * `user` pointer above all — will be called again, and its owner may free it (the reference drops a removed node's processor when
+ * the old schedule comes back through the ring, graph/processor.rs:182-188; rust/firewheel-gpu's HostNodeHandle and the Python
+ * wrapper keep removed host nodes in limbo until this says so).  Any thread may ask. */
+int fwgpu_plan_pending(fwgpu_ctx* ctx);
 /* Diagnostics for the same hand-over: which part of fwgpu_update / fwgpu_schedule_upload the control thread is in right now —
  * 0 none, 1 compiling the graph (host only: graph/compiler.rs), 21..28 the sections of the plan build that upload tables
  * (23 node tables, 26 buffer pool, 27 voice tables, 28 staging areas), 3 waiting for the last upload.  Any thread may ask;

@@ -13,22 +13,66 @@ use firewheel_core::SilenceMask;
 
 use crate::{ffi, GpuContext, GpuError};
 
-/// Keeps a custom processor alive for as long as the device graph may call it.  Drop it only after the node has been removed
-/// and the plan without it adopted (`GpuContext::plan_handover_stats`), like Firewheel drops processors that come back with the
-/// old schedule (processor.rs:182-188).
+/// Owner of a custom processor inside the device graph.  Dropping it removes the node (if it still exists), updates the plan and
+/// hands the processor to the context's graveyard, which frees it only once a plan WITHOUT the node is the active one
+/// (`fwgpu_plan_pending`) — until then the audio thread may still be inside, or about to enter, the trampoline with the raw
+/// `user` pointer.  That is Firewheel's own rule (a removed node's processor is dropped when the old schedule comes back through
+/// the ring, processor.rs:182-188), made part of the type instead of the documentation: dropping the handle at any time, from any
+/// thread, with the stream running, is sound.
 pub struct HostNodeHandle {
     pub node: i64,
-    _state: Box<HostState>,
-    _cx: Arc<GpuContext>,
+    state: Option<Box<HostState>>,
+    cx: Arc<GpuContext>,
+}
+impl Drop for HostNodeHandle {
+    fn drop(&mut self) {
+        // Err = the host removed it already (remove_node); either way the graph no longer names it after this line
+        let _ = self.cx.remove_node(self.node);
+        // the plan that no longer calls it; on failure (a graph that does not compile right now) the processor simply waits in the
+        // graveyard for the next successful update
+        let updated = self.cx.update().is_ok();
+        if let Some(st) = self.state.take() {
+            self.cx.bury(st, updated);
+        }
+    }
 }
 /// what the C side's `user` pointer names: the processor and the global user context ProcInfo hands every node
 /// (core/node.rs:117-118; the reference's processor owns one `Box<dyn Any + Send>` per graph, processor.rs:41 — here one per node,
 /// supplied by the host at registration)
-struct HostState {
+pub(crate) struct HostState {
     processor: Box<dyn AudioNodeProcessor>,
     user_cx: Box<dyn std::any::Any + Send>,
 }
 unsafe impl Send for HostNodeHandle {}
+unsafe impl Send for HostState {}
+
+/// A processor whose node is gone from the graph but which a plan may still call: (state, an update has succeeded since the removal).
+pub(crate) struct Grave {
+    _state: Box<HostState>,
+    updated: bool,
+}
+impl GpuContext {
+    pub(crate) fn bury(&self, st: Box<HostState>, updated: bool) {
+        let mut g = self.graveyard.lock().unwrap_or_else(|e| e.into_inner());
+        g.push(Grave { _state: st, updated });
+        drop(g);
+        self.reap(false);
+    }
+    /// Free the processors no plan can call any more: an update has returned since their removal AND no built plan is waiting
+    /// for adoption — so the newest plan, which does not name them, is the one the audio thread runs.  Called after every
+    /// `update` / `upload_schedule` (with `updated = true`), after every drop of a handle, and by `GpuContext::drop` (everything).
+    pub(crate) fn reap(&self, updated: bool) {
+        let mut g = self.graveyard.lock().unwrap_or_else(|e| e.into_inner());
+        if updated {
+            for gr in g.iter_mut() {
+                gr.updated = true;
+            }
+        }
+        if !g.is_empty() && unsafe { ffi::fwgpu_plan_pending(self.as_ptr()) } == 0 {
+            g.retain(|gr| !gr.updated);
+        }
+    }
+}
 
 unsafe extern "C" fn trampoline(
     user: *mut c_void,
@@ -82,6 +126,6 @@ impl GpuContext {
             unsafe { ffi::fwgpu_remove_node(self.as_ptr(), node) };
             return Err(e);
         }
-        Ok(HostNodeHandle { node, _state: boxed, _cx: Arc::clone(self) })
+        Ok(HostNodeHandle { node, state: Some(boxed), cx: Arc::clone(self) })
     }
 }

@@ -45,6 +45,8 @@ impl std::error::Error for GpuError {}
 pub struct GpuContext {
     raw: NonNull<ffi::fwgpu_ctx>,
     control: Mutex<()>,
+    /// processors of host nodes that were removed while a plan could still call them (host_node.rs)
+    pub(crate) graveyard: Mutex<Vec<host_node::Grave>>,
     pub sample_rate: u32,
     pub max_block_frames: u32,
 }
@@ -72,7 +74,7 @@ impl GpuContext {
             )
         };
         match NonNull::new(raw) {
-            Some(raw) => Ok(Arc::new(Self { raw, control: Mutex::new(()), sample_rate, max_block_frames })),
+            Some(raw) => Ok(Arc::new(Self { raw, control: Mutex::new(()), graveyard: Mutex::new(Vec::new()), sample_rate, max_block_frames })),
             None => Err(GpuError {
                 code: ffi::FWGPU_ERR_DEVICE,
                 message: unsafe { CStr::from_ptr(ffi::fwgpu_create_error()) }.to_string_lossy().into_owned(),
@@ -124,8 +126,18 @@ impl GpuContext {
     }
     /// `FirewheelGraphCtx::update` (graph/context.rs:93-137) when the graph is mirrored with `add_node` / `connect`.
     pub fn update(&self) -> Result<(), GpuError> {
-        let _g = self.control();
-        self.check(unsafe { ffi::fwgpu_update(self.as_ptr()) } as i64).map(|_| ())
+        let r = {
+            let _g = self.control();
+            self.check(unsafe { ffi::fwgpu_update(self.as_ptr()) } as i64).map(|_| ())
+        };
+        if r.is_ok() {
+            self.reap(true);
+        }
+        r
+    }
+    /// true while a plan built by `update` / `upload_schedule` waits for a process call to adopt it (`fwgpu_plan_pending`)
+    pub fn plan_pending(&self) -> bool {
+        unsafe { ffi::fwgpu_plan_pending(self.as_ptr()) != 0 }
     }
     /// Blocks one launch sequence may cover (a realtime host never needs more than one; an offline bounce wants many).
     pub fn set_max_batch(&self, blocks: u32) -> Result<(), GpuError> {
@@ -153,11 +165,17 @@ impl GpuContext {
                 out_buffer_index: v.out_buffer_index.as_ptr(),
             })
             .collect();
-        let _g = self.control();
-        self.check(unsafe {
-            ffi::fwgpu_schedule_upload(self.as_ptr(), nodes.as_ptr(), nodes.len() as u32, num_buffers as u32)
-        } as i64)
-        .map(|_| ())
+        let r = {
+            let _g = self.control();
+            self.check(unsafe {
+                ffi::fwgpu_schedule_upload(self.as_ptr(), nodes.as_ptr(), nodes.len() as u32, num_buffers as u32)
+            } as i64)
+            .map(|_| ())
+        };
+        if r.is_ok() {
+            self.reap(true);
+        }
+        r
     }
 
     /// 0 = generic level-batched executor, 1 = fused voice-bank plan, 2 = fused chain plan, 3 = hybrid (voice banks on the fused
@@ -182,6 +200,8 @@ impl GpuContext {
 
 impl Drop for GpuContext {
     fn drop(&mut self) {
+        // the ctx first (it ends every kernel and no audio call can be in flight: the GpuProcessor holds an Arc); the graveyard's
+        // processors are fields and go after it
         unsafe { ffi::fwgpu_ctx_destroy(self.as_ptr()) }
     }
 }

@@ -363,6 +363,21 @@ def test_exchange_wait_is_bounded_a_missing_peer_is_an_error_and_a_zero_bus_not_
         x0.status()
     assert time.perf_counter() - t0 < 2.0
     assert not out.cpu().numpy().any()  # fully written, zeros (core/node.rs:41-42)
+    # a timeout is final.  Rank 1 now pushes steps 1 and 2 — rank 0, which skipped step 1, must not come back and sum
+    # slots whose parity it may have run over: the host refuses (the exchange has to be reopened on every rank) ...
+    with pytest.raises(FwgpuError, match="exchange is closed"):
+        x0.step(part.data_ptr(), out.data_ptr(), 4096)
+    # ... and rank 1, whose peer pushed step 1 (before it timed out) but will never push step 2, gets step 1's sum and then its
+    # own timeout: zeros and an error, not a stale slot
+    x1.set_timeout_ms(40)
+    out1 = torch.full((4096,), float("nan"), dtype=torch.float32, device="cuda")
+    x1.step(part.data_ptr(), out1.data_ptr(), 4096)
+    x1.status()
+    assert (out1.cpu().numpy() == 2.0).all()
+    x1.step(part.data_ptr(), out1.data_ptr(), 4096)
+    with pytest.raises(FwgpuError, match="did not arrive"):
+        x1.status()
+    assert not out1.cpu().numpy().any()
     x0.close()
     x1.close()
 

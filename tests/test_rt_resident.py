@@ -184,3 +184,79 @@ def test_varied_banks_through_the_resident_kernel_match_the_oracle(mbf, n_voices
     if os.environ.get("FWGPU_RT_PERSIST") != "0":
         launches, doorbells = g.cx.rt_resident_stats()
         assert doorbells >= n_cb // 2, (launches, doorbells)
+
+
+def test_control_calls_that_free_device_memory_do_not_wait_for_a_fed_resident_kernel():
+    """hipFree / hipHostFree / hipDeviceSynchronize wait for EVERY stream, and the resident kernel ends only when
+    told to or 20 ms after its last doorbell — a steady stream of callbacks kept it alive for ever, and with it an fwgpu_update
+    that had to grow a table (or a sample_create that grew the sample table: the audio thread then sat at its gate until the
+    watchdog fired).  Now the control call raises RtMailbox::hold first (RtHold): the kernel ends at its next poll, callbacks go
+    out as ordinary launches meanwhile.  Audio thread = the library's own callback loop (fwgpu_stream_run, no GIL held), control
+    side = this thread: a graph edit that grows every table of the voice-bank plan, then 40 new samples (the table doubles)."""
+    import threading
+
+    if os.environ.get("FWGPU_RT_PERSIST") == "0":
+        pytest.skip("the resident kernel is switched off")
+    g = GpuEngine(max_block_frames=MBF)
+
+    def leaf(first):
+        m = g.sum(32)
+        vs = []
+        for p in range(32):
+            s, vol = g.sampler(100.0), g.volume(40.0 + p)
+            g.connect_stereo(s, vol)
+            g.connect_stereo(vol, m, 2 * p)
+            vs.append(s)
+        return m, vs
+
+    root = g.sum(8)   # six of its stereo ports stay free for the edit (unconnected = the cleared buffer: still the voice-bank plan)
+    samplers = []
+    for p in range(2):
+        m, vs = leaf(32 * p)
+        g.connect_stereo(m, root, 2 * p)
+        samplers += vs
+    g.connect_stereo(root, g.graph_out_node)
+    g.update()
+    for v, s in enumerate(samplers):
+        g.sampler_set_sample(s, g.new_sample(scenarios.PLANAR_F32, 2, scenarios.voice_source(v, 4000, 2)))
+        g.sampler_set_loop_range(s, LOOP_FULL)
+        g.sampler_play(s)
+    for _ in range(3):
+        g.process_interleaved(MBF)
+    assert g.cx.plan_kind() == 1
+    st = g.cx.open_stream(0, 2)
+    st.run(MBF, 20, 0.0)
+    l0, d0 = g.cx.rt_resident_stats()
+    assert d0 > 0, "the resident kernel is not in use: nothing to test"
+    res = {}
+    N = 240000   # ~6 s of back-to-back callbacks at ~25 us each: the doorbell never rests for the watchdog's 20 ms
+
+    def audio():
+        res["run"] = st.run(MBF, N, 21 * MBF / 48000.0)
+
+    th = threading.Thread(target=audio)
+    th.start()
+    time.sleep(0.3)
+    t0 = time.perf_counter()
+    for p in range(2, 6):   # 128 more voices: node / voice / record tables all grow (DevBuf::ensure frees the old ones)
+        m, _ = leaf(32 * p)
+        g.connect_stereo(m, root, 2 * p)
+    g.update()
+    t_update = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    ids = [g.new_sample(scenarios.PLANAR_F32, 2, scenarios.voice_source(900 + i, 512, 2)) for i in range(80)]
+    t_samples = time.perf_counter() - t1
+    alive_after = th.is_alive()
+    th.join(timeout=60)
+    assert not th.is_alive(), "the callback loop never returned"
+    assert alive_after, "the stream ended before the control calls did: nothing was measured (%.2f s, %.2f s)" % (t_update, t_samples)
+    assert g.cx.plan_kind() == 1
+    # bounds far above what the calls take (tens of ms) and far below "until the stream stops" (seconds)
+    assert t_update < 1.5, "fwgpu_update waited %.2f s beside a fed resident kernel" % t_update
+    assert t_samples < 1.5, "%d sample_create calls took %.2f s beside a fed resident kernel" % (len(ids), t_samples)
+    l1, d1 = g.cx.rt_resident_stats()
+    assert d1 - d0 > N // 2 and l1 > l0, (l0, d0, l1, d1)   # ended (hold) and launched again; doorbells carried the rest
+    cbs, unders, _ = st.stats()
+    assert cbs == 20 + N
+    st.close()
+    g.cx.close()

@@ -221,7 +221,13 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
         bool ok = hipHostMalloc((void**)&c->h_rt_mb, sizeof(RtMailbox), hipHostMallocMapped) == hipSuccess &&
                   hipHostGetDevicePointer((void**)&c->d_rt_mb, c->h_rt_mb, 0) == hipSuccess;
         if (ok) memset(c->h_rt_mb, 0, sizeof(RtMailbox));
-        ok = ok && hipStreamCreateWithFlags(&c->rt_stream, hipStreamNonBlocking) == hipSuccess &&
+        // HIGH priority, not for the priority: ROCm multiplexes a process's streams onto a few hardware queues PER PRIORITY LEVEL, and
+        // whatever shares a queue with a kernel that never ends waits behind it — a plain hipMemcpy of a control thread (the null
+        // stream) sat out the whole 4 s of a fed resident kernel (r04, tests/test_rt_resident.py).  The high-priority pool holds
+        // only this stream and ctl_stream, which is never used while a resident kernel runs (throughput calls end it first).
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        ok = ok && hipStreamCreateWithPriority(&c->rt_stream, hipStreamNonBlocking, hi) == hipSuccess &&
              hipEventCreateWithFlags(&c->rt_ev, hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();

@@ -292,6 +292,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     // microseconds of the member swap, and only when it found the gate at 0).  A process call takes the gate for its whole
     // duration; the control thread BUILDS outside the gate and only tries it to adopt when the audio side is idle.
     std::atomic<int> gate{0};
+    std::atomic<int> gate_ctl_waiting{0};  // control calls waiting at ControlGate: the audio side lets them in before its next call
     std::atomic<fwgpu::PlanImage*> pending{nullptr};  // built and published, waiting for the next process call
     fwgpu::PlanImage* spare = nullptr;                // control side: a retired image, the next build target (its buffers are reused)
     static constexpr uint32_t RETIRE_CAP = 8;
@@ -537,9 +538,12 @@ void collect_retired(fwgpu_ctx* c);                   // control side: reuse / f
 struct AudioGate {
     fwgpu_ctx* c;
     explicit AudioGate(fwgpu_ctx* ctx) : c(ctx) {
-        int expected = 0;
-        while (!c->gate.compare_exchange_weak(expected, 1, std::memory_order_acquire)) {
-            expected = 0;
+        // (a control call waiting at ControlGate goes first: a stream of back-to-back callbacks holds the gate ~100 % of the time, and a
+        //  waiter that has to catch the instant between two of them starved for tens of milliseconds — 80 sample_create calls beside
+        //  fwgpu_stream_run took 4.1 s, r04.  The audio side waits here for the waiter's few microseconds instead.)
+        for (;;) {
+            int expected = 0;
+            if (c->gate_ctl_waiting.load(std::memory_order_acquire) == 0 && c->gate.compare_exchange_weak(expected, 1, std::memory_order_acquire)) break;
 #if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
 #endif
@@ -566,11 +570,16 @@ struct AudioGate {
 struct ControlGate {
     fwgpu_ctx* c;
     explicit ControlGate(fwgpu_ctx* ctx) : c(ctx) {
+        c->gate_ctl_waiting.fetch_add(1, std::memory_order_acq_rel);
         int expected = 0;
-        while (!c->gate.compare_exchange_weak(expected, 2, std::memory_order_acquire)) {
+        for (unsigned spins = 1; !c->gate.compare_exchange_weak(expected, 2, std::memory_order_acquire); ++spins) {
             expected = 0;
-            std::this_thread::yield();
+            if ((spins & 1023u) == 0) std::this_thread::yield();
+#if defined(__x86_64__) || defined(__i386__)
+            else __builtin_ia32_pause();
+#endif
         }
+        c->gate_ctl_waiting.fetch_sub(1, std::memory_order_acq_rel);
     }
     ~ControlGate() { c->gate.store(0, std::memory_order_release); }
 };

@@ -507,6 +507,7 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
 // One WAVE per voice: the state machines are run by all 64 lanes redundantly (wave-uniform; lane 0 stores),
 // the steady tail is split across the lanes.  A voice that ended the previous call steady and has no message
 // in this one skips the state machines altogether (VoiceCache): its whole call is a steady tail.
+template <bool EARLY_VC = false>
 __device__ inline void voice_control_wave(const FusedView& fv, const int vi, const int lane, const int K, const uint32_t cmd_block0) {
 #ifdef FW_CTL_TRACE
     unsigned long long tr[12];
@@ -518,7 +519,12 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
     const VoiceDesc vd = fv.voices[vi];
     // (the steady cache is indexed by the voice too: asked for HERE it shares the descriptor's round trip instead of following it —
     //  a message-free call's wave is three dependent round trips and a few stores, nothing else)
-    const VoiceCache vc = fv.cache[vi];
+    //  — in the control KERNEL (EARLY_VC).  The one-launch realtime kernels keep the load where it was, behind the message spans: with
+    //  it up here k_rt_persist rendered 8 garbage frames per block (r04, every run; k_rt_block did not) — not understood, the
+    //  kernel is 237 VGPRs + 788 spilled SGPRs either way; they gain nothing from the early load anyway (their steady voices take
+    //  voice_control_lane_steady).
+    VoiceCache vc;
+    if (EARLY_VC) vc = fv.cache[vi];
     const int frames = fv.frames;
     const bool simple_frames = (frames & 3) == 0;
     const bool fx = vd.bq_state >= 0 || vd.dl_state >= 0;  // the voice has a biquad / delay: silence does not pass it
@@ -665,6 +671,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
     bool k0_gset = false;    // gain set 0 of this call already holds the steady gains
     GainSet k0_gs;
     {
+        if (!EARLY_VC) vc = fv.cache[vi];
         const int Kp = first_cmd < K ? first_cmd : K;  // blocks [0, Kp) are steady
         if (vc.epoch == fv.epoch && Kp > 0) {
             TailJob job;
@@ -1201,7 +1208,7 @@ __device__ __forceinline__ void voice_control_kernel(const FusedView& fv, const 
     // dispatch order: the voices with a message in this call (or the one before: their glides continue) go first — theirs are the
     // long waves (a glide is 22-25 us of serial latency)
     const int vi = fv.ctl_order ? __builtin_amdgcn_readfirstlane(fv.ctl_order[w]) : w;
-    voice_control_wave(fv, vi, threadIdx.x & (WAVE - 1), K, cmd_block0);
+    voice_control_wave<true>(fv, vi, threadIdx.x & (WAVE - 1), K, cmd_block0);
 }
 __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint32_t cmd_block0) { voice_control_kernel<1>(fv, K, cmd_block0); }
 __global__ __launch_bounds__(256, 3) void k_voice_control_small(FusedView fv, int K, uint32_t cmd_block0) { voice_control_kernel<3>(fv, K, cmd_block0); }

@@ -52,6 +52,8 @@ DEFAULTS = {
 # node kinds of include/fwgpu.h (both engines take raw kinds)
 K_BEEP, K_VOLUME, K_SUM, K_SAMPLER, K_HARD_CLIP, K_PAN, K_WIDTH, K_BIQUAD, K_DELAY, K_FIR, K_RESAMPLER, K_SPATIAL = 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, 14
 PLANAR_F32, INTERLEAVED_I16 = 5, 0
+# --rs-source: the resamplers' ratios are U(lo, hi); the driver line's is (0.5, 1.5).  FWGPU_BENCH_RS_RATIO=lo,hi: kernel experiments only
+RS_RATIO = tuple(float(x) for x in os.environ.get("FWGPU_BENCH_RS_RATIO", "0.5,1.5").split(","))
 
 
 # ------------------------------------------------------------------------------------------------ the two engines
@@ -178,7 +180,7 @@ def graph_bank(e, voices, radix, seed=0, master=False, extra=(), rs_samples=None
     ends, samplers, volumes = [], [], []
     for v in range(voices):
         if rs_samples is not None:
-            s = e.add(K_RESAMPLER, 0, 2, [float(rs_samples[v]), float(rng_ratio.uniform(0.5, 1.5)), 1.0, 1.0])
+            s = e.add(K_RESAMPLER, 0, 2, [float(rs_samples[v]), float(rng_ratio.uniform(*RS_RATIO)), 1.0, 1.0])
         else:
             s = e.add(K_SAMPLER, 0, 2, [100.0])
         vol = e.add(K_VOLUME, 2, 2, [float(rng.uniform(10, 100))])
@@ -432,7 +434,8 @@ def parity_check(fa, torch, wl, V, B, K, radix, seed, args, src, F, sfmt, stream
         res["error"] = "the reference output is all zeros: nothing was compared"
     cx.close()
     res["voices_checked"], res["blocks_checked"] = V, len(blocks)
-    if wl in ("cfg3", "cfg4") and not (getattr(args, "send", False) or args.master or getattr(args, "master_iir", False)) and K >= 2:
+    carried = rs or getattr(args, "voice_spatial", False)  # resampler positions / spatialiser histories carry from block to block too
+    if (wl in ("cfg3", "cfg4") or (carried and wl == "cfg2" and sfmt == "f32")) and not (getattr(args, "send", False) or args.master or getattr(args, "master_iir", False)) and K >= 2:
         # filter / delay / FIR history carries from block to block, so blocks deep inside the call need their whole prefix from
         # the oracle: a SLICE of the voices (same launch shape, same K), every block of the call
         try:
@@ -451,7 +454,10 @@ def parity_deep(fa, torch, wl, B, K, radix, seed, args, src, F, stream, device):
     import numpy as np
 
     t0 = time.perf_counter()
-    Vd = min(src.shape[0], 256 if wl == "cfg3" else 8)
+    rs = getattr(args, "rs_source", False) and wl == "cfg2"
+    # (cfg2 with resampler sources / spatialiser stages: 64 voices — two full leaves — x all 768 blocks of one call; VERDICT r3: the
+    #  fresh-context check looked at blocks {0, 1} of 768 only)
+    Vd = min(src.shape[0], 256 if wl == "cfg3" else (64 if wl == "cfg2" else 8))
     assert F >= K * B
     cx, g, samplers, _ = make_gpu(fa, wl, Vd, B, K, radix, src, F, "f32", seed, args, stream, device)
     out = torch.empty(K * B * 2, dtype=torch.float32, device=src.device)
@@ -459,7 +465,8 @@ def parity_deep(fa, torch, wl, B, K, radix, seed, args, src, F, stream, device):
     cx.process_blocks_device(K, out.data_ptr(), 2)
     cx.synchronize()
     got = out.cpu().numpy()
-    o, _, _ = make_oracle(wl, Vd, B, radix, seed, args, src[:Vd, :, :K * B].cpu().numpy())
+    # (a looping resampler reads past K x B source frames at ratios > 1 and wraps its window around the sample's end: whole samples)
+    o, _, _ = make_oracle(wl, Vd, B, radix, seed, args, (src[:Vd] if rs else src[:Vd, :, :K * B]).cpu().numpy())
     ref = o.e.process_blocks(K)
     same = bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32))) and bool(np.any(ref))
     per_block = (got.view(np.uint32).reshape(K, -1) == ref.view(np.uint32).reshape(K, -1)).all(axis=1)
@@ -816,11 +823,16 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
             avg_s = fir_ms / fir_n / 1e3
             ach = flops / avg_s / 1e12
             traffic, traffic_src = pmc_traffic("k_fir_gemm", V, B, K, wl)
+            step_us = dt / steps * 1e6
             roofline = {"bound": "mfma", "kernel": "k_fir_gemm", "achieved": ach,
                         "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic,
                         "traffic_source": traffic_src, "algorithmic_flops_per_launch": flops, "avg_launch_us": avg_s * 1e6,
                         "launches": fir_n, "blocks_per_launch": K, "timing": "HIP events, separate pass after the timed region",
-                        "whole_block_us_all_kernels": gen_ms / max(gen_n, 1) / K * 1e3}
+                        "whole_block_us_all_kernels": gen_ms / max(gen_n, 1) / K * 1e3,
+                        # the WHOLE step against the same peak: the step's algorithmic flops / its wall time in the timed region
+                        "whole_step_frac": flops * (fir_n / float(ev_steps)) / (step_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF,
+                        "other_kernels_us_per_step": {"levels+reduce (all but k_fir_gemm)": (gen_ms - fir_ms) / ev_steps * 1e3},
+                        "idle_us_per_step": step_us - gen_ms / ev_steps * 1e3}
         elif dom_n:
             # source L+R once (f32: 8 B, i16: 4 B) (+ delay ring read + write)
             per_vs = 24.0 if wl == "cfg3" else (4.0 if sfmt == "i16" else 8.0)
@@ -836,14 +848,56 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
                          ("_spatial" if getattr(args, "voice_spatial", False) else ""))
             plain = not (args.master or getattr(args, "master_iir", False) or variant != "A" or args.force_generic or getattr(args, "send", False))
             traffic, traffic_src = pmc_traffic(kernel, V, B, K, prof_name) if sfmt == "f32" and plain else (None, None)
+            step_us = dt / steps * 1e6
+            others = {"k_voice_control": ctl_ms / ev_steps * 1e3, "upper_sums+graph_out": up_ms / ev_steps * 1e3}
+            if gen_n:
+                others["level executor (hybrid plan / master chain)"] = gen_ms / ev_steps * 1e3
+            frac = ach / HBM_PEAK_GBS
             roofline = {
                 "bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "frac": frac, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_voice_sample": per_vs, "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_us": avg_s * 1e6, "launches": dom_n, "timing": "HIP events, separate pass after the timed region",
-                "other_kernels_us_per_step": {"k_voice_control": ctl_ms / max(ctl_n, 1) * 1e3,
-                                              "upper_sums+graph_out": up_ms / max(up_n, 1) * 1e3},
+                "avg_launch_us": avg_s * 1e6, "launches": dom_n, "launches_per_step": dom_n / float(ev_steps),
+                "timing": "HIP events, separate pass after the timed region",
+                # north_star's "throughput as achieved fraction of the HBM roofline": the step's algorithmic bytes / its wall time in
+                # the TIMED region (every kernel, every gap) against the same 8 TB/s — `frac` above is the dominant kernel alone
+                "whole_step_frac": V * B * K * per_vs * playing / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "other_kernels_us_per_step": others,
+                # what is left of the timed step once every kernel's own duration is taken out: launch gaps, cross-stream waits
+                # (control kernels of calls WITH messages run a call ahead on their own stream and are then not in the step at all)
+                "idle_us_per_step": step_us - (dom_ms + ctl_ms + up_ms + gen_ms) / ev_steps * 1e3,
+                # k_leaf_sum's two HBM placement states (profiles/PLACEMENT.md), fixed per context at allocation
+                "placement_state": (("fast" if frac >= 0.76 else "slow") if kernel == "k_leaf_sum" and sfmt == "f32" and playing == 1.0 else None),
             }
+    own = None
+    if (full and rank == 0 and world == 1 and not hostonly and not args.no_parity_check and wl in ("cfg2", "cfg5") and sfmt == "f32" and variant == "A"
+            and not args.host_buffers and F % B == 0 and K >= 4 and
+            not (args.master or getattr(args, "master_iir", False) or getattr(args, "send", False) or getattr(args, "rs_source", False) or
+                 getattr(args, "voice_spatial", False) or args.voice_fx or args.force_generic)):
+        # The TIMED context's own output (parity ran on a fresh context only): one more call on the context that was just
+        # timed, blocks {0, 1, K/2, K-1} of it against the oracle.  Every voice loops over its whole F-frame buffer and has played
+        # step_no x K blocks since frame 0, so block b of this call reads source frames [(p + b*B) mod F, +B) with p = calls x K x B
+        # mod F (F is a multiple of B: no wrap inside a block) — the oracle, starting at frame 0, is handed exactly those frames.
+        import numpy as np
+
+        t_own = time.perf_counter()
+        p0 = (step_no[0] * K * B) % F
+        step()
+        finish_reductions()
+        sync()
+        b_used = ((slot[0] - 1) // R) % 2
+        r_used = (slot[0] - 1) % R
+        got_all = outs[b_used][r_used * step_elems:(r_used + 1) * step_elems]
+        blocks = [0, 1, K // 2, K - 1]
+        got = torch.cat([got_all[b * B * 2:(b + 1) * B * 2] for b in blocks]).cpu().numpy()
+        host = torch.cat([src[:, :, (p0 + b * B) % F:(p0 + b * B) % F + B] for b in blocks], dim=2).cpu().numpy()
+        o, _, _ = make_oracle(wl, V, B, args.radix, rank, args, host)
+        ref = o.e.process_blocks(len(blocks))
+        same = bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32))) and bool(np.any(ref))
+        own = {"bit_exact": same, "what": "one more call on the context that was just timed (after %d calls of %d blocks), compared with the oracle"
+               % (step_no[0] - 1, K), "block_indices": blocks, "voices": V, "source_frame_of_block_0": p0,
+               "samples_compared": int(got.size), "secs": round(time.perf_counter() - t_own, 2)}
+        del o
     res = None
     if rank == 0:
         total = float(V) * B * K * steps * world
@@ -859,6 +913,10 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
             desc += " + StereoWidth + HardClip in every voice"
         if args.rs_source and wl in ("cfg2", "cfg5"):
             desc = desc.replace("sampler->", "resampler(ratio U(0.5,1.5), looping)->")
+        if getattr(args, "voice_spatial", False) and wl in ("cfg2", "cfg5"):
+            desc = desc.replace("->pan->", "->pan->3D spatialiser(ITD + distance + equal-power gains)->")
+        if getattr(args, "send", False) and wl in ("cfg2", "cfg3", "cfg5"):
+            desc += " + every 4th leaf bus tapped into a send -> gain -> width -> limiter return (hybrid plan)"
         res = {
             "value": total / dt,
             "ms_per_step": dt / steps * 1e3,
@@ -875,6 +933,8 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
             },
             "roofline": roofline,
         }
+        if own is not None:
+            res["parity_check_timed_context"] = own
     if reducer is not None and hasattr(reducer, "close"):
         if res is not None:  # how far the ranks ran apart: the longest rank 0's reduce kernels waited for each rank's arrival
             res["config"]["bus_exchange_max_wait_us"] = reducer.x.wait_stats()
@@ -899,6 +959,19 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
     return res
 
 
+def context_summary(runs, mid):
+    """the fresh contexts one entry was timed in: every run's step time, kernel time, roofline fractions and placement state"""
+    rf = [(r["roofline"] or {}) for r in runs]
+    ms = [r["ms_per_step"] for r in runs]
+    return {"n": len(runs), "ms_per_step_runs": ms, "kernel_us_runs": [x.get("avg_launch_us") for x in rf],
+            "roofline_frac_runs": [x.get("frac") for x in rf], "whole_step_frac_runs": [x.get("whole_step_frac") for x in rf],
+            "placement_state_runs": [x.get("placement_state") for x in rf],
+            "median": ms[mid], "min": min(ms), "max": max(ms),
+            "reported": "the median context (run %d of %d): value, ms_per_step and roofline are its own" % (mid, len(runs)),
+            "why": "k_leaf_sum runs in one of two HBM placement states fixed per context at allocation (DESIGN.md section 7): "
+                   "`fast` = kernel-only roofline fraction >= 0.76, else `slow`"}
+
+
 def other_configs(env, args):
     """configs 1, 3, 4, 5 (one shard) and the hybrid-plan variant of config 2 in short form, each on the driver-run line next to the headline: a few steps at the
     config's own size, its roofline, and the same parity check against the oracle (~45 s together)."""
@@ -914,11 +987,16 @@ def other_configs(env, args):
     # (cfg2_rs / cfg2_spatial: the headline graph with every voice's source a SPEC resampler (ratio U(0.5, 1.5), looping) / every
     #  voice ending in a SPEC spatialiser — the other two north-star node families on the voice-bank plan; cfg2_variantB: 64 voices
     #  with a volume glide every ~20 blocks, the reference's automation case)
-    for name, steps in (("cfg3", 12), ("cfg5", 12), ("cfg4", 6), ("cfg2_sends", 12), ("cfg2_rs", 10), ("cfg2_spatial", 10), ("cfg2_variantB", 10)):
+    # (cfg2_i16: SURVEY 8d's 4 B row — the headline graph on interleaved 16-bit PCM sources, core/sample_resource.rs:338-340)
+    # cfg3 / cfg5: three fresh contexts each, the median reported and all three listed with their placement state — one context is
+    # a coin toss between k_leaf_sum's two HBM placement states (the profile and the line disagreed by 12 % on cfg5)
+    for name, steps, n_ctx in (("cfg3", 12, 3), ("cfg5", 12, 3), ("cfg4", 6, 1), ("cfg2_sends", 12, 1), ("cfg2_rs", 10, 1), ("cfg2_spatial", 10, 1),
+                               ("cfg2_variantB", 10, 1), ("cfg2_i16", 12, 1)):
         wl = name.split("_")[0]
         V, B, K, F, _ = DEFAULTS[wl]
         try:
             wargs = args
+            sfmt = "f32"
             if name != wl:
                 wargs = copy.copy(args)
                 wargs.send = name == "cfg2_sends"
@@ -926,18 +1004,27 @@ def other_configs(env, args):
                 wargs.voice_spatial = name == "cfg2_spatial"
                 if name == "cfg2_variantB":
                     wargs.variant = "B"
-            r = run_workload(env, wargs, wl, V, B, K, F, steps, 3, full=False)
+                if name == "cfg2_i16":
+                    wargs.source_format = sfmt = "i16"
+            runs = [run_workload(env, wargs, wl, V, B, K, F, steps, 3, full=False) for _ in range(n_ctx)]
+            order = sorted(range(n_ctx), key=lambda i: runs[i]["ms_per_step"])
+            r = runs[order[n_ctx // 2]]
             cfg = r["config"]
             ent = {"workload": cfg["workload"], "value": r["value"], "unit": "voice-samples/s", "ms_per_step": r["ms_per_step"],
                    "steps": steps, "blocks_per_step": K, "launch_plan": cfg["launch_plan"], "realtime_factor": cfg["realtime_factor"],
                    "roofline": r["roofline"]}
+            if n_ctx > 1:
+                ent["contexts"] = context_summary(runs, order[n_ctx // 2])
             if not args.no_parity_check:
                 torch = env["torch"]
                 gen = torch.Generator(device=env["dev"])
                 gen.manual_seed(env["shard"].voice_seed(0))
-                src = torch.empty((V, 2, F), dtype=torch.float32, device=env["dev"])
-                src.uniform_(-1.0, 1.0, generator=gen)
-                ent["parity_check"] = parity_check(env["fa"], torch, wl, V, B, K, args.radix, 0, wargs, src, F, "f32",
+                if sfmt == "i16":
+                    src = torch.randint(-32768, 32768, (V, F, 2), dtype=torch.int16, device=env["dev"], generator=gen)
+                else:
+                    src = torch.empty((V, 2, F), dtype=torch.float32, device=env["dev"])
+                    src.uniform_(-1.0, 1.0, generator=gen)
+                ent["parity_check"] = parity_check(env["fa"], torch, wl, V, B, K, args.radix, 0, wargs, src, F, sfmt,
                                                    torch.cuda.current_stream().cuda_stream, env["device"])
                 del src
                 torch.cuda.empty_cache()
@@ -1055,7 +1142,7 @@ def main():
                     help="cfg2/cfg5: every fourth leaf bus also feeds a send -> gain -> width -> limiter return mixed with the root "
                          "(buses consumed twice: the hybrid plan — voice banks on the voice-bank kernels, the rest on the level executor)")
     ap.add_argument("--voice-spatial", action="store_true",
-                    help="cfg2/cfg5: a SPEC 3D spatialiser node at the end of every voice (not a fused shape: generic executor)")
+                    help="cfg2/cfg5: a SPEC 3D spatialiser node at the end of every voice (the voice-bank plan's last stage, k_leaf_sum<.., SP>)")
     ap.add_argument("--voice-fx", action="store_true",
                     help="cfg2/cfg5: a StereoWidthNode + HardClipNode at the end of every voice chain")
     ap.add_argument("--rs-source", action="store_true",
@@ -1170,11 +1257,7 @@ def main():
         ctx_runs.append(res)
         order = sorted(range(len(ctx_runs)), key=lambda i: ctx_runs[i]["ms_per_step"])
         mid = order[len(order) // 2]
-        ms = [r["ms_per_step"] for r in ctx_runs]
-        kus = [(r["roofline"] or {}).get("avg_launch_us") for r in ctx_runs]
-        contexts = {"n": len(ctx_runs), "ms_per_step_runs": ms, "kernel_us_runs": kus, "roofline_frac_runs": [(r["roofline"] or {}).get("frac") for r in ctx_runs],
-                    "median": ms[mid], "min": min(ms), "max": max(ms), "reported": "the median context (run %d of %d): value, ms_per_step and roofline are its own" % (mid, len(ctx_runs)),
-                    "why": "the kernel runs in one of two HBM placement states fixed per context at allocation (DESIGN.md section 7)"}
+        contexts = context_summary(ctx_runs, mid)
         for k in ("value", "ms_per_step", "roofline"):
             res[k] = ctx_runs[mid][k]
     if rank == 0:
@@ -1195,6 +1278,7 @@ def main():
             "roofline": res["roofline"],
             "cpu_baseline": res.get("cpu_baseline"),
             "parity_check": res.get("parity_check"),
+            "parity_check_timed_context": res.get("parity_check_timed_context"),
             "realtime_us_per_callback": res.get("realtime_us_per_callback"),
             "realtime_us_per_callback_from_python": res.get("realtime_us_per_callback_from_python"),
             "ranks_seen": ranks_seen,

@@ -1216,6 +1216,16 @@ int fwgpu_timing_reset(fwgpu_ctx* c) {
     }
     return 0;
 }
+// debugging aid (not part of include/fwgpu.h): the fused plan's mix buses of block 0 of the last call, [n_bus][stride] floats
+int fwgpu_debug_read_bus(fwgpu_ctx* c, float* out, uint64_t max_floats) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    (void)rt_persist_stop(c);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (!c->d_bus.p) return fail(c, FWGPU_ERR_INVALID, "no fused plan");
+    const uint64_t n = std::min<uint64_t>(max_floats, (uint64_t)c->n_bus * c->stride);
+    HIPC(c, hipMemcpy(out, c->d_bus.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return (int)c->n_bus;
+}
 #ifdef FW_CHAIN_TRACE
 // profiling builds only (scripts/chain_trace.py): timestamps [step 0..63][wave 0..15][slot 0..7] of workgroup 0
 int fwgpu_debug_read_trace(fwgpu_ctx* c, unsigned long long* out) {

@@ -181,6 +181,8 @@ struct PlanImage {
     DevBuf d_ctl_order;
     bool ctl_order_live = false;        // the device copy holds this call's order (else: identity, nothing uploaded)
     DevBuf d_rs_wl;           // resampler plans: the work list between k_leaf_rs and k_leaf_sum_wl (FusedView::rs_wl)
+    DevBuf d_rs_tmpl;         // resampler plans: [2][n_voices] VoiceBlk — the template a steady resampler voice's VB_RS_LEAN blocks of a call
+                              // share (FusedView::rs_tmpl); two copies: the control-ahead mode writes call n+1's while call n renders
     DevBuf d_progs, d_hist;   // d_hist: [n_voices][SP_HIST] mono histories the spatialiser voices enter the call with
     DevBuf d_voices, d_leaves, d_blks, d_refs, d_gsets, d_cache, d_ramps, d_bus, d_bus_flags, d_chain_start, d_chain_dummy, d_chain_stats;
     DevBuf d_up_nodes, d_up_in, d_up_out, d_up_level_nodes, d_root_bufs;

@@ -63,6 +63,7 @@ struct FusedView {
     VoiceCache* cache;  // [n_voices]
     uint32_t epoch;     // >= 1
     VoiceBlk* blks;   // [K][n_voices], written only for blocks that are neither silent nor VB_SIMPLE
+    VoiceBlk* rs_tmpl;  // has_rs: [n_voices] the descriptor a steady resampler voice's VB_RS_LEAN blocks of this call share (all but off0)
     const float* rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS] (voices whose source is a resampler)
     const uint32_t* progs;  // [n_voices] stage programs (SK_*, 4 bits per chain stage); nullptr / all 0 on gains-only plans
     int has_prog;           // some voice's program is not 0 (or its source is a resampler): k_leaf_sum<true>

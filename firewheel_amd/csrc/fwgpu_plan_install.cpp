@@ -266,7 +266,7 @@ static int zero(fwgpu_ctx* c, void* p, size_t bytes) { return fill_rows(c, p, by
 
 void PlanImage::release_device() {
     DevBuf* bufs[] = {&d_nodes, &d_in_buf, &d_out_buf, &d_level_nodes, &d_pool, &d_flags, &d_gin_bufs, &d_gout_bufs, &d_groups, &d_blks2, &d_refs2,
-                      &d_gsets2, &d_ramps2, &d_progs, &d_hist, &d_rs_wl, &d_ctl_order, &d_slot_voice, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
+                      &d_gsets2, &d_ramps2, &d_progs, &d_hist, &d_rs_wl, &d_rs_tmpl, &d_ctl_order, &d_slot_voice, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
                       &d_chain_start, &d_chain_dummy, &d_chain_stats, &d_up_nodes, &d_up_in, &d_up_out, &d_up_level_nodes, &d_root_bufs, &d_tail_nodes,
                       &d_tail_in, &d_tail_out, &d_tail_idx, &d_tail_frozen, &d_frozen_ph, &d_frozen, &d_fir_rows, &d_fir_tiles, &d_fir_partials,
                       &d_hlevel_nodes, &grow_states, &grow_ext, &d_state_inits, &d_ext_jobs};
@@ -377,6 +377,7 @@ static int alloc_voice_tables(fwgpu_ctx* c, PlanImage& P) {
     if (P.fused_rs) {  // one item per (leaf, block, 256-frame piece) at most
         HIPC(c, P.d_rs_wl.ensure_n("d_rs_wl", (2 + 2 * (size_t)P.n_leaves * K * LEAF_WPB_MAX) * sizeof(unsigned int)));
         if ((rc = zero(c, P.d_rs_wl.p, 2 * sizeof(unsigned int)))) return rc;
+        HIPC(c, P.d_rs_tmpl.ensure_n("d_rs_tmpl", 2 * std::max<size_t>(1, (size_t)P.n_voices) * sizeof(VoiceBlk)));
     }
     return 0;
 }

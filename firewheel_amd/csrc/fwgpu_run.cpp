@@ -293,6 +293,7 @@ static void fill_fused_view(fwgpu_ctx* c, FusedView& fv) {
     fv.has_rs = c->fused_rs ? 1 : 0;
     fv.has_sp = c->fused_sp ? 1 : 0;
     fv.rs_wl = c->d_rs_wl.as<unsigned int>();
+    fv.rs_tmpl = c->fused_rs ? c->d_rs_tmpl.as<VoiceBlk>() : nullptr;
     fv.ctl_order = c->ctl_order_live ? c->d_ctl_order.as<int>() : nullptr;
     fv.sp_hist_in_render = (c->ahead_this_call && c->fused_sp) ? 1 : 0;
     fv.hist = c->d_hist.as<float>();
@@ -569,6 +570,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
             fv.refs = c->d_refs2.as<VoiceRef>();
             fv.gsets = c->d_gsets2.as<GainSet>();
             fv.ramps = c->d_ramps2.as<float>();
+            if (fv.rs_tmpl) fv.rs_tmpl += c->n_voices;
         }
         if (c->ahead_seq >= 2) HIPC(c, hipStreamWaitEvent(c->ctl_stream, c->ev_render[p], 0));  // batch b-2 has read this copy
         LCHK(c, launch_voice_control(c->ctl_stream, fv, K, cmd_block0, true));

@@ -145,6 +145,10 @@ enum : uint32_t {
                           //   delay sits between the sampler and the gain stages: their tails keep ringing)
     VB_RESAMPLE = 64u,    // resampling source (SPEC): off0 = 32.32 position of frame 0, off1 = 32.32 step, n1 = loops;
                           //   every such block carries a full VoiceBlk (the 16-tap polyphase fetch is the leaf kernel's slow path)
+    VB_RS_LEAN = 128u,    // a resampler block of a STEADY voice (VoiceRef::flags_gset only; round 4): its full descriptor is the voice's
+                          //   template FusedView::rs_tmpl[voice] — written once per call — with off0 = the 32.32 position carried in
+                          //   VoiceRef::src_l; no VoiceBlk row is written for it (they were 75 MB per 768-block call of 1 024 voices,
+                          //   and what the control kernel's 42 us went into)
     VB_FMT_SHIFT = 24,    // VB_RESAMPLE blocks: bits 24..26 = the sample's format (FMT_*), src_l = its data, pad = its frames (< 2^31)
                           //   — the leaf kernel needs no second dependent load for the sample table
     VB_RAMP_SHIFT = 8,    // bit (VB_RAMP_SHIFT + 2*stage + ch): that gain is a per-frame ramp (12 bits: 8..19)

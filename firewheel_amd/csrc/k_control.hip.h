@@ -371,7 +371,9 @@ __device__ __forceinline__ bool rs_survives(uint64_t pos, uint64_t step, uint64_
 // the loop end (nodes/sampler.rs:445-484) — closed form (base + j*frames) mod L, so the 64 lanes of the
 // voice's wave fill 64 blocks at a time.  Returns the playhead the reference holds after block K-1.
 __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int lane, int k_first, int K, const TailJob& job,
-                                                const SampleDesc& sd, uint32_t gset, bool simple_ok, bool fx, bool fxp) {
+                                                const SampleDesc& sd, uint32_t gset, bool simple_ok, bool fx, bool fxp, bool rs_lean = true) {
+    // rs_lean: this tail may use the voice's resampler template (VB_RS_LEAN) — at most ONE tail per voice and call does (a call with
+    // a message in it has two steady stretches, and the second one's step or gains may differ from the first's)
     // fx: this voice has a biquad / delay (silence does not pass it); fxp: the PLAN is the chain plan — k_chain reads
     // either a VB_SIMPLE record (planar f32, or VB_SRC_ZERO) or a full descriptor for EVERY voice of the plan, dry ones too
     const int frames = fv.frames;
@@ -480,22 +482,48 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
     }
     if (job.mode == 3) {  // resampling source: position of block j = (pos + j * frames * step) mod (len << 32) when it loops
         const uint64_t adv = fr * job.loop_start;
-        for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
-            const uint32_t rb = tail_ramp_bits(job, k2);
-            uint64_t pos = job.playhead + (uint64_t)(k2 - k_first) * adv;
-            if (job.loop_end) pos %= job.loop_end;
-            t.flags = job.flags | (rb << VB_RAMP_SHIFT) | ((uint32_t)sd.format << VB_FMT_SHIFT);
-            t.off0 = pos;
-            t.off1 = job.loop_start;
-            t.n1 = job.loop_end ? 1u : 0u;
-            t.src_l = (const float*)sd.data;
-            t.src_r = nullptr;
-            t.pad = (uint32_t)sd.frames;
-            put_blk(fv, vi, k2, t, gset, sd, fxp);
+        const uint64_t M = job.loop_end;
+        // the lane's first block, then 64 blocks further per round: ONE 64-bit remainder per lane instead of one per block
+        uint64_t pos = job.playhead + (uint64_t)lane * adv;
+        uint64_t inc = (uint64_t)WAVE * adv;
+        if (M) {
+            pos %= M;
+            inc %= M;
         }
-        uint64_t pos = job.playhead + n * adv;
-        if (job.loop_end) pos %= job.loop_end;
-        return pos;
+        t.off1 = job.loop_start;
+        t.n1 = M ? 1u : 0u;
+        t.src_l = (const float*)sd.data;
+        t.src_r = nullptr;
+        t.pad = (uint32_t)sd.frames;
+        // Round 4: blocks without a ramp share everything but the position — ONE template per voice and call (rs_tmpl) and a
+        // 16-byte record per block (VB_RS_LEAN: the position rides in src_l) instead of a 96-byte VoiceBlk row per block: those
+        // rows were 75 MB per 768-block call of 1 024 voices, written 96 bytes at a time into lines two waves share.
+        const uint32_t flags0 = job.flags | ((uint32_t)sd.format << VB_FMT_SHIFT);
+        const bool lean_ok = rs_lean && !fxp && !(flags0 & (VB_SIMPLE | VB_SILENT)) && fv.rs_tmpl != nullptr;
+        if (lean_ok && lane == 0) {
+            t.flags = flags0;
+            t.off0 = 0;
+            fv.rs_tmpl[vi] = t;
+        }
+        VoiceRef lref;
+        lref.r_delta = 0u;
+        lref.flags_gset = (flags0 & 0xffu) | VB_RS_LEAN | (gset << 8) | ((uint32_t)SF_P_F32 << 16);
+        for (int k2 = k_first + lane; k2 < K; k2 += WAVE) {
+            const uint32_t rb = k2 >= ramps_end ? 0u : tail_ramp_bits(job, k2);
+            if (lean_ok && rb == 0) {
+                lref.src_l = (const float*)pos;
+                fv.refs[ref_index(vi, k2, fv.ref_kgroups)] = lref;
+            } else {
+                t.flags = flags0 | (rb << VB_RAMP_SHIFT);
+                t.off0 = pos;
+                put_blk(fv, vi, k2, t, gset, sd, fxp);
+            }
+            pos += inc;
+            if (M && pos >= M) pos -= M;
+        }
+        uint64_t end = job.playhead + n * adv;
+        if (M) end %= M;
+        return end;
     }
     // nothing moves (mode 0 <=> the sampler is frozen): with fx the block still runs (zeros in, constant gains)
     if (fxp && simple_ok) t.flags |= VB_SIMPLE;
@@ -519,10 +547,9 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
     const VoiceDesc vd = fv.voices[vi];
     // (the steady cache is indexed by the voice too: asked for HERE it shares the descriptor's round trip instead of following it —
     //  a message-free call's wave is three dependent round trips and a few stores, nothing else)
-    //  — in the control KERNEL (EARLY_VC).  The one-launch realtime kernels keep the load where it was, behind the message spans: with
-    //  it up here k_rt_persist rendered 8 garbage frames per block (r04, every run; k_rt_block did not) — not understood, the
-    //  kernel is 237 VGPRs + 788 spilled SGPRs either way; they gain nothing from the early load anyway (their steady voices take
-    //  voice_control_lane_steady).
+    //  — in the control KERNEL (EARLY_VC): the one-launch realtime kernels gain nothing from it, their steady voices take
+    //  voice_control_lane_steady.  (Round 4 first blamed this load for 8 garbage frames per block out of k_rt_persist; the cause
+    //  was the leaf bus stores' inline asm, k_leaf.hip.h bus_store_pair, which any change of register allocation could expose.)
     VoiceCache vc;
     if (EARLY_VC) vc = fv.cache[vi];
     const int frames = fv.frames;
@@ -1111,7 +1138,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                 simple_ok = (probe.flags & VB_SIMPLE) != 0;  // false when the voice ran out of gain-set slots
             }
             CTL_T(6);
-            uint64_t ph = steady_tail(fv, vi, lane, k + 1, K, job, sd, tail_gs, simple_ok, fx, fxp);
+            uint64_t ph = steady_tail(fv, vi, lane, k + 1, K, job, sd, tail_gs, simple_ok, fx, fxp, k0 == 0);
             if (mode != 0) ss.playhead = ph;
         }
         break;

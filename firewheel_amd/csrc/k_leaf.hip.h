@@ -46,6 +46,37 @@ __device__ __forceinline__ int64_t rs_slot(int64_t q, const int64_t len, const b
     return in ? q : 0;
 }
 
+// A leaf's two bus rows go out write-through (sc0 sc1: the root reads them from another XCD's L2 side).  ONE asm statement for the
+// pair, both addresses computed before it and every operand live across it, and wait states behind it: written as two statements
+// the compiler — which cannot see that the asm is a 128-bit store still reading its data registers — put the second store's
+// address into v[2:3] of the first store's data three instructions after issuing it, and the last four lanes of every 16 took
+// the pointer for audio (k_rt_persist, round 4: frames 48-63 of a leaf bus, whenever register allocation fell that way; round 3
+// met the same garbage and blamed the kernel's size).  LLVM's hazard recognizer covers this for stores it knows
+// (checkVALUHazardsHelper: VMEM store > 64 bits followed by a VALU write of its data); inline asm is opaque to it.
+__device__ __forceinline__ void bus_store_pair(float* pl, float* pr, const v4f& a, const v4f& b) {
+    asm volatile(
+        "global_store_dwordx4 %0, %2, off sc0 sc1\n\t"
+        "global_store_dwordx4 %1, %3, off sc0 sc1\n\t"
+        "s_nop 7\n\t"
+        "s_nop 7" ::"v"(pl),
+        "v"(pr), "v"(a), "v"(b)
+        : "memory");
+}
+
+// The full descriptor of (block k, voice): its VoiceBlk row — or, for a VB_RS_LEAN block (a steady resampler voice: fg = the
+// record's flags, ref_src = its src_l field), the voice's template with the block's 32.32 position put in.
+template <bool RS>
+__device__ __forceinline__ VoiceBlk blk_load(const FusedView& fv, const size_t k, const int voice, const uint32_t fg, const float* ref_src) {
+    if constexpr (RS) {
+        if (fg & VB_RS_LEAN) {
+            VoiceBlk d = fv.rs_tmpl[voice];
+            d.off0 = (uint64_t)ref_src;
+            return d;
+        }
+    }
+    return fv.blks[k * fv.n_voices + voice];
+}
+
 // RS: the plan has voices whose source is a resampler (only the program instantiation of the leaf kernel carries that code)
 // j_end: stages [0, j_end) are applied (a spatialiser voice stops in front of its last stage: leaf_sp_port does that one)
 template <bool RS>
@@ -380,7 +411,7 @@ __device__ __forceinline__ void sp_upstream(const FusedView& fv, uint32_t fg, co
         for (int j = 0; j < FW_MAX_STAGES; ++j)
             if (j <= js) apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(gs_lane->g[j][0], p)), splat(readlane_f(gs_lane->g[j][1], p)), a, b);
     } else {
-        const VoiceBlk d = fv.blks[(size_t)k * fv.n_voices + voice];
+        const VoiceBlk d = blk_load<RS>(fv, k, voice, fg, src);
         voice_eval<RS>(fv, d, k, voice, f0, frames, a, b, prog, RsLds{nullptr, nullptr}, js + 1);
     }
 }
@@ -522,8 +553,8 @@ template <bool PROG, bool RS>
 __device__ __forceinline__ void leaf_rs_piece(const FusedView& fv, const LeafDesc& ld, const uint32_t k, const size_t row, const int f0, const int frames,
                                               const RsLds rs, const float* my_l, const uint32_t my_rd, const uint32_t my_cls, const GainSet& my_g,
                                               const uint32_t my_prog, const uint64_t my_off0, const uint64_t my_off1, const uint32_t my_df,
-                                              const uint64_t silent_ports, const uint64_t simple_ports, const uint64_t rs_ports, const bool masked,
-                                              v4f& accl, v4f& accr) {
+                                              const uint64_t silent_ports, const uint64_t simple_ports, const uint64_t rs_ports, const uint64_t lean_ports,
+                                              const bool masked, v4f& accl, v4f& accr) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int fbase = __builtin_amdgcn_readfirstlane(f0 - lane * 4);  // the wave's piece of the block starts here
     const int nfr = frames - fbase < 256 ? frames - fbase : 256;
@@ -612,7 +643,7 @@ __device__ __forceinline__ void leaf_rs_piece(const FusedView& fv, const LeafDes
                     if (j < fv.n_gain_stages)
                         apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)), xl, xr);
             } else {
-                const VoiceBlk d = fv.blks[row + p];
+                const VoiceBlk d = blk_load<RS>(fv, k, ld.first_voice + p, (lean_ports >> p) & 1ull ? VB_RS_LEAN : 0u, readlane_ptr(my_l, p));
                 voice_eval<RS>(fv, d, k, ld.first_voice + p, f0, frames, xl, xr, prog);
             }
         }
@@ -642,7 +673,7 @@ struct RsPure {
     bool pure;
 };
 __device__ __forceinline__ RsPure rs_pure_lane(const FusedView& fv, const size_t row, const int lane, const int ports, const uint32_t my_flags,
-                                               const int frames) {
+                                               const int frames, const int voice, const uint64_t ref_pos) {
     RsPure r;
     r.s0 = nullptr;
     r.len = 0u;
@@ -651,11 +682,12 @@ __device__ __forceinline__ RsPure rs_pure_lane(const FusedView& fv, const size_t
     r.df = 0u;
     r.pure = false;
     if (lane < ports && !(my_flags & (VB_SILENT | VB_SIMPLE))) {
-        const VoiceBlk* b = fv.blks + row + lane;
+        const bool lean = (my_flags & VB_RS_LEAN) != 0;  // a steady voice: the call's template + this block's position from the record
+        const VoiceBlk* b = lean ? fv.rs_tmpl + voice : fv.blks + row + lane;
         const uint32_t df = b->flags;
         if ((df & VB_RESAMPLE) && !(df & VB_RAMP_MASK) && ((df >> VB_FMT_SHIFT) & 7u) == (uint32_t)FMT_P_F32) {
             const uint32_t len = b->pad;
-            const uint64_t off0 = b->off0, step = b->off1;
+            const uint64_t off0 = lean ? ref_pos : b->off0, step = b->off1;
             const bool loop = b->n1 != 0;
             const int nfr = frames < 256 ? frames : 256;
             const uint64_t w_max = (((uint64_t)nfr * step + 0xffffffffull) >> 32) + 1 + RS_TAPS;  // any piece of the block
@@ -820,8 +852,7 @@ __device__ __forceinline__ void leaf_sp_fast(const FusedView& fv, const LeafDesc
             __builtin_amdgcn_wave_barrier();  // (the next batch overwrites the rows)
         }
         if (act) {
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(outl + f0), "v"(accl) : "memory");
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(outr + f0), "v"(accr) : "memory");
+            bus_store_pair(outl + f0, outr + f0, accl, accr);
         }
     }
 }
@@ -964,7 +995,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                                     if (j < fv.n_gain_stages)
                                         apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)), xl, xr);
                             } else {
-                                const VoiceBlk d = fv.blks[row + p];
+                                const VoiceBlk d = blk_load<RS>(fv, k, voice, pfg, readlane_ptr(my_l, p));
                                 voice_eval<RS>(fv, d, k, voice, f0, frames, xl, xr, prog, rs);
                             }
                         }
@@ -1045,8 +1076,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                     any_live = any_live || !psil;
                 }
                 if (act) {
-                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(outl + f0), "v"(accl) : "memory");
-                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(outr + f0), "v"(accr) : "memory");
+                    bus_store_pair(outl + f0, outr + f0, accl, accr);
                 }
             }
             if (lane < 2 && part == 0) bflags[ld.out_buf + lane] = 0;  // a spatialiser port is never silent: the mixer's out mask is 0
@@ -1061,14 +1091,16 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
     // position and step, flags, the constant gains — and says whether the staged path can render it (leaf_rs_piece)
     uint64_t rs_ports = 0ull, my_off0 = 0ull, my_off1 = 0ull;
     uint32_t my_df = 0u;
+    const uint64_t lean_ports = RS ? __ballot((my_flags & VB_RS_LEAN) != 0) & lanes_in : 0ull;
     if constexpr (RS) {
         bool el = false;
         if (rs.tab != nullptr && lane < ld.ports && !(my_flags & (VB_SILENT | VB_SIMPLE))) {
-            const VoiceBlk* b = fv.blks + row + lane;
+            const bool lean = (my_flags & VB_RS_LEAN) != 0;
+            const VoiceBlk* b = lean ? fv.rs_tmpl + (ld.first_voice + lane) : fv.blks + row + lane;
             const uint32_t df = b->flags;
             if (df & VB_RESAMPLE) {
                 const uint32_t len = b->pad;
-                const uint64_t off0 = b->off0, step = b->off1;
+                const uint64_t off0 = lean ? (uint64_t)ref.src_l : b->off0, step = b->off1;
                 const bool loop = b->n1 != 0;
                 const int nfr = frames < 256 ? frames : 256;
                 const uint64_t w_max = (((uint64_t)nfr * step + 0xffffffffull) >> 32) + 1 + RS_TAPS;  // any piece of the block
@@ -1117,7 +1149,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
         if constexpr (RS) {
             if (rs_ports) {
                 leaf_rs_piece<PROG, RS>(fv, ld, k, row, f0, frames, rs, my_l, my_rd, my_cls, my_g, my_prog, my_off0, my_off1, my_df, silent_ports,
-                                        simple_ports, rs_ports, masked, accl, accr);
+                                        simple_ports, rs_ports, lean_ports, masked, accl, accr);
                 rs_done = true;
             }
         }
@@ -1171,7 +1203,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                                 apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)),
                                             xl, xr);
                     } else {
-                        const VoiceBlk d = fv.blks[row + p];
+                        const VoiceBlk d = blk_load<RS>(fv, k, ld.first_voice + p, (lean_ports >> p) & 1ull ? VB_RS_LEAN : 0u, readlane_ptr(my_l, p));
                         voice_eval<RS>(fv, d, k, ld.first_voice + p, f0, frames, xl, xr, prog, rs);
                     }
                 }
@@ -1186,8 +1218,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
             }
         }
 #if LEAF_NT_STORE == 2
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(outl + f0), "v"(accl) : "memory");
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(outr + f0), "v"(accr) : "memory");
+        bus_store_pair(outl + f0, outr + f0, accl, accr);
 #elif LEAF_NT_STORE
         __builtin_nontemporal_store(accl, (v4f*)(outl + f0));
         __builtin_nontemporal_store(accr, (v4f*)(outr + f0));
@@ -1274,10 +1305,15 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, 4) void k_leaf_rs(FusedView fv, int
     v2f_rs* win = (v2f_rs*)(s_leaf_dyn + RS_PHASES * RS_TAPS + wave * (2 * RS2_WIN));
     const size_t row = (size_t)k * fv.n_voices + ld.first_voice;
     uint32_t my_flags = VB_SILENT;
-    if (lane < ld.ports) my_flags = fv.refs[ref_index(ld.first_voice + lane, (int)k, fv.ref_kgroups)].flags_gset & 0xffu;
+    uint64_t my_pos = 0ull;
+    if (lane < ld.ports) {
+        const VoiceRef ref = fv.refs[ref_index(ld.first_voice + lane, (int)k, fv.ref_kgroups)];
+        my_flags = ref.flags_gset & 0xffu;
+        my_pos = (uint64_t)ref.src_l;
+    }
     const uint64_t lanes_in = mask_all_silent_bits(ld.ports);
     const uint64_t silent_ports = __ballot((my_flags & VB_SILENT) != 0) & lanes_in;
-    const RsPure me = rs_pure_lane(fv, row, lane, ld.ports, my_flags, frames);
+    const RsPure me = rs_pure_lane(fv, row, lane, ld.ports, my_flags, frames, ld.first_voice + lane, my_pos);
     const uint64_t pure_ports = __ballot(me.pure) & lanes_in;
     if (!(pure_ports && ((pure_ports | silent_ports) & lanes_in) == lanes_in)) {  // not ours: onto the general kernel's work list
         if (lane == 0) {
@@ -1297,7 +1333,7 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, 4) void k_leaf_rs(FusedView fv, int
     for (int j = 0; j < FW_MAX_STAGES; ++j) my_g[j][0] = my_g[j][1] = 1.0f;
     if (me.pure) {
         my_prog = fv.progs[ld.first_voice + lane];
-        const VoiceBlk* b = fv.blks + row + lane;
+        const VoiceBlk* b = (my_flags & VB_RS_LEAN) ? fv.rs_tmpl + (ld.first_voice + lane) : fv.blks + row + lane;
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES; ++j) {
             my_g[j][0] = b->g[j][0];
@@ -1469,9 +1505,12 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, 4) void k_leaf_rs(FusedView fv, int
 // empties the list for the next pair of launches.
 __global__ __launch_bounds__(WAVE* LEAF_WPB, 3) void k_leaf_sum_wl(FusedView fv, int K, int wpk) {
     extern __shared__ float s_leaf_dyn[];
+    // (an empty list — every leaf resampler-pure, the steady state of a bank of resampled voices — is the common case: nothing to set
+    //  up, nothing to reset; the launch then costs its dispatch, not 768 filter-bank copies: 13.4 -> ~3 us per step, r04)
+    const unsigned int count = __hip_atomic_load(fv.rs_wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (count == 0u) return;
     const RsLds rs = rs_lds_setup(fv, s_leaf_dyn);
     const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned int count = __hip_atomic_load(fv.rs_wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (unsigned int it = blockIdx.x * LEAF_WPB + wave; it < count; it += gridDim.x * LEAF_WPB) {
         const int leaf = __builtin_amdgcn_readfirstlane((int)fv.rs_wl[2 + 2 * it]);
         const unsigned int kp = (unsigned int)__builtin_amdgcn_readfirstlane((int)fv.rs_wl[3 + 2 * it]);

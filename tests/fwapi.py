@@ -442,9 +442,28 @@ class PlannerEngine(Engine):
 
 
 def xorshift_uniform(seed, n):
-    """Deterministic uniform(-1,1) f32 stream (seeded xorshift), vectorised per call."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    return (rng.random(n, dtype=np.float32) * 2.0 - 1.0).astype(np.float32)
+    """Deterministic uniform [-1, 1) f32 stream, LANGUAGE-NEUTRAL (round 4: the scenarios are exported as JSON for a Rust test on the
+    real firewheel-graph, tests/golden/scenarios/ — numpy's PCG64 could not be restated there): element i of stream `seed` is
+        x = (seed + (i + 1) * 0x9E3779B9) mod 2^32          (counter-based: no state, any element on its own)
+        x ^= x >> 16;  x *= 0x85EBCA6B;  x ^= x >> 13;  x *= 0xC2B2AE35;  x ^= x >> 16     (murmur3's 32-bit finaliser, mod 2^32)
+        value = f32(x >> 8) * 2^-23 - 1                      (exact in f32: 24 bits, a multiple of 2^-23 in [-1, 1))
+    (The name is historical: SURVEY 8d's "seeded xorshift".)"""
+    i = np.arange(1, n + 1, dtype=np.uint64)
+    x = (np.uint64(int(seed) & 0xFFFFFFFF) + i * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    out = ((x >> np.uint64(8)).astype(np.float32) * np.float32(2.0 ** -23) - np.float32(1.0)).astype(np.float32)
+    _GEN_LOG.append((int(seed) & 0xFFFFFFFF, int(n), out))
+    if len(_GEN_LOG) > 4096:
+        del _GEN_LOG[:2048]
+    return out
+
+
+# the streams handed out lately: (seed, n, array) — tests/golden/make_scenarios_json.py finds the recipe of a sample's data among them
+_GEN_LOG = []
 
 
 class _DeviceResult(object):

@@ -139,6 +139,104 @@ def scenario_voice_bank_events(e, n_voices=70, radix=32, mbf=None, src_frames=10
     return np.concatenate(outs)
 
 
+def scenario_ref_desk(e, n_voices=30, radix=8, src_frames=1100, seed=5):
+    """REFERENCE KINDS ONLY (sampler, volume, hard clip, mono<->stereo, sum, beep: crates/firewheel-graph/src/basic_nodes/) — the
+    scenario the Rust replay on the real firewheel-graph can run (rust/firewheel-gpu/tests/reference_digests.rs): a small desk of
+    sampler -> volume [-> hard clip] voices in all six sample formats, mono samplers through MonoToStereo, a beep, a radix sum
+    tree, a master volume; loop wraps inside blocks, one-shot ends, pauses (silence masks), gain changes that settle and that stall,
+    a fade to zero, sample swaps, playhead jumps, loop ranges (Q7) — whole blocks only (Q5), ranges inside the samples (Q8)."""
+    fmts = [PLANAR_F32, INTERLEAVED_I16, PLANAR_U16, INTERLEAVED_F32, PLANAR_I16, INTERLEAVED_U16]
+    voices, ends = [], []
+    for v in range(n_voices):
+        mono = v % 6 == 4
+        s = e.sampler(100.0 if v % 4 else 70.0, n_out=1 if mono else 2)
+        cur = s
+        if mono:
+            m2s = e.add_node(MONO_TO_STEREO, 1, 2)
+            e.connect(s, 0, m2s, 0)
+            cur = m2s
+        vol = e.volume(30.0 + 2.0 * v)
+        e.connect_stereo(cur, vol)
+        cur = vol
+        if v % 3 == 1:
+            clip = e.hard_clip(-6.0 - v * 0.25)
+            e.connect_stereo(cur, clip)
+            cur = clip
+        voices.append(dict(sampler=s, volume=vol, mono=mono))
+        ends.append(cur)
+    beep = e.beep(330.0, -18.0, True, n_out=2)
+    ends.append(beep)
+    level = ends
+    while len(level) > 1:
+        nxt = []
+        for i in range(0, len(level), radix):
+            grp = level[i:i + radix]
+            m = e.sum(len(grp))
+            for p, n in enumerate(grp):
+                e.connect_stereo(n, m, 2 * p)
+            nxt.append(m)
+        level = nxt
+    master = e.volume(80.0)
+    e.connect_stereo(level[0], master)
+    e.connect_stereo(master, e.graph_out_node)
+    e.update()
+    samples = []
+    for v, vc in enumerate(voices):
+        ch = 1 if (vc["mono"] or v % 7 == 2) else 2
+        vfmt = fmts[v % 6]
+        data = voice_source(seed * 100000 + v, src_frames + 13 * v, ch)
+        if vfmt in (PLANAR_I16, INTERLEAVED_I16):
+            raw = np.round(data * 32767).astype(np.int16)
+        elif vfmt in (PLANAR_U16, INTERLEAVED_U16):
+            raw = np.round((data + 1) * 32767.5).astype(np.uint16)
+        else:
+            raw = data
+        if vfmt <= INTERLEAVED_F32:
+            raw = raw.T.copy()
+        samples.append(e.new_sample(vfmt, ch, raw))
+        vc["frames"] = src_frames + 13 * v
+        e.sampler_set_sample(vc["sampler"], samples[-1])
+        if v % 5 != 3:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)   # v % 5 == 3: one-shots
+        if v % 4 != 1:
+            e.sampler_play(vc["sampler"])                         # v % 4 == 1: started later
+    outs = [e.process_blocks(3)]
+    for v, vc in enumerate(voices):
+        if v % 3 == 0:
+            e.set_param(vc["volume"], 0, 25.0 if v % 2 else 90.0, at_block=0)
+        if v % 10 == 4:
+            e.set_param(vc["sampler"], 0, 0.0, at_block=1)        # fades to 0, settles (Q3)
+        if v % 4 == 1:
+            e.sampler_play(vc["sampler"], at_block=1)
+        if v % 11 == 5:
+            e.sampler_pause(vc["sampler"], at_block=3)
+    e.set_param(master, 0, 55.0, at_block=2)
+    outs.append(e.process_blocks(5))
+    outs.append(e.process_blocks(26))                              # ramps settle or stall (Q28), one-shots end, loops wrap
+    for v, vc in enumerate(voices):
+        if v % 9 == 0:
+            e.sampler_stop(vc["sampler"])
+        if v % 9 == 1:
+            e.sampler_set_playhead_secs(vc["sampler"], 300.25 / e.sample_rate)
+        if v % 9 == 2:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_RANGE_SECS, 100.0 / e.sample_rate, (vc["frames"] - 100.0) / e.sample_rate)
+        if v % 9 == 3:
+            e.sampler_play(vc["sampler"])
+        if v % 9 == 4 and not vc["mono"]:                          # another sample, playback kept / stopped
+            e.sampler_set_sample(vc["sampler"], samples[(v + 6) % n_voices], stop_playback=(v % 2 == 0))
+        if v % 9 == 5:
+            e.set_param(vc["volume"], 0, 0.0)                      # mute: the chain behind it goes silent once it has settled
+    outs.append(e.process_blocks(4))
+    for v, vc in enumerate(voices):
+        if v % 9 == 0 or (v % 9 == 4 and v % 2 == 0):
+            e.sampler_play(vc["sampler"], at_block=1)
+        if v % 9 == 5:
+            e.set_param(vc["volume"], 0, 65.0, at_block=2)
+    e.set_param(master, 0, 100.0)
+    outs.append(e.process_blocks(7))
+    return np.concatenate(outs)
+
+
 def scenario_message_storm(e, n_voices=48, radix=8, blocks=40, per_voice=6, src_frames=5000, seed=3):
     """hundreds to thousands of messages inside ONE call: every voice gets `per_voice` gain / pan / pause / play messages at
     random blocks (several per block on some voices).  The control kernel finds a voice's messages in the sorted list of the

@@ -40,6 +40,12 @@ CASES = {
                                                                              fmt=fwapi.PLANAR_I16, src_frames=333),
     "steady_fmt_mixed_leaf": lambda: scenarios.scenario_voice_bank_steady(oracle(max_block_frames=128), 26, 8, radix=32,
                                                                            fmt_cycle=list(range(6)), mono_every=5, src_frames=900),
+    # reference kinds only: what rust/firewheel-gpu/tests/reference_digests.rs can replay on the real firewheel-graph
+    "ref_steady_64": lambda: scenarios.scenario_voice_bank_steady(oracle(max_block_frames=256), 64, 6, with_pan=False),
+    "ref_steady_33_i16_r8": lambda: scenarios.scenario_voice_bank_steady(oracle(max_block_frames=64), 33, 9, radix=8, with_pan=False,
+                                                                          fmt=fwapi.INTERLEAVED_I16, mono_every=5, src_frames=777),
+    "ref_desk_30": lambda: scenarios.scenario_ref_desk(oracle(max_block_frames=128)),
+    "ref_desk_21_b64": lambda: scenarios.scenario_ref_desk(oracle(max_block_frames=64), 21, radix=4, src_frames=500, seed=9),
     "events_33_i16": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=128), 33, radix=8, src_frames=777,
                                                                    fmt=fwapi.INTERLEAVED_I16),
     "events_70": lambda: scenarios.scenario_voice_bank_events(oracle(max_block_frames=256), 70),

@@ -56,6 +56,40 @@ def test_gpus_3_default_exchange_mode_with_the_n_rank_extras():
         assert "error" not in ent and ent["bus_reduce"] == m and ent["value"] is None
 
 
+def test_gpus_8_launched_like_the_driver_launches_it():
+    """the round-end scaling run at N = 8, command for command: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W` — eight ranks, the default exchange with eight
+    handles carried through the control plane, configs[4] with the reduction after every step, the RCCL modes beside it, the
+    whole-graph parity plumbing for eight shards under one 8-port SumNode (skipped on this tier: the harness computes no audio)."""
+    import socket
+
+    fwapi.hostonly_lib()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, FWGPU_BENCH_HOSTONLY="1", FWGPU_LIB=os.path.join(ROOT, "tests", "host_harness", "_hostonly.so"), OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "cfg2", "--voices", "64", "--block", "64", "--blocks-per-step", "4",
+           "--src-frames", "1024", "--steps", "4", "--warmup", "1", "--force-other-configs"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [x for x in r.stdout.splitlines() if x.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["scaling"] == "weak"
+    assert d["config"]["bus_reduce"] == "exchange" and d["config"]["bus_reduce_fallback"] is None
+    assert d["config"]["parallelism"].startswith("voice-shard x8")
+    pc = d["parity_check"]
+    assert pc["ranks"] == 8 and pc["oracle_whole_graph_nonzero"] and "skipped" in pc
+    c5 = d["other_configs"]["cfg5"]
+    assert "error" not in c5 and c5["parity_check"]["ranks"] == 8
+    assert sorted(d["bus_reduce_modes"]) == ["allreduce", "ordered"] and d["rccl_ranks_seen"] == 8
+    assert d["value"] is None and "host-only harness" in d["invalid"]
+
+
 def test_single_rank_line_has_the_contract_fields():
     d = run_bench([])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",

@@ -206,9 +206,10 @@ class Recorder(fwapi.OracleEngine):
         return self.doc
 
 
-def replay(doc, e):
+def replay(doc, e, verify=True):
     """run a document on engine `e` (fwapi's primitive surface, created by the caller with the document's header); returns the
-    concatenated process outputs after checking every call's digest"""
+    concatenated process outputs after checking every call's digest (verify=False: the caller compares — BeepTest's `sinf` is
+    the platform's, device and host libm differ in the last bits)"""
     assert doc["version"] == VERSION
     nodes, edges, samples, outs = [], [], [], []
 
@@ -256,7 +257,7 @@ def replay(doc, e):
         elif k == "process":
             inp = data_of(op[4]) if op[4] is not None else None
             out = np.asarray(e.process_interleaved(op[1], op[3], inp, op[2], op[5], op[6]), dtype=np.float32)
-            assert sha(out) == op[7], "%s: output of process call %d differs from the recorded digest" % (doc.get("name"), len(outs))
+            assert not verify or sha(out) == op[7], "%s: output of process call %d differs from the recorded digest" % (doc.get("name"), len(outs))
             outs.append(out)
         else:
             raise ValueError("unknown op %r" % (k,))

@@ -506,6 +506,9 @@ if mode == "long":
             time.sleep(0.01)
         hs.append(open(p, "rb").read())
     lx.connect_all(hs)
+    # (N processes TIME-SHARE one device here: a rank's one-wave wait can sit out whole scheduling quanta of its peers — 3 s, the
+    #  default budget, was exceeded once in a 4-process run.  The budget is about hung peers, not about this.)
+    lx.set_timeout_ms(30000)
     naps = np.random.default_rng(77 + rank)
     out = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
     keep = []

@@ -340,3 +340,38 @@ def test_hip_path_reproduces_the_independent_models_golden_digests(name):
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refmodel_digests.json")))
     _, out_g, g = run_case(name)
     assert digest(out_g) == gold[name], name
+
+
+def _replayable_docs():
+    import glob
+    import json
+    import os
+
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenarios")
+    return sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(d, "*.json"))
+                  if not p.endswith("index.json") and json.load(open(p))["reference_kinds_only"])
+
+
+@pytest.mark.parametrize("name", _replayable_docs())
+def test_hip_path_replays_the_reference_replayable_documents_call_for_call(name):
+    """the language-neutral documents a Rust test runs on the real firewheel-graph (tests/golden/scenarios, rust/firewheel-gpu/tests/
+    reference_digests.rs) — the same documents through the C ABI on the device: every process call's sha256 must be the recorded
+    one.  When tests/golden/reference_digests.json exists, those digests are the REFERENCE's: this is then GPU == reference, with
+    nothing of this repository's making in between."""
+    import json
+    import os
+
+    import scenario_json
+
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenarios", name + ".json")))
+    g = GpuEngine(sample_rate=doc["sample_rate"], max_block_frames=doc["max_block_frames"], num_graph_inputs=doc["num_graph_inputs"],
+                  num_graph_outputs=doc["num_graph_outputs"])
+    beep = 1 in doc["node_kinds"]   # BeepTest: `sinf` of the device's libm vs the host's, 2e-6 absolute (DESIGN.md H6)
+    out = scenario_json.replay(doc, g, verify=not beep)
+    if not beep:
+        assert scenario_json.sha(out) == doc["sha256_calls"]
+    else:
+        o = OracleEngine(sample_rate=doc["sample_rate"], max_block_frames=doc["max_block_frames"], num_graph_inputs=doc["num_graph_inputs"],
+                         num_graph_outputs=doc["num_graph_outputs"])
+        ref = scenario_json.replay(doc, o)
+        assert out.shape == ref.shape and float(np.max(np.abs(out - ref))) <= 2e-6

@@ -184,6 +184,11 @@ def run_case(name, **gpu_kw):
     out_o = CASES[name]()
     fn = {
         "steady_96x32": lambda e: scenarios.scenario_voice_bank_steady(e, 96, 6),
+        "ref_steady_64": lambda e: scenarios.scenario_voice_bank_steady(e, 64, 6, with_pan=False),
+        "ref_steady_33_i16_r8": lambda e: scenarios.scenario_voice_bank_steady(e, 33, 9, radix=8, with_pan=False, fmt=fwapi.INTERLEAVED_I16,
+                                                                                mono_every=5, src_frames=777),
+        "ref_desk_30": scenarios.scenario_ref_desk,
+        "ref_desk_21_b64": lambda e: scenarios.scenario_ref_desk(e, 21, radix=4, src_frames=500, seed=9),
         "steady_40x4_i16": lambda e: scenarios.scenario_voice_bank_steady(e, 40, 5, radix=4, fmt=fwapi.INTERLEAVED_I16),
         "steady_9x3_u16": lambda e: scenarios.scenario_voice_bank_steady(e, 9, 4, radix=3, fmt=fwapi.PLANAR_U16),
         "steady_fmt_p_i16_mono3": lambda e: scenarios.scenario_voice_bank_steady(e, 20, 9, radix=8, fmt=fwapi.PLANAR_I16,
@@ -256,7 +261,8 @@ def run_case(name, **gpu_kw):
            "chain_steady_dl_only_pan": 128, "chain_events_37": 128, "chain_events_19_r2_pan": 64,
            "chain_steady_40_d128": 256, "chain_events_37_d130": 128, "chain_events_21_d256": 256, "chain_calls_37_b256": 256, "chain_calls_20_b128_pan": 128,
            "chain_calls_33_b64": 64, "chain_calls_37_b256_wrap": 256, "chain_calls_21_b128_wrap": 128,
-           "chain_calls_33_b64_wrap": 64, "master_chain_bank": 128, "master_chain_fx": 128, "spatial_scene": 128, "spatial_scene_b96": 96}[name]
+           "chain_calls_33_b64_wrap": 64, "master_chain_bank": 128, "master_chain_fx": 128, "spatial_scene": 128, "spatial_scene_b96": 96,
+           "ref_steady_64": 256, "ref_steady_33_i16_r8": 64, "ref_desk_30": 128, "ref_desk_21_b64": 64}[name]
     kw = dict(max_block_frames=mbf)
     if name == "graph_inputs":
         kw["num_graph_inputs"] = 3

@@ -215,7 +215,7 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
     if (const char* e = getenv("FWGPU_QUIET_WAIT_US")) c->quiet_wait_us = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("FWGPU_UP_DIFF")) c->up_diff = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_BUILD_ONE_KERNEL")) c->build_one_kernel = atoi(e) != 0;
-    if (const char* e = getenv("FWGPU_BUILD_STREAM")) c->build_on_audio_stream = !strcmp(e, "audio");
+    if (const char* e = getenv("FWGPU_BUILD_STREAM")) c->build_on_audio_stream = strcmp(e, "own") != 0;
     if (const char* e = getenv("FWGPU_UP_PIECE")) c->up_piece = (uint32_t)std::max(4096, atoi(e));
     if (c->rt_persist && c->h_rt_flag) {  // mailbox in pinned, device-mapped host memory + the kernel's own (non-blocking) stream
         bool ok = hipHostMalloc((void**)&c->h_rt_mb, sizeof(RtMailbox), hipHostMallocMapped) == hipSuccess &&

@@ -416,7 +416,8 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     bool up_diff = true;            // FWGPU_UP_DIFF=0: every table uploaded whole, every build
     bool build_one_kernel = true;   // FWGPU_BUILD_ONE_KERNEL=0: the build's copies / fills as separate runtime calls
     std::vector<BuildJob> build_jobs;  // control thread: what build_apply will launch (fwgpu_plan_install.cpp)
-    bool build_on_audio_stream = false;  // FWGPU_BUILD_STREAM=audio (experiment, see build_apply)
+    bool build_on_audio_stream = true;   // a build's job groups go into the AUDIO stream (round 4 default; FWGPU_BUILD_STREAM=own: the
+                                         // build's own low-priority stream, round 3) — see build_apply
     hipEvent_t ev_build = nullptr;
     char* h_jobs = nullptr;            // ... and the pinned memory the launched lists travel in
     size_t h_jobs_cap = 0, h_jobs_used = 0;

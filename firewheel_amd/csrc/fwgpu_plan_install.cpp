@@ -138,10 +138,12 @@ static int build_apply(fwgpu_ctx* c) {
         }
         if (live) quiet_window(c);
         if (c->build_on_audio_stream) {
-            // EXPERIMENT for the next round (FWGPU_BUILD_STREAM=audio, never measured): the fixed ~27 us a callback pays per operation
-            // on the build's stream may be the price of waking an idle hardware queue beside the audio one.  The same groups in the
-            // AUDIO stream — the jobs only touch the image nobody reads, HIP streams take launches from two threads — would cost
-            // a callback their own few microseconds instead.  Waited for through an event (the stream itself never idles).
+            // Round 4 (measured, scripts/r04_session1.sh, config 3's 4 096 voices, callbacks back to back): the same groups in the
+            // AUDIO stream — the jobs only touch the image nobody reads, HIP streams take launches from two threads — cost a
+            // callback their own few microseconds: p99 80-82 us while a plan is built against 59 steady (+21-23), maximum 87-88
+            // against 70-75; on the build's own stream the same run had p99 99-126 and maxima of 130-148 — the fixed ~27 us a
+            // callback paid per operation on the other stream was the price of a second hardware queue waking beside the audio
+            // one (round 3's open question).  Waited for through an event (the stream itself never idles).
             if (!c->ev_build) HIPC(c, hipEventCreateWithFlags(&c->ev_build, hipEventDisableTiming));
             LCHK(c, launch_build_apply(c->stream, at + i, (int)(k - i)));
             HIPC(c, hipEventRecord(c->ev_build, c->stream));

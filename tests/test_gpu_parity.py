@@ -552,19 +552,6 @@ def test_cfg4_fir_reverb_mfma_bit_exact(name):
     assert digest(out_g) == gold[name]
 
 
-@pytest.mark.parametrize("mbf,max_batch", [(128, 64), (64, 8), (256, 1), (512, 16)])
-def test_spatialiser_voices_on_the_voice_bank_plan_bit_exact(mbf, max_batch):
-    g = GpuEngine(max_block_frames=mbf, max_batch=max_batch)
-    o = scenarios.TaggedOracle(OracleEngine(max_block_frames=mbf))
-    out_g = scenarios.scenario_spatial_bank(g)
-    out_o = scenarios.scenario_spatial_bank(o)
-    assert g.cx.plan_kind() == 1 and g.cx.plan_fused_voices() == 23
-    assert_bits_equal(out_o, out_g, "spatial bank mbf %d batch %d" % (mbf, max_batch))
-    # ... and the level executor agrees (same graph, generic plan): the two paths hand the history to each other's blocks
-    f = GpuEngine(max_block_frames=mbf, max_batch=max_batch, force_generic=True)
-    assert_bits_equal(out_o, scenarios.scenario_spatial_bank(f), "spatial bank, level executor")
-
-
 def test_fir_long_ir_impulse_and_linearity_properties():
     # full-length 65536-tap IR (config 4), too slow for the oracle: size-independent properties instead
     taps, frames = 65536, 256

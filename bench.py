@@ -777,6 +777,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
     if dist is not None:
         dist.barrier()
     sync()
+    lazy0 = cx.lazy_stats() if hasattr(cx, "lazy_stats") else (0, 0)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -786,6 +787,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    lazy1 = cx.lazy_stats() if hasattr(cx, "lazy_stats") else (0, 0)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if env.get("ctrl_cpu") else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -929,6 +931,9 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
                 "parallelism": "voice-shard x%d%s" % (world, (" + mix-bus %s" % REDUCE_DESC[reduce_mode]) if world > 1 else ""),
                 "bus_reduce": reduce_mode, "bus_reduce_fallback": reduce_note,
                 "realtime_factor": (total / dt) / (48000.0 * V * world),
+                # launch batches of the timed region rendered without / with a control kernel (include/fwgpu.h fwgpu_lazy_stats): a
+                # message-free step of a plan whose every voice is steady and plain needs no per-block state machine pass
+                "batches_without_control_kernel": lazy1[0] - lazy0[0], "batches_with_control_kernel": lazy1[1] - lazy0[1],
                 "device": name, "compute_units": cus,
             },
             "roofline": roofline,

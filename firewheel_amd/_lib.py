@@ -77,6 +77,7 @@ SIGNATURES = {
     "fwgpu_plan_node_inputs_clear": (ci, [vp, i64, C.POINTER(ci), ci]),
     "fwgpu_plan_handover_stats": (ci, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
     "fwgpu_plan_pending": (ci, [vp]),
+    "fwgpu_lazy_stats": (ci, [vp, C.POINTER(u64), C.POINTER(u64)]),
     "fwgpu_update_phase": (ci, [vp]),
     "fwgpu_rt_resident_stats": (ci, [vp, C.POINTER(u64), C.POINTER(u64)]),
     "fwgpu_plan_chain_stats": (ci, [vp, C.POINTER(u64), C.POINTER(u64)]),

@@ -210,6 +210,18 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
             c->ctl_ahead = false;
         }
     }
+    if (const char* e = getenv("FWGPU_LAZY")) c->lazy_on = atoi(e) != 0;
+    if (c->lazy_on) {  // the control kernels' horizon word + where it is published for the host (fwgpu_types.h LazyRec)
+        bool ok = c->d_lazy_horizon.ensure_n("d_lazy_horizon", 256) == hipSuccess && hipMemset(c->d_lazy_horizon.p, 0xff, 256) == hipSuccess &&
+                  hipHostMalloc((void**)&c->h_lazy_pub, 64, hipHostMallocMapped) == hipSuccess &&
+                  hipHostGetDevicePointer((void**)&c->d_lazy_pub, c->h_lazy_pub, 0) == hipSuccess;
+        if (ok) {
+            memset(c->h_lazy_pub, 0, 64);
+        } else {
+            (void)hipGetLastError();
+            c->lazy_on = false;
+        }
+    }
     if (const char* e = getenv("FWGPU_RT_PERSIST")) c->rt_persist = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_IDLE_MS")) c->rt_idle_ms = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("FWGPU_QUIET_WAIT_US")) c->quiet_wait_us = (uint32_t)std::max(0, atoi(e));
@@ -259,6 +271,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     if (c->rt_stream) (void)hipStreamDestroy(c->rt_stream);
     if (c->rt_ev) (void)hipEventDestroy(c->rt_ev);
     if (c->h_rt_mb) (void)hipHostFree(c->h_rt_mb);
+    if (c->h_lazy_pub) (void)hipHostFree(c->h_lazy_pub);
     (void)hipStreamSynchronize(c->stream);
     if (c->ctl_stream) {
         (void)hipStreamSynchronize(c->ctl_stream);
@@ -287,7 +300,7 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     if (c->h_up) (void)hipHostFree(c->h_up);
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
     if (c->ev_build) (void)hipEventDestroy(c->ev_build);
-    DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_rt_sync, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
+    DevBuf* bufs[] = {&c->d_states, &c->d_ext, &c->d_samples, &c->d_rt_sync, &c->d_lazy_horizon, &c->d_cmds, &c->d_in_stage, &c->d_out_stage, &c->d_scratch_pool,
                       &c->d_scratch_flags, &c->d_scratch_tab, &c->d_mask, &c->d_trace, &c->d_rs_table};
     for (DevBuf* b : bufs) b->release();
     for (TimerCat& t : c->timers)
@@ -550,6 +563,12 @@ int fwgpu_plan_handover_stats(fwgpu_ctx* c, uint64_t* adoptions, uint64_t* audio
 int fwgpu_plan_pending(fwgpu_ctx* c) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     return c->pending.load(std::memory_order_acquire) != nullptr ? 1 : 0;
+}
+int fwgpu_lazy_stats(fwgpu_ctx* c, uint64_t* lazy_batches, uint64_t* control_batches) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    if (lazy_batches) *lazy_batches = c->lazy_calls;
+    if (control_batches) *control_batches = c->ctl_calls;
+    return 0;
 }
 int fwgpu_rt_resident_stats(fwgpu_ctx* c, uint64_t* launches, uint64_t* doorbells) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
@@ -1110,6 +1129,7 @@ int fwgpu_node_process(fwgpu_ctx* c, int64_t node, uint64_t frames, const float*
     use_device(c);
     AudioGate gate(c);
     { const int prc = rt_persist_stop(c); if (prc) return prc; }
+    { const int prc = lazy_flush(c); if (prc) return prc; }  // (this node's state may lag behind lazily rendered blocks)
     // the node as the ACTIVE plan knows it (the graph belongs to the control thread, which may be editing it right now:
     // Firewheel activates and deactivates nodes while the audio thread is inside process(), graph.rs:586-612)
     const uint32_t nslot = (uint32_t)(node & 0xffffffff);
@@ -1216,7 +1236,9 @@ int fwgpu_timing_reset(fwgpu_ctx* c) {
     }
     return 0;
 }
-// debugging aid (not part of include/fwgpu.h): the fused plan's mix buses of block 0 of the last call, [n_bus][stride] floats
+#ifdef FW_DEBUG_BUS
+// debugging builds only (make EXTRA=-DFW_DEBUG_BUS; scripts/dbg_rt.py — how round 4 found the leaf-bus store hazard): the fused plan's
+// mix buses of block 0 of the last call, [n_bus][stride] floats
 int fwgpu_debug_read_bus(fwgpu_ctx* c, float* out, uint64_t max_floats) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     (void)rt_persist_stop(c);
@@ -1226,6 +1248,7 @@ int fwgpu_debug_read_bus(fwgpu_ctx* c, float* out, uint64_t max_floats) {
     HIPC(c, hipMemcpy(out, c->d_bus.p, n * sizeof(float), hipMemcpyDeviceToHost));
     return (int)c->n_bus;
 }
+#endif
 #ifdef FW_CHAIN_TRACE
 // profiling builds only (scripts/chain_trace.py): timestamps [step 0..63][wave 0..15][slot 0..7] of workgroup 0
 int fwgpu_debug_read_trace(fwgpu_ctx* c, unsigned long long* out) {

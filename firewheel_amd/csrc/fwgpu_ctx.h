@@ -181,6 +181,9 @@ struct PlanImage {
     DevBuf d_ctl_order;
     bool ctl_order_live = false;        // the device copy holds this call's order (else: identity, nothing uploaded)
     DevBuf d_rs_wl;           // resampler plans: the work list between k_leaf_rs and k_leaf_sum_wl (FusedView::rs_wl)
+    DevBuf d_lazy;            // plain voice-bank plans (no resampler source, no spatialiser stage, no chain voices): [n_voices] LazyRec —
+                              // what every steady voice leaves behind for the calls after a control run (fwgpu_types.h)
+    bool lazy_capable = false;
     DevBuf d_rs_tmpl;         // resampler plans: [2][n_voices] VoiceBlk — the template a steady resampler voice's VB_RS_LEAN blocks of a call
                               // share (FusedView::rs_tmpl); two copies: the control-ahead mode writes call n+1's while call n renders
     DevBuf d_progs, d_hist;   // d_hist: [n_voices][SP_HIST] mono histories the spatialiser voices enter the call with
@@ -338,6 +341,22 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     // the render kernels read exists twice (parity = batch number & 1); what orders the two streams is one event per parity and
     // direction.  The kernels do not know: they get pointers.
     bool ctl_ahead = true;           // wanted (default since round 3; FWGPU_CTL_AHEAD=0 switches it off)
+    // Lazy records (round 4, fwgpu_types.h LazyRec): a message-free call of a plan whose every voice was left steady AND plain by
+    // the last control kernel — the host knows because that kernel's horizon has arrived in pinned memory — is rendered without a
+    // control kernel: the leaf waves compute their records from the LazyRecs.  Node state then lags by `lazy_pending` blocks until
+    // the next thing that reads it (a control kernel, the realtime kernels, the level executor, an adoption) — lazy_flush first.
+    // FWGPU_LAZY=0 switches it off.
+    bool lazy_on = true;
+    DevBuf d_lazy_horizon;                       // one u64, re-armed to ~0 by k_lazy_publish
+    unsigned long long *h_lazy_pub = nullptr, *d_lazy_pub = nullptr;  // pinned {horizon, seq of the control launch it belongs to}
+    uint64_t ctl_launch_seq = 0;                 // control kernels launched (with a publish behind each)
+    uint64_t abs_blk = 0;                        // blocks the fused voice-bank plan has rendered (any plan image: it only orders)
+    uint64_t lazy_base_blk = 0;                  // abs_blk right behind the last control run: the LazyRecs' block 0
+    uint64_t lazy_pending = 0;                   // blocks rendered from the LazyRecs that node state has not seen yet
+    uint32_t lazy_epoch = 0;                     // epoch the LazyRecs were made under
+    bool lazy_valid = false;                     // nothing but lazy calls has moved the voices since they were made
+    bool lazy_this_call = false;
+    uint64_t lazy_calls = 0, ctl_calls = 0;      // fused batches rendered without / with a control kernel (fwgpu_lazy_stats)
     int ctl_ahead_mode = 2;          // 1 = every qualifying call (round 3), 2 = only calls with messages / continuing glides (round 4)
     hipStream_t ctl_stream = nullptr;
     hipEvent_t ev_ctl[2] = {nullptr, nullptr}, ev_render[2] = {nullptr, nullptr}, ev_join = nullptr;
@@ -634,6 +653,7 @@ int join_streams(fwgpu_ctx* c);  // control-ahead mode: both streams wait for ea
 void drain_ring(fwgpu_ctx* c);  // ring -> cmds (consumer side: the audio thread, or an edit call that does not overlap it)
 int upload_cmds(fwgpu_ctx* c, bool drained = false);  // drained: the caller has emptied the ring into cmds already
 int rt_persist_stop(fwgpu_ctx* c);
+int lazy_flush(fwgpu_ctx* c);  // audio side (or whoever holds the gate): node state brought up to date after lazily rendered blocks; the LazyRecs end here
 int rt_block_relaunch(fwgpu_ctx* c, float* d_out, unsigned long long seq);  // after the watchdog race: the same block through k_rt_block  // ends the resident realtime kernel, if one is running, and waits for it
 void finish_returns(fwgpu_ctx* c);  // end of a process call: completion event for the samples it handed back
 void retire_cmds(fwgpu_ctx* c, uint32_t nblocks);

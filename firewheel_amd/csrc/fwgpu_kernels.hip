@@ -270,6 +270,24 @@ int launch_sp_hist_copy(hipStream_t s, const FusedView& fv) {
     hipLaunchKernelGGL(k_sp_hist_copy, dim3((fv.n_voices * SP_HIST + 255) / 256), dim3(256), 0, s, fv);
     return (int)hipGetLastError();
 }
+int launch_leaf_sum_lazy(hipStream_t s, const FusedView& fv, int K) {
+    if (fv.n_leaves <= 0) return 0;
+    const int wpk = (fv.frames % (256 * LEAF_WPB) == 0) ? LEAF_WPB : (fv.frames % 512 == 0 && LEAF_WPB % 2 == 0) ? 2 : 1;
+    const int bpw = LEAF_WPB / wpk;
+    dim3 grid(fv.n_leaves, (K + bpw - 1) / bpw);
+    if (fv.has_prog) hipLaunchKernelGGL((k_leaf_sum_lazy<true>), grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
+    else hipLaunchKernelGGL((k_leaf_sum_lazy<false>), grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
+    return (int)hipGetLastError();
+}
+int launch_lazy_publish(hipStream_t s, unsigned long long* d_horizon, unsigned long long* pinned_pub, unsigned long long seq) {
+    hipLaunchKernelGGL(k_lazy_publish, dim3(1), dim3(1), 0, s, d_horizon, pinned_pub, seq);
+    return (int)hipGetLastError();
+}
+int launch_lazy_flush(hipStream_t s, const LazyRec* lazy, NodeState* states, int n_voices, unsigned long long blocks) {
+    if (n_voices <= 0 || blocks == 0) return 0;
+    hipLaunchKernelGGL(k_lazy_flush, dim3((n_voices + 255) / 256), dim3(256), 0, s, lazy, states, n_voices, blocks);
+    return (int)hipGetLastError();
+}
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
     if (fv.n_leaves <= 0) return 0;
     // waves per block: long blocks are cut into 256-frame pieces so that every wave is one short streaming pass

@@ -268,7 +268,7 @@ static int zero(fwgpu_ctx* c, void* p, size_t bytes) { return fill_rows(c, p, by
 
 void PlanImage::release_device() {
     DevBuf* bufs[] = {&d_nodes, &d_in_buf, &d_out_buf, &d_level_nodes, &d_pool, &d_flags, &d_gin_bufs, &d_gout_bufs, &d_groups, &d_blks2, &d_refs2,
-                      &d_gsets2, &d_ramps2, &d_progs, &d_hist, &d_rs_wl, &d_rs_tmpl, &d_ctl_order, &d_slot_voice, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
+                      &d_gsets2, &d_ramps2, &d_progs, &d_hist, &d_rs_wl, &d_rs_tmpl, &d_lazy, &d_ctl_order, &d_slot_voice, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
                       &d_chain_start, &d_chain_dummy, &d_chain_stats, &d_up_nodes, &d_up_in, &d_up_out, &d_up_level_nodes, &d_root_bufs, &d_tail_nodes,
                       &d_tail_in, &d_tail_out, &d_tail_idx, &d_tail_frozen, &d_frozen_ph, &d_frozen, &d_fir_rows, &d_fir_tiles, &d_fir_partials,
                       &d_hlevel_nodes, &grow_states, &grow_ext, &d_state_inits, &d_ext_jobs};
@@ -298,7 +298,7 @@ static void reset_for_build(PlanImage& P) {
     P.slot_index.clear();
     P.slot_voice.clear();
     P.ctl_order_live = false;
-    P.fused = P.fused_fx = P.ctl_ahead_on = P.fused_rs = P.fused_prog = P.fused_sp = P.hybrid = P.hybrid_fx = false;
+    P.fused = P.fused_fx = P.ctl_ahead_on = P.fused_rs = P.fused_prog = P.fused_sp = P.hybrid = P.hybrid_fx = P.lazy_capable = false;
     P.generic_k = 1;
     P.chain_nq = 1;
     P.n_voices = P.n_leaves = P.ramp_slots = P.n_groups = P.n_tail = P.n_fused_real = 0;
@@ -376,6 +376,12 @@ static int alloc_voice_tables(fwgpu_ctx* c, PlanImage& P) {
     P.hot_prev.reserve((size_t)P.n_voices);
     P.hot_now.reserve((size_t)P.n_voices);
     P.ctl_order_live = false;
+    // lazy records: plain voice-bank plans only (the leaf kernel's lazy instantiation knows samplers and gain / program stages)
+    // (P.lazy_capable is set by the caller: the voice-bank branch of install_plan, never the hybrid one)
+    if (P.lazy_capable && P.n_voices > 0) {
+        HIPC(c, P.d_lazy.ensure_n("d_lazy", (size_t)P.n_voices * sizeof(LazyRec)));
+        if ((rc = fill_rows(c, P.d_lazy.p, (size_t)P.n_voices * sizeof(LazyRec), (size_t)P.n_voices * sizeof(LazyRec), 1, 0xff))) return rc;  // mode = -1 everywhere
+    }
     if (P.fused_rs) {  // one item per (leaf, block, 256-frame piece) at most
         HIPC(c, P.d_rs_wl.ensure_n("d_rs_wl", (2 + 2 * (size_t)P.n_leaves * K * LEAF_WPB_MAX) * sizeof(unsigned int)));
         if ((rc = zero(c, P.d_rs_wl.p, 2 * sizeof(unsigned int)))) return rc;
@@ -824,6 +830,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             if ((rc = upload_chain_groups(c, P, fb.leaves))) return rc;
         }
         const size_t K = P.kmax;
+        P.lazy_capable = c->lazy_on && !fb.has_fx && !fb.has_rs && !fb.has_sp;
         if ((rc = alloc_voice_tables(c, P))) return rc;
         // (spatialiser stages: their 64-frame history goes from the LAST block of a call to the first block of the next through the ext
         //  pool; in this mode the copy into the call's scratch is made on the render stream — k_sp_hist_copy — because the control
@@ -927,6 +934,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         if ((rc = up(c, P.d_voices, hb.voices.data(), hb.voices.size() * sizeof(VoiceDesc)))) return rc;
         if ((rc = up(c, P.d_leaves, hb.leaves.data(), hb.leaves.size() * sizeof(LeafDesc)))) return rc;
         if ((rc = up(c, P.d_progs, hb.progs.data(), hb.progs.size() * sizeof(uint32_t)))) return rc;
+        P.lazy_capable = false;
         if ((rc = alloc_voice_tables(c, P))) return rc;
         // the level lists without the nodes the voice-bank kernels render
         std::vector<char> cov(N, 0);
@@ -1001,6 +1009,7 @@ void adopt_image(fwgpu_ctx* c, PlanImage* n, bool on_audio_thread) {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != c->device) (void)hipSetDevice(c->device);
     (void)rt_persist_stop(c);  // the resident realtime kernel was launched with the old plan's tables
+    (void)lazy_flush(c);       // blocks rendered from the OLD plan's LazyRecs reach node state before the voices are renumbered
     (void)join_streams(c);  // control-ahead mode: the control stream's work so far is ordered before the swap
     c->ahead_seq = 0;
     // 1. larger persistent arrays: old contents copied over on the stream, then the pointers change hands

@@ -294,6 +294,10 @@ static void fill_fused_view(fwgpu_ctx* c, FusedView& fv) {
     fv.has_sp = c->fused_sp ? 1 : 0;
     fv.rs_wl = c->d_rs_wl.as<unsigned int>();
     fv.rs_tmpl = c->fused_rs ? c->d_rs_tmpl.as<VoiceBlk>() : nullptr;
+    fv.lazy = (c->lazy_capable && c->d_lazy.p) ? c->d_lazy.as<LazyRec>() : nullptr;
+    fv.horizon = fv.lazy ? c->d_lazy_horizon.as<unsigned long long>() : nullptr;
+    fv.abs_blk_end = 0;
+    fv.lazy_blk0 = 0;
     fv.ctl_order = c->ctl_order_live ? c->d_ctl_order.as<int>() : nullptr;
     fv.sp_hist_in_render = (c->ahead_this_call && c->fused_sp) ? 1 : 0;
     fv.hist = c->d_hist.as<float>();
@@ -371,6 +375,7 @@ static int run_host_level(fwgpu_ctx* c, const DevView& v, const std::vector<fwgp
 // all K blocks: each block has its own pool slice, a stateful node walks its K blocks in order inside one wave)
 int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const float* d_in, int n_in_ch, float* d_out,
                       int n_out_ch) {
+    c->lazy_valid = false;  // (the level executor and the hybrid plan move node state their own way)
     DevView v = generic_view(c, frames);
     // which gain-like stateful nodes cannot change during this batch (their blocks then run in parallel): decided once,
     // before the first level
@@ -447,6 +452,20 @@ int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const
     return 0;
 }
 
+// ---------------------------------------------------------------- lazy records (fwgpu_types.h LazyRec)
+// Node state lags behind the audio by the blocks that were rendered straight from the LazyRecs; whatever reads or moves it next
+// — a control kernel, the realtime kernels, the level executor, fwgpu_node_process, a plan adoption — calls this first.  One small
+// launch on the ctx stream (nothing of a lazy call ever runs on the control stream); the LazyRecs are spent afterwards.
+int lazy_flush(fwgpu_ctx* c) {
+    c->lazy_valid = false;
+    if (!c->lazy_pending) return 0;
+    const uint64_t n = c->lazy_pending;
+    c->lazy_pending = 0;
+    if (!c->d_lazy.p || c->n_voices <= 0) return 0;
+    LCHK(c, launch_lazy_flush(c->stream, c->d_lazy.as<LazyRec>(), c->d_states.as<NodeState>(), c->n_voices, n));
+    return 0;
+}
+
 // K full blocks through the fused voice-bank plan
 // ---------------------------------------------------------------- the resident realtime kernel (k_rt.hip.h)
 int rt_persist_stop(fwgpu_ctx* c) {
@@ -509,6 +528,9 @@ int rt_block_relaunch(fwgpu_ctx* c, float* d_out, unsigned long long seq) {
     if (rc) return rc;
     FusedView fv;
     fill_fused_view(c, fv);
+    fv.lazy = nullptr;  // (the one-launch kernels run their own control and leave no LazyRecs)
+    fv.horizon = nullptr;
+    c->lazy_valid = false;
     DevView v;
     rt_root_view(c, fv, v);
     LCHK(c, launch_rt_block(c->stream, fv, v, c->root_args, d_out, 0, c->d_rt_sync.as<unsigned>(), c->d_rt_flag, seq));
@@ -519,10 +541,13 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     FusedView fv;
     fill_fused_view(c, fv);
     // realtime edge: one block, tree = leaves + root, stereo stream -> the whole callback is ONE launch (k_rt_block)
-    if (K == 1 && c->rt_one_launch && !c->fused_sp && !c->out_sil && !c->ahead_this_call && !c->fused_fx && !c->timing && c->n_tail == 0 && c->up_root_node >= 0 && n_out_ch == 2 &&
+    if (K == 1 && c->rt_one_launch && !c->lazy_this_call && !c->fused_sp && !c->out_sil && !c->ahead_this_call && !c->fused_fx && !c->timing && c->n_tail == 0 && c->up_root_node >= 0 && n_out_ch == 2 &&
         c->up_level_cnt.size() == 1 && c->d_rt_sync.p) {
         DevView v;
         rt_root_view(c, fv, v);
+        c->lazy_valid = false;  // (the one-launch kernels run their own control: the LazyRecs no longer describe the voices)
+        fv.lazy = nullptr;
+        fv.horizon = nullptr;
         unsigned long long* flag = nullptr;
         if (c->rt_signal_seq && c->rt_last_batch) {  // the realtime edge asked for the completion flag and this is the call's
                                                        // last launch: the kernel raises it itself
@@ -563,7 +588,14 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         return 0;
     }
     hipEvent_t e0, e1;
-    if (c->ahead_this_call) {
+    const bool lazy = c->lazy_this_call && fv.lazy != nullptr;
+    fv.abs_blk_end = c->abs_blk + (uint64_t)K;
+    if (lazy) {
+        // no control kernel: every voice's records of these K blocks follow from its LazyRec and the block index
+        fv.lazy_blk0 = c->abs_blk - c->lazy_base_blk;
+        c->lazy_pending += (uint64_t)K;
+        c->lazy_calls++;
+    } else if (c->ahead_this_call) {
         const int p = (int)(c->ahead_seq & 1);
         if (p) {
             fv.blks = c->d_blks2.as<VoiceBlk>();
@@ -574,6 +606,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         }
         if (c->ahead_seq >= 2) HIPC(c, hipStreamWaitEvent(c->ctl_stream, c->ev_render[p], 0));  // batch b-2 has read this copy
         LCHK(c, launch_voice_control(c->ctl_stream, fv, K, cmd_block0, true));
+        if (fv.lazy) LCHK(c, launch_lazy_publish(c->ctl_stream, fv.horizon, c->d_lazy_pub, ++c->ctl_launch_seq));
         HIPC(c, hipEventRecord(c->ev_ctl[p], c->ctl_stream));
         HIPC(c, hipStreamWaitEvent(c->stream, c->ev_ctl[p], 0));
         c->streams_split = true;
@@ -581,10 +614,21 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         timer_begin(c, 1, &e0, &e1);
         LCHK(c, launch_voice_control(c->stream, fv, K, cmd_block0));
         timer_end(c, e1);
+        if (fv.lazy) LCHK(c, launch_lazy_publish(c->stream, fv.horizon, c->d_lazy_pub, ++c->ctl_launch_seq));
     }
+    if (!lazy) {
+        c->ctl_calls++;
+        if (fv.lazy) {  // the LazyRecs this control kernel leaves: block 0 = right behind this batch
+            c->lazy_base_blk = c->abs_blk + (uint64_t)K;
+            c->lazy_epoch = c->epoch;
+            c->lazy_valid = true;
+        }
+    }
+    c->abs_blk += (uint64_t)K;
     timer_begin(c, 0, &e0, &e1);
     if (fv.sp_hist_in_render) LCHK(c, launch_sp_hist_copy(c->stream, fv));
     if (c->fused_fx) LCHK(c, launch_chain(c->stream, fv, K, cmd_block0, c->chain_nq));
+    else if (lazy) LCHK(c, launch_leaf_sum_lazy(c->stream, fv, K));
     else LCHK(c, launch_leaf_sum(c->stream, fv, K));
     timer_end(c, e1);
     timer_begin(c, 2, &e0, &e1);
@@ -702,6 +746,22 @@ static int run_blocks_impl(fwgpu_ctx* c, uint64_t frames, const float* d_in, int
     const bool ahead = c->ctl_ahead_on && hot && can_fuse && !c->timing && !stable_out && frames % mbf == 0 && frames / mbf > 1;
     if (!ahead && c->streams_split) {
         rc = join_streams(c);
+        if (rc) return rc;
+    }
+    // Lazy records: no message anywhere on the list, none in the call before (glides), whole blocks, the plan's LazyRecs made under
+    // this epoch and not overtaken by anything else — and the host has SEEN what the control kernel that made them reported: its
+    // sequence number and, beside it, the absolute block up to which every voice of the plan holds (0: some voice is not plain).
+    c->lazy_this_call = false;
+    // (one-block callbacks belong to the realtime kernels, which run their own control)
+    if (c->lazy_on && can_fuse && c->lazy_capable && !ahead && !(stable_out && frames == mbf) && !c->rt_use_graph && frames % mbf == 0 && c->cmds.empty() &&
+        c->hot_prev.empty() &&
+        c->lazy_valid && c->lazy_epoch == c->epoch && c->h_lazy_pub) {
+        const unsigned long long seq = __atomic_load_n(&c->h_lazy_pub[1], __ATOMIC_ACQUIRE);
+        const unsigned long long horizon = __atomic_load_n(&c->h_lazy_pub[0], __ATOMIC_RELAXED);
+        c->lazy_this_call = seq == c->ctl_launch_seq && c->abs_blk + nblocks <= horizon;
+    }
+    if (!c->lazy_this_call) {
+        rc = lazy_flush(c);  // (on the ctx stream, in front of everything this call launches — the control stream joins behind it)
         if (rc) return rc;
     }
     if (ahead && !c->streams_split) {  // the control stream picks up behind everything the main stream holds so far

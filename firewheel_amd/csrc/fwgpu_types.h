@@ -226,6 +226,30 @@ struct BuildJob {
 static_assert(sizeof(BuildJob) == 48, "BuildJob layout");
 
 // plan adoption: which steady caches travel from the old plan to the new one (k_adopt_init / carry_cache_voice); n_new = 0: none
+// Round 4 — "lazy" records.  A voice that ends a call STEADY (constant gains, nothing but the playhead moving) and whose blocks
+// are all plain ones (silent, or a contiguous planar-f32 source that never wraps inside a block) has records that are a pure
+// function of (this record, block index): the control kernel writes one of these per voice at the end of a call, and the NEXT
+// calls — as long as they carry no message, the plan has not changed and the host has SEEN that every voice of the plan left
+// one behind (FusedView::horizon -> pinned memory) — are rendered without a control kernel at all: the leaf wave's lane p loads
+// port p's LazyRec (descriptor AND gains: one round trip where records + gain sets were two) and computes the block's source
+// address itself.  Node state is brought up to date (k_lazy_flush) before anything else reads it.
+struct LazyRec {
+    uint64_t base;        // mode 1: sample data + loop_start (floats); mode 2: sample data; mode 0: unused
+    uint64_t off0;        // mode 2: playhead (frames) at the record's block 0
+    uint64_t loop_start;  // mode 1 (k_lazy_flush rebuilds the playhead from it)
+    uint32_t r_delta;     // the record's r_delta (channel-1 offset in elements; 0 = mono)
+    uint32_t flags_gset;  // the record's flags_gset (gain-set index bits unused: the gains are `g` below)
+    uint32_t q;           // mode 1: loop length in BLOCKS
+    uint32_t r0b;         // mode 1: playhead offset from the loop start at the record's block 0, in blocks
+    uint32_t frames;      // block size the block counts refer to
+    int mode;             // 0 nothing moves, 1 looping playhead, 2 one-shot playhead (TailJob::mode); -1 = not lazy-capable
+    int sampler_state;    // the voice's sampler state slot (-1: a null voice)
+    uint32_t pad[3];
+    GainSet g;
+    uint32_t pad2[4];
+};
+static_assert(sizeof(LazyRec) == 128, "LazyRec layout");
+
 struct VoiceDesc;
 struct CarryArgs {
     VoiceCache* new_cache;

@@ -532,6 +532,96 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
     return job.playhead;
 }
 
+// Round 4, lazy records (fwgpu_types.h LazyRec): what a voice that ends the call steady leaves behind for the calls after it.
+// `job` is the steady tail's job with the playhead as it stands AFTER this call.  The record is lazy-capable when every later
+// block's compact record is a pure function of the block index: silent-flagged (a constant record), or a planar-f32 source read
+// contiguously whose loop is a whole number of blocks long and entered on a block boundary (so that no block wraps inside itself),
+// or a one-shot (until it runs out: that is the horizon).  Everything else — other formats, loops that wrap inside blocks,
+// resampler sources, chain-plan voices — says "not capable" and the next call runs the control kernel as before.
+// the playhead steady_tail(…, k_first, K, job, …) will return: the state behind the call's last block
+__device__ __forceinline__ uint64_t tail_end_playhead(const TailJob& job, const int k_first, const int K, const uint64_t fr) {
+    const uint64_t n = (uint64_t)(K - k_first);
+    if (n == 0) return job.playhead;
+    if (job.mode == 1) {
+        const uint64_t L = job.loop_end - job.loop_start;
+        const uint64_t base = job.playhead >= job.loop_end ? 0 : job.playhead - job.loop_start;
+        const uint64_t r_last = (base + (n - 1) * fr) % L;
+        const uint64_t left = L - r_last;
+        return left < fr ? job.loop_start + (fr - left) : job.loop_start + r_last + fr;
+    }
+    if (job.mode == 2) return job.playhead + n * fr;
+    return job.playhead;
+}
+// (called BEFORE the tail is written, with the playhead the tail will end on: the record is built and stored at once, and the tail's
+//  store loops do not have to keep the job alive for it — the kernel sits at its register limit)
+__device__ __forceinline__ void make_lazy(const FusedView& fv, const int vi, const int sampler_state, const TailJob& job, const uint64_t ph_end,
+                                          const SampleDesc& sd, const bool fx, const bool fxp, const bool w0) {
+    if (fv.lazy == nullptr) return;
+    // (fields are stored as they are made, by lane 0: a LazyRec built in registers first cost the kernel its second wave per SIMD)
+    LazyRec* const o = fv.lazy + vi;
+    const uint64_t fr = (uint64_t)fv.frames;
+    int mode = -1;
+    unsigned long long horizon = 0ull;
+    if (!fx && !fxp && job.mode >= 0 && job.mode <= 2) {
+        const bool silent = (job.flags & VB_SILENT) != 0;
+        const bool has_src = !(job.flags & VB_SRC_ZERO) && !silent && job.sample >= 0;
+        // (steady_tail's `lean`: the record it writes straight from its loop)
+        const bool lean = has_src && (fv.frames & 3) == 0 && simple_capable(sd, false) && sd.format == FMT_P_F32 && sd.frames < 0xffffffffull;
+        bool moves_ok = true;
+        horizon = ~0ull;
+        if (job.mode == 1) {
+            const uint64_t L = job.loop_end - job.loop_start;
+            const uint64_t r0 = ph_end >= job.loop_end ? 0 : ph_end - job.loop_start;
+            moves_ok = L >= fr && L % fr == 0 && r0 % fr == 0 && L / fr <= 0xffffffffull;
+            if (moves_ok && w0) {
+                o->q = (uint32_t)(L / fr);
+                o->r0b = (uint32_t)(r0 / fr);
+                o->loop_start = job.loop_start;
+                o->base = (uint64_t)((const float*)sd.data + job.loop_start);
+            }
+        } else if (job.mode == 2) {
+            // whole blocks left inside the sample (the block the one-shot ends in needs the state machines)
+            horizon = fv.abs_blk_end + (sd.frames > ph_end ? (sd.frames - ph_end) / fr : 0);
+            if (w0) {
+                o->off0 = ph_end;
+                o->base = (uint64_t)(const float*)sd.data;
+            }
+        }
+        // silent: put_blk's record of a block that fetches nothing (no source pointer, class P_F32); else steady_tail's lean record.
+        // (nothing moves AND something sounds — a constant full descriptor — is not handled here)
+        if (moves_ok && (silent || (job.mode != 0 && lean))) {
+            mode = job.mode;
+            if (w0) {
+                o->flags_gset = ((silent ? job.flags : (job.flags | VB_SIMPLE)) & 0xffu) | ((uint32_t)SF_P_F32 << 16) | (job.flags & VB_SP_MASK);
+                o->r_delta = (silent || (job.flags & VB_MONO)) ? 0u : (uint32_t)sd.frames;
+                o->g = job.g;
+            }
+        }
+    }
+    if (w0) {
+        o->frames = (uint32_t)fv.frames;
+        o->sampler_state = sampler_state;
+        o->mode = mode;
+        if (fv.horizon) atomicMin(fv.horizon, mode < 0 ? 0ull : horizon);
+    }
+}
+// ... and node state brought up to date after `blocks` blocks rendered from the LazyRecs: the playhead is the only thing that moved
+__global__ __launch_bounds__(256) void k_lazy_flush(const LazyRec* __restrict__ lazy, NodeState* __restrict__ states, int n_voices, unsigned long long blocks) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_voices) return;
+    const LazyRec r = lazy[v];
+    if (r.sampler_state < 0 || r.mode <= 0) return;
+    if (r.mode == 1) states[r.sampler_state].playhead = r.loop_start + (uint64_t)((r.r0b + blocks) % r.q) * r.frames;
+    else states[r.sampler_state].playhead = r.off0 + blocks * r.frames;
+}
+// the horizon of the control kernel that has just run -> pinned host memory {horizon, seq}; the device word is re-armed
+__global__ void k_lazy_publish(unsigned long long* d_horizon, unsigned long long* pub, unsigned long long seq) {
+    const unsigned long long h = __hip_atomic_load(d_horizon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d_horizon, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pub, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(pub + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // One WAVE per voice: the state machines are run by all 64 lanes redundantly (wave-uniform; lane 0 stores),
 // the steady tail is split across the lanes.  A voice that ended the previous call steady and has no message
 // in this one skips the state machines altogether (VoiceCache): its whole call is a steady tail.
@@ -569,6 +659,24 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
 #pragma unroll
             for (int j = 0; j < FW_MAX_STAGES; ++j) one.g[j][0] = one.g[j][1] = 1.0f;
             fv.gsets[(size_t)vi * FW_GSETS + lane] = one;
+        }
+        if (fv.lazy != nullptr && !fxp && w0) {  // a constant silent record for as long as the plan lives
+            LazyRec lr;
+            lr.base = lr.off0 = lr.loop_start = 0;
+            lr.r_delta = 0;
+            lr.flags_gset = VB_SILENT;
+            lr.q = 1;
+            lr.r0b = 0;
+            lr.frames = (uint32_t)frames;
+            lr.mode = 0;
+            lr.sampler_state = -1;
+            lr.pad[0] = lr.pad[1] = lr.pad[2] = 0;
+#pragma unroll
+            for (int j = 0; j < FW_MAX_STAGES; ++j) lr.g.g[j][0] = lr.g.g[j][1] = 1.0f;
+            lr.pad2[0] = lr.pad2[1] = lr.pad2[2] = lr.pad2[3] = 0;
+            fv.lazy[vi] = lr;
+        } else if (fv.lazy != nullptr && w0 && fv.horizon) {
+            atomicMin(fv.horizon, 0ull);
         }
         return;
     }
@@ -732,6 +840,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                 const bool simple_ok = vc.mode != 3 && (no_src ? (fxp && simple_frames)
                                                                : (job.sample >= 0 && simple_frames && simple_capable(sd, fxp)));
                 if (simple_ok && w0) my_gsets[0] = job.g;
+                if (Kp == K) make_lazy(fv, vi, vd.sampler_state, job, tail_end_playhead(job, 0, K, (uint64_t)frames), sd, fx, fxp, w0);
                 uint64_t ph = steady_tail(fv, vi, lane, 0, Kp, job, sd, 0u, simple_ok, fx, fxp);
                 if (Kp == K) {
                     if (w0 && vc.mode != 0) fv.states[vd.sampler_state].playhead = ph;
@@ -1121,6 +1230,8 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             vc.g = job.g;
             fv.cache[vi] = vc;
         }
+        // (lazy records: what the calls after this one render from, fwgpu_types.h LazyRec)
+        if (became_steady) make_lazy(fv, vi, vd.sampler_state, job, tail_end_playhead(job, k + 1, K, (uint64_t)frames), sd, fx, fxp, w0);
         if (k + 1 < K) {
             uint32_t tail_gs = 0;
             bool simple_ok = false;
@@ -1151,6 +1262,10 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                tr[11] - tr[10], tr[3] - tr[11], tr[4] - tr[3], tr[5] - tr[4], tr[6] - tr[5], tr[7] - tr[6]);
 #endif
     if (!w0) return;
+    if (!became_steady && fv.lazy != nullptr) {  // (lazy records: only a voice that ends the call steady leaves one)
+        fv.lazy[vi].mode = -1;
+        if (fv.horizon) atomicMin(fv.horizon, 0ull);
+    }
     if (!became_steady) fv.cache[vi].epoch = 0;
     fv.states[vd.sampler_state] = ss;
 #pragma unroll

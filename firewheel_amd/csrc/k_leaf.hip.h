@@ -859,7 +859,9 @@ __device__ __forceinline__ void leaf_sp_fast(const FusedView& fv, const LeafDesc
 
 // PROG: some voice of the plan has a stage that is not a plain gain (width / hard clip) — lane p then also carries port
 // p's stage program.  The gains-only instantiation is the headline kernel and does not pay for the other ones' registers.
-template <bool PROG, bool RS = false, int U = LEAF_U, bool SP = false>
+// LAZY (round 4, fwgpu_types.h LazyRec): no control kernel ran for this call — lane p computes port p's record from the voice's
+// LazyRec (one 128-byte load: descriptor AND gains) and the block index.
+template <bool PROG, bool RS = false, int U = LEAF_U, bool SP = false, bool LAZY = false>
 __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int leaf, const uint32_t k, const int part, const int wpk,
                                               const RsLds rs = RsLds{nullptr, nullptr}, const int K = 1, float* sp_lds = nullptr) {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -881,13 +883,29 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
     for (int j = 0; j < FW_MAX_STAGES; ++j) my_g.g[j][0] = my_g.g[j][1] = 1.0f;
 #if LEAF_SPEC_GSET
     GainSet g0 = my_g;
-    if (lane < ld.ports) {  // (slot 0 may hold anything on a voice that is not VB_SIMPLE this block: then it is not used)
+    if constexpr (LAZY) {
+        if (lane < ld.ports) {
+            const LazyRec* lr = fv.lazy + (ld.first_voice + lane);
+            const uint64_t base = lr->base, off0 = lr->off0;
+            const uint32_t q = lr->q, r0b = lr->r0b;
+            const int mode = lr->mode;
+            ref.r_delta = lr->r_delta;
+            ref.flags_gset = lr->flags_gset;
+            g0 = lr->g;
+            // the block's source address: what steady_tail's lean record would hold — (r0 + block * frames) mod L from the loop
+            // start (L a whole number of blocks: no block wraps inside itself), or straight on for a one-shot
+            const uint64_t bi = fv.lazy_blk0 + (uint64_t)k;
+            if (ref.flags_gset & VB_SIMPLE)
+                ref.src_l = mode == 1 ? (const float*)base + (uint64_t)((r0b + bi) % q) * (uint64_t)(uint32_t)frames
+                                      : (const float*)base + off0 + bi * (uint64_t)(uint32_t)frames;
+        }
+    } else if (lane < ld.ports) {  // (slot 0 may hold anything on a voice that is not VB_SIMPLE this block: then it is not used)
         g0 = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS];
         ref = fv.refs[ref_index(ld.first_voice + lane, (int)k, fv.ref_kgroups)];
     }
     const uint32_t my_flags = ref.flags_gset & 0xffu;
     if (my_flags & VB_SIMPLE) {
-        const uint32_t gi = (ref.flags_gset >> 8) & 0xffu;
+        const uint32_t gi = LAZY ? 0u : (ref.flags_gset >> 8) & 0xffu;
         my_g = g0;
         if (gi != 0) my_g = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + gi];
     }
@@ -1253,7 +1271,7 @@ __device__ __forceinline__ RsLds rs_lds_setup(const FusedView& fv, float* dyn) {
 //   <true,  false>  stage programs (width / hard clip)
 //   <true,  true>   ... and voices whose source is a resampler (LDS-staged polyphase fetch)
 //   <true,  false, true>  ... and voices that end in a spatialiser (a 320-float mono row per wave in LDS)
-template <bool PROG, bool RS, bool SP>
+template <bool PROG, bool RS, bool SP, bool LAZY = false>
 __device__ __forceinline__ void leaf_kernel_body(const FusedView& fv, const int K, const int wpk) {
     extern __shared__ float s_leaf_dyn[];
     RsLds rs{nullptr, nullptr};
@@ -1275,11 +1293,16 @@ __device__ __forceinline__ void leaf_kernel_body(const FusedView& fv, const int 
     if (leaf >= fv.n_leaves) return;
     const uint32_t k = blockIdx.y;
 #endif
-    leaf_sum_wave<PROG, RS, LEAF_U, SP>(fv, leaf, k, part, wpk, rs, K, sp_lds);
+    leaf_sum_wave<PROG, RS, LEAF_U, SP, LAZY>(fv, leaf, k, part, wpk, rs, K, sp_lds);
 }
 template <bool PROG, bool RS, bool SP = false>
 __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K, int wpk) {
     leaf_kernel_body<PROG, RS, SP>(fv, K, wpk);
+}
+// the same kernel for a call no control kernel ran for (plans without resampler sources / spatialiser stages)
+template <bool PROG>
+__global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum_lazy(FusedView fv, int K, int wpk) {
+    leaf_kernel_body<PROG, false, false, true>(fv, K, wpk);
 }
 // The resampler-pure leaves of a plan (rs_pure_lane above).  One wave per (leaf, block, 256-frame piece); lane p holds port p.
 // Accumulators, stages and the final store stay in the convolution's round-robin frame layout (lane l: frames l, l + nact, ...):

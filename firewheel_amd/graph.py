@@ -459,6 +459,12 @@ class FirewheelGpuCtx(object):
         self._check(self.L.fwgpu_rt_resident_stats(self.c, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def lazy_stats(self):
+        """(launch batches rendered without a control kernel, with one) — include/fwgpu.h fwgpu_lazy_stats"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.L.fwgpu_lazy_stats(self.c, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def plan_handover_stats(self):
         """(plans adopted so far, those adopted by a process call, the longest one of those held up its call in ns)"""
         a, b, m = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)

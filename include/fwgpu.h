@@ -177,6 +177,13 @@ int fwgpu_plan_handover_stats(fwgpu_ctx* ctx, uint64_t* adoptions, uint64_t* aud
  * the old schedule comes back through the ring, graph/processor.rs:182-188; rust/firewheel-gpu's HostNodeHandle and the Python
  * wrapper keep removed host nodes in limbo until this says so).  Any thread may ask. */
 int fwgpu_plan_pending(fwgpu_ctx* ctx);
+/* Voice-bank plan, diagnostics: launch batches of process calls rendered WITHOUT a control kernel (*lazy_batches) and with one.
+ * A message-free call of a plan whose every voice the last control kernel left steady and plain (silent, or a planar-f32 source
+ * that never wraps inside a block) needs no per-block state machine pass — the reference's processors do nothing in such a block
+ * but advance a playhead (nodes/sampler.rs:445-484) — and the leaf kernel derives each block's record from one per-voice
+ * record; the host skips the control kernel once it has SEEN (pinned memory) that the last one found every voice so.  A host that
+ * never waits for the device between calls sees no difference but the time.  FWGPU_LAZY=0 switches it off.  Either may be NULL. */
+int fwgpu_lazy_stats(fwgpu_ctx* ctx, uint64_t* lazy_batches, uint64_t* control_batches);
 /* Diagnostics for the same hand-over: which part of fwgpu_update / fwgpu_schedule_upload the control thread is in right now —
  * 0 none, 1 compiling the graph (host only: graph/compiler.rs), 21..28 the sections of the plan build that upload tables
  * (23 node tables, 26 buffer pool, 27 voice tables, 28 staging areas), 3 waiting for the last upload.  Any thread may ask;

@@ -1,3 +1,6 @@
+"""debugging aid (needs a library built with `make -C firewheel_amd/csrc EXTRA=-DFW_DEBUG_BUS`): the same three one-block callbacks with
+and without the resident realtime kernel, outputs and LEAF BUSES compared — how round 4 found that the garbage frames of the resident
+kernel were pointer bits in lanes 12-15 of every 16 of a leaf bus (the inline-asm store hazard, k_leaf.hip.h bus_store_pair)."""
 import sys, os, ctypes as C
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np

@@ -279,9 +279,72 @@ int launch_get_flags(hipStream_t, const uint8_t* flags, const int* d_bufs, int n
     touch(d_mask, 8);
     return 0;
 }
+// Lazy records (fwgpu_types.h LazyRec), as the harness can model them: every voice ends every control launch steady and plain
+// (the publish stub reports an unbounded horizon).  What IS checked is the host's book-keeping: a lazy leaf launch names the block
+// offset that follows from the launches since the control launch its LazyRecs came from; nothing reads or moves node state — a
+// control launch, the realtime kernels — while lazily rendered blocks have not been flushed into it; a flush names exactly them.
+struct LazyBook {
+    unsigned long long since_ctl = 0, unflushed = 0;
+    bool have_ctl = false;
+};
+static LazyBook g_lazy[64];
+static const void* g_lazy_key[64];
+static LazyBook& lazy_book(const void* key) {
+    for (int i = 0; i < 64; ++i) {
+        if (g_lazy_key[i] == key) return g_lazy[i];
+        if (!g_lazy_key[i]) {
+            g_lazy_key[i] = key;
+            g_lazy[i] = LazyBook();
+            return g_lazy[i];
+        }
+    }
+    g_lazy_key[0] = key;  // (more than 64 plans alive in one process: start over)
+    g_lazy[0] = LazyBook();
+    return g_lazy[0];
+}
+unsigned long long g_lazy_launches = 0;
+extern "C" unsigned long long fwh_lazy_launches(void) { return g_lazy_launches; }
+int launch_leaf_sum_lazy(hipStream_t, const FusedView& fv, int K) {
+    g_launches[2]++;
+    g_lazy_launches++;
+    check_fused_common(fv, K);
+    REQUIRE(!fv.fx_plan && fv.lazy != nullptr && !fv.has_rs && !fv.has_sp, fv.has_rs, fv.has_sp);
+    touch(fv.lazy, sizeof(LazyRec) * (size_t)fv.n_voices);
+    LazyBook& b = lazy_book(fv.lazy);
+    REQUIRE(b.have_ctl && fv.lazy_blk0 == b.since_ctl, (long long)fv.lazy_blk0, (long long)b.since_ctl);
+    b.since_ctl += (unsigned long long)K;
+    b.unflushed += (unsigned long long)K;
+    return 0;
+}
+int launch_lazy_publish(hipStream_t, unsigned long long* d_horizon, unsigned long long* pub, unsigned long long seq) {
+    g_launches[7]++;
+    touch(d_horizon, 8);
+    touch(pub, 16);
+    pub[0] = ~0ull;  // (the fake device is done when the launch returns)
+    pub[1] = seq;
+    return 0;
+}
+int launch_lazy_flush(hipStream_t, const LazyRec* lazy, NodeState* states, int n_voices, unsigned long long blocks) {
+    g_launches[7]++;
+    touch(lazy, sizeof(LazyRec) * (size_t)n_voices);
+    (void)states;
+    LazyBook& b = lazy_book(lazy);
+    REQUIRE(blocks == b.unflushed && blocks > 0, (long long)blocks, (long long)b.unflushed);
+    b.unflushed = 0;
+    b.have_ctl = false;  // (the LazyRecs are spent: the next lazy launch needs a control launch first)
+    return 0;
+}
 int launch_voice_control(hipStream_t, const FusedView& fv, int K, uint32_t cmd_block0, bool) {
     g_launches[1]++;
     check_fused_common(fv, K);
+    if (fv.lazy) {
+        touch(fv.lazy, sizeof(LazyRec) * (size_t)fv.n_voices);
+        touch(fv.horizon, 8);
+        LazyBook& b = lazy_book(fv.lazy);
+        REQUIRE(b.unflushed == 0, (long long)b.unflushed);  // node state is current when the state machines run
+        b.since_ctl = 0;
+        b.have_ctl = true;
+    }
     for (int i = 0; i < fv.n_cmds; ++i) {  // messages the control kernel would APPLY in this launch (each exactly once in its life)
         if (i > 0) {
             const Cmd &a = fv.cmds[i - 1], &b = fv.cmds[i];
@@ -496,6 +559,7 @@ int launch_rt_block(hipStream_t, const FusedView& fv, const DevView& upv, const 
     if (d_done_flag) *d_done_flag = done_seq;
     g_launches[7]++;
     check_fused_common(fv, 1);
+    REQUIRE(fv.lazy == nullptr);  // (the one-launch kernels run their own control and leave no LazyRecs)
     REQUIRE(!fv.fx_plan && root.ports >= 1 && root.ports <= 32 && root.n_in == 2 * root.ports, root.ports, root.n_in);
     touch(d_sync, sizeof(unsigned));
     touch(d_out, sizeof(float) * 2 * (size_t)upv.frames);

@@ -512,16 +512,26 @@ if mode == "long":
     naps = np.random.default_rng(77 + rank)
     out = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
     keep = []
-    for step in range(1000):
-        rng = np.random.default_rng(5000 + step)
-        parts, sils = T.random_buses(rng, world, blocks, frames)
-        part = torch.from_numpy(parts[rank]).cuda(); sil = torch.from_numpy(sils[rank].reshape(-1).copy()).cuda()
-        if naps.random() < 0.3:
-            time.sleep(float(naps.uniform(0.0, 0.001)))
-        lx.step(part.data_ptr(), out.data_ptr(), n, sil.data_ptr(), None, blocks, frames, 2)
-        if step % 50 == 49 or step == 999:
+    # the inputs of 50 steps at a time are uploaded in ONE copy each and waited for; the 50 steps then go out asynchronously (push /
+    # wait / reduce kernels only, no copy in between that could overtake a pending push), and status() drains them
+    for s0 in range(0, 1000, 50):
+        ps, ss = [], []
+        for step in range(s0, s0 + 50):
+            parts, sils = T.random_buses(np.random.default_rng(5000 + step), world, blocks, frames)
+            ps.append(parts[rank]); ss.append(sils[rank].reshape(-1).copy())
+        dp = torch.from_numpy(np.stack(ps)).cuda(); ds = torch.from_numpy(np.stack(ss)).cuda()
+        torch.cuda.synchronize()
+        for i in range(50):
+            if naps.random() < 0.3:
+                time.sleep(float(naps.uniform(0.0, 0.001)))
+            lx.step(dp[i].data_ptr(), out.data_ptr(), n, ds[i].data_ptr(), None, blocks, frames, 2)
+        t_step = time.time()
+        try:
             lx.status()
-            keep.append(out.cpu().numpy().copy())
+        except Exception:
+            print("rank", rank, "steps", s0, "..", s0 + 49, "status failed after %.2f s" % (time.time() - t_step), flush=True)
+            raise
+        keep.append(out.cpu().numpy().copy())
     lx.status()
     outs.append(np.concatenate(keep))
     calls = []
@@ -662,6 +672,9 @@ def test_exchange_1000_steps_with_skewed_ranks_on_one_device_stay_bit_exact(worl
     """8 ranks = the node north_star names, as 8 processes on the one device this pool has: real hipIpc handles, real peer-mapped
     slots, 1 000 steps, ranks napping at random — every sampled step (each 50th and the last) must carry the whole graph's bits on
     every rank.  What a multi-GPU box adds to this is xGMI instead of the local fabric; the protocol is the same code."""
+    import time
+
+    time.sleep(float(os.environ.get("FWGPU_TEST_SETTLE_S", "0")))
     got = _run_ranks(world, "long")
     want = []
     for step in range(1000):

@@ -375,3 +375,47 @@ def test_hip_path_replays_the_reference_replayable_documents_call_for_call(name)
                          num_graph_outputs=doc["num_graph_outputs"])
         ref = scenario_json.replay(doc, o)
         assert out.shape == ref.shape and float(np.max(np.abs(out - ref))) <= 2e-6
+
+
+def test_lazy_records_calls_without_a_control_kernel_are_bit_exact_and_happen():
+    """Round 4 (fwgpu_types.h LazyRec): message-free calls of a plain voice bank whose loops are whole blocks long are rendered without
+    a control kernel — the leaf waves compute their records — until something happens: a message, a one-shot running out (the
+    horizon the last control kernel reported), a one-block callback, a recompile.  Every call against the oracle, bit for bit; and
+    the counters say the path was taken (a host that has SEEN the control kernel's report: every call here waits for its output)."""
+    mbf = 64
+
+    def run(e):
+        voices = scenarios.build_voice_bank(e, 41, radix=8, src_frames=mbf * 9, mono_every=6)
+        for v, vc in enumerate(voices):
+            if v % 7 != 3:
+                e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)       # v % 7 == 3: one-shots: they end after 9 blocks
+            if v % 10 != 9:
+                e.sampler_play(vc["sampler"])                            # v % 10 == 9: never started (silent, constant records)
+        outs, marks = [], []
+        for i, k in enumerate([3, 2, 2, 2, 5, 1, 4, 4, 9, 2, 2, 3, 3]):
+            if i == 9:
+                e.set_param(voices[4]["volume"], 0, 33.0)               # a glide: control until it has settled, then lazy again
+            if i == 11:
+                e.sampler_play(voices[9]["sampler"])
+            outs.append(np.asarray(e.process_blocks(k)))
+            if hasattr(e, "cx"):
+                marks.append(e.cx.lazy_stats())
+        return np.concatenate(outs), marks
+
+    out_o, _ = run(scenarios.TaggedOracle(OracleEngine(max_block_frames=mbf)))
+    g = GpuEngine(max_block_frames=mbf, max_batch=8)
+    out_g, marks = run(g)
+    assert g.cx.plan_kind() == 1
+    assert np.array_equal(bits(out_g), bits(out_o))
+    if os.environ.get("FWGPU_LAZY") == "0":
+        assert marks[-1][0] == 0
+        return
+    lazy = [m[0] for m in marks]
+    # call 0 carries the play messages, call 1 follows them (glides may continue): control; calls 2 and 3 are lazy; call 4 (5 blocks)
+    # would cross the one-shots' end (block 9): the horizon says no -> control; call 5 is ONE block (its batch takes the ordinary
+    # path here: no realtime flag on process_blocks... it is lazy too if the host may) ...
+    assert lazy[1] == 0 and lazy[3] == 2, marks
+    assert lazy[4] == 2, marks                      # the horizon held the control kernel in for the call the one-shots end in
+    assert lazy[8] > lazy[4], marks                 # after it: lazy again, a 9-block call as two batches
+    assert lazy[9] == lazy[8] and lazy[10] == lazy[9], marks    # the message and the call after it
+    assert lazy[-1] >= lazy[10], marks

@@ -626,3 +626,49 @@ def test_a_build_larger_than_the_upload_arena_goes_out_in_flushes_and_stays_whol
         e.process_blocks(4)
         assert e.violation() == "", e.violation()
     assert sent[0] > 4 << 20 and max(sent[1:]) < 1 << 20, sent   # the OTHER image's first build is whole; after that: chunks
+
+
+def test_lazy_records_host_bookkeeping():
+    """Round 4, lazy records (fwgpu_types.h LazyRec): a message-free multi-block call of a plain voice-bank plan is rendered without a
+    control launch once the host has seen the last control launch's horizon — and node state is flushed before anything else
+    touches it.  The stubs model a device on which every voice ends every control launch steady and check the book-keeping: the
+    block offset a lazy launch names, "no control / realtime launch over unflushed blocks", "a flush names exactly them"."""
+    e = HostOnlyEngine(max_block_frames=64, max_batch=8)
+    smp = bank(e)
+    assert e.cx.plan_kind() == 1
+    for s in smp:
+        e.sampler_play(s)
+    e.reset_launches()
+    e.process_blocks(8)                      # messages: control launch (+ publish)
+    assert e.launches()["voice_control"] == 1 and e.cx.lazy_stats() == (0, 1)
+    e.process_blocks(8)                      # the call before had messages (glides may continue): control again
+    e.process_blocks(8)                      # quiet, and the publish has been seen: lazy
+    e.process_blocks(20)                     # 8 + 8 + 4: three lazy batches, block offsets 8, 16, 24 (checked by the stub)
+    lazy, ctl = e.cx.lazy_stats()
+    assert (lazy, ctl) == (4, 2), (lazy, ctl)
+    assert e.launches()["voice_control"] == 2 and e.violation() == ""
+    e.set_param(smp[0], 0, 50.0)             # a message: flush (28 blocks), then control
+    e.process_blocks(3)
+    assert e.cx.lazy_stats() == (4, 3) and e.violation() == ""
+    e.process_blocks(2)                      # hot_prev: control
+    e.process_blocks(2)                      # lazy again
+    assert e.cx.lazy_stats() == (5, 4)
+    e.process_interleaved(64)                # a one-block realtime-sized call: flush first, the one-launch kernel, LazyRecs spent
+    assert e.violation() == ""
+    e.process_blocks(4)                      # so this one runs control
+    assert e.cx.lazy_stats() == (5, 5)
+    e.process_blocks(4)
+    assert e.cx.lazy_stats() == (6, 5)
+    e.cx.set_max_batch(4)                    # a recompile (same graph, new tables): the adoption flushes the 4 lazy blocks against the OLD
+    e.update()                               # plan's LazyRecs, the new plan starts with a control launch
+    assert e.cx.plan_kind() == 1
+    e.process_blocks(4)
+    e.process_blocks(4)
+    lazy, ctl = e.cx.lazy_stats()
+    assert ctl == 6 and lazy == 7 and e.violation() == "", (lazy, ctl, e.violation())
+    # chain plans and plans with resampler sources never go lazy
+    e2 = HostOnlyEngine(max_block_frames=64, max_batch=8)
+    bank(e2, chain=True)
+    for _ in range(4):
+        e2.process_blocks(8)
+    assert e2.cx.lazy_stats()[0] == 0 and e2.violation() == ""

@@ -234,7 +234,7 @@ static_assert(sizeof(BuildJob) == 48, "BuildJob layout");
 // port p's LazyRec (descriptor AND gains: one round trip where records + gain sets were two) and computes the block's source
 // address itself.  Node state is brought up to date (k_lazy_flush) before anything else reads it.
 struct LazyRec {
-    uint64_t base;        // mode 1: sample data + loop_start (floats); mode 2: sample data; mode 0: unused
+    uint64_t base;        // BYTE address of source frame 0 of the record: mode 1: the loop start; mode 2: the sample's start; mode 0: unused
     uint64_t off0;        // mode 2: playhead (frames) at the record's block 0
     uint64_t loop_start;  // mode 1 (k_lazy_flush rebuilds the playhead from it)
     uint32_t r_delta;     // the record's r_delta (channel-1 offset in elements; 0 = mono)
@@ -244,7 +244,9 @@ struct LazyRec {
     uint32_t frames;      // block size the block counts refer to
     int mode;             // 0 nothing moves, 1 looping playhead, 2 one-shot playhead (TailJob::mode); -1 = not lazy-capable
     int sampler_state;    // the voice's sampler state slot (-1: a null voice)
-    uint32_t pad[3];
+    uint32_t bpf;         // bytes per source frame at `base` (the record's source class: planar f32 4, planar 16-bit 2, interleaved
+                          // stereo 16-bit 4, interleaved stereo f32 8)
+    uint32_t pad[2];
     GainSet g;
     uint32_t pad2[4];
 };

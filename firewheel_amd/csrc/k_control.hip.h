@@ -565,8 +565,26 @@ __device__ __forceinline__ void make_lazy(const FusedView& fv, const int vi, con
     if (!fx && !fxp && job.mode >= 0 && job.mode <= 2) {
         const bool silent = (job.flags & VB_SILENT) != 0;
         const bool has_src = !(job.flags & VB_SRC_ZERO) && !silent && job.sample >= 0;
-        // (steady_tail's `lean`: the record it writes straight from its loop)
-        const bool lean = has_src && (fv.frames & 3) == 0 && simple_capable(sd, false) && sd.format == FMT_P_F32 && sd.frames < 0xffffffffull;
+        // the compact record every later block gets (steady_tail's lean record for planar f32, put_blk's VB_SIMPLE record for the other
+        // source classes): its class depends on the parity of the block's first source frame only, which is the origin's here — loop
+        // start / sample start plus whole blocks of a multiple of 4 frames
+        const uint64_t origin = job.mode == 1 ? job.loop_start : 0ull;
+        const uint32_t cls = has_src ? simple_class(sd, job.mode == 1 ? origin : ph_end, false) : (uint32_t)SF_NONE;
+        const bool lean = has_src && (fv.frames & 3) == 0 && cls != (uint32_t)SF_NONE && sd.frames < 0xffffffffull;
+        // (address of source frame `origin` and bytes per frame, by class: put_blk's pointer arithmetic)
+        uint64_t base = 0;
+        uint32_t bpf = 4, rdelta = 0;
+        if (lean) {
+            const bool mono = (job.flags & VB_MONO) != 0;
+            switch (cls) {
+                case SF_P_F32: base = (uint64_t)((const float*)sd.data + origin); bpf = 4; rdelta = mono ? 0u : (uint32_t)sd.frames; break;
+                case SF_P_I16:
+                case SF_P_U16: base = (uint64_t)((const int16_t*)sd.data + origin); bpf = 2; rdelta = mono ? 0u : (uint32_t)sd.frames; break;
+                case SF_I_I16:
+                case SF_I_U16: base = (uint64_t)((const int16_t*)sd.data + 2 * origin); bpf = 4; rdelta = 1u; break;
+                default: base = (uint64_t)((const float*)sd.data + 2 * origin); bpf = 8; rdelta = 1u; break;  // SF_I_F32
+            }
+        }
         bool moves_ok = true;
         horizon = ~0ull;
         if (job.mode == 1) {
@@ -577,23 +595,21 @@ __device__ __forceinline__ void make_lazy(const FusedView& fv, const int vi, con
                 o->q = (uint32_t)(L / fr);
                 o->r0b = (uint32_t)(r0 / fr);
                 o->loop_start = job.loop_start;
-                o->base = (uint64_t)((const float*)sd.data + job.loop_start);
             }
         } else if (job.mode == 2) {
             // whole blocks left inside the sample (the block the one-shot ends in needs the state machines)
             horizon = fv.abs_blk_end + (sd.frames > ph_end ? (sd.frames - ph_end) / fr : 0);
-            if (w0) {
-                o->off0 = ph_end;
-                o->base = (uint64_t)(const float*)sd.data;
-            }
+            if (w0) o->off0 = ph_end;
         }
         // silent: put_blk's record of a block that fetches nothing (no source pointer, class P_F32); else steady_tail's lean record.
         // (nothing moves AND something sounds — a constant full descriptor — is not handled here)
         if (moves_ok && (silent || (job.mode != 0 && lean))) {
             mode = job.mode;
             if (w0) {
-                o->flags_gset = ((silent ? job.flags : (job.flags | VB_SIMPLE)) & 0xffu) | ((uint32_t)SF_P_F32 << 16) | (job.flags & VB_SP_MASK);
-                o->r_delta = (silent || (job.flags & VB_MONO)) ? 0u : (uint32_t)sd.frames;
+                o->flags_gset = ((silent ? job.flags : (job.flags | VB_SIMPLE)) & 0xffu) | ((silent ? (uint32_t)SF_P_F32 : cls) << 16) | (job.flags & VB_SP_MASK);
+                o->r_delta = silent ? 0u : rdelta;
+                o->base = base;
+                o->bpf = bpf;
                 o->g = job.g;
             }
         }
@@ -670,7 +686,8 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             lr.frames = (uint32_t)frames;
             lr.mode = 0;
             lr.sampler_state = -1;
-            lr.pad[0] = lr.pad[1] = lr.pad[2] = 0;
+            lr.bpf = 4;
+            lr.pad[0] = lr.pad[1] = 0;
 #pragma unroll
             for (int j = 0; j < FW_MAX_STAGES; ++j) lr.g.g[j][0] = lr.g.g[j][1] = 1.0f;
             lr.pad2[0] = lr.pad2[1] = lr.pad2[2] = lr.pad2[3] = 0;

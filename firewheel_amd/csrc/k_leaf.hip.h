@@ -887,7 +887,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
         if (lane < ld.ports) {
             const LazyRec* lr = fv.lazy + (ld.first_voice + lane);
             const uint64_t base = lr->base, off0 = lr->off0;
-            const uint32_t q = lr->q, r0b = lr->r0b;
+            const uint32_t q = lr->q, r0b = lr->r0b, bpf = lr->bpf;
             const int mode = lr->mode;
             ref.r_delta = lr->r_delta;
             ref.flags_gset = lr->flags_gset;
@@ -895,9 +895,10 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
             // the block's source address: what steady_tail's lean record would hold — (r0 + block * frames) mod L from the loop
             // start (L a whole number of blocks: no block wraps inside itself), or straight on for a one-shot
             const uint64_t bi = fv.lazy_blk0 + (uint64_t)k;
-            if (ref.flags_gset & VB_SIMPLE)
-                ref.src_l = mode == 1 ? (const float*)base + (uint64_t)((r0b + bi) % q) * (uint64_t)(uint32_t)frames
-                                      : (const float*)base + off0 + bi * (uint64_t)(uint32_t)frames;
+            if (ref.flags_gset & VB_SIMPLE) {  // (frames into the record's source, then bytes: the classes differ in bytes per frame)
+                const uint64_t fo = mode == 1 ? (uint64_t)((r0b + bi) % q) * (uint64_t)(uint32_t)frames : off0 + bi * (uint64_t)(uint32_t)frames;
+                ref.src_l = (const float*)(base + fo * bpf);
+            }
         }
     } else if (lane < ld.ports) {  // (slot 0 may hold anything on a voice that is not VB_SIMPLE this block: then it is not used)
         g0 = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS];

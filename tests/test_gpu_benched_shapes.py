@@ -385,7 +385,7 @@ def test_lazy_records_calls_without_a_control_kernel_are_bit_exact_and_happen():
     mbf = 64
 
     def run(e):
-        voices = scenarios.build_voice_bank(e, 41, radix=8, src_frames=mbf * 9, mono_every=6)
+        voices = scenarios.build_voice_bank(e, 41, radix=8, src_frames=mbf * 9, mono_every=6, fmt_cycle=list(range(6)))  # every sample format
         for v, vc in enumerate(voices):
             if v % 7 != 3:
                 e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)       # v % 7 == 3: one-shots: they end after 9 blocks

@@ -871,6 +871,25 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
                 # k_leaf_sum's two HBM placement states (profiles/PLACEMENT.md), fixed per context at allocation
                 "placement_state": (("fast" if frac >= 0.76 else "slow") if kernel == "k_leaf_sum" and sfmt == "f32" and playing == 1.0 else None),
             }
+    step_dist = None
+    if timing and world == 1 and steps >= 5:
+        # SURVEY 8d's per-step statistics: a distribution INSIDE the context (the line's `contexts` entry is one across contexts).
+        # One event per step boundary in a pass of its own: a boundary event costs a few us of idle stream, which is inside
+        # every sample — so the median here sits slightly above ms_per_step of the timed region, which has no events in it.
+        n_d = min(steps, 20)
+        ctx_stream = torch.cuda.ExternalStream(cx.hip_stream(), device=dev)  # the stream the kernels are launched on (fwgpu_hip_stream)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_d + 1)]
+        evs[0].record(ctx_stream)
+        for i in range(n_d):
+            step()
+            evs[i + 1].record(ctx_stream)
+        finish_reductions()
+        sync()
+        us = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(n_d))
+        pick = lambda q: us[min(n_d - 1, int(round(q * (n_d - 1))))]
+        step_dist = {"n": n_d, "min": us[0], "p10": pick(0.10), "median": pick(0.50), "p90": pick(0.90), "max": us[-1], "unit": "us per step",
+                     "per_block_us": {"p10": pick(0.10) / K, "median": pick(0.50) / K, "p90": pick(0.90) / K},
+                     "how": "one stream event per step boundary, a separate pass after the timed region (the events' own gaps are inside the samples)"}
     own = None
     if (full and rank == 0 and world == 1 and not hostonly and not args.no_parity_check and wl in ("cfg2", "cfg5") and sfmt == "f32" and variant == "A"
             and not args.host_buffers and F % B == 0 and K >= 4 and
@@ -937,6 +956,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
                 "device": name, "compute_units": cus,
             },
             "roofline": roofline,
+            "step_time_distribution": step_dist,
         }
         if own is not None:
             res["parity_check_timed_context"] = own
@@ -1263,8 +1283,8 @@ def main():
         order = sorted(range(len(ctx_runs)), key=lambda i: ctx_runs[i]["ms_per_step"])
         mid = order[len(order) // 2]
         contexts = context_summary(ctx_runs, mid)
-        for k in ("value", "ms_per_step", "roofline"):
-            res[k] = ctx_runs[mid][k]
+        for k in ("value", "ms_per_step", "roofline", "step_time_distribution"):
+            res[k] = ctx_runs[mid].get(k)
     if rank == 0:
         line = {
             "metric": "stereo voice-samples/sec @ block=256, 48kHz; % HBM roofline; 1/2/4/8 GPU",
@@ -1281,6 +1301,7 @@ def main():
             "data": "synthetic" if not args.host_buffers else "synthetic; output delivered to HOST buffers (PCIe-inclusive)",
             "config": res["config"],
             "roofline": res["roofline"],
+            "step_time_distribution": res.get("step_time_distribution"),
             "cpu_baseline": res.get("cpu_baseline"),
             "parity_check": res.get("parity_check"),
             "parity_check_timed_context": res.get("parity_check_timed_context"),

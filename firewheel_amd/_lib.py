@@ -78,6 +78,7 @@ SIGNATURES = {
     "fwgpu_plan_handover_stats": (ci, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
     "fwgpu_plan_pending": (ci, [vp]),
     "fwgpu_lazy_stats": (ci, [vp, C.POINTER(u64), C.POINTER(u64)]),
+    "fwgpu_hip_stream": (vp, [vp]),
     "fwgpu_update_phase": (ci, [vp]),
     "fwgpu_rt_resident_stats": (ci, [vp, C.POINTER(u64), C.POINTER(u64)]),
     "fwgpu_plan_chain_stats": (ci, [vp, C.POINTER(u64), C.POINTER(u64)]),

@@ -570,6 +570,7 @@ int fwgpu_lazy_stats(fwgpu_ctx* c, uint64_t* lazy_batches, uint64_t* control_bat
     if (control_batches) *control_batches = c->ctl_calls;
     return 0;
 }
+void* fwgpu_hip_stream(fwgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int fwgpu_rt_resident_stats(fwgpu_ctx* c, uint64_t* launches, uint64_t* doorbells) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     if (launches) *launches = c->rtp.launches;

@@ -170,7 +170,7 @@ struct PlanImage {
     DevBuf d_blks2, d_refs2, d_gsets2, d_ramps2;
     bool fused_rs = false;    // the plan has resampler-sourced voices
     bool fused_prog = false;  // the voice-bank plan carries stage programs (k_leaf_sum<true>)
-    bool fused_sp = false;    // ... and spatialiser stages (k_leaf_sum<true, false, true>)
+    bool fused_sp = false;    // ... and spatialiser stages (k_leaf_sum_sp)
     // control-kernel dispatch order (FusedView::ctl_order), rebuilt by upload_cmds for every call that has messages
     std::vector<int> slot_voice;        // node state slot -> voice of the voice-bank plan (-1: none)
     DevBuf d_slot_voice;                // ... on the device, for the plan that replaces this one (k_carry_cache)

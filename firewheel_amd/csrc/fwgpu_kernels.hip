@@ -299,7 +299,7 @@ int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
     dim3 grid((fv.n_leaves + LEAF_WPB - 1) / LEAF_WPB, K);
 #endif
     if (fv.has_sp && fv.has_rs) hipLaunchKernelGGL((k_leaf_sum<true, true, true>), grid, dim3(WAVE * LEAF_WPB), RS_LDS_BYTES(LEAF_WPB), s, fv, K, wpk);
-    else if (fv.has_sp) hipLaunchKernelGGL((k_leaf_sum<true, false, true>), grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
+    else if (fv.has_sp) hipLaunchKernelGGL(k_leaf_sum_sp, grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
     else if (fv.has_rs) {  // a pair: the resampler-pure leaves (k_leaf_rs), then whatever it put on the work list
         hipLaunchKernelGGL(k_leaf_rs, grid, dim3(WAVE * LEAF_WPB), RS2_LDS_BYTES(LEAF_WPB), s, fv, K, wpk);
         const int items = fv.n_leaves * K * wpk;

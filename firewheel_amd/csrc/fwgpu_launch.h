@@ -72,7 +72,7 @@ struct FusedView {
     const uint32_t* progs;  // [n_voices] stage programs (SK_*, 4 bits per chain stage); nullptr / all 0 on gains-only plans
     int has_prog;           // some voice's program is not 0 (or its source is a resampler): k_leaf_sum<true>
     int has_rs;             // some voice's source is a resampler: the program instantiation stages windows + filter bank in LDS
-    int has_sp;             // some voice ends in a spatialiser stage: k_leaf_sum<true, false, true>
+    int has_sp;             // some voice ends in a spatialiser stage: k_leaf_sum_sp
     int sp_hist_in_render;  // control-ahead mode + spatialiser stages: k_sp_hist_copy makes the history copy, not k_voice_control
     const int* ctl_order;   // k_voice_control: wave w works voice ctl_order[w] (nullptr: w) — voices with messages first
     unsigned int* rs_wl;    // has_rs: work list k_leaf_rs leaves for k_leaf_sum_wl — [0] items, [1] workgroups done, then (leaf, block*4 + piece) pairs

@@ -1300,6 +1300,14 @@ template <bool PROG, bool RS, bool SP = false>
 __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K, int wpk) {
     leaf_kernel_body<PROG, RS, SP>(fv, K, wpk);
 }
+// the spatialiser instantiation under its own occupancy target: the default heuristic settles at 172 VGPRs, four over
+// the three-waves-per-SIMD line; the kernel is latency-bound (one HBM round trip per SP_U ports, then LDS), so the third wave pays
+#ifndef SP_OCC
+#define SP_OCC 3
+#endif
+__global__ __launch_bounds__(WAVE* LEAF_WPB, SP_OCC) void k_leaf_sum_sp(FusedView fv, int K, int wpk) {
+    leaf_kernel_body<true, false, true>(fv, K, wpk);
+}
 // the same kernel for a call no control kernel ran for (plans without resampler sources / spatialiser stages)
 template <bool PROG>
 __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum_lazy(FusedView fv, int K, int wpk) {

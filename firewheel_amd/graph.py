@@ -459,6 +459,10 @@ class FirewheelGpuCtx(object):
         self._check(self.L.fwgpu_rt_resident_stats(self.c, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def hip_stream(self):
+        """the hipStream_t (int) the ctx's process calls launch on — include/fwgpu.h fwgpu_hip_stream"""
+        return int(self.L.fwgpu_hip_stream(self.c) or 0)
+
     def lazy_stats(self):
         """(launch batches rendered without a control kernel, with one) — include/fwgpu.h fwgpu_lazy_stats"""
         a, b = C.c_uint64(0), C.c_uint64(0)

@@ -184,6 +184,9 @@ int fwgpu_plan_pending(fwgpu_ctx* ctx);
  * record; the host skips the control kernel once it has SEEN (pinned memory) that the last one found every voice so.  A host that
  * never waits for the device between calls sees no difference but the time.  FWGPU_LAZY=0 switches it off.  Either may be NULL. */
 int fwgpu_lazy_stats(fwgpu_ctx* ctx, uint64_t* lazy_batches, uint64_t* control_batches);
+/* The hipStream_t every process call of this ctx launches on (the caller's, or the one fwgpu_ctx_create made): for callers that
+ * order their own device work or events against the engine's (bench.py's per-step time distribution).  NULL ctx -> NULL. */
+void* fwgpu_hip_stream(fwgpu_ctx* ctx);
 /* Diagnostics for the same hand-over: which part of fwgpu_update / fwgpu_schedule_upload the control thread is in right now —
  * 0 none, 1 compiling the graph (host only: graph/compiler.rs), 21..28 the sections of the plan build that upload tables
  * (23 node tables, 26 buffer pool, 27 voice tables, 28 staging areas), 3 waiting for the last upload.  Any thread may ask;

@@ -111,6 +111,7 @@ extern "C" {
     pub fn fwgpu_plan_handover_stats(ctx: *mut fwgpu_ctx, adoptions: *mut u64, audio_adoptions: *mut u64, max_adopt_ns: *mut u64) -> c_int;
     pub fn fwgpu_plan_pending(ctx: *mut fwgpu_ctx) -> c_int;
     pub fn fwgpu_lazy_stats(ctx: *mut fwgpu_ctx, lazy_batches: *mut u64, control_batches: *mut u64) -> c_int;
+    pub fn fwgpu_hip_stream(ctx: *mut fwgpu_ctx) -> *mut c_void;
     pub fn fwgpu_update_phase(ctx: *mut fwgpu_ctx) -> c_int;
     pub fn fwgpu_rt_resident_stats(ctx: *mut fwgpu_ctx, launches: *mut u64, doorbells: *mut u64) -> c_int;
     pub fn fwgpu_set_max_batch(ctx: *mut fwgpu_ctx, max_blocks: u32) -> c_int;

@@ -53,6 +53,8 @@ if per_vs and "i16" in extra.split():  # (--source-format i16: SURVEY 8d's 4 B r
 dom = {"cfg2": "k_leaf_sum", "cfg3": "k_chain", "cfg5": "k_leaf_sum", "cfg4": "k_fir_gemm"}[cfg]
 if "--rs-source" in extra.split():
     dom = "k_leaf_rs"
+if "--voice-spatial" in extra.split():
+    dom = "k_leaf_sum_sp"
 out = {
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --workload %s --lean "
                "--no-kernel-timing --steps 4 --warmup 2 %s (one pass per counter)" % (cfg, extra),

@@ -249,6 +249,7 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
         c->rt_persist = false;
     }
     if (const char* e = getenv("FWGPU_HOST_PROF")) c->host_prof = atoi(e) != 0;
+    if (const char* e = getenv("FWGPU_UPDATE_PROF")) c->update_prof = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_GRAPH")) c->rt_use_graph = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_ONE_LAUNCH")) c->rt_one_launch = atoi(e) != 0;
     if (c->d_rt_sync.ensure_n("d_rt_sync", 256) != hipSuccess || hipMemset(c->d_rt_sync.p, 0, 256) != hipSuccess) c->d_rt_sync.release();
@@ -264,6 +265,12 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     if (c->host_prof && c->hp_calls) {
         fprintf(stderr, "fwgpu host profile: host time inside run_blocks, 25 us bins:");
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", (unsigned long long)c->hp_hist[i]);
+        fprintf(stderr, "\n");
+    }
+    if (c->update_prof && c->phase_updates) {
+        fprintf(stderr, "fwgpu update profile: %llu updates; mean us per phase (fwgpu_update_phase):", (unsigned long long)c->phase_updates);
+        for (int i = 1; i < 32; ++i)
+            if (c->phase_ns[i]) fprintf(stderr, " [%d] %.1f", i, c->phase_ns[i] / 1e3 / (double)c->phase_updates);
         fprintf(stderr, "\n");
     }
     use_device(c);
@@ -442,20 +449,21 @@ int fwgpu_update(fwgpu_ctx* c) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     use_device(c);
     if (!c->graph.needs_compile && c->info.have_plan) return 0;
-    Plan plan;
+    Plan plan = std::move(c->spare_plan);  // (the node array of the image recycled by the last build: control side only)
+    c->spare_plan = Plan();
     std::string err;
-    c->update_phase = 1;
+    phase_mark(c, 1);
     int rc = c->graph.build_plan(plan, err);
     if (rc) {
-        c->update_phase = 0;
+        phase_mark(c, 0);
         return fail(c, rc, err);
     }
-    c->update_phase = 2;
+    phase_mark(c, 2);
     {
         RtHold hold(c);  // table growth frees device memory (hipFree waits for every stream): no resident realtime kernel meanwhile
         rc = install_plan(c, plan);
     }
-    c->update_phase = 0;
+    phase_mark(c, 0);
     return rc;
 }
 

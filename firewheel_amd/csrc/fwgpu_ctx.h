@@ -427,6 +427,10 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     size_t h_up_cap = 0, h_up_used = 0;
     // the build's GPU work goes out in pieces, each in a window with no process call in flight (fwgpu_plan_install.cpp, quiet_window):
     // how long a piece waits for such a window (0 = the old behaviour: everything at once), and the size of an upload piece
+    Plan spare_plan;  // control side: a retired plan's node array, reused by the next fwgpu_update
+    // FWGPU_UPDATE_PROF=1: host nanoseconds of the control thread per update phase, printed when the ctx is destroyed
+    bool update_prof = false;
+    uint64_t phase_ns[32] = {0}, phase_t0 = 0, phase_updates = 0;
     std::atomic<int> update_phase{0};  // fwgpu_update_phase: 0 none, 1 graph compile, 21..28 the sections of build_image, 3 waiting for the uploads
     std::atomic<uint64_t> last_audio_ns{0};  // steady_clock at the end of the last process call (0: none yet)
     std::atomic<uint64_t> cb_start_ns{0}, cb_period_ns{0}, cb_dur_ns{0};  // the last call's start, its distance to the one before, its length
@@ -481,6 +485,18 @@ struct fwgpu_ctx : fwgpu::PlanImage {
 };
 
 namespace fwgpu {
+
+// every change of fwgpu_update_phase goes through here (the phase that ends is charged with the time since the last mark)
+inline void phase_mark(fwgpu_ctx* c, int p) {
+    if (c->update_prof) {
+        const uint64_t now = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        const int was = c->update_phase.load(std::memory_order_relaxed);
+        if (was > 0 && was < 32) c->phase_ns[was] += now - c->phase_t0;
+        c->phase_t0 = now;
+        if (p == 0) c->phase_updates++;
+    }
+    c->update_phase.store(p, std::memory_order_relaxed);
+}
 
 int fail(fwgpu_ctx* c, int code, const char* msg);  // no allocation: the message is copied into a fixed buffer
 inline int fail(fwgpu_ctx* c, int code, const std::string& msg) { return fail(c, code, msg.c_str()); }

@@ -45,6 +45,8 @@ int64_t HostGraph::add_node(int kind, uint32_t n_in, uint32_t n_out, const NodeS
     n.init = init;
     n.in_edge.assign(n_in, -1);
     n.out_edges.assign(n_out, std::vector<int>());
+    if (meta.size() < nodes.size()) meta.resize(nodes.size());
+    meta[slot] = NodeMeta{kind, n_in, n_out, true};
     nodes_to_activate.push_back(slot);
     needs_compile = true;
     return make_id(slot, gen);
@@ -76,6 +78,7 @@ int HostGraph::remove_node(int64_t id) {
     }
     n->alive = false;
     n->activated = false;
+    meta[slot].alive = false;
     if (limbo) limbo->push_back(slot);  // reusable only once no running plan holds the node (fwgpu_plan_install.cpp)
     else free_nodes.push_back(slot);
     nodes_to_activate.erase(std::remove(nodes_to_activate.begin(), nodes_to_activate.end(), slot), nodes_to_activate.end());
@@ -145,38 +148,44 @@ int HostGraph::disconnect_edge(int64_t edge) {
 
 bool HostGraph::topo_order(std::vector<uint32_t>& order) {
     // graph/graph/compiler.rs:232-300 (Kahn BFS: graph_in first, other roots in slot order, out-edges in
-    // edge-slot order, graph_out forced last)
+    // edge-slot order, graph_out forced last).
+    // The walk never touches a HostNode (200 bytes apiece, vectors inside): one sequential pass over the edge arena builds a
+    // CSR adjacency by source — an edge arena walked in slot order leaves every node's list in edge-slot order, the order the
+    // reference collects them in — and the in-degrees; per node only `meta` (8 bytes) is read.
+    const size_t NS = nodes.size();
     order.clear();
-    order.reserve(nodes.size());
-    std::vector<int> in_degree(nodes.size(), 0);
-    size_t alive = 0;
+    order.reserve(NS);
+    std::vector<uint32_t>& off = cs_off;
+    std::vector<uint32_t>& adj = cs_adj;
+    std::vector<int>& in_degree = cs_indeg;
+    off.assign(NS + 1, 0);
+    in_degree.assign(NS, 0);
     for (const HostEdge& e : edges)
-        if (e.alive) in_degree[e.dst] += 1;
-    std::vector<uint32_t> queue;  // (a FIFO that only grows: read through `head`)
-    queue.reserve(nodes.size());
-    size_t head = 0;
+        if (e.alive) {
+            off[e.src + 1]++;
+            in_degree[e.dst]++;
+        }
+    for (size_t s = 0; s < NS; ++s) off[s + 1] += off[s];
+    adj.resize(off[NS]);
+    cs_cur.assign(off.begin(), off.end() - 1);
+    for (const HostEdge& e : edges)
+        if (e.alive) adj[cs_cur[e.src]++] = e.dst;
+    std::vector<uint32_t>& queue = cs_queue;  // (a FIFO that only grows: read through `head`)
+    queue.clear();
+    queue.reserve(NS);
+    size_t head = 0, alive = 0;
     queue.push_back(graph_in_slot);
-    for (uint32_t s = 0; s < nodes.size(); ++s) {
-        if (!nodes[s].alive) continue;
+    for (uint32_t s = 0; s < NS; ++s) {
+        if (!meta[s].alive) continue;
         alive++;
-        if (s == graph_in_slot) continue;
-        bool has_in = false;
-        for (int e : nodes[s].in_edge)
-            if (e >= 0) has_in = true;
-        if (!has_in) queue.push_back(s);
+        if (s != graph_in_slot && in_degree[s] == 0) queue.push_back(s);
     }
     size_t visited = 0;
-    std::vector<int> outs;
     while (head < queue.size()) {
-        uint32_t s = queue[head++];
+        const uint32_t s = queue[head++];
         visited++;
-        // outgoing edges in edge-slot order (the reference collects them by iterating the edge arena)
-        outs.clear();
-        for (const auto& pe : nodes[s].out_edges)
-            for (int e : pe) outs.push_back(e);
-        std::sort(outs.begin(), outs.end());
-        for (int e : outs) {
-            uint32_t d = edges[e].dst;
+        for (uint32_t k = off[s]; k < off[s + 1]; ++k) {
+            const uint32_t d = adj[k];
             if (--in_degree[d] == 0) queue.push_back(d);
         }
         if (s != graph_out_slot) order.push_back(s);
@@ -285,47 +294,81 @@ void finalize_plan(Plan& plan) {
 }
 
 int HostGraph::build_plan(Plan& plan, std::string& err) {
-    for (const HostNode& n : nodes)
-        if (n.alive && (n.n_in > 64 || n.n_out > 64)) {  // compiler.rs:202-203 (assert in the reference)
+    const size_t NS = nodes.size();
+    for (size_t s = 0; s < NS; ++s)
+        if (meta[s].alive && (meta[s].n_in > 64 || meta[s].n_out > 64)) {  // compiler.rs:202-203 (assert in the reference)
             err = "a node has more than 64 ports";
             return FWGPU_ERR_INVALID;
         }
-    std::vector<uint32_t> order;
+    std::vector<uint32_t>& order = cs_order;
     if (!topo_order(order)) {
         err = "cycle detected";
         return FWGPU_ERR_COMPILE_CYCLE;
     }
     for (uint32_t slot : order) {
-        const HostNode& n = nodes[slot];
-        if (!check_activation(n.kind, n.n_in, n.n_out, err)) return FWGPU_ERR_NODE_ACTIVATION_FAILED;
+        const NodeMeta& m = meta[slot];
+        if (!check_activation(m.kind, m.n_in, m.n_out, err)) return FWGPU_ERR_NODE_ACTIVATION_FAILED;
     }
-    std::vector<int> index_of(nodes.size(), -1);
-    plan = Plan();
-    plan.nodes.reserve(order.size());
-    for (uint32_t slot : order) {
-        index_of[slot] = (int)plan.nodes.size();
-        PlanNode pn;
-        const HostNode& n = nodes[slot];
+    // producers per (node, input port), flat, from one more sequential pass over the edge arena
+    std::vector<uint32_t>& in_off = cs_off;  // (the walk is over: its arrays are free)
+    in_off.assign(NS + 1, 0);
+    for (size_t s = 0; s < NS; ++s) in_off[s + 1] = in_off[s] + (meta[s].alive ? meta[s].n_in : 0u);
+    std::vector<int>& in_e = cs_indeg;
+    in_e.assign(in_off[NS], -1);
+    for (size_t e = 0; e < edges.size(); ++e)
+        if (edges[e].alive) in_e[in_off[edges[e].dst] + edges[e].dport] = (int)e;
+    std::vector<uint32_t>& index_of = cs_cur;
+    index_of.assign(NS, 0);
+    const size_t N = order.size();
+    for (size_t i = 0; i < N; ++i) index_of[order[i]] = (uint32_t)i;
+    // a recycled Plan keeps its node array AND the nodes in it (every field is assigned below; wide nodes keep their heap lists):
+    // a fresh array was 3 MB of first-touch page faults and 20 000 constructor / destructor pairs on config 3
+    plan.nodes.resize(N);
+    std::vector<uint32_t>& out_base = cs_queue;  // renamed buffer id of output port 0, per plan node (the order array is in cs_order)
+    out_base.assign(N, 0);
+    // levelise + rename in the same pass (finalize_plan's arithmetic: a node's producers come before it in the order)
+    int next_buf = 1, max_level = 0;  // 0 = constant zero buffer
+    for (size_t i = 0; i < N; ++i) {
+        const uint32_t slot = order[i];
+        const NodeMeta& m = meta[slot];
+        PlanNode& pn = plan.nodes[i];
         pn.slot = slot;
-        pn.kind = n.kind;
-        pn.n_in = (int)n.n_in;
-        pn.n_out = (int)n.n_out;
-        pn.level = 0;
+        pn.kind = m.kind;
+        pn.n_in = (int)m.n_in;
+        pn.n_out = (int)m.n_out;
         pn.is_graph_io = slot == graph_in_slot ? 1 : (slot == graph_out_slot ? 2 : 0);
-        plan.nodes.push_back(pn);
-    }
-    for (PlanNode& pn : plan.nodes) {
-        const HostNode& n = nodes[pn.slot];
-        pn.in_src_node.assign(pn.n_in, -1);
-        pn.in_src_port.assign(pn.n_in, 0);
-        for (int p = 0; p < pn.n_in; ++p) {
-            int e = n.in_edge[p];
-            if (e < 0) continue;
-            pn.in_src_node[p] = index_of[edges[e].src];
-            pn.in_src_port[p] = (int)edges[e].sport;
+        out_base[i] = (uint32_t)next_buf;
+        int* ob = pn.out_buf.reset(m.n_out);
+        for (uint32_t p = 0; p < m.n_out; ++p) ob[p] = next_buf++;
+        int* sn = pn.in_src_node.reset(m.n_in);
+        int* sp = pn.in_src_port.reset(m.n_in);
+        int* ib = pn.in_buf.reset(m.n_in);
+        int lvl = 0;
+        const int* ie = in_e.data() + in_off[slot];
+        for (uint32_t p = 0; p < m.n_in; ++p) {
+            if (ie[p] < 0) {
+                sn[p] = -1;
+                sp[p] = 0;
+                ib[p] = 0;
+                continue;
+            }
+            const HostEdge& e = edges[ie[p]];
+            const uint32_t src = index_of[e.src];
+            sn[p] = (int)src;
+            sp[p] = (int)e.sport;
+            ib[p] = (int)(out_base[src] + e.sport);
+            lvl = std::max(lvl, plan.nodes[src].level + 1);
         }
+        pn.level = lvl;
+        if (pn.is_graph_io != 2) max_level = std::max(max_level, lvl);
     }
-    finalize_plan(plan);
+    // graph_out closes the schedule (compiler.rs:286-292)
+    if (N && plan.nodes.back().is_graph_io == 2) {
+        plan.nodes.back().level = std::max(plan.nodes.back().level, max_level + 1);
+        max_level = plan.nodes.back().level;
+    }
+    plan.num_buffers = next_buf;
+    plan.num_levels = max_level + 1;
     return 0;
 }
 

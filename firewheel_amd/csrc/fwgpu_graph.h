@@ -79,6 +79,11 @@ public:
         int* d = data();
         for (size_t i = 0; i < n; ++i) d[i] = v;
     }
+    int* reset(size_t n) {  // n elements of unspecified value; returns data()
+        reserve_exact(n, false);
+        n_ = (uint32_t)n;
+        return data();
+    }
     void resize(size_t n) {  // new elements are 0
         const uint32_t old = n_;
         reserve_exact(n, true);
@@ -150,6 +155,13 @@ class HostGraph {
     HostGraph(uint32_t n_graph_in, uint32_t n_graph_out);
     uint32_t graph_in_slot, graph_out_slot;
     std::vector<HostNode> nodes;
+    // what the compiler reads of a node, 16 bytes apiece beside the 200-byte HostNodes (kept by add_node / remove_node)
+    struct NodeMeta {
+        int kind;
+        uint32_t n_in, n_out;
+        bool alive;
+    };
+    std::vector<NodeMeta> meta;
     std::vector<uint32_t> free_nodes;
     std::vector<uint32_t>* limbo = nullptr;  // when set, remove_node parks the freed slot there instead of free_nodes
     std::vector<HostEdge> edges;
@@ -174,6 +186,9 @@ class HostGraph {
 
   private:
     void remove_edge_slot(uint32_t e);
+    // the compiler's scratch arrays, kept between compiles (topo_order / build_plan say what each holds when)
+    std::vector<uint32_t> cs_off, cs_adj, cs_cur, cs_queue, cs_order;
+    std::vector<int> cs_indeg;
 };
 
 // node activation checks (AudioNode::activate of each kind: volume.rs:56-66, sum.rs:20-30,

@@ -114,6 +114,13 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
         if (sums[i].leaf) leaf_order.push_back(i);
     std::sort(leaf_order.begin(), leaf_order.end(), [&](int a, int b) { return sums[a].node < sums[b].node; });
     int next_bus = 1;
+    {
+        size_t nv = 0;
+        for (int li : leaf_order) nv += sums[li].kids.size();
+        fb.voices.reserve(nv);
+        fb.progs.reserve(nv);
+        fb.leaves.reserve(leaf_order.size());
+    }
     for (int li : leaf_order) {
         SumRec& r = sums[li];
         LeafDesc ld;
@@ -134,7 +141,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
             }
             // walk upstream: end -> ... -> sampler
             // accepted shape: sampler -> [biquad] -> [delay] -> (volume|pan)*
-            std::vector<int> chain;
+            int chain[FW_MAX_STAGES], n_chain = 0;  // (a vector here was an allocation per voice)
             int cur = end;
             int bq = -1, dl = -1;
             bool sp_voice = false;
@@ -150,13 +157,14 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
                 if (n.kind == K_VOLUME || n.kind == K_PAN || n.kind == K_WIDTH || n.kind == K_HARD_CLIP) {
                     if (bq >= 0 || dl >= 0) return false;  // gain stages before the filter: generic executor
                     if (n.kind == K_WIDTH || n.kind == K_HARD_CLIP) fb.has_prog = true;
-                    chain.push_back(cur);
+                    if (n_chain >= FW_MAX_STAGES - 1) return false;
+                    chain[n_chain++] = cur;
                 } else if (n.kind == K_SPATIAL) {
                     // a spatialiser as the LAST node of a dry voice (the first one met walking up from the mixer); its 64-frame
                     // history needs whole 64-frame blocks
-                    if (!chain.empty() || bq >= 0 || dl >= 0 || mbf % 64 != 0) return false;
+                    if (n_chain || bq >= 0 || dl >= 0 || mbf % 64 != 0) return false;
                     sp_voice = true;
-                    chain.push_back(cur);
+                    chain[n_chain++] = cur;
                 } else if (n.kind == K_DELAY) {
                     if (bq >= 0 || dl >= 0) return false;
                     if (graph.nodes[n.slot].init.loop_end < 64) return false;  // shorter than one k_chain tile
@@ -173,7 +181,6 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
                 if (!stereo_src(n, 0, src)) return false;
                 cur = src;
             }
-            if ((int)chain.size() > FW_MAX_STAGES - 1) return false;
             VoiceDesc vd;
             memset(&vd, 0, sizeof(vd));
             vd.bq_state = bq >= 0 ? (int)plan.nodes[bq].slot : -1;
@@ -193,10 +200,10 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
                 fb.has_sp = true;
                 vd.sp_ext_off = 0;  // the node's ext slice: filled in by the plan build (the node may be activated by this very plan)
             }
-            vd.n_stages = (int)chain.size();
+            vd.n_stages = n_chain;
             uint32_t prog = 0;
             for (int j = 0; j < vd.n_stages; ++j) {  // schedule order: nearest the sampler first
-                const PlanNode& n = plan.nodes[chain[chain.size() - 1 - j]];
+                const PlanNode& n = plan.nodes[chain[n_chain - 1 - j]];
                 vd.stage_kind[j] = n.kind;
                 vd.stage_state[j] = (int)n.slot;
                 prog |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : n.kind == K_SPATIAL ? SK_SPATIAL : SK_GAIN) << (4 * j);

@@ -288,7 +288,8 @@ void PlanImage::release_device() {
 }
 
 // a recycled image keeps its buffers (capacity) and its pinned staging area; everything that DESCRIBES a plan starts over
-static void reset_for_build(PlanImage& P) {
+static void reset_for_build(fwgpu_ctx* c, PlanImage& P) {
+    c->spare_plan = std::move(P.plan);  // its node array goes to the next fwgpu_update (capacity, not contents)
     P.plan = Plan();
     P.have_plan = false;
     P.level_off.clear();
@@ -430,13 +431,13 @@ static int upload_chain_groups(fwgpu_ctx* c, PlanImage& P, const std::vector<Lea
 // very end, when nothing can fail any more — a failure anywhere leaves the ctx exactly as it was and the next fwgpu_update
 // tries the same nodes again (the reference keeps its schedule when a compile fails, context.rs:115-131).
 static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
-    reset_for_build(P);
+    reset_for_build(c, P);
     c->build_jobs.clear();
     c->h_up_used = 0;
     c->h_jobs_used = 0;
     P.kmax = c->kmax_req;
     P.gen = ++c->build_gen;
-    c->update_phase = 21;
+    phase_mark(c, 21);
     // 1. node state capacity (persists across recompiles: processor.rs:19,195-197): a larger array is allocated here and
     //    swapped in — old contents copied over on the ctx stream — when the image is adopted
     {
@@ -455,7 +456,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             P.grow_slot_ids.assign(cap, -1);
         }
     }
-    c->update_phase = 22;
+    phase_mark(c, 22);
     // 2. activate new nodes (graph.rs:594-612): their initial states and ext-pool slices are worked out here and applied at
     //    adoption (scatter kernels on the ctx stream), never written into live buffers from this thread
     struct Act {
@@ -596,13 +597,24 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             hb.leaves[sp.leaf].out_buf = plan.num_buffers;
             plan.num_buffers += 2;
         }
-    c->update_phase = 23;
+    phase_mark(c, 23);
     // 3. node tables
     const int N = (int)plan.nodes.size();
     std::vector<NodeDesc> nd(N);
     std::vector<int> in_tab, out_tab;
     std::vector<std::vector<int>> levels(plan.num_levels);
     std::vector<int> gin_bufs, gout_bufs, host_nodes;
+    {  // (sized up front: growing these by doubling was a third of this step on config 3)
+        size_t n_in = 0;
+        std::vector<int> per_level(plan.num_levels, 0);
+        for (const PlanNode& p : plan.nodes) {
+            n_in += (size_t)p.n_in;
+            if (!p.is_graph_io && p.level >= 0 && p.level < plan.num_levels) per_level[p.level]++;
+        }
+        in_tab.reserve(n_in + 64);
+        out_tab.reserve((size_t)plan.num_buffers + 64);
+        for (int l = 0; l < plan.num_levels; ++l) levels[l].reserve(per_level[l]);
+    }
     for (int i = 0; i < N; ++i) {
         const PlanNode& p = plan.nodes[i];
         NodeDesc& d = nd[i];
@@ -665,7 +677,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
     if (gout_bufs.empty()) gout_bufs.push_back(0);
     if ((rc = up(c, P.d_gin_bufs, gin_bufs.data(), gin_bufs.size() * sizeof(int)))) return rc;
     if ((rc = up(c, P.d_gout_bufs, gout_bufs.data(), gout_bufs.size() * sizeof(int)))) return rc;
-    c->update_phase = 24;
+    phase_mark(c, 24);
     // 3c. host nodes (K_HOST): per level, what the audio side needs to call them — and one pinned, device-mapped staging area
     //     for their inputs and outputs of a whole K-batch, allocated here (a process call never allocates)
     {
@@ -713,7 +725,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         P.host_in_ptrs.assign(max_in, nullptr);
         P.host_out_ptrs.assign(max_out, nullptr);
     }
-    c->update_phase = 25;
+    phase_mark(c, 25);
     // 3b. FIR banks: one GEMM per (level, impulse-response channel)
     {
         std::map<std::tuple<int, uint32_t, uint32_t>, std::vector<FirRow>> groups;
@@ -771,7 +783,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             HIPC(c, P.d_fir_partials.ensure_n("d_fir_partials", partial_need * sizeof(float)));
         }
     }
-    c->update_phase = 26;
+    phase_mark(c, 26);
     // 4. buffer pool: a new schedule starts from zeroed buffers (schedule.rs:202-203); one slice per block of a
     //    generic K-batch.  generic_k: the FIR history rings were sized for the batch size in force when their node was
     //    activated — a later, larger kmax must not outrun them.
@@ -798,7 +810,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         if (plan.num_buffers > 0 && (rc = fill_rows(c, P.d_flags.p, (size_t)plan.num_buffers, (size_t)plan.num_buffers, Kg, 0, 1))) return rc;
     }
 
-    c->update_phase = 27;
+    phase_mark(c, 27);
     // 5. fused voice-bank plan
     P.fused = false;
     P.hybrid = false;
@@ -901,7 +913,7 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         P.n_fused_real = 0;
         for (const VoiceDesc& vd : fb.voices) P.n_fused_real += vd.sampler_state >= 0 ? 1 : 0;
     }
-    c->update_phase = 28;
+    phase_mark(c, 28);
     // 5b. hybrid plan: not a fused shape as a whole, but with voice banks inside that the fused kernels render
     // straight into their mixers' pool buffers; the level executor then runs the rest.
     P.hybrid_fx = false;
@@ -970,10 +982,10 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         if (plan.nodes[i].slot < P.slot_index.size()) P.slot_index[plan.nodes[i].slot] = i;
     P.plan = std::move(plan);  // (nothing below, and no caller, looks at `plan` again: a copy was 33 000 small vectors on config 3)
     P.have_plan = true;
-    c->update_phase = 3;
+    phase_mark(c, 3);
     if ((rc = build_apply(c))) return rc;
     HIPC(c, hipStreamSynchronize(c->up_stream));  // every table and every zeroed pool of the image is in place
-    c->update_phase = 4;
+    phase_mark(c, 4);
     c->h_up_used = 0;
     // ---- commit the control side's own bookkeeping: from here on the image WILL be adopted
     for (const Act& a : acts) {

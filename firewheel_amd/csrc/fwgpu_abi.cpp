@@ -267,11 +267,13 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", (unsigned long long)c->hp_hist[i]);
         fprintf(stderr, "\n");
     }
-    if (c->update_prof && c->phase_updates) {
-        fprintf(stderr, "fwgpu update profile: %llu updates; mean us per phase (fwgpu_update_phase):", (unsigned long long)c->phase_updates);
+    if (c->update_prof && c->phase_updates > 1) {
+        const double n = (double)(c->phase_updates - 1);
+        fprintf(stderr, "fwgpu update profile: %.0f updates after the first; mean us per phase (fwgpu_update_phase):", n);
         for (int i = 1; i < 32; ++i)
-            if (c->phase_ns[i]) fprintf(stderr, " [%d] %.1f", i, c->phase_ns[i] / 1e3 / (double)c->phase_updates);
-        fprintf(stderr, "\n");
+            if (c->phase_ns[i]) fprintf(stderr, " [%d] %.1f", i, c->phase_ns[i] / 1e3 / n);
+        fprintf(stderr, "; per update: %.1f launches of k_build_apply, %.1f jobs, %.1f KiB copied, %.1f KiB filled\n", c->prof_groups / n, c->prof_jobs / n,
+                c->prof_copy_bytes / 1024.0 / n, c->prof_fill_bytes / 1024.0 / n);
     }
     use_device(c);
     (void)rt_persist_stop(c);

@@ -431,11 +431,12 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     // FWGPU_UPDATE_PROF=1: host nanoseconds of the control thread per update phase, printed when the ctx is destroyed
     bool update_prof = false;
     uint64_t phase_ns[32] = {0}, phase_t0 = 0, phase_updates = 0;
+    uint64_t prof_groups = 0, prof_jobs = 0, prof_copy_bytes = 0, prof_fill_bytes = 0;  // build_apply's launches / jobs / bytes
     std::atomic<int> update_phase{0};  // fwgpu_update_phase: 0 none, 1 graph compile, 21..28 the sections of build_image, 3 waiting for the uploads
     std::atomic<uint64_t> last_audio_ns{0};  // steady_clock at the end of the last process call (0: none yet)
     std::atomic<uint64_t> cb_start_ns{0}, cb_period_ns{0}, cb_dur_ns{0};  // the last call's start, its distance to the one before, its length
     uint32_t quiet_wait_us = 100;   // FWGPU_QUIET_WAIT_US
-    uint32_t up_piece = 128u << 10; // FWGPU_UP_PIECE (bytes)
+    uint32_t up_piece = 256u << 10; // FWGPU_UP_PIECE (bytes): ~10 us of copy kernel per group (round 4: 128 -> 256 KiB, same p99 beside a saturated stream, half the groups)
     bool up_diff = true;            // FWGPU_UP_DIFF=0: every table uploaded whole, every build
     bool build_one_kernel = true;   // FWGPU_BUILD_ONE_KERNEL=0: the build's copies / fills as separate runtime calls
     std::vector<BuildJob> build_jobs;  // control thread: what build_apply will launch (fwgpu_plan_install.cpp)
@@ -493,7 +494,10 @@ inline void phase_mark(fwgpu_ctx* c, int p) {
         const int was = c->update_phase.load(std::memory_order_relaxed);
         if (was > 0 && was < 32) c->phase_ns[was] += now - c->phase_t0;
         c->phase_t0 = now;
-        if (p == 0) c->phase_updates++;
+        if (p == 0 && c->phase_updates++ == 0) {  // the first update (allocations, every table whole) is not what an edit costs
+            for (uint64_t& v : c->phase_ns) v = 0;
+            c->prof_groups = c->prof_jobs = c->prof_copy_bytes = c->prof_fill_bytes = 0;
+        }
     }
     c->update_phase.store(p, std::memory_order_relaxed);
 }

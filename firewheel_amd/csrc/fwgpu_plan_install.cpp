@@ -136,6 +136,11 @@ static int build_apply(fwgpu_ctx* c) {
             cost += jc;
             ++k;
         }
+        if (c->update_prof) {
+            c->prof_groups++;
+            c->prof_jobs += k - i;
+            for (size_t q = i; q < k; ++q) (jobs[q].src ? c->prof_copy_bytes : c->prof_fill_bytes) += (uint64_t)jobs[q].row_bytes * jobs[q].rows;
+        }
         if (live) quiet_window(c);
         if (c->build_on_audio_stream) {
             // Round 4 (measured, scripts/r04_session1.sh, config 3's 4 096 voices, callbacks back to back): the same groups in the
@@ -359,8 +364,14 @@ static int alloc_voice_tables(fwgpu_ctx* c, PlanImage& P) {
     int rc;
     if ((rc = zero(c, P.d_chain_stats.p, 2 * sizeof(unsigned long long)))) return rc;
     if ((rc = zero(c, P.d_chain_start.p, (size_t)P.n_voices * sizeof(ChainStart)))) return rc;
-    HIPC(c, P.d_cache.ensure_n("d_cache", (size_t)P.n_voices * sizeof(VoiceCache)));
-    if ((rc = zero(c, P.d_cache.p, (size_t)P.n_voices * sizeof(VoiceCache)))) return rc;  // (and adoption bumps the epoch)
+    {
+        // a cache row counts only when its epoch stamp is the running one, and adoption bumps the epoch: the rows a RECYCLED image
+        // still holds carry older stamps and are dead as they are.  Fresh memory can hold anything: cleared once.
+        const void* before = P.d_cache.p;
+        const size_t cap0 = P.d_cache.cap;
+        HIPC(c, P.d_cache.ensure_n("d_cache", (size_t)P.n_voices * sizeof(VoiceCache)));
+        if ((P.d_cache.p != before || P.d_cache.cap != cap0) && (rc = zero(c, P.d_cache.p, P.d_cache.cap))) return rc;
+    }
     HIPC(c, P.d_ramps.ensure_n("d_ramps", K * P.n_voices * (size_t)P.ramp_slots * c->stride * sizeof(float)));
     if (!P.h_ctl_order || P.h_ctl_order_cap < (size_t)P.n_voices) {  // (a recycled image keeps its pinned block)
         if (P.h_ctl_order) (void)hipHostFree(P.h_ctl_order);
@@ -858,7 +869,10 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         }
         size_t bus_bytes = K * (size_t)P.n_bus * c->stride * sizeof(float);
         HIPC(c, P.d_bus.ensure_n("d_bus", bus_bytes));
-        if ((rc = zero(c, P.d_bus.p, bus_bytes))) return rc;
+        // bus 0 of every block is the constant-zero bus (flagged silent below) and has to BE zero; every other bus is written by
+        // its leaf / sum / master-chain kernel before anything reads it, as in the pool (step 4): clearing all of it was a 4.4 MB
+        // fill per edit of config 3 — most of what an edit put on the stream
+        if (P.n_bus > 0 && (rc = fill_rows(c, P.d_bus.p, c->stride * sizeof(float), (size_t)P.n_bus * c->stride * sizeof(float), K, 0))) return rc;
         std::vector<uint8_t> bf(K * P.n_bus, 0);
         for (size_t k = 0; k < K; ++k) bf[k * P.n_bus] = 1;
         if ((rc = up(c, P.d_bus_flags, bf.data(), bf.size(), true))) return rc;  // (kernels write flags)

@@ -461,7 +461,7 @@ def test_control_dispatch_order_and_cache_carry_on_the_host_side():
 def test_plan_builds_go_out_in_pieces_only_while_a_stream_is_live(monkeypatch):
     """round 3, host half (fwgpu_plan_install.cpp, quiet_window / audio_live): a build with no process call in the last 200 ms
     uploads every table whole; a build right after a process call cuts its uploads into pieces of at most FWGPU_UP_PIECE bytes
-    (128 KiB), each issued when the gate word says no process call is in flight.  The fake HIP counts the asynchronous
+    (set to 128 KiB here; the default is 256), each issued when the gate word says no process call is in flight.  The fake HIP counts the asynchronous
     host-to-device copies and remembers the largest."""
     import ctypes as C
     import time
@@ -471,6 +471,7 @@ def test_plan_builds_go_out_in_pieces_only_while_a_stream_is_live(monkeypatch):
     L = hostonly_lib()
     for f in (L.fwh_h2d_count, L.fwh_h2d_max):
         f.restype = C.c_ulonglong
+    monkeypatch.setenv("FWGPU_UP_PIECE", str(128 * 1024))
     monkeypatch.setenv("FWGPU_UP_DIFF", "0")                                  # (every table whole, every build: the test below covers the diff)
     monkeypatch.setenv("FWGPU_BUILD_ONE_KERNEL", "0")                         # (the calls one by one: the default is one kernel per build, below)
     e = HostOnlyEngine(max_block_frames=256, max_batch=8)

@@ -12,10 +12,10 @@ import fwapi
 def test_graph_edits_while_the_audio_thread_runs_cost_the_callbacks_microseconds_not_milliseconds():
     """VERDICT r2 missing #3: examples/host_c/fw_edit_race (plain C + pthreads through the C ABI) replaces voices of the config-3
     graph — 4 096 voices of sampler -> biquad -> delay -> gain — one after another while an audio thread runs one-block
-    callbacks.  Each fwgpu_update recompiles and re-uploads the whole launch plan (~5 ms) ON THE CONTROL THREAD, off to the
-    side; the callback that follows adopts it (graph/processor.rs:167-206).  The bar: an adoption holds its callback up for
+    callbacks.  Each fwgpu_update recompiles the whole launch plan and uploads what changed of it (1.0-1.4 ms since round 4, 2-6 before) ON
+    THE CONTROL THREAD, off to the side; the callback that follows adopts it (graph/processor.rs:167-206).  The bar: an adoption holds its callback up for
     microseconds (measured 17-48), and the callbacks' median does not move.  Every timing bound below has room — the measured values
-    are in profiles/r03_edit_race_cfg3*.json and DESIGN.md section 1; a miss here would hide the parity tests that run after it."""
+    are in profiles/r04_edit_race_cfg3.json and DESIGN.md section 1; a miss here would hide the parity tests that run after it."""
     import json
     import subprocess
 
@@ -34,11 +34,12 @@ def test_graph_edits_while_the_audio_thread_runs_cost_the_callbacks_microseconds
         assert d["launch_plan"] == 2 and d["edits"] == 30
         assert d["adopted_by_a_callback"] >= 20, d      # the audio thread was running: (nearly) every plan was picked up by a callback
         assert d["longest_adoption_us"] < 200.0, d      # (measured 17-48 us; a build is 2-5 ms)
-        assert d["update_ms_mean"] > 0.5, d             # ... while each update really was milliseconds of work
+        assert d["update_ms_mean"] > 0.3, d             # ... while each update really was a millisecond of work
+    assert mid(lambda d: d["update_ms_mean"]) <= 2.0, runs  # (measured 1.04-1.39 on the box that ran the old host code at 2.1-2.5)
     assert mid(lambda d: d["callback_us_while_the_plan_is_built"]["median"] - d["callback_us_steady"]["median"]) <= 10.0, runs
     # VERDICT r3's bar for a SATURATED audio thread (callbacks back to back, no gap for the build's groups to use): p99 <= steady + 30 us,
-    # maximum <= steady maximum + 50 us.  Round 4 meets it with the build's job groups launched into the audio stream (measured +21-23 /
-    # +13-17, profiles/r04_edit_race_*.json; on the build's own stream — FWGPU_BUILD_STREAM=own — it was +40-65 / +60-75).
+    # maximum <= steady maximum + 50 us.  Round 4 meets it with the build's job groups launched into the audio stream (measured +3..+12 /
+    # -110..+11, profiles/r04_edit_race_cfg3.json; on the build's own stream — FWGPU_BUILD_STREAM=own — it was +40-65 / +60-75).
     if os.environ.get("FWGPU_QUIET_WAIT_US", "100") != "0" and os.environ.get("FWGPU_BUILD_STREAM", "audio") != "own":
         assert mid(lambda d: d["callback_us_while_the_plan_is_built"]["p99"] - d["callback_us_steady"]["p99"]) <= 30.0, runs
         assert mid(lambda d: d["callback_us_while_the_plan_is_built"]["max"] - d["callback_us_steady"]["max"]) <= 50.0, runs

@@ -304,7 +304,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         return true;
     };
     struct Bank {
-        int sum;
+        int sum;  // the SumNode — or, for a solo voice, the last node of its chain: the node whose output buffers the leaf writes
         std::vector<VoiceDesc> voices;
         std::vector<uint32_t> progs;
         std::vector<int> nodes;
@@ -312,9 +312,92 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         int stages = 0, real = 0;
         uint64_t min_delay = ~0ull;
         bool split = false;  // only the leading ports are voices: the SumNode stays on the levels as a continuation
+        bool solo = false;   // one voice chain on its own (below)
+    };
+    // one voice chain, walked upstream from its last node: gain stages, then [delay], then [biquad], then the source (as detect_fused)
+    struct Walk {
+        bool ok = false;
+        VoiceDesc vd;
+        uint32_t prog_bits = 0;
+        int nodes[FW_MAX_STAGES + 4], n_nodes = 0;
+        bool prog = false, rs = false, fx = false, sp = false;
+        uint64_t delay = ~0ull;
+    };
+    std::vector<char> taken(N, 0);  // nodes of a candidate bank (a chain node feeds one consumer, so banks cannot overlap)
+    auto walk_voice = [&](int cur) -> Walk {
+        Walk w;
+        memset(&w.vd, 0, sizeof(w.vd));
+        w.vd.sampler_state = w.vd.bq_state = w.vd.dl_state = w.vd.sp_ext_off = -1;
+        int chain[FW_MAX_STAGES], n_chain = 0;
+        int bq = -1, dl = -1;
+        bool sp_voice = false;
+        for (;;) {
+            const PlanNode& n = plan.nodes[cur];
+            if (taken[cur] || n.is_graph_io) return w;
+            if (n.kind == K_SAMPLER || n.kind == K_RESAMPLER) {
+                if (!(n.n_in == 0 && n.n_out == 2)) return w;
+                break;
+            }
+            if (n.n_in != 2 || n.n_out != 2) return w;
+            if (n.kind == K_VOLUME || n.kind == K_PAN || n.kind == K_WIDTH || n.kind == K_HARD_CLIP) {
+                if (bq >= 0 || dl >= 0 || n_chain >= FW_MAX_STAGES - 1) return w;
+                chain[n_chain++] = cur;
+            } else if (n.kind == K_SPATIAL) {  // (as detect_fused: the last node of a dry sampler voice)
+                if (n_chain || bq >= 0 || dl >= 0 || mbf % 64 != 0) return w;
+                sp_voice = true;
+                chain[n_chain++] = cur;
+            } else if (n.kind == K_DELAY) {
+                if (bq >= 0 || dl >= 0 || graph.nodes[n.slot].init.loop_end < 64) return w;
+                w.delay = graph.nodes[n.slot].init.loop_end;
+                dl = cur;
+            } else if (n.kind == K_BIQUAD) {
+                if (bq >= 0) return w;
+                bq = cur;
+            } else {
+                return w;
+            }
+            int src;
+            if (!stereo_src(n, 0, src)) return w;
+            cur = src;
+        }
+        if (sp_voice && (bq >= 0 || dl >= 0 || plan.nodes[cur].kind == K_RESAMPLER)) return w;
+        w.vd.sp_ext_off = sp_voice ? 0 : -1;
+        w.sp = sp_voice;
+        w.prog = sp_voice;
+        w.vd.sampler_state = (int)plan.nodes[cur].slot;
+        w.vd.src_kind = plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0;
+        w.vd.bq_state = bq >= 0 ? (int)plan.nodes[bq].slot : -1;
+        w.vd.dl_state = dl >= 0 ? (int)plan.nodes[dl].slot : -1;
+        w.fx = bq >= 0 || dl >= 0;
+        w.rs = w.vd.src_kind == 1;
+        w.vd.n_stages = n_chain;
+        for (int j = 0; j < n_chain; ++j) {  // schedule order: nearest the source first
+            const PlanNode& n = plan.nodes[chain[n_chain - 1 - j]];
+            w.vd.stage_kind[j] = n.kind;
+            w.vd.stage_state[j] = (int)n.slot;
+            w.prog_bits |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : n.kind == K_SPATIAL ? SK_SPATIAL : SK_GAIN) << (4 * j);
+            w.prog = w.prog || n.kind == K_WIDTH || n.kind == K_HARD_CLIP;
+        }
+        w.nodes[w.n_nodes++] = cur;
+        if (bq >= 0) w.nodes[w.n_nodes++] = bq;
+        if (dl >= 0) w.nodes[w.n_nodes++] = dl;
+        for (int j = 0; j < n_chain; ++j) w.nodes[w.n_nodes++] = chain[j];
+        w.ok = true;
+        return w;
+    };
+    auto take = [&](Bank& bk, const Walk& w) {
+        bk.sp = bk.sp || w.sp;
+        bk.prog = bk.prog || w.prog;
+        bk.fx = bk.fx || w.fx;
+        bk.rs = bk.rs || w.rs;
+        bk.min_delay = std::min(bk.min_delay, w.delay);
+        bk.stages = std::max(bk.stages, w.vd.n_stages);
+        bk.nodes.insert(bk.nodes.end(), w.nodes, w.nodes + w.n_nodes);
+        bk.voices.push_back(w.vd);
+        bk.progs.push_back(w.prog_bits);
+        bk.real++;
     };
     std::vector<Bank> banks;
-    std::vector<char> taken(N, 0);  // nodes of a candidate bank (a chain node feeds one consumer, so banks cannot overlap)
     for (int si = 0; si < N; ++si) {
         const PlanNode& s = plan.nodes[si];
         if (s.kind != K_SUM || s.is_graph_io || s.n_out != 2 || s.n_in < 2 || s.n_in % 2 || s.n_in > 64) continue;
@@ -322,13 +405,11 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         Bank bk;
         bk.sum = si;
         bool ok = true;
-        for (int p = 0; ok && p < s.n_in / 2; ++p) {
-            const size_t nodes_before = bk.nodes.size();
-            const Bank before = bk;  // (a port that turns out not to be a voice chain leaves the bank as it was)
-            VoiceDesc vd;
-            memset(&vd, 0, sizeof(vd));
-            vd.sampler_state = vd.bq_state = vd.dl_state = vd.sp_ext_off = -1;
+        for (int p = 0; p < s.n_in / 2; ++p) {  // (a port that turns out not to be a voice chain leaves the bank as it was)
             if (s.in_src_node[2 * p] < 0 && s.in_src_node[2 * p + 1] < 0) {  // an empty voice slot: a null voice
+                VoiceDesc vd;
+                memset(&vd, 0, sizeof(vd));
+                vd.sampler_state = vd.bq_state = vd.dl_state = vd.sp_ext_off = -1;
                 bk.voices.push_back(vd);
                 bk.progs.push_back(0u);
                 continue;
@@ -336,96 +417,14 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
             int cur;
             if (!stereo_src(s, 2 * p, cur)) {
                 ok = false;
-                bk = before;
                 break;
             }
-            // walking upstream: gain stages, then [delay], then [biquad], then the source (as detect_fused)
-            std::vector<int> chain;
-            int bq = -1, dl = -1;
-            bool sp_voice = false;
-            for (;;) {
-                const PlanNode& n = plan.nodes[cur];
-                if (taken[cur] || n.is_graph_io) {
-                    ok = false;
-                    break;
-                }
-                if (n.kind == K_SAMPLER || n.kind == K_RESAMPLER) {
-                    ok = n.n_in == 0 && n.n_out == 2;
-                    break;
-                }
-                if (n.n_in != 2 || n.n_out != 2) {
-                    ok = false;
-                    break;
-                }
-                if (n.kind == K_VOLUME || n.kind == K_PAN || n.kind == K_WIDTH || n.kind == K_HARD_CLIP) {
-                    if (bq >= 0 || dl >= 0 || (int)chain.size() >= FW_MAX_STAGES - 1) {
-                        ok = false;
-                        break;
-                    }
-                    chain.push_back(cur);
-                } else if (n.kind == K_SPATIAL) {  // (as detect_fused: the last node of a dry sampler voice)
-                    if (!chain.empty() || bq >= 0 || dl >= 0 || mbf % 64 != 0) {
-                        ok = false;
-                        break;
-                    }
-                    sp_voice = true;
-                    chain.push_back(cur);
-                } else if (n.kind == K_DELAY) {
-                    if (bq >= 0 || dl >= 0 || graph.nodes[n.slot].init.loop_end < 64) {
-                        ok = false;
-                        break;
-                    }
-                    bk.min_delay = std::min<uint64_t>(bk.min_delay, graph.nodes[n.slot].init.loop_end);
-                    dl = cur;
-                } else if (n.kind == K_BIQUAD) {
-                    if (bq >= 0) {
-                        ok = false;
-                        break;
-                    }
-                    bq = cur;
-                } else {
-                    ok = false;
-                    break;
-                }
-                int src;
-                if (!stereo_src(n, 0, src)) {
-                    ok = false;
-                    break;
-                }
-                cur = src;
-            }
-            if (ok && sp_voice && (bq >= 0 || dl >= 0 || plan.nodes[cur].kind == K_RESAMPLER)) ok = false;
-            if (!ok) {
-                bk = before;
-                bk.nodes.resize(nodes_before);
+            const Walk w = walk_voice(cur);
+            if (!w.ok) {
+                ok = false;
                 break;
             }
-            vd.sp_ext_off = sp_voice ? 0 : -1;
-            bk.sp = bk.sp || sp_voice;
-            bk.prog = bk.prog || sp_voice;
-            vd.sampler_state = (int)plan.nodes[cur].slot;
-            vd.src_kind = plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0;
-            vd.bq_state = bq >= 0 ? (int)plan.nodes[bq].slot : -1;
-            vd.dl_state = dl >= 0 ? (int)plan.nodes[dl].slot : -1;
-            bk.fx = bk.fx || bq >= 0 || dl >= 0;
-            bk.rs = bk.rs || vd.src_kind == 1;
-            vd.n_stages = (int)chain.size();
-            uint32_t pr = 0;
-            for (int j = 0; j < vd.n_stages; ++j) {  // schedule order: nearest the source first
-                const PlanNode& n = plan.nodes[chain[chain.size() - 1 - j]];
-                vd.stage_kind[j] = n.kind;
-                vd.stage_state[j] = (int)n.slot;
-                pr |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : n.kind == K_SPATIAL ? SK_SPATIAL : SK_GAIN) << (4 * j);
-                bk.prog = bk.prog || n.kind == K_WIDTH || n.kind == K_HARD_CLIP;
-            }
-            bk.stages = std::max(bk.stages, vd.n_stages);
-            bk.nodes.push_back(cur);
-            if (bq >= 0) bk.nodes.push_back(bq);
-            if (dl >= 0) bk.nodes.push_back(dl);
-            bk.nodes.insert(bk.nodes.end(), chain.begin(), chain.end());
-            bk.voices.push_back(vd);
-            bk.progs.push_back(pr);
-            bk.real++;
+            take(bk, w);
         }
         if (bk.real == 0) continue;
         if (!ok) {
@@ -453,6 +452,69 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         bool any_fx = false;
         for (const Bank& bk : banks) any_fx = any_fx || (bk.fx && keeps(bk, true));
         fx_mode = any_fx;
+    }
+    // Solo voices (round 4): a voice chain that is NOT a port of a bank — behind a mixer's first non-voice input, on a 2- / 3- /
+    // 4-port mixer beside a bus, feeding an effect or two consumers — is a leaf of ONE port whose output is the chain's last node's
+    // own pool buffers: a one-port sum is a copy (sum.rs:58-65, out mask passed through), so whatever reads those buffers on the
+    // levels sees the node's output and silence flag bit for bit.  The walk goes DOWN from each free source as far as the mode's
+    // kernels render (dry mode: gain / program stages, a spatialiser; chain mode: biquad, delay, plain gains), then the bank
+    // ports' own validator walks back up; a chain it refuses is tried again one node shorter (a bare source always passes).
+    static const bool solo_on = !(getenv("FWGPU_SOLO") && atoi(getenv("FWGPU_SOLO")) == 0);  // FWGPU_SOLO=0: banks only (A/B runs)
+    if (solo_on) {
+        std::vector<int> cons_node(cons.cnt.size(), -1);  // who reads (node, port): meaningful where the count is 1
+        for (int i = 0; i < N; ++i) {
+            const PlanNode& n = plan.nodes[i];
+            for (int p = 0; p < n.n_in; ++p)
+                if (n.in_src_node[p] >= 0) cons_node[cons.off[n.in_src_node[p]] + n.in_src_port[p]] = i;
+        }
+        if (banks.empty() && mbf % 64 == 0)  // no bank chose the mode: solo voices with a filter / delay behind the source choose the chain plan's kernels
+            for (int i = 0; i < N && !fx_mode; ++i) {
+                const PlanNode& src = plan.nodes[i];
+                if (src.kind != K_SAMPLER || src.n_in != 0 || src.n_out != 2 || cons[i][0] != 1 || cons[i][1] != 1) continue;
+                const int nx = cons_node[cons.off[i]];
+                if (nx < 0 || nx != cons_node[cons.off[i] + 1]) continue;
+                const PlanNode& n = plan.nodes[nx];
+                fx_mode = (n.kind == K_BIQUAD || (n.kind == K_DELAY && graph.nodes[n.slot].init.loop_end >= 64)) && n.n_in == 2 && n.n_out == 2 &&
+                          n.in_src_port[0] == 0 && n.in_src_port[1] == 1;
+            }
+        for (int i = 0; i < N; ++i) {
+            const PlanNode& src = plan.nodes[i];
+            if (!(src.kind == K_SAMPLER || src.kind == K_RESAMPLER) || taken[i] || src.n_in != 0 || src.n_out != 2) continue;
+            if (fx_mode && src.kind == K_RESAMPLER) continue;  // (the chain plan's source fetch is the sampler's)
+            int end = i, stages = 0;
+            for (;;) {
+                if (cons[end][0] != 1 || cons[end][1] != 1) break;
+                const int nx = cons_node[cons.off[end]];
+                if (nx < 0 || nx != cons_node[cons.off[end] + 1] || taken[nx]) break;
+                const PlanNode& n = plan.nodes[nx];
+                if (n.is_graph_io || n.n_in != 2 || n.n_out != 2) break;
+                if (n.in_src_node[0] != end || n.in_src_port[0] != 0 || n.in_src_node[1] != end || n.in_src_port[1] != 1) break;
+                const bool gain = n.kind == K_VOLUME || n.kind == K_PAN;
+                const bool progk = n.kind == K_WIDTH || n.kind == K_HARD_CLIP || n.kind == K_SPATIAL;
+                const bool fxk = n.kind == K_BIQUAD || n.kind == K_DELAY;
+                if (!(gain || (progk && !fx_mode) || (fxk && fx_mode))) break;
+                if (gain || progk) {
+                    if (++stages > (fx_mode ? FW_CHAIN_STAGES - 1 : FW_MAX_STAGES - 1)) break;
+                }
+                end = nx;
+            }
+            for (int cand = end;; cand = plan.nodes[cand].in_src_node[0]) {
+                const PlanNode& e = plan.nodes[cand];
+                const Walk w = e.out_buf[1] == e.out_buf[0] + 1 ? walk_voice(cand) : Walk();
+                if (w.ok && w.nodes[0] == i) {
+                    Bank bk;
+                    bk.sum = cand;
+                    bk.solo = true;
+                    take(bk, w);
+                    if (keeps(bk, fx_mode)) {
+                        for (int k : bk.nodes) taken[k] = 1;
+                        banks.push_back(std::move(bk));
+                        break;
+                    }
+                }
+                if (cand == i) break;
+            }
+        }
     }
     int real_voices = 0;
     for (const Bank& bk : banks) {

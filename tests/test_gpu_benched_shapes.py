@@ -163,7 +163,7 @@ def test_config4_real_size_65536_taps_k16_two_row_tiles_matches_the_oracle():
 
     g = GpuEngine(max_block_frames=frames, max_batch=16)
     og = run(g)
-    assert g.cx.plan_kind() == 0
+    assert g.cx.plan_kind() == 3 and g.cx.plan_fused_voices() == V   # (round 4: the samplers in front of the FIR nodes are solo voices of the hybrid plan)
     oo = run(OracleEngine(max_block_frames=frames))
     assert_bits_equal(oo, og, "65536-tap FIR bank, K = 16, 36 rows")
 

@@ -141,7 +141,9 @@ def test_hybrid_plan_selection_and_launch_sequence():
 def test_hybrid_plan_splits_a_mixer_that_also_takes_a_bus():
     """a mixer SumNode with 10 voices on its leading ports and a return on its last: the voices are summed by the voice-bank
     kernels into a partial bus, the node stays on the levels as the continuation (partial, return).  A 3-port mixer is not
-    split (its path is spelled out port by port in the reference), nor one whose FIRST port is the bus"""
+    split (its path is spelled out port by port in the reference), nor one whose FIRST port is the bus — round 4: the voices of
+    those two shapes are SOLO voices (one-port leaves writing the chain's own pool buffers), and so is the bare sampler in front of
+    the detour: the plan is hybrid either way"""
     def mixer(e, n_voices, bus_port_first=False):
         ends = []
         for v in range(n_voices):
@@ -166,13 +168,21 @@ def test_hybrid_plan_splits_a_mixer_that_also_takes_a_bus():
         return e
 
     e = mixer(HostOnlyEngine(max_block_frames=64, max_batch=8), 10)
-    assert e.cx.plan_kind() == 3 and e.cx.plan_fused_voices() == 10
+    assert e.cx.plan_kind() == 3 and e.cx.plan_fused_voices() == 10 + 1             # (+ the detour's sampler, solo)
     e.reset_launches()
     e.process_blocks(8)
     c = e.launches()
     assert (c["voice_control"], c["leaf_sum"]) == (1, 1) and c["level"] >= 3   # detour levels + the continuation
-    assert mixer(HostOnlyEngine(max_block_frames=64), 10, bus_port_first=True).cx.plan_kind() == 0
-    assert mixer(HostOnlyEngine(max_block_frames=64), 2).cx.plan_kind() == 0          # a 3-port sum: never split
+    assert e.violation() == "", e.violation()
+    for e2, nv in ((mixer(HostOnlyEngine(max_block_frames=64, max_batch=8), 10, bus_port_first=True), 11),   # voices BEHIND the bus: ten solo leaves
+                   (mixer(HostOnlyEngine(max_block_frames=64, max_batch=8), 7), 8)):                       # an 8-port mixer... (split: 7 + 1 solo)
+        assert e2.cx.plan_kind() == 3 and e2.cx.plan_fused_voices() == nv, (e2.cx.plan_kind(), e2.cx.plan_fused_voices())
+        e2.reset_launches()
+        e2.process_blocks(8)
+        c = e2.launches()
+        assert (c["voice_control"], c["leaf_sum"]) == (1, 1) and c["level"] >= 3
+        assert e2.violation() == "", e2.violation()
+    assert mixer(HostOnlyEngine(max_block_frames=64), 2).cx.plan_kind() == 0          # a 3-port sum is never split, and 3 solo voices are not worth the launches
 
 
 def test_imported_reference_schedule_selects_the_same_plan_and_levels():

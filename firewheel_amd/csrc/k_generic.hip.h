@@ -930,11 +930,132 @@ __device__ __forceinline__ void delay_walk(const DevView& v, const NodeDesc& nd,
     if (lane == 0) sp->playhead = (uint64_t)pos;  // (nothing else of the node's state moves)
 }
 
+// ---- frozen nodes of a wide level, several blocks at a time (round 4).  node_process_wave block by block is a chain of dependent
+// loads (descriptor -> port table -> flags -> 128 bytes of state) in front of 4 KB of audio: config 2 on the levels alone ran its
+// sampler / volume / pan levels at 1.9-2.4 TB/s.  For the three kinds such a level is made of — a stereo VolumeNode or a pan with
+// resting smoothers, a steadily playing stereo planar-f32 sampler — everything but the audio is the same in every block of the
+// batch: the wave reads it once and streams FZ_U blocks at a time, their loads in flight together.  Same operations per sample
+// as the cases of node_process_wave (volume.rs:94-142, sampler.rs:445-543); anything else returns false / goes block by block.
+#define FZ_U 4
+// Returns the blocks of [b0, b1) it did NOT render, bit (b - b0) each — all of them when the node is not one of the three shapes
+// (at most 32 blocks per wave).
+template <int SET>
+__device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node, const uint8_t fz, const uint32_t b0, const uint32_t b1, const uint32_t K) {
+    const NodeDesc nd = v.nodes[node];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int frames = v.frames;
+    if (nd.n_out != 2 || (frames & 3) || b1 - b0 > 32u) return ~0u;
+    const int* obt = v.out_buf + nd.out_off;
+    const int o0 = obt[0], o1 = obt[1];
+    const uint32_t u_l = (uint32_t)lane >> 1;  // flags: lane 2u + c holds (block b + u, channel c)
+    const int c_l = lane & 1;
+    if constexpr (SET == 0) {
+        if (fz != 1 || !(nd.kind == K_VOLUME || nd.kind == K_PAN) || nd.n_in != 2) return ~0u;
+        const int* ibt = v.in_buf + nd.in_off;
+        const int i0 = ibt[0], i1 = ibt[1];
+        const NodeState& s = v.states[nd.state];
+        const float gl = s.s0.input;                               // a resting smoother's block is its input (smoother.rs:162-167)
+        const float gr = nd.kind == K_PAN ? s.s1.input : gl;
+        const bool mute = nd.kind == K_VOLUME && s.s0.status == SM_INACTIVE && gl < 0.00001f;  // volume.rs:104-108
+        for (uint32_t b = b0; b < b1; b += FZ_U) {
+            uint8_t f = 0;
+            if (lane < 2 * FZ_U && b + u_l < b1) f = (v.flags + (size_t)(b + u_l) * v.flags_blk_stride)[c_l ? i1 : i0];
+            const uint32_t fm = (uint32_t)__ballot(f != 0);
+            for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+                v4f x[FZ_U][2];
+#pragma unroll
+                for (int u = 0; u < FZ_U; ++u) {
+                    x[u][0] = x[u][1] = splat(0.f);
+                    if (b + u < b1 && ((fm >> (2 * u)) & 3u) != 3u && !mute) {  // (all inputs silent: cleared, :94-100)
+                        const float* pl = v.pool + (size_t)(b + u) * v.pool_blk_stride;
+                        x[u][0] = *(const v4f*)(pl + (size_t)i0 * v.stride + f0);
+                        x[u][1] = *(const v4f*)(pl + (size_t)i1 * v.stride + f0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < FZ_U; ++u)
+                    if (b + u < b1) {
+                        float* pl = v.pool + (size_t)(b + u) * v.pool_blk_stride;
+                        const bool clr = ((fm >> (2 * u)) & 3u) == 3u || mute;
+                        *(v4f*)(pl + (size_t)o0 * v.stride + f0) = clr ? splat(0.f) : x[u][0] * gl;  // :123-126 (stereo path: both channels, flagged or not)
+                        *(v4f*)(pl + (size_t)o1 * v.stride + f0) = clr ? splat(0.f) : x[u][1] * gr;
+                    }
+            }
+            if (lane < 2 * FZ_U && b + u_l < b1) {  // out mask: all silent / muted -> both flagged, else the in mask (:110)
+                const uint32_t m = (fm >> (2 * u_l)) & 3u;
+                (v.flags + (size_t)(b + u_l) * v.flags_blk_stride)[c_l ? o1 : o0] = (m == 3u || mute) ? 1 : (uint8_t)((m >> c_l) & 1u);
+            }
+        }
+        return 0u;
+    } else if constexpr (SET == 2) {
+        if (fz != 2 || nd.kind != K_SAMPLER) return ~0u;
+        const NodeState& s0 = v.states[nd.state];
+        const SampleDesc sd = v.samples[s0.sample];
+        const uint64_t loop_start = s0.loop_start, loop_end = s0.loop_end;
+        const int has_loop = s0.has_loop;
+        uint32_t todo = 0u;
+        if (sd.format != FMT_P_F32 || sd.channels != 2) return ~0u;
+        const float g = s0.s0.input;  // (k_frozen_scan: the gain rests and is no mute)
+        const uint64_t ph0 = v.frozen_playhead[node];
+        for (uint32_t b = b0; b < b1; b += FZ_U) {
+            const float* src[FZ_U];
+            uint32_t slow = 0;
+#pragma unroll
+            for (int u = 0; u < FZ_U; ++u) {
+                src[u] = nullptr;
+                const uint32_t blk = b + u;
+                if (blk >= b1) continue;
+                NodeState t;  // the playhead of block blk in closed form (node_process_wave, K_SAMPLER), then the block's own advance
+                t.loop_start = loop_start;
+                t.loop_end = loop_end;
+                t.has_loop = has_loop;
+                t.playing = 1;
+                t.playhead = ph0;
+                const uint64_t adv = (uint64_t)blk * (uint64_t)frames;
+                if (blk) {
+                    if (t.has_loop) {
+                        const uint64_t L = t.loop_end - t.loop_start;
+                        const uint64_t off = t.playhead >= t.loop_end ? 0 : t.playhead - t.loop_start;
+                        if (L) t.playhead = t.loop_start + (off + adv) % L;
+                    } else {
+                        t.playhead += adv;
+                    }
+                }
+                Fetch ft;
+                const bool ok = sampler_advance(t, sd.frames, (uint32_t)frames, ft);
+                if (blk + 1 == K || !ok || ft.wrap || ft.tail_zero || ft.n1 != (uint32_t)frames) slow |= 1u << u;  // (the batch's last block stores the state)
+                else src[u] = (const float*)sd.data + ft.off0;
+            }
+            for (int f0 = lane * 4; f0 < frames; f0 += 256) {
+                v4f x[FZ_U][2];
+#pragma unroll
+                for (int u = 0; u < FZ_U; ++u)
+                    if (src[u]) {
+                        x[u][0] = (v4f)(*(const v4f_u*)(src[u] + f0));
+                        x[u][1] = (v4f)(*(const v4f_u*)(src[u] + (size_t)sd.frames + f0));
+                    }
+#pragma unroll
+                for (int u = 0; u < FZ_U; ++u)
+                    if (src[u]) {
+                        float* pl = v.pool + (size_t)(b + u) * v.pool_blk_stride;
+                        *(v4f*)(pl + (size_t)o0 * v.stride + f0) = x[u][0] * g;  // sampler.rs:521-543
+                        *(v4f*)(pl + (size_t)o1 * v.stride + f0) = x[u][1] * g;
+                    }
+            }
+            if (lane < 2 * FZ_U && b + u_l < b1 && !((slow >> u_l) & 1u)) (v.flags + (size_t)(b + u_l) * v.flags_blk_stride)[c_l ? o1 : o0] = 0;
+            todo |= slow << (b - b0);
+        }
+        return todo;
+    } else {
+        return ~0u;
+    }
+}
+
 // K blocks per launch (gridDim.y = K, one pool slice per block).  A node whose audio half carries state from block
 // to block is run by ONE wave that walks its K blocks in order; stateless nodes — and frozen ones — take their K
 // blocks in parallel.
 #ifndef LEVEL_BPW
-#define LEVEL_BPW 4  // consecutive blocks one wave takes for a stateless / frozen node of a WIDE level
+#define LEVEL_BPW 8  // consecutive blocks one wave takes for a stateless / frozen node of a WIDE level
 #endif
 // gridDim.y = ceil(K / bpw): a wave takes bpw consecutive blocks of its node, so the node's descriptor, port tables and
 // state come from HBM once and from the cache for the other blocks (the per-block work is ~4 KB behind a chain of dependent
@@ -955,8 +1076,9 @@ __global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __res
         if (fz) {
             const bool adv = fz == 2;  // playing sampler: per-block playhead in closed form, the last block stores the state
             const bool spat = fz == 3;
+            const uint32_t todo = bpw > 1 ? frozen_fast<SET>(v, node, fz, b0, b1, K) : ~0u;  // (what is left goes block by block)
             for (uint32_t b = b0; b < b1; ++b)
-                node_process_wave<SET>(v, node, b, cmd_block0 + b, adv && b + 1 == K, adv ? b : 0u, adv || spat);
+                if ((todo >> ((b - b0) & 31u)) & 1u) node_process_wave<SET>(v, node, b, cmd_block0 + b, adv && b + 1 == K, adv ? b : 0u, adv || spat);
             if (spat) {
                 if (b0 == 0) spatial_finish(v, node, K);
             } else if (!adv && b0 == 0) {

@@ -299,7 +299,16 @@ int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
     dim3 grid((fv.n_leaves + LEAF_WPB - 1) / LEAF_WPB, K);
 #endif
     if (fv.has_sp && fv.has_rs) hipLaunchKernelGGL((k_leaf_sum<true, true, true>), grid, dim3(WAVE * LEAF_WPB), RS_LDS_BYTES(LEAF_WPB), s, fv, K, wpk);
-    else if (fv.has_sp) hipLaunchKernelGGL(k_leaf_sum_sp, grid, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk);
+    else if (fv.has_sp) {
+        // one-piece blocks: a wave takes up to 8 consecutive blocks of its leaf (k_leaf.hip.h, leaf_kernel_body) while the launch still fills the chip
+        int nb = 1;
+        if (wpk == 1) {
+            const long long pairs = (long long)fv.n_leaves * K;
+            nb = (int)(pairs / 3072 < 1 ? 1 : (pairs / 3072 > 8 ? 8 : pairs / 3072));
+        }
+        const dim3 g2 = wpk == 1 ? dim3(fv.n_leaves, (K + LEAF_WPB * nb - 1) / (LEAF_WPB * nb)) : grid;
+        hipLaunchKernelGGL(k_leaf_sum_sp, g2, dim3(WAVE * LEAF_WPB), 0, s, fv, K, wpk, nb);
+    }
     else if (fv.has_rs) {  // a pair: the resampler-pure leaves (k_leaf_rs), then whatever it put on the work list
         hipLaunchKernelGGL(k_leaf_rs, grid, dim3(WAVE * LEAF_WPB), RS2_LDS_BYTES(LEAF_WPB), s, fv, K, wpk);
         const int items = fv.n_leaves * K * wpk;

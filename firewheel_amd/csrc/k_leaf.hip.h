@@ -739,19 +739,25 @@ template <uint32_t CLS>
 __device__ __forceinline__ void leaf_sp_fast(const FusedView& fv, const LeafDesc& ld, const uint32_t k, const int K, const int part, const int wpk,
                                              const uint32_t prog, const int jn, const float* my_l, const uint32_t my_rd, const GainSet& my_g,
                                              const uint32_t fg, const uint64_t plp, const uint32_t rdp, const GainSet& gp, float* sp_lds,
-                                             float* outl, float* outr) {
+                                             float* outl, float* outr, float* tails, bool& tails_valid) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int frames = fv.frames;
     const int tq = (lane & 15) * 4;
     for (int f0 = lane * 4 + part * 256; f0 - lane * 4 < frames; f0 += 256 * wpk) {
         const int fb = f0 - lane * 4;
         const bool act = f0 < frames;
-        const int hmode = fb > 0 ? 0 : (k > 0 ? 1 : 2);  // the 64 frames before the piece: same block / the block before / the call before
+        // the 64 frames before the piece: same block / the block before / the call before — or (3) what this wave kept of the piece it
+        // rendered just before this one (`tails`, LDS: [port][64] mono frames)
+        const int hmode = tails_valid ? 3 : (fb > 0 ? 0 : (k > 0 ? 1 : 2));
         v4f accl = splat(0.f), accr = splat(0.f);
         for (int p0 = 0; p0 < ld.ports; p0 += SP_U) {
-            RawQuad q[SP_U], t[SP_U];
+            RawQuad q[SP_U];
+            v4f tm[SP_U];  // lanes < 16: the 64 mono frames in front of the piece
 #pragma unroll
-            for (int u = 0; u < SP_U; ++u) q[u].a = q[u].b = t[u].a = t[u].b = (v4i){0, 0, 0, 0};
+            for (int u = 0; u < SP_U; ++u) {
+                q[u].a = q[u].b = (v4i){0, 0, 0, 0};
+                tm[u] = splat(0.f);
+            }
             if (act) {
 #pragma unroll
                 for (int u = 0; u < SP_U; ++u)
@@ -759,23 +765,43 @@ __device__ __forceinline__ void leaf_sp_fast(const FusedView& fv, const LeafDesc
                         q[u] = sp_raw<CLS>(readlane_ptr(my_l, p0 + u), (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p0 + u), f0);
             }
             if (lane < 16) {
-                if (hmode == 0) {
+                if (hmode == 3) {
 #pragma unroll
                     for (int u = 0; u < SP_U; ++u)
-                        if (p0 + u < ld.ports)
-                            t[u] = sp_raw<CLS>(readlane_ptr(my_l, p0 + u), (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p0 + u), fb - SP_HIST + tq);
-                } else if (hmode == 1) {
+                        if (p0 + u < ld.ports) tm[u] = *(const v4f*)(tails + (p0 + u) * SP_HIST + tq);
+                } else if (hmode == 2) {
+#pragma unroll
+                    for (int u = 0; u < SP_U; ++u)
+                        if (p0 + u < ld.ports) tm[u] = gload4(fv.hist + (size_t)(ld.first_voice + p0 + u) * SP_HIST + tq);
+                } else {
+                    // re-rendered from the source (the wave's FIRST piece only, once it keeps tails): the frames in front of the piece in
+                    // the same block, or the last 64 of the block before with that block's gains
 #pragma unroll
                     for (int u = 0; u < SP_U; ++u)
                         if (p0 + u < ld.ports) {
-                            const uint64_t qp = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(plp >> 32), p0 + u) << 32) |
-                                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)plp, p0 + u);
-                            t[u] = sp_raw<CLS>((const float*)qp, (uint32_t)__builtin_amdgcn_readlane((int)rdp, p0 + u), frames - SP_HIST + tq);
-                        }
-                } else {
+                            const int p = p0 + u;
+                            RawQuad t;
+                            if (hmode == 0) {
+                                t = sp_raw<CLS>(readlane_ptr(my_l, p), (uint32_t)__builtin_amdgcn_readlane((int)my_rd, p), fb - SP_HIST + tq);
+                            } else {
+                                const uint64_t qp = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(plp >> 32), p) << 32) |
+                                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)plp, p);
+                                t = sp_raw<CLS>((const float*)qp, (uint32_t)__builtin_amdgcn_readlane((int)rdp, p), frames - SP_HIST + tq);
+                            }
+                            v4f ta, tb;
+                            sp_cvt<CLS>(t, ta, tb);
+                            if (hmode == 0) {
 #pragma unroll
-                    for (int u = 0; u < SP_U; ++u)
-                        if (p0 + u < ld.ports) t[u].a = (v4i)gload4(fv.hist + (size_t)(ld.first_voice + p0 + u) * SP_HIST + tq);
+                                for (int j = 0; j < FW_MAX_STAGES; ++j)
+                                    if (j <= jn)
+                                        apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)), ta, tb);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < FW_MAX_STAGES; ++j)
+                                    if (j <= jn) apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(gp.g[j][0], p)), splat(readlane_f(gp.g[j][1], p)), ta, tb);
+                            }
+                            tm[u] = (ta + tb) * 0.5f;
+                        }
                 }
             }
 #pragma unroll
@@ -790,26 +816,9 @@ __device__ __forceinline__ void leaf_sp_fast(const FusedView& fv, const LeafDesc
                         if (j <= jn) apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)), a, b);
                     v4f m = (a + b) * 0.5f;
                     if (!act) m = splat(0.f);
-                    v4f tm;
-                    if (hmode == 2) {
-                        tm = (v4f)t[u].a;
-                    } else {
-                        v4f ta, tb;
-                        sp_cvt<CLS>(t[u], ta, tb);
-                        if (hmode == 0) {
-#pragma unroll
-                            for (int j = 0; j < FW_MAX_STAGES; ++j)
-                                if (j <= jn)
-                                    apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(my_g.g[j][0], p)), splat(readlane_f(my_g.g[j][1], p)), ta, tb);
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < FW_MAX_STAGES; ++j)
-                                if (j <= jn) apply_stage(((prog << 4) >> (4 * j)) & 15u, splat(readlane_f(gp.g[j][0], p)), splat(readlane_f(gp.g[j][1], p)), ta, tb);
-                        }
-                        tm = (ta + tb) * 0.5f;
-                    }
-                    if (lane < 16) *(v4f*)(row + tq) = tm;
+                    if (lane < 16) *(v4f*)(row + tq) = tm[u];
                     *(v4f*)(row + SP_HIST + lane * 4) = m;
+                    if (tails != nullptr && lane >= 48) *(v4f*)(tails + p * SP_HIST + (lane - 48) * 4) = m;  // (read above, by lanes < 16, before this)
                     // the last piece of the call's last block leaves the next call's history behind
                     if ((int)k == K - 1 && fb + 256 >= frames && act && f0 >= frames - SP_HIST)
                         *(v4f*)(fv.ext + (size_t)fv.voices[ld.first_voice + p].sp_ext_off + (f0 - (frames - SP_HIST))) = m;
@@ -854,6 +863,7 @@ __device__ __forceinline__ void leaf_sp_fast(const FusedView& fv, const LeafDesc
         if (act) {
             bus_store_pair(outl + f0, outr + f0, accl, accr);
         }
+        tails_valid = tails != nullptr && wpk == 1 && fb + 256 <= frames;  // a whole piece, and the next one this wave takes follows it in time
     }
 }
 
@@ -863,7 +873,8 @@ __device__ __forceinline__ void leaf_sp_fast(const FusedView& fv, const LeafDesc
 // LazyRec (one 128-byte load: descriptor AND gains) and the block index.
 template <bool PROG, bool RS = false, int U = LEAF_U, bool SP = false, bool LAZY = false>
 __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int leaf, const uint32_t k, const int part, const int wpk,
-                                              const RsLds rs = RsLds{nullptr, nullptr}, const int K = 1, float* sp_lds = nullptr) {
+                                              const RsLds rs = RsLds{nullptr, nullptr}, const int K = 1, float* sp_lds = nullptr, float* sp_tails = nullptr,
+                                              bool* sp_tails_valid = nullptr) {
     const int lane = threadIdx.x & (WAVE - 1);
     const LeafDesc ld = fv.leaves[leaf];
     const int frames = fv.frames;
@@ -952,7 +963,10 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
             refp.r_delta = 0;
             refp.flags_gset = VB_SRC_ZERO;
             GainSet gp = my_g;
-            if (k > 0 && lane < ld.ports && my_sp) {
+            // (the wave rendered the block before this one itself, on the batched path, and kept its tails: no record of that block needed)
+            bool tv = sp_tails_valid != nullptr && *sp_tails_valid;
+            if (sp_tails_valid != nullptr) *sp_tails_valid = false;
+            if (k > 0 && lane < ld.ports && my_sp && !tv) {
                 refp = fv.refs[ref_index(ld.first_voice + lane, (int)k - 1, fv.ref_kgroups)];
                 if (refp.flags_gset & VB_SIMPLE) gp = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + ((refp.flags_gset >> 8) & 0xffu)];
             }
@@ -968,13 +982,13 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                 const uint32_t cls0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_cls);
                 const uint32_t prog0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_prog);
                 const bool ok_now = (fg & (VB_SIMPLE | VB_SRC_ZERO | VB_SILENT)) == VB_SIMPLE && my_cls == cls0 && my_prog == prog0 && my_sp;
-                const bool ok_prev = k == 0 || ((fgp & (VB_SIMPLE | VB_SRC_ZERO)) == VB_SIMPLE && ((fgp >> 16) & 7u) == cls0);
+                const bool ok_prev = k == 0 || tv || ((fgp & (VB_SIMPLE | VB_SRC_ZERO)) == VB_SIMPLE && ((fgp >> 16) & 7u) == cls0);
                 if ((__ballot(ok_now && ok_prev) & lin) == lin) {
                     int jn0 = 0;
 #pragma unroll
                     for (int j = 0; j < FW_MAX_STAGES - 1; ++j)
                         if (((prog0 >> (4 * j)) & 15u) == SK_SPATIAL) jn0 = j;
-#define SP_FAST(C) leaf_sp_fast<C>(fv, ld, k, K, part, wpk, prog0, jn0, my_l, my_rd, my_g, fg, plp, rdp, gp, sp_lds, outl, outr)
+#define SP_FAST(C) leaf_sp_fast<C>(fv, ld, k, K, part, wpk, prog0, jn0, my_l, my_rd, my_g, fg, plp, rdp, gp, sp_lds, outl, outr, sp_tails, tv)
                     switch (cls0) {
                         case SF_P_F32: SP_FAST(SF_P_F32); break;
                         case SF_P_I16: SP_FAST(SF_P_I16); break;
@@ -984,6 +998,7 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
                         default: SP_FAST(SF_I_F32); break;
                     }
 #undef SP_FAST
+                    if (sp_tails_valid != nullptr) *sp_tails_valid = tv;
                     if (lane < 2 && part == 0) bflags[ld.out_buf + lane] = 0;
                     return;
                 }
@@ -1273,12 +1288,30 @@ __device__ __forceinline__ RsLds rs_lds_setup(const FusedView& fv, float* dyn) {
 //   <true,  true>   ... and voices whose source is a resampler (LDS-staged polyphase fetch)
 //   <true,  false, true>  ... and voices that end in a spatialiser (a 320-float mono row per wave in LDS)
 template <bool PROG, bool RS, bool SP, bool LAZY = false>
-__device__ __forceinline__ void leaf_kernel_body(const FusedView& fv, const int K, const int wpk) {
+__device__ __forceinline__ void leaf_kernel_body(const FusedView& fv, const int K, const int wpk, const int sp_nb = 1) {
     extern __shared__ float s_leaf_dyn[];
     RsLds rs{nullptr, nullptr};
     if constexpr (RS) rs = rs_lds_setup(fv, s_leaf_dyn);
     __shared__ float s_sp[SP ? LEAF_WPB * SP_U * SP_ROW : 1];
     float* sp_lds = SP ? s_sp + (threadIdx.x >> 6) * (SP_U * SP_ROW) : nullptr;
+    if constexpr (SP && !RS) {
+        // Spatialiser plan, blocks of one piece per wave: a wave takes sp_nb CONSECUTIVE blocks of its leaf and keeps every port's last 64
+        // mono frames in LDS from one to the next — the history of all but its first block costs no HBM read and no stage arithmetic
+        // (round 3 re-fetched and re-rendered it per block: traffic 1.15x the algorithmic bytes).
+        __shared__ float s_tails[LEAF_WPB * 32 * SP_HIST];
+        if (wpk == 1) {
+            const int leaf = blockIdx.x;
+            const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.y * LEAF_WPB + wave) * sp_nb));
+            bool tv = false;
+            for (uint32_t kk = 0; kk < (uint32_t)sp_nb && k0 + kk < (uint32_t)K; ++kk) {
+                int leaf_k = leaf;  // (opaque per iteration: what a block reads per lane — gain sets, programs — is loaded per block, not
+                asm volatile("" : "+s"(leaf_k));  // hoisted out of the loop into a dozen registers that live across all of it)
+                leaf_sum_wave<PROG, RS, LEAF_U, SP, LAZY>(fv, leaf_k, k0 + kk, 0, 1, rs, K, sp_lds, s_tails + wave * (32 * SP_HIST), &tv);
+            }
+            return;
+        }
+    }
 #if LEAF_MAP_BLOCKS
     // the waves of a workgroup take CONSECUTIVE 256-frame pieces of one leaf's stream — wpk (1, 2 or 4) waves per
     // block, LEAF_WPB / wpk consecutive blocks: a steady voice's source is contiguous across blocks, so the workgroup
@@ -1305,8 +1338,8 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum(FusedView fv, int K
 #ifndef SP_OCC
 #define SP_OCC 3
 #endif
-__global__ __launch_bounds__(WAVE* LEAF_WPB, SP_OCC) void k_leaf_sum_sp(FusedView fv, int K, int wpk) {
-    leaf_kernel_body<true, false, true>(fv, K, wpk);
+__global__ __launch_bounds__(WAVE* LEAF_WPB, SP_OCC) void k_leaf_sum_sp(FusedView fv, int K, int wpk, int sp_nb) {
+    leaf_kernel_body<true, false, true>(fv, K, wpk, sp_nb);
 }
 // the same kernel for a call no control kernel ran for (plans without resampler sources / spatialiser stages)
 template <bool PROG>

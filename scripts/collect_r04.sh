@@ -4,7 +4,7 @@
 #    tries): r04_<cfg>_kernel_stats_{fast,slow}.csv, the state and the kernel-only roofline fraction in the header line — so that a
 #    profile can be set beside the entry of the bench line that ran in the same state;
 #  * cfg3, cfg4, cfg2 + resampler sources / spatialiser stages / variant B / i16 sources: kernel stats + PMC HBM traffic;
-#  * SQ counters for the two LDS-heavy kernels; the full bench line; N = 2 on one device; the edit race in both build-stream modes.
+#  * SQ counters for the two LDS-heavy kernels; the full bench line; N = 2 on one device; config 2 on the level executor alone.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/profiles gpurun_out/raw
 P=$GRAFT_REPO_ROOT/gpurun_out/profiles
@@ -51,8 +51,13 @@ bash scripts/prof_sq.sh spatial --voice-spatial --contexts 1 > $P/r04_cfg2_spati
 cd $GRAFT_REPO_ROOT
 python bench.py > $P/r04_bench_line_full.json 2> gpurun_out/bench_full.err
 python bench.py --gpus 2 --share-device > $P/r04_n2_virtual_ranks_one_device_line.json 2> gpurun_out/bench_n2.err
-make -C examples/host_c > /dev/null 2>&1
-./examples/host_c/fw_edit_race 4096 512 300 30 > $P/r04_edit_race_cfg3.json 2> $P/r04_edit_race_cfg3_by_update_phase.txt
-./examples/host_c/fw_edit_race 4096 512 300 30 1000 > $P/r04_edit_race_cfg3_paced_1ms.json 2> /dev/null
-FWGPU_BUILD_STREAM=own ./examples/host_c/fw_edit_race 4096 512 300 30 > $P/r04_edit_race_cfg3_build_on_own_stream.json 2> /dev/null
+# config 2 on the level executor alone (--force-generic): kernel stats only
+out=$GRAFT_REPO_ROOT/gpurun_out/raw/r04_cfg2_levels_only
+(cd /tmp && TMPDIR=/tmp timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats -o s -- python $GRAFT_REPO_ROOT/bench.py --workload cfg2 --lean --contexts 1 --force-generic --steps 5 --warmup 2 > ${out}_stats.log 2>&1)
+f=$(find ${out}_stats -name "*kernel_stats.csv" | head -1)
+if [ -n "$f" ]; then
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --workload cfg2 --lean --contexts 1 --force-generic --steps 5 --warmup 2   (MI355X, r04; 1024 voices, block 256, 768 blocks per step: sampler / volume / pan / leaf sums / root levels)"; head -8 "$f" | cut -c1-220; } > $P/r04_cfg2_levels_only_kernel_stats.csv
+fi
+python bench.py --workload cfg2 --lean --contexts 1 --force-generic --steps 5 --warmup 2 > $P/r04_cfg2_levels_only_line.json 2> /dev/null
+# (the edit race: profiles/r04_edit_race_cfg3.json is a same-box A/B against the old host code — scripts/r04_edit_ab.sh — and is not collected here)
 ls -la $P | tail -40

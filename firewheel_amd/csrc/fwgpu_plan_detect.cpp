@@ -461,13 +461,20 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
     // ports' own validator walks back up; a chain it refuses is tried again one node shorter (a bare source always passes).
     static const bool solo_on = !(getenv("FWGPU_SOLO") && atoi(getenv("FWGPU_SOLO")) == 0);  // FWGPU_SOLO=0: banks only (A/B runs)
     if (solo_on) {
+        // a bank the mode's kernels refuse as a whole (a width / clip stage behind a delay, a resampler source beside filters, more than
+        // 32 ports on the chain kernels) gives its nodes back: its voices are tried one by one below, as far as the kernels render them
+        for (const Bank& bk : banks)
+            if (!keeps(bk, fx_mode))
+                for (int i : bk.nodes) taken[i] = 0;
         std::vector<int> cons_node(cons.cnt.size(), -1);  // who reads (node, port): meaningful where the count is 1
         for (int i = 0; i < N; ++i) {
             const PlanNode& n = plan.nodes[i];
             for (int p = 0; p < n.n_in; ++p)
                 if (n.in_src_node[p] >= 0) cons_node[cons.off[n.in_src_node[p]] + n.in_src_port[p]] = i;
         }
-        if (banks.empty() && mbf % 64 == 0)  // no bank chose the mode: solo voices with a filter / delay behind the source choose the chain plan's kernels
+        bool any_kept = false;
+        for (const Bank& bk : banks) any_kept = any_kept || keeps(bk, fx_mode);
+        if (!any_kept && mbf % 64 == 0)  // no bank chose the mode: solo voices with a filter / delay behind the source choose the chain plan's kernels
             for (int i = 0; i < N && !fx_mode; ++i) {
                 const PlanNode& src = plan.nodes[i];
                 if (src.kind != K_SAMPLER || src.n_in != 0 || src.n_out != 2 || cons[i][0] != 1 || cons[i][1] != 1) continue;

@@ -139,6 +139,17 @@ impl GpuContext {
     pub fn plan_pending(&self) -> bool {
         unsafe { ffi::fwgpu_plan_pending(self.as_ptr()) != 0 }
     }
+    /// (launch batches rendered without a control kernel, with one) — `fwgpu_lazy_stats`: a message-free call of a plain voice-bank
+    /// plan derives its block records from per-voice records the last control kernel left behind.
+    pub fn lazy_stats(&self) -> (u64, u64) {
+        let (mut a, mut b) = (0u64, 0u64);
+        unsafe { ffi::fwgpu_lazy_stats(self.as_ptr(), &mut a, &mut b) };
+        (a, b)
+    }
+    /// The `hipStream_t` every process call launches on (`fwgpu_hip_stream`), for hosts that order their own device work against it.
+    pub fn hip_stream(&self) -> *mut std::os::raw::c_void {
+        unsafe { ffi::fwgpu_hip_stream(self.as_ptr()) }
+    }
     /// Blocks one launch sequence may cover (a realtime host never needs more than one; an offline bounce wants many).
     pub fn set_max_batch(&self, blocks: u32) -> Result<(), GpuError> {
         let _g = self.control();

@@ -1350,7 +1350,10 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum_lazy(FusedView fv, 
 // Accumulators, stages and the final store stay in the convolution's round-robin frame layout (lane l: frames l, l + nact, ...):
 // the stages of a pure voice are per-frame constants, so nothing needs the four-consecutive-frames layout of the other kernels.
 #define RS2_LDS_BYTES(waves) ((RS_PHASES * RS_TAPS + (waves) * (2 * RS2_WIN)) * sizeof(float))
-__global__ __launch_bounds__(WAVE* LEAF_WPB, 4) void k_leaf_rs(FusedView fv, int K, int wpk) {
+#ifndef RS_OCC
+#define RS_OCC 4
+#endif
+__global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv, int K, int wpk) {
     extern __shared__ float s_leaf_dyn[];
     for (int i = threadIdx.x; i < RS_PHASES * RS_TAPS; i += blockDim.x) {  // [tap pair][phase][2]
         const int t = i % RS_TAPS, ph = i / RS_TAPS;

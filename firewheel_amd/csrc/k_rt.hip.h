@@ -19,6 +19,109 @@
 #else
 #define RT_T(i)
 #endif
+// The leaf sum of a one-block callback, every lane ONE frame: leaf_sum_wave gives a wave 256 frames — four per lane, 16 ports' loads in
+// flight, so a 32-port leaf is two cold HBM round trips on one wave while the workgroup's other three waves idle.  Here the four waves
+// take 64 frames each and a lane requests its frame of ALL ports (64 loads) before it waits: one round trip.  For leaves whose every
+// port is silent or a plain planar-f32 voice with gain stages only — the steady case; anything else returns false and takes
+// leaf_sum_wave.  Same operations per sample in the same order (leaf_fast / the port-by-port loop of leaf_sum_wave: sum.rs:41-136).
+typedef const float __attribute__((address_space(1)))* rt_gfp;
+// (branch-free on purpose: 32 small uniform branches around 64 live values made the register allocator shuffle everything through
+//  AGPRs and scratch — 2.4 KB per lane.  Absent and silent ports read the constant-zero bus and are kept out of the sum by selects)
+template <int NG>
+__device__ __forceinline__ void rt_leaf_quick_body(const float* my_l, const float* my_r, const GainSet& my_g, const int f, const uint64_t skip_mask, float& accl,
+                                                   float& accr) {
+    float xl[32], xr[32];
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        xl[p] = ((rt_gfp)readlane_ptr(my_l, p))[f];
+        xr[p] = ((rt_gfp)readlane_ptr(my_r, p))[f];
+    }
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        float a = xl[p], b = xr[p];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {  // sampler.rs:530-533, volume.rs:123-126, pan: one rounding each
+            a = a * readlane_f(my_g.g[j][0], p);
+            b = b * readlane_f(my_g.g[j][1], p);
+        }
+        if (p == 0) {  // sum.rs:117 copy_from_slice(port 0) — also when silent
+            accl = a;
+            accr = b;
+        } else {  // :122-124: silent ports are skipped on the n-port path only; ports the leaf does not have, always
+            const bool skip = (skip_mask >> p) & 1ull;
+            const float sl = accl + a, sr = accr + b;
+            accl = skip ? accl : sl;
+            accr = skip ? accr : sr;
+        }
+    }
+}
+template <bool PROG>
+__device__ __forceinline__ bool rt_leaf_quick(const FusedView& fv, const int leaf, const int wave) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const LeafDesc ld = fv.leaves[leaf];
+    const int frames = fv.frames;
+    if (frames > 256 || ld.ports < 1 || ld.ports > 32) return false;
+    VoiceRef ref;
+    ref.src_l = nullptr;
+    ref.r_delta = 0;
+    ref.flags_gset = VB_SILENT;
+    GainSet my_g;
+#pragma unroll
+    for (int j = 0; j < FW_MAX_STAGES; ++j) my_g.g[j][0] = my_g.g[j][1] = 1.0f;
+    GainSet g0 = my_g;
+    uint32_t my_prog = 0u;
+    if (lane < ld.ports) {
+        g0 = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS];  // (slot 0, requested beside the record; replaced below if the record names another)
+        ref = fv.refs[ref_index(ld.first_voice + lane, 0, fv.ref_kgroups)];
+        if constexpr (PROG) my_prog = fv.progs[ld.first_voice + lane];
+    }
+    const uint32_t fl = ref.flags_gset & 0xffu;
+    const bool sil = (fl & VB_SILENT) != 0;
+    const bool plain = !sil && (fl & VB_SIMPLE) != 0 && ((ref.flags_gset >> 16) & 7u) == SF_P_F32 && my_prog == 0u;
+    if (__ballot(lane < ld.ports && !sil && !plain)) return false;
+    if (plain) {  // (a silent port keeps gains of 1: its zeros stay +0)
+        my_g = g0;
+        const uint32_t gi = (ref.flags_gset >> 8) & 0xffu;
+        if (gi != 0u) my_g = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + gi];
+    }
+    const uint64_t lanes_in = mask_all_silent_bits(ld.ports);
+    const uint64_t silent_ports = __ballot(sil) & lanes_in;
+    const bool all_silent = silent_ports == lanes_in;
+    const int path_ports = ld.pad ? ld.pad : ld.ports;
+    const bool masked = !(path_ports == 2 || path_ports == 3 || path_ports == 4);  // sum.rs:67-133 (Q13)
+    const uint64_t skip_mask = ~lanes_in | (masked ? silent_ports : 0ull);
+    // silent and absent ports read bus 0 of block 0: the constant-zero bus
+    const float* my_l = plain ? ref.src_l : fv.bus;
+    const float* my_r = plain ? ref.src_l + ref.r_delta : fv.bus;
+    {  // (read with v_readlane where only the lanes that own frames are active: pinned under the full exec mask, as in leaf_sum_wave)
+        uint64_t pl = (uint64_t)my_l, pr = (uint64_t)my_r;
+        asm volatile("" : "+v"(pl), "+v"(pr));
+        my_l = (const float*)pl;
+        my_r = (const float*)pr;
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES; ++j) asm volatile("" : "+v"(my_g.g[j][0]), "+v"(my_g.g[j][1]));
+    }
+    float* outl = fv.bus + (size_t)ld.out_buf * fv.stride;  // block 0
+    float* outr = outl + fv.stride;
+    const int f = wave * WAVE + lane;
+    if (f < frames) {
+        float accl = 0.f, accr = 0.f;
+        switch (fv.n_gain_stages) {
+            case 1: rt_leaf_quick_body<1>(my_l, my_r, my_g, f, skip_mask, accl, accr); break;
+            case 2: rt_leaf_quick_body<2>(my_l, my_r, my_g, f, skip_mask, accl, accr); break;
+            case 3: rt_leaf_quick_body<3>(my_l, my_r, my_g, f, skip_mask, accl, accr); break;
+            case 4: rt_leaf_quick_body<4>(my_l, my_r, my_g, f, skip_mask, accl, accr); break;
+            case 5: rt_leaf_quick_body<5>(my_l, my_r, my_g, f, skip_mask, accl, accr); break;
+            default: rt_leaf_quick_body<6>(my_l, my_r, my_g, f, skip_mask, accl, accr); break;
+        }
+        if (all_silent) accl = accr = 0.f;  // clear_all_outputs (sum.rs:52-56)
+        outl[f] = accl;
+        outr[f] = accr;
+    }
+    if (lane < 2 && wave == 0) fv.bus_flags[ld.out_buf + lane] = all_silent ? 1 : 0;
+    return true;
+}
+
 template <bool PROG, bool RS>
 __device__ __forceinline__ void rt_block_body(const FusedView& fv, const DevView& upv, const RootArgs& ra, float* __restrict__ out, const uint32_t cmd_block0,
                                               unsigned* __restrict__ sync, unsigned long long* done_flag, const unsigned long long done_seq, const RsLds rs) {
@@ -58,7 +161,8 @@ __device__ __forceinline__ void rt_block_body(const FusedView& fv, const DevView
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     RT_T(3);
-    leaf_sum_wave<PROG, RS, 16>(fv, leaf, 0u, wave, 4, rs);  // 16 ports in flight: two round trips per leaf, not eight
+    if (!rt_leaf_quick<PROG>(fv, leaf, wave))
+        leaf_sum_wave<PROG, RS, 16>(fv, leaf, 0u, wave, 4, rs);  // 16 ports in flight: two round trips per leaf, not eight
     RT_T(4);
     // grid-wide hand-over to the root: every workgroup publishes its bus (agent scope: the XCDs have separate L2s), the
     // last one to arrive reads them all

@@ -1669,8 +1669,13 @@ __device__ __forceinline__ void root_out_body(const DevView& v, const RootArgs& 
     const uint8_t* flags = v.flags + (size_t)blk * v.flags_blk_stride;
     const int n_in = ra.n_in, ports = ra.ports;
     const int fc = f < v.frames ? f : 0;  // whole waves stay in: the ballot below needs lanes 0..n_in-1
-    // per-lane lookups go through the device copy of the table (indexing the argument struct by lane would spill it)
-    const uint8_t my_flag = lane < n_in ? flags[ra.in_tab[lane]] : (uint8_t)0;
+    // lane i needs the flag of input channel i.  Indexing the argument struct by lane would spill it, and going through the device
+    // copy of the table (ra.in_tab) put a second dependent cold miss in front of the flags — on the realtime edge, right behind an
+    // L2 invalidate, ~2 us of the callback.  A chain of selects on the scalar arguments instead: 2 NP v_cndmask, no memory.
+    int my_buf = 0;
+#pragma unroll
+    for (int i = 0; i < 2 * NP; ++i) my_buf = lane == i ? ra.in_buf[i] : my_buf;
+    const uint8_t my_flag = lane < n_in ? flags[my_buf] : (uint8_t)0;
     float xl[NP], xr[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {  // ports past the last one re-read port 0 (never added)

@@ -170,7 +170,9 @@ __device__ __forceinline__ void rt_block_body(const FusedView& fv, const DevView
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // (relaxed: the release is the fence above, the acquire the fence the last workgroup takes below — an acq_rel read-modify-write
+        //  here was a second L2 write-back and an invalidate in EVERY workgroup, on the callback's critical path)
+        const unsigned prev = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = prev == gridDim.x - 1 ? 1 : 0;
         if (s_last) __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next callback
     }

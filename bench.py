@@ -875,6 +875,15 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
                 # k_leaf_sum's two HBM placement states (profiles/PLACEMENT.md), fixed per context at allocation
                 "placement_state": (("fast" if frac >= 0.76 else "slow") if kernel == "k_leaf_sum" and sfmt == "f32" and playing == 1.0 else None),
             }
+    if roofline is None and timing and args.force_generic and wl in ("cfg2", "cfg5"):
+        # the level executor alone: no dominant kernel — the step against the same 8 B per voice-sample the fused plan is priced at
+        # (what the levels really move is 56 B per voice-sample of pool traffic: DESIGN.md section 3.1)
+        step_us = dt / steps * 1e6
+        ach = V * B * K * 8.0 / (step_us * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_level (sampler / volume / pan / sum levels)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "whole_step_frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_voice_sample": 8.0,
+                    "pool_traffic_bytes_per_voice_sample": 56.0, "avg_launch_us": gen_ms / max(gen_n, 1) * 1e3 if gen_n else None,
+                    "timing": "the timed region's wall clock (all level launches of a step)"}
     step_dist = None
     if timing and world == 1 and steps >= 5:
         # SURVEY 8d's per-step statistics: a distribution INSIDE the context (the line's `contexts` entry is one across contexts).
@@ -1017,10 +1026,11 @@ def other_configs(env, args):
     #  voice ending in a SPEC spatialiser — the other two north-star node families on the voice-bank plan; cfg2_variantB: 64 voices
     #  with a volume glide every ~20 blocks, the reference's automation case)
     # (cfg2_i16: SURVEY 8d's 4 B row — the headline graph on interleaved 16-bit PCM sources, core/sample_resource.rs:338-340)
+    # (cfg2_levels: --force-generic, no roofline object: five level kernels, none of them dominant)
     # cfg3 / cfg5: three fresh contexts each, the median reported and all three listed with their placement state — one context is
     # a coin toss between k_leaf_sum's two HBM placement states (the profile and the line disagreed by 12 % on cfg5)
     for name, steps, n_ctx in (("cfg3", 12, 3), ("cfg5", 12, 3), ("cfg4", 6, 1), ("cfg2_sends", 12, 1), ("cfg2_rs", 10, 1), ("cfg2_spatial", 10, 1),
-                               ("cfg2_variantB", 10, 1), ("cfg2_i16", 12, 1)):
+                               ("cfg2_variantB", 10, 1), ("cfg2_i16", 12, 1), ("cfg2_levels", 4, 1)):
         wl = name.split("_")[0]
         V, B, K, F, _ = DEFAULTS[wl]
         try:
@@ -1035,6 +1045,8 @@ def other_configs(env, args):
                     wargs.variant = "B"
                 if name == "cfg2_i16":
                     wargs.source_format = sfmt = "i16"
+                if name == "cfg2_levels":  # the headline graph on the level executor alone: what a graph no fused plan takes runs at
+                    wargs.force_generic = True
             runs = [run_workload(env, wargs, wl, V, B, K, F, steps, 3, full=False) for _ in range(n_ctx)]
             order = sorted(range(n_ctx), key=lambda i: runs[i]["ms_per_step"])
             r = runs[order[n_ctx // 2]]

@@ -195,6 +195,7 @@ int main(int argc, char** argv) {
     }
     /* phase 2: one voice after another is replaced while the callbacks go on */
     double upd_sum = 0, upd_max = 0;
+    double* upd_all = (double*)malloc(sizeof(double) * (size_t)(edits > 0 ? edits : 1));
     for (int e = 0; e < edits; ++e) {
         Voice* v = &g_voice[(e * 977 + 13) % g_voices];
         a.editing = 1;
@@ -207,6 +208,7 @@ int main(int argc, char** argv) {
         CK(fwgpu_update(g_cx));
         const double dt = now_us() - t0;
         upd_sum += dt;
+        upd_all[e] = dt;
         if (dt > upd_max) upd_max = dt;
         a.editing = 2; /* built and published: the next callback adopts the plan, the one after it starts the new voice */
         start_voice(v);
@@ -236,15 +238,22 @@ int main(int argc, char** argv) {
         stats(a.t_us, a.phase, a.n, ph, &md, &p9, &mx, &cn);
         if (cn) fprintf(stderr, "update phase %d: %ld callbacks, median %.1f p99 %.1f max %.1f us\n", ph, cn, md, p9, mx);
     }
+    /* (the first edit builds into the second plan image — its device allocations, tens of milliseconds on some boxes — and pulls the
+     * mean: the median is what an edit costs) */
+    double upd_median = 0;
+    if (edits > 0) {
+        qsort(upd_all, (size_t)edits, sizeof(double), cmp_d);
+        upd_median = upd_all[edits / 2];
+    }
     uint64_t adoptions = 0, by_audio = 0, worst_ns = 0;
     CK(fwgpu_plan_handover_stats(g_cx, &adoptions, &by_audio, &worst_ns));
     printf("{\"voices\": %d, \"block\": %u, \"launch_plan\": %d, \"callbacks\": %ld, \"edits\": %d, \"callback_period_us\": %.0f, \"first_update_ms\": %.2f, "
-           "\"update_ms_mean\": %.3f, \"update_ms_max\": %.3f, "
+           "\"update_ms_mean\": %.3f, \"update_ms_median\": %.3f, \"update_ms_max\": %.3f, "
            "\"callback_us_steady\": {\"n\": %ld, \"median\": %.1f, \"p99\": %.1f, \"max\": %.1f}, "
            "\"callback_us_while_the_plan_is_built\": {\"n\": %ld, \"median\": %.1f, \"p99\": %.1f, \"max\": %.1f}, "
            "\"callback_us_adoption_and_the_two_after\": {\"n\": %ld, \"median\": %.1f, \"p99\": %.1f, \"max\": %.1f}, "
            "\"plans_adopted\": %llu, \"adopted_by_a_callback\": %llu, \"longest_adoption_us\": %.1f}\n",
-           g_voices, g_block, plan, a.n, edits, g_period_us, first_update_us / 1e3, edits ? upd_sum / edits / 1e3 : 0.0, upd_max / 1e3, c0, m0, p0, x0, c1, m1, p1,
+           g_voices, g_block, plan, a.n, edits, g_period_us, first_update_us / 1e3, edits ? upd_sum / edits / 1e3 : 0.0, upd_median / 1e3, upd_max / 1e3, c0, m0, p0, x0, c1, m1, p1,
            x1, c2, m2, p2, x2, (unsigned long long)adoptions, (unsigned long long)by_audio, worst_ns / 1e3);
     fwgpu_ctx_destroy(g_cx);
     return 0;

@@ -224,10 +224,15 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
     }
     if (const char* e = getenv("FWGPU_RT_PERSIST")) c->rt_persist = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_IDLE_MS")) c->rt_idle_ms = (uint32_t)std::max(1, atoi(e));
+    const bool quiet_given = getenv("FWGPU_QUIET_WAIT_US") != nullptr;
     if (const char* e = getenv("FWGPU_QUIET_WAIT_US")) c->quiet_wait_us = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("FWGPU_UP_DIFF")) c->up_diff = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_BUILD_ONE_KERNEL")) c->build_one_kernel = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_BUILD_STREAM")) c->build_on_audio_stream = strcmp(e, "own") != 0;
+    // a group in the AUDIO stream queues behind whatever callback is in flight and costs the next one its own few microseconds wherever it
+    // lands: beside back-to-back callbacks the 100 us a group used to wait for a window that never comes were 0.2 ms of every edit
+    // (fw_edit_race, same box: typical edit 1.13 -> 0.96 ms, same p99).  On its own stream a group still waits the longer time.
+    if (!quiet_given && !c->build_on_audio_stream) c->quiet_wait_us = 100;
     if (const char* e = getenv("FWGPU_UP_PIECE")) c->up_piece = (uint32_t)std::max(4096, atoi(e));
     if (c->rt_persist && c->h_rt_flag) {  // mailbox in pinned, device-mapped host memory + the kernel's own (non-blocking) stream
         bool ok = hipHostMalloc((void**)&c->h_rt_mb, sizeof(RtMailbox), hipHostMallocMapped) == hipSuccess &&

@@ -435,7 +435,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     std::atomic<int> update_phase{0};  // fwgpu_update_phase: 0 none, 1 graph compile, 21..28 the sections of build_image, 3 waiting for the uploads
     std::atomic<uint64_t> last_audio_ns{0};  // steady_clock at the end of the last process call (0: none yet)
     std::atomic<uint64_t> cb_start_ns{0}, cb_period_ns{0}, cb_dur_ns{0};  // the last call's start, its distance to the one before, its length
-    uint32_t quiet_wait_us = 100;   // FWGPU_QUIET_WAIT_US
+    uint32_t quiet_wait_us = 30;    // FWGPU_QUIET_WAIT_US (100 when the build runs on its own stream)
     uint32_t up_piece = 256u << 10; // FWGPU_UP_PIECE (bytes): ~10 us of copy kernel per group (round 4: 128 -> 256 KiB, same p99 beside a saturated stream, half the groups)
     bool up_diff = true;            // FWGPU_UP_DIFF=0: every table uploaded whole, every build
     bool build_one_kernel = true;   // FWGPU_BUILD_ONE_KERNEL=0: the build's copies / fills as separate runtime calls

@@ -12,7 +12,7 @@ import fwapi
 def test_graph_edits_while_the_audio_thread_runs_cost_the_callbacks_microseconds_not_milliseconds():
     """VERDICT r2 missing #3: examples/host_c/fw_edit_race (plain C + pthreads through the C ABI) replaces voices of the config-3
     graph — 4 096 voices of sampler -> biquad -> delay -> gain — one after another while an audio thread runs one-block
-    callbacks.  Each fwgpu_update recompiles the whole launch plan and uploads what changed of it (1.0-1.4 ms since round 4, 2-6 before) ON
+    callbacks.  Each fwgpu_update recompiles the whole launch plan and uploads what changed of it (~1 ms since round 4, 2-6 before) ON
     THE CONTROL THREAD, off to the side; the callback that follows adopts it (graph/processor.rs:167-206).  The bar: an adoption holds its callback up for
     microseconds (measured 17-48), and the callbacks' median does not move.  Every timing bound below has room — the measured values
     are in profiles/r04_edit_race_cfg3.json and DESIGN.md section 1; a miss here would hide the parity tests that run after it."""
@@ -35,7 +35,8 @@ def test_graph_edits_while_the_audio_thread_runs_cost_the_callbacks_microseconds
         assert d["adopted_by_a_callback"] >= 20, d      # the audio thread was running: (nearly) every plan was picked up by a callback
         assert d["longest_adoption_us"] < 200.0, d      # (measured 17-48 us; a build is 2-5 ms)
         assert d["update_ms_mean"] > 0.3, d             # ... while each update really was a millisecond of work
-    assert mid(lambda d: d["update_ms_mean"]) <= 2.0, runs  # (measured 1.04-1.39 on the box that ran the old host code at 2.1-2.5)
+    assert mid(lambda d: d["update_ms_median"]) <= 1.6, runs  # (measured 0.94-1.00; the old host code on the box of the A/B: 2.1-2.5.  The mean
+                                                            #  carries the first edit's device allocations: 2-25 ms depending on the box)
     assert mid(lambda d: d["callback_us_while_the_plan_is_built"]["median"] - d["callback_us_steady"]["median"]) <= 10.0, runs
     # VERDICT r3's bar for a SATURATED audio thread (callbacks back to back, no gap for the build's groups to use): p99 <= steady + 30 us,
     # maximum <= steady maximum + 50 us.  Round 4 meets it with the build's job groups launched into the audio stream (measured +3..+12 /

@@ -737,11 +737,17 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
 
         host_out = np.empty(K * B * 2, dtype=np.float32)
 
+    # (variant B's message calls, bound once: through the wrapper objects a call cost ~3 us of Python and a hundred of them per step
+    #  made the HOST the limit of this entry — 0.34 ms per step whatever the GPU did; a native host pays ~50 ns per message)
+    set_param_raw = cx.L.fwgpu_node_set_param
+    ctx_ptr = cx.c
+
     def step():
         b = (slot[0] // R) % 2
         r = slot[0] % R
         for vol, pct, at in changes.get(step_no[0], ()):
-            g.set_param(vol, 0, pct, at)
+            if set_param_raw(ctx_ptr, vol, 0, pct, at) < 0:
+                raise RuntimeError("fwgpu_node_set_param failed")
         step_no[0] += 1
         slot[0] += 1
         if reducer is not None and r == 0:

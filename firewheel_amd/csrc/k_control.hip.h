@@ -1369,5 +1369,8 @@ __device__ __forceinline__ void voice_control_kernel(const FusedView& fv, const 
     const int vi = fv.ctl_order ? __builtin_amdgcn_readfirstlane(fv.ctl_order[w]) : w;
     voice_control_wave<true>(fv, vi, threadIdx.x & (WAVE - 1), K, cmd_block0);
 }
+#ifndef CTL_SMALL_OCC
+#define CTL_SMALL_OCC 3
+#endif
 __global__ __launch_bounds__(256) void k_voice_control(FusedView fv, int K, uint32_t cmd_block0) { voice_control_kernel<1>(fv, K, cmd_block0); }
-__global__ __launch_bounds__(256, 3) void k_voice_control_small(FusedView fv, int K, uint32_t cmd_block0) { voice_control_kernel<3>(fv, K, cmd_block0); }
+__global__ __launch_bounds__(256, CTL_SMALL_OCC) void k_voice_control_small(FusedView fv, int K, uint32_t cmd_block0) { voice_control_kernel<3>(fv, K, cmd_block0); }

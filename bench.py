@@ -737,17 +737,24 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
 
         host_out = np.empty(K * B * 2, dtype=np.float32)
 
-    # (variant B's message calls, bound once: through the wrapper objects a call cost ~3 us of Python and a hundred of them per step
-    #  made the HOST the limit of this entry — 0.34 ms per step whatever the GPU did; a native host pays ~50 ns per message)
-    set_param_raw = cx.L.fwgpu_node_set_param
+    # (variant B's messages go out as ONE foreign call per step — fwgpu_node_set_params; a hundred ctypes calls were ~0.15 ms of Python
+    #  per step, which a native host does not pay)
+    import ctypes as C
+
+    bulk = {}
+    for sno, lst in changes.items():
+        n = len(lst)
+        bulk[sno] = (n, (C.c_int64 * n)(*[x[0] for x in lst]), (C.c_int * n)(*([0] * n)), (C.c_float * n)(*[x[1] for x in lst]),
+                     (C.c_uint32 * n)(*[x[2] for x in lst]))
+    set_params_raw = cx.L.fwgpu_node_set_params
     ctx_ptr = cx.c
 
     def step():
         b = (slot[0] // R) % 2
         r = slot[0] % R
-        for vol, pct, at in changes.get(step_no[0], ()):
-            if set_param_raw(ctx_ptr, vol, 0, pct, at) < 0:
-                raise RuntimeError("fwgpu_node_set_param failed")
+        m = bulk.get(step_no[0])
+        if m is not None and set_params_raw(ctx_ptr, m[0], m[1], m[2], m[3], m[4]) < 0:
+            raise RuntimeError("fwgpu_node_set_params failed")
         step_no[0] += 1
         slot[0] += 1
         if reducer is not None and r == 0:
@@ -789,6 +796,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    dt_enqueue = time.perf_counter() - t0  # the host's share: message calls + launches of all the steps (the device runs behind them)
     finish_reductions()  # every bus of the timed region is fully reduced before the clock stops
     sync()
     if dist is not None:
@@ -972,6 +980,9 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
                 # launch batches of the timed region rendered without / with a control kernel (include/fwgpu.h fwgpu_lazy_stats): a
                 # message-free step of a plan whose every voice is steady and plain needs no per-block state machine pass
                 "batches_without_control_kernel": lazy1[0] - lazy0[0], "batches_with_control_kernel": lazy1[1] - lazy0[1],
+                # how long the host spent inside a step's calls (message calls + the process call: its launches AND, for a call with
+                # messages, its wait for the staging buffers of the call before — so a figure near ms_per_step means "paced by the device")
+                "host_enqueue_ms_per_step": dt_enqueue / steps * 1e3,
                 "device": name, "compute_units": cus,
             },
             "roofline": roofline,

@@ -97,6 +97,7 @@ SIGNATURES = {
     "fwgpu_stream_stats": (ci, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(f64)]),
     "fwgpu_stream_run": (ci, [vp, fp, u64, u32, f64, C.POINTER(f64)]),
     "fwgpu_node_set_param": (ci, [vp, i64, ci, f32, u32]),
+    "fwgpu_node_set_params": (ci, [vp, u32, C.POINTER(i64), C.POINTER(ci), C.POINTER(f32), C.POINTER(u32)]),
     "fwgpu_sampler_set_sample": (ci, [vp, i64, ci, ci, u32]),
     "fwgpu_sampler_play": (ci, [vp, i64, u32]),
     "fwgpu_sampler_pause": (ci, [vp, i64, u32]),

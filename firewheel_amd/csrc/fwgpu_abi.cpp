@@ -835,6 +835,15 @@ int fwgpu_node_set_param(fwgpu_ctx* c, int64_t node, int param, float value, uin
             return fail(c, FWGPU_ERR_INVALID, "node kind has no runtime params");
     }
 }
+int fwgpu_node_set_params(fwgpu_ctx* c, uint32_t n, const int64_t* nodes, const int* params, const float* values, const uint32_t* at_blocks) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    if (n && (!nodes || !params || !values || !at_blocks)) return fail(c, FWGPU_ERR_INVALID, "null message list");
+    for (uint32_t i = 0; i < n; ++i) {
+        const int rc = fwgpu_node_set_param(c, nodes[i], params[i], values[i], at_blocks[i]);
+        if (rc < 0) return rc;
+    }
+    return 0;
+}
 int fwgpu_sampler_set_sample(fwgpu_ctx* c, int64_t node, int sample, int stop_playback, uint32_t at_block) {
     NEED_CTX(c, FWGPU_ERR_INVALID);
     if (sample < 0 || sample >= (int)c->samples.size() || !c->samples[sample].alive)

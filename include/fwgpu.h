@@ -242,6 +242,10 @@ int fwgpu_sample_retired(fwgpu_ctx* ctx, int sample);
  * StereoWidth 0 = width; Biquad 1 = cutoff_hz, 2 = q; Delay 1 = feedback, 2 = mix; Resampler 1 = ratio,
  * 3 = playing, 4 = seek (source frame); Spatial 0/1/2 = x/y/z. */
 int fwgpu_node_set_param(fwgpu_ctx* ctx, int64_t node, int param, float value, uint32_t at_block);
+/* The same for `n` messages in one call, in order (hosts behind a foreign-function interface pay per call: bench.py's variant B
+ * issues a hundred per step).  Stops at the first message that fails and returns its (negative) error; the ones in front of it
+ * stay sent.  0 = all sent. */
+int fwgpu_node_set_params(fwgpu_ctx* ctx, uint32_t n, const int64_t* nodes, const int* params, const float* values, const uint32_t* at_blocks);
 int fwgpu_sampler_set_sample(fwgpu_ctx* ctx, int64_t node, int sample, int stop_playback,
                              uint32_t at_block);                                  /* sampler.rs:67-79 */
 int fwgpu_sampler_play(fwgpu_ctx* ctx, int64_t node, uint32_t at_block);  /* sampler.rs:82-97 */

@@ -123,6 +123,7 @@ extern "C" {
     pub fn fwgpu_poll_returned_samples(ctx: *mut fwgpu_ctx, nodes: *mut i64, samples: *mut c_int, cap: c_int) -> c_int;
     pub fn fwgpu_sample_retired(ctx: *mut fwgpu_ctx, sample: c_int) -> c_int;
     pub fn fwgpu_node_set_param(ctx: *mut fwgpu_ctx, node: i64, param: c_int, value: f32, at_block: u32) -> c_int;
+    pub fn fwgpu_node_set_params(ctx: *mut fwgpu_ctx, n: u32, nodes: *const i64, params: *const c_int, values: *const f32, at_blocks: *const u32) -> c_int;
     pub fn fwgpu_sampler_set_sample(ctx: *mut fwgpu_ctx, node: i64, sample: c_int, stop_playback: c_int, at_block: u32) -> c_int;
     pub fn fwgpu_sampler_play(ctx: *mut fwgpu_ctx, node: i64, at_block: u32) -> c_int;
     pub fn fwgpu_sampler_pause(ctx: *mut fwgpu_ctx, node: i64, at_block: u32) -> c_int;

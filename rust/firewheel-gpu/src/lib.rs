@@ -139,6 +139,14 @@ impl GpuContext {
     pub fn plan_pending(&self) -> bool {
         unsafe { ffi::fwgpu_plan_pending(self.as_ptr()) != 0 }
     }
+    /// `fwgpu_node_set_params`: a list of (node, param, value, at_block) messages in one foreign call, in order; stops at the first
+    /// one that fails.  (A Rust host pays nanoseconds per `fwgpu_node_set_param` call anyway: this is for symmetry with the C ABI.)
+    pub fn set_params(&self, nodes: &[i64], params: &[i32], values: &[f32], at_blocks: &[u32]) -> Result<(), GpuError> {
+        let n = nodes.len();
+        assert!(params.len() == n && values.len() == n && at_blocks.len() == n);
+        self.check(unsafe { ffi::fwgpu_node_set_params(self.as_ptr(), n as u32, nodes.as_ptr(), params.as_ptr(), values.as_ptr(), at_blocks.as_ptr()) } as i64)
+            .map(|_| ())
+    }
     /// (launch batches rendered without a control kernel, with one) — `fwgpu_lazy_stats`: a message-free call of a plain voice-bank
     /// plan derives its block records from per-voice records the last control kernel left behind.
     pub fn lazy_stats(&self) -> (u64, u64) {

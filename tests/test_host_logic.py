@@ -683,3 +683,33 @@ def test_lazy_records_host_bookkeeping():
     for _ in range(4):
         e2.process_blocks(8)
     assert e2.cx.lazy_stats()[0] == 0 and e2.violation() == ""
+
+
+def test_a_list_of_messages_in_one_call():
+    """fwgpu_node_set_params (include/fwgpu.h): n messages in order through one foreign call; it stops at the first message that fails,
+    returns that error, and the ones in front of it stay sent."""
+    import ctypes as C
+
+    e = HostOnlyEngine(max_block_frames=64, max_batch=8)
+    smp = bank(e)
+    L = e.cx.L
+    for s_ in smp:
+        e.sampler_play(s_)
+    e.process_blocks(2)
+    n = 5
+    nodes = (C.c_int64 * n)(*[smp[i] for i in range(n)])
+    params = (C.c_int * n)(*([0] * n))
+    values = (C.c_float * n)(*[10.0 * (i + 1) for i in range(n)])
+    at = (C.c_uint32 * n)(*[i for i in range(n)])
+    seen = hostonly_lib().fwh_cmds_seen
+    seen.restype = C.c_ulonglong
+    applied0 = seen()
+    assert L.fwgpu_node_set_params(e.cx.c, n, nodes, params, values, at) == 0
+    assert L.fwgpu_node_set_params(e.cx.c, 0, None, None, None, None) == 0
+    assert L.fwgpu_node_set_params(e.cx.c, 2, None, params, values, at) < 0          # a null list
+    bad = (C.c_int64 * 3)(smp[0], 1 << 40, smp[1])                                   # the second node does not exist
+    assert L.fwgpu_node_set_params(e.cx.c, 3, bad, params, values, at) < 0
+    assert b"unknown node" in L.fwgpu_last_error(e.cx.c)
+    e.process_blocks(8)                                                               # 5 + 1 messages reach the control kernel (the stub counts them)
+    assert e.violation() == "", e.violation()
+    assert seen() - applied0 == 6, seen() - applied0

@@ -932,8 +932,8 @@ __device__ __forceinline__ void delay_walk(const DevView& v, const NodeDesc& nd,
 
 // ---- frozen nodes of a wide level, several blocks at a time (round 4).  node_process_wave block by block is a chain of dependent
 // loads (descriptor -> port table -> flags -> 128 bytes of state) in front of 4 KB of audio: config 2 on the levels alone ran its
-// sampler / volume / pan levels at 1.9-2.4 TB/s.  For the three kinds such a level is made of — a stereo VolumeNode or a pan with
-// resting smoothers, a steadily playing stereo planar-f32 sampler — everything but the audio is the same in every block of the
+// sampler / volume / pan levels at 1.9-2.4 TB/s.  For the kinds such a level is made of — a stereo VolumeNode, pan or width with
+// resting smoothers, a stereo hard clip, a steadily playing stereo planar-f32 sampler — everything but the audio is the same in every block of the
 // batch: the wave reads it once and streams FZ_U blocks at a time, their loads in flight together.  Same operations per sample
 // as the cases of node_process_wave (volume.rs:94-142, sampler.rs:445-543); anything else returns false / goes block by block.
 #define FZ_U 4
@@ -950,13 +950,14 @@ __device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node
     const uint32_t u_l = (uint32_t)lane >> 1;  // flags: lane 2u + c holds (block b + u, channel c)
     const int c_l = lane & 1;
     if constexpr (SET == 0) {
-        if (fz != 1 || !(nd.kind == K_VOLUME || nd.kind == K_PAN) || nd.n_in != 2) return ~0u;
+        const int kind = nd.kind;
+        if (fz != 1 || !(kind == K_VOLUME || kind == K_PAN || kind == K_HARD_CLIP || kind == K_WIDTH) || nd.n_in != 2) return ~0u;
         const int* ibt = v.in_buf + nd.in_off;
         const int i0 = ibt[0], i1 = ibt[1];
         const NodeState& s = v.states[nd.state];
-        const float gl = s.s0.input;                               // a resting smoother's block is its input (smoother.rs:162-167)
-        const float gr = nd.kind == K_PAN ? s.s1.input : gl;
-        const bool mute = nd.kind == K_VOLUME && s.s0.status == SM_INACTIVE && gl < 0.00001f;  // volume.rs:104-108
+        const float gl = kind == K_HARD_CLIP ? s.p0 : s.s0.input;  // a resting smoother's block is its input (smoother.rs:162-167); clip: the threshold
+        const float gr = kind == K_PAN ? s.s1.input : gl;
+        const bool mute = kind == K_VOLUME && s.s0.status == SM_INACTIVE && gl < 0.00001f;  // volume.rs:104-108
         for (uint32_t b = b0; b < b1; b += FZ_U) {
             uint8_t f = 0;
             if (lane < 2 * FZ_U && b + u_l < b1) f = (v.flags + (size_t)(b + u_l) * v.flags_blk_stride)[c_l ? i1 : i0];
@@ -966,7 +967,7 @@ __device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node
 #pragma unroll
                 for (int u = 0; u < FZ_U; ++u) {
                     x[u][0] = x[u][1] = splat(0.f);
-                    if (b + u < b1 && ((fm >> (2 * u)) & 3u) != 3u && !mute) {  // (all inputs silent: cleared, :94-100)
+                    if (b + u < b1 && ((fm >> (2 * u)) & 3u) != 3u && !mute) {  // (all inputs silent: cleared — volume.rs:94-100 and its like)
                         const float* pl = v.pool + (size_t)(b + u) * v.pool_blk_stride;
                         x[u][0] = *(const v4f*)(pl + (size_t)i0 * v.stride + f0);
                         x[u][1] = *(const v4f*)(pl + (size_t)i1 * v.stride + f0);
@@ -976,14 +977,35 @@ __device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node
                 for (int u = 0; u < FZ_U; ++u)
                     if (b + u < b1) {
                         float* pl = v.pool + (size_t)(b + u) * v.pool_blk_stride;
-                        const bool clr = ((fm >> (2 * u)) & 3u) == 3u || mute;
-                        *(v4f*)(pl + (size_t)o0 * v.stride + f0) = clr ? splat(0.f) : x[u][0] * gl;  // :123-126 (stereo path: both channels, flagged or not)
-                        *(v4f*)(pl + (size_t)o1 * v.stride + f0) = clr ? splat(0.f) : x[u][1] * gr;
+                        const uint32_t m = (fm >> (2 * u)) & 3u;
+                        v4f yl = splat(0.f), yr = splat(0.f);
+                        if (m != 3u && !mute) {
+                            if (kind == K_HARD_CLIP) {  // hard_clip.rs:60-93: a silent channel of a half-silent pair is written as zeros
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    yl[j] = (m & 1u) ? 0.f : clipf(x[u][0][j], gl);
+                                    yr[j] = (m & 2u) ? 0.f : clipf(x[u][1][j], gl);
+                                }
+                            } else if (kind == K_WIDTH) {  // SPEC: m = (l + r) * 0.5; s = ((l - r) * 0.5) * w
+                                const v4f mid = (x[u][0] + x[u][1]) * 0.5f;
+                                const v4f sd = ((x[u][0] - x[u][1]) * 0.5f) * gl;
+                                yl = mid + sd;
+                                yr = mid - sd;
+                            } else {  // volume.rs:123-126 (stereo path: both channels, flagged or not), pan
+                                yl = x[u][0] * gl;
+                                yr = x[u][1] * gr;
+                            }
+                        }
+                        *(v4f*)(pl + (size_t)o0 * v.stride + f0) = yl;
+                        *(v4f*)(pl + (size_t)o1 * v.stride + f0) = yr;
                     }
             }
-            if (lane < 2 * FZ_U && b + u_l < b1) {  // out mask: all silent / muted -> both flagged, else the in mask (:110)
+            if (lane < 2 * FZ_U && b + u_l < b1) {
+                // out mask: all silent / muted -> both flagged; volume / pan / clip: the in mask (volume.rs:110, hard_clip.rs:93 — its fast
+                // path leaves 0, which IS the in mask there); width: 0
                 const uint32_t m = (fm >> (2 * u_l)) & 3u;
-                (v.flags + (size_t)(b + u_l) * v.flags_blk_stride)[c_l ? o1 : o0] = (m == 3u || mute) ? 1 : (uint8_t)((m >> c_l) & 1u);
+                (v.flags + (size_t)(b + u_l) * v.flags_blk_stride)[c_l ? o1 : o0] =
+                    (m == 3u || mute) ? 1 : (kind == K_WIDTH ? 0 : (uint8_t)((m >> c_l) & 1u));
             }
         }
         return 0u;

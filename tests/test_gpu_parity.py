@@ -830,6 +830,25 @@ def test_solo_voices_shapes_the_hybrid_plan_used_to_refuse(shape, max_batch):
     assert_bits_equal(ro, build(g2), shape + " (level executor alone)")
 
 
+@pytest.mark.parametrize("n_voices,max_batch", [(600, 32), (300, 32)])
+def test_level_executor_streams_frozen_nodes_several_blocks_at_a_time(n_voices, max_batch):
+    """round 4, k_level's frozen fast path (k_generic.hip.h frozen_fast): on a WIDE level — thousands of (node, block) pairs — a wave
+    takes 2 or 8 consecutive blocks of its node and, for a frozen stereo volume / pan / width / hard clip or a steadily playing
+    planar-f32 sampler, reads everything but the audio once and streams the blocks four at a time.  The small scenarios of this file
+    never reach that width: here 600 (8 blocks per wave) / 300 (2 per wave: partial groups) voices of sampler -> volume -> pan -> width
+    -> clip with width automation, mutes in front of the width (all-silent blocks: cleared + flagged), late starts, one-shot ends and
+    mono sources run on the levels alone, bit for bit the oracle."""
+    def run(e):
+        return scenarios.scenario_voice_fx_events(e, n_voices, radix=32, src_frames=700)
+
+    ro = run(oracle(max_block_frames=64))
+    g = GpuEngine(max_block_frames=64, max_batch=max_batch, force_generic=True)
+    rg = run(g)
+    assert g.cx.plan_kind() == 0
+    assert np.std(ro) > 0.01
+    assert_bits_equal(ro, rg, "voice fx bank on the levels alone")
+
+
 def test_plans_switch_between_fused_hybrid_and_levels_mid_stream():
     """a send is patched into a running voice bank and pulled out again, then a spatialised copy of the root bus is added (graph
     edits + recompile): voice-bank plan -> hybrid -> voice-bank plan -> hybrid; playheads, gliding smoothers and the

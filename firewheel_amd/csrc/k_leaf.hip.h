@@ -963,9 +963,18 @@ __device__ __forceinline__ void leaf_sum_wave(const FusedView& fv, const int lea
             refp.r_delta = 0;
             refp.flags_gset = VB_SRC_ZERO;
             GainSet gp = my_g;
-            // (the wave rendered the block before this one itself, on the batched path, and kept its tails: no record of that block needed)
+            // (the wave rendered the block before this one itself, on the batched path, and kept its tails: no record of that block needed
+            //  — IF this block takes the batched path too: a block with a wrap, a ramp or a silent port goes port by port below and
+            //  re-renders its history from the record of the block before, tails or not)
             bool tv = sp_tails_valid != nullptr && *sp_tails_valid;
             if (sp_tails_valid != nullptr) *sp_tails_valid = false;
+            if (tv) {
+                const uint32_t cls_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_cls);
+                const uint32_t prog_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_prog);
+                const bool now_a = (ref.flags_gset & (VB_SIMPLE | VB_SRC_ZERO | VB_SILENT)) == VB_SIMPLE && my_cls == cls_a && my_prog == prog_a && my_sp;
+                const uint64_t lin_a = mask_all_silent_bits(ld.ports);
+                tv = (__ballot(now_a) & lin_a) == lin_a;
+            }
             if (k > 0 && lane < ld.ports && my_sp && !tv) {
                 refp = fv.refs[ref_index(ld.first_voice + lane, (int)k - 1, fv.ref_kgroups)];
                 if (refp.flags_gset & VB_SIMPLE) gp = fv.gsets[(size_t)(ld.first_voice + lane) * FW_GSETS + ((refp.flags_gset >> 8) & 0xffu)];

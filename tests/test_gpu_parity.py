@@ -849,6 +849,64 @@ def test_level_executor_streams_frozen_nodes_several_blocks_at_a_time(n_voices, 
     assert_bits_equal(ro, rg, "voice fx bank on the levels alone")
 
 
+@pytest.mark.parametrize("n_leaves,K", [(32, 768), (16, 400)])
+def test_spatialiser_waves_keep_their_histories_in_lds_across_consecutive_blocks(n_leaves, K):
+    """round 4, k_leaf_sum_sp: on a launch with thousands of (leaf, block) pairs a wave takes up to 8 consecutive 256-frame blocks of its
+    leaf and keeps every port's last 64 mono frames in LDS — only the first block of its run re-fetches the history (leaf_sp_fast,
+    hmode 3).  The small scenarios never get there (one block per wave below 6 144 pairs): here config 2's shape — 32 x 32 voices of
+    sampler -> volume -> pan -> spatialiser, 768 blocks per call: 8 blocks per wave — and a half-size one (2 per wave), with a pause
+    and a position glide and a gain change INSIDE the long call (blocks that leave the batched path and come back: the kept tails
+    must be dropped and rebuilt), every block of every call against the oracle."""
+    rng = np.random.default_rng(5)
+
+    def run(e):
+        voices, ends = [], []
+        for v in range(n_leaves * 32):
+            s = e.sampler(float(rng.uniform(60, 100)))
+            vol = e.volume(float(rng.uniform(30, 100)))
+            pan = e.pan(float(rng.uniform(-1, 1)))
+            sp = e.spatial(float(rng.uniform(-5, 5)), float(rng.uniform(-1, 1)), float(rng.uniform(-5, 5)), n_in=2)
+            e.connect_stereo(s, vol)
+            e.connect_stereo(vol, pan)
+            e.connect_stereo(pan, sp)
+            voices.append(dict(s=s, vol=vol, sp=sp))
+            ends.append(sp)
+        leaves = []
+        for i in range(0, len(ends), 32):
+            m = e.sum(32)
+            for p, n in enumerate(ends[i:i + 32]):
+                e.connect_stereo(n, m, 2 * p)
+            leaves.append(m)
+        root = e.sum(len(leaves))
+        for p, m in enumerate(leaves):
+            e.connect_stereo(m, root, 2 * p)
+        e.connect_stereo(root, e.graph_out_node)
+        e.update()
+        smp = [e.new_sample(PLANAR_F32, 2, scenarios.voice_source(6100 + j, 30000 + 256 * j, 2)) for j in range(8)]
+        for v, vc in enumerate(voices):
+            e.sampler_set_sample(vc["s"], smp[v % 8])
+            e.sampler_set_loop_range(vc["s"], fwapi.LOOP_FULL)
+            e.sampler_play(vc["s"])
+        outs = [e.process_blocks(3)]
+        outs.append(e.process_blocks(K))                                   # steady: every wave on the batched path, tails kept
+        e.sampler_pause(voices[5]["s"], at_block=K // 4)                   # leaf 0 leaves the batched path for a while ...
+        e.sampler_play(voices[5]["s"], at_block=K // 4 + 37)               # ... and comes back
+        e.set_param(voices[40]["sp"], 0, 4.0, at_block=K // 8)             # leaf 1: a position glide (ear delays switch, gains ramp)
+        e.set_param(voices[n_leaves * 32 - 7]["vol"], 0, 15.0, at_block=K - K // 5)   # the last leaf: a gain glide late in the call
+        outs.append(e.process_blocks(K))
+        outs.append(e.process_blocks(5))
+        return np.concatenate(outs)
+
+    rng = np.random.default_rng(5)
+    ro = run(oracle(max_block_frames=256))
+    rng = np.random.default_rng(5)
+    g = GpuEngine(max_block_frames=256, max_batch=K)
+    rg = run(g)
+    assert g.cx.plan_kind() == 1
+    assert np.std(ro) > 0.01
+    assert_bits_equal(ro, rg, "spatialiser bank, %d blocks per call" % K)
+
+
 def test_plans_switch_between_fused_hybrid_and_levels_mid_stream():
     """a send is patched into a running voice bank and pulled out again, then a spatialised copy of the root bus is added (graph
     edits + recompile): voice-bank plan -> hybrid -> voice-bank plan -> hybrid; playheads, gliding smoothers and the

@@ -460,6 +460,8 @@ def parity_deep(fa, torch, wl, B, K, radix, seed, args, src, F, stream, device):
     # (cfg2 with resampler sources / spatialiser stages: 64 voices — two full leaves — x all 768 blocks of one call; VERDICT r3: the
     #  fresh-context check looked at blocks {0, 1} of 768 only)
     Vd = min(src.shape[0], 256 if wl == "cfg3" else (64 if wl == "cfg2" else 8))
+    if getattr(args, "voice_spatial", False) and wl == "cfg2":
+        Vd = src.shape[0]  # every leaf: only then does a spatialiser wave take several consecutive blocks and keep its histories in LDS
     assert F >= K * B
     cx, g, samplers, _ = make_gpu(fa, wl, Vd, B, K, radix, src, F, "f32", seed, args, stream, device)
     out = torch.empty(K * B * 2, dtype=torch.float32, device=src.device)

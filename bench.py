@@ -504,6 +504,7 @@ def parity_check_multi(env, args, wl, V, B, K, F, src, stream, device, mode):
     torch, fa, shard, dist = env["torch"], env["fa"], env["shard"], env["dist"]
     rank, world, dev, hostonly = env["rank"], env["world"], env["dev"], env["hostonly"]
     t0 = time.perf_counter()
+    progress(env, "%s: parity (whole graph, %d ranks, mode %s)" % (wl, world, mode))
     cx, g, samplers, _ = make_gpu(fa, wl, V, B, K, args.radix, src, F, "f32", rank, args, stream, device)
     n = K * B * 2
     part = [torch.zeros(n, dtype=torch.float32, device=dev)]
@@ -528,6 +529,7 @@ def parity_check_multi(env, args, wl, V, B, K, F, src, stream, device, mode):
     dist.all_gather_object(parts, pick(mine))  # the shards' own partial buses on the compared blocks: the tolerance's scale
     flags = [None] * world
     dist.all_gather_object(flags, sil[0].cpu().numpy().reshape(K, 2)[blocks])
+    progress(env, "%s: parity: device side done, the oracle's whole graph next (rank 0)" % wl)
     res = None
     if rank == 0:
         host_srcs = []
@@ -683,7 +685,17 @@ def rccl_group(env):
     return env["rccl"]
 
 
-def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_multi=False):
+_T0 = time.perf_counter()
+
+
+def progress(env, msg):
+    """FWGPU_BENCH_PROGRESS=1: where a run is, on stderr (a run of N ranks that stalls says where)"""
+    if os.environ.get("FWGPU_BENCH_PROGRESS"):
+        sys.stderr.write("[bench %7.1f s] rank %d/%d: %s\n" % (time.perf_counter() - _T0, env["rank"], env["world"], msg))
+        sys.stderr.flush()
+
+
+def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_multi=False, rt_probe=0):
     """times `steps` steps of one workload; returns the fields of its bench line (rank 0) — `full`: with the CPU baseline,
     the parity check and the realtime probe"""
     torch, fa, shard, dist = env["torch"], env["fa"], env["shard"], env["dist"]
@@ -704,7 +716,9 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
     else:
         # (--src-stagger: floats between consecutive voices' buffers — where the samples sit in HBM relative to one another)
         src = shard_sources(torch, shard, rank, V, F, dev, args.src_stagger)
+    progress(env, "%s: %d voices, block %d, K %d, %d + %d steps: sources made" % (wl, V, B, K, warmup, steps))
     cx, g, samplers, volumes = make_gpu(fa, wl, V, B, K, args.radix, src, F, sfmt, rank, args, stream, device)
+    progress(env, "%s: graph built, plan %d" % (wl, cx.plan_kind()))
     variant = args.variant if wl in ("cfg2", "cfg5") else "A"
     playing = 1.0
     changes = {}
@@ -773,6 +787,14 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
             cx.process_blocks_device(K, outs[b].data_ptr() + r * step_elems * 4, 2)
         if reducer is not None and r == R - 1:  # the mix bus: one exchange per R steps over R x K x 2 x block f32
             reducer.submit(b)
+            if env.get("share_device"):
+                # N processes time-sharing ONE device (no scaling figure comes out of this mode): every exchange is waited for before
+                # the next step is queued, as tests/test_bus_exchange.py does it — with 8 ranks' launch queues running ahead of one
+                # another on one device, config 5's every-step exchange did not come back within minutes (round 5)
+                try:
+                    reducer.wait_all()
+                except fa.FwgpuError as ex:
+                    xfail.append(repr(ex))
 
     def finish_reductions():
         """submit the partly filled buffer (steps % R != 0), then wait for every collective"""
@@ -791,6 +813,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
     finish_reductions()
     timing = not args.no_kernel_timing and not hostonly
     sync()
+    progress(env, "%s: warm" % wl)
     if dist is not None:
         dist.barrier()
     sync()
@@ -805,6 +828,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    progress(env, "%s: timed region done, %.3f ms per step" % (wl, dt / steps * 1e3))
     lazy1 = cx.lazy_stats() if hasattr(cx, "lazy_stats") else (0, 0)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if env.get("ctrl_cpu") else dev)
@@ -1000,6 +1024,18 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
         pc = parity_check_multi(env, args, wl, V, B, K, F, src, stream, device, reduce_mode)  # collective: every rank takes part
         if rank == 0:
             res["parity_check"] = pc
+    if rt_probe and not full and rank == 0 and world == 1 and not hostonly and not args.no_realtime:
+        # the reference's callback is one block per call for EVERY graph (firewheel-cpal/src/lib.rs:429-437): this
+        # config's graph through the headless stream, one block per callback, host buffers, back to back
+        try:
+            us = realtime_probe(cx, B, callbacks=rt_probe)[0]
+            res["realtime_us_per_callback"] = us
+            res["realtime_block_period_us"] = B / 48000.0 * 1e6
+            res["realtime_frac_of_block_period"] = us / (B / 48000.0 * 1e6)
+            if hasattr(cx, "rt_path_stats"):
+                res["realtime_path"] = dict(zip(("resident_kernel", "one_launch", "fused_launch_sequence", "level_executor"), cx.rt_path_stats()))
+        except Exception as ex:  # noqa: BLE001
+            res["realtime_us_per_callback"] = {"error": repr(ex)}
     if full and rank == 0 and world == 1 and not hostonly:
         if not args.no_realtime and wl != "cfg4":
             res["realtime_us_per_callback"], res["realtime_us_per_callback_from_python"] = realtime_probe(cx, B)
@@ -1066,13 +1102,18 @@ def other_configs(env, args):
                     wargs.source_format = sfmt = "i16"
                 if name == "cfg2_levels":  # the headline graph on the level executor alone: what a graph no fused plan takes runs at
                     wargs.force_generic = True
-            runs = [run_workload(env, wargs, wl, V, B, K, F, steps, 3, full=False) for _ in range(n_ctx)]
+            # (the BASELINE configs themselves also report their one-block-per-callback latency: the last context of each)
+            rt = 200 if name in ("cfg3", "cfg4", "cfg5") else 0
+            runs = [run_workload(env, wargs, wl, V, B, K, F, steps, 3, full=False, rt_probe=rt if i == n_ctx - 1 else 0) for i in range(n_ctx)]
             order = sorted(range(n_ctx), key=lambda i: runs[i]["ms_per_step"])
             r = runs[order[n_ctx // 2]]
             cfg = r["config"]
             ent = {"workload": cfg["workload"], "value": r["value"], "unit": "voice-samples/s", "ms_per_step": r["ms_per_step"],
                    "steps": steps, "blocks_per_step": K, "launch_plan": cfg["launch_plan"], "realtime_factor": cfg["realtime_factor"],
                    "roofline": r["roofline"]}
+            for key in ("realtime_us_per_callback", "realtime_block_period_us", "realtime_frac_of_block_period", "realtime_path"):
+                if key in runs[-1]:
+                    ent[key] = runs[-1][key]
             if n_ctx > 1:
                 ent["contexts"] = context_summary(runs, order[n_ctx // 2])
             if not args.no_parity_check:
@@ -1091,6 +1132,21 @@ def other_configs(env, args):
             out[name] = ent
         except Exception as ex:
             out[name] = {"error": repr(ex)}
+    # VERDICT r4 #4 / SURVEY H1: what a host that can only tolerate K blocks of batching gets — the headline graph with K blocks per
+    # device call (fwgpu_process_blocks_device, output left in HBM), a fresh context per K, ~3 000 blocks each; K x 5.33 ms is the
+    # latency the batching adds.  (K = 1 here is the multi-launch device call; the host-buffer callback edge is
+    # realtime_us_per_callback.)
+    try:
+        V, B, _, F, _ = DEFAULTS["cfg2"]
+        sweep = {}
+        for Kx in (1, 4, 16, 64, 256, 768):
+            n = max(4, min(1500, 3072 // Kx))
+            r = run_workload(env, args, "cfg2", V, B, Kx, F, n, 3, full=False)
+            sweep[str(Kx)] = {"value": r["value"], "ms_per_call": r["ms_per_step"], "calls": n, "batching_latency_ms": Kx * B / 48000.0 * 1e3,
+                              "whole_step_frac": (r["roofline"] or {}).get("whole_step_frac")}
+        out["k_sweep"] = {"workload": "cfg2 (the headline graph), K blocks per fwgpu_process_blocks_device call", "unit": "voice-samples/s", "by_K": sweep}
+    except Exception as ex:  # noqa: BLE001
+        out["k_sweep"] = {"error": repr(ex)}
     out["secs"] = round(time.perf_counter() - t0, 1)
     return out
 

@@ -81,6 +81,7 @@ SIGNATURES = {
     "fwgpu_hip_stream": (vp, [vp]),
     "fwgpu_update_phase": (ci, [vp]),
     "fwgpu_rt_resident_stats": (ci, [vp, C.POINTER(u64), C.POINTER(u64)]),
+    "fwgpu_rt_path_stats": (ci, [vp, C.POINTER(u64)]),
     "fwgpu_plan_chain_stats": (ci, [vp, C.POINTER(u64), C.POINTER(u64)]),
     "fwgpu_set_max_batch": (ci, [vp, u32]),
     "fwgpu_set_force_generic": (ci, [vp, ci]),

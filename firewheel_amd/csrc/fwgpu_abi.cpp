@@ -223,6 +223,8 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
         }
     }
     if (const char* e = getenv("FWGPU_RT_PERSIST")) c->rt_persist = atoi(e) != 0;
+    if (const char* e = getenv("FWGPU_LEVEL_FUSE")) c->level_fuse = atoi(e) != 0;
+    if (const char* e = getenv("FWGPU_GATE_DEFER_US")) c->gate_defer_ns = (uint64_t)std::max(0, atoi(e)) * 1000ull;
     if (const char* e = getenv("FWGPU_RT_IDLE_MS")) c->rt_idle_ms = (uint32_t)std::max(1, atoi(e));
     const bool quiet_given = getenv("FWGPU_QUIET_WAIT_US") != nullptr;
     if (const char* e = getenv("FWGPU_QUIET_WAIT_US")) c->quiet_wait_us = (uint32_t)std::max(0, atoi(e));
@@ -590,6 +592,12 @@ int fwgpu_rt_resident_stats(fwgpu_ctx* c, uint64_t* launches, uint64_t* doorbell
     NEED_CTX(c, FWGPU_ERR_INVALID);
     if (launches) *launches = c->rtp.launches;
     if (doorbells) *doorbells = c->rtp.doorbells;
+    return 0;
+}
+int fwgpu_rt_path_stats(fwgpu_ctx* c, uint64_t* paths) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    if (!paths) return fail(c, FWGPU_ERR_INVALID, "null paths");
+    for (int i = 0; i < 4; ++i) paths[i] = c->rt_path[i];
     return 0;
 }
 int fwgpu_plan_chain_stats(fwgpu_ctx* c, uint64_t* steady_workgroups, uint64_t* general_workgroups) {

@@ -63,13 +63,16 @@ struct DevBuf {
         const void* before = p;
         const size_t cap0 = cap;
         hipError_t e = ensure(bytes);
-        if (e == hipSuccess && (p != before || cap != cap0)) {
-            static const bool poison = getenv("FWGPU_POISON") && atoi(getenv("FWGPU_POISON")) != 0;
-            static const char* only = getenv("FWGPU_POISON_ONLY");
-            if (poison && (!only || !only[0] || !strcmp(only, name))) {
-                e = hipMemset(p, 0xCB, cap);
-                if (e == hipSuccess) e = hipDeviceSynchronize();  // (the fill is in place before any stream writes real data)
-            }
+        static const int poison = getenv("FWGPU_POISON") ? atoi(getenv("FWGPU_POISON")) : 0;
+        static const char* only = getenv("FWGPU_POISON_ONLY");
+        // FWGPU_POISON=2: the audio buffers a build no longer clears — the leaf / mix buses and the level executor's pool —
+        // are filled with NaNs at EVERY build, recycled images included: a kernel path that skips a write before a reader (an
+        // early-out leaf, an unmasked 2/3/4-port sum, a steady chain group) then mixes NaNs into the output instead of stale audio
+        // that may happen to be right.  (The image being built is not the active one: nothing reads it meanwhile.)
+        const bool audio_buf = !strcmp(name, "d_bus") || !strcmp(name, "d_pool");
+        if (e == hipSuccess && poison && ((p != before || cap != cap0) || (poison >= 2 && audio_buf)) && (!only || !only[0] || !strcmp(only, name))) {
+            e = hipMemset(p, (poison >= 2 && audio_buf) ? 0xFF : 0xCB, cap);
+            if (e == hipSuccess) e = hipDeviceSynchronize();  // (the fill is in place before any stream writes real data)
         }
         return e;
     }
@@ -195,6 +198,8 @@ struct PlanImage {
     DevBuf d_tail_nodes, d_tail_in, d_tail_out, d_tail_idx, d_tail_frozen;
     DevBuf d_frozen_ph;  // ... and its playhead snapshots
     DevBuf d_frozen;  // generic plan: k_frozen_scan's verdict per plan node, valid for the batch in flight
+    DevBuf d_chain_done;  // ... and, per node, chain_words words of "this block was rendered by the wave upstream" bits (vertical fusion)
+    int chain_words = 0;
     int up_root_node = -1;  // index (in the upper-tree node table) of the root SumNode when it is alone on the last level
     RootArgs root_args;     // that node's port table, handed to k_root_out in its kernel arguments
 
@@ -298,6 +303,10 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     // duration; the control thread BUILDS outside the gate and only tries it to adopt when the audio side is idle.
     std::atomic<int> gate{0};
     std::atomic<int> gate_ctl_waiting{0};  // control calls waiting at ControlGate: the audio side lets them in before its next call
+    bool level_fuse = true;                        // FWGPU_LEVEL_FUSE=0: the level executor without vertical fusion (A/B, bisecting)
+    uint64_t rt_path[4] = {0, 0, 0, 0};            // one-block launch batches by path (fwgpu_rt_path_stats); audio side writes
+    uint64_t gate_defer_ns = 20000;               // ... for at most this long per process call (FWGPU_GATE_DEFER_US; 0: never steps back)
+    std::atomic<uint64_t> gate_defer_expired{0};  // process calls that stopped waiting for a waiter that did not come
     std::atomic<fwgpu::PlanImage*> pending{nullptr};  // built and published, waiting for the next process call
     fwgpu::PlanImage* spare = nullptr;                // control side: a retired image, the next build target (its buffers are reused)
     static constexpr uint32_t RETIRE_CAP = 8;
@@ -583,9 +592,25 @@ struct AudioGate {
         // (a control call waiting at ControlGate goes first: a stream of back-to-back callbacks holds the gate ~100 % of the time, and a
         //  waiter that has to catch the instant between two of them starved for tens of milliseconds — 80 sample_create calls beside
         //  fwgpu_stream_run took 4.1 s, r04.  The audio side waits here for the waiter's few microseconds instead.)
+        //  The deference is BOUNDED: a waiter that raised the counter and was descheduled before it took the gate
+        //  must not cost the realtime thread a scheduler quantum.  The audio side steps back for at most gate_defer_ns per call —
+        //  a running waiter needs a fraction of a microsecond to win the CAS — then takes the free gate as it always did; the
+        //  waiter gets the same head start at the next callback.  (A control thread INSIDE its critical section still holds the
+        //  gate for its few microseconds: that is mutual exclusion, not deference.)
+        uint64_t defer_t0 = 0;
+        bool defer = c->gate_defer_ns != 0;
         for (;;) {
             int expected = 0;
-            if (c->gate_ctl_waiting.load(std::memory_order_acquire) == 0 && c->gate.compare_exchange_weak(expected, 1, std::memory_order_acquire)) break;
+            const bool waiter = defer && c->gate_ctl_waiting.load(std::memory_order_acquire) != 0;
+            if (!waiter && c->gate.compare_exchange_weak(expected, 1, std::memory_order_acquire)) break;
+            if (waiter) {
+                const uint64_t now = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+                if (!defer_t0) defer_t0 = now;
+                else if (now - defer_t0 > c->gate_defer_ns) {
+                    defer = false;
+                    c->gate_defer_expired.fetch_add(1, std::memory_order_relaxed);
+                }
+            }
 #if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
 #endif

@@ -31,6 +31,10 @@ struct DevView {
     // batch — k_level then runs its blocks in parallel (k_frozen_scan, launched once per batch before the levels)
     const uint8_t* frozen;
     const unsigned long long* frozen_playhead;  // per node: a frozen playing sampler's playhead at the start of the batch
+    // vertical fusion of frozen 1:1 chains (round 5, k_generic.hip.h fz_links): per node `chain_words` words of block bits — set by the
+    // wave that rendered a downstream node's block in registers, read by that node's own wave a level later.  nullptr: no fusion.
+    uint32_t* chain_done = nullptr;  // (initialised here: the upper-tree / master-chain / realtime views are filled field by field)
+    int chain_words = 0;
 };
 
 // The compact records are tiled: 32 voices x 8 blocks per 4 KiB tile, [voice % 32][block % 8].  A voice's 8 consecutive blocks

@@ -142,7 +142,9 @@ static int build_apply(fwgpu_ctx* c) {
             for (size_t q = i; q < k; ++q) (jobs[q].src ? c->prof_copy_bytes : c->prof_fill_bytes) += (uint64_t)jobs[q].row_bytes * jobs[q].rows;
         }
         if (live) quiet_window(c);
-        if (c->build_on_audio_stream) {
+        // (a caller-supplied stream, or one under FWGPU_RT_GRAPH capture, is not ours to launch into from the control thread: a
+        //  launch from another thread invalidates a thread-local capture — ADVICE r4: those contexts use the build's own stream)
+        if (c->build_on_audio_stream && c->own_stream && !c->rt_use_graph) {
             // Round 4 (measured, scripts/r04_session1.sh, config 3's 4 096 voices, callbacks back to back): the same groups in the
             // AUDIO stream — the jobs only touch the image nobody reads, HIP streams take launches from two threads — cost a
             // callback their own few microseconds: p99 80-82 us while a plan is built against 59 steady (+21-23), maximum 87-88
@@ -275,7 +277,7 @@ void PlanImage::release_device() {
     DevBuf* bufs[] = {&d_nodes, &d_in_buf, &d_out_buf, &d_level_nodes, &d_pool, &d_flags, &d_gin_bufs, &d_gout_bufs, &d_groups, &d_blks2, &d_refs2,
                       &d_gsets2, &d_ramps2, &d_progs, &d_hist, &d_rs_wl, &d_rs_tmpl, &d_lazy, &d_ctl_order, &d_slot_voice, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
                       &d_chain_start, &d_chain_dummy, &d_chain_stats, &d_up_nodes, &d_up_in, &d_up_out, &d_up_level_nodes, &d_root_bufs, &d_tail_nodes,
-                      &d_tail_in, &d_tail_out, &d_tail_idx, &d_tail_frozen, &d_frozen_ph, &d_frozen, &d_fir_rows, &d_fir_tiles, &d_fir_partials,
+                      &d_tail_in, &d_tail_out, &d_tail_idx, &d_tail_frozen, &d_frozen_ph, &d_frozen, &d_chain_done, &d_fir_rows, &d_fir_tiles, &d_fir_partials,
                       &d_hlevel_nodes, &grow_states, &grow_ext, &d_state_inits, &d_ext_jobs};
     for (DevBuf* b : bufs) b->release();
     if (h_ctl_order) (void)hipHostFree(h_ctl_order);
@@ -645,6 +647,33 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         else if (p.kind == K_HOST) host_nodes.push_back(i);  // no kernel runs it: the plan is cut at its level (step 3c)
         else levels[p.level].push_back(i);
     }
+    // vertical fusion of the level executor (k_generic.hip.h fz_links): a stereo sampler or gain-like node whose two output buffers
+    // are read by exactly ONE node — a 2 -> 2 volume / pan / width / hard clip, channel for channel — names it in aux0 (+ 1; aux0 is
+    // the port count of SumNodes only).  Whether a batch uses the link is decided on the device (both nodes frozen, block not silent).
+    {
+        std::vector<int> cnt((size_t)plan.num_buffers, 0), who((size_t)plan.num_buffers, -1), port((size_t)plan.num_buffers, -1);
+        for (int i = 0; i < N; ++i) {
+            const PlanNode& p = plan.nodes[i];
+            for (int q = 0; q < p.n_in; ++q) {
+                const int b = p.in_buf[q];
+                if (b <= 0 || b >= plan.num_buffers) continue;
+                cnt[b]++;
+                who[b] = i;
+                port[b] = q;
+            }
+        }
+        auto gainlike = [](int k) { return k == K_VOLUME || k == K_PAN || k == K_WIDTH || k == K_HARD_CLIP; };
+        for (int i = 0; i < N; ++i) {
+            const PlanNode& p = plan.nodes[i];
+            if (p.is_graph_io || p.n_out != 2) continue;
+            if (!((p.kind == K_SAMPLER && p.n_in == 0) || (gainlike(p.kind) && p.n_in == 2))) continue;
+            const int b0 = p.out_buf[0], b1 = p.out_buf[1];
+            if (b0 <= 0 || b1 <= 0 || cnt[b0] != 1 || cnt[b1] != 1 || who[b0] != who[b1] || port[b0] != 0 || port[b1] != 1) continue;
+            const PlanNode& q = plan.nodes[who[b0]];
+            if (q.is_graph_io || !gainlike(q.kind) || q.n_in != 2 || q.n_out != 2) continue;
+            nd[i].aux0 = who[b0] + 1;
+        }
+    }
     // hybrid plan: the continuation of a split SumNode — (partial bus, the ports behind the leading voices) on the path of the
     // node's full port count — as an extra entry behind the plan's nodes; the hybrid level lists name it instead of the node
     std::vector<int> split_entry(N, -1);
@@ -991,6 +1020,8 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
     // allocates
     HIPC(c, P.d_frozen.ensure_n("d_frozen", nd.size()));
     HIPC(c, P.d_frozen_ph.ensure_n("d_frozen_ph", nd.size() * sizeof(unsigned long long)));
+    P.chain_words = (int)((P.generic_k + 31) / 32);
+    HIPC(c, P.d_chain_done.ensure_n("d_chain_done", nd.size() * (size_t)P.chain_words * sizeof(uint32_t)));
     P.slot_index.assign(c->graph.nodes.size(), -1);
     for (int i = 0; i < N; ++i)
         if (plan.nodes[i].slot < P.slot_index.size()) P.slot_index[plan.nodes[i].slot] = i;

@@ -272,6 +272,8 @@ DevView generic_view(fwgpu_ctx* c, int frames) {
     v.n_cmds = c->n_cmds_dev;
     v.frozen = nullptr;
     v.frozen_playhead = nullptr;
+    v.chain_done = nullptr;
+    v.chain_words = 0;
     return v;
 }
 
@@ -376,11 +378,18 @@ static int run_host_level(fwgpu_ctx* c, const DevView& v, const std::vector<fwgp
 int run_generic_batch(fwgpu_ctx* c, int K, int frames, uint32_t cmd_block, const float* d_in, int n_in_ch, float* d_out,
                       int n_out_ch) {
     c->lazy_valid = false;  // (the level executor and the hybrid plan move node state their own way)
+    if (K == 1) c->rt_path[3]++;
     DevView v = generic_view(c, frames);
     // which gain-like stateful nodes cannot change during this batch (their blocks then run in parallel): decided once,
     // before the first level
     if (K > 1 && c->d_frozen.ensure_n("d_frozen", (size_t)c->plan.nodes.size()) == hipSuccess &&
         c->d_frozen_ph.ensure_n("d_frozen_ph", (size_t)c->plan.nodes.size() * sizeof(unsigned long long)) == hipSuccess) {
+        // vertical fusion: the scan clears this batch's "rendered upstream" bits (sized by the plan build for generic_k blocks)
+        if (c->level_fuse && c->d_chain_done.p && c->chain_words > 0 && K <= c->chain_words * 32 &&
+            c->d_chain_done.cap >= c->plan.nodes.size() * (size_t)c->chain_words * sizeof(uint32_t)) {
+            v.chain_done = c->d_chain_done.as<uint32_t>();
+            v.chain_words = c->chain_words;
+        }
         LCHK(c, launch_frozen_scan(c->stream, v, (int)c->plan.nodes.size(), cmd_block, K, c->d_frozen.as<uint8_t>(),
                                    c->d_frozen_ph.as<unsigned long long>()));
         v.frozen = c->d_frozen.as<uint8_t>();
@@ -563,12 +572,14 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
                 __atomic_store_n(&c->h_rt_mb->doorbell, seq, __ATOMIC_RELEASE);
                 r.next_seq = seq + 1;
                 r.doorbells++;
+                c->rt_path[0]++;
                 return 0;
             }
             int rc = rt_persist_stop(c);  // (the watchdog ended it, or it was launched for another plan / epoch / output block)
             if (rc) return rc;
             if (!__atomic_load_n(&c->h_rt_mb->hold, __ATOMIC_SEQ_CST)) {
                 rc = rt_persist_launch(c, fv, v, d_out, cmd_block0, seq);
+                if (rc == 0) c->rt_path[0]++;  // (the block the resident kernel was launched with)
                 if (rc <= 0) return rc;
             }
             // a control call holds the device: this callback is an ordinary launch (below)
@@ -577,6 +588,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
             int rc = rt_persist_stop(c);
             if (rc) return rc;
         }
+        c->rt_path[1]++;
         if (c->host_prof) {
             const auto t0 = std::chrono::steady_clock::now();
             LCHK(c, launch_rt_block(c->stream, fv, v, c->root_args, d_out, cmd_block0, c->d_rt_sync.as<unsigned>(), flag, c->rt_signal_seq));
@@ -587,6 +599,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         LCHK(c, launch_rt_block(c->stream, fv, v, c->root_args, d_out, cmd_block0, c->d_rt_sync.as<unsigned>(), flag, c->rt_signal_seq));
         return 0;
     }
+    if (K == 1) c->rt_path[2]++;
     hipEvent_t e0, e1;
     const bool lazy = c->lazy_this_call && fv.lazy != nullptr;
     fv.abs_blk_end = c->abs_blk + (uint64_t)K;

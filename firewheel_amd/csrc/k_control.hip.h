@@ -627,7 +627,10 @@ __global__ __launch_bounds__(256) void k_lazy_flush(const LazyRec* __restrict__ 
     if (v >= n_voices) return;
     const LazyRec r = lazy[v];
     if (r.sampler_state < 0 || r.mode <= 0) return;
-    if (r.mode == 1) states[r.sampler_state].playhead = r.loop_start + (uint64_t)((r.r0b + blocks) % r.q) * r.frames;
+    if (blocks == 0) return;
+    // (tail_end_playhead's value, not only an equivalent one: a last block that ends exactly on the loop end leaves playhead ==
+    //  loop_end — rendered like loop_start, sampler.rs:441-452, but node state must not depend on whether a call was lazy: ADVICE r4)
+    if (r.mode == 1) states[r.sampler_state].playhead = r.loop_start + ((uint64_t)((r.r0b + blocks - 1) % r.q) + 1) * r.frames;
     else states[r.sampler_state].playhead = r.off0 + blocks * r.frames;
 }
 // the horizon of the control kernel that has just run -> pinned host memory {horizon, seq}; the device word is re-armed

@@ -734,6 +734,8 @@ __global__ void k_frozen_scan(DevView v, int n_nodes, uint32_t cmd_block0, uint3
             }
         }
     }
+    if (v.chain_done)  // (this batch's "rendered upstream" bits: fz_links)
+        for (int w = 0; w < v.chain_words; ++w) v.chain_done[(size_t)i * v.chain_words + w] = 0u;
     frozen[i] = fz ? (adv ? 2 : (spat ? 3 : 1)) : 0;  // 2: a playing sampler — the last block's wave stores the state; 3: a spatialiser
     if (adv) playhead_snap[i] = v.states[nd.state].playhead;
 }
@@ -937,10 +939,89 @@ __device__ __forceinline__ void delay_walk(const DevView& v, const NodeDesc& nd,
 // batch: the wave reads it once and streams FZ_U blocks at a time, their loads in flight together.  Same operations per sample
 // as the cases of node_process_wave (volume.rs:94-142, sampler.rs:445-543); anything else returns false / goes block by block.
 #define FZ_U 4
+// ---- vertical fusion (round 5).  The level executor moved 56 bytes per voice-sample on config 2's graph: every node of a
+// sampler -> volume -> pan chain wrote its block to the pool and the next level read it back.  When the node a frozen wave renders feeds
+// exactly ONE consumer with both its channels, in order (NodeDesc::aux0 = that node + 1: the host's chain table, fwgpu_plan_install.cpp),
+// and the consumer is a frozen gain-like node too (volume / pan / width / hard clip, not muted), the wave applies the consumer's
+// operation to the block IN REGISTERS, and the consumer's consumer's, up to FZ_LINKS of them, and stores only the LAST node's output.
+// Only blocks whose head output is not flagged silent on either channel are fused: every link then sees in mask 0 and leaves out mask 0
+// (volume.rs:110, hard_clip.rs:93) — the flags of every skipped buffer are still written (frozen_finish reads them), the audio is not:
+// nobody else reads those buffers.  The links' own waves, a level later, find the blocks in `chain_done` and leave them alone.
+// Same operations per sample as each node's own case: one rounding per product, in chain order.
+#define FZ_LINKS 3
+struct FzLinks {
+    int n;
+    int kind[FZ_LINKS], node[FZ_LINKS], o0[FZ_LINKS], o1[FZ_LINKS];
+    float gl[FZ_LINKS], gr[FZ_LINKS];
+};
+__device__ __forceinline__ void fz_links(const DevView& v, const int next_plus_1, FzLinks& L) {
+    L.n = 0;
+#pragma unroll
+    for (int j = 0; j < FZ_LINKS; ++j) {
+        L.kind[j] = 0;
+        L.node[j] = L.o0[j] = L.o1[j] = 0;
+        L.gl[j] = L.gr[j] = 1.f;
+    }
+    if (!v.chain_done || !v.frozen) return;
+    int nx = next_plus_1 - 1;
+#pragma unroll
+    for (int j = 0; j < FZ_LINKS; ++j) {
+        if (nx < 0 || L.n != j) break;
+        if (v.frozen[nx] != 1) break;
+        const NodeDesc nn = v.nodes[nx];
+        const NodeState& s = v.states[nn.state];
+        const float gl = nn.kind == K_HARD_CLIP ? s.p0 : s.s0.input;
+        if (nn.kind == K_VOLUME && s.s0.status == SM_INACTIVE && gl < 0.00001f) break;  // a mute clears and flags: not a fused shape
+        L.kind[j] = nn.kind;
+        L.node[j] = nx;
+        L.gl[j] = gl;
+        L.gr[j] = nn.kind == K_PAN ? s.s1.input : gl;
+        L.o0[j] = (v.out_buf + nn.out_off)[0];
+        L.o1[j] = (v.out_buf + nn.out_off)[1];
+        L.n = j + 1;
+        nx = nn.aux0 - 1;
+    }
+}
+__device__ __forceinline__ void fz_apply(const FzLinks& L, v4f& yl, v4f& yr) {
+#pragma unroll
+    for (int j = 0; j < FZ_LINKS; ++j)
+        if (j < L.n) {
+            if (L.kind[j] == K_HARD_CLIP) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    yl[e] = clipf(yl[e], L.gl[j]);
+                    yr[e] = clipf(yr[e], L.gl[j]);
+                }
+            } else if (L.kind[j] == K_WIDTH) {
+                const v4f mid = (yl + yr) * 0.5f;
+                const v4f sd = ((yl - yr) * 0.5f) * L.gl[j];
+                yl = mid + sd;
+                yr = mid - sd;
+            } else {
+                yl = yl * L.gl[j];
+                yr = yr * L.gr[j];
+            }
+        }
+}
+// the flags of the buffers a fused block skipped (all clear), and the links' done bits for the blocks `chained` of [b0, ...)
+__device__ __forceinline__ void fz_flags(const DevView& v, const FzLinks& L, const uint32_t blk, const int c) {
+    uint8_t* fl = v.flags + (size_t)blk * v.flags_blk_stride;
+#pragma unroll
+    for (int j = 0; j < FZ_LINKS; ++j)
+        if (j < L.n) fl[c ? L.o1[j] : L.o0[j]] = 0;
+}
+__device__ __forceinline__ void fz_done(const DevView& v, const FzLinks& L, const uint32_t b0, const uint32_t chained) {
+    if (!chained || (threadIdx.x & (WAVE - 1)) != 0) return;
+#pragma unroll
+    for (int j = 0; j < FZ_LINKS; ++j)
+        if (j < L.n) atomicOr(&v.chain_done[(size_t)L.node[j] * v.chain_words + (b0 >> 5)], chained << (b0 & 31u));
+}
 // Returns the blocks of [b0, b1) it did NOT render, bit (b - b0) each — all of them when the node is not one of the three shapes
 // (at most 32 blocks per wave).
+// `skip`: blocks an upstream wave has rendered already (chain_done).
 template <int SET>
-__device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node, const uint8_t fz, const uint32_t b0, const uint32_t b1, const uint32_t K) {
+__device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node, const uint8_t fz, const uint32_t b0, const uint32_t b1, const uint32_t K,
+                                                const uint32_t skip) {
     const NodeDesc nd = v.nodes[node];
     const int lane = threadIdx.x & (WAVE - 1);
     const int frames = v.frames;
@@ -958,16 +1039,30 @@ __device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node
         const float gl = kind == K_HARD_CLIP ? s.p0 : s.s0.input;  // a resting smoother's block is its input (smoother.rs:162-167); clip: the threshold
         const float gr = kind == K_PAN ? s.s1.input : gl;
         const bool mute = kind == K_VOLUME && s.s0.status == SM_INACTIVE && gl < 0.00001f;  // volume.rs:104-108
+        FzLinks L;
+        fz_links(v, nd.aux0, L);
+        const int lo0 = L.n ? L.o0[L.n - 1] : o0, lo1 = L.n ? L.o1[L.n - 1] : o1;
+        uint32_t chained = 0u;
         for (uint32_t b = b0; b < b1; b += FZ_U) {
             uint8_t f = 0;
-            if (lane < 2 * FZ_U && b + u_l < b1) f = (v.flags + (size_t)(b + u_l) * v.flags_blk_stride)[c_l ? i1 : i0];
+            const bool live_l = b + u_l < b1 && !((skip >> (b + u_l - b0)) & 1u);
+            if (lane < 2 * FZ_U && live_l) f = (v.flags + (size_t)(b + u_l) * v.flags_blk_stride)[c_l ? i1 : i0];
             const uint32_t fm = (uint32_t)__ballot(f != 0);
+            // blocks of this round that are rendered on into the links: the node's own out mask is 0 there
+            uint32_t ch = 0u;
+#pragma unroll
+            for (int u = 0; u < FZ_U; ++u) {
+                const uint32_t m = (fm >> (2 * u)) & 3u;
+                if (L.n && b + u < b1 && !((skip >> (b + u - b0)) & 1u) && !mute && (kind == K_WIDTH ? m != 3u : m == 0u)) ch |= 1u << u;
+            }
+            chained |= ch << (b - b0);
             for (int f0 = lane * 4; f0 < frames; f0 += 256) {
                 v4f x[FZ_U][2];
 #pragma unroll
                 for (int u = 0; u < FZ_U; ++u) {
                     x[u][0] = x[u][1] = splat(0.f);
-                    if (b + u < b1 && ((fm >> (2 * u)) & 3u) != 3u && !mute) {  // (all inputs silent: cleared — volume.rs:94-100 and its like)
+                    const bool live = b + u < b1 && !((skip >> (b + u - b0)) & 1u);
+                    if (live && ((fm >> (2 * u)) & 3u) != 3u && !mute) {  // (all inputs silent: cleared — volume.rs:94-100 and its like)
                         const float* pl = v.pool + (size_t)(b + u) * v.pool_blk_stride;
                         x[u][0] = *(const v4f*)(pl + (size_t)i0 * v.stride + f0);
                         x[u][1] = *(const v4f*)(pl + (size_t)i1 * v.stride + f0);
@@ -975,7 +1070,7 @@ __device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node
                 }
 #pragma unroll
                 for (int u = 0; u < FZ_U; ++u)
-                    if (b + u < b1) {
+                    if (b + u < b1 && !((skip >> (b + u - b0)) & 1u)) {
                         float* pl = v.pool + (size_t)(b + u) * v.pool_blk_stride;
                         const uint32_t m = (fm >> (2 * u)) & 3u;
                         v4f yl = splat(0.f), yr = splat(0.f);
@@ -996,18 +1091,26 @@ __device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node
                                 yr = x[u][1] * gr;
                             }
                         }
-                        *(v4f*)(pl + (size_t)o0 * v.stride + f0) = yl;
-                        *(v4f*)(pl + (size_t)o1 * v.stride + f0) = yr;
+                        if ((ch >> u) & 1u) {  // on through the links, in registers: only the last one's buffers are written
+                            fz_apply(L, yl, yr);
+                            *(v4f*)(pl + (size_t)lo0 * v.stride + f0) = yl;
+                            *(v4f*)(pl + (size_t)lo1 * v.stride + f0) = yr;
+                        } else {
+                            *(v4f*)(pl + (size_t)o0 * v.stride + f0) = yl;
+                            *(v4f*)(pl + (size_t)o1 * v.stride + f0) = yr;
+                        }
                     }
             }
-            if (lane < 2 * FZ_U && b + u_l < b1) {
+            if (lane < 2 * FZ_U && live_l) {
                 // out mask: all silent / muted -> both flagged; volume / pan / clip: the in mask (volume.rs:110, hard_clip.rs:93 — its fast
                 // path leaves 0, which IS the in mask there); width: 0
                 const uint32_t m = (fm >> (2 * u_l)) & 3u;
                 (v.flags + (size_t)(b + u_l) * v.flags_blk_stride)[c_l ? o1 : o0] =
                     (m == 3u || mute) ? 1 : (kind == K_WIDTH ? 0 : (uint8_t)((m >> c_l) & 1u));
+                if ((ch >> u_l) & 1u) fz_flags(v, L, b + u_l, c_l);
             }
         }
+        fz_done(v, L, b0, chained);
         return 0u;
     } else if constexpr (SET == 2) {
         if (fz != 2 || nd.kind != K_SAMPLER) return ~0u;
@@ -1019,6 +1122,10 @@ __device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node
         if (sd.format != FMT_P_F32 || sd.channels != 2) return ~0u;
         const float g = s0.s0.input;  // (k_frozen_scan: the gain rests and is no mute)
         const uint64_t ph0 = v.frozen_playhead[node];
+        FzLinks L;  // (a playing sampler's block is never flagged silent: every block of the fast path goes on through the links)
+        fz_links(v, nd.aux0, L);
+        const int lo0 = L.n ? L.o0[L.n - 1] : o0, lo1 = L.n ? L.o1[L.n - 1] : o1;
+        uint32_t chained = 0u;
         for (uint32_t b = b0; b < b1; b += FZ_U) {
             const float* src[FZ_U];
             uint32_t slow = 0;
@@ -1060,13 +1167,20 @@ __device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node
                 for (int u = 0; u < FZ_U; ++u)
                     if (src[u]) {
                         float* pl = v.pool + (size_t)(b + u) * v.pool_blk_stride;
-                        *(v4f*)(pl + (size_t)o0 * v.stride + f0) = x[u][0] * g;  // sampler.rs:521-543
-                        *(v4f*)(pl + (size_t)o1 * v.stride + f0) = x[u][1] * g;
+                        v4f yl = x[u][0] * g, yr = x[u][1] * g;  // sampler.rs:521-543
+                        if (L.n) fz_apply(L, yl, yr);
+                        *(v4f*)(pl + (size_t)lo0 * v.stride + f0) = yl;
+                        *(v4f*)(pl + (size_t)lo1 * v.stride + f0) = yr;
                     }
             }
-            if (lane < 2 * FZ_U && b + u_l < b1 && !((slow >> u_l) & 1u)) (v.flags + (size_t)(b + u_l) * v.flags_blk_stride)[c_l ? o1 : o0] = 0;
+            if (lane < 2 * FZ_U && b + u_l < b1 && !((slow >> u_l) & 1u)) {
+                (v.flags + (size_t)(b + u_l) * v.flags_blk_stride)[c_l ? o1 : o0] = 0;
+                if (L.n) fz_flags(v, L, b + u_l, c_l);
+            }
             todo |= slow << (b - b0);
+            if (L.n) chained |= ((b1 - b >= FZ_U ? (1u << FZ_U) - 1u : (1u << (b1 - b)) - 1u) & ~slow) << (b - b0);
         }
+        fz_done(v, L, b0, chained);
         return todo;
     } else {
         return ~0u;
@@ -1098,7 +1212,13 @@ __global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __res
         if (fz) {
             const bool adv = fz == 2;  // playing sampler: per-block playhead in closed form, the last block stores the state
             const bool spat = fz == 3;
-            const uint32_t todo = bpw > 1 ? frozen_fast<SET>(v, node, fz, b0, b1, K) : ~0u;  // (what is left goes block by block)
+            // blocks an upstream wave rendered on into this node, in registers (fz_links): nothing left to do for them here
+            // (bpw divides 32: the range never straddles a word)
+            uint32_t skip = 0u;
+            if (v.chain_done && fz == 1 && b1 > b0)
+                skip = (v.chain_done[(size_t)node * v.chain_words + (b0 >> 5)] >> (b0 & 31u)) & (b1 - b0 >= 32u ? ~0u : (1u << (b1 - b0)) - 1u);
+            uint32_t todo = bpw > 1 ? frozen_fast<SET>(v, node, fz, b0, b1, K, skip) : ~0u;  // (what is left goes block by block)
+            todo &= ~skip;
             for (uint32_t b = b0; b < b1; ++b)
                 if ((todo >> ((b - b0) & 31u)) & 1u) node_process_wave<SET>(v, node, b, cmd_block0 + b, adv && b + 1 == K, adv ? b : 0u, adv || spat);
             if (spat) {

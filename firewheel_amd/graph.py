@@ -459,6 +459,13 @@ class FirewheelGpuCtx(object):
         self._check(self.L.fwgpu_rt_resident_stats(self.c, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def rt_path_stats(self):
+        """one-block launch batches by path: (resident kernel, one k_rt_block launch, the fused plans' launch sequence, the level
+        executor) — include/fwgpu.h fwgpu_rt_path_stats"""
+        a = (C.c_uint64 * 4)()
+        self._check(self.L.fwgpu_rt_path_stats(self.c, a))
+        return tuple(int(x) for x in a)
+
     def hip_stream(self):
         """the hipStream_t (int) the ctx's process calls launch on — include/fwgpu.h fwgpu_hip_stream"""
         return int(self.L.fwgpu_hip_stream(self.c) or 0)

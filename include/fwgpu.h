@@ -201,6 +201,12 @@ int fwgpu_update_phase(fwgpu_ctx* ctx);
  * FWGPU_RT_PERSIST=0 switches it off (every callback is then one k_rt_block launch).  *launches = resident kernels launched so far,
  * *doorbells = callbacks served without a launch.  Any pointer may be NULL. */
 int fwgpu_rt_resident_stats(fwgpu_ctx* ctx, uint64_t* launches, uint64_t* doorbells);
+/* Which path the ONE-BLOCK calls of this context took so far (cpal/lib.rs:429-437 calls once per block for every graph; only some
+ * plans have the one-launch edge): paths[0] = the resident kernel's doorbell (no launch), paths[1] = one k_rt_block launch,
+ * paths[2] = the fused plans' ordinary launch sequence (a chain plan, a spatialiser / master chain, a tree of more than two levels,
+ * a call that carried a message), paths[3] = the level executor (generic / hybrid plans).  A host reads it to see that its
+ * callbacks run where it expects them to. */
+int fwgpu_rt_path_stats(fwgpu_ctx* ctx, uint64_t* paths);  /* paths: room for 4 */
 /* K = the most blocks one fused launch sequence processes (default 64); sizes the K-batched descriptor,
  * ramp and bus buffers at the next fwgpu_update. */
 int fwgpu_set_max_batch(fwgpu_ctx* ctx, uint32_t max_blocks);

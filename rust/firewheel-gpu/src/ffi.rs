@@ -114,6 +114,7 @@ extern "C" {
     pub fn fwgpu_hip_stream(ctx: *mut fwgpu_ctx) -> *mut c_void;
     pub fn fwgpu_update_phase(ctx: *mut fwgpu_ctx) -> c_int;
     pub fn fwgpu_rt_resident_stats(ctx: *mut fwgpu_ctx, launches: *mut u64, doorbells: *mut u64) -> c_int;
+    pub fn fwgpu_rt_path_stats(ctx: *mut fwgpu_ctx, paths: *mut u64) -> c_int;
     pub fn fwgpu_set_max_batch(ctx: *mut fwgpu_ctx, max_blocks: u32) -> c_int;
     pub fn fwgpu_set_force_generic(ctx: *mut fwgpu_ctx, on: c_int) -> c_int;
     pub fn fwgpu_ext_pool_floats(ctx: *mut fwgpu_ctx, in_use: *mut u64, capacity: *mut u64) -> c_int;

@@ -13,12 +13,17 @@ use firewheel_core::SilenceMask;
 
 use crate::{ffi, GpuContext, GpuError};
 
-/// Owner of a custom processor inside the device graph.  Dropping it removes the node (if it still exists), updates the plan and
-/// hands the processor to the context's graveyard, which frees it only once a plan WITHOUT the node is the active one
-/// (`fwgpu_plan_pending`) — until then the audio thread may still be inside, or about to enter, the trampoline with the raw
-/// `user` pointer.  That is Firewheel's own rule (a removed node's processor is dropped when the old schedule comes back through
-/// the ring, processor.rs:182-188), made part of the type instead of the documentation: dropping the handle at any time, from any
-/// thread, with the stream running, is sound.
+/// Owner of a custom processor inside the device graph.  Dropping it removes the node (if it still exists) and hands the processor
+/// to the context's graveyard, which frees it only once a plan WITHOUT the node is the active one: the host's next explicit
+/// `update()` / `upload_schedule()` marks the graves as updated, `fwgpu_plan_pending() == 0` says that plan has been adopted — until
+/// then the audio thread may still be inside, or about to enter, the trampoline with the raw `user` pointer.  That is Firewheel's
+/// own rule (a removed node's processor is dropped when the old schedule comes back through the ring, processor.rs:182-188), made
+/// part of the type instead of the documentation: dropping the handle at any time, from any thread, with the stream running, is
+/// sound.
+///
+/// `drop` does NOT recompile: the reference only ever compiles in `update()` (graph/context.rs:93-137), and a handle
+/// dropped in the middle of a batch of edits must not publish the half-edited graph to the audio thread, swallow its compile
+/// error, or take the control mutex a second time.  The plan that still calls the node keeps running until the host updates.
 pub struct HostNodeHandle {
     pub node: i64,
     state: Option<Box<HostState>>,
@@ -28,20 +33,19 @@ impl Drop for HostNodeHandle {
     fn drop(&mut self) {
         // Err = the host removed it already (remove_node); either way the graph no longer names it after this line
         let _ = self.cx.remove_node(self.node);
-        // the plan that no longer calls it; on failure (a graph that does not compile right now) the processor simply waits in the
-        // graveyard for the next successful update
-        let updated = self.cx.update().is_ok();
         if let Some(st) = self.state.take() {
-            self.cx.bury(st, updated);
+            self.cx.bury(st);
         }
     }
 }
-/// what the C side's `user` pointer names: the processor and the global user context ProcInfo hands every node
-/// (core/node.rs:117-118; the reference's processor owns one `Box<dyn Any + Send>` per graph, processor.rs:41 — here one per node,
-/// supplied by the host at registration)
+/// what the C side's `user` pointer names: the processor and where the graph's ONE global user context lives.  The reference's
+/// processor owns one `Box<dyn Any + Send>` per graph and lends it to every node's `process` (processor.rs:21,224,240;
+/// core/node.rs:117-118): custom nodes may share state through it.  Here it belongs to the `GpuContext` (`set_user_cx`, before the
+/// stream starts); only the audio thread ever dereferences the pointer, one host node at a time, exactly as the reference's
+/// schedule loop does.
 pub(crate) struct HostState {
     processor: Box<dyn AudioNodeProcessor>,
-    user_cx: Box<dyn std::any::Any + Send>,
+    user_cx: *mut Box<dyn std::any::Any + Send>,
 }
 unsafe impl Send for HostNodeHandle {}
 unsafe impl Send for HostState {}
@@ -52,15 +56,19 @@ pub(crate) struct Grave {
     updated: bool,
 }
 impl GpuContext {
-    pub(crate) fn bury(&self, st: Box<HostState>, updated: bool) {
+    pub(crate) fn bury(&self, st: Box<HostState>) {
         let mut g = self.graveyard.lock().unwrap_or_else(|e| e.into_inner());
-        g.push(Grave { _state: st, updated });
-        drop(g);
-        self.reap(false);
+        g.push(Grave { _state: st, updated: false });
     }
     /// Free the processors no plan can call any more: an update has returned since their removal AND no built plan is waiting
     /// for adoption — so the newest plan, which does not name them, is the one the audio thread runs.  Called after every
-    /// `update` / `upload_schedule` (with `updated = true`), after every drop of a handle, and by `GpuContext::drop` (everything).
+    /// `update` / `upload_schedule` (with `updated = true`), by `GpuContext::release_removed_host_nodes` (`updated = false`: a plan built
+    /// earlier may have been adopted meanwhile), and by `GpuContext::drop` (everything).
+    /// Frees the processors of removed host nodes that no plan can call any more, without recompiling (a host that wants the memory
+    /// back before its next `update`).
+    pub fn release_removed_host_nodes(&self) {
+        self.reap(false);
+    }
     pub(crate) fn reap(&self, updated: bool) {
         let mut g = self.graveyard.lock().unwrap_or_else(|e| e.into_inner());
         if updated {
@@ -98,7 +106,7 @@ unsafe extern "C" fn trampoline(
         out_silence_mask: &mut out_mask,
         stream_time_secs,
         stream_status: StreamStatus::from_bits_truncate(stream_status),
-        cx: &mut st.user_cx,
+        cx: &mut *st.user_cx, // the graph's one context, as processor.rs:224,240 lends it
     }; // core/node.rs:94-118
     st.processor.process(frames, &ins, &mut outs, info);
     *out_silence_mask = out_mask.0;
@@ -113,10 +121,9 @@ impl GpuContext {
         num_inputs: u32,
         num_outputs: u32,
         processor: Box<dyn AudioNodeProcessor>,
-        user_cx: Box<dyn std::any::Any + Send>,
     ) -> Result<HostNodeHandle, GpuError> {
         assert!(num_inputs <= 64 && num_outputs <= 64);
-        let mut boxed = Box::new(HostState { processor, user_cx });
+        let mut boxed = Box::new(HostState { processor, user_cx: self.user_cx_ptr() });
         let user = &mut *boxed as *mut HostState as *mut c_void;
         let _g = self.control();
         let node = self.check(unsafe {

@@ -47,6 +47,9 @@ pub struct GpuContext {
     control: Mutex<()>,
     /// processors of host nodes that were removed while a plan could still call them (host_node.rs)
     pub(crate) graveyard: Mutex<Vec<host_node::Grave>>,
+    /// the graph's one global user context (`ProcInfo::cx`, core/node.rs:117-118; processor.rs:21 owns one per graph): every host
+    /// node's `process` is lent THIS box.  Written by `set_user_cx` before the stream starts, dereferenced by the audio thread only.
+    user_cx: std::cell::UnsafeCell<Box<dyn std::any::Any + Send>>,
     pub sample_rate: u32,
     pub max_block_frames: u32,
 }
@@ -74,7 +77,7 @@ impl GpuContext {
             )
         };
         match NonNull::new(raw) {
-            Some(raw) => Ok(Arc::new(Self { raw, control: Mutex::new(()), graveyard: Mutex::new(Vec::new()), sample_rate, max_block_frames })),
+            Some(raw) => Ok(Arc::new(Self { raw, control: Mutex::new(()), graveyard: Mutex::new(Vec::new()), user_cx: std::cell::UnsafeCell::new(Box::new(())), sample_rate, max_block_frames })),
             None => Err(GpuError {
                 code: ffi::FWGPU_ERR_DEVICE,
                 message: unsafe { CStr::from_ptr(ffi::fwgpu_create_error()) }.to_string_lossy().into_owned(),
@@ -84,6 +87,20 @@ impl GpuContext {
 
     pub fn as_ptr(&self) -> *mut ffi::fwgpu_ctx {
         self.raw.as_ptr()
+    }
+
+    /// The `user_cx` of `FirewheelGraphCtx::activate` (graph/context.rs:53-82 hands it to the processor, processor.rs:41): ONE per
+    /// graph, shared by every custom node.  Call it before the first process call (the default is `Box::new(())`).
+    ///
+    /// # Safety of the implementation
+    /// Takes the control lock; the audio thread reads the box only inside host-node callbacks, which exist only while a process call
+    /// runs — the contract is "before the stream starts", as in the reference, where `activate` consumes it.
+    pub fn set_user_cx(&self, user_cx: Box<dyn std::any::Any + Send>) {
+        let _g = self.control();
+        unsafe { *self.user_cx.get() = user_cx };
+    }
+    pub(crate) fn user_cx_ptr(&self) -> *mut Box<dyn std::any::Any + Send> {
+        self.user_cx.get()
     }
 
     /// The control side's lock: hold it around every control call made through `as_ptr()` directly (messages, samples).

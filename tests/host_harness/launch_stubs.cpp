@@ -94,7 +94,16 @@ void check_generic_node(const DevView& v, int idx, int K) {
     if (nd.kind == K_SUM) {  // aux0: port count (low half); high half, when set: the full port count of a split SumNode's continuation
         REQUIRE(nd.n_out > 0 && (nd.aux0 & 0xffff) * nd.n_out == nd.n_in, nd.aux0, nd.n_in);
         REQUIRE((nd.aux0 >> 16) == 0 || ((nd.aux0 >> 16) > (nd.aux0 & 0xffff) && (nd.aux0 >> 16) <= 32), nd.aux0);
+    } else if (nd.aux0 != 0) {
+        // vertical fusion (k_generic.hip.h fz_links): the ONE consumer of this stereo node — a 2 -> 2 gain-like node that reads exactly
+        // this node's two output buffers, channel for channel
+        REQUIRE(nd.n_out == 2 && (nd.kind == K_SAMPLER || nd.kind == K_VOLUME || nd.kind == K_PAN || nd.kind == K_WIDTH || nd.kind == K_HARD_CLIP), nd.kind);
+        const NodeDesc nx = v.nodes[nd.aux0 - 1];
+        REQUIRE(nx.n_in == 2 && nx.n_out == 2 && (nx.kind == K_VOLUME || nx.kind == K_PAN || nx.kind == K_WIDTH || nx.kind == K_HARD_CLIP), nx.kind);
+        REQUIRE(v.in_buf[nx.in_off] == v.out_buf[nd.out_off] && v.in_buf[nx.in_off + 1] == v.out_buf[nd.out_off + 1], idx, nd.aux0);
+        if (v.chain_done) touch(v.chain_done + (size_t)(nd.aux0 - 1) * v.chain_words, 4 * (size_t)v.chain_words);
     }
+    if (v.chain_done) REQUIRE(v.chain_words > 0 && K <= 32 * v.chain_words && v.frozen != nullptr, K, v.chain_words);
 }
 void check_view_common(const DevView& v, int K) {
     REQUIRE(K >= 1, K);
@@ -185,6 +194,10 @@ int launch_frozen_scan(hipStream_t, const DevView& v, int n_nodes, uint32_t, int
     touch(v.nodes, sizeof(NodeDesc) * (size_t)n_nodes);
     touch(d_frozen, (size_t)n_nodes);
     touch(d_snap, 8 * (size_t)n_nodes);
+    if (v.chain_done) {
+        REQUIRE(v.chain_words > 0 && K <= 32 * v.chain_words, K, v.chain_words);
+        touch(v.chain_done, 4 * (size_t)n_nodes * (size_t)v.chain_words);
+    }
     return 0;
 }
 int launch_bus_sum(hipStream_t, const DevView& v, const int* d_level_nodes, int n_nodes, int K, int n_out) {

@@ -149,11 +149,11 @@ def start_shard(e, rank, voices, src=700, paused_ranks=(), neg_zero_rank=None, o
             e.sampler_play(s)
 
 
-def whole_graph_oracle(world, total_voices, block, calls, **kw):
+def whole_graph_oracle(world, total_voices, block, calls, radix=4, **kw):
     e = OracleEngine(max_block_frames=block)
     roots, allv = [], []
     for r in range(world):
-        root, voices = shard_graph(e, r, world, total_voices)
+        root, voices = shard_graph(e, r, world, total_voices, radix=radix)
         roots.append(root)
         allv.append((r, voices))
     top = e.sum(world)  # the mix-bus reduction as the reference expresses it: one world-port stereo SumNode
@@ -442,8 +442,14 @@ rank, world, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 mode = sys.argv[4]
 total, block, calls = 23, 64, [3, 5, 9]
 kw = dict(paused_ranks=(3,), neg_zero_rank=0, one_shot_ranks=(1, 2, 4))
+radix = 4
+if mode == "cfg5":
+    # BASELINE configs[4] at its real size: world x 8 192 voices under radix-32 trees (256 + 8 + 1 mixers per rank), block 1024,
+    # the exchange after every call; two calls of 2 + 3 blocks.  One rank's one-shots end inside the run, one rank holds -0.0.
+    total, block, calls, radix = T.CFG5_VOICES_PER_RANK * world, 1024, T.CFG5_CALLS, 32
+    kw = dict(src=T.CFG5_SRC, neg_zero_rank=0, one_shot_ranks=(world - 1,))
 e = fwapi.GpuEngine(max_block_frames=block, max_batch=4)
-root, voices = T.shard_graph(e, rank, world, total)
+root, voices = T.shard_graph(e, rank, world, total, radix=radix)
 e.connect_stereo(root, e.graph_out_node)
 e.update()
 T.start_shard(e, rank, voices, **kw)
@@ -541,6 +547,8 @@ for k in calls:
     sil = torch.empty(k * 2, dtype=torch.uint8, device="cuda")
     out = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
+    if mode == "cfg5":
+        assert e.cx.plan_kind() == 1, "the shard is not on the fused voice-bank plan"
     e.cx.process_blocks_device_flags(k, part.data_ptr(), 2, sil.data_ptr())
     if mode == "noflags":
         x.step(part.data_ptr(), out.data_ptr(), n)
@@ -562,6 +570,9 @@ if mode == "long":
 '''
 
 
+CFG5_VOICES_PER_RANK, CFG5_SRC, CFG5_CALLS = 8192, 2500, [2, 3]
+
+
 def _run_ranks(world, mode):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
@@ -573,7 +584,7 @@ def _run_ranks(world, mode):
         logs = []
         for p in procs:
             try:
-                out, _ = p.communicate(timeout=300)
+                out, _ = p.communicate(timeout=900 if mode == "cfg5" else 300)
             except subprocess.TimeoutExpired:
                 p.kill()
                 out, _ = p.communicate()
@@ -596,6 +607,21 @@ def test_exchange_between_processes_over_hipipc_equals_the_whole_graph(world):
     if world == 5:  # and the flags matter: without them (no port ever silent) the sign of some zeros differs
         blind = _run_ranks(world, "noflags")
         assert np.array_equal(blind[0], want) and not np.array_equal(blind[0].view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_baseline_config5_whole_65536_voices_as_8_processes_equals_the_oracles_one_graph():
+    """BASELINE configs[4] as it is written — 65 536 voices sharded 8 ways (8 192 per rank, radix-32 trees), block 1024, the mix-bus
+    exchange after every call — as 8 PROCESSES on the one device this pool has (real hipIpc handles, peer-mapped slots).  The oracle
+    runs ONE graph of 65 536 voices whose top node is the 8-port SumNode (nodes/sum.rs:111-133); every rank must end with its bits
+    for all five blocks.  What an 8-GPU node adds is xGMI instead of the local fabric."""
+    world = 8
+    kw = dict(src=CFG5_SRC, neg_zero_rank=0, one_shot_ranks=(world - 1,))
+    want = np.concatenate(whole_graph_oracle(world, CFG5_VOICES_PER_RANK * world, 1024, CFG5_CALLS, radix=32, **kw))
+    assert np.abs(want).max() > 1.0  # 65 536 live voices: not a silent bus
+    got = _run_ranks(world, "cfg5")
+    for r in range(world):
+        assert np.array_equal(got[r].view(np.uint32), want.view(np.uint32)), "rank %d" % r
 
 
 # ---------------------------------------------------------------------------------------------- CPU: the torch paths of shard.py

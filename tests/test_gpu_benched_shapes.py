@@ -419,3 +419,78 @@ def test_lazy_records_calls_without_a_control_kernel_are_bit_exact_and_happen():
     assert lazy[8] > lazy[4], marks                 # after it: lazy again, a 9-block call as two batches
     assert lazy[9] == lazy[8] and lazy[10] == lazy[9], marks    # the message and the call after it
     assert lazy[-1] >= lazy[10], marks
+
+
+def test_node_state_after_lazily_rendered_blocks_is_the_control_paths_state():
+    """k_lazy_flush wrote loop_start where the control path (tail_end_playhead) leaves playhead == loop_end when the last
+    block of a call ends exactly on the loop end.  The two render alike until something READS the playhead: SetLoopRange keeps a
+    playhead that lies inside the new range (sampler.rs:293-321, Q7) — loop_end of [0, 768) lies inside [0, 1536), loop_start plays
+    from 0.  Loops of 12 blocks, lazy calls that end on the loop end, then the range is widened: every call against the oracle."""
+    mbf = 64
+
+    def run(e):
+        voices = scenarios.build_voice_bank(e, 19, radix=8, src_frames=mbf * 24, fmt_cycle=list(range(6)))
+        for vc in voices:
+            e.sampler_set_loop_range(vc["sampler"], fwapi.LOOP_RANGE_SECS, 0.0, 0.016)   # [0, 768) frames = 12 blocks
+            e.sampler_play(vc["sampler"])
+        outs, marks = [], []
+        for i, k in enumerate([6, 6, 12, 12, 3, 9, 12, 2, 5]):
+            if i in (4, 7):   # after calls that ended on the loop end (lazily, if the host may): widen / narrow the range
+                for vc in voices[::2]:
+                    e.sampler_set_loop_range(vc["sampler"], fwapi.LOOP_RANGE_SECS, 0.0, 0.032 if i == 4 else 0.016)
+            outs.append(np.asarray(e.process_blocks(k)))
+            if hasattr(e, "cx"):
+                marks.append(e.cx.lazy_stats())
+        return np.concatenate(outs), marks
+
+    out_o, _ = run(scenarios.TaggedOracle(OracleEngine(max_block_frames=mbf)))
+    g = GpuEngine(max_block_frames=mbf, max_batch=16)
+    out_g, marks = run(g)
+    assert g.cx.plan_kind() == 1
+    assert np.array_equal(bits(out_g), bits(out_o))
+    if os.environ.get("FWGPU_LAZY") != "0":
+        assert marks[3][0] > marks[1][0], marks    # the calls before the range change were lazy ones
+
+
+@pytest.mark.parametrize("mbf,max_batch", [(256, 16), (64, 8), (100, 4), (512, 4), (90, 3)])
+def test_resampler_bank_every_register_window_variant_bit_exact(mbf, max_batch):
+    """Round 5, k_leaf_rs: a lane owns four consecutive frames and reads ONE run of the window into registers; the chains are template
+    variants by (floor(step), floor(2 step), floor(3 step)), the per-lane carry picks one of two coefficient banks (a 17-tap chain with a
+    zero coefficient at one end).  Ratios in every variant's range and on its edges, ratios where the lanes' runs collide in the LDS
+    banks (0.8, 1.0, 1.15, 4/3, 1.6), the last pure ratio and the first one the general kernel takes (>= 2), loops that wrap inside
+    the run, one-shots that end in it, mono sources; block lengths whose last lane owns 1-3 frames (90) and that are shorter than a
+    piece (64, 100) or longer (512: two pieces per block)."""
+    ratios = [0.2, 1.0 / 3.0, 0.3334, 0.49999, 0.5, 0.61, 2.0 / 3.0, 0.6667, 0.8, 0.91875, 0.99999, 1.0, 1.00001, 1.15, 1.3333, 4.0 / 3.0,
+              1.41, 1.5, 1.50001, 1.6, 5.0 / 3.0, 1.6667, 1.9, 1.93, 1.99999, 2.0, 2.5, 0.75, 1.25, 1.088, 0.0371, 1.75]
+
+    def run(e):
+        ends = []
+        rng = np.random.default_rng(77)
+        for v, ratio in enumerate(ratios):
+            ch = 1 if v % 7 == 3 else 2
+            frames = 1400 + 37 * v
+            smp = e.new_sample(PLANAR_F32, ch, scenarios.voice_source(9300 + v, frames, ch))
+            src = e.resampler(smp, ratio, loop=(v % 3 != 1), playing=True, n_out=2)
+            vol = e.volume(float(rng.uniform(20, 110)))
+            pan = e.pan(float(rng.uniform(-1, 1)))
+            e.connect_stereo(src, vol)
+            e.connect_stereo(vol, pan)
+            ends.append(pan)
+        mixers = []
+        for i in range(0, len(ends), 16):
+            m = e.sum(16)
+            for p, n in enumerate(ends[i:i + 16]):
+                e.connect_stereo(n, m, 2 * p)
+            mixers.append(m)
+        top = e.sum(len(mixers))
+        for p, m in enumerate(mixers):
+            e.connect_stereo(m, top, 2 * p)
+        e.connect_stereo(top, e.graph_out_node)
+        e.update()
+        return np.concatenate([np.asarray(e.process_blocks(k)) for k in (3, max_batch, 2 * max_batch + 1, 5)])
+
+    out_o = run(scenarios.TaggedOracle(OracleEngine(max_block_frames=mbf)))
+    g = GpuEngine(max_block_frames=mbf, max_batch=max_batch)
+    out_g = run(g)
+    assert g.cx.plan_kind() == 1
+    assert np.array_equal(bits(out_g), bits(out_o))

@@ -49,6 +49,16 @@ def test_graph_edits_race_callbacks_under_tsan(tmp_path):
     assert r.returncode == 0 and "edits-run ok" in r.stdout and "ThreadSanitizer" not in r.stderr, (r.stdout[-2000:], r.stderr[-6000:])
 
 
+def test_audio_gate_steps_back_for_a_waiting_control_call_only_for_a_bounded_time(tmp_path):
+    """AudioGate lets a control call that waits at ControlGate go first — for at most gate_defer_ns.  A waiter
+    that raised the counter and never arrives (descheduled) costs a callback the bound, not a scheduler quantum; a waiter that does
+    arrive still gets in beside back-to-back callbacks."""
+    exe = str(tmp_path / "rt_gate")
+    _build_driver(exe, [])
+    r = subprocess.run([exe, "gate"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "gate-run ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_adopting_a_plan_does_not_touch_the_host_allocator_on_the_audio_thread(tmp_path):
     exe = str(tmp_path / "rt_alloc_edits")
     _build_driver(exe, ["-DCOUNT_ALLOCS"])

@@ -83,6 +83,30 @@ def test_consecutive_callbacks_ride_the_doorbell_and_match_the_oracle():
             assert launches <= 3, (launches, doorbells)
 
 
+def test_rt_path_stats_say_which_path_the_one_block_calls_took():
+    """fwgpu_rt_path_stats: the doorbell / one-launch edge exists for the plain voice-bank plan only — a host whose
+    callbacks run on the launch sequence (chain plan) or on the level executor (forced generic) sees it in the counters."""
+    g = GpuEngine(max_block_frames=MBF)
+    _run(g, Steady())
+    rk, one, seq, lev = g.cx.rt_path_stats()
+    assert lev == 0 and rk + one + seq == Steady.n, (rk, one, seq, lev)
+    if os.environ.get("FWGPU_RT_PERSIST") != "0":
+        assert rk >= Steady.n - 4, (rk, one, seq, lev)
+    c = GpuEngine(max_block_frames=128, max_batch=4)
+    scenarios.scenario_chain_steady(c, 12, 4, radix=4, src_frames=700, first_delay_frames=128, min_delay_frames=128)
+    assert c.cx.plan_kind() == 2
+    before = c.cx.rt_path_stats()
+    for _ in range(5):
+        c.process_interleaved(128)
+    after = c.cx.rt_path_stats()
+    assert after[2] - before[2] == 5 and after[0] == before[0] and after[1] == before[1] and after[3] == before[3], (before, after)
+    f = GpuEngine(max_block_frames=MBF, force_generic=True)
+    _bank(f, 8)
+    for _ in range(3):
+        f.process_interleaved(MBF)
+    assert f.cx.rt_path_stats()[3] == 3 and sum(f.cx.rt_path_stats()[:3]) == 0
+
+
 def test_messages_other_sizes_and_edits_end_the_kernel_and_nothing_is_lost():
     sg, so = Traffic(), Traffic()
     g, o = GpuEngine(max_block_frames=MBF), OracleEngine(max_block_frames=MBF)

@@ -743,7 +743,9 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
     sils = [torch.zeros(R * K * 2, dtype=torch.uint8, device=dev) for _ in range(2)] if dist is not None else None
     reducer, reduce_mode, reduce_note = (None, None, None)
     if dist is not None:
+        progress(env, "%s: opening the mix-bus reduction (%s)" % (wl, args.bus_reduce))
         reducer, reduce_mode, reduce_note = make_reducer(env, args, cx, outs, sils, B)
+        progress(env, "%s: reduction ready (%s)" % (wl, reduce_mode))
     step_no = [0]
     slot = [0]  # bus slot counter: buffer (slot // R) % 2, slice slot % R
     xfail = []

@@ -145,12 +145,28 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
             int cur = end;
             int bq = -1, dl = -1;
             bool sp_voice = false;
+            bool mono_src = false;
             for (;;) {
                 const PlanNode& n = plan.nodes[cur];
                 if (covered[cur]) return false;
                 if (n.kind == K_SAMPLER || n.kind == K_RESAMPLER) {
                     if (n.n_in != 0 || n.n_out != 2) return false;
                     covered[cur] = 1;
+                    break;
+                }
+                if (n.kind == K_MONO_TO_STEREO) {
+                    // sampler(0 -> 1) -> MonoToStereoNode (mono_to_stereo.rs:33-50): the reference's own adapter behind a ONE-output
+                    // sampler — channel 0 of its sample on both outputs, silence passed on: a voice whose every block is VB_MONO
+                    // (src_kind 2; k_control.hip.h mono_adapt).  Dry / gain chains only.
+                    if (n.n_in != 1 || n.n_out != 2 || bq >= 0 || dl >= 0 || sp_voice) return false;
+                    const int sidx = n.in_src_node[0];
+                    if (sidx < 0 || n.in_src_port[0] != 0 || covered[sidx]) return false;
+                    const PlanNode& sn = plan.nodes[sidx];
+                    if (sn.kind != K_SAMPLER || sn.n_in != 0 || sn.n_out != 1 || cons[sidx][0] != 1) return false;
+                    covered[cur] = 1;
+                    covered[sidx] = 1;
+                    mono_src = true;
+                    cur = sidx;
                     break;
                 }
                 if (n.n_in != 2 || n.n_out != 2) return false;
@@ -187,7 +203,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
             vd.dl_state = dl >= 0 ? (int)plan.nodes[dl].slot : -1;
             if (bq >= 0 || dl >= 0) fb.has_fx = true;
             vd.sampler_state = (int)plan.nodes[cur].slot;
-            vd.src_kind = plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0;
+            vd.src_kind = mono_src ? 2 : (plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0);
             if (vd.src_kind == 1) {
                 if (bq >= 0 || dl >= 0) return false;  // (the chain plan's source fetch is the sampler's)
                 fb.has_prog = true;                    // the polyphase fetch lives in the leaf kernel's program instantiation
@@ -331,11 +347,22 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         int chain[FW_MAX_STAGES], n_chain = 0;
         int bq = -1, dl = -1;
         bool sp_voice = false;
+        int mono_adapter = -1;
         for (;;) {
             const PlanNode& n = plan.nodes[cur];
             if (taken[cur] || n.is_graph_io) return w;
             if (n.kind == K_SAMPLER || n.kind == K_RESAMPLER) {
                 if (!(n.n_in == 0 && n.n_out == 2)) return w;
+                break;
+            }
+            if (n.kind == K_MONO_TO_STEREO) {  // (as detect_fused: a one-output sampler behind the reference's adapter)
+                if (n.n_in != 1 || n.n_out != 2 || bq >= 0 || dl >= 0 || sp_voice) return w;
+                const int sidx = n.in_src_node[0];
+                if (sidx < 0 || n.in_src_port[0] != 0 || taken[sidx]) return w;
+                const PlanNode& sn = plan.nodes[sidx];
+                if (sn.kind != K_SAMPLER || sn.n_in != 0 || sn.n_out != 1 || sn.is_graph_io || cons[sidx][0] != 1) return w;
+                mono_adapter = cur;
+                cur = sidx;
                 break;
             }
             if (n.n_in != 2 || n.n_out != 2) return w;
@@ -365,7 +392,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         w.sp = sp_voice;
         w.prog = sp_voice;
         w.vd.sampler_state = (int)plan.nodes[cur].slot;
-        w.vd.src_kind = plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0;
+        w.vd.src_kind = mono_adapter >= 0 ? 2 : (plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0);
         w.vd.bq_state = bq >= 0 ? (int)plan.nodes[bq].slot : -1;
         w.vd.dl_state = dl >= 0 ? (int)plan.nodes[dl].slot : -1;
         w.fx = bq >= 0 || dl >= 0;
@@ -379,6 +406,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
             w.prog = w.prog || n.kind == K_WIDTH || n.kind == K_HARD_CLIP;
         }
         w.nodes[w.n_nodes++] = cur;
+        if (mono_adapter >= 0) w.nodes[w.n_nodes++] = mono_adapter;
         if (bq >= 0) w.nodes[w.n_nodes++] = bq;
         if (dl >= 0) w.nodes[w.n_nodes++] = dl;
         for (int j = 0; j < n_chain; ++j) w.nodes[w.n_nodes++] = chain[j];

@@ -524,7 +524,7 @@ static int rt_persist_launch(fwgpu_ctx* c, const FusedView& fv, const DevView& v
 }
 
 static void rt_root_view(const fwgpu_ctx* c, const FusedView& fv, DevView& v) {
-    memset(&v, 0, sizeof(v));
+    v = DevView{};
     v.pool = fv.bus;
     v.flags = fv.bus_flags;
     v.pool_blk_stride = fv.bus_blk_stride;

@@ -129,7 +129,8 @@ struct VoiceDesc {  // static per voice chain: sampler -> [biquad] -> [delay] ->
     int stage_state[FW_MAX_STAGES - 1];
     int bq_state;                      // biquad between the sampler and the gain stages, -1 = none (k_chain plan)
     int dl_state;                      // delay after the biquad, -1 = none
-    int src_kind;                      // 0 = SamplerNode, 1 = SPEC resampling source (sampler_state = its state; no gain of its own)
+    int src_kind;                      // 0 = SamplerNode, 1 = SPEC resampling source (sampler_state = its state; no gain of its own),
+                                       // 2 = a ONE-output SamplerNode behind a MonoToStereoNode: channel 0 on both outputs (round 5)
     int sp_ext_off;                    // a SPEC spatialiser as the last stage: ext-pool offset of its SP_HIST-frame mono history; -1 = none
 };
 

@@ -220,6 +220,15 @@ __device__ __forceinline__ uint32_t simple_class(const SampleDesc& sd, uint64_t 
         default: return SF_NONE;
     }
 }
+// src_kind 2 — sampler(0 -> 1) -> MonoToStereoNode: the sampler fills min(outputs, channels) = 1 buffer with channel 0 (sampler.rs:521-543)
+// and the adapter copies it to both of its outputs (mono_to_stereo.rs:33-50).  To everything below that IS a 1-channel sample: channel 0
+// of a planar sample is a mono sample where it lies; an interleaved sample with more channels gets no compact class (format none of the
+// above: frame-by-frame fetch of channel 0 by the render side, which reads the sample table itself) and VB_MONO like any mono sample.
+__device__ __forceinline__ void mono_adapt(SampleDesc& sd) {
+    if (sd.channels <= 1) return;
+    if (!(sd.format == FMT_P_F32 || sd.format == FMT_P_I16 || sd.format == FMT_P_U16)) sd.format = 0x7f;
+    sd.channels = 1;
+}
 // format-only part of the test above (a voice whose sample can never be fetched compactly needs no gain-set slot)
 __device__ __forceinline__ bool simple_capable(const SampleDesc& sd, bool fx) {
     return simple_class(sd, 0, fx) != SF_NONE;
@@ -849,6 +858,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                 job.loop_start = sp->loop_start;
                 job.loop_end = sp->loop_end;
                 sd = fv.samples[vc.sample];
+                if (vd.src_kind == 2) mono_adapt(sd);
                 if (vc.mode == 2 && job.playhead + (uint64_t)Kp * (uint64_t)frames > sd.frames) ok = false;  // ends in these blocks
                 if (vc.mode == 3) {
                     job.loop_end = sp->has_loop ? (sd.frames << 32) : 0;
@@ -926,6 +936,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
     bool became_steady = false;
     if (ss.sample >= 0 && ss.playing) {  // the sample in use at the start of the call (messages may replace it below)
         sd = fv.samples[ss.sample];
+        if (vd.src_kind == 2) mono_adapt(sd);
         cached_sample = ss.sample;
     }
 
@@ -971,6 +982,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             }
             if (ss.sample >= 0 && ss.playing && cached_sample != ss.sample) {
                 sd = fv.samples[ss.sample];
+                if (vd.src_kind == 2) mono_adapt(sd);
                 cached_sample = ss.sample;
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
@@ -1345,6 +1357,7 @@ __device__ inline bool voice_control_lane_steady(const FusedView& fv, const int 
         job.loop_start = sp->loop_start;
         job.loop_end = sp->loop_end;
         sd = fv.samples[vc.sample];
+        if (vd.src_kind == 2) mono_adapt(sd);
         if (vc.mode == 2 && job.playhead + (uint64_t)frames > sd.frames) return false;  // the one-shot ends in this block
         if (vc.mode == 3) {
             job.loop_end = sp->has_loop ? (sd.frames << 32) : 0;

@@ -693,9 +693,7 @@ __device__ __forceinline__ RsPure rs_pure_lane(const FusedView& fv, const size_t
             const uint64_t w_max = (((uint64_t)nfr * step + 0xffffffffull) >> 32) + 1 + RS_TAPS;  // any piece of the block
             const uint64_t span = (((uint64_t)frames * step + 0xffffffffull) >> 32) + 1 + RS_TAPS + 4;  // the block's window, quad-rounded
             const uint64_t i_first = off0 >> 32;
-            // (step < 2: a lane's four consecutive frames span at most 5 + 17 window slots — k_leaf_rs's register window, RS2_NW;
-            //  a 256-frame piece never has more, w_max <= RS2_WIN, but a shorter block would)
-            if (w_max <= RS2_WIN && step < (2ull << 32) && i_first + span < (1ull << 30) && len < (1u << 30) && len >= 1u && (!loop || len >= (uint32_t)(RS2_WIN + RS_TAPS))) {
+            if (w_max <= RS2_WIN && i_first + span < (1ull << 30) && len < (1u << 30) && len >= 1u && (!loop || len >= (uint32_t)(RS2_WIN + RS_TAPS))) {
                 const uint32_t i0 = loop ? (uint32_t)i_first % len : (uint32_t)i_first;
                 const int qb0 = (int)i0 - (RS_TAPS / 2 - 1);
                 const bool contig = qb0 >= 0 && (uint64_t)qb0 + span <= (uint64_t)len;
@@ -1363,107 +1361,16 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum_lazy(FusedView fv, 
 // The resampler-pure leaves of a plan (rs_pure_lane above).  One wave per (leaf, block, 256-frame piece); lane p holds port p.
 // Accumulators, stages and the final store stay in the convolution's round-robin frame layout (lane l: frames l, l + nact, ...):
 // the stages of a pure voice are per-frame constants, so nothing needs the four-consecutive-frames layout of the other kernels.
-#ifndef RS_V2
-#define RS_V2 1
-#endif
-#if RS_V2
-// Round 5 — the convolution with the window in REGISTERS.  A lane owns FOUR CONSECUTIVE output frames of the piece (4 l .. 4 l + 3): their
-// windows overlap, so the lane reads ONE run of b3 + 17 <= 22 window slots ({L, R} pairs, ds_read_b64) for all four instead of 16 per
-// frame — 53-57 LDS reads per four frames where the round-robin layout (round 4) needed 96; that kernel was LDS-issue-bound at 293
-// LDS cycles per (wave, port), 77 of them bank conflicts (profiles/r04_cfg2_rs_sq_counters.txt).
-//   * frame j's first tap sits at slot o_j = floor(frac0 + j step) of the run: b_j or b_j + 1, b_j = floor(j step) wave-uniform (one
-//     port's step), e_j = o_j - b_j a per-lane bit.  Register indices must be compile-time, so the chain runs over the 17 slots
-//     w[b_j .. b_j + 16] and the per-lane bit moves into the COEFFICIENT address, which is per lane anyway: two banks in LDS, E0 = (h0,
-//     h1) .. (h14, h15), (0, 0) and E1 = (0, h0), (h1, h2) .. (h13, h14), (h15, 0).  fma(0, x, acc) == acc for every finite x and every
-//     acc a chain from +0.0 can hold (it is never -0.0), so the 17-tap chain IS the SPEC's 16-tap chain, bit for bit; the slot past the
-//     last frame's window is staged too (finite sample data; NaN / Inf samples would spread one slot further than in the SPEC).
-//   * the variants (b_1; b_2, b_3) are template instantiations behind wave-uniform branches: step < 1.934 (RS2_WIN) allows eight.
-//   * bank conflicts: the 32 lanes of a ds_read_b64 group read slots 4 step apart — ~2-way on average (tests/…/banksim in
-//     profiles/README.md), 22 reads; the round-robin layout paid 2-way on all 64 window reads of every port with step > 1.
-//   * accumulators, stages and the store are each lane's four consecutive frames: one dwordx4 per channel.
-#ifndef RS2_SCHED
-#define RS2_SCHED 1   // coefficient reads in groups of three pairs per chain (0: the scheduler's own order — all 18 up front)
-#endif
-#define RS2_NW 22     // window slots a lane reads at most: b3 + 17, b3 <= 5
-#define RS2_PAIRS 9   // coefficient pairs per bank and phase
-#define RS2_TAB_FLOATS (2 * RS2_PAIRS * RS_PHASES * 2)
-#define RS2_WIN_FLOATS (2 * (RS2_WIN + 8))  // (+ the slot past the window, + what idle lanes' clamped runs reach)
-#define RS2_GP_FLOATS 24                    // per port: g[FW_MAX_STAGES][2], the stage program, pad — 16-byte reads of the stages in use
-#define RS2_WAVE_FLOATS (RS2_WIN_FLOATS + 32 * RS2_GP_FLOATS)
-#define RS2_LDS_BYTES(waves) ((RS2_TAB_FLOATS + (waves) * RS2_WAVE_FLOATS) * sizeof(float))
-static_assert(FW_MAX_STAGES * 2 + 1 <= 16, "k_leaf_rs: the per-port row: gains + program in floats 0..15, the source in 16..23");
-// two frames' chains side by side (each is 16-17 dependent instructions long).  SHORT_A: frame 0 of a lane (e = 0 by construction)
-// runs the SPEC's 16 taps straight from bank E0.
-template <int BA, int BB, bool SHORT_A>
-__device__ __forceinline__ void rs2_pair(const v2f_rs (&w)[RS2_NW], const rs_lp ha_in, const rs_lp hb_in, v2f_rs& ra, v2f_rs& rb) {
-    // (the coefficient addresses pass through a statement with IMMEDIATE operands, and so do the results below: every instantiation
-    //  is then a body of its own.  Without the first the optimiser hoisted the coefficient reads of ALL variants — and a splat copy of
-    //  every coefficient — in front of the branch: 100 registers; without the second it sank the chains into ONE body behind a page of
-    //  register moves, or behind a run-time index into w[], which put the window into scratch memory.)
-    uint32_t ha_a = (uint32_t)(uintptr_t)ha_in, hb_a = (uint32_t)(uintptr_t)hb_in;
-    asm volatile("; rs2_pair %2 %3 {" : "+v"(ha_a), "+v"(hb_a) : "n"(BA), "n"(BB));
-    const rs_lp ha = (rs_lp)(uintptr_t)ha_a, hb = (rs_lp)(uintptr_t)hb_a;
-    // coefficient pairs in groups of three per chain, the next group's reads in flight while this one's products are added (left to
-    // itself the scheduler requests all 18 pairs up front: 36 registers on top of the window's 44)
-    v2f_rs acca = (v2f_rs){0.f, 0.f}, accb = (v2f_rs){0.f, 0.f};
-    v2f_rs ca[RS2_PAIRS], cb[RS2_PAIRS];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-        ca[m] = ha[m * RS_PHASES];
-        cb[m] = hb[m * RS_PHASES];
-    }
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        if (g < 2) {
-#pragma unroll
-            for (int m = 3 * g + 3; m < 3 * g + 6; ++m) {
-                if (!(SHORT_A && m == RS2_PAIRS - 1)) ca[m] = ha[m * RS_PHASES];
-                cb[m] = hb[m * RS_PHASES];
-            }
-        }
-#if RS2_SCHED
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-        for (int m = 3 * g; m < 3 * g + 3; ++m) {
-            if (!(SHORT_A && m == RS2_PAIRS - 1)) {
-                acca = __builtin_elementwise_fma((v2f_rs){ca[m].x, ca[m].x}, w[BA + 2 * m], acca);
-            }
-            accb = __builtin_elementwise_fma((v2f_rs){cb[m].x, cb[m].x}, w[BB + 2 * m], accb);
-            if (m < RS2_PAIRS - 1) {
-                acca = __builtin_elementwise_fma((v2f_rs){ca[m].y, ca[m].y}, w[BA + 2 * m + 1], acca);
-                accb = __builtin_elementwise_fma((v2f_rs){cb[m].y, cb[m].y}, w[BB + 2 * m + 1], accb);
-            }
-        }
-#if RS2_SCHED
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-    asm volatile("; } rs2_pair %2 %3" : "+v"(acca), "+v"(accb) : "n"(BA), "n"(BB));
-    ra = acca;
-    rb = accb;
-}
-#else
 #define RS2_LDS_BYTES(waves) ((RS_PHASES * RS_TAPS + (waves) * (2 * RS2_WIN)) * sizeof(float))
-#endif
 #ifndef RS_OCC
 #define RS_OCC 4
 #endif
 __global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv, int K, int wpk) {
     extern __shared__ float s_leaf_dyn[];
-#if RS_V2
-    // the two coefficient banks, [bank e][pair m][phase] as {c[2m], c[2m+1]}: c = (h0 .. h15, 0, 0) for e = 0, (0, h0 .. h15, 0) for e = 1
-    for (int i = threadIdx.x; i < RS2_TAB_FLOATS; i += blockDim.x) {
-        const int half = i & 1, ph = (i >> 1) % RS_PHASES, m = ((i >> 1) / RS_PHASES) % RS2_PAIRS, e = (i >> 1) / (RS_PHASES * RS2_PAIRS);
-        const int t = 2 * m + half - e;
-        s_leaf_dyn[i] = (t >= 0 && t < RS_TAPS) ? fv.rs_table[ph * RS_TAPS + t] : 0.f;
-    }
-#else
     for (int i = threadIdx.x; i < RS_PHASES * RS_TAPS; i += blockDim.x) {  // [tap pair][phase][2]
         const int t = i % RS_TAPS, ph = i / RS_TAPS;
         s_leaf_dyn[((t >> 1) * RS_PHASES + ph) * 2 + (t & 1)] = fv.rs_table[i];
     }
-#endif
     __syncthreads();
     const int leaf = blockIdx.x;
     const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1475,12 +1382,7 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv
     const int frames = fv.frames;
     if (part * 256 >= frames) return;
     const v2f_rs* tab = (const v2f_rs*)s_leaf_dyn;
-#if RS_V2
-    v2f_rs* win = (v2f_rs*)(s_leaf_dyn + RS2_TAB_FLOATS + wave * RS2_WAVE_FLOATS);
-    float* gp = s_leaf_dyn + RS2_TAB_FLOATS + wave * RS2_WAVE_FLOATS + RS2_WIN_FLOATS;  // [port][RS2_GP_FLOATS]
-#else
     v2f_rs* win = (v2f_rs*)(s_leaf_dyn + RS_PHASES * RS_TAPS + wave * (2 * RS2_WIN));
-#endif
     const size_t row = (size_t)k * fv.n_voices + ld.first_voice;
     uint32_t my_flags = VB_SILENT;
     uint64_t my_pos = 0ull;
@@ -1501,40 +1403,10 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv
         }
         return;
     }
-#if !RS_V2
     // lane p holds port p: sample, position, step, flags, stage program, constant gains (read with v_readlane below)
     const uint64_t my_s0 = (uint64_t)me.s0, my_off0 = me.off0, my_step = me.step;
     const uint32_t my_len = me.len, my_df = me.df;
     const int my_qb0 = me.qb0;
-#endif
-#if RS_V2
-    // the port's constant gains and stage program wait in LDS (a row per port, read by the whole wave when the port's frames are
-    // done: uniform address, a broadcast) — as lane-held registers + v_readlane they were 11 of the 128 registers the window needs
-    if (me.pure && lane < 32) {
-        const VoiceBlk* b = (my_flags & VB_RS_LEAN) ? fv.rs_tmpl + (ld.first_voice + lane) : fv.blks + row + lane;
-        float* o = gp + lane * RS2_GP_FLOATS;
-#pragma unroll
-        for (int j = 0; j < FW_MAX_STAGES; ++j) {
-            o[2 * j] = b->g[j][0];
-            o[2 * j + 1] = b->g[j][1];
-        }
-        o[2 * FW_MAX_STAGES] = __uint_as_float(fv.progs[ld.first_voice + lane]);
-        // ... and so does its source: sample, 32.32 position and step, flags (port() below)
-        uint32_t* u = (uint32_t*)(o + 16);
-        u[0] = (uint32_t)(uint64_t)me.s0;
-        u[1] = (uint32_t)((uint64_t)me.s0 >> 32);
-        u[2] = (uint32_t)me.off0;
-        u[3] = (uint32_t)(me.off0 >> 32);
-        u[4] = (uint32_t)me.step;
-        u[5] = (uint32_t)(me.step >> 32);
-        u[6] = me.len;
-        u[7] = me.df;
-        ((int*)o)[15] = me.qb0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
     uint32_t my_prog = 0u;
     float my_g[FW_MAX_STAGES][2];
 #pragma unroll
@@ -1548,7 +1420,6 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv
             my_g[j][1] = b->g[j][1];
         }
     }
-#endif
     const int path_ports = ld.pad ? ld.pad : ld.ports;
     const bool masked = !(path_ports == 2 || path_ports == 3 || path_ports == 4);  // sum.rs:67-133 (Q13)
     const int ng = fv.n_gain_stages;
@@ -1557,166 +1428,6 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv
     float* outr = outl + fv.stride;
     const int first = __builtin_ctzll(pure_ports);
 
-#if RS_V2
-    for (int fbase = part * 256; fbase < frames; fbase += 256 * wpk) {
-        const int nfr = frames - fbase < 256 ? frames - fbase : 256;
-        // lane l owns frames 4 l .. 4 l + 3 of the piece (lanes past its end convolve its last frame's run: no branch around the reads)
-        const int n0 = 4 * lane < nfr ? 4 * lane : nfr - 1;
-        v4f accl = splat(0.f), accr = splat(0.f);
-        v4f wa[2], wb[2];
-        wa[0] = wa[1] = wb[0] = wb[1] = splat(0.f);
-        // one port's piece: source, window length, flags (wave-uniform; the NEXT port's set is computed once, when its window is
-        // requested, and becomes the current one an iteration later).  W counts the slot PAST the last frame's window too.
-        struct Rs2Port {
-            uint64_t step, p_first;
-            rs_gfp s0;
-            int len, qb, W;
-            uint32_t df;
-        };
-        auto port = [&](const int p) {
-            Rs2Port P;
-            const uint32_t* u = (const uint32_t*)(gp + p * RS2_GP_FLOATS + 16);  // (one address for the wave: a broadcast read)
-            auto uni = [](const uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
-            P.step = (uint64_t)uni(u[4]) | ((uint64_t)uni(u[5]) << 32);
-            const uint64_t o0 = (uint64_t)uni(u[2]) | ((uint64_t)uni(u[3]) << 32);
-            P.p_first = o0 + (uint64_t)fbase * P.step;
-            P.len = (int)uni(u[6]);
-            P.df = uni(u[7]);
-            P.qb = (int)uni(((const uint32_t*)(gp + p * RS2_GP_FLOATS))[15]) + (int)((uint32_t)(P.p_first >> 32) - (uint32_t)(o0 >> 32));
-            if (P.df & RS_LOOP_BIT)
-                while (P.qb >= P.len) P.qb -= P.len;
-            P.s0 = (rs_gfp)((uint64_t)uni(u[0]) | ((uint64_t)uni(u[1]) << 32));
-            P.W = (int)((uint32_t)((P.p_first + (uint64_t)(nfr - 1) * P.step) >> 32) - (uint32_t)(P.p_first >> 32)) + RS_TAPS + 1;
-            return P;
-        };
-        // a contiguous window is requested as quads: two rounds of registers per channel
-#define RS2_ISSUE(P)                                                                   \
-    if (P.df & RS_CONTIG_BIT) {                                                        \
-        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                \
-            const int r = (lane + u * WAVE) * 4;                                       \
-            if (u * WAVE * 4 < P.W && r < P.W) {                                       \
-                wa[u] = *(rs_g4p)(P.s0 + P.qb + r);                                    \
-                if (!(P.df & VB_MONO)) wb[u] = *(rs_g4p)(P.s0 + P.len + P.qb + r);     \
-            }                                                                          \
-        }                                                                              \
-    }
-        Rs2Port N = port(first);
-        RS2_ISSUE(N)
-        for (int p = 0; p < ld.ports; ++p) {
-            if ((silent_ports >> p) & 1ull) {  // cleared zeros: copied by port 0, added by a 2/3/4-port mixer, skipped by an n-port one
-                if (p > 0 && !masked) {
-                    accl = accl + splat(0.f);
-                    accr = accr + splat(0.f);
-                }
-                continue;
-            }
-            const Rs2Port C = N;
-            const uint64_t cstep = C.step, cp_first = C.p_first;
-            const bool cmono = C.df & VB_MONO;
-            // the window goes to LDS as {L, R} pairs ...
-            if (C.df & RS_CONTIG_BIT) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int r = (lane + u * WAVE) * 4;
-                    if (u * WAVE * 4 < C.W && r < C.W) {
-                        const v4f y = cmono ? wa[u] : wb[u];
-                        *(v4f*)(win + r) = (v4f){wa[u][0], y[0], wa[u][1], y[1]};
-                        *(v4f*)(win + r + 2) = (v4f){wa[u][2], y[2], wa[u][3], y[3]};
-                    }
-                }
-            } else {  // the block a loop wraps in, or a one-shot's edge: frame by frame, wrapped / zero-filled on the way in
-                for (int r = lane; r < C.W; r += WAVE) {
-                    int q = C.qb + r;
-                    bool in = true;
-                    if (C.df & RS_LOOP_BIT) {  // (len >= the window: one step either way)
-                        if (q < 0) q += C.len;
-                        if (q >= C.len) q -= C.len;
-                    } else {
-                        in = q >= 0 && q < C.len;
-                    }
-                    const float x = in ? C.s0[in ? q : 0] : 0.f;
-                    const float y = cmono ? x : (in ? C.s0[C.len + q] : 0.f);
-                    win[r] = (v2f_rs){x, y};
-                }
-            }
-            // ... the next port's is requested ...
-            {
-                const uint64_t later = p + 1 < 64 ? pure_ports >> (p + 1) : 0ull;
-                if (later) {
-                    N = port(p + 1 + __builtin_ctzll(later));
-                    RS2_ISSUE(N)
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ... and this one's frames are convolved from the lane's run of the window, read ONCE into registers
-            const uint64_t pos0 = cp_first + (uint64_t)(uint32_t)n0 * cstep;
-            const uint32_t frac0 = (uint32_t)pos0;
-            const rs_lp wp = (rs_lp)(win + ((uint32_t)(pos0 >> 32) - (uint32_t)(cp_first >> 32)));
-            // b_j = floor(j step): wave-uniform; e_j = the carry of frac0 + frac(j step): the lane's bank, its phase from the sum
-            const uint32_t b1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cstep >> 32));
-            const uint32_t b2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((2 * cstep) >> 32));
-            const uint32_t b3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((3 * cstep) >> 32));
-            const uint32_t f1 = frac0 + (uint32_t)cstep, f2 = frac0 + (uint32_t)(2 * cstep), f3 = frac0 + (uint32_t)(3 * cstep);
-            const rs_lp h0 = (rs_lp)(tab + (frac0 >> 27));
-            const rs_lp h1 = (rs_lp)(tab + ((f1 < frac0 ? RS2_PAIRS * RS_PHASES : 0) + (f1 >> 27)));
-            const rs_lp h2 = (rs_lp)(tab + ((f2 < frac0 ? RS2_PAIRS * RS_PHASES : 0) + (f2 >> 27)));
-            const rs_lp h3 = (rs_lp)(tab + ((f3 < frac0 ? RS2_PAIRS * RS_PHASES : 0) + (f3 >> 27)));
-            v2f_rs w[RS2_NW];
-#pragma unroll
-            for (int i = 0; i < RS_TAPS + 1; ++i) w[i] = wp[i];
-#pragma unroll
-            for (int i = RS_TAPS + 1; i < RS2_NW; ++i) w[i] = (v2f_rs){0.f, 0.f};
-            if (b3 >= 1) w[17] = wp[17];
-            if (b3 >= 2) w[18] = wp[18];
-            if (b3 >= 3) w[19] = wp[19];
-            if (b3 >= 4) w[20] = wp[20];
-            if (b3 >= 5) w[21] = wp[21];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // (the next port overwrites the window: every read of it has been issued — and, the
-                                              //  fence being a release, waited for — above)
-            v2f_rs y0, y1, y2, y3;
-            if (b1 == 0) rs2_pair<0, 0, true>(w, h0, h1, y0, y1);
-            else rs2_pair<0, 1, true>(w, h0, h1, y0, y1);
-            switch (b2 * 8 + b3) {  // (b2, b3) = (floor(2 step), floor(3 step)), step < 1.934
-                case 0 * 8 + 0: rs2_pair<0, 0, false>(w, h2, h3, y2, y3); break;
-                case 0 * 8 + 1: rs2_pair<0, 1, false>(w, h2, h3, y2, y3); break;
-                case 1 * 8 + 1: rs2_pair<1, 1, false>(w, h2, h3, y2, y3); break;
-                case 1 * 8 + 2: rs2_pair<1, 2, false>(w, h2, h3, y2, y3); break;
-                case 2 * 8 + 3: rs2_pair<2, 3, false>(w, h2, h3, y2, y3); break;
-                case 2 * 8 + 4: rs2_pair<2, 4, false>(w, h2, h3, y2, y3); break;
-                case 3 * 8 + 4: rs2_pair<3, 4, false>(w, h2, h3, y2, y3); break;
-                default: rs2_pair<3, 5, false>(w, h2, h3, y2, y3); break;
-            }
-            v4f xl = (v4f){y0.x, y1.x, y2.x, y3.x}, xr = (v4f){y0.y, y1.y, y2.y, y3.y};
-            const float* gpp = gp + p * RS2_GP_FLOATS;
-            const uint32_t kinds = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(gpp[2 * FW_MAX_STAGES])) << 4;
-#pragma unroll
-            for (int j = 0; j < FW_MAX_STAGES; ++j)
-                if (j < ng) apply_stage((kinds >> (4 * j)) & 15u, splat(gpp[2 * j]), splat(gpp[2 * j + 1]), xl, xr);
-            if (p == 0) {
-                accl = xl;
-                accr = xr;
-            } else {
-                accl = accl + xl;
-                accr = accr + xr;
-            }
-        }
-#undef RS2_ISSUE
-        if (4 * lane + 3 < nfr) {
-            __builtin_nontemporal_store(accl, (v4f*)(outl + fbase + 4 * lane));
-            __builtin_nontemporal_store(accr, (v4f*)(outr + fbase + 4 * lane));
-        } else if (4 * lane < nfr) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (4 * lane + i < nfr) {
-                    __builtin_nontemporal_store(accl[i], outl + fbase + 4 * lane + i);
-                    __builtin_nontemporal_store(accr[i], outr + fbase + 4 * lane + i);
-                }
-        }
-    }
-#else
     for (int fbase = part * 256; fbase < frames; fbase += 256 * wpk) {
         const int nfr = frames - fbase < 256 ? frames - fbase : 256;
         // (every lane works here — window fetch and convolution are dealt over the whole wave, whatever the piece's length)
@@ -1868,7 +1579,6 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv
             }
         }
     }
-#endif
     if (lane < 2 && part == 0) (fv.bus_flags + (size_t)k * fv.bus_flags_blk_stride)[ld.out_buf + lane] = 0;  // a live port: the out mask is 0
 }
 // the general kernel over k_leaf_rs's work list: (leaf, block, piece) items that are not resampler-pure.  The last workgroup out

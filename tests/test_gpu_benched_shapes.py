@@ -454,12 +454,12 @@ def test_node_state_after_lazily_rendered_blocks_is_the_control_paths_state():
 
 @pytest.mark.parametrize("mbf,max_batch", [(256, 16), (64, 8), (100, 4), (512, 4), (90, 3)])
 def test_resampler_bank_every_register_window_variant_bit_exact(mbf, max_batch):
-    """Round 5, k_leaf_rs: a lane owns four consecutive frames and reads ONE run of the window into registers; the chains are template
-    variants by (floor(step), floor(2 step), floor(3 step)), the per-lane carry picks one of two coefficient banks (a 17-tap chain with a
-    zero coefficient at one end).  Ratios in every variant's range and on its edges, ratios where the lanes' runs collide in the LDS
-    banks (0.8, 1.0, 1.15, 4/3, 1.6), the last pure ratio and the first one the general kernel takes (>= 2), loops that wrap inside
-    the run, one-shots that end in it, mono sources; block lengths whose last lane owns 1-3 frames (90) and that are shorter than a
-    piece (64, 100) or longer (512: two pieces per block)."""
+    """Resampler-pure leaves (k_leaf_rs) over the ratio axis.  Written for round 5's register-window kernel (a lane owning four
+    consecutive frames, chains as template variants by (floor(step), floor(2 step), floor(3 step)): scripts/experiments/
+    r05_rs_register_window.patch — bit-exact, slower, not kept) and kept for the kernel that stayed: ratios in every such range and on
+    its edges, ratios where window reads collide in the LDS banks (0.8, 1.0, 1.15, 4/3, 1.6), the last ratio a 256-frame piece's
+    window fits (1.93) and ratios the general kernel takes (>= 2), loops that wrap inside a window, one-shots that end in it, mono
+    sources; block lengths that are no multiple of 4 frames per lane (90), shorter than a piece (64, 100) or longer (512)."""
     ratios = [0.2, 1.0 / 3.0, 0.3334, 0.49999, 0.5, 0.61, 2.0 / 3.0, 0.6667, 0.8, 0.91875, 0.99999, 1.0, 1.00001, 1.15, 1.3333, 4.0 / 3.0,
               1.41, 1.5, 1.50001, 1.6, 5.0 / 3.0, 1.6667, 1.9, 1.93, 1.99999, 2.0, 2.5, 0.75, 1.25, 1.088, 0.0371, 1.75]
 
@@ -493,4 +493,88 @@ def test_resampler_bank_every_register_window_variant_bit_exact(mbf, max_batch):
     g = GpuEngine(max_block_frames=mbf, max_batch=max_batch)
     out_g = run(g)
     assert g.cx.plan_kind() == 1
+    assert np.array_equal(bits(out_g), bits(out_o))
+
+
+@pytest.mark.parametrize("shape,mbf,max_batch", [("bank", 64, 8), ("bank", 256, 1), ("chain", 128, 4), ("hybrid", 64, 8)])
+def test_one_output_samplers_behind_the_mono_to_stereo_adapter_are_voices_of_the_fused_plans(shape, mbf, max_batch):
+    """VERDICT r4 missing #4: `sampler(0 -> 1) -> MonoToStereoNode` (mono_to_stereo.rs:33-50, the reference's own adapter) in front of a
+    gain chain fell off every fused plan.  Round 5: such a voice is a voice of the bank / chain / hybrid plans whose every block is
+    VB_MONO — channel 0 of whatever sample it plays: mono and stereo samples, all six formats, one-shots that end, pauses, a sample
+    swap to another format, gain glides; stereo samplers beside them under the same mixers.  Every call against the oracle."""
+    import fwapi as fw
+
+    def run(e):
+        rng = np.random.default_rng(5)
+        ends, voices = [], []
+        fmts = [fw.PLANAR_F32, fw.INTERLEAVED_I16, fw.PLANAR_I16, fw.INTERLEAVED_F32, fw.PLANAR_U16, fw.INTERLEAVED_U16]
+        samples = []
+        for v in range(22):
+            ch = 1 if v % 4 == 1 else 2
+            fmt = fmts[v % 6]
+            data = scenarios.voice_source(9900 + v, 1100 + 13 * v, ch)
+            if fmt in (fw.PLANAR_F32, fw.INTERLEAVED_F32):
+                raw = data if fmt == fw.PLANAR_F32 else data.T.copy()
+            elif fmt in (fw.PLANAR_I16, fw.INTERLEAVED_I16):
+                q = np.round(data * 32767).astype(np.int16)
+                raw = q if fmt == fw.PLANAR_I16 else q.T.copy()
+            else:
+                q = (np.round(data * 32767).astype(np.int32) + 32768).astype(np.uint16)
+                raw = q if fmt == fw.PLANAR_U16 else q.T.copy()
+            samples.append(e.new_sample(fmt, ch, raw))
+            mono_voice = v % 3 != 2
+            s = e.sampler(float(rng.uniform(40, 100)), n_out=1 if mono_voice else 2)
+            cur = s
+            if mono_voice:
+                m2s = e.add_node(fw.MONO_TO_STEREO, 1, 2)
+                e.connect(s, 0, m2s, 0)
+                cur = m2s
+            if shape == "chain" and v % 5 == 2 and not mono_voice:   # (stereo voices with a filter: the plan is the chain plan, the adapter voices its dry ones)
+                bq = e.biquad(0, 900.0 + 50 * v)
+                e.connect_stereo(cur, bq)
+                cur = bq
+            vol = e.volume(float(rng.uniform(20, 110)))
+            e.connect_stereo(cur, vol)
+            pan = e.pan(float(rng.uniform(-1, 1)))
+            e.connect_stereo(vol, pan)
+            ends.append(pan)
+            voices.append((s, vol))
+        mixers = []
+        for i in range(0, len(ends), 8):
+            m = e.sum(8)
+            for p, n in enumerate(ends[i:i + 8]):
+                e.connect_stereo(n, m, 2 * p)
+            mixers.append(m)
+        top = e.sum(len(mixers) + (1 if shape == "hybrid" else 0))
+        for p, m in enumerate(mixers):
+            e.connect_stereo(m, top, 2 * p)
+        if shape == "hybrid":   # a send off the first mixer through a delay: no fused shape as a whole
+            dl = e.delay(0.01, 0.3, 0.5)
+            e.connect_stereo(mixers[0], dl)
+            e.connect_stereo(dl, top, 2 * len(mixers))
+        e.connect_stereo(top, e.graph_out_node)
+        e.update()
+        for v, (s, vol) in enumerate(voices):
+            e.sampler_set_sample(s, samples[v])
+            if v % 5 != 4:
+                e.sampler_set_loop_range(s, LOOP_FULL)      # v % 5 == 4: one-shots, they end inside the run
+            if v % 7 != 6:
+                e.sampler_play(s)
+        outs = [np.asarray(e.process_blocks(3))]
+        e.set_param(voices[0][1], 0, 15.0)                   # a glide behind an adapter voice
+        e.sampler_pause(voices[3][0])
+        outs.append(np.asarray(e.process_blocks(max_batch + 2)))
+        e.sampler_set_sample(voices[1][0], samples[6])       # an adapter voice takes another voice's sample (another format)
+        e.sampler_play(voices[3][0])
+        e.sampler_play(voices[6][0])
+        outs.append(np.asarray(e.process_blocks(2 * max_batch + 1)))
+        outs.append(np.asarray(e.process_blocks(9)))
+        return np.concatenate(outs)
+
+    out_o = run(scenarios.TaggedOracle(OracleEngine(max_block_frames=mbf)))
+    g = GpuEngine(max_block_frames=mbf, max_batch=max_batch)
+    out_g = run(g)
+    assert g.cx.plan_kind() == {"bank": 1, "chain": 2, "hybrid": 3}[shape]
+    if shape != "hybrid":
+        assert g.cx.plan_fused_voices() == 22
     assert np.array_equal(bits(out_g), bits(out_o))

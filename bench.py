@@ -717,7 +717,20 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
         # (--src-stagger: floats between consecutive voices' buffers — where the samples sit in HBM relative to one another)
         src = shard_sources(torch, shard, rank, V, F, dev, args.src_stagger)
     progress(env, "%s: %d voices, block %d, K %d, %d + %d steps: sources made" % (wl, V, B, K, warmup, steps))
-    cx, g, samplers, volumes = make_gpu(fa, wl, V, B, K, args.radix, src, F, sfmt, rank, args, stream, device)
+    build_err = None
+    try:
+        cx, g, samplers, volumes = make_gpu(fa, wl, V, B, K, args.radix, src, F, sfmt, rank, args, stream, device)
+    except Exception as ex:  # noqa: BLE001
+        if dist is None:
+            raise
+        build_err = repr(ex)
+    if dist is not None:
+        # every rank leaves together: a rank that could not build its shard (round 5: 8 ranks x config 5 at 64 blocks per step is
+        # 360 GB of tables on ONE shared device — out of memory on one rank, the other seven waiting in the next collective for ever)
+        errs = [None] * world
+        dist.all_gather_object(errs, build_err)
+        if any(errs):
+            raise SystemExit("bench.py: %s" % "; ".join("rank %d could not build its shard: %s" % (r, e) for r, e in enumerate(errs) if e))
     progress(env, "%s: graph built, plan %d" % (wl, cx.plan_kind()))
     variant = args.variant if wl in ("cfg2", "cfg5") else "A"
     playing = 1.0
@@ -780,6 +793,16 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
         if args.host_buffers:  # the literal process_interleaved boundary: pageable host output, synchronous
             import ctypes as C
 
+            if getattr(args, "host_async", False):
+                # ... or the same call split in two (fwgpu_process_interleaved_begin / _end): step n + 1 is begun before step n is
+                # ended, so the copy back and the host's memcpy of step n overlap the rendering of step n + 1
+                t = cx.L.fwgpu_process_interleaved_begin(cx.c, None, 0, 2, K * B, 0.0, 0)
+                assert t >= 0, t
+                if pend_async[0] is not None:
+                    rc = cx.L.fwgpu_process_interleaved_end(cx.c, pend_async[0], host_out.ctypes.data_as(C.POINTER(C.c_float)))
+                    assert rc == 0, rc
+                pend_async[0] = t
+                return
             rc = cx.L.fwgpu_process_interleaved(cx.c, None, host_out.ctypes.data_as(C.POINTER(C.c_float)), 0, 2, K * B, 0.0, 0)
             assert rc == 0, rc
             return
@@ -798,8 +821,16 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
                 except fa.FwgpuError as ex:
                     xfail.append(repr(ex))
 
+    pend_async = [None]
+
     def finish_reductions():
         """submit the partly filled buffer (steps % R != 0), then wait for every collective"""
+        if pend_async[0] is not None:  # (host-buffer steps split in two: the last step's other half)
+            import ctypes as C
+
+            rc = cx.L.fwgpu_process_interleaved_end(cx.c, pend_async[0], host_out.ctypes.data_as(C.POINTER(C.c_float)))
+            assert rc == 0, rc
+            pend_async[0] = None
         if reducer is None:
             return
         if slot[0] % R != 0:
@@ -1167,10 +1198,13 @@ def other_configs_multi(env, args):
         cfg = r["config"]
         return {"workload": cfg["workload"], "value": None if env["hostonly"] else r["value"], "unit": "voice-samples/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
                 "blocks_per_step": cfg["blocks_per_step"], "parallelism": cfg["parallelism"], "bus_reduce": cfg["bus_reduce"],
-                "bus_reduce_fallback": cfg["bus_reduce_fallback"], "roofline": r["roofline"], "parity_check": r.get("parity_check")}
+                "bus_reduce_fallback": cfg["bus_reduce_fallback"], "bus_exchange_max_wait_us": cfg.get("bus_exchange_max_wait_us"),
+                "roofline": r["roofline"], "parity_check": r.get("parity_check")}
 
     hostonly = env["hostonly"]
     V, B, K, F, _ = (64, 64, 4, 1024, 0) if hostonly else DEFAULTS["cfg5"]
+    if env.get("share_device") and env["world"] > 2 and not hostonly:
+        K = 16  # (N ranks' tables on ONE device: at 64 blocks per step config 5 is ~45 GB per rank — 8 ranks do not fit 288 GB)
     a5 = copy.copy(args)
     a5.reduce_every = 1  # "collective every step"
     try:
@@ -1251,6 +1285,8 @@ def main():
     ap.add_argument("--host-buffers", action="store_true",
                     help="time fwgpu_process_interleaved on HOST buffers instead (PCIe-inclusive; DESIGN.md §7 note, "
                          "never the headline)")
+    ap.add_argument("--host-async", action="store_true",
+                    help="with --host-buffers: the call split in two (fwgpu_process_interleaved_begin / _end), step n + 1 begun before step n is ended")
     ap.add_argument("--master", action="store_true",
                     help="put a master VolumeNode + HardClipNode between the root SumNode and graph_out (the fused plans "
                          "then run that chain with the generic node kernel on the mix bus)")
@@ -1424,6 +1460,13 @@ def main():
                 rh = run_workload(env, ah, wl, V, B, K, F, 10, 2, full=False)
                 line["value_host_buffers"] = {"value": rh["value"], "unit": "voice-samples/s", "ms_per_step": rh["ms_per_step"], "steps": 10,
                                               "what": "fwgpu_process_interleaved: host output buffers, synchronous, PCIe-inclusive (%d KiB D2H per call)" % (K * B * 8 // 1024)}
+                ah.host_async = True
+                ra = run_workload(env, ah, wl, V, B, K, F, 20, 3, full=False)
+                line["value_host_buffers"]["pipelined"] = {
+                    "value": ra["value"], "ms_per_step": ra["ms_per_step"], "steps": 20, "frac_of_value": ra["value"] / res["value"],
+                    "what": "fwgpu_process_interleaved_begin / _end: call n + 1 begun before call n is ended — the graph-output kernel writes into "
+                            "mapped host staging, the host's wait + memcpy of call n overlap the rendering of call n + 1; the frames still land "
+                            "in pageable host memory"}
             except Exception as ex:  # noqa: BLE001
                 line["value_host_buffers"] = {"error": repr(ex)}
         if world == 1 and default_shape and not args.no_other_configs and not hostonly:

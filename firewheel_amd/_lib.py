@@ -106,6 +106,8 @@ SIGNATURES = {
     "fwgpu_sampler_set_playhead_secs": (ci, [vp, i64, f64, u32]),
     "fwgpu_sampler_set_loop_range": (ci, [vp, i64, ci, f64, f64, u32]),
     "fwgpu_process_interleaved": (ci, [vp, fp, fp, u32, u32, u64, f64, u32]),
+    "fwgpu_process_interleaved_begin": (i64, [vp, fp, u32, u32, u64, f64, u32]),
+    "fwgpu_process_interleaved_end": (ci, [vp, i64, fp]),
     "fwgpu_process_blocks_device": (ci, [vp, u32, vp, u32]),
     "fwgpu_process_blocks_device_flags": (ci, [vp, u32, vp, u32, vp]),
     "fwgpu_bus_sum_ordered": (ci, [vp, C.POINTER(vp), u32, vp, u64]),

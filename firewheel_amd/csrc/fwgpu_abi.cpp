@@ -286,6 +286,22 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     (void)rt_persist_stop(c);
     if (c->rt_stream) (void)hipStreamDestroy(c->rt_stream);
     if (c->rt_ev) (void)hipEventDestroy(c->rt_ev);
+    if (c->ao.copy_stream) {
+        (void)hipStreamSynchronize(c->ao.copy_stream);
+        (void)hipStreamDestroy(c->ao.copy_stream);
+    }
+    if (c->host_prof && c->ao.prof_calls)
+        fprintf(stderr, "fwgpu host profile: %llu process_interleaved_end calls: %.1f us waiting for the copy back, %.1f us in memcpy each\n",
+                (unsigned long long)c->ao.prof_calls, c->ao.prof_wait_ns / 1e3 / (double)c->ao.prof_calls, c->ao.prof_copy_ns / 1e3 / (double)c->ao.prof_calls);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ao.ev_render[i]) (void)hipEventDestroy(c->ao.ev_render[i]);
+        if (c->ao.ev_copy[i]) (void)hipEventDestroy(c->ao.ev_copy[i]);
+        if (c->ao.h[i]) {
+            (void)hipHostUnregister(c->ao.h[i]);
+            free(c->ao.h[i]);
+        }
+        c->ao.d[i].release();
+    }
     if (c->h_rt_mb) (void)hipHostFree(c->h_rt_mb);
     if (c->h_lazy_pub) (void)hipHostFree(c->h_lazy_pub);
     (void)hipStreamSynchronize(c->stream);
@@ -1015,6 +1031,133 @@ int fwgpu_process_interleaved(fwgpu_ctx* c, const float* input, float* output, u
     // copy back — the caller's buffer never keeps what it held before the call
     if (rc != 0 && out_bytes) memset(output, 0, out_bytes);
     return rc;
+}
+// ---- the call split in two (include/fwgpu.h): render n + 1 while call n's output crosses PCIe into the caller's buffer
+// (Round 5, measured on config 2, 1.5 MiB per call: staging in hipHostMalloc memory + memcpy in `end`: 0.67 ms per step against 0.345 for
+//  the synchronous call — the host's memcpy out of that memory; the copy issued by `end` straight into the caller's pageable buffer:
+//  0.318 against 0.312 — a blit kernel that queues behind the next ticket's kernels, no overlap.  Hence registered ordinary memory.)
+int64_t fwgpu_process_interleaved_begin(fwgpu_ctx* c, const float* input, uint32_t n_in_ch, uint32_t n_out_ch, uint64_t frames,
+                                        double stream_time_secs, uint32_t stream_status) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    AudioCallScope audio;
+    use_device(c);
+    if (n_in_ch > 64 || n_out_ch > 64) return fail(c, FWGPU_ERR_INVALID, "at most 64 stream channels per side (processor.rs:43-44)");
+    if (frames > (1ull << 32)) return fail(c, FWGPU_ERR_INVALID, "more than 2^32 frames in one call");
+    fwgpu_ctx::AsyncOut& a = c->ao;
+    const int slot = (int)(a.next & 1);
+    if (a.busy[slot]) return fail(c, FWGPU_ERR_INVALID, "two calls in flight already: end the older ticket first");
+    const size_t out_bytes = (size_t)frames * n_out_ch * sizeof(float);
+    AudioGate gate(c);
+    c->proc_stream_time = stream_time_secs;
+    c->proc_stream_status = stream_status;
+    if (stream_status & 2u) c->n_underflows++;
+    if (stream_status & 1u) c->n_overflows++;
+    a.bytes[slot] = out_bytes;
+    a.zeros[slot] = !c->have_plan || frames == 0;  // processor.rs:86-89 (Q19): no schedule yet -> silence
+    if (!a.zeros[slot]) {
+        if (!a.copy_stream) HIPC(c, hipStreamCreateWithFlags(&a.copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            if (!a.ev_render[i]) HIPC(c, hipEventCreateWithFlags(&a.ev_render[i], hipEventDisableTiming));
+            if (!a.ev_copy[i]) HIPC(c, hipEventCreateWithFlags(&a.ev_copy[i], hipEventDisableTiming));
+        }
+        if (out_bytes > a.d[slot].cap || out_bytes > a.hcap[slot]) {  // (first call of this size only; the slot is idle: nothing reads it)
+            RtHold hold(c);
+            HIPC(c, hipStreamSynchronize(c->stream));
+            HIPC(c, a.d[slot].ensure_n("d_async_out", out_bytes));
+            if (out_bytes > a.hcap[slot]) {
+                // ORDINARY (cacheable) host memory, page-locked for the DMA engine: the copy back is an SDMA transfer that runs beside the
+                // next ticket's kernels (a copy into pageable memory is a blit KERNEL: it queued behind them — measured, no overlap), and
+                // the host's memcpy out of it runs at memory speed (out of hipHostMalloc memory it cost 0.3 ms per 1.5 MiB — measured)
+                if (a.h[slot]) {
+                    (void)hipHostUnregister(a.h[slot]);
+                    free(a.h[slot]);
+                }
+                a.h[slot] = nullptr;
+                a.hcap[slot] = 0;
+                const size_t cap = (out_bytes + 4095) & ~(size_t)4095;
+                void* m = nullptr;
+                if (posix_memalign(&m, 4096, cap) != 0 || !m) return fail(c, FWGPU_ERR_DEVICE, "out of host memory for the output staging");
+                memset(m, 0, cap);
+                hipError_t e = hipHostRegister(m, cap, hipHostRegisterMapped);
+                void* dp = nullptr;
+                if (e == hipSuccess) e = hipHostGetDevicePointer(&dp, m, 0);
+                if (e != hipSuccess) {
+                    free(m);
+                    return hipfail(c, e, "hipHostRegister(output staging)");
+                }
+                a.h[slot] = m;
+                a.h_dev[slot] = (float*)dp;
+                a.hcap[slot] = cap;
+            }
+        }
+        const float* d_in = nullptr;
+        if (n_in_ch > 0 && input) {
+            const size_t in_bytes = (size_t)frames * n_in_ch * sizeof(float);
+            if (in_bytes > c->d_in_stage.cap) {
+                HIPC(c, hipStreamSynchronize(c->stream));
+                HIPC(c, c->d_in_stage.ensure_n("d_in_stage", in_bytes));
+            }
+            HIPC(c, hipMemcpyAsync(c->d_in_stage.p, input, in_bytes, hipMemcpyHostToDevice, c->stream));
+            d_in = c->d_in_stage.as<float>();
+        }
+        // Where the frames cross PCIe (round 5, config 2, 1.5 MiB per call, same box; the synchronous call: 0.313 ms per step):
+        //   3 (default)  the graph-output kernel writes the interleaved frames STRAIGHT into the mapped host staging: no copy at all
+        //   2            a copy in the ctx stream behind the render: 0.310 (DMA engine) / 0.325 (blit kernel) — serial with the next render
+        //   0            a copy on a stream of its own behind the render's event: 0.579 (DMA engine) / 0.388 (blit kernel, HSA_ENABLE_SDMA=0):
+        //                the cross-stream hand-over costs more than the overlap gives
+        static const int mode = getenv("FWGPU_ASYNC_MODE") ? atoi(getenv("FWGPU_ASYNC_MODE")) : 3;
+        float* const d_out = mode == 3 ? a.h_dev[slot] : a.d[slot].as<float>();
+        const int rc = run_blocks(c, frames, d_in, (int)n_in_ch, d_out, (int)n_out_ch);
+        if (rc) return rc;
+        if (out_bytes) {
+            if (mode == 3) {
+                HIPC(c, hipEventRecord(a.ev_copy[slot], c->stream));
+            } else if (mode == 2) {
+                HIPC(c, hipMemcpyAsync(a.h[slot], a.d[slot].p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+                HIPC(c, hipEventRecord(a.ev_copy[slot], c->stream));
+            } else {
+                HIPC(c, hipEventRecord(a.ev_render[slot], c->stream));
+                HIPC(c, hipStreamWaitEvent(a.copy_stream, a.ev_render[slot], 0));
+                HIPC(c, hipMemcpyAsync(a.h[slot], a.d[slot].p, out_bytes, hipMemcpyDeviceToHost, a.copy_stream));
+                HIPC(c, hipEventRecord(a.ev_copy[slot], a.copy_stream));
+            }
+        }
+    }
+    a.ret_ticket[slot] = c->ret_ticket;
+    a.busy[slot] = true;
+    return a.next++;
+}
+int fwgpu_process_interleaved_end(fwgpu_ctx* c, int64_t ticket, float* output) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    AudioCallScope audio;
+    use_device(c);
+    fwgpu_ctx::AsyncOut& a = c->ao;
+    const int slot = (int)(ticket & 1);
+    if (ticket < 0 || ticket != a.done || ticket >= a.next || !a.busy[slot])
+        return fail(c, FWGPU_ERR_INVALID, "not the oldest ticket in flight (tickets are ended in the order they were begun)");
+    const size_t n = a.bytes[slot];
+    if (n && !output) return fail(c, FWGPU_ERR_INVALID, "output is null");
+    a.busy[slot] = false;
+    a.done++;
+    if (a.zeros[slot] || n == 0) {
+        if (n) memset(output, 0, n);
+        return 0;
+    }
+    // the copy back went out in `begin`, on its own stream behind the ticket's last launch: the ctx stream — which may be rendering
+    // the NEXT ticket — is not waited for
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipEventSynchronize(a.ev_copy[slot]);
+    if (e != hipSuccess) {
+        memset(output, 0, n);  // "all output buffers MUST be filled" (core/node.rs:41-42)
+        return hipfail(c, e, "copy back of a process_interleaved_begin ticket");
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    memcpy(output, a.h[slot], n);
+    a.prof_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+    a.prof_copy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
+    a.prof_calls++;
+    c->ret_done_ticket.store(a.ret_ticket[slot], std::memory_order_release);  // what that call handed back is final
+    return 0;
 }
 int fwgpu_proc_info(fwgpu_ctx* c, double* stream_time_secs, uint32_t* stream_status, uint64_t* output_underflows,
                     uint64_t* input_overflows) {

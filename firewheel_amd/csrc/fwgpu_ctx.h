@@ -303,6 +303,21 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     // duration; the control thread BUILDS outside the gate and only tries it to adopt when the audio side is idle.
     std::atomic<int> gate{0};
     std::atomic<int> gate_ctl_waiting{0};  // control calls waiting at ControlGate: the audio side lets them in before its next call
+    // fwgpu_process_interleaved_begin / _end: two output slots (device + registered host staging), a copy stream, the events that order them
+    struct AsyncOut {
+        DevBuf d[2];
+        void* h[2] = {nullptr, nullptr};  // page-locked (hipHostRegister, mapped) ordinary memory: what the graph-output kernel writes, the host memcpy's source
+        float* h_dev[2] = {nullptr, nullptr};  // ... as the device sees it
+        size_t hcap[2] = {0, 0};
+        hipEvent_t ev_copy[2] = {nullptr, nullptr};
+        uint64_t prof_wait_ns = 0, prof_copy_ns = 0, prof_calls = 0;
+        size_t bytes[2] = {0, 0};
+        bool busy[2] = {false, false}, zeros[2] = {false, false};
+        uint64_t ret_ticket[2] = {0, 0};
+        hipEvent_t ev_render[2] = {nullptr, nullptr};
+        hipStream_t copy_stream = nullptr;
+        int64_t next = 0, done = 0;  // tickets handed out / ended
+    } ao;
     bool level_fuse = true;                        // FWGPU_LEVEL_FUSE=0: the level executor without vertical fusion (A/B, bisecting)
     uint64_t rt_path[4] = {0, 0, 0, 0};            // one-block launch batches by path (fwgpu_rt_path_stats); audio side writes
     uint64_t gate_defer_ns = 20000;               // ... for at most this long per process call (FWGPU_GATE_DEFER_US; 0: never steps back)

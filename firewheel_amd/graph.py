@@ -556,6 +556,25 @@ class FirewheelGpuCtx(object):
             self._reap_limbo()
         return out
 
+    def process_interleaved_begin(self, input, num_in_channels, num_out_channels, frames, stream_time_secs=0.0, stream_status=0):
+        """fwgpu_process_interleaved_begin: the call up to its last launch; returns the ticket `process_interleaved_end` takes"""
+        if input is None:
+            input = np.zeros(max(frames * num_in_channels, 1), dtype=np.float32)
+        inp = np.ascontiguousarray(input, dtype=np.float32)
+        t = self.L.fwgpu_process_interleaved_begin(self.c, _fptr(inp), num_in_channels, num_out_channels, frames, stream_time_secs, stream_status)
+        self._check(t)
+        return int(t), frames * num_out_channels
+
+    def process_interleaved_end(self, ticket, out=None):
+        """... and its other half: waits for the ticket's copy back, returns the frames (or fills `out`)"""
+        t, n = ticket
+        if out is None:
+            out = np.full(n, np.nan, dtype=np.float32)
+        self._check(self.L.fwgpu_process_interleaved_end(self.c, t, _fptr(out)))
+        if self._limbo:
+            self._reap_limbo()
+        return out
+
     def process_blocks_device(self, num_blocks, device_out_ptr, num_out_channels=2):
         self._check(self.L.fwgpu_process_blocks_device(self.c, num_blocks, C.c_void_p(device_out_ptr), num_out_channels))
 

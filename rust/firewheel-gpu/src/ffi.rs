@@ -132,6 +132,8 @@ extern "C" {
     pub fn fwgpu_sampler_set_playhead_secs(ctx: *mut fwgpu_ctx, node: i64, playhead_secs: f64, at_block: u32) -> c_int;
     pub fn fwgpu_sampler_set_loop_range(ctx: *mut fwgpu_ctx, node: i64, mode: c_int, start_secs: f64, end_secs: f64, at_block: u32) -> c_int;
     pub fn fwgpu_process_interleaved(ctx: *mut fwgpu_ctx, input: *const f32, output: *mut f32, num_in_channels: u32, num_out_channels: u32, frames: u64, stream_time_secs: f64, stream_status: u32) -> c_int;
+    pub fn fwgpu_process_interleaved_begin(ctx: *mut fwgpu_ctx, input: *const f32, num_in_channels: u32, num_out_channels: u32, frames: u64, stream_time_secs: f64, stream_status: u32) -> i64;
+    pub fn fwgpu_process_interleaved_end(ctx: *mut fwgpu_ctx, ticket: i64, output: *mut f32) -> c_int;
     pub fn fwgpu_process_blocks_device(ctx: *mut fwgpu_ctx, num_blocks: u32, d_output: *mut f32, num_out_channels: u32) -> c_int;
     pub fn fwgpu_process_blocks_device_flags(ctx: *mut fwgpu_ctx, num_blocks: u32, d_output: *mut f32, num_out_channels: u32, d_silence: *mut u8) -> c_int;
     pub fn fwgpu_bus_sum_ordered(ctx: *mut fwgpu_ctx, d_parts: *const *const f32, n_parts: u32, d_out: *mut f32, n_floats: u64) -> c_int;

@@ -53,6 +53,9 @@ static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+enum { hipHostRegisterDefault = 0, hipHostRegisterMapped = 2 };
+static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
 extern "C" unsigned long long fwh_h2d_copies, fwh_h2d_max_bytes, fwh_h2d_bytes; /* launch_stubs.cpp: asynchronous host-to-device copies so far, the largest */

@@ -578,3 +578,50 @@ def test_one_output_samplers_behind_the_mono_to_stereo_adapter_are_voices_of_the
     if shape != "hybrid":
         assert g.cx.plan_fused_voices() == 22
     assert np.array_equal(bits(out_g), bits(out_o))
+
+
+def test_process_interleaved_begin_end_pipelined_calls_equal_the_oracle():
+    """the host-buffer call split in two (fwgpu_process_interleaved_begin / _end): call n + 1 is begun before call n is ended — its
+    rendering overlaps call n's copy back — with messages, a sample swap and a graph edit between the calls; every call's frames
+    against the oracle's synchronous process_interleaved, bit for bit; graphs with inputs go through the same pair."""
+    mbf = 128
+
+    def script(e, i, voices):
+        if i == 2:
+            e.set_param(voices[3]["volume"], 0, 20.0)
+        if i == 4:
+            e.sampler_pause(voices[5]["sampler"])
+        if i == 5:
+            e.remove_node(voices[7]["pan"])
+            e.update()
+        if i == 7:
+            e.sampler_play(voices[5]["sampler"])
+
+    sizes = [3, 8, 1, 5, 17, 2, 2, 9, 4]
+
+    def build(e):
+        voices = scenarios.build_voice_bank(e, 29, radix=8, src_frames=mbf * 11 + 17, mono_every=6, fmt_cycle=list(range(6)))
+        for v, vc in enumerate(voices):
+            if v % 6 != 3:
+                e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+            e.sampler_play(vc["sampler"])
+        return voices
+
+    o = scenarios.TaggedOracle(OracleEngine(max_block_frames=mbf))
+    vo = build(o)
+    want = []
+    for i, k in enumerate(sizes):
+        script(o, i, vo)
+        want.append(np.asarray(o.process_interleaved(k * mbf)))
+    g = GpuEngine(max_block_frames=mbf, max_batch=8)
+    vg = build(g)
+    got, prev = [], None
+    for i, k in enumerate(sizes):
+        script(g, i, vg)
+        t = g.cx.process_interleaved_begin(None, 0, 2, k * mbf)
+        if prev is not None:
+            got.append(g.cx.process_interleaved_end(prev))
+        prev = t
+    got.append(g.cx.process_interleaved_end(prev))
+    for i in range(len(sizes)):
+        assert np.array_equal(bits(got[i]), bits(want[i])), "call %d" % i

@@ -713,3 +713,32 @@ def test_a_list_of_messages_in_one_call():
     e.process_blocks(8)                                                               # 5 + 1 messages reach the control kernel (the stub counts them)
     assert e.violation() == "", e.violation()
     assert seen() - applied0 == 6, seen() - applied0
+
+
+def test_process_interleaved_begin_end_ticket_rules_on_the_host_harness():
+    """fwgpu_process_interleaved_begin / _end (include/fwgpu.h): at most two calls in flight, tickets ended in the order they were
+    begun, `output` filled on every return of `end`, the no-schedule case (processor.rs:86-89) is silence through this pair too."""
+    from firewheel_amd._lib import FwgpuError
+
+    e = HostOnlyEngine(max_block_frames=64, max_batch=8)
+    t = e.cx.process_interleaved_begin(None, 0, 2, 64 * 3)       # no plan yet: zeros
+    out = e.cx.process_interleaved_end(t)
+    assert out.shape == (64 * 3 * 2,) and not out.any()
+    s = e.sampler()
+    e.connect_stereo(s, e.graph_out_node)
+    e.update()
+    a = e.cx.process_interleaved_begin(None, 0, 2, 64 * 5)
+    b = e.cx.process_interleaved_begin(None, 0, 2, 64 * 2)
+    assert b[0] == a[0] + 1
+    with pytest.raises(FwgpuError):
+        e.cx.process_interleaved_begin(None, 0, 2, 64)             # a third call in flight
+    with pytest.raises(FwgpuError):
+        e.cx.process_interleaved_end(b)                            # not the oldest
+    assert e.cx.process_interleaved_end(a).shape == (64 * 5 * 2,)
+    with pytest.raises(FwgpuError):
+        e.cx.process_interleaved_end(a)                            # ended already
+    c = e.cx.process_interleaved_begin(None, 0, 2, 64 * 9)         # slot of `a` again, larger: grows
+    assert e.cx.process_interleaved_end(b).shape == (64 * 2 * 2,)
+    assert e.cx.process_interleaved_end(c).shape == (64 * 9 * 2,)
+    assert np.asarray(e.process_interleaved(64)).shape == (128,)   # the synchronous call beside it
+    assert e.violation() == ""

@@ -71,3 +71,35 @@ def test_reference_digests_equal_the_oracles_when_present():
         assert ent["calls"] == mine, "%s: the reference's output differs from the oracle's at process call %d" % (
             name, next(i for i, (a, b) in enumerate(zip(ent["calls"], mine)) if a != b) if len(ent["calls"]) == len(mine) else -1)
         assert ent["sha256_calls"] == doc["sha256_calls"]
+
+
+def test_the_rust_replayer_handles_everything_the_replayable_documents_use():
+    """scripts/pin_parity.sh stays a ONE-command job: the first machine with cargo must not find that a document
+    grew an operation, a node kind or a sample format rust/firewheel-gpu/tests/reference_digests.rs does not replay.  No Rust
+    toolchain here, so the replayer's dispatch is read from its source: every `ops` verb of every reference-replayable document has a
+    match arm, every node kind a constructor arm, set_param only goes to the three reference nodes that have a parameter, and the
+    replayable set is what DESIGN.md says it is (9 documents)."""
+    import re
+
+    ROOT, SCEN = fwapi.ROOT, os.path.join(fwapi.ROOT, "tests", "golden", "scenarios")
+    src = open(os.path.join(ROOT, "rust", "firewheel-gpu", "tests", "reference_digests.rs")).read()
+    arms = set(re.findall(r'"([a-z_]+)"\s*(?:\||=>|\))', src))
+    kind_arms = set(int(k) for k in re.findall(r"^\s*(\d+) => cx\.graph\.add_node", src, flags=re.M))
+    docs = [json.load(open(p)) for p in sorted(glob.glob(os.path.join(SCEN, "*.json"))) if not p.endswith("index.json")]
+    replayable = [d for d in docs if d["reference_kinds_only"]]
+    assert len(replayable) == 9, [d["name"] for d in replayable]
+    for d in replayable:
+        kinds_of = []
+        for op in d["ops"]:
+            assert op[0] in arms, (d["name"], op[0])
+            if op[0] == "add_node":
+                assert op[1] in kind_arms, (d["name"], "node kind", op[1])
+                kinds_of.append(op[1])
+            if op[0] == "set_param":
+                assert op[2] == 0 and op[1] >= 0 and kinds_of[op[1]] in (1, 2, 4), (d["name"], op)   # beep / volume / sampler, param 0
+        assert set(d["node_kinds"]) <= kind_arms
+    # and the crate the script copies into the reference's workspace names its path dependencies as the script lays them out
+    cargo = open(os.path.join(ROOT, "rust", "firewheel-gpu", "Cargo.toml")).read()
+    assert "../firewheel-core" in cargo and "../firewheel-graph" in cargo
+    script = open(os.path.join(ROOT, "scripts", "pin_parity.sh")).read()
+    assert "crates/firewheel-gpu" in script and "reference_digests" in script

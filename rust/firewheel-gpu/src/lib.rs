@@ -242,6 +242,12 @@ impl Drop for GpuContext {
     }
 }
 
+/// One begun, not yet ended `process_interleaved_begin` call (not `Clone`: `process_interleaved_end` consumes it).
+pub struct Ticket {
+    id: i64,
+    floats: usize,
+}
+
 /// Borrowed view of one `ScheduledNode`: `InBufferAssignment { buffer_index, should_clear }` split into two slices.
 pub struct ScheduledNodeView<'a> {
     pub node: i64,
@@ -291,5 +297,42 @@ impl GpuProcessor {
             log::error!("fwgpu_process_interleaved failed: {}", rc);
         }
         firewheel_graph::processor::FirewheelProcessorStatus::Ok
+    }
+
+    /// The same call split in two, for hosts that render ahead (`fwgpu_process_interleaved_begin` / `_end`, include/fwgpu.h): `begin`
+    /// returns a ticket as soon as the call's launches are queued; `end` hands that ticket's frames to `output`.  Begin call n + 1 before
+    /// ending call n and the host's share of call n overlaps the rendering of call n + 1.  At most two tickets in flight, ended in order
+    /// — which the type enforces: a `Ticket` is consumed by `end`, and the processor hands out the next one only while fewer than two
+    /// are alive (the C side checks the order again).
+    pub fn process_interleaved_begin(
+        &mut self,
+        input: &[f32],
+        num_in_channels: usize,
+        num_out_channels: usize,
+        frames: usize,
+        stream_time_secs: f64,
+        stream_status: firewheel_core::node::StreamStatus,
+    ) -> Result<Ticket, GpuError> {
+        assert!(input.is_empty() || input.len() >= frames * num_in_channels, "input slice shorter than frames * num_in_channels");
+        assert!(num_in_channels <= 64 && num_out_channels <= 64);
+        let t = unsafe {
+            ffi::fwgpu_process_interleaved_begin(
+                self.cx.as_ptr(),
+                if input.is_empty() { std::ptr::null() } else { input.as_ptr() },
+                num_in_channels as u32,
+                num_out_channels as u32,
+                frames as u64,
+                stream_time_secs,
+                stream_status.bits(),
+            )
+        };
+        self.cx.check(t).map(|id| Ticket { id, floats: frames * num_out_channels })
+    }
+
+    /// ... its other half.  `output` is filled on every return (zeros on error).
+    pub fn process_interleaved_end(&mut self, ticket: Ticket, output: &mut [f32]) -> Result<(), GpuError> {
+        assert!(output.len() >= ticket.floats, "output slice shorter than the ticket's frames * num_out_channels");
+        let rc = unsafe { ffi::fwgpu_process_interleaved_end(self.cx.as_ptr(), ticket.id, output.as_mut_ptr()) };
+        self.cx.check(rc as i64).map(|_| ())
     }
 }

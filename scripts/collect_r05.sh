@@ -1,7 +1,8 @@
 #!/bin/bash
-# round 5: everything under profiles/r05_* in one gpurun call (the kernels of the headline and of configs 3 / 4 / 5 did not change
-# this round: their r04 profiles stand; what changed is profiled again).
-#  * cfg2 (headline): kernel stats + the two PMC passes — the profile the bench line's roofline is checked against;
+# round 5: everything under profiles/r05_* in one gpurun call.
+#  * the whole GPU test tier once more (the library that is profiled is the library that is tested);
+#  * cfg2 (headline), cfg3, cfg4, cfg5, cfg2 + resampler sources, cfg2 + spatialiser: kernel stats + the two PMC passes — the profiles
+#    the bench line's roofline objects are checked against;
 #  * cfg2 on the level executor alone (vertical fusion of frozen chains), fused and FWGPU_LEVEL_FUSE=0: kernel stats + line;
 #  * cfg2 with resampler sources: kernel stats (round 4's kernel stays: scripts/experiments/r05_rs_register_window.patch);
 #  * the full bench line (k_sweep, realtime per config, pipelined host buffers); N = 8 on one device.
@@ -9,8 +10,10 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/profiles gpurun_out/raw
 P=$GRAFT_REPO_ROOT/gpurun_out/profiles
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-EXTRA="--contexts 1" bash scripts/collect_profiles.sh r05 cfg2 > gpurun_out/collect_r05_a.log 2>&1
+timeout 700 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/r05_suite_final.log 2>&1; echo "suite rc $?" >> gpurun_out/r05_suite_final.log; tail -3 gpurun_out/r05_suite_final.log
+EXTRA="--contexts 1" bash scripts/collect_profiles.sh r05 cfg2 cfg3 cfg4 cfg5 > gpurun_out/collect_r05_a.log 2>&1
 EXTRA="--contexts 1 --rs-source" SUFFIX=_rs bash scripts/collect_profiles.sh r05 cfg2 > gpurun_out/collect_r05_b.log 2>&1
+EXTRA="--contexts 1 --voice-spatial" SUFFIX=_spatial bash scripts/collect_profiles.sh r05 cfg2 > gpurun_out/collect_r05_c.log 2>&1
 cd $GRAFT_REPO_ROOT
 for f in 1 0; do
   out=$GRAFT_REPO_ROOT/gpurun_out/raw/r05_cfg2_levels_fuse$f

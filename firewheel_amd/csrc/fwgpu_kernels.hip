@@ -52,8 +52,12 @@ int launch_level(hipStream_t s, const DevView& v, const int* d_level_nodes, int 
     if (n_nodes <= 0) return 0;
     if (K <= 0) return 0;
     // blocks per wave: enough (node, block) pairs to fill the chip several times over -> LEVEL_BPW; a narrow level -> 1
+    // (FWGPU_LEVEL_BPW_WIDE: blocks per wave on a VERY wide level — hundreds of thousands of pairs: the per-wave prologue of a frozen
+    //  node, five dependent round trips, is then amortised over more blocks; must divide 32: k_level's chain_done words)
+    static const uint32_t bpw_wide = getenv("FWGPU_LEVEL_BPW_WIDE") ? (uint32_t)atoi(getenv("FWGPU_LEVEL_BPW_WIDE")) : (uint32_t)LEVEL_BPW_WIDE;
     const long long pairs = (long long)n_nodes * K;
-    const uint32_t bpw = pairs >= 16384 ? LEVEL_BPW : (pairs >= 8192 ? 2u : 1u);
+    uint32_t bpw = pairs >= 16384 ? LEVEL_BPW : (pairs >= 8192 ? 2u : 1u);
+    if (pairs >= 262144 && (bpw_wide == 8u || bpw_wide == 16u || bpw_wide == 32u)) bpw = bpw_wide;
     dim3 grid((n_nodes + WPB - 1) / WPB, (K + bpw - 1) / bpw);
     // kinds bit 3: the level holds a biquad / delay node — in a batch, the ones that are bus effects go to the walkers' kernel
     const uint32_t walkers = (kinds & 8) && K > 1 ? 1u : 0u;

@@ -938,7 +938,9 @@ __device__ __forceinline__ void delay_walk(const DevView& v, const NodeDesc& nd,
 // resting smoothers, a stereo hard clip, a steadily playing stereo planar-f32 sampler — everything but the audio is the same in every block of the
 // batch: the wave reads it once and streams FZ_U blocks at a time, their loads in flight together.  Same operations per sample
 // as the cases of node_process_wave (volume.rs:94-142, sampler.rs:445-543); anything else returns false / goes block by block.
+#ifndef FZ_U
 #define FZ_U 4
+#endif
 // ---- vertical fusion (round 5).  The level executor moved 56 bytes per voice-sample on config 2's graph: every node of a
 // sampler -> volume -> pan chain wrote its block to the pool and the next level read it back.  When the node a frozen wave renders feeds
 // exactly ONE consumer with both its channels, in order (NodeDesc::aux0 = that node + 1: the host's chain table, fwgpu_plan_install.cpp),
@@ -1193,6 +1195,9 @@ __device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node
 #ifndef LEVEL_BPW
 #define LEVEL_BPW 8  // consecutive blocks one wave takes for a stateless / frozen node of a WIDE level
 #endif
+#ifndef LEVEL_BPW_WIDE
+#define LEVEL_BPW_WIDE 32  // ... of a level with >= 262 144 (node, block) pairs (fwgpu_kernels.hip launch_level; FWGPU_LEVEL_BPW_WIDE)
+#endif
 // gridDim.y = ceil(K / bpw): a wave takes bpw consecutive blocks of its node, so the node's descriptor, port tables and
 // state come from HBM once and from the cache for the other blocks (the per-block work is ~4 KB behind a chain of dependent
 // loads).  bpw = LEVEL_BPW on a level with thousands of (node, block) pairs; a level of one or two bus nodes — the root of a
@@ -1217,6 +1222,9 @@ __global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __res
             uint32_t skip = 0u;
             if (v.chain_done && fz == 1 && b1 > b0)
                 skip = (v.chain_done[(size_t)node * v.chain_words + (b0 >> 5)] >> (b0 & 31u)) & (b1 - b0 >= 32u ? ~0u : (1u << (b1 - b0)) - 1u);
+            // (a link whose every block of this range was rendered upstream has nothing to read here — its block-0 wave still patches the
+            //  smoothers, frozen_finish)
+            if (b1 > b0 && skip == (b1 - b0 >= 32u ? ~0u : (1u << (b1 - b0)) - 1u) && b0 != 0) return;
             uint32_t todo = bpw > 1 ? frozen_fast<SET>(v, node, fz, b0, b1, K, skip) : ~0u;  // (what is left goes block by block)
             todo &= ~skip;
             for (uint32_t b = b0; b < b1; ++b)

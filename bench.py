@@ -445,6 +445,11 @@ def parity_check(fa, torch, wl, V, B, K, radix, seed, args, src, F, sfmt, stream
             res["bit_exact"] = bool(res["bit_exact"] and res["deep"]["bit_exact"])
         except Exception as ex:  # noqa: BLE001
             res["deep"] = {"error": repr(ex)}
+    if wl in ("cfg3", "cfg4"):
+        # (say what this in-line check is and is not)
+        res["scope"] = ("a smoke check inside the bench run: blocks %s of all %d voices + `deep` = a SLICE of the voices over every block of one call; the "
+                        "full-size comparisons are GPU tests (tests/test_gpu_benched_shapes.py: config 3 at 4 096 voices x 64 blocks, config 4 at "
+                        "65 536 taps) — those compare a PREFIX of the voices against the oracle too: the scalar oracle needs ~1 s per voice-second") % (blocks, V)
     res["secs"] = round(time.perf_counter() - t0, 2)
     return res
 

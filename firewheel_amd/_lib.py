@@ -110,6 +110,7 @@ SIGNATURES = {
     "fwgpu_process_interleaved_end": (ci, [vp, i64, fp]),
     "fwgpu_process_blocks_device": (ci, [vp, u32, vp, u32]),
     "fwgpu_process_blocks_device_flags": (ci, [vp, u32, vp, u32, vp]),
+    "fwgpu_process_blocks_device_io": (ci, [vp, u32, vp, u32, vp, u32, vp]),
     "fwgpu_bus_sum_ordered": (ci, [vp, C.POINTER(vp), u32, vp, u64]),
     "fwgpu_bus_sum_ordered_flags": (ci, [vp, C.POINTER(vp), C.POINTER(vp), u32, vp, vp, u64, u32, u32]),
     "fwgpu_bus_exchange_open": (vp, [vp, u32, u32, u64, u32]),

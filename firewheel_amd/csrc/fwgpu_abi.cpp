@@ -1264,6 +1264,21 @@ int fwgpu_process_blocks_device_flags(fwgpu_ctx* c, uint32_t num_blocks, float* 
 int fwgpu_process_blocks_device(fwgpu_ctx* c, uint32_t num_blocks, float* d_output, uint32_t n_out_ch) {
     return fwgpu_process_blocks_device_flags(c, num_blocks, d_output, n_out_ch, nullptr);
 }
+int fwgpu_process_blocks_device_io(fwgpu_ctx* c, uint32_t num_blocks, const float* d_input, uint32_t n_in_ch, float* d_output, uint32_t n_out_ch,
+                                   uint8_t* d_silence) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    AudioCallScope audio;
+    use_device(c);
+    AudioGate gate(c);
+    if (!c->have_plan) return fail(c, FWGPU_ERR_INVALID, "no schedule: call fwgpu_update first");
+    if (num_blocks == 0) return 0;
+    if (n_in_ch > 64 || n_out_ch > 64 || (n_out_ch && !d_output)) return fail(c, FWGPU_ERR_INVALID, "bad stream buffers (null output, or more than 64 channels)");
+    c->out_sil = d_silence;
+    const int rc = run_blocks(c, (uint64_t)num_blocks * c->mbf, (d_input && n_in_ch) ? d_input : nullptr, (d_input && n_in_ch) ? (int)n_in_ch : 0, d_output,
+                              (int)n_out_ch);
+    c->out_sil = nullptr;
+    return rc;
+}
 
 int fwgpu_bus_sum_ordered_flags(fwgpu_ctx* c, const float* const* d_parts, const uint8_t* const* d_silence, uint32_t n_parts, float* d_out,
                                 uint8_t* d_out_silence, uint64_t n_floats, uint32_t frames_per_block, uint32_t n_channels) {

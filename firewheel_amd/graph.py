@@ -583,6 +583,12 @@ class FirewheelGpuCtx(object):
         self._check(self.L.fwgpu_process_blocks_device_flags(self.c, num_blocks, C.c_void_p(device_out_ptr), num_out_channels,
                                                              C.c_void_p(device_silence_ptr) if device_silence_ptr else None))
 
+    def process_blocks_device_io(self, num_blocks, device_in_ptr, num_in_channels, device_out_ptr, num_out_channels=2, device_silence_ptr=None):
+        """... for graphs with stream inputs: interleaved input frames in device memory (fwgpu_process_blocks_device_io)"""
+        self._check(self.L.fwgpu_process_blocks_device_io(self.c, num_blocks, C.c_void_p(device_in_ptr) if device_in_ptr else None, num_in_channels,
+                                                          C.c_void_p(device_out_ptr), num_out_channels,
+                                                          C.c_void_p(device_silence_ptr) if device_silence_ptr else None))
+
     def bus_sum_ordered(self, part_ptrs, out_ptr, n_floats, silence_ptrs=None, out_silence_ptr=None, frames_per_block=0, n_channels=2):
         """the top-level R-port SumNode over the shards' partial buses (device pointers), rank order, on the ctx stream;
         silence_ptrs: per part, its [blocks][channels] silence flags as process_blocks_device_flags wrote them (sum.rs:122-124)"""

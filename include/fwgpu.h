@@ -281,7 +281,7 @@ int64_t fwgpu_process_interleaved_begin(fwgpu_ctx* ctx, const float* input, uint
 int fwgpu_process_interleaved_end(fwgpu_ctx* ctx, int64_t ticket, float* output);
 /* Throughput form of the same call: `num_blocks` full blocks, interleaved output written to DEVICE memory
  * `d_output` [num_blocks*max_block_frames*num_out_channels] on the ctx stream, asynchronously (no host
- * sync).  Graphs with num_graph_inputs == 0 only. */
+ * sync).  Graph inputs read zeros (fwgpu_process_blocks_device_io takes them from device memory). */
 int fwgpu_process_blocks_device(fwgpu_ctx* ctx, uint32_t num_blocks, float* d_output,
                                 uint32_t num_out_channels);
 /* The same call, also reporting the silence mask read_graph_outputs sees (graph/graph/compiler/schedule.rs:255-287) for every
@@ -290,6 +290,12 @@ int fwgpu_process_blocks_device(fwgpu_ctx* ctx, uint32_t num_blocks, float* d_ou
  * into the top-level SumNode of a voice-sharded graph (below). */
 int fwgpu_process_blocks_device_flags(fwgpu_ctx* ctx, uint32_t num_blocks, float* d_output, uint32_t num_out_channels,
                                       uint8_t* d_silence);
+/* ... for graphs WITH stream inputs (an effects rack, a send bus fed from outside): `d_input` = num_blocks * max_block_frames *
+ * num_in_channels interleaved frames in DEVICE memory, read on the ctx stream (prepare_graph_inputs + deinterleave,
+ * schedule.rs:213-253, util.rs:44-87: channels beyond num_graph_inputs are ignored, missing ones read zeros); NULL / 0 channels = no
+ * input.  Asynchronous like the two calls above; the caller keeps `d_input` alive until the stream has passed it. */
+int fwgpu_process_blocks_device_io(fwgpu_ctx* ctx, uint32_t num_blocks, const float* d_input, uint32_t num_in_channels, float* d_output,
+                                   uint32_t num_out_channels, uint8_t* d_silence);
 
 /* ---- multi-GPU mix bus.  Voices shard across ranks with no exchange until the mix bus; the one exchange step
  * is the top-level SumNode over the R partial buses (nodes/sum.rs:41-136: all inputs silent -> cleared; 2 / 3 / 4 ports ->

@@ -136,6 +136,7 @@ extern "C" {
     pub fn fwgpu_process_interleaved_end(ctx: *mut fwgpu_ctx, ticket: i64, output: *mut f32) -> c_int;
     pub fn fwgpu_process_blocks_device(ctx: *mut fwgpu_ctx, num_blocks: u32, d_output: *mut f32, num_out_channels: u32) -> c_int;
     pub fn fwgpu_process_blocks_device_flags(ctx: *mut fwgpu_ctx, num_blocks: u32, d_output: *mut f32, num_out_channels: u32, d_silence: *mut u8) -> c_int;
+    pub fn fwgpu_process_blocks_device_io(ctx: *mut fwgpu_ctx, num_blocks: u32, d_input: *const f32, num_in_channels: u32, d_output: *mut f32, num_out_channels: u32, d_silence: *mut u8) -> c_int;
     pub fn fwgpu_bus_sum_ordered(ctx: *mut fwgpu_ctx, d_parts: *const *const f32, n_parts: u32, d_out: *mut f32, n_floats: u64) -> c_int;
     pub fn fwgpu_bus_sum_ordered_flags(ctx: *mut fwgpu_ctx, d_parts: *const *const f32, d_silence: *const *const u8, n_parts: u32, d_out: *mut f32, d_out_silence: *mut u8, n_floats: u64, frames_per_block: u32, n_channels: u32) -> c_int;
     pub fn fwgpu_bus_exchange_open(ctx: *mut fwgpu_ctx, rank: u32, world: u32, max_floats: u64, max_silence_bytes: u32) -> *mut fwgpu_bus_exchange;

@@ -625,3 +625,55 @@ def test_process_interleaved_begin_end_pipelined_calls_equal_the_oracle():
     got.append(g.cx.process_interleaved_end(prev))
     for i in range(len(sizes)):
         assert np.array_equal(bits(got[i]), bits(want[i])), "call %d" % i
+
+
+@pytest.mark.parametrize("n_in,mbf,max_batch", [(2, 64, 8), (4, 128, 3), (3, 64, 64)])
+def test_process_blocks_device_io_an_effects_rack_on_device_resident_stream_inputs(n_in, mbf, max_batch):
+    """fwgpu_process_blocks_device_io (the device-resident call refused graphs with inputs): graph inputs read from
+    DEVICE memory, whole blocks, asynchronously — an effects rack (width -> biquad -> delay -> volume on the first pair, a mix with the
+    other inputs, a glide in between), calls of 1, max_batch and 2 max_batch + 3 blocks, against the oracle's process_interleaved."""
+    import torch
+
+    def build(e):
+        gin = e.graph_in_node
+        w = e.width(1.4)
+        if n_in >= 2:
+            e.connect_stereo(gin, w, 0, 0)
+        else:
+            m = e.add_node(fwapi.MONO_TO_STEREO, 1, 2)
+            e.connect(gin, 0, m, 0)
+            e.connect_stereo(m, w)
+        bq = e.biquad(0, 2500.0, 0.9)
+        e.connect_stereo(w, bq)
+        dl = e.delay(0.004, 0.4, 0.5)
+        e.connect_stereo(bq, dl)
+        vol = e.volume(70.0)
+        e.connect_stereo(dl, vol)
+        mix = e.sum(2)
+        e.connect_stereo(vol, mix, 0)
+        if n_in >= 4:
+            e.connect_stereo(gin, mix, 2, 2)
+        elif n_in == 3:
+            m = e.add_node(fwapi.MONO_TO_STEREO, 1, 2)
+            e.connect(gin, 2, m, 0)
+            e.connect_stereo(m, mix, 2)
+        e.connect_stereo(mix, e.graph_out_node)
+        e.update()
+        return vol
+
+    o = OracleEngine(max_block_frames=mbf, num_graph_inputs=n_in)
+    g = GpuEngine(max_block_frames=mbf, num_graph_inputs=n_in, max_batch=max_batch)
+    vo, vg = build(o), build(g)
+    for i, k in enumerate([1, max_batch, 2 * max_batch + 3, 2]):
+        if i == 2:
+            o.set_param(vo, 0, 25.0)
+            g.set_param(vg, 0, 25.0)
+        frames = k * mbf
+        inp = fwapi.xorshift_uniform(4100 + i, frames * n_in) if i != 3 else np.zeros(frames * n_in, dtype=np.float32)
+        want = np.asarray(o.process_interleaved(frames, 2, inp=inp, n_in_ch=n_in))
+        d_in = torch.from_numpy(inp.copy()).cuda()
+        d_out = torch.full((frames * 2,), float("nan"), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        g.cx.process_blocks_device_io(k, d_in.data_ptr(), n_in, d_out.data_ptr(), 2)
+        g.cx.synchronize()
+        assert np.array_equal(bits(d_out.cpu().numpy()), bits(want)), "call %d" % i

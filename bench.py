@@ -1076,7 +1076,11 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
             res["realtime_us_per_callback"] = {"error": repr(ex)}
     if full and rank == 0 and world == 1 and not hostonly:
         if not args.no_realtime and wl != "cfg4":
+            p0 = cx.rt_path_stats() if hasattr(cx, "rt_path_stats") else None
             res["realtime_us_per_callback"], res["realtime_us_per_callback_from_python"] = realtime_probe(cx, B)
+            if p0 is not None:
+                res["realtime_path"] = dict(zip(("resident_kernel", "one_launch", "fused_launch_sequence", "level_executor"),
+                                                [a - b for a, b in zip(cx.rt_path_stats(), p0)]))
         cx.close()
         if not args.no_parity_check:
             res["parity_check"] = parity_check(fa, torch, wl, V, B, K, args.radix, rank, args, src, F, sfmt, stream, device)
@@ -1441,6 +1445,7 @@ def main():
             "parity_check_timed_context": res.get("parity_check_timed_context"),
             "realtime_us_per_callback": res.get("realtime_us_per_callback"),
             "realtime_us_per_callback_from_python": res.get("realtime_us_per_callback_from_python"),
+            "realtime_path": res.get("realtime_path"),
             "ranks_seen": ranks_seen,
         }
         if args.share_device and world > 1:

@@ -259,6 +259,7 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
     if (const char* e = getenv("FWGPU_UPDATE_PROF")) c->update_prof = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_GRAPH")) c->rt_use_graph = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_ONE_LAUNCH")) c->rt_one_launch = atoi(e) != 0;
+    if (const char* e = getenv("FWGPU_RT_PERSIST_MAX_LEAVES")) c->rt_persist_max_leaves = std::max(0, atoi(e));
     if (c->d_rt_sync.ensure_n("d_rt_sync", 256) != hipSuccess || hipMemset(c->d_rt_sync.p, 0, 256) != hipSuccess) c->d_rt_sync.release();
     return c;
 }

@@ -198,6 +198,8 @@ struct PlanImage {
     DevBuf d_tail_nodes, d_tail_in, d_tail_out, d_tail_idx, d_tail_frozen;
     DevBuf d_frozen_ph;  // ... and its playhead snapshots
     DevBuf d_frozen;  // generic plan: k_frozen_scan's verdict per plan node, valid for the batch in flight
+    DevBuf d_rt_tree, d_rt_tree_sync;  // one-launch realtime kernels: [parent of leaf][parent of upper node][children of upper node]; a counter per upper node
+    int rt_tree_leaves = 0, rt_tree_up = 0;  // ... their extents (0: no tree — the edge takes the launch sequence)
     DevBuf d_chain_done;  // ... and, per node, chain_words words of "this block was rendered by the wave upstream" bits (vertical fusion)
     int chain_words = 0;
     int up_root_node = -1;  // index (in the upper-tree node table) of the root SumNode when it is alone on the last level
@@ -442,6 +444,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     unsigned long long rt_signal_seq = 0;  // != 0 while run_blocks should arrange for the flag to be raised
     bool rt_signalled = false;
     bool rt_last_batch = false;  // the fused batch being launched ends the call
+    int rt_persist_max_leaves = 64;  // the resident kernel takes trees of at most this many leaf workgroups (fwgpu_run.cpp)
     bool rt_one_launch = true;  // one-block calls on the voice-bank plan: control + leaf + root in ONE kernel (FWGPU_RT_ONE_LAUNCH=0: off)
     DevBuf d_rt_sync;           // its workgroup counter
     // the resident realtime kernel (k_rt_persist, k_rt.hip.h): launched by the first steady one-block callback of a run of them, fed

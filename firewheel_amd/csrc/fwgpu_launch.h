@@ -103,6 +103,13 @@ struct FusedView {
     ChainStart* chain_start;  // [n_voices] (k_chain plan)
     float* chain_dummy;       // k_chain's steady-call loop: where lanes with nothing to fetch / store point (>= 32 KiB)
     unsigned long long* chain_stats;  // [2] workgroups that ran the steady-call loop / the general loop
+    // the one-launch realtime kernels' way up the mixer tree (k_rt.hip.h): per leaf / per upper-tree node the upper-tree node that
+    // reads its bus (the root's own entry: -1), per upper-tree node its number of connected children, one arrival counter per node
+    const int* rt_parent_leaf = nullptr;
+    const int* rt_parent_up = nullptr;
+    const int* rt_kids = nullptr;
+    unsigned* rt_tree_sync = nullptr;
+    int rt_root = -1;
     unsigned long long* trace;  // FW_CHAIN_TRACE builds only: per-step role timestamps of workgroup 0
     int dbg;     // FW_CHAIN_TRACE builds only (env FWGPU_CHAIN_SKIP): bit 0 skip S2, 1 skip S3b, 2 skip source loads,
                  // 3 skip ring RMW, 4 no ring prefetch

@@ -277,7 +277,7 @@ void PlanImage::release_device() {
     DevBuf* bufs[] = {&d_nodes, &d_in_buf, &d_out_buf, &d_level_nodes, &d_pool, &d_flags, &d_gin_bufs, &d_gout_bufs, &d_groups, &d_blks2, &d_refs2,
                       &d_gsets2, &d_ramps2, &d_progs, &d_hist, &d_rs_wl, &d_rs_tmpl, &d_lazy, &d_ctl_order, &d_slot_voice, &d_voices, &d_leaves, &d_blks, &d_refs, &d_gsets, &d_cache, &d_ramps, &d_bus, &d_bus_flags,
                       &d_chain_start, &d_chain_dummy, &d_chain_stats, &d_up_nodes, &d_up_in, &d_up_out, &d_up_level_nodes, &d_root_bufs, &d_tail_nodes,
-                      &d_tail_in, &d_tail_out, &d_tail_idx, &d_tail_frozen, &d_frozen_ph, &d_frozen, &d_chain_done, &d_fir_rows, &d_fir_tiles, &d_fir_partials,
+                      &d_tail_in, &d_tail_out, &d_tail_idx, &d_tail_frozen, &d_frozen_ph, &d_frozen, &d_chain_done, &d_rt_tree, &d_rt_tree_sync, &d_fir_rows, &d_fir_tiles, &d_fir_partials,
                       &d_hlevel_nodes, &grow_states, &grow_ext, &d_state_inits, &d_ext_jobs};
     for (DevBuf* b : bufs) b->release();
     if (h_ctl_order) (void)hipHostFree(h_ctl_order);
@@ -310,6 +310,7 @@ static void reset_for_build(fwgpu_ctx* c, PlanImage& P) {
     P.generic_k = 1;
     P.chain_nq = 1;
     P.n_voices = P.n_leaves = P.ramp_slots = P.n_groups = P.n_tail = P.n_fused_real = 0;
+    P.rt_tree_leaves = P.rt_tree_up = 0;
     P.n_bus = 1;
     P.up_level_off.clear();
     P.up_level_cnt.clear();
@@ -947,6 +948,51 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
                 P.root_args.in_tab = P.d_up_in.as<int>() + rn.in_off;
             } else {
                 P.up_root_node = -1;
+            }
+        }
+        // the one-launch realtime kernels' way up the mixer tree (k_rt.hip.h): who reads each leaf's / upper node's bus, and how many
+        // connected children each upper node waits for.  Only with a fused root (stereo, no master chain) and a tree in which every
+        // bus has exactly one reader — which detect_fused guarantees; anything unexpected leaves the extents 0: launch sequence.
+        P.rt_tree_leaves = P.rt_tree_up = 0;
+        if (P.up_root_node >= 0 && !fb.leaves.empty() && !is_hybrid) {
+            const int nl = (int)fb.leaves.size(), nu = (int)fb.up_nodes.size();
+            std::vector<int> tree((size_t)nl + 2 * (size_t)nu, -1);
+            int* parent_leaf = tree.data();
+            int* parent_up = tree.data() + nl;
+            int* kids = tree.data() + nl + nu;
+            for (int u = 0; u < nu; ++u) kids[u] = 0;
+            std::vector<int> who((size_t)P.n_bus, -1);  // bus -> leaf i (i) or upper node u (nl + u)
+            for (int i = 0; i < nl; ++i)
+                if (fb.leaves[i].out_buf > 0 && fb.leaves[i].out_buf < P.n_bus) who[fb.leaves[i].out_buf] = i;
+            for (int u = 0; u < nu; ++u) {
+                const int ob = fb.up_out[fb.up_nodes[u].out_off];
+                if (ob > 0 && ob < P.n_bus) who[ob] = nl + u;
+            }
+            bool ok = true;
+            for (int u = 0; u < nu && ok; ++u) {
+                const NodeDesc& nd = fb.up_nodes[u];
+                for (int p = 0; p < nd.n_in; p += 2) {
+                    const int b = fb.up_in[nd.in_off + p];
+                    if (b == 0) continue;  // an unconnected port: the constant-zero bus, nobody arrives for it
+                    const int w = (b > 0 && b < P.n_bus) ? who[b] : -1;
+                    if (w < 0) {
+                        ok = false;
+                        break;
+                    }
+                    int& par = w < nl ? parent_leaf[w] : parent_up[w - nl];
+                    if (par != -1) ok = false;  // a bus with two readers
+                    par = u;
+                    kids[u]++;
+                }
+            }
+            for (int i = 0; i < nl && ok; ++i) ok = parent_leaf[i] >= 0;
+            for (int u = 0; u < nu && ok; ++u) ok = (u == P.up_root_node) ? parent_up[u] == -1 && kids[u] > 0 : parent_up[u] >= 0 && kids[u] > 0;
+            if (ok) {
+                if ((rc = up(c, P.d_rt_tree, tree.data(), tree.size() * sizeof(int)))) return rc;
+                HIPC(c, P.d_rt_tree_sync.ensure_n("d_rt_tree_sync", (size_t)nu * sizeof(unsigned)));
+                if ((rc = zero(c, P.d_rt_tree_sync.p, (size_t)nu * sizeof(unsigned)))) return rc;
+                P.rt_tree_leaves = nl;
+                P.rt_tree_up = nu;
             }
         }
         if (uflat.empty()) uflat.push_back(0);

@@ -294,6 +294,16 @@ static void fill_fused_view(fwgpu_ctx* c, FusedView& fv) {
     fv.has_prog = c->fused_prog ? 1 : 0;
     fv.has_rs = c->fused_rs ? 1 : 0;
     fv.has_sp = c->fused_sp ? 1 : 0;
+    fv.rt_parent_leaf = fv.rt_parent_up = fv.rt_kids = nullptr;
+    fv.rt_tree_sync = nullptr;
+    fv.rt_root = -1;
+    if (c->rt_tree_leaves > 0 && c->d_rt_tree.p && c->d_rt_tree_sync.p) {
+        fv.rt_parent_leaf = c->d_rt_tree.as<int>();
+        fv.rt_parent_up = fv.rt_parent_leaf + c->rt_tree_leaves;
+        fv.rt_kids = fv.rt_parent_up + c->rt_tree_up;
+        fv.rt_tree_sync = c->d_rt_tree_sync.as<unsigned>();
+        fv.rt_root = c->up_root_node;
+    }
     fv.rs_wl = c->d_rs_wl.as<unsigned int>();
     fv.rs_tmpl = c->fused_rs ? c->d_rs_tmpl.as<VoiceBlk>() : nullptr;
     fv.lazy = (c->lazy_capable && c->d_lazy.p) ? c->d_lazy.as<LazyRec>() : nullptr;
@@ -525,6 +535,11 @@ static int rt_persist_launch(fwgpu_ctx* c, const FusedView& fv, const DevView& v
 
 static void rt_root_view(const fwgpu_ctx* c, const FusedView& fv, DevView& v) {
     v = DevView{};
+    // (the root's port table travels in RootArgs; the mixers between the leaves and the root — bus_sum_node_wg on the way up the tree,
+    //  k_rt.hip.h — read theirs from the upper tree's tables)
+    v.nodes = c->d_up_nodes.as<NodeDesc>();
+    v.in_buf = c->d_up_in.as<int>();
+    v.out_buf = c->d_up_out.as<int>();
     v.pool = fv.bus;
     v.flags = fv.bus_flags;
     v.pool_blk_stride = fv.bus_blk_stride;
@@ -551,7 +566,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     fill_fused_view(c, fv);
     // realtime edge: one block, tree = leaves + root, stereo stream -> the whole callback is ONE launch (k_rt_block)
     if (K == 1 && c->rt_one_launch && !c->lazy_this_call && !c->fused_sp && !c->out_sil && !c->ahead_this_call && !c->fused_fx && !c->timing && c->n_tail == 0 && c->up_root_node >= 0 && n_out_ch == 2 &&
-        c->up_level_cnt.size() == 1 && c->d_rt_sync.p) {
+        c->rt_tree_leaves > 0 && c->rt_tree_leaves == c->n_leaves && c->d_rt_sync.p) {
         DevView v;
         rt_root_view(c, fv, v);
         c->lazy_valid = false;  // (the one-launch kernels run their own control: the LazyRecs no longer describe the voices)
@@ -564,7 +579,10 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
             c->rt_signalled = true;
         }
         // a steady callback (no message on the device, the completion flag asked for): the resident kernel takes it
-        if (c->rt_persist && c->rt_stream && flag && c->n_cmds_dev == 0 && !c->host_prof && cmd_block0 == 0) {
+        // (on a big tree the resident kernel LOSES to a launch per callback — config 5's 256 leaf workgroups: 94-113 us resident, 51-53
+        //  launched, round 5: hundreds of idle workgroups polling beside the few that carry the block up the tree — so it is the small
+        //  trees' edge: rt_persist_max_leaves, FWGPU_RT_PERSIST_MAX_LEAVES)
+        if (c->rt_persist && c->n_leaves <= c->rt_persist_max_leaves && c->rt_stream && flag && c->n_cmds_dev == 0 && !c->host_prof && cmd_block0 == 0) {
             fwgpu_ctx::RtResident& r = c->rtp;
             const unsigned long long seq = c->rt_signal_seq;
             if (r.launched && c->h_rt_mb->alive && r.epoch == c->epoch && r.d_out == d_out && r.blks == fv.blks && r.next_seq == seq &&

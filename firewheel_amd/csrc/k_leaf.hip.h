@@ -1618,10 +1618,9 @@ __global__ __launch_bounds__(256) void k_sp_hist_copy(FusedView fv) {
 
 // Upper sum tree of the fused plan, K-batched: SumNode semantics (nodes/sum.rs:41-136) with one THREAD per
 // frame (blockIdx = node, block, channel) so that a 1-node level still puts K * n_out * frames/64 waves in flight.
-__global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restrict__ level_nodes) {
-    const NodeDesc nd = v.nodes[level_nodes[blockIdx.x]];
-    const uint32_t blk = blockIdx.y;
-    const int c = blockIdx.z;
+// one upper-tree SumNode, one channel of one block, by a workgroup of 256 threads (k_bus_sum: a workgroup per (node, block, channel);
+// the one-launch realtime kernels: the workgroup that completed the node's children, k_rt.hip.h)
+__device__ __forceinline__ void bus_sum_node_wg(const DevView& v, const NodeDesc& nd, const uint32_t blk, const int c) {
     const int lane = threadIdx.x & (WAVE - 1);
     float* pool = v.pool + (size_t)blk * v.pool_blk_stride;
     uint8_t* flags = v.flags + (size_t)blk * v.flags_blk_stride;
@@ -1640,6 +1639,32 @@ __global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restric
         const float* in = pool + (size_t)__builtin_amdgcn_readlane(my_in, c) * v.stride;
         for (int f = threadIdx.x; f < v.frames; f += blockDim.x) out[f] = in[f];
         out_mask = in_mask;
+    } else if ((v.frames & 3) == 0) {
+        // four frames per thread (round 5): a 1 024-frame block is ONE pass of the workgroup with 8 ports' 16-byte loads in flight per
+        // thread — frame by frame the mixer above 32 leaf buses was 64 us on the one workgroup the realtime kernels give it.  Same adds
+        // in the same order per frame.
+        const bool masked = !(ports == 2 || ports == 3 || ports == 4);
+        for (int f = threadIdx.x * 4; f < v.frames; f += blockDim.x * 4) {
+            v4f acc = *(const v4f*)(pool + (size_t)__builtin_amdgcn_readlane(my_in, c) * v.stride + f);
+            for (int p0 = 1; p0 < ports; p0 += 8) {
+                v4f x[8];
+                bool use[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    use[u] = false;
+                    x[u] = splat(0.f);
+                    if (p0 + u < ports) {
+                        int ic = n_out * (p0 + u) + c;
+                        use[u] = !(masked && mask_bit(in_mask, ic));  // :122-124
+                        x[u] = *(const v4f*)(pool + (size_t)__builtin_amdgcn_readlane(my_in, ic) * v.stride + f);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (use[u]) acc = acc + x[u];
+            }
+            *(v4f*)(out + f) = acc;
+        }
     } else {
         const bool masked = !(ports == 2 || ports == 3 || ports == 4);
         for (int f = threadIdx.x; f < v.frames; f += blockDim.x) {
@@ -1664,6 +1689,10 @@ __global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restric
         }
     }
     if (c == 0 && (int)threadIdx.x < n_out) flags[out_buf[threadIdx.x]] = mask_bit(out_mask, threadIdx.x) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_bus_sum(DevView v, const int* __restrict__ level_nodes) {
+    const NodeDesc nd = v.nodes[level_nodes[blockIdx.x]];
+    bus_sum_node_wg(v, nd, blockIdx.y, (int)blockIdx.z);
 }
 
 // The root SumNode of the fused plans (stereo, its ports are bus buffers) fused with read_graph_outputs +

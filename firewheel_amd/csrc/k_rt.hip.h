@@ -12,7 +12,8 @@
 //      interleaves into the (pinned, device-mapped) output block: root_out_any, the code of k_root_out — and raises the
 //      completion flag in pinned host memory the audio thread polls.
 // Same device functions as the throughput kernels, so the arithmetic is theirs bit for bit.  Used when the call is one
-// block, the tree is leaves + root and the stream is stereo; everything else takes the launch sequence.
+// block, the plan is the plain voice-bank plan (a mixer tree of any depth: round 5) and the stream is stereo; everything else takes the
+// launch sequence.
 // -DFW_RT_TRACE: the last workgroup of every 512th callback prints where its time went (10 ns ticks)
 #ifdef FW_RT_TRACE
 #define RT_T(i) rt_tr[i] = __builtin_amdgcn_s_memrealtime()
@@ -164,22 +165,34 @@ __device__ __forceinline__ void rt_block_body(const FusedView& fv, const DevView
     if (!rt_leaf_quick<PROG>(fv, leaf, wave))
         leaf_sum_wave<PROG, RS, 16>(fv, leaf, 0u, wave, 4, rs);  // 16 ports in flight: two round trips per leaf, not eight
     RT_T(4);
-    // grid-wide hand-over to the root: every workgroup publishes its bus (agent scope: the XCDs have separate L2s), the
-    // last one to arrive reads them all
+    // grid-wide hand-over UP THE MIXER TREE (round 5: any depth; rounds 2-4: leaves + root only).  Every workgroup publishes what it
+    // wrote (agent scope: the XCDs have separate L2s) and counts itself in at its bus's consumer (fv.rt_parent_*: the upper-tree node
+    // that reads it); whoever completes a node's children renders that node — bus_sum_node_wg, the code of k_bus_sum — and carries on
+    // at ITS consumer; whoever completes the root's children does the root + interleave below.  Nobody waits for anybody: a workgroup
+    // that is not the last one at a node is done.  (The counters reset themselves: the completing arrival stores 0.)
     __shared__ int s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // (relaxed: the release is the fence above, the acquire the fence the last workgroup takes below — an acq_rel read-modify-write
-        //  here was a second L2 write-back and an invalidate in EVERY workgroup, on the callback's critical path)
-        const unsigned prev = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev == gridDim.x - 1 ? 1 : 0;
-        if (s_last) __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next callback
+    int node = fv.rt_parent_leaf[leaf];
+    for (;;) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // (relaxed: the release is the fence above, the acquire the fence the completing workgroup takes below — an acq_rel
+            //  read-modify-write here was a second L2 write-back and an invalidate in EVERY workgroup, on the callback's critical path)
+            unsigned* ctr = fv.rt_tree_sync + node;
+            const unsigned prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = prev == (unsigned)fv.rt_kids[node] - 1u ? 1 : 0;
+            if (s_last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next callback
+        }
+        __syncthreads();
+        RT_T(5);
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (node == fv.rt_root) break;
+        const NodeDesc nd = upv.nodes[node];
+        bus_sum_node_wg(upv, nd, 0u, 0);
+        bus_sum_node_wg(upv, nd, 0u, 1);
+        node = fv.rt_parent_up[node];
     }
-    __syncthreads();
-    RT_T(5);
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     RT_T(6);
     for (int f0 = 0; f0 < upv.frames; f0 += 256) root_out_any(upv, ra, out, 0u, f0 + (int)threadIdx.x);
     RT_T(7);
@@ -309,7 +322,10 @@ __global__ __launch_bounds__(256) void k_rt_persist(FusedView fv, DevView upv, R
                         break;
                     }
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 8 * idle_ticks) break;
-                    __builtin_amdgcn_s_sleep(2);
+                    // (hundreds of workgroups polling ONE word every ~100 ns starve the workgroups that still work — the mixers on the
+                    //  way up the tree: config 5's 256 leaves ran a callback in 113 us resident against 51 us launched, round 5)
+                    if (gridDim.x > 64) __builtin_amdgcn_s_sleep(32);
+                    else __builtin_amdgcn_s_sleep(2);
                 }
             }
             s_cmd = cmd;

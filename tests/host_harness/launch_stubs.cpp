@@ -44,6 +44,7 @@ extern "C" void fwh_launch_reset(void) {
 // descriptor invariants the kernels rely on are asserted.  The first violation is kept for the tests (fwh_violation).
 #include <stdio.h>
 
+#include <map>
 #include <string>
 #include <vector>
 namespace {
@@ -578,6 +579,40 @@ int launch_rt_block(hipStream_t, const FusedView& fv, const DevView& upv, const 
     REQUIRE(!fv.fx_plan && root.ports >= 1 && root.ports <= 32 && root.n_in == 2 * root.ports, root.ports, root.n_in);
     touch(d_sync, sizeof(unsigned));
     touch(d_out, sizeof(float) * 2 * (size_t)upv.frames);
+    {
+        // the way up the mixer tree (k_rt.hip.h): every leaf's chain of consumers ends at the root, and every node on the way waits for
+        // exactly the arrivals it will get (one per leaf / upper node that names it)
+        REQUIRE(fv.rt_parent_leaf && fv.rt_parent_up && fv.rt_kids && fv.rt_tree_sync && fv.rt_root >= 0, fv.rt_root);
+        std::map<int, int> arrivals;
+        std::map<int, bool> seen;
+        for (int i = 0; i < fv.n_leaves && fv.rt_parent_leaf; ++i) {
+            touch(fv.rt_parent_leaf + i, sizeof(int));
+            int node = fv.rt_parent_leaf[i];
+            arrivals[node]++;
+            for (int hops = 0; hops < 70; ++hops) {
+                REQUIRE(node >= 0 && hops < 64, i, node);
+                if (node < 0) break;
+                touch(fv.rt_kids + node, sizeof(int));
+                touch(fv.rt_tree_sync + node, sizeof(unsigned));
+                REQUIRE(fv.rt_tree_sync[node] == 0u, node);  // (between callbacks every counter rests at 0)
+                if (node == fv.rt_root) break;
+                touch(fv.rt_parent_up + node, sizeof(int));
+                {  // a mixer between the leaves and the root: rendered by bus_sum_node_wg from the upper tree's tables
+                    REQUIRE(upv.nodes && upv.in_buf && upv.out_buf, node);
+                    const NodeDesc nd = upv.nodes[node];
+                    REQUIRE(nd.kind == K_SUM && nd.n_out == 2 && nd.aux0 * 2 == nd.n_in, node, nd.n_in);
+                    touch(upv.in_buf + nd.in_off, sizeof(int) * (size_t)nd.n_in);
+                    touch(upv.out_buf + nd.out_off, sizeof(int) * (size_t)nd.n_out);
+                }
+                if (!seen[node]) {
+                    seen[node] = true;
+                    arrivals[fv.rt_parent_up[node]]++;
+                }
+                node = fv.rt_parent_up[node];
+            }
+        }
+        for (const auto& a : arrivals) REQUIRE(a.first >= 0 && fv.rt_kids[a.first] == a.second, a.first, a.second);
+    }
     for (int i = 0; i < root.n_in; ++i) {
         touch(upv.pool + (size_t)root.in_buf[i] * upv.stride, sizeof(float) * (size_t)upv.frames);
         touch(upv.flags + root.in_buf[i], 1);

@@ -83,6 +83,38 @@ def test_consecutive_callbacks_ride_the_doorbell_and_match_the_oracle():
             assert launches <= 3, (launches, doorbells)
 
 
+@pytest.mark.parametrize("n_voices,radix,mbf", [(96, 4, 256), (200, 8, 64), (70, 4, 1024), (33, 2, 128)])
+def test_one_launch_edge_walks_mixer_trees_of_any_depth(n_voices, radix, mbf):
+    """Round 5: the one-launch / resident edge was the leaves + root tree's; now whoever completes a mixer's children renders the mixer
+    and carries on at ITS consumer (k_rt.hip.h) — trees of 3 to 7 levels (radix 2 .. 8: BASELINE configs[4]'s shard is 256 + 8 + 1),
+    blocks of 64 to 1024 frames, ragged last mixers, voices that never start, one-shots that end inside the run, a glide and a pause
+    between callbacks.  Every callback against the oracle; the counters say the callbacks rode the doorbell / the one launch."""
+    def run(e):
+        voices = scenarios.build_voice_bank(e, n_voices, radix=radix, src_frames=mbf * 7 + 33, mono_every=5)
+        for v, vc in enumerate(voices):
+            if v % 5 != 3:
+                e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+            if v % 9 != 4:
+                e.sampler_play(vc["sampler"])
+        outs = []
+        for i in range(24):
+            if i == 6:
+                e.set_param(voices[1]["volume"], 0, 30.0)
+            if i == 11:
+                e.sampler_pause(voices[2]["sampler"])
+            if i == 15:
+                e.sampler_play(voices[2]["sampler"])
+            outs.append(np.asarray(e.process_interleaved(mbf)))
+        return np.concatenate(outs)
+
+    g, o = GpuEngine(max_block_frames=mbf), OracleEngine(max_block_frames=mbf)
+    out_g, out_o = run(g), run(o)
+    assert g.cx.plan_kind() == 1
+    assert_bits_equal(out_o, out_g, "callbacks on a deep mixer tree")
+    rk, one, seq, lev = g.cx.rt_path_stats()
+    assert lev == 0 and seq == 0 and rk + one == 24, (rk, one, seq, lev)
+
+
 def test_rt_path_stats_say_which_path_the_one_block_calls_took():
     """fwgpu_rt_path_stats: the doorbell / one-launch edge exists for the plain voice-bank plan only — a host whose
     callbacks run on the launch sequence (chain plan) or on the level executor (forced generic) sees it in the counters."""

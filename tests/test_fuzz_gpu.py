@@ -44,9 +44,16 @@ def fuzz_run(e, seed):
     f32_only = rng.random() < 0.6  # (chain voices on other formats take k_chain's per-element fetch: valid, slower)
     spare_port = rng.random() < 0.5  # leaf SumNodes keep an unconnected port: voices are plugged in / out between calls
     voices, ends = [], []
+    rng_m = np.random.default_rng(seed + 7_000_003)  # (a stream of its own: the graphs of the seeds run before round 5 keep their other draws)
     for v in range(n_voices):
-        s = e.sampler(float(rng.uniform(30, 100)))
+        # round 5: one voice in eight is a ONE-output sampler behind the reference's MonoToStereoNode — a voice of the fused plans when its
+        # chain is gains only, a refused shape (solo prefix + levels) behind a filter / delay / spatialiser
+        mono_adapter = rng_m.random() < 0.125
+        s = e.sampler(float(rng.uniform(30, 100)), n_out=1) if mono_adapter else e.sampler(float(rng.uniform(30, 100)))
         cur = s
+        if mono_adapter:
+            cur = e.add_node(fwapi.MONO_TO_STEREO, 1, 2)
+            e.connect(s, 0, cur, 0)
         vc = dict(sampler=s, gains=[], pans=[], bq=None, dl=None)
         if shape == 4 or (shape in (1, 3) and rng.random() < 0.9):
             vc["bq"] = e.biquad(int(rng.integers(0, 3)), float(rng.uniform(200, 8000)), float(rng.uniform(0.5, 3.0)))

@@ -94,7 +94,8 @@ void check_generic_node(const DevView& v, int idx, int K) {
     if (v.frozen_playhead) touch(v.frozen_playhead + idx, 8);
     if (nd.kind == K_SUM) {  // aux0: port count (low half); high half, when set: the full port count of a split SumNode's continuation
         REQUIRE(nd.n_out > 0 && (nd.aux0 & 0xffff) * nd.n_out == nd.n_in, nd.aux0, nd.n_in);
-        REQUIRE((nd.aux0 >> 16) == 0 || ((nd.aux0 >> 16) > (nd.aux0 & 0xffff) && (nd.aux0 >> 16) <= 32), nd.aux0);
+        // (>=: a split that takes ONE leading voice port leaves a continuation of as many ports as the node has — partial bus + the rest)
+        REQUIRE((nd.aux0 >> 16) == 0 || ((nd.aux0 >> 16) >= (nd.aux0 & 0xffff) && (nd.aux0 >> 16) <= 32), nd.aux0);
     } else if (nd.aux0 != 0) {
         // vertical fusion (k_generic.hip.h fz_links): the ONE consumer of this stereo node — a 2 -> 2 gain-like node that reads exactly
         // this node's two output buffers, channel for channel
@@ -666,7 +667,10 @@ int launch_chain(hipStream_t, const FusedView& fv, int K, uint32_t, int nq) {
                         fv.leaves[leaf].first_voice == row + r, g, l);
             starts |= 1u << r;
             const int p = cg.ports[l];
-            if (!(p == 2 || p == 3 || p == 4))
+            // (a leaf that leads a WIDER SumNode — the hybrid plan's split mixers — takes that node's path: LeafDesc::pad; first met by the
+            //  harness in round 5, when mono-adapter voices behind a filter made split banks of chain voices)
+            const int path = fv.leaves[leaf].pad ? fv.leaves[leaf].pad : p;
+            if (!(path == 2 || path == 3 || path == 4))
                 for (int q = 0; q < p; ++q) masked |= 1u << (r + q);
             r += p;
         }

@@ -677,3 +677,39 @@ def test_process_blocks_device_io_an_effects_rack_on_device_resident_stream_inpu
         g.cx.process_blocks_device_io(k, d_in.data_ptr(), n_in, d_out.data_ptr(), 2)
         g.cx.synchronize()
         assert np.array_equal(bits(d_out.cpu().numpy()), bits(want)), "call %d" % i
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_level_executor_with_and_without_vertical_fusion_equals_the_oracle(fuse, monkeypatch):
+    """the level executor's vertical fusion (k_generic.hip.h fz_links) on and off: a wide bank forced onto the levels — resting
+    sampler -> volume -> pan [-> width -> clip] chains (links), a muted voice (a mute is no link), a glide that thaws one node of a chain
+    in the middle of the run (its blocks go the slow way, its neighbours' stay fused), paused and never-started voices (silent heads: not
+    fused), one-shots that end — 16-block batches so that the wide levels take 8 blocks per wave, every call against the oracle."""
+    monkeypatch.setenv("FWGPU_LEVEL_FUSE", fuse)
+    mbf = 64
+
+    def run(e):
+        def fx(e, v, rng):
+            return [e.width(float(rng.uniform(0.5, 1.5))), e.hard_clip(-3.0)] if v % 3 == 0 else []
+        voices = scenarios.build_voice_bank(e, 1100, radix=32, src_frames=mbf * 40 + 7, voice_fx=fx)
+        for v, vc in enumerate(voices):
+            if v % 6 != 5:
+                e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+            if v % 11 != 10:
+                e.sampler_play(vc["sampler"])
+        e.set_param(voices[8]["volume"], 0, 0.0)        # a mute
+        outs = [np.asarray(e.process_blocks(16))]
+        outs.append(np.asarray(e.process_blocks(16)))
+        e.set_param(voices[20]["pan"], 0, -0.4)         # a glide: the node thaws, then rests again
+        e.sampler_pause(voices[33]["sampler"])
+        outs.append(np.asarray(e.process_blocks(16)))
+        outs.append(np.asarray(e.process_blocks(16)))
+        e.sampler_play(voices[33]["sampler"])
+        outs.append(np.asarray(e.process_blocks(7)))
+        return np.concatenate(outs)
+
+    out_o = run(scenarios.TaggedOracle(OracleEngine(max_block_frames=mbf)))
+    g = GpuEngine(max_block_frames=mbf, max_batch=16, force_generic=True)
+    out_g = run(g)
+    assert g.cx.plan_kind() == 0
+    assert np.array_equal(bits(out_g), bits(out_o))

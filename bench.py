@@ -21,7 +21,8 @@ throughput mode); the interleaved mix bus stays in HBM.  With N >
 shard (weak scaling, one process per GPU) and the step ends with the mix-bus collective.  `--gpus N` without a
 launcher around it starts the N ranks itself (torch.distributed.run, 127.0.0.1).
 
-Prints ONE JSON line (rank 0).  `roofline` times the dominant kernel with HIP events on the stream it runs on;
+Prints ONE compact JSON line (rank 0, <= 8 KiB, strict JSON); the whole record goes to gpurun_out/bench_full.json (named in the
+line as `full`) and to stderr.  `roofline` times the dominant kernel with HIP events on the stream it runs on;
 `cpu_baseline` times the oracle (C++ restatement of the reference's single-threaded executor) on the SAME graph and the
 SAME source data, copied back from HBM; `parity_check` renders one call of the benched launch shape on a fresh context
 and compares chosen blocks of it, bit for bit, with the oracle; `other_configs` carries configs 1, 3, 4 and 5 (one
@@ -955,12 +956,12 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
             }
     if roofline is None and timing and args.force_generic and wl in ("cfg2", "cfg5"):
         # the level executor alone: no dominant kernel — the step against the same 8 B per voice-sample the fused plan is priced at
-        # (what the levels really move is 56 B per voice-sample of pool traffic: DESIGN.md section 3.1)
+        # (what the levels really move is 24 B per voice-sample of pool traffic since the vertical fusion: DESIGN.md section 3.1)
         step_us = dt / steps * 1e6
         ach = V * B * K * 8.0 / (step_us * 1e-6) / 1e9
         roofline = {"bound": "hbm", "kernel": "k_level (sampler / volume / pan / sum levels)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "whole_step_frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_voice_sample": 8.0,
-                    "pool_traffic_bytes_per_voice_sample": 56.0, "avg_launch_us": gen_ms / max(gen_n, 1) * 1e3 if gen_n else None,
+                    "pool_traffic_bytes_per_voice_sample": 24.0, "avg_launch_us": gen_ms / max(gen_n, 1) * 1e3 if gen_n else None,
                     "timing": "the timed region's wall clock (all level launches of a step)"}
     step_dist = None
     if timing and world == 1 and steps >= 5:
@@ -1239,6 +1240,158 @@ def other_configs_multi(env, args):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ the line
+LINE_BYTES_MAX = 8192  # the driver holds a bounded tail of stdout (round 5's 22.5 KB line came back `parsed: null`): the LAST stdout
+#                        line is this compact object; everything else goes to a side file (`full`, named in the line) and to stderr
+
+
+def _r(x, sig=6):
+    """floats to `sig` significant digits; non-finite floats (which strict JSON parsers refuse) to None"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, x))
+    if isinstance(x, dict):
+        return dict((k, _r(v, sig)) for k, v in x.items())
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return dict((k, d[k]) for k in keys if isinstance(d, dict) and k in d and d[k] is not None) if isinstance(d, dict) else d
+
+
+def _short(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + "~"
+
+
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "whole_step_frac", "traffic", "traffic_source",
+             "algorithmic_bytes_per_voice_sample", "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "avg_launch_us",
+             "placement_state", "pool_traffic_bytes_per_voice_sample")
+
+
+def _parity_short(pc):
+    if not isinstance(pc, dict):
+        return pc
+    out = _pick(pc, ("bit_exact", "within_tolerance", "expected", "blocks", "voices", "ranks", "bus_reduce", "samples_compared", "skipped",
+                     "oracle_whole_graph_nonzero", "mismatches", "error", "max_err_over_scale"))
+    if "against" in pc:
+        out["against"] = "oracle (C++ restatement of the reference)"
+    if isinstance(pc.get("deep"), dict):
+        out["deep"] = _pick(pc["deep"], ("bit_exact", "voices_checked", "blocks_checked", "error"))
+    return out
+
+
+def _cfg_short(ent):
+    """other_configs / bus_reduce_modes entries: {value, frac, whole_step_frac, bit_exact} + what names the run"""
+    if not isinstance(ent, dict) or "error" in ent:
+        return _pick(ent, ("error",)) if isinstance(ent, dict) else ent
+    rf = ent.get("roofline") or {}
+    pc = ent.get("parity_check")
+    out = _pick(ent, ("value", "ms_per_step", "bus_reduce", "bus_reduce_fallback", "realtime_us_per_callback", "us_per_callback",
+                      "within_tolerance", "max_abs_err_vs_oracle"))
+    if "bus_reduce_fallback" in out:
+        out["bus_reduce_fallback"] = _short(out["bus_reduce_fallback"], 120)
+    if "value" in ent:
+        out["value"] = ent["value"]  # (None on the host-only harness: kept, it is what says "no measurement")
+    if rf:
+        out.update(_pick(rf, ("kernel", "frac", "whole_step_frac", "avg_launch_us")))
+    if isinstance(pc, dict):
+        out["bit_exact"] = pc.get("bit_exact")
+        out["parity_check"] = _pick(pc, ("ranks", "bus_reduce", "within_tolerance", "expected", "skipped", "oracle_whole_graph_nonzero", "error"))
+        if isinstance(pc.get("deep"), dict):
+            out["parity_check"]["deep_bit_exact"] = pc["deep"].get("bit_exact")
+        if not out["parity_check"]:
+            del out["parity_check"]
+    return out
+
+
+def compact_line(line, full_path):
+    """the driver's line: the contract fields + roofline + cpu_baseline + parity, short forms of the rest (VERDICT r5 #1)"""
+    out = _pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    out["vs_baseline"] = line.get("vs_baseline")
+    for k in ("value", "ms_per_step"):
+        out.setdefault(k, line.get(k))
+    out.update(_pick(line, ("dtype", "data")))
+    cfg = line.get("config") or {}
+    out["config"] = _pick(cfg, ("workload", "voices_per_gpu", "block", "blocks_per_step", "variant", "launch_plan", "parallelism", "bus_reduce",
+                                "realtime_factor", "batches_without_control_kernel", "batches_with_control_kernel", "device", "compute_units"))
+    out["config"]["bus_reduce_fallback"] = _short(cfg.get("bus_reduce_fallback"), 160)
+    out["roofline"] = _pick(line.get("roofline"), ROOF_KEYS) if line.get("roofline") else None
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind"))
+        out["cpu_baseline"]["sample"] = _short(cb.get("sample"), 200)
+        if isinstance(cb.get("all_cores"), dict):
+            out["cpu_baseline"]["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+    else:
+        out["cpu_baseline"] = cb
+    out["parity_check"] = _parity_short(line.get("parity_check"))
+    if isinstance(line.get("parity_check_timed_context"), dict):
+        out["parity_check_timed_context"] = _pick(line["parity_check_timed_context"], ("bit_exact", "samples_compared"))
+    out.update(_pick(line, ("realtime_us_per_callback", "realtime_path", "virtual_ranks_on_one_device", "invalid")))
+    if "note" in line:
+        out["note"] = _short(line["note"], 200)
+    vh = line.get("value_host_buffers")
+    if isinstance(vh, dict):
+        out["value_host_buffers"] = _pick(vh, ("value", "error"))
+        if isinstance(vh.get("pipelined"), dict):
+            out["value_host_buffers"]["pipelined"] = vh["pipelined"].get("value")
+            out["value_host_buffers"]["pipelined_frac_of_value"] = vh["pipelined"].get("frac_of_value")
+        out["value_host_buffers"]["what"] = "fwgpu_process_interleaved on host buffers: including D2H (SURVEY 8d)"
+    if isinstance(line.get("contexts"), dict):
+        c = line["contexts"]
+        out["contexts"] = {"n": c.get("n"), "reported": "median", "ms_per_step_runs": _r(c.get("ms_per_step_runs"), 4),
+                           "roofline_frac_runs": _r(c.get("roofline_frac_runs"), 3)}
+    out["ranks_seen"] = line.get("ranks_seen")
+    out["rccl_ranks_seen"] = line.get("rccl_ranks_seen")
+    oc = line.get("other_configs")
+    if isinstance(oc, dict):
+        o2 = {}
+        for name, ent in oc.items():
+            if name == "k_sweep" and isinstance(ent, dict) and "by_K" in ent:
+                o2[name] = dict((k, _r(v.get("whole_step_frac"), 3)) for k, v in ent["by_K"].items())
+            elif name != "secs":
+                o2[name] = _cfg_short(ent)
+        out["other_configs"] = o2
+    if isinstance(line.get("bus_reduce_modes"), dict):
+        out["bus_reduce_modes"] = dict((m, _cfg_short(e)) for m, e in line["bus_reduce_modes"].items())
+    out["full"] = full_path
+    out = _r(out)
+    text = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    if len(text) > LINE_BYTES_MAX:  # never again: drop the optional short forms, largest first, until it fits
+        for k in ("bus_reduce_modes", "other_configs", "contexts", "value_host_buffers", "realtime_path", "parity_check_timed_context"):
+            if k in out:
+                out[k] = {"dropped": "line over %d bytes: see `full`" % LINE_BYTES_MAX}
+                text = json.dumps(out, allow_nan=False, separators=(",", ":"))
+                if len(text) <= LINE_BYTES_MAX:
+                    break
+    return text
+
+
+def write_full(line, world):
+    """the whole record (contexts, step distributions, the K sweep, every side config's roofline object) -> a side file + stderr"""
+    text = json.dumps(_r(line, 9), allow_nan=False)
+    path = None
+    for d in (os.path.join(ROOT, "gpurun_out"), os.environ.get("TMPDIR", "/tmp")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            p = os.path.join(d, "bench_full.json" if world == 1 else "bench_full_n%d.json" % world)
+            with open(p, "w") as f:
+                f.write(text + "\n")
+            path = os.path.relpath(p, ROOT) if p.startswith(ROOT) else p
+            break
+        except OSError:
+            continue
+    sys.stderr.write("[bench.py] full record (%d bytes) -> %s\n%s\n" % (len(text), path, text))
+    sys.stderr.flush()
+    return path
+
+
+
 # ------------------------------------------------------------------------------------------------ launcher
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks here, one process per GPU, exactly as the
@@ -1491,7 +1644,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        full_path = write_full(line, world)  # (stderr first: the compact line is the last thing any captured stream ends with)
+        os.write(json_fd, (compact_line(line, full_path) + "\n").encode())
     os.close(json_fd)
 
 

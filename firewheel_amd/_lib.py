@@ -108,6 +108,7 @@ SIGNATURES = {
     "fwgpu_process_interleaved": (ci, [vp, fp, fp, u32, u32, u64, f64, u32]),
     "fwgpu_process_interleaved_begin": (i64, [vp, fp, u32, u32, u64, f64, u32]),
     "fwgpu_process_interleaved_end": (ci, [vp, i64, fp]),
+    "fwgpu_process_interleaved_cancel": (ci, [vp, i64]),
     "fwgpu_process_blocks_device": (ci, [vp, u32, vp, u32]),
     "fwgpu_process_blocks_device_flags": (ci, [vp, u32, vp, u32, vp]),
     "fwgpu_process_blocks_device_io": (ci, [vp, u32, vp, u32, vp, u32, vp]),

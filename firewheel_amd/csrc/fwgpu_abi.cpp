@@ -285,6 +285,9 @@ void fwgpu_ctx_destroy(fwgpu_ctx* c) {
     }
     use_device(c);
     (void)rt_persist_stop(c);
+    // (in the default output mode the graph-output kernel writes the mapped host staging below FROM c->stream; a ctx
+    //  destroyed with a begun, un-ended ticket must not unregister / free it under a kernel that is still storing into it)
+    (void)hipStreamSynchronize(c->stream);
     if (c->rt_stream) (void)hipStreamDestroy(c->rt_stream);
     if (c->rt_ev) (void)hipEventDestroy(c->rt_ev);
     if (c->ao.copy_stream) {
@@ -1061,10 +1064,12 @@ int64_t fwgpu_process_interleaved_begin(fwgpu_ctx* c, const float* input, uint32
             if (!a.ev_render[i]) HIPC(c, hipEventCreateWithFlags(&a.ev_render[i], hipEventDisableTiming));
             if (!a.ev_copy[i]) HIPC(c, hipEventCreateWithFlags(&a.ev_copy[i], hipEventDisableTiming));
         }
-        if (out_bytes > a.d[slot].cap || out_bytes > a.hcap[slot]) {  // (first call of this size only; the slot is idle: nothing reads it)
+        // (the device-side output block exists only in the copy modes: in the default mode 3 nothing ever wrote it — ADVICE r5)
+        static const int mode = getenv("FWGPU_ASYNC_MODE") ? atoi(getenv("FWGPU_ASYNC_MODE")) : 3;
+        if ((mode != 3 && out_bytes > a.d[slot].cap) || out_bytes > a.hcap[slot]) {  // (first call of this size only; the slot is idle: nothing reads it)
             RtHold hold(c);
             HIPC(c, hipStreamSynchronize(c->stream));
-            HIPC(c, a.d[slot].ensure_n("d_async_out", out_bytes));
+            if (mode != 3) HIPC(c, a.d[slot].ensure_n("d_async_out", out_bytes));
             if (out_bytes > a.hcap[slot]) {
                 // ORDINARY (cacheable) host memory, page-locked for the DMA engine: the copy back is an SDMA transfer that runs beside the
                 // next ticket's kernels (a copy into pageable memory is a blit KERNEL: it queued behind them — measured, no overlap), and
@@ -1106,7 +1111,6 @@ int64_t fwgpu_process_interleaved_begin(fwgpu_ctx* c, const float* input, uint32
         //   2            a copy in the ctx stream behind the render: 0.310 (DMA engine) / 0.325 (blit kernel) — serial with the next render
         //   0            a copy on a stream of its own behind the render's event: 0.579 (DMA engine) / 0.388 (blit kernel, HSA_ENABLE_SDMA=0):
         //                the cross-stream hand-over costs more than the overlap gives
-        static const int mode = getenv("FWGPU_ASYNC_MODE") ? atoi(getenv("FWGPU_ASYNC_MODE")) : 3;
         float* const d_out = mode == 3 ? a.h_dev[slot] : a.d[slot].as<float>();
         const int rc = run_blocks(c, frames, d_in, (int)n_in_ch, d_out, (int)n_out_ch);
         if (rc) return rc;
@@ -1137,7 +1141,7 @@ int fwgpu_process_interleaved_end(fwgpu_ctx* c, int64_t ticket, float* output) {
     if (ticket < 0 || ticket != a.done || ticket >= a.next || !a.busy[slot])
         return fail(c, FWGPU_ERR_INVALID, "not the oldest ticket in flight (tickets are ended in the order they were begun)");
     const size_t n = a.bytes[slot];
-    if (n && !output) return fail(c, FWGPU_ERR_INVALID, "output is null");
+    if (n && !output) return fail(c, FWGPU_ERR_INVALID, "output is null (the ticket stays in flight: end it with a buffer, or fwgpu_process_interleaved_cancel)");
     a.busy[slot] = false;
     a.done++;
     if (a.zeros[slot] || n == 0) {
@@ -1159,6 +1163,27 @@ int fwgpu_process_interleaved_end(fwgpu_ctx* c, int64_t ticket, float* output) {
     a.prof_calls++;
     c->ret_done_ticket.store(a.ret_ticket[slot], std::memory_order_release);  // what that call handed back is final
     return 0;
+}
+// Abandon tickets: every ticket in flight up to and including `ticket` is waited for and its slot released, no frames copied — a host
+// that unwinds (a Rust `Ticket` dropped on an error path) must not leave `begin` refusing for ever after two.
+int fwgpu_process_interleaved_cancel(fwgpu_ctx* c, int64_t ticket) {
+    NEED_CTX(c, FWGPU_ERR_INVALID);
+    AudioCallScope audio;
+    use_device(c);
+    fwgpu_ctx::AsyncOut& a = c->ao;
+    if (ticket < a.done || ticket >= a.next) return fail(c, FWGPU_ERR_INVALID, "no such ticket in flight");
+    int rc = 0;
+    while (a.done <= ticket) {
+        const int slot = (int)(a.done & 1);
+        if (a.busy[slot] && !a.zeros[slot] && a.bytes[slot]) {
+            const hipError_t e = hipEventSynchronize(a.ev_copy[slot]);  // the staging block is idle again only once its writer has ended
+            if (e != hipSuccess) rc = hipfail(c, e, "waiting for a cancelled process_interleaved_begin ticket");
+            c->ret_done_ticket.store(a.ret_ticket[slot], std::memory_order_release);
+        }
+        a.busy[slot] = false;
+        a.done++;
+    }
+    return rc;
 }
 int fwgpu_proc_info(fwgpu_ctx* c, double* stream_time_secs, uint32_t* stream_status, uint64_t* output_underflows,
                     uint64_t* input_overflows) {

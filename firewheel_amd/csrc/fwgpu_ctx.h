@@ -128,6 +128,15 @@ inline int host_kind_set(int kind) {
 // a level's launch bits: the kernel set of the kind, plus bit 3 for a biquad / delay (a bus one goes to the batch walkers)
 inline int host_kind_bits(int kind) { return (1 << host_kind_set(kind)) | ((kind == K_BIQUAD || kind == K_DELAY) ? 8 : 0); }
 
+// A statistics counter the audio thread bumps and the control thread reads (fwgpu_rt_path_stats, fwgpu_lazy_stats,
+// fwgpu_rt_resident_stats): relaxed atomics — a plain uint64_t there is a data race by the letter (the race test runs under
+// ThreadSanitizer).  One writer, so ++ is a load + store, not a locked read-modify-write.
+struct StatCounter {
+    std::atomic<uint64_t> v{0};
+    void operator++(int) { v.store(v.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed); }
+    operator uint64_t() const { return v.load(std::memory_order_relaxed); }
+};
+
 struct TimerCat {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
@@ -321,7 +330,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
         int64_t next = 0, done = 0;  // tickets handed out / ended
     } ao;
     bool level_fuse = true;                        // FWGPU_LEVEL_FUSE=0: the level executor without vertical fusion (A/B, bisecting)
-    uint64_t rt_path[4] = {0, 0, 0, 0};            // one-block launch batches by path (fwgpu_rt_path_stats); audio side writes
+    StatCounter rt_path[4];                        // one-block launch batches by path (fwgpu_rt_path_stats); audio side writes
     uint64_t gate_defer_ns = 20000;               // ... for at most this long per process call (FWGPU_GATE_DEFER_US; 0: never steps back)
     std::atomic<uint64_t> gate_defer_expired{0};  // process calls that stopped waiting for a waiter that did not come
     std::atomic<fwgpu::PlanImage*> pending{nullptr};  // built and published, waiting for the next process call
@@ -382,7 +391,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     uint32_t lazy_epoch = 0;                     // epoch the LazyRecs were made under
     bool lazy_valid = false;                     // nothing but lazy calls has moved the voices since they were made
     bool lazy_this_call = false;
-    uint64_t lazy_calls = 0, ctl_calls = 0;      // fused batches rendered without / with a control kernel (fwgpu_lazy_stats)
+    StatCounter lazy_calls, ctl_calls;           // fused batches rendered without / with a control kernel (fwgpu_lazy_stats)
     int ctl_ahead_mode = 2;          // 1 = every qualifying call (round 3), 2 = only calls with messages / continuing glides (round 4)
     hipStream_t ctl_stream = nullptr;
     hipEvent_t ev_ctl[2] = {nullptr, nullptr}, ev_render[2] = {nullptr, nullptr}, ev_join = nullptr;
@@ -483,7 +492,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
         float* d_out = nullptr;
         const void* blks = nullptr;       // (the FusedView the kernel was launched with: any difference means a new launch)
         unsigned long long next_seq = 0;  // the doorbell value it waits for
-        uint64_t launches = 0, doorbells = 0;
+        StatCounter launches, doorbells;
         uint64_t held = 0;                // launches not made because a control call held the device (RtHold)
     } rtp;
     bool rt_use_graph = false;  // FWGPU_RT_GRAPH=1: measured 5 us SLOWER per callback than 4 plain launches on ROCm 7.2

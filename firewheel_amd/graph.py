@@ -575,6 +575,10 @@ class FirewheelGpuCtx(object):
             self._reap_limbo()
         return out
 
+    def process_interleaved_cancel(self, ticket):
+        """abandon every ticket in flight up to and including this one (no frames copied)"""
+        self._check(self.L.fwgpu_process_interleaved_cancel(self.c, ticket[0]))
+
     def process_blocks_device(self, num_blocks, device_out_ptr, num_out_channels=2):
         self._check(self.L.fwgpu_process_blocks_device(self.c, num_blocks, C.c_void_p(device_out_ptr), num_out_channels))
 

@@ -274,11 +274,18 @@ int fwgpu_process_interleaved(fwgpu_ctx* ctx, const float* input, float* output,
  * device-mapped host staging blocks — and returns a ticket (>= 0); `end` waits for that ticket's last launch and hands the frames to
  * `output`.  With begin(n + 1) called before end(n) the host's share of call n (the wait, the memcpy) overlaps the rendering of call
  * n + 1 and no copy engine or blit kernel sits between two renders: config 2 runs at 0.90 of the device-resident rate this way, 0.84
- * through the synchronous call.  At most two calls in flight; tickets are ended in order; `output` is
- * filled on every return of `end` (zeros on error, core/node.rs:41-42).  Audio-side calls, like process_interleaved itself. */
+ * through the synchronous call.  At most two calls in flight; tickets are ended in order.  `end` on the oldest
+ * ticket in flight fills `output` on every return (zeros when the device failed, core/node.rs:41-42); `end` on anything else — not a
+ * ticket, not the oldest one, a null `output` for a ticket with frames — returns FWGPU_ERR_INVALID, touches nothing (it does not know
+ * a size to fill) and leaves the tickets in flight as they were.  `cancel` abandons every ticket in flight up to and including
+ * `ticket`: waits for their launches, releases their slots, copies nothing — for hosts that unwind.  Stream INPUTS (`input` non-null)
+ * are copied host-to-device by `begin` itself on the ctx stream, behind the previous ticket's render: from pageable memory that copy
+ * is synchronous to the host, so a graph with stream inputs gets the output-side overlap only (hand device-resident inputs to
+ * fwgpu_process_blocks_device_io for the rest).  Audio-side calls, like process_interleaved itself. */
 int64_t fwgpu_process_interleaved_begin(fwgpu_ctx* ctx, const float* input, uint32_t num_in_channels, uint32_t num_out_channels,
                                         uint64_t frames, double stream_time_secs, uint32_t stream_status);
 int fwgpu_process_interleaved_end(fwgpu_ctx* ctx, int64_t ticket, float* output);
+int fwgpu_process_interleaved_cancel(fwgpu_ctx* ctx, int64_t ticket);
 /* Throughput form of the same call: `num_blocks` full blocks, interleaved output written to DEVICE memory
  * `d_output` [num_blocks*max_block_frames*num_out_channels] on the ctx stream, asynchronously (no host
  * sync).  Graph inputs read zeros (fwgpu_process_blocks_device_io takes them from device memory). */

@@ -134,6 +134,7 @@ extern "C" {
     pub fn fwgpu_process_interleaved(ctx: *mut fwgpu_ctx, input: *const f32, output: *mut f32, num_in_channels: u32, num_out_channels: u32, frames: u64, stream_time_secs: f64, stream_status: u32) -> c_int;
     pub fn fwgpu_process_interleaved_begin(ctx: *mut fwgpu_ctx, input: *const f32, num_in_channels: u32, num_out_channels: u32, frames: u64, stream_time_secs: f64, stream_status: u32) -> i64;
     pub fn fwgpu_process_interleaved_end(ctx: *mut fwgpu_ctx, ticket: i64, output: *mut f32) -> c_int;
+    pub fn fwgpu_process_interleaved_cancel(ctx: *mut fwgpu_ctx, ticket: i64) -> c_int;
     pub fn fwgpu_process_blocks_device(ctx: *mut fwgpu_ctx, num_blocks: u32, d_output: *mut f32, num_out_channels: u32) -> c_int;
     pub fn fwgpu_process_blocks_device_flags(ctx: *mut fwgpu_ctx, num_blocks: u32, d_output: *mut f32, num_out_channels: u32, d_silence: *mut u8) -> c_int;
     pub fn fwgpu_process_blocks_device_io(ctx: *mut fwgpu_ctx, num_blocks: u32, d_input: *const f32, num_in_channels: u32, d_output: *mut f32, num_out_channels: u32, d_silence: *mut u8) -> c_int;

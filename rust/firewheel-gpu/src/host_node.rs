@@ -14,8 +14,9 @@ use firewheel_core::SilenceMask;
 use crate::{ffi, GpuContext, GpuError};
 
 /// Owner of a custom processor inside the device graph.  Dropping it removes the node (if it still exists) and hands the processor
-/// to the context's graveyard, which frees it only once a plan WITHOUT the node is the active one: the host's next explicit
-/// `update()` / `upload_schedule()` marks the graves as updated, `fwgpu_plan_pending() == 0` says that plan has been adopted — until
+/// to the context's graveyard, which frees it only once a plan WITHOUT the node is the active one: the grave carries the number of
+/// compiles that had succeeded when the node left the graph (both read and bumped under the control lock), a compile AFTER that
+/// one builds a plan without the node, `fwgpu_plan_pending() == 0` says that plan has been adopted — until
 /// then the audio thread may still be inside, or about to enter, the trampoline with the raw `user` pointer.  That is Firewheel's
 /// own rule (a removed node's processor is dropped when the old schedule comes back through the ring, processor.rs:182-188), made
 /// part of the type instead of the documentation: dropping the handle at any time, from any thread, with the stream running, is
@@ -31,10 +32,14 @@ pub struct HostNodeHandle {
 }
 impl Drop for HostNodeHandle {
     fn drop(&mut self) {
-        // Err = the host removed it already (remove_node); either way the graph no longer names it after this line
-        let _ = self.cx.remove_node(self.node);
+        // ONE critical section for "the graph stops naming the node" and "which compile was the last one before that": a compile
+        // on another thread is either entirely before (its plan may call the node: the grave waits for a later one) or entirely
+        // after.  Err from the removal = the host removed it already (remove_node): the stamp is then merely later than needed.
+        let _g = self.cx.control();
+        let _ = unsafe { ffi::fwgpu_remove_node(self.cx.as_ptr(), self.node) };
         if let Some(st) = self.state.take() {
-            self.cx.bury(st);
+            let gen = self.cx.compile_gen.load(std::sync::atomic::Ordering::Acquire);
+            self.cx.bury(st, gen);
         }
     }
 }
@@ -50,35 +55,36 @@ pub(crate) struct HostState {
 unsafe impl Send for HostNodeHandle {}
 unsafe impl Send for HostState {}
 
-/// A processor whose node is gone from the graph but which a plan may still call: (state, an update has succeeded since the removal).
+/// A processor whose node is gone from the graph but which a plan may still call: (state, compiles that had succeeded at its removal).
 pub(crate) struct Grave {
     _state: Box<HostState>,
-    updated: bool,
+    removed_at_gen: u64,
 }
 impl GpuContext {
-    pub(crate) fn bury(&self, st: Box<HostState>) {
+    /// (called with the control lock held; lock order control -> graveyard everywhere)
+    pub(crate) fn bury(&self, st: Box<HostState>, removed_at_gen: u64) {
         let mut g = self.graveyard.lock().unwrap_or_else(|e| e.into_inner());
-        g.push(Grave { _state: st, updated: false });
+        g.push(Grave { _state: st, removed_at_gen });
     }
-    /// Free the processors no plan can call any more: an update has returned since their removal AND no built plan is waiting
-    /// for adoption — so the newest plan, which does not name them, is the one the audio thread runs.  Called after every
-    /// `update` / `upload_schedule` (with `updated = true`), by `GpuContext::release_removed_host_nodes` (`updated = false`: a plan built
-    /// earlier may have been adopted meanwhile), and by `GpuContext::drop` (everything).
+    /// Free the processors no plan can call any more: a compile that began after their removal has succeeded (`compile_gen` is past
+    /// the grave's stamp) AND no built plan is waiting for adoption — so the newest plan, which does not name them, is the one the
+    /// audio thread runs.  Called after every `update` / `upload_schedule`, by `release_removed_host_nodes` (a plan built earlier may
+    /// have been adopted meanwhile), and by `GpuContext::drop` (everything, as fields).  The generation is read BEFORE the pending
+    /// flag: a compile that lands in between only makes this pass keep a grave one call longer.
+    pub(crate) fn reap(&self) {
+        let mut g = self.graveyard.lock().unwrap_or_else(|e| e.into_inner());
+        if g.is_empty() {
+            return;
+        }
+        let gen = self.compile_gen.load(std::sync::atomic::Ordering::Acquire);
+        if unsafe { ffi::fwgpu_plan_pending(self.as_ptr()) } == 0 {
+            g.retain(|gr| gr.removed_at_gen >= gen);
+        }
+    }
     /// Frees the processors of removed host nodes that no plan can call any more, without recompiling (a host that wants the memory
     /// back before its next `update`).
     pub fn release_removed_host_nodes(&self) {
-        self.reap(false);
-    }
-    pub(crate) fn reap(&self, updated: bool) {
-        let mut g = self.graveyard.lock().unwrap_or_else(|e| e.into_inner());
-        if updated {
-            for gr in g.iter_mut() {
-                gr.updated = true;
-            }
-        }
-        if !g.is_empty() && unsafe { ffi::fwgpu_plan_pending(self.as_ptr()) } == 0 {
-            g.retain(|gr| !gr.updated);
-        }
+        self.reap();
     }
 }
 

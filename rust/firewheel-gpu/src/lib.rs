@@ -47,6 +47,11 @@ pub struct GpuContext {
     control: Mutex<()>,
     /// processors of host nodes that were removed while a plan could still call them (host_node.rs)
     pub(crate) graveyard: Mutex<Vec<host_node::Grave>>,
+    /// successful `update` / `upload_schedule` calls so far.  Written and read under `control` only where it decides anything: a
+    /// grave is stamped with the value at its removal, and is freed once a LATER compile — one that ran entirely after the removal,
+    /// both under the lock — has been adopted (marking graves after the lock was released let a removal slip in between
+    /// another thread's `fwgpu_update` and its mark, and freed a processor the adopted plan still called)
+    pub(crate) compile_gen: std::sync::atomic::AtomicU64,
     /// the graph's one global user context (`ProcInfo::cx`, core/node.rs:117-118; processor.rs:21 owns one per graph): every host
     /// node's `process` is lent THIS box.  Written by `set_user_cx` before the stream starts, dereferenced by the audio thread only.
     user_cx: std::cell::UnsafeCell<Box<dyn std::any::Any + Send>>,
@@ -77,7 +82,7 @@ impl GpuContext {
             )
         };
         match NonNull::new(raw) {
-            Some(raw) => Ok(Arc::new(Self { raw, control: Mutex::new(()), graveyard: Mutex::new(Vec::new()), user_cx: std::cell::UnsafeCell::new(Box::new(())), sample_rate, max_block_frames })),
+            Some(raw) => Ok(Arc::new(Self { raw, control: Mutex::new(()), graveyard: Mutex::new(Vec::new()), compile_gen: std::sync::atomic::AtomicU64::new(0), user_cx: std::cell::UnsafeCell::new(Box::new(())), sample_rate, max_block_frames })),
             None => Err(GpuError {
                 code: ffi::FWGPU_ERR_DEVICE,
                 message: unsafe { CStr::from_ptr(ffi::fwgpu_create_error()) }.to_string_lossy().into_owned(),
@@ -90,14 +95,16 @@ impl GpuContext {
     }
 
     /// The `user_cx` of `FirewheelGraphCtx::activate` (graph/context.rs:53-82 hands it to the processor, processor.rs:41): ONE per
-    /// graph, shared by every custom node.  Call it before the first process call (the default is `Box::new(())`).
+    /// graph, shared by every custom node (the default is `Box::new(())`).
     ///
-    /// # Safety of the implementation
-    /// Takes the control lock; the audio thread reads the box only inside host-node callbacks, which exist only while a process call
-    /// runs — the contract is "before the stream starts", as in the reference, where `activate` consumes it.
-    pub fn set_user_cx(&self, user_cx: Box<dyn std::any::Any + Send>) {
+    /// # Safety
+    /// The old box is dropped here while host-node trampolines lend `&mut` of it to `process()` on the audio thread, which the control
+    /// lock does not exclude.  The caller must guarantee that no process call of this context is running or can start during the call
+    /// — "before the stream starts", as in the reference, where `activate` consumes the context.  (this was a safe method
+    /// on a `Sync` type whose contract lived in a comment.)
+    pub unsafe fn set_user_cx(&self, user_cx: Box<dyn std::any::Any + Send>) {
         let _g = self.control();
-        unsafe { *self.user_cx.get() = user_cx };
+        *self.user_cx.get() = user_cx;
     }
     pub(crate) fn user_cx_ptr(&self) -> *mut Box<dyn std::any::Any + Send> {
         self.user_cx.get()
@@ -145,11 +152,13 @@ impl GpuContext {
     pub fn update(&self) -> Result<(), GpuError> {
         let r = {
             let _g = self.control();
-            self.check(unsafe { ffi::fwgpu_update(self.as_ptr()) } as i64).map(|_| ())
+            let r = self.check(unsafe { ffi::fwgpu_update(self.as_ptr()) } as i64).map(|_| ());
+            if r.is_ok() {
+                self.compile_gen.fetch_add(1, std::sync::atomic::Ordering::AcqRel); // still under the lock: see `compile_gen`
+            }
+            r
         };
-        if r.is_ok() {
-            self.reap(true);
-        }
+        self.reap();
         r
     }
     /// true while a plan built by `update` / `upload_schedule` waits for a process call to adopt it (`fwgpu_plan_pending`)
@@ -203,14 +212,17 @@ impl GpuContext {
             .collect();
         let r = {
             let _g = self.control();
-            self.check(unsafe {
-                ffi::fwgpu_schedule_upload(self.as_ptr(), nodes.as_ptr(), nodes.len() as u32, num_buffers as u32)
-            } as i64)
-            .map(|_| ())
+            let r = self
+                .check(unsafe {
+                    ffi::fwgpu_schedule_upload(self.as_ptr(), nodes.as_ptr(), nodes.len() as u32, num_buffers as u32)
+                } as i64)
+                .map(|_| ());
+            if r.is_ok() {
+                self.compile_gen.fetch_add(1, std::sync::atomic::Ordering::AcqRel); // still under the lock: see `compile_gen`
+            }
+            r
         };
-        if r.is_ok() {
-            self.reap(true);
-        }
+        self.reap();
         r
     }
 
@@ -242,10 +254,24 @@ impl Drop for GpuContext {
     }
 }
 
-/// One begun, not yet ended `process_interleaved_begin` call (not `Clone`: `process_interleaved_end` consumes it).
+/// One begun, not yet ended `process_interleaved_begin` call (not `Clone`: `process_interleaved_end` consumes it).  A ticket that is
+/// dropped instead — an error path, an unwinding panic — cancels itself and every older ticket still in flight
+/// (`fwgpu_process_interleaved_cancel`): the two slots never stay busy behind a lost ticket.  `!Send`: like
+/// `GpuProcessor`'s calls it belongs to the one audio thread.
 pub struct Ticket {
     id: i64,
     floats: usize,
+    cx: Arc<GpuContext>,
+    ended: bool,
+    _audio_thread: std::marker::PhantomData<*mut ()>,
+}
+impl Drop for Ticket {
+    fn drop(&mut self) {
+        if !self.ended {
+            // Err = an older drop already swept it: nothing is left in flight under this id
+            let _ = unsafe { ffi::fwgpu_process_interleaved_cancel(self.cx.as_ptr(), self.id) };
+        }
+    }
 }
 
 /// Borrowed view of one `ScheduledNode`: `InBufferAssignment { buffer_index, should_clear }` split into two slices.
@@ -326,13 +352,17 @@ impl GpuProcessor {
                 stream_status.bits(),
             )
         };
-        self.cx.check(t).map(|id| Ticket { id, floats: frames * num_out_channels })
+        self.cx.check(t).map(|id| Ticket { id, floats: frames * num_out_channels, cx: Arc::clone(&self.cx), ended: false, _audio_thread: std::marker::PhantomData })
     }
 
-    /// ... its other half.  `output` is filled on every return (zeros on error).
-    pub fn process_interleaved_end(&mut self, ticket: Ticket, output: &mut [f32]) -> Result<(), GpuError> {
+    /// ... its other half.  `output` is filled on every return for the oldest ticket in flight (zeros when the device failed); a
+    /// ticket that is not the oldest one is refused (`FWGPU_ERR_INVALID`), `output` untouched, and — being consumed here — cancelled
+    /// together with the older ones by its `Drop`.
+    pub fn process_interleaved_end(&mut self, mut ticket: Ticket, output: &mut [f32]) -> Result<(), GpuError> {
         assert!(output.len() >= ticket.floats, "output slice shorter than the ticket's frames * num_out_channels");
         let rc = unsafe { ffi::fwgpu_process_interleaved_end(self.cx.as_ptr(), ticket.id, output.as_mut_ptr()) };
+        // (ended = the C side released the slot: success, or a device failure on the oldest ticket — not a refused ticket)
+        ticket.ended = rc != ffi::FWGPU_ERR_INVALID;
         self.cx.check(rc as i64).map(|_| ())
     }
 }

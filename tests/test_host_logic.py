@@ -741,4 +741,22 @@ def test_process_interleaved_begin_end_ticket_rules_on_the_host_harness():
     assert e.cx.process_interleaved_end(b).shape == (64 * 2 * 2,)
     assert e.cx.process_interleaved_end(c).shape == (64 * 9 * 2,)
     assert np.asarray(e.process_interleaved(64)).shape == (128,)   # the synchronous call beside it
+    # a ticket nobody ends must not wedge `begin` for ever — cancel abandons every ticket up to and including the one named
+    a = e.cx.process_interleaved_begin(None, 0, 2, 64 * 2)
+    b = e.cx.process_interleaved_begin(None, 0, 2, 64 * 2)
+    with pytest.raises(FwgpuError):
+        e.cx.process_interleaved_begin(None, 0, 2, 64)
+    e.cx.process_interleaved_cancel(b)                              # sweeps `a` too
+    with pytest.raises(FwgpuError):
+        e.cx.process_interleaved_end(a)                            # gone
+    with pytest.raises(FwgpuError):
+        e.cx.process_interleaved_cancel(b)                          # nothing in flight under that id
+    c = e.cx.process_interleaved_begin(None, 0, 2, 64 * 4)
+    d = e.cx.process_interleaved_begin(None, 0, 2, 64)
+    e.cx.process_interleaved_cancel(c)                              # the oldest only
+    assert e.cx.process_interleaved_end(d).shape == (64 * 2,)
+    # `end` with a null buffer for a ticket with frames is refused and leaves the ticket in flight (include/fwgpu.h)
+    f = e.cx.process_interleaved_begin(None, 0, 2, 64)
+    assert e.cx.L.fwgpu_process_interleaved_end(e.cx.c, f[0], None) < 0
+    assert e.cx.process_interleaved_end(f).shape == (64 * 2,)
     assert e.violation() == ""

@@ -202,15 +202,30 @@ def graph_bank(e, voices, radix, seed=0, master=False, extra=(), rs_samples=None
     return samplers, volumes, root
 
 
-def graph_chain(e, voices, radix, seed=0, master=False, connect_out=True):
+def graph_chain(e, voices, radix, seed=0, master=False, connect_out=True, reordered=False):
     """cfg3 voice: sampler -> biquad LPF (cutoff U(200, 8000) Hz, Q 0.707) -> delay (U(10, 250) ms, feedback 0.3,
-    mix 0.5) -> gain."""
+    mix 0.5) -> gain.  reordered (round 6, the chain plan's wider grammar): sampler -> gain -> biquad LPF -> biquad
+    (a peaking band-pass beside it: an EQ cascade) -> delay -> pan."""
     import numpy as np
 
     rng = np.random.default_rng(4321 + seed)
     ends, samplers = [], []
+    # (FWGPU_BENCH_CHAIN_SHAPE: kernel experiments only — v gain, B / b the two biquads, D delay, p pan, in any accepted order)
+    shape = os.environ.get("FWGPU_BENCH_CHAIN_SHAPE", "vBbDp")
     for v in range(voices):
         s = e.add(K_SAMPLER, 0, 2, [100.0])
+        if reordered:
+            par = dict(B=(K_BIQUAD, [0.0, float(rng.uniform(200, 8000)), 0.707]), D=(K_DELAY, [float(rng.uniform(0.010, 0.250)), 0.3, 0.5]),
+                       v=(K_VOLUME, [float(rng.uniform(10, 100))]), b=(K_BIQUAD, [2.0, float(rng.uniform(300, 5000)), 1.2]),
+                       p=(K_PAN, [float(rng.uniform(-1, 1))]))  # (every voice draws all five, whatever the shape: one stream of parameters)
+            cur = s
+            for t in shape:
+                n = e.add(par[t][0], 2, 2, par[t][1])
+                e.connect_stereo(cur, n)
+                cur = n
+            samplers.append(s)
+            ends.append(cur)
+            continue
         bq = e.add(K_BIQUAD, 2, 2, [0.0, float(rng.uniform(200, 8000)), 0.707])
         dl = e.add(K_DELAY, 2, 2, [float(rng.uniform(0.010, 0.250)), 0.3, 0.5])
         vol = e.add(K_VOLUME, 2, 2, [float(rng.uniform(10, 100))])
@@ -254,7 +269,7 @@ def build_graph(e, wl, voices, radix, seed, master, ir_sample=None, voice_fx=Fal
     if wl == "cfg4":
         return graph_reverb(e, voices, radix, ir_sample, connect_out)
     if wl == "cfg3":
-        return graph_chain(e, voices, radix, seed, master, connect_out)
+        return graph_chain(e, voices, radix, seed, master, connect_out, reordered=voice_fx == "reordered")
     extra = ((K_WIDTH, [1.3]), (K_HARD_CLIP, [-3.0])) if voice_fx is True else ()
     if voice_fx == "spatial":  # a SPEC 3D spatialiser at the end of every voice (2 -> 2: mono sum, ITD, distance + pan gains)
         extra = ((K_SPATIAL, [2.0, 0.5, -3.0]),)
@@ -277,7 +292,8 @@ def make_gpu(fa, wl, V, B, K, radix, src, F, sfmt, seed, args, stream, device):
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
     ids = [cx.new_sample_device(fmt, 2, F, src[v].data_ptr()) for v in range(V)] if rs else None
     samplers, volumes, _ = build_graph(g, wl, V, radix, seed, "send" if getattr(args, "send", False) else ("iir" if getattr(args, "master_iir", False) else args.master), ir,
-                                       "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
+                                       "reordered" if (getattr(args, "chain_reordered", False) and wl == "cfg3") else
+                                       ("spatial" if getattr(args, "voice_spatial", False) else args.voice_fx), ids)
     if not rs:
         for v, s in enumerate(samplers):
             smp = cx.new_sample_device(fmt, 2, F, src[v].data_ptr())
@@ -297,7 +313,8 @@ def make_oracle(wl, V, B, radix, seed, args, host_src, fmt=PLANAR_F32):
     rs = getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5")
     ids = [o.e.new_sample(fmt, 2, host_src[v]) for v in range(V)] if rs else None
     samplers, volumes, _ = build_graph(o, wl, V, radix, seed, "send" if getattr(args, "send", False) else ("iir" if getattr(args, "master_iir", False) else args.master), ir,
-                                       "spatial" if getattr(args, "voice_spatial", False) else args.voice_fx, ids)
+                                       "reordered" if (getattr(args, "chain_reordered", False) and wl == "cfg3") else
+                                       ("spatial" if getattr(args, "voice_spatial", False) else args.voice_fx), ids)
     if not rs:
         for v, s in enumerate(samplers):
             o.start(s, o.e.new_sample(fmt, 2, host_src[v]))
@@ -442,7 +459,7 @@ def parity_check(fa, torch, wl, V, B, K, radix, seed, args, src, F, sfmt, stream
         # filter / delay / FIR history carries from block to block, so blocks deep inside the call need their whole prefix from
         # the oracle: a SLICE of the voices (same launch shape, same K), every block of the call
         try:
-            res["deep"] = parity_deep(fa, torch, wl, B, K, radix, seed, args, src, F, stream, device)
+            res["deep"] = parity_deep(fa, torch, wl, B, K, radix, seed, args, src, F, stream, device, sfmt)
             res["bit_exact"] = bool(res["bit_exact"] and res["deep"]["bit_exact"])
         except Exception as ex:  # noqa: BLE001
             res["deep"] = {"error": repr(ex)}
@@ -455,7 +472,7 @@ def parity_check(fa, torch, wl, V, B, K, radix, seed, args, src, F, sfmt, stream
     return res
 
 
-def parity_deep(fa, torch, wl, B, K, radix, seed, args, src, F, stream, device):
+def parity_deep(fa, torch, wl, B, K, radix, seed, args, src, F, stream, device, sfmt="f32"):
     """cfg3: 256 voices x ALL K = 64 blocks of one call (biquad + delay state through the whole call: blocks 31 and 63 are as
     checked as block 0); cfg4: 8 voices x all K = 16 blocks of one call at 65 536 taps (block 15 reads 15 blocks of FIR history
     written by the call itself; ~3.5 s of scalar oracle)."""
@@ -469,14 +486,17 @@ def parity_deep(fa, torch, wl, B, K, radix, seed, args, src, F, stream, device):
     if getattr(args, "voice_spatial", False) and wl == "cfg2":
         Vd = src.shape[0]  # every leaf: only then does a spatialiser wave take several consecutive blocks and keep its histories in LDS
     assert F >= K * B
-    cx, g, samplers, _ = make_gpu(fa, wl, Vd, B, K, radix, src, F, "f32", seed, args, stream, device)
+    cx, g, samplers, _ = make_gpu(fa, wl, Vd, B, K, radix, src, F, sfmt, seed, args, stream, device)
     out = torch.empty(K * B * 2, dtype=torch.float32, device=src.device)
     torch.cuda.synchronize()
     cx.process_blocks_device(K, out.data_ptr(), 2)
     cx.synchronize()
     got = out.cpu().numpy()
     # (a looping resampler reads past K x B source frames at ratios > 1 and wraps its window around the sample's end: whole samples)
-    o, _, _ = make_oracle(wl, Vd, B, radix, seed, args, (src[:Vd] if rs else src[:Vd, :, :K * B]).cpu().numpy())
+    if sfmt == "i16":  # interleaved stereo PCM: [voice][frame][channel]
+        o, _, _ = make_oracle(wl, Vd, B, radix, seed, args, src[:Vd, :K * B, :].cpu().numpy(), INTERLEAVED_I16)
+    else:
+        o, _, _ = make_oracle(wl, Vd, B, radix, seed, args, (src[:Vd] if rs else src[:Vd, :, :K * B]).cpu().numpy())
     ref = o.e.process_blocks(K)
     same = bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32))) and bool(np.any(ref))
     per_block = (got.view(np.uint32).reshape(K, -1) == ref.view(np.uint32).reshape(K, -1)).all(axis=1)
@@ -714,7 +734,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
 
     stream = torch.cuda.current_stream().cuda_stream if not hostonly else None
     # synthetic sources, generated in HBM: uniform(-1,1) f32, the stream keyed by the shard's first GLOBAL voice id
-    sfmt = args.source_format if wl in ("cfg2", "cfg5") else "f32"
+    sfmt = args.source_format if (wl in ("cfg2", "cfg5") or (wl == "cfg3" and getattr(args, "chain_reordered", False))) else "f32"
     if sfmt == "i16":  # interleaved stereo PCM, [voice][frame][channel]
         gen = torch.Generator(device=dev)
         gen.manual_seed(shard.voice_seed(rank * V))
@@ -920,7 +940,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
                         "idle_us_per_step": step_us - (gen_ms + ctl_ms + dom_ms) / ev_steps * 1e3}
         elif dom_n:
             # source L+R once (f32: 8 B, i16: 4 B) (+ delay ring read + write)
-            per_vs = 24.0 if wl == "cfg3" else (4.0 if sfmt == "i16" else 8.0)
+            per_vs = (20.0 if sfmt == "i16" else 24.0) if wl == "cfg3" else (4.0 if sfmt == "i16" else 8.0)  # (cfg3: source + ring read + ring write)
             kernel = "k_chain" if wl == "cfg3" else "k_leaf_sum"
             if getattr(args, "rs_source", False) and wl in ("cfg2", "cfg5"):
                 kernel = "k_leaf_rs"  # (+ k_leaf_sum_wl over its work list, timed together: fwgpu_kernels.hip launch_leaf_sum)
@@ -930,9 +950,9 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
             ach = alg_bytes / avg_s / 1e9
             # (PMC passes ran on f32 sources; a profile is quoted for the workload it was collected on: plain / --voice-fx / --rs-source)
             prof_name = (wl + ("_voicefx" if args.voice_fx else "") + ("_rs" if getattr(args, "rs_source", False) else "") +
-                         ("_spatial" if getattr(args, "voice_spatial", False) else ""))
+                         ("_spatial" if getattr(args, "voice_spatial", False) else "") + ("_reordered" if getattr(args, "chain_reordered", False) else ""))
             plain = not (args.master or getattr(args, "master_iir", False) or variant != "A" or args.force_generic or getattr(args, "send", False))
-            traffic, traffic_src = pmc_traffic(kernel, V, B, K, prof_name) if sfmt == "f32" and plain else (None, None)
+            traffic, traffic_src = pmc_traffic(kernel, V, B, K, prof_name) if (sfmt == "f32" or getattr(args, "chain_reordered", False)) and plain else (None, None)
             step_us = dt / steps * 1e6
             others = {"k_voice_control": ctl_ms / ev_steps * 1e3, "upper_sums+graph_out": up_ms / ev_steps * 1e3}
             if gen_n:
@@ -1028,6 +1048,8 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
             desc = desc.replace("sampler->", "resampler(ratio U(0.5,1.5), looping)->")
         if getattr(args, "voice_spatial", False) and wl in ("cfg2", "cfg5"):
             desc = desc.replace("->pan->", "->pan->3D spatialiser(ITD + distance + equal-power gains)->")
+        if getattr(args, "chain_reordered", False) and wl == "cfg3":
+            desc = "cfg3_reordered: %d stereo voices/GPU, sampler->gain->biquad LPF->biquad BP->delay(fb)->pan->radix-%d sum tree" % (V, args.radix)
         if getattr(args, "send", False) and wl in ("cfg2", "cfg3", "cfg5"):
             desc += " + every 4th leaf bus tapped into a send -> gain -> width -> limiter return (hybrid plan)"
         res = {
@@ -1127,8 +1149,10 @@ def other_configs(env, args):
     # (cfg2_levels: --force-generic, no roofline object: five level kernels, none of them dominant)
     # cfg3 / cfg5: three fresh contexts each, the median reported and all three listed with their placement state — one context is
     # a coin toss between k_leaf_sum's two HBM placement states (the profile and the line disagreed by 12 % on cfg5)
-    for name, steps, n_ctx in (("cfg3", 12, 3), ("cfg5", 12, 3), ("cfg4", 6, 1), ("cfg2_sends", 12, 1), ("cfg2_rs", 10, 1), ("cfg2_spatial", 10, 1),
-                               ("cfg2_variantB", 10, 1), ("cfg2_i16", 12, 1), ("cfg2_levels", 4, 1)):
+    # (cfg3_reordered, round 6: config 3's voices in an order the chain plan refused before — a gain in FRONT of the filter, two biquads,
+    #  interleaved 16-bit sources: 20 B per voice-sample)
+    for name, steps, n_ctx in (("cfg3", 12, 3), ("cfg3_reordered", 12, 1), ("cfg5", 12, 3), ("cfg4", 6, 1), ("cfg2_sends", 12, 1), ("cfg2_rs", 10, 1),
+                               ("cfg2_spatial", 10, 1), ("cfg2_variantB", 10, 1), ("cfg2_i16", 12, 1), ("cfg2_levels", 4, 1)):
         wl = name.split("_")[0]
         V, B, K, F, _ = DEFAULTS[wl]
         try:
@@ -1142,6 +1166,9 @@ def other_configs(env, args):
                 if name == "cfg2_variantB":
                     wargs.variant = "B"
                 if name == "cfg2_i16":
+                    wargs.source_format = sfmt = "i16"
+                wargs.chain_reordered = name == "cfg3_reordered"
+                if name == "cfg3_reordered":
                     wargs.source_format = sfmt = "i16"
                 if name == "cfg2_levels":  # the headline graph on the level executor alone: what a graph no fused plan takes runs at
                     wargs.force_generic = True
@@ -1463,6 +1490,9 @@ def main():
                     help="cfg2/cfg5: a StereoWidthNode + HardClipNode at the end of every voice chain")
     ap.add_argument("--rs-source", action="store_true",
                     help="cfg2/cfg5: the voices' sources are SPEC resamplers (looping, ratio U(0.5, 1.5)) instead of samplers")
+    ap.add_argument("--chain-reordered", action="store_true",
+                    help="cfg3: the voices as sampler -> gain -> biquad -> biquad -> delay -> pan (the chain plan's round-6 grammar); "
+                         "with --source-format i16 on interleaved 16-bit sources")
     ap.add_argument("--force-generic", action="store_true",
                     help="run the workload on the generic level-batched executor (plan 0) instead of its fused plan")
     ap.add_argument("--variant", choices=["A", "B", "C"], default="A",
@@ -1495,7 +1525,7 @@ def main():
     steps = args.steps or dS
     wl = args.workload
     default_shape = (wl == "cfg2" and (V, B, K, F) == (dV, dB, dK, dF) and args.source_format == "f32" and args.variant == "A" and
-                     not (args.master or args.master_iir or args.voice_fx or args.voice_spatial or args.send or args.rs_source or args.force_generic or args.host_buffers))
+                     not (args.master or args.master_iir or args.voice_fx or args.voice_spatial or args.send or args.rs_source or args.force_generic or args.host_buffers or args.chain_reordered))
 
     # stdout carries exactly ONE line (the JSON, rank 0): everything else that writes to fd 1 — RCCL's version banner
     # and warnings come from C stdio, flushed whenever — is sent to stderr for the life of the process

@@ -112,6 +112,13 @@ SIGNATURES = {
     "fwgpu_process_blocks_device": (ci, [vp, u32, vp, u32]),
     "fwgpu_process_blocks_device_flags": (ci, [vp, u32, vp, u32, vp]),
     "fwgpu_process_blocks_device_io": (ci, [vp, u32, vp, u32, vp, u32, vp]),
+    "fwgpu_rccl_unique_id": (ci, [vp]),
+    "fwgpu_rccl_comm_create": (vp, [vp, vp, u32, u32]),
+    "fwgpu_rccl_comm_destroy": (ci, [vp]),
+    "fwgpu_rccl_comm_info": (ci, [vp, C.POINTER(u32), C.POINTER(u32)]),
+    "fwgpu_bus_allreduce_rccl": (ci, [vp, vp, u64]),
+    "fwgpu_bus_allgather_ordered": (ci, [vp, vp, vp, vp, vp, u64, u32, u32]),
+    "fwgpu_rccl_last_error": (C.c_char_p, []),
     "fwgpu_bus_sum_ordered": (ci, [vp, C.POINTER(vp), u32, vp, u64]),
     "fwgpu_bus_sum_ordered_flags": (ci, [vp, C.POINTER(vp), C.POINTER(vp), u32, vp, vp, u64, u32, u32]),
     "fwgpu_bus_exchange_open": (vp, [vp, u32, u32, u64, u32]),

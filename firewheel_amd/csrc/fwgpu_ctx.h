@@ -174,7 +174,7 @@ struct PlanImage {
     bool fused = false;
     uint32_t generic_k = 1;  // blocks per generic-executor batch: kmax, capped by what the FIR history rings hold
     bool fused_fx = false;  // the fused plan's leaves run k_chain (biquad / delay in the voice chains)
-    int chain_nq = 1;       // k_chain tile size / 64 frames
+    int chain_nq = 1;       // k_chain tile size / 64 frames (bits 0..1); bit 2: some voice holds two biquads (the instantiation with a second recurrence stage)
     int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
     int n_groups = 0;  // k_chain workgroups (groups of consecutive leaves)
     DevBuf d_groups;

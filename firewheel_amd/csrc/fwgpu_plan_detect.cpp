@@ -25,6 +25,146 @@ struct ConsCounts {
     const int* operator[](int node) const { return cnt.data() + off[node]; }
     int n_out(int node) const { return off[node + 1] - off[node]; }
 };
+
+// both channels of input port pair `port0` come from ONE stereo node, each consumed exactly once
+bool stereo_src(const Plan& plan, const ConsCounts& cons, const PlanNode& n, int port0, int& src) {
+    int a = n.in_src_node[port0], b = n.in_src_node[port0 + 1];
+    if (a < 0 || a != b) return false;
+    if (n.in_src_port[port0] != 0 || n.in_src_port[port0 + 1] != 1) return false;
+    if (plan.nodes[a].n_out != 2 || cons[a][0] != 1 || cons[a][1] != 1) return false;
+    src = a;
+    return true;
+}
+
+VoiceDesc null_voice() {  // an unconnected mixer port: k_voice_control emits a constant silent, cleared-source record for it
+    VoiceDesc vd;
+    memset(&vd, 0, sizeof(vd));
+    vd.sampler_state = vd.bq_state = vd.dl_state = vd.sp_ext_off = vd.bq2_state = -1;
+    return vd;
+}
+
+// One voice chain, walked UPSTREAM from its last node to its source — the grammar of both fused plans:
+//   voice bank:  source -> {volume, pan, width, clip}* [-> spatialiser]            source = sampler | resampler | sampler(0->1) -> MonoToStereo
+//   chain plan:  sampler -> {volume, pan}{n_pre} -> FX -> {volume, pan, ...}*       FX = B | BB | D | BD | BBD | DB | DBB   (B biquad, D delay >= 64 frames)
+// Round 6: gain stages in FRONT of the filters (they see the source's silence flag: positional silence in k_voice_control), two
+// biquads in a row (an EQ cascade: the second one's recurrence runs on a wave of its own a tile behind the first's), the delay line
+// in front of the biquads.  Still refused: a gain BETWEEN two filters, B D B, width / clip in front of a filter (they need both
+// channels / a program stage in S1), a resampler, spatialiser or mono adapter with a filter.  A refused voice is not lost: the
+// hybrid plan renders its longest acceptable prefix as a solo voice, the level executor the rest.
+struct VoiceWalk {
+    bool ok = false;
+    VoiceDesc vd;
+    uint32_t prog_bits = 0;
+    int nodes[FW_MAX_STAGES + 6], n_nodes = 0;  // plan indices, the source first
+    bool prog = false, rs = false, fx = false, sp = false;
+    uint64_t delay = ~0ull;
+};
+VoiceWalk walk_voice_chain(const Plan& plan, const HostGraph& graph, const ConsCounts& cons, uint32_t mbf, const std::vector<char>& taken, int cur) {
+    VoiceWalk w;
+    w.vd = null_voice();
+    int chain[FW_MAX_STAGES], n_chain = 0;  // gain-like stages in walk order (nearest the mixer first)
+    int n_pre = 0;
+    int fxn[3], n_fx = 0;  // biquads / the delay in walk order
+    char fxk[4] = {0, 0, 0, 0};
+    bool sp_voice = false;
+    int mono_adapter = -1;
+    for (;;) {
+        const PlanNode& n = plan.nodes[cur];
+        if (taken[cur] || n.is_graph_io) return w;
+        if (n.kind == K_SAMPLER || n.kind == K_RESAMPLER) {
+            if (!(n.n_in == 0 && n.n_out == 2)) return w;
+            break;
+        }
+        if (n.kind == K_MONO_TO_STEREO) {
+            // sampler(0 -> 1) -> MonoToStereoNode (mono_to_stereo.rs:33-50): the reference's own adapter behind a ONE-output sampler —
+            // channel 0 of its sample on both outputs, silence passed on: a voice whose every block is VB_MONO (src_kind 2;
+            // k_control.hip.h mono_adapt).  Dry / gain chains only.
+            if (n.n_in != 1 || n.n_out != 2 || n_fx || sp_voice) return w;
+            const int sidx = n.in_src_node[0];
+            if (sidx < 0 || n.in_src_port[0] != 0 || taken[sidx]) return w;
+            const PlanNode& sn = plan.nodes[sidx];
+            if (sn.kind != K_SAMPLER || sn.n_in != 0 || sn.n_out != 1 || sn.is_graph_io || cons[sidx][0] != 1) return w;
+            mono_adapter = cur;
+            cur = sidx;
+            break;
+        }
+        if (n.n_in != 2 || n.n_out != 2) return w;
+        if (n.kind == K_VOLUME || n.kind == K_PAN || n.kind == K_WIDTH || n.kind == K_HARD_CLIP) {
+            if (n_chain >= FW_MAX_STAGES - 1) return w;
+            if (n_fx) {  // in FRONT of the filters: k_chain's S1 multiplies per channel, nothing else
+                if (n.kind != K_VOLUME && n.kind != K_PAN) return w;
+                n_pre++;
+            }
+            chain[n_chain++] = cur;
+        } else if (n.kind == K_SPATIAL) {
+            // a spatialiser as the LAST node of a dry voice (the first one met walking up from the mixer); its 64-frame history needs
+            // whole 64-frame blocks
+            if (n_chain || n_fx || mbf % 64 != 0) return w;
+            sp_voice = true;
+            chain[n_chain++] = cur;
+        } else if (n.kind == K_DELAY || n.kind == K_BIQUAD) {
+            if (n_pre || n_fx >= 3 || sp_voice) return w;  // (a gain between two filters: refused)
+            if (n.kind == K_DELAY) {
+                if (graph.nodes[n.slot].init.loop_end < 64) return w;  // shorter than one k_chain tile
+                w.delay = graph.nodes[n.slot].init.loop_end;
+            }
+            fxk[n_fx] = n.kind == K_DELAY ? 'D' : 'B';
+            fxn[n_fx++] = cur;
+        } else {
+            return w;
+        }
+        int src;
+        if (!stereo_src(plan, cons, n, 0, src)) return w;
+        cur = src;
+    }
+    // the filters in SCHEDULE order (the walk met them last one first)
+    int bq = -1, bq2 = -1, dl = -1, order = 0;
+    if (n_fx) {
+        char sched[4] = {0, 0, 0, 0};
+        int sn[3] = {-1, -1, -1};
+        for (int i = 0; i < n_fx; ++i) {
+            sched[i] = fxk[n_fx - 1 - i];
+            sn[i] = fxn[n_fx - 1 - i];
+        }
+        const std::string q(sched);
+        if (q == "B") bq = sn[0];
+        else if (q == "BB") bq = sn[0], bq2 = sn[1];
+        else if (q == "D") dl = sn[0];
+        else if (q == "BD") bq = sn[0], dl = sn[1];
+        else if (q == "BBD") bq = sn[0], bq2 = sn[1], dl = sn[2];
+        else if (q == "DB") dl = sn[0], bq = sn[1], order = 1;
+        else if (q == "DBB") dl = sn[0], bq = sn[1], bq2 = sn[2], order = 1;
+        else return w;
+    }
+    const bool rs = plan.nodes[cur].kind == K_RESAMPLER;
+    if (rs && (n_fx || sp_voice)) return w;  // (the chain plan's source fetch is the sampler's; a spatialiser voice is a dry sampler voice)
+    w.vd.sp_ext_off = sp_voice ? 0 : -1;  // the node's ext slice: filled in by the plan build (the node may be activated by this very plan)
+    w.sp = sp_voice;
+    w.prog = sp_voice;
+    w.vd.sampler_state = (int)plan.nodes[cur].slot;
+    w.vd.src_kind = mono_adapter >= 0 ? 2 : (rs ? 1 : 0);
+    w.vd.bq_state = bq >= 0 ? (int)plan.nodes[bq].slot : -1;
+    w.vd.bq2_state = bq2 >= 0 ? (int)plan.nodes[bq2].slot : -1;
+    w.vd.dl_state = dl >= 0 ? (int)plan.nodes[dl].slot : -1;
+    w.vd.fx_order = order;
+    w.vd.n_pre = n_pre;
+    w.fx = n_fx != 0;
+    w.rs = rs;
+    w.vd.n_stages = n_chain;
+    for (int j = 0; j < n_chain; ++j) {  // schedule order: nearest the source first
+        const PlanNode& n = plan.nodes[chain[n_chain - 1 - j]];
+        w.vd.stage_kind[j] = n.kind;
+        w.vd.stage_state[j] = (int)n.slot;
+        w.prog_bits |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : n.kind == K_SPATIAL ? SK_SPATIAL : SK_GAIN) << (4 * j);
+        w.prog = w.prog || n.kind == K_WIDTH || n.kind == K_HARD_CLIP;
+    }
+    w.nodes[w.n_nodes++] = cur;
+    if (mono_adapter >= 0) w.nodes[w.n_nodes++] = mono_adapter;
+    for (int i = 0; i < n_fx; ++i) w.nodes[w.n_nodes++] = fxn[i];
+    for (int j = 0; j < n_chain; ++j) w.nodes[w.n_nodes++] = chain[j];
+    w.ok = true;
+    return w;
+}
 }  // namespace
 
 
@@ -36,14 +176,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
     if (gout.is_graph_io != 2 || gout.n_in != 2) return false;
     // consumer counts per (node, port)
     const ConsCounts cons(plan);
-    auto stereo_src = [&](const PlanNode& n, int port0, int& src) -> bool {
-        int a = n.in_src_node[port0], b = n.in_src_node[port0 + 1];
-        if (a < 0 || a != b) return false;
-        if (n.in_src_port[port0] != 0 || n.in_src_port[port0 + 1] != 1) return false;
-        if (plan.nodes[a].n_out != 2 || cons[a][0] != 1 || cons[a][1] != 1) return false;
-        src = a;
-        return true;
-    };
+    auto stereo_src = [&](const PlanNode& n, int port0, int& src) -> bool { return fwgpu::stereo_src(plan, cons, n, port0, src); };
     int root;
     if (!stereo_src(gout, 0, root)) return false;
     std::vector<char> covered(N, 0);
@@ -132,101 +265,21 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
         next_bus += 2;
         for (int end : r.kids) {
             if (end < 0) {  // null voice: k_voice_control emits a constant silent, cleared-source record for it
-                VoiceDesc vd;
-                memset(&vd, 0, sizeof(vd));
-                vd.sampler_state = vd.bq_state = vd.dl_state = vd.sp_ext_off = -1;
-                fb.voices.push_back(vd);
+                fb.voices.push_back(null_voice());
                 fb.progs.push_back(0u);
                 continue;
             }
-            // walk upstream: end -> ... -> sampler
-            // accepted shape: sampler -> [biquad] -> [delay] -> (volume|pan)*
-            int chain[FW_MAX_STAGES], n_chain = 0;  // (a vector here was an allocation per voice)
-            int cur = end;
-            int bq = -1, dl = -1;
-            bool sp_voice = false;
-            bool mono_src = false;
-            for (;;) {
-                const PlanNode& n = plan.nodes[cur];
-                if (covered[cur]) return false;
-                if (n.kind == K_SAMPLER || n.kind == K_RESAMPLER) {
-                    if (n.n_in != 0 || n.n_out != 2) return false;
-                    covered[cur] = 1;
-                    break;
-                }
-                if (n.kind == K_MONO_TO_STEREO) {
-                    // sampler(0 -> 1) -> MonoToStereoNode (mono_to_stereo.rs:33-50): the reference's own adapter behind a ONE-output
-                    // sampler — channel 0 of its sample on both outputs, silence passed on: a voice whose every block is VB_MONO
-                    // (src_kind 2; k_control.hip.h mono_adapt).  Dry / gain chains only.
-                    if (n.n_in != 1 || n.n_out != 2 || bq >= 0 || dl >= 0 || sp_voice) return false;
-                    const int sidx = n.in_src_node[0];
-                    if (sidx < 0 || n.in_src_port[0] != 0 || covered[sidx]) return false;
-                    const PlanNode& sn = plan.nodes[sidx];
-                    if (sn.kind != K_SAMPLER || sn.n_in != 0 || sn.n_out != 1 || cons[sidx][0] != 1) return false;
-                    covered[cur] = 1;
-                    covered[sidx] = 1;
-                    mono_src = true;
-                    cur = sidx;
-                    break;
-                }
-                if (n.n_in != 2 || n.n_out != 2) return false;
-                if (n.kind == K_VOLUME || n.kind == K_PAN || n.kind == K_WIDTH || n.kind == K_HARD_CLIP) {
-                    if (bq >= 0 || dl >= 0) return false;  // gain stages before the filter: generic executor
-                    if (n.kind == K_WIDTH || n.kind == K_HARD_CLIP) fb.has_prog = true;
-                    if (n_chain >= FW_MAX_STAGES - 1) return false;
-                    chain[n_chain++] = cur;
-                } else if (n.kind == K_SPATIAL) {
-                    // a spatialiser as the LAST node of a dry voice (the first one met walking up from the mixer); its 64-frame
-                    // history needs whole 64-frame blocks
-                    if (n_chain || bq >= 0 || dl >= 0 || mbf % 64 != 0) return false;
-                    sp_voice = true;
-                    chain[n_chain++] = cur;
-                } else if (n.kind == K_DELAY) {
-                    if (bq >= 0 || dl >= 0) return false;
-                    if (graph.nodes[n.slot].init.loop_end < 64) return false;  // shorter than one k_chain tile
-                    fb.min_delay = std::min<uint64_t>(fb.min_delay, graph.nodes[n.slot].init.loop_end);
-                    dl = cur;
-                } else if (n.kind == K_BIQUAD) {
-                    if (bq >= 0) return false;
-                    bq = cur;
-                } else {
-                    return false;
-                }
-                covered[cur] = 1;
-                int src;
-                if (!stereo_src(n, 0, src)) return false;
-                cur = src;
-            }
-            VoiceDesc vd;
-            memset(&vd, 0, sizeof(vd));
-            vd.bq_state = bq >= 0 ? (int)plan.nodes[bq].slot : -1;
-            vd.dl_state = dl >= 0 ? (int)plan.nodes[dl].slot : -1;
-            if (bq >= 0 || dl >= 0) fb.has_fx = true;
-            vd.sampler_state = (int)plan.nodes[cur].slot;
-            vd.src_kind = mono_src ? 2 : (plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0);
-            if (vd.src_kind == 1) {
-                if (bq >= 0 || dl >= 0) return false;  // (the chain plan's source fetch is the sampler's)
-                fb.has_prog = true;                    // the polyphase fetch lives in the leaf kernel's program instantiation
-                fb.has_rs = true;
-            }
-            vd.sp_ext_off = -1;
-            if (sp_voice) {
-                if (bq >= 0 || dl >= 0 || vd.src_kind == 1) return false;  // (dry sampler voices only: generic executor otherwise)
-                fb.has_prog = true;
-                fb.has_sp = true;
-                vd.sp_ext_off = 0;  // the node's ext slice: filled in by the plan build (the node may be activated by this very plan)
-            }
-            vd.n_stages = n_chain;
-            uint32_t prog = 0;
-            for (int j = 0; j < vd.n_stages; ++j) {  // schedule order: nearest the sampler first
-                const PlanNode& n = plan.nodes[chain[n_chain - 1 - j]];
-                vd.stage_kind[j] = n.kind;
-                vd.stage_state[j] = (int)n.slot;
-                prog |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : n.kind == K_SPATIAL ? SK_SPATIAL : SK_GAIN) << (4 * j);
-            }
-            fb.progs.push_back(prog);
-            fb.max_stages = std::max(fb.max_stages, vd.n_stages);
-            fb.voices.push_back(vd);
+            const VoiceWalk w = walk_voice_chain(plan, graph, cons, mbf, covered, end);  // (a node met twice: covered -> refused)
+            if (!w.ok) return false;
+            for (int i = 0; i < w.n_nodes; ++i) covered[w.nodes[i]] = 1;
+            fb.has_fx = fb.has_fx || w.fx;
+            fb.has_prog = fb.has_prog || w.prog || w.rs;  // (the polyphase fetch lives in the leaf kernel's program instantiation)
+            fb.has_rs = fb.has_rs || w.rs;
+            fb.has_sp = fb.has_sp || w.sp;
+            fb.min_delay = std::min(fb.min_delay, w.delay);
+            fb.progs.push_back(w.prog_bits);
+            fb.max_stages = std::max(fb.max_stages, w.vd.n_stages);
+            fb.voices.push_back(w.vd);
         }
         fb.leaves.push_back(ld);
     }
@@ -311,14 +364,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
 bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedBuild& fb) {
     const int N = (int)plan.nodes.size();
     const ConsCounts cons(plan);
-    auto stereo_src = [&](const PlanNode& n, int port0, int& src) -> bool {  // both channels from ONE node, consumed once each
-        int a = n.in_src_node[port0], b = n.in_src_node[port0 + 1];
-        if (a < 0 || a != b) return false;
-        if (n.in_src_port[port0] != 0 || n.in_src_port[port0 + 1] != 1) return false;
-        if (plan.nodes[a].n_out != 2 || cons[a][0] != 1 || cons[a][1] != 1) return false;
-        src = a;
-        return true;
-    };
+    auto stereo_src = [&](const PlanNode& n, int port0, int& src) -> bool { return fwgpu::stereo_src(plan, cons, n, port0, src); };
     struct Bank {
         int sum;  // the SumNode — or, for a solo voice, the last node of its chain: the node whose output buffers the leaf writes
         std::vector<VoiceDesc> voices;
@@ -330,89 +376,9 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         bool split = false;  // only the leading ports are voices: the SumNode stays on the levels as a continuation
         bool solo = false;   // one voice chain on its own (below)
     };
-    // one voice chain, walked upstream from its last node: gain stages, then [delay], then [biquad], then the source (as detect_fused)
-    struct Walk {
-        bool ok = false;
-        VoiceDesc vd;
-        uint32_t prog_bits = 0;
-        int nodes[FW_MAX_STAGES + 4], n_nodes = 0;
-        bool prog = false, rs = false, fx = false, sp = false;
-        uint64_t delay = ~0ull;
-    };
+    typedef VoiceWalk Walk;  // one voice chain, walked upstream from its last node (walk_voice_chain above: the grammar of both fused plans)
     std::vector<char> taken(N, 0);  // nodes of a candidate bank (a chain node feeds one consumer, so banks cannot overlap)
-    auto walk_voice = [&](int cur) -> Walk {
-        Walk w;
-        memset(&w.vd, 0, sizeof(w.vd));
-        w.vd.sampler_state = w.vd.bq_state = w.vd.dl_state = w.vd.sp_ext_off = -1;
-        int chain[FW_MAX_STAGES], n_chain = 0;
-        int bq = -1, dl = -1;
-        bool sp_voice = false;
-        int mono_adapter = -1;
-        for (;;) {
-            const PlanNode& n = plan.nodes[cur];
-            if (taken[cur] || n.is_graph_io) return w;
-            if (n.kind == K_SAMPLER || n.kind == K_RESAMPLER) {
-                if (!(n.n_in == 0 && n.n_out == 2)) return w;
-                break;
-            }
-            if (n.kind == K_MONO_TO_STEREO) {  // (as detect_fused: a one-output sampler behind the reference's adapter)
-                if (n.n_in != 1 || n.n_out != 2 || bq >= 0 || dl >= 0 || sp_voice) return w;
-                const int sidx = n.in_src_node[0];
-                if (sidx < 0 || n.in_src_port[0] != 0 || taken[sidx]) return w;
-                const PlanNode& sn = plan.nodes[sidx];
-                if (sn.kind != K_SAMPLER || sn.n_in != 0 || sn.n_out != 1 || sn.is_graph_io || cons[sidx][0] != 1) return w;
-                mono_adapter = cur;
-                cur = sidx;
-                break;
-            }
-            if (n.n_in != 2 || n.n_out != 2) return w;
-            if (n.kind == K_VOLUME || n.kind == K_PAN || n.kind == K_WIDTH || n.kind == K_HARD_CLIP) {
-                if (bq >= 0 || dl >= 0 || n_chain >= FW_MAX_STAGES - 1) return w;
-                chain[n_chain++] = cur;
-            } else if (n.kind == K_SPATIAL) {  // (as detect_fused: the last node of a dry sampler voice)
-                if (n_chain || bq >= 0 || dl >= 0 || mbf % 64 != 0) return w;
-                sp_voice = true;
-                chain[n_chain++] = cur;
-            } else if (n.kind == K_DELAY) {
-                if (bq >= 0 || dl >= 0 || graph.nodes[n.slot].init.loop_end < 64) return w;
-                w.delay = graph.nodes[n.slot].init.loop_end;
-                dl = cur;
-            } else if (n.kind == K_BIQUAD) {
-                if (bq >= 0) return w;
-                bq = cur;
-            } else {
-                return w;
-            }
-            int src;
-            if (!stereo_src(n, 0, src)) return w;
-            cur = src;
-        }
-        if (sp_voice && (bq >= 0 || dl >= 0 || plan.nodes[cur].kind == K_RESAMPLER)) return w;
-        w.vd.sp_ext_off = sp_voice ? 0 : -1;
-        w.sp = sp_voice;
-        w.prog = sp_voice;
-        w.vd.sampler_state = (int)plan.nodes[cur].slot;
-        w.vd.src_kind = mono_adapter >= 0 ? 2 : (plan.nodes[cur].kind == K_RESAMPLER ? 1 : 0);
-        w.vd.bq_state = bq >= 0 ? (int)plan.nodes[bq].slot : -1;
-        w.vd.dl_state = dl >= 0 ? (int)plan.nodes[dl].slot : -1;
-        w.fx = bq >= 0 || dl >= 0;
-        w.rs = w.vd.src_kind == 1;
-        w.vd.n_stages = n_chain;
-        for (int j = 0; j < n_chain; ++j) {  // schedule order: nearest the source first
-            const PlanNode& n = plan.nodes[chain[n_chain - 1 - j]];
-            w.vd.stage_kind[j] = n.kind;
-            w.vd.stage_state[j] = (int)n.slot;
-            w.prog_bits |= (n.kind == K_WIDTH ? SK_WIDTH : n.kind == K_HARD_CLIP ? SK_CLIP : n.kind == K_SPATIAL ? SK_SPATIAL : SK_GAIN) << (4 * j);
-            w.prog = w.prog || n.kind == K_WIDTH || n.kind == K_HARD_CLIP;
-        }
-        w.nodes[w.n_nodes++] = cur;
-        if (mono_adapter >= 0) w.nodes[w.n_nodes++] = mono_adapter;
-        if (bq >= 0) w.nodes[w.n_nodes++] = bq;
-        if (dl >= 0) w.nodes[w.n_nodes++] = dl;
-        for (int j = 0; j < n_chain; ++j) w.nodes[w.n_nodes++] = chain[j];
-        w.ok = true;
-        return w;
-    };
+    auto walk_voice = [&](int cur) -> Walk { return walk_voice_chain(plan, graph, cons, mbf, taken, cur); };
     auto take = [&](Bank& bk, const Walk& w) {
         bk.sp = bk.sp || w.sp;
         bk.prog = bk.prog || w.prog;
@@ -435,10 +401,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         bool ok = true;
         for (int p = 0; p < s.n_in / 2; ++p) {  // (a port that turns out not to be a voice chain leaves the bank as it was)
             if (s.in_src_node[2 * p] < 0 && s.in_src_node[2 * p + 1] < 0) {  // an empty voice slot: a null voice
-                VoiceDesc vd;
-                memset(&vd, 0, sizeof(vd));
-                vd.sampler_state = vd.bq_state = vd.dl_state = vd.sp_ext_off = -1;
-                bk.voices.push_back(vd);
+                bk.voices.push_back(null_voice());
                 bk.progs.push_back(0u);
                 continue;
             }

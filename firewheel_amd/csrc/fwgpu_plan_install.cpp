@@ -347,6 +347,7 @@ static void build_slot_voice(PlanImage& P, const std::vector<VoiceDesc>& voices)
         f(vd.sampler_state);
         for (int j = 0; j < vd.n_stages && j < FW_MAX_STAGES - 1; ++j) f(vd.stage_state[j]);
         f(vd.bq_state);
+        f(vd.bq2_state);
         f(vd.dl_state);
     };
     for (const VoiceDesc& vd : voices) each(vd, [&](int s) { max_slot = std::max(max_slot, s); });
@@ -863,6 +864,8 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         if (const char* e = getenv("FWGPU_CHAIN_NQ")) {  // experiments: force the smaller tile
             if (atoi(e) == 1) P.chain_nq = 1;
         }
+        for (const VoiceDesc& vd : fb.voices)  // an EQ cascade somewhere: the instantiation with the second recurrence stage (bit 2)
+            if (vd.bq2_state >= 0) P.chain_nq |= 4;
         P.n_voices = (int)fb.voices.size();
         P.n_leaves = (int)fb.leaves.size();
         P.n_bus = fb.n_bus;
@@ -1020,6 +1023,8 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             if (const char* e = getenv("FWGPU_CHAIN_NQ")) {
                 if (atoi(e) == 1) P.chain_nq = 1;
             }
+            for (const VoiceDesc& vd : hb.voices)
+                if (vd.bq2_state >= 0) P.chain_nq |= 4;
             P.generic_k = std::min<uint32_t>(P.generic_k, CH_FAST_KMAX);
         }
         P.n_tail = 0;

@@ -122,17 +122,26 @@ enum : uint32_t {
                      // per-ear delays of the block's record (VB_SP_SHIFT) and the 64-frame mono history of the block before
 };
 
-struct VoiceDesc {  // static per voice chain: sampler -> [biquad] -> [delay] -> [volume|pan|width|hard clip]* -> leaf sum port
+// static per voice chain.  Voice-bank plan: source -> [volume|pan|width|hard clip|spatialiser]* -> leaf sum port.  Chain plan (round 6
+// grammar): sampler -> [volume|pan]{n_pre} -> FX -> [volume|pan]* -> leaf sum port with FX one of
+//   biquad, biquad biquad, delay, biquad delay, biquad biquad delay  (fx_order 0: filters first)   or
+//   delay biquad, delay biquad biquad                                (fx_order 1: the delay line first)
+struct VoiceDesc {
     int sampler_state;
-    int n_stages;                      // chain stages after the sampler (and after the biquad / delay, if any)
-    int stage_kind[FW_MAX_STAGES - 1];
+    int n_stages;                      // gain-like stages of the chain, in schedule order: the first n_pre sit between the source and the
+    int stage_kind[FW_MAX_STAGES - 1]; //   biquad / delay (they see the source's silence flag), the rest behind them (they never see one)
     int stage_state[FW_MAX_STAGES - 1];
-    int bq_state;                      // biquad between the sampler and the gain stages, -1 = none (k_chain plan)
-    int dl_state;                      // delay after the biquad, -1 = none
+    int bq_state;                      // the (first) biquad of the chain, -1 = none (k_chain plan)
+    int dl_state;                      // the delay line, -1 = none
     int src_kind;                      // 0 = SamplerNode, 1 = SPEC resampling source (sampler_state = its state; no gain of its own),
                                        // 2 = a ONE-output SamplerNode behind a MonoToStereoNode: channel 0 on both outputs (round 5)
     int sp_ext_off;                    // a SPEC spatialiser as the last stage: ext-pool offset of its SP_HIST-frame mono history; -1 = none
+    int n_pre;                         // chain plan: gain stages in FRONT of the biquad / delay (0 for a dry voice)
+    int bq2_state;                     // chain plan: a second biquad right behind the first (an EQ cascade), -1 = none
+    int fx_order;                      // chain plan: 0 = biquad(s) then delay, 1 = delay then biquad(s)
+    int pad_;
 };
+static_assert(sizeof(VoiceDesc) == 80, "VoiceDesc layout");
 
 // per (block, voice) record written by the control kernels, read by the leaf kernel (80 B)
 enum : uint32_t {
@@ -293,9 +302,10 @@ struct ChainStart {
     uint32_t pos;       // delay ring position
     float fb, mix, dry; // delay feedback / wet / dry
     float co[5];        // biquad b0 b1 b2 a1 a2
-    uint32_t pad[3];
+    float co2[5];       // the second biquad's (VoiceDesc::bq2_state)
+    uint32_t pad[2];
 };
-static_assert(sizeof(ChainStart) == 48, "ChainStart layout");
+static_assert(sizeof(ChainStart) == 64, "ChainStart layout");
 
 // the top-level SumNode over the partial mix buses of R voice shards (nodes/sum.rs:111-133), passed by value
 #define FW_MAX_BUS_PARTS 64

@@ -3,7 +3,8 @@
 #pragma once
 
 // ------------------------------------------------------------------ fused chain plan (config 3): k_chain
-// Voices of the shape  sampler -> [biquad] -> [delay] -> [volume|pan]* -> leaf SumNode.  The biquad (SPEC: DF1 in
+// Voices of the shape  sampler -> [volume|pan]* -> FX -> [volume|pan]* -> leaf SumNode, FX = B | BB | D | BD | BBD | DB | DBB (B = biquad,
+// D = delay; fwgpu_plan_detect.cpp walk_voice_chain).  The biquad (SPEC: DF1 in
 // f32, unfused feed-forward half + two fused feedback taps) is a serial recurrence in time, so time cannot be split across workgroups; what is
 // parallel is the voices — and the two channels, which never meet before the mix bus.  One workgroup owns one
 // (leaf SumNode of <= 32 voices, channel) for all K blocks of the call and walks time in tiles of TT = 64*NQ frames
@@ -16,6 +17,14 @@
 // Every rounding is the one the oracle performs (products and sums separately, same order), so the result is
 // bit-identical to the generic executor.  HBM traffic per stereo voice-sample: 8 B source + 8 B ring read + 8 B
 // ring write = the 24 B of SURVEY §8d.
+// Round 6: gain stages in FRONT of the filters are multiplied in by S1 (VoiceDesc::n_pre); a delay line in FRONT of the biquads
+// (fx_order 1) is read-modify-written by S1 instead of S3a (general loop only: the steady-call loop takes filter-first voices); a
+// SECOND biquad (an EQ cascade) is two more pipeline stages in the <NQ, true> instantiation (six tile buffers, S3a / S3b two tiles
+// later): S1b — the worker lanes form its feed-forward sums on the first biquad's output, in place — and S2b — its recurrence, a
+// second serial wave.  Measured (clock64 per role, profiles/r06_chain_roles.txt): a serial wave issues one instruction per ~7 cycles
+// whatever the instruction, the recurrence costs ~25 cycles per frame (two dependent fmas), and a wave that did the second filter's
+// five feed-forward operations per frame as well took 45 — longer than a whole step of the other roles; four other arrangements of
+// that work on ONE wave (frame-parallel feed-forward phase, lane pairs, hand-interleaved with the recurrence) were slower still.
 //
 // Latency hiding: the HBM loads a step consumes were issued during the previous step, right after their registers
 // were last used (ring slots of tile s-1 after S3a of tile s-2, source of tile s+1 after S1 of tile s), and stay in
@@ -60,6 +69,19 @@ __device__ __forceinline__ float row_ror1(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
 }
 
+// a quad of an interleaved stereo 16-bit source as it was loaded (4 frames x {L, R} x 16 bit = one dwordx4): this channel's halves
+// as f32 (core/sample_resource.rs:338-345: the conversions of k_leaf.hip.h cvt_i16 / cvt_u16).  c16: 1 = i16, 2 = u16
+__device__ __forceinline__ v4f chain_cvt16(const v4f raw, const int c16, const int ch) {
+    v4f o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int w = __float_as_int(raw[e]);
+        const int h = ch ? (w >> 16) : w;
+        o[e] = c16 == 1 ? cvt_i16(h) : cvt_u16(h);
+    }
+    return o;
+}
+
 struct ChainInfo {  // what a worker lane carries from S1 of a tile to S3a of the same tile (two steps later)
     uint32_t flags;                // VB_* of the tile's block, ramp bits included
     float g[FW_CHAIN_STAGES - 1];    // this channel's constant post-gain stages (1..)
@@ -83,13 +105,17 @@ __device__ __forceinline__ void chain_mix_uniform(const v4f (&x)[32], uint32_t s
     }
 }
 
-template <int NQ>
+template <int NQ, bool BQ2>
 __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint32_t cmd_block0) {
     constexpr int TT = 64 * NQ;        // frames per tile
     constexpr int PITCH = TT + 4;      // floats per voice row: + 4 -> the 32 S2 lanes' b128 reads are conflict-free
     constexpr int LF = 4 * NQ;         // frames per worker lane
-    __shared__ float tile[CH_NBUF][32][PITCH];  // row = voice (this workgroup's channel)
-    __shared__ uint32_t silf[CH_NBUF][32];      // chain output cleared + flagged silent (VB_SILENT) per voice
+    constexpr int NBUF = BQ2 ? 6 : CH_NBUF;  // tile buffers in flight
+    constexpr int LAG3 = BQ2 ? 4 : 2;        // S3a runs this many tiles behind S1 (two-biquad instantiation: S1b at 2 and S2b at 3 sit in between)
+    constexpr int LAG4 = LAG3 + 1;           // ... and S3b, the mixer, one more
+#define CH_BUF(t) ((unsigned)((t) + NBUF) % (unsigned)NBUF)  // buffer of tile t (t >= -NBUF)
+    __shared__ float tile[NBUF][32][PITCH];  // row = voice (this workgroup's channel)
+    __shared__ uint32_t silf[NBUF][32];      // chain output cleared + flagged silent (VB_SILENT) per voice
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
     // up to 8 consecutive leaves, <= 32 voices: this workgroup's rows.  Per-leaf fields are read through LDS (indexing a
     // register copy of the record by a run-time leaf index would push it to scratch)
@@ -114,9 +140,17 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     // The serial wave (2) gets a SIMD to itself — waves 6 and 10 only take part in the barriers — the mixer (11)
     // shares one with two workers, the other six workers fill the remaining two SIMDs.
     const bool is_serial = wave == 2;
-    const bool is_mixer = wave == 11;
-    const bool is_idle = wave == 6 || wave == 10;
-    const bool is_worker = !is_serial && !is_mixer && !is_idle;
+#ifndef CH_S2B_WAVE
+#define CH_S2B_WAVE 6
+#endif
+    // the second biquad's recurrence: wave 6 = a wave of its own on the first one's SIMD (no worker there).  Measured alternatives
+    // (profiles/r06_chain_roles.txt): 11 = on the SIMD of workers 3 and 7, the mixer then on wave 6: ~1 % faster, not worth the second
+    // role map; BOTH chains interleaved frame by frame in wave 2: 58 cycles per frame instead of 2 x 24 — one wave issues an instruction
+    // every ~12 cycles however independent the next one is, so two chains in one wave simply take twice as long.
+    const bool is_mixer = wave == ((BQ2 && CH_S2B_WAVE == 11) ? 6 : 11);
+    const bool is_serial2 = BQ2 && wave == CH_S2B_WAVE;
+    const bool is_idle = (wave == 6 || wave == 10) && !is_serial2 && !is_mixer;
+    const bool is_worker = !is_serial && !is_mixer && !is_idle && !is_serial2;
     const int widx = wave - (wave > 2 ? 1 : 0) - (wave > 6 ? 1 : 0);  // 0..7 among the worker waves 0,1,3,4,5,7,8,9
 
     // ---- per-role persistent registers; worker lane = (voice v, frames [LF*q, LF*q + LF) of every tile),
@@ -126,7 +160,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     const int wl = widx * WAVE + lane;
     const int v = is_worker ? (wl >> 4) : lane;
     const int q = wl & 15;
-    const bool active = v < ports && (is_worker || (is_serial && lane < 32));
+    const bool active = v < ports && (is_worker || ((is_serial || is_serial2) && lane < 32));
     const int voice = grp.first_voice + (active ? v : 0);
     const VoiceDesc vd = fv.voices[voice];
     const bool has_bq = active && vd.bq_state >= 0, has_dl = active && vd.dl_state >= 0;
@@ -141,6 +175,23 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             y2 = bq_st[3];
         }
     }
+    // the second biquad of an EQ cascade: coefficients and state live on its own wave (S2b)
+    const bool has_bq2 = BQ2 && active && vd.bq2_state >= 0;
+    float c0 = cs.co2[0], c1 = cs.co2[1], c2 = cs.co2[2], d1 = cs.co2[3], d2 = cs.co2[4];
+    float* bq2_st = nullptr;
+    float z1 = 0.f, z2 = 0.f;  // its y[n-1], y[n-2]
+    // its x[n-1], x[n-2] at the start of the next tile, per voice row: read by the row's first worker lane (S1b), written by its last
+    __shared__ float bq2_u[BQ2 ? 32 : 1][2];
+    if (has_bq2 && is_serial2) {
+        bq2_st = fv.ext + fv.states[vd.bq2_state].ext_off + 5 + 4 * ch;
+        bq2_u[lane][0] = bq2_st[0];
+        bq2_u[lane][1] = bq2_st[1];
+        z1 = bq2_st[2];
+        z2 = bq2_st[3];
+    }  // (made visible to the workers by the __syncthreads_or below)
+    const int n_pre = active ? vd.n_pre : 0;                         // gain stages in front of the filters (multiplied in by S1)
+    const bool dl_first = has_dl && vd.fx_order == 1;                // the delay line in front of the biquads: S1 does its read-modify-write
+    const bool any_pre = __syncthreads_or(n_pre > 0 ? 1 : 0) != 0;
     uint32_t D = 1, pos = cs.pos;
     float fb = cs.fb, mix = cs.mix, dry = cs.dry;
     float* ring = nullptr;
@@ -161,6 +212,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     __shared__ unsigned long long srcp[32][CH_FAST_KMAX];
     __shared__ unsigned long long srcp1[32][CH_FAST_KMAX];
     __shared__ uint32_t wrap_at[32][CH_FAST_KMAX];
+    __shared__ uint32_t vcls[32];  // per voice: bit c set = some block of the call fetches source class c (SF_*): exactly one for a steady voice
+    if (threadIdx.x < 32) vcls[threadIdx.x] = 0u;
+    __syncthreads();
     bool fast_ok = K <= CH_FAST_KMAX && !(fv.dbg & 32);  // FWGPU_CHAIN_SKIP=32: A/B against the general loop
     if (fv.n_cmds && active) {
         // messages for THIS leaf's biquads / delays in this call (coefficients, feedback, mix) are replayed block by
@@ -175,7 +229,12 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             const int i = chain_cmd_lower_bound(fv.cmds, fv.n_cmds, vd.dl_state, cmd_block0);
             fast_ok = fast_ok && !(i < fv.n_cmds && fv.cmds[i].state == vd.dl_state && fv.cmds[i].block < b1);
         }
+        if (has_bq2) {
+            const int i = chain_cmd_lower_bound(fv.cmds, fv.n_cmds, vd.bq2_state, cmd_block0);
+            fast_ok = fast_ok && !(i < fv.n_cmds && fv.cmds[i].state == vd.bq2_state && fv.cmds[i].block < b1);
+        }
     }
+    if (dl_first) fast_ok = false;  // (the steady-call loop's ring accesses are S3a's: filter-first voices)
     for (int i = threadIdx.x; i < ports * K; i += CH_THREADS) {
         const int pv = i / K, pk = i - pv * K, pvoice = grp.first_voice + pv;
         const VoiceRef rk = fv.refs[ref_index(pvoice, pk, fv.ref_kgroups)];
@@ -186,8 +245,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         const float* a1 = nullptr;
         uint32_t wr = 0xffffffffu;
         if (kind == VB_SIMPLE) {
-            ok = ok && ((rk.flags_gset >> 8) & 0xffu) == 0u && ((((rk.flags_gset >> 16) & 7u) == SF_P_F32) || (fk & VB_SRC_ZERO));
-            a0 = rk.src_l + (ch ? rk.r_delta : 0u);  // r_delta = 0 for a mono sample
+            const uint32_t cls = (rk.flags_gset >> 16) & 7u;
+            const bool c16 = cls == SF_I_I16 || cls == SF_I_U16;  // interleaved stereo 16-bit: 4 bytes per frame, the channel is a half-word
+            ok = ok && ((rk.flags_gset >> 8) & 0xffu) == 0u && (cls == SF_P_F32 || c16 || (fk & VB_SRC_ZERO));
+            a0 = rk.src_l + ((ch && !c16) ? rk.r_delta : 0u);  // r_delta = 0 for a mono sample
+            if (!(fk & VB_SRC_ZERO)) atomicOr(&vcls[pv], 1u << cls);
         } else if (kind == VB_WRAP && !(fk & VB_SRC_ZERO)) {
             const VoiceBlk* d = &fv.blks[(size_t)pk * fv.n_voices + pvoice];
             const GainSet* gs = &fv.gsets[(size_t)pvoice * FW_GSETS];
@@ -196,8 +258,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             for (int j = 0; j < FW_CHAIN_STAGES; ++j) ok = ok && (j >= fv.n_gain_stages || d->g[j][ch] == gs->g[j][ch]);
             if (ok) {
                 const SampleDesc sd = fv.samples[d->sample];
-                ok = sd.format == FMT_P_F32 && sd.frames < 0xffffffffull;
-                const float* base = (const float*)sd.data + ((fk & VB_MONO) || ch == 0 ? 0ull : sd.frames);
+                const bool c16 = (sd.format == FMT_I_I16 || sd.format == FMT_I_U16) && sd.channels == 2 && !(fk & VB_MONO);
+                ok = (sd.format == FMT_P_F32 || c16) && sd.frames < 0xffffffffull;
+                atomicOr(&vcls[pv], 1u << (c16 ? (sd.format == FMT_I_I16 ? SF_I_I16 : SF_I_U16) : SF_P_F32));
+                const float* base = (const float*)sd.data + ((fk & VB_MONO) || ch == 0 || c16 ? 0ull : sd.frames);
                 a0 = base + d->off0;
                 wr = d->n1;
                 a1 = base + d->off1 - wr;  // frame f >= wr of the block is a1[f]
@@ -211,16 +275,47 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         wrap_at[pv][pk] = wr;
     }
     if (active && has_dl && is_worker) fast_ok = fast_ok && D >= 3u * TT;  // (voices without a biquad / delay pass through)
+    __syncthreads();  // vcls complete
+    const uint32_t my_cls = active ? vcls[v] : 0u;
+    fast_ok = fast_ok && (my_cls & (my_cls - 1u)) == 0u;  // one source class per voice and call
+    const int c16 = (my_cls >> SF_I_I16) & 1u ? 1 : ((my_cls >> SF_I_U16) & 1u ? 2 : 0);
+    const bool any16 = __syncthreads_or(c16 ? 1 : 0) != 0;
     const bool wg_fast = __syncthreads_and(fast_ok ? 1 : 0) != 0;
-    const int n_steps = wg_fast ? ((n_tiles + 3 + 1) & ~1) : n_tiles + 3;  // the fast loop is unrolled by two
+    const int n_steps = wg_fast ? ((n_tiles + LAG4 + 1) & ~1) : n_tiles + LAG4;  // the fast loop is unrolled by two
     if (threadIdx.x == 0) atomicAdd(fv.chain_stats + (wg_fast ? 0 : 1), 1ull);  // fwgpu_plan_chain_stats (tests)
 
     // compute-side block registers (block of tile s) and issue-side ones (block of tile s+1, one step ahead)
     float g0 = 1.f;
-    ChainInfo inf0, inf1, inf2;  // tiles s, s-1, s-2
-    inf0.flags = inf1.flags = inf2.flags = VB_SRC_ZERO | VB_SIMPLE;
+    ChainInfo inf0, inf1, inf2, inf3, inf4;  // tiles s, s-1, s-2 (, s-3, s-4: S3a's in the two-biquad instantiation)
+    inf0.flags = inf1.flags = inf2.flags = inf3.flags = inf4.flags = VB_SRC_ZERO | VB_SIMPLE;
 #pragma unroll
-    for (int j = 0; j < FW_CHAIN_STAGES - 1; ++j) inf0.g[j] = inf1.g[j] = inf2.g[j] = 1.f;
+    for (int j = 0; j < FW_CHAIN_STAGES - 1; ++j) inf0.g[j] = inf1.g[j] = inf2.g[j] = inf3.g[j] = inf4.g[j] = 1.f;
+    // S1b (two-biquad instantiation), worker lanes, tile s-2: the second biquad's feed-forward sums on the first one's output, in place:
+    //   ff[n] = ((c0*x[n]) + (c1*x[n-1])) + (c2*x[n-2]), unfused (k_generic.hip.h K_BIQUAD).  x[n-1], x[n-2] of a lane's first frame are
+    // the two floats in front of it in the row (lane q = 0: the tile before's last two, bq2_u).  A voice's 16 lanes sit in ONE wave and
+    // every lane reads before any lane writes (DS operations of a wave retire in order): no barrier inside the stage.
+    auto ff2_stage = [&](const int t_tile, const bool real) {
+        float* const r2 = &tile[CH_BUF(t_tile)][v][LF * q];
+        const v2f hin = *(const v2f*)(r2 - (q ? 2 : 0));  // (lane 0: a valid address, the value is not used)
+        float h1 = q ? hin[1] : bq2_u[v][0], h2 = q ? hin[0] : bq2_u[v][1];
+        // the neighbour's two floats are IN REGISTERS before any store of this stage is issued: lane q - 1's last quad overwrites them, and to
+        // the compiler — which reasons per lane — that store and this load touch different addresses and may change places
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h1), "+v"(h2) : : "memory");
+        const bool on = real && has_bq2;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {  // (quad by quad: the worker lanes have no registers to spare for the whole tile slice)
+            const v4f x = *(const v4f*)(r2 + 4 * j);
+            const v4f x1v = (v4f){h1, x[0], x[1], x[2]}, x2v = (v4f){h2, h1, x[0], x[1]};
+            const v4f ff = ((x * c0) + (x1v * c1)) + (x2v * c2);
+            h1 = x[3];
+            h2 = x[2];
+            if (on) *(v4f*)(r2 + 4 * j) = ff;
+        }
+        if (on && q == 15) {
+            bq2_u[v][0] = h1;
+            bq2_u[v][1] = h2;
+        }
+    };
     VoiceRef ref_n;        // descriptor of the block that starts two tiles ahead (in flight)
     ref_n.src_l = nullptr;
     ref_n.r_delta = 0;
@@ -230,6 +325,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     for (int j = 0; j < FW_CHAIN_STAGES; ++j) gs_n[j] = 1.f;
     const float* nb_src = nullptr;  // issue-side block: this channel's source of frame 0, VB_* flags
     uint32_t nb_flags = VB_SRC_ZERO | VB_SIMPLE;
+    int nb_c16 = 0, cur_c16 = 0;    // 16-bit interleaved source (1 = i16, 2 = u16) of the issue-side block / of the block S1 computes
     v4f xs[NQ];  // source of the tile S1 computes next (prefetched)
     v4f rg[NQ];  // ring slots of the tile S3a consumes next (prefetched when ring_pref)
 #pragma unroll
@@ -242,7 +338,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     }
 
     // role-local (block, tile-in-block) counters: S1 computes tile s, S2 s-1, S3a s-2, S3b s-3; loads issue for s+1
-    int k1 = 0, t1 = 0, k2 = 0, t2 = 0, k3 = 0, t3 = 0, k4 = 0, t4 = 0, kla = 0, tla = 0;
+    int k1 = 0, t1 = 0, k2 = 0, t2 = 0, k3 = 0, t3 = 0, k4 = 0, t4 = 0, kla = 0, tla = 0, kf = 0, tf = 0;
     const uint64_t port_mask = mask_all_silent_bits(ports);
 
     // issue the HBM loads of tile `la` (= the tile S1 computes in the next step); at a block start first adopt the
@@ -250,7 +346,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     auto issue_source = [&]() {
         if (tla == 0) {
             nb_flags = ref_n.flags_gset & 0xffu;
-            nb_src = ref_n.src_l + (ch ? ref_n.r_delta : 0u);  // r_delta = 0 for a mono sample (sampler.rs:546-551)
+            const uint32_t ncls = (ref_n.flags_gset >> 16) & 7u;
+            nb_c16 = ncls == SF_I_I16 ? 1 : (ncls == SF_I_U16 ? 2 : 0);
+            nb_src = ref_n.src_l + ((ch && !nb_c16) ? ref_n.r_delta : 0u);  // r_delta = 0 for a mono sample (sampler.rs:546-551)
             if (nb_flags & VB_SIMPLE) {
                 const GainSet* gs = &fv.gsets[(size_t)voice * FW_GSETS + ((ref_n.flags_gset >> 8) & 0xffu)];
 #pragma unroll
@@ -302,8 +400,17 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     if (is_worker && active && !wg_fast) {  // prologue = the issue halves of steps -2 and -1
         ref_n = fv.refs[ref_index(voice, 0, fv.ref_kgroups)];
         issue_source();
+        if (dl_first && ring_pref) load_ring();  // (delay-first voices: S1 of tile 0 consumes them)
     }
 
+#ifdef CH_PROF  // experiments: per-role busy cycles (clock64 = shader clock, wall_clock64 = 100 MHz) of workgroup (0, 0), printed at the end
+    unsigned long long prof_busy = 0, prof_t0 = clock64(), prof_w0 = wall_clock64();
+#define CH_PROF_BEGIN() const unsigned long long prof_a = clock64()
+#define CH_PROF_END() prof_busy += clock64() - prof_a
+#else
+#define CH_PROF_BEGIN() do { } while (0)
+#define CH_PROF_END() do { } while (0)
+#endif
     // One loop per role (same number of barriers in each) so that the register allocation of a role does not
     // carry the other roles' loop state.
     if (is_worker && wg_fast) {
@@ -316,9 +423,14 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         const uint32_t vflags = fv.refs[ref_index(voice, 0, fv.ref_kgroups)].flags_gset & 0xffu;  // per-voice bits only are used
         const GainSet* gsp = &fv.gsets[(size_t)voice * FW_GSETS];
         const float g0f = gsp->g[0][ch];
-        float gpost[FW_CHAIN_STAGES - 1];
+        // stage j + 1's constant gain goes in front of the filters (S1) or behind them (S3a); the other place multiplies by 1.0f — exact
+        float gpre[FW_CHAIN_STAGES - 1], gpost[FW_CHAIN_STAGES - 1];
 #pragma unroll
-        for (int j = 0; j < FW_CHAIN_STAGES - 1; ++j) gpost[j] = gsp->g[j + 1][ch];
+        for (int j = 0; j < FW_CHAIN_STAGES - 1; ++j) {
+            const float gj = gsp->g[j + 1][ch];
+            gpre[j] = j < n_pre ? gj : 1.f;
+            gpost[j] = j < n_pre ? 1.f : gj;
+        }
         const bool src_zero = (vflags & VB_SRC_ZERO) != 0, silent = (vflags & VB_SILENT) != 0;
         float* const dummy = fv.chain_dummy + (size_t)threadIdx.x * (4 * NQ);
         const bool ringed = active && has_dl;  // this lane's voice has a delay line
@@ -351,7 +463,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             return sl >= Dv ? sl - Dv : sl;
         };
         auto issue_ring = [&](v4f(&rg)[NQ], int t) {
-            const bool real = t < n_tiles && ringed;
+            const bool real = t >= 0 && t < n_tiles && ringed;
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 const uint32_t sl = slot_of(pos_i, j);
@@ -366,11 +478,12 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         };
         auto wstep = [&](int s, v4f(&xs)[NQ], v4f(&rg)[NQ]) {
             const bool v1 = s < n_tiles;
-            const bool v3 = ringed && s >= 2 && s - 2 < n_tiles;  // S3a of a real tile of a voice with a delay line
+            const bool v3 = ringed && s >= LAG3 && s - LAG3 < n_tiles;  // S3a of a real tile of a voice with a delay line
             CH_TRACE(0);
+            CH_PROF_BEGIN();
             v4f yv[NQ];
             {
-                const float* yrow = &tile[(s - 2) & (CH_NBUF - 1)][v][LF * q];
+                const float* yrow = &tile[CH_BUF(s - LAG3)][v][LF * q];
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) yv[j] = *(const v4f*)(yrow + 4 * j);
             }
@@ -402,9 +515,20 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     tlc = wrapb ? 0 : tlc + 1;
                     klc = (wrapb && klc + 1 < K) ? klc + 1 : klc;
                 }
+                if (any16) {  // (wave-uniform: a plan of planar-f32 sources converts nothing)
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) xs[j] = c16 ? chain_cvt16(xs[j], c16, ch) : xs[j];
+                }
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) x[j] = src_zero ? splat(0.f) : xs[j] * g0f;  // sampler.rs:530-533
-                float* row = &tile[s & (CH_NBUF - 1)][v][LF * q];
+                if (any_pre) {  // gain stages in front of the filters: one rounding per stage, in schedule order (volume.rs:123-126)
+#pragma unroll
+                    for (int g = 0; g < FW_CHAIN_STAGES - 1; ++g) {
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) x[j] = src_zero ? splat(0.f) : x[j] * gpre[g];
+                    }
+                }
+                float* row = &tile[CH_BUF(s)][v][LF * q];
                 const bool q15 = q == 15;
                 float p1 = row_ror1(q15 ? prev_x[3] : x[NQ - 1][3]), p2 = row_ror1(q15 ? prev_x[2] : x[NQ - 1][2]);
 #pragma unroll
@@ -421,7 +545,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             }
             issue_src(xs, s + 2);
             CH_TRACE(2);
-            // ---- S3a on tile s-2
+            if constexpr (BQ2) ff2_stage(s - 2, s >= 2 && s - 2 < n_tiles);
+            // ---- S3a on tile s-LAG3
             {
                 uint32_t sl[NQ];
                 bool straddle = false;
@@ -446,7 +571,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                         }
                     }
                 }
-                float* row = &tile[(s - 2) & (CH_NBUF - 1)][v][LF * q];
+                float* row = &tile[CH_BUF(s - LAG3)][v][LF * q];
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
                     v4f y = yv[j];
@@ -478,10 +603,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     pos_c += TT;
                     if (pos_c >= Dv) pos_c -= Dv;
                 }
-                if (q == 0) silf[(s - 2) & (CH_NBUF - 1)][v] = silent ? 1u : 0u;
+                if (q == 0) silf[CH_BUF(s - LAG3)][v] = silent ? 1u : 0u;
             }
-            issue_ring(rg, s);
+            issue_ring(rg, s - (LAG3 - 2));
             CH_TRACE(3);
+            CH_PROF_END();
             __syncthreads();
             CH_TRACE(4);
         };
@@ -496,10 +622,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     } else if (is_worker) {
         for (int s = 0; s < n_steps; ++s) {
             const bool do1 = active && s < n_tiles;
-            const bool do3 = active && s >= 2 && s - 2 < n_tiles;
+            const bool do3 = active && s >= LAG3 && s - LAG3 < n_tiles;
             const bool dl_on = has_dl && !CH_SKIP(8);
             CH_TRACE(0);
             if (do1 && t1 == 0) {  // new block: adopt the issue-side descriptor (its gain set has landed)
+                cur_c16 = nb_c16;
                 if (nb_flags & VB_SIMPLE) {
                     inf0.flags = nb_flags;
                     g0 = gs_n[0];
@@ -524,11 +651,12 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             // S3a's LDS rows (tile s-2) are requested first and consumed after S1: the round trip hides behind S1's math
             v4f yv[NQ];
             if (do3) {
-                const float* yrow = &tile[(s - 2) & (CH_NBUF - 1)][v][LF * q];
+                const float* yrow = &tile[CH_BUF(s - LAG3)][v][LF * q];
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) yv[j] = *(const v4f*)(yrow + 4 * j);
             }
-            // ================= S1 on tile s: sampler gain + the feed-forward half of the biquad -> LDS
+            // ================= S1 on tile s: sampler gain (+ the gain stages and the delay line in front of the filters) + the
+            // feed-forward half of the biquad -> LDS
             if (do1) {
                 v4f x[NQ];
                 if (!(inf0.flags & VB_SIMPLE)) {  // ramps, loop wrap, one-shot tail, non-planar-f32 source: full descriptor
@@ -558,6 +686,12 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                             const float* rb = fv.ramps + ((size_t)k1 * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
                             const v4f gv = (rb0 >> ch) & 1u ? *(const v4f*)(rb + (size_t)ch * fv.stride) : splat(g0c);
                             x[j] = x[j] * gv;  // sampler.rs:530-533
+#pragma unroll
+                            for (int g = 1; g < FW_CHAIN_STAGES; ++g) {  // the gain stages in front of the filters, ramps included
+                                if (g > n_pre) break;
+                                const v4f gp = (rb0 >> (2 * g + ch)) & 1u ? *(const v4f*)(rb + (size_t)(2 * g + ch) * fv.stride) : splat(d->g[g][ch]);
+                                x[j] = x[j] * gp;
+                            }
                         }
                     }
                 } else if (inf0.flags & VB_SRC_ZERO) {
@@ -565,9 +699,42 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     for (int j = 0; j < NQ; ++j) x[j] = splat(0.f);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < NQ; ++j) x[j] = xs[j] * g0;
+                    for (int j = 0; j < NQ; ++j) x[j] = (cur_c16 ? chain_cvt16(xs[j], cur_c16, ch) : xs[j]) * g0;
+#pragma unroll
+                    for (int g = 0; g < FW_CHAIN_STAGES - 1; ++g) {  // constant gains in front of the filters
+                        if (g >= n_pre) break;
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) x[j] = x[j] * inf0.g[g];
+                    }
                 }
-                float* row = &tile[s & (CH_NBUF - 1)][v][LF * q];
+                if (dl_first && dl_on) {  // the delay line in front of the biquads: its read-modify-write on the tile S1 has just made
+                    if (t1 == 0 && fv.n_cmds) {
+                        const ChainDelay p = chain_delay_cmds(fv.cmds, fv.n_cmds, vd.dl_state, cmd_block0 + (uint32_t)k1, ChainDelay{fb, mix, dry});
+                        fb = p.fb;
+                        mix = p.mix;
+                        dry = p.dry;
+                    }
+                    if (!ring_pref) load_ring();
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const v4f nv = x[j] + (rg[j] * fb);  // ring[p] = x + (d*fb)
+                        const uint32_t sl = ring_slot(j);
+                        if (sl + 4u <= D) {
+                            *(v4f_u*)(ring + sl) = nv;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                uint32_t se = sl + (uint32_t)e;
+                                if (se >= D) se -= D;
+                                ring[se] = nv[e];
+                            }
+                        }
+                        x[j] = (x[j] * dry) + (rg[j] * mix);  // out = (x*dry) + (d*mix)
+                    }
+                    pos += TT;
+                    if (pos >= D) pos -= D;
+                }
+                float* row = &tile[CH_BUF(s)][v][LF * q];
                 if (has_bq) {
                     // x[n-1], x[n-2] of this lane's first frame: lane q-1's last quad of THIS tile, or for q == 0 lane
                     // 15's last quad of the PREVIOUS tile — one rotate inside the voice's 16-lane DPP row, no LDS
@@ -592,6 +759,22 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     ++k1;
                 }
             }
+            if constexpr (BQ2) {  // ================= S1b on tile s-2 (its coefficient messages at block starts, like S1's)
+                const bool real = s >= 2 && s - 2 < n_tiles;
+                if (real && has_bq2 && tf == 0 && fv.n_cmds) {
+                    const ChainCoefs co = chain_find_coefs(fv.cmds, fv.n_cmds, vd.bq2_state, cmd_block0 + (uint32_t)kf);
+                    if (co.found) {
+                        c0 = co.b0;
+                        c1 = co.b1;
+                        c2 = co.b2;
+                    }
+                }
+                ff2_stage(s - 2, real && active);
+                if (real && ++tf == tpb) {
+                    tf = 0;
+                    ++kf;
+                }
+            }
             // The ring slots S3a consumes below have been in flight since the end of the previous step.  Touch them
             // HERE, before the next source loads are issued: the compiler then places its (conservative, vmcnt(0))
             // wait for them ahead of those loads instead of draining them right after their issue.
@@ -601,8 +784,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             if (active && s + 1 < n_tiles) issue_source();
             CH_TRACE(2);
             // ================= S3a on tile s-2: delay RMW + gain stages, in place in LDS (its rows were requested above)
+            const bool dl3 = dl_on && !dl_first;  // S3a's delay line (filter-first voices)
             if (do3) {
-                if (dl_on) {
+                if (dl3) {
                     if (t3 == 0 && fv.n_cmds) {
                         const ChainDelay p = chain_delay_cmds(fv.cmds, fv.n_cmds, vd.dl_state, cmd_block0 + (uint32_t)k3,
                                                               ChainDelay{fb, mix, dry});
@@ -612,8 +796,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     }
                     if (!ring_pref) load_ring();
                 }
-                float* row = &tile[(s - 2) & (CH_NBUF - 1)][v][LF * q];
-                const uint32_t rbits = inf2.flags >> VB_RAMP_SHIFT;
+                float* row = &tile[CH_BUF(s - LAG3)][v][LF * q];
+                const ChainInfo& inf = BQ2 ? inf4 : inf2;  // the block of the tile S3a works on
+                const uint32_t rbits = inf.flags >> VB_RAMP_SHIFT;
 #ifdef FW_CHAIN_TRACE
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(yv[j]));
@@ -622,7 +807,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
                     v4f y = yv[j];
-                    if (dl_on) {
+                    if (dl3) {
                         const v4f nv = y + (rg[j] * fb);  // ring[p] = x + (d*fb)
                         const uint32_t sl = ring_slot(j);
                         if (sl + 4u <= D) {
@@ -641,13 +826,13 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                         }
                         y = (y * dry) + (rg[j] * mix);  // out = (x*dry) + (d*mix)
                     }
-                    if (inf2.flags & VB_SILENT) {  // muted gain stage / silent chain: cleared buffer
+                    if (inf.flags & VB_SILENT) {  // muted gain stage / silent chain: cleared buffer
                         y = splat(0.f);
                     } else if (rbits == 0) {
 #pragma unroll
                         for (int g = 0; g < FW_CHAIN_STAGES - 1; ++g) {
                             if (g + 1 >= fv.n_gain_stages) break;
-                            y = y * inf2.g[g];
+                            y = y * (g >= n_pre ? inf.g[g] : 1.f);  // (the stages in front of the filters went in with S1; x 1.0f is exact)
                         }
                     } else {
                         const int f0 = t3 * TT + LF * q + 4 * j;
@@ -655,25 +840,29 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
 #pragma unroll
                         for (int g = 1; g < FW_CHAIN_STAGES; ++g) {
                             if (g >= fv.n_gain_stages) break;
-                            const v4f gv = (rbits >> (2 * g + ch)) & 1u ? *(const v4f*)(rb + (size_t)(2 * g + ch) * fv.stride) : splat(inf2.g[g - 1]);
+                            if (g <= n_pre) continue;
+                            const v4f gv = (rbits >> (2 * g + ch)) & 1u ? *(const v4f*)(rb + (size_t)(2 * g + ch) * fv.stride) : splat(inf.g[g - 1]);
                             y = y * gv;
                         }
                     }
                     *(v4f*)(row + 4 * j) = y;
                 }
                 CH_TRACE(6);
-                if (dl_on) {
+                if (dl3) {
                     pos += TT;
                     if (pos >= D) pos -= D;
                 }
-                if (q == 0) silf[(s - 2) & (CH_NBUF - 1)][v] = (inf2.flags & VB_SILENT) ? 1u : 0u;
+                if (q == 0) silf[CH_BUF(s - LAG3)][v] = (inf.flags & VB_SILENT) ? 1u : 0u;
                 if (++t3 == tpb) {
                     t3 = 0;
                     ++k3;
                 }
             }
-            // ring slots of tile s-1 (S3a of the next step): issue now, after this step's ring stores
-            if (ring_pref && dl_on && s >= 1 && s - 1 < n_tiles) load_ring();
+            // ring slots of the tile the NEXT step consumes (S3a's tile s + 1 - LAG3; S1's tile s + 1 of a delay-first voice): issue
+            // now, after this step's ring stores
+            if (ring_pref && dl_on && (dl_first ? s + 1 < n_tiles : (s + 1 >= LAG3 && s + 1 - LAG3 < n_tiles))) load_ring();
+            inf4 = inf3;
+            inf3 = inf2;
             inf2 = inf1;
             inf1 = inf0;
             CH_TRACE(3);
@@ -686,7 +875,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         for (int s = 0; s < n_steps; ++s) {
             CH_TRACE(0);
             // ================= S2 on tile s-1: the recursive half of the biquad, lane = voice
-            if (any_bq && s >= 1 && s - 1 < n_tiles && !CH_SKIP(1)) {
+            CH_PROF_BEGIN();
+            if (any_bq && s >= 1 && s - 1 < n_tiles && !CH_SKIP(1) && !(fv.dbg & 256)) {  // (FWGPU_CHAIN_SKIP=256: timing experiments)
                 if (has_bq && t2 == 0 && fv.n_cmds) {
                     const ChainCoefs co = chain_find_coefs(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0 + (uint32_t)k2);
                     if (co.found) {
@@ -695,7 +885,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     }
                 }
                 if (has_bq) {
-                    float* row = &tile[(s - 1) & (CH_NBUF - 1)][v][0];
+                    float* row = &tile[CH_BUF(s - 1)][v][0];
                     v4f cur[4], nxt[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) cur[u] = *(const v4f*)(row + 4 * u);
@@ -735,8 +925,66 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                 }
             }
             CH_TRACE(3);
+            CH_PROF_END();
             __syncthreads();
             CH_TRACE(4);
+        }
+    } else if (is_serial2) {
+        // ================= S2b on tile s-3 (two-biquad instantiation): the second biquad's recurrence y[n] = fma(-d1, y[n-1], fma(-d2, y[n-2],
+        // ff[n])) on the sums S1b left in the row, lane = voice — S2's loop with the other filter's coefficients and state
+        __builtin_amdgcn_s_setprio(3);
+        const bool any_bq2 = __ballot(has_bq2) != 0ull;
+        int kb = 0, tb = 0;
+        for (int s = 0; s < n_steps; ++s) {
+            CH_PROF_BEGIN();
+            if (any_bq2 && s >= 3 && s - 3 < n_tiles && !(fv.dbg & 128)) {  // (FWGPU_CHAIN_SKIP=128: timing experiments, wrong audio)
+                if (has_bq2 && tb == 0 && fv.n_cmds) {
+                    const ChainCoefs co = chain_find_coefs(fv.cmds, fv.n_cmds, vd.bq2_state, cmd_block0 + (uint32_t)kb);
+                    if (co.found) {
+                        d1 = co.a1;
+                        d2 = co.a2;
+                    }
+                }
+                if (has_bq2) {
+                    float* row = &tile[CH_BUF(s - 3)][v][0];
+                    v4f cur[4], nxt[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cur[u] = *(const v4f*)(row + 4 * u);
+#pragma unroll 2
+                    for (int c = 0; c < TT / 16; ++c) {
+                        if (c + 1 < TT / 16) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) nxt[u] = *(const v4f*)(row + 16 * (c + 1) + 4 * u);
+                        }
+                        v4f o[4];
+                        float t = __builtin_fmaf(-d2, z2, cur[0][0]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int nu = e == 3 ? u + 1 : u, ne = (e + 1) & 3;
+                                const float tn = nu < 4 ? __builtin_fmaf(-d2, z1, cur[nu & 3][ne]) : 0.f;  // t of the next frame
+                                const float y = __builtin_fmaf(-d1, z1, t);
+                                __builtin_amdgcn_sched_barrier(0);
+                                z2 = z1;
+                                z1 = y;
+                                t = tn;
+                                o[u][e] = y;
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) *(v4f*)(row + 16 * c + 4 * u) = o[u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+                    }
+                }
+            }
+            if (s >= 3 && s - 3 < n_tiles && ++tb == tpb) {
+                tb = 0;
+                ++kb;
+            }
+            CH_PROF_END();
+            __syncthreads();
         }
     } else if (is_idle) {
         for (int s = 0; s < n_steps; ++s) __syncthreads();
@@ -744,8 +992,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         for (int s = 0; s < n_steps; ++s) {
             CH_TRACE(0);
             // ================= S3b on tile s-3: the leaf SumNode of this channel, lane = frame quad, ports in order
-            if (s >= 3 && s - 3 < n_tiles && lane < TT / 4 && !CH_SKIP(2)) {  // (the steady-call loop pads n_steps to even)
-                const int buf = (s - 3) & (CH_NBUF - 1);
+            CH_PROF_BEGIN();
+            if (s >= LAG4 && s - LAG4 < n_tiles && lane < TT / 4 && !CH_SKIP(2)) {  // (the steady-call loop pads n_steps to even)
+                const int buf = (int)CH_BUF(s - LAG4);
                 // ONE LDS round trip: every port's row (row index clamped, so the reads are unconditional) and the
                 // silence flags are requested together; the adds are masked
                 const float* col = &tile[buf][0][4 * lane];
@@ -804,11 +1053,19 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                 }
             }
             CH_TRACE(3);
+            CH_PROF_END();
             __syncthreads();
             CH_TRACE(4);
         }
     }
 
+#ifdef CH_PROF
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 2 || wave == 6 || wave == 11 || wave == 3)) {
+        const unsigned long long tot = clock64() - prof_t0, wall = wall_clock64() - prof_w0;
+        printf("k_chain prof: wave %d steps %d fast %d: busy %llu of %llu shader cycles (%.0f per step, total %.0f per step), wall %.2f us -> %.0f MHz\n", wave, n_steps,
+               (int)wg_fast, prof_busy, tot, (double)prof_busy / n_steps, (double)tot / n_steps, wall / 100.0, (double)tot / (wall / 100.0));
+    }
+#endif
     // ---- write this channel's biquad state back (everything shared was advanced by k_voice_control)
     if (is_worker && has_bq && q == 15) {
         bq_st[0] = prev_x[3];
@@ -818,5 +1075,12 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         bq_st[2] = y1;
         bq_st[3] = y2;
     }
+    if (is_serial2 && has_bq2) {  // (every S1b ran at least one barrier ago: bq2_u holds the inputs of the call's last two frames)
+        bq2_st[0] = bq2_u[lane][0];
+        bq2_st[1] = bq2_u[lane][1];
+        bq2_st[2] = z1;
+        bq2_st[3] = z2;
+    }
+#undef CH_BUF
 }
 

@@ -201,7 +201,7 @@ __device__ __forceinline__ bool smoother_is_constant(const Smoother& s, float ta
 // Source class of a block that starts at frame `off0` of sample `sd` and is contiguous in it (no wrap, no tail):
 // which vector fetch the leaf kernel may use (SF_*), or SF_NONE.  16-bit planar data needs a 4-byte aligned start
 // in both channels; interleaved data of more than two channels and anything in a k_chain voice other than planar
-// f32 stay on the per-element path.
+// f32 and interleaved stereo 16-bit PCM stay on the per-element path.
 __device__ __forceinline__ uint32_t simple_class(const SampleDesc& sd, uint64_t off0, bool fx) {
     if (sd.frames >= 0xffffffffull) return SF_NONE;
     const bool mono = sd.channels == 1;
@@ -214,7 +214,9 @@ __device__ __forceinline__ uint32_t simple_class(const SampleDesc& sd, uint64_t 
             return sd.format == FMT_P_I16 ? SF_P_I16 : SF_P_U16;
         case FMT_I_I16:
         case FMT_I_U16:
-            if (fx) return SF_NONE;
+            // (round 6: k_chain fetches interleaved STEREO 16-bit PCM itself — 4 bytes per frame, one dwordx4 per quad like planar f32, its
+            //  channel's half of every word converted in S1; mono and planar 16-bit data stay on the per-element path there)
+            if (fx) return (!mono && sd.channels == 2) ? (sd.format == FMT_I_I16 ? SF_I_I16 : SF_I_U16) : SF_NONE;
             if (mono) return (off0 & 1) ? SF_NONE : (sd.format == FMT_I_I16 ? SF_P_I16 : SF_P_U16);
             return sd.channels == 2 ? (sd.format == FMT_I_I16 ? SF_I_I16 : SF_I_U16) : SF_NONE;
         default: return SF_NONE;
@@ -739,9 +741,10 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         cs.fb = 0.f;
         cs.mix = 0.f;
         cs.dry = 1.f;
-        cs.co[0] = 1.f;
+        cs.co[0] = cs.co2[0] = 1.f;
         cs.co[1] = cs.co[2] = cs.co[3] = cs.co[4] = 0.f;
-        cs.pad[0] = cs.pad[1] = cs.pad[2] = 0;
+        cs.co2[1] = cs.co2[2] = cs.co2[3] = cs.co2[4] = 0.f;
+        cs.pad[0] = cs.pad[1] = 0;
         if (vd.dl_state >= 0) {
             NodeState* ds = &fv.states[vd.dl_state];
             const uint64_t D = ds->loop_end;
@@ -766,16 +769,19 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                 ds->gain = p.dry;
             }
         }
-        if (vd.bq_state >= 0) {
-            float* co = fv.ext + fv.states[vd.bq_state].ext_off;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) cs.co[j] = co[j];
+        for (int which = 0; which < 2; ++which) {  // the chain's biquad(s): the record holds the coefficients at the call's start, the ext
+            const int bqs = which ? vd.bq2_state : vd.bq_state;  // pool the ones at its end (k_chain replays the messages in between)
+            if (bqs < 0) continue;
+            float* co = fv.ext + fv.states[bqs].ext_off;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) (which ? cs.co2 : cs.co)[j] = co[j];
             if (fv.n_cmds) {
                 bool found = false;
                 float nc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int i = chain_cmd_lower_bound(fv.cmds, fv.n_cmds, vd.bq_state, cmd_block0); i < fv.n_cmds; ++i) {
+                for (int i = chain_cmd_lower_bound(fv.cmds, fv.n_cmds, bqs, cmd_block0); i < fv.n_cmds; ++i) {
                     const Cmd c = fv.cmds[i];
-                    if (c.state != vd.bq_state || c.block >= cmd_block0 + (uint32_t)K) break;
+                    if (c.state != bqs || c.block >= cmd_block0 + (uint32_t)K) break;
                     if (c.type != CMD_SET_COEFS) continue;
                     nc[0] = c.f0;
                     nc[1] = __int_as_float(c.i0);
@@ -1036,12 +1042,19 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         }
         CTL_T(10);
         // a biquad / delay between the sampler and the gain stages never reports silence (SPEC nodes: out mask 0)
+        // (round 6, positional silence: the stages in FRONT of the filters — the first n_pre — see the source's flag and reset like any
+        //  bank stage; `pre_silent` = what reaches the first filter: a cleared buffer it runs on all the same; from there on nothing is
+        //  flagged until a stage mutes)
         const bool src_silent = silent;
-        if (fx) silent = false;
+        bool pre_silent = silent;
         bool sp_in_zero = false;  // the spatialiser's input buffers are cleared zeros this block
         // ---- chain stages in schedule order
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+            if (fx && j == vd.n_pre) {
+                pre_silent = silent;
+                silent = false;
+            }
             if (j >= vd.n_stages) break;
             StageRegs& r = st[j];
             float* rb = ramp_base + (size_t)(j + 1) * 2 * fv.stride;
@@ -1111,7 +1124,12 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             }
         }
         CTL_T(11);
-        const bool need_src = !src_silent && !sp_in_zero && (fx || !silent);  // a dry voice whose output is muted fetches nothing
+        if (fx && vd.n_pre >= FW_MAX_STAGES - 1) {  // (every slot a stage in front of the filters: the loop above never reached the boundary)
+            pre_silent = silent;
+            silent = false;
+        }
+        // a dry voice whose output is muted fetches nothing; a filter voice fetches unless what reaches its first filter is cleared
+        const bool need_src = !src_silent && !sp_in_zero && (fx ? !pre_silent : !silent);
         d.flags |= sp_bits();
         if (need_src && !(d.flags & VB_RESAMPLE)) blk_set_source(d, sd, frames, fxp);
         else if (fxp && (d.flags & VB_RAMP_MASK) == 0 && simple_frames) d.flags |= VB_SIMPLE;  // chain plan: cleared-source block
@@ -1151,10 +1169,15 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                 else steady = false;  // the one-shot ends inside this call: stay on the exact path
             }
         }
-        bool sil = upstream_silent && !fx;
+        bool sil = upstream_silent;  // what the stage at hand is handed; a filter voice's flag ends at its first filter (pre_sil keeps it)
+        bool pre_sil = false;
         bool sp_zero = false;  // steady with a spatialiser whose input is cleared zeros (source stopped / muted upstream)
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
+            if (fx && j == vd.n_pre) {
+                pre_sil = sil;
+                sil = false;
+            }
             if (j >= vd.n_stages || !steady) break;
             const StageRegs& r = st[j];
             if (vd.stage_kind[j] == K_SPATIAL) {  // (its smoothers run whatever comes in; what goes out is never flagged silent)
@@ -1177,6 +1200,10 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         }
         // the continuation covers the common case only — a dry voice playing steadily while gains glide; silence anywhere
         // in the chain (resets instead of ramps) and chain-plan voices stay on the block-by-block path
+        if (fx && vd.n_pre >= FW_MAX_STAGES - 1) {
+            pre_sil = sil;
+            sil = false;
+        }
         if (ramping && (sil || upstream_silent || sp_zero || fx || k + 1 >= K)) steady = false;
         if (!steady) continue;
         // ---- ramp continuation.  From here to the end of the call nothing happens to this voice but (a) its playhead
@@ -1229,7 +1256,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         // smoother and `last` for one stalled at its f32 fixed point (Q28).
         TailJob job;
         job.mode = mode;
-        job.flags = (sil ? VB_SILENT : 0u) | ((upstream_silent || sp_zero) ? VB_SRC_ZERO : 0u) | sp_bits();
+        job.flags = (sil ? VB_SILENT : 0u) | ((upstream_silent || sp_zero || pre_sil) ? VB_SRC_ZERO : 0u) | sp_bits();
         job.sample = upstream_silent ? -1 : ss.sample;
         job.playhead = ss.playhead;
         job.loop_start = ss.loop_start;
@@ -1267,7 +1294,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         if (k + 1 < K) {
             uint32_t tail_gs = 0;
             bool simple_ok = false;
-            const bool tail_simple = mode != 3 && (fxp ? (simple_frames && (upstream_silent || (!fx && sil) || simple_capable(sd, true)))
+            const bool tail_simple = mode != 3 && (fxp ? (simple_frames && (upstream_silent || pre_sil || (!fx && sil) || simple_capable(sd, true)))
                                                        : (!sil && !upstream_silent && simple_frames && simple_capable(sd, false)));
             if (tail_simple) {
                 VoiceBlk probe;  // every non-wrapping tail block is VB_SIMPLE with the same gains: one gain set

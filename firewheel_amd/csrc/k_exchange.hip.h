@@ -358,7 +358,7 @@ __device__ __forceinline__ void carry_cache_voice(const CarryArgs& a, const int 
     const int vo = a.old_slot_voice[nv.sampler_state];
     if (vo < 0) return;
     const VoiceDesc ov = a.old_voices[vo];
-    bool same = nv.sampler_state == ov.sampler_state && nv.n_stages == ov.n_stages && nv.bq_state == ov.bq_state && nv.dl_state == ov.dl_state &&
+    bool same = nv.sampler_state == ov.sampler_state && nv.n_stages == ov.n_stages && nv.bq_state == ov.bq_state && nv.dl_state == ov.dl_state && nv.bq2_state == ov.bq2_state && nv.n_pre == ov.n_pre && nv.fx_order == ov.fx_order &&
                 nv.src_kind == ov.src_kind && nv.sp_ext_off == ov.sp_ext_off;
 #pragma unroll
     for (int j = 0; j < FW_MAX_STAGES - 1; ++j)

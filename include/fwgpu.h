@@ -359,6 +359,32 @@ int fwgpu_bus_exchange_status(fwgpu_bus_exchange* ex, uint64_t* steps, uint64_t*
  * microseconds (how far the ranks run apart: the slowest rank reads ~0 for everybody, the others read their lead over it).
  * Returns the world size; reset != 0 clears the maxima. */
 int fwgpu_bus_exchange_wait_stats(fwgpu_bus_exchange* ex, uint64_t* max_wait_us, uint32_t cap, int reset);
+/* ---- the mix bus over RCCL (north_star: "a single RCCL all-reduce over xGMI for the final mix bus"; the node being computed is the
+ * top-level R-port SumNode, nodes/sum.rs:111-133).  librccl is dlopen'ed by the first of these calls, never linked: a host that does
+ * not shard does not load it.  One process per GPU; rank 0 makes the unique id, the host carries its FWGPU_RCCL_UNIQUE_ID_BYTES bytes
+ * to every rank (the side channel that carries the exchange's handles), every rank creates its communicator on its ctx's device.
+ *   unique_id          rank 0: ncclGetUniqueId.
+ *   comm_create        collective (ncclCommInitRank): every rank of the id calls it; NULL on error (fwgpu_last_error of the ctx).
+ *                      Control side; the communicator belongs to the ctx and must be destroyed before it.
+ *   allreduce_rccl     ncclAllReduce(sum) IN PLACE on the ctx stream, asynchronous.  The ring re-associates the f32 sum for more
+ *                      than two ranks: within 1e-6 relative of the single-process graph, not its bits; silence flags play no part
+ *                      (a silent shard's bus is cleared zeros, and x + 0 = x).
+ *   allgather_ordered  ncclAllGather of the partial buses and of their per-(block, channel) silence flags (as
+ *                      fwgpu_process_blocks_device_flags wrote them; NULL = never silent), then fwgpu_bus_sum_ordered_flags over
+ *                      the gathered slots: sum.rs's port order and silent-port rule, bit-identical to the single-process graph on
+ *                      every rank.  n_floats a multiple of 4; d_out 16-byte aligned, may alias d_bus; d_out_silence may be NULL.
+ * Audio-side calls like the process calls they follow (same stream).  fwgpu_rccl_last_error: the text of the last failure of a
+ * call that has no ctx to report through (unique_id). */
+#define FWGPU_RCCL_UNIQUE_ID_BYTES 128
+typedef struct fwgpu_rccl_comm fwgpu_rccl_comm;
+int fwgpu_rccl_unique_id(uint8_t* id);
+fwgpu_rccl_comm* fwgpu_rccl_comm_create(fwgpu_ctx* ctx, const uint8_t* id, uint32_t world, uint32_t rank);
+int fwgpu_rccl_comm_destroy(fwgpu_rccl_comm* comm);
+int fwgpu_rccl_comm_info(fwgpu_rccl_comm* comm, uint32_t* world, uint32_t* rank);
+int fwgpu_bus_allreduce_rccl(fwgpu_rccl_comm* comm, float* d_bus, uint64_t n_floats);
+int fwgpu_bus_allgather_ordered(fwgpu_rccl_comm* comm, const float* d_bus, const uint8_t* d_silence, float* d_out,
+                                uint8_t* d_out_silence, uint64_t n_floats, uint32_t frames_per_block, uint32_t n_channels);
+const char* fwgpu_rccl_last_error(void);
 int fwgpu_synchronize(fwgpu_ctx* ctx);
 /* ProcInfo::stream_time_secs / stream_status (core/node.rs:111-132) of the most recent fwgpu_process_interleaved call —
  * what a custom node run through fwgpu_node_process inside that call would be handed — and how often the backend has

@@ -16,6 +16,11 @@ pub struct fwgpu_bus_exchange {
     _private: [u8; 0],
 }
 pub const FWGPU_EXCHANGE_HANDLE_BYTES: usize = 128;
+#[repr(C)]
+pub struct fwgpu_rccl_comm {
+    _private: [u8; 0],
+}
+pub const FWGPU_RCCL_UNIQUE_ID_BYTES: usize = 128;
 /// AudioNodeProcessor::process + ProcInfo (core/node.rs:37-53,94-118) as the C callback of a FWGPU_HOST_NODE
 pub type fwgpu_host_process_fn = Option<
     unsafe extern "C" fn(
@@ -150,6 +155,13 @@ extern "C" {
     pub fn fwgpu_bus_exchange_step(ex: *mut fwgpu_bus_exchange, d_partial: *const f32, d_silence: *const u8, d_out: *mut f32, d_out_silence: *mut u8, n_floats: u64, n_blocks: u32, frames_per_block: u32, n_channels: u32) -> c_int;
     pub fn fwgpu_bus_exchange_status(ex: *mut fwgpu_bus_exchange, steps: *mut u64, failed_step: *mut u64) -> c_int;
     pub fn fwgpu_bus_exchange_wait_stats(ex: *mut fwgpu_bus_exchange, max_wait_us: *mut u64, cap: u32, reset: c_int) -> c_int;
+    pub fn fwgpu_rccl_unique_id(id: *mut u8) -> c_int;
+    pub fn fwgpu_rccl_comm_create(ctx: *mut fwgpu_ctx, id: *const u8, world: u32, rank: u32) -> *mut fwgpu_rccl_comm;
+    pub fn fwgpu_rccl_comm_destroy(comm: *mut fwgpu_rccl_comm) -> c_int;
+    pub fn fwgpu_rccl_comm_info(comm: *mut fwgpu_rccl_comm, world: *mut u32, rank: *mut u32) -> c_int;
+    pub fn fwgpu_bus_allreduce_rccl(comm: *mut fwgpu_rccl_comm, d_bus: *mut f32, n_floats: u64) -> c_int;
+    pub fn fwgpu_bus_allgather_ordered(comm: *mut fwgpu_rccl_comm, d_bus: *const f32, d_silence: *const u8, d_out: *mut f32, d_out_silence: *mut u8, n_floats: u64, frames_per_block: u32, n_channels: u32) -> c_int;
+    pub fn fwgpu_rccl_last_error() -> *const c_char;
     pub fn fwgpu_synchronize(ctx: *mut fwgpu_ctx) -> c_int;
     pub fn fwgpu_proc_info(ctx: *mut fwgpu_ctx, stream_time_secs: *mut f64, stream_status: *mut u32, output_underflows: *mut u64, input_overflows: *mut u64) -> c_int;
     pub fn fwgpu_stream_open(ctx: *mut fwgpu_ctx, num_in_channels: u32, num_out_channels: u32) -> *mut fwgpu_stream;

@@ -11,7 +11,7 @@ OUT = os.path.join(ROOT, "rust", "firewheel-gpu", "src", "ffi.rs")
 
 BASE = {"int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "float": "f32", "double": "f64", "void": "c_void",
         "char": "c_char", "uint8_t": "u8", "size_t": "usize", "fwgpu_ctx": "fwgpu_ctx", "fwgpu_stream": "fwgpu_stream",
-        "fwgpu_sched_node": "fwgpu_sched_node", "fwgpu_bus_exchange": "fwgpu_bus_exchange",
+        "fwgpu_sched_node": "fwgpu_sched_node", "fwgpu_bus_exchange": "fwgpu_bus_exchange", "fwgpu_rccl_comm": "fwgpu_rccl_comm",
         "fwgpu_host_process_fn": "fwgpu_host_process_fn"}
 
 
@@ -81,6 +81,8 @@ def generate():
     o.append("#[repr(C)]\npub struct fwgpu_stream {\n    _private: [u8; 0],\n}")
     o.append("#[repr(C)]\npub struct fwgpu_bus_exchange {\n    _private: [u8; 0],\n}")
     o.append("pub const FWGPU_EXCHANGE_HANDLE_BYTES: usize = %d;" % int(re.search(r"#define FWGPU_EXCHANGE_HANDLE_BYTES (\d+)", open(HDR).read()).group(1)))
+    o.append("#[repr(C)]\npub struct fwgpu_rccl_comm {\n    _private: [u8; 0],\n}")
+    o.append("pub const FWGPU_RCCL_UNIQUE_ID_BYTES: usize = %d;" % int(re.search(r"#define FWGPU_RCCL_UNIQUE_ID_BYTES (\d+)", open(HDR).read()).group(1)))
     o.append("/// AudioNodeProcessor::process + ProcInfo (core/node.rs:37-53,94-118) as the C callback of a FWGPU_HOST_NODE")
     o.append("pub type fwgpu_host_process_fn = Option<\n    unsafe extern \"C\" fn(\n        user: *mut c_void,\n        frames: u64,\n        inputs: *const *const f32,\n"
              "        num_inputs: u32,\n        outputs: *const *mut f32,\n        num_outputs: u32,\n        in_silence_mask: u64,\n        out_silence_mask: *mut u64,\n"

@@ -150,7 +150,14 @@ void check_fused_common(const FusedView& fv, int K) {
             REQUIRE(sk == SK_GAIN || (fv.has_prog && !fv.fx_plan), i, j);
             touch(&fv.states[vd.stage_state[j]], sizeof(NodeState));
         }
-        REQUIRE(fv.fx_plan || (vd.bq_state < 0 && vd.dl_state < 0), i);
+        REQUIRE(fv.fx_plan || (vd.bq_state < 0 && vd.dl_state < 0 && vd.bq2_state < 0), i);
+        // round 6 grammar: gain stages in front of the filters are volume / pan only and only in a voice that has a filter; a second biquad
+        // needs a first; the delay-first order needs both kinds
+        REQUIRE(vd.n_pre >= 0 && vd.n_pre <= vd.n_stages && (vd.n_pre == 0 || vd.bq_state >= 0 || vd.dl_state >= 0), i, vd.n_pre);
+        for (int j = 0; j < vd.n_pre; ++j) REQUIRE(vd.stage_kind[j] == K_VOLUME || vd.stage_kind[j] == K_PAN, i, j);
+        REQUIRE(vd.bq2_state < 0 || vd.bq_state >= 0, i, vd.bq2_state);
+        REQUIRE((vd.fx_order == 0 || vd.fx_order == 1) && (vd.fx_order == 0 || (vd.bq_state >= 0 && vd.dl_state >= 0)), i, vd.fx_order);
+        if (vd.bq2_state >= 0) touch(&fv.states[vd.bq2_state], sizeof(NodeState));
         // 0 sampler, 1 SPEC resampler (program instantiation, no chain plan), 2 a one-output sampler behind MonoToStereo: no biquad / delay / spatialiser of its own
         REQUIRE(vd.src_kind == 0 || (vd.src_kind == 1 && fv.has_prog && !fv.fx_plan && fv.rs_table != nullptr) ||
                     (vd.src_kind == 2 && vd.bq_state < 0 && vd.dl_state < 0 && vd.sp_ext_off < 0), i, vd.src_kind);
@@ -389,7 +396,8 @@ int launch_voice_control(hipStream_t, const FusedView& fv, int K, uint32_t cmd_b
         for (int i = 0; i < fv.n_cmds; ++i)
             for (int v = 0; v < fv.n_voices; ++v) {
                 const VoiceDesc& vd = fv.voices[v];
-                bool mine = vd.sampler_state == fv.cmds[i].state || vd.bq_state == fv.cmds[i].state || vd.dl_state == fv.cmds[i].state;
+                bool mine = vd.sampler_state == fv.cmds[i].state || vd.bq_state == fv.cmds[i].state || vd.dl_state == fv.cmds[i].state ||
+                            vd.bq2_state == fv.cmds[i].state;
                 for (int j = 0; j < vd.n_stages && j < FW_MAX_STAGES - 1; ++j) mine = mine || vd.stage_state[j] == fv.cmds[i].state;
                 if (mine && fv.cmds[i].state >= 0 && !has[(size_t)v]) {
                     has[(size_t)v] = 1;
@@ -651,6 +659,10 @@ int launch_leaf_sum(hipStream_t, const FusedView& fv, int K) {
 int launch_chain(hipStream_t, const FusedView& fv, int K, uint32_t, int nq) {
     g_launches[3]++;
     check_fused_common(fv, K);
+    bool any_bq2 = false;
+    for (int i = 0; i < fv.n_voices; ++i) any_bq2 = any_bq2 || (fv.voices[i].sampler_state >= 0 && fv.voices[i].bq2_state >= 0);
+    REQUIRE(((nq & 4) != 0) == any_bq2, nq);  // bit 2: the instantiation with the second recurrence stage, exactly when some voice needs it
+    nq &= 3;
     REQUIRE(fv.fx_plan == 1 && K <= CH_FAST_KMAX && (nq == 1 || nq == 2) && fv.frames % (64 * nq) == 0, K, nq);
     touch(fv.chain_start, sizeof(ChainStart) * (size_t)fv.n_voices);
     touch(fv.chain_dummy, 32 * 1024);

@@ -156,4 +156,4 @@ def test_the_product_never_loads_the_oracle_or_the_test_harnesses():
     mk = open(os.path.join(pkg, "csrc", "Makefile")).read()
     srcs = re.search(r"^SRCS\s*:=\s*(.*)$", mk, flags=re.M).group(1).split()
     assert sorted(srcs) == ["fwgpu_abi.cpp", "fwgpu_control_math.cpp", "fwgpu_exchange.cpp", "fwgpu_graph.cpp", "fwgpu_kernels.hip",
-                            "fwgpu_plan_detect.cpp", "fwgpu_plan_install.cpp", "fwgpu_run.cpp"]
+                            "fwgpu_plan_detect.cpp", "fwgpu_plan_install.cpp", "fwgpu_rccl.cpp", "fwgpu_run.cpp"]

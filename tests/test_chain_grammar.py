@@ -1,0 +1,261 @@
+"""Round 6 — the chain plan's grammar.
+
+Reference: any edge is legal (crates/firewheel-graph/src/graph.rs:396-477), so a voice may put its gain in FRONT of its filter,
+cascade two biquads (an EQ), or run its delay line into a filter.  The chain plan (k_chain) took `sampler -> [biquad] -> [delay] ->
+gains` only; every other order fell to the level executor at a quarter of the speed.  It now takes
+
+    sampler -> {volume, pan}* -> FX -> {volume, pan}*     FX = B | BB | D | BD | BBD | DB | DBB     (<= 3 gain stages)
+
+CPU tier: the planner accepts exactly that (host-only harness: the real host code on a fake HIP runtime whose launch stubs validate
+every table the kernels would read).  GPU tier: every accepted shape bit for bit against the oracle — steady calls, source pauses
+(the stages in front of the filters see the sampler's silence flag and reset, the ones behind never do), muted pre-gains, gain
+glides on both sides of the filters, coefficient / feedback messages for every filter of the chain, every K batching.
+"""
+import numpy as np
+import pytest
+
+import fwapi
+import scenarios
+from fwapi import LOOP_FULL, GpuEngine, HostOnlyEngine, OracleEngine
+
+# token: v volume, p pan, B biquad, D delay.  One string = one voice chain behind its sampler.
+ACCEPTED = ["vB", "pBv", "vBD", "vBDv", "vpBDp", "BB", "BBv", "vBB", "vBBDp", "BBD", "DB", "DBv", "vDB", "DBB", "pDBBv", "vD", "vDp"]
+REFUSED = ["BvB", "BDB", "DBD", "BBB", "DD", "wB", "cB", "vBvDv"]  # a gain between filters, three filters in other orders, width / clip in front
+
+
+def build_voice(e, shape, rng, delay_frames):
+    s = e.sampler(100.0)
+    cur = s
+    nodes = dict(sampler=s, vols=[], pans=[], bqs=[], dls=[])
+    for t in shape:
+        if t == "v":
+            n = e.volume(float(rng.uniform(30, 100)))
+            nodes["vols"].append(n)
+        elif t == "p":
+            n = e.pan(float(rng.uniform(-1, 1)))
+            nodes["pans"].append(n)
+        elif t == "B":
+            n = e.biquad(int(rng.integers(0, 3)), float(rng.uniform(200, 8000)), float(rng.choice([0.707, 1.8])))
+            nodes["bqs"].append(n)
+        elif t == "D":
+            n = e.delay(delay_frames / float(e.sample_rate), feedback=float(rng.choice([0.0, 0.45])), mix=0.5)
+            nodes["dls"].append(n)
+        elif t == "w":
+            n = e.width(1.3)
+        elif t == "c":
+            n = e.hard_clip(-3.0)
+        else:
+            raise ValueError(t)
+        e.connect_stereo(cur, n)
+        cur = n
+    nodes["end"] = cur
+    return nodes
+
+
+def build_bank(e, shapes, radix=32, src_frames=1500, seed=0, delays=(64, 129, 300, 384, 700, 1000), fmt=fwapi.PLANAR_F32):
+    rng = np.random.default_rng(900 + seed)
+    voices = [build_voice(e, sh, rng, delays[i % len(delays)]) for i, sh in enumerate(shapes)]
+    level = [v["end"] for v in voices]
+    while True:
+        nxt = []
+        for i in range(0, len(level), radix):
+            grp = level[i:i + radix]
+            m = e.sum(max(2, len(grp)))
+            for p, n in enumerate(grp):
+                e.connect_stereo(n, m, 2 * p)
+            nxt.append(m)
+        level = nxt
+        if len(level) == 1:
+            break
+    e.connect_stereo(level[0], e.graph_out_node)
+    e.update()
+    for i, vc in enumerate(voices):
+        data = scenarios.voice_source(seed * 1000 + 77 + i, src_frames, 2)
+        if fmt == fwapi.INTERLEAVED_I16:
+            data = np.round(data * 32767).astype(np.int16).T.copy()
+        elif fmt == fwapi.INTERLEAVED_U16:
+            data = np.round((data + 1.0) * 32767.5).astype(np.uint16).T.copy()
+        vc["sample"] = e.new_sample(fmt, 2, data)
+        e.sampler_set_sample(vc["sampler"], vc["sample"])
+    return voices
+
+
+def run_events(e, shapes, calls=(3, 5, 2, 4, 6, 3), **kw):
+    """steady calls, then everything that can happen to such a voice, every kind of message landing inside a call"""
+    voices = build_bank(e, shapes, **kw)
+    for vc in voices:
+        e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+        e.sampler_play(vc["sampler"])
+    out = [e.process_blocks(calls[0])]           # start-up: smoothers settle
+    out.append(e.process_blocks(calls[1]))        # steady
+    for i, vc in enumerate(voices):               # glides on both sides of the filters, filter messages, one block into the call
+        for j, n in enumerate(vc["vols"]):
+            if (i + j) % 2 == 0:
+                e.set_param(n, 0, 20.0 + 7.0 * ((i + j) % 5), at_block=1 + (i % 2))
+        for n in vc["pans"]:
+            if i % 3 == 0:
+                e.set_param(n, 0, -0.5, at_block=1)
+        for j, n in enumerate(vc["bqs"]):
+            if (i + j) % 2 == 1:
+                e.set_param(n, 1, 500.0 + 300.0 * j + 100.0 * (i % 7), at_block=1)
+        for n in vc["dls"]:
+            if i % 4 == 1:
+                e.set_param(n, 1, 0.3, at_block=0)
+    out.append(e.process_blocks(calls[2]))
+    out.append(e.process_blocks(calls[3]))        # the glides settle, then steady again
+    for i, vc in enumerate(voices):               # source pauses (the stages in front reset), a muted pre-gain, a muted post-gain
+        if i % 3 == 0:
+            e.sampler_pause(vc["sampler"], at_block=1)
+        if i % 3 == 1 and vc["vols"]:
+            e.set_param(vc["vols"][0], 0, 0.0, at_block=0)
+        if i % 3 == 2 and len(vc["vols"]) > 1:
+            e.set_param(vc["vols"][-1], 0, 0.0, at_block=2)
+    out.append(e.process_blocks(calls[4]))
+    for i, vc in enumerate(voices):               # ... and back
+        if i % 3 == 0:
+            e.sampler_play(vc["sampler"], at_block=0)
+        if i % 3 == 1 and vc["vols"]:
+            e.set_param(vc["vols"][0], 0, 80.0, at_block=1)
+    out.append(e.process_blocks(calls[5]))
+    out.append(e.process_blocks(calls[1]))
+    return np.concatenate(out)
+
+
+# ------------------------------------------------------------------------------------------------ CPU tier: the planner
+@pytest.mark.parametrize("shape", ACCEPTED)
+def test_planner_takes_the_shape_on_the_chain_plan(shape):
+    e = HostOnlyEngine(max_block_frames=128, max_batch=8)
+    build_bank(e, [shape] * 5)
+    assert e.cx.plan_kind() == 2, shape
+    assert e.cx.plan_fused_voices() == 5
+    for vc in range(3):
+        e.process_blocks(3)
+    assert e.violation() == ""
+    la = e.launches()
+    assert la["chain"] >= 3 and la["level"] == 0, la
+
+
+@pytest.mark.parametrize("shape", REFUSED)
+def test_planner_refuses_the_shape_as_a_whole_and_keeps_its_prefix(shape):
+    """not lost: the hybrid plan renders the longest acceptable prefix of each voice as a solo voice, the level executor the rest"""
+    e = HostOnlyEngine(max_block_frames=128, max_batch=8)
+    build_bank(e, [shape] * 9)
+    assert e.cx.plan_kind() in (0, 3), shape
+    e.process_blocks(3)
+    assert e.violation() == ""
+    if e.cx.plan_kind() == 3:
+        assert e.cx.plan_fused_voices() == 9
+
+
+def test_planner_mixed_bank_of_every_accepted_shape_and_events_on_the_host_harness():
+    e = HostOnlyEngine(max_block_frames=128, max_batch=4)
+    run_events(e, ACCEPTED * 2, radix=8)
+    assert e.cx.plan_kind() == 2
+    assert e.violation() == ""
+
+
+# ------------------------------------------------------------------------------------------------ GPU tier: parity
+def both(shapes, mbf=128, max_batch=None, force_generic=False, **kw):
+    o = scenarios.TaggedOracle(OracleEngine(max_block_frames=mbf))  # (messages carry at_block, like the C ABI's)
+    g = GpuEngine(max_block_frames=mbf, max_batch=max_batch, force_generic=force_generic)
+    ro = run_events(o, shapes, **kw)
+    rg = run_events(g, shapes, **kw)
+    return ro, rg, g
+
+
+def assert_bits(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, what
+    bad = np.nonzero(fwapi.bits(a) != fwapi.bits(b))[0]
+    assert bad.size == 0, "%s: %d of %d samples differ, first at %d (block %d): %r vs %r" % (what, bad.size, a.size, bad[0], bad[0] // (2 * 128), a[bad[0]], b[bad[0]])
+    assert np.any(a != 0), what + ": nothing sounded"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ACCEPTED)
+@pytest.mark.parametrize("max_batch", [64, 2])
+def test_every_accepted_shape_is_bit_exact_on_the_chain_plan(shape, max_batch):
+    ro, rg, g = both([shape] * 7, max_batch=max_batch, radix=4)
+    assert g.cx.plan_kind() == 2, shape
+    assert_bits(ro, rg, "%s K<=%d" % (shape, max_batch))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_batch", [64, 3, 1])
+@pytest.mark.parametrize("mbf", [128, 64])
+def test_a_mixed_bank_of_every_accepted_shape_is_bit_exact(max_batch, mbf):
+    """voices of different shapes share workgroups (<= 32 rows each): per-lane stage positions, one instantiation for the whole plan;
+    mbf 64 = the small-tile instantiations"""
+    shapes = (ACCEPTED * 3)[:45]
+    ro, rg, g = both(shapes, mbf=mbf, max_batch=max_batch, radix=16, seed=3)
+    assert g.cx.plan_kind() == 2
+    assert_bits(ro, rg, "mixed bank K<=%d mbf %d" % (max_batch, mbf))
+    steady, general = g.cx.plan_chain_stats()  # (every workgroup of this bank holds a delay-first voice or a short delay: the general loop)
+    assert general > 0, (steady, general)
+
+
+@pytest.mark.gpu
+def test_filter_first_shapes_take_the_steady_call_loop():
+    """gain-before-filter and two-biquad voices with delays >= 3 tiles run k_chain's branch-free steady-call loop on message-free calls"""
+    shapes = ["vBDv", "BBDp", "vBBD", "pBD"] * 8
+    ro, rg, g = both(shapes, max_batch=16, radix=32, delays=(384, 500, 777, 1000), calls=(4, 16, 2, 12, 6, 3))
+    assert g.cx.plan_kind() == 2
+    assert_bits(ro, rg, "steady-call loop shapes")
+    steady, general = g.cx.plan_chain_stats()
+    assert steady >= 2 and general > 0, (steady, general)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["vBDv", "BBv", "DBp", "vDBB"])
+def test_the_level_executor_twin_of_the_new_shapes(shape):
+    ro, rg, g = both([shape] * 6, force_generic=True, radix=3)
+    assert g.cx.plan_kind() == 0
+    assert_bits(ro, rg, shape + " on the level executor")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", REFUSED)
+def test_refused_shapes_stay_bit_exact_on_the_hybrid_plan(shape):
+    ro, rg, g = both([shape] * 9, radix=3)
+    assert g.cx.plan_kind() in (0, 3)
+    assert_bits(ro, rg, shape + " (refused as a whole)")
+
+
+@pytest.mark.gpu
+def test_state_of_both_biquads_and_the_pre_gain_survives_plan_switches():
+    """chain plan -> level executor -> chain plan mid-stream: both filters' histories, the ring, the smoothers in front carry over"""
+    def run(e):
+        voices = build_bank(e, ["vBBDp", "pDBBv", "vBD"] * 3, radix=3)
+        for vc in voices:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)
+            e.sampler_play(vc["sampler"])
+        e.set_param(voices[0]["vols"][0], 0, 15.0, at_block=2)
+        a = e.process_blocks(4)
+        extra = e.sum(2)  # a dangling node: no fused plan covers the graph any more
+        e.update()
+        b = e.process_blocks(3)
+        e.remove_node(extra)
+        e.update()
+        c = e.process_blocks(5)
+        return np.concatenate([a, b, c])
+
+    o, g = scenarios.TaggedOracle(OracleEngine(max_block_frames=128)), GpuEngine(max_block_frames=128)
+    ro, rg = run(o), run(g)
+    assert g.cx.plan_kind() == 2
+    assert_bits(ro, rg, "plan switches")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["INTERLEAVED_I16", "INTERLEAVED_U16"])
+@pytest.mark.parametrize("max_batch", [16, 1])
+def test_interleaved_16_bit_sources_are_fetched_by_the_chain_kernel_itself(fmt, max_batch):
+    """16-bit PCM (core/sample_resource.rs:338-345) as a compact source class of the chain plan: one dwordx4 per quad like planar f32,
+    the channel's half-word converted in S1 — both loops (the sample length is no multiple of the block: loops wrap inside blocks),
+    message-free calls on the steady-call loop"""
+    shapes = ["vBDv", "BD", "BBDp", "vB", "D"] * 7 + ["vDB", "DBB"]  # (the last two share the second workgroup: delay-first = general loop)
+    ro, rg, g = both(shapes, max_batch=max_batch, radix=32, delays=(384, 500, 777, 1000), calls=(4, 16, 2, 12, 6, 3),
+                     fmt=getattr(fwapi, fmt), src_frames=1501)
+    assert g.cx.plan_kind() == 2
+    assert_bits(ro, rg, "16-bit sources K<=%d" % max_batch)
+    steady, general = g.cx.plan_chain_stats()
+    assert general > 0 and (steady > 0 or max_batch == 1), (steady, general)

@@ -48,8 +48,8 @@ def per_kernel(ctr):
 
 fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
 per_vs = {"cfg2": 8.0, "cfg3": 24.0, "cfg5": 8.0}.get(cfg)
-if per_vs and "i16" in extra.split():  # (--source-format i16: SURVEY 8d's 4 B row)
-    per_vs = 4.0
+if per_vs and "i16" in extra.split():  # (--source-format i16: SURVEY 8d's 4 B row; config 3: 4 B of source + ring read + ring write)
+    per_vs = 20.0 if cfg == "cfg3" else 4.0
 dom = {"cfg2": "k_leaf_sum", "cfg3": "k_chain", "cfg5": "k_leaf_sum", "cfg4": "k_fir_gemm"}[cfg]
 if "--rs-source" in extra.split():
     dom = "k_leaf_rs"

@@ -579,7 +579,7 @@ def parity_check_multi(env, args, wl, V, B, K, F, src, stream, device, mode):
                "voices": V * world, "voices_per_rank": V, "blocks_per_call": K, "samples_compared": int(got.size),
                "silent_flags_seen": int(sum(int(f.sum()) for f in flags)), "launch_plan": cx.plan_kind(),
                "against": "oracle (C++ restatement of the reference): the WHOLE graph, %d shards under one %d-port SumNode, same source frames" % (world, world),
-               "expected": "bit_exact" if used in ("exchange", "ordered") or world <= 2 else "within_tolerance"}
+               "expected": "bit_exact" if used in ("exchange", "ordered", "ordered_abi") or world <= 2 else "within_tolerance"}
         if hostonly:
             res = {"skipped": "host-only harness: no audio computed", "ranks": world, "bus_reduce": used, "oracle_whole_graph_nonzero": bool(np.any(ref))}
         elif not bool(np.any(ref)):
@@ -672,7 +672,9 @@ class ExchangeFailed(RuntimeError):
 
 
 REDUCE_DESC = {"exchange": "one-shot exchange over peer-mapped slots (fwgpu_bus_exchange, rank-ordered: bit-exact)",
-               "ordered": "RCCL all-gather + rank-ordered sum kernel (bit-exact)", "allreduce": "RCCL all-reduce", None: "none"}
+               "ordered": "RCCL all-gather + rank-ordered sum kernel (bit-exact)", "allreduce": "RCCL all-reduce",
+               "ordered_abi": "RCCL all-gather + rank-ordered sum through the C ABI (fwgpu_bus_allgather_ordered: bit-exact)",
+               "allreduce_abi": "RCCL all-reduce through the C ABI (fwgpu_bus_allreduce_rccl)", None: "none"}
 
 
 def make_reducer(env, args, cx, outs, sils, B, mode=None, reds=None):
@@ -693,6 +695,13 @@ def make_reducer(env, args, cx, outs, sils, B, mode=None, reds=None):
             mode = "allreduce"
     if env.get("share_device"):
         raise SystemExit("bench.py --share-device: RCCL refuses two ranks on one device; only --bus-reduce exchange runs there")
+    if mode in ("ordered_abi", "allreduce_abi"):  # libfwgpu's own RCCL calls (what a host bound to include/fwgpu.h gets); gloo carries the id
+        if env["hostonly"]:
+            raise SystemExit("bench.py: the C ABI's RCCL modes need librccl (tests/test_rccl_abi.py covers them on the host harness)")
+        reds = reds or [torch.empty_like(o) for o in outs]
+        r = shard.AbiRcclReducer(dist, outs, cx, mode, reds if mode == "ordered_abi" else None, sils, B, 2)
+        env["rccl_ranks_seen"] = dist.get_world_size()
+        return r, mode, note
     grp = rccl_group(env)
     if mode == "ordered":
         return shard.BusReducer(dist, outs, "ordered", group=grp, cx=cx, sils=sils, frames=B, n_ch=2), "ordered", note
@@ -1079,7 +1088,7 @@ def run_workload(env, args, wl, V, B, K, F, steps, warmup, full=True, parity_mul
             res["parity_check_timed_context"] = own
     if reducer is not None and hasattr(reducer, "close"):
         if res is not None:  # how far the ranks ran apart: the longest rank 0's reduce kernels waited for each rank's arrival
-            res["config"]["bus_exchange_max_wait_us"] = reducer.x.wait_stats()
+            res["config"]["bus_exchange_max_wait_us"] = reducer.x.wait_stats() if hasattr(reducer, "x") else None
         reducer.close(dist)
     if world > 1 and (full or parity_multi) and not args.no_parity_check and wl in ("cfg2", "cfg5", "cfg3") and sfmt == "f32":
         pc = parity_check_multi(env, args, wl, V, B, K, F, src, stream, device, reduce_mode)  # collective: every rank takes part
@@ -1252,7 +1261,8 @@ def other_configs_multi(env, args):
         out["other_configs"]["cfg5"] = {"error": repr(ex)}
     if not env.get("share_device"):
         dV, dB, dK, dF, _ = (64, 64, 4, 1024, 0) if hostonly else DEFAULTS["cfg2"]
-        for mode in ("allreduce", "ordered", "exchange"):
+        # (the two RCCL reductions through torch.distributed, the same two through libfwgpu's own C ABI — what a Rust host gets —, the exchange)
+        for mode in ("allreduce", "ordered", "exchange") + (() if hostonly else ("allreduce_abi", "ordered_abi")):
             if mode == args.bus_reduce:
                 continue
             am = copy.copy(args)
@@ -1500,7 +1510,7 @@ def main():
                          "(smoother ramps, message path inside the timed region); C every 4th voice paused (silence masks)")
     ap.add_argument("--reduce-every", type=int, default=4,
                     help="N>1: steps whose mix buses share one collective (the reduction of R steps overlaps the next R)")
-    ap.add_argument("--bus-reduce", choices=["exchange", "allreduce", "ordered"], default="exchange",
+    ap.add_argument("--bus-reduce", choices=["exchange", "allreduce", "ordered", "allreduce_abi", "ordered_abi"], default="exchange",
                     help="N>1, the mix bus: libfwgpu's one-shot exchange over peer-mapped slots (rank-ordered, bit-exact; falls back to "
                          "the all-reduce when IPC / peer access is unavailable), the RCCL all-reduce (north_star's named path; "
                          "re-associates the sum for N > 2), or RCCL all-gather + rank-ordered sum kernel (bit-exact)")

@@ -208,3 +208,65 @@ class ExchangeReducer(object):
         if dist is not None:
             dist.barrier(group=group)  # nobody unmaps a region a peer may still be storing into
         self.x.close()
+
+
+class AbiRcclReducer(object):
+    """BusReducer's interface over libfwgpu's OWN RCCL calls (include/fwgpu.h "the mix bus over RCCL": fwgpu_bus_allreduce_rccl /
+    fwgpu_bus_allgather_ordered — librccl dlopen'ed by the library, a communicator built from a unique id): what a Rust or C host
+    bound to the header gets.  torch.distributed is only the side channel that carries rank 0's 128-byte id.  mode "allreduce_abi"
+    reduces buffer i in place; "ordered_abi" all-gathers buses + silence flags and adds them in rank order into `outs[i]`
+    (bit-exact).  Both run on the ctx stream: `wait` has nothing to wait for on the host."""
+
+    def __init__(self, dist, bufs, cx, mode="allreduce_abi", outs=None, sils=None, frames=0, n_ch=2, group=None):
+        import ctypes as C
+
+        assert mode in ("allreduce_abi", "ordered_abi")
+        self.mode, self.bufs, self.cx, self.sils, self.frames, self.n_ch = mode, list(bufs), cx, sils, frames, n_ch
+        self.outs = list(outs) if outs is not None else self.bufs
+        L = cx.L
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        uid = (C.c_uint8 * 128)()
+        err = None
+        if rank == 0 and L.fwgpu_rccl_unique_id(uid) != 0:
+            err = (L.fwgpu_rccl_last_error() or b"").decode(errors="replace")
+        box = [bytes(uid) if err is None else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        self.m = None
+        if box[0] is not None:
+            got = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            self.m = L.fwgpu_rccl_comm_create(cx.c, got, world, rank)  # collective
+            if not self.m:
+                err = (L.fwgpu_last_error(cx.c) or b"").decode(errors="replace")
+        else:
+            err = err or "rank 0 could not make an RCCL unique id"
+        errs = [None] * world
+        dist.all_gather_object(errs, err, group=group)
+        bad = [(r, e) for r, e in enumerate(errs) if e]
+        if bad:
+            self.close()
+            raise RuntimeError("RCCL through the C ABI unavailable: " + "; ".join("rank %d: %s" % be for be in bad))
+
+    def submit(self, i):
+        import ctypes as C
+
+        L, b = self.cx.L, self.bufs[i]
+        if self.mode == "allreduce_abi":
+            self.cx._check(L.fwgpu_bus_allreduce_rccl(self.m, C.c_void_p(b.data_ptr()), b.numel()))
+        else:
+            s = self.sils[i] if self.sils is not None else None
+            self.cx._check(L.fwgpu_bus_allgather_ordered(self.m, C.c_void_p(b.data_ptr()), C.c_void_p(s.data_ptr()) if s is not None else None,
+                                                         C.c_void_p(self.outs[i].data_ptr()), None, b.numel(), self.frames, self.n_ch))
+
+    def wait(self, i):
+        return self.outs[i]
+
+    def wait_all(self):
+        self.cx.synchronize()
+
+    def close(self, dist=None, group=None):
+        if self.m:
+            self.cx.synchronize()
+            if dist is not None:
+                dist.barrier(group=group)
+            self.cx.L.fwgpu_rccl_comm_destroy(self.m)
+            self.m = None

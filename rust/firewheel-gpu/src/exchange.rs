@@ -96,3 +96,71 @@ impl Drop for BusExchange {
         unsafe { ffi::fwgpu_bus_exchange_close(self.raw.as_ptr()) }
     }
 }
+
+/// The same step over RCCL (include/fwgpu.h "the mix bus over RCCL"; north_star's named path): libfwgpu `dlopen`s librccl on first
+/// use.  Rank 0 makes the unique id ([`RcclComm::unique_id`]), the host carries its 128 bytes to every rank, every rank builds its
+/// communicator on its context's device (collective).
+pub const RCCL_ID_BYTES: usize = ffi::FWGPU_RCCL_UNIQUE_ID_BYTES;
+
+pub struct RcclComm {
+    cx: Arc<GpuContext>,
+    raw: NonNull<ffi::fwgpu_rccl_comm>,
+    pub rank: u32,
+    pub world: u32,
+}
+unsafe impl Send for RcclComm {}
+
+impl RcclComm {
+    pub fn unique_id() -> Result<[u8; RCCL_ID_BYTES], GpuError> {
+        let mut id = [0u8; RCCL_ID_BYTES];
+        let rc = unsafe { ffi::fwgpu_rccl_unique_id(id.as_mut_ptr()) };
+        if rc < 0 {
+            let message = unsafe { std::ffi::CStr::from_ptr(ffi::fwgpu_rccl_last_error()) }.to_string_lossy().into_owned();
+            return Err(GpuError { code: rc, message });
+        }
+        Ok(id)
+    }
+    /// Collective: every rank of `id` calls it (ncclCommInitRank).
+    pub fn create(cx: Arc<GpuContext>, id: &[u8; RCCL_ID_BYTES], world: u32, rank: u32) -> Result<Self, GpuError> {
+        let _g = cx.control();
+        let raw = unsafe { ffi::fwgpu_rccl_comm_create(cx.as_ptr(), id.as_ptr(), world, rank) };
+        drop(_g);
+        match NonNull::new(raw) {
+            Some(raw) => Ok(Self { cx, raw, rank, world }),
+            None => Err(cx.check(ffi::FWGPU_ERR_DEVICE as i64).unwrap_err()),
+        }
+    }
+    /// AUDIO side, asynchronous on the context's stream: ncclAllReduce(sum) in place.  Re-associates the f32 sum for more than two
+    /// ranks (within 1e-6 relative of the single-process graph, not its bits).
+    ///
+    /// # Safety
+    /// `d_bus` must be a device allocation of at least `n_floats` floats that stays alive until the stream has passed the call.
+    pub unsafe fn allreduce(&mut self, d_bus: *mut f32, n_floats: u64) -> Result<(), GpuError> {
+        self.cx.check(ffi::fwgpu_bus_allreduce_rccl(self.raw.as_ptr(), d_bus, n_floats) as i64).map(|_| ())
+    }
+    /// AUDIO side: ncclAllGather of buses and silence flags + the rank-ordered sum (sum.rs:111-133's order and silent-port rule):
+    /// bit-identical to the single-process graph on every rank.
+    ///
+    /// # Safety
+    /// As [`BusExchange::step`]: valid device pointers of the stated sizes until the stream has passed the call.
+    pub unsafe fn allgather_ordered(
+        &mut self,
+        d_bus: *const f32,
+        d_silence: *const u8,
+        d_out: *mut f32,
+        d_out_silence: *mut u8,
+        n_floats: u64,
+        frames_per_block: u32,
+        n_channels: u32,
+    ) -> Result<(), GpuError> {
+        self.cx
+            .check(ffi::fwgpu_bus_allgather_ordered(self.raw.as_ptr(), d_bus, d_silence, d_out, d_out_silence, n_floats, frames_per_block, n_channels) as i64)
+            .map(|_| ())
+    }
+}
+impl Drop for RcclComm {
+    fn drop(&mut self) {
+        let _g = self.cx.control();
+        unsafe { ffi::fwgpu_rccl_comm_destroy(self.raw.as_ptr()) };
+    }
+}

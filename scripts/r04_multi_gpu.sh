@@ -10,6 +10,8 @@
 #   exchange   libfwgpu's one-shot exchange over peer-mapped slots (hipIpc + xGMI stores; rank-ordered: bit-exact)   [default]
 #   ordered    RCCL all-gather + rank-ordered sum kernel (bit-exact)
 #   allreduce  RCCL all-reduce (north_star's named path; re-associates the f32 sum for N > 2: tolerance, not bits)
+#   allreduce_abi / ordered_abi (round 6)  the same two through libfwgpu's OWN C ABI (fwgpu_bus_allreduce_rccl / _allgather_ordered:
+#              librccl dlopen'ed by the library, communicator from a unique id) — what a Rust / C host bound to include/fwgpu.h gets
 # — each with its parity_check against the oracle's WHOLE graph, rccl_ranks_seen, the longest device-side wait per peer, and
 # BASELINE configs[4] (8 192 voices per GPU, block 1024, the reduction after every step) in other_configs.  One line per
 # (N, mode) in gpurun_out/r04/multi_gpu_N<N>.json, a table on stdout, scaling efficiency against N = 1 at the end.
@@ -24,8 +26,13 @@ done
 python - $NS <<'PY'
 import json, sys
 def load(n):
+    # (round 6: stdout carries a compact line; the whole record — every mode's parity object — is the side file it names)
     try:
-        return json.loads(open("gpurun_out/r04/multi_gpu_N%s.json" % n).read().strip().splitlines()[-1])
+        line = json.loads(open("gpurun_out/r04/multi_gpu_N%s.json" % n).read().strip().splitlines()[-1])
+        try:
+            return json.loads(open(line["full"]).read())
+        except Exception:
+            return line
     except Exception as ex:
         return {"error": repr(ex)}
 one = load(1)

@@ -242,7 +242,11 @@ int fwgpu_sample_retired(fwgpu_ctx* ctx, int sample);
 
 /* ---- control -> audio messages.  `at_block` = index of the max_block_frames-sized block, counted from
  * the start of the NEXT process call, before which the message is seen (the reference's rings/atomics
- * are polled at block start: nodes/sampler.rs:331, nodes/volume.rs:92). */
+ * are polled at block start: nodes/sampler.rs:331, nodes/volume.rs:92).  Messages to one node apply in (at_block, send) order.
+ * Send a node's messages in NON-DECREASING at_block order: the reference has no tag at all — "message, then process" is the only
+ * order it knows — and parameters the control side folds into derived state (a biquad's cutoff and Q into its five coefficients,
+ * computed in f64 with the host's libm) are folded WHEN THE MESSAGE IS SENT, with the node's other parameters as last sent; out
+ * of block order they take effect as sent, not as tagged (found by tests/test_chain_grammar.py's fuzz, round 6). */
 /* VolumeNode::set_percent_volume (volume.rs:28-34) / SamplerNode::set_percent_volume (sampler.rs:171-177):
  * param 0.  BeepTestNode::set_enabled (beep_test.rs:30-32): param 0.  SPEC nodes: StereoPan 0 = pan;
  * StereoWidth 0 = width; Biquad 1 = cutoff_hz, 2 = q; Delay 1 = feedback, 2 = mix; Resampler 1 = ratio,

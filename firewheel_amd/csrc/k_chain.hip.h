@@ -18,7 +18,8 @@
 // bit-identical to the generic executor.  HBM traffic per stereo voice-sample: 8 B source + 8 B ring read + 8 B
 // ring write = the 24 B of SURVEY §8d.
 // Round 6: gain stages in FRONT of the filters are multiplied in by S1 (VoiceDesc::n_pre); a delay line in FRONT of the biquads
-// (fx_order 1) is read-modify-written by S1 instead of S3a (general loop only: the steady-call loop takes filter-first voices); a
+// (fx_order 1) is read-modify-written by S1 instead of S3a (both loops: in the steady-call loop such a lane's ring requests run two
+// tiles ahead of S1 instead of behind it); a
 // SECOND biquad (an EQ cascade) is two more pipeline stages in the <NQ, true> instantiation (six tile buffers, S3a / S3b two tiles
 // later): S1b — the worker lanes form its feed-forward sums on the first biquad's output, in place — and S2b — its recurrence, a
 // second serial wave.  Measured (clock64 per role, profiles/r06_chain_roles.txt): a serial wave issues one instruction per ~7 cycles
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     const int n_pre = active ? vd.n_pre : 0;                         // gain stages in front of the filters (multiplied in by S1)
     const bool dl_first = has_dl && vd.fx_order == 1;                // the delay line in front of the biquads: S1 does its read-modify-write
     const bool any_pre = __syncthreads_or(n_pre > 0 ? 1 : 0) != 0;
+    const bool any_dlf = __syncthreads_or(dl_first ? 1 : 0) != 0;  // (a workgroup without delay-first voices carries none of their code path)
     uint32_t D = 1, pos = cs.pos;
     float fb = cs.fb, mix = cs.mix, dry = cs.dry;
     float* ring = nullptr;
@@ -247,7 +249,6 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             fast_ok = fast_ok && !(i < fv.n_cmds && fv.cmds[i].state == vd.bq2_state && fv.cmds[i].block < b1);
         }
     }
-    if (dl_first) fast_ok = false;  // (the steady-call loop's ring accesses are S3a's: filter-first voices)
     for (int i = threadIdx.x; i < ports * K; i += CH_THREADS) {
         const int pv = i / K, pk = i - pv * K, pvoice = grp.first_voice + pv;
         const VoiceRef rk = fv.refs[ref_index(pvoice, pk, fv.ref_kgroups)];
@@ -449,6 +450,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         const bool src_zero = (vflags & VB_SRC_ZERO) != 0, silent = (vflags & VB_SILENT) != 0;
         float* const dummy = fv.chain_dummy + (size_t)threadIdx.x * (4 * NQ);
         const bool ringed = active && has_dl;  // this lane's voice has a delay line
+        const bool o1 = ringed && dl_first;    // ... in FRONT of its biquads: S1 does the read-modify-write, on the tile it has just made
+        const bool ring3 = ringed && !o1;      // ... behind them: S3a's
         const float* const rbase = ringed ? ring : dummy;
         const uint32_t Dv = ringed ? D : 0x7fffffffu;
         uint32_t pos_c = ringed ? pos : 0u, pos_i = pos_c;  // ring position of the tile S3a consumes / the tile requested
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         };
         auto wstep = [&](int s, v4f(&xs)[NQ], v4f(&rg)[NQ]) {
             const bool v1 = s < n_tiles;
-            const bool v3 = ringed && s >= LAG3 && s - LAG3 < n_tiles;  // S3a of a real tile of a voice with a delay line
+            const bool v3 = ring3 && s >= LAG3 && s - LAG3 < n_tiles;  // S3a of a real tile of a voice with a delay line behind its filters
             CH_TRACE(0);
             CH_PROF_BEGIN();
             v4f yv[NQ];
@@ -551,6 +554,58 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                         for (int j = 0; j < NQ; ++j) x[j] = src_zero ? splat(0.f) : x[j] * gpre[g];
                     }
                 }
+                if (any_dlf) {
+                    // delay-first voices (round 6): the ring slots of tile s were requested two steps ago into THIS register set (issue_ring
+                    // below asks for tile s + 2 on their lanes); read-modify-write them here, branch-free like S3a's (dummy addresses for
+                    // every other lane), and hand the wet signal to the feed-forward half
+                    const bool v1d = o1 && v1;
+                    uint32_t sl1[NQ];
+                    bool str1 = false;
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        sl1[j] = slot_of(pos_c, j);
+                        str1 = str1 || (v1d && sl1[j] + 4u > Dv);
+                    }
+                    if (__ballot(str1) != 0ull) {  // rare: this lane's quad wraps around the end of the ring
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) {
+                            if (v1d && sl1[j] + 4u > Dv) {
+                                v4f t;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    uint32_t se = sl1[j] + (uint32_t)e;
+                                    if (se >= Dv) se -= Dv;
+                                    t[e] = rbase[se];
+                                }
+                                asm volatile("" : "+v"(t));
+                                rg[j] = t;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const v4f nv = x[j] + (rg[j] * fb);  // ring[p] = x + (d*fb)
+                        float* sp = (v1d && sl1[j] + 4u <= Dv) ? ring + sl1[j] : dummy + 4 * j;
+                        asm volatile("" : "+v"(sp));
+                        *(v4f_u __attribute__((address_space(1)))*)(uint64_t)sp = nv;
+                        const v4f wet = (x[j] * dry) + (rg[j] * mix);  // out = (x*dry) + (d*mix)
+                        if (__ballot(str1) != 0ull) {
+                            if (v1d && sl1[j] + 4u > Dv) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    uint32_t se = sl1[j] + (uint32_t)e;
+                                    if (se >= Dv) se -= Dv;
+                                    ring[se] = nv[e];
+                                }
+                            }
+                        }
+                        x[j] = o1 ? wet : x[j];
+                    }
+                    if (v1d) {
+                        pos_c += TT;
+                        if (pos_c >= Dv) pos_c -= Dv;
+                    }
+                }
                 float* row = &tile[CH_BUF(s)][v][LF * q];
                 const bool q15 = q == 15;
                 float p1 = row_ror1(q15 ? prev_x[3] : x[NQ - 1][3]), p2 = row_ror1(q15 ? prev_x[2] : x[NQ - 1][2]);
@@ -603,7 +658,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     asm volatile("" : "+v"(sp));
                     *(v4f_u __attribute__((address_space(1)))*)(uint64_t)sp = nv;
                     const v4f wet = (y * dry) + (rg[j] * mix);  // out = (x*dry) + (d*mix)
-                    y = ringed ? wet : y;                       // no delay: untouched
+                    y = ring3 ? wet : y;                        // no delay line behind the filters: untouched
 #pragma unroll
                     for (int g = 0; g < FW_CHAIN_STAGES - 1; ++g) {
                         if (g + 1 >= fv.n_gain_stages) break;
@@ -628,14 +683,14 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                 }
                 if (q == 0) silf[CH_BUF(s - LAG3)][v] = silent ? 1u : 0u;
             }
-            issue_ring(rg, s - (LAG3 - 2));
+            issue_ring(rg, o1 ? s + 2 : s - (LAG3 - 2));  // (consumed two steps on: by S3a as tile s + 2 - LAG3, by a delay-first lane's S1 as tile s + 2)
             CH_TRACE(3);
             CH_PROF_END();
             __syncthreads();
             CH_TRACE(4);
         };
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) rgA[j] = rgB[j] = splat(0.f);
+        issue_ring(rgA, o1 ? 0 : -1);  // (delay-first lanes: tiles 0 and 1; the others load their dummy line)
+        issue_ring(rgB, o1 ? 1 : -1);
         issue_src(xsA, 0);
         issue_src(xsB, 1);
         for (int s = 0; s < n_steps; s += 2) {

@@ -190,14 +190,16 @@ def test_a_mixed_bank_of_every_accepted_shape_is_bit_exact(max_batch, mbf):
     ro, rg, g = both(shapes, mbf=mbf, max_batch=max_batch, radix=16, seed=3)
     assert g.cx.plan_kind() == 2
     assert_bits(ro, rg, "mixed bank K<=%d mbf %d" % (max_batch, mbf))
-    steady, general = g.cx.plan_chain_stats()  # (every workgroup of this bank holds a delay-first voice or a short delay: the general loop)
+    steady, general = g.cx.plan_chain_stats()  # (every workgroup of this bank holds a delay shorter than three tiles: the general loop)
     assert general > 0, (steady, general)
 
 
 @pytest.mark.gpu
-def test_filter_first_shapes_take_the_steady_call_loop():
-    """gain-before-filter and two-biquad voices with delays >= 3 tiles run k_chain's branch-free steady-call loop on message-free calls"""
-    shapes = ["vBDv", "BBDp", "vBBD", "pBD"] * 8
+@pytest.mark.parametrize("shapes", [["vBDv", "BBDp", "vBBD", "pBD"], ["DB", "vDBp", "DBB", "pDBBv"], ["vBDv", "DBv", "BBD", "vDBB"]])
+def test_every_accepted_order_takes_the_steady_call_loop(shapes):
+    """gain-before-filter, two-biquad and delay-first voices with delays >= 3 tiles run k_chain's branch-free steady-call loop on
+    message-free calls (delay-first lanes request their ring slots two tiles AHEAD of S1 instead of behind it)"""
+    shapes = shapes * 8
     ro, rg, g = both(shapes, max_batch=16, radix=32, delays=(384, 500, 777, 1000), calls=(4, 16, 2, 12, 6, 3))
     assert g.cx.plan_kind() == 2
     assert_bits(ro, rg, "steady-call loop shapes")
@@ -252,7 +254,7 @@ def test_interleaved_16_bit_sources_are_fetched_by_the_chain_kernel_itself(fmt, 
     """16-bit PCM (core/sample_resource.rs:338-345) as a compact source class of the chain plan: one dwordx4 per quad like planar f32,
     the channel's half-word converted in S1 — both loops (the sample length is no multiple of the block: loops wrap inside blocks),
     message-free calls on the steady-call loop"""
-    shapes = ["vBDv", "BD", "BBDp", "vB", "D"] * 7 + ["vDB", "DBB"]  # (the last two share the second workgroup: delay-first = general loop)
+    shapes = ["vBDv", "BD", "BBDp", "vB", "D"] * 7 + ["vDB", "DBB"]
     ro, rg, g = both(shapes, max_batch=max_batch, radix=32, delays=(384, 500, 777, 1000), calls=(4, 16, 2, 12, 6, 3),
                      fmt=getattr(fwapi, fmt), src_frames=1501)
     assert g.cx.plan_kind() == 2

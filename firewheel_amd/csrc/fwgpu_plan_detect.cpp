@@ -49,7 +49,7 @@ VoiceDesc null_voice() {  // an unconnected mixer port: k_voice_control emits a 
 // Round 6: gain stages in FRONT of the filters (they see the source's silence flag: positional silence in k_voice_control), two
 // biquads in a row (an EQ cascade: the second one's recurrence runs on a wave of its own a tile behind the first's), the delay line
 // in front of the biquads.  Still refused: a gain BETWEEN two filters, B D B, width / clip in front of a filter (they need both
-// channels / a program stage in S1), a resampler, spatialiser or mono adapter with a filter.  A refused voice is not lost: the
+// channels / a program stage in S1), a resampler or spatialiser with a filter.  A refused voice is not lost: the
 // hybrid plan renders its longest acceptable prefix as a solo voice, the level executor the rest.
 struct VoiceWalk {
     bool ok = false;
@@ -78,8 +78,8 @@ VoiceWalk walk_voice_chain(const Plan& plan, const HostGraph& graph, const ConsC
         if (n.kind == K_MONO_TO_STEREO) {
             // sampler(0 -> 1) -> MonoToStereoNode (mono_to_stereo.rs:33-50): the reference's own adapter behind a ONE-output sampler —
             // channel 0 of its sample on both outputs, silence passed on: a voice whose every block is VB_MONO (src_kind 2;
-            // k_control.hip.h mono_adapt).  Dry / gain chains only.
-            if (n.n_in != 1 || n.n_out != 2 || n_fx || sp_voice) return w;
+            // k_control.hip.h mono_adapt).  Round 6: also in front of filters (k_chain fetches a mono source like any other: r_delta 0).
+            if (n.n_in != 1 || n.n_out != 2 || sp_voice) return w;
             const int sidx = n.in_src_node[0];
             if (sidx < 0 || n.in_src_port[0] != 0 || taken[sidx]) return w;
             const PlanNode& sn = plan.nodes[sidx];

@@ -158,9 +158,9 @@ void check_fused_common(const FusedView& fv, int K) {
         REQUIRE(vd.bq2_state < 0 || vd.bq_state >= 0, i, vd.bq2_state);
         REQUIRE((vd.fx_order == 0 || vd.fx_order == 1) && (vd.fx_order == 0 || (vd.bq_state >= 0 && vd.dl_state >= 0)), i, vd.fx_order);
         if (vd.bq2_state >= 0) touch(&fv.states[vd.bq2_state], sizeof(NodeState));
-        // 0 sampler, 1 SPEC resampler (program instantiation, no chain plan), 2 a one-output sampler behind MonoToStereo: no biquad / delay / spatialiser of its own
+        // 0 sampler, 1 SPEC resampler (program instantiation, no chain plan), 2 a one-output sampler behind MonoToStereo: no spatialiser of its own (round 6: filters are fine)
         REQUIRE(vd.src_kind == 0 || (vd.src_kind == 1 && fv.has_prog && !fv.fx_plan && fv.rs_table != nullptr) ||
-                    (vd.src_kind == 2 && vd.bq_state < 0 && vd.dl_state < 0 && vd.sp_ext_off < 0), i, vd.src_kind);
+                    (vd.src_kind == 2 && vd.sp_ext_off < 0), i, vd.src_kind);
         if (vd.bq_state >= 0) touch(&fv.states[vd.bq_state], sizeof(NodeState));
         if (vd.dl_state >= 0) touch(&fv.states[vd.dl_state], sizeof(NodeState));
     }

@@ -19,13 +19,19 @@ import scenarios
 from fwapi import LOOP_FULL, GpuEngine, HostOnlyEngine, OracleEngine
 
 # token: v volume, p pan, B biquad, D delay.  One string = one voice chain behind its sampler.
-ACCEPTED = ["vB", "pBv", "vBD", "vBDv", "vpBDp", "BB", "BBv", "vBB", "vBBDp", "BBD", "DB", "DBv", "vDB", "DBB", "pDBBv", "vD", "vDp"]
+# a leading m: a ONE-output sampler behind the reference's MonoToStereoNode (mono_to_stereo.rs:33-50) — round 6: also in front of filters
+ACCEPTED = ["vB", "pBv", "vBD", "vBDv", "vpBDp", "BB", "BBv", "vBB", "vBBDp", "BBD", "DB", "DBv", "vDB", "DBB", "pDBBv", "vD", "vDp", "mBD", "mvBBp", "mDBv"]
 REFUSED = ["BvB", "BDB", "DBD", "BBB", "DD", "wB", "cB", "vBvDv"]  # a gain between filters, three filters in other orders, width / clip in front
 
 
 def build_voice(e, shape, rng, delay_frames):
-    s = e.sampler(100.0)
+    mono = shape.startswith("m")
+    s = e.sampler(100.0, n_out=1) if mono else e.sampler(100.0)
     cur = s
+    if mono:
+        cur = e.add_node(fwapi.MONO_TO_STEREO, 1, 2)
+        e.connect(s, 0, cur, 0)
+        shape = shape[1:]
     nodes = dict(sampler=s, vols=[], pans=[], bqs=[], dls=[])
     for t in shape:
         if t == "v":

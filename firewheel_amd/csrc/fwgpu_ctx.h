@@ -174,7 +174,7 @@ struct PlanImage {
     bool fused = false;
     uint32_t generic_k = 1;  // blocks per generic-executor batch: kmax, capped by what the FIR history rings hold
     bool fused_fx = false;  // the fused plan's leaves run k_chain (biquad / delay in the voice chains)
-    int chain_nq = 1;       // k_chain tile size / 64 frames (bits 0..1); bit 2: some voice holds two biquads (the instantiation with a second recurrence stage)
+    int chain_nq = 1;       // k_chain tile size / 64 frames (bits 0..1); bit 2: some voice holds two biquads (the instantiation with a second recurrence stage); bit 3: some voice has a gain stage between two filters or a hard clip
     int n_voices = 0, n_leaves = 0, n_bus = 1, ramp_slots = 0;
     int n_groups = 0;  // k_chain workgroups (groups of consecutive leaves)
     DevBuf d_groups;
@@ -587,6 +587,7 @@ struct FusedBuild {
     bool has_prog = false;        // a width / hard-clip stage somewhere: the leaf kernel's program instantiation
     bool has_rs = false;          // a resampler-sourced voice somewhere
     bool has_sp = false;          // a voice whose last stage is a spatialiser somewhere
+    bool has_width = false;       // a stereo-width stage somewhere (the chain plan's kernels render none)
     bool has_fx = false;  // some chain holds a biquad / delay: the k_chain plan
     uint64_t min_delay = ~0ull;  // shortest delay line among the chains (frames)
     std::vector<int> covered;    // hybrid plan: plan indices of the nodes the fused kernels render (voice chains + their SumNode)

@@ -159,14 +159,20 @@ int launch_voice_control(hipStream_t s, const FusedView& fv, int K, uint32_t cmd
 }
 int launch_chain(hipStream_t s, const FusedView& fv, int K, uint32_t cmd_block0, int nq) {
     if (fv.n_groups <= 0 || K <= 0) return 0;
-    // nq: bits 0..1 = tile size / 64 frames, bit 2 = the plan holds a voice with two biquads (fwgpu_ctx.h chain_nq)
-    const bool bq2 = (nq & 4) != 0;
+    // nq: bits 0..1 = tile size / 64 frames, bit 2 = the plan holds a voice with two biquads, bit 3 = ... with a gain stage between two
+    // filters or a hard clip (fwgpu_ctx.h chain_nq)
+    const bool bq2 = (nq & 4) != 0, sites = (nq & 8) != 0;
     nq &= 3;
-    if (bq2) {
-        if (nq == 2) hipLaunchKernelGGL((k_chain<2, true>), dim3(fv.n_groups, 2), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
-        else hipLaunchKernelGGL((k_chain<1, true>), dim3(fv.n_groups, 2), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
-    } else if (nq == 2) hipLaunchKernelGGL((k_chain<2, false>), dim3(fv.n_groups, 2), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
-    else hipLaunchKernelGGL((k_chain<1, false>), dim3(fv.n_groups, 2), dim3(CH_THREADS), 0, s, fv, K, cmd_block0);
+    const dim3 grid(fv.n_groups, 2), block(CH_THREADS);
+#define FW_CHAIN_LAUNCH(N, B, S) hipLaunchKernelGGL((k_chain<N, B, S>), grid, block, 0, s, fv, K, cmd_block0)
+    if (nq == 2) {
+        if (bq2) { if (sites) FW_CHAIN_LAUNCH(2, true, true); else FW_CHAIN_LAUNCH(2, true, false); }
+        else { if (sites) FW_CHAIN_LAUNCH(2, false, true); else FW_CHAIN_LAUNCH(2, false, false); }
+    } else {
+        if (bq2) { if (sites) FW_CHAIN_LAUNCH(1, true, true); else FW_CHAIN_LAUNCH(1, true, false); }
+        else { if (sites) FW_CHAIN_LAUNCH(1, false, true); else FW_CHAIN_LAUNCH(1, false, false); }
+    }
+#undef FW_CHAIN_LAUNCH
     return (int)hipGetLastError();
 }
 int launch_bus_sum_ordered(hipStream_t s, const BusParts& bp, const uint8_t* const* sil, float* d_out, uint8_t* d_out_sil, size_t n_floats,

@@ -45,25 +45,26 @@ VoiceDesc null_voice() {  // an unconnected mixer port: k_voice_control emits a 
 
 // One voice chain, walked UPSTREAM from its last node to its source — the grammar of both fused plans:
 //   voice bank:  source -> {volume, pan, width, clip}* [-> spatialiser]            source = sampler | resampler | sampler(0->1) -> MonoToStereo
-//   chain plan:  sampler -> {volume, pan}{n_pre} -> FX -> {volume, pan, ...}*       FX = B | BB | D | BD | BBD | DB | DBB   (B biquad, D delay >= 64 frames)
-// Round 6: gain stages in FRONT of the filters (they see the source's silence flag: positional silence in k_voice_control), two
-// biquads in a row (an EQ cascade: the second one's recurrence runs on a wave of its own a tile behind the first's), the delay line
-// in front of the biquads.  Still refused: a gain BETWEEN two filters, B D B, width / clip in front of a filter (they need both
-// channels / a program stage in S1), a resampler or spatialiser with a filter.  A refused voice is not lost: the
-// hybrid plan renders its longest acceptable prefix as a solo voice, the level executor the rest.
+//   chain plan:  sampler -> G* -> F1 [-> G* -> F2 [-> G* -> F3]] -> G*     G = volume | pan | hard clip (<= 3 in all), F1 F2 F3 = B | BB | D | BD | BBD | DB | DBB
+// (B biquad, D delay >= 64 frames).  Round 6: gain stages anywhere around and between the filters (the ones in front of the first see
+// the source's silence flag, a muted one between two filters hands the next filter a cleared buffer: positional silence in
+// k_voice_control), two biquads (an EQ cascade: the second one's recurrence runs on a wave of its own), the delay line in front of
+// the biquads, hard clips at every position.  Still refused: B D B and more than three filters, a stereo width in a voice with a
+// filter (it needs both channels; k_chain's workgroups own one), a resampler or spatialiser with a filter.  A refused voice is not lost:
+// the hybrid plan renders its longest acceptable prefix as a solo voice, the level executor the rest.
 struct VoiceWalk {
     bool ok = false;
     VoiceDesc vd;
     uint32_t prog_bits = 0;
     int nodes[FW_MAX_STAGES + 6], n_nodes = 0;  // plan indices, the source first
-    bool prog = false, rs = false, fx = false, sp = false;
+    bool prog = false, rs = false, fx = false, sp = false, width = false;
     uint64_t delay = ~0ull;
 };
 VoiceWalk walk_voice_chain(const Plan& plan, const HostGraph& graph, const ConsCounts& cons, uint32_t mbf, const std::vector<char>& taken, int cur) {
     VoiceWalk w;
     w.vd = null_voice();
     int chain[FW_MAX_STAGES], n_chain = 0;  // gain-like stages in walk order (nearest the mixer first)
-    int n_pre = 0;
+    int seg_cnt[4] = {0, 0, 0, 0};  // gain-like stages met with 0 / 1 / 2 / 3 filters already behind us on the walk (= downstream of them)
     int fxn[3], n_fx = 0;  // biquads / the delay in walk order
     char fxk[4] = {0, 0, 0, 0};
     bool sp_voice = false;
@@ -91,10 +92,8 @@ VoiceWalk walk_voice_chain(const Plan& plan, const HostGraph& graph, const ConsC
         if (n.n_in != 2 || n.n_out != 2) return w;
         if (n.kind == K_VOLUME || n.kind == K_PAN || n.kind == K_WIDTH || n.kind == K_HARD_CLIP) {
             if (n_chain >= FW_MAX_STAGES - 1) return w;
-            if (n_fx) {  // in FRONT of the filters: k_chain's S1 multiplies per channel, nothing else
-                if (n.kind != K_VOLUME && n.kind != K_PAN) return w;
-                n_pre++;
-            }
+            w.width = w.width || n.kind == K_WIDTH;
+            seg_cnt[n_fx]++;
             chain[n_chain++] = cur;
         } else if (n.kind == K_SPATIAL) {
             // a spatialiser as the LAST node of a dry voice (the first one met walking up from the mixer); its 64-frame history needs
@@ -103,7 +102,7 @@ VoiceWalk walk_voice_chain(const Plan& plan, const HostGraph& graph, const ConsC
             sp_voice = true;
             chain[n_chain++] = cur;
         } else if (n.kind == K_DELAY || n.kind == K_BIQUAD) {
-            if (n_pre || n_fx >= 3 || sp_voice) return w;  // (a gain between two filters: refused)
+            if (n_fx >= 3 || sp_voice) return w;
             if (n.kind == K_DELAY) {
                 if (graph.nodes[n.slot].init.loop_end < 64) return w;  // shorter than one k_chain tile
                 w.delay = graph.nodes[n.slot].init.loop_end;
@@ -136,6 +135,7 @@ VoiceWalk walk_voice_chain(const Plan& plan, const HostGraph& graph, const ConsC
         else if (q == "DBB") dl = sn[0], bq = sn[1], bq2 = sn[2], order = 1;
         else return w;
     }
+    if (n_fx && w.width) return w;  // (a stereo width needs both channels of the voice: a chain-plan workgroup owns one)
     const bool rs = plan.nodes[cur].kind == K_RESAMPLER;
     if (rs && (n_fx || sp_voice)) return w;  // (the chain plan's source fetch is the sampler's; a spatialiser voice is a dry sampler voice)
     w.vd.sp_ext_off = sp_voice ? 0 : -1;  // the node's ext slice: filled in by the plan build (the node may be activated by this very plan)
@@ -147,7 +147,9 @@ VoiceWalk walk_voice_chain(const Plan& plan, const HostGraph& graph, const ConsC
     w.vd.bq2_state = bq2 >= 0 ? (int)plan.nodes[bq2].slot : -1;
     w.vd.dl_state = dl >= 0 ? (int)plan.nodes[dl].slot : -1;
     w.vd.fx_order = order;
-    w.vd.n_pre = n_pre;
+    // walk segment s (s filters downstream of the stage) is schedule position n_fx - s: 0 = in front of the first filter ... n_fx = behind the last
+    w.vd.n_pre = n_fx ? seg_cnt[n_fx] : 0;
+    w.vd.n_mid = (n_fx >= 2 ? seg_cnt[n_fx - 1] : 0) | ((n_fx >= 3 ? seg_cnt[n_fx - 2] : 0) << 8);
     w.fx = n_fx != 0;
     w.rs = rs;
     w.vd.n_stages = n_chain;
@@ -276,6 +278,7 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
             fb.has_prog = fb.has_prog || w.prog || w.rs;  // (the polyphase fetch lives in the leaf kernel's program instantiation)
             fb.has_rs = fb.has_rs || w.rs;
             fb.has_sp = fb.has_sp || w.sp;
+            fb.has_width = fb.has_width || w.width;
             fb.min_delay = std::min(fb.min_delay, w.delay);
             fb.progs.push_back(w.prog_bits);
             fb.max_stages = std::max(fb.max_stages, w.vd.n_stages);
@@ -349,7 +352,8 @@ bool detect_fused(const Plan& plan, const HostGraph& graph, uint32_t mbf, FusedB
     fb.root_buf[1] = rb + 1;
     fb.n_bus = next_bus;
     if (fb.has_fx) {  // k_chain: whole tiles, one workgroup per leaf of <= 32 voices, gain stages only behind the filter / delay
-        if (mbf % 64 != 0 || fb.has_prog || fb.max_stages > FW_CHAIN_STAGES - 1) return false;
+        // (k_chain's stages: gains and hard clips per channel; no width, no resampler fetch, no spatialiser)
+        if (mbf % 64 != 0 || fb.has_width || fb.has_rs || fb.has_sp || fb.max_stages > FW_CHAIN_STAGES - 1) return false;
         for (const LeafDesc& l : fb.leaves)
             if (l.ports > 32) return false;
     }
@@ -370,7 +374,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         std::vector<VoiceDesc> voices;
         std::vector<uint32_t> progs;
         std::vector<int> nodes;
-        bool prog = false, rs = false, fx = false, sp = false;
+        bool prog = false, rs = false, fx = false, sp = false, width = false;
         int stages = 0, real = 0;
         uint64_t min_delay = ~0ull;
         bool split = false;  // only the leading ports are voices: the SumNode stays on the levels as a continuation
@@ -381,6 +385,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
     auto walk_voice = [&](int cur) -> Walk { return walk_voice_chain(plan, graph, cons, mbf, taken, cur); };
     auto take = [&](Bank& bk, const Walk& w) {
         bk.sp = bk.sp || w.sp;
+        bk.width = bk.width || w.width;
         bk.prog = bk.prog || w.prog;
         bk.fx = bk.fx || w.fx;
         bk.rs = bk.rs || w.rs;
@@ -437,7 +442,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
         fx_mode = false;
     }
     auto keeps = [&](const Bank& bk, bool fxm) {
-        return fxm ? (!bk.prog && !bk.rs && !bk.sp && bk.stages <= FW_CHAIN_STAGES - 1 && (int)bk.voices.size() <= 32) : !bk.fx;
+        return fxm ? (!bk.width && !bk.rs && !bk.sp && bk.stages <= FW_CHAIN_STAGES - 1 && (int)bk.voices.size() <= 32) : !bk.fx;
     };
     if (fx_mode) {  // no bank with a filter survives the chain plan's rules: the dry banks are voice-bank banks, all of them
         bool any_fx = false;
@@ -487,7 +492,7 @@ bool detect_hybrid(const Plan& plan, const HostGraph& graph, uint32_t mbf, Fused
                 const PlanNode& n = plan.nodes[nx];
                 if (n.is_graph_io || n.n_in != 2 || n.n_out != 2) break;
                 if (n.in_src_node[0] != end || n.in_src_port[0] != 0 || n.in_src_node[1] != end || n.in_src_port[1] != 1) break;
-                const bool gain = n.kind == K_VOLUME || n.kind == K_PAN;
+                const bool gain = n.kind == K_VOLUME || n.kind == K_PAN || (fx_mode && n.kind == K_HARD_CLIP);  // (k_chain clips per channel)
                 const bool progk = n.kind == K_WIDTH || n.kind == K_HARD_CLIP || n.kind == K_SPATIAL;
                 const bool fxk = n.kind == K_BIQUAD || n.kind == K_DELAY;
                 if (!(gain || (progk && !fx_mode) || (fxk && fx_mode))) break;

@@ -864,8 +864,12 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
         if (const char* e = getenv("FWGPU_CHAIN_NQ")) {  // experiments: force the smaller tile
             if (atoi(e) == 1) P.chain_nq = 1;
         }
-        for (const VoiceDesc& vd : fb.voices)  // an EQ cascade somewhere: the instantiation with the second recurrence stage (bit 2)
-            if (vd.bq2_state >= 0) P.chain_nq |= 4;
+        for (const VoiceDesc& vd : fb.voices) {  // an EQ cascade somewhere: the instantiation with the second recurrence stage (bit 2); a gain
+            if (vd.bq2_state >= 0) P.chain_nq |= 4;  // stage between two filters or a hard clip: the one with the five-site stage logic (bit 3)
+            if (vd.sampler_state >= 0 && vd.n_mid) P.chain_nq |= 8;
+            for (int j = 0; j < vd.n_stages && vd.sampler_state >= 0; ++j)
+                if (vd.stage_kind[j] == K_HARD_CLIP) P.chain_nq |= 8;
+        }
         P.n_voices = (int)fb.voices.size();
         P.n_leaves = (int)fb.leaves.size();
         P.n_bus = fb.n_bus;
@@ -1023,8 +1027,12 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             if (const char* e = getenv("FWGPU_CHAIN_NQ")) {
                 if (atoi(e) == 1) P.chain_nq = 1;
             }
-            for (const VoiceDesc& vd : hb.voices)
+            for (const VoiceDesc& vd : hb.voices) {
                 if (vd.bq2_state >= 0) P.chain_nq |= 4;
+                if (vd.sampler_state >= 0 && vd.n_mid) P.chain_nq |= 8;
+                for (int j = 0; j < vd.n_stages && vd.sampler_state >= 0; ++j)
+                    if (vd.stage_kind[j] == K_HARD_CLIP) P.chain_nq |= 8;
+            }
             P.generic_k = std::min<uint32_t>(P.generic_k, CH_FAST_KMAX);
         }
         P.n_tail = 0;

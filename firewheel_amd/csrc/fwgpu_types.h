@@ -123,7 +123,7 @@ enum : uint32_t {
 };
 
 // static per voice chain.  Voice-bank plan: source -> [volume|pan|width|hard clip|spatialiser]* -> leaf sum port.  Chain plan (round 6
-// grammar): sampler -> [volume|pan]{n_pre} -> FX -> [volume|pan]* -> leaf sum port with FX one of
+// grammar): sampler -> G* -> F1 [-> G* -> F2 [-> G* -> F3]] -> G* -> leaf sum port, G = volume | pan | hard clip (<= 3 in all), F1 F2 F3 one of
 //   biquad, biquad biquad, delay, biquad delay, biquad biquad delay  (fx_order 0: filters first)   or
 //   delay biquad, delay biquad biquad                                (fx_order 1: the delay line first)
 struct VoiceDesc {
@@ -136,10 +136,11 @@ struct VoiceDesc {
     int src_kind;                      // 0 = SamplerNode, 1 = SPEC resampling source (sampler_state = its state; no gain of its own),
                                        // 2 = a ONE-output SamplerNode behind a MonoToStereoNode: channel 0 on both outputs (round 5)
     int sp_ext_off;                    // a SPEC spatialiser as the last stage: ext-pool offset of its SP_HIST-frame mono history; -1 = none
-    int n_pre;                         // chain plan: gain stages in FRONT of the biquad / delay (0 for a dry voice)
-    int bq2_state;                     // chain plan: a second biquad right behind the first (an EQ cascade), -1 = none
+    int n_pre;                         // chain plan: gain stages in FRONT of the first filter (0 for a dry voice)
+    int bq2_state;                     // chain plan: a second biquad behind the first (an EQ cascade), -1 = none
     int fx_order;                      // chain plan: 0 = biquad(s) then delay, 1 = delay then biquad(s)
-    int pad_;
+    int n_mid;                         // chain plan: gain stages BETWEEN the filters: bits 0..7 between the first and the second, 8..15 between
+                                       //   the second and the third (the stages behind n_pre, in schedule order)
 };
 static_assert(sizeof(VoiceDesc) == 80, "VoiceDesc layout");
 

@@ -119,7 +119,10 @@ __device__ __forceinline__ void chain_mix_uniform(const v4f (&x)[32], uint32_t s
     }
 }
 
-template <int NQ, bool BQ2>
+// SITES: some voice of the plan has a gain stage BETWEEN two filters or a hard clip (the instantiation with the five-site stage logic; the
+// other one knows "in front of the first filter" and "behind the last", multiplications only, and keeps its registers: the site tables cost
+// the one-biquad kernel 28 bytes of scratch per lane when they were unconditional)
+template <int NQ, bool BQ2, bool SITES>
 __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint32_t cmd_block0) {
     constexpr int TT = 64 * NQ;        // frames per tile
     constexpr int PITCH = TT + 4;      // floats per voice row: + 4 -> the 32 S2 lanes' b128 reads are conflict-free
@@ -203,9 +206,45 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         z1 = bq2_st[2];
         z2 = bq2_st[3];
     }  // (made visible to the workers by the __syncthreads_or below)
-    const int n_pre = active ? vd.n_pre : 0;                         // gain stages in front of the filters (multiplied in by S1)
     const bool dl_first = has_dl && vd.fx_order == 1;                // the delay line in front of the biquads: S1 does its read-modify-write
-    const bool any_pre = __syncthreads_or(n_pre > 0 ? 1 : 0) != 0;
+    // ---- where each gain-like stage of the voice is applied (round 6: stages in front of, between and behind the filters).  Five sites:
+    //   A  S1, on the source               B  S1, behind a delay-first voice's delay line      C  S1b, in front of the second biquad
+    //   D  S3a, in front of the delay line  E  S3a, last (behind every filter)
+    // A stage's position among the filters (VoiceDesc::n_pre / n_mid) and the voice's filter order give its site; its kind (gain or hard
+    // clip) comes from the voice's stage program.  Sites a wave's voices do not use cost it nothing (wave-uniform masks).
+    enum { SITE_A = 0, SITE_B = 1, SITE_C = 2, SITE_D = 3, SITE_E = 4 };
+    const int n_pre = active ? vd.n_pre : 0;
+    uint32_t site_bits = 0u;  // SITES: 3 bits of site + 1 bit "hard clip" per stage (ONE register: per-stage arrays spilled)
+    uint32_t my_sites = 0u;
+    if constexpr (SITES) {
+        const int n_mid1 = active ? (vd.n_mid & 0xff) : 0, n_mid2 = active ? ((vd.n_mid >> 8) & 0xff) : 0;
+        const uint32_t prog = active ? fv.progs[voice] : 0u;
+        const bool two_bq = active && vd.bq2_state >= 0;
+#pragma unroll
+        for (int j = 0; j < FW_CHAIN_STAGES - 1; ++j) {
+            const int posn = j < n_pre ? 0 : (j < n_pre + n_mid1 ? 1 : (j < n_pre + n_mid1 + n_mid2 ? 2 : 3));
+            int st = SITE_E;
+            if (posn == 0) st = (has_bq || has_dl) ? SITE_A : SITE_E;  // (a dry voice of a chain plan: everything at the end, as ever)
+            else if (posn == 1) st = dl_first ? SITE_B : (two_bq ? SITE_C : SITE_D);
+            else if (posn == 2) st = dl_first ? SITE_C : SITE_D;
+            const uint32_t clip = ((prog >> (4 * j)) & 15u) == SK_CLIP ? 8u : 0u;
+            site_bits |= ((uint32_t)st | clip) << (4 * j);
+            if (active && j < vd.n_stages) my_sites |= (1u << st) | (clip ? 32u : 0u);
+        }
+    } else {
+        my_sites = n_pre > 0 ? 1u : 0u;
+    }
+    auto stage_site = [&](const int j) -> int {
+        if constexpr (SITES) return (int)((site_bits >> (4 * j)) & 7u);
+        else return j < n_pre ? SITE_A : SITE_E;
+    };
+    auto stage_clip = [&](const int j) -> bool {
+        if constexpr (SITES) return ((site_bits >> (4 * j)) & 8u) != 0u;
+        else return false;
+    };
+    const bool any_A = __syncthreads_or((int)(my_sites & 1u)) != 0;
+    const bool any_B = SITES && __syncthreads_or((int)(my_sites & 2u)) != 0, any_C = SITES && __syncthreads_or((int)(my_sites & 4u)) != 0,
+               any_D = SITES && __syncthreads_or((int)(my_sites & 8u)) != 0, any_clip = SITES && __syncthreads_or((int)(my_sites & 32u)) != 0;
     const bool any_dlf = __syncthreads_or(dl_first ? 1 : 0) != 0;  // (a workgroup without delay-first voices carries none of their code path)
     uint32_t D = 1, pos = cs.pos;
     float fb = cs.fb, mix = cs.mix, dry = cs.dry;
@@ -306,21 +345,49 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     inf0.flags = inf1.flags = inf2.flags = inf3.flags = inf4.flags = VB_SRC_ZERO | VB_SIMPLE;
 #pragma unroll
     for (int j = 0; j < FW_CHAIN_STAGES - 1; ++j) inf0.g[j] = inf1.g[j] = inf2.g[j] = inf3.g[j] = inf4.g[j] = 1.f;
+    // the general loop's form of a site: the stages of site X on quad jq of tile (block kk, tile tt) — per-block constants from the tile's
+    // ChainInfo, per-frame ramps from the ramp rows, a clip's threshold, or the sentinel of a muted stage between two filters (-> +0.0)
+    auto gsite1 = [&](const int X, v4f x, const ChainInfo& I, const int kk, const int tt, const int jq) -> v4f {
+        const uint32_t rbits = I.flags >> VB_RAMP_SHIFT;
+#pragma unroll
+        for (int g = 1; g < FW_CHAIN_STAGES; ++g) {
+            if (g >= fv.n_gain_stages) break;
+            if (stage_site(g - 1) != X) continue;
+            const float gcv = I.g[g - 1];
+            if ((rbits >> (2 * g + ch)) & 1u) {
+                const int f0 = tt * TT + LF * q + 4 * jq;
+                const float* rb = fv.ramps + ((size_t)kk * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
+                x = x * *(const v4f*)(rb + (size_t)(2 * g + ch) * fv.stride);
+            } else if (SITES && gcv < 0.f) {
+                x = splat(0.f);
+            } else if (stage_clip(g - 1)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = clipf(x[e], gcv);
+            } else {
+                x = x * gcv;
+            }
+        }
+        return x;
+    };
     // S1b (two-biquad instantiation), worker lanes, tile s-2: the second biquad's feed-forward sums on the first one's output, in place:
     //   ff[n] = ((c0*x[n]) + (c1*x[n-1])) + (c2*x[n-2]), unfused (k_generic.hip.h K_BIQUAD).  x[n-1], x[n-2] of a lane's first frame are
     // the two floats in front of it in the row (lane q = 0: the tile before's last two, bq2_u).  A voice's 16 lanes sit in ONE wave and
     // every lane reads before any lane writes (DS operations of a wave retire in order): no barrier inside the stage.
-    auto ff2_stage = [&](const int t_tile, const bool real) {
+    auto ff2_stage = [&](const int t_tile, const bool real, auto&& pre) {  // pre(x, j): the gain stages between the two biquads, on quad j
         float* const r2 = &tile[CH_BUF(t_tile)][v][LF * q];
-        const v2f hin = *(const v2f*)(r2 - (q ? 2 : 0));  // (lane 0: a valid address, the value is not used)
-        float h1 = q ? hin[1] : bq2_u[v][0], h2 = q ? hin[0] : bq2_u[v][1];
+        // (the neighbour's last QUAD, through the same stages between the biquads as this lane's own: the second filter's x[n-1], x[n-2]
+        //  are ITS inputs, behind those stages — what bq2_u holds, too; lane 0: a valid address, the value is not used)
+        v4f hq = *(const v4f*)(r2 - (q ? 4 : 0));
+        pre(hq, q ? -1 : 0);  // (quad index -1: the frames in front of this lane's; lane 0's value is not used — and must not be fetched from in front of a ramp row)
+        float h1 = q ? hq[3] : bq2_u[v][0], h2 = q ? hq[2] : bq2_u[v][1];
         // the neighbour's two floats are IN REGISTERS before any store of this stage is issued: lane q - 1's last quad overwrites them, and to
         // the compiler — which reasons per lane — that store and this load touch different addresses and may change places
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h1), "+v"(h2) : : "memory");
         const bool on = real && has_bq2;
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {  // (quad by quad: the worker lanes have no registers to spare for the whole tile slice)
-            const v4f x = *(const v4f*)(r2 + 4 * j);
+            v4f x = *(const v4f*)(r2 + 4 * j);
+            pre(x, j);
             const v4f x1v = (v4f){h1, x[0], x[1], x[2]}, x2v = (v4f){h2, h1, x[0], x[1]};
             const v4f ff = ((x * c0) + (x1v * c1)) + (x2v * c2);
             h1 = x[3];
@@ -439,14 +506,39 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         const uint32_t vflags = fv.refs[ref_index(voice, 0, fv.ref_kgroups)].flags_gset & 0xffu;  // per-voice bits only are used
         const GainSet* gsp = &fv.gsets[(size_t)voice * FW_GSETS];
         const float g0f = gsp->g[0][ch];
-        // stage j + 1's constant gain goes in front of the filters (S1) or behind them (S3a); the other place multiplies by 1.0f — exact
-        float gpre[FW_CHAIN_STAGES - 1], gpost[FW_CHAIN_STAGES - 1];
+        // stage j + 1's constant: a gain (the sentinel -1.0f from a muted stage between two filters: a cleared buffer) or a clip threshold
+        float gc[FW_CHAIN_STAGES - 1];
+        bool my_mute = false;
 #pragma unroll
         for (int j = 0; j < FW_CHAIN_STAGES - 1; ++j) {
-            const float gj = gsp->g[j + 1][ch];
-            gpre[j] = j < n_pre ? gj : 1.f;
-            gpost[j] = j < n_pre ? 1.f : gj;
+            gc[j] = gsp->g[j + 1][ch];
+            my_mute = my_mute || (SITES && active && j < vd.n_stages && gc[j] < 0.f);
         }
+        const bool wave_mute = SITES && __ballot(my_mute) != 0ull;
+        // the stages of site X on a quad: every lane multiplies by its stage's gain there and by 1.0f (exact) elsewhere; clips and mutes
+        // are per-lane selects the wave only pays for when one of its voices has one
+        auto ssite1 = [&](const int X, v4f x) -> v4f {
+#pragma unroll
+            for (int g = 0; g < FW_CHAIN_STAGES - 1; ++g) {
+                if (g + 1 >= fv.n_gain_stages) break;
+                const bool here = stage_site(g) == X;
+                const float gm = here ? gc[g] : 1.f;
+                v4f y = x * gm;
+                if (any_clip) {
+                    v4f c;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c[e] = clipf(x[e], gc[g]);
+                    y = (here && stage_clip(g)) ? c : y;
+                }
+                if (wave_mute) y = (here && gc[g] < 0.f) ? splat(0.f) : y;
+                x = y;
+            }
+            return x;
+        };
+        auto ssite = [&](const int X, v4f(&x)[NQ]) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) x[j] = ssite1(X, x[j]);
+        };
         const bool src_zero = (vflags & VB_SRC_ZERO) != 0, silent = (vflags & VB_SILENT) != 0;
         float* const dummy = fv.chain_dummy + (size_t)threadIdx.x * (4 * NQ);
         const bool ringed = active && has_dl;  // this lane's voice has a delay line
@@ -547,12 +639,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                 }
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) x[j] = src_zero ? splat(0.f) : xs[j] * g0f;  // sampler.rs:530-533
-                if (any_pre) {  // gain stages in front of the filters: one rounding per stage, in schedule order (volume.rs:123-126)
+                if (any_A) {  // gain stages in front of the filters: one rounding per stage, in schedule order (volume.rs:123-126)
+                    ssite(SITE_A, x);
 #pragma unroll
-                    for (int g = 0; g < FW_CHAIN_STAGES - 1; ++g) {
-#pragma unroll
-                        for (int j = 0; j < NQ; ++j) x[j] = src_zero ? splat(0.f) : x[j] * gpre[g];
-                    }
+                    for (int j = 0; j < NQ; ++j) x[j] = src_zero ? splat(0.f) : x[j];
                 }
                 if (any_dlf) {
                     // delay-first voices (round 6): the ring slots of tile s were requested two steps ago into THIS register set (issue_ring
@@ -605,6 +695,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                         pos_c += TT;
                         if (pos_c >= Dv) pos_c -= Dv;
                     }
+                    if (any_B) ssite(SITE_B, x);
                 }
                 float* row = &tile[CH_BUF(s)][v][LF * q];
                 const bool q15 = q == 15;
@@ -623,7 +714,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             }
             issue_src(xs, s + 2);
             CH_TRACE(2);
-            if constexpr (BQ2) ff2_stage(s - 2, s >= 2 && s - 2 < n_tiles);
+            if constexpr (BQ2) ff2_stage(s - 2, s >= 2 && s - 2 < n_tiles, [&](v4f& xq, int) {
+                if (any_C) xq = ssite1(SITE_C, xq);
+            });
             // ---- S3a on tile s-LAG3
             {
                 uint32_t sl[NQ];
@@ -653,17 +746,14 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
                     v4f y = yv[j];
+                    if (any_D) y = ssite1(SITE_D, y);  // gain stages between the last biquad and the delay line
                     const v4f nv = y + (rg[j] * fb);  // ring[p] = x + (d*fb)
                     float* sp = (v3 && sl[j] + 4u <= Dv) ? ring + sl[j] : dummy + 4 * j;
                     asm volatile("" : "+v"(sp));
                     *(v4f_u __attribute__((address_space(1)))*)(uint64_t)sp = nv;
                     const v4f wet = (y * dry) + (rg[j] * mix);  // out = (x*dry) + (d*mix)
                     y = ring3 ? wet : y;                        // no delay line behind the filters: untouched
-#pragma unroll
-                    for (int g = 0; g < FW_CHAIN_STAGES - 1; ++g) {
-                        if (g + 1 >= fv.n_gain_stages) break;
-                        y = y * gpost[g];
-                    }
+                    y = ssite1(SITE_E, y);
                     if (silent) y = splat(0.f);  // muted gain stage: cleared buffer
                     *(v4f*)(row + 4 * j) = y;
                     if (__ballot(straddle) != 0ull) {
@@ -764,12 +854,6 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                             const float* rb = fv.ramps + ((size_t)k1 * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
                             const v4f gv = (rb0 >> ch) & 1u ? *(const v4f*)(rb + (size_t)ch * fv.stride) : splat(g0c);
                             x[j] = x[j] * gv;  // sampler.rs:530-533
-#pragma unroll
-                            for (int g = 1; g < FW_CHAIN_STAGES; ++g) {  // the gain stages in front of the filters, ramps included
-                                if (g > n_pre) break;
-                                const v4f gp = (rb0 >> (2 * g + ch)) & 1u ? *(const v4f*)(rb + (size_t)(2 * g + ch) * fv.stride) : splat(d->g[g][ch]);
-                                x[j] = x[j] * gp;
-                            }
                         }
                     }
                 } else if (inf0.flags & VB_SRC_ZERO) {
@@ -778,12 +862,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                 } else {
 #pragma unroll
                     for (int j = 0; j < NQ; ++j) x[j] = (cur_c16 ? chain_cvt16(xs[j], cur_c16, ch) : xs[j]) * g0;
+                }
+                if (any_A && !(inf0.flags & VB_SRC_ZERO)) {  // the stages in front of the first filter (a cleared source stays cleared)
 #pragma unroll
-                    for (int g = 0; g < FW_CHAIN_STAGES - 1; ++g) {  // constant gains in front of the filters
-                        if (g >= n_pre) break;
-#pragma unroll
-                        for (int j = 0; j < NQ; ++j) x[j] = x[j] * inf0.g[g];
-                    }
+                    for (int j = 0; j < NQ; ++j) x[j] = gsite1(SITE_A, x[j], inf0, k1, t1, j);
                 }
                 if (dl_first && dl_on) {  // the delay line in front of the biquads: its read-modify-write on the tile S1 has just made
                     if (t1 == 0 && fv.n_cmds) {
@@ -811,6 +893,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     }
                     pos += TT;
                     if (pos >= D) pos -= D;
+                }
+                if (any_B) {  // the stages between a delay-first voice's delay line and its first biquad
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) x[j] = gsite1(SITE_B, x[j], inf0, k1, t1, j);
                 }
                 float* row = &tile[CH_BUF(s)][v][LF * q];
                 if (has_bq) {
@@ -847,7 +933,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                         c2 = co.b2;
                     }
                 }
-                ff2_stage(s - 2, real && active);
+                ff2_stage(s - 2, real && active, [&](v4f& xq, int jq) {
+                    // (inf2: the block of tile s - 2.  Real tiles only: behind the call's last tile kf is one past its last block, and a
+                    //  stale ramp bit would fetch a ramp row behind the table — a memory fault at one block per call, found by the fuzz)
+                    if (any_C && real && active) xq = gsite1(SITE_C, xq, inf2, kf, tf, jq);
+                });
                 if (real && ++tf == tpb) {
                     tf = 0;
                     ++kf;
@@ -876,7 +966,6 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                 }
                 float* row = &tile[CH_BUF(s - LAG3)][v][LF * q];
                 const ChainInfo& inf = BQ2 ? inf4 : inf2;  // the block of the tile S3a works on
-                const uint32_t rbits = inf.flags >> VB_RAMP_SHIFT;
 #ifdef FW_CHAIN_TRACE
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(yv[j]));
@@ -885,6 +974,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
                     v4f y = yv[j];
+                    if (any_D) y = gsite1(SITE_D, y, inf, k3, t3, j);  // gain stages between the last biquad and the delay line
                     if (dl3) {
                         const v4f nv = y + (rg[j] * fb);  // ring[p] = x + (d*fb)
                         const uint32_t sl = ring_slot(j);
@@ -906,22 +996,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
                     }
                     if (inf.flags & VB_SILENT) {  // muted gain stage / silent chain: cleared buffer
                         y = splat(0.f);
-                    } else if (rbits == 0) {
-#pragma unroll
-                        for (int g = 0; g < FW_CHAIN_STAGES - 1; ++g) {
-                            if (g + 1 >= fv.n_gain_stages) break;
-                            y = y * (g >= n_pre ? inf.g[g] : 1.f);  // (the stages in front of the filters went in with S1; x 1.0f is exact)
-                        }
                     } else {
-                        const int f0 = t3 * TT + LF * q + 4 * j;
-                        const float* rb = fv.ramps + ((size_t)k3 * fv.n_voices + voice) * (size_t)fv.ramp_slots * (size_t)fv.stride + f0;
-#pragma unroll
-                        for (int g = 1; g < FW_CHAIN_STAGES; ++g) {
-                            if (g >= fv.n_gain_stages) break;
-                            if (g <= n_pre) continue;
-                            const v4f gv = (rbits >> (2 * g + ch)) & 1u ? *(const v4f*)(rb + (size_t)(2 * g + ch) * fv.stride) : splat(inf.g[g - 1]);
-                            y = y * gv;
-                        }
+                        y = gsite1(SITE_E, y, inf, k3, t3, j);
                     }
                     *(v4f*)(row + 4 * j) = y;
                 }

@@ -675,6 +675,12 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
     const int frames = fv.frames;
     const bool simple_frames = (frames & 3) == 0;
     const bool fx = vd.bq_state >= 0 || vd.dl_state >= 0;  // the voice has a biquad / delay: silence does not pass it
+    // (round 6) the stage indices in front of which a filter sits: the first filter, and the ones behind gain stages between filters.  A
+    // filter never reports silence (SPEC nodes: out mask 0): the flag ends there.  Stages in front of the FIRST filter see the source's
+    // flag (what reaches that filter cleared is VB_SRC_ZERO); a stage BETWEEN two filters that mutes hands the next filter a cleared
+    // buffer — its gain goes out as the sentinel -1.0f, which k_chain turns into +0.0 (x * 1e-6 would not be, and x * 0.0f has x's sign)
+    const int fb1 = fx ? vd.n_pre : 0x7fff, fb2 = fx && (vd.n_mid & 0xff) ? fb1 + (vd.n_mid & 0xff) : 0x7fff,
+              fb3 = fx && ((vd.n_mid >> 8) & 0xff) ? (fb2 == 0x7fff ? fb1 : fb2) + ((vd.n_mid >> 8) & 0xff) : 0x7fff;
     const bool fxp = fv.fx_plan != 0;                        // chain plan: k_chain's descriptor conventions for EVERY voice
     if (vd.sampler_state < 0) {
         // a null voice = an unconnected port of a leaf SumNode: the cleared, silent-flagged buffer of schedule.rs:310-313
@@ -1051,13 +1057,16 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         // ---- chain stages in schedule order
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
-            if (fx && j == vd.n_pre) {
+            if (fx && j == fb1) {
                 pre_silent = silent;
                 silent = false;
             }
+            if (j == fb2 || j == fb3) silent = false;  // (another filter: whatever a stage in front of it muted, it runs on and flags nothing)
             if (j >= vd.n_stages) break;
             StageRegs& r = st[j];
             float* rb = ramp_base + (size_t)(j + 1) * 2 * fv.stride;
+            const bool between = fx && j >= fb1 && j < (fb3 != 0x7fff ? fb3 : (fb2 != 0x7fff ? fb2 : fb1));  // a stage between two filters
+            if (between && silent) d.g[j + 1][0] = d.g[j + 1][1] = -1.0f;  // (behind a muted stage of its segment: cleared in, cleared out)
             if (vd.stage_kind[j] == K_VOLUME) {  // nodes/volume.rs:84-145
                 if (silent) {
                     smoother_reset(r.s0, r.p0);
@@ -1065,6 +1074,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                     GainRun run = smoother_begin(r.s0, r.p0, frames);
                     if (!smoother_is_smoothing(r.s0) && run.c < 0.00001f) {
                         silent = true;
+                        if (between) d.g[j + 1][0] = d.g[j + 1][1] = -1.0f;
                     } else {
                         if (run.ramp && ramp_emit(run, frames, rb, rb + fv.stride, lane)) {
                             d.flags |= 3u << (VB_RAMP_SHIFT + 2 * (j + 1));
@@ -1120,7 +1130,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                     d.g[j + 1][0] = d.g[j + 1][1] = rw.c;
                 }
             } else {  // K_HARD_CLIP (hard_clip.rs:51-95): no state; a silent (both-channel) input is zero-filled and stays flagged
-                d.g[j + 1][0] = d.g[j + 1][1] = r.p0;
+                if (!(between && silent)) d.g[j + 1][0] = d.g[j + 1][1] = r.p0;
             }
         }
         CTL_T(11);
@@ -1171,14 +1181,19 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
         }
         bool sil = upstream_silent;  // what the stage at hand is handed; a filter voice's flag ends at its first filter (pre_sil keeps it)
         bool pre_sil = false;
+        bool mid_sil[FW_MAX_STAGES - 1];  // stage j sits between two filters and hands on a cleared buffer (muted itself, or behind a muted one)
+#pragma unroll
+        for (int j = 0; j < FW_MAX_STAGES - 1; ++j) mid_sil[j] = false;
         bool sp_zero = false;  // steady with a spatialiser whose input is cleared zeros (source stopped / muted upstream)
 #pragma unroll
         for (int j = 0; j < FW_MAX_STAGES - 1; ++j) {
-            if (fx && j == vd.n_pre) {
+            if (fx && j == fb1) {
                 pre_sil = sil;
                 sil = false;
             }
+            if (j == fb2 || j == fb3) sil = false;
             if (j >= vd.n_stages || !steady) break;
+            mid_sil[j] = fx && j >= fb1 && j < (fb3 != 0x7fff ? fb3 : (fb2 != 0x7fff ? fb2 : fb1)) && sil;  // (cleared in: cleared out)
             const StageRegs& r = st[j];
             if (vd.stage_kind[j] == K_SPATIAL) {  // (its smoothers run whatever comes in; what goes out is never flagged silent)
                 sp_zero = sil || upstream_silent;
@@ -1191,7 +1206,10 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
                 if (vd.stage_kind[j] == K_PAN && !(r.s1.status == SM_INACTIVE && r.s1.input == r.p1)) steady = false;
             } else if (vd.stage_kind[j] == K_VOLUME) {
                 if (!smoother_is_constant(r.s0, r.p0)) ramping = true;
-                else if (r.s0.status == SM_INACTIVE && r.s0.input < 0.00001f) sil = true;
+                else if (r.s0.status == SM_INACTIVE && r.s0.input < 0.00001f) {
+                    sil = true;
+                    mid_sil[j] = fx && j >= fb1 && j < (fb3 != 0x7fff ? fb3 : (fb2 != 0x7fff ? fb2 : fb1));
+                }
             } else if (vd.stage_kind[j] == K_PAN) {
                 if (!smoother_is_constant(r.s0, r.p0) || !smoother_is_constant(r.s1, r.p1)) ramping = true;
             } else if (vd.stage_kind[j] == K_WIDTH) {
@@ -1276,6 +1294,7 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             job.g.g[j + 1][0] = vd.stage_kind[j] == K_HARD_CLIP ? r.p0 : (r.s0.status == SM_ACTIVE ? r.s0.last : r.s0.input);
             job.g.g[j + 1][1] = (vd.stage_kind[j] == K_PAN || vd.stage_kind[j] == K_SPATIAL) ? (r.s1.status == SM_ACTIVE ? r.s1.last : r.s1.input)
                                                           : job.g.g[j + 1][0];
+            if (mid_sil[j]) job.g.g[j + 1][0] = job.g.g[j + 1][1] = -1.0f;  // (the sentinel: k_chain writes +0.0 there)
         }
 #pragma unroll
         for (int sl = 0; sl < 2 * FW_MAX_STAGES; ++sl) job.ramp_until[sl] = ramp_until[sl];

@@ -16,7 +16,7 @@ import test_chain_grammar as t  # noqa: E402
 fwapi.build_oracle()
 for seed in [int(x) for x in sys.argv[1:]]:
     mbf = [128, 64, 256][seed % 3]
-    max_batch = [64, 1, 3, 8][seed % 4]
+    max_batch = int(os.environ.get("DBG_MAX_BATCH", [64, 1, 3, 8][seed % 4]))
 
     def both(only=None, generic=False, log=None):
         o = scenarios.TaggedOracle(fwapi.OracleEngine(max_block_frames=mbf))

@@ -147,14 +147,21 @@ void check_fused_common(const FusedView& fv, int K) {
                 touch(fv.ext + vd.sp_ext_off, sizeof(float) * SP_HIST);
                 touch(fv.hist + (size_t)i * SP_HIST, sizeof(float) * SP_HIST);
             }
-            REQUIRE(sk == SK_GAIN || (fv.has_prog && !fv.fx_plan), i, j);
+            REQUIRE(sk == SK_GAIN || (fv.has_prog && !fv.fx_plan) || (fv.fx_plan && sk == SK_CLIP), i, j);  // (k_chain clips per channel: round 6)
             touch(&fv.states[vd.stage_state[j]], sizeof(NodeState));
         }
         REQUIRE(fv.fx_plan || (vd.bq_state < 0 && vd.dl_state < 0 && vd.bq2_state < 0), i);
         // round 6 grammar: gain stages in front of the filters are volume / pan only and only in a voice that has a filter; a second biquad
         // needs a first; the delay-first order needs both kinds
-        REQUIRE(vd.n_pre >= 0 && vd.n_pre <= vd.n_stages && (vd.n_pre == 0 || vd.bq_state >= 0 || vd.dl_state >= 0), i, vd.n_pre);
-        for (int j = 0; j < vd.n_pre; ++j) REQUIRE(vd.stage_kind[j] == K_VOLUME || vd.stage_kind[j] == K_PAN, i, j);
+        {
+            const int m1 = vd.n_mid & 0xff, m2 = (vd.n_mid >> 8) & 0xff, nf = (vd.bq_state >= 0) + (vd.bq2_state >= 0) + (vd.dl_state >= 0);
+            REQUIRE(vd.n_pre >= 0 && vd.n_pre + m1 + m2 <= vd.n_stages && (vd.n_pre + m1 + m2 == 0 || nf >= 1), i, vd.n_pre);
+            REQUIRE((m1 == 0 || nf >= 2) && (m2 == 0 || nf >= 3) && (vd.n_mid >> 16) == 0, i, vd.n_mid);  // stages between filters need the filters
+            if (nf) {
+                REQUIRE(vd.n_stages <= FW_CHAIN_STAGES - 1, i, vd.n_stages);
+                for (int j = 0; j < vd.n_stages; ++j) REQUIRE(vd.stage_kind[j] == K_VOLUME || vd.stage_kind[j] == K_PAN || vd.stage_kind[j] == K_HARD_CLIP, i, j);
+            }
+        }
         REQUIRE(vd.bq2_state < 0 || vd.bq_state >= 0, i, vd.bq2_state);
         REQUIRE((vd.fx_order == 0 || vd.fx_order == 1) && (vd.fx_order == 0 || (vd.bq_state >= 0 && vd.dl_state >= 0)), i, vd.fx_order);
         if (vd.bq2_state >= 0) touch(&fv.states[vd.bq2_state], sizeof(NodeState));
@@ -662,6 +669,14 @@ int launch_chain(hipStream_t, const FusedView& fv, int K, uint32_t, int nq) {
     bool any_bq2 = false;
     for (int i = 0; i < fv.n_voices; ++i) any_bq2 = any_bq2 || (fv.voices[i].sampler_state >= 0 && fv.voices[i].bq2_state >= 0);
     REQUIRE(((nq & 4) != 0) == any_bq2, nq);  // bit 2: the instantiation with the second recurrence stage, exactly when some voice needs it
+    bool any_sites = false;
+    for (int i = 0; i < fv.n_voices; ++i) {
+        const VoiceDesc& vd = fv.voices[i];
+        if (vd.sampler_state < 0) continue;
+        any_sites = any_sites || vd.n_mid != 0;
+        for (int j = 0; j < vd.n_stages; ++j) any_sites = any_sites || vd.stage_kind[j] == K_HARD_CLIP;
+    }
+    REQUIRE(((nq & 8) != 0) == any_sites, nq);  // bit 3: the five-site stage logic, exactly when some voice needs it
     nq &= 3;
     REQUIRE(fv.fx_plan == 1 && K <= CH_FAST_KMAX && (nq == 1 || nq == 2) && fv.frames % (64 * nq) == 0, K, nq);
     touch(fv.chain_start, sizeof(ChainStart) * (size_t)fv.n_voices);

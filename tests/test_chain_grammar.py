@@ -4,7 +4,7 @@ Reference: any edge is legal (crates/firewheel-graph/src/graph.rs:396-477), so a
 cascade two biquads (an EQ), or run its delay line into a filter.  The chain plan (k_chain) took `sampler -> [biquad] -> [delay] ->
 gains` only; every other order fell to the level executor at a quarter of the speed.  It now takes
 
-    sampler -> {volume, pan}* -> FX -> {volume, pan}*     FX = B | BB | D | BD | BBD | DB | DBB     (<= 3 gain stages)
+    sampler -> G* -> F1 [-> G* -> F2 [-> G* -> F3]] -> G*     G = volume | pan | hard clip (<= 3),  F1 F2 F3 = B | BB | D | BD | BBD | DB | DBB
 
 CPU tier: the planner accepts exactly that (host-only harness: the real host code on a fake HIP runtime whose launch stubs validate
 every table the kernels would read).  GPU tier: every accepted shape bit for bit against the oracle — steady calls, source pauses
@@ -20,8 +20,10 @@ from fwapi import LOOP_FULL, GpuEngine, HostOnlyEngine, OracleEngine
 
 # token: v volume, p pan, B biquad, D delay.  One string = one voice chain behind its sampler.
 # a leading m: a ONE-output sampler behind the reference's MonoToStereoNode (mono_to_stereo.rs:33-50) — round 6: also in front of filters
-ACCEPTED = ["vB", "pBv", "vBD", "vBDv", "vpBDp", "BB", "BBv", "vBB", "vBBDp", "BBD", "DB", "DBv", "vDB", "DBB", "pDBBv", "vD", "vDp", "mBD", "mvBBp", "mDBv"]
-REFUSED = ["BvB", "BDB", "DBD", "BBB", "DD", "wB", "cB", "vBvDv"]  # a gain between filters, three filters in other orders, width / clip in front
+# (c = hard clip, w = stereo width)
+ACCEPTED = ["vB", "pBv", "vBD", "vBDv", "vpBDp", "BB", "BBv", "vBB", "vBBDp", "BBD", "DB", "DBv", "vDB", "DBB", "pDBBv", "vD", "vDp", "mBD", "mvBBp", "mDBv",
+            "BvB", "BvD", "BpBvD", "BBvD", "vBvDv", "DvB", "DpBvB", "cB", "BcD", "BDc", "vBcBD", "DcBv", "mBvBc"]  # gains between filters, clips anywhere
+REFUSED = ["BDB", "DBD", "BBB", "DD", "wB", "Bw", "BwD", "vBvDvp"]  # filter orders k_chain has no pipeline for, a width beside a filter, four gain stages
 
 
 def build_voice(e, shape, rng, delay_frames):

@@ -66,9 +66,9 @@ def bank(e, n_voices=12, radix=4, chain=False, clip_in_voice=False, master=False
     return smp
 
 
-# a hard clip (or a width) among a dry voice's stages rides the voice-bank plan as a stage program; behind a biquad / delay
-# the chain plan keeps gains only: the bank with that voice goes to the level executor, the other banks stay on k_chain (hybrid)
-@pytest.mark.parametrize("kw,plan", [({}, 1), ({"chain": True}, 2), ({"clip_in_voice": True}, 1), ({"chain": True, "clip_in_voice": True}, 3),
+# a hard clip (or a width) among a dry voice's stages rides the voice-bank plan as a stage program; round 6: k_chain clips per channel
+# too, so a hard clip behind a biquad / delay stays on the chain plan (a stereo WIDTH there still sends its bank to the level executor)
+@pytest.mark.parametrize("kw,plan", [({}, 1), ({"chain": True}, 2), ({"clip_in_voice": True}, 1), ({"chain": True, "clip_in_voice": True}, 2),
                                      ({"master": True}, 1),
                                      ({"chain": True, "master": True}, 2), ({"radix": 32, "n_voices": 70}, 1)])
 def test_plan_selection(kw, plan):

@@ -299,9 +299,9 @@ int launch_lazy_publish(hipStream_t s, unsigned long long* d_horizon, unsigned l
     hipLaunchKernelGGL(k_lazy_publish, dim3(1), dim3(1), 0, s, d_horizon, pinned_pub, seq);
     return (int)hipGetLastError();
 }
-int launch_lazy_flush(hipStream_t s, const LazyRec* lazy, NodeState* states, int n_voices, unsigned long long blocks) {
+int launch_lazy_flush(hipStream_t s, const LazyRec* lazy, NodeState* states, int n_voices, unsigned long long blocks, const VoiceDesc* chain_voices) {
     if (n_voices <= 0 || blocks == 0) return 0;
-    hipLaunchKernelGGL(k_lazy_flush, dim3((n_voices + 255) / 256), dim3(256), 0, s, lazy, states, n_voices, blocks);
+    hipLaunchKernelGGL(k_lazy_flush, dim3((n_voices + 255) / 256), dim3(256), 0, s, lazy, states, n_voices, blocks, chain_voices);
     return (int)hipGetLastError();
 }
 int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {

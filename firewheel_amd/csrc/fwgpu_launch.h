@@ -71,6 +71,7 @@ struct FusedView {
     unsigned long long* horizon;  // k_voice_control: atomicMin of the absolute block up to which every voice's LazyRec holds (0: some voice has none)
     uint64_t abs_blk_end;         // k_voice_control: absolute block index right behind this call (the LazyRecs' block 0)
     uint64_t lazy_blk0;           // lazy leaf kernel: this call's first block, counted from the LazyRecs' block 0
+    int lazy_chain = 0;           // round 6: this k_chain launch derives its block records from the LazyRecs too (no control kernel ran)
     VoiceBlk* rs_tmpl;  // has_rs: [n_voices] the descriptor a steady resampler voice's VB_RS_LEAN blocks of this call share (all but off0)
     const float* rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS] (voices whose source is a resampler)
     const uint32_t* progs;  // [n_voices] stage programs (SK_*, 4 bits per chain stage); nullptr / all 0 on gains-only plans
@@ -142,7 +143,8 @@ int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K);
 // node state brought up to date after `blocks` lazily rendered blocks
 int launch_leaf_sum_lazy(hipStream_t s, const FusedView& fv, int K);
 int launch_lazy_publish(hipStream_t s, unsigned long long* d_horizon, unsigned long long* pinned_pub, unsigned long long seq);
-int launch_lazy_flush(hipStream_t s, const LazyRec* lazy, NodeState* states, int n_voices, unsigned long long blocks);
+int launch_lazy_flush(hipStream_t s, const LazyRec* lazy, NodeState* states, int n_voices, unsigned long long blocks,
+                      const VoiceDesc* chain_voices = nullptr);  // chain plans: the voices (their delay lines' positions moved too)
 int launch_sp_hist_copy(hipStream_t s, const FusedView& fv);
 // realtime edge: control + leaf sums + root sum + interleave of ONE block in one launch (tree = leaves + root, stereo out);
 // d_sync: one zero-initialised unsigned the workgroups count themselves in with

@@ -890,7 +890,8 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             if ((rc = upload_chain_groups(c, P, fb.leaves))) return rc;
         }
         const size_t K = P.kmax;
-        P.lazy_capable = c->lazy_on && !fb.has_fx && !fb.has_rs && !fb.has_sp;
+        // (round 6: chain plans too — k_chain derives its records from the LazyRecs; resampler and spatialiser banks keep their control kernel)
+        P.lazy_capable = c->lazy_on && !fb.has_rs && !fb.has_sp;
         if ((rc = alloc_voice_tables(c, P))) return rc;
         // (spatialiser stages: their 64-frame history goes from the LAST block of a call to the first block of the next through the ext
         //  pool; in this mode the copy into the call's scratch is made on the render stream — k_sp_hist_copy — because the control

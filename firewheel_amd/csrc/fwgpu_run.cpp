@@ -481,7 +481,8 @@ int lazy_flush(fwgpu_ctx* c) {
     const uint64_t n = c->lazy_pending;
     c->lazy_pending = 0;
     if (!c->d_lazy.p || c->n_voices <= 0) return 0;
-    LCHK(c, launch_lazy_flush(c->stream, c->d_lazy.as<LazyRec>(), c->d_states.as<NodeState>(), c->n_voices, n));
+    LCHK(c, launch_lazy_flush(c->stream, c->d_lazy.as<LazyRec>(), c->d_states.as<NodeState>(), c->n_voices, n,
+                              c->fused_fx ? c->d_voices.as<VoiceDesc>() : nullptr));
     return 0;
 }
 
@@ -624,6 +625,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     if (lazy) {
         // no control kernel: every voice's records of these K blocks follow from its LazyRec and the block index
         fv.lazy_blk0 = c->abs_blk - c->lazy_base_blk;
+        fv.lazy_chain = c->fused_fx ? 1 : 0;
         c->lazy_pending += (uint64_t)K;
         c->lazy_calls++;
     } else if (c->ahead_this_call) {

@@ -181,7 +181,47 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     const int voice = grp.first_voice + (active ? v : 0);
     const VoiceDesc vd = fv.voices[voice];
     const bool has_bq = active && vd.bq_state >= 0, has_dl = active && vd.dl_state >= 0;
-    const ChainStart cs = fv.chain_start[voice];
+    ChainStart cs = fv.chain_start[voice];
+    // Lazy call (round 6): no control kernel ran.  A voice's block records follow from its LazyRec and the block index (as in the leaf
+    // kernel's lazy instantiation), its gains are the record's, and what the ChainStart holds is read from node state instead — which
+    // nothing has written since the control kernel that made the records (no message since, by the host's lazy test): coefficients in
+    // the ext pool, the delay's parameters, its position the blocks of the lazy calls so far further on (k_lazy_flush moves it for good).
+    const bool lazy = fv.lazy_chain != 0;
+    if (lazy) {
+        if (vd.bq_state >= 0) {
+            const float* co = fv.ext + fv.states[vd.bq_state].ext_off;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) cs.co[j] = co[j];
+        }
+        if (BQ2 && vd.bq2_state >= 0) {
+            const float* co = fv.ext + fv.states[vd.bq2_state].ext_off;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) cs.co2[j] = co[j];
+        }
+        if (vd.dl_state >= 0) {
+            const NodeState* ds = &fv.states[vd.dl_state];
+            const uint64_t Dl = ds->loop_end;
+            cs.pos = (uint32_t)((ds->playhead + (fv.lazy_blk0 % Dl) * (uint64_t)frames) % Dl);
+            cs.fb = ds->p0;
+            cs.mix = ds->p1;
+            cs.dry = ds->gain;
+        }
+    }
+    auto chain_ref = [&](const int pvoice, const int pk) -> VoiceRef {
+        if (!lazy) return fv.refs[ref_index(pvoice, pk, fv.ref_kgroups)];
+        const LazyRec* lr = fv.lazy + pvoice;
+        VoiceRef r;
+        const uint32_t mode = (uint32_t)lr->mode, lfr = lr->frames, bpf = lr->bpf;
+        const uint64_t bi = fv.lazy_blk0 + (uint64_t)pk;
+        uint64_t fo = 0;
+        if (mode == 1u) fo = (uint64_t)(uint32_t)(((uint64_t)lr->r0b + bi) % lr->q) * lfr;
+        else if (mode == 2u) fo = lr->off0 + bi * lfr;
+        r.src_l = (const float*)(lr->base + fo * bpf);
+        r.r_delta = lr->r_delta;
+        r.flags_gset = lr->flags_gset & ~0xff00u;
+        return r;
+    };
+    auto chain_gsets = [&](const int pvoice) -> const GainSet* { return lazy ? &fv.lazy[pvoice].g : &fv.gsets[(size_t)pvoice * FW_GSETS]; };
     float b0 = cs.co[0], b1 = cs.co[1], b2 = cs.co[2], a1 = cs.co[3], a2 = cs.co[4];
     float* bq_st = nullptr;  // this channel's [x1 x2 y1 y2]
     float y1 = 0.f, y2 = 0.f;
@@ -290,10 +330,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
     }
     for (int i = threadIdx.x; i < ports * K; i += CH_THREADS) {
         const int pv = i / K, pk = i - pv * K, pvoice = grp.first_voice + pv;
-        const VoiceRef rk = fv.refs[ref_index(pvoice, pk, fv.ref_kgroups)];
+        const VoiceRef rk = chain_ref(pvoice, pk);
         const uint32_t fk = rk.flags_gset & 0xffu, kind = fk & (VB_SIMPLE | VB_WRAP | VB_TAIL_ZERO);
         const uint32_t per_voice = VB_SILENT | VB_MONO | VB_SRC_ZERO;  // what must not change inside the call
-        bool ok = ((fk ^ fv.refs[ref_index(pvoice, 0, fv.ref_kgroups)].flags_gset) & per_voice) == 0u;
+        bool ok = lazy || ((fk ^ fv.refs[ref_index(pvoice, 0, fv.ref_kgroups)].flags_gset) & per_voice) == 0u;
         const float* a0 = nullptr;
         const float* a1 = nullptr;
         uint32_t wr = 0xffffffffu;
@@ -433,7 +473,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             nb_c16 = ncls == SF_I_I16 ? 1 : (ncls == SF_I_U16 ? 2 : 0);
             nb_src = ref_n.src_l + ((ch && !nb_c16) ? ref_n.r_delta : 0u);  // r_delta = 0 for a mono sample (sampler.rs:546-551)
             if (nb_flags & VB_SIMPLE) {
-                const GainSet* gs = &fv.gsets[(size_t)voice * FW_GSETS + ((ref_n.flags_gset >> 8) & 0xffu)];
+                const GainSet* gs = chain_gsets(voice) + ((ref_n.flags_gset >> 8) & 0xffu);
 #pragma unroll
                 for (int j = 0; j < FW_CHAIN_STAGES; ++j) gs_n[j] = gs->g[j][ch];
             }
@@ -454,7 +494,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
             ++kla;
         }
         // the tile after that starts a block: request its descriptor now
-        if (tla == 0 && kla < K) ref_n = fv.refs[ref_index(voice, kla, fv.ref_kgroups)];
+        if (tla == 0 && kla < K) ref_n = chain_ref(voice, kla);
     };
     auto ring_slot = [&](int j) -> uint32_t {
         uint32_t sl = pos + (uint32_t)(LF * q + 4 * j);
@@ -481,7 +521,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         }
     };
     if (is_worker && active && !wg_fast) {  // prologue = the issue halves of steps -2 and -1
-        ref_n = fv.refs[ref_index(voice, 0, fv.ref_kgroups)];
+        ref_n = chain_ref(voice, 0);
         issue_source();
         if (dl_first && ring_pref) load_ring();  // (delay-first voices: S1 of tile 0 consumes them)
     }
@@ -503,8 +543,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(FusedView fv, int K, uint3
         // path and emits exact vmcnt(N) waits: the source of tile s+2 and the ring slots of tile s are requested in
         // step s and stay in flight for two whole steps (two static register sets, loop unrolled by two).  A quad
         // that straddles the end of its ring (once per lap) is fixed up on a rare path with plain in-step accesses.
-        const uint32_t vflags = fv.refs[ref_index(voice, 0, fv.ref_kgroups)].flags_gset & 0xffu;  // per-voice bits only are used
-        const GainSet* gsp = &fv.gsets[(size_t)voice * FW_GSETS];
+        const uint32_t vflags = (lazy ? fv.lazy[voice].flags_gset : fv.refs[ref_index(voice, 0, fv.ref_kgroups)].flags_gset) & 0xffu;  // per-voice bits only are used
+        const GainSet* gsp = chain_gsets(voice);
         const float g0f = gsp->g[0][ch];
         // stage j + 1's constant: a gain (the sentinel -1.0f from a muted stage between two filters: a cleared buffer) or a clip threshold
         float gc[FW_CHAIN_STAGES - 1];

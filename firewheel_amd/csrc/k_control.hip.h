@@ -548,7 +548,8 @@ __device__ __forceinline__ uint64_t steady_tail(const FusedView& fv, int vi, int
 // block's compact record is a pure function of the block index: silent-flagged (a constant record), or a planar-f32 source read
 // contiguously whose loop is a whole number of blocks long and entered on a block boundary (so that no block wraps inside itself),
 // or a one-shot (until it runs out: that is the horizon).  Everything else — other formats, loops that wrap inside blocks,
-// resampler sources, chain-plan voices — says "not capable" and the next call runs the control kernel as before.
+// resampler sources — says "not capable" and the next call runs the control kernel as before.  Chain-plan voices (round 6) leave
+// records of k_chain's compact classes the same way; what the ChainStart record holds k_chain then takes from node state.
 // the playhead steady_tail(…, k_first, K, job, …) will return: the state behind the call's last block
 __device__ __forceinline__ uint64_t tail_end_playhead(const TailJob& job, const int k_first, const int K, const uint64_t fr) {
     const uint64_t n = (uint64_t)(K - k_first);
@@ -573,14 +574,16 @@ __device__ __forceinline__ void make_lazy(const FusedView& fv, const int vi, con
     const uint64_t fr = (uint64_t)fv.frames;
     int mode = -1;
     unsigned long long horizon = 0ull;
-    if (!fx && !fxp && job.mode >= 0 && job.mode <= 2) {
-        const bool silent = (job.flags & VB_SILENT) != 0;
+    if (job.mode >= 0 && job.mode <= 2) {
+        // (round 6: chain plans too.  `silent` = the block fetches nothing.  A filter voice fetches its source whatever its output's flag
+        //  says — the filters run on; what it does not fetch is a cleared source, VB_SRC_ZERO — steady_tail's no_src)
+        const bool silent = fxp ? ((job.flags & VB_SRC_ZERO) != 0 || (!fx && (job.flags & VB_SILENT) != 0)) : (job.flags & VB_SILENT) != 0;
         const bool has_src = !(job.flags & VB_SRC_ZERO) && !silent && job.sample >= 0;
         // the compact record every later block gets (steady_tail's lean record for planar f32, put_blk's VB_SIMPLE record for the other
         // source classes): its class depends on the parity of the block's first source frame only, which is the origin's here — loop
         // start / sample start plus whole blocks of a multiple of 4 frames
         const uint64_t origin = job.mode == 1 ? job.loop_start : 0ull;
-        const uint32_t cls = has_src ? simple_class(sd, job.mode == 1 ? origin : ph_end, false) : (uint32_t)SF_NONE;
+        const uint32_t cls = has_src ? simple_class(sd, job.mode == 1 ? origin : ph_end, fxp) : (uint32_t)SF_NONE;
         const bool lean = has_src && (fv.frames & 3) == 0 && cls != (uint32_t)SF_NONE && sd.frames < 0xffffffffull;
         // (address of source frame `origin` and bytes per frame, by class: put_blk's pointer arithmetic)
         uint64_t base = 0;
@@ -617,7 +620,9 @@ __device__ __forceinline__ void make_lazy(const FusedView& fv, const int vi, con
         if (moves_ok && (silent || (job.mode != 0 && lean))) {
             mode = job.mode;
             if (w0) {
-                o->flags_gset = ((silent ? job.flags : (job.flags | VB_SIMPLE)) & 0xffu) | ((silent ? (uint32_t)SF_P_F32 : cls) << 16) | (job.flags & VB_SP_MASK);
+                // (chain plan: every record is VB_SIMPLE — a source of one of k_chain's classes, or a cleared one — and keeps the chain output's flag)
+                const uint32_t fl = fxp ? (job.flags | VB_SIMPLE | (has_src ? 0u : VB_SRC_ZERO)) : (silent ? job.flags : (job.flags | VB_SIMPLE));
+                o->flags_gset = (fl & 0xffu) | ((has_src ? cls : (uint32_t)SF_P_F32) << 16) | (job.flags & VB_SP_MASK);
                 o->r_delta = silent ? 0u : rdelta;
                 o->base = base;
                 o->bpf = bpf;
@@ -633,12 +638,19 @@ __device__ __forceinline__ void make_lazy(const FusedView& fv, const int vi, con
     }
 }
 // ... and node state brought up to date after `blocks` blocks rendered from the LazyRecs: the playhead is the only thing that moved
-__global__ __launch_bounds__(256) void k_lazy_flush(const LazyRec* __restrict__ lazy, NodeState* __restrict__ states, int n_voices, unsigned long long blocks) {
+// (chain plans, round 6: and the position in the voice's delay line, which k_chain advanced from the state by itself in every lazy call)
+__global__ __launch_bounds__(256) void k_lazy_flush(const LazyRec* __restrict__ lazy, NodeState* __restrict__ states, int n_voices, unsigned long long blocks,
+                                                    const VoiceDesc* __restrict__ chain_voices) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_voices) return;
     const LazyRec r = lazy[v];
-    if (r.sampler_state < 0 || r.mode <= 0) return;
     if (blocks == 0) return;
+    if (chain_voices != nullptr && chain_voices[v].dl_state >= 0) {
+        NodeState* ds = &states[chain_voices[v].dl_state];
+        const uint64_t D = ds->loop_end;
+        ds->playhead = (ds->playhead + (blocks % D) * (uint64_t)r.frames) % D;
+    }
+    if (r.sampler_state < 0 || r.mode <= 0) return;
     // (tail_end_playhead's value, not only an equivalent one: a last block that ends exactly on the loop end leaves playhead ==
     //  loop_end — rendered like loop_start, sampler.rs:441-452, but node state must not depend on whether a call was lazy: ADVICE r4)
     if (r.mode == 1) states[r.sampler_state].playhead = r.loop_start + ((uint64_t)((r.r0b + blocks - 1) % r.q) + 1) * r.frames;
@@ -696,11 +708,11 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             for (int j = 0; j < FW_MAX_STAGES; ++j) one.g[j][0] = one.g[j][1] = 1.0f;
             fv.gsets[(size_t)vi * FW_GSETS + lane] = one;
         }
-        if (fv.lazy != nullptr && !fxp && w0) {  // a constant silent record for as long as the plan lives
+        if (fv.lazy != nullptr && w0) {  // a constant silent record for as long as the plan lives (chain plan: as a cleared-source record)
             LazyRec lr;
             lr.base = lr.off0 = lr.loop_start = 0;
             lr.r_delta = 0;
-            lr.flags_gset = VB_SILENT;
+            lr.flags_gset = VB_SILENT | (fxp ? (VB_SRC_ZERO | VB_SIMPLE) : 0u);
             lr.q = 1;
             lr.r0b = 0;
             lr.frames = (uint32_t)frames;
@@ -712,8 +724,6 @@ __device__ inline void voice_control_wave(const FusedView& fv, const int vi, con
             for (int j = 0; j < FW_MAX_STAGES; ++j) lr.g.g[j][0] = lr.g.g[j][1] = 1.0f;
             lr.pad2[0] = lr.pad2[1] = lr.pad2[2] = lr.pad2[3] = 0;
             fv.lazy[vi] = lr;
-        } else if (fv.lazy != nullptr && w0 && fv.horizon) {
-            atomicMin(fv.horizon, 0ull);
         }
         return;
     }

@@ -50,7 +50,8 @@ static inline hipError_t hipMalloc(void** p, size_t n) {
 }
 template <class T>
 static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
-static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+extern "C" void fwh_freed(const void* p);  // launch_stubs.cpp: books the stubs keep per device buffer end with the buffer
+static inline hipError_t hipFree(void* p) { if (p) fwh_freed(p); free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 enum { hipHostRegisterDefault = 0, hipHostRegisterMapped = 2 };

@@ -317,6 +317,7 @@ int launch_get_flags(hipStream_t, const uint8_t* flags, const int* d_bufs, int n
 struct LazyBook {
     unsigned long long since_ctl = 0, unflushed = 0;
     bool have_ctl = false;
+    bool chain = false;  // the unflushed blocks were rendered by k_chain
 };
 static LazyBook g_lazy[64];
 static const void* g_lazy_key[64];
@@ -333,6 +334,11 @@ static LazyBook& lazy_book(const void* key) {
     g_lazy[0] = LazyBook();
     return g_lazy[0];
 }
+// (a freed LazyRec table takes its book along: the next context's table may get the same address)
+extern "C" void fwh_freed(const void* p) {
+    for (int i = 0; i < 64; ++i)
+        if (g_lazy_key[i] == p) g_lazy[i] = LazyBook();
+}
 unsigned long long g_lazy_launches = 0;
 extern "C" unsigned long long fwh_lazy_launches(void) { return g_lazy_launches; }
 int launch_leaf_sum_lazy(hipStream_t, const FusedView& fv, int K) {
@@ -345,6 +351,7 @@ int launch_leaf_sum_lazy(hipStream_t, const FusedView& fv, int K) {
     REQUIRE(b.have_ctl && fv.lazy_blk0 == b.since_ctl, (long long)fv.lazy_blk0, (long long)b.since_ctl);
     b.since_ctl += (unsigned long long)K;
     b.unflushed += (unsigned long long)K;
+    b.chain = false;
     return 0;
 }
 int launch_lazy_publish(hipStream_t, unsigned long long* d_horizon, unsigned long long* pub, unsigned long long seq) {
@@ -355,13 +362,17 @@ int launch_lazy_publish(hipStream_t, unsigned long long* d_horizon, unsigned lon
     pub[1] = seq;
     return 0;
 }
-int launch_lazy_flush(hipStream_t, const LazyRec* lazy, NodeState* states, int n_voices, unsigned long long blocks) {
+int launch_lazy_flush(hipStream_t, const LazyRec* lazy, NodeState* states, int n_voices, unsigned long long blocks, const VoiceDesc* chain_voices) {
     g_launches[7]++;
     touch(lazy, sizeof(LazyRec) * (size_t)n_voices);
     (void)states;
     LazyBook& b = lazy_book(lazy);
+    // (a chain plan's flush moves the delay lines too: it names the voices — exactly when the lazy launches were k_chain's)
+    REQUIRE((chain_voices != nullptr) == b.chain, (int)b.chain);
+    if (chain_voices) touch(chain_voices, sizeof(VoiceDesc) * (size_t)n_voices);
     REQUIRE(blocks == b.unflushed && blocks > 0, (long long)blocks, (long long)b.unflushed);
     b.unflushed = 0;
+    b.chain = false;
     b.have_ctl = false;  // (the LazyRecs are spent: the next lazy launch needs a control launch first)
     return 0;
 }
@@ -679,6 +690,18 @@ int launch_chain(hipStream_t, const FusedView& fv, int K, uint32_t, int nq) {
     REQUIRE(((nq & 8) != 0) == any_sites, nq);  // bit 3: the five-site stage logic, exactly when some voice needs it
     nq &= 3;
     REQUIRE(fv.fx_plan == 1 && K <= CH_FAST_KMAX && (nq == 1 || nq == 2) && fv.frames % (64 * nq) == 0, K, nq);
+    if (fv.lazy_chain) {  // no control launch in front of this one: the same book-keeping as the leaf kernel's lazy launch
+        g_lazy_launches++;
+        REQUIRE(fv.lazy != nullptr && fv.n_cmds == 0, fv.n_cmds);
+        touch(fv.lazy, sizeof(LazyRec) * (size_t)fv.n_voices);
+        LazyBook& b = lazy_book(fv.lazy);
+        REQUIRE(b.have_ctl && fv.lazy_blk0 == b.since_ctl, (long long)fv.lazy_blk0, (long long)b.since_ctl);
+        b.since_ctl += (unsigned long long)K;
+        b.unflushed += (unsigned long long)K;
+        b.chain = true;
+    } else if (fv.lazy) {  // (behind a control launch: node state was current, launch_voice_control checked it)
+        REQUIRE(lazy_book(fv.lazy).since_ctl == 0);
+    }
     touch(fv.chain_start, sizeof(ChainStart) * (size_t)fv.n_voices);
     touch(fv.chain_dummy, 32 * 1024);
     touch(fv.chain_stats, 16);

@@ -11,6 +11,8 @@ every table the kernels would read).  GPU tier: every accepted shape bit for bit
 (the stages in front of the filters see the sampler's silence flag and reset, the ones behind never do), muted pre-gains, gain
 glides on both sides of the filters, coefficient / feedback messages for every filter of the chain, every K batching.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -350,6 +352,84 @@ def fuzz_grammar(e, seed, only=None, log=None):
                 e.sampler_stop(vc["sampler"], at_block=at)
         out.append(e.process_blocks(k))
     return np.concatenate(out)
+
+
+# ------------------------------------------------------------------------------------------------ lazy calls (no control kernel)
+def run_quiet(e, shapes, mbf, fmt, seed=0):
+    """Loops a whole number of blocks long (the lazy records' condition), long message-free stretches, and in between everything a
+    later lazy call must not miss: filter coefficients and delay parameters changed INSIDE a control call (the ChainStart record holds the
+    values at that call's start, node state the ones at its end: a lazy call reads the state), one-shots running out (the horizon),
+    pauses, a muted stage between two filters, a one-block call, a call longer than a batch."""
+    voices = build_bank(e, shapes, radix=8, src_frames=mbf * 6, fmt=fmt, seed=seed, delays=(64, 129, 300, 384, 700, 1000, 2048))
+    for i, vc in enumerate(voices):
+        if i % 7 != 3:
+            e.sampler_set_loop_range(vc["sampler"], LOOP_FULL)   # i % 7 == 3: one-shots, 6 blocks long
+        if i % 10 != 9:
+            e.sampler_play(vc["sampler"])                        # i % 10 == 9: never started
+    outs, marks = [], []
+    for c, k in enumerate([3, 2, 2, 3, 4, 1, 4, 4, 9, 2, 2, 3, 3, 5, 2, 2, 2, 6] + [8] * 12 + [4, 4]):
+        if c == 8:
+            for i, vc in enumerate(voices):
+                for j, n in enumerate(vc["bqs"]):
+                    if (i + j) % 2 == 0:
+                        e.set_param(n, 1, 400.0 + 250.0 * j + 90.0 * (i % 9), at_block=1 + (i % 3))
+                for n in vc["dls"]:
+                    if i % 2 == 1:
+                        e.set_param(n, 1 + (i % 4) // 2, 0.15 + 0.05 * (i % 5), at_block=2)
+        if c == 12:
+            for i, vc in enumerate(voices):
+                if i % 5 == 0:
+                    e.sampler_pause(vc["sampler"], at_block=1)
+                if i % 5 == 1 and len(vc["vols"]) > 1:
+                    e.set_param(vc["vols"][1], 0, 0.0, at_block=0)   # (between two filters in the shapes that have a mid stage)
+        if c == 16:
+            for i, vc in enumerate(voices):
+                if i % 5 == 0:
+                    e.sampler_play(vc["sampler"], at_block=0)
+        outs.append(np.asarray(e.process_blocks(k)))
+        if hasattr(e, "cx"):
+            marks.append(e.cx.lazy_stats())
+    return np.concatenate(outs), marks
+
+
+
+
+def test_chain_plan_lazy_calls_on_the_host_harness():
+    """the host's side of it on the fake device (whose control launches always report an unbounded horizon): the launch stubs check the
+    block offset every lazy k_chain launch names and that the flush names the voice table"""
+    e = HostOnlyEngine(max_block_frames=128, max_batch=8)
+    _, marks = run_quiet(e, (ACCEPTED + ["v", "vp", "mvp", "pc"])[:41], 128, fwapi.PLANAR_F32)
+    assert e.cx.plan_kind() == 2 and e.violation() == "", e.violation()
+    assert marks[-1][0] >= 8, marks
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [fwapi.PLANAR_F32, fwapi.INTERLEAVED_I16, fwapi.INTERLEAVED_U16])
+@pytest.mark.parametrize("mbf,max_batch", [(128, 8), (64, 3), (256, 64)])
+def test_chain_plan_calls_without_a_control_kernel_are_bit_exact_and_happen(fmt, mbf, max_batch):
+    """Round 6: lazy records for chain plans.  k_chain derives every block's record from the voice's LazyRec, takes coefficients,
+    delay parameters and the delay position from node state, and k_lazy_flush moves the delay positions along with the playheads."""
+    shapes = (ACCEPTED + ["v", "vp", "mvp", "pc"])[:41]   # every accepted shape, dry voices beside them
+    if fmt != fwapi.PLANAR_F32:
+        # (channel 0 of an interleaved sample behind the mono adapter is fetched frame by frame — no compact class, k_control.hip.h
+        #  mono_adapt — so such a voice leaves no lazy record and holds the whole plan on the control path: correct, and not this test)
+        shapes = [sh for sh in shapes if not sh.startswith("m")]
+    ro, _ = run_quiet(scenarios.TaggedOracle(OracleEngine(max_block_frames=mbf)), shapes, mbf, fmt)
+    g = GpuEngine(max_block_frames=mbf, max_batch=max_batch)
+    rg, marks = run_quiet(g, shapes, mbf, fmt)
+    assert g.cx.plan_kind() == 2
+    assert_bits(ro, rg, "quiet calls fmt %d mbf %d K<=%d" % (fmt, mbf, max_batch))
+    lazy = [m[0] for m in marks]
+    if os.environ.get("FWGPU_LAZY") == "0":
+        assert lazy[-1] == 0
+        return
+    # calls 0 and 1: messages and the call after them; the one-shots end in block 6 (call 2): the horizon keeps control in until then
+    assert lazy[2] == 0, marks
+    assert lazy[7] > lazy[3], marks            # quiet calls 4, 6, 7 (call 5 is ONE block)
+    assert lazy[9] == lazy[8], marks           # the messages of call 8 (that call is a control call) and the call after it
+    assert lazy[11] > lazy[9], marks           # ... then lazy again, with the coefficients and delay parameters of call 8's END
+    assert lazy[13] == lazy[12], marks         # pauses and mutes: control for as long as their glides last ...
+    assert lazy[-1] > lazy[17], marks          # ... and lazy once more when the last of them has settled (a glide to 0.0 takes ~45 blocks of 128)
 
 
 @pytest.mark.gpu

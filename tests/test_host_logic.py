@@ -680,12 +680,21 @@ def test_lazy_records_host_bookkeeping():
     e.process_blocks(4)
     lazy, ctl = e.cx.lazy_stats()
     assert ctl == 6 and lazy == 7 and e.violation() == "", (lazy, ctl, e.violation())
-    # chain plans and plans with resampler sources never go lazy
+    # chain plans (round 6): the same rule — k_chain derives its records from the LazyRecs, and the flush names the voices, whose delay
+    # lines' positions it moves (the stubs check both: launch_chain's block offset, launch_lazy_flush's voice table)
     e2 = HostOnlyEngine(max_block_frames=64, max_batch=8)
-    bank(e2, chain=True)
+    smp2 = bank(e2, chain=True)
+    assert e2.cx.plan_kind() == 2
+    for s_ in smp2:
+        e2.sampler_play(s_)
     for _ in range(4):
-        e2.process_blocks(8)
-    assert e2.cx.lazy_stats()[0] == 0 and e2.violation() == ""
+        e2.process_blocks(8)                 # control, control (hot_prev), lazy, lazy
+    assert e2.cx.lazy_stats() == (2, 2) and e2.violation() == "", (e2.cx.lazy_stats(), e2.violation())
+    e2.process_blocks(20)                    # three lazy batches: offsets 16, 24, 32
+    assert e2.cx.lazy_stats() == (5, 2) and e2.violation() == "", (e2.cx.lazy_stats(), e2.violation())
+    e2.set_param(smp2[1], 0, 40.0)           # a message: flush (36 blocks, with the voice table), control
+    e2.process_blocks(4)
+    assert e2.cx.lazy_stats() == (5, 3) and e2.violation() == "", (e2.cx.lazy_stats(), e2.violation())
 
 
 def test_a_list_of_messages_in_one_call():

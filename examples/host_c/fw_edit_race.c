@@ -232,6 +232,15 @@ int main(int argc, char** argv) {
     double m2, p2, x2;
     long c2;
     stats(a.t_us, a.tag, a.n, 2, &m2, &p2, &x2, &c2);
+    { /* diagnostics on stderr: the slow callbacks among those that began while an edit was in flight — which edit, which update phase */
+        int edit = -1;
+        for (long i = 1; i < a.n; ++i) {
+            if (a.tag[i] == 1 && a.tag[i - 1] != 1) ++edit;
+            if (i >= 50 && a.tag[i] == 1 && a.t_us[i] > p0 + 15.0)
+                fprintf(stderr, "slow callback %ld while edit %d was built: %.1f us, update phase %d (the one before it: %.1f us, tag %d)\n", i, edit, a.t_us[i], a.phase[i],
+                        a.t_us[i - 1], a.tag[i - 1]);
+        }
+    }
     for (int ph = 0; ph <= 40; ++ph) { /* diagnostics on stderr: the callbacks by what the updating thread was doing when they began */
         double md, p9, mx;
         long cn;

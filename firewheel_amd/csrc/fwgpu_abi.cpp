@@ -256,7 +256,11 @@ fwgpu_ctx* fwgpu_ctx_create(int device, uint32_t sample_rate, uint32_t max_block
         c->rt_persist = false;
     }
     if (const char* e = getenv("FWGPU_HOST_PROF")) c->host_prof = atoi(e) != 0;
-    if (const char* e = getenv("FWGPU_UPDATE_PROF")) c->update_prof = atoi(e) != 0;
+    if (const char* e = getenv("FWGPU_PLAN_ORDER")) c->graph.canonical_order = strcmp(e, "reference") != 0;
+    if (const char* e = getenv("FWGPU_UPDATE_PROF")) {
+        c->update_prof = atoi(e) != 0;
+        c->update_prof_tables = atoi(e) >= 2;
+    }
     if (const char* e = getenv("FWGPU_RT_GRAPH")) c->rt_use_graph = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_ONE_LAUNCH")) c->rt_one_launch = atoi(e) != 0;
     if (const char* e = getenv("FWGPU_RT_PERSIST_MAX_LEAVES")) c->rt_persist_max_leaves = std::max(0, atoi(e));

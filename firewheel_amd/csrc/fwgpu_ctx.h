@@ -466,6 +466,7 @@ struct fwgpu_ctx : fwgpu::PlanImage {
     Plan spare_plan;  // control side: a retired plan's node array, reused by the next fwgpu_update
     // FWGPU_UPDATE_PROF=1: host nanoseconds of the control thread per update phase, printed when the ctx is destroyed
     bool update_prof = false;
+    bool update_prof_tables = false;  // FWGPU_UPDATE_PROF=2: one stderr line per table a build uploads (bytes, bytes that differed)
     uint64_t phase_ns[32] = {0}, phase_t0 = 0, phase_updates = 0;
     uint64_t prof_groups = 0, prof_jobs = 0, prof_copy_bytes = 0, prof_fill_bytes = 0;  // build_apply's launches / jobs / bytes
     std::atomic<int> update_phase{0};  // fwgpu_update_phase: 0 none, 1 graph compile, 21..28 the sections of build_image, 3 waiting for the uploads

@@ -315,11 +315,82 @@ int HostGraph::build_plan(Plan& plan, std::string& err) {
     for (size_t s = 0; s < NS; ++s) in_off[s + 1] = in_off[s] + (meta[s].alive ? meta[s].n_in : 0u);
     std::vector<int>& in_e = cs_indeg;
     in_e.assign(in_off[NS], -1);
+    std::vector<uint32_t>& in_s = cs_insrc;  // ... and the producer's slot beside it (the passes below then leave the edge arena alone)
+    if (canonical_order) in_s.resize(in_off[NS]);
     for (size_t e = 0; e < edges.size(); ++e)
-        if (edges[e].alive) in_e[in_off[edges[e].dst] + edges[e].dport] = (int)e;
+        if (edges[e].alive) {
+            const uint32_t at = in_off[edges[e].dst] + edges[e].dport;
+            in_e[at] = (int)e;
+            if (canonical_order) in_s[at] = edges[e].src;
+        }
     std::vector<uint32_t>& index_of = cs_cur;
     index_of.assign(NS, 0);
     const size_t N = order.size();
+    // Round 6 — a CANONICAL order for the plan's tables: the post-order of a depth-first walk from graph_out over the INPUT ports,
+    // ascending (a node behind all of its producers: a schedule; nodes graph_out does not reach: the same walk from each, slots
+    // ascending, behind the rest).  The reference's order (the Kahn walk above: compiler.rs:232-300) follows the edge arena, so
+    // replacing one voice — its new edges go to the arena's end — moved that voice to the end of its level and shifted every node,
+    // buffer id and voice behind it by one voice: 0.4-0.6 MB of the 1.1 MB of tables differed after every edit of config 3's 4 096
+    // voices (FWGPU_UPDATE_PROF=2); ordering by slot would do the same (a removed node's slot is reusable only when no plan holds it
+    // any more: the replacement gets new slots).  Every table names its producers by index and levels follow from the producers, so
+    // any schedule renders the same audio; this one depends on WHERE a node is connected only: a voice put into the mixer port of
+    // the voice it replaces takes that voice's entries, and an edit differs in O(1) chunks.  One pass, O(nodes + edges), no sort.
+    if (canonical_order && N > 2) {
+        std::vector<uint32_t>& out = cs_byl;
+        std::vector<uint8_t>& seen = cs_seen;
+        std::vector<uint32_t>& st_node = cs_adj;  // (the walk's adjacency is spent) the DFS stack: node, next input port
+        std::vector<uint32_t>& st_port = cs_fill;
+        out.resize(N);
+        seen.assign(NS, 0);
+        st_node.resize(N + 1);
+        st_port.resize(N + 1);
+        // (raw pointers: the walk is a third of the compile as it is)
+        uint32_t* const o = out.data();
+        uint8_t* const sn = seen.data();
+        uint32_t* const sk_n = st_node.data();
+        uint32_t* const sk_p = st_port.data();
+        const int* const ine = in_e.data();
+        const uint32_t* const ins = in_s.data();
+        const uint32_t* const ioff = in_off.data();
+        const NodeMeta* const mt = meta.data();
+        size_t pos = 0;
+        o[pos++] = graph_in_slot;  // (first, as in the reference's order)
+        sn[graph_in_slot] = 1;
+        sn[graph_out_slot] = 1;
+        auto walk = [&](uint32_t root) {
+            size_t sp = 0;
+            sk_n[0] = root;
+            sk_p[0] = 0;
+            for (;;) {
+                const uint32_t n = sk_n[sp];
+                uint32_t p = sk_p[sp];
+                const uint32_t n_in = mt[n].n_in;
+                const int* ie = ine + ioff[n];
+                const uint32_t* is = ins + ioff[n];
+                while (p < n_in && (ie[p] < 0 || sn[is[p]])) ++p;
+                if (p < n_in) {
+                    sk_p[sp] = p + 1;
+                    sn[is[p]] = 1;
+                    ++sp;
+                    sk_n[sp] = is[p];
+                    sk_p[sp] = 0;
+                } else {
+                    if (n != graph_out_slot) o[pos++] = n;
+                    if (sp == 0) break;
+                    --sp;
+                }
+            }
+        };
+        walk(graph_out_slot);
+        if (pos + 1 < N)
+            for (uint32_t slot = 0; slot < NS; ++slot)
+                if (mt[slot].alive && !sn[slot]) {
+                    sn[slot] = 1;
+                    walk(slot);
+                }
+        out[pos++] = graph_out_slot;
+        order.swap(out);
+    }
     for (size_t i = 0; i < N; ++i) index_of[order[i]] = (uint32_t)i;
     // a recycled Plan keeps its node array AND the nodes in it (every field is assigned below; wide nodes keep their heap lists):
     // a fresh array was 3 MB of first-touch page faults and 20 000 constructor / destructor pairs on config 3

@@ -167,6 +167,7 @@ class HostGraph {
     std::vector<HostEdge> edges;
     std::vector<uint32_t> free_edges;
     bool needs_compile = true;
+    bool canonical_order = true;  // build_plan: level by level, slots ascending (FWGPU_PLAN_ORDER=reference: the reference's Kahn order)
     std::vector<uint32_t> nodes_to_activate;
 
     HostNode* get(int64_t id);
@@ -187,7 +188,8 @@ class HostGraph {
   private:
     void remove_edge_slot(uint32_t e);
     // the compiler's scratch arrays, kept between compiles (topo_order / build_plan say what each holds when)
-    std::vector<uint32_t> cs_off, cs_adj, cs_cur, cs_queue, cs_order;
+    std::vector<uint32_t> cs_off, cs_adj, cs_cur, cs_queue, cs_order, cs_byl, cs_fill, cs_insrc;
+    std::vector<uint8_t> cs_seen;
     std::vector<int> cs_indeg;
 };
 

@@ -33,12 +33,17 @@ namespace fwgpu {
 //  A PACED stream (gaps between the calls of at least 2 x QUIET_MARGIN) is also looked at ahead: a group launched just before a
 //  call begins still meets it, so when the next call is due within the margin — the last period and the last start say when — the
 //  group waits for that call to come and go.)
-static constexpr uint64_t QUIET_MARGIN_NS = 60000;  // a group and its launch
+// a group and its launch (FWGPU_QUIET_MARGIN_US: experiments)
+static const uint64_t QUIET_MARGIN_NS = getenv("FWGPU_QUIET_MARGIN_US") ? (uint64_t)atoll(getenv("FWGPU_QUIET_MARGIN_US")) * 1000ull : 60000ull;
 void quiet_window(fwgpu_ctx* c) {
     if (!c->quiet_wait_us) return;
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
-    const auto deadline = t0 + std::chrono::microseconds(3 * (uint64_t)c->quiet_wait_us);
+    auto deadline = t0 + std::chrono::microseconds(3 * (uint64_t)c->quiet_wait_us);
+    {  // (a paced stream: room for one whole call to come and go)
+        const uint64_t period = c->cb_period_ns.load(std::memory_order_relaxed), dur = c->cb_dur_ns.load(std::memory_order_relaxed);
+        if (period && period <= 200000000ull && period >= dur + 2 * QUIET_MARGIN_NS) deadline = std::max(deadline, t0 + std::chrono::nanoseconds(3 * dur));
+    }
     auto wait_gate = [&](bool busy, clk::time_point until) {  // spin while (gate == 1) == busy; false: timed out
         for (;;) {
             for (int i = 0; i < 64; ++i) {
@@ -51,10 +56,17 @@ void quiet_window(fwgpu_ctx* c) {
         }
     };
     for (int round = 0; round < 2; ++round) {
-        if (c->gate.load(std::memory_order_acquire) == 1 && !wait_gate(true, round ? deadline : t0 + std::chrono::microseconds(c->quiet_wait_us))) return;
-        // no call in flight.  Is the next one about to begin?
         const uint64_t period = c->cb_period_ns.load(std::memory_order_relaxed), dur = c->cb_dur_ns.load(std::memory_order_relaxed);
         const uint64_t start = c->cb_start_ns.load(std::memory_order_relaxed);
+        // A call in flight: wait for its end — quiet_wait_us for a stream without gaps (the group then goes out anyway: it queues
+        // behind the call's kernels), but a PACED stream's call (gaps of two margins and more) is waited out: it ends within its usual
+        // length, and a group launched from this thread while the audio thread is still enqueuing its kernels lands BETWEEN them
+        // (round 6: one callback of +40-60 us per paced run once a build had shrunk to a single group; scripts/r06_edit_paced_ab.sh)
+        const bool paced = period && period <= 200000000ull && period >= dur + 2 * QUIET_MARGIN_NS;
+        const auto in_flight_until = paced ? std::max(t0 + std::chrono::microseconds(c->quiet_wait_us), t0 + std::chrono::nanoseconds(dur + dur / 2)) :
+                                             t0 + std::chrono::microseconds(c->quiet_wait_us);
+        if (c->gate.load(std::memory_order_acquire) == 1 && !wait_gate(true, round ? deadline : in_flight_until)) return;
+        // no call in flight.  Is the next one about to begin?
         if (round || !quiet_next_call_is_due((uint64_t)clk::now().time_since_epoch().count(), start, period, dur, QUIET_MARGIN_NS)) return;
         if (!wait_gate(false, deadline)) return;  // ... wait for it to begin, then (second round) to end
     }
@@ -184,8 +196,8 @@ static int arena_room(fwgpu_ctx* c, size_t need) {
 // Every other table is read-only on the device (const in DevView / FusedView): the image keeps a host copy of what it last
 // uploaded and a build copies only the 4 KiB chunks that differ — an edit of one voice of config 3's 4 096 leaves 89 % of the
 // table bytes as the image's previous build left them (the two images alternate, so "previous" is two edits ago).
-static int up(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes, bool device_writes = false) {
-    HIPC(c, b.ensure_n("b", bytes));
+static int up_impl(fwgpu_ctx* c, const char* tag, DevBuf& b, const void* src, size_t bytes, bool device_writes = false) {
+    HIPC(c, b.ensure_n(tag, bytes));
     if (!bytes) return 0;
     const size_t need = (bytes + 255) & ~(size_t)255;
     int rc = arena_room(c, need);
@@ -197,7 +209,7 @@ static int up(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes, bool devic
     const bool diff = c->up_diff && !device_writes;
     constexpr size_t CH = 4096;
     // runs of chunks that differ from the shadow
-    size_t off = 0;
+    size_t off = 0, sent = 0;
     while (off < bytes) {
         size_t end = bytes;
         if (diff) {
@@ -211,6 +223,7 @@ static int up(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes, bool devic
             while (end < bytes && !same(end)) end += CH;
             end = std::min(end, bytes);
         }
+        sent += end - off;
         if (one) {
             BuildJob j{};
             j.dst = (char*)b.p + off;
@@ -233,8 +246,10 @@ static int up(fwgpu_ctx* c, DevBuf& b, const void* src, size_t bytes, bool devic
     if (diff) b.shadow.assign((const uint8_t*)src, (const uint8_t*)src + bytes);
     else b.shadow.clear();
     c->h_up_used += need;
+    if (c->update_prof_tables) fprintf(stderr, "fwgpu up %-22s %9zu bytes, %9zu sent\n", tag, bytes, sent);
     return 0;
 }
+#define up(c, b, ...) up_impl(c, #b, b, __VA_ARGS__)  // (the table's name: FWGPU_UPDATE_PROF=2 lists what every build sends, table by table)
 // rows x row_bytes at a pitch, every byte `value`; head >= 0: byte 0 of every row is `head` instead
 static int fill_rows(fwgpu_ctx* c, void* p, size_t row_bytes, size_t pitch, size_t rows, int value, int head = -1) {
     if (!row_bytes || !rows) return 0;

@@ -1361,7 +1361,10 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB) void k_leaf_sum_lazy(FusedView fv, 
 // The resampler-pure leaves of a plan (rs_pure_lane above).  One wave per (leaf, block, 256-frame piece); lane p holds port p.
 // Accumulators, stages and the final store stay in the convolution's round-robin frame layout (lane l: frames l, l + nact, ...):
 // the stages of a pure voice are per-frame constants, so nothing needs the four-consecutive-frames layout of the other kernels.
-#define RS2_LDS_BYTES(waves) ((RS_PHASES * RS_TAPS + (waves) * (2 * RS2_WIN)) * sizeof(float))
+// LDS: the filter bank shifted by one tap [9 tap pairs][phase][2] = (h[2tp - 1], h[2tp]) (the pair convolution's second frame), the filter
+// bank [8 tap pairs][phase][2] = (h[2tp], h[2tp + 1]), one window per wave (+ 2 slots the pair convolution may read past the last one)
+#define RS2_TAB1 (RS_PHASES * (RS_TAPS + 2))
+#define RS2_LDS_BYTES(waves) ((RS2_TAB1 + RS_PHASES * RS_TAPS + (waves) * (2 * RS2_WIN) + 4) * sizeof(float))
 #ifndef RS_OCC
 #define RS_OCC 4
 #endif
@@ -1369,7 +1372,11 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv
     extern __shared__ float s_leaf_dyn[];
     for (int i = threadIdx.x; i < RS_PHASES * RS_TAPS; i += blockDim.x) {  // [tap pair][phase][2]
         const int t = i % RS_TAPS, ph = i / RS_TAPS;
-        s_leaf_dyn[((t >> 1) * RS_PHASES + ph) * 2 + (t & 1)] = fv.rs_table[i];
+        s_leaf_dyn[RS2_TAB1 + ((t >> 1) * RS_PHASES + ph) * 2 + (t & 1)] = fv.rs_table[i];
+    }
+    for (int i = threadIdx.x; i < RS2_TAB1; i += blockDim.x) {  // the same, one tap later: [tap pair][phase][2] = taps 2tp - 1, 2tp (taps -1 and 16: never used)
+        const int e = i & 1, ph = (i >> 1) % RS_PHASES, tp = (i >> 1) / RS_PHASES, t = 2 * tp - 1 + e;
+        s_leaf_dyn[i] = (t >= 0 && t < RS_TAPS) ? fv.rs_table[ph * RS_TAPS + t] : 0.f;
     }
     __syncthreads();
     const int leaf = blockIdx.x;
@@ -1381,8 +1388,9 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv
     const LeafDesc ld = fv.leaves[leaf];
     const int frames = fv.frames;
     if (part * 256 >= frames) return;
-    const v2f_rs* tab = (const v2f_rs*)s_leaf_dyn;
-    v2f_rs* win = (v2f_rs*)(s_leaf_dyn + RS_PHASES * RS_TAPS + wave * (2 * RS2_WIN));
+    const v2f_rs* tab = (const v2f_rs*)(s_leaf_dyn + RS2_TAB1);
+    const v2f_rs* tab1 = (const v2f_rs*)s_leaf_dyn;  // (in FRONT of the bank: the pair convolution reads one tap pair below `tab` and discards it)
+    v2f_rs* win = (v2f_rs*)(s_leaf_dyn + RS2_TAB1 + RS_PHASES * RS_TAPS + wave * (2 * RS2_WIN));
     const size_t row = (size_t)k * fv.n_voices + ld.first_voice;
     uint32_t my_flags = VB_SILENT;
     uint64_t my_pos = 0ull;
@@ -1433,6 +1441,7 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv
         // (every lane works here — window fetch and convolution are dealt over the whole wave, whatever the piece's length)
         const int nact = nfr < WAVE ? nfr : WAVE;                       // lanes that own frames
         const int per = (nfr + nact - 1) / nact;                        // frames per lane: <= 4
+        const bool pairs = nfr == 256 && !(fv.dbg & 512);               // (frames 2l, 2l+1, 128+2l, 128+2l+1 instead; FWGPU_CHAIN_SKIP=512: A/B)
         v4f accl = splat(0.f), accr = splat(0.f);                       // frames lane, lane + nact, lane + 2 nact, lane + 3 nact
         v4f wa[2], wb[2];
         wa[0] = wa[1] = wb[0] = wb[1] = splat(0.f);
@@ -1525,6 +1534,76 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv
             const uint32_t i_first = (uint32_t)(cp_first >> 32);
             uint64_t pos = cp_first + (uint64_t)lane * cstep;
             v4f xl = splat(0.f), xr = splat(0.f);
+            if (pairs) {
+                // Round 6 — a full piece (256 frames): lane l convolves frames 2l, 2l+1 and 128+2l, 128+2l+1.  The windows of two
+                // NEIGHBOURING frames A, B overlap in all but s = floor(step) or floor(step) + 1 slots, so the pair reads 18 window slots
+                // where two separate frames read 32 (the frame-per-lane loop below keeps the LDS pipe 91 % busy: SQ_LDS_IDX_ACTIVE,
+                // profiles/r06_rs_pairs_sq.txt).  B's chain walks the slots A's chain walks — same registers — with ITS coefficients
+                // moved instead: by s taps, which is a per-lane choice between the filter bank and its copy shifted by one tap (and one
+                // tap pair up or down), made once per pair.  Where the shifted row has no tap (slot in front of B's first / behind its last)
+                // the fmaf is computed and dropped by a select — not fed a zero: (-0.0) + 0 * x is +0.0, and 0 * inf is not 0.
+                // Each frame's chain is the same 16 fmaf ascending from +0.0 as below — same bits.
+                auto conv_pairs = [&](auto flc) {
+                    constexpr int FL = decltype(flc)::value;  // floor(step): 0 or 1 (a pure port's step is < 2)
+                    const v2f_rs zero2 = (v2f_rs){0.f, 0.f};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {  // (one pair at a time: two chains side by side, as below — four cost the kernel its registers)
+                        const uint64_t pa = cp_first + (uint64_t)(2 * lane + 128 * h) * cstep, pb = pa + cstep;
+                        const bool sh = ((uint32_t)(pb >> 32) - (uint32_t)(pa >> 32)) != (uint32_t)FL;  // B's window starts FL + 1 slots behind A's
+                        // B's coefficients for slot pair tp: s = 0: the bank's pair tp; s = 1: the shifted bank's; s = 2: the bank's pair tp - 1
+                        const v2f_rs* bt = FL == 0 ? (sh ? tab1 : tab) : (sh ? tab - RS_PHASES : tab1);
+                        rs_lp ha = (rs_lp)(tab + ((uint32_t)(pa >> 27) & (RS_PHASES - 1)));
+                        rs_lp hb = (rs_lp)(bt + ((uint32_t)(pb >> 27) & (RS_PHASES - 1)));
+                        rs_lp wp = (rs_lp)(win + ((uint32_t)(pa >> 32) - i_first));
+                        v2f_rs acca = zero2, accb = zero2;
+                        // (one tap pair ahead, by hand, and the addresses AND the sums laundered through an empty asm per tap pair: left alone
+                        //  the compiler hoists every load of the chain to its top — 100 registers — and spills: the kernel has 128 at four
+                        //  waves per SIMD.  A sched_barrier alone held in one of the four copies of this loop and not in the others.)
+                        v2f_rs lo = wp[0], hi = wp[1], c0 = ha[0], c1 = hb[0];
+#pragma unroll
+                        for (int tp = 0; tp < RS_TAPS / 2; ++tp) {
+                            asm volatile("" : "+v"(wp), "+v"(ha), "+v"(hb), "+v"(acca), "+v"(accb));
+                            const v2f_rs nlo = wp[2 * tp + 2];
+                            v2f_rs nhi = zero2, n0 = zero2;
+                            if (FL == 1 || tp + 1 < RS_TAPS / 2) nhi = wp[2 * tp + 3];  // (slot 17: only a step >= 1 gets there)
+                            if (tp + 1 < RS_TAPS / 2) n0 = ha[(tp + 1) * RS_PHASES];
+                            const v2f_rs n1 = hb[(tp + 1) * RS_PHASES];
+                            acca = __builtin_elementwise_fma((v2f_rs){c0.x, c0.x}, lo, acca);
+                            if (FL == 0) {  // slot 2 tp: B's first tap sits here (s = 0) or one slot on (s = 1)
+                                const v2f_rs t = __builtin_elementwise_fma((v2f_rs){c1.x, c1.x}, lo, accb);
+                                accb = tp == 0 ? (sh ? zero2 : t) : t;
+                            } else if (tp > 0) {  // (slot 0 is never B's)
+                                accb = __builtin_elementwise_fma((v2f_rs){c1.x, c1.x}, lo, accb);
+                            }
+                            acca = __builtin_elementwise_fma((v2f_rs){c0.y, c0.y}, hi, acca);
+                            {
+                                const v2f_rs t = __builtin_elementwise_fma((v2f_rs){c1.y, c1.y}, hi, accb);
+                                accb = (FL == 1 && tp == 0) ? (sh ? zero2 : t) : t;  // slot 1: B's first tap when s = 1, none when s = 2
+                            }
+                            lo = nlo;
+                            hi = nhi;
+                            c0 = n0;
+                            c1 = n1;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        // slots 16, 17: what is left of B's chain
+                        if (FL == 0) {
+                            const v2f_rs t = __builtin_elementwise_fma((v2f_rs){c1.x, c1.x}, lo, accb);
+                            accb = sh ? t : accb;  // s = 1: tap 15; s = 0: done
+                        } else {
+                            accb = __builtin_elementwise_fma((v2f_rs){c1.x, c1.x}, lo, accb);  // s = 1: tap 15; s = 2: tap 14
+                            const v2f_rs t = __builtin_elementwise_fma((v2f_rs){c1.y, c1.y}, hi, accb);
+                            accb = sh ? t : accb;  // s = 2: tap 15
+                        }
+                        xl[2 * h] = acca.x;
+                        xr[2 * h] = acca.y;
+                        xl[2 * h + 1] = accb.x;
+                        xr[2 * h + 1] = accb.y;
+                    }
+                };
+                if ((uint32_t)(cstep >> 32) == 0u) conv_pairs(std::integral_constant<int, 0>());
+                else conv_pairs(std::integral_constant<int, 1>());
+            } else
 #pragma unroll
             for (int i = 0; i < 4; i += 2) {
                 if (i < per) {  // (uniform.  Two frames' chains side by side: each is 16 dependent instructions long)
@@ -1568,7 +1647,16 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv
             }
         }
 #undef RS2_ISSUE
-        if (lane < nact) {
+        if (pairs) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int f = fbase + 128 * h + 2 * lane;
+                __builtin_nontemporal_store(accl[2 * h], outl + f);
+                __builtin_nontemporal_store(accl[2 * h + 1], outl + f + 1);
+                __builtin_nontemporal_store(accr[2 * h], outr + f);
+                __builtin_nontemporal_store(accr[2 * h + 1], outr + f + 1);
+            }
+        } else if (lane < nact) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int f = lane + i * nact;

@@ -361,6 +361,7 @@ def planner_lib():
             "fwp_add_node": (i64, [vp, ci, u32, u32]), "fwp_remove_node": (ci, [vp, i64]),
             "fwp_connect": (i64, [vp, i64, u32, i64, u32, ci]), "fwp_disconnect": (ci, [vp, i64, u32, i64, u32]),
             "fwp_disconnect_edge": (ci, [vp, i64]), "fwp_cycle_detected": (ci, [vp]), "fwp_update": (ci, [vp]),
+            "fwp_set_canonical_order": (None, [vp, ci]),
             "fwp_sched_len": (ci, [vp]), "fwp_sched_num_buffers": (ci, [vp]), "fwp_sched_num_levels": (ci, [vp]),
             "fwp_sched_node": (i64, [vp, ci]), "fwp_sched_level": (ci, [vp, ci]),
             "fwp_sched_in": (ci, [vp, ci, ip, ip, ci]), "fwp_sched_out": (ci, [vp, ci, ip, ci]),
@@ -413,6 +414,11 @@ class PlannerEngine(Engine):
 
     def disconnect_by_edge_id(self, e):
         return self.L.fwp_disconnect_edge(self.c, e)
+
+    def set_canonical_order(self, on):
+        """build_plan's order of the plan's tables: True (the default) = level by level, by where a node is connected; False = the
+        reference's Kahn order (compiler.rs:232-300)"""
+        self.L.fwp_set_canonical_order(self.c, 1 if on else 0)
 
     def cycle_detected(self):
         return bool(self.L.fwp_cycle_detected(self.c))

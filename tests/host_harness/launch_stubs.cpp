@@ -42,6 +42,7 @@ extern "C" void fwh_launch_reset(void) {
 // ---- what the stubs CHECK instead of computing: every table a kernel would index is touched at the extent the kernel
 // indexes it (first and last byte: under ASan an under-sized allocation of the host side is a report), and the
 // descriptor invariants the kernels rely on are asserted.  The first violation is kept for the tests (fwh_violation).
+#include <mutex>
 #include <stdio.h>
 
 #include <map>
@@ -321,7 +322,9 @@ struct LazyBook {
 };
 static LazyBook g_lazy[64];
 static const void* g_lazy_key[64];
+static std::mutex g_lazy_mu;  // (launches come from the audio thread, frees from whichever thread retires an image)
 static LazyBook& lazy_book(const void* key) {
+    std::lock_guard<std::mutex> lk(g_lazy_mu);
     for (int i = 0; i < 64; ++i) {
         if (g_lazy_key[i] == key) return g_lazy[i];
         if (!g_lazy_key[i]) {
@@ -336,6 +339,7 @@ static LazyBook& lazy_book(const void* key) {
 }
 // (a freed LazyRec table takes its book along: the next context's table may get the same address)
 extern "C" void fwh_freed(const void* p) {
+    std::lock_guard<std::mutex> lk(g_lazy_mu);
     for (int i = 0; i < 64; ++i)
         if (g_lazy_key[i] == p) g_lazy[i] = LazyBook();
 }

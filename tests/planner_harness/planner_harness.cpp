@@ -34,6 +34,7 @@ int64_t fwp_connect(void* h, int64_t s, uint32_t sp, int64_t d, uint32_t dp, int
 }
 int fwp_disconnect(void* h, int64_t s, uint32_t sp, int64_t d, uint32_t dp) { return ((Harness*)h)->g.disconnect(s, sp, d, dp); }
 int fwp_disconnect_edge(void* h, int64_t e) { return ((Harness*)h)->g.disconnect_edge(e); }
+void fwp_set_canonical_order(void* h, int on) { ((Harness*)h)->g.canonical_order = on != 0; }  // build_plan's table order (round 6)
 int fwp_cycle_detected(void* h) { return ((Harness*)h)->g.cycle_detected() ? 1 : 0; }
 int fwp_update(void* h) {
     Harness* x = (Harness*)h;

@@ -772,3 +772,70 @@ def test_process_interleaved_begin_end_ticket_rules_on_the_host_harness():
     assert e.cx.L.fwgpu_process_interleaved_end(e.cx.c, f[0], None) < 0
     assert e.cx.process_interleaved_end(f).shape == (64 * 2,)
     assert e.violation() == ""
+
+
+def test_a_one_voice_replace_uploads_a_few_chunks_not_the_tables(monkeypatch):
+    """Round 6 (contract: context.rs:93-137, swap at processor.rs:167-206).  examples/host_c/fw_edit_race's edit on the
+    host-only harness: config 3's bank — 4 096 voices of sampler -> biquad -> delay -> gain under 32-port mixers — with one voice after
+    another (scattered: (e * 977 + 13) % 4096) removed and rebuilt into its mixer port.  build_plan's canonical order (fwgpu_graph.cpp)
+    keeps every other voice's entries where they were, so from the third edit on (both plan images have been built once) an edit
+    sends <= 64 KB of the 1.1 MB of tables; with the reference's order (FWGPU_PLAN_ORDER=reference) it sent 0.4-0.6 MB."""
+    import ctypes as C
+
+    from fwapi import HostOnlyEngine, hostonly_lib
+
+    for k in ("FWGPU_UP_PIECE", "FWGPU_UP_DIFF", "FWGPU_BUILD_ONE_KERNEL", "FWGPU_QUIET_WAIT_US", "FWGPU_BUILD_STREAM", "FWGPU_PLAN_ORDER"):
+        monkeypatch.delenv(k, raising=False)
+    L = hostonly_lib()
+    L.fwh_h2d_total.restype = C.c_ulonglong
+
+    def run(n_edits):
+        e = HostOnlyEngine(max_block_frames=512, max_batch=8)
+
+        def voice(v):
+            s, b, d, g = e.sampler(90.0), e.biquad(0, 1000.0 + v, 0.7), e.delay(0.01, feedback=0.2, mix=0.5), e.volume(60.0)
+            e.connect_stereo(s, b)
+            e.connect_stereo(b, d)
+            e.connect_stereo(d, g)
+            return [s, b, d, g]
+
+        N = 4096
+        voices = [voice(v) for v in range(N)]
+        leaves = []
+        for i in range(0, N, 32):
+            m = e.sum(32)
+            for k in range(32):
+                e.connect_stereo(voices[i + k][3], m, 2 * k)
+            leaves.append(m)
+        tops = []
+        for i in range(0, len(leaves), 32):
+            m = e.sum(32)
+            for k, n in enumerate(leaves[i:i + 32]):
+                e.connect_stereo(n, m, 2 * k)
+            tops.append(m)
+        root = e.sum(len(tops))
+        for k, n in enumerate(tops):
+            e.connect_stereo(n, root, 2 * k)
+        e.connect_stereo(root, e.graph_out_node)
+        e.update()
+        assert e.cx.plan_kind() == 2 and e.cx.plan_fused_voices() == N
+        e.process_blocks(2)
+        sent = []
+        for it in range(n_edits):
+            v = (it * 977 + 13) % N
+            for n in voices[v]:
+                e.remove_node(n)
+            voices[v] = voice(N + it)
+            e.connect_stereo(voices[v][3], leaves[v // 32], 2 * (v % 32))
+            L.fwh_h2d_reset()
+            e.update()
+            sent.append(L.fwh_h2d_total())
+            e.process_blocks(1)
+            assert e.violation() == "", e.violation()
+        return sent
+
+    sent = run(7)
+    assert max(sent[2:]) <= 64 << 10, sent
+    monkeypatch.setenv("FWGPU_PLAN_ORDER", "reference")
+    ref = run(5)
+    assert min(ref[2:]) > 200 << 10, ref   # (what the canonical order is for)

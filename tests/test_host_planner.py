@@ -35,12 +35,20 @@ def verify_node(sched, node, n_in, n_out, should_clear):
         seen.add(buf)
 
 
+def reference_order(g):
+    """the KATs below restate the reference's own tests of ITS schedule order (schedule.rs:407-710): they run on the walk that
+    reproduces it; the order build_plan writes the plan's tables in by default (round 6: by where a node is connected) is checked by
+    the random-graph family and the voice-replacement test further down"""
+    g.set_canonical_order(False)
+    return g
+
+
 def verify_edge(sched, src, sp, dst, dp):
     assert _find(sched, src)["out"][sp] == _find(sched, dst)["in"][dp][0]  # schedule.rs:637-660
 
 
 def test_simplest_graph_compile():
-    g = PlannerEngine(num_graph_inputs=1, num_graph_outputs=1)
+    g = reference_order(PlannerEngine(num_graph_inputs=1, num_graph_outputs=1))
     n0, n1 = g.graph_in_node, g.graph_out_node
     g.connect(n0, 0, n1, 0)
     g.update()
@@ -52,7 +60,7 @@ def test_simplest_graph_compile():
 
 
 def test_graph_compile_1():
-    g = PlannerEngine(num_graph_inputs=2, num_graph_outputs=2)
+    g = reference_order(PlannerEngine(num_graph_inputs=2, num_graph_outputs=2))
     n0 = g.graph_in_node
     n1, n2, n3, n4, n5 = (g.add_node(DUMMY, *p) for p in ((1, 2), (1, 1), (2, 2), (2, 2), (5, 2)))
     n6 = g.graph_out_node
@@ -73,7 +81,7 @@ def test_graph_compile_1():
 
 
 def test_graph_compile_2():
-    g = PlannerEngine(num_graph_inputs=2, num_graph_outputs=2)
+    g = reference_order(PlannerEngine(num_graph_inputs=2, num_graph_outputs=2))
     n0 = g.graph_in_node
     n1, n2, n3, n4 = (g.add_node(DUMMY, *p) for p in ((1, 1), (2, 2), (2, 2), (5, 4)))
     n5 = g.graph_out_node
@@ -95,7 +103,7 @@ def test_graph_compile_2():
 
 
 def test_many_to_one_detection():
-    g = PlannerEngine(num_graph_inputs=2, num_graph_outputs=1)
+    g = reference_order(PlannerEngine(num_graph_inputs=2, num_graph_outputs=1))
     g.connect(g.graph_in_node, 0, g.graph_out_node, 0)
     with pytest.raises(AddEdgeError) as ei:
         g.connect(g.graph_in_node, 1, g.graph_out_node, 0)
@@ -103,7 +111,7 @@ def test_many_to_one_detection():
 
 
 def test_cycle_detection():
-    g = PlannerEngine(num_graph_inputs=0, num_graph_outputs=2)
+    g = reference_order(PlannerEngine(num_graph_inputs=0, num_graph_outputs=2))
     n1, n2, n3 = g.add_node(DUMMY, 1, 1), g.add_node(DUMMY, 2, 1), g.add_node(DUMMY, 1, 1)
     g.connect(n1, 0, n2, 0)
     g.connect(n2, 0, n3, 0)
@@ -119,7 +127,7 @@ def test_cycle_detection():
 
 
 def test_add_edge_error_variants():
-    g = PlannerEngine()
+    g = reference_order(PlannerEngine())
     a, b = g.add_node(DUMMY, 1, 1), g.add_node(DUMMY, 1, 1)
     for args, name in [((a, 1, b, 0), "OutPortOutOfRange"), ((a, 0, b, 1), "InPortOutOfRange"),
                        ((a, 0, a, 0), "CycleDetected"), ((12345 << 32 | 99, 0, b, 0), "SrcNodeNotFound"),
@@ -148,7 +156,7 @@ def test_rejected_checked_connect_is_rolled_back_completely_unlike_the_reference
         assert not g.cycle_detected()
         return a, b, c
 
-    g = PlannerEngine()
+    g = reference_order(PlannerEngine())
     a, b, c = setup(g)
     g.connect(c, 0, a, 0)  # the port is free again
     g.update()
@@ -210,17 +218,29 @@ class Pair(object):
 
     def compare_schedules(self):
         assert self.p.cycle_detected() == self.o.cycle_detected()
+        self.p.set_canonical_order(False)      # the walk itself: the reference's order
         r = self.both(self.p.update, self.o.update)
         if r is None:
             return False
-        sp, so = self.p.schedule(), self.o.schedule()
+        self.check(self.p.schedule(), self.o.schedule(), kahn=True)
+        self.p.set_canonical_order(True)       # ... and the order the plan's tables are written in (round 6, the default)
+        self.p.update()
+        self.check(self.p.schedule(), self.o.schedule(), kahn=False)
+        return True
+
+    def check(self, sp, so, kahn):
         pidx = {n[0]: i for i, n in enumerate(self.nodes) if n is not None}
         oidx = {n[1]: i for i, n in enumerate(self.nodes) if n is not None}
         order_p = [pidx[x["id"]] for x in sp]
         order_o = [oidx[x["id"]] for x in so]
         assert order_p[-1] == 1 and sorted(order_p) == sorted(order_o)  # graph_out closes the product's schedule
-        # same order as the reference's Kahn BFS, except that graph_out is moved to the end
-        assert [i for i in order_p if i != 1] == [i for i in order_o if i != 1]
+        if kahn:  # same order as the reference's Kahn BFS, except that graph_out is moved to the end
+            assert [i for i in order_p if i != 1] == [i for i in order_o if i != 1]
+        else:     # a schedule: graph_in first, every node behind all of its producers
+            assert order_p[0] == 0
+            at = {i: k for k, i in enumerate(order_p)}
+            for (si, _, di, _) in self.edges:
+                assert at[si] < at[di]
         by_p = {pidx[x["id"]]: x for x in sp}
         by_o = {oidx[x["id"]]: x for x in so}
         written = set()
@@ -237,7 +257,6 @@ class Pair(object):
             want = 1 + max(srcs) if srcs else 0
             assert x["level"] == want or (i == 1 and x["level"] >= want)
         assert self.p.num_levels() == 1 + max(x["level"] for x in sp)
-        return True
 
 
 @pytest.mark.parametrize("seed", range(300))
@@ -285,3 +304,57 @@ def test_random_graphs_and_edit_sequences_match_the_oracle_compiler(seed):
     compiled += g.compare_schedules()
     # removing graph_in / graph_out is refused by both
     assert g.p.remove_node(g.nodes[0][0]) != 0 and g.p.remove_node(g.nodes[1][0]) != 0
+
+
+def test_replacing_a_voice_moves_only_that_voices_entries_in_the_plan_tables():
+    """Round 6: build_plan writes the plan's tables in an order that depends on where a node is CONNECTED — the order
+    in which the levels above, walked from graph_out down with input ports ascending, name it — not on the edge arena (the reference's
+    Kahn walk: a voice whose edges were made last is scheduled last in its level) and not on graph slots (a replacement's slots
+    differ).  A voice put into the mixer port of the voice it replaces takes that voice's positions and buffer ids; nothing else moves:
+    a one-voice edit of a large graph then differs in O(1) 4 KiB chunks of the uploaded tables (fwgpu_plan_install.cpp up())."""
+    SAMPLER, VOLUME, SUM = 3, 1, 4
+    g = PlannerEngine()
+
+    def voice():
+        s = g.add_node(SAMPLER, 0, 2)
+        a = g.add_node(VOLUME, 2, 2)
+        b = g.add_node(VOLUME, 2, 2)
+        for p in (0, 1):
+            g.connect(s, p, a, p)
+            g.connect(a, p, b, p)
+        return [s, a, b]
+
+    voices = [voice() for _ in range(64)]
+    leaves = [g.add_node(SUM, 32, 2) for _ in range(4)]
+    top = g.add_node(SUM, 8, 2)
+    for v, vc in enumerate(voices):
+        for p in (0, 1):
+            g.connect(vc[2], p, leaves[v // 16], 2 * (v % 16) + p)
+    for i, m in enumerate(leaves):
+        for p in (0, 1):
+            g.connect(m, p, top, 2 * i + p)
+    for p in (0, 1):
+        g.connect(top, p, g.graph_out_node, p)
+    g.update()
+    before = g.schedule()
+    pos = {x["id"]: i for i, x in enumerate(before)}
+    # voices sit in mixer-port order inside their levels, whatever order they were made and connected in
+    assert [pos[vc[0]] for vc in voices] == sorted(pos[vc[0]] for vc in voices)
+    for rnd, v in enumerate((37, 5, 37, 63, 0)):
+        old = voices[v]
+        spare = g.add_node(VOLUME, 2, 2)      # (other slots come and go meanwhile: the replacement's slots are not the old ones)
+        for n in old:
+            g.remove_node(n)
+        new = voice()
+        g.remove_node(spare)
+        for p in (0, 1):
+            g.connect(new[2], p, leaves[v // 16], 2 * (v % 16) + p)
+        voices[v] = new
+        g.update()
+        after = g.schedule()
+        assert len(after) == len(before)
+        swapped = dict(zip(old, new))
+        for i, (x, y) in enumerate(zip(before, after)):
+            assert y["id"] == swapped.get(x["id"], x["id"]), (rnd, i)          # same position: the same node, or the replacement of the node that sat there
+            assert (y["in"], y["out"], y["level"]) == (x["in"], x["out"], x["level"]), (rnd, i)   # same buffers, same level
+        before = after

@@ -308,7 +308,12 @@ def fuzz_grammar(e, seed, only=None, log=None):
     for i, vc in enumerate(voices):
         fmt = fmts[int(rng.integers(0, len(fmts)))]
         ch = 1 if rng.random() < 0.15 else 2
+        if seed % 4 == 3:  # (every fourth seed: only what k_chain fetches compactly — planar f32, interleaved stereo 16-bit — so that the whole
+            fmt = fmts[int(rng.integers(0, 5))]  # bank can leave lazy records)
+            ch = 2 if fmt != fwapi.PLANAR_F32 else ch
         frames = int(rng.integers(mbf + 40, 6 * mbf))
+        if seed % 2 == 1:
+            frames = mbf * int(rng.integers(2, 7))  # odd seeds: loops a whole number of blocks long — the quiet calls at the end can go lazy
         data = scenarios.voice_source(seed * 5000 + i, frames, ch)
         if fmt in (fwapi.INTERLEAVED_I16, fwapi.PLANAR_I16):
             data = np.round(data * 32767).astype(np.int16)
@@ -350,6 +355,17 @@ def fuzz_grammar(e, seed, only=None, log=None):
                     e.sampler_play(vc["sampler"], at_block=at)
             else:
                 e.sampler_stop(vc["sampler"], at_block=at)
+        out.append(e.process_blocks(k))
+    # quiet calls: when every voice has settled (and loops in whole blocks) these run without the control kernel (lazy records); one more
+    # message in the middle of them: filter coefficients / delay parameters changed INSIDE a control call, read back from node state
+    for k in (int(rng.integers(2, 9)), int(rng.integers(1, 9)), int(rng.integers(2, 20))) + ((24, 24, 24, 7) if seed % 4 == 3 else ()):
+        out.append(e.process_blocks(k))  # (every fourth seed: long enough for a glide to 0.0 to settle)
+    vi = int(rng.integers(0, n))
+    if voices[vi]["bqs"]:
+        e.set_param(voices[vi]["bqs"][0], 1, float(rng.uniform(200.0, 6000.0)), at_block=1)
+    if voices[vi]["dls"]:
+        e.set_param(voices[vi]["dls"][0], 2, float(rng.uniform(0.1, 0.6)), at_block=0)
+    for k in (3, int(rng.integers(2, 6)), int(rng.integers(2, 12)), int(rng.integers(1, 9))):
         out.append(e.process_blocks(k))
     return np.concatenate(out)
 

@@ -177,9 +177,9 @@ int fwgpu_plan_handover_stats(fwgpu_ctx* ctx, uint64_t* adoptions, uint64_t* aud
  * the old schedule comes back through the ring, graph/processor.rs:182-188; rust/firewheel-gpu's HostNodeHandle and the Python
  * wrapper keep removed host nodes in limbo until this says so).  Any thread may ask. */
 int fwgpu_plan_pending(fwgpu_ctx* ctx);
-/* Voice-bank plan, diagnostics: launch batches of process calls rendered WITHOUT a control kernel (*lazy_batches) and with one.
+/* Voice-bank and chain plans, diagnostics: launch batches of process calls rendered WITHOUT a control kernel (*lazy_batches) and with one.
  * A message-free call of a plan whose every voice the last control kernel left steady and plain (silent, or a planar-f32 source
- * that never wraps inside a block) needs no per-block state machine pass — the reference's processors do nothing in such a block
+ * or interleaved 16-bit source that never wraps inside a block) needs no per-block state machine pass — the reference's processors do nothing in such a block
  * but advance a playhead (nodes/sampler.rs:445-484) — and the leaf kernel derives each block's record from one per-voice
  * record; the host skips the control kernel once it has SEEN (pinned memory) that the last one found every voice so.  A host that
  * never waits for the device between calls sees no difference but the time.  FWGPU_LAZY=0 switches it off.  Either may be NULL. */

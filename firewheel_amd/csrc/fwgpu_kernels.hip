@@ -327,6 +327,9 @@ int launch_leaf_sum(hipStream_t s, const FusedView& fv, int K) {
     }
     else if (fv.has_rs) {  // a pair: the resampler-pure leaves (k_leaf_rs), then whatever it put on the work list
         hipLaunchKernelGGL(k_leaf_rs, grid, dim3(WAVE * LEAF_WPB), RS2_LDS_BYTES(LEAF_WPB), s, fv, K, wpk);
+        // (a lazy call's records are resampler voices k_leaf_rs renders itself and silence — make_lazy, k_control.hip.h — so it leaves
+        //  the work list empty: no second launch, which would read block records nobody wrote)
+        if (fv.lazy_rs) return (int)hipGetLastError();
         const int items = fv.n_leaves * K * wpk;
         const int wgs = (items + LEAF_WPB - 1) / LEAF_WPB;
         hipLaunchKernelGGL(k_leaf_sum_wl, dim3(wgs < 768 ? wgs : 768), dim3(WAVE * LEAF_WPB), RS_LDS_BYTES(LEAF_WPB), s, fv, K, wpk);

@@ -72,6 +72,8 @@ struct FusedView {
     uint64_t abs_blk_end;         // k_voice_control: absolute block index right behind this call (the LazyRecs' block 0)
     uint64_t lazy_blk0;           // lazy leaf kernel: this call's first block, counted from the LazyRecs' block 0
     int lazy_chain = 0;           // round 6: this k_chain launch derives its block records from the LazyRecs too (no control kernel ran)
+    int lazy_rs = 0;              // round 6: ... and this k_leaf_rs launch (rs_tmpl then points at the LazyRecs' templates)
+    VoiceBlk* lazy_tmpl = nullptr;  // resampler plans with lazy records: [n_voices] the template of a voice's LazyRec (control kernel: written with the record)
     VoiceBlk* rs_tmpl;  // has_rs: [n_voices] the descriptor a steady resampler voice's VB_RS_LEAN blocks of this call share (all but off0)
     const float* rs_table;  // SPEC resampler filter bank [RS_PHASES][RS_TAPS] (voices whose source is a resampler)
     const uint32_t* progs;  // [n_voices] stage programs (SK_*, 4 bits per chain stage); nullptr / all 0 on gains-only plans

@@ -416,7 +416,8 @@ static int alloc_voice_tables(fwgpu_ctx* c, PlanImage& P) {
     if (P.fused_rs) {  // one item per (leaf, block, 256-frame piece) at most
         HIPC(c, P.d_rs_wl.ensure_n("d_rs_wl", (2 + 2 * (size_t)P.n_leaves * K * LEAF_WPB_MAX) * sizeof(unsigned int)));
         if ((rc = zero(c, P.d_rs_wl.p, 2 * sizeof(unsigned int)))) return rc;
-        HIPC(c, P.d_rs_tmpl.ensure_n("d_rs_tmpl", 2 * std::max<size_t>(1, (size_t)P.n_voices) * sizeof(VoiceBlk)));
+        // (two copies for the control kernel a call ahead, a third for the lazy records' templates)
+        HIPC(c, P.d_rs_tmpl.ensure_n("d_rs_tmpl", 3 * std::max<size_t>(1, (size_t)P.n_voices) * sizeof(VoiceBlk)));
     }
     return 0;
 }
@@ -905,8 +906,9 @@ static int build_image(fwgpu_ctx* c, Plan& plan, PlanImage& P) {
             if ((rc = upload_chain_groups(c, P, fb.leaves))) return rc;
         }
         const size_t K = P.kmax;
-        // (round 6: chain plans too — k_chain derives its records from the LazyRecs; resampler and spatialiser banks keep their control kernel)
-        P.lazy_capable = c->lazy_on && !fb.has_rs && !fb.has_sp;
+        // (round 6: chain plans too — k_chain derives its records from the LazyRecs — and resampler banks (k_leaf_rs); spatialiser banks
+        //  keep their control kernel)
+        P.lazy_capable = c->lazy_on && !fb.has_sp && !(fb.has_rs && fb.has_fx);
         if ((rc = alloc_voice_tables(c, P))) return rc;
         // (spatialiser stages: their 64-frame history goes from the LAST block of a call to the first block of the next through the ext
         //  pool; in this mode the copy into the call's scratch is made on the render stream — k_sp_hist_copy — because the control

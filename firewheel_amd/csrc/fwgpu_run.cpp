@@ -307,6 +307,7 @@ static void fill_fused_view(fwgpu_ctx* c, FusedView& fv) {
     fv.rs_wl = c->d_rs_wl.as<unsigned int>();
     fv.rs_tmpl = c->fused_rs ? c->d_rs_tmpl.as<VoiceBlk>() : nullptr;
     fv.lazy = (c->lazy_capable && c->d_lazy.p) ? c->d_lazy.as<LazyRec>() : nullptr;
+    fv.lazy_tmpl = (fv.lazy && c->fused_rs && c->d_rs_tmpl.p) ? c->d_rs_tmpl.as<VoiceBlk>() + 2 * (size_t)c->n_voices : nullptr;
     fv.horizon = fv.lazy ? c->d_lazy_horizon.as<unsigned long long>() : nullptr;
     fv.abs_blk_end = 0;
     fv.lazy_blk0 = 0;
@@ -626,6 +627,10 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
         // no control kernel: every voice's records of these K blocks follow from its LazyRec and the block index
         fv.lazy_blk0 = c->abs_blk - c->lazy_base_blk;
         fv.lazy_chain = c->fused_fx ? 1 : 0;
+        if (c->fused_rs && !c->fused_fx) {  // k_leaf_rs: records from the LazyRecs, templates from the copy the last control kernel left beside them
+            fv.lazy_rs = 1;
+            fv.rs_tmpl = fv.lazy_tmpl;
+        }
         c->lazy_pending += (uint64_t)K;
         c->lazy_calls++;
     } else if (c->ahead_this_call) {
@@ -661,7 +666,7 @@ int run_fused_batch(fwgpu_ctx* c, int K, uint32_t cmd_block0, float* d_out, int 
     timer_begin(c, 0, &e0, &e1);
     if (fv.sp_hist_in_render) LCHK(c, launch_sp_hist_copy(c->stream, fv));
     if (c->fused_fx) LCHK(c, launch_chain(c->stream, fv, K, cmd_block0, c->chain_nq));
-    else if (lazy) LCHK(c, launch_leaf_sum_lazy(c->stream, fv, K));
+    else if (lazy && !c->fused_rs) LCHK(c, launch_leaf_sum_lazy(c->stream, fv, K));
     else LCHK(c, launch_leaf_sum(c->stream, fv, K));
     timer_end(c, e1);
     timer_begin(c, 2, &e0, &e1);

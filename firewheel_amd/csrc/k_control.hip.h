@@ -562,6 +562,10 @@ __device__ __forceinline__ uint64_t tail_end_playhead(const TailJob& job, const 
         return left < fr ? job.loop_start + (fr - left) : job.loop_start + r_last + fr;
     }
     if (job.mode == 2) return job.playhead + n * fr;
+    if (job.mode == 3) {  // a resampling source's 32.32 position (step in loop_start, loop modulus in loop_end: steady_tail)
+        const uint64_t end = job.playhead + n * (fr * job.loop_start);
+        return job.loop_end ? end % job.loop_end : end;
+    }
     return job.playhead;
 }
 // (called BEFORE the tail is written, with the playhead the tail will end on: the record is built and stored at once, and the tail's
@@ -574,7 +578,54 @@ __device__ __forceinline__ void make_lazy(const FusedView& fv, const int vi, con
     const uint64_t fr = (uint64_t)fv.frames;
     int mode = -1;
     unsigned long long horizon = 0ull;
-    if (job.mode >= 0 && job.mode <= 2) {
+    if (job.mode == 3 && !fxp && fv.lazy_tmpl != nullptr) {
+        // Round 6 — a resampler voice (k_leaf_rs): block j's 32.32 position is (pos + j * frames * step) mod (len << 32), everything else
+        // the template the record keeps beside it (lazy_tmpl, the rs_tmpl of lazy calls).  Capable when k_leaf_rs renders every block of
+        // it (rs_pure_lane's position-independent conditions: a leaf it hands to the work-list kernel would be read from records nobody
+        // wrote) and for as long as the position arithmetic stays inside 64 bits / the one-shot inside its sample.
+        const uint64_t step = job.loop_start, M = job.loop_end, len = sd.frames;
+        const int nfr = fv.frames < 256 ? fv.frames : 256;
+        const uint64_t w_max = (((uint64_t)nfr * step + 0xffffffffull) >> 32) + 1 + RS_TAPS;
+        const bool plain = !(job.flags & (VB_SIMPLE | VB_SILENT | VB_SRC_ZERO)) && job.sample >= 0 && sd.format == FMT_P_F32 && sd.data != nullptr;
+        if (plain && w_max <= 512 && len >= 1 && len < (1ull << 30) - 8192 && (!M || len >= (uint64_t)(512 + RS_TAPS)) && step < (1ull << 33) && fr <= 4096) {
+            mode = 3;
+            const uint64_t adv = fr * step;
+            if (M) {
+                horizon = fv.abs_blk_end + (1ull << 17);  // (j * frames * step < 2^62)
+            } else {
+                // blocks the one-shot still has in it: rs_survives(pos, step, frames, j, len) for every j up to there
+                const uint64_t lim = (len + RS_TAPS / 2) << 32;
+                const uint64_t left = lim > ph_end ? (lim - 1 - ph_end) / (adv ? adv : 1) : 0;
+                horizon = fv.abs_blk_end + (left > (1ull << 17) ? (1ull << 17) : left);
+            }
+            if (w0) {
+                VoiceBlk t;
+                t.flags = job.flags | ((uint32_t)sd.format << VB_FMT_SHIFT);
+                t.n1 = M ? 1u : 0u;
+                t.src_l = (const float*)sd.data;
+                t.src_r = nullptr;
+                t.off0 = 0;
+                t.off1 = step;
+                t.sample = job.sample;
+                t.pad = (uint32_t)len;
+#pragma unroll
+                for (int j = 0; j < FW_MAX_STAGES; ++j) {
+                    t.g[j][0] = job.g.g[j][0];
+                    t.g[j][1] = job.g.g[j][1];
+                }
+                fv.lazy_tmpl[vi] = t;
+                o->base = M;
+                o->off0 = ph_end;
+                o->loop_start = step;
+                o->r_delta = 0u;
+                o->flags_gset = (t.flags & 0xffu) | VB_RS_LEAN | ((uint32_t)SF_P_F32 << 16);
+                o->q = 1u;
+                o->r0b = 0u;
+                o->bpf = 4u;
+                o->g = job.g;
+            }
+        }
+    } else if (job.mode >= 0 && job.mode <= 2) {
         // (round 6: chain plans too.  `silent` = the block fetches nothing.  A filter voice fetches its source whatever its output's flag
         //  says — the filters run on; what it does not fetch is a cleared source, VB_SRC_ZERO — steady_tail's no_src)
         const bool silent = fxp ? ((job.flags & VB_SRC_ZERO) != 0 || (!fx && (job.flags & VB_SILENT) != 0)) : (job.flags & VB_SILENT) != 0;
@@ -617,7 +668,9 @@ __device__ __forceinline__ void make_lazy(const FusedView& fv, const int vi, con
         }
         // silent: put_blk's record of a block that fetches nothing (no source pointer, class P_F32); else steady_tail's lean record.
         // (nothing moves AND something sounds — a constant full descriptor — is not handled here)
-        if (moves_ok && (silent || (job.mode != 0 && lean))) {
+        // (resampler plans: k_leaf_rs renders resampler voices and silence; a sounding sampler voice beside them goes through the
+        //  work-list kernel, which reads real records — not capable)
+        if (moves_ok && (silent || (job.mode != 0 && lean && !fv.has_rs))) {
             mode = job.mode;
             if (w0) {
                 // (chain plan: every record is VB_SIMPLE — a source of one of k_chain's classes, or a cleared one — and keeps the chain output's flag)
@@ -651,6 +704,11 @@ __global__ __launch_bounds__(256) void k_lazy_flush(const LazyRec* __restrict__ 
         ds->playhead = (ds->playhead + (blocks % D) * (uint64_t)r.frames) % D;
     }
     if (r.sampler_state < 0 || r.mode <= 0) return;
+    if (r.mode == 3) {  // a resampler voice: its 32.32 position (tail_end_playhead's arithmetic)
+        const uint64_t end = r.off0 + blocks * ((uint64_t)r.frames * r.loop_start);
+        states[r.sampler_state].playhead = r.base ? end % r.base : end;
+        return;
+    }
     // (tail_end_playhead's value, not only an equivalent one: a last block that ends exactly on the loop end leaves playhead ==
     //  loop_end — rendered like loop_start, sampler.rs:441-452, but node state must not depend on whether a call was lazy: ADVICE r4)
     if (r.mode == 1) states[r.sampler_state].playhead = r.loop_start + ((uint64_t)((r.r0b + blocks - 1) % r.q) + 1) * r.frames;

@@ -1395,12 +1395,35 @@ __global__ __launch_bounds__(WAVE* LEAF_WPB, RS_OCC) void k_leaf_rs(FusedView fv
     uint32_t my_flags = VB_SILENT;
     uint64_t my_pos = 0ull;
     if (lane < ld.ports) {
-        const VoiceRef ref = fv.refs[ref_index(ld.first_voice + lane, (int)k, fv.ref_kgroups)];
-        my_flags = ref.flags_gset & 0xffu;
-        my_pos = (uint64_t)ref.src_l;
+        if (fv.lazy_rs) {
+            // Round 6 — a lazy call (no control kernel ran): the block's record from the voice's LazyRec and the absolute block index —
+            // a resampler voice's 32.32 position (pos + j * frames * step) mod (len << 32), its template in rs_tmpl (= the LazyRecs'
+            // copy); anything else in such a plan is silent (k_control.hip.h make_lazy)
+            const LazyRec* lr = fv.lazy + (ld.first_voice + lane);
+            my_flags = lr->flags_gset & 0xffu;
+            if (lr->mode == 3) {
+                const uint64_t M = lr->base;
+                const uint64_t pos = lr->off0 + (fv.lazy_blk0 + (uint64_t)k) * ((uint64_t)lr->frames * lr->loop_start);
+                my_pos = M ? pos % M : pos;
+            }
+        } else {
+            const VoiceRef ref = fv.refs[ref_index(ld.first_voice + lane, (int)k, fv.ref_kgroups)];
+            my_flags = ref.flags_gset & 0xffu;
+            my_pos = (uint64_t)ref.src_l;
+        }
     }
     const uint64_t lanes_in = mask_all_silent_bits(ld.ports);
     const uint64_t silent_ports = __ballot((my_flags & VB_SILENT) != 0) & lanes_in;
+    if (fv.lazy_rs && silent_ports == lanes_in) {
+        // every port silent: clear_all_outputs (sum.rs:52-56) — the work-list kernel's job on a control call; its records do not exist here
+        float* const bus0 = fv.bus + (size_t)k * fv.bus_blk_stride + (size_t)ld.out_buf * fv.stride;
+        for (int f = part * 256 + lane * 4; f < fv.frames; f += 256 * wpk) {  // (this wave's 256-frame pieces; rows are padded to 64 frames)
+            *(v4f*)(bus0 + f) = splat(0.f);
+            *(v4f*)(bus0 + fv.stride + f) = splat(0.f);
+        }
+        if (lane < 2 && part == 0) (fv.bus_flags + (size_t)k * fv.bus_flags_blk_stride)[ld.out_buf + lane] = 1;
+        return;
+    }
     const RsPure me = rs_pure_lane(fv, row, lane, ld.ports, my_flags, frames, ld.first_voice + lane, my_pos);
     const uint64_t pure_ports = __ballot(me.pure) & lanes_in;
     if (!(pure_ports && ((pure_ports | silent_ports) & lanes_in) == lanes_in)) {  // not ours: onto the general kernel's work list

@@ -11,7 +11,8 @@ cd /tmp && export TMPDIR=/tmp
 for cfg in $cfgs; do
   steps=20
   out=$root/gpurun_out/raw/${tag}_${cfg}${SUFFIX}
-  timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats -o s -- python $root/bench.py --workload $cfg --lean --steps $steps --warmup 3 $EXTRA > ${out}_stats.log 2>&1
+  # (--warm-ms: untimed steps until the device's clocks have settled, as bench.py's other_configs entries are timed — round 6)
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats -o s -- python $root/bench.py --workload $cfg --lean --steps $steps --warmup 3 --warm-ms ${WARM_MS:-60} $EXTRA > ${out}_stats.log 2>&1
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout 150 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d ${out}_$ctr -o p -- python $root/bench.py --workload $cfg --lean --no-kernel-timing --steps 4 --warmup 2 $EXTRA > ${out}_$ctr.log 2>&1
   done

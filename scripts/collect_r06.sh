@@ -16,12 +16,12 @@ EXTRA="--contexts 1 --rs-source" SUFFIX=_rs bash scripts/collect_profiles.sh r06
 EXTRA="--contexts 1 --voice-spatial" SUFFIX=_spatial bash scripts/collect_profiles.sh r06 cfg2 > gpurun_out/collect_r06_c.log 2>&1
 cd $GRAFT_REPO_ROOT
 out=$GRAFT_REPO_ROOT/gpurun_out/raw/r06_cfg2_levels
-(cd /tmp && TMPDIR=/tmp timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats -o s -- python $GRAFT_REPO_ROOT/bench.py --workload cfg2 --lean --contexts 1 --force-generic --steps 5 --warmup 2 > ${out}_stats.log 2>&1)
+(cd /tmp && TMPDIR=/tmp timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats -o s -- python $GRAFT_REPO_ROOT/bench.py --workload cfg2 --lean --contexts 1 --force-generic --steps 5 --warmup 2 --warm-ms 60 > ${out}_stats.log 2>&1)
 g=$(find ${out}_stats -name "*kernel_stats.csv" | head -1)
 if [ -n "$g" ]; then
   { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --workload cfg2 --lean --contexts 1 --force-generic --steps 5 --warmup 2   (MI355X, r06; 1024 voices, block 256, 768 blocks per step: the level executor alone)"; head -8 "$g" | cut -c1-220; } > $P/r06_cfg2_levels_only_kernel_stats.csv
 fi
-python bench.py --workload cfg2 --lean --contexts 1 --force-generic --steps 5 --warmup 2 > $P/r06_cfg2_levels_only_line.json 2> /dev/null
+python bench.py --workload cfg2 --lean --contexts 1 --force-generic --steps 5 --warmup 2 --warm-ms 60 > $P/r06_cfg2_levels_only_line.json 2> /dev/null
 python bench.py --gpus 1 --steps 20 --warmup 5 > $P/r06_bench_line.json 2> gpurun_out/bench_line.err
 cp gpurun_out/bench_full.json $P/r06_bench_full.json
 for m in allreduce_abi ordered_abi; do

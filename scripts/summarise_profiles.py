@@ -28,9 +28,30 @@ def find(pattern):
 stats = find(raw + "_stats/**/*kernel_stats.csv")
 if stats:
     rows = list(csv.reader(open(stats)))
+    # the stats table averages EVERY launch of the process — the clock ramp of the first tens of milliseconds included (round 6:
+    # --warm-ms).  bench.py's avg_launch_us is measured over the 20 steps right behind the timed region: the same launches are the last
+    # 2 x steps of the trace, so their mean is written beside the table's
+    warm_note = ""
+    trace = find(raw + "_stats/**/*kernel_trace.csv")
+    if trace:
+        by = collections.defaultdict(list)
+        for row in csv.DictReader(open(trace)):
+            try:
+                by[row["Kernel_Name"]].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+            except (KeyError, ValueError):
+                pass
+        fw = {k: sorted(v) for k, v in by.items() if "fwgpu::k_" in k}
+        if fw:
+            domk = max(fw, key=lambda k: sum(d for _, d in fw[k]))
+            d = [x for _, x in fw[domk]]
+            last = d[-2 * steps:]
+            warm_note = ("# dominant kernel %s: %d launches, mean %.1f us over all of them (clock ramp included), mean %.1f us / min %.1f us over the last %d "
+                         "(the timed region and the event pass behind it: what bench.py's avg_launch_us measures)\n"
+                         % (domk.split("(")[0].replace("void ", ""), len(d), sum(d) / len(d) / 1e3, sum(last) / len(last) / 1e3, min(last) / 1e3, len(last)))
     with open(os.path.join(outdir, "%s_%s%s_kernel_stats.csv" % (tag, cfg, suffix)), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --workload %s --lean --steps %d --warmup 3 %s"
-                "   (MI355X, %s; %d voices, block %d, %d blocks per step)\n" % (cfg, steps, extra, tag, V, B, K))
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --workload %s --lean --steps %d --warmup 3 --warm-ms %s %s"
+                "   (MI355X, %s; %d voices, block %d, %d blocks per step)\n" % (cfg, steps, os.environ.get("WARM_MS", "60"), extra, tag, V, B, K))
+        f.write(warm_note)
         w = csv.writer(f)
         for r in rows[:14]:
             w.writerow(r)

@@ -676,6 +676,19 @@ int launch_leaf_sum(hipStream_t, const FusedView& fv, int K) {
     g_launches[2]++;
     check_fused_common(fv, K);
     REQUIRE(!fv.fx_plan);
+    if (fv.lazy_rs) {  // a resampler plan's lazy call: k_leaf_rs takes records and templates from the LazyRecs (the book-keeping of the other lazy launches)
+        g_lazy_launches++;
+        REQUIRE(fv.has_rs && !fv.has_sp && fv.lazy != nullptr && fv.n_cmds == 0 && fv.lazy_tmpl != nullptr && fv.rs_tmpl == fv.lazy_tmpl, fv.has_rs, fv.n_cmds);
+        touch(fv.lazy, sizeof(LazyRec) * (size_t)fv.n_voices);
+        touch(fv.lazy_tmpl, sizeof(VoiceBlk) * (size_t)fv.n_voices);
+        LazyBook& b = lazy_book(fv.lazy);
+        REQUIRE(b.have_ctl && fv.lazy_blk0 == b.since_ctl, (long long)fv.lazy_blk0, (long long)b.since_ctl);
+        b.since_ctl += (unsigned long long)K;
+        b.unflushed += (unsigned long long)K;
+        b.chain = false;
+    } else if (fv.has_rs && fv.rs_tmpl) {
+        touch(fv.rs_tmpl, sizeof(VoiceBlk) * (size_t)fv.n_voices);
+    }
     return 0;
 }
 int launch_chain(hipStream_t, const FusedView& fv, int K, uint32_t, int nq) {

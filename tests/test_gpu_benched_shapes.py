@@ -713,3 +713,73 @@ def test_level_executor_with_and_without_vertical_fusion_equals_the_oracle(fuse,
     out_g = run(g)
     assert g.cx.plan_kind() == 0
     assert np.array_equal(bits(out_g), bits(out_o))
+
+
+def rs_quiet_run(e, mbf):
+    """a bank of resampler voices (k_leaf_rs) with long message-free stretches: looping and one-shot sources (the one-shots run out: the
+    horizon), ratios on both sides of 1 up to the last one a piece's window fits, mono sources, paused voices — one leaf of nothing but
+    paused voices (clear_all_outputs) — and in between ratio changes, seeks, a pause / resume and gain glides inside control calls"""
+    ratios = [1.0, 44100.0 / 48000.0, 1.5, 0.37, 1.93, 0.999, 1.0 / 3.0, 1.088, 0.75, 1.25]
+    rng = np.random.default_rng(99)
+    voices, ends = [], []
+    for v in range(40):
+        ch = 1 if v % 5 == 2 else 2
+        smp = e.new_sample(PLANAR_F32, ch, scenarios.voice_source(8800 + v, 1100 + 13 * v, ch))
+        paused = v % 7 == 3 or 32 <= v < 40          # (voices 32..39: a whole leaf silent)
+        src = e.resampler(smp, ratios[v % len(ratios)], loop=(v % 4 != 1), playing=not paused, n_out=2)
+        vol = e.volume(float(rng.uniform(20, 110)))
+        pan = e.pan(float(rng.uniform(-1, 1)))
+        e.connect_stereo(src, vol)
+        e.connect_stereo(vol, pan)
+        voices.append(dict(src=src, volume=vol, pan=pan))
+        ends.append(pan)
+    mixers = []
+    for i in range(0, len(ends), 8):
+        m = e.sum(8)
+        for p, n in enumerate(ends[i:i + 8]):
+            e.connect_stereo(n, m, 2 * p)
+        mixers.append(m)
+    top = e.sum(len(mixers))
+    for p, m in enumerate(mixers):
+        e.connect_stereo(m, top, 2 * p)
+    e.connect_stereo(top, e.graph_out_node)
+    e.update()
+    outs, marks = [], []
+    for c, k in enumerate([3, 2, 2, 3, 4, 1, 4, 4, 9, 2, 2, 3, 3, 5] + [8] * 8 + [3, 4]):
+        if c == 8:
+            for v, vc in enumerate(voices[:32]):
+                if v % 6 == 0:
+                    e.set_param(vc["src"], 1, [0.5, 1.25, 1.8][v % 3], at_block=1)     # ratio
+                if v % 6 == 4:
+                    e.set_param(vc["src"], 4, float(v * 7 % 900), at_block=2)          # seek
+                if v % 9 == 5:
+                    e.set_param(vc["src"], 3, 0.0, at_block=0)                         # pause ...
+                    e.set_param(vc["src"], 3, 1.0, at_block=3)                         # ... and resume
+                if v % 4 == 0:
+                    e.set_param(vc["volume"], 0, 35.0 + v, at_block=2)
+        if c == 12:
+            e.set_param(voices[33]["src"], 3, 1.0, at_block=1)                         # one voice of the silent leaf starts
+            e.set_param(voices[3]["src"], 3, 1.0, at_block=0)
+        outs.append(np.asarray(e.process_blocks(k)))
+        if hasattr(e, "cx"):
+            marks.append(e.cx.lazy_stats())
+    return np.concatenate(outs), marks
+
+
+@pytest.mark.parametrize("mbf,max_batch", [(256, 8), (512, 4), (64, 16), (100, 3)])
+def test_resampler_bank_calls_without_a_control_kernel_are_bit_exact_and_happen(mbf, max_batch):
+    """Round 6: lazy records for resampler plans — a message-free call launches k_leaf_rs (+ the empty work-list
+    kernel) alone: block j's 32.32 position is (pos + j * frames * step) mod (len << 32) from the voice's LazyRec, the rest the
+    template the control kernel left beside it; k_lazy_flush writes the positions back.  Every call against the oracle, bit for bit."""
+    ro, _ = rs_quiet_run(scenarios.TaggedOracle(OracleEngine(max_block_frames=mbf)), mbf)
+    g = GpuEngine(max_block_frames=mbf, max_batch=max_batch)
+    rg, marks = rs_quiet_run(g, mbf)
+    assert g.cx.plan_kind() == 1
+    assert np.array_equal(bits(rg), bits(ro))
+    assert np.any(ro != 0)
+    lazy = [m[0] for m in marks]
+    if os.environ.get("FWGPU_LAZY") == "0":
+        assert lazy[-1] == 0
+        return
+    assert lazy[-1] > lazy[13] >= lazy[9], marks   # ... and the quiet calls at the end run without a control kernel
+    assert lazy[9] == lazy[8], marks            # the messages of call 8 and the call after it

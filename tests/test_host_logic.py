@@ -839,3 +839,16 @@ def test_a_one_voice_replace_uploads_a_few_chunks_not_the_tables(monkeypatch):
     monkeypatch.setenv("FWGPU_PLAN_ORDER", "reference")
     ref = run(5)
     assert min(ref[2:]) > 200 << 10, ref   # (what the canonical order is for)
+
+
+def test_resampler_plan_lazy_calls_on_the_host_harness():
+    """Round 6: lazy records for resampler plans, the host's side — the launch stubs check the block offset every lazy k_leaf_rs launch
+    names, that its templates are the LazyRecs' copy, and that the flush names no voice table (no delay lines to move).  (The fake
+    device reports every voice steady with an unbounded horizon.)"""
+    from fwapi import HostOnlyEngine
+    from test_gpu_benched_shapes import rs_quiet_run
+
+    e = HostOnlyEngine(max_block_frames=256, max_batch=8)
+    _, marks = rs_quiet_run(e, 256)
+    assert e.cx.plan_kind() == 1 and e.violation() == "", e.violation()
+    assert marks[-1][0] >= 6, marks

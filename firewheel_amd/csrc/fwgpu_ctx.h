@@ -88,6 +88,11 @@ struct DevBuf {
             cap = 0;
         }
         size_t want = bytes < 256 ? 256 : bytes;
+        // (round 6: tables up to 16 MB get an eighth of headroom from the start — slot-indexed tables grow by a few entries with every
+        //  one of a graph's first edits (a removed node's slot is reusable only when no plan holds it), and a regrow is a hipFree +
+        //  hipMalloc on the control thread: the free waits for every stream, and the callback that runs beside it took +35 us in
+        //  fw_edit_race's paced runs — one or two edits of thirty, scripts/r06_edit_paced_ab.sh.  Pools keep their exact size.)
+        if (!regrow && want <= ((size_t)16 << 20)) want += want / 8 > 4096 ? want / 8 : 4096;
         hipError_t e = hipErrorOutOfMemory;
         if (regrow) {
             const size_t roomy = want + want / 4;

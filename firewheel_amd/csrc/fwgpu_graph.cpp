@@ -301,13 +301,15 @@ int HostGraph::build_plan(Plan& plan, std::string& err) {
             return FWGPU_ERR_INVALID;
         }
     std::vector<uint32_t>& order = cs_order;
-    if (!topo_order(order)) {
-        err = "cycle detected";
-        return FWGPU_ERR_COMPILE_CYCLE;
-    }
-    for (uint32_t slot : order) {
-        const NodeMeta& m = meta[slot];
-        if (!check_activation(m.kind, m.n_in, m.n_out, err)) return FWGPU_ERR_NODE_ACTIVATION_FAILED;
+    if (!canonical_order) {  // the reference's walk (cycle check included); the canonical order below makes its own
+        if (!topo_order(order)) {
+            err = "cycle detected";
+            return FWGPU_ERR_COMPILE_CYCLE;
+        }
+    } else {
+        order.clear();
+        for (uint32_t s = 0; s < NS; ++s)
+            if (meta[s].alive) order.push_back(s);  // (which nodes: the walk below puts them in order)
     }
     // producers per (node, input port), flat, from one more sequential pass over the edge arena
     std::vector<uint32_t>& in_off = cs_off;  // (the walk is over: its arrays are free)
@@ -326,6 +328,7 @@ int HostGraph::build_plan(Plan& plan, std::string& err) {
     std::vector<uint32_t>& index_of = cs_cur;
     index_of.assign(NS, 0);
     const size_t N = order.size();
+    bool cyclic = false;
     // Round 6 — a CANONICAL order for the plan's tables: the post-order of a depth-first walk from graph_out over the INPUT ports,
     // ascending (a node behind all of its producers: a schedule; nodes graph_out does not reach: the same walk from each, slots
     // ascending, behind the rest).  The reference's order (the Kahn walk above: compiler.rs:232-300) follows the edge arena, so
@@ -335,7 +338,7 @@ int HostGraph::build_plan(Plan& plan, std::string& err) {
     // any more: the replacement gets new slots).  Every table names its producers by index and levels follow from the producers, so
     // any schedule renders the same audio; this one depends on WHERE a node is connected only: a voice put into the mixer port of
     // the voice it replaces takes that voice's entries, and an edit differs in O(1) chunks.  One pass, O(nodes + edges), no sort.
-    if (canonical_order && N > 2) {
+    if (canonical_order && N >= 2) {
         std::vector<uint32_t>& out = cs_byl;
         std::vector<uint8_t>& seen = cs_seen;
         std::vector<uint32_t>& st_node = cs_adj;  // (the walk's adjacency is spent) the DFS stack: node, next input port
@@ -355,26 +358,33 @@ int HostGraph::build_plan(Plan& plan, std::string& err) {
         const NodeMeta* const mt = meta.data();
         size_t pos = 0;
         o[pos++] = graph_in_slot;  // (first, as in the reference's order)
-        sn[graph_in_slot] = 1;
-        sn[graph_out_slot] = 1;
+        // (the walk is the cycle check too — the reference's Kahn walk is not run in this mode: a node met again while it is still ON the
+        //  stack (1; done nodes are 2) closes a cycle, and every alive node is walked)
+        sn[graph_in_slot] = 2;
         auto walk = [&](uint32_t root) {
             size_t sp = 0;
             sk_n[0] = root;
             sk_p[0] = 0;
+            sn[root] = 1;
             for (;;) {
                 const uint32_t n = sk_n[sp];
                 uint32_t p = sk_p[sp];
                 const uint32_t n_in = mt[n].n_in;
                 const int* ie = ine + ioff[n];
                 const uint32_t* is = ins + ioff[n];
-                while (p < n_in && (ie[p] < 0 || sn[is[p]])) ++p;
+                while (p < n_in && (ie[p] < 0 || sn[is[p]] == 2)) ++p;
                 if (p < n_in) {
+                    if (sn[is[p]] == 1) {
+                        cyclic = true;
+                        return;
+                    }
                     sk_p[sp] = p + 1;
                     sn[is[p]] = 1;
                     ++sp;
                     sk_n[sp] = is[p];
                     sk_p[sp] = 0;
                 } else {
+                    sn[n] = 2;
                     if (n != graph_out_slot) o[pos++] = n;
                     if (sp == 0) break;
                     --sp;
@@ -382,14 +392,19 @@ int HostGraph::build_plan(Plan& plan, std::string& err) {
             }
         };
         walk(graph_out_slot);
-        if (pos + 1 < N)
-            for (uint32_t slot = 0; slot < NS; ++slot)
-                if (mt[slot].alive && !sn[slot]) {
-                    sn[slot] = 1;
-                    walk(slot);
-                }
+        if (!cyclic && pos + 1 < N)
+            for (uint32_t slot = 0; slot < NS && !cyclic; ++slot)
+                if (mt[slot].alive && !sn[slot]) walk(slot);
+        if (cyclic) {
+            err = "cycle detected";
+            return FWGPU_ERR_COMPILE_CYCLE;
+        }
         out[pos++] = graph_out_slot;
         order.swap(out);
+    }
+    for (uint32_t slot : order) {
+        const NodeMeta& m = meta[slot];
+        if (!check_activation(m.kind, m.n_in, m.n_out, err)) return FWGPU_ERR_NODE_ACTIVATION_FAILED;
     }
     for (size_t i = 0; i < N; ++i) index_of[order[i]] = (uint32_t)i;
     // a recycled Plan keeps its node array AND the nodes in it (every field is assigned below; wide nodes keep their heap lists):

@@ -221,6 +221,10 @@ class Pair(object):
         self.p.set_canonical_order(False)      # the walk itself: the reference's order
         r = self.both(self.p.update, self.o.update)
         if r is None:
+            # both refused (a cycle, a node that cannot be activated): the canonical order's own walk — it does not run the Kahn walk —
+            # must refuse with the same error
+            self.p.set_canonical_order(True)
+            assert self.both(self.p.update, self.o.update) is None
             return False
         self.check(self.p.schedule(), self.o.schedule(), kahn=True)
         self.p.set_canonical_order(True)       # ... and the order the plan's tables are written in (round 6, the default)
@@ -358,3 +362,44 @@ def test_replacing_a_voice_moves_only_that_voices_entries_in_the_plan_tables():
             assert y["id"] == swapped.get(x["id"], x["id"]), (rnd, i)          # same position: the same node, or the replacement of the node that sat there
             assert (y["in"], y["out"], y["level"]) == (x["in"], x["out"], x["level"]), (rnd, i)   # same buffers, same level
         before = after
+
+
+def test_canonical_order_finds_cycles_wherever_they_sit():
+    """build_plan's canonical walk is its own cycle check (round 6: the reference's Kahn walk is not run in that mode): cycles behind
+    graph_out, cycles in a part of the graph graph_out does not reach, a two-node loop, a long ring — CycleDetected every time, and the
+    same graph compiles once the closing edge is gone"""
+    VOLUME, SUM = 1, 4
+    for where in ("reachable", "island", "pair", "ring"):
+        for canonical in (True, False):
+            g = PlannerEngine()
+            g.set_canonical_order(canonical)
+            a, b, c, d = (g.add_node(VOLUME, 2, 2) for _ in range(4))
+            m = g.add_node(SUM, 4, 2)
+            g.connect(a, 0, b, 0)
+            g.connect(b, 0, m, 0)
+            g.connect(m, 0, g.graph_out_node, 0)
+            if where == "reachable":
+                g.connect(m, 1, a, 1)          # m -> a -> b -> m
+                closing = (m, 1, a, 1)
+            elif where == "island":
+                g.connect(c, 0, d, 0)
+                g.connect(d, 0, c, 0)          # c <-> d, nobody listens
+                closing = (d, 0, c, 0)
+            elif where == "pair":
+                g.connect(b, 1, a, 1)          # a <-> b in front of the mixer
+                closing = (b, 1, a, 1)
+            else:
+                ring = [g.add_node(VOLUME, 2, 2) for _ in range(50)]
+                for x, y in zip(ring, ring[1:]):
+                    g.connect(x, 0, y, 0)
+                g.connect(ring[-1], 0, ring[0], 0)
+                g.connect(ring[7], 1, m, 2)
+                closing = (ring[-1], 0, ring[0], 0)
+            assert g.cycle_detected()
+            with pytest.raises(CompileGraphError) as ei:
+                g.update()
+            assert ei.value.name == "CycleDetected", (where, canonical, ei.value.name)
+            assert g.disconnect(*closing) == 1
+            g.update()
+            ids = [x["id"] for x in g.schedule()]
+            assert len(ids) == len(set(ids)) and ids[-1] == g.graph_out_node

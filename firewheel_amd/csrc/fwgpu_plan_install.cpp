@@ -199,6 +199,41 @@ static int arena_room(fwgpu_ctx* c, size_t need) {
 static int up_impl(fwgpu_ctx* c, const char* tag, DevBuf& b, const void* src, size_t bytes, bool device_writes = false) {
     HIPC(c, b.ensure_n(tag, bytes));
     if (!bytes) return 0;
+    if (c->build_one_kernel && c->up_diff && !device_writes && b.shadow.size() == bytes) {
+        // The usual case of an edit (round 6): compare FIRST, then copy only the chunks that differ — into the pinned arena and into
+        // the shadow.  (Copying the whole table into the arena, comparing, and assigning the whole shadow were three passes over
+        // 1.1 MB of tables per update of config 3's graph: most of the "node tables" phase was memcpy.)
+        constexpr size_t CH = 4096;
+        const char* s8 = (const char*)src;
+        uint8_t* sh = b.shadow.data();
+        size_t off = 0, sent = 0;
+        auto same = [&](size_t o) { return !memcmp(sh + o, s8 + o, std::min(CH, bytes - o)); };
+        while (off < bytes) {
+            while (off < bytes && same(off)) off += CH;
+            if (off >= bytes) break;
+            size_t end = off;
+            while (end < bytes && !same(end)) end += CH;
+            end = std::min(end, bytes);
+            const size_t len = end - off, room = (len + 255) & ~(size_t)255;
+            int rc = arena_room(c, room);
+            if (rc) return rc;
+            char* at = c->h_up + c->h_up_used;
+            memcpy(at, s8 + off, len);
+            memcpy(sh + off, s8 + off, len);
+            BuildJob j{};
+            j.dst = (char*)b.p + off;
+            j.src = at;
+            j.row_bytes = len;
+            j.pitch = len;
+            j.rows = 1;
+            c->build_jobs.push_back(j);
+            c->h_up_used += room;
+            sent += len;
+            off = end;
+        }
+        if (c->update_prof_tables) fprintf(stderr, "fwgpu up %-22s %9zu bytes, %9zu sent\n", tag, bytes, sent);
+        return 0;
+    }
     const size_t need = (bytes + 255) & ~(size_t)255;
     int rc = arena_room(c, need);
     if (rc) return rc;

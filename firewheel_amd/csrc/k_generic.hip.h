@@ -1202,8 +1202,14 @@ __device__ __forceinline__ uint32_t frozen_fast(const DevView& v, const int node
 // state come from HBM once and from the cache for the other blocks (the per-block work is ~4 KB behind a chain of dependent
 // loads).  bpw = LEVEL_BPW on a level with thousands of (node, block) pairs; a level of one or two bus nodes — the root of a
 // hybrid plan, a return chain — gets a wave per block instead: its blocks in sequence were 10-38 us per level of pure latency.
+// Registers capped for THREE waves per SIMD (round 6): the fused head of a frozen chain (k_level<2>: sampler -> volume -> pan in
+// registers) took 191 and ran two — config 2 on the levels alone 1.64-1.68e11 -> 1.76-1.83e11 voice-samples/s; four (128 registers)
+// spills its way to 1.50e11.  (-DLEVEL_MINW=n: experiments.)
+#ifndef LEVEL_MINW
+#define LEVEL_MINW 3
+#endif
 template <int SET>
-__global__ __launch_bounds__(WAVE* WPB) void k_level(DevView v, const int* __restrict__ level_nodes, int n_nodes,
+__global__ __launch_bounds__(WAVE* WPB, LEVEL_MINW) void k_level(DevView v, const int* __restrict__ level_nodes, int n_nodes,
                                                       uint32_t cmd_block0, uint32_t K, uint32_t bpw, uint32_t walkers) {
     int w = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (w >= n_nodes) return;
